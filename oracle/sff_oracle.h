@@ -1,0 +1,114 @@
+/* sff_oracle.h — C interface of the CPU ORACLE (test infrastructure, NOT the product).
+ *
+ * This library is a plain, single-threaded CPU restatement of the reference's
+ * SFF / SFF* tree-expansion hot path (ctu-mrs/space_filling_forest_star), used ONLY as
+ * the checker by tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.
+ * The shipped HIP path (space_filling_forest_star_amd/csrc) never links or calls it.
+ *
+ * PARITY STATUS: pinned for a1-a5, a9 (RNG stream, sampling, metric, steer, rotation
+ * matrix, D6Distance functor) against outputs of the reference's own headers compiled
+ * in oracle/_ref (tests/golden/ref_primitives.json).  UNPINNED for the collision
+ * boolean (RAPID 2.01 is not in the reference tree: lib/rapid-2.01/README.md:1-2) and
+ * for the solver loop (src/forest.h, src/rrt.h cannot be compiled without RAPID.H and
+ * no reference test or golden vector exists for them) — those follow the reference
+ * source line by line (citations in sff_oracle.cpp) and RAPID's published algorithm.
+ */
+#pragma once
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { SFFO_TRIG_LIBM = 0, SFFO_TRIG_PORTABLE = 1 };
+
+/* ---- mesh parsing (reference src/environment.h:125-223 quirks kept) ---- */
+/* returns number of triangles written (9 doubles each), or -1 on error, -2 if cap too small */
+int sffo_parse_obj(const char* path, const double pos[3], double scale, double* tri9, int cap);
+int sffo_parse_tri2d(const char* path, const double pos[3], double scale, double* tri9, int cap);
+
+/* ---- primitives (reference src/primitives.h:224-292) ---- */
+double sffo_distance(const double a[6], const double b[6]);
+void sffo_steer(const double from[6], const double to[6], double dist, double out[6]);
+void sffo_rotation(const double p[6], int trig, double R[9]);
+double sffo_sin(double x, int trig);
+double sffo_cos(double x, int trig);
+double sffo_acos(double x, int trig);
+
+/* ---- RNG (reference src/randGen.h + libstdc++ distributions) ---- */
+typedef struct sffo_rng sffo_rng;
+sffo_rng* sffo_rng_create(uint64_t seed, const double limits[6], int trig);
+void sffo_rng_destroy(sffo_rng*);
+uint64_t sffo_rng_raw(sffo_rng*);
+int sffo_rng_int(sffo_rng*, int lo, int hi);
+double sffo_rng_prob(sffo_rng*);
+int sffo_rng_point_in_distance(sffo_rng*, const double center[6], double dist, int dim, double out[6]);
+void sffo_rng_point_in_space(sffo_rng*, int dim, double out[6]);
+/* same maths as point_in_distance but fed with pre-drawn raw engine words (6 for dim 6, 1 for dim 2) */
+int sffo_sample_from_words(const uint64_t* words, const double center[6], double dist, int dim,
+                           const double limits[6], int trig, double out[6]);
+
+/* ---- collision world (reference src/environment.h:268-316, src/problemStruct.h:154-168) ---- */
+typedef struct sffo_world sffo_world;
+sffo_world* sffo_world_create(const double* env_tri9, int n_env, const double* robot_tri9, int n_robot, int trig);
+void sffo_world_destroy(sffo_world*);
+int sffo_tri_contact(const double P[9], const double Q[9]);
+int sffo_collide_pose_brute(sffo_world*, const double p[6]);
+int sffo_collide_pose(sffo_world*, const double p[6]);
+/* returns 1 if free; *first_hit = index of first colliding sample (or -1); *n_samples = samples on the edge */
+int sffo_path_free(sffo_world*, const double a[6], const double b[6], int* first_hit, int* n_samples);
+uint64_t sffo_world_collide_calls(sffo_world*);
+
+/* ---- exact neighbour queries over a point set (replaces FLANN; true 6-D metric, double) ---- */
+/* pts: n x 6 doubles.  Results sorted by (distance, index).  Returns count (<= cap). */
+int sffo_radius(const double* pts, int n, const double q[6], double r, int32_t* idx, double* dist, int cap);
+int sffo_knn(const double* pts, int n, const double q[6], int k, int32_t* idx, double* dist);
+
+/* ---- SFF / SFF* solver (reference src/forest.h:57-418) ---- */
+typedef struct {
+  int dim;                 /* 2 or 6 (reference enum Dimensions) */
+  int optimize;            /* SFF* */
+  int has_goal;
+  double goal[6];
+  double limits[6];        /* minX maxX minY maxY minZ maxZ */
+  double dist_tree;        /* already scaled */
+  double sampling_dist;    /* Node::SamplingDistance, already scaled */
+  int threshold_misses;    /* Node::ThresholdMisses */
+  int max_iterations;
+  int node_budget;         /* 0 = none (reference has only the iteration cap) */
+  int wave;                /* slots per wave; 1 == the reference's sequential loop */
+  uint64_t seed;
+  int trig;
+} sffo_forest_cfg;
+
+typedef struct {
+  int32_t iterations;
+  int32_t solved;
+  int32_t n_nodes;
+  int32_t n_trees;
+  int32_t frontier_size;
+  int32_t closed_size;
+  int32_t n_connected;
+  int32_t n_borders;
+  uint64_t collide_calls;  /* Environment::Collide invocations (reference-equivalent count) */
+  uint64_t path_free_calls;
+  uint64_t nn_queries;
+  uint64_t waves;
+} sffo_forest_stats;
+
+typedef struct sffo_forest sffo_forest;
+sffo_forest* sffo_forest_create(sffo_world* w, const sffo_forest_cfg* cfg, const double* roots6, int n_roots);
+void sffo_forest_destroy(sffo_forest*);
+/* run until termination, or for at most max_waves waves when max_waves > 0 */
+void sffo_forest_run(sffo_forest*, int max_waves);
+void sffo_forest_get_stats(sffo_forest*, sffo_forest_stats*);
+/* per node, in global creation order: pos[6], parent id (-1 root), tree id, creation iteration, cost-to-root, dist-to-parent */
+void sffo_forest_get_nodes(sffo_forest*, double* pos6, int32_t* parent, int32_t* tree, int32_t* iter,
+                           double* cost, double* dpar);
+/* borders: per entry tree_a, tree_b, node1, node2, distance; returns count (<= cap) */
+int sffo_forest_get_borders(sffo_forest*, int32_t* ta, int32_t* tb, int32_t* n1, int32_t* n2, double* dist, int cap);
+/* FNV-1a over (parent, tree, iter, pos bits) of all nodes — cheap topology fingerprint */
+uint64_t sffo_forest_fingerprint(sffo_forest*);
+
+#ifdef __cplusplus
+}
+#endif
