@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the SFF hot path on MI355X.
+
+Workload (BASELINE.json configs[2], the headline): dense_3D.obj map, 6-DoF cylinder robot,
+10 roots, SFF solver, 1M-node budget (authored step circum=14 / dtree=18: SURVEY.md §8(d)).
+A "step" is one WAVE of the tree-expansion loop: `--wave` frontier slots, each sampled /
+neighbour-swept / collision-checked for up to ThresholdMisses rounds, then committed.
+`value` = accepted node expansions per second over the K timed waves (whole job), with the
+map, robot and node store resident in HBM before the timed region starts.
+
+Prints ONE JSON line (rank 0) with the driver's contract plus `roofline` (neighbour-sweep
+kernel, HIP-event timed inside the library on its launch stream) and `cpu_baseline` (the CPU
+oracle, wave=1 == the reference's sequential loop, on a bounded sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=120)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--wave", type=int, default=4096)
+    ap.add_argument("--budget", type=int, default=1000000)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--cpu-iters", type=int, default=120000, help="iterations of the CPU baseline sample (0 = skip)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    distributed = world > 1
+    torch.cuda.set_device(local_rank)
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    import common
+    import space_filling_forest_star_amd as S
+
+    sc = common.scenario("dense3d")
+    ctx = S.Context(local_rank)
+    ctx.upload_env(sc["env"])
+    ctx.upload_robot(sc["robot"])
+    # 10 seeded collision-free roots (identical on every rank): drawn with the GPU collision kernel
+    roots = common.free_roots(lambda p: int(ctx.collide_poses(p[None, :])[0]), sc["limits"], 10, seed=1)
+    # multi-GPU: the waves of one forest do not shard without the record exchange (DESIGN.md
+    # "Multi-GPU"); until that lands every rank grows an independent forest (own seed) of the
+    # same workload, so per-GPU work is fixed: weak scaling of replicas.
+    forest = S.Forest(ctx, roots, sc["limits"], dist_tree=sc["dist_tree"], sampling_dist=sc["sampling_dist"], dim=6,
+                      max_iterations=2**31 - 1, node_budget=args.budget, wave=args.wave, seed=args.seed + rank)
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    forest.run(args.warmup)
+    s0 = forest.stats()
+    barrier()
+    t0 = time.perf_counter()
+    forest.run(args.steps)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    barrier()
+    s1 = forest.stats()
+    elapsed = t1 - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    steps_done = int(s1["waves"] - s0["waves"])
+    acc = float(s1["n_nodes"] - s0["n_nodes"])
+    checks = float(s1["collide_calls"] - s0["collide_calls"])
+    executed = float(s1["poses_executed"] - s0["poses_executed"] + s1["samples_executed"] - s0["samples_executed"])
+    if distributed:
+        t = torch.tensor([acc, checks, executed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        acc, checks, executed = (float(x) for x in t.tolist())
+
+    out = None
+    if rank == 0:
+        sweep_ms = s1["sweep_ms"] - s0["sweep_ms"]
+        sweeps = s1["sweeps"] - s0["sweeps"]
+        sweep_nodes = s1["sweep_nodes"] - s0["sweep_nodes"]
+        achieved = (24.0 * sweep_nodes / (sweep_ms * 1e-3)) / 1e9 if sweep_ms > 0 else 0.0
+        out = {
+            "metric": "accepted node expansions/sec + collision checks/sec, dense_3D 6-DoF",
+            "value": acc / elapsed,
+            "unit": "accepted nodes/s",
+            "n_gpus": world,
+            "steps": steps_done,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / max(1, steps_done),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": "dense_3D.obj (1832 tris) + robot_cylinder_small (124 tris), 6-DoF, 10 seeded roots, SFF, "
+                            "circum=14 dtree=18, 1M-node budget; step = one wave of %d frontier slots" % args.wave,
+                "wave": args.wave, "node_budget": args.budget, "seed": args.seed,
+                "nodes_at_start": s0["n_nodes"], "nodes_at_end": s1["n_nodes"],
+                "parallelism": "1 GPU" if world == 1 else "%d independent forests (replicas, one per GPU)" % world,
+            },
+            "collision_checks_per_s": checks / elapsed,
+            "collision_checks_executed_per_s": executed / elapsed,
+            "iterations": s1["iterations"] - s0["iterations"],
+            "time_split_ms": {"total": 1e3 * elapsed, "sweep_kernel": sweep_ms,
+                              "collide_kernels": s1["collide_ms"] - s0["collide_ms"],
+                              "sample_kernel": s1["sample_ms"] - s0["sample_ms"],
+                              "host_logic": s1["host_ms"] - s0["host_ms"]},
+            "roofline": {
+                "bound": "hbm", "kernel": "sffk::k_sweep",
+                "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                "traffic": None,
+                "launches": int(sweeps), "avg_launch_us": 1e3 * sweep_ms / max(1, sweeps),
+                "avg_nodes_per_launch": sweep_nodes / max(1, sweeps),
+                "avg_queries_per_launch": (s1["sweep_queries"] - s0["sweep_queries"]) / max(1, sweeps),
+            },
+        }
+        if args.cpu_iters > 0:
+            import oracle_lib as O
+            w = O.World(sc["env"], sc["robot"], O.TRIG_PORTABLE)
+            fo = O.Forest(w, roots, sc["limits"], dist_tree=sc["dist_tree"], sampling_dist=sc["sampling_dist"], dim=6,
+                          max_iterations=args.cpu_iters, wave=1, seed=args.seed)
+            c0 = time.perf_counter()
+            fo.run()
+            c1 = time.perf_counter()
+            so = fo.stats()
+            out["cpu_baseline"] = {
+                "value": (so["n_nodes"] - 10) / (c1 - c0), "unit": "accepted nodes/s", "cores": 1, "kind": "port",
+                "sample": "first %d iterations of the same workload from the same roots and seed, wave=1 (the "
+                          "reference's sequential loop), CPU oracle; reached %d nodes in %.1f s"
+                          % (args.cpu_iters, so["n_nodes"], c1 - c0),
+                "collision_checks_per_s": so["collide_calls"] / (c1 - c0),
+            }
+        print(json.dumps(out), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,147 @@
+/* sffgpu.h — C ABI of the MI355X-native SFF / SFF* hot path (libsffgpu.so).
+ *
+ * Drop-in boundary for the tree-expansion loop of ctu-mrs/space_filling_forest_star:
+ * each entry point replaces one call the reference makes into FLANN / RAPID / its own
+ * Solver base (file:line of the reference interface given per function).  Plain pointers
+ * and sizes only; all buffers are caller-owned HOST memory unless a name ends in `_dev`.
+ * Every call returns 0 on success and a negative code on failure, with a message
+ * available from sffgpu_last_error().  A context is bound to one GPU and is not
+ * thread-safe (the reference is single-threaded and keeps state in statics:
+ * src/primitives.h:443-445,493, src/environment.h:76).  There is NO CPU fallback: without a
+ * usable gfx950 device sffgpu_create() fails.
+ */
+#ifndef SFFGPU_H
+#define SFFGPU_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sffgpu_ctx sffgpu_ctx;
+typedef struct sffgpu_forest sffgpu_forest;
+
+enum { SFFGPU_OK = 0, SFFGPU_ERR_ARG = -1, SFFGPU_ERR_HIP = -2, SFFGPU_ERR_STATE = -3, SFFGPU_ERR_CAPACITY = -4 };
+enum { SFFGPU_MESH_ENV = 0, SFFGPU_MESH_ROBOT = 1 };
+
+/* library / device */
+const char* sffgpu_version(void);
+int sffgpu_device_count(void);
+int sffgpu_create(int device, sffgpu_ctx** out);
+void sffgpu_destroy(sffgpu_ctx* ctx);
+const char* sffgpu_last_error(sffgpu_ctx* ctx); /* ctx may be NULL: last create() error */
+
+/* Collision models.  Replaces RAPID_model::BeginModel/AddTri/EndModel as driven by
+ * Obstacle<T>::Obstacle / addFacet (src/environment.h:101-115, :212-223).  tri9 = n x 9 doubles
+ * (three xyz vertices), already offset and scaled like the reference parser does.  All obstacles
+ * of an Environment are merged into the one ENV model (Environment::Collide ORs over them,
+ * src/environment.h:306-316).  The ENV model may be empty (HasMap == false). */
+int sffgpu_mesh_upload(sffgpu_ctx* ctx, int role, const double* tri9, int n_tri);
+
+/* Environment::Collide(position) (src/environment.h:306-316 -> RAPID_Collide :268-276):
+ * hit[i] = 1 if the robot posed at pos6[i] = (x y z yaw pitch roll) touches any ENV triangle. */
+int sffgpu_collide_poses(sffgpu_ctx* ctx, const double* pos6, int n, uint8_t* hit);
+
+/* Solver::isPathFree(start, finish) (src/problemStruct.h:154-168), batched over n edges.
+ * is_free[i] = 1 if no interpolated sample collides; first_hit[i] = index of the first colliding
+ * sample (the reference stops there) or -1; n_samples[i] = samples the edge has.  The last two
+ * may be NULL. */
+int sffgpu_collide_segments(sffgpu_ctx* ctx, const double* a6, const double* b6, int n, uint8_t* is_free,
+                            int32_t* first_hit, int32_t* n_samples);
+
+/* RandGen::randomPointInDistance (src/randGen.h:70-109) for n centres in one launch.  `words`
+ * are raw std::mt19937_64 outputs in the reference's draw order: 6 per sample when dim == 6,
+ * 1 when dim == 2 (always strided by 6).  limits = minX maxX minY maxY minZ maxZ. */
+int sffgpu_sample_steer(sffgpu_ctx* ctx, const uint64_t* words, const double* center6, int n, double dist, int dim,
+                        const double limits[6], double* out6, uint8_t* in_limits);
+
+/* Node store = the FLANN index of every tree (Tree::flannIndex, src/primitives.h:506).
+ * append replaces Index::addPoints (src/forest.h:367, src/rrt.h:215); tree_id tags each node. */
+int sffgpu_nodes_reset(sffgpu_ctx* ctx, int capacity);
+int sffgpu_nodes_append(sffgpu_ctx* ctx, const double* pos6, const int32_t* tree_id, int n);
+int sffgpu_nodes_count(sffgpu_ctx* ctx);
+
+/* Exact radius query, replaces Index::radiusSearch (src/forest.h:266-267).  For each of nq
+ * queries returns every stored node with 6-D distance < r[q] (true metric of
+ * src/primitives.h:224-235, double), restricted to tree[q] (or all trees when tree[q] < 0) and
+ * to node ids < max_id[q] (all when max_id is NULL).  Results per query are sorted by
+ * (distance, node id); idx/dist are nq x cap, cnt[q] is the TOTAL number found (entries beyond
+ * cap are dropped, check cnt[q] <= cap). */
+int sffgpu_radius(sffgpu_ctx* ctx, const double* q6, int nq, const double* r, const int32_t* tree,
+                  const int32_t* max_id, int32_t* idx, double* dist, int32_t* cnt, int cap);
+
+/* Exact k nearest, replaces Index::knnSearch (src/forest.h:317, src/rrt.h:143,166,228); same
+ * filters and ordering as sffgpu_radius; cnt[q] = min(k, eligible nodes). idx/dist are nq x k. */
+int sffgpu_knn(sffgpu_ctx* ctx, const double* q6, int nq, int k, const int32_t* tree, const int32_t* max_id,
+               int32_t* idx, double* dist, int32_t* cnt);
+
+/* ---------------------------------------------------------------- solver session
+ * SpaceForest<T,R> (src/forest.h:31-54): constructor :57-110, Solve() main loop :113-202,
+ * expandNode :240-376, maxConnected :379-418 — run as waves of `wave` frontier slots evaluated
+ * together on the GPU; wave == 1 is the reference's sequential loop. */
+typedef struct {
+  int32_t dim;              /* Dimensions: 2 (D2) or 6 (D3), src/primitives.h:75-78 */
+  int32_t optimize;         /* Problem::optimal -> SFF* choose-parent + rewire */
+  int32_t has_goal;         /* Problem::hasGoal */
+  double goal[6];           /* Problem::goal (already scaled) */
+  double limits[6];         /* Environment::limits */
+  double dist_tree;         /* Problem::distTree (scaled) */
+  double sampling_dist;     /* Node::SamplingDistance (scaled) */
+  int32_t threshold_misses; /* Node::ThresholdMisses */
+  int32_t max_iterations;   /* Problem::maxIterations */
+  int32_t node_budget;      /* extra stop: total nodes >= budget (0 = off; not in the reference) */
+  int32_t wave;             /* frontier slots per wave */
+  uint64_t seed;            /* mt19937_64 seed (reference: clock, src/randGen.h:52-55) */
+  int32_t rank;             /* multi-GPU: this process's shard of every wave ... */
+  int32_t world;            /* ... out of `world` shards (1 = single GPU) */
+} sffgpu_forest_cfg;
+
+typedef struct {
+  int32_t iterations, solved, n_nodes, n_trees, frontier_size, closed_size, n_connected, n_borders;
+  uint64_t collide_calls;    /* Environment::Collide calls the reference would have made */
+  uint64_t path_free_calls;  /* isPathFree calls the reference would have made */
+  uint64_t nn_queries;       /* FLANN queries the reference would have made */
+  uint64_t waves;
+  uint64_t poses_executed;   /* pose checks launched on the GPU (incl. speculative) */
+  uint64_t segments_executed;/* edge checks launched on the GPU (incl. speculative) */
+  uint64_t samples_executed; /* edge samples those segments cover */
+  uint64_t sweeps;           /* neighbour-sweep launches */
+  uint64_t sweep_nodes;      /* sum over sweeps of nodes streamed */
+  uint64_t sweep_queries;    /* sum over sweeps of queries */
+  double sweep_ms;           /* device time of the sweep kernel (HIP events) */
+  double collide_ms;         /* device time of the pose + segment kernels */
+  double sample_ms;          /* device time of the sample+steer kernel */
+  double host_ms;            /* host time inside run() not waiting on the device */
+  double total_ms;           /* wall time inside run() */
+} sffgpu_forest_stats;
+
+int sffgpu_forest_create(sffgpu_ctx* ctx, const sffgpu_forest_cfg* cfg, const double* roots6, int n_roots,
+                         sffgpu_forest** out);
+void sffgpu_forest_destroy(sffgpu_forest* f);
+/* run to termination, or for at most max_waves waves when max_waves > 0 */
+int sffgpu_forest_run(sffgpu_forest* f, int max_waves);
+int sffgpu_forest_get_stats(sffgpu_forest* f, sffgpu_forest_stats* out);
+/* nodes in global creation order (Solver::allNodes): any output may be NULL */
+int sffgpu_forest_get_nodes(sffgpu_forest* f, double* pos6, int32_t* parent, int32_t* tree, int32_t* iter,
+                            double* cost, double* dist_parent);
+/* SpaceForest::borders entries; returns the count (may exceed cap) or a negative error */
+int sffgpu_forest_get_borders(sffgpu_forest* f, int32_t* tree_a, int32_t* tree_b, int32_t* node1, int32_t* node2,
+                              double* dist, int cap);
+uint64_t sffgpu_forest_fingerprint(sffgpu_forest* f);
+
+/* Multi-GPU wave protocol (one process per GPU; the exchange itself is the caller's RCCL /
+ * gloo all-gather).  A wave round is: begin -> local records -> [all-gather] -> commit.
+ *   sffgpu_forest_round_begin : draws this round's samples for ALL slots (replicated,
+ *        deterministic) and evaluates the slots of this rank's shard on the GPU;
+ *        *n_local = records produced, *done = 1 when the solver has terminated.
+ *   sffgpu_forest_round_records : copies the local fixed-size records (see SFFGPU_RECORD_BYTES).
+ *   sffgpu_forest_round_commit : takes the concatenated records of all ranks (rank order) and
+ *        applies the deterministic in-order decision pass; every rank ends in the same state. */
+#define SFFGPU_RECORD_BYTES 64
+int sffgpu_forest_round_begin(sffgpu_forest* f, int32_t* n_local, int32_t* done);
+int sffgpu_forest_round_records(sffgpu_forest* f, void* records, int cap_records);
+int sffgpu_forest_round_commit(sffgpu_forest* f, const void* all_records, const int32_t* counts_per_rank, int world);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -334,6 +334,17 @@ struct World {
       }
     }
     if (n) build(0, n);
+    int nv = (int)robot.size() / 3;
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int v = 0; v < nv; ++v)
+      for (int i = 0; i < 3; ++i) { lo[i] = std::min(lo[i], robot[3 * v + i]); hi[i] = std::max(hi[i], robot[3 * v + i]); }
+    for (int i = 0; i < 3; ++i) rc[i] = nv ? 0.5 * (lo[i] + hi[i]) : 0;
+    rrad = 0;
+    for (int v = 0; v < nv; ++v) {
+      double d2 = 0;
+      for (int i = 0; i < 3; ++i) d2 += (robot[3 * v + i] - rc[i]) * (robot[3 * v + i] - rc[i]);
+      rrad = std::max(rrad, std::sqrt(d2));
+    }
   }
 
   // src/environment.h:268-276 + :306-316 — boolean "robot at pose p touches any obstacle triangle".
@@ -358,7 +369,24 @@ struct World {
     ++collide_calls;
     if (!has_map) return false;  // src/environment.h:307-309
     double R[9];
-    rotation(p, trig, R);
+    const bool ident = p[3] == 0 && p[4] == 0 && p[5] == 0;
+    if (ident) {
+      // cos(0) = 1 and sin(0) = 0 exactly in both trig modes, so FillRotationMatrix yields the
+      // identity (up to the sign of zeros, which no product below can observe)
+      R[0] = R[4] = R[8] = 1; R[1] = R[2] = R[3] = R[5] = R[6] = R[7] = 0;
+    } else {
+      rotation(p, trig, R);
+    }
+    // conservative pre-test: a box around the robot's bounding sphere (slightly inflated for
+    // rounding) that misses every leaf box proves that no triangle boxes overlap
+    {
+      double c[3];
+      xform(R, p, rc, c);
+      double rr = rrad * (1 + 1e-9) + 1e-9 * (std::fabs(c[0]) + std::fabs(c[1]) + std::fabs(c[2]) + 1);
+      Box sb;
+      for (int i = 0; i < 3; ++i) { sb.lo[i] = c[i] - rr; sb.hi[i] = c[i] + rr; }
+      if (!any_leaf_overlap(sb)) return false;
+    }
     int nr = (int)robot.size() / 9;
     std::vector<double>& W = scratch;
     W.resize(robot.size());
@@ -391,6 +419,24 @@ struct World {
     }
     return false;
   }
+  bool any_leaf_overlap(const Box& b) const {
+    int stack[128], sp = 0;
+    stack[sp++] = 0;
+    while (sp) {
+      const BvhNode& nd = nodes[stack[--sp]];
+      if (!box_overlap(nd.box, b)) continue;
+      if (nd.left < 0) {
+        int first = -1 - nd.left;
+        for (int k = first; k < first + nd.right; ++k)
+          if (box_overlap(env_box[order[k]], b)) return true;
+      } else {
+        stack[sp++] = nd.left;
+        stack[sp++] = nd.right;
+      }
+    }
+    return false;
+  }
+  double rc[3] = {0, 0, 0}, rrad = 0;  // robot bounding sphere (model frame)
   std::vector<double> scratch;
 
   // src/problemStruct.h:154-168 — samples index = 1 .. < parts, rotation fixed at zero,
@@ -537,7 +583,7 @@ struct Forest {
   int goal_node = -1;
   int iter = 0;
   bool solved = false, empty_frontier = false;
-  uint64_t path_free_calls = 0, nn_queries = 0, waves = 0;
+  uint64_t path_free_calls = 0, nn_queries = 0, waves = 0, collide_base = 0;
   Grid grid;
 
   bool path_free(const double* a, const double* b) {
@@ -727,7 +773,10 @@ struct Forest {
       ++done;
       ++waves;
       std::vector<Slot> slots;
-      for (int s = 0; s < cfg.wave; ++s) {
+      // a wave never holds more slots than the pool it draws from (wave == 1 unaffected)
+      const int pool = (!closed.empty() && empty_frontier) ? (int)closed.size() : (int)frontier.size();
+      const int n_slots = std::max(1, std::min(cfg.wave, pool));
+      for (int s = 0; s < n_slots; ++s) {
         Slot sl;
         if (!closed.empty() && empty_frontier) {              // :138-141
           int pos = rng.rand_int(0, (int)closed.size() - 1);
@@ -888,6 +937,7 @@ sffo_forest* sffo_forest_create(sffo_world* w, const sffo_forest_cfg* cfg, const
   sffo_forest* h = new sffo_forest;
   Forest& f = h->f;
   f.w = &w->w;
+  f.collide_base = w->w.collide_calls;
   f.cfg = *cfg;
   if (f.cfg.wave < 1) f.cfg.wave = 1;
   f.rng.eng.reseed(cfg->seed);
@@ -920,7 +970,7 @@ void sffo_forest_get_stats(sffo_forest* h, sffo_forest_stats* s) {
   int nb = 0;
   for (auto& kv : f.borders) nb += (int)kv.second.size();
   s->n_borders = nb;
-  s->collide_calls = f.w->collide_calls;
+  s->collide_calls = f.w->collide_calls - f.collide_base;
   s->path_free_calls = f.path_free_calls;
   s->nn_queries = f.nn_queries;
   s->waves = f.waves;

@@ -1,0 +1,11 @@
+"""space_filling_forest_star_amd — MI355X-native SFF / SFF* tree-expansion hot path.
+
+Thin ctypes binding of libsffgpu.so (C ABI in include/sffgpu.h).  There is no CPU fallback:
+importing works anywhere (so the symbol table can be checked), but creating a Context
+without a gfx950 GPU raises.
+"""
+from ._lib import (Context, Forest, ForestCfg, ForestStats, SffGpuError, lib, lib_path, build_library,
+                   EXPORTED_SYMBOLS)
+
+__all__ = ["Context", "Forest", "ForestCfg", "ForestStats", "SffGpuError", "lib", "lib_path", "build_library",
+           "EXPORTED_SYMBOLS"]

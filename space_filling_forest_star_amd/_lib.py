@@ -1,0 +1,283 @@
+"""ctypes binding of libsffgpu.so.  Names mirror the reference's interface for the hot path:
+Context ~ Environment (+ the FLANN indices), Forest ~ SpaceForest (src/forest.h:31-54)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+EXPORTED_SYMBOLS = [
+    "sffgpu_version", "sffgpu_device_count", "sffgpu_create", "sffgpu_destroy", "sffgpu_last_error",
+    "sffgpu_mesh_upload", "sffgpu_collide_poses", "sffgpu_collide_segments", "sffgpu_sample_steer",
+    "sffgpu_nodes_reset", "sffgpu_nodes_append", "sffgpu_nodes_count", "sffgpu_radius", "sffgpu_knn",
+    "sffgpu_forest_create", "sffgpu_forest_destroy", "sffgpu_forest_run", "sffgpu_forest_get_stats",
+    "sffgpu_forest_get_nodes", "sffgpu_forest_get_borders", "sffgpu_forest_fingerprint",
+    "sffgpu_forest_round_begin", "sffgpu_forest_round_records", "sffgpu_forest_round_commit",
+]
+
+c_dp = C.POINTER(C.c_double)
+c_ip = C.POINTER(C.c_int32)
+c_u8p = C.POINTER(C.c_uint8)
+c_u64p = C.POINTER(C.c_uint64)
+
+
+class SffGpuError(RuntimeError):
+    pass
+
+
+class ForestCfg(C.Structure):
+    _fields_ = [("dim", C.c_int32), ("optimize", C.c_int32), ("has_goal", C.c_int32), ("goal", C.c_double * 6),
+                ("limits", C.c_double * 6), ("dist_tree", C.c_double), ("sampling_dist", C.c_double),
+                ("threshold_misses", C.c_int32), ("max_iterations", C.c_int32), ("node_budget", C.c_int32),
+                ("wave", C.c_int32), ("seed", C.c_uint64), ("rank", C.c_int32), ("world", C.c_int32)]
+
+
+class ForestStats(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("solved", C.c_int32), ("n_nodes", C.c_int32), ("n_trees", C.c_int32),
+                ("frontier_size", C.c_int32), ("closed_size", C.c_int32), ("n_connected", C.c_int32),
+                ("n_borders", C.c_int32), ("collide_calls", C.c_uint64), ("path_free_calls", C.c_uint64),
+                ("nn_queries", C.c_uint64), ("waves", C.c_uint64), ("poses_executed", C.c_uint64),
+                ("segments_executed", C.c_uint64), ("samples_executed", C.c_uint64), ("sweeps", C.c_uint64),
+                ("sweep_nodes", C.c_uint64), ("sweep_queries", C.c_uint64), ("sweep_ms", C.c_double),
+                ("collide_ms", C.c_double), ("sample_ms", C.c_double), ("host_ms", C.c_double),
+                ("total_ms", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+def lib_path():
+    return os.path.join(_HERE, "libsffgpu.so")
+
+
+def build_library(force=False):
+    """Compile the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    if force:
+        subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "csrc"), "clean"])
+    subprocess.check_call(["make", "-s", "-j4", "-C", os.path.join(_HERE, "csrc")])
+    return lib_path()
+
+
+def lib():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise SffGpuError("libsffgpu.so is not built (%s): run __graft_entry__.build() or "
+                          "`make -C space_filling_forest_star_amd/csrc`; there is no CPU fallback" % path)
+    L = C.CDLL(path)
+    L.sffgpu_version.restype = C.c_char_p
+    L.sffgpu_last_error.restype = C.c_char_p
+    L.sffgpu_last_error.argtypes = [C.c_void_p]
+    L.sffgpu_create.argtypes = [C.c_int, C.POINTER(C.c_void_p)]
+    L.sffgpu_destroy.argtypes = [C.c_void_p]
+    L.sffgpu_mesh_upload.argtypes = [C.c_void_p, C.c_int, c_dp, C.c_int]
+    L.sffgpu_collide_poses.argtypes = [C.c_void_p, c_dp, C.c_int, c_u8p]
+    L.sffgpu_collide_segments.argtypes = [C.c_void_p, c_dp, c_dp, C.c_int, c_u8p, c_ip, c_ip]
+    L.sffgpu_sample_steer.argtypes = [C.c_void_p, c_u64p, c_dp, C.c_int, C.c_double, C.c_int, c_dp, c_dp, c_u8p]
+    L.sffgpu_nodes_reset.argtypes = [C.c_void_p, C.c_int]
+    L.sffgpu_nodes_append.argtypes = [C.c_void_p, c_dp, c_ip, C.c_int]
+    L.sffgpu_nodes_count.argtypes = [C.c_void_p]
+    L.sffgpu_radius.argtypes = [C.c_void_p, c_dp, C.c_int, c_dp, c_ip, c_ip, c_ip, c_dp, c_ip, C.c_int]
+    L.sffgpu_knn.argtypes = [C.c_void_p, c_dp, C.c_int, C.c_int, c_ip, c_ip, c_ip, c_dp, c_ip]
+    L.sffgpu_forest_create.argtypes = [C.c_void_p, C.POINTER(ForestCfg), c_dp, C.c_int, C.POINTER(C.c_void_p)]
+    L.sffgpu_forest_destroy.argtypes = [C.c_void_p]
+    L.sffgpu_forest_run.argtypes = [C.c_void_p, C.c_int]
+    L.sffgpu_forest_get_stats.argtypes = [C.c_void_p, C.POINTER(ForestStats)]
+    L.sffgpu_forest_get_nodes.argtypes = [C.c_void_p, c_dp, c_ip, c_ip, c_ip, c_dp, c_dp]
+    L.sffgpu_forest_get_borders.argtypes = [C.c_void_p, c_ip, c_ip, c_ip, c_ip, c_dp, C.c_int]
+    L.sffgpu_forest_fingerprint.restype = C.c_uint64
+    L.sffgpu_forest_fingerprint.argtypes = [C.c_void_p]
+    L.sffgpu_forest_round_begin.argtypes = [C.c_void_p, c_ip, c_ip]
+    L.sffgpu_forest_round_records.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
+    L.sffgpu_forest_round_commit.argtypes = [C.c_void_p, C.c_void_p, c_ip, C.c_int]
+    _LIB = L
+    return L
+
+
+def _f64(a, cols=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if cols is not None:
+        a = a.reshape(-1, cols)
+    return a
+
+
+def _i32(a):
+    return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _dp(a):
+    return a.ctypes.data_as(c_dp)
+
+
+def _ip(a):
+    return None if a is None else a.ctypes.data_as(c_ip)
+
+
+class Context:
+    """One GPU: the collision world (robot + merged obstacles) and the node store."""
+
+    def __init__(self, device=0):
+        self._L = lib()
+        h = C.c_void_p()
+        rc = self._L.sffgpu_create(device, C.byref(h))
+        if rc != 0:
+            raise SffGpuError("sffgpu_create failed: %s" % self._L.sffgpu_last_error(None).decode())
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._L.sffgpu_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc < 0:
+            raise SffGpuError("sffgpu error %d: %s" % (rc, self._L.sffgpu_last_error(self.h).decode()))
+        return rc
+
+    def upload_env(self, tri9):
+        t = _f64(tri9, 9)
+        self._chk(self._L.sffgpu_mesh_upload(self.h, 0, _dp(t), len(t)))
+
+    def upload_robot(self, tri9):
+        t = _f64(tri9, 9)
+        self._chk(self._L.sffgpu_mesh_upload(self.h, 1, _dp(t), len(t)))
+
+    def collide_poses(self, pos6):
+        p = _f64(pos6, 6)
+        out = np.zeros(len(p), np.uint8)
+        self._chk(self._L.sffgpu_collide_poses(self.h, _dp(p), len(p), out.ctypes.data_as(c_u8p)))
+        return out
+
+    def collide_segments(self, a6, b6):
+        a, b = _f64(a6, 6), _f64(b6, 6)
+        n = len(a)
+        free = np.zeros(n, np.uint8)
+        fh = np.zeros(n, np.int32)
+        ns = np.zeros(n, np.int32)
+        self._chk(self._L.sffgpu_collide_segments(self.h, _dp(a), _dp(b), n, free.ctypes.data_as(c_u8p), _ip(fh), _ip(ns)))
+        return free, fh, ns
+
+    def sample_steer(self, words, center6, dist, dim, limits):
+        w = np.ascontiguousarray(words, dtype=np.uint64).reshape(-1, 6)
+        cen = _f64(center6, 6)
+        lim = _f64(limits)
+        out = np.zeros((len(w), 6))
+        ok = np.zeros(len(w), np.uint8)
+        self._chk(self._L.sffgpu_sample_steer(self.h, w.ctypes.data_as(c_u64p), _dp(cen), len(w), dist, dim, _dp(lim),
+                                              _dp(out), ok.ctypes.data_as(c_u8p)))
+        return out, ok
+
+    def nodes_reset(self, capacity=0):
+        self._chk(self._L.sffgpu_nodes_reset(self.h, capacity))
+
+    def nodes_append(self, pos6, tree_id):
+        p = _f64(pos6, 6)
+        t = _i32(tree_id)
+        self._chk(self._L.sffgpu_nodes_append(self.h, _dp(p), _ip(t), len(p)))
+
+    def nodes_count(self):
+        return self._L.sffgpu_nodes_count(self.h)
+
+    def radius(self, q6, r, tree=None, max_id=None, cap=256):
+        q = _f64(q6, 6)
+        nq = len(q)
+        rr = _f64(np.broadcast_to(np.asarray(r, dtype=np.float64), (nq,)))
+        tr = None if tree is None else _i32(np.broadcast_to(np.asarray(tree), (nq,)))
+        mx = None if max_id is None else _i32(np.broadcast_to(np.asarray(max_id), (nq,)))
+        idx = np.full((nq, cap), -1, np.int32)
+        dist = np.zeros((nq, cap))
+        cnt = np.zeros(nq, np.int32)
+        self._chk(self._L.sffgpu_radius(self.h, _dp(q), nq, _dp(rr), _ip(tr), _ip(mx), _ip(idx), _dp(dist), _ip(cnt), cap))
+        return idx, dist, cnt
+
+    def knn(self, q6, k, tree=None, max_id=None):
+        q = _f64(q6, 6)
+        nq = len(q)
+        tr = None if tree is None else _i32(np.broadcast_to(np.asarray(tree), (nq,)))
+        mx = None if max_id is None else _i32(np.broadcast_to(np.asarray(max_id), (nq,)))
+        idx = np.full((nq, k), -1, np.int32)
+        dist = np.zeros((nq, k))
+        cnt = np.zeros(nq, np.int32)
+        self._chk(self._L.sffgpu_knn(self.h, _dp(q), nq, k, _ip(tr), _ip(mx), _ip(idx), _dp(dist), _ip(cnt)))
+        return idx, dist, cnt
+
+
+class Forest:
+    """SpaceForest solver session (reference src/forest.h:31-54) on one Context."""
+
+    def __init__(self, ctx, roots, limits, dist_tree, sampling_dist, dim=6, optimize=False, goal=None,
+                 threshold_misses=5, max_iterations=100000, node_budget=0, wave=1, seed=1, rank=0, world=1):
+        self.ctx = ctx
+        cfg = ForestCfg()
+        cfg.dim = dim
+        cfg.optimize = int(optimize)
+        cfg.has_goal = int(goal is not None)
+        if goal is not None:
+            cfg.goal = (C.c_double * 6)(*goal)
+        cfg.limits = (C.c_double * 6)(*limits)
+        cfg.dist_tree = dist_tree
+        cfg.sampling_dist = sampling_dist
+        cfg.threshold_misses = threshold_misses
+        cfg.max_iterations = max_iterations
+        cfg.node_budget = node_budget
+        cfg.wave = wave
+        cfg.seed = seed
+        cfg.rank = rank
+        cfg.world = world
+        self.cfg = cfg
+        r = _f64(roots, 6)
+        h = C.c_void_p()
+        ctx._chk(ctx._L.sffgpu_forest_create(ctx.h, C.byref(cfg), _dp(r), len(r), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx._L.sffgpu_forest_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run(self, max_waves=0):
+        self.ctx._chk(self.ctx._L.sffgpu_forest_run(self.h, max_waves))
+
+    def stats(self):
+        s = ForestStats()
+        self.ctx._chk(self.ctx._L.sffgpu_forest_get_stats(self.h, C.byref(s)))
+        return s.as_dict()
+
+    def nodes(self):
+        n = self.stats()["n_nodes"]
+        pos = np.zeros((n, 6))
+        parent = np.zeros(n, np.int32)
+        tree = np.zeros(n, np.int32)
+        it = np.zeros(n, np.int32)
+        cost = np.zeros(n)
+        dpar = np.zeros(n)
+        self.ctx._chk(self.ctx._L.sffgpu_forest_get_nodes(self.h, _dp(pos), _ip(parent), _ip(tree), _ip(it), _dp(cost),
+                                                          _dp(dpar)))
+        return dict(pos=pos, parent=parent, tree=tree, iter=it, cost=cost, dpar=dpar)
+
+    def borders(self, cap=1 << 20):
+        ta, tb, n1, n2 = (np.zeros(cap, np.int32) for _ in range(4))
+        d = np.zeros(cap)
+        k = self.ctx._chk(self.ctx._L.sffgpu_forest_get_borders(self.h, _ip(ta), _ip(tb), _ip(n1), _ip(n2), _dp(d), cap))
+        k = min(k, cap)
+        return dict(ta=ta[:k].copy(), tb=tb[:k].copy(), n1=n1[:k].copy(), n2=n2[:k].copy(), dist=d[:k].copy())
+
+    def fingerprint(self):
+        return self.ctx._L.sffgpu_forest_fingerprint(self.h)

@@ -1,0 +1,199 @@
+// capi.cpp — extern "C" surface of libsffgpu.so (declared in include/sffgpu.h).
+#include <cstring>
+#include <string>
+
+#include "engine.h"
+
+using namespace sff;
+
+struct sffgpu_ctx {
+  Ctx* c;
+};
+struct sffgpu_forest {
+  Forest* f;
+  sffgpu_ctx* owner;
+};
+
+static std::string g_create_err;
+
+#define GUARD(ctxp, body)                          \
+  try {                                            \
+    body;                                          \
+    return SFFGPU_OK;                              \
+  } catch (const HipError& e) {                    \
+    (ctxp)->c->err = e.msg;                        \
+    return SFFGPU_ERR_HIP;                         \
+  } catch (const std::exception& e) {              \
+    (ctxp)->c->err = e.what();                     \
+    return SFFGPU_ERR_STATE;                       \
+  }
+
+extern "C" {
+
+const char* sffgpu_version(void) { return "sffgpu 0.1 (gfx950)"; }
+
+int sffgpu_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+
+int sffgpu_create(int device, sffgpu_ctx** out) {
+  if (!out) return SFFGPU_ERR_ARG;
+  *out = nullptr;
+  try {
+    Ctx* c = new Ctx(device);
+    *out = new sffgpu_ctx{c};
+    return SFFGPU_OK;
+  } catch (const HipError& e) {
+    g_create_err = e.msg;
+    return SFFGPU_ERR_HIP;
+  }
+}
+
+void sffgpu_destroy(sffgpu_ctx* ctx) {
+  if (!ctx) return;
+  delete ctx->c;
+  delete ctx;
+}
+
+const char* sffgpu_last_error(sffgpu_ctx* ctx) { return ctx ? ctx->c->err.c_str() : g_create_err.c_str(); }
+
+int sffgpu_mesh_upload(sffgpu_ctx* ctx, int role, const double* tri9, int n_tri) {
+  if (!ctx || n_tri < 0 || (n_tri > 0 && !tri9)) return SFFGPU_ERR_ARG;
+  GUARD(ctx, ctx->c->upload_mesh(role, tri9, n_tri));
+}
+
+int sffgpu_collide_poses(sffgpu_ctx* ctx, const double* pos6, int n, uint8_t* hit) {
+  if (!ctx || n < 0 || (n > 0 && (!pos6 || !hit))) return SFFGPU_ERR_ARG;
+  GUARD(ctx, ctx->c->collide_poses(pos6, n, hit));
+}
+
+int sffgpu_collide_segments(sffgpu_ctx* ctx, const double* a6, const double* b6, int n, uint8_t* is_free,
+                            int32_t* first_hit, int32_t* n_samples) {
+  if (!ctx || n < 0 || (n > 0 && (!a6 || !b6 || !is_free))) return SFFGPU_ERR_ARG;
+  GUARD(ctx, ctx->c->collide_segments(a6, b6, n, is_free, first_hit, n_samples));
+}
+
+int sffgpu_sample_steer(sffgpu_ctx* ctx, const uint64_t* words, const double* center6, int n, double dist, int dim,
+                        const double limits[6], double* out6, uint8_t* in_limits) {
+  if (!ctx || n < 0 || (dim != 2 && dim != 6) || (n > 0 && (!words || !center6 || !limits || !out6 || !in_limits)))
+    return SFFGPU_ERR_ARG;
+  GUARD(ctx, ctx->c->sample_steer(words, center6, n, dist, dim, limits, out6, in_limits));
+}
+
+int sffgpu_nodes_reset(sffgpu_ctx* ctx, int capacity) {
+  if (!ctx || capacity < 0) return SFFGPU_ERR_ARG;
+  GUARD(ctx, ctx->c->store_reset(capacity));
+}
+int sffgpu_nodes_append(sffgpu_ctx* ctx, const double* pos6, const int32_t* tree_id, int n) {
+  if (!ctx || n < 0 || (n > 0 && (!pos6 || !tree_id))) return SFFGPU_ERR_ARG;
+  GUARD(ctx, ctx->c->store_append(pos6, tree_id, n));
+}
+int sffgpu_nodes_count(sffgpu_ctx* ctx) { return ctx ? ctx->c->store_n : SFFGPU_ERR_ARG; }
+
+int sffgpu_radius(sffgpu_ctx* ctx, const double* q6, int nq, const double* r, const int32_t* tree,
+                  const int32_t* max_id, int32_t* idx, double* dist, int32_t* cnt, int cap) {
+  if (!ctx || nq < 0 || cap <= 0 || (nq > 0 && (!q6 || !r || !idx || !cnt))) return SFFGPU_ERR_ARG;
+  GUARD(ctx, ctx->c->radius(q6, nq, r, tree, max_id, idx, dist, cnt, cap));
+}
+int sffgpu_knn(sffgpu_ctx* ctx, const double* q6, int nq, int k, const int32_t* tree, const int32_t* max_id,
+               int32_t* idx, double* dist, int32_t* cnt) {
+  if (!ctx || nq < 0 || k <= 0 || (nq > 0 && (!q6 || !idx || !cnt))) return SFFGPU_ERR_ARG;
+  GUARD(ctx, ctx->c->knn(q6, nq, k, tree, max_id, idx, dist, cnt));
+}
+
+int sffgpu_forest_create(sffgpu_ctx* ctx, const sffgpu_forest_cfg* cfg, const double* roots6, int n_roots,
+                         sffgpu_forest** out) {
+  if (!ctx || !cfg || !roots6 || n_roots <= 0 || !out) return SFFGPU_ERR_ARG;
+  *out = nullptr;
+  GUARD(ctx, {
+    Forest* F = new Forest(ctx->c, *cfg, roots6, n_roots);
+    sffgpu_forest* h = new sffgpu_forest;
+    h->f = F;
+    h->owner = ctx;
+    *out = h;
+  });
+}
+void sffgpu_forest_destroy(sffgpu_forest* f) {
+  if (!f) return;
+  delete f->f;
+  delete f;
+}
+int sffgpu_forest_run(sffgpu_forest* f, int max_waves) {
+  if (!f) return SFFGPU_ERR_ARG;
+  GUARD(f->owner, f->f->run(max_waves));
+}
+int sffgpu_forest_get_stats(sffgpu_forest* f, sffgpu_forest_stats* out) {
+  if (!f || !out) return SFFGPU_ERR_ARG;
+  Forest& F = *f->f;
+  sffgpu_forest_stats s = F.st;
+  s.iterations = F.iter;
+  bool solved = F.solved;
+  if (!solved && !F.cfg.has_goal) solved = F.max_connected() == F.num_roots;  // src/forest.h:204-206
+  s.solved = solved;
+  s.n_nodes = (int)F.nodes.size();
+  s.n_trees = (int)F.trees.size();
+  s.frontier_size = (int)F.frontier.size();
+  s.closed_size = (int)F.closed.size();
+  s.n_connected = (int)F.connected.size();
+  int nb = 0;
+  for (auto& kv : F.borders) nb += (int)kv.second.size();
+  s.n_borders = nb;
+  s.sweep_ms = F.ctx->kernel_ms[T_SWEEP];
+  s.collide_ms = F.ctx->kernel_ms[T_COLLIDE];
+  s.sample_ms = F.ctx->kernel_ms[T_SAMPLE];
+  *out = s;
+  return SFFGPU_OK;
+}
+int sffgpu_forest_get_nodes(sffgpu_forest* f, double* pos6, int32_t* parent, int32_t* tree, int32_t* iter, double* cost,
+                            double* dist_parent) {
+  if (!f) return SFFGPU_ERR_ARG;
+  Forest& F = *f->f;
+  for (size_t i = 0; i < F.nodes.size(); ++i) {
+    const FNode& n = F.nodes[i];
+    if (pos6) memcpy(pos6 + 6 * i, n.pos, sizeof n.pos);
+    if (parent) parent[i] = n.parent;
+    if (tree) tree[i] = n.tree;
+    if (iter) iter[i] = (int32_t)n.iter;
+    if (cost) cost[i] = n.d_root;
+    if (dist_parent) dist_parent[i] = n.d_closest;
+  }
+  return SFFGPU_OK;
+}
+int sffgpu_forest_get_borders(sffgpu_forest* f, int32_t* ta, int32_t* tb, int32_t* n1, int32_t* n2, double* dist,
+                              int cap) {
+  if (!f) return SFFGPU_ERR_ARG;
+  int k = 0;
+  for (auto& kv : f->f->borders)
+    for (const Border& b : kv.second) {
+      if (k < cap) {
+        if (ta) ta[k] = kv.first.first;
+        if (tb) tb[k] = kv.first.second;
+        if (n1) n1[k] = b.n1;
+        if (n2) n2[k] = b.n2;
+        if (dist) dist[k] = b.dist;
+      }
+      ++k;
+    }
+  return k;
+}
+uint64_t sffgpu_forest_fingerprint(sffgpu_forest* f) { return f ? f->f->fingerprint() : 0; }
+
+int sffgpu_forest_round_begin(sffgpu_forest* f, int32_t*, int32_t*) {
+  if (!f) return SFFGPU_ERR_ARG;
+  f->owner->c->err = "multi-GPU round protocol: not implemented in this build";
+  return SFFGPU_ERR_STATE;
+}
+int sffgpu_forest_round_records(sffgpu_forest* f, void*, int) {
+  if (!f) return SFFGPU_ERR_ARG;
+  f->owner->c->err = "multi-GPU round protocol: not implemented in this build";
+  return SFFGPU_ERR_STATE;
+}
+int sffgpu_forest_round_commit(sffgpu_forest* f, const void*, const int32_t*, int) {
+  if (!f) return SFFGPU_ERR_ARG;
+  f->owner->c->err = "multi-GPU round protocol: not implemented in this build";
+  return SFFGPU_ERR_STATE;
+}
+
+}  // extern "C"

@@ -1,0 +1,523 @@
+// engine.cpp — device context and batched primitive operations of libsffgpu.
+#include "engine.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+#include "sff_geom.h"
+
+namespace sff {
+
+void hip_check(hipError_t e, const char* what) {
+  if (e != hipSuccess) throw HipError{std::string(what) + ": " + hipGetErrorString(e)};
+}
+#define HIPCHK(x) hip_check((x), #x)
+
+void DevBuf::ensure(size_t bytes) {
+  if (bytes <= cap) return;
+  size_t want = std::max(bytes, cap * 2);
+  want = (want + 255) & ~(size_t)255;
+  void* np = nullptr;
+  HIPCHK(hipMalloc(&np, want));
+  if (p) {
+    HIPCHK(hipMemcpy(np, p, cap, hipMemcpyDeviceToDevice));
+    (void)hipFree(p);
+  }
+  p = np;
+  cap = want;
+}
+void DevBuf::release() {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+  cap = 0;
+}
+void PinBuf::ensure(size_t bytes) {
+  if (bytes <= cap) return;
+  size_t want = std::max(bytes, cap * 2);
+  void* np = nullptr;
+  HIPCHK(hipHostMalloc(&np, want, hipHostMallocDefault));
+  if (p) {
+    memcpy(np, p, cap);
+    (void)hipHostFree(p);
+  }
+  p = np;
+  cap = want;
+}
+void PinBuf::release() {
+  if (p) (void)hipHostFree(p);
+  p = nullptr;
+  cap = 0;
+}
+
+// ------------------------------------------------------------------ RNG
+void Mt64::reseed(uint64_t seed) {
+  mt[0] = seed;
+  for (int i = 1; i < 312; ++i) mt[i] = 6364136223846793005ULL * (mt[i - 1] ^ (mt[i - 1] >> 62)) + (uint64_t)i;
+  idx = 312;
+}
+uint64_t Mt64::next() {
+  if (idx >= 312) {
+    for (int i = 0; i < 312; ++i) {
+      uint64_t x = (mt[i] & 0xFFFFFFFF80000000ULL) | (mt[(i + 1) % 312] & 0x7FFFFFFFULL);
+      uint64_t xa = x >> 1;
+      if (x & 1ULL) xa ^= 0xB5026F5AA96619E9ULL;
+      mt[i] = mt[(i + 156) % 312] ^ xa;
+    }
+    idx = 0;
+  }
+  uint64_t y = mt[idx++];
+  y ^= (y >> 29) & 0x5555555555555555ULL;
+  y ^= (y << 17) & 0x71D67FFFEDA60000ULL;
+  y ^= (y << 37) & 0xFFF7EEE000000000ULL;
+  y ^= (y >> 43);
+  return y;
+}
+int Mt64::uniform_int(int lo, int hi) {
+  uint64_t range = (uint64_t)((int64_t)hi - (int64_t)lo) + 1ULL;
+  unsigned __int128 prod = (unsigned __int128)next() * range;
+  uint64_t low = (uint64_t)prod;
+  if (low < range) {
+    uint64_t thr = (0ULL - range) % range;
+    while (low < thr) {
+      prod = (unsigned __int128)next() * range;
+      low = (uint64_t)prod;
+    }
+  }
+  return lo + (int)(uint64_t)(prod >> 64);
+}
+
+// ------------------------------------------------------------------ context
+Ctx::Ctx(int dev) : device(dev) {
+  int n = 0;
+  HIPCHK(hipGetDeviceCount(&n));
+  if (n <= 0) throw HipError{"no HIP device visible: libsffgpu has no CPU fallback"};
+  if (dev < 0 || dev >= n) throw HipError{"device index out of range"};
+  HIPCHK(hipSetDevice(dev));
+  hipDeviceProp_t prop;
+  HIPCHK(hipGetDeviceProperties(&prop, dev));
+  if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
+    throw HipError{std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only"};
+  HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+}
+
+Ctx::~Ctx() {
+  (void)hipSetDevice(device);
+  if (stream) (void)hipStreamSynchronize(stream);
+  for (auto& t : pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+  for (auto e : pool) (void)hipEventDestroy(e);
+  DevBuf* bufs[] = {&env_tri, &env_box, &rob_tri, &sx, &sy, &sz, &syaw, &spitch, &sroll, &stree, &spos,
+                    &d_a, &d_b, &d_c, &d_d, &d_e, &d_f, &d_g, &d_h};
+  for (DevBuf* b : bufs) b->release();
+  for (auto& b : level_box) b.release();
+  PinBuf* pins[] = {&h_a, &h_b, &h_c, &h_d, &h_e, &h_f, &h_g, &h_h};
+  for (PinBuf* b : pins) b->release();
+  if (stream) (void)hipStreamDestroy(stream);
+}
+
+hipEvent_t Ctx::get_event() {
+  if (!pool.empty()) {
+    hipEvent_t e = pool.back();
+    pool.pop_back();
+    return e;
+  }
+  hipEvent_t e;
+  HIPCHK(hipEventCreate(&e));
+  return e;
+}
+void Ctx::time_begin(int kind) {
+  Timed t{get_event(), get_event(), kind};
+  HIPCHK(hipEventRecord(t.a, stream));
+  pending.push_back(t);
+}
+void Ctx::time_end() { HIPCHK(hipEventRecord(pending.back().b, stream)); }
+void Ctx::sync() {
+  HIPCHK(hipStreamSynchronize(stream));
+  for (auto& t : pending) {
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, t.a, t.b));
+    kernel_ms[t.kind] += ms;
+    kernel_launches[t.kind] += 1;
+    pool.push_back(t.a);
+    pool.push_back(t.b);
+  }
+  pending.clear();
+}
+
+// ------------------------------------------------------------------ collision models
+static inline uint64_t spread21(uint64_t v) {
+  v &= 0x1FFFFF;
+  v = (v | v << 32) & 0x1F00000000FFFFULL;
+  v = (v | v << 16) & 0x1F0000FF0000FFULL;
+  v = (v | v << 8) & 0x100F00F00F00F00FULL;
+  v = (v | v << 4) & 0x10C30C30C30C30C3ULL;
+  v = (v | v << 2) & 0x1249249249249249ULL;
+  return v;
+}
+
+// Replaces RAPID_model::BeginModel/AddTri/EndModel (src/environment.h:101-115,222).  The
+// environment hierarchy is 64-ary so that one wavefront tests all children of a node at once:
+// triangles are ordered along a Morton curve of their box centres, 64 consecutive triangles
+// form a level-0 group, 64 consecutive groups a level-1 group, and so on until <= 64 remain.
+void Ctx::upload_mesh(int role, const double* tri9, int n) {
+  HIPCHK(hipSetDevice(device));
+  if (role == SFFGPU_MESH_ROBOT) {
+    if (n <= 0) throw HipError{"robot mesh must have at least one triangle"};
+    rob_tri.ensure((size_t)n * 9 * sizeof(double));
+    HIPCHK(hipMemcpy(rob_tri.p, tri9, (size_t)n * 9 * sizeof(double), hipMemcpyHostToDevice));
+    robv.tri = rob_tri.as<double>();
+    robv.n_tri = n;
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    for (int v = 0; v < n * 3; ++v)
+      for (int i = 0; i < 3; ++i) {
+        lo[i] = std::min(lo[i], tri9[3 * v + i]);
+        hi[i] = std::max(hi[i], tri9[3 * v + i]);
+      }
+    double rad = 0;
+    for (int i = 0; i < 3; ++i) { robv.lo[i] = lo[i]; robv.hi[i] = hi[i]; robv.center[i] = 0.5 * (lo[i] + hi[i]); }
+    for (int v = 0; v < n * 3; ++v) {
+      double d2 = 0;
+      for (int i = 0; i < 3; ++i) d2 += (tri9[3 * v + i] - robv.center[i]) * (tri9[3 * v + i] - robv.center[i]);
+      rad = std::max(rad, std::sqrt(d2));
+    }
+    robv.radius = rad;
+    have_robot = true;
+    return;
+  }
+  if (role != SFFGPU_MESH_ENV) throw HipError{"unknown mesh role"};
+  envv = sffk::EnvView{};
+  have_env = true;
+  if (n <= 0) return;  // HasMap == false
+  std::vector<double> box((size_t)n * 6);
+  double glo[3] = {1e300, 1e300, 1e300}, ghi[3] = {-1e300, -1e300, -1e300};
+  for (int t = 0; t < n; ++t)
+    for (int a = 0; a < 3; ++a) {
+      const double* P = tri9 + 9 * (size_t)t;
+      double lo = std::min(P[a], std::min(P[3 + a], P[6 + a])), hi = std::max(P[a], std::max(P[3 + a], P[6 + a]));
+      box[6 * (size_t)t + a] = lo;
+      box[6 * (size_t)t + 3 + a] = hi;
+      glo[a] = std::min(glo[a], lo);
+      ghi[a] = std::max(ghi[a], hi);
+    }
+  env_maxabs = 1.0;
+  for (int a = 0; a < 3; ++a) env_maxabs = std::max(env_maxabs, std::max(std::fabs(glo[a]), std::fabs(ghi[a])));
+  std::vector<std::pair<uint64_t, int>> order(n);
+  for (int t = 0; t < n; ++t) {
+    uint64_t code = 0;
+    for (int a = 0; a < 3; ++a) {
+      double ext = ghi[a] - glo[a];
+      double c = 0.5 * (box[6 * (size_t)t + a] + box[6 * (size_t)t + 3 + a]);
+      double u = ext > 0 ? (c - glo[a]) / ext : 0.0;
+      uint64_t q = (uint64_t)std::min(2097151.0, std::max(0.0, u * 2097151.0));
+      code |= spread21(q) << a;
+    }
+    order[t] = {code, t};
+  }
+  std::sort(order.begin(), order.end());
+  std::vector<double> tri_s((size_t)n * 9), box_s((size_t)n * 6);
+  for (int k = 0; k < n; ++k) {
+    memcpy(&tri_s[9 * (size_t)k], tri9 + 9 * (size_t)order[k].second, 9 * sizeof(double));
+    memcpy(&box_s[6 * (size_t)k], &box[6 * (size_t)order[k].second], 6 * sizeof(double));
+  }
+  env_tri.ensure(tri_s.size() * sizeof(double));
+  env_box.ensure(box_s.size() * sizeof(double));
+  HIPCHK(hipMemcpy(env_tri.p, tri_s.data(), tri_s.size() * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(env_box.p, box_s.data(), box_s.size() * sizeof(double), hipMemcpyHostToDevice));
+  envv.tri = env_tri.as<double>();
+  envv.tri_box = env_box.as<double>();
+  envv.n_tri = n;
+  // levels
+  std::vector<double> cur = box_s;
+  int count = n, L = 0;
+  while (true) {
+    int groups = (count + 63) / 64;
+    std::vector<double> nxt((size_t)groups * 6);
+    for (int g = 0; g < groups; ++g) {
+      double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+      for (int k = g * 64; k < std::min(count, g * 64 + 64); ++k)
+        for (int a = 0; a < 3; ++a) {
+          lo[a] = std::min(lo[a], cur[6 * (size_t)k + a]);
+          hi[a] = std::max(hi[a], cur[6 * (size_t)k + 3 + a]);
+        }
+      for (int a = 0; a < 3; ++a) { nxt[6 * (size_t)g + a] = lo[a]; nxt[6 * (size_t)g + 3 + a] = hi[a]; }
+    }
+    if (L >= SFFK_MAX_LEVELS) throw HipError{"environment mesh too large for the box hierarchy"};
+    level_box[L].ensure(nxt.size() * sizeof(double));
+    HIPCHK(hipMemcpy(level_box[L].p, nxt.data(), nxt.size() * sizeof(double), hipMemcpyHostToDevice));
+    envv.level_box[L] = level_box[L].as<double>();
+    envv.level_count[L] = groups;
+    ++L;
+    cur.swap(nxt);
+    count = groups;
+    if (groups <= 64) break;
+  }
+  envv.n_levels = L;
+}
+
+// ------------------------------------------------------------------ node store
+sffk::NodeStoreView Ctx::store_view() const {
+  return sffk::NodeStoreView{sx.as<float>(), sy.as<float>(), sz.as<float>(), syaw.as<float>(), spitch.as<float>(),
+                             sroll.as<float>(), stree.as<int32_t>(), spos.as<double>()};
+}
+static sffk::NodeStoreMut store_mut(const Ctx& c) {
+  return sffk::NodeStoreMut{c.sx.as<float>(), c.sy.as<float>(), c.sz.as<float>(), c.syaw.as<float>(),
+                            c.spitch.as<float>(), c.sroll.as<float>(), c.stree.as<int32_t>(), c.spos.as<double>()};
+}
+void Ctx::store_reserve(int capacity) {
+  if (capacity <= store_cap) return;
+  HIPCHK(hipSetDevice(device));
+  sync();
+  int cap = std::max(capacity, store_cap * 2);
+  cap = (cap + 1023) & ~1023;
+  DevBuf* cols[] = {&sx, &sy, &sz, &syaw, &spitch, &sroll};
+  for (DevBuf* b : cols) b->ensure((size_t)cap * sizeof(float));
+  stree.ensure((size_t)cap * sizeof(int32_t));
+  spos.ensure((size_t)cap * 6 * sizeof(double));
+  store_cap = cap;
+}
+void Ctx::store_reset(int capacity) {
+  store_n = 0;
+  store_maxabs = 1.0;
+  store_reserve(std::max(capacity, 1024));
+}
+void Ctx::store_append(const double* pos6, const int32_t* tree, int n) {
+  if (n <= 0) return;
+  HIPCHK(hipSetDevice(device));
+  store_reserve(store_n + n);
+  h_a.ensure((size_t)n * 6 * sizeof(double));
+  h_b.ensure((size_t)n * sizeof(int32_t));
+  memcpy(h_a.p, pos6, (size_t)n * 6 * sizeof(double));
+  memcpy(h_b.p, tree, (size_t)n * sizeof(int32_t));
+  for (int i = 0; i < n * 6; ++i)
+    if (i % 6 < 3) store_maxabs = std::max(store_maxabs, std::fabs(pos6[i]));
+  d_a.ensure((size_t)n * 6 * sizeof(double));
+  d_b.ensure((size_t)n * sizeof(int32_t));
+  HIPCHK(hipMemcpyAsync(d_a.p, h_a.p, (size_t)n * 6 * sizeof(double), hipMemcpyHostToDevice, stream));
+  HIPCHK(hipMemcpyAsync(d_b.p, h_b.p, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+  sffk::launch_store_write(stream, store_mut(*this), d_a.as<double>(), d_b.as<int32_t>(), nullptr, nullptr, n, store_n);
+  sync();
+  store_n += n;
+}
+
+// slack that makes the fp32 sweep filter a superset of the exact fp64 test: a few fp32 ulps of
+// the largest coordinate magnitude in play
+double Ctx::sweep_eps() const { return std::max(store_maxabs, env_maxabs) * std::ldexp(1.0, -20); }
+
+// ------------------------------------------------------------------ batched primitives
+void Ctx::collide_poses(const double* pos6, int n, uint8_t* hit) {
+  if (n <= 0) return;
+  if (!have_env || !have_robot) throw HipError{"collide_poses: upload ENV and ROBOT meshes first"};
+  HIPCHK(hipSetDevice(device));
+  h_a.ensure((size_t)n * 6 * sizeof(double));
+  h_b.ensure((size_t)n);
+  memcpy(h_a.p, pos6, (size_t)n * 6 * sizeof(double));
+  d_a.ensure((size_t)n * 6 * sizeof(double));
+  d_b.ensure((size_t)n);
+  HIPCHK(hipMemcpyAsync(d_a.p, h_a.p, (size_t)n * 6 * sizeof(double), hipMemcpyHostToDevice, stream));
+  time_begin(T_COLLIDE);
+  sffk::launch_collide_poses(stream, envv, robv, d_a.as<double>(), n, d_b.as<uint8_t>());
+  time_end();
+  HIPCHK(hipMemcpyAsync(h_b.p, d_b.p, (size_t)n, hipMemcpyDeviceToHost, stream));
+  sync();
+  memcpy(hit, h_b.p, (size_t)n);
+}
+
+void Ctx::collide_segments(const double* a6, const double* b6, int n, uint8_t* is_free, int32_t* first_hit,
+                           int32_t* n_samples) {
+  if (n <= 0) return;
+  if (!have_env || !have_robot) throw HipError{"collide_segments: upload ENV and ROBOT meshes first"};
+  HIPCHK(hipSetDevice(device));
+  const size_t pb = (size_t)n * 6 * sizeof(double);
+  h_a.ensure(pb); h_b.ensure(pb); h_c.ensure((size_t)n); h_d.ensure((size_t)n * 4); h_e.ensure((size_t)n * 4);
+  memcpy(h_a.p, a6, pb);
+  memcpy(h_b.p, b6, pb);
+  d_a.ensure(pb); d_b.ensure(pb); d_c.ensure((size_t)n); d_d.ensure((size_t)n * 4); d_e.ensure((size_t)n * 4);
+  HIPCHK(hipMemcpyAsync(d_a.p, h_a.p, pb, hipMemcpyHostToDevice, stream));
+  HIPCHK(hipMemcpyAsync(d_b.p, h_b.p, pb, hipMemcpyHostToDevice, stream));
+  time_begin(T_COLLIDE);
+  sffk::launch_collide_segments(stream, envv, robv, d_a.as<double>(), d_b.as<double>(), n, d_c.as<uint8_t>(),
+                                d_d.as<int32_t>(), d_e.as<int32_t>());
+  time_end();
+  HIPCHK(hipMemcpyAsync(h_c.p, d_c.p, (size_t)n, hipMemcpyDeviceToHost, stream));
+  HIPCHK(hipMemcpyAsync(h_d.p, d_d.p, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
+  HIPCHK(hipMemcpyAsync(h_e.p, d_e.p, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
+  sync();
+  std::vector<uint8_t> fr(h_c.as<uint8_t>(), h_c.as<uint8_t>() + n);
+  std::vector<int32_t> fh(h_d.as<int32_t>(), h_d.as<int32_t>() + n), ns(h_e.as<int32_t>(), h_e.as<int32_t>() + n);
+  // edges whose candidate list overflowed are re-run sample by sample through the pose kernel
+  for (int i = 0; i < n; ++i) {
+    if (fr[i] != 2) continue;
+    const double* a = a6 + 6 * (size_t)i;
+    const double* b = b6 + 6 * (size_t)i;
+    double parts = sffg::edge_parts(a, b);
+    int cnt = sffg::edge_samples(parts);
+    double dir[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
+    std::vector<double> poses((size_t)cnt * 6, 0.0);
+    for (int s = 1; s <= cnt; ++s) sffg::edge_sample_pos(a, dir, parts, s, &poses[6 * (size_t)(s - 1)]);
+    std::vector<uint8_t> hits(cnt);
+    collide_poses(poses.data(), cnt, hits.data());
+    fh[i] = -1;
+    for (int s = 0; s < cnt; ++s)
+      if (hits[s]) { fh[i] = s + 1; break; }
+    fr[i] = fh[i] < 0 ? 1 : 0;
+  }
+  for (int i = 0; i < n; ++i) {
+    is_free[i] = fr[i];
+    if (first_hit) first_hit[i] = fh[i];
+    if (n_samples) n_samples[i] = ns[i];
+  }
+}
+
+void Ctx::sample_steer(const uint64_t* words, const double* center6, int n, double dist, int dim, const double* limits,
+                       double* out6, uint8_t* in_limits) {
+  if (n <= 0) return;
+  HIPCHK(hipSetDevice(device));
+  const size_t wb = (size_t)n * 6 * sizeof(uint64_t), pb = (size_t)n * 6 * sizeof(double);
+  h_a.ensure(wb); h_b.ensure(pb); h_c.ensure(pb); h_d.ensure((size_t)n);
+  memcpy(h_a.p, words, wb);
+  memcpy(h_b.p, center6, pb);
+  d_a.ensure(wb); d_b.ensure(pb); d_c.ensure(pb); d_d.ensure((size_t)n);
+  HIPCHK(hipMemcpyAsync(d_a.p, h_a.p, wb, hipMemcpyHostToDevice, stream));
+  HIPCHK(hipMemcpyAsync(d_b.p, h_b.p, pb, hipMemcpyHostToDevice, stream));
+  sffk::SampleParams prm{};
+  memcpy(prm.limits, limits, sizeof prm.limits);
+  time_begin(T_SAMPLE);
+  sffk::launch_sample_steer(stream, d_a.as<uint64_t>(), nullptr, nullptr, d_b.as<double>(), n, dist, dim, prm,
+                            d_c.as<double>(), d_d.as<uint8_t>(), nullptr, nullptr, 0);
+  time_end();
+  HIPCHK(hipMemcpyAsync(h_c.p, d_c.p, pb, hipMemcpyDeviceToHost, stream));
+  HIPCHK(hipMemcpyAsync(h_d.p, d_d.p, (size_t)n, hipMemcpyDeviceToHost, stream));
+  sync();
+  memcpy(out6, h_c.p, pb);
+  memcpy(in_limits, h_d.p, (size_t)n);
+}
+
+namespace {
+struct HitRec {
+  double d;
+  int id;
+  bool operator<(const HitRec& o) const { return d < o.d || (d == o.d && id < o.id); }
+};
+}  // namespace
+
+// One sweep launch + host-side ordering.  Returns the raw per-query totals.
+static void sweep_once(Ctx& c, const double* q6, int nq, const std::vector<double>& r, const int32_t* tree,
+                       const int32_t* max_id, const std::vector<uint8_t>& active, int cap, std::vector<int32_t>& cnt,
+                       std::vector<std::vector<HitRec>>& out) {
+  const double eps = c.sweep_eps();
+  c.h_a.ensure((size_t)nq * sizeof(sffk::SweepQuery));
+  c.h_b.ensure((size_t)nq * 6 * sizeof(double));
+  sffk::SweepQuery* hq = c.h_a.as<sffk::SweepQuery>();
+  for (int i = 0; i < nq; ++i) {
+    const double* p = q6 + 6 * (size_t)i;
+    sffk::SweepQuery q{};
+    q.x = (float)p[0]; q.y = (float)p[1]; q.z = (float)p[2];
+    q.yaw = (float)p[3]; q.pitch = (float)p[4]; q.roll = (float)p[5];
+    q.r = r[i];
+    double ri = (r[i] + eps) * (1.0 + 1e-5);
+    double r2 = ri * ri;
+    q.r2f = r2 > 1e37 ? 3.0e38f : (float)r2 * 1.000001f;
+    q.tree = tree ? tree[i] : -1;
+    q.max_id = max_id ? max_id[i] : std::numeric_limits<int32_t>::max();
+    q.active = active[i];
+    hq[i] = q;
+  }
+  memcpy(c.h_b.p, q6, (size_t)nq * 6 * sizeof(double));
+  c.d_a.ensure((size_t)nq * sizeof(sffk::SweepQuery));
+  c.d_b.ensure((size_t)nq * 6 * sizeof(double));
+  c.d_c.ensure((size_t)nq * sizeof(int32_t));
+  c.d_d.ensure((size_t)nq * cap * sizeof(int32_t));
+  c.d_e.ensure((size_t)nq * cap * sizeof(double));
+  HIPCHK(hipMemcpyAsync(c.d_a.p, c.h_a.p, (size_t)nq * sizeof(sffk::SweepQuery), hipMemcpyHostToDevice, c.stream));
+  HIPCHK(hipMemcpyAsync(c.d_b.p, c.h_b.p, (size_t)nq * 6 * sizeof(double), hipMemcpyHostToDevice, c.stream));
+  HIPCHK(hipMemsetAsync(c.d_c.p, 0, (size_t)nq * sizeof(int32_t), c.stream));
+  c.time_begin(T_SWEEP);
+  sffk::launch_sweep(c.stream, c.store_view(), c.store_n, c.d_a.as<sffk::SweepQuery>(), c.d_b.as<double>(), nq,
+                     c.d_c.as<int32_t>(), c.d_d.as<int32_t>(), c.d_e.as<double>(), cap);
+  c.time_end();
+  c.h_c.ensure((size_t)nq * sizeof(int32_t));
+  c.h_d.ensure((size_t)nq * cap * sizeof(int32_t));
+  c.h_e.ensure((size_t)nq * cap * sizeof(double));
+  HIPCHK(hipMemcpyAsync(c.h_c.p, c.d_c.p, (size_t)nq * sizeof(int32_t), hipMemcpyDeviceToHost, c.stream));
+  HIPCHK(hipMemcpyAsync(c.h_d.p, c.d_d.p, (size_t)nq * cap * sizeof(int32_t), hipMemcpyDeviceToHost, c.stream));
+  HIPCHK(hipMemcpyAsync(c.h_e.p, c.d_e.p, (size_t)nq * cap * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+  c.sync();
+  cnt.assign(c.h_c.as<int32_t>(), c.h_c.as<int32_t>() + nq);
+  out.assign(nq, {});
+  for (int i = 0; i < nq; ++i) {
+    if (!active[i]) continue;
+    int m = std::min(cnt[i], cap);
+    out[i].resize(m);
+    for (int k = 0; k < m; ++k)
+      out[i][k] = {c.h_e.as<double>()[(size_t)i * cap + k], c.h_d.as<int32_t>()[(size_t)i * cap + k]};
+    std::sort(out[i].begin(), out[i].end());
+  }
+}
+
+void Ctx::radius(const double* q6, int nq, const double* r, const int32_t* tree, const int32_t* max_id, int32_t* idx,
+                 double* dist, int32_t* cnt, int cap) {
+  if (nq <= 0) return;
+  HIPCHK(hipSetDevice(device));
+  std::vector<double> rv(r, r + nq);
+  std::vector<uint8_t> active(nq, 1);
+  std::vector<int32_t> c;
+  std::vector<std::vector<HitRec>> out;
+  sweep_once(*this, q6, nq, rv, tree, max_id, active, cap, c, out);
+  for (int i = 0; i < nq; ++i) {
+    cnt[i] = c[i];
+    for (size_t k = 0; k < out[i].size(); ++k) {
+      idx[(size_t)i * cap + k] = out[i][k].id;
+      if (dist) dist[(size_t)i * cap + k] = out[i][k].d;
+    }
+  }
+}
+
+// k nearest through radius sweeps: the radius of each query is adapted (grow while fewer than k
+// are inside, shrink when the hit list overflows) until the k smallest exact distances are known.
+void Ctx::knn(const double* q6, int nq, int k, const int32_t* tree, const int32_t* max_id, int32_t* idx, double* dist,
+              int32_t* cnt) {
+  if (nq <= 0 || k <= 0) return;
+  HIPCHK(hipSetDevice(device));
+  const int cap = std::max(4 * k, 256);
+  // initial guess: radius of a ball expected to hold ~2k nodes at uniform density
+  double ext = std::max(store_maxabs, 1.0) * 2.0;
+  double r0 = ext * std::cbrt(2.0 * k / std::max(1, store_n)) + 1e-6;
+  std::vector<double> r(nq, r0), lo(nq, 0.0), hi(nq, -1.0);
+  std::vector<uint8_t> active(nq, 1);
+  std::vector<std::vector<HitRec>> best(nq);
+  std::vector<int32_t> found(nq, 0);
+  const double RMAX = 1e30;
+  for (int it = 0; it < 200; ++it) {
+    bool any = false;
+    for (int i = 0; i < nq; ++i) any |= active[i] != 0;
+    if (!any) break;
+    std::vector<int32_t> c;
+    std::vector<std::vector<HitRec>> out;
+    sweep_once(*this, q6, nq, r, tree, max_id, active, cap, c, out);
+    for (int i = 0; i < nq; ++i) {
+      if (!active[i]) continue;
+      if (c[i] > cap) {            // too many: shrink
+        hi[i] = r[i];
+        r[i] = 0.5 * (lo[i] + hi[i]);
+      } else if (c[i] >= k || r[i] >= RMAX) {
+        best[i] = out[i];
+        found[i] = std::min(c[i], k);
+        active[i] = 0;
+      } else {                     // too few: grow
+        lo[i] = r[i];
+        r[i] = hi[i] > 0 ? 0.5 * (lo[i] + hi[i]) : std::min(RMAX, r[i] * 2.0);
+      }
+    }
+  }
+  for (int i = 0; i < nq; ++i) {
+    cnt[i] = found[i];
+    for (int j = 0; j < found[i]; ++j) {
+      idx[(size_t)i * k + j] = best[i][j].id;
+      if (dist) dist[(size_t)i * k + j] = best[i][j].d;
+    }
+  }
+}
+
+}  // namespace sff

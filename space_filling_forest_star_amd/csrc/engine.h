@@ -1,0 +1,151 @@
+// engine.h — host side of libsffgpu: device context, batched primitive operations and the
+// wave-parallel SpaceForest engine.  C++17, compiled with hipcc; exported through capi.cpp.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "../../include/sffgpu.h"
+#include "kernels.h"
+
+namespace sff {
+
+struct HipError {
+  std::string msg;
+};
+void hip_check(hipError_t e, const char* what);
+
+// growable device buffer
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  void ensure(size_t bytes);
+  void release();
+  template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+// growable pinned host buffer
+struct PinBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  void ensure(size_t bytes);
+  void release();
+  template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+// std::mt19937_64 (ISO C++ [rand.predef]) + the libstdc++ distribution algorithms the reference's
+// RandGen relies on (src/randGen.h:50-62,149-157)
+struct Mt64 {
+  uint64_t mt[312];
+  int idx;
+  explicit Mt64(uint64_t seed = 5489ULL) { reseed(seed); }
+  void reseed(uint64_t seed);
+  uint64_t next();
+  int uniform_int(int lo, int hi);  // uniform_int_distribution<int>(lo,hi) (Lemire multiply-shift)
+};
+
+enum TimerKind { T_SWEEP = 0, T_COLLIDE = 1, T_SAMPLE = 2, T_KINDS = 3 };
+
+struct Ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+
+  // collision models
+  DevBuf env_tri, env_box, level_box[SFFK_MAX_LEVELS], rob_tri;
+  sffk::EnvView envv{};
+  sffk::RobotView robv{};
+  bool have_env = false, have_robot = false;
+  double env_maxabs = 1.0;
+
+  // node store
+  int store_cap = 0, store_n = 0;
+  DevBuf sx, sy, sz, syaw, spitch, sroll, stree, spos;
+  double store_maxabs = 1.0;
+
+  // scratch
+  DevBuf d_a, d_b, d_c, d_d, d_e, d_f, d_g, d_h;
+  PinBuf h_a, h_b, h_c, h_d, h_e, h_f, h_g, h_h;
+
+  // kernel timing (HIP events on the launch stream)
+  struct Timed { hipEvent_t a, b; int kind; };
+  std::vector<Timed> pending;
+  std::vector<hipEvent_t> pool;
+  double kernel_ms[T_KINDS] = {0, 0, 0};
+  uint64_t kernel_launches[T_KINDS] = {0, 0, 0};
+
+  explicit Ctx(int dev);
+  ~Ctx();
+  void sync();  // stream sync + harvest timers
+  hipEvent_t get_event();
+  void time_begin(int kind);
+  void time_end();
+
+  void upload_mesh(int role, const double* tri9, int n);
+  sffk::NodeStoreView store_view() const;
+  void store_reset(int capacity);
+  void store_reserve(int capacity);
+  void store_append(const double* pos6, const int32_t* tree, int n);
+
+  void collide_poses(const double* pos6, int n, uint8_t* hit);
+  void collide_segments(const double* a6, const double* b6, int n, uint8_t* is_free, int32_t* first_hit,
+                        int32_t* n_samples);
+  void sample_steer(const uint64_t* words, const double* center6, int n, double dist, int dim, const double* limits,
+                    double* out6, uint8_t* in_limits);
+  // exact radius query; results sorted by (dist, id).  Returns per-query totals in cnt.
+  void radius(const double* q6, int nq, const double* r, const int32_t* tree, const int32_t* max_id, int32_t* idx,
+              double* dist, int32_t* cnt, int cap);
+  void knn(const double* q6, int nq, int k, const int32_t* tree, const int32_t* max_id, int32_t* idx, double* dist,
+           int32_t* cnt);
+  double sweep_eps() const;
+};
+
+struct FNode {
+  double pos[6];
+  int tree, parent, idx_in_tree;
+  bool force_children = false;
+  double d_closest, d_root;
+  unsigned iter;
+};
+struct Border {
+  int n1, n2;
+  double dist;
+};
+
+struct Forest {
+  Ctx* ctx;
+  sffgpu_forest_cfg cfg;
+  Mt64 rng;
+  std::vector<FNode> nodes;
+  std::vector<std::vector<int>> trees;
+  std::vector<int> frontier, closed;
+  std::vector<int> frontier_pos;  // node id -> 1 if on the frontier (for O(1) membership)
+  std::map<std::pair<int, int>, std::vector<Border>> borders;
+  std::vector<int> connected;
+  int num_roots = 0;
+  int iter = 0;
+  bool solved = false, empty_frontier = false;
+  sffgpu_forest_stats st{};
+
+  struct Slot { int node; bool from_closed; bool failing; };
+  std::vector<Slot> slots;
+  int round = 0;
+  bool in_wave = false;
+
+  Forest(Ctx* c, const sffgpu_forest_cfg& cf, const double* roots6, int n_roots);
+  int add_node(const double* pos, int tree, int parent, double dclosest, double droot, unsigned it);
+  std::vector<Border>& border(int i, int j);
+  int max_connected();
+  bool budget_hit() const { return cfg.node_budget > 0 && (int)nodes.size() >= cfg.node_budget; }
+  bool terminated() const { return solved || iter >= cfg.max_iterations || budget_hit(); }
+  void begin_wave();
+  void end_wave();
+  void do_round();
+  void run(int max_waves);
+  uint64_t fingerprint() const;
+};
+
+}  // namespace sff

@@ -1,0 +1,464 @@
+// forest.cpp — wave-parallel SpaceForest (SFF) engine of libsffgpu.
+//
+// Reference: SpaceForest<T,R> — constructor src/forest.h:57-110, Solve() :113-202, expandNode
+// :240-376, maxConnected :379-418.  The reference expands ONE frontier node per outer iteration;
+// this engine draws `wave` frontier slots at once, evaluates every slot's sample on the GPU
+// against the frozen node store (+ the earlier samples of the same round), and then replays
+// the reference's accept/reject logic on the host in slot order, looking the collision and
+// neighbour answers up instead of computing them.  The result is, by construction, what the
+// reference loop would produce if it ran the same slots one after another; with wave == 1 it is
+// the reference loop itself (same RNG consumption order).
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+
+#include "engine.h"
+#include "sff_geom.h"
+
+namespace sff {
+
+#define HIPCHK(x) hip_check((x), #x)
+using Clock = std::chrono::steady_clock;
+static double ms_since(Clock::time_point t0) {
+  return std::chrono::duration<double, std::milli>(Clock::now() - t0).count();
+}
+
+Forest::Forest(Ctx* c, const sffgpu_forest_cfg& cf, const double* roots6, int n_roots) : ctx(c), cfg(cf) {
+  if (cfg.wave < 1) cfg.wave = 1;
+  if (cfg.dim != 2 && cfg.dim != 6) throw HipError{"forest: dim must be 2 or 6"};
+  if (cfg.has_goal) throw HipError{"forest: single-goal mode (Problem::hasGoal) is not implemented on the GPU path yet"};
+  if (cfg.optimize) throw HipError{"forest: optimize (SFF*) is not implemented on the GPU path yet"};
+  if (cfg.world > 1) throw HipError{"forest: use the round_begin/round_commit protocol for world > 1"};
+  if (n_roots < 1) throw HipError{"forest: at least one root"};
+  if (!c->have_env || !c->have_robot) throw HipError{"forest: upload ENV and ROBOT meshes first"};
+  rng.reseed(cfg.seed);
+  num_roots = n_roots;
+  trees.resize(num_roots);
+  ctx->store_reset(std::max(cfg.node_budget, 4096) + cfg.wave + 64);
+  std::vector<int32_t> tids(n_roots);
+  for (int j = 0; j < n_roots; ++j) {          // src/forest.h:60-76
+    int id = add_node(roots6 + 6 * (size_t)j, j, -1, 0, 0, 0);
+    frontier.push_back(id);
+    tids[j] = j;
+  }
+  ctx->store_append(roots6, tids.data(), n_roots);
+  memset(&st, 0, sizeof st);
+}
+
+int Forest::add_node(const double* pos, int tree, int parent, double dclosest, double droot, unsigned it) {
+  FNode n;
+  memcpy(n.pos, pos, sizeof n.pos);
+  n.tree = tree;
+  n.parent = parent;
+  n.d_closest = dclosest;
+  n.d_root = droot;
+  n.iter = it;
+  n.idx_in_tree = (int)trees[tree].size();
+  int id = (int)nodes.size();
+  nodes.push_back(n);
+  trees[tree].push_back(id);
+  return id;
+}
+
+std::vector<Border>& Forest::border(int i, int j) {  // SymmetricMatrix, src/primitives.h:572-596
+  if (i > j) std::swap(i, j);
+  return borders[{i, j}];
+}
+
+// src/forest.h:379-418
+int Forest::max_connected() {
+  int max_conn = 0, remaining = num_roots;
+  std::vector<char> conn(num_roots, 0);
+  int unconnected = 0;
+  while (max_conn < remaining) {
+    connected.clear();
+    std::vector<int> stack{unconnected};
+    conn[unconnected] = 1;
+    while (!stack.empty()) {
+      int root = stack.front();
+      stack.erase(stack.begin());
+      connected.push_back(root);
+      for (int i = 0; i < num_roots; ++i) {
+        if (root == i) continue;
+        auto it = borders.find({std::min(root, i), std::max(root, i)});
+        if (it != borders.end() && !it->second.empty() && !conn[i]) {
+          conn[i] = 1;
+          stack.insert(stack.begin(), i);
+        }
+      }
+    }
+    max_conn = (int)connected.size();
+    for (int i = 0; i < num_roots; ++i)
+      if (!conn[i]) { unconnected = i; break; }
+    remaining -= max_conn;
+  }
+  return max_conn;
+}
+
+// node selection for every slot of the wave, src/forest.h:136-151 (non-priority mode)
+void Forest::begin_wave() {
+  slots.clear();
+  const bool use_closed = !closed.empty() && empty_frontier;
+  const int pool = use_closed ? (int)closed.size() : (int)frontier.size();
+  const int n_slots = std::max(1, std::min(cfg.wave, pool));
+  for (int s = 0; s < n_slots; ++s) {
+    Slot sl;
+    if (use_closed) {
+      sl.node = closed[rng.uniform_int(0, (int)closed.size() - 1)];
+      sl.from_closed = true;
+    } else {
+      sl.node = frontier[rng.uniform_int(0, (int)frontier.size() - 1)];
+      sl.from_closed = false;
+    }
+    sl.failing = true;
+    slots.push_back(sl);
+  }
+  round = 0;
+  in_wave = true;
+  ++st.waves;
+}
+
+// src/forest.h:160-201
+void Forest::end_wave() {
+  for (Slot& sl : slots) {
+    if (sl.failing && !sl.from_closed) {
+      auto it = std::find(frontier.begin(), frontier.end(), sl.node);
+      if (it != frontier.end()) {
+        frontier.erase(it);
+        nodes[sl.node].force_children = true;
+        closed.push_back(sl.node);
+      }
+    }
+  }
+  empty_frontier = frontier.empty();
+  if (!solved) {
+    bool conn = max_connected() == num_roots;
+    solved = (!cfg.has_goal && empty_frontier && conn);
+  } else {
+    max_connected();
+  }
+  in_wave = false;
+}
+
+namespace {
+struct Nb {       // one neighbour that can end the reference's neighbour loop (src/forest.h:270-300)
+  int tree;       // sort key 1: trees are visited in ascending id (:262)
+  double d;       // sort key 2: FLANN returns a tree's hits by ascending distance
+  int order;      // sort key 3: index inside the tree (store) / after all store nodes (wave-mates)
+  int id;         // store node id, or -1-c for candidate c of this round
+  bool same_tree;
+  int seg;        // index of the edge task that decides it
+};
+struct Cand {
+  int slot, expanded;
+  double pos[6];
+  bool in_lim;
+  double pdist;
+  int pose_task = -1, seg_parent = -1;
+  std::vector<Nb> nbs;
+  int accepted_id = -1;
+};
+}  // namespace
+
+void Forest::do_round() {
+  Ctx& c = *ctx;
+  HIPCHK(hipSetDevice(c.device));
+  auto t_host = Clock::now();
+  double wait_ms = 0;
+  auto timed_sync = [&]() {
+    auto t0 = Clock::now();
+    c.sync();
+    wait_ms += ms_since(t0);
+  };
+  // ---- active slots of this round (src/forest.h:155: i < ThresholdMisses && expandResult && iter < max)
+  std::vector<Cand> cands;
+  for (int s = 0; s < (int)slots.size(); ++s) {
+    if (!slots[s].failing) continue;
+    if (iter + (int)cands.size() >= cfg.max_iterations) break;
+    Cand cd;
+    cd.slot = s;
+    cd.expanded = slots[s].node;
+    cands.push_back(cd);
+  }
+  const int n = (int)cands.size();
+  ++round;
+  if (n == 0) return;
+  const int iter0 = iter;
+  iter += n;
+  const int N0 = (int)nodes.size();
+  c.store_reserve(N0 + n + 4);
+
+  // ---- draw the raw engine words in reference order and launch sample+steer -> sweep
+  const int words_per = cfg.dim == 2 ? 1 : 6;
+  c.h_a.ensure((size_t)n * 6 * sizeof(uint64_t));
+  c.h_b.ensure((size_t)n * sizeof(int32_t));
+  uint64_t* hw = c.h_a.as<uint64_t>();
+  int32_t* hp = c.h_b.as<int32_t>();
+  for (int i = 0; i < n; ++i) {
+    for (int k = 0; k < 6; ++k) hw[6 * (size_t)i + k] = k < words_per ? rng.next() : 0;
+    hp[i] = cands[i].expanded;
+  }
+  const int CAP = 64;
+  const size_t pb = (size_t)n * 6 * sizeof(double);
+  c.d_a.ensure((size_t)n * 6 * sizeof(uint64_t));
+  c.d_b.ensure((size_t)n * sizeof(int32_t));
+  c.d_c.ensure(pb);                                   // new positions
+  c.d_d.ensure((size_t)n);                            // in-limits
+  c.d_e.ensure((size_t)n * sizeof(double));           // parent distance
+  c.d_f.ensure((size_t)n * sizeof(sffk::SweepQuery)); // sweep queries
+  c.d_g.ensure((size_t)n * sizeof(int32_t) + (size_t)n * CAP * sizeof(int32_t));  // cnt | hit idx
+  c.d_h.ensure((size_t)n * CAP * sizeof(double));     // hit dist
+  int32_t* d_cnt = c.d_g.as<int32_t>();
+  int32_t* d_hidx = d_cnt + n;
+  HIPCHK(hipMemcpyAsync(c.d_a.p, hw, (size_t)n * 6 * sizeof(uint64_t), hipMemcpyHostToDevice, c.stream));
+  HIPCHK(hipMemcpyAsync(c.d_b.p, hp, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, c.stream));
+  HIPCHK(hipMemsetAsync(d_cnt, 0, (size_t)n * sizeof(int32_t), c.stream));
+  sffk::SampleParams prm{};
+  memcpy(prm.limits, cfg.limits, sizeof prm.limits);
+  prm.dist_tree = cfg.dist_tree;
+  prm.sweep_abs_eps = c.sweep_eps();
+  c.time_begin(T_SAMPLE);
+  sffk::launch_sample_steer(c.stream, c.d_a.as<uint64_t>(), c.d_b.as<int32_t>(), c.spos.as<double>(), nullptr, n,
+                            cfg.sampling_dist, cfg.dim, prm, c.d_c.as<double>(), c.d_d.as<uint8_t>(),
+                            c.d_e.as<double>(), c.d_f.as<sffk::SweepQuery>(), N0);
+  // the round's samples become temporary store entries [N0, N0+n) so that the same sweep also
+  // finds, for every sample, the EARLIER samples of this round (query i sees ids < N0 + i)
+  sffk::NodeStoreMut mut{c.sx.as<float>(), c.sy.as<float>(), c.sz.as<float>(), c.syaw.as<float>(),
+                         c.spitch.as<float>(), c.sroll.as<float>(), c.stree.as<int32_t>(), c.spos.as<double>()};
+  sffk::launch_store_write(c.stream, mut, c.d_c.as<double>(), nullptr, c.d_b.as<int32_t>(), c.d_d.as<uint8_t>(), n, N0);
+  c.time_end();
+  c.time_begin(T_SWEEP);
+  sffk::launch_sweep(c.stream, c.store_view(), N0 + n, c.d_f.as<sffk::SweepQuery>(), c.d_c.as<double>(), n, d_cnt,
+                     d_hidx, c.d_h.as<double>(), CAP);
+  c.time_end();
+  st.sweeps += 1;
+  st.sweep_nodes += (uint64_t)(N0 + n);
+  st.sweep_queries += (uint64_t)n;
+  c.h_c.ensure(pb);
+  c.h_d.ensure((size_t)n);
+  c.h_e.ensure((size_t)n * sizeof(double));
+  c.h_g.ensure((size_t)n * sizeof(int32_t) + (size_t)n * CAP * sizeof(int32_t));
+  c.h_h.ensure((size_t)n * CAP * sizeof(double));
+  HIPCHK(hipMemcpyAsync(c.h_c.p, c.d_c.p, pb, hipMemcpyDeviceToHost, c.stream));
+  HIPCHK(hipMemcpyAsync(c.h_d.p, c.d_d.p, (size_t)n, hipMemcpyDeviceToHost, c.stream));
+  HIPCHK(hipMemcpyAsync(c.h_e.p, c.d_e.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+  HIPCHK(hipMemcpyAsync(c.h_g.p, c.d_g.p, (size_t)n * sizeof(int32_t) + (size_t)n * CAP * sizeof(int32_t),
+                        hipMemcpyDeviceToHost, c.stream));
+  HIPCHK(hipMemcpyAsync(c.h_h.p, c.d_h.p, (size_t)n * CAP * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+  timed_sync();
+
+  const double* hpos = c.h_c.as<double>();
+  const uint8_t* hlim = c.h_d.as<uint8_t>();
+  const double* hpd = c.h_e.as<double>();
+  const int32_t* hcnt = c.h_g.as<int32_t>();
+  const int32_t* hidx = hcnt + n;
+  const double* hdist = c.h_h.as<double>();
+
+  // ---- classify neighbours, build the pose / edge task lists
+  std::vector<double> pose_tasks, seg_a, seg_b;
+  auto add_seg = [&](const double* a, const double* b) {
+    int id = (int)(seg_a.size() / 6);
+    seg_a.insert(seg_a.end(), a, a + 6);
+    seg_b.insert(seg_b.end(), b, b + 6);
+    return id;
+  };
+  std::vector<int> overflow_q;
+  for (int i = 0; i < n; ++i) {
+    Cand& cd = cands[i];
+    memcpy(cd.pos, hpos + 6 * (size_t)i, sizeof cd.pos);
+    cd.in_lim = hlim[i] != 0;
+    cd.pdist = hpd[i];
+    if (!cd.in_lim) continue;
+    if (hcnt[i] > CAP) overflow_q.push_back(i);
+  }
+  // rare: a hit list overflowed -> redo those queries with a big list through the generic path
+  std::vector<std::vector<std::pair<double, int>>> big(n);
+  if (!overflow_q.empty()) {
+    const int BIG = 4096;
+    int m = (int)overflow_q.size();
+    std::vector<double> q6((size_t)m * 6), rr(m);
+    std::vector<int32_t> mx(m), cn(m), ix((size_t)m * BIG);
+    std::vector<double> dd((size_t)m * BIG);
+    for (int k = 0; k < m; ++k) {
+      int i = overflow_q[k];
+      memcpy(&q6[6 * (size_t)k], cands[i].pos, 6 * sizeof(double));
+      rr[k] = std::max(cands[i].pdist, cfg.dist_tree);
+      mx[k] = N0 + i;
+    }
+    int keep = c.store_n;
+    c.store_n = N0 + n;  // include the temporaries
+    c.radius(q6.data(), m, rr.data(), nullptr, mx.data(), ix.data(), dd.data(), cn.data(), BIG);
+    c.store_n = keep;
+    for (int k = 0; k < m; ++k) {
+      if (cn[k] > BIG) throw HipError{"forest: neighbour list overflow (> 4096 hits)"};
+      for (int j = 0; j < cn[k]; ++j) big[overflow_q[k]].push_back({dd[(size_t)k * BIG + j], ix[(size_t)k * BIG + j]});
+    }
+  }
+  for (int i = 0; i < n; ++i) {
+    Cand& cd = cands[i];
+    if (!cd.in_lim) continue;
+    const FNode& ex = nodes[cd.expanded];
+    cd.pose_task = (int)(pose_tasks.size() / 6);
+    pose_tasks.insert(pose_tasks.end(), cd.pos, cd.pos + 6);
+    cd.seg_parent = add_seg(ex.pos, cd.pos);
+    const int mine = ex.tree;
+    std::vector<Nb> all;
+    auto consider = [&](double d, int id) {
+      Nb nb;
+      nb.d = d;
+      if (id < N0) {
+        nb.id = id;
+        nb.tree = nodes[id].tree;
+        nb.order = nodes[id].idx_in_tree;
+      } else {
+        int cc = id - N0;
+        if (!cands[cc].in_lim) return;
+        nb.id = -1 - cc;
+        nb.tree = nodes[cands[cc].expanded].tree;
+        nb.order = 0x40000000 + cc;
+      }
+      nb.same_tree = nb.tree == mine;
+      nb.seg = -1;
+      if (nb.same_tree) {
+        if (ex.force_children || !(d < cd.pdist - SFFG_TOL)) return;   // src/forest.h:276
+      } else {
+        if (!(d < cfg.dist_tree - SFFG_TOL)) return;                    // src/forest.h:283
+      }
+      all.push_back(nb);
+    };
+    if (!big[i].empty() || hcnt[i] > CAP) {
+      for (auto& h : big[i]) consider(h.first, h.second);
+    } else {
+      for (int k = 0; k < hcnt[i]; ++k) consider(hdist[(size_t)i * CAP + k], hidx[(size_t)i * CAP + k]);
+    }
+    std::sort(all.begin(), all.end(), [](const Nb& a, const Nb& b) {
+      if (a.tree != b.tree) return a.tree < b.tree;
+      if (a.d != b.d) return a.d < b.d;
+      return a.order < b.order;
+    });
+    // everything after the first STORE neighbour of another tree is unreachable (:296-299)
+    for (Nb& nb : all) {
+      const double* npos = nb.id >= 0 ? nodes[nb.id].pos : cands[-1 - nb.id].pos;
+      if (nb.same_tree) nb.seg = add_seg(npos, cd.pos);     // isPathFree(neighbour, newPoint)  :276
+      else nb.seg = add_seg(ex.pos, npos);                  // isPathFree(expanded, neighbour)  :288
+      cd.nbs.push_back(nb);
+      if (!nb.same_tree && nb.id >= 0) break;
+    }
+  }
+
+  // ---- collision launches
+  const int n_pose = (int)(pose_tasks.size() / 6), n_seg = (int)(seg_a.size() / 6);
+  std::vector<uint8_t> pose_hit(n_pose), seg_free(n_seg);
+  std::vector<int32_t> seg_fh(n_seg), seg_ns(n_seg);
+  double host_before = ms_since(t_host) - wait_ms;
+  (void)host_before;
+  if (n_pose) {
+    auto t0 = Clock::now();
+    c.collide_poses(pose_tasks.data(), n_pose, pose_hit.data());
+    c.collide_segments(seg_a.data(), seg_b.data(), n_seg, seg_free.data(), seg_fh.data(), seg_ns.data());
+    wait_ms += ms_since(t0);
+  }
+  st.poses_executed += n_pose;
+  st.segments_executed += n_seg;
+  for (int k = 0; k < n_seg; ++k) st.samples_executed += (uint64_t)seg_ns[k];
+
+  // ---- replay expandNode in slot order (src/forest.h:240-376)
+  auto seg_calls = [&](int k) -> uint64_t {   // Collide calls isPathFree makes (early exit at the first hit)
+    return seg_fh[k] > 0 ? (uint64_t)seg_fh[k] : (uint64_t)seg_ns[k];
+  };
+  std::vector<double> app_pos;
+  std::vector<int32_t> app_tree;
+  for (int i = 0; i < n; ++i) {
+    Cand& cd = cands[i];
+    Slot& sl = slots[cd.slot];
+    const unsigned iteration = (unsigned)(iter0 + i + 1);
+    if (!cd.in_lim) continue;                                  // :246 !result
+    st.collide_calls += 1;
+    if (pose_hit[cd.pose_task]) continue;                      // :246 env.Collide(newPoint)
+    st.path_free_calls += 1;
+    st.collide_calls += seg_calls(cd.seg_parent);
+    if (!seg_free[cd.seg_parent]) continue;                    // :246 !isPathFree(expanded, newPoint)
+    st.nn_queries += (uint64_t)trees.size();                   // :262-267 one radiusSearch per tree
+    const int expanded = cd.expanded;
+    const int mine = nodes[expanded].tree;
+    bool reject = false;
+    for (const Nb& nb : cd.nbs) {
+      int nb_node;
+      if (nb.id >= 0) nb_node = nb.id;
+      else {
+        nb_node = cands[-1 - nb.id].accepted_id;
+        if (nb_node < 0) continue;                             // that sample never became a node
+      }
+      if (nb.same_tree) {
+        st.path_free_calls += 1;
+        st.collide_calls += seg_calls(nb.seg);
+        if (seg_free[nb.seg]) { reject = true; break; }        // :276-280 overcrowded
+      } else {
+        st.path_free_calls += 1;
+        st.collide_calls += seg_calls(nb.seg);
+        if (seg_free[nb.seg]) {                                // :288-294
+          std::vector<Border>& bp = border(nb.tree, mine);
+          int a = std::min(nb_node, expanded), b = std::max(nb_node, expanded);
+          bool found = false;
+          for (const Border& x : bp) if (x.n1 == a && x.n2 == b) { found = true; break; }
+          if (!found) {
+            double d = nodes[nb_node].d_root + nodes[expanded].d_root + sffg::dist6(nodes[nb_node].pos, nodes[expanded].pos);
+            bp.push_back({a, b, d});
+          }
+        }
+        reject = true;                                         // :296-299
+        break;
+      }
+    }
+    if (reject) continue;
+    int id = add_node(cd.pos, mine, expanded, cd.pdist, cd.pdist + nodes[expanded].d_root, iteration);  // :353
+    cd.accepted_id = id;
+    frontier.push_back(id);                                    // :365
+    sl.failing = false;
+    app_pos.insert(app_pos.end(), cd.pos, cd.pos + 6);
+    app_tree.push_back(mine);
+  }
+  // ---- commit the accepted nodes to the device store (replaces flannIndex->addPoints, :367)
+  if (!app_tree.empty()) {
+    auto t0 = Clock::now();
+    c.store_n = N0;
+    c.store_append(app_pos.data(), app_tree.data(), (int)app_tree.size());
+    wait_ms += ms_since(t0);
+  }
+  st.host_ms += ms_since(t_host) - wait_ms;
+}
+
+void Forest::run(int max_waves) {
+  auto t0 = Clock::now();
+  int done = 0;
+  while (!terminated()) {
+    if (max_waves > 0 && done >= max_waves) break;
+    ++done;
+    begin_wave();
+    for (int r = 0; r < cfg.threshold_misses && !solved; ++r) {
+      bool any = false;
+      for (const Slot& s : slots) any |= s.failing;
+      if (!any || iter >= cfg.max_iterations) break;
+      do_round();
+    }
+    end_wave();
+  }
+  st.total_ms += ms_since(t0);
+}
+
+uint64_t Forest::fingerprint() const {
+  uint64_t x = 1469598103934665603ULL;
+  auto mix = [&](const void* p, size_t n) {
+    const unsigned char* c = (const unsigned char*)p;
+    for (size_t i = 0; i < n; ++i) { x ^= c[i]; x *= 1099511628211ULL; }
+  };
+  for (const FNode& n : nodes) {
+    int32_t v[3] = {n.parent, n.tree, (int32_t)n.iter};
+    mix(v, sizeof v);
+    mix(n.pos, sizeof n.pos);
+  }
+  return x;
+}
+
+}  // namespace sff

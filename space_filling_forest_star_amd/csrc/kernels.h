@@ -1,0 +1,80 @@
+// kernels.h — device views and launchers of the gfx950 kernels (kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sffk {
+
+// fp32 SoA node store (the sweep streams these six columns: 24 B per node) plus the
+// authoritative fp64 positions and the tree-id column.
+struct NodeStoreView {
+  const float* x;
+  const float* y;
+  const float* z;
+  const float* yaw;
+  const float* pitch;
+  const float* roll;
+  const int32_t* tree;
+  const double* pos;  // n x 6
+};
+
+struct NodeStoreMut {
+  float *x, *y, *z, *yaw, *pitch, *roll;
+  int32_t* tree;
+  double* pos;
+};
+
+struct SweepQuery {   // 56 bytes, read through the scalar cache
+  float x, y, z, yaw, pitch, roll;
+  float r2f;          // inflated fp32 squared radius (superset filter)
+  int32_t tree;       // -1 = all trees
+  double r;           // exact radius (strict <)
+  int32_t max_id;     // only node ids < max_id
+  int32_t active;
+  int32_t pad, pad2;
+};
+
+struct SampleParams {
+  double limits[6];
+  double dist_tree;
+  double sweep_abs_eps;
+};
+
+#define SFFK_MAX_LEVELS 4
+// 64-ary box hierarchy over the environment triangles (leaf order = Morton order).
+struct EnvView {
+  const double* tri;      // n_tri x 9, world frame
+  const double* tri_box;  // n_tri x 6 (lo xyz, hi xyz), exact
+  int n_tri;
+  int n_levels;           // level 0 groups 64 triangles, level k groups 64 boxes of level k-1
+  const double* level_box[SFFK_MAX_LEVELS];
+  int level_count[SFFK_MAX_LEVELS];
+};
+
+struct RobotView {
+  const double* tri;  // n_tri x 9, model frame
+  int n_tri;
+  double center[3];   // bounding sphere (model frame)
+  double radius;
+  double lo[3], hi[3];  // exact box of the un-rotated model
+};
+
+size_t collide_lds_bytes(int n_robot_tri, int waves);
+
+void launch_sample_steer(hipStream_t s, const uint64_t* words, const int32_t* parent, const double* node_pos,
+                         const double* center_in, int n, double dist, int dim, const SampleParams& prm, double* out6,
+                         uint8_t* in_lim, double* parent_dist, SweepQuery* queries, int32_t q_max_base);
+
+void launch_store_write(hipStream_t s, const NodeStoreMut& st, const double* pos6, const int32_t* tree,
+                        const int32_t* parent, const uint8_t* active, int n, int base);
+
+void launch_sweep(hipStream_t s, const NodeStoreView& st, int n_nodes, const SweepQuery* queries, const double* qpos,
+                  int nq, int32_t* cnt, int32_t* hit_idx, double* hit_dist, int cap);
+
+void launch_collide_poses(hipStream_t s, const EnvView& env, const RobotView& rob, const double* pos6, int n,
+                          uint8_t* hit);
+
+void launch_collide_segments(hipStream_t s, const EnvView& env, const RobotView& rob, const double* a6,
+                             const double* b6, int n, uint8_t* is_free, int32_t* first_hit, int32_t* n_samples);
+
+}  // namespace sffk

@@ -1,0 +1,443 @@
+// kernels.hip — hand-written gfx950 (CDNA4, wave64) kernels of the SFF hot path.
+//
+//   k_sample_steer   : RandGen::randomPointInDistance + Point::getStateInDistance (+ limits test)
+//                      for a whole wave of frontier slots in one launch; also emits the fp32
+//                      neighbour-sweep query of each sample.
+//   k_sweep          : linear neighbour sweep over the SoA fp32 node store (replaces FLANN
+//                      radiusSearch / knnSearch).  HBM-streaming kernel: 16 B/lane coalesced
+//                      column loads, queries read through the scalar cache (wave-uniform),
+//                      fp32 superset filter, exact fp64 re-test of the rare survivors.
+//   k_collide_poses  : Environment::Collide — one wave per pose, wave-cooperative traversal of a
+//                      64-ary box hierarchy (one child box per lane, __ballot compaction), robot
+//                      triangles staged in LDS, exact fp64 triangle contact at the leaves.
+//   k_collide_segments: Solver::isPathFree — one wave per edge; broad phase with the swept robot
+//                      box, then samples in ascending order, 64 per step.
+//
+// Compiled with -ffp-contract=off: every fp64 value that feeds a decision has the same bits as
+// the host evaluation of sff_geom.h.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "kernels.h"
+#include "sff_geom.h"
+
+namespace sffk {
+
+using namespace sffg;
+
+// ------------------------------------------------------------------ sample + steer
+__global__ __launch_bounds__(256) void k_sample_steer(const uint64_t* __restrict__ words,
+                                                      const int32_t* __restrict__ parent,
+                                                      const double* __restrict__ node_pos,  // store, n x 6
+                                                      const double* __restrict__ center_in, // or explicit centres
+                                                      int n, double dist, int dim, SampleParams prm,
+                                                      double* __restrict__ out6, uint8_t* __restrict__ in_lim,
+                                                      double* __restrict__ parent_dist, SweepQuery* __restrict__ queries,
+                                                      int32_t q_max_base) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double c[6], o[6];
+  const double* src = center_in ? center_in + 6 * (size_t)i : node_pos + 6 * (size_t)parent[i];
+  for (int k = 0; k < 6; ++k) c[k] = src[k];
+  uint64_t w[6];
+  for (int k = 0; k < 6; ++k) w[k] = words[6 * (size_t)i + k];
+  bool ok = sample_point(w, c, dist, dim, prm.limits, o);
+  for (int k = 0; k < 6; ++k) out6[6 * (size_t)i + k] = o[k];
+  in_lim[i] = ok ? 1 : 0;
+  if (parent_dist) {
+    double pd = dist6(c, o);  // parentDistance, src/forest.h:250
+    parent_dist[i] = pd;
+    if (queries) {
+      SweepQuery q;
+      q.x = (float)o[0]; q.y = (float)o[1]; q.z = (float)o[2];
+      q.yaw = (float)o[3]; q.pitch = (float)o[4]; q.roll = (float)o[5];
+      double r = pd > prm.dist_tree ? pd : prm.dist_tree;
+      q.r = r;
+      double ri = (r + prm.sweep_abs_eps) * (1.0 + 1e-5);
+      q.r2f = (float)(ri * ri) * 1.000001f;
+      q.tree = -1;
+      q.max_id = q_max_base + i;
+      q.active = ok ? 1 : 0;
+      q.pad = 0;
+      queries[i] = q;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ neighbour sweep
+__device__ __forceinline__ float wrapf(float d) {
+  const float PI_F = 3.14159274f;
+  if (d < -PI_F) return d + 2.0f * PI_F;
+  if (d >= PI_F) return d - 2.0f * PI_F;
+  return d;
+}
+
+// One thread owns 4 consecutive nodes (float4 per column = 16 B/lane, fully coalesced) and loops
+// over the wave-uniform query list; a query's parameters are fetched with scalar loads.
+__global__ __launch_bounds__(256) void k_sweep(NodeStoreView st, int n_nodes, const SweepQuery* __restrict__ queries,
+                                               const double* __restrict__ qpos,  // nq x 6 exact query positions
+                                               int nq, int32_t* __restrict__ cnt, int32_t* __restrict__ hit_idx,
+                                               double* __restrict__ hit_dist, int cap) {
+  const int n4 = (n_nodes + 3) >> 2;
+  for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n4; t += gridDim.x * blockDim.x) {
+    const int base = t << 2;
+    float4 X = reinterpret_cast<const float4*>(st.x)[t];
+    float4 Y = reinterpret_cast<const float4*>(st.y)[t];
+    float4 Z = reinterpret_cast<const float4*>(st.z)[t];
+    float4 A = reinterpret_cast<const float4*>(st.yaw)[t];
+    float4 B = reinterpret_cast<const float4*>(st.pitch)[t];
+    float4 C = reinterpret_cast<const float4*>(st.roll)[t];
+    const float xs[4] = {X.x, X.y, X.z, X.w}, ys[4] = {Y.x, Y.y, Y.z, Y.w}, zs[4] = {Z.x, Z.y, Z.z, Z.w};
+    const float as[4] = {A.x, A.y, A.z, A.w}, bs[4] = {B.x, B.y, B.z, B.w}, cs[4] = {C.x, C.y, C.z, C.w};
+    for (int q = 0; q < nq; ++q) {
+      const SweepQuery Q = queries[q];  // wave-uniform address -> scalar loads
+      if (!Q.active) continue;
+      float d3[4];
+      bool any = false;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float dx = xs[j] - Q.x, dy = ys[j] - Q.y, dz = zs[j] - Q.z;
+        d3[j] = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+        any |= d3[j] <= Q.r2f;
+      }
+      if (!any) continue;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int id = base + j;
+        if (d3[j] > Q.r2f || id >= n_nodes || id >= Q.max_id) continue;
+        float da = wrapf(as[j] - Q.yaw), db = wrapf(bs[j] - Q.pitch), dc = wrapf(cs[j] - Q.roll);
+        float d6 = fmaf(dc, dc, fmaf(db, db, fmaf(da, da, d3[j])));
+        if (d6 > Q.r2f) continue;
+        if (Q.tree >= 0 && st.tree[id] != Q.tree) continue;
+        // exact re-test in fp64 on the authoritative positions (reference: realDist, src/forest.h:274)
+        double np[6], qp[6];
+        for (int k = 0; k < 6; ++k) { np[k] = st.pos[6 * (size_t)id + k]; qp[k] = qpos[6 * (size_t)q + k]; }
+        double d = dist6(np, qp);
+        if (d < Q.r) {
+          int slot = atomicAdd(&cnt[q], 1);
+          if (slot < cap) {
+            hit_idx[(size_t)q * cap + slot] = id;
+            hit_dist[(size_t)q * cap + slot] = d;
+          }
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------ collision: shared pieces
+struct WaveStack {
+  int32_t* s;  // LDS, STACK_CAP entries per wave
+  int sp;      // wave-uniform
+};
+#define STACK_CAP 256
+
+// push the set lanes of `mask`: entry = code_base + lane
+__device__ __forceinline__ void push_mask(WaveStack& st, unsigned long long mask, int code_base, int lane) {
+  int before = __popcll(mask & ((1ULL << lane) - 1ULL));
+  if ((mask >> lane) & 1ULL) {
+    int at = st.sp + before;
+    if (at < STACK_CAP) st.s[at] = code_base + lane;
+  }
+  st.sp += __popcll(mask);
+  if (st.sp > STACK_CAP) st.sp = STACK_CAP;  // overflow is reported by the caller's check
+}
+
+__device__ __forceinline__ bool box_hit(const double* lo, const double* hi, const double* qlo, const double* qhi) {
+  return !(lo[0] > qhi[0] || qlo[0] > hi[0] || lo[1] > qhi[1] || qlo[1] > hi[1] || lo[2] > qhi[2] || qlo[2] > hi[2]);
+}
+
+// Traverse the 64-ary hierarchy with query box [qlo,qhi]; collects overlapping leaf triangles
+// (indices into the leaf-ordered env arrays) into cand[] (LDS, cap entries).  Returns the
+// number found; *overflow set when a stack or the list ran over.
+__device__ int collect_candidates(const EnvView& env, const double* qlo, const double* qhi, int lane, WaveStack& st,
+                                  int32_t* cand, int cap, bool* overflow) {
+  int n_cand = 0;
+  st.sp = 0;
+  *overflow = false;
+  // top level: up to 64 boxes
+  {
+    const int L = env.n_levels - 1;
+    const int cnt = env.level_count[L];
+    bool h = false;
+    if (lane < cnt) {
+      const double* b = env.level_box[L] + 6 * (size_t)lane;
+      h = box_hit(b, b + 3, qlo, qhi);
+    }
+    unsigned long long m = __ballot(h);
+    push_mask(st, m, (L << 24), lane);
+  }
+  while (st.sp > 0) {
+    int code = st.s[st.sp - 1];
+    st.sp -= 1;
+    const int L = code >> 24, idx = code & 0xFFFFFF;
+    if (L == 0) {
+      // leaf group: triangles [64 idx, 64 idx + 64)
+      const int t = idx * 64 + lane;
+      bool h = false;
+      if (t < env.n_tri) {
+        const double* b = env.tri_box + 6 * (size_t)t;
+        h = box_hit(b, b + 3, qlo, qhi);
+      }
+      unsigned long long m = __ballot(h);
+      if (m) {
+        int before = __popcll(m & ((1ULL << lane) - 1ULL));
+        if (h && n_cand + before < cap) cand[n_cand + before] = t;
+        n_cand += __popcll(m);
+        if (n_cand > cap) { *overflow = true; n_cand = cap; }
+      }
+    } else {
+      const int child = idx * 64 + lane;
+      const int cnt = env.level_count[L - 1];
+      bool h = false;
+      if (child < cnt) {
+        const double* b = env.level_box[L - 1] + 6 * (size_t)child;
+        h = box_hit(b, b + 3, qlo, qhi);
+      }
+      unsigned long long m = __ballot(h);
+      if (st.sp + __popcll(m) > STACK_CAP) *overflow = true;
+      push_mask(st, m, ((L - 1) << 24) + idx * 64, lane);
+    }
+  }
+  return n_cand;
+}
+
+// ------------------------------------------------------------------ pose kernel
+#define POSE_WAVES 4
+#define CAND_CAP 256
+
+__global__ __launch_bounds__(64 * POSE_WAVES) void k_collide_poses(EnvView env, RobotView rob,
+                                                                   const double* __restrict__ pos6, int n,
+                                                                   uint8_t* __restrict__ hit_out) {
+  extern __shared__ double lds_d[];
+  // layout: robot triangles (n_tri*9 doubles) | per-wave stacks | per-wave candidate lists
+  double* rtri = lds_d;
+  int32_t* ibase = reinterpret_cast<int32_t*>(rtri + (size_t)rob.n_tri * 9);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int32_t* stack = ibase + wave * STACK_CAP;
+  int32_t* cand = ibase + POSE_WAVES * STACK_CAP + wave * CAND_CAP;
+  for (int i = threadIdx.x; i < rob.n_tri * 9; i += blockDim.x) rtri[i] = rob.tri[i];
+  __syncthreads();
+
+  const int pose = blockIdx.x * POSE_WAVES + wave;
+  if (pose >= n) return;
+  if (env.n_tri == 0) {  // HasMap == false (src/environment.h:307-309)
+    if (lane == 0) hit_out[pose] = 0;
+    return;
+  }
+  double p[6], R[9];
+  for (int k = 0; k < 6; ++k) p[k] = pos6[6 * (size_t)pose + k];
+  if (p[3] == 0 && p[4] == 0 && p[5] == 0) {
+    R[0] = R[4] = R[8] = 1; R[1] = R[2] = R[3] = R[5] = R[6] = R[7] = 0;
+  } else {
+    rotation(p, R);
+  }
+  // conservative query box around the posed bounding sphere
+  double c[3], qlo[3], qhi[3];
+  xform(R, p, rob.center, c);
+  double rr = rob.radius * (1 + 1e-9) + 1e-9 * (fabs(c[0]) + fabs(c[1]) + fabs(c[2]) + 1);
+  for (int k = 0; k < 3; ++k) { qlo[k] = c[k] - rr; qhi[k] = c[k] + rr; }
+
+  WaveStack st{stack, 0};
+  bool overflow;
+  int nc = collect_candidates(env, qlo, qhi, lane, st, cand, CAND_CAP, &overflow);
+  bool hit = false;
+  if (nc > 0 || overflow) {
+    // every lane poses up to ceil(n_tri/64) robot triangles once, then walks the candidates
+    for (int r0 = 0; r0 < rob.n_tri && !hit; r0 += 64) {
+      const int r = r0 + lane;
+      double Q[9];
+      bool have = r < rob.n_tri;
+      if (have)
+        for (int v = 0; v < 3; ++v) xform(R, p, rtri + 9 * r + 3 * v, Q + 3 * v);
+      bool lane_hit = false;
+      if (!overflow) {
+        for (int k = 0; k < nc; ++k) {
+          const int t = cand[k];
+          if (have && !lane_hit) {
+            const double* b = env.tri_box + 6 * (size_t)t;
+            if (tri_box_overlap(b, b + 3, Q)) lane_hit = sat17(env.tri + 9 * (size_t)t, Q);
+          }
+        }
+      } else {
+        // list overflowed: fall back to every env triangle (correct, slow, practically unreachable)
+        for (int t = 0; t < env.n_tri; ++t) {
+          if (have && !lane_hit) {
+            const double* b = env.tri_box + 6 * (size_t)t;
+            if (tri_box_overlap(b, b + 3, Q)) lane_hit = sat17(env.tri + 9 * (size_t)t, Q);
+          }
+        }
+      }
+      hit = __any(lane_hit);
+    }
+  }
+  if (lane == 0) hit_out[pose] = hit ? 1 : 0;
+}
+
+// ------------------------------------------------------------------ segment kernel
+#define SEG_WAVES 4
+
+__global__ __launch_bounds__(64 * SEG_WAVES) void k_collide_segments(EnvView env, RobotView rob,
+                                                                     const double* __restrict__ a6,
+                                                                     const double* __restrict__ b6, int n,
+                                                                     uint8_t* __restrict__ free_out,
+                                                                     int32_t* __restrict__ first_hit,
+                                                                     int32_t* __restrict__ n_samples) {
+  extern __shared__ double lds_d[];
+  double* rtri = lds_d;
+  int32_t* ibase = reinterpret_cast<int32_t*>(rtri + (size_t)rob.n_tri * 9);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int32_t* stack = ibase + wave * STACK_CAP;
+  int32_t* cand = ibase + SEG_WAVES * STACK_CAP + wave * CAND_CAP;
+  for (int i = threadIdx.x; i < rob.n_tri * 9; i += blockDim.x) rtri[i] = rob.tri[i];
+  __syncthreads();
+
+  const int seg = blockIdx.x * SEG_WAVES + wave;
+  if (seg >= n) return;
+  double a[6], b[6];
+  for (int k = 0; k < 6; ++k) { a[k] = a6[6 * (size_t)seg + k]; b[k] = b6[6 * (size_t)seg + k]; }
+  const double parts = edge_parts(a, b);
+  const int ns = edge_samples(parts);
+  if (lane == 0 && n_samples) n_samples[seg] = ns;
+  int fh = -1;
+  if (ns > 0 && env.n_tri > 0) {
+    const double dir[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
+    // swept box of the un-rotated robot: every sample position lies between a and a+dir
+    // (monotone rounding), so [min,max] of the end points plus the robot's identity box bounds
+    // every posed vertex exactly; a hair of slack is added on top.
+    double qlo[3], qhi[3];
+    for (int k = 0; k < 3; ++k) {
+      double e = a[k] + dir[k];
+      double lo = a[k] < e ? a[k] : e, hi = a[k] > e ? a[k] : e;
+      double slack = 1e-9 * (fabs(lo) + fabs(hi) + 1);
+      qlo[k] = lo + rob.lo[k] - slack;
+      qhi[k] = hi + rob.hi[k] + slack;
+    }
+    WaveStack st{stack, 0};
+    bool overflow;
+    int nc = collect_candidates(env, qlo, qhi, lane, st, cand, CAND_CAP, &overflow);
+    if (overflow) {
+      fh = -2;  // host re-runs this edge sample by sample through the pose kernel
+    } else if (nc > 0) {
+      for (int s0 = 1; s0 <= ns && fh < 0; s0 += 64) {
+        const int idx = s0 + lane;
+        const bool live = idx <= ns;
+        double P[3] = {0, 0, 0};
+        if (live) edge_sample_pos(a, dir, parts, idx, P);
+        // which candidates' boxes does the robot box at this sample touch?
+        // process candidates one at a time; per candidate, ballot the samples that touch it
+        unsigned long long hit_samples = 0;
+        for (int k = 0; k < nc; ++k) {
+          const int t = cand[k];
+          const double* bx = env.tri_box + 6 * (size_t)t;
+          bool touch = false;
+          if (live) {
+            touch = true;
+            for (int ax = 0; ax < 3; ++ax) {
+              // exact bounds of v + P over the robot vertices (monotone rounding of one add)
+              double rlo = rob.lo[ax] + P[ax], rhi = rob.hi[ax] + P[ax];
+              if (bx[ax] > rhi || rlo > bx[3 + ax]) touch = false;
+            }
+          }
+          unsigned long long m = __ballot(touch);
+          // narrow phase: for each touching sample (ascending), all lanes test robot triangles
+          unsigned long long todo = m & ~hit_samples;
+          if (hit_samples) todo &= (hit_samples & (~hit_samples + 1ULL)) - 1ULL;  // only samples before the first hit
+          while (todo) {
+            const int sl = __ffsll((long long)todo) - 1;
+            todo &= todo - 1;
+            double S[3];
+            S[0] = __shfl(P[0], sl); S[1] = __shfl(P[1], sl); S[2] = __shfl(P[2], sl);
+            bool lane_hit = false;
+            for (int r0 = 0; r0 < rob.n_tri; r0 += 64) {
+              const int r = r0 + lane;
+              if (r < rob.n_tri && !lane_hit) {
+                double Q[9];
+                // identity rotation: ((1*v0 + 0*v1) + 0*v2) + T == v0 + T
+                for (int v = 0; v < 3; ++v)
+                  for (int ax = 0; ax < 3; ++ax) Q[3 * v + ax] = rtri[9 * r + 3 * v + ax] + S[ax];
+                if (tri_box_overlap(bx, bx + 3, Q)) lane_hit = sat17(env.tri + 9 * (size_t)t, Q);
+              }
+            }
+            if (__any(lane_hit)) hit_samples |= 1ULL << sl;
+          }
+        }
+        if (hit_samples) fh = s0 + (__ffsll((long long)hit_samples) - 1);
+      }
+    }
+  }
+  if (lane == 0) {
+    if (first_hit) first_hit[seg] = fh;
+    free_out[seg] = fh == -1 ? 1 : (fh == -2 ? 2 : 0);
+  }
+}
+
+// ------------------------------------------------------------------ node store writes
+// Writes n positions into the SoA store at [base, base+n): the same double->float cast the
+// reference applies when it fills FLANN matrices (src/forest.h:258-260).  Inactive entries are
+// written as NaN so that no query can match them.
+__global__ __launch_bounds__(256) void k_store_write(NodeStoreMut st, const double* __restrict__ pos6,
+                                                     const int32_t* __restrict__ tree, const int32_t* __restrict__ parent,
+                                                     const uint8_t* __restrict__ active, int n, int base) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const bool on = active ? active[i] != 0 : true;
+  const float nanv = __int_as_float(0x7fc00000);
+  const size_t o = (size_t)base + i;
+  double p[6];
+  for (int k = 0; k < 6; ++k) p[k] = pos6[6 * (size_t)i + k];
+  st.x[o] = on ? (float)p[0] : nanv;
+  st.y[o] = on ? (float)p[1] : nanv;
+  st.z[o] = on ? (float)p[2] : nanv;
+  st.yaw[o] = on ? (float)p[3] : nanv;
+  st.pitch[o] = on ? (float)p[4] : nanv;
+  st.roll[o] = on ? (float)p[5] : nanv;
+  for (int k = 0; k < 6; ++k) st.pos[6 * o + k] = p[k];
+  st.tree[o] = tree ? tree[i] : st.tree[parent[i]];
+}
+
+// ------------------------------------------------------------------ launchers
+size_t collide_lds_bytes(int n_robot_tri, int waves) {
+  return (size_t)n_robot_tri * 9 * sizeof(double) + (size_t)waves * (STACK_CAP + CAND_CAP) * sizeof(int32_t);
+}
+
+void launch_sample_steer(hipStream_t s, const uint64_t* words, const int32_t* parent, const double* node_pos,
+                         const double* center_in, int n, double dist, int dim, const SampleParams& prm, double* out6,
+                         uint8_t* in_lim, double* parent_dist, SweepQuery* queries, int32_t q_max_base) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_sample_steer, dim3((n + 255) / 256), dim3(256), 0, s, words, parent, node_pos, center_in, n,
+                     dist, dim, prm, out6, in_lim, parent_dist, queries, q_max_base);
+}
+
+void launch_store_write(hipStream_t s, const NodeStoreMut& st, const double* pos6, const int32_t* tree,
+                        const int32_t* parent, const uint8_t* active, int n, int base) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_store_write, dim3((n + 255) / 256), dim3(256), 0, s, st, pos6, tree, parent, active, n, base);
+}
+
+void launch_sweep(hipStream_t s, const NodeStoreView& st, int n_nodes, const SweepQuery* queries, const double* qpos,
+                  int nq, int32_t* cnt, int32_t* hit_idx, double* hit_dist, int cap) {
+  if (n_nodes <= 0 || nq <= 0) return;
+  int n4 = (n_nodes + 3) / 4;
+  int blocks = (n4 + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_sweep, dim3(blocks), dim3(256), 0, s, st, n_nodes, queries, qpos, nq, cnt, hit_idx, hit_dist,
+                     cap);
+}
+
+void launch_collide_poses(hipStream_t s, const EnvView& env, const RobotView& rob, const double* pos6, int n,
+                          uint8_t* hit) {
+  if (n <= 0) return;
+  size_t lds = collide_lds_bytes(rob.n_tri, POSE_WAVES);
+  hipLaunchKernelGGL(k_collide_poses, dim3((n + POSE_WAVES - 1) / POSE_WAVES), dim3(64 * POSE_WAVES), lds, s, env,
+                     rob, pos6, n, hit);
+}
+
+void launch_collide_segments(hipStream_t s, const EnvView& env, const RobotView& rob, const double* a6,
+                             const double* b6, int n, uint8_t* is_free, int32_t* first_hit, int32_t* n_samples) {
+  if (n <= 0) return;
+  size_t lds = collide_lds_bytes(rob.n_tri, SEG_WAVES);
+  hipLaunchKernelGGL(k_collide_segments, dim3((n + SEG_WAVES - 1) / SEG_WAVES), dim3(64 * SEG_WAVES), lds, s, env,
+                     rob, a6, b6, n, is_free, first_hit, n_samples);
+}
+
+}  // namespace sffk

@@ -1,0 +1,195 @@
+"""GPU parity: every hot-path entry point of libsffgpu.so (through the C ABI) against the CPU
+oracle on the same seeded inputs.  Integer / boolean / index results must be identical and the
+fp64 values bit-equal (both sides evaluate the same IEEE expressions, -ffp-contract=off)."""
+import numpy as np
+import pytest
+
+import common
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def S():
+    import space_filling_forest_star_amd as S
+    return S
+
+
+@pytest.fixture(scope="module")
+def ctx(S):
+    c = S.Context(0)
+    yield c
+    c.close()
+
+
+def load_world(ctx, name):
+    sc = common.scenario(name)
+    ctx.upload_env(sc["env"])
+    ctx.upload_robot(sc["robot"])
+    w = O.World(sc["env"], sc["robot"], O.TRIG_PORTABLE)
+    return sc, w
+
+
+@pytest.mark.parametrize("dim", [6, 2])
+def test_sample_steer_bit_exact(ctx, dim):
+    lim = [-60, 2060, -60, 2110, 0, 1000]
+    rs = np.random.RandomState(3)
+    n = 20000
+    words = rs.randint(0, 2**63, size=(n, 6), dtype=np.uint64) * np.uint64(2) + rs.randint(0, 2, (n, 6)).astype(np.uint64)
+    words[0] = 0
+    words[1] = np.uint64(2**64 - 1)
+    cen = common.random_poses(lim, n, 4, dim)
+    cen[:, 3:] *= 2.2  # angles outside [-pi, pi) too (they drift un-normalised in the reference)
+    if dim == 2:
+        cen[:, 3:] = 0
+    out, ok = ctx.sample_steer(words, cen, 14.0, dim, lim)
+    L = O.lib()
+    ref = np.zeros(6)
+    limv = O.f64(lim)
+    bad = 0
+    for i in range(n):
+        r = L.sffo_sample_from_words(words[i].ctypes.data_as(O.c_u64p), O.dp(cen[i]), 14.0, dim, O.dp(limv),
+                                     O.TRIG_PORTABLE, O.dp(ref))
+        if r != ok[i] or not np.array_equal(ref, out[i]):
+            bad += 1
+    assert bad == 0
+
+
+@pytest.mark.parametrize("name", ["dense3d", "triang", "dense2d"])
+def test_collide_poses_match_oracle(ctx, name):
+    sc, w = load_world(ctx, name)
+    dim = sc["dim"]
+    spread = 0.4 * sc["scale"]
+    poses = np.vstack([common.random_poses(sc["limits"], 4000, 5, dim),
+                       common.poses_near_surface(sc["env"], 12000, 6, spread, dim),
+                       common.poses_near_surface(sc["env"], 4000, 7, 0.02 * sc["scale"], dim)])
+    got = ctx.collide_poses(poses)
+    want = w.collide_many(poses)
+    assert np.array_equal(got, want)
+    assert 0.05 < want.mean() < 0.95  # the set really exercises both outcomes
+    # oracle's hierarchy against its own brute force on a subset
+    sub = poses[::40]
+    assert np.array_equal(np.array([w.collide_brute(p) for p in sub], np.uint8), want[::40])
+
+
+@pytest.mark.parametrize("name", ["dense3d", "triang", "dense2d"])
+def test_collide_segments_match_oracle(ctx, name):
+    sc, w = load_world(ctx, name)
+    dim = sc["dim"]
+    n = 3000
+    a = common.poses_near_surface(sc["env"], n, 8, (3.0 if dim == 6 else 30.0) * sc["scale"], dim)
+    rs = np.random.RandomState(9)
+    d = rs.normal(0, 1, (n, 3))
+    if dim == 2:
+        d[:, 2] = 0
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    b = a.copy()
+    b[:, :3] += d * sc["sampling_dist"] * rs.uniform(0.01, 1.5, (n, 1))
+    if dim == 6:
+        b[:, 3:] = a[:, 3:] + rs.uniform(-0.5, 0.5, (n, 3))
+    # degenerate edges: zero length, shorter than one step
+    b[0] = a[0]
+    b[1, :3] = a[1, :3] + 1e-3
+    free, fh, ns = ctx.collide_segments(a, b)
+    for i in range(n):
+        r, first, cnt = w.path_free(a[i], b[i])
+        assert (free[i], fh[i], ns[i]) == (r, first, cnt), i
+    assert 0.02 < free.mean() < 0.98
+
+
+def test_radius_and_knn_exact(ctx):
+    rs = np.random.RandomState(11)
+    n = 30000
+    pts = common.random_poses([0, 400, 0, 400, 0, 400], n, 12)
+    pts[:, 3:] *= 1.5
+    tree = rs.randint(0, 7, n).astype(np.int32)
+    ctx.nodes_reset(n)
+    ctx.nodes_append(pts[:20000], tree[:20000])
+    ctx.nodes_append(pts[20000:], tree[20000:])
+    assert ctx.nodes_count() == n
+    q = common.random_poses([0, 400, 0, 400, 0, 400], 64, 13)
+    L = O.lib()
+    idx, dist, cnt = ctx.radius(q, 30.0, cap=512)
+    for i in range(len(q)):
+        ri = np.zeros(4096, np.int32)
+        rd = np.zeros(4096)
+        k = L.sffo_radius(O.dp(pts), n, O.dp(q[i]), 30.0, O.ip(ri), O.dp(rd), 4096)
+        assert cnt[i] == k
+        assert np.array_equal(idx[i, :k], ri[:k])
+        assert np.array_equal(dist[i, :k], rd[:k])
+    # per-tree + max_id filters, k nearest
+    for t, mx in ((3, n), (5, 15000)):
+        idx, dist, cnt = ctx.knn(q, 32, tree=t, max_id=mx)
+        sel = np.where((tree == t) & (np.arange(n) < mx))[0]
+        sub = np.ascontiguousarray(pts[sel])
+        for i in range(len(q)):
+            ri = np.zeros(32, np.int32)
+            rd = np.zeros(32)
+            k = L.sffo_knn(O.dp(sub), len(sub), O.dp(q[i]), 32, O.ip(ri), O.dp(rd))
+            assert cnt[i] == k
+            assert np.array_equal(idx[i, :k], sel[ri[:k]])
+            assert np.array_equal(dist[i, :k], rd[:k])
+    # fewer eligible nodes than k
+    idx, dist, cnt = ctx.knn(q[:4], 32, tree=2, max_id=40)
+    want = int(np.sum(tree[:40] == 2))
+    assert np.all(cnt == want)
+
+
+def run_pair(S, ctx, name, wave, iters, seed, n_roots=5, budget=0):
+    sc, w = load_world(ctx, name)
+    if sc["xml_points"] is not None:
+        roots = sc["xml_points"][:n_roots]
+    else:
+        roots = common.free_roots(w.collide, sc["limits"], n_roots, seed=seed, dim=sc["dim"])
+    kw = dict(dist_tree=sc["dist_tree"], sampling_dist=sc["sampling_dist"], dim=sc["dim"], max_iterations=iters,
+              node_budget=budget, wave=wave, seed=seed)
+    fo = O.Forest(w, roots, sc["limits"], **kw)
+    fo.run()
+    fg = S.Forest(ctx, roots, sc["limits"], **kw)
+    fg.run()
+    return fo, fg
+
+
+def assert_same_forest(fo, fg):
+    so, sg = fo.stats(), fg.stats()
+    for k in ("iterations", "solved", "n_nodes", "n_trees", "frontier_size", "closed_size", "n_connected", "n_borders",
+              "collide_calls", "path_free_calls", "nn_queries", "waves"):
+        assert so[k] == sg[k], (k, so[k], sg[k])
+    no, ng = fo.nodes(), fg.nodes()
+    for k in ("parent", "tree", "iter"):
+        assert np.array_equal(no[k], ng[k]), k
+    for k in ("pos", "cost", "dpar"):
+        assert np.array_equal(no[k], ng[k]), k  # bit-exact fp64
+    bo, bg = fo.borders(), fg.borders()
+    for k in bo:
+        assert np.array_equal(bo[k], bg[k]), k
+    assert fo.fingerprint() == fg.fingerprint()
+
+
+@pytest.mark.parametrize("name,wave,iters", [
+    ("dense3d", 1, 1500), ("dense3d", 16, 4000), ("dense3d", 256, 12000),
+    ("dense3d_coarse", 1, 1500), ("dense3d_coarse", 64, 6000),
+    ("triang", 1, 1500), ("triang", 128, 8000),
+    ("dense2d", 1, 1500), ("dense2d", 32, 4000),
+])
+def test_forest_topology_identical(S, ctx, name, wave, iters):
+    fo, fg = run_pair(S, ctx, name, wave, iters, seed=2)
+    assert fo.stats()["n_nodes"] > 50
+    assert_same_forest(fo, fg)
+
+
+def test_forest_node_budget_and_seeds(S, ctx):
+    for seed in (1, 3):
+        fo, fg = run_pair(S, ctx, "dense3d", 512, 10**6, seed=seed, n_roots=10, budget=6000)
+        assert fo.stats()["n_nodes"] >= 6000
+        assert_same_forest(fo, fg)
+
+
+def test_forest_errors(S, ctx):
+    sc, w = load_world(ctx, "dense3d")
+    roots = common.free_roots(w.collide, sc["limits"], 3)
+    with pytest.raises(S.SffGpuError):
+        S.Forest(ctx, roots, sc["limits"], 18.0, 14.0, dim=3)
+    with pytest.raises(S.SffGpuError):
+        S.Forest(ctx, roots, sc["limits"], 18.0, 14.0, goal=[1, 2, 3, 0, 0, 0])
