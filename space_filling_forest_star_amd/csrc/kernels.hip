@@ -75,9 +75,12 @@ __device__ __forceinline__ float wrapf(float d) {
 // over the wave-uniform query list; a query's parameters are fetched with scalar loads.
 __global__ __launch_bounds__(256) void k_sweep(NodeStoreView st, int n_nodes, const SweepQuery* __restrict__ queries,
                                                const double* __restrict__ qpos,  // nq x 6 exact query positions
-                                               int nq, int32_t* __restrict__ cnt, int32_t* __restrict__ hit_idx,
-                                               double* __restrict__ hit_dist, int cap) {
+                                               int nq, int q_per_block, int32_t* __restrict__ cnt,
+                                               int32_t* __restrict__ hit_idx, double* __restrict__ hit_dist, int cap) {
   const int n4 = (n_nodes + 3) >> 2;
+  // blockIdx.y selects a slice of the query list: small stores still fill the chip
+  const int q_begin = blockIdx.y * q_per_block;
+  const int q_end = q_begin + q_per_block < nq ? q_begin + q_per_block : nq;
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n4; t += gridDim.x * blockDim.x) {
     const int base = t << 2;
     float4 X = reinterpret_cast<const float4*>(st.x)[t];
@@ -88,7 +91,7 @@ __global__ __launch_bounds__(256) void k_sweep(NodeStoreView st, int n_nodes, co
     float4 C = reinterpret_cast<const float4*>(st.roll)[t];
     const float xs[4] = {X.x, X.y, X.z, X.w}, ys[4] = {Y.x, Y.y, Y.z, Y.w}, zs[4] = {Z.x, Z.y, Z.z, Z.w};
     const float as[4] = {A.x, A.y, A.z, A.w}, bs[4] = {B.x, B.y, B.z, B.w}, cs[4] = {C.x, C.y, C.z, C.w};
-    for (int q = 0; q < nq; ++q) {
+    for (int q = q_begin; q < q_end; ++q) {
       const SweepQuery Q = queries[q];  // wave-uniform address -> scalar loads
       if (!Q.active) continue;
       float d3[4];
@@ -420,8 +423,16 @@ void launch_sweep(hipStream_t s, const NodeStoreView& st, int n_nodes, const Swe
   int n4 = (n_nodes + 3) / 4;
   int blocks = (n4 + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(k_sweep, dim3(blocks), dim3(256), 0, s, st, n_nodes, queries, qpos, nq, cnt, hit_idx, hit_dist,
-                     cap);
+  // aim at >= ~2048 workgroups (8 per CU) but keep >= 16 queries per slice so that a node tile
+  // loaded into registers is reused
+  int qsplit = (2048 + blocks - 1) / blocks;
+  int max_split = (nq + 15) / 16;
+  if (qsplit > max_split) qsplit = max_split;
+  if (qsplit < 1) qsplit = 1;
+  int q_per_block = (nq + qsplit - 1) / qsplit;
+  qsplit = (nq + q_per_block - 1) / q_per_block;
+  hipLaunchKernelGGL(k_sweep, dim3(blocks, qsplit), dim3(256), 0, s, st, n_nodes, queries, qpos, nq, q_per_block, cnt,
+                     hit_idx, hit_dist, cap);
 }
 
 void launch_collide_poses(hipStream_t s, const EnvView& env, const RobotView& rob, const double* pos6, int n,
