@@ -56,22 +56,29 @@ def main():
     ctx.upload_robot(sc["robot"])
     # 10 seeded collision-free roots (identical on every rank): drawn with the GPU collision kernel
     roots = common.free_roots(lambda p: int(ctx.collide_poses(p[None, :])[0]), sc["limits"], 10, seed=1)
-    # multi-GPU: the waves of one forest do not shard without the record exchange (DESIGN.md
-    # "Multi-GPU"); until that lands every rank grows an independent forest (own seed) of the
-    # same workload, so per-GPU work is fixed: weak scaling of replicas.
+    # multi-GPU: ONE forest shared by all ranks.  Every wave holds `--wave` slots PER GPU (weak
+    # scaling: per-GPU work fixed); rank r evaluates candidates i with i % world == r, the answers
+    # are all-gathered over RCCL once per round and every rank replays the identical commit.
     forest = S.Forest(ctx, roots, sc["limits"], dist_tree=sc["dist_tree"], sampling_dist=sc["sampling_dist"], dim=6,
-                      max_iterations=2**31 - 1, node_budget=args.budget, wave=args.wave, seed=args.seed + rank)
+                      max_iterations=2**31 - 1, node_budget=args.budget, wave=args.wave * world, seed=args.seed,
+                      rank=rank, world=world)
+
+    def run_waves(k):
+        if distributed:
+            S.run_distributed(forest, k)
+        else:
+            forest.run(k)
 
     def barrier():
         if distributed:
             dist.barrier()
         torch.cuda.synchronize()
 
-    forest.run(args.warmup)
+    run_waves(args.warmup)
     s0 = forest.stats()
     barrier()
     t0 = time.perf_counter()
-    forest.run(args.steps)
+    run_waves(args.steps)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     barrier()
@@ -85,10 +92,10 @@ def main():
     acc = float(s1["n_nodes"] - s0["n_nodes"])
     checks = float(s1["collide_calls"] - s0["collide_calls"])
     executed = float(s1["poses_executed"] - s0["poses_executed"] + s1["samples_executed"] - s0["samples_executed"])
-    if distributed:
-        t = torch.tensor([acc, checks, executed], dtype=torch.float64, device="cuda")
+    if distributed:  # the forest (nodes, reference-equivalent checks) is shared; executed work is per rank
+        t = torch.tensor([executed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        acc, checks, executed = (float(x) for x in t.tolist())
+        executed = float(t.item())
 
     out = None
     if rank == 0:
@@ -111,10 +118,11 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "dense_3D.obj (1832 tris) + robot_cylinder_small (124 tris), 6-DoF, 10 seeded roots, SFF, "
-                            "circum=14 dtree=18, 1M-node budget; step = one wave of %d frontier slots" % args.wave,
-                "wave": args.wave, "node_budget": args.budget, "seed": args.seed,
+                            "circum=14 dtree=18, 1M-node budget; step = one wave of %d frontier slots" % (args.wave * world),
+                "wave": args.wave * world, "wave_per_gpu": args.wave, "node_budget": args.budget, "seed": args.seed,
                 "nodes_at_start": s0["n_nodes"], "nodes_at_end": s1["n_nodes"],
-                "parallelism": "1 GPU" if world == 1 else "%d independent forests (replicas, one per GPU)" % world,
+                "parallelism": "1 GPU" if world == 1 else
+                "one forest, wave slots sharded over %d GPUs (i %% world), RCCL all-gather of answer records per round" % world,
             },
             "collision_checks_per_s": checks / elapsed,
             "collision_checks_executed_per_s": executed / elapsed,

@@ -128,18 +128,22 @@ int sffgpu_forest_get_borders(sffgpu_forest* f, int32_t* tree_a, int32_t* tree_b
                               double* dist, int cap);
 uint64_t sffgpu_forest_fingerprint(sffgpu_forest* f);
 
-/* Multi-GPU wave protocol (one process per GPU; the exchange itself is the caller's RCCL /
- * gloo all-gather).  A wave round is: begin -> local records -> [all-gather] -> commit.
- *   sffgpu_forest_round_begin : draws this round's samples for ALL slots (replicated,
- *        deterministic) and evaluates the slots of this rank's shard on the GPU;
- *        *n_local = records produced, *done = 1 when the solver has terminated.
- *   sffgpu_forest_round_records : copies the local fixed-size records (see SFFGPU_RECORD_BYTES).
- *   sffgpu_forest_round_commit : takes the concatenated records of all ranks (rank order) and
- *        applies the deterministic in-order decision pass; every rank ends in the same state. */
-#define SFFGPU_RECORD_BYTES 64
-int sffgpu_forest_round_begin(sffgpu_forest* f, int32_t* n_local, int32_t* done);
-int sffgpu_forest_round_records(sffgpu_forest* f, void* records, int cap_records);
-int sffgpu_forest_round_commit(sffgpu_forest* f, const void* all_records, const int32_t* counts_per_rank, int world);
+/* Multi-GPU wave protocol (one process per GPU; the exchange itself is the caller's RCCL / gloo
+ * all-gather).  Every rank holds a full replica of the forest and of the node store; a round is
+ *   begin  -> the active slots are drawn and sampled on EVERY rank (replicated, deterministic);
+ *             the neighbour sweep, the classification and all collision checks run only for the
+ *             candidates this rank owns (candidate i -> rank i % world); their answers are
+ *             serialised into an int32 record stream.  *n_words = its length, *done = 1 when the
+ *             solver has terminated (then there is nothing to exchange or commit).
+ *   records-> copies this rank's stream (n_words int32).
+ *   commit -> takes the streams of ALL ranks concatenated in rank order (+ their lengths) and
+ *             replays the reference's accept / reject logic in slot order; every rank ends the
+ *             round in the same state.  No second collective is needed.
+ * sffgpu_forest_run() is this protocol with world == 1. */
+int sffgpu_forest_in_wave(sffgpu_forest* f); /* 1 while a wave is open (between its first begin and last commit) */
+int sffgpu_forest_round_begin(sffgpu_forest* f, int32_t* n_words, int32_t* done);
+int sffgpu_forest_round_records(sffgpu_forest* f, int32_t* words, int cap_words);
+int sffgpu_forest_round_commit(sffgpu_forest* f, const int32_t* all_words, const int32_t* words_per_rank, int world);
 
 #ifdef __cplusplus
 }

@@ -15,7 +15,7 @@ EXPORTED_SYMBOLS = [
     "sffgpu_nodes_reset", "sffgpu_nodes_append", "sffgpu_nodes_count", "sffgpu_radius", "sffgpu_knn",
     "sffgpu_forest_create", "sffgpu_forest_destroy", "sffgpu_forest_run", "sffgpu_forest_get_stats",
     "sffgpu_forest_get_nodes", "sffgpu_forest_get_borders", "sffgpu_forest_fingerprint",
-    "sffgpu_forest_round_begin", "sffgpu_forest_round_records", "sffgpu_forest_round_commit",
+    "sffgpu_forest_in_wave", "sffgpu_forest_round_begin", "sffgpu_forest_round_records", "sffgpu_forest_round_commit",
 ]
 
 c_dp = C.POINTER(C.c_double)
@@ -92,9 +92,10 @@ def lib():
     L.sffgpu_forest_get_borders.argtypes = [C.c_void_p, c_ip, c_ip, c_ip, c_ip, c_dp, C.c_int]
     L.sffgpu_forest_fingerprint.restype = C.c_uint64
     L.sffgpu_forest_fingerprint.argtypes = [C.c_void_p]
+    L.sffgpu_forest_in_wave.argtypes = [C.c_void_p]
     L.sffgpu_forest_round_begin.argtypes = [C.c_void_p, c_ip, c_ip]
-    L.sffgpu_forest_round_records.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
-    L.sffgpu_forest_round_commit.argtypes = [C.c_void_p, C.c_void_p, c_ip, C.c_int]
+    L.sffgpu_forest_round_records.argtypes = [C.c_void_p, c_ip, C.c_int]
+    L.sffgpu_forest_round_commit.argtypes = [C.c_void_p, c_ip, c_ip, C.c_int]
     _LIB = L
     return L
 
@@ -281,3 +282,63 @@ class Forest:
 
     def fingerprint(self):
         return self.ctx._L.sffgpu_forest_fingerprint(self.h)
+
+    def in_wave(self):
+        return bool(self.ctx._L.sffgpu_forest_in_wave(self.h))
+
+    # ---- multi-GPU round protocol (include/sffgpu.h "Multi-GPU wave protocol")
+    def round_begin(self):
+        """returns (records int32 array, done)"""
+        n = C.c_int32(0)
+        done = C.c_int32(0)
+        self.ctx._chk(self.ctx._L.sffgpu_forest_round_begin(self.h, C.byref(n), C.byref(done)))
+        rec = np.zeros(max(1, n.value), np.int32)
+        if n.value:
+            self.ctx._chk(self.ctx._L.sffgpu_forest_round_records(self.h, _ip(rec), n.value))
+        return rec[:n.value], bool(done.value)
+
+    def round_commit(self, all_words, words_per_rank):
+        a = _i32(all_words)
+        cnt = _i32(words_per_rank)
+        self.ctx._chk(self.ctx._L.sffgpu_forest_round_commit(self.h, _ip(a), _ip(cnt), len(cnt)))
+
+
+def exchange_records(local, group=None):
+    """All-gather variable-length int32 record streams with torch.distributed (RCCL on GPUs, gloo on
+    CPU): returns (concatenated stream in rank order, words per rank).  Two collectives per round:
+    the lengths (world x int32) and the zero-padded payloads."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    backend = dist.get_backend(group)
+    dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
+    n = torch.tensor([len(local)], dtype=torch.int32, device=dev)
+    counts = torch.zeros(world, dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(counts, n, group=group)
+    counts_h = counts.cpu().numpy()
+    width = int(counts_h.max())
+    buf = torch.zeros(width, dtype=torch.int32, device=dev)
+    if len(local):
+        buf[:len(local)] = torch.from_numpy(np.ascontiguousarray(local, dtype=np.int32)).to(dev)
+    allbuf = torch.zeros(world * width, dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(allbuf, buf, group=group)
+    allh = allbuf.cpu().numpy().reshape(world, width)
+    out = np.concatenate([allh[r, :counts_h[r]] for r in range(world)]) if width else np.zeros(0, np.int32)
+    return out.astype(np.int32), counts_h.astype(np.int32)
+
+
+def run_distributed(forest, max_waves=0, group=None):
+    """Drive one shared forest over all ranks of the process group; returns waves done."""
+    w0 = forest.stats()["waves"]
+    while True:
+        if max_waves > 0:
+            s = forest.stats()
+            # stop only at a wave boundary (frontier bookkeeping done), identically on every rank
+            if s["waves"] - w0 >= max_waves and not forest.in_wave():
+                break
+        rec, done = forest.round_begin()
+        if done:
+            break
+        allw, counts = exchange_records(rec, group)
+        forest.round_commit(allw, counts)
+    return forest.stats()["waves"] - w0

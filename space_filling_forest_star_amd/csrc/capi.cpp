@@ -180,20 +180,31 @@ int sffgpu_forest_get_borders(sffgpu_forest* f, int32_t* ta, int32_t* tb, int32_
 }
 uint64_t sffgpu_forest_fingerprint(sffgpu_forest* f) { return f ? f->f->fingerprint() : 0; }
 
-int sffgpu_forest_round_begin(sffgpu_forest* f, int32_t*, int32_t*) {
-  if (!f) return SFFGPU_ERR_ARG;
-  f->owner->c->err = "multi-GPU round protocol: not implemented in this build";
-  return SFFGPU_ERR_STATE;
+int sffgpu_forest_in_wave(sffgpu_forest* f) { return f ? (f->f->in_wave ? 1 : 0) : SFFGPU_ERR_ARG; }
+int sffgpu_forest_round_begin(sffgpu_forest* f, int32_t* n_words, int32_t* done) {
+  if (!f || !n_words || !done) return SFFGPU_ERR_ARG;
+  GUARD(f->owner, {
+    Forest& F = *f->f;
+    *done = 0;
+    *n_words = 0;
+    if (!F.in_wave && F.terminated()) {
+      *done = 1;
+    } else {
+      F.round_begin();
+      *n_words = (int32_t)F.records.size();
+    }
+  });
 }
-int sffgpu_forest_round_records(sffgpu_forest* f, void*, int) {
-  if (!f) return SFFGPU_ERR_ARG;
-  f->owner->c->err = "multi-GPU round protocol: not implemented in this build";
-  return SFFGPU_ERR_STATE;
+int sffgpu_forest_round_records(sffgpu_forest* f, int32_t* words, int cap_words) {
+  if (!f || !words) return SFFGPU_ERR_ARG;
+  Forest& F = *f->f;
+  if ((int)F.records.size() > cap_words) return SFFGPU_ERR_CAPACITY;
+  memcpy(words, F.records.data(), F.records.size() * sizeof(int32_t));
+  return SFFGPU_OK;
 }
-int sffgpu_forest_round_commit(sffgpu_forest* f, const void*, const int32_t*, int) {
-  if (!f) return SFFGPU_ERR_ARG;
-  f->owner->c->err = "multi-GPU round protocol: not implemented in this build";
-  return SFFGPU_ERR_STATE;
+int sffgpu_forest_round_commit(sffgpu_forest* f, const int32_t* all_words, const int32_t* words_per_rank, int world) {
+  if (!f || !all_words || !words_per_rank || world < 1) return SFFGPU_ERR_ARG;
+  GUARD(f->owner, f->f->round_commit(all_words, words_per_rank, world));
 }
 
 }  // extern "C"

@@ -383,6 +383,8 @@ void Ctx::sample_steer(const uint64_t* words, const double* center6, int n, doub
   HIPCHK(hipMemcpyAsync(d_b.p, h_b.p, pb, hipMemcpyHostToDevice, stream));
   sffk::SampleParams prm{};
   memcpy(prm.limits, limits, sizeof prm.limits);
+  prm.rank = 0;
+  prm.world = 1;
   time_begin(T_SAMPLE);
   sffk::launch_sample_steer(stream, d_a.as<uint64_t>(), nullptr, nullptr, d_b.as<double>(), n, dist, dim, prm,
                             d_c.as<double>(), d_d.as<uint8_t>(), nullptr, nullptr, 0);

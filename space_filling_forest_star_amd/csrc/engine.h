@@ -135,6 +135,33 @@ struct Forest {
   int round = 0;
   bool in_wave = false;
 
+  // one neighbour that can end the reference's neighbour loop (src/forest.h:270-300)
+  struct Nb {
+    int tree;        // sort key 1: trees are visited in ascending id (:262)
+    double d;        // sort key 2: a tree's hits come by ascending distance
+    int order;       // sort key 3: index inside the tree (store) / after all store nodes (wave-mates)
+    int id;          // store node id, or -1-c for candidate c of this round
+    bool same_tree;
+    int seg;         // local edge task that decides it
+    bool free = false;
+    int fh = -1, ns = 0;
+  };
+  struct Cand {      // one sample of the current round
+    int slot, expanded;
+    double pos[6];
+    bool in_lim = false;
+    double pdist = 0;
+    int pose_task = -1, seg_parent = -1;
+    bool answered = false, pose_hit = false, par_free = false;
+    int par_fh = -1, par_ns = 0;
+    std::vector<Nb> nbs;
+    int accepted_id = -1;
+  };
+  std::vector<Cand> cands;
+  std::vector<int32_t> records;  // this rank's answers of the pending round (int32 stream)
+  bool pending_round = false;
+  int iter0 = 0, N0 = 0;
+
   Forest(Ctx* c, const sffgpu_forest_cfg& cf, const double* roots6, int n_roots);
   int add_node(const double* pos, int tree, int parent, double dclosest, double droot, unsigned it);
   std::vector<Border>& border(int i, int j);
@@ -143,7 +170,8 @@ struct Forest {
   bool terminated() const { return solved || iter >= cfg.max_iterations || budget_hit(); }
   void begin_wave();
   void end_wave();
-  void do_round();
+  void round_begin();
+  void round_commit(const int32_t* all, const int32_t* counts, int world);
   void run(int max_waves);
   uint64_t fingerprint() const;
 };

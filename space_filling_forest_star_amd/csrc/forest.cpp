@@ -29,7 +29,8 @@ Forest::Forest(Ctx* c, const sffgpu_forest_cfg& cf, const double* roots6, int n_
   if (cfg.dim != 2 && cfg.dim != 6) throw HipError{"forest: dim must be 2 or 6"};
   if (cfg.has_goal) throw HipError{"forest: single-goal mode (Problem::hasGoal) is not implemented on the GPU path yet"};
   if (cfg.optimize) throw HipError{"forest: optimize (SFF*) is not implemented on the GPU path yet"};
-  if (cfg.world > 1) throw HipError{"forest: use the round_begin/round_commit protocol for world > 1"};
+  if (cfg.world < 1) cfg.world = 1;
+  if (cfg.rank < 0 || cfg.rank >= cfg.world) throw HipError{"forest: rank outside [0, world)"};
   if (n_roots < 1) throw HipError{"forest: at least one root"};
   if (!c->have_env || !c->have_robot) throw HipError{"forest: upload ENV and ROBOT meshes first"};
   rng.reseed(cfg.seed);
@@ -141,29 +142,25 @@ void Forest::end_wave() {
   in_wave = false;
 }
 
-namespace {
-struct Nb {       // one neighbour that can end the reference's neighbour loop (src/forest.h:270-300)
-  int tree;       // sort key 1: trees are visited in ascending id (:262)
-  double d;       // sort key 2: FLANN returns a tree's hits by ascending distance
-  int order;      // sort key 3: index inside the tree (store) / after all store nodes (wave-mates)
-  int id;         // store node id, or -1-c for candidate c of this round
-  bool same_tree;
-  int seg;        // index of the edge task that decides it
-};
-struct Cand {
-  int slot, expanded;
-  double pos[6];
-  bool in_lim;
-  double pdist;
-  int pose_task = -1, seg_parent = -1;
-  std::vector<Nb> nbs;
-  int accepted_id = -1;
-};
-}  // namespace
+// ---------------------------------------------------------------------------------------
+// A round in two phases.
+//   round_begin : (replicated) pick the active slots, draw the engine words, sample ALL of them on
+//                 this GPU; (sharded) sweep / classify / collision-check only the candidates this
+//                 rank owns (candidate i -> rank i % world) and serialise their answers.
+//   round_commit: (replicated) take the answers of all ranks, replay expandNode in slot order,
+//                 append the accepted nodes to the host forest and the device store.
+// With world == 1 the local answers are consumed directly.
+// ---------------------------------------------------------------------------------------
+static const int32_t REC_MAGIC = 0x53464652;  // "SFFR"
 
-void Forest::do_round() {
+void Forest::round_begin() {
   Ctx& c = *ctx;
   HIPCHK(hipSetDevice(c.device));
+  if (pending_round) throw HipError{"forest: round_begin called twice without round_commit"};
+  if (!in_wave) {
+    if (terminated()) return;
+    begin_wave();
+  }
   auto t_host = Clock::now();
   double wait_ms = 0;
   auto timed_sync = [&]() {
@@ -172,7 +169,7 @@ void Forest::do_round() {
     wait_ms += ms_since(t0);
   };
   // ---- active slots of this round (src/forest.h:155: i < ThresholdMisses && expandResult && iter < max)
-  std::vector<Cand> cands;
+  cands.clear();
   for (int s = 0; s < (int)slots.size(); ++s) {
     if (!slots[s].failing) continue;
     if (iter + (int)cands.size() >= cfg.max_iterations) break;
@@ -183,13 +180,17 @@ void Forest::do_round() {
   }
   const int n = (int)cands.size();
   ++round;
+  pending_round = true;
+  records.clear();
+  records.push_back(REC_MAGIC);
+  records.push_back(n);
   if (n == 0) return;
-  const int iter0 = iter;
+  iter0 = iter;
   iter += n;
-  const int N0 = (int)nodes.size();
+  N0 = (int)nodes.size();
   c.store_reserve(N0 + n + 4);
 
-  // ---- draw the raw engine words in reference order and launch sample+steer -> sweep
+  // ---- draw the raw engine words in reference order; sample + steer every candidate
   const int words_per = cfg.dim == 2 ? 1 : 6;
   c.h_a.ensure((size_t)n * 6 * sizeof(uint64_t));
   c.h_b.ensure((size_t)n * sizeof(int32_t));
@@ -218,6 +219,8 @@ void Forest::do_round() {
   memcpy(prm.limits, cfg.limits, sizeof prm.limits);
   prm.dist_tree = cfg.dist_tree;
   prm.sweep_abs_eps = c.sweep_eps();
+  prm.rank = cfg.rank;
+  prm.world = cfg.world;
   c.time_begin(T_SAMPLE);
   sffk::launch_sample_steer(c.stream, c.d_a.as<uint64_t>(), c.d_b.as<int32_t>(), c.spos.as<double>(), nullptr, n,
                             cfg.sampling_dist, cfg.dim, prm, c.d_c.as<double>(), c.d_d.as<uint8_t>(),
@@ -228,13 +231,14 @@ void Forest::do_round() {
                          c.spitch.as<float>(), c.sroll.as<float>(), c.stree.as<int32_t>(), c.spos.as<double>()};
   sffk::launch_store_write(c.stream, mut, c.d_c.as<double>(), nullptr, c.d_b.as<int32_t>(), c.d_d.as<uint8_t>(), n, N0);
   c.time_end();
+  // the sweep only serves the queries of this rank's shard (the others are marked inactive)
   c.time_begin(T_SWEEP);
   sffk::launch_sweep(c.stream, c.store_view(), N0 + n, c.d_f.as<sffk::SweepQuery>(), c.d_c.as<double>(), n, d_cnt,
                      d_hidx, c.d_h.as<double>(), CAP);
   c.time_end();
   st.sweeps += 1;
   st.sweep_nodes += (uint64_t)(N0 + n);
-  st.sweep_queries += (uint64_t)n;
+  st.sweep_queries += (uint64_t)((n - cfg.rank + cfg.world - 1) / cfg.world);
   c.h_c.ensure(pb);
   c.h_d.ensure((size_t)n);
   c.h_e.ensure((size_t)n * sizeof(double));
@@ -254,8 +258,9 @@ void Forest::do_round() {
   const int32_t* hcnt = c.h_g.as<int32_t>();
   const int32_t* hidx = hcnt + n;
   const double* hdist = c.h_h.as<double>();
+  auto mine_shard = [&](int i) { return i % cfg.world == cfg.rank; };
 
-  // ---- classify neighbours, build the pose / edge task lists
+  // ---- classify neighbours, build the pose / edge task lists (own shard only)
   std::vector<double> pose_tasks, seg_a, seg_b;
   auto add_seg = [&](const double* a, const double* b) {
     int id = (int)(seg_a.size() / 6);
@@ -269,7 +274,7 @@ void Forest::do_round() {
     memcpy(cd.pos, hpos + 6 * (size_t)i, sizeof cd.pos);
     cd.in_lim = hlim[i] != 0;
     cd.pdist = hpd[i];
-    if (!cd.in_lim) continue;
+    if (!cd.in_lim || !mine_shard(i)) continue;
     if (hcnt[i] > CAP) overflow_q.push_back(i);
   }
   // rare: a hit list overflowed -> redo those queries with a big list through the generic path
@@ -280,6 +285,7 @@ void Forest::do_round() {
     std::vector<double> q6((size_t)m * 6), rr(m);
     std::vector<int32_t> mx(m), cn(m), ix((size_t)m * BIG);
     std::vector<double> dd((size_t)m * BIG);
+    std::vector<int32_t> hcnt_copy(hcnt, hcnt + n);
     for (int k = 0; k < m; ++k) {
       int i = overflow_q[k];
       memcpy(&q6[6 * (size_t)k], cands[i].pos, 6 * sizeof(double));
@@ -295,9 +301,11 @@ void Forest::do_round() {
       for (int j = 0; j < cn[k]; ++j) big[overflow_q[k]].push_back({dd[(size_t)k * BIG + j], ix[(size_t)k * BIG + j]});
     }
   }
+  std::vector<char> overflowed(n, 0);
+  for (int i : overflow_q) overflowed[i] = 1;
   for (int i = 0; i < n; ++i) {
     Cand& cd = cands[i];
-    if (!cd.in_lim) continue;
+    if (!cd.in_lim || !mine_shard(i)) continue;
     const FNode& ex = nodes[cd.expanded];
     cd.pose_task = (int)(pose_tasks.size() / 6);
     pose_tasks.insert(pose_tasks.end(), cd.pos, cd.pos + 6);
@@ -327,10 +335,13 @@ void Forest::do_round() {
       }
       all.push_back(nb);
     };
-    if (!big[i].empty() || hcnt[i] > CAP) {
+    if (overflowed[i]) {
       for (auto& h : big[i]) consider(h.first, h.second);
     } else {
-      for (int k = 0; k < hcnt[i]; ++k) consider(hdist[(size_t)i * CAP + k], hidx[(size_t)i * CAP + k]);
+      const int32_t* hc = c.h_g.as<int32_t>();  // (buffers may have been re-allocated by the overflow path)
+      const int32_t* hi = hc + n;
+      const double* hd = c.h_h.as<double>();
+      for (int k = 0; k < hc[i]; ++k) consider(hd[(size_t)i * CAP + k], hi[(size_t)i * CAP + k]);
     }
     std::sort(all.begin(), all.end(), [](const Nb& a, const Nb& b) {
       if (a.tree != b.tree) return a.tree < b.tree;
@@ -346,13 +357,12 @@ void Forest::do_round() {
       if (!nb.same_tree && nb.id >= 0) break;
     }
   }
+  (void)hidx; (void)hdist;
 
   // ---- collision launches
   const int n_pose = (int)(pose_tasks.size() / 6), n_seg = (int)(seg_a.size() / 6);
   std::vector<uint8_t> pose_hit(n_pose), seg_free(n_seg);
   std::vector<int32_t> seg_fh(n_seg), seg_ns(n_seg);
-  double host_before = ms_since(t_host) - wait_ms;
-  (void)host_before;
   if (n_pose) {
     auto t0 = Clock::now();
     c.collide_poses(pose_tasks.data(), n_pose, pose_hit.data());
@@ -363,9 +373,82 @@ void Forest::do_round() {
   st.segments_executed += n_seg;
   for (int k = 0; k < n_seg; ++k) st.samples_executed += (uint64_t)seg_ns[k];
 
+  // ---- answers of the owned candidates -> Cand fields + the int32 record stream
+  for (int i = 0; i < n; ++i) {
+    Cand& cd = cands[i];
+    if (!cd.in_lim || !mine_shard(i)) continue;
+    cd.answered = true;
+    cd.pose_hit = pose_hit[cd.pose_task] != 0;
+    cd.par_free = seg_free[cd.seg_parent] != 0;
+    cd.par_fh = seg_fh[cd.seg_parent];
+    cd.par_ns = seg_ns[cd.seg_parent];
+    for (Nb& nb : cd.nbs) {
+      nb.free = seg_free[nb.seg] != 0;
+      nb.fh = seg_fh[nb.seg];
+      nb.ns = seg_ns[nb.seg];
+    }
+    records.push_back(i);
+    records.push_back((cd.pose_hit ? 1 : 0) | (cd.par_free ? 2 : 0));
+    records.push_back(cd.par_fh);
+    records.push_back(cd.par_ns);
+    records.push_back((int32_t)cd.nbs.size());
+    for (const Nb& nb : cd.nbs) {
+      records.push_back(nb.id);
+      records.push_back(nb.tree);
+      records.push_back((nb.same_tree ? 1 : 0) | (nb.free ? 2 : 0));
+      records.push_back(nb.fh);
+      records.push_back(nb.ns);
+    }
+  }
+  st.host_ms += ms_since(t_host) - wait_ms;
+}
+
+// all = concatenation of every rank's record stream (rank order), counts in int32 words
+void Forest::round_commit(const int32_t* all, const int32_t* counts, int world) {
+  Ctx& c = *ctx;
+  HIPCHK(hipSetDevice(c.device));
+  if (!pending_round) throw HipError{"forest: round_commit without round_begin"};
+  if (world != cfg.world) throw HipError{"forest: round_commit world size mismatch"};
+  auto t_host = Clock::now();
+  double wait_ms = 0;
+  const int n = (int)cands.size();
+  // ---- absorb the other ranks' answers
+  size_t off = 0;
+  for (int r = 0; r < world; ++r) {
+    const int32_t* p = all + off;
+    const int32_t* end = p + counts[r];
+    off += (size_t)counts[r];
+    if (counts[r] < 2 || p[0] != REC_MAGIC || p[1] != n) throw HipError{"forest: ranks disagree on the round (diverged state)"};
+    p += 2;
+    while (p < end) {
+      int i = p[0];
+      if (i < 0 || i >= n || i % world != r) throw HipError{"forest: malformed record stream"};
+      Cand& cd = cands[i];
+      int flags = p[1], nn = p[4];
+      if (r != cfg.rank) {
+        cd.answered = true;
+        cd.pose_hit = flags & 1;
+        cd.par_free = (flags & 2) != 0;
+        cd.par_fh = p[2];
+        cd.par_ns = p[3];
+        cd.nbs.resize(nn);
+        for (int k = 0; k < nn; ++k) {
+          const int32_t* q = p + 5 + 5 * k;
+          Nb& nb = cd.nbs[k];
+          nb.id = q[0];
+          nb.tree = q[1];
+          nb.same_tree = q[2] & 1;
+          nb.free = (q[2] & 2) != 0;
+          nb.fh = q[3];
+          nb.ns = q[4];
+        }
+      }
+      p += 5 + 5 * (size_t)nn;
+    }
+  }
   // ---- replay expandNode in slot order (src/forest.h:240-376)
-  auto seg_calls = [&](int k) -> uint64_t {   // Collide calls isPathFree makes (early exit at the first hit)
-    return seg_fh[k] > 0 ? (uint64_t)seg_fh[k] : (uint64_t)seg_ns[k];
+  auto calls = [](int fh, int ns) -> uint64_t {  // Collide calls isPathFree makes (early exit at the first hit)
+    return fh > 0 ? (uint64_t)fh : (uint64_t)ns;
   };
   std::vector<double> app_pos;
   std::vector<int32_t> app_tree;
@@ -374,11 +457,12 @@ void Forest::do_round() {
     Slot& sl = slots[cd.slot];
     const unsigned iteration = (unsigned)(iter0 + i + 1);
     if (!cd.in_lim) continue;                                  // :246 !result
+    if (!cd.answered) throw HipError{"forest: a candidate has no answer record (missing rank?)"};
     st.collide_calls += 1;
-    if (pose_hit[cd.pose_task]) continue;                      // :246 env.Collide(newPoint)
+    if (cd.pose_hit) continue;                                 // :246 env.Collide(newPoint)
     st.path_free_calls += 1;
-    st.collide_calls += seg_calls(cd.seg_parent);
-    if (!seg_free[cd.seg_parent]) continue;                    // :246 !isPathFree(expanded, newPoint)
+    st.collide_calls += calls(cd.par_fh, cd.par_ns);
+    if (!cd.par_free) continue;                                // :246 !isPathFree(expanded, newPoint)
     st.nn_queries += (uint64_t)trees.size();                   // :262-267 one radiusSearch per tree
     const int expanded = cd.expanded;
     const int mine = nodes[expanded].tree;
@@ -390,14 +474,12 @@ void Forest::do_round() {
         nb_node = cands[-1 - nb.id].accepted_id;
         if (nb_node < 0) continue;                             // that sample never became a node
       }
+      st.path_free_calls += 1;
+      st.collide_calls += calls(nb.fh, nb.ns);
       if (nb.same_tree) {
-        st.path_free_calls += 1;
-        st.collide_calls += seg_calls(nb.seg);
-        if (seg_free[nb.seg]) { reject = true; break; }        // :276-280 overcrowded
+        if (nb.free) { reject = true; break; }                 // :276-280 overcrowded
       } else {
-        st.path_free_calls += 1;
-        st.collide_calls += seg_calls(nb.seg);
-        if (seg_free[nb.seg]) {                                // :288-294
+        if (nb.free) {                                         // :288-294
           std::vector<Border>& bp = border(nb.tree, mine);
           int a = std::min(nb_node, expanded), b = std::max(nb_node, expanded);
           bool found = false;
@@ -420,29 +502,32 @@ void Forest::do_round() {
     app_tree.push_back(mine);
   }
   // ---- commit the accepted nodes to the device store (replaces flannIndex->addPoints, :367)
+  if (n > 0) c.store_n = N0;
   if (!app_tree.empty()) {
     auto t0 = Clock::now();
-    c.store_n = N0;
     c.store_append(app_pos.data(), app_tree.data(), (int)app_tree.size());
     wait_ms += ms_since(t0);
   }
+  pending_round = false;
+  // ---- wave bookkeeping (src/forest.h:155: at most ThresholdMisses attempts per slot)
+  bool any_failing = false;
+  for (const Slot& s : slots) any_failing |= s.failing;
+  if (round >= cfg.threshold_misses || !any_failing || solved || iter >= cfg.max_iterations) end_wave();
   st.host_ms += ms_since(t_host) - wait_ms;
 }
 
 void Forest::run(int max_waves) {
+  if (cfg.world != 1) throw HipError{"forest: run() drives a single-GPU forest; use round_begin/round_commit"};
   auto t0 = Clock::now();
-  int done = 0;
-  while (!terminated()) {
-    if (max_waves > 0 && done >= max_waves) break;
-    ++done;
-    begin_wave();
-    for (int r = 0; r < cfg.threshold_misses && !solved; ++r) {
-      bool any = false;
-      for (const Slot& s : slots) any |= s.failing;
-      if (!any || iter >= cfg.max_iterations) break;
-      do_round();
+  const uint64_t w0 = st.waves;
+  while (true) {
+    if (!in_wave) {
+      if (terminated()) break;
+      if (max_waves > 0 && (int)(st.waves - w0) >= max_waves) break;
     }
-    end_wave();
+    round_begin();
+    int32_t cnt = (int32_t)records.size();
+    round_commit(records.data(), &cnt, 1);
   }
   st.total_ms += ms_since(t0);
 }

@@ -38,6 +38,7 @@ struct SampleParams {
   double limits[6];
   double dist_tree;
   double sweep_abs_eps;
+  int rank, world;  // only the queries of candidates i with i % world == rank are active
 };
 
 #define SFFK_MAX_LEVELS 4

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void k_sample_steer(const uint64_t* __restrict
       q.r2f = (float)(ri * ri) * 1.000001f;
       q.tree = -1;
       q.max_id = q_max_base + i;
-      q.active = ok ? 1 : 0;
+      q.active = (ok && (prm.world <= 1 || i % prm.world == prm.rank)) ? 1 : 0;
       q.pad = 0;
       queries[i] = q;
     }

@@ -193,3 +193,45 @@ def test_forest_errors(S, ctx):
         S.Forest(ctx, roots, sc["limits"], 18.0, 14.0, dim=3)
     with pytest.raises(S.SffGpuError):
         S.Forest(ctx, roots, sc["limits"], 18.0, 14.0, goal=[1, 2, 3, 0, 0, 0])
+
+
+@pytest.mark.parametrize("world,wave,name", [(2, 64, "dense3d"), (3, 256, "dense3d"), (4, 128, "triang")])
+def test_sharded_rounds_equal_single_gpu(S, name, world, wave):
+    """Multi-GPU wave protocol on ONE device: `world` contexts play the ranks, the record streams
+    are exchanged in-process.  Every rank must end in the state of the world=1 run == the oracle."""
+    sc = common.scenario(name)
+    w = O.World(sc["env"], sc["robot"], O.TRIG_PORTABLE)
+    roots = sc["xml_points"][:5] if sc["xml_points"] is not None else common.free_roots(w.collide, sc["limits"], 5, seed=4)
+    kw = dict(dist_tree=sc["dist_tree"], sampling_dist=sc["sampling_dist"], dim=sc["dim"], max_iterations=6000,
+              wave=wave, seed=4)
+    fo = O.Forest(w, roots, sc["limits"], **kw)
+    fo.run()
+    ctxs, forests = [], []
+    for r in range(world):
+        c = S.Context(0)
+        c.upload_env(sc["env"])
+        c.upload_robot(sc["robot"])
+        ctxs.append(c)
+        forests.append(S.Forest(c, roots, sc["limits"], rank=r, world=world, **kw))
+    rounds = 0
+    while True:
+        outs = [f.round_begin() for f in forests]
+        dones = [d for _, d in outs]
+        assert len(set(dones)) == 1
+        if dones[0]:
+            break
+        allw = np.concatenate([r for r, _ in outs]).astype(np.int32)
+        counts = np.array([len(r) for r, _ in outs], np.int32)
+        for f in forests:
+            f.round_commit(allw, counts)
+        rounds += 1
+        assert rounds < 100000
+    for f in forests:
+        assert_same_forest(fo, f)
+    # the work really was sharded: each rank executed roughly 1/world of the edge checks
+    ex = [f.stats()["segments_executed"] for f in forests]
+    assert max(ex) < 1.0 * sum(ex) / world * 1.5 + 50
+    for f in forests:
+        f.close()
+    for c in ctxs:
+        c.close()
