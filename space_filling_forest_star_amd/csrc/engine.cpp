@@ -396,18 +396,11 @@ void Ctx::sample_steer(const uint64_t* words, const double* center6, int n, doub
   memcpy(in_limits, h_d.p, (size_t)n);
 }
 
-namespace {
-struct HitRec {
-  double d;
-  int id;
-  bool operator<(const HitRec& o) const { return d < o.d || (d == o.d && id < o.id); }
-};
-}  // namespace
-
 // One sweep launch + host-side ordering.  Returns the raw per-query totals.
-static void sweep_once(Ctx& c, const double* q6, int nq, const std::vector<double>& r, const int32_t* tree,
-                       const int32_t* max_id, const std::vector<uint8_t>& active, int cap, std::vector<int32_t>& cnt,
-                       std::vector<std::vector<HitRec>>& out) {
+void Ctx::sweep_lists(const double* q6, int nq, const std::vector<double>& r, const int32_t* tree,
+                      const int32_t* max_id, const std::vector<uint8_t>& active, int cap, int n_store,
+                      std::vector<int32_t>& cnt, std::vector<std::vector<HitRec>>& out) {
+  Ctx& c = *this;
   const double eps = c.sweep_eps();
   c.h_a.ensure((size_t)nq * sizeof(sffk::SweepQuery));
   c.h_b.ensure((size_t)nq * 6 * sizeof(double));
@@ -436,7 +429,7 @@ static void sweep_once(Ctx& c, const double* q6, int nq, const std::vector<doubl
   HIPCHK(hipMemcpyAsync(c.d_b.p, c.h_b.p, (size_t)nq * 6 * sizeof(double), hipMemcpyHostToDevice, c.stream));
   HIPCHK(hipMemsetAsync(c.d_c.p, 0, (size_t)nq * sizeof(int32_t), c.stream));
   c.time_begin(T_SWEEP);
-  sffk::launch_sweep(c.stream, c.store_view(), c.store_n, c.d_a.as<sffk::SweepQuery>(), c.d_b.as<double>(), nq,
+  sffk::launch_sweep(c.stream, c.store_view(), n_store, c.d_a.as<sffk::SweepQuery>(), c.d_b.as<double>(), nq,
                      c.d_c.as<int32_t>(), c.d_d.as<int32_t>(), c.d_e.as<double>(), cap);
   c.time_end();
   c.h_c.ensure((size_t)nq * sizeof(int32_t));
@@ -466,7 +459,7 @@ void Ctx::radius(const double* q6, int nq, const double* r, const int32_t* tree,
   std::vector<uint8_t> active(nq, 1);
   std::vector<int32_t> c;
   std::vector<std::vector<HitRec>> out;
-  sweep_once(*this, q6, nq, rv, tree, max_id, active, cap, c, out);
+  sweep_lists(q6, nq, rv, tree, max_id, active, cap, store_n, c, out);
   for (int i = 0; i < nq; ++i) {
     cnt[i] = c[i];
     for (size_t k = 0; k < out[i].size(); ++k) {
@@ -497,7 +490,7 @@ void Ctx::knn(const double* q6, int nq, int k, const int32_t* tree, const int32_
     if (!any) break;
     std::vector<int32_t> c;
     std::vector<std::vector<HitRec>> out;
-    sweep_once(*this, q6, nq, r, tree, max_id, active, cap, c, out);
+    sweep_lists(q6, nq, r, tree, max_id, active, cap, store_n, c, out);
     for (int i = 0; i < nq; ++i) {
       if (!active[i]) continue;
       if (c[i] > cap) {            // too many: shrink

@@ -47,6 +47,12 @@ struct Mt64 {
   int uniform_int(int lo, int hi);  // uniform_int_distribution<int>(lo,hi) (Lemire multiply-shift)
 };
 
+struct HitRec {
+  double d;
+  int id;
+  bool operator<(const HitRec& o) const { return d < o.d || (d == o.d && id < o.id); }
+};
+
 enum TimerKind { T_SWEEP = 0, T_COLLIDE = 1, T_SAMPLE = 2, T_KINDS = 3 };
 
 struct Ctx {
@@ -101,6 +107,10 @@ struct Ctx {
   void knn(const double* q6, int nq, int k, const int32_t* tree, const int32_t* max_id, int32_t* idx, double* dist,
            int32_t* cnt);
   double sweep_eps() const;
+  // one sweep launch over the first n_store entries; per-query hit lists sorted by (dist, id)
+  void sweep_lists(const double* q6, int nq, const std::vector<double>& r, const int32_t* tree, const int32_t* max_id,
+                   const std::vector<uint8_t>& active, int cap, int n_store, std::vector<int32_t>& cnt,
+                   std::vector<std::vector<HitRec>>& out);
 };
 
 struct FNode {
@@ -146,6 +156,12 @@ struct Forest {
     bool free = false;
     int fh = -1, ns = 0;
   };
+  struct Member {    // SFF*: one potential k-nearest neighbour, both edge directions answered
+    int id;          // store node id, or -1-c for candidate c of this round
+    bool fwd_free = false, bwd_free = false;  // isPathFree(new, nb) (:323) / isPathFree(nb, new) (:336)
+    int fwd_fh = -1, fwd_ns = 0, bwd_fh = -1, bwd_ns = 0;
+    int seg_f = -1, seg_b = -1;
+  };
   struct Cand {      // one sample of the current round
     int slot, expanded;
     double pos[6];
@@ -155,12 +171,14 @@ struct Forest {
     bool answered = false, pose_hit = false, par_free = false;
     int par_fh = -1, par_ns = 0;
     std::vector<Nb> nbs;
+    std::vector<Member> members;  // SFF*: candidates for the k-nearest set (src/forest.h:317)
     int accepted_id = -1;
   };
   std::vector<Cand> cands;
   std::vector<int32_t> records;  // this rank's answers of the pending round (int32 stream)
   bool pending_round = false;
   int iter0 = 0, N0 = 0;
+  double knn_r = 0;  // running guess of the k-nearest radius (SFF*)
 
   Forest(Ctx* c, const sffgpu_forest_cfg& cf, const double* roots6, int n_roots);
   int add_node(const double* pos, int tree, int parent, double dclosest, double droot, unsigned it);

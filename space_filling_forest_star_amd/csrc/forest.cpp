@@ -12,6 +12,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <limits>
 
 #include "engine.h"
 #include "sff_geom.h"
@@ -28,7 +29,6 @@ Forest::Forest(Ctx* c, const sffgpu_forest_cfg& cf, const double* roots6, int n_
   if (cfg.wave < 1) cfg.wave = 1;
   if (cfg.dim != 2 && cfg.dim != 6) throw HipError{"forest: dim must be 2 or 6"};
   if (cfg.has_goal) throw HipError{"forest: single-goal mode (Problem::hasGoal) is not implemented on the GPU path yet"};
-  if (cfg.optimize) throw HipError{"forest: optimize (SFF*) is not implemented on the GPU path yet"};
   if (cfg.world < 1) cfg.world = 1;
   if (cfg.rank < 0 || cfg.rank >= cfg.world) throw HipError{"forest: rank outside [0, world)"};
   if (n_roots < 1) throw HipError{"forest: at least one root"};
@@ -45,6 +45,7 @@ Forest::Forest(Ctx* c, const sffgpu_forest_cfg& cf, const double* roots6, int n_
   }
   ctx->store_append(roots6, tids.data(), n_roots);
   memset(&st, 0, sizeof st);
+  knn_r = 2.5 * cfg.sampling_dist;
 }
 
 int Forest::add_node(const double* pos, int tree, int parent, double dclosest, double droot, unsigned it) {
@@ -373,7 +374,7 @@ void Forest::round_begin() {
   st.segments_executed += n_seg;
   for (int k = 0; k < n_seg; ++k) st.samples_executed += (uint64_t)seg_ns[k];
 
-  // ---- answers of the owned candidates -> Cand fields + the int32 record stream
+  // ---- answers of the owned candidates -> Cand fields
   for (int i = 0; i < n; ++i) {
     Cand& cd = cands[i];
     if (!cd.in_lim || !mine_shard(i)) continue;
@@ -387,17 +388,148 @@ void Forest::round_begin() {
       nb.fh = seg_fh[nb.seg];
       nb.ns = seg_ns[nb.seg];
     }
+  }
+
+  // ---- SFF* (src/forest.h:307-351): candidates that no STORE neighbour rejects may be accepted;
+  // for them fetch the potential k-nearest set of their tree and answer both edge directions
+  if (cfg.optimize) {
+    std::vector<int> maybe;
+    for (int i = 0; i < n; ++i) {
+      Cand& cd = cands[i];
+      if (!cd.answered || cd.pose_hit || !cd.par_free) continue;
+      bool rejected = false;
+      for (const Nb& nb : cd.nbs) {
+        if (nb.id < 0) continue;
+        if (nb.same_tree) { if (nb.free) { rejected = true; break; } }
+        else { rejected = true; break; }
+      }
+      if (!rejected) maybe.push_back(i);
+    }
+    const int m = (int)maybe.size();
+    if (m) {
+      auto t0 = Clock::now();
+      const int KCAP = 256;
+      std::vector<double> q6((size_t)m * 6), r(m, knn_r), lo(m, 0.0), hi(m, -1.0);
+      std::vector<int32_t> qtree(m), qmax(m), kmax(m);
+      std::vector<uint8_t> active(m, 1);
+      std::vector<std::vector<HitRec>> lists(m);
+      for (int k = 0; k < m; ++k) {
+        const Cand& cd = cands[maybe[k]];
+        memcpy(&q6[6 * (size_t)k], cd.pos, 6 * sizeof(double));
+        qtree[k] = nodes[cd.expanded].tree;
+        qmax[k] = N0 + maybe[k];
+        // k = 2e log10(#nodes) (:309) can only grow with the nodes accepted earlier in this round
+        kmax[k] = (int32_t)(size_t)(2 * M_E * std::log10((double)(N0 + maybe[k])));
+        if (kmax[k] <= 0) active[k] = 0;
+      }
+      const double RMAX = 1e30;
+      for (int it = 0; it < 200; ++it) {
+        bool any = false;
+        for (int k = 0; k < m; ++k) any |= active[k] != 0;
+        if (!any) break;
+        std::vector<int32_t> cnt;
+        std::vector<std::vector<HitRec>> out;
+        c.sweep_lists(q6.data(), m, r, qtree.data(), qmax.data(), active, KCAP, N0 + n, cnt, out);
+        st.sweeps += 1;
+        st.sweep_nodes += (uint64_t)(N0 + n);
+        for (int k = 0; k < m; ++k) {
+          if (!active[k]) continue;
+          st.sweep_queries += 1;
+          if (cnt[k] > KCAP) { hi[k] = r[k]; r[k] = 0.5 * (lo[k] + hi[k]); continue; }
+          int store_hits = 0;
+          for (const HitRec& h : out[k]) store_hits += h.id < N0;
+          if (store_hits >= kmax[k] || r[k] >= RMAX) {
+            lists[k] = out[k];
+            active[k] = 0;
+          } else {
+            lo[k] = r[k];
+            r[k] = hi[k] > 0 ? 0.5 * (lo[k] + hi[k]) : std::min(RMAX, r[k] * 1.5);
+          }
+        }
+      }
+      double rsum = 0;
+      int rcount = 0;
+      for (int k = 0; k < m; ++k) {
+        Cand& cd = cands[maybe[k]];
+        if (kmax[k] <= 0) continue;
+        // store members: the kmax nearest; wave-mates: closer than the kmax-th store member
+        double dk = std::numeric_limits<double>::infinity();
+        int seen = 0;
+        for (const HitRec& h : lists[k]) {
+          if (h.id >= N0) continue;
+          if (++seen == kmax[k]) { dk = h.d; break; }
+        }
+        seen = 0;
+        for (const HitRec& h : lists[k]) {
+          Member mb;
+          if (h.id < N0) {
+            if (seen >= kmax[k]) continue;
+            ++seen;
+            mb.id = h.id;
+          } else {
+            if (!(h.d <= dk)) continue;
+            mb.id = -1 - (h.id - N0);
+          }
+          cd.members.push_back(mb);
+        }
+        if (dk < 1e29) { rsum += dk; ++rcount; }
+      }
+      if (rcount) knn_r = 1.15 * rsum / rcount;
+      // both directions of every member edge
+      std::vector<double> sa, sb;
+      for (int k = 0; k < m; ++k) {
+        Cand& cd = cands[maybe[k]];
+        for (Member& mb : cd.members) {
+          const double* mp = mb.id >= 0 ? nodes[mb.id].pos : cands[-1 - mb.id].pos;
+          mb.seg_f = (int)(sa.size() / 6);
+          sa.insert(sa.end(), cd.pos, cd.pos + 6);   // isPathFree(newPoint, neighbor)   :323
+          sb.insert(sb.end(), mp, mp + 6);
+          mb.seg_b = (int)(sa.size() / 6);
+          sa.insert(sa.end(), mp, mp + 6);           // isPathFree(neighbor, newPoint)   :336
+          sb.insert(sb.end(), cd.pos, cd.pos + 6);
+        }
+      }
+      const int ns2 = (int)(sa.size() / 6);
+      if (ns2) {
+        std::vector<uint8_t> fr(ns2);
+        std::vector<int32_t> fh(ns2), nsv(ns2);
+        c.collide_segments(sa.data(), sb.data(), ns2, fr.data(), fh.data(), nsv.data());
+        st.segments_executed += ns2;
+        for (int k = 0; k < ns2; ++k) st.samples_executed += (uint64_t)nsv[k];
+        for (int k = 0; k < m; ++k)
+          for (Member& mb : cands[maybe[k]].members) {
+            mb.fwd_free = fr[mb.seg_f] != 0; mb.fwd_fh = fh[mb.seg_f]; mb.fwd_ns = nsv[mb.seg_f];
+            mb.bwd_free = fr[mb.seg_b] != 0; mb.bwd_fh = fh[mb.seg_b]; mb.bwd_ns = nsv[mb.seg_b];
+          }
+      }
+      wait_ms += ms_since(t0);
+    }
+  }
+
+  // ---- the int32 record stream of the owned candidates
+  for (int i = 0; i < n; ++i) {
+    Cand& cd = cands[i];
+    if (!cd.answered) continue;
     records.push_back(i);
     records.push_back((cd.pose_hit ? 1 : 0) | (cd.par_free ? 2 : 0));
     records.push_back(cd.par_fh);
     records.push_back(cd.par_ns);
     records.push_back((int32_t)cd.nbs.size());
+    records.push_back((int32_t)cd.members.size());
     for (const Nb& nb : cd.nbs) {
       records.push_back(nb.id);
       records.push_back(nb.tree);
       records.push_back((nb.same_tree ? 1 : 0) | (nb.free ? 2 : 0));
       records.push_back(nb.fh);
       records.push_back(nb.ns);
+    }
+    for (const Member& mb : cd.members) {
+      records.push_back(mb.id);
+      records.push_back((mb.fwd_free ? 1 : 0) | (mb.bwd_free ? 2 : 0));
+      records.push_back(mb.fwd_fh);
+      records.push_back(mb.fwd_ns);
+      records.push_back(mb.bwd_fh);
+      records.push_back(mb.bwd_ns);
     }
   }
   st.host_ms += ms_since(t_host) - wait_ms;
@@ -424,7 +556,7 @@ void Forest::round_commit(const int32_t* all, const int32_t* counts, int world) 
       int i = p[0];
       if (i < 0 || i >= n || i % world != r) throw HipError{"forest: malformed record stream"};
       Cand& cd = cands[i];
-      int flags = p[1], nn = p[4];
+      int flags = p[1], nn = p[4], nm = p[5];
       if (r != cfg.rank) {
         cd.answered = true;
         cd.pose_hit = flags & 1;
@@ -433,7 +565,7 @@ void Forest::round_commit(const int32_t* all, const int32_t* counts, int world) 
         cd.par_ns = p[3];
         cd.nbs.resize(nn);
         for (int k = 0; k < nn; ++k) {
-          const int32_t* q = p + 5 + 5 * k;
+          const int32_t* q = p + 6 + 5 * k;
           Nb& nb = cd.nbs[k];
           nb.id = q[0];
           nb.tree = q[1];
@@ -442,8 +574,17 @@ void Forest::round_commit(const int32_t* all, const int32_t* counts, int world) 
           nb.fh = q[3];
           nb.ns = q[4];
         }
+        cd.members.resize(nm);
+        for (int k = 0; k < nm; ++k) {
+          const int32_t* q = p + 6 + 5 * (size_t)nn + 6 * k;
+          Member& mb = cd.members[k];
+          mb.id = q[0];
+          mb.fwd_free = q[1] & 1;
+          mb.bwd_free = (q[1] & 2) != 0;
+          mb.fwd_fh = q[2]; mb.fwd_ns = q[3]; mb.bwd_fh = q[4]; mb.bwd_ns = q[5];
+        }
       }
-      p += 5 + 5 * (size_t)nn;
+      p += 6 + 5 * (size_t)nn + 6 * (size_t)nm;
     }
   }
   // ---- replay expandNode in slot order (src/forest.h:240-376)
@@ -494,7 +635,48 @@ void Forest::round_commit(const int32_t* all, const int32_t* counts, int world) 
       }
     }
     if (reject) continue;
-    int id = add_node(cd.pos, mine, expanded, cd.pdist, cd.pdist + nodes[expanded].d_root, iteration);  // :353
+    int id;
+    if (cfg.optimize) {                                        // :307-351 SFF*: choose parent, rewire
+      double best = sffg::dist6(cd.pos, nodes[expanded].pos) + nodes[expanded].d_root;
+      const size_t ksff = (size_t)(2 * M_E * std::log10((double)nodes.size()));  // Node::globId (:309)
+      struct KN { double d; int order; int node; const Member* mb; };
+      std::vector<KN> knn;
+      for (const Member& mb : cd.members) {
+        int nd = mb.id >= 0 ? mb.id : cands[-1 - mb.id].accepted_id;
+        if (nd < 0) continue;
+        knn.push_back({sffg::dist6(cd.pos, nodes[nd].pos), nodes[nd].idx_in_tree, nd, &mb});
+      }
+      std::sort(knn.begin(), knn.end(), [](const KN& a, const KN& b) { return a.d < b.d || (a.d == b.d && a.order < b.order); });
+      if (knn.size() > ksff) knn.resize(ksff);
+      if (knn.size() < std::min(ksff, trees[mine].size()))
+        throw HipError{"forest: k-nearest candidate set incomplete (internal error)"};
+      int parent = expanded;
+      for (const KN& kn : knn) {                               // :320-327
+        double nd = sffg::dist6(cd.pos, nodes[kn.node].pos) + nodes[kn.node].d_root;
+        if (nd < best - SFFG_TOL) {
+          st.path_free_calls += 1;
+          st.collide_calls += calls(kn.mb->fwd_fh, kn.mb->fwd_ns);
+          if (kn.mb->fwd_free) { best = nd; parent = kn.node; }
+        }
+      }
+      id = add_node(cd.pos, mine, parent, sffg::dist6(cd.pos, nodes[parent].pos), best, iteration);  // :329
+      for (const KN& kn : knn) {                               // :332-350
+        double npd = sffg::dist6(nodes[kn.node].pos, cd.pos);
+        double proposed = best + npd;
+        if (proposed < nodes[kn.node].d_root - SFFG_TOL) {
+          st.path_free_calls += 1;
+          st.collide_calls += calls(kn.mb->bwd_fh, kn.mb->bwd_ns);
+          if (kn.mb->bwd_free) {
+            nodes[kn.node].parent = id;
+            nodes[kn.node].d_closest = npd;
+            nodes[kn.node].d_root = proposed;                  // descendants keep their old cost (Appendix A.6)
+          }
+        }
+      }
+      st.nn_queries += 1;                                      // :317 knnSearch
+    } else {
+      id = add_node(cd.pos, mine, expanded, cd.pdist, cd.pdist + nodes[expanded].d_root, iteration);  // :353
+    }
     cd.accepted_id = id;
     frontier.push_back(id);                                    // :365
     sl.failing = false;

@@ -27,6 +27,8 @@ SCENARIOS = {
     "dense3d_coarse": ("dense_3D", "robot_cylinder_small", 1.0, [-60, 2060, -60, 2110, 0, 1000], 100.0, 80.0, 6),
     # C2: test_triang.xml geometry (scale 10, dtree 0.5, circum 0.4, ranges +-10 / 0..10)
     "triang": ("triang", "robot_cylinder_small", 10.0, [-100, 100, -100, 100, 0, 100], 5.0, 4.0, 6),
+    # C5: test_building.xml geometry (building.obj 26 908 tris, scale 10, ranges +-7 / 0..14)
+    "building": ("building", "robot_cylinder_small", 10.0, [-70, 70, -70, 70, 0, 140], 5.0, 4.0, 6),
     # C1: test_2D.xml geometry (dense.tri, 2-D robot)
     "dense2d": ("dense_2D", "robot_small_2D", 1.0, [-60, 2060, -60, 2110, 0, 0], 100.0, 80.0, 2),
 }
@@ -35,6 +37,10 @@ SCENARIOS = {
 # start points the reference's example XMLs list (test_triang.xml, test_2D.xml), un-scaled
 XML_POINTS = {
     "triang": [[-1.5, 4, 3], [2.9, 0.3, 7], [2.7, -3.4, 5], [-3.96, -2.4, 1], [4.2, 3.5, 1], [-4.3, 3.5, 8]],
+    "building": [[-5.376207930019596, -5.338214644384135, 0.7519141368058615],
+                 [5.309629695920314, -5.3435510614853206, 2.225339932086428],
+                 [-5.445894591081855, 4.942949264187298, 8.034669391216193],
+                 [3.4004901456614443, 0.3800196290706541, 10], [0.30319967716688234, 0.057430173261578954, 7]],
     "dense2d": [[1500, 1600, 0], [100, 100, 0], [500, 1700, 0], [1440, 330, 0]],
 }
 

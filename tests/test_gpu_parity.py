@@ -136,14 +136,14 @@ def test_radius_and_knn_exact(ctx):
     assert np.all(cnt == want)
 
 
-def run_pair(S, ctx, name, wave, iters, seed, n_roots=5, budget=0):
+def run_pair(S, ctx, name, wave, iters, seed, n_roots=5, budget=0, optimize=False):
     sc, w = load_world(ctx, name)
     if sc["xml_points"] is not None:
         roots = sc["xml_points"][:n_roots]
     else:
         roots = common.free_roots(w.collide, sc["limits"], n_roots, seed=seed, dim=sc["dim"])
     kw = dict(dist_tree=sc["dist_tree"], sampling_dist=sc["sampling_dist"], dim=sc["dim"], max_iterations=iters,
-              node_budget=budget, wave=wave, seed=seed)
+              node_budget=budget, wave=wave, seed=seed, optimize=optimize)
     fo = O.Forest(w, roots, sc["limits"], **kw)
     fo.run()
     fg = S.Forest(ctx, roots, sc["limits"], **kw)
@@ -179,6 +179,30 @@ def test_forest_topology_identical(S, ctx, name, wave, iters):
     assert_same_forest(fo, fg)
 
 
+@pytest.mark.parametrize("name,wave,iters", [
+    ("dense3d", 1, 1200), ("dense3d", 64, 5000), ("triang", 1, 1500), ("triang", 256, 10000),
+    ("dense3d_coarse", 32, 3000), ("building", 128, 6000), ("dense2d", 16, 2500),
+])
+def test_sff_star_rewire_identical(S, ctx, name, wave, iters):
+    """SFF* (optimize=true): choose-parent + rewire (src/forest.h:307-351) — parents, costs and the
+    reference-equivalent call counters must equal the oracle's sequential replay."""
+    fo, fg = run_pair(S, ctx, name, wave, iters, seed=5, optimize=True)
+    assert fo.stats()["n_nodes"] > 50
+    assert_same_forest(fo, fg)
+    # rewiring really happened: some node's parent is younger than the node itself
+    no = fo.nodes()
+    assert np.any(no["parent"] > np.arange(len(no["parent"])))
+
+
+@pytest.mark.parametrize("name", ["building"])
+def test_building_map_collision(ctx, name):
+    sc, w = load_world(ctx, name)
+    poses = np.vstack([common.random_poses(sc["limits"], 2000, 15), common.poses_near_surface(sc["env"], 6000, 16, 2.0)])
+    assert np.array_equal(ctx.collide_poses(poses), w.collide_many(poses))
+    fo, fg = run_pair(__import__("space_filling_forest_star_amd"), ctx, name, 64, 3000, seed=6)
+    assert_same_forest(fo, fg)
+
+
 def test_forest_node_budget_and_seeds(S, ctx):
     for seed in (1, 3):
         fo, fg = run_pair(S, ctx, "dense3d", 512, 10**6, seed=seed, n_roots=10, budget=6000)
@@ -193,17 +217,20 @@ def test_forest_errors(S, ctx):
         S.Forest(ctx, roots, sc["limits"], 18.0, 14.0, dim=3)
     with pytest.raises(S.SffGpuError):
         S.Forest(ctx, roots, sc["limits"], 18.0, 14.0, goal=[1, 2, 3, 0, 0, 0])
+    with pytest.raises(S.SffGpuError):
+        S.Forest(ctx, roots, sc["limits"], 18.0, 14.0, rank=2, world=2)
 
 
-@pytest.mark.parametrize("world,wave,name", [(2, 64, "dense3d"), (3, 256, "dense3d"), (4, 128, "triang")])
-def test_sharded_rounds_equal_single_gpu(S, name, world, wave):
+@pytest.mark.parametrize("world,wave,name,optimize", [(2, 64, "dense3d", False), (3, 256, "dense3d", False),
+                                                      (4, 128, "triang", False), (2, 128, "triang", True)])
+def test_sharded_rounds_equal_single_gpu(S, name, world, wave, optimize):
     """Multi-GPU wave protocol on ONE device: `world` contexts play the ranks, the record streams
     are exchanged in-process.  Every rank must end in the state of the world=1 run == the oracle."""
     sc = common.scenario(name)
     w = O.World(sc["env"], sc["robot"], O.TRIG_PORTABLE)
     roots = sc["xml_points"][:5] if sc["xml_points"] is not None else common.free_roots(w.collide, sc["limits"], 5, seed=4)
     kw = dict(dist_tree=sc["dist_tree"], sampling_dist=sc["sampling_dist"], dim=sc["dim"], max_iterations=6000,
-              wave=wave, seed=4)
+              wave=wave, seed=4, optimize=optimize)
     fo = O.Forest(w, roots, sc["limits"], **kw)
     fo.run()
     ctxs, forests = [], []
