@@ -108,7 +108,7 @@ Ctx::~Ctx() {
   if (stream) (void)hipStreamSynchronize(stream);
   for (auto& t : pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto e : pool) (void)hipEventDestroy(e);
-  DevBuf* bufs[] = {&env_tri, &env_box, &rob_tri, &sx, &sy, &sz, &syaw, &spitch, &sroll, &stree, &spos,
+  DevBuf* bufs[] = {&env_tri, &env_box, &env_plane, &rob_tri, &sx, &sy, &sz, &syaw, &spitch, &sroll, &stree, &spos,
                     &d_a, &d_b, &d_c, &d_d, &d_e, &d_f, &d_g, &d_h};
   for (DevBuf* b : bufs) b->release();
   for (auto& b : level_box) b.release();
@@ -225,8 +225,22 @@ void Ctx::upload_mesh(int role, const double* tri9, int n) {
   env_box.ensure(box_s.size() * sizeof(double));
   HIPCHK(hipMemcpy(env_tri.p, tri_s.data(), tri_s.size() * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(env_box.p, box_s.data(), box_s.size() * sizeof(double), hipMemcpyHostToDevice));
+  std::vector<double> plane((size_t)n * 5);
+  for (int k = 0; k < n; ++k) {
+    const double* P = &tri_s[9 * (size_t)k];
+    double e1[3] = {P[3] - P[0], P[4] - P[1], P[5] - P[2]}, e2[3] = {P[6] - P[0], P[7] - P[1], P[8] - P[2]}, nn[3];
+    sffg::cross(e1, e2, nn);
+    plane[5 * (size_t)k + 0] = nn[0];
+    plane[5 * (size_t)k + 1] = nn[1];
+    plane[5 * (size_t)k + 2] = nn[2];
+    plane[5 * (size_t)k + 3] = (nn[0] * P[0] + nn[1] * P[1]) + nn[2] * P[2];
+    plane[5 * (size_t)k + 4] = std::sqrt(nn[0] * nn[0] + nn[1] * nn[1] + nn[2] * nn[2]);
+  }
+  env_plane.ensure(plane.size() * sizeof(double));
+  HIPCHK(hipMemcpy(env_plane.p, plane.data(), plane.size() * sizeof(double), hipMemcpyHostToDevice));
   envv.tri = env_tri.as<double>();
   envv.tri_box = env_box.as<double>();
+  envv.tri_plane = env_plane.as<double>();
   envv.n_tri = n;
   // levels
   std::vector<double> cur = box_s;
@@ -329,30 +343,52 @@ void Ctx::collide_segments(const double* a6, const double* b6, int n, uint8_t* i
   if (n <= 0) return;
   if (!have_env || !have_robot) throw HipError{"collide_segments: upload ENV and ROBOT meshes first"};
   HIPCHK(hipSetDevice(device));
+  // work list: one item per (edge, chunk of 64 samples); sample counts from the same fp64 expressions
+  // the kernel evaluates (src/problemStruct.h:155-156)
+  std::vector<int32_t> ns(n);
+  size_t n_items = 0;
+  for (int i = 0; i < n; ++i) {
+    ns[i] = sffg::edge_samples(sffg::edge_parts(a6 + 6 * (size_t)i, b6 + 6 * (size_t)i));
+    n_items += (size_t)(ns[i] + 63) / 64;
+  }
   const size_t pb = (size_t)n * 6 * sizeof(double);
-  h_a.ensure(pb); h_b.ensure(pb); h_c.ensure((size_t)n); h_d.ensure((size_t)n * 4); h_e.ensure((size_t)n * 4);
+  h_a.ensure(pb); h_b.ensure(pb); h_c.ensure(std::max<size_t>(1, n_items) * sizeof(int2));
+  h_d.ensure((size_t)n * 4); h_e.ensure((size_t)n * 4);
   memcpy(h_a.p, a6, pb);
   memcpy(h_b.p, b6, pb);
-  d_a.ensure(pb); d_b.ensure(pb); d_c.ensure((size_t)n); d_d.ensure((size_t)n * 4); d_e.ensure((size_t)n * 4);
-  HIPCHK(hipMemcpyAsync(d_a.p, h_a.p, pb, hipMemcpyHostToDevice, stream));
-  HIPCHK(hipMemcpyAsync(d_b.p, h_b.p, pb, hipMemcpyHostToDevice, stream));
-  time_begin(T_COLLIDE);
-  sffk::launch_collide_segments(stream, envv, robv, d_a.as<double>(), d_b.as<double>(), n, d_c.as<uint8_t>(),
-                                d_d.as<int32_t>(), d_e.as<int32_t>());
-  time_end();
-  HIPCHK(hipMemcpyAsync(h_c.p, d_c.p, (size_t)n, hipMemcpyDeviceToHost, stream));
-  HIPCHK(hipMemcpyAsync(h_d.p, d_d.p, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
-  HIPCHK(hipMemcpyAsync(h_e.p, d_e.p, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
-  sync();
-  std::vector<uint8_t> fr(h_c.as<uint8_t>(), h_c.as<uint8_t>() + n);
-  std::vector<int32_t> fh(h_d.as<int32_t>(), h_d.as<int32_t>() + n), ns(h_e.as<int32_t>(), h_e.as<int32_t>() + n);
+  int2* items = h_c.as<int2>();
+  size_t k = 0;
+  for (int i = 0; i < n; ++i)
+    for (int ch = 0; ch < (ns[i] + 63) / 64; ++ch) items[k++] = make_int2(i, ch);
+  std::vector<int32_t> fh(n, -1);
+  std::vector<uint8_t> ovf(n, 0);
+  if (n_items > 0 && envv.n_tri > 0) {
+    d_a.ensure(pb); d_b.ensure(pb); d_c.ensure(n_items * sizeof(int2)); d_d.ensure((size_t)n * 4); d_e.ensure((size_t)n * 4);
+    HIPCHK(hipMemcpyAsync(d_a.p, h_a.p, pb, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(d_b.p, h_b.p, pb, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(d_c.p, h_c.p, n_items * sizeof(int2), hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)d_d.p, 0x7fffffff, (size_t)n, stream));
+    HIPCHK(hipMemsetAsync(d_e.p, 0, (size_t)n * 4, stream));
+    time_begin(T_COLLIDE);
+    sffk::launch_collide_segments(stream, envv, robv, d_a.as<double>(), d_b.as<double>(), d_c.as<int2>(), (int)n_items,
+                                  d_d.as<int32_t>(), d_e.as<int32_t>());
+    time_end();
+    HIPCHK(hipMemcpyAsync(h_d.p, d_d.p, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipMemcpyAsync(h_e.p, d_e.p, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
+    sync();
+    for (int i = 0; i < n; ++i) {
+      int32_t v = h_d.as<int32_t>()[i];
+      fh[i] = v == 0x7fffffff ? -1 : v;
+      ovf[i] = h_e.as<int32_t>()[i] != 0;
+    }
+  }
   // edges whose candidate list overflowed are re-run sample by sample through the pose kernel
   for (int i = 0; i < n; ++i) {
-    if (fr[i] != 2) continue;
+    if (!ovf[i]) continue;
     const double* a = a6 + 6 * (size_t)i;
     const double* b = b6 + 6 * (size_t)i;
     double parts = sffg::edge_parts(a, b);
-    int cnt = sffg::edge_samples(parts);
+    int cnt = ns[i];
     double dir[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
     std::vector<double> poses((size_t)cnt * 6, 0.0);
     for (int s = 1; s <= cnt; ++s) sffg::edge_sample_pos(a, dir, parts, s, &poses[6 * (size_t)(s - 1)]);
@@ -361,10 +397,9 @@ void Ctx::collide_segments(const double* a6, const double* b6, int n, uint8_t* i
     fh[i] = -1;
     for (int s = 0; s < cnt; ++s)
       if (hits[s]) { fh[i] = s + 1; break; }
-    fr[i] = fh[i] < 0 ? 1 : 0;
   }
   for (int i = 0; i < n; ++i) {
-    is_free[i] = fr[i];
+    is_free[i] = fh[i] < 0 ? 1 : 0;
     if (first_hit) first_hit[i] = fh[i];
     if (n_samples) n_samples[i] = ns[i];
   }

@@ -61,7 +61,7 @@ struct Ctx {
   std::string err;
 
   // collision models
-  DevBuf env_tri, env_box, level_box[SFFK_MAX_LEVELS], rob_tri;
+  DevBuf env_tri, env_box, env_plane, level_box[SFFK_MAX_LEVELS], rob_tri;
   sffk::EnvView envv{};
   sffk::RobotView robv{};
   bool have_env = false, have_robot = false;

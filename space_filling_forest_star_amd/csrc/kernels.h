@@ -46,6 +46,7 @@ struct SampleParams {
 struct EnvView {
   const double* tri;      // n_tri x 9, world frame
   const double* tri_box;  // n_tri x 6 (lo xyz, hi xyz), exact
+  const double* tri_plane; // n_tri x 5: unnormalised normal, offset n.p1, |n|
   int n_tri;
   int n_levels;           // level 0 groups 64 triangles, level k groups 64 boxes of level k-1
   const double* level_box[SFFK_MAX_LEVELS];
@@ -75,7 +76,9 @@ void launch_sweep(hipStream_t s, const NodeStoreView& st, int n_nodes, const Swe
 void launch_collide_poses(hipStream_t s, const EnvView& env, const RobotView& rob, const double* pos6, int n,
                           uint8_t* hit);
 
+// items = (edge index, chunk index) work list; first_hit must be pre-set to INT32_MAX, overflow_flag to 0
 void launch_collide_segments(hipStream_t s, const EnvView& env, const RobotView& rob, const double* a6,
-                             const double* b6, int n, uint8_t* is_free, int32_t* first_hit, int32_t* n_samples);
+                             const double* b6, const int2* items, int n_items, int32_t* first_hit,
+                             int32_t* overflow_flag);
 
 }  // namespace sffk

@@ -10,8 +10,9 @@
 //   k_collide_poses  : Environment::Collide — one wave per pose, wave-cooperative traversal of a
 //                      64-ary box hierarchy (one child box per lane, __ballot compaction), robot
 //                      triangles staged in LDS, exact fp64 triangle contact at the leaves.
-//   k_collide_segments: Solver::isPathFree — one wave per edge; broad phase with the swept robot
-//                      box, then samples in ascending order, 64 per step.
+//   k_collide_segments: Solver::isPathFree — one wave per (edge, 64-sample chunk), lane = sample;
+//                      broad phase with the chunk's swept robot box, plane + box culls per
+//                      (sample, triangle), exact first-hit index via atomicMin.
 //
 // Compiled with -ffp-contract=off: every fp64 value that feeds a decision has the same bits as
 // the host evaluation of sff_geom.h.
@@ -204,6 +205,16 @@ __device__ int collect_candidates(const EnvView& env, const double* qlo, const d
   return n_cand;
 }
 
+// conservative plane test: the robot's bounding sphere (centre c, radius rr) lies strictly on one
+// side of the triangle's plane, by far more than the rounding noise of the exact test's normal
+// axis, so the 17-axis test would separate the pair on that axis anyway
+__device__ __forceinline__ bool plane_clear(const double* pl, const double* c, double rr) {
+  double s = (pl[0] * c[0] + pl[1] * c[1]) + pl[2] * c[2] - pl[3];
+  double as = s < 0 ? -s : s;
+  double slack = 1e-9 * (pl[4] * (fabs(c[0]) + fabs(c[1]) + fabs(c[2]) + 1.0) + fabs(pl[3]));
+  return as > rr * pl[4] * (1.0 + 1e-9) + slack;
+}
+
 // ------------------------------------------------------------------ pose kernel
 #define POSE_WAVES 4
 #define CAND_CAP 256
@@ -256,6 +267,7 @@ __global__ __launch_bounds__(64 * POSE_WAVES) void k_collide_poses(EnvView env, 
       if (!overflow) {
         for (int k = 0; k < nc; ++k) {
           const int t = cand[k];
+          if (plane_clear(env.tri_plane + 5 * (size_t)t, c, rr)) continue;  // wave-uniform
           if (have && !lane_hit) {
             const double* b = env.tri_box + 6 * (size_t)t;
             if (tri_box_overlap(b, b + 3, Q)) lane_hit = sat17(env.tri + 9 * (size_t)t, Q);
@@ -279,12 +291,15 @@ __global__ __launch_bounds__(64 * POSE_WAVES) void k_collide_poses(EnvView env, 
 // ------------------------------------------------------------------ segment kernel
 #define SEG_WAVES 4
 
+// One wavefront per (edge, chunk of 64 consecutive samples): lane = sample.  The chunk's own swept
+// box gives a tight broad phase; the smallest colliding sample index of an edge is reduced with
+// atomicMin, so the answer does not depend on which chunk finishes first.
 __global__ __launch_bounds__(64 * SEG_WAVES) void k_collide_segments(EnvView env, RobotView rob,
                                                                      const double* __restrict__ a6,
-                                                                     const double* __restrict__ b6, int n,
-                                                                     uint8_t* __restrict__ free_out,
+                                                                     const double* __restrict__ b6,
+                                                                     const int2* __restrict__ items, int n_items,
                                                                      int32_t* __restrict__ first_hit,
-                                                                     int32_t* __restrict__ n_samples) {
+                                                                     int32_t* __restrict__ overflow_flag) {
   extern __shared__ double lds_d[];
   double* rtri = lds_d;
   int32_t* ibase = reinterpret_cast<int32_t*>(rtri + (size_t)rob.n_tri * 9);
@@ -294,84 +309,82 @@ __global__ __launch_bounds__(64 * SEG_WAVES) void k_collide_segments(EnvView env
   for (int i = threadIdx.x; i < rob.n_tri * 9; i += blockDim.x) rtri[i] = rob.tri[i];
   __syncthreads();
 
-  const int seg = blockIdx.x * SEG_WAVES + wave;
-  if (seg >= n) return;
+  const int item = blockIdx.x * SEG_WAVES + wave;
+  if (item >= n_items || env.n_tri == 0) return;
+  const int seg = items[item].x, chunk = items[item].y;
   double a[6], b[6];
   for (int k = 0; k < 6; ++k) { a[k] = a6[6 * (size_t)seg + k]; b[k] = b6[6 * (size_t)seg + k]; }
   const double parts = edge_parts(a, b);
   const int ns = edge_samples(parts);
-  if (lane == 0 && n_samples) n_samples[seg] = ns;
-  int fh = -1;
-  if (ns > 0 && env.n_tri > 0) {
-    const double dir[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
-    // swept box of the un-rotated robot: every sample position lies between a and a+dir
-    // (monotone rounding), so [min,max] of the end points plus the robot's identity box bounds
-    // every posed vertex exactly; a hair of slack is added on top.
-    double qlo[3], qhi[3];
-    for (int k = 0; k < 3; ++k) {
-      double e = a[k] + dir[k];
-      double lo = a[k] < e ? a[k] : e, hi = a[k] > e ? a[k] : e;
-      double slack = 1e-9 * (fabs(lo) + fabs(hi) + 1);
-      qlo[k] = lo + rob.lo[k] - slack;
-      qhi[k] = hi + rob.hi[k] + slack;
+  const int s0 = 1 + 64 * chunk;
+  if (s0 > ns) return;
+  const int s1 = s0 + 63 < ns ? s0 + 63 : ns;
+  const double dir[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
+  const int idx = s0 + lane;
+  const bool live = idx <= ns;
+  double P[3] = {0, 0, 0};
+  if (live) edge_sample_pos(a, dir, parts, idx, P);
+  // sample positions are monotone in the index per coordinate (monotone rounding), so the chunk's
+  // first and last sample bound all of them; + the un-rotated robot box bounds every posed vertex
+  double F[3], L[3], qlo[3], qhi[3];
+  edge_sample_pos(a, dir, parts, s0, F);
+  edge_sample_pos(a, dir, parts, s1, L);
+  for (int k = 0; k < 3; ++k) {
+    double lo = F[k] < L[k] ? F[k] : L[k], hi = F[k] > L[k] ? F[k] : L[k];
+    double slack = 1e-9 * (fabs(lo) + fabs(hi) + 1);
+    qlo[k] = lo + rob.lo[k] - slack;
+    qhi[k] = hi + rob.hi[k] + slack;
+  }
+  WaveStack st{stack, 0};
+  bool overflow;
+  int nc = collect_candidates(env, qlo, qhi, lane, st, cand, CAND_CAP, &overflow);
+  if (overflow) {
+    if (lane == 0) atomicOr(overflow_flag + seg, 1);  // host re-runs this edge through the pose kernel
+    return;
+  }
+  if (nc == 0) return;
+  const double C[3] = {P[0] + rob.center[0], P[1] + rob.center[1], P[2] + rob.center[2]};
+  const double rr = rob.radius * (1 + 1e-9) + 1e-9 * (fabs(C[0]) + fabs(C[1]) + fabs(C[2]) + 1);
+  unsigned long long hit_samples = 0;
+  for (int k = 0; k < nc; ++k) {
+    const int t = cand[k];
+    const double* bx = env.tri_box + 6 * (size_t)t;
+    bool touch = false;
+    if (live) {
+      touch = true;
+      for (int ax = 0; ax < 3; ++ax) {
+        // exact bounds of v + P over the robot vertices (monotone rounding of one add)
+        double rlo = rob.lo[ax] + P[ax], rhi = rob.hi[ax] + P[ax];
+        if (bx[ax] > rhi || rlo > bx[3 + ax]) touch = false;
+      }
+      if (touch && plane_clear(env.tri_plane + 5 * (size_t)t, C, rr)) touch = false;
     }
-    WaveStack st{stack, 0};
-    bool overflow;
-    int nc = collect_candidates(env, qlo, qhi, lane, st, cand, CAND_CAP, &overflow);
-    if (overflow) {
-      fh = -2;  // host re-runs this edge sample by sample through the pose kernel
-    } else if (nc > 0) {
-      for (int s0 = 1; s0 <= ns && fh < 0; s0 += 64) {
-        const int idx = s0 + lane;
-        const bool live = idx <= ns;
-        double P[3] = {0, 0, 0};
-        if (live) edge_sample_pos(a, dir, parts, idx, P);
-        // which candidates' boxes does the robot box at this sample touch?
-        // process candidates one at a time; per candidate, ballot the samples that touch it
-        unsigned long long hit_samples = 0;
-        for (int k = 0; k < nc; ++k) {
-          const int t = cand[k];
-          const double* bx = env.tri_box + 6 * (size_t)t;
-          bool touch = false;
-          if (live) {
-            touch = true;
-            for (int ax = 0; ax < 3; ++ax) {
-              // exact bounds of v + P over the robot vertices (monotone rounding of one add)
-              double rlo = rob.lo[ax] + P[ax], rhi = rob.hi[ax] + P[ax];
-              if (bx[ax] > rhi || rlo > bx[3 + ax]) touch = false;
-            }
-          }
-          unsigned long long m = __ballot(touch);
-          // narrow phase: for each touching sample (ascending), all lanes test robot triangles
-          unsigned long long todo = m & ~hit_samples;
-          if (hit_samples) todo &= (hit_samples & (~hit_samples + 1ULL)) - 1ULL;  // only samples before the first hit
-          while (todo) {
-            const int sl = __ffsll((long long)todo) - 1;
-            todo &= todo - 1;
-            double S[3];
-            S[0] = __shfl(P[0], sl); S[1] = __shfl(P[1], sl); S[2] = __shfl(P[2], sl);
-            bool lane_hit = false;
-            for (int r0 = 0; r0 < rob.n_tri; r0 += 64) {
-              const int r = r0 + lane;
-              if (r < rob.n_tri && !lane_hit) {
-                double Q[9];
-                // identity rotation: ((1*v0 + 0*v1) + 0*v2) + T == v0 + T
-                for (int v = 0; v < 3; ++v)
-                  for (int ax = 0; ax < 3; ++ax) Q[3 * v + ax] = rtri[9 * r + 3 * v + ax] + S[ax];
-                if (tri_box_overlap(bx, bx + 3, Q)) lane_hit = sat17(env.tri + 9 * (size_t)t, Q);
-              }
-            }
-            if (__any(lane_hit)) hit_samples |= 1ULL << sl;
-          }
+    unsigned long long todo = __ballot(touch) & ~hit_samples;
+    if (hit_samples) todo &= (hit_samples & (~hit_samples + 1ULL)) - 1ULL;  // only samples before the first hit
+    // narrow phase: for each touching sample (ascending), all lanes test robot triangles
+    while (todo) {
+      const int sl = __ffsll((long long)todo) - 1;
+      todo &= todo - 1;
+      double S[3];
+      S[0] = __shfl(P[0], sl); S[1] = __shfl(P[1], sl); S[2] = __shfl(P[2], sl);
+      bool lane_hit = false;
+      for (int r0 = 0; r0 < rob.n_tri; r0 += 64) {
+        const int r = r0 + lane;
+        if (r < rob.n_tri && !lane_hit) {
+          double Q[9];
+          // identity rotation: ((1*v0 + 0*v1) + 0*v2) + T == v0 + T
+          for (int v = 0; v < 3; ++v)
+            for (int ax = 0; ax < 3; ++ax) Q[3 * v + ax] = rtri[9 * r + 3 * v + ax] + S[ax];
+          if (tri_box_overlap(bx, bx + 3, Q)) lane_hit = sat17(env.tri + 9 * (size_t)t, Q);
         }
-        if (hit_samples) fh = s0 + (__ffsll((long long)hit_samples) - 1);
+      }
+      if (__any(lane_hit)) {
+        hit_samples |= 1ULL << sl;
+        todo &= (1ULL << sl) - 1ULL;
       }
     }
   }
-  if (lane == 0) {
-    if (first_hit) first_hit[seg] = fh;
-    free_out[seg] = fh == -1 ? 1 : (fh == -2 ? 2 : 0);
-  }
+  if (hit_samples && lane == 0) atomicMin(first_hit + seg, s0 + (__ffsll((long long)hit_samples) - 1));
 }
 
 // ------------------------------------------------------------------ node store writes
@@ -444,11 +457,12 @@ void launch_collide_poses(hipStream_t s, const EnvView& env, const RobotView& ro
 }
 
 void launch_collide_segments(hipStream_t s, const EnvView& env, const RobotView& rob, const double* a6,
-                             const double* b6, int n, uint8_t* is_free, int32_t* first_hit, int32_t* n_samples) {
-  if (n <= 0) return;
+                             const double* b6, const int2* items, int n_items, int32_t* first_hit,
+                             int32_t* overflow_flag) {
+  if (n_items <= 0) return;
   size_t lds = collide_lds_bytes(rob.n_tri, SEG_WAVES);
-  hipLaunchKernelGGL(k_collide_segments, dim3((n + SEG_WAVES - 1) / SEG_WAVES), dim3(64 * SEG_WAVES), lds, s, env,
-                     rob, a6, b6, n, is_free, first_hit, n_samples);
+  hipLaunchKernelGGL(k_collide_segments, dim3((n_items + SEG_WAVES - 1) / SEG_WAVES), dim3(64 * SEG_WAVES), lds, s,
+                     env, rob, a6, b6, items, n_items, first_hit, overflow_flag);
 }
 
 }  // namespace sffk
