@@ -97,6 +97,8 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         executed = float(t.item())
 
+    forest.close()
+
     out = None
     if rank == 0:
         sweep_ms = s1["sweep_ms"] - s0["sweep_ms"]

@@ -107,6 +107,7 @@ typedef struct {
   uint64_t sweeps;           /* neighbour-sweep launches */
   uint64_t sweep_nodes;      /* sum over sweeps of nodes streamed */
   uint64_t sweep_queries;    /* sum over sweeps of queries */
+  uint64_t slow_path_samples;/* samples whose device lists overflowed and were redone on the host path */
   double sweep_ms;           /* device time of the sweep kernel (HIP events) */
   double collide_ms;         /* device time of the pose + segment kernels */
   double sample_ms;          /* device time of the sample+steer kernel */

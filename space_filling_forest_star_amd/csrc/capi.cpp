@@ -4,6 +4,7 @@
 
 #include "engine.h"
 
+namespace sff { void forest_profile_dump(); }
 using namespace sff;
 
 struct sffgpu_ctx {
@@ -117,6 +118,7 @@ int sffgpu_forest_create(sffgpu_ctx* ctx, const sffgpu_forest_cfg* cfg, const do
 }
 void sffgpu_forest_destroy(sffgpu_forest* f) {
   if (!f) return;
+  sff::forest_profile_dump();
   delete f->f;
   delete f;
 }

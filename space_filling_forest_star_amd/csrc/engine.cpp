@@ -109,10 +109,11 @@ Ctx::~Ctx() {
   for (auto& t : pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto e : pool) (void)hipEventDestroy(e);
   DevBuf* bufs[] = {&env_tri, &env_box, &env_plane, &rob_tri, &sx, &sy, &sz, &syaw, &spitch, &sroll, &stree, &spos,
-                    &d_a, &d_b, &d_c, &d_d, &d_e, &d_f, &d_g, &d_h};
+                    &d_a, &d_b, &d_c, &d_d, &d_e, &d_f, &d_g, &d_h, &r_in, &r_pos, &r_lim, &r_pd, &r_q, &r_cnt, &r_hidx,
+                    &r_hdist, &r_rec, &r_sega, &r_segb, &r_segi, &r_items, &r_ctrl, &r_pose};
   for (DevBuf* b : bufs) b->release();
   for (auto& b : level_box) b.release();
-  PinBuf* pins[] = {&h_a, &h_b, &h_c, &h_d, &h_e, &h_f, &h_g, &h_h};
+  PinBuf* pins[] = {&h_a, &h_b, &h_c, &h_d, &h_e, &h_f, &h_g, &h_h, &p_in, &p_out};
   for (PinBuf* b : pins) b->release();
   if (stream) (void)hipStreamDestroy(stream);
 }
@@ -331,7 +332,7 @@ void Ctx::collide_poses(const double* pos6, int n, uint8_t* hit) {
   d_b.ensure((size_t)n);
   HIPCHK(hipMemcpyAsync(d_a.p, h_a.p, (size_t)n * 6 * sizeof(double), hipMemcpyHostToDevice, stream));
   time_begin(T_COLLIDE);
-  sffk::launch_collide_poses(stream, envv, robv, d_a.as<double>(), n, d_b.as<uint8_t>());
+  sffk::launch_collide_poses(stream, envv, robv, d_a.as<double>(), n, nullptr, d_b.as<uint8_t>());
   time_end();
   HIPCHK(hipMemcpyAsync(h_b.p, d_b.p, (size_t)n, hipMemcpyDeviceToHost, stream));
   sync();

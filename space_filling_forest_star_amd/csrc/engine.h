@@ -75,6 +75,9 @@ struct Ctx {
   // scratch
   DevBuf d_a, d_b, d_c, d_d, d_e, d_f, d_g, d_h;
   PinBuf h_a, h_b, h_c, h_d, h_e, h_f, h_g, h_h;
+  // round pipeline buffers of the forest engine (kept apart from the batch entry points' scratch)
+  DevBuf r_in, r_pos, r_lim, r_pd, r_q, r_cnt, r_hidx, r_hdist, r_rec, r_sega, r_segb, r_segi, r_items, r_ctrl, r_pose;
+  PinBuf p_in, p_out;
 
   // kernel timing (HIP events on the launch stream)
   struct Timed { hipEvent_t a, b; int kind; };
@@ -117,6 +120,7 @@ struct FNode {
   double pos[6];
   int tree, parent, idx_in_tree;
   bool force_children = false;
+  bool on_frontier = false;
   double d_closest, d_root;
   unsigned iter;
 };
@@ -132,7 +136,6 @@ struct Forest {
   std::vector<FNode> nodes;
   std::vector<std::vector<int>> trees;
   std::vector<int> frontier, closed;
-  std::vector<int> frontier_pos;  // node id -> 1 if on the frontier (for O(1) membership)
   std::map<std::pair<int, int>, std::vector<Border>> borders;
   std::vector<int> connected;
   int num_roots = 0;
@@ -179,6 +182,7 @@ struct Forest {
   bool pending_round = false;
   int iter0 = 0, N0 = 0;
   double knn_r = 0;  // running guess of the k-nearest radius (SFF*)
+  int hit_cap = 64, nb_cap = 15;  // device list capacities (env SFFGPU_TEST_HITCAP / _NBCAP shrink them in tests)
 
   Forest(Ctx* c, const sffgpu_forest_cfg& cf, const double* roots6, int n_roots);
   int add_node(const double* pos, int tree, int parent, double dclosest, double droot, unsigned it);

@@ -11,6 +11,8 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 
@@ -21,6 +23,17 @@ namespace sff {
 
 #define HIPCHK(x) hip_check((x), #x)
 using Clock = std::chrono::steady_clock;
+static double g_sec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+static const bool g_prof = getenv("SFFGPU_PROFILE") != nullptr;
+struct Sec {
+  int k;
+  Clock::time_point t0;
+  explicit Sec(int kk) : k(kk), t0(Clock::now()) {}
+  ~Sec() { g_sec[k] += std::chrono::duration<double, std::milli>(Clock::now() - t0).count(); }
+};
+void forest_profile_dump() {
+  if (g_prof) fprintf(stderr, "[sffgpu host ms] prep %.1f launch %.1f read %.1f records %.1f deser %.1f replay %.1f append %.1f endwave %.1f\n", g_sec[0], g_sec[1], g_sec[2], g_sec[3], g_sec[4], g_sec[5], g_sec[6], g_sec[7]);
+}
 static double ms_since(Clock::time_point t0) {
   return std::chrono::duration<double, std::milli>(Clock::now() - t0).count();
 }
@@ -41,11 +54,14 @@ Forest::Forest(Ctx* c, const sffgpu_forest_cfg& cf, const double* roots6, int n_
   for (int j = 0; j < n_roots; ++j) {          // src/forest.h:60-76
     int id = add_node(roots6 + 6 * (size_t)j, j, -1, 0, 0, 0);
     frontier.push_back(id);
+    nodes[id].on_frontier = true;
     tids[j] = j;
   }
   ctx->store_append(roots6, tids.data(), n_roots);
   memset(&st, 0, sizeof st);
   knn_r = 2.5 * cfg.sampling_dist;
+  if (const char* e = getenv("SFFGPU_TEST_HITCAP")) hit_cap = std::max(1, atoi(e));
+  if (const char* e = getenv("SFFGPU_TEST_NBCAP")) nb_cap = std::max(1, atoi(e));
 }
 
 int Forest::add_node(const double* pos, int tree, int parent, double dclosest, double droot, unsigned it) {
@@ -123,15 +139,22 @@ void Forest::begin_wave() {
 
 // src/forest.h:160-201
 void Forest::end_wave() {
+  // the reference erases each exhausted node from the frontier deque one by one (:160-163); all
+  // removals of a wave are applied in one order-preserving compaction, which leaves the same deque
+  bool removed = false;
   for (Slot& sl : slots) {
-    if (sl.failing && !sl.from_closed) {
-      auto it = std::find(frontier.begin(), frontier.end(), sl.node);
-      if (it != frontier.end()) {
-        frontier.erase(it);
-        nodes[sl.node].force_children = true;
-        closed.push_back(sl.node);
-      }
+    if (sl.failing && !sl.from_closed && nodes[sl.node].on_frontier) {
+      nodes[sl.node].on_frontier = false;
+      nodes[sl.node].force_children = true;
+      closed.push_back(sl.node);
+      removed = true;
     }
+  }
+  if (removed) {
+    size_t w = 0;
+    for (size_t r = 0; r < frontier.size(); ++r)
+      if (nodes[frontier[r]].on_frontier) frontier[w++] = frontier[r];
+    frontier.resize(w);
   }
   empty_frontier = frontier.empty();
   if (!solved) {
@@ -170,6 +193,7 @@ void Forest::round_begin() {
     wait_ms += ms_since(t0);
   };
   // ---- active slots of this round (src/forest.h:155: i < ThresholdMisses && expandResult && iter < max)
+  auto _t0 = Clock::now();
   cands.clear();
   for (int s = 0; s < (int)slots.size(); ++s) {
     if (!slots[s].failing) continue;
@@ -191,31 +215,53 @@ void Forest::round_begin() {
   N0 = (int)nodes.size();
   c.store_reserve(N0 + n + 4);
 
-  // ---- draw the raw engine words in reference order; sample + steer every candidate
+  g_sec[0] += ms_since(_t0);
+  auto _t1 = Clock::now();
+  // ---- one GPU pipeline per round, a single host sync at its end:
+  //   H2D {engine words, expanded ids, ForceChildren flags}
+  //   k_sample_steer -> k_store_write (temporaries) -> k_sweep -> k_classify -> k_collide_poses
+  //   -> k_collide_segments_dyn -> D2H {samples, flags, neighbour records, pose / edge answers}
   const int words_per = cfg.dim == 2 ? 1 : 6;
-  c.h_a.ensure((size_t)n * 6 * sizeof(uint64_t));
-  c.h_b.ensure((size_t)n * sizeof(int32_t));
-  uint64_t* hw = c.h_a.as<uint64_t>();
-  int32_t* hp = c.h_b.as<int32_t>();
-  for (int i = 0; i < n; ++i) {
-    for (int k = 0; k < 6; ++k) hw[6 * (size_t)i + k] = k < words_per ? rng.next() : 0;
-    hp[i] = cands[i].expanded;
+  const int CAP = hit_cap, NBCAP = nb_cap, STRIDE = 1 + NBCAP;
+  const int items_cap = n * 48 + 1024;
+  // packed host input: words (n*6 u64) | parent (n i32) | force (n u8)
+  const size_t in_words = 0, in_parent = (size_t)n * 48, in_force = in_parent + (size_t)n * 4;
+  const size_t in_bytes = ((in_force + (size_t)n + 15) / 16) * 16;
+  c.p_in.ensure(in_bytes);
+  c.r_in.ensure(in_bytes);
+  {
+    uint64_t* hw = reinterpret_cast<uint64_t*>(c.p_in.as<char>() + in_words);
+    int32_t* hp = reinterpret_cast<int32_t*>(c.p_in.as<char>() + in_parent);
+    uint8_t* hf = reinterpret_cast<uint8_t*>(c.p_in.as<char>() + in_force);
+    for (int i = 0; i < n; ++i) {
+      for (int k = 0; k < 6; ++k) hw[6 * (size_t)i + k] = k < words_per ? rng.next() : 0;
+      hp[i] = cands[i].expanded;
+      hf[i] = nodes[cands[i].expanded].force_children ? 1 : 0;
+    }
   }
-  const int CAP = 64;
-  const size_t pb = (size_t)n * 6 * sizeof(double);
-  c.d_a.ensure((size_t)n * 6 * sizeof(uint64_t));
-  c.d_b.ensure((size_t)n * sizeof(int32_t));
-  c.d_c.ensure(pb);                                   // new positions
-  c.d_d.ensure((size_t)n);                            // in-limits
-  c.d_e.ensure((size_t)n * sizeof(double));           // parent distance
-  c.d_f.ensure((size_t)n * sizeof(sffk::SweepQuery)); // sweep queries
-  c.d_g.ensure((size_t)n * sizeof(int32_t) + (size_t)n * CAP * sizeof(int32_t));  // cnt | hit idx
-  c.d_h.ensure((size_t)n * CAP * sizeof(double));     // hit dist
-  int32_t* d_cnt = c.d_g.as<int32_t>();
-  int32_t* d_hidx = d_cnt + n;
-  HIPCHK(hipMemcpyAsync(c.d_a.p, hw, (size_t)n * 6 * sizeof(uint64_t), hipMemcpyHostToDevice, c.stream));
-  HIPCHK(hipMemcpyAsync(c.d_b.p, hp, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, c.stream));
-  HIPCHK(hipMemsetAsync(d_cnt, 0, (size_t)n * sizeof(int32_t), c.stream));
+  const uint64_t* d_words = reinterpret_cast<const uint64_t*>(c.r_in.as<char>() + in_words);
+  const int32_t* d_parent = reinterpret_cast<const int32_t*>(c.r_in.as<char>() + in_parent);
+  const uint8_t* d_force = reinterpret_cast<const uint8_t*>(c.r_in.as<char>() + in_force);
+  c.r_pos.ensure((size_t)n * 48);
+  c.r_lim.ensure((size_t)n);
+  c.r_pd.ensure((size_t)n * 8);
+  c.r_q.ensure((size_t)n * sizeof(sffk::SweepQuery));
+  c.r_cnt.ensure((size_t)n * 4);
+  c.r_hidx.ensure((size_t)n * CAP * 4);
+  c.r_hdist.ensure((size_t)n * CAP * 8);
+  // records: flags (n) | nnb (n) | nb ids (n*NBCAP) | nb meta (n*NBCAP)
+  const size_t rec_ints = (size_t)n * (2 + 2 * NBCAP);
+  c.r_rec.ensure(rec_ints * 4);
+  c.r_sega.ensure((size_t)n * STRIDE * 48);
+  c.r_segb.ensure((size_t)n * STRIDE * 48);
+  // per edge slot: samples | first hit | overflow
+  c.r_segi.ensure((size_t)n * STRIDE * 3 * 4);
+  c.r_items.ensure((size_t)items_cap * sizeof(int2));
+  c.r_ctrl.ensure(16);
+  c.r_pose.ensure((size_t)n);
+  HIPCHK(hipMemcpyAsync(c.r_in.p, c.p_in.p, in_bytes, hipMemcpyHostToDevice, c.stream));
+  HIPCHK(hipMemsetAsync(c.r_cnt.p, 0, (size_t)n * 4, c.stream));
+  HIPCHK(hipMemsetAsync(c.r_ctrl.p, 0, 16, c.stream));
   sffk::SampleParams prm{};
   memcpy(prm.limits, cfg.limits, sizeof prm.limits);
   prm.dist_tree = cfg.dist_tree;
@@ -223,72 +269,163 @@ void Forest::round_begin() {
   prm.rank = cfg.rank;
   prm.world = cfg.world;
   c.time_begin(T_SAMPLE);
-  sffk::launch_sample_steer(c.stream, c.d_a.as<uint64_t>(), c.d_b.as<int32_t>(), c.spos.as<double>(), nullptr, n,
-                            cfg.sampling_dist, cfg.dim, prm, c.d_c.as<double>(), c.d_d.as<uint8_t>(),
-                            c.d_e.as<double>(), c.d_f.as<sffk::SweepQuery>(), N0);
+  sffk::launch_sample_steer(c.stream, d_words, d_parent, c.spos.as<double>(), nullptr, n, cfg.sampling_dist, cfg.dim,
+                            prm, c.r_pos.as<double>(), c.r_lim.as<uint8_t>(), c.r_pd.as<double>(),
+                            c.r_q.as<sffk::SweepQuery>(), N0);
   // the round's samples become temporary store entries [N0, N0+n) so that the same sweep also
   // finds, for every sample, the EARLIER samples of this round (query i sees ids < N0 + i)
   sffk::NodeStoreMut mut{c.sx.as<float>(), c.sy.as<float>(), c.sz.as<float>(), c.syaw.as<float>(),
                          c.spitch.as<float>(), c.sroll.as<float>(), c.stree.as<int32_t>(), c.spos.as<double>()};
-  sffk::launch_store_write(c.stream, mut, c.d_c.as<double>(), nullptr, c.d_b.as<int32_t>(), c.d_d.as<uint8_t>(), n, N0);
+  sffk::launch_store_write(c.stream, mut, c.r_pos.as<double>(), nullptr, d_parent, c.r_lim.as<uint8_t>(), n, N0);
   c.time_end();
   // the sweep only serves the queries of this rank's shard (the others are marked inactive)
   c.time_begin(T_SWEEP);
-  sffk::launch_sweep(c.stream, c.store_view(), N0 + n, c.d_f.as<sffk::SweepQuery>(), c.d_c.as<double>(), n, d_cnt,
-                     d_hidx, c.d_h.as<double>(), CAP);
+  sffk::launch_sweep(c.stream, c.store_view(), N0 + n, c.r_q.as<sffk::SweepQuery>(), c.r_pos.as<double>(), n,
+                     c.r_cnt.as<int32_t>(), c.r_hidx.as<int32_t>(), c.r_hdist.as<double>(), CAP);
   c.time_end();
   st.sweeps += 1;
   st.sweep_nodes += (uint64_t)(N0 + n);
   st.sweep_queries += (uint64_t)((n - cfg.rank + cfg.world - 1) / cfg.world);
-  c.h_c.ensure(pb);
-  c.h_d.ensure((size_t)n);
-  c.h_e.ensure((size_t)n * sizeof(double));
-  c.h_g.ensure((size_t)n * sizeof(int32_t) + (size_t)n * CAP * sizeof(int32_t));
-  c.h_h.ensure((size_t)n * CAP * sizeof(double));
-  HIPCHK(hipMemcpyAsync(c.h_c.p, c.d_c.p, pb, hipMemcpyDeviceToHost, c.stream));
-  HIPCHK(hipMemcpyAsync(c.h_d.p, c.d_d.p, (size_t)n, hipMemcpyDeviceToHost, c.stream));
-  HIPCHK(hipMemcpyAsync(c.h_e.p, c.d_e.p, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, c.stream));
-  HIPCHK(hipMemcpyAsync(c.h_g.p, c.d_g.p, (size_t)n * sizeof(int32_t) + (size_t)n * CAP * sizeof(int32_t),
-                        hipMemcpyDeviceToHost, c.stream));
-  HIPCHK(hipMemcpyAsync(c.h_h.p, c.d_h.p, (size_t)n * CAP * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+  sffk::ClassifyArgs ca{};
+  ca.n = n; ca.N0 = N0; ca.cap = CAP; ca.nbcap = NBCAP; ca.rank = cfg.rank; ca.world = cfg.world;
+  ca.items_cap = items_cap;
+  ca.dist_tree = cfg.dist_tree;
+  ca.newpos = c.r_pos.as<double>();
+  ca.in_lim = c.r_lim.as<uint8_t>();
+  ca.pdist = c.r_pd.as<double>();
+  ca.parent = d_parent;
+  ca.force = d_force;
+  ca.cnt = c.r_cnt.as<int32_t>();
+  ca.hit_idx = c.r_hidx.as<int32_t>();
+  ca.hit_dist = c.r_hdist.as<double>();
+  ca.tree = c.stree.as<int32_t>();
+  ca.pos = c.spos.as<double>();
+  ca.rec_flags = c.r_rec.as<int32_t>();
+  ca.rec_nnb = ca.rec_flags + n;
+  ca.rec_nb = ca.rec_nnb + n;
+  ca.rec_meta = ca.rec_nb + (size_t)n * NBCAP;
+  ca.seg_a = c.r_sega.as<double>();
+  ca.seg_b = c.r_segb.as<double>();
+  ca.seg_ns = c.r_segi.as<int32_t>();
+  ca.first_hit = ca.seg_ns + (size_t)n * STRIDE;
+  ca.seg_ovf = ca.first_hit + (size_t)n * STRIDE;
+  ca.items = c.r_items.as<int2>();
+  ca.ctrl = c.r_ctrl.as<int32_t>();
+  c.time_begin(T_COLLIDE);
+  sffk::launch_classify(c.stream, ca);
+  sffk::launch_collide_poses(c.stream, c.envv, c.robv, c.r_pos.as<double>(), n, ca.rec_flags, c.r_pose.as<uint8_t>());
+  sffk::launch_collide_segments_dyn(c.stream, c.envv, c.robv, ca.seg_a, ca.seg_b, ca.items, ca.ctrl, items_cap,
+                                    ca.first_hit, ca.seg_ovf);
+  c.time_end();
+  // packed host output: pos | pdist | records | edge ints | ctrl | in_lim | pose
+  const size_t o_pos = 0, o_pd = o_pos + (size_t)n * 48, o_rec = o_pd + (size_t)n * 8, o_segi = o_rec + rec_ints * 4,
+               o_ctrl = o_segi + (size_t)n * STRIDE * 12, o_lim = o_ctrl + 16, o_pose = o_lim + (size_t)n,
+               o_bytes = o_pose + (size_t)n;
+  c.p_out.ensure(o_bytes);
+  char* ho = c.p_out.as<char>();
+  HIPCHK(hipMemcpyAsync(ho + o_pos, c.r_pos.p, (size_t)n * 48, hipMemcpyDeviceToHost, c.stream));
+  HIPCHK(hipMemcpyAsync(ho + o_pd, c.r_pd.p, (size_t)n * 8, hipMemcpyDeviceToHost, c.stream));
+  HIPCHK(hipMemcpyAsync(ho + o_rec, c.r_rec.p, rec_ints * 4, hipMemcpyDeviceToHost, c.stream));
+  HIPCHK(hipMemcpyAsync(ho + o_segi, c.r_segi.p, (size_t)n * STRIDE * 12, hipMemcpyDeviceToHost, c.stream));
+  HIPCHK(hipMemcpyAsync(ho + o_ctrl, c.r_ctrl.p, 16, hipMemcpyDeviceToHost, c.stream));
+  HIPCHK(hipMemcpyAsync(ho + o_lim, c.r_lim.p, (size_t)n, hipMemcpyDeviceToHost, c.stream));
+  HIPCHK(hipMemcpyAsync(ho + o_pose, c.r_pose.p, (size_t)n, hipMemcpyDeviceToHost, c.stream));
+  g_sec[1] += ms_since(_t1);
   timed_sync();
 
-  const double* hpos = c.h_c.as<double>();
-  const uint8_t* hlim = c.h_d.as<uint8_t>();
-  const double* hpd = c.h_e.as<double>();
-  const int32_t* hcnt = c.h_g.as<int32_t>();
-  const int32_t* hidx = hcnt + n;
-  const double* hdist = c.h_h.as<double>();
+  const double* hpos = reinterpret_cast<const double*>(ho + o_pos);
+  const double* hpd = reinterpret_cast<const double*>(ho + o_pd);
+  const int32_t* hflags = reinterpret_cast<const int32_t*>(ho + o_rec);
+  const int32_t* hnnb = hflags + n;
+  const int32_t* hnb = hnnb + n;
+  const int32_t* hmeta = hnb + (size_t)n * NBCAP;
+  const int32_t* hns = reinterpret_cast<const int32_t*>(ho + o_segi);
+  const int32_t* hfh = hns + (size_t)n * STRIDE;
+  const int32_t* hovf = hfh + (size_t)n * STRIDE;
+  const int32_t* hctrl = reinterpret_cast<const int32_t*>(ho + o_ctrl);
+  const uint8_t* hlim = reinterpret_cast<const uint8_t*>(ho + o_lim);
+  const uint8_t* hpose = reinterpret_cast<const uint8_t*>(ho + o_pose);
+  if (hctrl[0] > items_cap) throw HipError{"forest: edge work list overflow"};
   auto mine_shard = [&](int i) { return i % cfg.world == cfg.rank; };
 
-  // ---- classify neighbours, build the pose / edge task lists (own shard only)
-  std::vector<double> pose_tasks, seg_a, seg_b;
-  auto add_seg = [&](const double* a, const double* b) {
-    int id = (int)(seg_a.size() / 6);
-    seg_a.insert(seg_a.end(), a, a + 6);
-    seg_b.insert(seg_b.end(), b, b + 6);
-    return id;
-  };
-  std::vector<int> overflow_q;
+  auto _t2 = Clock::now();
+  // ---- read the answers; samples whose lists overflowed (and edges whose candidate lists did)
+  // take the host path below
+  std::vector<int> slow;        // samples to redo entirely on the host path
+  std::vector<double> fix_a, fix_b;
+  struct Fix { int cand; int slot; };
+  std::vector<Fix> fixes;       // single edges to redo (triangle candidate list overflow)
   for (int i = 0; i < n; ++i) {
     Cand& cd = cands[i];
     memcpy(cd.pos, hpos + 6 * (size_t)i, sizeof cd.pos);
     cd.in_lim = hlim[i] != 0;
     cd.pdist = hpd[i];
     if (!cd.in_lim || !mine_shard(i)) continue;
-    if (hcnt[i] > CAP) overflow_q.push_back(i);
+    if (hflags[i] & 2) { slow.push_back(i); continue; }
+    cd.answered = true;
+    cd.pose_hit = hpose[i] != 0;
+    st.poses_executed += 1;
+    const size_t s0 = (size_t)i * STRIDE;
+    auto edge = [&](size_t slot, bool& fr, int& fh, int& ns) {
+      ns = hns[slot];
+      fh = hfh[slot] == 0x7fffffff ? -1 : hfh[slot];
+      fr = fh < 0;
+      st.segments_executed += 1;
+      st.samples_executed += (uint64_t)ns;
+    };
+    edge(s0, cd.par_free, cd.par_fh, cd.par_ns);
+    if (hovf[s0]) fixes.push_back({i, 0});
+    const int nnb = hnnb[i];
+    cd.nbs.resize(nnb);
+    for (int k = 0; k < nnb; ++k) {
+      Nb& nb = cd.nbs[k];
+      const int id = hnb[(size_t)i * NBCAP + k];
+      const int meta = hmeta[(size_t)i * NBCAP + k];
+      nb.id = id < N0 ? id : -1 - (id - N0);
+      nb.tree = meta >> 1;
+      nb.same_tree = meta & 1;
+      nb.seg = -1;
+      edge(s0 + 1 + k, nb.free, nb.fh, nb.ns);
+      if (hovf[s0 + 1 + k]) fixes.push_back({i, 1 + k});
+    }
   }
-  // rare: a hit list overflowed -> redo those queries with a big list through the generic path
-  std::vector<std::vector<std::pair<double, int>>> big(n);
-  if (!overflow_q.empty()) {
+  g_sec[2] += ms_since(_t2);
+  if (!fixes.empty()) {
+    auto t0 = Clock::now();
+    for (const Fix& f : fixes) {
+      const Cand& cd = cands[f.cand];
+      const double* ex = nodes[cd.expanded].pos;
+      if (f.slot == 0) { fix_a.insert(fix_a.end(), ex, ex + 6); fix_b.insert(fix_b.end(), cd.pos, cd.pos + 6); }
+      else {
+        const Nb& nb = cd.nbs[f.slot - 1];
+        const double* npos = nb.id >= 0 ? nodes[nb.id].pos : cands[-1 - nb.id].pos;
+        if (nb.same_tree) { fix_a.insert(fix_a.end(), npos, npos + 6); fix_b.insert(fix_b.end(), cd.pos, cd.pos + 6); }
+        else { fix_a.insert(fix_a.end(), ex, ex + 6); fix_b.insert(fix_b.end(), npos, npos + 6); }
+      }
+    }
+    const int m = (int)fixes.size();
+    std::vector<uint8_t> fr(m);
+    std::vector<int32_t> fh(m), nsv(m);
+    c.collide_segments(fix_a.data(), fix_b.data(), m, fr.data(), fh.data(), nsv.data());
+    for (int k = 0; k < m; ++k) {
+      Cand& cd = cands[fixes[k].cand];
+      if (fixes[k].slot == 0) { cd.par_free = fr[k] != 0; cd.par_fh = fh[k]; cd.par_ns = nsv[k]; }
+      else { Nb& nb = cd.nbs[fixes[k].slot - 1]; nb.free = fr[k] != 0; nb.fh = fh[k]; nb.ns = nsv[k]; }
+    }
+    wait_ms += ms_since(t0);
+  }
+
+  // ---- host path for the (rare) samples whose hit or neighbour lists overflowed on the device:
+  // unbounded lists through the generic radius query, classification and batched checks here
+  if (!slow.empty()) {
+    auto t0 = Clock::now();
     const int BIG = 4096;
-    int m = (int)overflow_q.size();
+    const int m = (int)slow.size();
     std::vector<double> q6((size_t)m * 6), rr(m);
     std::vector<int32_t> mx(m), cn(m), ix((size_t)m * BIG);
     std::vector<double> dd((size_t)m * BIG);
-    std::vector<int32_t> hcnt_copy(hcnt, hcnt + n);
     for (int k = 0; k < m; ++k) {
-      int i = overflow_q[k];
+      int i = slow[k];
       memcpy(&q6[6 * (size_t)k], cands[i].pos, 6 * sizeof(double));
       rr[k] = std::max(cands[i].pdist, cfg.dist_tree);
       mx[k] = N0 + i;
@@ -297,97 +434,84 @@ void Forest::round_begin() {
     c.store_n = N0 + n;  // include the temporaries
     c.radius(q6.data(), m, rr.data(), nullptr, mx.data(), ix.data(), dd.data(), cn.data(), BIG);
     c.store_n = keep;
+    std::vector<double> pose_tasks, seg_a, seg_b;
+    auto add_seg = [&](const double* a, const double* b) {
+      int id = (int)(seg_a.size() / 6);
+      seg_a.insert(seg_a.end(), a, a + 6);
+      seg_b.insert(seg_b.end(), b, b + 6);
+      return id;
+    };
     for (int k = 0; k < m; ++k) {
       if (cn[k] > BIG) throw HipError{"forest: neighbour list overflow (> 4096 hits)"};
-      for (int j = 0; j < cn[k]; ++j) big[overflow_q[k]].push_back({dd[(size_t)k * BIG + j], ix[(size_t)k * BIG + j]});
-    }
-  }
-  std::vector<char> overflowed(n, 0);
-  for (int i : overflow_q) overflowed[i] = 1;
-  for (int i = 0; i < n; ++i) {
-    Cand& cd = cands[i];
-    if (!cd.in_lim || !mine_shard(i)) continue;
-    const FNode& ex = nodes[cd.expanded];
-    cd.pose_task = (int)(pose_tasks.size() / 6);
-    pose_tasks.insert(pose_tasks.end(), cd.pos, cd.pos + 6);
-    cd.seg_parent = add_seg(ex.pos, cd.pos);
-    const int mine = ex.tree;
-    std::vector<Nb> all;
-    auto consider = [&](double d, int id) {
-      Nb nb;
-      nb.d = d;
-      if (id < N0) {
-        nb.id = id;
-        nb.tree = nodes[id].tree;
-        nb.order = nodes[id].idx_in_tree;
-      } else {
-        int cc = id - N0;
-        if (!cands[cc].in_lim) return;
-        nb.id = -1 - cc;
-        nb.tree = nodes[cands[cc].expanded].tree;
-        nb.order = 0x40000000 + cc;
+      Cand& cd = cands[slow[k]];
+      const FNode& ex = nodes[cd.expanded];
+      cd.pose_task = (int)(pose_tasks.size() / 6);
+      pose_tasks.insert(pose_tasks.end(), cd.pos, cd.pos + 6);
+      cd.seg_parent = add_seg(ex.pos, cd.pos);
+      const int mine = ex.tree;
+      std::vector<Nb> all;
+      for (int j = 0; j < cn[k]; ++j) {
+        const double d = dd[(size_t)k * BIG + j];
+        const int id = ix[(size_t)k * BIG + j];
+        Nb nb;
+        nb.d = d;
+        if (id < N0) {
+          nb.id = id;
+          nb.tree = nodes[id].tree;
+          nb.order = nodes[id].idx_in_tree;
+        } else {
+          int cc = id - N0;
+          if (!cands[cc].in_lim) continue;
+          nb.id = -1 - cc;
+          nb.tree = nodes[cands[cc].expanded].tree;
+          nb.order = 0x40000000 + cc;
+        }
+        nb.same_tree = nb.tree == mine;
+        nb.seg = -1;
+        if (nb.same_tree) {
+          if (ex.force_children || !(d < cd.pdist - SFFG_TOL)) continue;   // src/forest.h:276
+        } else {
+          if (!(d < cfg.dist_tree - SFFG_TOL)) continue;                    // src/forest.h:283
+        }
+        all.push_back(nb);
       }
-      nb.same_tree = nb.tree == mine;
-      nb.seg = -1;
-      if (nb.same_tree) {
-        if (ex.force_children || !(d < cd.pdist - SFFG_TOL)) return;   // src/forest.h:276
-      } else {
-        if (!(d < cfg.dist_tree - SFFG_TOL)) return;                    // src/forest.h:283
+      std::sort(all.begin(), all.end(), [](const Nb& a, const Nb& b) {
+        if (a.tree != b.tree) return a.tree < b.tree;
+        if (a.d != b.d) return a.d < b.d;
+        return a.order < b.order;
+      });
+      // everything after the first STORE neighbour of another tree is unreachable (:296-299)
+      for (Nb& nb : all) {
+        const double* npos = nb.id >= 0 ? nodes[nb.id].pos : cands[-1 - nb.id].pos;
+        if (nb.same_tree) nb.seg = add_seg(npos, cd.pos);     // isPathFree(neighbour, newPoint)  :276
+        else nb.seg = add_seg(ex.pos, npos);                  // isPathFree(expanded, neighbour)  :288
+        cd.nbs.push_back(nb);
+        if (!nb.same_tree && nb.id >= 0) break;
       }
-      all.push_back(nb);
-    };
-    if (overflowed[i]) {
-      for (auto& h : big[i]) consider(h.first, h.second);
-    } else {
-      const int32_t* hc = c.h_g.as<int32_t>();  // (buffers may have been re-allocated by the overflow path)
-      const int32_t* hi = hc + n;
-      const double* hd = c.h_h.as<double>();
-      for (int k = 0; k < hc[i]; ++k) consider(hd[(size_t)i * CAP + k], hi[(size_t)i * CAP + k]);
     }
-    std::sort(all.begin(), all.end(), [](const Nb& a, const Nb& b) {
-      if (a.tree != b.tree) return a.tree < b.tree;
-      if (a.d != b.d) return a.d < b.d;
-      return a.order < b.order;
-    });
-    // everything after the first STORE neighbour of another tree is unreachable (:296-299)
-    for (Nb& nb : all) {
-      const double* npos = nb.id >= 0 ? nodes[nb.id].pos : cands[-1 - nb.id].pos;
-      if (nb.same_tree) nb.seg = add_seg(npos, cd.pos);     // isPathFree(neighbour, newPoint)  :276
-      else nb.seg = add_seg(ex.pos, npos);                  // isPathFree(expanded, neighbour)  :288
-      cd.nbs.push_back(nb);
-      if (!nb.same_tree && nb.id >= 0) break;
-    }
-  }
-  (void)hidx; (void)hdist;
-
-  // ---- collision launches
-  const int n_pose = (int)(pose_tasks.size() / 6), n_seg = (int)(seg_a.size() / 6);
-  std::vector<uint8_t> pose_hit(n_pose), seg_free(n_seg);
-  std::vector<int32_t> seg_fh(n_seg), seg_ns(n_seg);
-  if (n_pose) {
-    auto t0 = Clock::now();
+    const int n_pose = (int)(pose_tasks.size() / 6), n_seg = (int)(seg_a.size() / 6);
+    std::vector<uint8_t> pose_hit(n_pose), seg_free(n_seg);
+    std::vector<int32_t> seg_fh(n_seg), seg_ns(n_seg);
     c.collide_poses(pose_tasks.data(), n_pose, pose_hit.data());
     c.collide_segments(seg_a.data(), seg_b.data(), n_seg, seg_free.data(), seg_fh.data(), seg_ns.data());
-    wait_ms += ms_since(t0);
-  }
-  st.poses_executed += n_pose;
-  st.segments_executed += n_seg;
-  for (int k = 0; k < n_seg; ++k) st.samples_executed += (uint64_t)seg_ns[k];
-
-  // ---- answers of the owned candidates -> Cand fields
-  for (int i = 0; i < n; ++i) {
-    Cand& cd = cands[i];
-    if (!cd.in_lim || !mine_shard(i)) continue;
-    cd.answered = true;
-    cd.pose_hit = pose_hit[cd.pose_task] != 0;
-    cd.par_free = seg_free[cd.seg_parent] != 0;
-    cd.par_fh = seg_fh[cd.seg_parent];
-    cd.par_ns = seg_ns[cd.seg_parent];
-    for (Nb& nb : cd.nbs) {
-      nb.free = seg_free[nb.seg] != 0;
-      nb.fh = seg_fh[nb.seg];
-      nb.ns = seg_ns[nb.seg];
+    st.poses_executed += n_pose;
+    st.segments_executed += n_seg;
+    for (int k = 0; k < n_seg; ++k) st.samples_executed += (uint64_t)seg_ns[k];
+    for (int k = 0; k < m; ++k) {
+      Cand& cd = cands[slow[k]];
+      cd.answered = true;
+      cd.pose_hit = pose_hit[cd.pose_task] != 0;
+      cd.par_free = seg_free[cd.seg_parent] != 0;
+      cd.par_fh = seg_fh[cd.seg_parent];
+      cd.par_ns = seg_ns[cd.seg_parent];
+      for (Nb& nb : cd.nbs) {
+        nb.free = seg_free[nb.seg] != 0;
+        nb.fh = seg_fh[nb.seg];
+        nb.ns = seg_ns[nb.seg];
+      }
     }
+    st.slow_path_samples += (uint64_t)m;
+    wait_ms += ms_since(t0);
   }
 
   // ---- SFF* (src/forest.h:307-351): candidates that no STORE neighbour rejects may be accepted;
@@ -506,6 +630,7 @@ void Forest::round_begin() {
     }
   }
 
+  auto _t3 = Clock::now();
   // ---- the int32 record stream of the owned candidates
   for (int i = 0; i < n; ++i) {
     Cand& cd = cands[i];
@@ -532,6 +657,7 @@ void Forest::round_begin() {
       records.push_back(mb.bwd_ns);
     }
   }
+  g_sec[3] += ms_since(_t3);
   st.host_ms += ms_since(t_host) - wait_ms;
 }
 
@@ -544,6 +670,7 @@ void Forest::round_commit(const int32_t* all, const int32_t* counts, int world) 
   auto t_host = Clock::now();
   double wait_ms = 0;
   const int n = (int)cands.size();
+  auto _t4 = Clock::now();
   // ---- absorb the other ranks' answers
   size_t off = 0;
   for (int r = 0; r < world; ++r) {
@@ -587,6 +714,8 @@ void Forest::round_commit(const int32_t* all, const int32_t* counts, int world) 
       p += 6 + 5 * (size_t)nn + 6 * (size_t)nm;
     }
   }
+  g_sec[4] += ms_since(_t4);
+  auto _t5 = Clock::now();
   // ---- replay expandNode in slot order (src/forest.h:240-376)
   auto calls = [](int fh, int ns) -> uint64_t {  // Collide calls isPathFree makes (early exit at the first hit)
     return fh > 0 ? (uint64_t)fh : (uint64_t)ns;
@@ -679,10 +808,13 @@ void Forest::round_commit(const int32_t* all, const int32_t* counts, int world) 
     }
     cd.accepted_id = id;
     frontier.push_back(id);                                    // :365
+    nodes[id].on_frontier = true;
     sl.failing = false;
     app_pos.insert(app_pos.end(), cd.pos, cd.pos + 6);
     app_tree.push_back(mine);
   }
+  g_sec[5] += ms_since(_t5);
+  auto _t6 = Clock::now();
   // ---- commit the accepted nodes to the device store (replaces flannIndex->addPoints, :367)
   if (n > 0) c.store_n = N0;
   if (!app_tree.empty()) {
@@ -691,10 +823,13 @@ void Forest::round_commit(const int32_t* all, const int32_t* counts, int world) 
     wait_ms += ms_since(t0);
   }
   pending_round = false;
+  g_sec[6] += ms_since(_t6);
+  auto _t7 = Clock::now();
   // ---- wave bookkeeping (src/forest.h:155: at most ThresholdMisses attempts per slot)
   bool any_failing = false;
   for (const Slot& s : slots) any_failing |= s.failing;
   if (round >= cfg.threshold_misses || !any_failing || solved || iter >= cfg.max_iterations) end_wave();
+  g_sec[7] += ms_since(_t7);
   st.host_ms += ms_since(t_host) - wait_ms;
 }
 

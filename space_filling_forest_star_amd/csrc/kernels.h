@@ -74,7 +74,38 @@ void launch_sweep(hipStream_t s, const NodeStoreView& st, int n_nodes, const Swe
                   int nq, int32_t* cnt, int32_t* hit_idx, double* hit_dist, int cap);
 
 void launch_collide_poses(hipStream_t s, const EnvView& env, const RobotView& rob, const double* pos6, int n,
-                          uint8_t* hit);
+                          const int32_t* live_flags, uint8_t* hit);
+
+// arguments of k_classify (one thread per sample of the round)
+struct ClassifyArgs {
+  int n, N0, cap, nbcap, rank, world, items_cap;
+  double dist_tree;
+  const double* newpos;     // n x 6
+  const uint8_t* in_lim;    // n
+  const double* pdist;      // n
+  const int32_t* parent;    // n (store id of the expanded node)
+  const uint8_t* force;     // n (Node::ForceChildren of the expanded node)
+  const int32_t* cnt;       // n sweep hit totals
+  int32_t* hit_idx;         // n x cap (reordered in place)
+  double* hit_dist;         // n x cap
+  const int32_t* tree;      // store column (incl. the round's temporaries)
+  const double* pos;        // store positions (incl. temporaries)
+  int32_t* rec_flags;       // n: bit0 = evaluated here, bit1 = list overflow -> host path
+  int32_t* rec_nnb;         // n
+  int32_t* rec_nb;          // n x nbcap neighbour ids
+  int32_t* rec_meta;        // n x nbcap: tree << 1 | same_tree
+  double* seg_a;            // n x (1+nbcap) x 6 edge tasks (slot 0 = parent edge)
+  double* seg_b;
+  int32_t* seg_ns;          // n x (1+nbcap): samples of the edge, -1 = no task
+  int32_t* first_hit;       // n x (1+nbcap): preset to INT32_MAX
+  int32_t* seg_ovf;         // n x (1+nbcap)
+  int2* items;              // work list (slot, chunk)
+  int32_t* ctrl;            // [0] item count, [1] next item
+};
+void launch_classify(hipStream_t s, const ClassifyArgs& a);
+void launch_collide_segments_dyn(hipStream_t s, const EnvView& env, const RobotView& rob, const double* a6,
+                                 const double* b6, const int2* items, int32_t* ctrl, int items_cap,
+                                 int32_t* first_hit, int32_t* overflow_flag);
 
 // items = (edge index, chunk index) work list; first_hit must be pre-set to INT32_MAX, overflow_flag to 0
 void launch_collide_segments(hipStream_t s, const EnvView& env, const RobotView& rob, const double* a6,

@@ -221,6 +221,7 @@ __device__ __forceinline__ bool plane_clear(const double* pl, const double* c, d
 
 __global__ __launch_bounds__(64 * POSE_WAVES) void k_collide_poses(EnvView env, RobotView rob,
                                                                    const double* __restrict__ pos6, int n,
+                                                                   const int32_t* __restrict__ live_flags,
                                                                    uint8_t* __restrict__ hit_out) {
   extern __shared__ double lds_d[];
   // layout: robot triangles (n_tri*9 doubles) | per-wave stacks | per-wave candidate lists
@@ -234,6 +235,10 @@ __global__ __launch_bounds__(64 * POSE_WAVES) void k_collide_poses(EnvView env, 
 
   const int pose = blockIdx.x * POSE_WAVES + wave;
   if (pose >= n) return;
+  if (live_flags && (live_flags[pose] & 3) != 1) {  // not owned / out of limits / host path
+    if (lane == 0) hit_out[pose] = 0;
+    return;
+  }
   if (env.n_tri == 0) {  // HasMap == false (src/environment.h:307-309)
     if (lane == 0) hit_out[pose] = 0;
     return;
@@ -294,24 +299,9 @@ __global__ __launch_bounds__(64 * POSE_WAVES) void k_collide_poses(EnvView env, 
 // One wavefront per (edge, chunk of 64 consecutive samples): lane = sample.  The chunk's own swept
 // box gives a tight broad phase; the smallest colliding sample index of an edge is reduced with
 // atomicMin, so the answer does not depend on which chunk finishes first.
-__global__ __launch_bounds__(64 * SEG_WAVES) void k_collide_segments(EnvView env, RobotView rob,
-                                                                     const double* __restrict__ a6,
-                                                                     const double* __restrict__ b6,
-                                                                     const int2* __restrict__ items, int n_items,
-                                                                     int32_t* __restrict__ first_hit,
-                                                                     int32_t* __restrict__ overflow_flag) {
-  extern __shared__ double lds_d[];
-  double* rtri = lds_d;
-  int32_t* ibase = reinterpret_cast<int32_t*>(rtri + (size_t)rob.n_tri * 9);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  int32_t* stack = ibase + wave * STACK_CAP;
-  int32_t* cand = ibase + SEG_WAVES * STACK_CAP + wave * CAND_CAP;
-  for (int i = threadIdx.x; i < rob.n_tri * 9; i += blockDim.x) rtri[i] = rob.tri[i];
-  __syncthreads();
-
-  const int item = blockIdx.x * SEG_WAVES + wave;
-  if (item >= n_items || env.n_tri == 0) return;
-  const int seg = items[item].x, chunk = items[item].y;
+__device__ void segment_chunk(const EnvView& env, const RobotView& rob, const double* rtri, int32_t* stack,
+                              int32_t* cand, const double* __restrict__ a6, const double* __restrict__ b6, int seg,
+                              int chunk, int32_t* __restrict__ first_hit, int32_t* __restrict__ overflow_flag, int lane) {
   double a[6], b[6];
   for (int k = 0; k < 6; ++k) { a[k] = a6[6 * (size_t)seg + k]; b[k] = b6[6 * (size_t)seg + k]; }
   const double parts = edge_parts(a, b);
@@ -387,6 +377,156 @@ __global__ __launch_bounds__(64 * SEG_WAVES) void k_collide_segments(EnvView env
   if (hit_samples && lane == 0) atomicMin(first_hit + seg, s0 + (__ffsll((long long)hit_samples) - 1));
 }
 
+// static work list (C-ABI batch entry point)
+__global__ __launch_bounds__(64 * SEG_WAVES) void k_collide_segments(EnvView env, RobotView rob,
+                                                                     const double* __restrict__ a6,
+                                                                     const double* __restrict__ b6,
+                                                                     const int2* __restrict__ items, int n_items,
+                                                                     int32_t* __restrict__ first_hit,
+                                                                     int32_t* __restrict__ overflow_flag) {
+  extern __shared__ double lds_d[];
+  double* rtri = lds_d;
+  int32_t* ibase = reinterpret_cast<int32_t*>(rtri + (size_t)rob.n_tri * 9);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int i = threadIdx.x; i < rob.n_tri * 9; i += blockDim.x) rtri[i] = rob.tri[i];
+  __syncthreads();
+  const int item = blockIdx.x * SEG_WAVES + wave;
+  if (item >= n_items || env.n_tri == 0) return;
+  segment_chunk(env, rob, rtri, ibase + wave * STACK_CAP, ibase + SEG_WAVES * STACK_CAP + wave * CAND_CAP, a6, b6,
+                items[item].x, items[item].y, first_hit, overflow_flag, lane);
+}
+
+// device-built work list (ctrl[0] = number of items, ctrl[1] = next item): persistent wavefronts
+// pull items until the list is drained, which also evens out the very uneven cost per edge
+__global__ __launch_bounds__(64 * SEG_WAVES) void k_collide_segments_dyn(EnvView env, RobotView rob,
+                                                                         const double* __restrict__ a6,
+                                                                         const double* __restrict__ b6,
+                                                                         const int2* __restrict__ items,
+                                                                         int32_t* __restrict__ ctrl, int items_cap,
+                                                                         int32_t* __restrict__ first_hit,
+                                                                         int32_t* __restrict__ overflow_flag) {
+  extern __shared__ double lds_d[];
+  double* rtri = lds_d;
+  int32_t* ibase = reinterpret_cast<int32_t*>(rtri + (size_t)rob.n_tri * 9);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (int i = threadIdx.x; i < rob.n_tri * 9; i += blockDim.x) rtri[i] = rob.tri[i];
+  __syncthreads();
+  if (env.n_tri == 0) return;
+  int n_items = ctrl[0];
+  if (n_items > items_cap) n_items = items_cap;
+  while (true) {
+    int item = 0;
+    if (lane == 0) item = atomicAdd(ctrl + 1, 1);
+    item = __shfl(item, 0);
+    if (item >= n_items) break;
+    segment_chunk(env, rob, rtri, ibase + wave * STACK_CAP, ibase + SEG_WAVES * STACK_CAP + wave * CAND_CAP, a6, b6,
+                  items[item].x, items[item].y, first_hit, overflow_flag, lane);
+  }
+}
+
+// ------------------------------------------------------------------ neighbour classification
+// One thread per sample of the round.  Replays, for its sample, the part of the reference's
+// neighbour loop (src/forest.h:262-300) that decides WHICH edges have to be checked: filters the
+// sweep hits by the two distance conditions (:276, :283), orders them as the reference visits
+// them (tree id, then distance, then index), cuts the list after the first store neighbour of
+// another tree (the loop returns there, :296-299) and writes the edge tasks + their work items.
+__global__ __launch_bounds__(256) void k_classify(ClassifyArgs A) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= A.n) return;
+  const int stride = 1 + A.nbcap;
+  int flags = 0, nnb = 0;
+  for (int k = 0; k < stride; ++k) {
+    A.seg_ns[(size_t)i * stride + k] = -1;
+    A.first_hit[(size_t)i * stride + k] = 0x7fffffff;
+    A.seg_ovf[(size_t)i * stride + k] = 0;
+  }
+  const bool mine_shard = A.world <= 1 || i % A.world == A.rank;
+  if (A.in_lim[i] && mine_shard) {
+    flags |= 1;
+    const int cnt = A.cnt[i];
+    if (cnt > A.cap) {
+      flags |= 2;
+    } else {
+      const int ex = A.parent[i];
+      const int mine = A.tree[ex];
+      const bool force = A.force[i] != 0;
+      const double pdist = A.pdist[i];
+      int32_t* hid = A.hit_idx + (size_t)i * A.cap;
+      double* hd = A.hit_dist + (size_t)i * A.cap;
+      int m = 0;
+      for (int k = 0; k < cnt; ++k) {
+        const int id = hid[k];
+        const double d = hd[k];
+        const bool same = A.tree[id] == mine;
+        if (same) {
+          if (force || !(d < pdist - SFFG_TOL)) continue;       // src/forest.h:276
+        } else {
+          if (!(d < A.dist_tree - SFFG_TOL)) continue;          // src/forest.h:283
+        }
+        hid[m] = id;
+        hd[m] = d;
+        ++m;
+      }
+      for (int a = 1; a < m; ++a) {                             // insertion sort by (tree, dist, id)
+        const int id = hid[a];
+        const double d = hd[a];
+        const int t = A.tree[id];
+        int b = a - 1;
+        while (b >= 0) {
+          const int tb = A.tree[hid[b]];
+          const bool greater = tb > t || (tb == t && (hd[b] > d || (hd[b] == d && hid[b] > id)));
+          if (!greater) break;
+          hid[b + 1] = hid[b];
+          hd[b + 1] = hd[b];
+          --b;
+        }
+        hid[b + 1] = id;
+        hd[b + 1] = d;
+      }
+      const double* exp = A.pos + 6 * (size_t)ex;
+      const double* np = A.newpos + 6 * (size_t)i;
+      // slot 0: isPathFree(expanded, newPoint)  (src/forest.h:246)
+      {
+        double* sa = A.seg_a + 6 * ((size_t)i * stride);
+        double* sb = A.seg_b + 6 * ((size_t)i * stride);
+        for (int k = 0; k < 6; ++k) { sa[k] = exp[k]; sb[k] = np[k]; }
+      }
+      for (int k = 0; k < m; ++k) {
+        if (nnb == A.nbcap) { flags |= 2; break; }
+        const int id = hid[k];
+        const int t = A.tree[id];
+        const bool same = t == mine;
+        A.rec_nb[(size_t)i * A.nbcap + nnb] = id;
+        A.rec_meta[(size_t)i * A.nbcap + nnb] = (t << 1) | (same ? 1 : 0);
+        const double* nbp = A.pos + 6 * (size_t)id;
+        double* sa = A.seg_a + 6 * ((size_t)i * stride + 1 + nnb);
+        double* sb = A.seg_b + 6 * ((size_t)i * stride + 1 + nnb);
+        if (same) { for (int q = 0; q < 6; ++q) { sa[q] = nbp[q]; sb[q] = np[q]; } }     // isPathFree(neighbour, newPoint) :276
+        else      { for (int q = 0; q < 6; ++q) { sa[q] = exp[q]; sb[q] = nbp[q]; } }    // isPathFree(expanded, neighbour) :288
+        ++nnb;
+        if (!same && id < A.N0) break;
+      }
+      if (flags & 2) {
+        nnb = 0;  // the host path redoes this sample with unbounded lists
+      } else {
+        for (int k = 0; k < 1 + nnb; ++k) {
+          const size_t slot = (size_t)i * stride + k;
+          const int ns = edge_samples(edge_parts(A.seg_a + 6 * slot, A.seg_b + 6 * slot));
+          A.seg_ns[slot] = ns;
+          const int chunks = (ns + 63) >> 6;
+          if (chunks > 0) {
+            const int base = atomicAdd(A.ctrl, chunks);
+            for (int c = 0; c < chunks; ++c)
+              if (base + c < A.items_cap) A.items[base + c] = make_int2((int)slot, c);
+          }
+        }
+      }
+    }
+  }
+  A.rec_flags[i] = flags;
+  A.rec_nnb[i] = nnb;
+}
+
 // ------------------------------------------------------------------ node store writes
 // Writes n positions into the SoA store at [base, base+n): the same double->float cast the
 // reference applies when it fills FLANN matrices (src/forest.h:258-260).  Inactive entries are
@@ -449,11 +589,25 @@ void launch_sweep(hipStream_t s, const NodeStoreView& st, int n_nodes, const Swe
 }
 
 void launch_collide_poses(hipStream_t s, const EnvView& env, const RobotView& rob, const double* pos6, int n,
-                          uint8_t* hit) {
+                          const int32_t* live_flags, uint8_t* hit) {
   if (n <= 0) return;
   size_t lds = collide_lds_bytes(rob.n_tri, POSE_WAVES);
   hipLaunchKernelGGL(k_collide_poses, dim3((n + POSE_WAVES - 1) / POSE_WAVES), dim3(64 * POSE_WAVES), lds, s, env,
-                     rob, pos6, n, hit);
+                     rob, pos6, n, live_flags, hit);
+}
+
+void launch_classify(hipStream_t s, const ClassifyArgs& a) {
+  if (a.n <= 0) return;
+  hipLaunchKernelGGL(k_classify, dim3((a.n + 255) / 256), dim3(256), 0, s, a);
+}
+
+void launch_collide_segments_dyn(hipStream_t s, const EnvView& env, const RobotView& rob, const double* a6,
+                                 const double* b6, const int2* items, int32_t* ctrl, int items_cap,
+                                 int32_t* first_hit, int32_t* overflow_flag) {
+  size_t lds = collide_lds_bytes(rob.n_tri, SEG_WAVES);
+  // 8 workgroups per CU keep every SIMD busy (3 waves/SIMD fit the kernel's register budget)
+  hipLaunchKernelGGL(k_collide_segments_dyn, dim3(2048), dim3(64 * SEG_WAVES), lds, s, env, rob, a6, b6, items, ctrl,
+                     items_cap, first_hit, overflow_flag);
 }
 
 void launch_collide_segments(hipStream_t s, const EnvView& env, const RobotView& rob, const double* a6,

@@ -210,6 +210,18 @@ def test_forest_node_budget_and_seeds(S, ctx):
         assert_same_forest(fo, fg)
 
 
+def test_device_list_overflow_takes_host_path(S, ctx, monkeypatch):
+    """Shrink the device-side hit / neighbour lists so that they overflow constantly: the host
+    path (generic radius query + host classification) must give the same forest."""
+    monkeypatch.setenv("SFFGPU_TEST_HITCAP", "3")
+    monkeypatch.setenv("SFFGPU_TEST_NBCAP", "1")
+    fo, fg = run_pair(S, ctx, "dense3d_coarse", 64, 5000, seed=7)
+    assert_same_forest(fo, fg)
+    assert fg.stats()["slow_path_samples"] > 20
+    fo, fg = run_pair(S, ctx, "dense3d", 128, 4000, seed=7, optimize=True)
+    assert_same_forest(fo, fg)
+
+
 def test_forest_errors(S, ctx):
     sc, w = load_world(ctx, "dense3d")
     roots = common.free_roots(w.collide, sc["limits"], 3)
