@@ -110,7 +110,7 @@ Ctx::~Ctx() {
   for (auto e : pool) (void)hipEventDestroy(e);
   DevBuf* bufs[] = {&env_tri, &env_box, &env_plane, &rob_tri, &sx, &sy, &sz, &syaw, &spitch, &sroll, &stree, &spos,
                     &d_a, &d_b, &d_c, &d_d, &d_e, &d_f, &d_g, &d_h, &r_in, &r_pos, &r_lim, &r_pd, &r_q, &r_cnt, &r_hidx,
-                    &r_hdist, &r_rec, &r_sega, &r_segb, &r_segi, &r_items, &r_ctrl, &r_pose};
+                    &r_hdist, &r_rec, &r_sega, &r_segb, &r_segi, &r_items, &r_ctrl, &r_pose, &g_cnt, &g_items, &g_ovfcnt, &g_ovf};
   for (DevBuf* b : bufs) b->release();
   for (auto& b : level_box) b.release();
   PinBuf* pins[] = {&h_a, &h_b, &h_c, &h_d, &h_e, &h_f, &h_g, &h_h, &p_in, &p_out};
@@ -294,6 +294,8 @@ void Ctx::store_reserve(int capacity) {
 }
 void Ctx::store_reset(int capacity) {
   store_n = 0;
+  grid_on = false;
+  grid_inserted = 0;
   store_maxabs = 1.0;
   store_reserve(std::max(capacity, 1024));
 }
@@ -314,6 +316,53 @@ void Ctx::store_append(const double* pos6, const int32_t* tree, int n) {
   sffk::launch_store_write(stream, store_mut(*this), d_a.as<double>(), d_b.as<int32_t>(), nullptr, nullptr, n, store_n);
   sync();
   store_n += n;
+}
+
+// ------------------------------------------------------------------ grid
+void Ctx::grid_setup(const double limits[6], double cell) {
+  HIPCHK(hipSetDevice(device));
+  double ext[3] = {limits[1] - limits[0], limits[3] - limits[2], limits[5] - limits[4]};
+  for (int tries = 0; tries < 64; ++tries) {
+    double cells = 1;
+    for (int a = 0; a < 3; ++a) cells *= std::floor(ext[a] / cell) + 1;
+    if (cells <= 16777216.0) break;
+    cell *= 1.26;
+  }
+  gridv = sffk::GridView{};
+  gridv.ox = (float)limits[0];
+  gridv.oy = (float)limits[2];
+  gridv.oz = (float)limits[4];
+  gridv.inv_cell = (float)(1.0 / cell);
+  gridv.nx = (int)std::floor(ext[0] / cell) + 1;
+  gridv.ny = (int)std::floor(ext[1] / cell) + 1;
+  gridv.nz = (int)std::floor(ext[2] / cell) + 1;
+  gridv.bk = 8;
+  const size_t ncells = (size_t)gridv.nx * gridv.ny * gridv.nz;
+  gridv.ovf_cap = 65536;
+  g_cnt.ensure(ncells * sizeof(int32_t));
+  g_items.ensure(ncells * gridv.bk * sizeof(sffk::GridItem));
+  g_ovfcnt.ensure(16);
+  g_ovf.ensure((size_t)gridv.ovf_cap * sizeof(sffk::GridItem));
+  HIPCHK(hipMemsetAsync(g_cnt.p, 0, ncells * sizeof(int32_t), stream));
+  HIPCHK(hipMemsetAsync(g_ovfcnt.p, 0, 16, stream));
+  gridv.cnt = g_cnt.as<int32_t>();
+  gridv.items = g_items.as<sffk::GridItem>();
+  gridv.ovf_cnt = g_ovfcnt.as<int32_t>();
+  gridv.ovf = g_ovf.as<sffk::GridItem>();
+  grid_on = true;
+  grid_inserted = 0;
+}
+void Ctx::grid_insert_new() {
+  if (!grid_on || grid_inserted >= store_n) return;
+  sffk::launch_grid_insert(stream, gridv, store_view(), grid_inserted, store_n - grid_inserted);
+  grid_inserted = store_n;
+}
+void Ctx::grid_check() {
+  if (!grid_on) return;
+  int32_t v = 0;
+  HIPCHK(hipMemcpyAsync(&v, g_ovfcnt.p, 4, hipMemcpyDeviceToHost, stream));
+  HIPCHK(hipStreamSynchronize(stream));
+  if (v > gridv.ovf_cap) throw HipError{"grid overflow list exhausted"};
 }
 
 // slack that makes the fp32 sweep filter a superset of the exact fp64 test: a few fp32 ulps of
@@ -465,7 +514,7 @@ void Ctx::sweep_lists(const double* q6, int nq, const std::vector<double>& r, co
   HIPCHK(hipMemcpyAsync(c.d_b.p, c.h_b.p, (size_t)nq * 6 * sizeof(double), hipMemcpyHostToDevice, c.stream));
   HIPCHK(hipMemsetAsync(c.d_c.p, 0, (size_t)nq * sizeof(int32_t), c.stream));
   c.time_begin(T_SWEEP);
-  sffk::launch_sweep(c.stream, c.store_view(), n_store, c.d_a.as<sffk::SweepQuery>(), c.d_b.as<double>(), nq,
+  sffk::launch_sweep(c.stream, c.store_view(), 0, n_store, c.d_a.as<sffk::SweepQuery>(), c.d_b.as<double>(), nq,
                      c.d_c.as<int32_t>(), c.d_d.as<int32_t>(), c.d_e.as<double>(), cap);
   c.time_end();
   c.h_c.ensure((size_t)nq * sizeof(int32_t));

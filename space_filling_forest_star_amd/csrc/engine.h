@@ -72,6 +72,15 @@ struct Ctx {
   DevBuf sx, sy, sz, syaw, spitch, sroll, stree, spos;
   double store_maxabs = 1.0;
 
+  // uniform grid over the store (forest engine only)
+  bool grid_on = false;
+  sffk::GridView gridv{};
+  DevBuf g_cnt, g_items, g_ovfcnt, g_ovf;
+  int grid_inserted = 0;
+  void grid_setup(const double limits[6], double cell);
+  void grid_insert_new();   // store entries [grid_inserted, store_n)
+  void grid_check();        // throws if the shared overflow list ran over
+
   // scratch
   DevBuf d_a, d_b, d_c, d_d, d_e, d_f, d_g, d_h;
   PinBuf h_a, h_b, h_c, h_d, h_e, h_f, h_g, h_h;
@@ -180,7 +189,7 @@ struct Forest {
   std::vector<Cand> cands;
   std::vector<int32_t> records;  // this rank's answers of the pending round (int32 stream)
   bool pending_round = false;
-  int iter0 = 0, N0 = 0;
+  int iter0 = 0, N0 = 0, Tb = 0;  // Tb: 4-aligned base of the round's temporary store entries
   double knn_r = 0;  // running guess of the k-nearest radius (SFF*)
   int hit_cap = 64, nb_cap = 15;  // device list capacities (env SFFGPU_TEST_HITCAP / _NBCAP shrink them in tests)
 

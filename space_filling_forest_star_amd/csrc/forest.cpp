@@ -57,7 +57,13 @@ Forest::Forest(Ctx* c, const sffgpu_forest_cfg& cf, const double* roots6, int n_
     nodes[id].on_frontier = true;
     tids[j] = j;
   }
+  {
+    // cell edge >= the planner's neighbour radius max(parentDistance ~ SamplingDistance, treeDistance)
+    double cell = 1.01 * std::max(cfg.sampling_dist, cfg.dist_tree) + 4 * ctx->sweep_eps();
+    ctx->grid_setup(cfg.limits, cell);
+  }
   ctx->store_append(roots6, tids.data(), n_roots);
+  ctx->grid_insert_new();
   memset(&st, 0, sizeof st);
   knn_r = 2.5 * cfg.sampling_dist;
   if (const char* e = getenv("SFFGPU_TEST_HITCAP")) hit_cap = std::max(1, atoi(e));
@@ -156,6 +162,7 @@ void Forest::end_wave() {
       if (nodes[frontier[r]].on_frontier) frontier[w++] = frontier[r];
     frontier.resize(w);
   }
+  ctx->grid_check();
   empty_frontier = frontier.empty();
   if (!solved) {
     bool conn = max_connected() == num_roots;
@@ -213,7 +220,8 @@ void Forest::round_begin() {
   iter0 = iter;
   iter += n;
   N0 = (int)nodes.size();
-  c.store_reserve(N0 + n + 4);
+  Tb = (N0 + 3) & ~3;
+  c.store_reserve(Tb + n + 4);
 
   g_sec[0] += ms_since(_t0);
   auto _t1 = Clock::now();
@@ -271,23 +279,27 @@ void Forest::round_begin() {
   c.time_begin(T_SAMPLE);
   sffk::launch_sample_steer(c.stream, d_words, d_parent, c.spos.as<double>(), nullptr, n, cfg.sampling_dist, cfg.dim,
                             prm, c.r_pos.as<double>(), c.r_lim.as<uint8_t>(), c.r_pd.as<double>(),
-                            c.r_q.as<sffk::SweepQuery>(), N0);
+                            c.r_q.as<sffk::SweepQuery>(), Tb);
   // the round's samples become temporary store entries [N0, N0+n) so that the same sweep also
   // finds, for every sample, the EARLIER samples of this round (query i sees ids < N0 + i)
   sffk::NodeStoreMut mut{c.sx.as<float>(), c.sy.as<float>(), c.sz.as<float>(), c.syaw.as<float>(),
                          c.spitch.as<float>(), c.sroll.as<float>(), c.stree.as<int32_t>(), c.spos.as<double>()};
-  sffk::launch_store_write(c.stream, mut, c.r_pos.as<double>(), nullptr, d_parent, c.r_lim.as<uint8_t>(), n, N0);
+  sffk::launch_store_nan(c.stream, mut, N0, Tb - N0);
+  sffk::launch_store_write(c.stream, mut, c.r_pos.as<double>(), nullptr, d_parent, c.r_lim.as<uint8_t>(), n, Tb);
   c.time_end();
   // the sweep only serves the queries of this rank's shard (the others are marked inactive)
   c.time_begin(T_SWEEP);
-  sffk::launch_sweep(c.stream, c.store_view(), N0 + n, c.r_q.as<sffk::SweepQuery>(), c.r_pos.as<double>(), n,
+  // permanent nodes through the grid (27 cells per query), this round's temporaries by a linear slice sweep
+  sffk::launch_grid_query(c.stream, c.gridv, c.store_view(), c.r_q.as<sffk::SweepQuery>(), c.r_pos.as<double>(), n,
+                          c.r_cnt.as<int32_t>(), c.r_hidx.as<int32_t>(), c.r_hdist.as<double>(), CAP);
+  sffk::launch_sweep(c.stream, c.store_view(), Tb, n, c.r_q.as<sffk::SweepQuery>(), c.r_pos.as<double>(), n,
                      c.r_cnt.as<int32_t>(), c.r_hidx.as<int32_t>(), c.r_hdist.as<double>(), CAP);
   c.time_end();
   st.sweeps += 1;
   st.sweep_nodes += (uint64_t)(N0 + n);
   st.sweep_queries += (uint64_t)((n - cfg.rank + cfg.world - 1) / cfg.world);
   sffk::ClassifyArgs ca{};
-  ca.n = n; ca.N0 = N0; ca.cap = CAP; ca.nbcap = NBCAP; ca.rank = cfg.rank; ca.world = cfg.world;
+  ca.n = n; ca.N0 = Tb; ca.cap = CAP; ca.nbcap = NBCAP; ca.rank = cfg.rank; ca.world = cfg.world;
   ca.items_cap = items_cap;
   ca.dist_tree = cfg.dist_tree;
   ca.newpos = c.r_pos.as<double>();
@@ -381,7 +393,7 @@ void Forest::round_begin() {
       Nb& nb = cd.nbs[k];
       const int id = hnb[(size_t)i * NBCAP + k];
       const int meta = hmeta[(size_t)i * NBCAP + k];
-      nb.id = id < N0 ? id : -1 - (id - N0);
+      nb.id = id < Tb ? id : -1 - (id - Tb);
       nb.tree = meta >> 1;
       nb.same_tree = meta & 1;
       nb.seg = -1;
@@ -428,10 +440,10 @@ void Forest::round_begin() {
       int i = slow[k];
       memcpy(&q6[6 * (size_t)k], cands[i].pos, 6 * sizeof(double));
       rr[k] = std::max(cands[i].pdist, cfg.dist_tree);
-      mx[k] = N0 + i;
+      mx[k] = Tb + i;
     }
     int keep = c.store_n;
-    c.store_n = N0 + n;  // include the temporaries
+    c.store_n = Tb + n;  // include the temporaries
     c.radius(q6.data(), m, rr.data(), nullptr, mx.data(), ix.data(), dd.data(), cn.data(), BIG);
     c.store_n = keep;
     std::vector<double> pose_tasks, seg_a, seg_b;
@@ -460,7 +472,7 @@ void Forest::round_begin() {
           nb.tree = nodes[id].tree;
           nb.order = nodes[id].idx_in_tree;
         } else {
-          int cc = id - N0;
+          int cc = id - Tb;
           if (!cands[cc].in_lim) continue;
           nb.id = -1 - cc;
           nb.tree = nodes[cands[cc].expanded].tree;
@@ -541,7 +553,7 @@ void Forest::round_begin() {
         const Cand& cd = cands[maybe[k]];
         memcpy(&q6[6 * (size_t)k], cd.pos, 6 * sizeof(double));
         qtree[k] = nodes[cd.expanded].tree;
-        qmax[k] = N0 + maybe[k];
+        qmax[k] = Tb + maybe[k];
         // k = 2e log10(#nodes) (:309) can only grow with the nodes accepted earlier in this round
         kmax[k] = (int32_t)(size_t)(2 * M_E * std::log10((double)(N0 + maybe[k])));
         if (kmax[k] <= 0) active[k] = 0;
@@ -553,7 +565,7 @@ void Forest::round_begin() {
         if (!any) break;
         std::vector<int32_t> cnt;
         std::vector<std::vector<HitRec>> out;
-        c.sweep_lists(q6.data(), m, r, qtree.data(), qmax.data(), active, KCAP, N0 + n, cnt, out);
+        c.sweep_lists(q6.data(), m, r, qtree.data(), qmax.data(), active, KCAP, Tb + n, cnt, out);
         st.sweeps += 1;
         st.sweep_nodes += (uint64_t)(N0 + n);
         for (int k = 0; k < m; ++k) {
@@ -592,7 +604,7 @@ void Forest::round_begin() {
             mb.id = h.id;
           } else {
             if (!(h.d <= dk)) continue;
-            mb.id = -1 - (h.id - N0);
+            mb.id = -1 - (h.id - Tb);
           }
           cd.members.push_back(mb);
         }
@@ -820,6 +832,7 @@ void Forest::round_commit(const int32_t* all, const int32_t* counts, int world) 
   if (!app_tree.empty()) {
     auto t0 = Clock::now();
     c.store_append(app_pos.data(), app_tree.data(), (int)app_tree.size());
+    c.grid_insert_new();
     wait_ms += ms_since(t0);
   }
   pending_round = false;

@@ -34,6 +34,23 @@ struct SweepQuery {   // 56 bytes, read through the scalar cache
   int32_t pad, pad2;
 };
 
+// Uniform grid over xyz (cell edge >= the neighbour radius of the planner): every cell owns a bucket
+// of `bk` items; the rare extra items of an over-full cell go to one shared overflow list.
+struct GridItem {   // 32 bytes
+  float x, y, z, yaw, pitch, roll;
+  int32_t id;
+  int32_t tree;
+};
+struct GridView {
+  float ox, oy, oz, inv_cell;
+  int nx, ny, nz, bk;
+  int32_t* cnt;       // per cell: items ever inserted (may exceed bk)
+  GridItem* items;    // ncells x bk
+  int32_t* ovf_cnt;   // [0] entries in the overflow list
+  GridItem* ovf;
+  int ovf_cap;
+};
+
 struct SampleParams {
   double limits[6];
   double dist_tree;
@@ -70,8 +87,14 @@ void launch_sample_steer(hipStream_t s, const uint64_t* words, const int32_t* pa
 void launch_store_write(hipStream_t s, const NodeStoreMut& st, const double* pos6, const int32_t* tree,
                         const int32_t* parent, const uint8_t* active, int n, int base);
 
-void launch_sweep(hipStream_t s, const NodeStoreView& st, int n_nodes, const SweepQuery* queries, const double* qpos,
-                  int nq, int32_t* cnt, int32_t* hit_idx, double* hit_dist, int cap);
+// linear sweep over store entries [first, first + n_nodes) (first must be a multiple of 4)
+void launch_sweep(hipStream_t s, const NodeStoreView& st, int first, int n_nodes, const SweepQuery* queries,
+                  const double* qpos, int nq, int32_t* cnt, int32_t* hit_idx, double* hit_dist, int cap);
+// grid: insert store entries [first, first+n) / answer the queries from the cells their ball touches
+void launch_grid_insert(hipStream_t s, const GridView& g, const NodeStoreView& st, int first, int n);
+void launch_grid_query(hipStream_t s, const GridView& g, const NodeStoreView& st, const SweepQuery* queries,
+                       const double* qpos, int nq, int32_t* cnt, int32_t* hit_idx, double* hit_dist, int cap);
+void launch_store_nan(hipStream_t s, const NodeStoreMut& st, int first, int n);
 
 void launch_collide_poses(hipStream_t s, const EnvView& env, const RobotView& rob, const double* pos6, int n,
                           const int32_t* live_flags, uint8_t* hit);

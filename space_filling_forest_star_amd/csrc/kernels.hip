@@ -18,6 +18,7 @@
 // the host evaluation of sff_geom.h.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "kernels.h"
 #include "sff_geom.h"
 
@@ -74,7 +75,8 @@ __device__ __forceinline__ float wrapf(float d) {
 
 // One thread owns 4 consecutive nodes (float4 per column = 16 B/lane, fully coalesced) and loops
 // over the wave-uniform query list; a query's parameters are fetched with scalar loads.
-__global__ __launch_bounds__(256) void k_sweep(NodeStoreView st, int n_nodes, const SweepQuery* __restrict__ queries,
+__global__ __launch_bounds__(256) void k_sweep(NodeStoreView st, int first, int n_nodes,
+                                               const SweepQuery* __restrict__ queries,
                                                const double* __restrict__ qpos,  // nq x 6 exact query positions
                                                int nq, int q_per_block, int32_t* __restrict__ cnt,
                                                int32_t* __restrict__ hit_idx, double* __restrict__ hit_dist, int cap) {
@@ -83,13 +85,14 @@ __global__ __launch_bounds__(256) void k_sweep(NodeStoreView st, int n_nodes, co
   const int q_begin = blockIdx.y * q_per_block;
   const int q_end = q_begin + q_per_block < nq ? q_begin + q_per_block : nq;
   for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n4; t += gridDim.x * blockDim.x) {
-    const int base = t << 2;
-    float4 X = reinterpret_cast<const float4*>(st.x)[t];
-    float4 Y = reinterpret_cast<const float4*>(st.y)[t];
-    float4 Z = reinterpret_cast<const float4*>(st.z)[t];
-    float4 A = reinterpret_cast<const float4*>(st.yaw)[t];
-    float4 B = reinterpret_cast<const float4*>(st.pitch)[t];
-    float4 C = reinterpret_cast<const float4*>(st.roll)[t];
+    const int base = first + (t << 2);
+    const int t4 = (first >> 2) + t;
+    float4 X = reinterpret_cast<const float4*>(st.x)[t4];
+    float4 Y = reinterpret_cast<const float4*>(st.y)[t4];
+    float4 Z = reinterpret_cast<const float4*>(st.z)[t4];
+    float4 A = reinterpret_cast<const float4*>(st.yaw)[t4];
+    float4 B = reinterpret_cast<const float4*>(st.pitch)[t4];
+    float4 C = reinterpret_cast<const float4*>(st.roll)[t4];
     const float xs[4] = {X.x, X.y, X.z, X.w}, ys[4] = {Y.x, Y.y, Y.z, Y.w}, zs[4] = {Z.x, Z.y, Z.z, Z.w};
     const float as[4] = {A.x, A.y, A.z, A.w}, bs[4] = {B.x, B.y, B.z, B.w}, cs[4] = {C.x, C.y, C.z, C.w};
     for (int q = q_begin; q < q_end; ++q) {
@@ -107,7 +110,7 @@ __global__ __launch_bounds__(256) void k_sweep(NodeStoreView st, int n_nodes, co
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int id = base + j;
-        if (d3[j] > Q.r2f || id >= n_nodes || id >= Q.max_id) continue;
+        if (d3[j] > Q.r2f || id >= first + n_nodes || id >= Q.max_id) continue;
         float da = wrapf(as[j] - Q.yaw), db = wrapf(bs[j] - Q.pitch), dc = wrapf(cs[j] - Q.roll);
         float d6 = fmaf(dc, dc, fmaf(db, db, fmaf(da, da, d3[j])));
         if (d6 > Q.r2f) continue;
@@ -126,6 +129,100 @@ __global__ __launch_bounds__(256) void k_sweep(NodeStoreView st, int n_nodes, co
       }
     }
   }
+}
+
+// ------------------------------------------------------------------ grid neighbour query
+__device__ __forceinline__ int grid_coord(float v, float o, float inv, int n) {
+  float f = floorf((v - o) * inv);
+  int c = f < 0.0f ? 0 : (f > (float)(n - 1) ? n - 1 : (int)f);  // NaN compares false twice -> cast of NaN; guarded by callers
+  return c;
+}
+
+__global__ __launch_bounds__(256) void k_grid_insert(GridView g, NodeStoreView st, int first, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int id = first + i;
+  GridItem it;
+  it.x = st.x[id]; it.y = st.y[id]; it.z = st.z[id];
+  it.yaw = st.yaw[id]; it.pitch = st.pitch[id]; it.roll = st.roll[id];
+  it.id = id;
+  it.tree = st.tree[id];
+  if (!(it.x == it.x)) return;  // NaN placeholder
+  const int cx = grid_coord(it.x, g.ox, g.inv_cell, g.nx), cy = grid_coord(it.y, g.oy, g.inv_cell, g.ny),
+            cz = grid_coord(it.z, g.oz, g.inv_cell, g.nz);
+  const size_t cell = ((size_t)cz * g.ny + cy) * g.nx + cx;
+  const int slot = atomicAdd(g.cnt + cell, 1);
+  if (slot < g.bk) {
+    g.items[cell * g.bk + slot] = it;
+  } else {
+    const int o = atomicAdd(g.ovf_cnt, 1);
+    if (o < g.ovf_cap) g.ovf[o] = it;   // the host checks ovf_cnt against ovf_cap
+  }
+}
+
+__device__ __forceinline__ void grid_test(const GridItem& it, const SweepQuery& Q, int q, const NodeStoreView& st,
+                                          const double* __restrict__ qpos, int32_t* __restrict__ cnt,
+                                          int32_t* __restrict__ hit_idx, double* __restrict__ hit_dist, int cap) {
+  if (it.id >= Q.max_id) return;
+  if (Q.tree >= 0 && it.tree != Q.tree) return;
+  float dx = it.x - Q.x, dy = it.y - Q.y, dz = it.z - Q.z;
+  float d3 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+  if (d3 > Q.r2f) return;
+  float da = wrapf(it.yaw - Q.yaw), db = wrapf(it.pitch - Q.pitch), dc = wrapf(it.roll - Q.roll);
+  float d6 = fmaf(dc, dc, fmaf(db, db, fmaf(da, da, d3)));
+  if (d6 > Q.r2f) return;
+  double np[6], qp[6];
+  for (int k = 0; k < 6; ++k) { np[k] = st.pos[6 * (size_t)it.id + k]; qp[k] = qpos[6 * (size_t)q + k]; }
+  double d = dist6(np, qp);
+  if (d < Q.r) {
+    int slot = atomicAdd(&cnt[q], 1);
+    if (slot < cap) {
+      hit_idx[(size_t)q * cap + slot] = it.id;
+      hit_dist[(size_t)q * cap + slot] = d;
+    }
+  }
+}
+
+// One wavefront per query: the cells touched by the query ball's bounding box are dealt to the
+// lanes (27 cells for the planner's radius), each lane walks its cell's bucket; all lanes then
+// share the overflow list.  Same fp32 superset filter + exact fp64 re-test as the linear sweep.
+__global__ __launch_bounds__(256) void k_grid_query(GridView g, NodeStoreView st, const SweepQuery* __restrict__ queries,
+                                                    const double* __restrict__ qpos, int nq, int32_t* __restrict__ cnt,
+                                                    int32_t* __restrict__ hit_idx, double* __restrict__ hit_dist,
+                                                    int cap) {
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (q >= nq) return;
+  const SweepQuery Q = queries[q];
+  if (!Q.active) return;
+  const float rf = sqrtf(Q.r2f) * 1.000001f;
+  const int lx = grid_coord(Q.x - rf, g.ox, g.inv_cell, g.nx), hx = grid_coord(Q.x + rf, g.ox, g.inv_cell, g.nx);
+  const int ly = grid_coord(Q.y - rf, g.oy, g.inv_cell, g.ny), hy = grid_coord(Q.y + rf, g.oy, g.inv_cell, g.ny);
+  const int lz = grid_coord(Q.z - rf, g.oz, g.inv_cell, g.nz), hz = grid_coord(Q.z + rf, g.oz, g.inv_cell, g.nz);
+  const int wx = hx - lx + 1, wy = hy - ly + 1, wz = hz - lz + 1;
+  const int total = wx * wy * wz;
+  for (int c0 = 0; c0 < total; c0 += 64) {
+    const int c = c0 + lane;
+    if (c < total) {
+      const int cx = lx + c % wx, cy = ly + (c / wx) % wy, cz = lz + c / (wx * wy);
+      const size_t cell = ((size_t)cz * g.ny + cy) * g.nx + cx;
+      int m = g.cnt[cell];
+      if (m > g.bk) m = g.bk;
+      const GridItem* items = g.items + cell * g.bk;
+      for (int j = 0; j < m; ++j) grid_test(items[j], Q, q, st, qpos, cnt, hit_idx, hit_dist, cap);
+    }
+  }
+  int no = g.ovf_cnt[0];
+  if (no > g.ovf_cap) no = g.ovf_cap;
+  for (int j = lane; j < no; j += 64) grid_test(g.ovf[j], Q, q, st, qpos, cnt, hit_idx, hit_dist, cap);
+}
+
+__global__ __launch_bounds__(64) void k_store_nan(NodeStoreMut st, int first, int n) {
+  const int i = threadIdx.x;
+  if (i >= n) return;
+  const float nanv = __int_as_float(0x7fc00000);
+  const size_t o = (size_t)first + i;
+  st.x[o] = nanv; st.y[o] = nanv; st.z[o] = nanv; st.yaw[o] = nanv; st.pitch[o] = nanv; st.roll[o] = nanv;
 }
 
 // ------------------------------------------------------------------ collision: shared pieces
@@ -570,8 +667,8 @@ void launch_store_write(hipStream_t s, const NodeStoreMut& st, const double* pos
   hipLaunchKernelGGL(k_store_write, dim3((n + 255) / 256), dim3(256), 0, s, st, pos6, tree, parent, active, n, base);
 }
 
-void launch_sweep(hipStream_t s, const NodeStoreView& st, int n_nodes, const SweepQuery* queries, const double* qpos,
-                  int nq, int32_t* cnt, int32_t* hit_idx, double* hit_dist, int cap) {
+void launch_sweep(hipStream_t s, const NodeStoreView& st, int first, int n_nodes, const SweepQuery* queries,
+                  const double* qpos, int nq, int32_t* cnt, int32_t* hit_idx, double* hit_dist, int cap) {
   if (n_nodes <= 0 || nq <= 0) return;
   int n4 = (n_nodes + 3) / 4;
   int blocks = (n4 + 255) / 256;
@@ -584,8 +681,23 @@ void launch_sweep(hipStream_t s, const NodeStoreView& st, int n_nodes, const Swe
   if (qsplit < 1) qsplit = 1;
   int q_per_block = (nq + qsplit - 1) / qsplit;
   qsplit = (nq + q_per_block - 1) / q_per_block;
-  hipLaunchKernelGGL(k_sweep, dim3(blocks, qsplit), dim3(256), 0, s, st, n_nodes, queries, qpos, nq, q_per_block, cnt,
+  hipLaunchKernelGGL(k_sweep, dim3(blocks, qsplit), dim3(256), 0, s, st, first, n_nodes, queries, qpos, nq, q_per_block, cnt,
                      hit_idx, hit_dist, cap);
+}
+
+void launch_grid_insert(hipStream_t s, const GridView& g, const NodeStoreView& st, int first, int n) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_grid_insert, dim3((n + 255) / 256), dim3(256), 0, s, g, st, first, n);
+}
+void launch_grid_query(hipStream_t s, const GridView& g, const NodeStoreView& st, const SweepQuery* queries,
+                       const double* qpos, int nq, int32_t* cnt, int32_t* hit_idx, double* hit_dist, int cap) {
+  if (nq <= 0) return;
+  hipLaunchKernelGGL(k_grid_query, dim3((nq + 3) / 4), dim3(256), 0, s, g, st, queries, qpos, nq, cnt, hit_idx,
+                     hit_dist, cap);
+}
+void launch_store_nan(hipStream_t s, const NodeStoreMut& st, int first, int n) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_store_nan, dim3(1), dim3(64), 0, s, st, first, n);
 }
 
 void launch_collide_poses(hipStream_t s, const EnvView& env, const RobotView& rob, const double* pos6, int n,
@@ -606,7 +718,8 @@ void launch_collide_segments_dyn(hipStream_t s, const EnvView& env, const RobotV
                                  int32_t* first_hit, int32_t* overflow_flag) {
   size_t lds = collide_lds_bytes(rob.n_tri, SEG_WAVES);
   // 8 workgroups per CU keep every SIMD busy (3 waves/SIMD fit the kernel's register budget)
-  hipLaunchKernelGGL(k_collide_segments_dyn, dim3(2048), dim3(64 * SEG_WAVES), lds, s, env, rob, a6, b6, items, ctrl,
+  static const int blocks = getenv("SFFGPU_SEG_BLOCKS") ? atoi(getenv("SFFGPU_SEG_BLOCKS")) : 2048;
+  hipLaunchKernelGGL(k_collide_segments_dyn, dim3(blocks), dim3(64 * SEG_WAVES), lds, s, env, rob, a6, b6, items, ctrl,
                      items_cap, first_hit, overflow_flag);
 }
 
