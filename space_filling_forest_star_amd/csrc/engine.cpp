@@ -109,8 +109,8 @@ Ctx::~Ctx() {
   for (auto& t : pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto e : pool) (void)hipEventDestroy(e);
   DevBuf* bufs[] = {&env_tri, &env_box, &env_plane, &rob_tri, &sx, &sy, &sz, &syaw, &spitch, &sroll, &stree, &spos,
-                    &d_a, &d_b, &d_c, &d_d, &d_e, &d_f, &d_g, &d_h, &r_in, &r_pos, &r_lim, &r_pd, &r_q, &r_cnt, &r_hidx,
-                    &r_hdist, &r_rec, &r_sega, &r_segb, &r_segi, &r_items, &r_ctrl, &r_pose, &g_cnt, &g_items, &g_ovfcnt, &g_ovf};
+                    &d_a, &d_b, &d_c, &d_d, &d_e, &d_f, &d_g, &d_h, &r_in, &r_out, &r_q, &r_cnt, &r_hidx,
+                    &r_hdist, &r_sega, &r_segb, &r_items, &g_cnt, &g_items, &g_ovfcnt, &g_ovf};
   for (DevBuf* b : bufs) b->release();
   for (auto& b : level_box) b.release();
   PinBuf* pins[] = {&h_a, &h_b, &h_c, &h_d, &h_e, &h_f, &h_g, &h_h, &p_in, &p_out};

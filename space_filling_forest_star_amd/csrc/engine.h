@@ -85,7 +85,7 @@ struct Ctx {
   DevBuf d_a, d_b, d_c, d_d, d_e, d_f, d_g, d_h;
   PinBuf h_a, h_b, h_c, h_d, h_e, h_f, h_g, h_h;
   // round pipeline buffers of the forest engine (kept apart from the batch entry points' scratch)
-  DevBuf r_in, r_pos, r_lim, r_pd, r_q, r_cnt, r_hidx, r_hdist, r_rec, r_sega, r_segb, r_segi, r_items, r_ctrl, r_pose;
+  DevBuf r_in, r_out, r_q, r_cnt, r_hidx, r_hdist, r_sega, r_segb, r_items;
   PinBuf p_in, p_out;
 
   // kernel timing (HIP events on the launch stream)
@@ -185,8 +185,13 @@ struct Forest {
     std::vector<Nb> nbs;
     std::vector<Member> members;  // SFF*: candidates for the k-nearest set (src/forest.h:317)
     int accepted_id = -1;
+    void reset(int s, int e) {   // reuse across rounds: keeps the vectors' capacity
+      slot = s; expanded = e; in_lim = false; pdist = 0; pose_task = seg_parent = -1;
+      answered = pose_hit = par_free = false; par_fh = -1; par_ns = 0; nbs.clear(); members.clear(); accepted_id = -1;
+    }
   };
-  std::vector<Cand> cands;
+  std::vector<Cand> cands;   // storage (only grows); the current round uses the first n_cands
+  int n_cands = 0;
   std::vector<int32_t> records;  // this rank's answers of the pending round (int32 stream)
   bool pending_round = false;
   int iter0 = 0, N0 = 0, Tb = 0;  // Tb: 4-aligned base of the round's temporary store entries

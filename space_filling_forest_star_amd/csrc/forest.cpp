@@ -201,16 +201,14 @@ void Forest::round_begin() {
   };
   // ---- active slots of this round (src/forest.h:155: i < ThresholdMisses && expandResult && iter < max)
   auto _t0 = Clock::now();
-  cands.clear();
+  if (cands.size() < slots.size()) cands.resize(slots.size());
+  n_cands = 0;
   for (int s = 0; s < (int)slots.size(); ++s) {
     if (!slots[s].failing) continue;
-    if (iter + (int)cands.size() >= cfg.max_iterations) break;
-    Cand cd;
-    cd.slot = s;
-    cd.expanded = slots[s].node;
-    cands.push_back(cd);
+    if (iter + n_cands >= cfg.max_iterations) break;
+    cands[n_cands++].reset(s, slots[s].node);
   }
-  const int n = (int)cands.size();
+  const int n = n_cands;
   ++round;
   pending_round = true;
   records.clear();
@@ -250,26 +248,31 @@ void Forest::round_begin() {
   const uint64_t* d_words = reinterpret_cast<const uint64_t*>(c.r_in.as<char>() + in_words);
   const int32_t* d_parent = reinterpret_cast<const int32_t*>(c.r_in.as<char>() + in_parent);
   const uint8_t* d_force = reinterpret_cast<const uint8_t*>(c.r_in.as<char>() + in_force);
-  c.r_pos.ensure((size_t)n * 48);
-  c.r_lim.ensure((size_t)n);
-  c.r_pd.ensure((size_t)n * 8);
+  // device output block, one D2H copy: pos | pdist | records | edge ints | ctrl | in_lim | pose
+  // records: flags (n) | nnb (n) | nb ids (n*NBCAP) | nb meta (n*NBCAP); edge ints: samples | first hit | overflow
+  const size_t rec_ints = (size_t)n * (2 + 2 * NBCAP);
+  const size_t o_pos = 0, o_pd = o_pos + (size_t)n * 48, o_rec = o_pd + (size_t)n * 8, o_segi = o_rec + rec_ints * 4,
+               o_ctrl = o_segi + (size_t)n * STRIDE * 12, o_lim = o_ctrl + 16, o_pose = o_lim + (size_t)n,
+               o_bytes = o_pose + (size_t)n;
+  c.r_out.ensure(o_bytes);
+  char* dout = c.r_out.as<char>();
+  double* d_pos = reinterpret_cast<double*>(dout + o_pos);
+  double* d_pd = reinterpret_cast<double*>(dout + o_pd);
+  int32_t* d_rec = reinterpret_cast<int32_t*>(dout + o_rec);
+  int32_t* d_segi = reinterpret_cast<int32_t*>(dout + o_segi);
+  int32_t* d_ctrl = reinterpret_cast<int32_t*>(dout + o_ctrl);
+  uint8_t* d_lim = reinterpret_cast<uint8_t*>(dout + o_lim);
+  uint8_t* d_pose = reinterpret_cast<uint8_t*>(dout + o_pose);
   c.r_q.ensure((size_t)n * sizeof(sffk::SweepQuery));
   c.r_cnt.ensure((size_t)n * 4);
   c.r_hidx.ensure((size_t)n * CAP * 4);
   c.r_hdist.ensure((size_t)n * CAP * 8);
-  // records: flags (n) | nnb (n) | nb ids (n*NBCAP) | nb meta (n*NBCAP)
-  const size_t rec_ints = (size_t)n * (2 + 2 * NBCAP);
-  c.r_rec.ensure(rec_ints * 4);
   c.r_sega.ensure((size_t)n * STRIDE * 48);
   c.r_segb.ensure((size_t)n * STRIDE * 48);
-  // per edge slot: samples | first hit | overflow
-  c.r_segi.ensure((size_t)n * STRIDE * 3 * 4);
   c.r_items.ensure((size_t)items_cap * sizeof(int2));
-  c.r_ctrl.ensure(16);
-  c.r_pose.ensure((size_t)n);
   HIPCHK(hipMemcpyAsync(c.r_in.p, c.p_in.p, in_bytes, hipMemcpyHostToDevice, c.stream));
   HIPCHK(hipMemsetAsync(c.r_cnt.p, 0, (size_t)n * 4, c.stream));
-  HIPCHK(hipMemsetAsync(c.r_ctrl.p, 0, 16, c.stream));
+  HIPCHK(hipMemsetAsync(d_ctrl, 0, 16, c.stream));
   sffk::SampleParams prm{};
   memcpy(prm.limits, cfg.limits, sizeof prm.limits);
   prm.dist_tree = cfg.dist_tree;
@@ -278,21 +281,20 @@ void Forest::round_begin() {
   prm.world = cfg.world;
   c.time_begin(T_SAMPLE);
   sffk::launch_sample_steer(c.stream, d_words, d_parent, c.spos.as<double>(), nullptr, n, cfg.sampling_dist, cfg.dim,
-                            prm, c.r_pos.as<double>(), c.r_lim.as<uint8_t>(), c.r_pd.as<double>(),
-                            c.r_q.as<sffk::SweepQuery>(), Tb);
+                            prm, d_pos, d_lim, d_pd, c.r_q.as<sffk::SweepQuery>(), Tb);
   // the round's samples become temporary store entries [N0, N0+n) so that the same sweep also
   // finds, for every sample, the EARLIER samples of this round (query i sees ids < N0 + i)
   sffk::NodeStoreMut mut{c.sx.as<float>(), c.sy.as<float>(), c.sz.as<float>(), c.syaw.as<float>(),
                          c.spitch.as<float>(), c.sroll.as<float>(), c.stree.as<int32_t>(), c.spos.as<double>()};
   sffk::launch_store_nan(c.stream, mut, N0, Tb - N0);
-  sffk::launch_store_write(c.stream, mut, c.r_pos.as<double>(), nullptr, d_parent, c.r_lim.as<uint8_t>(), n, Tb);
+  sffk::launch_store_write(c.stream, mut, d_pos, nullptr, d_parent, d_lim, n, Tb);
   c.time_end();
   // the sweep only serves the queries of this rank's shard (the others are marked inactive)
   c.time_begin(T_SWEEP);
   // permanent nodes through the grid (27 cells per query), this round's temporaries by a linear slice sweep
-  sffk::launch_grid_query(c.stream, c.gridv, c.store_view(), c.r_q.as<sffk::SweepQuery>(), c.r_pos.as<double>(), n,
+  sffk::launch_grid_query(c.stream, c.gridv, c.store_view(), c.r_q.as<sffk::SweepQuery>(), d_pos, n,
                           c.r_cnt.as<int32_t>(), c.r_hidx.as<int32_t>(), c.r_hdist.as<double>(), CAP);
-  sffk::launch_sweep(c.stream, c.store_view(), Tb, n, c.r_q.as<sffk::SweepQuery>(), c.r_pos.as<double>(), n,
+  sffk::launch_sweep(c.stream, c.store_view(), Tb, n, c.r_q.as<sffk::SweepQuery>(), d_pos, n,
                      c.r_cnt.as<int32_t>(), c.r_hidx.as<int32_t>(), c.r_hdist.as<double>(), CAP);
   c.time_end();
   st.sweeps += 1;
@@ -302,9 +304,9 @@ void Forest::round_begin() {
   ca.n = n; ca.N0 = Tb; ca.cap = CAP; ca.nbcap = NBCAP; ca.rank = cfg.rank; ca.world = cfg.world;
   ca.items_cap = items_cap;
   ca.dist_tree = cfg.dist_tree;
-  ca.newpos = c.r_pos.as<double>();
-  ca.in_lim = c.r_lim.as<uint8_t>();
-  ca.pdist = c.r_pd.as<double>();
+  ca.newpos = d_pos;
+  ca.in_lim = d_lim;
+  ca.pdist = d_pd;
   ca.parent = d_parent;
   ca.force = d_force;
   ca.cnt = c.r_cnt.as<int32_t>();
@@ -312,36 +314,26 @@ void Forest::round_begin() {
   ca.hit_dist = c.r_hdist.as<double>();
   ca.tree = c.stree.as<int32_t>();
   ca.pos = c.spos.as<double>();
-  ca.rec_flags = c.r_rec.as<int32_t>();
+  ca.rec_flags = d_rec;
   ca.rec_nnb = ca.rec_flags + n;
   ca.rec_nb = ca.rec_nnb + n;
   ca.rec_meta = ca.rec_nb + (size_t)n * NBCAP;
   ca.seg_a = c.r_sega.as<double>();
   ca.seg_b = c.r_segb.as<double>();
-  ca.seg_ns = c.r_segi.as<int32_t>();
+  ca.seg_ns = d_segi;
   ca.first_hit = ca.seg_ns + (size_t)n * STRIDE;
   ca.seg_ovf = ca.first_hit + (size_t)n * STRIDE;
   ca.items = c.r_items.as<int2>();
-  ca.ctrl = c.r_ctrl.as<int32_t>();
+  ca.ctrl = d_ctrl;
   c.time_begin(T_COLLIDE);
   sffk::launch_classify(c.stream, ca);
-  sffk::launch_collide_poses(c.stream, c.envv, c.robv, c.r_pos.as<double>(), n, ca.rec_flags, c.r_pose.as<uint8_t>());
+  sffk::launch_collide_poses(c.stream, c.envv, c.robv, d_pos, n, ca.rec_flags, d_pose);
   sffk::launch_collide_segments_dyn(c.stream, c.envv, c.robv, ca.seg_a, ca.seg_b, ca.items, ca.ctrl, items_cap,
                                     ca.first_hit, ca.seg_ovf);
   c.time_end();
-  // packed host output: pos | pdist | records | edge ints | ctrl | in_lim | pose
-  const size_t o_pos = 0, o_pd = o_pos + (size_t)n * 48, o_rec = o_pd + (size_t)n * 8, o_segi = o_rec + rec_ints * 4,
-               o_ctrl = o_segi + (size_t)n * STRIDE * 12, o_lim = o_ctrl + 16, o_pose = o_lim + (size_t)n,
-               o_bytes = o_pose + (size_t)n;
   c.p_out.ensure(o_bytes);
   char* ho = c.p_out.as<char>();
-  HIPCHK(hipMemcpyAsync(ho + o_pos, c.r_pos.p, (size_t)n * 48, hipMemcpyDeviceToHost, c.stream));
-  HIPCHK(hipMemcpyAsync(ho + o_pd, c.r_pd.p, (size_t)n * 8, hipMemcpyDeviceToHost, c.stream));
-  HIPCHK(hipMemcpyAsync(ho + o_rec, c.r_rec.p, rec_ints * 4, hipMemcpyDeviceToHost, c.stream));
-  HIPCHK(hipMemcpyAsync(ho + o_segi, c.r_segi.p, (size_t)n * STRIDE * 12, hipMemcpyDeviceToHost, c.stream));
-  HIPCHK(hipMemcpyAsync(ho + o_ctrl, c.r_ctrl.p, 16, hipMemcpyDeviceToHost, c.stream));
-  HIPCHK(hipMemcpyAsync(ho + o_lim, c.r_lim.p, (size_t)n, hipMemcpyDeviceToHost, c.stream));
-  HIPCHK(hipMemcpyAsync(ho + o_pose, c.r_pose.p, (size_t)n, hipMemcpyDeviceToHost, c.stream));
+  HIPCHK(hipMemcpyAsync(ho, dout, o_bytes, hipMemcpyDeviceToHost, c.stream));
   g_sec[1] += ms_since(_t1);
   timed_sync();
 
@@ -603,7 +595,7 @@ void Forest::round_begin() {
             ++seen;
             mb.id = h.id;
           } else {
-            if (!(h.d <= dk)) continue;
+            if (h.id < Tb || !(h.d <= dk)) continue;
             mb.id = -1 - (h.id - Tb);
           }
           cd.members.push_back(mb);
@@ -643,8 +635,8 @@ void Forest::round_begin() {
   }
 
   auto _t3 = Clock::now();
-  // ---- the int32 record stream of the owned candidates
-  for (int i = 0; i < n; ++i) {
+  // ---- the int32 record stream of the owned candidates (only needed when there are other ranks)
+  for (int i = 0; i < n && cfg.world > 1; ++i) {
     Cand& cd = cands[i];
     if (!cd.answered) continue;
     records.push_back(i);
@@ -681,11 +673,11 @@ void Forest::round_commit(const int32_t* all, const int32_t* counts, int world) 
   if (world != cfg.world) throw HipError{"forest: round_commit world size mismatch"};
   auto t_host = Clock::now();
   double wait_ms = 0;
-  const int n = (int)cands.size();
+  const int n = n_cands;
   auto _t4 = Clock::now();
   // ---- absorb the other ranks' answers
   size_t off = 0;
-  for (int r = 0; r < world; ++r) {
+  for (int r = 0; r < world && world > 1; ++r) {
     const int32_t* p = all + off;
     const int32_t* end = p + counts[r];
     off += (size_t)counts[r];
@@ -728,6 +720,16 @@ void Forest::round_commit(const int32_t* all, const int32_t* counts, int world) 
   }
   g_sec[4] += ms_since(_t4);
   auto _t5 = Clock::now();
+  if (getenv("SFFGPU_DIGEST")) {
+    for (int i = 0; i < n; ++i) {
+      const Cand& cd = cands[i];
+      if (!cd.in_lim) continue;
+      fprintf(stderr, "D %d %d | %d %d %d %d |", iter0, i, (int)cd.pose_hit, (int)cd.par_free, cd.par_fh, cd.par_ns);
+      for (const Nb& nb : cd.nbs) fprintf(stderr, " nb(%d %d %d %d %d)", nb.id, (int)nb.same_tree, (int)nb.free, nb.fh, nb.ns);
+      for (const Member& mb : cd.members) fprintf(stderr, " mb(%d %d %d %d %d %d %d)", mb.id, (int)mb.fwd_free, mb.fwd_fh, mb.fwd_ns, (int)mb.bwd_free, mb.bwd_fh, mb.bwd_ns);
+      fprintf(stderr, "\n");
+    }
+  }
   // ---- replay expandNode in slot order (src/forest.h:240-376)
   auto calls = [](int fh, int ns) -> uint64_t {  // Collide calls isPathFree makes (early exit at the first hit)
     return fh > 0 ? (uint64_t)fh : (uint64_t)ns;

@@ -110,10 +110,10 @@ __global__ __launch_bounds__(256) void k_sweep(NodeStoreView st, int first, int 
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int id = base + j;
-        if (d3[j] > Q.r2f || id >= first + n_nodes || id >= Q.max_id) continue;
+        if (!(d3[j] <= Q.r2f) || id >= first + n_nodes || id >= Q.max_id) continue;  // NaN placeholders fail here
         float da = wrapf(as[j] - Q.yaw), db = wrapf(bs[j] - Q.pitch), dc = wrapf(cs[j] - Q.roll);
         float d6 = fmaf(dc, dc, fmaf(db, db, fmaf(da, da, d3[j])));
-        if (d6 > Q.r2f) continue;
+        if (!(d6 <= Q.r2f)) continue;
         if (Q.tree >= 0 && st.tree[id] != Q.tree) continue;
         // exact re-test in fp64 on the authoritative positions (reference: realDist, src/forest.h:274)
         double np[6], qp[6];
@@ -167,10 +167,10 @@ __device__ __forceinline__ void grid_test(const GridItem& it, const SweepQuery& 
   if (Q.tree >= 0 && it.tree != Q.tree) return;
   float dx = it.x - Q.x, dy = it.y - Q.y, dz = it.z - Q.z;
   float d3 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-  if (d3 > Q.r2f) return;
+  if (!(d3 <= Q.r2f)) return;
   float da = wrapf(it.yaw - Q.yaw), db = wrapf(it.pitch - Q.pitch), dc = wrapf(it.roll - Q.roll);
   float d6 = fmaf(dc, dc, fmaf(db, db, fmaf(da, da, d3)));
-  if (d6 > Q.r2f) return;
+  if (!(d6 <= Q.r2f)) return;
   double np[6], qp[6];
   for (int k = 0; k < 6; ++k) { np[k] = st.pos[6 * (size_t)it.id + k]; qp[k] = qpos[6 * (size_t)q + k]; }
   double d = dist6(np, qp);
@@ -511,13 +511,18 @@ __global__ __launch_bounds__(64 * SEG_WAVES) void k_collide_segments_dyn(EnvView
   if (env.n_tri == 0) return;
   int n_items = ctrl[0];
   if (n_items > items_cap) n_items = items_cap;
+  // one returning atomic on a single word saturates near 90 dequeues/us chip-wide, so every
+  // dequeue takes a batch of consecutive items
+  const int BATCH = 8;
   while (true) {
-    int item = 0;
-    if (lane == 0) item = atomicAdd(ctrl + 1, 1);
-    item = __shfl(item, 0);
-    if (item >= n_items) break;
-    segment_chunk(env, rob, rtri, ibase + wave * STACK_CAP, ibase + SEG_WAVES * STACK_CAP + wave * CAND_CAP, a6, b6,
-                  items[item].x, items[item].y, first_hit, overflow_flag, lane);
+    int first = 0;
+    if (lane == 0) first = atomicAdd(ctrl + 1, BATCH);
+    first = __shfl(first, 0);
+    if (first >= n_items) break;
+    const int last = first + BATCH < n_items ? first + BATCH : n_items;
+    for (int item = first; item < last; ++item)
+      segment_chunk(env, rob, rtri, ibase + wave * STACK_CAP, ibase + SEG_WAVES * STACK_CAP + wave * CAND_CAP, a6, b6,
+                    items[item].x, items[item].y, first_hit, overflow_flag, lane);
   }
 }
 
@@ -717,8 +722,8 @@ void launch_collide_segments_dyn(hipStream_t s, const EnvView& env, const RobotV
                                  const double* b6, const int2* items, int32_t* ctrl, int items_cap,
                                  int32_t* first_hit, int32_t* overflow_flag) {
   size_t lds = collide_lds_bytes(rob.n_tri, SEG_WAVES);
-  // 8 workgroups per CU keep every SIMD busy (3 waves/SIMD fit the kernel's register budget)
-  static const int blocks = getenv("SFFGPU_SEG_BLOCKS") ? atoi(getenv("SFFGPU_SEG_BLOCKS")) : 2048;
+  // 3 workgroups of 4 waves per CU = what the kernel's register budget keeps resident (256 CUs)
+  static const int blocks = getenv("SFFGPU_SEG_BLOCKS") ? atoi(getenv("SFFGPU_SEG_BLOCKS")) : 768;
   hipLaunchKernelGGL(k_collide_segments_dyn, dim3(blocks), dim3(64 * SEG_WAVES), lds, s, env, rob, a6, b6, items, ctrl,
                      items_cap, first_hit, overflow_flag);
 }
