@@ -129,6 +129,36 @@ int sffgpu_forest_get_borders(sffgpu_forest* f, int32_t* tree_a, int32_t* tree_b
                               double* dist, int cap);
 uint64_t sffgpu_forest_fingerprint(sffgpu_forest* f);
 
+/* ---------------------------------------------------------------- RRT / RRT* / Multi-T-RRT
+ * RapidExpTree<T,R> (src/rrt.h:25-44): constructor :47-83, Solve() :86-99, expandNode :128-322
+ * (nearest + steer, RRT* choose-parent / rewire, connect-and-merge of trees). */
+typedef struct {
+  int32_t dim, optimize, has_goal;
+  double goal[6];
+  double limits[6];
+  double dist_tree, sampling_dist;  /* Problem::distTree, Node::SamplingDistance (scaled) */
+  double priority_bias;             /* Problem::priorityBias: probability of steering at the goal */
+  int32_t max_iterations;
+  uint64_t seed;
+} sffgpu_rrt_cfg;
+
+typedef struct {
+  int32_t iterations, solved, n_nodes, n_live_trees, merges, n_links;
+  uint64_t collide_calls, path_free_calls, nn_queries;  /* what the reference would have executed */
+  double total_ms;
+} sffgpu_rrt_stats;
+
+typedef struct sffgpu_rrt sffgpu_rrt;
+int sffgpu_rrt_create(sffgpu_ctx* ctx, const sffgpu_rrt_cfg* cfg, const double* roots6, int n_roots, sffgpu_rrt** out);
+void sffgpu_rrt_destroy(sffgpu_rrt* r);
+int sffgpu_rrt_run(sffgpu_rrt* r, int max_iterations); /* 0 = until solved / Problem::maxIterations */
+int sffgpu_rrt_get_stats(sffgpu_rrt* r, sffgpu_rrt_stats* out);
+/* nodes in creation order; tree = the (possibly merged) tree currently holding the node, root_tree = Node::Root */
+int sffgpu_rrt_get_nodes(sffgpu_rrt* r, double* pos6, int32_t* parent, int32_t* tree, int32_t* root_tree,
+                         int32_t* iter, double* cost, double* dist_parent);
+/* Tree::links entries (src/rrt.h:233); returns the count (may exceed cap) */
+int sffgpu_rrt_get_links(sffgpu_rrt* r, int32_t* tree, int32_t* node1, int32_t* node2, double* dist, int cap);
+
 /* Multi-GPU wave protocol (one process per GPU; the exchange itself is the caller's RCCL / gloo
  * all-gather).  Every rank holds a full replica of the forest and of the node store; a round is
  *   begin  -> the active slots are drawn and sampled on EVERY rank (replicated, deterministic);

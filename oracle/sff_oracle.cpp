@@ -820,6 +820,157 @@ struct Forest {
   }
 };
 
+
+// ------------------------------------------------------------------ RRT / RRT* / Multi-T-RRT
+// src/rrt.h:47-83 (constructor), :86-99 (Solve loop), :128-322 (expandNode incl. tree merging).
+// A node keeps ONE identity (its global id); the reference's merge copies the `from` tree's nodes
+// into `to` (:243-249) and re-resolves parents / children / links by id (:251-296) — restated as
+// moving the ids to the end of `to`'s list in `from` order.  Neighbour queries are exact (true
+// metric); the reference's merge fills only 2 of 6 FLANN columns (:243-245), which is not kept.
+struct RNode {
+  double pos[6];
+  int root_tree;   // Node::Root (tree it was created in; RRT* rewire copies it, :195)
+  int tree;        // Node::ExpandedRoot: the tree whose list currently holds it
+  int parent;
+  int idx_in_tree;
+  double d_closest, d_root;
+  unsigned iter;
+};
+struct RLink { int n1, n2; double dist; };
+
+struct Rrt {
+  World* w;
+  sffo_rrt_cfg cfg;
+  Rng rng;
+  std::vector<RNode> nodes;
+  std::vector<std::vector<int>> trees;       // tree id -> node ids in list order
+  std::vector<std::vector<RLink>> links;     // Tree::links
+  std::vector<std::vector<int>> eaten;       // Tree::eaten
+  std::vector<int> tree_frontier;            // treeFrontier (tree ids)
+  int num_trees = 0;                          // numTrees
+  int goal_node = -1;
+  int iter = 0;
+  bool solved = false;
+  uint64_t path_free_calls = 0, nn_queries = 0, collide_base = 0, merges = 0;
+
+  bool path_free(const double* a, const double* b) {
+    ++path_free_calls;
+    return w->path_free(a, b, nullptr, nullptr);
+  }
+  int add_node(const double* pos, int root_tree, int tree, int parent, double dc, double dr, unsigned it) {
+    RNode n;
+    memcpy(n.pos, pos, sizeof n.pos);
+    n.root_tree = root_tree; n.tree = tree; n.parent = parent; n.d_closest = dc; n.d_root = dr; n.iter = it;
+    n.idx_in_tree = (int)trees[tree].size();
+    int id = (int)nodes.size();
+    nodes.push_back(n);
+    trees[tree].push_back(id);
+    return id;
+  }
+  void knn(int tree, const double* q, size_t k, std::vector<Hit>& out) {
+    out.clear();
+    for (int id : trees[tree]) out.push_back({distance6(q, nodes[id].pos), nodes[id].idx_in_tree});
+    if (out.size() > k) { std::partial_sort(out.begin(), out.begin() + k, out.end()); out.resize(k); }
+    else std::sort(out.begin(), out.end());
+    ++nn_queries;
+  }
+  RLink make_link(int a, int b) {   // DistanceHolder(first, second), src/primitives.h:609-618
+    double d = nodes[a].d_root + nodes[b].d_root + distance6(nodes[a].pos, nodes[b].pos);
+    return {std::min(a, b), std::max(a, b), d};
+  }
+
+  void expand(int tree_to_expand, unsigned iteration) {
+    double rnd[6], np[6];
+    if (cfg.priority_bias != 0 && rng.prob() <= cfg.priority_bias) {          // :130-131
+      memcpy(rnd, nodes[goal_node].pos, sizeof rnd);
+    } else {                                                                    // :133, src/randGen.h:124-146
+      double y = uniform_real_from_word(rng.raw(), cfg.limits[2], cfg.limits[3]);
+      double x = uniform_real_from_word(rng.raw(), cfg.limits[0], cfg.limits[1]);
+      rnd[0] = x; rnd[1] = y; rnd[2] = 0; rnd[3] = rnd[4] = rnd[5] = 0;
+      if (cfg.dim == 6) {
+        rnd[2] = uniform_real_from_word(rng.raw(), cfg.limits[4], cfg.limits[5]);
+        rnd[3] = uniform_real_from_word(rng.raw(), -M_PI, M_PI);
+        double phi = tacos(1 - 2 * uniform_real_from_word(rng.raw(), 0.0, 1.0), cfg.trig) + M_PI_2;
+        if (uniform_real_from_word(rng.raw(), 0.0, 1.0) < 0.5) { if (phi < 0) phi += M_PI; else phi -= M_PI; }
+        rnd[4] = phi;
+        rnd[5] = uniform_real_from_word(rng.raw(), -M_PI, M_PI);
+      }
+    }
+    std::vector<Hit> hits;
+    knn(tree_to_expand, rnd, 1, hits);                                          // :143
+    int nearest = trees[tree_to_expand][hits[0].idx];
+    steer6(nodes[nearest].pos, rnd, cfg.sampling_dist, np);                     // :148
+    if (w->collide(np) || !path_free(nodes[nearest].pos, np)) return;           // :149-151
+    int new_id;
+    if (cfg.optimize) {                                                         // :156-201
+      double best = distance6(np, nodes[nearest].pos) + nodes[nearest].d_root;
+      double krrt = 2 * M_E * std::log10((double)nodes.size());
+      std::vector<Hit> kn;
+      knn(tree_to_expand, np, (size_t)krrt, kn);
+      for (const Hit& h : kn) {
+        int nb = trees[tree_to_expand][h.idx];
+        double nd = distance6(np, nodes[nb].pos) + nodes[nb].d_root;
+        if (nd < best - TOLERANCE && path_free(np, nodes[nb].pos)) { best = nd; nearest = nb; }
+      }
+      new_id = add_node(np, nodes[nearest].root_tree, tree_to_expand, nearest, distance6(nodes[nearest].pos, np), best, iteration);
+      for (const Hit& h : kn) {
+        int nb = trees[tree_to_expand][h.idx];
+        double npd = distance6(nodes[nb].pos, np);
+        double proposed = best + npd;
+        if (proposed < nodes[nb].d_root - TOLERANCE && path_free(nodes[nb].pos, np)) {
+          nodes[nb].parent = new_id;
+          nodes[nb].root_tree = nodes[new_id].root_tree;                        // :195
+          nodes[nb].d_closest = npd;
+          nodes[nb].d_root = proposed;
+        }
+      }
+    } else {                                                                    // :203
+      new_id = add_node(np, nodes[nearest].root_tree, tree_to_expand, nearest, cfg.sampling_dist,
+                        nodes[nearest].d_root + cfg.sampling_dist, iteration);
+    }
+    // :219-319 connect to / merge with the other live trees
+    for (int i = 0; i < (int)tree_frontier.size(); ++i) {
+      int tree = tree_frontier[i];
+      if (tree == tree_to_expand) continue;
+      knn(tree, np, 1, hits);
+      int nb = trees[tree][hits[0].idx];
+      double nd = distance6(nodes[nb].pos, np);
+      if (nd < cfg.dist_tree && path_free(np, nodes[nb].pos)) {                  // :231 (no TOLERANCE here)
+        links[tree_to_expand].push_back(make_link(new_id, nb));                  // :233
+        int nbt = nodes[nb].tree;
+        int to = tree_to_expand < nbt ? tree_to_expand : nbt;
+        int from = tree_to_expand < nbt ? nbt : tree_to_expand;
+        for (int id : trees[from]) {                                             // :240-250
+          nodes[id].tree = to;
+          nodes[id].idx_in_tree = (int)trees[to].size();
+          trees[to].push_back(id);
+        }
+        for (RLink& l : links[to]) l = make_link(l.n1, l.n2);                    // :278-289 re-created -> distance recomputed
+        for (const RLink& l : links[from]) links[to].push_back(make_link(l.n1, l.n2));  // :291-299
+        eaten[to].push_back(from);                                               // :305-308
+        for (int t : eaten[from]) eaten[to].push_back(t);
+        tree_frontier.erase(std::find(tree_frontier.begin(), tree_frontier.end(), from));  // :310-315
+        tree_to_expand = to;
+        solved = tree_frontier.size() == 1;
+        --num_trees;
+        --i;
+        ++merges;
+      }
+    }
+  }
+
+  void run(int max_iters) {
+    int done = 0;
+    while (!(solved || iter == cfg.max_iterations)) {                            // :93
+      if (max_iters > 0 && done >= max_iters) break;
+      ++done;
+      ++iter;
+      int tree = tree_frontier[rng.rand_int(0, num_trees)];                      // :95
+      expand(tree, (unsigned)iter);
+    }
+  }
+};
+
 }  // namespace
 
 // =================================================================== C interface
@@ -1011,6 +1162,69 @@ uint64_t sffo_forest_fingerprint(sffo_forest* h) {
     mix(n.pos, sizeof n.pos);
   }
   return x;
+}
+
+struct sffo_rrt { Rrt r; };
+sffo_rrt* sffo_rrt_create(sffo_world* w, const sffo_rrt_cfg* cfg, const double* roots6, int n_roots) {
+  sffo_rrt* h = new sffo_rrt;
+  Rrt& r = h->r;
+  r.w = &w->w;
+  r.collide_base = w->w.collide_calls;
+  r.cfg = *cfg;
+  r.rng.eng.reseed(cfg->seed);
+  memcpy(r.rng.lim, cfg->limits, sizeof r.rng.lim);
+  r.rng.trig = cfg->trig;
+  int nt = n_roots + (cfg->has_goal ? 1 : 0);
+  r.trees.resize(nt); r.links.resize(nt); r.eaten.resize(nt);
+  for (int j = 0; j < n_roots; ++j) {                                            // src/rrt.h:48-62
+    r.add_node(roots6 + 6 * j, j, j, -1, 0, 0, 0);
+    r.tree_frontier.push_back(j);
+  }
+  r.num_trees = n_roots - 1;                                                     // :63
+  if (cfg->has_goal) {                                                           // :66-82
+    r.goal_node = r.add_node(cfg->goal, n_roots, n_roots, -1, 0, 0, 0);
+    r.tree_frontier.push_back(n_roots);
+  }
+  return h;
+}
+void sffo_rrt_destroy(sffo_rrt* h) { delete h; }
+void sffo_rrt_run(sffo_rrt* h, int max_iters) { h->r.run(max_iters); }
+void sffo_rrt_get_stats(sffo_rrt* h, sffo_rrt_stats* s) {
+  Rrt& r = h->r;
+  s->iterations = r.iter;
+  s->solved = r.solved;
+  s->n_nodes = (int)r.nodes.size();
+  s->n_live_trees = (int)r.tree_frontier.size();
+  s->merges = (int)r.merges;
+  int nl = 0;
+  for (auto& l : r.links) nl += (int)l.size();
+  s->n_links = nl;
+  s->collide_calls = r.w->collide_calls - r.collide_base;
+  s->path_free_calls = r.path_free_calls;
+  s->nn_queries = r.nn_queries;
+}
+void sffo_rrt_get_nodes(sffo_rrt* h, double* pos6, int32_t* parent, int32_t* tree, int32_t* root_tree, int32_t* iter,
+                        double* cost, double* dpar) {
+  Rrt& r = h->r;
+  for (size_t i = 0; i < r.nodes.size(); ++i) {
+    const RNode& n = r.nodes[i];
+    if (pos6) memcpy(pos6 + 6 * i, n.pos, sizeof n.pos);
+    if (parent) parent[i] = n.parent;
+    if (tree) tree[i] = n.tree;
+    if (root_tree) root_tree[i] = n.root_tree;
+    if (iter) iter[i] = (int32_t)n.iter;
+    if (cost) cost[i] = n.d_root;
+    if (dpar) dpar[i] = n.d_closest;
+  }
+}
+int sffo_rrt_get_links(sffo_rrt* h, int32_t* tree, int32_t* n1, int32_t* n2, double* dist, int cap) {
+  int k = 0;
+  for (size_t t = 0; t < h->r.links.size(); ++t)
+    for (const RLink& l : h->r.links[t]) {
+      if (k < cap) { tree[k] = (int32_t)t; n1[k] = l.n1; n2[k] = l.n2; dist[k] = l.dist; }
+      ++k;
+    }
+  return k;
 }
 
 }  // extern "C"

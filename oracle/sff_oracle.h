@@ -109,6 +109,30 @@ int sffo_forest_get_borders(sffo_forest*, int32_t* ta, int32_t* tb, int32_t* n1,
 /* FNV-1a over (parent, tree, iter, pos bits) of all nodes — cheap topology fingerprint */
 uint64_t sffo_forest_fingerprint(sffo_forest*);
 
+/* ---- RRT / RRT* / Multi-T-RRT solver (reference src/rrt.h:47-322) ---- */
+typedef struct {
+  int dim, optimize, has_goal;
+  double goal[6];
+  double limits[6];
+  double dist_tree, sampling_dist;
+  double priority_bias;    /* Problem::priorityBias (goal bias; needs has_goal) */
+  int max_iterations;
+  uint64_t seed;
+  int trig;
+} sffo_rrt_cfg;
+typedef struct {
+  int32_t iterations, solved, n_nodes, n_live_trees, merges, n_links;
+  uint64_t collide_calls, path_free_calls, nn_queries;
+} sffo_rrt_stats;
+typedef struct sffo_rrt sffo_rrt;
+sffo_rrt* sffo_rrt_create(sffo_world* w, const sffo_rrt_cfg* cfg, const double* roots6, int n_roots);
+void sffo_rrt_destroy(sffo_rrt*);
+void sffo_rrt_run(sffo_rrt*, int max_iters);
+void sffo_rrt_get_stats(sffo_rrt*, sffo_rrt_stats*);
+void sffo_rrt_get_nodes(sffo_rrt*, double* pos6, int32_t* parent, int32_t* tree, int32_t* root_tree, int32_t* iter,
+                        double* cost, double* dpar);
+int sffo_rrt_get_links(sffo_rrt*, int32_t* tree, int32_t* n1, int32_t* n2, double* dist, int cap);
+
 #ifdef __cplusplus
 }
 #endif

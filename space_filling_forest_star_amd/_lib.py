@@ -15,7 +15,8 @@ EXPORTED_SYMBOLS = [
     "sffgpu_nodes_reset", "sffgpu_nodes_append", "sffgpu_nodes_count", "sffgpu_radius", "sffgpu_knn",
     "sffgpu_forest_create", "sffgpu_forest_destroy", "sffgpu_forest_run", "sffgpu_forest_get_stats",
     "sffgpu_forest_get_nodes", "sffgpu_forest_get_borders", "sffgpu_forest_fingerprint",
-    "sffgpu_forest_in_wave", "sffgpu_forest_round_begin", "sffgpu_forest_round_records", "sffgpu_forest_round_commit",
+    "sffgpu_rrt_create", "sffgpu_rrt_destroy", "sffgpu_rrt_run", "sffgpu_rrt_get_stats", "sffgpu_rrt_get_nodes",
+    "sffgpu_rrt_get_links", "sffgpu_forest_in_wave", "sffgpu_forest_round_begin", "sffgpu_forest_round_records", "sffgpu_forest_round_commit",
 ]
 
 c_dp = C.POINTER(C.c_double)
@@ -45,6 +46,21 @@ class ForestStats(C.Structure):
                 ("sweep_ms", C.c_double),
                 ("collide_ms", C.c_double), ("sample_ms", C.c_double), ("host_ms", C.c_double),
                 ("total_ms", C.c_double)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class RrtCfg(C.Structure):
+    _fields_ = [("dim", C.c_int32), ("optimize", C.c_int32), ("has_goal", C.c_int32), ("goal", C.c_double * 6),
+                ("limits", C.c_double * 6), ("dist_tree", C.c_double), ("sampling_dist", C.c_double),
+                ("priority_bias", C.c_double), ("max_iterations", C.c_int32), ("seed", C.c_uint64)]
+
+
+class RrtStats(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("solved", C.c_int32), ("n_nodes", C.c_int32), ("n_live_trees", C.c_int32),
+                ("merges", C.c_int32), ("n_links", C.c_int32), ("collide_calls", C.c_uint64),
+                ("path_free_calls", C.c_uint64), ("nn_queries", C.c_uint64), ("total_ms", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -93,6 +109,12 @@ def lib():
     L.sffgpu_forest_get_borders.argtypes = [C.c_void_p, c_ip, c_ip, c_ip, c_ip, c_dp, C.c_int]
     L.sffgpu_forest_fingerprint.restype = C.c_uint64
     L.sffgpu_forest_fingerprint.argtypes = [C.c_void_p]
+    L.sffgpu_rrt_create.argtypes = [C.c_void_p, C.POINTER(RrtCfg), c_dp, C.c_int, C.POINTER(C.c_void_p)]
+    L.sffgpu_rrt_destroy.argtypes = [C.c_void_p]
+    L.sffgpu_rrt_run.argtypes = [C.c_void_p, C.c_int]
+    L.sffgpu_rrt_get_stats.argtypes = [C.c_void_p, C.POINTER(RrtStats)]
+    L.sffgpu_rrt_get_nodes.argtypes = [C.c_void_p, c_dp, c_ip, c_ip, c_ip, c_ip, c_dp, c_dp]
+    L.sffgpu_rrt_get_links.argtypes = [C.c_void_p, c_ip, c_ip, c_ip, c_dp, C.c_int]
     L.sffgpu_forest_in_wave.argtypes = [C.c_void_p]
     L.sffgpu_forest_round_begin.argtypes = [C.c_void_p, c_ip, c_ip]
     L.sffgpu_forest_round_records.argtypes = [C.c_void_p, c_ip, C.c_int]
@@ -302,6 +324,65 @@ class Forest:
         a = _i32(all_words)
         cnt = _i32(words_per_rank)
         self.ctx._chk(self.ctx._L.sffgpu_forest_round_commit(self.h, _ip(a), _ip(cnt), len(cnt)))
+
+
+class Rrt:
+    """RapidExpTree solver session (reference src/rrt.h:25-44) on one Context."""
+
+    def __init__(self, ctx, roots, limits, dist_tree, sampling_dist, dim=6, optimize=False, goal=None,
+                 priority_bias=0.0, max_iterations=10000, seed=1):
+        self.ctx = ctx
+        cfg = RrtCfg()
+        cfg.dim = dim
+        cfg.optimize = int(optimize)
+        cfg.has_goal = int(goal is not None)
+        if goal is not None:
+            cfg.goal = (C.c_double * 6)(*goal)
+        cfg.limits = (C.c_double * 6)(*limits)
+        cfg.dist_tree = dist_tree
+        cfg.sampling_dist = sampling_dist
+        cfg.priority_bias = priority_bias
+        cfg.max_iterations = max_iterations
+        cfg.seed = seed
+        r = _f64(roots, 6)
+        h = C.c_void_p()
+        ctx._chk(ctx._L.sffgpu_rrt_create(ctx.h, C.byref(cfg), _dp(r), len(r), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.ctx._L.sffgpu_rrt_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def run(self, max_iterations=0):
+        self.ctx._chk(self.ctx._L.sffgpu_rrt_run(self.h, max_iterations))
+
+    def stats(self):
+        s = RrtStats()
+        self.ctx._chk(self.ctx._L.sffgpu_rrt_get_stats(self.h, C.byref(s)))
+        return s.as_dict()
+
+    def nodes(self):
+        n = self.stats()["n_nodes"]
+        pos = np.zeros((n, 6))
+        parent, tree, root_tree, it = (np.zeros(n, np.int32) for _ in range(4))
+        cost = np.zeros(n)
+        dpar = np.zeros(n)
+        self.ctx._chk(self.ctx._L.sffgpu_rrt_get_nodes(self.h, _dp(pos), _ip(parent), _ip(tree), _ip(root_tree), _ip(it),
+                                                       _dp(cost), _dp(dpar)))
+        return dict(pos=pos, parent=parent, tree=tree, root_tree=root_tree, iter=it, cost=cost, dpar=dpar)
+
+    def links(self, cap=1 << 16):
+        t, n1, n2 = (np.zeros(cap, np.int32) for _ in range(3))
+        d = np.zeros(cap)
+        k = min(self.ctx._chk(self.ctx._L.sffgpu_rrt_get_links(self.h, _ip(t), _ip(n1), _ip(n2), _dp(d), cap)), cap)
+        return dict(tree=t[:k].copy(), n1=n1[:k].copy(), n2=n2[:k].copy(), dist=d[:k].copy())
 
 
 def exchange_records(local, group=None):

@@ -10,6 +10,10 @@ using namespace sff;
 struct sffgpu_ctx {
   Ctx* c;
 };
+struct sffgpu_rrt {
+  Rrt* r;
+  sffgpu_ctx* owner;
+};
 struct sffgpu_forest {
   Forest* f;
   sffgpu_ctx* owner;
@@ -181,6 +185,72 @@ int sffgpu_forest_get_borders(sffgpu_forest* f, int32_t* ta, int32_t* tb, int32_
   return k;
 }
 uint64_t sffgpu_forest_fingerprint(sffgpu_forest* f) { return f ? f->f->fingerprint() : 0; }
+
+int sffgpu_rrt_create(sffgpu_ctx* ctx, const sffgpu_rrt_cfg* cfg, const double* roots6, int n_roots, sffgpu_rrt** out) {
+  if (!ctx || !cfg || !roots6 || n_roots <= 0 || !out) return SFFGPU_ERR_ARG;
+  *out = nullptr;
+  GUARD(ctx, {
+    Rrt* R = new Rrt(ctx->c, *cfg, roots6, n_roots);
+    sffgpu_rrt* h = new sffgpu_rrt;
+    h->r = R;
+    h->owner = ctx;
+    *out = h;
+  });
+}
+void sffgpu_rrt_destroy(sffgpu_rrt* r) {
+  if (!r) return;
+  delete r->r;
+  delete r;
+}
+int sffgpu_rrt_run(sffgpu_rrt* r, int max_iterations) {
+  if (!r) return SFFGPU_ERR_ARG;
+  GUARD(r->owner, r->r->run(max_iterations));
+}
+int sffgpu_rrt_get_stats(sffgpu_rrt* r, sffgpu_rrt_stats* out) {
+  if (!r || !out) return SFFGPU_ERR_ARG;
+  Rrt& R = *r->r;
+  sffgpu_rrt_stats s = R.st;
+  s.iterations = R.iter;
+  s.solved = R.solved;
+  s.n_nodes = (int)R.nodes.size();
+  s.n_live_trees = (int)R.tree_frontier.size();
+  int nl = 0;
+  for (auto& l : R.links) nl += (int)l.size();
+  s.n_links = nl;
+  *out = s;
+  return SFFGPU_OK;
+}
+int sffgpu_rrt_get_nodes(sffgpu_rrt* r, double* pos6, int32_t* parent, int32_t* tree, int32_t* root_tree, int32_t* iter,
+                         double* cost, double* dist_parent) {
+  if (!r) return SFFGPU_ERR_ARG;
+  Rrt& R = *r->r;
+  for (size_t i = 0; i < R.nodes.size(); ++i) {
+    const RNode& n = R.nodes[i];
+    if (pos6) memcpy(pos6 + 6 * i, n.pos, sizeof n.pos);
+    if (parent) parent[i] = n.parent;
+    if (tree) tree[i] = n.tree;
+    if (root_tree) root_tree[i] = n.root_tree;
+    if (iter) iter[i] = (int32_t)n.iter;
+    if (cost) cost[i] = n.d_root;
+    if (dist_parent) dist_parent[i] = n.d_closest;
+  }
+  return SFFGPU_OK;
+}
+int sffgpu_rrt_get_links(sffgpu_rrt* r, int32_t* tree, int32_t* n1, int32_t* n2, double* dist, int cap) {
+  if (!r) return SFFGPU_ERR_ARG;
+  int k = 0;
+  for (size_t t = 0; t < r->r->links.size(); ++t)
+    for (const RLink& l : r->r->links[t]) {
+      if (k < cap) {
+        if (tree) tree[k] = (int32_t)t;
+        if (n1) n1[k] = l.n1;
+        if (n2) n2[k] = l.n2;
+        if (dist) dist[k] = l.dist;
+      }
+      ++k;
+    }
+  return k;
+}
 
 int sffgpu_forest_in_wave(sffgpu_forest* f) { return f ? (f->f->in_wave ? 1 : 0) : SFFGPU_ERR_ARG; }
 int sffgpu_forest_round_begin(sffgpu_forest* f, int32_t* n_words, int32_t* done) {

@@ -318,6 +318,17 @@ void Ctx::store_append(const double* pos6, const int32_t* tree, int n) {
   store_n += n;
 }
 
+void Ctx::store_set_tree(const int32_t* ids, int n, int32_t tree) {
+  if (n <= 0) return;
+  HIPCHK(hipSetDevice(device));
+  h_a.ensure((size_t)n * 4);
+  d_a.ensure((size_t)n * 4);
+  memcpy(h_a.p, ids, (size_t)n * 4);
+  HIPCHK(hipMemcpyAsync(d_a.p, h_a.p, (size_t)n * 4, hipMemcpyHostToDevice, stream));
+  sffk::launch_set_tree(stream, stree.as<int32_t>(), d_a.as<int32_t>(), n, tree);
+  sync();
+}
+
 // ------------------------------------------------------------------ grid
 void Ctx::grid_setup(const double limits[6], double cell) {
   HIPCHK(hipSetDevice(device));

@@ -107,6 +107,7 @@ struct Ctx {
   void store_reset(int capacity);
   void store_reserve(int capacity);
   void store_append(const double* pos6, const int32_t* tree, int n);
+  void store_set_tree(const int32_t* ids, int n, int32_t tree);  // relabel nodes (tree merging, src/rrt.h:240-250)
 
   void collide_poses(const double* pos6, int n, uint8_t* hit);
   void collide_segments(const double* a6, const double* b6, int n, uint8_t* is_free, int32_t* first_hit,
@@ -210,6 +211,41 @@ struct Forest {
   void round_commit(const int32_t* all, const int32_t* counts, int world);
   void run(int max_waves);
   uint64_t fingerprint() const;
+};
+
+struct RNode {
+  double pos[6];
+  int root_tree;   // Node::Root
+  int tree;        // Node::ExpandedRoot: the tree whose list currently holds the node
+  int parent, idx_in_tree;
+  double d_closest, d_root;
+  unsigned iter;
+};
+struct RLink {
+  int n1, n2;
+  double dist;
+};
+
+// RapidExpTree (src/rrt.h:25-44)
+struct Rrt {
+  Ctx* ctx;
+  sffgpu_rrt_cfg cfg;
+  Mt64 rng;
+  std::vector<RNode> nodes;
+  std::vector<std::vector<int>> trees;
+  std::vector<std::vector<RLink>> links;
+  std::vector<std::vector<int>> eaten;
+  std::vector<int> tree_frontier;
+  int num_trees = 0, goal_node = -1, iter = 0;
+  bool solved = false;
+  sffgpu_rrt_stats st{};
+
+  Rrt(Ctx* c, const sffgpu_rrt_cfg& cf, const double* roots6, int n_roots);
+  int add_node(const double* pos, int root_tree, int tree, int parent, double dc, double dr, unsigned it);
+  RLink make_link(int a, int b);
+  void knn(const double* q, int nq, const int32_t* tree, int k, std::vector<std::vector<int>>& out);
+  void expand(int tree_to_expand, unsigned iteration);
+  void run(int max_iters);
 };
 
 }  // namespace sff

@@ -225,6 +225,12 @@ __global__ __launch_bounds__(64) void k_store_nan(NodeStoreMut st, int first, in
   st.x[o] = nanv; st.y[o] = nanv; st.z[o] = nanv; st.yaw[o] = nanv; st.pitch[o] = nanv; st.roll[o] = nanv;
 }
 
+__global__ __launch_bounds__(256) void k_set_tree(int32_t* __restrict__ tree_col, const int32_t* __restrict__ ids, int n,
+                                                  int32_t value) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) tree_col[ids[i]] = value;
+}
+
 // ------------------------------------------------------------------ collision: shared pieces
 struct WaveStack {
   int32_t* s;  // LDS, STACK_CAP entries per wave
@@ -703,6 +709,11 @@ void launch_grid_query(hipStream_t s, const GridView& g, const NodeStoreView& st
 void launch_store_nan(hipStream_t s, const NodeStoreMut& st, int first, int n) {
   if (n <= 0) return;
   hipLaunchKernelGGL(k_store_nan, dim3(1), dim3(64), 0, s, st, first, n);
+}
+
+void launch_set_tree(hipStream_t s, int32_t* tree_col, const int32_t* ids, int n, int32_t value) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_set_tree, dim3((n + 255) / 256), dim3(256), 0, s, tree_col, ids, n, value);
 }
 
 void launch_collide_poses(hipStream_t s, const EnvView& env, const RobotView& rob, const double* pos6, int n,

@@ -35,6 +35,21 @@ class ForestStats(C.Structure):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
+class RrtCfg(C.Structure):
+    _fields_ = [("dim", C.c_int), ("optimize", C.c_int), ("has_goal", C.c_int), ("goal", C.c_double * 6),
+                ("limits", C.c_double * 6), ("dist_tree", C.c_double), ("sampling_dist", C.c_double),
+                ("priority_bias", C.c_double), ("max_iterations", C.c_int), ("seed", C.c_uint64), ("trig", C.c_int)]
+
+
+class RrtStats(C.Structure):
+    _fields_ = [("iterations", C.c_int32), ("solved", C.c_int32), ("n_nodes", C.c_int32), ("n_live_trees", C.c_int32),
+                ("merges", C.c_int32), ("n_links", C.c_int32), ("collide_calls", C.c_uint64),
+                ("path_free_calls", C.c_uint64), ("nn_queries", C.c_uint64)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
 def build():
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "libsff_oracle.so"])
 
@@ -87,6 +102,13 @@ def lib():
     L.sffo_forest_get_borders.argtypes = [C.c_void_p, c_ip, c_ip, c_ip, c_ip, c_dp, C.c_int]
     L.sffo_forest_fingerprint.restype = C.c_uint64
     L.sffo_forest_fingerprint.argtypes = [C.c_void_p]
+    L.sffo_rrt_create.restype = C.c_void_p
+    L.sffo_rrt_create.argtypes = [C.c_void_p, C.POINTER(RrtCfg), c_dp, C.c_int]
+    L.sffo_rrt_destroy.argtypes = [C.c_void_p]
+    L.sffo_rrt_run.argtypes = [C.c_void_p, C.c_int]
+    L.sffo_rrt_get_stats.argtypes = [C.c_void_p, C.POINTER(RrtStats)]
+    L.sffo_rrt_get_nodes.argtypes = [C.c_void_p, c_dp, c_ip, c_ip, c_ip, c_ip, c_dp, c_dp]
+    L.sffo_rrt_get_links.argtypes = [C.c_void_p, c_ip, c_ip, c_ip, c_dp, C.c_int]
     _LIB = L
     return L
 
@@ -233,3 +255,52 @@ class Forest:
 
     def fingerprint(self):
         return lib().sffo_forest_fingerprint(self.h)
+
+
+class Rrt:
+    def __init__(self, world, roots, limits, dist_tree, sampling_dist, dim=6, optimize=False, goal=None,
+                 priority_bias=0.0, max_iterations=10000, seed=1, trig=None):
+        self.world = world
+        cfg = RrtCfg()
+        cfg.dim = dim
+        cfg.optimize = int(optimize)
+        cfg.has_goal = int(goal is not None)
+        if goal is not None:
+            cfg.goal = (C.c_double * 6)(*goal)
+        cfg.limits = (C.c_double * 6)(*limits)
+        cfg.dist_tree = dist_tree
+        cfg.sampling_dist = sampling_dist
+        cfg.priority_bias = priority_bias
+        cfg.max_iterations = max_iterations
+        cfg.seed = seed
+        cfg.trig = world.trig if trig is None else trig
+        roots = f64(roots).reshape(-1, 6)
+        self.h = lib().sffo_rrt_create(world.h, C.byref(cfg), dp(roots), len(roots))
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().sffo_rrt_destroy(self.h)
+            self.h = None
+
+    def run(self, max_iters=0):
+        lib().sffo_rrt_run(self.h, max_iters)
+
+    def stats(self):
+        s = RrtStats()
+        lib().sffo_rrt_get_stats(self.h, C.byref(s))
+        return s.as_dict()
+
+    def nodes(self):
+        n = self.stats()["n_nodes"]
+        pos = np.zeros((n, 6))
+        parent, tree, root_tree, it = (np.zeros(n, np.int32) for _ in range(4))
+        cost = np.zeros(n)
+        dpar = np.zeros(n)
+        lib().sffo_rrt_get_nodes(self.h, dp(pos), ip(parent), ip(tree), ip(root_tree), ip(it), dp(cost), dp(dpar))
+        return dict(pos=pos, parent=parent, tree=tree, root_tree=root_tree, iter=it, cost=cost, dpar=dpar)
+
+    def links(self, cap=1 << 16):
+        t, n1, n2 = (np.zeros(cap, np.int32) for _ in range(3))
+        d = np.zeros(cap)
+        k = min(lib().sffo_rrt_get_links(self.h, ip(t), ip(n1), ip(n2), dp(d), cap), cap)
+        return dict(tree=t[:k].copy(), n1=n1[:k].copy(), n2=n2[:k].copy(), dist=d[:k].copy())

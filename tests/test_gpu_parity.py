@@ -274,3 +274,36 @@ def test_sharded_rounds_equal_single_gpu(S, name, world, wave, optimize):
         f.close()
     for c in ctxs:
         c.close()
+
+
+@pytest.mark.parametrize("name,optimize,n_roots,goal,bias,iters", [
+    ("triang", False, 4, False, 0.0, 1500),        # Multi-T-RRT: trees merge until one is left
+    ("triang", True, 1, True, 0.1, 600),           # RRT* towards a goal with goal bias
+    ("dense2d", False, 3, False, 0.0, 800),        # 2-D
+    ("building", True, 1, False, 0.0, 500),        # RRT* rewiring on the big map
+    ("dense3d_coarse", False, 5, False, 0.0, 700),
+])
+def test_rrt_identical(S, ctx, name, optimize, n_roots, goal, bias, iters):
+    """RapidExpTree (src/rrt.h): nodes, parents, merged tree membership, links and the
+    reference-equivalent counters equal the oracle's."""
+    sc, w = load_world(ctx, name)
+    pts = sc["xml_points"] if sc["xml_points"] is not None else common.free_roots(w.collide, sc["limits"], 6, seed=3,
+                                                                                 dim=sc["dim"])
+    roots = pts[:n_roots]
+    g = pts[4] if goal else None
+    kw = dict(dist_tree=sc["dist_tree"], sampling_dist=sc["sampling_dist"], dim=sc["dim"], optimize=optimize, goal=g,
+              priority_bias=bias, max_iterations=iters, seed=3)
+    ro = O.Rrt(w, roots, sc["limits"], **kw)
+    ro.run()
+    rg = S.Rrt(ctx, roots, sc["limits"], **kw)
+    rg.run()
+    so, sg = ro.stats(), rg.stats()
+    for k in so:
+        assert so[k] == sg[k], (k, so[k], sg[k])
+    no, ng = ro.nodes(), rg.nodes()
+    for k in no:
+        assert np.array_equal(no[k], ng[k]), k
+    lo, lg = ro.links(), rg.links()
+    for k in lo:
+        assert np.array_equal(lo[k], lg[k]), k
+    assert so["n_nodes"] > 30
