@@ -148,7 +148,8 @@ struct Forest {
   std::vector<int> frontier, closed;
   std::map<std::pair<int, int>, std::vector<Border>> borders;
   std::vector<int> connected;
-  int num_roots = 0;
+  int num_roots = 0;   // Problem::GetNumRoots(): roots + the goal tree
+  int goal_node = -1;
   int iter = 0;
   bool solved = false, empty_frontier = false;
   sffgpu_forest_stats st{};

@@ -41,13 +41,12 @@ static double ms_since(Clock::time_point t0) {
 Forest::Forest(Ctx* c, const sffgpu_forest_cfg& cf, const double* roots6, int n_roots) : ctx(c), cfg(cf) {
   if (cfg.wave < 1) cfg.wave = 1;
   if (cfg.dim != 2 && cfg.dim != 6) throw HipError{"forest: dim must be 2 or 6"};
-  if (cfg.has_goal) throw HipError{"forest: single-goal mode (Problem::hasGoal) is not implemented on the GPU path yet"};
   if (cfg.world < 1) cfg.world = 1;
   if (cfg.rank < 0 || cfg.rank >= cfg.world) throw HipError{"forest: rank outside [0, world)"};
   if (n_roots < 1) throw HipError{"forest: at least one root"};
   if (!c->have_env || !c->have_robot) throw HipError{"forest: upload ENV and ROBOT meshes first"};
   rng.reseed(cfg.seed);
-  num_roots = n_roots;
+  num_roots = n_roots + (cfg.has_goal ? 1 : 0);
   trees.resize(num_roots);
   ctx->store_reset(std::max(cfg.node_budget, 4096) + cfg.wave + 64);
   std::vector<int32_t> tids(n_roots);
@@ -63,6 +62,11 @@ Forest::Forest(Ctx* c, const sffgpu_forest_cfg& cf, const double* roots6, int n_
     ctx->grid_setup(cfg.limits, cell);
   }
   ctx->store_append(roots6, tids.data(), n_roots);
+  if (cfg.has_goal) {                          // src/forest.h:91-109: searched like any tree, never expanded
+    goal_node = add_node(cfg.goal, n_roots, -1, 0, 0, 0);
+    int32_t gt = n_roots;
+    ctx->store_append(cfg.goal, &gt, 1);
+  }
   ctx->grid_insert_new();
   memset(&st, 0, sizeof st);
   knn_r = 2.5 * cfg.sampling_dist;
@@ -303,6 +307,7 @@ void Forest::round_begin() {
   sffk::ClassifyArgs ca{};
   ca.n = n; ca.N0 = Tb; ca.cap = CAP; ca.nbcap = NBCAP; ca.rank = cfg.rank; ca.world = cfg.world;
   ca.items_cap = items_cap;
+  ca.goal_id = goal_node;
   ca.dist_tree = cfg.dist_tree;
   ca.newpos = d_pos;
   ca.in_lim = d_lim;
@@ -404,6 +409,7 @@ void Forest::round_begin() {
         const Nb& nb = cd.nbs[f.slot - 1];
         const double* npos = nb.id >= 0 ? nodes[nb.id].pos : cands[-1 - nb.id].pos;
         if (nb.same_tree) { fix_a.insert(fix_a.end(), npos, npos + 6); fix_b.insert(fix_b.end(), cd.pos, cd.pos + 6); }
+        else if (nb.id == goal_node && goal_node >= 0) { fix_a.insert(fix_a.end(), cd.pos, cd.pos + 6); fix_b.insert(fix_b.end(), npos, npos + 6); }
         else { fix_a.insert(fix_a.end(), ex, ex + 6); fix_b.insert(fix_b.end(), npos, npos + 6); }
       }
     }
@@ -488,6 +494,7 @@ void Forest::round_begin() {
       for (Nb& nb : all) {
         const double* npos = nb.id >= 0 ? nodes[nb.id].pos : cands[-1 - nb.id].pos;
         if (nb.same_tree) nb.seg = add_seg(npos, cd.pos);     // isPathFree(neighbour, newPoint)  :276
+        else if (nb.id == goal_node && goal_node >= 0) nb.seg = add_seg(cd.pos, npos);  // isPathFree(newPoint, goal) :287
         else nb.seg = add_seg(ex.pos, npos);                  // isPathFree(expanded, neighbour)  :288
         cd.nbs.push_back(nb);
         if (!nb.same_tree && nb.id >= 0) break;
@@ -529,6 +536,7 @@ void Forest::round_begin() {
       for (const Nb& nb : cd.nbs) {
         if (nb.id < 0) continue;
         if (nb.same_tree) { if (nb.free) { rejected = true; break; } }
+        else if (cfg.has_goal && nb.id == goal_node) { if (!nb.free) { rejected = true; break; } }
         else { rejected = true; break; }
       }
       if (!rejected) maybe.push_back(i);
@@ -739,6 +747,10 @@ void Forest::round_commit(const int32_t* all, const int32_t* counts, int world) 
   for (int i = 0; i < n; ++i) {
     Cand& cd = cands[i];
     Slot& sl = slots[cd.slot];
+    if (solved) {          // goal reached by an earlier slot of this round: the remaining slots are not run
+      iter = iter0 + i;
+      break;
+    }
     const unsigned iteration = (unsigned)(iter0 + i + 1);
     if (!cd.in_lim) continue;                                  // :246 !result
     if (!cd.answered) throw HipError{"forest: a candidate has no answer record (missing rank?)"};
@@ -758,11 +770,20 @@ void Forest::round_commit(const int32_t* all, const int32_t* counts, int world) 
         nb_node = cands[-1 - nb.id].accepted_id;
         if (nb_node < 0) continue;                             // that sample never became a node
       }
-      st.path_free_calls += 1;
-      st.collide_calls += calls(nb.fh, nb.ns);
       if (nb.same_tree) {
+        st.path_free_calls += 1;
+        st.collide_calls += calls(nb.fh, nb.ns);
         if (nb.free) { reject = true; break; }                 // :276-280 overcrowded
+      } else if (cfg.has_goal) {
+        if (nb_node == goal_node) {                            // :286-287 goal reached?
+          st.path_free_calls += 1;
+          st.collide_calls += calls(nb.fh, nb.ns);
+          solved = nb.free;
+        }
+        if (!solved) { reject = true; break; }                 // :296-299
       } else {
+        st.path_free_calls += 1;
+        st.collide_calls += calls(nb.fh, nb.ns);
         if (nb.free) {                                         // :288-294
           std::vector<Border>& bp = border(nb.tree, mine);
           int a = std::min(nb_node, expanded), b = std::max(nb_node, expanded);
@@ -823,6 +844,10 @@ void Forest::round_commit(const int32_t* all, const int32_t* counts, int world) 
     cd.accepted_id = id;
     frontier.push_back(id);                                    // :365
     nodes[id].on_frontier = true;
+    if (solved) {                                              // :369-372
+      double gd = sffg::dist6(cd.pos, cfg.goal);
+      border(num_roots - 1, mine).push_back({std::min(id, goal_node), std::max(id, goal_node), nodes[id].d_root + gd});
+    }
     sl.failing = false;
     app_pos.insert(app_pos.end(), cd.pos, cd.pos + 6);
     app_tree.push_back(mine);

@@ -103,6 +103,7 @@ void launch_collide_poses(hipStream_t s, const EnvView& env, const RobotView& ro
 // arguments of k_classify (one thread per sample of the round)
 struct ClassifyArgs {
   int n, N0, cap, nbcap, rank, world, items_cap;
+  int goal_id;              // store id of the goal node, -1 without a goal (src/forest.h:286-287)
   double dist_tree;
   const double* newpos;     // n x 6
   const uint8_t* in_lim;    // n

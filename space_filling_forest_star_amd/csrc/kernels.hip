@@ -610,6 +610,7 @@ __global__ __launch_bounds__(256) void k_classify(ClassifyArgs A) {
         double* sa = A.seg_a + 6 * ((size_t)i * stride + 1 + nnb);
         double* sb = A.seg_b + 6 * ((size_t)i * stride + 1 + nnb);
         if (same) { for (int q = 0; q < 6; ++q) { sa[q] = nbp[q]; sb[q] = np[q]; } }     // isPathFree(neighbour, newPoint) :276
+        else if (id == A.goal_id) { for (int q = 0; q < 6; ++q) { sa[q] = np[q]; sb[q] = nbp[q]; } }  // isPathFree(newPoint, goal) :287
         else      { for (int q = 0; q < 6; ++q) { sa[q] = exp[q]; sb[q] = nbp[q]; } }    // isPathFree(expanded, neighbour) :288
         ++nnb;
         if (!same && id < A.N0) break;

@@ -136,7 +136,7 @@ def test_radius_and_knn_exact(ctx):
     assert np.all(cnt == want)
 
 
-def run_pair(S, ctx, name, wave, iters, seed, n_roots=5, budget=0, optimize=False):
+def run_pair(S, ctx, name, wave, iters, seed, n_roots=5, budget=0, optimize=False, goal_idx=None):
     sc, w = load_world(ctx, name)
     if sc["xml_points"] is not None:
         roots = sc["xml_points"][:n_roots]
@@ -144,6 +144,10 @@ def run_pair(S, ctx, name, wave, iters, seed, n_roots=5, budget=0, optimize=Fals
         roots = common.free_roots(w.collide, sc["limits"], n_roots, seed=seed, dim=sc["dim"])
     kw = dict(dist_tree=sc["dist_tree"], sampling_dist=sc["sampling_dist"], dim=sc["dim"], max_iterations=iters,
               node_budget=budget, wave=wave, seed=seed, optimize=optimize)
+    if goal_idx is not None:   # a goal a few steps away from the first root (free in triang / building)
+        g = roots[0].copy()
+        g[:3] += np.array(goal_idx, dtype=np.float64)
+        kw["goal"] = g
     fo = O.Forest(w, roots, sc["limits"], **kw)
     fo.run()
     fg = S.Forest(ctx, roots, sc["limits"], **kw)
@@ -203,6 +207,16 @@ def test_building_map_collision(ctx, name):
     assert_same_forest(fo, fg)
 
 
+@pytest.mark.parametrize("name,wave,n_roots,optimize", [("triang", 1, 1, False), ("triang", 64, 2, False),
+                                                         ("triang", 32, 1, True), ("building", 128, 1, False)])
+def test_forest_single_goal_mode(S, ctx, name, wave, n_roots, optimize):
+    """Problem::hasGoal (src/forest.h:91-109, :286-287, :369-372): the goal is a one-node tree that is
+    searched but never expanded; reaching it ends the run."""
+    fo, fg = run_pair(S, ctx, name, wave, 20000, seed=8, n_roots=n_roots, optimize=optimize, goal_idx=[12, 8, 5])
+    assert_same_forest(fo, fg)
+    assert fo.stats()["solved"] == 1 and fo.stats()["n_borders"] >= 1
+
+
 def test_forest_node_budget_and_seeds(S, ctx):
     for seed in (1, 3):
         fo, fg = run_pair(S, ctx, "dense3d", 512, 10**6, seed=seed, n_roots=10, budget=6000)
@@ -227,8 +241,6 @@ def test_forest_errors(S, ctx):
     roots = common.free_roots(w.collide, sc["limits"], 3)
     with pytest.raises(S.SffGpuError):
         S.Forest(ctx, roots, sc["limits"], 18.0, 14.0, dim=3)
-    with pytest.raises(S.SffGpuError):
-        S.Forest(ctx, roots, sc["limits"], 18.0, 14.0, goal=[1, 2, 3, 0, 0, 0])
     with pytest.raises(S.SffGpuError):
         S.Forest(ctx, roots, sc["limits"], 18.0, 14.0, rank=2, world=2)
 
