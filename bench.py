@@ -105,6 +105,17 @@ def main():
         sweeps = s1["sweeps"] - s0["sweeps"]
         sweep_nodes = s1["sweep_nodes"] - s0["sweep_nodes"]
         achieved = (24.0 * sweep_nodes / (sweep_ms * 1e-3)) / 1e9 if sweep_ms > 0 else 0.0
+        # HBM-side bytes per neighbour query from the committed PMC summary (separate rocprofv3 --pmc
+        # passes of this command; FETCH_SIZE doubled per MI355X_MICROARCH.md, gather pattern uncalibrated)
+        traffic = None
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r1c_bench_pmc_summary.json")))
+            kib = 0.0
+            for k in ("sffk::k_grid_query", "sffk::k_sweep"):
+                kib += 2.0 * pm["FETCH_SIZE"][k]["avg_KiB_per_launch"] + pm["WRITE_SIZE"][k]["avg_KiB_per_launch"]
+            traffic = kib * 1024.0
+        except Exception:
+            traffic = None
         out = {
             "metric": "accepted node expansions/sec + collision checks/sec, dense_3D 6-DoF",
             "value": acc / elapsed,
@@ -134,9 +145,13 @@ def main():
                               "sample_kernel": s1["sample_ms"] - s0["sample_ms"],
                               "host_logic": s1["host_ms"] - s0["host_ms"]},
             "roofline": {
-                "bound": "hbm", "kernel": "sffk::k_sweep",
+                # neighbour query of one round = k_grid_query (permanent nodes) + k_sweep (the round's own
+                # samples), timed together with HIP events on the library's launch stream.  Algorithmic
+                # bytes = 24 B x nodes the query has to cover; the grid touches far fewer
+                # bytes than that, see `traffic` (rocprofv3 PMC pass of this same command, profiles/).
+                "bound": "hbm", "kernel": "sffk::k_grid_query + sffk::k_sweep (round temporaries)",
                 "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                "traffic": None,
+                "traffic": traffic,
                 "launches": int(sweeps), "avg_launch_us": 1e3 * sweep_ms / max(1, sweeps),
                 "avg_nodes_per_launch": sweep_nodes / max(1, sweeps),
                 "avg_queries_per_launch": (s1["sweep_queries"] - s0["sweep_queries"]) / max(1, sweeps),
