@@ -1,0 +1,91 @@
+// forest.h — source-compatible SpaceForest<T,R> (reference src/forest.h:31-54): same constructor and
+// Solve(); the main loop (:122-202) runs inside libsffgpu as waves of frontier slots on the GPU, the
+// post-processing (:203-235) stays here.
+#pragma once
+#include <cstring>
+
+#include "problemStruct.h"
+
+#ifndef SFF_COMPAT_WAVE
+#define SFF_COMPAT_WAVE 4096
+#endif
+
+template <class T, class R = Point<T>>
+class SpaceForest : public Solver<T, R> {
+ public:
+  SpaceForest(Problem<T>& problem) : Solver<T, R>(problem) {
+    if (this->usePriority) {   // src/heap.h priority frontier: host-only mode, not in this build yet
+      std::cout << "SpaceForest: priorityBias != 0 (priority frontier) is not implemented in this build\n";
+      std::exit(1);
+    }
+  }
+
+  void Solve() override {
+    Problem<T>& P = this->problem;
+    P.environment.upload();
+    sffgpu_forest_cfg cfg;
+    std::memset(&cfg, 0, sizeof cfg);
+    cfg.dim = P.dimension;
+    cfg.optimize = P.optimal;
+    cfg.has_goal = P.hasGoal;
+    P.goal.toArray(cfg.goal);
+    const Range<T>& l = P.environment.limits;
+    const double lim[6] = {l.minX, l.maxX, l.minY, l.maxY, l.minZ, l.maxZ};
+    std::memcpy(cfg.limits, lim, sizeof lim);
+    cfg.dist_tree = this->treeDistance;
+    cfg.sampling_dist = Node<T, R>::SamplingDistance;
+    cfg.threshold_misses = Node<T, R>::ThresholdMisses;
+    cfg.max_iterations = P.maxIterations;
+    const char* w = std::getenv("SFF_WAVE");
+    cfg.wave = w ? std::atoi(w) : SFF_COMPAT_WAVE;
+    const char* s = std::getenv("SFF_SEED");   // the reference seeds from the clock (src/randGen.h:52-55)
+    cfg.seed = s ? std::strtoull(s, nullptr, 10)
+                 : (uint64_t)std::chrono::high_resolution_clock::now().time_since_epoch().count();
+    cfg.rank = 0;
+    cfg.world = 1;
+    std::vector<double> roots;
+    for (const Point<T>& p : P.roots) {
+      double a[6];
+      p.toArray(a);
+      roots.insert(roots.end(), a, a + 6);
+    }
+    sffgpu_forest* f = nullptr;
+    sff_compat::check(sffgpu_forest_create(sff_compat::gpu(), &cfg, roots.data(), (int)P.roots.size(), &f), "forest");
+
+    auto startingTime = std::chrono::high_resolution_clock::now();   // :117
+    sff_compat::check(sffgpu_forest_run(f, 0), "forest run");
+    auto stopTime = std::chrono::high_resolution_clock::now();       // :203
+
+    sffgpu_forest_stats st;
+    sffgpu_forest_get_stats(f, &st);
+    const int n = st.n_nodes;
+    std::vector<double> pos((size_t)n * 6), cost(n), dpar(n);
+    std::vector<int32_t> parent(n), tree(n), iter(n);
+    sffgpu_forest_get_nodes(f, pos.data(), parent.data(), tree.data(), iter.data(), cost.data(), dpar.data());
+    this->fillNodes(n, pos.data(), parent.data(), tree.data(), iter.data(), cost.data(), dpar.data());
+    this->numTrees = st.n_trees;
+    this->neighboringMatrix.assign((size_t)st.n_trees * st.n_trees, 0.0);
+    std::vector<int32_t> conn(st.n_trees);
+    int nc = sffgpu_forest_paths(f, this->neighboringMatrix.data(), conn.data(), st.n_trees);   // getPaths + getAllPaths
+    this->connectedTrees.assign(conn.begin(), conn.begin() + nc);
+    this->plans.assign((size_t)st.n_trees * st.n_trees, {});
+    for (int i = 0; i < st.n_trees; ++i)
+      for (int j = i + 1; j < st.n_trees; ++j) {
+        int len = sffgpu_forest_path_plan(f, i, j, nullptr, 0);
+        if (len <= 0) continue;
+        std::vector<int32_t> ids(len);
+        sffgpu_forest_path_plan(f, i, j, ids.data(), len);
+        this->plans[(size_t)i * st.n_trees + j].assign(ids.begin(), ids.end());
+      }
+    sffgpu_forest_destroy(f);
+
+    // :114-116, :207-235 — same order of outputs as the reference
+    if (SaveGoals <= P.saveOptions) this->saveCities(P.fileNames[SaveGoals]);
+    if (SaveTree <= P.saveOptions) this->saveTrees(P.fileNames[SaveTree]);
+    if (SaveRaw <= P.saveOptions) this->savePaths(P.fileNames[SaveRaw]);
+    if (P.smoothing) std::cout << "SpaceForest: path smoothing is not implemented in this build; raw paths kept\n";
+    if (SaveParams <= P.saveOptions) this->saveParams(P.fileNames[SaveParams], st.iterations, st.solved != 0, stopTime - startingTime);
+    if (SaveTSP <= P.saveOptions) this->saveTsp(P.fileNames[SaveTSP]);
+    if (SaveFrontiers <= P.saveOptions) std::cout << "SpaceForest: frontier dump is not implemented in this build\n";
+  }
+};

@@ -1,0 +1,60 @@
+// rrt.h — source-compatible RapidExpTree<T,R> (reference src/rrt.h:25-44) on top of libsffgpu's
+// RRT / RRT* / Multi-T-RRT session.
+#pragma once
+#include <cstring>
+
+#include "problemStruct.h"
+
+template <class T, class R = Point<T>>
+class RapidExpTree : public Solver<T, R> {
+ public:
+  RapidExpTree(Problem<T>& problem) : Solver<T, R>(problem) {}
+
+  void Solve() override {
+    Problem<T>& P = this->problem;
+    P.environment.upload();
+    sffgpu_rrt_cfg cfg;
+    std::memset(&cfg, 0, sizeof cfg);
+    cfg.dim = P.dimension;
+    cfg.optimize = P.optimal;
+    cfg.has_goal = P.hasGoal;
+    P.goal.toArray(cfg.goal);
+    const Range<T>& l = P.environment.limits;
+    const double lim[6] = {l.minX, l.maxX, l.minY, l.maxY, l.minZ, l.maxZ};
+    std::memcpy(cfg.limits, lim, sizeof lim);
+    cfg.dist_tree = this->treeDistance;
+    cfg.sampling_dist = Node<T, R>::SamplingDistance;
+    cfg.priority_bias = P.priorityBias;
+    cfg.max_iterations = P.maxIterations;
+    const char* s = std::getenv("SFF_SEED");
+    cfg.seed = s ? std::strtoull(s, nullptr, 10)
+                 : (uint64_t)std::chrono::high_resolution_clock::now().time_since_epoch().count();
+    std::vector<double> roots;
+    for (const Point<T>& p : P.roots) {
+      double a[6];
+      p.toArray(a);
+      roots.insert(roots.end(), a, a + 6);
+    }
+    sffgpu_rrt* r = nullptr;
+    sff_compat::check(sffgpu_rrt_create(sff_compat::gpu(), &cfg, roots.data(), (int)P.roots.size(), &r), "rrt");
+    auto startingTime = std::chrono::high_resolution_clock::now();   // src/rrt.h:90
+    sff_compat::check(sffgpu_rrt_run(r, 0), "rrt run");
+    auto stopTime = std::chrono::high_resolution_clock::now();       // :100
+    sffgpu_rrt_stats st;
+    sffgpu_rrt_get_stats(r, &st);
+    const int n = st.n_nodes;
+    std::vector<double> pos((size_t)n * 6), cost(n), dpar(n);
+    std::vector<int32_t> parent(n), tree(n), root(n), iter(n);
+    sffgpu_rrt_get_nodes(r, pos.data(), parent.data(), tree.data(), root.data(), iter.data(), cost.data(), dpar.data());
+    this->fillNodes(n, pos.data(), parent.data(), root.data(), iter.data(), cost.data(), dpar.data());
+    this->numTrees = P.GetNumRoots();
+    this->neighboringMatrix.assign((size_t)this->numTrees * this->numTrees, 1.7976931348623157e308);
+    this->plans.assign((size_t)this->numTrees * this->numTrees, {});
+    sffgpu_rrt_destroy(r);
+    if (SaveGoals <= P.saveOptions) this->saveCities(P.fileNames[SaveGoals]);
+    if (SaveTree <= P.saveOptions) this->saveTrees(P.fileNames[SaveTree]);
+    if (SaveRaw <= P.saveOptions || SaveTSP <= P.saveOptions)
+      std::cout << "RapidExpTree: path extraction (src/rrt.h:324-352) is not implemented in this build\n";
+    if (SaveParams <= P.saveOptions) this->saveParams(P.fileNames[SaveParams], st.iterations, st.solved != 0, stopTime - startingTime);
+  }
+};

@@ -128,6 +128,13 @@ int sffgpu_forest_get_nodes(sffgpu_forest* f, double* pos6, int32_t* parent, int
 int sffgpu_forest_get_borders(sffgpu_forest* f, int32_t* tree_a, int32_t* tree_b, int32_t* node1, int32_t* node2,
                               double* dist, int cap);
 uint64_t sffgpu_forest_fingerprint(sffgpu_forest* f);
+/* Post-loop path extraction: SpaceForest::getPaths (src/forest.h:420-462) + Solver::getAllPaths
+ * (src/problemStruct.h:184-253).  dist = n_trees x n_trees matrix of root-to-root path costs
+ * (DBL_MAX where there is none) = Solver::neighboringMatrix; connected = Solver::connectedTrees
+ * (tree ids); returns their count.  path_plan copies the node ids of one pair's path (lower node
+ * id first, like DistanceHolder) and returns its length. */
+int sffgpu_forest_paths(sffgpu_forest* f, double* dist, int32_t* connected, int cap_connected);
+int sffgpu_forest_path_plan(sffgpu_forest* f, int i, int j, int32_t* node_ids, int cap);
 
 /* ---------------------------------------------------------------- RRT / RRT* / Multi-T-RRT
  * RapidExpTree<T,R> (src/rrt.h:25-44): constructor :47-83, Solve() :86-99, expandNode :128-322

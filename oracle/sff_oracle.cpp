@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstring>
 #include <fstream>
+#include <limits>
 #include <map>
 #include <string>
 #include <unordered_map>
@@ -760,6 +761,91 @@ struct Forest {
     return max_conn;
   }
 
+
+  // ---- path extraction (post-loop; src/forest.h:420-462 getPaths, src/problemStruct.h:184-253 getAllPaths)
+  struct Holder {            // DistanceHolder, src/primitives.h:598-655
+    int n1 = -1, n2 = -1;
+    double dist = std::numeric_limits<double>::max();
+    std::vector<int> plan;
+    bool exists() const { return n1 >= 0; }
+  };
+  std::vector<Holder> nm;    // neighboringMatrix (symmetric, num_roots x num_roots)
+  Holder& NM(int i, int j) { return nm[(size_t)std::min(i, j) * num_roots + std::max(i, j)]; }
+  bool is_root(int n) const { return nodes[n].d_root == 0; }   // Node::IsRoot, src/primitives.h:476-478
+
+  void get_paths() {
+    nm.assign((size_t)num_roots * num_roots, Holder());
+    for (int i = 0; i < num_roots; ++i)
+      for (int j = i + 1; j < num_roots; ++j) {
+        auto it = borders.find({i, j});
+        if (it == borders.end() || it->second.empty()) continue;
+        double best = -1;
+        for (Border& b : it->second) {
+          b.dist = nodes[b.n1].d_root + nodes[b.n2].d_root + distance6(nodes[b.n1].pos, nodes[b.n2].pos);  // UpdateDistance
+          if (best == -1 || b.dist < best - TOLERANCE) {
+            best = b.dist;
+            Holder h;
+            h.n1 = b.n1; h.n2 = b.n2; h.dist = b.dist;
+            NM(i, j) = h;
+          }
+        }
+        Holder& h = NM(i, j);
+        std::vector<int> front;
+        int n = h.n1;
+        front.push_back(n);
+        while (!is_root(n)) { n = nodes[n].parent; front.push_back(n); }
+        std::reverse(front.begin(), front.end());
+        h.plan = front;
+        n = h.n2;
+        h.plan.push_back(n);
+        while (!is_root(n)) { n = nodes[n].parent; h.plan.push_back(n); }
+        if (cfg.optimize)
+          h.dist = nodes[h.n1].d_root + nodes[h.n2].d_root + distance6(nodes[h.n1].pos, nodes[h.n2].pos);
+      }
+  }
+  double plan_length(const std::vector<int>& plan) const {   // Solver::computeDistance, src/problemStruct.h:170-181
+    double d = 0;
+    for (size_t k = 1; k < plan.size(); ++k) d += distance6(nodes[plan[k - 1]].pos, nodes[plan[k]].pos);
+    return d;
+  }
+  Holder make_holder(int a, int b, double dist, std::vector<int> plan) {  // DistanceHolder(first, second, dist, plan)
+    Holder h;
+    h.dist = dist;
+    if (a < b) { h.n1 = a; h.n2 = b; h.plan = plan; }
+    else { h.n1 = b; h.n2 = a; std::reverse(plan.begin(), plan.end()); h.plan = plan; }
+    return h;
+  }
+  void get_all_paths() {
+    const int nc = (int)connected.size();
+    for (int k = 0; k < nc; ++k) {
+      int id3 = connected[k];
+      for (int i = 0; i < nc; ++i) {
+        int id1 = connected[i];
+        if (i == k || !NM(id1, id3).exists()) continue;
+        for (int j = 0; j < nc; ++j) {
+          int id2 = connected[j];
+          if (i == j || !NM(id2, id3).exists()) continue;
+          const Holder h1 = NM(id1, id3), h2 = NM(id2, id3);
+          std::vector<int> plan1 = h1.plan, plan2 = h2.plan;
+          int node1, node2;
+          if (nodes[h1.n1].tree == id1) node1 = h1.n1; else { node1 = h1.n2; std::reverse(plan1.begin(), plan1.end()); }
+          if (nodes[h2.n1].tree == id2) node2 = h2.n1; else { node2 = h2.n2; std::reverse(plan2.begin(), plan2.end()); }
+          int last = -1;
+          while (!plan1.empty() && !plan2.empty() && plan1.back() == plan2.back()) {
+            last = plan1.back();
+            plan1.pop_back();
+            plan2.pop_back();
+          }
+          std::vector<int> fin(plan1.begin(), plan1.end());
+          fin.push_back(last);
+          for (size_t q = plan2.size(); q-- > 0;) fin.push_back(plan2[q]);
+          double d = plan_length(fin);
+          if (d < NM(id1, id2).dist - TOLERANCE) NM(id1, id2) = make_holder(node1, node2, d, fin);
+        }
+      }
+    }
+  }
+
   bool budget_hit() const { return cfg.node_budget > 0 && (int)nodes.size() >= cfg.node_budget; }
 
   // src/forest.h:122-202, generalised to waves of cfg.wave slots; wave == 1 is the
@@ -1149,6 +1235,23 @@ int sffo_forest_get_borders(sffo_forest* h, int32_t* ta, int32_t* tb, int32_t* n
       ++k;
     }
   return k;
+}
+/* post-loop path extraction: dist = num_roots x num_roots matrix (max double where no path); returns num_roots */
+int sffo_forest_paths(sffo_forest* h, double* dist) {
+  Forest& f = h->f;
+  if (!f.solved && !f.cfg.has_goal) f.solved = f.max_connected() == f.num_roots; else f.max_connected();
+  f.get_paths();
+  f.get_all_paths();
+  for (int i = 0; i < f.num_roots; ++i)
+    for (int j = 0; j < f.num_roots; ++j) dist[(size_t)i * f.num_roots + j] = i == j ? 0.0 : f.NM(i, j).dist;
+  return f.num_roots;
+}
+int sffo_forest_path_plan(sffo_forest* h, int i, int j, int32_t* node_ids, int cap) {
+  Forest& f = h->f;
+  if (f.nm.empty() || i == j) return 0;
+  const auto& p = f.NM(i, j).plan;
+  for (size_t k = 0; k < p.size() && (int)k < cap; ++k) node_ids[k] = p[k];
+  return (int)p.size();
 }
 uint64_t sffo_forest_fingerprint(sffo_forest* h) {
   uint64_t x = 1469598103934665603ULL;

@@ -106,6 +106,10 @@ void sffo_forest_get_nodes(sffo_forest*, double* pos6, int32_t* parent, int32_t*
                            double* cost, double* dpar);
 /* borders: per entry tree_a, tree_b, node1, node2, distance; returns count (<= cap) */
 int sffo_forest_get_borders(sffo_forest*, int32_t* ta, int32_t* tb, int32_t* n1, int32_t* n2, double* dist, int cap);
+/* post-loop getPaths + getAllPaths (src/forest.h:420-462, src/problemStruct.h:184-253): pairwise path cost
+ * matrix (num_roots x num_roots, max double = no path) and the node-id plan of one pair */
+int sffo_forest_paths(sffo_forest*, double* dist);
+int sffo_forest_path_plan(sffo_forest*, int i, int j, int32_t* node_ids, int cap);
 /* FNV-1a over (parent, tree, iter, pos bits) of all nodes — cheap topology fingerprint */
 uint64_t sffo_forest_fingerprint(sffo_forest*);
 

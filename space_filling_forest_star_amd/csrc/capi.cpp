@@ -186,6 +186,27 @@ int sffgpu_forest_get_borders(sffgpu_forest* f, int32_t* ta, int32_t* tb, int32_
 }
 uint64_t sffgpu_forest_fingerprint(sffgpu_forest* f) { return f ? f->f->fingerprint() : 0; }
 
+int sffgpu_forest_paths(sffgpu_forest* f, double* dist, int32_t* connected, int cap_connected) {
+  if (!f || !dist) return SFFGPU_ERR_ARG;
+  Forest& F = *f->f;
+  F.max_connected();                 // Solver::connectedTrees as Solve() leaves it (src/forest.h:196-206)
+  F.get_paths();
+  F.get_all_paths();
+  for (int i = 0; i < F.num_roots; ++i)
+    for (int j = 0; j < F.num_roots; ++j) dist[(size_t)i * F.num_roots + j] = i == j ? 0.0 : F.NM(i, j).dist;
+  if (connected)
+    for (size_t k = 0; k < F.connected.size() && (int)k < cap_connected; ++k) connected[k] = F.connected[k];
+  return (int)F.connected.size();
+}
+int sffgpu_forest_path_plan(sffgpu_forest* f, int i, int j, int32_t* node_ids, int cap) {
+  if (!f || i < 0 || j < 0 || i >= f->f->num_roots || j >= f->f->num_roots) return SFFGPU_ERR_ARG;
+  Forest& F = *f->f;
+  if (F.nm.empty() || i == j) return 0;
+  const std::vector<int>& p = F.NM(i, j).plan;
+  for (size_t k = 0; k < p.size() && (int)k < cap; ++k) node_ids[k] = p[k];
+  return (int)p.size();
+}
+
 int sffgpu_rrt_create(sffgpu_ctx* ctx, const sffgpu_rrt_cfg* cfg, const double* roots6, int n_roots, sffgpu_rrt** out) {
   if (!ctx || !cfg || !roots6 || n_roots <= 0 || !out) return SFFGPU_ERR_ARG;
   *out = nullptr;

@@ -200,6 +200,18 @@ struct Forest {
   double knn_r = 0;  // running guess of the k-nearest radius (SFF*)
   int hit_cap = 64, nb_cap = 15;  // device list capacities (env SFFGPU_TEST_HITCAP / _NBCAP shrink them in tests)
 
+  // post-loop path extraction (src/forest.h:420-462, src/problemStruct.h:184-253)
+  struct Holder {            // DistanceHolder (src/primitives.h:598-655)
+    int n1 = -1, n2 = -1;
+    double dist = 1.7976931348623157e308;
+    std::vector<int> plan;
+    bool exists() const { return n1 >= 0; }
+  };
+  std::vector<Holder> nm;    // Solver::neighboringMatrix
+  Holder& NM(int i, int j) { return nm[(size_t)(i < j ? i : j) * num_roots + (i < j ? j : i)]; }
+  void get_paths();
+  void get_all_paths();
+
   Forest(Ctx* c, const sffgpu_forest_cfg& cf, const double* roots6, int n_roots);
   int add_node(const double* pos, int tree, int parent, double dclosest, double droot, unsigned it);
   std::vector<Border>& border(int i, int j);

@@ -100,6 +100,8 @@ def lib():
     L.sffo_forest_get_stats.argtypes = [C.c_void_p, C.POINTER(ForestStats)]
     L.sffo_forest_get_nodes.argtypes = [C.c_void_p, c_dp, c_ip, c_ip, c_ip, c_dp, c_dp]
     L.sffo_forest_get_borders.argtypes = [C.c_void_p, c_ip, c_ip, c_ip, c_ip, c_dp, C.c_int]
+    L.sffo_forest_paths.argtypes = [C.c_void_p, c_dp]
+    L.sffo_forest_path_plan.argtypes = [C.c_void_p, C.c_int, C.c_int, c_ip, C.c_int]
     L.sffo_forest_fingerprint.restype = C.c_uint64
     L.sffo_forest_fingerprint.argtypes = [C.c_void_p]
     L.sffo_rrt_create.restype = C.c_void_p
@@ -255,6 +257,17 @@ class Forest:
 
     def fingerprint(self):
         return lib().sffo_forest_fingerprint(self.h)
+
+    def paths(self):
+        n = self.stats()["n_trees"]
+        d = np.zeros((n, n))
+        lib().sffo_forest_paths(self.h, dp(d))
+        return d
+
+    def plan(self, i, j, cap=1 << 16):
+        ids = np.zeros(cap, np.int32)
+        k = lib().sffo_forest_path_plan(self.h, i, j, ip(ids), cap)
+        return ids[:min(k, cap)].copy()
 
 
 class Rrt:

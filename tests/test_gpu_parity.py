@@ -217,6 +217,26 @@ def test_forest_single_goal_mode(S, ctx, name, wave, n_roots, optimize):
     assert fo.stats()["solved"] == 1 and fo.stats()["n_borders"] >= 1
 
 
+@pytest.mark.parametrize("optimize", [False, True])
+def test_path_costs_and_plans_match(S, ctx, optimize):
+    """getPaths + getAllPaths: the root-to-root cost matrix (what params.csv / the TSP file print) and the
+    node plans.  BASELINE north_star allows 1e-5 relative on path costs; both sides run the same fp64
+    expressions, so they are compared for equality."""
+    fo, fg = run_pair(S, ctx, "dense3d_coarse", 64, 6000, seed=2, optimize=optimize)
+    assert_same_forest(fo, fg)
+    do = fo.paths()
+    dg, conn = fg.paths()
+    assert len(conn) >= 3
+    finite = do < 1e300
+    assert finite.sum() > len(do)
+    assert np.array_equal(finite, dg < 1e300)
+    assert np.array_equal(do[finite], dg[finite])
+    assert np.allclose(do[finite], dg[finite], rtol=1e-5)
+    for i in range(len(do)):
+        for j in range(i + 1, len(do)):
+            assert np.array_equal(fo.plan(i, j), fg.plan(i, j))
+
+
 def test_forest_node_budget_and_seeds(S, ctx):
     for seed in (1, 3):
         fo, fg = run_pair(S, ctx, "dense3d", 512, 10**6, seed=seed, n_roots=10, budget=6000)
