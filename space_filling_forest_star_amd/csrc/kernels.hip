@@ -318,6 +318,65 @@ __device__ __forceinline__ bool plane_clear(const double* pl, const double* c, d
   return as > rr * pl[4] * (1.0 + 1e-9) + slack;
 }
 
+// conservative sphere / triangle test: true when the closest point of triangle T to the centre c is
+// farther than rr (plus slack).  The robot lies inside that sphere, so no robot triangle can touch T
+// and the exact 17-axis test would find a separating axis; the slack (1e-9 relative) dwarfs rounding.
+__device__ __forceinline__ bool tri_far(const double* T, const double* c, double rr) {
+  double ab[3], ac[3], ap[3];
+  for (int i = 0; i < 3; ++i) { ab[i] = T[3 + i] - T[i]; ac[i] = T[6 + i] - T[i]; ap[i] = c[i] - T[i]; }
+  double d1 = dot(ab, ap), d2 = dot(ac, ap);
+  double q[3];
+  bool done = false;
+  if (d1 <= 0 && d2 <= 0) { for (int i = 0; i < 3; ++i) q[i] = T[i]; done = true; }
+  double bp[3], cp[3], d3 = 0, d4 = 0, d5 = 0, d6 = 0;
+  if (!done) {
+    for (int i = 0; i < 3; ++i) bp[i] = c[i] - T[3 + i];
+    d3 = dot(ab, bp); d4 = dot(ac, bp);
+    if (d3 >= 0 && d4 <= d3) { for (int i = 0; i < 3; ++i) q[i] = T[3 + i]; done = true; }
+  }
+  if (!done) {
+    double vc = d1 * d4 - d3 * d2;
+    if (vc <= 0 && d1 >= 0 && d3 <= 0) {
+      double v = d1 / (d1 - d3);
+      for (int i = 0; i < 3; ++i) q[i] = T[i] + v * ab[i];
+      done = true;
+    }
+  }
+  if (!done) {
+    for (int i = 0; i < 3; ++i) cp[i] = c[i] - T[6 + i];
+    d5 = dot(ab, cp); d6 = dot(ac, cp);
+    if (d6 >= 0 && d5 <= d6) { for (int i = 0; i < 3; ++i) q[i] = T[6 + i]; done = true; }
+  }
+  if (!done) {
+    double vb = d5 * d2 - d1 * d6;
+    if (vb <= 0 && d2 >= 0 && d6 <= 0) {
+      double w = d2 / (d2 - d6);
+      for (int i = 0; i < 3; ++i) q[i] = T[i] + w * ac[i];
+      done = true;
+    }
+  }
+  if (!done) {
+    double va = d3 * d6 - d5 * d4;
+    if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) {
+      double w = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+      for (int i = 0; i < 3; ++i) q[i] = T[3 + i] + w * (T[6 + i] - T[3 + i]);
+      done = true;
+    }
+  }
+  if (!done) {
+    double vc = d1 * d4 - d3 * d2, vb = d5 * d2 - d1 * d6, va = d3 * d6 - d5 * d4;
+    double den = va + vb + vc;
+    if (!(den != 0)) return false;          // degenerate triangle: do not cull
+    double v = vb / den, w = vc / den;
+    for (int i = 0; i < 3; ++i) q[i] = T[i] + ab[i] * v + ac[i] * w;
+  }
+  double dd = 0, mag = 0;
+  for (int i = 0; i < 3; ++i) { double e = c[i] - q[i]; dd += e * e; mag += fabs(c[i]) + fabs(q[i]); }
+  if (!(dd == dd)) return false;            // NaN guard: never cull on garbage
+  double lim = rr * (1.0 + 1e-9) + 1e-9 * (mag + 1.0);
+  return dd > lim * lim;
+}
+
 // ------------------------------------------------------------------ pose kernel
 #define POSE_WAVES 4
 #define CAND_CAP 256
@@ -398,12 +457,13 @@ __global__ __launch_bounds__(64 * POSE_WAVES) void k_collide_poses(EnvView env, 
 
 // ------------------------------------------------------------------ segment kernel
 #define SEG_WAVES 4
+#define QUEUE_CAP 128
 
 // One wavefront per (edge, chunk of 64 consecutive samples): lane = sample.  The chunk's own swept
 // box gives a tight broad phase; the smallest colliding sample index of an edge is reduced with
 // atomicMin, so the answer does not depend on which chunk finishes first.
 __device__ void segment_chunk(const EnvView& env, const RobotView& rob, const double* rtri, int32_t* stack,
-                              int32_t* cand, const double* __restrict__ a6, const double* __restrict__ b6, int seg,
+                              int32_t* cand, int32_t* queue, const double* __restrict__ a6, const double* __restrict__ b6, int seg,
                               int chunk, int32_t* __restrict__ first_hit, int32_t* __restrict__ overflow_flag, int lane) {
   double a[6], b[6];
   for (int k = 0; k < 6; ++k) { a[k] = a6[6 * (size_t)seg + k]; b[k] = b6[6 * (size_t)seg + k]; }
@@ -438,12 +498,42 @@ __device__ void segment_chunk(const EnvView& env, const RobotView& rob, const do
   if (nc == 0) return;
   const double C[3] = {P[0] + rob.center[0], P[1] + rob.center[1], P[2] + rob.center[2]};
   const double rr = rob.radius * (1 + 1e-9) + 1e-9 * (fabs(C[0]) + fabs(C[1]) + fabs(C[2]) + 1);
-  unsigned long long hit_samples = 0;
+  // Narrow phase with compaction: (sample, robot triangle, candidate) triples that survive the cheap box
+  // tests are queued in LDS and the expensive exact test runs on 64 queued triples at a time, so every
+  // lane of an exact-test step does useful work.  minhit = smallest colliding sample of this chunk so far.
+  int qn = 0;
+  int minhit = 0x7fffffff;
+  auto flush = [&](int count) {
+    int v = 0x7fffffff;
+    if (lane < count) {
+      const int e = queue[lane];
+      const int sl = e & 63, r = (e >> 6) & 1023, k = e >> 16;
+      const int sidx = s0 + sl;
+      if (sidx < minhit) {
+        double S[3], Q[9];
+        edge_sample_pos(a, dir, parts, sidx, S);
+        // identity rotation: ((1*v0 + 0*v1) + 0*v2) + T == v0 + T
+        for (int vv = 0; vv < 3; ++vv)
+          for (int ax = 0; ax < 3; ++ax) Q[3 * vv + ax] = rtri[9 * r + 3 * vv + ax] + S[ax];
+        if (sat17(env.tri + 9 * (size_t)cand[k], Q)) v = sidx;
+      }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      int o = __shfl_xor(v, off);
+      v = o < v ? o : v;
+    }
+    if (v < minhit) minhit = v;
+    // keep the entries beyond `count` (at most 63 of them)
+    int keep = 0;
+    if (lane + count < qn) keep = queue[lane + count];
+    if (lane + count < qn) queue[lane] = keep;
+    qn -= count;
+  };
   for (int k = 0; k < nc; ++k) {
     const int t = cand[k];
     const double* bx = env.tri_box + 6 * (size_t)t;
     bool touch = false;
-    if (live) {
+    if (live && idx < minhit) {
       touch = true;
       for (int ax = 0; ax < 3; ++ax) {
         // exact bounds of v + P over the robot vertices (monotone rounding of one add)
@@ -451,33 +541,36 @@ __device__ void segment_chunk(const EnvView& env, const RobotView& rob, const do
         if (bx[ax] > rhi || rlo > bx[3 + ax]) touch = false;
       }
       if (touch && plane_clear(env.tri_plane + 5 * (size_t)t, C, rr)) touch = false;
+      if (touch && tri_far(env.tri + 9 * (size_t)t, C, rr)) touch = false;
     }
-    unsigned long long todo = __ballot(touch) & ~hit_samples;
-    if (hit_samples) todo &= (hit_samples & (~hit_samples + 1ULL)) - 1ULL;  // only samples before the first hit
-    // narrow phase: for each touching sample (ascending), all lanes test robot triangles
+    unsigned long long todo = __ballot(touch);
     while (todo) {
       const int sl = __ffsll((long long)todo) - 1;
       todo &= todo - 1;
+      if (s0 + sl >= minhit) break;   // later samples cannot improve the first hit
       double S[3];
       S[0] = __shfl(P[0], sl); S[1] = __shfl(P[1], sl); S[2] = __shfl(P[2], sl);
-      bool lane_hit = false;
       for (int r0 = 0; r0 < rob.n_tri; r0 += 64) {
         const int r = r0 + lane;
-        if (r < rob.n_tri && !lane_hit) {
+        bool ok = false;
+        if (r < rob.n_tri) {
           double Q[9];
-          // identity rotation: ((1*v0 + 0*v1) + 0*v2) + T == v0 + T
-          for (int v = 0; v < 3; ++v)
-            for (int ax = 0; ax < 3; ++ax) Q[3 * v + ax] = rtri[9 * r + 3 * v + ax] + S[ax];
-          if (tri_box_overlap(bx, bx + 3, Q)) lane_hit = sat17(env.tri + 9 * (size_t)t, Q);
+          for (int vv = 0; vv < 3; ++vv)
+            for (int ax = 0; ax < 3; ++ax) Q[3 * vv + ax] = rtri[9 * r + 3 * vv + ax] + S[ax];
+          ok = tri_box_overlap(bx, bx + 3, Q);
         }
-      }
-      if (__any(lane_hit)) {
-        hit_samples |= 1ULL << sl;
-        todo &= (1ULL << sl) - 1ULL;
+        const unsigned long long mm = __ballot(ok);
+        if (mm) {
+          const int before = __popcll(mm & ((1ULL << lane) - 1ULL));
+          if (ok) queue[qn + before] = sl | (r << 6) | (k << 16);
+          qn += __popcll(mm);
+          if (qn >= 64) flush(64);
+        }
       }
     }
   }
-  if (hit_samples && lane == 0) atomicMin(first_hit + seg, s0 + (__ffsll((long long)hit_samples) - 1));
+  while (qn > 0) flush(qn < 64 ? qn : 64);
+  if (minhit != 0x7fffffff && lane == 0) atomicMin(first_hit + seg, minhit);
 }
 
 // static work list (C-ABI batch entry point)
@@ -495,7 +588,8 @@ __global__ __launch_bounds__(64 * SEG_WAVES) void k_collide_segments(EnvView env
   __syncthreads();
   const int item = blockIdx.x * SEG_WAVES + wave;
   if (item >= n_items || env.n_tri == 0) return;
-  segment_chunk(env, rob, rtri, ibase + wave * STACK_CAP, ibase + SEG_WAVES * STACK_CAP + wave * CAND_CAP, a6, b6,
+  segment_chunk(env, rob, rtri, ibase + wave * STACK_CAP, ibase + SEG_WAVES * STACK_CAP + wave * CAND_CAP,
+                  ibase + SEG_WAVES * (STACK_CAP + CAND_CAP) + wave * QUEUE_CAP, a6, b6,
                 items[item].x, items[item].y, first_hit, overflow_flag, lane);
 }
 
@@ -527,7 +621,8 @@ __global__ __launch_bounds__(64 * SEG_WAVES) void k_collide_segments_dyn(EnvView
     if (first >= n_items) break;
     const int last = first + BATCH < n_items ? first + BATCH : n_items;
     for (int item = first; item < last; ++item)
-      segment_chunk(env, rob, rtri, ibase + wave * STACK_CAP, ibase + SEG_WAVES * STACK_CAP + wave * CAND_CAP, a6, b6,
+      segment_chunk(env, rob, rtri, ibase + wave * STACK_CAP, ibase + SEG_WAVES * STACK_CAP + wave * CAND_CAP,
+                  ibase + SEG_WAVES * (STACK_CAP + CAND_CAP) + wave * QUEUE_CAP, a6, b6,
                     items[item].x, items[item].y, first_hit, overflow_flag, lane);
   }
 }
@@ -662,7 +757,7 @@ __global__ __launch_bounds__(256) void k_store_write(NodeStoreMut st, const doub
 
 // ------------------------------------------------------------------ launchers
 size_t collide_lds_bytes(int n_robot_tri, int waves) {
-  return (size_t)n_robot_tri * 9 * sizeof(double) + (size_t)waves * (STACK_CAP + CAND_CAP) * sizeof(int32_t);
+  return (size_t)n_robot_tri * 9 * sizeof(double) + (size_t)waves * (STACK_CAP + CAND_CAP + QUEUE_CAP) * sizeof(int32_t);
 }
 
 void launch_sample_steer(hipStream_t s, const uint64_t* words, const int32_t* parent, const double* node_pos,
