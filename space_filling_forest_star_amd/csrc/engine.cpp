@@ -299,7 +299,7 @@ void Ctx::store_reset(int capacity) {
   store_maxabs = 1.0;
   store_reserve(std::max(capacity, 1024));
 }
-void Ctx::store_append(const double* pos6, const int32_t* tree, int n) {
+void Ctx::store_append(const double* pos6, const int32_t* tree, int n, bool wait) {
   if (n <= 0) return;
   HIPCHK(hipSetDevice(device));
   store_reserve(store_n + n);
@@ -314,7 +314,7 @@ void Ctx::store_append(const double* pos6, const int32_t* tree, int n) {
   HIPCHK(hipMemcpyAsync(d_a.p, h_a.p, (size_t)n * 6 * sizeof(double), hipMemcpyHostToDevice, stream));
   HIPCHK(hipMemcpyAsync(d_b.p, h_b.p, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, stream));
   sffk::launch_store_write(stream, store_mut(*this), d_a.as<double>(), d_b.as<int32_t>(), nullptr, nullptr, n, store_n);
-  sync();
+  if (wait) sync();   // callers that keep the stream ordered (the forest engine) skip the wait
   store_n += n;
 }
 

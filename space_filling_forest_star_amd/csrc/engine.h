@@ -106,7 +106,7 @@ struct Ctx {
   sffk::NodeStoreView store_view() const;
   void store_reset(int capacity);
   void store_reserve(int capacity);
-  void store_append(const double* pos6, const int32_t* tree, int n);
+  void store_append(const double* pos6, const int32_t* tree, int n, bool wait = true);
   void store_set_tree(const int32_t* ids, int n, int32_t tree);  // relabel nodes (tree merging, src/rrt.h:240-250)
 
   void collide_poses(const double* pos6, int n, uint8_t* hit);

@@ -102,7 +102,7 @@ void launch_collide_poses(hipStream_t s, const EnvView& env, const RobotView& ro
 
 // arguments of k_classify (one thread per sample of the round)
 struct ClassifyArgs {
-  int n, N0, cap, nbcap, rank, world, items_cap;
+  int n, N0, cap, nbcap, rank, world;
   int goal_id;              // store id of the goal node, -1 without a goal (src/forest.h:286-287)
   double dist_tree;
   const double* newpos;     // n x 6
@@ -124,12 +124,11 @@ struct ClassifyArgs {
   int32_t* seg_ns;          // n x (1+nbcap): samples of the edge, -1 = no task
   int32_t* first_hit;       // n x (1+nbcap): preset to INT32_MAX
   int32_t* seg_ovf;         // n x (1+nbcap)
-  int2* items;              // work list (slot, chunk)
-  int32_t* ctrl;            // [0] item count, [1] next item
+  int32_t* ctrl;            // [1] next task slot of the persistent edge kernel
 };
 void launch_classify(hipStream_t s, const ClassifyArgs& a);
 void launch_collide_segments_dyn(hipStream_t s, const EnvView& env, const RobotView& rob, const double* a6,
-                                 const double* b6, const int2* items, int32_t* ctrl, int items_cap,
+                                 const double* b6, const int32_t* seg_ns, int n_slots, int32_t* ctrl,
                                  int32_t* first_hit, int32_t* overflow_flag);
 
 // items = (edge index, chunk index) work list; first_hit must be pre-set to INT32_MAX, overflow_flag to 0

@@ -593,13 +593,15 @@ __global__ __launch_bounds__(64 * SEG_WAVES) void k_collide_segments(EnvView env
                 items[item].x, items[item].y, first_hit, overflow_flag, lane);
 }
 
-// device-built work list (ctrl[0] = number of items, ctrl[1] = next item): persistent wavefronts
-// pull items until the list is drained, which also evens out the very uneven cost per edge
+// Edge tasks written on the device by k_classify: persistent wavefronts pull BATCH (<= 64) consecutive task
+// slots per dequeue (a returning atomic on one word saturates near 90 dequeues/us chip-wide, so the
+// dequeue is coarse), keep the live ones (seg_ns > 0) and run their 64-sample chunks.  This also evens
+// out the very uneven cost per edge.
 __global__ __launch_bounds__(64 * SEG_WAVES) void k_collide_segments_dyn(EnvView env, RobotView rob,
                                                                          const double* __restrict__ a6,
                                                                          const double* __restrict__ b6,
-                                                                         const int2* __restrict__ items,
-                                                                         int32_t* __restrict__ ctrl, int items_cap,
+                                                                         const int32_t* __restrict__ seg_ns, int n_slots,
+                                                                         int32_t* __restrict__ ctrl, int BATCH,
                                                                          int32_t* __restrict__ first_hit,
                                                                          int32_t* __restrict__ overflow_flag) {
   extern __shared__ double lds_d[];
@@ -609,40 +611,49 @@ __global__ __launch_bounds__(64 * SEG_WAVES) void k_collide_segments_dyn(EnvView
   for (int i = threadIdx.x; i < rob.n_tri * 9; i += blockDim.x) rtri[i] = rob.tri[i];
   __syncthreads();
   if (env.n_tri == 0) return;
-  int n_items = ctrl[0];
-  if (n_items > items_cap) n_items = items_cap;
-  // one returning atomic on a single word saturates near 90 dequeues/us chip-wide, so every
-  // dequeue takes a batch of consecutive items
-  const int BATCH = 8;
   while (true) {
     int first = 0;
     if (lane == 0) first = atomicAdd(ctrl + 1, BATCH);
     first = __shfl(first, 0);
-    if (first >= n_items) break;
-    const int last = first + BATCH < n_items ? first + BATCH : n_items;
-    for (int item = first; item < last; ++item)
-      segment_chunk(env, rob, rtri, ibase + wave * STACK_CAP, ibase + SEG_WAVES * STACK_CAP + wave * CAND_CAP,
-                  ibase + SEG_WAVES * (STACK_CAP + CAND_CAP) + wave * QUEUE_CAP, a6, b6,
-                    items[item].x, items[item].y, first_hit, overflow_flag, lane);
+    if (first >= n_slots) break;
+    const int slot = first + lane;
+    const int ns = (lane < BATCH && slot < n_slots) ? seg_ns[slot] : -1;
+    unsigned long long live = __ballot(ns > 0);
+    while (live) {
+      const int b = __ffsll((long long)live) - 1;
+      live &= live - 1;
+      const int nsb = __shfl(ns, b);
+      for (int chunk = 0; chunk * 64 < nsb; ++chunk)
+        segment_chunk(env, rob, rtri, ibase + wave * STACK_CAP, ibase + SEG_WAVES * STACK_CAP + wave * CAND_CAP,
+                      ibase + SEG_WAVES * (STACK_CAP + CAND_CAP) + wave * QUEUE_CAP, a6, b6, first + b, chunk, first_hit,
+                      overflow_flag, lane);
+    }
   }
 }
 
 // ------------------------------------------------------------------ neighbour classification
-// One thread per sample of the round.  Replays, for its sample, the part of the reference's
-// neighbour loop (src/forest.h:262-300) that decides WHICH edges have to be checked: filters the
-// sweep hits by the two distance conditions (:276, :283), orders them as the reference visits
-// them (tree id, then distance, then index), cuts the list after the first store neighbour of
-// another tree (the loop returns there, :296-299) and writes the edge tasks + their work items.
+// One wavefront per sample of the round, lane = sweep hit.  Replays, for its sample, the part of the
+// reference's neighbour loop (src/forest.h:262-300) that decides WHICH edges have to be checked:
+// keeps the hits that satisfy one of the two distance conditions (:276, :283), ranks them in the
+// order the reference visits them (tree id, then distance, then index), cuts the list after the
+// first store neighbour of another tree (the loop returns there, :296-299) and writes the edge
+// tasks + their (edge, chunk) work items.
+__device__ __forceinline__ void emit_items(const ClassifyArgs& A, size_t slot) {
+  // the edge's sample count doubles as its "live" mark; the persistent edge kernel scans these
+  A.seg_ns[slot] = edge_samples(edge_parts(A.seg_a + 6 * slot, A.seg_b + 6 * slot));
+}
+
 __global__ __launch_bounds__(256) void k_classify(ClassifyArgs A) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
   if (i >= A.n) return;
   const int stride = 1 + A.nbcap;
-  int flags = 0, nnb = 0;
-  for (int k = 0; k < stride; ++k) {
+  for (int k = lane; k < stride; k += 64) {
     A.seg_ns[(size_t)i * stride + k] = -1;
     A.first_hit[(size_t)i * stride + k] = 0x7fffffff;
     A.seg_ovf[(size_t)i * stride + k] = 0;
   }
+  int flags = 0, nnb = 0;
   const bool mine_shard = A.world <= 1 || i % A.world == A.rank;
   if (A.in_lim[i] && mine_shard) {
     flags |= 1;
@@ -654,81 +665,59 @@ __global__ __launch_bounds__(256) void k_classify(ClassifyArgs A) {
       const int mine = A.tree[ex];
       const bool force = A.force[i] != 0;
       const double pdist = A.pdist[i];
-      int32_t* hid = A.hit_idx + (size_t)i * A.cap;
-      double* hd = A.hit_dist + (size_t)i * A.cap;
-      int m = 0;
-      for (int k = 0; k < cnt; ++k) {
-        const int id = hid[k];
-        const double d = hd[k];
-        const bool same = A.tree[id] == mine;
-        if (same) {
-          if (force || !(d < pdist - SFFG_TOL)) continue;       // src/forest.h:276
-        } else {
-          if (!(d < A.dist_tree - SFFG_TOL)) continue;          // src/forest.h:283
-        }
-        hid[m] = id;
-        hd[m] = d;
-        ++m;
+      const bool have = lane < cnt;
+      const int id = have ? A.hit_idx[(size_t)i * A.cap + lane] : 0x7fffffff;
+      const double d = have ? A.hit_dist[(size_t)i * A.cap + lane] : 0.0;
+      const int t = have ? A.tree[id] : 0x7fffffff;
+      const bool same = t == mine;
+      bool q = false;
+      if (have) q = same ? (!force && d < pdist - SFFG_TOL)          // src/forest.h:276
+                         : (d < A.dist_tree - SFFG_TOL);             // src/forest.h:283
+      int rank = 0;
+      for (int j = 0; j < 64; ++j) {
+        const int tj = __shfl(t, j), idj = __shfl(id, j), qj = __shfl((int)q, j);
+        const double dj = __shfl(d, j);
+        if (qj && (tj < t || (tj == t && (dj < d || (dj == d && idj < id))))) ++rank;
       }
-      for (int a = 1; a < m; ++a) {                             // insertion sort by (tree, dist, id)
-        const int id = hid[a];
-        const double d = hd[a];
-        const int t = A.tree[id];
-        int b = a - 1;
-        while (b >= 0) {
-          const int tb = A.tree[hid[b]];
-          const bool greater = tb > t || (tb == t && (hd[b] > d || (hd[b] == d && hid[b] > id)));
-          if (!greater) break;
-          hid[b + 1] = hid[b];
-          hd[b + 1] = hd[b];
-          --b;
-        }
-        hid[b + 1] = id;
-        hd[b + 1] = d;
+      int cut = (q && !same && id < A.N0) ? rank : 0x7fffffff;
+      for (int off = 32; off > 0; off >>= 1) {
+        const int o = __shfl_xor(cut, off);
+        cut = o < cut ? o : cut;
       }
-      const double* exp = A.pos + 6 * (size_t)ex;
-      const double* np = A.newpos + 6 * (size_t)i;
-      // slot 0: isPathFree(expanded, newPoint)  (src/forest.h:246)
-      {
-        double* sa = A.seg_a + 6 * ((size_t)i * stride);
-        double* sb = A.seg_b + 6 * ((size_t)i * stride);
-        for (int k = 0; k < 6; ++k) { sa[k] = exp[k]; sb[k] = np[k]; }
-      }
-      for (int k = 0; k < m; ++k) {
-        if (nnb == A.nbcap) { flags |= 2; break; }
-        const int id = hid[k];
-        const int t = A.tree[id];
-        const bool same = t == mine;
-        A.rec_nb[(size_t)i * A.nbcap + nnb] = id;
-        A.rec_meta[(size_t)i * A.nbcap + nnb] = (t << 1) | (same ? 1 : 0);
-        const double* nbp = A.pos + 6 * (size_t)id;
-        double* sa = A.seg_a + 6 * ((size_t)i * stride + 1 + nnb);
-        double* sb = A.seg_b + 6 * ((size_t)i * stride + 1 + nnb);
-        if (same) { for (int q = 0; q < 6; ++q) { sa[q] = nbp[q]; sb[q] = np[q]; } }     // isPathFree(neighbour, newPoint) :276
-        else if (id == A.goal_id) { for (int q = 0; q < 6; ++q) { sa[q] = np[q]; sb[q] = nbp[q]; } }  // isPathFree(newPoint, goal) :287
-        else      { for (int q = 0; q < 6; ++q) { sa[q] = exp[q]; sb[q] = nbp[q]; } }    // isPathFree(expanded, neighbour) :288
-        ++nnb;
-        if (!same && id < A.N0) break;
-      }
-      if (flags & 2) {
-        nnb = 0;  // the host path redoes this sample with unbounded lists
+      const bool keep = q && rank <= cut;
+      const int nkeep = __popcll(__ballot(keep));
+      if (nkeep > A.nbcap) {
+        flags |= 2;   // the host path redoes this sample with unbounded lists
       } else {
-        for (int k = 0; k < 1 + nnb; ++k) {
-          const size_t slot = (size_t)i * stride + k;
-          const int ns = edge_samples(edge_parts(A.seg_a + 6 * slot, A.seg_b + 6 * slot));
-          A.seg_ns[slot] = ns;
-          const int chunks = (ns + 63) >> 6;
-          if (chunks > 0) {
-            const int base = atomicAdd(A.ctrl, chunks);
-            for (int c = 0; c < chunks; ++c)
-              if (base + c < A.items_cap) A.items[base + c] = make_int2((int)slot, c);
-          }
+        nnb = nkeep;
+        const double* exp = A.pos + 6 * (size_t)ex;
+        const double* np = A.newpos + 6 * (size_t)i;
+        if (keep) {
+          A.rec_nb[(size_t)i * A.nbcap + rank] = id;
+          A.rec_meta[(size_t)i * A.nbcap + rank] = (t << 1) | (same ? 1 : 0);
+          const size_t slot = (size_t)i * stride + 1 + rank;
+          const double* nbp = A.pos + 6 * (size_t)id;
+          double* sa = A.seg_a + 6 * slot;
+          double* sb = A.seg_b + 6 * slot;
+          if (same) { for (int k = 0; k < 6; ++k) { sa[k] = nbp[k]; sb[k] = np[k]; } }                 // isPathFree(neighbour, newPoint) :276
+          else if (id == A.goal_id) { for (int k = 0; k < 6; ++k) { sa[k] = np[k]; sb[k] = nbp[k]; } } // isPathFree(newPoint, goal) :287
+          else { for (int k = 0; k < 6; ++k) { sa[k] = exp[k]; sb[k] = nbp[k]; } }                     // isPathFree(expanded, neighbour) :288
+          emit_items(A, slot);
+        }
+        if (lane == 0) {   // slot 0: isPathFree(expanded, newPoint)  (src/forest.h:246)
+          const size_t slot = (size_t)i * stride;
+          double* sa = A.seg_a + 6 * slot;
+          double* sb = A.seg_b + 6 * slot;
+          for (int k = 0; k < 6; ++k) { sa[k] = exp[k]; sb[k] = np[k]; }
+          emit_items(A, slot);
         }
       }
     }
   }
-  A.rec_flags[i] = flags;
-  A.rec_nnb[i] = nnb;
+  if (lane == 0) {
+    A.rec_flags[i] = flags;
+    A.rec_nnb[i] = nnb;
+  }
 }
 
 // ------------------------------------------------------------------ node store writes
@@ -822,17 +811,19 @@ void launch_collide_poses(hipStream_t s, const EnvView& env, const RobotView& ro
 
 void launch_classify(hipStream_t s, const ClassifyArgs& a) {
   if (a.n <= 0) return;
-  hipLaunchKernelGGL(k_classify, dim3((a.n + 255) / 256), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_classify, dim3((a.n + 3) / 4), dim3(256), 0, s, a);
 }
 
 void launch_collide_segments_dyn(hipStream_t s, const EnvView& env, const RobotView& rob, const double* a6,
-                                 const double* b6, const int2* items, int32_t* ctrl, int items_cap,
+                                 const double* b6, const int32_t* seg_ns, int n_slots, int32_t* ctrl,
                                  int32_t* first_hit, int32_t* overflow_flag) {
+  if (n_slots <= 0) return;
   size_t lds = collide_lds_bytes(rob.n_tri, SEG_WAVES);
   // 3 workgroups of 4 waves per CU = what the kernel's register budget keeps resident (256 CUs)
   static const int blocks = getenv("SFFGPU_SEG_BLOCKS") ? atoi(getenv("SFFGPU_SEG_BLOCKS")) : 768;
-  hipLaunchKernelGGL(k_collide_segments_dyn, dim3(blocks), dim3(64 * SEG_WAVES), lds, s, env, rob, a6, b6, items, ctrl,
-                     items_cap, first_hit, overflow_flag);
+  static const int batch = getenv("SFFGPU_SEG_BATCH") ? atoi(getenv("SFFGPU_SEG_BATCH")) : 16;
+  hipLaunchKernelGGL(k_collide_segments_dyn, dim3(blocks), dim3(64 * SEG_WAVES), lds, s, env, rob, a6, b6, seg_ns,
+                     n_slots, ctrl, batch, first_hit, overflow_flag);
 }
 
 void launch_collide_segments(hipStream_t s, const EnvView& env, const RobotView& rob, const double* a6,
