@@ -26,11 +26,12 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=120)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=480)   # 3 + 480 waves of 4096 slots: ~10 -> ~950k nodes of the 1M budget
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--wave", type=int, default=4096)
     ap.add_argument("--budget", type=int, default=1000000)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--force-dist", action="store_true", help="run the RCCL record exchange even with one rank")
     ap.add_argument("--cpu-iters", type=int, default=120000, help="iterations of the CPU baseline sample (0 = skip)")
     args = ap.parse_args()
 
@@ -41,10 +42,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    distributed = world > 1
+    distributed = world > 1 or args.force_dist
     torch.cuda.set_device(local_rank)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     import common
@@ -157,7 +159,7 @@ def main():
                 "avg_queries_per_launch": (s1["sweep_queries"] - s0["sweep_queries"]) / max(1, sweeps),
             },
         }
-        if args.cpu_iters > 0:
+        if args.cpu_iters > 0 and world == 1:
             import oracle_lib as O
             w = O.World(sc["env"], sc["robot"], O.TRIG_PORTABLE)
             fo = O.Forest(w, roots, sc["limits"], dist_tree=sc["dist_tree"], sampling_dist=sc["sampling_dist"], dim=6,
@@ -173,10 +175,16 @@ def main():
                           % (args.cpu_iters, so["n_nodes"], c1 - c0),
                 "collision_checks_per_s": so["collide_calls"] / (c1 - c0),
             }
-        print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints its version banner through C stdio, which would otherwise be flushed AFTER this line at
+        # exit: flush it first so that the JSON line is the last thing on stdout
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
