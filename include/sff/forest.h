@@ -68,22 +68,28 @@ class SpaceForest : public Solver<T, R> {
     std::vector<int32_t> conn(st.n_trees);
     int nc = sffgpu_forest_paths(f, this->neighboringMatrix.data(), conn.data(), st.n_trees);   // getPaths + getAllPaths
     this->connectedTrees.assign(conn.begin(), conn.begin() + nc);
-    this->plans.assign((size_t)st.n_trees * st.n_trees, {});
-    for (int i = 0; i < st.n_trees; ++i)
-      for (int j = i + 1; j < st.n_trees; ++j) {
-        int len = sffgpu_forest_path_plan(f, i, j, nullptr, 0);
-        if (len <= 0) continue;
-        std::vector<int32_t> ids(len);
-        sffgpu_forest_path_plan(f, i, j, ids.data(), len);
-        this->plans[(size_t)i * st.n_trees + j].assign(ids.begin(), ids.end());
-      }
-    sffgpu_forest_destroy(f);
-
+    auto loadPlans = [&]() {
+      this->plans.assign((size_t)st.n_trees * st.n_trees, {});
+      for (int i = 0; i < st.n_trees; ++i)
+        for (int j = i + 1; j < st.n_trees; ++j) {
+          int len = sffgpu_forest_path_plan(f, i, j, nullptr, 0);
+          if (len <= 0) continue;
+          std::vector<int32_t> ids(len);
+          sffgpu_forest_path_plan(f, i, j, ids.data(), len);
+          this->plans[(size_t)i * st.n_trees + j].assign(ids.begin(), ids.end());
+        }
+    };
+    loadPlans();
     // :114-116, :207-235 — same order of outputs as the reference
     if (SaveGoals <= P.saveOptions) this->saveCities(P.fileNames[SaveGoals]);
     if (SaveTree <= P.saveOptions) this->saveTrees(P.fileNames[SaveTree]);
     if (SaveRaw <= P.saveOptions) this->savePaths(P.fileNames[SaveRaw]);
-    if (P.smoothing) std::cout << "SpaceForest: path smoothing is not implemented in this build; raw paths kept\n";
+    if (P.smoothing) {                                               // :219-224
+      sff_compat::check(sffgpu_forest_smooth_paths(f, this->neighboringMatrix.data()), "smooth paths");
+      loadPlans();
+      if (SaveSmooth <= P.saveOptions) this->savePaths(P.fileNames[SaveSmooth]);
+    }
+    sffgpu_forest_destroy(f);
     if (SaveParams <= P.saveOptions) this->saveParams(P.fileNames[SaveParams], st.iterations, st.solved != 0, stopTime - startingTime);
     if (SaveTSP <= P.saveOptions) this->saveTsp(P.fileNames[SaveTSP]);
     if (SaveFrontiers <= P.saveOptions) std::cout << "SpaceForest: frontier dump is not implemented in this build\n";

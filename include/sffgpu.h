@@ -135,6 +135,9 @@ uint64_t sffgpu_forest_fingerprint(sffgpu_forest* f);
  * id first, like DistanceHolder) and returns its length. */
 int sffgpu_forest_paths(sffgpu_forest* f, double* dist, int32_t* connected, int cap_connected);
 int sffgpu_forest_path_plan(sffgpu_forest* f, int i, int j, int32_t* node_ids, int cap);
+/* SpaceForest::smoothPaths (src/forest.h:464-511) on the paths extracted by sffgpu_forest_paths: shortcuts
+ * every path with batched isPathFree checks; dist receives the updated cost matrix, path_plan the new plans. */
+int sffgpu_forest_smooth_paths(sffgpu_forest* f, double* dist);
 
 /* ---------------------------------------------------------------- RRT / RRT* / Multi-T-RRT
  * RapidExpTree<T,R> (src/rrt.h:25-44): constructor :47-83, Solve() :86-99, expandNode :128-322

@@ -846,6 +846,38 @@ struct Forest {
     }
   }
 
+  // src/forest.h:464-511 smoothPaths: shortcut every path from its far end; indices restate the reference's
+  // reverse-iterator walk (tempGoal = plan index g, testNode = index t running from the start of the plan)
+  void smooth_paths() {
+    for (int i = 0; i < num_roots; ++i)
+      for (int j = i + 1; j < num_roots; ++j) {
+        Holder& h = NM(i, j);
+        if (!h.exists()) continue;
+        std::vector<int>& plan = h.plan;
+        int g = (int)plan.size() - 1;
+        double prev_dist = h.dist;
+        while (g > 0) {
+          int p = 0, t = 0;
+          double cum = 0;
+          bool changed = false;
+          while (t < g - 1) {
+            if (p != t) cum += distance6(nodes[plan[t]].pos, nodes[plan[p]].pos);
+            if (path_free(nodes[plan[t]].pos, nodes[plan[g]].pos)) { changed = true; break; }
+            p = t;
+            ++t;
+          }
+          if (t == g - 1) cum += distance6(nodes[plan[t]].pos, nodes[plan[p]].pos);
+          if (changed) {
+            double dif = prev_dist - cum - distance6(nodes[plan[t]].pos, nodes[plan[g]].pos);
+            h.dist -= dif;
+            plan.erase(plan.begin() + t + 1, plan.begin() + g);
+          }
+          prev_dist = cum;
+          g = t;
+        }
+      }
+  }
+
   bool budget_hit() const { return cfg.node_budget > 0 && (int)nodes.size() >= cfg.node_budget; }
 
   // src/forest.h:122-202, generalised to waves of cfg.wave slots; wave == 1 is the
@@ -1242,6 +1274,14 @@ int sffo_forest_paths(sffo_forest* h, double* dist) {
   if (!f.solved && !f.cfg.has_goal) f.solved = f.max_connected() == f.num_roots; else f.max_connected();
   f.get_paths();
   f.get_all_paths();
+  for (int i = 0; i < f.num_roots; ++i)
+    for (int j = 0; j < f.num_roots; ++j) dist[(size_t)i * f.num_roots + j] = i == j ? 0.0 : f.NM(i, j).dist;
+  return f.num_roots;
+}
+int sffo_forest_smooth(sffo_forest* h, double* dist) {
+  Forest& f = h->f;
+  if (f.nm.empty()) return -1;
+  f.smooth_paths();
   for (int i = 0; i < f.num_roots; ++i)
     for (int j = 0; j < f.num_roots; ++j) dist[(size_t)i * f.num_roots + j] = i == j ? 0.0 : f.NM(i, j).dist;
   return f.num_roots;

@@ -110,6 +110,8 @@ int sffo_forest_get_borders(sffo_forest*, int32_t* ta, int32_t* tb, int32_t* n1,
  * matrix (num_roots x num_roots, max double = no path) and the node-id plan of one pair */
 int sffo_forest_paths(sffo_forest*, double* dist);
 int sffo_forest_path_plan(sffo_forest*, int i, int j, int32_t* node_ids, int cap);
+/* smoothPaths (src/forest.h:464-511) on the extracted paths; returns the updated cost matrix */
+int sffo_forest_smooth(sffo_forest*, double* dist);
 /* FNV-1a over (parent, tree, iter, pos bits) of all nodes — cheap topology fingerprint */
 uint64_t sffo_forest_fingerprint(sffo_forest*);
 

@@ -15,7 +15,7 @@ EXPORTED_SYMBOLS = [
     "sffgpu_nodes_reset", "sffgpu_nodes_append", "sffgpu_nodes_count", "sffgpu_radius", "sffgpu_knn",
     "sffgpu_forest_create", "sffgpu_forest_destroy", "sffgpu_forest_run", "sffgpu_forest_get_stats",
     "sffgpu_forest_get_nodes", "sffgpu_forest_get_borders", "sffgpu_forest_fingerprint", "sffgpu_forest_paths",
-    "sffgpu_forest_path_plan",
+    "sffgpu_forest_path_plan", "sffgpu_forest_smooth_paths",
     "sffgpu_rrt_create", "sffgpu_rrt_destroy", "sffgpu_rrt_run", "sffgpu_rrt_get_stats", "sffgpu_rrt_get_nodes",
     "sffgpu_rrt_get_links", "sffgpu_forest_in_wave", "sffgpu_forest_round_begin", "sffgpu_forest_round_records", "sffgpu_forest_round_commit",
 ]
@@ -109,6 +109,7 @@ def lib():
     L.sffgpu_forest_get_nodes.argtypes = [C.c_void_p, c_dp, c_ip, c_ip, c_ip, c_dp, c_dp]
     L.sffgpu_forest_get_borders.argtypes = [C.c_void_p, c_ip, c_ip, c_ip, c_ip, c_dp, C.c_int]
     L.sffgpu_forest_paths.argtypes = [C.c_void_p, c_dp, c_ip, C.c_int]
+    L.sffgpu_forest_smooth_paths.argtypes = [C.c_void_p, c_dp]
     L.sffgpu_forest_path_plan.argtypes = [C.c_void_p, C.c_int, C.c_int, c_ip, C.c_int]
     L.sffgpu_forest_fingerprint.restype = C.c_uint64
     L.sffgpu_forest_fingerprint.argtypes = [C.c_void_p]
@@ -316,6 +317,12 @@ class Forest:
         conn = np.zeros(n, np.int32)
         k = self.ctx._chk(self.ctx._L.sffgpu_forest_paths(self.h, _dp(d), _ip(conn), n))
         return d, conn[:k].copy()
+
+    def smooth(self):
+        n = self.stats()["n_trees"]
+        d = np.zeros((n, n))
+        self.ctx._chk(self.ctx._L.sffgpu_forest_smooth_paths(self.h, _dp(d)))
+        return d
 
     def plan(self, i, j, cap=1 << 16):
         ids = np.zeros(cap, np.int32)

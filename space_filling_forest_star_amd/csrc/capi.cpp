@@ -198,6 +198,16 @@ int sffgpu_forest_paths(sffgpu_forest* f, double* dist, int32_t* connected, int 
     for (size_t k = 0; k < F.connected.size() && (int)k < cap_connected; ++k) connected[k] = F.connected[k];
   return (int)F.connected.size();
 }
+int sffgpu_forest_smooth_paths(sffgpu_forest* f, double* dist) {
+  if (!f || !dist) return SFFGPU_ERR_ARG;
+  Forest& F = *f->f;
+  if (F.nm.empty()) { f->owner->c->err = "smooth_paths: call sffgpu_forest_paths first"; return SFFGPU_ERR_STATE; }
+  GUARD(f->owner, {
+    F.smooth_paths();
+    for (int i = 0; i < F.num_roots; ++i)
+      for (int j = 0; j < F.num_roots; ++j) dist[(size_t)i * F.num_roots + j] = i == j ? 0.0 : F.NM(i, j).dist;
+  });
+}
 int sffgpu_forest_path_plan(sffgpu_forest* f, int i, int j, int32_t* node_ids, int cap) {
   if (!f || i < 0 || j < 0 || i >= f->f->num_roots || j >= f->f->num_roots) return SFFGPU_ERR_ARG;
   Forest& F = *f->f;

@@ -211,6 +211,7 @@ struct Forest {
   Holder& NM(int i, int j) { return nm[(size_t)(i < j ? i : j) * num_roots + (i < j ? j : i)]; }
   void get_paths();
   void get_all_paths();
+  void smooth_paths();   // src/forest.h:464-511, edge checks batched on the GPU
 
   Forest(Ctx* c, const sffgpu_forest_cfg& cf, const double* roots6, int n_roots);
   int add_node(const double* pos, int tree, int parent, double dclosest, double droot, unsigned it);

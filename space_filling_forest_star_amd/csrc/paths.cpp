@@ -7,6 +7,7 @@
 // (src/problemStruct.h:391-468); they are the "path cost" the parity bound is stated on.
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 
 #include "engine.h"
 #include "sff_geom.h"
@@ -86,6 +87,54 @@ void Forest::get_all_paths() {
       }
     }
   }
+}
+
+// SpaceForest::smoothPaths (src/forest.h:464-511): walk every path from its far end (index g) and connect
+// it to the EARLIEST node t < g-1 whose straight edge is free, dropping the nodes in between.  The
+// reference tests t = 0, 1, ... one isPathFree at a time and stops at the first free one; here all
+// candidate edges of one g go to the GPU in a single batch and the first free one is taken, which is the
+// same choice (isPathFree is pure).  Reference-equivalent call counters follow the early stop.
+void Forest::smooth_paths() {
+  for (int i = 0; i < num_roots; ++i)
+    for (int j = i + 1; j < num_roots; ++j) {
+      Holder& h = NM(i, j);
+      if (!h.exists()) continue;
+      std::vector<int>& plan = h.plan;
+      int g = (int)plan.size() - 1;
+      double prev_dist = h.dist;
+      while (g > 0) {
+        const int m = g - 1;   // candidates t = 0 .. g-2
+        std::vector<uint8_t> fr(std::max(m, 0));
+        std::vector<int32_t> fh(std::max(m, 0)), nsv(std::max(m, 0));
+        if (m > 0) {
+          std::vector<double> a((size_t)m * 6), b((size_t)m * 6);
+          for (int t = 0; t < m; ++t) {
+            memcpy(&a[6 * (size_t)t], nodes[plan[t]].pos, 48);
+            memcpy(&b[6 * (size_t)t], nodes[plan[g]].pos, 48);
+          }
+          ctx->collide_segments(a.data(), b.data(), m, fr.data(), fh.data(), nsv.data());
+        }
+        int p = 0, t = 0;
+        double cum = 0;
+        bool changed = false;
+        while (t < g - 1) {
+          if (p != t) cum += sffg::dist6(nodes[plan[t]].pos, nodes[plan[p]].pos);
+          st.path_free_calls += 1;
+          st.collide_calls += fh[t] > 0 ? (uint64_t)fh[t] : (uint64_t)nsv[t];
+          if (fr[t]) { changed = true; break; }
+          p = t;
+          ++t;
+        }
+        if (t == g - 1) cum += sffg::dist6(nodes[plan[t]].pos, nodes[plan[p]].pos);
+        if (changed) {
+          double dif = prev_dist - cum - sffg::dist6(nodes[plan[t]].pos, nodes[plan[g]].pos);
+          h.dist -= dif;
+          plan.erase(plan.begin() + t + 1, plan.begin() + g);
+        }
+        prev_dist = cum;
+        g = t;
+      }
+    }
 }
 
 }  // namespace sff

@@ -101,6 +101,7 @@ def lib():
     L.sffo_forest_get_nodes.argtypes = [C.c_void_p, c_dp, c_ip, c_ip, c_ip, c_dp, c_dp]
     L.sffo_forest_get_borders.argtypes = [C.c_void_p, c_ip, c_ip, c_ip, c_ip, c_dp, C.c_int]
     L.sffo_forest_paths.argtypes = [C.c_void_p, c_dp]
+    L.sffo_forest_smooth.argtypes = [C.c_void_p, c_dp]
     L.sffo_forest_path_plan.argtypes = [C.c_void_p, C.c_int, C.c_int, c_ip, C.c_int]
     L.sffo_forest_fingerprint.restype = C.c_uint64
     L.sffo_forest_fingerprint.argtypes = [C.c_void_p]
@@ -262,6 +263,12 @@ class Forest:
         n = self.stats()["n_trees"]
         d = np.zeros((n, n))
         lib().sffo_forest_paths(self.h, dp(d))
+        return d
+
+    def smooth(self):
+        n = self.stats()["n_trees"]
+        d = np.zeros((n, n))
+        assert lib().sffo_forest_smooth(self.h, dp(d)) == n
         return d
 
     def plan(self, i, j, cap=1 << 16):

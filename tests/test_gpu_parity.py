@@ -235,6 +235,14 @@ def test_path_costs_and_plans_match(S, ctx, optimize):
     for i in range(len(do)):
         for j in range(i + 1, len(do)):
             assert np.array_equal(fo.plan(i, j), fg.plan(i, j))
+    # smoothPaths (src/forest.h:464-511): shortcutting with batched edge checks gives the same plans and costs
+    so, sg = fo.smooth(), fg.smooth()
+    assert np.array_equal(so[finite], sg[finite])
+    assert np.all(so[finite] <= do[finite] + 1e-9) and np.any(so[finite] < do[finite] - 1e-6)
+    for i in range(len(do)):
+        for j in range(i + 1, len(do)):
+            assert np.array_equal(fo.plan(i, j), fg.plan(i, j))
+    assert fo.stats()["collide_calls"] == fg.stats()["collide_calls"]
 
 
 def test_forest_node_budget_and_seeds(S, ctx):
