@@ -404,43 +404,35 @@ void Ctx::collide_segments(const double* a6, const double* b6, int n, uint8_t* i
   if (n <= 0) return;
   if (!have_env || !have_robot) throw HipError{"collide_segments: upload ENV and ROBOT meshes first"};
   HIPCHK(hipSetDevice(device));
-  // work list: one item per (edge, chunk of 64 samples); sample counts from the same fp64 expressions
-  // the kernel evaluates (src/problemStruct.h:155-156)
-  std::vector<int32_t> ns(n);
-  size_t n_items = 0;
-  for (int i = 0; i < n; ++i) {
-    ns[i] = sffg::edge_samples(sffg::edge_parts(a6 + 6 * (size_t)i, b6 + 6 * (size_t)i));
-    n_items += (size_t)(ns[i] + 63) / 64;
-  }
+  // sample counts (src/problemStruct.h:155-156) and result presets are computed on the device; the persistent
+  // edge kernel then scans the n task slots
   const size_t pb = (size_t)n * 6 * sizeof(double);
-  h_a.ensure(pb); h_b.ensure(pb); h_c.ensure(std::max<size_t>(1, n_items) * sizeof(int2));
-  h_d.ensure((size_t)n * 4); h_e.ensure((size_t)n * 4);
+  h_a.ensure(pb); h_b.ensure(pb); h_c.ensure((size_t)n * 12 + 16);
   memcpy(h_a.p, a6, pb);
   memcpy(h_b.p, b6, pb);
-  int2* items = h_c.as<int2>();
-  size_t k = 0;
-  for (int i = 0; i < n; ++i)
-    for (int ch = 0; ch < (ns[i] + 63) / 64; ++ch) items[k++] = make_int2(i, ch);
-  std::vector<int32_t> fh(n, -1);
+  std::vector<int32_t> ns(n, 0), fh(n, -1);
   std::vector<uint8_t> ovf(n, 0);
-  if (n_items > 0 && envv.n_tri > 0) {
-    d_a.ensure(pb); d_b.ensure(pb); d_c.ensure(n_items * sizeof(int2)); d_d.ensure((size_t)n * 4); d_e.ensure((size_t)n * 4);
-    HIPCHK(hipMemcpyAsync(d_a.p, h_a.p, pb, hipMemcpyHostToDevice, stream));
-    HIPCHK(hipMemcpyAsync(d_b.p, h_b.p, pb, hipMemcpyHostToDevice, stream));
-    HIPCHK(hipMemcpyAsync(d_c.p, h_c.p, n_items * sizeof(int2), hipMemcpyHostToDevice, stream));
-    HIPCHK(hipMemsetD32Async((hipDeviceptr_t)d_d.p, 0x7fffffff, (size_t)n, stream));
-    HIPCHK(hipMemsetAsync(d_e.p, 0, (size_t)n * 4, stream));
-    time_begin(T_COLLIDE);
-    sffk::launch_collide_segments(stream, envv, robv, d_a.as<double>(), d_b.as<double>(), d_c.as<int2>(), (int)n_items,
-                                  d_d.as<int32_t>(), d_e.as<int32_t>());
-    time_end();
-    HIPCHK(hipMemcpyAsync(h_d.p, d_d.p, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
-    HIPCHK(hipMemcpyAsync(h_e.p, d_e.p, (size_t)n * 4, hipMemcpyDeviceToHost, stream));
-    sync();
+  d_a.ensure(pb); d_b.ensure(pb); d_c.ensure((size_t)n * 12 + 16);
+  int32_t* d_ns = d_c.as<int32_t>();
+  int32_t* d_fh = d_ns + n;
+  int32_t* d_ov = d_fh + n;
+  int32_t* d_ctrl = d_ov + n;
+  HIPCHK(hipMemcpyAsync(d_a.p, h_a.p, pb, hipMemcpyHostToDevice, stream));
+  HIPCHK(hipMemcpyAsync(d_b.p, h_b.p, pb, hipMemcpyHostToDevice, stream));
+  HIPCHK(hipMemsetAsync(d_ctrl, 0, 16, stream));
+  time_begin(T_COLLIDE);
+  sffk::launch_seg_prepare(stream, d_a.as<double>(), d_b.as<double>(), n, d_ns, d_fh, d_ov);
+  sffk::launch_collide_segments_dyn(stream, envv, robv, d_a.as<double>(), d_b.as<double>(), d_ns, n, d_ctrl, d_fh, d_ov, 2);
+  time_end();
+  HIPCHK(hipMemcpyAsync(h_c.p, d_c.p, (size_t)n * 12, hipMemcpyDeviceToHost, stream));
+  sync();
+  {
+    const int32_t* hn = h_c.as<int32_t>();
     for (int i = 0; i < n; ++i) {
-      int32_t v = h_d.as<int32_t>()[i];
+      ns[i] = hn[i];
+      int32_t v = hn[n + i];
       fh[i] = v == 0x7fffffff ? -1 : v;
-      ovf[i] = h_e.as<int32_t>()[i] != 0;
+      ovf[i] = hn[2 * (size_t)n + i] != 0;
     }
   }
   // edges whose candidate list overflowed are re-run sample by sample through the pose kernel

@@ -330,7 +330,7 @@ void Forest::round_begin() {
   sffk::launch_classify(c.stream, ca);
   sffk::launch_collide_poses(c.stream, c.envv, c.robv, d_pos, n, ca.rec_flags, d_pose);
   sffk::launch_collide_segments_dyn(c.stream, c.envv, c.robv, ca.seg_a, ca.seg_b, ca.seg_ns, n * STRIDE, ca.ctrl,
-                                    ca.first_hit, ca.seg_ovf);
+                                    ca.first_hit, ca.seg_ovf, 16);
   c.time_end();
   c.p_out.ensure(o_bytes);
   char* ho = c.p_out.as<char>();
@@ -553,6 +553,7 @@ void Forest::round_begin() {
         // k = 2e log10(#nodes) (:309) can only grow with the nodes accepted earlier in this round
         kmax[k] = (int32_t)(size_t)(2 * M_E * std::log10((double)(N0 + maybe[k])));
         if (kmax[k] <= 0) active[k] = 0;
+        if ((int)trees[qtree[k]].size() <= kmax[k]) r[k] = 1e30;   // the whole tree is wanted
       }
       const double RMAX = 1e30;
       for (int it = 0; it < 200; ++it) {
@@ -570,12 +571,13 @@ void Forest::round_begin() {
           if (cnt[k] > KCAP) { hi[k] = r[k]; r[k] = 0.5 * (lo[k] + hi[k]); continue; }
           int store_hits = 0;
           for (const HitRec& h : out[k]) store_hits += h.id < N0;
-          if (store_hits >= kmax[k] || r[k] >= RMAX) {
+          // complete when kmax store nodes are inside, or the whole tree already is (small trees)
+          if (store_hits >= kmax[k] || store_hits >= (int)trees[qtree[k]].size() || r[k] >= RMAX) {
             lists[k] = out[k];
             active[k] = 0;
           } else {
             lo[k] = r[k];
-            r[k] = hi[k] > 0 ? 0.5 * (lo[k] + hi[k]) : std::min(RMAX, r[k] * 1.5);
+            r[k] = hi[k] > 0 ? 0.5 * (lo[k] + hi[k]) : std::min(RMAX, r[k] * 2.0);
           }
         }
       }

@@ -127,13 +127,13 @@ struct ClassifyArgs {
   int32_t* ctrl;            // [1] next task slot of the persistent edge kernel
 };
 void launch_classify(hipStream_t s, const ClassifyArgs& a);
+void launch_seg_prepare(hipStream_t s, const double* a6, const double* b6, int n, int32_t* seg_ns, int32_t* first_hit,
+                        int32_t* ovf);
 void launch_collide_segments_dyn(hipStream_t s, const EnvView& env, const RobotView& rob, const double* a6,
                                  const double* b6, const int32_t* seg_ns, int n_slots, int32_t* ctrl,
-                                 int32_t* first_hit, int32_t* overflow_flag);
+                                 int32_t* first_hit, int32_t* overflow_flag, int batch);
+// batch = task slots per dequeue: 16 for the sparse per-sample slot table of a forest round (most slots are
+// empty), 2 for dense host batches where every slot is a live edge
 
-// items = (edge index, chunk index) work list; first_hit must be pre-set to INT32_MAX, overflow_flag to 0
-void launch_collide_segments(hipStream_t s, const EnvView& env, const RobotView& rob, const double* a6,
-                             const double* b6, const int2* items, int n_items, int32_t* first_hit,
-                             int32_t* overflow_flag);
 
 }  // namespace sffk

@@ -573,27 +573,7 @@ __device__ void segment_chunk(const EnvView& env, const RobotView& rob, const do
   if (minhit != 0x7fffffff && lane == 0) atomicMin(first_hit + seg, minhit);
 }
 
-// static work list (C-ABI batch entry point)
-__global__ __launch_bounds__(64 * SEG_WAVES) void k_collide_segments(EnvView env, RobotView rob,
-                                                                     const double* __restrict__ a6,
-                                                                     const double* __restrict__ b6,
-                                                                     const int2* __restrict__ items, int n_items,
-                                                                     int32_t* __restrict__ first_hit,
-                                                                     int32_t* __restrict__ overflow_flag) {
-  extern __shared__ double lds_d[];
-  double* rtri = lds_d;
-  int32_t* ibase = reinterpret_cast<int32_t*>(rtri + (size_t)rob.n_tri * 9);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  for (int i = threadIdx.x; i < rob.n_tri * 9; i += blockDim.x) rtri[i] = rob.tri[i];
-  __syncthreads();
-  const int item = blockIdx.x * SEG_WAVES + wave;
-  if (item >= n_items || env.n_tri == 0) return;
-  segment_chunk(env, rob, rtri, ibase + wave * STACK_CAP, ibase + SEG_WAVES * STACK_CAP + wave * CAND_CAP,
-                  ibase + SEG_WAVES * (STACK_CAP + CAND_CAP) + wave * QUEUE_CAP, a6, b6,
-                items[item].x, items[item].y, first_hit, overflow_flag, lane);
-}
-
-// Edge tasks written on the device by k_classify: persistent wavefronts pull BATCH (<= 64) consecutive task
+// Edge tasks written on the device (k_classify for the forest rounds, k_seg_prepare for host batches): persistent wavefronts pull BATCH (<= 64) consecutive task
 // slots per dequeue (a returning atomic on one word saturates near 90 dequeues/us chip-wide, so the
 // dequeue is coarse), keep the live ones (seg_ns > 0) and run their 64-sample chunks.  This also evens
 // out the very uneven cost per edge.
@@ -629,6 +609,17 @@ __global__ __launch_bounds__(64 * SEG_WAVES) void k_collide_segments_dyn(EnvView
                       overflow_flag, lane);
     }
   }
+}
+
+// sample counts + result presets for a host-supplied batch of edges (C-ABI sffgpu_collide_segments)
+__global__ __launch_bounds__(256) void k_seg_prepare(const double* __restrict__ a6, const double* __restrict__ b6, int n,
+                                                     int32_t* __restrict__ seg_ns, int32_t* __restrict__ first_hit,
+                                                     int32_t* __restrict__ ovf) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  seg_ns[i] = edge_samples(edge_parts(a6 + 6 * (size_t)i, b6 + 6 * (size_t)i));
+  first_hit[i] = 0x7fffffff;
+  ovf[i] = 0;
 }
 
 // ------------------------------------------------------------------ neighbour classification
@@ -814,25 +805,22 @@ void launch_classify(hipStream_t s, const ClassifyArgs& a) {
   hipLaunchKernelGGL(k_classify, dim3((a.n + 3) / 4), dim3(256), 0, s, a);
 }
 
+void launch_seg_prepare(hipStream_t s, const double* a6, const double* b6, int n, int32_t* seg_ns, int32_t* first_hit,
+                        int32_t* ovf) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_seg_prepare, dim3((n + 255) / 256), dim3(256), 0, s, a6, b6, n, seg_ns, first_hit, ovf);
+}
+
 void launch_collide_segments_dyn(hipStream_t s, const EnvView& env, const RobotView& rob, const double* a6,
                                  const double* b6, const int32_t* seg_ns, int n_slots, int32_t* ctrl,
-                                 int32_t* first_hit, int32_t* overflow_flag) {
+                                 int32_t* first_hit, int32_t* overflow_flag, int batch) {
   if (n_slots <= 0) return;
   size_t lds = collide_lds_bytes(rob.n_tri, SEG_WAVES);
   // 3 workgroups of 4 waves per CU = what the kernel's register budget keeps resident (256 CUs)
   static const int blocks = getenv("SFFGPU_SEG_BLOCKS") ? atoi(getenv("SFFGPU_SEG_BLOCKS")) : 768;
-  static const int batch = getenv("SFFGPU_SEG_BATCH") ? atoi(getenv("SFFGPU_SEG_BATCH")) : 16;
+  if (getenv("SFFGPU_SEG_BATCH")) batch = atoi(getenv("SFFGPU_SEG_BATCH"));
   hipLaunchKernelGGL(k_collide_segments_dyn, dim3(blocks), dim3(64 * SEG_WAVES), lds, s, env, rob, a6, b6, seg_ns,
                      n_slots, ctrl, batch, first_hit, overflow_flag);
-}
-
-void launch_collide_segments(hipStream_t s, const EnvView& env, const RobotView& rob, const double* a6,
-                             const double* b6, const int2* items, int n_items, int32_t* first_hit,
-                             int32_t* overflow_flag) {
-  if (n_items <= 0) return;
-  size_t lds = collide_lds_bytes(rob.n_tri, SEG_WAVES);
-  hipLaunchKernelGGL(k_collide_segments, dim3((n_items + SEG_WAVES - 1) / SEG_WAVES), dim3(64 * SEG_WAVES), lds, s,
-                     env, rob, a6, b6, items, n_items, first_hit, overflow_flag);
 }
 
 }  // namespace sffk
