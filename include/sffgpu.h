@@ -108,6 +108,7 @@ typedef struct {
   uint64_t sweep_nodes;      /* sum over sweeps of nodes streamed */
   uint64_t sweep_queries;    /* sum over sweeps of queries */
   uint64_t slow_path_samples;/* samples whose device lists overflowed and were redone on the host path */
+  uint64_t grid_rebuilds;    /* times the neighbour grid was re-celled because its overflow list filled up */
   double sweep_ms;           /* device time of the sweep kernel (HIP events) */
   double collide_ms;         /* device time of the pose + segment kernels */
   double sample_ms;          /* device time of the sample+steer kernel */

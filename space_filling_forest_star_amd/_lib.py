@@ -43,7 +43,7 @@ class ForestStats(C.Structure):
                 ("n_borders", C.c_int32), ("collide_calls", C.c_uint64), ("path_free_calls", C.c_uint64),
                 ("nn_queries", C.c_uint64), ("waves", C.c_uint64), ("poses_executed", C.c_uint64),
                 ("segments_executed", C.c_uint64), ("samples_executed", C.c_uint64), ("sweeps", C.c_uint64),
-                ("sweep_nodes", C.c_uint64), ("sweep_queries", C.c_uint64), ("slow_path_samples", C.c_uint64),
+                ("sweep_nodes", C.c_uint64), ("sweep_queries", C.c_uint64), ("slow_path_samples", C.c_uint64), ("grid_rebuilds", C.c_uint64),
                 ("sweep_ms", C.c_double),
                 ("collide_ms", C.c_double), ("sample_ms", C.c_double), ("host_ms", C.c_double),
                 ("total_ms", C.c_double)]

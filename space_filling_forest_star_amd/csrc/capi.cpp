@@ -146,6 +146,7 @@ int sffgpu_forest_get_stats(sffgpu_forest* f, sffgpu_forest_stats* out) {
   int nb = 0;
   for (auto& kv : F.borders) nb += (int)kv.second.size();
   s.n_borders = nb;
+  s.grid_rebuilds = (uint64_t)F.ctx->grid_rebuilds;
   s.sweep_ms = F.ctx->kernel_ms[T_SWEEP];
   s.collide_ms = F.ctx->kernel_ms[T_COLLIDE];
   s.sample_ms = F.ctx->kernel_ms[T_SAMPLE];

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 
@@ -332,6 +333,7 @@ void Ctx::store_set_tree(const int32_t* ids, int n, int32_t tree) {
 // ------------------------------------------------------------------ grid
 void Ctx::grid_setup(const double limits[6], double cell) {
   HIPCHK(hipSetDevice(device));
+  memcpy(grid_limits, limits, sizeof grid_limits);
   double ext[3] = {limits[1] - limits[0], limits[3] - limits[2], limits[5] - limits[4]};
   for (int tries = 0; tries < 64; ++tries) {
     double cells = 1;
@@ -343,13 +345,17 @@ void Ctx::grid_setup(const double limits[6], double cell) {
   gridv.ox = (float)limits[0];
   gridv.oy = (float)limits[2];
   gridv.oz = (float)limits[4];
+  grid_cell = cell;
   gridv.inv_cell = (float)(1.0 / cell);
   gridv.nx = (int)std::floor(ext[0] / cell) + 1;
   gridv.ny = (int)std::floor(ext[1] / cell) + 1;
   gridv.nz = (int)std::floor(ext[2] / cell) + 1;
   gridv.bk = 8;
   const size_t ncells = (size_t)gridv.nx * gridv.ny * gridv.nz;
-  gridv.ovf_cap = 65536;
+  if (gridv_ovf_cap_next < 65536) gridv_ovf_cap_next = 65536;
+  gridv.ovf_cap = gridv_ovf_cap_next;
+  if (const char* e = getenv("SFFGPU_TEST_GRID_OVF")) gridv.ovf_cap = std::max(gridv.ovf_cap / 65536 * atoi(e), atoi(e));  // tests: tiny list
+  if (const char* e = getenv("SFFGPU_TEST_GRID_BK")) gridv.bk = std::max(1, std::min(8, atoi(e)));
   g_cnt.ensure(ncells * sizeof(int32_t));
   g_items.ensure(ncells * gridv.bk * sizeof(sffk::GridItem));
   g_ovfcnt.ensure(16);
@@ -368,9 +374,24 @@ void Ctx::grid_insert_new() {
   sffk::launch_grid_insert(stream, gridv, store_view(), grid_inserted, store_n - grid_inserted);
   grid_inserted = store_n;
 }
+// The shared overflow list is scanned by every query, so it must stay short.  When a quarter of it is in use
+// (many nodes per xyz cell: dense forests, or forests that fill the angular dimensions) the grid is rebuilt
+// with smaller cells — queries then visit more cells but shorter buckets — and all nodes are re-inserted.
 void Ctx::grid_check() {
   if (!grid_on) return;
   int32_t v = 0;
+  HIPCHK(hipMemcpyAsync(&v, g_ovfcnt.p, 4, hipMemcpyDeviceToHost, stream));
+  HIPCHK(hipStreamSynchronize(stream));
+  if (v <= gridv.ovf_cap / 4) return;
+  const size_t cells_now = (size_t)gridv.nx * gridv.ny * gridv.nz;
+  double cell = grid_cell;
+  if (cells_now * 4 <= 16777216) cell = grid_cell * 0.63;   // ~4x the cells
+  else gridv_ovf_cap_next = gridv.ovf_cap * 4;              // cell count exhausted: a longer list instead
+  double lim[6];
+  memcpy(lim, grid_limits, sizeof lim);
+  grid_setup(lim, cell);
+  grid_insert_new();
+  ++grid_rebuilds;
   HIPCHK(hipMemcpyAsync(&v, g_ovfcnt.p, 4, hipMemcpyDeviceToHost, stream));
   HIPCHK(hipStreamSynchronize(stream));
   if (v > gridv.ovf_cap) throw HipError{"grid overflow list exhausted"};

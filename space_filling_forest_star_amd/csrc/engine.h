@@ -79,7 +79,10 @@ struct Ctx {
   int grid_inserted = 0;
   void grid_setup(const double limits[6], double cell);
   void grid_insert_new();   // store entries [grid_inserted, store_n)
-  void grid_check();        // throws if the shared overflow list ran over
+  void grid_check();        // re-cells the grid when the shared overflow list fills up
+  double grid_cell = 0, grid_limits[6] = {0, 0, 0, 0, 0, 0};
+  int grid_rebuilds = 0;
+  int gridv_ovf_cap_next = 65536;
 
   // scratch
   DevBuf d_a, d_b, d_c, d_d, d_e, d_f, d_g, d_h;

@@ -59,6 +59,8 @@ Forest::Forest(Ctx* c, const sffgpu_forest_cfg& cf, const double* roots6, int n_
   {
     // cell edge >= the planner's neighbour radius max(parentDistance ~ SamplingDistance, treeDistance)
     double cell = 1.01 * std::max(cfg.sampling_dist, cfg.dist_tree) + 4 * ctx->sweep_eps();
+    ctx->grid_rebuilds = 0;
+    ctx->gridv_ovf_cap_next = 65536;
     ctx->grid_setup(cfg.limits, cell);
   }
   ctx->store_append(roots6, tids.data(), n_roots);

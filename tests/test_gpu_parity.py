@@ -264,6 +264,16 @@ def test_device_list_overflow_takes_host_path(S, ctx, monkeypatch):
     assert_same_forest(fo, fg)
 
 
+def test_grid_recells_under_overflow_pressure(S, ctx, monkeypatch):
+    """One-item buckets and a 64-entry overflow list: the grid has to re-cell itself repeatedly; the
+    neighbour sets (hence the forest) must not change."""
+    monkeypatch.setenv("SFFGPU_TEST_GRID_BK", "1")
+    monkeypatch.setenv("SFFGPU_TEST_GRID_OVF", "64")
+    fo, fg = run_pair(S, ctx, "triang", 128, 12000, seed=12)
+    assert_same_forest(fo, fg)
+    assert fg.stats()["grid_rebuilds"] >= 1
+
+
 def test_forest_errors(S, ctx):
     sc, w = load_world(ctx, "dense3d")
     roots = common.free_roots(w.collide, sc["limits"], 3)
