@@ -151,12 +151,14 @@ typedef struct {
   double priority_bias;             /* Problem::priorityBias: probability of steering at the goal */
   int32_t max_iterations;
   uint64_t seed;
+  int32_t wave;                     /* iterations speculated per GPU wave: 1 = one by one, 0 = automatic (~sqrt of the tree size) */
 } sffgpu_rrt_cfg;
 
 typedef struct {
   int32_t iterations, solved, n_nodes, n_live_trees, merges, n_links;
   uint64_t collide_calls, path_free_calls, nn_queries;  /* what the reference would have executed */
   double total_ms;
+  uint64_t waves, speculated, committed;                /* wave engine: launched waves, iterations evaluated / kept */
 } sffgpu_rrt_stats;
 
 typedef struct sffgpu_rrt sffgpu_rrt;

@@ -55,13 +55,14 @@ class ForestStats(C.Structure):
 class RrtCfg(C.Structure):
     _fields_ = [("dim", C.c_int32), ("optimize", C.c_int32), ("has_goal", C.c_int32), ("goal", C.c_double * 6),
                 ("limits", C.c_double * 6), ("dist_tree", C.c_double), ("sampling_dist", C.c_double),
-                ("priority_bias", C.c_double), ("max_iterations", C.c_int32), ("seed", C.c_uint64)]
+                ("priority_bias", C.c_double), ("max_iterations", C.c_int32), ("seed", C.c_uint64), ("wave", C.c_int32)]
 
 
 class RrtStats(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("solved", C.c_int32), ("n_nodes", C.c_int32), ("n_live_trees", C.c_int32),
                 ("merges", C.c_int32), ("n_links", C.c_int32), ("collide_calls", C.c_uint64),
-                ("path_free_calls", C.c_uint64), ("nn_queries", C.c_uint64), ("total_ms", C.c_double)]
+                ("path_free_calls", C.c_uint64), ("nn_queries", C.c_uint64), ("total_ms", C.c_double),
+                ("waves", C.c_uint64), ("speculated", C.c_uint64), ("committed", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -353,9 +354,10 @@ class Rrt:
     """RapidExpTree solver session (reference src/rrt.h:25-44) on one Context."""
 
     def __init__(self, ctx, roots, limits, dist_tree, sampling_dist, dim=6, optimize=False, goal=None,
-                 priority_bias=0.0, max_iterations=10000, seed=1):
+                 priority_bias=0.0, max_iterations=10000, seed=1, wave=0):
         self.ctx = ctx
         cfg = RrtCfg()
+        cfg.wave = wave
         cfg.dim = dim
         cfg.optimize = int(optimize)
         cfg.has_goal = int(goal is not None)

@@ -58,6 +58,7 @@ void Mt64::reseed(uint64_t seed) {
   mt[0] = seed;
   for (int i = 1; i < 312; ++i) mt[i] = 6364136223846793005ULL * (mt[i - 1] ^ (mt[i - 1] >> 62)) + (uint64_t)i;
   idx = 312;
+  draws = 0;
 }
 uint64_t Mt64::next() {
   if (idx >= 312) {
@@ -69,6 +70,7 @@ uint64_t Mt64::next() {
     }
     idx = 0;
   }
+  ++draws;
   uint64_t y = mt[idx++];
   y ^= (y >> 29) & 0x5555555555555555ULL;
   y ^= (y << 17) & 0x71D67FFFEDA60000ULL;

@@ -41,6 +41,7 @@ struct PinBuf {
 struct Mt64 {
   uint64_t mt[312];
   int idx;
+  uint64_t draws = 0;   // engine words handed out so far (lets a speculative wave rewind)
   explicit Mt64(uint64_t seed = 5489ULL) { reseed(seed); }
   void reseed(uint64_t seed);
   uint64_t next();
@@ -262,7 +263,13 @@ struct Rrt {
   RLink make_link(int a, int b);
   void knn(const double* q, int nq, const int32_t* tree, int k, std::vector<std::vector<int>>& out);
   void expand(int tree_to_expand, unsigned iteration);
+  void draw_target(double rnd[6]);
+  int merge_or_link(int tree_to_expand, int new_id, int nb, bool edge_free, int fh, int ns, int& i);
+  int run_wave(int B);   // speculative wave of up to B iterations; returns how many were committed
   void run(int max_iters);
+  std::vector<double> pend_pos;       // accepted nodes of the current wave not yet in the device store
+  std::vector<int32_t> pend_tree;
+  bool defer_append = false;
 };
 
 }  // namespace sff

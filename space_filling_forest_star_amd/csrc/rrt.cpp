@@ -11,6 +11,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <limits>
 
 #include "engine.h"
 #include "sff_geom.h"
@@ -56,7 +57,12 @@ int Rrt::add_node(const double* pos, int root_tree, int tree, int parent, double
   nodes.push_back(n);
   trees[tree].push_back(id);
   int32_t t = tree;
-  ctx->store_append(pos, &t, 1);                // replaces flannIndex->addPoints (:215)
+  if (defer_append) {                            // wave engine: appended in one batch at the end of the wave
+    pend_pos.insert(pend_pos.end(), pos, pos + 6);
+    pend_tree.push_back(t);
+  } else {
+    ctx->store_append(pos, &t, 1);              // replaces flannIndex->addPoints (:215)
+  }
   return id;
 }
 
@@ -86,26 +92,32 @@ void Rrt::knn(const double* q, int nq, const int32_t* tree, int k, std::vector<s
 
 static uint64_t seg_calls(int fh, int ns) { return fh > 0 ? (uint64_t)fh : (uint64_t)ns; }
 
+// the iteration's steering target: the goal with probability priorityBias (:130-131), else
+// RandGen::randomPointInSpace (src/randGen.h:124-146); Y is drawn before X (g++ evaluates the two arguments
+// of point.set(...) right to left — pinned by tests/golden/ref_primitives.json)
+void Rrt::draw_target(double rnd[6]) {
+  using namespace sffg;
+  if (cfg.priority_bias != 0 && uniform_real(rng.next(), 0.0, 1.0) <= cfg.priority_bias) {
+    memcpy(rnd, nodes[goal_node].pos, 48);
+    return;
+  }
+  double y = uniform_real(rng.next(), cfg.limits[2], cfg.limits[3]);
+  double x = uniform_real(rng.next(), cfg.limits[0], cfg.limits[1]);
+  rnd[0] = x; rnd[1] = y; rnd[2] = 0; rnd[3] = rnd[4] = rnd[5] = 0;
+  if (cfg.dim == 6) {
+    rnd[2] = uniform_real(rng.next(), cfg.limits[4], cfg.limits[5]);
+    rnd[3] = uniform_real(rng.next(), -SFFG_PI, SFFG_PI);
+    double phi = sffp::pacos(1 - 2 * uniform_real(rng.next(), 0.0, 1.0)) + SFFG_PI_2;
+    if (uniform_real(rng.next(), 0.0, 1.0) < 0.5) { if (phi < 0) phi += SFFG_PI; else phi -= SFFG_PI; }
+    rnd[4] = phi;
+    rnd[5] = uniform_real(rng.next(), -SFFG_PI, SFFG_PI);
+  }
+}
+
 void Rrt::expand(int tree_to_expand, unsigned iteration) {
   using namespace sffg;
   double rnd[6], np[6];
-  if (cfg.priority_bias != 0 && uniform_real(rng.next(), 0.0, 1.0) <= cfg.priority_bias) {   // :130-131
-    memcpy(rnd, nodes[goal_node].pos, sizeof rnd);
-  } else {
-    // RandGen::randomPointInSpace (src/randGen.h:124-146); Y is drawn before X (g++ evaluates the
-    // two arguments of point.set(...) right to left — pinned by tests/golden/ref_primitives.json)
-    double y = uniform_real(rng.next(), cfg.limits[2], cfg.limits[3]);
-    double x = uniform_real(rng.next(), cfg.limits[0], cfg.limits[1]);
-    rnd[0] = x; rnd[1] = y; rnd[2] = 0; rnd[3] = rnd[4] = rnd[5] = 0;
-    if (cfg.dim == 6) {
-      rnd[2] = uniform_real(rng.next(), cfg.limits[4], cfg.limits[5]);
-      rnd[3] = uniform_real(rng.next(), -SFFG_PI, SFFG_PI);
-      double phi = sffp::pacos(1 - 2 * uniform_real(rng.next(), 0.0, 1.0)) + SFFG_PI_2;
-      if (uniform_real(rng.next(), 0.0, 1.0) < 0.5) { if (phi < 0) phi += SFFG_PI; else phi -= SFFG_PI; }
-      rnd[4] = phi;
-      rnd[5] = uniform_real(rng.next(), -SFFG_PI, SFFG_PI);
-    }
-  }
+  draw_target(rnd);
   std::vector<std::vector<int>> res;
   int32_t tq = tree_to_expand;
   knn(rnd, 1, &tq, 1, res);                                                     // :143
@@ -205,7 +217,14 @@ void Rrt::expand(int tree_to_expand, unsigned iteration) {
     st.path_free_calls += 1;
     st.collide_calls += seg_calls(fhs[j], nss[j]);
     if (!fr[j]) continue;
-    links[tree_to_expand].push_back(make_link(new_id, nb));                     // :233
+    tree_to_expand = merge_or_link(tree_to_expand, new_id, nb, true, 0, 0, i);
+  }
+}
+
+// src/rrt.h:233-316: link the new node to `nb` and merge the two trees (the one with the lower id eats the
+// other); returns the surviving tree and fixes the caller's frontier cursor like the reference's --i.
+int Rrt::merge_or_link(int tree_to_expand, int new_id, int nb, bool, int, int, int& i) {
+  links[tree_to_expand].push_back(make_link(new_id, nb));                     // :233
     int nbt = nodes[nb].tree;
     int to = tree_to_expand < nbt ? tree_to_expand : nbt;
     int from = tree_to_expand < nbt ? nbt : tree_to_expand;
@@ -214,6 +233,11 @@ void Rrt::expand(int tree_to_expand, unsigned iteration) {
       nodes[id].tree = to;
       nodes[id].idx_in_tree = (int)trees[to].size();
       trees[to].push_back(id);
+    }
+    if (!pend_tree.empty()) {                                                   // wave engine: nodes not on the device yet
+      ctx->store_append(pend_pos.data(), pend_tree.data(), (int)pend_tree.size());
+      pend_pos.clear();
+      pend_tree.clear();
     }
     ctx->store_set_tree(moved.data(), (int)moved.size(), to);                   // the moved nodes now answer tree `to`
     for (RLink& l : links[to]) l = make_link(l.n1, l.n2);                       // :278-289
@@ -226,18 +250,333 @@ void Rrt::expand(int tree_to_expand, unsigned iteration) {
     --num_trees;
     --i;
     ++st.merges;
+  return tree_to_expand;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Speculative wave.  The reference runs one iteration at a time because iteration j's nearest neighbour may
+// be the node iteration i < j has just added.  A wave evaluates B iterations against the FROZEN trees on the
+// GPU (nearest node, steer, pose + parent edge, RRT* k-nearest edges, links to other trees) and then replays
+// them in order on the host.  The replay checks, with the exact metric, whether a node accepted earlier in
+// the same wave would have been the nearest neighbour of iteration j (or a tree merge happened): if so the
+// wave is cut at j, the RNG is rewound to the start of iteration j, and j starts the next wave.  Whatever
+// is committed is therefore exactly what the one-by-one loop produces — the oracle needs no wave notion.
+// ---------------------------------------------------------------------------------------------------
+namespace {
+struct WCand {
+  int tree;
+  uint64_t draws_before;
+  double rnd[6], np[6];
+  int nearest;
+  double d_near;
+  bool pose_hit = false, par_free = false;
+  int par_fh = -1, par_ns = 0;
+  std::vector<int> members;                       // RRT*: k_max nearest store nodes of the tree, in order
+  struct Edge { int other; bool free_f, free_b; int fh_f, ns_f, fh_b, ns_b; };
+  std::vector<Edge> medges;                       // member edges (store members then mates), both directions
+  struct Conn { int tree; int node; double d; int order; bool free; int fh, ns; };
+  std::vector<Conn> conns;                        // nearest node of each OTHER tree within treeDistance
+  int accepted = -1;
+};
+}  // namespace
+
+int Rrt::run_wave(int B) {
+  using namespace sffg;
+  Ctx& c = *ctx;
+  if (iter + B > cfg.max_iterations) B = cfg.max_iterations - iter;
+  if (B <= 0) return 0;
+  const Mt64 snapshot = rng;
+  const int N0 = (int)nodes.size();
+  std::vector<WCand> w(B);
+  // ---- 1. per iteration: tree pick (:95) and steering target (:130-134), in the reference's draw order
+  for (int j = 0; j < B; ++j) {
+    w[j].draws_before = rng.draws;
+    w[j].tree = tree_frontier[rng.uniform_int(0, num_trees)];
+    draw_target(w[j].rnd);
   }
+  const uint64_t draws_end = rng.draws;
+  // ---- 2. nearest node of the frozen tree (:143), steer (:148)
+  {
+    std::vector<double> q((size_t)B * 6);
+    std::vector<int32_t> tq(B);
+    for (int j = 0; j < B; ++j) { memcpy(&q[6 * (size_t)j], w[j].rnd, 48); tq[j] = w[j].tree; }
+    std::vector<std::vector<int>> res;
+    const uint64_t keep = st.nn_queries;
+    knn(q.data(), B, tq.data(), 1, res);
+    st.nn_queries = keep;   // accounted per committed iteration below
+    for (int j = 0; j < B; ++j) {
+      w[j].nearest = res[j][0];
+      w[j].d_near = dist6(w[j].rnd, nodes[w[j].nearest].pos);
+      steer(nodes[w[j].nearest].pos, w[j].rnd, cfg.sampling_dist, w[j].np);
+    }
+  }
+  // ---- 3. new pose + parent edge (:149-151)
+  {
+    std::vector<double> p((size_t)B * 6), a((size_t)B * 6);
+    for (int j = 0; j < B; ++j) { memcpy(&p[6 * (size_t)j], w[j].np, 48); memcpy(&a[6 * (size_t)j], nodes[w[j].nearest].pos, 48); }
+    std::vector<uint8_t> hit(B), fr(B);
+    std::vector<int32_t> fh(B), ns(B);
+    c.collide_poses(p.data(), B, hit.data());
+    c.collide_segments(a.data(), p.data(), B, fr.data(), fh.data(), ns.data());
+    for (int j = 0; j < B; ++j) {
+      w[j].pose_hit = hit[j] != 0;
+      w[j].par_free = fr[j] != 0;
+      w[j].par_fh = fh[j];
+      w[j].par_ns = ns[j];
+    }
+  }
+  std::vector<int> alive;
+  for (int j = 0; j < B; ++j)
+    if (!w[j].pose_hit && w[j].par_free) alive.push_back(j);
+  const int nA = (int)alive.size();
+  // ---- 4. RRT*: k_max nearest store nodes around every surviving new point (:166)
+  const int kmax = cfg.optimize ? (int)(size_t)(2 * M_E * std::log10((double)(N0 + B))) : 0;
+  if (kmax > 0 && nA > 0) {
+    std::vector<double> q((size_t)nA * 6);
+    std::vector<int32_t> tq(nA);
+    for (int k = 0; k < nA; ++k) { memcpy(&q[6 * (size_t)k], w[alive[k]].np, 48); tq[k] = w[alive[k]].tree; }
+    std::vector<std::vector<int>> res;
+    const uint64_t keep = st.nn_queries;
+    knn(q.data(), nA, tq.data(), kmax, res);
+    st.nn_queries = keep;
+    for (int k = 0; k < nA; ++k) w[alive[k]].members = res[k];
+  }
+  // ---- 5. other trees: every node within treeDistance of the new point; per tree the nearest one (:228-231)
+  if (nA > 0 && tree_frontier.size() > 1) {
+    std::vector<double> q((size_t)nA * 6), rr(nA, cfg.dist_tree);
+    for (int k = 0; k < nA; ++k) memcpy(&q[6 * (size_t)k], w[alive[k]].np, 48);
+    int cap = 256;
+    std::vector<int32_t> idx, cnt(nA);
+    std::vector<double> dd;
+    for (int tries = 0; tries < 6; ++tries) {
+      idx.assign((size_t)nA * cap, -1);
+      dd.assign((size_t)nA * cap, 0.0);
+      c.radius(q.data(), nA, rr.data(), nullptr, nullptr, idx.data(), dd.data(), cnt.data(), cap);
+      int mx = 0;
+      for (int k = 0; k < nA; ++k) mx = std::max(mx, (int)cnt[k]);
+      if (mx <= cap) break;
+      cap = mx + 64;
+    }
+    for (int k = 0; k < nA; ++k) {
+      WCand& cd = w[alive[k]];
+      for (int h = 0; h < cnt[k]; ++h) {
+        const int id = idx[(size_t)k * cap + h];
+        const int t = nodes[id].tree;
+        if (t == cd.tree) continue;
+        const double d = dd[(size_t)k * cap + h];
+        bool found = false;
+        for (auto& cn : cd.conns)
+          if (cn.tree == t) {
+            found = true;
+            if (d < cn.d || (d == cn.d && nodes[id].idx_in_tree < cn.order)) { cn.node = id; cn.d = d; cn.order = nodes[id].idx_in_tree; }
+          }
+        if (!found) cd.conns.push_back({t, id, d, nodes[id].idx_in_tree, false, -1, 0});
+      }
+    }
+  }
+  // ---- 6. all remaining edges in one launch: RRT* member edges in both directions (store members and the
+  // earlier new points of the same tree that may enter the k-nearest set), links to other trees (store
+  // nearest and earlier new points of other trees within treeDistance)
+  std::vector<double> ea, eb;
+  auto add_edge = [&](const double* a, const double* b) {
+    int id = (int)(ea.size() / 6);
+    ea.insert(ea.end(), a, a + 6);
+    eb.insert(eb.end(), b, b + 6);
+    return id;
+  };
+  struct Ref { int cand, kind, idx; };   // kind 0 = member fwd, 1 = member bwd, 2 = store conn, 3 = mate conn
+  std::vector<Ref> refs;
+  struct MateConn { int cand, mate; int edge; };
+  std::vector<MateConn> mate_conns;
+  for (int k = 0; k < nA; ++k) {
+    const int j = alive[k];
+    WCand& cd = w[j];
+    if (kmax > 0) {
+      // distance of the k_max-th store member bounds which mates can enter the set
+      double dk = std::numeric_limits<double>::infinity();
+      if ((int)cd.members.size() >= kmax) dk = dist6(cd.np, nodes[cd.members[kmax - 1]].pos);
+      for (int id : cd.members) cd.medges.push_back({id, false, false, -1, 0, -1, 0});
+      for (int kk = 0; kk < k; ++kk) {
+        const int i = alive[kk];
+        if (w[i].tree != cd.tree) continue;
+        if (std::fabs(w[i].np[0] - cd.np[0]) > dk) continue;
+        if (dist6(cd.np, w[i].np) <= dk) cd.medges.push_back({-1 - i, false, false, -1, 0, -1, 0});
+      }
+      for (size_t e = 0; e < cd.medges.size(); ++e) {
+        const double* op = cd.medges[e].other >= 0 ? nodes[cd.medges[e].other].pos : w[-1 - cd.medges[e].other].np;
+        refs.push_back({j, 0, (int)e});
+        add_edge(cd.np, op);          // isPathFree(newPoint, neighbor)  :172
+        refs.push_back({j, 1, (int)e});
+        add_edge(op, cd.np);          // isPathFree(neighbor, newPoint)  :184
+      }
+    }
+    for (size_t e = 0; e < cd.conns.size(); ++e) {
+      refs.push_back({j, 2, (int)e});
+      add_edge(cd.np, nodes[cd.conns[e].node].pos);   // isPathFree(newPoint, neighbor)  :231
+    }
+    for (int kk = 0; kk < k; ++kk) {
+      const int i = alive[kk];
+      if (w[i].tree == cd.tree) continue;
+      if (std::fabs(w[i].np[0] - cd.np[0]) >= cfg.dist_tree) continue;
+      if (dist6(w[i].np, cd.np) < cfg.dist_tree) {
+        mate_conns.push_back({j, i, add_edge(cd.np, w[i].np)});
+        refs.push_back({j, 3, (int)mate_conns.size() - 1});
+      }
+    }
+  }
+  const int nE = (int)(ea.size() / 6);
+  std::vector<uint8_t> efr(nE);
+  std::vector<int32_t> efh(nE), ens(nE);
+  if (nE) c.collide_segments(ea.data(), eb.data(), nE, efr.data(), efh.data(), ens.data());
+  for (int e = 0; e < nE; ++e) {
+    const Ref& r = refs[e];
+    WCand& cd = w[r.cand];
+    if (r.kind == 0) { cd.medges[r.idx].free_f = efr[e] != 0; cd.medges[r.idx].fh_f = efh[e]; cd.medges[r.idx].ns_f = ens[e]; }
+    else if (r.kind == 1) { cd.medges[r.idx].free_b = efr[e] != 0; cd.medges[r.idx].fh_b = efh[e]; cd.medges[r.idx].ns_b = ens[e]; }
+    else if (r.kind == 2) { cd.conns[r.idx].free = efr[e] != 0; cd.conns[r.idx].fh = efh[e]; cd.conns[r.idx].ns = ens[e]; }
+  }
+  // ---- 7. replay in order; cut the wave at the first iteration the speculation does not cover
+  defer_append = true;
+  int done = 0;
+  bool merged = false;
+  std::vector<int> acc;   // wave indices of the iterations that became nodes
+  for (int j = 0; j < B && !merged && !solved; ++j) {
+    WCand& cd = w[j];
+    // would a node added earlier in this wave have been the nearest neighbour? (ties go to the older node)
+    bool conflict = false;
+    for (int i : acc) {
+      if (w[i].tree != cd.tree) continue;
+      if (std::fabs(w[i].np[0] - cd.rnd[0]) >= cd.d_near) continue;
+      if (dist6(cd.rnd, w[i].np) < cd.d_near) { conflict = true; break; }
+    }
+    if (conflict) break;
+    ++done;
+    ++iter;
+    const unsigned iteration = (unsigned)iter;
+    st.nn_queries += 1;                                                          // :143
+    st.collide_calls += 1;                                                       // :149
+    if (cd.pose_hit) continue;
+    st.path_free_calls += 1;
+    st.collide_calls += seg_calls(cd.par_fh, cd.par_ns);
+    if (!cd.par_free) continue;
+    int tree_to_expand = cd.tree;
+    int nearest = cd.nearest;
+    int new_id;
+    if (cfg.optimize) {                                                          // :156-201
+      double best = dist6(cd.np, nodes[nearest].pos) + nodes[nearest].d_root;
+      const size_t krrt = (size_t)(2 * M_E * std::log10((double)nodes.size()));
+      st.nn_queries += 1;
+      struct KN { double d; int order; int node; const WCand::Edge* e; };
+      std::vector<KN> kn;
+      for (const WCand::Edge& e : cd.medges) {
+        int nd = e.other >= 0 ? e.other : w[-1 - e.other].accepted;
+        if (nd < 0) continue;
+        kn.push_back({dist6(cd.np, nodes[nd].pos), nodes[nd].idx_in_tree, nd, &e});
+      }
+      std::sort(kn.begin(), kn.end(), [](const KN& a, const KN& b) { return a.d < b.d || (a.d == b.d && a.order < b.order); });
+      if (kn.size() > krrt) kn.resize(krrt);
+      if (kn.size() < std::min(krrt, trees[tree_to_expand].size()))
+        throw HipError{"rrt: k-nearest candidate set incomplete (internal error)"};
+      for (const KN& x : kn) {                                                   // :168-175
+        double nd = dist6(cd.np, nodes[x.node].pos) + nodes[x.node].d_root;
+        if (nd < best - SFFG_TOL) {
+          st.path_free_calls += 1;
+          st.collide_calls += seg_calls(x.e->fh_f, x.e->ns_f);
+          if (x.e->free_f) { best = nd; nearest = x.node; }
+        }
+      }
+      new_id = add_node(cd.np, nodes[nearest].root_tree, tree_to_expand, nearest, dist6(nodes[nearest].pos, cd.np), best, iteration);
+      for (const KN& x : kn) {                                                   // :181-201
+        double npd = dist6(nodes[x.node].pos, cd.np);
+        double proposed = best + npd;
+        if (proposed < nodes[x.node].d_root - SFFG_TOL) {
+          st.path_free_calls += 1;
+          st.collide_calls += seg_calls(x.e->fh_b, x.e->ns_b);
+          if (x.e->free_b) {
+            nodes[x.node].parent = new_id;
+            nodes[x.node].root_tree = nodes[new_id].root_tree;
+            nodes[x.node].d_closest = npd;
+            nodes[x.node].d_root = proposed;
+          }
+        }
+      }
+    } else {                                                                     // :203
+      new_id = add_node(cd.np, nodes[nearest].root_tree, tree_to_expand, nearest, cfg.sampling_dist,
+                        nodes[nearest].d_root + cfg.sampling_dist, iteration);
+    }
+    cd.accepted = new_id;
+    acc.push_back(j);
+    // :219-319 links to the other live trees, in frontier order
+    for (int i = 0; i < (int)tree_frontier.size(); ++i) {
+      const int tree = tree_frontier[i];
+      if (tree == tree_to_expand) continue;
+      st.nn_queries += 1;
+      // nearest node of that tree: the frozen tree's candidate vs the nodes it gained earlier in this wave
+      int nb = -1, nb_order = 0, fh = -1, ns = 0;
+      double nbd = 0;
+      bool nb_free = false;
+      for (const WCand::Conn& cn : cd.conns)
+        if (cn.tree == tree) { nb = cn.node; nbd = cn.d; nb_order = cn.order; nb_free = cn.free; fh = cn.fh; ns = cn.ns; }
+      for (const MateConn& mc : mate_conns) {
+        if (mc.cand != j || w[mc.mate].tree != tree || w[mc.mate].accepted < 0) continue;
+        const int id = w[mc.mate].accepted;
+        const double d = dist6(nodes[id].pos, cd.np);
+        if (nb < 0 || d < nbd || (d == nbd && nodes[id].idx_in_tree < nb_order)) {
+          nb = id; nbd = d; nb_order = nodes[id].idx_in_tree; nb_free = efr[mc.edge] != 0; fh = efh[mc.edge]; ns = ens[mc.edge];
+        }
+      }
+      if (nb < 0) continue;                        // nothing of that tree within treeDistance: :231 is false
+      if (!(dist6(nodes[nb].pos, cd.np) < cfg.dist_tree)) continue;
+      st.path_free_calls += 1;
+      st.collide_calls += seg_calls(fh, ns);
+      if (!nb_free) continue;
+      tree_to_expand = merge_or_link(tree_to_expand, new_id, nb, true, 0, 0, i);
+      merged = true;                               // tree ids / frontier changed: later picks are stale
+    }
+  }
+  // ---- 8. commit: device store, RNG position
+  if (!pend_tree.empty()) {
+    c.store_append(pend_pos.data(), pend_tree.data(), (int)pend_tree.size());
+    pend_pos.clear();
+    pend_tree.clear();
+  }
+  defer_append = false;
+  if (done < B) {
+    const uint64_t target = w[done].draws_before;
+    rng = snapshot;
+    while (rng.draws < target) rng.next();
+  } else if (rng.draws != draws_end) {
+    throw HipError{"rrt: RNG bookkeeping error"};
+  }
+  st.waves += 1;
+  st.speculated += (uint64_t)B;
+  st.committed += (uint64_t)done;
+  return done;
 }
 
 void Rrt::run(int max_iters) {
   auto t0 = std::chrono::steady_clock::now();
   int done = 0;
+  int B = 1;
   while (!(solved || iter == cfg.max_iterations)) {                             // :93
     if (max_iters > 0 && done >= max_iters) break;
-    ++done;
-    ++iter;
-    int tree = tree_frontier[rng.uniform_int(0, num_trees)];                    // :95
-    expand(tree, (unsigned)iter);
+    if (cfg.wave == 1) {
+      ++done;
+      ++iter;
+      int tree = tree_frontier[rng.uniform_int(0, num_trees)];                  // :95
+      expand(tree, (unsigned)iter);
+      continue;
+    }
+    // wave size: fixed by the caller, or adapted to how much of the last wave survived
+    int want = cfg.wave > 1 ? cfg.wave : B;
+    if (max_iters > 0) want = std::min(want, max_iters - done);
+    const int got = run_wave(std::max(1, want));
+    done += got;
+    if (cfg.wave <= 0) {
+      if (got >= want) B = std::min(4096, B * 2);
+      else B = std::max(1, std::min(4096, (3 * got) / 2 + 1));
+    }
+    if (got == 0 && want > 0 && iter >= cfg.max_iterations) break;
   }
   st.total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }

@@ -345,15 +345,23 @@ def test_rrt_identical(S, ctx, name, optimize, n_roots, goal, bias, iters):
               priority_bias=bias, max_iterations=iters, seed=3)
     ro = O.Rrt(w, roots, sc["limits"], **kw)
     ro.run()
-    rg = S.Rrt(ctx, roots, sc["limits"], **kw)
-    rg.run()
-    so, sg = ro.stats(), rg.stats()
-    for k in so:
-        assert so[k] == sg[k], (k, so[k], sg[k])
-    no, ng = ro.nodes(), rg.nodes()
-    for k in no:
-        assert np.array_equal(no[k], ng[k]), k
-    lo, lg = ro.links(), rg.links()
-    for k in lo:
-        assert np.array_equal(lo[k], lg[k]), k
+    so = ro.stats()
+    no, lo = ro.nodes(), ro.links()
     assert so["n_nodes"] > 30
+    # wave = 1: one iteration per GPU round trip; 0: adaptive speculative waves; 64 / 1000: fixed wave sizes.
+    # Every wave size must commit exactly the reference's sequence (conflicts cut the wave, the RNG rewinds).
+    for wave in (1, 0, 64, 1000):
+        rg = S.Rrt(ctx, roots, sc["limits"], wave=wave, **kw)
+        rg.run()
+        sg = rg.stats()
+        for k in so:
+            assert so[k] == sg[k], (wave, k, so[k], sg[k])
+        ng = rg.nodes()
+        for k in no:
+            assert np.array_equal(no[k], ng[k]), (wave, k)
+        lg = rg.links()
+        for k in lo:
+            assert np.array_equal(lo[k], lg[k]), (wave, k)
+        if wave != 1:
+            assert sg["waves"] < so["iterations"] or so["iterations"] < 8
+        rg.close()
