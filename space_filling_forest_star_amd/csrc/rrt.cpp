@@ -260,7 +260,7 @@ int Rrt::merge_or_link(int tree_to_expand, int new_id, int nb, bool, int, int, i
 // them in order on the host.  The replay checks, with the exact metric, whether a node accepted earlier in
 // the same wave would have been the nearest neighbour of iteration j (or a tree merge happened): if so the
 // wave is cut at j, the RNG is rewound to the start of iteration j, and j starts the next wave.  Whatever
-// is committed is therefore exactly what the one-by-one loop produces — the oracle needs no wave notion.
+// is committed is therefore exactly what the one-by-one loop produces, at every wave size.
 // ---------------------------------------------------------------------------------------------------
 namespace {
 struct WCand {
