@@ -13,12 +13,7 @@
 template <class T, class R = Point<T>>
 class SpaceForest : public Solver<T, R> {
  public:
-  SpaceForest(Problem<T>& problem) : Solver<T, R>(problem) {
-    if (this->usePriority) {   // src/heap.h priority frontier: host-only mode, not in this build yet
-      std::cout << "SpaceForest: priorityBias != 0 (priority frontier) is not implemented in this build\n";
-      std::exit(1);
-    }
-  }
+  SpaceForest(Problem<T>& problem) : Solver<T, R>(problem) {}
 
   void Solve() override {
     Problem<T>& P = this->problem;
@@ -43,6 +38,7 @@ class SpaceForest : public Solver<T, R> {
                  : (uint64_t)std::chrono::high_resolution_clock::now().time_since_epoch().count();
     cfg.rank = 0;
     cfg.world = 1;
+    cfg.priority_bias = P.priorityBias;   // != 0: priority frontier heaps (src/heap.h)
     std::vector<double> roots;
     for (const Point<T>& p : P.roots) {
       double a[6];

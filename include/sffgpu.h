@@ -93,6 +93,8 @@ typedef struct {
   uint64_t seed;            /* mt19937_64 seed (reference: clock, src/randGen.h:52-55) */
   int32_t rank;             /* multi-GPU: this process's shard of every wave ... */
   int32_t world;            /* ... out of `world` shards (1 = single GPU) */
+  double priority_bias;     /* Problem::priorityBias: != 0 selects frontier nodes through the priority heaps of
+                               src/heap.h (best node with this probability, a random one otherwise; src/forest.h:126-147) */
 } sffgpu_forest_cfg;
 
 typedef struct {

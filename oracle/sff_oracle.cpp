@@ -571,6 +571,52 @@ struct Grid {
   }
 };
 
+
+// Priority frontier (src/heap.h): binary min-heap of node ids keyed by Distance(node, refPoint)
+// (src/primitives.h:726-729), with the reference's BubbleUp / BubbleDown and its pop-at-index.
+struct PHeap {
+  std::vector<int> v;
+  const std::vector<FNode>* nodes = nullptr;
+  double ref[6];
+  double cost(int i) const { return distance6((*nodes)[v[i]].pos, ref); }   // HEAPCOST_GET
+  void bubble_down(int index) {                                              // src/heap.h:122-153
+    const int size = (int)v.size();
+    const int l = 2 * index + 1, r = 2 * index + 2;
+    if (l >= size) return;
+    int mi = index;
+    if (cost(index) > cost(l)) mi = l;
+    if (r < size && cost(mi) > cost(r)) mi = r;
+    if (mi != index) { std::swap(v[index], v[mi]); bubble_down(mi); }
+  }
+  void bubble_up(int index) {                                                // src/heap.h:155-173
+    if (index == 0) return;
+    const int p = (index - 1) / 2;
+    if (cost(p) > cost(index)) { std::swap(v[p], v[index]); bubble_up(p); }
+  }
+  void push(int n) { v.push_back(n); bubble_up((int)v.size() - 1); }         // :175-187
+  int pop() {                                                                // :189-207
+    int mn = v[0];
+    v[0] = v.back();
+    v.pop_back();
+    bubble_down(0);
+    return mn;
+  }
+  int pop_at(int id) {                                                       // :209-238
+    const int size = (int)v.size();
+    const double old_cost = cost(id);
+    int val = -1;
+    if (id == size - 1) { val = v.back(); v.pop_back(); }
+    else if (size > id) {
+      const double new_cost = cost(size - 1);
+      val = v[id];
+      v[id] = v[size - 1];
+      v.pop_back();
+      if (new_cost < old_cost) bubble_up(id); else bubble_down(id);
+    }
+    return val;
+  }
+};
+
 struct Forest {
   World* w;
   sffo_forest_cfg cfg;
@@ -586,6 +632,16 @@ struct Forest {
   bool solved = false, empty_frontier = false;
   uint64_t path_free_calls = 0, nn_queries = 0, waves = 0, collide_base = 0;
   Grid grid;
+  std::vector<std::vector<PHeap>> heaps;    // Tree::frontiers, only with priorityBias != 0
+  bool use_priority() const { return cfg.priority_bias != 0; }
+  bool tree_frontiers_empty(int t) const {   // Tree::EmptyFrontiers (src/primitives.h:542-556; the filter is never set)
+    for (const PHeap& h : heaps[t]) if (!h.v.empty()) return false;
+    return true;
+  }
+  bool all_frontiers_empty() const {
+    for (size_t t = 0; t < heaps.size(); ++t) if (!tree_frontiers_empty((int)t)) return false;
+    return true;
+  }
 
   bool path_free(const double* a, const double* b) {
     ++path_free_calls;
@@ -717,7 +773,11 @@ struct Forest {
     } else {
       new_id = add_node(np, my_tree, expanded, parent_dist, parent_dist + nodes[expanded].d_root, iteration);  // :353
     }
-    frontier.push_back(new_id);                                // :365
+    if (use_priority()) {                                      // :360-363
+      for (PHeap& h : heaps[my_tree]) h.push(new_id);
+    } else {
+      frontier.push_back(new_id);                              // :365
+    }
     if (solved) {                                              // :369-372
       double d = distance6(np, cfg.goal);
       border(num_roots - 1, my_tree).push_back({std::min(new_id, goal_node), std::max(new_id, goal_node),
@@ -883,7 +943,7 @@ struct Forest {
   // src/forest.h:122-202, generalised to waves of cfg.wave slots; wave == 1 is the
   // reference loop verbatim (same RNG consumption order).
   void run(int max_waves) {
-    struct Slot { int node; bool from_closed; bool failing; };
+    struct Slot { int node; bool from_closed; bool failing; int tree = -1, heap = -1; };
     int done = 0;
     const int words_per = cfg.dim == 2 ? 1 : 6;
     while (!(solved || iter >= cfg.max_iterations || budget_hit())) {
@@ -891,6 +951,27 @@ struct Forest {
       ++done;
       ++waves;
       std::vector<Slot> slots;
+      if (use_priority() && !empty_frontier) {                 // :126-147 priority frontier
+        int pool = 0;
+        for (auto& hs : heaps) if (!hs.empty()) pool += (int)hs[0].v.size();
+        const int n_slots = std::max(1, std::min(cfg.wave, pool));
+        for (int s = 0; s < n_slots; ++s) {
+          if (all_frontiers_empty()) break;                    // every frontier node is already in a slot
+          int t = -1;
+          while (t < 0 || tree_frontiers_empty(t)) t = rng.rand_int(0, (int)trees.size() - 1);
+          int hp = -1;
+          while (hp < 0 || heaps[t][hp].v.empty()) hp = rng.rand_int(0, (int)heaps[t].size() - 1);
+          PHeap& prior = heaps[t][hp];
+          Slot sl;
+          if (rng.prob() <= cfg.priority_bias) sl.node = prior.pop();
+          else sl.node = prior.pop_at(rng.rand_int(0, (int)prior.v.size() - 1));
+          sl.from_closed = false;
+          sl.failing = true;
+          sl.tree = t;
+          sl.heap = hp;
+          slots.push_back(sl);
+        }
+      } else {
       // a wave never holds more slots than the pool it draws from (wave == 1 unaffected)
       const int pool = (!closed.empty() && empty_frontier) ? (int)closed.size() : (int)frontier.size();
       const int n_slots = std::max(1, std::min(cfg.wave, pool));
@@ -908,6 +989,7 @@ struct Forest {
         sl.failing = true;
         slots.push_back(sl);
       }
+      }
       for (int round = 0; round < cfg.threshold_misses && !solved; ++round) {  // :155
         for (Slot& sl : slots) {
           if (!sl.failing || iter >= cfg.max_iterations || solved) continue;
@@ -917,7 +999,24 @@ struct Forest {
           sl.failing = expand_node(sl.node, (unsigned)iter, words);
         }
       }
-      for (Slot& sl : slots) {                                 // :160-178
+      for (Slot& sl : slots) {                                 // :160-181
+        if (use_priority() && sl.tree >= 0) {
+          if (sl.failing) {                                    // exhausted: drop it from the tree's other heaps too
+            for (int i = (int)heaps[sl.tree].size() - 1; i > -1; --i) {
+              if (i == sl.heap) continue;
+              PHeap& p = heaps[sl.tree][i];
+              for (int j = (int)p.v.size() - 1; j > -1; --j)
+                if (j < (int)p.v.size() && p.v[j] == sl.node) p.pop_at(j);
+            }
+            if (!nodes[sl.node].force_children) {
+              nodes[sl.node].force_children = true;
+              closed.push_back(sl.node);
+            }
+          } else {
+            heaps[sl.tree][sl.heap].push(sl.node);             // :179-181 back onto the heap it was taken from
+          }
+          continue;
+        }
         if (sl.failing && !sl.from_closed) {
           auto it = std::find(frontier.begin(), frontier.end(), sl.node);
           if (it != frontier.end()) {
@@ -927,6 +1026,8 @@ struct Forest {
           }
         }
       }
+      if (!solved && use_priority()) empty_frontier = all_frontiers_empty();  // :184-191
+      else
       empty_frontier = frontier.empty();                       // :193
       if (!solved) {                                           // :196-201
         bool conn = max_connected() == num_roots;
@@ -1220,6 +1321,24 @@ sffo_forest* sffo_forest_create(sffo_world* w, const sffo_forest_cfg* cfg, const
     f.frontier.push_back(id);
   }
   if (cfg->has_goal) f.goal_node = f.add_node(cfg->goal, n_roots, -1, 0, 0, 0);
+  if (f.use_priority()) {                      // Tree::AddFrontier (src/primitives.h:530-540) as called at src/forest.h:78-88,104-108
+    f.heaps.resize(f.num_roots);
+    auto add_heap = [&](int tree, int ref_node) {
+      PHeap hp;
+      hp.nodes = &f.nodes;
+      memcpy(hp.ref, f.nodes[ref_node].pos, sizeof hp.ref);
+      for (int id : f.trees[tree]) hp.v.push_back(id);
+      for (int k = (int)hp.v.size() - 1; k >= 0; --k) hp.bubble_down(k);   // Heap::sort
+      f.heaps[tree].push_back(hp);
+    };
+    if (!cfg->has_goal) {
+      for (int i = 0; i < n_roots; ++i)
+        for (int j = 0; j < n_roots; ++j)
+          if (i != j) add_heap(i, f.trees[j][0]);
+    } else {
+      for (int i = 0; i < n_roots; ++i) add_heap(i, f.goal_node);
+    }
+  }
   return h;
 }
 void sffo_forest_destroy(sffo_forest* h) { delete h; }

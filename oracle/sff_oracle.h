@@ -78,6 +78,7 @@ typedef struct {
   int wave;                /* slots per wave; 1 == the reference's sequential loop */
   uint64_t seed;
   int trig;
+  double priority_bias;    /* Problem::priorityBias != 0 -> priority frontier heaps (src/heap.h, src/forest.h:126-147) */
 } sffo_forest_cfg;
 
 typedef struct {

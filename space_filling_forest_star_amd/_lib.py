@@ -34,7 +34,8 @@ class ForestCfg(C.Structure):
     _fields_ = [("dim", C.c_int32), ("optimize", C.c_int32), ("has_goal", C.c_int32), ("goal", C.c_double * 6),
                 ("limits", C.c_double * 6), ("dist_tree", C.c_double), ("sampling_dist", C.c_double),
                 ("threshold_misses", C.c_int32), ("max_iterations", C.c_int32), ("node_budget", C.c_int32),
-                ("wave", C.c_int32), ("seed", C.c_uint64), ("rank", C.c_int32), ("world", C.c_int32)]
+                ("wave", C.c_int32), ("seed", C.c_uint64), ("rank", C.c_int32), ("world", C.c_int32),
+                ("priority_bias", C.c_double)]
 
 
 class ForestStats(C.Structure):
@@ -246,9 +247,11 @@ class Forest:
     """SpaceForest solver session (reference src/forest.h:31-54) on one Context."""
 
     def __init__(self, ctx, roots, limits, dist_tree, sampling_dist, dim=6, optimize=False, goal=None,
-                 threshold_misses=5, max_iterations=100000, node_budget=0, wave=1, seed=1, rank=0, world=1):
+                 threshold_misses=5, max_iterations=100000, node_budget=0, wave=1, seed=1, rank=0, world=1,
+                 priority_bias=0.0):
         self.ctx = ctx
         cfg = ForestCfg()
+        cfg.priority_bias = priority_bias
         cfg.dim = dim
         cfg.optimize = int(optimize)
         cfg.has_goal = int(goal is not None)

@@ -143,6 +143,19 @@ struct Border {
   double dist;
 };
 
+// Priority frontier (src/heap.h): binary min-heap of node ids keyed by Distance(node, refPoint)
+struct PHeap {
+  std::vector<int> v;
+  const std::vector<FNode>* nodes = nullptr;
+  double ref[6];
+  double cost(int i) const;
+  void bubble_down(int index);
+  void bubble_up(int index);
+  void push(int n);
+  int pop();
+  int pop_at(int id);
+};
+
 struct Forest {
   Ctx* ctx;
   sffgpu_forest_cfg cfg;
@@ -158,8 +171,12 @@ struct Forest {
   bool solved = false, empty_frontier = false;
   sffgpu_forest_stats st{};
 
-  struct Slot { int node; bool from_closed; bool failing; };
+  struct Slot { int node; bool from_closed; bool failing; int tree = -1, heap = -1; };
   std::vector<Slot> slots;
+  std::vector<std::vector<PHeap>> heaps;   // Tree::frontiers (priorityBias != 0 only)
+  bool use_priority() const { return cfg.priority_bias != 0; }
+  bool tree_frontiers_empty(int t) const;
+  bool all_frontiers_empty() const;
   int round = 0;
   bool in_wave = false;
 

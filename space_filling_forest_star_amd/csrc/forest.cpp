@@ -38,6 +38,53 @@ static double ms_since(Clock::time_point t0) {
   return std::chrono::duration<double, std::milli>(Clock::now() - t0).count();
 }
 
+// ---- priority frontier heap: the reference's BubbleDown / BubbleUp / pop-at-index (src/heap.h:122-238)
+double PHeap::cost(int i) const { return sffg::dist6((*nodes)[v[i]].pos, ref); }   // Distance(node, refPoint)
+void PHeap::bubble_down(int index) {
+  const int size = (int)v.size();
+  const int l = 2 * index + 1, r = 2 * index + 2;
+  if (l >= size) return;
+  int mi = index;
+  if (cost(index) > cost(l)) mi = l;
+  if (r < size && cost(mi) > cost(r)) mi = r;
+  if (mi != index) { std::swap(v[index], v[mi]); bubble_down(mi); }
+}
+void PHeap::bubble_up(int index) {
+  if (index == 0) return;
+  const int p = (index - 1) / 2;
+  if (cost(p) > cost(index)) { std::swap(v[p], v[index]); bubble_up(p); }
+}
+void PHeap::push(int n) { v.push_back(n); bubble_up((int)v.size() - 1); }
+int PHeap::pop() {
+  int mn = v[0];
+  v[0] = v.back();
+  v.pop_back();
+  bubble_down(0);
+  return mn;
+}
+int PHeap::pop_at(int id) {
+  const int size = (int)v.size();
+  const double old_cost = cost(id);
+  int val = -1;
+  if (id == size - 1) { val = v.back(); v.pop_back(); }
+  else if (size > id) {
+    const double new_cost = cost(size - 1);
+    val = v[id];
+    v[id] = v[size - 1];
+    v.pop_back();
+    if (new_cost < old_cost) bubble_up(id); else bubble_down(id);
+  }
+  return val;
+}
+bool Forest::tree_frontiers_empty(int t) const {   // Tree::EmptyFrontiers (src/primitives.h:542-556)
+  for (const PHeap& h : heaps[t]) if (!h.v.empty()) return false;
+  return true;
+}
+bool Forest::all_frontiers_empty() const {
+  for (size_t t = 0; t < heaps.size(); ++t) if (!tree_frontiers_empty((int)t)) return false;
+  return true;
+}
+
 Forest::Forest(Ctx* c, const sffgpu_forest_cfg& cf, const double* roots6, int n_roots) : ctx(c), cfg(cf) {
   if (cfg.wave < 1) cfg.wave = 1;
   if (cfg.dim != 2 && cfg.dim != 6) throw HipError{"forest: dim must be 2 or 6"};
@@ -70,6 +117,24 @@ Forest::Forest(Ctx* c, const sffgpu_forest_cfg& cf, const double* roots6, int n_
     ctx->store_append(cfg.goal, &gt, 1);
   }
   ctx->grid_insert_new();
+  if (use_priority()) {            // Tree::AddFrontier as called at src/forest.h:78-88 / :104-108
+    heaps.resize(num_roots);
+    auto add_heap = [&](int tree, int ref_node) {
+      PHeap hp;
+      hp.nodes = &nodes;
+      memcpy(hp.ref, nodes[ref_node].pos, sizeof hp.ref);
+      for (int id : trees[tree]) hp.v.push_back(id);
+      for (int k = (int)hp.v.size() - 1; k >= 0; --k) hp.bubble_down(k);   // Heap::sort
+      heaps[tree].push_back(hp);
+    };
+    if (!cfg.has_goal) {
+      for (int i = 0; i < n_roots; ++i)
+        for (int j = 0; j < n_roots; ++j)
+          if (i != j) add_heap(i, trees[j][0]);
+    } else {
+      for (int i = 0; i < n_roots; ++i) add_heap(i, goal_node);
+    }
+  }
   memset(&st, 0, sizeof st);
   knn_r = 2.5 * cfg.sampling_dist;
   if (const char* e = getenv("SFFGPU_TEST_HITCAP")) hit_cap = std::min(64, std::max(1, atoi(e)));  // one lane per hit
@@ -129,20 +194,42 @@ int Forest::max_connected() {
 // node selection for every slot of the wave, src/forest.h:136-151 (non-priority mode)
 void Forest::begin_wave() {
   slots.clear();
-  const bool use_closed = !closed.empty() && empty_frontier;
-  const int pool = use_closed ? (int)closed.size() : (int)frontier.size();
-  const int n_slots = std::max(1, std::min(cfg.wave, pool));
-  for (int s = 0; s < n_slots; ++s) {
-    Slot sl;
-    if (use_closed) {
-      sl.node = closed[rng.uniform_int(0, (int)closed.size() - 1)];
-      sl.from_closed = true;
-    } else {
-      sl.node = frontier[rng.uniform_int(0, (int)frontier.size() - 1)];
+  if (use_priority() && !empty_frontier) {     // src/forest.h:126-147 priority frontier
+    int pool = 0;
+    for (auto& hs : heaps) if (!hs.empty()) pool += (int)hs[0].v.size();
+    const int n_slots = std::max(1, std::min(cfg.wave, pool));
+    for (int s = 0; s < n_slots; ++s) {
+      if (all_frontiers_empty()) break;        // every frontier node is already held by a slot
+      int t = -1;
+      while (t < 0 || tree_frontiers_empty(t)) t = rng.uniform_int(0, (int)trees.size() - 1);
+      int hp = -1;
+      while (hp < 0 || heaps[t][hp].v.empty()) hp = rng.uniform_int(0, (int)heaps[t].size() - 1);
+      PHeap& prior = heaps[t][hp];
+      Slot sl;
+      if (sffg::uniform_real(rng.next(), 0.0, 1.0) <= cfg.priority_bias) sl.node = prior.pop();     // :143-144
+      else sl.node = prior.pop_at(rng.uniform_int(0, (int)prior.v.size() - 1));                      // :145-147
       sl.from_closed = false;
+      sl.failing = true;
+      sl.tree = t;
+      sl.heap = hp;
+      slots.push_back(sl);
     }
-    sl.failing = true;
-    slots.push_back(sl);
+  } else {
+    const bool use_closed = !closed.empty() && empty_frontier;
+    const int pool = use_closed ? (int)closed.size() : (int)frontier.size();
+    const int n_slots = std::max(1, std::min(cfg.wave, pool));
+    for (int s = 0; s < n_slots; ++s) {
+      Slot sl;
+      if (use_closed) {
+        sl.node = closed[rng.uniform_int(0, (int)closed.size() - 1)];
+        sl.from_closed = true;
+      } else {
+        sl.node = frontier[rng.uniform_int(0, (int)frontier.size() - 1)];
+        sl.from_closed = false;
+      }
+      sl.failing = true;
+      slots.push_back(sl);
+    }
   }
   round = 0;
   in_wave = true;
@@ -155,6 +242,23 @@ void Forest::end_wave() {
   // removals of a wave are applied in one order-preserving compaction, which leaves the same deque
   bool removed = false;
   for (Slot& sl : slots) {
+    if (use_priority() && sl.tree >= 0) {      // src/forest.h:164-181
+      if (sl.failing) {                        // exhausted: drop it from the tree's other heaps too
+        for (int i = (int)heaps[sl.tree].size() - 1; i > -1; --i) {
+          if (i == sl.heap) continue;
+          PHeap& p = heaps[sl.tree][i];
+          for (int j = (int)p.v.size() - 1; j > -1; --j)
+            if (j < (int)p.v.size() && p.v[j] == sl.node) p.pop_at(j);
+        }
+        if (!nodes[sl.node].force_children) {
+          nodes[sl.node].force_children = true;
+          closed.push_back(sl.node);
+        }
+      } else {
+        heaps[sl.tree][sl.heap].push(sl.node); // back onto the heap it was taken from
+      }
+      continue;
+    }
     if (sl.failing && !sl.from_closed && nodes[sl.node].on_frontier) {
       nodes[sl.node].on_frontier = false;
       nodes[sl.node].force_children = true;
@@ -169,7 +273,8 @@ void Forest::end_wave() {
     frontier.resize(w);
   }
   ctx->grid_check();
-  empty_frontier = frontier.empty();
+  if (!solved && use_priority()) empty_frontier = all_frontiers_empty();   // src/forest.h:184-191
+  else empty_frontier = frontier.empty();
   if (!solved) {
     bool conn = max_connected() == num_roots;
     solved = (!cfg.has_goal && empty_frontier && conn);
@@ -842,8 +947,12 @@ void Forest::round_commit(const int32_t* all, const int32_t* counts, int world) 
       id = add_node(cd.pos, mine, expanded, cd.pdist, cd.pdist + nodes[expanded].d_root, iteration);  // :353
     }
     cd.accepted_id = id;
-    frontier.push_back(id);                                    // :365
-    nodes[id].on_frontier = true;
+    if (use_priority()) {                                      // :360-363
+      for (PHeap& h : heaps[mine]) h.push(id);
+    } else {
+      frontier.push_back(id);                                  // :365
+      nodes[id].on_frontier = true;
+    }
     if (solved) {                                              // :369-372
       double gd = sffg::dist6(cd.pos, cfg.goal);
       border(num_roots - 1, mine).push_back({std::min(id, goal_node), std::max(id, goal_node), nodes[id].d_root + gd});

@@ -22,7 +22,7 @@ class ForestCfg(C.Structure):
     _fields_ = [("dim", C.c_int), ("optimize", C.c_int), ("has_goal", C.c_int), ("goal", C.c_double * 6),
                 ("limits", C.c_double * 6), ("dist_tree", C.c_double), ("sampling_dist", C.c_double),
                 ("threshold_misses", C.c_int), ("max_iterations", C.c_int), ("node_budget", C.c_int),
-                ("wave", C.c_int), ("seed", C.c_uint64), ("trig", C.c_int)]
+                ("wave", C.c_int), ("seed", C.c_uint64), ("trig", C.c_int), ("priority_bias", C.c_double)]
 
 
 class ForestStats(C.Structure):
@@ -204,9 +204,11 @@ class World:
 
 class Forest:
     def __init__(self, world, roots, limits, dist_tree, sampling_dist, dim=6, optimize=False, goal=None,
-                 threshold_misses=5, max_iterations=100000, node_budget=0, wave=1, seed=1, trig=None):
+                 threshold_misses=5, max_iterations=100000, node_budget=0, wave=1, seed=1, trig=None,
+                 priority_bias=0.0):
         self.world = world
         cfg = ForestCfg()
+        cfg.priority_bias = priority_bias
         cfg.dim = dim
         cfg.optimize = int(optimize)
         cfg.has_goal = int(goal is not None)

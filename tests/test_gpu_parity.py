@@ -136,14 +136,14 @@ def test_radius_and_knn_exact(ctx):
     assert np.all(cnt == want)
 
 
-def run_pair(S, ctx, name, wave, iters, seed, n_roots=5, budget=0, optimize=False, goal_idx=None):
+def run_pair(S, ctx, name, wave, iters, seed, n_roots=5, budget=0, optimize=False, goal_idx=None, priority_bias=0.0):
     sc, w = load_world(ctx, name)
     if sc["xml_points"] is not None:
         roots = sc["xml_points"][:n_roots]
     else:
         roots = common.free_roots(w.collide, sc["limits"], n_roots, seed=seed, dim=sc["dim"])
     kw = dict(dist_tree=sc["dist_tree"], sampling_dist=sc["sampling_dist"], dim=sc["dim"], max_iterations=iters,
-              node_budget=budget, wave=wave, seed=seed, optimize=optimize)
+              node_budget=budget, wave=wave, seed=seed, optimize=optimize, priority_bias=priority_bias)
     if goal_idx is not None:   # a goal a few steps away from the first root (free in triang / building)
         g = roots[0].copy()
         g[:3] += np.array(goal_idx, dtype=np.float64)
@@ -243,6 +243,22 @@ def test_path_costs_and_plans_match(S, ctx, optimize):
         for j in range(i + 1, len(do)):
             assert np.array_equal(fo.plan(i, j), fg.plan(i, j))
     assert fo.stats()["collide_calls"] == fg.stats()["collide_calls"]
+
+
+@pytest.mark.parametrize("name,wave,n_roots,optimize,goal", [
+    ("dense3d_coarse", 1, 5, False, None), ("dense3d_coarse", 64, 5, False, None), ("triang", 128, 4, True, None),
+    ("triang", 1, 1, False, [12, 8, 5]), ("triang", 32, 2, False, [12, 8, 5]), ("dense2d", 16, 3, False, None),
+])
+def test_priority_frontier_mode(S, ctx, name, wave, n_roots, optimize, goal):
+    """Problem::priorityBias = 0.95 (what the reference's example XMLs set): frontier nodes come from the
+    per-tree priority heaps of src/heap.h (best node w.p. bias, random heap position otherwise)."""
+    fo, fg = run_pair(S, ctx, name, wave, 5000, seed=14, n_roots=n_roots, optimize=optimize, goal_idx=goal,
+                      priority_bias=0.95)
+    assert fo.stats()["n_nodes"] > 5
+    assert_same_forest(fo, fg)
+    # and it is not the plain mode in disguise
+    fp, _ = run_pair(S, ctx, name, wave, 5000, seed=14, n_roots=n_roots, optimize=optimize, goal_idx=goal)
+    assert fp.fingerprint() != fo.fingerprint()
 
 
 def test_forest_node_budget_and_seeds(S, ctx):
