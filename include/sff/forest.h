@@ -15,6 +15,23 @@ class SpaceForest : public Solver<T, R> {
  public:
   SpaceForest(Problem<T>& problem) : Solver<T, R>(problem) {}
 
+  // src/forest.h:513-568
+  void saveFrontiers(const FileStruct file, const std::vector<int32_t>& open_nodes) {
+    std::ofstream f;
+    if (!this->open(f, file, "Saving frontiers")) return;
+    if (file.type == Obj) f << "o Open nodes\n";
+    for (int32_t id : open_nodes) {
+      const Point<T> p = this->allNodes[id].Position / this->problem.environment.ScaleFactor;
+      if (file.type == Obj) {
+        f << "v" << DELIMITER_OUT;
+        if (this->usePriority) p.printPosOnly(f); else f << p;
+        f << "\n";
+      } else {
+        f << p << DELIMITER_OUT << "1\n";
+      }
+    }
+  }
+
   void Solve() override {
     Problem<T>& P = this->problem;
     P.environment.upload();
@@ -85,9 +102,15 @@ class SpaceForest : public Solver<T, R> {
       loadPlans();
       if (SaveSmooth <= P.saveOptions) this->savePaths(P.fileNames[SaveSmooth]);
     }
+    std::vector<int32_t> open_nodes;
+    if (SaveFrontiers <= P.saveOptions) {
+      int k = sffgpu_forest_get_frontier(f, nullptr, 0);
+      open_nodes.resize(k > 0 ? k : 0);
+      if (k > 0) sffgpu_forest_get_frontier(f, open_nodes.data(), k);
+    }
     sffgpu_forest_destroy(f);
     if (SaveParams <= P.saveOptions) this->saveParams(P.fileNames[SaveParams], st.iterations, st.solved != 0, stopTime - startingTime);
     if (SaveTSP <= P.saveOptions) this->saveTsp(P.fileNames[SaveTSP]);
-    if (SaveFrontiers <= P.saveOptions) std::cout << "SpaceForest: frontier dump is not implemented in this build\n";
+    if (SaveFrontiers <= P.saveOptions) saveFrontiers(P.fileNames[SaveFrontiers], open_nodes);
   }
 };

@@ -49,12 +49,24 @@ class RapidExpTree : public Solver<T, R> {
     this->fillNodes(n, pos.data(), parent.data(), root.data(), iter.data(), cost.data(), dpar.data());
     this->numTrees = P.GetNumRoots();
     this->neighboringMatrix.assign((size_t)this->numTrees * this->numTrees, 1.7976931348623157e308);
+    std::vector<int32_t> conn(this->numTrees);
+    int nc = sffgpu_rrt_paths(r, this->neighboringMatrix.data(), conn.data(), this->numTrees);   // getConnectedTrees + getPaths
+    this->connectedTrees.assign(conn.begin(), conn.begin() + (nc > 0 ? nc : 0));
     this->plans.assign((size_t)this->numTrees * this->numTrees, {});
+    for (int i = 0; i < this->numTrees; ++i)
+      for (int j = i + 1; j < this->numTrees; ++j) {
+        int len = sffgpu_rrt_path_plan(r, i, j, nullptr, 0);
+        if (len <= 0) continue;
+        std::vector<int32_t> ids(len);
+        sffgpu_rrt_path_plan(r, i, j, ids.data(), len);
+        this->plans[(size_t)i * this->numTrees + j].assign(ids.begin(), ids.end());
+      }
     sffgpu_rrt_destroy(r);
     if (SaveGoals <= P.saveOptions) this->saveCities(P.fileNames[SaveGoals]);
     if (SaveTree <= P.saveOptions) this->saveTrees(P.fileNames[SaveTree]);
-    if (SaveRaw <= P.saveOptions || SaveTSP <= P.saveOptions)
-      std::cout << "RapidExpTree: path extraction (src/rrt.h:324-352) is not implemented in this build\n";
+    if (SaveRaw <= P.saveOptions) this->savePaths(P.fileNames[SaveRaw]);
+    if (P.smoothing) std::cout << "RapidExpTree: path smoothing (src/rrt.h:354-379) is not implemented in this build\n";
     if (SaveParams <= P.saveOptions) this->saveParams(P.fileNames[SaveParams], st.iterations, st.solved != 0, stopTime - startingTime);
+    if (SaveTSP <= P.saveOptions) this->saveTsp(P.fileNames[SaveTSP]);
   }
 };

@@ -131,6 +131,9 @@ int sffgpu_forest_get_nodes(sffgpu_forest* f, double* pos6, int32_t* parent, int
 int sffgpu_forest_get_borders(sffgpu_forest* f, int32_t* tree_a, int32_t* tree_b, int32_t* node1, int32_t* node2,
                               double* dist, int cap);
 uint64_t sffgpu_forest_fingerprint(sffgpu_forest* f);
+/* open (frontier) nodes in the order SpaceForest::saveFrontiers writes them (src/forest.h:513-568): the frontier
+ * deque, or with priorityBias the first heap of every tree in heap order; returns the count (may exceed cap) */
+int sffgpu_forest_get_frontier(sffgpu_forest* f, int32_t* node_ids, int cap);
 /* Post-loop path extraction: SpaceForest::getPaths (src/forest.h:420-462) + Solver::getAllPaths
  * (src/problemStruct.h:184-253).  dist = n_trees x n_trees matrix of root-to-root path costs
  * (DBL_MAX where there is none) = Solver::neighboringMatrix; connected = Solver::connectedTrees
@@ -173,6 +176,11 @@ int sffgpu_rrt_get_nodes(sffgpu_rrt* r, double* pos6, int32_t* parent, int32_t* 
                          int32_t* iter, double* cost, double* dist_parent);
 /* Tree::links entries (src/rrt.h:233); returns the count (may exceed cap) */
 int sffgpu_rrt_get_links(sffgpu_rrt* r, int32_t* tree, int32_t* node1, int32_t* node2, double* dist, int cap);
+/* RapidExpTree::getConnectedTrees + getPaths (src/rrt.h:324-352, :381-393): the links of the tree that ate the most
+ * others become root-to-root paths.  dist = n_trees x n_trees cost matrix (DBL_MAX = none) indexed by Node::Root ids,
+ * connected = the central tree's eaten trees + itself; returns their count.  path_plan copies one pair's node ids. */
+int sffgpu_rrt_paths(sffgpu_rrt* r, double* dist, int32_t* connected, int cap_connected);
+int sffgpu_rrt_path_plan(sffgpu_rrt* r, int i, int j, int32_t* node_ids, int cap);
 
 /* Multi-GPU wave protocol (one process per GPU; the exchange itself is the caller's RCCL / gloo
  * all-gather).  Every rank holds a full replica of the forest and of the node store; a round is

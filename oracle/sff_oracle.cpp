@@ -1178,6 +1178,62 @@ struct Rrt {
     }
   }
 
+  // post-loop: getConnectedTrees (src/rrt.h:381-393), getPaths (:324-352), Solver::getAllPaths (problemStruct.h:184-253)
+  struct PH { int n1 = -1, n2 = -1; double dist = std::numeric_limits<double>::max(); std::vector<int> plan; };
+  std::vector<PH> nm;
+  std::vector<int> connected;
+  PH& NM(int i, int j) { int nt = (int)trees.size(); return nm[(size_t)std::min(i, j) * nt + std::max(i, j)]; }
+  void get_paths() {
+    const int nt = (int)trees.size();
+    nm.assign((size_t)nt * nt, PH());
+    connected.clear();
+    size_t max_conn = 0;
+    int central = 0;
+    const int num_roots = cfg.has_goal ? num_trees + 2 : num_trees + 1;
+    for (int i = 0; i < num_roots && i < nt; ++i)
+      if (eaten[i].size() > max_conn) { max_conn = eaten[i].size(); central = i; connected = eaten[i]; connected.push_back(i); }
+    for (const RLink& link : links[central]) {
+      PH h;
+      h.n1 = link.n1; h.n2 = link.n2; h.dist = link.dist;
+      std::vector<int> chain;
+      for (int n = link.n1;; n = nodes[n].parent) { chain.push_back(n); if (nodes[n].d_root == 0) break; }
+      h.plan.assign(chain.rbegin(), chain.rend());
+      for (int n = link.n2;; n = nodes[n].parent) { h.plan.push_back(n); if (nodes[n].d_root == 0) break; }
+      NM(nodes[link.n1].root_tree, nodes[link.n2].root_tree) = h;
+    }
+    const int nc = (int)connected.size();
+    for (int k = 0; k < nc; ++k) {
+      int id3 = connected[k];
+      for (int i = 0; i < nc; ++i) {
+        int id1 = connected[i];
+        if (i == k || NM(id1, id3).n1 < 0) continue;
+        for (int j = 0; j < nc; ++j) {
+          int id2 = connected[j];
+          if (i == j || NM(id2, id3).n1 < 0) continue;
+          const PH h1 = NM(id1, id3), h2 = NM(id2, id3);
+          std::vector<int> plan1 = h1.plan, plan2 = h2.plan;
+          int node1, node2;
+          if (nodes[h1.n1].root_tree == id1) node1 = h1.n1; else { node1 = h1.n2; std::reverse(plan1.begin(), plan1.end()); }
+          if (nodes[h2.n1].root_tree == id2) node2 = h2.n1; else { node2 = h2.n2; std::reverse(plan2.begin(), plan2.end()); }
+          int last = -1;
+          while (!plan1.empty() && !plan2.empty() && plan1.back() == plan2.back()) { last = plan1.back(); plan1.pop_back(); plan2.pop_back(); }
+          std::vector<int> fin(plan1.begin(), plan1.end());
+          fin.push_back(last);
+          for (size_t q = plan2.size(); q-- > 0;) fin.push_back(plan2[q]);
+          double d = 0;
+          for (size_t q = 1; q < fin.size(); ++q) d += distance6(nodes[fin[q - 1]].pos, nodes[fin[q]].pos);
+          if (d < NM(id1, id2).dist - TOLERANCE) {
+            PH h;
+            h.dist = d;
+            if (node1 < node2) { h.n1 = node1; h.n2 = node2; h.plan = fin; }
+            else { h.n1 = node2; h.n2 = node1; h.plan.assign(fin.rbegin(), fin.rend()); }
+            NM(id1, id2) = h;
+          }
+        }
+      }
+    }
+  }
+
   void run(int max_iters) {
     int done = 0;
     while (!(solved || iter == cfg.max_iterations)) {                            // :93
@@ -1478,6 +1534,21 @@ void sffo_rrt_get_nodes(sffo_rrt* h, double* pos6, int32_t* parent, int32_t* tre
     if (cost) cost[i] = n.d_root;
     if (dpar) dpar[i] = n.d_closest;
   }
+}
+int sffo_rrt_paths(sffo_rrt* h, double* dist) {
+  Rrt& r = h->r;
+  r.get_paths();
+  const int nt = (int)r.trees.size();
+  for (int i = 0; i < nt; ++i)
+    for (int j = 0; j < nt; ++j) dist[(size_t)i * nt + j] = i == j ? 0.0 : r.NM(i, j).dist;
+  return (int)r.connected.size();
+}
+int sffo_rrt_path_plan(sffo_rrt* h, int i, int j, int32_t* node_ids, int cap) {
+  Rrt& r = h->r;
+  if (r.nm.empty() || i == j) return 0;
+  const auto& p = r.NM(i, j).plan;
+  for (size_t k = 0; k < p.size() && (int)k < cap; ++k) node_ids[k] = p[k];
+  return (int)p.size();
 }
 int sffo_rrt_get_links(sffo_rrt* h, int32_t* tree, int32_t* n1, int32_t* n2, double* dist, int cap) {
   int k = 0;

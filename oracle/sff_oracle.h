@@ -139,6 +139,9 @@ void sffo_rrt_get_stats(sffo_rrt*, sffo_rrt_stats*);
 void sffo_rrt_get_nodes(sffo_rrt*, double* pos6, int32_t* parent, int32_t* tree, int32_t* root_tree, int32_t* iter,
                         double* cost, double* dpar);
 int sffo_rrt_get_links(sffo_rrt*, int32_t* tree, int32_t* n1, int32_t* n2, double* dist, int cap);
+/* getConnectedTrees + getPaths + getAllPaths (src/rrt.h:381-393, :324-352, src/problemStruct.h:184-253) */
+int sffo_rrt_paths(sffo_rrt*, double* dist);
+int sffo_rrt_path_plan(sffo_rrt*, int i, int j, int32_t* node_ids, int cap);
 
 #ifdef __cplusplus
 }

@@ -17,7 +17,8 @@ EXPORTED_SYMBOLS = [
     "sffgpu_forest_get_nodes", "sffgpu_forest_get_borders", "sffgpu_forest_fingerprint", "sffgpu_forest_paths",
     "sffgpu_forest_path_plan", "sffgpu_forest_smooth_paths",
     "sffgpu_rrt_create", "sffgpu_rrt_destroy", "sffgpu_rrt_run", "sffgpu_rrt_get_stats", "sffgpu_rrt_get_nodes",
-    "sffgpu_rrt_get_links", "sffgpu_forest_in_wave", "sffgpu_forest_round_begin", "sffgpu_forest_round_records", "sffgpu_forest_round_commit",
+    "sffgpu_rrt_get_links", "sffgpu_rrt_paths", "sffgpu_rrt_path_plan", "sffgpu_forest_get_frontier",
+    "sffgpu_forest_in_wave", "sffgpu_forest_round_begin", "sffgpu_forest_round_records", "sffgpu_forest_round_commit",
 ]
 
 c_dp = C.POINTER(C.c_double)
@@ -121,6 +122,9 @@ def lib():
     L.sffgpu_rrt_get_stats.argtypes = [C.c_void_p, C.POINTER(RrtStats)]
     L.sffgpu_rrt_get_nodes.argtypes = [C.c_void_p, c_dp, c_ip, c_ip, c_ip, c_ip, c_dp, c_dp]
     L.sffgpu_rrt_get_links.argtypes = [C.c_void_p, c_ip, c_ip, c_ip, c_dp, C.c_int]
+    L.sffgpu_rrt_paths.argtypes = [C.c_void_p, c_dp, c_ip, C.c_int]
+    L.sffgpu_rrt_path_plan.argtypes = [C.c_void_p, C.c_int, C.c_int, c_ip, C.c_int]
+    L.sffgpu_forest_get_frontier.argtypes = [C.c_void_p, c_ip, C.c_int]
     L.sffgpu_forest_in_wave.argtypes = [C.c_void_p]
     L.sffgpu_forest_round_begin.argtypes = [C.c_void_p, c_ip, c_ip]
     L.sffgpu_forest_round_records.argtypes = [C.c_void_p, c_ip, C.c_int]
@@ -333,6 +337,11 @@ class Forest:
         k = self.ctx._chk(self.ctx._L.sffgpu_forest_path_plan(self.h, i, j, _ip(ids), cap))
         return ids[:min(k, cap)].copy()
 
+    def frontier(self, cap=1 << 22):
+        ids = np.zeros(cap, np.int32)
+        k = self.ctx._chk(self.ctx._L.sffgpu_forest_get_frontier(self.h, _ip(ids), cap))
+        return ids[:min(k, cap)].copy()
+
     def in_wave(self):
         return bool(self.ctx._L.sffgpu_forest_in_wave(self.h))
 
@@ -405,6 +414,17 @@ class Rrt:
         self.ctx._chk(self.ctx._L.sffgpu_rrt_get_nodes(self.h, _dp(pos), _ip(parent), _ip(tree), _ip(root_tree), _ip(it),
                                                        _dp(cost), _dp(dpar)))
         return dict(pos=pos, parent=parent, tree=tree, root_tree=root_tree, iter=it, cost=cost, dpar=dpar)
+
+    def paths(self, n_trees):
+        d = np.zeros((n_trees, n_trees))
+        conn = np.zeros(n_trees, np.int32)
+        k = self.ctx._chk(self.ctx._L.sffgpu_rrt_paths(self.h, _dp(d), _ip(conn), n_trees))
+        return d, conn[:k].copy()
+
+    def plan(self, i, j, cap=1 << 16):
+        ids = np.zeros(cap, np.int32)
+        k = self.ctx._chk(self.ctx._L.sffgpu_rrt_path_plan(self.h, i, j, _ip(ids), cap))
+        return ids[:min(k, cap)].copy()
 
     def links(self, cap=1 << 16):
         t, n1, n2 = (np.zeros(cap, np.int32) for _ in range(3))

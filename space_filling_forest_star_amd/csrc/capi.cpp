@@ -1,4 +1,5 @@
 // capi.cpp — extern "C" surface of libsffgpu.so (declared in include/sffgpu.h).
+#include <algorithm>
 #include <cstring>
 #include <string>
 
@@ -281,6 +282,41 @@ int sffgpu_rrt_get_links(sffgpu_rrt* r, int32_t* tree, int32_t* n1, int32_t* n2,
       }
       ++k;
     }
+  return k;
+}
+
+int sffgpu_rrt_paths(sffgpu_rrt* r, double* dist, int32_t* connected, int cap_connected) {
+  if (!r || !dist) return SFFGPU_ERR_ARG;
+  Rrt& R = *r->r;
+  R.get_paths();
+  const int nt = (int)R.trees.size();
+  for (int i = 0; i < nt; ++i)
+    for (int j = 0; j < nt; ++j)
+      dist[(size_t)i * nt + j] = i == j ? 0.0 : R.nm[(size_t)std::min(i, j) * nt + std::max(i, j)].dist;
+  if (connected)
+    for (size_t k = 0; k < R.connected.size() && (int)k < cap_connected; ++k) connected[k] = R.connected[k];
+  return (int)R.connected.size();
+}
+int sffgpu_rrt_path_plan(sffgpu_rrt* r, int i, int j, int32_t* node_ids, int cap) {
+  if (!r) return SFFGPU_ERR_ARG;
+  Rrt& R = *r->r;
+  const int nt = (int)R.trees.size();
+  if (R.nm.empty() || i == j || i < 0 || j < 0 || i >= nt || j >= nt) return 0;
+  const std::vector<int>& p = R.nm[(size_t)std::min(i, j) * nt + std::max(i, j)].plan;
+  for (size_t k = 0; k < p.size() && (int)k < cap; ++k) node_ids[k] = p[k];
+  return (int)p.size();
+}
+int sffgpu_forest_get_frontier(sffgpu_forest* f, int32_t* node_ids, int cap) {
+  if (!f) return SFFGPU_ERR_ARG;
+  Forest& F = *f->f;
+  int k = 0;
+  auto put = [&](int id) { if (k < cap && node_ids) node_ids[k] = id; ++k; };
+  if (F.use_priority()) {
+    for (auto& hs : F.heaps)
+      if (!hs.empty()) for (int id : hs[0].v) put(id);
+  } else {
+    for (int id : F.frontier) put(id);
+  }
   return k;
 }
 

@@ -284,6 +284,11 @@ struct Rrt {
   int merge_or_link(int tree_to_expand, int new_id, int nb, bool edge_free, int fh, int ns, int& i);
   int run_wave(int B);   // speculative wave of up to B iterations; returns how many were committed
   void run(int max_iters);
+  // post-loop (src/rrt.h:324-352, :381-393)
+  struct PathHolder { int n1 = -1, n2 = -1; double dist = 1.7976931348623157e308; std::vector<int> plan; };
+  std::vector<PathHolder> nm;         // n_trees x n_trees, symmetric
+  std::vector<int> connected;
+  void get_paths();
   std::vector<double> pend_pos;       // accepted nodes of the current wave not yet in the device store
   std::vector<int32_t> pend_tree;
   bool defer_append = false;

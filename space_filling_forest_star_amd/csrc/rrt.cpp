@@ -581,4 +581,76 @@ void Rrt::run(int max_iters) {
   st.total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 }
 
+// RapidExpTree::getConnectedTrees (src/rrt.h:381-393) + getPaths (:324-352)
+void Rrt::get_paths() {
+  const int nt = (int)trees.size();
+  nm.assign((size_t)nt * nt, PathHolder());
+  connected.clear();
+  size_t max_conn = 0;
+  int central = 0;
+  const int num_roots = cfg.has_goal ? num_trees + 2 : num_trees + 1;   // :384 (numTrees was decremented per merge)
+  for (int i = 0; i < num_roots && i < nt; ++i)
+    if (eaten[i].size() > max_conn) {
+      max_conn = eaten[i].size();
+      central = i;
+      connected = eaten[i];
+      connected.push_back(i);
+    }
+  for (const RLink& link : links[central]) {
+    PathHolder h;
+    h.n1 = link.n1;
+    h.n2 = link.n2;
+    h.dist = link.dist;
+    std::vector<int> chain;
+    for (int n = link.n1;; n = nodes[n].parent) {   // push_front up to the root (IsRoot: DistanceToRoot == 0)
+      chain.push_back(n);
+      if (nodes[n].d_root == 0) break;
+    }
+    h.plan.assign(chain.rbegin(), chain.rend());
+    for (int n = link.n2;; n = nodes[n].parent) {
+      h.plan.push_back(n);
+      if (nodes[n].d_root == 0) break;
+    }
+    const int a = nodes[link.n1].root_tree, b = nodes[link.n2].root_tree;   // :350 neighboringMatrix(Root ids)
+    nm[(size_t)std::min(a, b) * nt + std::max(a, b)] = h;
+  }
+  // Solver::getAllPaths (src/problemStruct.h:184-253), called right after getPaths (src/rrt.h:106-107)
+  auto NM = [&](int i, int j) -> PathHolder& { return nm[(size_t)std::min(i, j) * nt + std::max(i, j)]; };
+  const int nc = (int)connected.size();
+  for (int k = 0; k < nc; ++k) {
+    const int id3 = connected[k];
+    for (int i = 0; i < nc; ++i) {
+      const int id1 = connected[i];
+      if (i == k || NM(id1, id3).n1 < 0) continue;
+      for (int j = 0; j < nc; ++j) {
+        const int id2 = connected[j];
+        if (i == j || NM(id2, id3).n1 < 0) continue;
+        const PathHolder h1 = NM(id1, id3), h2 = NM(id2, id3);
+        std::vector<int> plan1 = h1.plan, plan2 = h2.plan;
+        int node1, node2;
+        if (nodes[h1.n1].root_tree == id1) node1 = h1.n1; else { node1 = h1.n2; std::reverse(plan1.begin(), plan1.end()); }
+        if (nodes[h2.n1].root_tree == id2) node2 = h2.n1; else { node2 = h2.n2; std::reverse(plan2.begin(), plan2.end()); }
+        int last = -1;
+        while (!plan1.empty() && !plan2.empty() && plan1.back() == plan2.back()) {
+          last = plan1.back();
+          plan1.pop_back();
+          plan2.pop_back();
+        }
+        std::vector<int> fin(plan1.begin(), plan1.end());
+        fin.push_back(last);
+        fin.insert(fin.end(), plan2.rbegin(), plan2.rend());
+        double d = 0;
+        for (size_t q = 1; q < fin.size(); ++q) d += sffg::dist6(nodes[fin[q - 1]].pos, nodes[fin[q]].pos);
+        if (d < NM(id1, id2).dist - SFFG_TOL) {
+          PathHolder h;
+          h.dist = d;
+          if (node1 < node2) { h.n1 = node1; h.n2 = node2; h.plan = fin; }
+          else { h.n1 = node2; h.n2 = node1; h.plan.assign(fin.rbegin(), fin.rend()); }
+          NM(id1, id2) = h;
+        }
+      }
+    }
+  }
+}
+
 }  // namespace sff

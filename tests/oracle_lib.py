@@ -111,6 +111,8 @@ def lib():
     L.sffo_rrt_run.argtypes = [C.c_void_p, C.c_int]
     L.sffo_rrt_get_stats.argtypes = [C.c_void_p, C.POINTER(RrtStats)]
     L.sffo_rrt_get_nodes.argtypes = [C.c_void_p, c_dp, c_ip, c_ip, c_ip, c_ip, c_dp, c_dp]
+    L.sffo_rrt_paths.argtypes = [C.c_void_p, c_dp]
+    L.sffo_rrt_path_plan.argtypes = [C.c_void_p, C.c_int, C.c_int, c_ip, C.c_int]
     L.sffo_rrt_get_links.argtypes = [C.c_void_p, c_ip, c_ip, c_ip, c_dp, C.c_int]
     _LIB = L
     return L
@@ -326,3 +328,13 @@ class Rrt:
         d = np.zeros(cap)
         k = min(lib().sffo_rrt_get_links(self.h, ip(t), ip(n1), ip(n2), dp(d), cap), cap)
         return dict(tree=t[:k].copy(), n1=n1[:k].copy(), n2=n2[:k].copy(), dist=d[:k].copy())
+
+    def paths(self, n_trees):
+        d = np.zeros((n_trees, n_trees))
+        k = lib().sffo_rrt_paths(self.h, dp(d))
+        return d, k
+
+    def plan(self, i, j, cap=1 << 16):
+        ids = np.zeros(cap, np.int32)
+        k = lib().sffo_rrt_path_plan(self.h, i, j, ip(ids), cap)
+        return ids[:min(k, cap)].copy()

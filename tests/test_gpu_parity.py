@@ -378,6 +378,13 @@ def test_rrt_identical(S, ctx, name, optimize, n_roots, goal, bias, iters):
         lg = rg.links()
         for k in lo:
             assert np.array_equal(lo[k], lg[k]), (wave, k)
+        nt = n_roots + (1 if goal else 0)
+        do, co = ro.paths(nt)
+        dg, cg = rg.paths(nt)
+        assert co == len(cg) and np.array_equal(do, dg)
+        for a in range(nt):
+            for b in range(a + 1, nt):
+                assert np.array_equal(ro.plan(a, b), rg.plan(a, b))
         if wave != 1:
             assert sg["waves"] < so["iterations"] or so["iterations"] < 8
         rg.close()
