@@ -261,6 +261,32 @@ def test_priority_frontier_mode(S, ctx, name, wave, n_roots, optimize, goal):
     assert fp.fingerprint() != fo.fingerprint()
 
 
+def test_gpu_matches_committed_golden_runs(S, ctx, golden_dir):
+    """The GPU path against the COMMITTED fixture tests/golden/oracle_runs.json (not only against the oracle
+    built on this box): node counts, reference-equivalent collision calls, parent and cost checksums."""
+    import json
+    import os
+    from test_oracle_cpu import RUNS
+    gold = json.load(open(os.path.join(golden_dir, "oracle_runs.json")))
+    for name, wave, opt, rrt in RUNS:
+        key = "%s/w%d/%s/%s" % (name, wave, "star" if opt else "plain", "rrt" if rrt else "sff")
+        sc, w = load_world(ctx, name)
+        roots = sc["xml_points"][:4] if sc["xml_points"] is not None else common.free_roots(w.collide, sc["limits"], 4, seed=13,
+                                                                                            dim=sc["dim"])
+        if rrt:
+            r = S.Rrt(ctx, roots[:1] if opt else roots, sc["limits"], sc["dist_tree"], sc["sampling_dist"], dim=sc["dim"],
+                      optimize=opt, max_iterations=1200, seed=13)
+        else:
+            r = S.Forest(ctx, roots, sc["limits"], dist_tree=sc["dist_tree"], sampling_dist=sc["sampling_dist"], dim=sc["dim"],
+                         optimize=opt, max_iterations=1200, wave=wave, seed=13)
+        r.run()
+        s, n = r.stats(), r.nodes()
+        got = {"n_nodes": int(s["n_nodes"]), "iterations": int(s["iterations"]), "collide_calls": int(s["collide_calls"]),
+               "parent_sum": int(n["parent"].astype(np.int64).sum()), "cost_sum": float(n["cost"].sum()).hex()}
+        assert got == gold[key], key
+        r.close()
+
+
 def test_forest_node_budget_and_seeds(S, ctx):
     for seed in (1, 3):
         fo, fg = run_pair(S, ctx, "dense3d", 512, 10**6, seed=seed, n_roots=10, budget=6000)
