@@ -316,9 +316,13 @@ void Ctx::store_append(const double* pos6, const int32_t* tree, int n, bool wait
   d_b.ensure((size_t)n * sizeof(int32_t));
   HIPCHK(hipMemcpyAsync(d_a.p, h_a.p, (size_t)n * 6 * sizeof(double), hipMemcpyHostToDevice, stream));
   HIPCHK(hipMemcpyAsync(d_b.p, h_b.p, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, stream));
-  sffk::launch_store_write(stream, store_mut(*this), d_a.as<double>(), d_b.as<int32_t>(), nullptr, nullptr, n, store_n);
+  // with an up-to-date grid the new nodes are inserted by the same launch
+  const bool fuse_grid = grid_on && grid_inserted == store_n;
+  sffk::launch_store_write(stream, store_mut(*this), d_a.as<double>(), d_b.as<int32_t>(), nullptr, nullptr, n, store_n,
+                           fuse_grid ? &gridv : nullptr);
   if (wait) sync();   // callers that keep the stream ordered (the forest engine) skip the wait
   store_n += n;
+  if (fuse_grid) grid_inserted = store_n;
 }
 
 void Ctx::store_set_tree(const int32_t* ids, int n, int32_t tree) {
@@ -498,7 +502,7 @@ void Ctx::sample_steer(const uint64_t* words, const double* center6, int n, doub
   prm.world = 1;
   time_begin(T_SAMPLE);
   sffk::launch_sample_steer(stream, d_a.as<uint64_t>(), nullptr, nullptr, d_b.as<double>(), n, dist, dim, prm,
-                            d_c.as<double>(), d_d.as<uint8_t>(), nullptr, nullptr, 0);
+                            d_c.as<double>(), d_d.as<uint8_t>(), nullptr, nullptr, 0, sffk::RoundTemps{});
   time_end();
   HIPCHK(hipMemcpyAsync(h_c.p, d_c.p, pb, hipMemcpyDeviceToHost, stream));
   HIPCHK(hipMemcpyAsync(h_d.p, d_d.p, (size_t)n, hipMemcpyDeviceToHost, stream));

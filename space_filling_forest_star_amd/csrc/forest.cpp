@@ -380,23 +380,25 @@ void Forest::round_begin() {
   c.r_sega.ensure((size_t)n * STRIDE * 48);
   c.r_segb.ensure((size_t)n * STRIDE * 48);
   HIPCHK(hipMemcpyAsync(c.r_in.p, c.p_in.p, in_bytes, hipMemcpyHostToDevice, c.stream));
-  HIPCHK(hipMemsetAsync(c.r_cnt.p, 0, (size_t)n * 4, c.stream));
-  HIPCHK(hipMemsetAsync(d_ctrl, 0, 16, c.stream));
   sffk::SampleParams prm{};
   memcpy(prm.limits, cfg.limits, sizeof prm.limits);
   prm.dist_tree = cfg.dist_tree;
   prm.sweep_abs_eps = c.sweep_eps();
   prm.rank = cfg.rank;
   prm.world = cfg.world;
+  // one launch: sample + steer + limits, the round's temporary store entries [Tb, Tb+n) (the same query pass then
+  // also finds, for every sample, the EARLIER samples of this round: query i sees ids < Tb + i), NaN placeholders
+  // for [N0, Tb), and the per-round counter resets
+  sffk::RoundTemps tmp{};
+  tmp.st = sffk::NodeStoreMut{c.sx.as<float>(), c.sy.as<float>(), c.sz.as<float>(), c.syaw.as<float>(),
+                              c.spitch.as<float>(), c.sroll.as<float>(), c.stree.as<int32_t>(), c.spos.as<double>()};
+  tmp.cnt = c.r_cnt.as<int32_t>();
+  tmp.ctrl = d_ctrl;
+  tmp.n_perm = N0;
+  tmp.base = Tb;
   c.time_begin(T_SAMPLE);
   sffk::launch_sample_steer(c.stream, d_words, d_parent, c.spos.as<double>(), nullptr, n, cfg.sampling_dist, cfg.dim,
-                            prm, d_pos, d_lim, d_pd, c.r_q.as<sffk::SweepQuery>(), Tb);
-  // the round's samples become temporary store entries [N0, N0+n) so that the same sweep also
-  // finds, for every sample, the EARLIER samples of this round (query i sees ids < N0 + i)
-  sffk::NodeStoreMut mut{c.sx.as<float>(), c.sy.as<float>(), c.sz.as<float>(), c.syaw.as<float>(),
-                         c.spitch.as<float>(), c.sroll.as<float>(), c.stree.as<int32_t>(), c.spos.as<double>()};
-  sffk::launch_store_nan(c.stream, mut, N0, Tb - N0);
-  sffk::launch_store_write(c.stream, mut, d_pos, nullptr, d_parent, d_lim, n, Tb);
+                            prm, d_pos, d_lim, d_pd, c.r_q.as<sffk::SweepQuery>(), Tb, tmp);
   c.time_end();
   // the sweep only serves the queries of this rank's shard (the others are marked inactive)
   c.time_begin(T_SWEEP);

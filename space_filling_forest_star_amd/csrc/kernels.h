@@ -78,14 +78,26 @@ struct RobotView {
   double lo[3], hi[3];  // exact box of the un-rotated model
 };
 
+// forest rounds only: where k_sample_steer writes the round's temporary store entries and which per-round
+// counters it resets (all null / zero for the plain batch entry point)
+struct RoundTemps {
+  NodeStoreMut st;
+  int32_t* cnt;    // n hit counters
+  int32_t* ctrl;   // 4 ints of the persistent edge kernel's cursor
+  int n_perm;      // permanent nodes in the store
+  int base;        // 4-aligned index of the first temporary (>= n_perm)
+};
+
 size_t collide_lds_bytes(int n_robot_tri, int waves);
 
 void launch_sample_steer(hipStream_t s, const uint64_t* words, const int32_t* parent, const double* node_pos,
                          const double* center_in, int n, double dist, int dim, const SampleParams& prm, double* out6,
-                         uint8_t* in_lim, double* parent_dist, SweepQuery* queries, int32_t q_max_base);
+                         uint8_t* in_lim, double* parent_dist, SweepQuery* queries, int32_t q_max_base,
+                         const RoundTemps& tmp);
 
+// grid != nullptr: the written nodes are also inserted into the neighbour grid in the same launch
 void launch_store_write(hipStream_t s, const NodeStoreMut& st, const double* pos6, const int32_t* tree,
-                        const int32_t* parent, const uint8_t* active, int n, int base);
+                        const int32_t* parent, const uint8_t* active, int n, int base, const GridView* grid);
 
 // linear sweep over store entries [first, first + n_nodes) (first must be a multiple of 4)
 void launch_sweep(hipStream_t s, const NodeStoreView& st, int first, int n_nodes, const SweepQuery* queries,

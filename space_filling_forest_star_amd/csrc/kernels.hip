@@ -34,8 +34,20 @@ __global__ __launch_bounds__(256) void k_sample_steer(const uint64_t* __restrict
                                                       int n, double dist, int dim, SampleParams prm,
                                                       double* __restrict__ out6, uint8_t* __restrict__ in_lim,
                                                       double* __restrict__ parent_dist, SweepQuery* __restrict__ queries,
-                                                      int32_t q_max_base) {
+                                                      int32_t q_max_base, RoundTemps tmp) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (tmp.cnt) {
+    // per-round housekeeping folded into this launch: hit counters, the work-list cursor, and NaN
+    // placeholders for the store entries between the permanent nodes and the 4-aligned temporaries
+    if (i < n) tmp.cnt[i] = 0;
+    if (i < 4) tmp.ctrl[i] = 0;
+    if (i < tmp.base - tmp.n_perm) {
+      const float nanv = __int_as_float(0x7fc00000);
+      const size_t o = (size_t)tmp.n_perm + i;
+      tmp.st.x[o] = nanv; tmp.st.y[o] = nanv; tmp.st.z[o] = nanv;
+      tmp.st.yaw[o] = nanv; tmp.st.pitch[o] = nanv; tmp.st.roll[o] = nanv;
+    }
+  }
   if (i >= n) return;
   double c[6], o[6];
   const double* src = center_in ? center_in + 6 * (size_t)i : node_pos + 6 * (size_t)parent[i];
@@ -45,6 +57,20 @@ __global__ __launch_bounds__(256) void k_sample_steer(const uint64_t* __restrict
   bool ok = sample_point(w, c, dist, dim, prm.limits, o);
   for (int k = 0; k < 6; ++k) out6[6 * (size_t)i + k] = o[k];
   in_lim[i] = ok ? 1 : 0;
+  if (tmp.cnt) {
+    // the sample becomes temporary store entry base + i (NaN floats when out of limits, so that no query
+    // can match it), with the tree of the node it was expanded from
+    const float nanv = __int_as_float(0x7fc00000);
+    const size_t t = (size_t)tmp.base + i;
+    tmp.st.x[t] = ok ? (float)o[0] : nanv;
+    tmp.st.y[t] = ok ? (float)o[1] : nanv;
+    tmp.st.z[t] = ok ? (float)o[2] : nanv;
+    tmp.st.yaw[t] = ok ? (float)o[3] : nanv;
+    tmp.st.pitch[t] = ok ? (float)o[4] : nanv;
+    tmp.st.roll[t] = ok ? (float)o[5] : nanv;
+    for (int k = 0; k < 6; ++k) tmp.st.pos[6 * t + k] = o[k];
+    tmp.st.tree[t] = tmp.st.tree[parent[i]];
+  }
   if (parent_dist) {
     double pd = dist6(c, o);  // parentDistance, src/forest.h:250
     parent_dist[i] = pd;
@@ -717,7 +743,8 @@ __global__ __launch_bounds__(256) void k_classify(ClassifyArgs A) {
 // written as NaN so that no query can match them.
 __global__ __launch_bounds__(256) void k_store_write(NodeStoreMut st, const double* __restrict__ pos6,
                                                      const int32_t* __restrict__ tree, const int32_t* __restrict__ parent,
-                                                     const uint8_t* __restrict__ active, int n, int base) {
+                                                     const uint8_t* __restrict__ active, int n, int base, GridView g,
+                                                     int with_grid) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const bool on = active ? active[i] != 0 : true;
@@ -732,7 +759,24 @@ __global__ __launch_bounds__(256) void k_store_write(NodeStoreMut st, const doub
   st.pitch[o] = on ? (float)p[4] : nanv;
   st.roll[o] = on ? (float)p[5] : nanv;
   for (int k = 0; k < 6; ++k) st.pos[6 * o + k] = p[k];
-  st.tree[o] = tree ? tree[i] : st.tree[parent[i]];
+  const int tr = tree ? tree[i] : st.tree[parent[i]];
+  st.tree[o] = tr;
+  if (with_grid && on) {   // permanent nodes also enter the neighbour grid (replaces a separate k_grid_insert launch)
+    GridItem it;
+    it.x = (float)p[0]; it.y = (float)p[1]; it.z = (float)p[2];
+    it.yaw = (float)p[3]; it.pitch = (float)p[4]; it.roll = (float)p[5];
+    it.id = (int)o;
+    it.tree = tr;
+    const int cx = grid_coord(it.x, g.ox, g.inv_cell, g.nx), cy = grid_coord(it.y, g.oy, g.inv_cell, g.ny),
+              cz = grid_coord(it.z, g.oz, g.inv_cell, g.nz);
+    const size_t cell = ((size_t)cz * g.ny + cy) * g.nx + cx;
+    const int slot = atomicAdd(g.cnt + cell, 1);
+    if (slot < g.bk) g.items[cell * g.bk + slot] = it;
+    else {
+      const int ov = atomicAdd(g.ovf_cnt, 1);
+      if (ov < g.ovf_cap) g.ovf[ov] = it;
+    }
+  }
 }
 
 // ------------------------------------------------------------------ launchers
@@ -742,16 +786,20 @@ size_t collide_lds_bytes(int n_robot_tri, int waves) {
 
 void launch_sample_steer(hipStream_t s, const uint64_t* words, const int32_t* parent, const double* node_pos,
                          const double* center_in, int n, double dist, int dim, const SampleParams& prm, double* out6,
-                         uint8_t* in_lim, double* parent_dist, SweepQuery* queries, int32_t q_max_base) {
+                         uint8_t* in_lim, double* parent_dist, SweepQuery* queries, int32_t q_max_base,
+                         const RoundTemps& tmp) {
   if (n <= 0) return;
   hipLaunchKernelGGL(k_sample_steer, dim3((n + 255) / 256), dim3(256), 0, s, words, parent, node_pos, center_in, n,
-                     dist, dim, prm, out6, in_lim, parent_dist, queries, q_max_base);
+                     dist, dim, prm, out6, in_lim, parent_dist, queries, q_max_base, tmp);
 }
 
 void launch_store_write(hipStream_t s, const NodeStoreMut& st, const double* pos6, const int32_t* tree,
-                        const int32_t* parent, const uint8_t* active, int n, int base) {
+                        const int32_t* parent, const uint8_t* active, int n, int base, const GridView* grid) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(k_store_write, dim3((n + 255) / 256), dim3(256), 0, s, st, pos6, tree, parent, active, n, base);
+  GridView g{};
+  if (grid) g = *grid;
+  hipLaunchKernelGGL(k_store_write, dim3((n + 255) / 256), dim3(256), 0, s, st, pos6, tree, parent, active, n, base, g,
+                     grid ? 1 : 0);
 }
 
 void launch_sweep(hipStream_t s, const NodeStoreView& st, int first, int n_nodes, const SweepQuery* queries,
