@@ -433,28 +433,47 @@ class Rrt:
         return dict(tree=t[:k].copy(), n1=n1[:k].copy(), n2=n2[:k].copy(), dist=d[:k].copy())
 
 
+_XCHG = {"cap": 4096, "bufs": {}}
+
+
 def exchange_records(local, group=None):
     """All-gather variable-length int32 record streams with torch.distributed (RCCL on GPUs, gloo on
-    CPU): returns (concatenated stream in rank order, words per rank).  Two collectives per round:
-    the lengths (world x int32) and the zero-padded payloads."""
+    CPU): returns (concatenated stream in rank order, words per rank).
+
+    One collective per round in the common case: every rank sends a fixed-capacity buffer
+    [length, payload..., padding]; the capacity is a running bound shared by construction (every rank sees
+    every length), and only when some stream does not fit is the gather repeated with a doubled capacity."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
     backend = dist.get_backend(group)
     dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
-    n = torch.tensor([len(local)], dtype=torch.int32, device=dev)
-    counts = torch.zeros(world, dtype=torch.int32, device=dev)
-    dist.all_gather_into_tensor(counts, n, group=group)
-    counts_h = counts.cpu().numpy()
-    width = int(counts_h.max())
-    buf = torch.zeros(width, dtype=torch.int32, device=dev)
-    if len(local):
-        buf[:len(local)] = torch.from_numpy(np.ascontiguousarray(local, dtype=np.int32)).to(dev)
-    allbuf = torch.zeros(world * width, dtype=torch.int32, device=dev)
-    dist.all_gather_into_tensor(allbuf, buf, group=group)
-    allh = allbuf.cpu().numpy().reshape(world, width)
-    out = np.concatenate([allh[r, :counts_h[r]] for r in range(world)]) if width else np.zeros(0, np.int32)
-    return out.astype(np.int32), counts_h.astype(np.int32)
+    local = np.ascontiguousarray(local, dtype=np.int32)
+    n = len(local)
+    while True:
+        cap = _XCHG["cap"]
+        key = (cap, world, str(dev))
+        if key not in _XCHG["bufs"]:
+            _XCHG["bufs"] = {key: (torch.zeros(1 + cap, dtype=torch.int32).pin_memory() if dev.type == "cuda"
+                                   else torch.zeros(1 + cap, dtype=torch.int32),
+                                   torch.zeros(1 + cap, dtype=torch.int32, device=dev),
+                                   torch.zeros(world * (1 + cap), dtype=torch.int32, device=dev))}
+        host, send, recv = _XCHG["bufs"][key]
+        hv = host.numpy()
+        hv[0] = n
+        m = min(n, cap)
+        hv[1:1 + m] = local[:m]
+        send.copy_(host, non_blocking=True)
+        dist.all_gather_into_tensor(recv, send, group=group)
+        allh = recv.cpu().numpy().reshape(world, 1 + cap)
+        counts = allh[:, 0].astype(np.int32)
+        if int(counts.max()) <= cap:
+            out = np.concatenate([allh[r, 1:1 + counts[r]] for r in range(world)]) if counts.sum() else np.zeros(0, np.int32)
+            # keep the bound comfortable: grow ahead of need, identically on every rank
+            if int(counts.max()) * 2 > cap:
+                _XCHG["cap"] = cap * 2
+            return out.astype(np.int32), counts
+        _XCHG["cap"] = int(2 ** int(np.ceil(np.log2(int(counts.max()) + 1)))) * 2
 
 
 def run_distributed(forest, max_waves=0, group=None):

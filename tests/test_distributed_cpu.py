@@ -26,8 +26,9 @@ def _worker(rank, world, port, out_dir):
     from space_filling_forest_star_amd import exchange_records
     rs = np.random.RandomState(100 + rank)
     results = []
-    for it in range(6):
-        n = [0, 7, 1000, 3][(it + rank) % 4] if it else (5 if rank == 0 else 0)
+    for it in range(8):
+        # 9000 words exceed the initial capacity: the gather is repeated once with a bigger buffer
+        n = [0, 7, 1000, 3, 9000, 2][(it + rank) % 6] if it else (5 if rank == 0 else 0)
         local = rs.randint(-2**31, 2**31 - 1, n).astype(np.int32)
         allw, counts = exchange_records(local)
         assert counts[rank] == n
