@@ -232,10 +232,24 @@ __global__ __launch_bounds__(256) void k_grid_query(GridView g, NodeStoreView st
     if (c < total) {
       const int cx = lx + c % wx, cy = ly + (c / wx) % wy, cz = lz + c / (wx * wy);
       const size_t cell = ((size_t)cz * g.ny + cy) * g.nx + cx;
+      // the first two items of the bucket are fetched together with its fill count (three independent loads
+      // in flight; most cells hold 0-2 nodes), the rest only when the count says they exist
+      const GridItem* items = g.items + cell * g.bk;
+      GridItem i0 = items[0];
+      GridItem i1 = g.bk > 1 ? items[1] : i0;
       int m = g.cnt[cell];
       if (m > g.bk) m = g.bk;
-      const GridItem* items = g.items + cell * g.bk;
-      for (int j = 0; j < m; ++j) grid_test(items[j], Q, q, st, qpos, cnt, hit_idx, hit_dist, cap);
+      if (m > 0) grid_test(i0, Q, q, st, qpos, cnt, hit_idx, hit_dist, cap);
+      if (m > 1) grid_test(i1, Q, q, st, qpos, cnt, hit_idx, hit_dist, cap);
+      if (m > 2) {
+        GridItem it[6];
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+          if (j + 2 < m) it[j] = items[j + 2];
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+          if (j + 2 < m) grid_test(it[j], Q, q, st, qpos, cnt, hit_idx, hit_dist, cap);
+      }
     }
   }
   int no = g.ovf_cnt[0];
@@ -808,10 +822,10 @@ void launch_sweep(hipStream_t s, const NodeStoreView& st, int first, int n_nodes
   int n4 = (n_nodes + 3) / 4;
   int blocks = (n4 + 255) / 256;
   if (blocks > 2048) blocks = 2048;
-  // aim at >= ~2048 workgroups (8 per CU) but keep >= 16 queries per slice so that a node tile
+  // aim at >= ~2048 workgroups (8 per CU) but keep >= 4 queries per slice so that a node tile
   // loaded into registers is reused
   int qsplit = (2048 + blocks - 1) / blocks;
-  int max_split = (nq + 15) / 16;
+  int max_split = (nq + 3) / 4;
   if (qsplit > max_split) qsplit = max_split;
   if (qsplit < 1) qsplit = 1;
   int q_per_block = (nq + qsplit - 1) / qsplit;
