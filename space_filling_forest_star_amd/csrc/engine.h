@@ -204,18 +204,20 @@ struct Forest {
     double pdist = 0;
     int pose_task = -1, seg_parent = -1;
     bool answered = false, pose_hit = false, par_free = false;
+    bool bulk = false;   // fate settled by its owner (rejected, no side effect): only counters travel
     int par_fh = -1, par_ns = 0;
     std::vector<Nb> nbs;
     std::vector<Member> members;  // SFF*: candidates for the k-nearest set (src/forest.h:317)
     int accepted_id = -1;
     void reset(int s, int e) {   // reuse across rounds: keeps the vectors' capacity
       slot = s; expanded = e; in_lim = false; pdist = 0; pose_task = seg_parent = -1;
-      answered = pose_hit = par_free = false; par_fh = -1; par_ns = 0; nbs.clear(); members.clear(); accepted_id = -1;
+      answered = pose_hit = par_free = bulk = false; par_fh = -1; par_ns = 0; nbs.clear(); members.clear(); accepted_id = -1;
     }
   };
   std::vector<Cand> cands;   // storage (only grows); the current round uses the first n_cands
   int n_cands = 0;
   std::vector<int32_t> records;  // this rank's answers of the pending round (int32 stream)
+  uint64_t bulk_counts[4] = {0, 0, 0, 0};  // collide / path_free / nn counters + number of bulk-settled samples (own shard)
   bool pending_round = false;
   int iter0 = 0, N0 = 0, Tb = 0;  // Tb: 4-aligned base of the round's temporary store entries
   double knn_r = 0;  // running guess of the k-nearest radius (SFF*)

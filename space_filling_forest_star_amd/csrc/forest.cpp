@@ -325,6 +325,8 @@ void Forest::round_begin() {
   records.clear();
   records.push_back(REC_MAGIC);
   records.push_back(n);
+  for (int k = 0; k < 8; ++k) records.push_back(0);   // bulk counters, filled at the end of round_begin
+  bulk_counts[0] = bulk_counts[1] = bulk_counts[2] = bulk_counts[3] = 0;
   if (n == 0) return;
   iter0 = iter;
   iter += n;
@@ -750,10 +752,61 @@ void Forest::round_begin() {
   }
 
   auto _t3 = Clock::now();
+  // ---- samples whose fate this rank can settle alone: rejected by their own collision checks, or by a STORE
+  // neighbour with no neighbour from this round anywhere in their list, and without side effect (no border
+  // entry, no goal test).  Only their reference-equivalent counters travel; the in-order replay skips them.
+  {
+    auto calls = [](int fh, int ns) -> uint64_t { return fh > 0 ? (uint64_t)fh : (uint64_t)ns; };
+    // (with a goal the replay may stop in the middle of the round, so every sample stays in it)
+    // On a single rank the replay sees every sample anyway, so the extra pass is skipped.
+    for (int i = 0; i < n && !cfg.has_goal && cfg.world > 1; ++i) {
+      Cand& cd = cands[i];
+      if (!cd.answered) continue;
+      uint64_t cc = 1, pf = 0, nq = 0;   // :246 env.Collide(newPoint)
+      bool settled = false;
+      if (cd.pose_hit) settled = true;
+      else {
+        pf += 1;
+        cc += calls(cd.par_fh, cd.par_ns);
+        if (!cd.par_free) settled = true;
+        else {
+          bool mates = false;
+          for (const Nb& nb : cd.nbs) mates |= nb.id < 0;
+          if (!mates) {
+            nq += (uint64_t)trees.size();
+            for (const Nb& nb : cd.nbs) {
+              if (nb.same_tree) {
+                pf += 1;
+                cc += calls(nb.fh, nb.ns);
+                if (nb.free) { settled = true; break; }      // :276-280
+              } else {
+                pf += 1;
+                cc += calls(nb.fh, nb.ns);
+                if (!nb.free) settled = true;                // :296-299 without a border entry
+                break;                                       // (a free edge records a border: replay)
+              }
+            }
+          }
+        }
+      }
+      if (settled) {
+        cd.bulk = true;
+        bulk_counts[0] += cc;
+        bulk_counts[1] += pf;
+        bulk_counts[2] += nq;
+        bulk_counts[3] += 1;
+      }
+    }
+    for (int k = 0; k < 4; ++k) {
+      records[2 + 2 * k] = (int32_t)(uint32_t)(bulk_counts[k] & 0xffffffffu);
+      records[3 + 2 * k] = (int32_t)(uint32_t)(bulk_counts[k] >> 32);
+    }
+  }
+
   // ---- the int32 record stream of the owned candidates (only needed when there are other ranks)
   for (int i = 0; i < n && cfg.world > 1; ++i) {
     Cand& cd = cands[i];
-    if (!cd.answered) continue;
+    if (!cd.answered || cd.bulk) continue;
     records.push_back(i);
     records.push_back((cd.pose_hit ? 1 : 0) | (cd.par_free ? 2 : 0));
     records.push_back(cd.par_fh);
@@ -791,13 +844,25 @@ void Forest::round_commit(const int32_t* all, const int32_t* counts, int world) 
   const int n = n_cands;
   auto _t4 = Clock::now();
   // ---- absorb the other ranks' answers
+  uint64_t settled_elsewhere = 0;
+  st.collide_calls += bulk_counts[0];   // this rank's own bulk-settled samples
+  st.path_free_calls += bulk_counts[1];
+  st.nn_queries += bulk_counts[2];
   size_t off = 0;
   for (int r = 0; r < world && world > 1; ++r) {
     const int32_t* p = all + off;
     const int32_t* end = p + counts[r];
     off += (size_t)counts[r];
-    if (counts[r] < 2 || p[0] != REC_MAGIC || p[1] != n) throw HipError{"forest: ranks disagree on the round (diverged state)"};
-    p += 2;
+    if (counts[r] < 10 || p[0] != REC_MAGIC || p[1] != n) throw HipError{"forest: ranks disagree on the round (diverged state)"};
+    if (r != cfg.rank) {   // the other ranks' bulk-settled samples: counters only
+      uint64_t v[4];
+      for (int k = 0; k < 4; ++k) v[k] = (uint64_t)(uint32_t)p[2 + 2 * k] | ((uint64_t)(uint32_t)p[3 + 2 * k] << 32);
+      st.collide_calls += v[0];
+      st.path_free_calls += v[1];
+      st.nn_queries += v[2];
+      settled_elsewhere += v[3];
+    }
+    p += 10;
     while (p < end) {
       int i = p[0];
       if (i < 0 || i >= n || i % world != r) throw HipError{"forest: malformed record stream"};
@@ -851,6 +916,7 @@ void Forest::round_commit(const int32_t* all, const int32_t* counts, int world) 
   };
   std::vector<double> app_pos;
   std::vector<int32_t> app_tree;
+  uint64_t unrecorded = 0;
   for (int i = 0; i < n; ++i) {
     Cand& cd = cands[i];
     Slot& sl = slots[cd.slot];
@@ -860,7 +926,11 @@ void Forest::round_commit(const int32_t* all, const int32_t* counts, int world) 
     }
     const unsigned iteration = (unsigned)(iter0 + i + 1);
     if (!cd.in_lim) continue;                                  // :246 !result
-    if (!cd.answered) throw HipError{"forest: a candidate has no answer record (missing rank?)"};
+    if (cd.bulk) continue;                                     // settled (rejected, no side effect) by its owner
+    if (!cd.answered) {                                        // another rank's sample without a record: settled there
+      if (world > 1 && i % world != cfg.rank) { ++unrecorded; continue; }
+      throw HipError{"forest: a candidate has no answer record"};
+    }
     st.collide_calls += 1;
     if (cd.pose_hit) continue;                                 // :246 env.Collide(newPoint)
     st.path_free_calls += 1;
@@ -965,6 +1035,8 @@ void Forest::round_commit(const int32_t* all, const int32_t* counts, int world) 
   }
   g_sec[5] += ms_since(_t5);
   auto _t6 = Clock::now();
+  if (!solved && unrecorded != settled_elsewhere)   // (a goal hit stops the replay early: counts then differ legitimately)
+    throw HipError{"forest: answer records missing (a rank did not report all of its samples)"};
   // ---- commit the accepted nodes to the device store (replaces flannIndex->addPoints, :367)
   if (n > 0) c.store_n = N0;
   if (!app_tree.empty()) {
