@@ -106,7 +106,6 @@ void launch_sweep(hipStream_t s, const NodeStoreView& st, int first, int n_nodes
 void launch_grid_insert(hipStream_t s, const GridView& g, const NodeStoreView& st, int first, int n);
 void launch_grid_query(hipStream_t s, const GridView& g, const NodeStoreView& st, const SweepQuery* queries,
                        const double* qpos, int nq, int32_t* cnt, int32_t* hit_idx, double* hit_dist, int cap);
-void launch_store_nan(hipStream_t s, const NodeStoreMut& st, int first, int n);
 void launch_set_tree(hipStream_t s, int32_t* tree_col, const int32_t* ids, int n, int32_t value);
 
 void launch_collide_poses(hipStream_t s, const EnvView& env, const RobotView& rob, const double* pos6, int n,

@@ -257,14 +257,6 @@ __global__ __launch_bounds__(256) void k_grid_query(GridView g, NodeStoreView st
   for (int j = lane; j < no; j += 64) grid_test(g.ovf[j], Q, q, st, qpos, cnt, hit_idx, hit_dist, cap);
 }
 
-__global__ __launch_bounds__(64) void k_store_nan(NodeStoreMut st, int first, int n) {
-  const int i = threadIdx.x;
-  if (i >= n) return;
-  const float nanv = __int_as_float(0x7fc00000);
-  const size_t o = (size_t)first + i;
-  st.x[o] = nanv; st.y[o] = nanv; st.z[o] = nanv; st.yaw[o] = nanv; st.pitch[o] = nanv; st.roll[o] = nanv;
-}
-
 __global__ __launch_bounds__(256) void k_set_tree(int32_t* __restrict__ tree_col, const int32_t* __restrict__ ids, int n,
                                                   int32_t value) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -844,11 +836,6 @@ void launch_grid_query(hipStream_t s, const GridView& g, const NodeStoreView& st
   hipLaunchKernelGGL(k_grid_query, dim3((nq + 3) / 4), dim3(256), 0, s, g, st, queries, qpos, nq, cnt, hit_idx,
                      hit_dist, cap);
 }
-void launch_store_nan(hipStream_t s, const NodeStoreMut& st, int first, int n) {
-  if (n <= 0) return;
-  hipLaunchKernelGGL(k_store_nan, dim3(1), dim3(64), 0, s, st, first, n);
-}
-
 void launch_set_tree(hipStream_t s, int32_t* tree_col, const int32_t* ids, int n, int32_t value) {
   if (n <= 0) return;
   hipLaunchKernelGGL(k_set_tree, dim3((n + 255) / 256), dim3(256), 0, s, tree_col, ids, n, value);
