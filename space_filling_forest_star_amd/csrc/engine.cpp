@@ -431,8 +431,8 @@ void Ctx::collide_segments(const double* a6, const double* b6, int n, uint8_t* i
   if (n <= 0) return;
   if (!have_env || !have_robot) throw HipError{"collide_segments: upload ENV and ROBOT meshes first"};
   HIPCHK(hipSetDevice(device));
-  // sample counts (src/problemStruct.h:155-156) and result presets are computed on the device; the persistent
-  // edge kernel then scans the n task slots
+  // sample counts (src/problemStruct.h:155-156) and result presets are computed on the device, then the slot
+  // table is compacted into (edge, chunk) work items for the persistent edge kernel
   const size_t pb = (size_t)n * 6 * sizeof(double);
   h_a.ensure(pb); h_b.ensure(pb); h_c.ensure((size_t)n * 12 + 16);
   memcpy(h_a.p, a6, pb);
@@ -447,9 +447,12 @@ void Ctx::collide_segments(const double* a6, const double* b6, int n, uint8_t* i
   HIPCHK(hipMemcpyAsync(d_a.p, h_a.p, pb, hipMemcpyHostToDevice, stream));
   HIPCHK(hipMemcpyAsync(d_b.p, h_b.p, pb, hipMemcpyHostToDevice, stream));
   HIPCHK(hipMemsetAsync(d_ctrl, 0, 16, stream));
+  const int list_cap = 8 * n + 65536;
+  r_items.ensure((size_t)list_cap * 8);
   time_begin(T_COLLIDE);
   sffk::launch_seg_prepare(stream, d_a.as<double>(), d_b.as<double>(), n, d_ns, d_fh, d_ov);
-  sffk::launch_collide_segments_dyn(stream, envv, robv, d_a.as<double>(), d_b.as<double>(), d_ns, n, d_ctrl, d_fh, d_ov, 2);
+  sffk::launch_collide_segments_dyn(stream, envv, robv, d_a.as<double>(), d_b.as<double>(), d_ns, n, d_ctrl,
+                                    r_items.as<int32_t>(), list_cap, d_fh, d_ov);
   time_end();
   HIPCHK(hipMemcpyAsync(h_c.p, d_c.p, (size_t)n * 12, hipMemcpyDeviceToHost, stream));
   sync();

@@ -440,8 +440,10 @@ void Forest::round_begin() {
   c.time_begin(T_COLLIDE);
   sffk::launch_classify(c.stream, ca);
   sffk::launch_collide_poses(c.stream, c.envv, c.robv, d_pos, n, ca.rec_flags, d_pose);
+  const int list_cap = 4 * n * STRIDE + 65536;
+  c.r_items.ensure((size_t)list_cap * 8);
   sffk::launch_collide_segments_dyn(c.stream, c.envv, c.robv, ca.seg_a, ca.seg_b, ca.seg_ns, n * STRIDE, ca.ctrl,
-                                    ca.first_hit, ca.seg_ovf, 16);
+                                    c.r_items.as<int32_t>(), list_cap, ca.first_hit, ca.seg_ovf);
   c.time_end();
   c.p_out.ensure(o_bytes);
   char* ho = c.p_out.as<char>();

@@ -140,11 +140,10 @@ struct ClassifyArgs {
 void launch_classify(hipStream_t s, const ClassifyArgs& a);
 void launch_seg_prepare(hipStream_t s, const double* a6, const double* b6, int n, int32_t* seg_ns, int32_t* first_hit,
                         int32_t* ovf);
+// ctrl = 4 zeroed ints ([1] scan cursor, [2] work items, [3] list overflow); list = 2 ints per work item
+// (slot, chunk), list_cap items.  An overflowing list only costs speed (the kernel scans the slot table).
 void launch_collide_segments_dyn(hipStream_t s, const EnvView& env, const RobotView& rob, const double* a6,
                                  const double* b6, const int32_t* seg_ns, int n_slots, int32_t* ctrl,
-                                 int32_t* first_hit, int32_t* overflow_flag, int batch);
-// batch = task slots per dequeue: 16 for the sparse per-sample slot table of a forest round (most slots are
-// empty), 2 for dense host batches where every slot is a live edge
-
+                                 int32_t* list, int list_cap, int32_t* first_hit, int32_t* overflow_flag);
 
 }  // namespace sffk

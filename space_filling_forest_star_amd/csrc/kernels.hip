@@ -605,15 +605,52 @@ __device__ void segment_chunk(const EnvView& env, const RobotView& rob, const do
   if (minhit != 0x7fffffff && lane == 0) atomicMin(first_hit + seg, minhit);
 }
 
-// Edge tasks written on the device (k_classify for the forest rounds, k_seg_prepare for host batches): persistent wavefronts pull BATCH (<= 64) consecutive task
-// slots per dequeue (a returning atomic on one word saturates near 90 dequeues/us chip-wide, so the
-// dequeue is coarse), keep the live ones (seg_ns > 0) and run their 64-sample chunks.  This also evens
-// out the very uneven cost per edge.
+// Edge tasks are written on the device (k_classify for the forest rounds, k_seg_prepare for host batches)
+// into a sparse slot table (seg_ns > 0 = live edge).  k_seg_compact turns the table into a dense list of
+// (slot, chunk) work items - one block-level scan and ONE atomic per block, because returning atomics on a
+// single word saturate near 90/us chip-wide and a per-item dequeue would cost more than the work itself.
+// ctrl[2] = items reserved, ctrl[3] = 1 when the list ran over (the edge kernel then scans the table).
+__global__ __launch_bounds__(256) void k_seg_compact(const int32_t* __restrict__ seg_ns, int n_slots,
+                                                     int32_t* __restrict__ ctrl, int32_t* __restrict__ list, int cap) {
+  __shared__ int wsum[4];
+  __shared__ int base_s;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int s0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  int c[4], tot = 0;
+  for (int j = 0; j < 4; ++j) {
+    const int ns = (s0 + j < n_slots) ? seg_ns[s0 + j] : 0;
+    c[j] = ns > 0 ? (ns + 63) >> 6 : 0;
+    tot += c[j];
+  }
+  int inc = tot;  // inclusive scan inside the wave
+  for (int off = 1; off < 64; off <<= 1) {
+    int o = __shfl_up(inc, off);
+    if (lane >= off) inc += o;
+  }
+  if (lane == 63) wsum[wave] = inc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int all = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    base_s = all > 0 ? atomicAdd(ctrl + 2, all) : 0;
+  }
+  __syncthreads();
+  int at = base_s + inc - tot;
+  for (int w = 0; w < wave; ++w) at += wsum[w];
+  for (int j = 0; j < 4; ++j)
+    for (int k = 0; k < c[j]; ++k, ++at) {
+      if (at < cap) { list[2 * (size_t)at] = s0 + j; list[2 * (size_t)at + 1] = k; }
+      else ctrl[3] = 1;
+    }
+}
+
+// Persistent wavefronts walk the work list with a fixed stride (no dequeue atomics); a chunk whose edge
+// already has a hit below its first sample is skipped (only the smallest index matters).
 __global__ __launch_bounds__(64 * SEG_WAVES) void k_collide_segments_dyn(EnvView env, RobotView rob,
                                                                          const double* __restrict__ a6,
                                                                          const double* __restrict__ b6,
                                                                          const int32_t* __restrict__ seg_ns, int n_slots,
-                                                                         int32_t* __restrict__ ctrl, int BATCH,
+                                                                         int32_t* __restrict__ ctrl,
+                                                                         const int32_t* __restrict__ list, int cap,
                                                                          int32_t* __restrict__ first_hit,
                                                                          int32_t* __restrict__ overflow_flag) {
   extern __shared__ double lds_d[];
@@ -623,22 +660,36 @@ __global__ __launch_bounds__(64 * SEG_WAVES) void k_collide_segments_dyn(EnvView
   for (int i = threadIdx.x; i < rob.n_tri * 9; i += blockDim.x) rtri[i] = rob.tri[i];
   __syncthreads();
   if (env.n_tri == 0) return;
+  int32_t* stack = ibase + wave * STACK_CAP;
+  int32_t* cand = ibase + SEG_WAVES * STACK_CAP + wave * CAND_CAP;
+  int32_t* queue = ibase + SEG_WAVES * (STACK_CAP + CAND_CAP) + wave * QUEUE_CAP;
+  if (!ctrl[3]) {
+    const int M = ctrl[2];
+    const int W = gridDim.x * SEG_WAVES;
+    // wave w of block b takes items b + gridDim.x * w + W * i: neighbouring items (chunks of one edge,
+    // edges of one sample) go to different CUs
+    for (int e = blockIdx.x + gridDim.x * wave; e < M; e += W) {
+      const int slot = list[2 * (size_t)e], chunk = list[2 * (size_t)e + 1];
+      if (chunk > 0 && first_hit[slot] <= 64 * chunk) continue;
+      segment_chunk(env, rob, rtri, stack, cand, queue, a6, b6, slot, chunk, first_hit, overflow_flag, lane);
+    }
+    return;
+  }
+  // the list ran over: scan the slot table, 64 slots per dequeue
   while (true) {
     int first = 0;
-    if (lane == 0) first = atomicAdd(ctrl + 1, BATCH);
+    if (lane == 0) first = atomicAdd(ctrl + 1, 64);
     first = __shfl(first, 0);
     if (first >= n_slots) break;
     const int slot = first + lane;
-    const int ns = (lane < BATCH && slot < n_slots) ? seg_ns[slot] : -1;
+    const int ns = slot < n_slots ? seg_ns[slot] : -1;
     unsigned long long live = __ballot(ns > 0);
     while (live) {
       const int b = __ffsll((long long)live) - 1;
       live &= live - 1;
       const int nsb = __shfl(ns, b);
       for (int chunk = 0; chunk * 64 < nsb; ++chunk)
-        segment_chunk(env, rob, rtri, ibase + wave * STACK_CAP, ibase + SEG_WAVES * STACK_CAP + wave * CAND_CAP,
-                      ibase + SEG_WAVES * (STACK_CAP + CAND_CAP) + wave * QUEUE_CAP, a6, b6, first + b, chunk, first_hit,
-                      overflow_flag, lane);
+        segment_chunk(env, rob, rtri, stack, cand, queue, a6, b6, first + b, chunk, first_hit, overflow_flag, lane);
     }
   }
 }
@@ -862,14 +913,17 @@ void launch_seg_prepare(hipStream_t s, const double* a6, const double* b6, int n
 
 void launch_collide_segments_dyn(hipStream_t s, const EnvView& env, const RobotView& rob, const double* a6,
                                  const double* b6, const int32_t* seg_ns, int n_slots, int32_t* ctrl,
-                                 int32_t* first_hit, int32_t* overflow_flag, int batch) {
+                                 int32_t* list, int list_cap, int32_t* first_hit, int32_t* overflow_flag) {
   if (n_slots <= 0) return;
   size_t lds = collide_lds_bytes(rob.n_tri, SEG_WAVES);
-  // 3 workgroups of 4 waves per CU = what the kernel's register budget keeps resident (256 CUs)
-  static const int blocks = getenv("SFFGPU_SEG_BLOCKS") ? atoi(getenv("SFFGPU_SEG_BLOCKS")) : 768;
-  if (getenv("SFFGPU_SEG_BATCH")) batch = atoi(getenv("SFFGPU_SEG_BATCH"));
+  // 2 workgroups of 4 waves per CU = what the kernel's register budget keeps resident (256 CUs)
+  static const int blocks = getenv("SFFGPU_SEG_BLOCKS") ? atoi(getenv("SFFGPU_SEG_BLOCKS")) : 512;
+  const int cap_override = getenv("SFFGPU_SEG_LISTCAP") ? atoi(getenv("SFFGPU_SEG_LISTCAP")) : -1;  // tests
+  if (cap_override >= 0 && cap_override < list_cap) list_cap = cap_override;
+  hipLaunchKernelGGL(k_seg_compact, dim3((n_slots + 1023) / 1024), dim3(256), 0, s, seg_ns, n_slots, ctrl, list,
+                     list_cap);
   hipLaunchKernelGGL(k_collide_segments_dyn, dim3(blocks), dim3(64 * SEG_WAVES), lds, s, env, rob, a6, b6, seg_ns,
-                     n_slots, ctrl, batch, first_hit, overflow_flag);
+                     n_slots, ctrl, list, list_cap, first_hit, overflow_flag);
 }
 
 }  // namespace sffk

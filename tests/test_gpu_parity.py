@@ -306,6 +306,22 @@ def test_device_list_overflow_takes_host_path(S, ctx, monkeypatch):
     assert_same_forest(fo, fg)
 
 
+def test_edge_work_list_overflow_scans_slot_table(S, ctx, monkeypatch):
+    """A work list too small for the round's (edge, chunk) items: the edge kernel falls back to scanning the
+    slot table; edges and forests must not change."""
+    monkeypatch.setenv("SFFGPU_SEG_LISTCAP", "5")
+    sc, w = load_world(ctx, "dense3d")
+    n = 400
+    a = common.poses_near_surface(sc["env"], n, 8, 3.0 * sc["scale"], 6)
+    b = a.copy()
+    b[:, :3] += np.random.RandomState(2).normal(0, 1, (n, 3)) * sc["sampling_dist"]
+    free, fh, ns = ctx.collide_segments(a, b)
+    for i in range(n):
+        assert (free[i], fh[i], ns[i]) == w.path_free(a[i], b[i]), i
+    fo, fg = run_pair(S, ctx, "dense3d", 128, 3000, seed=3, optimize=True)
+    assert_same_forest(fo, fg)
+
+
 def test_grid_recells_under_overflow_pressure(S, ctx, monkeypatch):
     """One-item buckets and a 64-entry overflow list: the grid has to re-cell itself repeatedly; the
     neighbour sets (hence the forest) must not change."""
