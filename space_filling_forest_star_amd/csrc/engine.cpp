@@ -59,24 +59,63 @@ void Mt64::reseed(uint64_t seed) {
   for (int i = 1; i < 312; ++i) mt[i] = 6364136223846793005ULL * (mt[i - 1] ^ (mt[i - 1] >> 62)) + (uint64_t)i;
   idx = 312;
   draws = 0;
+  q = nullptr;
+  qh = qn = 0;
 }
-uint64_t Mt64::next() {
-  if (idx >= 312) {
-    for (int i = 0; i < 312; ++i) {
-      uint64_t x = (mt[i] & 0xFFFFFFFF80000000ULL) | (mt[(i + 1) % 312] & 0x7FFFFFFFULL);
-      uint64_t xa = x >> 1;
-      if (x & 1ULL) xa ^= 0xB5026F5AA96619E9ULL;
-      mt[i] = mt[(i + 156) % 312] ^ xa;
-    }
-    idx = 0;
-  }
-  ++draws;
-  uint64_t y = mt[idx++];
+static inline uint64_t mt_step(uint64_t a, uint64_t b, uint64_t far) {
+  const uint64_t x = (a & 0xFFFFFFFF80000000ULL) | (b & 0x7FFFFFFFULL);
+  return far ^ (x >> 1) ^ ((0ULL - (x & 1ULL)) & 0xB5026F5AA96619E9ULL);
+}
+static inline uint64_t mt_temper(uint64_t y) {
   y ^= (y >> 29) & 0x5555555555555555ULL;
   y ^= (y << 17) & 0x71D67FFFEDA60000ULL;
   y ^= (y << 37) & 0xFFF7EEE000000000ULL;
   y ^= (y >> 43);
   return y;
+}
+void Mt64::twist() {
+  for (int i = 0; i < 156; ++i) mt[i] = mt_step(mt[i], mt[i + 1], mt[i + 156]);
+  for (int i = 156; i < 311; ++i) mt[i] = mt_step(mt[i], mt[i + 1], mt[i - 156]);
+  mt[311] = mt_step(mt[311], mt[0], mt[155]);
+  idx = 0;
+}
+uint64_t Mt64::next() {
+  ++draws;
+  if (qh < qn) return q[qh++];
+  if (idx >= 312) twist();
+  return mt_temper(mt[idx++]);
+}
+void Mt64::fill(uint64_t* out, size_t n) {
+  draws += n;
+  size_t k = 0;
+  if (qh < qn) {
+    k = std::min(n, qn - qh);
+    memcpy(out, q + qh, k * sizeof(uint64_t));
+    qh += k;
+  }
+  while (k < n) {
+    if (idx >= 312) twist();
+    const size_t take = std::min<size_t>(312 - idx, n - k);
+    for (size_t j = 0; j < take; ++j) out[k + j] = mt_temper(mt[idx + j]);
+    idx += (int)take;
+    k += take;
+  }
+}
+void Mt64::prefetch(uint64_t* buf, size_t want) {
+  if (q != buf || qh > 0) {
+    const size_t left = qn - qh;
+    if (left) memmove(buf, q + qh, left * sizeof(uint64_t));
+    q = buf;
+    qh = 0;
+    qn = left;
+  }
+  while (qn < want) {
+    if (idx >= 312) twist();
+    size_t take = std::min<size_t>(312 - idx, want - qn);
+    for (size_t k = 0; k < take; ++k) buf[qn + k] = mt_temper(mt[idx + k]);
+    idx += (int)take;
+    qn += take;
+  }
 }
 int Mt64::uniform_int(int lo, int hi) {
   uint64_t range = (uint64_t)((int64_t)hi - (int64_t)lo) + 1ULL;
@@ -104,20 +143,27 @@ Ctx::Ctx(int dev) : device(dev) {
   if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
     throw HipError{std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only"};
   HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+  HIPCHK(hipEventCreateWithFlags(&ev_mid, hipEventDisableTiming));
+  HIPCHK(hipEventCreateWithFlags(&ev_early, hipEventDisableTiming));
 }
 
 Ctx::~Ctx() {
   (void)hipSetDevice(device);
   if (stream) (void)hipStreamSynchronize(stream);
+  if (copy_stream) (void)hipStreamSynchronize(copy_stream);
+  if (ev_mid) (void)hipEventDestroy(ev_mid);
+  if (ev_early) (void)hipEventDestroy(ev_early);
   for (auto& t : pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto e : pool) (void)hipEventDestroy(e);
   DevBuf* bufs[] = {&env_tri, &env_box, &env_plane, &rob_tri, &sx, &sy, &sz, &syaw, &spitch, &sroll, &stree, &spos,
                     &d_a, &d_b, &d_c, &d_d, &d_e, &d_f, &d_g, &d_h, &r_in, &r_out, &r_q, &r_cnt, &r_hidx,
-                    &r_hdist, &r_sega, &r_segb, &r_items, &g_cnt, &g_items, &g_ovfcnt, &g_ovf};
+                    &r_hdist, &r_sega, &r_segb, &r_items, &env_clear, &g_cnt, &g_items, &g_ovfcnt, &g_ovf};
   for (DevBuf* b : bufs) b->release();
   for (auto& b : level_box) b.release();
   PinBuf* pins[] = {&h_a, &h_b, &h_c, &h_d, &h_e, &h_f, &h_g, &h_h, &p_in, &p_out};
   for (PinBuf* b : pins) b->release();
+  if (copy_stream) (void)hipStreamDestroy(copy_stream);
   if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -131,12 +177,16 @@ hipEvent_t Ctx::get_event() {
   HIPCHK(hipEventCreate(&e));
   return e;
 }
+static const int g_timer_mask = getenv("SFFGPU_TIMER_MASK") ? atoi(getenv("SFFGPU_TIMER_MASK")) : 7;
+static bool g_timer_on = true;
 void Ctx::time_begin(int kind) {
+  g_timer_on = (g_timer_mask >> kind) & 1;
+  if (!g_timer_on) return;
   Timed t{get_event(), get_event(), kind};
   HIPCHK(hipEventRecord(t.a, stream));
   pending.push_back(t);
 }
-void Ctx::time_end() { HIPCHK(hipEventRecord(pending.back().b, stream)); }
+void Ctx::time_end() { if (g_timer_on) HIPCHK(hipEventRecord(pending.back().b, stream)); }
 void Ctx::sync() {
   HIPCHK(hipStreamSynchronize(stream));
   for (auto& t : pending) {
@@ -188,11 +238,13 @@ void Ctx::upload_mesh(int role, const double* tri9, int n) {
     }
     robv.radius = rad;
     have_robot = true;
+    build_clearance();
     return;
   }
   if (role != SFFGPU_MESH_ENV) throw HipError{"unknown mesh role"};
   envv = sffk::EnvView{};
   have_env = true;
+  clear_cells = 0;
   if (n <= 0) return;  // HasMap == false
   std::vector<double> box((size_t)n * 6);
   double glo[3] = {1e300, 1e300, 1e300}, ghi[3] = {-1e300, -1e300, -1e300};
@@ -205,6 +257,7 @@ void Ctx::upload_mesh(int role, const double* tri9, int n) {
       glo[a] = std::min(glo[a], lo);
       ghi[a] = std::max(ghi[a], hi);
     }
+  for (int a = 0; a < 3; ++a) { env_lo[a] = glo[a]; env_hi[a] = ghi[a]; }
   env_maxabs = 1.0;
   for (int a = 0; a < 3; ++a) env_maxabs = std::max(env_maxabs, std::max(std::fabs(glo[a]), std::fabs(ghi[a])));
   std::vector<std::pair<uint64_t, int>> order(n);
@@ -272,6 +325,50 @@ void Ctx::upload_mesh(int role, const double* tri9, int n) {
     if (groups <= 64) break;
   }
   envv.n_levels = L;
+  build_clearance();
+}
+
+// Clearance bits over the environment box (kernels.h, EnvView): one bit per cell, set when a robot whose
+// bounding-sphere centre lies anywhere in the cell cannot touch a triangle.  The cell edge follows the
+// robot radius but the grid is capped at 2^27 cells (16 MB of bits) and by the build cost.
+void Ctx::build_clearance() {
+  envv.clear_bits = nullptr;
+  clear_cells = 0;
+  if (!have_env || !have_robot || envv.n_tri <= 0) return;
+  if (const char* e = getenv("SFFGPU_NO_CLEARANCE")) if (atoi(e)) return;
+  const double rr = robv.radius;
+  double ext[3], vol_ext = 0;
+  for (int a = 0; a < 3; ++a) { ext[a] = env_hi[a] - env_lo[a]; vol_ext = std::max(vol_ext, ext[a]); }
+  if (!(vol_ext > 0) || !(rr >= 0)) return;
+  double cap = 134217728.0;
+  if (const char* e = getenv("SFFGPU_CLEAR_CELLS")) cap = std::max(512.0, atof(e));
+  cap = std::min(cap, std::max(32768.0, 4e10 / (double)std::max(1, envv.level_count[0])));
+  double h = std::max(rr * 0.5, vol_ext * 1e-4);
+  int n[3];
+  double thr = 0;
+  for (int it = 0; it < 64; ++it) {
+    const double halfdiag = 0.5 * std::sqrt(3.0) * h;
+    const double m0 = rr + halfdiag;
+    thr = rr * (1 + 1e-9) + halfdiag * (1 + 1e-5) + 1e-8 * (3 * (env_maxabs + 2 * m0) + 1);
+    double cells = 1;
+    for (int a = 0; a < 3; ++a) {
+      double c = std::ceil((ext[a] + 2 * thr) / h) + 1;
+      n[a] = (int)std::min(c, 1e9);
+      cells *= c;
+    }
+    if (cells <= cap) break;
+    h *= std::max(1.02, std::cbrt(cells / cap));
+  }
+  const long long cells = (long long)n[0] * n[1] * n[2];
+  if (cells <= 0 || cells > (1LL << 31)) return;
+  for (int a = 0; a < 3; ++a) { envv.clear_org[a] = env_lo[a] - thr; envv.clear_n[a] = n[a]; }
+  envv.clear_inv = 1.0 / h;
+  const long long padded = (cells + 255) / 256 * 256;
+  env_clear.ensure((size_t)(padded / 8));
+  sffk::launch_clear_build(stream, envv, thr, env_clear.as<uint32_t>(), cells);
+  HIPCHK(hipStreamSynchronize(stream));
+  envv.clear_bits = env_clear.as<uint32_t>();
+  clear_cells = cells;
 }
 
 // ------------------------------------------------------------------ node store

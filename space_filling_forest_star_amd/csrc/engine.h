@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include <map>
+#include <unordered_set>
 #include <string>
 #include <utility>
 #include <vector>
@@ -42,9 +43,16 @@ struct Mt64 {
   uint64_t mt[312];
   int idx;
   uint64_t draws = 0;   // engine words handed out so far (lets a speculative wave rewind)
+  // optional queue of words generated ahead of their use (the forest engine fills it while the GPU works);
+  // the words come out in the same order either way
+  uint64_t* q = nullptr;
+  size_t qh = 0, qn = 0;
   explicit Mt64(uint64_t seed = 5489ULL) { reseed(seed); }
   void reseed(uint64_t seed);
+  void twist();
+  void prefetch(uint64_t* buf, size_t want);   // top the queue (in buf, >= want words large) up to `want` words
   uint64_t next();
+  void fill(uint64_t* out, size_t n);          // n consecutive words (same as n calls of next())
   int uniform_int(int lo, int hi);  // uniform_int_distribution<int>(lo,hi) (Lemire multiply-shift)
 };
 
@@ -59,14 +67,19 @@ enum TimerKind { T_SWEEP = 0, T_COLLIDE = 1, T_SAMPLE = 2, T_KINDS = 3 };
 struct Ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t copy_stream = nullptr;          // early D2H of a forest round (runs beside the collision kernels)
+  hipEvent_t ev_mid = nullptr, ev_early = nullptr;
   std::string err;
 
   // collision models
-  DevBuf env_tri, env_box, env_plane, level_box[SFFK_MAX_LEVELS], rob_tri;
+  DevBuf env_tri, env_box, env_plane, level_box[SFFK_MAX_LEVELS], rob_tri, env_clear;
   sffk::EnvView envv{};
   sffk::RobotView robv{};
   bool have_env = false, have_robot = false;
   double env_maxabs = 1.0;
+  double env_lo[3] = {0, 0, 0}, env_hi[3] = {0, 0, 0};
+  long long clear_cells = 0;   // cells of the clearance grid (0 = none)
+  void build_clearance();
 
   // node store
   int store_cap = 0, store_n = 0;
@@ -160,10 +173,12 @@ struct Forest {
   Ctx* ctx;
   sffgpu_forest_cfg cfg;
   Mt64 rng;
+  std::vector<uint64_t> rng_ahead;   // engine words generated while the GPU works (fixed size: Mt64 keeps a pointer)
   std::vector<FNode> nodes;
   std::vector<std::vector<int>> trees;
   std::vector<int> frontier, closed;
   std::map<std::pair<int, int>, std::vector<Border>> borders;
+  std::unordered_set<uint64_t> border_keys;   // (n1, n2) pairs present in any border list (the reference scans the list)
   std::vector<int> connected;
   int num_roots = 0;   // Problem::GetNumRoots(): roots + the goal tree
   int goal_node = -1;
@@ -215,6 +230,7 @@ struct Forest {
     }
   };
   std::vector<Cand> cands;   // storage (only grows); the current round uses the first n_cands
+  std::vector<uint8_t> round_skip;   // per candidate: 1 = the replay has nothing to do (outside the limits / settled by this rank)
   int n_cands = 0;
   std::vector<int32_t> records;  // this rank's answers of the pending round (int32 stream)
   uint64_t bulk_counts[4] = {0, 0, 0, 0};  // collide / path_free / nn counters + number of bulk-settled samples (own shard)

@@ -24,6 +24,7 @@ namespace sff {
 #define HIPCHK(x) hip_check((x), #x)
 using Clock = std::chrono::steady_clock;
 static double g_sec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+static uint64_t g_cnt[4] = {0, 0, 0, 0};   // candidates, skipped by the replay, settled on the device, accepted
 static const bool g_prof = getenv("SFFGPU_PROFILE") != nullptr;
 struct Sec {
   int k;
@@ -32,6 +33,7 @@ struct Sec {
   ~Sec() { g_sec[k] += std::chrono::duration<double, std::milli>(Clock::now() - t0).count(); }
 };
 void forest_profile_dump() {
+  if (g_prof) fprintf(stderr, "[sffgpu candidates] %llu skipped %llu settled %llu\n", (unsigned long long)g_cnt[0], (unsigned long long)g_cnt[1], (unsigned long long)g_cnt[2]);
   if (g_prof) fprintf(stderr, "[sffgpu host ms] prep %.1f launch %.1f read %.1f records %.1f deser %.1f replay %.1f append %.1f endwave %.1f\n", g_sec[0], g_sec[1], g_sec[2], g_sec[3], g_sec[4], g_sec[5], g_sec[6], g_sec[7]);
 }
 static double ms_since(Clock::time_point t0) {
@@ -93,6 +95,7 @@ Forest::Forest(Ctx* c, const sffgpu_forest_cfg& cf, const double* roots6, int n_
   if (n_roots < 1) throw HipError{"forest: at least one root"};
   if (!c->have_env || !c->have_robot) throw HipError{"forest: upload ENV and ROBOT meshes first"};
   rng.reseed(cfg.seed);
+  if (cfg.wave >= 64) rng_ahead.assign((size_t)8 * cfg.wave + 4096, 0);
   num_roots = n_roots + (cfg.has_goal ? 1 : 0);
   trees.resize(num_roots);
   ctx->store_reset(std::max(cfg.node_budget, 4096) + cfg.wave + 64);
@@ -351,8 +354,11 @@ void Forest::round_begin() {
     uint64_t* hw = reinterpret_cast<uint64_t*>(c.p_in.as<char>() + in_words);
     int32_t* hp = reinterpret_cast<int32_t*>(c.p_in.as<char>() + in_parent);
     uint8_t* hf = reinterpret_cast<uint8_t*>(c.p_in.as<char>() + in_force);
+    if (words_per == 6) rng.fill(hw, (size_t)n * 6);
     for (int i = 0; i < n; ++i) {
-      for (int k = 0; k < 6; ++k) hw[6 * (size_t)i + k] = k < words_per ? rng.next() : 0;
+      if (words_per != 6)
+        for (int k = 0; k < 6; ++k) hw[6 * (size_t)i + k] = k < words_per ? rng.next() : 0;
+      if (i + 16 < n) __builtin_prefetch(&nodes[cands[i + 16].expanded].force_children);
       hp[i] = cands[i].expanded;
       hf[i] = nodes[cands[i].expanded].force_children ? 1 : 0;
     }
@@ -360,18 +366,22 @@ void Forest::round_begin() {
   const uint64_t* d_words = reinterpret_cast<const uint64_t*>(c.r_in.as<char>() + in_words);
   const int32_t* d_parent = reinterpret_cast<const int32_t*>(c.r_in.as<char>() + in_parent);
   const uint8_t* d_force = reinterpret_cast<const uint8_t*>(c.r_in.as<char>() + in_force);
-  // device output block, one D2H copy: pos | pdist | records | edge ints | ctrl | in_lim | pose
-  // records: flags (n) | nnb (n) | nb ids (n*NBCAP) | nb meta (n*NBCAP); edge ints: samples | first hit | overflow
+  // device output block in two D2H copies.  Early part (complete after k_classify, copied on a second stream
+  // while the collision kernels run): pos | pdist | in_lim | records | edge sample counts.  Late part: edge
+  // first hits | edge overflow flags | ctrl (4 ints + 4 u64 settle counters) | pose answers | settle codes.
+  // records: flags (n) | nnb (n) | nb ids (n*NBCAP) | nb meta (n*NBCAP)
   const size_t rec_ints = (size_t)n * (2 + 2 * NBCAP);
-  const size_t o_pos = 0, o_pd = o_pos + (size_t)n * 48, o_rec = o_pd + (size_t)n * 8, o_segi = o_rec + rec_ints * 4,
-               o_ctrl = o_segi + (size_t)n * STRIDE * 12, o_lim = o_ctrl + 16, o_pose = o_lim + (size_t)n,
-               o_bytes = o_pose + (size_t)n;
+  const size_t o_pos = 0, o_pd = o_pos + (size_t)n * 48, o_lim = o_pd + (size_t)n * 8,
+               o_rec = o_lim + ((size_t)n + 15) / 16 * 16, o_ns = o_rec + rec_ints * 4,
+               o_fh = o_ns + (size_t)n * STRIDE * 4, o_ovf = o_fh + (size_t)n * STRIDE * 4,
+               o_ctrl = o_ovf + (size_t)n * STRIDE * 4, o_pose = o_ctrl + 48, o_code = o_pose + (size_t)n,
+               o_bytes = o_code + (size_t)n;
+  const size_t early_bytes = o_fh;
   c.r_out.ensure(o_bytes);
   char* dout = c.r_out.as<char>();
   double* d_pos = reinterpret_cast<double*>(dout + o_pos);
   double* d_pd = reinterpret_cast<double*>(dout + o_pd);
   int32_t* d_rec = reinterpret_cast<int32_t*>(dout + o_rec);
-  int32_t* d_segi = reinterpret_cast<int32_t*>(dout + o_segi);
   int32_t* d_ctrl = reinterpret_cast<int32_t*>(dout + o_ctrl);
   uint8_t* d_lim = reinterpret_cast<uint8_t*>(dout + o_lim);
   uint8_t* d_pose = reinterpret_cast<uint8_t*>(dout + o_pose);
@@ -433,23 +443,41 @@ void Forest::round_begin() {
   ca.rec_meta = ca.rec_nb + (size_t)n * NBCAP;
   ca.seg_a = c.r_sega.as<double>();
   ca.seg_b = c.r_segb.as<double>();
-  ca.seg_ns = d_segi;
-  ca.first_hit = ca.seg_ns + (size_t)n * STRIDE;
-  ca.seg_ovf = ca.first_hit + (size_t)n * STRIDE;
+  ca.seg_ns = reinterpret_cast<int32_t*>(dout + o_ns);
+  ca.first_hit = reinterpret_cast<int32_t*>(dout + o_fh);
+  ca.seg_ovf = reinterpret_cast<int32_t*>(dout + o_ovf);
   ca.ctrl = d_ctrl;
   c.time_begin(T_COLLIDE);
   sffk::launch_classify(c.stream, ca);
+  c.p_out.ensure(o_bytes);
+  char* ho = c.p_out.as<char>();
+  HIPCHK(hipEventRecord(c.ev_mid, c.stream));
+  HIPCHK(hipStreamWaitEvent(c.copy_stream, c.ev_mid, 0));
+  HIPCHK(hipMemcpyAsync(ho, dout, early_bytes, hipMemcpyDeviceToHost, c.copy_stream));
+  HIPCHK(hipEventRecord(c.ev_early, c.copy_stream));
   sffk::launch_collide_poses(c.stream, c.envv, c.robv, d_pos, n, ca.rec_flags, d_pose);
   const int list_cap = 4 * n * STRIDE + 65536;
   c.r_items.ensure((size_t)list_cap * 8);
   sffk::launch_collide_segments_dyn(c.stream, c.envv, c.robv, ca.seg_a, ca.seg_b, ca.seg_ns, n * STRIDE, ca.ctrl,
                                     c.r_items.as<int32_t>(), list_cap, ca.first_hit, ca.seg_ovf);
   c.time_end();
-  c.p_out.ensure(o_bytes);
-  char* ho = c.p_out.as<char>();
-  HIPCHK(hipMemcpyAsync(ho, dout, o_bytes, hipMemcpyDeviceToHost, c.stream));
+  // samples this rank can settle alone need no replay (with a goal the replay may stop in the middle of the
+  // round, so there every sample stays in it)
+  const bool settle_on_device = !cfg.has_goal;
+  if (settle_on_device) {
+    sffk::SettleArgs sa{};
+    sa.n = n; sa.Tb = Tb; sa.nbcap = NBCAP; sa.stride = STRIDE; sa.n_trees = (int)trees.size();
+    sa.in_lim = d_lim; sa.rec_flags = ca.rec_flags; sa.rec_nnb = ca.rec_nnb; sa.rec_nb = ca.rec_nb;
+    sa.rec_meta = ca.rec_meta; sa.seg_ns = ca.seg_ns; sa.first_hit = ca.first_hit; sa.seg_ovf = ca.seg_ovf;
+    sa.pose_hit = d_pose;
+    sa.code = reinterpret_cast<uint8_t*>(dout + o_code);
+    sa.bulk = reinterpret_cast<unsigned long long*>(dout + o_ctrl + 16);
+    sffk::launch_settle(c.stream, sa);
+  }
+  HIPCHK(hipMemcpyAsync(ho + early_bytes, dout + early_bytes, o_bytes - early_bytes, hipMemcpyDeviceToHost, c.stream));
   g_sec[1] += ms_since(_t1);
-  timed_sync();
+  // the GPU is busy for a while: generate the engine words of the next draws now
+  if (!rng_ahead.empty()) rng.prefetch(rng_ahead.data(), rng_ahead.size());
 
   const double* hpos = reinterpret_cast<const double*>(ho + o_pos);
   const double* hpd = reinterpret_cast<const double*>(ho + o_pd);
@@ -457,22 +485,23 @@ void Forest::round_begin() {
   const int32_t* hnnb = hflags + n;
   const int32_t* hnb = hnnb + n;
   const int32_t* hmeta = hnb + (size_t)n * NBCAP;
-  const int32_t* hns = reinterpret_cast<const int32_t*>(ho + o_segi);
-  const int32_t* hfh = hns + (size_t)n * STRIDE;
-  const int32_t* hovf = hfh + (size_t)n * STRIDE;
-  const int32_t* hctrl = reinterpret_cast<const int32_t*>(ho + o_ctrl);
+  const int32_t* hns = reinterpret_cast<const int32_t*>(ho + o_ns);
+  const int32_t* hfh = reinterpret_cast<const int32_t*>(ho + o_fh);
+  const int32_t* hovf = reinterpret_cast<const int32_t*>(ho + o_ovf);
   const uint8_t* hlim = reinterpret_cast<const uint8_t*>(ho + o_lim);
   const uint8_t* hpose = reinterpret_cast<const uint8_t*>(ho + o_pose);
-  (void)hctrl;
+  const uint8_t* hcode = reinterpret_cast<const uint8_t*>(ho + o_code);
   auto mine_shard = [&](int i) { return i % cfg.world == cfg.rank; };
 
-  auto _t2 = Clock::now();
-  // ---- read the answers; samples whose lists overflowed (and edges whose candidate lists did)
-  // take the host path below
+  // ---- read the answers in two passes: samples, neighbour records and edge sample counts as soon as the early
+  // copy has landed (the collision kernels are still running), the pose / edge answers after the final sync.
+  // Samples whose lists overflowed (and edges whose candidate lists did) take the host path below.
   std::vector<int> slow;        // samples to redo entirely on the host path
   std::vector<double> fix_a, fix_b;
   struct Fix { int cand; int slot; };
   std::vector<Fix> fixes;       // single edges to redo (triangle candidate list overflow)
+  HIPCHK(hipEventSynchronize(c.ev_early));
+  auto _t2 = Clock::now();
   for (int i = 0; i < n; ++i) {
     Cand& cd = cands[i];
     memcpy(cd.pos, hpos + 6 * (size_t)i, sizeof cd.pos);
@@ -481,19 +510,11 @@ void Forest::round_begin() {
     if (!cd.in_lim || !mine_shard(i)) continue;
     if (hflags[i] & 2) { slow.push_back(i); continue; }
     cd.answered = true;
-    cd.pose_hit = hpose[i] != 0;
     st.poses_executed += 1;
     const size_t s0 = (size_t)i * STRIDE;
-    auto edge = [&](size_t slot, bool& fr, int& fh, int& ns) {
-      ns = hns[slot];
-      fh = hfh[slot] == 0x7fffffff ? -1 : hfh[slot];
-      fr = fh < 0;
-      st.segments_executed += 1;
-      st.samples_executed += (uint64_t)ns;
-    };
-    edge(s0, cd.par_free, cd.par_fh, cd.par_ns);
-    if (hovf[s0]) fixes.push_back({i, 0});
     const int nnb = hnnb[i];
+    cd.par_ns = hns[s0];
+    uint64_t samples = (uint64_t)cd.par_ns;
     cd.nbs.resize(nnb);
     for (int k = 0; k < nnb; ++k) {
       Nb& nb = cd.nbs[k];
@@ -503,7 +524,41 @@ void Forest::round_begin() {
       nb.tree = meta >> 1;
       nb.same_tree = meta & 1;
       nb.seg = -1;
-      edge(s0 + 1 + k, nb.free, nb.fh, nb.ns);
+      nb.ns = hns[s0 + 1 + k];
+      samples += (uint64_t)nb.ns;
+    }
+    st.segments_executed += 1 + (uint64_t)nnb;
+    st.samples_executed += samples;
+  }
+  g_sec[2] += ms_since(_t2);
+  timed_sync();
+  _t2 = Clock::now();
+  if (settle_on_device) {
+    const uint64_t* hb = reinterpret_cast<const uint64_t*>(ho + o_ctrl + 16);
+    for (int k = 0; k < 4; ++k) bulk_counts[k] += hb[k];
+  }
+  round_skip.assign((size_t)n, 0);
+  g_cnt[0] += (uint64_t)n;
+  for (int i = 0; i < n; ++i) {
+    if (settle_on_device && hcode[i]) {      // settled on the device (1) or outside the limits (2)
+      round_skip[i] = 1;
+      g_cnt[1] += 1;
+      if (hcode[i] == 1) { cands[i].bulk = true; g_cnt[2] += 1; }
+      continue;
+    }
+    Cand& cd = cands[i];
+    if (!cd.in_lim) { round_skip[i] = 1; continue; }
+    if (!cd.answered) continue;
+    cd.pose_hit = hpose[i] != 0;
+    const size_t s0 = (size_t)i * STRIDE;
+    cd.par_fh = hfh[s0] == 0x7fffffff ? -1 : hfh[s0];
+    cd.par_free = cd.par_fh < 0;
+    if (hovf[s0]) fixes.push_back({i, 0});
+    const int nnb = (int)cd.nbs.size();
+    for (int k = 0; k < nnb; ++k) {
+      Nb& nb = cd.nbs[k];
+      nb.fh = hfh[s0 + 1 + k] == 0x7fffffff ? -1 : hfh[s0 + 1 + k];
+      nb.free = nb.fh < 0;
       if (hovf[s0 + 1 + k]) fixes.push_back({i, 1 + k});
     }
   }
@@ -640,7 +695,7 @@ void Forest::round_begin() {
     std::vector<int> maybe;
     for (int i = 0; i < n; ++i) {
       Cand& cd = cands[i];
-      if (!cd.answered || cd.pose_hit || !cd.par_free) continue;
+      if (!cd.answered || cd.bulk || cd.pose_hit || !cd.par_free) continue;
       bool rejected = false;
       for (const Nb& nb : cd.nbs) {
         if (nb.id < 0) continue;
@@ -754,51 +809,9 @@ void Forest::round_begin() {
   }
 
   auto _t3 = Clock::now();
-  // ---- samples whose fate this rank can settle alone: rejected by their own collision checks, or by a STORE
-  // neighbour with no neighbour from this round anywhere in their list, and without side effect (no border
-  // entry, no goal test).  Only their reference-equivalent counters travel; the in-order replay skips them.
+  // ---- samples whose fate this rank settled alone (k_settle): only their reference-equivalent counters travel;
+  // the in-order replay skips them
   {
-    auto calls = [](int fh, int ns) -> uint64_t { return fh > 0 ? (uint64_t)fh : (uint64_t)ns; };
-    // (with a goal the replay may stop in the middle of the round, so every sample stays in it)
-    // On a single rank the replay sees every sample anyway, so the extra pass is skipped.
-    for (int i = 0; i < n && !cfg.has_goal && cfg.world > 1; ++i) {
-      Cand& cd = cands[i];
-      if (!cd.answered) continue;
-      uint64_t cc = 1, pf = 0, nq = 0;   // :246 env.Collide(newPoint)
-      bool settled = false;
-      if (cd.pose_hit) settled = true;
-      else {
-        pf += 1;
-        cc += calls(cd.par_fh, cd.par_ns);
-        if (!cd.par_free) settled = true;
-        else {
-          bool mates = false;
-          for (const Nb& nb : cd.nbs) mates |= nb.id < 0;
-          if (!mates) {
-            nq += (uint64_t)trees.size();
-            for (const Nb& nb : cd.nbs) {
-              if (nb.same_tree) {
-                pf += 1;
-                cc += calls(nb.fh, nb.ns);
-                if (nb.free) { settled = true; break; }      // :276-280
-              } else {
-                pf += 1;
-                cc += calls(nb.fh, nb.ns);
-                if (!nb.free) settled = true;                // :296-299 without a border entry
-                break;                                       // (a free edge records a border: replay)
-              }
-            }
-          }
-        }
-      }
-      if (settled) {
-        cd.bulk = true;
-        bulk_counts[0] += cc;
-        bulk_counts[1] += pf;
-        bulk_counts[2] += nq;
-        bulk_counts[3] += 1;
-      }
-    }
     for (int k = 0; k < 4; ++k) {
       records[2 + 2 * k] = (int32_t)(uint32_t)(bulk_counts[k] & 0xffffffffu);
       records[3 + 2 * k] = (int32_t)(uint32_t)(bulk_counts[k] >> 32);
@@ -920,12 +933,13 @@ void Forest::round_commit(const int32_t* all, const int32_t* counts, int world) 
   std::vector<int32_t> app_tree;
   uint64_t unrecorded = 0;
   for (int i = 0; i < n; ++i) {
-    Cand& cd = cands[i];
-    Slot& sl = slots[cd.slot];
     if (solved) {          // goal reached by an earlier slot of this round: the remaining slots are not run
       iter = iter0 + i;
       break;
     }
+    if (round_skip[i]) continue;                               // outside the limits (:246 !result) or settled by its owner
+    Cand& cd = cands[i];
+    Slot& sl = slots[cd.slot];
     const unsigned iteration = (unsigned)(iter0 + i + 1);
     if (!cd.in_lim) continue;                                  // :246 !result
     if (cd.bulk) continue;                                     // settled (rejected, no side effect) by its owner
@@ -964,13 +978,11 @@ void Forest::round_commit(const int32_t* all, const int32_t* counts, int world) 
         st.path_free_calls += 1;
         st.collide_calls += calls(nb.fh, nb.ns);
         if (nb.free) {                                         // :288-294
-          std::vector<Border>& bp = border(nb.tree, mine);
           int a = std::min(nb_node, expanded), b = std::max(nb_node, expanded);
-          bool found = false;
-          for (const Border& x : bp) if (x.n1 == a && x.n2 == b) { found = true; break; }
-          if (!found) {
+          // (two nodes belong to one tree pair only, so the pair itself identifies the list entry)
+          if (border_keys.insert(((uint64_t)(uint32_t)a << 32) | (uint32_t)b).second) {
             double d = nodes[nb_node].d_root + nodes[expanded].d_root + sffg::dist6(nodes[nb_node].pos, nodes[expanded].pos);
-            bp.push_back({a, b, d});
+            border(nb.tree, mine).push_back({a, b, d});
           }
         }
         reject = true;                                         // :296-299
@@ -1029,6 +1041,7 @@ void Forest::round_commit(const int32_t* all, const int32_t* counts, int world) 
     }
     if (solved) {                                              // :369-372
       double gd = sffg::dist6(cd.pos, cfg.goal);
+      border_keys.insert(((uint64_t)(uint32_t)std::min(id, goal_node) << 32) | (uint32_t)std::max(id, goal_node));
       border(num_roots - 1, mine).push_back({std::min(id, goal_node), std::max(id, goal_node), nodes[id].d_root + gd});
     }
     sl.failing = false;

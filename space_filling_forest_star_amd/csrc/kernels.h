@@ -68,7 +68,16 @@ struct EnvView {
   int n_levels;           // level 0 groups 64 triangles, level k groups 64 boxes of level k-1
   const double* level_box[SFFK_MAX_LEVELS];
   int level_count[SFFK_MAX_LEVELS];
+  // clearance bits (built once both meshes are known): bit = 1 when every point of the cell is farther from
+  // every triangle than the robot's bounding-sphere radius (plus slack), so a robot centred there cannot touch
+  // the environment.  The grid spans the environment box inflated by clear_thr; null = not built.
+  const uint32_t* clear_bits;
+  double clear_org[3];
+  double clear_inv;       // 1 / cell edge
+  int clear_n[3];
 };
+// thr = radius below which a cell centre blocks the cell (robot radius + half cell diagonal + slack)
+void launch_clear_build(hipStream_t s, const EnvView& env, double thr, uint32_t* bits, long long n_cells);
 
 struct RobotView {
   const double* tri;  // n_tri x 9, model frame
@@ -83,7 +92,7 @@ struct RobotView {
 struct RoundTemps {
   NodeStoreMut st;
   int32_t* cnt;    // n hit counters
-  int32_t* ctrl;   // 4 ints of the persistent edge kernel's cursor
+  int32_t* ctrl;   // 12 ints zeroed per round: 4 of the edge kernel's work list + 4 x u64 settle counters
   int n_perm;      // permanent nodes in the store
   int base;        // 4-aligned index of the first temporary (>= n_perm)
 };
@@ -138,6 +147,21 @@ struct ClassifyArgs {
   int32_t* ctrl;            // [1] next task slot of the persistent edge kernel
 };
 void launch_classify(hipStream_t s, const ClassifyArgs& a);
+struct SettleArgs {
+  int n, Tb, nbcap, stride, n_trees;
+  const uint8_t* in_lim;
+  const int32_t* rec_flags;
+  const int32_t* rec_nnb;
+  const int32_t* rec_nb;
+  const int32_t* rec_meta;
+  const int32_t* seg_ns;
+  const int32_t* first_hit;
+  const int32_t* seg_ovf;
+  const uint8_t* pose_hit;
+  uint8_t* code;                  // n
+  unsigned long long* bulk;       // 4 counters (zeroed by k_sample_steer with the ctrl words)
+};
+void launch_settle(hipStream_t s, const SettleArgs& a);
 void launch_seg_prepare(hipStream_t s, const double* a6, const double* b6, int n, int32_t* seg_ns, int32_t* first_hit,
                         int32_t* ovf);
 // ctrl = 4 zeroed ints ([1] scan cursor, [2] work items, [3] list overflow); list = 2 ints per work item

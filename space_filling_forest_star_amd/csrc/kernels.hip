@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void k_sample_steer(const uint64_t* __restrict
     // per-round housekeeping folded into this launch: hit counters, the work-list cursor, and NaN
     // placeholders for the store entries between the permanent nodes and the 4-aligned temporaries
     if (i < n) tmp.cnt[i] = 0;
-    if (i < 4) tmp.ctrl[i] = 0;
+    if (i < 12) tmp.ctrl[i] = 0;
     if (i < tmp.base - tmp.n_perm) {
       const float nanv = __int_as_float(0x7fc00000);
       const size_t o = (size_t)tmp.n_perm + i;
@@ -409,6 +409,58 @@ __device__ __forceinline__ bool tri_far(const double* T, const double* c, double
   return dd > lim * lim;
 }
 
+// Clearance bits: true when a robot whose bounding-sphere centre is c provably touches nothing (the exact
+// test would find a separating axis for every pair), so the traversal and the exact tests can be skipped.
+// Points outside the grid are farther than the build threshold from the environment's box.
+__device__ __forceinline__ bool surely_clear(const EnvView& env, const double* c) {
+  if (!env.clear_bits) return false;
+  const double fx = (c[0] - env.clear_org[0]) * env.clear_inv, fy = (c[1] - env.clear_org[1]) * env.clear_inv,
+               fz = (c[2] - env.clear_org[2]) * env.clear_inv;
+  if (!(fx == fx && fy == fy && fz == fz)) return false;
+  if (fx < 0 || fy < 0 || fz < 0 || fx >= env.clear_n[0] || fy >= env.clear_n[1] || fz >= env.clear_n[2]) return true;
+  const long long idx = ((long long)(int)fz * env.clear_n[1] + (int)fy) * env.clear_n[0] + (int)fx;
+  return (env.clear_bits[idx >> 5] >> (idx & 31)) & 1u;
+}
+
+__device__ __forceinline__ double box_dist2(const double* b, const double* c) {
+  double d2 = 0;
+  for (int a = 0; a < 3; ++a) {
+    double d = b[a] - c[a] > c[a] - b[3 + a] ? b[a] - c[a] : c[a] - b[3 + a];
+    d = d > 0 ? d : 0;
+    d2 += d * d;
+  }
+  return d2;
+}
+
+// one thread per cell: blocked as soon as one triangle comes within thr of the cell centre (group boxes
+// first, then the triangle boxes of a near group, then the conservative sphere / triangle test)
+__global__ __launch_bounds__(256) void k_clear_build(EnvView env, double thr, uint32_t* __restrict__ bits,
+                                                     long long n_cells) {
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int nx = env.clear_n[0], ny = env.clear_n[1];
+  const double h = 1.0 / env.clear_inv;
+  const long long iz = idx / ((long long)nx * ny), rem = idx - iz * (long long)nx * ny;
+  const long long iy = rem / nx, ix = rem - iy * nx;
+  const double c[3] = {env.clear_org[0] + ((double)ix + 0.5) * h, env.clear_org[1] + ((double)iy + 0.5) * h,
+                       env.clear_org[2] + ((double)iz + 0.5) * h};
+  const double lim2 = thr * thr * (1.0 + 1e-9);
+  bool blocked = idx >= n_cells;
+  const int n_groups = env.level_count[0];
+  for (int g = 0; g < n_groups && !blocked; ++g) {
+    if (box_dist2(env.level_box[0] + 6 * (size_t)g, c) > lim2) continue;
+    const int t1 = g * 64 + 64 < env.n_tri ? g * 64 + 64 : env.n_tri;
+    for (int t = g * 64; t < t1 && !blocked; ++t) {
+      if (box_dist2(env.tri_box + 6 * (size_t)t, c) > lim2) continue;
+      if (!tri_far(env.tri + 9 * (size_t)t, c, thr)) blocked = true;
+    }
+  }
+  const unsigned long long m = __ballot(!blocked);
+  if ((threadIdx.x & 63) == 0) {
+    bits[idx >> 5] = (uint32_t)m;
+    bits[(idx >> 5) + 1] = (uint32_t)(m >> 32);
+  }
+}
+
 // ------------------------------------------------------------------ pose kernel
 #define POSE_WAVES 4
 #define CAND_CAP 256
@@ -424,29 +476,30 @@ __global__ __launch_bounds__(64 * POSE_WAVES) void k_collide_poses(EnvView env, 
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   int32_t* stack = ibase + wave * STACK_CAP;
   int32_t* cand = ibase + POSE_WAVES * STACK_CAP + wave * CAND_CAP;
+  // which poses of this workgroup need the exact test at all (most do not: clearance bits)
+  const int pose = blockIdx.x * POSE_WAVES + wave;
+  bool need = false;
+  double p[6], R[9], c[3] = {0, 0, 0};
+  if (pose < n) {
+    const bool run = !live_flags || (live_flags[pose] & 3) == 1;   // else not owned / out of limits / host path
+    if (run && env.n_tri != 0) {                                     // (HasMap == false: src/environment.h:307-309)
+      for (int k = 0; k < 6; ++k) p[k] = pos6[6 * (size_t)pose + k];
+      if (p[3] == 0 && p[4] == 0 && p[5] == 0) {
+        R[0] = R[4] = R[8] = 1; R[1] = R[2] = R[3] = R[5] = R[6] = R[7] = 0;
+      } else {
+        rotation(p, R);
+      }
+      xform(R, p, rob.center, c);
+      need = !surely_clear(env, c);
+    }
+    if (!need && lane == 0) hit_out[pose] = 0;
+  }
+  if (!__syncthreads_or(need ? 1 : 0)) return;
   for (int i = threadIdx.x; i < rob.n_tri * 9; i += blockDim.x) rtri[i] = rob.tri[i];
   __syncthreads();
-
-  const int pose = blockIdx.x * POSE_WAVES + wave;
-  if (pose >= n) return;
-  if (live_flags && (live_flags[pose] & 3) != 1) {  // not owned / out of limits / host path
-    if (lane == 0) hit_out[pose] = 0;
-    return;
-  }
-  if (env.n_tri == 0) {  // HasMap == false (src/environment.h:307-309)
-    if (lane == 0) hit_out[pose] = 0;
-    return;
-  }
-  double p[6], R[9];
-  for (int k = 0; k < 6; ++k) p[k] = pos6[6 * (size_t)pose + k];
-  if (p[3] == 0 && p[4] == 0 && p[5] == 0) {
-    R[0] = R[4] = R[8] = 1; R[1] = R[2] = R[3] = R[5] = R[6] = R[7] = 0;
-  } else {
-    rotation(p, R);
-  }
+  if (!need) return;
   // conservative query box around the posed bounding sphere
-  double c[3], qlo[3], qhi[3];
-  xform(R, p, rob.center, c);
+  double qlo[3], qhi[3];
   double rr = rob.radius * (1 + 1e-9) + 1e-9 * (fabs(c[0]) + fabs(c[1]) + fabs(c[2]) + 1);
   for (int k = 0; k < 3; ++k) { qlo[k] = c[k] - rr; qhi[k] = c[k] + rr; }
 
@@ -503,17 +556,22 @@ __device__ void segment_chunk(const EnvView& env, const RobotView& rob, const do
   const int ns = edge_samples(parts);
   const int s0 = 1 + 64 * chunk;
   if (s0 > ns) return;
-  const int s1 = s0 + 63 < ns ? s0 + 63 : ns;
   const double dir[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
   const int idx = s0 + lane;
   const bool live = idx <= ns;
   double P[3] = {0, 0, 0};
   if (live) edge_sample_pos(a, dir, parts, idx, P);
-  // sample positions are monotone in the index per coordinate (monotone rounding), so the chunk's
-  // first and last sample bound all of them; + the un-rotated robot box bounds every posed vertex
+  const double C[3] = {P[0] + rob.center[0], P[1] + rob.center[1], P[2] + rob.center[2]};
+  // samples whose clearance bit is set need nothing; the others bound the chunk's broad-phase box
+  const bool need = live && !surely_clear(env, C);
+  const unsigned long long nm = __ballot(need);
+  if (!nm) return;
+  const int l0 = __ffsll((long long)nm) - 1, l1 = 63 - __clzll((long long)nm);
+  // sample positions are monotone in the index per coordinate (monotone rounding), so the first and the
+  // last sample that need a test bound all of them; + the un-rotated robot box bounds every posed vertex
   double F[3], L[3], qlo[3], qhi[3];
-  edge_sample_pos(a, dir, parts, s0, F);
-  edge_sample_pos(a, dir, parts, s1, L);
+  edge_sample_pos(a, dir, parts, s0 + l0, F);
+  edge_sample_pos(a, dir, parts, s0 + l1, L);
   for (int k = 0; k < 3; ++k) {
     double lo = F[k] < L[k] ? F[k] : L[k], hi = F[k] > L[k] ? F[k] : L[k];
     double slack = 1e-9 * (fabs(lo) + fabs(hi) + 1);
@@ -528,7 +586,6 @@ __device__ void segment_chunk(const EnvView& env, const RobotView& rob, const do
     return;
   }
   if (nc == 0) return;
-  const double C[3] = {P[0] + rob.center[0], P[1] + rob.center[1], P[2] + rob.center[2]};
   const double rr = rob.radius * (1 + 1e-9) + 1e-9 * (fabs(C[0]) + fabs(C[1]) + fabs(C[2]) + 1);
   // Narrow phase with compaction: (sample, robot triangle, candidate) triples that survive the cheap box
   // tests are queued in LDS and the expensive exact test runs on 64 queued triples at a time, so every
@@ -565,7 +622,7 @@ __device__ void segment_chunk(const EnvView& env, const RobotView& rob, const do
     const int t = cand[k];
     const double* bx = env.tri_box + 6 * (size_t)t;
     bool touch = false;
-    if (live && idx < minhit) {
+    if (need && idx < minhit) {
       touch = true;
       for (int ax = 0; ax < 3; ++ax) {
         // exact bounds of v + P over the robot vertices (monotone rounding of one add)
@@ -794,6 +851,65 @@ __global__ __launch_bounds__(256) void k_classify(ClassifyArgs A) {
   }
 }
 
+// Samples whose fate needs no in-order replay (src/forest.h:246-299): rejected by their own pose or parent-edge
+// check, or by a STORE neighbour when no sample of this round appears anywhere in their neighbour list, and
+// without side effect (no border entry).  code: 0 = replay on the host, 1 = settled, 2 = outside the limits.
+// The reference-equivalent counters of the settled samples are summed here: bulk[0] Collide calls,
+// [1] isPathFree calls, [2] radius queries, [3] settled samples.
+__global__ __launch_bounds__(256) void k_settle(SettleArgs A) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  unsigned long long cc = 0, pf = 0, nq = 0, ns_settled = 0;
+  if (i < A.n) {
+    int code = 0;
+    if (!A.in_lim[i]) code = 2;
+    else if ((A.rec_flags[i] & 3) == 1) {       // owned by this rank and fully answered on the device
+      auto calls = [](int fh, int ns) -> unsigned long long {
+        return fh != 0x7fffffff ? (unsigned long long)fh : (unsigned long long)ns;
+      };
+      const size_t s0 = (size_t)i * A.stride;
+      const int nnb = A.rec_nnb[i];
+      bool ovf = A.seg_ovf[s0] != 0;
+      for (int k = 0; k < nnb; ++k) ovf |= A.seg_ovf[s0 + 1 + k] != 0;
+      if (!ovf) {
+        unsigned long long c1 = 1, p1 = 0, q1 = 0;   // :246 env.Collide(newPoint)
+        bool settled = false;
+        if (A.pose_hit[i]) settled = true;
+        else {
+          p1 += 1;
+          c1 += calls(A.first_hit[s0], A.seg_ns[s0]);
+          if (A.first_hit[s0] != 0x7fffffff) settled = true;   // parent edge blocked
+          else {
+            bool mates = false;
+            for (int k = 0; k < nnb; ++k) mates |= A.rec_nb[(size_t)i * A.nbcap + k] >= A.Tb;
+            if (!mates) {
+              q1 += (unsigned long long)A.n_trees;
+              for (int k = 0; k < nnb; ++k) {
+                const bool fr = A.first_hit[s0 + 1 + k] == 0x7fffffff;
+                p1 += 1;
+                c1 += calls(A.first_hit[s0 + 1 + k], A.seg_ns[s0 + 1 + k]);
+                if (A.rec_meta[(size_t)i * A.nbcap + k] & 1) {
+                  if (fr) { settled = true; break; }            // :276-280 overcrowded
+                } else {
+                  if (!fr) settled = true;                      // :296-299 without a border entry
+                  break;                                        // (a free edge records a border: replay)
+                }
+              }
+            }
+          }
+        }
+        if (settled) { code = 1; cc = c1; pf = p1; nq = q1; ns_settled = 1; }
+      }
+    }
+    A.code[i] = (uint8_t)code;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    cc += __shfl_xor(cc, off); pf += __shfl_xor(pf, off); nq += __shfl_xor(nq, off); ns_settled += __shfl_xor(ns_settled, off);
+  }
+  if ((threadIdx.x & 63) == 0 && ns_settled) {
+    atomicAdd(A.bulk + 0, cc); atomicAdd(A.bulk + 1, pf); atomicAdd(A.bulk + 2, nq); atomicAdd(A.bulk + 3, ns_settled);
+  }
+}
+
 // ------------------------------------------------------------------ node store writes
 // Writes n positions into the SoA store at [base, base+n): the same double->float cast the
 // reference applies when it fills FLANN matrices (src/forest.h:258-260).  Inactive entries are
@@ -898,6 +1014,16 @@ void launch_collide_poses(hipStream_t s, const EnvView& env, const RobotView& ro
   size_t lds = collide_lds_bytes(rob.n_tri, POSE_WAVES);
   hipLaunchKernelGGL(k_collide_poses, dim3((n + POSE_WAVES - 1) / POSE_WAVES), dim3(64 * POSE_WAVES), lds, s, env,
                      rob, pos6, n, live_flags, hit);
+}
+
+void launch_clear_build(hipStream_t s, const EnvView& env, double thr, uint32_t* bits, long long n_cells) {
+  const long long blocks = (n_cells + 255) / 256;
+  hipLaunchKernelGGL(k_clear_build, dim3((unsigned)blocks), dim3(256), 0, s, env, thr, bits, n_cells);
+}
+
+void launch_settle(hipStream_t s, const SettleArgs& a) {
+  if (a.n <= 0) return;
+  hipLaunchKernelGGL(k_settle, dim3((a.n + 255) / 256), dim3(256), 0, s, a);
 }
 
 void launch_classify(hipStream_t s, const ClassifyArgs& a) {

@@ -144,3 +144,41 @@ def test_one_triangle_robot_and_wave_larger_than_frontier(S):
     assert fo.fingerprint() == fg.fingerprint() and fo.stats()["collide_calls"] == fg.stats()["collide_calls"]
     fg.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("mode", ["off", "coarse", "fine"])
+@pytest.mark.parametrize("name", ["dense3d", "building"])
+def test_clearance_bits_never_change_an_answer(S, monkeypatch, name, mode):
+    """The clearance grid only skips work: with it disabled, very coarse (a few thousand cells) or fine,
+    poses and edges that graze the surfaces must get the oracle's answers."""
+    if mode == "off":
+        monkeypatch.setenv("SFFGPU_NO_CLEARANCE", "1")
+    elif mode == "coarse":
+        monkeypatch.setenv("SFFGPU_CLEAR_CELLS", "4096")
+    sc = common.scenario(name)
+    ctx = S.Context(0)
+    ctx.upload_robot(sc["robot"])       # robot first: the grid is built when the second mesh arrives
+    ctx.upload_env(sc["env"])
+    w = O.World(sc["env"], sc["robot"], O.TRIG_PORTABLE)
+    rs = np.random.RandomState(31)
+    # bounding-sphere radius of the robot: poses from far inside the clear cells to touching
+    r = np.asarray(sc["robot"]).reshape(-1, 3)
+    rr = float(np.linalg.norm(r - (r.min(0) + r.max(0)) / 2, axis=1).max())
+    n = 1500
+    p = np.concatenate([common.poses_near_surface(sc["env"], n // 4, 5, k * rr, 6) for k in (0.6, 1.5, 6.0, 40.0)])
+    got = ctx.collide_poses(p)
+    want = np.array([w.collide(q) for q in p], dtype=np.uint8)
+    assert np.array_equal(got, want)
+    assert 0.02 < want.mean() < 0.98
+    a = p[: n // 2].copy()
+    b = a.copy()
+    d = rs.normal(0, 1, (len(a), 3))
+    b[:, :3] += d / np.linalg.norm(d, axis=1)[:, None] * sc["sampling_dist"] * rs.uniform(0.2, 2.0, (len(a), 1))
+    free, fh, ns = ctx.collide_segments(a, b)
+    for i in range(len(a)):
+        assert (free[i], fh[i], ns[i]) == w.path_free(a[i], b[i]), i
+    # far outside the environment's box: outside the grid
+    far = p[:50].copy()
+    far[:, :3] += 1e4
+    assert not ctx.collide_poses(far).any()
+    ctx.close()
