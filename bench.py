@@ -26,9 +26,9 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=480)   # 3 + 480 waves of 4096 slots: ~10 -> ~950k nodes of the 1M budget
+    ap.add_argument("--steps", type=int, default=255)   # 3 + 255 waves of 8192 slots: ~10 -> ~940k nodes of the 1M budget
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--wave", type=int, default=4096)
+    ap.add_argument("--wave", type=int, default=8192)
     ap.add_argument("--budget", type=int, default=1000000)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--force-dist", action="store_true", help="run the RCCL record exchange even with one rank")

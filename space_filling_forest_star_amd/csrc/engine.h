@@ -230,6 +230,7 @@ struct Forest {
     }
   };
   std::vector<Cand> cands;   // storage (only grows); the current round uses the first n_cands
+  std::vector<int> round_todo;       // the other candidates, ascending
   std::vector<uint8_t> round_skip;   // per candidate: 1 = the replay has nothing to do (outside the limits / settled by this rank)
   int n_cands = 0;
   std::vector<int32_t> records;  // this rank's answers of the pending round (int32 stream)

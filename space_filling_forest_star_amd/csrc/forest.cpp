@@ -24,6 +24,7 @@ namespace sff {
 #define HIPCHK(x) hip_check((x), #x)
 using Clock = std::chrono::steady_clock;
 static double g_sec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+static double g_wait[3] = {0, 0, 0};   // blocked on: early copy, final sync; [2] = second read pass
 static uint64_t g_cnt[4] = {0, 0, 0, 0};   // candidates, skipped by the replay, settled on the device, accepted
 static const bool g_prof = getenv("SFFGPU_PROFILE") != nullptr;
 struct Sec {
@@ -34,6 +35,7 @@ struct Sec {
 };
 void forest_profile_dump() {
   if (g_prof) fprintf(stderr, "[sffgpu candidates] %llu skipped %llu settled %llu\n", (unsigned long long)g_cnt[0], (unsigned long long)g_cnt[1], (unsigned long long)g_cnt[2]);
+  if (g_prof) fprintf(stderr, "[sffgpu waits ms] early copy %.1f final sync %.1f | read pass 2 %.1f\n", g_wait[0], g_wait[1], g_wait[2]);
   if (g_prof) fprintf(stderr, "[sffgpu host ms] prep %.1f launch %.1f read %.1f records %.1f deser %.1f replay %.1f append %.1f endwave %.1f\n", g_sec[0], g_sec[1], g_sec[2], g_sec[3], g_sec[4], g_sec[5], g_sec[6], g_sec[7]);
 }
 static double ms_since(Clock::time_point t0) {
@@ -368,16 +370,16 @@ void Forest::round_begin() {
   const uint8_t* d_force = reinterpret_cast<const uint8_t*>(c.r_in.as<char>() + in_force);
   // device output block in two D2H copies.  Early part (complete after k_classify, copied on a second stream
   // while the collision kernels run): pos | pdist | in_lim | records | edge sample counts.  Late part: edge
-  // first hits | edge overflow flags | ctrl (4 ints + 4 u64 settle counters) | pose answers | settle codes.
+  // first hits (0 = redo on the host path) | ctrl (4 ints + 4 u64 settle counters) | pose answers | settle codes.
   // records: flags (n) | nnb (n) | nb ids (n*NBCAP) | nb meta (n*NBCAP)
   const size_t rec_ints = (size_t)n * (2 + 2 * NBCAP);
   const size_t o_pos = 0, o_pd = o_pos + (size_t)n * 48, o_lim = o_pd + (size_t)n * 8,
                o_rec = o_lim + ((size_t)n + 15) / 16 * 16, o_ns = o_rec + rec_ints * 4,
-               o_fh = o_ns + (size_t)n * STRIDE * 4, o_ovf = o_fh + (size_t)n * STRIDE * 4,
-               o_ctrl = o_ovf + (size_t)n * STRIDE * 4, o_pose = o_ctrl + 48, o_code = o_pose + (size_t)n,
-               o_bytes = o_code + (size_t)n;
+               o_fh = o_ns + (size_t)n * STRIDE * 4, o_ctrl = o_fh + (size_t)n * STRIDE * 4, o_pose = o_ctrl + 48,
+               o_code = o_pose + (size_t)n, o_bytes = (o_code + (size_t)n + 15) / 16 * 16,
+               o_ovf = o_bytes;   // (device-only scratch behind the copied block)
   const size_t early_bytes = o_fh;
-  c.r_out.ensure(o_bytes);
+  c.r_out.ensure(o_ovf + (size_t)n * STRIDE * 4);
   char* dout = c.r_out.as<char>();
   double* d_pos = reinterpret_cast<double*>(dout + o_pos);
   double* d_pd = reinterpret_cast<double*>(dout + o_pd);
@@ -468,7 +470,7 @@ void Forest::round_begin() {
     sffk::SettleArgs sa{};
     sa.n = n; sa.Tb = Tb; sa.nbcap = NBCAP; sa.stride = STRIDE; sa.n_trees = (int)trees.size();
     sa.in_lim = d_lim; sa.rec_flags = ca.rec_flags; sa.rec_nnb = ca.rec_nnb; sa.rec_nb = ca.rec_nb;
-    sa.rec_meta = ca.rec_meta; sa.seg_ns = ca.seg_ns; sa.first_hit = ca.first_hit; sa.seg_ovf = ca.seg_ovf;
+    sa.rec_meta = ca.rec_meta; sa.seg_ns = ca.seg_ns; sa.first_hit = ca.first_hit;
     sa.pose_hit = d_pose;
     sa.code = reinterpret_cast<uint8_t*>(dout + o_code);
     sa.bulk = reinterpret_cast<unsigned long long*>(dout + o_ctrl + 16);
@@ -487,7 +489,6 @@ void Forest::round_begin() {
   const int32_t* hmeta = hnb + (size_t)n * NBCAP;
   const int32_t* hns = reinterpret_cast<const int32_t*>(ho + o_ns);
   const int32_t* hfh = reinterpret_cast<const int32_t*>(ho + o_fh);
-  const int32_t* hovf = reinterpret_cast<const int32_t*>(ho + o_ovf);
   const uint8_t* hlim = reinterpret_cast<const uint8_t*>(ho + o_lim);
   const uint8_t* hpose = reinterpret_cast<const uint8_t*>(ho + o_pose);
   const uint8_t* hcode = reinterpret_cast<const uint8_t*>(ho + o_code);
@@ -500,7 +501,7 @@ void Forest::round_begin() {
   std::vector<double> fix_a, fix_b;
   struct Fix { int cand; int slot; };
   std::vector<Fix> fixes;       // single edges to redo (triangle candidate list overflow)
-  HIPCHK(hipEventSynchronize(c.ev_early));
+  { auto tw = Clock::now(); HIPCHK(hipEventSynchronize(c.ev_early)); g_wait[0] += ms_since(tw); }
   auto _t2 = Clock::now();
   for (int i = 0; i < n; ++i) {
     Cand& cd = cands[i];
@@ -531,38 +532,49 @@ void Forest::round_begin() {
     st.samples_executed += samples;
   }
   g_sec[2] += ms_since(_t2);
-  timed_sync();
+  { auto tw = Clock::now(); timed_sync(); g_wait[1] += ms_since(tw); }
   _t2 = Clock::now();
   if (settle_on_device) {
     const uint64_t* hb = reinterpret_cast<const uint64_t*>(ho + o_ctrl + 16);
     for (int k = 0; k < 4; ++k) bulk_counts[k] += hb[k];
   }
+  // the replay's work list: samples inside the limits that were not settled on the device
   round_skip.assign((size_t)n, 0);
+  round_todo.clear();
   g_cnt[0] += (uint64_t)n;
   for (int i = 0; i < n; ++i) {
-    if (settle_on_device && hcode[i]) {      // settled on the device (1) or outside the limits (2)
+    if (settle_on_device ? hcode[i] != 0 : hlim[i] == 0) {   // settled (1) / outside the limits (2)
       round_skip[i] = 1;
       g_cnt[1] += 1;
-      if (hcode[i] == 1) { cands[i].bulk = true; g_cnt[2] += 1; }
-      continue;
+      if (settle_on_device && hcode[i] == 1) g_cnt[2] += 1;
+    } else {
+      round_todo.push_back(i);
     }
+  }
+  const size_t n_todo = round_todo.size();
+  for (size_t j = 0; j < n_todo; ++j) {
+    if (j + 8 < n_todo) {
+      __builtin_prefetch(hfh + (size_t)round_todo[j + 8] * STRIDE);
+      __builtin_prefetch(&cands[round_todo[j + 8]].answered);
+    }
+    const int i = round_todo[j];
     Cand& cd = cands[i];
-    if (!cd.in_lim) { round_skip[i] = 1; continue; }
     if (!cd.answered) continue;
     cd.pose_hit = hpose[i] != 0;
     const size_t s0 = (size_t)i * STRIDE;
     cd.par_fh = hfh[s0] == 0x7fffffff ? -1 : hfh[s0];
     cd.par_free = cd.par_fh < 0;
-    if (hovf[s0]) fixes.push_back({i, 0});
+    if (hfh[s0] == 0) fixes.push_back({i, 0});
     const int nnb = (int)cd.nbs.size();
     for (int k = 0; k < nnb; ++k) {
       Nb& nb = cd.nbs[k];
       nb.fh = hfh[s0 + 1 + k] == 0x7fffffff ? -1 : hfh[s0 + 1 + k];
       nb.free = nb.fh < 0;
-      if (hovf[s0 + 1 + k]) fixes.push_back({i, 1 + k});
+      if (hfh[s0 + 1 + k] == 0) fixes.push_back({i, 1 + k});
     }
   }
   g_sec[2] += ms_since(_t2);
+  g_wait[2] += ms_since(_t2);
   if (!fixes.empty()) {
     auto t0 = Clock::now();
     for (const Fix& f : fixes) {
@@ -695,7 +707,7 @@ void Forest::round_begin() {
     std::vector<int> maybe;
     for (int i = 0; i < n; ++i) {
       Cand& cd = cands[i];
-      if (!cd.answered || cd.bulk || cd.pose_hit || !cd.par_free) continue;
+      if (round_skip[i] || !cd.answered || cd.pose_hit || !cd.par_free) continue;
       bool rejected = false;
       for (const Nb& nb : cd.nbs) {
         if (nb.id < 0) continue;
@@ -820,8 +832,9 @@ void Forest::round_begin() {
 
   // ---- the int32 record stream of the owned candidates (only needed when there are other ranks)
   for (int i = 0; i < n && cfg.world > 1; ++i) {
+    if (round_skip[i]) continue;
     Cand& cd = cands[i];
-    if (!cd.answered || cd.bulk) continue;
+    if (!cd.answered) continue;
     records.push_back(i);
     records.push_back((cd.pose_hit ? 1 : 0) | (cd.par_free ? 2 : 0));
     records.push_back(cd.par_fh);
@@ -932,17 +945,18 @@ void Forest::round_commit(const int32_t* all, const int32_t* counts, int world) 
   std::vector<double> app_pos;
   std::vector<int32_t> app_tree;
   uint64_t unrecorded = 0;
-  for (int i = 0; i < n; ++i) {
-    if (solved) {          // goal reached by an earlier slot of this round: the remaining slots are not run
-      iter = iter0 + i;
-      break;
-    }
-    if (round_skip[i]) continue;                               // outside the limits (:246 !result) or settled by its owner
+  // (samples outside the limits (:246 !result) and the ones settled by their owner are not on the work list)
+  const size_t n_todo = round_todo.size();
+  int last_i = -1;
+  for (size_t j = 0; j < n_todo; ++j) {
+    if (solved) break;     // goal reached by an earlier slot of this round: the remaining slots are not run
+    if (j + 12 < n_todo) __builtin_prefetch(&cands[round_todo[j + 12]]);
+    if (j + 6 < n_todo) __builtin_prefetch(&nodes[cands[round_todo[j + 6]].expanded].tree);
+    const int i = round_todo[j];
+    last_i = i;
     Cand& cd = cands[i];
     Slot& sl = slots[cd.slot];
     const unsigned iteration = (unsigned)(iter0 + i + 1);
-    if (!cd.in_lim) continue;                                  // :246 !result
-    if (cd.bulk) continue;                                     // settled (rejected, no side effect) by its owner
     if (!cd.answered) {                                        // another rank's sample without a record: settled there
       if (world > 1 && i % world != cfg.rank) { ++unrecorded; continue; }
       throw HipError{"forest: a candidate has no answer record"};
@@ -1048,6 +1062,7 @@ void Forest::round_commit(const int32_t* all, const int32_t* counts, int world) 
     app_pos.insert(app_pos.end(), cd.pos, cd.pos + 6);
     app_tree.push_back(mine);
   }
+  if (solved) iter = iter0 + last_i + 1;   // the iterations after the solving one were never run
   g_sec[5] += ms_since(_t5);
   auto _t6 = Clock::now();
   if (!solved && unrecorded != settled_elsewhere)   // (a goal hit stops the replay early: counts then differ legitimately)

@@ -156,7 +156,6 @@ struct SettleArgs {
   const int32_t* rec_meta;
   const int32_t* seg_ns;
   const int32_t* first_hit;
-  const int32_t* seg_ovf;
   const uint8_t* pose_hit;
   uint8_t* code;                  // n
   unsigned long long* bulk;       // 4 counters (zeroed by k_sample_steer with the ctrl words)

@@ -582,7 +582,10 @@ __device__ void segment_chunk(const EnvView& env, const RobotView& rob, const do
   bool overflow;
   int nc = collect_candidates(env, qlo, qhi, lane, st, cand, CAND_CAP, &overflow);
   if (overflow) {
-    if (lane == 0) atomicOr(overflow_flag + seg, 1);  // host re-runs this edge through the pose kernel
+    if (lane == 0) {   // host re-runs this edge through the pose kernel; first_hit 0 (no sample has index 0) also says so
+      atomicOr(overflow_flag + seg, 1);
+      atomicMin(first_hit + seg, 0);
+    }
     return;
   }
   if (nc == 0) return;
@@ -868,8 +871,8 @@ __global__ __launch_bounds__(256) void k_settle(SettleArgs A) {
       };
       const size_t s0 = (size_t)i * A.stride;
       const int nnb = A.rec_nnb[i];
-      bool ovf = A.seg_ovf[s0] != 0;
-      for (int k = 0; k < nnb; ++k) ovf |= A.seg_ovf[s0 + 1 + k] != 0;
+      bool ovf = A.first_hit[s0] == 0;            // 0 = the edge's triangle candidate list ran over
+      for (int k = 0; k < nnb; ++k) ovf |= A.first_hit[s0 + 1 + k] == 0;
       if (!ovf) {
         unsigned long long c1 = 1, p1 = 0, q1 = 0;   // :246 env.Collide(newPoint)
         bool settled = false;
