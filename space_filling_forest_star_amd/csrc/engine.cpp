@@ -158,7 +158,7 @@ Ctx::~Ctx() {
   for (auto e : pool) (void)hipEventDestroy(e);
   DevBuf* bufs[] = {&env_tri, &env_box, &env_plane, &rob_tri, &sx, &sy, &sz, &syaw, &spitch, &sroll, &stree, &spos,
                     &d_a, &d_b, &d_c, &d_d, &d_e, &d_f, &d_g, &d_h, &r_in, &r_out, &r_q, &r_cnt, &r_hidx,
-                    &r_hdist, &r_sega, &r_segb, &r_items, &env_clear, &g_cnt, &g_items, &g_ovfcnt, &g_ovf};
+                    &r_hdist, &r_sega, &r_segb, &r_items, &r_items2, &r_poselist, &env_clear, &g_cnt, &g_items, &g_ovfcnt, &g_ovf};
   for (DevBuf* b : bufs) b->release();
   for (auto& b : level_box) b.release();
   PinBuf* pins[] = {&h_a, &h_b, &h_c, &h_d, &h_e, &h_f, &h_g, &h_h, &p_in, &p_out};
@@ -531,25 +531,26 @@ void Ctx::collide_segments(const double* a6, const double* b6, int n, uint8_t* i
   // sample counts (src/problemStruct.h:155-156) and result presets are computed on the device, then the slot
   // table is compacted into (edge, chunk) work items for the persistent edge kernel
   const size_t pb = (size_t)n * 6 * sizeof(double);
-  h_a.ensure(pb); h_b.ensure(pb); h_c.ensure((size_t)n * 12 + 16);
+  h_a.ensure(pb); h_b.ensure(pb); h_c.ensure((size_t)n * 12 + 64);
   memcpy(h_a.p, a6, pb);
   memcpy(h_b.p, b6, pb);
   std::vector<int32_t> ns(n, 0), fh(n, -1);
   std::vector<uint8_t> ovf(n, 0);
-  d_a.ensure(pb); d_b.ensure(pb); d_c.ensure((size_t)n * 12 + 16);
+  d_a.ensure(pb); d_b.ensure(pb); d_c.ensure((size_t)n * 12 + 64);
   int32_t* d_ns = d_c.as<int32_t>();
   int32_t* d_fh = d_ns + n;
   int32_t* d_ov = d_fh + n;
   int32_t* d_ctrl = d_ov + n;
   HIPCHK(hipMemcpyAsync(d_a.p, h_a.p, pb, hipMemcpyHostToDevice, stream));
   HIPCHK(hipMemcpyAsync(d_b.p, h_b.p, pb, hipMemcpyHostToDevice, stream));
-  HIPCHK(hipMemsetAsync(d_ctrl, 0, 16, stream));
+  HIPCHK(hipMemsetAsync(d_ctrl, 0, 64, stream));
   const int list_cap = 8 * n + 65536;
   r_items.ensure((size_t)list_cap * 8);
+  r_items2.ensure((size_t)list_cap * 16);
   time_begin(T_COLLIDE);
   sffk::launch_seg_prepare(stream, d_a.as<double>(), d_b.as<double>(), n, d_ns, d_fh, d_ov);
   sffk::launch_collide_segments_dyn(stream, envv, robv, d_a.as<double>(), d_b.as<double>(), d_ns, n, d_ctrl,
-                                    r_items.as<int32_t>(), list_cap, d_fh, d_ov);
+                                    r_items.as<int32_t>(), list_cap, r_items2.as<int32_t>(), d_fh, d_ov);
   time_end();
   HIPCHK(hipMemcpyAsync(h_c.p, d_c.p, (size_t)n * 12, hipMemcpyDeviceToHost, stream));
   sync();

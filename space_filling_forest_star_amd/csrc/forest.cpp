@@ -370,12 +370,12 @@ void Forest::round_begin() {
   const uint8_t* d_force = reinterpret_cast<const uint8_t*>(c.r_in.as<char>() + in_force);
   // device output block in two D2H copies.  Early part (complete after k_classify, copied on a second stream
   // while the collision kernels run): pos | pdist | in_lim | records | edge sample counts.  Late part: edge
-  // first hits (0 = redo on the host path) | ctrl (4 ints + 4 u64 settle counters) | pose answers | settle codes.
+  // first hits (0 = redo on the host path) | ctrl (16 ints incl. the 4 u64 settle counters) | pose answers | settle codes.
   // records: flags (n) | nnb (n) | nb ids (n*NBCAP) | nb meta (n*NBCAP)
   const size_t rec_ints = (size_t)n * (2 + 2 * NBCAP);
   const size_t o_pos = 0, o_pd = o_pos + (size_t)n * 48, o_lim = o_pd + (size_t)n * 8,
                o_rec = o_lim + ((size_t)n + 15) / 16 * 16, o_ns = o_rec + rec_ints * 4,
-               o_fh = o_ns + (size_t)n * STRIDE * 4, o_ctrl = o_fh + (size_t)n * STRIDE * 4, o_pose = o_ctrl + 48,
+               o_fh = o_ns + (size_t)n * STRIDE * 4, o_ctrl = o_fh + (size_t)n * STRIDE * 4, o_pose = o_ctrl + 64,
                o_code = o_pose + (size_t)n, o_bytes = (o_code + (size_t)n + 15) / 16 * 16,
                o_ovf = o_bytes;   // (device-only scratch behind the copied block)
   const size_t early_bytes = o_fh;
@@ -457,11 +457,14 @@ void Forest::round_begin() {
   HIPCHK(hipStreamWaitEvent(c.copy_stream, c.ev_mid, 0));
   HIPCHK(hipMemcpyAsync(ho, dout, early_bytes, hipMemcpyDeviceToHost, c.copy_stream));
   HIPCHK(hipEventRecord(c.ev_early, c.copy_stream));
-  sffk::launch_collide_poses(c.stream, c.envv, c.robv, d_pos, n, ca.rec_flags, d_pose);
+  // poses and edges together: work-list compaction -> clearance cull -> exact kernel
   const int list_cap = 4 * n * STRIDE + 65536;
   c.r_items.ensure((size_t)list_cap * 8);
-  sffk::launch_collide_segments_dyn(c.stream, c.envv, c.robv, ca.seg_a, ca.seg_b, ca.seg_ns, n * STRIDE, ca.ctrl,
-                                    c.r_items.as<int32_t>(), list_cap, ca.first_hit, ca.seg_ovf);
+  c.r_items2.ensure((size_t)list_cap * 16);
+  c.r_poselist.ensure((size_t)n * 4);
+  sffk::launch_round_collide(c.stream, c.envv, c.robv, d_pos, n, ca.rec_flags, d_pose, c.r_poselist.as<int32_t>(),
+                             ca.seg_a, ca.seg_b, ca.seg_ns, n * STRIDE, ca.ctrl, c.r_items.as<int32_t>(), list_cap,
+                             c.r_items2.as<int32_t>(), ca.first_hit, ca.seg_ovf);
   c.time_end();
   // samples this rank can settle alone need no replay (with a goal the replay may stop in the middle of the
   // round, so there every sample stays in it)

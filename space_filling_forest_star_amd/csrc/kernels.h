@@ -92,7 +92,7 @@ struct RobotView {
 struct RoundTemps {
   NodeStoreMut st;
   int32_t* cnt;    // n hit counters
-  int32_t* ctrl;   // 12 ints zeroed per round: 4 of the edge kernel's work list + 4 x u64 settle counters
+  int32_t* ctrl;   // 16 ints zeroed per round (see launch_collide_segments_dyn)
   int n_perm;      // permanent nodes in the store
   int base;        // 4-aligned index of the first temporary (>= n_perm)
 };
@@ -163,10 +163,19 @@ struct SettleArgs {
 void launch_settle(hipStream_t s, const SettleArgs& a);
 void launch_seg_prepare(hipStream_t s, const double* a6, const double* b6, int n, int32_t* seg_ns, int32_t* first_hit,
                         int32_t* ovf);
-// ctrl = 4 zeroed ints ([1] scan cursor, [2] work items, [3] list overflow); list = 2 ints per work item
-// (slot, chunk), list_cap items.  An overflowing list only costs speed (the kernel scans the slot table).
+// ctrl = 16 zeroed ints: [1] scan cursor, [2] work items, [3] list overflow, [4..11] settle counters,
+// [12] culled work items, [13] culled poses.  list = 2 ints per (slot, chunk) work item, list_cap items;
+// list2 = 4 ints per item that survives the clearance cull (same capacity).  An overflowing list only costs
+// speed (the exact kernel then scans the slot table).
 void launch_collide_segments_dyn(hipStream_t s, const EnvView& env, const RobotView& rob, const double* a6,
                                  const double* b6, const int32_t* seg_ns, int n_slots, int32_t* ctrl,
-                                 int32_t* list, int list_cap, int32_t* first_hit, int32_t* overflow_flag);
+                                 int32_t* list, int list_cap, int32_t* list2, int32_t* first_hit,
+                                 int32_t* overflow_flag);
+// a forest round: the same pipeline, and the round's poses (pose_list: n_pose ints of scratch) go through the
+// cull and the exact kernel with the edges
+void launch_round_collide(hipStream_t s, const EnvView& env, const RobotView& rob, const double* pos6, int n_pose,
+                          const int32_t* live_flags, uint8_t* pose_hit, int32_t* pose_list, const double* a6,
+                          const double* b6, const int32_t* seg_ns, int n_slots, int32_t* ctrl, int32_t* list,
+                          int list_cap, int32_t* list2, int32_t* first_hit, int32_t* overflow_flag);
 
 }  // namespace sffk

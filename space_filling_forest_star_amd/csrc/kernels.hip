@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void k_sample_steer(const uint64_t* __restrict
     // per-round housekeeping folded into this launch: hit counters, the work-list cursor, and NaN
     // placeholders for the store entries between the permanent nodes and the 4-aligned temporaries
     if (i < n) tmp.cnt[i] = 0;
-    if (i < 12) tmp.ctrl[i] = 0;
+    if (i < 16) tmp.ctrl[i] = 0;
     if (i < tmp.base - tmp.n_perm) {
       const float nanv = __int_as_float(0x7fc00000);
       const size_t o = (size_t)tmp.n_perm + i;
@@ -465,39 +465,20 @@ __global__ __launch_bounds__(256) void k_clear_build(EnvView env, double thr, ui
 #define POSE_WAVES 4
 #define CAND_CAP 256
 
-__global__ __launch_bounds__(64 * POSE_WAVES) void k_collide_poses(EnvView env, RobotView rob,
-                                                                   const double* __restrict__ pos6, int n,
-                                                                   const int32_t* __restrict__ live_flags,
-                                                                   uint8_t* __restrict__ hit_out) {
-  extern __shared__ double lds_d[];
-  // layout: robot triangles (n_tri*9 doubles) | per-wave stacks | per-wave candidate lists
-  double* rtri = lds_d;
-  int32_t* ibase = reinterpret_cast<int32_t*>(rtri + (size_t)rob.n_tri * 9);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  int32_t* stack = ibase + wave * STACK_CAP;
-  int32_t* cand = ibase + POSE_WAVES * STACK_CAP + wave * CAND_CAP;
-  // which poses of this workgroup need the exact test at all (most do not: clearance bits)
-  const int pose = blockIdx.x * POSE_WAVES + wave;
-  bool need = false;
-  double p[6], R[9], c[3] = {0, 0, 0};
-  if (pose < n) {
-    const bool run = !live_flags || (live_flags[pose] & 3) == 1;   // else not owned / out of limits / host path
-    if (run && env.n_tri != 0) {                                     // (HasMap == false: src/environment.h:307-309)
-      for (int k = 0; k < 6; ++k) p[k] = pos6[6 * (size_t)pose + k];
-      if (p[3] == 0 && p[4] == 0 && p[5] == 0) {
-        R[0] = R[4] = R[8] = 1; R[1] = R[2] = R[3] = R[5] = R[6] = R[7] = 0;
-      } else {
-        rotation(p, R);
-      }
-      xform(R, p, rob.center, c);
-      need = !surely_clear(env, c);
-    }
-    if (!need && lane == 0) hit_out[pose] = 0;
+__device__ __forceinline__ void pose_frame(const RobotView& rob, const double* __restrict__ pos6, int pose, double* p,
+                                           double* R, double* c) {
+  for (int k = 0; k < 6; ++k) p[k] = pos6[6 * (size_t)pose + k];
+  if (p[3] == 0 && p[4] == 0 && p[5] == 0) {
+    R[0] = R[4] = R[8] = 1; R[1] = R[2] = R[3] = R[5] = R[6] = R[7] = 0;
+  } else {
+    rotation(p, R);
   }
-  if (!__syncthreads_or(need ? 1 : 0)) return;
-  for (int i = threadIdx.x; i < rob.n_tri * 9; i += blockDim.x) rtri[i] = rob.tri[i];
-  __syncthreads();
-  if (!need) return;
+  xform(R, p, rob.center, c);
+}
+
+// exact test of one posed robot (pose p, rotation R, bounding-sphere centre c) by one wavefront
+__device__ bool pose_exact(const EnvView& env, const RobotView& rob, const double* rtri, int32_t* stack, int32_t* cand,
+                           const double* p, const double* R, const double* c, int lane) {
   // conservative query box around the posed bounding sphere
   double qlo[3], qhi[3];
   double rr = rob.radius * (1 + 1e-9) + 1e-9 * (fabs(c[0]) + fabs(c[1]) + fabs(c[2]) + 1);
@@ -537,6 +518,43 @@ __global__ __launch_bounds__(64 * POSE_WAVES) void k_collide_poses(EnvView env, 
       hit = __any(lane_hit);
     }
   }
+  return hit;
+}
+
+__global__ __launch_bounds__(64 * POSE_WAVES) void k_collide_poses(EnvView env, RobotView rob,
+                                                                   const double* __restrict__ pos6, int n,
+                                                                   const int32_t* __restrict__ live_flags,
+                                                                   uint8_t* __restrict__ hit_out) {
+  extern __shared__ double lds_d[];
+  // layout: robot triangles (n_tri*9 doubles) | per-wave stacks | per-wave candidate lists
+  double* rtri = lds_d;
+  int32_t* ibase = reinterpret_cast<int32_t*>(rtri + (size_t)rob.n_tri * 9);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  int32_t* stack = ibase + wave * STACK_CAP;
+  int32_t* cand = ibase + POSE_WAVES * STACK_CAP + wave * CAND_CAP;
+  // which poses of this workgroup need the exact test at all (most do not: clearance bits)
+  const int pose = blockIdx.x * POSE_WAVES + wave;
+  bool need = false;
+  double p[6], R[9], c[3] = {0, 0, 0};
+  if (pose < n) {
+    const bool run = !live_flags || (live_flags[pose] & 3) == 1;   // else not owned / out of limits / host path
+    if (run && env.n_tri != 0) {                                     // (HasMap == false: src/environment.h:307-309)
+      for (int k = 0; k < 6; ++k) p[k] = pos6[6 * (size_t)pose + k];
+      if (p[3] == 0 && p[4] == 0 && p[5] == 0) {
+        R[0] = R[4] = R[8] = 1; R[1] = R[2] = R[3] = R[5] = R[6] = R[7] = 0;
+      } else {
+        rotation(p, R);
+      }
+      xform(R, p, rob.center, c);
+      need = !surely_clear(env, c);
+    }
+    if (!need && lane == 0) hit_out[pose] = 0;
+  }
+  if (!__syncthreads_or(need ? 1 : 0)) return;
+  for (int i = threadIdx.x; i < rob.n_tri * 9; i += blockDim.x) rtri[i] = rob.tri[i];
+  __syncthreads();
+  if (!need) return;
+  const bool hit = pose_exact(env, rob, rtri, stack, cand, p, R, c, lane);
   if (lane == 0) hit_out[pose] = hit ? 1 : 0;
 }
 
@@ -544,14 +562,33 @@ __global__ __launch_bounds__(64 * POSE_WAVES) void k_collide_poses(EnvView env, 
 #define SEG_WAVES 4
 #define QUEUE_CAP 128
 
+#ifdef SFFK_DEBUG_COUNTERS
+__device__ unsigned long long g_dbg[16];
+struct DbgAcc { unsigned long long v[12]; };
+#define DBG_DECL DbgAcc dbg_acc = {{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
+#define DBG_ARG , DbgAcc& dbg_acc
+#define DBG_PASS , dbg_acc
+#define DBG_T() wall_clock64()
+#define DBG_ADD(i, x) dbg_acc.v[i] += (unsigned long long)(x)
+#define DBG_FLUSH() do { if (lane == 0) for (int q_ = 0; q_ < 12; ++q_) if (dbg_acc.v[q_]) atomicAdd(&g_dbg[q_], dbg_acc.v[q_]); } while (0)
+#else
+#define DBG_DECL
+#define DBG_ARG
+#define DBG_PASS
+#define DBG_T() 0ULL
+#define DBG_ADD(i, x) do { } while (0)
+#define DBG_FLUSH() do { } while (0)
+#endif
+
 // One wavefront per (edge, chunk of 64 consecutive samples): lane = sample.  The chunk's own swept
 // box gives a tight broad phase; the smallest colliding sample index of an edge is reduced with
 // atomicMin, so the answer does not depend on which chunk finishes first.
 __device__ void segment_chunk(const EnvView& env, const RobotView& rob, const double* rtri, int32_t* stack,
-                              int32_t* cand, int32_t* queue, const double* __restrict__ a6, const double* __restrict__ b6, int seg,
-                              int chunk, int32_t* __restrict__ first_hit, int32_t* __restrict__ overflow_flag, int lane) {
-  double a[6], b[6];
-  for (int k = 0; k < 6; ++k) { a[k] = a6[6 * (size_t)seg + k]; b[k] = b6[6 * (size_t)seg + k]; }
+                              int32_t* cand, int32_t* queue, const double* a, const double* b, int seg,
+                              int chunk, bool have_mask, unsigned long long mask, int32_t* __restrict__ first_hit,
+                              int32_t* __restrict__ overflow_flag, int lane DBG_ARG) {
+  [[maybe_unused]] const unsigned long long t0_ = DBG_T();
+  DBG_ADD(0, 1);
   const double parts = edge_parts(a, b);
   const int ns = edge_samples(parts);
   const int s0 = 1 + 64 * chunk;
@@ -563,9 +600,13 @@ __device__ void segment_chunk(const EnvView& env, const RobotView& rob, const do
   if (live) edge_sample_pos(a, dir, parts, idx, P);
   const double C[3] = {P[0] + rob.center[0], P[1] + rob.center[1], P[2] + rob.center[2]};
   // samples whose clearance bit is set need nothing; the others bound the chunk's broad-phase box
-  const bool need = live && !surely_clear(env, C);
+  // (the cull kernel already looked the bits up when it hands a mask over)
+  const bool need = have_mask ? ((mask >> lane) & 1ULL) != 0 : (live && !surely_clear(env, C));
   const unsigned long long nm = __ballot(need);
+  [[maybe_unused]] const unsigned long long t1_ = DBG_T();
+  DBG_ADD(4, t1_ - t0_);
   if (!nm) return;
+  DBG_ADD(1, 1);
   const int l0 = __ffsll((long long)nm) - 1, l1 = 63 - __clzll((long long)nm);
   // sample positions are monotone in the index per coordinate (monotone rounding), so the first and the
   // last sample that need a test bound all of them; + the un-rotated robot box bounds every posed vertex
@@ -581,6 +622,9 @@ __device__ void segment_chunk(const EnvView& env, const RobotView& rob, const do
   WaveStack st{stack, 0};
   bool overflow;
   int nc = collect_candidates(env, qlo, qhi, lane, st, cand, CAND_CAP, &overflow);
+  [[maybe_unused]] const unsigned long long t2_ = DBG_T();
+  DBG_ADD(5, t2_ - t1_);
+  DBG_ADD(7, nc);
   if (overflow) {
     if (lane == 0) {   // host re-runs this edge through the pose kernel; first_hit 0 (no sample has index 0) also says so
       atomicOr(overflow_flag + seg, 1);
@@ -589,6 +633,7 @@ __device__ void segment_chunk(const EnvView& env, const RobotView& rob, const do
     return;
   }
   if (nc == 0) return;
+  DBG_ADD(2, 1);
   const double rr = rob.radius * (1 + 1e-9) + 1e-9 * (fabs(C[0]) + fabs(C[1]) + fabs(C[2]) + 1);
   // Narrow phase with compaction: (sample, robot triangle, candidate) triples that survive the cheap box
   // tests are queued in LDS and the expensive exact test runs on 64 queued triples at a time, so every
@@ -596,6 +641,7 @@ __device__ void segment_chunk(const EnvView& env, const RobotView& rob, const do
   int qn = 0;
   int minhit = 0x7fffffff;
   auto flush = [&](int count) {
+    DBG_ADD(3, 1);
     int v = 0x7fffffff;
     if (lane < count) {
       const int e = queue[lane];
@@ -662,6 +708,7 @@ __device__ void segment_chunk(const EnvView& env, const RobotView& rob, const do
     }
   }
   while (qn > 0) flush(qn < 64 ? qn : 64);
+  DBG_ADD(6, DBG_T() - t2_);
   if (minhit != 0x7fffffff && lane == 0) atomicMin(first_hit + seg, minhit);
 }
 
@@ -703,14 +750,112 @@ __global__ __launch_bounds__(256) void k_seg_compact(const int32_t* __restrict__
     }
 }
 
-// Persistent wavefronts walk the work list with a fixed stride (no dequeue atomics); a chunk whose edge
-// already has a hit below its first sample is skipped (only the smallest index matters).
+// Lean, high-occupancy pass in front of the exact kernel: looks up the clearance bits of every pose (one thread
+// each, blocks [0, pose_blocks)) and of every sample of every (edge, chunk) item (one wavefront per item, the
+// other blocks) and keeps only what needs an exact test: pose_list (ctrl[13] entries) and list2 (ctrl[12] entries
+// of 4 ints: slot, chunk, 64-bit sample mask).  Everything else is answered here (pose_hit = 0; an edge whose
+// chunks are all dropped keeps its preset "free").  One atomic per workgroup.
+#define CULL_KEEP 48
+__global__ __launch_bounds__(256) void k_cull(EnvView env, RobotView rob, const double* __restrict__ pos6, int n_pose,
+                                              int pose_blocks, const int32_t* __restrict__ live_flags,
+                                              uint8_t* __restrict__ pose_hit, int32_t* __restrict__ pose_list,
+                                              const double* __restrict__ a6, const double* __restrict__ b6,
+                                              const int32_t* __restrict__ list, int32_t* __restrict__ list2,
+                                              int32_t* __restrict__ ctrl) {
+  __shared__ int wcnt[4];
+  __shared__ int base_s;
+  __shared__ int32_t keep[4][CULL_KEEP][4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if ((int)blockIdx.x < pose_blocks) {
+    const int pose = blockIdx.x * 256 + threadIdx.x;
+    bool need = false;
+    if (pose < n_pose) {
+      const bool run = !live_flags || (live_flags[pose] & 3) == 1;   // else not owned / out of limits / host path
+      if (run && env.n_tri != 0) {                                     // (HasMap == false: src/environment.h:307-309)
+        double p[6], R[9], c[3];
+        pose_frame(rob, pos6, pose, p, R, c);
+        need = !surely_clear(env, c);
+      }
+      if (!need) pose_hit[pose] = 0;
+    }
+    const unsigned long long m = __ballot(need);
+    if (lane == 0) wcnt[wave] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const int all = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+      base_s = all > 0 ? atomicAdd(ctrl + 13, all) : 0;
+    }
+    __syncthreads();
+    if (need) {
+      int at = base_s + __popcll(m & ((1ULL << lane) - 1ULL));
+      for (int w = 0; w < wave; ++w) at += wcnt[w];
+      pose_list[at] = pose;
+    }
+    return;
+  }
+  if (ctrl[3] || env.n_tri == 0) return;     // work list ran over: the exact kernel scans the slot table itself
+  const int M = ctrl[2];
+  const int cb = blockIdx.x - pose_blocks, nb = gridDim.x - pose_blocks;
+  const int W = nb * 4;
+  int kept = 0;   // wave-uniform
+  auto flush_wave = [&]() {   // this wave's buffer is full: write it out with its own atomic
+    int base = 0;
+    if (lane == 0) base = atomicAdd(ctrl + 12, kept);
+    base = __shfl(base, 0);
+    if (lane < kept)
+      for (int q = 0; q < 4; ++q) list2[4 * (size_t)(base + lane) + q] = keep[wave][lane][q];
+    kept = 0;
+  };
+  for (int e = cb + nb * wave; e < M; e += W) {
+    const int slot = list[2 * (size_t)e], chunk = list[2 * (size_t)e + 1];
+    double a[6], b[6];
+    for (int k = 0; k < 6; ++k) { a[k] = a6[6 * (size_t)slot + k]; b[k] = b6[6 * (size_t)slot + k]; }
+    const double parts = edge_parts(a, b);
+    const int ns = edge_samples(parts);
+    const int idx = 1 + 64 * chunk + lane;
+    bool need = false;
+    if (idx <= ns) {
+      const double dir[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
+      double P[3];
+      edge_sample_pos(a, dir, parts, idx, P);
+      const double C[3] = {P[0] + rob.center[0], P[1] + rob.center[1], P[2] + rob.center[2]};
+      need = !surely_clear(env, C);
+    }
+    const unsigned long long nm = __ballot(need);
+    if (nm) {
+      if (kept == CULL_KEEP) flush_wave();
+      if (lane == 0) {
+        keep[wave][kept][0] = slot; keep[wave][kept][1] = chunk;
+        keep[wave][kept][2] = (int32_t)(uint32_t)nm; keep[wave][kept][3] = (int32_t)(uint32_t)(nm >> 32);
+      }
+      kept += 1;
+    }
+  }
+  if (lane == 0) wcnt[wave] = kept;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int all = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+    base_s = all > 0 ? atomicAdd(ctrl + 12, all) : 0;
+  }
+  __syncthreads();
+  int at = base_s;
+  for (int w = 0; w < wave; ++w) at += wcnt[w];
+  if (lane < kept)
+    for (int q = 0; q < 4; ++q) list2[4 * (size_t)(at + lane) + q] = keep[wave][lane][q];
+}
+
+// Exact kernel: persistent wavefronts walk the culled lists with a fixed stride (no dequeue atomics): first the
+// poses that need an exact test, then the (edge, chunk) items.  A chunk whose edge already has a hit below its
+// first sample is skipped (only the smallest index matters).
 __global__ __launch_bounds__(64 * SEG_WAVES) void k_collide_segments_dyn(EnvView env, RobotView rob,
+                                                                         const double* __restrict__ pos6,
+                                                                         const int32_t* __restrict__ pose_list,
+                                                                         uint8_t* __restrict__ pose_hit,
                                                                          const double* __restrict__ a6,
                                                                          const double* __restrict__ b6,
                                                                          const int32_t* __restrict__ seg_ns, int n_slots,
                                                                          int32_t* __restrict__ ctrl,
-                                                                         const int32_t* __restrict__ list, int cap,
+                                                                         const int32_t* __restrict__ list2,
                                                                          int32_t* __restrict__ first_hit,
                                                                          int32_t* __restrict__ overflow_flag) {
   extern __shared__ double lds_d[];
@@ -723,16 +868,35 @@ __global__ __launch_bounds__(64 * SEG_WAVES) void k_collide_segments_dyn(EnvView
   int32_t* stack = ibase + wave * STACK_CAP;
   int32_t* cand = ibase + SEG_WAVES * STACK_CAP + wave * CAND_CAP;
   int32_t* queue = ibase + SEG_WAVES * (STACK_CAP + CAND_CAP) + wave * QUEUE_CAP;
-  if (!ctrl[3]) {
-    const int M = ctrl[2];
-    const int W = gridDim.x * SEG_WAVES;
-    // wave w of block b takes items b + gridDim.x * w + W * i: neighbouring items (chunks of one edge,
-    // edges of one sample) go to different CUs
-    for (int e = blockIdx.x + gridDim.x * wave; e < M; e += W) {
-      const int slot = list[2 * (size_t)e], chunk = list[2 * (size_t)e + 1];
-      if (chunk > 0 && first_hit[slot] <= 64 * chunk) continue;
-      segment_chunk(env, rob, rtri, stack, cand, queue, a6, b6, slot, chunk, first_hit, overflow_flag, lane);
+  DBG_DECL
+  [[maybe_unused]] const unsigned long long tk_ = DBG_T();
+  const int W = gridDim.x * SEG_WAVES;
+  // wave w of block b takes items b + gridDim.x * w + W * i: neighbouring items go to different CUs
+  const int e0 = blockIdx.x + gridDim.x * wave;
+  if (pose_list) {
+    const int NP = ctrl[13];
+    for (int e = e0; e < NP; e += W) {
+      const int pose = pose_list[e];
+      double p[6], R[9], c[3];
+      pose_frame(rob, pos6, pose, p, R, c);
+      const bool hit = pose_exact(env, rob, rtri, stack, cand, p, R, c, lane);
+      if (lane == 0) pose_hit[pose] = hit ? 1 : 0;
     }
+  }
+  if (!ctrl[3]) {
+    const int M = ctrl[12];
+    for (int e = e0; e < M; e += W) {
+      const int slot = list2[4 * (size_t)e], chunk = list2[4 * (size_t)e + 1];
+      const unsigned long long nm = (unsigned long long)(uint32_t)list2[4 * (size_t)e + 2] |
+                                    ((unsigned long long)(uint32_t)list2[4 * (size_t)e + 3] << 32);
+      if (chunk > 0 && first_hit[slot] <= 64 * chunk) continue;
+      double a[6], b[6];
+      for (int k = 0; k < 6; ++k) { a[k] = a6[6 * (size_t)slot + k]; b[k] = b6[6 * (size_t)slot + k]; }
+      segment_chunk(env, rob, rtri, stack, cand, queue, a, b, slot, chunk, true, nm, first_hit, overflow_flag, lane DBG_PASS);
+    }
+    DBG_ADD(8, DBG_T() - tk_);
+    DBG_ADD(9, 1);
+    DBG_FLUSH();
     return;
   }
   // the list ran over: scan the slot table, 64 slots per dequeue
@@ -748,8 +912,10 @@ __global__ __launch_bounds__(64 * SEG_WAVES) void k_collide_segments_dyn(EnvView
       const int b = __ffsll((long long)live) - 1;
       live &= live - 1;
       const int nsb = __shfl(ns, b);
+      double a[6], bb[6];
+      for (int k = 0; k < 6; ++k) { a[k] = a6[6 * (size_t)(first + b) + k]; bb[k] = b6[6 * (size_t)(first + b) + k]; }
       for (int chunk = 0; chunk * 64 < nsb; ++chunk)
-        segment_chunk(env, rob, rtri, stack, cand, queue, a6, b6, first + b, chunk, first_hit, overflow_flag, lane);
+        segment_chunk(env, rob, rtri, stack, cand, queue, a, bb, first + b, chunk, false, 0ULL, first_hit, overflow_flag, lane DBG_PASS);
     }
   }
 }
@@ -1019,6 +1185,10 @@ void launch_collide_poses(hipStream_t s, const EnvView& env, const RobotView& ro
                      rob, pos6, n, live_flags, hit);
 }
 
+#ifdef SFFK_DEBUG_COUNTERS
+void debug_counters(unsigned long long* out16) { (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_dbg), sizeof(unsigned long long) * 16); }
+#endif
+
 void launch_clear_build(hipStream_t s, const EnvView& env, double thr, uint32_t* bits, long long n_cells) {
   const long long blocks = (n_cells + 255) / 256;
   hipLaunchKernelGGL(k_clear_build, dim3((unsigned)blocks), dim3(256), 0, s, env, thr, bits, n_cells);
@@ -1040,19 +1210,35 @@ void launch_seg_prepare(hipStream_t s, const double* a6, const double* b6, int n
   hipLaunchKernelGGL(k_seg_prepare, dim3((n + 255) / 256), dim3(256), 0, s, a6, b6, n, seg_ns, first_hit, ovf);
 }
 
-void launch_collide_segments_dyn(hipStream_t s, const EnvView& env, const RobotView& rob, const double* a6,
-                                 const double* b6, const int32_t* seg_ns, int n_slots, int32_t* ctrl,
-                                 int32_t* list, int list_cap, int32_t* first_hit, int32_t* overflow_flag) {
-  if (n_slots <= 0) return;
+// compact -> cull -> exact.  pos6 / pose_list / pose_hit may be null (edges only).
+void launch_round_collide(hipStream_t s, const EnvView& env, const RobotView& rob, const double* pos6, int n_pose,
+                          const int32_t* live_flags, uint8_t* pose_hit, int32_t* pose_list, const double* a6,
+                          const double* b6, const int32_t* seg_ns, int n_slots, int32_t* ctrl, int32_t* list,
+                          int list_cap, int32_t* list2, int32_t* first_hit, int32_t* overflow_flag) {
+  if (n_slots <= 0 && n_pose <= 0) return;
   size_t lds = collide_lds_bytes(rob.n_tri, SEG_WAVES);
-  // 2 workgroups of 4 waves per CU = what the kernel's register budget keeps resident (256 CUs)
+  // 2 workgroups of 4 waves per CU = what the exact kernel's register budget keeps resident (256 CUs)
   static const int blocks = getenv("SFFGPU_SEG_BLOCKS") ? atoi(getenv("SFFGPU_SEG_BLOCKS")) : 512;
+  static const int cull_blocks = getenv("SFFGPU_CULL_BLOCKS") ? atoi(getenv("SFFGPU_CULL_BLOCKS")) : 2048;
   const int cap_override = getenv("SFFGPU_SEG_LISTCAP") ? atoi(getenv("SFFGPU_SEG_LISTCAP")) : -1;  // tests
   if (cap_override >= 0 && cap_override < list_cap) list_cap = cap_override;
-  hipLaunchKernelGGL(k_seg_compact, dim3((n_slots + 1023) / 1024), dim3(256), 0, s, seg_ns, n_slots, ctrl, list,
-                     list_cap);
-  hipLaunchKernelGGL(k_collide_segments_dyn, dim3(blocks), dim3(64 * SEG_WAVES), lds, s, env, rob, a6, b6, seg_ns,
-                     n_slots, ctrl, list, list_cap, first_hit, overflow_flag);
+  if (n_slots > 0)
+    hipLaunchKernelGGL(k_seg_compact, dim3((n_slots + 1023) / 1024), dim3(256), 0, s, seg_ns, n_slots, ctrl, list,
+                       list_cap);
+  const int pose_blocks = pose_list ? (n_pose + 255) / 256 : 0;
+  hipLaunchKernelGGL(k_cull, dim3(pose_blocks + (n_slots > 0 ? cull_blocks : 0)), dim3(256), 0, s, env, rob, pos6,
+                     n_pose, pose_blocks, live_flags, pose_hit, pose_list, a6, b6, list, list2, ctrl);
+  hipLaunchKernelGGL(k_collide_segments_dyn, dim3(blocks), dim3(64 * SEG_WAVES), lds, s, env, rob, pos6, pose_list,
+                     pose_hit, a6, b6, seg_ns, n_slots, ctrl, list2, first_hit, overflow_flag);
+}
+
+void launch_collide_segments_dyn(hipStream_t s, const EnvView& env, const RobotView& rob, const double* a6,
+                                 const double* b6, const int32_t* seg_ns, int n_slots, int32_t* ctrl,
+                                 int32_t* list, int list_cap, int32_t* list2, int32_t* first_hit,
+                                 int32_t* overflow_flag) {
+  if (n_slots <= 0) return;
+  launch_round_collide(s, env, rob, nullptr, 0, nullptr, nullptr, nullptr, a6, b6, seg_ns, n_slots, ctrl, list,
+                       list_cap, list2, first_hit, overflow_flag);
 }
 
 }  // namespace sffk
