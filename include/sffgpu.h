@@ -111,7 +111,8 @@ typedef struct {
   uint64_t sweep_queries;    /* sum over sweeps of queries */
   uint64_t slow_path_samples;/* samples whose device lists overflowed and were redone on the host path */
   uint64_t grid_rebuilds;    /* times the neighbour grid was re-celled because its overflow list filled up */
-  double sweep_ms;           /* device time of the sweep kernel (HIP events) */
+  double sweep_ms;           /* device time of the neighbour-query kernels: HIP events on every 8th round
+                                (SFFGPU_TIMER_STRIDE), scaled to all rounds - likewise the next two */
   double collide_ms;         /* device time of the pose + segment kernels */
   double sample_ms;          /* device time of the sample+steer kernel */
   double host_ms;            /* host time inside run() not waiting on the device */

@@ -148,9 +148,9 @@ int sffgpu_forest_get_stats(sffgpu_forest* f, sffgpu_forest_stats* out) {
   for (auto& kv : F.borders) nb += (int)kv.second.size();
   s.n_borders = nb;
   s.grid_rebuilds = (uint64_t)F.ctx->grid_rebuilds;
-  s.sweep_ms = F.ctx->kernel_ms[T_SWEEP];
-  s.collide_ms = F.ctx->kernel_ms[T_COLLIDE];
-  s.sample_ms = F.ctx->kernel_ms[T_SAMPLE];
+  s.sweep_ms = F.ctx->kernel_ms_total(T_SWEEP);
+  s.collide_ms = F.ctx->kernel_ms_total(T_COLLIDE);
+  s.sample_ms = F.ctx->kernel_ms_total(T_SAMPLE);
   *out = s;
   return SFFGPU_OK;
 }

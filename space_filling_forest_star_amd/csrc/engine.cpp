@@ -133,6 +133,7 @@ int Mt64::uniform_int(int lo, int hi) {
 
 // ------------------------------------------------------------------ context
 Ctx::Ctx(int dev) : device(dev) {
+  if (const char* e = getenv("SFFGPU_TIMER_STRIDE")) timer_stride = std::max(1, atoi(e));
   int n = 0;
   HIPCHK(hipGetDeviceCount(&n));
   if (n <= 0) throw HipError{"no HIP device visible: libsffgpu has no CPU fallback"};
@@ -177,16 +178,21 @@ hipEvent_t Ctx::get_event() {
   HIPCHK(hipEventCreate(&e));
   return e;
 }
-static const int g_timer_mask = getenv("SFFGPU_TIMER_MASK") ? atoi(getenv("SFFGPU_TIMER_MASK")) : 7;
-static bool g_timer_on = true;
+// HIP events between kernels cost ~5-10 us of idle GPU each, so the forest engine brackets its kernels only on
+// every timer_stride-th round (timing_on); the batch entry points always time.
 void Ctx::time_begin(int kind) {
-  g_timer_on = (g_timer_mask >> kind) & 1;
-  if (!g_timer_on) return;
+  kernel_calls[kind] += 1;
+  timed_now = timing_on;
+  if (!timed_now) return;
   Timed t{get_event(), get_event(), kind};
   HIPCHK(hipEventRecord(t.a, stream));
   pending.push_back(t);
 }
-void Ctx::time_end() { if (g_timer_on) HIPCHK(hipEventRecord(pending.back().b, stream)); }
+void Ctx::time_end() { if (timed_now) HIPCHK(hipEventRecord(pending.back().b, stream)); }
+double Ctx::kernel_ms_total(int kind) const {   // measured sum scaled to all launches
+  if (!kernel_launches[kind]) return 0.0;
+  return kernel_ms[kind] * ((double)kernel_calls[kind] / (double)kernel_launches[kind]);
+}
 void Ctx::sync() {
   HIPCHK(hipStreamSynchronize(stream));
   for (auto& t : pending) {
@@ -336,7 +342,9 @@ void Ctx::build_clearance() {
   clear_cells = 0;
   if (!have_env || !have_robot || envv.n_tri <= 0) return;
   if (const char* e = getenv("SFFGPU_NO_CLEARANCE")) if (atoi(e)) return;
-  const double rr = robv.radius;
+  // radius about the model origin: the bounding sphere (centre c, radius r) in any rotation stays inside |c| + r
+  const double rr = robv.radius + std::sqrt(robv.center[0] * robv.center[0] + robv.center[1] * robv.center[1] +
+                                            robv.center[2] * robv.center[2]) * (1 + 1e-9);
   double ext[3], vol_ext = 0;
   for (int a = 0; a < 3; ++a) { ext[a] = env_hi[a] - env_lo[a]; vol_ext = std::max(vol_ext, ext[a]); }
   if (!(vol_ext > 0) || !(rr >= 0)) return;
@@ -545,7 +553,7 @@ void Ctx::collide_segments(const double* a6, const double* b6, int n, uint8_t* i
   HIPCHK(hipMemcpyAsync(d_b.p, h_b.p, pb, hipMemcpyHostToDevice, stream));
   HIPCHK(hipMemsetAsync(d_ctrl, 0, 64, stream));
   const int list_cap = 8 * n + 65536;
-  r_items.ensure((size_t)list_cap * 8);
+  r_items.ensure((size_t)list_cap * 16);
   r_items2.ensure((size_t)list_cap * 16);
   time_begin(T_COLLIDE);
   sffk::launch_seg_prepare(stream, d_a.as<double>(), d_b.as<double>(), n, d_ns, d_fh, d_ov);

@@ -110,7 +110,11 @@ struct Ctx {
   std::vector<Timed> pending;
   std::vector<hipEvent_t> pool;
   double kernel_ms[T_KINDS] = {0, 0, 0};
-  uint64_t kernel_launches[T_KINDS] = {0, 0, 0};
+  uint64_t kernel_launches[T_KINDS] = {0, 0, 0};   // timed launches
+  uint64_t kernel_calls[T_KINDS] = {0, 0, 0};      // all launches
+  bool timing_on = true, timed_now = true;
+  int timer_stride = 8;
+  double kernel_ms_total(int kind) const;
 
   explicit Ctx(int dev);
   ~Ctx();

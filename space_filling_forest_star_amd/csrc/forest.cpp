@@ -25,6 +25,7 @@ namespace sff {
 using Clock = std::chrono::steady_clock;
 static double g_sec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 static double g_wait[3] = {0, 0, 0};   // blocked on: early copy, final sync; [2] = second read pass
+static uint64_t g_items[4] = {0, 0, 0, 0};   // rounds, edge work items, items after the cull, poses after the cull
 static uint64_t g_cnt[4] = {0, 0, 0, 0};   // candidates, skipped by the replay, settled on the device, accepted
 static const bool g_prof = getenv("SFFGPU_PROFILE") != nullptr;
 struct Sec {
@@ -34,6 +35,7 @@ struct Sec {
   ~Sec() { g_sec[k] += std::chrono::duration<double, std::milli>(Clock::now() - t0).count(); }
 };
 void forest_profile_dump() {
+  if (g_prof && g_items[0]) fprintf(stderr, "[sffgpu per round] edge chunks %.0f -> %.0f after the clearance cull, poses -> %.0f\n", (double)g_items[1] / g_items[0], (double)g_items[2] / g_items[0], (double)g_items[3] / g_items[0]);
   if (g_prof) fprintf(stderr, "[sffgpu candidates] %llu skipped %llu settled %llu\n", (unsigned long long)g_cnt[0], (unsigned long long)g_cnt[1], (unsigned long long)g_cnt[2]);
   if (g_prof) fprintf(stderr, "[sffgpu waits ms] early copy %.1f final sync %.1f | read pass 2 %.1f\n", g_wait[0], g_wait[1], g_wait[2]);
   if (g_prof) fprintf(stderr, "[sffgpu host ms] prep %.1f launch %.1f read %.1f records %.1f deser %.1f replay %.1f append %.1f endwave %.1f\n", g_sec[0], g_sec[1], g_sec[2], g_sec[3], g_sec[4], g_sec[5], g_sec[6], g_sec[7]);
@@ -365,6 +367,7 @@ void Forest::round_begin() {
       hf[i] = nodes[cands[i].expanded].force_children ? 1 : 0;
     }
   }
+  c.timing_on = c.timer_stride <= 1 || st.sweeps % (uint64_t)c.timer_stride == 0;
   const uint64_t* d_words = reinterpret_cast<const uint64_t*>(c.r_in.as<char>() + in_words);
   const int32_t* d_parent = reinterpret_cast<const int32_t*>(c.r_in.as<char>() + in_parent);
   const uint8_t* d_force = reinterpret_cast<const uint8_t*>(c.r_in.as<char>() + in_force);
@@ -459,7 +462,7 @@ void Forest::round_begin() {
   HIPCHK(hipEventRecord(c.ev_early, c.copy_stream));
   // poses and edges together: work-list compaction -> clearance cull -> exact kernel
   const int list_cap = 4 * n * STRIDE + 65536;
-  c.r_items.ensure((size_t)list_cap * 8);
+  c.r_items.ensure((size_t)list_cap * 16);
   c.r_items2.ensure((size_t)list_cap * 16);
   c.r_poselist.ensure((size_t)n * 4);
   sffk::launch_round_collide(c.stream, c.envv, c.robv, d_pos, n, ca.rec_flags, d_pose, c.r_poselist.as<int32_t>(),
@@ -480,6 +483,7 @@ void Forest::round_begin() {
     sffk::launch_settle(c.stream, sa);
   }
   HIPCHK(hipMemcpyAsync(ho + early_bytes, dout + early_bytes, o_bytes - early_bytes, hipMemcpyDeviceToHost, c.stream));
+  c.timing_on = true;
   g_sec[1] += ms_since(_t1);
   // the GPU is busy for a while: generate the engine words of the next draws now
   if (!rng_ahead.empty()) rng.prefetch(rng_ahead.data(), rng_ahead.size());
@@ -537,6 +541,10 @@ void Forest::round_begin() {
   g_sec[2] += ms_since(_t2);
   { auto tw = Clock::now(); timed_sync(); g_wait[1] += ms_since(tw); }
   _t2 = Clock::now();
+  {
+    const int32_t* hc = reinterpret_cast<const int32_t*>(ho + o_ctrl);
+    g_items[0] += 1; g_items[1] += (uint64_t)hc[2]; g_items[2] += (uint64_t)hc[12]; g_items[3] += (uint64_t)hc[13];
+  }
   if (settle_on_device) {
     const uint64_t* hb = reinterpret_cast<const uint64_t*>(ho + o_ctrl + 16);
     for (int k = 0; k < 4; ++k) bulk_counts[k] += hb[k];

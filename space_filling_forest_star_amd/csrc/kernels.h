@@ -69,8 +69,8 @@ struct EnvView {
   const double* level_box[SFFK_MAX_LEVELS];
   int level_count[SFFK_MAX_LEVELS];
   // clearance bits (built once both meshes are known): bit = 1 when every point of the cell is farther from
-  // every triangle than the robot's bounding-sphere radius (plus slack), so a robot centred there cannot touch
-  // the environment.  The grid spans the environment box inflated by clear_thr; null = not built.
+  // every triangle than the radius of the sphere around the robot's model origin that holds the robot in any
+  // rotation (plus slack), so a robot posed there cannot touch the environment.  The grid spans the environment box inflated by clear_thr; null = not built.
   const uint32_t* clear_bits;
   double clear_org[3];
   double clear_inv;       // 1 / cell edge
@@ -164,7 +164,7 @@ void launch_settle(hipStream_t s, const SettleArgs& a);
 void launch_seg_prepare(hipStream_t s, const double* a6, const double* b6, int n, int32_t* seg_ns, int32_t* first_hit,
                         int32_t* ovf);
 // ctrl = 16 zeroed ints: [1] scan cursor, [2] work items, [3] list overflow, [4..11] settle counters,
-// [12] culled work items, [13] culled poses.  list = 2 ints per (slot, chunk) work item, list_cap items;
+// [12] culled work items, [13] culled poses.  list = 4 ints per (slot, chunk, 1/parts) work item, list_cap items;
 // list2 = 4 ints per item that survives the clearance cull (same capacity).  An overflowing list only costs
 // speed (the exact kernel then scans the slot table).
 void launch_collide_segments_dyn(hipStream_t s, const EnvView& env, const RobotView& rob, const double* a6,

@@ -409,8 +409,8 @@ __device__ __forceinline__ bool tri_far(const double* T, const double* c, double
   return dd > lim * lim;
 }
 
-// Clearance bits: true when a robot whose bounding-sphere centre is c provably touches nothing (the exact
-// test would find a separating axis for every pair), so the traversal and the exact tests can be skipped.
+// Clearance bits: true when a robot whose MODEL ORIGIN is at c provably touches nothing in any rotation (the
+// exact test would find a separating axis for every pair), so the traversal and the exact tests can be skipped.
 // Points outside the grid are farther than the build threshold from the environment's box.
 __device__ __forceinline__ bool surely_clear(const EnvView& env, const double* c) {
   if (!env.clear_bits) return false;
@@ -460,6 +460,24 @@ __global__ __launch_bounds__(256) void k_clear_build(EnvView env, double thr, ui
     bits[(idx >> 5) + 1] = (uint32_t)(m >> 32);
   }
 }
+
+#ifdef SFFK_DEBUG_COUNTERS
+__device__ unsigned long long g_dbg[16];
+struct DbgAcc { unsigned long long v[12]; };
+#define DBG_DECL DbgAcc dbg_acc = {{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
+#define DBG_ARG , DbgAcc& dbg_acc
+#define DBG_PASS , dbg_acc
+#define DBG_T() wall_clock64()
+#define DBG_ADD(i, x) dbg_acc.v[i] += (unsigned long long)(x)
+#define DBG_FLUSH() do { if (lane == 0) for (int q_ = 0; q_ < 12; ++q_) if (dbg_acc.v[q_]) atomicAdd(&g_dbg[q_], dbg_acc.v[q_]); } while (0)
+#else
+#define DBG_DECL
+#define DBG_ARG
+#define DBG_PASS
+#define DBG_T() 0ULL
+#define DBG_ADD(i, x) do { } while (0)
+#define DBG_FLUSH() do { } while (0)
+#endif
 
 // ------------------------------------------------------------------ pose kernel
 #define POSE_WAVES 4
@@ -540,13 +558,8 @@ __global__ __launch_bounds__(64 * POSE_WAVES) void k_collide_poses(EnvView env, 
     const bool run = !live_flags || (live_flags[pose] & 3) == 1;   // else not owned / out of limits / host path
     if (run && env.n_tri != 0) {                                     // (HasMap == false: src/environment.h:307-309)
       for (int k = 0; k < 6; ++k) p[k] = pos6[6 * (size_t)pose + k];
-      if (p[3] == 0 && p[4] == 0 && p[5] == 0) {
-        R[0] = R[4] = R[8] = 1; R[1] = R[2] = R[3] = R[5] = R[6] = R[7] = 0;
-      } else {
-        rotation(p, R);
-      }
-      xform(R, p, rob.center, c);
-      need = !surely_clear(env, c);
+      need = !surely_clear(env, p);
+      if (need) pose_frame(rob, pos6, pose, p, R, c);
     }
     if (!need && lane == 0) hit_out[pose] = 0;
   }
@@ -561,24 +574,6 @@ __global__ __launch_bounds__(64 * POSE_WAVES) void k_collide_poses(EnvView env, 
 // ------------------------------------------------------------------ segment kernel
 #define SEG_WAVES 4
 #define QUEUE_CAP 128
-
-#ifdef SFFK_DEBUG_COUNTERS
-__device__ unsigned long long g_dbg[16];
-struct DbgAcc { unsigned long long v[12]; };
-#define DBG_DECL DbgAcc dbg_acc = {{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
-#define DBG_ARG , DbgAcc& dbg_acc
-#define DBG_PASS , dbg_acc
-#define DBG_T() wall_clock64()
-#define DBG_ADD(i, x) dbg_acc.v[i] += (unsigned long long)(x)
-#define DBG_FLUSH() do { if (lane == 0) for (int q_ = 0; q_ < 12; ++q_) if (dbg_acc.v[q_]) atomicAdd(&g_dbg[q_], dbg_acc.v[q_]); } while (0)
-#else
-#define DBG_DECL
-#define DBG_ARG
-#define DBG_PASS
-#define DBG_T() 0ULL
-#define DBG_ADD(i, x) do { } while (0)
-#define DBG_FLUSH() do { } while (0)
-#endif
 
 // One wavefront per (edge, chunk of 64 consecutive samples): lane = sample.  The chunk's own swept
 // box gives a tight broad phase; the smallest colliding sample index of an edge is reduced with
@@ -601,7 +596,7 @@ __device__ void segment_chunk(const EnvView& env, const RobotView& rob, const do
   const double C[3] = {P[0] + rob.center[0], P[1] + rob.center[1], P[2] + rob.center[2]};
   // samples whose clearance bit is set need nothing; the others bound the chunk's broad-phase box
   // (the cull kernel already looked the bits up when it hands a mask over)
-  const bool need = have_mask ? ((mask >> lane) & 1ULL) != 0 : (live && !surely_clear(env, C));
+  const bool need = have_mask ? ((mask >> lane) & 1ULL) != 0 : (live && !surely_clear(env, P));
   const unsigned long long nm = __ballot(need);
   [[maybe_unused]] const unsigned long long t1_ = DBG_T();
   DBG_ADD(4, t1_ - t0_);
@@ -714,10 +709,11 @@ __device__ void segment_chunk(const EnvView& env, const RobotView& rob, const do
 
 // Edge tasks are written on the device (k_classify for the forest rounds, k_seg_prepare for host batches)
 // into a sparse slot table (seg_ns > 0 = live edge).  k_seg_compact turns the table into a dense list of
-// (slot, chunk) work items - one block-level scan and ONE atomic per block, because returning atomics on a
+// (slot, chunk, 1/parts) work items - one block-level scan and ONE atomic per block, because returning atomics on a
 // single word saturate near 90/us chip-wide and a per-item dequeue would cost more than the work itself.
 // ctrl[2] = items reserved, ctrl[3] = 1 when the list ran over (the edge kernel then scans the table).
 __global__ __launch_bounds__(256) void k_seg_compact(const int32_t* __restrict__ seg_ns, int n_slots,
+                                                     const double* __restrict__ a6, const double* __restrict__ b6,
                                                      int32_t* __restrict__ ctrl, int32_t* __restrict__ list, int cap) {
   __shared__ int wsum[4];
   __shared__ int base_s;
@@ -743,11 +739,21 @@ __global__ __launch_bounds__(256) void k_seg_compact(const int32_t* __restrict__
   __syncthreads();
   int at = base_s + inc - tot;
   for (int w = 0; w < wave; ++w) at += wsum[w];
-  for (int j = 0; j < 4; ++j)
+  // an item = slot, chunk, 1 / parts of the edge (the cull kernel places its samples with it)
+  for (int j = 0; j < 4; ++j) {
+    if (!c[j]) continue;
+    const double inv = 1.0 / edge_parts(a6 + 6 * (size_t)(s0 + j), b6 + 6 * (size_t)(s0 + j));
+    const long long ib = __double_as_longlong(inv);
     for (int k = 0; k < c[j]; ++k, ++at) {
-      if (at < cap) { list[2 * (size_t)at] = s0 + j; list[2 * (size_t)at + 1] = k; }
-      else ctrl[3] = 1;
+      if (at < cap) {
+        int4 it;
+        it.x = s0 + j; it.y = k; it.z = (int)(uint32_t)(unsigned long long)ib; it.w = (int)(uint32_t)((unsigned long long)ib >> 32);
+        reinterpret_cast<int4*>(list)[at] = it;
+      } else {
+        ctrl[3] = 1;
+      }
     }
+  }
 }
 
 // Lean, high-occupancy pass in front of the exact kernel: looks up the clearance bits of every pose (one thread
@@ -760,21 +766,23 @@ __global__ __launch_bounds__(256) void k_cull(EnvView env, RobotView rob, const 
                                               int pose_blocks, const int32_t* __restrict__ live_flags,
                                               uint8_t* __restrict__ pose_hit, int32_t* __restrict__ pose_list,
                                               const double* __restrict__ a6, const double* __restrict__ b6,
+                                              const int32_t* __restrict__ seg_ns,
                                               const int32_t* __restrict__ list, int32_t* __restrict__ list2,
                                               int32_t* __restrict__ ctrl) {
   __shared__ int wcnt[4];
   __shared__ int base_s;
   __shared__ int32_t keep[4][CULL_KEEP][4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  [[maybe_unused]] const unsigned long long tc0_ = DBG_T();
   if ((int)blockIdx.x < pose_blocks) {
     const int pose = blockIdx.x * 256 + threadIdx.x;
     bool need = false;
     if (pose < n_pose) {
       const bool run = !live_flags || (live_flags[pose] & 3) == 1;   // else not owned / out of limits / host path
       if (run && env.n_tri != 0) {                                     // (HasMap == false: src/environment.h:307-309)
-        double p[6], R[9], c[3];
-        pose_frame(rob, pos6, pose, p, R, c);
-        need = !surely_clear(env, c);
+        // the bits are built for a sphere around the model origin that holds the robot in every rotation
+        const double o[3] = {pos6[6 * (size_t)pose], pos6[6 * (size_t)pose + 1], pos6[6 * (size_t)pose + 2]};
+        need = !surely_clear(env, o);
       }
       if (!need) pose_hit[pose] = 0;
     }
@@ -791,6 +799,9 @@ __global__ __launch_bounds__(256) void k_cull(EnvView env, RobotView rob, const 
       for (int w = 0; w < wave; ++w) at += wcnt[w];
       pose_list[at] = pose;
     }
+#ifdef SFFK_DEBUG_COUNTERS
+    if (lane == 0) { atomicAdd(&g_dbg[12], DBG_T() - tc0_); atomicAdd(&g_dbg[13], 1ULL); atomicMax(&g_dbg[14], DBG_T() - tc0_); }
+#endif
     return;
   }
   if (ctrl[3] || env.n_tri == 0) return;     // work list ran over: the exact kernel scans the slot table itself
@@ -806,29 +817,69 @@ __global__ __launch_bounds__(256) void k_cull(EnvView env, RobotView rob, const 
       for (int q = 0; q < 4; ++q) list2[4 * (size_t)(base + lane) + q] = keep[wave][lane][q];
     kept = 0;
   };
-  for (int e = cb + nb * wave; e < M; e += W) {
-    const int slot = list[2 * (size_t)e], chunk = list[2 * (size_t)e + 1];
-    double a[6], b[6];
-    for (int k = 0; k < 6; ++k) { a[k] = a6[6 * (size_t)slot + k]; b[k] = b6[6 * (size_t)slot + k]; }
-    const double parts = edge_parts(a, b);
-    const int ns = edge_samples(parts);
-    const int idx = 1 + 64 * chunk + lane;
-    bool need = false;
-    if (idx <= ns) {
-      const double dir[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
-      double P[3];
-      edge_sample_pos(a, dir, parts, idx, P);
-      const double C[3] = {P[0] + rob.center[0], P[1] + rob.center[1], P[2] + rob.center[2]};
-      need = !surely_clear(env, C);
+  // Four items per step: their three dependent loads (item -> edge endpoints -> clearance word) are issued
+  // side by side, so a wave pays the memory latency once per four items.  Positions are only needed to a
+  // tolerance far inside the slack of the clearance bits here, so idx * dir / parts becomes a multiplication.
+  for (int e = cb + nb * wave; e < M; e += 4 * W) {
+    int slot[4], chunk[4];
+    double inv[4];
+    bool val[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      val[u] = e + u * W < M;
+      const int4 it = reinterpret_cast<const int4*>(list)[val[u] ? e + u * W : e];
+      slot[u] = it.x;
+      chunk[u] = it.y;
+      inv[u] = __longlong_as_double((long long)((unsigned long long)(uint32_t)it.z | ((unsigned long long)(uint32_t)it.w << 32)));
     }
-    const unsigned long long nm = __ballot(need);
-    if (nm) {
-      if (kept == CULL_KEEP) flush_wave();
-      if (lane == 0) {
-        keep[wave][kept][0] = slot; keep[wave][kept][1] = chunk;
-        keep[wave][kept][2] = (int32_t)(uint32_t)nm; keep[wave][kept][3] = (int32_t)(uint32_t)(nm >> 32);
+    double ea[4][3], eb[4][3];
+    int ens[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      for (int k = 0; k < 3; ++k) { ea[u][k] = a6[6 * (size_t)slot[u] + k]; eb[u][k] = b6[6 * (size_t)slot[u] + k]; }
+      ens[u] = seg_ns[slot[u]];
+    }
+    bool need[4];
+    const uint32_t* wp[4];
+    int sh[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = 1 + 64 * chunk[u] + lane;
+      const double t = (double)idx * inv[u];
+      const double C[3] = {ea[u][0] + t * (eb[u][0] - ea[u][0]), ea[u][1] + t * (eb[u][1] - ea[u][1]),
+                           ea[u][2] + t * (eb[u][2] - ea[u][2])};   // the model origin at this sample
+      need[u] = val[u] && idx <= ens[u];
+      wp[u] = nullptr;
+      sh[u] = 0;
+      if (need[u]) {
+        const double fx = (C[0] - env.clear_org[0]) * env.clear_inv, fy = (C[1] - env.clear_org[1]) * env.clear_inv,
+                     fz = (C[2] - env.clear_org[2]) * env.clear_inv;
+        if (env.clear_bits && fx == fx && fy == fy && fz == fz) {
+          if (fx < 0 || fy < 0 || fz < 0 || fx >= env.clear_n[0] || fy >= env.clear_n[1] || fz >= env.clear_n[2]) {
+            need[u] = false;                        // beyond the inflated box of the environment
+          } else {                                  // (the grid has fewer than 2^31 cells)
+            const uint32_t ci = ((uint32_t)(int)fz * (uint32_t)env.clear_n[1] + (uint32_t)(int)fy) * (uint32_t)env.clear_n[0] + (uint32_t)(int)fx;
+            wp[u] = env.clear_bits + (ci >> 5);
+            sh[u] = (int)(ci & 31u);
+          }
+        }
       }
-      kept += 1;
+    }
+    uint32_t word[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) word[u] = wp[u] ? *wp[u] : 0u;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      if (wp[u] && ((word[u] >> sh[u]) & 1u)) need[u] = false;
+      const unsigned long long nm = __ballot(need[u]);
+      if (nm) {
+        if (kept == CULL_KEEP) flush_wave();
+        if (lane == 0) {
+          keep[wave][kept][0] = slot[u]; keep[wave][kept][1] = chunk[u];
+          keep[wave][kept][2] = (int32_t)(uint32_t)nm; keep[wave][kept][3] = (int32_t)(uint32_t)(nm >> 32);
+        }
+        kept += 1;
+      }
     }
   }
   if (lane == 0) wcnt[wave] = kept;
@@ -842,6 +893,9 @@ __global__ __launch_bounds__(256) void k_cull(EnvView env, RobotView rob, const 
   for (int w = 0; w < wave; ++w) at += wcnt[w];
   if (lane < kept)
     for (int q = 0; q < 4; ++q) list2[4 * (size_t)(at + lane) + q] = keep[wave][lane][q];
+#ifdef SFFK_DEBUG_COUNTERS
+  if (lane == 0) { atomicAdd(&g_dbg[10], DBG_T() - tc0_); atomicAdd(&g_dbg[11], 1ULL); atomicMax(&g_dbg[15], DBG_T() - tc0_); }
+#endif
 }
 
 // Exact kernel: persistent wavefronts walk the culled lists with a fixed stride (no dequeue atomics): first the
@@ -1223,11 +1277,11 @@ void launch_round_collide(hipStream_t s, const EnvView& env, const RobotView& ro
   const int cap_override = getenv("SFFGPU_SEG_LISTCAP") ? atoi(getenv("SFFGPU_SEG_LISTCAP")) : -1;  // tests
   if (cap_override >= 0 && cap_override < list_cap) list_cap = cap_override;
   if (n_slots > 0)
-    hipLaunchKernelGGL(k_seg_compact, dim3((n_slots + 1023) / 1024), dim3(256), 0, s, seg_ns, n_slots, ctrl, list,
-                       list_cap);
+    hipLaunchKernelGGL(k_seg_compact, dim3((n_slots + 1023) / 1024), dim3(256), 0, s, seg_ns, n_slots, a6, b6, ctrl,
+                       list, list_cap);
   const int pose_blocks = pose_list ? (n_pose + 255) / 256 : 0;
   hipLaunchKernelGGL(k_cull, dim3(pose_blocks + (n_slots > 0 ? cull_blocks : 0)), dim3(256), 0, s, env, rob, pos6,
-                     n_pose, pose_blocks, live_flags, pose_hit, pose_list, a6, b6, list, list2, ctrl);
+                     n_pose, pose_blocks, live_flags, pose_hit, pose_list, a6, b6, seg_ns, list, list2, ctrl);
   hipLaunchKernelGGL(k_collide_segments_dyn, dim3(blocks), dim3(64 * SEG_WAVES), lds, s, env, rob, pos6, pose_list,
                      pose_hit, a6, b6, seg_ns, n_slots, ctrl, list2, first_hit, overflow_flag);
 }
