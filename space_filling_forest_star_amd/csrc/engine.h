@@ -150,8 +150,6 @@ struct Ctx {
 struct FNode {
   double pos[6];
   int tree, parent, idx_in_tree;
-  bool force_children = false;
-  bool on_frontier = false;
   double d_closest, d_root;
   unsigned iter;
 };
@@ -179,6 +177,9 @@ struct Forest {
   Mt64 rng;
   std::vector<uint64_t> rng_ahead;   // engine words generated while the GPU works (fixed size: Mt64 keeps a pointer)
   std::vector<FNode> nodes;
+  // per node, kept apart from the 88-byte records because whole-frontier passes and the per-sample input only
+  // need these bits: 1 = Node::ForceChildren, 2 = currently on the frontier deque
+  std::vector<uint8_t> nflag;
   std::vector<std::vector<int>> trees;
   std::vector<int> frontier, closed;
   std::map<std::pair<int, int>, std::vector<Border>> borders;

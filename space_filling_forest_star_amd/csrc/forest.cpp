@@ -102,12 +102,17 @@ Forest::Forest(Ctx* c, const sffgpu_forest_cfg& cf, const double* roots6, int n_
   if (cfg.wave >= 64) rng_ahead.assign((size_t)8 * cfg.wave + 4096, 0);
   num_roots = n_roots + (cfg.has_goal ? 1 : 0);
   trees.resize(num_roots);
+  {   // no reallocation (and copy) of the node records while the forest grows
+    const size_t cap = (size_t)std::min(std::max(cfg.node_budget, 4096), 1 << 26) + (size_t)cfg.wave + 64;
+    nodes.reserve(cap);
+    nflag.reserve(cap);
+  }
   ctx->store_reset(std::max(cfg.node_budget, 4096) + cfg.wave + 64);
   std::vector<int32_t> tids(n_roots);
   for (int j = 0; j < n_roots; ++j) {          // src/forest.h:60-76
     int id = add_node(roots6 + 6 * (size_t)j, j, -1, 0, 0, 0);
     frontier.push_back(id);
-    nodes[id].on_frontier = true;
+    nflag[id] |= 2;
     tids[j] = j;
   }
   {
@@ -159,6 +164,7 @@ int Forest::add_node(const double* pos, int tree, int parent, double dclosest, d
   n.idx_in_tree = (int)trees[tree].size();
   int id = (int)nodes.size();
   nodes.push_back(n);
+  nflag.push_back(0);
   trees[tree].push_back(id);
   return id;
 }
@@ -257,8 +263,8 @@ void Forest::end_wave() {
           for (int j = (int)p.v.size() - 1; j > -1; --j)
             if (j < (int)p.v.size() && p.v[j] == sl.node) p.pop_at(j);
         }
-        if (!nodes[sl.node].force_children) {
-          nodes[sl.node].force_children = true;
+        if (!(nflag[sl.node] & 1)) {
+          nflag[sl.node] |= 1;
           closed.push_back(sl.node);
         }
       } else {
@@ -266,9 +272,8 @@ void Forest::end_wave() {
       }
       continue;
     }
-    if (sl.failing && !sl.from_closed && nodes[sl.node].on_frontier) {
-      nodes[sl.node].on_frontier = false;
-      nodes[sl.node].force_children = true;
+    if (sl.failing && !sl.from_closed && (nflag[sl.node] & 2)) {
+      nflag[sl.node] = (uint8_t)((nflag[sl.node] & ~2) | 1);
       closed.push_back(sl.node);
       removed = true;
     }
@@ -276,7 +281,7 @@ void Forest::end_wave() {
   if (removed) {
     size_t w = 0;
     for (size_t r = 0; r < frontier.size(); ++r)
-      if (nodes[frontier[r]].on_frontier) frontier[w++] = frontier[r];
+      if (nflag[frontier[r]] & 2) frontier[w++] = frontier[r];
     frontier.resize(w);
   }
   ctx->grid_check();
@@ -362,9 +367,8 @@ void Forest::round_begin() {
     for (int i = 0; i < n; ++i) {
       if (words_per != 6)
         for (int k = 0; k < 6; ++k) hw[6 * (size_t)i + k] = k < words_per ? rng.next() : 0;
-      if (i + 16 < n) __builtin_prefetch(&nodes[cands[i + 16].expanded].force_children);
       hp[i] = cands[i].expanded;
-      hf[i] = nodes[cands[i].expanded].force_children ? 1 : 0;
+      hf[i] = nflag[cands[i].expanded] & 1;
     }
   }
   c.timing_on = c.timer_stride <= 1 || st.sweeps % (uint64_t)c.timer_stride == 0;
@@ -666,7 +670,7 @@ void Forest::round_begin() {
         nb.same_tree = nb.tree == mine;
         nb.seg = -1;
         if (nb.same_tree) {
-          if (ex.force_children || !(d < cd.pdist - SFFG_TOL)) continue;   // src/forest.h:276
+          if ((nflag[cd.expanded] & 1) || !(d < cd.pdist - SFFG_TOL)) continue;   // src/forest.h:276
         } else {
           if (!(d < cfg.dist_tree - SFFG_TOL)) continue;                    // src/forest.h:283
         }
@@ -1062,7 +1066,7 @@ void Forest::round_commit(const int32_t* all, const int32_t* counts, int world) 
       for (PHeap& h : heaps[mine]) h.push(id);
     } else {
       frontier.push_back(id);                                  // :365
-      nodes[id].on_frontier = true;
+      nflag[id] |= 2;
     }
     if (solved) {                                              // :369-372
       double gd = sffg::dist6(cd.pos, cfg.goal);
