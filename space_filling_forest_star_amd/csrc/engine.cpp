@@ -159,7 +159,7 @@ Ctx::~Ctx() {
   for (auto e : pool) (void)hipEventDestroy(e);
   DevBuf* bufs[] = {&env_tri, &env_box, &env_plane, &rob_tri, &sx, &sy, &sz, &syaw, &spitch, &sroll, &stree, &spos,
                     &d_a, &d_b, &d_c, &d_d, &d_e, &d_f, &d_g, &d_h, &r_in, &r_out, &r_q, &r_cnt, &r_hidx,
-                    &r_hdist, &r_sega, &r_segb, &r_items, &r_items2, &r_poselist, &env_clear, &g_cnt, &g_items, &g_ovfcnt, &g_ovf};
+                    &r_hdist, &r_sega, &r_segb, &r_items, &r_items2, &env_clear, &g_cnt, &g_items, &g_ovfcnt, &g_ovf};
   for (DevBuf* b : bufs) b->release();
   for (auto& b : level_box) b.release();
   PinBuf* pins[] = {&h_a, &h_b, &h_c, &h_d, &h_e, &h_f, &h_g, &h_h, &p_in, &p_out};
@@ -553,12 +553,12 @@ void Ctx::collide_segments(const double* a6, const double* b6, int n, uint8_t* i
   HIPCHK(hipMemcpyAsync(d_b.p, h_b.p, pb, hipMemcpyHostToDevice, stream));
   HIPCHK(hipMemsetAsync(d_ctrl, 0, 64, stream));
   const int list_cap = 8 * n + 65536;
-  r_items.ensure((size_t)list_cap * 16);
-  r_items2.ensure((size_t)list_cap * 16);
+  r_items.ensure((size_t)list_cap * SFFK_ITEM_BYTES);
+  r_items2.ensure(((size_t)list_cap + (1u << 20)) * 8);   // (+ one window of the exact kernel, see mask_slot)
   time_begin(T_COLLIDE);
   sffk::launch_seg_prepare(stream, d_a.as<double>(), d_b.as<double>(), n, d_ns, d_fh, d_ov);
   sffk::launch_collide_segments_dyn(stream, envv, robv, d_a.as<double>(), d_b.as<double>(), d_ns, n, d_ctrl,
-                                    r_items.as<int32_t>(), list_cap, r_items2.as<int32_t>(), d_fh, d_ov);
+                                    r_items.p, list_cap, r_items2.p, d_fh, d_ov);
   time_end();
   HIPCHK(hipMemcpyAsync(h_c.p, d_c.p, (size_t)n * 12, hipMemcpyDeviceToHost, stream));
   sync();

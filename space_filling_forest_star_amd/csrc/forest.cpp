@@ -35,7 +35,7 @@ struct Sec {
   ~Sec() { g_sec[k] += std::chrono::duration<double, std::milli>(Clock::now() - t0).count(); }
 };
 void forest_profile_dump() {
-  if (g_prof && g_items[0]) fprintf(stderr, "[sffgpu per round] edge chunks %.0f -> %.0f after the clearance cull, poses -> %.0f\n", (double)g_items[1] / g_items[0], (double)g_items[2] / g_items[0], (double)g_items[3] / g_items[0]);
+  if (g_prof && g_items[0]) fprintf(stderr, "[sffgpu per round] edge work items (64-sample chunks) %.0f\n", (double)g_items[1] / g_items[0]);
   if (g_prof) fprintf(stderr, "[sffgpu candidates] %llu skipped %llu settled %llu\n", (unsigned long long)g_cnt[0], (unsigned long long)g_cnt[1], (unsigned long long)g_cnt[2]);
   if (g_prof) fprintf(stderr, "[sffgpu waits ms] early copy %.1f final sync %.1f | read pass 2 %.1f\n", g_wait[0], g_wait[1], g_wait[2]);
   if (g_prof) fprintf(stderr, "[sffgpu host ms] prep %.1f launch %.1f read %.1f records %.1f deser %.1f replay %.1f append %.1f endwave %.1f\n", g_sec[0], g_sec[1], g_sec[2], g_sec[3], g_sec[4], g_sec[5], g_sec[6], g_sec[7]);
@@ -466,12 +466,10 @@ void Forest::round_begin() {
   HIPCHK(hipEventRecord(c.ev_early, c.copy_stream));
   // poses and edges together: work-list compaction -> clearance cull -> exact kernel
   const int list_cap = 4 * n * STRIDE + 65536;
-  c.r_items.ensure((size_t)list_cap * 16);
-  c.r_items2.ensure((size_t)list_cap * 16);
-  c.r_poselist.ensure((size_t)n * 4);
-  sffk::launch_round_collide(c.stream, c.envv, c.robv, d_pos, n, ca.rec_flags, d_pose, c.r_poselist.as<int32_t>(),
-                             ca.seg_a, ca.seg_b, ca.seg_ns, n * STRIDE, ca.ctrl, c.r_items.as<int32_t>(), list_cap,
-                             c.r_items2.as<int32_t>(), ca.first_hit, ca.seg_ovf);
+  c.r_items.ensure((size_t)list_cap * SFFK_ITEM_BYTES);
+  c.r_items2.ensure(((size_t)list_cap + (1u << 20)) * 8);   // (+ one window of the exact kernel, see mask_slot)
+  sffk::launch_round_collide(c.stream, c.envv, c.robv, d_pos, n, ca.rec_flags, d_pose, ca.seg_a, ca.seg_b, ca.seg_ns,
+                             n * STRIDE, ca.ctrl, c.r_items.p, list_cap, c.r_items2.p, ca.first_hit, ca.seg_ovf);
   c.time_end();
   // samples this rank can settle alone need no replay (with a goal the replay may stop in the middle of the
   // round, so there every sample stays in it)
@@ -547,7 +545,7 @@ void Forest::round_begin() {
   _t2 = Clock::now();
   {
     const int32_t* hc = reinterpret_cast<const int32_t*>(ho + o_ctrl);
-    g_items[0] += 1; g_items[1] += (uint64_t)hc[2]; g_items[2] += (uint64_t)hc[12]; g_items[3] += (uint64_t)hc[13];
+    g_items[0] += 1; g_items[1] += (uint64_t)hc[2];
   }
   if (settle_on_device) {
     const uint64_t* hb = reinterpret_cast<const uint64_t*>(ho + o_ctrl + 16);

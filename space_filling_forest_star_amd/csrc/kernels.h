@@ -163,19 +163,18 @@ struct SettleArgs {
 void launch_settle(hipStream_t s, const SettleArgs& a);
 void launch_seg_prepare(hipStream_t s, const double* a6, const double* b6, int n, int32_t* seg_ns, int32_t* first_hit,
                         int32_t* ovf);
-// ctrl = 16 zeroed ints: [1] scan cursor, [2] work items, [3] list overflow, [4..11] settle counters,
-// [12] culled work items, [13] culled poses.  list = 4 ints per (slot, chunk, 1/parts) work item, list_cap items;
-// list2 = 4 ints per item that survives the clearance cull (same capacity).  An overflowing list only costs
-// speed (the exact kernel then scans the slot table).
+// ctrl = 16 zeroed ints: [1] scan cursor, [2] work items, [3] list overflow, [4..11] settle counters.
+// list = list_cap work items of SFFK_ITEM_BYTES each; masks = list_cap u64 (samples of an item that survive the
+// clearance cull).  An overflowing list only costs speed (the exact kernel then scans the slot table).
+#define SFFK_ITEM_BYTES 64
 void launch_collide_segments_dyn(hipStream_t s, const EnvView& env, const RobotView& rob, const double* a6,
                                  const double* b6, const int32_t* seg_ns, int n_slots, int32_t* ctrl,
-                                 int32_t* list, int list_cap, int32_t* list2, int32_t* first_hit,
-                                 int32_t* overflow_flag);
-// a forest round: the same pipeline, and the round's poses (pose_list: n_pose ints of scratch) go through the
-// cull and the exact kernel with the edges
+                                 void* list, int list_cap, void* masks, int32_t* first_hit, int32_t* overflow_flag);
+// a forest round: the same pipeline, and the round's poses go through the cull and the exact kernel with the
+// edges (pose_hit: 0 free / 1 hit on return)
 void launch_round_collide(hipStream_t s, const EnvView& env, const RobotView& rob, const double* pos6, int n_pose,
-                          const int32_t* live_flags, uint8_t* pose_hit, int32_t* pose_list, const double* a6,
-                          const double* b6, const int32_t* seg_ns, int n_slots, int32_t* ctrl, int32_t* list,
-                          int list_cap, int32_t* list2, int32_t* first_hit, int32_t* overflow_flag);
+                          const int32_t* live_flags, uint8_t* pose_hit, const double* a6, const double* b6,
+                          const int32_t* seg_ns, int n_slots, int32_t* ctrl, void* list, int list_cap, void* masks,
+                          int32_t* first_hit, int32_t* overflow_flag);
 
 }  // namespace sffk

@@ -20,6 +20,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include "kernels.h"
+#include <algorithm>
 #include "sff_geom.h"
 
 namespace sffk {
@@ -707,14 +708,20 @@ __device__ void segment_chunk(const EnvView& env, const RobotView& rob, const do
   if (minhit != 0x7fffffff && lane == 0) atomicMin(first_hit + seg, minhit);
 }
 
+struct WorkItem {   // 64 bytes: one (edge, chunk of 64 samples) unit of collision work
+  int32_t slot, chunk, ns, pad;
+  double a[3];      // start point of the edge (xyz)
+  double step[3];   // (b - a) / parts: distance between two consecutive samples
+};
+
 // Edge tasks are written on the device (k_classify for the forest rounds, k_seg_prepare for host batches)
 // into a sparse slot table (seg_ns > 0 = live edge).  k_seg_compact turns the table into a dense list of
-// (slot, chunk, 1/parts) work items - one block-level scan and ONE atomic per block, because returning atomics on a
+// 64-byte (slot, chunk, ...) work items - one block-level scan and ONE atomic per block, because returning atomics on a
 // single word saturate near 90/us chip-wide and a per-item dequeue would cost more than the work itself.
 // ctrl[2] = items reserved, ctrl[3] = 1 when the list ran over (the edge kernel then scans the table).
 __global__ __launch_bounds__(256) void k_seg_compact(const int32_t* __restrict__ seg_ns, int n_slots,
                                                      const double* __restrict__ a6, const double* __restrict__ b6,
-                                                     int32_t* __restrict__ ctrl, int32_t* __restrict__ list, int cap) {
+                                                     int32_t* __restrict__ ctrl, WorkItem* __restrict__ list, int cap) {
   __shared__ int wsum[4];
   __shared__ int base_s;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -739,116 +746,80 @@ __global__ __launch_bounds__(256) void k_seg_compact(const int32_t* __restrict__
   __syncthreads();
   int at = base_s + inc - tot;
   for (int w = 0; w < wave; ++w) at += wsum[w];
-  // an item = slot, chunk, 1 / parts of the edge (the cull kernel places its samples with it)
+  // an item (64 bytes) = slot, chunk, samples of the edge | its start point | the step between two samples:
+  // everything the cull kernel needs to place the chunk's samples (to a tolerance, see there)
   for (int j = 0; j < 4; ++j) {
     if (!c[j]) continue;
-    const double inv = 1.0 / edge_parts(a6 + 6 * (size_t)(s0 + j), b6 + 6 * (size_t)(s0 + j));
-    const long long ib = __double_as_longlong(inv);
+    const double* ea = a6 + 6 * (size_t)(s0 + j);
+    const double* eb = b6 + 6 * (size_t)(s0 + j);
+    const double inv = 1.0 / edge_parts(ea, eb);
+    WorkItem it;
+    it.slot = s0 + j;
+    it.ns = seg_ns[s0 + j];
+    it.pad = 0;
+    for (int q = 0; q < 3; ++q) { it.a[q] = ea[q]; it.step[q] = (eb[q] - ea[q]) * inv; }
     for (int k = 0; k < c[j]; ++k, ++at) {
-      if (at < cap) {
-        int4 it;
-        it.x = s0 + j; it.y = k; it.z = (int)(uint32_t)(unsigned long long)ib; it.w = (int)(uint32_t)((unsigned long long)ib >> 32);
-        reinterpret_cast<int4*>(list)[at] = it;
-      } else {
-        ctrl[3] = 1;
-      }
+      if (at < cap) { it.chunk = k; list[at] = it; }
+      else ctrl[3] = 1;
     }
   }
 }
 
+// The exact kernel's wave w looks at items w + W * lane of each window of 64 W items (W = its wave count); their
+// masks are stored so that this is one contiguous 512-byte read.
+__device__ __forceinline__ size_t mask_slot(int e, int W) {
+  const int win = e / (64 * W), r = e - win * 64 * W;
+  return (size_t)win * 64 * W + (size_t)(r % W) * 64 + (size_t)(r / W);
+}
+
 // Lean, high-occupancy pass in front of the exact kernel: looks up the clearance bits of every pose (one thread
-// each, blocks [0, pose_blocks)) and of every sample of every (edge, chunk) item (one wavefront per item, the
-// other blocks) and keeps only what needs an exact test: pose_list (ctrl[13] entries) and list2 (ctrl[12] entries
-// of 4 ints: slot, chunk, 64-bit sample mask).  Everything else is answered here (pose_hit = 0; an edge whose
-// chunks are all dropped keeps its preset "free").  One atomic per workgroup.
-#define CULL_KEEP 48
-__global__ __launch_bounds__(256) void k_cull(EnvView env, RobotView rob, const double* __restrict__ pos6, int n_pose,
-                                              int pose_blocks, const int32_t* __restrict__ live_flags,
-                                              uint8_t* __restrict__ pose_hit, int32_t* __restrict__ pose_list,
-                                              const double* __restrict__ a6, const double* __restrict__ b6,
-                                              const int32_t* __restrict__ seg_ns,
-                                              const int32_t* __restrict__ list, int32_t* __restrict__ list2,
-                                              int32_t* __restrict__ ctrl) {
-  __shared__ int wcnt[4];
-  __shared__ int base_s;
-  __shared__ int32_t keep[4][CULL_KEEP][4];
+// each, blocks [0, pose_blocks)) and of every sample of every (edge, chunk) work item (one wavefront per item, the
+// other blocks).  A pose that needs the exact test gets pose_hit = 2, the others are answered here (0); an item
+// gets the 64-bit mask of its samples that need the exact test (0 = drop the item; an edge whose items are all
+// dropped keeps its preset "free").  No atomics, no barriers: the exact kernel scans both arrays.
+// Sample positions are only needed to a tolerance far inside the slack of the clearance bits here, so
+// a + idx * dir / parts becomes a + idx * step.
+__global__ __launch_bounds__(256) void k_cull(EnvView env, const double* __restrict__ pos6, int n_pose, int pose_blocks,
+                                              const int32_t* __restrict__ live_flags, uint8_t* __restrict__ pose_hit,
+                                              const WorkItem* __restrict__ list, unsigned long long* __restrict__ masks,
+                                              int exact_waves, const int32_t* __restrict__ ctrl) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  [[maybe_unused]] const unsigned long long tc0_ = DBG_T();
   if ((int)blockIdx.x < pose_blocks) {
     const int pose = blockIdx.x * 256 + threadIdx.x;
+    if (pose >= n_pose) return;
     bool need = false;
-    if (pose < n_pose) {
-      const bool run = !live_flags || (live_flags[pose] & 3) == 1;   // else not owned / out of limits / host path
-      if (run && env.n_tri != 0) {                                     // (HasMap == false: src/environment.h:307-309)
-        // the bits are built for a sphere around the model origin that holds the robot in every rotation
-        const double o[3] = {pos6[6 * (size_t)pose], pos6[6 * (size_t)pose + 1], pos6[6 * (size_t)pose + 2]};
-        need = !surely_clear(env, o);
-      }
-      if (!need) pose_hit[pose] = 0;
+    const bool run = !live_flags || (live_flags[pose] & 3) == 1;   // else not owned / out of limits / host path
+    if (run && env.n_tri != 0) {                                     // (HasMap == false: src/environment.h:307-309)
+      // the bits are built for a sphere around the model origin that holds the robot in every rotation
+      const double o[3] = {pos6[6 * (size_t)pose], pos6[6 * (size_t)pose + 1], pos6[6 * (size_t)pose + 2]};
+      need = !surely_clear(env, o);
     }
-    const unsigned long long m = __ballot(need);
-    if (lane == 0) wcnt[wave] = __popcll(m);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const int all = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
-      base_s = all > 0 ? atomicAdd(ctrl + 13, all) : 0;
-    }
-    __syncthreads();
-    if (need) {
-      int at = base_s + __popcll(m & ((1ULL << lane) - 1ULL));
-      for (int w = 0; w < wave; ++w) at += wcnt[w];
-      pose_list[at] = pose;
-    }
-#ifdef SFFK_DEBUG_COUNTERS
-    if (lane == 0) { atomicAdd(&g_dbg[12], DBG_T() - tc0_); atomicAdd(&g_dbg[13], 1ULL); atomicMax(&g_dbg[14], DBG_T() - tc0_); }
-#endif
+    pose_hit[pose] = need ? 2 : 0;
     return;
   }
   if (ctrl[3] || env.n_tri == 0) return;     // work list ran over: the exact kernel scans the slot table itself
   const int M = ctrl[2];
   const int cb = blockIdx.x - pose_blocks, nb = gridDim.x - pose_blocks;
   const int W = nb * 4;
-  int kept = 0;   // wave-uniform
-  auto flush_wave = [&]() {   // this wave's buffer is full: write it out with its own atomic
-    int base = 0;
-    if (lane == 0) base = atomicAdd(ctrl + 12, kept);
-    base = __shfl(base, 0);
-    if (lane < kept)
-      for (int q = 0; q < 4; ++q) list2[4 * (size_t)(base + lane) + q] = keep[wave][lane][q];
-    kept = 0;
-  };
-  // Four items per step: their three dependent loads (item -> edge endpoints -> clearance word) are issued
-  // side by side, so a wave pays the memory latency once per four items.  Positions are only needed to a
-  // tolerance far inside the slack of the clearance bits here, so idx * dir / parts becomes a multiplication.
+  // four items per step: their dependent loads (item -> clearance word) are issued side by side
   for (int e = cb + nb * wave; e < M; e += 4 * W) {
-    int slot[4], chunk[4];
-    double inv[4];
+    WorkItem it[4];
     bool val[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       val[u] = e + u * W < M;
-      const int4 it = reinterpret_cast<const int4*>(list)[val[u] ? e + u * W : e];
-      slot[u] = it.x;
-      chunk[u] = it.y;
-      inv[u] = __longlong_as_double((long long)((unsigned long long)(uint32_t)it.z | ((unsigned long long)(uint32_t)it.w << 32)));
-    }
-    double ea[4][3], eb[4][3];
-    int ens[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      for (int k = 0; k < 3; ++k) { ea[u][k] = a6[6 * (size_t)slot[u] + k]; eb[u][k] = b6[6 * (size_t)slot[u] + k]; }
-      ens[u] = seg_ns[slot[u]];
+      it[u] = list[val[u] ? e + u * W : e];
     }
     bool need[4];
     const uint32_t* wp[4];
     int sh[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const int idx = 1 + 64 * chunk[u] + lane;
-      const double t = (double)idx * inv[u];
-      const double C[3] = {ea[u][0] + t * (eb[u][0] - ea[u][0]), ea[u][1] + t * (eb[u][1] - ea[u][1]),
-                           ea[u][2] + t * (eb[u][2] - ea[u][2])};   // the model origin at this sample
-      need[u] = val[u] && idx <= ens[u];
+      const int idx = 1 + 64 * it[u].chunk + lane;
+      const double t = (double)idx;
+      const double C[3] = {it[u].a[0] + t * it[u].step[0], it[u].a[1] + t * it[u].step[1],
+                           it[u].a[2] + t * it[u].step[2]};   // the model origin at this sample
+      need[u] = val[u] && idx <= it[u].ns;
       wp[u] = nullptr;
       sh[u] = 0;
       if (need[u]) {
@@ -872,44 +843,24 @@ __global__ __launch_bounds__(256) void k_cull(EnvView env, RobotView rob, const 
     for (int u = 0; u < 4; ++u) {
       if (wp[u] && ((word[u] >> sh[u]) & 1u)) need[u] = false;
       const unsigned long long nm = __ballot(need[u]);
-      if (nm) {
-        if (kept == CULL_KEEP) flush_wave();
-        if (lane == 0) {
-          keep[wave][kept][0] = slot[u]; keep[wave][kept][1] = chunk[u];
-          keep[wave][kept][2] = (int32_t)(uint32_t)nm; keep[wave][kept][3] = (int32_t)(uint32_t)(nm >> 32);
-        }
-        kept += 1;
-      }
+      if (val[u] && lane == 0) masks[mask_slot(e + u * W, exact_waves)] = nm;
     }
   }
-  if (lane == 0) wcnt[wave] = kept;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const int all = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
-    base_s = all > 0 ? atomicAdd(ctrl + 12, all) : 0;
-  }
-  __syncthreads();
-  int at = base_s;
-  for (int w = 0; w < wave; ++w) at += wcnt[w];
-  if (lane < kept)
-    for (int q = 0; q < 4; ++q) list2[4 * (size_t)(at + lane) + q] = keep[wave][lane][q];
-#ifdef SFFK_DEBUG_COUNTERS
-  if (lane == 0) { atomicAdd(&g_dbg[10], DBG_T() - tc0_); atomicAdd(&g_dbg[11], 1ULL); atomicMax(&g_dbg[15], DBG_T() - tc0_); }
-#endif
 }
 
-// Exact kernel: persistent wavefronts walk the culled lists with a fixed stride (no dequeue atomics): first the
-// poses that need an exact test, then the (edge, chunk) items.  A chunk whose edge already has a hit below its
-// first sample is skipped (only the smallest index matters).
+// Exact kernel: persistent wavefronts scan what the cull left over - wave w looks at entries w + W * lane of a
+// 64 W window, so the survivors (a few percent, clustered along the list) spread evenly over the waves without
+// a compaction step - first the poses marked 2, then the (edge, chunk) items with a non-zero mask.  A chunk whose
+// edge already has a hit below its first sample is skipped (only the smallest index matters).
 __global__ __launch_bounds__(64 * SEG_WAVES) void k_collide_segments_dyn(EnvView env, RobotView rob,
-                                                                         const double* __restrict__ pos6,
-                                                                         const int32_t* __restrict__ pose_list,
+                                                                         const double* __restrict__ pos6, int n_pose,
                                                                          uint8_t* __restrict__ pose_hit,
                                                                          const double* __restrict__ a6,
                                                                          const double* __restrict__ b6,
                                                                          const int32_t* __restrict__ seg_ns, int n_slots,
                                                                          int32_t* __restrict__ ctrl,
-                                                                         const int32_t* __restrict__ list2,
+                                                                         const WorkItem* __restrict__ list,
+                                                                         const unsigned long long* __restrict__ masks,
                                                                          int32_t* __restrict__ first_hit,
                                                                          int32_t* __restrict__ overflow_flag) {
   extern __shared__ double lds_d[];
@@ -925,12 +876,14 @@ __global__ __launch_bounds__(64 * SEG_WAVES) void k_collide_segments_dyn(EnvView
   DBG_DECL
   [[maybe_unused]] const unsigned long long tk_ = DBG_T();
   const int W = gridDim.x * SEG_WAVES;
-  // wave w of block b takes items b + gridDim.x * w + W * i: neighbouring items go to different CUs
-  const int e0 = blockIdx.x + gridDim.x * wave;
-  if (pose_list) {
-    const int NP = ctrl[13];
-    for (int e = e0; e < NP; e += W) {
-      const int pose = pose_list[e];
+  const int w0 = blockIdx.x + gridDim.x * wave;   // neighbouring entries go to different CUs
+  for (int base = 0; base < n_pose; base += 64 * W) {
+    const int mine = base + w0 + W * lane;
+    unsigned long long todo = __ballot(mine < n_pose && pose_hit[mine] == 2);
+    while (todo) {
+      const int l = __ffsll((long long)todo) - 1;
+      todo &= todo - 1;
+      const int pose = base + w0 + W * l;
       double p[6], R[9], c[3];
       pose_frame(rob, pos6, pose, p, R, c);
       const bool hit = pose_exact(env, rob, rtri, stack, cand, p, R, c, lane);
@@ -938,15 +891,23 @@ __global__ __launch_bounds__(64 * SEG_WAVES) void k_collide_segments_dyn(EnvView
     }
   }
   if (!ctrl[3]) {
-    const int M = ctrl[12];
-    for (int e = e0; e < M; e += W) {
-      const int slot = list2[4 * (size_t)e], chunk = list2[4 * (size_t)e + 1];
-      const unsigned long long nm = (unsigned long long)(uint32_t)list2[4 * (size_t)e + 2] |
-                                    ((unsigned long long)(uint32_t)list2[4 * (size_t)e + 3] << 32);
-      if (chunk > 0 && first_hit[slot] <= 64 * chunk) continue;
-      double a[6], b[6];
-      for (int k = 0; k < 6; ++k) { a[k] = a6[6 * (size_t)slot + k]; b[k] = b6[6 * (size_t)slot + k]; }
-      segment_chunk(env, rob, rtri, stack, cand, queue, a, b, slot, chunk, true, nm, first_hit, overflow_flag, lane DBG_PASS);
+    const int M = ctrl[2];
+    for (int base = 0; base < M; base += 64 * W) {
+      const int mine = base + w0 + W * lane;
+      const unsigned long long m = mine < M ? masks[(size_t)base + (size_t)w0 * 64 + lane] : 0ULL;
+      unsigned long long todo = __ballot(m != 0ULL);
+      while (todo) {
+        const int l = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int e = base + w0 + W * l;
+        const unsigned long long nm = (unsigned long long)(uint32_t)__shfl((int)(uint32_t)m, l) |
+                                      ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(m >> 32), l) << 32);
+        const int slot = list[e].slot, chunk = list[e].chunk;
+        if (chunk > 0 && first_hit[slot] <= 64 * chunk) continue;
+        double a[6], b[6];
+        for (int k = 0; k < 6; ++k) { a[k] = a6[6 * (size_t)slot + k]; b[k] = b6[6 * (size_t)slot + k]; }
+        segment_chunk(env, rob, rtri, stack, cand, queue, a, b, slot, chunk, true, nm, first_hit, overflow_flag, lane DBG_PASS);
+      }
     }
     DBG_ADD(8, DBG_T() - tk_);
     DBG_ADD(9, 1);
@@ -1028,7 +989,7 @@ __global__ __launch_bounds__(256) void k_classify(ClassifyArgs A) {
       if (have) q = same ? (!force && d < pdist - SFFG_TOL)          // src/forest.h:276
                          : (d < A.dist_tree - SFFG_TOL);             // src/forest.h:283
       int rank = 0;
-      for (int j = 0; j < 64; ++j) {
+      for (int j = 0; j < cnt; ++j) {   // (lanes >= cnt hold no hit)
         const int tj = __shfl(t, j), idj = __shfl(id, j), qj = __shfl((int)q, j);
         const double dj = __shfl(d, j);
         if (qj && (tj < t || (tj == t && (dj < d || (dj == d && idj < id))))) ++rank;
@@ -1264,35 +1225,38 @@ void launch_seg_prepare(hipStream_t s, const double* a6, const double* b6, int n
   hipLaunchKernelGGL(k_seg_prepare, dim3((n + 255) / 256), dim3(256), 0, s, a6, b6, n, seg_ns, first_hit, ovf);
 }
 
-// compact -> cull -> exact.  pos6 / pose_list / pose_hit may be null (edges only).
+// compact -> cull -> exact.  pos6 / pose_hit may be null (edges only).
 void launch_round_collide(hipStream_t s, const EnvView& env, const RobotView& rob, const double* pos6, int n_pose,
-                          const int32_t* live_flags, uint8_t* pose_hit, int32_t* pose_list, const double* a6,
-                          const double* b6, const int32_t* seg_ns, int n_slots, int32_t* ctrl, int32_t* list,
-                          int list_cap, int32_t* list2, int32_t* first_hit, int32_t* overflow_flag) {
+                          const int32_t* live_flags, uint8_t* pose_hit, const double* a6, const double* b6,
+                          const int32_t* seg_ns, int n_slots, int32_t* ctrl, void* list, int list_cap, void* masks,
+                          int32_t* first_hit, int32_t* overflow_flag) {
+  if (!pose_hit) n_pose = 0;
   if (n_slots <= 0 && n_pose <= 0) return;
   size_t lds = collide_lds_bytes(rob.n_tri, SEG_WAVES);
   // 2 workgroups of 4 waves per CU = what the exact kernel's register budget keeps resident (256 CUs)
-  static const int blocks = getenv("SFFGPU_SEG_BLOCKS") ? atoi(getenv("SFFGPU_SEG_BLOCKS")) : 512;
+  static const int blocks = std::min(4096, std::max(1, getenv("SFFGPU_SEG_BLOCKS") ? atoi(getenv("SFFGPU_SEG_BLOCKS")) : 512));
   static const int cull_blocks = getenv("SFFGPU_CULL_BLOCKS") ? atoi(getenv("SFFGPU_CULL_BLOCKS")) : 2048;
   const int cap_override = getenv("SFFGPU_SEG_LISTCAP") ? atoi(getenv("SFFGPU_SEG_LISTCAP")) : -1;  // tests
   if (cap_override >= 0 && cap_override < list_cap) list_cap = cap_override;
   if (n_slots > 0)
     hipLaunchKernelGGL(k_seg_compact, dim3((n_slots + 1023) / 1024), dim3(256), 0, s, seg_ns, n_slots, a6, b6, ctrl,
-                       list, list_cap);
-  const int pose_blocks = pose_list ? (n_pose + 255) / 256 : 0;
-  hipLaunchKernelGGL(k_cull, dim3(pose_blocks + (n_slots > 0 ? cull_blocks : 0)), dim3(256), 0, s, env, rob, pos6,
-                     n_pose, pose_blocks, live_flags, pose_hit, pose_list, a6, b6, seg_ns, list, list2, ctrl);
-  hipLaunchKernelGGL(k_collide_segments_dyn, dim3(blocks), dim3(64 * SEG_WAVES), lds, s, env, rob, pos6, pose_list,
-                     pose_hit, a6, b6, seg_ns, n_slots, ctrl, list2, first_hit, overflow_flag);
+                       static_cast<WorkItem*>(list), list_cap);
+  const int pose_blocks = (n_pose + 255) / 256;
+  hipLaunchKernelGGL(k_cull, dim3(pose_blocks + (n_slots > 0 ? cull_blocks : 0)), dim3(256), 0, s, env, pos6, n_pose,
+                     pose_blocks, live_flags, pose_hit, static_cast<const WorkItem*>(list),
+                     static_cast<unsigned long long*>(masks), blocks * SEG_WAVES, ctrl);
+  hipLaunchKernelGGL(k_collide_segments_dyn, dim3(blocks), dim3(64 * SEG_WAVES), lds, s, env, rob, pos6, n_pose,
+                     pose_hit, a6, b6, seg_ns, n_slots, ctrl, static_cast<const WorkItem*>(list),
+                     static_cast<const unsigned long long*>(masks), first_hit, overflow_flag);
 }
 
 void launch_collide_segments_dyn(hipStream_t s, const EnvView& env, const RobotView& rob, const double* a6,
                                  const double* b6, const int32_t* seg_ns, int n_slots, int32_t* ctrl,
-                                 int32_t* list, int list_cap, int32_t* list2, int32_t* first_hit,
+                                 void* list, int list_cap, void* masks, int32_t* first_hit,
                                  int32_t* overflow_flag) {
   if (n_slots <= 0) return;
-  launch_round_collide(s, env, rob, nullptr, 0, nullptr, nullptr, nullptr, a6, b6, seg_ns, n_slots, ctrl, list,
-                       list_cap, list2, first_hit, overflow_flag);
+  launch_round_collide(s, env, rob, nullptr, 0, nullptr, nullptr, a6, b6, seg_ns, n_slots, ctrl, list, list_cap, masks,
+                       first_hit, overflow_flag);
 }
 
 }  // namespace sffk
