@@ -111,7 +111,7 @@ def main():
         # passes of this command; FETCH_SIZE doubled per MI355X_MICROARCH.md, gather pattern uncalibrated)
         traffic = None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r1h_bench_pmc_summary.json")))
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r1p_bench_pmc_summary.json")))
             kib = 0.0
             for k in ("sffk::k_grid_query", "sffk::k_sweep"):
                 kib += 2.0 * pm["FETCH_SIZE"][k]["avg_KiB_per_launch"] + pm["WRITE_SIZE"][k]["avg_KiB_per_launch"]
