@@ -61,11 +61,14 @@ class RapidExpTree : public Solver<T, R> {
         sffgpu_rrt_path_plan(r, i, j, ids.data(), len);
         this->plans[(size_t)i * this->numTrees + j].assign(ids.begin(), ids.end());
       }
+    // smoothPaths (src/rrt.h:113-118, :354-379) shortens the plans held by the central tree's links; the matrix
+    // the writers read keeps the copies made in getPaths (:350), so the "smooth" file repeats the raw paths
+    if (P.smoothing) sff_compat::check(sffgpu_rrt_smooth_paths(r) < 0 ? -1 : 0, "rrt smoothing");
     sffgpu_rrt_destroy(r);
     if (SaveGoals <= P.saveOptions) this->saveCities(P.fileNames[SaveGoals]);
     if (SaveTree <= P.saveOptions) this->saveTrees(P.fileNames[SaveTree]);
     if (SaveRaw <= P.saveOptions) this->savePaths(P.fileNames[SaveRaw]);
-    if (P.smoothing) std::cout << "RapidExpTree: path smoothing (src/rrt.h:354-379) is not implemented in this build\n";
+    if (P.smoothing && SaveSmooth <= P.saveOptions) this->savePaths(P.fileNames[SaveSmooth]);
     if (SaveParams <= P.saveOptions) this->saveParams(P.fileNames[SaveParams], st.iterations, st.solved != 0, stopTime - startingTime);
     if (SaveTSP <= P.saveOptions) this->saveTsp(P.fileNames[SaveTSP]);
   }

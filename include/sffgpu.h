@@ -182,6 +182,12 @@ int sffgpu_rrt_get_links(sffgpu_rrt* r, int32_t* tree, int32_t* node1, int32_t* 
  * connected = the central tree's eaten trees + itself; returns their count.  path_plan copies one pair's node ids. */
 int sffgpu_rrt_paths(sffgpu_rrt* r, double* dist, int32_t* connected, int cap_connected);
 int sffgpu_rrt_path_plan(sffgpu_rrt* r, int i, int j, int32_t* node_ids, int cap);
+/* RapidExpTree::smoothPaths (src/rrt.h:354-379), after sffgpu_rrt_paths: shortcuts the plans stored in the central
+ * tree's links (isPathFree batched on the GPU).  The reference's neighboringMatrix - what its writers read - holds
+ * copies made before (src/rrt.h:350), so costs and sffgpu_rrt_path_plan do not change; the shortened plans are
+ * read with sffgpu_rrt_link_plan(k).  Returns the number of link plans. */
+int sffgpu_rrt_smooth_paths(sffgpu_rrt* r);
+int sffgpu_rrt_link_plan(sffgpu_rrt* r, int k, int32_t* node_ids, int cap);
 
 /* Multi-GPU wave protocol (one process per GPU; the exchange itself is the caller's RCCL / gloo
  * all-gather).  Every rank holds a full replica of the forest and of the node store; a round is

@@ -1178,6 +1178,30 @@ struct Rrt {
     }
   }
 
+  // RapidExpTree::smoothPaths (src/rrt.h:354-379): the same far-end shortcutting as the forest's, but on the
+  // plans stored in the central tree's LINKS.  neighboringMatrix received copies of those plans in getPaths
+  // (:350) and every writer reads the matrix, so the reference's outputs do not change; the shortened link
+  // plans are what this restatement exposes.  Reverse-iterator walk restated with forward indices
+  // (tempGoal = g, testNode = t); the erase is [t+1, g).
+  std::vector<std::vector<int>> link_plans;
+  uint64_t smooth_path_free_calls = 0;
+  void smooth_paths() {
+    for (std::vector<int>& plan : link_plans) {
+      int g = (int)plan.size() - 1;
+      while (g > 0) {
+        int t = 0;
+        bool changed = false;
+        while (t < g - 1) {
+          ++smooth_path_free_calls;
+          if (path_free(nodes[plan[t]].pos, nodes[plan[g]].pos)) { changed = true; break; }
+          ++t;
+        }
+        if (changed) plan.erase(plan.begin() + t + 1, plan.begin() + g);
+        g = t;
+      }
+    }
+  }
+
   // post-loop: getConnectedTrees (src/rrt.h:381-393), getPaths (:324-352), Solver::getAllPaths (problemStruct.h:184-253)
   struct PH { int n1 = -1, n2 = -1; double dist = std::numeric_limits<double>::max(); std::vector<int> plan; };
   std::vector<PH> nm;
@@ -1192,6 +1216,7 @@ struct Rrt {
     const int num_roots = cfg.has_goal ? num_trees + 2 : num_trees + 1;
     for (int i = 0; i < num_roots && i < nt; ++i)
       if (eaten[i].size() > max_conn) { max_conn = eaten[i].size(); central = i; connected = eaten[i]; connected.push_back(i); }
+    link_plans.clear();
     for (const RLink& link : links[central]) {
       PH h;
       h.n1 = link.n1; h.n2 = link.n2; h.dist = link.dist;
@@ -1200,6 +1225,7 @@ struct Rrt {
       h.plan.assign(chain.rbegin(), chain.rend());
       for (int n = link.n2;; n = nodes[n].parent) { h.plan.push_back(n); if (nodes[n].d_root == 0) break; }
       NM(nodes[link.n1].root_tree, nodes[link.n2].root_tree) = h;
+      link_plans.push_back(h.plan);   // DistanceHolder::plan of the link itself (the matrix holds a COPY, :350)
     }
     const int nc = (int)connected.size();
     for (int k = 0; k < nc; ++k) {
@@ -1548,6 +1574,17 @@ int sffo_rrt_path_plan(sffo_rrt* h, int i, int j, int32_t* node_ids, int cap) {
   if (r.nm.empty() || i == j) return 0;
   const auto& p = r.NM(i, j).plan;
   for (size_t k = 0; k < p.size() && (int)k < cap; ++k) node_ids[k] = p[k];
+  return (int)p.size();
+}
+int sffo_rrt_smooth(sffo_rrt* h) {
+  h->r.smooth_paths();
+  return (int)h->r.link_plans.size();
+}
+int sffo_rrt_link_plan(sffo_rrt* h, int k, int32_t* node_ids, int cap) {
+  Rrt& r = h->r;
+  if (k < 0 || k >= (int)r.link_plans.size()) return -1;
+  const auto& p = r.link_plans[k];
+  for (size_t q = 0; q < p.size() && (int)q < cap; ++q) node_ids[q] = p[q];
   return (int)p.size();
 }
 int sffo_rrt_get_links(sffo_rrt* h, int32_t* tree, int32_t* n1, int32_t* n2, double* dist, int cap) {

@@ -138,6 +138,10 @@ void sffo_rrt_run(sffo_rrt*, int max_iters);
 void sffo_rrt_get_stats(sffo_rrt*, sffo_rrt_stats*);
 void sffo_rrt_get_nodes(sffo_rrt*, double* pos6, int32_t* parent, int32_t* tree, int32_t* root_tree, int32_t* iter,
                         double* cost, double* dpar);
+/* smoothPaths (src/rrt.h:354-379) on the plans of the central tree's links (after sffo_rrt_paths); returns the
+   number of link plans; sffo_rrt_link_plan reads plan k */
+int sffo_rrt_smooth(sffo_rrt*);
+int sffo_rrt_link_plan(sffo_rrt*, int k, int32_t* node_ids, int cap);
 int sffo_rrt_get_links(sffo_rrt*, int32_t* tree, int32_t* n1, int32_t* n2, double* dist, int cap);
 /* getConnectedTrees + getPaths + getAllPaths (src/rrt.h:381-393, :324-352, src/problemStruct.h:184-253) */
 int sffo_rrt_paths(sffo_rrt*, double* dist);

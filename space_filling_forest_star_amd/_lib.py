@@ -17,7 +17,8 @@ EXPORTED_SYMBOLS = [
     "sffgpu_forest_get_nodes", "sffgpu_forest_get_borders", "sffgpu_forest_fingerprint", "sffgpu_forest_paths",
     "sffgpu_forest_path_plan", "sffgpu_forest_smooth_paths",
     "sffgpu_rrt_create", "sffgpu_rrt_destroy", "sffgpu_rrt_run", "sffgpu_rrt_get_stats", "sffgpu_rrt_get_nodes",
-    "sffgpu_rrt_get_links", "sffgpu_rrt_paths", "sffgpu_rrt_path_plan", "sffgpu_forest_get_frontier",
+    "sffgpu_rrt_get_links", "sffgpu_rrt_paths", "sffgpu_rrt_path_plan", "sffgpu_rrt_smooth_paths",
+    "sffgpu_rrt_link_plan", "sffgpu_forest_get_frontier",
     "sffgpu_forest_in_wave", "sffgpu_forest_round_begin", "sffgpu_forest_round_records", "sffgpu_forest_round_commit",
 ]
 
@@ -124,6 +125,8 @@ def lib():
     L.sffgpu_rrt_get_links.argtypes = [C.c_void_p, c_ip, c_ip, c_ip, c_dp, C.c_int]
     L.sffgpu_rrt_paths.argtypes = [C.c_void_p, c_dp, c_ip, C.c_int]
     L.sffgpu_rrt_path_plan.argtypes = [C.c_void_p, C.c_int, C.c_int, c_ip, C.c_int]
+    L.sffgpu_rrt_smooth_paths.argtypes = [C.c_void_p]
+    L.sffgpu_rrt_link_plan.argtypes = [C.c_void_p, C.c_int, c_ip, C.c_int]
     L.sffgpu_forest_get_frontier.argtypes = [C.c_void_p, c_ip, C.c_int]
     L.sffgpu_forest_in_wave.argtypes = [C.c_void_p]
     L.sffgpu_forest_round_begin.argtypes = [C.c_void_p, c_ip, c_ip]
@@ -425,6 +428,16 @@ class Rrt:
         ids = np.zeros(cap, np.int32)
         k = self.ctx._chk(self.ctx._L.sffgpu_rrt_path_plan(self.h, i, j, _ip(ids), cap))
         return ids[:min(k, cap)].copy()
+
+    def smooth(self, cap=1 << 16):
+        """RapidExpTree::smoothPaths on the central tree's link plans (after paths()); returns the plans"""
+        n = self.ctx._chk(self.ctx._L.sffgpu_rrt_smooth_paths(self.h))
+        out = []
+        for k in range(n):
+            ids = np.zeros(cap, np.int32)
+            m = self.ctx._chk(self.ctx._L.sffgpu_rrt_link_plan(self.h, k, _ip(ids), cap))
+            out.append(ids[:min(m, cap)].copy())
+        return out
 
     def links(self, cap=1 << 16):
         t, n1, n2 = (np.zeros(cap, np.int32) for _ in range(3))

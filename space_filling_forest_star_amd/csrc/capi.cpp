@@ -306,6 +306,26 @@ int sffgpu_rrt_path_plan(sffgpu_rrt* r, int i, int j, int32_t* node_ids, int cap
   for (size_t k = 0; k < p.size() && (int)k < cap; ++k) node_ids[k] = p[k];
   return (int)p.size();
 }
+int sffgpu_rrt_smooth_paths(sffgpu_rrt* r) {
+  if (!r) return SFFGPU_ERR_ARG;
+  Rrt& R = *r->r;
+  if (R.nm.empty()) { r->owner->c->err = "rrt smooth_paths: call sffgpu_rrt_paths first"; return SFFGPU_ERR_STATE; }
+  try {
+    R.smooth_paths();
+  } catch (const HipError& e) {
+    r->owner->c->err = e.msg;
+    return SFFGPU_ERR_HIP;
+  }
+  return (int)R.link_plans.size();
+}
+int sffgpu_rrt_link_plan(sffgpu_rrt* r, int k, int32_t* node_ids, int cap) {
+  if (!r) return SFFGPU_ERR_ARG;
+  Rrt& R = *r->r;
+  if (k < 0 || k >= (int)R.link_plans.size()) return 0;
+  const std::vector<int>& p = R.link_plans[k];
+  for (size_t q = 0; q < p.size() && (int)q < cap; ++q) node_ids[q] = p[q];
+  return (int)p.size();
+}
 int sffgpu_forest_get_frontier(sffgpu_forest* f, int32_t* node_ids, int cap) {
   if (!f) return SFFGPU_ERR_ARG;
   Forest& F = *f->f;

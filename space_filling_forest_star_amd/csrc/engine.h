@@ -313,6 +313,8 @@ struct Rrt {
   std::vector<PathHolder> nm;         // n_trees x n_trees, symmetric
   std::vector<int> connected;
   void get_paths();
+  std::vector<std::vector<int>> link_plans;   // plans of the central tree's links (what smoothPaths works on)
+  void smooth_paths();                        // src/rrt.h:354-379, edge checks batched on the GPU
   std::vector<double> pend_pos;       // accepted nodes of the current wave not yet in the device store
   std::vector<int32_t> pend_tree;
   bool defer_append = false;

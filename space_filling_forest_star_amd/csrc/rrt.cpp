@@ -582,6 +582,41 @@ void Rrt::run(int max_iters) {
 }
 
 // RapidExpTree::getConnectedTrees (src/rrt.h:381-393) + getPaths (:324-352)
+// RapidExpTree::smoothPaths (src/rrt.h:354-379): walk every link plan from its far end (index g) and connect it
+// to the EARLIEST node t < g-1 whose straight edge is free, dropping the nodes in between.  The reference
+// tests t = 0, 1, ... one isPathFree at a time; here all candidate edges of one g go to the GPU in one batch and
+// the first free one is taken (isPathFree is pure).  It shortens the plans stored in the central tree's links;
+// neighboringMatrix holds copies made earlier (:350) and every writer reads the matrix, so - as in the
+// reference - the saved paths and costs do not change.
+void Rrt::smooth_paths() {
+  for (std::vector<int>& plan : link_plans) {
+    int g = (int)plan.size() - 1;
+    while (g > 0) {
+      const int m = g - 1;   // candidates t = 0 .. g-2
+      std::vector<uint8_t> fr(std::max(m, 0));
+      std::vector<int32_t> fh(std::max(m, 0)), nsv(std::max(m, 0));
+      if (m > 0) {
+        std::vector<double> a((size_t)m * 6), b((size_t)m * 6);
+        for (int t = 0; t < m; ++t) {
+          memcpy(&a[6 * (size_t)t], nodes[plan[t]].pos, 48);
+          memcpy(&b[6 * (size_t)t], nodes[plan[g]].pos, 48);
+        }
+        ctx->collide_segments(a.data(), b.data(), m, fr.data(), fh.data(), nsv.data());
+      }
+      int t = 0;
+      bool changed = false;
+      while (t < g - 1) {
+        st.path_free_calls += 1;
+        st.collide_calls += fh[t] > 0 ? (uint64_t)fh[t] : (uint64_t)nsv[t];
+        if (fr[t]) { changed = true; break; }
+        ++t;
+      }
+      if (changed) plan.erase(plan.begin() + t + 1, plan.begin() + g);
+      g = t;
+    }
+  }
+}
+
 void Rrt::get_paths() {
   const int nt = (int)trees.size();
   nm.assign((size_t)nt * nt, PathHolder());
@@ -596,6 +631,7 @@ void Rrt::get_paths() {
       connected = eaten[i];
       connected.push_back(i);
     }
+  link_plans.clear();
   for (const RLink& link : links[central]) {
     PathHolder h;
     h.n1 = link.n1;
@@ -613,6 +649,7 @@ void Rrt::get_paths() {
     }
     const int a = nodes[link.n1].root_tree, b = nodes[link.n2].root_tree;   // :350 neighboringMatrix(Root ids)
     nm[(size_t)std::min(a, b) * nt + std::max(a, b)] = h;
+    link_plans.push_back(h.plan);   // the link's own DistanceHolder::plan; the matrix keeps a copy (:350)
   }
   // Solver::getAllPaths (src/problemStruct.h:184-253), called right after getPaths (src/rrt.h:106-107)
   auto NM = [&](int i, int j) -> PathHolder& { return nm[(size_t)std::min(i, j) * nt + std::max(i, j)]; };

@@ -114,6 +114,8 @@ def lib():
     L.sffo_rrt_paths.argtypes = [C.c_void_p, c_dp]
     L.sffo_rrt_path_plan.argtypes = [C.c_void_p, C.c_int, C.c_int, c_ip, C.c_int]
     L.sffo_rrt_get_links.argtypes = [C.c_void_p, c_ip, c_ip, c_ip, c_dp, C.c_int]
+    L.sffo_rrt_smooth.argtypes = [C.c_void_p]
+    L.sffo_rrt_link_plan.argtypes = [C.c_void_p, C.c_int, c_ip, C.c_int]
     _LIB = L
     return L
 
@@ -338,3 +340,13 @@ class Rrt:
         ids = np.zeros(cap, np.int32)
         k = lib().sffo_rrt_path_plan(self.h, i, j, ip(ids), cap)
         return ids[:min(k, cap)].copy()
+
+    def smooth(self, cap=1 << 16):
+        """smoothPaths on the central tree's link plans (after paths()); returns the list of plans"""
+        n = lib().sffo_rrt_smooth(self.h)
+        out = []
+        for k in range(n):
+            ids = np.zeros(cap, np.int32)
+            m = lib().sffo_rrt_link_plan(self.h, k, ip(ids), cap)
+            out.append(ids[:m].copy())
+        return out

@@ -427,6 +427,17 @@ def test_rrt_identical(S, ctx, name, optimize, n_roots, goal, bias, iters):
         for a in range(nt):
             for b in range(a + 1, nt):
                 assert np.array_equal(ro.plan(a, b), rg.plan(a, b))
+        if wave == 0:
+            # RapidExpTree::smoothPaths (src/rrt.h:354-379): the link plans shrink identically, and - as in the
+            # reference, whose matrix holds earlier copies - the cost matrix and matrix plans stay what they were
+            po = ro.smooth() if not hasattr(ro, "_smoothed") else ro._smoothed
+            ro._smoothed = po
+            pg = rg.smooth()
+            assert len(po) == len(pg)
+            for x, y in zip(po, pg):
+                assert np.array_equal(x, y)
+            dg2, _ = rg.paths(nt)
+            assert np.array_equal(dg, dg2)
         if wave != 1:
             assert sg["waves"] < so["iterations"] or so["iterations"] < 8
         rg.close()

@@ -135,3 +135,34 @@ def test_oracle_regression_fixture(golden_dir):
         got = {"n_nodes": int(s["n_nodes"]), "iterations": int(s["iterations"]), "collide_calls": int(s["collide_calls"]),
                "parent_sum": int(n["parent"].astype(np.int64).sum()), "cost_sum": float(n["cost"].sum()).hex()}
         assert got == gold[key], key
+
+
+def test_rrt_smoothing_only_shortens_link_plans():
+    """RapidExpTree::smoothPaths (src/rrt.h:354-379) works on the central tree's link plans: every smoothed plan is
+    a subsequence of the raw one with the same end points, its new edges are collision-free, and the matrix
+    (copies made in getPaths, src/rrt.h:350) is untouched."""
+    sc = common.scenario("triang")
+    w = O.World(sc["env"], sc["robot"], O.TRIG_LIBM)
+    pts = sc["xml_points"]
+    r = O.Rrt(w, pts[:3], sc["limits"], dist_tree=sc["dist_tree"], sampling_dist=sc["sampling_dist"], dim=6,
+              max_iterations=2500, seed=5)
+    r.run()
+    d0, c0 = r.paths(3)
+    raw = [r.plan(a, b) for a in range(3) for b in range(a + 1, 3)]
+    nodes = r.nodes()
+    plans = r.smooth()
+    assert len(plans) >= 1
+    shortened = 0
+    for p in plans:
+        cands = [q for q in raw if len(q) and q[0] == p[0] and q[-1] == p[-1]]
+        assert cands, "a link plan keeps its end points"
+        q = list(cands[0])
+        it = iter(q)
+        assert all(any(x == y for y in it) for x in p), "subsequence of the raw plan"
+        shortened += len(p) < len(q)
+        for a, b in zip(p[:-1], p[1:]):
+            if abs(q.index(a) - q.index(b)) > 1:
+                assert w.path_free(nodes["pos"][a], nodes["pos"][b])[0]
+    d1, c1 = r.paths(3)
+    assert np.array_equal(d0, d1) and c0 == c1
+    assert shortened >= 1
