@@ -58,11 +58,12 @@ def main():
     ctx.upload_robot(sc["robot"])
     # 10 seeded collision-free roots (identical on every rank): drawn with the GPU collision kernel
     roots = common.free_roots(lambda p: int(ctx.collide_poses(p[None, :])[0]), sc["limits"], 10, seed=1)
-    # multi-GPU: ONE forest shared by all ranks.  Every wave holds `--wave` slots PER GPU and the node budget
-    # grows with the rank count (weak scaling: per-GPU work fixed, K waves stay inside the budget); rank r evaluates candidates i with i % world == r, the answers
-    # are all-gathered over RCCL once per round and every rank replays the identical commit.
+    # multi-GPU (BASELINE configs[3]): the SAME forest and the same 1 M-node budget, the wave's sample batch
+    # sharded over the ranks (strong scaling: total work fixed).  Rank r evaluates candidates i with
+    # i % world == r, the answers are all-gathered over RCCL once per round and every rank replays the identical
+    # commit, so the result equals the 1-GPU run bit for bit.
     forest = S.Forest(ctx, roots, sc["limits"], dist_tree=sc["dist_tree"], sampling_dist=sc["sampling_dist"], dim=6,
-                      max_iterations=2**31 - 1, node_budget=args.budget * world, wave=args.wave * world, seed=args.seed,
+                      max_iterations=2**31 - 1, node_budget=args.budget, wave=args.wave, seed=args.seed,
                       rank=rank, world=world)
 
     def run_waves(k):
@@ -127,14 +128,14 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / max(1, steps_done),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {
                 "workload": "dense_3D.obj (1832 tris) + robot_cylinder_small (124 tris), 6-DoF, 10 seeded roots, SFF, "
-                            "circum=14 dtree=18, 1M-node budget; step = one wave of %d frontier slots" % (args.wave * world),
-                "wave": args.wave * world, "wave_per_gpu": args.wave, "node_budget": args.budget * world, "seed": args.seed,
+                            "circum=14 dtree=18, 1M-node budget; step = one wave of %d frontier slots" % args.wave,
+                "wave": args.wave, "wave_per_gpu": args.wave // world, "node_budget": args.budget, "seed": args.seed,
                 "nodes_at_start": s0["n_nodes"], "nodes_at_end": s1["n_nodes"],
                 "parallelism": "1 GPU" if world == 1 else
                 "one forest, wave slots sharded over %d GPUs (i %% world), RCCL all-gather of answer records per round" % world,

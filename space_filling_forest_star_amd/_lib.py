@@ -467,10 +467,10 @@ def exchange_records(local, group=None):
         cap = _XCHG["cap"]
         key = (cap, world, str(dev))
         if key not in _XCHG["bufs"]:
-            _XCHG["bufs"] = {key: (torch.zeros(1 + cap, dtype=torch.int32).pin_memory() if dev.type == "cuda"
+            _XCHG["bufs"][key] = (torch.zeros(1 + cap, dtype=torch.int32).pin_memory() if dev.type == "cuda"
                                    else torch.zeros(1 + cap, dtype=torch.int32),
                                    torch.zeros(1 + cap, dtype=torch.int32, device=dev),
-                                   torch.zeros(world * (1 + cap), dtype=torch.int32, device=dev))}
+                                   torch.zeros(world * (1 + cap), dtype=torch.int32, device=dev))
         host, send, recv = _XCHG["bufs"][key]
         hv = host.numpy()
         hv[0] = n
@@ -482,9 +482,9 @@ def exchange_records(local, group=None):
         counts = allh[:, 0].astype(np.int32)
         if int(counts.max()) <= cap:
             out = np.concatenate([allh[r, 1:1 + counts[r]] for r in range(world)]) if counts.sum() else np.zeros(0, np.int32)
-            # keep the bound comfortable: grow ahead of need, identically on every rank
-            if int(counts.max()) * 2 > cap:
-                _XCHG["cap"] = cap * 2
+            # keep the bound comfortable but tight (the whole buffer crosses PCIe twice per round): twice the
+            # longest stream of this round, identically on every rank
+            _XCHG["cap"] = max(1024, int(2 ** int(np.ceil(np.log2(2 * int(counts.max()) + 1)))))
             return out.astype(np.int32), counts
         _XCHG["cap"] = int(2 ** int(np.ceil(np.log2(int(counts.max()) + 1)))) * 2
 

@@ -235,7 +235,10 @@ struct Forest {
     }
   };
   std::vector<Cand> cands;   // storage (only grows); the current round uses the first n_cands
-  std::vector<int> round_todo;       // the other candidates, ascending
+  std::vector<int> round_todo;       // the other candidates, ascending (own shard after round_begin, all ranks' after the exchange)
+  const double* round_hpos = nullptr; // the round's sample positions / parent distances / limit flags for ALL
+  const double* round_hpd = nullptr;  // candidates (pinned early block, valid until the next round_begin)
+  const uint8_t* round_hlim = nullptr;
   std::vector<uint8_t> round_skip;   // per candidate: 1 = the replay has nothing to do (outside the limits / settled by this rank)
   int n_cands = 0;
   std::vector<int32_t> records;  // this rank's answers of the pending round (int32 stream)

@@ -501,7 +501,6 @@ void Forest::round_begin() {
   const uint8_t* hlim = reinterpret_cast<const uint8_t*>(ho + o_lim);
   const uint8_t* hpose = reinterpret_cast<const uint8_t*>(ho + o_pose);
   const uint8_t* hcode = reinterpret_cast<const uint8_t*>(ho + o_code);
-  auto mine_shard = [&](int i) { return i % cfg.world == cfg.rank; };
 
   // ---- read the answers in two passes: samples, neighbour records and edge sample counts as soon as the early
   // copy has landed (the collision kernels are still running), the pose / edge answers after the final sync.
@@ -512,12 +511,16 @@ void Forest::round_begin() {
   std::vector<Fix> fixes;       // single edges to redo (triangle candidate list overflow)
   { auto tw = Clock::now(); HIPCHK(hipEventSynchronize(c.ev_early)); g_wait[0] += ms_since(tw); }
   auto _t2 = Clock::now();
-  for (int i = 0; i < n; ++i) {
+  round_hpos = hpos;
+  round_hpd = hpd;
+  round_hlim = hlim;
+  // (another rank's sample is filled in from its record, if it sends one)
+  for (int i = cfg.rank; i < n; i += cfg.world) {
     Cand& cd = cands[i];
     memcpy(cd.pos, hpos + 6 * (size_t)i, sizeof cd.pos);
     cd.in_lim = hlim[i] != 0;
     cd.pdist = hpd[i];
-    if (!cd.in_lim || !mine_shard(i)) continue;
+    if (!cd.in_lim) continue;
     if (hflags[i] & 2) { slow.push_back(i); continue; }
     cd.answered = true;
     st.poses_executed += 1;
@@ -552,10 +555,11 @@ void Forest::round_begin() {
     for (int k = 0; k < 4; ++k) bulk_counts[k] += hb[k];
   }
   // the replay's work list: samples inside the limits that were not settled on the device
-  round_skip.assign((size_t)n, 0);
-  round_todo.clear();
+  round_skip.assign((size_t)n, cfg.world > 1 ? 1 : 0);   // (another rank's sample joins the list in round_commit
+  round_todo.clear();                                     //  if its owner reports it)
   g_cnt[0] += (uint64_t)n;
-  for (int i = 0; i < n; ++i) {
+  for (int i = cfg.rank; i < n; i += cfg.world) {
+    round_skip[i] = 0;
     if (settle_on_device ? hcode[i] != 0 : hlim[i] == 0) {   // settled (1) / outside the limits (2)
       round_skip[i] = 1;
       g_cnt[1] += 1;
@@ -596,7 +600,7 @@ void Forest::round_begin() {
       if (f.slot == 0) { fix_a.insert(fix_a.end(), ex, ex + 6); fix_b.insert(fix_b.end(), cd.pos, cd.pos + 6); }
       else {
         const Nb& nb = cd.nbs[f.slot - 1];
-        const double* npos = nb.id >= 0 ? nodes[nb.id].pos : cands[-1 - nb.id].pos;
+        const double* npos = nb.id >= 0 ? nodes[nb.id].pos : round_hpos + 6 * (size_t)(-1 - nb.id);
         if (nb.same_tree) { fix_a.insert(fix_a.end(), npos, npos + 6); fix_b.insert(fix_b.end(), cd.pos, cd.pos + 6); }
         else if (nb.id == goal_node && goal_node >= 0) { fix_a.insert(fix_a.end(), cd.pos, cd.pos + 6); fix_b.insert(fix_b.end(), npos, npos + 6); }
         else { fix_a.insert(fix_a.end(), ex, ex + 6); fix_b.insert(fix_b.end(), npos, npos + 6); }
@@ -660,7 +664,7 @@ void Forest::round_begin() {
           nb.order = nodes[id].idx_in_tree;
         } else {
           int cc = id - Tb;
-          if (!cands[cc].in_lim) continue;
+          if (!round_hlim[cc]) continue;
           nb.id = -1 - cc;
           nb.tree = nodes[cands[cc].expanded].tree;
           nb.order = 0x40000000 + cc;
@@ -681,7 +685,7 @@ void Forest::round_begin() {
       });
       // everything after the first STORE neighbour of another tree is unreachable (:296-299)
       for (Nb& nb : all) {
-        const double* npos = nb.id >= 0 ? nodes[nb.id].pos : cands[-1 - nb.id].pos;
+        const double* npos = nb.id >= 0 ? nodes[nb.id].pos : round_hpos + 6 * (size_t)(-1 - nb.id);
         if (nb.same_tree) nb.seg = add_seg(npos, cd.pos);     // isPathFree(neighbour, newPoint)  :276
         else if (nb.id == goal_node && goal_node >= 0) nb.seg = add_seg(cd.pos, npos);  // isPathFree(newPoint, goal) :287
         else nb.seg = add_seg(ex.pos, npos);                  // isPathFree(expanded, neighbour)  :288
@@ -807,7 +811,7 @@ void Forest::round_begin() {
       for (int k = 0; k < m; ++k) {
         Cand& cd = cands[maybe[k]];
         for (Member& mb : cd.members) {
-          const double* mp = mb.id >= 0 ? nodes[mb.id].pos : cands[-1 - mb.id].pos;
+          const double* mp = mb.id >= 0 ? nodes[mb.id].pos : round_hpos + 6 * (size_t)(-1 - mb.id);
           mb.seg_f = (int)(sa.size() / 6);
           sa.insert(sa.end(), cd.pos, cd.pos + 6);   // isPathFree(newPoint, neighbor)   :323
           sb.insert(sb.end(), mp, mp + 6);
@@ -844,8 +848,8 @@ void Forest::round_begin() {
   }
 
   // ---- the int32 record stream of the owned candidates (only needed when there are other ranks)
-  for (int i = 0; i < n && cfg.world > 1; ++i) {
-    if (round_skip[i]) continue;
+  for (size_t j = 0; j < round_todo.size() && cfg.world > 1; ++j) {   // (still only this rank's samples)
+    const int i = round_todo[j];
     Cand& cd = cands[i];
     if (!cd.answered) continue;
     records.push_back(i);
@@ -885,7 +889,9 @@ void Forest::round_commit(const int32_t* all, const int32_t* counts, int world) 
   const int n = n_cands;
   auto _t4 = Clock::now();
   // ---- absorb the other ranks' answers
-  uint64_t settled_elsewhere = 0;
+  uint64_t settled_elsewhere = 0, recorded_elsewhere = 0;
+  const size_t own_todo = round_todo.size();
+  std::vector<size_t> run_bounds;   // end of every other rank's run in round_todo
   st.collide_calls += bulk_counts[0];   // this rank's own bulk-settled samples
   st.path_free_calls += bulk_counts[1];
   st.nn_queries += bulk_counts[2];
@@ -910,6 +916,12 @@ void Forest::round_commit(const int32_t* all, const int32_t* counts, int world) 
       Cand& cd = cands[i];
       int flags = p[1], nn = p[4], nm = p[5];
       if (r != cfg.rank) {
+        memcpy(cd.pos, round_hpos + 6 * (size_t)i, sizeof cd.pos);   // (sampling is replicated: every rank has them)
+        cd.pdist = round_hpd[i];
+        cd.in_lim = true;
+        round_skip[i] = 0;
+        round_todo.push_back(i);
+        ++recorded_elsewhere;
         cd.answered = true;
         cd.pose_hit = flags & 1;
         cd.par_free = (flags & 2) != 0;
@@ -938,6 +950,23 @@ void Forest::round_commit(const int32_t* all, const int32_t* counts, int world) 
       }
       p += 6 + 5 * (size_t)nn + 6 * (size_t)nm;
     }
+    if (r != cfg.rank) run_bounds.push_back(round_todo.size());
+  }
+  if (world > 1) {
+    // the work list of the replay: own unsettled samples + every sample another rank sent a record for
+    // (every rank's records come in ascending sample order: merge the runs)
+    size_t sorted_end = own_todo;
+    for (size_t rb : run_bounds) {
+      std::inplace_merge(round_todo.begin(), round_todo.begin() + sorted_end, round_todo.begin() + rb);
+      sorted_end = rb;
+    }
+    // every in-limit sample of another rank is either recorded or counted as settled there
+    uint64_t inlim_all = 0, inlim_own = 0;
+    for (int i = 0; i < n; ++i) inlim_all += round_hlim[i];
+    for (int i = cfg.rank; i < n; i += world) inlim_own += round_hlim[i];
+    const uint64_t inlim_elsewhere = inlim_all - inlim_own;
+    if (inlim_elsewhere != recorded_elsewhere + settled_elsewhere)
+      throw HipError{"forest: answer records missing (a rank did not report all of its samples)"};
   }
   g_sec[4] += ms_since(_t4);
   auto _t5 = Clock::now();
@@ -957,7 +986,6 @@ void Forest::round_commit(const int32_t* all, const int32_t* counts, int world) 
   };
   std::vector<double> app_pos;
   std::vector<int32_t> app_tree;
-  uint64_t unrecorded = 0;
   // (samples outside the limits (:246 !result) and the ones settled by their owner are not on the work list)
   const size_t n_todo = round_todo.size();
   int last_i = -1;
@@ -970,10 +998,7 @@ void Forest::round_commit(const int32_t* all, const int32_t* counts, int world) 
     Cand& cd = cands[i];
     Slot& sl = slots[cd.slot];
     const unsigned iteration = (unsigned)(iter0 + i + 1);
-    if (!cd.answered) {                                        // another rank's sample without a record: settled there
-      if (world > 1 && i % world != cfg.rank) { ++unrecorded; continue; }
-      throw HipError{"forest: a candidate has no answer record"};
-    }
+    if (!cd.answered) throw HipError{"forest: a candidate has no answer record"};
     st.collide_calls += 1;
     if (cd.pose_hit) continue;                                 // :246 env.Collide(newPoint)
     st.path_free_calls += 1;
@@ -1078,8 +1103,6 @@ void Forest::round_commit(const int32_t* all, const int32_t* counts, int world) 
   if (solved) iter = iter0 + last_i + 1;   // the iterations after the solving one were never run
   g_sec[5] += ms_since(_t5);
   auto _t6 = Clock::now();
-  if (!solved && unrecorded != settled_elsewhere)   // (a goal hit stops the replay early: counts then differ legitimately)
-    throw HipError{"forest: answer records missing (a rank did not report all of its samples)"};
   // ---- commit the accepted nodes to the device store (replaces flannIndex->addPoints, :367)
   if (n > 0) c.store_n = N0;
   if (!app_tree.empty()) {
