@@ -59,6 +59,9 @@ int sffgpu_sample_steer(sffgpu_ctx* ctx, const uint64_t* words, const double* ce
 int sffgpu_nodes_reset(sffgpu_ctx* ctx, int capacity);
 int sffgpu_nodes_append(sffgpu_ctx* ctx, const double* pos6, const int32_t* tree_id, int n);
 int sffgpu_nodes_count(sffgpu_ctx* ctx);
+/* Device time of the context's kernels since it was created, measured with HIP events on the library's launch
+ * stream: [0] neighbour query (sweep / grid), [1] collision, [2] sampling; launches = kernel groups timed. */
+int sffgpu_kernel_times(sffgpu_ctx* ctx, double ms[3], uint64_t launches[3]);
 
 /* Exact radius query, replaces Index::radiusSearch (src/forest.h:266-267).  For each of nq
  * queries returns every stored node with 6-D distance < r[q] (true metric of

@@ -18,7 +18,7 @@ EXPORTED_SYMBOLS = [
     "sffgpu_forest_path_plan", "sffgpu_forest_smooth_paths",
     "sffgpu_rrt_create", "sffgpu_rrt_destroy", "sffgpu_rrt_run", "sffgpu_rrt_get_stats", "sffgpu_rrt_get_nodes",
     "sffgpu_rrt_get_links", "sffgpu_rrt_paths", "sffgpu_rrt_path_plan", "sffgpu_rrt_smooth_paths",
-    "sffgpu_rrt_link_plan", "sffgpu_forest_get_frontier",
+    "sffgpu_rrt_link_plan", "sffgpu_kernel_times", "sffgpu_forest_get_frontier",
     "sffgpu_forest_in_wave", "sffgpu_forest_round_begin", "sffgpu_forest_round_records", "sffgpu_forest_round_commit",
 ]
 
@@ -104,6 +104,7 @@ def lib():
     L.sffgpu_nodes_reset.argtypes = [C.c_void_p, C.c_int]
     L.sffgpu_nodes_append.argtypes = [C.c_void_p, c_dp, c_ip, C.c_int]
     L.sffgpu_nodes_count.argtypes = [C.c_void_p]
+    L.sffgpu_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.sffgpu_radius.argtypes = [C.c_void_p, c_dp, C.c_int, c_dp, c_ip, c_ip, c_ip, c_dp, c_ip, C.c_int]
     L.sffgpu_knn.argtypes = [C.c_void_p, c_dp, C.c_int, C.c_int, c_ip, c_ip, c_ip, c_dp, c_ip]
     L.sffgpu_forest_create.argtypes = [C.c_void_p, C.POINTER(ForestCfg), c_dp, C.c_int, C.POINTER(C.c_void_p)]
@@ -225,6 +226,13 @@ class Context:
 
     def nodes_count(self):
         return self._L.sffgpu_nodes_count(self.h)
+
+    def kernel_times(self):
+        """(ms[3], launches[3]) of the neighbour-query / collision / sampling kernels (HIP events)"""
+        ms = (C.c_double * 3)()
+        n = (C.c_uint64 * 3)()
+        self._chk(self._L.sffgpu_kernel_times(self.h, ms, n))
+        return list(ms), list(n)
 
     def radius(self, q6, r, tree=None, max_id=None, cap=256):
         q = _f64(q6, 6)

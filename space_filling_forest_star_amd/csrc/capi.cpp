@@ -97,6 +97,11 @@ int sffgpu_nodes_append(sffgpu_ctx* ctx, const double* pos6, const int32_t* tree
   GUARD(ctx, ctx->c->store_append(pos6, tree_id, n));
 }
 int sffgpu_nodes_count(sffgpu_ctx* ctx) { return ctx ? ctx->c->store_n : SFFGPU_ERR_ARG; }
+int sffgpu_kernel_times(sffgpu_ctx* ctx, double ms[3], uint64_t launches[3]) {
+  if (!ctx || !ms || !launches) return SFFGPU_ERR_ARG;
+  for (int k = 0; k < 3; ++k) { ms[k] = ctx->c->kernel_ms_total(k); launches[k] = ctx->c->kernel_calls[k]; }
+  return SFFGPU_OK;
+}
 
 int sffgpu_radius(sffgpu_ctx* ctx, const double* q6, int nq, const double* r, const int32_t* tree,
                   const int32_t* max_id, int32_t* idx, double* dist, int32_t* cnt, int cap) {
