@@ -159,7 +159,7 @@ Ctx::~Ctx() {
   for (auto e : pool) (void)hipEventDestroy(e);
   DevBuf* bufs[] = {&env_tri, &env_box, &env_plane, &rob_tri, &sx, &sy, &sz, &syaw, &spitch, &sroll, &stree, &spos,
                     &d_a, &d_b, &d_c, &d_d, &d_e, &d_f, &d_g, &d_h, &r_in, &r_out, &r_q, &r_cnt, &r_hidx,
-                    &r_hdist, &r_sega, &r_segb, &r_items, &r_items2, &env_clear, &g_cnt, &g_items, &g_ovfcnt, &g_ovf};
+                    &r_hdist, &r_sega, &r_segb, &r_items, &r_items2, &env_clear, &g_cnt, &g_items, &g_ovfcnt, &g_ovf, &t_cnt, &t_items, &t_ovfcnt, &t_ovf};
   for (DevBuf* b : bufs) b->release();
   for (auto& b : level_box) b.release();
   PinBuf* pins[] = {&h_a, &h_b, &h_c, &h_d, &h_e, &h_f, &h_g, &h_h, &p_in, &p_out};
@@ -477,6 +477,20 @@ void Ctx::grid_setup(const double limits[6], double cell) {
   gridv.items = g_items.as<sffk::GridItem>();
   gridv.ovf_cnt = g_ovfcnt.as<int32_t>();
   gridv.ovf = g_ovf.as<sffk::GridItem>();
+  // the round's own grid: same cells, its own buckets / overflow list, all counters zero between rounds
+  tgridv = gridv;
+  tgridv.bk = 8;
+  tgridv.ovf_cap = 1 << 20;
+  t_cnt.ensure(ncells * sizeof(int32_t));
+  t_items.ensure(ncells * tgridv.bk * sizeof(sffk::GridItem));
+  t_ovfcnt.ensure(16);
+  t_ovf.ensure((size_t)tgridv.ovf_cap * sizeof(sffk::GridItem));
+  HIPCHK(hipMemsetAsync(t_cnt.p, 0, ncells * sizeof(int32_t), stream));
+  HIPCHK(hipMemsetAsync(t_ovfcnt.p, 0, 16, stream));
+  tgridv.cnt = t_cnt.as<int32_t>();
+  tgridv.items = t_items.as<sffk::GridItem>();
+  tgridv.ovf_cnt = t_ovfcnt.as<int32_t>();
+  tgridv.ovf = t_ovf.as<sffk::GridItem>();
   grid_on = true;
   grid_inserted = 0;
 }

@@ -414,6 +414,7 @@ void Forest::round_begin() {
   tmp.st = sffk::NodeStoreMut{c.sx.as<float>(), c.sy.as<float>(), c.sz.as<float>(), c.syaw.as<float>(),
                               c.spitch.as<float>(), c.sroll.as<float>(), c.stree.as<int32_t>(), c.spos.as<double>()};
   tmp.cnt = c.r_cnt.as<int32_t>();
+  tmp.tg = c.tgridv;
   tmp.ctrl = d_ctrl;
   tmp.n_perm = N0;
   tmp.base = Tb;
@@ -423,11 +424,10 @@ void Forest::round_begin() {
   c.time_end();
   // the sweep only serves the queries of this rank's shard (the others are marked inactive)
   c.time_begin(T_SWEEP);
-  // permanent nodes through the grid (27 cells per query), this round's temporaries by a linear slice sweep
-  sffk::launch_grid_query(c.stream, c.gridv, c.store_view(), c.r_q.as<sffk::SweepQuery>(), d_pos, n,
+  // permanent nodes through the grid (27 cells per query); the same walk over the round's own grid finds the
+  // EARLIER samples of this round
+  sffk::launch_grid_query(c.stream, c.gridv, &c.tgridv, c.store_view(), c.r_q.as<sffk::SweepQuery>(), d_pos, n,
                           c.r_cnt.as<int32_t>(), c.r_hidx.as<int32_t>(), c.r_hdist.as<double>(), CAP);
-  sffk::launch_sweep(c.stream, c.store_view(), Tb, n, c.r_q.as<sffk::SweepQuery>(), d_pos, n,
-                     c.r_cnt.as<int32_t>(), c.r_hidx.as<int32_t>(), c.r_hdist.as<double>(), CAP);
   c.time_end();
   st.sweeps += 1;
   st.sweep_nodes += (uint64_t)(N0 + n);
@@ -468,8 +468,9 @@ void Forest::round_begin() {
   const int list_cap = 4 * n * STRIDE + 65536;
   c.r_items.ensure((size_t)list_cap * SFFK_ITEM_BYTES);
   c.r_items2.ensure(((size_t)list_cap + (1u << 20)) * 8);   // (+ one window of the exact kernel, see mask_slot)
+  sffk::TempGridRef tref{c.tgridv, c.sx.as<float>() + Tb, c.sy.as<float>() + Tb, c.sz.as<float>() + Tb, n};
   sffk::launch_round_collide(c.stream, c.envv, c.robv, d_pos, n, ca.rec_flags, d_pose, ca.seg_a, ca.seg_b, ca.seg_ns,
-                             n * STRIDE, ca.ctrl, c.r_items.p, list_cap, c.r_items2.p, ca.first_hit, ca.seg_ovf);
+                             n * STRIDE, ca.ctrl, c.r_items.p, list_cap, c.r_items2.p, ca.first_hit, ca.seg_ovf, &tref);
   c.time_end();
   // samples this rank can settle alone need no replay (with a goal the replay may stop in the middle of the
   // round, so there every sample stays in it)

@@ -90,6 +90,7 @@ struct RobotView {
 // forest rounds only: where k_sample_steer writes the round's temporary store entries and which per-round
 // counters it resets (all null / zero for the plain batch entry point)
 struct RoundTemps {
+  GridView tg;     // per-round grid of the round's own samples (cnt == nullptr: none); same cells as the node grid
   NodeStoreMut st;
   int32_t* cnt;    // n hit counters
   int32_t* ctrl;   // 16 ints zeroed per round (see launch_collide_segments_dyn)
@@ -113,8 +114,11 @@ void launch_sweep(hipStream_t s, const NodeStoreView& st, int first, int n_nodes
                   const double* qpos, int nq, int32_t* cnt, int32_t* hit_idx, double* hit_dist, int cap);
 // grid: insert store entries [first, first+n) / answer the queries from the cells their ball touches
 void launch_grid_insert(hipStream_t s, const GridView& g, const NodeStoreView& st, int first, int n);
-void launch_grid_query(hipStream_t s, const GridView& g, const NodeStoreView& st, const SweepQuery* queries,
-                       const double* qpos, int nq, int32_t* cnt, int32_t* hit_idx, double* hit_dist, int cap);
+// tg (optional): a second grid with the same cells that holds the round's own samples (filled by k_sample_steer,
+// emptied again by k_seg_compact); query i sees its entries with id < max_id like any other
+void launch_grid_query(hipStream_t s, const GridView& g, const GridView* tg, const NodeStoreView& st,
+                       const SweepQuery* queries, const double* qpos, int nq, int32_t* cnt, int32_t* hit_idx,
+                       double* hit_dist, int cap);
 void launch_set_tree(hipStream_t s, int32_t* tree_col, const int32_t* ids, int n, int32_t value);
 
 void launch_collide_poses(hipStream_t s, const EnvView& env, const RobotView& rob, const double* pos6, int n,
@@ -172,9 +176,14 @@ void launch_collide_segments_dyn(hipStream_t s, const EnvView& env, const RobotV
                                  void* list, int list_cap, void* masks, int32_t* first_hit, int32_t* overflow_flag);
 // a forest round: the same pipeline, and the round's poses go through the cull and the exact kernel with the
 // edges (pose_hit: 0 free / 1 hit on return)
+struct TempGridRef {   // the round's own grid + the fp32 coordinates of its n samples (store columns at the temp base)
+  GridView tg;
+  const float *x, *y, *z;
+  int n;
+};
 void launch_round_collide(hipStream_t s, const EnvView& env, const RobotView& rob, const double* pos6, int n_pose,
                           const int32_t* live_flags, uint8_t* pose_hit, const double* a6, const double* b6,
                           const int32_t* seg_ns, int n_slots, int32_t* ctrl, void* list, int list_cap, void* masks,
-                          int32_t* first_hit, int32_t* overflow_flag);
+                          int32_t* first_hit, int32_t* overflow_flag, const TempGridRef* temps);
 
 }  // namespace sffk

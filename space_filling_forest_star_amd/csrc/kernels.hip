@@ -27,6 +27,28 @@ namespace sffk {
 
 using namespace sffg;
 
+__device__ __forceinline__ int grid_coord(float v, float o, float inv, int n) {
+  float f = floorf((v - o) * inv);
+  int c = f < 0.0f ? 0 : (f > (float)(n - 1) ? n - 1 : (int)f);  // NaN compares false twice -> cast of NaN; guarded by callers
+  return c;
+}
+
+__device__ __forceinline__ size_t grid_cell_of(const GridView& g, float x, float y, float z) {
+  const int cx = grid_coord(x, g.ox, g.inv_cell, g.nx), cy = grid_coord(y, g.oy, g.inv_cell, g.ny),
+            cz = grid_coord(z, g.oz, g.inv_cell, g.nz);
+  return ((size_t)cz * g.ny + cy) * g.nx + cx;
+}
+__device__ __forceinline__ void grid_put(const GridView& g, const GridItem& it) {
+  const size_t cell = grid_cell_of(g, it.x, it.y, it.z);
+  const int slot = atomicAdd(g.cnt + cell, 1);
+  if (slot < g.bk) {
+    g.items[cell * g.bk + slot] = it;
+  } else {
+    const int o = atomicAdd(g.ovf_cnt, 1);
+    if (o < g.ovf_cap) g.ovf[o] = it;   // the host checks ovf_cnt against ovf_cap
+  }
+}
+
 // ------------------------------------------------------------------ sample + steer
 __global__ __launch_bounds__(256) void k_sample_steer(const uint64_t* __restrict__ words,
                                                       const int32_t* __restrict__ parent,
@@ -70,7 +92,16 @@ __global__ __launch_bounds__(256) void k_sample_steer(const uint64_t* __restrict
     tmp.st.pitch[t] = ok ? (float)o[4] : nanv;
     tmp.st.roll[t] = ok ? (float)o[5] : nanv;
     for (int k = 0; k < 6; ++k) tmp.st.pos[6 * t + k] = o[k];
-    tmp.st.tree[t] = tmp.st.tree[parent[i]];
+    const int tr = tmp.st.tree[parent[i]];
+    tmp.st.tree[t] = tr;
+    if (ok && tmp.tg.cnt) {   // and into the round's own grid, where the later samples of the round look for it
+      GridItem it;
+      it.x = (float)o[0]; it.y = (float)o[1]; it.z = (float)o[2];
+      it.yaw = (float)o[3]; it.pitch = (float)o[4]; it.roll = (float)o[5];
+      it.id = (int32_t)t;
+      it.tree = tr;
+      grid_put(tmp.tg, it);
+    }
   }
   if (parent_dist) {
     double pd = dist6(c, o);  // parentDistance, src/forest.h:250
@@ -159,12 +190,6 @@ __global__ __launch_bounds__(256) void k_sweep(NodeStoreView st, int first, int 
 }
 
 // ------------------------------------------------------------------ grid neighbour query
-__device__ __forceinline__ int grid_coord(float v, float o, float inv, int n) {
-  float f = floorf((v - o) * inv);
-  int c = f < 0.0f ? 0 : (f > (float)(n - 1) ? n - 1 : (int)f);  // NaN compares false twice -> cast of NaN; guarded by callers
-  return c;
-}
-
 __global__ __launch_bounds__(256) void k_grid_insert(GridView g, NodeStoreView st, int first, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -175,16 +200,7 @@ __global__ __launch_bounds__(256) void k_grid_insert(GridView g, NodeStoreView s
   it.id = id;
   it.tree = st.tree[id];
   if (!(it.x == it.x)) return;  // NaN placeholder
-  const int cx = grid_coord(it.x, g.ox, g.inv_cell, g.nx), cy = grid_coord(it.y, g.oy, g.inv_cell, g.ny),
-            cz = grid_coord(it.z, g.oz, g.inv_cell, g.nz);
-  const size_t cell = ((size_t)cz * g.ny + cy) * g.nx + cx;
-  const int slot = atomicAdd(g.cnt + cell, 1);
-  if (slot < g.bk) {
-    g.items[cell * g.bk + slot] = it;
-  } else {
-    const int o = atomicAdd(g.ovf_cnt, 1);
-    if (o < g.ovf_cap) g.ovf[o] = it;   // the host checks ovf_cnt against ovf_cap
-  }
+  grid_put(g, it);
 }
 
 __device__ __forceinline__ void grid_test(const GridItem& it, const SweepQuery& Q, int q, const NodeStoreView& st,
@@ -213,16 +229,10 @@ __device__ __forceinline__ void grid_test(const GridItem& it, const SweepQuery& 
 // One wavefront per query: the cells touched by the query ball's bounding box are dealt to the
 // lanes (27 cells for the planner's radius), each lane walks its cell's bucket; all lanes then
 // share the overflow list.  Same fp32 superset filter + exact fp64 re-test as the linear sweep.
-__global__ __launch_bounds__(256) void k_grid_query(GridView g, NodeStoreView st, const SweepQuery* __restrict__ queries,
-                                                    const double* __restrict__ qpos, int nq, int32_t* __restrict__ cnt,
-                                                    int32_t* __restrict__ hit_idx, double* __restrict__ hit_dist,
-                                                    int cap) {
-  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
-  if (q >= nq) return;
-  const SweepQuery Q = queries[q];
-  if (!Q.active) return;
-  const float rf = sqrtf(Q.r2f) * 1.000001f;
+__device__ __forceinline__ void grid_walk(const GridView& g, const SweepQuery& Q, int q, int lane, float rf,
+                                          const NodeStoreView& st, const double* __restrict__ qpos,
+                                          int32_t* __restrict__ cnt, int32_t* __restrict__ hit_idx,
+                                          double* __restrict__ hit_dist, int cap) {
   const int lx = grid_coord(Q.x - rf, g.ox, g.inv_cell, g.nx), hx = grid_coord(Q.x + rf, g.ox, g.inv_cell, g.nx);
   const int ly = grid_coord(Q.y - rf, g.oy, g.inv_cell, g.ny), hy = grid_coord(Q.y + rf, g.oy, g.inv_cell, g.ny);
   const int lz = grid_coord(Q.z - rf, g.oz, g.inv_cell, g.nz), hz = grid_coord(Q.z + rf, g.oz, g.inv_cell, g.nz);
@@ -256,6 +266,25 @@ __global__ __launch_bounds__(256) void k_grid_query(GridView g, NodeStoreView st
   int no = g.ovf_cnt[0];
   if (no > g.ovf_cap) no = g.ovf_cap;
   for (int j = lane; j < no; j += 64) grid_test(g.ovf[j], Q, q, st, qpos, cnt, hit_idx, hit_dist, cap);
+}
+
+// One wavefront per query: the cells touched by the query ball's bounding box are dealt to the
+// lanes (27 cells for the planner's radius), each lane walks its cell's bucket; all lanes then
+// share the overflow list.  Same fp32 superset filter + exact fp64 re-test as the linear sweep.  With tg the
+// same walk is repeated over the grid of the round's own samples (query i keeps the ids below its max_id).
+__global__ __launch_bounds__(256) void k_grid_query(GridView g, GridView tg, NodeStoreView st,
+                                                    const SweepQuery* __restrict__ queries,
+                                                    const double* __restrict__ qpos, int nq, int32_t* __restrict__ cnt,
+                                                    int32_t* __restrict__ hit_idx, double* __restrict__ hit_dist,
+                                                    int cap) {
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (q >= nq) return;
+  const SweepQuery Q = queries[q];
+  if (!Q.active) return;
+  const float rf = sqrtf(Q.r2f) * 1.000001f;
+  grid_walk(g, Q, q, lane, rf, st, qpos, cnt, hit_idx, hit_dist, cap);
+  if (tg.cnt) grid_walk(tg, Q, q, lane, rf, st, qpos, cnt, hit_idx, hit_dist, cap);
 }
 
 __global__ __launch_bounds__(256) void k_set_tree(int32_t* __restrict__ tree_col, const int32_t* __restrict__ ids, int n,
@@ -721,10 +750,20 @@ struct WorkItem {   // 64 bytes: one (edge, chunk of 64 samples) unit of collisi
 // ctrl[2] = items reserved, ctrl[3] = 1 when the list ran over (the edge kernel then scans the table).
 __global__ __launch_bounds__(256) void k_seg_compact(const int32_t* __restrict__ seg_ns, int n_slots,
                                                      const double* __restrict__ a6, const double* __restrict__ b6,
-                                                     int32_t* __restrict__ ctrl, WorkItem* __restrict__ list, int cap) {
+                                                     int32_t* __restrict__ ctrl, WorkItem* __restrict__ list, int cap,
+                                                     GridView tg, const float* __restrict__ tx,
+                                                     const float* __restrict__ ty, const float* __restrict__ tz,
+                                                     int n_temps) {
   __shared__ int wsum[4];
   __shared__ int base_s;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (tg.cnt) {   // housekeeping: the round's own grid has been read (k_grid_query), empty the cells it used
+    for (int t = blockIdx.x * 256 + threadIdx.x; t < n_temps; t += gridDim.x * 256) {
+      const float x = tx[t];
+      if (x == x) tg.cnt[grid_cell_of(tg, x, ty[t], tz[t])] = 0;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) tg.ovf_cnt[0] = 0;
+  }
   const int s0 = (blockIdx.x * 256 + threadIdx.x) * 4;
   int c[4], tot = 0;
   for (int j = 0; j < 4; ++j) {
@@ -1181,11 +1220,13 @@ void launch_grid_insert(hipStream_t s, const GridView& g, const NodeStoreView& s
   if (n <= 0) return;
   hipLaunchKernelGGL(k_grid_insert, dim3((n + 255) / 256), dim3(256), 0, s, g, st, first, n);
 }
-void launch_grid_query(hipStream_t s, const GridView& g, const NodeStoreView& st, const SweepQuery* queries,
-                       const double* qpos, int nq, int32_t* cnt, int32_t* hit_idx, double* hit_dist, int cap) {
+void launch_grid_query(hipStream_t s, const GridView& g, const GridView* tg, const NodeStoreView& st,
+                       const SweepQuery* queries, const double* qpos, int nq, int32_t* cnt, int32_t* hit_idx,
+                       double* hit_dist, int cap) {
   if (nq <= 0) return;
-  hipLaunchKernelGGL(k_grid_query, dim3((nq + 3) / 4), dim3(256), 0, s, g, st, queries, qpos, nq, cnt, hit_idx,
-                     hit_dist, cap);
+  GridView none{};
+  hipLaunchKernelGGL(k_grid_query, dim3((nq + 3) / 4), dim3(256), 0, s, g, tg ? *tg : none, st, queries, qpos, nq, cnt,
+                     hit_idx, hit_dist, cap);
 }
 void launch_set_tree(hipStream_t s, int32_t* tree_col, const int32_t* ids, int n, int32_t value) {
   if (n <= 0) return;
@@ -1225,11 +1266,12 @@ void launch_seg_prepare(hipStream_t s, const double* a6, const double* b6, int n
   hipLaunchKernelGGL(k_seg_prepare, dim3((n + 255) / 256), dim3(256), 0, s, a6, b6, n, seg_ns, first_hit, ovf);
 }
 
-// compact -> cull -> exact.  pos6 / pose_hit may be null (edges only).
+// compact -> cull -> exact.  pos6 / pose_hit may be null (edges only); temps (optional) = the round's own grid
+// and the fp32 coordinates of its n_temps samples, emptied by the compaction launch.
 void launch_round_collide(hipStream_t s, const EnvView& env, const RobotView& rob, const double* pos6, int n_pose,
                           const int32_t* live_flags, uint8_t* pose_hit, const double* a6, const double* b6,
                           const int32_t* seg_ns, int n_slots, int32_t* ctrl, void* list, int list_cap, void* masks,
-                          int32_t* first_hit, int32_t* overflow_flag) {
+                          int32_t* first_hit, int32_t* overflow_flag, const TempGridRef* temps) {
   if (!pose_hit) n_pose = 0;
   if (n_slots <= 0 && n_pose <= 0) return;
   size_t lds = collide_lds_bytes(rob.n_tri, SEG_WAVES);
@@ -1240,7 +1282,8 @@ void launch_round_collide(hipStream_t s, const EnvView& env, const RobotView& ro
   if (cap_override >= 0 && cap_override < list_cap) list_cap = cap_override;
   if (n_slots > 0)
     hipLaunchKernelGGL(k_seg_compact, dim3((n_slots + 1023) / 1024), dim3(256), 0, s, seg_ns, n_slots, a6, b6, ctrl,
-                       static_cast<WorkItem*>(list), list_cap);
+                       static_cast<WorkItem*>(list), list_cap, temps ? temps->tg : GridView{}, temps ? temps->x : nullptr,
+                       temps ? temps->y : nullptr, temps ? temps->z : nullptr, temps ? temps->n : 0);
   const int pose_blocks = (n_pose + 255) / 256;
   hipLaunchKernelGGL(k_cull, dim3(pose_blocks + (n_slots > 0 ? cull_blocks : 0)), dim3(256), 0, s, env, pos6, n_pose,
                      pose_blocks, live_flags, pose_hit, static_cast<const WorkItem*>(list),
@@ -1256,7 +1299,7 @@ void launch_collide_segments_dyn(hipStream_t s, const EnvView& env, const RobotV
                                  int32_t* overflow_flag) {
   if (n_slots <= 0) return;
   launch_round_collide(s, env, rob, nullptr, 0, nullptr, nullptr, a6, b6, seg_ns, n_slots, ctrl, list, list_cap, masks,
-                       first_hit, overflow_flag);
+                       first_hit, overflow_flag, nullptr);
 }
 
 }  // namespace sffk
