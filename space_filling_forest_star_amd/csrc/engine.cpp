@@ -635,10 +635,12 @@ void Ctx::sample_steer(const uint64_t* words, const double* center6, int n, doub
 }
 
 // One sweep launch + host-side ordering.  Returns the raw per-query totals.
+double g_sweep_dbg[4] = {0, 0, 0, 0};   // sweep_lists: enqueue, wait, unpack ms; queries
 void Ctx::sweep_lists(const double* q6, int nq, const std::vector<double>& r, const int32_t* tree,
                       const int32_t* max_id, const std::vector<uint8_t>& active, int cap, int n_store,
                       std::vector<int32_t>& cnt, std::vector<std::vector<HitRec>>& out) {
   Ctx& c = *this;
+  auto tq0 = std::chrono::steady_clock::now();
   const double eps = c.sweep_eps();
   c.h_a.ensure((size_t)nq * sizeof(sffk::SweepQuery));
   c.h_b.ensure((size_t)nq * 6 * sizeof(double));
@@ -676,17 +678,26 @@ void Ctx::sweep_lists(const double* q6, int nq, const std::vector<double>& r, co
   HIPCHK(hipMemcpyAsync(c.h_c.p, c.d_c.p, (size_t)nq * sizeof(int32_t), hipMemcpyDeviceToHost, c.stream));
   HIPCHK(hipMemcpyAsync(c.h_d.p, c.d_d.p, (size_t)nq * cap * sizeof(int32_t), hipMemcpyDeviceToHost, c.stream));
   HIPCHK(hipMemcpyAsync(c.h_e.p, c.d_e.p, (size_t)nq * cap * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+  auto tq1 = std::chrono::steady_clock::now();
   c.sync();
+  auto tq2 = std::chrono::steady_clock::now();
   cnt.assign(c.h_c.as<int32_t>(), c.h_c.as<int32_t>() + nq);
-  out.assign(nq, {});
+  out.resize(nq);   // (the lists keep their capacity from call to call)
+  const double* hd = c.h_e.as<double>();
+  const int32_t* hi = c.h_d.as<int32_t>();
   for (int i = 0; i < nq; ++i) {
+    out[i].clear();
     if (!active[i]) continue;
-    int m = std::min(cnt[i], cap);
+    const int m = std::min(cnt[i], cap);
     out[i].resize(m);
-    for (int k = 0; k < m; ++k)
-      out[i][k] = {c.h_e.as<double>()[(size_t)i * cap + k], c.h_d.as<int32_t>()[(size_t)i * cap + k]};
+    for (int k = 0; k < m; ++k) out[i][k] = {hd[(size_t)i * cap + k], hi[(size_t)i * cap + k]};
     std::sort(out[i].begin(), out[i].end());
   }
+  auto tq3 = std::chrono::steady_clock::now();
+  g_sweep_dbg[0] += std::chrono::duration<double, std::milli>(tq1 - tq0).count();
+  g_sweep_dbg[1] += std::chrono::duration<double, std::milli>(tq2 - tq1).count();
+  g_sweep_dbg[2] += std::chrono::duration<double, std::milli>(tq3 - tq2).count();
+  g_sweep_dbg[3] += nq;
 }
 
 void Ctx::radius(const double* q6, int nq, const double* r, const int32_t* tree, const int32_t* max_id, int32_t* idx,

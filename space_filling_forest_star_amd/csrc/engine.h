@@ -248,6 +248,7 @@ struct Forest {
   bool pending_round = false;
   int iter0 = 0, N0 = 0, Tb = 0;  // Tb: 4-aligned base of the round's temporary store entries
   double knn_r = 0;  // running guess of the k-nearest radius (SFF*)
+  std::vector<std::vector<HitRec>> knn_out;   // scratch of the SFF* k-nearest passes
   int hit_cap = 64, nb_cap = 15;  // device list capacities (env SFFGPU_TEST_HITCAP / _NBCAP shrink them in tests)
 
   // post-loop path extraction (src/forest.h:420-462, src/problemStruct.h:184-253)

@@ -24,6 +24,8 @@ namespace sff {
 #define HIPCHK(x) hip_check((x), #x)
 using Clock = std::chrono::steady_clock;
 static double g_sec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+extern double g_sweep_dbg[4];
+static double g_star[4] = {0, 0, 0, 0};   // SFF* second stage: k-nearest sweeps, member lists, edge batch, sweep iterations
 static double g_wait[3] = {0, 0, 0};   // blocked on: early copy, final sync; [2] = second read pass
 static uint64_t g_items[4] = {0, 0, 0, 0};   // rounds, edge work items, items after the cull, poses after the cull
 static uint64_t g_cnt[4] = {0, 0, 0, 0};   // candidates, skipped by the replay, settled on the device, accepted
@@ -37,6 +39,8 @@ struct Sec {
 void forest_profile_dump() {
   if (g_prof && g_items[0]) fprintf(stderr, "[sffgpu per round] edge work items (64-sample chunks) %.0f\n", (double)g_items[1] / g_items[0]);
   if (g_prof) fprintf(stderr, "[sffgpu candidates] %llu skipped %llu settled %llu\n", (unsigned long long)g_cnt[0], (unsigned long long)g_cnt[1], (unsigned long long)g_cnt[2]);
+  if (g_prof && g_star[3] > 0) fprintf(stderr, "[sffgpu sweep_lists ms] enqueue %.1f wait %.1f unpack %.1f, %.0f queries\n", g_sweep_dbg[0], g_sweep_dbg[1], g_sweep_dbg[2], g_sweep_dbg[3]);
+  if (g_prof && g_star[3] > 0) fprintf(stderr, "[sffgpu SFF* stage 2 ms] k-nearest sweeps %.1f (%.0f passes) member lists %.1f edge batch %.1f\n", g_star[0], g_star[3], g_star[1], g_star[2]);
   if (g_prof) fprintf(stderr, "[sffgpu waits ms] early copy %.1f final sync %.1f | read pass 2 %.1f\n", g_wait[0], g_wait[1], g_wait[2]);
   if (g_prof) fprintf(stderr, "[sffgpu host ms] prep %.1f launch %.1f read %.1f records %.1f deser %.1f replay %.1f append %.1f endwave %.1f\n", g_sec[0], g_sec[1], g_sec[2], g_sec[3], g_sec[4], g_sec[5], g_sec[6], g_sec[7]);
 }
@@ -754,13 +758,15 @@ void Forest::round_begin() {
         if ((int)trees[qtree[k]].size() <= kmax[k]) r[k] = 1e30;   // the whole tree is wanted
       }
       const double RMAX = 1e30;
+      auto ts0 = Clock::now();
+      std::vector<int32_t> cnt;
+      std::vector<std::vector<HitRec>>& out = knn_out;   // (member: the lists keep their capacity across rounds)
       for (int it = 0; it < 200; ++it) {
         bool any = false;
         for (int k = 0; k < m; ++k) any |= active[k] != 0;
         if (!any) break;
-        std::vector<int32_t> cnt;
-        std::vector<std::vector<HitRec>> out;
         c.sweep_lists(q6.data(), m, r, qtree.data(), qmax.data(), active, KCAP, Tb + n, cnt, out);
+        g_star[3] += 1;
         st.sweeps += 1;
         st.sweep_nodes += (uint64_t)(N0 + n);
         for (int k = 0; k < m; ++k) {
@@ -771,7 +777,7 @@ void Forest::round_begin() {
           for (const HitRec& h : out[k]) store_hits += h.id < N0;
           // complete when kmax store nodes are inside, or the whole tree already is (small trees)
           if (store_hits >= kmax[k] || store_hits >= (int)trees[qtree[k]].size() || r[k] >= RMAX) {
-            lists[k] = out[k];
+            lists[k].swap(out[k]);
             active[k] = 0;
           } else {
             lo[k] = r[k];
@@ -779,6 +785,8 @@ void Forest::round_begin() {
           }
         }
       }
+      g_star[0] += ms_since(ts0);
+      auto ts1 = Clock::now();
       double rsum = 0;
       int rcount = 0;
       for (int k = 0; k < m; ++k) {
@@ -821,6 +829,8 @@ void Forest::round_begin() {
           sb.insert(sb.end(), cd.pos, cd.pos + 6);
         }
       }
+      g_star[1] += ms_since(ts1);
+      auto ts2 = Clock::now();
       const int ns2 = (int)(sa.size() / 6);
       if (ns2) {
         std::vector<uint8_t> fr(ns2);
@@ -834,6 +844,7 @@ void Forest::round_begin() {
             mb.bwd_free = fr[mb.seg_b] != 0; mb.bwd_fh = fh[mb.seg_b]; mb.bwd_ns = nsv[mb.seg_b];
           }
       }
+      g_star[2] += ms_since(ts2);
       wait_ms += ms_since(t0);
     }
   }

@@ -287,6 +287,51 @@ def test_gpu_matches_committed_golden_runs(S, ctx, golden_dir):
         r.close()
 
 
+def test_full_size_headline_run_equals_the_oracle(S, ctx, golden_dir):
+    """BASELINE's headline configuration at full size (dense_3D, 10 roots, 1 M-node budget, waves of 8192 slots,
+    3 + 255 waves = what bench.py times): the GPU run must reproduce the committed summary of the CPU oracle's run
+    (tests/golden/full_size_run.json: fingerprint over every node's parent / tree / iteration, counters, cost
+    checksum) - also when the waves are split over several calls - and satisfy the size-independent properties
+    of a forest: nodes inside the limits, parents older and in the same tree, costs accumulating along the
+    parent chain, and - on a sample checked by the oracle - collision-free poses and parent edges."""
+    import json
+    import os
+    path = os.path.join(golden_dir, "full_size_run.json")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/full_size_run.json not generated (tests/golden/make_full_size.py)")
+    g = json.load(open(path))
+    sc, w = load_world(ctx, "dense3d")
+    roots = common.free_roots(lambda p: int(ctx.collide_poses(p[None, :])[0]), sc["limits"], 10, seed=1)
+    f = S.Forest(ctx, roots, sc["limits"], dist_tree=sc["dist_tree"], sampling_dist=sc["sampling_dist"], dim=6,
+                 max_iterations=2**31 - 1, node_budget=1000000, wave=8192, seed=1)
+    f.run(100)
+    f.run(g["waves"] - 100)
+    s, n = f.stats(), f.nodes()
+    got = {"fingerprint": "%016x" % f.fingerprint(), "n_nodes": int(s["n_nodes"]), "iterations": int(s["iterations"]),
+           "collide_calls": int(s["collide_calls"]), "path_free_calls": int(s["path_free_calls"]),
+           "nn_queries": int(s["nn_queries"]), "n_borders": int(s["n_borders"]),
+           "parent_sum": int(n["parent"].astype(np.int64).sum()), "cost_sum": float(n["cost"].sum()).hex()}
+    for k in got:
+        assert got[k] == g[k], (k, got[k], g[k])
+    # size-independent properties
+    N = s["n_nodes"]
+    pos, par, tree, cost, dpar = n["pos"], n["parent"], n["tree"], n["cost"], n["dpar"]
+    lim = np.asarray(sc["limits"], dtype=np.float64)
+    for a in range(3):
+        assert (pos[:, a] >= lim[2 * a]).all() and (pos[:, a] <= lim[2 * a + 1]).all()
+    kids = np.nonzero(par >= 0)[0]
+    assert len(kids) == N - 10
+    assert (par[kids] < kids).all() and (tree[par[kids]] == tree[kids]).all()
+    assert np.array_equal(cost[kids], cost[par[kids]] + dpar[kids])        # src/forest.h:353, same additions
+    d3 = np.linalg.norm(pos[kids, :3] - pos[par[kids], :3], axis=1)
+    assert (d3 <= dpar[kids] * (1 + 1e-12)).all() and (dpar[kids] <= sc["sampling_dist"] * (1 + 1e-9)).all()
+    rs = np.random.RandomState(4)
+    for i in rs.choice(kids, 1500, replace=False):
+        assert not w.collide(pos[i])
+        assert w.path_free(pos[par[i]], pos[i])[0], i
+    f.close()
+
+
 def test_forest_node_budget_and_seeds(S, ctx):
     for seed in (1, 3):
         fo, fg = run_pair(S, ctx, "dense3d", 512, 10**6, seed=seed, n_roots=10, budget=6000)
