@@ -173,6 +173,32 @@ struct PHeap {
   int pop_at(int id);
 };
 
+// open-addressing set of 64-bit keys (key 0 is not used by its callers): the border dedup does one insert per
+// border event, std::unordered_set spends ~100 ns in each
+struct FlatSet64 {
+  std::vector<uint64_t> tab;
+  size_t used = 0;
+  bool insert(uint64_t key) {   // true if the key was new
+    if (tab.empty()) tab.assign(1024, 0);
+    if ((used + 1) * 10 > tab.size() * 7) grow();
+    size_t m = tab.size() - 1, h = (size_t)((key * 0x9E3779B97F4A7C15ULL) >> 20) & m;
+    while (tab[h] != 0) {
+      if (tab[h] == key) return false;
+      h = (h + 1) & m;
+    }
+    tab[h] = key;
+    ++used;
+    return true;
+  }
+  void grow() {
+    std::vector<uint64_t> old;
+    old.swap(tab);
+    tab.assign(old.size() * 2, 0);
+    used = 0;
+    for (uint64_t k : old) if (k) insert(k);
+  }
+};
+
 struct Forest {
   Ctx* ctx;
   sffgpu_forest_cfg cfg;
@@ -185,7 +211,7 @@ struct Forest {
   std::vector<std::vector<int>> trees;
   std::vector<int> frontier, closed;
   std::map<std::pair<int, int>, std::vector<Border>> borders;
-  std::unordered_set<uint64_t> border_keys;   // (n1, n2) pairs present in any border list (the reference scans the list)
+  FlatSet64 border_keys;   // (n1, n2) pairs present in any border list (the reference scans the list)
   std::vector<int> connected;
   int num_roots = 0;   // Problem::GetNumRoots(): roots + the goal tree
   int goal_node = -1;

@@ -1044,7 +1044,7 @@ void Forest::round_commit(const int32_t* all, const int32_t* counts, int world) 
         if (nb.free) {                                         // :288-294
           int a = std::min(nb_node, expanded), b = std::max(nb_node, expanded);
           // (two nodes belong to one tree pair only, so the pair itself identifies the list entry)
-          if (border_keys.insert(((uint64_t)(uint32_t)a << 32) | (uint32_t)b).second) {
+          if (border_keys.insert(((uint64_t)(uint32_t)a << 32) | ((uint64_t)(uint32_t)b + 1))) {   // (+1: never 0)
             double d = nodes[nb_node].d_root + nodes[expanded].d_root + sffg::dist6(nodes[nb_node].pos, nodes[expanded].pos);
             border(nb.tree, mine).push_back({a, b, d});
           }
@@ -1105,7 +1105,7 @@ void Forest::round_commit(const int32_t* all, const int32_t* counts, int world) 
     }
     if (solved) {                                              // :369-372
       double gd = sffg::dist6(cd.pos, cfg.goal);
-      border_keys.insert(((uint64_t)(uint32_t)std::min(id, goal_node) << 32) | (uint32_t)std::max(id, goal_node));
+      border_keys.insert(((uint64_t)(uint32_t)std::min(id, goal_node) << 32) | ((uint64_t)(uint32_t)std::max(id, goal_node) + 1));
       border(num_roots - 1, mine).push_back({std::min(id, goal_node), std::max(id, goal_node), nodes[id].d_root + gd});
     }
     sl.failing = false;
