@@ -65,18 +65,55 @@ class SpaceForest : public Solver<T, R> {
     sffgpu_forest* f = nullptr;
     sff_compat::check(sffgpu_forest_create(sff_compat::gpu(), &cfg, roots.data(), (int)P.roots.size(), &f), "forest");
 
+    sffgpu_forest_stats st;
+    auto loadNodes = [&]() {
+      sffgpu_forest_get_stats(f, &st);
+      const int n = st.n_nodes;
+      std::vector<double> pos((size_t)n * 6), cost(n), dpar(n);
+      std::vector<int32_t> parent(n), tree(n), iter(n);
+      sffgpu_forest_get_nodes(f, pos.data(), parent.data(), tree.data(), iter.data(), cost.data(), dpar.data());
+      this->fillNodes(n, pos.data(), parent.data(), tree.data(), iter.data(), cost.data(), dpar.data());
+      this->numTrees = st.n_trees;
+    };
+    auto loadFrontier = [&](std::vector<int32_t>& open_nodes) {
+      int k = sffgpu_forest_get_frontier(f, nullptr, 0);
+      open_nodes.resize(k > 0 ? k : 0);
+      if (k > 0) sffgpu_forest_get_frontier(f, open_nodes.data(), k);
+    };
+
     auto startingTime = std::chrono::high_resolution_clock::now();   // :117
-    sff_compat::check(sffgpu_forest_run(f, 0), "forest run");
+    if (P.saveTreeIter == 0 && P.saveFrontiersIter == 0) {
+      sff_compat::check(sffgpu_forest_run(f, 0), "forest run");
+    } else {
+      // saveIterCheck (src/problemStruct.h:256-261, src/forest.h:570-578) dumps after every k-th iteration.  Here
+      // the loop advances by waves, so "iter_<k>_" files hold the state at the END OF THE WAVE in which iteration
+      // k fell (SFF_WAVE=1 keeps that within ThresholdMisses iterations of the reference's snapshot).
+      long nextTree = P.saveTreeIter, nextFront = P.saveFrontiersIter;
+      uint64_t wavesBefore = ~0ULL;
+      while (true) {
+        sffgpu_forest_get_stats(f, &st);
+        if (st.waves == wavesBefore) break;   // terminated: the last call did not start a wave
+        wavesBefore = st.waves;
+        sff_compat::check(sffgpu_forest_run(f, 1), "forest run");
+        sffgpu_forest_get_stats(f, &st);
+        bool loaded = false;
+        while (P.saveTreeIter != 0 && (long)st.iterations >= nextTree) {
+          if (!loaded) { loadNodes(); loaded = true; }
+          this->saveTrees(prefixFileName(P.fileNames[SaveTree], "iter_" + std::to_string(nextTree) + "_"));
+          nextTree += P.saveTreeIter;
+        }
+        while (P.saveFrontiersIter != 0 && (long)st.iterations >= nextFront) {
+          if (!loaded) { loadNodes(); loaded = true; }
+          std::vector<int32_t> open_now;
+          loadFrontier(open_now);
+          saveFrontiers(prefixFileName(P.fileNames[SaveFrontiers], "iter_" + std::to_string(nextFront) + "_"), open_now);
+          nextFront += P.saveFrontiersIter;
+        }
+      }
+    }
     auto stopTime = std::chrono::high_resolution_clock::now();       // :203
 
-    sffgpu_forest_stats st;
-    sffgpu_forest_get_stats(f, &st);
-    const int n = st.n_nodes;
-    std::vector<double> pos((size_t)n * 6), cost(n), dpar(n);
-    std::vector<int32_t> parent(n), tree(n), iter(n);
-    sffgpu_forest_get_nodes(f, pos.data(), parent.data(), tree.data(), iter.data(), cost.data(), dpar.data());
-    this->fillNodes(n, pos.data(), parent.data(), tree.data(), iter.data(), cost.data(), dpar.data());
-    this->numTrees = st.n_trees;
+    loadNodes();
     this->neighboringMatrix.assign((size_t)st.n_trees * st.n_trees, 0.0);
     std::vector<int32_t> conn(st.n_trees);
     int nc = sffgpu_forest_paths(f, this->neighboringMatrix.data(), conn.data(), st.n_trees);   // getPaths + getAllPaths
@@ -103,11 +140,7 @@ class SpaceForest : public Solver<T, R> {
       if (SaveSmooth <= P.saveOptions) this->savePaths(P.fileNames[SaveSmooth]);
     }
     std::vector<int32_t> open_nodes;
-    if (SaveFrontiers <= P.saveOptions) {
-      int k = sffgpu_forest_get_frontier(f, nullptr, 0);
-      open_nodes.resize(k > 0 ? k : 0);
-      if (k > 0) sffgpu_forest_get_frontier(f, open_nodes.data(), k);
-    }
+    if (SaveFrontiers <= P.saveOptions) loadFrontier(open_nodes);
     sffgpu_forest_destroy(f);
     if (SaveParams <= P.saveOptions) this->saveParams(P.fileNames[SaveParams], st.iterations, st.solved != 0, stopTime - startingTime);
     if (SaveTSP <= P.saveOptions) this->saveTsp(P.fileNames[SaveTSP]);

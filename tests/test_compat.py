@@ -62,9 +62,10 @@ def test_reference_main_drives_the_gpu_path(tmp_path, solver, optimize):
            "</Points>",
            '<Range autoDetect="false"><RangeX min="-10" max="10"/><RangeY min="-10" max="10"/><RangeZ min="0" max="10"/></Range>',
            '<Distances dtree="0.5" circum="0.4"/>', '<Thresholds standard="5"/>', '<MaxIterations value="3000"/>',
-           '<Save><Tree file="%s" is_obj="false"/><Params file="%s" id="compat"/><Goals file="%s" is_obj="false"/>'
+           '<Save><Tree file="%s" is_obj="false"%s/><Params file="%s" id="compat"/><Goals file="%s" is_obj="false"/>'
            '<RawPath file="%s" is_obj="false"/></Save>'
-           % (tmp_path / "tree.tri", tmp_path / "params.csv", tmp_path / "goals.tri", tmp_path / "paths.tri"),
+           % (tmp_path / "tree.tri", ' everyIteration="1000"' if (solver, optimize) == ("sff", "false") else "",
+              tmp_path / "params.csv", tmp_path / "goals.tri", tmp_path / "paths.tri"),
            "</Problem>"]
     (tmp_path / "cfg.xml").write_text("\n".join(xml))
     env = dict(os.environ, SFF_SEED="21", SFF_WAVE="64")
@@ -104,5 +105,15 @@ def test_reference_main_drives_the_gpu_path(tmp_path, solver, optimize):
     assert got == want
     row = (tmp_path / "params.csv").read_text().strip().split(",")
     assert row[0] == "compat" and int(row[2]) == iters
+    if (solver, optimize) == ("sff", "false"):
+        # saveIterCheck (src/problemStruct.h:256-261): "iter_<k>_" dumps = the forest at the end of the wave in which
+        # iteration k fell: every node created up to iteration k is in it, and it is a subset of the final dump
+        final = set(got[1:])
+        for k in (1000, 2000):
+            dump = (tmp_path / ("iter_%d_tree.tri" % k)).read_text().strip().split("\n")
+            assert dump[0] == want[0]
+            lines = set(dump[1:])
+            assert lines <= final and len(lines) < len(final)
+            assert {l for l in final if int(l.split()[-1]) <= k} <= lines
     f.close()
     ctx.close()
