@@ -112,10 +112,11 @@ def main():
         # passes of this command; FETCH_SIZE doubled per MI355X_MICROARCH.md, gather pattern uncalibrated)
         traffic = None
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r1p_bench_pmc_summary.json")))
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r1q_bench_pmc_summary.json")))
             kib = 0.0
-            for k in ("sffk::k_grid_query", "sffk::k_sweep"):
-                kib += 2.0 * pm["FETCH_SIZE"][k]["avg_KiB_per_launch"] + pm["WRITE_SIZE"][k]["avg_KiB_per_launch"]
+            for k in ("sffk::k_grid_query", "sffk::k_sweep"):   # (k_sweep only when a profile saw it in the rounds)
+                if k in pm["FETCH_SIZE"]:
+                    kib += 2.0 * pm["FETCH_SIZE"][k]["avg_KiB_per_launch"] + pm["WRITE_SIZE"][k]["avg_KiB_per_launch"]
             traffic = kib * 1024.0
         except Exception:
             traffic = None
@@ -148,11 +149,11 @@ def main():
                               "sample_kernel": s1["sample_ms"] - s0["sample_ms"],
                               "host_logic": s1["host_ms"] - s0["host_ms"]},
             "roofline": {
-                # neighbour query of one round = k_grid_query (permanent nodes) + k_sweep (the round's own
-                # samples), timed together with HIP events on the library's launch stream.  Algorithmic
+                # neighbour query of one round = k_grid_query over the node grid and over the round's own
+                # grid, timed with HIP events on the library's launch stream (every 8th round).  Algorithmic
                 # bytes = 24 B x nodes the query has to cover; the grid touches far fewer
                 # bytes than that, see `traffic` (rocprofv3 PMC pass of this same command, profiles/).
-                "bound": "hbm", "kernel": "sffk::k_grid_query + sffk::k_sweep (round temporaries)",
+                "bound": "hbm", "kernel": "sffk::k_grid_query (node grid + the round's own grid)",
                 "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                 "traffic": traffic,
                 "launches": int(sweeps), "avg_launch_us": 1e3 * sweep_ms / max(1, sweeps),
