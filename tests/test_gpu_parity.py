@@ -332,6 +332,32 @@ def test_full_size_headline_run_equals_the_oracle(S, ctx, golden_dir):
     f.close()
 
 
+def test_baseline_configs_equal_the_oracle(S, ctx, golden_dir):
+    """BASELINE.json configs[1] (triang, 5 roots, 100 k nodes) in full and configs[4] (building, 20 roots, SFF* with
+    rewire) at a 150 k-node budget: the GPU runs reproduce the committed oracle summaries
+    (tests/golden/config_runs.json, tests/golden/make_config_runs.py)."""
+    import json
+    import os
+    sys_path = os.path.join(golden_dir, "config_runs.json")
+    if not os.path.exists(sys_path):
+        pytest.skip("tests/golden/config_runs.json not generated")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_config_runs", os.path.join(golden_dir, "make_config_runs.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    gold = json.load(open(sys_path))
+    for key, (name, nroots, opt, budget, wave, waves) in mk.CONFIGS.items():
+        sc, w = load_world(ctx, name)
+        roots = common.free_roots(lambda p: int(ctx.collide_poses(p[None, :])[0]), sc["limits"], nroots, seed=1)
+        f = S.Forest(ctx, roots, sc["limits"], dist_tree=sc["dist_tree"], sampling_dist=sc["sampling_dist"], dim=6,
+                     optimize=opt, max_iterations=2**31 - 1, node_budget=budget, wave=wave, seed=1)
+        f.run(waves)
+        got = mk.summary(f)
+        for k in got:
+            assert got[k] == gold[key][k], (key, k, got[k], gold[key][k])
+        f.close()
+
+
 def test_forest_node_budget_and_seeds(S, ctx):
     for seed in (1, 3):
         fo, fg = run_pair(S, ctx, "dense3d", 512, 10**6, seed=seed, n_roots=10, budget=6000)
