@@ -638,7 +638,7 @@ void Ctx::sample_steer(const uint64_t* words, const double* center6, int n, doub
 double g_sweep_dbg[4] = {0, 0, 0, 0};   // sweep_lists: enqueue, wait, unpack ms; queries
 void Ctx::sweep_lists(const double* q6, int nq, const std::vector<double>& r, const int32_t* tree,
                       const int32_t* max_id, const std::vector<uint8_t>& active, int cap, int n_store,
-                      std::vector<int32_t>& cnt, std::vector<std::vector<HitRec>>& out) {
+                      std::vector<int32_t>& cnt, std::vector<std::vector<HitRec>>& out, bool sort_lists) {
   Ctx& c = *this;
   auto tq0 = std::chrono::steady_clock::now();
   const double eps = c.sweep_eps();
@@ -691,7 +691,7 @@ void Ctx::sweep_lists(const double* q6, int nq, const std::vector<double>& r, co
     const int m = std::min(cnt[i], cap);
     out[i].resize(m);
     for (int k = 0; k < m; ++k) out[i][k] = {hd[(size_t)i * cap + k], hi[(size_t)i * cap + k]};
-    std::sort(out[i].begin(), out[i].end());
+    if (sort_lists) std::sort(out[i].begin(), out[i].end());
   }
   auto tq3 = std::chrono::steady_clock::now();
   g_sweep_dbg[0] += std::chrono::duration<double, std::milli>(tq1 - tq0).count();

@@ -146,7 +146,7 @@ struct Ctx {
   // one sweep launch over the first n_store entries; per-query hit lists sorted by (dist, id)
   void sweep_lists(const double* q6, int nq, const std::vector<double>& r, const int32_t* tree, const int32_t* max_id,
                    const std::vector<uint8_t>& active, int cap, int n_store, std::vector<int32_t>& cnt,
-                   std::vector<std::vector<HitRec>>& out);
+                   std::vector<std::vector<HitRec>>& out, bool sort_lists = true);
 };
 
 struct FNode {

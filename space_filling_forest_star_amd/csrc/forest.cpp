@@ -765,7 +765,7 @@ void Forest::round_begin() {
         bool any = false;
         for (int k = 0; k < m; ++k) any |= active[k] != 0;
         if (!any) break;
-        c.sweep_lists(q6.data(), m, r, qtree.data(), qmax.data(), active, KCAP, Tb + n, cnt, out);
+        c.sweep_lists(q6.data(), m, r, qtree.data(), qmax.data(), active, KCAP, Tb + n, cnt, out, /*sort_lists=*/false);
         g_star[3] += 1;
         st.sweeps += 1;
         st.sweep_nodes += (uint64_t)(N0 + n);
@@ -792,24 +792,27 @@ void Forest::round_begin() {
       for (int k = 0; k < m; ++k) {
         Cand& cd = cands[maybe[k]];
         if (kmax[k] <= 0) continue;
-        // store members: the kmax nearest; wave-mates: closer than the kmax-th store member
+        // store members: the kmax nearest; wave-mates: closer than the kmax-th store member.  (The lists come
+        // unsorted; only the kmax-th smallest has to be found, the replay orders the members itself.)
+        std::vector<HitRec>& L = lists[k];
+        auto mid = std::partition(L.begin(), L.end(), [&](const HitRec& h) { return h.id < N0; });
+        const size_t n_store_hits = (size_t)(mid - L.begin());
+        size_t take = n_store_hits;
         double dk = std::numeric_limits<double>::infinity();
-        int seen = 0;
-        for (const HitRec& h : lists[k]) {
-          if (h.id >= N0) continue;
-          if (++seen == kmax[k]) { dk = h.d; break; }
+        if (n_store_hits >= (size_t)kmax[k]) {
+          take = (size_t)kmax[k];
+          std::nth_element(L.begin(), L.begin() + (take - 1), mid);
+          dk = L[take - 1].d;
         }
-        seen = 0;
-        for (const HitRec& h : lists[k]) {
+        for (size_t q = 0; q < take; ++q) {
           Member mb;
-          if (h.id < N0) {
-            if (seen >= kmax[k]) continue;
-            ++seen;
-            mb.id = h.id;
-          } else {
-            if (h.id < Tb || !(h.d <= dk)) continue;
-            mb.id = -1 - (h.id - Tb);
-          }
+          mb.id = L[q].id;
+          cd.members.push_back(mb);
+        }
+        for (auto it = mid; it != L.end(); ++it) {
+          if (it->id < Tb || !(it->d <= dk)) continue;
+          Member mb;
+          mb.id = -1 - (it->id - Tb);
           cd.members.push_back(mb);
         }
         if (dk < 1e29) { rsum += dk; ++rcount; }
@@ -1071,7 +1074,7 @@ void Forest::round_commit(const int32_t* all, const int32_t* counts, int world) 
         throw HipError{"forest: k-nearest candidate set incomplete (internal error)"};
       int parent = expanded;
       for (const KN& kn : knn) {                               // :320-327
-        double nd = sffg::dist6(cd.pos, nodes[kn.node].pos) + nodes[kn.node].d_root;
+        double nd = kn.d + nodes[kn.node].d_root;               // kn.d = dist6(new, node), computed above
         if (nd < best - SFFG_TOL) {
           st.path_free_calls += 1;
           st.collide_calls += calls(kn.mb->fwd_fh, kn.mb->fwd_ns);
@@ -1080,7 +1083,7 @@ void Forest::round_commit(const int32_t* all, const int32_t* counts, int world) 
       }
       id = add_node(cd.pos, mine, parent, sffg::dist6(cd.pos, nodes[parent].pos), best, iteration);  // :329
       for (const KN& kn : knn) {                               // :332-350
-        double npd = sffg::dist6(nodes[kn.node].pos, cd.pos);
+        double npd = kn.d;   // dist6(node, new) == dist6(new, node) bit for bit (squares of exactly negated terms)
         double proposed = best + npd;
         if (proposed < nodes[kn.node].d_root - SFFG_TOL) {
           st.path_free_calls += 1;
