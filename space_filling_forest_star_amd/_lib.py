@@ -478,15 +478,22 @@ def exchange_records(local, group=None):
             _XCHG["bufs"][key] = (torch.zeros(1 + cap, dtype=torch.int32).pin_memory() if dev.type == "cuda"
                                    else torch.zeros(1 + cap, dtype=torch.int32),
                                    torch.zeros(1 + cap, dtype=torch.int32, device=dev),
-                                   torch.zeros(world * (1 + cap), dtype=torch.int32, device=dev))
-        host, send, recv = _XCHG["bufs"][key]
+                                   torch.zeros(world * (1 + cap), dtype=torch.int32, device=dev),
+                                   torch.zeros(world * (1 + cap), dtype=torch.int32).pin_memory() if dev.type == "cuda"
+                                   else None)
+        host, send, recv, hrecv = _XCHG["bufs"][key]
         hv = host.numpy()
         hv[0] = n
         m = min(n, cap)
         hv[1:1 + m] = local[:m]
         send.copy_(host, non_blocking=True)
         dist.all_gather_into_tensor(recv, send, group=group)
-        allh = recv.cpu().numpy().reshape(world, 1 + cap)
+        if hrecv is not None:   # pinned landing buffer: one async copy + one stream sync (no pageable staging)
+            hrecv.copy_(recv, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            allh = hrecv.numpy().reshape(world, 1 + cap)
+        else:
+            allh = recv.numpy().reshape(world, 1 + cap)
         counts = allh[:, 0].astype(np.int32)
         if int(counts.max()) <= cap:
             out = np.concatenate([allh[r, 1:1 + counts[r]] for r in range(world)]) if counts.sum() else np.zeros(0, np.int32)
