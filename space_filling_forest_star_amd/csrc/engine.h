@@ -246,20 +246,23 @@ struct Forest {
     int seg_f = -1, seg_b = -1;
   };
   struct Cand {      // one sample of the current round
+    // --- what reset() writes, in one cache line
     int slot, expanded;
-    double pos[6];
-    bool in_lim = false;
-    double pdist = 0;
-    int pose_task = -1, seg_parent = -1;
-    bool answered = false, pose_hit = false, par_free = false;
-    bool bulk = false;   // fate settled by its owner (rejected, no side effect): only counters travel
-    int par_fh = -1, par_ns = 0;
-    std::vector<Nb> nbs;
-    std::vector<Member> members;  // SFF*: candidates for the k-nearest set (src/forest.h:317)
     int accepted_id = -1;
+    bool in_lim = false;
+    bool answered = false, pose_hit = false, par_free = false;
+    bool has_members = false;   // members is non-empty (SFF* only)
+    int par_fh = -1, par_ns = 0;
+    double pdist = 0;
+    // --- filled when the sample is answered
+    double pos[6];
+    int pose_task = -1, seg_parent = -1;
+    std::vector<Nb> nbs;          // valid only while answered (stale entries of earlier rounds otherwise)
+    std::vector<Member> members;  // SFF*: candidates for the k-nearest set (src/forest.h:317)
     void reset(int s, int e) {   // reuse across rounds: keeps the vectors' capacity
-      slot = s; expanded = e; in_lim = false; pdist = 0; pose_task = seg_parent = -1;
-      answered = pose_hit = par_free = bulk = false; par_fh = -1; par_ns = 0; nbs.clear(); members.clear(); accepted_id = -1;
+      slot = s; expanded = e; accepted_id = -1; in_lim = false;
+      answered = pose_hit = par_free = false; par_fh = -1; par_ns = 0; pdist = 0;
+      if (has_members) { members.clear(); has_members = false; }
     }
   };
   std::vector<Cand> cands;   // storage (only grows); the current round uses the first n_cands

@@ -652,6 +652,7 @@ void Forest::round_begin() {
     for (int k = 0; k < m; ++k) {
       if (cn[k] > BIG) throw HipError{"forest: neighbour list overflow (> 4096 hits)"};
       Cand& cd = cands[slow[k]];
+      cd.nbs.clear();   // (reset() leaves the list of an earlier round in place)
       const FNode& ex = nodes[cd.expanded];
       cd.pose_task = (int)(pose_tasks.size() / 6);
       pose_tasks.insert(pose_tasks.end(), cd.pos, cd.pos + 6);
@@ -808,12 +809,14 @@ void Forest::round_begin() {
           Member mb;
           mb.id = L[q].id;
           cd.members.push_back(mb);
+          cd.has_members = true;
         }
         for (auto it = mid; it != L.end(); ++it) {
           if (it->id < Tb || !(it->d <= dk)) continue;
           Member mb;
           mb.id = -1 - (it->id - Tb);
           cd.members.push_back(mb);
+          cd.has_members = true;
         }
         if (dk < 1e29) { rsum += dk; ++rcount; }
       }
@@ -954,6 +957,7 @@ void Forest::round_commit(const int32_t* all, const int32_t* counts, int world) 
           nb.ns = q[4];
         }
         cd.members.resize(nm);
+        cd.has_members = nm > 0;
         for (int k = 0; k < nm; ++k) {
           const int32_t* q = p + 6 + 5 * (size_t)nn + 6 * k;
           Member& mb = cd.members[k];
