@@ -916,37 +916,61 @@ __global__ __launch_bounds__(64 * SEG_WAVES) void k_collide_segments_dyn(EnvView
   [[maybe_unused]] const unsigned long long tk_ = DBG_T();
   const int W = gridDim.x * SEG_WAVES;
   const int w0 = blockIdx.x + gridDim.x * wave;   // neighbouring entries go to different CUs
+  // The survivors of a workgroup's four windows are pooled in LDS and handed out one at a time (LDS atomics),
+  // so a wave whose window happened to hold several of them does not become the kernel's tail.
+  __shared__ int pool_n, pool_next;
+  __shared__ int pool_e[64 * SEG_WAVES];
+  __shared__ unsigned long long pool_m[64 * SEG_WAVES];
+  auto pool_put = [&](bool s, int e, unsigned long long m) {
+    const unsigned long long bal = __ballot(s);
+    int off = 0;
+    if (lane == 0 && bal) off = atomicAdd(&pool_n, __popcll(bal));
+    off = __shfl(off, 0);
+    if (s) {
+      const int at = off + __popcll(bal & ((1ULL << lane) - 1ULL));
+      pool_e[at] = e;
+      pool_m[at] = m;
+    }
+  };
+  auto pool_take = [&]() -> int {
+    int i = 0;
+    if (lane == 0) i = atomicAdd(&pool_next, 1);
+    return __shfl(i, 0);
+  };
   for (int base = 0; base < n_pose; base += 64 * W) {
+    if (threadIdx.x == 0) { pool_n = 0; pool_next = 0; }
+    __syncthreads();
     const int mine = base + w0 + W * lane;
-    unsigned long long todo = __ballot(mine < n_pose && pose_hit[mine] == 2);
-    while (todo) {
-      const int l = __ffsll((long long)todo) - 1;
-      todo &= todo - 1;
-      const int pose = base + w0 + W * l;
+    pool_put(mine < n_pose && pose_hit[mine] == 2, mine, 0ULL);
+    __syncthreads();
+    for (int i = pool_take(); i < pool_n; i = pool_take()) {
+      const int pose = pool_e[i];
       double p[6], R[9], c[3];
       pose_frame(rob, pos6, pose, p, R, c);
       const bool hit = pose_exact(env, rob, rtri, stack, cand, p, R, c, lane);
       if (lane == 0) pose_hit[pose] = hit ? 1 : 0;
     }
+    __syncthreads();
   }
   if (!ctrl[3]) {
     const int M = ctrl[2];
     for (int base = 0; base < M; base += 64 * W) {
+      if (threadIdx.x == 0) { pool_n = 0; pool_next = 0; }
+      __syncthreads();
       const int mine = base + w0 + W * lane;
       const unsigned long long m = mine < M ? masks[(size_t)base + (size_t)w0 * 64 + lane] : 0ULL;
-      unsigned long long todo = __ballot(m != 0ULL);
-      while (todo) {
-        const int l = __ffsll((long long)todo) - 1;
-        todo &= todo - 1;
-        const int e = base + w0 + W * l;
-        const unsigned long long nm = (unsigned long long)(uint32_t)__shfl((int)(uint32_t)m, l) |
-                                      ((unsigned long long)(uint32_t)__shfl((int)(uint32_t)(m >> 32), l) << 32);
+      pool_put(m != 0ULL, mine, m);
+      __syncthreads();
+      for (int i = pool_take(); i < pool_n; i = pool_take()) {
+        const int e = pool_e[i];
+        const unsigned long long nm = pool_m[i];
         const int slot = list[e].slot, chunk = list[e].chunk;
         if (chunk > 0 && first_hit[slot] <= 64 * chunk) continue;
         double a[6], b[6];
         for (int k = 0; k < 6; ++k) { a[k] = a6[6 * (size_t)slot + k]; b[k] = b6[6 * (size_t)slot + k]; }
         segment_chunk(env, rob, rtri, stack, cand, queue, a, b, slot, chunk, true, nm, first_hit, overflow_flag, lane DBG_PASS);
       }
+      __syncthreads();
     }
     DBG_ADD(8, DBG_T() - tk_);
     DBG_ADD(9, 1);
