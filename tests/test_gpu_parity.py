@@ -333,7 +333,7 @@ def test_full_size_headline_run_equals_the_oracle(S, ctx, golden_dir):
 
 
 def test_baseline_configs_equal_the_oracle(S, ctx, golden_dir):
-    """BASELINE.json configs[1] (triang, 5 roots, 100 k nodes) in full and configs[4] (building, 20 roots, SFF* with
+    """BASELINE.json configs[0] (2-D, 3 roots, 10 k nodes) and configs[1] (triang, 5 roots, 100 k nodes) in full and configs[4] (building, 20 roots, SFF* with
     rewire) at a 150 k-node budget: the GPU runs reproduce the committed oracle summaries
     (tests/golden/config_runs.json, tests/golden/make_config_runs.py)."""
     import json
@@ -348,8 +348,9 @@ def test_baseline_configs_equal_the_oracle(S, ctx, golden_dir):
     gold = json.load(open(sys_path))
     for key, (name, nroots, opt, budget, wave, waves) in mk.CONFIGS.items():
         sc, w = load_world(ctx, name)
-        roots = common.free_roots(lambda p: int(ctx.collide_poses(p[None, :])[0]), sc["limits"], nroots, seed=1)
-        f = S.Forest(ctx, roots, sc["limits"], dist_tree=sc["dist_tree"], sampling_dist=sc["sampling_dist"], dim=6,
+        roots = common.free_roots(lambda p: int(ctx.collide_poses(p[None, :])[0]), sc["limits"], nroots, seed=1,
+                                  dim=sc["dim"])
+        f = S.Forest(ctx, roots, sc["limits"], dist_tree=sc["dist_tree"], sampling_dist=sc["sampling_dist"], dim=sc["dim"],
                      optimize=opt, max_iterations=2**31 - 1, node_budget=budget, wave=wave, seed=1)
         f.run(waves)
         got = mk.summary(f)
