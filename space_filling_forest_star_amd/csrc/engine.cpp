@@ -547,6 +547,14 @@ void Ctx::collide_poses(const double* pos6, int n, uint8_t* hit) {
 
 void Ctx::collide_segments(const double* a6, const double* b6, int n, uint8_t* is_free, int32_t* first_hit,
                            int32_t* n_samples) {
+  collide_segments_core(a6, b6, nullptr, nullptr, n, is_free, first_hit, n_samples);
+}
+void Ctx::collide_segments_ids(const int32_t* ida, const int32_t* idb, int n, uint8_t* is_free, int32_t* first_hit,
+                               int32_t* n_samples) {
+  collide_segments_core(nullptr, nullptr, ida, idb, n, is_free, first_hit, n_samples);
+}
+void Ctx::collide_segments_core(const double* a6, const double* b6, const int32_t* ida, const int32_t* idb, int n,
+                                uint8_t* is_free, int32_t* first_hit, int32_t* n_samples) {
   if (n <= 0) return;
   if (!have_env || !have_robot) throw HipError{"collide_segments: upload ENV and ROBOT meshes first"};
   HIPCHK(hipSetDevice(device));
@@ -554,8 +562,13 @@ void Ctx::collide_segments(const double* a6, const double* b6, int n, uint8_t* i
   // table is compacted into (edge, chunk) work items for the persistent edge kernel
   const size_t pb = (size_t)n * 6 * sizeof(double);
   h_a.ensure(pb); h_b.ensure(pb); h_c.ensure((size_t)n * 12 + 64);
-  memcpy(h_a.p, a6, pb);
-  memcpy(h_b.p, b6, pb);
+  if (a6) {
+    memcpy(h_a.p, a6, pb);
+    memcpy(h_b.p, b6, pb);
+  } else {
+    memcpy(h_a.p, ida, (size_t)n * 4);
+    memcpy(h_b.p, idb, (size_t)n * 4);
+  }
   std::vector<int32_t> ns(n, 0), fh(n, -1);
   std::vector<uint8_t> ovf(n, 0);
   d_a.ensure(pb); d_b.ensure(pb); d_c.ensure((size_t)n * 12 + 64);
@@ -563,8 +576,16 @@ void Ctx::collide_segments(const double* a6, const double* b6, int n, uint8_t* i
   int32_t* d_fh = d_ns + n;
   int32_t* d_ov = d_fh + n;
   int32_t* d_ctrl = d_ov + n;
-  HIPCHK(hipMemcpyAsync(d_a.p, h_a.p, pb, hipMemcpyHostToDevice, stream));
-  HIPCHK(hipMemcpyAsync(d_b.p, h_b.p, pb, hipMemcpyHostToDevice, stream));
+  if (a6) {
+    HIPCHK(hipMemcpyAsync(d_a.p, h_a.p, pb, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(d_b.p, h_b.p, pb, hipMemcpyHostToDevice, stream));
+  } else {   // ids up, positions gathered from the store on the device
+    d_d.ensure((size_t)n * 8);
+    HIPCHK(hipMemcpyAsync(d_d.p, h_a.p, (size_t)n * 4, hipMemcpyHostToDevice, stream));
+    HIPCHK(hipMemcpyAsync(d_d.as<int32_t>() + n, h_b.p, (size_t)n * 4, hipMemcpyHostToDevice, stream));
+    sffk::launch_seg_gather(stream, spos.as<double>(), d_d.as<int32_t>(), d_d.as<int32_t>() + n, n, d_a.as<double>(),
+                            d_b.as<double>());
+  }
   HIPCHK(hipMemsetAsync(d_ctrl, 0, 64, stream));
   const int list_cap = 8 * n + 65536;
   r_items.ensure((size_t)list_cap * SFFK_ITEM_BYTES);
@@ -586,7 +607,18 @@ void Ctx::collide_segments(const double* a6, const double* b6, int n, uint8_t* i
     }
   }
   // edges whose candidate list overflowed are re-run sample by sample through the pose kernel
-  for (int i = 0; i < n; ++i) {
+  bool any_ovf = false;
+  for (int i = 0; i < n; ++i) any_ovf |= ovf[i] != 0;
+  std::vector<double> ga, gb;
+  if (any_ovf && !a6) {   // (their end points only exist on the device: fetch the gathered arrays)
+    ga.resize((size_t)n * 6);
+    gb.resize((size_t)n * 6);
+    HIPCHK(hipMemcpy(ga.data(), d_a.p, pb, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(gb.data(), d_b.p, pb, hipMemcpyDeviceToHost));
+    a6 = ga.data();
+    b6 = gb.data();
+  }
+  for (int i = 0; i < n && any_ovf; ++i) {
     if (!ovf[i]) continue;
     const double* a = a6 + 6 * (size_t)i;
     const double* b = b6 + 6 * (size_t)i;
@@ -642,10 +674,22 @@ void Ctx::sweep_lists(const double* q6, int nq, const std::vector<double>& r, co
   Ctx& c = *this;
   auto tq0 = std::chrono::steady_clock::now();
   const double eps = c.sweep_eps();
-  c.h_a.ensure((size_t)nq * sizeof(sffk::SweepQuery));
-  c.h_b.ensure((size_t)nq * 6 * sizeof(double));
+  // only the active queries travel (the later passes of an adaptive-radius search hold a handful of them)
+  std::vector<int> act;
+  act.reserve(nq);
+  for (int i = 0; i < nq; ++i)
+    if (active[i]) act.push_back(i);
+  const int na = (int)act.size();
+  cnt.assign(nq, 0);
+  out.resize(nq);   // (the lists keep their capacity from call to call)
+  for (int i = 0; i < nq; ++i) out[i].clear();
+  if (na == 0) return;
+  c.h_a.ensure((size_t)na * sizeof(sffk::SweepQuery));
+  c.h_b.ensure((size_t)na * 6 * sizeof(double));
   sffk::SweepQuery* hq = c.h_a.as<sffk::SweepQuery>();
-  for (int i = 0; i < nq; ++i) {
+  double* hp = c.h_b.as<double>();
+  for (int j = 0; j < na; ++j) {
+    const int i = act[j];
     const double* p = q6 + 6 * (size_t)i;
     sffk::SweepQuery q{};
     q.x = (float)p[0]; q.y = (float)p[1]; q.z = (float)p[2];
@@ -656,48 +700,47 @@ void Ctx::sweep_lists(const double* q6, int nq, const std::vector<double>& r, co
     q.r2f = r2 > 1e37 ? 3.0e38f : (float)r2 * 1.000001f;
     q.tree = tree ? tree[i] : -1;
     q.max_id = max_id ? max_id[i] : std::numeric_limits<int32_t>::max();
-    q.active = active[i];
-    hq[i] = q;
+    q.active = 1;
+    hq[j] = q;
+    memcpy(hp + 6 * (size_t)j, p, 6 * sizeof(double));
   }
-  memcpy(c.h_b.p, q6, (size_t)nq * 6 * sizeof(double));
-  c.d_a.ensure((size_t)nq * sizeof(sffk::SweepQuery));
-  c.d_b.ensure((size_t)nq * 6 * sizeof(double));
-  c.d_c.ensure((size_t)nq * sizeof(int32_t));
-  c.d_d.ensure((size_t)nq * cap * sizeof(int32_t));
-  c.d_e.ensure((size_t)nq * cap * sizeof(double));
-  HIPCHK(hipMemcpyAsync(c.d_a.p, c.h_a.p, (size_t)nq * sizeof(sffk::SweepQuery), hipMemcpyHostToDevice, c.stream));
-  HIPCHK(hipMemcpyAsync(c.d_b.p, c.h_b.p, (size_t)nq * 6 * sizeof(double), hipMemcpyHostToDevice, c.stream));
-  HIPCHK(hipMemsetAsync(c.d_c.p, 0, (size_t)nq * sizeof(int32_t), c.stream));
+  c.d_a.ensure((size_t)na * sizeof(sffk::SweepQuery));
+  c.d_b.ensure((size_t)na * 6 * sizeof(double));
+  c.d_c.ensure((size_t)na * sizeof(int32_t));
+  c.d_d.ensure((size_t)na * cap * sizeof(int32_t));
+  c.d_e.ensure((size_t)na * cap * sizeof(double));
+  HIPCHK(hipMemcpyAsync(c.d_a.p, c.h_a.p, (size_t)na * sizeof(sffk::SweepQuery), hipMemcpyHostToDevice, c.stream));
+  HIPCHK(hipMemcpyAsync(c.d_b.p, c.h_b.p, (size_t)na * 6 * sizeof(double), hipMemcpyHostToDevice, c.stream));
+  HIPCHK(hipMemsetAsync(c.d_c.p, 0, (size_t)na * sizeof(int32_t), c.stream));
   c.time_begin(T_SWEEP);
-  sffk::launch_sweep(c.stream, c.store_view(), 0, n_store, c.d_a.as<sffk::SweepQuery>(), c.d_b.as<double>(), nq,
+  sffk::launch_sweep(c.stream, c.store_view(), 0, n_store, c.d_a.as<sffk::SweepQuery>(), c.d_b.as<double>(), na,
                      c.d_c.as<int32_t>(), c.d_d.as<int32_t>(), c.d_e.as<double>(), cap);
   c.time_end();
-  c.h_c.ensure((size_t)nq * sizeof(int32_t));
-  c.h_d.ensure((size_t)nq * cap * sizeof(int32_t));
-  c.h_e.ensure((size_t)nq * cap * sizeof(double));
-  HIPCHK(hipMemcpyAsync(c.h_c.p, c.d_c.p, (size_t)nq * sizeof(int32_t), hipMemcpyDeviceToHost, c.stream));
-  HIPCHK(hipMemcpyAsync(c.h_d.p, c.d_d.p, (size_t)nq * cap * sizeof(int32_t), hipMemcpyDeviceToHost, c.stream));
-  HIPCHK(hipMemcpyAsync(c.h_e.p, c.d_e.p, (size_t)nq * cap * sizeof(double), hipMemcpyDeviceToHost, c.stream));
+  c.h_c.ensure((size_t)na * sizeof(int32_t));
+  c.h_d.ensure((size_t)na * cap * sizeof(int32_t));
+  c.h_e.ensure((size_t)na * cap * sizeof(double));
+  HIPCHK(hipMemcpyAsync(c.h_c.p, c.d_c.p, (size_t)na * sizeof(int32_t), hipMemcpyDeviceToHost, c.stream));
+  HIPCHK(hipMemcpyAsync(c.h_d.p, c.d_d.p, (size_t)na * cap * sizeof(int32_t), hipMemcpyDeviceToHost, c.stream));
+  HIPCHK(hipMemcpyAsync(c.h_e.p, c.d_e.p, (size_t)na * cap * sizeof(double), hipMemcpyDeviceToHost, c.stream));
   auto tq1 = std::chrono::steady_clock::now();
   c.sync();
   auto tq2 = std::chrono::steady_clock::now();
-  cnt.assign(c.h_c.as<int32_t>(), c.h_c.as<int32_t>() + nq);
-  out.resize(nq);   // (the lists keep their capacity from call to call)
+  const int32_t* hc = c.h_c.as<int32_t>();
   const double* hd = c.h_e.as<double>();
   const int32_t* hi = c.h_d.as<int32_t>();
-  for (int i = 0; i < nq; ++i) {
-    out[i].clear();
-    if (!active[i]) continue;
+  for (int j = 0; j < na; ++j) {
+    const int i = act[j];
+    cnt[i] = hc[j];
     const int m = std::min(cnt[i], cap);
     out[i].resize(m);
-    for (int k = 0; k < m; ++k) out[i][k] = {hd[(size_t)i * cap + k], hi[(size_t)i * cap + k]};
+    for (int k = 0; k < m; ++k) out[i][k] = {hd[(size_t)j * cap + k], hi[(size_t)j * cap + k]};
     if (sort_lists) std::sort(out[i].begin(), out[i].end());
   }
   auto tq3 = std::chrono::steady_clock::now();
   g_sweep_dbg[0] += std::chrono::duration<double, std::milli>(tq1 - tq0).count();
   g_sweep_dbg[1] += std::chrono::duration<double, std::milli>(tq2 - tq1).count();
   g_sweep_dbg[2] += std::chrono::duration<double, std::milli>(tq3 - tq2).count();
-  g_sweep_dbg[3] += nq;
+  g_sweep_dbg[3] += na;
 }
 
 void Ctx::radius(const double* q6, int nq, const double* r, const int32_t* tree, const int32_t* max_id, int32_t* idx,

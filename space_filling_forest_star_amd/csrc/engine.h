@@ -135,6 +135,12 @@ struct Ctx {
   void collide_poses(const double* pos6, int n, uint8_t* hit);
   void collide_segments(const double* a6, const double* b6, int n, uint8_t* is_free, int32_t* first_hit,
                         int32_t* n_samples);
+  // the same with the end points given as store ids (fp64 positions of the device store: permanent nodes and the
+  // round's temporary entries): 8 bytes per edge over PCIe instead of 96
+  void collide_segments_ids(const int32_t* ida, const int32_t* idb, int n, uint8_t* is_free, int32_t* first_hit,
+                            int32_t* n_samples);
+  void collide_segments_core(const double* a6, const double* b6, const int32_t* ida, const int32_t* idb, int n,
+                             uint8_t* is_free, int32_t* first_hit, int32_t* n_samples);
   void sample_steer(const uint64_t* words, const double* center6, int n, double dist, int dim, const double* limits,
                     double* out6, uint8_t* in_limits);
   // exact radius query; results sorted by (dist, id).  Returns per-query totals in cnt.
@@ -278,6 +284,7 @@ struct Forest {
   int iter0 = 0, N0 = 0, Tb = 0;  // Tb: 4-aligned base of the round's temporary store entries
   double knn_r = 0;  // running guess of the k-nearest radius (SFF*)
   std::vector<std::vector<HitRec>> knn_out;   // scratch of the SFF* k-nearest passes
+  std::vector<int32_t> edge_ia, edge_ib;      // ... and of its edge batch
   int hit_cap = 64, nb_cap = 15;  // device list capacities (env SFFGPU_TEST_HITCAP / _NBCAP shrink them in tests)
 
   // post-loop path extraction (src/forest.h:420-462, src/problemStruct.h:184-253)

@@ -820,28 +820,31 @@ void Forest::round_begin() {
         }
         if (dk < 1e29) { rsum += dk; ++rcount; }
       }
-      if (rcount) knn_r = 1.15 * rsum / rcount;
-      // both directions of every member edge
-      std::vector<double> sa, sb;
+      if (rcount) knn_r = 1.5 * rsum / rcount;   // (generous: most queries then finish in one pass; the lists are trimmed by nth_element)
+      // both directions of every member edge, as pairs of store ids (the sample itself is the temporary store
+      // entry Tb + i, a round-mate Tb + its index): the device gathers the positions
+      std::vector<int32_t>& ia = edge_ia;
+      std::vector<int32_t>& ib = edge_ib;
+      ia.clear();
+      ib.clear();
       for (int k = 0; k < m; ++k) {
         Cand& cd = cands[maybe[k]];
+        const int32_t self = Tb + maybe[k];
         for (Member& mb : cd.members) {
-          const double* mp = mb.id >= 0 ? nodes[mb.id].pos : round_hpos + 6 * (size_t)(-1 - mb.id);
-          mb.seg_f = (int)(sa.size() / 6);
-          sa.insert(sa.end(), cd.pos, cd.pos + 6);   // isPathFree(newPoint, neighbor)   :323
-          sb.insert(sb.end(), mp, mp + 6);
-          mb.seg_b = (int)(sa.size() / 6);
-          sa.insert(sa.end(), mp, mp + 6);           // isPathFree(neighbor, newPoint)   :336
-          sb.insert(sb.end(), cd.pos, cd.pos + 6);
+          const int32_t other = mb.id >= 0 ? mb.id : Tb + (-1 - mb.id);
+          mb.seg_f = (int)ia.size();
+          ia.push_back(self);  ib.push_back(other);   // isPathFree(newPoint, neighbor)   :323
+          mb.seg_b = (int)ia.size();
+          ia.push_back(other); ib.push_back(self);    // isPathFree(neighbor, newPoint)   :336
         }
       }
       g_star[1] += ms_since(ts1);
       auto ts2 = Clock::now();
-      const int ns2 = (int)(sa.size() / 6);
+      const int ns2 = (int)ia.size();
       if (ns2) {
         std::vector<uint8_t> fr(ns2);
         std::vector<int32_t> fh(ns2), nsv(ns2);
-        c.collide_segments(sa.data(), sb.data(), ns2, fr.data(), fh.data(), nsv.data());
+        c.collide_segments_ids(ia.data(), ib.data(), ns2, fr.data(), fh.data(), nsv.data());
         st.segments_executed += ns2;
         for (int k = 0; k < ns2; ++k) st.samples_executed += (uint64_t)nsv[k];
         for (int k = 0; k < m; ++k)

@@ -165,6 +165,9 @@ struct SettleArgs {
   unsigned long long* bulk;       // 4 counters (zeroed by k_sample_steer with the ctrl words)
 };
 void launch_settle(hipStream_t s, const SettleArgs& a);
+// end points of edges given as store ids -> a6 / b6
+void launch_seg_gather(hipStream_t s, const double* store_pos, const int32_t* ida, const int32_t* idb, int n, double* a6,
+                       double* b6);
 void launch_seg_prepare(hipStream_t s, const double* a6, const double* b6, int n, int32_t* seg_ns, int32_t* first_hit,
                         int32_t* ovf);
 // ctrl = 16 zeroed ints: [1] scan cursor, [2] work items, [3] list overflow, [4..11] settle counters.

@@ -998,6 +998,16 @@ __global__ __launch_bounds__(64 * SEG_WAVES) void k_collide_segments_dyn(EnvView
   }
 }
 
+__global__ __launch_bounds__(256) void k_seg_gather(const double* __restrict__ store_pos, const int32_t* __restrict__ ida,
+                                                    const int32_t* __restrict__ idb, int n, double* __restrict__ a6,
+                                                    double* __restrict__ b6) {
+  const int t = blockIdx.x * 256 + threadIdx.x;   // 6 threads per edge end: one double each
+  const int e = t / 12, k = t % 12;
+  if (e >= n) return;
+  if (k < 6) a6[6 * (size_t)e + k] = store_pos[6 * (size_t)ida[e] + k];
+  else b6[6 * (size_t)e + (k - 6)] = store_pos[6 * (size_t)idb[e] + (k - 6)];
+}
+
 // sample counts + result presets for a host-supplied batch of edges (C-ABI sffgpu_collide_segments)
 __global__ __launch_bounds__(256) void k_seg_prepare(const double* __restrict__ a6, const double* __restrict__ b6, int n,
                                                      int32_t* __restrict__ seg_ns, int32_t* __restrict__ first_hit,
@@ -1282,6 +1292,13 @@ void launch_settle(hipStream_t s, const SettleArgs& a) {
 void launch_classify(hipStream_t s, const ClassifyArgs& a) {
   if (a.n <= 0) return;
   hipLaunchKernelGGL(k_classify, dim3((a.n + 3) / 4), dim3(256), 0, s, a);
+}
+
+void launch_seg_gather(hipStream_t s, const double* store_pos, const int32_t* ida, const int32_t* idb, int n, double* a6,
+                       double* b6) {
+  if (n <= 0) return;
+  const long long threads = (long long)n * 12;
+  hipLaunchKernelGGL(k_seg_gather, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, store_pos, ida, idb, n, a6, b6);
 }
 
 void launch_seg_prepare(hipStream_t s, const double* a6, const double* b6, int n, int32_t* seg_ns, int32_t* first_hit,
