@@ -37,16 +37,37 @@ class RapidExpTree : public Solver<T, R> {
     }
     sffgpu_rrt* r = nullptr;
     sff_compat::check(sffgpu_rrt_create(sff_compat::gpu(), &cfg, roots.data(), (int)P.roots.size(), &r), "rrt");
-    auto startingTime = std::chrono::high_resolution_clock::now();   // src/rrt.h:90
-    sff_compat::check(sffgpu_rrt_run(r, 0), "rrt run");
-    auto stopTime = std::chrono::high_resolution_clock::now();       // :100
     sffgpu_rrt_stats st;
-    sffgpu_rrt_get_stats(r, &st);
-    const int n = st.n_nodes;
-    std::vector<double> pos((size_t)n * 6), cost(n), dpar(n);
-    std::vector<int32_t> parent(n), tree(n), root(n), iter(n);
-    sffgpu_rrt_get_nodes(r, pos.data(), parent.data(), tree.data(), root.data(), iter.data(), cost.data(), dpar.data());
-    this->fillNodes(n, pos.data(), parent.data(), root.data(), iter.data(), cost.data(), dpar.data());
+    auto loadNodes = [&]() {
+      sffgpu_rrt_get_stats(r, &st);
+      const int n = st.n_nodes;
+      std::vector<double> pos((size_t)n * 6), cost(n), dpar(n);
+      std::vector<int32_t> parent(n), tree(n), root(n), iter(n);
+      sffgpu_rrt_get_nodes(r, pos.data(), parent.data(), tree.data(), root.data(), iter.data(), cost.data(), dpar.data());
+      this->fillNodes(n, pos.data(), parent.data(), root.data(), iter.data(), cost.data(), dpar.data());
+      this->numTrees = P.GetNumRoots();
+    };
+    auto startingTime = std::chrono::high_resolution_clock::now();   // src/rrt.h:90
+    if (P.saveTreeIter == 0) {
+      sff_compat::check(sffgpu_rrt_run(r, 0), "rrt run");
+    } else {
+      // saveIterCheck (src/rrt.h:98, src/problemStruct.h:256-261): the engine runs exactly up to the next multiple
+      // of saveTreeIter, so the "iter_<k>_" dumps are the reference's snapshots after iteration k
+      while (true) {
+        sffgpu_rrt_get_stats(r, &st);
+        if (st.solved || st.iterations >= P.maxIterations) break;
+        const int before = st.iterations;
+        sff_compat::check(sffgpu_rrt_run(r, P.saveTreeIter - before % P.saveTreeIter), "rrt run");
+        sffgpu_rrt_get_stats(r, &st);
+        if (st.iterations == before) break;
+        if (st.iterations % P.saveTreeIter == 0) {
+          loadNodes();
+          this->saveTrees(prefixFileName(P.fileNames[SaveTree], "iter_" + std::to_string(st.iterations) + "_"));
+        }
+      }
+    }
+    auto stopTime = std::chrono::high_resolution_clock::now();       // :100
+    loadNodes();
     this->numTrees = P.GetNumRoots();
     this->neighboringMatrix.assign((size_t)this->numTrees * this->numTrees, 1.7976931348623157e308);
     std::vector<int32_t> conn(this->numTrees);
