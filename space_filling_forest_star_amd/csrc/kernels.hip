@@ -229,6 +229,7 @@ __device__ __forceinline__ void grid_test(const GridItem& it, const SweepQuery& 
 // One wavefront per query: the cells touched by the query ball's bounding box are dealt to the
 // lanes (27 cells for the planner's radius), each lane walks its cell's bucket; all lanes then
 // share the overflow list.  Same fp32 superset filter + exact fp64 re-test as the linear sweep.
+template <bool SPECULATE>
 __device__ __forceinline__ void grid_walk(const GridView& g, const SweepQuery& Q, int q, int lane, float rf,
                                           const NodeStoreView& st, const double* __restrict__ qpos,
                                           int32_t* __restrict__ cnt, int32_t* __restrict__ hit_idx,
@@ -238,7 +239,7 @@ __device__ __forceinline__ void grid_walk(const GridView& g, const SweepQuery& Q
   const int lz = grid_coord(Q.z - rf, g.oz, g.inv_cell, g.nz), hz = grid_coord(Q.z + rf, g.oz, g.inv_cell, g.nz);
   const int wx = hx - lx + 1, wy = hy - ly + 1, wz = hz - lz + 1;
   const int total = wx * wy * wz;
-  for (int c0 = 0; c0 < total; c0 += 64) {
+  for (int c0 = 0; c0 < total; c0 += 32) {   // (lane = index within the query's half-wave)
     const int c = c0 + lane;
     if (c < total) {
       const int cx = lx + c % wx, cy = ly + (c / wx) % wy, cz = lz + c / (wx * wy);
@@ -246,9 +247,17 @@ __device__ __forceinline__ void grid_walk(const GridView& g, const SweepQuery& Q
       // the first two items of the bucket are fetched together with its fill count (three independent loads
       // in flight; most cells hold 0-2 nodes), the rest only when the count says they exist
       const GridItem* items = g.items + cell * g.bk;
-      GridItem i0 = items[0];
-      GridItem i1 = g.bk > 1 ? items[1] : i0;
-      int m = g.cnt[cell];
+      GridItem i0, i1;
+      int m;
+      if (SPECULATE) {   // node grid: most cells near a query hold a node or two
+        i0 = items[0];
+        i1 = g.bk > 1 ? items[1] : i0;
+        m = g.cnt[cell];
+      } else {           // the round's own grid is nearly empty: look at the count first
+        m = g.cnt[cell];
+        if (m > 0) i0 = items[0];
+        if (m > 1) i1 = items[1];
+      }
       if (m > g.bk) m = g.bk;
       if (m > 0) grid_test(i0, Q, q, st, qpos, cnt, hit_idx, hit_dist, cap);
       if (m > 1) grid_test(i1, Q, q, st, qpos, cnt, hit_idx, hit_dist, cap);
@@ -265,10 +274,10 @@ __device__ __forceinline__ void grid_walk(const GridView& g, const SweepQuery& Q
   }
   int no = g.ovf_cnt[0];
   if (no > g.ovf_cap) no = g.ovf_cap;
-  for (int j = lane; j < no; j += 64) grid_test(g.ovf[j], Q, q, st, qpos, cnt, hit_idx, hit_dist, cap);
+  for (int j = lane; j < no; j += 32) grid_test(g.ovf[j], Q, q, st, qpos, cnt, hit_idx, hit_dist, cap);
 }
 
-// One wavefront per query: the cells touched by the query ball's bounding box are dealt to the
+// One half-wavefront (32 lanes) per query: the cells touched by the query ball's bounding box are dealt to the
 // lanes (27 cells for the planner's radius), each lane walks its cell's bucket; all lanes then
 // share the overflow list.  Same fp32 superset filter + exact fp64 re-test as the linear sweep.  With tg the
 // same walk is repeated over the grid of the round's own samples (query i keeps the ids below its max_id).
@@ -277,14 +286,14 @@ __global__ __launch_bounds__(256) void k_grid_query(GridView g, GridView tg, Nod
                                                     const double* __restrict__ qpos, int nq, int32_t* __restrict__ cnt,
                                                     int32_t* __restrict__ hit_idx, double* __restrict__ hit_dist,
                                                     int cap) {
-  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int lane = threadIdx.x & 63;
+  const int q = blockIdx.x * 8 + (threadIdx.x >> 5);
+  const int lane = threadIdx.x & 31;
   if (q >= nq) return;
   const SweepQuery Q = queries[q];
   if (!Q.active) return;
   const float rf = sqrtf(Q.r2f) * 1.000001f;
-  grid_walk(g, Q, q, lane, rf, st, qpos, cnt, hit_idx, hit_dist, cap);
-  if (tg.cnt) grid_walk(tg, Q, q, lane, rf, st, qpos, cnt, hit_idx, hit_dist, cap);
+  grid_walk<true>(g, Q, q, lane, rf, st, qpos, cnt, hit_idx, hit_dist, cap);
+  if (tg.cnt) grid_walk<false>(tg, Q, q, lane, rf, st, qpos, cnt, hit_idx, hit_dist, cap);
 }
 
 __global__ __launch_bounds__(256) void k_set_tree(int32_t* __restrict__ tree_col, const int32_t* __restrict__ ids, int n,
@@ -1259,7 +1268,7 @@ void launch_grid_query(hipStream_t s, const GridView& g, const GridView* tg, con
                        double* hit_dist, int cap) {
   if (nq <= 0) return;
   GridView none{};
-  hipLaunchKernelGGL(k_grid_query, dim3((nq + 3) / 4), dim3(256), 0, s, g, tg ? *tg : none, st, queries, qpos, nq, cnt,
+  hipLaunchKernelGGL(k_grid_query, dim3((nq + 7) / 8), dim3(256), 0, s, g, tg ? *tg : none, st, queries, qpos, nq, cnt,
                      hit_idx, hit_dist, cap);
 }
 void launch_set_tree(hipStream_t s, int32_t* tree_col, const int32_t* ids, int n, int32_t value) {
