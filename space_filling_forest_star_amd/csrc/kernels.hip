@@ -1228,7 +1228,8 @@ void launch_sample_steer(hipStream_t s, const uint64_t* words, const int32_t* pa
                          uint8_t* in_lim, double* parent_dist, SweepQuery* queries, int32_t q_max_base,
                          const RoundTemps& tmp) {
   if (n <= 0) return;
-  hipLaunchKernelGGL(k_sample_steer, dim3((n + 255) / 256), dim3(256), 0, s, words, parent, node_pos, center_in, n,
+  // (64-thread workgroups: a round has a few thousand samples, this spreads them over the whole chip)
+  hipLaunchKernelGGL(k_sample_steer, dim3((n + 63) / 64), dim3(64), 0, s, words, parent, node_pos, center_in, n,
                      dist, dim, prm, out6, in_lim, parent_dist, queries, q_max_base, tmp);
 }
 
