@@ -7,7 +7,7 @@
 #include "problemStruct.h"
 
 #ifndef SFF_COMPAT_WAVE
-#define SFF_COMPAT_WAVE 4096
+#define SFF_COMPAT_WAVE 8192
 #endif
 
 template <class T, class R = Point<T>>
