@@ -411,19 +411,19 @@ void Ctx::store_append(const double* pos6, const int32_t* tree, int n, bool wait
   if (n <= 0) return;
   HIPCHK(hipSetDevice(device));
   store_reserve(store_n + n);
-  h_a.ensure((size_t)n * 6 * sizeof(double));
-  h_b.ensure((size_t)n * sizeof(int32_t));
-  memcpy(h_a.p, pos6, (size_t)n * 6 * sizeof(double));
-  memcpy(h_b.p, tree, (size_t)n * sizeof(int32_t));
+  // one packed block: positions, then tree ids
+  const size_t pb = (size_t)n * 6 * sizeof(double), tb = (size_t)n * sizeof(int32_t);
+  h_a.ensure(pb + tb);
+  memcpy(h_a.p, pos6, pb);
+  memcpy(h_a.as<char>() + pb, tree, tb);
   for (int i = 0; i < n * 6; ++i)
     if (i % 6 < 3) store_maxabs = std::max(store_maxabs, std::fabs(pos6[i]));
-  d_a.ensure((size_t)n * 6 * sizeof(double));
-  d_b.ensure((size_t)n * sizeof(int32_t));
-  HIPCHK(hipMemcpyAsync(d_a.p, h_a.p, (size_t)n * 6 * sizeof(double), hipMemcpyHostToDevice, stream));
-  HIPCHK(hipMemcpyAsync(d_b.p, h_b.p, (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice, stream));
+  d_a.ensure(pb + tb);
+  HIPCHK(hipMemcpyAsync(d_a.p, h_a.p, pb + tb, hipMemcpyHostToDevice, stream));
   // with an up-to-date grid the new nodes are inserted by the same launch
   const bool fuse_grid = grid_on && grid_inserted == store_n;
-  sffk::launch_store_write(stream, store_mut(*this), d_a.as<double>(), d_b.as<int32_t>(), nullptr, nullptr, n, store_n,
+  sffk::launch_store_write(stream, store_mut(*this), d_a.as<double>(), reinterpret_cast<const int32_t*>(d_a.as<char>() + pb),
+                           nullptr, nullptr, n, store_n,
                            fuse_grid ? &gridv : nullptr);
   if (wait) sync();   // callers that keep the stream ordered (the forest engine) skip the wait
   store_n += n;
