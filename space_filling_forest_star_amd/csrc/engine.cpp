@@ -182,23 +182,26 @@ hipEvent_t Ctx::get_event() {
 // every timer_stride-th round (timing_on); the batch entry points always time.
 void Ctx::time_begin(int kind) {
   kernel_calls[kind] += 1;
+  if (round_scope) round_calls[kind] += 1;
   timed_now = timing_on;
   if (!timed_now) return;
-  Timed t{get_event(), get_event(), kind};
+  Timed t{get_event(), get_event(), kind, round_scope};
   HIPCHK(hipEventRecord(t.a, stream));
   pending.push_back(t);
 }
 void Ctx::time_end() { if (timed_now) HIPCHK(hipEventRecord(pending.back().b, stream)); }
-double Ctx::kernel_ms_total(int kind) const {   // measured sum scaled to all launches
-  if (!kernel_launches[kind]) return 0.0;
-  return kernel_ms[kind] * ((double)kernel_calls[kind] / (double)kernel_launches[kind]);
+double Ctx::kernel_ms_total(int kind) const {   // batch calls as measured + the sampled rounds scaled to all rounds
+  double ms = kernel_ms[kind];
+  if (round_timed[kind]) ms += round_ms[kind] * ((double)round_calls[kind] / (double)round_timed[kind]);
+  return ms;
 }
 void Ctx::sync() {
   HIPCHK(hipStreamSynchronize(stream));
   for (auto& t : pending) {
     float ms = 0;
     HIPCHK(hipEventElapsedTime(&ms, t.a, t.b));
-    kernel_ms[t.kind] += ms;
+    if (t.round) { round_ms[t.kind] += ms; round_timed[t.kind] += 1; }
+    else kernel_ms[t.kind] += ms;
     kernel_launches[t.kind] += 1;
     pool.push_back(t.a);
     pool.push_back(t.b);

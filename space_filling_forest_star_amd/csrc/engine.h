@@ -108,12 +108,17 @@ struct Ctx {
   PinBuf p_in, p_out;
 
   // kernel timing (HIP events on the launch stream)
-  struct Timed { hipEvent_t a, b; int kind; };
+  struct Timed { hipEvent_t a, b; int kind; bool round; };
   std::vector<Timed> pending;
   std::vector<hipEvent_t> pool;
   double kernel_ms[T_KINDS] = {0, 0, 0};
   uint64_t kernel_launches[T_KINDS] = {0, 0, 0};   // timed launches
   uint64_t kernel_calls[T_KINDS] = {0, 0, 0};      // all launches
+  // the forest engine's rounds are sampled (every timer_stride-th is bracketed): their sum is scaled to all rounds,
+  // the always-timed batch calls are added as measured
+  double round_ms[T_KINDS] = {0, 0, 0};
+  uint64_t round_calls[T_KINDS] = {0, 0, 0}, round_timed[T_KINDS] = {0, 0, 0};
+  bool round_scope = false;
   bool timing_on = true, timed_now = true;
   int timer_stride = 8;
   double kernel_ms_total(int kind) const;

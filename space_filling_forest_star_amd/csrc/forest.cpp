@@ -376,6 +376,7 @@ void Forest::round_begin() {
     }
   }
   c.timing_on = c.timer_stride <= 1 || st.sweeps % (uint64_t)c.timer_stride == 0;
+  c.round_scope = true;
   const uint64_t* d_words = reinterpret_cast<const uint64_t*>(c.r_in.as<char>() + in_words);
   const int32_t* d_parent = reinterpret_cast<const int32_t*>(c.r_in.as<char>() + in_parent);
   const uint8_t* d_force = reinterpret_cast<const uint8_t*>(c.r_in.as<char>() + in_force);
@@ -491,6 +492,7 @@ void Forest::round_begin() {
   }
   HIPCHK(hipMemcpyAsync(ho + early_bytes, dout + early_bytes, o_bytes - early_bytes, hipMemcpyDeviceToHost, c.stream));
   c.timing_on = true;
+  c.round_scope = false;
   g_sec[1] += ms_since(_t1);
   // the GPU is busy for a while: generate the engine words of the next draws now
   if (!rng_ahead.empty()) rng.prefetch(rng_ahead.data(), rng_ahead.size());
