@@ -332,6 +332,54 @@ __device__ int collect_candidates(const EnvView& env, const double* qlo, const d
   int n_cand = 0;
   st.sp = 0;
   *overflow = false;
+  if (env.n_levels == 1) {
+    // small environments (<= 4096 triangles): the top level IS the list of leaf groups.  Walk the hit groups
+    // straight off the ballot mask and fetch the next group's triangle boxes while the current ones are tested,
+    // so the dependent loads of consecutive groups overlap (the general stack walk below pays them one by one).
+    const int cnt = env.level_count[0];
+    bool h = false;
+    if (lane < cnt) {
+      const double* b = env.level_box[0] + 6 * (size_t)lane;
+      h = box_hit(b, b + 3, qlo, qhi);
+    }
+    unsigned long long groups = __ballot(h);
+    double cur[6] = {0, 0, 0, 0, 0, 0}, nxt[6] = {0, 0, 0, 0, 0, 0};
+    auto fetch = [&](int g, double* out) -> bool {
+      const int t = g * 64 + lane;
+      if (t >= env.n_tri) return false;
+      const double* b = env.tri_box + 6 * (size_t)t;
+      for (int k = 0; k < 6; ++k) out[k] = b[k];
+      return true;
+    };
+    bool have_cur = false;
+    int g = -1;
+    if (groups) {
+      g = __ffsll((long long)groups) - 1;
+      groups &= groups - 1;
+      have_cur = fetch(g, cur);
+    }
+    while (g >= 0) {
+      int gn = -1;
+      bool have_nxt = false;
+      if (groups) {
+        gn = __ffsll((long long)groups) - 1;
+        groups &= groups - 1;
+        have_nxt = fetch(gn, nxt);
+      }
+      const bool hit = have_cur && box_hit(cur, cur + 3, qlo, qhi);
+      const unsigned long long m = __ballot(hit);
+      if (m) {
+        const int before = __popcll(m & ((1ULL << lane) - 1ULL));
+        if (hit && n_cand + before < cap) cand[n_cand + before] = g * 64 + lane;
+        n_cand += __popcll(m);
+        if (n_cand > cap) { *overflow = true; n_cand = cap; }
+      }
+      for (int k = 0; k < 6; ++k) cur[k] = nxt[k];
+      have_cur = have_nxt;
+      g = gn;
+    }
+    return n_cand;
+  }
   // top level: up to 64 boxes
   {
     const int L = env.n_levels - 1;
