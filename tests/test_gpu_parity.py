@@ -359,6 +359,35 @@ def test_baseline_configs_equal_the_oracle(S, ctx, golden_dir):
         f.close()
 
 
+def test_more_seeds_equal_the_oracle(S, ctx, golden_dir):
+    """More seeds, root counts and wave sizes of mid-size runs (SFF and SFF*, all four maps) against the committed
+    oracle summaries tests/golden/soak_runs.json (tests/golden/make_soak_runs.py)."""
+    import json
+    import os
+    path = os.path.join(golden_dir, "soak_runs.json")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/soak_runs.json not generated")
+    import importlib.util
+    import sys
+    sys.path.insert(0, golden_dir)
+    spec = importlib.util.spec_from_file_location("make_soak_runs", os.path.join(golden_dir, "make_soak_runs.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    gold = json.load(open(path))
+    for name, nroots, opt, budget, wave, seed in mk.RUNS:
+        key = "%s/%d roots/%s/budget %d/wave %d/seed %d" % (name, nroots, "star" if opt else "plain", budget, wave, seed)
+        sc, w = load_world(ctx, name)
+        roots = common.free_roots(lambda p: int(ctx.collide_poses(p[None, :])[0]), sc["limits"], nroots, seed=seed,
+                                  dim=sc["dim"])
+        f = S.Forest(ctx, roots, sc["limits"], dist_tree=sc["dist_tree"], sampling_dist=sc["sampling_dist"], dim=sc["dim"],
+                     optimize=opt, max_iterations=2**31 - 1, node_budget=budget, wave=wave, seed=seed)
+        f.run(0)
+        got = mk.summary(f)
+        for k in got:
+            assert got[k] == gold[key][k], (key, k, got[k], gold[key][k])
+        f.close()
+
+
 def test_forest_node_budget_and_seeds(S, ctx):
     for seed in (1, 3):
         fo, fg = run_pair(S, ctx, "dense3d", 512, 10**6, seed=seed, n_roots=10, budget=6000)
