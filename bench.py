@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--force-dist", action="store_true", help="run the RCCL record exchange even with one rank")
     ap.add_argument("--cpu-iters", type=int, default=120000, help="iterations of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-sweep-micro", action="store_true", help="skip the stand-alone k_sweep roofline measurement")
     args = ap.parse_args()
 
     import numpy as np
@@ -111,13 +112,16 @@ def main():
         # HBM-side bytes per neighbour query from the committed PMC summary (separate rocprofv3 --pmc
         # passes of this command; FETCH_SIZE doubled per MI355X_MICROARCH.md, gather pattern uncalibrated)
         traffic = None
+        sweep_traffic = None
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "r1q_bench_pmc_summary.json")))
             kib = 0.0
-            for k in ("sffk::k_grid_query", "sffk::k_sweep"):   # (k_sweep only when a profile saw it in the rounds)
-                if k in pm["FETCH_SIZE"]:
-                    kib += 2.0 * pm["FETCH_SIZE"][k]["avg_KiB_per_launch"] + pm["WRITE_SIZE"][k]["avg_KiB_per_launch"]
+            k = "sffk::k_grid_query"
+            kib = 2.0 * pm["FETCH_SIZE"][k]["avg_KiB_per_launch"] + pm["WRITE_SIZE"][k]["avg_KiB_per_launch"]
             traffic = kib * 1024.0
+            k = "sffk::k_sweep"   # (only launched by the stand-alone sweep measurement below)
+            if k in pm["FETCH_SIZE"]:
+                sweep_traffic = 1024.0 * (2.0 * pm["FETCH_SIZE"][k]["avg_KiB_per_launch"] + pm["WRITE_SIZE"][k]["avg_KiB_per_launch"])
         except Exception:
             traffic = None
         out = {
@@ -161,6 +165,31 @@ def main():
                 "avg_queries_per_launch": (s1["sweep_queries"] - s0["sweep_queries"]) / max(1, sweeps),
             },
         }
+        if world == 1 and not args.no_sweep_micro:
+            # the linear k-NN sweep on its own (SURVEY.md 8(d) micro-benchmark, see profiles/sweep_microbench.py): N
+            # uniform nodes, ONE query per pass, radius for ~32 neighbours; kernel time from the library's HIP events
+            rs = np.random.RandomState(1)
+            lim = np.asarray(sc["limits"], dtype=np.float64)
+            Nn = 2000000
+            pts = np.empty((Nn, 6))
+            for a in range(3):
+                pts[:, a] = rs.uniform(lim[2 * a], lim[2 * a + 1], Nn)
+            pts[:, 3:] = rs.uniform(-np.pi, np.pi, (Nn, 3))
+            ctx.nodes_reset(Nn + 64)
+            ctx.nodes_append(pts, np.zeros(Nn, np.int32))
+            vol = (lim[1] - lim[0]) * (lim[3] - lim[2]) * (lim[5] - lim[4])
+            rad = (32.0 * vol / Nn / 4.19) ** (1.0 / 3.0)
+            qq = pts[rs.randint(0, Nn, 1)] + rs.normal(0, 5.0, (1, 6))
+            ctx.radius(qq, rad, cap=64)
+            ms0, _ = ctx.kernel_times()
+            reps = 30
+            for _ in range(reps):
+                ctx.radius(qq, rad, cap=64)
+            ms1, _ = ctx.kernel_times()
+            tt = (ms1[0] - ms0[0]) / reps * 1e-3
+            out["sweep_kernel_roofline"] = {"kernel": "sffk::k_sweep", "bound": "hbm", "nodes": Nn, "queries_per_pass": 1,
+                                            "us_per_pass": tt * 1e6, "achieved": 24.0 * Nn / tt / 1e9, "peak": 8000.0,
+                                            "unit": "GB/s", "frac": 24.0 * Nn / tt / 8e12, "traffic": sweep_traffic}
         if args.cpu_iters > 0 and world == 1:
             import oracle_lib as O
             w = O.World(sc["env"], sc["robot"], O.TRIG_PORTABLE)
