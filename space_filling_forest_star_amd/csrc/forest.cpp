@@ -1071,7 +1071,8 @@ void Forest::round_commit(const int32_t* all, const int32_t* counts, int world) 
       double best = sffg::dist6(cd.pos, nodes[expanded].pos) + nodes[expanded].d_root;
       const size_t ksff = (size_t)(2 * M_E * std::log10((double)nodes.size()));  // Node::globId (:309)
       struct KN { double d; int order; int node; const Member* mb; };
-      std::vector<KN> knn;
+      static thread_local std::vector<KN> knn;   // (scratch: one allocation for the whole run)
+      knn.clear();
       for (const Member& mb : cd.members) {
         int nd = mb.id >= 0 ? mb.id : cands[-1 - mb.id].accepted_id;
         if (nd < 0) continue;
