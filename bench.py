@@ -1,20 +1,30 @@
 #!/usr/bin/env python3
 """bench.py — headline benchmark of the SFF hot path on MI355X.
 
-Workload (BASELINE.json configs[2], the headline): dense_3D.obj map, 6-DoF cylinder robot,
-10 roots, SFF solver, 1M-node budget (authored step circum=14 / dtree=18: SURVEY.md §8(d)).
-A "step" is one WAVE of the tree-expansion loop: `--wave` frontier slots, each sampled /
-neighbour-swept / collision-checked for up to ThresholdMisses rounds, then committed.
-`value` = accepted node expansions per second over the K timed waves (whole job), with the
-map, robot and node store resident in HBM before the timed region starts.
+Workload (BASELINE.json configs[2], the headline): dense_3D.obj map, 6-DoF cylinder robot, 10 seeded roots,
+SFF solver, 1M-node budget (authored step circum=14 / dtree=18: SURVEY.md §8(d)).
 
-Prints ONE JSON line (rank 0) with the driver's contract plus `roofline` (neighbour-sweep
-kernel, HIP-event timed inside the library on its launch stream) and `cpu_baseline` (the CPU
-oracle, wave=1 == the reference's sequential loop, on a bounded sample of the same workload).
+A "step" is a fixed block of `--waves-per-step` waves of the tree-expansion loop (a wave = `--wave` frontier
+slots, each sampled / neighbour-queried / collision-checked for up to ThresholdMisses rounds, then committed in
+order).  With the defaults (and the driver's `--steps 20 --warmup 5`) the 20 timed steps of 13 waves span the WHOLE
+job: 10 roots -> the 1M-node budget (~258 waves).  The warm-up steps run on a separate, discarded forest of the
+same workload so that the timed region starts from the roots with warm kernels, allocations and caches.
+`value` = accepted node expansions per second over the timed steps, whole job, with the map, the robot and the
+node store resident in HBM before the timed region starts.
+
+Prints ONE JSON line (rank 0): the driver's contract plus
+  roofline      neighbour-query kernel of the timed region, HIP-event timed inside the library on its launch
+                stream; `traffic` only from a PMC summary collected with exactly these arguments (profiles/)
+  cpu_baseline  the CPU oracle (kind "port": the reference binary cannot be built, RAPID is absent from its
+                tree), wave = 1 == the reference's sequential loop, on a bounded sample of the same workload
+  wave_sweep    the same forest at wave = 1 / 64 / 512 (bounded samples) and a quality block that compares
+                the planner's output at small and large waves (the reference loop is wave = 1)
+`--gpus N` (N > 1) without a torchrun environment re-launches itself under torch.distributed.run.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -22,19 +32,85 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r2_bench_pmc_summary.json")
 
-def main():
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=255)   # 3 + 255 waves of 8192 slots: ~10 -> ~940k nodes of the 1M budget
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--wave", type=int, default=8192)
+    ap.add_argument("--waves-per-step", type=int, default=13,
+                    help="waves per bench step: 20 steps x 13 waves of 8192 slots reach the 1M-node budget")
     ap.add_argument("--budget", type=int, default=1000000)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--force-dist", action="store_true", help="run the RCCL record exchange even with one rank")
     ap.add_argument("--cpu-iters", type=int, default=120000, help="iterations of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-sweep-micro", action="store_true", help="skip the stand-alone k_sweep roofline measurement")
-    args = ap.parse_args()
+    ap.add_argument("--no-wave-sweep", action="store_true", help="skip the wave = 1 / 64 / 512 legs and the quality block")
+    return ap.parse_args()
+
+
+def relaunch_under_torchrun(args):
+    """--gpus N without RANK/WORLD_SIZE: start the N ranks as a child job (before anything touches the GPU)."""
+    port = 29500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    for ln in lines[:-1]:
+        print(ln, file=sys.stderr)
+    if lines:
+        print(lines[-1], flush=True)
+    sys.exit(p.returncode)
+
+
+def forest_quality(S, forest, ctx, sc):
+    """Planner-quality figures of a finished forest: acceptance rate, coverage of the free space, tree costs."""
+    import numpy as np
+    st = forest.stats()
+    nd = forest.nodes()
+    n = st["n_nodes"]
+    q = {"nodes": n, "iterations": st["iterations"], "nodes_per_iteration": n / max(1, st["iterations"]),
+         "borders": st["n_borders"], "trees_connected": st["n_connected"]}
+    # cost-to-root per unit of straight-line distance to the root (1.0 = straight line): how direct the trees are
+    root_of = np.arange(n)
+    par = nd["parent"]
+    roots = np.where(par < 0)[0]
+    root_pos = {int(t): nd["pos"][r] for r, t in zip(roots, nd["tree"][roots])}
+    rp = np.array([root_pos[int(t)] for t in nd["tree"]])
+    dd = nd["pos"] - rp
+    dd[:, 3:] = (dd[:, 3:] + np.pi) % (2 * np.pi) - np.pi
+    straight = np.sqrt((dd ** 2).sum(axis=1))
+    m = straight > 5 * sc["sampling_dist"]
+    if m.any():
+        ratio = nd["cost"][m] / straight[m]
+        q["cost_over_straight_line"] = {"median": float(np.median(ratio)), "p90": float(np.percentile(ratio, 90)),
+                                       "max": float(ratio.max())}
+    q["mean_edge_length_over_step"] = float(nd["dpar"][par >= 0].mean() / sc["sampling_dist"]) if n > len(roots) else None
+    # coverage: seeded free probe poses that have a node within 2 steps (xyz), among probes inside the hull the
+    # forest has reached so far (bounding box of its nodes)
+    rs = np.random.RandomState(7)
+    lim = sc["limits"]
+    lo, hi = nd["pos"][:, :3].min(axis=0), nd["pos"][:, :3].max(axis=0)
+    pr = np.zeros((4000, 6))
+    for a in range(3):
+        pr[:, a] = rs.uniform(max(lim[2 * a], lo[a]), min(lim[2 * a + 1], hi[a]), len(pr))
+    free = ctx.collide_poses(pr) == 0
+    pr = pr[free]
+    if len(pr):
+        from scipy.spatial import cKDTree
+        d, _ = cKDTree(nd["pos"][:, :3]).query(pr[:, :3])
+        q["coverage_within_2_steps"] = float((d < 2 * sc["sampling_dist"]).mean())
+        q["coverage_probes"] = int(len(pr))
+    return q
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch_under_torchrun(args)
 
     import numpy as np
     import torch
@@ -43,6 +119,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node %d)" % (args.gpus, world, args.gpus))
     distributed = world > 1 or args.force_dist
     torch.cuda.set_device(local_rank)
     if distributed:
@@ -59,15 +137,14 @@ def main():
     ctx.upload_robot(sc["robot"])
     # 10 seeded collision-free roots (identical on every rank): drawn with the GPU collision kernel
     roots = common.free_roots(lambda p: int(ctx.collide_poses(p[None, :])[0]), sc["limits"], 10, seed=1)
-    # multi-GPU (BASELINE configs[3]): the SAME forest and the same 1 M-node budget, the wave's sample batch
-    # sharded over the ranks (strong scaling: total work fixed).  Rank r evaluates candidates i with
-    # i % world == r, the answers are all-gathered over RCCL once per round and every rank replays the identical
-    # commit, so the result equals the 1-GPU run bit for bit.
-    forest = S.Forest(ctx, roots, sc["limits"], dist_tree=sc["dist_tree"], sampling_dist=sc["sampling_dist"], dim=6,
-                      max_iterations=2**31 - 1, node_budget=args.budget, wave=args.wave, seed=args.seed,
-                      rank=rank, world=world)
 
-    def run_waves(k):
+    # multi-GPU (BASELINE configs[3]): the SAME forest and the same 1 M-node budget, the wave's sample batch
+    # sharded over the ranks (strong scaling: total work fixed); the result equals the 1-GPU run bit for bit.
+    def make_forest(wave=args.wave, budget=args.budget, max_iterations=2**31 - 1, rk=rank, wd=world):
+        return S.Forest(ctx, roots, sc["limits"], dist_tree=sc["dist_tree"], sampling_dist=sc["sampling_dist"], dim=6,
+                        max_iterations=max_iterations, node_budget=budget, wave=wave, seed=args.seed, rank=rk, world=wd)
+
+    def run_waves(forest, k):
         if distributed:
             S.run_distributed(forest, k)
         else:
@@ -78,11 +155,29 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    run_waves(args.warmup)
+    B = max(1, args.waves_per_step)
+    # ---- warm-up: W steps of the same workload on a forest that is then thrown away
+    if args.warmup > 0:
+        fw = make_forest()
+        run_waves(fw, args.warmup * B)
+        fw.close()
+
+    # ---- timed region: exactly K steps (the last one ends early if the node budget is reached inside it)
+    forest = make_forest()
     s0 = forest.stats()
+    step_ms = []
     barrier()
     t0 = time.perf_counter()
-    run_waves(args.steps)
+    steps_done = 0
+    for _ in range(args.steps):
+        w_before = forest.stats()["waves"]
+        ts = time.perf_counter()
+        run_waves(forest, B)
+        step_ms.append(1e3 * (time.perf_counter() - ts))
+        if forest.stats()["waves"] == w_before:
+            step_ms.pop()
+            break           # the job had already finished: no step was run
+        steps_done += 1
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     barrier()
@@ -92,7 +187,6 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    steps_done = int(s1["waves"] - s0["waves"])
     acc = float(s1["n_nodes"] - s0["n_nodes"])
     checks = float(s1["collide_calls"] - s0["collide_calls"])
     executed = float(s1["poses_executed"] - s0["poses_executed"] + s1["samples_executed"] - s0["samples_executed"])
@@ -100,7 +194,7 @@ def main():
         t = torch.tensor([executed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
         executed = float(t.item())
-
+    quality_main = forest_quality(S, forest, ctx, sc) if rank == 0 else None
     forest.close()
 
     out = None
@@ -109,21 +203,22 @@ def main():
         sweeps = s1["sweeps"] - s0["sweeps"]
         sweep_nodes = s1["sweep_nodes"] - s0["sweep_nodes"]
         achieved = (24.0 * sweep_nodes / (sweep_ms * 1e-3)) / 1e9 if sweep_ms > 0 else 0.0
-        # HBM-side bytes per neighbour query from the committed PMC summary (separate rocprofv3 --pmc
-        # passes of this command; FETCH_SIZE doubled per MI355X_MICROARCH.md, gather pattern uncalibrated)
-        traffic = None
-        sweep_traffic = None
+        # HBM-side bytes per launch of the neighbour-query kernel: only from a PMC summary that was collected
+        # (separate rocprofv3 --pmc passes, profiles/collect.sh) with exactly the arguments of this run
+        traffic, traffic_source, sweep_traffic = None, None, None
+        run_key = {"steps": args.steps, "warmup": args.warmup, "wave": args.wave, "waves_per_step": B,
+                   "budget": args.budget, "seed": args.seed, "gpus": world}
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r1q_bench_pmc_summary.json")))
-            kib = 0.0
-            k = "sffk::k_grid_query"
-            kib = 2.0 * pm["FETCH_SIZE"][k]["avg_KiB_per_launch"] + pm["WRITE_SIZE"][k]["avg_KiB_per_launch"]
-            traffic = kib * 1024.0
-            k = "sffk::k_sweep"   # (only launched by the stand-alone sweep measurement below)
-            if k in pm["FETCH_SIZE"]:
-                sweep_traffic = 1024.0 * (2.0 * pm["FETCH_SIZE"][k]["avg_KiB_per_launch"] + pm["WRITE_SIZE"][k]["avg_KiB_per_launch"])
+            pm = json.load(open(PMC_SUMMARY))
+            if pm.get("bench_args") == run_key:
+                k = pm.get("query_kernel", "sffk::k_grid_query")
+                traffic = 1024.0 * (2.0 * pm["FETCH_SIZE"][k]["avg_KiB_per_launch"] + pm["WRITE_SIZE"][k]["avg_KiB_per_launch"])
+                traffic_source = "profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; 2 x FETCH + WRITE (gfx950 correction of MI355X_MICROARCH.md)" % os.path.basename(PMC_SUMMARY)
+                k = "sffk::k_sweep"
+                if k in pm["FETCH_SIZE"]:
+                    sweep_traffic = 1024.0 * (2.0 * pm["FETCH_SIZE"][k]["avg_KiB_per_launch"] + pm["WRITE_SIZE"][k]["avg_KiB_per_launch"])
         except Exception:
-            traffic = None
+            pass
         out = {
             "metric": "accepted node expansions/sec + collision checks/sec, dense_3D 6-DoF",
             "value": acc / elapsed,
@@ -139,31 +234,33 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": "dense_3D.obj (1832 tris) + robot_cylinder_small (124 tris), 6-DoF, 10 seeded roots, SFF, "
-                            "circum=14 dtree=18, 1M-node budget; step = one wave of %d frontier slots" % args.wave,
-                "wave": args.wave, "wave_per_gpu": args.wave // world, "node_budget": args.budget, "seed": args.seed,
-                "nodes_at_start": s0["n_nodes"], "nodes_at_end": s1["n_nodes"],
+                            "circum=14 dtree=18, 1M-node budget; step = %d waves of %d frontier slots; the timed steps "
+                            "run the whole job from the roots (warm-up on a separate forest)" % (B, args.wave),
+                "wave": args.wave, "waves_per_step": B, "wave_per_gpu": args.wave // world, "node_budget": args.budget,
+                "seed": args.seed, "nodes_at_start": s0["n_nodes"], "nodes_at_end": s1["n_nodes"],
+                "waves": int(s1["waves"] - s0["waves"]),
                 "parallelism": "1 GPU" if world == 1 else
                 "one forest, wave slots sharded over %d GPUs (i %% world), RCCL all-gather of answer records per round" % world,
             },
             "collision_checks_per_s": checks / elapsed,
             "collision_checks_executed_per_s": executed / elapsed,
             "iterations": s1["iterations"] - s0["iterations"],
+            "step_ms": [round(x, 3) for x in step_ms],
             "time_split_ms": {"total": 1e3 * elapsed, "sweep_kernel": sweep_ms,
                               "collide_kernels": s1["collide_ms"] - s0["collide_ms"],
                               "sample_kernel": s1["sample_ms"] - s0["sample_ms"],
                               "host_logic": s1["host_ms"] - s0["host_ms"]},
             "roofline": {
-                # neighbour query of one round = k_grid_query over the node grid and over the round's own
-                # grid, timed with HIP events on the library's launch stream (every 8th round).  Algorithmic
-                # bytes = 24 B x nodes the query has to cover; the grid touches far fewer
-                # bytes than that, see `traffic` (rocprofv3 PMC pass of this same command, profiles/).
+                # neighbour query of one round, timed with HIP events on the library's launch stream (every 8th
+                # round).  Algorithmic bytes = 24 B x nodes the query has to cover.
                 "bound": "hbm", "kernel": "sffk::k_grid_query (node grid + the round's own grid)",
                 "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                "traffic": traffic,
+                "traffic": traffic, "traffic_source": traffic_source,
                 "launches": int(sweeps), "avg_launch_us": 1e3 * sweep_ms / max(1, sweeps),
                 "avg_nodes_per_launch": sweep_nodes / max(1, sweeps),
                 "avg_queries_per_launch": (s1["sweep_queries"] - s0["sweep_queries"]) / max(1, sweeps),
             },
+            "quality": {"wave_%d_full_run" % args.wave: quality_main},
         }
         if world == 1 and not args.no_sweep_micro:
             # the linear k-NN sweep on its own (SURVEY.md 8(d) micro-benchmark, see profiles/sweep_microbench.py): N
@@ -190,6 +287,27 @@ def main():
             out["sweep_kernel_roofline"] = {"kernel": "sffk::k_sweep", "bound": "hbm", "nodes": Nn, "queries_per_pass": 1,
                                             "us_per_pass": tt * 1e6, "achieved": 24.0 * Nn / tt / 1e9, "peak": 8000.0,
                                             "unit": "GB/s", "frac": 24.0 * Nn / tt / 8e12, "traffic": sweep_traffic}
+        if world == 1 and not args.no_wave_sweep:
+            # the small-wave end: wave = 1 IS the reference's sequential loop (one sample per GPU round trip)
+            legs = {}
+            for wv, iters in ((1, 8000), (64, 150000), (512, 1000000)):
+                f = make_forest(wave=wv, budget=0, max_iterations=iters, rk=0, wd=1)
+                c0 = time.perf_counter()
+                f.run()
+                dt = time.perf_counter() - c0
+                st = f.stats()
+                legs["wave_%d" % wv] = {"accepted_nodes_per_s": (st["n_nodes"] - len(roots)) / dt,
+                                        "iterations_per_s": st["iterations"] / dt, "iterations": st["iterations"],
+                                        "nodes": st["n_nodes"], "seconds": dt}
+                f.close()
+            out["wave_sweep"] = legs
+            # does a large wave degrade the planner?  The same 30 k-node budget at wave 64 (close to the sequential
+            # loop: the frontier holds thousands of nodes) and at the bench's wave
+            for wv in (64, args.wave):
+                f = make_forest(wave=wv, budget=30000, rk=0, wd=1)
+                f.run()
+                out["quality"]["wave_%d_30k_nodes" % wv] = forest_quality(S, f, ctx, sc)
+                f.close()
         if args.cpu_iters > 0 and world == 1:
             import oracle_lib as O
             w = O.World(sc["env"], sc["robot"], O.TRIG_PORTABLE)
@@ -202,7 +320,8 @@ def main():
             out["cpu_baseline"] = {
                 "value": (so["n_nodes"] - 10) / (c1 - c0), "unit": "accepted nodes/s", "cores": 1, "kind": "port",
                 "sample": "first %d iterations of the same workload from the same roots and seed, wave=1 (the "
-                          "reference's sequential loop), CPU oracle; reached %d nodes in %.1f s"
+                          "reference's sequential loop), CPU oracle (the reference binary itself cannot be built: RAPID "
+                          "is absent from its tree); reached %d nodes in %.1f s"
                           % (args.cpu_iters, so["n_nodes"], c1 - c0),
                 "collision_checks_per_s": so["collide_calls"] / (c1 - c0),
             }

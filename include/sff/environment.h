@@ -10,32 +10,11 @@
 #include <string>
 #include <vector>
 
-#include "../sffgpu.h"
+#include "sff_gpu.h"
 #include "primitives.h"
 
 template <class T> class Obstacle;
 
-namespace sff_compat {
-// one process-wide GPU context, like the reference's process-wide RAPID state
-inline sffgpu_ctx*& gpu_slot() { static sffgpu_ctx* c = nullptr; return c; }
-inline sffgpu_ctx* gpu() {
-  sffgpu_ctx*& c = gpu_slot();
-  if (!c) {
-    const char* dev = std::getenv("SFFGPU_DEVICE");
-    if (sffgpu_create(dev ? std::atoi(dev) : 0, &c) != SFFGPU_OK) {
-      std::cout << "libsffgpu: " << sffgpu_last_error(nullptr) << "\n";   // reference style: message + exit(1)
-      std::exit(1);
-    }
-  }
-  return c;
-}
-inline void check(int rc, const char* what) {
-  if (rc < 0) {
-    std::cout << "libsffgpu: " << what << ": " << sffgpu_last_error(gpu()) << "\n";
-    std::exit(1);
-  }
-}
-}  // namespace sff_compat
 
 template <class T>
 class Environment {

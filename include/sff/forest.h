@@ -21,7 +21,7 @@ class SpaceForest : public Solver<T, R> {
     if (!this->open(f, file, "Saving frontiers")) return;
     if (file.type == Obj) f << "o Open nodes\n";
     for (int32_t id : open_nodes) {
-      const Point<T> p = this->allNodes[id].Position / this->problem.environment.ScaleFactor;
+      const Point<T> p = this->allNodes[id]->Position / this->problem.environment.ScaleFactor;
       if (file.type == Obj) {
         f << "v" << DELIMITER_OUT;
         if (this->usePriority) p.printPosOnly(f); else f << p;
@@ -72,8 +72,7 @@ class SpaceForest : public Solver<T, R> {
       std::vector<double> pos((size_t)n * 6), cost(n), dpar(n);
       std::vector<int32_t> parent(n), tree(n), iter(n);
       sffgpu_forest_get_nodes(f, pos.data(), parent.data(), tree.data(), iter.data(), cost.data(), dpar.data());
-      this->fillNodes(n, pos.data(), parent.data(), tree.data(), iter.data(), cost.data(), dpar.data());
-      this->numTrees = st.n_trees;
+      this->fillNodes(n, st.n_trees, pos.data(), parent.data(), tree.data(), iter.data(), cost.data(), dpar.data());
     };
     auto loadFrontier = [&](std::vector<int32_t>& open_nodes) {
       int k = sffgpu_forest_get_frontier(f, nullptr, 0);
@@ -114,10 +113,10 @@ class SpaceForest : public Solver<T, R> {
     auto stopTime = std::chrono::high_resolution_clock::now();       // :203
 
     loadNodes();
-    this->neighboringMatrix.assign((size_t)st.n_trees * st.n_trees, 0.0);
+    this->pathCost.assign((size_t)st.n_trees * st.n_trees, 0.0);
     std::vector<int32_t> conn(st.n_trees);
-    int nc = sffgpu_forest_paths(f, this->neighboringMatrix.data(), conn.data(), st.n_trees);   // getPaths + getAllPaths
-    this->connectedTrees.assign(conn.begin(), conn.begin() + nc);
+    int nc = sffgpu_forest_paths(f, this->pathCost.data(), conn.data(), st.n_trees);   // getPaths + getAllPaths
+    const std::vector<int> connected(conn.begin(), conn.begin() + nc);
     auto loadPlans = [&]() {
       this->plans.assign((size_t)st.n_trees * st.n_trees, {});
       for (int i = 0; i < st.n_trees; ++i)
@@ -130,13 +129,15 @@ class SpaceForest : public Solver<T, R> {
         }
     };
     loadPlans();
+    this->fillPaths(connected);
     // :114-116, :207-235 — same order of outputs as the reference
     if (SaveGoals <= P.saveOptions) this->saveCities(P.fileNames[SaveGoals]);
     if (SaveTree <= P.saveOptions) this->saveTrees(P.fileNames[SaveTree]);
     if (SaveRaw <= P.saveOptions) this->savePaths(P.fileNames[SaveRaw]);
     if (P.smoothing) {                                               // :219-224
-      sff_compat::check(sffgpu_forest_smooth_paths(f, this->neighboringMatrix.data()), "smooth paths");
+      sff_compat::check(sffgpu_forest_smooth_paths(f, this->pathCost.data()), "smooth paths");
       loadPlans();
+      this->fillPaths(connected);
       if (SaveSmooth <= P.saveOptions) this->savePaths(P.fileNames[SaveSmooth]);
     }
     std::vector<int32_t> open_nodes;

@@ -44,8 +44,8 @@ class RapidExpTree : public Solver<T, R> {
       std::vector<double> pos((size_t)n * 6), cost(n), dpar(n);
       std::vector<int32_t> parent(n), tree(n), root(n), iter(n);
       sffgpu_rrt_get_nodes(r, pos.data(), parent.data(), tree.data(), root.data(), iter.data(), cost.data(), dpar.data());
-      this->fillNodes(n, pos.data(), parent.data(), root.data(), iter.data(), cost.data(), dpar.data());
-      this->numTrees = P.GetNumRoots();
+      this->fillNodes(n, P.GetNumRoots(), pos.data(), parent.data(), root.data(), iter.data(), cost.data(), dpar.data(),
+                      tree.data());
     };
     auto startingTime = std::chrono::high_resolution_clock::now();   // src/rrt.h:90
     if (P.saveTreeIter == 0) {
@@ -68,11 +68,10 @@ class RapidExpTree : public Solver<T, R> {
     }
     auto stopTime = std::chrono::high_resolution_clock::now();       // :100
     loadNodes();
-    this->numTrees = P.GetNumRoots();
-    this->neighboringMatrix.assign((size_t)this->numTrees * this->numTrees, 1.7976931348623157e308);
+    this->pathCost.assign((size_t)this->numTrees * this->numTrees, 1.7976931348623157e308);
     std::vector<int32_t> conn(this->numTrees);
-    int nc = sffgpu_rrt_paths(r, this->neighboringMatrix.data(), conn.data(), this->numTrees);   // getConnectedTrees + getPaths
-    this->connectedTrees.assign(conn.begin(), conn.begin() + (nc > 0 ? nc : 0));
+    int nc = sffgpu_rrt_paths(r, this->pathCost.data(), conn.data(), this->numTrees);   // getConnectedTrees + getPaths
+    const std::vector<int> connected(conn.begin(), conn.begin() + (nc > 0 ? nc : 0));
     this->plans.assign((size_t)this->numTrees * this->numTrees, {});
     for (int i = 0; i < this->numTrees; ++i)
       for (int j = i + 1; j < this->numTrees; ++j) {
@@ -82,6 +81,7 @@ class RapidExpTree : public Solver<T, R> {
         sffgpu_rrt_path_plan(r, i, j, ids.data(), len);
         this->plans[(size_t)i * this->numTrees + j].assign(ids.begin(), ids.end());
       }
+    this->fillPaths(connected);
     // smoothPaths (src/rrt.h:113-118, :354-379) shortens the plans held by the central tree's links; the matrix
     // the writers read keeps the copies made in getPaths (:350), so the "smooth" file repeats the raw paths
     if (P.smoothing) sff_compat::check(sffgpu_rrt_smooth_paths(r) < 0 ? -1 : 0, "rrt smoothing");

@@ -41,6 +41,11 @@ int sffgpu_mesh_upload(sffgpu_ctx* ctx, int role, const double* tri9, int n_tri)
  * hit[i] = 1 if the robot posed at pos6[i] = (x y z yaw pitch roll) touches any ENV triangle. */
 int sffgpu_collide_poses(sffgpu_ctx* ctx, const double* pos6, int n, uint8_t* hit);
 
+/* The same with the robot placed by an explicit rigid transform, x_world = R x_model + T: rt12[i] = the 3x3
+ * rotation (row-major) followed by the translation.  This is RAPID_Collide's own calling convention
+ * (src/environment.h:246,274 pass rotation matrices and translation vectors) and what include/sff/RAPID.H forwards to. */
+int sffgpu_collide_transforms(sffgpu_ctx* ctx, const double* rt12, int n, uint8_t* hit);
+
 /* Solver::isPathFree(start, finish) (src/problemStruct.h:154-168), batched over n edges.
  * is_free[i] = 1 if no interpolated sample collides; first_hit[i] = index of the first colliding
  * sample (the reference stops there) or -1; n_samples[i] = samples the edge has.  The last two
@@ -207,7 +212,8 @@ int sffgpu_rrt_link_plan(sffgpu_rrt* r, int k, int32_t* node_ids, int cap);
 int sffgpu_forest_in_wave(sffgpu_forest* f); /* 1 while a wave is open (between its first begin and last commit) */
 int sffgpu_forest_round_begin(sffgpu_forest* f, int32_t* n_words, int32_t* done);
 int sffgpu_forest_round_records(sffgpu_forest* f, int32_t* words, int cap_words);
-int sffgpu_forest_round_commit(sffgpu_forest* f, const int32_t* all_words, const int32_t* words_per_rank, int world);
+int sffgpu_forest_round_commit(sffgpu_forest* f, const int32_t* all_words, int total_words,
+                               const int32_t* words_per_rank, int world); /* total_words = length of all_words */
 
 #ifdef __cplusplus
 }

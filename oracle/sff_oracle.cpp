@@ -1373,6 +1373,33 @@ int sffo_radius(const double* pts, int n, const double q[6], double r, int32_t* 
   for (int i = 0; i < m; ++i) { idx[i] = hits[i].idx; if (dist) dist[i] = hits[i].d; }
   return (int)hits.size();
 }
+// The priority-frontier heap on its own (test entry): a heap over nodes 0 .. n_initial-1 keyed by the distance to
+// `ref` (Tree::AddFrontier, src/primitives.h:530-540 -> Heap ctor + sort, src/heap.h:72-83,107-113), then a script of
+// operations - kind 0 pop (:189-207), 1/2 pop at index arg (:209-238), 3 push of the next unused node (:175-187).
+// ret[i] = node returned / pushed, state[i * cap ..] = heap array after the operation (-1 padded).
+int sffo_heap_script(const double* pos6, int n_total, int n_initial, const double ref[6], const int32_t* ops, int n_ops,
+                     int32_t* initial, int32_t* ret, int32_t* state, int cap) {
+  std::vector<FNode> nodes((size_t)n_total);
+  for (int i = 0; i < n_total; ++i) memcpy(nodes[i].pos, pos6 + 6 * (size_t)i, sizeof nodes[i].pos);
+  PHeap hp;
+  hp.nodes = &nodes;
+  memcpy(hp.ref, ref, sizeof hp.ref);
+  for (int i = 0; i < n_initial; ++i) hp.v.push_back(i);
+  for (int k = (int)hp.v.size() - 1; k >= 0; --k) hp.bubble_down(k);
+  for (int j = 0; j < cap; ++j) initial[j] = j < (int)hp.v.size() ? hp.v[j] : -1;
+  int next = n_initial;
+  for (int i = 0; i < n_ops; ++i) {
+    const int kind = ops[2 * i], arg = ops[2 * i + 1];
+    int r = -1;
+    if (kind == 0) { if (hp.v.empty()) return -1; r = hp.pop(); }
+    else if (kind == 1 || kind == 2) { if (arg < 0 || arg >= (int)hp.v.size()) return -1; r = hp.pop_at(arg); }
+    else { if (next >= n_total) return -1; r = next; hp.push(next++); }
+    ret[i] = r;
+    for (int j = 0; j < cap; ++j) state[(size_t)i * cap + j] = j < (int)hp.v.size() ? hp.v[j] : -1;
+  }
+  return 0;
+}
+
 int sffo_knn(const double* pts, int n, const double q[6], int k, int32_t* idx, double* dist) {
   std::vector<Hit> hits(n);
   for (int i = 0; i < n; ++i) hits[i] = {distance6(q, pts + 6 * i), i};

@@ -6,8 +6,9 @@
  * The shipped HIP path (space_filling_forest_star_amd/csrc) never links or calls it.
  *
  * PARITY STATUS: pinned for a1-a5, a9 (RNG stream, sampling, metric, steer, rotation
- * matrix, D6Distance functor) against outputs of the reference's own headers compiled
- * in oracle/_ref (tests/golden/ref_primitives.json).  UNPINNED for the collision
+ * matrix, D6Distance functor) and for the priority-frontier heap (src/heap.h) against
+ * outputs of the reference's own headers compiled in oracle/_ref
+ * (tests/golden/ref_primitives.json, tests/golden/ref_types.json).  UNPINNED for the collision
  * boolean (RAPID 2.01 is not in the reference tree: lib/rapid-2.01/README.md:1-2) and
  * for the solver loop (src/forest.h, src/rrt.h cannot be compiled without RAPID.H and
  * no reference test or golden vector exists for them) — those follow the reference
@@ -62,6 +63,10 @@ uint64_t sffo_world_collide_calls(sffo_world*);
 /* pts: n x 6 doubles.  Results sorted by (distance, index).  Returns count (<= cap). */
 int sffo_radius(const double* pts, int n, const double q[6], double r, int32_t* idx, double* dist, int cap);
 int sffo_knn(const double* pts, int n, const double q[6], int k, int32_t* idx, double* dist);
+
+/* ---- priority-frontier heap on its own (src/heap.h; pinned by tests/golden/ref_types.json) ---- */
+int sffo_heap_script(const double* pos6, int n_total, int n_initial, const double ref[6], const int32_t* ops, int n_ops,
+                     int32_t* initial, int32_t* ret, int32_t* state, int cap);
 
 /* ---- SFF / SFF* solver (reference src/forest.h:57-418) ---- */
 typedef struct {

@@ -1,13 +1,32 @@
 """Per-kernel sums of rocprofv3 --pmc passes (counter_collection.csv files) -> JSON on stdout.
 FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB; bench.py applies the gfx950 correction
-(FETCH_SIZE x 2, MI355X_MICROARCH.md) when it quotes `roofline.traffic`."""
+(FETCH_SIZE x 2, MI355X_MICROARCH.md) when it quotes `roofline.traffic`.  --bench-args records the bench
+arguments of the profiled command: bench.py only quotes the traffic when its own arguments are the same."""
+import argparse
 import collections
 import csv
 import json
 import sys
 
-out = {}
-for path in sys.argv[1:]:
+ap = argparse.ArgumentParser()
+ap.add_argument("--bench-args", default="")
+ap.add_argument("--query-kernel", default="sffk::k_grid_query")
+ap.add_argument("files", nargs="+")
+a = ap.parse_args()
+
+bp = argparse.ArgumentParser()
+bp.add_argument("--gpus", type=int, default=1)
+bp.add_argument("--steps", type=int, default=20)
+bp.add_argument("--warmup", type=int, default=5)
+bp.add_argument("--wave", type=int, default=8192)
+bp.add_argument("--waves-per-step", type=int, default=13)
+bp.add_argument("--budget", type=int, default=1000000)
+bp.add_argument("--seed", type=int, default=1)
+b, _ = bp.parse_known_args(a.bench_args.split())
+out = {"bench_args": {"steps": b.steps, "warmup": b.warmup, "wave": b.wave, "waves_per_step": b.waves_per_step,
+                      "budget": b.budget, "seed": b.seed, "gpus": b.gpus},
+       "query_kernel": a.query_kernel}
+for path in a.files:
     acc = collections.defaultdict(lambda: [0, 0.0])
     name = None
     for r in csv.DictReader(open(path)):

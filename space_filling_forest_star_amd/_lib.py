@@ -19,7 +19,7 @@ EXPORTED_SYMBOLS = [
     "sffgpu_rrt_create", "sffgpu_rrt_destroy", "sffgpu_rrt_run", "sffgpu_rrt_get_stats", "sffgpu_rrt_get_nodes",
     "sffgpu_rrt_get_links", "sffgpu_rrt_paths", "sffgpu_rrt_path_plan", "sffgpu_rrt_smooth_paths",
     "sffgpu_rrt_link_plan", "sffgpu_kernel_times", "sffgpu_forest_get_frontier",
-    "sffgpu_forest_in_wave", "sffgpu_forest_round_begin", "sffgpu_forest_round_records", "sffgpu_forest_round_commit",
+    "sffgpu_collide_transforms", "sffgpu_forest_in_wave", "sffgpu_forest_round_begin", "sffgpu_forest_round_records", "sffgpu_forest_round_commit",
 ]
 
 c_dp = C.POINTER(C.c_double)
@@ -99,6 +99,7 @@ def lib():
     L.sffgpu_destroy.argtypes = [C.c_void_p]
     L.sffgpu_mesh_upload.argtypes = [C.c_void_p, C.c_int, c_dp, C.c_int]
     L.sffgpu_collide_poses.argtypes = [C.c_void_p, c_dp, C.c_int, c_u8p]
+    L.sffgpu_collide_transforms.argtypes = [C.c_void_p, c_dp, C.c_int, c_u8p]
     L.sffgpu_collide_segments.argtypes = [C.c_void_p, c_dp, c_dp, C.c_int, c_u8p, c_ip, c_ip]
     L.sffgpu_sample_steer.argtypes = [C.c_void_p, c_u64p, c_dp, C.c_int, C.c_double, C.c_int, c_dp, c_dp, c_u8p]
     L.sffgpu_nodes_reset.argtypes = [C.c_void_p, C.c_int]
@@ -132,7 +133,7 @@ def lib():
     L.sffgpu_forest_in_wave.argtypes = [C.c_void_p]
     L.sffgpu_forest_round_begin.argtypes = [C.c_void_p, c_ip, c_ip]
     L.sffgpu_forest_round_records.argtypes = [C.c_void_p, c_ip, C.c_int]
-    L.sffgpu_forest_round_commit.argtypes = [C.c_void_p, c_ip, c_ip, C.c_int]
+    L.sffgpu_forest_round_commit.argtypes = [C.c_void_p, c_ip, C.c_int, c_ip, C.c_int]
     _LIB = L
     return L
 
@@ -195,6 +196,13 @@ class Context:
         p = _f64(pos6, 6)
         out = np.zeros(len(p), np.uint8)
         self._chk(self._L.sffgpu_collide_poses(self.h, _dp(p), len(p), out.ctypes.data_as(c_u8p)))
+        return out
+
+    def collide_transforms(self, rt12):
+        """robot placed by explicit transforms: rows of 9 rotation entries (row-major) + 3 translation entries"""
+        p = _f64(rt12, 12)
+        out = np.zeros(len(p), np.uint8)
+        self._chk(self._L.sffgpu_collide_transforms(self.h, _dp(p), len(p), out.ctypes.data_as(c_u8p)))
         return out
 
     def collide_segments(self, a6, b6):
@@ -370,7 +378,7 @@ class Forest:
     def round_commit(self, all_words, words_per_rank):
         a = _i32(all_words)
         cnt = _i32(words_per_rank)
-        self.ctx._chk(self.ctx._L.sffgpu_forest_round_commit(self.h, _ip(a), _ip(cnt), len(cnt)))
+        self.ctx._chk(self.ctx._L.sffgpu_forest_round_commit(self.h, _ip(a), len(a), _ip(cnt), len(cnt)))
 
 
 class Rrt:

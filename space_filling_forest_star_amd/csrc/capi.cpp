@@ -75,6 +75,11 @@ int sffgpu_collide_poses(sffgpu_ctx* ctx, const double* pos6, int n, uint8_t* hi
   GUARD(ctx, ctx->c->collide_poses(pos6, n, hit));
 }
 
+int sffgpu_collide_transforms(sffgpu_ctx* ctx, const double* rt12, int n, uint8_t* hit) {
+  if (!ctx || n < 0 || (n > 0 && (!rt12 || !hit))) return SFFGPU_ERR_ARG;
+  GUARD(ctx, ctx->c->collide_poses(rt12, n, hit, /*explicit_rt=*/true));
+}
+
 int sffgpu_collide_segments(sffgpu_ctx* ctx, const double* a6, const double* b6, int n, uint8_t* is_free,
                             int32_t* first_hit, int32_t* n_samples) {
   if (!ctx || n < 0 || (n > 0 && (!a6 || !b6 || !is_free))) return SFFGPU_ERR_ARG;
@@ -367,9 +372,9 @@ int sffgpu_forest_round_records(sffgpu_forest* f, int32_t* words, int cap_words)
   memcpy(words, F.records.data(), F.records.size() * sizeof(int32_t));
   return SFFGPU_OK;
 }
-int sffgpu_forest_round_commit(sffgpu_forest* f, const int32_t* all_words, const int32_t* words_per_rank, int world) {
+int sffgpu_forest_round_commit(sffgpu_forest* f, const int32_t* all_words, int total_words, const int32_t* words_per_rank, int world) {
   if (!f || !all_words || !words_per_rank || world < 1) return SFFGPU_ERR_ARG;
-  GUARD(f->owner, f->f->round_commit(all_words, words_per_rank, world));
+  GUARD(f->owner, f->f->round_commit(all_words, total_words, words_per_rank, world));
 }
 
 }  // extern "C"

@@ -483,7 +483,7 @@ void Ctx::grid_setup(const double limits[6], double cell) {
   // the round's own grid: same cells, its own buckets / overflow list, all counters zero between rounds
   tgridv = gridv;
   tgridv.bk = 8;
-  tgridv.ovf_cap = 1 << 20;
+  tgridv.ovf_cap = std::max(1 << 20, tgrid_ovf_min);   // >= the samples of one round (Forest::Forest)
   t_cnt.ensure(ncells * sizeof(int32_t));
   t_items.ensure(ncells * tgridv.bk * sizeof(sffk::GridItem));
   t_ovfcnt.ensure(16);
@@ -510,6 +510,10 @@ void Ctx::grid_check() {
   int32_t v = 0;
   HIPCHK(hipMemcpyAsync(&v, g_ovfcnt.p, 4, hipMemcpyDeviceToHost, stream));
   HIPCHK(hipStreamSynchronize(stream));
+  // entries beyond the capacity were dropped by grid_put / k_store_write: the queries of the wave that has just
+  // finished may have missed nodes, so its results cannot be trusted (the capacity is sized so that one wave
+  // cannot get here from below the rebuild threshold: ovf_cap - ovf_cap / 4 >= wave, see Forest::Forest)
+  if (v > gridv.ovf_cap) throw HipError{"neighbour grid overflow list exhausted during a wave (nodes were dropped)"};
   if (v <= gridv.ovf_cap / 4) return;
   const size_t cells_now = (size_t)gridv.nx * gridv.ny * gridv.nz;
   double cell = grid_cell;
@@ -530,18 +534,19 @@ void Ctx::grid_check() {
 double Ctx::sweep_eps() const { return std::max(store_maxabs, env_maxabs) * std::ldexp(1.0, -20); }
 
 // ------------------------------------------------------------------ batched primitives
-void Ctx::collide_poses(const double* pos6, int n, uint8_t* hit) {
+void Ctx::collide_poses(const double* pos6, int n, uint8_t* hit, bool explicit_rt) {
   if (n <= 0) return;
   if (!have_env || !have_robot) throw HipError{"collide_poses: upload ENV and ROBOT meshes first"};
   HIPCHK(hipSetDevice(device));
-  h_a.ensure((size_t)n * 6 * sizeof(double));
+  const size_t per = (explicit_rt ? 12 : 6) * sizeof(double);
+  h_a.ensure((size_t)n * per);
   h_b.ensure((size_t)n);
-  memcpy(h_a.p, pos6, (size_t)n * 6 * sizeof(double));
-  d_a.ensure((size_t)n * 6 * sizeof(double));
+  memcpy(h_a.p, pos6, (size_t)n * per);
+  d_a.ensure((size_t)n * per);
   d_b.ensure((size_t)n);
-  HIPCHK(hipMemcpyAsync(d_a.p, h_a.p, (size_t)n * 6 * sizeof(double), hipMemcpyHostToDevice, stream));
+  HIPCHK(hipMemcpyAsync(d_a.p, h_a.p, (size_t)n * per, hipMemcpyHostToDevice, stream));
   time_begin(T_COLLIDE);
-  sffk::launch_collide_poses(stream, envv, robv, d_a.as<double>(), n, nullptr, d_b.as<uint8_t>());
+  sffk::launch_collide_poses(stream, envv, robv, d_a.as<double>(), n, nullptr, d_b.as<uint8_t>(), explicit_rt);
   time_end();
   HIPCHK(hipMemcpyAsync(h_b.p, d_b.p, (size_t)n, hipMemcpyDeviceToHost, stream));
   sync();

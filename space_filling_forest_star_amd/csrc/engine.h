@@ -99,6 +99,7 @@ struct Ctx {
   double grid_cell = 0, grid_limits[6] = {0, 0, 0, 0, 0, 0};
   int grid_rebuilds = 0;
   int gridv_ovf_cap_next = 65536;
+  int tgrid_ovf_min = 0;    // lower bound of the round grid's overflow list (one wave of samples)
 
   // scratch
   DevBuf d_a, d_b, d_c, d_d, d_e, d_f, d_g, d_h;
@@ -137,7 +138,7 @@ struct Ctx {
   void store_append(const double* pos6, const int32_t* tree, int n, bool wait = true);
   void store_set_tree(const int32_t* ids, int n, int32_t tree);  // relabel nodes (tree merging, src/rrt.h:240-250)
 
-  void collide_poses(const double* pos6, int n, uint8_t* hit);
+  void collide_poses(const double* pos6, int n, uint8_t* hit, bool explicit_rt = false);   // explicit_rt: n x 12 (R, T)
   void collide_segments(const double* a6, const double* b6, int n, uint8_t* is_free, int32_t* first_hit,
                         int32_t* n_samples);
   // the same with the end points given as store ids (fp64 positions of the device store: permanent nodes and the
@@ -314,7 +315,7 @@ struct Forest {
   void begin_wave();
   void end_wave();
   void round_begin();
-  void round_commit(const int32_t* all, const int32_t* counts, int world);
+  void round_commit(const int32_t* all, int total_words, const int32_t* counts, int world);
   void run(int max_waves);
   uint64_t fingerprint() const;
 };

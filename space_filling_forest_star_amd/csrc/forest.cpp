@@ -123,7 +123,11 @@ Forest::Forest(Ctx* c, const sffgpu_forest_cfg& cf, const double* roots6, int n_
     // cell edge >= the planner's neighbour radius max(parentDistance ~ SamplingDistance, treeDistance)
     double cell = 1.01 * std::max(cfg.sampling_dist, cfg.dist_tree) + 4 * ctx->sweep_eps();
     ctx->grid_rebuilds = 0;
-    ctx->gridv_ovf_cap_next = 65536;
+    // the overflow list is checked once per wave and re-celled at a quarter full: three quarters of it must hold
+    // whatever one wave can add (at most `wave` nodes), so that no insert is ever dropped between two checks
+    if (cfg.wave > (1 << 28)) throw HipError{"forest: wave too large"};
+    ctx->gridv_ovf_cap_next = std::max(65536, 2 * cfg.wave);
+    ctx->tgrid_ovf_min = cfg.wave + 64;
     ctx->grid_setup(cfg.limits, cell);
   }
   ctx->store_append(roots6, tids.data(), n_roots);
@@ -902,11 +906,19 @@ void Forest::round_begin() {
 }
 
 // all = concatenation of every rank's record stream (rank order), counts in int32 words
-void Forest::round_commit(const int32_t* all, const int32_t* counts, int world) {
+void Forest::round_commit(const int32_t* all, int total_words, const int32_t* counts, int world) {
   Ctx& c = *ctx;
   HIPCHK(hipSetDevice(c.device));
   if (!pending_round) throw HipError{"forest: round_commit without round_begin"};
   if (world != cfg.world) throw HipError{"forest: round_commit world size mismatch"};
+  {   // the per-rank lengths must tile the supplied buffer exactly
+    long long sum = 0;
+    for (int r = 0; r < world; ++r) {
+      if (counts[r] < 0) throw HipError{"forest: negative record stream length"};
+      sum += counts[r];
+    }
+    if (sum != (long long)total_words) throw HipError{"forest: record stream lengths do not add up to the buffer size"};
+  }
   auto t_host = Clock::now();
   double wait_ms = 0;
   const int n = n_cands;
@@ -934,10 +946,14 @@ void Forest::round_commit(const int32_t* all, const int32_t* counts, int world) 
     }
     p += 10;
     while (p < end) {
+      // a truncated or mismatched gather must end in a clean error, not in reads past the buffer
+      if (end - p < 6) throw HipError{"forest: truncated record stream"};
       int i = p[0];
       if (i < 0 || i >= n || i % world != r) throw HipError{"forest: malformed record stream"};
       Cand& cd = cands[i];
       int flags = p[1], nn = p[4], nm = p[5];
+      if (nn < 0 || nm < 0 || nn > (1 << 20) || nm > (1 << 20) || (size_t)(end - p) < 6 + 5 * (size_t)nn + 6 * (size_t)nm)
+        throw HipError{"forest: malformed record (neighbour / member counts run past the stream)"};
       if (r != cfg.rank) {
         memcpy(cd.pos, round_hpos + 6 * (size_t)i, sizeof cd.pos);   // (sampling is replicated: every rank has them)
         cd.pdist = round_hpd[i];
@@ -1158,7 +1174,7 @@ void Forest::run(int max_waves) {
     }
     round_begin();
     int32_t cnt = (int32_t)records.size();
-    round_commit(records.data(), &cnt, 1);
+    round_commit(records.data(), cnt, &cnt, 1);
   }
   st.total_ms += ms_since(t0);
 }

@@ -121,8 +121,9 @@ void launch_grid_query(hipStream_t s, const GridView& g, const GridView* tg, con
                        double* hit_dist, int cap);
 void launch_set_tree(hipStream_t s, int32_t* tree_col, const int32_t* ids, int n, int32_t value);
 
+// explicit_rt: pos6 holds n x 12 doubles (row-major rotation + translation) instead of n x 6 pose parameters
 void launch_collide_poses(hipStream_t s, const EnvView& env, const RobotView& rob, const double* pos6, int n,
-                          const int32_t* live_flags, uint8_t* hit);
+                          const int32_t* live_flags, uint8_t* hit, bool explicit_rt = false);
 
 // arguments of k_classify (one thread per sample of the round)
 struct ClassifyArgs {

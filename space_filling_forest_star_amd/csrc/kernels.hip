@@ -629,7 +629,7 @@ __device__ bool pose_exact(const EnvView& env, const RobotView& rob, const doubl
 __global__ __launch_bounds__(64 * POSE_WAVES) void k_collide_poses(EnvView env, RobotView rob,
                                                                    const double* __restrict__ pos6, int n,
                                                                    const int32_t* __restrict__ live_flags,
-                                                                   uint8_t* __restrict__ hit_out) {
+                                                                   uint8_t* __restrict__ hit_out, int explicit_rt) {
   extern __shared__ double lds_d[];
   // layout: robot triangles (n_tri*9 doubles) | per-wave stacks | per-wave candidate lists
   double* rtri = lds_d;
@@ -644,9 +644,17 @@ __global__ __launch_bounds__(64 * POSE_WAVES) void k_collide_poses(EnvView env, 
   if (pose < n) {
     const bool run = !live_flags || (live_flags[pose] & 3) == 1;   // else not owned / out of limits / host path
     if (run && env.n_tri != 0) {                                     // (HasMap == false: src/environment.h:307-309)
-      for (int k = 0; k < 6; ++k) p[k] = pos6[6 * (size_t)pose + k];
-      need = !surely_clear(env, p);
-      if (need) pose_frame(rob, pos6, pose, p, R, c);
+      if (explicit_rt) {   // pos6 holds n x 12 doubles: the 3x3 rotation (row-major) and the translation
+        const double* rt = pos6 + 12 * (size_t)pose;
+        for (int k = 0; k < 9; ++k) R[k] = rt[k];
+        for (int k = 0; k < 3; ++k) { p[k] = rt[9 + k]; p[3 + k] = 0; }
+        need = !surely_clear(env, p);
+        if (need) xform(R, p, rob.center, c);
+      } else {
+        for (int k = 0; k < 6; ++k) p[k] = pos6[6 * (size_t)pose + k];
+        need = !surely_clear(env, p);
+        if (need) pose_frame(rob, pos6, pose, p, R, c);
+      }
     }
     if (!need && lane == 0) hit_out[pose] = 0;
   }
@@ -1326,11 +1334,11 @@ void launch_set_tree(hipStream_t s, int32_t* tree_col, const int32_t* ids, int n
 }
 
 void launch_collide_poses(hipStream_t s, const EnvView& env, const RobotView& rob, const double* pos6, int n,
-                          const int32_t* live_flags, uint8_t* hit) {
+                          const int32_t* live_flags, uint8_t* hit, bool explicit_rt) {
   if (n <= 0) return;
   size_t lds = collide_lds_bytes(rob.n_tri, POSE_WAVES);
   hipLaunchKernelGGL(k_collide_poses, dim3((n + POSE_WAVES - 1) / POSE_WAVES), dim3(64 * POSE_WAVES), lds, s, env,
-                     rob, pos6, n, live_flags, hit);
+                     rob, pos6, n, live_flags, hit, explicit_rt ? 1 : 0);
 }
 
 #ifdef SFFK_DEBUG_COUNTERS

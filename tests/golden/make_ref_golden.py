@@ -14,3 +14,9 @@ out = subprocess.check_output([os.path.join(ROOT, "oracle", "_ref", "ref_harness
 with open(os.path.join(ROOT, "tests", "golden", "ref_primitives.json"), "wb") as f:
     f.write(out)
 print("wrote ref_primitives.json", len(out), "bytes")
+# node / tree API types (Node, Tree, Heap, DistanceHolder, SymmetricMatrix, Point(string)): oracle/types_harness.cpp
+# built against the reference's own src/primitives.h + src/heap.h
+out = subprocess.check_output([os.path.join(ROOT, "oracle", "_ref", "ref_types_harness")])
+with open(os.path.join(ROOT, "tests", "golden", "ref_types.json"), "wb") as f:
+    f.write(out)
+print("wrote ref_types.json", len(out), "bytes")

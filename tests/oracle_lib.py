@@ -93,6 +93,7 @@ def lib():
     L.sffo_world_collide_calls.argtypes = [C.c_void_p]
     L.sffo_radius.argtypes = [c_dp, C.c_int, c_dp, C.c_double, c_ip, c_dp, C.c_int]
     L.sffo_knn.argtypes = [c_dp, C.c_int, c_dp, C.c_int, c_ip, c_dp]
+    L.sffo_heap_script.argtypes = [c_dp, C.c_int, C.c_int, c_dp, c_ip, C.c_int, c_ip, c_ip, c_ip, C.c_int]
     L.sffo_forest_create.restype = C.c_void_p
     L.sffo_forest_create.argtypes = [C.c_void_p, C.POINTER(ForestCfg), c_dp, C.c_int]
     L.sffo_forest_destroy.argtypes = [C.c_void_p]
