@@ -143,31 +143,13 @@ int sffgpu_forest_run(sffgpu_forest* f, int max_waves) {
 }
 int sffgpu_forest_get_stats(sffgpu_forest* f, sffgpu_forest_stats* out) {
   if (!f || !out) return SFFGPU_ERR_ARG;
-  Forest& F = *f->f;
-  sffgpu_forest_stats s = F.st;
-  s.iterations = F.iter;
-  bool solved = F.solved;
-  if (!solved && !F.cfg.has_goal) solved = F.max_connected() == F.num_roots;  // src/forest.h:204-206
-  s.solved = solved;
-  s.n_nodes = (int)F.nodes.size();
-  s.n_trees = (int)F.trees.size();
-  s.frontier_size = (int)F.frontier.size();
-  s.closed_size = (int)F.closed.size();
-  s.n_connected = (int)F.connected.size();
-  int nb = 0;
-  for (auto& kv : F.borders) nb += (int)kv.second.size();
-  s.n_borders = nb;
-  s.grid_rebuilds = (uint64_t)F.ctx->grid_rebuilds;
-  s.sweep_ms = F.ctx->kernel_ms_total(T_SWEEP);
-  s.collide_ms = F.ctx->kernel_ms_total(T_COLLIDE);
-  s.sample_ms = F.ctx->kernel_ms_total(T_SAMPLE);
-  *out = s;
-  return SFFGPU_OK;
+  GUARD(f->owner, f->f->fill_stats(out));
 }
 int sffgpu_forest_get_nodes(sffgpu_forest* f, double* pos6, int32_t* parent, int32_t* tree, int32_t* iter, double* cost,
                             double* dist_parent) {
   if (!f) return SFFGPU_ERR_ARG;
   Forest& F = *f->f;
+  try { F.sync_host(); } catch (const HipError& e) { f->owner->c->err = e.msg; return SFFGPU_ERR_HIP; }
   for (size_t i = 0; i < F.nodes.size(); ++i) {
     const FNode& n = F.nodes[i];
     if (pos6) memcpy(pos6 + 6 * i, n.pos, sizeof n.pos);
@@ -182,6 +164,7 @@ int sffgpu_forest_get_nodes(sffgpu_forest* f, double* pos6, int32_t* parent, int
 int sffgpu_forest_get_borders(sffgpu_forest* f, int32_t* ta, int32_t* tb, int32_t* n1, int32_t* n2, double* dist,
                               int cap) {
   if (!f) return SFFGPU_ERR_ARG;
+  try { f->f->sync_host(); } catch (const HipError& e) { f->owner->c->err = e.msg; return SFFGPU_ERR_HIP; }
   int k = 0;
   for (auto& kv : f->f->borders)
     for (const Border& b : kv.second) {
@@ -196,11 +179,16 @@ int sffgpu_forest_get_borders(sffgpu_forest* f, int32_t* ta, int32_t* tb, int32_
     }
   return k;
 }
-uint64_t sffgpu_forest_fingerprint(sffgpu_forest* f) { return f ? f->f->fingerprint() : 0; }
+uint64_t sffgpu_forest_fingerprint(sffgpu_forest* f) {
+  if (!f) return 0;
+  try { f->f->sync_host(); } catch (const HipError& e) { f->owner->c->err = e.msg; return 0; }
+  return f->f->fingerprint();
+}
 
 int sffgpu_forest_paths(sffgpu_forest* f, double* dist, int32_t* connected, int cap_connected) {
   if (!f || !dist) return SFFGPU_ERR_ARG;
   Forest& F = *f->f;
+  try { F.sync_host(); } catch (const HipError& e) { f->owner->c->err = e.msg; return SFFGPU_ERR_HIP; }
   F.max_connected();                 // Solver::connectedTrees as Solve() leaves it (src/forest.h:196-206)
   F.get_paths();
   F.get_all_paths();
@@ -339,6 +327,7 @@ int sffgpu_rrt_link_plan(sffgpu_rrt* r, int k, int32_t* node_ids, int cap) {
 int sffgpu_forest_get_frontier(sffgpu_forest* f, int32_t* node_ids, int cap) {
   if (!f) return SFFGPU_ERR_ARG;
   Forest& F = *f->f;
+  try { F.sync_host(); } catch (const HipError& e) { f->owner->c->err = e.msg; return SFFGPU_ERR_HIP; }
   int k = 0;
   auto put = [&](int id) { if (k < cap && node_ids) node_ids[k] = id; ++k; };
   if (F.use_priority()) {
@@ -350,13 +339,18 @@ int sffgpu_forest_get_frontier(sffgpu_forest* f, int32_t* node_ids, int cap) {
   return k;
 }
 
-int sffgpu_forest_in_wave(sffgpu_forest* f) { return f ? (f->f->in_wave ? 1 : 0) : SFFGPU_ERR_ARG; }
+int sffgpu_forest_in_wave(sffgpu_forest* f) {
+  if (!f) return SFFGPU_ERR_ARG;
+  const Forest& F = *f->f;
+  return ((F.dev.active && F.dev.host_stale) ? F.dev.last.in_wave != 0 : F.in_wave) ? 1 : 0;
+}
 int sffgpu_forest_round_begin(sffgpu_forest* f, int32_t* n_words, int32_t* done) {
   if (!f || !n_words || !done) return SFFGPU_ERR_ARG;
   GUARD(f->owner, {
     Forest& F = *f->f;
     *done = 0;
     *n_words = 0;
+    if (F.dev.active) F.dev_to_host();   // the round protocol runs on the host path
     if (!F.in_wave && F.terminated()) {
       *done = 1;
     } else {

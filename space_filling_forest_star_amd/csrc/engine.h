@@ -211,9 +211,42 @@ struct FlatSet64 {
   }
 };
 
+// buffers and bookkeeping of the device-resident engine (forest_dev.cpp / devforest.hip)
+struct DevEngine {
+  bool on = false;        // this forest runs its waves through the device engine
+  bool inited = false;    // fixed-size buffers allocated
+  bool active = false;    // the authoritative state currently lives on the device
+  bool host_stale = false;// ... and is ahead of the host mirror
+  bool table_dirty = false, ring_pending = false;
+  DevBuf ctrl, parent, d_root, d_closest, iter, nflag, frontier, closed, claim, slot_node, slot_fail, act_slot, b_n1,
+      b_n2, b_ta, b_tb, b_dist, bt_key, bt_val, pair, ring, ustate, ulist, uacc, d_parent, d_force, fault_pending;
+  PinBuf h_ctrl, h_ring;
+  hipEvent_t ev_ring = nullptr, ev_wave = nullptr;
+  int node_cap = 0, border_cap = 0, temp_base = 0;
+  uint64_t bt_size = 0, ring_words = 0, max_wave_words = 0;
+  uint64_t produced = 0;        // engine words generated so far (absolute position of the generator)
+  uint64_t rounds_enqueued = 0;
+  int host_nodes = 0, host_borders = 0;   // how much of the device arrays the host mirror holds
+  sffk::DevCtrl last{};         // status block after the last completed wave
+};
+
 struct Forest {
   Ctx* ctx;
   sffgpu_forest_cfg cfg;
+  DevEngine dev;
+  bool device_eligible() const;
+  sffk::DevForestView dev_view() const;
+  void dev_size_node_arrays();
+  void dev_size_border_arrays(int want_cap);
+  void dev_ring_append(const uint64_t* words, size_t n);
+  void dev_ring_top_up(uint64_t cursor, uint64_t ahead);
+  void dev_upload_state();
+  void dev_to_host();
+  void dev_enqueue_wave(int first_round);
+  void run_device(int max_waves);
+  void sync_host();             // refresh the host mirror (nodes, frontier, borders, counters) from the device
+  void fill_stats(sffgpu_forest_stats* out);
+  ~Forest();
   Mt64 rng;
   std::vector<uint64_t> rng_ahead;   // engine words generated while the GPU works (fixed size: Mt64 keeps a pointer)
   std::vector<FNode> nodes;
@@ -310,6 +343,7 @@ struct Forest {
   int add_node(const double* pos, int tree, int parent, double dclosest, double droot, unsigned it);
   std::vector<Border>& border(int i, int j);
   int max_connected();
+  template <class HasBorder> int max_connected_over(HasBorder has_border, std::vector<int>& out_connected) const;
   bool budget_hit() const { return cfg.node_budget > 0 && (int)nodes.size() >= cfg.node_budget; }
   bool terminated() const { return solved || iter >= cfg.max_iterations || budget_hit(); }
   void begin_wave();

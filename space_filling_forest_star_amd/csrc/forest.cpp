@@ -111,7 +111,14 @@ Forest::Forest(Ctx* c, const sffgpu_forest_cfg& cf, const double* roots6, int n_
     nodes.reserve(cap);
     nflag.reserve(cap);
   }
-  ctx->store_reset(std::max(cfg.node_budget, 4096) + cfg.wave + 64);
+  {   // which engine commits the rounds: the device-resident one (forest_dev.cpp) for plain SFF at GPU-sized waves,
+      // the host replay below otherwise (SFF*, goal / priority modes, sharded runs, tiny waves)
+    const char* e = getenv("SFFGPU_ENGINE");
+    const std::string want = e ? e : "";
+    dev.on = device_eligible() && want != "host" && (cfg.wave >= 256 || want == "device");
+  }
+  // (device engine: a wave of new nodes past the budget plus the round's temporaries behind them)
+  ctx->store_reset(std::max(cfg.node_budget, 4096) + (dev.on ? 2 * cfg.wave + 128 : cfg.wave + 64));
   std::vector<int32_t> tids(n_roots);
   for (int j = 0; j < n_roots; ++j) {          // src/forest.h:60-76
     int id = add_node(roots6 + 6 * (size_t)j, j, -1, 0, 0, 0);
@@ -183,33 +190,104 @@ std::vector<Border>& Forest::border(int i, int j) {  // SymmetricMatrix, src/pri
 }
 
 // src/forest.h:379-418
-int Forest::max_connected() {
+template <class HasBorder>
+int Forest::max_connected_over(HasBorder has_border, std::vector<int>& out_connected) const {
   int max_conn = 0, remaining = num_roots;
   std::vector<char> conn(num_roots, 0);
   int unconnected = 0;
   while (max_conn < remaining) {
-    connected.clear();
+    out_connected.clear();
     std::vector<int> stack{unconnected};
     conn[unconnected] = 1;
     while (!stack.empty()) {
       int root = stack.front();
       stack.erase(stack.begin());
-      connected.push_back(root);
+      out_connected.push_back(root);
       for (int i = 0; i < num_roots; ++i) {
         if (root == i) continue;
-        auto it = borders.find({std::min(root, i), std::max(root, i)});
-        if (it != borders.end() && !it->second.empty() && !conn[i]) {
+        if (!conn[i] && has_border(std::min(root, i), std::max(root, i))) {
           conn[i] = 1;
           stack.insert(stack.begin(), i);
         }
       }
     }
-    max_conn = (int)connected.size();
+    max_conn = (int)out_connected.size();
     for (int i = 0; i < num_roots; ++i)
       if (!conn[i]) { unconnected = i; break; }
     remaining -= max_conn;
   }
   return max_conn;
+}
+int Forest::max_connected() {
+  return max_connected_over([&](int a, int b) {
+    auto it = borders.find({a, b});
+    return it != borders.end() && !it->second.empty();
+  }, connected);
+}
+
+// what sffgpu_forest_get_stats reports; while the device engine owns the state the figures come from its status
+// block (and the small pair matrix), without downloading the forest
+void Forest::fill_stats(sffgpu_forest_stats* out) {
+  sffgpu_forest_stats s = st;
+  if (dev.active && dev.host_stale) {
+    const sffk::DevCtrl& k = dev.last;
+    std::vector<uint8_t> pair((size_t)num_roots * num_roots);
+    HIPCHK(hipMemcpy(pair.data(), dev.pair.p, pair.size(), hipMemcpyDeviceToHost));
+    std::vector<int> conn;
+    const int mc = max_connected_over([&](int a, int b) { return pair[(size_t)a * num_roots + b] != 0; }, conn);
+    s.iterations = k.iter;
+    s.solved = (k.solved || (!cfg.has_goal && mc == num_roots)) ? 1 : 0;
+    s.n_nodes = k.n_nodes;
+    s.frontier_size = k.frontier_n;
+    s.closed_size = k.closed_n;
+    s.n_connected = (int)conn.size();
+    s.n_borders = k.n_borders;
+    s.collide_calls = k.collide_calls;
+    s.path_free_calls = k.path_free_calls;
+    s.nn_queries = k.nn_queries;
+    s.poses_executed = k.poses_executed;
+    s.segments_executed = k.segments_executed;
+    s.samples_executed = k.samples_executed;
+    s.waves = k.waves;
+    s.sweeps = k.rounds;
+    s.sweep_nodes = k.round_nodes;
+    s.sweep_queries = k.round_queries;
+  } else {
+    s.iterations = iter;
+    bool sv = solved;
+    if (!sv && !cfg.has_goal) sv = max_connected() == num_roots;  // src/forest.h:204-206
+    s.solved = sv;
+    s.n_nodes = (int)nodes.size();
+    s.frontier_size = (int)frontier.size();
+    s.closed_size = (int)closed.size();
+    s.n_connected = (int)connected.size();
+    int nb = 0;
+    for (auto& kv : borders) nb += (int)kv.second.size();
+    s.n_borders = nb;
+  }
+  s.n_trees = (int)trees.size();
+  s.grid_rebuilds = (uint64_t)ctx->grid_rebuilds;
+  s.sweep_ms = ctx->kernel_ms_total(T_SWEEP);
+  s.collide_ms = ctx->kernel_ms_total(T_COLLIDE);
+  s.sample_ms = ctx->kernel_ms_total(T_SAMPLE);
+  *out = s;
+}
+
+Forest::~Forest() {
+  DevBuf* bufs[] = {&dev.ctrl, &dev.parent, &dev.d_root, &dev.d_closest, &dev.iter, &dev.nflag, &dev.frontier, &dev.closed,
+                    &dev.claim, &dev.slot_node, &dev.slot_fail, &dev.act_slot, &dev.b_n1, &dev.b_n2, &dev.b_ta, &dev.b_tb,
+                    &dev.b_dist, &dev.bt_key, &dev.bt_val, &dev.pair, &dev.ring, &dev.ustate, &dev.ulist, &dev.uacc,
+                    &dev.d_parent, &dev.d_force, &dev.fault_pending};
+  if (dev.inited) {
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(ctx->copy_stream);
+  }
+  for (DevBuf* b : bufs) b->release();
+  dev.h_ctrl.release();
+  dev.h_ring.release();
+  if (dev.ev_ring) (void)hipEventDestroy(dev.ev_ring);
+  if (dev.ev_wave) (void)hipEventDestroy(dev.ev_wave);
 }
 
 // node selection for every slot of the wave, src/forest.h:136-151 (non-priority mode)
@@ -319,6 +397,7 @@ void Forest::round_begin() {
   Ctx& c = *ctx;
   HIPCHK(hipSetDevice(c.device));
   if (pending_round) throw HipError{"forest: round_begin called twice without round_commit"};
+  if (dev.active) dev_to_host();   // the round protocol runs on the host path
   if (!in_wave) {
     if (terminated()) return;
     begin_wave();
@@ -386,12 +465,12 @@ void Forest::round_begin() {
   const uint8_t* d_force = reinterpret_cast<const uint8_t*>(c.r_in.as<char>() + in_force);
   // device output block in two D2H copies.  Early part (complete after k_classify, copied on a second stream
   // while the collision kernels run): pos | pdist | in_lim | records | edge sample counts.  Late part: edge
-  // first hits (0 = redo on the host path) | ctrl (16 ints incl. the 4 u64 settle counters) | pose answers | settle codes.
+  // first hits (0 = redo on the host path) | ctrl (32 ints incl. the u64 settle counters) | pose answers | settle codes.
   // records: flags (n) | nnb (n) | nb ids (n*NBCAP) | nb meta (n*NBCAP)
   const size_t rec_ints = (size_t)n * (2 + 2 * NBCAP);
   const size_t o_pos = 0, o_pd = o_pos + (size_t)n * 48, o_lim = o_pd + (size_t)n * 8,
                o_rec = o_lim + ((size_t)n + 15) / 16 * 16, o_ns = o_rec + rec_ints * 4,
-               o_fh = o_ns + (size_t)n * STRIDE * 4, o_ctrl = o_fh + (size_t)n * STRIDE * 4, o_pose = o_ctrl + 64,
+               o_fh = o_ns + (size_t)n * STRIDE * 4, o_ctrl = o_fh + (size_t)n * STRIDE * 4, o_pose = o_ctrl + 128,
                o_code = o_pose + (size_t)n, o_bytes = (o_code + (size_t)n + 15) / 16 * 16,
                o_ovf = o_bytes;   // (device-only scratch behind the copied block)
   const size_t early_bytes = o_fh;
@@ -1165,6 +1244,7 @@ void Forest::round_commit(const int32_t* all, int total_words, const int32_t* co
 
 void Forest::run(int max_waves) {
   if (cfg.world != 1) throw HipError{"forest: run() drives a single-GPU forest; use round_begin/round_commit"};
+  if (dev.on) { run_device(max_waves); return; }
   auto t0 = Clock::now();
   const uint64_t w0 = st.waves;
   while (true) {

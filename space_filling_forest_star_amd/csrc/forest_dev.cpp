@@ -1,0 +1,606 @@
+// forest_dev.cpp — host driver of the device-resident SFF engine (devforest.hip).
+//
+// The forest's authoritative state (node records, frontier, closed list, slots, borders, counters, RNG cursor)
+// lives in HBM while this engine runs.  Per wave the host enqueues  k_wave_begin, ThresholdMisses x {sample, query,
+// classify, compact, cull, exact, settle, resolve}, k_wave_end  and one 256-byte status copy, then waits once.  While
+// the GPU works on wave w the host generates and uploads the engine words wave w+1 may need.  The host mirror
+// (Forest::nodes, frontier, borders ...) is refreshed lazily: only when a getter, the fault path or a caller of the
+// round protocol needs it.
+//
+// Faults: a round in which a bounded device list overflowed is not committed by k_resolve; the host downloads the
+// state, finishes that wave on the host path of forest.cpp (unbounded lists) and uploads the result.  A full border
+// table or node / border arrays that need to grow only cost a reallocation on the host and a resumed wave.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#include "engine.h"
+#include "sff_geom.h"
+
+namespace sff {
+
+#define HIPCHK(x) hip_check((x), #x)
+using Clock = std::chrono::steady_clock;
+static double ms_since(Clock::time_point t0) { return std::chrono::duration<double, std::milli>(Clock::now() - t0).count(); }
+
+static uint64_t next_pow2(uint64_t v) {
+  uint64_t p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+
+bool Forest::device_eligible() const {
+  return cfg.world == 1 && !cfg.optimize && !cfg.has_goal && !use_priority();
+}
+
+sffk::DevForestView Forest::dev_view() const {
+  const DevEngine& d = dev;
+  sffk::DevForestView v{};
+  v.ctrl = d.ctrl.as<sffk::DevCtrl>();
+  v.parent = d.parent.as<int32_t>();
+  v.d_root = d.d_root.as<double>();
+  v.d_closest = d.d_closest.as<double>();
+  v.iter = d.iter.as<uint32_t>();
+  v.nflag = d.nflag.as<uint8_t>();
+  v.frontier = d.frontier.as<int32_t>();
+  v.closed = d.closed.as<int32_t>();
+  v.claim = d.claim.as<int32_t>();
+  v.slot_node = d.slot_node.as<int32_t>();
+  v.slot_fail = d.slot_fail.as<uint8_t>();
+  v.act_slot = d.act_slot.as<int32_t>();
+  v.b_n1 = d.b_n1.as<int32_t>();
+  v.b_n2 = d.b_n2.as<int32_t>();
+  v.b_ta = d.b_ta.as<int32_t>();
+  v.b_tb = d.b_tb.as<int32_t>();
+  v.b_dist = d.b_dist.as<double>();
+  v.bt_key = d.bt_key.as<unsigned long long>();
+  v.bt_val = d.bt_val.as<unsigned long long>();
+  v.bt_mask = d.bt_size - 1;
+  v.pair = d.pair.as<uint8_t>();
+  v.ring = d.ring.as<uint64_t>();
+  v.ring_mask = d.ring_words - 1;
+  v.node_cap = d.node_cap;
+  v.border_cap = d.border_cap;
+  v.wave = cfg.wave;
+  v.n_trees = num_roots;
+  v.words_per = cfg.dim == 2 ? 1 : 6;
+  v.threshold_misses = cfg.threshold_misses;
+  v.max_iterations = cfg.max_iterations;
+  v.node_budget = cfg.node_budget;
+  v.temp_base = d.temp_base;
+  v.ustate = d.ustate.as<uint8_t>();
+  v.ulist = d.ulist.as<int32_t>();
+  v.uacc = d.uacc.as<int32_t>();
+  return v;
+}
+
+// (re)allocates the per-node arrays for the store's current capacity and places the temporaries of a round behind
+// every node the forest can hold
+void Forest::dev_size_node_arrays() {
+  Ctx& c = *ctx;
+  DevEngine& d = dev;
+  const int cap = c.store_cap;
+  d.node_cap = cap - cfg.wave - 16;                    // nodes live in [0, node_cap), temporaries behind them
+  d.temp_base = (cap - cfg.wave - 8) & ~3;
+  if (d.node_cap < 64) throw HipError{"forest: node store too small for the device engine"};
+  d.parent.ensure((size_t)cap * 4);
+  d.d_root.ensure((size_t)cap * 8);
+  d.d_closest.ensure((size_t)cap * 8);
+  d.iter.ensure((size_t)cap * 4);
+  d.nflag.ensure((size_t)cap);
+  d.frontier.ensure((size_t)cap * 4);
+  d.closed.ensure((size_t)cap * 4);
+  const size_t old_claim = d.claim.cap;
+  d.claim.ensure((size_t)cap * 4);
+  if (d.claim.cap != old_claim)   // (fresh part must read "unclaimed"; the whole array is unclaimed between waves)
+    HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d.claim.p), 0x7fffffff, d.claim.cap / 4, c.stream));
+}
+
+void Forest::dev_size_border_arrays(int want_cap) {
+  Ctx& c = *ctx;
+  DevEngine& d = dev;
+  if (want_cap > d.border_cap) {
+    d.border_cap = want_cap;
+    d.b_n1.ensure((size_t)want_cap * 4);
+    d.b_n2.ensure((size_t)want_cap * 4);
+    d.b_ta.ensure((size_t)want_cap * 4);
+    d.b_tb.ensure((size_t)want_cap * 4);
+    d.b_dist.ensure((size_t)want_cap * 8);
+  }
+  const uint64_t want_tab = next_pow2((uint64_t)std::max(getenv("SFFGPU_TEST_BORDER_CAP") ? 64 : 1 << 16, 4 * d.border_cap));
+  if (want_tab > d.bt_size) {
+    d.bt_size = want_tab;
+    d.bt_key.release();
+    d.bt_val.release();
+    d.bt_key.ensure((size_t)want_tab * 8);
+    d.bt_val.ensure((size_t)want_tab * 8);
+    HIPCHK(hipMemsetAsync(d.bt_key.p, 0, (size_t)want_tab * 8, c.stream));
+    HIPCHK(hipMemsetAsync(d.bt_val.p, 0xFF, (size_t)want_tab * 8, c.stream));
+    d.table_dirty = true;   // the list entries have to be re-inserted
+  }
+}
+
+// ---- engine words: rng is the generator; in device mode it holds no queue and rng.draws == dev.produced
+void Forest::dev_ring_append(const uint64_t* words, size_t n) {   // words for absolute positions [produced, produced + n)
+  DevEngine& d = dev;
+  Ctx& c = *ctx;
+  uint64_t* hr = d.h_ring.as<uint64_t>();
+  size_t done = 0;
+  while (done < n) {
+    const uint64_t at = (d.produced + done) & (d.ring_words - 1);
+    const size_t run = std::min<size_t>(n - done, (size_t)(d.ring_words - at));
+    if (words) memcpy(hr + at, words + done, run * 8);
+    else rng.fill(hr + at, run);
+    HIPCHK(hipMemcpyAsync(d.ring.as<uint64_t>() + at, hr + at, run * 8, hipMemcpyHostToDevice, c.copy_stream));
+    done += run;
+  }
+  d.produced += n;
+  HIPCHK(hipEventRecord(d.ev_ring, c.copy_stream));
+  d.ring_pending = true;
+}
+
+void Forest::dev_ring_top_up(uint64_t cursor, uint64_t ahead) {   // make [cursor, cursor + ahead) resident
+  DevEngine& d = dev;
+  if (d.produced >= cursor + ahead) return;
+  const uint64_t need = cursor + ahead - d.produced;
+  if (d.produced + need - cursor > d.ring_words) throw HipError{"forest: engine-word ring too small (internal error)"};
+  dev_ring_append(nullptr, (size_t)need);
+}
+
+// host state -> device (first use, and after a wave finished on the host path)
+void Forest::dev_upload_state() {
+  Ctx& c = *ctx;
+  DevEngine& d = dev;
+  HIPCHK(hipSetDevice(c.device));
+  const int wave = cfg.wave;
+  const int words_per = cfg.dim == 2 ? 1 : 6;
+  if (!d.inited) {
+    HIPCHK(hipEventCreateWithFlags(&d.ev_ring, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&d.ev_wave, hipEventDisableTiming));
+    d.max_wave_words = (uint64_t)wave * (1 + (uint64_t)std::max(1, cfg.threshold_misses) * words_per) + 64;
+    d.ring_words = next_pow2(4 * d.max_wave_words);
+    d.ring.ensure((size_t)d.ring_words * 8);
+    d.h_ring.ensure((size_t)d.ring_words * 8);
+    d.ctrl.ensure(sizeof(sffk::DevCtrl));
+    d.h_ctrl.ensure(sizeof(sffk::DevCtrl));
+    d.slot_node.ensure((size_t)wave * 4);
+    d.slot_fail.ensure((size_t)wave);
+    d.act_slot.ensure((size_t)wave * 4);
+    d.ustate.ensure((size_t)wave);
+    d.ulist.ensure((size_t)wave * 4);
+    d.uacc.ensure((size_t)wave * 4);
+    d.d_parent.ensure((size_t)wave * 4);
+    d.d_force.ensure((size_t)wave);
+    d.fault_pending.ensure(16);
+    HIPCHK(hipMemsetAsync(d.fault_pending.p, 0, 16, c.stream));
+    d.pair.ensure((size_t)num_roots * num_roots);
+    d.inited = true;
+  }
+  // a store that leaves room for a wave of new nodes plus the round's temporaries behind them
+  c.store_reserve((int)nodes.size() + 2 * wave + 64);
+  dev_size_node_arrays();
+  int nb = 0;
+  for (auto& kv : borders) nb += (int)kv.second.size();
+  {
+    int first_cap = std::max(1 << 16, 2 * (nb + wave));
+    if (const char* e = getenv("SFFGPU_TEST_BORDER_CAP")) first_cap = std::max(nb + 1, atoi(e));   // tests: force growth
+    dev_size_border_arrays(first_cap);
+  }
+  // all nodes lie inside the limits: a bound for the fp32 filter slack that does not depend on the nodes to come
+  for (int a = 0; a < 6; ++a) c.store_maxabs = std::max(c.store_maxabs, std::fabs(cfg.limits[a]));
+
+  const int n = (int)nodes.size();
+  {
+    std::vector<int32_t> par(n);
+    std::vector<double> dr(n), dc(n);
+    std::vector<uint32_t> it(n);
+    for (int i = 0; i < n; ++i) { par[i] = nodes[i].parent; dr[i] = nodes[i].d_root; dc[i] = nodes[i].d_closest; it[i] = nodes[i].iter; }
+    HIPCHK(hipMemcpyAsync(d.parent.p, par.data(), (size_t)n * 4, hipMemcpyHostToDevice, c.stream));
+    HIPCHK(hipMemcpyAsync(d.d_root.p, dr.data(), (size_t)n * 8, hipMemcpyHostToDevice, c.stream));
+    HIPCHK(hipMemcpyAsync(d.d_closest.p, dc.data(), (size_t)n * 8, hipMemcpyHostToDevice, c.stream));
+    HIPCHK(hipMemcpyAsync(d.iter.p, it.data(), (size_t)n * 4, hipMemcpyHostToDevice, c.stream));
+    HIPCHK(hipMemcpyAsync(d.nflag.p, nflag.data(), (size_t)n, hipMemcpyHostToDevice, c.stream));
+    if (!frontier.empty()) HIPCHK(hipMemcpyAsync(d.frontier.p, frontier.data(), frontier.size() * 4, hipMemcpyHostToDevice, c.stream));
+    if (!closed.empty()) HIPCHK(hipMemcpyAsync(d.closed.p, closed.data(), closed.size() * 4, hipMemcpyHostToDevice, c.stream));
+    HIPCHK(hipStreamSynchronize(c.stream));   // (the staging vectors go out of scope)
+  }
+  {   // borders: per-pair order is what matters (SpaceForest::borders is a matrix of lists)
+    std::vector<int32_t> n1, n2, ta, tb;
+    std::vector<double> ds;
+    std::vector<uint8_t> pair((size_t)num_roots * num_roots, 0);
+    for (auto& kv : borders)
+      for (const Border& b : kv.second) {
+        n1.push_back(b.n1); n2.push_back(b.n2); ta.push_back(kv.first.first); tb.push_back(kv.first.second); ds.push_back(b.dist);
+        pair[(size_t)kv.first.first * num_roots + kv.first.second] = 1;
+        pair[(size_t)kv.first.second * num_roots + kv.first.first] = 1;
+      }
+    const size_t m = n1.size();
+    if (m) {
+      HIPCHK(hipMemcpyAsync(d.b_n1.p, n1.data(), m * 4, hipMemcpyHostToDevice, c.stream));
+      HIPCHK(hipMemcpyAsync(d.b_n2.p, n2.data(), m * 4, hipMemcpyHostToDevice, c.stream));
+      HIPCHK(hipMemcpyAsync(d.b_ta.p, ta.data(), m * 4, hipMemcpyHostToDevice, c.stream));
+      HIPCHK(hipMemcpyAsync(d.b_tb.p, tb.data(), m * 4, hipMemcpyHostToDevice, c.stream));
+      HIPCHK(hipMemcpyAsync(d.b_dist.p, ds.data(), m * 8, hipMemcpyHostToDevice, c.stream));
+    }
+    HIPCHK(hipMemcpyAsync(d.pair.p, pair.data(), pair.size(), hipMemcpyHostToDevice, c.stream));
+    // fresh table: every list entry is re-inserted
+    HIPCHK(hipMemsetAsync(d.bt_key.p, 0, (size_t)d.bt_size * 8, c.stream));
+    HIPCHK(hipMemsetAsync(d.bt_val.p, 0xFF, (size_t)d.bt_size * 8, c.stream));
+    d.table_dirty = false;
+    sffk::launch_border_rehash(c.stream, dev_view(), (int)m);
+    HIPCHK(hipStreamSynchronize(c.stream));
+    d.host_borders = (int)m;
+  }
+  // engine words: what the host generated ahead moves into the ring, the generator continues behind it
+  {
+    const uint64_t cursor = rng.draws;
+    d.produced = cursor;
+    const size_t left = rng.qn - rng.qh;
+    std::vector<uint64_t> ahead(rng.q ? rng.q + rng.qh : nullptr, rng.q ? rng.q + rng.qn : nullptr);
+    rng.q = nullptr;
+    rng.qh = rng.qn = 0;
+    if (left) dev_ring_append(ahead.data(), std::min<size_t>(left, (size_t)d.ring_words));
+    if (left > d.ring_words) throw HipError{"forest: look-ahead queue larger than the engine-word ring"};
+    rng.draws = d.produced;
+    sffk::DevCtrl k{};
+    k.n_nodes = n;
+    k.iter = iter;
+    k.round = round;
+    k.in_wave = in_wave ? 1 : 0;
+    k.frontier_n = (int)frontier.size();
+    k.closed_n = (int)closed.size();
+    k.solved = solved ? 1 : 0;
+    k.empty_frontier = empty_frontier ? 1 : 0;
+    k.terminated = (!in_wave && terminated()) ? 1 : 0;
+    k.halt = k.terminated;
+    k.n_borders = d.host_borders;
+    k.cursor = cursor;
+    k.collide_calls = st.collide_calls;
+    k.path_free_calls = st.path_free_calls;
+    k.nn_queries = st.nn_queries;
+    k.poses_executed = st.poses_executed;
+    k.segments_executed = st.segments_executed;
+    k.samples_executed = st.samples_executed;
+    k.waves = st.waves;
+    k.rounds = st.sweeps;
+    k.round_nodes = st.sweep_nodes;
+    k.round_queries = st.sweep_queries;
+    k.epoch = 1;
+    if (in_wave) {
+      k.n_slots = (int)slots.size();
+      k.use_closed = (!slots.empty() && slots[0].from_closed) ? 1 : 0;
+      std::vector<int32_t> sn(slots.size());
+      std::vector<uint8_t> sf(slots.size());
+      for (size_t s = 0; s < slots.size(); ++s) { sn[s] = slots[s].node; sf[s] = slots[s].failing ? 1 : 0; }
+      HIPCHK(hipMemcpy(d.slot_node.p, sn.data(), sn.size() * 4, hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(d.slot_fail.p, sf.data(), sf.size(), hipMemcpyHostToDevice));
+    }
+    HIPCHK(hipMemcpy(d.ctrl.p, &k, sizeof k, hipMemcpyHostToDevice));
+    d.last = k;
+  }
+  d.host_nodes = n;
+  d.host_stale = false;
+  d.active = true;
+}
+
+// device state -> host mirror
+void Forest::sync_host() {
+  DevEngine& d = dev;
+  if (!d.active || !d.host_stale) return;
+  Ctx& c = *ctx;
+  HIPCHK(hipSetDevice(c.device));
+  HIPCHK(hipStreamSynchronize(c.stream));
+  sffk::DevCtrl k;
+  HIPCHK(hipMemcpy(&k, d.ctrl.p, sizeof k, hipMemcpyDeviceToHost));
+  d.last = k;
+  const int n = k.n_nodes, n0 = d.host_nodes;
+  if (n > n0) {
+    const int m = n - n0;
+    std::vector<double> pos((size_t)m * 6), dr(m), dc(m);
+    std::vector<int32_t> par(m), tr(m);
+    std::vector<uint32_t> it(m);
+    HIPCHK(hipMemcpy(pos.data(), c.spos.as<double>() + 6 * (size_t)n0, (size_t)m * 48, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(tr.data(), c.stree.as<int32_t>() + n0, (size_t)m * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(par.data(), d.parent.as<int32_t>() + n0, (size_t)m * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(dr.data(), d.d_root.as<double>() + n0, (size_t)m * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(dc.data(), d.d_closest.as<double>() + n0, (size_t)m * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(it.data(), d.iter.as<uint32_t>() + n0, (size_t)m * 4, hipMemcpyDeviceToHost));
+    for (int j = 0; j < m; ++j) add_node(&pos[6 * (size_t)j], tr[j], par[j], dc[j], dr[j], it[j]);
+  }
+  if (n > 0) HIPCHK(hipMemcpy(nflag.data(), d.nflag.p, (size_t)n, hipMemcpyDeviceToHost));
+  frontier.resize((size_t)k.frontier_n);
+  closed.resize((size_t)k.closed_n);
+  if (k.frontier_n) HIPCHK(hipMemcpy(frontier.data(), d.frontier.p, (size_t)k.frontier_n * 4, hipMemcpyDeviceToHost));
+  if (k.closed_n) HIPCHK(hipMemcpy(closed.data(), d.closed.p, (size_t)k.closed_n * 4, hipMemcpyDeviceToHost));
+  if (k.n_borders > d.host_borders) {
+    const int b0 = d.host_borders, m = k.n_borders - b0;
+    std::vector<int32_t> n1(m), n2(m), ta(m), tb(m);
+    std::vector<double> ds(m);
+    HIPCHK(hipMemcpy(n1.data(), d.b_n1.as<int32_t>() + b0, (size_t)m * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(n2.data(), d.b_n2.as<int32_t>() + b0, (size_t)m * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(ta.data(), d.b_ta.as<int32_t>() + b0, (size_t)m * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(tb.data(), d.b_tb.as<int32_t>() + b0, (size_t)m * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(ds.data(), d.b_dist.as<double>() + b0, (size_t)m * 8, hipMemcpyDeviceToHost));
+    for (int j = 0; j < m; ++j) {
+      border(ta[j], tb[j]).push_back({n1[j], n2[j], ds[j]});
+      border_keys.insert(((uint64_t)(uint32_t)n1[j] << 32) | ((uint64_t)(uint32_t)n2[j] + 1));
+    }
+    d.host_borders = k.n_borders;
+  }
+  iter = k.iter;
+  solved = k.solved != 0;
+  empty_frontier = k.empty_frontier != 0;
+  in_wave = k.in_wave != 0;
+  round = k.round;
+  st.collide_calls = k.collide_calls;
+  st.path_free_calls = k.path_free_calls;
+  st.nn_queries = k.nn_queries;
+  st.poses_executed = k.poses_executed;
+  st.segments_executed = k.segments_executed;
+  st.samples_executed = k.samples_executed;
+  st.waves = k.waves;
+  st.sweeps = k.rounds;
+  st.sweep_nodes = k.round_nodes;
+  st.sweep_queries = k.round_queries;
+  if (in_wave) {
+    std::vector<int32_t> sn(k.n_slots);
+    std::vector<uint8_t> sf(k.n_slots);
+    HIPCHK(hipMemcpy(sn.data(), d.slot_node.p, (size_t)k.n_slots * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(sf.data(), d.slot_fail.p, (size_t)k.n_slots, hipMemcpyDeviceToHost));
+    slots.resize((size_t)k.n_slots);
+    for (int s = 0; s < k.n_slots; ++s) { slots[s].node = sn[s]; slots[s].failing = sf[s] != 0; slots[s].from_closed = k.use_closed != 0; slots[s].tree = -1; slots[s].heap = -1; }
+  }
+  c.store_n = n;
+  c.grid_inserted = n;
+  d.host_nodes = n;
+  d.host_stale = false;
+}
+
+// leave device mode: the host path owns the state again (its rng continues at the device's cursor)
+void Forest::dev_to_host() {
+  DevEngine& d = dev;
+  if (!d.active) return;
+  d.host_stale = true;
+  sync_host();
+  Ctx& c = *ctx;
+  HIPCHK(hipStreamSynchronize(c.copy_stream));
+  const uint64_t cursor = d.last.cursor;
+  const size_t left = (size_t)(d.produced - cursor);
+  const size_t keep = std::max(rng_ahead.size(), left + 16);
+  std::vector<uint64_t> buf(keep, 0);
+  const uint64_t* hr = d.h_ring.as<uint64_t>();
+  for (size_t j = 0; j < left; ++j) buf[j] = hr[(cursor + j) & (d.ring_words - 1)];
+  rng_ahead.swap(buf);
+  rng.q = rng_ahead.data();
+  rng.qh = 0;
+  rng.qn = left;
+  rng.draws = cursor;
+  d.active = false;
+}
+
+void Forest::dev_enqueue_wave(int first_round) {
+  Ctx& c = *ctx;
+  DevEngine& d = dev;
+  const sffk::DevForestView V = dev_view();
+  const int wave = cfg.wave;
+  const int n = wave;   // launch bound; the kernels read the real count from DevCtrl
+  const int CAP = hit_cap, NBCAP = nb_cap, STRIDE = 1 + NBCAP;
+  // device output block of a round (same layout as the host path's, sized for a full wave)
+  const size_t rec_ints = (size_t)n * (2 + 2 * NBCAP);
+  const size_t o_pos = 0, o_pd = o_pos + (size_t)n * 48, o_lim = o_pd + (size_t)n * 8,
+               o_rec = o_lim + ((size_t)n + 15) / 16 * 16, o_ns = o_rec + rec_ints * 4,
+               o_fh = o_ns + (size_t)n * STRIDE * 4, o_ctrl = o_fh + (size_t)n * STRIDE * 4, o_pose = o_ctrl + 128,
+               o_code = o_pose + (size_t)n, o_bytes = (o_code + (size_t)n + 15) / 16 * 16, o_ovf = o_bytes;
+  c.r_out.ensure(o_ovf + (size_t)n * STRIDE * 4);
+  char* dout = c.r_out.as<char>();
+  double* d_pos = reinterpret_cast<double*>(dout + o_pos);
+  double* d_pd = reinterpret_cast<double*>(dout + o_pd);
+  int32_t* d_rec = reinterpret_cast<int32_t*>(dout + o_rec);
+  int32_t* d_rctrl = reinterpret_cast<int32_t*>(dout + o_ctrl);
+  uint8_t* d_lim = reinterpret_cast<uint8_t*>(dout + o_lim);
+  uint8_t* d_pose = reinterpret_cast<uint8_t*>(dout + o_pose);
+  c.r_q.ensure((size_t)n * sizeof(sffk::SweepQuery));
+  c.r_cnt.ensure((size_t)n * 4);
+  c.r_hidx.ensure((size_t)n * CAP * 4);
+  c.r_hdist.ensure((size_t)n * CAP * 8);
+  c.r_sega.ensure((size_t)n * STRIDE * 48);
+  c.r_segb.ensure((size_t)n * STRIDE * 48);
+  const int list_cap = 4 * n * STRIDE + 65536;
+  c.r_items.ensure((size_t)list_cap * SFFK_ITEM_BYTES);
+  c.r_items2.ensure(((size_t)list_cap + (1u << 20)) * 8);
+  const int32_t* dev_n = reinterpret_cast<const int32_t*>(d.ctrl.p);   // {n_act, halt}
+
+  if (d.ring_pending) {   // the words this wave may read have to be resident
+    HIPCHK(hipStreamWaitEvent(c.stream, d.ev_ring, 0));
+    d.ring_pending = false;
+  }
+  sffk::launch_wave_begin(c.stream, V);
+  sffk::NodeStoreMut stm{c.sx.as<float>(), c.sy.as<float>(), c.sz.as<float>(), c.syaw.as<float>(),
+                         c.spitch.as<float>(), c.sroll.as<float>(), c.stree.as<int32_t>(), c.spos.as<double>()};
+  for (int r = first_round; r < std::max(1, cfg.threshold_misses); ++r) {
+    c.timing_on = c.timer_stride <= 1 || d.rounds_enqueued % (uint64_t)c.timer_stride == 0;
+    c.round_scope = true;
+    ++d.rounds_enqueued;
+    sffk::SampleParams prm{};
+    memcpy(prm.limits, cfg.limits, sizeof prm.limits);
+    prm.dist_tree = cfg.dist_tree;
+    prm.sweep_abs_eps = c.sweep_eps();
+    prm.rank = 0;
+    prm.world = 1;
+    sffk::RoundTemps tmp{};
+    tmp.st = stm;
+    tmp.cnt = c.r_cnt.as<int32_t>();
+    tmp.tg = c.tgridv;
+    tmp.ctrl = d_rctrl;
+    tmp.n_perm = d.temp_base;
+    tmp.base = d.temp_base;
+    sffk::DevRound dv{};
+    dv.ctrl = V.ctrl;
+    dv.act_slot = V.act_slot;
+    dv.slot_node = V.slot_node;
+    dv.nflag = V.nflag;
+    dv.ring = V.ring;
+    dv.ring_mask = V.ring_mask;
+    dv.words_per = V.words_per;
+    dv.parent_out = d.d_parent.as<int32_t>();
+    dv.force_out = d.d_force.as<uint8_t>();
+    c.time_begin(T_SAMPLE);
+    sffk::launch_sample_steer(c.stream, nullptr, nullptr, c.spos.as<double>(), nullptr, n, cfg.sampling_dist, cfg.dim, prm,
+                              d_pos, d_lim, d_pd, c.r_q.as<sffk::SweepQuery>(), d.temp_base, tmp, &dv);
+    c.time_end();
+    c.time_begin(T_SWEEP);
+    sffk::launch_grid_query(c.stream, c.gridv, &c.tgridv, c.store_view(), c.r_q.as<sffk::SweepQuery>(), d_pos, n,
+                            c.r_cnt.as<int32_t>(), c.r_hidx.as<int32_t>(), c.r_hdist.as<double>(), CAP, dev_n);
+    c.time_end();
+    sffk::ClassifyArgs ca{};
+    ca.n = n; ca.N0 = d.temp_base; ca.cap = CAP; ca.nbcap = NBCAP; ca.rank = 0; ca.world = 1;
+    ca.goal_id = -1;
+    ca.dist_tree = cfg.dist_tree;
+    ca.newpos = d_pos;
+    ca.in_lim = d_lim;
+    ca.pdist = d_pd;
+    ca.parent = d.d_parent.as<int32_t>();
+    ca.force = d.d_force.as<uint8_t>();
+    ca.cnt = c.r_cnt.as<int32_t>();
+    ca.hit_idx = c.r_hidx.as<int32_t>();
+    ca.hit_dist = c.r_hdist.as<double>();
+    ca.tree = c.stree.as<int32_t>();
+    ca.pos = c.spos.as<double>();
+    ca.rec_flags = d_rec;
+    ca.rec_nnb = ca.rec_flags + n;
+    ca.rec_nb = ca.rec_nnb + n;
+    ca.rec_meta = ca.rec_nb + (size_t)n * NBCAP;
+    ca.seg_a = c.r_sega.as<double>();
+    ca.seg_b = c.r_segb.as<double>();
+    ca.seg_ns = reinterpret_cast<int32_t*>(dout + o_ns);
+    ca.first_hit = reinterpret_cast<int32_t*>(dout + o_fh);
+    ca.seg_ovf = reinterpret_cast<int32_t*>(dout + o_ovf);
+    ca.ctrl = d_rctrl;
+    ca.dev_n = dev_n;
+    c.time_begin(T_COLLIDE);
+    sffk::launch_classify(c.stream, ca);
+    sffk::TempGridRef tref{c.tgridv, c.sx.as<float>() + d.temp_base, c.sy.as<float>() + d.temp_base,
+                           c.sz.as<float>() + d.temp_base, n};
+    sffk::launch_round_collide(c.stream, c.envv, c.robv, d_pos, n, ca.rec_flags, d_pose, ca.seg_a, ca.seg_b, ca.seg_ns,
+                               n * STRIDE, ca.ctrl, c.r_items.p, list_cap, c.r_items2.p, ca.first_hit, ca.seg_ovf, &tref,
+                               dev_n, STRIDE);
+    c.time_end();
+    sffk::SettleArgs sa{};
+    sa.n = n; sa.Tb = d.temp_base; sa.nbcap = NBCAP; sa.stride = STRIDE; sa.n_trees = (int)trees.size();
+    sa.in_lim = d_lim; sa.rec_flags = ca.rec_flags; sa.rec_nnb = ca.rec_nnb; sa.rec_nb = ca.rec_nb;
+    sa.rec_meta = ca.rec_meta; sa.seg_ns = ca.seg_ns; sa.first_hit = ca.first_hit;
+    sa.pose_hit = d_pose;
+    sa.code = reinterpret_cast<uint8_t*>(dout + o_code);
+    sa.bulk = reinterpret_cast<unsigned long long*>(dout + o_ctrl + 16);
+    sa.dev_n = dev_n;
+    sa.fault = d.fault_pending.as<int32_t>();
+    sa.count_executed = 1;
+    sffk::launch_settle(c.stream, sa);
+    sffk::ResolveArgs ra{};
+    ra.f = V;
+    ra.st = stm;
+    ra.g = c.gridv;
+    ra.nbcap = NBCAP;
+    ra.stride = STRIDE;
+    ra.newpos = d_pos;
+    ra.pdist = d_pd;
+    ra.parent = d.d_parent.as<int32_t>();
+    ra.code = sa.code;
+    ra.rec_nnb = ca.rec_nnb;
+    ra.rec_nb = ca.rec_nb;
+    ra.rec_meta = ca.rec_meta;
+    ra.seg_ns = ca.seg_ns;
+    ra.first_hit = ca.first_hit;
+    ra.bulk = sa.bulk;
+    ra.round_ctrl = d_rctrl;
+    ra.fault_pending = d.fault_pending.as<int32_t>();
+    sffk::launch_resolve(c.stream, ra);
+    c.timing_on = true;
+    c.round_scope = false;
+  }
+  sffk::launch_wave_end(c.stream, V, c.gridv.ovf_cnt, c.tgridv.ovf_cnt);
+  HIPCHK(hipMemcpyAsync(d.h_ctrl.p, d.ctrl.p, sizeof(sffk::DevCtrl), hipMemcpyDeviceToHost, c.stream));
+  HIPCHK(hipEventRecord(d.ev_wave, c.stream));
+}
+
+void Forest::run_device(int max_waves) {
+  Ctx& c = *ctx;
+  DevEngine& d = dev;
+  HIPCHK(hipSetDevice(c.device));
+  auto t0 = Clock::now();
+  double wait_ms = 0;
+  if (!d.active) dev_upload_state();
+  const uint64_t w0 = d.last.waves;
+  int resume_round = 0;
+  while (true) {
+    const sffk::DevCtrl& k = d.last;
+    if (!k.in_wave) {
+      if (k.terminated) break;
+      if (max_waves > 0 && (int)(k.waves - w0) >= max_waves) break;
+    }
+    dev_ring_top_up(k.cursor, d.max_wave_words);
+    dev_enqueue_wave(resume_round);
+    resume_round = 0;
+    d.host_stale = true;
+    // while the GPU works: the words the NEXT wave may need, whatever this one consumes
+    dev_ring_top_up(k.cursor, 2 * d.max_wave_words);
+    {
+      auto tw = Clock::now();
+      HIPCHK(hipEventSynchronize(d.ev_wave));
+      c.sync();   // (harvests the timing events; the stream is idle)
+      wait_ms += ms_since(tw);
+    }
+    d.last = *d.h_ctrl.as<sffk::DevCtrl>();
+    const sffk::DevCtrl& s = d.last;
+    if (s.fault) {
+      const int fault = s.fault;
+      if (fault == SFFK_FAULT_LISTS) {
+        // a bounded device list overflowed: finish this wave on the host path, then come back
+        dev_to_host();
+        while (in_wave) {
+          round_begin();
+          int32_t cnt = (int32_t)records.size();
+          round_commit(records.data(), cnt, &cnt, 1);
+        }
+        dev_upload_state();
+        continue;
+      }
+      if (fault == SFFK_FAULT_CAPACITY) {
+        // (nodes and temporaries share the store: grow it, re-place the temporaries)
+        c.store_reserve(std::max(c.store_cap * 2, s.n_nodes + 4 * cfg.wave + 64));
+        dev_size_node_arrays();
+        dev_size_border_arrays(std::max(d.border_cap, 2 * (s.n_borders + cfg.wave)));
+      } else if (fault == SFFK_FAULT_BORDER_TABLE) {
+        dev_size_border_arrays(std::max(4 * d.border_cap, 2 * (s.n_borders + cfg.wave)));
+      } else {
+        throw HipError{"forest: unknown device fault"};
+      }
+      if (d.table_dirty) {
+        sffk::launch_border_rehash(c.stream, dev_view(), s.n_borders);
+        d.table_dirty = false;
+      }
+      int32_t clear[2] = {0, 0};
+      HIPCHK(hipMemcpyAsync(reinterpret_cast<char*>(d.ctrl.p) + offsetof(sffk::DevCtrl, fault), &clear[0], 4, hipMemcpyHostToDevice, c.stream));
+      HIPCHK(hipMemcpyAsync(reinterpret_cast<char*>(d.ctrl.p) + offsetof(sffk::DevCtrl, halt), &clear[1], 4, hipMemcpyHostToDevice, c.stream));
+      HIPCHK(hipStreamSynchronize(c.stream));
+      d.last.fault = 0;
+      d.last.halt = 0;
+      continue;   // (in_wave is still set: k_wave_begin only rebuilds the active list)
+    }
+    // the neighbour grid's shared overflow list (checked once per wave like the host path does)
+    if (s.grid_ovf > c.gridv.ovf_cap || s.tgrid_ovf > c.tgridv.ovf_cap)
+      throw HipError{"neighbour grid overflow list exhausted during a wave (nodes were dropped)"};
+    if (s.grid_ovf > c.gridv.ovf_cap / 4) {
+      c.store_n = s.n_nodes;
+      c.grid_inserted = s.n_nodes;
+      c.grid_check();
+    }
+  }
+  st.total_ms += ms_since(t0);
+  st.host_ms += ms_since(t0) - wait_ms;
+}
+
+}  // namespace sff

@@ -87,6 +87,44 @@ struct RobotView {
   double lo[3], hi[3];  // exact box of the un-rotated model
 };
 
+// ---- device-resident forest (devforest.hip): the round loop of SpaceForest::Solve with the in-order commit on the
+// GPU.  DevCtrl lives in HBM, is advanced by single-workgroup kernels (k_wave_begin / k_resolve / k_wave_end) and is
+// copied to the host once per wave.  Every round kernel reads the number of samples from it (the host launches
+// grids sized for the wave), and returns at once when `halt` is set (solver terminated, or a fault the host has
+// to handle: a device list overflowed and the round must be redone on the host path).
+struct DevCtrl {
+  int32_t n_act;            // [0] samples (active slots) of the current round
+  int32_t halt;             // [1] != 0: every kernel returns immediately
+  int32_t n_nodes, iter, round, in_wave;
+  int32_t n_slots, frontier_n, closed_n, use_closed;
+  int32_t terminated, solved, empty_frontier, fault;
+  int32_t N0, iter0, n_borders, n_unsettled;
+  int32_t fault_pending, redraws, grid_ovf, tgrid_ovf;
+  unsigned long long cursor;        // engine words consumed so far
+  unsigned long long words_base;    // cursor at which the current round's sample words start
+  unsigned long long collide_calls, path_free_calls, nn_queries;          // reference-equivalent counters
+  unsigned long long poses_executed, segments_executed, samples_executed; // what the GPU actually ran
+  unsigned long long waves, rounds, round_nodes, round_queries;
+  unsigned long long epoch;         // commit counter (border dedup stamps)
+  unsigned long long work_items;    // (edge, chunk) items of all rounds
+};
+#define SFFK_FAULT_LISTS 1        // a hit / neighbour / triangle-candidate list overflowed: redo the round on the host
+#define SFFK_FAULT_BORDER_TABLE 2 // the border hash table is full: the host grows it
+#define SFFK_FAULT_CAPACITY 4     // node / frontier / border arrays would overflow: the host grows them
+
+// indirections of the round kernels in device mode (ctrl == nullptr: host mode, everything comes as arguments)
+struct DevRound {
+  const DevCtrl* ctrl;
+  const int32_t* act_slot;     // n_act slot indices (ascending)
+  const int32_t* slot_node;    // node expanded by each slot
+  const uint8_t* nflag;        // per node: 1 = ForceChildren, 2 = on the frontier
+  const uint64_t* ring;        // engine words (std::mt19937_64 outputs), ring of ring_mask + 1 words
+  uint64_t ring_mask;
+  int32_t words_per;           // words per sample: 6 (3-D) / 1 (2-D)
+  int32_t* parent_out;         // n: expanded node of every sample (read by k_classify)
+  uint8_t* force_out;          // n: its ForceChildren flag
+};
+
 // forest rounds only: where k_sample_steer writes the round's temporary store entries and which per-round
 // counters it resets (all null / zero for the plain batch entry point)
 struct RoundTemps {
@@ -103,7 +141,7 @@ size_t collide_lds_bytes(int n_robot_tri, int waves);
 void launch_sample_steer(hipStream_t s, const uint64_t* words, const int32_t* parent, const double* node_pos,
                          const double* center_in, int n, double dist, int dim, const SampleParams& prm, double* out6,
                          uint8_t* in_lim, double* parent_dist, SweepQuery* queries, int32_t q_max_base,
-                         const RoundTemps& tmp);
+                         const RoundTemps& tmp, const DevRound* dev = nullptr);
 
 // grid != nullptr: the written nodes are also inserted into the neighbour grid in the same launch
 void launch_store_write(hipStream_t s, const NodeStoreMut& st, const double* pos6, const int32_t* tree,
@@ -116,9 +154,10 @@ void launch_sweep(hipStream_t s, const NodeStoreView& st, int first, int n_nodes
 void launch_grid_insert(hipStream_t s, const GridView& g, const NodeStoreView& st, int first, int n);
 // tg (optional): a second grid with the same cells that holds the round's own samples (filled by k_sample_steer,
 // emptied again by k_seg_compact); query i sees its entries with id < max_id like any other
+// dev_n (optional, device memory): {number of queries, halt flag} read by the kernel instead of nq
 void launch_grid_query(hipStream_t s, const GridView& g, const GridView* tg, const NodeStoreView& st,
                        const SweepQuery* queries, const double* qpos, int nq, int32_t* cnt, int32_t* hit_idx,
-                       double* hit_dist, int cap);
+                       double* hit_dist, int cap, const int32_t* dev_n = nullptr);
 void launch_set_tree(hipStream_t s, int32_t* tree_col, const int32_t* ids, int n, int32_t value);
 
 // explicit_rt: pos6 holds n x 12 doubles (row-major rotation + translation) instead of n x 6 pose parameters
@@ -150,6 +189,7 @@ struct ClassifyArgs {
   int32_t* first_hit;       // n x (1+nbcap): preset to INT32_MAX
   int32_t* seg_ovf;         // n x (1+nbcap)
   int32_t* ctrl;            // [1] next task slot of the persistent edge kernel
+  const int32_t* dev_n;     // device mode: {n, halt} (n above is then the launch bound only)
 };
 void launch_classify(hipStream_t s, const ClassifyArgs& a);
 struct SettleArgs {
@@ -164,6 +204,11 @@ struct SettleArgs {
   const uint8_t* pose_hit;
   uint8_t* code;                  // n
   unsigned long long* bulk;       // 4 counters (zeroed by k_sample_steer with the ctrl words)
+  // device mode (all optional): {n, halt}; a flag raised when a sample needs the host path (a bounded list
+  // overflowed); 3 more counters behind bulk[3]: poses / edges / edge samples this rank executed
+  const int32_t* dev_n;
+  int32_t* fault;
+  int count_executed;
 };
 void launch_settle(hipStream_t s, const SettleArgs& a);
 // end points of edges given as store ids -> a6 / b6
@@ -188,6 +233,40 @@ struct TempGridRef {   // the round's own grid + the fp32 coordinates of its n s
 void launch_round_collide(hipStream_t s, const EnvView& env, const RobotView& rob, const double* pos6, int n_pose,
                           const int32_t* live_flags, uint8_t* pose_hit, const double* a6, const double* b6,
                           const int32_t* seg_ns, int n_slots, int32_t* ctrl, void* list, int list_cap, void* masks,
-                          int32_t* first_hit, int32_t* overflow_flag, const TempGridRef* temps);
+                          int32_t* first_hit, int32_t* overflow_flag, const TempGridRef* temps,
+                          const int32_t* dev_n = nullptr, int stride = 0);
+
+// ---- device-resident forest: state views + the single-workgroup kernels that advance it
+struct DevForestView {
+  DevCtrl* ctrl;
+  // node records beside the store columns (store_view / NodeStoreMut)
+  int32_t* parent; double* d_root; double* d_closest; uint32_t* iter; uint8_t* nflag;
+  int32_t* frontier; int32_t* closed; int32_t* claim;      // claim: per node scratch (INT_MAX between uses)
+  int32_t* slot_node; uint8_t* slot_fail; int32_t* act_slot;
+  // borders: append-only list + open-addressing table of (n1, n2) keys with a commit stamp
+  int32_t* b_n1; int32_t* b_n2; int32_t* b_ta; int32_t* b_tb; double* b_dist;
+  unsigned long long* bt_key; unsigned long long* bt_val; unsigned long long bt_mask;
+  uint8_t* pair;               // n_trees x n_trees: 1 = the pair has a border entry
+  const uint64_t* ring; uint64_t ring_mask;
+  int32_t node_cap, border_cap, wave, n_trees, words_per, threshold_misses, max_iterations, node_budget;
+  int32_t temp_base;           // store index of the round's temporaries
+  uint8_t* ustate; int32_t* ulist; int32_t* uacc;   // k_resolve scratch: per sample state / unsettled list / accepted id
+};
+struct ResolveArgs {
+  DevForestView f;
+  NodeStoreMut st;
+  GridView g;
+  int nbcap, stride;
+  const double* newpos; const double* pdist; const int32_t* parent; const uint8_t* code;
+  const int32_t* rec_nnb; const int32_t* rec_nb; const int32_t* rec_meta; const int32_t* seg_ns; const int32_t* first_hit;
+  unsigned long long* bulk;    // counters of the samples k_settle settled (7 words)
+  const int32_t* round_ctrl;   // the round's 16-int scratch block ([2] = work items)
+  int32_t* fault_pending;
+};
+void launch_wave_begin(hipStream_t s, const DevForestView& f);
+void launch_resolve(hipStream_t s, const ResolveArgs& a);
+void launch_wave_end(hipStream_t s, const DevForestView& f, const int32_t* grid_ovf, const int32_t* tgrid_ovf);
+// border table maintenance: re-insert list entries [0, n) after the host grew the table
+void launch_border_rehash(hipStream_t s, const DevForestView& f, int n);
 
 }  // namespace sffk

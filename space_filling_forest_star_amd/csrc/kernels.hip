@@ -22,32 +22,12 @@
 #include "kernels.h"
 #include <algorithm>
 #include "sff_geom.h"
+#include "kernels_dev.h"
 
 namespace sffk {
 
 using namespace sffg;
 
-__device__ __forceinline__ int grid_coord(float v, float o, float inv, int n) {
-  float f = floorf((v - o) * inv);
-  int c = f < 0.0f ? 0 : (f > (float)(n - 1) ? n - 1 : (int)f);  // NaN compares false twice -> cast of NaN; guarded by callers
-  return c;
-}
-
-__device__ __forceinline__ size_t grid_cell_of(const GridView& g, float x, float y, float z) {
-  const int cx = grid_coord(x, g.ox, g.inv_cell, g.nx), cy = grid_coord(y, g.oy, g.inv_cell, g.ny),
-            cz = grid_coord(z, g.oz, g.inv_cell, g.nz);
-  return ((size_t)cz * g.ny + cy) * g.nx + cx;
-}
-__device__ __forceinline__ void grid_put(const GridView& g, const GridItem& it) {
-  const size_t cell = grid_cell_of(g, it.x, it.y, it.z);
-  const int slot = atomicAdd(g.cnt + cell, 1);
-  if (slot < g.bk) {
-    g.items[cell * g.bk + slot] = it;
-  } else {
-    const int o = atomicAdd(g.ovf_cnt, 1);
-    if (o < g.ovf_cap) g.ovf[o] = it;   // the host checks ovf_cnt against ovf_cap
-  }
-}
 
 // ------------------------------------------------------------------ sample + steer
 __global__ __launch_bounds__(256) void k_sample_steer(const uint64_t* __restrict__ words,
@@ -57,13 +37,17 @@ __global__ __launch_bounds__(256) void k_sample_steer(const uint64_t* __restrict
                                                       int n, double dist, int dim, SampleParams prm,
                                                       double* __restrict__ out6, uint8_t* __restrict__ in_lim,
                                                       double* __restrict__ parent_dist, SweepQuery* __restrict__ queries,
-                                                      int32_t q_max_base, RoundTemps tmp) {
+                                                      int32_t q_max_base, RoundTemps tmp, DevRound dv) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (dv.ctrl) {   // device-resident forest: the round's size lives in HBM
+    if (dv.ctrl->halt) return;
+    n = dv.ctrl->n_act;
+  }
   if (tmp.cnt) {
     // per-round housekeeping folded into this launch: hit counters, the work-list cursor, and NaN
     // placeholders for the store entries between the permanent nodes and the 4-aligned temporaries
     if (i < n) tmp.cnt[i] = 0;
-    if (i < 16) tmp.ctrl[i] = 0;
+    if (i < 32) tmp.ctrl[i] = 0;
     if (i < tmp.base - tmp.n_perm) {
       const float nanv = __int_as_float(0x7fc00000);
       const size_t o = (size_t)tmp.n_perm + i;
@@ -73,10 +57,23 @@ __global__ __launch_bounds__(256) void k_sample_steer(const uint64_t* __restrict
   }
   if (i >= n) return;
   double c[6], o[6];
-  const double* src = center_in ? center_in + 6 * (size_t)i : node_pos + 6 * (size_t)parent[i];
+  int par = 0;
+  if (dv.ctrl) {
+    par = dv.slot_node[dv.act_slot[i]];
+    dv.parent_out[i] = par;
+    dv.force_out[i] = dv.nflag[par] & 1;
+  } else if (!center_in) {
+    par = parent[i];
+  }
+  const double* src = center_in ? center_in + 6 * (size_t)i : node_pos + 6 * (size_t)par;
   for (int k = 0; k < 6; ++k) c[k] = src[k];
   uint64_t w[6];
-  for (int k = 0; k < 6; ++k) w[k] = words[6 * (size_t)i + k];
+  if (dv.ctrl) {   // the sample's words sit in the engine-word ring, in the reference's draw order
+    const unsigned long long base = dv.ctrl->words_base + (unsigned long long)dv.words_per * (unsigned long long)i;
+    for (int k = 0; k < 6; ++k) w[k] = k < dv.words_per ? dv.ring[(base + k) & dv.ring_mask] : 0ULL;
+  } else {
+    for (int k = 0; k < 6; ++k) w[k] = words[6 * (size_t)i + k];
+  }
   bool ok = sample_point(w, c, dist, dim, prm.limits, o);
   for (int k = 0; k < 6; ++k) out6[6 * (size_t)i + k] = o[k];
   in_lim[i] = ok ? 1 : 0;
@@ -92,7 +89,7 @@ __global__ __launch_bounds__(256) void k_sample_steer(const uint64_t* __restrict
     tmp.st.pitch[t] = ok ? (float)o[4] : nanv;
     tmp.st.roll[t] = ok ? (float)o[5] : nanv;
     for (int k = 0; k < 6; ++k) tmp.st.pos[6 * t + k] = o[k];
-    const int tr = tmp.st.tree[parent[i]];
+    const int tr = tmp.st.tree[par];
     tmp.st.tree[t] = tr;
     if (ok && tmp.tg.cnt) {   // and into the round's own grid, where the later samples of the round look for it
       GridItem it;
@@ -285,7 +282,11 @@ __global__ __launch_bounds__(256) void k_grid_query(GridView g, GridView tg, Nod
                                                     const SweepQuery* __restrict__ queries,
                                                     const double* __restrict__ qpos, int nq, int32_t* __restrict__ cnt,
                                                     int32_t* __restrict__ hit_idx, double* __restrict__ hit_dist,
-                                                    int cap) {
+                                                    int cap, const int32_t* __restrict__ dev_n) {
+  if (dev_n) {
+    if (dev_n[1]) return;
+    nq = dev_n[0];
+  }
   const int q = blockIdx.x * 8 + (threadIdx.x >> 5);
   const int lane = threadIdx.x & 31;
   if (q >= nq) return;
@@ -818,7 +819,12 @@ __global__ __launch_bounds__(256) void k_seg_compact(const int32_t* __restrict__
                                                      int32_t* __restrict__ ctrl, WorkItem* __restrict__ list, int cap,
                                                      GridView tg, const float* __restrict__ tx,
                                                      const float* __restrict__ ty, const float* __restrict__ tz,
-                                                     int n_temps) {
+                                                     int n_temps, const int32_t* __restrict__ dev_n, int stride) {
+  if (dev_n) {
+    if (dev_n[1]) return;
+    n_temps = dev_n[0];
+    n_slots = dev_n[0] * stride;
+  }
   __shared__ int wsum[4];
   __shared__ int base_s;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -886,7 +892,12 @@ __device__ __forceinline__ size_t mask_slot(int e, int W) {
 __global__ __launch_bounds__(256) void k_cull(EnvView env, const double* __restrict__ pos6, int n_pose, int pose_blocks,
                                               const int32_t* __restrict__ live_flags, uint8_t* __restrict__ pose_hit,
                                               const WorkItem* __restrict__ list, unsigned long long* __restrict__ masks,
-                                              int exact_waves, const int32_t* __restrict__ ctrl) {
+                                              int exact_waves, const int32_t* __restrict__ ctrl,
+                                              const int32_t* __restrict__ dev_n) {
+  if (dev_n) {
+    if (dev_n[1]) return;
+    n_pose = dev_n[0];
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   if ((int)blockIdx.x < pose_blocks) {
     const int pose = blockIdx.x * 256 + threadIdx.x;
@@ -966,7 +977,13 @@ __global__ __launch_bounds__(64 * SEG_WAVES) void k_collide_segments_dyn(EnvView
                                                                          const WorkItem* __restrict__ list,
                                                                          const unsigned long long* __restrict__ masks,
                                                                          int32_t* __restrict__ first_hit,
-                                                                         int32_t* __restrict__ overflow_flag) {
+                                                                         int32_t* __restrict__ overflow_flag,
+                                                                         const int32_t* __restrict__ dev_n, int stride) {
+  if (dev_n) {
+    if (dev_n[1]) return;
+    n_pose = dev_n[0];
+    n_slots = dev_n[0] * stride;
+  }
   extern __shared__ double lds_d[];
   double* rtri = lds_d;
   int32_t* ibase = reinterpret_cast<int32_t*>(rtri + (size_t)rob.n_tri * 9);
@@ -1097,6 +1114,10 @@ __device__ __forceinline__ void emit_items(const ClassifyArgs& A, size_t slot) {
 }
 
 __global__ __launch_bounds__(256) void k_classify(ClassifyArgs A) {
+  if (A.dev_n) {
+    if (A.dev_n[1]) return;
+    A.n = A.dev_n[0];
+  }
   const int i = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (i >= A.n) return;
@@ -1179,11 +1200,17 @@ __global__ __launch_bounds__(256) void k_classify(ClassifyArgs A) {
 // The reference-equivalent counters of the settled samples are summed here: bulk[0] Collide calls,
 // [1] isPathFree calls, [2] radius queries, [3] settled samples.
 __global__ __launch_bounds__(256) void k_settle(SettleArgs A) {
+  if (A.dev_n) {
+    if (A.dev_n[1]) return;
+    A.n = A.dev_n[0];
+  }
   const int i = blockIdx.x * 256 + threadIdx.x;
   unsigned long long cc = 0, pf = 0, nq = 0, ns_settled = 0;
+  unsigned long long ex_pose = 0, ex_seg = 0, ex_smp = 0;
   if (i < A.n) {
     int code = 0;
     if (!A.in_lim[i]) code = 2;
+    else if (A.fault && (A.rec_flags[i] & 2)) atomicOr(A.fault, 1);   // hit / neighbour list overflow: host path
     else if ((A.rec_flags[i] & 3) == 1) {       // owned by this rank and fully answered on the device
       auto calls = [](int fh, int ns) -> unsigned long long {
         return fh != 0x7fffffff ? (unsigned long long)fh : (unsigned long long)ns;
@@ -1192,6 +1219,13 @@ __global__ __launch_bounds__(256) void k_settle(SettleArgs A) {
       const int nnb = A.rec_nnb[i];
       bool ovf = A.first_hit[s0] == 0;            // 0 = the edge's triangle candidate list ran over
       for (int k = 0; k < nnb; ++k) ovf |= A.first_hit[s0 + 1 + k] == 0;
+      if (ovf && A.fault) atomicOr(A.fault, 1);
+      if (A.count_executed) {
+        ex_pose = 1;
+        ex_seg = 1 + (unsigned long long)nnb;
+        ex_smp = (unsigned long long)A.seg_ns[s0];
+        for (int k = 0; k < nnb; ++k) ex_smp += (unsigned long long)A.seg_ns[s0 + 1 + k];
+      }
       if (!ovf) {
         unsigned long long c1 = 1, p1 = 0, q1 = 0;   // :246 env.Collide(newPoint)
         bool settled = false;
@@ -1229,6 +1263,14 @@ __global__ __launch_bounds__(256) void k_settle(SettleArgs A) {
   }
   if ((threadIdx.x & 63) == 0 && ns_settled) {
     atomicAdd(A.bulk + 0, cc); atomicAdd(A.bulk + 1, pf); atomicAdd(A.bulk + 2, nq); atomicAdd(A.bulk + 3, ns_settled);
+  }
+  if (A.count_executed) {
+    for (int off = 32; off > 0; off >>= 1) {
+      ex_pose += __shfl_xor(ex_pose, off); ex_seg += __shfl_xor(ex_seg, off); ex_smp += __shfl_xor(ex_smp, off);
+    }
+    if ((threadIdx.x & 63) == 0 && ex_pose) {
+      atomicAdd(A.bulk + 4, ex_pose); atomicAdd(A.bulk + 5, ex_seg); atomicAdd(A.bulk + 6, ex_smp);
+    }
   }
 }
 
@@ -1282,11 +1324,11 @@ size_t collide_lds_bytes(int n_robot_tri, int waves) {
 void launch_sample_steer(hipStream_t s, const uint64_t* words, const int32_t* parent, const double* node_pos,
                          const double* center_in, int n, double dist, int dim, const SampleParams& prm, double* out6,
                          uint8_t* in_lim, double* parent_dist, SweepQuery* queries, int32_t q_max_base,
-                         const RoundTemps& tmp) {
+                         const RoundTemps& tmp, const DevRound* dev) {
   if (n <= 0) return;
   // (64-thread workgroups: a round has a few thousand samples, this spreads them over the whole chip)
   hipLaunchKernelGGL(k_sample_steer, dim3((n + 63) / 64), dim3(64), 0, s, words, parent, node_pos, center_in, n,
-                     dist, dim, prm, out6, in_lim, parent_dist, queries, q_max_base, tmp);
+                     dist, dim, prm, out6, in_lim, parent_dist, queries, q_max_base, tmp, dev ? *dev : DevRound{});
 }
 
 void launch_store_write(hipStream_t s, const NodeStoreMut& st, const double* pos6, const int32_t* tree,
@@ -1322,11 +1364,11 @@ void launch_grid_insert(hipStream_t s, const GridView& g, const NodeStoreView& s
 }
 void launch_grid_query(hipStream_t s, const GridView& g, const GridView* tg, const NodeStoreView& st,
                        const SweepQuery* queries, const double* qpos, int nq, int32_t* cnt, int32_t* hit_idx,
-                       double* hit_dist, int cap) {
+                       double* hit_dist, int cap, const int32_t* dev_n) {
   if (nq <= 0) return;
   GridView none{};
   hipLaunchKernelGGL(k_grid_query, dim3((nq + 7) / 8), dim3(256), 0, s, g, tg ? *tg : none, st, queries, qpos, nq, cnt,
-                     hit_idx, hit_dist, cap);
+                     hit_idx, hit_dist, cap, dev_n);
 }
 void launch_set_tree(hipStream_t s, int32_t* tree_col, const int32_t* ids, int n, int32_t value) {
   if (n <= 0) return;
@@ -1378,7 +1420,8 @@ void launch_seg_prepare(hipStream_t s, const double* a6, const double* b6, int n
 void launch_round_collide(hipStream_t s, const EnvView& env, const RobotView& rob, const double* pos6, int n_pose,
                           const int32_t* live_flags, uint8_t* pose_hit, const double* a6, const double* b6,
                           const int32_t* seg_ns, int n_slots, int32_t* ctrl, void* list, int list_cap, void* masks,
-                          int32_t* first_hit, int32_t* overflow_flag, const TempGridRef* temps) {
+                          int32_t* first_hit, int32_t* overflow_flag, const TempGridRef* temps, const int32_t* dev_n,
+                          int stride) {
   if (!pose_hit) n_pose = 0;
   if (n_slots <= 0 && n_pose <= 0) return;
   size_t lds = collide_lds_bytes(rob.n_tri, SEG_WAVES);
@@ -1390,14 +1433,14 @@ void launch_round_collide(hipStream_t s, const EnvView& env, const RobotView& ro
   if (n_slots > 0)
     hipLaunchKernelGGL(k_seg_compact, dim3((n_slots + 1023) / 1024), dim3(256), 0, s, seg_ns, n_slots, a6, b6, ctrl,
                        static_cast<WorkItem*>(list), list_cap, temps ? temps->tg : GridView{}, temps ? temps->x : nullptr,
-                       temps ? temps->y : nullptr, temps ? temps->z : nullptr, temps ? temps->n : 0);
+                       temps ? temps->y : nullptr, temps ? temps->z : nullptr, temps ? temps->n : 0, dev_n, stride);
   const int pose_blocks = (n_pose + 255) / 256;
   hipLaunchKernelGGL(k_cull, dim3(pose_blocks + (n_slots > 0 ? cull_blocks : 0)), dim3(256), 0, s, env, pos6, n_pose,
                      pose_blocks, live_flags, pose_hit, static_cast<const WorkItem*>(list),
-                     static_cast<unsigned long long*>(masks), blocks * SEG_WAVES, ctrl);
+                     static_cast<unsigned long long*>(masks), blocks * SEG_WAVES, ctrl, dev_n);
   hipLaunchKernelGGL(k_collide_segments_dyn, dim3(blocks), dim3(64 * SEG_WAVES), lds, s, env, rob, pos6, n_pose,
                      pose_hit, a6, b6, seg_ns, n_slots, ctrl, static_cast<const WorkItem*>(list),
-                     static_cast<const unsigned long long*>(masks), first_hit, overflow_flag);
+                     static_cast<const unsigned long long*>(masks), first_hit, overflow_flag, dev_n, stride);
 }
 
 void launch_collide_segments_dyn(hipStream_t s, const EnvView& env, const RobotView& rob, const double* a6,

@@ -1,0 +1,149 @@
+"""The device-resident SFF engine (csrc/devforest.hip + forest_dev.cpp: in-order commit, frontier picks and wave
+bookkeeping on the GPU, one host sync per wave) against the CPU oracle at the same wave size - and against the
+host-replay engine it replaces.  Also its fault paths: bounded device lists that overflow (the round is redone on
+the host path), arrays and the border table that have to grow, staged runs with getters in between."""
+import os
+
+import numpy as np
+import pytest
+
+import common
+import oracle_lib as O
+from test_gpu_parity import assert_same_forest, load_world
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def S():
+    import space_filling_forest_star_amd as S
+    return S
+
+
+@pytest.fixture(scope="module")
+def ctx(S):
+    c = S.Context(0)
+    yield c
+    c.close()
+
+
+class engine:
+    """SFFGPU_ENGINE / test knobs are read when a forest is created"""
+
+    def __init__(self, **env):
+        self.env = {k: str(v) for k, v in env.items()}
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.env}
+        os.environ.update(self.env)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def make(S, ctx, name, wave, iters, seed, n_roots=5, budget=0, which="device", **env):
+    sc, w = load_world(ctx, name)
+    roots = sc["xml_points"][:n_roots] if sc["xml_points"] is not None else \
+        common.free_roots(w.collide, sc["limits"], n_roots, seed=seed, dim=sc["dim"])
+    kw = dict(dist_tree=sc["dist_tree"], sampling_dist=sc["sampling_dist"], dim=sc["dim"], max_iterations=iters,
+              node_budget=budget, wave=wave, seed=seed)
+    fo = O.Forest(w, roots, sc["limits"], **kw)
+    with engine(SFFGPU_ENGINE=which, **env):
+        fg = S.Forest(ctx, roots, sc["limits"], **kw)
+    return fo, fg
+
+
+@pytest.mark.parametrize("name,wave,iters", [
+    ("dense3d", 1, 600), ("dense3d", 7, 2500), ("dense3d", 64, 8000), ("dense3d", 512, 40000), ("dense3d", 4096, 150000),
+    ("dense3d_coarse", 1, 800), ("dense3d_coarse", 64, 8000), ("dense3d_coarse", 1024, 30000),
+    ("triang", 1, 600), ("triang", 128, 10000), ("triang", 2048, 60000),
+    ("dense2d", 3, 1500), ("dense2d", 256, 8000), ("building", 256, 8000),
+])
+def test_device_engine_equals_the_oracle(S, ctx, name, wave, iters):
+    fo, fg = make(S, ctx, name, wave, iters, seed=3)
+    fo.run()
+    fg.run()
+    assert fo.stats()["n_nodes"] > 40
+    assert_same_forest(fo, fg)
+
+
+def test_device_engine_is_the_default_for_gpu_sized_waves_and_equals_the_host_engine(S, ctx):
+    # (a forest owns its context's node store while it lives: one at a time)
+    fo, fd = make(S, ctx, "dense3d", 1024, 60000, seed=11, which="")       # default choice
+    fd.run()
+    fo.run()
+    assert_same_forest(fo, fd)
+    fp_d, sd = fd.fingerprint(), fd.stats()
+    fd.close()
+    _, fh = make(S, ctx, "dense3d", 1024, 60000, seed=11, which="host")
+    fh.run()
+    assert fp_d == fh.fingerprint()
+    sh = fh.stats()
+    for k in ("iterations", "n_nodes", "n_borders", "collide_calls", "path_free_calls", "nn_queries", "waves", "sweeps",
+              "sweep_queries", "sweep_nodes", "poses_executed", "segments_executed", "samples_executed"):
+        assert sd[k] == sh[k], k
+    # the device engine really ran: far less host time per wave than the replaying engine
+    assert sd["host_ms"] < 0.6 * sh["host_ms"]
+
+
+def test_saturating_forest_terminates_solved_with_closed_list_picks(S, ctx):
+    """coarse steps: the frontier runs empty, the engine keeps expanding from the closed list (src/forest.h:
+    136-141) until every tree is connected -> solved"""
+    fo, fg = make(S, ctx, "dense3d_coarse", 512, 10 ** 7, seed=2)
+    fo.run()
+    fg.run()
+    so = fo.stats()
+    assert so["solved"] == 1 and so["frontier_size"] == 0 and so["closed_size"] > 100
+    assert_same_forest(fo, fg)
+
+
+def test_staged_runs_with_getters_in_between(S, ctx):
+    fo, fg = make(S, ctx, "dense3d", 512, 10 ** 7, seed=5, budget=20000)
+    fo.run()
+    fps = []
+    while True:
+        w0 = fg.stats()["waves"]
+        fg.run(3)
+        if fg.stats()["waves"] == w0:
+            break
+        fps.append(fg.fingerprint())          # forces a host-mirror refresh in the middle of the run
+        assert len(fg.nodes()["parent"]) == fg.stats()["n_nodes"]
+        assert len(fg.frontier()) == fg.stats()["frontier_size"]
+    assert len(fps) > 3 and len(set(fps)) == len(fps)
+    assert_same_forest(fo, fg)
+    # path extraction works on the refreshed mirror
+    do = fo.paths()
+    dg, _ = fg.paths()
+    assert np.array_equal(do, dg)
+
+
+@pytest.mark.parametrize("env", [dict(SFFGPU_TEST_HITCAP=3), dict(SFFGPU_TEST_NBCAP=1)])
+def test_list_overflow_faults_finish_the_wave_on_the_host_path(S, ctx, env):
+    fo, fg = make(S, ctx, "dense3d_coarse", 256, 12000, seed=4, **env)
+    fo.run()
+    fg.run()
+    assert fg.stats()["slow_path_samples"] > 0      # the fault path ran
+    assert_same_forest(fo, fg)
+
+
+def test_arrays_and_border_table_grow_on_demand(S, ctx):
+    """no node budget: the store starts at 4096 nodes and has to grow; many borders: the border list and its hash
+    table start small (test knob) and have to grow too"""
+    fo, fg = make(S, ctx, "dense3d_coarse", 256, 60000, seed=6, SFFGPU_TEST_BORDER_CAP=64)
+    fo.run()
+    fg.run()
+    assert fo.stats()["n_nodes"] > 3000 and fo.stats()["n_borders"] > 300
+    assert_same_forest(fo, fg)
+
+
+def test_iteration_cap_inside_a_round(S, ctx):
+    for iters in (1000, 1003, 2500):
+        fo, fg = make(S, ctx, "triang", 300, iters, seed=8)
+        fo.run()
+        fg.run()
+        assert fo.stats()["iterations"] == iters
+        assert_same_forest(fo, fg)
