@@ -17,15 +17,15 @@ mkdir -p $out
 BENCH="$root/bench.py --gpus 1 --steps 20 --warmup 5 $extra"
 LEAN="--cpu-iters 0 --no-sweep-micro --no-wave-sweep"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_trace -o t -- python3 $BENCH $LEAN > $out/${tag}_trace.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_trace -o t -- python3 $BENCH $LEAN > $out/${tag}_trace.log 2>&1
 cp $out/${tag}_trace/t_kernel_stats.csv $out/${tag}_kernel_stats.csv
 tail -1 $out/${tag}_trace.log > $out/${tag}_bench_line_under_trace.json
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $c --output-format csv -d $out/${tag}_pmc_$c -o p -- python3 $BENCH $LEAN > $out/${tag}_pmc_$c.log 2>&1
+  timeout 300 rocprofv3 --pmc $c --output-format csv -d $out/${tag}_pmc_$c -o p -- python3 $BENCH $LEAN > $out/${tag}_pmc_$c.log 2>&1
 done
 python3 $root/profiles/summarize_pmc.py --bench-args "--steps 20 --warmup 5 $extra" \
   $out/${tag}_pmc_FETCH_SIZE/p_counter_collection.csv $out/${tag}_pmc_WRITE_SIZE/p_counter_collection.csv > $out/${tag}_pmc_summary.json
-cd $root && python3 $BENCH > $out/${tag}_bench_full.log 2>&1
+cd $root && timeout 600 python3 $BENCH > $out/${tag}_bench_full.log 2>&1
 tail -1 $out/${tag}_bench_full.log > $out/${tag}_bench_line.json
 rm -rf $out/${tag}_trace/t_kernel_trace.csv $out/${tag}_pmc_FETCH_SIZE $out/${tag}_pmc_WRITE_SIZE
 echo done

@@ -14,7 +14,13 @@
 //                 node store, the neighbour grid and the frontier; border events are de-duplicated "first in slot
 //                 order wins" through a stamped hash table; then the next round's active list is built
 //   k_wave_end    one workgroup: exhausted slots move their node to the closed list (first occurrence in slot
-//                 order), order-preserving frontier compaction (src/forest.h:160-163), termination tests (:184-201)
+//                 order) and mark their frontier position; termination tests (src/forest.h:184-201)
+//   k_frontier_compact  wide: order-preserving removal of the marked positions (the reference erases them one by
+//                 one, :160-163) from one frontier buffer into the other
+//
+// Ordered compactions inside the single-workgroup kernels use 64-bit ballot words kept in LDS (one word per 64
+// elements, a prefix over the words' popcounts by one wavefront) instead of block-wide scans per 1024 elements:
+// two barriers per list, whatever its length.
 //
 // Everything here is integer / index bookkeeping plus the few fp64 expressions of expandNode, evaluated in the same
 // order as the host engine and the CPU oracle (-ffp-contract=off), so the forests are bit-identical.
@@ -30,26 +36,53 @@ using namespace sffg;
 
 #define DF_THREADS 1024
 #define DF_WAVES (DF_THREADS / 64)
+#define DF_EV_LDS 1024                      // border events of a round whose details stay in LDS
+#define DF_MAX_GROUPS SFFK_DEV_MAX_GROUPS   // ballot words in LDS: 64 x this many elements per list
 
-// exclusive prefix sum of one int per thread over the workgroup; returns the thread's offset, *total = sum
-__device__ __forceinline__ int block_scan(int v, int* total, int* wsum /* DF_WAVES + 1 ints of LDS */) {
+struct WgLists {                     // LDS of the single-workgroup kernels
+  unsigned long long words[DF_MAX_GROUPS];
+  int pref[DF_MAX_GROUPS];
+  int total;
+};
+
+// flags of elements [0, n) -> ballot words (every wave takes every 16th group of 64 elements)
+template <class Pred>
+__device__ __forceinline__ void wg_flags(WgLists& L, int n, Pred pred) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int inc = v;
-  for (int off = 1; off < 64; off <<= 1) {
-    const int o = __shfl_up(inc, off);
-    if (lane >= off) inc += o;
+  const int ng = (n + 63) >> 6;
+  for (int g = wave; g < ng; g += DF_WAVES) {
+    const int i = g * 64 + lane;
+    const bool fl = i < n && pred(i);
+    const unsigned long long m = __ballot(fl);
+    if (lane == 0) L.words[g] = m;
   }
-  __syncthreads();   // (wsum may still be read from a previous call)
-  if (lane == 63) wsum[wave] = inc;
+}
+// exclusive prefix of the words' popcounts (wave 0); returns the number of flagged elements.  Barriers inside.
+__device__ __forceinline__ int wg_prefix(WgLists& L, int n) {
+  const int ng = (n + 63) >> 6;
   __syncthreads();
-  if (threadIdx.x == 0) {
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x;
     int run = 0;
-    for (int w = 0; w < DF_WAVES; ++w) { const int t = wsum[w]; wsum[w] = run; run += t; }
-    wsum[DF_WAVES] = run;
+    for (int b = 0; b < ng; b += 64) {
+      const int g = b + lane;
+      const int c = g < ng ? __popcll(L.words[g]) : 0;
+      int inc = c;
+      for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(inc, off);
+        if (lane >= off) inc += o;
+      }
+      if (g < ng) L.pref[g] = run + inc - c;
+      run += __shfl(inc, 63);
+    }
+    if (lane == 0) L.total = run;
   }
   __syncthreads();
-  *total = wsum[DF_WAVES];
-  return wsum[wave] + inc - v;
+  return L.total;
+}
+__device__ __forceinline__ bool wg_flagged(const WgLists& L, int i) { return (L.words[i >> 6] >> (i & 63)) & 1ULL; }
+__device__ __forceinline__ int wg_rank(const WgLists& L, int i) {
+  return L.pref[i >> 6] + __popcll(L.words[i >> 6] & ((1ULL << (i & 63)) - 1ULL));
 }
 
 // libstdc++ uniform_int_distribution<int>(0, range - 1) on one 64-bit engine word (Lemire's multiply-shift):
@@ -64,33 +97,30 @@ __device__ __forceinline__ int lemire_pick(unsigned long long word, unsigned lon
   return (int)hi;
 }
 
-// The next round's active list: the failing slots in slot order, cut at the iteration cap (src/forest.h:155:
-// i < ThresholdMisses && expandResult && iter < maxIterations).  Called by all threads of the single workgroup.
-__device__ void round_begin(const DevForestView& f, int* wsum) {
-  DevCtrl* c = f.ctrl;
-  const int n_slots = c->n_slots;
-  __shared__ int run_s;
-  if (threadIdx.x == 0) run_s = 0;
-  __syncthreads();
-  for (int base = 0; base < n_slots; base += DF_THREADS) {
-    const int s = base + threadIdx.x;
-    const int fail = (s < n_slots && f.slot_fail[s]) ? 1 : 0;
-    int tot;
-    const int off = block_scan(fail, &tot, wsum);
-    if (fail) f.act_slot[run_s + off] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) run_s += tot;
-    __syncthreads();
+__device__ __forceinline__ int32_t* frontier_now(const DevForestView& f) { return f.ctrl->front_sel ? f.frontier2 : f.frontier; }
+__device__ __forceinline__ int32_t* act_now(const DevForestView& f) { return f.ctrl->act_sel ? f.act_slot2 : f.act_slot; }
+
+// Sizes the next round from the active list (already in place, act_cnt entries): src/forest.h:155 - i <
+// ThresholdMisses && expandResult && iter < maxIterations.  Thread 0 of the single workgroup.
+__device__ void round_begin_scalars(const DevForestView& f, DevCtrl* c) {
+  const int cnt = c->act_cnt;
+  int n = 0;
+  if (c->round < f.threshold_misses && cnt > 0 && c->iter < f.max_iterations && !c->solved) {
+    const int left = f.max_iterations - c->iter;
+    n = cnt < left ? cnt : left;
   }
-  if (threadIdx.x == 0) {
-    const int cnt = run_s;
-    int n = 0;
-    if (c->round < f.threshold_misses && cnt > 0 && c->iter < f.max_iterations && !c->solved) {
-      const int left = f.max_iterations - c->iter;
-      n = cnt < left ? cnt : left;
-    }
-    c->n_act = n;
-    if (n > 0) {
+  c->n_act = n;
+  if (n > 0) {
+    // the arrays a round can grow: one node / frontier entry / border per sample at most
+    if (c->n_nodes + n > f.node_cap - 8 || c->n_borders + n > f.border_cap) {
+      c->fault = SFFK_FAULT_CAPACITY;
+      c->halt = 1;
+      c->n_act = 0;
+    } else if ((unsigned long long)(c->n_borders + n) * 2ULL > f.bt_mask + 1ULL) {
+      c->fault = SFFK_FAULT_BORDER_TABLE;
+      c->halt = 1;
+      c->n_act = 0;
+    } else {
       c->round += 1;
       c->iter0 = c->iter;
       c->iter += n;
@@ -100,36 +130,18 @@ __device__ void round_begin(const DevForestView& f, int* wsum) {
       c->rounds += 1;
       c->round_nodes += (unsigned long long)(c->n_nodes + n);
       c->round_queries += (unsigned long long)n;
-      // the arrays a round can grow: one node / frontier entry / border per sample at most
-      if (c->n_nodes + n > f.node_cap - 8 || c->n_borders + n > f.border_cap) {
-        c->fault = SFFK_FAULT_CAPACITY;
-        c->halt = 1;
-      } else if ((unsigned long long)(c->n_borders + n) * 2ULL > f.bt_mask + 1ULL) {
-        c->fault = SFFK_FAULT_BORDER_TABLE;
-        c->halt = 1;
-      }
-      if (c->halt) {   // nothing of this round has happened yet: hand the host the state before it
-        c->round -= 1;
-        c->iter = c->iter0;
-        c->cursor = c->words_base;
-        c->rounds -= 1;
-        c->round_nodes -= (unsigned long long)(c->n_nodes + n);
-        c->round_queries -= (unsigned long long)n;
-        c->n_act = 0;
-      }
     }
   }
-  __syncthreads();
 }
 
 // ------------------------------------------------------------------ wave begin
 __global__ __launch_bounds__(DF_THREADS) void k_wave_begin(DevForestView f) {
-  __shared__ int wsum[DF_WAVES + 1];
   __shared__ int any_redraw;
   DevCtrl* c = f.ctrl;
+  if (threadIdx.x == 0) { c->compact_from = 0; c->app_n = 0; }   // (no stale order for the wide follow-up kernels)
   if (c->halt) return;
-  if (c->in_wave) {   // resuming inside a wave (after the host handled a fault): only rebuild the active list
-    round_begin(f, wsum);
+  if (c->in_wave) {   // resuming inside a wave (after the host handled a fault): the active list is in place
+    if (threadIdx.x == 0) round_begin_scalars(f, c);
     return;
   }
   // node selection of every slot, src/forest.h:136-151 (non-priority mode): a uniform pick from the frozen frontier,
@@ -138,15 +150,16 @@ __global__ __launch_bounds__(DF_THREADS) void k_wave_begin(DevForestView f) {
   const int pool = use_closed ? c->closed_n : c->frontier_n;
   int n_slots = f.wave < pool ? f.wave : pool;
   if (n_slots < 1) n_slots = 1;
-  const int32_t* from = use_closed ? f.closed : f.frontier;
+  const int32_t* from = use_closed ? f.closed : frontier_now(f);
+  int32_t* act = act_now(f);
   const unsigned long long cur = c->cursor;
   if (threadIdx.x == 0) any_redraw = 0;
   __syncthreads();
   for (int s = threadIdx.x; s < n_slots; s += DF_THREADS) {
     const int pick = lemire_pick(f.ring[(cur + (unsigned long long)s) & f.ring_mask], (unsigned long long)pool);
     if (pick < 0) any_redraw = 1;
-    else f.slot_node[s] = from[pick];
-    f.slot_fail[s] = 1;
+    else { f.slot_node[s] = from[pick]; f.slot_pos[s] = pick; }
+    act[s] = s;                 // every slot starts the wave failing
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -157,22 +170,91 @@ __global__ __launch_bounds__(DF_THREADS) void k_wave_begin(DevForestView f) {
         int pick;
         do { pick = lemire_pick(f.ring[at & f.ring_mask], (unsigned long long)pool); ++at; } while (pick < 0);
         f.slot_node[s] = from[pick];
+        f.slot_pos[s] = pick;
       }
       used = at - cur;
       c->redraws += 1;
     }
     c->cursor = cur + used;
     c->n_slots = n_slots;
+    c->act_cnt = n_slots;
     c->use_closed = use_closed ? 1 : 0;
     c->round = 0;
     c->in_wave = 1;
     c->waves += 1;
+    round_begin_scalars(f, c);
   }
-  __syncthreads();
-  round_begin(f, wsum);
 }
 
-// ------------------------------------------------------------------ in-order commit of one round
+// ------------------------------------------------------------------ the commit of one round
+// k_decide (wide): everything about a sample that does not depend on the other samples of the round.  Walks the
+// neighbour list in the reference's order (src/forest.h:262-300) until a verdict falls or the first round-mate is
+// reached; the reference-equivalent counters of what it walked go straight into the round's bulk sums (they are
+// plain sums), so k_resolve only adds what it walks itself.
+__global__ __launch_bounds__(256) void k_decide(ResolveArgs A) {
+  const DevForestView& f = A.f;
+  if (f.ctrl->halt) return;
+  const int n = f.ctrl->n_act;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  unsigned long long cc = 0, pf = 0, nq = 0, ex_pose = 0, ex_seg = 0, ex_smp = 0;
+  if (i < n) {
+    int code = SFFK_REJECTED, dk = 0;
+    if (!A.in_lim[i]) code = SFFK_OUTSIDE;
+    else if (A.rec_flags[i] & 2) atomicOr(A.fault_pending, 1);   // hit / neighbour list overflow: host path
+    else if ((A.rec_flags[i] & 3) == 1) {
+      auto calls = [](int fh, int ns) -> unsigned long long {
+        return fh != 0x7fffffff ? (unsigned long long)fh : (unsigned long long)ns;
+      };
+      const size_t s0 = (size_t)i * A.stride;
+      const int nnb = A.rec_nnb[i];
+      bool ovf = A.first_hit[s0] == 0;            // 0 = the edge's triangle candidate list ran over
+      ex_pose = 1;
+      ex_seg = 1 + (unsigned long long)nnb;
+      ex_smp = (unsigned long long)A.seg_ns[s0];
+      for (int k = 0; k < nnb; ++k) {
+        ovf |= A.first_hit[s0 + 1 + k] == 0;
+        ex_smp += (unsigned long long)A.seg_ns[s0 + 1 + k];
+      }
+      if (ovf) atomicOr(A.fault_pending, 1);
+      else {
+        cc = 1;                                    // :246 env.Collide(newPoint)
+        if (!A.pose_hit[i]) {
+          pf = 1;
+          cc += calls(A.first_hit[s0], A.seg_ns[s0]);
+          if (A.first_hit[s0] == 0x7fffffff) {     // parent edge free: the neighbour loop decides
+            nq = (unsigned long long)f.n_trees;    // :262-267 one radiusSearch per tree
+            code = SFFK_ACCEPT;
+            for (int k = 0; k < nnb; ++k) {
+              if (A.rec_nb[(size_t)i * A.nbcap + k] >= f.temp_base) { code = SFFK_DEPENDS; dk = k; break; }
+              const int fh = A.first_hit[s0 + 1 + k];
+              const bool fr = fh == 0x7fffffff;
+              pf += 1;
+              cc += calls(fh, A.seg_ns[s0 + 1 + k]);
+              if (A.rec_meta[(size_t)i * A.nbcap + k] & 1) {
+                if (fr) { code = SFFK_REJECTED; break; }                       // :276-280 overcrowded
+              } else {
+                code = fr ? SFFK_REJECT_EVENT : SFFK_REJECTED;                  // :288-299
+                dk = k;
+                break;
+              }
+            }
+          }
+        }
+      }
+    }
+    A.code[i] = (uint8_t)code;
+    f.dk[i] = (uint8_t)dk;
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    cc += __shfl_xor(cc, off); pf += __shfl_xor(pf, off); nq += __shfl_xor(nq, off);
+    ex_pose += __shfl_xor(ex_pose, off); ex_seg += __shfl_xor(ex_seg, off); ex_smp += __shfl_xor(ex_smp, off);
+  }
+  if ((threadIdx.x & 63) == 0 && ex_pose) {
+    atomicAdd(A.bulk + 0, cc); atomicAdd(A.bulk + 1, pf); atomicAdd(A.bulk + 2, nq);
+    atomicAdd(A.bulk + 4, ex_pose); atomicAdd(A.bulk + 5, ex_seg); atomicAdd(A.bulk + 6, ex_smp);
+  }
+}
+
 // border de-duplication: open addressing on the key (n1 << 32 | n2 + 1); the value is a stamp (epoch << 32 | sample)
 // that only ever decreases, so among the events of one round the smallest sample index owns the key and every
 // entry of an earlier round (smaller epoch) beats them all
@@ -189,21 +271,26 @@ __device__ __forceinline__ size_t border_slot(const DevForestView& f, unsigned l
   }
 }
 
+// k_resolve (one workgroup): what needs the slot order.  Sample states: 0 undecided, 1 rejected, 2 accepted,
+// 3 rejected with a border event (neighbour dk).
 __global__ __launch_bounds__(DF_THREADS) void k_resolve(ResolveArgs A) {
-  __shared__ int wsum[DF_WAVES + 1];
-  __shared__ int n_uns_s, undecided_s, run_s, n_ev_s;
+  __shared__ WgLists L;
+  __shared__ int undecided_s;
   __shared__ unsigned long long cnt_s[3];
+  __shared__ DevCtrl K;              // the control block, worked on in LDS and written back once
+  __shared__ int ev_nb_s[DF_EV_LDS], ev_ex_s[DF_EV_LDS];
+  __shared__ unsigned int ev_h_s[DF_EV_LDS];
   const DevForestView& f = A.f;
   DevCtrl* c = f.ctrl;
+  if (threadIdx.x == 0) c->app_n = 0;
   if (c->halt) return;
   const int n = c->n_act;
-  if (n == 0) {
-    if (c->in_wave) round_begin(f, wsum);   // (a wave that is over keeps n_act = 0)
-    return;
-  }
+  if (n == 0) return;      // (a wave that is over keeps n_act = 0)
+  for (int w = threadIdx.x; w < (int)(sizeof(DevCtrl) / 4); w += DF_THREADS)
+    reinterpret_cast<int32_t*>(&K)[w] = reinterpret_cast<const int32_t*>(c)[w];
   if (*A.fault_pending) {
-    // a bounded device list overflowed somewhere in this round: nothing is committed, the bookkeeping of
-    // round_begin is rolled back and the host redoes the round on its unbounded path
+    // a bounded device list overflowed somewhere in this round: nothing is committed, the bookkeeping of the
+    // round's begin is rolled back and the host redoes the round on its unbounded path
     if (threadIdx.x == 0) {
       c->fault = SFFK_FAULT_LISTS;
       c->halt = 1;
@@ -218,44 +305,50 @@ __global__ __launch_bounds__(DF_THREADS) void k_resolve(ResolveArgs A) {
     }
     return;
   }
-  const int Tb = f.temp_base, N0 = c->N0, iter0 = c->iter0;
-  const int stride = A.stride, nbcap = A.nbcap;
-  if (threadIdx.x == 0) { n_uns_s = 0; cnt_s[0] = cnt_s[1] = cnt_s[2] = 0ULL; }
   __syncthreads();
-  // ---- 1. the samples k_settle left open (code 0), in slot order
-  for (int base = 0; base < n; base += DF_THREADS) {
-    const int i = base + threadIdx.x;
-    const int open = (i < n && A.code[i] == 0) ? 1 : 0;
-    if (i < n) f.ustate[i] = open ? 0 : 1;            // 0 undecided, 1 rejected, 2 accepted
-    int tot;
-    const int off = block_scan(open, &tot, wsum);
-    if (open) f.ulist[n_uns_s + off] = i;
-    __syncthreads();
-    if (threadIdx.x == 0) n_uns_s += tot;
-    __syncthreads();
-  }
-  const int n_uns = n_uns_s;
-  // ---- 2. fixed point over the dependencies on earlier samples of the round: an open sample has a free pose and
-  // a free parent edge; its neighbour list (order of src/forest.h:262-300) decides.  A round-mate neighbour only
-  // exists if that sample was accepted.
-  unsigned long long cc = 0, pf = 0, nq = 0;
-  for (int pass = 0; pass < n + 2; ++pass) {
+  const int Tb = f.temp_base, N0 = K.N0, fn0 = K.frontier_n, nb0 = K.n_borders, act_cnt = K.act_cnt;
+  const int act_sel = K.act_sel;
+  const int32_t* act_old = act_sel ? f.act_slot2 : f.act_slot;
+  int32_t* act_new = act_sel ? f.act_slot : f.act_slot2;
+  const unsigned long long stamp_hi = (K.epoch + 1ULL) << 32;
+  const int stride = A.stride, nbcap = A.nbcap;
+  if (threadIdx.x == 0) { cnt_s[0] = cnt_s[1] = 0ULL; }
+  unsigned long long tk[6];
+  tk[0] = wall_clock64();
+  // ---- 1. states from k_decide's verdicts; the samples that wait for an earlier sample of the round, in slot order
+  wg_flags(L, n, [&](int i) {
+    const int code = A.code[i];
+    f.ustate[i] = code == SFFK_DEPENDS ? 0 : (code == SFFK_ACCEPT ? 2 : (code == SFFK_REJECT_EVENT ? 3 : 1));
+    return code == SFFK_DEPENDS;
+  });
+  const int n_dep = wg_prefix(L, n);
+  for (int i = threadIdx.x; i < n; i += DF_THREADS)
+    if (wg_flagged(L, i)) f.ulist[wg_rank(L, i)] = i;
+  __threadfence_block();
+  __syncthreads();
+  // ---- 2. fixed point: a dependent sample continues its neighbour walk (order of src/forest.h:262-300) at the
+  // round-mate where k_decide stopped.  A round-mate neighbour only exists if that sample was accepted.
+  unsigned long long cc = 0, pf = 0;
+  tk[1] = wall_clock64();
+  int passes = 0;
+  for (int pass = 0; pass < n + 2 && n_dep > 0; ++pass) {
+    ++passes;
     if (threadIdx.x == 0) undecided_s = 0;
     __syncthreads();
     int mine_undecided = 0;
-    for (int u = threadIdx.x; u < n_uns; u += DF_THREADS) {
+    for (int u = threadIdx.x; u < n_dep; u += DF_THREADS) {
       const int i = f.ulist[u];
       if (f.ustate[i] != 0) continue;
       const size_t s0 = (size_t)i * stride;
       const int nnb = A.rec_nnb[i];
-      unsigned long long c1 = 1 + (unsigned long long)A.seg_ns[s0], p1 = 1, q1 = (unsigned long long)f.n_trees;
-      int verdict = 2, ev_nb = -1;
-      for (int k = 0; k < nnb; ++k) {
+      unsigned long long c1 = 0, p1 = 0;
+      int verdict = 2, ev_nb = 0;
+      for (int k = f.dk[i]; k < nnb; ++k) {
         const int id = A.rec_nb[(size_t)i * nbcap + k];
         if (id >= Tb) {
           const int sj = f.ustate[id - Tb];
           if (sj == 0) { verdict = 0; break; }        // not known yet: next pass
-          if (sj == 1) continue;                      // that sample never became a node
+          if (sj != 2) continue;                      // that sample never became a node
         }
         const int fh = A.first_hit[s0 + 1 + k];
         const bool fr = fh == 0x7fffffff;
@@ -264,14 +357,14 @@ __global__ __launch_bounds__(DF_THREADS) void k_resolve(ResolveArgs A) {
         if (A.rec_meta[(size_t)i * nbcap + k] & 1) {
           if (fr) { verdict = 1; break; }             // :276-280 overcrowded
         } else {
-          if (fr) ev_nb = k;                          // :288-294 border entry
-          verdict = 1;                                // :296-299
+          verdict = fr ? 3 : 1;                       // :288-299
+          ev_nb = k;
           break;
         }
       }
       if (verdict == 0) { mine_undecided = 1; continue; }
-      cc += c1; pf += p1; nq += q1;
-      f.uacc[i] = ev_nb;                              // (accepted ids are filled in below; rejected keep the event slot)
+      cc += c1; pf += p1;
+      if (verdict == 3) f.dk[i] = (uint8_t)ev_nb;
       __threadfence_block();
       f.ustate[i] = (uint8_t)verdict;
     }
@@ -280,187 +373,233 @@ __global__ __launch_bounds__(DF_THREADS) void k_resolve(ResolveArgs A) {
     if (!undecided_s) break;
     __syncthreads();
   }
-  // ---- 3. node ids of the accepted samples: N0 + rank in slot order; append to store, grid, frontier
-  if (threadIdx.x == 0) { run_s = 0; n_ev_s = 0; }
+  // ---- 3. node ids of the accepted samples: N0 + rank in slot order (k_append writes the nodes)
+  tk[2] = wall_clock64();
   __syncthreads();
-  for (int base = 0; base < n_uns; base += DF_THREADS) {
-    const int u = base + threadIdx.x;
-    const int i = u < n_uns ? f.ulist[u] : 0;
-    const int acc = (u < n_uns && f.ustate[i] == 2) ? 1 : 0;
-    int tot;
-    const int off = block_scan(acc, &tot, wsum);
-    if (acc) {
-      const int id = N0 + run_s + off;
-      f.uacc[i] = id;
-      const int ex = A.parent[i];
-      const double* p = A.newpos + 6 * (size_t)i;
-      const size_t o = (size_t)id;
-      GridItem it;
-      it.x = (float)p[0]; it.y = (float)p[1]; it.z = (float)p[2];
-      it.yaw = (float)p[3]; it.pitch = (float)p[4]; it.roll = (float)p[5];
-      it.id = id;
-      it.tree = A.st.tree[ex];
-      A.st.x[o] = it.x; A.st.y[o] = it.y; A.st.z[o] = it.z;
-      A.st.yaw[o] = it.yaw; A.st.pitch[o] = it.pitch; A.st.roll[o] = it.roll;
-      for (int k = 0; k < 6; ++k) A.st.pos[6 * o + k] = p[k];
-      A.st.tree[o] = it.tree;
-      const double pd = A.pdist[i];
-      f.parent[o] = ex;                                // src/forest.h:353
-      f.d_closest[o] = pd;
-      f.d_root[o] = pd + f.d_root[ex];
-      f.iter[o] = (uint32_t)(iter0 + i + 1);
-      f.nflag[o] = 2;
-      f.frontier[c->frontier_n + run_s + off] = id;    // :365
-      f.slot_fail[f.act_slot[i]] = 0;
-      grid_put(A.g, it);                               // flannIndex->addPoints, :367
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) run_s += tot;
-    __syncthreads();
-  }
-  const int n_acc = run_s;
-  __threadfence();
+  wg_flags(L, n, [&](int i) { return f.ustate[i] == 2; });
+  const int n_acc = wg_prefix(L, n);
+  for (int i = threadIdx.x; i < n; i += DF_THREADS)
+    if (wg_flagged(L, i)) f.uacc[i] = N0 + wg_rank(L, i);
+  __threadfence_block();
   __syncthreads();
   // ---- 4. border events (a free edge to a neighbour of another tree, :288-294), first in slot order wins
-  const unsigned long long stamp_hi = (c->epoch + 1ULL) << 32;
-  for (int u = threadIdx.x; u < n_uns; u += DF_THREADS) {
-    const int i = f.ulist[u];
-    if (f.ustate[i] != 1) continue;
-    const int k = f.uacc[i];
-    if (k < 0) continue;
-    const int raw = A.rec_nb[(size_t)i * nbcap + k];
-    const int nb = raw >= Tb ? f.uacc[raw - Tb] : raw;
-    const int ex = A.parent[i];
+  tk[3] = wall_clock64();
+  wg_flags(L, n, [&](int i) { return f.ustate[i] == 3; });
+  const int n_evc = wg_prefix(L, n);
+  for (int i = threadIdx.x; i < n; i += DF_THREADS)
+    if (wg_flagged(L, i)) f.ulist[wg_rank(L, i)] = i;          // (the dependent list is done with: reuse)
+  __threadfence_block();
+  __syncthreads();
+  auto event_of = [&](int i, int& nb, int& ex, unsigned long long& key) {
+    const int raw = A.rec_nb[(size_t)i * nbcap + f.dk[i]];
+    nb = raw >= Tb ? f.uacc[raw - Tb] : raw;       // (a round-mate neighbour was accepted: its new id)
+    ex = A.parent[i];
     const int a = nb < ex ? nb : ex, b = nb < ex ? ex : nb;
-    const unsigned long long key = ((unsigned long long)(uint32_t)a << 32) | ((unsigned long long)(uint32_t)b + 1ULL);
+    key = ((unsigned long long)(uint32_t)a << 32) | ((unsigned long long)(uint32_t)b + 1ULL);
+  };
+  // (what an event needs - neighbour id, expanded node, table slot - is kept in LDS between the three steps)
+  for (int e = threadIdx.x; e < n_evc; e += DF_THREADS) {
+    const int i = f.ulist[e];
+    int nb, ex;
+    unsigned long long key;
+    event_of(i, nb, ex, key);
     const size_t h = border_slot(f, key);
+    if (e < DF_EV_LDS) { ev_nb_s[e] = nb; ev_ex_s[e] = ex; ev_h_s[e] = (unsigned int)h; }
     atomicMin(&f.bt_val[h], stamp_hi | (unsigned long long)(uint32_t)i);
   }
-  __threadfence();
+  __threadfence_block();   // (one workgroup: its L1 and the barrier order everything; an agent-scope fence would write the L2 back)
   __syncthreads();
-  for (int base = 0; base < n_uns; base += DF_THREADS) {
-    const int u = base + threadIdx.x;
-    int keep = 0, i = 0, nb = 0, ex = 0, a = 0, b = 0;
-    if (u < n_uns) {
-      i = f.ulist[u];
-      const int k = f.ustate[i] == 1 ? f.uacc[i] : -1;
-      if (k >= 0) {
-        const int raw = A.rec_nb[(size_t)i * nbcap + k];
-        nb = raw >= Tb ? f.uacc[raw - Tb] : raw;
-        ex = A.parent[i];
-        a = nb < ex ? nb : ex; b = nb < ex ? ex : nb;
-        const unsigned long long key = ((unsigned long long)(uint32_t)a << 32) | ((unsigned long long)(uint32_t)b + 1ULL);
-        // (atomic read: the stamps were written by L2 atomics a moment ago)
-        const unsigned long long owner = __hip_atomic_load(&f.bt_val[border_slot(f, key)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        keep = owner == (stamp_hi | (unsigned long long)(uint32_t)i) ? 1 : 0;
-      }
+  wg_flags(L, n_evc, [&](int e) {
+    const int i = f.ulist[e];
+    size_t h;
+    if (e < DF_EV_LDS) h = ev_h_s[e];
+    else {
+      int nb, ex;
+      unsigned long long key;
+      event_of(i, nb, ex, key);
+      h = border_slot(f, key);
     }
-    int tot;
-    const int off = block_scan(keep, &tot, wsum);
-    if (keep) {
-      const int at = c->n_borders + n_ev_s + off;
-      const int ta = A.st.tree[nb], tb = A.st.tree[ex];
-      f.b_n1[at] = a; f.b_n2[at] = b;
-      f.b_ta[at] = ta < tb ? ta : tb; f.b_tb[at] = ta < tb ? tb : ta;
-      double pn[6], pe[6];
-      for (int q = 0; q < 6; ++q) { pn[q] = A.st.pos[6 * (size_t)nb + q]; pe[q] = A.st.pos[6 * (size_t)ex + q]; }
-      f.b_dist[at] = f.d_root[nb] + f.d_root[ex] + dist6(pn, pe);   // :291
-      f.pair[(size_t)ta * f.n_trees + tb] = 1;
-      f.pair[(size_t)tb * f.n_trees + ta] = 1;
+    // (atomic read: the stamps were written by L2 atomics a moment ago)
+    const unsigned long long owner = __hip_atomic_load(&f.bt_val[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return owner == (stamp_hi | (unsigned long long)(uint32_t)i);
+  });
+  const int n_ev = n_evc > 0 ? wg_prefix(L, n_evc) : 0;
+  for (int e = threadIdx.x; e < n_evc; e += DF_THREADS) {
+    if (!wg_flagged(L, e)) continue;
+    const int i = f.ulist[e];
+    int nb, ex;
+    if (e < DF_EV_LDS) { nb = ev_nb_s[e]; ex = ev_ex_s[e]; }
+    else {
+      unsigned long long key;
+      event_of(i, nb, ex, key);
     }
-    __syncthreads();
-    if (threadIdx.x == 0) n_ev_s += tot;
-    __syncthreads();
+    const int at = nb0 + wg_rank(L, e);
+    // d = costs to the roots + the edge (:291).  A neighbour accepted in this very round is not in the store yet
+    // (k_append runs next): its tree is its parent's, its position the sample's, its cost the one k_append will write.
+    double pn[6], pe[6], dn;
+    int ta;
+    const int raw = A.rec_nb[(size_t)i * nbcap + f.dk[i]];
+    if (raw >= Tb) {
+      const int j = raw - Tb;
+      for (int q = 0; q < 6; ++q) pn[q] = A.newpos[6 * (size_t)j + q];
+      dn = A.pdist[j] + f.d_root[A.parent[j]];
+      ta = A.st.tree[A.parent[j]];
+    } else {
+      for (int q = 0; q < 6; ++q) pn[q] = A.st.pos[6 * (size_t)nb + q];
+      dn = f.d_root[nb];
+      ta = A.st.tree[nb];
+    }
+    const int tb = A.st.tree[ex];
+    f.b_n1[at] = nb < ex ? nb : ex; f.b_n2[at] = nb < ex ? ex : nb;
+    f.b_ta[at] = ta < tb ? ta : tb; f.b_tb[at] = ta < tb ? tb : ta;
+    for (int q = 0; q < 6; ++q) pe[q] = A.st.pos[6 * (size_t)ex + q];
+    f.b_dist[at] = dn + f.d_root[ex] + dist6(pn, pe);
+    f.pair[(size_t)ta * f.n_trees + tb] = 1;
+    f.pair[(size_t)tb * f.n_trees + ta] = 1;
   }
-  // ---- 5. counters, sizes
-  for (int off = 32; off > 0; off >>= 1) { cc += __shfl_xor(cc, off); pf += __shfl_xor(pf, off); nq += __shfl_xor(nq, off); }
-  if ((threadIdx.x & 63) == 0 && (cc | pf | nq)) { atomicAdd(&cnt_s[0], cc); atomicAdd(&cnt_s[1], pf); atomicAdd(&cnt_s[2], nq); }
+  // ---- 5. the next round's active list: the slots of this round that were not accepted, then the slots the
+  // iteration cap kept out of this round
+  tk[4] = wall_clock64();
+  __syncthreads();
+  wg_flags(L, n, [&](int i) { return f.ustate[i] != 2; });
+  const int n_still = wg_prefix(L, n);
+  for (int i = threadIdx.x; i < n; i += DF_THREADS)
+    if (wg_flagged(L, i)) act_new[wg_rank(L, i)] = act_old[i];
+  for (int i = n + threadIdx.x; i < act_cnt; i += DF_THREADS) act_new[n_still + (i - n)] = act_old[i];
+  // ---- 6. counters, sizes
+  for (int off = 32; off > 0; off >>= 1) { cc += __shfl_xor(cc, off); pf += __shfl_xor(pf, off); }
+  if ((threadIdx.x & 63) == 0 && (cc | pf)) { atomicAdd(&cnt_s[0], cc); atomicAdd(&cnt_s[1], pf); }
+  __threadfence_block();   // (one workgroup: its L1 and the barrier order everything; an agent-scope fence would write the L2 back)
   __syncthreads();
   if (threadIdx.x == 0) {
-    c->collide_calls += cnt_s[0] + A.bulk[0];
-    c->path_free_calls += cnt_s[1] + A.bulk[1];
-    c->nn_queries += cnt_s[2] + A.bulk[2];
-    c->poses_executed += A.bulk[4];
-    c->segments_executed += A.bulk[5];
-    c->samples_executed += A.bulk[6];
-    c->work_items += (unsigned long long)A.round_ctrl[2];
-    c->n_nodes = N0 + n_acc;
-    c->frontier_n += n_acc;
-    c->n_borders += n_ev_s;
-    c->n_unsettled += n_uns;
-    c->epoch += 1ULL;
+    K.collide_calls += cnt_s[0] + A.bulk[0];
+    K.path_free_calls += cnt_s[1] + A.bulk[1];
+    K.nn_queries += A.bulk[2];
+    K.poses_executed += A.bulk[4];
+    K.segments_executed += A.bulk[5];
+    K.samples_executed += A.bulk[6];
+    K.work_items += (unsigned long long)A.round_ctrl[2];
+    K.app_n = n;                  // k_append applies this commit
+    K.app_N0 = N0;
+    K.app_fn0 = fn0;
+    K.app_act_sel = act_sel;
+    K.iter0_app = K.iter0;
+    K.n_nodes = N0 + n_acc;
+    K.frontier_n = fn0 + n_acc;
+    K.n_borders = nb0 + n_ev;
+    K.n_unsettled += n_dep;
+    K.epoch += 1ULL;
+    K.act_sel = act_sel ^ 1;
+    K.act_cnt = n_still + (act_cnt - n);
+    round_begin_scalars(f, &K);
+    tk[5] = wall_clock64();
+    for (int q = 0; q < 5; ++q) K.prof[q] += tk[q + 1] - tk[q];
+    K.prof[5] += (unsigned long long)passes;
+    K.prof[6] += 1ULL;
+    if ((unsigned long long)passes > K.prof[7]) K.prof[7] = (unsigned long long)passes;
   }
-  __threadfence();
   __syncthreads();
-  round_begin(f, wsum);
+  for (int w = threadIdx.x; w < (int)(sizeof(DevCtrl) / 4); w += DF_THREADS)
+    reinterpret_cast<int32_t*>(c)[w] = reinterpret_cast<const int32_t*>(&K)[w];
+}
+
+
+
+// k_append (wide): the accepted samples become nodes - store columns, node records, neighbour grid, frontier
+// (src/forest.h:353-367).  Runs although the NEXT round may already be halted: this commit is final.
+__global__ __launch_bounds__(256) void k_append(ResolveArgs A) {
+  const DevForestView& f = A.f;
+  const DevCtrl* c = f.ctrl;
+  const int n = c->app_n;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n || f.ustate[i] != 2) return;
+  const int N0 = c->app_N0, fn0 = c->app_fn0;
+  int32_t* const frontier = frontier_now(f);
+  const int id = f.uacc[i];
+  const int ex = A.parent[i];
+  const double* p = A.newpos + 6 * (size_t)i;
+  const size_t o = (size_t)id;
+  GridItem it;
+  it.x = (float)p[0]; it.y = (float)p[1]; it.z = (float)p[2];
+  it.yaw = (float)p[3]; it.pitch = (float)p[4]; it.roll = (float)p[5];
+  it.id = id;
+  it.tree = A.st.tree[ex];
+  A.st.x[o] = it.x; A.st.y[o] = it.y; A.st.z[o] = it.z;
+  A.st.yaw[o] = it.yaw; A.st.pitch[o] = it.pitch; A.st.roll[o] = it.roll;
+  for (int k = 0; k < 6; ++k) A.st.pos[6 * o + k] = p[k];
+  A.st.tree[o] = it.tree;
+  const double pd = A.pdist[i];
+  f.parent[o] = ex;                                  // src/forest.h:353
+  f.d_closest[o] = pd;
+  f.d_root[o] = pd + f.d_root[ex];
+  f.iter[o] = (uint32_t)(c->iter0_app + i + 1);
+  f.nflag[o] = 2;
+  frontier[fn0 + (id - N0)] = id;                    // :365
+  grid_put(A.g, it);                                 // flannIndex->addPoints, :367
 }
 
 // ------------------------------------------------------------------ wave end
 __global__ __launch_bounds__(DF_THREADS) void k_wave_end(DevForestView f, const int32_t* __restrict__ grid_ovf,
                                                          const int32_t* __restrict__ tgrid_ovf) {
-  __shared__ int wsum[DF_WAVES + 1];
-  __shared__ int run_s, removed_s;
+  __shared__ WgLists L;
   DevCtrl* c = f.ctrl;
   if (c->halt || !c->in_wave) return;
-  const int n_slots = c->n_slots;
   const bool from_closed = c->use_closed != 0;
+  const int fn = c->frontier_n;
+  const int nw = (fn + 63) >> 6;
+  const int n_fail = c->act_cnt;                 // the slots still failing, in slot order
+  const int32_t* act = act_now(f);
+  int removed = 0;
   // ---- exhausted slots: the node leaves the frontier for the closed list (src/forest.h:160-178); a node held by
-  // several slots moves once, at its first slot
+  // several slots moves once, at its first slot.  Its position in the frontier (the pick index) is marked in rm_words.
   if (!from_closed) {
-    for (int s = threadIdx.x; s < n_slots; s += DF_THREADS)
-      if (f.slot_fail[s] && (f.nflag[f.slot_node[s]] & 2)) atomicMin(&f.claim[f.slot_node[s]], s);
-  }
-  if (threadIdx.x == 0) { run_s = 0; removed_s = 0; }
-  __threadfence();
-  __syncthreads();
-  if (!from_closed) {
-    for (int base = 0; base < n_slots; base += DF_THREADS) {
-      const int s = base + threadIdx.x;
-      int win = 0, node = 0;
-      if (s < n_slots && f.slot_fail[s]) {
-        node = f.slot_node[s];
-        win = ((f.nflag[node] & 2) && __hip_atomic_load(&f.claim[node], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == s) ? 1 : 0;
-      }
-      int tot;
-      const int off = block_scan(win, &tot, wsum);
-      if (win) f.closed[c->closed_n + run_s + off] = node;
-      __syncthreads();
-      if (threadIdx.x == 0) run_s += tot;
-      __syncthreads();
-    }
-    // (flags and claims are cleared only now: every slot of a node had to see them)
-    for (int s = threadIdx.x; s < n_slots; s += DF_THREADS) {
-      if (!f.slot_fail[s]) continue;
+    for (int w = threadIdx.x; w < nw; w += DF_THREADS) f.rm_words[w] = 0ULL;
+    for (int e = threadIdx.x; e < n_fail; e += DF_THREADS) atomicMin(&f.claim[f.slot_node[act[e]]], e);
+    __threadfence_block();   // (one workgroup: its L1 and the barrier order everything; an agent-scope fence would write the L2 back)
+    __syncthreads();
+    wg_flags(L, n_fail, [&](int e) {
+      return __hip_atomic_load(&f.claim[f.slot_node[act[e]]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == e;
+    });
+    removed = wg_prefix(L, n_fail);
+    const int cn0 = c->closed_n;
+    for (int e = threadIdx.x; e < n_fail; e += DF_THREADS) {
+      if (!wg_flagged(L, e)) continue;
+      const int s = act[e];
       const int node = f.slot_node[s];
-      if (__hip_atomic_load(&f.claim[node], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == s) {
-        f.nflag[node] = (uint8_t)((f.nflag[node] & ~2) | 1);
-        f.claim[node] = 0x7fffffff;
+      f.closed[cn0 + wg_rank(L, e)] = node;
+      f.nflag[node] = (uint8_t)((f.nflag[node] & ~2) | 1);
+      const int pos = f.slot_pos[s];
+      atomicOr(&f.rm_words[pos >> 6], 1ULL << (pos & 63));
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < n_fail; e += DF_THREADS)     // (claims cleared only now: every slot of a node saw them)
+      f.claim[f.slot_node[act[e]]] = 0x7fffffff;
+    // exclusive prefix of the removed positions per 64-entry word (k_frontier_compact shifts by it)
+    __threadfence_block();   // (one workgroup: its L1 and the barrier order everything; an agent-scope fence would write the L2 back)
+    __syncthreads();
+    if (removed > 0 && threadIdx.x < 64) {
+      const int lane = threadIdx.x;
+      int run = 0;
+      for (int b = 0; b < nw; b += 64) {
+        const int w = b + lane;
+        const int cnt = w < nw ? __popcll(__hip_atomic_load(&f.rm_words[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0;
+        int inc = cnt;
+        for (int off = 1; off < 64; off <<= 1) {
+          const int o = __shfl_up(inc, off);
+          if (lane >= off) inc += o;
+        }
+        if (w < nw) f.rm_pref[w] = run + inc - cnt;
+        run += __shfl(inc, 63);
       }
     }
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) { c->closed_n += run_s; removed_s = run_s; run_s = 0; }
-    __syncthreads();
-  }
-  // ---- order-preserving compaction of the frontier (the reference erases the entries one by one)
-  if (removed_s > 0) {
-    const int fn = c->frontier_n;
-    for (int base = 0; base < fn; base += DF_THREADS) {
-      const int r = base + threadIdx.x;
-      const int node = r < fn ? f.frontier[r] : 0;
-      const int keep = (r < fn && (f.nflag[node] & 2)) ? 1 : 0;
-      int tot;
-      const int off = block_scan(keep, &tot, wsum);   // (its barriers sit between every read and every write of the chunk)
-      if (keep) f.frontier[run_s + off] = node;
-      __syncthreads();
-      if (threadIdx.x == 0) run_s += tot;
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) c->frontier_n = run_s;
     __syncthreads();
   }
   // ---- termination (src/forest.h:184-201)
   if (threadIdx.x == 0) {
+    c->closed_n += removed;
+    c->compact_from = removed > 0 ? fn : 0;     // k_frontier_compact: entries of the old buffer to sift
+    c->frontier_n = fn - removed;
+    if (removed > 0) c->front_sel ^= 1;
     c->empty_frontier = c->frontier_n == 0 ? 1 : 0;
     if (!c->solved && c->empty_frontier) {
       // maxConnected() == numRoots (:379-418): every tree reachable from tree 0 over pairs that hold a border
@@ -491,6 +630,20 @@ __global__ __launch_bounds__(DF_THREADS) void k_wave_end(DevForestView f, const 
   }
 }
 
+// order-preserving removal of the marked positions: old buffer -> the other one (selected by k_wave_end already)
+__global__ __launch_bounds__(256) void k_frontier_compact(DevForestView f) {
+  const DevCtrl* c = f.ctrl;
+  const int n = c->compact_from;
+  if (n <= 0) return;                       // nothing was removed in this wave (or the kernel ran before a wave ended)
+  const int32_t* src = c->front_sel ? f.frontier : f.frontier2;   // (front_sel already names the NEW buffer)
+  int32_t* dst = c->front_sel ? f.frontier2 : f.frontier;
+  for (int r = blockIdx.x * 256 + threadIdx.x; r < n; r += gridDim.x * 256) {
+    const unsigned long long w = f.rm_words[r >> 6];
+    if ((w >> (r & 63)) & 1ULL) continue;
+    dst[r - f.rm_pref[r >> 6] - __popcll(w & ((1ULL << (r & 63)) - 1ULL))] = src[r];
+  }
+}
+
 __global__ __launch_bounds__(256) void k_border_rehash(DevForestView f, int n) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= n) return;
@@ -502,11 +655,15 @@ __global__ __launch_bounds__(256) void k_border_rehash(DevForestView f, int n) {
 void launch_wave_begin(hipStream_t s, const DevForestView& f) {
   hipLaunchKernelGGL(k_wave_begin, dim3(1), dim3(DF_THREADS), 0, s, f);
 }
-void launch_resolve(hipStream_t s, const ResolveArgs& a) {
+void launch_commit(hipStream_t s, const ResolveArgs& a, int n_bound) {
+  if (n_bound <= 0) return;
+  hipLaunchKernelGGL(k_decide, dim3((n_bound + 255) / 256), dim3(256), 0, s, a);
   hipLaunchKernelGGL(k_resolve, dim3(1), dim3(DF_THREADS), 0, s, a);
+  hipLaunchKernelGGL(k_append, dim3((n_bound + 255) / 256), dim3(256), 0, s, a);
 }
 void launch_wave_end(hipStream_t s, const DevForestView& f, const int32_t* grid_ovf, const int32_t* tgrid_ovf) {
   hipLaunchKernelGGL(k_wave_end, dim3(1), dim3(DF_THREADS), 0, s, f, grid_ovf, tgrid_ovf);
+  hipLaunchKernelGGL(k_frontier_compact, dim3(512), dim3(256), 0, s, f);
 }
 void launch_border_rehash(hipStream_t s, const DevForestView& f, int n) {
   if (n <= 0) return;

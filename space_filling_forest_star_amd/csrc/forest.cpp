@@ -115,7 +115,8 @@ Forest::Forest(Ctx* c, const sffgpu_forest_cfg& cf, const double* roots6, int n_
       // the host replay below otherwise (SFF*, goal / priority modes, sharded runs, tiny waves)
     const char* e = getenv("SFFGPU_ENGINE");
     const std::string want = e ? e : "";
-    dev.on = device_eligible() && want != "host" && (cfg.wave >= 256 || want == "device");
+    dev.on = device_eligible() && want != "host" && (cfg.wave >= 256 || want == "device") &&
+             cfg.wave <= 64 * SFFK_DEV_MAX_GROUPS;
   }
   // (device engine: a wave of new nodes past the budget plus the round's temporaries behind them)
   ctx->store_reset(std::max(cfg.node_budget, 4096) + (dev.on ? 2 * cfg.wave + 128 : cfg.wave + 64));
@@ -277,7 +278,8 @@ Forest::~Forest() {
   DevBuf* bufs[] = {&dev.ctrl, &dev.parent, &dev.d_root, &dev.d_closest, &dev.iter, &dev.nflag, &dev.frontier, &dev.closed,
                     &dev.claim, &dev.slot_node, &dev.slot_fail, &dev.act_slot, &dev.b_n1, &dev.b_n2, &dev.b_ta, &dev.b_tb,
                     &dev.b_dist, &dev.bt_key, &dev.bt_val, &dev.pair, &dev.ring, &dev.ustate, &dev.ulist, &dev.uacc,
-                    &dev.d_parent, &dev.d_force, &dev.fault_pending};
+                    &dev.d_parent, &dev.d_force, &dev.fault_pending, &dev.frontier2, &dev.rm_words, &dev.rm_pref,
+                    &dev.slot_pos, &dev.act_slot2, &dev.dk};
   if (dev.inited) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);

@@ -46,11 +46,16 @@ sffk::DevForestView Forest::dev_view() const {
   v.iter = d.iter.as<uint32_t>();
   v.nflag = d.nflag.as<uint8_t>();
   v.frontier = d.frontier.as<int32_t>();
+  v.frontier2 = d.frontier2.as<int32_t>();
+  v.rm_words = d.rm_words.as<unsigned long long>();
+  v.rm_pref = d.rm_pref.as<int32_t>();
+  v.slot_pos = d.slot_pos.as<int32_t>();
   v.closed = d.closed.as<int32_t>();
   v.claim = d.claim.as<int32_t>();
   v.slot_node = d.slot_node.as<int32_t>();
-  v.slot_fail = d.slot_fail.as<uint8_t>();
   v.act_slot = d.act_slot.as<int32_t>();
+  v.act_slot2 = d.act_slot2.as<int32_t>();
+  v.dk = d.dk.as<uint8_t>();
   v.b_n1 = d.b_n1.as<int32_t>();
   v.b_n2 = d.b_n2.as<int32_t>();
   v.b_ta = d.b_ta.as<int32_t>();
@@ -92,6 +97,9 @@ void Forest::dev_size_node_arrays() {
   d.iter.ensure((size_t)cap * 4);
   d.nflag.ensure((size_t)cap);
   d.frontier.ensure((size_t)cap * 4);
+  d.frontier2.ensure((size_t)cap * 4);
+  d.rm_words.ensure(((size_t)cap / 64 + 2) * 8);
+  d.rm_pref.ensure(((size_t)cap / 64 + 2) * 4);
   d.closed.ensure((size_t)cap * 4);
   const size_t old_claim = d.claim.cap;
   d.claim.ensure((size_t)cap * 4);
@@ -167,8 +175,10 @@ void Forest::dev_upload_state() {
     d.ctrl.ensure(sizeof(sffk::DevCtrl));
     d.h_ctrl.ensure(sizeof(sffk::DevCtrl));
     d.slot_node.ensure((size_t)wave * 4);
-    d.slot_fail.ensure((size_t)wave);
+    d.slot_pos.ensure((size_t)wave * 4);
     d.act_slot.ensure((size_t)wave * 4);
+    d.act_slot2.ensure((size_t)wave * 4);
+    d.dk.ensure((size_t)wave);
     d.ustate.ensure((size_t)wave);
     d.ulist.ensure((size_t)wave * 4);
     d.uacc.ensure((size_t)wave * 4);
@@ -272,11 +282,19 @@ void Forest::dev_upload_state() {
     if (in_wave) {
       k.n_slots = (int)slots.size();
       k.use_closed = (!slots.empty() && slots[0].from_closed) ? 1 : 0;
-      std::vector<int32_t> sn(slots.size());
-      std::vector<uint8_t> sf(slots.size());
-      for (size_t s = 0; s < slots.size(); ++s) { sn[s] = slots[s].node; sf[s] = slots[s].failing ? 1 : 0; }
+      std::vector<int32_t> sn(slots.size()), sp(slots.size(), 0), act;
+      std::vector<int32_t> where(nodes.size(), 0);   // frontier position of every node (k_wave_end marks positions)
+      for (size_t r = 0; r < frontier.size(); ++r) where[frontier[r]] = (int32_t)r;
+      for (size_t s = 0; s < slots.size(); ++s) {
+        sn[s] = slots[s].node;
+        sp[s] = where[slots[s].node];
+        if (slots[s].failing) act.push_back((int32_t)s);   // the active list: failing slots in slot order
+      }
+      k.act_cnt = (int)act.size();
+      k.act_sel = 0;
+      HIPCHK(hipMemcpy(d.slot_pos.p, sp.data(), sp.size() * 4, hipMemcpyHostToDevice));
       HIPCHK(hipMemcpy(d.slot_node.p, sn.data(), sn.size() * 4, hipMemcpyHostToDevice));
-      HIPCHK(hipMemcpy(d.slot_fail.p, sf.data(), sf.size(), hipMemcpyHostToDevice));
+      if (!act.empty()) HIPCHK(hipMemcpy(d.act_slot.p, act.data(), act.size() * 4, hipMemcpyHostToDevice));
     }
     HIPCHK(hipMemcpy(d.ctrl.p, &k, sizeof k, hipMemcpyHostToDevice));
     d.last = k;
@@ -313,7 +331,7 @@ void Forest::sync_host() {
   if (n > 0) HIPCHK(hipMemcpy(nflag.data(), d.nflag.p, (size_t)n, hipMemcpyDeviceToHost));
   frontier.resize((size_t)k.frontier_n);
   closed.resize((size_t)k.closed_n);
-  if (k.frontier_n) HIPCHK(hipMemcpy(frontier.data(), d.frontier.p, (size_t)k.frontier_n * 4, hipMemcpyDeviceToHost));
+  if (k.frontier_n) HIPCHK(hipMemcpy(frontier.data(), k.front_sel ? d.frontier2.p : d.frontier.p, (size_t)k.frontier_n * 4, hipMemcpyDeviceToHost));
   if (k.closed_n) HIPCHK(hipMemcpy(closed.data(), d.closed.p, (size_t)k.closed_n * 4, hipMemcpyDeviceToHost));
   if (k.n_borders > d.host_borders) {
     const int b0 = d.host_borders, m = k.n_borders - b0;
@@ -346,10 +364,11 @@ void Forest::sync_host() {
   st.sweep_nodes = k.round_nodes;
   st.sweep_queries = k.round_queries;
   if (in_wave) {
-    std::vector<int32_t> sn(k.n_slots);
-    std::vector<uint8_t> sf(k.n_slots);
+    std::vector<int32_t> sn(k.n_slots), act((size_t)k.act_cnt);
+    std::vector<uint8_t> sf(k.n_slots, 0);
     HIPCHK(hipMemcpy(sn.data(), d.slot_node.p, (size_t)k.n_slots * 4, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(sf.data(), d.slot_fail.p, (size_t)k.n_slots, hipMemcpyDeviceToHost));
+    if (k.act_cnt) HIPCHK(hipMemcpy(act.data(), k.act_sel ? d.act_slot2.p : d.act_slot.p, (size_t)k.act_cnt * 4, hipMemcpyDeviceToHost));
+    for (int32_t s : act) sf[s] = 1;     // still failing = still on the active list
     slots.resize((size_t)k.n_slots);
     for (int s = 0; s < k.n_slots; ++s) { slots[s].node = sn[s]; slots[s].failing = sf[s] != 0; slots[s].from_closed = k.use_closed != 0; slots[s].tree = -1; slots[s].heap = -1; }
   }
@@ -440,6 +459,7 @@ void Forest::dev_enqueue_wave(int first_round) {
     sffk::DevRound dv{};
     dv.ctrl = V.ctrl;
     dv.act_slot = V.act_slot;
+    dv.act_slot2 = V.act_slot2;
     dv.slot_node = V.slot_node;
     dv.nflag = V.nflag;
     dv.ring = V.ring;
@@ -488,17 +508,6 @@ void Forest::dev_enqueue_wave(int first_round) {
                                n * STRIDE, ca.ctrl, c.r_items.p, list_cap, c.r_items2.p, ca.first_hit, ca.seg_ovf, &tref,
                                dev_n, STRIDE);
     c.time_end();
-    sffk::SettleArgs sa{};
-    sa.n = n; sa.Tb = d.temp_base; sa.nbcap = NBCAP; sa.stride = STRIDE; sa.n_trees = (int)trees.size();
-    sa.in_lim = d_lim; sa.rec_flags = ca.rec_flags; sa.rec_nnb = ca.rec_nnb; sa.rec_nb = ca.rec_nb;
-    sa.rec_meta = ca.rec_meta; sa.seg_ns = ca.seg_ns; sa.first_hit = ca.first_hit;
-    sa.pose_hit = d_pose;
-    sa.code = reinterpret_cast<uint8_t*>(dout + o_code);
-    sa.bulk = reinterpret_cast<unsigned long long*>(dout + o_ctrl + 16);
-    sa.dev_n = dev_n;
-    sa.fault = d.fault_pending.as<int32_t>();
-    sa.count_executed = 1;
-    sffk::launch_settle(c.stream, sa);
     sffk::ResolveArgs ra{};
     ra.f = V;
     ra.st = stm;
@@ -508,16 +517,19 @@ void Forest::dev_enqueue_wave(int first_round) {
     ra.newpos = d_pos;
     ra.pdist = d_pd;
     ra.parent = d.d_parent.as<int32_t>();
-    ra.code = sa.code;
+    ra.code = reinterpret_cast<uint8_t*>(dout + o_code);
+    ra.in_lim = d_lim;
+    ra.rec_flags = ca.rec_flags;
+    ra.pose_hit = d_pose;
     ra.rec_nnb = ca.rec_nnb;
     ra.rec_nb = ca.rec_nb;
     ra.rec_meta = ca.rec_meta;
     ra.seg_ns = ca.seg_ns;
     ra.first_hit = ca.first_hit;
-    ra.bulk = sa.bulk;
+    ra.bulk = reinterpret_cast<unsigned long long*>(dout + o_ctrl + 16);
     ra.round_ctrl = d_rctrl;
     ra.fault_pending = d.fault_pending.as<int32_t>();
-    sffk::launch_resolve(c.stream, ra);
+    sffk::launch_commit(c.stream, ra, n);
     c.timing_on = true;
     c.round_scope = false;
   }
@@ -601,6 +613,14 @@ void Forest::run_device(int max_waves) {
   }
   st.total_ms += ms_since(t0);
   st.host_ms += ms_since(t0) - wait_ms;
+  if (getenv("SFFGPU_PROFILE")) {
+    const sffk::DevCtrl& k = d.last;
+    const double r = (double)std::max<unsigned long long>(1ULL, k.prof[6]);
+    fprintf(stderr, "[sffgpu k_resolve us/commit] states %.1f fixed point %.1f (%.2f passes, max %llu) ranks %.1f borders %.1f "
+            "next list+counters %.1f | dependent/round %.0f\n", k.prof[0] / r / 100.0, k.prof[1] / r / 100.0, k.prof[5] / r,
+            (unsigned long long)k.prof[7], k.prof[2] / r / 100.0, k.prof[3] / r / 100.0, k.prof[4] / r / 100.0,
+            (double)k.n_unsettled / r);
+  }
 }
 
 }  // namespace sff

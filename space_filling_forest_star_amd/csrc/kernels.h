@@ -100,6 +100,11 @@ struct DevCtrl {
   int32_t terminated, solved, empty_frontier, fault;
   int32_t N0, iter0, n_borders, n_unsettled;
   int32_t fault_pending, redraws, grid_ovf, tgrid_ovf;
+  int32_t front_sel;        // which of the two frontier buffers is current
+  int32_t compact_from;     // entries of the other buffer k_frontier_compact has to sift (0 = nothing to do)
+  int32_t act_sel, act_cnt; // which of the two active-slot lists is current; its length (>= n_act: the still-failing slots)
+  int32_t app_n, app_N0, app_fn0, app_act_sel;   // the commit k_append has to apply (app_n = 0: none)
+  int32_t iter0_app, pad_app;
   unsigned long long cursor;        // engine words consumed so far
   unsigned long long words_base;    // cursor at which the current round's sample words start
   unsigned long long collide_calls, path_free_calls, nn_queries;          // reference-equivalent counters
@@ -107,7 +112,11 @@ struct DevCtrl {
   unsigned long long waves, rounds, round_nodes, round_queries;
   unsigned long long epoch;         // commit counter (border dedup stamps)
   unsigned long long work_items;    // (edge, chunk) items of all rounds
+  // k_resolve phase clocks (wall_clock64 ticks of 10 ns, thread 0): open list, fixed point, append, borders,
+  // counters + next active list; [5] = passes of the fixed point, [6] = commits, [7] = longest pass count
+  unsigned long long prof[8];
 };
+#define SFFK_DEV_MAX_GROUPS 1024   // single-workgroup list kernels: 64 x this many slots per wave at most
 #define SFFK_FAULT_LISTS 1        // a hit / neighbour / triangle-candidate list overflowed: redo the round on the host
 #define SFFK_FAULT_BORDER_TABLE 2 // the border hash table is full: the host grows it
 #define SFFK_FAULT_CAPACITY 4     // node / frontier / border arrays would overflow: the host grows them
@@ -115,7 +124,8 @@ struct DevCtrl {
 // indirections of the round kernels in device mode (ctrl == nullptr: host mode, everything comes as arguments)
 struct DevRound {
   const DevCtrl* ctrl;
-  const int32_t* act_slot;     // n_act slot indices (ascending)
+  const int32_t* act_slot;     // n_act slot indices (ascending): list 0 / list 1, DevCtrl::act_sel names the current one
+  const int32_t* act_slot2;
   const int32_t* slot_node;    // node expanded by each slot
   const uint8_t* nflag;        // per node: 1 = ForceChildren, 2 = on the frontier
   const uint64_t* ring;        // engine words (std::mt19937_64 outputs), ring of ring_mask + 1 words
@@ -241,8 +251,11 @@ struct DevForestView {
   DevCtrl* ctrl;
   // node records beside the store columns (store_view / NodeStoreMut)
   int32_t* parent; double* d_root; double* d_closest; uint32_t* iter; uint8_t* nflag;
-  int32_t* frontier; int32_t* closed; int32_t* claim;      // claim: per node scratch (INT_MAX between uses)
-  int32_t* slot_node; uint8_t* slot_fail; int32_t* act_slot;
+  int32_t* frontier; int32_t* frontier2;                   // two buffers: compaction sifts from one into the other
+  int32_t* closed; int32_t* claim;                         // claim: per node scratch (INT_MAX between uses)
+  unsigned long long* rm_words; int32_t* rm_pref;          // frontier positions removed by the wave (bit per entry)
+  int32_t* slot_node; int32_t* slot_pos;
+  int32_t* act_slot; int32_t* act_slot2;                   // the still-failing slots in slot order (two buffers)
   // borders: append-only list + open-addressing table of (n1, n2) keys with a commit stamp
   int32_t* b_n1; int32_t* b_n2; int32_t* b_ta; int32_t* b_tb; double* b_dist;
   unsigned long long* bt_key; unsigned long long* bt_val; unsigned long long bt_mask;
@@ -250,21 +263,30 @@ struct DevForestView {
   const uint64_t* ring; uint64_t ring_mask;
   int32_t node_cap, border_cap, wave, n_trees, words_per, threshold_misses, max_iterations, node_budget;
   int32_t temp_base;           // store index of the round's temporaries
-  uint8_t* ustate; int32_t* ulist; int32_t* uacc;   // k_resolve scratch: per sample state / unsettled list / accepted id
+  uint8_t* ustate; int32_t* ulist; int32_t* uacc;   // k_resolve scratch: per sample state / dependent list / accepted id
+  uint8_t* dk;                 // per sample: neighbour index where k_decide stopped (first round-mate / border event)
 };
+// per-sample verdicts of k_decide
+#define SFFK_DEPENDS 0     // the neighbour walk reached a sample of the same round first: k_resolve continues at dk
+#define SFFK_REJECTED 1
+#define SFFK_OUTSIDE 2
+#define SFFK_ACCEPT 3
+#define SFFK_REJECT_EVENT 4 // rejected by a free edge to another tree: border entry with neighbour dk
 struct ResolveArgs {
   DevForestView f;
   NodeStoreMut st;
   GridView g;
   int nbcap, stride;
-  const double* newpos; const double* pdist; const int32_t* parent; const uint8_t* code;
+  const double* newpos; const double* pdist; const int32_t* parent; uint8_t* code;
+  const uint8_t* in_lim; const int32_t* rec_flags; const uint8_t* pose_hit;
   const int32_t* rec_nnb; const int32_t* rec_nb; const int32_t* rec_meta; const int32_t* seg_ns; const int32_t* first_hit;
-  unsigned long long* bulk;    // counters of the samples k_settle settled (7 words)
-  const int32_t* round_ctrl;   // the round's 16-int scratch block ([2] = work items)
+  unsigned long long* bulk;    // counters of the samples k_decide decided (7 words)
+  const int32_t* round_ctrl;   // the round's scratch block ([2] = work items)
   int32_t* fault_pending;
 };
 void launch_wave_begin(hipStream_t s, const DevForestView& f);
-void launch_resolve(hipStream_t s, const ResolveArgs& a);
+// the commit of one round: k_decide (wide) -> k_resolve (one workgroup) -> k_append (wide); n_bound = launch bound
+void launch_commit(hipStream_t s, const ResolveArgs& a, int n_bound);
 void launch_wave_end(hipStream_t s, const DevForestView& f, const int32_t* grid_ovf, const int32_t* tgrid_ovf);
 // border table maintenance: re-insert list entries [0, n) after the host grew the table
 void launch_border_rehash(hipStream_t s, const DevForestView& f, int n);

@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void k_sample_steer(const uint64_t* __restrict
   double c[6], o[6];
   int par = 0;
   if (dv.ctrl) {
-    par = dv.slot_node[dv.act_slot[i]];
+    par = dv.slot_node[(dv.ctrl->act_sel ? dv.act_slot2 : dv.act_slot)[i]];
     dv.parent_out[i] = par;
     dv.force_out[i] = dv.nflag[par] & 1;
   } else if (!center_in) {
