@@ -211,7 +211,7 @@ def main():
         try:
             pm = json.load(open(PMC_SUMMARY))
             if pm.get("bench_args") == run_key:
-                k = pm.get("query_kernel", "sffk::k_grid_query")
+                k = pm.get("query_kernel", "sffk::k_query_classify")
                 traffic = 1024.0 * (2.0 * pm["FETCH_SIZE"][k]["avg_KiB_per_launch"] + pm["WRITE_SIZE"][k]["avg_KiB_per_launch"])
                 traffic_source = "profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; 2 x FETCH + WRITE (gfx950 correction of MI355X_MICROARCH.md)" % os.path.basename(PMC_SUMMARY)
                 k = "sffk::k_sweep"
@@ -251,9 +251,11 @@ def main():
                               "sample_kernel": s1["sample_ms"] - s0["sample_ms"],
                               "host_logic": s1["host_ms"] - s0["host_ms"]},
             "roofline": {
-                # neighbour query of one round, timed with HIP events on the library's launch stream (every 8th
-                # round).  Algorithmic bytes = 24 B x nodes the query has to cover.
-                "bound": "hbm", "kernel": "sffk::k_grid_query (node grid + the round's own grid)",
+                # neighbour query of one round (grid walk over the node grid and the round's own grid, exact fp64
+                # re-test, classification of the hits: one fused kernel), timed with HIP events on the library's
+                # launch stream (every 8th round).  Algorithmic bytes = 24 B x nodes the query has to cover
+                # (SURVEY.md 8(d)).
+                "bound": "hbm", "kernel": "sffk::k_query_classify (node grid + the round's own grid + hit classification)",
                 "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                 "traffic": traffic, "traffic_source": traffic_source,
                 "launches": int(sweeps), "avg_launch_us": 1e3 * sweep_ms / max(1, sweeps),

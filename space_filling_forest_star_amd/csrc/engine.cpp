@@ -159,7 +159,7 @@ Ctx::~Ctx() {
   for (auto e : pool) (void)hipEventDestroy(e);
   DevBuf* bufs[] = {&env_tri, &env_box, &env_plane, &rob_tri, &sx, &sy, &sz, &syaw, &spitch, &sroll, &stree, &spos,
                     &d_a, &d_b, &d_c, &d_d, &d_e, &d_f, &d_g, &d_h, &r_in, &r_out, &r_q, &r_cnt, &r_hidx,
-                    &r_hdist, &r_sega, &r_segb, &r_items, &r_items2, &env_clear, &g_cnt, &g_items, &g_ovfcnt, &g_ovf, &t_cnt, &t_items, &t_ovfcnt, &t_ovf};
+                    &r_hdist, &r_sega, &r_segb, &r_items, &r_items2, &env_clear, &g_cnt, &g_items, &g_ovfcnt, &g_ovf, &t_cnt, &t_items, &t_ovfcnt, &t_ovf, &t_occ};
   for (DevBuf* b : bufs) b->release();
   for (auto& b : level_box) b.release();
   PinBuf* pins[] = {&h_a, &h_b, &h_c, &h_d, &h_e, &h_f, &h_g, &h_h, &p_in, &p_out};
@@ -494,6 +494,9 @@ void Ctx::grid_setup(const double limits[6], double cell) {
   tgridv.items = t_items.as<sffk::GridItem>();
   tgridv.ovf_cnt = t_ovfcnt.as<int32_t>();
   tgridv.ovf = t_ovf.as<sffk::GridItem>();
+  t_occ.ensure((ncells / 32 + 2) * 4);
+  HIPCHK(hipMemsetAsync(t_occ.p, 0, (ncells / 32 + 2) * 4, stream));
+  tgridv.occ = t_occ.as<uint32_t>();
   grid_on = true;
   grid_inserted = 0;
 }

@@ -513,12 +513,6 @@ void Forest::round_begin() {
                             prm, d_pos, d_lim, d_pd, c.r_q.as<sffk::SweepQuery>(), Tb, tmp);
   c.time_end();
   // the sweep only serves the queries of this rank's shard (the others are marked inactive)
-  c.time_begin(T_SWEEP);
-  // permanent nodes through the grid (27 cells per query); the same walk over the round's own grid finds the
-  // EARLIER samples of this round
-  sffk::launch_grid_query(c.stream, c.gridv, &c.tgridv, c.store_view(), c.r_q.as<sffk::SweepQuery>(), d_pos, n,
-                          c.r_cnt.as<int32_t>(), c.r_hidx.as<int32_t>(), c.r_hdist.as<double>(), CAP);
-  c.time_end();
   st.sweeps += 1;
   st.sweep_nodes += (uint64_t)(N0 + n);
   st.sweep_queries += (uint64_t)((n - cfg.rank + cfg.world - 1) / cfg.world);
@@ -546,8 +540,12 @@ void Forest::round_begin() {
   ca.first_hit = reinterpret_cast<int32_t*>(dout + o_fh);
   ca.seg_ovf = reinterpret_cast<int32_t*>(dout + o_ovf);
   ca.ctrl = d_ctrl;
+  // neighbour query (27 grid cells per sample in the node grid, plus the round's own grid for the EARLIER samples of
+  // this round) and classification of the hits, one wavefront per sample
+  c.time_begin(T_SWEEP);
+  sffk::launch_query_classify(c.stream, c.gridv, &c.tgridv, c.store_view(), c.r_q.as<sffk::SweepQuery>(), ca);
+  c.time_end();
   c.time_begin(T_COLLIDE);
-  sffk::launch_classify(c.stream, ca);
   c.p_out.ensure(o_bytes);
   char* ho = c.p_out.as<char>();
   HIPCHK(hipEventRecord(c.ev_mid, c.stream));

@@ -471,10 +471,6 @@ void Forest::dev_enqueue_wave(int first_round) {
     sffk::launch_sample_steer(c.stream, nullptr, nullptr, c.spos.as<double>(), nullptr, n, cfg.sampling_dist, cfg.dim, prm,
                               d_pos, d_lim, d_pd, c.r_q.as<sffk::SweepQuery>(), d.temp_base, tmp, &dv);
     c.time_end();
-    c.time_begin(T_SWEEP);
-    sffk::launch_grid_query(c.stream, c.gridv, &c.tgridv, c.store_view(), c.r_q.as<sffk::SweepQuery>(), d_pos, n,
-                            c.r_cnt.as<int32_t>(), c.r_hidx.as<int32_t>(), c.r_hdist.as<double>(), CAP, dev_n);
-    c.time_end();
     sffk::ClassifyArgs ca{};
     ca.n = n; ca.N0 = d.temp_base; ca.cap = CAP; ca.nbcap = NBCAP; ca.rank = 0; ca.world = 1;
     ca.goal_id = -1;
@@ -500,8 +496,10 @@ void Forest::dev_enqueue_wave(int first_round) {
     ca.seg_ovf = reinterpret_cast<int32_t*>(dout + o_ovf);
     ca.ctrl = d_rctrl;
     ca.dev_n = dev_n;
+    c.time_begin(T_SWEEP);
+    sffk::launch_query_classify(c.stream, c.gridv, &c.tgridv, c.store_view(), c.r_q.as<sffk::SweepQuery>(), ca);
+    c.time_end();
     c.time_begin(T_COLLIDE);
-    sffk::launch_classify(c.stream, ca);
     sffk::TempGridRef tref{c.tgridv, c.sx.as<float>() + d.temp_base, c.sy.as<float>() + d.temp_base,
                            c.sz.as<float>() + d.temp_base, n};
     sffk::launch_round_collide(c.stream, c.envv, c.robv, d_pos, n, ca.rec_flags, d_pose, ca.seg_a, ca.seg_b, ca.seg_ns,

@@ -49,6 +49,8 @@ struct GridView {
   int32_t* ovf_cnt;   // [0] entries in the overflow list
   GridItem* ovf;
   int ovf_cap;
+  uint32_t* occ;      // optional occupancy bits (one per cell): the round's own grid is nearly empty, its 100 KB of
+                      // bits stay in L2 and spare the queries 27 scattered count loads
 };
 
 struct SampleParams {
@@ -202,6 +204,9 @@ struct ClassifyArgs {
   const int32_t* dev_n;     // device mode: {n, halt} (n above is then the launch bound only)
 };
 void launch_classify(hipStream_t s, const ClassifyArgs& a);
+// neighbour query + classification in one launch (one wavefront per sample): the hits never leave the wave
+void launch_query_classify(hipStream_t s, const GridView& g, const GridView* tg, const NodeStoreView& st,
+                           const SweepQuery* queries, const ClassifyArgs& a);
 struct SettleArgs {
   int n, Tb, nbcap, stride, n_trees;
   const uint8_t* in_lim;

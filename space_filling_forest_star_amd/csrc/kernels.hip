@@ -831,7 +831,11 @@ __global__ __launch_bounds__(256) void k_seg_compact(const int32_t* __restrict__
   if (tg.cnt) {   // housekeeping: the round's own grid has been read (k_grid_query), empty the cells it used
     for (int t = blockIdx.x * 256 + threadIdx.x; t < n_temps; t += gridDim.x * 256) {
       const float x = tx[t];
-      if (x == x) tg.cnt[grid_cell_of(tg, x, ty[t], tz[t])] = 0;
+      if (x == x) {
+        const size_t cell = grid_cell_of(tg, x, ty[t], tz[t]);
+        tg.cnt[cell] = 0;
+        if (tg.occ) tg.occ[cell >> 5] = 0u;   // (every set bit of the word belongs to a sample of this round)
+      }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) tg.ovf_cnt[0] = 0;
   }
@@ -1194,6 +1198,229 @@ __global__ __launch_bounds__(256) void k_classify(ClassifyArgs A) {
   }
 }
 
+// ------------------------------------------------------------------ neighbour query + classification, fused
+// One wavefront per sample.  Candidates: the items of the grid cells the query ball touches (27 for the planner's
+// radius), in the node grid and - where its occupancy bit is set - in the round's own grid, flattened over the
+// lanes (lane = candidate, not lane = cell, so that a cell with several items costs no extra step), fp32 superset
+// filter, exact fp64 re-test of the survivors.  The hits are compacted with __ballot into the wave's LDS slice
+// (no atomics, no hit list in HBM) and classified right away exactly like k_classify does.
+#define QC_WAVES 4
+__device__ __forceinline__ void qc_candidates(const GridView& g, int m, int cell, int lane, const SweepQuery& Q,
+                                              const double* qp, const NodeStoreView& st, int32_t* h_id, double* h_d,
+                                              int32_t* h_tree, int& nh) {
+  // exclusive prefix of the per-lane item counts
+  int inc = m;
+  for (int off = 1; off < 64; off <<= 1) {
+    const int o = __shfl_up(inc, off);
+    if (lane >= off) inc += o;
+  }
+  const int total = __shfl(inc, 63);
+  for (int base = 0; base < total; base += 64) {
+    const int j = base + lane;
+    bool hit = false;
+    double d = 0;
+    GridItem it;
+    it.id = 0; it.tree = 0;
+    // the lane whose cell holds candidate j: the first lane with inclusive prefix > j.  Every lane takes part in the
+    // shuffles (lanes beyond the list search for the last candidate), the loop always runs 6 steps.
+    const int jj = j < total ? j : total - 1;
+    int lo = 0, hi = 63;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (__shfl(inc, mid) > jj) hi = mid; else lo = mid + 1;
+    }
+    const int src_cell = __shfl(cell, lo);
+    const int slot = jj - (__shfl(inc, lo) - __shfl(m, lo));
+    if (j < total) {
+      it = g.items[(size_t)src_cell * g.bk + slot];
+      if (it.id < Q.max_id && (Q.tree < 0 || it.tree == Q.tree)) {
+        const float dx = it.x - Q.x, dy = it.y - Q.y, dz = it.z - Q.z;
+        const float d3 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+        if (d3 <= Q.r2f) {
+          const float da = wrapf(it.yaw - Q.yaw), db = wrapf(it.pitch - Q.pitch), dc = wrapf(it.roll - Q.roll);
+          const float d6 = fmaf(dc, dc, fmaf(db, db, fmaf(da, da, d3)));
+          if (d6 <= Q.r2f) {
+            double np[6];
+            for (int k = 0; k < 6; ++k) np[k] = st.pos[6 * (size_t)it.id + k];
+            d = dist6(np, qp);
+            hit = d < Q.r;
+          }
+        }
+      }
+    }
+    const unsigned long long hm = __ballot(hit);
+    if (hit) {
+      const int at = nh + __popcll(hm & ((1ULL << lane) - 1ULL));
+      if (at < 64) { h_id[at] = it.id; h_d[at] = d; h_tree[at] = it.tree; }
+    }
+    nh += __popcll(hm);
+  }
+}
+__device__ __forceinline__ void qc_overflow(const GridView& g, int no, int lane, const SweepQuery& Q, const double* qp,
+                                            const NodeStoreView& st, int32_t* h_id, double* h_d, int32_t* h_tree, int& nh) {
+  if (no > g.ovf_cap) no = g.ovf_cap;
+  for (int base = 0; base < no; base += 64) {
+    const int j = base + lane;
+    bool hit = false;
+    double d = 0;
+    GridItem it;
+    it.id = 0; it.tree = 0;
+    if (j < no) {
+      it = g.ovf[j];
+      if (it.id < Q.max_id && (Q.tree < 0 || it.tree == Q.tree)) {
+        const float dx = it.x - Q.x, dy = it.y - Q.y, dz = it.z - Q.z;
+        const float d3 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+        if (d3 <= Q.r2f) {
+          const float da = wrapf(it.yaw - Q.yaw), db = wrapf(it.pitch - Q.pitch), dc = wrapf(it.roll - Q.roll);
+          const float d6 = fmaf(dc, dc, fmaf(db, db, fmaf(da, da, d3)));
+          if (d6 <= Q.r2f) {
+            double np[6];
+            for (int k = 0; k < 6; ++k) np[k] = st.pos[6 * (size_t)it.id + k];
+            d = dist6(np, qp);
+            hit = d < Q.r;
+          }
+        }
+      }
+    }
+    const unsigned long long hm = __ballot(hit);
+    if (hit) {
+      const int at = nh + __popcll(hm & ((1ULL << lane) - 1ULL));
+      if (at < 64) { h_id[at] = it.id; h_d[at] = d; h_tree[at] = it.tree; }
+    }
+    nh += __popcll(hm);
+  }
+}
+
+__global__ __launch_bounds__(64 * QC_WAVES) void k_query_classify(GridView g, GridView tg, NodeStoreView st,
+                                                                  const SweepQuery* __restrict__ queries, ClassifyArgs A) {
+  __shared__ int32_t s_id[QC_WAVES][64];
+  __shared__ int32_t s_tree[QC_WAVES][64];
+  __shared__ double s_d[QC_WAVES][64];
+  if (A.dev_n) {
+    if (A.dev_n[1]) return;
+    A.n = A.dev_n[0];
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i = blockIdx.x * QC_WAVES + wave;
+  if (i >= A.n) return;
+  const int stride = 1 + A.nbcap;
+  // ---- everything the sample needs, loaded before the first store (a wave runs one long chain of dependent
+  // memory steps: independent loads are issued together, up front)
+  const bool inl = A.in_lim[i] != 0;
+  const int ex = A.parent[i];
+  const bool force = A.force[i] != 0;
+  const double pdist = A.pdist[i];
+  const SweepQuery Q = queries[i];
+  double qp[6], exp[6];
+  for (int k = 0; k < 6; ++k) qp[k] = A.newpos[6 * (size_t)i + k];
+  const int no_g = g.ovf_cnt[0];
+  const int no_t = tg.cnt ? tg.ovf_cnt[0] : 0;
+  const int mine = A.tree[ex];
+  for (int k = 0; k < 6; ++k) exp[k] = A.pos[6 * (size_t)ex + k];
+  int flags = 0, nnb = 0;
+  int used_slots = 0;                     // edge-task slots this sample fills (the others are cleared at the end)
+  const bool mine_shard = A.world <= 1 || i % A.world == A.rank;
+  if (inl && mine_shard) {
+    flags |= 1;
+    int32_t* h_id = s_id[wave];
+    int32_t* h_tree = s_tree[wave];
+    double* h_d = s_d[wave];
+    int nh = 0;
+    // ---- the cells the query ball's box touches
+    const float rf = sqrtf(Q.r2f) * 1.000001f;
+    const int lx = grid_coord(Q.x - rf, g.ox, g.inv_cell, g.nx), hx = grid_coord(Q.x + rf, g.ox, g.inv_cell, g.nx);
+    const int ly = grid_coord(Q.y - rf, g.oy, g.inv_cell, g.ny), hy = grid_coord(Q.y + rf, g.oy, g.inv_cell, g.ny);
+    const int lz = grid_coord(Q.z - rf, g.oz, g.inv_cell, g.nz), hz = grid_coord(Q.z + rf, g.oz, g.inv_cell, g.nz);
+    const int wx = hx - lx + 1, wy = hy - ly + 1, wz = hz - lz + 1;
+    const int total = wx * wy * wz;
+    for (int c0 = 0; c0 < total; c0 += 64) {
+      const int c = c0 + lane;
+      int cell = 0, m = 0, mt = 0;
+      if (c < total) {
+        const int cx = lx + c % wx, cy = ly + (c / wx) % wy, cz = lz + c / (wx * wy);
+        cell = (cz * g.ny + cy) * g.nx + cx;
+        m = g.cnt[cell];
+        if (m > g.bk) m = g.bk;
+        if (tg.cnt) {
+          const bool maybe = tg.occ ? ((tg.occ[cell >> 5] >> (cell & 31)) & 1u) != 0 : true;
+          if (maybe) { mt = tg.cnt[cell]; if (mt > tg.bk) mt = tg.bk; }
+        }
+      }
+      qc_candidates(g, m, cell, lane, Q, qp, st, h_id, h_d, h_tree, nh);
+      if (tg.cnt && __any(mt > 0)) qc_candidates(tg, mt, cell, lane, Q, qp, st, h_id, h_d, h_tree, nh);
+    }
+    if (no_g > 0) qc_overflow(g, no_g, lane, Q, qp, st, h_id, h_d, h_tree, nh);
+    if (no_t > 0) qc_overflow(tg, no_t, lane, Q, qp, st, h_id, h_d, h_tree, nh);
+    // ---- classification (k_classify's logic on the wave's own hit list)
+    const int cnt = nh;
+    if (cnt > A.cap) {
+      flags |= 2;
+    } else {
+      const bool have = lane < cnt;
+      const int id = have ? h_id[lane] : 0x7fffffff;
+      const double d = have ? h_d[lane] : 0.0;
+      const int t = have ? h_tree[lane] : 0x7fffffff;
+      const bool same = t == mine;
+      bool q = false;
+      if (have) q = same ? (!force && d < pdist - SFFG_TOL)          // src/forest.h:276
+                         : (d < A.dist_tree - SFFG_TOL);             // src/forest.h:283
+      int rank = 0;
+      for (int j = 0; j < cnt; ++j) {   // (lanes >= cnt hold no hit)
+        const int tj = __shfl(t, j), idj = __shfl(id, j), qj = __shfl((int)q, j);
+        const double dj = __shfl(d, j);
+        if (qj && (tj < t || (tj == t && (dj < d || (dj == d && idj < id))))) ++rank;
+      }
+      int cut = (q && !same && id < A.N0) ? rank : 0x7fffffff;
+      for (int off = 32; off > 0; off >>= 1) {
+        const int o = __shfl_xor(cut, off);
+        cut = o < cut ? o : cut;
+      }
+      const bool keep = q && rank <= cut;
+      const int nkeep = __popcll(__ballot(keep));
+      if (nkeep > A.nbcap) {
+        flags |= 2;   // the host path redoes this sample with unbounded lists
+      } else {
+        nnb = nkeep;
+        used_slots = 1 + nkeep;
+        if (keep) {
+          A.rec_nb[(size_t)i * A.nbcap + rank] = id;
+          A.rec_meta[(size_t)i * A.nbcap + rank] = (t << 1) | (same ? 1 : 0);
+          const size_t slot = (size_t)i * stride + 1 + rank;
+          double nbp[6], ea[6], eb[6];
+          for (int k = 0; k < 6; ++k) nbp[k] = A.pos[6 * (size_t)id + k];
+          if (same) { for (int k = 0; k < 6; ++k) { ea[k] = nbp[k]; eb[k] = qp[k]; } }                 // isPathFree(neighbour, newPoint) :276
+          else if (id == A.goal_id) { for (int k = 0; k < 6; ++k) { ea[k] = qp[k]; eb[k] = nbp[k]; } } // isPathFree(newPoint, goal) :287
+          else { for (int k = 0; k < 6; ++k) { ea[k] = exp[k]; eb[k] = nbp[k]; } }                     // isPathFree(expanded, neighbour) :288
+          double* sa = A.seg_a + 6 * slot;
+          double* sb = A.seg_b + 6 * slot;
+          for (int k = 0; k < 6; ++k) { sa[k] = ea[k]; sb[k] = eb[k]; }
+          A.seg_ns[slot] = edge_samples(edge_parts(ea, eb));   // the edge's sample count doubles as its "live" mark
+          A.first_hit[slot] = 0x7fffffff;
+          A.seg_ovf[slot] = 0;
+        }
+        if (lane == 0) {   // slot 0: isPathFree(expanded, newPoint)  (src/forest.h:246)
+          const size_t slot = (size_t)i * stride;
+          double* sa = A.seg_a + 6 * slot;
+          double* sb = A.seg_b + 6 * slot;
+          for (int k = 0; k < 6; ++k) { sa[k] = exp[k]; sb[k] = qp[k]; }
+          A.seg_ns[slot] = edge_samples(edge_parts(exp, qp));
+          A.first_hit[slot] = 0x7fffffff;
+          A.seg_ovf[slot] = 0;
+        }
+      }
+    }
+  }
+  for (int k = used_slots + lane; k < stride; k += 64) {   // the task slots this sample does not use
+    A.seg_ns[(size_t)i * stride + k] = -1;
+    A.first_hit[(size_t)i * stride + k] = 0x7fffffff;
+    A.seg_ovf[(size_t)i * stride + k] = 0;
+  }
+  if (lane == 0) {
+    A.rec_flags[i] = flags;
+    A.rec_nnb[i] = nnb;
+  }
+}
+
 // Samples whose fate needs no in-order replay (src/forest.h:246-299): rejected by their own pose or parent-edge
 // check, or by a STORE neighbour when no sample of this round appears anywhere in their neighbour list, and
 // without side effect (no border entry).  code: 0 = replay on the host, 1 = settled, 2 = outside the limits.
@@ -1395,6 +1622,14 @@ void launch_clear_build(hipStream_t s, const EnvView& env, double thr, uint32_t*
 void launch_settle(hipStream_t s, const SettleArgs& a) {
   if (a.n <= 0) return;
   hipLaunchKernelGGL(k_settle, dim3((a.n + 255) / 256), dim3(256), 0, s, a);
+}
+
+void launch_query_classify(hipStream_t s, const GridView& g, const GridView* tg, const NodeStoreView& st,
+                           const SweepQuery* queries, const ClassifyArgs& a) {
+  if (a.n <= 0) return;
+  GridView none{};
+  hipLaunchKernelGGL(k_query_classify, dim3((a.n + QC_WAVES - 1) / QC_WAVES), dim3(64 * QC_WAVES), 0, s, g, tg ? *tg : none, st,
+                     queries, a);
 }
 
 void launch_classify(hipStream_t s, const ClassifyArgs& a) {

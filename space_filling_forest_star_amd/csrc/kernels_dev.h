@@ -20,6 +20,7 @@ __device__ __forceinline__ size_t grid_cell_of(const GridView& g, float x, float
 __device__ __forceinline__ void grid_put(const GridView& g, const GridItem& it) {
   const size_t cell = grid_cell_of(g, it.x, it.y, it.z);
   const int slot = atomicAdd(g.cnt + cell, 1);
+  if (g.occ) atomicOr(g.occ + (cell >> 5), 1u << (cell & 31));
   if (slot < g.bk) {
     g.items[cell * g.bk + slot] = it;
   } else {
