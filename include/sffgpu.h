@@ -103,6 +103,11 @@ typedef struct {
   int32_t world;            /* ... out of `world` shards (1 = single GPU) */
   double priority_bias;     /* Problem::priorityBias: != 0 selects frontier nodes through the priority heaps of
                                src/heap.h (best node with this probability, a random one otherwise; src/forest.h:126-147) */
+  int32_t libm_sampling;    /* 1 = parity mode: RandGen::randomPointInDistance (src/randGen.h:70-109) is evaluated on the
+                               host with the C library's cos / sin / acos - the reference's own arithmetic - and the
+                               samples are uploaded; 0 = sampled on the GPU with the portable trig of csrc/sff_pmath.h
+                               (<= 1 ulp from glibc).  Slower (host engine, one extra upload per round); for parity runs. */
+  int32_t reserved_;
 } sffgpu_forest_cfg;
 
 typedef struct {

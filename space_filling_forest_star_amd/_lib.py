@@ -37,7 +37,7 @@ class ForestCfg(C.Structure):
                 ("limits", C.c_double * 6), ("dist_tree", C.c_double), ("sampling_dist", C.c_double),
                 ("threshold_misses", C.c_int32), ("max_iterations", C.c_int32), ("node_budget", C.c_int32),
                 ("wave", C.c_int32), ("seed", C.c_uint64), ("rank", C.c_int32), ("world", C.c_int32),
-                ("priority_bias", C.c_double)]
+                ("priority_bias", C.c_double), ("libm_sampling", C.c_int32), ("reserved_", C.c_int32)]
 
 
 class ForestStats(C.Structure):
@@ -271,10 +271,11 @@ class Forest:
 
     def __init__(self, ctx, roots, limits, dist_tree, sampling_dist, dim=6, optimize=False, goal=None,
                  threshold_misses=5, max_iterations=100000, node_budget=0, wave=1, seed=1, rank=0, world=1,
-                 priority_bias=0.0):
+                 priority_bias=0.0, libm_sampling=False):
         self.ctx = ctx
         cfg = ForestCfg()
         cfg.priority_bias = priority_bias
+        cfg.libm_sampling = int(libm_sampling)
         cfg.dim = dim
         cfg.optimize = int(optimize)
         cfg.has_goal = int(goal is not None)

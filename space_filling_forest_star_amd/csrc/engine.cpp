@@ -778,6 +778,46 @@ void Ctx::knn(const double* q6, int nq, int k, const int32_t* tree, const int32_
               int32_t* cnt) {
   if (nq <= 0 || k <= 0) return;
   HIPCHK(hipSetDevice(device));
+  if (k <= 64) {
+    // device top-k: one wavefront per query keeps its k best in registers while it streams the store (k_knn_linear)
+    h_a.ensure((size_t)nq * sizeof(sffk::KnnQuery));
+    sffk::KnnQuery* hq = h_a.as<sffk::KnnQuery>();
+    for (int i = 0; i < nq; ++i) {
+      memcpy(hq[i].pos, q6 + 6 * (size_t)i, sizeof hq[i].pos);
+      hq[i].tree = tree ? tree[i] : -1;
+      hq[i].max_id = max_id ? max_id[i] : std::numeric_limits<int32_t>::max();
+      hq[i].k = k;
+      hq[i].mate_base = std::numeric_limits<int32_t>::max();
+      hq[i].whole_tree = 0;
+      hq[i].pad_ = 0;
+    }
+    d_a.ensure((size_t)nq * sizeof(sffk::KnnQuery));
+    d_b.ensure((size_t)nq * k * 4);
+    d_c.ensure((size_t)nq * k * 8);
+    d_d.ensure((size_t)nq * 4);
+    HIPCHK(hipMemcpyAsync(d_a.p, h_a.p, (size_t)nq * sizeof(sffk::KnnQuery), hipMemcpyHostToDevice, stream));
+    time_begin(T_SWEEP);
+    sffk::launch_knn_linear(stream, store_view(), store_n, d_a.as<sffk::KnnQuery>(), nq, k, d_b.as<int32_t>(),
+                            d_c.as<double>(), d_d.as<int32_t>(), sweep_eps());
+    time_end();
+    h_b.ensure((size_t)nq * k * 4);
+    h_c.ensure((size_t)nq * k * 8);
+    h_d.ensure((size_t)nq * 4);
+    HIPCHK(hipMemcpyAsync(h_b.p, d_b.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipMemcpyAsync(h_c.p, d_c.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipMemcpyAsync(h_d.p, d_d.p, (size_t)nq * 4, hipMemcpyDeviceToHost, stream));
+    sync();
+    for (int i = 0; i < nq; ++i) {
+      const int m = h_d.as<int32_t>()[i];
+      cnt[i] = m;
+      for (int j = 0; j < m; ++j) {
+        idx[(size_t)i * k + j] = h_b.as<int32_t>()[(size_t)i * k + j];
+        if (dist) dist[(size_t)i * k + j] = h_c.as<double>()[(size_t)i * k + j];
+      }
+    }
+    return;
+  }
+  // k > 64: adaptive-radius sweeps (grow while fewer than k are inside, shrink when the hit list overflows)
   const int cap = std::max(4 * k, 256);
   // initial guess: radius of a ball expected to hold ~2k nodes at uniform density
   double ext = std::max(store_maxabs, 1.0) * 2.0;
@@ -809,6 +849,8 @@ void Ctx::knn(const double* q6, int nq, int k, const int32_t* tree, const int32_
       }
     }
   }
+  for (int i = 0; i < nq; ++i)
+    if (active[i]) throw HipError{"knn: the radius search did not converge (more than 4k nodes at one distance?)"};
   for (int i = 0; i < nq; ++i) {
     cnt[i] = found[i];
     for (int j = 0; j < found[i]; ++j) {

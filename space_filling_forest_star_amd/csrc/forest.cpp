@@ -115,7 +115,7 @@ Forest::Forest(Ctx* c, const sffgpu_forest_cfg& cf, const double* roots6, int n_
       // the host replay below otherwise (SFF*, goal / priority modes, sharded runs, tiny waves)
     const char* e = getenv("SFFGPU_ENGINE");
     const std::string want = e ? e : "";
-    dev.on = device_eligible() && want != "host" && (cfg.wave >= 256 || want == "device") &&
+    dev.on = device_eligible() && !cfg.libm_sampling && want != "host" && (cfg.wave >= 256 || want == "device") &&
              cfg.wave <= 64 * SFFK_DEV_MAX_GROUPS;
   }
   // (device engine: a wave of new nodes past the budget plus the round's temporaries behind them)
@@ -395,6 +395,33 @@ void Forest::end_wave() {
 // ---------------------------------------------------------------------------------------
 static const int32_t REC_MAGIC = 0x53464652;  // "SFFR"
 
+// RandGen::randomPointInDistance (src/randGen.h:70-109) with the C library's trig: the same expressions, in the same
+// order, as sffg::sample_point (csrc/sff_geom.h) - which the kernels evaluate with the portable trig - so that the two
+// differ exactly where glibc and sff_pmath.h differ (<= 1 ulp).  Parity mode only (cfg.libm_sampling).
+static void sample_point_libm(const uint64_t* w, const double* center, double dist, int dim, double* out) {
+  const double phi = sffg::uniform_real(w[0], -SFFG_PI, SFFG_PI);
+  if (dim == 2) {
+    out[0] = center[0] + std::cos(phi) * dist;
+    out[1] = center[1] + std::sin(phi) * dist;
+    out[2] = 0; out[3] = 0; out[4] = 0; out[5] = 0;
+    return;
+  }
+  double temp[6];
+  const double theta = sffg::uniform_real(w[1], -SFFG_PI, SFFG_PI);
+  const double sphi = std::sin(phi);
+  temp[0] = center[0] + std::cos(theta) * sphi * dist;
+  temp[1] = center[1] + std::sin(theta) * sphi * dist;
+  temp[2] = center[2] + std::cos(phi) * dist;
+  temp[3] = sffg::uniform_real(w[2], -SFFG_PI, SFFG_PI);
+  double pitch = std::acos(1 - 2 * sffg::uniform_real(w[3], 0.0, 1.0)) + SFFG_PI_2;
+  if (sffg::uniform_real(w[4], 0.0, 1.0) < 0.5) {
+    if (pitch < 0) pitch += SFFG_PI; else pitch -= SFFG_PI;
+  }
+  temp[4] = pitch;
+  temp[5] = sffg::uniform_real(w[5], -SFFG_PI, SFFG_PI);
+  sffg::steer(center, temp, dist, out);
+}
+
 void Forest::round_begin() {
   Ctx& c = *ctx;
   HIPCHK(hipSetDevice(c.device));
@@ -445,7 +472,8 @@ void Forest::round_begin() {
   const int CAP = hit_cap, NBCAP = nb_cap, STRIDE = 1 + NBCAP;
   // packed host input: words (n*6 u64) | parent (n i32) | force (n u8)
   const size_t in_words = 0, in_parent = (size_t)n * 48, in_force = in_parent + (size_t)n * 4;
-  const size_t in_bytes = ((in_force + (size_t)n + 15) / 16) * 16;
+  const size_t in_preset = ((in_force + (size_t)n + 15) / 16) * 16;   // (libm parity mode: n x 6 sample positions)
+  const size_t in_bytes = in_preset + (cfg.libm_sampling ? (size_t)n * 48 : 0);
   c.p_in.ensure(in_bytes);
   c.r_in.ensure(in_bytes);
   {
@@ -458,6 +486,11 @@ void Forest::round_begin() {
         for (int k = 0; k < 6; ++k) hw[6 * (size_t)i + k] = k < words_per ? rng.next() : 0;
       hp[i] = cands[i].expanded;
       hf[i] = nflag[cands[i].expanded] & 1;
+    }
+    if (cfg.libm_sampling) {
+      double* hs = reinterpret_cast<double*>(c.p_in.as<char>() + in_preset);
+      for (int i = 0; i < n; ++i)
+        sample_point_libm(hw + 6 * (size_t)i, nodes[cands[i].expanded].pos, cfg.sampling_dist, cfg.dim, hs + 6 * (size_t)i);
     }
   }
   c.timing_on = c.timer_stride <= 1 || st.sweeps % (uint64_t)c.timer_stride == 0;
@@ -508,6 +541,7 @@ void Forest::round_begin() {
   tmp.ctrl = d_ctrl;
   tmp.n_perm = N0;
   tmp.base = Tb;
+  tmp.preset = cfg.libm_sampling ? reinterpret_cast<const double*>(c.r_in.as<char>() + in_preset) : nullptr;
   c.time_begin(T_SAMPLE);
   sffk::launch_sample_steer(c.stream, d_words, d_parent, c.spos.as<double>(), nullptr, n, cfg.sampling_dist, cfg.dim,
                             prm, d_pos, d_lim, d_pd, c.r_q.as<sffk::SweepQuery>(), Tb, tmp);
@@ -557,8 +591,13 @@ void Forest::round_begin() {
   c.r_items.ensure((size_t)list_cap * SFFK_ITEM_BYTES);
   c.r_items2.ensure(((size_t)list_cap + (1u << 20)) * 8);   // (+ one window of the exact kernel, see mask_slot)
   sffk::TempGridRef tref{c.tgridv, c.sx.as<float>() + Tb, c.sy.as<float>() + Tb, c.sz.as<float>() + Tb, n};
+  // (SFF*: the k-nearest stage below still reads the round's own grid; it is emptied after that)
+  sffk::TempGridRef tref_keep = tref;
+  tref_keep.tg = sffk::GridView{};
+  tref_keep.n = 0;
   sffk::launch_round_collide(c.stream, c.envv, c.robv, d_pos, n, ca.rec_flags, d_pose, ca.seg_a, ca.seg_b, ca.seg_ns,
-                             n * STRIDE, ca.ctrl, c.r_items.p, list_cap, c.r_items2.p, ca.first_hit, ca.seg_ovf, &tref);
+                             n * STRIDE, ca.ctrl, c.r_items.p, list_cap, c.r_items2.p, ca.first_hit, ca.seg_ovf,
+                             cfg.optimize ? &tref_keep : &tref);
   c.time_end();
   // samples this rank can settle alone need no replay (with a goal the replay may stop in the middle of the
   // round, so there every sample stays in it)
@@ -828,84 +867,75 @@ void Forest::round_begin() {
     const int m = (int)maybe.size();
     if (m) {
       auto t0 = Clock::now();
-      const int KCAP = 256;
-      std::vector<double> q6((size_t)m * 6), r(m, knn_r), lo(m, 0.0), hi(m, -1.0);
-      std::vector<int32_t> qtree(m), qmax(m), kmax(m);
-      std::vector<uint8_t> active(m, 1);
-      std::vector<std::vector<HitRec>> lists(m);
+      // k-nearest sets on the device (k_knn_grid): per sample one wavefront grows a cube of grid cells until its k-th
+      // nearest STORE node of the tree lies inside the covered ball, keeping the k best in its lanes; the round's own
+      // samples (ids >= Tb, earlier in the round) that are not farther than that k-th node come from the round grid.
+      auto ts0 = Clock::now();
+      const int KCAP = 64;
+      c.h_f.ensure((size_t)m * sizeof(sffk::KnnQuery));
+      sffk::KnnQuery* hq = c.h_f.as<sffk::KnnQuery>();
+      std::vector<int32_t> kmax(m);
       for (int k = 0; k < m; ++k) {
         const Cand& cd = cands[maybe[k]];
-        memcpy(&q6[6 * (size_t)k], cd.pos, 6 * sizeof(double));
-        qtree[k] = nodes[cd.expanded].tree;
-        qmax[k] = Tb + maybe[k];
+        memcpy(hq[k].pos, cd.pos, sizeof hq[k].pos);
+        hq[k].tree = nodes[cd.expanded].tree;
+        hq[k].max_id = Tb + maybe[k];
         // k = 2e log10(#nodes) (:309) can only grow with the nodes accepted earlier in this round
         kmax[k] = (int32_t)(size_t)(2 * M_E * std::log10((double)(N0 + maybe[k])));
-        if (kmax[k] <= 0) active[k] = 0;
-        if ((int)trees[qtree[k]].size() <= kmax[k]) r[k] = 1e30;   // the whole tree is wanted
+        if (kmax[k] > KCAP) throw HipError{"forest: k of the k-nearest set exceeds 64"};
+        // (a tree with fewer nodes than that is wanted whole: asking for exactly its size lets the search stop as
+        // soon as the last of them is found instead of growing the cube over the whole grid)
+        hq[k].k = std::max(0, std::min<int>(kmax[k], (int)trees[hq[k].tree].size()));
+        hq[k].mate_base = Tb;
+        hq[k].whole_tree = (int)trees[hq[k].tree].size() <= kmax[k] ? 1 : 0;
       }
-      const double RMAX = 1e30;
-      auto ts0 = Clock::now();
-      std::vector<int32_t> cnt;
-      std::vector<std::vector<HitRec>>& out = knn_out;   // (member: the lists keep their capacity across rounds)
-      for (int it = 0; it < 200; ++it) {
-        bool any = false;
-        for (int k = 0; k < m; ++k) any |= active[k] != 0;
-        if (!any) break;
-        c.sweep_lists(q6.data(), m, r, qtree.data(), qmax.data(), active, KCAP, Tb + n, cnt, out, /*sort_lists=*/false);
-        g_star[3] += 1;
-        st.sweeps += 1;
-        st.sweep_nodes += (uint64_t)(N0 + n);
+      const size_t q_b = (size_t)m * sizeof(sffk::KnnQuery);
+      const size_t o_idx = 0, o_cnt = o_idx + (size_t)m * KCAP * 4, o_mate = o_cnt + (size_t)m * 4,
+                   o_mcnt = o_mate + (size_t)m * SFFK_KNN_MATES * 4, o_end = o_mcnt + (size_t)m * 4;
+      c.d_f.ensure(q_b);
+      c.d_g.ensure(o_end);
+      c.d_h.ensure((size_t)m * KCAP * 8);
+      c.h_g.ensure(o_end);
+      HIPCHK(hipMemcpyAsync(c.d_f.p, c.h_f.p, q_b, hipMemcpyHostToDevice, c.stream));
+      char* dres = c.d_g.as<char>();
+      c.time_begin(T_SWEEP);
+      sffk::launch_knn_grid(c.stream, c.gridv, &c.tgridv, c.store_view(), c.d_f.as<sffk::KnnQuery>(), m, KCAP,
+                            reinterpret_cast<int32_t*>(dres + o_idx), c.d_h.as<double>(), reinterpret_cast<int32_t*>(dres + o_cnt),
+                            reinterpret_cast<int32_t*>(dres + o_mate), reinterpret_cast<int32_t*>(dres + o_mcnt), c.grid_cell,
+                            8 * c.sweep_eps());
+      c.time_end();
+      HIPCHK(hipMemcpyAsync(c.h_g.p, c.d_g.p, o_end, hipMemcpyDeviceToHost, c.stream));
+      timed_sync();
+      g_star[3] += 1;
+      st.sweeps += 1;
+      st.sweep_nodes += (uint64_t)(N0 + n);
+      st.sweep_queries += (uint64_t)m;
+      g_star[0] += ms_since(ts0);
+      auto ts1 = Clock::now();
+      {
+        const char* hres = c.h_g.as<char>();
+        const int32_t* r_idx = reinterpret_cast<const int32_t*>(hres + o_idx);
+        const int32_t* r_cnt = reinterpret_cast<const int32_t*>(hres + o_cnt);
+        const int32_t* r_mate = reinterpret_cast<const int32_t*>(hres + o_mate);
+        const int32_t* r_mcnt = reinterpret_cast<const int32_t*>(hres + o_mcnt);
         for (int k = 0; k < m; ++k) {
-          if (!active[k]) continue;
-          st.sweep_queries += 1;
-          if (cnt[k] > KCAP) { hi[k] = r[k]; r[k] = 0.5 * (lo[k] + hi[k]); continue; }
-          int store_hits = 0;
-          for (const HitRec& h : out[k]) store_hits += h.id < N0;
-          // complete when kmax store nodes are inside, or the whole tree already is (small trees)
-          if (store_hits >= kmax[k] || store_hits >= (int)trees[qtree[k]].size() || r[k] >= RMAX) {
-            lists[k].swap(out[k]);
-            active[k] = 0;
-          } else {
-            lo[k] = r[k];
-            r[k] = hi[k] > 0 ? 0.5 * (lo[k] + hi[k]) : std::min(RMAX, r[k] * 2.0);
+          Cand& cd = cands[maybe[k]];
+          if (kmax[k] <= 0) continue;
+          if (r_mcnt[k] > SFFK_KNN_MATES) throw HipError{"forest: more than 64 samples of one round inside a k-nearest ball"};
+          for (int q = 0; q < r_cnt[k]; ++q) {
+            Member mb;
+            mb.id = r_idx[(size_t)k * KCAP + q];
+            cd.members.push_back(mb);
+            cd.has_members = true;
+          }
+          for (int q = 0; q < r_mcnt[k]; ++q) {
+            Member mb;
+            mb.id = -1 - (r_mate[(size_t)k * SFFK_KNN_MATES + q] - Tb);
+            cd.members.push_back(mb);
+            cd.has_members = true;
           }
         }
       }
-      g_star[0] += ms_since(ts0);
-      auto ts1 = Clock::now();
-      double rsum = 0;
-      int rcount = 0;
-      for (int k = 0; k < m; ++k) {
-        Cand& cd = cands[maybe[k]];
-        if (kmax[k] <= 0) continue;
-        // store members: the kmax nearest; wave-mates: closer than the kmax-th store member.  (The lists come
-        // unsorted; only the kmax-th smallest has to be found, the replay orders the members itself.)
-        std::vector<HitRec>& L = lists[k];
-        auto mid = std::partition(L.begin(), L.end(), [&](const HitRec& h) { return h.id < N0; });
-        const size_t n_store_hits = (size_t)(mid - L.begin());
-        size_t take = n_store_hits;
-        double dk = std::numeric_limits<double>::infinity();
-        if (n_store_hits >= (size_t)kmax[k]) {
-          take = (size_t)kmax[k];
-          std::nth_element(L.begin(), L.begin() + (take - 1), mid);
-          dk = L[take - 1].d;
-        }
-        for (size_t q = 0; q < take; ++q) {
-          Member mb;
-          mb.id = L[q].id;
-          cd.members.push_back(mb);
-          cd.has_members = true;
-        }
-        for (auto it = mid; it != L.end(); ++it) {
-          if (it->id < Tb || !(it->d <= dk)) continue;
-          Member mb;
-          mb.id = -1 - (it->id - Tb);
-          cd.members.push_back(mb);
-          cd.has_members = true;
-        }
-        if (dk < 1e29) { rsum += dk; ++rcount; }
-      }
-      if (rcount) knn_r = 1.5 * rsum / rcount;   // (generous: most queries then finish in one pass; the lists are trimmed by nth_element)
       // both directions of every member edge, as pairs of store ids (the sample itself is the temporary store
       // entry Tb + i, a round-mate Tb + its index): the device gathers the positions
       std::vector<int32_t>& ia = edge_ia;
@@ -943,6 +973,7 @@ void Forest::round_begin() {
     }
   }
 
+  if (cfg.optimize) sffk::launch_tgrid_clear(c.stream, tref);
   auto _t3 = Clock::now();
   // ---- samples whose fate this rank settled alone (k_settle): only their reference-equivalent counters travel;
   // the in-order replay skips them

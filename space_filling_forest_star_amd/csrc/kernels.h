@@ -146,6 +146,8 @@ struct RoundTemps {
   int32_t* ctrl;   // 16 ints zeroed per round (see launch_collide_segments_dyn)
   int n_perm;      // permanent nodes in the store
   int base;        // 4-aligned index of the first temporary (>= n_perm)
+  const double* preset;   // optional n x 6: sample positions computed by the caller (libm parity mode); the kernel
+                          // then only applies the limits test and does its bookkeeping
 };
 
 size_t collide_lds_bytes(int n_robot_tri, int waves);
@@ -171,6 +173,32 @@ void launch_grid_query(hipStream_t s, const GridView& g, const GridView* tg, con
                        const SweepQuery* queries, const double* qpos, int nq, int32_t* cnt, int32_t* hit_idx,
                        double* hit_dist, int cap, const int32_t* dev_n = nullptr);
 void launch_set_tree(hipStream_t s, int32_t* tree_col, const int32_t* ids, int n, int32_t value);
+
+// ---- exact k nearest (replaces flann::Index::knnSearch: src/forest.h:317, src/rrt.h:143,166,228)
+// One wavefront per query keeps the k best (distance, id) pairs it has seen in its lanes (lane j = j-th nearest,
+// k <= 64): a batch of 64 candidates is compared with the current k-th distance, the few that beat it are inserted by
+// rank (__ballot / __popcll / __shfl_up) - no sort, no atomics, nothing spilled to memory before the end.
+struct KnnQuery {
+  double pos[6];
+  int32_t tree;       // only nodes of this tree (-1 = all)
+  int32_t max_id;     // only node ids < max_id
+  int32_t k;          // <= 64
+  int32_t mate_base;  // grid variant: ids >= mate_base are the round's temporaries, reported separately (below); INT_MAX = none
+  int32_t whole_tree; // grid variant: k is the size of the whole tree: every temporary of the tree counts as a mate
+  int32_t pad_;
+};
+#define SFFK_KNN_MATES 64
+// linear variant: every store entry [0, n_store) is a candidate (coalesced column reads, fp32 pre-filter against the
+// current k-th distance, exact fp64 distance for what passes).  idx / dist: nq x kcap, cnt: nq.
+void launch_knn_linear(hipStream_t s, const NodeStoreView& st, int n_store, const KnnQuery* q, int nq, int kcap,
+                       int32_t* idx, double* dist, int32_t* cnt, double abs_eps);
+// grid variant (forest engines): cubes of cells around the query grow ring by ring until the k-th distance lies
+// inside the covered ball.  Besides the k nearest STORE nodes it reports the round's temporaries (ids in
+// [mate_base, max_id)) that are not farther than the k-th store node: mate_idx nq x SFFK_KNN_MATES, mate_cnt nq
+// (> SFFK_KNN_MATES = overflow).
+void launch_knn_grid(hipStream_t s, const GridView& g, const GridView* tg, const NodeStoreView& st, const KnnQuery* q, int nq,
+                     int kcap, int32_t* idx, double* dist, int32_t* cnt, int32_t* mate_idx, int32_t* mate_cnt, double cell,
+                     double slack);
 
 // explicit_rt: pos6 holds n x 12 doubles (row-major rotation + translation) instead of n x 6 pose parameters
 void launch_collide_poses(hipStream_t s, const EnvView& env, const RobotView& rob, const double* pos6, int n,
@@ -245,6 +273,8 @@ struct TempGridRef {   // the round's own grid + the fp32 coordinates of its n s
   const float *x, *y, *z;
   int n;
 };
+// empties the cells (and occupancy bits) the round's n samples used in the round's own grid
+void launch_tgrid_clear(hipStream_t s, const TempGridRef& t);
 void launch_round_collide(hipStream_t s, const EnvView& env, const RobotView& rob, const double* pos6, int n_pose,
                           const int32_t* live_flags, uint8_t* pose_hit, const double* a6, const double* b6,
                           const int32_t* seg_ns, int n_slots, int32_t* ctrl, void* list, int list_cap, void* masks,

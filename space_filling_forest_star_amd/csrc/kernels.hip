@@ -74,7 +74,13 @@ __global__ __launch_bounds__(256) void k_sample_steer(const uint64_t* __restrict
   } else {
     for (int k = 0; k < 6; ++k) w[k] = words[6 * (size_t)i + k];
   }
-  bool ok = sample_point(w, c, dist, dim, prm.limits, o);
+  bool ok;
+  if (tmp.preset) {
+    for (int k = 0; k < 6; ++k) o[k] = tmp.preset[6 * (size_t)i + k];
+    ok = in_limits(o, prm.limits);
+  } else {
+    ok = sample_point(w, c, dist, dim, prm.limits, o);
+  }
   for (int k = 0; k < 6; ++k) out6[6 * (size_t)i + k] = o[k];
   in_lim[i] = ok ? 1 : 0;
   if (tmp.cnt) {
@@ -295,6 +301,263 @@ __global__ __launch_bounds__(256) void k_grid_query(GridView g, GridView tg, Nod
   const float rf = sqrtf(Q.r2f) * 1.000001f;
   grid_walk<true>(g, Q, q, lane, rf, st, qpos, cnt, hit_idx, hit_dist, cap);
   if (tg.cnt) grid_walk<false>(tg, Q, q, lane, rf, st, qpos, cnt, hit_idx, hit_dist, cap);
+}
+
+// ------------------------------------------------------------------ exact k nearest
+// The wave's k best so far: lane j holds the j-th smallest (distance, id) key; lanes >= have hold +inf.
+struct TopK {
+  double d;
+  int id;
+};
+__device__ __forceinline__ bool key_less(double da, int ia, double db, int ib) { return da < db || (da == db && ia < ib); }
+// inserts the candidates flagged in `take` (one per lane: cd, cid), smallest lanes first; k = capacity, have = filled
+__device__ __forceinline__ void topk_insert(TopK& t, int lane, int k, int& have, unsigned long long take, double cd, int cid) {
+  while (take) {
+    const int src = __ffsll((long long)take) - 1;
+    take &= take - 1;
+    const double nd = __shfl(cd, src);
+    const int ni = __shfl(cid, src);
+    // rank of the newcomer = entries that sort before it
+    const bool before = lane < have && key_less(t.d, t.id, nd, ni);
+    const int rank = __popcll(__ballot(before));
+    if (rank >= k) continue;                       // (beaten by k entries that arrived in the meantime)
+    const double pd = __shfl_up(t.d, 1);
+    const int pi = __shfl_up(t.id, 1);
+    if (lane > rank) { t.d = pd; t.id = pi; }
+    else if (lane == rank) { t.d = nd; t.id = ni; }
+    if (have < k) ++have;
+  }
+}
+__device__ __forceinline__ double topk_worst(const TopK& t, int k, int have) {   // current k-th distance (inf while not full)
+  return have < k ? 1.0e300 : __shfl(t.d, k - 1);
+}
+
+__global__ __launch_bounds__(256) void k_knn_linear(NodeStoreView st, int n_store, const KnnQuery* __restrict__ queries, int nq,
+                                                    int kcap, int32_t* __restrict__ idx, double* __restrict__ dist,
+                                                    int32_t* __restrict__ cnt, double abs_eps) {
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (q >= nq) return;
+  const KnnQuery Q = queries[q];
+  const int k = Q.k < 64 ? Q.k : 64;
+  const float qx = (float)Q.pos[0], qy = (float)Q.pos[1], qz = (float)Q.pos[2];
+  const float qa = (float)Q.pos[3], qb = (float)Q.pos[4], qc = (float)Q.pos[5];
+  TopK t{1.0e300, 0x7fffffff};
+  int have = 0;
+  const int lim = n_store < Q.max_id ? n_store : Q.max_id;
+  for (int base = 0; base < lim; base += 64) {
+    const int id = base + lane;
+    // fp32 superset filter against the current k-th distance (slack: a few fp32 ulps of the coordinates)
+    const double worst = topk_worst(t, k, have);
+    bool cand = false;
+    if (id < lim) {
+      const float dx = st.x[id] - qx, dy = st.y[id] - qy, dz = st.z[id] - qz;
+      const float da = wrapf(st.yaw[id] - qa), db = wrapf(st.pitch[id] - qb), dc = wrapf(st.roll[id] - qc);
+      const float d6 = fmaf(dc, dc, fmaf(db, db, fmaf(da, da, fmaf(dz, dz, fmaf(dy, dy, dx * dx)))));
+      if (d6 == d6) {                                 // (NaN placeholders never match)
+        const double wi = (worst + abs_eps) * (1.0 + 1e-5);
+        cand = worst >= 1.0e299 || (double)d6 <= wi * wi * 1.000001;
+        if (cand && Q.tree >= 0 && st.tree[id] != Q.tree) cand = false;
+      }
+    }
+    if (!__any(cand)) continue;
+    double d = 1.0e300;
+    if (cand) {
+      double np[6];
+      for (int c = 0; c < 6; ++c) np[c] = st.pos[6 * (size_t)id + c];
+      d = dist6(np, Q.pos);
+      cand = have < k || key_less(d, id, worst, 0x7fffffff);
+    }
+    topk_insert(t, lane, k, have, __ballot(cand), d, id);
+  }
+  if (lane == 0) cnt[q] = have;
+  if (lane < have && lane < kcap) {
+    idx[(size_t)q * kcap + lane] = t.id;
+    dist[(size_t)q * kcap + lane] = t.d;
+  }
+}
+
+// candidates of one group of up to 64 cells (lane = cell, m = its item count), flattened over the lanes
+__device__ __forceinline__ void knn_cells(const GridView& g, int m, int cell, int lane, const KnnQuery& Q, const NodeStoreView& st,
+                                          TopK& t, int k, int& have, bool mates, double mate_limit, int32_t* mate_out, int& n_mates) {
+  int inc = m;
+  for (int off = 1; off < 64; off <<= 1) {
+    const int o = __shfl_up(inc, off);
+    if (lane >= off) inc += o;
+  }
+  const int total = __shfl(inc, 63);
+  for (int base = 0; base < total; base += 64) {
+    const int j = base + lane;
+    const int jj = j < total ? j : total - 1;
+    int lo = 0, hi = 63;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (__shfl(inc, mid) > jj) hi = mid; else lo = mid + 1;
+    }
+    const int src_cell = __shfl(cell, lo);
+    const int slot = jj - (__shfl(inc, lo) - __shfl(m, lo));
+    bool cand = false;
+    double d = 1.0e300;
+    int id = 0x7fffffff;
+    if (j < total) {
+      const GridItem it = g.items[(size_t)src_cell * g.bk + slot];
+      id = it.id;
+      if (id < Q.max_id && (Q.tree < 0 || it.tree == Q.tree) && (mates ? id >= Q.mate_base : id < Q.mate_base)) {
+        double np[6];
+        for (int c = 0; c < 6; ++c) np[c] = st.pos[6 * (size_t)id + c];
+        d = dist6(np, Q.pos);
+        cand = true;
+      }
+    }
+    if (mates) {
+      cand = cand && d <= mate_limit;
+      const unsigned long long mm = __ballot(cand);
+      if (cand) {
+        const int at = n_mates + __popcll(mm & ((1ULL << lane) - 1ULL));
+        if (at < SFFK_KNN_MATES) mate_out[at] = id;
+      }
+      n_mates += __popcll(mm);
+    } else {
+      const double worst = topk_worst(t, k, have);
+      cand = cand && (have < k || key_less(d, id, worst, 0x7fffffff));
+      topk_insert(t, lane, k, have, __ballot(cand), d, id);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_knn_grid(GridView g, GridView tg, NodeStoreView st, const KnnQuery* __restrict__ queries,
+                                                  int nq, int kcap, int32_t* __restrict__ idx, double* __restrict__ dist,
+                                                  int32_t* __restrict__ cnt, int32_t* __restrict__ mate_idx,
+                                                  int32_t* __restrict__ mate_cnt, double cell_edge, double slack) {
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (q >= nq) return;
+  const KnnQuery Q = queries[q];
+  const int k = Q.k < 64 ? Q.k : 64;
+  TopK t{1.0e300, 0x7fffffff};
+  int have = 0, n_mates = 0;
+  const int cx = grid_coord((float)Q.pos[0], g.ox, g.inv_cell, g.nx), cy = grid_coord((float)Q.pos[1], g.oy, g.inv_cell, g.ny),
+            cz = grid_coord((float)Q.pos[2], g.oz, g.inv_cell, g.nz);
+  // shared overflow list first (usually empty)
+  {
+    int no = g.ovf_cnt[0];
+    if (no > g.ovf_cap) no = g.ovf_cap;
+    for (int base = 0; base < no; base += 64) {
+      const int j = base + lane;
+      bool cand = false;
+      double d = 1.0e300;
+      int id = 0x7fffffff;
+      const double worst = topk_worst(t, k, have);   // (a shuffle: outside the divergent code below)
+      if (j < no) {
+        const GridItem it = g.ovf[j];
+        id = it.id;
+        if (id < Q.max_id && id < Q.mate_base && (Q.tree < 0 || it.tree == Q.tree)) {
+          double np[6];
+          for (int c = 0; c < 6; ++c) np[c] = st.pos[6 * (size_t)id + c];
+          d = dist6(np, Q.pos);
+          cand = have < k || key_less(d, id, worst, 0x7fffffff);
+        }
+      }
+      topk_insert(t, lane, k, have, __ballot(cand), d, id);
+    }
+  }
+  // shells of cells around the query's cell: shell r = the cube of half-width r minus the cube of half-width r-1.
+  // After shell r every node within r * cell_edge (minus fp32 slack) of the query has been seen.
+  const int rmax = max(max(g.nx, g.ny), g.nz);
+  int r_done = -1;
+  for (int r = 0; r <= rmax; ++r) {
+    const int w = 2 * r + 1;
+    const int total = w * w * w;
+    const int inner = r > 0 ? (w - 2) * (w - 2) * (w - 2) : 0;
+    (void)inner;
+    for (int c0 = 0; c0 < total; c0 += 64) {
+      const int c = c0 + lane;
+      int cell = 0, m = 0;
+      if (c < total) {
+        const int ox = c % w - r, oy = (c / w) % w - r, oz = c / (w * w) - r;
+        const bool shell = ox == -r || ox == r || oy == -r || oy == r || oz == -r || oz == r;
+        const int x = cx + ox, y = cy + oy, z = cz + oz;
+        if (shell && x >= 0 && x < g.nx && y >= 0 && y < g.ny && z >= 0 && z < g.nz) {
+          cell = (z * g.ny + y) * g.nx + x;
+          m = g.cnt[cell];
+          if (m > g.bk) m = g.bk;
+        }
+      }
+      if (__any(m > 0)) knn_cells(g, m, cell, lane, Q, st, t, k, have, false, 0.0, nullptr, n_mates);
+    }
+    r_done = r;
+    const double covered = (double)r * cell_edge - slack;   // (cells are assigned from fp32 coordinates)
+    if (have >= k && topk_worst(t, k, have) <= covered) break;
+    if (cx - r <= 0 && cy - r <= 0 && cz - r <= 0 && cx + r >= g.nx - 1 && cy + r >= g.ny - 1 && cz + r >= g.nz - 1) break;
+  }
+  // the round's temporaries not farther than the k-th store node - all of the tree's while the k nearest are the
+  // whole tree (then they are read straight from the temporary store entries: coalesced, no cube over the grid)
+  if (tg.cnt && Q.mate_base < Q.max_id) {
+    const bool all = Q.whole_tree != 0 || have < k;
+    const double limit = all ? 1.0e300 : topk_worst(t, k, have);
+    if (all) {
+      for (int base = Q.mate_base; base < Q.max_id; base += 64) {
+        const int id = base + lane;
+        bool cand = false;
+        if (id < Q.max_id) {
+          const float x = st.x[id];
+          cand = x == x && (Q.tree < 0 || st.tree[id] == Q.tree);     // (NaN: the sample fell outside the limits)
+        }
+        const unsigned long long mm = __ballot(cand);
+        if (cand) {
+          const int at = n_mates + __popcll(mm & ((1ULL << lane) - 1ULL));
+          if (at < SFFK_KNN_MATES) mate_idx[(size_t)q * SFFK_KNN_MATES + at] = id;
+        }
+        n_mates += __popcll(mm);
+      }
+    } else {
+      int rr = (int)((limit + slack) / cell_edge) + 1;
+      if (rr > rmax) rr = rmax;
+      const int w = 2 * rr + 1;
+      const int total = w * w * w;
+      for (int c0 = 0; c0 < total; c0 += 64) {
+        const int c = c0 + lane;
+        int cell = 0, m = 0;
+        if (c < total) {
+          const int x = cx + c % w - rr, y = cy + (c / w) % w - rr, z = cz + c / (w * w) - rr;
+          if (x >= 0 && x < g.nx && y >= 0 && y < g.ny && z >= 0 && z < g.nz) {
+            cell = (z * g.ny + y) * g.nx + x;
+            const bool maybe = tg.occ ? ((tg.occ[cell >> 5] >> (cell & 31)) & 1u) != 0 : true;
+            if (maybe) { m = tg.cnt[cell]; if (m > tg.bk) m = tg.bk; }
+          }
+        }
+        if (__any(m > 0)) knn_cells(tg, m, cell, lane, Q, st, t, k, have, true, limit, mate_idx + (size_t)q * SFFK_KNN_MATES, n_mates);
+      }
+      int no = tg.ovf_cnt[0];
+      if (no > tg.ovf_cap) no = tg.ovf_cap;
+      for (int base = 0; base < no; base += 64) {
+        const int j = base + lane;
+        bool cand = false;
+        int id = 0x7fffffff;
+        if (j < no) {
+          const GridItem it = tg.ovf[j];
+          id = it.id;
+          if (id < Q.max_id && id >= Q.mate_base && (Q.tree < 0 || it.tree == Q.tree)) {
+            double np[6];
+            for (int c = 0; c < 6; ++c) np[c] = st.pos[6 * (size_t)id + c];
+            cand = dist6(np, Q.pos) <= limit;
+          }
+        }
+        const unsigned long long mm = __ballot(cand);
+        if (cand) {
+          const int at = n_mates + __popcll(mm & ((1ULL << lane) - 1ULL));
+          if (at < SFFK_KNN_MATES) mate_idx[(size_t)q * SFFK_KNN_MATES + at] = id;
+        }
+        n_mates += __popcll(mm);
+      }
+    }
+  }
+  (void)r_done;
+  if (lane == 0) { cnt[q] = have; if (mate_cnt) mate_cnt[q] = n_mates; }
+  if (lane < have && lane < kcap) {
+    idx[(size_t)q * kcap + lane] = t.id;
+    dist[(size_t)q * kcap + lane] = t.d;
+  }
 }
 
 __global__ __launch_bounds__(256) void k_set_tree(int32_t* __restrict__ tree_col, const int32_t* __restrict__ ids, int n,
@@ -1597,6 +1860,19 @@ void launch_grid_query(hipStream_t s, const GridView& g, const GridView* tg, con
   hipLaunchKernelGGL(k_grid_query, dim3((nq + 7) / 8), dim3(256), 0, s, g, tg ? *tg : none, st, queries, qpos, nq, cnt,
                      hit_idx, hit_dist, cap, dev_n);
 }
+void launch_knn_linear(hipStream_t s, const NodeStoreView& st, int n_store, const KnnQuery* q, int nq, int kcap,
+                       int32_t* idx, double* dist, int32_t* cnt, double abs_eps) {
+  if (nq <= 0) return;
+  hipLaunchKernelGGL(k_knn_linear, dim3((nq + 3) / 4), dim3(256), 0, s, st, n_store, q, nq, kcap, idx, dist, cnt, abs_eps);
+}
+void launch_knn_grid(hipStream_t s, const GridView& g, const GridView* tg, const NodeStoreView& st, const KnnQuery* q, int nq,
+                     int kcap, int32_t* idx, double* dist, int32_t* cnt, int32_t* mate_idx, int32_t* mate_cnt, double cell,
+                     double slack) {
+  if (nq <= 0) return;
+  GridView none{};
+  hipLaunchKernelGGL(k_knn_grid, dim3((nq + 3) / 4), dim3(256), 0, s, g, tg ? *tg : none, st, q, nq, kcap, idx, dist, cnt,
+                     mate_idx, mate_cnt, cell, slack);
+}
 void launch_set_tree(hipStream_t s, int32_t* tree_col, const int32_t* ids, int n, int32_t value) {
   if (n <= 0) return;
   hipLaunchKernelGGL(k_set_tree, dim3((n + 255) / 256), dim3(256), 0, s, tree_col, ids, n, value);
@@ -1648,6 +1924,22 @@ void launch_seg_prepare(hipStream_t s, const double* a6, const double* b6, int n
                         int32_t* ovf) {
   if (n <= 0) return;
   hipLaunchKernelGGL(k_seg_prepare, dim3((n + 255) / 256), dim3(256), 0, s, a6, b6, n, seg_ns, first_hit, ovf);
+}
+
+__global__ __launch_bounds__(256) void k_tgrid_clear(GridView tg, const float* __restrict__ tx, const float* __restrict__ ty,
+                                                     const float* __restrict__ tz, int n) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  if (t == 0) tg.ovf_cnt[0] = 0;
+  if (t >= n) return;
+  const float x = tx[t];
+  if (x == x) {
+    const size_t cell = grid_cell_of(tg, x, ty[t], tz[t]);
+    tg.cnt[cell] = 0;
+    if (tg.occ) tg.occ[cell >> 5] = 0u;
+  }
+}
+void launch_tgrid_clear(hipStream_t s, const TempGridRef& t) {
+  hipLaunchKernelGGL(k_tgrid_clear, dim3((std::max(t.n, 1) + 255) / 256), dim3(256), 0, s, t.tg, t.x, t.y, t.z, t.n);
 }
 
 // compact -> cull -> exact.  pos6 / pose_hit may be null (edges only); temps (optional) = the round's own grid

@@ -1,0 +1,57 @@
+"""The multi-GPU wave protocol across REAL processes: N fresh interpreters (started before they touch the GPU), one
+rank each, all on GPU 0, exchanging their per-round answer records with torch.distributed (gloo) exactly like
+`bench.py --gpus N` does over RCCL.  Every rank must end with the forest the single-process CPU oracle builds at the
+same wave size, and the work must really have been split."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import common
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize("name,world,wave,iters,optimize", [("dense3d", 2, 512, 12000, 0), ("triang", 3, 256, 6000, 1)])
+def test_sharded_forest_across_processes_equals_the_oracle(name, world, wave, iters, optimize):
+    port = free_port()
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "mp_forest_worker.py"), str(r), str(world),
+                               str(port), name, str(wave), str(iters), "3", str(optimize)],
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for r in range(world)]
+    outs = []
+    for p in procs:
+        so, se = p.communicate(timeout=600)
+        assert p.returncode == 0, se[-2000:]
+        line = [ln for ln in so.splitlines() if ln.startswith("RESULT ")][-1]
+        outs.append(json.loads(line[7:]))
+    sc = common.scenario(name)
+    w = O.World(sc["env"], sc["robot"], O.TRIG_PORTABLE)
+    roots = sc["xml_points"][:5] if sc["xml_points"] is not None else \
+        common.free_roots(w.collide, sc["limits"], 5, seed=3, dim=sc["dim"])
+    fo = O.Forest(w, roots, sc["limits"], dist_tree=sc["dist_tree"], sampling_dist=sc["sampling_dist"], dim=sc["dim"],
+                  max_iterations=iters, wave=wave, seed=3, optimize=bool(optimize))
+    fo.run()
+    so = fo.stats()
+    assert so["n_nodes"] > 300
+    for o in outs:
+        assert o["fingerprint"] == "%016x" % fo.fingerprint(), o["rank"]
+        for k, v in o["stats"].items():
+            assert v == so[k], (o["rank"], k, v, so[k])
+    # the candidates were sharded: no rank evaluated all poses, together they evaluated each exactly once
+    ex = np.array([o["executed"] for o in outs])
+    assert ex.max() < 0.75 * ex.sum() and ex.min() > 0

@@ -359,6 +359,47 @@ def test_baseline_configs_equal_the_oracle(S, ctx, golden_dir):
         f.close()
 
 
+def test_libm_sampling_mode_equals_the_libm_oracle(S, ctx, golden_dir):
+    """Parity mode sffgpu_forest_cfg::libm_sampling: the samples are computed on the host with glibc's cos / sin /
+    acos - the arithmetic tests/golden/ref_primitives.json pins to the reference's own randGen.h - and the GPU forest
+    must reproduce the oracle's TRIG_LIBM runs (tests/golden/libm_runs.json): BASELINE configs[0] at wave 1 (the
+    reference's sequential loop), configs[1] in full, a 100 k-node slice of configs[2]."""
+    import importlib.util
+    import json
+    import os
+    path = os.path.join(golden_dir, "libm_runs.json")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/libm_runs.json not generated")
+    spec = importlib.util.spec_from_file_location("make_config_runs", os.path.join(golden_dir, "make_config_runs.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    RUNS = {   # (same table as tests/golden/make_libm_runs.py)
+        "configs[0] dense2d 3 xml points wave 1": ("dense2d", 3, 10000, 200000, 1),
+        "configs[1] triang 5 xml points 100k wave 64": ("triang", 5, 100000, 2**31 - 1, 64),
+        "configs[2] dense3d 10 roots 100k slice wave 8192": ("dense3d", 10, 100000, 2**31 - 1, 8192),
+    }
+    gold = json.load(open(path))["runs"]
+    for key, (name, nroots, budget, iters, wave) in RUNS.items():
+        sc, w = load_world(ctx, name)
+        roots = sc["xml_points"][:nroots] if sc["xml_points"] is not None else \
+            common.free_roots(w.collide, sc["limits"], nroots, seed=1, dim=sc["dim"])
+        kw = dict(dist_tree=sc["dist_tree"], sampling_dist=sc["sampling_dist"], dim=sc["dim"], max_iterations=iters,
+                  node_budget=budget, wave=wave, seed=1)
+        f = S.Forest(ctx, roots, sc["limits"], libm_sampling=True, **kw)
+        f.run()
+        got = mk.summary(f)
+        for k in got:
+            assert got[k] == gold[key][k], (key, k, got[k], gold[key][k])
+        f.close()
+    # the mode is not a no-op: the default (portable trig on the GPU) run of configs[0] differs in the position bits
+    sc, w = load_world(ctx, "dense2d")
+    f = S.Forest(ctx, sc["xml_points"][:3], sc["limits"], dist_tree=sc["dist_tree"], sampling_dist=sc["sampling_dist"],
+                 dim=2, max_iterations=200000, node_budget=10000, wave=1, seed=1)
+    f.run()
+    assert "%016x" % f.fingerprint() != gold["configs[0] dense2d 3 xml points wave 1"]["fingerprint"]
+    f.close()
+
+
 def test_more_seeds_equal_the_oracle(S, ctx, golden_dir):
     """More seeds, root counts and wave sizes of mid-size runs (SFF and SFF*, all four maps) against the committed
     oracle summaries tests/golden/soak_runs.json (tests/golden/make_soak_runs.py)."""

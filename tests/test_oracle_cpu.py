@@ -123,6 +123,44 @@ RUNS = [("triang", 1, False, False), ("triang", 32, True, False), ("dense3d", 16
         ("dense2d", 8, False, False), ("building", 64, True, False), ("triang", 1, False, True), ("building", 1, True, True)]
 
 
+def test_collision_boolean_does_not_depend_on_the_trig_implementation():
+    """The rotation matrix of a pose differs by <= 1 ulp between glibc's and the portable cos / sin; the triangle
+    contact boolean does not move: 60 k poses scattered around the obstacle surfaces (both outcomes, many grazing)."""
+    for name, n in (("dense3d", 30000), ("triang", 30000)):
+        sc = common.scenario(name)
+        wl = O.World(sc["env"], sc["robot"], O.TRIG_LIBM)
+        wp = O.World(sc["env"], sc["robot"], O.TRIG_PORTABLE)
+        poses = np.vstack([common.poses_near_surface(sc["env"], n * 2 // 3, 31, 0.4 * sc["scale"]),
+                           common.poses_near_surface(sc["env"], n // 3, 32, 0.02 * sc["scale"])])
+        a, b = wl.collide_many(poses), wp.collide_many(poses)
+        assert np.array_equal(a, b)
+        assert 0.1 < a.mean() < 0.9
+
+
+def test_libm_divergence_record_is_reproducible(golden_dir):
+    """tests/golden/libm_runs.json records, for 24 seeds x 2 maps, whether PORTABLE and LIBM sampling give the same
+    forest; three of the entries are recomputed here."""
+    import json
+    import os
+    path = os.path.join(golden_dir, "libm_runs.json")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/libm_runs.json not generated")
+    rec = json.load(open(path))["divergence"]
+    assert len(rec) >= 40
+    for e in rec[:2] + rec[24:25]:
+        sc = common.scenario(e["map"])
+        w = O.World(sc["env"], sc["robot"], O.TRIG_PORTABLE)
+        roots = sc["xml_points"][:5] if sc["xml_points"] is not None else common.free_roots(w.collide, sc["limits"], 5, seed=1)
+        fp = []
+        for trig in (O.TRIG_PORTABLE, O.TRIG_LIBM):
+            f = O.Forest(w, roots, sc["limits"], dist_tree=sc["dist_tree"], sampling_dist=sc["sampling_dist"], dim=sc["dim"],
+                         max_iterations=20000, wave=1, seed=e["seed"], trig=trig)
+            f.run()
+            fp.append((f.fingerprint(), f.stats()["n_nodes"]))
+        assert (fp[0][0] == fp[1][0]) == e["bit_identical"]
+        assert fp[0][1] == e["nodes"]
+
+
 def test_oracle_regression_fixture(golden_dir):
     """Pins today's oracle behaviour (tests/golden/make_oracle_runs.py regenerates the file)."""
     with open(os.path.join(golden_dir, "oracle_runs.json")) as f:
