@@ -332,6 +332,49 @@ def test_full_size_headline_run_equals_the_oracle(S, ctx, golden_dir):
     f.close()
 
 
+def test_c5_building_sff_star_full_run_properties(S, ctx):
+    """BASELINE configs[4] on one GPU at full size: building.obj (26 908 triangles), 20 seeded roots, SFF* (optimize =
+    true: choose-parent + rewire), 2 M-node budget, waves of 8192 slots.  With the example's distances (dtree 0.5,
+    circum 0.4, scale 10) the forest SATURATES before the budget: every tree connected, frontier empty -> "solved" at
+    ~2.1e5 nodes, so the run is the whole job.  Size-independent properties on every node (limits, tree of the
+    parent, edge length = stored parent distance, costs along the parent chain: equal where nothing was rewired
+    above, never smaller otherwise - the reference leaves descendants' costs untouched),
+    oracle-checked poses and parent edges on a sample; the first 150 k nodes' worth of the same run is pinned
+    bit for bit by test_baseline_configs_equal_the_oracle."""
+    sc, w = load_world(ctx, "building")
+    roots = common.free_roots(lambda p: int(ctx.collide_poses(p[None, :])[0]), sc["limits"], 20, seed=1)
+    f = S.Forest(ctx, roots, sc["limits"], dist_tree=sc["dist_tree"], sampling_dist=sc["sampling_dist"], dim=6, optimize=True,
+                 max_iterations=2**31 - 1, node_budget=2000000, wave=8192, seed=1)
+    f.run()
+    s, n = f.stats(), f.nodes()
+    N = s["n_nodes"]
+    assert s["solved"] == 1 and s["frontier_size"] == 0 and 150000 < N < 2000000 and s["n_connected"] == 20
+    pos, par, tree, cost, dpar = n["pos"], n["parent"], n["tree"], n["cost"], n["dpar"]
+    lim = np.asarray(sc["limits"], dtype=np.float64)
+    for a in range(3):
+        assert (pos[:, a] >= lim[2 * a]).all() and (pos[:, a] <= lim[2 * a + 1]).all()
+    kids = np.nonzero(par >= 0)[0]
+    assert len(kids) == N - 20 and (cost[par < 0] == 0).all()
+    assert (tree[par[kids]] == tree[kids]).all()
+    rewired_up = (par[kids] > kids).sum()
+    assert rewired_up > 1000                                  # rewiring happened: younger parents
+    # costs: cost = parent's cost + edge at the moment the edge was made; a later rewire of an ancestor only lowers
+    # the ancestor's cost
+    slack = cost[kids] - (cost[par[kids]] + dpar[kids])
+    assert (slack >= -1e-9).all() and (slack == 0).mean() > 0.5
+    # stored parent distance = the 6-D metric of the edge, bit for bit (the oracle's Point::distance)
+    L = O.lib()
+    rs = np.random.RandomState(9)
+    for i in rs.choice(kids, 4000, replace=False):
+        assert L.sffo_distance(O.dp(np.ascontiguousarray(pos[i])), O.dp(np.ascontiguousarray(pos[par[i]]))) == dpar[i]
+    for i in rs.choice(kids, 600, replace=False):
+        assert not w.collide(pos[i])
+        # choose-parent checks isPathFree(new, neighbour), rewire isPathFree(neighbour, new), the default parent edge
+        # isPathFree(expanded, new) (src/forest.h:246,323,336): one direction of the stored edge was verified
+        assert w.path_free(pos[par[i]], pos[i])[0] or w.path_free(pos[i], pos[par[i]])[0], i
+    f.close()
+
+
 def test_baseline_configs_equal_the_oracle(S, ctx, golden_dir):
     """BASELINE.json configs[0] (2-D, 3 roots, 10 k nodes) and configs[1] (triang, 5 roots, 100 k nodes) in full and configs[4] (building, 20 roots, SFF* with
     rewire) at a 150 k-node budget: the GPU runs reproduce the committed oracle summaries
