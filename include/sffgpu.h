@@ -220,6 +220,29 @@ int sffgpu_forest_round_records(sffgpu_forest* f, int32_t* words, int cap_words)
 int sffgpu_forest_round_commit(sffgpu_forest* f, const int32_t* all_words, int total_words,
                                const int32_t* words_per_rank, int world); /* total_words = length of all_words */
 
+
+/* The same protocol on the device-resident engine (plain SFF): nothing of a round crosses PCIe.  Every rank runs
+ * the replicated kernels (frontier picks, sampling, the in-order commit) itself and evaluates only the candidates it
+ * owns; their fixed-size answer records are packed into `send_dev` (sffgpu_forest_exchange_bytes() bytes of DEVICE
+ * memory), the caller all-gathers them over RCCL into `recv_dev` (world x that many bytes, rank order) on the stream
+ * handed over with sffgpu_ctx_set_stream(), and the commit reads the other ranks' records from there:
+ *   sffgpu_forest_dev_wave_begin -> done != 0: the solver has terminated
+ *   sffgpu_forest_rounds_per_wave() x { sffgpu_forest_dev_round_eval(send_dev); <all-gather>; sffgpu_forest_dev_round_commit(recv_dev) }
+ *   sffgpu_forest_dev_wave_end   -> the one host synchronisation of the wave; fault != 0: a bounded device list
+ *                                   overflowed in this wave - the forest is back on the host engine mid-wave and the
+ *                                   caller finishes the wave with sffgpu_forest_round_begin / _commit (every rank
+ *                                   takes the same decision: the replicas are identical).
+ * With world == 1 the buffers may be NULL.  sffgpu_forest_device_engine() tells whether this forest runs on the
+ * device engine (plain SFF, wave >= 256, not in libm_sampling mode; SFFGPU_ENGINE=host|device overrides). */
+int sffgpu_ctx_set_stream(sffgpu_ctx* ctx, void* hip_stream);   /* NULL: back to the context's own stream */
+int sffgpu_forest_device_engine(sffgpu_forest* f);
+long long sffgpu_forest_exchange_bytes(sffgpu_forest* f);
+int sffgpu_forest_rounds_per_wave(sffgpu_forest* f);
+int sffgpu_forest_dev_wave_begin(sffgpu_forest* f, int32_t* done);
+int sffgpu_forest_dev_round_eval(sffgpu_forest* f, void* send_dev);
+int sffgpu_forest_dev_round_commit(sffgpu_forest* f, const void* recv_dev);
+int sffgpu_forest_dev_wave_end(sffgpu_forest* f, int32_t* fault);
+
 #ifdef __cplusplus
 }
 #endif

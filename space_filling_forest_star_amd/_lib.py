@@ -19,7 +19,9 @@ EXPORTED_SYMBOLS = [
     "sffgpu_rrt_create", "sffgpu_rrt_destroy", "sffgpu_rrt_run", "sffgpu_rrt_get_stats", "sffgpu_rrt_get_nodes",
     "sffgpu_rrt_get_links", "sffgpu_rrt_paths", "sffgpu_rrt_path_plan", "sffgpu_rrt_smooth_paths",
     "sffgpu_rrt_link_plan", "sffgpu_kernel_times", "sffgpu_forest_get_frontier",
-    "sffgpu_collide_transforms", "sffgpu_forest_in_wave", "sffgpu_forest_round_begin", "sffgpu_forest_round_records", "sffgpu_forest_round_commit",
+    "sffgpu_collide_transforms", "sffgpu_ctx_set_stream", "sffgpu_forest_device_engine", "sffgpu_forest_exchange_bytes",
+    "sffgpu_forest_rounds_per_wave", "sffgpu_forest_dev_wave_begin", "sffgpu_forest_dev_round_eval",
+    "sffgpu_forest_dev_round_commit", "sffgpu_forest_dev_wave_end", "sffgpu_forest_in_wave", "sffgpu_forest_round_begin", "sffgpu_forest_round_records", "sffgpu_forest_round_commit",
 ]
 
 c_dp = C.POINTER(C.c_double)
@@ -131,6 +133,15 @@ def lib():
     L.sffgpu_rrt_link_plan.argtypes = [C.c_void_p, C.c_int, c_ip, C.c_int]
     L.sffgpu_forest_get_frontier.argtypes = [C.c_void_p, c_ip, C.c_int]
     L.sffgpu_forest_in_wave.argtypes = [C.c_void_p]
+    L.sffgpu_ctx_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    L.sffgpu_forest_device_engine.argtypes = [C.c_void_p]
+    L.sffgpu_forest_exchange_bytes.argtypes = [C.c_void_p]
+    L.sffgpu_forest_exchange_bytes.restype = C.c_longlong
+    L.sffgpu_forest_rounds_per_wave.argtypes = [C.c_void_p]
+    L.sffgpu_forest_dev_wave_begin.argtypes = [C.c_void_p, c_ip]
+    L.sffgpu_forest_dev_round_eval.argtypes = [C.c_void_p, C.c_void_p]
+    L.sffgpu_forest_dev_round_commit.argtypes = [C.c_void_p, C.c_void_p]
+    L.sffgpu_forest_dev_wave_end.argtypes = [C.c_void_p, c_ip]
     L.sffgpu_forest_round_begin.argtypes = [C.c_void_p, c_ip, c_ip]
     L.sffgpu_forest_round_records.argtypes = [C.c_void_p, c_ip, C.c_int]
     L.sffgpu_forest_round_commit.argtypes = [C.c_void_p, c_ip, C.c_int, c_ip, C.c_int]
@@ -223,6 +234,10 @@ class Context:
         self._chk(self._L.sffgpu_sample_steer(self.h, w.ctypes.data_as(c_u64p), _dp(cen), len(w), dist, dim, _dp(lim),
                                               _dp(out), ok.ctypes.data_as(c_u8p)))
         return out, ok
+
+    def set_stream(self, hip_stream):
+        """run the library's launches on the caller's HIP stream (e.g. torch.cuda.current_stream().cuda_stream)"""
+        self._chk(self._L.sffgpu_ctx_set_stream(self.h, C.c_void_p(hip_stream)))
 
     def nodes_reset(self, capacity=0):
         self._chk(self._L.sffgpu_nodes_reset(self.h, capacity))
@@ -364,6 +379,32 @@ class Forest:
 
     def in_wave(self):
         return bool(self.ctx._L.sffgpu_forest_in_wave(self.h))
+
+    # ---- multi-GPU on the device-resident engine (include/sffgpu.h)
+    def device_engine(self):
+        return bool(self.ctx._L.sffgpu_forest_device_engine(self.h))
+
+    def exchange_bytes(self):
+        return int(self.ctx._L.sffgpu_forest_exchange_bytes(self.h))
+
+    def rounds_per_wave(self):
+        return int(self.ctx._L.sffgpu_forest_rounds_per_wave(self.h))
+
+    def dev_wave_begin(self):
+        done = C.c_int32(0)
+        self.ctx._chk(self.ctx._L.sffgpu_forest_dev_wave_begin(self.h, C.byref(done)))
+        return bool(done.value)
+
+    def dev_round_eval(self, send_ptr):
+        self.ctx._chk(self.ctx._L.sffgpu_forest_dev_round_eval(self.h, C.c_void_p(send_ptr)))
+
+    def dev_round_commit(self, recv_ptr):
+        self.ctx._chk(self.ctx._L.sffgpu_forest_dev_round_commit(self.h, C.c_void_p(recv_ptr)))
+
+    def dev_wave_end(self):
+        fault = C.c_int32(0)
+        self.ctx._chk(self.ctx._L.sffgpu_forest_dev_wave_end(self.h, C.byref(fault)))
+        return int(fault.value)
 
     # ---- multi-GPU round protocol (include/sffgpu.h "Multi-GPU wave protocol")
     def round_begin(self):
@@ -513,8 +554,62 @@ def exchange_records(local, group=None):
         _XCHG["cap"] = int(2 ** int(np.ceil(np.log2(int(counts.max()) + 1)))) * 2
 
 
+def _run_distributed_device(forest, max_waves, group):
+    """The device-resident engine over all ranks: per round one all-gather of fixed-size answer records between
+    DEVICE buffers (RCCL on the stream the library launches on), one host synchronisation per wave."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    nccl = dist.get_backend(group) == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device())
+    words = forest.exchange_bytes() // 4
+    send = torch.zeros(words, dtype=torch.int32, device=dev)
+    recv = torch.zeros(world * words, dtype=torch.int32, device=dev)
+    # kernels and collectives in one order, no host hand-over: a stream of our own (torch's default stream is the
+    # null stream, which the library cannot adopt) that is torch's current stream while the waves run
+    stream = torch.cuda.Stream(device=dev)
+    stream.wait_stream(torch.cuda.current_stream())
+    forest.ctx.set_stream(stream.cuda_stream)
+    rounds = forest.rounds_per_wave()
+    w0 = forest.stats()["waves"]
+    try:
+        with torch.cuda.stream(stream):
+            while True:
+                if max_waves > 0:
+                    s = forest.stats()
+                    if s["waves"] - w0 >= max_waves and not forest.in_wave():
+                        break
+                if forest.dev_wave_begin():
+                    break
+                for _ in range(rounds):
+                    forest.dev_round_eval(send.data_ptr())
+                    if nccl:
+                        dist.all_gather_into_tensor(recv, send, group=group)
+                    else:   # (gloo in the CPU-side tests: staged through the host)
+                        stream.synchronize()
+                        parts = [torch.zeros(words, dtype=torch.int32) for _ in range(world)]
+                        dist.all_gather(parts, send.cpu(), group=group)
+                        recv.copy_(torch.cat(parts))
+                    forest.dev_round_commit(recv.data_ptr())
+                if forest.dev_wave_end():
+                    # a bounded device list overflowed in this wave on every (identical) replica: finish it on the
+                    # host protocol; the next dev_wave_begin moves the state back to the device
+                    while forest.in_wave():
+                        rec, done = forest.round_begin()
+                        if done:
+                            break
+                        allw, counts = exchange_records(rec, group)
+                        forest.round_commit(allw, counts)
+    finally:
+        stream.synchronize()
+        forest.ctx.set_stream(None)
+    return forest.stats()["waves"] - w0
+
+
 def run_distributed(forest, max_waves=0, group=None):
     """Drive one shared forest over all ranks of the process group; returns waves done."""
+    if forest.device_engine():
+        return _run_distributed_device(forest, max_waves, group)
     w0 = forest.stats()["waves"]
     while True:
         if max_waves > 0:

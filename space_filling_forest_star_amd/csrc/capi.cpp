@@ -359,6 +359,35 @@ int sffgpu_forest_round_begin(sffgpu_forest* f, int32_t* n_words, int32_t* done)
     }
   });
 }
+// ---- multi-GPU on the device-resident engine: the caller owns the collective of a round
+int sffgpu_ctx_set_stream(sffgpu_ctx* ctx, void* hip_stream) {
+  if (!ctx) return SFFGPU_ERR_ARG;
+  GUARD(ctx, ctx->c->set_stream(static_cast<hipStream_t>(hip_stream)));
+}
+int sffgpu_forest_device_engine(sffgpu_forest* f) { return f ? (f->f->dev.on ? 1 : 0) : SFFGPU_ERR_ARG; }
+long long sffgpu_forest_exchange_bytes(sffgpu_forest* f) { return f ? (long long)f->f->dev_exchange_bytes() : SFFGPU_ERR_ARG; }
+int sffgpu_forest_dev_wave_begin(sffgpu_forest* f, int32_t* done) {
+  if (!f || !done) return SFFGPU_ERR_ARG;
+  GUARD(f->owner, *done = f->f->dev_wave_begin() ? 0 : 1);
+}
+int sffgpu_forest_dev_round_eval(sffgpu_forest* f, void* send_dev) {
+  if (!f) return SFFGPU_ERR_ARG;
+  GUARD(f->owner, f->f->dev_enqueue_round_eval(f->f->cfg.world > 1 ? send_dev : nullptr));
+}
+int sffgpu_forest_dev_round_commit(sffgpu_forest* f, const void* recv_dev) {
+  if (!f) return SFFGPU_ERR_ARG;
+  GUARD(f->owner, f->f->dev_enqueue_round_commit(f->f->cfg.world > 1 ? recv_dev : nullptr));
+}
+int sffgpu_forest_dev_wave_end(sffgpu_forest* f, int32_t* fault) {
+  if (!f || !fault) return SFFGPU_ERR_ARG;
+  GUARD(f->owner, {
+    f->f->dev_enqueue_end();
+    *fault = f->f->dev_finish_wave(nullptr);
+    if (*fault) f->f->dev_to_host();   // (a list overflowed: the caller finishes the wave through the host protocol)
+  });
+}
+int sffgpu_forest_rounds_per_wave(sffgpu_forest* f) { return f ? std::max(1, f->f->cfg.threshold_misses) : SFFGPU_ERR_ARG; }
+
 int sffgpu_forest_round_records(sffgpu_forest* f, int32_t* words, int cap_words) {
   if (!f || !words) return SFFGPU_ERR_ARG;
   Forest& F = *f->f;

@@ -23,7 +23,7 @@
 // two barriers per list, whatever its length.
 //
 // Everything here is integer / index bookkeeping plus the few fp64 expressions of expandNode, evaluated in the same
-// order as the host engine and the CPU oracle (-ffp-contract=off), so the forests are bit-identical.
+// order as the host engine (-ffp-contract=off), so the forests are bit-identical.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "kernels.h"
@@ -38,6 +38,8 @@ using namespace sffg;
 #define DF_WAVES (DF_THREADS / 64)
 #define DF_EV_LDS 1024                      // border events of a round whose details stay in LDS
 #define DF_MAX_GROUPS SFFK_DEV_MAX_GROUPS   // ballot words in LDS: 64 x this many elements per list
+
+__device__ __forceinline__ int record_words_dev(int nbcap) { return 6 + 4 * nbcap; }
 
 struct WgLists {                     // LDS of the single-workgroup kernels
   unsigned long long words[DF_MAX_GROUPS];
@@ -208,12 +210,15 @@ __global__ __launch_bounds__(256) void k_decide(ResolveArgs A) {
       const size_t s0 = (size_t)i * A.stride;
       const int nnb = A.rec_nnb[i];
       bool ovf = A.first_hit[s0] == 0;            // 0 = the edge's triangle candidate list ran over
-      ex_pose = 1;
-      ex_seg = 1 + (unsigned long long)nnb;
-      ex_smp = (unsigned long long)A.seg_ns[s0];
+      const bool mine = A.world <= 1 || i % A.world == A.rank;   // (executed work is counted by the rank that ran it)
+      if (mine) {
+        ex_pose = 1;
+        ex_seg = 1 + (unsigned long long)nnb;
+        ex_smp = (unsigned long long)A.seg_ns[s0];
+      }
       for (int k = 0; k < nnb; ++k) {
         ovf |= A.first_hit[s0 + 1 + k] == 0;
-        ex_smp += (unsigned long long)A.seg_ns[s0 + 1 + k];
+        if (mine) ex_smp += (unsigned long long)A.seg_ns[s0 + 1 + k];
       }
       if (ovf) atomicOr(A.fault_pending, 1);
       else {
@@ -249,7 +254,7 @@ __global__ __launch_bounds__(256) void k_decide(ResolveArgs A) {
     cc += __shfl_xor(cc, off); pf += __shfl_xor(pf, off); nq += __shfl_xor(nq, off);
     ex_pose += __shfl_xor(ex_pose, off); ex_seg += __shfl_xor(ex_seg, off); ex_smp += __shfl_xor(ex_smp, off);
   }
-  if ((threadIdx.x & 63) == 0 && ex_pose) {
+  if ((threadIdx.x & 63) == 0 && (cc | ex_pose)) {
     atomicAdd(A.bulk + 0, cc); atomicAdd(A.bulk + 1, pf); atomicAdd(A.bulk + 2, nq);
     atomicAdd(A.bulk + 4, ex_pose); atomicAdd(A.bulk + 5, ex_seg); atomicAdd(A.bulk + 6, ex_smp);
   }
@@ -644,6 +649,49 @@ __global__ __launch_bounds__(256) void k_frontier_compact(DevForestView f) {
   }
 }
 
+// ------------------------------------------------------------------ multi-GPU: answer records of a round
+__global__ __launch_bounds__(256) void k_pack_records(ResolveArgs A, int rank, int world, int32_t* __restrict__ send) {
+  const DevForestView& f = A.f;
+  if (f.ctrl->halt) return;
+  const int n = f.ctrl->n_act;
+  const int W = record_words_dev(A.nbcap);
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int j = (int)(t / W), k = (int)(t % W);
+  const int i = j * world + rank;
+  if (i >= n) return;
+  const size_t s0 = (size_t)i * A.stride;
+  int32_t v;
+  if (k == 0) v = A.rec_flags[i];
+  else if (k == 1) v = A.rec_nnb[i];
+  else if (k == 2) v = A.pose_hit[i];
+  else if (k == 3) v = 0;
+  else if (k < 4 + A.nbcap) v = A.rec_nb[(size_t)i * A.nbcap + (k - 4)];
+  else if (k < 4 + 2 * A.nbcap) v = A.rec_meta[(size_t)i * A.nbcap + (k - 4 - A.nbcap)];
+  else if (k < 4 + 2 * A.nbcap + A.stride) v = A.seg_ns[s0 + (k - 4 - 2 * A.nbcap)];
+  else v = A.first_hit[s0 + (k - 4 - 2 * A.nbcap - A.stride)];
+  send[(size_t)j * W + k] = v;
+}
+__global__ __launch_bounds__(256) void k_unpack_records(ResolveArgs A, int rank, int world, int per_rank,
+                                                        const int32_t* __restrict__ recv) {
+  const DevForestView& f = A.f;
+  if (f.ctrl->halt) return;
+  const int n = f.ctrl->n_act;
+  const int W = record_words_dev(A.nbcap);
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  const int i = (int)(t / W), k = (int)(t % W);
+  if (i >= n || i % world == rank) return;
+  const int32_t v = recv[((size_t)(i % world) * per_rank + (size_t)(i / world)) * W + k];
+  const size_t s0 = (size_t)i * A.stride;
+  if (k == 0) A.rec_flags[i] = v;
+  else if (k == 1) A.rec_nnb[i] = v;
+  else if (k == 2) A.pose_hit[i] = (uint8_t)v;
+  else if (k == 3) { }
+  else if (k < 4 + A.nbcap) A.rec_nb[(size_t)i * A.nbcap + (k - 4)] = v;
+  else if (k < 4 + 2 * A.nbcap) A.rec_meta[(size_t)i * A.nbcap + (k - 4 - A.nbcap)] = v;
+  else if (k < 4 + 2 * A.nbcap + A.stride) A.seg_ns[s0 + (k - 4 - 2 * A.nbcap)] = v;
+  else A.first_hit[s0 + (k - 4 - 2 * A.nbcap - A.stride)] = v;
+}
+
 __global__ __launch_bounds__(256) void k_border_rehash(DevForestView f, int n) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= n) return;
@@ -664,6 +712,16 @@ void launch_commit(hipStream_t s, const ResolveArgs& a, int n_bound) {
 void launch_wave_end(hipStream_t s, const DevForestView& f, const int32_t* grid_ovf, const int32_t* tgrid_ovf) {
   hipLaunchKernelGGL(k_wave_end, dim3(1), dim3(DF_THREADS), 0, s, f, grid_ovf, tgrid_ovf);
   hipLaunchKernelGGL(k_frontier_compact, dim3(512), dim3(256), 0, s, f);
+}
+void launch_pack_records(hipStream_t s, const ResolveArgs& a, int rank, int world, int n_bound, int32_t* send) {
+  const int per_rank = (n_bound + world - 1) / world;
+  const long long threads = (long long)per_rank * record_words(a.nbcap);
+  hipLaunchKernelGGL(k_pack_records, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, a, rank, world, send);
+}
+void launch_unpack_records(hipStream_t s, const ResolveArgs& a, int rank, int world, int n_bound, const int32_t* recv) {
+  const int per_rank = (n_bound + world - 1) / world;
+  const long long threads = (long long)n_bound * record_words(a.nbcap);
+  hipLaunchKernelGGL(k_unpack_records, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, a, rank, world, per_rank, recv);
 }
 void launch_border_rehash(hipStream_t s, const DevForestView& f, int n) {
   if (n <= 0) return;

@@ -144,6 +144,7 @@ Ctx::Ctx(int dev) : device(dev) {
   if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
     throw HipError{std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only"};
   HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+  own_stream = stream;
   HIPCHK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
   HIPCHK(hipEventCreateWithFlags(&ev_mid, hipEventDisableTiming));
   HIPCHK(hipEventCreateWithFlags(&ev_early, hipEventDisableTiming));
@@ -165,7 +166,15 @@ Ctx::~Ctx() {
   PinBuf* pins[] = {&h_a, &h_b, &h_c, &h_d, &h_e, &h_f, &h_g, &h_h, &p_in, &p_out};
   for (PinBuf* b : pins) b->release();
   if (copy_stream) (void)hipStreamDestroy(copy_stream);
-  if (stream) (void)hipStreamDestroy(stream);
+  if (own_stream) (void)hipStreamDestroy(own_stream);
+}
+
+// Run every launch of this context on the caller's stream (multi-GPU: the stream the RCCL collectives of a round are
+// issued on, so that kernels and collectives are ordered without host synchronisation).
+void Ctx::set_stream(hipStream_t s) {
+  HIPCHK(hipSetDevice(device));
+  sync();
+  stream = s ? s : own_stream;
 }
 
 hipEvent_t Ctx::get_event() {

@@ -67,6 +67,8 @@ enum TimerKind { T_SWEEP = 0, T_COLLIDE = 1, T_SAMPLE = 2, T_KINDS = 3 };
 struct Ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t own_stream = nullptr;           // the stream the context created (stream may be replaced by the caller's)
+  void set_stream(hipStream_t s);             // nullptr = back to the own stream
   hipStream_t copy_stream = nullptr;          // early D2H of a forest round (runs beside the collision kernels)
   hipEvent_t ev_mid = nullptr, ev_early = nullptr;
   std::string err;
@@ -243,7 +245,13 @@ struct Forest {
   void dev_ring_top_up(uint64_t cursor, uint64_t ahead);
   void dev_upload_state();
   void dev_to_host();
-  void dev_enqueue_wave(int first_round);
+  void dev_enqueue_begin();
+  void dev_enqueue_round_eval(void* send_dev);
+  void dev_enqueue_round_commit(const void* recv_dev);
+  void dev_enqueue_end();
+  int dev_finish_wave(double* wait_ms);
+  bool dev_wave_begin();
+  size_t dev_exchange_bytes() const;
   void run_device(int max_waves);
   void sync_host();             // refresh the host mirror (nodes, frontier, borders, counters) from the device
   void fill_stats(sffgpu_forest_stats* out);

@@ -33,7 +33,7 @@ static uint64_t next_pow2(uint64_t v) {
 }
 
 bool Forest::device_eligible() const {
-  return cfg.world == 1 && !cfg.optimize && !cfg.has_goal && !use_priority();
+  return !cfg.optimize && !cfg.has_goal && !use_priority();
 }
 
 sffk::DevForestView Forest::dev_view() const {
@@ -400,140 +400,252 @@ void Forest::dev_to_host() {
   d.active = false;
 }
 
-void Forest::dev_enqueue_wave(int first_round) {
-  Ctx& c = *ctx;
-  DevEngine& d = dev;
-  const sffk::DevForestView V = dev_view();
-  const int wave = cfg.wave;
-  const int n = wave;   // launch bound; the kernels read the real count from DevCtrl
-  const int CAP = hit_cap, NBCAP = nb_cap, STRIDE = 1 + NBCAP;
-  // device output block of a round (same layout as the host path's, sized for a full wave)
-  const size_t rec_ints = (size_t)n * (2 + 2 * NBCAP);
+// buffers of one round (same layout as the host path's output block, sized for a full wave)
+struct DevRoundBufs {
+  int n, CAP, NBCAP, STRIDE, list_cap;
+  double *d_pos, *d_pd;
+  int32_t *d_rec, *d_rctrl, *seg_ns, *first_hit, *seg_ovf;
+  uint8_t *d_lim, *d_pose, *code;
+  unsigned long long* bulk;
+};
+static DevRoundBufs dev_round_bufs(Forest& F) {
+  Ctx& c = *F.ctx;
+  DevRoundBufs B{};
+  const int n = F.cfg.wave;   // launch bound; the kernels read the real count from DevCtrl
+  B.n = n; B.CAP = F.hit_cap; B.NBCAP = F.nb_cap; B.STRIDE = 1 + B.NBCAP;
+  const size_t rec_ints = (size_t)n * (2 + 2 * B.NBCAP);
   const size_t o_pos = 0, o_pd = o_pos + (size_t)n * 48, o_lim = o_pd + (size_t)n * 8,
                o_rec = o_lim + ((size_t)n + 15) / 16 * 16, o_ns = o_rec + rec_ints * 4,
-               o_fh = o_ns + (size_t)n * STRIDE * 4, o_ctrl = o_fh + (size_t)n * STRIDE * 4, o_pose = o_ctrl + 128,
+               o_fh = o_ns + (size_t)n * B.STRIDE * 4, o_ctrl = o_fh + (size_t)n * B.STRIDE * 4, o_pose = o_ctrl + 128,
                o_code = o_pose + (size_t)n, o_bytes = (o_code + (size_t)n + 15) / 16 * 16, o_ovf = o_bytes;
-  c.r_out.ensure(o_ovf + (size_t)n * STRIDE * 4);
+  c.r_out.ensure(o_ovf + (size_t)n * B.STRIDE * 4);
   char* dout = c.r_out.as<char>();
-  double* d_pos = reinterpret_cast<double*>(dout + o_pos);
-  double* d_pd = reinterpret_cast<double*>(dout + o_pd);
-  int32_t* d_rec = reinterpret_cast<int32_t*>(dout + o_rec);
-  int32_t* d_rctrl = reinterpret_cast<int32_t*>(dout + o_ctrl);
-  uint8_t* d_lim = reinterpret_cast<uint8_t*>(dout + o_lim);
-  uint8_t* d_pose = reinterpret_cast<uint8_t*>(dout + o_pose);
+  B.d_pos = reinterpret_cast<double*>(dout + o_pos);
+  B.d_pd = reinterpret_cast<double*>(dout + o_pd);
+  B.d_rec = reinterpret_cast<int32_t*>(dout + o_rec);
+  B.d_rctrl = reinterpret_cast<int32_t*>(dout + o_ctrl);
+  B.d_lim = reinterpret_cast<uint8_t*>(dout + o_lim);
+  B.d_pose = reinterpret_cast<uint8_t*>(dout + o_pose);
+  B.seg_ns = reinterpret_cast<int32_t*>(dout + o_ns);
+  B.first_hit = reinterpret_cast<int32_t*>(dout + o_fh);
+  B.seg_ovf = reinterpret_cast<int32_t*>(dout + o_ovf);
+  B.code = reinterpret_cast<uint8_t*>(dout + o_code);
+  B.bulk = reinterpret_cast<unsigned long long*>(dout + o_ctrl + 16);
   c.r_q.ensure((size_t)n * sizeof(sffk::SweepQuery));
   c.r_cnt.ensure((size_t)n * 4);
-  c.r_hidx.ensure((size_t)n * CAP * 4);
-  c.r_hdist.ensure((size_t)n * CAP * 8);
-  c.r_sega.ensure((size_t)n * STRIDE * 48);
-  c.r_segb.ensure((size_t)n * STRIDE * 48);
-  const int list_cap = 4 * n * STRIDE + 65536;
-  c.r_items.ensure((size_t)list_cap * SFFK_ITEM_BYTES);
-  c.r_items2.ensure(((size_t)list_cap + (1u << 20)) * 8);
-  const int32_t* dev_n = reinterpret_cast<const int32_t*>(d.ctrl.p);   // {n_act, halt}
+  c.r_sega.ensure((size_t)n * B.STRIDE * 48);
+  c.r_segb.ensure((size_t)n * B.STRIDE * 48);
+  B.list_cap = 4 * n * B.STRIDE + 65536;
+  c.r_items.ensure((size_t)B.list_cap * SFFK_ITEM_BYTES);
+  c.r_items2.ensure(((size_t)B.list_cap + (1u << 20)) * 8);
+  return B;
+}
+static sffk::ResolveArgs dev_resolve_args(Forest& F, const DevRoundBufs& B) {
+  Ctx& c = *F.ctx;
+  DevEngine& d = F.dev;
+  sffk::ResolveArgs ra{};
+  ra.f = F.dev_view();
+  ra.st = sffk::NodeStoreMut{c.sx.as<float>(), c.sy.as<float>(), c.sz.as<float>(), c.syaw.as<float>(),
+                             c.spitch.as<float>(), c.sroll.as<float>(), c.stree.as<int32_t>(), c.spos.as<double>()};
+  ra.g = c.gridv;
+  ra.nbcap = B.NBCAP;
+  ra.stride = B.STRIDE;
+  ra.rank = F.cfg.rank;
+  ra.world = F.cfg.world;
+  ra.newpos = B.d_pos;
+  ra.pdist = B.d_pd;
+  ra.parent = d.d_parent.as<int32_t>();
+  ra.code = B.code;
+  ra.in_lim = B.d_lim;
+  ra.rec_flags = B.d_rec;
+  ra.pose_hit = B.d_pose;
+  ra.rec_nnb = B.d_rec + B.n;
+  ra.rec_nb = B.d_rec + 2 * (size_t)B.n;
+  ra.rec_meta = B.d_rec + 2 * (size_t)B.n + (size_t)B.n * B.NBCAP;
+  ra.seg_ns = B.seg_ns;
+  ra.first_hit = B.first_hit;
+  ra.bulk = B.bulk;
+  ra.round_ctrl = B.d_rctrl;
+  ra.fault_pending = d.fault_pending.as<int32_t>();
+  return ra;
+}
 
+size_t Forest::dev_exchange_bytes() const {   // what one rank contributes to the all-gather of a round
+  const int per_rank = (cfg.wave + cfg.world - 1) / cfg.world;
+  return (size_t)per_rank * sffk::record_words(nb_cap) * 4;
+}
+
+void Forest::dev_enqueue_begin() {
+  Ctx& c = *ctx;
+  DevEngine& d = dev;
   if (d.ring_pending) {   // the words this wave may read have to be resident
     HIPCHK(hipStreamWaitEvent(c.stream, d.ev_ring, 0));
     d.ring_pending = false;
   }
-  sffk::launch_wave_begin(c.stream, V);
+  sffk::launch_wave_begin(c.stream, dev_view());
+}
+
+// sample -> neighbour query + classification -> collision, for the samples this rank owns; with send_dev the owned
+// samples' answer records are packed for the all-gather
+void Forest::dev_enqueue_round_eval(void* send_dev) {
+  Ctx& c = *ctx;
+  DevEngine& d = dev;
+  const sffk::DevForestView V = dev_view();
+  const DevRoundBufs B = dev_round_bufs(*this);
+  const int n = B.n;
+  const int32_t* dev_n = reinterpret_cast<const int32_t*>(d.ctrl.p);   // {n_act, halt}
   sffk::NodeStoreMut stm{c.sx.as<float>(), c.sy.as<float>(), c.sz.as<float>(), c.syaw.as<float>(),
                          c.spitch.as<float>(), c.sroll.as<float>(), c.stree.as<int32_t>(), c.spos.as<double>()};
-  for (int r = first_round; r < std::max(1, cfg.threshold_misses); ++r) {
-    c.timing_on = c.timer_stride <= 1 || d.rounds_enqueued % (uint64_t)c.timer_stride == 0;
-    c.round_scope = true;
-    ++d.rounds_enqueued;
-    sffk::SampleParams prm{};
-    memcpy(prm.limits, cfg.limits, sizeof prm.limits);
-    prm.dist_tree = cfg.dist_tree;
-    prm.sweep_abs_eps = c.sweep_eps();
-    prm.rank = 0;
-    prm.world = 1;
-    sffk::RoundTemps tmp{};
-    tmp.st = stm;
-    tmp.cnt = c.r_cnt.as<int32_t>();
-    tmp.tg = c.tgridv;
-    tmp.ctrl = d_rctrl;
-    tmp.n_perm = d.temp_base;
-    tmp.base = d.temp_base;
-    sffk::DevRound dv{};
-    dv.ctrl = V.ctrl;
-    dv.act_slot = V.act_slot;
-    dv.act_slot2 = V.act_slot2;
-    dv.slot_node = V.slot_node;
-    dv.nflag = V.nflag;
-    dv.ring = V.ring;
-    dv.ring_mask = V.ring_mask;
-    dv.words_per = V.words_per;
-    dv.parent_out = d.d_parent.as<int32_t>();
-    dv.force_out = d.d_force.as<uint8_t>();
-    c.time_begin(T_SAMPLE);
-    sffk::launch_sample_steer(c.stream, nullptr, nullptr, c.spos.as<double>(), nullptr, n, cfg.sampling_dist, cfg.dim, prm,
-                              d_pos, d_lim, d_pd, c.r_q.as<sffk::SweepQuery>(), d.temp_base, tmp, &dv);
-    c.time_end();
-    sffk::ClassifyArgs ca{};
-    ca.n = n; ca.N0 = d.temp_base; ca.cap = CAP; ca.nbcap = NBCAP; ca.rank = 0; ca.world = 1;
-    ca.goal_id = -1;
-    ca.dist_tree = cfg.dist_tree;
-    ca.newpos = d_pos;
-    ca.in_lim = d_lim;
-    ca.pdist = d_pd;
-    ca.parent = d.d_parent.as<int32_t>();
-    ca.force = d.d_force.as<uint8_t>();
-    ca.cnt = c.r_cnt.as<int32_t>();
-    ca.hit_idx = c.r_hidx.as<int32_t>();
-    ca.hit_dist = c.r_hdist.as<double>();
-    ca.tree = c.stree.as<int32_t>();
-    ca.pos = c.spos.as<double>();
-    ca.rec_flags = d_rec;
-    ca.rec_nnb = ca.rec_flags + n;
-    ca.rec_nb = ca.rec_nnb + n;
-    ca.rec_meta = ca.rec_nb + (size_t)n * NBCAP;
-    ca.seg_a = c.r_sega.as<double>();
-    ca.seg_b = c.r_segb.as<double>();
-    ca.seg_ns = reinterpret_cast<int32_t*>(dout + o_ns);
-    ca.first_hit = reinterpret_cast<int32_t*>(dout + o_fh);
-    ca.seg_ovf = reinterpret_cast<int32_t*>(dout + o_ovf);
-    ca.ctrl = d_rctrl;
-    ca.dev_n = dev_n;
-    c.time_begin(T_SWEEP);
-    sffk::launch_query_classify(c.stream, c.gridv, &c.tgridv, c.store_view(), c.r_q.as<sffk::SweepQuery>(), ca);
-    c.time_end();
-    c.time_begin(T_COLLIDE);
-    sffk::TempGridRef tref{c.tgridv, c.sx.as<float>() + d.temp_base, c.sy.as<float>() + d.temp_base,
-                           c.sz.as<float>() + d.temp_base, n};
-    sffk::launch_round_collide(c.stream, c.envv, c.robv, d_pos, n, ca.rec_flags, d_pose, ca.seg_a, ca.seg_b, ca.seg_ns,
-                               n * STRIDE, ca.ctrl, c.r_items.p, list_cap, c.r_items2.p, ca.first_hit, ca.seg_ovf, &tref,
-                               dev_n, STRIDE);
-    c.time_end();
-    sffk::ResolveArgs ra{};
-    ra.f = V;
-    ra.st = stm;
-    ra.g = c.gridv;
-    ra.nbcap = NBCAP;
-    ra.stride = STRIDE;
-    ra.newpos = d_pos;
-    ra.pdist = d_pd;
-    ra.parent = d.d_parent.as<int32_t>();
-    ra.code = reinterpret_cast<uint8_t*>(dout + o_code);
-    ra.in_lim = d_lim;
-    ra.rec_flags = ca.rec_flags;
-    ra.pose_hit = d_pose;
-    ra.rec_nnb = ca.rec_nnb;
-    ra.rec_nb = ca.rec_nb;
-    ra.rec_meta = ca.rec_meta;
-    ra.seg_ns = ca.seg_ns;
-    ra.first_hit = ca.first_hit;
-    ra.bulk = reinterpret_cast<unsigned long long*>(dout + o_ctrl + 16);
-    ra.round_ctrl = d_rctrl;
-    ra.fault_pending = d.fault_pending.as<int32_t>();
-    sffk::launch_commit(c.stream, ra, n);
-    c.timing_on = true;
-    c.round_scope = false;
-  }
-  sffk::launch_wave_end(c.stream, V, c.gridv.ovf_cnt, c.tgridv.ovf_cnt);
+  c.timing_on = c.timer_stride <= 1 || d.rounds_enqueued % (uint64_t)c.timer_stride == 0;
+  c.round_scope = true;
+  ++d.rounds_enqueued;
+  sffk::SampleParams prm{};
+  memcpy(prm.limits, cfg.limits, sizeof prm.limits);
+  prm.dist_tree = cfg.dist_tree;
+  prm.sweep_abs_eps = c.sweep_eps();
+  prm.rank = cfg.rank;
+  prm.world = cfg.world;
+  sffk::RoundTemps tmp{};
+  tmp.st = stm;
+  tmp.cnt = c.r_cnt.as<int32_t>();
+  tmp.tg = c.tgridv;
+  tmp.ctrl = B.d_rctrl;
+  tmp.n_perm = d.temp_base;
+  tmp.base = d.temp_base;
+  sffk::DevRound dv{};
+  dv.ctrl = V.ctrl;
+  dv.act_slot = V.act_slot;
+  dv.act_slot2 = V.act_slot2;
+  dv.slot_node = V.slot_node;
+  dv.nflag = V.nflag;
+  dv.ring = V.ring;
+  dv.ring_mask = V.ring_mask;
+  dv.words_per = V.words_per;
+  dv.parent_out = d.d_parent.as<int32_t>();
+  dv.force_out = d.d_force.as<uint8_t>();
+  c.time_begin(T_SAMPLE);
+  sffk::launch_sample_steer(c.stream, nullptr, nullptr, c.spos.as<double>(), nullptr, n, cfg.sampling_dist, cfg.dim, prm,
+                            B.d_pos, B.d_lim, B.d_pd, c.r_q.as<sffk::SweepQuery>(), d.temp_base, tmp, &dv);
+  c.time_end();
+  sffk::ClassifyArgs ca{};
+  ca.n = n; ca.N0 = d.temp_base; ca.cap = B.CAP; ca.nbcap = B.NBCAP; ca.rank = cfg.rank; ca.world = cfg.world;
+  ca.goal_id = -1;
+  ca.dist_tree = cfg.dist_tree;
+  ca.newpos = B.d_pos;
+  ca.in_lim = B.d_lim;
+  ca.pdist = B.d_pd;
+  ca.parent = d.d_parent.as<int32_t>();
+  ca.force = d.d_force.as<uint8_t>();
+  ca.cnt = c.r_cnt.as<int32_t>();
+  ca.hit_idx = nullptr;
+  ca.hit_dist = nullptr;
+  ca.tree = c.stree.as<int32_t>();
+  ca.pos = c.spos.as<double>();
+  ca.rec_flags = B.d_rec;
+  ca.rec_nnb = ca.rec_flags + n;
+  ca.rec_nb = ca.rec_nnb + n;
+  ca.rec_meta = ca.rec_nb + (size_t)n * B.NBCAP;
+  ca.seg_a = c.r_sega.as<double>();
+  ca.seg_b = c.r_segb.as<double>();
+  ca.seg_ns = B.seg_ns;
+  ca.first_hit = B.first_hit;
+  ca.seg_ovf = B.seg_ovf;
+  ca.ctrl = B.d_rctrl;
+  ca.dev_n = dev_n;
+  c.time_begin(T_SWEEP);
+  sffk::launch_query_classify(c.stream, c.gridv, &c.tgridv, c.store_view(), c.r_q.as<sffk::SweepQuery>(), ca);
+  c.time_end();
+  c.time_begin(T_COLLIDE);
+  sffk::TempGridRef tref{c.tgridv, c.sx.as<float>() + d.temp_base, c.sy.as<float>() + d.temp_base,
+                         c.sz.as<float>() + d.temp_base, n};
+  sffk::launch_round_collide(c.stream, c.envv, c.robv, B.d_pos, n, ca.rec_flags, B.d_pose, ca.seg_a, ca.seg_b, ca.seg_ns,
+                             n * B.STRIDE, ca.ctrl, c.r_items.p, B.list_cap, c.r_items2.p, ca.first_hit, ca.seg_ovf, &tref,
+                             dev_n, B.STRIDE);
+  c.time_end();
+  if (send_dev) sffk::launch_pack_records(c.stream, dev_resolve_args(*this, B), cfg.rank, cfg.world, n, static_cast<int32_t*>(send_dev));
+  c.timing_on = true;
+  c.round_scope = false;
+}
+
+// the in-order commit, replicated on every rank; with recv_dev the other ranks' answer records are unpacked first
+void Forest::dev_enqueue_round_commit(const void* recv_dev) {
+  Ctx& c = *ctx;
+  const DevRoundBufs B = dev_round_bufs(*this);
+  const sffk::ResolveArgs ra = dev_resolve_args(*this, B);
+  if (recv_dev) sffk::launch_unpack_records(c.stream, ra, cfg.rank, cfg.world, B.n, static_cast<const int32_t*>(recv_dev));
+  sffk::launch_commit(c.stream, ra, B.n);
+}
+
+void Forest::dev_enqueue_end() {
+  Ctx& c = *ctx;
+  DevEngine& d = dev;
+  sffk::launch_wave_end(c.stream, dev_view(), c.gridv.ovf_cnt, c.tgridv.ovf_cnt);
   HIPCHK(hipMemcpyAsync(d.h_ctrl.p, d.ctrl.p, sizeof(sffk::DevCtrl), hipMemcpyDeviceToHost, c.stream));
   HIPCHK(hipEventRecord(d.ev_wave, c.stream));
+}
+
+// waits for the wave, reads its status block and deals with what the host has to do between waves.  Returns the
+// fault the caller has to handle (SFFK_FAULT_LISTS: finish the wave on the host path) or 0; growth faults are
+// resolved here (the wave is then resumed by simply enqueuing it again).
+int Forest::dev_finish_wave(double* wait_ms) {
+  Ctx& c = *ctx;
+  DevEngine& d = dev;
+  {
+    auto tw = Clock::now();
+    HIPCHK(hipEventSynchronize(d.ev_wave));
+    c.sync();   // (harvests the timing events; the stream is idle)
+    if (wait_ms) *wait_ms += ms_since(tw);
+  }
+  d.last = *d.h_ctrl.as<sffk::DevCtrl>();
+  d.host_stale = true;
+  const sffk::DevCtrl& s = d.last;
+  if (s.fault) {
+    const int fault = s.fault;
+    if (fault == SFFK_FAULT_LISTS) return fault;
+    if (fault == SFFK_FAULT_CAPACITY) {
+      // (nodes and temporaries share the store: grow it, re-place the temporaries)
+      c.store_reserve(std::max(c.store_cap * 2, s.n_nodes + 4 * cfg.wave + 64));
+      dev_size_node_arrays();
+      dev_size_border_arrays(std::max(d.border_cap, 2 * (s.n_borders + cfg.wave)));
+    } else if (fault == SFFK_FAULT_BORDER_TABLE) {
+      dev_size_border_arrays(std::max(4 * d.border_cap, 2 * (s.n_borders + cfg.wave)));
+    } else {
+      throw HipError{"forest: unknown device fault"};
+    }
+    if (d.table_dirty) {
+      sffk::launch_border_rehash(c.stream, dev_view(), s.n_borders);
+      d.table_dirty = false;
+    }
+    int32_t clear[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(reinterpret_cast<char*>(d.ctrl.p) + offsetof(sffk::DevCtrl, fault), &clear[0], 4, hipMemcpyHostToDevice, c.stream));
+    HIPCHK(hipMemcpyAsync(reinterpret_cast<char*>(d.ctrl.p) + offsetof(sffk::DevCtrl, halt), &clear[1], 4, hipMemcpyHostToDevice, c.stream));
+    HIPCHK(hipStreamSynchronize(c.stream));
+    d.last.fault = 0;
+    d.last.halt = 0;
+    return 0;   // (in_wave is still set: the next k_wave_begin resumes the wave)
+  }
+  // the neighbour grid's shared overflow list (checked once per wave like the host path does)
+  if (s.grid_ovf > c.gridv.ovf_cap || s.tgrid_ovf > c.tgridv.ovf_cap)
+    throw HipError{"neighbour grid overflow list exhausted during a wave (nodes were dropped)"};
+  if (s.grid_ovf > c.gridv.ovf_cap / 4) {
+    c.store_n = s.n_nodes;
+    c.grid_inserted = s.n_nodes;
+    c.grid_check();
+  }
+  return 0;
+}
+
+// one wave of the device engine for a caller that owns the exchange (multi-GPU): begin -> done?
+bool Forest::dev_wave_begin() {
+  if (!dev.on) throw HipError{"forest: the device engine does not drive this forest"};
+  HIPCHK(hipSetDevice(ctx->device));
+  if (!dev.active) dev_upload_state();
+  const sffk::DevCtrl& k = dev.last;
+  if (!k.in_wave && k.terminated) return false;
+  dev_ring_top_up(k.cursor, 2 * dev.max_wave_words);
+  dev_enqueue_begin();
+  dev.host_stale = true;
+  return true;
 }
 
 void Forest::run_device(int max_waves) {
@@ -544,7 +656,6 @@ void Forest::run_device(int max_waves) {
   double wait_ms = 0;
   if (!d.active) dev_upload_state();
   const uint64_t w0 = d.last.waves;
-  int resume_round = 0;
   while (true) {
     const sffk::DevCtrl& k = d.last;
     if (!k.in_wave) {
@@ -552,61 +663,25 @@ void Forest::run_device(int max_waves) {
       if (max_waves > 0 && (int)(k.waves - w0) >= max_waves) break;
     }
     dev_ring_top_up(k.cursor, d.max_wave_words);
-    dev_enqueue_wave(resume_round);
-    resume_round = 0;
+    dev_enqueue_begin();
+    for (int r = 0; r < std::max(1, cfg.threshold_misses); ++r) {
+      dev_enqueue_round_eval(nullptr);
+      dev_enqueue_round_commit(nullptr);
+    }
+    dev_enqueue_end();
     d.host_stale = true;
     // while the GPU works: the words the NEXT wave may need, whatever this one consumes
     dev_ring_top_up(k.cursor, 2 * d.max_wave_words);
-    {
-      auto tw = Clock::now();
-      HIPCHK(hipEventSynchronize(d.ev_wave));
-      c.sync();   // (harvests the timing events; the stream is idle)
-      wait_ms += ms_since(tw);
-    }
-    d.last = *d.h_ctrl.as<sffk::DevCtrl>();
-    const sffk::DevCtrl& s = d.last;
-    if (s.fault) {
-      const int fault = s.fault;
-      if (fault == SFFK_FAULT_LISTS) {
-        // a bounded device list overflowed: finish this wave on the host path, then come back
-        dev_to_host();
-        while (in_wave) {
-          round_begin();
-          int32_t cnt = (int32_t)records.size();
-          round_commit(records.data(), cnt, &cnt, 1);
-        }
-        dev_upload_state();
-        continue;
+    const int fault = dev_finish_wave(&wait_ms);
+    if (fault == SFFK_FAULT_LISTS) {
+      // a bounded device list overflowed: finish this wave on the host path, then come back
+      dev_to_host();
+      while (in_wave) {
+        round_begin();
+        int32_t cnt = (int32_t)records.size();
+        round_commit(records.data(), cnt, &cnt, 1);
       }
-      if (fault == SFFK_FAULT_CAPACITY) {
-        // (nodes and temporaries share the store: grow it, re-place the temporaries)
-        c.store_reserve(std::max(c.store_cap * 2, s.n_nodes + 4 * cfg.wave + 64));
-        dev_size_node_arrays();
-        dev_size_border_arrays(std::max(d.border_cap, 2 * (s.n_borders + cfg.wave)));
-      } else if (fault == SFFK_FAULT_BORDER_TABLE) {
-        dev_size_border_arrays(std::max(4 * d.border_cap, 2 * (s.n_borders + cfg.wave)));
-      } else {
-        throw HipError{"forest: unknown device fault"};
-      }
-      if (d.table_dirty) {
-        sffk::launch_border_rehash(c.stream, dev_view(), s.n_borders);
-        d.table_dirty = false;
-      }
-      int32_t clear[2] = {0, 0};
-      HIPCHK(hipMemcpyAsync(reinterpret_cast<char*>(d.ctrl.p) + offsetof(sffk::DevCtrl, fault), &clear[0], 4, hipMemcpyHostToDevice, c.stream));
-      HIPCHK(hipMemcpyAsync(reinterpret_cast<char*>(d.ctrl.p) + offsetof(sffk::DevCtrl, halt), &clear[1], 4, hipMemcpyHostToDevice, c.stream));
-      HIPCHK(hipStreamSynchronize(c.stream));
-      d.last.fault = 0;
-      d.last.halt = 0;
-      continue;   // (in_wave is still set: k_wave_begin only rebuilds the active list)
-    }
-    // the neighbour grid's shared overflow list (checked once per wave like the host path does)
-    if (s.grid_ovf > c.gridv.ovf_cap || s.tgrid_ovf > c.tgridv.ovf_cap)
-      throw HipError{"neighbour grid overflow list exhausted during a wave (nodes were dropped)"};
-    if (s.grid_ovf > c.gridv.ovf_cap / 4) {
-      c.store_n = s.n_nodes;
-      c.grid_inserted = s.n_nodes;
-      c.grid_check();
+      dev_upload_state();
     }
   }
   st.total_ms += ms_since(t0);

@@ -312,14 +312,23 @@ struct ResolveArgs {
   NodeStoreMut st;
   GridView g;
   int nbcap, stride;
+  int rank, world;             // multi-GPU: which samples this rank evaluated itself (executed-work counters)
   const double* newpos; const double* pdist; const int32_t* parent; uint8_t* code;
-  const uint8_t* in_lim; const int32_t* rec_flags; const uint8_t* pose_hit;
-  const int32_t* rec_nnb; const int32_t* rec_nb; const int32_t* rec_meta; const int32_t* seg_ns; const int32_t* first_hit;
+  const uint8_t* in_lim; int32_t* rec_flags; uint8_t* pose_hit;
+  int32_t* rec_nnb; int32_t* rec_nb; int32_t* rec_meta; int32_t* seg_ns; int32_t* first_hit;
   unsigned long long* bulk;    // counters of the samples k_decide decided (7 words)
   const int32_t* round_ctrl;   // the round's scratch block ([2] = work items)
   int32_t* fault_pending;
 };
 void launch_wave_begin(hipStream_t s, const DevForestView& f);
+// multi-GPU: the answer record of one sample as it travels in the all-gather of a round:
+// flags, nnb, pose_hit, 0 | nb[nbcap] | meta[nbcap] | seg_ns[1 + nbcap] | first_hit[1 + nbcap]
+inline int record_words(int nbcap) { return 6 + 4 * nbcap; }
+// pack: the samples this rank owns (i % world == rank) -> send[(i / world) * record_words ...];
+// unpack: recv = world segments of ceil(n_bound / world) records; every sample another rank owns is copied back
+// into the round's arrays (a.code / rec_* / seg_ns / first_hit / pose_hit)
+void launch_pack_records(hipStream_t s, const ResolveArgs& a, int rank, int world, int n_bound, int32_t* send);
+void launch_unpack_records(hipStream_t s, const ResolveArgs& a, int rank, int world, int n_bound, const int32_t* recv);
 // the commit of one round: k_decide (wide) -> k_resolve (one workgroup) -> k_append (wide); n_bound = launch bound
 void launch_commit(hipStream_t s, const ResolveArgs& a, int n_bound);
 void launch_wave_end(hipStream_t s, const DevForestView& f, const int32_t* grid_ovf, const int32_t* tgrid_ovf);

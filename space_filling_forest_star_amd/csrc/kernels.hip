@@ -572,6 +572,25 @@ struct WaveStack {
   int sp;      // wave-uniform
 };
 #define STACK_CAP 256
+// candidate triangles of an item are staged in LDS 64 at a time: box (6) + plane (5) + vertices (9) doubles each.
+// One lane fetches one candidate (20 independent loads in flight) instead of every lane waiting on each candidate's
+// data in turn: the exact kernel is bound by exactly that latency (83 % of its wave cycles are parked on memory,
+// profiles/r2g_sq_summary.json).
+#define STAGE_TRI 20
+#define STAGE_DOUBLES (64 * STAGE_TRI)
+__device__ __forceinline__ void stage_candidates(const EnvView& env, const int32_t* cand, int k0, int kc, int lane, double* stage) {
+  if (lane < kc) {
+    const int t = cand[k0 + lane];
+    double* o = stage + lane * STAGE_TRI;
+    const double* b = env.tri_box + 6 * (size_t)t;
+    const double* pl = env.tri_plane + 5 * (size_t)t;
+    const double* tr = env.tri + 9 * (size_t)t;
+    for (int q = 0; q < 6; ++q) o[q] = b[q];
+    for (int q = 0; q < 5; ++q) o[6 + q] = pl[q];
+    for (int q = 0; q < 9; ++q) o[11 + q] = tr[q];
+  }
+  __builtin_amdgcn_wave_barrier();
+}
 
 // push the set lanes of `mask`: entry = code_base + lane
 __device__ __forceinline__ void push_mask(WaveStack& st, unsigned long long mask, int code_base, int lane) {
@@ -847,7 +866,7 @@ __device__ __forceinline__ void pose_frame(const RobotView& rob, const double* _
 
 // exact test of one posed robot (pose p, rotation R, bounding-sphere centre c) by one wavefront
 __device__ bool pose_exact(const EnvView& env, const RobotView& rob, const double* rtri, int32_t* stack, int32_t* cand,
-                           const double* p, const double* R, const double* c, int lane) {
+                           double* stage, const double* p, const double* R, const double* c, int lane) {
   // conservative query box around the posed bounding sphere
   double qlo[3], qhi[3];
   double rr = rob.radius * (1 + 1e-9) + 1e-9 * (fabs(c[0]) + fabs(c[1]) + fabs(c[2]) + 1);
@@ -857,34 +876,45 @@ __device__ bool pose_exact(const EnvView& env, const RobotView& rob, const doubl
   bool overflow;
   int nc = collect_candidates(env, qlo, qhi, lane, st, cand, CAND_CAP, &overflow);
   bool hit = false;
-  if (nc > 0 || overflow) {
-    // every lane poses up to ceil(n_tri/64) robot triangles once, then walks the candidates
+  if (overflow) {
+    // list overflowed: fall back to every env triangle (correct, slow, practically unreachable)
     for (int r0 = 0; r0 < rob.n_tri && !hit; r0 += 64) {
       const int r = r0 + lane;
       double Q[9];
-      bool have = r < rob.n_tri;
+      const bool have = r < rob.n_tri;
       if (have)
         for (int v = 0; v < 3; ++v) xform(R, p, rtri + 9 * r + 3 * v, Q + 3 * v);
       bool lane_hit = false;
-      if (!overflow) {
-        for (int k = 0; k < nc; ++k) {
-          const int t = cand[k];
-          if (plane_clear(env.tri_plane + 5 * (size_t)t, c, rr)) continue;  // wave-uniform
-          if (have && !lane_hit) {
-            const double* b = env.tri_box + 6 * (size_t)t;
-            if (tri_box_overlap(b, b + 3, Q)) lane_hit = sat17(env.tri + 9 * (size_t)t, Q);
-          }
-        }
-      } else {
-        // list overflowed: fall back to every env triangle (correct, slow, practically unreachable)
-        for (int t = 0; t < env.n_tri; ++t) {
-          if (have && !lane_hit) {
-            const double* b = env.tri_box + 6 * (size_t)t;
-            if (tri_box_overlap(b, b + 3, Q)) lane_hit = sat17(env.tri + 9 * (size_t)t, Q);
-          }
+      for (int t = 0; t < env.n_tri; ++t) {
+        if (have && !lane_hit) {
+          const double* b = env.tri_box + 6 * (size_t)t;
+          if (tri_box_overlap(b, b + 3, Q)) lane_hit = sat17(env.tri + 9 * (size_t)t, Q);
         }
       }
       hit = __any(lane_hit);
+    }
+  } else {
+    // candidates staged 64 at a time; every lane poses up to ceil(n_tri/64) robot triangles and walks the stage
+    for (int k0 = 0; k0 < nc && !hit; k0 += 64) {
+      const int kc = nc - k0 < 64 ? nc - k0 : 64;
+      stage_candidates(env, cand, k0, kc, lane, stage);
+      for (int r0 = 0; r0 < rob.n_tri && !hit; r0 += 64) {
+        const int r = r0 + lane;
+        double Q[9];
+        const bool have = r < rob.n_tri;
+        if (have)
+          for (int v = 0; v < 3; ++v) xform(R, p, rtri + 9 * r + 3 * v, Q + 3 * v);
+        bool lane_hit = false;
+        for (int k = 0; k < kc; ++k) {
+          const double* sb = stage + k * STAGE_TRI;
+          if (plane_clear(sb + 6, c, rr)) continue;  // wave-uniform
+          if (have && !lane_hit) {
+            if (tri_box_overlap(sb, sb + 3, Q)) lane_hit = sat17(sb + 11, Q);
+          }
+        }
+        hit = __any(lane_hit);
+      }
+      __builtin_amdgcn_wave_barrier();
     }
   }
   return hit;
@@ -895,10 +925,11 @@ __global__ __launch_bounds__(64 * POSE_WAVES) void k_collide_poses(EnvView env, 
                                                                    const int32_t* __restrict__ live_flags,
                                                                    uint8_t* __restrict__ hit_out, int explicit_rt) {
   extern __shared__ double lds_d[];
-  // layout: robot triangles (n_tri*9 doubles) | per-wave stacks | per-wave candidate lists
+  // layout: robot triangles (n_tri*9 doubles) | per-wave candidate stages | per-wave stacks | per-wave candidate lists
   double* rtri = lds_d;
-  int32_t* ibase = reinterpret_cast<int32_t*>(rtri + (size_t)rob.n_tri * 9);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double* stage = rtri + (size_t)rob.n_tri * 9 + (size_t)wave * STAGE_DOUBLES;
+  int32_t* ibase = reinterpret_cast<int32_t*>(rtri + (size_t)rob.n_tri * 9 + (size_t)POSE_WAVES * STAGE_DOUBLES);
   int32_t* stack = ibase + wave * STACK_CAP;
   int32_t* cand = ibase + POSE_WAVES * STACK_CAP + wave * CAND_CAP;
   // which poses of this workgroup need the exact test at all (most do not: clearance bits)
@@ -926,7 +957,7 @@ __global__ __launch_bounds__(64 * POSE_WAVES) void k_collide_poses(EnvView env, 
   for (int i = threadIdx.x; i < rob.n_tri * 9; i += blockDim.x) rtri[i] = rob.tri[i];
   __syncthreads();
   if (!need) return;
-  const bool hit = pose_exact(env, rob, rtri, stack, cand, p, R, c, lane);
+  const bool hit = pose_exact(env, rob, rtri, stack, cand, stage, p, R, c, lane);
   if (lane == 0) hit_out[pose] = hit ? 1 : 0;
 }
 
@@ -938,7 +969,7 @@ __global__ __launch_bounds__(64 * POSE_WAVES) void k_collide_poses(EnvView env, 
 // box gives a tight broad phase; the smallest colliding sample index of an edge is reduced with
 // atomicMin, so the answer does not depend on which chunk finishes first.
 __device__ void segment_chunk(const EnvView& env, const RobotView& rob, const double* rtri, int32_t* stack,
-                              int32_t* cand, int32_t* queue, const double* a, const double* b, int seg,
+                              int32_t* cand, int32_t* queue, double* stage, const double* a, const double* b, int seg,
                               int chunk, bool have_mask, unsigned long long mask, int32_t* __restrict__ first_hit,
                               int32_t* __restrict__ overflow_flag, int lane DBG_ARG) {
   [[maybe_unused]] const unsigned long long t0_ = DBG_T();
@@ -999,7 +1030,7 @@ __device__ void segment_chunk(const EnvView& env, const RobotView& rob, const do
     int v = 0x7fffffff;
     if (lane < count) {
       const int e = queue[lane];
-      const int sl = e & 63, r = (e >> 6) & 1023, k = e >> 16;
+      const int sl = e & 63, r = (e >> 6) & 1023, k = e >> 16;   // (k: index in the current stage)
       const int sidx = s0 + sl;
       if (sidx < minhit) {
         double S[3], Q[9];
@@ -1007,7 +1038,7 @@ __device__ void segment_chunk(const EnvView& env, const RobotView& rob, const do
         // identity rotation: ((1*v0 + 0*v1) + 0*v2) + T == v0 + T
         for (int vv = 0; vv < 3; ++vv)
           for (int ax = 0; ax < 3; ++ax) Q[3 * vv + ax] = rtri[9 * r + 3 * vv + ax] + S[ax];
-        if (sat17(env.tri + 9 * (size_t)cand[k], Q)) v = sidx;
+        if (sat17(stage + k * STAGE_TRI + 11, Q)) v = sidx;
       }
     }
     for (int off = 32; off > 0; off >>= 1) {
@@ -1021,45 +1052,50 @@ __device__ void segment_chunk(const EnvView& env, const RobotView& rob, const do
     if (lane + count < qn) queue[lane] = keep;
     qn -= count;
   };
-  for (int k = 0; k < nc; ++k) {
-    const int t = cand[k];
-    const double* bx = env.tri_box + 6 * (size_t)t;
-    bool touch = false;
-    if (need && idx < minhit) {
-      touch = true;
-      for (int ax = 0; ax < 3; ++ax) {
-        // exact bounds of v + P over the robot vertices (monotone rounding of one add)
-        double rlo = rob.lo[ax] + P[ax], rhi = rob.hi[ax] + P[ax];
-        if (bx[ax] > rhi || rlo > bx[3 + ax]) touch = false;
-      }
-      if (touch && plane_clear(env.tri_plane + 5 * (size_t)t, C, rr)) touch = false;
-      if (touch && tri_far(env.tri + 9 * (size_t)t, C, rr)) touch = false;
-    }
-    unsigned long long todo = __ballot(touch);
-    while (todo) {
-      const int sl = __ffsll((long long)todo) - 1;
-      todo &= todo - 1;
-      if (s0 + sl >= minhit) break;   // later samples cannot improve the first hit
-      double S[3];
-      S[0] = __shfl(P[0], sl); S[1] = __shfl(P[1], sl); S[2] = __shfl(P[2], sl);
-      for (int r0 = 0; r0 < rob.n_tri; r0 += 64) {
-        const int r = r0 + lane;
-        bool ok = false;
-        if (r < rob.n_tri) {
-          double Q[9];
-          for (int vv = 0; vv < 3; ++vv)
-            for (int ax = 0; ax < 3; ++ax) Q[3 * vv + ax] = rtri[9 * r + 3 * vv + ax] + S[ax];
-          ok = tri_box_overlap(bx, bx + 3, Q);
+  for (int k0 = 0; k0 < nc; k0 += 64) {
+    const int kc = nc - k0 < 64 ? nc - k0 : 64;
+    stage_candidates(env, cand, k0, kc, lane, stage);
+    for (int k = 0; k < kc; ++k) {
+      const double* bx = stage + k * STAGE_TRI;
+      bool touch = false;
+      if (need && idx < minhit) {
+        touch = true;
+        for (int ax = 0; ax < 3; ++ax) {
+          // exact bounds of v + P over the robot vertices (monotone rounding of one add)
+          double rlo = rob.lo[ax] + P[ax], rhi = rob.hi[ax] + P[ax];
+          if (bx[ax] > rhi || rlo > bx[3 + ax]) touch = false;
         }
-        const unsigned long long mm = __ballot(ok);
-        if (mm) {
-          const int before = __popcll(mm & ((1ULL << lane) - 1ULL));
-          if (ok) queue[qn + before] = sl | (r << 6) | (k << 16);
-          qn += __popcll(mm);
-          if (qn >= 64) flush(64);
+        if (touch && plane_clear(bx + 6, C, rr)) touch = false;
+        if (touch && tri_far(bx + 11, C, rr)) touch = false;
+      }
+      unsigned long long todo = __ballot(touch);
+      while (todo) {
+        const int sl = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        if (s0 + sl >= minhit) break;   // later samples cannot improve the first hit
+        double S[3];
+        S[0] = __shfl(P[0], sl); S[1] = __shfl(P[1], sl); S[2] = __shfl(P[2], sl);
+        for (int r0 = 0; r0 < rob.n_tri; r0 += 64) {
+          const int r = r0 + lane;
+          bool ok = false;
+          if (r < rob.n_tri) {
+            double Q[9];
+            for (int vv = 0; vv < 3; ++vv)
+              for (int ax = 0; ax < 3; ++ax) Q[3 * vv + ax] = rtri[9 * r + 3 * vv + ax] + S[ax];
+            ok = tri_box_overlap(bx, bx + 3, Q);
+          }
+          const unsigned long long mm = __ballot(ok);
+          if (mm) {
+            const int before = __popcll(mm & ((1ULL << lane) - 1ULL));
+            if (ok) queue[qn + before] = sl | (r << 6) | (k << 16);
+            qn += __popcll(mm);
+            if (qn >= 64) flush(64);
+          }
         }
       }
     }
+    while (qn > 0) flush(qn < 64 ? qn : 64);   // (the stage is about to be overwritten)
+    __builtin_amdgcn_wave_barrier();
   }
   while (qn > 0) flush(qn < 64 ? qn : 64);
   DBG_ADD(6, DBG_T() - t2_);
@@ -1253,8 +1289,9 @@ __global__ __launch_bounds__(64 * SEG_WAVES) void k_collide_segments_dyn(EnvView
   }
   extern __shared__ double lds_d[];
   double* rtri = lds_d;
-  int32_t* ibase = reinterpret_cast<int32_t*>(rtri + (size_t)rob.n_tri * 9);
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double* stage = rtri + (size_t)rob.n_tri * 9 + (size_t)wave * STAGE_DOUBLES;
+  int32_t* ibase = reinterpret_cast<int32_t*>(rtri + (size_t)rob.n_tri * 9 + (size_t)SEG_WAVES * STAGE_DOUBLES);
   for (int i = threadIdx.x; i < rob.n_tri * 9; i += blockDim.x) rtri[i] = rob.tri[i];
   __syncthreads();
   if (env.n_tri == 0) return;
@@ -1296,7 +1333,7 @@ __global__ __launch_bounds__(64 * SEG_WAVES) void k_collide_segments_dyn(EnvView
       const int pose = pool_e[i];
       double p[6], R[9], c[3];
       pose_frame(rob, pos6, pose, p, R, c);
-      const bool hit = pose_exact(env, rob, rtri, stack, cand, p, R, c, lane);
+      const bool hit = pose_exact(env, rob, rtri, stack, cand, stage, p, R, c, lane);
       if (lane == 0) pose_hit[pose] = hit ? 1 : 0;
     }
     __syncthreads();
@@ -1317,7 +1354,7 @@ __global__ __launch_bounds__(64 * SEG_WAVES) void k_collide_segments_dyn(EnvView
         if (chunk > 0 && first_hit[slot] <= 64 * chunk) continue;
         double a[6], b[6];
         for (int k = 0; k < 6; ++k) { a[k] = a6[6 * (size_t)slot + k]; b[k] = b6[6 * (size_t)slot + k]; }
-        segment_chunk(env, rob, rtri, stack, cand, queue, a, b, slot, chunk, true, nm, first_hit, overflow_flag, lane DBG_PASS);
+        segment_chunk(env, rob, rtri, stack, cand, queue, stage, a, b, slot, chunk, true, nm, first_hit, overflow_flag, lane DBG_PASS);
       }
       __syncthreads();
     }
@@ -1342,7 +1379,7 @@ __global__ __launch_bounds__(64 * SEG_WAVES) void k_collide_segments_dyn(EnvView
       double a[6], bb[6];
       for (int k = 0; k < 6; ++k) { a[k] = a6[6 * (size_t)(first + b) + k]; bb[k] = b6[6 * (size_t)(first + b) + k]; }
       for (int chunk = 0; chunk * 64 < nsb; ++chunk)
-        segment_chunk(env, rob, rtri, stack, cand, queue, a, bb, first + b, chunk, false, 0ULL, first_hit, overflow_flag, lane DBG_PASS);
+        segment_chunk(env, rob, rtri, stack, cand, queue, stage, a, bb, first + b, chunk, false, 0ULL, first_hit, overflow_flag, lane DBG_PASS);
     }
   }
 }
@@ -1808,7 +1845,8 @@ __global__ __launch_bounds__(256) void k_store_write(NodeStoreMut st, const doub
 
 // ------------------------------------------------------------------ launchers
 size_t collide_lds_bytes(int n_robot_tri, int waves) {
-  return (size_t)n_robot_tri * 9 * sizeof(double) + (size_t)waves * (STACK_CAP + CAND_CAP + QUEUE_CAP) * sizeof(int32_t);
+  return (size_t)n_robot_tri * 9 * sizeof(double) + (size_t)waves * STAGE_DOUBLES * sizeof(double) +
+         (size_t)waves * (STACK_CAP + CAND_CAP + QUEUE_CAP) * sizeof(int32_t);
 }
 
 void launch_sample_steer(hipStream_t s, const uint64_t* words, const int32_t* parent, const double* node_pos,
@@ -1882,6 +1920,7 @@ void launch_collide_poses(hipStream_t s, const EnvView& env, const RobotView& ro
                           const int32_t* live_flags, uint8_t* hit, bool explicit_rt) {
   if (n <= 0) return;
   size_t lds = collide_lds_bytes(rob.n_tri, POSE_WAVES);
+  if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_collide_poses), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(k_collide_poses, dim3((n + POSE_WAVES - 1) / POSE_WAVES), dim3(64 * POSE_WAVES), lds, s, env,
                      rob, pos6, n, live_flags, hit, explicit_rt ? 1 : 0);
 }
@@ -1952,6 +1991,7 @@ void launch_round_collide(hipStream_t s, const EnvView& env, const RobotView& ro
   if (!pose_hit) n_pose = 0;
   if (n_slots <= 0 && n_pose <= 0) return;
   size_t lds = collide_lds_bytes(rob.n_tri, SEG_WAVES);
+  if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_collide_segments_dyn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   // 2 workgroups of 4 waves per CU = what the exact kernel's register budget keeps resident (256 CUs)
   static const int blocks = std::min(4096, std::max(1, getenv("SFFGPU_SEG_BLOCKS") ? atoi(getenv("SFFGPU_SEG_BLOCKS")) : 512));
   static const int cull_blocks = getenv("SFFGPU_CULL_BLOCKS") ? atoi(getenv("SFFGPU_CULL_BLOCKS")) : 2048;

@@ -27,7 +27,7 @@ def main():
                  max_iterations=iters, wave=wave, seed=seed, optimize=bool(optimize), rank=rank, world=world)
     waves = S.run_distributed(f)
     st = f.stats()
-    out = {"rank": rank, "fingerprint": "%016x" % f.fingerprint(), "waves": int(waves),
+    out = {"rank": rank, "fingerprint": "%016x" % f.fingerprint(), "waves": int(waves), "device_engine": f.device_engine(),
            "stats": {k: int(st[k]) for k in ("iterations", "n_nodes", "n_borders", "collide_calls", "path_free_calls",
                                              "nn_queries", "frontier_size", "closed_size", "solved")},
            "executed": int(st["poses_executed"])}
