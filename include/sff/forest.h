@@ -56,6 +56,8 @@ class SpaceForest : public Solver<T, R> {
     cfg.rank = 0;
     cfg.world = 1;
     cfg.priority_bias = P.priorityBias;   // != 0: priority frontier heaps (src/heap.h)
+    const char* lm = std::getenv("SFF_LIBM");   // 1: samples with the C library's trig, like the reference (parity mode)
+    cfg.libm_sampling = (lm && std::atoi(lm)) ? 1 : 0;
     std::vector<double> roots;
     for (const Point<T>& p : P.roots) {
       double a[6];
