@@ -202,6 +202,12 @@ def main():
         sweep_ms = s1["sweep_ms"] - s0["sweep_ms"]
         sweeps = s1["sweeps"] - s0["sweeps"]
         sweep_nodes = s1["sweep_nodes"] - s0["sweep_nodes"]
+        event_ms = sweep_ms
+        # the device engine brackets the query kernel of EVERY round on the device clock (first wavefront in .. last
+        # wavefront out): that is the duration rocprofv3 reports; a HIP event pair adds ~3 us around a ~20 us kernel
+        clock_launches = s1["query_clock_launches"] - s0["query_clock_launches"]
+        if clock_launches > 0 and clock_launches == sweeps:
+            sweep_ms = s1["query_clock_ms"] - s0["query_clock_ms"]
         achieved = (24.0 * sweep_nodes / (sweep_ms * 1e-3)) / 1e9 if sweep_ms > 0 else 0.0
         # HBM-side bytes per launch of the neighbour-query kernel: only from a PMC summary that was collected
         # (separate rocprofv3 --pmc passes, profiles/collect.sh) with exactly the arguments of this run
@@ -252,13 +258,15 @@ def main():
                               "host_logic": s1["host_ms"] - s0["host_ms"]},
             "roofline": {
                 # neighbour query of one round (grid walk over the node grid and the round's own grid, exact fp64
-                # re-test, classification of the hits: one fused kernel), timed with HIP events on the library's
-                # launch stream (every 8th round).  Algorithmic bytes = 24 B x nodes the query has to cover
-                # (SURVEY.md 8(d)).
+                # re-test, classification of the hits: one fused kernel), timed live on the library's launch stream:
+                # device-clock bracket of every launch (and HIP events around every 8th round beside it).
+                # Algorithmic bytes = 24 B x nodes the query has to cover.
                 "bound": "hbm", "kernel": "sffk::k_query_classify (node grid + the round's own grid + hit classification)",
                 "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                 "traffic": traffic, "traffic_source": traffic_source,
                 "launches": int(sweeps), "avg_launch_us": 1e3 * sweep_ms / max(1, sweeps),
+                "timing": "device clock around every launch" if sweep_ms is not event_ms else "HIP events, every 8th round",
+                "avg_launch_us_by_hip_events": 1e3 * event_ms / max(1, sweeps),
                 "avg_nodes_per_launch": sweep_nodes / max(1, sweeps),
                 "avg_queries_per_launch": (s1["sweep_queries"] - s0["sweep_queries"]) / max(1, sweeps),
             },

@@ -130,6 +130,9 @@ typedef struct {
   double sample_ms;          /* device time of the sample+steer kernel */
   double host_ms;            /* host time inside run() not waiting on the device */
   double total_ms;           /* wall time inside run() */
+  double query_clock_ms;     /* device-resident engine: neighbour-query kernel time of ALL rounds, bracketed on the device
+                                (first wavefront in .. last wavefront out, wall_clock64) - what rocprofv3 reports */
+  uint64_t query_clock_launches;
 } sffgpu_forest_stats;
 
 int sffgpu_forest_create(sffgpu_ctx* ctx, const sffgpu_forest_cfg* cfg, const double* roots6, int n_roots,

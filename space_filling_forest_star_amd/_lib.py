@@ -51,7 +51,7 @@ class ForestStats(C.Structure):
                 ("sweep_nodes", C.c_uint64), ("sweep_queries", C.c_uint64), ("slow_path_samples", C.c_uint64), ("grid_rebuilds", C.c_uint64),
                 ("sweep_ms", C.c_double),
                 ("collide_ms", C.c_double), ("sample_ms", C.c_double), ("host_ms", C.c_double),
-                ("total_ms", C.c_double)]
+                ("total_ms", C.c_double), ("query_clock_ms", C.c_double), ("query_clock_launches", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -484,6 +484,7 @@ __global__ __launch_bounds__(DF_THREADS) void k_resolve(ResolveArgs A) {
     K.segments_executed += A.bulk[5];
     K.samples_executed += A.bulk[6];
     K.work_items += (unsigned long long)A.round_ctrl[2];
+    if (K.q_t1 > K.q_t0) { K.q_ticks += K.q_t1 - K.q_t0; K.q_launches += 1ULL; }
     K.app_n = n;                  // k_append applies this commit
     K.app_N0 = N0;
     K.app_fn0 = fn0;

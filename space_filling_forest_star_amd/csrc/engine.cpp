@@ -143,6 +143,10 @@ Ctx::Ctx(int dev) : device(dev) {
   HIPCHK(hipGetDeviceProperties(&prop, dev));
   if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
     throw HipError{std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only"};
+  {
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) == hipSuccess && khz > 0) wall_clock_khz = khz;
+  }
   HIPCHK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
   own_stream = stream;
   HIPCHK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));

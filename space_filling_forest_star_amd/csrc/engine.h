@@ -66,6 +66,7 @@ enum TimerKind { T_SWEEP = 0, T_COLLIDE = 1, T_SAMPLE = 2, T_KINDS = 3 };
 
 struct Ctx {
   int device = 0;
+  int wall_clock_khz = 100000;                // rate of wall_clock64() on this device
   hipStream_t stream = nullptr;
   hipStream_t own_stream = nullptr;           // the stream the context created (stream may be replaced by the caller's)
   void set_stream(hipStream_t s);             // nullptr = back to the own stream

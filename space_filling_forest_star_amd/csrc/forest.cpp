@@ -267,6 +267,10 @@ void Forest::fill_stats(sffgpu_forest_stats* out) {
     s.n_borders = nb;
   }
   s.n_trees = (int)trees.size();
+  if (dev.active || dev.inited) {
+    s.query_clock_ms = (double)dev.last.q_ticks / (double)ctx->wall_clock_khz;
+    s.query_clock_launches = dev.last.q_launches;
+  }
   s.grid_rebuilds = (uint64_t)ctx->grid_rebuilds;
   s.sweep_ms = ctx->kernel_ms_total(T_SWEEP);
   s.collide_ms = ctx->kernel_ms_total(T_COLLIDE);

@@ -523,6 +523,7 @@ void Forest::dev_enqueue_round_eval(void* send_dev) {
   dv.words_per = V.words_per;
   dv.parent_out = d.d_parent.as<int32_t>();
   dv.force_out = d.d_force.as<uint8_t>();
+  dv.qclk = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(d.ctrl.p) + offsetof(sffk::DevCtrl, q_t0));
   c.time_begin(T_SAMPLE);
   sffk::launch_sample_steer(c.stream, nullptr, nullptr, c.spos.as<double>(), nullptr, n, cfg.sampling_dist, cfg.dim, prm,
                             B.d_pos, B.d_lim, B.d_pd, c.r_q.as<sffk::SweepQuery>(), d.temp_base, tmp, &dv);
@@ -552,6 +553,7 @@ void Forest::dev_enqueue_round_eval(void* send_dev) {
   ca.seg_ovf = B.seg_ovf;
   ca.ctrl = B.d_rctrl;
   ca.dev_n = dev_n;
+  ca.qclk = dv.qclk;
   c.time_begin(T_SWEEP);
   sffk::launch_query_classify(c.stream, c.gridv, &c.tgridv, c.store_view(), c.r_q.as<sffk::SweepQuery>(), ca);
   c.time_end();

@@ -117,6 +117,10 @@ struct DevCtrl {
   // k_resolve phase clocks (wall_clock64 ticks of 10 ns, thread 0): open list, fixed point, append, borders,
   // counters + next active list; [5] = passes of the fixed point, [6] = commits, [7] = longest pass count
   unsigned long long prof[8];
+  // device-clock bracket of the neighbour-query kernel of the current round (first wave in .. last wave out, 100 MHz
+  // wall_clock64 ticks) and its sum over all committed rounds: the duration rocprofv3 reports, without the ~3 us a
+  // HIP event pair adds around a 20 us kernel
+  unsigned long long q_t0, q_t1, q_ticks, q_launches;
 };
 #define SFFK_DEV_MAX_GROUPS 1024   // single-workgroup list kernels: 64 x this many slots per wave at most
 #define SFFK_FAULT_LISTS 1        // a hit / neighbour / triangle-candidate list overflowed: redo the round on the host
@@ -135,6 +139,7 @@ struct DevRound {
   int32_t words_per;           // words per sample: 6 (3-D) / 1 (2-D)
   int32_t* parent_out;         // n: expanded node of every sample (read by k_classify)
   uint8_t* force_out;          // n: its ForceChildren flag
+  unsigned long long* qclk;    // DevCtrl::q_t0 / q_t1, reset here for the query kernel that follows
 };
 
 // forest rounds only: where k_sample_steer writes the round's temporary store entries and which per-round
@@ -230,6 +235,7 @@ struct ClassifyArgs {
   int32_t* seg_ovf;         // n x (1+nbcap)
   int32_t* ctrl;            // [1] next task slot of the persistent edge kernel
   const int32_t* dev_n;     // device mode: {n, halt} (n above is then the launch bound only)
+  unsigned long long* qclk; // device mode: {first wave in, last wave out} clock bracket of the query kernel
 };
 void launch_classify(hipStream_t s, const ClassifyArgs& a);
 // neighbour query + classification in one launch (one wavefront per sample): the hits never leave the wave

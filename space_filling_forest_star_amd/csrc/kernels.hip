@@ -42,6 +42,7 @@ __global__ __launch_bounds__(256) void k_sample_steer(const uint64_t* __restrict
   if (dv.ctrl) {   // device-resident forest: the round's size lives in HBM
     if (dv.ctrl->halt) return;
     n = dv.ctrl->n_act;
+    if (i == 0 && dv.qclk) { dv.qclk[0] = ~0ULL; dv.qclk[1] = 0ULL; }
   }
   if (tmp.cnt) {
     // per-round housekeeping folded into this launch: hit counters, the work-list cursor, and NaN
@@ -1603,6 +1604,9 @@ __global__ __launch_bounds__(64 * QC_WAVES) void k_query_classify(GridView g, Gr
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int i = blockIdx.x * QC_WAVES + wave;
   if (i >= A.n) return;
+  // (every 16th workgroup reports: ten thousand atomics on one word would cost more than the kernel itself)
+  const bool clocked = A.qclk && (blockIdx.x & 15) == 0 && threadIdx.x == 0;
+  if (clocked) atomicMin(A.qclk, wall_clock64());
   const int stride = 1 + A.nbcap;
   // ---- everything the sample needs, loaded before the first store (a wave runs one long chain of dependent
   // memory steps: independent loads are issued together, up front)
@@ -1718,6 +1722,7 @@ __global__ __launch_bounds__(64 * QC_WAVES) void k_query_classify(GridView g, Gr
   if (lane == 0) {
     A.rec_flags[i] = flags;
     A.rec_nnb[i] = nnb;
+    if (clocked) atomicMax(A.qclk + 1, wall_clock64());
   }
 }
 
