@@ -526,12 +526,12 @@ __global__ __launch_bounds__(256) void k_append(ResolveArgs A) {
   const double* p = A.newpos + 6 * (size_t)i;
   const size_t o = (size_t)id;
   GridItem it;
-  it.x = (float)p[0]; it.y = (float)p[1]; it.z = (float)p[2];
-  it.yaw = (float)p[3]; it.pitch = (float)p[4]; it.roll = (float)p[5];
+  for (int k = 0; k < 6; ++k) it.p[k] = p[k];
   it.id = id;
   it.tree = A.st.tree[ex];
-  A.st.x[o] = it.x; A.st.y[o] = it.y; A.st.z[o] = it.z;
-  A.st.yaw[o] = it.yaw; A.st.pitch[o] = it.pitch; A.st.roll[o] = it.roll;
+  it.pad[0] = it.pad[1] = 0;
+  A.st.x[o] = (float)p[0]; A.st.y[o] = (float)p[1]; A.st.z[o] = (float)p[2];
+  A.st.yaw[o] = (float)p[3]; A.st.pitch[o] = (float)p[4]; A.st.roll[o] = (float)p[5];
   for (int k = 0; k < 6; ++k) A.st.pos[6 * o + k] = p[k];
   A.st.tree[o] = it.tree;
   const double pd = A.pdist[i];

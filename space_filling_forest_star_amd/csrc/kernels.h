@@ -36,10 +36,11 @@ struct SweepQuery {   // 56 bytes, read through the scalar cache
 
 // Uniform grid over xyz (cell edge >= the neighbour radius of the planner): every cell owns a bucket
 // of `bk` items; the rare extra items of an over-full cell go to one shared overflow list.
-struct GridItem {   // 32 bytes
-  float x, y, z, yaw, pitch, roll;
+struct GridItem {   // 64 bytes = one sector pair: the node's authoritative fp64 position travels with the item, so a
+  double p[6];      // query needs no second, dependent gather for the exact distance (nor for the edge task it writes)
   int32_t id;
   int32_t tree;
+  int32_t pad[2];
 };
 struct GridView {
   float ox, oy, oz, inv_cell;

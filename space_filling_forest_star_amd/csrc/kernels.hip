@@ -100,10 +100,10 @@ __global__ __launch_bounds__(256) void k_sample_steer(const uint64_t* __restrict
     tmp.st.tree[t] = tr;
     if (ok && tmp.tg.cnt) {   // and into the round's own grid, where the later samples of the round look for it
       GridItem it;
-      it.x = (float)o[0]; it.y = (float)o[1]; it.z = (float)o[2];
-      it.yaw = (float)o[3]; it.pitch = (float)o[4]; it.roll = (float)o[5];
+      for (int k = 0; k < 6; ++k) it.p[k] = o[k];
       it.id = (int32_t)t;
       it.tree = tr;
+      it.pad[0] = it.pad[1] = 0;
       grid_put(tmp.tg, it);
     }
   }
@@ -198,12 +198,12 @@ __global__ __launch_bounds__(256) void k_grid_insert(GridView g, NodeStoreView s
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int id = first + i;
+  if (!(st.x[id] == st.x[id])) return;  // NaN placeholder
   GridItem it;
-  it.x = st.x[id]; it.y = st.y[id]; it.z = st.z[id];
-  it.yaw = st.yaw[id]; it.pitch = st.pitch[id]; it.roll = st.roll[id];
+  for (int k = 0; k < 6; ++k) it.p[k] = st.pos[6 * (size_t)id + k];
   it.id = id;
   it.tree = st.tree[id];
-  if (!(it.x == it.x)) return;  // NaN placeholder
+  it.pad[0] = it.pad[1] = 0;
   grid_put(g, it);
 }
 
@@ -212,15 +212,9 @@ __device__ __forceinline__ void grid_test(const GridItem& it, const SweepQuery& 
                                           int32_t* __restrict__ hit_idx, double* __restrict__ hit_dist, int cap) {
   if (it.id >= Q.max_id) return;
   if (Q.tree >= 0 && it.tree != Q.tree) return;
-  float dx = it.x - Q.x, dy = it.y - Q.y, dz = it.z - Q.z;
-  float d3 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-  if (!(d3 <= Q.r2f)) return;
-  float da = wrapf(it.yaw - Q.yaw), db = wrapf(it.pitch - Q.pitch), dc = wrapf(it.roll - Q.roll);
-  float d6 = fmaf(dc, dc, fmaf(db, db, fmaf(da, da, d3)));
-  if (!(d6 <= Q.r2f)) return;
-  double np[6], qp[6];
-  for (int k = 0; k < 6; ++k) { np[k] = st.pos[6 * (size_t)it.id + k]; qp[k] = qpos[6 * (size_t)q + k]; }
-  double d = dist6(np, qp);
+  double qp[6];
+  for (int k = 0; k < 6; ++k) qp[k] = qpos[6 * (size_t)q + k];
+  const double d = dist6(it.p, qp);
   if (d < Q.r) {
     int slot = atomicAdd(&cnt[q], 1);
     if (slot < cap) {
@@ -404,9 +398,7 @@ __device__ __forceinline__ void knn_cells(const GridView& g, int m, int cell, in
       const GridItem it = g.items[(size_t)src_cell * g.bk + slot];
       id = it.id;
       if (id < Q.max_id && (Q.tree < 0 || it.tree == Q.tree) && (mates ? id >= Q.mate_base : id < Q.mate_base)) {
-        double np[6];
-        for (int c = 0; c < 6; ++c) np[c] = st.pos[6 * (size_t)id + c];
-        d = dist6(np, Q.pos);
+        d = dist6(it.p, Q.pos);
         cand = true;
       }
     }
@@ -453,9 +445,7 @@ __global__ __launch_bounds__(256) void k_knn_grid(GridView g, GridView tg, NodeS
         const GridItem it = g.ovf[j];
         id = it.id;
         if (id < Q.max_id && id < Q.mate_base && (Q.tree < 0 || it.tree == Q.tree)) {
-          double np[6];
-          for (int c = 0; c < 6; ++c) np[c] = st.pos[6 * (size_t)id + c];
-          d = dist6(np, Q.pos);
+          d = dist6(it.p, Q.pos);
           cand = have < k || key_less(d, id, worst, 0x7fffffff);
         }
       }
@@ -538,11 +528,7 @@ __global__ __launch_bounds__(256) void k_knn_grid(GridView g, GridView tg, NodeS
         if (j < no) {
           const GridItem it = tg.ovf[j];
           id = it.id;
-          if (id < Q.max_id && id >= Q.mate_base && (Q.tree < 0 || it.tree == Q.tree)) {
-            double np[6];
-            for (int c = 0; c < 6; ++c) np[c] = st.pos[6 * (size_t)id + c];
-            cand = dist6(np, Q.pos) <= limit;
-          }
+          if (id < Q.max_id && id >= Q.mate_base && (Q.tree < 0 || it.tree == Q.tree)) cand = dist6(it.p, Q.pos) <= limit;
         }
         const unsigned long long mm = __ballot(cand);
         if (cand) {
@@ -1507,8 +1493,8 @@ __global__ __launch_bounds__(256) void k_classify(ClassifyArgs A) {
 // (no atomics, no hit list in HBM) and classified right away exactly like k_classify does.
 #define QC_WAVES 4
 __device__ __forceinline__ void qc_candidates(const GridView& g, int m, int cell, int lane, const SweepQuery& Q,
-                                              const double* qp, const NodeStoreView& st, int32_t* h_id, double* h_d,
-                                              int32_t* h_tree, int& nh) {
+                                              const double* qp, int32_t* h_id, double* h_d, int32_t* h_tree, double* h_pos,
+                                              int& nh) {
   // exclusive prefix of the per-lane item counts
   int inc = m;
   for (int off = 1; off < 64; off <<= 1) {
@@ -1535,30 +1521,23 @@ __device__ __forceinline__ void qc_candidates(const GridView& g, int m, int cell
     if (j < total) {
       it = g.items[(size_t)src_cell * g.bk + slot];
       if (it.id < Q.max_id && (Q.tree < 0 || it.tree == Q.tree)) {
-        const float dx = it.x - Q.x, dy = it.y - Q.y, dz = it.z - Q.z;
-        const float d3 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-        if (d3 <= Q.r2f) {
-          const float da = wrapf(it.yaw - Q.yaw), db = wrapf(it.pitch - Q.pitch), dc = wrapf(it.roll - Q.roll);
-          const float d6 = fmaf(dc, dc, fmaf(db, db, fmaf(da, da, d3)));
-          if (d6 <= Q.r2f) {
-            double np[6];
-            for (int k = 0; k < 6; ++k) np[k] = st.pos[6 * (size_t)it.id + k];
-            d = dist6(np, qp);
-            hit = d < Q.r;
-          }
-        }
+        d = dist6(it.p, qp);          // the item carries the node's fp64 position: exact at once
+        hit = d < Q.r;
       }
     }
     const unsigned long long hm = __ballot(hit);
     if (hit) {
       const int at = nh + __popcll(hm & ((1ULL << lane) - 1ULL));
-      if (at < 64) { h_id[at] = it.id; h_d[at] = d; h_tree[at] = it.tree; }
+      if (at < 64) {
+        h_id[at] = it.id; h_d[at] = d; h_tree[at] = it.tree;
+        for (int k = 0; k < 6; ++k) h_pos[6 * at + k] = it.p[k];
+      }
     }
     nh += __popcll(hm);
   }
 }
 __device__ __forceinline__ void qc_overflow(const GridView& g, int no, int lane, const SweepQuery& Q, const double* qp,
-                                            const NodeStoreView& st, int32_t* h_id, double* h_d, int32_t* h_tree, int& nh) {
+                                            int32_t* h_id, double* h_d, int32_t* h_tree, double* h_pos, int& nh) {
   if (no > g.ovf_cap) no = g.ovf_cap;
   for (int base = 0; base < no; base += 64) {
     const int j = base + lane;
@@ -1569,24 +1548,17 @@ __device__ __forceinline__ void qc_overflow(const GridView& g, int no, int lane,
     if (j < no) {
       it = g.ovf[j];
       if (it.id < Q.max_id && (Q.tree < 0 || it.tree == Q.tree)) {
-        const float dx = it.x - Q.x, dy = it.y - Q.y, dz = it.z - Q.z;
-        const float d3 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-        if (d3 <= Q.r2f) {
-          const float da = wrapf(it.yaw - Q.yaw), db = wrapf(it.pitch - Q.pitch), dc = wrapf(it.roll - Q.roll);
-          const float d6 = fmaf(dc, dc, fmaf(db, db, fmaf(da, da, d3)));
-          if (d6 <= Q.r2f) {
-            double np[6];
-            for (int k = 0; k < 6; ++k) np[k] = st.pos[6 * (size_t)it.id + k];
-            d = dist6(np, qp);
-            hit = d < Q.r;
-          }
-        }
+        d = dist6(it.p, qp);
+        hit = d < Q.r;
       }
     }
     const unsigned long long hm = __ballot(hit);
     if (hit) {
       const int at = nh + __popcll(hm & ((1ULL << lane) - 1ULL));
-      if (at < 64) { h_id[at] = it.id; h_d[at] = d; h_tree[at] = it.tree; }
+      if (at < 64) {
+        h_id[at] = it.id; h_d[at] = d; h_tree[at] = it.tree;
+        for (int k = 0; k < 6; ++k) h_pos[6 * at + k] = it.p[k];
+      }
     }
     nh += __popcll(hm);
   }
@@ -1597,6 +1569,7 @@ __global__ __launch_bounds__(64 * QC_WAVES) void k_query_classify(GridView g, Gr
   __shared__ int32_t s_id[QC_WAVES][64];
   __shared__ int32_t s_tree[QC_WAVES][64];
   __shared__ double s_d[QC_WAVES][64];
+  __shared__ double s_pos[QC_WAVES][64 * 6];
   if (A.dev_n) {
     if (A.dev_n[1]) return;
     A.n = A.dev_n[0];
@@ -1629,6 +1602,7 @@ __global__ __launch_bounds__(64 * QC_WAVES) void k_query_classify(GridView g, Gr
     int32_t* h_id = s_id[wave];
     int32_t* h_tree = s_tree[wave];
     double* h_d = s_d[wave];
+    double* h_pos = s_pos[wave];
     int nh = 0;
     // ---- the cells the query ball's box touches
     const float rf = sqrtf(Q.r2f) * 1.000001f;
@@ -1650,11 +1624,11 @@ __global__ __launch_bounds__(64 * QC_WAVES) void k_query_classify(GridView g, Gr
           if (maybe) { mt = tg.cnt[cell]; if (mt > tg.bk) mt = tg.bk; }
         }
       }
-      qc_candidates(g, m, cell, lane, Q, qp, st, h_id, h_d, h_tree, nh);
-      if (tg.cnt && __any(mt > 0)) qc_candidates(tg, mt, cell, lane, Q, qp, st, h_id, h_d, h_tree, nh);
+      qc_candidates(g, m, cell, lane, Q, qp, h_id, h_d, h_tree, h_pos, nh);
+      if (tg.cnt && __any(mt > 0)) qc_candidates(tg, mt, cell, lane, Q, qp, h_id, h_d, h_tree, h_pos, nh);
     }
-    if (no_g > 0) qc_overflow(g, no_g, lane, Q, qp, st, h_id, h_d, h_tree, nh);
-    if (no_t > 0) qc_overflow(tg, no_t, lane, Q, qp, st, h_id, h_d, h_tree, nh);
+    if (no_g > 0) qc_overflow(g, no_g, lane, Q, qp, h_id, h_d, h_tree, h_pos, nh);
+    if (no_t > 0) qc_overflow(tg, no_t, lane, Q, qp, h_id, h_d, h_tree, h_pos, nh);
     // ---- classification (k_classify's logic on the wave's own hit list)
     const int cnt = nh;
     if (cnt > A.cap) {
@@ -1691,7 +1665,7 @@ __global__ __launch_bounds__(64 * QC_WAVES) void k_query_classify(GridView g, Gr
           A.rec_meta[(size_t)i * A.nbcap + rank] = (t << 1) | (same ? 1 : 0);
           const size_t slot = (size_t)i * stride + 1 + rank;
           double nbp[6], ea[6], eb[6];
-          for (int k = 0; k < 6; ++k) nbp[k] = A.pos[6 * (size_t)id + k];
+          for (int k = 0; k < 6; ++k) nbp[k] = h_pos[6 * lane + k];   // (the hit's position came with its grid item)
           if (same) { for (int k = 0; k < 6; ++k) { ea[k] = nbp[k]; eb[k] = qp[k]; } }                 // isPathFree(neighbour, newPoint) :276
           else if (id == A.goal_id) { for (int k = 0; k < 6; ++k) { ea[k] = qp[k]; eb[k] = nbp[k]; } } // isPathFree(newPoint, goal) :287
           else { for (int k = 0; k < 6; ++k) { ea[k] = exp[k]; eb[k] = nbp[k]; } }                     // isPathFree(expanded, neighbour) :288
@@ -1832,19 +1806,11 @@ __global__ __launch_bounds__(256) void k_store_write(NodeStoreMut st, const doub
   st.tree[o] = tr;
   if (with_grid && on) {   // permanent nodes also enter the neighbour grid (replaces a separate k_grid_insert launch)
     GridItem it;
-    it.x = (float)p[0]; it.y = (float)p[1]; it.z = (float)p[2];
-    it.yaw = (float)p[3]; it.pitch = (float)p[4]; it.roll = (float)p[5];
+    for (int k = 0; k < 6; ++k) it.p[k] = p[k];
     it.id = (int)o;
     it.tree = tr;
-    const int cx = grid_coord(it.x, g.ox, g.inv_cell, g.nx), cy = grid_coord(it.y, g.oy, g.inv_cell, g.ny),
-              cz = grid_coord(it.z, g.oz, g.inv_cell, g.nz);
-    const size_t cell = ((size_t)cz * g.ny + cy) * g.nx + cx;
-    const int slot = atomicAdd(g.cnt + cell, 1);
-    if (slot < g.bk) g.items[cell * g.bk + slot] = it;
-    else {
-      const int ov = atomicAdd(g.ovf_cnt, 1);
-      if (ov < g.ovf_cap) g.ovf[ov] = it;
-    }
+    it.pad[0] = it.pad[1] = 0;
+    grid_put(g, it);
   }
 }
 

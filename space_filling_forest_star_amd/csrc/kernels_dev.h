@@ -18,7 +18,7 @@ __device__ __forceinline__ size_t grid_cell_of(const GridView& g, float x, float
   return ((size_t)cz * g.ny + cy) * g.nx + cx;
 }
 __device__ __forceinline__ void grid_put(const GridView& g, const GridItem& it) {
-  const size_t cell = grid_cell_of(g, it.x, it.y, it.z);
+  const size_t cell = grid_cell_of(g, (float)it.p[0], (float)it.p[1], (float)it.p[2]);
   const int slot = atomicAdd(g.cnt + cell, 1);
   if (g.occ) atomicOr(g.occ + (cell >> 5), 1u << (cell & 31));
   if (slot < g.bk) {
