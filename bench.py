@@ -6,8 +6,9 @@ SFF solver, 1M-node budget (authored step circum=14 / dtree=18: SURVEY.md §8(d)
 
 A "step" is a fixed block of `--waves-per-step` waves of the tree-expansion loop (a wave = `--wave` frontier
 slots, each sampled / neighbour-queried / collision-checked for up to ThresholdMisses rounds, then committed in
-order).  With the defaults (and the driver's `--steps 20 --warmup 5`) the 20 timed steps of 13 waves span the WHOLE
-job: 10 roots -> the 1M-node budget (~258 waves).  The warm-up steps run on a separate, discarded forest of the
+order).  With the defaults (and the driver's `--steps 20 --warmup 5`) the 20 timed steps of 9 waves span the WHOLE
+job: 10 roots -> the 1M-node budget (166 waves of 16384 slots; the CPU oracle's run of exactly this job is pinned in
+tests/golden/full_size_run_w16384.json and the GPU must reproduce it node for node).  The warm-up steps run on a separate, discarded forest of the
 same workload so that the timed region starts from the roots with warm kernels, allocations and caches.
 `value` = accepted node expansions per second over the timed steps, whole job, with the map, the robot and the
 node store resident in HBM before the timed region starts.
@@ -40,9 +41,9 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--wave", type=int, default=8192)
-    ap.add_argument("--waves-per-step", type=int, default=13,
-                    help="waves per bench step: 20 steps x 13 waves of 8192 slots reach the 1M-node budget")
+    ap.add_argument("--wave", type=int, default=16384)
+    ap.add_argument("--waves-per-step", type=int, default=9,
+                    help="waves per bench step: 20 steps x 9 waves of 16384 slots reach the 1M-node budget (166 waves)")
     ap.add_argument("--budget", type=int, default=1000000)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--force-dist", action="store_true", help="run the RCCL record exchange even with one rank")

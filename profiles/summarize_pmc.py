@@ -18,8 +18,8 @@ bp = argparse.ArgumentParser()
 bp.add_argument("--gpus", type=int, default=1)
 bp.add_argument("--steps", type=int, default=20)
 bp.add_argument("--warmup", type=int, default=5)
-bp.add_argument("--wave", type=int, default=8192)
-bp.add_argument("--waves-per-step", type=int, default=13)
+bp.add_argument("--wave", type=int, default=16384)
+bp.add_argument("--waves-per-step", type=int, default=9)
 bp.add_argument("--budget", type=int, default=1000000)
 bp.add_argument("--seed", type=int, default=1)
 b, _ = bp.parse_known_args(a.bench_args.split())

@@ -164,7 +164,7 @@ Ctx::~Ctx() {
   for (auto e : pool) (void)hipEventDestroy(e);
   DevBuf* bufs[] = {&env_tri, &env_box, &env_plane, &rob_tri, &sx, &sy, &sz, &syaw, &spitch, &sroll, &stree, &spos,
                     &d_a, &d_b, &d_c, &d_d, &d_e, &d_f, &d_g, &d_h, &r_in, &r_out, &r_q, &r_cnt, &r_hidx,
-                    &r_hdist, &r_sega, &r_segb, &r_items, &r_items2, &env_clear, &g_cnt, &g_items, &g_ovfcnt, &g_ovf, &t_cnt, &t_items, &t_ovfcnt, &t_ovf, &t_occ};
+                    &r_hdist, &r_sega, &r_segb, &r_items, &r_items2, &env_clear, &g_cnt, &g_items, &g_ovfcnt, &g_ovf, &t_cnt, &t_items, &t_ovfcnt, &t_ovf, &t_occ, &env_tg_start, &env_tg_list};
   for (DevBuf* b : bufs) b->release();
   for (auto& b : level_box) b.release();
   PinBuf* pins[] = {&h_a, &h_b, &h_c, &h_d, &h_e, &h_f, &h_g, &h_h, &p_in, &p_out};
@@ -261,6 +261,7 @@ void Ctx::upload_mesh(int role, const double* tri9, int n) {
     robv.radius = rad;
     have_robot = true;
     build_clearance();
+    build_tri_grid();
     return;
   }
   if (role != SFFGPU_MESH_ENV) throw HipError{"unknown mesh role"};
@@ -348,6 +349,7 @@ void Ctx::upload_mesh(int role, const double* tri9, int n) {
   }
   envv.n_levels = L;
   build_clearance();
+  build_tri_grid();
 }
 
 // Clearance bits over the environment box (kernels.h, EnvView): one bit per cell, set when a robot whose
@@ -393,6 +395,47 @@ void Ctx::build_clearance() {
   HIPCHK(hipStreamSynchronize(stream));
   envv.clear_bits = env_clear.as<uint32_t>();
   clear_cells = cells;
+}
+
+// Triangle grid over the environment's box (kernels.h, EnvView): cell edge = a third of the largest query box the
+// collision kernels ask with (robot extent + one 64-sample chunk of an edge, 6.4 units), but at most 128 cells per
+// axis.  Built on the device in two passes around a host prefix sum.
+void Ctx::build_tri_grid() {
+  envv.tg_start = nullptr;
+  envv.tg_list = nullptr;
+  if (!have_env || !have_robot || envv.n_tri <= 0 || envv.n_levels < 1) return;
+  if (const char* e = getenv("SFFGPU_NO_TRIGRID")) if (atoi(e)) return;
+  double rext = 0, ext = 0;
+  for (int a = 0; a < 3; ++a) {
+    rext = std::max(rext, robv.hi[a] - robv.lo[a]);
+    ext = std::max(ext, env_hi[a] - env_lo[a]);
+  }
+  rext = std::max(rext, 2 * robv.radius);
+  if (!(ext > 0)) return;
+  const double h = std::max((rext + 6.4) / 3.0, ext / 128.0);
+  long long cells = 1;
+  for (int a = 0; a < 3; ++a) {
+    envv.tg_org[a] = env_lo[a];
+    envv.tg_n[a] = std::max(1, (int)std::ceil((env_hi[a] - env_lo[a]) / h + 1e-9));
+    cells *= envv.tg_n[a];
+  }
+  envv.tg_inv = 1.0 / h;
+  if (cells > (1LL << 24)) return;
+  env_tg_start.ensure((size_t)(cells + 1) * 4);
+  sffk::launch_tgrid_build(stream, envv, env_tg_start.as<int32_t>(), nullptr, false);
+  std::vector<int32_t> cnt((size_t)cells + 1, 0);
+  HIPCHK(hipMemcpyAsync(cnt.data(), env_tg_start.p, (size_t)cells * 4, hipMemcpyDeviceToHost, stream));
+  HIPCHK(hipStreamSynchronize(stream));
+  long long run = 0;
+  for (long long c = 0; c < cells; ++c) { const int32_t m = cnt[(size_t)c]; cnt[(size_t)c] = (int32_t)run; run += m; }
+  cnt[(size_t)cells] = (int32_t)run;
+  if (run > (1LL << 30)) return;
+  env_tg_list.ensure((size_t)std::max<long long>(run, 1) * 4);
+  HIPCHK(hipMemcpyAsync(env_tg_start.p, cnt.data(), (size_t)(cells + 1) * 4, hipMemcpyHostToDevice, stream));
+  sffk::launch_tgrid_build(stream, envv, env_tg_start.as<int32_t>(), env_tg_list.as<int32_t>(), true);
+  HIPCHK(hipStreamSynchronize(stream));
+  envv.tg_start = env_tg_start.as<int32_t>();
+  envv.tg_list = env_tg_list.as<int32_t>();
 }
 
 // ------------------------------------------------------------------ node store

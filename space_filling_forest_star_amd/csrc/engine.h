@@ -83,6 +83,8 @@ struct Ctx {
   double env_lo[3] = {0, 0, 0}, env_hi[3] = {0, 0, 0};
   long long clear_cells = 0;   // cells of the clearance grid (0 = none)
   void build_clearance();
+  void build_tri_grid();       // cell -> triangle lists for the collision kernels' broad phase
+  DevBuf env_tg_start, env_tg_list;
 
   // node store
   int store_cap = 0, store_n = 0;

@@ -695,6 +695,15 @@ void Forest::run_device(int max_waves) {
             "next list+counters %.1f | dependent/round %.0f\n", k.prof[0] / r / 100.0, k.prof[1] / r / 100.0, k.prof[5] / r,
             (unsigned long long)k.prof[7], k.prof[2] / r / 100.0, k.prof[3] / r / 100.0, k.prof[4] / r / 100.0,
             (double)k.n_unsettled / r);
+#ifdef SFFK_DEBUG_COUNTERS
+    unsigned long long g[16];
+    sffk::debug_counters(g);
+    const double items = (double)std::max<unsigned long long>(1ULL, g[1]);
+    fprintf(stderr, "[sffgpu exact kernel, per masked chunk] chunks %llu (with work %llu, with candidates %llu) flushes %.2f "
+            "candidates %.1f | us: setup %.2f hierarchy %.2f narrow %.2f | per wave total %.1f us over %llu waves\n",
+            g[0], g[1], g[2], g[3] / items, g[7] / items, g[4] / items / 100.0, g[5] / items / 100.0, g[6] / items / 100.0,
+            (double)g[8] / (double)std::max<unsigned long long>(1ULL, g[9]) / 100.0, g[9]);
+#endif
   }
 }
 

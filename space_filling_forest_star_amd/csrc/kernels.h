@@ -78,7 +78,17 @@ struct EnvView {
   double clear_org[3];
   double clear_inv;       // 1 / cell edge
   int clear_n[3];
+  // triangle grid (built once both meshes are known): cell -> the triangles that touch it, CSR.  A query box gets its
+  // candidate triangles in two dependent loads (cell ranges, triangle ids) instead of walking the box hierarchy
+  // group by group (11 us of the exact kernel's 21 us per work item went there).  null = not built.
+  const int32_t* tg_start; // n cells + 1
+  const int32_t* tg_list;
+  double tg_org[3];
+  double tg_inv;
+  int tg_n[3];
 };
+// triangle grid build: per cell the number of triangles touching it (cnt), then - after the host's prefix sum - their ids
+void launch_tgrid_build(hipStream_t s, const EnvView& env, int32_t* cnt_or_start, int32_t* list, bool fill);
 // thr = radius below which a cell centre blocks the cell (robot radius + half cell diagonal + slack)
 void launch_clear_build(hipStream_t s, const EnvView& env, double thr, uint32_t* bits, long long n_cells);
 
@@ -341,5 +351,9 @@ void launch_commit(hipStream_t s, const ResolveArgs& a, int n_bound);
 void launch_wave_end(hipStream_t s, const DevForestView& f, const int32_t* grid_ovf, const int32_t* tgrid_ovf);
 // border table maintenance: re-insert list entries [0, n) after the host grew the table
 void launch_border_rehash(hipStream_t s, const DevForestView& f, int n);
+
+#ifdef SFFK_DEBUG_COUNTERS
+void debug_counters(unsigned long long* out16);   // exact-kernel phase clocks (make EXTRA=-DSFFK_DEBUG_COUNTERS)
+#endif
 
 }  // namespace sffk

@@ -557,6 +557,7 @@ __global__ __launch_bounds__(256) void k_set_tree(int32_t* __restrict__ tree_col
 struct WaveStack {
   int32_t* s;  // LDS, STACK_CAP entries per wave
   int sp;      // wave-uniform
+  int32_t* hash;   // LDS, TG_HASH entries per wave (triangle-grid path)
 };
 #define STACK_CAP 256
 // candidate triangles of an item are staged in LDS 64 at a time: box (6) + plane (5) + vertices (9) doubles each.
@@ -565,6 +566,7 @@ struct WaveStack {
 // profiles/r2g_sq_summary.json).
 #define STAGE_TRI 20
 #define STAGE_DOUBLES (64 * STAGE_TRI)
+#define TG_HASH 512   // per-wave LDS hash set: a triangle listed by several cells of a query enters the candidates once
 __device__ __forceinline__ void stage_candidates(const EnvView& env, const int32_t* cand, int k0, int kc, int lane, double* stage) {
   if (lane < kc) {
     const int t = cand[k0 + lane];
@@ -597,8 +599,83 @@ __device__ __forceinline__ bool box_hit(const double* lo, const double* hi, cons
 // Traverse the 64-ary hierarchy with query box [qlo,qhi]; collects overlapping leaf triangles
 // (indices into the leaf-ordered env arrays) into cand[] (LDS, cap entries).  Returns the
 // number found; *overflow set when a stack or the list ran over.
+// candidates of a query box from the triangle grid: lanes = cells of the box (64 at a time), their CSR ranges are
+// flattened over the lanes (lane = list entry), every triangle id goes through the wave's LDS hash set so that it
+// enters cand[] once however many cells list it
+__device__ int collect_from_grid(const EnvView& env, const double* qlo, const double* qhi, int lane, int32_t* hash,
+                                 int32_t* cand, int cap, bool* overflow) {
+  for (int k = lane; k < TG_HASH; k += 64) hash[k] = 0;
+  __builtin_amdgcn_wave_barrier();
+  int c_lo[3], c_n[3];
+  for (int a = 0; a < 3; ++a) {
+    double flo = (qlo[a] - env.tg_org[a]) * env.tg_inv, fhi = (qhi[a] - env.tg_org[a]) * env.tg_inv;
+    int lo = flo < 0 ? 0 : (flo >= env.tg_n[a] ? env.tg_n[a] - 1 : (int)flo);
+    int hi = fhi < 0 ? 0 : (fhi >= env.tg_n[a] ? env.tg_n[a] - 1 : (int)fhi);
+    if (!(flo == flo)) lo = 0;
+    if (!(fhi == fhi)) hi = env.tg_n[a] - 1;
+    c_lo[a] = lo;
+    c_n[a] = hi - lo + 1;
+  }
+  const int total_cells = c_n[0] * c_n[1] * c_n[2];
+  int n_cand = 0;
+  *overflow = false;
+  for (int c0 = 0; c0 < total_cells; c0 += 64) {
+    const int c = c0 + lane;
+    int start = 0, m = 0;
+    if (c < total_cells) {
+      const int x = c_lo[0] + c % c_n[0], y = c_lo[1] + (c / c_n[0]) % c_n[1], z = c_lo[2] + c / (c_n[0] * c_n[1]);
+      const size_t cell = ((size_t)z * env.tg_n[1] + y) * env.tg_n[0] + x;
+      start = env.tg_start[cell];
+      m = env.tg_start[cell + 1] - start;
+    }
+    int inc = m;
+    for (int off = 1; off < 64; off <<= 1) {
+      const int o = __shfl_up(inc, off);
+      if (lane >= off) inc += o;
+    }
+    const int total = __shfl(inc, 63);
+    for (int base = 0; base < total; base += 64) {
+      const int j = base + lane;
+      const int jj = j < total ? j : total - 1;
+      int lo = 0, hi = 63;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (__shfl(inc, mid) > jj) hi = mid; else lo = mid + 1;
+      }
+      const int src_start = __shfl(start, lo);
+      const int slot = jj - (__shfl(inc, lo) - __shfl(m, lo));
+      bool fresh = false;
+      int t = 0;
+      if (j < total) {
+        t = env.tg_list[src_start + slot];
+        // the triangle's own box against the query box (it touches the cell, not necessarily the query)
+        const double* b = env.tri_box + 6 * (size_t)t;
+        if (box_hit(b, b + 3, qlo, qhi)) {
+          unsigned h = ((unsigned)t * 2654435761u) >> 23;
+          while (true) {
+            h &= TG_HASH - 1;
+            const int old = atomicCAS(&hash[h], 0, t + 1);
+            if (old == 0) { fresh = true; break; }
+            if (old == t + 1) break;
+            ++h;
+          }
+        }
+      }
+      const unsigned long long fm = __ballot(fresh);
+      if (fresh) {
+        const int at = n_cand + __popcll(fm & ((1ULL << lane) - 1ULL));
+        if (at < cap) cand[at] = t;
+      }
+      n_cand += __popcll(fm);
+      if (n_cand > cap || n_cand > TG_HASH / 2) { *overflow = true; return n_cand > cap ? cap : n_cand; }
+    }
+  }
+  return n_cand;
+}
+
 __device__ int collect_candidates(const EnvView& env, const double* qlo, const double* qhi, int lane, WaveStack& st,
                                   int32_t* cand, int cap, bool* overflow) {
+  if (env.tg_start) return collect_from_grid(env, qlo, qhi, lane, st.hash, cand, cap, overflow);
   int n_cand = 0;
   st.sp = 0;
   *overflow = false;
@@ -818,6 +895,43 @@ __global__ __launch_bounds__(256) void k_clear_build(EnvView env, double thr, ui
   }
 }
 
+// ------------------------------------------------------------------ triangle grid build
+// One thread per cell: the triangles whose (slightly inflated) cell box they touch - group boxes first, then the
+// triangle's box, then the exact triangle / box test.  Pass 1 counts, pass 2 (after the host's prefix sum) writes ids.
+__global__ __launch_bounds__(256) void k_tgrid_build(EnvView env, int32_t* __restrict__ cnt_or_start,
+                                                     int32_t* __restrict__ list, int fill) {
+  const long long n_cells = (long long)env.tg_n[0] * env.tg_n[1] * env.tg_n[2];
+  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n_cells) return;
+  const int nx = env.tg_n[0], ny = env.tg_n[1];
+  const long long iz = idx / ((long long)nx * ny), rem = idx - iz * (long long)nx * ny;
+  const long long iy = rem / nx, ix = rem - iy * nx;
+  const double h = 1.0 / env.tg_inv, eps = 1e-6 * h;
+  const double lo[3] = {env.tg_org[0] + (double)ix * h - eps, env.tg_org[1] + (double)iy * h - eps, env.tg_org[2] + (double)iz * h - eps};
+  const double hi[3] = {env.tg_org[0] + (double)(ix + 1) * h + eps, env.tg_org[1] + (double)(iy + 1) * h + eps,
+                        env.tg_org[2] + (double)(iz + 1) * h + eps};
+  int n = 0;
+  int at = fill ? cnt_or_start[idx] : 0;
+  const int n_groups = env.level_count[0];
+  for (int g = 0; g < n_groups; ++g) {
+    const double* gb = env.level_box[0] + 6 * (size_t)g;
+    if (!box_hit(gb, gb + 3, lo, hi)) continue;
+    const int t1 = g * 64 + 64 < env.n_tri ? g * 64 + 64 : env.n_tri;
+    for (int t = g * 64; t < t1; ++t) {
+      const double* b = env.tri_box + 6 * (size_t)t;
+      if (!box_hit(b, b + 3, lo, hi)) continue;
+      if (!tri_box_overlap(lo, hi, env.tri + 9 * (size_t)t)) continue;
+      if (fill) list[at++] = t;
+      ++n;
+    }
+  }
+  if (!fill) cnt_or_start[idx] = n;
+}
+void launch_tgrid_build(hipStream_t s, const EnvView& env, int32_t* cnt_or_start, int32_t* list, bool fill) {
+  const long long n_cells = (long long)env.tg_n[0] * env.tg_n[1] * env.tg_n[2];
+  hipLaunchKernelGGL(k_tgrid_build, dim3((unsigned)((n_cells + 255) / 256)), dim3(256), 0, s, env, cnt_or_start, list, fill ? 1 : 0);
+}
+
 #ifdef SFFK_DEBUG_COUNTERS
 __device__ unsigned long long g_dbg[16];
 struct DbgAcc { unsigned long long v[12]; };
@@ -859,7 +973,7 @@ __device__ bool pose_exact(const EnvView& env, const RobotView& rob, const doubl
   double rr = rob.radius * (1 + 1e-9) + 1e-9 * (fabs(c[0]) + fabs(c[1]) + fabs(c[2]) + 1);
   for (int k = 0; k < 3; ++k) { qlo[k] = c[k] - rr; qhi[k] = c[k] + rr; }
 
-  WaveStack st{stack, 0};
+  WaveStack st{stack, 0, stack + STACK_CAP};
   bool overflow;
   int nc = collect_candidates(env, qlo, qhi, lane, st, cand, CAND_CAP, &overflow);
   bool hit = false;
@@ -917,8 +1031,8 @@ __global__ __launch_bounds__(64 * POSE_WAVES) void k_collide_poses(EnvView env, 
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   double* stage = rtri + (size_t)rob.n_tri * 9 + (size_t)wave * STAGE_DOUBLES;
   int32_t* ibase = reinterpret_cast<int32_t*>(rtri + (size_t)rob.n_tri * 9 + (size_t)POSE_WAVES * STAGE_DOUBLES);
-  int32_t* stack = ibase + wave * STACK_CAP;
-  int32_t* cand = ibase + POSE_WAVES * STACK_CAP + wave * CAND_CAP;
+  int32_t* stack = ibase + wave * (STACK_CAP + TG_HASH);   // (+ the wave's triangle-grid hash set behind its stack)
+  int32_t* cand = ibase + POSE_WAVES * (STACK_CAP + TG_HASH) + wave * CAND_CAP;
   // which poses of this workgroup need the exact test at all (most do not: clearance bits)
   const int pose = blockIdx.x * POSE_WAVES + wave;
   bool need = false;
@@ -991,7 +1105,7 @@ __device__ void segment_chunk(const EnvView& env, const RobotView& rob, const do
     qlo[k] = lo + rob.lo[k] - slack;
     qhi[k] = hi + rob.hi[k] + slack;
   }
-  WaveStack st{stack, 0};
+  WaveStack st{stack, 0, stack + STACK_CAP};
   bool overflow;
   int nc = collect_candidates(env, qlo, qhi, lane, st, cand, CAND_CAP, &overflow);
   [[maybe_unused]] const unsigned long long t2_ = DBG_T();
@@ -1282,9 +1396,9 @@ __global__ __launch_bounds__(64 * SEG_WAVES) void k_collide_segments_dyn(EnvView
   for (int i = threadIdx.x; i < rob.n_tri * 9; i += blockDim.x) rtri[i] = rob.tri[i];
   __syncthreads();
   if (env.n_tri == 0) return;
-  int32_t* stack = ibase + wave * STACK_CAP;
-  int32_t* cand = ibase + SEG_WAVES * STACK_CAP + wave * CAND_CAP;
-  int32_t* queue = ibase + SEG_WAVES * (STACK_CAP + CAND_CAP) + wave * QUEUE_CAP;
+  int32_t* stack = ibase + wave * (STACK_CAP + TG_HASH);   // (+ the wave's triangle-grid hash set behind its stack)
+  int32_t* cand = ibase + SEG_WAVES * (STACK_CAP + TG_HASH) + wave * CAND_CAP;
+  int32_t* queue = ibase + SEG_WAVES * (STACK_CAP + TG_HASH + CAND_CAP) + wave * QUEUE_CAP;
   DBG_DECL
   [[maybe_unused]] const unsigned long long tk_ = DBG_T();
   const int W = gridDim.x * SEG_WAVES;
@@ -1817,7 +1931,7 @@ __global__ __launch_bounds__(256) void k_store_write(NodeStoreMut st, const doub
 // ------------------------------------------------------------------ launchers
 size_t collide_lds_bytes(int n_robot_tri, int waves) {
   return (size_t)n_robot_tri * 9 * sizeof(double) + (size_t)waves * STAGE_DOUBLES * sizeof(double) +
-         (size_t)waves * (STACK_CAP + CAND_CAP + QUEUE_CAP) * sizeof(int32_t);
+         (size_t)waves * (STACK_CAP + CAND_CAP + QUEUE_CAP + TG_HASH) * sizeof(int32_t);
 }
 
 void launch_sample_steer(hipStream_t s, const uint64_t* words, const int32_t* parent, const double* node_pos,

@@ -287,6 +287,32 @@ def test_gpu_matches_committed_golden_runs(S, ctx, golden_dir):
         r.close()
 
 
+def test_full_size_run_at_the_bench_wave_equals_the_oracle(S, ctx, golden_dir):
+    """The headline job exactly as bench.py runs it (waves of 16 384 slots, to the 1 M-node budget) against the CPU
+    oracle's run of the same configuration (tests/golden/full_size_run_w16384.json, FULL_SIZE_WAVE=16384
+    FULL_SIZE_WAVES=0 tests/golden/make_full_size.py): fingerprint over every node, counters, checksums."""
+    import json
+    import os
+    path = os.path.join(golden_dir, "full_size_run_w16384.json")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/full_size_run_w16384.json not generated")
+    g = json.load(open(path))
+    sc, w = load_world(ctx, "dense3d")
+    roots = common.free_roots(lambda p: int(ctx.collide_poses(p[None, :])[0]), sc["limits"], 10, seed=1)
+    f = S.Forest(ctx, roots, sc["limits"], dist_tree=sc["dist_tree"], sampling_dist=sc["sampling_dist"], dim=6,
+                 max_iterations=2**31 - 1, node_budget=1000000, wave=g["wave"], seed=1)
+    f.run()
+    s, n = f.stats(), f.nodes()
+    got = {"waves": int(s["waves"]), "fingerprint": "%016x" % f.fingerprint(), "n_nodes": int(s["n_nodes"]),
+           "iterations": int(s["iterations"]), "collide_calls": int(s["collide_calls"]),
+           "path_free_calls": int(s["path_free_calls"]), "nn_queries": int(s["nn_queries"]), "n_borders": int(s["n_borders"]),
+           "parent_sum": int(n["parent"].astype(np.int64).sum()), "cost_sum": float(n["cost"].sum()).hex()}
+    for k in got:
+        assert got[k] == g[k], (k, got[k], g[k])
+    assert got["n_nodes"] >= 1000000
+    f.close()
+
+
 def test_full_size_headline_run_equals_the_oracle(S, ctx, golden_dir):
     """BASELINE's headline configuration at full size (dense_3D, 10 roots, 1 M-node budget, waves of 8192 slots,
     3 + 255 waves = what bench.py times): the GPU run must reproduce the committed summary of the CPU oracle's run
