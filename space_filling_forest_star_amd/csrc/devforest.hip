@@ -199,6 +199,7 @@ __global__ __launch_bounds__(256) void k_decide(ResolveArgs A) {
   const int n = f.ctrl->n_act;
   const int i = blockIdx.x * 256 + threadIdx.x;
   unsigned long long cc = 0, pf = 0, nq = 0, ex_pose = 0, ex_seg = 0, ex_smp = 0;
+  int verdict = -1;
   if (i < n) {
     int code = SFFK_REJECTED, dk = 0;
     if (!A.in_lim[i]) code = SFFK_OUTSIDE;
@@ -249,6 +250,15 @@ __global__ __launch_bounds__(256) void k_decide(ResolveArgs A) {
     }
     A.code[i] = (uint8_t)code;
     f.dk[i] = (uint8_t)dk;
+    // sample state for the commit: 0 undecided (depends on a round-mate), 1 rejected, 2 accepted, 3 rejected + border event
+    f.ustate[i] = code == SFFK_DEPENDS ? 0 : (code == SFFK_ACCEPT ? 2 : (code == SFFK_REJECT_EVENT ? 3 : 1));
+    verdict = code;
+  }
+  {   // one word per 64 samples for each of the three lists k_resolve works on
+    const unsigned long long wd = __ballot(verdict == SFFK_DEPENDS), wa = __ballot(verdict == SFFK_ACCEPT),
+                             we = __ballot(verdict == SFFK_REJECT_EVENT);
+    const int g = (blockIdx.x * 256 + (threadIdx.x & ~63)) >> 6;
+    if ((threadIdx.x & 63) == 0 && g * 64 < n) { f.w_dep[g] = wd; f.w_acc[g] = wa; f.w_ev[g] = we; }
   }
   for (int off = 32; off > 0; off >>= 1) {
     cc += __shfl_xor(cc, off); pf += __shfl_xor(pf, off); nq += __shfl_xor(nq, off);
@@ -285,6 +295,8 @@ __global__ __launch_bounds__(DF_THREADS) void k_resolve(ResolveArgs A) {
   __shared__ DevCtrl K;              // the control block, worked on in LDS and written back once
   __shared__ int ev_nb_s[DF_EV_LDS], ev_ex_s[DF_EV_LDS];
   __shared__ unsigned int ev_h_s[DF_EV_LDS];
+  __shared__ unsigned long long W_acc[DF_MAX_GROUPS], W_ev[DF_MAX_GROUPS];   // accepted / border-event words of the round
+  __shared__ int W_accp[DF_MAX_GROUPS];
   const DevForestView& f = A.f;
   DevCtrl* c = f.ctrl;
   if (threadIdx.x == 0) c->app_n = 0;
@@ -313,22 +325,23 @@ __global__ __launch_bounds__(DF_THREADS) void k_resolve(ResolveArgs A) {
   __syncthreads();
   const int Tb = f.temp_base, N0 = K.N0, fn0 = K.frontier_n, nb0 = K.n_borders, act_cnt = K.act_cnt;
   const int act_sel = K.act_sel;
-  const int32_t* act_old = act_sel ? f.act_slot2 : f.act_slot;
-  int32_t* act_new = act_sel ? f.act_slot : f.act_slot2;
   const unsigned long long stamp_hi = (K.epoch + 1ULL) << 32;
   const int stride = A.stride, nbcap = A.nbcap;
+  const int ng = (n + 63) >> 6;
   if (threadIdx.x == 0) { cnt_s[0] = cnt_s[1] = 0ULL; }
   unsigned long long tk[6];
   tk[0] = wall_clock64();
-  // ---- 1. states from k_decide's verdicts; the samples that wait for an earlier sample of the round, in slot order
-  wg_flags(L, n, [&](int i) {
-    const int code = A.code[i];
-    f.ustate[i] = code == SFFK_DEPENDS ? 0 : (code == SFFK_ACCEPT ? 2 : (code == SFFK_REJECT_EVENT ? 3 : 1));
-    return code == SFFK_DEPENDS;
-  });
+  // ---- 1. k_decide's words: dependent samples (they wait for an earlier sample of the round), accepted, border events
+  for (int g = threadIdx.x; g < ng; g += DF_THREADS) { L.words[g] = f.w_dep[g]; W_acc[g] = f.w_acc[g]; W_ev[g] = f.w_ev[g]; }
   const int n_dep = wg_prefix(L, n);
-  for (int i = threadIdx.x; i < n; i += DF_THREADS)
-    if (wg_flagged(L, i)) f.ulist[wg_rank(L, i)] = i;
+  for (int g = threadIdx.x; g < ng; g += DF_THREADS) {   // the dependent list, in slot order (set bits only)
+    unsigned long long w = L.words[g];
+    int at = L.pref[g];
+    while (w) {
+      f.ulist[at++] = g * 64 + __ffsll((long long)w) - 1;
+      w &= w - 1;
+    }
+  }
   __threadfence_block();
   __syncthreads();
   // ---- 2. fixed point: a dependent sample continues its neighbour walk (order of src/forest.h:262-300) at the
@@ -369,7 +382,8 @@ __global__ __launch_bounds__(DF_THREADS) void k_resolve(ResolveArgs A) {
       }
       if (verdict == 0) { mine_undecided = 1; continue; }
       cc += c1; pf += p1;
-      if (verdict == 3) f.dk[i] = (uint8_t)ev_nb;
+      if (verdict == 3) { f.dk[i] = (uint8_t)ev_nb; atomicOr(&W_ev[i >> 6], 1ULL << (i & 63)); }
+      if (verdict == 2) atomicOr(&W_acc[i >> 6], 1ULL << (i & 63));
       __threadfence_block();
       f.ustate[i] = (uint8_t)verdict;
     }
@@ -378,26 +392,34 @@ __global__ __launch_bounds__(DF_THREADS) void k_resolve(ResolveArgs A) {
     if (!undecided_s) break;
     __syncthreads();
   }
-  // ---- 3. node ids of the accepted samples: N0 + rank in slot order (k_append writes the nodes)
+  // ---- 3. node ids of the accepted samples: N0 + rank in slot order.  Only the words are touched here; k_append
+  // turns (word, prefix) into ids, store entries and the next round's active list.
   tk[2] = wall_clock64();
   __syncthreads();
-  wg_flags(L, n, [&](int i) { return f.ustate[i] == 2; });
+  for (int g = threadIdx.x; g < ng; g += DF_THREADS) L.words[g] = W_acc[g];
   const int n_acc = wg_prefix(L, n);
-  for (int i = threadIdx.x; i < n; i += DF_THREADS)
-    if (wg_flagged(L, i)) f.uacc[i] = N0 + wg_rank(L, i);
-  __threadfence_block();
+  for (int g = threadIdx.x; g < ng; g += DF_THREADS) { f.w_acc[g] = L.words[g]; f.acc_pref[g] = L.pref[g]; W_accp[g] = L.pref[g]; }
   __syncthreads();
+  auto id_of = [&](int j) {   // node id of sample j, accepted in this round
+    return N0 + W_accp[j >> 6] + __popcll(W_acc[j >> 6] & ((1ULL << (j & 63)) - 1ULL));
+  };
   // ---- 4. border events (a free edge to a neighbour of another tree, :288-294), first in slot order wins
   tk[3] = wall_clock64();
-  wg_flags(L, n, [&](int i) { return f.ustate[i] == 3; });
+  for (int g = threadIdx.x; g < ng; g += DF_THREADS) L.words[g] = W_ev[g];
   const int n_evc = wg_prefix(L, n);
-  for (int i = threadIdx.x; i < n; i += DF_THREADS)
-    if (wg_flagged(L, i)) f.ulist[wg_rank(L, i)] = i;          // (the dependent list is done with: reuse)
+  for (int g = threadIdx.x; g < ng; g += DF_THREADS) {
+    unsigned long long w = L.words[g];
+    int at = L.pref[g];
+    while (w) {
+      f.ulist[at++] = g * 64 + __ffsll((long long)w) - 1;          // (the dependent list is done with: reuse)
+      w &= w - 1;
+    }
+  }
   __threadfence_block();
   __syncthreads();
   auto event_of = [&](int i, int& nb, int& ex, unsigned long long& key) {
     const int raw = A.rec_nb[(size_t)i * nbcap + f.dk[i]];
-    nb = raw >= Tb ? f.uacc[raw - Tb] : raw;       // (a round-mate neighbour was accepted: its new id)
+    nb = raw >= Tb ? id_of(raw - Tb) : raw;        // (a round-mate neighbour was accepted: its new id)
     ex = A.parent[i];
     const int a = nb < ex ? nb : ex, b = nb < ex ? ex : nb;
     key = ((unsigned long long)(uint32_t)a << 32) | ((unsigned long long)(uint32_t)b + 1ULL);
@@ -412,7 +434,7 @@ __global__ __launch_bounds__(DF_THREADS) void k_resolve(ResolveArgs A) {
     if (e < DF_EV_LDS) { ev_nb_s[e] = nb; ev_ex_s[e] = ex; ev_h_s[e] = (unsigned int)h; }
     atomicMin(&f.bt_val[h], stamp_hi | (unsigned long long)(uint32_t)i);
   }
-  __threadfence_block();   // (one workgroup: its L1 and the barrier order everything; an agent-scope fence would write the L2 back)
+  __threadfence_block();
   __syncthreads();
   wg_flags(L, n_evc, [&](int e) {
     const int i = f.ulist[e];
@@ -462,19 +484,12 @@ __global__ __launch_bounds__(DF_THREADS) void k_resolve(ResolveArgs A) {
     f.pair[(size_t)ta * f.n_trees + tb] = 1;
     f.pair[(size_t)tb * f.n_trees + ta] = 1;
   }
-  // ---- 5. the next round's active list: the slots of this round that were not accepted, then the slots the
-  // iteration cap kept out of this round
+  // ---- 5. counters, sizes (the next round's active list = the slots of this round that were not accepted, then
+  // the slots the iteration cap kept out of it: k_append writes it from the accepted words)
   tk[4] = wall_clock64();
-  __syncthreads();
-  wg_flags(L, n, [&](int i) { return f.ustate[i] != 2; });
-  const int n_still = wg_prefix(L, n);
-  for (int i = threadIdx.x; i < n; i += DF_THREADS)
-    if (wg_flagged(L, i)) act_new[wg_rank(L, i)] = act_old[i];
-  for (int i = n + threadIdx.x; i < act_cnt; i += DF_THREADS) act_new[n_still + (i - n)] = act_old[i];
-  // ---- 6. counters, sizes
   for (int off = 32; off > 0; off >>= 1) { cc += __shfl_xor(cc, off); pf += __shfl_xor(pf, off); }
   if ((threadIdx.x & 63) == 0 && (cc | pf)) { atomicAdd(&cnt_s[0], cc); atomicAdd(&cnt_s[1], pf); }
-  __threadfence_block();   // (one workgroup: its L1 and the barrier order everything; an agent-scope fence would write the L2 back)
+  __threadfence_block();
   __syncthreads();
   if (threadIdx.x == 0) {
     K.collide_calls += cnt_s[0] + A.bulk[0];
@@ -489,6 +504,7 @@ __global__ __launch_bounds__(DF_THREADS) void k_resolve(ResolveArgs A) {
     K.app_N0 = N0;
     K.app_fn0 = fn0;
     K.app_act_sel = act_sel;
+    K.app_act_cnt = act_cnt;
     K.iter0_app = K.iter0;
     K.n_nodes = N0 + n_acc;
     K.frontier_n = fn0 + n_acc;
@@ -496,7 +512,7 @@ __global__ __launch_bounds__(DF_THREADS) void k_resolve(ResolveArgs A) {
     K.n_unsettled += n_dep;
     K.epoch += 1ULL;
     K.act_sel = act_sel ^ 1;
-    K.act_cnt = n_still + (act_cnt - n);
+    K.act_cnt = (n - n_acc) + (act_cnt - n);
     round_begin_scalars(f, &K);
     tk[5] = wall_clock64();
     for (int q = 0; q < 5; ++q) K.prof[q] += tk[q + 1] - tk[q];
@@ -509,19 +525,31 @@ __global__ __launch_bounds__(DF_THREADS) void k_resolve(ResolveArgs A) {
     reinterpret_cast<int32_t*>(c)[w] = reinterpret_cast<const int32_t*>(&K)[w];
 }
 
-
-
 // k_append (wide): the accepted samples become nodes - store columns, node records, neighbour grid, frontier
 // (src/forest.h:353-367).  Runs although the NEXT round may already be halted: this commit is final.
 __global__ __launch_bounds__(256) void k_append(ResolveArgs A) {
   const DevForestView& f = A.f;
   const DevCtrl* c = f.ctrl;
   const int n = c->app_n;
+  if (n <= 0) return;
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n || f.ustate[i] != 2) return;
+  const int act_cnt = c->app_act_cnt;
+  const int32_t* act_old = c->app_act_sel ? f.act_slot2 : f.act_slot;
+  int32_t* act_new = c->app_act_sel ? f.act_slot : f.act_slot2;
+  if (i >= n) {
+    // the slots the iteration cap kept out of the committed round stay on the list, behind the still-failing ones
+    if (i < act_cnt) act_new[(c->act_cnt - (act_cnt - n)) + (i - n)] = act_old[i];
+    return;
+  }
+  const unsigned long long w = f.w_acc[i >> 6];
+  const int rank = f.acc_pref[i >> 6] + __popcll(w & ((1ULL << (i & 63)) - 1ULL));
+  if (!((w >> (i & 63)) & 1ULL)) {
+    act_new[i - rank] = act_old[i];     // not accepted: the slot tries again (rank = accepted samples before it)
+    return;
+  }
   const int N0 = c->app_N0, fn0 = c->app_fn0;
   int32_t* const frontier = frontier_now(f);
-  const int id = f.uacc[i];
+  const int id = N0 + rank;
   const int ex = A.parent[i];
   const double* p = A.newpos + 6 * (size_t)i;
   const size_t o = (size_t)id;
@@ -540,7 +568,7 @@ __global__ __launch_bounds__(256) void k_append(ResolveArgs A) {
   f.d_root[o] = pd + f.d_root[ex];
   f.iter[o] = (uint32_t)(c->iter0_app + i + 1);
   f.nflag[o] = 2;
-  frontier[fn0 + (id - N0)] = id;                    // :365
+  frontier[fn0 + rank] = id;                         // :365
   grid_put(A.g, it);                                 // flannIndex->addPoints, :367
 }
 

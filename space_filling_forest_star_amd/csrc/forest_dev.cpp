@@ -56,6 +56,10 @@ sffk::DevForestView Forest::dev_view() const {
   v.act_slot = d.act_slot.as<int32_t>();
   v.act_slot2 = d.act_slot2.as<int32_t>();
   v.dk = d.dk.as<uint8_t>();
+  v.w_dep = d.w_dep.as<unsigned long long>();
+  v.w_acc = d.w_acc.as<unsigned long long>();
+  v.w_ev = d.w_ev.as<unsigned long long>();
+  v.acc_pref = d.acc_pref.as<int32_t>();
   v.b_n1 = d.b_n1.as<int32_t>();
   v.b_n2 = d.b_n2.as<int32_t>();
   v.b_ta = d.b_ta.as<int32_t>();
@@ -179,6 +183,10 @@ void Forest::dev_upload_state() {
     d.act_slot.ensure((size_t)wave * 4);
     d.act_slot2.ensure((size_t)wave * 4);
     d.dk.ensure((size_t)wave);
+    d.w_dep.ensure(((size_t)wave / 64 + 2) * 8);
+    d.w_acc.ensure(((size_t)wave / 64 + 2) * 8);
+    d.w_ev.ensure(((size_t)wave / 64 + 2) * 8);
+    d.acc_pref.ensure(((size_t)wave / 64 + 2) * 4);
     d.ustate.ensure((size_t)wave);
     d.ulist.ensure((size_t)wave * 4);
     d.uacc.ensure((size_t)wave * 4);

@@ -117,7 +117,7 @@ struct DevCtrl {
   int32_t compact_from;     // entries of the other buffer k_frontier_compact has to sift (0 = nothing to do)
   int32_t act_sel, act_cnt; // which of the two active-slot lists is current; its length (>= n_act: the still-failing slots)
   int32_t app_n, app_N0, app_fn0, app_act_sel;   // the commit k_append has to apply (app_n = 0: none)
-  int32_t iter0_app, pad_app;
+  int32_t iter0_app, app_act_cnt;
   unsigned long long cursor;        // engine words consumed so far
   unsigned long long words_base;    // cursor at which the current round's sample words start
   unsigned long long collide_calls, path_free_calls, nn_queries;          // reference-equivalent counters
@@ -247,11 +247,29 @@ struct ClassifyArgs {
   int32_t* ctrl;            // [1] next task slot of the persistent edge kernel
   const int32_t* dev_n;     // device mode: {n, halt} (n above is then the launch bound only)
   unsigned long long* qclk; // device mode: {first wave in, last wave out} clock bracket of the query kernel
+  // fused clearance cull (k_query_classify): the wave that wrote a sample's edge tasks looks the clearance bits of
+  // their samples (and of the sample's own pose) up right away and appends only the (edge, 64-sample chunk, mask) /
+  // pose items that need the exact test to `items` (ctrl[2] = count) - no work-list compaction, no cull kernel
+  const EnvView* env_dev;   // unused (the view travels by value, see launch_query_classify)
+  void* items;              // SurvivorItem[items_cap]
+  int items_cap;
+  uint8_t* pose_hit;        // n: preset to 0 here, 1 written by the exact kernel
+};
+struct SurvivorItem {       // 16 bytes
+  int32_t slot;             // edge task slot, or -1 - sample for a pose
+  int32_t chunk;
+  unsigned long long mask;  // samples of the chunk that need the exact test
 };
 void launch_classify(hipStream_t s, const ClassifyArgs& a);
 // neighbour query + classification in one launch (one wavefront per sample): the hits never leave the wave
+// env != nullptr: with the fused clearance cull (a.items / a.pose_hit / a.ctrl[2]); the exact work is then done by
+// launch_collide_items
 void launch_query_classify(hipStream_t s, const GridView& g, const GridView* tg, const NodeStoreView& st,
-                           const SweepQuery* queries, const ClassifyArgs& a);
+                           const SweepQuery* queries, const ClassifyArgs& a, const EnvView* env = nullptr);
+// exact collision work of a round from the survivor list k_query_classify wrote (count in ctrl[2])
+void launch_collide_items(hipStream_t s, const EnvView& env, const RobotView& rob, const double* pos6, uint8_t* pose_hit,
+                          const double* a6, const double* b6, const int32_t* ctrl, const void* items, int32_t* first_hit,
+                          int32_t* overflow_flag, const int32_t* dev_n);
 struct SettleArgs {
   int n, Tb, nbcap, stride, n_trees;
   const uint8_t* in_lim;
@@ -317,6 +335,10 @@ struct DevForestView {
   int32_t temp_base;           // store index of the round's temporaries
   uint8_t* ustate; int32_t* ulist; int32_t* uacc;   // k_resolve scratch: per sample state / dependent list / accepted id
   uint8_t* dk;                 // per sample: neighbour index where k_decide stopped (first round-mate / border event)
+  // one 64-bit word per 64 samples, written by k_decide (ballots) and finished by k_resolve: dependent / accepted /
+  // border-event flags; acc_pref = accepted samples before the word (k_append turns both into node ids and the
+  // next round's active list without k_resolve ever walking the samples)
+  unsigned long long* w_dep; unsigned long long* w_acc; unsigned long long* w_ev; int32_t* acc_pref;
 };
 // per-sample verdicts of k_decide
 #define SFFK_DEPENDS 0     // the neighbour walk reached a sample of the same round first: k_resolve continues at dk

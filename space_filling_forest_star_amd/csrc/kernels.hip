@@ -1678,8 +1678,12 @@ __device__ __forceinline__ void qc_overflow(const GridView& g, int no, int lane,
   }
 }
 
+#define QC_TASKS 64   // edge tasks of one sample whose clearance cull is fused (1 + nbcap <= 64)
 __global__ __launch_bounds__(64 * QC_WAVES) void k_query_classify(GridView g, GridView tg, NodeStoreView st,
-                                                                  const SweepQuery* __restrict__ queries, ClassifyArgs A) {
+                                                                  const SweepQuery* __restrict__ queries, ClassifyArgs A,
+                                                                  EnvView env, int fused_cull) {
+  __shared__ double s_ta[QC_WAVES][QC_TASKS][3], s_tstep[QC_WAVES][QC_TASKS][3];
+  __shared__ int s_tns[QC_WAVES][QC_TASKS];
   __shared__ int32_t s_id[QC_WAVES][64];
   __shared__ int32_t s_tree[QC_WAVES][64];
   __shared__ double s_d[QC_WAVES][64];
@@ -1786,18 +1790,32 @@ __global__ __launch_bounds__(64 * QC_WAVES) void k_query_classify(GridView g, Gr
           double* sa = A.seg_a + 6 * slot;
           double* sb = A.seg_b + 6 * slot;
           for (int k = 0; k < 6; ++k) { sa[k] = ea[k]; sb[k] = eb[k]; }
-          A.seg_ns[slot] = edge_samples(edge_parts(ea, eb));   // the edge's sample count doubles as its "live" mark
+          const double parts = edge_parts(ea, eb);
+          const int ns = edge_samples(parts);
+          A.seg_ns[slot] = ns;   // the edge's sample count doubles as its "live" mark
           A.first_hit[slot] = 0x7fffffff;
           A.seg_ovf[slot] = 0;
+          if (fused_cull && 1 + rank < QC_TASKS) {
+            const double inv = 1.0 / parts;
+            for (int k = 0; k < 3; ++k) { s_ta[wave][1 + rank][k] = ea[k]; s_tstep[wave][1 + rank][k] = (eb[k] - ea[k]) * inv; }
+            s_tns[wave][1 + rank] = ns;
+          }
         }
         if (lane == 0) {   // slot 0: isPathFree(expanded, newPoint)  (src/forest.h:246)
           const size_t slot = (size_t)i * stride;
           double* sa = A.seg_a + 6 * slot;
           double* sb = A.seg_b + 6 * slot;
           for (int k = 0; k < 6; ++k) { sa[k] = exp[k]; sb[k] = qp[k]; }
-          A.seg_ns[slot] = edge_samples(edge_parts(exp, qp));
+          const double parts = edge_parts(exp, qp);
+          const int ns = edge_samples(parts);
+          A.seg_ns[slot] = ns;
           A.first_hit[slot] = 0x7fffffff;
           A.seg_ovf[slot] = 0;
+          if (fused_cull) {
+            const double inv = 1.0 / parts;
+            for (int k = 0; k < 3; ++k) { s_ta[wave][0][k] = exp[k]; s_tstep[wave][0][k] = (qp[k] - exp[k]) * inv; }
+            s_tns[wave][0] = ns;
+          }
         }
       }
     }
@@ -1807,11 +1825,101 @@ __global__ __launch_bounds__(64 * QC_WAVES) void k_query_classify(GridView g, Gr
     A.first_hit[(size_t)i * stride + k] = 0x7fffffff;
     A.seg_ovf[(size_t)i * stride + k] = 0;
   }
+  if (fused_cull) {
+    // ---- clearance cull of this sample's own work: its pose and every 64-sample chunk of its edge tasks.  ~97 % are
+    // answered "free" by one bit; what is not goes onto the survivor list of the exact kernel (one atomic per
+    // surviving item: they are rare).  Sample positions a + idx * step: far inside the slack of the bits.
+    SurvivorItem* list = static_cast<SurvivorItem*>(A.items);
+    __builtin_amdgcn_wave_barrier();
+    if (lane == 0) {
+      bool need = false;
+      if ((flags & 3) == 1 && env.n_tri != 0) need = !surely_clear(env, qp);
+      A.pose_hit[i] = 0;
+      if (need) {
+        const int at = atomicAdd(A.ctrl + 2, 1);
+        if (at < A.items_cap) list[at] = SurvivorItem{-1 - i, 0, 0ULL};
+        else A.ctrl[3] = 1;
+      }
+    }
+    if (env.n_tri != 0) {
+      const int n_tasks = used_slots < QC_TASKS ? used_slots : QC_TASKS;
+      for (int t = 0; t < n_tasks; ++t) {
+        const int ns = s_tns[wave][t];
+        const double a0 = s_ta[wave][t][0], a1 = s_ta[wave][t][1], a2 = s_ta[wave][t][2];
+        const double d0 = s_tstep[wave][t][0], d1 = s_tstep[wave][t][1], d2 = s_tstep[wave][t][2];
+        for (int c0 = 0; c0 * 64 < ns; c0 += 4) {   // four chunks in flight: their clearance words load side by side
+          unsigned long long nm[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int idx = 1 + 64 * (c0 + u) + lane;
+            bool need = idx <= ns;
+            if (need) {
+              const double td = (double)idx;
+              const double P[3] = {a0 + td * d0, a1 + td * d1, a2 + td * d2};
+              need = !surely_clear(env, P);
+            }
+            nm[u] = __ballot(need);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (nm[u] && lane == 0) {
+              const int at = atomicAdd(A.ctrl + 2, 1);
+              if (at < A.items_cap) list[at] = SurvivorItem{(int32_t)(i * stride + t), c0 + u, nm[u]};
+              else A.ctrl[3] = 1;
+            }
+          }
+        }
+      }
+    }
+  }
   if (lane == 0) {
     A.rec_flags[i] = flags;
     A.rec_nnb[i] = nnb;
     if (clocked) atomicMax(A.qclk + 1, wall_clock64());
   }
+}
+
+// Exact collision work of a round straight from the survivor list: persistent wavefronts, wave w takes items
+// w, w + W, ... (about a thousand items over two thousand waves: one item per wave, no pooling needed).
+__global__ __launch_bounds__(64 * SEG_WAVES) void k_collide_items(EnvView env, RobotView rob, const double* __restrict__ pos6,
+                                                                  uint8_t* __restrict__ pose_hit,
+                                                                  const double* __restrict__ a6, const double* __restrict__ b6,
+                                                                  const int32_t* __restrict__ ctrl,
+                                                                  const SurvivorItem* __restrict__ list,
+                                                                  int32_t* __restrict__ first_hit,
+                                                                  int32_t* __restrict__ overflow_flag,
+                                                                  const int32_t* __restrict__ dev_n) {
+  if (dev_n && dev_n[1]) return;
+  extern __shared__ double lds_d[];
+  double* rtri = lds_d;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double* stage = rtri + (size_t)rob.n_tri * 9 + (size_t)wave * STAGE_DOUBLES;
+  int32_t* ibase = reinterpret_cast<int32_t*>(rtri + (size_t)rob.n_tri * 9 + (size_t)SEG_WAVES * STAGE_DOUBLES);
+  const int M = ctrl[2];
+  if (M <= 0 || env.n_tri == 0) return;
+  for (int i = threadIdx.x; i < rob.n_tri * 9; i += blockDim.x) rtri[i] = rob.tri[i];
+  __syncthreads();
+  int32_t* stack = ibase + wave * (STACK_CAP + TG_HASH);
+  int32_t* cand = ibase + SEG_WAVES * (STACK_CAP + TG_HASH) + wave * CAND_CAP;
+  int32_t* queue = ibase + SEG_WAVES * (STACK_CAP + TG_HASH + CAND_CAP) + wave * QUEUE_CAP;
+  DBG_DECL
+  const int W = gridDim.x * SEG_WAVES;
+  for (int e = blockIdx.x + gridDim.x * wave; e < M; e += W) {   // (neighbouring items go to different CUs)
+    const SurvivorItem it = list[e];
+    if (it.slot < 0) {
+      const int pose = -1 - it.slot;
+      double p[6], R[9], c[3];
+      pose_frame(rob, pos6, pose, p, R, c);
+      const bool hit = pose_exact(env, rob, rtri, stack, cand, stage, p, R, c, lane);
+      if (lane == 0) pose_hit[pose] = hit ? 1 : 0;
+    } else {
+      if (it.chunk > 0 && first_hit[it.slot] <= 64 * it.chunk) continue;
+      double a[6], b[6];
+      for (int k = 0; k < 6; ++k) { a[k] = a6[6 * (size_t)it.slot + k]; b[k] = b6[6 * (size_t)it.slot + k]; }
+      segment_chunk(env, rob, rtri, stack, cand, queue, stage, a, b, it.slot, it.chunk, true, it.mask, first_hit, overflow_flag, lane DBG_PASS);
+    }
+  }
+  DBG_FLUSH();
 }
 
 // Samples whose fate needs no in-order replay (src/forest.h:246-299): rejected by their own pose or parent-edge
@@ -2025,11 +2133,20 @@ void launch_settle(hipStream_t s, const SettleArgs& a) {
 }
 
 void launch_query_classify(hipStream_t s, const GridView& g, const GridView* tg, const NodeStoreView& st,
-                           const SweepQuery* queries, const ClassifyArgs& a) {
+                           const SweepQuery* queries, const ClassifyArgs& a, const EnvView* env) {
   if (a.n <= 0) return;
   GridView none{};
   hipLaunchKernelGGL(k_query_classify, dim3((a.n + QC_WAVES - 1) / QC_WAVES), dim3(64 * QC_WAVES), 0, s, g, tg ? *tg : none, st,
-                     queries, a);
+                     queries, a, env ? *env : EnvView{}, env ? 1 : 0);
+}
+void launch_collide_items(hipStream_t s, const EnvView& env, const RobotView& rob, const double* pos6, uint8_t* pose_hit,
+                          const double* a6, const double* b6, const int32_t* ctrl, const void* items, int32_t* first_hit,
+                          int32_t* overflow_flag, const int32_t* dev_n) {
+  size_t lds = collide_lds_bytes(rob.n_tri, SEG_WAVES);
+  if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_collide_items), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static const int blocks = std::min(4096, std::max(1, getenv("SFFGPU_SEG_BLOCKS") ? atoi(getenv("SFFGPU_SEG_BLOCKS")) : 512));
+  hipLaunchKernelGGL(k_collide_items, dim3(blocks), dim3(64 * SEG_WAVES), lds, s, env, rob, pos6, pose_hit, a6, b6, ctrl,
+                     static_cast<const SurvivorItem*>(items), first_hit, overflow_flag, dev_n);
 }
 
 void launch_classify(hipStream_t s, const ClassifyArgs& a) {
