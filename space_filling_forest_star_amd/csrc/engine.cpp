@@ -376,11 +376,18 @@ void Ctx::build_clearance() {
     const double halfdiag = 0.5 * std::sqrt(3.0) * h;
     const double m0 = rr + halfdiag;
     thr = rr * (1 + 1e-9) + halfdiag * (1 + 1e-5) + 1e-8 * (3 * (env_maxabs + 2 * m0) + 1);
-    double cells = 1;
-    for (int a = 0; a < 3; ++a) {
-      double c = std::ceil((ext[a] + 2 * thr) / h) + 1;
-      n[a] = (int)std::min(c, 1e9);
-      cells *= c;
+    double cells = 1, nmax = 1;
+    for (int pass = 0; pass < 2; ++pass) {
+      cells = 1;
+      for (int a = 0; a < 3; ++a) {
+        double c = std::ceil((ext[a] + 2 * thr) / h) + 1;
+        n[a] = (int)std::min(c, 1e9);
+        cells *= c;
+        nmax = std::max(nmax, c);
+      }
+      // the neighbour-query kernel places edge samples in fp32 cell units (k_query_classify): three roundings of
+      // at most 2^-24 * cells-per-axis each; the bits cover 1e-6 * cells-per-axis cells of misplacement
+      if (pass == 0) thr += 1e-6 * (nmax + 2) * h;
     }
     if (cells <= cap) break;
     h *= std::max(1.02, std::cbrt(cells / cap));

@@ -581,7 +581,13 @@ void Forest::round_begin() {
   // neighbour query (27 grid cells per sample in the node grid, plus the round's own grid for the EARLIER samples of
   // this round) and classification of the hits, one wavefront per sample
   c.time_begin(T_SWEEP);
-  sffk::launch_query_classify(c.stream, c.gridv, &c.tgridv, c.store_view(), c.r_q.as<sffk::SweepQuery>(), ca);
+  // (the clearance cull of the sample's pose and edge chunks is fused in: what needs the exact test is on r_items)
+  const int list_cap = 4 * n * STRIDE + 65536;
+  c.r_items.ensure((size_t)list_cap * SFFK_ITEM_BYTES);
+  ca.items = c.r_items.p;
+  ca.items_cap = list_cap;
+  ca.pose_hit = d_pose;
+  sffk::launch_query_classify(c.stream, c.gridv, &c.tgridv, c.store_view(), c.r_q.as<sffk::SweepQuery>(), ca, &c.envv);
   c.time_end();
   c.time_begin(T_COLLIDE);
   c.p_out.ensure(o_bytes);
@@ -590,18 +596,14 @@ void Forest::round_begin() {
   HIPCHK(hipStreamWaitEvent(c.copy_stream, c.ev_mid, 0));
   HIPCHK(hipMemcpyAsync(ho, dout, early_bytes, hipMemcpyDeviceToHost, c.copy_stream));
   HIPCHK(hipEventRecord(c.ev_early, c.copy_stream));
-  // poses and edges together: work-list compaction -> clearance cull -> exact kernel
-  const int list_cap = 4 * n * STRIDE + 65536;
-  c.r_items.ensure((size_t)list_cap * SFFK_ITEM_BYTES);
-  c.r_items2.ensure(((size_t)list_cap + (1u << 20)) * 8);   // (+ one window of the exact kernel, see mask_slot)
+  // poses and edges together: the exact kernel on the survivors of the fused cull
   sffk::TempGridRef tref{c.tgridv, c.sx.as<float>() + Tb, c.sy.as<float>() + Tb, c.sz.as<float>() + Tb, n};
   // (SFF*: the k-nearest stage below still reads the round's own grid; it is emptied after that)
   sffk::TempGridRef tref_keep = tref;
   tref_keep.tg = sffk::GridView{};
   tref_keep.n = 0;
-  sffk::launch_round_collide(c.stream, c.envv, c.robv, d_pos, n, ca.rec_flags, d_pose, ca.seg_a, ca.seg_b, ca.seg_ns,
-                             n * STRIDE, ca.ctrl, c.r_items.p, list_cap, c.r_items2.p, ca.first_hit, ca.seg_ovf,
-                             cfg.optimize ? &tref_keep : &tref);
+  sffk::launch_collide_items(c.stream, c.envv, c.robv, d_pos, n, ca.rec_flags, d_pose, ca.seg_a, ca.seg_b, ca.seg_ns,
+                             STRIDE, ca.ctrl, c.r_items.p, ca.first_hit, ca.seg_ovf, cfg.optimize ? &tref_keep : &tref);
   c.time_end();
   // samples this rank can settle alone need no replay (with a goal the replay may stop in the middle of the
   // round, so there every sample stays in it)

@@ -563,14 +563,16 @@ void Forest::dev_enqueue_round_eval(void* send_dev) {
   ca.dev_n = dev_n;
   ca.qclk = dv.qclk;
   c.time_begin(T_SWEEP);
-  sffk::launch_query_classify(c.stream, c.gridv, &c.tgridv, c.store_view(), c.r_q.as<sffk::SweepQuery>(), ca);
+  ca.items = c.r_items.p;
+  ca.items_cap = B.list_cap;
+  ca.pose_hit = B.d_pose;
+  sffk::launch_query_classify(c.stream, c.gridv, &c.tgridv, c.store_view(), c.r_q.as<sffk::SweepQuery>(), ca, &c.envv);
   c.time_end();
   c.time_begin(T_COLLIDE);
   sffk::TempGridRef tref{c.tgridv, c.sx.as<float>() + d.temp_base, c.sy.as<float>() + d.temp_base,
                          c.sz.as<float>() + d.temp_base, n};
-  sffk::launch_round_collide(c.stream, c.envv, c.robv, B.d_pos, n, ca.rec_flags, B.d_pose, ca.seg_a, ca.seg_b, ca.seg_ns,
-                             n * B.STRIDE, ca.ctrl, c.r_items.p, B.list_cap, c.r_items2.p, ca.first_hit, ca.seg_ovf, &tref,
-                             dev_n, B.STRIDE);
+  sffk::launch_collide_items(c.stream, c.envv, c.robv, B.d_pos, n, ca.rec_flags, B.d_pose, ca.seg_a, ca.seg_b, ca.seg_ns,
+                             B.STRIDE, ca.ctrl, c.r_items.p, ca.first_hit, ca.seg_ovf, &tref, dev_n);
   c.time_end();
   if (send_dev) sffk::launch_pack_records(c.stream, dev_resolve_args(*this, B), cfg.rank, cfg.world, n, static_cast<int32_t*>(send_dev));
   c.timing_on = true;
@@ -711,6 +713,13 @@ void Forest::run_device(int max_waves) {
             "candidates %.1f | us: setup %.2f hierarchy %.2f narrow %.2f | per wave total %.1f us over %llu waves\n",
             g[0], g[1], g[2], g[3] / items, g[7] / items, g[4] / items / 100.0, g[5] / items / 100.0, g[6] / items / 100.0,
             (double)g[8] / (double)std::max<unsigned long long>(1ULL, g[9]) / 100.0, g[9]);
+    unsigned long long q[8];
+    sffk::debug_counters_query(q);
+    const double qw = (double)std::max<unsigned long long>(1ULL, q[0]);
+    fprintf(stderr, "[sffgpu query kernel, per sampled wave] us: grid scan %.2f classify %.2f cull %.2f (flushes %.2f) | live %.2f "
+            "pairs/live %.1f survivors/live %.2f\n", q[1] / qw / 100.0, q[2] / qw / 100.0, q[3] / qw / 100.0, q[4] / qw / 100.0,
+            q[7] / qw, (double)q[5] / (double)std::max<unsigned long long>(1ULL, q[7]),
+            (double)q[6] / (double)std::max<unsigned long long>(1ULL, q[7]));
 #endif
   }
 }

@@ -250,7 +250,6 @@ struct ClassifyArgs {
   // fused clearance cull (k_query_classify): the wave that wrote a sample's edge tasks looks the clearance bits of
   // their samples (and of the sample's own pose) up right away and appends only the (edge, 64-sample chunk, mask) /
   // pose items that need the exact test to `items` (ctrl[2] = count) - no work-list compaction, no cull kernel
-  const EnvView* env_dev;   // unused (the view travels by value, see launch_query_classify)
   void* items;              // SurvivorItem[items_cap]
   int items_cap;
   uint8_t* pose_hit;        // n: preset to 0 here, 1 written by the exact kernel
@@ -267,9 +266,11 @@ void launch_classify(hipStream_t s, const ClassifyArgs& a);
 void launch_query_classify(hipStream_t s, const GridView& g, const GridView* tg, const NodeStoreView& st,
                            const SweepQuery* queries, const ClassifyArgs& a, const EnvView* env = nullptr);
 // exact collision work of a round from the survivor list k_query_classify wrote (count in ctrl[2])
-void launch_collide_items(hipStream_t s, const EnvView& env, const RobotView& rob, const double* pos6, uint8_t* pose_hit,
-                          const double* a6, const double* b6, const int32_t* ctrl, const void* items, int32_t* first_hit,
-                          int32_t* overflow_flag, const int32_t* dev_n);
+struct TempGridRef;
+void launch_collide_items(hipStream_t s, const EnvView& env, const RobotView& rob, const double* pos6, int n_pose,
+                          const int32_t* live_flags, uint8_t* pose_hit, const double* a6, const double* b6,
+                          const int32_t* seg_ns, int stride, int32_t* ctrl, const void* items, int32_t* first_hit,
+                          int32_t* overflow_flag, const TempGridRef* temps, const int32_t* dev_n = nullptr);
 struct SettleArgs {
   int n, Tb, nbcap, stride, n_trees;
   const uint8_t* in_lim;
@@ -376,6 +377,7 @@ void launch_border_rehash(hipStream_t s, const DevForestView& f, int n);
 
 #ifdef SFFK_DEBUG_COUNTERS
 void debug_counters(unsigned long long* out16);   // exact-kernel phase clocks (make EXTRA=-DSFFK_DEBUG_COUNTERS)
+void debug_counters_query(unsigned long long* out8);
 #endif
 
 }  // namespace sffk

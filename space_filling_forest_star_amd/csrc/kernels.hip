@@ -934,6 +934,8 @@ void launch_tgrid_build(hipStream_t s, const EnvView& env, int32_t* cnt_or_start
 
 #ifdef SFFK_DEBUG_COUNTERS
 __device__ unsigned long long g_dbg[16];
+__device__ unsigned long long g_dbg_q[8];   // k_query_classify: sampled waves | ticks: scan, classify, cull, flushes | pairs, survivors, live
+#define QDBG(i, x) do { if (qdbg_on) atomicAdd(&g_dbg_q[i], (unsigned long long)(x)); } while (0)
 struct DbgAcc { unsigned long long v[12]; };
 #define DBG_DECL DbgAcc dbg_acc = {{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
 #define DBG_ARG , DbgAcc& dbg_acc
@@ -948,6 +950,7 @@ struct DbgAcc { unsigned long long v[12]; };
 #define DBG_T() 0ULL
 #define DBG_ADD(i, x) do { } while (0)
 #define DBG_FLUSH() do { } while (0)
+#define QDBG(i, x) do { } while (0)
 #endif
 
 // ------------------------------------------------------------------ pose kernel
@@ -1678,12 +1681,13 @@ __device__ __forceinline__ void qc_overflow(const GridView& g, int no, int lane,
   }
 }
 
-#define QC_TASKS 64   // edge tasks of one sample whose clearance cull is fused (1 + nbcap <= 64)
-__global__ __launch_bounds__(64 * QC_WAVES) void k_query_classify(GridView g, GridView tg, NodeStoreView st,
+#ifndef QC_OCC
+#define QC_OCC 5   // wavefronts per SIMD the register allocation aims at (measured: 4 -> 45.5 us, 5 -> 42.0, 6 -> 47.4, 8 -> 67.7)
+#endif
+__global__ __launch_bounds__(64 * QC_WAVES) __attribute__((amdgpu_waves_per_eu(QC_OCC))) void k_query_classify(GridView g, GridView tg, NodeStoreView st,
                                                                   const SweepQuery* __restrict__ queries, ClassifyArgs A,
                                                                   EnvView env, int fused_cull) {
-  __shared__ double s_ta[QC_WAVES][QC_TASKS][3], s_tstep[QC_WAVES][QC_TASKS][3];
-  __shared__ int s_tns[QC_WAVES][QC_TASKS];
+  __shared__ SurvivorItem s_surv[QC_WAVES][64];   // fused cull: the sample's items for the exact kernel
   __shared__ int32_t s_id[QC_WAVES][64];
   __shared__ int32_t s_tree[QC_WAVES][64];
   __shared__ double s_d[QC_WAVES][64];
@@ -1698,6 +1702,9 @@ __global__ __launch_bounds__(64 * QC_WAVES) void k_query_classify(GridView g, Gr
   // (every 16th workgroup reports: ten thousand atomics on one word would cost more than the kernel itself)
   const bool clocked = A.qclk && (blockIdx.x & 15) == 0 && threadIdx.x == 0;
   if (clocked) atomicMin(A.qclk, wall_clock64());
+  [[maybe_unused]] const bool qdbg_on = (blockIdx.x & 15) == 0 && lane == 0;
+  [[maybe_unused]] const unsigned long long qt0 = DBG_T();
+  [[maybe_unused]] unsigned long long qt1 = qt0, qt_fl = 0;
   const int stride = 1 + A.nbcap;
   // ---- everything the sample needs, loaded before the first store (a wave runs one long chain of dependent
   // memory steps: independent loads are issued together, up front)
@@ -1748,6 +1755,7 @@ __global__ __launch_bounds__(64 * QC_WAVES) void k_query_classify(GridView g, Gr
     if (no_g > 0) qc_overflow(g, no_g, lane, Q, qp, h_id, h_d, h_tree, h_pos, nh);
     if (no_t > 0) qc_overflow(tg, no_t, lane, Q, qp, h_id, h_d, h_tree, h_pos, nh);
     // ---- classification (k_classify's logic on the wave's own hit list)
+    qt1 = DBG_T();
     const int cnt = nh;
     if (cnt > A.cap) {
       flags |= 2;
@@ -1795,10 +1803,17 @@ __global__ __launch_bounds__(64 * QC_WAVES) void k_query_classify(GridView g, Gr
           A.seg_ns[slot] = ns;   // the edge's sample count doubles as its "live" mark
           A.first_hit[slot] = 0x7fffffff;
           A.seg_ovf[slot] = 0;
-          if (fused_cull && 1 + rank < QC_TASKS) {
-            const double inv = 1.0 / parts;
-            for (int k = 0; k < 3; ++k) { s_ta[wave][1 + rank][k] = ea[k]; s_tstep[wave][1 + rank][k] = (eb[k] - ea[k]) * inv; }
-            s_tns[wave][1 + rank] = ns;
+          if (fused_cull) {
+            // the hit list is dead from here on (every lane holds its own hit in registers): the kept edges' start
+            // points, sample steps and sample counts take its place, indexed by rank
+            // (in cells of the clearance grid, fp32: see the fused cull below)
+            const double inv = env.clear_inv / parts;
+            float* tf = reinterpret_cast<float*>(h_pos);
+            for (int k = 0; k < 3; ++k) {
+              tf[8 * rank + k] = (float)((ea[k] - env.clear_org[k]) * env.clear_inv);
+              tf[8 * rank + 4 + k] = (float)((eb[k] - ea[k]) * inv);
+            }
+            h_id[rank] = ns;
           }
         }
         if (lane == 0) {   // slot 0: isPathFree(expanded, newPoint)  (src/forest.h:246)
@@ -1811,11 +1826,6 @@ __global__ __launch_bounds__(64 * QC_WAVES) void k_query_classify(GridView g, Gr
           A.seg_ns[slot] = ns;
           A.first_hit[slot] = 0x7fffffff;
           A.seg_ovf[slot] = 0;
-          if (fused_cull) {
-            const double inv = 1.0 / parts;
-            for (int k = 0; k < 3; ++k) { s_ta[wave][0][k] = exp[k]; s_tstep[wave][0][k] = (qp[k] - exp[k]) * inv; }
-            s_tns[wave][0] = ns;
-          }
         }
       }
     }
@@ -1827,50 +1837,129 @@ __global__ __launch_bounds__(64 * QC_WAVES) void k_query_classify(GridView g, Gr
   }
   if (fused_cull) {
     // ---- clearance cull of this sample's own work: its pose and every 64-sample chunk of its edge tasks.  ~97 % are
-    // answered "free" by one bit; what is not goes onto the survivor list of the exact kernel (one atomic per
-    // surviving item: they are rare).  Sample positions a + idx * step: far inside the slack of the bits.
+    // answered "free" by one bit; what is not goes onto the survivor list of the exact kernel.  The (task, chunk)
+    // pairs are flattened so that eight dependent lookups are in flight at a time whatever the edge lengths are;
+    // survivors are gathered in LDS and reserved on the list with one atomic per sample.
+    // Sample positions a + idx * step: far inside the slack of the bits.
     SurvivorItem* list = static_cast<SurvivorItem*>(A.items);
-    __builtin_amdgcn_wave_barrier();
-    if (lane == 0) {
-      bool need = false;
-      if ((flags & 3) == 1 && env.n_tri != 0) need = !surely_clear(env, qp);
-      A.pose_hit[i] = 0;
-      if (need) {
-        const int at = atomicAdd(A.ctrl + 2, 1);
-        if (at < A.items_cap) list[at] = SurvivorItem{-1 - i, 0, 0ULL};
+    SurvivorItem* buf = s_surv[wave];
+    int n_buf = 0;
+    [[maybe_unused]] const unsigned long long qt2 = DBG_T();
+    QDBG(0, 1); QDBG(1, qt1 - qt0); QDBG(2, qt2 - qt1);
+    auto flush = [&]() {
+      [[maybe_unused]] const unsigned long long f0 = DBG_T();
+      QDBG(6, n_buf);
+      int base = 0;
+      if (lane == 0) base = atomicAdd(A.ctrl + 2, n_buf);
+      base = __shfl(base, 0);
+      if (lane < n_buf) {
+        if (base + lane < A.items_cap) list[base + lane] = buf[lane];
         else A.ctrl[3] = 1;
       }
-    }
-    if (env.n_tri != 0) {
-      const int n_tasks = used_slots < QC_TASKS ? used_slots : QC_TASKS;
-      for (int t = 0; t < n_tasks; ++t) {
-        const int ns = s_tns[wave][t];
-        const double a0 = s_ta[wave][t][0], a1 = s_ta[wave][t][1], a2 = s_ta[wave][t][2];
-        const double d0 = s_tstep[wave][t][0], d1 = s_tstep[wave][t][1], d2 = s_tstep[wave][t][2];
-        for (int c0 = 0; c0 * 64 < ns; c0 += 4) {   // four chunks in flight: their clearance words load side by side
-          unsigned long long nm[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int idx = 1 + 64 * (c0 + u) + lane;
-            bool need = idx <= ns;
-            if (need) {
-              const double td = (double)idx;
-              const double P[3] = {a0 + td * d0, a1 + td * d1, a2 + td * d2};
-              need = !surely_clear(env, P);
-            }
-            nm[u] = __ballot(need);
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            if (nm[u] && lane == 0) {
-              const int at = atomicAdd(A.ctrl + 2, 1);
-              if (at < A.items_cap) list[at] = SurvivorItem{(int32_t)(i * stride + t), c0 + u, nm[u]};
-              else A.ctrl[3] = 1;
-            }
+      n_buf = 0;
+      qt_fl += DBG_T() - f0;
+    };
+    const bool live = (flags & 3) == 1 && env.n_tri != 0;
+    if (lane == 0) A.pose_hit[i] = 0;
+    if (live) {
+      // the pose's own bit: the load is issued here and looked at after the edges' (one latency for everything)
+      const uint32_t* wp_pose = nullptr;
+      int sh_pose = 0;
+      bool need_pose = true;
+      if (env.clear_bits) {
+        const double fx = (qp[0] - env.clear_org[0]) * env.clear_inv, fy = (qp[1] - env.clear_org[1]) * env.clear_inv,
+                     fz = (qp[2] - env.clear_org[2]) * env.clear_inv;
+        if (fx == fx && fy == fy && fz == fz) {
+          if (fx < 0 || fy < 0 || fz < 0 || fx >= env.clear_n[0] || fy >= env.clear_n[1] || fz >= env.clear_n[2]) {
+            need_pose = false;
+          } else {
+            const long long ci = ((long long)(int)fz * env.clear_n[1] + (int)fy) * env.clear_n[0] + (int)fx;
+            wp_pose = env.clear_bits + (ci >> 5);
+            sh_pose = (int)(ci & 31);
           }
         }
       }
+      const uint32_t word_pose = wp_pose ? *wp_pose : 0u;
+      // lane r < nnb = the kept edge of rank r; the parent edge (task 0) is uniform.  Positions in cells of the
+      // clearance grid, in fp32: cell = a + idx * step is off the exact kernel's fp64 sample position by less than
+      // 1e-6 * (cells per axis) cells - the slack Ctx::build_clearance puts into the bits for exactly this
+      const double parts0 = edge_parts(exp, qp);
+      const int ns0 = edge_samples(parts0);
+      const double inv0 = env.clear_inv / parts0;
+      const float g0[3] = {(float)((exp[0] - env.clear_org[0]) * env.clear_inv), (float)((exp[1] - env.clear_org[1]) * env.clear_inv),
+                           (float)((exp[2] - env.clear_org[2]) * env.clear_inv)};
+      const float st0[3] = {(float)((qp[0] - exp[0]) * inv0), (float)((qp[1] - exp[1]) * inv0), (float)((qp[2] - exp[2]) * inv0)};
+      const int C0 = ns0 > 0 ? (ns0 + 63) >> 6 : 0;
+      const int my_ns = lane < nnb ? s_id[wave][lane] : 0;
+      const int my_nch = my_ns > 0 ? (my_ns + 63) >> 6 : 0;
+      int incl = my_nch;
+      for (int off = 1; off < nnb; off <<= 1) {
+        const int o = __shfl_up(incl, off);
+        if (lane >= off) incl += o;
+      }
+      const int excl = incl - my_nch;
+      const int P = C0 + (nnb > 0 ? __shfl(incl, nnb - 1) : 0);
+      const float* T = reinterpret_cast<const float*>(s_pos[wave]);
+      const float nxd = (float)env.clear_n[0], nyd = (float)env.clear_n[1], nzd = (float)env.clear_n[2];
+      for (int p0 = 0; p0 < P; p0 += 8) {
+        const uint32_t* wp[8];
+        int sh[8], ts[8], cs[8];
+        bool need[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int p = p0 + u;
+          wp[u] = nullptr; sh[u] = 0; ts[u] = 0; cs[u] = 0; need[u] = false;
+          if (p >= P) continue;   // (uniform)
+          int c, ns;
+          float a0, a1, a2, d0, d1, d2;
+          if (p < C0) {
+            c = p; ns = ns0;
+            a0 = g0[0]; a1 = g0[1]; a2 = g0[2]; d0 = st0[0]; d1 = st0[1]; d2 = st0[2];
+          } else {
+            const int pp = p - C0;
+            const int r = __builtin_amdgcn_readfirstlane(__popcll(__ballot(lane < nnb && incl <= pp)));   // the edge pair pp belongs to
+            ts[u] = 1 + r;
+            c = pp - __shfl(excl, r);
+            ns = __shfl(my_ns, r);
+            a0 = T[8 * r]; a1 = T[8 * r + 1]; a2 = T[8 * r + 2]; d0 = T[8 * r + 4]; d1 = T[8 * r + 5]; d2 = T[8 * r + 6];
+          }
+          cs[u] = c;
+          const int idx = 1 + 64 * c + lane;
+          const float td = (float)idx;
+          need[u] = idx <= ns;
+          if (env.clear_bits) {
+            const float fx = __builtin_fmaf(td, d0, a0), fy = __builtin_fmaf(td, d1, a1), fz = __builtin_fmaf(td, d2, a2);
+            if (fx >= 0 && fy >= 0 && fz >= 0 && fx < nxd && fy < nyd && fz < nzd) {   // (the grid has fewer than 2^31 cells)
+              const uint32_t ci = ((uint32_t)(int)fz * (uint32_t)env.clear_n[1] + (uint32_t)(int)fy) * (uint32_t)env.clear_n[0] + (uint32_t)(int)fx;
+              if (need[u]) wp[u] = env.clear_bits + (ci >> 5);
+              sh[u] = (int)(ci & 31u);
+            } else if (fx == fx && fy == fy && fz == fz) {
+              need[u] = false;                        // beyond the inflated box of the environment
+            }
+          }
+        }
+        uint32_t word[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) word[u] = wp[u] ? *wp[u] : 0u;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          if (p0 + u >= P) break;
+          if (wp[u] && ((word[u] >> sh[u]) & 1u)) need[u] = false;
+          const unsigned long long nm = __ballot(need[u]);
+          if (nm) {
+            if (lane == 0) buf[n_buf] = SurvivorItem{(int32_t)(i * stride + ts[u]), cs[u], nm};
+            if (++n_buf == 64) flush();
+          }
+        }
+      }
+      if (need_pose && !((word_pose >> sh_pose) & 1u)) {   // (uniform)
+        if (lane == 0) buf[n_buf] = SurvivorItem{-1 - i, 0, 0ULL};
+        ++n_buf;   // (flushed at 64: there is room)
+      }
+      if (n_buf) flush();
+      QDBG(5, P); QDBG(7, 1);
     }
+    QDBG(3, DBG_T() - qt2); QDBG(4, qt_fl);
   }
   if (lane == 0) {
     A.rec_flags[i] = flags;
@@ -1881,22 +1970,44 @@ __global__ __launch_bounds__(64 * QC_WAVES) void k_query_classify(GridView g, Gr
 
 // Exact collision work of a round straight from the survivor list: persistent wavefronts, wave w takes items
 // w, w + W, ... (about a thousand items over two thousand waves: one item per wave, no pooling needed).
+// Housekeeping first: the round's own grid has been read by the query kernel, the cells it used are emptied here.
+// List overflow (ctrl[3]): every live pose and every chunk of every live edge takes the exact test.
 __global__ __launch_bounds__(64 * SEG_WAVES) void k_collide_items(EnvView env, RobotView rob, const double* __restrict__ pos6,
+                                                                  int n_pose, const int32_t* __restrict__ live_flags,
                                                                   uint8_t* __restrict__ pose_hit,
                                                                   const double* __restrict__ a6, const double* __restrict__ b6,
-                                                                  const int32_t* __restrict__ ctrl,
+                                                                  const int32_t* __restrict__ seg_ns, int stride,
+                                                                  int32_t* __restrict__ ctrl,
                                                                   const SurvivorItem* __restrict__ list,
                                                                   int32_t* __restrict__ first_hit,
-                                                                  int32_t* __restrict__ overflow_flag,
+                                                                  int32_t* __restrict__ overflow_flag, GridView tg,
+                                                                  const float* __restrict__ tx, const float* __restrict__ ty,
+                                                                  const float* __restrict__ tz, int n_temps,
                                                                   const int32_t* __restrict__ dev_n) {
-  if (dev_n && dev_n[1]) return;
+  if (dev_n) {
+    if (dev_n[1]) return;
+    n_pose = dev_n[0];
+    if (n_temps) n_temps = dev_n[0];
+  }
+  if (tg.cnt) {
+    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n_temps; t += gridDim.x * blockDim.x) {
+      const float x = tx[t];
+      if (x == x) {
+        const size_t cell = grid_cell_of(tg, x, ty[t], tz[t]);
+        tg.cnt[cell] = 0;
+        if (tg.occ) tg.occ[cell >> 5] = 0u;   // (every set bit of the word belongs to a sample of this round)
+      }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) tg.ovf_cnt[0] = 0;
+  }
   extern __shared__ double lds_d[];
   double* rtri = lds_d;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   double* stage = rtri + (size_t)rob.n_tri * 9 + (size_t)wave * STAGE_DOUBLES;
   int32_t* ibase = reinterpret_cast<int32_t*>(rtri + (size_t)rob.n_tri * 9 + (size_t)SEG_WAVES * STAGE_DOUBLES);
   const int M = ctrl[2];
-  if (M <= 0 || env.n_tri == 0) return;
+  const bool ran_over = ctrl[3] != 0;
+  if ((M <= 0 && !ran_over) || env.n_tri == 0) return;
   for (int i = threadIdx.x; i < rob.n_tri * 9; i += blockDim.x) rtri[i] = rob.tri[i];
   __syncthreads();
   int32_t* stack = ibase + wave * (STACK_CAP + TG_HASH);
@@ -1904,19 +2015,38 @@ __global__ __launch_bounds__(64 * SEG_WAVES) void k_collide_items(EnvView env, R
   int32_t* queue = ibase + SEG_WAVES * (STACK_CAP + TG_HASH + CAND_CAP) + wave * QUEUE_CAP;
   DBG_DECL
   const int W = gridDim.x * SEG_WAVES;
-  for (int e = blockIdx.x + gridDim.x * wave; e < M; e += W) {   // (neighbouring items go to different CUs)
-    const SurvivorItem it = list[e];
-    if (it.slot < 0) {
-      const int pose = -1 - it.slot;
+  // one loop for both sources of work (the exact test is inlined once): the list's items, or - list overflow -
+  // every live pose followed by every live edge with all its chunks
+  const int n_slots = n_pose * stride;
+  const int E = ran_over ? n_pose + n_slots : M;
+  for (int e = blockIdx.x + gridDim.x * wave; e < E; e += W) {   // (neighbouring items go to different CUs)
+    int slot, c_lo, c_hi;
+    unsigned long long mask = 0ULL;
+    if (!ran_over) {
+      const SurvivorItem it = list[e];
+      slot = it.slot; c_lo = it.chunk; c_hi = it.chunk + 1; mask = it.mask;
+    } else if (e < n_pose) {
+      if ((live_flags[e] & 3) != 1) continue;
+      slot = -1 - e; c_lo = c_hi = 0;
+    } else {
+      slot = e - n_pose;
+      const int ns = seg_ns[slot];
+      if (ns <= 0) continue;
+      c_lo = 0; c_hi = (ns + 63) >> 6;
+    }
+    if (slot < 0) {
+      const int pose = -1 - slot;
       double p[6], R[9], c[3];
       pose_frame(rob, pos6, pose, p, R, c);
       const bool hit = pose_exact(env, rob, rtri, stack, cand, stage, p, R, c, lane);
       if (lane == 0) pose_hit[pose] = hit ? 1 : 0;
-    } else {
-      if (it.chunk > 0 && first_hit[it.slot] <= 64 * it.chunk) continue;
-      double a[6], b[6];
-      for (int k = 0; k < 6; ++k) { a[k] = a6[6 * (size_t)it.slot + k]; b[k] = b6[6 * (size_t)it.slot + k]; }
-      segment_chunk(env, rob, rtri, stack, cand, queue, stage, a, b, it.slot, it.chunk, true, it.mask, first_hit, overflow_flag, lane DBG_PASS);
+      continue;
+    }
+    double a[6], b[6];
+    for (int k = 0; k < 6; ++k) { a[k] = a6[6 * (size_t)slot + k]; b[k] = b6[6 * (size_t)slot + k]; }
+    for (int chunk = c_lo; chunk < c_hi; ++chunk) {
+      if (chunk > 0 && first_hit[slot] <= 64 * chunk) break;
+      segment_chunk(env, rob, rtri, stack, cand, queue, stage, a, b, slot, chunk, !ran_over, mask, first_hit, overflow_flag, lane DBG_PASS);
     }
   }
   DBG_FLUSH();
@@ -2120,6 +2250,7 @@ void launch_collide_poses(hipStream_t s, const EnvView& env, const RobotView& ro
 
 #ifdef SFFK_DEBUG_COUNTERS
 void debug_counters(unsigned long long* out16) { (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_dbg), sizeof(unsigned long long) * 16); }
+void debug_counters_query(unsigned long long* out8) { (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_dbg_q), sizeof(unsigned long long) * 8); }
 #endif
 
 void launch_clear_build(hipStream_t s, const EnvView& env, double thr, uint32_t* bits, long long n_cells) {
@@ -2136,17 +2267,27 @@ void launch_query_classify(hipStream_t s, const GridView& g, const GridView* tg,
                            const SweepQuery* queries, const ClassifyArgs& a, const EnvView* env) {
   if (a.n <= 0) return;
   GridView none{};
+  ClassifyArgs aa = a;
+  if (env) {   // tests shrink the survivor list to drive the exact kernel's table-scan path
+    const int cap_override = getenv("SFFGPU_SEG_LISTCAP") ? atoi(getenv("SFFGPU_SEG_LISTCAP")) : -1;
+    if (cap_override >= 0 && cap_override < aa.items_cap) aa.items_cap = cap_override;
+  }
   hipLaunchKernelGGL(k_query_classify, dim3((a.n + QC_WAVES - 1) / QC_WAVES), dim3(64 * QC_WAVES), 0, s, g, tg ? *tg : none, st,
-                     queries, a, env ? *env : EnvView{}, env ? 1 : 0);
+                     queries, aa, env ? *env : EnvView{}, env ? 1 : 0);
 }
-void launch_collide_items(hipStream_t s, const EnvView& env, const RobotView& rob, const double* pos6, uint8_t* pose_hit,
-                          const double* a6, const double* b6, const int32_t* ctrl, const void* items, int32_t* first_hit,
-                          int32_t* overflow_flag, const int32_t* dev_n) {
+void launch_collide_items(hipStream_t s, const EnvView& env, const RobotView& rob, const double* pos6, int n_pose,
+                          const int32_t* live_flags, uint8_t* pose_hit, const double* a6, const double* b6,
+                          const int32_t* seg_ns, int stride, int32_t* ctrl, const void* items, int32_t* first_hit,
+                          int32_t* overflow_flag, const TempGridRef* temps, const int32_t* dev_n) {
+  if (n_pose <= 0) return;
   size_t lds = collide_lds_bytes(rob.n_tri, SEG_WAVES);
   if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_collide_items), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  // 2 workgroups of 4 waves per CU = what the exact kernel's register budget keeps resident (256 CUs)
   static const int blocks = std::min(4096, std::max(1, getenv("SFFGPU_SEG_BLOCKS") ? atoi(getenv("SFFGPU_SEG_BLOCKS")) : 512));
-  hipLaunchKernelGGL(k_collide_items, dim3(blocks), dim3(64 * SEG_WAVES), lds, s, env, rob, pos6, pose_hit, a6, b6, ctrl,
-                     static_cast<const SurvivorItem*>(items), first_hit, overflow_flag, dev_n);
+  hipLaunchKernelGGL(k_collide_items, dim3(blocks), dim3(64 * SEG_WAVES), lds, s, env, rob, pos6, n_pose, live_flags, pose_hit,
+                     a6, b6, seg_ns, stride, ctrl, static_cast<const SurvivorItem*>(items), first_hit, overflow_flag,
+                     temps ? temps->tg : GridView{}, temps ? temps->x : nullptr, temps ? temps->y : nullptr,
+                     temps ? temps->z : nullptr, temps ? temps->n : 0, dev_n);
 }
 
 void launch_classify(hipStream_t s, const ClassifyArgs& a) {
