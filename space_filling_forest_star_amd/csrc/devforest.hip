@@ -193,80 +193,168 @@ __global__ __launch_bounds__(DF_THREADS) void k_wave_begin(DevForestView f) {
 // neighbour list in the reference's order (src/forest.h:262-300) until a verdict falls or the first round-mate is
 // reached; the reference-equivalent counters of what it walked go straight into the round's bulk sums (they are
 // plain sums), so k_resolve only adds what it walks itself.
-__global__ __launch_bounds__(256) void k_decide(ResolveArgs A) {
+// One sample's verdict from its answers, walking the neighbours one after the other (any list width).
+__device__ __forceinline__ void decide_serial(const ResolveArgs& A, const DevForestView& f, int i, int& code, int& dk,
+                                              unsigned long long* cnt) {
+  auto calls = [](int fh, int ns) -> unsigned long long {
+    return fh != 0x7fffffff ? (unsigned long long)fh : (unsigned long long)ns;
+  };
+  unsigned long long &cc = cnt[0], &pf = cnt[1], &nq = cnt[2], &ex_pose = cnt[3], &ex_seg = cnt[4], &ex_smp = cnt[5];
+  const size_t s0 = (size_t)i * A.stride;
+  const int nnb = A.rec_nnb[i];
+  bool ovf = A.first_hit[s0] == 0;            // 0 = the edge's triangle candidate list ran over
+  const bool mine = A.world <= 1 || i % A.world == A.rank;   // (executed work is counted by the rank that ran it)
+  if (mine) {
+    ex_pose = 1;
+    ex_seg = 1 + (unsigned long long)nnb;
+    ex_smp = (unsigned long long)A.seg_ns[s0];
+  }
+  for (int k = 0; k < nnb; ++k) {
+    ovf |= A.first_hit[s0 + 1 + k] == 0;
+    if (mine) ex_smp += (unsigned long long)A.seg_ns[s0 + 1 + k];
+  }
+  if (ovf) { atomicOr(A.fault_pending, 1); return; }
+  cc = 1;                                    // :246 env.Collide(newPoint)
+  if (A.pose_hit[i]) return;
+  pf = 1;
+  cc += calls(A.first_hit[s0], A.seg_ns[s0]);
+  if (A.first_hit[s0] != 0x7fffffff) return;
+  nq = (unsigned long long)f.n_trees;        // parent edge free: the neighbour loop decides (:262-267 one radiusSearch per tree)
+  code = SFFK_ACCEPT;
+  for (int k = 0; k < nnb; ++k) {
+    if (A.rec_nb[(size_t)i * A.nbcap + k] >= f.temp_base) { code = SFFK_DEPENDS; dk = k; break; }
+    const int fh = A.first_hit[s0 + 1 + k];
+    const bool fr = fh == 0x7fffffff;
+    pf += 1;
+    cc += calls(fh, A.seg_ns[s0 + 1 + k]);
+    if (A.rec_meta[(size_t)i * A.nbcap + k] & 1) {
+      if (fr) { code = SFFK_REJECTED; break; }                       // :276-280 overcrowded
+    } else {
+      code = fr ? SFFK_REJECT_EVENT : SFFK_REJECTED;                  // :288-299
+      dk = k;
+      break;
+    }
+  }
+}
+
+// k_decide (wide): every sample's verdict as far as it can be told without the slot order.  16 lanes per sample -
+// lane 0 holds the parent edge, lane l the l-th neighbour - so the answers of a sample arrive with ONE round of
+// loads instead of one per neighbour visited (the kernel is a chain of dependent loads, nothing else); the walk
+// over the neighbours (src/forest.h:262-300) becomes "first lane that stops it".  64 samples per workgroup = one
+// word of each of the three lists k_resolve works on.
+__global__ __launch_bounds__(1024) void k_decide(ResolveArgs A, int n_bound) {
+  __shared__ int s_verdict[64];
+  __shared__ unsigned long long s_cnt[64][6];
   const DevForestView& f = A.f;
+  const int grp = threadIdx.x >> 4, gl = threadIdx.x & 15, lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 64 + grp;
+  // every answer the verdict may need is requested before anything is looked at - control block included: after a
+  // kernel boundary each dependent step is a trip to the memory side of the chip (the L2s start cold), and the buffers
+  // hold n_bound samples whatever the round's size is
+  const bool inb = i < n_bound;
+  const bool par16 = A.stride <= 16;
+  const size_t s0 = (size_t)i * A.stride;
+  const bool inl = inb && A.in_lim[i] != 0;
+  const int flags = inb ? A.rec_flags[i] : 0;
+  const int nnb = inb ? A.rec_nnb[i] : 0;
+  const bool pose_hit = inb && A.pose_hit[i] != 0;
+  int fh = 0x7fffffff, ns = 0, nb = 0, meta = 0;
+  if (inb && par16) {
+    fh = A.first_hit[s0 + gl]; ns = A.seg_ns[s0 + gl];
+    if (gl > 0) { nb = A.rec_nb[(size_t)i * A.nbcap + gl - 1]; meta = A.rec_meta[(size_t)i * A.nbcap + gl - 1]; }
+  }
   if (f.ctrl->halt) return;
   const int n = f.ctrl->n_act;
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  unsigned long long cc = 0, pf = 0, nq = 0, ex_pose = 0, ex_seg = 0, ex_smp = 0;
+  if (blockIdx.x * 64 >= n) return;
+  unsigned long long cnt[6] = {0, 0, 0, 0, 0, 0};   // cc, pf, nq, ex_pose, ex_seg, ex_smp
   int verdict = -1;
   if (i < n) {
     int code = SFFK_REJECTED, dk = 0;
-    if (!A.in_lim[i]) code = SFFK_OUTSIDE;
-    else if (A.rec_flags[i] & 2) atomicOr(A.fault_pending, 1);   // hit / neighbour list overflow: host path
-    else if ((A.rec_flags[i] & 3) == 1) {
-      auto calls = [](int fh, int ns) -> unsigned long long {
-        return fh != 0x7fffffff ? (unsigned long long)fh : (unsigned long long)ns;
-      };
-      const size_t s0 = (size_t)i * A.stride;
-      const int nnb = A.rec_nnb[i];
-      bool ovf = A.first_hit[s0] == 0;            // 0 = the edge's triangle candidate list ran over
-      const bool mine = A.world <= 1 || i % A.world == A.rank;   // (executed work is counted by the rank that ran it)
-      if (mine) {
-        ex_pose = 1;
-        ex_seg = 1 + (unsigned long long)nnb;
-        ex_smp = (unsigned long long)A.seg_ns[s0];
-      }
-      for (int k = 0; k < nnb; ++k) {
-        ovf |= A.first_hit[s0 + 1 + k] == 0;
-        if (mine) ex_smp += (unsigned long long)A.seg_ns[s0 + 1 + k];
-      }
-      if (ovf) atomicOr(A.fault_pending, 1);
-      else {
-        cc = 1;                                    // :246 env.Collide(newPoint)
-        if (!A.pose_hit[i]) {
-          pf = 1;
-          cc += calls(A.first_hit[s0], A.seg_ns[s0]);
-          if (A.first_hit[s0] == 0x7fffffff) {     // parent edge free: the neighbour loop decides
-            nq = (unsigned long long)f.n_trees;    // :262-267 one radiusSearch per tree
-            code = SFFK_ACCEPT;
-            for (int k = 0; k < nnb; ++k) {
-              if (A.rec_nb[(size_t)i * A.nbcap + k] >= f.temp_base) { code = SFFK_DEPENDS; dk = k; break; }
-              const int fh = A.first_hit[s0 + 1 + k];
-              const bool fr = fh == 0x7fffffff;
-              pf += 1;
-              cc += calls(fh, A.seg_ns[s0 + 1 + k]);
-              if (A.rec_meta[(size_t)i * A.nbcap + k] & 1) {
-                if (fr) { code = SFFK_REJECTED; break; }                       // :276-280 overcrowded
-              } else {
-                code = fr ? SFFK_REJECT_EVENT : SFFK_REJECTED;                  // :288-299
-                dk = k;
-                break;
+    if (!inl) code = SFFK_OUTSIDE;
+    else if (flags & 2) { if (gl == 0) atomicOr(A.fault_pending, 1); }   // hit / neighbour list overflow: host path
+    else if ((flags & 3) == 1) {
+      if (A.stride > 16) {
+        if (gl == 0) decide_serial(A, f, i, code, dk, cnt);
+        code = __shfl(code, lane & 48); dk = __shfl(dk, lane & 48);
+      } else {
+        auto calls = [](int fh, int ns) -> unsigned long long {
+          return fh != 0x7fffffff ? (unsigned long long)fh : (unsigned long long)ns;
+        };
+        const int gsh = lane & 48;                         // first lane of the group in its wavefront
+        auto gballot = [&](bool p) -> unsigned { return (unsigned)((__ballot(p) >> gsh) & 0xffffULL); };
+        auto gsum = [&](unsigned long long v) -> unsigned long long {
+          for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off);
+          return v;
+        };
+        const bool have = gl <= nnb;                       // (nnb <= nbcap <= 15)
+        if (!have) { fh = 0x7fffffff; ns = 0; nb = 0; meta = 0; }
+        const bool ovf = gballot(have && fh == 0) != 0;    // 0 = the edge's triangle candidate list ran over
+        const bool mine = A.world <= 1 || i % A.world == A.rank;   // (executed work is counted by the rank that ran it)
+        const unsigned long long smp = gsum(have ? (unsigned long long)ns : 0ULL);
+        if (mine) { cnt[3] = 1; cnt[4] = 1 + (unsigned long long)nnb; cnt[5] = smp; }
+        const bool fr = fh == 0x7fffffff;
+        const int fh0 = __shfl(fh, gsh), ns0 = __shfl(ns, gsh);
+        const bool walk = !ovf && !pose_hit && fh0 == 0x7fffffff;
+        // the neighbour walk: a lane stops it when its neighbour is a round-mate (the verdict waits), of another
+        // tree (:283-299), or of the same tree with a free edge (:276-280 overcrowded)
+        const bool is_nb = have && gl > 0;
+        const bool mate = is_nb && nb >= f.temp_base;
+        const bool same = (meta & 1) != 0;
+        const unsigned stops = gballot(is_nb && (mate || !same || fr));
+        const int ks = stops ? __ffs((int)stops) - 1 : 16;            // (group lane of the first stop)
+        const unsigned mates = gballot(mate);
+        const bool ks_mate = stops && ((mates >> ks) & 1u);
+        const bool visited = walk && is_nb && (gl < ks || (gl == ks && !ks_mate));
+        const unsigned long long v_pf = gsum(visited ? 1ULL : 0ULL), v_cc = gsum(visited ? calls(fh, ns) : 0ULL);
+        if (ovf) { if (gl == 0) atomicOr(A.fault_pending, 1); }
+        else {
+          cnt[0] = 1;                                // :246 env.Collide(newPoint)
+          if (!pose_hit) {
+            cnt[1] = 1;
+            cnt[0] += calls(fh0, ns0);
+            if (walk) {                              // parent edge free: the neighbour loop decides
+              cnt[2] = (unsigned long long)f.n_trees;   // :262-267 one radiusSearch per tree
+              cnt[1] += v_pf;
+              cnt[0] += v_cc;
+              code = SFFK_ACCEPT;
+              if (stops) {
+                const bool s_same = __shfl((int)same, gsh + ks) != 0, s_fr = __shfl((int)fr, gsh + ks) != 0;
+                if (ks_mate) { code = SFFK_DEPENDS; dk = ks - 1; }
+                else if (s_same) code = SFFK_REJECTED;
+                else { code = s_fr ? SFFK_REJECT_EVENT : SFFK_REJECTED; dk = ks - 1; }
               }
             }
           }
         }
       }
     }
-    A.code[i] = (uint8_t)code;
-    f.dk[i] = (uint8_t)dk;
-    // sample state for the commit: 0 undecided (depends on a round-mate), 1 rejected, 2 accepted, 3 rejected + border event
-    f.ustate[i] = code == SFFK_DEPENDS ? 0 : (code == SFFK_ACCEPT ? 2 : (code == SFFK_REJECT_EVENT ? 3 : 1));
+    if (gl == 0) {
+      A.code[i] = (uint8_t)code;
+      f.dk[i] = (uint8_t)dk;
+      // sample state for the commit: 0 undecided (depends on a round-mate), 1 rejected, 2 accepted, 3 rejected + border event
+      f.ustate[i] = code == SFFK_DEPENDS ? 0 : (code == SFFK_ACCEPT ? 2 : (code == SFFK_REJECT_EVENT ? 3 : 1));
+    }
     verdict = code;
   }
-  {   // one word per 64 samples for each of the three lists k_resolve works on
-    const unsigned long long wd = __ballot(verdict == SFFK_DEPENDS), wa = __ballot(verdict == SFFK_ACCEPT),
-                             we = __ballot(verdict == SFFK_REJECT_EVENT);
-    const int g = (blockIdx.x * 256 + (threadIdx.x & ~63)) >> 6;
-    if ((threadIdx.x & 63) == 0 && g * 64 < n) { f.w_dep[g] = wd; f.w_acc[g] = wa; f.w_ev[g] = we; }
+  if (gl == 0) {
+    s_verdict[grp] = verdict;
+    for (int q = 0; q < 6; ++q) s_cnt[grp][q] = cnt[q];
   }
-  for (int off = 32; off > 0; off >>= 1) {
-    cc += __shfl_xor(cc, off); pf += __shfl_xor(pf, off); nq += __shfl_xor(nq, off);
-    ex_pose += __shfl_xor(ex_pose, off); ex_seg += __shfl_xor(ex_seg, off); ex_smp += __shfl_xor(ex_smp, off);
-  }
-  if ((threadIdx.x & 63) == 0 && (cc | ex_pose)) {
-    atomicAdd(A.bulk + 0, cc); atomicAdd(A.bulk + 1, pf); atomicAdd(A.bulk + 2, nq);
-    atomicAdd(A.bulk + 4, ex_pose); atomicAdd(A.bulk + 5, ex_seg); atomicAdd(A.bulk + 6, ex_smp);
+  __syncthreads();
+  if (threadIdx.x < 64) {   // one word per 64 samples for each of the three lists k_resolve works on
+    const int v = s_verdict[threadIdx.x];
+    const unsigned long long wd = __ballot(v == SFFK_DEPENDS), wa = __ballot(v == SFFK_ACCEPT), we = __ballot(v == SFFK_REJECT_EVENT);
+    unsigned long long c6[6];
+    for (int q = 0; q < 6; ++q) {
+      c6[q] = s_cnt[threadIdx.x][q];
+      for (int off = 32; off > 0; off >>= 1) c6[q] += __shfl_xor(c6[q], off);
+    }
+    if (threadIdx.x == 0) {
+      const int g = blockIdx.x;
+      f.w_dep[g] = wd; f.w_acc[g] = wa; f.w_ev[g] = we;
+      // (no atomics: a thousand of them on one cache line take longer than the rest of this kernel)
+      for (int q = 0; q < 6; ++q) f.w_cnt[6 * (size_t)g + q] = c6[q];
+    }
   }
 }
 
@@ -291,7 +379,7 @@ __device__ __forceinline__ size_t border_slot(const DevForestView& f, unsigned l
 __global__ __launch_bounds__(DF_THREADS) void k_resolve(ResolveArgs A) {
   __shared__ WgLists L;
   __shared__ int undecided_s;
-  __shared__ unsigned long long cnt_s[3];
+  __shared__ unsigned long long cnt_s[8];
   __shared__ DevCtrl K;              // the control block, worked on in LDS and written back once
   __shared__ int ev_nb_s[DF_EV_LDS], ev_ex_s[DF_EV_LDS];
   __shared__ unsigned int ev_h_s[DF_EV_LDS];
@@ -328,7 +416,7 @@ __global__ __launch_bounds__(DF_THREADS) void k_resolve(ResolveArgs A) {
   const unsigned long long stamp_hi = (K.epoch + 1ULL) << 32;
   const int stride = A.stride, nbcap = A.nbcap;
   const int ng = (n + 63) >> 6;
-  if (threadIdx.x == 0) { cnt_s[0] = cnt_s[1] = 0ULL; }
+  if (threadIdx.x < 8) cnt_s[threadIdx.x] = 0ULL;
   unsigned long long tk[6];
   tk[0] = wall_clock64();
   // ---- 1. k_decide's words: dependent samples (they wait for an earlier sample of the round), accepted, border events
@@ -487,17 +575,29 @@ __global__ __launch_bounds__(DF_THREADS) void k_resolve(ResolveArgs A) {
   // ---- 5. counters, sizes (the next round's active list = the slots of this round that were not accepted, then
   // the slots the iteration cap kept out of it: k_append writes it from the accepted words)
   tk[4] = wall_clock64();
-  for (int off = 32; off > 0; off >>= 1) { cc += __shfl_xor(cc, off); pf += __shfl_xor(pf, off); }
-  if ((threadIdx.x & 63) == 0 && (cc | pf)) { atomicAdd(&cnt_s[0], cc); atomicAdd(&cnt_s[1], pf); }
+  {   // + k_decide's sums, one set per 64 samples
+    unsigned long long d6[6] = {0, 0, 0, 0, 0, 0};
+    for (int g = threadIdx.x; g < ng; g += DF_THREADS)
+      for (int q = 0; q < 6; ++q) d6[q] += f.w_cnt[6 * (size_t)g + q];
+    cc += d6[0]; pf += d6[1];
+    for (int off = 32; off > 0; off >>= 1) {
+      cc += __shfl_xor(cc, off); pf += __shfl_xor(pf, off);
+      for (int q = 2; q < 6; ++q) d6[q] += __shfl_xor(d6[q], off);
+    }
+    if ((threadIdx.x & 63) == 0 && (cc | pf | d6[3])) {
+      atomicAdd(&cnt_s[0], cc); atomicAdd(&cnt_s[1], pf);
+      for (int q = 2; q < 6; ++q) atomicAdd(&cnt_s[q], d6[q]);
+    }
+  }
   __threadfence_block();
   __syncthreads();
   if (threadIdx.x == 0) {
-    K.collide_calls += cnt_s[0] + A.bulk[0];
-    K.path_free_calls += cnt_s[1] + A.bulk[1];
-    K.nn_queries += A.bulk[2];
-    K.poses_executed += A.bulk[4];
-    K.segments_executed += A.bulk[5];
-    K.samples_executed += A.bulk[6];
+    K.collide_calls += cnt_s[0];
+    K.path_free_calls += cnt_s[1];
+    K.nn_queries += cnt_s[2];
+    K.poses_executed += cnt_s[3];
+    K.segments_executed += cnt_s[4];
+    K.samples_executed += cnt_s[5];
     K.work_items += (unsigned long long)A.round_ctrl[2];
     if (K.q_t1 > K.q_t0) { K.q_ticks += K.q_t1 - K.q_t0; K.q_launches += 1ULL; }
     K.app_n = n;                  // k_append applies this commit
@@ -734,7 +834,7 @@ void launch_wave_begin(hipStream_t s, const DevForestView& f) {
 }
 void launch_commit(hipStream_t s, const ResolveArgs& a, int n_bound) {
   if (n_bound <= 0) return;
-  hipLaunchKernelGGL(k_decide, dim3((n_bound + 255) / 256), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(k_decide, dim3((n_bound + 63) / 64), dim3(1024), 0, s, a, n_bound);
   hipLaunchKernelGGL(k_resolve, dim3(1), dim3(DF_THREADS), 0, s, a);
   hipLaunchKernelGGL(k_append, dim3((n_bound + 255) / 256), dim3(256), 0, s, a);
 }

@@ -110,7 +110,7 @@ struct Ctx {
   DevBuf d_a, d_b, d_c, d_d, d_e, d_f, d_g, d_h;
   PinBuf h_a, h_b, h_c, h_d, h_e, h_f, h_g, h_h;
   // round pipeline buffers of the forest engine (kept apart from the batch entry points' scratch)
-  DevBuf r_in, r_out, r_q, r_cnt, r_hidx, r_hdist, r_sega, r_segb, r_items, r_items2;
+  DevBuf r_in, r_out, r_q, r_cnt, r_hidx, r_hdist, r_sega, r_segb, r_items, r_items2, r_sub;
   PinBuf p_in, p_out;
 
   // kernel timing (HIP events on the launch stream)
@@ -223,7 +223,7 @@ struct DevEngine {
   bool active = false;    // the authoritative state currently lives on the device
   bool host_stale = false;// ... and is ahead of the host mirror
   bool table_dirty = false, ring_pending = false;
-  DevBuf frontier2, rm_words, rm_pref, slot_pos, act_slot2, dk, w_dep, w_acc, w_ev, acc_pref;
+  DevBuf frontier2, rm_words, rm_pref, slot_pos, act_slot2, dk, w_dep, w_acc, w_ev, acc_pref, w_cnt;
   DevBuf ctrl, parent, d_root, d_closest, iter, nflag, frontier, closed, claim, slot_node, slot_fail, act_slot, b_n1,
       b_n2, b_ta, b_tb, b_dist, bt_key, bt_val, pair, ring, ustate, ulist, uacc, d_parent, d_force, fault_pending;
   PinBuf h_ctrl, h_ring;

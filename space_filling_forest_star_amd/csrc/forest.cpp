@@ -283,7 +283,7 @@ Forest::~Forest() {
                     &dev.claim, &dev.slot_node, &dev.slot_fail, &dev.act_slot, &dev.b_n1, &dev.b_n2, &dev.b_ta, &dev.b_tb,
                     &dev.b_dist, &dev.bt_key, &dev.bt_val, &dev.pair, &dev.ring, &dev.ustate, &dev.ulist, &dev.uacc,
                     &dev.d_parent, &dev.d_force, &dev.fault_pending, &dev.frontier2, &dev.rm_words, &dev.rm_pref,
-                    &dev.slot_pos, &dev.act_slot2, &dev.dk, &dev.w_dep, &dev.w_acc, &dev.w_ev, &dev.acc_pref};
+                    &dev.slot_pos, &dev.act_slot2, &dev.dk, &dev.w_dep, &dev.w_acc, &dev.w_ev, &dev.acc_pref, &dev.w_cnt};
   if (dev.inited) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
@@ -543,6 +543,8 @@ void Forest::round_begin() {
   tmp.cnt = c.r_cnt.as<int32_t>();
   tmp.tg = c.tgridv;
   tmp.ctrl = d_ctrl;
+  c.r_sub.ensure((size_t)SFFK_SUBLISTS * SFFK_SUB_STRIDE * 4);
+  tmp.sub = c.r_sub.as<int32_t>();
   tmp.n_perm = N0;
   tmp.base = Tb;
   tmp.preset = cfg.libm_sampling ? reinterpret_cast<const double*>(c.r_in.as<char>() + in_preset) : nullptr;
@@ -586,6 +588,7 @@ void Forest::round_begin() {
   c.r_items.ensure((size_t)list_cap * SFFK_ITEM_BYTES);
   ca.items = c.r_items.p;
   ca.items_cap = list_cap;
+  ca.sub = c.r_sub.as<int32_t>();
   ca.pose_hit = d_pose;
   sffk::launch_query_classify(c.stream, c.gridv, &c.tgridv, c.store_view(), c.r_q.as<sffk::SweepQuery>(), ca, &c.envv);
   c.time_end();
@@ -603,7 +606,7 @@ void Forest::round_begin() {
   tref_keep.tg = sffk::GridView{};
   tref_keep.n = 0;
   sffk::launch_collide_items(c.stream, c.envv, c.robv, d_pos, n, ca.rec_flags, d_pose, ca.seg_a, ca.seg_b, ca.seg_ns,
-                             STRIDE, ca.ctrl, c.r_items.p, ca.first_hit, ca.seg_ovf, cfg.optimize ? &tref_keep : &tref);
+                             STRIDE, ca.ctrl, c.r_items.p, ca.items_cap, ca.sub, ca.first_hit, ca.seg_ovf, cfg.optimize ? &tref_keep : &tref);
   c.time_end();
   // samples this rank can settle alone need no replay (with a goal the replay may stop in the middle of the
   // round, so there every sample stays in it)

@@ -60,6 +60,7 @@ sffk::DevForestView Forest::dev_view() const {
   v.w_acc = d.w_acc.as<unsigned long long>();
   v.w_ev = d.w_ev.as<unsigned long long>();
   v.acc_pref = d.acc_pref.as<int32_t>();
+  v.w_cnt = d.w_cnt.as<unsigned long long>();
   v.b_n1 = d.b_n1.as<int32_t>();
   v.b_n2 = d.b_n2.as<int32_t>();
   v.b_ta = d.b_ta.as<int32_t>();
@@ -187,6 +188,7 @@ void Forest::dev_upload_state() {
     d.w_acc.ensure(((size_t)wave / 64 + 2) * 8);
     d.w_ev.ensure(((size_t)wave / 64 + 2) * 8);
     d.acc_pref.ensure(((size_t)wave / 64 + 2) * 4);
+    d.w_cnt.ensure(((size_t)wave / 64 + 2) * 6 * 8);
     d.ustate.ensure((size_t)wave);
     d.ulist.ensure((size_t)wave * 4);
     d.uacc.ensure((size_t)wave * 4);
@@ -445,7 +447,7 @@ static DevRoundBufs dev_round_bufs(Forest& F) {
   c.r_segb.ensure((size_t)n * B.STRIDE * 48);
   B.list_cap = 4 * n * B.STRIDE + 65536;
   c.r_items.ensure((size_t)B.list_cap * SFFK_ITEM_BYTES);
-  c.r_items2.ensure(((size_t)B.list_cap + (1u << 20)) * 8);
+  c.r_sub.ensure((size_t)SFFK_SUBLISTS * SFFK_SUB_STRIDE * 4);
   return B;
 }
 static sffk::ResolveArgs dev_resolve_args(Forest& F, const DevRoundBufs& B) {
@@ -518,6 +520,7 @@ void Forest::dev_enqueue_round_eval(void* send_dev) {
   tmp.cnt = c.r_cnt.as<int32_t>();
   tmp.tg = c.tgridv;
   tmp.ctrl = B.d_rctrl;
+  tmp.sub = c.r_sub.as<int32_t>();
   tmp.n_perm = d.temp_base;
   tmp.base = d.temp_base;
   sffk::DevRound dv{};
@@ -565,6 +568,7 @@ void Forest::dev_enqueue_round_eval(void* send_dev) {
   c.time_begin(T_SWEEP);
   ca.items = c.r_items.p;
   ca.items_cap = B.list_cap;
+  ca.sub = c.r_sub.as<int32_t>();
   ca.pose_hit = B.d_pose;
   sffk::launch_query_classify(c.stream, c.gridv, &c.tgridv, c.store_view(), c.r_q.as<sffk::SweepQuery>(), ca, &c.envv);
   c.time_end();
@@ -572,7 +576,7 @@ void Forest::dev_enqueue_round_eval(void* send_dev) {
   sffk::TempGridRef tref{c.tgridv, c.sx.as<float>() + d.temp_base, c.sy.as<float>() + d.temp_base,
                          c.sz.as<float>() + d.temp_base, n};
   sffk::launch_collide_items(c.stream, c.envv, c.robv, B.d_pos, n, ca.rec_flags, B.d_pose, ca.seg_a, ca.seg_b, ca.seg_ns,
-                             B.STRIDE, ca.ctrl, c.r_items.p, ca.first_hit, ca.seg_ovf, &tref, dev_n);
+                             B.STRIDE, ca.ctrl, c.r_items.p, ca.items_cap, ca.sub, ca.first_hit, ca.seg_ovf, &tref, dev_n);
   c.time_end();
   if (send_dev) sffk::launch_pack_records(c.stream, dev_resolve_args(*this, B), cfg.rank, cfg.world, n, static_cast<int32_t*>(send_dev));
   c.timing_on = true;

@@ -159,7 +159,8 @@ struct RoundTemps {
   GridView tg;     // per-round grid of the round's own samples (cnt == nullptr: none); same cells as the node grid
   NodeStoreMut st;
   int32_t* cnt;    // n hit counters
-  int32_t* ctrl;   // 16 ints zeroed per round (see launch_collide_segments_dyn)
+  int32_t* ctrl;   // 32 ints zeroed per round (see launch_collide_segments_dyn)
+  int32_t* sub;    // optional: the survivor list's SFFK_SUBLISTS counters (SFFK_SUB_STRIDE ints apart), zeroed per round
   int n_perm;      // permanent nodes in the store
   int base;        // 4-aligned index of the first temporary (>= n_perm)
   const double* preset;   // optional n x 6: sample positions computed by the caller (libm parity mode); the kernel
@@ -250,10 +251,13 @@ struct ClassifyArgs {
   // fused clearance cull (k_query_classify): the wave that wrote a sample's edge tasks looks the clearance bits of
   // their samples (and of the sample's own pose) up right away and appends only the (edge, 64-sample chunk, mask) /
   // pose items that need the exact test to `items` (ctrl[2] = count) - no work-list compaction, no cull kernel
-  void* items;              // SurvivorItem[items_cap]
-  int items_cap;
+  void* items;              // SurvivorItem[items_cap], split into SFFK_SUBLISTS equal sub-lists (workgroup b appends to
+  int items_cap;            // sub-list b % SFFK_SUBLISTS): one counter would see every append of the round, and
+  int32_t* sub;             // returning atomics on ONE word saturate near 90 per microsecond chip-wide
   uint8_t* pose_hit;        // n: preset to 0 here, 1 written by the exact kernel
 };
+#define SFFK_SUBLISTS 64
+#define SFFK_SUB_STRIDE 64   // ints between two sub-list counters (their own cache lines)
 struct SurvivorItem {       // 16 bytes
   int32_t slot;             // edge task slot, or -1 - sample for a pose
   int32_t chunk;
@@ -269,8 +273,9 @@ void launch_query_classify(hipStream_t s, const GridView& g, const GridView* tg,
 struct TempGridRef;
 void launch_collide_items(hipStream_t s, const EnvView& env, const RobotView& rob, const double* pos6, int n_pose,
                           const int32_t* live_flags, uint8_t* pose_hit, const double* a6, const double* b6,
-                          const int32_t* seg_ns, int stride, int32_t* ctrl, const void* items, int32_t* first_hit,
-                          int32_t* overflow_flag, const TempGridRef* temps, const int32_t* dev_n = nullptr);
+                          const int32_t* seg_ns, int stride, int32_t* ctrl, const void* items, int items_cap,
+                          const int32_t* sub, int32_t* first_hit, int32_t* overflow_flag, const TempGridRef* temps,
+                          const int32_t* dev_n = nullptr);
 struct SettleArgs {
   int n, Tb, nbcap, stride, n_trees;
   const uint8_t* in_lim;
@@ -340,6 +345,7 @@ struct DevForestView {
   // border-event flags; acc_pref = accepted samples before the word (k_append turns both into node ids and the
   // next round's active list without k_resolve ever walking the samples)
   unsigned long long* w_dep; unsigned long long* w_acc; unsigned long long* w_ev; int32_t* acc_pref;
+  unsigned long long* w_cnt;   // 6 counters per word (k_decide's sums over its 64 samples; k_resolve adds them up)
 };
 // per-sample verdicts of k_decide
 #define SFFK_DEPENDS 0     // the neighbour walk reached a sample of the same round first: k_resolve continues at dk

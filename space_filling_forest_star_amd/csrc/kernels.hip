@@ -49,6 +49,7 @@ __global__ __launch_bounds__(256) void k_sample_steer(const uint64_t* __restrict
     // placeholders for the store entries between the permanent nodes and the 4-aligned temporaries
     if (i < n) tmp.cnt[i] = 0;
     if (i < 32) tmp.ctrl[i] = 0;
+    if (tmp.sub && i < SFFK_SUBLISTS) tmp.sub[i * SFFK_SUB_STRIDE] = 0;
     if (i < tmp.base - tmp.n_perm) {
       const float nanv = __int_as_float(0x7fc00000);
       const size_t o = (size_t)tmp.n_perm + i;
@@ -1844,16 +1845,17 @@ __global__ __launch_bounds__(64 * QC_WAVES) __attribute__((amdgpu_waves_per_eu(Q
     SurvivorItem* list = static_cast<SurvivorItem*>(A.items);
     SurvivorItem* buf = s_surv[wave];
     int n_buf = 0;
+    const int sub_list = blockIdx.x & (SFFK_SUBLISTS - 1), sub_cap = A.items_cap / SFFK_SUBLISTS;
     [[maybe_unused]] const unsigned long long qt2 = DBG_T();
     QDBG(0, 1); QDBG(1, qt1 - qt0); QDBG(2, qt2 - qt1);
     auto flush = [&]() {
       [[maybe_unused]] const unsigned long long f0 = DBG_T();
       QDBG(6, n_buf);
       int base = 0;
-      if (lane == 0) base = atomicAdd(A.ctrl + 2, n_buf);
+      if (lane == 0) base = atomicAdd(A.sub + sub_list * SFFK_SUB_STRIDE, n_buf);
       base = __shfl(base, 0);
       if (lane < n_buf) {
-        if (base + lane < A.items_cap) list[base + lane] = buf[lane];
+        if (base + lane < sub_cap) list[(size_t)sub_list * sub_cap + base + lane] = buf[lane];
         else A.ctrl[3] = 1;
       }
       n_buf = 0;
@@ -1978,7 +1980,8 @@ __global__ __launch_bounds__(64 * SEG_WAVES) void k_collide_items(EnvView env, R
                                                                   const double* __restrict__ a6, const double* __restrict__ b6,
                                                                   const int32_t* __restrict__ seg_ns, int stride,
                                                                   int32_t* __restrict__ ctrl,
-                                                                  const SurvivorItem* __restrict__ list,
+                                                                  const SurvivorItem* __restrict__ list, int items_cap,
+                                                                  const int32_t* __restrict__ sub,
                                                                   int32_t* __restrict__ first_hit,
                                                                   int32_t* __restrict__ overflow_flag, GridView tg,
                                                                   const float* __restrict__ tx, const float* __restrict__ ty,
@@ -2005,8 +2008,18 @@ __global__ __launch_bounds__(64 * SEG_WAVES) void k_collide_items(EnvView env, R
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   double* stage = rtri + (size_t)rob.n_tri * 9 + (size_t)wave * STAGE_DOUBLES;
   int32_t* ibase = reinterpret_cast<int32_t*>(rtri + (size_t)rob.n_tri * 9 + (size_t)SEG_WAVES * STAGE_DOUBLES);
-  const int M = ctrl[2];
+  // the sub-lists' fill counts, one per lane (SFFK_SUBLISTS == 64), and their running sum
+  const int sub_cap = items_cap / SFFK_SUBLISTS;
+  int sub_n = sub[lane * SFFK_SUB_STRIDE];
+  sub_n = sub_n < sub_cap ? sub_n : sub_cap;
+  int sub_incl = sub_n;
+  for (int off = 1; off < 64; off <<= 1) {
+    const int o = __shfl_up(sub_incl, off);
+    if (lane >= off) sub_incl += o;
+  }
+  const int M = __shfl(sub_incl, 63);
   const bool ran_over = ctrl[3] != 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) ctrl[2] = M;   // (statistics)
   if ((M <= 0 && !ran_over) || env.n_tri == 0) return;
   for (int i = threadIdx.x; i < rob.n_tri * 9; i += blockDim.x) rtri[i] = rob.tri[i];
   __syncthreads();
@@ -2023,7 +2036,9 @@ __global__ __launch_bounds__(64 * SEG_WAVES) void k_collide_items(EnvView env, R
     int slot, c_lo, c_hi;
     unsigned long long mask = 0ULL;
     if (!ran_over) {
-      const SurvivorItem it = list[e];
+      const int sl = __popcll(__ballot(sub_incl <= e));   // the sub-list item e lies in
+      const int j = e - (__shfl(sub_incl, sl) - __shfl(sub_n, sl));
+      const SurvivorItem it = list[(size_t)sl * sub_cap + j];
       slot = it.slot; c_lo = it.chunk; c_hi = it.chunk + 1; mask = it.mask;
     } else if (e < n_pose) {
       if ((live_flags[e] & 3) != 1) continue;
@@ -2277,15 +2292,21 @@ void launch_query_classify(hipStream_t s, const GridView& g, const GridView* tg,
 }
 void launch_collide_items(hipStream_t s, const EnvView& env, const RobotView& rob, const double* pos6, int n_pose,
                           const int32_t* live_flags, uint8_t* pose_hit, const double* a6, const double* b6,
-                          const int32_t* seg_ns, int stride, int32_t* ctrl, const void* items, int32_t* first_hit,
-                          int32_t* overflow_flag, const TempGridRef* temps, const int32_t* dev_n) {
+                          const int32_t* seg_ns, int stride, int32_t* ctrl, const void* items, int items_cap,
+                          const int32_t* sub, int32_t* first_hit, int32_t* overflow_flag, const TempGridRef* temps,
+                          const int32_t* dev_n) {
   if (n_pose <= 0) return;
+  {
+    const int cap_override = getenv("SFFGPU_SEG_LISTCAP") ? atoi(getenv("SFFGPU_SEG_LISTCAP")) : -1;
+    if (cap_override >= 0 && cap_override < items_cap) items_cap = cap_override;
+  }
   size_t lds = collide_lds_bytes(rob.n_tri, SEG_WAVES);
   if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_collide_items), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   // 2 workgroups of 4 waves per CU = what the exact kernel's register budget keeps resident (256 CUs)
   static const int blocks = std::min(4096, std::max(1, getenv("SFFGPU_SEG_BLOCKS") ? atoi(getenv("SFFGPU_SEG_BLOCKS")) : 512));
   hipLaunchKernelGGL(k_collide_items, dim3(blocks), dim3(64 * SEG_WAVES), lds, s, env, rob, pos6, n_pose, live_flags, pose_hit,
-                     a6, b6, seg_ns, stride, ctrl, static_cast<const SurvivorItem*>(items), first_hit, overflow_flag,
+                     a6, b6, seg_ns, stride, ctrl, static_cast<const SurvivorItem*>(items), items_cap, sub, first_hit,
+                     overflow_flag,
                      temps ? temps->tg : GridView{}, temps ? temps->x : nullptr, temps ? temps->y : nullptr,
                      temps ? temps->z : nullptr, temps ? temps->n : 0, dev_n);
 }

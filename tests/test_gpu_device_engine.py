@@ -130,6 +130,16 @@ def test_list_overflow_faults_finish_the_wave_on_the_host_path(S, ctx, env):
     assert_same_forest(fo, fg)
 
 
+def test_survivor_list_overflow_scans_the_slot_table(S, ctx):
+    """the fused cull's survivor list holds 5 items only: the exact kernel has to test every live pose and every chunk
+    of every live edge itself; the forest must not change"""
+    fo, fg = make(S, ctx, "dense3d", 512, 30000, seed=6, SFFGPU_SEG_LISTCAP=5)
+    with engine(SFFGPU_SEG_LISTCAP=5):
+        fo.run()
+        fg.run()
+    assert_same_forest(fo, fg)
+
+
 def test_arrays_and_border_table_grow_on_demand(S, ctx):
     """no node budget: the store starts at 4096 nodes and has to grow; many borders: the border list and its hash
     table start small (test knob) and have to grow too"""
