@@ -36,6 +36,7 @@ using namespace sffg;
 
 #define DF_THREADS 1024
 #define DF_WAVES (DF_THREADS / 64)
+#define DF_DEPB 32                          // x 64 dependent samples whose records k_resolve keeps in registers (two per thread)
 #define DF_EV_LDS 1024                      // border events of a round whose details stay in LDS
 #define DF_MAX_GROUPS SFFK_DEV_MAX_GROUPS   // ballot words in LDS: 64 x this many elements per list
 
@@ -140,6 +141,7 @@ __device__ void round_begin_scalars(const DevForestView& f, DevCtrl* c) {
 __global__ __launch_bounds__(DF_THREADS) void k_wave_begin(DevForestView f) {
   __shared__ int any_redraw;
   DevCtrl* c = f.ctrl;
+  const unsigned long long tb0 = wall_clock64();
   if (threadIdx.x == 0) { c->compact_from = 0; c->app_n = 0; }   // (no stale order for the wide follow-up kernels)
   if (c->halt) return;
   if (c->in_wave) {   // resuming inside a wave (after the host handled a fault): the active list is in place
@@ -157,11 +159,30 @@ __global__ __launch_bounds__(DF_THREADS) void k_wave_begin(DevForestView f) {
   const unsigned long long cur = c->cursor;
   if (threadIdx.x == 0) any_redraw = 0;
   __syncthreads();
-  for (int s = threadIdx.x; s < n_slots; s += DF_THREADS) {
-    const int pick = lemire_pick(f.ring[(cur + (unsigned long long)s) & f.ring_mask], (unsigned long long)pool);
-    if (pick < 0) any_redraw = 1;
-    else { f.slot_node[s] = from[pick]; f.slot_pos[s] = pick; }
-    act[s] = s;                 // every slot starts the wave failing
+  // (eight slots per thread and step: the words, then the picked nodes, arrive as two rounds of independent loads -
+  // one slot at a time the kernel is a chain of a hundred dependent round trips)
+  for (int s0 = 0; s0 < n_slots; s0 += 8 * DF_THREADS) {
+    unsigned long long wd[8];
+    int pick[8], node[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int sl = s0 + u * DF_THREADS + threadIdx.x;
+      wd[u] = sl < n_slots ? f.ring[(cur + (unsigned long long)sl) & f.ring_mask] : 0ULL;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int sl = s0 + u * DF_THREADS + threadIdx.x;
+      pick[u] = sl < n_slots ? lemire_pick(wd[u], (unsigned long long)pool) : -1;
+      node[u] = pick[u] >= 0 ? from[pick[u]] : 0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int sl = s0 + u * DF_THREADS + threadIdx.x;
+      if (sl >= n_slots) continue;
+      if (pick[u] < 0) any_redraw = 1;
+      else { f.slot_node[sl] = node[u]; f.slot_pos[sl] = pick[u]; }
+      act[sl] = sl;                 // every slot starts the wave failing
+    }
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -185,6 +206,7 @@ __global__ __launch_bounds__(DF_THREADS) void k_wave_begin(DevForestView f) {
     c->in_wave = 1;
     c->waves += 1;
     round_begin_scalars(f, c);
+    c->wprof[6] += wall_clock64() - tb0;
   }
 }
 
@@ -319,7 +341,22 @@ __global__ __launch_bounds__(1024) void k_decide(ResolveArgs A, int n_bound) {
               code = SFFK_ACCEPT;
               if (stops) {
                 const bool s_same = __shfl((int)same, gsh + ks) != 0, s_fr = __shfl((int)fr, gsh + ks) != 0;
-                if (ks_mate) { code = SFFK_DEPENDS; dk = ks - 1; }
+                if (ks_mate) {
+                  code = SFFK_DEPENDS; dk = ks - 1;
+                  // what is left of the walk, for k_resolve: the neighbours from the round-mate on, up to the first one
+                  // that ends the walk whatever the round-mates turn out to be.  The first four entries travel in the
+                  // record (id | edge free, same tree, reference-equivalent calls); longer walks are rare and re-read
+                  // the lists.
+                  const unsigned defs = gballot(is_nb && gl > ks && !mate && (!same || fr));
+                  const int last = defs ? __ffs((int)defs) - 1 : nnb;            // (group lane of the last entry)
+                  int32_t* rec = f.dep_rec + (size_t)i * SFFK_DEP_REC;
+                  if (gl == 0) { rec[0] = last - ks + 1; rec[1] = dk; }
+                  const int at = gl - ks;
+                  if (at >= 0 && at < 4 && gl <= last) {
+                    rec[2 + 2 * at] = nb;
+                    rec[3 + 2 * at] = (int)((calls(fh, ns) << 2) | (fr ? 2ULL : 0ULL) | (same ? 1ULL : 0ULL));
+                  }
+                }
                 else if (s_same) code = SFFK_REJECTED;
                 else { code = s_fr ? SFFK_REJECT_EVENT : SFFK_REJECTED; dk = ks - 1; }
               }
@@ -374,6 +411,37 @@ __device__ __forceinline__ size_t border_slot(const DevForestView& f, unsigned l
   }
 }
 
+// A dependent sample's neighbour walk out of the answer lists, from the neighbour k_decide stopped at (f.dk).  Returns
+// the verdict (0 = a round-mate it meets is not decided yet, 1 rejected, 2 accepted, 3 rejected + border event at
+// neighbour ev_nb) and the reference-equivalent call counts of what it visited.
+__device__ int walk_lists(const ResolveArgs& A, const DevForestView& f, int i, int Tb, unsigned long long& c1,
+                          unsigned long long& p1, int& ev_nb, const WgLists* dep = nullptr, const uint8_t* dstate = nullptr) {
+  const size_t s0 = (size_t)i * A.stride;
+  const int nnb = A.rec_nnb[i];
+  c1 = 0; p1 = 0;
+  for (int k = f.dk[i]; k < nnb; ++k) {
+    const int id = A.rec_nb[(size_t)i * A.nbcap + k];
+    if (id >= Tb) {
+      int sj = f.ustate[id - Tb];
+      // (dep: the verdicts of this round's dependent samples are still in LDS, by position in the dependent list)
+      if (sj == 0 && dep) sj = dstate[wg_rank(*dep, id - Tb)];
+      if (sj == 0) return 0;                      // not known yet: next pass
+      if (sj != 2) continue;                      // that sample never became a node
+    }
+    const int fh = A.first_hit[s0 + 1 + k];
+    const bool fr = fh == 0x7fffffff;
+    p1 += 1;
+    c1 += fr ? (unsigned long long)A.seg_ns[s0 + 1 + k] : (unsigned long long)fh;
+    if (A.rec_meta[(size_t)i * A.nbcap + k] & 1) {
+      if (fr) return 1;                           // :276-280 overcrowded
+    } else {
+      ev_nb = k;                                  // :288-299
+      return fr ? 3 : 1;
+    }
+  }
+  return 2;
+}
+
 // k_resolve (one workgroup): what needs the slot order.  Sample states: 0 undecided, 1 rejected, 2 accepted,
 // 3 rejected with a border event (neighbour dk).
 __global__ __launch_bounds__(DF_THREADS) void k_resolve(ResolveArgs A) {
@@ -385,6 +453,9 @@ __global__ __launch_bounds__(DF_THREADS) void k_resolve(ResolveArgs A) {
   __shared__ unsigned int ev_h_s[DF_EV_LDS];
   __shared__ unsigned long long W_acc[DF_MAX_GROUPS], W_ev[DF_MAX_GROUPS];   // accepted / border-event words of the round
   __shared__ int W_accp[DF_MAX_GROUPS];
+  __shared__ int dep_s[DF_DEPB * 64];
+  __shared__ uint8_t dstate_s[DF_DEPB * 64];
+   // verdicts of the dependent samples, by position in the dependent list
   const DevForestView& f = A.f;
   DevCtrl* c = f.ctrl;
   if (threadIdx.x == 0) c->app_n = 0;
@@ -419,14 +490,21 @@ __global__ __launch_bounds__(DF_THREADS) void k_resolve(ResolveArgs A) {
   if (threadIdx.x < 8) cnt_s[threadIdx.x] = 0ULL;
   unsigned long long tk[6];
   tk[0] = wall_clock64();
+  // k_decide's counter sums, one set per 64 samples: requested now, added up at the end
+  unsigned long long d6[6] = {0, 0, 0, 0, 0, 0};
+  for (int g = threadIdx.x; g < ng; g += DF_THREADS)
+    for (int q = 0; q < 6; ++q) d6[q] += f.w_cnt[6 * (size_t)g + q];
   // ---- 1. k_decide's words: dependent samples (they wait for an earlier sample of the round), accepted, border events
   for (int g = threadIdx.x; g < ng; g += DF_THREADS) { L.words[g] = f.w_dep[g]; W_acc[g] = f.w_acc[g]; W_ev[g] = f.w_ev[g]; }
   const int n_dep = wg_prefix(L, n);
+  const bool fast = stride <= 16 && n_dep <= DF_DEPB * 64;   // (k_decide left a record per dependent sample)
   for (int g = threadIdx.x; g < ng; g += DF_THREADS) {   // the dependent list, in slot order (set bits only)
     unsigned long long w = L.words[g];
     int at = L.pref[g];
     while (w) {
-      f.ulist[at++] = g * 64 + __ffsll((long long)w) - 1;
+      const int i = g * 64 + __ffsll((long long)w) - 1;
+      if (fast) dep_s[at] = i;
+      f.ulist[at++] = i;
       w &= w - 1;
     }
   }
@@ -437,7 +515,103 @@ __global__ __launch_bounds__(DF_THREADS) void k_resolve(ResolveArgs A) {
   unsigned long long cc = 0, pf = 0;
   tk[1] = wall_clock64();
   int passes = 0;
-  for (int pass = 0; pass < n + 2 && n_dep > 0; ++pass) {
+  bool fast_done = false;
+  if (fast && n_dep > 0) {
+    // one thread per dependent sample (two if there are more than a workgroup's worth): its record is read ONCE and
+    // stays in registers, a pass only polls LDS - no global traffic, no fence.  (One workgroup = one compute unit:
+    // walking the lists out of global memory pass after pass is bound by that unit's address rate and by the
+    // write-through of every verdict.)  A record longer than four entries walks the lists, polling LDS as well.
+    int ri[2], rlen[2], rbase[2], ra[2][4], rb[2][4], vr[2], ve[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      const int u = r * DF_THREADS + threadIdx.x;
+      ri[r] = u < n_dep ? dep_s[u] : -1;
+      rlen[r] = 0; rbase[r] = 0; vr[r] = 0; ve[r] = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { ra[r][e] = 0; rb[r][e] = 0; }
+      if (u < n_dep) dstate_s[u] = 0;
+      if (ri[r] >= 0) {
+        const int4* rec = reinterpret_cast<const int4*>(f.dep_rec + (size_t)ri[r] * SFFK_DEP_REC);
+        const int4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
+        rlen[r] = q0.x; rbase[r] = q0.y;
+        ra[r][0] = q0.z; rb[r][0] = q0.w; ra[r][1] = q1.x; rb[r][1] = q1.y;
+        ra[r][2] = q1.z; rb[r][2] = q1.w; ra[r][3] = q2.x; rb[r][3] = q2.y;
+      }
+    }
+    // round-mates k_decide has settled are folded into the entries for good (accepted: an ordinary neighbour,
+    // rejected: no neighbour at all); the others are dependent samples themselves and are polled in LDS by their
+    // position in the dependent list (L still holds the dependent words and their prefix)
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      if (ri[r] < 0) continue;
+      int sj[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sj[e] = (e < rlen[r] && ra[r][e] >= Tb) ? (int)f.ustate[ra[r][e] - Tb] : -1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (sj[e] < 0) continue;                                         // (an ordinary neighbour)
+        if (sj[e] == 0) ra[r][e] = -1 - wg_rank(L, ra[r][e] - Tb);
+        else if (sj[e] == 2) ra[r][e] = 0;
+        else rb[r][e] = -1;                                              // that sample never became a node
+      }
+    }
+    __syncthreads();
+    {
+      fast_done = true;
+      for (int pass = 0; pass < n + 2; ++pass) {
+        ++passes;
+        if (threadIdx.x == 0) undecided_s = 0;
+        __syncthreads();
+        int mine_undecided = 0;
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+          if (ri[r] < 0 || vr[r] != 0) continue;
+          unsigned long long c1 = 0, p1 = 0;
+          int verdict = 2, ev_nb = 0;
+          bool walking = rlen[r] <= 4;
+          if (!walking) verdict = walk_lists(A, f, ri[r], Tb, c1, p1, ev_nb, &L, dstate_s);   // (a long walk: rare)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (!walking || e >= rlen[r]) continue;
+            const int id = ra[r][e], fl = rb[r][e];
+            if (fl < 0) continue;                                        // (a round-mate that never became a node)
+            if (id < 0) {
+              const int sj = dstate_s[-1 - id];
+              if (sj == 0) { verdict = 0; walking = false; continue; }   // not known yet: next pass
+              if (sj != 2) continue;                                     // that sample never became a node
+            }
+            p1 += 1;
+            c1 += (unsigned long long)(fl >> 2);
+            if (fl & 1) {
+              if (fl & 2) { verdict = 1; walking = false; }              // :276-280 overcrowded
+            } else {
+              verdict = (fl & 2) ? 3 : 1;                                // :288-299
+              ev_nb = rbase[r] + e;
+              walking = false;
+            }
+          }
+          if (verdict == 0) { mine_undecided = 1; continue; }
+          cc += c1; pf += p1;
+          vr[r] = verdict; ve[r] = ev_nb;
+          dstate_s[r * DF_THREADS + threadIdx.x] = (uint8_t)verdict;
+        }
+        if (mine_undecided) undecided_s = 1;
+        __syncthreads();
+        if (!undecided_s) break;
+        __syncthreads();
+      }
+#pragma unroll
+      for (int r = 0; r < 2; ++r) {   // the verdicts, for the steps below and for k_append
+        const int i = ri[r];
+        if (i < 0) continue;
+        if (vr[r] == 3) { f.dk[i] = (uint8_t)ve[r]; atomicOr(&W_ev[i >> 6], 1ULL << (i & 63)); }
+        if (vr[r] == 2) atomicOr(&W_acc[i >> 6], 1ULL << (i & 63));
+        f.ustate[i] = (uint8_t)vr[r];
+      }
+      __threadfence_block();
+    }
+  }
+  for (int pass = 0; pass < n + 2 && n_dep > 0 && !fast_done; ++pass) {
     ++passes;
     if (threadIdx.x == 0) undecided_s = 0;
     __syncthreads();
@@ -445,29 +619,9 @@ __global__ __launch_bounds__(DF_THREADS) void k_resolve(ResolveArgs A) {
     for (int u = threadIdx.x; u < n_dep; u += DF_THREADS) {
       const int i = f.ulist[u];
       if (f.ustate[i] != 0) continue;
-      const size_t s0 = (size_t)i * stride;
-      const int nnb = A.rec_nnb[i];
       unsigned long long c1 = 0, p1 = 0;
-      int verdict = 2, ev_nb = 0;
-      for (int k = f.dk[i]; k < nnb; ++k) {
-        const int id = A.rec_nb[(size_t)i * nbcap + k];
-        if (id >= Tb) {
-          const int sj = f.ustate[id - Tb];
-          if (sj == 0) { verdict = 0; break; }        // not known yet: next pass
-          if (sj != 2) continue;                      // that sample never became a node
-        }
-        const int fh = A.first_hit[s0 + 1 + k];
-        const bool fr = fh == 0x7fffffff;
-        p1 += 1;
-        c1 += fr ? (unsigned long long)A.seg_ns[s0 + 1 + k] : (unsigned long long)fh;
-        if (A.rec_meta[(size_t)i * nbcap + k] & 1) {
-          if (fr) { verdict = 1; break; }             // :276-280 overcrowded
-        } else {
-          verdict = fr ? 3 : 1;                       // :288-299
-          ev_nb = k;
-          break;
-        }
-      }
+      int ev_nb = 0;
+      const int verdict = walk_lists(A, f, i, Tb, c1, p1, ev_nb);
       if (verdict == 0) { mine_undecided = 1; continue; }
       cc += c1; pf += p1;
       if (verdict == 3) { f.dk[i] = (uint8_t)ev_nb; atomicOr(&W_ev[i >> 6], 1ULL << (i & 63)); }
@@ -576,9 +730,6 @@ __global__ __launch_bounds__(DF_THREADS) void k_resolve(ResolveArgs A) {
   // the slots the iteration cap kept out of it: k_append writes it from the accepted words)
   tk[4] = wall_clock64();
   {   // + k_decide's sums, one set per 64 samples
-    unsigned long long d6[6] = {0, 0, 0, 0, 0, 0};
-    for (int g = threadIdx.x; g < ng; g += DF_THREADS)
-      for (int q = 0; q < 6; ++q) d6[q] += f.w_cnt[6 * (size_t)g + q];
     cc += d6[0]; pf += d6[1];
     for (int off = 32; off > 0; off >>= 1) {
       cc += __shfl_xor(cc, off); pf += __shfl_xor(pf, off);
@@ -684,51 +835,123 @@ __global__ __launch_bounds__(DF_THREADS) void k_wave_end(DevForestView f, const 
   const int n_fail = c->act_cnt;                 // the slots still failing, in slot order
   const int32_t* act = act_now(f);
   int removed = 0;
+  unsigned long long tw[7];
+  for (int q = 0; q < 7; ++q) tw[q] = wall_clock64();
   // ---- exhausted slots: the node leaves the frontier for the closed list (src/forest.h:160-178); a node held by
   // several slots moves once, at its first slot.  Its position in the frontier (the pick index) is marked in rm_words.
   if (!from_closed) {
-    for (int w = threadIdx.x; w < nw; w += DF_THREADS) f.rm_words[w] = 0ULL;
-    for (int e = threadIdx.x; e < n_fail; e += DF_THREADS) atomicMin(&f.claim[f.slot_node[act[e]]], e);
+    // (rm_words is all zero between waves: k_frontier_compact clears the words it has consumed.  Loads in batches of
+    // eight independent ones per thread; the failing slots' nodes are parked in ulist for the later passes.)
+    int32_t* nodes = f.ulist;
+    for (int e0 = 0; e0 < n_fail; e0 += 8 * DF_THREADS) {
+      int sl[8], nd[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int e = e0 + u * DF_THREADS + threadIdx.x; sl[u] = e < n_fail ? act[e] : -1; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) nd[u] = sl[u] >= 0 ? f.slot_node[sl[u]] : -1;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + u * DF_THREADS + threadIdx.x;
+        if (nd[u] >= 0) { atomicMin(&f.claim[nd[u]], e); nodes[e] = nd[u]; }
+      }
+    }
     __threadfence_block();   // (one workgroup: its L1 and the barrier order everything; an agent-scope fence would write the L2 back)
     __syncthreads();
-    wg_flags(L, n_fail, [&](int e) {
-      return __hip_atomic_load(&f.claim[f.slot_node[act[e]]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == e;
-    });
+    tw[1] = wall_clock64();
+    {   // flags: the slot that owns its node's claim (four groups of 64 per wave in flight)
+      const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+      const int ngf = (n_fail + 63) >> 6;
+      for (int g0 = wave; g0 < ngf; g0 += 4 * DF_WAVES) {
+        int nd[4], own[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const int e = (g0 + u * DF_WAVES) * 64 + lane; nd[u] = e < n_fail ? nodes[e] : -1; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          own[u] = nd[u] >= 0 ? __hip_atomic_load(&f.claim[nd[u]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int g = g0 + u * DF_WAVES;
+          const int e = g * 64 + lane;
+          const unsigned long long m = __ballot(nd[u] >= 0 && own[u] == e);
+          if (lane == 0 && g < ngf) L.words[g] = m;
+        }
+      }
+    }
     removed = wg_prefix(L, n_fail);
+    tw[2] = wall_clock64();
     const int cn0 = c->closed_n;
-    for (int e = threadIdx.x; e < n_fail; e += DF_THREADS) {
-      if (!wg_flagged(L, e)) continue;
-      const int s = act[e];
-      const int node = f.slot_node[s];
-      f.closed[cn0 + wg_rank(L, e)] = node;
-      f.nflag[node] = (uint8_t)((f.nflag[node] & ~2) | 1);
-      const int pos = f.slot_pos[s];
-      atomicOr(&f.rm_words[pos >> 6], 1ULL << (pos & 63));
+    for (int e0 = 0; e0 < n_fail; e0 += 8 * DF_THREADS) {
+      int nd[8], ps[8], fl[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + u * DF_THREADS + threadIdx.x;
+        const bool on = e < n_fail && wg_flagged(L, e);
+        nd[u] = on ? nodes[e] : -1;
+        ps[u] = on ? f.slot_pos[act[e]] : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) fl[u] = nd[u] >= 0 ? f.nflag[nd[u]] : 0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int e = e0 + u * DF_THREADS + threadIdx.x;
+        if (nd[u] < 0) continue;
+        f.closed[cn0 + wg_rank(L, e)] = nd[u];
+        f.nflag[nd[u]] = (uint8_t)((fl[u] & ~2) | 1);
+        atomicOr(&f.rm_words[ps[u] >> 6], 1ULL << (ps[u] & 63));
+      }
     }
     __syncthreads();
+    tw[3] = wall_clock64();
     for (int e = threadIdx.x; e < n_fail; e += DF_THREADS)     // (claims cleared only now: every slot of a node saw them)
-      f.claim[f.slot_node[act[e]]] = 0x7fffffff;
-    // exclusive prefix of the removed positions per 64-entry word (k_frontier_compact shifts by it)
-    __threadfence_block();   // (one workgroup: its L1 and the barrier order everything; an agent-scope fence would write the L2 back)
+      f.claim[nodes[e]] = 0x7fffffff;
+    // exclusive prefix of the removed positions per 64-entry word (k_frontier_compact shifts by it): every thread
+    // sums a contiguous run of words, the runs are scanned through LDS
+    __threadfence_block();
     __syncthreads();
-    if (removed > 0 && threadIdx.x < 64) {
-      const int lane = threadIdx.x;
-      int run = 0;
-      for (int b = 0; b < nw; b += 64) {
-        const int w = b + lane;
-        const int cnt = w < nw ? __popcll(__hip_atomic_load(&f.rm_words[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) : 0;
-        int inc = cnt;
-        for (int off = 1; off < 64; off <<= 1) {
-          const int o = __shfl_up(inc, off);
-          if (lane >= off) inc += o;
+    tw[4] = wall_clock64();
+    if (removed > 0) {
+      const int per = (nw + DF_THREADS - 1) / DF_THREADS;
+      const int w0 = threadIdx.x * per;
+      int mine = 0;
+      for (int k0 = 0; k0 < per; k0 += 8) {
+        unsigned long long wv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int w = w0 + k0 + u;
+          wv[u] = (k0 + u < per && w < nw) ? __hip_atomic_load(&f.rm_words[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ULL;
         }
-        if (w < nw) f.rm_pref[w] = run + inc - cnt;
-        run += __shfl(inc, 63);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) mine += __popcll(wv[u]);
+      }
+      L.pref[threadIdx.x] = mine;        // (DF_THREADS <= DF_MAX_GROUPS)
+      __syncthreads();
+      if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        int run = 0;
+        for (int b = 0; b < DF_THREADS; b += 64) {
+          const int v = L.pref[b + lane];
+          int inc = v;
+          for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(inc, off);
+            if (lane >= off) inc += o;
+          }
+          L.pref[b + lane] = run + inc - v;
+          run += __shfl(inc, 63);
+        }
+      }
+      __syncthreads();
+      int run = L.pref[threadIdx.x];
+      for (int k = 0; k < per; ++k) {
+        const int w = w0 + k;
+        if (w >= nw) break;
+        f.rm_pref[w] = run;
+        run += __popcll(__hip_atomic_load(&f.rm_words[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
       }
     }
     __syncthreads();
   }
   // ---- termination (src/forest.h:184-201)
+  tw[5] = wall_clock64();
   if (threadIdx.x == 0) {
     c->closed_n += removed;
     c->compact_from = removed > 0 ? fn : 0;     // k_frontier_compact: entries of the old buffer to sift
@@ -761,6 +984,9 @@ __global__ __launch_bounds__(DF_THREADS) void k_wave_end(DevForestView f, const 
     c->n_act = 0;
     c->grid_ovf = grid_ovf[0];
     c->tgrid_ovf = tgrid_ovf[0];
+    tw[6] = wall_clock64();
+    if (!from_closed) for (int q = 0; q < 6; ++q) c->wprof[q] += tw[q + 1] - tw[q];
+    c->wprof[7] += 1ULL;
   }
 }
 
@@ -771,10 +997,16 @@ __global__ __launch_bounds__(256) void k_frontier_compact(DevForestView f) {
   if (n <= 0) return;                       // nothing was removed in this wave (or the kernel ran before a wave ended)
   const int32_t* src = c->front_sel ? f.frontier : f.frontier2;   // (front_sel already names the NEW buffer)
   int32_t* dst = c->front_sel ? f.frontier2 : f.frontier;
-  for (int r = blockIdx.x * 256 + threadIdx.x; r < n; r += gridDim.x * 256) {
+  // (a word's 64 positions are one wavefront's lanes in one step: all of them have read it when lane 0 clears it for
+  // the next wave)
+  const int n_up = (n + 63) & ~63;
+  for (int r = blockIdx.x * 256 + threadIdx.x; r < n_up; r += gridDim.x * 256) {
     const unsigned long long w = f.rm_words[r >> 6];
-    if ((w >> (r & 63)) & 1ULL) continue;
-    dst[r - f.rm_pref[r >> 6] - __popcll(w & ((1ULL << (r & 63)) - 1ULL))] = src[r];
+    const int pref = f.rm_pref[r >> 6];
+    __builtin_amdgcn_wave_barrier();
+    if ((r & 63) == 0 && w) f.rm_words[r >> 6] = 0ULL;
+    if (r >= n || ((w >> (r & 63)) & 1ULL)) continue;
+    dst[r - pref - __popcll(w & ((1ULL << (r & 63)) - 1ULL))] = src[r];
   }
 }
 

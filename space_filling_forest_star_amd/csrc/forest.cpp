@@ -283,7 +283,7 @@ Forest::~Forest() {
                     &dev.claim, &dev.slot_node, &dev.slot_fail, &dev.act_slot, &dev.b_n1, &dev.b_n2, &dev.b_ta, &dev.b_tb,
                     &dev.b_dist, &dev.bt_key, &dev.bt_val, &dev.pair, &dev.ring, &dev.ustate, &dev.ulist, &dev.uacc,
                     &dev.d_parent, &dev.d_force, &dev.fault_pending, &dev.frontier2, &dev.rm_words, &dev.rm_pref,
-                    &dev.slot_pos, &dev.act_slot2, &dev.dk, &dev.w_dep, &dev.w_acc, &dev.w_ev, &dev.acc_pref, &dev.w_cnt};
+                    &dev.slot_pos, &dev.act_slot2, &dev.dk, &dev.w_dep, &dev.w_acc, &dev.w_ev, &dev.acc_pref, &dev.w_cnt, &dev.dep_rec};
   if (dev.inited) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);

@@ -61,6 +61,7 @@ sffk::DevForestView Forest::dev_view() const {
   v.w_ev = d.w_ev.as<unsigned long long>();
   v.acc_pref = d.acc_pref.as<int32_t>();
   v.w_cnt = d.w_cnt.as<unsigned long long>();
+  v.dep_rec = d.dep_rec.as<int32_t>();
   v.b_n1 = d.b_n1.as<int32_t>();
   v.b_n2 = d.b_n2.as<int32_t>();
   v.b_ta = d.b_ta.as<int32_t>();
@@ -103,7 +104,10 @@ void Forest::dev_size_node_arrays() {
   d.nflag.ensure((size_t)cap);
   d.frontier.ensure((size_t)cap * 4);
   d.frontier2.ensure((size_t)cap * 4);
+  const size_t old_rm = d.rm_words.cap;
   d.rm_words.ensure(((size_t)cap / 64 + 2) * 8);
+  if (d.rm_words.cap != old_rm)   // (all zero between waves: k_frontier_compact clears what k_wave_end marked)
+    HIPCHK(hipMemsetAsync(d.rm_words.p, 0, d.rm_words.cap, c.stream));
   d.rm_pref.ensure(((size_t)cap / 64 + 2) * 4);
   d.closed.ensure((size_t)cap * 4);
   const size_t old_claim = d.claim.cap;
@@ -189,6 +193,7 @@ void Forest::dev_upload_state() {
     d.w_ev.ensure(((size_t)wave / 64 + 2) * 8);
     d.acc_pref.ensure(((size_t)wave / 64 + 2) * 4);
     d.w_cnt.ensure(((size_t)wave / 64 + 2) * 6 * 8);
+    d.dep_rec.ensure(((size_t)wave + 64) * SFFK_DEP_REC * 4);
     d.ustate.ensure((size_t)wave);
     d.ulist.ensure((size_t)wave * 4);
     d.uacc.ensure((size_t)wave * 4);
@@ -704,6 +709,12 @@ void Forest::run_device(int max_waves) {
   st.host_ms += ms_since(t0) - wait_ms;
   if (getenv("SFFGPU_PROFILE")) {
     const sffk::DevCtrl& k = d.last;
+    {
+      const double w = (double)std::max<unsigned long long>(1ULL, k.wprof[7]);
+      fprintf(stderr, "[sffgpu k_wave_end us/wave] claims %.1f owner flags %.1f closed list %.1f clear claims %.1f removal prefix %.1f "
+              "termination %.1f | k_wave_begin %.1f\n", k.wprof[0] / w / 100.0, k.wprof[1] / w / 100.0, k.wprof[2] / w / 100.0,
+              k.wprof[3] / w / 100.0, k.wprof[4] / w / 100.0, k.wprof[5] / w / 100.0, k.wprof[6] / w / 100.0);
+    }
     const double r = (double)std::max<unsigned long long>(1ULL, k.prof[6]);
     fprintf(stderr, "[sffgpu k_resolve us/commit] states %.1f fixed point %.1f (%.2f passes, max %llu) ranks %.1f borders %.1f "
             "next list+counters %.1f | dependent/round %.0f\n", k.prof[0] / r / 100.0, k.prof[1] / r / 100.0, k.prof[5] / r,

@@ -132,7 +132,11 @@ struct DevCtrl {
   // wall_clock64 ticks) and its sum over all committed rounds: the duration rocprofv3 reports, without the ~3 us a
   // HIP event pair adds around a 20 us kernel
   unsigned long long q_t0, q_t1, q_ticks, q_launches;
+  // k_wave_end phase clocks (thread 0): claims, owner flags, closed list, clear claims, removal prefix, termination;
+  // [6] = k_wave_begin as a whole, [7] = waves
+  unsigned long long wprof[8];
 };
+#define SFFK_DEP_REC 12   // {entries, first neighbour index, 4 x (id, calls << 2 | edge free << 1 | same tree)}, 16-byte aligned
 #define SFFK_DEV_MAX_GROUPS 1024   // single-workgroup list kernels: 64 x this many slots per wave at most
 #define SFFK_FAULT_LISTS 1        // a hit / neighbour / triangle-candidate list overflowed: redo the round on the host
 #define SFFK_FAULT_BORDER_TABLE 2 // the border hash table is full: the host grows it
@@ -345,6 +349,7 @@ struct DevForestView {
   // border-event flags; acc_pref = accepted samples before the word (k_append turns both into node ids and the
   // next round's active list without k_resolve ever walking the samples)
   unsigned long long* w_dep; unsigned long long* w_acc; unsigned long long* w_ev; int32_t* acc_pref;
+  int32_t* dep_rec;            // SFFK_DEP_REC ints per sample: what is left of a dependent sample's neighbour walk (k_decide -> k_resolve)
   unsigned long long* w_cnt;   // 6 counters per word (k_decide's sums over its 64 samples; k_resolve adds them up)
 };
 // per-sample verdicts of k_decide

@@ -1709,17 +1709,26 @@ __global__ __launch_bounds__(64 * QC_WAVES) __attribute__((amdgpu_waves_per_eu(Q
   const int stride = 1 + A.nbcap;
   // ---- everything the sample needs, loaded before the first store (a wave runs one long chain of dependent
   // memory steps: independent loads are issued together, up front)
-  const bool inl = A.in_lim[i] != 0;
-  const int ex = A.parent[i];
-  const bool force = A.force[i] != 0;
-  const double pdist = A.pdist[i];
-  const SweepQuery Q = queries[i];
+  // (all of it is the same in every lane: pinned to scalar registers - the kernel's occupancy is set by its vector
+  // registers, and a wave's sample, expanded node and query would take forty of them)
+  auto uni_i = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+  auto uni_f = [](float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); };
+  auto uni_d = [](double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+  };
+  const bool inl = uni_i(A.in_lim[i]) != 0;
+  const int ex = uni_i(A.parent[i]);
+  const bool force = uni_i(A.force[i]) != 0;
+  const double pdist = uni_d(A.pdist[i]);
+  SweepQuery Q = queries[i];
+  Q.x = uni_f(Q.x); Q.y = uni_f(Q.y); Q.z = uni_f(Q.z); Q.yaw = uni_f(Q.yaw); Q.pitch = uni_f(Q.pitch); Q.roll = uni_f(Q.roll);
+  Q.r2f = uni_f(Q.r2f); Q.tree = uni_i(Q.tree); Q.r = uni_d(Q.r); Q.max_id = uni_i(Q.max_id); Q.active = uni_i(Q.active);
   double qp[6], exp[6];
-  for (int k = 0; k < 6; ++k) qp[k] = A.newpos[6 * (size_t)i + k];
-  const int no_g = g.ovf_cnt[0];
-  const int no_t = tg.cnt ? tg.ovf_cnt[0] : 0;
-  const int mine = A.tree[ex];
-  for (int k = 0; k < 6; ++k) exp[k] = A.pos[6 * (size_t)ex + k];
+  for (int k = 0; k < 6; ++k) qp[k] = uni_d(A.newpos[6 * (size_t)i + k]);
+  const int no_g = uni_i(g.ovf_cnt[0]);
+  const int no_t = tg.cnt ? uni_i(tg.ovf_cnt[0]) : 0;
+  const int mine = uni_i(A.tree[ex]);
+  for (int k = 0; k < 6; ++k) exp[k] = uni_d(A.pos[6 * (size_t)ex + k]);
   int flags = 0, nnb = 0;
   int used_slots = 0;                     // edge-task slots this sample fills (the others are cleared at the end)
   const bool mine_shard = A.world <= 1 || i % A.world == A.rank;
