@@ -260,6 +260,8 @@ void Ctx::upload_mesh(int role, const double* tri9, int n) {
     }
     robv.radius = rad;
     have_robot = true;
+    h_rob.assign(tri9, tri9 + (size_t)n * 9);
+    build_robot_extents();
     build_clearance();
     build_tri_grid();
     return;
@@ -322,6 +324,7 @@ void Ctx::upload_mesh(int role, const double* tri9, int n) {
   envv.tri_box = env_box.as<double>();
   envv.tri_plane = env_plane.as<double>();
   envv.n_tri = n;
+  h_plane = plane;
   // levels
   std::vector<double> cur = box_s;
   int count = n, L = 0;
@@ -348,8 +351,33 @@ void Ctx::upload_mesh(int role, const double* tri9, int n) {
     if (groups <= 64) break;
   }
   envv.n_levels = L;
+  build_robot_extents();
   build_clearance();
   build_tri_grid();
+}
+
+// Extent of the un-rotated robot along every environment triangle's normal (kernels.h, EnvView::tri_ext): edge samples
+// carry no rotation (src/problemStruct.h:157-165), so "the whole robot on one side of the triangle's plane" is one
+// comparison per (sample, triangle) in the exact kernel.
+void Ctx::build_robot_extents() {
+  envv.tri_ext = nullptr;
+  if (!have_env || !have_robot || envv.n_tri <= 0 || h_rob.empty() || h_plane.size() != (size_t)envv.n_tri * 5) return;
+  std::vector<double> ext((size_t)envv.n_tri * 2);
+  const size_t nv = h_rob.size() / 3;
+  for (int k = 0; k < envv.n_tri; ++k) {
+    const double* pl = &h_plane[5 * (size_t)k];
+    double lo = 1e300, hi = -1e300;
+    for (size_t v = 0; v < nv; ++v) {
+      const double d = (pl[0] * h_rob[3 * v] + pl[1] * h_rob[3 * v + 1]) + pl[2] * h_rob[3 * v + 2];
+      lo = std::min(lo, d);
+      hi = std::max(hi, d);
+    }
+    ext[2 * (size_t)k] = lo;
+    ext[2 * (size_t)k + 1] = hi;
+  }
+  env_ext.ensure(ext.size() * sizeof(double));
+  HIPCHK(hipMemcpy(env_ext.p, ext.data(), ext.size() * sizeof(double), hipMemcpyHostToDevice));
+  envv.tri_ext = env_ext.as<double>();
 }
 
 // Clearance bits over the environment box (kernels.h, EnvView): one bit per cell, set when a robot whose

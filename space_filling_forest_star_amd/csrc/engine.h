@@ -75,7 +75,9 @@ struct Ctx {
   std::string err;
 
   // collision models
-  DevBuf env_tri, env_box, env_plane, level_box[SFFK_MAX_LEVELS], rob_tri, env_clear;
+  DevBuf env_tri, env_box, env_plane, level_box[SFFK_MAX_LEVELS], rob_tri, env_clear, env_ext;
+  std::vector<double> h_plane, h_rob;   // host copies (robot extents along the triangle normals)
+  void build_robot_extents();
   sffk::EnvView envv{};
   sffk::RobotView robv{};
   bool have_env = false, have_robot = false;

@@ -728,6 +728,8 @@ void Forest::run_device(int max_waves) {
             "candidates %.1f | us: setup %.2f hierarchy %.2f narrow %.2f | per wave total %.1f us over %llu waves\n",
             g[0], g[1], g[2], g[3] / items, g[7] / items, g[4] / items / 100.0, g[5] / items / 100.0, g[6] / items / 100.0,
             (double)g[8] / (double)std::max<unsigned long long>(1ULL, g[9]) / 100.0, g[9]);
+    fprintf(stderr, "[sffgpu exact kernel, chunk time histogram] <10us %llu <20 %llu <40 %llu <80 %llu >=80 %llu | candidates per chunk of "
+            "the >=40us ones %.1f\n", g[10], g[11], g[12], g[13], g[14], (double)g[15] / (double)std::max<unsigned long long>(1ULL, g[13] + g[14]));
     unsigned long long q[8];
     sffk::debug_counters_query(q);
     const double qw = (double)std::max<unsigned long long>(1ULL, q[0]);

@@ -67,6 +67,7 @@ struct EnvView {
   const double* tri;      // n_tri x 9, world frame
   const double* tri_box;  // n_tri x 6 (lo xyz, hi xyz), exact
   const double* tri_plane; // n_tri x 5: unnormalised normal, offset n.p1, |n|
+  const double* tri_ext;   // n_tri x 2 or null: extent of the un-rotated robot's vertices along that normal (min, max of n.v)
   int n_tri;
   int n_levels;           // level 0 groups 64 triangles, level k groups 64 boxes of level k-1
   const double* level_box[SFFK_MAX_LEVELS];

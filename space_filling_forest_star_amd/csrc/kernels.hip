@@ -561,12 +561,16 @@ struct WaveStack {
   int32_t* hash;   // LDS, TG_HASH entries per wave (triangle-grid path)
 };
 #define STACK_CAP 256
-// candidate triangles of an item are staged in LDS 64 at a time: box (6) + plane (5) + vertices (9) doubles each.
+// candidate triangles of an item are staged in LDS 64 at a time: box (6) + plane (5) + vertices (9) + the robot's
+// extent along the normal (2) doubles each.
 // One lane fetches one candidate (20 independent loads in flight) instead of every lane waiting on each candidate's
 // data in turn: the exact kernel is bound by exactly that latency (83 % of its wave cycles are parked on memory,
 // profiles/r2g_sq_summary.json).
-#define STAGE_TRI 20
-#define STAGE_DOUBLES (64 * STAGE_TRI)
+#define STAGE_TRI 22
+#ifndef STAGE_N
+#define STAGE_N 64      // candidates per staging step (32 with three waves per SIMD measured slower: 59 vs 53 us)
+#endif
+#define STAGE_DOUBLES (STAGE_N * STAGE_TRI)
 #define TG_HASH 512   // per-wave LDS hash set: a triangle listed by several cells of a query enters the candidates once
 __device__ __forceinline__ void stage_candidates(const EnvView& env, const int32_t* cand, int k0, int kc, int lane, double* stage) {
   if (lane < kc) {
@@ -578,6 +582,8 @@ __device__ __forceinline__ void stage_candidates(const EnvView& env, const int32
     for (int q = 0; q < 6; ++q) o[q] = b[q];
     for (int q = 0; q < 5; ++q) o[6 + q] = pl[q];
     for (int q = 0; q < 9; ++q) o[11 + q] = tr[q];
+    o[20] = env.tri_ext ? env.tri_ext[2 * (size_t)t] : -1e300;      // (no extents: the plane-side cull never fires)
+    o[21] = env.tri_ext ? env.tri_ext[2 * (size_t)t + 1] : 1e300;
   }
   __builtin_amdgcn_wave_barrier();
 }
@@ -1000,8 +1006,8 @@ __device__ bool pose_exact(const EnvView& env, const RobotView& rob, const doubl
     }
   } else {
     // candidates staged 64 at a time; every lane poses up to ceil(n_tri/64) robot triangles and walks the stage
-    for (int k0 = 0; k0 < nc && !hit; k0 += 64) {
-      const int kc = nc - k0 < 64 ? nc - k0 : 64;
+    for (int k0 = 0; k0 < nc && !hit; k0 += STAGE_N) {
+      const int kc = nc - k0 < STAGE_N ? nc - k0 : STAGE_N;
       stage_candidates(env, cand, k0, kc, lane, stage);
       for (int r0 = 0; r0 < rob.n_tri && !hit; r0 += 64) {
         const int r = r0 + lane;
@@ -1157,11 +1163,19 @@ __device__ void segment_chunk(const EnvView& env, const RobotView& rob, const do
     if (lane + count < qn) queue[lane] = keep;
     qn -= count;
   };
-  for (int k0 = 0; k0 < nc; k0 += 64) {
-    const int kc = nc - k0 < 64 ? nc - k0 : 64;
+  for (int k0 = 0; k0 < nc; k0 += STAGE_N) {
+    const int kc = nc - k0 < STAGE_N ? nc - k0 : STAGE_N;
     stage_candidates(env, cand, k0, kc, lane, stage);
     for (int k = 0; k < kc; ++k) {
       const double* bx = stage + k * STAGE_TRI;
+      // extent of the (un-rotated: edge samples carry no rotation) robot along the triangle's normal, over all its
+      // triangle vertices: a sample whose whole robot stays on one side of the triangle's plane touches nothing of it
+      // (the exact test would separate them on that very axis; the slack, 1e-9 relative, dwarfs the rounding)
+      // bx[20..21]: extent of the (un-rotated: edge samples carry no rotation) robot along the triangle's normal.  A
+      // sample whose whole robot stays on one side of the triangle's plane touches nothing of it (the exact test would
+      // separate them on that very axis; the slack, 1e-9 relative, dwarfs the rounding).
+      const double* pl = bx + 6;
+      const double elo = bx[20], ehi = bx[21];
       bool touch = false;
       if (need && idx < minhit) {
         touch = true;
@@ -1170,7 +1184,12 @@ __device__ void segment_chunk(const EnvView& env, const RobotView& rob, const do
           double rlo = rob.lo[ax] + P[ax], rhi = rob.hi[ax] + P[ax];
           if (bx[ax] > rhi || rlo > bx[3 + ax]) touch = false;
         }
-        if (touch && plane_clear(bx + 6, C, rr)) touch = false;
+        if (touch && plane_clear(pl, C, rr)) touch = false;
+        if (touch) {
+          const double base = (pl[0] * P[0] + pl[1] * P[1]) + pl[2] * P[2] - pl[3];
+          const double slack = 1e-9 * (pl[4] * (fabs(P[0]) + fabs(P[1]) + fabs(P[2]) + 1.0) + fabs(pl[3]) + (elo > -1e299 ? fabs(elo) + fabs(ehi) : 0.0));
+          if (base + elo > slack || base + ehi < -slack) touch = false;
+        }
         if (touch && tri_far(bx + 11, C, rr)) touch = false;
       }
       unsigned long long todo = __ballot(touch);
@@ -1204,6 +1223,13 @@ __device__ void segment_chunk(const EnvView& env, const RobotView& rob, const do
   }
   while (qn > 0) flush(qn < 64 ? qn : 64);
   DBG_ADD(6, DBG_T() - t2_);
+#ifdef SFFK_DEBUG_COUNTERS
+  {   // histogram of the chunk's total time: < 10, < 20, < 40, < 80, >= 80 us; [15] = candidates of the >= 40 us ones
+    const unsigned long long dt = DBG_T() - t0_;
+    const int bk = dt < 1000 ? 10 : (dt < 2000 ? 11 : (dt < 4000 ? 12 : (dt < 8000 ? 13 : 14)));
+    if (lane == 0) { atomicAdd(&g_dbg[bk], 1ULL); if (dt >= 4000) atomicAdd(&g_dbg[15], (unsigned long long)nc); }
+  }
+#endif
   if (minhit != 0x7fffffff && lane == 0) atomicMin(first_hit + seg, minhit);
 }
 
@@ -1983,7 +2009,10 @@ __global__ __launch_bounds__(64 * QC_WAVES) __attribute__((amdgpu_waves_per_eu(Q
 // w, w + W, ... (about a thousand items over two thousand waves: one item per wave, no pooling needed).
 // Housekeeping first: the round's own grid has been read by the query kernel, the cells it used are emptied here.
 // List overflow (ctrl[3]): every live pose and every chunk of every live edge takes the exact test.
-__global__ __launch_bounds__(64 * SEG_WAVES) void k_collide_items(EnvView env, RobotView rob, const double* __restrict__ pos6,
+#ifndef CI_OCC
+#define CI_OCC 2
+#endif
+__global__ __launch_bounds__(64 * SEG_WAVES) __attribute__((amdgpu_waves_per_eu(CI_OCC))) void k_collide_items(EnvView env, RobotView rob, const double* __restrict__ pos6,
                                                                   int n_pose, const int32_t* __restrict__ live_flags,
                                                                   uint8_t* __restrict__ pose_hit,
                                                                   const double* __restrict__ a6, const double* __restrict__ b6,
@@ -2312,7 +2341,7 @@ void launch_collide_items(hipStream_t s, const EnvView& env, const RobotView& ro
   size_t lds = collide_lds_bytes(rob.n_tri, SEG_WAVES);
   if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_collide_items), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   // 2 workgroups of 4 waves per CU = what the exact kernel's register budget keeps resident (256 CUs)
-  static const int blocks = std::min(4096, std::max(1, getenv("SFFGPU_SEG_BLOCKS") ? atoi(getenv("SFFGPU_SEG_BLOCKS")) : 512));
+  static const int blocks = std::min(4096, std::max(1, getenv("SFFGPU_SEG_BLOCKS") ? atoi(getenv("SFFGPU_SEG_BLOCKS")) : 256 * CI_OCC));
   hipLaunchKernelGGL(k_collide_items, dim3(blocks), dim3(64 * SEG_WAVES), lds, s, env, rob, pos6, n_pose, live_flags, pose_hit,
                      a6, b6, seg_ns, stride, ctrl, static_cast<const SurvivorItem*>(items), items_cap, sub, first_hit,
                      overflow_flag,
