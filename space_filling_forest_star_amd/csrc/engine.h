@@ -229,7 +229,7 @@ struct DevEngine {
   DevBuf ctrl, parent, d_root, d_closest, iter, nflag, frontier, closed, claim, slot_node, slot_fail, act_slot, b_n1,
       b_n2, b_ta, b_tb, b_dist, bt_key, bt_val, pair, ring, ustate, ulist, uacc, d_parent, d_force, fault_pending;
   PinBuf h_ctrl, h_ring;
-  hipEvent_t ev_ring = nullptr, ev_wave = nullptr;
+  hipEvent_t ev_ring = nullptr, ev_wave = nullptr, ev_wave2 = nullptr;   // (two status slots: one wave may be enqueued ahead)
   int node_cap = 0, border_cap = 0, temp_base = 0;
   uint64_t bt_size = 0, ring_words = 0, max_wave_words = 0;
   uint64_t produced = 0;        // engine words generated so far (absolute position of the generator)
@@ -253,8 +253,9 @@ struct Forest {
   void dev_enqueue_begin();
   void dev_enqueue_round_eval(void* send_dev);
   void dev_enqueue_round_commit(const void* recv_dev);
-  void dev_enqueue_end();
-  int dev_finish_wave(double* wait_ms);
+  void dev_enqueue_end(int slot = 0);
+  int dev_finish_wave(double* wait_ms, int slot = 0, bool stream_idle = true);
+  void dev_enqueue_wave(int slot);
   bool dev_wave_begin();
   size_t dev_exchange_bytes() const;
   void run_device(int max_waves);

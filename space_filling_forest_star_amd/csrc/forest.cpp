@@ -294,6 +294,7 @@ Forest::~Forest() {
   dev.h_ring.release();
   if (dev.ev_ring) (void)hipEventDestroy(dev.ev_ring);
   if (dev.ev_wave) (void)hipEventDestroy(dev.ev_wave);
+  if (dev.ev_wave2) (void)hipEventDestroy(dev.ev_wave2);
 }
 
 // node selection for every slot of the wave, src/forest.h:136-151 (non-priority mode)

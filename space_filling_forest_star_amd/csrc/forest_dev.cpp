@@ -177,12 +177,13 @@ void Forest::dev_upload_state() {
   if (!d.inited) {
     HIPCHK(hipEventCreateWithFlags(&d.ev_ring, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&d.ev_wave, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&d.ev_wave2, hipEventDisableTiming));
     d.max_wave_words = (uint64_t)wave * (1 + (uint64_t)std::max(1, cfg.threshold_misses) * words_per) + 64;
     d.ring_words = next_pow2(4 * d.max_wave_words);
     d.ring.ensure((size_t)d.ring_words * 8);
     d.h_ring.ensure((size_t)d.ring_words * 8);
     d.ctrl.ensure(sizeof(sffk::DevCtrl));
-    d.h_ctrl.ensure(sizeof(sffk::DevCtrl));
+    d.h_ctrl.ensure(2 * sizeof(sffk::DevCtrl));
     d.slot_node.ensure((size_t)wave * 4);
     d.slot_pos.ensure((size_t)wave * 4);
     d.act_slot.ensure((size_t)wave * 4);
@@ -597,27 +598,40 @@ void Forest::dev_enqueue_round_commit(const void* recv_dev) {
   sffk::launch_commit(c.stream, ra, B.n);
 }
 
-void Forest::dev_enqueue_end() {
+void Forest::dev_enqueue_end(int slot) {
   Ctx& c = *ctx;
   DevEngine& d = dev;
   sffk::launch_wave_end(c.stream, dev_view(), c.gridv.ovf_cnt, c.tgridv.ovf_cnt);
-  HIPCHK(hipMemcpyAsync(d.h_ctrl.p, d.ctrl.p, sizeof(sffk::DevCtrl), hipMemcpyDeviceToHost, c.stream));
-  HIPCHK(hipEventRecord(d.ev_wave, c.stream));
+  HIPCHK(hipMemcpyAsync(d.h_ctrl.as<sffk::DevCtrl>() + slot, d.ctrl.p, sizeof(sffk::DevCtrl), hipMemcpyDeviceToHost, c.stream));
+  HIPCHK(hipEventRecord(slot ? d.ev_wave2 : d.ev_wave, c.stream));
+}
+
+// one whole wave: begin, ThresholdMisses rounds (the device skips what it does not need), end + status copy
+void Forest::dev_enqueue_wave(int slot) {
+  dev_enqueue_begin();
+  for (int r = 0; r < std::max(1, cfg.threshold_misses); ++r) {
+    dev_enqueue_round_eval(nullptr);
+    dev_enqueue_round_commit(nullptr);
+  }
+  dev_enqueue_end(slot);
+  dev.host_stale = true;
 }
 
 // waits for the wave, reads its status block and deals with what the host has to do between waves.  Returns the
 // fault the caller has to handle (SFFK_FAULT_LISTS: finish the wave on the host path) or 0; growth faults are
-// resolved here (the wave is then resumed by simply enqueuing it again).
-int Forest::dev_finish_wave(double* wait_ms) {
+// resolved here (the wave is then resumed by simply enqueuing it again).  stream_idle = false: another wave is
+// enqueued behind this one - only the status is read, nothing that needs the stream to be idle is done.
+int Forest::dev_finish_wave(double* wait_ms, int slot, bool stream_idle) {
   Ctx& c = *ctx;
   DevEngine& d = dev;
   {
     auto tw = Clock::now();
-    HIPCHK(hipEventSynchronize(d.ev_wave));
-    c.sync();   // (harvests the timing events; the stream is idle)
+    HIPCHK(hipEventSynchronize(slot ? d.ev_wave2 : d.ev_wave));
+    if (stream_idle) c.sync();   // (harvests the timing events; the stream is idle)
     if (wait_ms) *wait_ms += ms_since(tw);
   }
-  d.last = *d.h_ctrl.as<sffk::DevCtrl>();
+  d.last = d.h_ctrl.as<sffk::DevCtrl>()[slot];
+  if (!stream_idle) return d.last.fault;
   d.host_stale = true;
   const sffk::DevCtrl& s = d.last;
   if (s.fault) {
@@ -677,23 +691,54 @@ void Forest::run_device(int max_waves) {
   double wait_ms = 0;
   if (!d.active) dev_upload_state();
   const uint64_t w0 = d.last.waves;
+  // One wave is kept enqueued AHEAD of the one the host waits for: the status round trip (device -> pinned host ->
+  // wake-up -> some thirty launches) otherwise leaves the GPU idle for ~40 us per wave.  Everything the device does is
+  // self-guarding - after termination or a fault every kernel of the wave behind returns at once - so the wave ahead
+  // is harmless when the wave in front ends the run or needs the host.
+  const bool ahead_ok = !getenv("SFFGPU_NO_WAVE_AHEAD");
+  int slot = 0;          // status slot of the wave the host waits for next
+  bool have_next = false;   // a second wave is enqueued behind it (status slot 1 - slot)
+  uint64_t started = 0;  // waves enqueued since the last known status (fresh waves the device may have begun)
   while (true) {
     const sffk::DevCtrl& k = d.last;
-    if (!k.in_wave) {
-      if (k.terminated) break;
-      if (max_waves > 0 && (int)(k.waves - w0) >= max_waves) break;
+    if (!have_next) {      // nothing in flight
+      if (!k.in_wave) {
+        if (k.terminated) break;
+        if (max_waves > 0 && (int)(k.waves - w0) >= max_waves) break;
+      }
+      dev_ring_top_up(k.cursor, d.max_wave_words);
+      dev_enqueue_wave(slot);
+      started = 1;
+    } else {
+      have_next = false;   // the wave enqueued ahead is now the one waited for
     }
-    dev_ring_top_up(k.cursor, d.max_wave_words);
-    dev_enqueue_begin();
-    for (int r = 0; r < std::max(1, cfg.threshold_misses); ++r) {
-      dev_enqueue_round_eval(nullptr);
-      dev_enqueue_round_commit(nullptr);
+    // the wave behind: only from a clean, known state (the in-flight wave is a fresh one, or the resume of one), and
+    // only if the caller's wave budget has room for it whatever the in-flight wave turns out to be
+    const bool room = max_waves <= 0 || (int)(k.waves - w0) + (int)started + 1 <= max_waves;
+    if (ahead_ok && room && !k.fault) {
+      dev_ring_top_up(k.cursor, 2 * d.max_wave_words);
+      dev_enqueue_wave(1 - slot);
+      have_next = true;
+    } else {
+      // while the GPU works: the words the NEXT wave may need, whatever this one consumes
+      dev_ring_top_up(k.cursor, 2 * d.max_wave_words);
     }
-    dev_enqueue_end();
-    d.host_stale = true;
-    // while the GPU works: the words the NEXT wave may need, whatever this one consumes
-    dev_ring_top_up(k.cursor, 2 * d.max_wave_words);
-    const int fault = dev_finish_wave(&wait_ms);
+    int fault = dev_finish_wave(&wait_ms, slot, !have_next);
+    const sffk::DevCtrl& s1 = d.last;
+    const bool needs_host = fault != 0 || s1.terminated || s1.grid_ovf > c.gridv.ovf_cap / 4 || s1.tgrid_ovf > c.tgridv.ovf_cap;
+    if (have_next && needs_host) {
+      // the wave behind did nothing (halted device) or - grid overflow list filling up - ran normally: wait for it,
+      // then handle whatever the LAST status says with an idle stream
+      fault = dev_finish_wave(&wait_ms, 1 - slot, true);
+      have_next = false;
+      started = 0;
+    } else if (have_next) {
+      slot = 1 - slot;
+      started = 1;         // (the wave ahead may already have begun)
+      continue;
+    } else {
+      started = 0;
+    }
     if (fault == SFFK_FAULT_LISTS) {
       // a bounded device list overflowed: finish this wave on the host path, then come back
       dev_to_host();
