@@ -132,9 +132,10 @@ Forest::Forest(Ctx* c, const sffgpu_forest_cfg& cf, const double* roots6, int n_
     double cell = 1.01 * std::max(cfg.sampling_dist, cfg.dist_tree) + 4 * ctx->sweep_eps();
     ctx->grid_rebuilds = 0;
     // the overflow list is checked once per wave and re-celled at a quarter full: three quarters of it must hold
-    // whatever one wave can add (at most `wave` nodes), so that no insert is ever dropped between two checks
-    if (cfg.wave > (1 << 28)) throw HipError{"forest: wave too large"};
-    ctx->gridv_ovf_cap_next = std::max(65536, 2 * cfg.wave);
+    // whatever TWO waves can add (at most `wave` nodes each; the device engine keeps one wave enqueued ahead of the
+    // one whose status it reads), so that no insert is ever dropped between two checks
+    if (cfg.wave > (1 << 27)) throw HipError{"forest: wave too large"};
+    ctx->gridv_ovf_cap_next = std::max(65536, 4 * cfg.wave);
     ctx->tgrid_ovf_min = cfg.wave + 64;
     ctx->grid_setup(cfg.limits, cell);
   }
