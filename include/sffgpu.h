@@ -174,6 +174,12 @@ typedef struct {
   int32_t max_iterations;
   uint64_t seed;
   int32_t wave;                     /* iterations speculated per GPU wave: 1 = one by one, 0 = automatic (~sqrt of the tree size) */
+  /* LazyTSP<T,R>::runRRT (src/lazy.h:160-284), the Lazy solver's inner planner: ONE tree grown from roots6[0] towards
+   * `goal` (has_goal = 0, priority_bias = 0): no tree pick in the RNG stream (:181), k = 2e*log10(tree size + 1)
+   * (:199), solved as soon as a new node lies within dist_tree of the goal - no edge check (:258-273).  rng_skip
+   * engine words are discarded after seeding: the reference draws all edges' samples from one RandGen. */
+  int32_t lazy_edge;
+  uint64_t rng_skip;
 } sffgpu_rrt_cfg;
 
 typedef struct {
@@ -181,6 +187,8 @@ typedef struct {
   uint64_t collide_calls, path_free_calls, nn_queries;  /* what the reference would have executed */
   double total_ms;
   uint64_t waves, speculated, committed;                /* wave engine: launched waves, iterations evaluated / kept */
+  uint64_t rng_draws;                                   /* engine words consumed so far (rng_skip included) */
+  double lazy_distance;                                 /* lazy_edge: edge->distance (src/lazy.h:262; DBL_MAX unsolved, :280) */
 } sffgpu_rrt_stats;
 
 typedef struct sffgpu_rrt sffgpu_rrt;
@@ -204,6 +212,9 @@ int sffgpu_rrt_path_plan(sffgpu_rrt* r, int i, int j, int32_t* node_ids, int cap
  * read with sffgpu_rrt_link_plan(k).  Returns the number of link plans. */
 int sffgpu_rrt_smooth_paths(sffgpu_rrt* r);
 int sffgpu_rrt_link_plan(sffgpu_rrt* r, int k, int32_t* node_ids, int cap);
+/* lazy_edge: the solved edge's plan without its goal entry (src/lazy.h:265-272): root ... the node that reached the
+ * goal; returns its length (0 = unsolved; may exceed cap) */
+int sffgpu_rrt_lazy_plan(sffgpu_rrt* r, int32_t* node_ids, int cap);
 
 /* Multi-GPU wave protocol (one process per GPU; the exchange itself is the caller's RCCL / gloo
  * all-gather).  Every rank holds a full replica of the forest and of the node store; a round is

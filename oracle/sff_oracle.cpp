@@ -85,13 +85,16 @@ inline void rotation(const double* p, int trig, double R[9]) {
 struct Mt64 {
   uint64_t mt[312];
   int idx;
+  uint64_t n_drawn = 0;   // outputs produced since the last reseed
   explicit Mt64(uint64_t seed = 5489ULL) { reseed(seed); }
   void reseed(uint64_t seed) {
     mt[0] = seed;
     for (int i = 1; i < 312; ++i) mt[i] = 6364136223846793005ULL * (mt[i - 1] ^ (mt[i - 1] >> 62)) + (uint64_t)i;
     idx = 312;
+    n_drawn = 0;
   }
   uint64_t next() {
+    ++n_drawn;
     if (idx >= 312) {
       const uint64_t UM = 0xFFFFFFFF80000000ULL, LM = 0x7FFFFFFFULL;
       for (int i = 0; i < 312; ++i) {
@@ -1071,6 +1074,8 @@ struct Rrt {
   int iter = 0;
   bool solved = false;
   uint64_t path_free_calls = 0, nn_queries = 0, collide_base = 0, merges = 0;
+  int lazy_last = -1;                                   // lazy_edge: the node that reached the goal
+  double lazy_distance = std::numeric_limits<double>::max();
 
   bool path_free(const double* a, const double* b) {
     ++path_free_calls;
@@ -1123,7 +1128,7 @@ struct Rrt {
     int new_id;
     if (cfg.optimize) {                                                         // :156-201
       double best = distance6(np, nodes[nearest].pos) + nodes[nearest].d_root;
-      double krrt = 2 * M_E * std::log10((double)nodes.size());
+      double krrt = 2 * M_E * std::log10((double)nodes.size() + (cfg.lazy_edge ? 1.0 : 0.0));   // src/lazy.h:199
       std::vector<Hit> kn;
       knn(tree_to_expand, np, (size_t)krrt, kn);
       for (const Hit& h : kn) {
@@ -1146,6 +1151,15 @@ struct Rrt {
     } else {                                                                    // :203
       new_id = add_node(np, nodes[nearest].root_tree, tree_to_expand, nearest, cfg.sampling_dist,
                         nodes[nearest].d_root + cfg.sampling_dist, iteration);
+    }
+    if (cfg.lazy_edge) {                                                        // src/lazy.h:258-273
+      const double gd = distance6(cfg.goal, nodes[new_id].pos);
+      if (gd < cfg.dist_tree) {
+        solved = true;
+        lazy_distance = gd + nodes[new_id].d_root;
+        lazy_last = new_id;
+      }
+      return;
     }
     // :219-319 connect to / merge with the other live trees
     for (int i = 0; i < (int)tree_frontier.size(); ++i) {
@@ -1266,7 +1280,7 @@ struct Rrt {
       if (max_iters > 0 && done >= max_iters) break;
       ++done;
       ++iter;
-      int tree = tree_frontier[rng.rand_int(0, num_trees)];                      // :95
+      int tree = cfg.lazy_edge ? 0 : tree_frontier[rng.rand_int(0, num_trees)];  // :95 (src/lazy.h:181 draws no tree)
       expand(tree, (unsigned)iter);
     }
   }
@@ -1543,6 +1557,7 @@ sffo_rrt* sffo_rrt_create(sffo_world* w, const sffo_rrt_cfg* cfg, const double* 
   r.collide_base = w->w.collide_calls;
   r.cfg = *cfg;
   r.rng.eng.reseed(cfg->seed);
+  for (uint64_t k = 0; k < cfg->rng_skip; ++k) (void)r.rng.raw();
   memcpy(r.rng.lim, cfg->limits, sizeof r.rng.lim);
   r.rng.trig = cfg->trig;
   int nt = n_roots + (cfg->has_goal ? 1 : 0);
@@ -1573,6 +1588,17 @@ void sffo_rrt_get_stats(sffo_rrt* h, sffo_rrt_stats* s) {
   s->collide_calls = r.w->collide_calls - r.collide_base;
   s->path_free_calls = r.path_free_calls;
   s->nn_queries = r.nn_queries;
+  s->rng_draws = r.rng.eng.n_drawn;
+  s->lazy_distance = r.lazy_distance;
+}
+int sffo_rrt_lazy_plan(sffo_rrt* h, int32_t* node_ids, int cap) {
+  Rrt& r = h->r;
+  if (r.lazy_last < 0) return 0;
+  std::vector<int> chain;
+  for (int n = r.lazy_last;; n = r.nodes[n].parent) { chain.push_back(n); if (r.nodes[n].d_root == 0) break; }   // IsRoot(), src/primitives.h:476
+  std::reverse(chain.begin(), chain.end());
+  for (int k = 0; k < (int)chain.size() && k < cap; ++k) node_ids[k] = chain[k];
+  return (int)chain.size();
 }
 void sffo_rrt_get_nodes(sffo_rrt* h, double* pos6, int32_t* parent, int32_t* tree, int32_t* root_tree, int32_t* iter,
                         double* cost, double* dpar) {

@@ -131,10 +131,18 @@ typedef struct {
   int max_iterations;
   uint64_t seed;
   int trig;
+  /* LazyTSP::runRRT (src/lazy.h:160-284): ONE tree from roots6[0] towards `goal` (has_goal = 0), no tree pick and no
+     goal bias in the RNG stream, k = 2e*log10(tree size + 1), solved when a new node lies within dist_tree of the
+     goal (no edge check).  rng_skip engine words are discarded first: the reference's solver draws every edge's
+     samples from ONE RandGen. */
+  int lazy_edge;
+  uint64_t rng_skip;
 } sffo_rrt_cfg;
 typedef struct {
   int32_t iterations, solved, n_nodes, n_live_trees, merges, n_links;
   uint64_t collide_calls, path_free_calls, nn_queries;
+  uint64_t rng_draws;      /* engine words consumed so far (rng_skip included) */
+  double lazy_distance;    /* lazy_edge: edge->distance (src/lazy.h:262), DBL_MAX while unsolved (:280) */
 } sffo_rrt_stats;
 typedef struct sffo_rrt sffo_rrt;
 sffo_rrt* sffo_rrt_create(sffo_world* w, const sffo_rrt_cfg* cfg, const double* roots6, int n_roots);
@@ -151,6 +159,8 @@ int sffo_rrt_get_links(sffo_rrt*, int32_t* tree, int32_t* n1, int32_t* n2, doubl
 /* getConnectedTrees + getPaths + getAllPaths (src/rrt.h:381-393, :324-352, src/problemStruct.h:184-253) */
 int sffo_rrt_paths(sffo_rrt*, double* dist);
 int sffo_rrt_path_plan(sffo_rrt*, int i, int j, int32_t* node_ids, int cap);
+/* lazy_edge: the plan of the solved edge without its goal entry (src/lazy.h:265-272): root ... last node */
+int sffo_rrt_lazy_plan(sffo_rrt*, int32_t* node_ids, int cap);
 
 #ifdef __cplusplus
 }

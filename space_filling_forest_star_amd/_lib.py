@@ -18,7 +18,7 @@ EXPORTED_SYMBOLS = [
     "sffgpu_forest_path_plan", "sffgpu_forest_smooth_paths",
     "sffgpu_rrt_create", "sffgpu_rrt_destroy", "sffgpu_rrt_run", "sffgpu_rrt_get_stats", "sffgpu_rrt_get_nodes",
     "sffgpu_rrt_get_links", "sffgpu_rrt_paths", "sffgpu_rrt_path_plan", "sffgpu_rrt_smooth_paths",
-    "sffgpu_rrt_link_plan", "sffgpu_kernel_times", "sffgpu_forest_get_frontier",
+    "sffgpu_rrt_link_plan", "sffgpu_rrt_lazy_plan", "sffgpu_kernel_times", "sffgpu_forest_get_frontier",
     "sffgpu_collide_transforms", "sffgpu_ctx_set_stream", "sffgpu_forest_device_engine", "sffgpu_forest_exchange_bytes",
     "sffgpu_forest_rounds_per_wave", "sffgpu_forest_dev_wave_begin", "sffgpu_forest_dev_round_eval",
     "sffgpu_forest_dev_round_commit", "sffgpu_forest_dev_wave_end", "sffgpu_forest_in_wave", "sffgpu_forest_round_begin", "sffgpu_forest_round_records", "sffgpu_forest_round_commit",
@@ -60,14 +60,16 @@ class ForestStats(C.Structure):
 class RrtCfg(C.Structure):
     _fields_ = [("dim", C.c_int32), ("optimize", C.c_int32), ("has_goal", C.c_int32), ("goal", C.c_double * 6),
                 ("limits", C.c_double * 6), ("dist_tree", C.c_double), ("sampling_dist", C.c_double),
-                ("priority_bias", C.c_double), ("max_iterations", C.c_int32), ("seed", C.c_uint64), ("wave", C.c_int32)]
+                ("priority_bias", C.c_double), ("max_iterations", C.c_int32), ("seed", C.c_uint64), ("wave", C.c_int32),
+                ("lazy_edge", C.c_int32), ("rng_skip", C.c_uint64)]
 
 
 class RrtStats(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("solved", C.c_int32), ("n_nodes", C.c_int32), ("n_live_trees", C.c_int32),
                 ("merges", C.c_int32), ("n_links", C.c_int32), ("collide_calls", C.c_uint64),
                 ("path_free_calls", C.c_uint64), ("nn_queries", C.c_uint64), ("total_ms", C.c_double),
-                ("waves", C.c_uint64), ("speculated", C.c_uint64), ("committed", C.c_uint64)]
+                ("waves", C.c_uint64), ("speculated", C.c_uint64), ("committed", C.c_uint64), ("rng_draws", C.c_uint64),
+                ("lazy_distance", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -131,6 +133,7 @@ def lib():
     L.sffgpu_rrt_path_plan.argtypes = [C.c_void_p, C.c_int, C.c_int, c_ip, C.c_int]
     L.sffgpu_rrt_smooth_paths.argtypes = [C.c_void_p]
     L.sffgpu_rrt_link_plan.argtypes = [C.c_void_p, C.c_int, c_ip, C.c_int]
+    L.sffgpu_rrt_lazy_plan.argtypes = [C.c_void_p, c_ip, C.c_int]
     L.sffgpu_forest_get_frontier.argtypes = [C.c_void_p, c_ip, C.c_int]
     L.sffgpu_forest_in_wave.argtypes = [C.c_void_p]
     L.sffgpu_ctx_set_stream.argtypes = [C.c_void_p, C.c_void_p]
@@ -427,13 +430,15 @@ class Rrt:
     """RapidExpTree solver session (reference src/rrt.h:25-44) on one Context."""
 
     def __init__(self, ctx, roots, limits, dist_tree, sampling_dist, dim=6, optimize=False, goal=None,
-                 priority_bias=0.0, max_iterations=10000, seed=1, wave=0):
+                 priority_bias=0.0, max_iterations=10000, seed=1, wave=0, lazy_edge=False, rng_skip=0):
         self.ctx = ctx
         cfg = RrtCfg()
         cfg.wave = wave
         cfg.dim = dim
         cfg.optimize = int(optimize)
-        cfg.has_goal = int(goal is not None)
+        cfg.has_goal = int(goal is not None and not lazy_edge)   # (lazy_edge: the goal is only a stopping test)
+        cfg.lazy_edge = int(lazy_edge)
+        cfg.rng_skip = rng_skip
         if goal is not None:
             cfg.goal = (C.c_double * 6)(*goal)
         cfg.limits = (C.c_double * 6)(*limits)
@@ -485,6 +490,12 @@ class Rrt:
     def plan(self, i, j, cap=1 << 16):
         ids = np.zeros(cap, np.int32)
         k = self.ctx._chk(self.ctx._L.sffgpu_rrt_path_plan(self.h, i, j, _ip(ids), cap))
+        return ids[:min(k, cap)].copy()
+
+    def lazy_plan(self, cap=1 << 16):
+        """lazy_edge: node ids root ... the node that reached the goal (empty while unsolved)"""
+        ids = np.zeros(cap, np.int32)
+        k = self.ctx._chk(self.ctx._L.sffgpu_rrt_lazy_plan(self.h, _ip(ids), cap))
         return ids[:min(k, cap)].copy()
 
     def smooth(self, cap=1 << 16):

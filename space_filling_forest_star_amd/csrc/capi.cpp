@@ -248,8 +248,20 @@ int sffgpu_rrt_get_stats(sffgpu_rrt* r, sffgpu_rrt_stats* out) {
   int nl = 0;
   for (auto& l : R.links) nl += (int)l.size();
   s.n_links = nl;
+  s.rng_draws = R.rng.draws;
+  s.lazy_distance = R.lazy_distance;
   *out = s;
   return SFFGPU_OK;
+}
+int sffgpu_rrt_lazy_plan(sffgpu_rrt* r, int32_t* node_ids, int cap) {
+  if (!r) return SFFGPU_ERR_ARG;
+  Rrt& R = *r->r;
+  if (R.lazy_last < 0) return 0;
+  std::vector<int> chain;
+  for (int n = R.lazy_last;; n = R.nodes[n].parent) { chain.push_back(n); if (R.nodes[n].d_root == 0) break; }   // Node::IsRoot()
+  std::reverse(chain.begin(), chain.end());
+  for (int k = 0; k < (int)chain.size() && k < cap; ++k) if (node_ids) node_ids[k] = chain[k];
+  return (int)chain.size();
 }
 int sffgpu_rrt_get_nodes(sffgpu_rrt* r, double* pos6, int32_t* parent, int32_t* tree, int32_t* root_tree, int32_t* iter,
                          double* cost, double* dist_parent) {

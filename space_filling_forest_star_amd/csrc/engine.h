@@ -394,6 +394,9 @@ struct Rrt {
   std::vector<int> tree_frontier;
   int num_trees = 0, goal_node = -1, iter = 0;
   bool solved = false;
+  int lazy_last = -1;                                   // lazy_edge: the node that reached the goal
+  double lazy_distance = 1.7976931348623157e308;
+  bool lazy_goal_check(int new_id);                     // src/lazy.h:258-273
   sffgpu_rrt_stats st{};
 
   Rrt(Ctx* c, const sffgpu_rrt_cfg& cf, const double* roots6, int n_roots);

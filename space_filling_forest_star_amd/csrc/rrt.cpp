@@ -25,7 +25,10 @@ Rrt::Rrt(Ctx* c, const sffgpu_rrt_cfg& cf, const double* roots6, int n_roots) : 
   if (n_roots < 1) throw HipError{"rrt: at least one root"};
   if (cfg.priority_bias != 0 && !cfg.has_goal) throw HipError{"rrt: goal bias needs a goal (src/main.cpp:330-331)"};
   if (!c->have_env || !c->have_robot) throw HipError{"rrt: upload ENV and ROBOT meshes first"};
+  if (cfg.lazy_edge && (n_roots != 1 || cfg.has_goal || cfg.priority_bias != 0))
+    throw HipError{"rrt: lazy_edge grows ONE tree from one root towards cfg.goal (has_goal = 0, no goal bias)"};
   rng.reseed(cfg.seed);
+  for (uint64_t k = 0; k < cfg.rng_skip; ++k) (void)rng.next();
   const int nt = n_roots + (cfg.has_goal ? 1 : 0);
   trees.resize(nt);
   links.resize(nt);
@@ -64,6 +67,17 @@ int Rrt::add_node(const double* pos, int root_tree, int tree, int parent, double
     ctx->store_append(pos, &t, 1);              // replaces flannIndex->addPoints (:215)
   }
   return id;
+}
+
+// LazyTSP::runRRT's goal test (src/lazy.h:258-273): the new node within treeDistance of the goal ends the edge's
+// search - there is no edge check towards the goal
+bool Rrt::lazy_goal_check(int new_id) {
+  const double gd = sffg::dist6(cfg.goal, nodes[new_id].pos);
+  if (!(gd < cfg.dist_tree)) return false;
+  solved = true;
+  lazy_distance = gd + nodes[new_id].d_root;
+  lazy_last = new_id;
+  return true;
 }
 
 RLink Rrt::make_link(int a, int b) {            // DistanceHolder(first, second), src/primitives.h:609-618
@@ -135,7 +149,7 @@ void Rrt::expand(int tree_to_expand, unsigned iteration) {
   int new_id;
   if (cfg.optimize) {                                                           // :156-201
     double best = dist6(np, nodes[nearest].pos) + nodes[nearest].d_root;
-    const size_t krrt = (size_t)(2 * M_E * std::log10((double)nodes.size()));
+    const size_t krrt = (size_t)(2 * M_E * std::log10((double)nodes.size() + (cfg.lazy_edge ? 1.0 : 0.0)));   // src/lazy.h:199
     std::vector<int> kn;
     if (krrt > 0) {
       knn(np, 1, &tq, (int)krrt, res);
@@ -184,6 +198,7 @@ void Rrt::expand(int tree_to_expand, unsigned iteration) {
     new_id = add_node(np, nodes[nearest].root_tree, tree_to_expand, nearest, cfg.sampling_dist,
                       nodes[nearest].d_root + cfg.sampling_dist, iteration);
   }
+  if (cfg.lazy_edge) { lazy_goal_check(new_id); return; }
   // :219-319 connect to / merge with the other live trees.  Merging changes neither the node set
   // of any third tree nor the new point, so the nearest node of every other live tree and its
   // edge check can be fetched up front in one sweep + one collision launch.
@@ -291,7 +306,7 @@ int Rrt::run_wave(int B) {
   // ---- 1. per iteration: tree pick (:95) and steering target (:130-134), in the reference's draw order
   for (int j = 0; j < B; ++j) {
     w[j].draws_before = rng.draws;
-    w[j].tree = tree_frontier[rng.uniform_int(0, num_trees)];
+    w[j].tree = cfg.lazy_edge ? 0 : tree_frontier[rng.uniform_int(0, num_trees)];   // (src/lazy.h:181 draws no tree)
     draw_target(w[j].rnd);
   }
   const uint64_t draws_end = rng.draws;
@@ -330,7 +345,7 @@ int Rrt::run_wave(int B) {
     if (!w[j].pose_hit && w[j].par_free) alive.push_back(j);
   const int nA = (int)alive.size();
   // ---- 4. RRT*: k_max nearest store nodes around every surviving new point (:166)
-  const int kmax = cfg.optimize ? (int)(size_t)(2 * M_E * std::log10((double)(N0 + B))) : 0;
+  const int kmax = cfg.optimize ? (int)(size_t)(2 * M_E * std::log10((double)(N0 + B) + (cfg.lazy_edge ? 1.0 : 0.0))) : 0;
   if (kmax > 0 && nA > 0) {
     std::vector<double> q((size_t)nA * 6);
     std::vector<int32_t> tq(nA);
@@ -464,7 +479,7 @@ int Rrt::run_wave(int B) {
     int new_id;
     if (cfg.optimize) {                                                          // :156-201
       double best = dist6(cd.np, nodes[nearest].pos) + nodes[nearest].d_root;
-      const size_t krrt = (size_t)(2 * M_E * std::log10((double)nodes.size()));
+      const size_t krrt = (size_t)(2 * M_E * std::log10((double)nodes.size() + (cfg.lazy_edge ? 1.0 : 0.0)));
       st.nn_queries += 1;
       struct KN { double d; int order; int node; const WCand::Edge* e; };
       std::vector<KN> kn;
@@ -506,6 +521,7 @@ int Rrt::run_wave(int B) {
     }
     cd.accepted = new_id;
     acc.push_back(j);
+    if (cfg.lazy_edge) { lazy_goal_check(new_id); continue; }   // (solved ends the replay loop)
     // :219-319 links to the other live trees, in frontier order
     for (int i = 0; i < (int)tree_frontier.size(); ++i) {
       const int tree = tree_frontier[i];
@@ -563,7 +579,7 @@ void Rrt::run(int max_iters) {
     if (cfg.wave == 1) {
       ++done;
       ++iter;
-      int tree = tree_frontier[rng.uniform_int(0, num_trees)];                  // :95
+      int tree = cfg.lazy_edge ? 0 : tree_frontier[rng.uniform_int(0, num_trees)];   // :95
       expand(tree, (unsigned)iter);
       continue;
     }

@@ -38,13 +38,15 @@ class ForestStats(C.Structure):
 class RrtCfg(C.Structure):
     _fields_ = [("dim", C.c_int), ("optimize", C.c_int), ("has_goal", C.c_int), ("goal", C.c_double * 6),
                 ("limits", C.c_double * 6), ("dist_tree", C.c_double), ("sampling_dist", C.c_double),
-                ("priority_bias", C.c_double), ("max_iterations", C.c_int), ("seed", C.c_uint64), ("trig", C.c_int)]
+                ("priority_bias", C.c_double), ("max_iterations", C.c_int), ("seed", C.c_uint64), ("trig", C.c_int),
+                ("lazy_edge", C.c_int), ("rng_skip", C.c_uint64)]
 
 
 class RrtStats(C.Structure):
     _fields_ = [("iterations", C.c_int32), ("solved", C.c_int32), ("n_nodes", C.c_int32), ("n_live_trees", C.c_int32),
                 ("merges", C.c_int32), ("n_links", C.c_int32), ("collide_calls", C.c_uint64),
-                ("path_free_calls", C.c_uint64), ("nn_queries", C.c_uint64)]
+                ("path_free_calls", C.c_uint64), ("nn_queries", C.c_uint64), ("rng_draws", C.c_uint64),
+                ("lazy_distance", C.c_double)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -117,6 +119,7 @@ def lib():
     L.sffo_rrt_get_links.argtypes = [C.c_void_p, c_ip, c_ip, c_ip, c_dp, C.c_int]
     L.sffo_rrt_smooth.argtypes = [C.c_void_p]
     L.sffo_rrt_link_plan.argtypes = [C.c_void_p, C.c_int, c_ip, C.c_int]
+    L.sffo_rrt_lazy_plan.argtypes = [C.c_void_p, c_ip, C.c_int]
     _LIB = L
     return L
 
@@ -286,12 +289,14 @@ class Forest:
 
 class Rrt:
     def __init__(self, world, roots, limits, dist_tree, sampling_dist, dim=6, optimize=False, goal=None,
-                 priority_bias=0.0, max_iterations=10000, seed=1, trig=None):
+                 priority_bias=0.0, max_iterations=10000, seed=1, trig=None, lazy_edge=False, rng_skip=0):
         self.world = world
         cfg = RrtCfg()
         cfg.dim = dim
         cfg.optimize = int(optimize)
-        cfg.has_goal = int(goal is not None)
+        cfg.has_goal = int(goal is not None and not lazy_edge)
+        cfg.lazy_edge = int(lazy_edge)
+        cfg.rng_skip = rng_skip
         if goal is not None:
             cfg.goal = (C.c_double * 6)(*goal)
         cfg.limits = (C.c_double * 6)(*limits)
@@ -336,6 +341,11 @@ class Rrt:
         d = np.zeros((n_trees, n_trees))
         k = lib().sffo_rrt_paths(self.h, dp(d))
         return d, k
+
+    def lazy_plan(self, cap=1 << 16):
+        ids = np.zeros(cap, np.int32)
+        k = lib().sffo_rrt_lazy_plan(self.h, ip(ids), cap)
+        return ids[:k].copy()
 
     def plan(self, i, j, cap=1 << 16):
         ids = np.zeros(cap, np.int32)

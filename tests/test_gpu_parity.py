@@ -595,6 +595,45 @@ def test_sharded_rounds_equal_single_gpu(S, name, world, wave, optimize):
         c.close()
 
 
+@pytest.mark.parametrize("name,optimize,iters,edges,expect_solved", [
+    ("dense2d", False, 3000, ((0, 1), (2, 1)), 2), ("dense2d", True, 3000, ((0, 1), (2, 1)), 2),
+    ("dense3d_coarse", True, 8000, ((2, 1), (0, 1)), 1),      # the second start is walled in: DBL_MAX edge (src/lazy.h:280)
+    ("triang", False, 1500, ((0, 1), (2, 1)), 0),             # 6-D goal never reached within the budget
+])
+def test_lazy_edge_rrt_identical(S, ctx, name, optimize, iters, edges, expect_solved):
+    """LazyTSP::runRRT (src/lazy.h:160-284): one tree from one root towards a goal, solved when a node comes within
+    treeDistance of it.  Two consecutive edges drawn from ONE engine stream (rng_skip), every wave size: nodes,
+    parents, costs, the edge's distance and plan, the counters and the stream position equal the oracle's."""
+    sc, w = load_world(ctx, name)
+    pts = sc["xml_points"] if sc["xml_points"] is not None else common.free_roots(w.collide, sc["limits"], 6, seed=3,
+                                                                                 dim=sc["dim"])
+    kw = dict(dist_tree=sc["dist_tree"], sampling_dist=sc["sampling_dist"], dim=sc["dim"], optimize=optimize,
+              max_iterations=iters, seed=11, lazy_edge=True)
+    skip_o = 0
+    n_solved = 0
+    for a, b in edges:
+        ro = O.Rrt(w, pts[a:a + 1], sc["limits"], goal=pts[b], rng_skip=skip_o, **kw)
+        ro.run()
+        so, no, po = ro.stats(), ro.nodes(), ro.lazy_plan()
+        assert so["iterations"] > 20
+        n_solved += int(so["solved"])
+        assert (len(po) > 0) == bool(so["solved"])
+        assert (so["lazy_distance"] < 1e300) == bool(so["solved"])
+        for wave in (1, 0, 64):
+            rg = S.Rrt(ctx, pts[a:a + 1], sc["limits"], goal=pts[b], rng_skip=skip_o, wave=wave, **kw)
+            rg.run()
+            sg = rg.stats()
+            for k in so:
+                assert so[k] == sg[k], (a, b, wave, k, so[k], sg[k])
+            ng = rg.nodes()
+            for k in no:
+                assert np.array_equal(no[k], ng[k]), (a, b, wave, k)
+            assert np.array_equal(po, rg.lazy_plan())
+            rg.close()
+        skip_o = so["rng_draws"]          # the next edge continues the stream (one RandGen per solver, src/lazy.h:181)
+    assert n_solved == expect_solved
+
+
 @pytest.mark.parametrize("name,optimize,n_roots,goal,bias,iters", [
     ("triang", False, 4, False, 0.0, 1500),        # Multi-T-RRT: trees merge until one is left
     ("triang", True, 1, True, 0.1, 600),           # RRT* towards a goal with goal bias

@@ -204,3 +204,32 @@ def test_rrt_smoothing_only_shortens_link_plans():
     d1, c1 = r.paths(3)
     assert np.array_equal(d0, d1) and c0 == c1
     assert shortened >= 1
+
+
+def test_lazy_edge_rrt_oracle_properties():
+    """LazyTSP::runRRT restatement (src/lazy.h:160-284): the plan runs root -> ... -> the node that came within
+    treeDistance of the goal, the edge's distance is that node's cost plus its distance to the goal (:262), an
+    unsolved edge reports DBL_MAX (:280), and rng_skip continues one engine stream across sessions."""
+    sc = common.scenario("dense2d")
+    w = O.World(sc["env"], sc["robot"])
+    pts = sc["xml_points"]
+    kw = dict(dist_tree=sc["dist_tree"], sampling_dist=sc["sampling_dist"], dim=2, seed=9, lazy_edge=True)
+    r = O.Rrt(w, pts[0:1], sc["limits"], goal=pts[1], max_iterations=4000, **kw)
+    r.run()
+    st, n, plan = r.stats(), r.nodes(), r.lazy_plan()
+    assert st["solved"] == 1 and st["n_live_trees"] == 1 and st["merges"] == 0
+    assert plan[0] == 0 and all(n["parent"][plan[k + 1]] == plan[k] for k in range(len(plan) - 1))
+    last = plan[-1]
+    gd = np.sqrt(((n["pos"][last] - pts[1]) ** 2).sum())
+    assert gd < sc["dist_tree"] and st["lazy_distance"] == gd + n["cost"][last]
+    assert last == st["n_nodes"] - 1                      # the search stops with the node that reached the goal
+    # too few iterations: unsolved, DBL_MAX, no plan
+    r2 = O.Rrt(w, pts[0:1], sc["limits"], goal=pts[1], max_iterations=50, **kw)
+    r2.run()
+    s2 = r2.stats()
+    assert s2["solved"] == 0 and s2["iterations"] == 50 and s2["lazy_distance"] > 1e300 and len(r2.lazy_plan()) == 0
+    # the stream: a session started with rng_skip = the words the first one consumed draws what a fresh engine
+    # draws after discarding that many words (the RRT* variant consumes the same words per iteration)
+    r3 = O.Rrt(w, pts[2:3], sc["limits"], goal=pts[1], max_iterations=300, rng_skip=st["rng_draws"], **kw)
+    r3.run()
+    assert r3.stats()["rng_draws"] == st["rng_draws"] + 2 * 300 or r3.stats()["solved"] == 1
