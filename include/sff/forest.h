@@ -68,12 +68,16 @@ class SpaceForest : public Solver<T, R> {
     sff_compat::check(sffgpu_forest_create(sff_compat::gpu(), &cfg, roots.data(), (int)P.roots.size(), &f), "forest");
 
     sffgpu_forest_stats st;
-    auto loadNodes = [&]() {
+    // upTo >= 0: only the nodes created up to that iteration.  Node ids follow the order of creation and (plain SFF)
+    // a parent is always older than its child, so that forest is a prefix of the node arrays.
+    auto loadNodes = [&](long upTo = -1) {
       sffgpu_forest_get_stats(f, &st);
-      const int n = st.n_nodes;
+      int n = st.n_nodes;
       std::vector<double> pos((size_t)n * 6), cost(n), dpar(n);
       std::vector<int32_t> parent(n), tree(n), iter(n);
       sffgpu_forest_get_nodes(f, pos.data(), parent.data(), tree.data(), iter.data(), cost.data(), dpar.data());
+      if (upTo >= 0)
+        while (n > 0 && (long)iter[n - 1] > upTo) --n;
       this->fillNodes(n, st.n_trees, pos.data(), parent.data(), tree.data(), iter.data(), cost.data(), dpar.data());
     };
     auto loadFrontier = [&](std::vector<int32_t>& open_nodes) {
@@ -86,9 +90,11 @@ class SpaceForest : public Solver<T, R> {
     if (P.saveTreeIter == 0 && P.saveFrontiersIter == 0) {
       sff_compat::check(sffgpu_forest_run(f, 0), "forest run");
     } else {
-      // saveIterCheck (src/problemStruct.h:256-261, src/forest.h:570-578) dumps after every k-th iteration.  Here
-      // the loop advances by waves, so "iter_<k>_" files hold the state at the END OF THE WAVE in which iteration
-      // k fell (SFF_WAVE=1 keeps that within ThresholdMisses iterations of the reference's snapshot).
+      // saveIterCheck (src/problemStruct.h:256-261, src/forest.h:570-578) dumps after every k-th iteration.  The
+      // loop advances by waves; a plain SFF tree dump is nevertheless exactly the forest after iteration k (the nodes
+      // created up to k, their parents never change).  SFF* rewires parents later in the wave and the frontier of an
+      // earlier iteration cannot be told afterwards: those "iter_<k>_" files hold the state at the END OF THE WAVE
+      // in which iteration k fell (SFF_WAVE=1 keeps that within ThresholdMisses iterations of the reference's).
       long nextTree = P.saveTreeIter, nextFront = P.saveFrontiersIter;
       uint64_t wavesBefore = ~0ULL;
       while (true) {
@@ -99,7 +105,8 @@ class SpaceForest : public Solver<T, R> {
         sffgpu_forest_get_stats(f, &st);
         bool loaded = false;
         while (P.saveTreeIter != 0 && (long)st.iterations >= nextTree) {
-          if (!loaded) { loadNodes(); loaded = true; }
+          if (!P.optimal) { loadNodes(nextTree); loaded = false; }
+          else if (!loaded) { loadNodes(); loaded = true; }
           this->saveTrees(prefixFileName(P.fileNames[SaveTree], "iter_" + std::to_string(nextTree) + "_"));
           nextTree += P.saveTreeIter;
         }
