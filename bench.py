@@ -123,6 +123,8 @@ def main():
     if world != args.gpus:
         sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node %d)" % (args.gpus, world, args.gpus))
     distributed = world > 1 or args.force_dist
+    if args.force_dist and world == 1:
+        os.environ["SFFGPU_TEST_EXCHANGE_SELF"] = "1"   # pack -> ncclAllGather (one rank) -> unpack in every round
     torch.cuda.set_device(local_rank)
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -247,7 +249,9 @@ def main():
                 "seed": args.seed, "nodes_at_start": s0["n_nodes"], "nodes_at_end": s1["n_nodes"],
                 "waves": int(s1["waves"] - s0["waves"]),
                 "parallelism": "1 GPU" if world == 1 else
-                "one forest, wave slots sharded over %d GPUs (i %% world), RCCL all-gather of answer records per round" % world,
+                "one forest, wave slots sharded over %d GPUs (i %% world), RCCL all-gather of answer records per round "
+                "(%s)" % (world, "the library's own communicator, whole waves enqueued by the library"
+                          if getattr(ctx, "rccl", None) else "torch.distributed on the library's stream"),
             },
             "collision_checks_per_s": checks / elapsed,
             "collision_checks_executed_per_s": executed / elapsed,
@@ -338,9 +342,13 @@ def main():
                           % (args.cpu_iters, so["n_nodes"], c1 - c0),
                 "collision_checks_per_s": so["collide_calls"] / (c1 - c0),
             }
+    ctx.close()   # (also tears the library's own RCCL communicator down before the line is printed)
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+    if rank != 0:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
     if rank == 0:
         # RCCL prints its version banner through C stdio, which would otherwise be flushed AFTER this line at
         # exit: flush it first so that the JSON line is the last thing on stdout

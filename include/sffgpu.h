@@ -249,6 +249,16 @@ int sffgpu_forest_round_commit(sffgpu_forest* f, const int32_t* all_words, int t
  * With world == 1 the buffers may be NULL.  sffgpu_forest_device_engine() tells whether this forest runs on the
  * device engine (plain SFF, wave >= 256, not in libm_sampling mode; SFFGPU_ENGINE=host|device overrides). */
 int sffgpu_ctx_set_stream(sffgpu_ctx* ctx, void* hip_stream);   /* NULL: back to the context's own stream */
+/* The same exchange driven by the library itself: an RCCL communicator of its own (one rank per process and GPU).
+ * Rank 0 makes the 128-byte id (sffgpu_rccl_unique_id), the caller ships it to every rank (any channel), every rank
+ * calls sffgpu_ctx_rccl_init(ctx, id, rank, world).  sffgpu_forest_run() of a device-engine forest created with the
+ * same rank / world then runs whole waves - replicated kernels, ncclAllGather of the answer records between device
+ * buffers on the library's stream, one wave enqueued ahead - with no per-round call from the host language.  Returns
+ * SFFGPU_NEED_HOST_EXCHANGE when a bounded device list overflowed: the forest is on the host engine mid-wave and the
+ * caller finishes that wave with sffgpu_forest_round_begin / _commit (then calls run again). */
+#define SFFGPU_NEED_HOST_EXCHANGE 100
+int sffgpu_rccl_unique_id(uint8_t id128[128]);
+int sffgpu_ctx_rccl_init(sffgpu_ctx* ctx, const uint8_t id128[128], int rank, int world);
 int sffgpu_forest_device_engine(sffgpu_forest* f);
 long long sffgpu_forest_exchange_bytes(sffgpu_forest* f);
 int sffgpu_forest_rounds_per_wave(sffgpu_forest* f);

@@ -19,7 +19,7 @@ EXPORTED_SYMBOLS = [
     "sffgpu_rrt_create", "sffgpu_rrt_destroy", "sffgpu_rrt_run", "sffgpu_rrt_get_stats", "sffgpu_rrt_get_nodes",
     "sffgpu_rrt_get_links", "sffgpu_rrt_paths", "sffgpu_rrt_path_plan", "sffgpu_rrt_smooth_paths",
     "sffgpu_rrt_link_plan", "sffgpu_rrt_lazy_plan", "sffgpu_kernel_times", "sffgpu_forest_get_frontier",
-    "sffgpu_collide_transforms", "sffgpu_ctx_set_stream", "sffgpu_forest_device_engine", "sffgpu_forest_exchange_bytes",
+    "sffgpu_collide_transforms", "sffgpu_ctx_set_stream", "sffgpu_rccl_unique_id", "sffgpu_ctx_rccl_init", "sffgpu_forest_device_engine", "sffgpu_forest_exchange_bytes",
     "sffgpu_forest_rounds_per_wave", "sffgpu_forest_dev_wave_begin", "sffgpu_forest_dev_round_eval",
     "sffgpu_forest_dev_round_commit", "sffgpu_forest_dev_wave_end", "sffgpu_forest_in_wave", "sffgpu_forest_round_begin", "sffgpu_forest_round_records", "sffgpu_forest_round_commit",
 ]
@@ -73,6 +73,17 @@ class RrtStats(C.Structure):
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+NEED_HOST_EXCHANGE = 100   # sffgpu_forest_run: SFFGPU_NEED_HOST_EXCHANGE
+
+
+def rccl_unique_id():
+    """128-byte id for Context.rccl_init, made by rank 0 and shipped to the other ranks by the caller"""
+    buf = (C.c_uint8 * 128)()
+    if lib().sffgpu_rccl_unique_id(buf) != 0:
+        raise SffGpuError("librccl could not be bound")
+    return bytes(buf)
 
 
 def lib_path():
@@ -137,6 +148,8 @@ def lib():
     L.sffgpu_forest_get_frontier.argtypes = [C.c_void_p, c_ip, C.c_int]
     L.sffgpu_forest_in_wave.argtypes = [C.c_void_p]
     L.sffgpu_ctx_set_stream.argtypes = [C.c_void_p, C.c_void_p]
+    L.sffgpu_rccl_unique_id.argtypes = [C.c_void_p]
+    L.sffgpu_ctx_rccl_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
     L.sffgpu_forest_device_engine.argtypes = [C.c_void_p]
     L.sffgpu_forest_exchange_bytes.argtypes = [C.c_void_p]
     L.sffgpu_forest_exchange_bytes.restype = C.c_longlong
@@ -242,6 +255,12 @@ class Context:
         """run the library's launches on the caller's HIP stream (e.g. torch.cuda.current_stream().cuda_stream)"""
         self._chk(self._L.sffgpu_ctx_set_stream(self.h, C.c_void_p(hip_stream)))
 
+    def rccl_init(self, id128, rank, world):
+        """give the context an RCCL communicator of its own (id128: the 128 bytes of rccl_unique_id() of rank 0)"""
+        buf = (C.c_uint8 * 128)(*bytes(id128))
+        self._chk(self._L.sffgpu_ctx_rccl_init(self.h, buf, rank, world))
+        self.rccl = (rank, world)
+
     def nodes_reset(self, capacity=0):
         self._chk(self._L.sffgpu_nodes_reset(self.h, capacity))
 
@@ -327,7 +346,12 @@ class Forest:
             pass
 
     def run(self, max_waves=0):
-        self.ctx._chk(self.ctx._L.sffgpu_forest_run(self.h, max_waves))
+        """returns True when a sharded wave has to be finished through round_begin / round_commit (native RCCL
+        exchange, a bounded device list overflowed), else None"""
+        rc = self.ctx._L.sffgpu_forest_run(self.h, max_waves)
+        if rc == NEED_HOST_EXCHANGE:
+            return True
+        self.ctx._chk(rc)
 
     def stats(self):
         s = ForestStats()
@@ -617,9 +641,56 @@ def _run_distributed_device(forest, max_waves, group):
     return forest.stats()["waves"] - w0
 
 
+def _native_rccl(forest, group):
+    """True when the forest's context owns (or can be given) an RCCL communicator matching the process group: the
+    library then drives the waves - kernels and ncclAllGather - by itself (no per-round Python)."""
+    import torch
+    import torch.distributed as dist
+    if os.environ.get("SFFGPU_NO_NATIVE_RCCL") or dist.get_backend(group) != "nccl":
+        return False
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if getattr(forest.ctx, "rccl", None) == (rank, world):
+        return True
+    try:
+        dev = torch.device("cuda", torch.cuda.current_device())
+        ident = torch.zeros(128, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            ident = torch.tensor(list(rccl_unique_id()), dtype=torch.uint8, device=dev)
+        dist.broadcast(ident, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        forest.ctx.rccl_init(bytes(ident.cpu().tolist()), rank, world)
+        ok = 1
+    except Exception:
+        ok = 0
+    flag = torch.tensor([ok], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)      # every rank takes the same path
+    return bool(flag.item())
+
+
+def _run_distributed_native(forest, max_waves, group):
+    w0 = forest.stats()["waves"]
+    while True:
+        left = 0
+        if max_waves > 0:
+            left = max_waves - (forest.stats()["waves"] - w0)
+            if left <= 0 and not forest.in_wave():
+                break
+        if not forest.run(max(left, 1) if max_waves > 0 else 0):
+            break
+        # a bounded device list overflowed in this wave on every (identical) replica: finish it on the host protocol
+        while forest.in_wave():
+            rec, done = forest.round_begin()
+            if done:
+                break
+            allw, counts = exchange_records(rec, group)
+            forest.round_commit(allw, counts)
+    return forest.stats()["waves"] - w0
+
+
 def run_distributed(forest, max_waves=0, group=None):
     """Drive one shared forest over all ranks of the process group; returns waves done."""
     if forest.device_engine():
+        if _native_rccl(forest, group):
+            return _run_distributed_native(forest, max_waves, group)
         return _run_distributed_device(forest, max_waves, group)
     w0 = forest.stats()["waves"]
     while True:

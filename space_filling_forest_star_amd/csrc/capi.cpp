@@ -139,7 +139,22 @@ void sffgpu_forest_destroy(sffgpu_forest* f) {
 }
 int sffgpu_forest_run(sffgpu_forest* f, int max_waves) {
   if (!f) return SFFGPU_ERR_ARG;
-  GUARD(f->owner, f->f->run(max_waves));
+  try {
+    f->f->run(max_waves);
+  } catch (const HipError& e) {
+    f->owner->c->err = e.msg;
+    return SFFGPU_ERR_HIP;
+  }
+  return f->f->need_host_exchange ? SFFGPU_NEED_HOST_EXCHANGE : SFFGPU_OK;
+}
+int sffgpu_rccl_unique_id(uint8_t id128[128]) {
+  if (!id128) return SFFGPU_ERR_ARG;
+  try { Ctx::rccl_unique_id(id128); } catch (const HipError&) { return SFFGPU_ERR_HIP; }
+  return SFFGPU_OK;
+}
+int sffgpu_ctx_rccl_init(sffgpu_ctx* ctx, const uint8_t id128[128], int rank, int world) {
+  if (!ctx || !id128) return SFFGPU_ERR_ARG;
+  GUARD(ctx, ctx->c->rccl_init(id128, rank, world));
 }
 int sffgpu_forest_get_stats(sffgpu_forest* f, sffgpu_forest_stats* out) {
   if (!f || !out) return SFFGPU_ERR_ARG;

@@ -1,5 +1,6 @@
 // engine.cpp — device context and batched primitive operations of libsffgpu.
 #include "engine.h"
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <chrono>
@@ -154,8 +155,70 @@ Ctx::Ctx(int dev) : device(dev) {
   HIPCHK(hipEventCreateWithFlags(&ev_early, hipEventDisableTiming));
 }
 
+// ---- RCCL, bound at run time (the library has no link-time dependency on it; a copy already mapped by the host
+// process - PyTorch ships one - is reused)
+namespace {
+struct RcclApi {
+  struct Id128 { char b[128]; };   // ncclUniqueId (passed by value)
+  int (*GetUniqueId)(void*) = nullptr;
+  int (*CommInitRank)(void**, int, Id128, int) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  int (*CommDestroy)(void*) = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  bool ok = false;
+};
+RcclApi& rccl() {
+  static RcclApi api;
+  static bool tried = false;
+  if (tried) return api;
+  tried = true;
+  void* h = nullptr;
+  for (const char* name : {"librccl.so.1", "librccl.so"}) {
+    h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+    if (h) break;
+  }
+  for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+    if (h) break;
+    h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+  }
+  if (!h) return api;
+  api.GetUniqueId = reinterpret_cast<decltype(api.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+  api.CommInitRank = reinterpret_cast<decltype(api.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+  api.AllGather = reinterpret_cast<decltype(api.AllGather)>(dlsym(h, "ncclAllGather"));
+  api.CommDestroy = reinterpret_cast<decltype(api.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+  api.GetErrorString = reinterpret_cast<decltype(api.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+  api.ok = api.GetUniqueId && api.CommInitRank && api.AllGather && api.CommDestroy;
+  return api;
+}
+void rccl_check(int rc, const char* what) {
+  if (rc == 0) return;
+  const char* msg = rccl().GetErrorString ? rccl().GetErrorString(rc) : "?";
+  throw HipError{std::string("rccl: ") + what + " failed: " + msg};
+}
+}  // namespace
+
+void Ctx::rccl_unique_id(uint8_t* id128) {
+  if (!rccl().ok) throw HipError{"rccl: librccl could not be bound"};
+  rccl_check(rccl().GetUniqueId(id128), "ncclGetUniqueId");
+}
+void Ctx::rccl_init(const uint8_t* id128, int rank, int world) {
+  if (!rccl().ok) throw HipError{"rccl: librccl could not be bound"};
+  if (world < 1 || rank < 0 || rank >= world) throw HipError{"rccl: bad rank / world"};
+  HIPCHK(hipSetDevice(device));
+  if (rccl_comm) { (void)rccl().CommDestroy(rccl_comm); rccl_comm = nullptr; }
+  RcclApi::Id128 id;
+  memcpy(id.b, id128, 128);
+  rccl_check(rccl().CommInitRank(&rccl_comm, world, id, rank), "ncclCommInitRank");
+  rccl_rank = rank;
+  rccl_world = world;
+}
+void Ctx::rccl_all_gather_i32(const void* send, void* recv, size_t words) {
+  rccl_check(rccl().AllGather(send, recv, words, /* ncclInt32 */ 2, rccl_comm, stream), "ncclAllGather");
+}
+
 Ctx::~Ctx() {
   (void)hipSetDevice(device);
+  if (rccl_comm && rccl().CommDestroy) { (void)rccl().CommDestroy(rccl_comm); rccl_comm = nullptr; }
   if (stream) (void)hipStreamSynchronize(stream);
   if (copy_stream) (void)hipStreamSynchronize(copy_stream);
   if (ev_mid) (void)hipEventDestroy(ev_mid);
@@ -164,7 +227,7 @@ Ctx::~Ctx() {
   for (auto e : pool) (void)hipEventDestroy(e);
   DevBuf* bufs[] = {&env_tri, &env_box, &env_plane, &rob_tri, &sx, &sy, &sz, &syaw, &spitch, &sroll, &stree, &spos,
                     &d_a, &d_b, &d_c, &d_d, &d_e, &d_f, &d_g, &d_h, &r_in, &r_out, &r_q, &r_cnt, &r_hidx,
-                    &r_hdist, &r_sega, &r_segb, &r_items, &r_items2, &env_clear, &g_cnt, &g_items, &g_ovfcnt, &g_ovf, &t_cnt, &t_items, &t_ovfcnt, &t_ovf, &t_occ, &env_tg_start, &env_tg_list};
+                    &r_hdist, &r_sega, &r_segb, &r_items, &r_items2, &env_clear, &g_cnt, &g_items, &g_ovfcnt, &g_ovf, &t_cnt, &t_items, &t_ovfcnt, &t_ovf, &t_occ, &env_tg_start, &env_tg_list, &r_sub, &env_ext};
   for (DevBuf* b : bufs) b->release();
   for (auto& b : level_box) b.release();
   PinBuf* pins[] = {&h_a, &h_b, &h_c, &h_d, &h_e, &h_f, &h_g, &h_h, &p_in, &p_out};

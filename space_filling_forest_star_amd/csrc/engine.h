@@ -78,6 +78,12 @@ struct Ctx {
   DevBuf env_tri, env_box, env_plane, level_box[SFFK_MAX_LEVELS], rob_tri, env_clear, env_ext;
   std::vector<double> h_plane, h_rob;   // host copies (robot extents along the triangle normals)
   void build_robot_extents();
+  // RCCL communicator of the library's own (multi-GPU device engine; librccl is bound at run time)
+  void* rccl_comm = nullptr;
+  int rccl_rank = 0, rccl_world = 1;
+  void rccl_init(const uint8_t* id128, int rank, int world);
+  void rccl_all_gather_i32(const void* send, void* recv, size_t words);
+  static void rccl_unique_id(uint8_t* id128);
   sffk::EnvView envv{};
   sffk::RobotView robv{};
   bool have_env = false, have_robot = false;
@@ -256,6 +262,8 @@ struct Forest {
   void dev_enqueue_end(int slot = 0);
   int dev_finish_wave(double* wait_ms, int slot = 0, bool stream_idle = true);
   void dev_enqueue_wave(int slot);
+  DevBuf x_send, x_recv;   // answer records of a round: this rank's, all ranks' (native RCCL exchange)
+  bool need_host_exchange = false;   // run(): a sharded wave has to be finished through round_begin / round_commit
   bool dev_wave_begin();
   size_t dev_exchange_bytes() const;
   void run_device(int max_waves);

@@ -284,7 +284,7 @@ Forest::~Forest() {
                     &dev.claim, &dev.slot_node, &dev.slot_fail, &dev.act_slot, &dev.b_n1, &dev.b_n2, &dev.b_ta, &dev.b_tb,
                     &dev.b_dist, &dev.bt_key, &dev.bt_val, &dev.pair, &dev.ring, &dev.ustate, &dev.ulist, &dev.uacc,
                     &dev.d_parent, &dev.d_force, &dev.fault_pending, &dev.frontier2, &dev.rm_words, &dev.rm_pref,
-                    &dev.slot_pos, &dev.act_slot2, &dev.dk, &dev.w_dep, &dev.w_acc, &dev.w_ev, &dev.acc_pref, &dev.w_cnt, &dev.dep_rec};
+                    &dev.slot_pos, &dev.act_slot2, &dev.dk, &dev.w_dep, &dev.w_acc, &dev.w_ev, &dev.acc_pref, &dev.w_cnt, &dev.dep_rec, &x_send, &x_recv};
   if (dev.inited) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
@@ -1285,7 +1285,12 @@ void Forest::round_commit(const int32_t* all, int total_words, const int32_t* co
 }
 
 void Forest::run(int max_waves) {
-  if (cfg.world != 1) throw HipError{"forest: run() drives a single-GPU forest; use round_begin/round_commit"};
+  if (cfg.world != 1) {
+    // the library's own RCCL exchange (sffgpu_ctx_rccl_init) drives a sharded device-engine forest by itself
+    if (!(dev.on && ctx->rccl_comm && ctx->rccl_world == cfg.world && ctx->rccl_rank == cfg.rank))
+      throw HipError{"forest: run() drives a single-GPU forest, or a device-engine forest on a context with an RCCL "
+                     "communicator of the same rank / world; otherwise use round_begin/round_commit"};
+  }
   if (dev.on) { run_device(max_waves); return; }
   auto t0 = Clock::now();
   const uint64_t w0 = st.waves;

@@ -609,9 +609,19 @@ void Forest::dev_enqueue_end(int slot) {
 // one whole wave: begin, ThresholdMisses rounds (the device skips what it does not need), end + status copy
 void Forest::dev_enqueue_wave(int slot) {
   dev_enqueue_begin();
+  // (SFFGPU_TEST_EXCHANGE_SELF: a one-rank forest packs, all-gathers and unpacks too - the collective on one GPU)
+  const bool self_exchange = getenv("SFFGPU_TEST_EXCHANGE_SELF") != nullptr;
+  const bool sharded = cfg.world > 1 || (self_exchange && ctx->rccl_comm != nullptr);
+  size_t words = 0;
+  if (sharded) {   // this rank's answer records of a round -> all ranks' (ncclAllGather between device buffers)
+    words = dev_exchange_bytes() / 4;
+    x_send.ensure(words * 4);
+    x_recv.ensure(words * 4 * (size_t)cfg.world);
+  }
   for (int r = 0; r < std::max(1, cfg.threshold_misses); ++r) {
-    dev_enqueue_round_eval(nullptr);
-    dev_enqueue_round_commit(nullptr);
+    dev_enqueue_round_eval(sharded ? x_send.p : nullptr);
+    if (sharded) ctx->rccl_all_gather_i32(x_send.p, x_recv.p, words);
+    dev_enqueue_round_commit(sharded ? x_recv.p : nullptr);
   }
   dev_enqueue_end(slot);
   dev.host_stale = true;
@@ -691,6 +701,7 @@ void Forest::run_device(int max_waves) {
   double wait_ms = 0;
   if (!d.active) dev_upload_state();
   const uint64_t w0 = d.last.waves;
+  need_host_exchange = false;
   // One wave is kept enqueued AHEAD of the one the host waits for: the status round trip (device -> pinned host ->
   // wake-up -> some thirty launches) otherwise leaves the GPU idle for ~40 us per wave.  Everything the device does is
   // self-guarding - after termination or a fault every kernel of the wave behind returns at once - so the wave ahead
@@ -738,6 +749,12 @@ void Forest::run_device(int max_waves) {
       continue;
     } else {
       started = 0;
+    }
+    if (fault == SFFK_FAULT_LISTS && cfg.world > 1) {
+      // sharded forest: the host protocol of that wave needs the caller's variable-size record exchange
+      dev_to_host();
+      need_host_exchange = true;
+      break;
     }
     if (fault == SFFK_FAULT_LISTS) {
       // a bounded device list overflowed: finish this wave on the host path, then come back

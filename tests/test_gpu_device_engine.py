@@ -140,6 +140,25 @@ def test_survivor_list_overflow_scans_the_slot_table(S, ctx):
     assert_same_forest(fo, fg)
 
 
+def test_library_driven_rccl_exchange_on_one_rank(S):
+    """the library's own RCCL communicator (sffgpu_ctx_rccl_init): with the self-exchange knob a one-rank forest packs
+    its answer records, all-gathers them with ncclAllGather on the library's stream and unpacks them in every round,
+    whole waves enqueued by the library - the forest must not change"""
+    import space_filling_forest_star_amd._lib as L
+    c2 = S.Context(0)
+    try:
+        c2.rccl_init(L.rccl_unique_id(), 0, 1)
+        fo, fg = make(S, c2, "dense3d", 1024, 60000, seed=8, SFFGPU_TEST_EXCHANGE_SELF=1)
+        with engine(SFFGPU_TEST_EXCHANGE_SELF=1):
+            fo.run()
+            assert fg.run() is None
+        assert fo.stats()["n_nodes"] > 2000
+        assert_same_forest(fo, fg)
+        fg.close()
+    finally:
+        c2.close()
+
+
 def test_arrays_and_border_table_grow_on_demand(S, ctx):
     """no node budget: the store starts at 4096 nodes and has to grow; many borders: the border list and its hash
     table start small (test knob) and have to grow too"""
