@@ -1708,13 +1708,19 @@ __device__ __forceinline__ void qc_overflow(const GridView& g, int no, int lane,
   }
 }
 
+#ifndef QC_U
+#define QC_U 4      // clearance lookups of the fused cull in flight per step (8: 79 VGPRs, 4: 59)
+#endif
+#define QC_SURV 32  // survivors of a sample gathered in LDS before they are appended (one atomic)
 #ifndef QC_OCC
-#define QC_OCC 5   // wavefronts per SIMD the register allocation aims at (measured: 4 -> 45.5 us, 5 -> 42.0, 6 -> 47.4, 8 -> 67.7)
+#define QC_OCC 7   // wavefronts per SIMD the register allocation aims at (59 VGPRs).  Measured 5 ... 8: 42 / 40.3 / 39.3 / 40.9 us -
+                    // beyond five resident waves the kernel is bound by the memory system's rate of scattered 64-byte
+                    // accesses (~1.2 TB/s of sector traffic), not by latency
 #endif
 __global__ __launch_bounds__(64 * QC_WAVES) __attribute__((amdgpu_waves_per_eu(QC_OCC))) void k_query_classify(GridView g, GridView tg, NodeStoreView st,
                                                                   const SweepQuery* __restrict__ queries, ClassifyArgs A,
                                                                   EnvView env, int fused_cull) {
-  __shared__ SurvivorItem s_surv[QC_WAVES][64];   // fused cull: the sample's items for the exact kernel
+  __shared__ SurvivorItem s_surv[QC_WAVES][QC_SURV];   // fused cull: the sample's items for the exact kernel
   __shared__ int32_t s_id[QC_WAVES][64];
   __shared__ int32_t s_tree[QC_WAVES][64];
   __shared__ double s_d[QC_WAVES][64];
@@ -1938,12 +1944,12 @@ __global__ __launch_bounds__(64 * QC_WAVES) __attribute__((amdgpu_waves_per_eu(Q
       const int P = C0 + (nnb > 0 ? __shfl(incl, nnb - 1) : 0);
       const float* T = reinterpret_cast<const float*>(s_pos[wave]);
       const float nxd = (float)env.clear_n[0], nyd = (float)env.clear_n[1], nzd = (float)env.clear_n[2];
-      for (int p0 = 0; p0 < P; p0 += 8) {
-        const uint32_t* wp[8];
-        int sh[8], ts[8], cs[8];
-        bool need[8];
+      for (int p0 = 0; p0 < P; p0 += QC_U) {
+        const uint32_t* wp[QC_U];
+        int sh[QC_U], ts[QC_U], cs[QC_U];
+        bool need[QC_U];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < QC_U; ++u) {
           const int p = p0 + u;
           wp[u] = nullptr; sh[u] = 0; ts[u] = 0; cs[u] = 0; need[u] = false;
           if (p >= P) continue;   // (uniform)
@@ -1975,17 +1981,17 @@ __global__ __launch_bounds__(64 * QC_WAVES) __attribute__((amdgpu_waves_per_eu(Q
             }
           }
         }
-        uint32_t word[8];
+        uint32_t word[QC_U];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) word[u] = wp[u] ? *wp[u] : 0u;
+        for (int u = 0; u < QC_U; ++u) word[u] = wp[u] ? *wp[u] : 0u;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
+        for (int u = 0; u < QC_U; ++u) {
           if (p0 + u >= P) break;
           if (wp[u] && ((word[u] >> sh[u]) & 1u)) need[u] = false;
           const unsigned long long nm = __ballot(need[u]);
           if (nm) {
             if (lane == 0) buf[n_buf] = SurvivorItem{(int32_t)(i * stride + ts[u]), cs[u], nm};
-            if (++n_buf == 64) flush();
+            if (++n_buf == QC_SURV) flush();
           }
         }
       }
