@@ -478,7 +478,9 @@ void Ctx::build_clearance() {
       }
       // the neighbour-query kernel places edge samples in fp32 cell units (k_query_classify): three roundings of
       // at most 2^-24 * cells-per-axis each; the bits cover 1e-6 * cells-per-axis cells of misplacement
-      if (pass == 0) thr += 1e-6 * (nmax + 2) * h;
+      // ... and tests ONE sample for a group of eight consecutive ones: they lie within four sample spacings
+      // (4 x 0.1 scaled units, src/problemStruct.h:121) of it, so the bits hold that reach on top
+      if (pass == 0) thr += 1e-6 * (nmax + 2) * h + 0.4 * (1 + 1e-6);
     }
     if (cells <= cap) break;
     h *= std::max(1.02, std::cbrt(cells / cap));

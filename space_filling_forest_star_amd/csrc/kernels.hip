@@ -1708,10 +1708,8 @@ __device__ __forceinline__ void qc_overflow(const GridView& g, int no, int lane,
   }
 }
 
-#ifndef QC_U
-#define QC_U 4      // clearance lookups of the fused cull in flight per step (8: 79 VGPRs, 4: 59)
-#endif
 #define QC_SURV 32  // survivors of a sample gathered in LDS before they are appended (one atomic)
+#define QC_TAB 128  // (task, chunk) pairs of a sample unfolded at a time
 #ifndef QC_OCC
 #define QC_OCC 7   // wavefronts per SIMD the register allocation aims at (59 VGPRs).  Measured 5 ... 8: 42 / 40.3 / 39.3 / 40.9 us -
                     // beyond five resident waves the kernel is bound by the memory system's rate of scattered 64-byte
@@ -1721,6 +1719,7 @@ __global__ __launch_bounds__(64 * QC_WAVES) __attribute__((amdgpu_waves_per_eu(Q
                                                                   const SweepQuery* __restrict__ queries, ClassifyArgs A,
                                                                   EnvView env, int fused_cull) {
   __shared__ SurvivorItem s_surv[QC_WAVES][QC_SURV];   // fused cull: the sample's items for the exact kernel
+  __shared__ int32_t s_tab[QC_WAVES][QC_TAB];           // fused cull: (task, chunk) of a window of pairs
   __shared__ int32_t s_id[QC_WAVES][64];
   __shared__ int32_t s_tree[QC_WAVES][64];
   __shared__ double s_d[QC_WAVES][64];
@@ -1943,55 +1942,66 @@ __global__ __launch_bounds__(64 * QC_WAVES) __attribute__((amdgpu_waves_per_eu(Q
       const int excl = incl - my_nch;
       const int P = C0 + (nnb > 0 ? __shfl(incl, nnb - 1) : 0);
       const float* T = reinterpret_cast<const float*>(s_pos[wave]);
+      const int32_t* NS = s_id[wave];
+      int32_t* tab = s_tab[wave];
       const float nxd = (float)env.clear_n[0], nyd = (float)env.clear_n[1], nzd = (float)env.clear_n[2];
-      for (int p0 = 0; p0 < P; p0 += QC_U) {
-        const uint32_t* wp[QC_U];
-        int sh[QC_U], ts[QC_U], cs[QC_U];
-        bool need[QC_U];
-#pragma unroll
-        for (int u = 0; u < QC_U; ++u) {
-          const int p = p0 + u;
-          wp[u] = nullptr; sh[u] = 0; ts[u] = 0; cs[u] = 0; need[u] = false;
-          if (p >= P) continue;   // (uniform)
-          int c, ns;
-          float a0, a1, a2, d0, d1, d2;
-          if (p < C0) {
-            c = p; ns = ns0;
-            a0 = g0[0]; a1 = g0[1]; a2 = g0[2]; d0 = st0[0]; d1 = st0[1]; d2 = st0[2];
-          } else {
-            const int pp = p - C0;
-            const int r = __builtin_amdgcn_readfirstlane(__popcll(__ballot(lane < nnb && incl <= pp)));   // the edge pair pp belongs to
-            ts[u] = 1 + r;
-            c = pp - __shfl(excl, r);
-            ns = __shfl(my_ns, r);
-            a0 = T[8 * r]; a1 = T[8 * r + 1]; a2 = T[8 * r + 2]; d0 = T[8 * r + 4]; d1 = T[8 * r + 5]; d2 = T[8 * r + 6];
+      // Eight consecutive samples of an edge lie within 0.4 units of the fifth one (the sample spacing never exceeds
+      // the 0.1 of src/problemStruct.h:121), and the bits are built with that reach on top (Ctx::build_clearance): ONE
+      // lookup answers a group of eight samples, a lane takes a group, a step of the wave eight (task, chunk) pairs.
+      // A group that is not clear goes to the exact kernel whole.  tab[]: pair -> (task << 16 | chunk), built in
+      // windows of QC_TAB pairs.
+      const int pu = lane >> 3, g = lane & 7;
+      for (int w0 = 0; w0 < P; w0 += QC_TAB) {
+        __builtin_amdgcn_wave_barrier();
+        for (int c = lane; c < C0; c += 64)
+          if (c >= w0 && c < w0 + QC_TAB) tab[c - w0] = c;                                      // the parent edge: task 0
+        if (lane < nnb)
+          for (int c = 0; c < my_nch; ++c) {
+            const int p = C0 + excl + c;
+            if (p >= w0 && p < w0 + QC_TAB) tab[p - w0] = ((1 + lane) << 16) | (c & 0xffff);
           }
-          cs[u] = c;
-          const int idx = 1 + 64 * c + lane;
-          const float td = (float)idx;
-          need[u] = idx <= ns;
-          if (env.clear_bits) {
+        __builtin_amdgcn_wave_barrier();
+        const int wn = P - w0 < QC_TAB ? P - w0 : QC_TAB;
+        for (int q0 = 0; q0 < wn; q0 += 8) {
+          const bool valid = q0 + pu < wn;
+          const int ent = valid ? tab[q0 + pu] : 0;
+          const int t = ent >> 16, c = ent & 0xffff;
+          float a0 = g0[0], a1 = g0[1], a2 = g0[2], d0 = st0[0], d1 = st0[1], d2 = st0[2];
+          int ns = ns0;
+          if (t > 0) {
+            const float* tt = T + 8 * (t - 1);
+            a0 = tt[0]; a1 = tt[1]; a2 = tt[2]; d0 = tt[4]; d1 = tt[5]; d2 = tt[6];
+            ns = NS[t - 1];
+          }
+          const int first = 1 + 64 * c + 8 * g;                 // the group's first sample
+          bool need = valid && first <= ns;
+          const int left = ns - first + 1;                      // valid samples from there on
+          const int probe = first + 4 <= ns ? first + 4 : ns;   // within four steps of every valid sample of the group
+          const uint32_t* wp = nullptr;
+          int sh = 0;
+          if (need && env.clear_bits) {
+            const float td = (float)probe;
             const float fx = __builtin_fmaf(td, d0, a0), fy = __builtin_fmaf(td, d1, a1), fz = __builtin_fmaf(td, d2, a2);
             if (fx >= 0 && fy >= 0 && fz >= 0 && fx < nxd && fy < nyd && fz < nzd) {   // (the grid has fewer than 2^31 cells)
               const uint32_t ci = ((uint32_t)(int)fz * (uint32_t)env.clear_n[1] + (uint32_t)(int)fy) * (uint32_t)env.clear_n[0] + (uint32_t)(int)fx;
-              if (need[u]) wp[u] = env.clear_bits + (ci >> 5);
-              sh[u] = (int)(ci & 31u);
+              wp = env.clear_bits + (ci >> 5);
+              sh = (int)(ci & 31u);
             } else if (fx == fx && fy == fy && fz == fz) {
-              need[u] = false;                        // beyond the inflated box of the environment
+              need = false;                                     // beyond the inflated box of the environment
             }
           }
-        }
-        uint32_t word[QC_U];
-#pragma unroll
-        for (int u = 0; u < QC_U; ++u) word[u] = wp[u] ? *wp[u] : 0u;
-#pragma unroll
-        for (int u = 0; u < QC_U; ++u) {
-          if (p0 + u >= P) break;
-          if (wp[u] && ((word[u] >> sh[u]) & 1u)) need[u] = false;
-          const unsigned long long nm = __ballot(need[u]);
-          if (nm) {
-            if (lane == 0) buf[n_buf] = SurvivorItem{(int32_t)(i * stride + ts[u]), cs[u], nm};
-            if (++n_buf == QC_SURV) flush();
+          const uint32_t word = wp ? *wp : 0u;
+          if (wp && ((word >> sh) & 1u)) need = false;
+          unsigned long long m = need ? (((left >= 8 ? 0xffULL : ((1ULL << left) - 1ULL))) << (8 * g)) : 0ULL;
+          m |= __shfl_xor(m, 1);
+          m |= __shfl_xor(m, 2);
+          m |= __shfl_xor(m, 4);
+          const bool lead = g == 0 && m != 0ULL;
+          const unsigned long long lm = __ballot(lead);
+          if (lm) {
+            if (lead) buf[n_buf + __popcll(lm & ((1ULL << lane) - 1ULL))] = SurvivorItem{(int32_t)(i * stride + t), c, m};
+            n_buf += __popcll(lm);
+            if (n_buf > QC_SURV - 8) flush();
           }
         }
       }
