@@ -1762,6 +1762,8 @@ __global__ __launch_bounds__(64 * QC_WAVES) __attribute__((amdgpu_waves_per_eu(Q
   for (int k = 0; k < 6; ++k) exp[k] = uni_d(A.pos[6 * (size_t)ex + k]);
   int flags = 0, nnb = 0;
   int used_slots = 0;                     // edge-task slots this sample fills (the others are cleared at the end)
+  const double parts0 = edge_parts(exp, qp);   // the parent edge (task slot 0), used by the task write and by the cull
+  const int ns0 = edge_samples(parts0);
   const bool mine_shard = A.world <= 1 || i % A.world == A.rank;
   if (inl && mine_shard) {
     flags |= 1;
@@ -1777,11 +1779,22 @@ __global__ __launch_bounds__(64 * QC_WAVES) __attribute__((amdgpu_waves_per_eu(Q
     const int lz = grid_coord(Q.z - rf, g.oz, g.inv_cell, g.nz), hz = grid_coord(Q.z + rf, g.oz, g.inv_cell, g.nz);
     const int wx = hx - lx + 1, wy = hy - ly + 1, wz = hz - lz + 1;
     const int total = wx * wy * wz;
+    const float rwx = __frcp_rn((float)wx), rwy = __frcp_rn((float)wy);
     for (int c0 = 0; c0 < total; c0 += 64) {
       const int c = c0 + lane;
       int cell = 0, m = 0, mt = 0;
       if (c < total) {
-        const int cx = lx + c % wx, cy = ly + (c / wx) % wy, cz = lz + c / (wx * wy);
+        // (c, wx, wy < 2^11 here: (c + 0.5) / w is at least 0.5 / w away from an integer, so the fp32 quotient
+        // truncates to the exact one - three integer divisions are ~90 instructions)
+        int q1, q2;
+        if (total <= 2048) {
+          q1 = (int)(((float)c + 0.5f) * rwx);
+          q2 = (int)(((float)q1 + 0.5f) * rwy);
+        } else {
+          q1 = c / wx;
+          q2 = q1 / wy;
+        }
+        const int cx = lx + (c - q1 * wx), cy = ly + (q1 - q2 * wy), cz = lz + q2;
         cell = (cz * g.ny + cy) * g.nx + cx;
         m = g.cnt[cell];
         if (m > g.bk) m = g.bk;
@@ -1848,11 +1861,11 @@ __global__ __launch_bounds__(64 * QC_WAVES) __attribute__((amdgpu_waves_per_eu(Q
             // the hit list is dead from here on (every lane holds its own hit in registers): the kept edges' start
             // points, sample steps and sample counts take its place, indexed by rank
             // (in cells of the clearance grid, fp32: see the fused cull below)
-            const double inv = env.clear_inv / parts;
+            const float inv = (float)env.clear_inv * __frcp_rn((float)parts);
             float* tf = reinterpret_cast<float*>(h_pos);
             for (int k = 0; k < 3; ++k) {
               tf[8 * rank + k] = (float)((ea[k] - env.clear_org[k]) * env.clear_inv);
-              tf[8 * rank + 4 + k] = (float)((eb[k] - ea[k]) * inv);
+              tf[8 * rank + 4 + k] = (float)(eb[k] - ea[k]) * inv;
             }
             h_id[rank] = ns;
           }
@@ -1862,9 +1875,7 @@ __global__ __launch_bounds__(64 * QC_WAVES) __attribute__((amdgpu_waves_per_eu(Q
           double* sa = A.seg_a + 6 * slot;
           double* sb = A.seg_b + 6 * slot;
           for (int k = 0; k < 6; ++k) { sa[k] = exp[k]; sb[k] = qp[k]; }
-          const double parts = edge_parts(exp, qp);
-          const int ns = edge_samples(parts);
-          A.seg_ns[slot] = ns;
+          A.seg_ns[slot] = ns0;
           A.first_hit[slot] = 0x7fffffff;
           A.seg_ovf[slot] = 0;
         }
@@ -1925,12 +1936,12 @@ __global__ __launch_bounds__(64 * QC_WAVES) __attribute__((amdgpu_waves_per_eu(Q
       // lane r < nnb = the kept edge of rank r; the parent edge (task 0) is uniform.  Positions in cells of the
       // clearance grid, in fp32: cell = a + idx * step is off the exact kernel's fp64 sample position by less than
       // 1e-6 * (cells per axis) cells - the slack Ctx::build_clearance puts into the bits for exactly this
-      const double parts0 = edge_parts(exp, qp);
-      const int ns0 = edge_samples(parts0);
-      const double inv0 = env.clear_inv / parts0;
+      // (steps in fp32 with the hardware reciprocal: a relative 1e-7 on a step that spans a few cells is far inside
+      // the slack of the bits)
+      const float inv0 = (float)env.clear_inv * __frcp_rn((float)parts0);
       const float g0[3] = {(float)((exp[0] - env.clear_org[0]) * env.clear_inv), (float)((exp[1] - env.clear_org[1]) * env.clear_inv),
                            (float)((exp[2] - env.clear_org[2]) * env.clear_inv)};
-      const float st0[3] = {(float)((qp[0] - exp[0]) * inv0), (float)((qp[1] - exp[1]) * inv0), (float)((qp[2] - exp[2]) * inv0)};
+      const float st0[3] = {(float)(qp[0] - exp[0]) * inv0, (float)(qp[1] - exp[1]) * inv0, (float)(qp[2] - exp[2]) * inv0};
       const int C0 = ns0 > 0 ? (ns0 + 63) >> 6 : 0;
       const int my_ns = lane < nnb ? s_id[wave][lane] : 0;
       const int my_nch = my_ns > 0 ? (my_ns + 63) >> 6 : 0;
