@@ -1784,10 +1784,11 @@ __global__ __launch_bounds__(64 * QC_WAVES) __attribute__((amdgpu_waves_per_eu(Q
       const int c = c0 + lane;
       int cell = 0, m = 0, mt = 0;
       if (c < total) {
-        // (c, wx, wy < 2^11 here: (c + 0.5) / w is at least 0.5 / w away from an integer, so the fp32 quotient
-        // truncates to the exact one - three integer divisions are ~90 instructions)
+        // (c, wx, wy <= 512 here: (c + 0.5) / w is at least 0.5 / w ~ 1e-3 away from an integer and the fp32 product
+        // is off by less than 1e-4, so it truncates to the exact quotient - three integer divisions are ~90
+        // instructions)
         int q1, q2;
-        if (total <= 2048) {
+        if (total <= 512) {
           q1 = (int)(((float)c + 0.5f) * rwx);
           q2 = (int)(((float)q1 + 0.5f) * rwy);
         } else {
