@@ -268,7 +268,7 @@ def main():
                 # Algorithmic bytes = 24 B x nodes the query has to cover.
                 "bound": "hbm", "kernel": "sffk::k_query_classify (node grid + the round's own grid + hit classification; "
                                           "since r2 the same launch also looks up the clearance bits of the sample's pose "
-                                          "and edge chunks - about a third of its time, DESIGN.md 5)",
+                                          "and edge samples - about an eighth of its time, DESIGN.md 5)",
                 "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                 "traffic": traffic, "traffic_source": traffic_source,
                 "launches": int(sweeps), "avg_launch_us": 1e3 * sweep_ms / max(1, sweeps),
