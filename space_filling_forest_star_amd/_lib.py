@@ -651,19 +651,31 @@ def _native_rccl(forest, group):
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     if getattr(forest.ctx, "rccl", None) == (rank, world):
         return True
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    def agreed(ok):   # every rank takes the same path
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        return bool(flag.item())
+
+    # 1. can every rank bind librccl at all?  (decided BEFORE anybody enters the communicator's collective set-up: a
+    #    rank that cannot would leave the others waiting in ncclCommInitRank)
     try:
-        dev = torch.device("cuda", torch.cuda.current_device())
-        ident = torch.zeros(128, dtype=torch.uint8, device=dev)
-        if rank == 0:
-            ident = torch.tensor(list(rccl_unique_id()), dtype=torch.uint8, device=dev)
+        mine = rccl_unique_id()
+        bound = True
+    except Exception:
+        mine, bound = bytes(128), False
+    if not agreed(bound):
+        return False
+    # 2. rank 0's id travels in a broadcast, every rank joins
+    try:
+        ident = torch.tensor(list(mine), dtype=torch.uint8, device=dev)
         dist.broadcast(ident, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
         forest.ctx.rccl_init(bytes(ident.cpu().tolist()), rank, world)
-        ok = 1
+        ok = True
     except Exception:
-        ok = 0
-    flag = torch.tensor([ok], dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)      # every rank takes the same path
-    return bool(flag.item())
+        ok = False
+    return agreed(ok)
 
 
 def _run_distributed_native(forest, max_waves, group):
