@@ -133,6 +133,12 @@ typedef struct {
   double query_clock_ms;     /* device-resident engine: neighbour-query kernel time of ALL rounds, bracketed on the device
                                 (first wavefront in .. last wavefront out, wall_clock64) - what rocprofv3 reports */
   uint64_t query_clock_launches;
+  uint64_t mate_overflow_requeries; /* SFF* host engine: k-nearest queries asked again with a round-sized mate list */
+  uint64_t star_rounds;      /* SFF* device engine: rounds whose choose-parent / rewire step ran on the device ... */
+  uint64_t star_passes;      /* ... fixed-point passes those rounds took in all (>= 1 each) ... */
+  uint64_t star_members;     /* ... k-nearest members (choose-parent / rewire candidates) they looked at */
+  uint64_t star_rewires;     /* ... and rewires they applied (src/forest.h:336-348) */
+  uint64_t host_fallback_waves; /* device engine: waves finished on the host-replay engine after a device list overflowed */
 } sffgpu_forest_stats;
 
 int sffgpu_forest_create(sffgpu_ctx* ctx, const sffgpu_forest_cfg* cfg, const double* roots6, int n_roots,

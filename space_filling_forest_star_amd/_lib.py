@@ -2,6 +2,7 @@
 Context ~ Environment (+ the FLANN indices), Forest ~ SpaceForest (src/forest.h:31-54)."""
 import ctypes as C
 import os
+import sys
 import subprocess
 
 import numpy as np
@@ -51,7 +52,9 @@ class ForestStats(C.Structure):
                 ("sweep_nodes", C.c_uint64), ("sweep_queries", C.c_uint64), ("slow_path_samples", C.c_uint64), ("grid_rebuilds", C.c_uint64),
                 ("sweep_ms", C.c_double),
                 ("collide_ms", C.c_double), ("sample_ms", C.c_double), ("host_ms", C.c_double),
-                ("total_ms", C.c_double), ("query_clock_ms", C.c_double), ("query_clock_launches", C.c_uint64)]
+                ("total_ms", C.c_double), ("query_clock_ms", C.c_double), ("query_clock_launches", C.c_uint64),
+                ("mate_overflow_requeries", C.c_uint64), ("star_rounds", C.c_uint64), ("star_passes", C.c_uint64),
+                ("star_members", C.c_uint64), ("star_rewires", C.c_uint64), ("host_fallback_waves", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -646,7 +649,10 @@ def _native_rccl(forest, group):
     library then drives the waves - kernels and ncclAllGather - by itself (no per-round Python)."""
     import torch
     import torch.distributed as dist
-    if os.environ.get("SFFGPU_NO_NATIVE_RCCL") or dist.get_backend(group) != "nccl":
+    # Opt-in (SFFGPU_NATIVE_RCCL=1): the library-driven exchange keeps a wave enqueued ahead and issues ncclAllGather by
+    # itself; it has only ever run with ONE rank (this pool has single-GPU boxes), so the default stays the path the
+    # multi-process tests cover (_run_distributed_device: torch.distributed's collective on the library's stream).
+    if os.environ.get("SFFGPU_NATIVE_RCCL", "0") in ("", "0") or dist.get_backend(group) != "nccl":
         return False
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     if getattr(forest.ctx, "rccl", None) == (rank, world):
@@ -663,7 +669,8 @@ def _native_rccl(forest, group):
     try:
         mine = rccl_unique_id()
         bound = True
-    except Exception:
+    except Exception as e:   # (falls back to the torch.distributed exchange: say why)
+        print("sffgpu: librccl cannot be bound on rank %d (%s); using the torch.distributed exchange" % (rank, e), file=sys.stderr)
         mine, bound = bytes(128), False
     if not agreed(bound):
         return False
@@ -671,9 +678,12 @@ def _native_rccl(forest, group):
     try:
         ident = torch.tensor(list(mine), dtype=torch.uint8, device=dev)
         dist.broadcast(ident, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        # (a rank that fails INSIDE ncclCommInitRank leaves its peers waiting there: that failure is fatal for the job,
+        # which is why step 1 weeds out everything that can be known beforehand)
         forest.ctx.rccl_init(bytes(ident.cpu().tolist()), rank, world)
         ok = True
-    except Exception:
+    except Exception as e:
+        print("sffgpu: RCCL communicator set-up failed on rank %d (%s); using the torch.distributed exchange" % (rank, e), file=sys.stderr)
         ok = False
     return agreed(ok)
 

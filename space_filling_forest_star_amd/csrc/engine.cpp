@@ -218,9 +218,11 @@ void Ctx::rccl_all_gather_i32(const void* send, void* recv, size_t words) {
 
 Ctx::~Ctx() {
   (void)hipSetDevice(device);
-  if (rccl_comm && rccl().CommDestroy) { (void)rccl().CommDestroy(rccl_comm); rccl_comm = nullptr; }
+  // (the streams may still carry all-gathers of the communicator: drain them before it goes)
   if (stream) (void)hipStreamSynchronize(stream);
+  if (own_stream && own_stream != stream) (void)hipStreamSynchronize(own_stream);
   if (copy_stream) (void)hipStreamSynchronize(copy_stream);
+  if (rccl_comm && rccl().CommDestroy) { (void)rccl().CommDestroy(rccl_comm); rccl_comm = nullptr; }
   if (ev_mid) (void)hipEventDestroy(ev_mid);
   if (ev_early) (void)hipEventDestroy(ev_early);
   for (auto& t : pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }

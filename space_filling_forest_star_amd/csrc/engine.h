@@ -234,7 +234,8 @@ struct DevEngine {
   DevBuf frontier2, rm_words, rm_pref, slot_pos, act_slot2, dk, w_dep, w_acc, w_ev, acc_pref, w_cnt, dep_rec;
   DevBuf ctrl, parent, d_root, d_closest, iter, nflag, frontier, closed, claim, slot_node, slot_fail, act_slot, b_n1,
       b_n2, b_ta, b_tb, b_dist, bt_key, bt_val, pair, ring, ustate, ulist, uacc, d_parent, d_force, fault_pending;
-  PinBuf h_ctrl, h_ring;
+  PinBuf h_ctrl, h_ring, h_trig;
+  DevBuf trig;   // libm parity mode: the C library's cos / sin / acos of every ring word (3 doubles per word)
   hipEvent_t ev_ring = nullptr, ev_wave = nullptr, ev_wave2 = nullptr;   // (two status slots: one wave may be enqueued ahead)
   int node_cap = 0, border_cap = 0, temp_base = 0;
   uint64_t bt_size = 0, ring_words = 0, max_wave_words = 0;

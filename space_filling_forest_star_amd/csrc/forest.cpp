@@ -115,7 +115,7 @@ Forest::Forest(Ctx* c, const sffgpu_forest_cfg& cf, const double* roots6, int n_
       // the host replay below otherwise (SFF*, goal / priority modes, sharded runs, tiny waves)
     const char* e = getenv("SFFGPU_ENGINE");
     const std::string want = e ? e : "";
-    dev.on = device_eligible() && !cfg.libm_sampling && want != "host" && (cfg.wave >= 256 || want == "device") &&
+    dev.on = device_eligible() && want != "host" && (cfg.wave >= 256 || want == "device") &&
              cfg.wave <= 64 * SFFK_DEV_MAX_GROUPS;
   }
   // (device engine: a wave of new nodes past the budget plus the round's temporaries behind them)
@@ -284,7 +284,7 @@ Forest::~Forest() {
                     &dev.claim, &dev.slot_node, &dev.slot_fail, &dev.act_slot, &dev.b_n1, &dev.b_n2, &dev.b_ta, &dev.b_tb,
                     &dev.b_dist, &dev.bt_key, &dev.bt_val, &dev.pair, &dev.ring, &dev.ustate, &dev.ulist, &dev.uacc,
                     &dev.d_parent, &dev.d_force, &dev.fault_pending, &dev.frontier2, &dev.rm_words, &dev.rm_pref,
-                    &dev.slot_pos, &dev.act_slot2, &dev.dk, &dev.w_dep, &dev.w_acc, &dev.w_ev, &dev.acc_pref, &dev.w_cnt, &dev.dep_rec, &x_send, &x_recv};
+                    &dev.slot_pos, &dev.act_slot2, &dev.dk, &dev.trig, &dev.w_dep, &dev.w_acc, &dev.w_ev, &dev.acc_pref, &dev.w_cnt, &dev.dep_rec, &x_send, &x_recv};
   if (dev.inited) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
@@ -293,6 +293,7 @@ Forest::~Forest() {
   for (DevBuf* b : bufs) b->release();
   dev.h_ctrl.release();
   dev.h_ring.release();
+  dev.h_trig.release();
   if (dev.ev_ring) (void)hipEventDestroy(dev.ev_ring);
   if (dev.ev_wave) (void)hipEventDestroy(dev.ev_wave);
   if (dev.ev_wave2) (void)hipEventDestroy(dev.ev_wave2);
@@ -405,27 +406,18 @@ static const int32_t REC_MAGIC = 0x53464652;  // "SFFR"
 // order, as sffg::sample_point (csrc/sff_geom.h) - which the kernels evaluate with the portable trig - so that the two
 // differ exactly where glibc and sff_pmath.h differ (<= 1 ulp).  Parity mode only (cfg.libm_sampling).
 static void sample_point_libm(const uint64_t* w, const double* center, double dist, int dim, double* out) {
-  const double phi = sffg::uniform_real(w[0], -SFFG_PI, SFFG_PI);
-  if (dim == 2) {
-    out[0] = center[0] + std::cos(phi) * dist;
-    out[1] = center[1] + std::sin(phi) * dist;
-    out[2] = 0; out[3] = 0; out[4] = 0; out[5] = 0;
-    return;
+  sffg::SampleTrig t{};
+  const double phi = sffg::sample_angle(w[0]);
+  t.c_phi = std::cos(phi);
+  t.s_phi = std::sin(phi);
+  if (dim != 2) {
+    const double theta = sffg::sample_angle(w[1]);
+    t.c_theta = std::cos(theta);
+    t.s_theta = std::sin(theta);
+    t.acos_u = std::acos(sffg::sample_acos_arg(w[3]));
   }
-  double temp[6];
-  const double theta = sffg::uniform_real(w[1], -SFFG_PI, SFFG_PI);
-  const double sphi = std::sin(phi);
-  temp[0] = center[0] + std::cos(theta) * sphi * dist;
-  temp[1] = center[1] + std::sin(theta) * sphi * dist;
-  temp[2] = center[2] + std::cos(phi) * dist;
-  temp[3] = sffg::uniform_real(w[2], -SFFG_PI, SFFG_PI);
-  double pitch = std::acos(1 - 2 * sffg::uniform_real(w[3], 0.0, 1.0)) + SFFG_PI_2;
-  if (sffg::uniform_real(w[4], 0.0, 1.0) < 0.5) {
-    if (pitch < 0) pitch += SFFG_PI; else pitch -= SFFG_PI;
-  }
-  temp[4] = pitch;
-  temp[5] = sffg::uniform_real(w[5], -SFFG_PI, SFFG_PI);
-  sffg::steer(center, temp, dist, out);
+  const double nolim[6] = {-1e300, 1e300, -1e300, 1e300, -1e300, 1e300};   // (the kernel applies the limits test)
+  sffg::sample_point_with(w, center, dist, dim, nolim, out, t);
 }
 
 void Forest::round_begin() {
@@ -929,19 +921,56 @@ void Forest::round_begin() {
         const int32_t* r_cnt = reinterpret_cast<const int32_t*>(hres + o_cnt);
         const int32_t* r_mate = reinterpret_cast<const int32_t*>(hres + o_mate);
         const int32_t* r_mcnt = reinterpret_cast<const int32_t*>(hres + o_mcnt);
+        // (a dense young frontier under a large wave can put more than SFFK_KNN_MATES earlier samples of the round inside
+        // one k-nearest ball, and a tree that is wanted whole has no ball at all: those queries are asked again with a
+        // mate list that holds the whole round)
+        std::vector<int> big;
+        for (int k = 0; k < m; ++k)
+          if (kmax[k] > 0 && r_mcnt[k] > SFFK_KNN_MATES) big.push_back(k);
+        std::vector<int32_t> big_mates;
+        if (!big.empty()) {
+          const int mb = (int)big.size(), mcap = n;
+          c.h_e.ensure((size_t)mb * sizeof(sffk::KnnQuery));
+          sffk::KnnQuery* bq = c.h_e.as<sffk::KnnQuery>();
+          for (int j = 0; j < mb; ++j) bq[j] = hq[big[j]];
+          const size_t b_idx = 0, b_cnt = b_idx + (size_t)mb * KCAP * 4, b_mate = b_cnt + (size_t)mb * 4,
+                       b_mcnt = b_mate + (size_t)mb * mcap * 4, b_end = b_mcnt + (size_t)mb * 4;
+          c.d_e.ensure((size_t)mb * sizeof(sffk::KnnQuery));
+          c.d_c.ensure(b_end);
+          c.d_d.ensure((size_t)mb * KCAP * 8);
+          HIPCHK(hipMemcpyAsync(c.d_e.p, c.h_e.p, (size_t)mb * sizeof(sffk::KnnQuery), hipMemcpyHostToDevice, c.stream));
+          char* db = c.d_c.as<char>();
+          sffk::launch_knn_grid(c.stream, c.gridv, &c.tgridv, c.store_view(), c.d_e.as<sffk::KnnQuery>(), mb, KCAP,
+                                reinterpret_cast<int32_t*>(db + b_idx), c.d_d.as<double>(), reinterpret_cast<int32_t*>(db + b_cnt),
+                                reinterpret_cast<int32_t*>(db + b_mate), reinterpret_cast<int32_t*>(db + b_mcnt), c.grid_cell,
+                                8 * c.sweep_eps(), mcap);
+          big_mates.resize((size_t)mb * mcap + mb);
+          HIPCHK(hipMemcpyAsync(big_mates.data(), db + b_mate, ((size_t)mb * mcap + mb) * 4, hipMemcpyDeviceToHost, c.stream));
+          timed_sync();
+          st.mate_overflow_requeries += (uint64_t)mb;
+        }
+        size_t big_at = 0;
         for (int k = 0; k < m; ++k) {
           Cand& cd = cands[maybe[k]];
           if (kmax[k] <= 0) continue;
-          if (r_mcnt[k] > SFFK_KNN_MATES) throw HipError{"forest: more than 64 samples of one round inside a k-nearest ball"};
+          const int32_t* mate_list = r_mate + (size_t)k * SFFK_KNN_MATES;
+          int mate_n = r_mcnt[k];
+          if (mate_n > SFFK_KNN_MATES) {     // the second pass's list (same store neighbours, every mate)
+            const int mb = (int)big.size(), mcap = n;
+            mate_list = big_mates.data() + big_at * mcap;
+            mate_n = big_mates[(size_t)mb * mcap + big_at];
+            if (mate_n != r_mcnt[k] || mate_n > mcap) throw HipError{"forest: k-nearest mate list of the second pass is inconsistent (internal error)"};
+            ++big_at;
+          }
           for (int q = 0; q < r_cnt[k]; ++q) {
             Member mb;
             mb.id = r_idx[(size_t)k * KCAP + q];
             cd.members.push_back(mb);
             cd.has_members = true;
           }
-          for (int q = 0; q < r_mcnt[k]; ++q) {
+          for (int q = 0; q < mate_n; ++q) {
             Member mb;
-            mb.id = -1 - (r_mate[(size_t)k * SFFK_KNN_MATES + q] - Tb);
+            mb.id = -1 - (mate_list[q] - Tb);
             cd.members.push_back(mb);
             cd.has_members = true;
           }

@@ -16,6 +16,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
+#include <vector>
 
 #include "engine.h"
 #include "sff_geom.h"
@@ -152,6 +154,34 @@ void Forest::dev_ring_append(const uint64_t* words, size_t n) {   // words for a
     if (words) memcpy(hr + at, words + done, run * 8);
     else rng.fill(hr + at, run);
     HIPCHK(hipMemcpyAsync(d.ring.as<uint64_t>() + at, hr + at, run * 8, hipMemcpyHostToDevice, c.copy_stream));
+    if (cfg.libm_sampling) {
+      // parity mode: RandGen::randomPointInDistance's transcendental functions (src/randGen.h:78-100) are evaluated
+      // HERE, by the C library the reference itself calls.  Which word of the stream becomes which angle is only known on
+      // the device (frontier picks and samples share the stream), so every word gets all three values it could be asked
+      // for: cos / sin of the word as phi or theta, acos of the word as the pitch draw.
+      double* ht = d.h_trig.as<double>() + 3 * at;
+      const uint64_t* hw = hr + at;
+      const unsigned hw_threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+      const size_t per = (run + hw_threads - 1) / hw_threads;
+      auto work = [&](size_t b, size_t e) {
+        for (size_t j = b; j < e; ++j) {
+          const double ang = sffg::sample_angle(hw[j]);
+          ht[3 * j] = std::cos(ang);
+          ht[3 * j + 1] = std::sin(ang);
+          ht[3 * j + 2] = std::acos(sffg::sample_acos_arg(hw[j]));
+        }
+      };
+      if (run < 4096 || hw_threads == 1) work(0, run);
+      else {
+        std::vector<std::thread> th;
+        for (unsigned t = 0; t < hw_threads; ++t) {
+          const size_t b = std::min(run, t * per), e = std::min(run, b + per);
+          if (b < e) th.emplace_back(work, b, e);
+        }
+        for (auto& x : th) x.join();
+      }
+      HIPCHK(hipMemcpyAsync(d.trig.as<double>() + 3 * at, ht, run * 24, hipMemcpyHostToDevice, c.copy_stream));
+    }
     done += run;
   }
   d.produced += n;
@@ -182,6 +212,10 @@ void Forest::dev_upload_state() {
     d.ring_words = next_pow2(4 * d.max_wave_words);
     d.ring.ensure((size_t)d.ring_words * 8);
     d.h_ring.ensure((size_t)d.ring_words * 8);
+    if (cfg.libm_sampling) {
+      d.trig.ensure((size_t)d.ring_words * 24);
+      d.h_trig.ensure((size_t)d.ring_words * 24);
+    }
     d.ctrl.ensure(sizeof(sffk::DevCtrl));
     d.h_ctrl.ensure(2 * sizeof(sffk::DevCtrl));
     d.slot_node.ensure((size_t)wave * 4);
@@ -538,6 +572,7 @@ void Forest::dev_enqueue_round_eval(void* send_dev) {
   dv.ring = V.ring;
   dv.ring_mask = V.ring_mask;
   dv.words_per = V.words_per;
+  dv.trig = cfg.libm_sampling ? d.trig.as<double>() : nullptr;
   dv.parent_out = d.d_parent.as<int32_t>();
   dv.force_out = d.d_force.as<uint8_t>();
   dv.qclk = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(d.ctrl.p) + offsetof(sffk::DevCtrl, q_t0));

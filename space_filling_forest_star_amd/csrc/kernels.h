@@ -152,6 +152,9 @@ struct DevRound {
   const uint8_t* nflag;        // per node: 1 = ForceChildren, 2 = on the frontier
   const uint64_t* ring;        // engine words (std::mt19937_64 outputs), ring of ring_mask + 1 words
   uint64_t ring_mask;
+  const double* trig;          // libm parity mode: 3 doubles per ring word {cos, sin of the word as an angle in [-pi, pi),
+                               // acos(1 - 2 u) of the word as u in [0, 1)} evaluated by the HOST's C library; null = the
+                               // kernel's own portable trig
   int32_t words_per;           // words per sample: 6 (3-D) / 1 (2-D)
   int32_t* parent_out;         // n: expanded node of every sample (read by k_classify)
   uint8_t* force_out;          // n: its ForceChildren flag
@@ -216,11 +219,11 @@ void launch_knn_linear(hipStream_t s, const NodeStoreView& st, int n_store, cons
                        int32_t* idx, double* dist, int32_t* cnt, double abs_eps);
 // grid variant (forest engines): cubes of cells around the query grow ring by ring until the k-th distance lies
 // inside the covered ball.  Besides the k nearest STORE nodes it reports the round's temporaries (ids in
-// [mate_base, max_id)) that are not farther than the k-th store node: mate_idx nq x SFFK_KNN_MATES, mate_cnt nq
-// (> SFFK_KNN_MATES = overflow).
+// [mate_base, max_id)) that are not farther than the k-th store node: mate_idx nq x mate_cap, mate_cnt nq
+// (> mate_cap = overflow: the caller asks again with a larger list; SFFK_KNN_MATES is the first pass's capacity).
 void launch_knn_grid(hipStream_t s, const GridView& g, const GridView* tg, const NodeStoreView& st, const KnnQuery* q, int nq,
                      int kcap, int32_t* idx, double* dist, int32_t* cnt, int32_t* mate_idx, int32_t* mate_cnt, double cell,
-                     double slack);
+                     double slack, int mate_cap = SFFK_KNN_MATES);
 
 // explicit_rt: pos6 holds n x 12 doubles (row-major rotation + translation) instead of n x 6 pose parameters
 void launch_collide_poses(hipStream_t s, const EnvView& env, const RobotView& rob, const double* pos6, int n,

@@ -70,14 +70,27 @@ __global__ __launch_bounds__(256) void k_sample_steer(const uint64_t* __restrict
   const double* src = center_in ? center_in + 6 * (size_t)i : node_pos + 6 * (size_t)par;
   for (int k = 0; k < 6; ++k) c[k] = src[k];
   uint64_t w[6];
+  SampleTrig host_trig{};
   if (dv.ctrl) {   // the sample's words sit in the engine-word ring, in the reference's draw order
     const unsigned long long base = dv.ctrl->words_base + (unsigned long long)dv.words_per * (unsigned long long)i;
     for (int k = 0; k < 6; ++k) w[k] = k < dv.words_per ? dv.ring[(base + k) & dv.ring_mask] : 0ULL;
+    if (dv.trig) {   // libm parity mode: the transcendental values of these words, evaluated by the host's C library
+      const double* t0 = dv.trig + 3 * (size_t)(base & dv.ring_mask);
+      host_trig.c_phi = t0[0]; host_trig.s_phi = t0[1];
+      if (dv.words_per == 6) {
+        const double* t1 = dv.trig + 3 * (size_t)((base + 1) & dv.ring_mask);
+        const double* t3 = dv.trig + 3 * (size_t)((base + 3) & dv.ring_mask);
+        host_trig.c_theta = t1[0]; host_trig.s_theta = t1[1];
+        host_trig.acos_u = t3[2];
+      }
+    }
   } else {
     for (int k = 0; k < 6; ++k) w[k] = words[6 * (size_t)i + k];
   }
   bool ok;
-  if (tmp.preset) {
+  if (dv.ctrl && dv.trig) {
+    ok = sample_point_with(w, c, dist, dim, prm.limits, o, host_trig);
+  } else if (tmp.preset) {
     for (int k = 0; k < 6; ++k) o[k] = tmp.preset[6 * (size_t)i + k];
     ok = in_limits(o, prm.limits);
   } else {
@@ -375,7 +388,7 @@ __global__ __launch_bounds__(256) void k_knn_linear(NodeStoreView st, int n_stor
 
 // candidates of one group of up to 64 cells (lane = cell, m = its item count), flattened over the lanes
 __device__ __forceinline__ void knn_cells(const GridView& g, int m, int cell, int lane, const KnnQuery& Q, const NodeStoreView& st,
-                                          TopK& t, int k, int& have, bool mates, double mate_limit, int32_t* mate_out, int& n_mates) {
+                                          TopK& t, int k, int& have, bool mates, double mate_limit, int32_t* mate_out, int& n_mates, int mate_cap) {
   int inc = m;
   for (int off = 1; off < 64; off <<= 1) {
     const int o = __shfl_up(inc, off);
@@ -408,7 +421,7 @@ __device__ __forceinline__ void knn_cells(const GridView& g, int m, int cell, in
       const unsigned long long mm = __ballot(cand);
       if (cand) {
         const int at = n_mates + __popcll(mm & ((1ULL << lane) - 1ULL));
-        if (at < SFFK_KNN_MATES) mate_out[at] = id;
+        if (at < mate_cap) mate_out[at] = id;
       }
       n_mates += __popcll(mm);
     } else {
@@ -422,7 +435,7 @@ __device__ __forceinline__ void knn_cells(const GridView& g, int m, int cell, in
 __global__ __launch_bounds__(256) void k_knn_grid(GridView g, GridView tg, NodeStoreView st, const KnnQuery* __restrict__ queries,
                                                   int nq, int kcap, int32_t* __restrict__ idx, double* __restrict__ dist,
                                                   int32_t* __restrict__ cnt, int32_t* __restrict__ mate_idx,
-                                                  int32_t* __restrict__ mate_cnt, double cell_edge, double slack) {
+                                                  int32_t* __restrict__ mate_cnt, double cell_edge, double slack, int mate_cap) {
   const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (q >= nq) return;
@@ -475,7 +488,7 @@ __global__ __launch_bounds__(256) void k_knn_grid(GridView g, GridView tg, NodeS
           if (m > g.bk) m = g.bk;
         }
       }
-      if (__any(m > 0)) knn_cells(g, m, cell, lane, Q, st, t, k, have, false, 0.0, nullptr, n_mates);
+      if (__any(m > 0)) knn_cells(g, m, cell, lane, Q, st, t, k, have, false, 0.0, nullptr, n_mates, 0);
     }
     r_done = r;
     const double covered = (double)r * cell_edge - slack;   // (cells are assigned from fp32 coordinates)
@@ -498,7 +511,7 @@ __global__ __launch_bounds__(256) void k_knn_grid(GridView g, GridView tg, NodeS
         const unsigned long long mm = __ballot(cand);
         if (cand) {
           const int at = n_mates + __popcll(mm & ((1ULL << lane) - 1ULL));
-          if (at < SFFK_KNN_MATES) mate_idx[(size_t)q * SFFK_KNN_MATES + at] = id;
+          if (at < mate_cap) mate_idx[(size_t)q * mate_cap + at] = id;
         }
         n_mates += __popcll(mm);
       }
@@ -518,7 +531,7 @@ __global__ __launch_bounds__(256) void k_knn_grid(GridView g, GridView tg, NodeS
             if (maybe) { m = tg.cnt[cell]; if (m > tg.bk) m = tg.bk; }
           }
         }
-        if (__any(m > 0)) knn_cells(tg, m, cell, lane, Q, st, t, k, have, true, limit, mate_idx + (size_t)q * SFFK_KNN_MATES, n_mates);
+        if (__any(m > 0)) knn_cells(tg, m, cell, lane, Q, st, t, k, have, true, limit, mate_idx + (size_t)q * mate_cap, n_mates, mate_cap);
       }
       int no = tg.ovf_cnt[0];
       if (no > tg.ovf_cap) no = tg.ovf_cap;
@@ -534,7 +547,7 @@ __global__ __launch_bounds__(256) void k_knn_grid(GridView g, GridView tg, NodeS
         const unsigned long long mm = __ballot(cand);
         if (cand) {
           const int at = n_mates + __popcll(mm & ((1ULL << lane) - 1ULL));
-          if (at < SFFK_KNN_MATES) mate_idx[(size_t)q * SFFK_KNN_MATES + at] = id;
+          if (at < mate_cap) mate_idx[(size_t)q * mate_cap + at] = id;
         }
         n_mates += __popcll(mm);
       }
@@ -2309,11 +2322,11 @@ void launch_knn_linear(hipStream_t s, const NodeStoreView& st, int n_store, cons
 }
 void launch_knn_grid(hipStream_t s, const GridView& g, const GridView* tg, const NodeStoreView& st, const KnnQuery* q, int nq,
                      int kcap, int32_t* idx, double* dist, int32_t* cnt, int32_t* mate_idx, int32_t* mate_cnt, double cell,
-                     double slack) {
+                     double slack, int mate_cap) {
   if (nq <= 0) return;
   GridView none{};
   hipLaunchKernelGGL(k_knn_grid, dim3((nq + 3) / 4), dim3(256), 0, s, g, tg ? *tg : none, st, q, nq, kcap, idx, dist, cnt,
-                     mate_idx, mate_cnt, cell, slack);
+                     mate_idx, mate_cnt, cell, slack, mate_cap);
 }
 void launch_set_tree(hipStream_t s, int32_t* tree_col, const int32_t* ids, int n, int32_t value) {
   if (n <= 0) return;

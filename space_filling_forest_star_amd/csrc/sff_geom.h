@@ -81,22 +81,30 @@ SFF_HD bool in_limits(const double* p, const double* lim) {
 
 // RandGen::randomPointInDistance from pre-drawn engine words (draw order: phi, theta, yaw,
 // pitch-u, flip-u, roll; 2-D uses phi only).  Returns the limits test.
-SFF_HD bool sample_point(const uint64_t* w, const double* center, double dist, int dim, const double* lim,
-                         double* out) {
-  double phi = uniform_real(w[0], -SFFG_PI, SFFG_PI);
+// The five transcendental values of a sample come in from outside: the kernels evaluate them with the portable trig
+// (sample_point below), the libm parity mode with the C library's cos / sin / acos - on the host, per engine word,
+// because that arithmetic is the reference's own (src/randGen.h:70-109) and exists nowhere else.
+struct SampleTrig {
+  double c_phi, s_phi;      // cos / sin of phi   = uniform_real(w[0], -pi, pi)
+  double c_theta, s_theta;  // cos / sin of theta = uniform_real(w[1], -pi, pi)
+  double acos_u;            // acos(1 - 2 uniform_real(w[3], 0, 1))
+};
+SFF_HD double sample_angle(uint64_t w) { return uniform_real(w, -SFFG_PI, SFFG_PI); }
+SFF_HD double sample_acos_arg(uint64_t w) { return 1 - 2 * uniform_real(w, 0.0, 1.0); }
+SFF_HD bool sample_point_with(const uint64_t* w, const double* center, double dist, int dim, const double* lim,
+                              double* out, const SampleTrig& t) {
   if (dim == 2) {
-    out[0] = center[0] + sffp::pcos(phi) * dist;
-    out[1] = center[1] + sffp::psin(phi) * dist;
+    out[0] = center[0] + t.c_phi * dist;
+    out[1] = center[1] + t.s_phi * dist;
     out[2] = 0; out[3] = 0; out[4] = 0; out[5] = 0;
   } else {
     double temp[6];
-    double theta = uniform_real(w[1], -SFFG_PI, SFFG_PI);
-    double sphi = sffp::psin(phi);
-    temp[0] = center[0] + sffp::pcos(theta) * sphi * dist;
-    temp[1] = center[1] + sffp::psin(theta) * sphi * dist;
-    temp[2] = center[2] + sffp::pcos(phi) * dist;
+    double sphi = t.s_phi;
+    temp[0] = center[0] + t.c_theta * sphi * dist;
+    temp[1] = center[1] + t.s_theta * sphi * dist;
+    temp[2] = center[2] + t.c_phi * dist;
     temp[3] = uniform_real(w[2], -SFFG_PI, SFFG_PI);
-    double pitch = sffp::pacos(1 - 2 * uniform_real(w[3], 0.0, 1.0)) + SFFG_PI_2;
+    double pitch = t.acos_u + SFFG_PI_2;
     if (uniform_real(w[4], 0.0, 1.0) < 0.5) {
       if (pitch < 0) pitch += SFFG_PI; else pitch -= SFFG_PI;
     }
@@ -105,6 +113,21 @@ SFF_HD bool sample_point(const uint64_t* w, const double* center, double dist, i
     steer(center, temp, dist, out);
   }
   return in_limits(out, lim);
+}
+SFF_HD bool sample_point(const uint64_t* w, const double* center, double dist, int dim, const double* lim,
+                         double* out) {
+  SampleTrig t;
+  const double phi = sample_angle(w[0]);
+  t.c_phi = sffp::pcos(phi);
+  t.s_phi = sffp::psin(phi);
+  t.c_theta = 0; t.s_theta = 0; t.acos_u = 0;
+  if (dim != 2) {
+    const double theta = sample_angle(w[1]);
+    t.c_theta = sffp::pcos(theta);
+    t.s_theta = sffp::psin(theta);
+    t.acos_u = sffp::pacos(sample_acos_arg(w[3]));
+  }
+  return sample_point_with(w, center, dist, dim, lim, out, t);
 }
 
 // ---- local planner (Solver::isPathFree): parts = dist/0.1, samples index = 1 .. < parts

@@ -19,11 +19,15 @@ import oracle_lib as O  # noqa: E402
 
 WAVES = int(os.environ.get("FULL_SIZE_WAVES", "258"))     # 0 = until the node budget stops the run
 WAVE = int(os.environ.get("FULL_SIZE_WAVE", "8192"))       # slots per wave; != 8192 writes full_size_run_w<WAVE>.json
+# FULL_SIZE_TRIG=libm: the REFERENCE-PINNED sampling arithmetic (glibc cos / sin / acos, tests/golden/ref_primitives.json)
+# instead of the kernels' portable trig; writes ..._libm.json (replayed on the GPU with libm_sampling = 1)
+LIBM = os.environ.get("FULL_SIZE_TRIG", "portable") == "libm"
 sc = common.scenario("dense3d")
 w = O.World(sc["env"], sc["robot"], O.TRIG_PORTABLE)
 roots = common.free_roots(w.collide, sc["limits"], 10, seed=1)
 f = O.Forest(w, roots, sc["limits"], dist_tree=sc["dist_tree"], sampling_dist=sc["sampling_dist"], dim=6,
-             max_iterations=2**31 - 1, node_budget=1000000, wave=WAVE, seed=1)
+             max_iterations=2**31 - 1, node_budget=1000000, wave=WAVE, seed=1,
+             trig=O.TRIG_LIBM if LIBM else O.TRIG_PORTABLE)
 t0 = time.time()
 f.run(WAVES)
 s = f.stats()
@@ -34,6 +38,7 @@ out = {"config": "dense3d, 10 roots (seed 1), dist_tree %g, sampling_dist %g, bu
        "n_nodes": int(s["n_nodes"]), "iterations": int(s["iterations"]), "collide_calls": int(s["collide_calls"]),
        "path_free_calls": int(s["path_free_calls"]), "nn_queries": int(s["nn_queries"]), "n_borders": int(s["n_borders"]),
        "parent_sum": int(n["parent"].astype(np.int64).sum()), "cost_sum": float(n["cost"].sum()).hex(),
-       "oracle_seconds": round(time.time() - t0, 1)}
+       "sampling_trig": "libm" if LIBM else "portable", "oracle_seconds": round(time.time() - t0, 1)}
 print(out)
-json.dump(out, open(os.path.join(HERE, "full_size_run.json" if WAVE == 8192 else "full_size_run_w%d.json" % WAVE), "w"), indent=1)
+name = ("full_size_run" if WAVE == 8192 else "full_size_run_w%d" % WAVE) + ("_libm" if LIBM else "") + ".json"
+json.dump(out, open(os.path.join(HERE, name), "w"), indent=1)

@@ -313,6 +313,36 @@ def test_full_size_run_at_the_bench_wave_equals_the_oracle(S, ctx, golden_dir):
     f.close()
 
 
+def test_full_size_bench_job_in_the_reference_pinned_arithmetic(S, ctx, golden_dir):
+    """The headline job (bench.py: waves of 16 384 slots to the 1 M-node budget) with sffgpu_forest_cfg::libm_sampling on
+    the DEVICE-RESIDENT engine: the transcendental functions of RandGen::randomPointInDistance are evaluated by the host's
+    C library (the arithmetic tests/golden/ref_primitives.json pins to the reference's own randGen.h) and travel beside
+    the engine words; everything else runs as in the bench.  Must reproduce the CPU oracle's TRIG_LIBM run of the same job
+    (tests/golden/full_size_run_w16384_libm.json; FULL_SIZE_TRIG=libm FULL_SIZE_WAVE=16384 FULL_SIZE_WAVES=0
+    tests/golden/make_full_size.py) fingerprint for fingerprint."""
+    import json
+    import os
+    path = os.path.join(golden_dir, "full_size_run_w16384_libm.json")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/full_size_run_w16384_libm.json not generated")
+    g = json.load(open(path))
+    assert g["sampling_trig"] == "libm"
+    sc, w = load_world(ctx, "dense3d")
+    roots = common.free_roots(lambda p: int(ctx.collide_poses(p[None, :])[0]), sc["limits"], 10, seed=1)
+    f = S.Forest(ctx, roots, sc["limits"], dist_tree=sc["dist_tree"], sampling_dist=sc["sampling_dist"], dim=6,
+                 max_iterations=2**31 - 1, node_budget=1000000, wave=g["wave"], seed=1, libm_sampling=True)
+    assert f.device_engine()
+    f.run()
+    s, n = f.stats(), f.nodes()
+    got = {"waves": int(s["waves"]), "fingerprint": "%016x" % f.fingerprint(), "n_nodes": int(s["n_nodes"]),
+           "iterations": int(s["iterations"]), "collide_calls": int(s["collide_calls"]),
+           "path_free_calls": int(s["path_free_calls"]), "nn_queries": int(s["nn_queries"]), "n_borders": int(s["n_borders"]),
+           "parent_sum": int(n["parent"].astype(np.int64).sum()), "cost_sum": float(n["cost"].sum()).hex()}
+    for k in got:
+        assert got[k] == g[k], (k, got[k], g[k])
+    f.close()
+
+
 def test_full_size_headline_run_equals_the_oracle(S, ctx, golden_dir):
     """BASELINE's headline configuration at full size (dense_3D, 10 roots, 1 M-node budget, waves of 8192 slots,
     3 + 255 waves = what bench.py times): the GPU run must reproduce the committed summary of the CPU oracle's run
@@ -455,6 +485,8 @@ def test_libm_sampling_mode_equals_the_libm_oracle(S, ctx, golden_dir):
         kw = dict(dist_tree=sc["dist_tree"], sampling_dist=sc["sampling_dist"], dim=sc["dim"], max_iterations=iters,
                   node_budget=budget, wave=wave, seed=1)
         f = S.Forest(ctx, roots, sc["limits"], libm_sampling=True, **kw)
+        # (waves >= 256 commit on the device-resident engine: the host's libm values travel in the engine-word ring)
+        assert f.device_engine() == (wave >= 256)
         f.run()
         got = mk.summary(f)
         for k in got:
