@@ -410,7 +410,10 @@ int sffgpu_forest_dev_wave_end(sffgpu_forest* f, int32_t* fault) {
   GUARD(f->owner, {
     f->f->dev_enqueue_end();
     *fault = f->f->dev_finish_wave(nullptr);
-    if (*fault) f->f->dev_to_host();   // (a list overflowed: the caller finishes the wave through the host protocol)
+    if (*fault) {                      // (a list overflowed: the caller finishes the wave through the host protocol)
+      ++f->f->st.host_fallback_waves;
+      f->f->dev_to_host();
+    }
   });
 }
 int sffgpu_forest_rounds_per_wave(sffgpu_forest* f) { return f ? std::max(1, f->f->cfg.threshold_misses) : SFFGPU_ERR_ARG; }

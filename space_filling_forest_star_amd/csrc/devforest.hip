@@ -459,6 +459,7 @@ __global__ __launch_bounds__(DF_THREADS) void k_resolve(ResolveArgs A) {
   const DevForestView& f = A.f;
   DevCtrl* c = f.ctrl;
   if (threadIdx.x == 0) c->app_n = 0;
+  if (A.star && threadIdx.x == 0) { A.S.hdr[0] = 0; A.S.hdr[1] = 1; A.S.hdr[2] = 0; A.S.hdr[4] = 0; }   // (no star stage unless this round commits)
   if (c->halt) return;
   const int n = c->n_act;
   if (n == 0) return;      // (a wave that is over keeps n_act = 0)
@@ -482,6 +483,27 @@ __global__ __launch_bounds__(DF_THREADS) void k_resolve(ResolveArgs A) {
     return;
   }
   __syncthreads();
+  if (A.star) {
+    // SFF*: the star stage may still fault after this kernel has committed the round's bookkeeping (a member edge's
+    // candidate list, the fixed point's launch budget): the control block as a rolled-back round leaves it, for k_star_apply
+    for (int w = threadIdx.x; w < (int)(sizeof(DevCtrl) / 4); w += DF_THREADS)
+      reinterpret_cast<int32_t*>(A.S.backup)[w] = reinterpret_cast<const int32_t*>(&K)[w];
+    __threadfence_block();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      DevCtrl* b = A.S.backup;
+      b->fault = SFFK_FAULT_LISTS;
+      b->halt = 1;
+      b->round -= 1;
+      b->iter = b->iter0;
+      b->cursor = b->words_base;
+      b->rounds -= 1;
+      b->round_nodes -= (unsigned long long)(b->N0 + n);
+      b->round_queries -= (unsigned long long)n;
+      b->n_act = 0;
+      b->app_n = 0;
+    }
+  }
   const int Tb = f.temp_base, N0 = K.N0, fn0 = K.frontier_n, nb0 = K.n_borders, act_cnt = K.act_cnt;
   const int act_sel = K.act_sel;
   const unsigned long long stamp_hi = (K.epoch + 1ULL) << 32;
@@ -722,6 +744,13 @@ __global__ __launch_bounds__(DF_THREADS) void k_resolve(ResolveArgs A) {
     f.b_n1[at] = nb < ex ? nb : ex; f.b_n2[at] = nb < ex ? ex : nb;
     f.b_ta[at] = ta < tb ? ta : tb; f.b_tb[at] = ta < tb ? tb : ta;
     for (int q = 0; q < 6; ++q) pe[q] = A.st.pos[6 * (size_t)ex + q];
+    if (A.star) {
+      // SFF*: the two costs are the ones the sample's turn finds (earlier samples of the round may have rewired either
+      // node): k_star_pass adds them to the distance
+      const int e = at - nb0;
+      A.S.ev_sample[e] = i; A.S.ev_nb[e] = nb; A.S.ev_ex[e] = ex; A.S.ev_dist[e] = dist6(pn, pe);
+      f.b_dist[at] = 0.0;
+    } else
     f.b_dist[at] = dn + f.d_root[ex] + dist6(pn, pe);
     f.pair[(size_t)ta * f.n_trees + tb] = 1;
     f.pair[(size_t)tb * f.n_trees + ta] = 1;
@@ -762,6 +791,10 @@ __global__ __launch_bounds__(DF_THREADS) void k_resolve(ResolveArgs A) {
     K.n_borders = nb0 + n_ev;
     K.n_unsettled += n_dep;
     K.epoch += 1ULL;
+    if (A.star) {
+      K.nn_queries += (unsigned long long)n_acc;       // one knnSearch per accepted sample (src/forest.h:317)
+      A.S.hdr[0] = n_acc; A.S.hdr[1] = 0; A.S.hdr[2] = n_ev; A.S.hdr[3] = nb0;
+    }
     K.act_sel = act_sel ^ 1;
     K.act_cnt = (n - n_acc) + (act_cnt - n);
     round_begin_scalars(f, &K);
@@ -798,6 +831,7 @@ __global__ __launch_bounds__(256) void k_append(ResolveArgs A) {
     act_new[i - rank] = act_old[i];     // not accepted: the slot tries again (rank = accepted samples before it)
     return;
   }
+  if (A.star) return;                   // SFF*: k_star_apply has made the accepted samples nodes
   const int N0 = c->app_N0, fn0 = c->app_fn0;
   int32_t* const frontier = frontier_now(f);
   const int id = N0 + rank;
@@ -825,10 +859,20 @@ __global__ __launch_bounds__(256) void k_append(ResolveArgs A) {
 
 // ------------------------------------------------------------------ wave end
 __global__ __launch_bounds__(DF_THREADS) void k_wave_end(DevForestView f, const int32_t* __restrict__ grid_ovf,
-                                                         const int32_t* __restrict__ tgrid_ovf) {
+                                                         const int32_t* __restrict__ tgrid_ovf, unsigned long long* star_acc) {
   __shared__ WgLists L;
+  __shared__ unsigned long long star_s[SFFK_STAR_ACC];
   DevCtrl* c = f.ctrl;
   if (c->halt || !c->in_wave) return;
+  if (star_acc) {   // SFF*: the wave's sub-counters (64 lines, k_star_apply) are folded into the control block below
+    if (threadIdx.x < SFFK_STAR_ACC) star_s[threadIdx.x] = 0ULL;
+    __syncthreads();
+    if (threadIdx.x < 64 * SFFK_STAR_ACC) {
+      const unsigned long long v = star_acc[threadIdx.x];
+      if (v) { atomicAdd(&star_s[threadIdx.x % SFFK_STAR_ACC], v); star_acc[threadIdx.x] = 0ULL; }
+    }
+    __syncthreads();
+  }
   const bool from_closed = c->use_closed != 0;
   const int fn = c->frontier_n;
   const int nw = (fn + 63) >> 6;
@@ -984,6 +1028,10 @@ __global__ __launch_bounds__(DF_THREADS) void k_wave_end(DevForestView f, const 
     c->n_act = 0;
     c->grid_ovf = grid_ovf[0];
     c->tgrid_ovf = tgrid_ovf[0];
+    if (star_acc) {
+      c->collide_calls += star_s[0]; c->path_free_calls += star_s[1];
+      c->star_rounds += star_s[2]; c->star_passes += star_s[3]; c->star_members += star_s[4]; c->star_rewires += star_s[5];
+    }
     tw[6] = wall_clock64();
     if (!from_closed) for (int q = 0; q < 6; ++q) c->wprof[q] += tw[q + 1] - tw[q];
     c->wprof[7] += 1ULL;
@@ -1064,14 +1112,16 @@ __global__ __launch_bounds__(256) void k_border_rehash(DevForestView f, int n) {
 void launch_wave_begin(hipStream_t s, const DevForestView& f) {
   hipLaunchKernelGGL(k_wave_begin, dim3(1), dim3(DF_THREADS), 0, s, f);
 }
-void launch_commit(hipStream_t s, const ResolveArgs& a, int n_bound) {
+void launch_commit(hipStream_t s, const ResolveArgs& a, int n_bound, const StarLaunch* star) {
   if (n_bound <= 0) return;
   hipLaunchKernelGGL(k_decide, dim3((n_bound + 63) / 64), dim3(1024), 0, s, a, n_bound);
   hipLaunchKernelGGL(k_resolve, dim3(1), dim3(DF_THREADS), 0, s, a);
+  if (a.star && star) launch_star_stage(s, a, n_bound, *star);
   hipLaunchKernelGGL(k_append, dim3((n_bound + 255) / 256), dim3(256), 0, s, a);
 }
-void launch_wave_end(hipStream_t s, const DevForestView& f, const int32_t* grid_ovf, const int32_t* tgrid_ovf) {
-  hipLaunchKernelGGL(k_wave_end, dim3(1), dim3(DF_THREADS), 0, s, f, grid_ovf, tgrid_ovf);
+void launch_wave_end(hipStream_t s, const DevForestView& f, const int32_t* grid_ovf, const int32_t* tgrid_ovf,
+                     unsigned long long* star_acc) {
+  hipLaunchKernelGGL(k_wave_end, dim3(1), dim3(DF_THREADS), 0, s, f, grid_ovf, tgrid_ovf, star_acc);
   hipLaunchKernelGGL(k_frontier_compact, dim3(512), dim3(256), 0, s, f);
 }
 void launch_pack_records(hipStream_t s, const ResolveArgs& a, int rank, int world, int n_bound, int32_t* send) {

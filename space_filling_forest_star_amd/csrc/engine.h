@@ -234,6 +234,11 @@ struct DevEngine {
   DevBuf frontier2, rm_words, rm_pref, slot_pos, act_slot2, dk, w_dep, w_acc, w_ev, acc_pref, w_cnt, dep_rec;
   DevBuf ctrl, parent, d_root, d_closest, iter, nflag, frontier, closed, claim, slot_node, slot_fail, act_slot, b_n1,
       b_n2, b_ta, b_tb, b_dist, bt_key, bt_val, pair, ring, ustate, ulist, uacc, d_parent, d_force, fault_pending;
+  // SFF* on the device (devstar.hip; StarView in kernels.h)
+  DevBuf s_ktab, s_tree_cnt, s_head, s_mcnt, s_mid, s_md, s_next, s_prop, s_best, s_psel, s_dcl, s_cnt, s_accs, s_hdr, s_changed,
+      s_ectrl, s_sega, s_segb, s_segns, s_fh, s_sovf, s_evs, s_evn, s_eve, s_evd, s_acc, s_backup, s_list, s_masks;
+  int s_list_cap = 0;
+  bool star_inited = false;
   PinBuf h_ctrl, h_ring, h_trig;
   DevBuf trig;   // libm parity mode: the C library's cos / sin / acos of every ring word (3 doubles per word)
   hipEvent_t ev_ring = nullptr, ev_wave = nullptr, ev_wave2 = nullptr;   // (two status slots: one wave may be enqueued ahead)
@@ -251,6 +256,8 @@ struct Forest {
   DevEngine dev;
   bool device_eligible() const;
   sffk::DevForestView dev_view() const;
+  sffk::StarView star_view() const;
+  void dev_star_setup();            // buffers of the SFF* stage (first use) + per-tree node counts from the host mirror
   void dev_size_node_arrays();
   void dev_size_border_arrays(int want_cap);
   void dev_ring_append(const uint64_t* words, size_t n);
@@ -349,6 +356,7 @@ struct Forest {
   std::vector<std::vector<HitRec>> knn_out;   // scratch of the SFF* k-nearest passes
   std::vector<int32_t> edge_ia, edge_ib;      // ... and of its edge batch
   int hit_cap = 64, nb_cap = 15;  // device list capacities (env SFFGPU_TEST_HITCAP / _NBCAP shrink them in tests)
+  int star_pass_limit = 0;        // SFF* device stage: fixed-point launches per round (0 = SFFK_STAR_PASSES; SFFGPU_TEST_STAR_PASSES)
 
   // post-loop path extraction (src/forest.h:420-462, src/problemStruct.h:184-253)
   struct Holder {            // DistanceHolder (src/primitives.h:598-655)

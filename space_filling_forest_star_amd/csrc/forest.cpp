@@ -168,6 +168,7 @@ Forest::Forest(Ctx* c, const sffgpu_forest_cfg& cf, const double* roots6, int n_
   knn_r = 2.5 * cfg.sampling_dist;
   if (const char* e = getenv("SFFGPU_TEST_HITCAP")) hit_cap = std::min(64, std::max(1, atoi(e)));  // one lane per hit
   if (const char* e = getenv("SFFGPU_TEST_NBCAP")) nb_cap = std::max(1, atoi(e));
+  if (const char* e = getenv("SFFGPU_TEST_STAR_PASSES")) star_pass_limit = std::max(1, atoi(e));
 }
 
 int Forest::add_node(const double* pos, int tree, int parent, double dclosest, double droot, unsigned it) {
@@ -254,6 +255,10 @@ void Forest::fill_stats(sffgpu_forest_stats* out) {
     s.sweeps = k.rounds;
     s.sweep_nodes = k.round_nodes;
     s.sweep_queries = k.round_queries;
+    s.star_rounds = k.star_rounds;
+    s.star_passes = k.star_passes;
+    s.star_members = k.star_members;
+    s.star_rewires = k.star_rewires;
   } else {
     s.iterations = iter;
     bool sv = solved;
@@ -284,7 +289,10 @@ Forest::~Forest() {
                     &dev.claim, &dev.slot_node, &dev.slot_fail, &dev.act_slot, &dev.b_n1, &dev.b_n2, &dev.b_ta, &dev.b_tb,
                     &dev.b_dist, &dev.bt_key, &dev.bt_val, &dev.pair, &dev.ring, &dev.ustate, &dev.ulist, &dev.uacc,
                     &dev.d_parent, &dev.d_force, &dev.fault_pending, &dev.frontier2, &dev.rm_words, &dev.rm_pref,
-                    &dev.slot_pos, &dev.act_slot2, &dev.dk, &dev.trig, &dev.w_dep, &dev.w_acc, &dev.w_ev, &dev.acc_pref, &dev.w_cnt, &dev.dep_rec, &x_send, &x_recv};
+                    &dev.slot_pos, &dev.act_slot2, &dev.dk, &dev.trig, &dev.s_ktab, &dev.s_tree_cnt, &dev.s_head, &dev.s_mcnt, &dev.s_mid, &dev.s_md,
+                    &dev.s_next, &dev.s_prop, &dev.s_best, &dev.s_psel, &dev.s_dcl, &dev.s_cnt, &dev.s_accs, &dev.s_hdr, &dev.s_changed,
+                    &dev.s_ectrl, &dev.s_sega, &dev.s_segb, &dev.s_segns, &dev.s_fh, &dev.s_sovf, &dev.s_evs, &dev.s_evn, &dev.s_eve,
+                    &dev.s_evd, &dev.s_acc, &dev.s_backup, &dev.s_list, &dev.s_masks, &dev.w_dep, &dev.w_acc, &dev.w_ev, &dev.acc_pref, &dev.w_cnt, &dev.dep_rec, &x_send, &x_recv};
   if (dev.inited) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);

@@ -35,7 +35,102 @@ static uint64_t next_pow2(uint64_t v) {
 }
 
 bool Forest::device_eligible() const {
-  return !cfg.optimize && !cfg.has_goal && !use_priority();
+  // plain SFF and SFF* (choose-parent + rewire on the device: devstar.hip); single-goal and priority-frontier modes run
+  // on the host-replay engine
+  return !cfg.has_goal && !use_priority();
+}
+
+sffk::StarView Forest::star_view() const {
+  const DevEngine& d = dev;
+  sffk::StarView v{};
+  v.ktab = d.s_ktab.as<int32_t>();
+  v.tree_cnt = d.s_tree_cnt.as<int32_t>();
+  v.head = d.s_head.as<unsigned long long>();
+  v.m_cnt = d.s_mcnt.as<int32_t>();
+  v.m_id = d.s_mid.as<int32_t>();
+  v.m_d = d.s_md.as<double>();
+  v.next = d.s_next.as<int32_t>();
+  v.prop = d.s_prop.as<double>();
+  v.best = d.s_best.as<double>();
+  v.psel = d.s_psel.as<int32_t>();
+  v.dcl = d.s_dcl.as<double>();
+  v.cnt = d.s_cnt.as<unsigned long long>();
+  v.acc_sample = d.s_accs.as<int32_t>();
+  v.hdr = d.s_hdr.as<int32_t>();
+  v.changed = d.s_changed.as<int32_t>();
+  v.ectrl = d.s_ectrl.as<int32_t>();
+  v.seg_a = d.s_sega.as<double>();
+  v.seg_b = d.s_segb.as<double>();
+  v.seg_ns = d.s_segns.as<int32_t>();
+  v.first_hit = d.s_fh.as<int32_t>();
+  v.seg_ovf = d.s_sovf.as<int32_t>();
+  v.ev_sample = d.s_evs.as<int32_t>();
+  v.ev_nb = d.s_evn.as<int32_t>();
+  v.ev_ex = d.s_eve.as<int32_t>();
+  v.ev_dist = d.s_evd.as<double>();
+  v.acc = d.s_acc.as<unsigned long long>();
+  v.backup = d.s_backup.as<sffk::DevCtrl>();
+  return v;
+}
+
+void Forest::dev_star_setup() {
+  DevEngine& d = dev;
+  const size_t W = (size_t)cfg.wave, KC = SFFK_STAR_KC;
+  if (!d.star_inited) {
+    // k = (size_t)(2e log10(#nodes)) (src/forest.h:309): the node counts at which it steps, found with the C library's
+    // log10 in the reference's own expression (the kernels only compare integers)
+    std::vector<int32_t> ktab(64, 0x7fffffff);
+    auto k_of = [](long long nn) { return (long long)(size_t)(2 * M_E * std::log10((double)nn)); };
+    ktab[0] = 0;
+    for (int m = 1; m < 64; ++m) {
+      long long lo = 1, hi = 0x7fffffffLL;
+      if (k_of(hi) < m) { ktab[m] = 0x7fffffff; continue; }
+      while (lo < hi) {
+        const long long mid = (lo + hi) / 2;
+        if (k_of(mid) >= m) hi = mid; else lo = mid + 1;
+      }
+      ktab[m] = (int32_t)lo;
+    }
+    d.s_ktab.ensure(64 * 4);
+    HIPCHK(hipMemcpy(d.s_ktab.p, ktab.data(), 64 * 4, hipMemcpyHostToDevice));
+    d.s_tree_cnt.ensure((size_t)num_roots * 16 * 4);
+    d.s_mcnt.ensure(W * 4);
+    d.s_mid.ensure(W * KC * 4);
+    d.s_md.ensure(W * KC * 8);
+    d.s_next.ensure(W * KC * 4);
+    d.s_prop.ensure(W * KC * 8);
+    d.s_best.ensure(W * 8);
+    d.s_psel.ensure(W * 4);
+    d.s_dcl.ensure(W * 8);
+    d.s_cnt.ensure(W * 16);
+    d.s_accs.ensure(W * 4);
+    d.s_hdr.ensure(64);
+    d.s_changed.ensure(64);
+    d.s_ectrl.ensure(128);
+    d.s_sega.ensure(W * KC * 2 * 48);
+    d.s_segb.ensure(W * KC * 2 * 48);
+    d.s_segns.ensure(W * KC * 2 * 4);
+    d.s_fh.ensure(W * KC * 2 * 4);
+    d.s_sovf.ensure(W * KC * 2 * 4);
+    d.s_evs.ensure(W * 4);
+    d.s_evn.ensure(W * 4);
+    d.s_eve.ensure(W * 4);
+    d.s_evd.ensure(W * 8);
+    d.s_acc.ensure(64 * SFFK_STAR_ACC * 8);
+    d.s_backup.ensure(sizeof(sffk::DevCtrl));
+    d.s_list_cap = (int)std::min<size_t>(48 * W + 65536, (size_t)1 << 26);
+    d.s_list.ensure((size_t)d.s_list_cap * SFFK_ITEM_BYTES);
+    d.s_masks.ensure(((size_t)d.s_list_cap + (1u << 20)) * 8);
+    HIPCHK(hipMemset(d.s_hdr.p, 0, 64));
+    HIPCHK(hipMemset(d.s_changed.p, 0, 64));
+    HIPCHK(hipMemset(d.s_acc.p, 0, 64 * SFFK_STAR_ACC * 8));
+    d.star_inited = true;
+  }
+  // (the control block's epoch restarts with every upload: no list head of an earlier stay on the device may match it)
+  if (d.s_head.p) HIPCHK(hipMemset(d.s_head.p, 0, d.s_head.cap));
+  std::vector<int32_t> tc((size_t)num_roots * 16, 0);
+  for (int t = 0; t < num_roots; ++t) tc[(size_t)t * 16] = (int32_t)trees[t].size();
+  HIPCHK(hipMemcpy(d.s_tree_cnt.p, tc.data(), tc.size() * 4, hipMemcpyHostToDevice));
 }
 
 sffk::DevForestView Forest::dev_view() const {
@@ -112,6 +207,11 @@ void Forest::dev_size_node_arrays() {
     HIPCHK(hipMemsetAsync(d.rm_words.p, 0, d.rm_words.cap, c.stream));
   d.rm_pref.ensure(((size_t)cap / 64 + 2) * 4);
   d.closed.ensure((size_t)cap * 4);
+  if (cfg.optimize) {   // SFF*: heads of the per-node toucher lists (stamped with the round's epoch; 0 = never used)
+    const size_t old_head = d.s_head.cap;
+    d.s_head.ensure((size_t)cap * 8);
+    if (d.s_head.cap != old_head) HIPCHK(hipMemsetAsync(d.s_head.p, 0, d.s_head.cap, c.stream));
+  }
   const size_t old_claim = d.claim.cap;
   d.claim.ensure((size_t)cap * 4);
   if (d.claim.cap != old_claim)   // (fresh part must read "unclaimed"; the whole array is unclaimed between waves)
@@ -249,6 +349,7 @@ void Forest::dev_upload_state() {
     if (const char* e = getenv("SFFGPU_TEST_BORDER_CAP")) first_cap = std::max(nb + 1, atoi(e));   // tests: force growth
     dev_size_border_arrays(first_cap);
   }
+  if (cfg.optimize) dev_star_setup();
   // all nodes lie inside the limits: a bound for the fp32 filter slack that does not depend on the nodes to come
   for (int a = 0; a < 6; ++a) c.store_maxabs = std::max(c.store_maxabs, std::fabs(cfg.limits[a]));
 
@@ -328,6 +429,10 @@ void Forest::dev_upload_state() {
     k.rounds = st.sweeps;
     k.round_nodes = st.sweep_nodes;
     k.round_queries = st.sweep_queries;
+    k.star_rounds = st.star_rounds;
+    k.star_passes = st.star_passes;
+    k.star_members = st.star_members;
+    k.star_rewires = st.star_rewires;
     k.epoch = 1;
     if (in_wave) {
       k.n_slots = (int)slots.size();
@@ -363,6 +468,20 @@ void Forest::sync_host() {
   HIPCHK(hipStreamSynchronize(c.stream));
   sffk::DevCtrl k;
   HIPCHK(hipMemcpy(&k, d.ctrl.p, sizeof k, hipMemcpyDeviceToHost));
+  if (cfg.optimize && d.star_inited) {
+    // the star stage's sub-counters are folded into the control block at every wave end; what a wave that stopped in
+    // the middle (a fault) left in them is folded here
+    unsigned long long acc[64 * SFFK_STAR_ACC], sum[SFFK_STAR_ACC] = {0, 0, 0, 0, 0, 0, 0, 0};
+    HIPCHK(hipMemcpy(acc, d.s_acc.p, sizeof acc, hipMemcpyDeviceToHost));
+    bool any = false;
+    for (int j = 0; j < 64 * SFFK_STAR_ACC; ++j) { sum[j % SFFK_STAR_ACC] += acc[j]; any |= acc[j] != 0; }
+    if (any) {
+      k.collide_calls += sum[0]; k.path_free_calls += sum[1];
+      k.star_rounds += sum[2]; k.star_passes += sum[3]; k.star_members += sum[4]; k.star_rewires += sum[5];
+      HIPCHK(hipMemset(d.s_acc.p, 0, sizeof acc));
+      HIPCHK(hipMemcpy(d.ctrl.p, &k, sizeof k, hipMemcpyHostToDevice));
+    }
+  }
   d.last = k;
   const int n = k.n_nodes, n0 = d.host_nodes;
   if (n > n0) {
@@ -377,6 +496,14 @@ void Forest::sync_host() {
     HIPCHK(hipMemcpy(dc.data(), d.d_closest.as<double>() + n0, (size_t)m * 8, hipMemcpyDeviceToHost));
     HIPCHK(hipMemcpy(it.data(), d.iter.as<uint32_t>() + n0, (size_t)m * 4, hipMemcpyDeviceToHost));
     for (int j = 0; j < m; ++j) add_node(&pos[6 * (size_t)j], tr[j], par[j], dc[j], dr[j], it[j]);
+  }
+  if (cfg.optimize && n0 > 0) {   // SFF*: rewires change parent / costs of nodes the mirror already holds
+    std::vector<double> dr(n0), dc(n0);
+    std::vector<int32_t> par(n0);
+    HIPCHK(hipMemcpy(par.data(), d.parent.p, (size_t)n0 * 4, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(dr.data(), d.d_root.p, (size_t)n0 * 8, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(dc.data(), d.d_closest.p, (size_t)n0 * 8, hipMemcpyDeviceToHost));
+    for (int j = 0; j < n0; ++j) { nodes[j].parent = par[j]; nodes[j].d_root = dr[j]; nodes[j].d_closest = dc[j]; }
   }
   if (n > 0) HIPCHK(hipMemcpy(nflag.data(), d.nflag.p, (size_t)n, hipMemcpyDeviceToHost));
   frontier.resize((size_t)k.frontier_n);
@@ -413,6 +540,10 @@ void Forest::sync_host() {
   st.sweeps = k.rounds;
   st.sweep_nodes = k.round_nodes;
   st.sweep_queries = k.round_queries;
+  st.star_rounds = k.star_rounds;
+  st.star_passes = k.star_passes;
+  st.star_members = k.star_members;
+  st.star_rewires = k.star_rewires;
   if (in_wave) {
     std::vector<int32_t> sn(k.n_slots), act((size_t)k.act_cnt);
     std::vector<uint8_t> sf(k.n_slots, 0);
@@ -517,6 +648,8 @@ static sffk::ResolveArgs dev_resolve_args(Forest& F, const DevRoundBufs& B) {
   ra.bulk = B.bulk;
   ra.round_ctrl = B.d_rctrl;
   ra.fault_pending = d.fault_pending.as<int32_t>();
+  ra.star = F.cfg.optimize ? 1 : 0;
+  if (ra.star) ra.S = F.star_view();
   return ra;
 }
 
@@ -616,8 +749,13 @@ void Forest::dev_enqueue_round_eval(void* send_dev) {
   c.time_begin(T_COLLIDE);
   sffk::TempGridRef tref{c.tgridv, c.sx.as<float>() + d.temp_base, c.sy.as<float>() + d.temp_base,
                          c.sz.as<float>() + d.temp_base, n};
+  // (SFF*: the star stage of the commit still reads the round's own grid - k_star_apply empties it)
+  sffk::TempGridRef tref_keep = tref;
+  tref_keep.tg = sffk::GridView{};
+  tref_keep.n = 0;
   sffk::launch_collide_items(c.stream, c.envv, c.robv, B.d_pos, n, ca.rec_flags, B.d_pose, ca.seg_a, ca.seg_b, ca.seg_ns,
-                             B.STRIDE, ca.ctrl, c.r_items.p, ca.items_cap, ca.sub, ca.first_hit, ca.seg_ovf, &tref, dev_n);
+                             B.STRIDE, ca.ctrl, c.r_items.p, ca.items_cap, ca.sub, ca.first_hit, ca.seg_ovf,
+                             cfg.optimize ? &tref_keep : &tref, dev_n);
   c.time_end();
   if (send_dev) sffk::launch_pack_records(c.stream, dev_resolve_args(*this, B), cfg.rank, cfg.world, n, static_cast<int32_t*>(send_dev));
   c.timing_on = true;
@@ -630,13 +768,31 @@ void Forest::dev_enqueue_round_commit(const void* recv_dev) {
   const DevRoundBufs B = dev_round_bufs(*this);
   const sffk::ResolveArgs ra = dev_resolve_args(*this, B);
   if (recv_dev) sffk::launch_unpack_records(c.stream, ra, cfg.rank, cfg.world, B.n, static_cast<const int32_t*>(recv_dev));
-  sffk::launch_commit(c.stream, ra, B.n);
+  if (cfg.optimize) {
+    // SFF*: k nearest + member edges + the rewire fixed point for the accepted samples, between k_resolve and k_append
+    sffk::StarLaunch sl{};
+    sl.g = c.gridv;
+    sl.tg = c.tgridv;
+    sl.st = c.store_view();
+    sl.env = c.envv;
+    sl.rob = c.robv;
+    sl.cell_edge = c.grid_cell;
+    sl.slack = 8 * c.sweep_eps();
+    sl.list = dev.s_list.p;
+    sl.list_cap = dev.s_list_cap;
+    sl.masks = dev.s_masks.p;
+    sl.passes = star_pass_limit;
+    sffk::launch_commit(c.stream, ra, B.n, &sl);
+  } else {
+    sffk::launch_commit(c.stream, ra, B.n);
+  }
 }
 
 void Forest::dev_enqueue_end(int slot) {
   Ctx& c = *ctx;
   DevEngine& d = dev;
-  sffk::launch_wave_end(c.stream, dev_view(), c.gridv.ovf_cnt, c.tgridv.ovf_cnt);
+  sffk::launch_wave_end(c.stream, dev_view(), c.gridv.ovf_cnt, c.tgridv.ovf_cnt,
+                        cfg.optimize ? d.s_acc.as<unsigned long long>() : nullptr);
   HIPCHK(hipMemcpyAsync(d.h_ctrl.as<sffk::DevCtrl>() + slot, d.ctrl.p, sizeof(sffk::DevCtrl), hipMemcpyDeviceToHost, c.stream));
   HIPCHK(hipEventRecord(slot ? d.ev_wave2 : d.ev_wave, c.stream));
 }
@@ -793,6 +949,7 @@ void Forest::run_device(int max_waves) {
     }
     if (fault == SFFK_FAULT_LISTS) {
       // a bounded device list overflowed: finish this wave on the host path, then come back
+      ++st.host_fallback_waves;
       dev_to_host();
       while (in_wave) {
         round_begin();

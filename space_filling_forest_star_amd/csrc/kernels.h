@@ -136,6 +136,9 @@ struct DevCtrl {
   // k_wave_end phase clocks (thread 0): claims, owner flags, closed list, clear claims, removal prefix, termination;
   // [6] = k_wave_begin as a whole, [7] = waves
   unsigned long long wprof[8];
+  // SFF* on the device (devstar.hip): rounds whose choose-parent / rewire step ran here, the fixed-point passes they
+  // took, the k-nearest members they looked at, the rewires they applied (folded in from StarView::acc by k_wave_end)
+  unsigned long long star_rounds, star_passes, star_members, star_rewires;
 };
 #define SFFK_DEP_REC 12   // {entries, first neighbour index, 4 x (id, calls << 2 | edge free << 1 | same tree)}, 16-byte aligned
 #define SFFK_DEV_MAX_GROUPS 1024   // single-workgroup list kernels: 64 x this many slots per wave at most
@@ -356,6 +359,47 @@ struct DevForestView {
   int32_t* dep_rec;            // SFFK_DEP_REC ints per sample: what is left of a dependent sample's neighbour walk (k_decide -> k_resolve)
   unsigned long long* w_cnt;   // 6 counters per word (k_decide's sums over its 64 samples; k_resolve adds them up)
 };
+// ---- SFF* (optimize = true) on the device engine: choose-parent + rewire of src/forest.h:307-351 (devstar.hip).
+// The accept / reject logic does not depend on costs, so k_decide / k_resolve settle WHICH samples of the round become
+// nodes (and their ids) exactly as for plain SFF; then, for the accepted samples only:
+//   k_star_knn    one wavefront per accepted sample: its k = floor(2e log10(#nodes at its turn)) nearest nodes of its
+//                 tree among the store AND the samples accepted earlier in the round (replaces knnSearch, :317), the
+//                 two edge tasks per member (new -> member :323, member -> new :336), and the member joins the toucher
+//                 list of its node (per-node linked lists, heads stamped with the round's epoch: no clearing)
+//   (k_seg_compact -> k_cull -> k_collide_segments_dyn answer the member edges)
+//   k_star_pass   the sequential semantics "sample i sees the rewires of every accepted sample before it" as a fixed
+//                 point: a sample's view of a member's DistanceToRoot = the proposal of the LATEST earlier sample that
+//                 rewires that node (walk of the node's toucher list), else the node's stored cost; from its views it
+//                 recomputes its parent / cost / rewire proposals.  Dependencies only point backwards in slot order, so
+//                 the iteration reaches the unique fixed point in (longest chain + 1) passes; a pass that changes
+//                 nothing proves it.  One launch per pass, later launches return at once.
+//   k_star_apply  accepted samples -> nodes (store, records, grid, frontier); per node the LAST active rewire in slot
+//                 order is written (descendants' costs are NOT propagated, as in the reference, :344-348)
+#define SFFK_STAR_KC 64        // member slots per sample (k <= 50 for any int32 node count; lane k holds the expanded node)
+#define SFFK_STAR_KMAX 56
+#define SFFK_STAR_PASSES 8     // launches per round; not converged by then = fault (the round is redone on the host)
+#define SFFK_STAR_ACC 8        // sub-counter words per line of StarView::acc
+struct StarView {
+  const int32_t* ktab;         // ktab[m] = smallest node count N with floor(2e log10 N) >= m (host libm, the reference's expression)
+  int32_t* tree_cnt;           // nodes per tree in the store, one counter per 64 bytes (16 ints apart)
+  unsigned long long* head;    // per node: (epoch << 32 | pair + 1) = head of this round's toucher list
+  int32_t* m_cnt;              // per sample: members
+  int32_t* m_id;               // W x KC node ids: store id, or N0 + rank of an earlier accepted sample of the round
+  double* m_d;                 // W x KC distances sample <-> member
+  int32_t* next;               // per pair (sample * KC + m): next pair + 1 in its node's list, 0 = end
+  double* prop;                // per pair: proposed DistanceToRoot when the rewire is active (:336), +inf otherwise
+  double* best; int32_t* psel; double* dcl;   // per sample: cost, chosen parent (node id), distance to it (:320-329)
+  unsigned long long* cnt;     // per sample: {Collide calls, isPathFree calls} of its choose-parent / rewire loops
+  int32_t* acc_sample;         // rank among the accepted samples -> sample
+  int32_t* hdr;                // {n_acc, skip, n_events, first border entry of the round, fault} (hdr[0..1] = dev_n of the edge kernels)
+  int32_t* changed;            // SFFK_STAR_PASSES flags: pass t changed something
+  int32_t* ectrl;              // 32-int control block of the member-edge pipeline (launch_round_collide)
+  double* seg_a; double* seg_b; int32_t* seg_ns; int32_t* first_hit; int32_t* seg_ovf;   // slot = (rank * KC + m) * 2 + dir
+  // border entries created by the round (k_resolve): the two nodes' costs are read "at the time of the sample"
+  int32_t* ev_sample; int32_t* ev_nb; int32_t* ev_ex; double* ev_dist;
+  unsigned long long* acc;     // 64 lines x SFFK_STAR_ACC: Collide calls, isPathFree calls, rounds, passes, members, rewires
+  DevCtrl* backup;             // the control block as a rolled-back round leaves it (restored when the star stage faults)
+};
 // per-sample verdicts of k_decide
 #define SFFK_DEPENDS 0     // the neighbour walk reached a sample of the same round first: k_resolve continues at dk
 #define SFFK_REJECTED 1
@@ -374,6 +418,8 @@ struct ResolveArgs {
   unsigned long long* bulk;    // counters of the samples k_decide decided (7 words)
   const int32_t* round_ctrl;   // the round's scratch block ([2] = work items)
   int32_t* fault_pending;
+  int star;                    // SFF*: the accepted samples are appended by the star stage (S below)
+  StarView S;
 };
 void launch_wave_begin(hipStream_t s, const DevForestView& f);
 // multi-GPU: the answer record of one sample as it travels in the all-gather of a round:
@@ -384,9 +430,21 @@ inline int record_words(int nbcap) { return 6 + 4 * nbcap; }
 // into the round's arrays (a.code / rec_* / seg_ns / first_hit / pose_hit)
 void launch_pack_records(hipStream_t s, const ResolveArgs& a, int rank, int world, int n_bound, int32_t* send);
 void launch_unpack_records(hipStream_t s, const ResolveArgs& a, int rank, int world, int n_bound, const int32_t* recv);
-// the commit of one round: k_decide (wide) -> k_resolve (one workgroup) -> k_append (wide); n_bound = launch bound
-void launch_commit(hipStream_t s, const ResolveArgs& a, int n_bound);
-void launch_wave_end(hipStream_t s, const DevForestView& f, const int32_t* grid_ovf, const int32_t* tgrid_ovf);
+struct StarLaunch {            // what the host adds for the SFF* stage of a commit
+  GridView g, tg;
+  NodeStoreView st;
+  EnvView env;
+  RobotView rob;
+  double cell_edge, slack;
+  void* list; int list_cap; void* masks;   // work list + masks of the member-edge pipeline
+  int passes;                // fixed-point launches per round (<= SFFK_STAR_PASSES; tests shrink it to drive the fault path)
+};
+void launch_star_stage(hipStream_t s, const ResolveArgs& a, int n_bound, const StarLaunch& L);   // devstar.hip
+// the commit of one round: k_decide (wide) -> k_resolve (one workgroup) [-> the SFF* stage] -> k_append (wide);
+// n_bound = launch bound
+void launch_commit(hipStream_t s, const ResolveArgs& a, int n_bound, const StarLaunch* star = nullptr);
+void launch_wave_end(hipStream_t s, const DevForestView& f, const int32_t* grid_ovf, const int32_t* tgrid_ovf,
+                     unsigned long long* star_acc = nullptr);
 // border table maintenance: re-insert list entries [0, n) after the host grew the table
 void launch_border_rehash(hipStream_t s, const DevForestView& f, int n);
 

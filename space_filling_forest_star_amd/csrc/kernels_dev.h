@@ -29,4 +29,35 @@ __device__ __forceinline__ void grid_put(const GridView& g, const GridItem& it) 
   }
 }
 
+// ---- exact k nearest: the wave-resident top-k list shared by k_knn_linear / k_knn_grid (kernels.hip) and k_star_knn
+// (devstar.hip)
+// The wave's k best so far: lane j holds the j-th smallest (distance, id) key; lanes >= have hold +inf.
+struct TopK {
+  double d;
+  int id;
+};
+__device__ __forceinline__ bool key_less(double da, int ia, double db, int ib) { return da < db || (da == db && ia < ib); }
+// inserts the candidates flagged in `take` (one per lane: cd, cid), smallest lanes first; k = capacity, have = filled
+__device__ __forceinline__ void topk_insert(TopK& t, int lane, int k, int& have, unsigned long long take, double cd, int cid) {
+  while (take) {
+    const int src = __ffsll((long long)take) - 1;
+    take &= take - 1;
+    const double nd = __shfl(cd, src);
+    const int ni = __shfl(cid, src);
+    // rank of the newcomer = entries that sort before it
+    const bool before = lane < have && key_less(t.d, t.id, nd, ni);
+    const int rank = __popcll(__ballot(before));
+    if (rank >= k) continue;                       // (beaten by k entries that arrived in the meantime)
+    const double pd = __shfl_up(t.d, 1);
+    const int pi = __shfl_up(t.id, 1);
+    if (lane > rank) { t.d = pd; t.id = pi; }
+    else if (lane == rank) { t.d = nd; t.id = ni; }
+    if (have < k) ++have;
+  }
+}
+__device__ __forceinline__ double topk_worst(const TopK& t, int k, int have) {   // current k-th distance (inf while not full)
+  return have < k ? 1.0e300 : __shfl(t.d, k - 1);
+}
+
+
 }  // namespace sffk

@@ -45,12 +45,12 @@ class engine:
                 os.environ[k] = v
 
 
-def make(S, ctx, name, wave, iters, seed, n_roots=5, budget=0, which="device", **env):
+def make(S, ctx, name, wave, iters, seed, n_roots=5, budget=0, which="device", optimize=False, **env):
     sc, w = load_world(ctx, name)
     roots = sc["xml_points"][:n_roots] if sc["xml_points"] is not None else \
         common.free_roots(w.collide, sc["limits"], n_roots, seed=seed, dim=sc["dim"])
     kw = dict(dist_tree=sc["dist_tree"], sampling_dist=sc["sampling_dist"], dim=sc["dim"], max_iterations=iters,
-              node_budget=budget, wave=wave, seed=seed)
+              node_budget=budget, wave=wave, seed=seed, optimize=optimize)
     fo = O.Forest(w, roots, sc["limits"], **kw)
     with engine(SFFGPU_ENGINE=which, **env):
         fg = S.Forest(ctx, roots, sc["limits"], **kw)
@@ -68,6 +68,72 @@ def test_device_engine_equals_the_oracle(S, ctx, name, wave, iters):
     fo.run()
     fg.run()
     assert fo.stats()["n_nodes"] > 40
+    assert_same_forest(fo, fg)
+
+
+@pytest.mark.parametrize("name,wave,iters", [
+    ("dense3d", 1, 500), ("dense3d", 7, 2500), ("dense3d", 64, 8000), ("dense3d", 512, 40000), ("dense3d", 4096, 150000),
+    ("dense3d_coarse", 64, 8000), ("dense3d_coarse", 1024, 30000),
+    ("triang", 1, 600), ("triang", 128, 10000), ("triang", 2048, 60000),
+    ("dense2d", 3, 1500), ("dense2d", 256, 8000), ("building", 256, 8000), ("building", 2048, 80000),
+])
+def test_sff_star_on_the_device_engine_equals_the_oracle(S, ctx, name, wave, iters):
+    """SFF* (optimize = true) with the rounds committed on the GPU: the k-nearest sets, choose-parent and the rewires
+    (src/forest.h:307-351) of the samples a round accepts are the fixed point of "sample i sees the rewires of every
+    accepted sample before it" (csrc/devstar.hip) - parents, costs, borders and the reference-equivalent call counters
+    must equal the oracle's sequential loop."""
+    fo, fg = make(S, ctx, name, wave, iters, seed=5, optimize=True)
+    assert fg.device_engine()
+    fo.run()
+    fg.run()
+    assert fo.stats()["n_nodes"] > 40
+    assert_same_forest(fo, fg)
+    sg = fg.stats()
+    assert sg["star_rounds"] > 0 and sg["star_passes"] >= sg["star_rounds"] and sg["star_members"] > 0
+    assert sg["host_fallback_waves"] == 0
+    no = fo.nodes()
+    if len(no["parent"]) > 300:
+        # rewiring really happened: some node's parent is younger than the node itself
+        assert np.any(no["parent"] > np.arange(len(no["parent"]))) and sg["star_rewires"] > 0
+
+
+def test_sff_star_device_engine_staged_runs_and_the_host_engine(S, ctx):
+    """SFF* on the device engine in stages with getters in between (the host mirror has to pick up rewired parents and
+    costs of nodes it already holds), against the oracle and against the host-replay engine."""
+    fo, fg = make(S, ctx, "dense3d", 512, 10 ** 7, seed=8, budget=15000, optimize=True)
+    fo.run()
+    fps = []
+    while True:
+        w0 = fg.stats()["waves"]
+        fg.run(4)
+        if fg.stats()["waves"] == w0:
+            break
+        fps.append(fg.fingerprint())
+        assert len(fg.nodes()["parent"]) == fg.stats()["n_nodes"]
+    assert len(fps) > 3
+    assert_same_forest(fo, fg)
+    do = fo.paths()
+    dg, _ = fg.paths()
+    assert np.array_equal(do, dg)
+    fp, sd = fg.fingerprint(), fg.stats()
+    fg.close()
+    _, fh = make(S, ctx, "dense3d", 512, 10 ** 7, seed=8, budget=15000, optimize=True, which="host")
+    assert not fh.device_engine()
+    fh.run()
+    assert fh.fingerprint() == fp
+    sh = fh.stats()
+    for k in ("iterations", "n_nodes", "n_borders", "collide_calls", "path_free_calls", "nn_queries", "waves"):
+        assert sd[k] == sh[k], k
+
+
+@pytest.mark.parametrize("env", [dict(SFFGPU_TEST_HITCAP=3), dict(SFFGPU_TEST_NBCAP=1), dict(SFFGPU_TEST_STAR_PASSES=1)])
+def test_sff_star_device_faults_finish_the_wave_on_the_host_path(S, ctx, env):
+    """a bounded device list that overflows - or a rewire fixed point that does not settle within the launches of a round
+    (forced: one pass only) - hands the wave to the host-replay engine; the forest must not change"""
+    fo, fg = make(S, ctx, "dense3d_coarse", 256, 12000, seed=4, optimize=True, **env)
+    fo.run()
+    fg.run()
+    assert fg.stats()["host_fallback_waves"] > 0
     assert_same_forest(fo, fg)
 
 
