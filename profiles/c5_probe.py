@@ -29,4 +29,7 @@ st = f.stats()
 print(json.dumps({"config": "building.obj 20 roots SFF* budget %d wave %d" % (budget, wave), "nodes": st["n_nodes"],
                   "iterations": st["iterations"], "solved": st["solved"], "seconds": dt,
                   "accepted_nodes_per_s": (st["n_nodes"] - 20) / dt, "collision_checks_per_s": st["collide_calls"] / dt,
-                  "host_ms": st["host_ms"], "sweep_ms": st["sweep_ms"], "collide_ms": st["collide_ms"]}))
+                  "host_ms": st["host_ms"], "total_ms": st["total_ms"], "sweep_ms": st["sweep_ms"], "collide_ms": st["collide_ms"],
+                  "device_engine": bool(f.device_engine()), "waves": st["waves"], "rounds": st["sweeps"],
+                  "star_rounds": st["star_rounds"], "star_passes": st["star_passes"], "star_members": st["star_members"],
+                  "star_rewires": st["star_rewires"], "host_fallback_waves": st["host_fallback_waves"]}))

@@ -431,6 +431,36 @@ def test_c5_building_sff_star_full_run_properties(S, ctx):
     f.close()
 
 
+@pytest.mark.parametrize("fixture", ["c5_full_run.json", "c5_full_run_w8192.json"])
+def test_c5_building_sff_star_whole_job_equals_the_oracle(S, ctx, golden_dir, fixture):
+    """BASELINE configs[4] run to its END (building.obj, 20 seeded roots, SFF* with rewire, 2 M-node budget): the forest
+    saturates - frontier empty, every tree connected, "solved" - at about 2e5 nodes, so the WHOLE job is pinned against
+    the CPU oracle (tests/golden/make_c5_full.py; waves of 4096 and of 8192 slots): fingerprint over every node,
+    counters, checksums.  Runs on the device-resident engine (rewire fixed point on the GPU, csrc/devstar.hip)."""
+    import json
+    import os
+    path = os.path.join(golden_dir, fixture)
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/%s not generated" % fixture)
+    g = json.load(open(path))
+    sc, w = load_world(ctx, "building")
+    roots = common.free_roots(w.collide, sc["limits"], 20, seed=1, dim=sc["dim"])
+    f = S.Forest(ctx, roots, sc["limits"], dist_tree=sc["dist_tree"], sampling_dist=sc["sampling_dist"], dim=6, optimize=True,
+                 max_iterations=2**31 - 1, node_budget=2000000, wave=g["wave"], seed=1)
+    assert f.device_engine()
+    f.run()
+    s, n = f.stats(), f.nodes()
+    got = {"waves": int(s["waves"]), "fingerprint": "%016x" % f.fingerprint(), "n_nodes": int(s["n_nodes"]),
+           "iterations": int(s["iterations"]), "collide_calls": int(s["collide_calls"]), "solved": int(s["solved"]),
+           "path_free_calls": int(s["path_free_calls"]), "nn_queries": int(s["nn_queries"]), "n_borders": int(s["n_borders"]),
+           "frontier_size": int(s["frontier_size"]),
+           "parent_sum": int(n["parent"].astype(np.int64).sum()), "cost_sum": float(n["cost"].sum()).hex()}
+    for k in got:
+        assert got[k] == g[k], (k, got[k], g[k])
+    assert got["solved"] == 1 and got["frontier_size"] == 0 and s["host_fallback_waves"] == 0
+    f.close()
+
+
 def test_baseline_configs_equal_the_oracle(S, ctx, golden_dir):
     """BASELINE.json configs[0] (2-D, 3 roots, 10 k nodes) and configs[1] (triang, 5 roots, 100 k nodes) in full and configs[4] (building, 20 roots, SFF* with
     rewire) at a 150 k-node budget: the GPU runs reproduce the committed oracle summaries
