@@ -663,6 +663,15 @@ __global__ __launch_bounds__(DF_THREADS) void k_resolve(ResolveArgs A) {
   for (int g = threadIdx.x; g < ng; g += DF_THREADS) L.words[g] = W_acc[g];
   const int n_acc = wg_prefix(L, n);
   for (int g = threadIdx.x; g < ng; g += DF_THREADS) { f.w_acc[g] = L.words[g]; f.acc_pref[g] = L.pref[g]; W_accp[g] = L.pref[g]; }
+  if (A.star)   // SFF*: the accepted samples as a list (rank -> sample), for the star stage
+    for (int g = threadIdx.x; g < ng; g += DF_THREADS) {
+      unsigned long long w = L.words[g];
+      int at = L.pref[g];
+      while (w) {
+        A.S.acc_sample[at++] = g * 64 + __ffsll((long long)w) - 1;
+        w &= w - 1;
+      }
+    }
   __syncthreads();
   auto id_of = [&](int j) {   // node id of sample j, accepted in this round
     return N0 + W_accp[j >> 6] + __popcll(W_acc[j >> 6] & ((1ULL << (j & 63)) - 1ULL));

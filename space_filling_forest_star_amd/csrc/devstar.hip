@@ -32,12 +32,10 @@ __device__ __forceinline__ bool star_accepted(const DevForestView& f, int i, int
   return (w >> (i & 63)) & 1ULL;
 }
 
-// candidates of a group of up to 64 cells (lane = cell, m = its item count), flattened over the lanes.
-// store = true: the node grid (permanent nodes of the sample's tree); false: the round's own grid - samples accepted
-// EARLIER in the round (temporary id < self), of the same tree, not farther than `limit`
-__device__ __forceinline__ void star_cells(const GridView& g, int m, int cell, int lane, const double* qp, int tree, bool store,
-                                           int N0, int Tb, int self, double limit, const DevForestView& f, TopK& t, int k,
-                                           int& have) {
+// candidates of a group of up to 64 cells of the node grid (lane = cell, m = its item count), flattened over the lanes:
+// permanent nodes (id < N0) of the sample's tree
+__device__ __forceinline__ void star_cells(const GridView& g, int m, int cell, int lane, const double* qp, int tree, int N0,
+                                           TopK& t, int k, int& have) {
   int inc = m;
   for (int off = 1; off < 64; off <<= 1) {
     const int o = __shfl_up(inc, off);
@@ -60,14 +58,44 @@ __device__ __forceinline__ void star_cells(const GridView& g, int m, int cell, i
     if (j < total) {
       const GridItem it = g.items[(size_t)src_cell * g.bk + slot];
       id = it.id;
-      if (it.tree == tree) {
-        if (store) cand = id < N0;
-        else {
-          int rk;
-          cand = id >= Tb && id < self && star_accepted(f, id - Tb, rk);
-        }
-        if (cand) d = dist6(it.p, qp);
-        if (cand && !store) cand = d <= limit;
+      if (it.tree == tree && id < N0) { d = dist6(it.p, qp); cand = true; }
+    }
+    const double worst = topk_worst(t, k, have);
+    cand = cand && (have < k || key_less(d, id, worst, 0x7fffffff));
+    topk_insert(t, lane, k, have, __ballot(cand), d, id);
+  }
+}
+
+// the same over cells of the round's own grid: samples accepted EARLIER in the round (temporary id in [Tb, self)) of
+// the same tree, not farther than `limit`
+__device__ __forceinline__ void star_cells_mates(const GridView& tg, int m, int cell, int lane, const double* qp, int tree, int Tb,
+                                                 int self, double limit, const DevForestView& f, TopK& t, int k, int& have) {
+  int inc = m;
+  for (int off = 1; off < 64; off <<= 1) {
+    const int o = __shfl_up(inc, off);
+    if (lane >= off) inc += o;
+  }
+  const int total = __shfl(inc, 63);
+  for (int base = 0; base < total; base += 64) {
+    const int j = base + lane;
+    const int jj = j < total ? j : total - 1;
+    int lo = 0, hi = 63;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (__shfl(inc, mid) > jj) hi = mid; else lo = mid + 1;
+    }
+    const int src_cell = __shfl(cell, lo);
+    const int slot = jj - (__shfl(inc, lo) - __shfl(m, lo));
+    bool cand = false;
+    double d = 1.0e300;
+    int id = 0x7fffffff;
+    if (j < total) {
+      const GridItem it = tg.items[(size_t)src_cell * tg.bk + slot];
+      id = it.id;
+      int rk;
+      if (it.tree == tree && id >= Tb && id < self && star_accepted(f, id - Tb, rk)) {
+        d = dist6(it.p, qp);
+        cand = d <= limit;
       }
     }
     const double worst = topk_worst(t, k, have);
@@ -76,15 +104,18 @@ __device__ __forceinline__ void star_cells(const GridView& g, int m, int cell, i
   }
 }
 
-// ------------------------------------------------------------------ k nearest + member edges + toucher lists
+// ------------------------------------------------------------------ k nearest + toucher lists
+#define STAR_R0 2                                   // half-width (cells) of the cube gathered in one go
+#define STAR_CUBE ((2 * STAR_R0 + 1) * (2 * STAR_R0 + 1) * (2 * STAR_R0 + 1))
+#define STAR_U ((STAR_CUBE + 63) / 64)
 __global__ __launch_bounds__(256) void k_star_knn(ResolveArgs A, GridView g, GridView tg, NodeStoreView st, double cell_edge,
                                                   double slack) {
   const DevForestView& f = A.f;
   const StarView& S = A.S;
   const DevCtrl* c = f.ctrl;
   const int n = c->app_n;
-  if (blockIdx.x == 0 && threadIdx.x < 32) S.ectrl[threadIdx.x] = 0;                       // the member-edge pipeline's block
   if (blockIdx.x == 0 && threadIdx.x < SFFK_STAR_PASSES) S.changed[threadIdx.x] = 0;
+  for (int t = blockIdx.x * 256 + threadIdx.x; t < SFFK_STAR_PASSES * SFFK_SUBLISTS * SFFK_STAR_SUB; t += gridDim.x * 256) S.sub[t] = 0;
   if (n <= 0) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + wave;
@@ -93,6 +124,9 @@ __global__ __launch_bounds__(256) void k_star_knn(ResolveArgs A, GridView g, Gri
   if (!star_accepted(f, i, r)) return;
   const int N0 = c->app_N0, Tb = f.temp_base;
   const unsigned ep = (unsigned)c->epoch;
+  const unsigned long long dbg_t0 = S.dbg ? wall_clock64() : 0ULL;
+  unsigned long long dbg_t1 = 0, dbg_t2 = 0, dbg_t3 = 0;
+  int dbg_shells = 0, dbg_total = 0;
   // k = (size_t)(2e log10(#nodes)) with the nodes accepted before this sample counted in (src/forest.h:309)
   const int Nn = N0 + r;
   const int k_ref = __popcll(__ballot(lane > 0 && lane <= SFFK_STAR_KMAX + 1 && S.ktab[lane] <= Nn));
@@ -101,6 +135,10 @@ __global__ __launch_bounds__(256) void k_star_knn(ResolveArgs A, GridView g, Gri
   double qp[6];
   for (int q = 0; q < 6; ++q) qp[q] = A.newpos[6 * (size_t)i + q];
   const int tcnt = S.tree_cnt[16 * mine];
+  {   // the sample's edge slots: nothing asked for yet
+    const size_t s0 = ((size_t)i * SFFK_STAR_KC + lane) * 2;
+    S.ew[s0] = 0; S.ew[s0 + 1] = 0;
+  }
   if (k_ref > SFFK_STAR_KMAX) {   // (a node count beyond what the member slots are sized for: host path)
     if (lane == 0) atomicOr(S.hdr + STAR_FAULT, 1);
     return;
@@ -112,8 +150,27 @@ __global__ __launch_bounds__(256) void k_star_knn(ResolveArgs A, GridView g, Gri
   if (k > 0) {
     const int cx = grid_coord((float)qp[0], g.ox, g.inv_cell, g.nx), cy = grid_coord((float)qp[1], g.oy, g.inv_cell, g.ny),
               cz = grid_coord((float)qp[2], g.oz, g.inv_cell, g.nz);
-    {   // the node grid's shared overflow list first (usually empty)
-      int no = g.ovf_cnt[0];
+    // ---- the cube of half-width STAR_R0 in one go: every cell's count is requested before anything is looked at (one
+    // trip to memory instead of one per shell), then the cube's candidates are flattened over the lanes
+    int cellv[STAR_U], mv[STAR_U];
+    const int no_raw = g.ovf_cnt[0];
+#pragma unroll
+    for (int u = 0; u < STAR_U; ++u) {
+      const int cc = u * 64 + lane;
+      cellv[u] = 0; mv[u] = 0;
+      if (cc < STAR_CUBE) {
+        const int W5 = 2 * STAR_R0 + 1;
+        const int x = cx + cc % W5 - STAR_R0, y = cy + (cc / W5) % W5 - STAR_R0, z = cz + cc / (W5 * W5) - STAR_R0;
+        if (x >= 0 && x < g.nx && y >= 0 && y < g.ny && z >= 0 && z < g.nz) {
+          cellv[u] = (z * g.ny + y) * g.nx + x;
+          mv[u] = g.cnt[cellv[u]];
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < STAR_U; ++u) if (mv[u] > g.bk) mv[u] = g.bk;
+    {   // the node grid's shared overflow list (usually empty)
+      int no = no_raw;
       if (no > g.ovf_cap) no = g.ovf_cap;
       for (int base = 0; base < no; base += 64) {
         const int j = base + lane;
@@ -132,54 +189,118 @@ __global__ __launch_bounds__(256) void k_star_knn(ResolveArgs A, GridView g, Gri
         topk_insert(t, lane, k, have, __ballot(cand), d, id);
       }
     }
-    // shells of cells around the sample's cell; after shell r every node within r * cell_edge (minus the fp32 slack
-    // of the cell assignment) has been seen.  A tree with fewer than k nodes is complete as soon as all of them are in.
-    const int rmax = max(max(g.nx, g.ny), g.nz);
-    for (int rr = 0; rr <= rmax; ++rr) {
-      if (have >= k_store && k_store == tcnt) break;      // the whole tree is in the list
-      const int w = 2 * rr + 1;
-      const int total = w * w * w;
-      for (int c0 = 0; c0 < total; c0 += 64) {
-        const int cc = c0 + lane;
-        int cell = 0, m = 0;
-        if (cc < total) {
-          const int ox = cc % w - rr, oy = (cc / w) % w - rr, oz = cc / (w * w) - rr;
-          const bool shell = ox == -rr || ox == rr || oy == -rr || oy == rr || oz == -rr || oz == rr;
-          const int x = cx + ox, y = cy + oy, z = cz + oz;
-          if (shell && x >= 0 && x < g.nx && y >= 0 && y < g.ny && z >= 0 && z < g.nz) {
-            cell = (z * g.ny + y) * g.nx + x;
-            m = g.cnt[cell];
-            if (m > g.bk) m = g.bk;
+    {
+      int mine_sum = 0;
+#pragma unroll
+      for (int u = 0; u < STAR_U; ++u) mine_sum += mv[u];
+      int inc = mine_sum;
+      for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(inc, off);
+        if (lane >= off) inc += o;
+      }
+      const int total = __shfl(inc, 63);
+      dbg_total = total;
+      // two batches of 64 candidates per step: their item loads are in flight together
+      for (int base = 0; base < total; base += 128) {
+        GridItem it[2];
+        bool val[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int j = base + 64 * h + lane;
+          const int jj = j < total ? j : total - 1;
+          int lo = 0, hi = 63;
+          while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (__shfl(inc, mid) > jj) hi = mid; else lo = mid + 1;
           }
+          int rest = jj - (__shfl(inc, lo) - __shfl(mine_sum, lo));   // index among the owner lane's items
+          int src_cell = 0;
+#pragma unroll
+          for (int u = 0; u < STAR_U; ++u) {
+            const int mu = __shfl(mv[u], lo), cu = __shfl(cellv[u], lo);
+            if (rest >= 0 && rest < mu) { src_cell = cu; rest += 1 << 20; }   // (found: park the index out of every later range)
+            else if (rest >= 0 && rest < (1 << 20)) rest -= mu;
+          }
+          val[h] = j < total;
+          it[h].id = 0x7fffffff; it[h].tree = -1;
+          if (val[h]) it[h] = g.items[(size_t)src_cell * g.bk + (rest - (1 << 20))];
         }
-        if (__any(m > 0)) star_cells(g, m, cell, lane, qp, mine, true, N0, Tb, self, 0.0, f, t, k, have);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          if (base + 64 * h >= total) break;
+          bool cand = false;
+          double d = 1.0e300;
+          const int id = it[h].id;
+          if (val[h] && it[h].tree == mine && id < N0) { d = dist6(it[h].p, qp); cand = true; }
+          const double worst = topk_worst(t, k, have);
+          cand = cand && (have < k || key_less(d, id, worst, 0x7fffffff));
+          topk_insert(t, lane, k, have, __ballot(cand), d, id);
+        }
+      }
+    }
+    // ---- beyond the cube (rare: young, sparse trees): shells of cells until the k-th distance lies inside the covered
+    // ball; a tree with fewer than k nodes is complete as soon as all of them are in
+    const int rmax = max(max(g.nx, g.ny), g.nz);
+    if (S.dbg) dbg_t1 = wall_clock64();
+    for (int rr = STAR_R0; rr <= rmax; ++rr) {
+      if (have >= k_store && k_store == tcnt) break;      // the whole tree is in the list
+      if (rr > STAR_R0) {
+        ++dbg_shells;
+        const int w = 2 * rr + 1;
+        const int total = w * w * w;
+        for (int c0 = 0; c0 < total; c0 += 64) {
+          const int cc = c0 + lane;
+          int cell = 0, m = 0;
+          if (cc < total) {
+            const int ox = cc % w - rr, oy = (cc / w) % w - rr, oz = cc / (w * w) - rr;
+            const bool shell = ox == -rr || ox == rr || oy == -rr || oy == rr || oz == -rr || oz == rr;
+            const int x = cx + ox, y = cy + oy, z = cz + oz;
+            if (shell && x >= 0 && x < g.nx && y >= 0 && y < g.ny && z >= 0 && z < g.nz) {
+              cell = (z * g.ny + y) * g.nx + x;
+              m = g.cnt[cell];
+              if (m > g.bk) m = g.bk;
+            }
+          }
+          if (__any(m > 0)) star_cells(g, m, cell, lane, qp, mine, N0, t, k, have);
+        }
       }
       const double covered = (double)rr * cell_edge - slack;
       if (have >= k && topk_worst(t, k, have) <= covered) break;
       if (cx - rr <= 0 && cy - rr <= 0 && cz - rr <= 0 && cx + rr >= g.nx - 1 && cy + rr >= g.ny - 1 && cz + rr >= g.nz - 1) break;
     }
-    // the samples accepted earlier in this round (same tree): not farther than the k-th store node, or - while the
-    // store holds fewer than k nodes of the tree - all of them (read straight from the temporary store entries)
-    if (i > 0) {
+    // ---- the samples accepted earlier in this round (ranks below this one's, k_resolve's list) of the same tree: not
+    // farther than the k-th store node - or, while the store holds fewer than k nodes of the tree, all of them
+    if (S.dbg) dbg_t2 = wall_clock64();
+    if (r > 0) {
       const bool all = have < k;
-      if (all) {
-        for (int base = 0; base < i; base += 64) {
-          const int j = base + lane;
-          bool cand = false;
-          double d = 1.0e300;
-          int rk;
-          if (j < i && star_accepted(f, j, rk) && st.tree[Tb + j] == mine) {
-            double mp[6];
-            for (int q = 0; q < 6; ++q) mp[q] = st.pos[6 * (size_t)(Tb + j) + q];
-            d = dist6(mp, qp);
-            cand = true;
+      const double limit = all ? 1.0e300 : topk_worst(t, k, have);
+      if (all || r <= 256) {
+        // few of them (or all are wanted): k_resolve's list, four batches of 64 ranks per step (their loads in flight together)
+        for (int base = 0; base < r; base += 256) {
+          int sidv[4], trv[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { const int rq = base + 64 * u + lane; sidv[u] = rq < r ? Tb + S.acc_sample[rq] : -1; }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) trv[u] = sidv[u] >= 0 ? st.tree[sidv[u]] : -1;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            if (base + 64 * u >= r) break;
+            bool cand = sidv[u] >= 0 && trv[u] == mine;
+            if (!__any(cand)) continue;
+            double d = 1.0e300;
+            if (cand) {
+              double mp[6];
+              for (int q = 0; q < 6; ++q) mp[q] = st.pos[6 * (size_t)sidv[u] + q];
+              d = dist6(mp, qp);
+              cand = d <= limit;
+            }
+            const double worst = topk_worst(t, k, have);
+            cand = cand && (have < k || key_less(d, sidv[u], worst, 0x7fffffff));
+            topk_insert(t, lane, k, have, __ballot(cand), d, sidv[u]);
           }
-          const double worst = topk_worst(t, k, have);
-          cand = cand && (have < k || key_less(d, Tb + j, worst, 0x7fffffff));
-          topk_insert(t, lane, k, have, __ballot(cand), d, Tb + j);
         }
       } else {
-        const double limit = topk_worst(t, k, have);
+        // a large round: the round's own grid, cells of the cube around the ball of the k-th store node
         int rr = (int)((limit + slack) / cell_edge) + 1;
         if (rr > rmax) rr = rmax;
         const int w = 2 * rr + 1;
@@ -195,7 +316,7 @@ __global__ __launch_bounds__(256) void k_star_knn(ResolveArgs A, GridView g, Gri
               if (maybe) { m = tg.cnt[cell]; if (m > tg.bk) m = tg.bk; }
             }
           }
-          if (__any(m > 0)) star_cells(tg, m, cell, lane, qp, mine, false, N0, Tb, self, limit, f, t, k, have);
+          if (__any(m > 0)) star_cells_mates(tg, m, cell, lane, qp, mine, Tb, self, limit, f, t, k, have);
         }
         int no = tg.ovf_cnt[0];
         if (no > tg.ovf_cap) no = tg.ovf_cap;
@@ -219,7 +340,8 @@ __global__ __launch_bounds__(256) void k_star_knn(ResolveArgs A, GridView g, Gri
       }
     }
   }
-  // ---- the members: ids, distances, toucher lists, the two edge tasks each
+  if (S.dbg) dbg_t3 = wall_clock64();
+  // ---- the members: ids, distances, toucher lists
   const int cnt = have;
   const bool mem = lane < cnt;
   int node = -1;
@@ -236,30 +358,20 @@ __global__ __launch_bounds__(256) void k_star_knn(ResolveArgs A, GridView g, Gri
     const unsigned long long old = atomicExch(&S.head[node], mark);
     S.next[p] = (unsigned)(old >> 32) == ep ? (int)(unsigned)(old & 0xffffffffULL) : 0;
   }
-  {
-    const size_t s0 = ((size_t)r * SFFK_STAR_KC + lane) * 2;
-    if (mem) {
-      double mp[6];
-      for (int q = 0; q < 6; ++q) mp[q] = st.pos[6 * (size_t)t.id + q];
-      double* fa = S.seg_a + 6 * s0;
-      double* fb = S.seg_b + 6 * s0;
-      for (int q = 0; q < 6; ++q) { fa[q] = qp[q]; fb[q] = mp[q]; fa[6 + q] = mp[q]; fb[6 + q] = qp[q]; }   // :323 / :336
-      const int ns = edge_samples(edge_parts(qp, mp));
-      S.seg_ns[s0] = ns; S.seg_ns[s0 + 1] = edge_samples(edge_parts(mp, qp));
-    } else {
-      S.seg_ns[s0] = -1; S.seg_ns[s0 + 1] = -1;
-    }
-    S.first_hit[s0] = 0x7fffffff; S.first_hit[s0 + 1] = 0x7fffffff;
-    S.seg_ovf[s0] = 0; S.seg_ovf[s0 + 1] = 0;
-  }
   if (lane == 0) {
     S.m_cnt[i] = cnt;
-    S.acc_sample[r] = i;
     const int ex = A.parent[i];
     S.best[i] = A.pdist[i] + f.d_root[ex];   // (first guess: the plain SFF cost)
     S.psel[i] = ex;
     S.dcl[i] = A.pdist[i];
     S.cnt[2 * (size_t)i] = 0ULL; S.cnt[2 * (size_t)i + 1] = 0ULL;
+    if (S.dbg && k > 0) {   // waves | ticks: cube, shells, mates, lists | shells walked | cube candidates | longest wave
+      const unsigned long long t4 = wall_clock64();
+      atomicAdd(S.dbg + 0, 1ULL); atomicAdd(S.dbg + 1, dbg_t1 - dbg_t0); atomicAdd(S.dbg + 2, dbg_t2 - dbg_t1);
+      atomicAdd(S.dbg + 3, dbg_t3 - dbg_t2); atomicAdd(S.dbg + 4, t4 - dbg_t3); atomicAdd(S.dbg + 5, (unsigned long long)dbg_shells);
+      atomicAdd(S.dbg + 6, (unsigned long long)dbg_total); atomicMax(S.dbg + 7, t4 - dbg_t0);
+      if (dbg_shells) atomicAdd(S.dbg + 8, 1ULL);
+    }
   }
 }
 
@@ -284,13 +396,21 @@ __device__ __forceinline__ double star_view(const DevForestView& f, const StarVi
 }
 
 // ------------------------------------------------------------------ one pass of the fixed point
-__global__ __launch_bounds__(256) void k_star_pass(ResolveArgs A, int pass, int sample_blocks) {
+#define STAR_SURV 48   // survivors of a sample gathered in LDS before they are appended (one atomic)
+#define STAR_TAB 128   // (edge, chunk) pairs of a sample unfolded at a time
+__device__ __forceinline__ int star_pack(int calls, bool free_) { return (((calls << 1) | (free_ ? 1 : 0)) << 1) | 1; }
+
+__global__ __launch_bounds__(256) void k_star_pass(ResolveArgs A, EnvView env, NodeStoreView st, int pass, int sample_blocks) {
+  __shared__ SurvivorItem s_surv[4][STAR_SURV];
+  __shared__ int32_t s_tab[4][STAR_TAB];
+  __shared__ float s_edge[4][128][8];     // per requested edge (lane * 2 + dir): start (clearance cells), step, samples
+  __shared__ int32_t s_any[4][128];       // ... 1 = some chunk of it went to the exact kernel
   const DevForestView& f = A.f;
   const StarView& S = A.S;
   const DevCtrl* c = f.ctrl;
   if (c->app_n <= 0 || S.hdr[1] || S.hdr[STAR_FAULT]) return;
   if (pass > 0 && S.changed[pass - 1] == 0) return;        // the pass before wrote nothing: fixed point reached
-  const int N0 = c->app_N0;
+  const int N0 = c->app_N0, Tb = f.temp_base;
   const unsigned ep = (unsigned)c->epoch;
   if ((int)blockIdx.x >= sample_blocks) {
     // border entries of the round (src/forest.h:288-294): d = cost(neighbour) + cost(expanded) + their distance, the
@@ -312,24 +432,186 @@ __global__ __launch_bounds__(256) void k_star_pass(ResolveArgs A, int pass, int 
   const int ex = A.parent[i];
   const int x = mem ? S.m_id[p] : (lane == cnt ? ex : -1);
   const double d = mem ? S.m_d[p] : 0.0;
-  // the member edges' answers: free, and the Collide calls isPathFree makes (early exit at the first hit)
-  const size_t s0 = ((size_t)r * SFFK_STAR_KC + lane) * 2;
-  int fh_f = 0x7fffffff, fh_b = 0x7fffffff, ns_f = 0, ns_b = 0;
-  if (mem) { fh_f = S.first_hit[s0]; fh_b = S.first_hit[s0 + 1]; ns_f = S.seg_ns[s0]; ns_b = S.seg_ns[s0 + 1]; }
-  if (__any(mem && (fh_f == 0 || fh_b == 0))) {   // an edge's triangle candidate list ran over: host path
-    if (lane == 0) atomicOr(S.hdr + STAR_FAULT, 1);
-    return;
-  }
-  const bool free_f = fh_f == 0x7fffffff, free_b = fh_b == 0x7fffffff;
-  const unsigned long long calls_f = free_f ? (unsigned long long)ns_f : (unsigned long long)fh_f;
-  const unsigned long long calls_b = free_b ? (unsigned long long)ns_b : (unsigned long long)fh_b;
-  const double v = x >= 0 ? star_view(f, S, x, i, N0, ep) : 0.0;
-  // ---- choose parent (:320-327): the members in (distance, id) order against the running best
+  const size_t s0 = p * 2;
+  int ew_f = mem ? S.ew[s0] : 0, ew_b = mem ? S.ew[s0 + 1] : 0;
   const double pd = A.pdist[i];
-  double best = pd + __shfl(v, cnt);           // dist(new, expanded) + expanded->DistanceToRoot (:308)
+  const double v = x >= 0 ? star_view(f, S, x, i, N0, ep) : 0.0;
+  // ---- edges sent to the exact kernel by the pass before: their answers are in
+  {
+    bool bad = false;
+    if (ew_f == -1) {
+      const int fh = S.first_hit[s0], ns = S.ens[s0];
+      bad |= fh == 0;                                     // 0 = the edge's triangle candidate list ran over
+      ew_f = star_pack(fh == 0x7fffffff ? ns : fh, fh == 0x7fffffff);
+      S.ew[s0] = ew_f;
+    }
+    if (ew_b == -1) {
+      const int fh = S.first_hit[s0 + 1], ns = S.ens[s0 + 1];
+      bad |= fh == 0;
+      ew_b = star_pack(fh == 0x7fffffff ? ns : fh, fh == 0x7fffffff);
+      S.ew[s0 + 1] = ew_b;
+    }
+    if (__any(bad)) {
+      if (lane == 0) atomicOr(S.hdr + STAR_FAULT, 1);
+      return;
+    }
+  }
+  // ---- which member edges can the two loops reach at all, given the views?  Choose-parent (:320-327) only looks at a
+  // member whose cost through it beats the running best, and the running best never exceeds its start value; the rewire
+  // loop (:332-350) only at a member the new node's cost - at least the smallest cost any member offers - improves.
+  const double best0 = pd + __shfl(v, cnt);           // dist(new, expanded) + expanded->DistanceToRoot (:308)
+  const double nd = d + v;
+  const bool need_f = mem && nd < best0 - SFFG_TOL;
+  double best_low = need_f ? nd : best0;
+  for (int off = 32; off > 0; off >>= 1) {
+    const double o = __shfl_xor(best_low, off);
+    best_low = o < best_low ? o : best_low;
+  }
+  const bool need_b = mem && best_low + d < v - SFFG_TOL;
+  const bool req_f = need_f && ew_f == 0, req_b = need_b && ew_b == 0;
+  if (__any(req_f || req_b)) {
+    // ---- new requests: sample counts, then the clearance cull of their samples right here (~97 % of the chunks are
+    // answered "free" by the bits); what is not goes onto the exact kernel's list and is answered before the next pass
+    const double qp[6] = {A.newpos[6 * (size_t)i], A.newpos[6 * (size_t)i + 1], A.newpos[6 * (size_t)i + 2],
+                          A.newpos[6 * (size_t)i + 3], A.newpos[6 * (size_t)i + 4], A.newpos[6 * (size_t)i + 5]};
+    int nch_f = 0, nch_b = 0, ns_f = 0, ns_b = 0;
+    const int sid = mem ? (x < N0 ? x : Tb + S.acc_sample[x - N0]) : 0;
+    if (req_f || req_b) {
+      double mp[6];
+      for (int q = 0; q < 6; ++q) mp[q] = st.pos[6 * (size_t)sid + q];
+      float* ef = s_edge[wave][2 * lane];
+      float* eb = s_edge[wave][2 * lane + 1];
+      if (req_f) {
+        const double parts = edge_parts(qp, mp);
+        ns_f = edge_samples(parts);
+        nch_f = ns_f > 0 ? (ns_f + 63) >> 6 : 0;
+        const float inv = (float)env.clear_inv * __frcp_rn((float)parts);
+        for (int q = 0; q < 3; ++q) {
+          ef[q] = (float)((qp[q] - env.clear_org[q]) * env.clear_inv);
+          ef[4 + q] = (float)(mp[q] - qp[q]) * inv;
+        }
+        ef[3] = __int_as_float(ns_f);
+        s_any[wave][2 * lane] = 0;
+      }
+      if (req_b) {
+        const double parts = edge_parts(mp, qp);
+        ns_b = edge_samples(parts);
+        nch_b = ns_b > 0 ? (ns_b + 63) >> 6 : 0;
+        const float inv = (float)env.clear_inv * __frcp_rn((float)parts);
+        for (int q = 0; q < 3; ++q) {
+          eb[q] = (float)((mp[q] - env.clear_org[q]) * env.clear_inv);
+          eb[4 + q] = (float)(qp[q] - mp[q]) * inv;
+        }
+        eb[3] = __int_as_float(ns_b);
+        s_any[wave][2 * lane + 1] = 0;
+      }
+    }
+    const int my_nch = nch_f + nch_b;
+    int incl = my_nch;
+    for (int off = 1; off < 64; off <<= 1) {
+      const int o = __shfl_up(incl, off);
+      if (lane >= off) incl += o;
+    }
+    const int excl = incl - my_nch;
+    const int P = __shfl(incl, 63);
+    SurvivorItem* list = static_cast<SurvivorItem*>(S.items);
+    SurvivorItem* buf = s_surv[wave];
+    int32_t* tab = s_tab[wave];
+    int n_buf = 0;
+    const int sub_list = blockIdx.x & (SFFK_SUBLISTS - 1), sub_cap = S.items_cap / SFFK_SUBLISTS;
+    int32_t* sub = S.sub + ((size_t)pass * SFFK_SUBLISTS + sub_list) * SFFK_STAR_SUB;
+    auto flush = [&]() {
+      int base = 0;
+      if (lane == 0) base = atomicAdd(sub, n_buf);
+      base = __shfl(base, 0);
+      if (lane < n_buf && base + lane < sub_cap) list[(size_t)sub_list * sub_cap + base + lane] = buf[lane];
+      n_buf = 0;     // (a sub-list that ran over is noticed by k_star_exact: fault)
+    };
+    const float nxd = (float)env.clear_n[0], nyd = (float)env.clear_n[1], nzd = (float)env.clear_n[2];
+    const int pu = lane >> 3, gq = lane & 7;
+    for (int w0 = 0; w0 < P; w0 += STAR_TAB) {
+      __builtin_amdgcn_wave_barrier();
+      for (int cc = 0; cc < my_nch; ++cc) {
+        const int pp = excl + cc;
+        if (pp >= w0 && pp < w0 + STAR_TAB) {
+          const int e = cc < nch_f ? 2 * lane : 2 * lane + 1;
+          const int ch = cc < nch_f ? cc : cc - nch_f;
+          tab[pp - w0] = (e << 16) | ch;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      const int wn = P - w0 < STAR_TAB ? P - w0 : STAR_TAB;
+      for (int q0 = 0; q0 < wn; q0 += 8) {
+        // eight consecutive samples of an edge lie within 0.4 units of the fifth one (the sample spacing never exceeds
+        // the 0.1 of src/problemStruct.h:121) and the bits are built with that reach on top (Ctx::build_clearance): one
+        // lookup answers a group of eight samples, a lane takes a group, a step of the wave eight (edge, chunk) pairs
+        const bool valid = q0 + pu < wn;
+        const int ent = valid ? tab[q0 + pu] : 0;
+        const int e = ent >> 16, ch = ent & 0xffff;
+        const float* ee = s_edge[wave][e];
+        const int ns = __float_as_int(ee[3]);
+        const int first = 1 + 64 * ch + 8 * gq;
+        bool need = valid && first <= ns;
+        const int left = ns - first + 1;
+        const int probe = first + 4 <= ns ? first + 4 : ns;
+        const uint32_t* wp = nullptr;
+        int sh = 0;
+        if (need && env.clear_bits) {
+          const float td = (float)probe;
+          const float fx = __builtin_fmaf(td, ee[4], ee[0]), fy = __builtin_fmaf(td, ee[5], ee[1]), fz = __builtin_fmaf(td, ee[6], ee[2]);
+          if (fx >= 0 && fy >= 0 && fz >= 0 && fx < nxd && fy < nyd && fz < nzd) {
+            const uint32_t ci = ((uint32_t)(int)fz * (uint32_t)env.clear_n[1] + (uint32_t)(int)fy) * (uint32_t)env.clear_n[0] + (uint32_t)(int)fx;
+            wp = env.clear_bits + (ci >> 5);
+            sh = (int)(ci & 31u);
+          } else if (fx == fx && fy == fy && fz == fz) {
+            need = false;                                     // beyond the inflated box of the environment
+          }
+        }
+        const uint32_t word = wp ? *wp : 0u;
+        if (wp && ((word >> sh) & 1u)) need = false;
+        unsigned long long m = need ? (((left >= 8 ? 0xffULL : ((1ULL << left) - 1ULL))) << (8 * gq)) : 0ULL;
+        m |= __shfl_xor(m, 1);
+        m |= __shfl_xor(m, 2);
+        m |= __shfl_xor(m, 4);
+        const bool lead = gq == 0 && m != 0ULL && env.n_tri != 0;
+        const unsigned long long lm = __ballot(lead);
+        if (lm) {
+          if (lead) {
+            const int slot = (int)(((size_t)i * SFFK_STAR_KC) * 2) + e;
+            buf[n_buf + __popcll(lm & ((1ULL << lane) - 1ULL))] = SurvivorItem{slot, ch, m};
+            s_any[wave][e] = 1;
+          }
+          n_buf += __popcll(lm);
+          if (n_buf > STAR_SURV - 8) flush();
+        }
+      }
+    }
+    if (n_buf) flush();
+    __builtin_amdgcn_wave_barrier();
+    if (req_f) {
+      if (s_any[wave][2 * lane]) {
+        ew_f = -1;
+        S.first_hit[s0] = 0x7fffffff; S.seg_ovf[s0] = 0; S.ens[s0] = ns_f; S.ida[s0] = Tb + i; S.idb[s0] = sid;
+      } else ew_f = star_pack(ns_f, true);
+      S.ew[s0] = ew_f;
+    }
+    if (req_b) {
+      if (s_any[wave][2 * lane + 1]) {
+        ew_b = -1;
+        S.first_hit[s0 + 1] = 0x7fffffff; S.seg_ovf[s0 + 1] = 0; S.ens[s0 + 1] = ns_b; S.ida[s0 + 1] = sid; S.idb[s0 + 1] = Tb + i;
+      } else ew_b = star_pack(ns_b, true);
+      S.ew[s0 + 1] = ew_b;
+    }
+  }
+  const bool pending = __any((need_f && ew_f == -1) || (need_b && ew_b == -1));
+  // (an edge still with the exact kernel counts as blocked here; the pass after its answer redoes the sample)
+  const bool free_f = ew_f > 0 && ((ew_f >> 1) & 1), free_b = ew_b > 0 && ((ew_b >> 1) & 1);
+  const unsigned long long calls_f = ew_f > 0 ? (unsigned long long)(ew_f >> 2) : 0ULL;
+  const unsigned long long calls_b = ew_b > 0 ? (unsigned long long)(ew_b >> 2) : 0ULL;
+  // ---- choose parent (:320-327): the members in (distance, id) order against the running best
+  double best = best0;
   int psel = ex;
   double dcl = pd;
-  const double nd = d + v;
   unsigned long long cc = 0, pf = 0;
   int cur = 0;
   while (true) {
@@ -356,12 +638,13 @@ __global__ __launch_bounds__(256) void k_star_pass(ResolveArgs A, int pass, int 
     diff |= __double_as_longlong(S.best[i]) != __double_as_longlong(best) || S.psel[i] != psel ||
             __double_as_longlong(S.dcl[i]) != __double_as_longlong(dcl) || S.cnt[2 * (size_t)i] != cc || S.cnt[2 * (size_t)i + 1] != pf;
   if (diff && mem) S.prop[p] = np;
-  if (__any(diff)) {
-    if (lane == 0) {
+  const bool any_diff = __any(diff);
+  if (lane == 0) {
+    if (any_diff) {
       S.best[i] = best; S.psel[i] = psel; S.dcl[i] = dcl;
       S.cnt[2 * (size_t)i] = cc; S.cnt[2 * (size_t)i + 1] = pf;
-      S.changed[pass] = 1;
     }
+    if (any_diff || pending) S.changed[pass] = 1;
   }
 }
 
@@ -486,14 +769,13 @@ void launch_star_stage(hipStream_t s, const ResolveArgs& a, int n_bound, const S
   if (n_bound <= 0) return;
   const int sample_blocks = (n_bound + 3) / 4;
   hipLaunchKernelGGL(k_star_knn, dim3(sample_blocks), dim3(256), 0, s, a, L.g, L.tg, L.st, L.cell_edge, L.slack);
-  // the member edges: compact -> clearance cull -> exact, sized by the header the commit wrote ({accepted samples, skip})
-  launch_round_collide(s, L.env, L.rob, nullptr, 0, nullptr, nullptr, a.S.seg_a, a.S.seg_b, a.S.seg_ns,
-                       n_bound * SFFK_STAR_KC * 2, a.S.ectrl, L.list, L.list_cap, L.masks, a.S.first_hit, a.S.seg_ovf, nullptr,
-                       a.S.hdr, SFFK_STAR_KC * 2);
   const int event_blocks = (n_bound + 255) / 256;
   const int passes = L.passes > 0 && L.passes < SFFK_STAR_PASSES ? L.passes : SFFK_STAR_PASSES;
-  for (int pass = 0; pass < passes; ++pass)
-    hipLaunchKernelGGL(k_star_pass, dim3(sample_blocks + event_blocks), dim3(256), 0, s, a, pass, sample_blocks);
+  for (int pass = 0; pass < passes; ++pass) {
+    hipLaunchKernelGGL(k_star_pass, dim3(sample_blocks + event_blocks), dim3(256), 0, s, a, L.env, L.st, pass, sample_blocks);
+    // (what the pass could not answer from the clearance bits; nothing to do = the launch returns at once)
+    if (pass + 1 < passes) launch_star_exact(s, L.env, L.rob, L.st.pos, a.S, pass);
+  }
   hipLaunchKernelGGL(k_star_apply, dim3(sample_blocks), dim3(256), 0, s, a, L.tg, n_bound, passes);
 }
 

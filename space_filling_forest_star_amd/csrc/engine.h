@@ -236,8 +236,8 @@ struct DevEngine {
       b_n2, b_ta, b_tb, b_dist, bt_key, bt_val, pair, ring, ustate, ulist, uacc, d_parent, d_force, fault_pending;
   // SFF* on the device (devstar.hip; StarView in kernels.h)
   DevBuf s_ktab, s_tree_cnt, s_head, s_mcnt, s_mid, s_md, s_next, s_prop, s_best, s_psel, s_dcl, s_cnt, s_accs, s_hdr, s_changed,
-      s_ectrl, s_sega, s_segb, s_segns, s_fh, s_sovf, s_evs, s_evn, s_eve, s_evd, s_acc, s_backup, s_list, s_masks;
-  int s_list_cap = 0;
+      s_ew, s_ida, s_idb, s_sub, s_segns, s_fh, s_sovf, s_evs, s_evn, s_eve, s_evd, s_acc, s_backup, s_items, s_dbg;
+  int s_items_cap = 0;
   bool star_inited = false;
   PinBuf h_ctrl, h_ring, h_trig;
   DevBuf trig;   // libm parity mode: the C library's cos / sin / acos of every ring word (3 doubles per word)

@@ -291,8 +291,8 @@ Forest::~Forest() {
                     &dev.d_parent, &dev.d_force, &dev.fault_pending, &dev.frontier2, &dev.rm_words, &dev.rm_pref,
                     &dev.slot_pos, &dev.act_slot2, &dev.dk, &dev.trig, &dev.s_ktab, &dev.s_tree_cnt, &dev.s_head, &dev.s_mcnt, &dev.s_mid, &dev.s_md,
                     &dev.s_next, &dev.s_prop, &dev.s_best, &dev.s_psel, &dev.s_dcl, &dev.s_cnt, &dev.s_accs, &dev.s_hdr, &dev.s_changed,
-                    &dev.s_ectrl, &dev.s_sega, &dev.s_segb, &dev.s_segns, &dev.s_fh, &dev.s_sovf, &dev.s_evs, &dev.s_evn, &dev.s_eve,
-                    &dev.s_evd, &dev.s_acc, &dev.s_backup, &dev.s_list, &dev.s_masks, &dev.w_dep, &dev.w_acc, &dev.w_ev, &dev.acc_pref, &dev.w_cnt, &dev.dep_rec, &x_send, &x_recv};
+                    &dev.s_ew, &dev.s_ida, &dev.s_idb, &dev.s_sub, &dev.s_segns, &dev.s_fh, &dev.s_sovf, &dev.s_evs, &dev.s_evn, &dev.s_eve,
+                    &dev.s_evd, &dev.s_acc, &dev.s_backup, &dev.s_items, &dev.s_dbg, &dev.w_dep, &dev.w_acc, &dev.w_ev, &dev.acc_pref, &dev.w_cnt, &dev.dep_rec, &x_send, &x_recv};
   if (dev.inited) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);

@@ -58,18 +58,22 @@ sffk::StarView Forest::star_view() const {
   v.acc_sample = d.s_accs.as<int32_t>();
   v.hdr = d.s_hdr.as<int32_t>();
   v.changed = d.s_changed.as<int32_t>();
-  v.ectrl = d.s_ectrl.as<int32_t>();
-  v.seg_a = d.s_sega.as<double>();
-  v.seg_b = d.s_segb.as<double>();
-  v.seg_ns = d.s_segns.as<int32_t>();
+  v.ew = d.s_ew.as<int32_t>();
+  v.ens = d.s_segns.as<int32_t>();
   v.first_hit = d.s_fh.as<int32_t>();
   v.seg_ovf = d.s_sovf.as<int32_t>();
+  v.ida = d.s_ida.as<int32_t>();
+  v.idb = d.s_idb.as<int32_t>();
+  v.sub = d.s_sub.as<int32_t>();
+  v.items = d.s_items.p;
+  v.items_cap = d.s_items_cap;
   v.ev_sample = d.s_evs.as<int32_t>();
   v.ev_nb = d.s_evn.as<int32_t>();
   v.ev_ex = d.s_eve.as<int32_t>();
   v.ev_dist = d.s_evd.as<double>();
   v.acc = d.s_acc.as<unsigned long long>();
   v.backup = d.s_backup.as<sffk::DevCtrl>();
+  v.dbg = d.s_dbg.as<unsigned long long>();
   return v;
 }
 
@@ -106,9 +110,10 @@ void Forest::dev_star_setup() {
     d.s_accs.ensure(W * 4);
     d.s_hdr.ensure(64);
     d.s_changed.ensure(64);
-    d.s_ectrl.ensure(128);
-    d.s_sega.ensure(W * KC * 2 * 48);
-    d.s_segb.ensure(W * KC * 2 * 48);
+    d.s_ew.ensure(W * KC * 2 * 4);
+    d.s_ida.ensure(W * KC * 2 * 4);
+    d.s_idb.ensure(W * KC * 2 * 4);
+    d.s_sub.ensure((size_t)SFFK_STAR_PASSES * SFFK_SUBLISTS * SFFK_STAR_SUB * 4);
     d.s_segns.ensure(W * KC * 2 * 4);
     d.s_fh.ensure(W * KC * 2 * 4);
     d.s_sovf.ensure(W * KC * 2 * 4);
@@ -118,9 +123,15 @@ void Forest::dev_star_setup() {
     d.s_evd.ensure(W * 8);
     d.s_acc.ensure(64 * SFFK_STAR_ACC * 8);
     d.s_backup.ensure(sizeof(sffk::DevCtrl));
-    d.s_list_cap = (int)std::min<size_t>(48 * W + 65536, (size_t)1 << 26);
-    d.s_list.ensure((size_t)d.s_list_cap * SFFK_ITEM_BYTES);
-    d.s_masks.ensure(((size_t)d.s_list_cap + (1u << 20)) * 8);
+    // (survivor items of ONE pass: the chunks of the reachable member edges the clearance bits leave open)
+    d.s_items_cap = (int)std::min<size_t>(16 * W + 65536, (size_t)1 << 26) / SFFK_SUBLISTS * SFFK_SUBLISTS;
+    if (const char* e = getenv("SFFGPU_TEST_STAR_ITEMS")) d.s_items_cap = std::max(SFFK_SUBLISTS, atoi(e)) / SFFK_SUBLISTS * SFFK_SUBLISTS;
+    d.s_items.ensure((size_t)d.s_items_cap * sizeof(sffk::SurvivorItem));
+    HIPCHK(hipMemset(d.s_sub.p, 0, d.s_sub.cap));
+    if (getenv("SFFGPU_PROFILE")) {
+      d.s_dbg.ensure(32 * 8);
+      HIPCHK(hipMemset(d.s_dbg.p, 0, 32 * 8));
+    }
     HIPCHK(hipMemset(d.s_hdr.p, 0, 64));
     HIPCHK(hipMemset(d.s_changed.p, 0, 64));
     HIPCHK(hipMemset(d.s_acc.p, 0, 64 * SFFK_STAR_ACC * 8));
@@ -778,9 +789,6 @@ void Forest::dev_enqueue_round_commit(const void* recv_dev) {
     sl.rob = c.robv;
     sl.cell_edge = c.grid_cell;
     sl.slack = 8 * c.sweep_eps();
-    sl.list = dev.s_list.p;
-    sl.list_cap = dev.s_list_cap;
-    sl.masks = dev.s_masks.p;
     sl.passes = star_pass_limit;
     sffk::launch_commit(c.stream, ra, B.n, &sl);
   } else {
@@ -968,6 +976,14 @@ void Forest::run_device(int max_waves) {
       fprintf(stderr, "[sffgpu k_wave_end us/wave] claims %.1f owner flags %.1f closed list %.1f clear claims %.1f removal prefix %.1f "
               "termination %.1f | k_wave_begin %.1f\n", k.wprof[0] / w / 100.0, k.wprof[1] / w / 100.0, k.wprof[2] / w / 100.0,
               k.wprof[3] / w / 100.0, k.wprof[4] / w / 100.0, k.wprof[5] / w / 100.0, k.wprof[6] / w / 100.0);
+    }
+    if (d.s_dbg.p) {
+      unsigned long long g[32];
+      HIPCHK(hipMemcpy(g, d.s_dbg.p, sizeof g, hipMemcpyDeviceToHost));
+      const double w = (double)std::max<unsigned long long>(1ULL, g[0]);
+      fprintf(stderr, "[sffgpu k_star_knn per accepted sample] us: cube %.1f shells %.1f mates %.1f lists %.1f | longest %.1f | shells walked %.2f "
+              "(samples beyond the cube %.3f) cube candidates %.0f | samples %llu\n", g[1] / w / 100.0, g[2] / w / 100.0, g[3] / w / 100.0,
+              g[4] / w / 100.0, g[7] / 100.0, g[5] / w, g[8] / w, g[6] / w, g[0]);
     }
     const double r = (double)std::max<unsigned long long>(1ULL, k.prof[6]);
     fprintf(stderr, "[sffgpu k_resolve us/commit] states %.1f fixed point %.1f (%.2f passes, max %llu) ranks %.1f borders %.1f "

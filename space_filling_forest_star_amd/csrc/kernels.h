@@ -363,22 +363,25 @@ struct DevForestView {
 // The accept / reject logic does not depend on costs, so k_decide / k_resolve settle WHICH samples of the round become
 // nodes (and their ids) exactly as for plain SFF; then, for the accepted samples only:
 //   k_star_knn    one wavefront per accepted sample: its k = floor(2e log10(#nodes at its turn)) nearest nodes of its
-//                 tree among the store AND the samples accepted earlier in the round (replaces knnSearch, :317), the
-//                 two edge tasks per member (new -> member :323, member -> new :336), and the member joins the toucher
-//                 list of its node (per-node linked lists, heads stamped with the round's epoch: no clearing)
-//   (k_seg_compact -> k_cull -> k_collide_segments_dyn answer the member edges)
+//                 tree among the store AND the samples accepted earlier in the round (replaces knnSearch, :317); every
+//                 member joins the toucher list of its node (per-node linked lists, heads stamped with the round's
+//                 epoch: no clearing)
 //   k_star_pass   the sequential semantics "sample i sees the rewires of every accepted sample before it" as a fixed
 //                 point: a sample's view of a member's DistanceToRoot = the proposal of the LATEST earlier sample that
 //                 rewires that node (walk of the node's toucher list), else the node's stored cost; from its views it
 //                 recomputes its parent / cost / rewire proposals.  Dependencies only point backwards in slot order, so
 //                 the iteration reaches the unique fixed point in (longest chain + 1) passes; a pass that changes
 //                 nothing proves it.  One launch per pass, later launches return at once.
+//                 Member edges (new -> member :323, member -> new :336) are answered lazily: only the edges the two loops
+//                 can reach given the views are looked at - the pass culls their samples against the clearance bits
+//                 itself (most edges are answered right there), the rest goes to k_star_exact between two passes.
 //   k_star_apply  accepted samples -> nodes (store, records, grid, frontier); per node the LAST active rewire in slot
 //                 order is written (descendants' costs are NOT propagated, as in the reference, :344-348)
 #define SFFK_STAR_KC 64        // member slots per sample (k <= 50 for any int32 node count; lane k holds the expanded node)
 #define SFFK_STAR_KMAX 56
-#define SFFK_STAR_PASSES 8     // launches per round; not converged by then = fault (the round is redone on the host)
+#define SFFK_STAR_PASSES 8     // most launches per round; not converged by then = fault (the round is redone on the host)
 #define SFFK_STAR_ACC 8        // sub-counter words per line of StarView::acc
+#define SFFK_STAR_SUB 16       // ints between two survivor sub-list counters (their own cache lines)
 struct StarView {
   const int32_t* ktab;         // ktab[m] = smallest node count N with floor(2e log10 N) >= m (host libm, the reference's expression)
   int32_t* tree_cnt;           // nodes per tree in the store, one counter per 64 bytes (16 ints apart)
@@ -390,15 +393,20 @@ struct StarView {
   double* prop;                // per pair: proposed DistanceToRoot when the rewire is active (:336), +inf otherwise
   double* best; int32_t* psel; double* dcl;   // per sample: cost, chosen parent (node id), distance to it (:320-329)
   unsigned long long* cnt;     // per sample: {Collide calls, isPathFree calls} of its choose-parent / rewire loops
-  int32_t* acc_sample;         // rank among the accepted samples -> sample
-  int32_t* hdr;                // {n_acc, skip, n_events, first border entry of the round, fault} (hdr[0..1] = dev_n of the edge kernels)
-  int32_t* changed;            // SFFK_STAR_PASSES flags: pass t changed something
-  int32_t* ectrl;              // 32-int control block of the member-edge pipeline (launch_round_collide)
-  double* seg_a; double* seg_b; int32_t* seg_ns; int32_t* first_hit; int32_t* seg_ovf;   // slot = (rank * KC + m) * 2 + dir
+  int32_t* acc_sample;         // rank among the accepted samples -> sample (k_resolve)
+  int32_t* hdr;                // {accepted samples, skip, border entries of the round, first of them, fault}
+  int32_t* changed;            // SFFK_STAR_PASSES flags: pass t changed something / still waits for an edge
+  // member edges, answered LAZILY: edge slot = (sample * KC + m) * 2 + dir (0: new -> member :323, 1: member -> new :336).
+  // ew: 0 = never asked for; -1 = on the exact kernel's list (answer in first_hit after the launch that follows the pass);
+  // else ((Collide calls << 1 | free) << 1) | 1.  Only the edges the loops can reach at all are ever looked at.
+  int32_t* ew; int32_t* ens; int32_t* first_hit; int32_t* seg_ovf; int32_t* ida; int32_t* idb;
+  int32_t* sub;                // survivor sub-list counters: SFFK_STAR_PASSES x SFFK_SUBLISTS x SFFK_STAR_SUB ints
+  void* items; int items_cap;  // SurvivorItem list of the pass in flight (SFFK_SUBLISTS equal sub-lists)
   // border entries created by the round (k_resolve): the two nodes' costs are read "at the time of the sample"
   int32_t* ev_sample; int32_t* ev_nb; int32_t* ev_ex; double* ev_dist;
   unsigned long long* acc;     // 64 lines x SFFK_STAR_ACC: Collide calls, isPathFree calls, rounds, passes, members, rewires
   DevCtrl* backup;             // the control block as a rolled-back round leaves it (restored when the star stage faults)
+  unsigned long long* dbg;     // SFFGPU_PROFILE: 32 counters of the star kernels (null = off)
 };
 // per-sample verdicts of k_decide
 #define SFFK_DEPENDS 0     // the neighbour walk reached a sample of the same round first: k_resolve continues at dk
@@ -436,10 +444,12 @@ struct StarLaunch {            // what the host adds for the SFF* stage of a com
   EnvView env;
   RobotView rob;
   double cell_edge, slack;
-  void* list; int list_cap; void* masks;   // work list + masks of the member-edge pipeline
   int passes;                // fixed-point launches per round (<= SFFK_STAR_PASSES; tests shrink it to drive the fault path)
 };
 void launch_star_stage(hipStream_t s, const ResolveArgs& a, int n_bound, const StarLaunch& L);   // devstar.hip
+// exact collision test of the member-edge chunks a star pass could not answer from the clearance bits (kernels.hip)
+void launch_star_exact(hipStream_t s, const EnvView& env, const RobotView& rob, const double* store_pos, const StarView& S,
+                       int pass);
 // the commit of one round: k_decide (wide) -> k_resolve (one workgroup) [-> the SFF* stage] -> k_append (wide);
 // n_bound = launch bound
 void launch_commit(hipStream_t s, const ResolveArgs& a, int n_bound, const StarLaunch* star = nullptr);

@@ -2119,6 +2119,53 @@ __global__ __launch_bounds__(64 * SEG_WAVES) __attribute__((amdgpu_waves_per_eu(
   DBG_FLUSH();
 }
 
+// SFF* on the device (devstar.hip): the member-edge chunks a star pass could not answer from the clearance bits.  Same
+// persistent scheme as k_collide_items; an edge's end points are store entries (the new sample's temporary entry and
+// the member), named per edge slot by ida / idb.
+__global__ __launch_bounds__(64 * SEG_WAVES) __attribute__((amdgpu_waves_per_eu(CI_OCC))) void k_star_exact(
+    EnvView env, RobotView rob, const double* __restrict__ store_pos, const int32_t* __restrict__ ida,
+    const int32_t* __restrict__ idb, const SurvivorItem* __restrict__ list, int items_cap, const int32_t* __restrict__ sub,
+    int32_t* __restrict__ first_hit, int32_t* __restrict__ overflow_flag, int32_t* __restrict__ hdr) {
+  if (hdr[1] || hdr[4]) return;
+  extern __shared__ double lds_d[];
+  double* rtri = lds_d;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  double* stage = rtri + (size_t)rob.n_tri * 9 + (size_t)wave * STAGE_DOUBLES;
+  int32_t* ibase = reinterpret_cast<int32_t*>(rtri + (size_t)rob.n_tri * 9 + (size_t)SEG_WAVES * STAGE_DOUBLES);
+  const int sub_cap = items_cap / SFFK_SUBLISTS;
+  int sub_n = sub[lane * SFFK_STAR_SUB];
+  if (sub_n > sub_cap) {   // a sub-list ran over: items were dropped - the round is redone on the host path
+    if (blockIdx.x == 0 && wave == 0) atomicOr(hdr + 4, 1);
+    sub_n = sub_cap;
+  }
+  int sub_incl = sub_n;
+  for (int off = 1; off < 64; off <<= 1) {
+    const int o = __shfl_up(sub_incl, off);
+    if (lane >= off) sub_incl += o;
+  }
+  const int M = __shfl(sub_incl, 63);
+  if (M <= 0 || env.n_tri == 0) return;
+  for (int i = threadIdx.x; i < rob.n_tri * 9; i += blockDim.x) rtri[i] = rob.tri[i];
+  __syncthreads();
+  int32_t* stack = ibase + wave * (STACK_CAP + TG_HASH);
+  int32_t* cand = ibase + SEG_WAVES * (STACK_CAP + TG_HASH) + wave * CAND_CAP;
+  int32_t* queue = ibase + SEG_WAVES * (STACK_CAP + TG_HASH + CAND_CAP) + wave * QUEUE_CAP;
+  DBG_DECL
+  const int W = gridDim.x * SEG_WAVES;
+  for (int e = blockIdx.x + gridDim.x * wave; e < M; e += W) {
+    const int sl = __popcll(__ballot(sub_incl <= e));
+    const int j = e - (__shfl(sub_incl, sl) - __shfl(sub_n, sl));
+    const SurvivorItem it = list[(size_t)sl * sub_cap + j];
+    const int slot = it.slot;
+    if (it.chunk > 0 && first_hit[slot] <= 64 * it.chunk) continue;
+    double a[6], b[6];
+    const double* pa = store_pos + 6 * (size_t)ida[slot];
+    const double* pb = store_pos + 6 * (size_t)idb[slot];
+    for (int k = 0; k < 6; ++k) { a[k] = pa[k]; b[k] = pb[k]; }
+    segment_chunk(env, rob, rtri, stack, cand, queue, stage, a, b, slot, it.chunk, true, it.mask, first_hit, overflow_flag, lane DBG_PASS);
+  }
+}
+
 // Samples whose fate needs no in-order replay (src/forest.h:246-299): rejected by their own pose or parent-edge
 // check, or by a STORE neighbour when no sample of this round appears anywhere in their neighbour list, and
 // without side effect (no border entry).  code: 0 = replay on the host, 1 = settled, 2 = outside the limits.
@@ -2361,6 +2408,16 @@ void launch_collide_items(hipStream_t s, const EnvView& env, const RobotView& ro
                      overflow_flag,
                      temps ? temps->tg : GridView{}, temps ? temps->x : nullptr, temps ? temps->y : nullptr,
                      temps ? temps->z : nullptr, temps ? temps->n : 0, dev_n);
+}
+
+void launch_star_exact(hipStream_t s, const EnvView& env, const RobotView& rob, const double* store_pos, const StarView& S,
+                       int pass) {
+  size_t lds = collide_lds_bytes(rob.n_tri, SEG_WAVES);
+  if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_star_exact), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  static const int blocks = std::min(4096, std::max(1, getenv("SFFGPU_SEG_BLOCKS") ? atoi(getenv("SFFGPU_SEG_BLOCKS")) : 256 * CI_OCC));
+  hipLaunchKernelGGL(k_star_exact, dim3(blocks), dim3(64 * SEG_WAVES), lds, s, env, rob, store_pos, S.ida, S.idb,
+                     static_cast<const SurvivorItem*>(S.items), S.items_cap, S.sub + (size_t)pass * SFFK_SUBLISTS * SFFK_STAR_SUB,
+                     S.first_hit, S.seg_ovf, S.hdr);
 }
 
 void launch_classify(hipStream_t s, const ClassifyArgs& a) {
