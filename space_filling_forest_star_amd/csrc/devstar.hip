@@ -18,6 +18,7 @@
 #include "kernels.h"
 #include "sff_geom.h"
 #include "kernels_dev.h"
+#include <cmath>
 
 namespace sffk {
 
@@ -105,11 +106,18 @@ __device__ __forceinline__ void star_cells_mates(const GridView& tg, int m, int 
 }
 
 // ------------------------------------------------------------------ k nearest + toucher lists
-#define STAR_R0 2                                   // half-width (cells) of the cube gathered in one go
-#define STAR_CUBE ((2 * STAR_R0 + 1) * (2 * STAR_R0 + 1) * (2 * STAR_R0 + 1))
-#define STAR_U ((STAR_CUBE + 63) / 64)
+// half-width R0 (cells) of the cube gathered in one go: 2 .. STAR_R0_MAX, chosen by the host so that the cube covers about
+// two sampling distances whatever the grid's cell size has become (the grid re-cells itself as the forest gets denser)
+#define STAR_R0_MAX 4
+#define STAR_U (((2 * STAR_R0_MAX + 1) * (2 * STAR_R0_MAX + 1) * (2 * STAR_R0_MAX + 1) + 63) / 64)
+#define STAR_MATE_U 16                              // x 64 accepted samples of a round whose list is scanned from registers
+#define STAR_POOL 6                                 // batches of 64 cube candidates selected from at once
+#define STAR_INF_BITS 0x7ff0000000000000ULL
 __global__ __launch_bounds__(256) void k_star_knn(ResolveArgs A, GridView g, GridView tg, NodeStoreView st, double cell_edge,
-                                                  double slack) {
+                                                  double slack, int R0) {
+  __shared__ double s_sel_d[4][64], s_srt_d[4][64];
+  __shared__ int s_sel_i[4][64], s_srt_i[4][64];
+  __shared__ int s_mate[4][64 * STAR_MATE_U];
   const DevForestView& f = A.f;
   const StarView& S = A.S;
   const DevCtrl* c = f.ctrl;
@@ -125,7 +133,7 @@ __global__ __launch_bounds__(256) void k_star_knn(ResolveArgs A, GridView g, Gri
   const int N0 = c->app_N0, Tb = f.temp_base;
   const unsigned ep = (unsigned)c->epoch;
   const unsigned long long dbg_t0 = S.dbg ? wall_clock64() : 0ULL;
-  unsigned long long dbg_t1 = 0, dbg_t2 = 0, dbg_t3 = 0;
+  unsigned long long dbg_t1 = 0, dbg_t2 = 0, dbg_t3 = 0, dbg_c1 = 0, dbg_c2 = 0, dbg_c3 = 0;
   int dbg_shells = 0, dbg_total = 0;
   // k = (size_t)(2e log10(#nodes)) with the nodes accepted before this sample counted in (src/forest.h:309)
   const int Nn = N0 + r;
@@ -150,17 +158,17 @@ __global__ __launch_bounds__(256) void k_star_knn(ResolveArgs A, GridView g, Gri
   if (k > 0) {
     const int cx = grid_coord((float)qp[0], g.ox, g.inv_cell, g.nx), cy = grid_coord((float)qp[1], g.oy, g.inv_cell, g.ny),
               cz = grid_coord((float)qp[2], g.oz, g.inv_cell, g.nz);
-    // ---- the cube of half-width STAR_R0 in one go: every cell's count is requested before anything is looked at (one
+    // ---- the cube of half-width R0 in one go: every cell's count is requested before anything is looked at (one
     // trip to memory instead of one per shell), then the cube's candidates are flattened over the lanes
     int cellv[STAR_U], mv[STAR_U];
     const int no_raw = g.ovf_cnt[0];
+    const int W5 = 2 * R0 + 1, cube = W5 * W5 * W5;
 #pragma unroll
     for (int u = 0; u < STAR_U; ++u) {
       const int cc = u * 64 + lane;
       cellv[u] = 0; mv[u] = 0;
-      if (cc < STAR_CUBE) {
-        const int W5 = 2 * STAR_R0 + 1;
-        const int x = cx + cc % W5 - STAR_R0, y = cy + (cc / W5) % W5 - STAR_R0, z = cz + cc / (W5 * W5) - STAR_R0;
+      if (cc < cube) {
+        const int x = cx + cc % W5 - R0, y = cy + (cc / W5) % W5 - R0, z = cz + cc / (W5 * W5) - R0;
         if (x >= 0 && x < g.nx && y >= 0 && y < g.ny && z >= 0 && z < g.nz) {
           cellv[u] = (z * g.ny + y) * g.nx + x;
           mv[u] = g.cnt[cellv[u]];
@@ -169,6 +177,147 @@ __global__ __launch_bounds__(256) void k_star_knn(ResolveArgs A, GridView g, Gri
     }
 #pragma unroll
     for (int u = 0; u < STAR_U; ++u) if (mv[u] > g.bk) mv[u] = g.bk;
+    {
+      int mine_sum = 0;
+#pragma unroll
+      for (int u = 0; u < STAR_U; ++u) mine_sum += mv[u];
+      int inc = mine_sum;
+      for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(inc, off);
+        if (lane >= off) inc += o;
+      }
+      const int total = __shfl(inc, 63);
+      dbg_total = total;
+      if (S.dbg) dbg_c1 = wall_clock64();
+      // candidate j of the flattened cube -> its grid item (two batches of 64 per step: their loads are in flight together)
+      auto fetch2 = [&](int base, GridItem* it, bool* val) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int j = base + 64 * h + lane;
+          const int jj = j < total ? j : total - 1;
+          int lo = 0, hi = 63;
+          while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (__shfl(inc, mid) > jj) hi = mid; else lo = mid + 1;
+          }
+          int rest = jj - (__shfl(inc, lo) - __shfl(mine_sum, lo));   // index among the owner lane's items
+          int src_cell = 0;
+#pragma unroll
+          for (int u = 0; u < STAR_U; ++u) {
+            if (u * 64 >= cube) break;
+            const int mu = __shfl(mv[u], lo), cu = __shfl(cellv[u], lo);
+            if (rest >= 0 && rest < mu) { src_cell = cu; rest += 1 << 20; }   // (found: park the index out of every later range)
+            else if (rest >= 0 && rest < (1 << 20)) rest -= mu;
+          }
+          val[h] = j < total;
+          it[h].id = 0x7fffffff; it[h].tree = -1;
+          if (val[h]) it[h] = g.items[(size_t)src_cell * g.bk + (rest - (1 << 20))];
+        }
+      };
+      // The first STAR_POOL x 64 candidates are only measured, not ranked one by one: their k smallest keys are found
+      // by bisection on the distance bits (ballots and scalar counts), and only those k are sorted into the list - the
+      // list's rank-insertion costs a dozen cross-lane moves per newcomer, and while it fills nearly every candidate is one
+      unsigned long long kb[STAR_POOL];
+      int kid[STAR_POOL];
+#pragma unroll
+      for (int b = 0; b < STAR_POOL; ++b) { kb[b] = STAR_INF_BITS; kid[b] = 0x7fffffff; }
+#pragma unroll
+      for (int sp = 0; sp < STAR_POOL / 2; ++sp) {
+        if (sp * 128 < total) {
+          GridItem it[2];
+          bool val[2];
+          fetch2(sp * 128, it, val);
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+            if (val[h] && it[h].tree == mine && it[h].id < N0) {
+              kb[2 * sp + h] = (unsigned long long)__double_as_longlong(dist6(it[h].p, qp));
+              kid[2 * sp + h] = it[h].id;
+            }
+        }
+      }
+      {
+        if (S.dbg) dbg_c2 = wall_clock64();
+        int n_valid = 0;
+#pragma unroll
+        for (int b = 0; b < STAR_POOL; ++b) n_valid += __popcll(__ballot(kb[b] < STAR_INF_BITS));
+        unsigned long long V = STAR_INF_BITS;     // winners: key < V, or key == V with id <= I
+        int I = 0x7fffffff;
+        if (n_valid > k) {
+          V = 0ULL;
+          for (int bit = 62; bit >= 0; --bit) {   // V = the k-th smallest distance: the largest x with count(key < x) < k
+            const unsigned long long trial = V | (1ULL << bit);
+            int cnt_less = 0;
+#pragma unroll
+            for (int b = 0; b < STAR_POOL; ++b) cnt_less += __popcll(__ballot(kb[b] < trial));
+            if (cnt_less < k) V = trial;
+          }
+          int c_less = 0, ties = 0;
+#pragma unroll
+          for (int b = 0; b < STAR_POOL; ++b) { c_less += __popcll(__ballot(kb[b] < V)); ties += __popcll(__ballot(kb[b] == V)); }
+          const int need = k - c_less;
+          if (ties > need) {                      // equal distances: the smallest ids among them
+            unsigned int Iu = 0u;
+            for (int bit = 30; bit >= 0; --bit) {
+              const unsigned int trial = Iu | (1u << bit);
+              int cl = 0;
+#pragma unroll
+              for (int b = 0; b < STAR_POOL; ++b) cl += __popcll(__ballot(kb[b] == V && (unsigned int)kid[b] < trial));
+              if (cl < need) Iu = trial;
+            }
+            I = (int)Iu;
+          }
+        }
+        if (S.dbg) dbg_c3 = wall_clock64();
+        // the winners, compacted into LDS, then ranked among themselves (k reads each, all lanes the same address)
+        double* ud = s_sel_d[wave];
+        int* ui = s_sel_i[wave];
+        int nsel = 0;
+#pragma unroll
+        for (int b = 0; b < STAR_POOL; ++b) {
+          const bool win = kb[b] < V || (kb[b] == V && kb[b] < STAR_INF_BITS && kid[b] <= I);
+          const unsigned long long m = __ballot(win);
+          if (win) {
+            const int at = nsel + __popcll(m & ((1ULL << lane) - 1ULL));
+            ud[at] = __longlong_as_double((long long)kb[b]);
+            ui[at] = kid[b];
+          }
+          nsel += __popcll(m);
+        }
+        __builtin_amdgcn_wave_barrier();
+        double md = 1.0e300;
+        int mi = 0x7fffffff, rank = 0;
+        if (lane < nsel) { md = ud[lane]; mi = ui[lane]; }
+        for (int q = 0; q < nsel; ++q) {
+          const double od = ud[q];
+          const int oi = ui[q];
+          if (key_less(od, oi, md, mi)) ++rank;
+        }
+        __builtin_amdgcn_wave_barrier();
+        double* sd = s_srt_d[wave];
+        int* si = s_srt_i[wave];
+        if (lane < nsel) { sd[rank] = md; si[rank] = mi; }
+        __builtin_amdgcn_wave_barrier();
+        if (lane < nsel) { t.d = sd[lane]; t.id = si[lane]; }
+        have = nsel;
+      }
+      // whatever the pool did not hold (a cube with more than STAR_POOL x 64 nodes), one by one
+      for (int base = STAR_POOL * 64; base < total; base += 128) {
+        GridItem it[2];
+        bool val[2];
+        fetch2(base, it, val);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          if (base + 64 * h >= total) break;
+          bool cand = false;
+          double d = 1.0e300;
+          const int id = it[h].id;
+          if (val[h] && it[h].tree == mine && id < N0) { d = dist6(it[h].p, qp); cand = true; }
+          const double worst = topk_worst(t, k, have);
+          cand = cand && (have < k || key_less(d, id, worst, 0x7fffffff));
+          topk_insert(t, lane, k, have, __ballot(cand), d, id);
+        }
+      }
+    }
     {   // the node grid's shared overflow list (usually empty)
       int no = no_raw;
       if (no > g.ovf_cap) no = g.ovf_cap;
@@ -189,62 +338,13 @@ __global__ __launch_bounds__(256) void k_star_knn(ResolveArgs A, GridView g, Gri
         topk_insert(t, lane, k, have, __ballot(cand), d, id);
       }
     }
-    {
-      int mine_sum = 0;
-#pragma unroll
-      for (int u = 0; u < STAR_U; ++u) mine_sum += mv[u];
-      int inc = mine_sum;
-      for (int off = 1; off < 64; off <<= 1) {
-        const int o = __shfl_up(inc, off);
-        if (lane >= off) inc += o;
-      }
-      const int total = __shfl(inc, 63);
-      dbg_total = total;
-      // two batches of 64 candidates per step: their item loads are in flight together
-      for (int base = 0; base < total; base += 128) {
-        GridItem it[2];
-        bool val[2];
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int j = base + 64 * h + lane;
-          const int jj = j < total ? j : total - 1;
-          int lo = 0, hi = 63;
-          while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (__shfl(inc, mid) > jj) hi = mid; else lo = mid + 1;
-          }
-          int rest = jj - (__shfl(inc, lo) - __shfl(mine_sum, lo));   // index among the owner lane's items
-          int src_cell = 0;
-#pragma unroll
-          for (int u = 0; u < STAR_U; ++u) {
-            const int mu = __shfl(mv[u], lo), cu = __shfl(cellv[u], lo);
-            if (rest >= 0 && rest < mu) { src_cell = cu; rest += 1 << 20; }   // (found: park the index out of every later range)
-            else if (rest >= 0 && rest < (1 << 20)) rest -= mu;
-          }
-          val[h] = j < total;
-          it[h].id = 0x7fffffff; it[h].tree = -1;
-          if (val[h]) it[h] = g.items[(size_t)src_cell * g.bk + (rest - (1 << 20))];
-        }
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          if (base + 64 * h >= total) break;
-          bool cand = false;
-          double d = 1.0e300;
-          const int id = it[h].id;
-          if (val[h] && it[h].tree == mine && id < N0) { d = dist6(it[h].p, qp); cand = true; }
-          const double worst = topk_worst(t, k, have);
-          cand = cand && (have < k || key_less(d, id, worst, 0x7fffffff));
-          topk_insert(t, lane, k, have, __ballot(cand), d, id);
-        }
-      }
-    }
     // ---- beyond the cube (rare: young, sparse trees): shells of cells until the k-th distance lies inside the covered
     // ball; a tree with fewer than k nodes is complete as soon as all of them are in
     const int rmax = max(max(g.nx, g.ny), g.nz);
     if (S.dbg) dbg_t1 = wall_clock64();
-    for (int rr = STAR_R0; rr <= rmax; ++rr) {
+    for (int rr = R0; rr <= rmax; ++rr) {
       if (have >= k_store && k_store == tcnt) break;      // the whole tree is in the list
-      if (rr > STAR_R0) {
+      if (rr > R0) {
         ++dbg_shells;
         const int w = 2 * rr + 1;
         const int total = w * w * w;
@@ -274,30 +374,59 @@ __global__ __launch_bounds__(256) void k_star_knn(ResolveArgs A, GridView g, Gri
     if (r > 0) {
       const bool all = have < k;
       const double limit = all ? 1.0e300 : topk_worst(t, k, have);
-      if (all || r <= 256) {
-        // few of them (or all are wanted): k_resolve's list, four batches of 64 ranks per step (their loads in flight together)
-        for (int base = 0; base < r; base += 256) {
-          int sidv[4], trv[4];
+      if (r <= 64 * STAR_MATE_U) {
+        // k_resolve's list of the accepted samples: every rank's sample and tree are requested up front (two trips to
+        // memory whatever the length), the few of the same tree are compacted in LDS and measured a batch at a time
+        int sidv[STAR_MATE_U], trv[STAR_MATE_U];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) { const int rq = base + 64 * u + lane; sidv[u] = rq < r ? Tb + S.acc_sample[rq] : -1; }
+        for (int u = 0; u < STAR_MATE_U; ++u) { const int rq = 64 * u + lane; sidv[u] = rq < r ? Tb + S.acc_sample[rq] : -1; }
 #pragma unroll
-          for (int u = 0; u < 4; ++u) trv[u] = sidv[u] >= 0 ? st.tree[sidv[u]] : -1;
+        for (int u = 0; u < STAR_MATE_U; ++u) trv[u] = sidv[u] >= 0 ? st.tree[sidv[u]] : -1;
+        int* ml = s_mate[wave];
+        int nm = 0;
 #pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            if (base + 64 * u >= r) break;
-            bool cand = sidv[u] >= 0 && trv[u] == mine;
-            if (!__any(cand)) continue;
-            double d = 1.0e300;
-            if (cand) {
-              double mp[6];
-              for (int q = 0; q < 6; ++q) mp[q] = st.pos[6 * (size_t)sidv[u] + q];
-              d = dist6(mp, qp);
-              cand = d <= limit;
-            }
-            const double worst = topk_worst(t, k, have);
-            cand = cand && (have < k || key_less(d, sidv[u], worst, 0x7fffffff));
-            topk_insert(t, lane, k, have, __ballot(cand), d, sidv[u]);
+        for (int u = 0; u < STAR_MATE_U; ++u) {
+          if (64 * u >= r) break;
+          const bool mt = sidv[u] >= 0 && trv[u] == mine;
+          const unsigned long long mm = __ballot(mt);
+          if (mt) ml[nm + __popcll(mm & ((1ULL << lane) - 1ULL))] = sidv[u];
+          nm += __popcll(mm);
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int base = 0; base < nm; base += 64) {
+          const int j = base + lane;
+          bool cand = false;
+          double d = 1.0e300;
+          int sid = 0x7fffffff;
+          if (j < nm) {
+            sid = ml[j];
+            double mp[6];
+            for (int q = 0; q < 6; ++q) mp[q] = st.pos[6 * (size_t)sid + q];
+            d = dist6(mp, qp);
+            cand = d <= limit;
           }
+          const double worst = topk_worst(t, k, have);
+          cand = cand && (have < k || key_less(d, sid, worst, 0x7fffffff));
+          topk_insert(t, lane, k, have, __ballot(cand), d, sid);
+        }
+      } else if (all) {
+        for (int base = 0; base < r; base += 64) {   // (a tree wanted whole in a huge round: rare)
+          const int rq = base + lane;
+          bool cand = false;
+          double d = 1.0e300;
+          int sid = 0x7fffffff;
+          if (rq < r) {
+            sid = Tb + S.acc_sample[rq];
+            if (st.tree[sid] == mine) {
+              double mp[6];
+              for (int q = 0; q < 6; ++q) mp[q] = st.pos[6 * (size_t)sid + q];
+              d = dist6(mp, qp);
+              cand = true;
+            }
+          }
+          const double worst = topk_worst(t, k, have);
+          cand = cand && (have < k || key_less(d, sid, worst, 0x7fffffff));
+          topk_insert(t, lane, k, have, __ballot(cand), d, sid);
         }
       } else {
         // a large round: the round's own grid, cells of the cube around the ball of the k-th store node
@@ -371,6 +500,8 @@ __global__ __launch_bounds__(256) void k_star_knn(ResolveArgs A, GridView g, Gri
       atomicAdd(S.dbg + 3, dbg_t3 - dbg_t2); atomicAdd(S.dbg + 4, t4 - dbg_t3); atomicAdd(S.dbg + 5, (unsigned long long)dbg_shells);
       atomicAdd(S.dbg + 6, (unsigned long long)dbg_total); atomicMax(S.dbg + 7, t4 - dbg_t0);
       if (dbg_shells) atomicAdd(S.dbg + 8, 1ULL);
+      atomicAdd(S.dbg + 9, dbg_c1 - dbg_t0); atomicAdd(S.dbg + 10, dbg_c2 - dbg_c1); atomicAdd(S.dbg + 11, dbg_c3 - dbg_c2);
+      atomicAdd(S.dbg + 12, dbg_t1 - dbg_c3);
     }
   }
 }
@@ -396,7 +527,7 @@ __device__ __forceinline__ double star_view(const DevForestView& f, const StarVi
 }
 
 // ------------------------------------------------------------------ one pass of the fixed point
-#define STAR_SURV 48   // survivors of a sample gathered in LDS before they are appended (one atomic)
+#define STAR_SURV 64   // survivors of a sample gathered in LDS before they are appended (one atomic)
 #define STAR_TAB 128   // (edge, chunk) pairs of a sample unfolded at a time
 __device__ __forceinline__ int star_pack(int calls, bool free_) { return (((calls << 1) | (free_ ? 1 : 0)) << 1) | 1; }
 
@@ -524,7 +655,8 @@ __global__ __launch_bounds__(256) void k_star_pass(ResolveArgs A, EnvView env, N
       int base = 0;
       if (lane == 0) base = atomicAdd(sub, n_buf);
       base = __shfl(base, 0);
-      if (lane < n_buf && base + lane < sub_cap) list[(size_t)sub_list * sub_cap + base + lane] = buf[lane];
+      for (int o = lane; o < n_buf; o += 64)
+        if (base + o < sub_cap) list[(size_t)sub_list * sub_cap + base + o] = buf[o];
       n_buf = 0;     // (a sub-list that ran over is noticed by k_star_exact: fault)
     };
     const float nxd = (float)env.clear_n[0], nyd = (float)env.clear_n[1], nzd = (float)env.clear_n[2];
@@ -574,15 +706,10 @@ __global__ __launch_bounds__(256) void k_star_pass(ResolveArgs A, EnvView env, N
         m |= __shfl_xor(m, 2);
         m |= __shfl_xor(m, 4);
         const bool lead = gq == 0 && m != 0ULL && env.n_tri != 0;
-        const unsigned long long lm = __ballot(lead);
-        if (lm) {
-          if (lead) {
-            const int slot = (int)(((size_t)i * SFFK_STAR_KC) * 2) + e;
-            buf[n_buf + __popcll(lm & ((1ULL << lane) - 1ULL))] = SurvivorItem{slot, ch, m};
-            s_any[wave][e] = 1;
-          }
-          n_buf += __popcll(lm);
-          if (n_buf > STAR_SURV - 8) flush();
+        if (__any(lead)) {
+          if (lead) s_any[wave][e] = 1;
+          surv_emit(buf, n_buf, lead, lane, (int)(((size_t)i * SFFK_STAR_KC) * 2) + e, ch, m);
+          if (n_buf > STAR_SURV - 33) flush();
         }
       }
     }
@@ -768,7 +895,9 @@ __global__ __launch_bounds__(256) void k_star_apply(ResolveArgs A, GridView tg, 
 void launch_star_stage(hipStream_t s, const ResolveArgs& a, int n_bound, const StarLaunch& L) {
   if (n_bound <= 0) return;
   const int sample_blocks = (n_bound + 3) / 4;
-  hipLaunchKernelGGL(k_star_knn, dim3(sample_blocks), dim3(256), 0, s, a, L.g, L.tg, L.st, L.cell_edge, L.slack);
+  int R0 = (int)std::ceil(L.cube_reach / L.cell_edge);
+  R0 = R0 < 2 ? 2 : (R0 > STAR_R0_MAX ? STAR_R0_MAX : R0);
+  hipLaunchKernelGGL(k_star_knn, dim3(sample_blocks), dim3(256), 0, s, a, L.g, L.tg, L.st, L.cell_edge, L.slack, R0);
   const int event_blocks = (n_bound + 255) / 256;
   const int passes = L.passes > 0 && L.passes < SFFK_STAR_PASSES ? L.passes : SFFK_STAR_PASSES;
   for (int pass = 0; pass < passes; ++pass) {

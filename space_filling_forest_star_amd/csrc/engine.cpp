@@ -622,7 +622,7 @@ void Ctx::grid_setup(const double limits[6], double cell) {
   gridv.nx = (int)std::floor(ext[0] / cell) + 1;
   gridv.ny = (int)std::floor(ext[1] / cell) + 1;
   gridv.nz = (int)std::floor(ext[2] / cell) + 1;
-  gridv.bk = 8;
+  gridv.bk = grid_bk;
   const size_t ncells = (size_t)gridv.nx * gridv.ny * gridv.nz;
   if (gridv_ovf_cap_next < 65536) gridv_ovf_cap_next = 65536;
   gridv.ovf_cap = gridv_ovf_cap_next;
@@ -675,11 +675,13 @@ void Ctx::grid_check() {
   // finished may have missed nodes, so its results cannot be trusted (the capacity is sized so that one wave
   // cannot get here from below the rebuild threshold: ovf_cap - ovf_cap / 4 >= wave, see Forest::Forest)
   if (v > gridv.ovf_cap) throw HipError{"neighbour grid overflow list exhausted during a wave (nodes were dropped)"};
-  if (v <= gridv.ovf_cap / 4) return;
+  if (v <= grid_rebuild_at()) return;
   const size_t cells_now = (size_t)gridv.nx * gridv.ny * gridv.nz;
   double cell = grid_cell;
-  if (cells_now * 4 <= 16777216) cell = grid_cell * 0.63;   // ~4x the cells
-  else gridv_ovf_cap_next = gridv.ovf_cap * 4;              // cell count exhausted: a longer list instead
+  if (cells_now * 4 <= 16777216 && grid_cell * 0.63 >= 0.5 * grid_cell0) cell = grid_cell * 0.63;   // ~4x the cells
+  else if (grid_bk < 64 && cells_now * (size_t)grid_bk * 2 * sizeof(sffk::GridItem) <= ((size_t)24 << 30))
+    grid_bk *= 2;                                           // cell count exhausted: deeper buckets (HBM is plentiful) ...
+  else gridv_ovf_cap_next = gridv.ovf_cap * 4;              // ... and only then a longer list
   double lim[6];
   memcpy(lim, grid_limits, sizeof lim);
   grid_setup(lim, cell);

@@ -4,6 +4,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
 #include <map>
 #include <unordered_set>
 #include <string>
@@ -112,6 +113,11 @@ struct Ctx {
   double grid_cell = 0, grid_limits[6] = {0, 0, 0, 0, 0, 0};
   int grid_rebuilds = 0;
   int gridv_ovf_cap_next = 65536;
+  int grid_bk = 8;          // items per cell bucket (doubled when the cells cannot shrink any further)
+  // the shared overflow list is scanned by EVERY query: the grid is re-celled as soon as it holds a few batches' worth
+  int grid_rebuild_at() const { return std::min(gridv.ovf_cap / 4, 128); }
+  double grid_cell0 = 0;    // the cell edge the forest asked for (re-celling never goes below half of it: a query's
+                            // cell count grows with the cube of the ratio)
   int tgrid_ovf_min = 0;    // lower bound of the round grid's overflow list (one wave of samples)
 
   // scratch

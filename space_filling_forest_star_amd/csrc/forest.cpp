@@ -131,6 +131,8 @@ Forest::Forest(Ctx* c, const sffgpu_forest_cfg& cf, const double* roots6, int n_
     // cell edge >= the planner's neighbour radius max(parentDistance ~ SamplingDistance, treeDistance)
     double cell = 1.01 * std::max(cfg.sampling_dist, cfg.dist_tree) + 4 * ctx->sweep_eps();
     ctx->grid_rebuilds = 0;
+    ctx->grid_bk = 8;
+    ctx->grid_cell0 = cell;
     // the overflow list is checked once per wave and re-celled at a quarter full: three quarters of it must hold
     // whatever TWO waves can add (at most `wave` nodes each; the device engine keeps one wave enqueued ahead of the
     // one whose status it reads), so that no insert is ever dropped between two checks

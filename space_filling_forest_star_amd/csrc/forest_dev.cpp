@@ -789,6 +789,7 @@ void Forest::dev_enqueue_round_commit(const void* recv_dev) {
     sl.rob = c.robv;
     sl.cell_edge = c.grid_cell;
     sl.slack = 8 * c.sweep_eps();
+    sl.cube_reach = 2.0 * cfg.sampling_dist;
     sl.passes = star_pass_limit;
     sffk::launch_commit(c.stream, ra, B.n, &sl);
   } else {
@@ -871,7 +872,7 @@ int Forest::dev_finish_wave(double* wait_ms, int slot, bool stream_idle) {
   // the neighbour grid's shared overflow list (checked once per wave like the host path does)
   if (s.grid_ovf > c.gridv.ovf_cap || s.tgrid_ovf > c.tgridv.ovf_cap)
     throw HipError{"neighbour grid overflow list exhausted during a wave (nodes were dropped)"};
-  if (s.grid_ovf > c.gridv.ovf_cap / 4) {
+  if (s.grid_ovf > c.grid_rebuild_at()) {
     c.store_n = s.n_nodes;
     c.grid_inserted = s.n_nodes;
     c.grid_check();
@@ -935,7 +936,7 @@ void Forest::run_device(int max_waves) {
     }
     int fault = dev_finish_wave(&wait_ms, slot, !have_next);
     const sffk::DevCtrl& s1 = d.last;
-    const bool needs_host = fault != 0 || s1.terminated || s1.grid_ovf > c.gridv.ovf_cap / 4 || s1.tgrid_ovf > c.tgridv.ovf_cap;
+    const bool needs_host = fault != 0 || s1.terminated || s1.grid_ovf > c.grid_rebuild_at() || s1.tgrid_ovf > c.tgridv.ovf_cap;
     if (have_next && needs_host) {
       // the wave behind did nothing (halted device) or - grid overflow list filling up - ran normally: wait for it,
       // then handle whatever the LAST status says with an idle stream
@@ -984,6 +985,8 @@ void Forest::run_device(int max_waves) {
       fprintf(stderr, "[sffgpu k_star_knn per accepted sample] us: cube %.1f shells %.1f mates %.1f lists %.1f | longest %.1f | shells walked %.2f "
               "(samples beyond the cube %.3f) cube candidates %.0f | samples %llu\n", g[1] / w / 100.0, g[2] / w / 100.0, g[3] / w / 100.0,
               g[4] / w / 100.0, g[7] / 100.0, g[5] / w, g[8] / w, g[6] / w, g[0]);
+      fprintf(stderr, "[sffgpu k_star_knn cube phase] us: counts %.1f items+distances %.1f bisection %.1f sort+rest %.1f\n", g[9] / w / 100.0,
+              g[10] / w / 100.0, g[11] / w / 100.0, g[12] / w / 100.0);
     }
     const double r = (double)std::max<unsigned long long>(1ULL, k.prof[6]);
     fprintf(stderr, "[sffgpu k_resolve us/commit] states %.1f fixed point %.1f (%.2f passes, max %llu) ranks %.1f borders %.1f "

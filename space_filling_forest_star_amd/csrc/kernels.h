@@ -444,6 +444,7 @@ struct StarLaunch {            // what the host adds for the SFF* stage of a com
   EnvView env;
   RobotView rob;
   double cell_edge, slack;
+  double cube_reach;         // k_star_knn gathers the cube of cells that covers this radius in one go (~ 2 sampling distances)
   int passes;                // fixed-point launches per round (<= SFFK_STAR_PASSES; tests shrink it to drive the fault path)
 };
 void launch_star_stage(hipStream_t s, const ResolveArgs& a, int n_bound, const StarLaunch& L);   // devstar.hip

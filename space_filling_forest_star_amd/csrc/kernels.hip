@@ -1694,7 +1694,7 @@ __device__ __forceinline__ void qc_overflow(const GridView& g, int no, int lane,
   }
 }
 
-#define QC_SURV 32  // survivors of a sample gathered in LDS before they are appended (one atomic)
+#define QC_SURV 64  // survivors of a sample gathered in LDS before they are appended (one atomic)
 #define QC_TAB 128  // (task, chunk) pairs of a sample unfolded at a time
 #ifndef QC_OCC
 #define QC_OCC 7   // wavefronts per SIMD the register allocation aims at (59 VGPRs).  Measured 5 ... 8: 42 / 40.3 / 39.3 / 40.9 us -
@@ -1892,8 +1892,8 @@ __global__ __launch_bounds__(64 * QC_WAVES) __attribute__((amdgpu_waves_per_eu(Q
       int base = 0;
       if (lane == 0) base = atomicAdd(A.sub + sub_list * SFFK_SUB_STRIDE, n_buf);
       base = __shfl(base, 0);
-      if (lane < n_buf) {
-        if (base + lane < sub_cap) list[(size_t)sub_list * sub_cap + base + lane] = buf[lane];
+      for (int o = lane; o < n_buf; o += 64) {
+        if (base + o < sub_cap) list[(size_t)sub_list * sub_cap + base + o] = buf[o];
         else A.ctrl[3] = 1;
       }
       n_buf = 0;
@@ -1995,11 +1995,9 @@ __global__ __launch_bounds__(64 * QC_WAVES) __attribute__((amdgpu_waves_per_eu(Q
           m |= __shfl_xor(m, 2);
           m |= __shfl_xor(m, 4);
           const bool lead = g == 0 && m != 0ULL;
-          const unsigned long long lm = __ballot(lead);
-          if (lm) {
-            if (lead) buf[n_buf + __popcll(lm & ((1ULL << lane) - 1ULL))] = SurvivorItem{(int32_t)(i * stride + t), c, m};
-            n_buf += __popcll(lm);
-            if (n_buf > QC_SURV - 8) flush();
+          if (__any(lead)) {
+            surv_emit(buf, n_buf, lead, lane, (int32_t)(i * stride + t), c, m);
+            if (n_buf > QC_SURV - 33) flush();
           }
         }
       }

@@ -29,6 +29,39 @@ __device__ __forceinline__ void grid_put(const GridView& g, const GridItem& it) 
   }
 }
 
+// ---- survivors of the clearance cull -> items of the exact kernel.  The lead lanes (lane % 8 == 0) of a step each hold one
+// (edge slot, 64-sample chunk, mask) survivor.  The exact kernel's length is its longest item (one wavefront per item:
+// broad phase of the masked samples' swept box, then every sample against every candidate triangle), so a survivor with
+// many samples is emitted as up to four 16-sample items: four wavefronts, each with a tighter box and a quarter of the
+// samples.  buf must have room for 32 more entries.
+// Measured (profiles/r3_head_a / r3_c5_d, split at > 20 samples): the longest launch shrinks (178 -> 104 us on dense_3D)
+// but the average grows (37 -> 49 us: every item pays its own broad phase), on building.obj 102 -> 96 us: off by default.
+#ifndef SFFK_SPLIT_MIN
+#define SFFK_SPLIT_MIN 64
+#endif
+__device__ __forceinline__ void surv_emit(SurvivorItem* buf, int& n_buf, bool lead, int lane, int slot, int chunk,
+                                          unsigned long long m) {
+  int parts = 0;
+  const bool split = lead && __popcll(m) > SFFK_SPLIT_MIN;
+  if (lead) parts = split ? ((m & 0xffffULL) != 0) + ((m & 0xffff0000ULL) != 0) + ((m & 0xffff00000000ULL) != 0) + ((m >> 48) != 0) : 1;
+  int inc = parts;
+  for (int off = 8; off < 64; off <<= 1) {
+    const int o = __shfl_up(inc, off);
+    if (lane >= off) inc += o;
+  }
+  const int total = __shfl(inc, 56);
+  if (lead) {
+    int at = n_buf + inc - parts;
+    if (!split) buf[at] = SurvivorItem{slot, chunk, m};
+    else
+      for (int q = 0; q < 4; ++q) {
+        const unsigned long long mq = m & (0xffffULL << (16 * q));
+        if (mq) buf[at++] = SurvivorItem{slot, chunk, mq};
+      }
+  }
+  n_buf += total;
+}
+
 // ---- exact k nearest: the wave-resident top-k list shared by k_knn_linear / k_knn_grid (kernels.hip) and k_star_knn
 // (devstar.hip)
 // The wave's k best so far: lane j holds the j-th smallest (distance, id) key; lanes >= have hold +inf.
