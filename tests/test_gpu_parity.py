@@ -341,6 +341,19 @@ def test_full_size_bench_job_in_the_reference_pinned_arithmetic(S, ctx, golden_d
     for k in got:
         assert got[k] == g[k], (k, got[k], g[k])
     f.close()
+    # and what the kernels' own (portable, <= 1 ulp from glibc) trig changes at this size: position bits, not the
+    # forest's shape - the same nodes with the same parents, trees and iterations of creation
+    fp = S.Forest(ctx, roots, sc["limits"], dist_tree=sc["dist_tree"], sampling_dist=sc["sampling_dist"], dim=6,
+                  max_iterations=2**31 - 1, node_budget=1000000, wave=g["wave"], seed=1)
+    fp.run()
+    npn = fp.nodes()
+    assert "%016x" % fp.fingerprint() != g["fingerprint"]
+    same_topology = (len(npn["parent"]) == len(n["parent"]) and np.array_equal(npn["parent"], n["parent"])
+                     and np.array_equal(npn["tree"], n["tree"]) and np.array_equal(npn["iter"], n["iter"]))
+    print("portable vs libm sampling at 1 M nodes: same topology = %s, max |dpos| = %.3g"
+          % (same_topology, float(np.abs(npn["pos"] - n["pos"]).max()) if same_topology else float("nan")))
+    assert same_topology
+    fp.close()
 
 
 def test_full_size_headline_run_equals_the_oracle(S, ctx, golden_dir):
