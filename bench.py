@@ -50,6 +50,7 @@ def parse_args():
     ap.add_argument("--cpu-iters", type=int, default=120000, help="iterations of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-sweep-micro", action="store_true", help="skip the stand-alone k_sweep roofline measurement")
     ap.add_argument("--no-wave-sweep", action="store_true", help="skip the wave = 1 / 64 / 512 legs and the quality block")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the SFF* (configs[4]) and RRT* legs")
     return ap.parse_args()
 
 
@@ -284,13 +285,14 @@ def main():
             # uniform nodes, ONE query per pass, radius for ~32 neighbours; kernel time from the library's HIP events
             rs = np.random.RandomState(1)
             lim = np.asarray(sc["limits"], dtype=np.float64)
-            Nn = 2000000
+            Nn = 16000000   # 384 MB of fp32 columns: beyond the 256 MB Infinity Cache, so the figure is an HBM one
             pts = np.empty((Nn, 6))
             for a in range(3):
                 pts[:, a] = rs.uniform(lim[2 * a], lim[2 * a + 1], Nn)
             pts[:, 3:] = rs.uniform(-np.pi, np.pi, (Nn, 3))
             ctx.nodes_reset(Nn + 64)
-            ctx.nodes_append(pts, np.zeros(Nn, np.int32))
+            for a0 in range(0, Nn, 4000000):
+                ctx.nodes_append(pts[a0:a0 + 4000000], np.zeros(len(pts[a0:a0 + 4000000]), np.int32))
             vol = (lim[1] - lim[0]) * (lim[3] - lim[2]) * (lim[5] - lim[4])
             rad = (32.0 * vol / Nn / 4.19) ** (1.0 / 3.0)
             qq = pts[rs.randint(0, Nn, 1)] + rs.normal(0, 5.0, (1, 6))
@@ -325,6 +327,69 @@ def main():
                 f.run()
                 out["quality"]["wave_%d_30k_nodes" % wv] = forest_quality(S, f, ctx, sc)
                 f.close()
+        if world == 1 and not args.no_extra_legs:
+            # the other two solvers north_star names, each with the CPU oracle's sequential loop beside it (bounded samples)
+            import oracle_lib as O
+            legs = {}
+            # ---- SFF* (BASELINE configs[4]: building.obj, 20 seeded roots, optimize = true: choose-parent + rewire on the
+            # device engine): the whole job - the forest saturates ("solved") at ~2e5 nodes, far below the 2 M budget
+            scb = common.scenario("building")
+            cb = S.Context(local_rank)
+            cb.upload_env(scb["env"])
+            cb.upload_robot(scb["robot"])
+            rb = common.free_roots(lambda p: int(cb.collide_poses(p[None, :])[0]), scb["limits"], 20, seed=1)
+            kwb = dict(dist_tree=scb["dist_tree"], sampling_dist=scb["sampling_dist"], dim=6, optimize=True, seed=1)
+            for rep in range(2):       # (the first run warms the kernels and the allocations up)
+                f = S.Forest(cb, rb, scb["limits"], max_iterations=2**31 - 1, node_budget=2000000, wave=8192, **kwb)
+                c0 = time.perf_counter()
+                f.run()
+                dt = time.perf_counter() - c0
+                st = f.stats()
+                f.close()
+            wb = O.World(scb["env"], scb["robot"], O.TRIG_PORTABLE)
+            fo = O.Forest(wb, rb, scb["limits"], max_iterations=40000, wave=1, **kwb)
+            c0 = time.perf_counter()
+            fo.run()
+            dto = time.perf_counter() - c0
+            so = fo.stats()
+            legs["sff_star"] = {
+                "workload": "BASELINE configs[4]: building.obj (26908 tris), 6-DoF, 20 seeded roots, SFF* optimize=true, 2M-node "
+                            "budget, waves of 8192 slots, run to its end (saturates: solved)",
+                "accepted_nodes_per_s": (st["n_nodes"] - 20) / dt, "collision_checks_per_s": st["collide_calls"] / dt,
+                "nodes": st["n_nodes"], "iterations": st["iterations"], "solved": st["solved"], "seconds": dt,
+                "device_engine": bool(st["star_rounds"] > 0), "host_ms": st["host_ms"], "rounds": st["sweeps"],
+                "rewire_fixed_point_passes_per_round": st["star_passes"] / max(1, st["star_rounds"]),
+                "rewires": st["star_rewires"], "host_fallback_waves": st["host_fallback_waves"],
+                "cpu_oracle_wave_1": {"accepted_nodes_per_s": (so["n_nodes"] - 20) / dto, "iterations": so["iterations"],
+                                      "nodes": so["n_nodes"], "seconds": dto, "cores": 1,
+                                      "collision_checks_per_s": so["collide_calls"] / dto}}
+            cb.close()
+            # ---- RRT* (src/rrt.h:128-322, rewire :156-201): one tree from the first root of the headline workload, no goal,
+            # speculative waves (conflicts cut a wave, the RNG rewinds: the committed sequence is the reference's)
+            kwr = dict(dist_tree=sc["dist_tree"], sampling_dist=sc["sampling_dist"], dim=6, optimize=True, seed=1)
+            for rep in range(2):
+                r = S.Rrt(ctx, roots[:1], sc["limits"], max_iterations=150000, wave=0, **kwr)
+                c0 = time.perf_counter()
+                r.run()
+                dtr = time.perf_counter() - c0
+                sr = r.stats()
+                r.close()
+            wr = O.World(sc["env"], sc["robot"], O.TRIG_PORTABLE)
+            ro = O.Rrt(wr, roots[:1], sc["limits"], max_iterations=5000, **kwr)
+            c0 = time.perf_counter()
+            ro.run()
+            dtro = time.perf_counter() - c0
+            sro = ro.stats()
+            legs["rrt_star"] = {
+                "workload": "dense_3D.obj, 6-DoF, RRT* (optimize=true) from one root, no goal, 150 k iterations, adaptive "
+                            "speculative waves",
+                "iterations_per_s": sr["iterations"] / dtr, "accepted_nodes_per_s": (sr["n_nodes"] - 1) / dtr,
+                "collision_checks_per_s": sr["collide_calls"] / dtr, "nodes": sr["n_nodes"], "iterations": sr["iterations"],
+                "waves": sr["waves"], "speculated": sr["speculated"], "committed": sr["committed"], "seconds": dtr,
+                "cpu_oracle_sequential": {"iterations_per_s": sro["iterations"] / dtro,
+                                          "accepted_nodes_per_s": (sro["n_nodes"] - 1) / dtro, "iterations": sro["iterations"],
+                                          "seconds": dtro, "cores": 1, "collision_checks_per_s": sro["collide_calls"] / dtro}}
+            out["extra_legs"] = legs
         if args.cpu_iters > 0 and world == 1:
             import oracle_lib as O
             w = O.World(sc["env"], sc["robot"], O.TRIG_PORTABLE)

@@ -82,6 +82,14 @@ int sffgpu_radius(sffgpu_ctx* ctx, const double* q6, int nq, const double* r, co
 int sffgpu_knn(sffgpu_ctx* ctx, const double* q6, int nq, int k, const int32_t* tree, const int32_t* max_id,
                int32_t* idx, double* dist, int32_t* cnt);
 
+/* Spatial index over the node store, the counterpart of Index::buildIndex (src/forest.h:66-72, src/rrt.h:56-62): a
+ * uniform grid over the xyz limits with cells of edge `cell` (>= the typical query radius; it re-cells itself as nodes
+ * get denser).  Nodes appended later enter it in the same launch.  With the index, sffgpu_knn calls that are not
+ * restricted to one tree answer every query from the cells around it (k_knn_grid: time independent of the store's size)
+ * instead of sweeping the whole store per query (k_knn_linear); the results are the same exact lists.
+ * sffgpu_nodes_reset drops it. */
+int sffgpu_nodes_index(sffgpu_ctx* ctx, const double limits[6], double cell);
+
 /* ---------------------------------------------------------------- solver session
  * SpaceForest<T,R> (src/forest.h:31-54): constructor :57-110, Solve() main loop :113-202,
  * expandNode :240-376, maxConnected :379-418 — run as waves of `wave` frontier slots evaluated

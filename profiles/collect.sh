@@ -15,7 +15,7 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out
 mkdir -p $out
 BENCH="$root/bench.py --gpus 1 --steps 20 --warmup 5 $extra"
-LEAN="--cpu-iters 0 --no-sweep-micro --no-wave-sweep"
+LEAN="--cpu-iters 0 --no-sweep-micro --no-wave-sweep --no-extra-legs"
 cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_trace -o t -- python3 $BENCH $LEAN > $out/${tag}_trace.log 2>&1
 cp $out/${tag}_trace/t_kernel_stats.csv $out/${tag}_kernel_stats.csv

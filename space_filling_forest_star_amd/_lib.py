@@ -13,7 +13,7 @@ _LIB = None
 EXPORTED_SYMBOLS = [
     "sffgpu_version", "sffgpu_device_count", "sffgpu_create", "sffgpu_destroy", "sffgpu_last_error",
     "sffgpu_mesh_upload", "sffgpu_collide_poses", "sffgpu_collide_segments", "sffgpu_sample_steer",
-    "sffgpu_nodes_reset", "sffgpu_nodes_append", "sffgpu_nodes_count", "sffgpu_radius", "sffgpu_knn",
+    "sffgpu_nodes_reset", "sffgpu_nodes_append", "sffgpu_nodes_count", "sffgpu_nodes_index", "sffgpu_radius", "sffgpu_knn",
     "sffgpu_forest_create", "sffgpu_forest_destroy", "sffgpu_forest_run", "sffgpu_forest_get_stats",
     "sffgpu_forest_get_nodes", "sffgpu_forest_get_borders", "sffgpu_forest_fingerprint", "sffgpu_forest_paths",
     "sffgpu_forest_path_plan", "sffgpu_forest_smooth_paths",
@@ -126,6 +126,7 @@ def lib():
     L.sffgpu_kernel_times.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.sffgpu_radius.argtypes = [C.c_void_p, c_dp, C.c_int, c_dp, c_ip, c_ip, c_ip, c_dp, c_ip, C.c_int]
     L.sffgpu_knn.argtypes = [C.c_void_p, c_dp, C.c_int, C.c_int, c_ip, c_ip, c_ip, c_dp, c_ip]
+    L.sffgpu_nodes_index.argtypes = [C.c_void_p, c_dp, C.c_double]
     L.sffgpu_forest_create.argtypes = [C.c_void_p, C.POINTER(ForestCfg), c_dp, C.c_int, C.POINTER(C.c_void_p)]
     L.sffgpu_forest_destroy.argtypes = [C.c_void_p]
     L.sffgpu_forest_run.argtypes = [C.c_void_p, C.c_int]
@@ -271,6 +272,12 @@ class Context:
         p = _f64(pos6, 6)
         t = _i32(tree_id)
         self._chk(self._L.sffgpu_nodes_append(self.h, _dp(p), _ip(t), len(p)))
+
+    def nodes_index(self, limits, cell):
+        """uniform grid over the store (Index::buildIndex): knn() without a tree filter then answers from the cells around
+        each query instead of sweeping the store"""
+        lim = _f64(limits)
+        self._chk(self._L.sffgpu_nodes_index(self.h, _dp(lim), float(cell)))
 
     def nodes_count(self):
         return self._L.sffgpu_nodes_count(self.h)

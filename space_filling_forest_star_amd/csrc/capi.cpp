@@ -101,6 +101,18 @@ int sffgpu_nodes_append(sffgpu_ctx* ctx, const double* pos6, const int32_t* tree
   if (!ctx || n < 0 || (n > 0 && (!pos6 || !tree_id))) return SFFGPU_ERR_ARG;
   GUARD(ctx, ctx->c->store_append(pos6, tree_id, n));
 }
+int sffgpu_nodes_index(sffgpu_ctx* ctx, const double limits[6], double cell) {
+  if (!ctx || !limits || !(cell > 0)) return SFFGPU_ERR_ARG;
+  GUARD(ctx, {
+    Ctx& c = *ctx->c;
+    c.grid_bk = 8;
+    c.grid_cell0 = cell;
+    c.grid_rebuilds = 0;
+    c.grid_setup(limits, cell);
+    c.grid_insert_new();
+    c.grid_check(/*bulk=*/true);
+  });
+}
 int sffgpu_nodes_count(sffgpu_ctx* ctx) { return ctx ? ctx->c->store_n : SFFGPU_ERR_ARG; }
 int sffgpu_kernel_times(sffgpu_ctx* ctx, double ms[3], uint64_t launches[3]) {
   if (!ctx || !ms || !launches) return SFFGPU_ERR_ARG;

@@ -666,11 +666,32 @@ void Ctx::grid_insert_new() {
 // The shared overflow list is scanned by every query, so it must stay short.  When a quarter of it is in use
 // (many nodes per xyz cell: dense forests, or forests that fill the angular dimensions) the grid is rebuilt
 // with smaller cells — queries then visit more cells but shorter buckets — and all nodes are re-inserted.
-void Ctx::grid_check() {
+void Ctx::grid_check(bool bulk) {
   if (!grid_on) return;
   int32_t v = 0;
   HIPCHK(hipMemcpyAsync(&v, g_ovfcnt.p, 4, hipMemcpyDeviceToHost, stream));
   HIPCHK(hipStreamSynchronize(stream));
+  if (bulk) {
+    // an index built over a store that already holds many nodes (sffgpu_nodes_index): nothing has been queried yet, so
+    // a list that ran over only means "rebuild with smaller cells / deeper buckets" - until everything fits
+    for (int tries = 0; tries < 40 && v > grid_rebuild_at(); ++tries) {
+      const size_t cells_now = (size_t)gridv.nx * gridv.ny * gridv.nz;
+      double cell = grid_cell;
+      if (cells_now * 4 <= 16777216 && grid_cell * 0.63 >= 0.5 * grid_cell0) cell = grid_cell * 0.63;
+      else if (grid_bk < 64 && cells_now * (size_t)grid_bk * 2 * sizeof(sffk::GridItem) <= ((size_t)24 << 30)) grid_bk *= 2;
+      else if (cells_now * 4 <= 16777216) cell = grid_cell * 0.63;
+      else gridv_ovf_cap_next = gridv.ovf_cap * 4;
+      double lim[6];
+      memcpy(lim, grid_limits, sizeof lim);
+      grid_setup(lim, cell);
+      grid_insert_new();
+      ++grid_rebuilds;
+      HIPCHK(hipMemcpyAsync(&v, g_ovfcnt.p, 4, hipMemcpyDeviceToHost, stream));
+      HIPCHK(hipStreamSynchronize(stream));
+    }
+    if (v > gridv.ovf_cap) throw HipError{"grid overflow list exhausted"};
+    return;
+  }
   // entries beyond the capacity were dropped by grid_put / k_store_write: the queries of the wave that has just
   // finished may have missed nodes, so its results cannot be trusted (the capacity is sized so that one wave
   // cannot get here from below the rebuild threshold: ovf_cap - ovf_cap / 4 >= wave, see Forest::Forest)
@@ -956,9 +977,20 @@ void Ctx::knn(const double* q6, int nq, int k, const int32_t* tree, const int32_
     d_c.ensure((size_t)nq * k * 8);
     d_d.ensure((size_t)nq * 4);
     HIPCHK(hipMemcpyAsync(d_a.p, h_a.p, (size_t)nq * sizeof(sffk::KnnQuery), hipMemcpyHostToDevice, stream));
+    // with an index over the store (sffgpu_nodes_index) and no per-tree restriction (a tree with fewer than k nodes
+    // would make the shells grow over the whole grid) every query is answered from the cells around it
+    const bool by_grid = grid_on && tree == nullptr && store_n >= k;
+    if (by_grid) {
+      grid_insert_new();
+      grid_check(/*bulk=*/true);
+    }
     time_begin(T_SWEEP);
-    sffk::launch_knn_linear(stream, store_view(), store_n, d_a.as<sffk::KnnQuery>(), nq, k, d_b.as<int32_t>(),
-                            d_c.as<double>(), d_d.as<int32_t>(), sweep_eps());
+    if (by_grid)
+      sffk::launch_knn_grid(stream, gridv, nullptr, store_view(), d_a.as<sffk::KnnQuery>(), nq, k, d_b.as<int32_t>(),
+                            d_c.as<double>(), d_d.as<int32_t>(), nullptr, nullptr, grid_cell, 8 * sweep_eps());
+    else
+      sffk::launch_knn_linear(stream, store_view(), store_n, d_a.as<sffk::KnnQuery>(), nq, k, d_b.as<int32_t>(),
+                              d_c.as<double>(), d_d.as<int32_t>(), sweep_eps());
     time_end();
     h_b.ensure((size_t)nq * k * 4);
     h_c.ensure((size_t)nq * k * 8);

@@ -109,7 +109,8 @@ struct Ctx {
   int grid_inserted = 0;
   void grid_setup(const double limits[6], double cell);
   void grid_insert_new();   // store entries [grid_inserted, store_n)
-  void grid_check();        // re-cells the grid when the shared overflow list fills up
+  void grid_check(bool bulk = false);   // re-cells the grid when the shared overflow list fills up (bulk: an index
+                                        // built over an existing store - rebuilt until everything fits)
   double grid_cell = 0, grid_limits[6] = {0, 0, 0, 0, 0, 0};
   int grid_rebuilds = 0;
   int gridv_ovf_cap_next = 65536;

@@ -136,6 +136,39 @@ def test_radius_and_knn_exact(ctx):
     assert np.all(cnt == want)
 
 
+def test_indexed_knn_equals_the_linear_sweep(ctx):
+    """sffgpu_nodes_index (the Index::buildIndex counterpart): with the grid over the store, sffgpu_knn answers from the
+    cells around each query (k_knn_grid) - the same exact lists as the per-query sweep (k_knn_linear) and the oracle,
+    also for nodes appended after the index was built, queries outside the limits and k larger than a sparse corner holds."""
+    rs = np.random.RandomState(11)
+    lim = np.array([-60.0, 2060.0, -60.0, 2110.0, 0.0, 1000.0])
+    n = 60000
+    pts = np.empty((n, 6))
+    for a in range(3):
+        pts[:, a] = rs.uniform(lim[2 * a], lim[2 * a + 1], n)
+    pts[:4000, :3] = rs.normal(500.0, 6.0, (4000, 3))      # a dense clump: cells far over their bucket size
+    pts[:, 3:] = rs.uniform(-np.pi, np.pi, (n, 3))
+    tree = rs.randint(0, 8, n).astype(np.int32)
+    q = np.vstack([pts[rs.randint(0, n, 200)] + rs.normal(0, 4.0, (200, 6)),
+                   np.array([[-500.0, -500.0, -200.0, 0.1, 0.2, 0.3], [3000.0, 1000.0, 500.0, 0.0, 0.0, 0.0]])])
+    ctx.nodes_reset(n + 64)
+    ctx.nodes_append(pts[:40000], tree[:40000])
+    lin = {k: ctx.knn(q, k) for k in (1, 32, 64)}
+    ctx.nodes_index(lim, 18.2)
+    for k in (1, 32, 64):
+        gi, gd, gc = ctx.knn(q, k)
+        assert np.array_equal(gc, lin[k][2]) and np.array_equal(gi, lin[k][0]) and np.array_equal(gd, lin[k][1])
+    ctx.nodes_append(pts[40000:], tree[40000:])             # enters the index in the same launch
+    gi, gd, gc = ctx.knn(q, 32)
+    L = O.lib()
+    for i in range(0, len(q), 7):
+        ri = np.zeros(32, np.int32)
+        rd = np.zeros(32)
+        k = L.sffo_knn(O.dp(np.ascontiguousarray(pts)), n, O.dp(q[i]), 32, O.ip(ri), O.dp(rd))
+        assert gc[i] == k and np.array_equal(gi[i, :k], ri[:k]) and np.array_equal(gd[i, :k], rd[:k])
+    ctx.nodes_reset(1024)
+
+
 def run_pair(S, ctx, name, wave, iters, seed, n_roots=5, budget=0, optimize=False, goal_idx=None, priority_bias=0.0):
     sc, w = load_world(ctx, name)
     if sc["xml_points"] is not None:
