@@ -47,6 +47,10 @@ def parse_args():
     ap.add_argument("--budget", type=int, default=1000000)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--force-dist", action="store_true", help="run the RCCL record exchange even with one rank")
+    ap.add_argument("--native-rccl", action="store_true",
+                    help="sharded runs: the library drives the exchange itself (ncclAllGather on its own communicator, "
+                         "whole waves enqueued ahead) instead of torch.distributed per round; opt-in until validated on "
+                         "a multi-GPU node")
     ap.add_argument("--cpu-iters", type=int, default=120000, help="iterations of the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-sweep-micro", action="store_true", help="skip the stand-alone k_sweep roofline measurement")
     ap.add_argument("--no-wave-sweep", action="store_true", help="skip the wave = 1 / 64 / 512 legs and the quality block")
@@ -124,6 +128,8 @@ def main():
     if world != args.gpus:
         sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node %d)" % (args.gpus, world, args.gpus))
     distributed = world > 1 or args.force_dist
+    if args.native_rccl:
+        os.environ["SFFGPU_NATIVE_RCCL"] = "1"
     if args.force_dist and world == 1:
         os.environ["SFFGPU_TEST_EXCHANGE_SELF"] = "1"   # pack -> ncclAllGather (one rank) -> unpack in every round
     torch.cuda.set_device(local_rank)
@@ -280,6 +286,21 @@ def main():
             },
             "quality": {"wave_%d_full_run" % args.wave: quality_main},
         }
+        out["time_split_ms"]["commit_kernels"] = s1["commit_ms"] - s0["commit_ms"]
+        out["time_split_ms"]["graph_launched_waves"] = int(s1["graph_launches"] - s0["graph_launches"])
+        if distributed:
+            # what bounds the strong scaling of ONE forest over N GPUs: per round, the part every rank
+            # repeats (sampling + the in-order commit), the part that shards (neighbour query + collision: 1/N each) and
+            # the exchange (pack + all-gather of the answer records + unpack).  HIP events of this run (rank 0); the
+            # per-wave kernels (frontier picks, closed list: replicated too) are not in it.
+            rounds = max(1, sweeps)
+            rep = 1e3 * ((s1["sample_ms"] - s0["sample_ms"]) + (s1["commit_ms"] - s0["commit_ms"])) / rounds
+            shd = 1e3 * ((s1["sweep_ms"] - s0["sweep_ms"]) + (s1["collide_ms"] - s0["collide_ms"])) / rounds
+            exc = 1e3 * (s1["exchange_ms"] - s0["exchange_ms"]) / rounds
+            out["dist_budget_us_per_round"] = {
+                "replicated": rep, "sharded_over_ranks": shd, "pack_gather_unpack": exc, "ranks": world,
+                "amdahl_speedup_bound_at_8_ranks": (rep + shd) / (rep + shd / 8.0 + exc) if rep + shd > 0 else None,
+                "note": "measured with %d rank(s); the all-gather of 8 ranks moves 8 x the bytes over xGMI" % world}
         if world == 1 and not args.no_sweep_micro:
             # the linear k-NN sweep on its own (SURVEY.md 8(d) micro-benchmark, see profiles/sweep_microbench.py): N
             # uniform nodes, ONE query per pass, radius for ~32 neighbours; kernel time from the library's HIP events

@@ -58,6 +58,8 @@ class SpaceForest : public Solver<T, R> {
     cfg.priority_bias = P.priorityBias;   // != 0: priority frontier heaps (src/heap.h)
     const char* lm = std::getenv("SFF_LIBM");   // 1: samples with the C library's trig, like the reference (parity mode)
     cfg.libm_sampling = (lm && std::atoi(lm)) ? 1 : 0;
+    // SFF* + per-iteration tree dumps: rewires change parents later on, so the library keeps the parent history
+    cfg.record_parents = (P.optimal && P.saveTreeIter != 0) ? 1 : 0;
     std::vector<double> roots;
     for (const Point<T>& p : P.roots) {
       double a[6];
@@ -76,8 +78,18 @@ class SpaceForest : public Solver<T, R> {
       std::vector<double> pos((size_t)n * 6), cost(n), dpar(n);
       std::vector<int32_t> parent(n), tree(n), iter(n);
       sffgpu_forest_get_nodes(f, pos.data(), parent.data(), tree.data(), iter.data(), cost.data(), dpar.data());
-      if (upTo >= 0)
+      if (upTo >= 0) {
         while (n > 0 && (long)iter[n - 1] > upTo) --n;
+        if (cfg.record_parents) {
+          // SFF*: every node's parent as iteration upTo left it = its last history entry up to then (src/forest.h:329, :344)
+          const int m = sffgpu_forest_get_parent_history(f, nullptr, nullptr, nullptr, 0);
+          sff_compat::check(m < 0 ? m : 0, "parent history");
+          std::vector<int32_t> hn(m), hp(m), hi(m);
+          sffgpu_forest_get_parent_history(f, hn.data(), hp.data(), hi.data(), m);
+          for (int e = 0; e < m && (long)hi[e] <= upTo; ++e)
+            if (hn[e] < n) parent[hn[e]] = hp[e];
+        }
+      }
       this->fillNodes(n, st.n_trees, pos.data(), parent.data(), tree.data(), iter.data(), cost.data(), dpar.data());
     };
     auto loadFrontier = [&](std::vector<int32_t>& open_nodes) {
@@ -91,29 +103,40 @@ class SpaceForest : public Solver<T, R> {
       sff_compat::check(sffgpu_forest_run(f, 0), "forest run");
     } else {
       // saveIterCheck (src/problemStruct.h:256-261, src/forest.h:570-578) dumps after every k-th iteration.  The
-      // loop advances by waves; a plain SFF tree dump is nevertheless exactly the forest after iteration k (the nodes
-      // created up to k, their parents never change).  SFF* rewires parents later in the wave and the frontier of an
-      // earlier iteration cannot be told afterwards: those "iter_<k>_" files hold the state at the END OF THE WAVE
-      // in which iteration k fell (SFF_WAVE=1 keeps that within ThresholdMisses iterations of the reference's).
+      // loop advances by waves, the dumps are nevertheless the state after iteration k:
+      //  * trees: the nodes created up to k; SFF: their parents never change; SFF*: the parent history gives every
+      //    node's parent as iteration k left it (rewires of later iterations undone);
+      //  * frontier: a node joins the open list when it is created and leaves it when its slot is exhausted, which the
+      //    reference does AFTER the slot's last saveIterCheck (:160-163) - here at the end of the wave: the open list after
+      //    iteration k is the list the wave started with plus the nodes the wave has created up to k.
+      //    (Priority-frontier mode pops a slot's node off its heap for the duration of the wave: wave-granular there.)
       long nextTree = P.saveTreeIter, nextFront = P.saveFrontiersIter;
       uint64_t wavesBefore = ~0ULL;
+      const bool exactFront = P.saveFrontiersIter != 0 && P.priorityBias == 0;
       while (true) {
         sffgpu_forest_get_stats(f, &st);
         if (st.waves == wavesBefore) break;   // terminated: the last call did not start a wave
         wavesBefore = st.waves;
+        std::vector<int32_t> open_before;
+        const int nodes_before = st.n_nodes;
+        if (exactFront) loadFrontier(open_before);
         sff_compat::check(sffgpu_forest_run(f, 1), "forest run");
         sffgpu_forest_get_stats(f, &st);
-        bool loaded = false;
         while (P.saveTreeIter != 0 && (long)st.iterations >= nextTree) {
-          if (!P.optimal) { loadNodes(nextTree); loaded = false; }
-          else if (!loaded) { loadNodes(); loaded = true; }
+          loadNodes(nextTree);
           this->saveTrees(prefixFileName(P.fileNames[SaveTree], "iter_" + std::to_string(nextTree) + "_"));
           nextTree += P.saveTreeIter;
         }
         while (P.saveFrontiersIter != 0 && (long)st.iterations >= nextFront) {
-          if (!loaded) { loadNodes(); loaded = true; }
           std::vector<int32_t> open_now;
-          loadFrontier(open_now);
+          if (exactFront) {
+            loadNodes(nextFront);
+            open_now = open_before;
+            for (int id = nodes_before; id < (int)this->allNodes.size(); ++id) open_now.push_back(id);
+          } else {
+            loadNodes();
+            loadFrontier(open_now);
+          }
           saveFrontiers(prefixFileName(P.fileNames[SaveFrontiers], "iter_" + std::to_string(nextFront) + "_"), open_now);
           nextFront += P.saveFrontiersIter;
         }

@@ -115,7 +115,8 @@ typedef struct {
                                host with the C library's cos / sin / acos - the reference's own arithmetic - and the
                                samples are uploaded; 0 = sampled on the GPU with the portable trig of csrc/sff_pmath.h
                                (<= 1 ulp from glibc).  Slower (host engine, one extra upload per round); for parity runs. */
-  int32_t reserved_;
+  int32_t record_parents;   /* SFF* (optimize): 1 = keep the complete parent history (sffgpu_forest_get_parent_history), what
+                               an exact tree dump after a given iteration needs (saveIterCheck, src/forest.h:570-578) */
 } sffgpu_forest_cfg;
 
 typedef struct {
@@ -147,6 +148,11 @@ typedef struct {
   uint64_t star_members;     /* ... k-nearest members (choose-parent / rewire candidates) they looked at */
   uint64_t star_rewires;     /* ... and rewires they applied (src/forest.h:336-348) */
   uint64_t host_fallback_waves; /* device engine: waves finished on the host-replay engine after a device list overflowed */
+  double commit_ms;          /* device time of the in-order commit of all rounds (k_decide, k_resolve, the SFF* stage,
+                                k_append): the part every rank of a sharded forest repeats; HIP events on the eagerly
+                                launched waves, scaled like sweep_ms */
+  double exchange_ms;        /* sharded forests: pack + all-gather + unpack of the answer records of all rounds */
+  uint64_t graph_launches;   /* device engine: waves launched as one hipGraph replay */
 } sffgpu_forest_stats;
 
 int sffgpu_forest_create(sffgpu_ctx* ctx, const sffgpu_forest_cfg* cfg, const double* roots6, int n_roots,
@@ -162,6 +168,12 @@ int sffgpu_forest_get_nodes(sffgpu_forest* f, double* pos6, int32_t* parent, int
 int sffgpu_forest_get_borders(sffgpu_forest* f, int32_t* tree_a, int32_t* tree_b, int32_t* node1, int32_t* node2,
                               double* dist, int cap);
 uint64_t sffgpu_forest_fingerprint(sffgpu_forest* f);
+/* SFF* with sffgpu_forest_cfg::record_parents = 1: one entry per node creation (roots: parent -1, iteration 0) and per
+ * applied rewire (src/forest.h:336-348) - the node, its parent from that iteration on, the iteration - sorted by
+ * iteration.  The forest after iteration k consists of the nodes created up to k, each with the parent of its last entry
+ * with iteration <= k: what the reference's per-iteration tree dumps show (src/problemStruct.h:255-261).  Returns the
+ * number of entries (may exceed cap) or a negative error. */
+int sffgpu_forest_get_parent_history(sffgpu_forest* f, int32_t* node, int32_t* parent, int32_t* iteration, int cap);
 /* open (frontier) nodes in the order SpaceForest::saveFrontiers writes them (src/forest.h:513-568): the frontier
  * deque, or with priorityBias the first heap of every tree in heap order; returns the count (may exceed cap) */
 int sffgpu_forest_get_frontier(sffgpu_forest* f, int32_t* node_ids, int cap);

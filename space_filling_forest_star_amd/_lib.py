@@ -15,7 +15,7 @@ EXPORTED_SYMBOLS = [
     "sffgpu_mesh_upload", "sffgpu_collide_poses", "sffgpu_collide_segments", "sffgpu_sample_steer",
     "sffgpu_nodes_reset", "sffgpu_nodes_append", "sffgpu_nodes_count", "sffgpu_nodes_index", "sffgpu_radius", "sffgpu_knn",
     "sffgpu_forest_create", "sffgpu_forest_destroy", "sffgpu_forest_run", "sffgpu_forest_get_stats",
-    "sffgpu_forest_get_nodes", "sffgpu_forest_get_borders", "sffgpu_forest_fingerprint", "sffgpu_forest_paths",
+    "sffgpu_forest_get_nodes", "sffgpu_forest_get_borders", "sffgpu_forest_fingerprint", "sffgpu_forest_get_parent_history", "sffgpu_forest_paths",
     "sffgpu_forest_path_plan", "sffgpu_forest_smooth_paths",
     "sffgpu_rrt_create", "sffgpu_rrt_destroy", "sffgpu_rrt_run", "sffgpu_rrt_get_stats", "sffgpu_rrt_get_nodes",
     "sffgpu_rrt_get_links", "sffgpu_rrt_paths", "sffgpu_rrt_path_plan", "sffgpu_rrt_smooth_paths",
@@ -40,7 +40,7 @@ class ForestCfg(C.Structure):
                 ("limits", C.c_double * 6), ("dist_tree", C.c_double), ("sampling_dist", C.c_double),
                 ("threshold_misses", C.c_int32), ("max_iterations", C.c_int32), ("node_budget", C.c_int32),
                 ("wave", C.c_int32), ("seed", C.c_uint64), ("rank", C.c_int32), ("world", C.c_int32),
-                ("priority_bias", C.c_double), ("libm_sampling", C.c_int32), ("reserved_", C.c_int32)]
+                ("priority_bias", C.c_double), ("libm_sampling", C.c_int32), ("record_parents", C.c_int32)]
 
 
 class ForestStats(C.Structure):
@@ -54,7 +54,8 @@ class ForestStats(C.Structure):
                 ("collide_ms", C.c_double), ("sample_ms", C.c_double), ("host_ms", C.c_double),
                 ("total_ms", C.c_double), ("query_clock_ms", C.c_double), ("query_clock_launches", C.c_uint64),
                 ("mate_overflow_requeries", C.c_uint64), ("star_rounds", C.c_uint64), ("star_passes", C.c_uint64),
-                ("star_members", C.c_uint64), ("star_rewires", C.c_uint64), ("host_fallback_waves", C.c_uint64)]
+                ("star_members", C.c_uint64), ("star_rewires", C.c_uint64), ("host_fallback_waves", C.c_uint64),
+                ("commit_ms", C.c_double), ("exchange_ms", C.c_double), ("graph_launches", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -318,11 +319,12 @@ class Forest:
 
     def __init__(self, ctx, roots, limits, dist_tree, sampling_dist, dim=6, optimize=False, goal=None,
                  threshold_misses=5, max_iterations=100000, node_budget=0, wave=1, seed=1, rank=0, world=1,
-                 priority_bias=0.0, libm_sampling=False):
+                 priority_bias=0.0, libm_sampling=False, record_parents=False):
         self.ctx = ctx
         cfg = ForestCfg()
         cfg.priority_bias = priority_bias
         cfg.libm_sampling = int(libm_sampling)
+        cfg.record_parents = int(record_parents)
         cfg.dim = dim
         cfg.optimize = int(optimize)
         cfg.has_goal = int(goal is not None)
@@ -389,6 +391,13 @@ class Forest:
 
     def fingerprint(self):
         return self.ctx._L.sffgpu_forest_fingerprint(self.h)
+
+    def parent_history(self):
+        """record_parents=True (SFF*): (node, parent, iteration) of every node creation and applied rewire, by iteration"""
+        n = self.ctx._chk(self.ctx._L.sffgpu_forest_get_parent_history(self.h, None, None, None, 0))
+        node, par, it = (np.zeros(n, np.int32) for _ in range(3))
+        self.ctx._chk(self.ctx._L.sffgpu_forest_get_parent_history(self.h, _ip(node), _ip(par), _ip(it), n))
+        return dict(node=node, parent=par, iter=it)
 
     def paths(self):
         """(cost matrix n_trees x n_trees, connected tree ids)"""

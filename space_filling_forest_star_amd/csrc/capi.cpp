@@ -363,6 +363,31 @@ int sffgpu_rrt_link_plan(sffgpu_rrt* r, int k, int32_t* node_ids, int cap) {
   for (size_t q = 0; q < p.size() && (int)q < cap; ++q) node_ids[q] = p[q];
   return (int)p.size();
 }
+int sffgpu_forest_get_parent_history(sffgpu_forest* f, int32_t* node, int32_t* parent, int32_t* iteration, int cap) {
+  if (!f || cap < 0) return SFFGPU_ERR_ARG;
+  Forest& F = *f->f;
+  if (!F.cfg.record_parents) { f->owner->c->err = "forest: created without record_parents"; return SFFGPU_ERR_ARG; }
+  try { F.sync_host(); } catch (const HipError& e) { f->owner->c->err = e.msg; return SFFGPU_ERR_HIP; }
+  if (F.hist_overflow) { f->owner->c->err = "forest: the device's parent-history buffer ran over"; return SFFGPU_ERR_CAPACITY; }
+  if (!F.cfg.optimize) {   // plain SFF: a node keeps the parent it was created with
+    const int n = (int)F.nodes.size();
+    for (int i = 0; i < n && i < cap; ++i) {
+      if (node) node[i] = i;
+      if (parent) parent[i] = F.nodes[i].parent;
+      if (iteration) iteration[i] = (int32_t)F.nodes[i].iter;
+    }
+    return n;
+  }
+  // (entries of one iteration touch distinct nodes; creation order of the entries is kept among equal keys)
+  std::stable_sort(F.hist.begin(), F.hist.end(), [](const Forest::HistRec& a, const Forest::HistRec& b) { return a.iter < b.iter; });
+  const int n = (int)F.hist.size();
+  for (int i = 0; i < n && i < cap; ++i) {
+    if (node) node[i] = F.hist[i].node;
+    if (parent) parent[i] = F.hist[i].parent;
+    if (iteration) iteration[i] = (int32_t)F.hist[i].iter;
+  }
+  return n;
+}
 int sffgpu_forest_get_frontier(sffgpu_forest* f, int32_t* node_ids, int cap) {
   if (!f) return SFFGPU_ERR_ARG;
   Forest& F = *f->f;

@@ -843,6 +843,24 @@ __global__ __launch_bounds__(256) void k_star_apply(ResolveArgs A, GridView tg, 
     }
   }
   const int n_rew = __popcll(__ballot(rewired != 0));
+  if (S.hist) {
+    // the parent history (exact per-iteration tree dumps): this sample's node with the parent it chose, then every member
+    // its proposal rewires at its turn - whether or not a later sample of the round rewires that node again
+    const bool actv = lane < cnt && S.prop[p] < STAR_INF;
+    const unsigned long long am = __ballot(actv);
+    const int nrec = 1 + __popcll(am);
+    int base = 0;
+    if (lane == 0) base = atomicAdd(S.hist_ctl, nrec);
+    base = __shfl(base, 0);
+    const int it_i = c->iter0_app + i + 1;
+    if (base + nrec <= S.hist_cap) {
+      if (lane == 0) { S.hist[3 * (size_t)base] = id; S.hist[3 * (size_t)base + 1] = S.psel[i]; S.hist[3 * (size_t)base + 2] = it_i; }
+      if (actv) {
+        const size_t at = (size_t)base + 1 + __popcll(am & ((1ULL << lane) - 1ULL));
+        S.hist[3 * at] = S.m_id[p]; S.hist[3 * at + 1] = id; S.hist[3 * at + 2] = it_i;
+      }
+    } else if (lane == 0) S.hist_ctl[1] = 1;
+  }
   if (lane == 0) {
     // ---- the new node (:329, :353-367); a later sample of the round may already have rewired it
     const int ex = A.parent[i];

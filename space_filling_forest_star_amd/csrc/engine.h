@@ -63,7 +63,9 @@ struct HitRec {
   bool operator<(const HitRec& o) const { return d < o.d || (d == o.d && id < o.id); }
 };
 
-enum TimerKind { T_SWEEP = 0, T_COLLIDE = 1, T_SAMPLE = 2, T_KINDS = 3 };
+// T_COMMIT: the in-order commit of a round (k_decide / k_resolve [/ the SFF* stage] / k_append) - the part every rank
+// of a sharded forest repeats; T_EXCHANGE: pack + all-gather + unpack of the answer records
+enum TimerKind { T_SWEEP = 0, T_COLLIDE = 1, T_SAMPLE = 2, T_COMMIT = 3, T_EXCHANGE = 4, T_KINDS = 5 };
 
 struct Ctx {
   int device = 0;
@@ -132,13 +134,13 @@ struct Ctx {
   struct Timed { hipEvent_t a, b; int kind; bool round; };
   std::vector<Timed> pending;
   std::vector<hipEvent_t> pool;
-  double kernel_ms[T_KINDS] = {0, 0, 0};
-  uint64_t kernel_launches[T_KINDS] = {0, 0, 0};   // timed launches
-  uint64_t kernel_calls[T_KINDS] = {0, 0, 0};      // all launches
+  double kernel_ms[T_KINDS] = {0, 0, 0, 0, 0};
+  uint64_t kernel_launches[T_KINDS] = {0, 0, 0, 0, 0};   // timed launches
+  uint64_t kernel_calls[T_KINDS] = {0, 0, 0, 0, 0};      // all launches
   // the forest engine's rounds are sampled (every timer_stride-th is bracketed): their sum is scaled to all rounds,
   // the always-timed batch calls are added as measured
-  double round_ms[T_KINDS] = {0, 0, 0};
-  uint64_t round_calls[T_KINDS] = {0, 0, 0}, round_timed[T_KINDS] = {0, 0, 0};
+  double round_ms[T_KINDS] = {0, 0, 0, 0, 0};
+  uint64_t round_calls[T_KINDS] = {0, 0, 0, 0, 0}, round_timed[T_KINDS] = {0, 0, 0, 0, 0};
   bool round_scope = false;
   bool timing_on = true, timed_now = true;
   int timer_stride = 8;
@@ -243,9 +245,20 @@ struct DevEngine {
       b_n2, b_ta, b_tb, b_dist, bt_key, bt_val, pair, ring, ustate, ulist, uacc, d_parent, d_force, fault_pending;
   // SFF* on the device (devstar.hip; StarView in kernels.h)
   DevBuf s_ktab, s_tree_cnt, s_head, s_mcnt, s_mid, s_md, s_next, s_prop, s_best, s_psel, s_dcl, s_cnt, s_accs, s_hdr, s_changed,
-      s_ew, s_ida, s_idb, s_sub, s_segns, s_fh, s_sovf, s_evs, s_evn, s_eve, s_evd, s_acc, s_backup, s_items, s_dbg;
+      s_ew, s_ida, s_idb, s_sub, s_segns, s_fh, s_sovf, s_evs, s_evn, s_eve, s_evd, s_acc, s_backup, s_items, s_dbg, s_hist;
+  int hist_cap = 0;
   int s_items_cap = 0;
   bool star_inited = false;
+  // a wave's launch chain (k_wave_begin, ThresholdMisses rounds, k_wave_end: 30-100 launches) as ONE hipGraph: the
+  // host's share of a wave drops from ~4 us per launch to one graph launch.  The graph bakes every kernel argument in,
+  // so it is re-captured whenever the signature of those arguments (buffer addresses, sizes, grid geometry) changes.
+  hipGraphExec_t wave_graph = nullptr;
+  uint64_t wave_graph_sig = 0;
+  bool graph_enabled = true;
+  int force_timing = -1;             // >= 0: dev_enqueue_round_eval takes this instead of the per-round stride
+  bool round_timing = false;         // the timing decision of the round being enqueued (evaluation -> commit)
+  uint64_t graph_calls[T_KINDS] = {0, 0, 0, 0, 0};   // timed-kernel launches one replay stands for
+  uint64_t waves_enqueued = 0, graph_launches = 0, graph_captures = 0;
   PinBuf h_ctrl, h_ring, h_trig;
   DevBuf trig;   // libm parity mode: the C library's cos / sin / acos of every ring word (3 doubles per word)
   hipEvent_t ev_ring = nullptr, ev_wave = nullptr, ev_wave2 = nullptr;   // (two status slots: one wave may be enqueued ahead)
@@ -277,8 +290,12 @@ struct Forest {
   void dev_enqueue_end(int slot = 0);
   int dev_finish_wave(double* wait_ms, int slot = 0, bool stream_idle = true);
   void dev_enqueue_wave(int slot);
+  void dev_enqueue_wave_kernels(bool sharded, size_t words);   // begin .. end kernels of one wave (what a graph captures)
+  uint64_t dev_launch_signature();
   DevBuf x_send, x_recv;   // answer records of a round: this rank's, all ranks' (native RCCL exchange)
   bool need_host_exchange = false;   // run(): a sharded wave has to be finished through round_begin / round_commit
+  bool exchange_open = false;        // a T_EXCHANGE timer waits for its closing event (recorded behind the unpack)
+  size_t exchange_idx = 0;
   bool dev_wave_begin();
   size_t dev_exchange_bytes() const;
   void run_device(int max_waves);
@@ -287,6 +304,10 @@ struct Forest {
   ~Forest();
   Mt64 rng;
   std::vector<uint64_t> rng_ahead;   // engine words generated while the GPU works (fixed size: Mt64 keeps a pointer)
+  // cfg.record_parents (SFF*): every node creation and applied rewire as (node, parent from then on, iteration)
+  struct HistRec { int32_t node, parent; uint32_t iter; };
+  std::vector<HistRec> hist;
+  bool hist_overflow = false;
   std::vector<FNode> nodes;
   // per node, kept apart from the 88-byte records because whole-frontier passes and the per-sample input only
   // need these bits: 1 = Node::ForceChildren, 2 = currently on the frontier deque

@@ -111,18 +111,20 @@ Forest::Forest(Ctx* c, const sffgpu_forest_cfg& cf, const double* roots6, int n_
     nodes.reserve(cap);
     nflag.reserve(cap);
   }
-  {   // which engine commits the rounds: the device-resident one (forest_dev.cpp) for plain SFF at GPU-sized waves,
-      // the host replay below otherwise (SFF*, goal / priority modes, sharded runs, tiny waves)
+  {   // which engine commits the rounds: the device-resident one (forest_dev.cpp) for plain SFF and SFF*,
+      // the host replay below for goal / priority modes (and when SFFGPU_ENGINE=host asks for it)
     const char* e = getenv("SFFGPU_ENGINE");
     const std::string want = e ? e : "";
-    dev.on = device_eligible() && want != "host" && (cfg.wave >= 256 || want == "device") &&
-             cfg.wave <= 64 * SFFK_DEV_MAX_GROUPS;
+    // (every wave size: at wave = 1 - the reference's own order - the device engine's one graph launch + one status
+    // read per wave is 1.3x the host replay's per-round synchronisation, at wave 64 1.6x: profiles/r3_small_waves.txt)
+    dev.on = device_eligible() && want != "host" && cfg.wave <= 64 * SFFK_DEV_MAX_GROUPS;
   }
   // (device engine: a wave of new nodes past the budget plus the round's temporaries behind them)
   ctx->store_reset(std::max(cfg.node_budget, 4096) + (dev.on ? 2 * cfg.wave + 128 : cfg.wave + 64));
   std::vector<int32_t> tids(n_roots);
   for (int j = 0; j < n_roots; ++j) {          // src/forest.h:60-76
     int id = add_node(roots6 + 6 * (size_t)j, j, -1, 0, 0, 0);
+    if (cfg.record_parents) hist.push_back({id, -1, 0u});
     frontier.push_back(id);
     nflag[id] |= 2;
     tids[j] = j;
@@ -144,6 +146,7 @@ Forest::Forest(Ctx* c, const sffgpu_forest_cfg& cf, const double* roots6, int n_
   ctx->store_append(roots6, tids.data(), n_roots);
   if (cfg.has_goal) {                          // src/forest.h:91-109: searched like any tree, never expanded
     goal_node = add_node(cfg.goal, n_roots, -1, 0, 0, 0);
+    if (cfg.record_parents) hist.push_back({goal_node, -1, 0u});
     int32_t gt = n_roots;
     ctx->store_append(cfg.goal, &gt, 1);
   }
@@ -171,6 +174,7 @@ Forest::Forest(Ctx* c, const sffgpu_forest_cfg& cf, const double* roots6, int n_
   if (const char* e = getenv("SFFGPU_TEST_HITCAP")) hit_cap = std::min(64, std::max(1, atoi(e)));  // one lane per hit
   if (const char* e = getenv("SFFGPU_TEST_NBCAP")) nb_cap = std::max(1, atoi(e));
   if (const char* e = getenv("SFFGPU_TEST_STAR_PASSES")) star_pass_limit = std::max(1, atoi(e));
+  if (const char* e = getenv("SFFGPU_NO_GRAPH")) dev.graph_enabled = atoi(e) == 0;
 }
 
 int Forest::add_node(const double* pos, int tree, int parent, double dclosest, double droot, unsigned it) {
@@ -283,6 +287,9 @@ void Forest::fill_stats(sffgpu_forest_stats* out) {
   s.sweep_ms = ctx->kernel_ms_total(T_SWEEP);
   s.collide_ms = ctx->kernel_ms_total(T_COLLIDE);
   s.sample_ms = ctx->kernel_ms_total(T_SAMPLE);
+  s.commit_ms = ctx->kernel_ms_total(T_COMMIT);
+  s.exchange_ms = ctx->kernel_ms_total(T_EXCHANGE);
+  s.graph_launches = dev.graph_launches;
   *out = s;
 }
 
@@ -294,7 +301,7 @@ Forest::~Forest() {
                     &dev.slot_pos, &dev.act_slot2, &dev.dk, &dev.trig, &dev.s_ktab, &dev.s_tree_cnt, &dev.s_head, &dev.s_mcnt, &dev.s_mid, &dev.s_md,
                     &dev.s_next, &dev.s_prop, &dev.s_best, &dev.s_psel, &dev.s_dcl, &dev.s_cnt, &dev.s_accs, &dev.s_hdr, &dev.s_changed,
                     &dev.s_ew, &dev.s_ida, &dev.s_idb, &dev.s_sub, &dev.s_segns, &dev.s_fh, &dev.s_sovf, &dev.s_evs, &dev.s_evn, &dev.s_eve,
-                    &dev.s_evd, &dev.s_acc, &dev.s_backup, &dev.s_items, &dev.s_dbg, &dev.w_dep, &dev.w_acc, &dev.w_ev, &dev.acc_pref, &dev.w_cnt, &dev.dep_rec, &x_send, &x_recv};
+                    &dev.s_evd, &dev.s_acc, &dev.s_backup, &dev.s_items, &dev.s_dbg, &dev.s_hist, &dev.w_dep, &dev.w_acc, &dev.w_ev, &dev.acc_pref, &dev.w_cnt, &dev.dep_rec, &x_send, &x_recv};
   if (dev.inited) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
@@ -304,6 +311,7 @@ Forest::~Forest() {
   dev.h_ctrl.release();
   dev.h_ring.release();
   dev.h_trig.release();
+  if (dev.wave_graph) (void)hipGraphExecDestroy(dev.wave_graph);
   if (dev.ev_ring) (void)hipEventDestroy(dev.ev_ring);
   if (dev.ev_wave) (void)hipEventDestroy(dev.ev_wave);
   if (dev.ev_wave2) (void)hipEventDestroy(dev.ev_wave2);
@@ -1268,6 +1276,7 @@ void Forest::round_commit(const int32_t* all, int total_words, const int32_t* co
         }
       }
       id = add_node(cd.pos, mine, parent, sffg::dist6(cd.pos, nodes[parent].pos), best, iteration);  // :329
+      if (cfg.record_parents) hist.push_back({id, parent, iteration});
       for (const KN& kn : knn) {                               // :332-350
         double npd = kn.d;   // dist6(node, new) == dist6(new, node) bit for bit (squares of exactly negated terms)
         double proposed = best + npd;
@@ -1276,6 +1285,7 @@ void Forest::round_commit(const int32_t* all, int total_words, const int32_t* co
           st.collide_calls += calls(kn.mb->bwd_fh, kn.mb->bwd_ns);
           if (kn.mb->bwd_free) {
             nodes[kn.node].parent = id;
+            if (cfg.record_parents) hist.push_back({kn.node, id, iteration});
             nodes[kn.node].d_closest = npd;
             nodes[kn.node].d_root = proposed;                  // descendants keep their old cost (Appendix A.6)
           }
@@ -1284,6 +1294,7 @@ void Forest::round_commit(const int32_t* all, int total_words, const int32_t* co
       st.nn_queries += 1;                                      // :317 knnSearch
     } else {
       id = add_node(cd.pos, mine, expanded, cd.pdist, cd.pdist + nodes[expanded].d_root, iteration);  // :353
+      if (cfg.record_parents) hist.push_back({id, expanded, iteration});
     }
     cd.accepted_id = id;
     if (use_priority()) {                                      // :360-363

@@ -74,6 +74,11 @@ sffk::StarView Forest::star_view() const {
   v.acc = d.s_acc.as<unsigned long long>();
   v.backup = d.s_backup.as<sffk::DevCtrl>();
   v.dbg = d.s_dbg.as<unsigned long long>();
+  if (cfg.record_parents) {
+    v.hist = d.s_hist.as<int32_t>() + 4;
+    v.hist_ctl = d.s_hist.as<int32_t>();
+    v.hist_cap = d.hist_cap;
+  }
   return v;
 }
 
@@ -136,6 +141,11 @@ void Forest::dev_star_setup() {
     HIPCHK(hipMemset(d.s_changed.p, 0, 64));
     HIPCHK(hipMemset(d.s_acc.p, 0, 64 * SFFK_STAR_ACC * 8));
     d.star_inited = true;
+  }
+  if (cfg.record_parents) {   // (device entries start at 0 with every upload: the host's list holds everything before)
+    d.hist_cap = std::max(d.hist_cap, 4 * ctx->store_cap + 4 * cfg.wave);
+    d.s_hist.ensure(((size_t)3 * d.hist_cap + 4) * 4);
+    HIPCHK(hipMemset(d.s_hist.p, 0, 16));
   }
   // (the control block's epoch restarts with every upload: no list head of an earlier stay on the device may match it)
   if (d.s_head.p) HIPCHK(hipMemset(d.s_head.p, 0, d.s_head.cap));
@@ -222,6 +232,10 @@ void Forest::dev_size_node_arrays() {
     const size_t old_head = d.s_head.cap;
     d.s_head.ensure((size_t)cap * 8);
     if (d.s_head.cap != old_head) HIPCHK(hipMemsetAsync(d.s_head.p, 0, d.s_head.cap, c.stream));
+  }
+  if (cfg.record_parents && d.s_hist.p && 4 * cap + 4 * cfg.wave > d.hist_cap) {   // (grows with the store; entries are kept)
+    d.hist_cap = 4 * cap + 4 * cfg.wave;
+    d.s_hist.ensure(((size_t)3 * d.hist_cap + 4) * 4);
   }
   const size_t old_claim = d.claim.cap;
   d.claim.ensure((size_t)cap * 4);
@@ -320,7 +334,9 @@ void Forest::dev_upload_state() {
     HIPCHK(hipEventCreateWithFlags(&d.ev_wave, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&d.ev_wave2, hipEventDisableTiming));
     d.max_wave_words = (uint64_t)wave * (1 + (uint64_t)std::max(1, cfg.threshold_misses) * words_per) + 64;
-    d.ring_words = next_pow2(4 * d.max_wave_words);
+    // (room for four waves' worth - and for everything the host engine may have generated ahead when the state moves
+    // to the device in the middle of a run)
+    d.ring_words = next_pow2(std::max<uint64_t>(4 * d.max_wave_words, (uint64_t)rng_ahead.size() + 2 * d.max_wave_words + 64));
     d.ring.ensure((size_t)d.ring_words * 8);
     d.h_ring.ensure((size_t)d.ring_words * 8);
     if (cfg.libm_sampling) {
@@ -508,6 +524,18 @@ void Forest::sync_host() {
     HIPCHK(hipMemcpy(it.data(), d.iter.as<uint32_t>() + n0, (size_t)m * 4, hipMemcpyDeviceToHost));
     for (int j = 0; j < m; ++j) add_node(&pos[6 * (size_t)j], tr[j], par[j], dc[j], dr[j], it[j]);
   }
+  if (cfg.optimize && cfg.record_parents && d.s_hist.p) {   // the device's new history entries join the host's list
+    int32_t ctl[4];
+    HIPCHK(hipMemcpy(ctl, d.s_hist.p, 16, hipMemcpyDeviceToHost));
+    if (ctl[1]) hist_overflow = true;
+    const int m = std::min(ctl[0], d.hist_cap);
+    if (m > 0) {
+      std::vector<int32_t> raw((size_t)3 * m);
+      HIPCHK(hipMemcpy(raw.data(), d.s_hist.as<int32_t>() + 4, raw.size() * 4, hipMemcpyDeviceToHost));
+      for (int j = 0; j < m; ++j) hist.push_back({raw[3 * (size_t)j], raw[3 * (size_t)j + 1], (uint32_t)raw[3 * (size_t)j + 2]});
+      HIPCHK(hipMemset(d.s_hist.p, 0, 16));
+    }
+  }
   if (cfg.optimize && n0 > 0) {   // SFF*: rewires change parent / costs of nodes the mirror already holds
     std::vector<double> dr(n0), dc(n0);
     std::vector<int32_t> par(n0);
@@ -690,7 +718,9 @@ void Forest::dev_enqueue_round_eval(void* send_dev) {
   const int32_t* dev_n = reinterpret_cast<const int32_t*>(d.ctrl.p);   // {n_act, halt}
   sffk::NodeStoreMut stm{c.sx.as<float>(), c.sy.as<float>(), c.sz.as<float>(), c.syaw.as<float>(),
                          c.spitch.as<float>(), c.sroll.as<float>(), c.stree.as<int32_t>(), c.spos.as<double>()};
-  c.timing_on = c.timer_stride <= 1 || d.rounds_enqueued % (uint64_t)c.timer_stride == 0;
+  c.timing_on = d.force_timing >= 0 ? d.force_timing != 0
+                                   : (c.timer_stride <= 1 || d.rounds_enqueued % (uint64_t)c.timer_stride == 0);
+  d.round_timing = c.timing_on;   // (the commit of this round is timed like its evaluation)
   c.round_scope = true;
   ++d.rounds_enqueued;
   sffk::SampleParams prm{};
@@ -768,7 +798,12 @@ void Forest::dev_enqueue_round_eval(void* send_dev) {
                              B.STRIDE, ca.ctrl, c.r_items.p, ca.items_cap, ca.sub, ca.first_hit, ca.seg_ovf,
                              cfg.optimize ? &tref_keep : &tref, dev_n);
   c.time_end();
-  if (send_dev) sffk::launch_pack_records(c.stream, dev_resolve_args(*this, B), cfg.rank, cfg.world, n, static_cast<int32_t*>(send_dev));
+  if (send_dev) {
+    c.time_begin(T_EXCHANGE);     // (closed by the commit: pack, the caller's / the library's all-gather, unpack)
+    sffk::launch_pack_records(c.stream, dev_resolve_args(*this, B), cfg.rank, cfg.world, n, static_cast<int32_t*>(send_dev));
+    exchange_open = c.timed_now;
+    exchange_idx = c.pending.empty() ? 0 : c.pending.size() - 1;
+  }
   c.timing_on = true;
   c.round_scope = false;
 }
@@ -778,7 +813,13 @@ void Forest::dev_enqueue_round_commit(const void* recv_dev) {
   Ctx& c = *ctx;
   const DevRoundBufs B = dev_round_bufs(*this);
   const sffk::ResolveArgs ra = dev_resolve_args(*this, B);
-  if (recv_dev) sffk::launch_unpack_records(c.stream, ra, cfg.rank, cfg.world, B.n, static_cast<const int32_t*>(recv_dev));
+  if (recv_dev) {
+    sffk::launch_unpack_records(c.stream, ra, cfg.rank, cfg.world, B.n, static_cast<const int32_t*>(recv_dev));
+    if (exchange_open) { HIPCHK(hipEventRecord(c.pending[exchange_idx].b, c.stream)); exchange_open = false; }
+  }
+  c.round_scope = true;
+  c.timing_on = dev.round_timing;
+  c.time_begin(T_COMMIT);
   if (cfg.optimize) {
     // SFF*: k nearest + member edges + the rewire fixed point for the accepted samples, between k_resolve and k_append
     sffk::StarLaunch sl{};
@@ -795,6 +836,9 @@ void Forest::dev_enqueue_round_commit(const void* recv_dev) {
   } else {
     sffk::launch_commit(c.stream, ra, B.n);
   }
+  c.time_end();
+  c.timing_on = true;
+  c.round_scope = false;
 }
 
 void Forest::dev_enqueue_end(int slot) {
@@ -806,9 +850,51 @@ void Forest::dev_enqueue_end(int slot) {
   HIPCHK(hipEventRecord(slot ? d.ev_wave2 : d.ev_wave, c.stream));
 }
 
+// FNV-1a over everything a wave's launches bake in: a captured graph is only valid while this stays the same
+uint64_t Forest::dev_launch_signature() {
+  Ctx& c = *ctx;
+  uint64_t x = 1469598103934665603ULL;
+  auto mix = [&](const void* p, size_t n) {
+    const unsigned char* q = static_cast<const unsigned char*>(p);
+    for (size_t i = 0; i < n; ++i) { x ^= q[i]; x *= 1099511628211ULL; }
+  };
+  const DevRoundBufs B = dev_round_bufs(*this);
+  const sffk::ResolveArgs ra = dev_resolve_args(*this, B);
+  mix(&B, sizeof B);
+  mix(&ra, sizeof ra);
+  mix(&c.gridv, sizeof c.gridv);
+  mix(&c.tgridv, sizeof c.tgridv);
+  mix(&c.envv, sizeof c.envv);
+  mix(&c.robv, sizeof c.robv);
+  const void* ptrs[] = {c.r_q.p, c.r_cnt.p, c.r_sega.p, c.r_segb.p, c.r_items.p, c.r_sub.p, c.r_out.p, dev.d_parent.p, dev.d_force.p,
+                        dev.ctrl.p, dev.ring.p, dev.trig.p, c.sx.p, c.spos.p, c.stree.p};
+  mix(ptrs, sizeof ptrs);
+  const double scal[] = {c.sweep_eps(), c.grid_cell, cfg.sampling_dist, cfg.dist_tree};
+  mix(scal, sizeof scal);
+  const int ints[] = {cfg.threshold_misses, star_pass_limit, cfg.wave, c.store_cap, dev.temp_base, hit_cap, nb_cap};
+  mix(ints, sizeof ints);
+  return x ? x : 1;
+}
+
+void Forest::dev_enqueue_wave_kernels(bool sharded, size_t words) {
+  sffk::launch_wave_begin(ctx->stream, dev_view());
+  for (int r = 0; r < std::max(1, cfg.threshold_misses); ++r) {
+    dev_enqueue_round_eval(sharded ? x_send.p : nullptr);
+    if (sharded) ctx->rccl_all_gather_i32(x_send.p, x_recv.p, words);
+    dev_enqueue_round_commit(sharded ? x_recv.p : nullptr);
+  }
+  sffk::launch_wave_end(ctx->stream, dev_view(), ctx->gridv.ovf_cnt, ctx->tgridv.ovf_cnt,
+                        cfg.optimize ? dev.s_acc.as<unsigned long long>() : nullptr);
+}
+
 // one whole wave: begin, ThresholdMisses rounds (the device skips what it does not need), end + status copy
 void Forest::dev_enqueue_wave(int slot) {
-  dev_enqueue_begin();
+  Ctx& c = *ctx;
+  DevEngine& d = dev;
+  if (d.ring_pending) {   // the words this wave may read have to be resident
+    HIPCHK(hipStreamWaitEvent(c.stream, d.ev_ring, 0));
+    d.ring_pending = false;
+  }
   // (SFFGPU_TEST_EXCHANGE_SELF: a one-rank forest packs, all-gathers and unpacks too - the collective on one GPU)
   const bool self_exchange = getenv("SFFGPU_TEST_EXCHANGE_SELF") != nullptr;
   const bool sharded = cfg.world > 1 || (self_exchange && ctx->rccl_comm != nullptr);
@@ -818,12 +904,52 @@ void Forest::dev_enqueue_wave(int slot) {
     x_send.ensure(words * 4);
     x_recv.ensure(words * 4 * (size_t)cfg.world);
   }
-  for (int r = 0; r < std::max(1, cfg.threshold_misses); ++r) {
-    dev_enqueue_round_eval(sharded ? x_send.p : nullptr);
-    if (sharded) ctx->rccl_all_gather_i32(x_send.p, x_recv.p, words);
-    dev_enqueue_round_commit(sharded ? x_recv.p : nullptr);
+  // every timer_stride-th wave is launched kernel by kernel with HIP events around the timed kernels (the figures are
+  // scaled to all waves); the others replay the captured graph
+  const bool timed_wave = c.timer_stride <= 1 || d.waves_enqueued % (uint64_t)c.timer_stride == 0;
+  ++d.waves_enqueued;
+  const bool use_graph = d.graph_enabled && !sharded && !timed_wave;
+  if (use_graph) {
+    const uint64_t sig = dev_launch_signature();   // (also makes sure every buffer of a round exists: no allocation inside the capture)
+    if (!d.wave_graph || sig != d.wave_graph_sig) {
+      if (d.wave_graph) { (void)hipGraphExecDestroy(d.wave_graph); d.wave_graph = nullptr; }
+      uint64_t before[T_KINDS];
+      for (int k = 0; k < T_KINDS; ++k) before[k] = c.round_calls[k];
+      d.force_timing = 0;
+      HIPCHK(hipStreamBeginCapture(c.stream, hipStreamCaptureModeRelaxed));
+      hipGraph_t g = nullptr;
+      try {
+        dev_enqueue_wave_kernels(false, 0);
+      } catch (...) {
+        (void)hipStreamEndCapture(c.stream, &g);
+        if (g) (void)hipGraphDestroy(g);
+        d.force_timing = -1;
+        throw;
+      }
+      d.force_timing = -1;
+      HIPCHK(hipStreamEndCapture(c.stream, &g));
+      HIPCHK(hipGraphInstantiate(&d.wave_graph, g, nullptr, nullptr, 0));
+      (void)hipGraphDestroy(g);
+      for (int k = 0; k < T_KINDS; ++k) {   // (the capture itself executed nothing: its counts are taken back)
+        d.graph_calls[k] = c.round_calls[k] - before[k];
+        c.round_calls[k] = before[k];
+        c.kernel_calls[k] -= d.graph_calls[k];
+      }
+      d.rounds_enqueued -= (uint64_t)std::max(1, cfg.threshold_misses);
+      d.wave_graph_sig = sig;
+      ++d.graph_captures;
+    }
+    HIPCHK(hipGraphLaunch(d.wave_graph, c.stream));
+    for (int k = 0; k < T_KINDS; ++k) { c.round_calls[k] += d.graph_calls[k]; c.kernel_calls[k] += d.graph_calls[k]; }
+    d.rounds_enqueued += (uint64_t)std::max(1, cfg.threshold_misses);
+    ++d.graph_launches;
+  } else {
+    d.force_timing = d.graph_enabled && !sharded ? 1 : -1;   // (graph mode: the eager waves are the timed ones, all their rounds)
+    dev_enqueue_wave_kernels(sharded, words);
+    d.force_timing = -1;
   }
-  dev_enqueue_end(slot);
+  HIPCHK(hipMemcpyAsync(d.h_ctrl.as<sffk::DevCtrl>() + slot, d.ctrl.p, sizeof(sffk::DevCtrl), hipMemcpyDeviceToHost, c.stream));
+  HIPCHK(hipEventRecord(slot ? d.ev_wave2 : d.ev_wave, c.stream));
   dev.host_stale = true;
 }
 

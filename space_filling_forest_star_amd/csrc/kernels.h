@@ -407,6 +407,9 @@ struct StarView {
   unsigned long long* acc;     // 64 lines x SFFK_STAR_ACC: Collide calls, isPathFree calls, rounds, passes, members, rewires
   DevCtrl* backup;             // the control block as a rolled-back round leaves it (restored when the star stage faults)
   unsigned long long* dbg;     // SFFGPU_PROFILE: 32 counters of the star kernels (null = off)
+  // record_parents: (node, parent, iteration) triples appended by k_star_apply - one per created node and per ACTIVE
+  // rewire (also those a later sample of the round overrides); hist[0] of hist_ctl = entries, [1] = ran over
+  int32_t* hist; int32_t* hist_ctl; int hist_cap;
 };
 // per-sample verdicts of k_decide
 #define SFFK_DEPENDS 0     // the neighbour walk reached a sample of the same round first: k_resolve continues at dk

@@ -137,6 +137,38 @@ def test_sff_star_device_faults_finish_the_wave_on_the_host_path(S, ctx, env):
     assert_same_forest(fo, fg)
 
 
+@pytest.mark.parametrize("which", ["device", "host"])
+def test_sff_star_parent_history_gives_the_forest_after_any_iteration(S, ctx, which):
+    """record_parents: the (node, parent, iteration) history of node creations and applied rewires - what an exact
+    per-iteration tree dump of SFF* needs (saveIterCheck, src/forest.h:570-578).  The forest "after iteration k" rebuilt
+    from it must equal the oracle's run that stops at iteration k (same waves, same seed: a prefix of the longer run)."""
+    sc, w = load_world(ctx, "triang")
+    roots = sc["xml_points"][:4]
+    kw = dict(dist_tree=sc["dist_tree"], sampling_dist=sc["sampling_dist"], dim=6, wave=96, seed=9, optimize=True)
+    with engine(SFFGPU_ENGINE=which):
+        fg = S.Forest(ctx, roots, sc["limits"], max_iterations=9000, record_parents=True, **kw)
+    assert fg.device_engine() == (which == "device")
+    fg.run()
+    h = fg.parent_history()
+    ng = fg.nodes()
+    assert np.all(np.diff(h["iter"]) >= 0) and len(h["node"]) > len(ng["parent"])     # creations + rewires
+    # the last entry of every node is its final parent
+    last = np.full(len(ng["parent"]), -2, np.int32)
+    last[h["node"]] = h["parent"]
+    assert np.array_equal(last, ng["parent"])
+    for k in (137, 1000, 4321, 9000):
+        fo = O.Forest(w, roots, sc["limits"], max_iterations=k, **kw)
+        fo.run()
+        no = fo.nodes()
+        n_k = int(np.sum(ng["iter"] <= k))
+        assert n_k == len(no["parent"])
+        par = np.full(n_k, -2, np.int32)
+        m = h["iter"] <= k
+        par[h["node"][m]] = h["parent"][m]          # (entries are sorted by iteration: the last one wins)
+        assert np.array_equal(par, no["parent"]), k
+    fg.close()
+
+
 def test_device_engine_is_the_default_for_gpu_sized_waves_and_equals_the_host_engine(S, ctx):
     # (a forest owns its context's node store while it lives: one at a time)
     fo, fd = make(S, ctx, "dense3d", 1024, 60000, seed=11, which="")       # default choice

@@ -561,8 +561,8 @@ def test_libm_sampling_mode_equals_the_libm_oracle(S, ctx, golden_dir):
         kw = dict(dist_tree=sc["dist_tree"], sampling_dist=sc["sampling_dist"], dim=sc["dim"], max_iterations=iters,
                   node_budget=budget, wave=wave, seed=1)
         f = S.Forest(ctx, roots, sc["limits"], libm_sampling=True, **kw)
-        # (waves >= 256 commit on the device-resident engine: the host's libm values travel in the engine-word ring)
-        assert f.device_engine() == (wave >= 256)
+        # (the device-resident engine at every wave size: the host's libm values travel beside the engine words)
+        assert f.device_engine()
         f.run()
         got = mk.summary(f)
         for k in got:
