@@ -202,6 +202,12 @@ class Context:
 
     def close(self):
         if getattr(self, "h", None):
+            # (solver sessions hold a pointer to this context: they go first, whoever still references them)
+            for child in list(getattr(self, "_children", ())):
+                try:
+                    child.close()
+                except Exception:
+                    pass
             self._L.sffgpu_destroy(self.h)
             self.h = None
 
@@ -210,6 +216,12 @@ class Context:
             self.close()
         except Exception:
             pass
+
+    def _adopt(self, child):
+        import weakref
+        if not hasattr(self, "_children"):
+            self._children = weakref.WeakSet()
+        self._children.add(child)
 
     def _chk(self, rc):
         if rc < 0:
@@ -345,10 +357,12 @@ class Forest:
         h = C.c_void_p()
         ctx._chk(ctx._L.sffgpu_forest_create(ctx.h, C.byref(cfg), _dp(r), len(r), C.byref(h)))
         self.h = h
+        ctx._adopt(self)
 
     def close(self):
         if getattr(self, "h", None):
-            self.ctx._L.sffgpu_forest_destroy(self.h)
+            if getattr(self.ctx, "h", None):     # (a context that is gone took its sessions with it)
+                self.ctx._L.sffgpu_forest_destroy(self.h)
             self.h = None
 
     def __del__(self):
@@ -494,10 +508,12 @@ class Rrt:
         h = C.c_void_p()
         ctx._chk(ctx._L.sffgpu_rrt_create(ctx.h, C.byref(cfg), _dp(r), len(r), C.byref(h)))
         self.h = h
+        ctx._adopt(self)
 
     def close(self):
         if getattr(self, "h", None):
-            self.ctx._L.sffgpu_rrt_destroy(self.h)
+            if getattr(self.ctx, "h", None):
+                self.ctx._L.sffgpu_rrt_destroy(self.h)
             self.h = None
 
     def __del__(self):

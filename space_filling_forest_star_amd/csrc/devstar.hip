@@ -111,7 +111,7 @@ __device__ __forceinline__ void star_cells_mates(const GridView& tg, int m, int 
 #define STAR_R0_MAX 4
 #define STAR_U (((2 * STAR_R0_MAX + 1) * (2 * STAR_R0_MAX + 1) * (2 * STAR_R0_MAX + 1) + 63) / 64)
 #define STAR_MATE_U 16                              // x 64 accepted samples of a round whose list is scanned from registers
-#define STAR_POOL 6                                 // batches of 64 cube candidates selected from at once
+#define STAR_POOL 10                                // batches of 64 cube candidates selected from at once
 #define STAR_INF_BITS 0x7ff0000000000000ULL
 __global__ __launch_bounds__(256) void k_star_knn(ResolveArgs A, GridView g, GridView tg, NodeStoreView st, double cell_edge,
                                                   double slack, int R0) {

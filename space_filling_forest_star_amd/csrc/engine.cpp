@@ -627,7 +627,6 @@ void Ctx::grid_setup(const double limits[6], double cell) {
   if (gridv_ovf_cap_next < 65536) gridv_ovf_cap_next = 65536;
   gridv.ovf_cap = gridv_ovf_cap_next;
   if (const char* e = getenv("SFFGPU_TEST_GRID_OVF")) gridv.ovf_cap = std::max(gridv.ovf_cap / 65536 * atoi(e), atoi(e));  // tests: tiny list
-  if (const char* e = getenv("SFFGPU_TEST_GRID_BK")) gridv.bk = std::max(1, std::min(8, atoi(e)));
   g_cnt.ensure(ncells * sizeof(int32_t));
   g_items.ensure(ncells * gridv.bk * sizeof(sffk::GridItem));
   g_ovfcnt.ensure(16);
