@@ -33,7 +33,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r2_bench_pmc_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r3_bench_pmc_summary.json")
 
 
 def parse_args():

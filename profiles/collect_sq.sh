@@ -9,7 +9,7 @@ out=$root/gpurun_out
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_LDS_BANK_CONFLICT \
-  --output-format csv -d $out/${tag}_sq -o p -- python3 $root/bench.py --gpus 1 --steps 20 --warmup 5 --cpu-iters 0 --no-sweep-micro --no-wave-sweep > $out/${tag}_sq.log 2>&1
+  --output-format csv -d $out/${tag}_sq -o p -- python3 $root/bench.py --gpus 1 --steps 20 --warmup 5 --cpu-iters 0 --no-sweep-micro --no-wave-sweep --no-extra-legs > $out/${tag}_sq.log 2>&1
 python3 - "$out/${tag}_sq/p_counter_collection.csv" > $out/${tag}_sq_summary.json <<'PY'
 import collections, csv, json, sys
 acc = collections.defaultdict(lambda: collections.defaultdict(float))

@@ -600,6 +600,13 @@ void Ctx::store_set_tree(const int32_t* ids, int n, int32_t tree) {
   HIPCHK(hipMemcpyAsync(d_a.p, h_a.p, (size_t)n * 4, hipMemcpyHostToDevice, stream));
   sffk::launch_set_tree(stream, stree.as<int32_t>(), d_a.as<int32_t>(), n, tree);
   sync();
+  if (grid_on) {   // the index's items carry their node's tree id: re-inserted with the new labels (merges are rare)
+    double lim[6];
+    memcpy(lim, grid_limits, sizeof lim);
+    grid_setup(lim, grid_cell);
+    grid_insert_new();
+    grid_check(/*bulk=*/true);
+  }
 }
 
 // ------------------------------------------------------------------ grid
@@ -955,7 +962,7 @@ void Ctx::radius(const double* q6, int nq, const double* r, const int32_t* tree,
 // k nearest through radius sweeps: the radius of each query is adapted (grow while fewer than k
 // are inside, shrink when the hit list overflows) until the k smallest exact distances are known.
 void Ctx::knn(const double* q6, int nq, int k, const int32_t* tree, const int32_t* max_id, int32_t* idx, double* dist,
-              int32_t* cnt) {
+              int32_t* cnt, bool tree_by_grid) {
   if (nq <= 0 || k <= 0) return;
   HIPCHK(hipSetDevice(device));
   if (k <= 64) {
@@ -978,7 +985,7 @@ void Ctx::knn(const double* q6, int nq, int k, const int32_t* tree, const int32_
     HIPCHK(hipMemcpyAsync(d_a.p, h_a.p, (size_t)nq * sizeof(sffk::KnnQuery), hipMemcpyHostToDevice, stream));
     // with an index over the store (sffgpu_nodes_index) and no per-tree restriction (a tree with fewer than k nodes
     // would make the shells grow over the whole grid) every query is answered from the cells around it
-    const bool by_grid = grid_on && tree == nullptr && store_n >= k;
+    const bool by_grid = grid_on && (tree == nullptr || tree_by_grid) && store_n >= k;
     if (by_grid) {
       grid_insert_new();
       grid_check(/*bulk=*/true);

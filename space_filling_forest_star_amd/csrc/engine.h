@@ -174,8 +174,10 @@ struct Ctx {
   // exact radius query; results sorted by (dist, id).  Returns per-query totals in cnt.
   void radius(const double* q6, int nq, const double* r, const int32_t* tree, const int32_t* max_id, int32_t* idx,
               double* dist, int32_t* cnt, int cap);
+  // tree_by_grid: the caller vouches that every queried tree holds (nearly) all nodes, so per-tree queries may use the
+  // index too (sffgpu_nodes_index / the RRT session's grid)
   void knn(const double* q6, int nq, int k, const int32_t* tree, const int32_t* max_id, int32_t* idx, double* dist,
-           int32_t* cnt);
+           int32_t* cnt, bool tree_by_grid = false);
   double sweep_eps() const;
   // one sweep launch over the first n_store entries; per-query hit lists sorted by (dist, id)
   void sweep_lists(const double* q6, int nq, const std::vector<double>& r, const int32_t* tree, const int32_t* max_id,

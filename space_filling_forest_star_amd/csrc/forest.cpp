@@ -176,6 +176,12 @@ Forest::Forest(Ctx* c, const sffgpu_forest_cfg& cf, const double* roots6, int n_
   if (const char* e = getenv("SFFGPU_TEST_NBCAP")) nb_cap = std::max(1, atoi(e));
   if (const char* e = getenv("SFFGPU_TEST_STAR_PASSES")) star_pass_limit = std::max(1, atoi(e));
   if (const char* e = getenv("SFFGPU_NO_GRAPH")) dev.graph_enabled = atoi(e) == 0;
+  else if (cfg.optimize) {
+    // rocprofv3 (ROCm 7.2) crashes while tracing replays of the SFF* wave graph (~130 kernel nodes; the plain SFF graph
+    // of ~35 nodes traces fine): under the profiler SFF* waves are launched kernel by kernel
+    const char* pre = getenv("LD_PRELOAD");
+    if (pre && strstr(pre, "rocprofiler")) dev.graph_enabled = false;
+  }
 }
 
 int Forest::add_node(const double* pos, int tree, int parent, double dclosest, double droot, unsigned it) {

@@ -34,6 +34,15 @@ Rrt::Rrt(Ctx* c, const sffgpu_rrt_cfg& cf, const double* roots6, int n_roots) : 
   links.resize(nt);
   eaten.resize(nt);
   ctx->store_reset(std::max(4096, cfg.max_iterations + nt + 16));
+  if (!getenv("SFFGPU_RRT_NO_GRID")) {
+    // index over the store (the counterpart of flannIndex->buildIndex, src/rrt.h:56-62): used by knn() above
+    const double cell = 1.01 * std::max(cfg.sampling_dist, cfg.dist_tree);
+    ctx->grid_bk = 8;
+    ctx->grid_cell0 = cell;
+    ctx->grid_rebuilds = 0;
+    ctx->gridv_ovf_cap_next = 65536;
+    ctx->grid_setup(cfg.limits, cell);
+  }
   for (int j = 0; j < n_roots; ++j) {          // src/rrt.h:48-62
     add_node(roots6 + 6 * (size_t)j, j, j, -1, 0, 0, 0);
     tree_frontier.push_back(j);
@@ -89,7 +98,16 @@ RLink Rrt::make_link(int a, int b) {            // DistanceHolder(first, second)
 void Rrt::knn(const double* q, int nq, const int32_t* tree, int k, std::vector<std::vector<int>>& out) {
   std::vector<int32_t> idx((size_t)nq * k), cnt(nq);
   std::vector<double> dist((size_t)nq * k);
-  ctx->knn(q, nq, k, tree, nullptr, idx.data(), dist.data(), cnt.data());
+  // One tree that holds (nearly) every node - single-root RRT / RRT*, lazy edges, a forest after its merges: the
+  // queries are answered from the grid cells around them (k_knn_grid) instead of one sweep of the store per query.
+  // (Several live trees: a query for a small tree far away would grow its shells over the whole grid - linear sweep.)
+  bool by_grid = ctx->grid_on && nq > 0 && (int)nodes.size() >= 2048;
+  for (int i = 0; i < nq && by_grid; ++i) {
+    const int t = tree ? tree[i] : -1;
+    if (t >= 0 && (int)trees[t].size() * 10 < (int)nodes.size() * 9) by_grid = false;
+    if (t >= 0 && (int)trees[t].size() < std::max(k, 1024)) by_grid = false;
+  }
+  ctx->knn(q, nq, k, tree, nullptr, idx.data(), dist.data(), cnt.data(), by_grid);
   out.assign(nq, {});
   for (int i = 0; i < nq; ++i) {
     struct E { double d; int order; int id; };
