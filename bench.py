@@ -385,6 +385,24 @@ def main():
                                       "nodes": so["n_nodes"], "seconds": dto, "cores": 1,
                                       "collision_checks_per_s": so["collide_calls"] / dto}}
             cb.close()
+            # ---- SFF* in the regime configs[4] names (2 M nodes, k = 34) but building.obj never reaches: the headline map with
+            # a step of 11 / dtree 14 has room for it (tests/test_gpu_parity.py::test_sff_star_at_two_million_nodes)
+            for rep in range(2):
+                f = S.Forest(ctx, roots, sc["limits"], dist_tree=14.0, sampling_dist=11.0, dim=6, optimize=True,
+                             max_iterations=2**31 - 1, node_budget=2000000, wave=16384, seed=1)
+                c0 = time.perf_counter()
+                f.run()
+                dt2 = time.perf_counter() - c0
+                st2 = f.stats()
+                f.close()
+            legs["sff_star_2m_nodes"] = {
+                "workload": "dense_3D.obj, 6-DoF, 10 seeded roots, SFF* optimize=true, circum 11 / dtree 14, 2M-node budget, "
+                            "waves of 16384 slots (k-nearest sets of 33-34 members at the end)",
+                "accepted_nodes_per_s": (st2["n_nodes"] - 10) / dt2, "collision_checks_per_s": st2["collide_calls"] / dt2,
+                "nodes": st2["n_nodes"], "iterations": st2["iterations"], "seconds": dt2, "rounds": st2["sweeps"],
+                "rewire_fixed_point_passes_per_round": st2["star_passes"] / max(1, st2["star_rounds"]),
+                "k_nearest_members_per_accepted_node": st2["star_members"] / max(1, st2["n_nodes"] - 10),
+                "rewires": st2["star_rewires"], "host_fallback_waves": st2["host_fallback_waves"]}
             # ---- RRT* (src/rrt.h:128-322, rewire :156-201): one tree from the first root of the headline workload, no goal,
             # speculative waves (conflicts cut a wave, the RNG rewinds: the committed sequence is the reference's)
             kwr = dict(dist_tree=sc["dist_tree"], sampling_dist=sc["sampling_dist"], dim=6, optimize=True, seed=1)

@@ -229,7 +229,7 @@ Ctx::~Ctx() {
   for (auto e : pool) (void)hipEventDestroy(e);
   DevBuf* bufs[] = {&env_tri, &env_box, &env_plane, &rob_tri, &sx, &sy, &sz, &syaw, &spitch, &sroll, &stree, &spos,
                     &d_a, &d_b, &d_c, &d_d, &d_e, &d_f, &d_g, &d_h, &r_in, &r_out, &r_q, &r_cnt, &r_hidx,
-                    &r_hdist, &r_sega, &r_segb, &r_items, &r_items2, &env_clear, &g_cnt, &g_items, &g_ovfcnt, &g_ovf, &t_cnt, &t_items, &t_ovfcnt, &t_ovf, &t_occ, &env_tg_start, &env_tg_list, &r_sub, &env_ext};
+                    &r_hdist, &r_sega, &r_segb, &r_items, &r_items2, &r_center, &env_clear, &g_cnt, &g_items, &g_ovfcnt, &g_ovf, &t_cnt, &t_items, &t_ovfcnt, &t_ovf, &t_occ, &env_tg_start, &env_tg_list, &r_sub, &env_ext};
   for (DevBuf* b : bufs) b->release();
   for (auto& b : level_box) b.release();
   PinBuf* pins[] = {&h_a, &h_b, &h_c, &h_d, &h_e, &h_f, &h_g, &h_h, &p_in, &p_out};
@@ -514,7 +514,9 @@ void Ctx::build_tri_grid() {
   }
   rext = std::max(rext, 2 * robv.radius);
   if (!(ext > 0)) return;
-  const double h = std::max((rext + 6.4) / 3.0, ext / 128.0);
+  double div = 3.0;
+  if (const char* e = getenv("SFFGPU_TG_DIV")) div = std::max(1.0, atof(e));
+  const double h = std::max((rext + 6.4) / div, ext / (div > 3.0 ? 256.0 : 128.0));
   long long cells = 1;
   for (int a = 0; a < 3; ++a) {
     envv.tg_org[a] = env_lo[a];

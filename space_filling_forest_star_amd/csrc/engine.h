@@ -127,7 +127,7 @@ struct Ctx {
   DevBuf d_a, d_b, d_c, d_d, d_e, d_f, d_g, d_h;
   PinBuf h_a, h_b, h_c, h_d, h_e, h_f, h_g, h_h;
   // round pipeline buffers of the forest engine (kept apart from the batch entry points' scratch)
-  DevBuf r_in, r_out, r_q, r_cnt, r_hidx, r_hdist, r_sega, r_segb, r_items, r_items2, r_sub;
+  DevBuf r_in, r_out, r_q, r_cnt, r_hidx, r_hdist, r_sega, r_segb, r_items, r_items2, r_sub, r_center;
   PinBuf p_in, p_out;
 
   // kernel timing (HIP events on the launch stream)

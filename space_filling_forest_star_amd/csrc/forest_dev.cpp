@@ -655,6 +655,7 @@ static DevRoundBufs dev_round_bufs(Forest& F) {
   c.r_cnt.ensure((size_t)n * 4);
   c.r_sega.ensure((size_t)n * B.STRIDE * 48);
   c.r_segb.ensure((size_t)n * B.STRIDE * 48);
+  c.r_center.ensure((size_t)n * 48);
   B.list_cap = 4 * n * B.STRIDE + 65536;
   c.r_items.ensure((size_t)B.list_cap * SFFK_ITEM_BYTES);
   c.r_sub.ensure((size_t)SFFK_SUBLISTS * SFFK_SUB_STRIDE * 4);
@@ -737,6 +738,7 @@ void Forest::dev_enqueue_round_eval(void* send_dev) {
   tmp.sub = c.r_sub.as<int32_t>();
   tmp.n_perm = d.temp_base;
   tmp.base = d.temp_base;
+  tmp.center_out = c.r_center.as<double>();
   sffk::DevRound dv{};
   dv.ctrl = V.ctrl;
   dv.act_slot = V.act_slot;
@@ -762,6 +764,7 @@ void Forest::dev_enqueue_round_eval(void* send_dev) {
   ca.in_lim = B.d_lim;
   ca.pdist = B.d_pd;
   ca.parent = d.d_parent.as<int32_t>();
+  ca.center = c.r_center.as<double>();
   ca.force = d.d_force.as<uint8_t>();
   ca.cnt = c.r_cnt.as<int32_t>();
   ca.hit_idx = nullptr;
@@ -866,7 +869,7 @@ uint64_t Forest::dev_launch_signature() {
   mix(&c.tgridv, sizeof c.tgridv);
   mix(&c.envv, sizeof c.envv);
   mix(&c.robv, sizeof c.robv);
-  const void* ptrs[] = {c.r_q.p, c.r_cnt.p, c.r_sega.p, c.r_segb.p, c.r_items.p, c.r_sub.p, c.r_out.p, dev.d_parent.p, dev.d_force.p,
+  const void* ptrs[] = {c.r_q.p, c.r_cnt.p, c.r_sega.p, c.r_segb.p, c.r_items.p, c.r_sub.p, c.r_out.p, c.r_center.p, dev.d_parent.p, dev.d_force.p,
                         dev.ctrl.p, dev.ring.p, dev.trig.p, c.sx.p, c.spos.p, c.stree.p};
   mix(ptrs, sizeof ptrs);
   const double scal[] = {c.sweep_eps(), c.grid_cell, cfg.sampling_dist, cfg.dist_tree};

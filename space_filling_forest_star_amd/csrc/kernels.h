@@ -176,6 +176,8 @@ struct RoundTemps {
   int base;        // 4-aligned index of the first temporary (>= n_perm)
   const double* preset;   // optional n x 6: sample positions computed by the caller (libm parity mode); the kernel
                           // then only applies the limits test and does its bookkeeping
+  double* center_out;     // optional n x 6: the expanded node's position, for k_query_classify (which would otherwise
+                          // wait for the sample's parent id before it can ask for that position: one dependent load less)
 };
 
 size_t collide_lds_bytes(int n_robot_tri, int waves);
@@ -241,6 +243,8 @@ struct ClassifyArgs {
   const uint8_t* in_lim;    // n
   const double* pdist;      // n
   const int32_t* parent;    // n (store id of the expanded node)
+  const double* center;     // optional n x 6: its position (RoundTemps::center_out); the sample's tree is the tree of its
+                            // temporary store entry N0 + i either way
   const uint8_t* force;     // n (Node::ForceChildren of the expanded node)
   const int32_t* cnt;       // n sweep hit totals
   int32_t* hit_idx;         // n x cap (reordered in place)

@@ -69,6 +69,7 @@ __global__ __launch_bounds__(256) void k_sample_steer(const uint64_t* __restrict
   }
   const double* src = center_in ? center_in + 6 * (size_t)i : node_pos + 6 * (size_t)par;
   for (int k = 0; k < 6; ++k) c[k] = src[k];
+  if (tmp.center_out) for (int k = 0; k < 6; ++k) tmp.center_out[6 * (size_t)i + k] = c[k];
   uint64_t w[6];
   SampleTrig host_trig{};
   if (dv.ctrl) {   // the sample's words sit in the engine-word ring, in the reference's draw order
@@ -1744,8 +1745,9 @@ __global__ __launch_bounds__(64 * QC_WAVES) __attribute__((amdgpu_waves_per_eu(Q
   for (int k = 0; k < 6; ++k) qp[k] = uni_d(A.newpos[6 * (size_t)i + k]);
   const int no_g = uni_i(g.ovf_cnt[0]);
   const int no_t = tg.cnt ? uni_i(tg.ovf_cnt[0]) : 0;
-  const int mine = uni_i(A.tree[ex]);
-  for (int k = 0; k < 6; ++k) exp[k] = uni_d(A.pos[6 * (size_t)ex + k]);
+  // (the sample's temporary store entry carries the expanded node's tree; its position came with the sample)
+  const int mine = uni_i(A.center ? A.tree[A.N0 + i] : A.tree[ex]);
+  for (int k = 0; k < 6; ++k) exp[k] = uni_d(A.center ? A.center[6 * (size_t)i + k] : A.pos[6 * (size_t)ex + k]);
   int flags = 0, nnb = 0;
   int used_slots = 0;                     // edge-task slots this sample fills (the others are cleared at the end)
   const double parts0 = edge_parts(exp, qp);   // the parent edge (task slot 0), used by the task write and by the cull

@@ -477,6 +477,53 @@ def test_c5_building_sff_star_full_run_properties(S, ctx):
     f.close()
 
 
+def test_sff_star_at_two_million_nodes(S, ctx):
+    """The regime BASELINE configs[4] names but its own map never reaches (building.obj saturates at 2e5 nodes): SFF* with
+    a 2 M-node store and k = floor(2e log10 N) = 34 neighbours per accepted sample.  dense_3D with a step of 11 (dtree 14)
+    has the room: 10 roots, waves of 16 384 slots, optimize = true, 2 M-node budget on the device engine.  The start of the job is pinned bit for bit
+    against the oracle (60 k-node budget, same waves); the whole 2 M-node forest is checked through the size-independent
+    properties (limits, trees, edge lengths = stored parent distances bit for bit, costs never below parent cost + edge,
+    equal where nothing above was rewired, oracle-checked poses and edges on a sample)."""
+    sc, w = load_world(ctx, "dense3d")
+    roots = common.free_roots(w.collide, sc["limits"], 10, seed=1)
+    # (with the bench's step - circum 14 / dtree 18 - dense_3D saturates at 1.05 M nodes: a step of 11 / 14 has room for 2 M)
+    kw = dict(dist_tree=14.0, sampling_dist=11.0, dim=6, optimize=True, max_iterations=2**31 - 1, wave=16384, seed=1)
+    fo = O.Forest(w, roots, sc["limits"], node_budget=60000, **kw)
+    fo.run()
+    fg = S.Forest(ctx, roots, sc["limits"], node_budget=60000, **kw)
+    assert fg.device_engine()
+    fg.run()
+    assert_same_forest(fo, fg)
+    fg.close()
+    f = S.Forest(ctx, roots, sc["limits"], node_budget=2000000, **kw)
+    f.run()
+    s, n = f.stats(), f.nodes()
+    N = s["n_nodes"]
+    assert N >= 2000000 and s["host_fallback_waves"] == 0 and s["star_rounds"] > 100
+    # the k-nearest sets really were 33-34 members large at the end (k(1.9e6) = 34)
+    assert s["star_members"] / (N - 10) > 28
+    pos, par, tree, cost, dpar = n["pos"], n["parent"], n["tree"], n["cost"], n["dpar"]
+    lim = np.asarray(sc["limits"], dtype=np.float64)
+    for a in range(3):
+        assert (pos[:, a] >= lim[2 * a]).all() and (pos[:, a] <= lim[2 * a + 1]).all()
+    kids = np.nonzero(par >= 0)[0]
+    assert len(kids) == N - 10 and (cost[par < 0] == 0).all()
+    assert (tree[par[kids]] == tree[kids]).all()
+    assert (par[kids] > kids).sum() > 1000                    # rewiring happened: younger parents
+    slack = cost[kids] - (cost[par[kids]] + dpar[kids])
+    assert (slack >= -1e-9).all() and (slack == 0).mean() > 0.5
+    L = O.lib()
+    rs = np.random.RandomState(9)
+    for i in rs.choice(kids, 4000, replace=False):
+        assert L.sffo_distance(O.dp(np.ascontiguousarray(pos[i])), O.dp(np.ascontiguousarray(pos[par[i]]))) == dpar[i]
+    for i in rs.choice(kids, 300, replace=False):
+        assert not w.collide(pos[i])
+        assert w.path_free(pos[par[i]], pos[i])[0] or w.path_free(pos[i], pos[par[i]])[0], i
+    print("SFF* dense_3D 2 M nodes: %.2f s, %.2f M nodes/s, %.2f passes per round, %d rewires"
+          % (s["total_ms"] / 1e3, (N - 10) / s["total_ms"] / 1e3, s["star_passes"] / s["star_rounds"], s["star_rewires"]))
+    f.close()
+
+
 @pytest.mark.parametrize("fixture", ["c5_full_run.json", "c5_full_run_w8192.json"])
 def test_c5_building_sff_star_whole_job_equals_the_oracle(S, ctx, golden_dir, fixture):
     """BASELINE configs[4] run to its END (building.obj, 20 seeded roots, SFF* with rewire, 2 M-node budget): the forest
