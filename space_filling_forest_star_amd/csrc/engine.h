@@ -301,6 +301,9 @@ struct Forest {
   bool dev_wave_begin();
   size_t dev_exchange_bytes() const;
   void run_device(int max_waves);
+  bool seq_eligible() const;        // waves of one slot, plain SFF: the persistent single-wavefront loop (k_seq_waves)
+  void run_device_seq(int max_waves);
+  bool seq_suspended = false;
   void sync_host();             // refresh the host mirror (nodes, frontier, borders, counters) from the device
   void fill_stats(sffgpu_forest_stats* out);
   ~Forest();

@@ -337,6 +337,7 @@ void Forest::dev_upload_state() {
     // (room for four waves' worth - and for everything the host engine may have generated ahead when the state moves
     // to the device in the middle of a run)
     d.ring_words = next_pow2(std::max<uint64_t>(4 * d.max_wave_words, (uint64_t)rng_ahead.size() + 2 * d.max_wave_words + 64));
+    if (cfg.wave == 1) d.ring_words = std::max<uint64_t>(d.ring_words, 1 << 18);   // (k_seq_waves: thousands of waves per launch)
     d.ring.ensure((size_t)d.ring_words * 8);
     d.h_ring.ensure((size_t)d.ring_words * 8);
     if (cfg.libm_sampling) {
@@ -1022,7 +1023,84 @@ bool Forest::dev_wave_begin() {
   return true;
 }
 
+bool Forest::seq_eligible() const {
+  static const bool off = getenv("SFFGPU_NO_SEQ") != nullptr && atoi(getenv("SFFGPU_NO_SEQ")) != 0;
+  return dev.on && cfg.wave == 1 && !cfg.optimize && cfg.world == 1 && !off && !seq_suspended && num_roots <= 64;
+}
+
+// waves of ONE slot (the reference's own order): k_seq_waves runs whole outer iterations back to back inside one launch,
+// thousands of waves per launch; the host tops the engine-word ring up between launches and handles what the round engine's
+// host side handles (growth, re-celling, a list overflow -> that wave is finished on the host-replay engine)
+void Forest::run_device_seq(int max_waves) {
+  Ctx& c = *ctx;
+  DevEngine& d = dev;
+  HIPCHK(hipSetDevice(c.device));
+  auto t0 = Clock::now();
+  double wait_ms = 0;
+  if (!d.active) dev_upload_state();
+  const uint64_t w0 = d.last.waves;
+  const uint64_t per_wave = (uint64_t)(8 + std::max(1, cfg.threshold_misses) * (cfg.dim == 2 ? 1 : 6));
+  while (true) {
+    const sffk::DevCtrl& k = d.last;
+    if (!k.in_wave && k.terminated) break;
+    if (max_waves > 0 && !k.in_wave && (int)(k.waves - w0) >= max_waves) break;
+    if (k.in_wave) {   // (a wave the host-replay engine left unfinished: through the round engine)
+      seq_suspended = true;
+      st.total_ms += ms_since(t0);
+      st.host_ms += ms_since(t0) - wait_ms;
+      run_device(1);
+      seq_suspended = false;
+      t0 = Clock::now();
+      wait_ms = 0;
+      continue;
+    }
+    int batch = (int)std::min<uint64_t>(4096, d.ring_words / (2 * per_wave));
+    if (max_waves > 0) batch = std::min(batch, max_waves - (int)(k.waves - w0));
+    dev_ring_top_up(k.cursor, (uint64_t)batch * per_wave + 16);
+    if (d.ring_pending) {
+      HIPCHK(hipStreamWaitEvent(c.stream, d.ev_ring, 0));
+      d.ring_pending = false;
+    }
+    sffk::SeqArgs a{};
+    a.f = dev_view();
+    a.st = sffk::NodeStoreMut{c.sx.as<float>(), c.sy.as<float>(), c.sz.as<float>(), c.syaw.as<float>(),
+                              c.spitch.as<float>(), c.sroll.as<float>(), c.stree.as<int32_t>(), c.spos.as<double>()};
+    a.g = c.gridv;
+    a.env = c.envv;
+    a.rob = c.robv;
+    memcpy(a.limits, cfg.limits, sizeof a.limits);
+    a.dist_tree = cfg.dist_tree;
+    a.sampling_dist = cfg.sampling_dist;
+    a.sweep_abs_eps = c.sweep_eps();
+    a.trig = cfg.libm_sampling ? d.trig.as<double>() : nullptr;
+    a.words_end = d.produced;
+    a.grid_ovf_src = c.gridv.ovf_cnt;
+    a.dim = cfg.dim;
+    a.max_waves = batch;
+    a.hit_cap = hit_cap;
+    a.grid_ovf_limit = c.grid_rebuild_at();
+    sffk::launch_seq_waves(c.stream, a);
+    HIPCHK(hipMemcpyAsync(d.h_ctrl.as<sffk::DevCtrl>(), d.ctrl.p, sizeof(sffk::DevCtrl), hipMemcpyDeviceToHost, c.stream));
+    HIPCHK(hipEventRecord(d.ev_wave, c.stream));
+    d.host_stale = true;
+    const int fault = dev_finish_wave(&wait_ms, 0, true);
+    if (fault == SFFK_FAULT_LISTS) {
+      ++st.host_fallback_waves;
+      dev_to_host();
+      while (in_wave) {
+        round_begin();
+        int32_t cnt = (int32_t)records.size();
+        round_commit(records.data(), cnt, &cnt, 1);
+      }
+      dev_upload_state();
+    }
+  }
+  st.total_ms += ms_since(t0);
+  st.host_ms += ms_since(t0) - wait_ms;
+}
+
 void Forest::run_device(int max_waves) {
+  if (seq_eligible()) { run_device_seq(max_waves); return; }
   Ctx& c = *ctx;
   DevEngine& d = dev;
   HIPCHK(hipSetDevice(c.device));

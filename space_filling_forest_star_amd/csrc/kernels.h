@@ -437,6 +437,27 @@ struct ResolveArgs {
   StarView S;
 };
 void launch_wave_begin(hipStream_t s, const DevForestView& f);
+// ---- waves of ONE slot = the reference's own loop order (src/forest.h:122-202): one persistent wavefront runs whole
+// outer iterations - frontier pick, up to ThresholdMisses x (sample, pose check, parent edge, 27-cell neighbour query,
+// the neighbour edges in the order the reference reaches them, append), closed list / frontier erase, termination - for as
+// many waves as the engine words last, instead of ~33 launches per wave.  Plain SFF only.  Evaluation is lazy exactly like
+// the reference's (an edge is only checked when the loop gets to it), so the reference-equivalent counters ARE the
+// executed ones.  Stops early (halt + fault in the control block, the faulted attempt rolled back) where the round
+// engine would: a bounded list overflowed, arrays / border table to grow, the grid's overflow list to re-cell.
+struct SeqArgs {
+  DevForestView f;
+  NodeStoreMut st;
+  GridView g;
+  EnvView env;
+  RobotView rob;
+  double limits[6];
+  double dist_tree, sampling_dist, sweep_abs_eps;
+  const double* trig;                 // libm parity mode (DevRound::trig) or null
+  unsigned long long words_end;       // engine words resident in the ring (absolute position)
+  int32_t* grid_ovf_src;              // the node grid's overflow counter
+  int dim, max_waves, hit_cap, grid_ovf_limit;
+};
+void launch_seq_waves(hipStream_t s, const SeqArgs& a);
 // multi-GPU: the answer record of one sample as it travels in the all-gather of a round:
 // flags, nnb, pose_hit, 0 | nb[nbcap] | meta[nbcap] | seg_ns[1 + nbcap] | first_hit[1 + nbcap]
 inline int record_words(int nbcap) { return 6 + 4 * nbcap; }

@@ -2246,6 +2246,364 @@ __global__ __launch_bounds__(256) void k_settle(SettleArgs A) {
   }
 }
 
+// ------------------------------------------------------------------ waves of one slot: the reference's loop, one wavefront
+// Loads of forest state this launch may itself have written go past the vector L1 (agent-scope relaxed atomic loads =
+// `sc1` loads served by the L2 the one workgroup's stores write through to); the environment, the robot and the engine
+// words are immutable while it runs.
+__device__ __forceinline__ int sq_i32(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long sq_u64(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double sq_f64(const double* p) {
+  return __longlong_as_double((long long)__hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+                                                            __HIP_MEMORY_SCOPE_AGENT));
+}
+__device__ __forceinline__ int sq_u8(const uint8_t* p) { return (int)__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void sq_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+__device__ __forceinline__ int sq_lemire(unsigned long long word, unsigned long long range) {   // (devforest.hip: lemire_pick)
+  const unsigned long long lo = word * range;
+  const unsigned long long hi = __umul64hi(word, range);
+  if (lo < range) {
+    const unsigned long long thr = (0ULL - range) % range;
+    if (lo < thr) return -1;
+  }
+  return (int)hi;
+}
+
+// Solver::isPathFree(a, b) by the wavefront: chunk after chunk until the first hit (the chunks come in sample order, so
+// the first chunk with a hit holds the edge's first hit).  Returns free; calls = Collide calls the reference makes.
+__device__ bool sq_path_free(const EnvView& env, const RobotView& rob, const double* rtri, int32_t* stack, int32_t* cand, int32_t* queue,
+                             double* stage, const double* a, const double* b, int32_t* fh_lds, int32_t* ovf_lds, int lane,
+                             unsigned long long& calls, unsigned long long& samples, bool& fault) {
+  const int ns = edge_samples(edge_parts(a, b));
+  samples += (unsigned long long)ns;
+  if (lane == 0) { *fh_lds = 0x7fffffff; *ovf_lds = 0; }
+  __builtin_amdgcn_wave_barrier();
+  int fh = 0x7fffffff;
+  if (env.n_tri != 0) {
+    DBG_DECL
+    // (asking for the clearance bits of several chunks at once was measured slower: 15.3 -> 12.7 k nodes/s - one wavefront
+    // is bound by its own instruction stream, the sample positions' fp64 divisions, not by the trips to memory)
+    for (int chunk = 0; chunk * 64 < ns; ++chunk) {
+      segment_chunk(env, rob, rtri, stack, cand, queue, stage, a, b, 0, chunk, false, 0ULL, fh_lds, ovf_lds, lane DBG_PASS);
+      __builtin_amdgcn_wave_barrier();
+      fh = *fh_lds;
+      if (*ovf_lds) { fault = true; return false; }
+      if (fh != 0x7fffffff) break;
+    }
+  }
+  calls += fh == 0x7fffffff ? (unsigned long long)ns : (unsigned long long)fh;
+  return fh == 0x7fffffff;
+}
+
+__global__ __launch_bounds__(64) void k_seq_waves(SeqArgs A) {
+  extern __shared__ double lds_d[];
+  __shared__ int32_t s_fh, s_ovf;
+  __shared__ int32_t h_id[64], h_tree[64];
+  __shared__ double h_d[64], h_pos[64 * 6];
+  const DevForestView& f = A.f;
+  DevCtrl* c = f.ctrl;
+  const int lane = threadIdx.x;
+  if (c->halt || c->in_wave) return;            // (a wave the host left half done goes through the round engine)
+  double* rtri = lds_d;
+  double* stage = rtri + (size_t)A.rob.n_tri * 9;
+  int32_t* ibase = reinterpret_cast<int32_t*>(stage + STAGE_DOUBLES);
+  int32_t* stack = ibase;                        // (+ the triangle-grid hash set behind it)
+  int32_t* cand = ibase + (STACK_CAP + TG_HASH);
+  int32_t* queue = cand + CAND_CAP;
+  for (int i = lane; i < A.rob.n_tri * 9; i += 64) rtri[i] = A.rob.tri[i];
+  __builtin_amdgcn_wave_barrier();
+  // ---- the control block, in registers (everything here is the same in every lane)
+  int n_nodes = c->n_nodes, iter = c->iter, fn = c->frontier_n, cn = c->closed_n, nb = c->n_borders;
+  int solved = c->solved, empty_frontier = c->empty_frontier, terminated = c->terminated;
+  const int front_sel = c->front_sel;
+  unsigned long long cursor = c->cursor, cc = c->collide_calls, pf = c->path_free_calls, nq = c->nn_queries;
+  unsigned long long ex_pose = c->poses_executed, ex_seg = c->segments_executed, ex_smp = c->samples_executed;
+  unsigned long long waves = c->waves, rounds = c->rounds, rnodes = c->round_nodes, rqueries = c->round_queries, redraws = 0;
+  int32_t* frontier = front_sel ? f.frontier2 : f.frontier;
+  const int TM = f.threshold_misses, WP = f.words_per, R = f.n_trees;
+  int fault = 0, w_round = 0, w_node = 0, w_pos = 0, w_closed = 0, in_wave = 0;
+  for (int wv = 0; wv < A.max_waves && !terminated && !fault; ++wv) {
+    // ---- what the round engine checks before a round (round_begin_scalars), and what this launch has to leave to the host
+    if (n_nodes + 1 > f.node_cap - 8 || nb + TM > f.border_cap) { fault = SFFK_FAULT_CAPACITY; break; }
+    if ((unsigned long long)(nb + TM) * 2ULL > f.bt_mask + 1ULL) { fault = SFFK_FAULT_BORDER_TABLE; break; }
+    if (cursor + 8ULL + (unsigned long long)(TM * WP) > A.words_end) break;      // out of engine words: the host tops the ring up
+    if (sq_i32(A.grid_ovf_src) > A.grid_ovf_limit) break;                         // the grid wants to re-cell itself
+    // ---- node selection (src/forest.h:136-151)
+    const int use_closed = cn > 0 && empty_frontier;
+    const int pool = use_closed ? cn : fn;
+    if (pool < 1) { terminated = 1; break; }
+    int pick;
+    do { pick = sq_lemire(f.ring[cursor & f.ring_mask], (unsigned long long)pool); ++cursor; if (pick < 0) ++redraws; } while (pick < 0);
+    const int node = sq_i32((use_closed ? f.closed : frontier) + pick);
+    ++waves;
+    double cpos[6];
+    for (int k = 0; k < 6; ++k) cpos[k] = sq_f64(A.st.pos + 6 * (size_t)node + k);
+    const int mine = sq_i32(A.st.tree + node);
+    const double droot_ex = sq_f64(f.d_root + node);
+    const bool force = (sq_u8(f.nflag + node) & 1) != 0;
+    bool failing = true;
+    w_node = node; w_pos = pick; w_closed = use_closed;
+    for (int rd = 0; rd < TM && failing && iter < f.max_iterations; ++rd) {
+      // (attempt-start snapshot: a fault rolls exactly this attempt back)
+      const int iter_a = iter;
+      const unsigned long long cur_a = cursor, cc_a = cc, pf_a = pf, nq_a = nq, xp_a = ex_pose, xs_a = ex_seg, xm_a = ex_smp;
+      bool flt = false;
+      uint64_t w[6];
+      for (int k = 0; k < 6; ++k) w[k] = k < WP ? f.ring[(cursor + k) & f.ring_mask] : 0ULL;
+      SampleTrig ht{};
+      if (A.trig) {
+        const double* t0 = A.trig + 3 * (size_t)(cursor & f.ring_mask);
+        ht.c_phi = t0[0]; ht.s_phi = t0[1];
+        if (WP == 6) {
+          const double* t1 = A.trig + 3 * (size_t)((cursor + 1) & f.ring_mask);
+          const double* t3 = A.trig + 3 * (size_t)((cursor + 3) & f.ring_mask);
+          ht.c_theta = t1[0]; ht.s_theta = t1[1]; ht.acos_u = t3[2];
+        }
+      }
+      cursor += (unsigned long long)WP;
+      ++iter;
+      ++rounds; rnodes += (unsigned long long)(n_nodes + 1); ++rqueries;
+      double qp[6];
+      const bool ok = A.trig ? sample_point_with(w, cpos, A.sampling_dist, A.dim, A.limits, qp, ht)
+                             : sample_point(w, cpos, A.sampling_dist, A.dim, A.limits, qp);
+      if (!ok) continue;                                           // :246 !result
+      // ---- Environment::Collide(newPoint)
+      cc += 1; ex_pose += 1;
+      bool hit = false;
+      if (A.env.n_tri != 0 && !surely_clear(A.env, qp)) {
+        double Rm[9], c3[3];
+        if (qp[3] == 0 && qp[4] == 0 && qp[5] == 0) { Rm[0] = Rm[4] = Rm[8] = 1; Rm[1] = Rm[2] = Rm[3] = Rm[5] = Rm[6] = Rm[7] = 0; }
+        else rotation(qp, Rm);
+        xform(Rm, qp, A.rob.center, c3);
+        hit = pose_exact(A.env, A.rob, rtri, stack, cand, stage, qp, Rm, c3, lane);
+      }
+      if (hit) continue;
+      // ---- isPathFree(expanded, newPoint)
+      pf += 1; ex_seg += 1;
+      const bool free0 = sq_path_free(A.env, A.rob, rtri, stack, cand, queue, stage, cpos, qp, &s_fh, &s_ovf, lane, cc, ex_smp, flt);
+      bool reject = !free0;
+      const double pdist = dist6(cpos, qp);                        // parentDistance, :250
+      int n_hit = 0;
+      if (!flt && !reject) {
+        nq += (unsigned long long)R;                               // :262-267 one radiusSearch per tree
+        // ---- the neighbours: exact 6-D ball of radius max(parentDistance, treeDistance) from the cells its box touches
+        const double r = pdist > A.dist_tree ? pdist : A.dist_tree;
+        const double ri = (r + A.sweep_abs_eps) * (1.0 + 1e-5);
+        const float rf = sqrtf((float)(ri * ri) * 1.000001f) * 1.000001f;
+        const GridView& g = A.g;
+        const float qx = (float)qp[0], qy = (float)qp[1], qz = (float)qp[2];
+        const int lx = grid_coord(qx - rf, g.ox, g.inv_cell, g.nx), hx = grid_coord(qx + rf, g.ox, g.inv_cell, g.nx);
+        const int ly = grid_coord(qy - rf, g.oy, g.inv_cell, g.ny), hy = grid_coord(qy + rf, g.oy, g.inv_cell, g.ny);
+        const int lz = grid_coord(qz - rf, g.oz, g.inv_cell, g.nz), hz = grid_coord(qz + rf, g.oz, g.inv_cell, g.nz);
+        const int wx = hx - lx + 1, wy = hy - ly + 1, wz = hz - lz + 1;
+        const int total = wx * wy * wz;
+        auto take = [&](bool valid, const GridItem* src) {        // one candidate per lane -> the hit list in LDS
+          bool h = false;
+          double d = 0, p6[6];
+          int id = 0, tr = 0;
+          if (valid) {
+            const unsigned long long* q8 = reinterpret_cast<const unsigned long long*>(src);
+            for (int k = 0; k < 6; ++k) p6[k] = __longlong_as_double((long long)sq_u64(q8 + k));
+            const unsigned long long it = sq_u64(q8 + 6);
+            id = (int)(unsigned)(it & 0xffffffffULL); tr = (int)(unsigned)(it >> 32);
+            d = dist6(p6, qp);
+            h = d < r;
+          }
+          const unsigned long long hm = __ballot(h);
+          if (h) {
+            const int at = n_hit + __popcll(hm & ((1ULL << lane) - 1ULL));
+            if (at < 64) { h_id[at] = id; h_tree[at] = tr; h_d[at] = d; for (int k = 0; k < 6; ++k) h_pos[6 * at + k] = p6[k]; }
+          }
+          n_hit += __popcll(hm);
+        };
+        for (int c0 = 0; c0 < total; c0 += 64) {
+          const int ci = c0 + lane;
+          int cell = 0, m = 0;
+          if (ci < total) {
+            const int q1 = ci / wx, q2 = q1 / wy;
+            cell = ((lz + q2) * g.ny + (ly + q1 - q2 * wy)) * g.nx + (lx + ci - q1 * wx);
+            m = sq_i32(g.cnt + cell);
+            if (m > g.bk) m = g.bk;
+          }
+          int inc = m;
+          for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(inc, off);
+            if (lane >= off) inc += o;
+          }
+          const int tot = __shfl(inc, 63);
+          for (int base = 0; base < tot; base += 64) {
+            const int j = base + lane;
+            const int jj = j < tot ? j : tot - 1;
+            int lo = 0, hi = 63;
+            while (lo < hi) {
+              const int mid = (lo + hi) >> 1;
+              if (__shfl(inc, mid) > jj) hi = mid; else lo = mid + 1;
+            }
+            const int src_cell = __shfl(cell, lo);
+            const int slot = jj - (__shfl(inc, lo) - __shfl(m, lo));
+            take(j < tot, g.items + (size_t)src_cell * g.bk + slot);
+          }
+        }
+        int no = sq_i32(g.ovf_cnt);
+        if (no > g.ovf_cap) no = g.ovf_cap;
+        for (int base = 0; base < no; base += 64) take(base + lane < no, g.ovf + base + lane);
+        if (n_hit > A.hit_cap || n_hit > 64) flt = true;
+      }
+      if (!flt && !reject) {
+        // ---- the neighbour loop (:270-300) in the reference's order: tree id, then distance, then id; an edge is only
+        // checked when the loop reaches it
+        __builtin_amdgcn_wave_barrier();
+        const bool have = lane < n_hit;
+        const int id = have ? h_id[lane] : 0x7fffffff;
+        const int t = have ? h_tree[lane] : 0x7fffffff;
+        const double d = have ? h_d[lane] : 0.0;
+        const bool same = t == mine;
+        const bool qk = have && (same ? (!force && d < pdist - SFFG_TOL) : (d < A.dist_tree - SFFG_TOL));   // :276 / :283
+        int rank = 0;
+        for (int j = 0; j < n_hit; ++j) {
+          const int tj = __shfl(t, j), idj = __shfl(id, j), qj = __shfl((int)qk, j);
+          const double dj = __shfl(d, j);
+          if (qj && (tj < t || (tj == t && (dj < d || (dj == d && idj < id))))) ++rank;
+        }
+        const int n_q = __popcll(__ballot(qk));
+        for (int rk = 0; rk < n_q && !reject && !flt; ++rk) {
+          const unsigned long long sel = __ballot(qk && rank == rk);
+          const int src = __ffsll((long long)sel) - 1;
+          const int s_same = __shfl((int)same, src), s_id = __shfl(id, src), s_tree = __shfl(t, src);
+          double np6[6];
+          for (int k = 0; k < 6; ++k) np6[k] = h_pos[6 * src + k];
+          pf += 1; ex_seg += 1;
+          if (s_same) {
+            const bool fr = sq_path_free(A.env, A.rob, rtri, stack, cand, queue, stage, np6, qp, &s_fh, &s_ovf, lane, cc, ex_smp, flt);
+            if (fr) reject = true;                                 // :276-280 overcrowded
+          } else {
+            const bool fr = sq_path_free(A.env, A.rob, rtri, stack, cand, queue, stage, cpos, np6, &s_fh, &s_ovf, lane, cc, ex_smp, flt);
+            if (fr && !flt) {                                      // :288-294 border entry unless the pair has one
+              const int a = s_id < node ? s_id : node, b = s_id < node ? node : s_id;
+              const unsigned long long key = ((unsigned long long)(uint32_t)a << 32) | ((unsigned long long)(uint32_t)b + 1ULL);
+              size_t h = (size_t)((key * 0x9E3779B97F4A7C15ULL) >> 17) & (size_t)f.bt_mask;
+              bool fresh = false;
+              for (int guard = 0; guard < (1 << 24); ++guard) {
+                const unsigned long long cur = sq_u64(f.bt_key + h);
+                if (cur == key) { fresh = sq_u64(f.bt_val + h) == ~0ULL; break; }
+                if (cur == 0ULL) { fresh = true; break; }
+                h = (h + 1) & (size_t)f.bt_mask;
+              }
+              if (fresh) {
+                if (lane == 0) {
+                  f.bt_key[h] = key;
+                  f.bt_val[h] = c->epoch << 32;
+                  f.b_n1[nb] = a; f.b_n2[nb] = b;
+                  f.b_ta[nb] = s_tree < mine ? s_tree : mine; f.b_tb[nb] = s_tree < mine ? mine : s_tree;
+                  f.b_dist[nb] = sq_f64(f.d_root + s_id) + droot_ex + dist6(np6, cpos);
+                  f.pair[(size_t)s_tree * R + mine] = 1;
+                  f.pair[(size_t)mine * R + s_tree] = 1;
+                }
+                sq_drain();
+                ++nb;
+              }
+            }
+            reject = true;                                         // :296-299
+          }
+        }
+      }
+      if (flt) {
+        // a bounded list overflowed (hits, triangle candidates): this attempt never happened - the host finishes the wave
+        iter = iter_a; cursor = cur_a; cc = cc_a; pf = pf_a; nq = nq_a; ex_pose = xp_a; ex_seg = xs_a; ex_smp = xm_a;
+        --rounds; rnodes -= (unsigned long long)(n_nodes + 1); --rqueries;
+        fault = SFFK_FAULT_LISTS; w_round = rd; in_wave = 1;
+        break;
+      }
+      if (reject) continue;
+      // ---- the new node (:353-367)
+      const int idn = n_nodes;
+      if (lane == 0) {
+        const size_t o = (size_t)idn;
+        A.st.x[o] = (float)qp[0]; A.st.y[o] = (float)qp[1]; A.st.z[o] = (float)qp[2];
+        A.st.yaw[o] = (float)qp[3]; A.st.pitch[o] = (float)qp[4]; A.st.roll[o] = (float)qp[5];
+        for (int k = 0; k < 6; ++k) A.st.pos[6 * o + k] = qp[k];
+        A.st.tree[o] = mine;
+        f.parent[o] = node;
+        f.d_closest[o] = pdist;
+        f.d_root[o] = pdist + droot_ex;
+        f.iter[o] = (uint32_t)iter;
+        f.nflag[o] = 2;
+        frontier[fn] = idn;
+        GridItem it;
+        for (int k = 0; k < 6; ++k) it.p[k] = qp[k];
+        it.id = idn; it.tree = mine; it.pad[0] = it.pad[1] = 0;
+        grid_put(A.g, it);
+      }
+      sq_drain();
+      ++n_nodes; ++fn;
+      failing = false;
+    }
+    if (fault) break;
+    // ---- the slot is exhausted: its node leaves the frontier for the closed list (:160-178; the erase keeps the order)
+    if (failing && !use_closed) {
+      const int fl = sq_u8(f.nflag + node);
+      if (fl & 2) {
+        if (lane == 0) { f.nflag[node] = (uint8_t)((fl & ~2) | 1); f.closed[cn] = node; }
+        ++cn;
+        for (int j0 = pick; j0 < fn - 1; j0 += 256) {
+          int v[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { const int j = j0 + 64 * u + lane; v[u] = j < fn - 1 ? sq_i32(frontier + j + 1) : 0; }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { const int j = j0 + 64 * u + lane; if (j < fn - 1) frontier[j] = v[u]; }
+          sq_drain();
+        }
+        --fn;
+      }
+    }
+    sq_drain();
+    // ---- termination (:184-201)
+    empty_frontier = fn == 0 ? 1 : 0;
+    if (!solved && empty_frontier) {
+      // maxConnected() == numRoots: every tree reachable from tree 0 over pairs that hold a border (R <= 64: a lane per tree)
+      unsigned long long reach = 1ULL, frontier_set = 1ULL;
+      if (R <= 64) {
+        unsigned long long row = 0ULL;   // lane a: bit b = pair (a, b) has a border
+        if (lane < R) for (int b2 = 0; b2 < R; ++b2) if (sq_u8(f.pair + (size_t)lane * R + b2)) row |= 1ULL << b2;
+        while (frontier_set) {
+          const int a = __ffsll((long long)frontier_set) - 1;
+          frontier_set &= frontier_set - 1;
+          const unsigned long long ra = __shfl(row, a) & ~reach;
+          reach |= ra; frontier_set |= ra;
+        }
+        solved = __popcll(reach) == R ? 1 : 0;
+      } else fault = SFFK_FAULT_LISTS;   // (more trees than lanes: the round engine's serial walk)
+    }
+    const bool budget = f.node_budget > 0 && n_nodes >= f.node_budget;
+    terminated = (solved || iter >= f.max_iterations || budget) ? 1 : 0;
+  }
+  if (lane == 0) {
+    c->n_nodes = n_nodes; c->iter = iter; c->frontier_n = fn; c->closed_n = cn; c->n_borders = nb;
+    c->solved = solved; c->empty_frontier = empty_frontier; c->terminated = terminated;
+    c->cursor = cursor; c->collide_calls = cc; c->path_free_calls = pf; c->nn_queries = nq;
+    c->poses_executed = ex_pose; c->segments_executed = ex_seg; c->samples_executed = ex_smp;
+    c->waves = waves; c->rounds = rounds; c->round_nodes = rnodes; c->round_queries = rqueries;
+    c->redraws += (int)redraws;
+    c->n_act = 0; c->app_n = 0; c->compact_from = 0;
+    c->grid_ovf = sq_i32(A.grid_ovf_src); c->tgrid_ovf = 0;
+    c->fault = fault;
+    c->halt = (terminated || fault) ? 1 : 0;
+    c->in_wave = in_wave;
+    if (in_wave) {   // the state the host engine resumes the wave from: its one slot, still failing, w_round rounds done
+      c->round = w_round; c->n_slots = 1; c->use_closed = w_closed; c->act_sel = 0; c->act_cnt = 1;
+      f.slot_node[0] = w_node; f.slot_pos[0] = w_pos; f.act_slot[0] = 0;
+    } else c->round = 0;
+  }
+}
+
+void launch_seq_waves(hipStream_t s, const SeqArgs& a) {
+  const size_t lds = collide_lds_bytes(a.rob.n_tri, 1);
+  if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_seq_waves), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipLaunchKernelGGL(k_seq_waves, dim3(1), dim3(64), lds, s, a);
+}
+
 // ------------------------------------------------------------------ node store writes
 // Writes n positions into the SoA store at [base, base+n): the same double->float cast the
 // reference applies when it fills FLANN matrices (src/forest.h:258-260).  Inactive entries are

@@ -199,6 +199,46 @@ def test_saturating_forest_terminates_solved_with_closed_list_picks(S, ctx):
     assert_same_forest(fo, fg)
 
 
+def test_waves_of_one_slot_run_as_one_persistent_wavefront(S, ctx):
+    """wave = 1 - the reference's own loop order - on the device: k_seq_waves runs whole outer iterations back to back
+    inside one launch.  Saturating forest (closed-list picks, frontier erases, termination by maxConnected), staged runs
+    with getters in between, the node budget, a forced hit-list overflow (that wave is finished on the host engine), the
+    libm parity mode - all against the oracle's sequential loop - and the round engine at wave 1 gives the same forest."""
+    # saturation: every tree connected, frontier empty
+    fo, fg = make(S, ctx, "dense3d_coarse", 1, 10 ** 7, seed=2)
+    fo.run()
+    fg.run()
+    so = fo.stats()
+    assert so["solved"] == 1 and so["frontier_size"] == 0 and so["closed_size"] > 100
+    assert_same_forest(fo, fg)
+    assert fg.stats()["sweeps"] == so["iterations"]          # (one round per iteration)
+    fp = fg.fingerprint()
+    fg.close()
+    with engine(SFFGPU_NO_SEQ=1):                            # the round engine (33 launches per wave) on the same job
+        _, fr = make(S, ctx, "dense3d_coarse", 1, 10 ** 7, seed=2)
+        fr.run()
+    assert fr.fingerprint() == fp
+    fr.close()
+    # staged, with a node budget
+    fo, fg = make(S, ctx, "triang", 1, 10 ** 7, seed=5, budget=3000)
+    fo.run()
+    while True:
+        w0 = fg.stats()["waves"]
+        fg.run(700)
+        if fg.stats()["waves"] == w0:
+            break
+        assert len(fg.nodes()["parent"]) == fg.stats()["n_nodes"] and len(fg.frontier()) == fg.stats()["frontier_size"]
+    assert_same_forest(fo, fg)
+    fg.close()
+    # a hit list of three entries: overflows hand single waves to the host engine
+    fo, fg = make(S, ctx, "dense3d_coarse", 1, 6000, seed=4, SFFGPU_TEST_HITCAP=3)
+    fo.run()
+    fg.run()
+    assert fg.stats()["host_fallback_waves"] > 0
+    assert_same_forest(fo, fg)
+    fg.close()
+
+
 def test_staged_runs_with_getters_in_between(S, ctx):
     fo, fg = make(S, ctx, "dense3d", 512, 10 ** 7, seed=5, budget=20000)
     fo.run()
