@@ -1097,6 +1097,14 @@ void Forest::run_device_seq(int max_waves) {
   }
   st.total_ms += ms_since(t0);
   st.host_ms += ms_since(t0) - wait_ms;
+  if (getenv("SFFGPU_PROFILE")) {
+    const sffk::DevCtrl& k = d.last;
+    const double it = (double)std::max(1, k.iter);
+    fprintf(stderr, "[sffgpu k_seq_waves us/iteration] pick + node %.2f sample %.2f pose %.2f parent edge %.2f neighbour query %.2f "
+            "neighbour loop %.2f append %.2f wave end %.2f | %d iterations\n", k.wprof[0] / it / 100.0, k.wprof[1] / it / 100.0,
+            k.wprof[2] / it / 100.0, k.wprof[3] / it / 100.0, k.wprof[4] / it / 100.0, k.wprof[5] / it / 100.0, k.wprof[6] / it / 100.0,
+            k.wprof[7] / it / 100.0, k.iter);
+  }
 }
 
 void Forest::run_device(int max_waves) {

@@ -2276,21 +2276,58 @@ __device__ __forceinline__ int sq_lemire(unsigned long long word, unsigned long 
 __device__ bool sq_path_free(const EnvView& env, const RobotView& rob, const double* rtri, int32_t* stack, int32_t* cand, int32_t* queue,
                              double* stage, const double* a, const double* b, int32_t* fh_lds, int32_t* ovf_lds, int lane,
                              unsigned long long& calls, unsigned long long& samples, bool& fault) {
-  const int ns = edge_samples(edge_parts(a, b));
+  const double parts = edge_parts(a, b);
+  const int ns = edge_samples(parts);
   samples += (unsigned long long)ns;
   if (lane == 0) { *fh_lds = 0x7fffffff; *ovf_lds = 0; }
   __builtin_amdgcn_wave_barrier();
   int fh = 0x7fffffff;
   if (env.n_tri != 0) {
     DBG_DECL
-    // (asking for the clearance bits of several chunks at once was measured slower: 15.3 -> 12.7 k nodes/s - one wavefront
-    // is bound by its own instruction stream, the sample positions' fp64 divisions, not by the trips to memory)
-    for (int chunk = 0; chunk * 64 < ns; ++chunk) {
-      segment_chunk(env, rob, rtri, stack, cand, queue, stage, a, b, 0, chunk, false, 0ULL, fh_lds, ovf_lds, lane DBG_PASS);
-      __builtin_amdgcn_wave_barrier();
-      fh = *fh_lds;
-      if (*ovf_lds) { fault = true; return false; }
-      if (fh != 0x7fffffff) break;
+    // The samples' clearance bits first, placed like k_query_classify's fused cull places them: in cells of the clearance
+    // grid, fp32, a + idx * step (the bits carry the slack for exactly that) - one wavefront is bound by its own
+    // instruction stream, and the exact positions cost three fp64 divisions per sample (measured on one box: 14.4 vs
+    // 19.4 us per iteration).  Four chunks' lookups are in flight together; only a chunk with a sample left goes through
+    // the exact test.
+    const float inv = (float)env.clear_inv * __frcp_rn((float)parts);
+    const float g0 = (float)((a[0] - env.clear_org[0]) * env.clear_inv), g1 = (float)((a[1] - env.clear_org[1]) * env.clear_inv),
+                g2 = (float)((a[2] - env.clear_org[2]) * env.clear_inv);
+    const float d0 = (float)(b[0] - a[0]) * inv, d1 = (float)(b[1] - a[1]) * inv, d2 = (float)(b[2] - a[2]) * inv;
+    const float nxd = (float)env.clear_n[0], nyd = (float)env.clear_n[1], nzd = (float)env.clear_n[2];
+    for (int c0 = 0; c0 * 64 < ns && fh == 0x7fffffff; c0 += 4) {
+      const uint32_t* wp[4];
+      int sh[4];
+      bool need[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = 1 + 64 * (c0 + u) + lane;
+        need[u] = idx <= ns;
+        wp[u] = nullptr; sh[u] = 0;
+        if (need[u] && env.clear_bits) {
+          const float td = (float)idx;
+          const float fx = __builtin_fmaf(td, d0, g0), fy = __builtin_fmaf(td, d1, g1), fz = __builtin_fmaf(td, d2, g2);
+          if (fx >= 0 && fy >= 0 && fz >= 0 && fx < nxd && fy < nyd && fz < nzd) {
+            const uint32_t ci = ((uint32_t)(int)fz * (uint32_t)env.clear_n[1] + (uint32_t)(int)fy) * (uint32_t)env.clear_n[0] + (uint32_t)(int)fx;
+            wp[u] = env.clear_bits + (ci >> 5);
+            sh[u] = (int)(ci & 31u);
+          } else if (fx == fx && fy == fy && fz == fz) {
+            need[u] = false;                                  // beyond the inflated box of the environment
+          }
+        }
+      }
+      uint32_t word[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) word[u] = wp[u] ? *wp[u] : 0u;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (wp[u] && ((word[u] >> sh[u]) & 1u)) need[u] = false;
+        const unsigned long long mask = __ballot(need[u]);
+        if (mask == 0ULL || fh != 0x7fffffff) continue;
+        segment_chunk(env, rob, rtri, stack, cand, queue, stage, a, b, 0, c0 + u, true, mask, fh_lds, ovf_lds, lane DBG_PASS);
+        __builtin_amdgcn_wave_barrier();
+        fh = *fh_lds;
+        if (*ovf_lds) { fault = true; return false; }
+      }
     }
   }
   calls += fh == 0x7fffffff ? (unsigned long long)ns : (unsigned long long)fh;
@@ -2324,6 +2361,11 @@ __global__ __launch_bounds__(64) void k_seq_waves(SeqArgs A) {
   int32_t* frontier = front_sel ? f.frontier2 : f.frontier;
   const int TM = f.threshold_misses, WP = f.words_per, R = f.n_trees;
   int fault = 0, w_round = 0, w_node = 0, w_pos = 0, w_closed = 0, in_wave = 0;
+  // phase clocks (10 ns ticks): pick + node, sample, pose, parent edge, neighbour query, neighbour loop, append, wave end
+  uint64_t pre_w[6] = {0, 0, 0, 0, 0, 0};
+  unsigned long long pre_at = ~0ULL;
+  unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tq = wall_clock64();
+  auto lap = [&](int k) { const unsigned long long t = wall_clock64(); ph[k] += t - tq; tq = t; };
   for (int wv = 0; wv < A.max_waves && !terminated && !fault; ++wv) {
     // ---- what the round engine checks before a round (round_begin_scalars), and what this launch has to leave to the host
     if (n_nodes + 1 > f.node_cap - 8 || nb + TM > f.border_cap) { fault = SFFK_FAULT_CAPACITY; break; }
@@ -2345,13 +2387,19 @@ __global__ __launch_bounds__(64) void k_seq_waves(SeqArgs A) {
     const bool force = (sq_u8(f.nflag + node) & 1) != 0;
     bool failing = true;
     w_node = node; w_pos = pick; w_closed = use_closed;
+    lap(0);
     for (int rd = 0; rd < TM && failing && iter < f.max_iterations; ++rd) {
       // (attempt-start snapshot: a fault rolls exactly this attempt back)
       const int iter_a = iter;
       const unsigned long long cur_a = cursor, cc_a = cc, pf_a = pf, nq_a = nq, xp_a = ex_pose, xs_a = ex_seg, xm_a = ex_smp;
       bool flt = false;
+      // (the words of this attempt were asked for while the previous one ran, whenever the stream position was the
+      // expected one; the next attempt's are asked for now)
       uint64_t w[6];
-      for (int k = 0; k < 6; ++k) w[k] = k < WP ? f.ring[(cursor + k) & f.ring_mask] : 0ULL;
+      if (pre_at == cursor) { for (int k = 0; k < 6; ++k) w[k] = pre_w[k]; }
+      else { for (int k = 0; k < 6; ++k) w[k] = k < WP ? f.ring[(cursor + k) & f.ring_mask] : 0ULL; }
+      pre_at = cursor + (unsigned long long)WP;
+      for (int k = 0; k < 6; ++k) pre_w[k] = k < WP ? f.ring[(pre_at + k) & f.ring_mask] : 0ULL;
       SampleTrig ht{};
       if (A.trig) {
         const double* t0 = A.trig + 3 * (size_t)(cursor & f.ring_mask);
@@ -2366,8 +2414,17 @@ __global__ __launch_bounds__(64) void k_seq_waves(SeqArgs A) {
       ++iter;
       ++rounds; rnodes += (unsigned long long)(n_nodes + 1); ++rqueries;
       double qp[6];
-      const bool ok = A.trig ? sample_point_with(w, cpos, A.sampling_dist, A.dim, A.limits, qp, ht)
-                             : sample_point(w, cpos, A.sampling_dist, A.dim, A.limits, qp);
+      if (!A.trig) {
+        // the five transcendental values of the sample, two at a time: lanes 0 / 1 evaluate the same function on phi / theta
+        // (one instruction stream whatever the lane count; the same portable routines, so the same bits as sample_point)
+        const double ang = sample_angle(w[lane == 1 ? 1 : 0]);
+        const double sv = sffp::psin(ang), cv = sffp::pcos(ang);
+        ht.s_phi = __shfl(sv, 0); ht.c_phi = __shfl(cv, 0);
+        ht.s_theta = __shfl(sv, 1); ht.c_theta = __shfl(cv, 1);
+        ht.acos_u = WP == 6 ? sffp::pacos(sample_acos_arg(w[3])) : 0.0;
+      }
+      const bool ok = sample_point_with(w, cpos, A.sampling_dist, A.dim, A.limits, qp, ht);
+      lap(1);
       if (!ok) continue;                                           // :246 !result
       // ---- Environment::Collide(newPoint)
       cc += 1; ex_pose += 1;
@@ -2379,11 +2436,13 @@ __global__ __launch_bounds__(64) void k_seq_waves(SeqArgs A) {
         xform(Rm, qp, A.rob.center, c3);
         hit = pose_exact(A.env, A.rob, rtri, stack, cand, stage, qp, Rm, c3, lane);
       }
+      lap(2);
       if (hit) continue;
       // ---- isPathFree(expanded, newPoint)
       pf += 1; ex_seg += 1;
       const bool free0 = sq_path_free(A.env, A.rob, rtri, stack, cand, queue, stage, cpos, qp, &s_fh, &s_ovf, lane, cc, ex_smp, flt);
       bool reject = !free0;
+      lap(3);
       const double pdist = dist6(cpos, qp);                        // parentDistance, :250
       int n_hit = 0;
       if (!flt && !reject) {
@@ -2451,6 +2510,7 @@ __global__ __launch_bounds__(64) void k_seq_waves(SeqArgs A) {
         for (int base = 0; base < no; base += 64) take(base + lane < no, g.ovf + base + lane);
         if (n_hit > A.hit_cap || n_hit > 64) flt = true;
       }
+      lap(4);
       if (!flt && !reject) {
         // ---- the neighbour loop (:270-300) in the reference's order: tree id, then distance, then id; an edge is only
         // checked when the loop reaches it
@@ -2509,6 +2569,7 @@ __global__ __launch_bounds__(64) void k_seq_waves(SeqArgs A) {
           }
         }
       }
+      lap(5);
       if (flt) {
         // a bounded list overflowed (hits, triangle candidates): this attempt never happened - the host finishes the wave
         iter = iter_a; cursor = cur_a; cc = cc_a; pf = pf_a; nq = nq_a; ex_pose = xp_a; ex_seg = xs_a; ex_smp = xm_a;
@@ -2539,6 +2600,7 @@ __global__ __launch_bounds__(64) void k_seq_waves(SeqArgs A) {
       sq_drain();
       ++n_nodes; ++fn;
       failing = false;
+      lap(6);
     }
     if (fault) break;
     // ---- the slot is exhausted: its node leaves the frontier for the closed list (:160-178; the erase keeps the order)
@@ -2578,8 +2640,10 @@ __global__ __launch_bounds__(64) void k_seq_waves(SeqArgs A) {
     }
     const bool budget = f.node_budget > 0 && n_nodes >= f.node_budget;
     terminated = (solved || iter >= f.max_iterations || budget) ? 1 : 0;
+    lap(7);
   }
   if (lane == 0) {
+    for (int k = 0; k < 8; ++k) c->wprof[k] += ph[k];
     c->n_nodes = n_nodes; c->iter = iter; c->frontier_n = fn; c->closed_n = cn; c->n_borders = nb;
     c->solved = solved; c->empty_frontier = empty_frontier; c->terminated = terminated;
     c->cursor = cursor; c->collide_calls = cc; c->path_free_calls = pf; c->nn_queries = nq;
@@ -2599,6 +2663,7 @@ __global__ __launch_bounds__(64) void k_seq_waves(SeqArgs A) {
 }
 
 void launch_seq_waves(hipStream_t s, const SeqArgs& a) {
+
   const size_t lds = collide_lds_bytes(a.rob.n_tri, 1);
   if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_seq_waves), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipLaunchKernelGGL(k_seq_waves, dim3(1), dim3(64), lds, s, a);
