@@ -1025,7 +1025,7 @@ bool Forest::dev_wave_begin() {
 
 bool Forest::seq_eligible() const {
   static const bool off = getenv("SFFGPU_NO_SEQ") != nullptr && atoi(getenv("SFFGPU_NO_SEQ")) != 0;
-  return dev.on && cfg.wave == 1 && !cfg.optimize && cfg.world == 1 && !off && !seq_suspended && num_roots <= 64;
+  return dev.on && cfg.wave == 1 && cfg.world == 1 && !off && !seq_suspended && num_roots <= 64;
 }
 
 // waves of ONE slot (the reference's own order): k_seq_waves runs whole outer iterations back to back inside one launch,
@@ -1079,6 +1079,17 @@ void Forest::run_device_seq(int max_waves) {
     a.max_waves = batch;
     a.hit_cap = hit_cap;
     a.grid_ovf_limit = c.grid_rebuild_at();
+    a.optimize = cfg.optimize ? 1 : 0;
+    if (cfg.optimize) {
+      const sffk::StarView sv = star_view();
+      a.ktab = sv.ktab;
+      a.tree_cnt = sv.tree_cnt;
+      a.hist = sv.hist;
+      a.hist_ctl = sv.hist_ctl;
+      a.hist_cap = sv.hist_cap;
+      a.cell_edge = c.grid_cell;
+      a.knn_slack = 8 * c.sweep_eps();
+    }
     sffk::launch_seq_waves(c.stream, a);
     HIPCHK(hipMemcpyAsync(d.h_ctrl.as<sffk::DevCtrl>(), d.ctrl.p, sizeof(sffk::DevCtrl), hipMemcpyDeviceToHost, c.stream));
     HIPCHK(hipEventRecord(d.ev_wave, c.stream));

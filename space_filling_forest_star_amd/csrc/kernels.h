@@ -456,6 +456,12 @@ struct SeqArgs {
   unsigned long long words_end;       // engine words resident in the ring (absolute position)
   int32_t* grid_ovf_src;              // the node grid's overflow counter
   int dim, max_waves, hit_cap, grid_ovf_limit;
+  // SFF* (optimize): choose-parent + rewire run in the loop itself, in the reference's order (src/forest.h:307-351)
+  int optimize;
+  const int32_t* ktab;                // StarView::ktab
+  int32_t* tree_cnt;                  // StarView::tree_cnt
+  int32_t* hist; int32_t* hist_ctl; int hist_cap;   // StarView's parent history (record_parents) or null
+  double cell_edge, knn_slack;
 };
 void launch_seq_waves(hipStream_t s, const SeqArgs& a);
 // multi-GPU: the answer record of one sample as it travels in the all-gather of a round:

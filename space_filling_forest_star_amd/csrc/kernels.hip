@@ -2273,7 +2273,7 @@ __device__ __forceinline__ int sq_lemire(unsigned long long word, unsigned long 
 
 // Solver::isPathFree(a, b) by the wavefront: chunk after chunk until the first hit (the chunks come in sample order, so
 // the first chunk with a hit holds the edge's first hit).  Returns free; calls = Collide calls the reference makes.
-__device__ bool sq_path_free(const EnvView& env, const RobotView& rob, const double* rtri, int32_t* stack, int32_t* cand, int32_t* queue,
+__device__ __attribute__((noinline)) bool sq_path_free(const EnvView& env, const RobotView& rob, const double* rtri, int32_t* stack, int32_t* cand, int32_t* queue,
                              double* stage, const double* a, const double* b, int32_t* fh_lds, int32_t* ovf_lds, int lane,
                              unsigned long long& calls, unsigned long long& samples, bool& fault) {
   const double parts = edge_parts(a, b);
@@ -2318,15 +2318,39 @@ __device__ bool sq_path_free(const EnvView& env, const RobotView& rob, const dou
       uint32_t word[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) word[u] = wp[u] ? *wp[u] : 0u;
+      unsigned long long m0, m1, m2, m3;
+      {
+        unsigned long long mm[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (wp[u] && ((word[u] >> sh[u]) & 1u)) need[u] = false;
-        const unsigned long long mask = __ballot(need[u]);
-        if (mask == 0ULL || fh != 0x7fffffff) continue;
+        for (int u = 0; u < 4; ++u) {
+          if (wp[u] && ((word[u] >> sh[u]) & 1u)) need[u] = false;
+          mm[u] = __ballot(need[u]);
+        }
+        m0 = mm[0]; m1 = mm[1]; m2 = mm[2]; m3 = mm[3];
+      }
+      for (int u = 0; u < 4 && fh == 0x7fffffff; ++u) {
+        const unsigned long long mask = u == 0 ? m0 : (u == 1 ? m1 : (u == 2 ? m2 : m3));
+        if (mask == 0ULL) continue;
         segment_chunk(env, rob, rtri, stack, cand, queue, stage, a, b, 0, c0 + u, true, mask, fh_lds, ovf_lds, lane DBG_PASS);
         __builtin_amdgcn_wave_barrier();
         fh = *fh_lds;
-        if (*ovf_lds) { fault = true; return false; }
+        if (*ovf_lds) {
+          // (rare) the chunk's triangle candidate list ran over: its samples one by one through the pose test, which
+          // never runs over (it falls back to every triangle) - the same contact definition, so the same first hit
+          __builtin_amdgcn_wave_barrier();
+          if (lane == 0) { *fh_lds = 0x7fffffff; *ovf_lds = 0; }
+          __builtin_amdgcn_wave_barrier();
+          fh = 0x7fffffff;
+          const double dir[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
+          const int last = 64 * (c0 + u) + 64 < ns ? 64 * (c0 + u) + 64 : ns;
+          for (int idx = 1 + 64 * (c0 + u); idx <= last && fh == 0x7fffffff; ++idx) {
+            double P[6] = {0, 0, 0, 0, 0, 0}, Rm[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, c3[3];
+            edge_sample_pos(a, dir, parts, idx, P);
+            if (surely_clear(env, P)) continue;
+            xform(Rm, P, rob.center, c3);
+            if (pose_exact(env, rob, rtri, stack, cand, stage, P, Rm, c3, lane)) fh = idx;
+          }
+        }
       }
     }
   }
@@ -2334,6 +2358,83 @@ __device__ bool sq_path_free(const EnvView& env, const RobotView& rob, const dou
   return fh == 0x7fffffff;
 }
 
+// the k nearest nodes of one tree around qp, by the wavefront (lane j = j-th nearest, (distance, id) order): shells of grid
+// cells until the k-th distance lies inside the covered ball; a tree with fewer than k nodes is complete once all are in
+__device__ __attribute__((noinline)) void sq_knn(const GridView& g, const double* qp, int tree, int k, int tcnt, double cell_edge, double slack, int lane,
+                       TopK& t, int& have) {
+  t.d = 1.0e300; t.id = 0x7fffffff;
+  have = 0;
+  if (k <= 0) return;
+  const int k_store = k < tcnt ? k : tcnt;
+  auto offer = [&](bool valid, const GridItem* src) {
+    bool cand = false;
+    double d = 1.0e300;
+    int id = 0x7fffffff;
+    if (valid) {
+      const unsigned long long* q8 = reinterpret_cast<const unsigned long long*>(src);
+      const unsigned long long it = sq_u64(q8 + 6);
+      id = (int)(unsigned)(it & 0xffffffffULL);
+      if ((int)(unsigned)(it >> 32) == tree) {
+        double p6[6];
+        for (int q = 0; q < 6; ++q) p6[q] = __longlong_as_double((long long)sq_u64(q8 + q));
+        d = dist6(p6, qp);
+        cand = true;
+      }
+    }
+    const double worst = topk_worst(t, k, have);
+    cand = cand && (have < k || key_less(d, id, worst, 0x7fffffff));
+    topk_insert(t, lane, k, have, __ballot(cand), d, id);
+  };
+  int no = sq_i32(g.ovf_cnt);
+  if (no > g.ovf_cap) no = g.ovf_cap;
+  for (int base = 0; base < no; base += 64) offer(base + lane < no, g.ovf + base + lane);
+  const int cx = grid_coord((float)qp[0], g.ox, g.inv_cell, g.nx), cy = grid_coord((float)qp[1], g.oy, g.inv_cell, g.ny),
+            cz = grid_coord((float)qp[2], g.oz, g.inv_cell, g.nz);
+  const int rmax = max(max(g.nx, g.ny), g.nz);
+  for (int rr = 0; rr <= rmax; ++rr) {
+    if (have >= k_store && k_store == tcnt) break;
+    const int w = 2 * rr + 1;
+    const int total = w * w * w;
+    for (int c0 = 0; c0 < total; c0 += 64) {
+      const int cc = c0 + lane;
+      int cell = 0, m = 0;
+      if (cc < total) {
+        const int ox = cc % w - rr, oy = (cc / w) % w - rr, oz = cc / (w * w) - rr;
+        const bool shell = ox == -rr || ox == rr || oy == -rr || oy == rr || oz == -rr || oz == rr;
+        const int x = cx + ox, y = cy + oy, z = cz + oz;
+        if (shell && x >= 0 && x < g.nx && y >= 0 && y < g.ny && z >= 0 && z < g.nz) {
+          cell = (z * g.ny + y) * g.nx + x;
+          m = sq_i32(g.cnt + cell);
+          if (m > g.bk) m = g.bk;
+        }
+      }
+      if (!__any(m > 0)) continue;
+      int inc = m;
+      for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(inc, off);
+        if (lane >= off) inc += o;
+      }
+      const int tot = __shfl(inc, 63);
+      for (int base = 0; base < tot; base += 64) {
+        const int j = base + lane;
+        const int jj = j < tot ? j : tot - 1;
+        int lo = 0, hi = 63;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (__shfl(inc, mid) > jj) hi = mid; else lo = mid + 1;
+        }
+        const int src_cell = __shfl(cell, lo);
+        const int slot = jj - (__shfl(inc, lo) - __shfl(m, lo));
+        offer(j < tot, g.items + (size_t)src_cell * g.bk + slot);
+      }
+    }
+    const double covered = (double)rr * cell_edge - slack;
+    if (have >= k && topk_worst(t, k, have) <= covered) break;
+    if (cx - rr <= 0 && cy - rr <= 0 && cz - rr <= 0 && cx + rr >= g.nx - 1 && cy + rr >= g.ny - 1 && cz + rr >= g.nz - 1) break;
+  }
+}
+
+template <bool OPT>
 __global__ __launch_bounds__(64) void k_seq_waves(SeqArgs A) {
   extern __shared__ double lds_d[];
   __shared__ int32_t s_fh, s_ovf;
@@ -2361,6 +2462,7 @@ __global__ __launch_bounds__(64) void k_seq_waves(SeqArgs A) {
   int32_t* frontier = front_sel ? f.frontier2 : f.frontier;
   const int TM = f.threshold_misses, WP = f.words_per, R = f.n_trees;
   int fault = 0, w_round = 0, w_node = 0, w_pos = 0, w_closed = 0, in_wave = 0;
+  unsigned long long st_rounds = 0, st_members = 0, st_rewires = 0;
   // phase clocks (10 ns ticks): pick + node, sample, pose, parent edge, neighbour query, neighbour loop, append, wave end
   uint64_t pre_w[6] = {0, 0, 0, 0, 0, 0};
   unsigned long long pre_at = ~0ULL;
@@ -2417,7 +2519,7 @@ __global__ __launch_bounds__(64) void k_seq_waves(SeqArgs A) {
       if (!A.trig) {
         // the five transcendental values of the sample, two at a time: lanes 0 / 1 evaluate the same function on phi / theta
         // (one instruction stream whatever the lane count; the same portable routines, so the same bits as sample_point)
-        const double ang = sample_angle(w[lane == 1 ? 1 : 0]);
+        const double ang = sample_angle(lane == 1 ? w[1] : w[0]);
         const double sv = sffp::psin(ang), cv = sffp::pcos(ang);
         ht.s_phi = __shfl(sv, 0); ht.c_phi = __shfl(cv, 0);
         ht.s_theta = __shfl(sv, 1); ht.c_theta = __shfl(cv, 1);
@@ -2578,7 +2680,40 @@ __global__ __launch_bounds__(64) void k_seq_waves(SeqArgs A) {
         break;
       }
       if (reject) continue;
-      // ---- the new node (:353-367)
+      // ---- SFF* (:307-351): the k nearest of the tree, choose parent, (the node), rewire - each edge checked when its turn comes
+      int par_new = node;
+      double dcl_new = pdist, best = pdist + droot_ex;
+      TopK mt{1.0e300, 0x7fffffff};
+      int n_mem = 0;
+      double m_droot = 0;
+      if (OPT) {
+        const int k = __popcll(__ballot(lane > 0 && lane <= SFFK_STAR_KMAX + 1 && A.ktab[lane] <= n_nodes));   // (size_t)(2e log10 N), :309
+        if (k > SFFK_STAR_KMAX) flt = true;
+        else {
+          nq += 1;                                                                          // :317 knnSearch
+          sq_knn(A.g, qp, mine, k, sq_i32(A.tree_cnt + 16 * mine), A.cell_edge, A.knn_slack, lane, mt, n_mem);
+          if (lane < n_mem) m_droot = sq_f64(f.d_root + mt.id);
+          for (int m = 0; m < n_mem && !flt; ++m) {                                         // :320-327
+            const double nd = __shfl(mt.d, m) + __shfl(m_droot, m);
+            if (nd < best - SFFG_TOL) {
+              const int idm = __shfl(mt.id, m);
+              double mp[6];
+              for (int q = 0; q < 6; ++q) mp[q] = sq_f64(A.st.pos + 6 * (size_t)idm + q);
+              pf += 1; ex_seg += 1;
+              if (sq_path_free(A.env, A.rob, rtri, stack, cand, queue, stage, qp, mp, &s_fh, &s_ovf, lane, cc, ex_smp, flt) && !flt) {
+                best = nd; par_new = idm; dcl_new = __shfl(mt.d, m);
+              }
+            }
+          }
+        }
+        if (flt) {
+          iter = iter_a; cursor = cur_a; cc = cc_a; pf = pf_a; nq = nq_a; ex_pose = xp_a; ex_seg = xs_a; ex_smp = xm_a;
+          --rounds; rnodes -= (unsigned long long)(n_nodes + 1); --rqueries;
+          fault = SFFK_FAULT_LISTS; w_round = rd; in_wave = 1;
+          break;
+        }
+      }
+      // ---- the new node (:329, :353-367)
       const int idn = n_nodes;
       if (lane == 0) {
         const size_t o = (size_t)idn;
@@ -2586,12 +2721,20 @@ __global__ __launch_bounds__(64) void k_seq_waves(SeqArgs A) {
         A.st.yaw[o] = (float)qp[3]; A.st.pitch[o] = (float)qp[4]; A.st.roll[o] = (float)qp[5];
         for (int k = 0; k < 6; ++k) A.st.pos[6 * o + k] = qp[k];
         A.st.tree[o] = mine;
-        f.parent[o] = node;
-        f.d_closest[o] = pdist;
-        f.d_root[o] = pdist + droot_ex;
+        f.parent[o] = par_new;
+        f.d_closest[o] = dcl_new;
+        f.d_root[o] = best;
         f.iter[o] = (uint32_t)iter;
         f.nflag[o] = 2;
         frontier[fn] = idn;
+        if (OPT) {
+          atomicAdd(A.tree_cnt + 16 * mine, 1);
+          if (A.hist) {
+            const int at = atomicAdd(A.hist_ctl, 1);
+            if (at < A.hist_cap) { A.hist[3 * (size_t)at] = idn; A.hist[3 * (size_t)at + 1] = par_new; A.hist[3 * (size_t)at + 2] = iter; }
+            else A.hist_ctl[1] = 1;
+          }
+        }
         GridItem it;
         for (int k = 0; k < 6; ++k) it.p[k] = qp[k];
         it.id = idn; it.tree = mine; it.pad[0] = it.pad[1] = 0;
@@ -2600,6 +2743,34 @@ __global__ __launch_bounds__(64) void k_seq_waves(SeqArgs A) {
       sq_drain();
       ++n_nodes; ++fn;
       failing = false;
+      if (OPT) {
+        // rewire (:332-350): a member the new node's cost improves, if the edge member -> new is free
+        ++st_rounds; st_members += (unsigned long long)n_mem;
+        for (int m = 0; m < n_mem; ++m) {
+          const double dm = __shfl(mt.d, m), drm = __shfl(m_droot, m);
+          const double proposed = best + dm;
+          if (proposed < drm - SFFG_TOL) {
+            const int idm = __shfl(mt.id, m);
+            double mp[6];
+            for (int q = 0; q < 6; ++q) mp[q] = sq_f64(A.st.pos + 6 * (size_t)idm + q);
+            pf += 1; ex_seg += 1;
+            bool f2 = false;
+            const bool fr = sq_path_free(A.env, A.rob, rtri, stack, cand, queue, stage, mp, qp, &s_fh, &s_ovf, lane, cc, ex_smp, f2);
+            if (fr) {
+              if (lane == 0) {
+                f.parent[idm] = idn; f.d_closest[idm] = dm; f.d_root[idm] = proposed;
+                if (A.hist) {
+                  const int at = atomicAdd(A.hist_ctl, 1);
+                  if (at < A.hist_cap) { A.hist[3 * (size_t)at] = idm; A.hist[3 * (size_t)at + 1] = idn; A.hist[3 * (size_t)at + 2] = iter; }
+                  else A.hist_ctl[1] = 1;
+                }
+              }
+              ++st_rewires;
+            }
+          }
+        }
+        sq_drain();
+      }
       lap(6);
     }
     if (fault) break;
@@ -2650,6 +2821,7 @@ __global__ __launch_bounds__(64) void k_seq_waves(SeqArgs A) {
     c->poses_executed = ex_pose; c->segments_executed = ex_seg; c->samples_executed = ex_smp;
     c->waves = waves; c->rounds = rounds; c->round_nodes = rnodes; c->round_queries = rqueries;
     c->redraws += (int)redraws;
+    c->star_rounds += st_rounds; c->star_passes += st_rounds; c->star_members += st_members; c->star_rewires += st_rewires;
     c->n_act = 0; c->app_n = 0; c->compact_from = 0;
     c->grid_ovf = sq_i32(A.grid_ovf_src); c->tgrid_ovf = 0;
     c->fault = fault;
@@ -2665,8 +2837,13 @@ __global__ __launch_bounds__(64) void k_seq_waves(SeqArgs A) {
 void launch_seq_waves(hipStream_t s, const SeqArgs& a) {
 
   const size_t lds = collide_lds_bytes(a.rob.n_tri, 1);
-  if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_seq_waves), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  hipLaunchKernelGGL(k_seq_waves, dim3(1), dim3(64), lds, s, a);
+  if (a.optimize) {
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_seq_waves<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_seq_waves<true>, dim3(1), dim3(64), lds, s, a);
+  } else {
+    if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_seq_waves<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_seq_waves<false>, dim3(1), dim3(64), lds, s, a);
+  }
 }
 
 // ------------------------------------------------------------------ node store writes
