@@ -26,6 +26,7 @@
 // order as the host engine (-ffp-contract=off), so the forests are bit-identical.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "kernels.h"
 #include "sff_geom.h"
 #include "kernels_dev.h"
@@ -141,7 +142,7 @@ __device__ void round_begin_scalars(const DevForestView& f, DevCtrl* c) {
 __global__ __launch_bounds__(DF_THREADS) void k_wave_begin(DevForestView f) {
   __shared__ int any_redraw;
   DevCtrl* c = f.ctrl;
-  const unsigned long long tb0 = wall_clock64();
+  const unsigned long long tb0 = f.profile ? wall_clock64() : 0ULL;
   if (threadIdx.x == 0) { c->compact_from = 0; c->app_n = 0; }   // (no stale order for the wide follow-up kernels)
   if (c->halt) return;
   if (c->in_wave) {   // resuming inside a wave (after the host handled a fault): the active list is in place
@@ -206,7 +207,7 @@ __global__ __launch_bounds__(DF_THREADS) void k_wave_begin(DevForestView f) {
     c->in_wave = 1;
     c->waves += 1;
     round_begin_scalars(f, c);
-    c->wprof[6] += wall_clock64() - tb0;
+    if (f.profile) c->wprof[6] += wall_clock64() - tb0;
   }
 }
 
@@ -818,6 +819,458 @@ __global__ __launch_bounds__(DF_THREADS) void k_resolve(ResolveArgs A) {
     reinterpret_cast<int32_t*>(c)[w] = reinterpret_cast<const int32_t*>(&K)[w];
 }
 
+// ------------------------------------------------------------------ the commit of one round as ONE wide kernel
+// k_commit = k_decide + k_resolve without the single workgroup: 64 samples per workgroup, 16 lanes per sample (lane 0 the
+// parent edge, lane l the l-th neighbour).  Everything that needs the slot order only ever looks BACKWARDS in it:
+//   - a sample whose walk (src/forest.h:262-300) reaches a sample of the same round waits for that sample's state
+//     (ustate32, polled; the earlier sample sits in this or in a lower workgroup);
+//   - node ids / border list positions are prefixes over the LOWER workgroups' published counts;
+//   - a border key belongs to the first event in slot order: an event knows its fate once the lower workgroups (and its
+//     own) have posted their stamps (atomicMin on the table entry) - later stamps can only be larger.
+// So a workgroup waits for lower ones only, and workgroups start in index order: the lowest unfinished one never waits.
+// The LAST workgroup of the round adds everything up and writes the control block (what k_resolve's thread 0 did).
+// Published words are (launch sequence number << 32 | value): nothing is cleared between launches.
+#define KC_SPIN_LIMIT (1 << 20)   // polls before a wait gives up (then: fault, the host redoes the round) - never reached
+#define KC_ACC 0      // accepted samples of the workgroup
+#define KC_PREF 1     // accepted samples of all lower workgroups
+#define KC_WLO 2      // accepted word, low / high half
+#define KC_WHI 3
+#define KC_POSTED 4   // its border stamps are in the table
+#define KC_OWN 5      // border events it owns
+#define KC_CNT 6      // 6 counters (k_decide's) + [12] dependent samples
+#define KC_DEP 12
+
+__device__ __forceinline__ unsigned long long kc_load(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void kc_publish(unsigned long long* p, unsigned seq, unsigned v) {
+  __hip_atomic_store(p, ((unsigned long long)seq << 32) | (unsigned long long)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// waits for this launch's word; 0 + fault when it never comes
+__device__ __forceinline__ unsigned kc_wait(const unsigned long long* p, unsigned seq, int32_t* fault) {
+  for (int spin = 0; spin < KC_SPIN_LIMIT; ++spin) {
+    const unsigned long long v = kc_load(p);
+    if ((unsigned)(v >> 32) == seq) return (unsigned)v;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  atomicOr(fault, 1);
+  return 0u;
+}
+// sum over the workgroup (every thread calls it; barriers inside)
+__device__ __forceinline__ unsigned long long kc_block_sum(unsigned long long v, unsigned long long* slot) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  __syncthreads();
+  if (threadIdx.x == 0) *slot = 0ULL;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0 && v) atomicAdd(slot, v);
+  __syncthreads();
+  return *slot;
+}
+
+// eight sums at once (entries below `from` are skipped)
+__device__ __forceinline__ void kc_block_sum8(unsigned long long* v, unsigned long long* slots, int from) {
+  for (int q = from; q < 8; ++q)
+    for (int off = 32; off > 0; off >>= 1) v[q] += __shfl_xor(v[q], off);
+  __syncthreads();
+  if (threadIdx.x < 8) slots[threadIdx.x] = 0ULL;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0)
+    for (int q = from; q < 8; ++q) if (v[q]) atomicAdd(&slots[q], v[q]);
+  __syncthreads();
+  for (int q = from; q < 8; ++q) v[q] = slots[q];
+}
+
+__global__ __launch_bounds__(1024) void k_commit(ResolveArgs A, int n_bound) {
+  __shared__ int s_state[64], s_dk[64], s_dep[64];
+  __shared__ unsigned long long s_cnt[64][6];
+  __shared__ unsigned long long s_sum;
+  __shared__ unsigned long long s_wa, s_we, s_c6[7];
+  __shared__ int s_ev_total;
+  __shared__ unsigned long long s_tot[8];
+  __shared__ DevCtrl K;
+  const DevForestView& f = A.f;
+  DevCtrl* c = f.ctrl;
+  const int b = blockIdx.x;
+  const int grp = threadIdx.x >> 4, gl = threadIdx.x & 15, lane = threadIdx.x & 63;
+  const int i = b * 64 + grp;
+  // every answer the verdict may need is requested before anything is looked at (after a kernel boundary each dependent
+  // step is a trip to the memory side of the chip); the buffers hold n_bound samples whatever the round's size is
+  const bool inb = i < n_bound;
+  const size_t s0 = (size_t)i * A.stride;
+  const bool inl = inb && A.in_lim[i] != 0;
+  const int flags = inb ? A.rec_flags[i] : 0;
+  int nnb = inb ? A.rec_nnb[i] : 0;
+  const bool pose_hit = inb && A.pose_hit[i] != 0;
+  int fh = 0x7fffffff, ns = 0, nb = 0, meta = 0;
+  if (inb) {
+    fh = A.first_hit[s0 + gl]; ns = A.seg_ns[s0 + gl];
+    if (gl > 0) { nb = A.rec_nb[(size_t)i * A.nbcap + gl - 1]; meta = A.rec_meta[(size_t)i * A.nbcap + gl - 1]; }
+  }
+  const int halt = c->halt, n = c->n_act;
+  if (halt || n == 0) {
+    if (b == 0 && threadIdx.x == 0) {
+      c->app_n = 0;
+      if (A.star) { A.S.hdr[0] = 0; A.S.hdr[1] = 1; A.S.hdr[2] = 0; A.S.hdr[4] = 0; }   // (no star stage unless a round commits)
+    }
+    return;
+  }
+  if (b * 64 >= n) return;
+  const int nwg = (n + 63) >> 6;
+  const bool last = b == nwg - 1;
+  const unsigned seq = (unsigned)f.commit_seq[0] + 1u;
+  const int seq30 = (int)(seq & 0x3fffffffu);
+  const int Tb = f.temp_base, N0 = c->N0, nb0 = c->n_borders;
+  const unsigned long long stamp_hi = (c->epoch + 1ULL) << 32;
+  unsigned long long* pub = f.wg_pub + (size_t)b * SFFK_PUB_WORDS;
+  unsigned long long tk[6];   // (phase clocks of the last workgroup; reading the clock is a scalar memory round trip)
+  const bool clk = last && f.profile;
+  tk[0] = clk ? wall_clock64() : 0ULL;
+  unsigned long long* trace = (f.kc_trace && (int)c->rounds == f.kc_trace_round && threadIdx.x == 0) ? f.kc_trace + 8 * (size_t)b : nullptr;
+#define KC_TRACE(k) do { if (trace) trace[k] = wall_clock64(); } while (0)
+  KC_TRACE(0);
+  int work_items = 0;
+  if (last) {   // (the control block does not change before this workgroup rewrites it: requested now, used at the end)
+    for (int w = threadIdx.x; w < (int)(sizeof(DevCtrl) / 4); w += 1024)
+      reinterpret_cast<int32_t*>(&K)[w] = reinterpret_cast<const int32_t*>(c)[w];
+    work_items = A.round_ctrl[2];
+  }
+
+  // ---- 1. every sample's walk, as far as the states of the earlier samples allow
+  auto calls_of = [](int fh, int ns) -> unsigned long long {
+    return fh != 0x7fffffff ? (unsigned long long)fh : (unsigned long long)ns;
+  };
+  const int gsh = lane & 48;                         // first lane of the group in its wavefront
+  auto gballot = [&](bool p) -> unsigned { return (unsigned)((__ballot(p) >> gsh) & 0xffffULL); };
+  auto gsum = [&](unsigned long long v) -> unsigned long long {
+    for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+  };
+  unsigned long long cnt[6] = {0, 0, 0, 0, 0, 0};   // cc, pf, nq, ex_pose, ex_seg, ex_smp
+  int st = 1, code = SFFK_REJECTED, dk = 0, was_dep = 0;
+  const bool live = i < n;
+  bool pending = false;
+  if (nnb > 15) nnb = 15;
+  const bool have = gl <= nnb;
+  if (!have) { fh = 0x7fffffff; ns = 0; nb = 0; meta = 0; }
+  const bool is_nb = have && gl > 0;
+  const bool mate = is_nb && nb >= Tb;
+  const bool same = (meta & 1) != 0;
+  const bool fr = fh == 0x7fffffff;
+  const unsigned long long my_calls = calls_of(fh, ns);
+  const unsigned stops = gballot(is_nb && (mate || !same || fr));
+  const unsigned mates = gballot(mate), sames = gballot(same), frees = gballot(fr);
+  if (live) {
+    if (!inl) code = SFFK_OUTSIDE;
+    else if (flags & 2) { if (gl == 0) atomicOr(A.fault_pending, 1); }   // hit / neighbour list overflow: host path
+    else if ((flags & 3) == 1) {
+      const bool ovf = gballot(have && fh == 0) != 0;    // 0 = the edge's triangle candidate list ran over
+      const bool mine = A.world <= 1 || i % A.world == A.rank;   // (executed work is counted by the rank that ran it)
+      const unsigned long long smp = gsum(have ? (unsigned long long)ns : 0ULL);
+      if (mine) { cnt[3] = 1; cnt[4] = 1 + (unsigned long long)nnb; cnt[5] = smp; }
+      const int fh0 = __shfl(fh, gsh), ns0 = __shfl(ns, gsh);
+      if (ovf) { if (gl == 0) atomicOr(A.fault_pending, 1); }
+      else {
+        cnt[0] = 1;                                // :246 env.Collide(newPoint)
+        if (!pose_hit) {
+          cnt[1] = 1;
+          cnt[0] += calls_of(fh0, ns0);
+          if (fh0 == 0x7fffffff) {                 // parent edge free: the neighbour loop decides
+            cnt[2] = (unsigned long long)f.n_trees;   // :262-267 one radiusSearch per tree
+            pending = true;
+          }
+        }
+      }
+    }
+  }
+  // the walk: from stop to stop (a stop = a round-mate, a neighbour of another tree, or one of the same tree with a
+  // free edge; the neighbours in between are visited and change nothing).  A round-mate only exists if that sample
+  // became a node: its state is polled - all unknown mates of a sample at once, so a step of the outer loop is one
+  // level of the dependency chain.
+  int ks = stops ? __ffs((int)stops) - 1 : 16;
+  int end = 16;                                     // (group lane of the stop that ended the walk; 16 = none: accepted)
+  unsigned long long m_pf = 0, m_cc = 0;            // round-mates visited as nodes
+  int mate_state = mate ? 0 : -1;                   // this lane's round-mate: 0 unknown
+  if (pending && stops && ((mates >> ks) & 1u)) was_dep = 1;
+  bool published = false;
+  int passes = 0;
+  for (int spin = 0; ; ++spin) {
+    if (pending && mate && mate_state == 0 && gl >= ks) {
+      const int v = __hip_atomic_load(&f.ustate32[nb - Tb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((v >> 2) == seq30) mate_state = v & 3;
+    }
+    bool blocked = false;
+    while (true) {
+      const int kq = ks < 16 ? ks : 0;
+      const int ms = __shfl(mate_state, gsh + kq);
+      const unsigned long long ck = __shfl(my_calls, gsh + kq);
+      if (pending && !blocked) {
+        if (ks >= 16) { st = 2; code = SFFK_ACCEPT; end = 16; pending = false; }
+        else {
+          const bool k_mate = (mates >> ks) & 1u, k_same = (sames >> ks) & 1u, k_fr = (frees >> ks) & 1u;
+          const unsigned after = stops & ~((2u << ks) - 1u);
+          const int nxt = after ? __ffs((int)after) - 1 : 16;
+          if (k_mate && ms == 0) blocked = true;                       // not known yet
+          else if (k_mate && ms != 2) ks = nxt;                        // that sample never became a node
+          else {
+            if (k_mate) { m_pf += 1; m_cc += ck; }                     // (an ordinary neighbour now)
+            if (k_same) {
+              if (k_fr) { st = 1; code = SFFK_REJECTED; end = ks; pending = false; }   // :276-280 overcrowded
+              else ks = nxt;
+            } else {                                                   // :288-299
+              st = k_fr ? 3 : 1; code = k_fr ? SFFK_REJECT_EVENT : SFFK_REJECTED;
+              dk = ks - 1; end = ks; pending = false;
+            }
+          }
+        }
+      }
+      if (!__any(pending && !blocked)) break;
+    }
+    if (live && !pending && !published) {
+      published = true;
+      if (gl == 0) __hip_atomic_store(&f.ustate32[i], (seq30 << 2) | st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!__any(pending)) break;
+    ++passes;
+    if (spin >= KC_SPIN_LIMIT) {                    // (never: the states it waits for are earlier samples')
+      if (gl == 0 && pending) atomicOr(A.fault_pending, 1);
+      pending = false; st = 1; code = SFFK_REJECTED;
+      if (live && !published && gl == 0) __hip_atomic_store(&f.ustate32[i], (seq30 << 2) | 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      published = true;
+      break;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+  {
+    const bool walked = cnt[2] != 0;
+    const bool vis = walked && is_nb && !mate && gl <= end;
+    const unsigned long long v_pf = gsum(vis ? 1ULL : 0ULL), v_cc = gsum(vis ? my_calls : 0ULL);
+    if (walked) { cnt[1] += v_pf + m_pf; cnt[0] += v_cc + m_cc; }
+  }
+  if (gl == 0) {
+    if (live) A.code[i] = (uint8_t)code;
+    s_state[grp] = live ? st : 0;
+    s_dk[grp] = dk;
+    s_dep[grp] = live ? was_dep : 0;
+    for (int q = 0; q < 6; ++q) s_cnt[grp][q] = cnt[q];
+  }
+  __syncthreads();
+  if (clk) tk[1] = wall_clock64();
+  KC_TRACE(1);
+  // ---- 2. the workgroup's words, counts and counters
+  if (threadIdx.x < 64) {
+    const int v = s_state[threadIdx.x];
+    const unsigned long long wa = __ballot(v == 2), we = __ballot(v == 3), wd = __ballot(s_dep[threadIdx.x] != 0);
+    unsigned long long c6[6];
+    for (int q = 0; q < 6; ++q) {
+      c6[q] = s_cnt[threadIdx.x][q];
+      for (int off = 32; off > 0; off >>= 1) c6[q] += __shfl_xor(c6[q], off);
+    }
+    if (threadIdx.x == 0) {
+      s_wa = wa; s_we = we;
+      for (int q = 0; q < 6; ++q) s_c6[q] = c6[q];
+      s_c6[6] = (unsigned long long)__popcll(wd);
+      f.w_acc[b] = wa;                              // (k_append, the star stage)
+      kc_publish(pub + KC_WLO, seq, (unsigned)(wa & 0xffffffffULL));
+      kc_publish(pub + KC_WHI, seq, (unsigned)(wa >> 32));
+      kc_publish(pub + KC_ACC, seq, (unsigned)__popcll(wa));
+      KC_TRACE(2);
+      for (int q = 0; q < 6; ++q) kc_publish(pub + KC_CNT + q, seq, (unsigned)c6[q]);
+      kc_publish(pub + KC_DEP, seq, (unsigned)__popcll(wd));
+    }
+  }
+  __syncthreads();
+  const unsigned long long wa = s_wa, we = s_we;
+  // ---- 3. node ids: N0 + accepted samples before, in slot order
+  unsigned long long part = 0;
+  if ((int)threadIdx.x < b) part = kc_wait(f.wg_pub + (size_t)threadIdx.x * SFFK_PUB_WORDS + KC_ACC, seq, A.fault_pending);
+  const int acc_pref = (int)kc_block_sum(part, &s_sum);
+  if (threadIdx.x == 0) {
+    f.acc_pref[b] = acc_pref;
+    kc_publish(pub + KC_PREF, seq, (unsigned)acc_pref);
+  }
+  if (A.star && threadIdx.x < 64 && ((wa >> threadIdx.x) & 1ULL))   // SFF*: the accepted samples as a list (rank -> sample)
+    A.S.acc_sample[acc_pref + __popcll(wa & ((1ULL << threadIdx.x) - 1ULL))] = b * 64 + (int)threadIdx.x;
+  if (clk) tk[2] = wall_clock64();
+  KC_TRACE(4);
+  // ---- 4. border events (a free edge to a neighbour of another tree, :288-294), first in slot order wins
+  int n_own = 0, ev_pref = 0;
+  if (we != 0ULL || last) {
+    int e_nb = 0, e_ex = 0, e_i = 0;
+    size_t e_h = 0;
+    bool is_ev = false;
+    if (threadIdx.x < 64 && ((we >> threadIdx.x) & 1ULL)) {
+      is_ev = true;
+      e_i = b * 64 + (int)threadIdx.x;
+      const int raw = A.rec_nb[(size_t)e_i * A.nbcap + s_dk[threadIdx.x]];
+      if (raw >= Tb) {                       // (a round-mate neighbour was accepted: its new id)
+        const int j = raw - Tb, bj = j >> 6;
+        int pj = acc_pref;
+        unsigned long long wj = wa;
+        if (bj != b) {
+          const unsigned long long* pp = f.wg_pub + (size_t)bj * SFFK_PUB_WORDS;
+          pj = (int)kc_wait(pp + KC_PREF, seq, A.fault_pending);
+          wj = (unsigned long long)kc_wait(pp + KC_WLO, seq, A.fault_pending) |
+               ((unsigned long long)kc_wait(pp + KC_WHI, seq, A.fault_pending) << 32);
+        }
+        e_nb = N0 + pj + __popcll(wj & ((1ULL << (j & 63)) - 1ULL));
+      } else e_nb = raw;
+      e_ex = A.parent[e_i];
+      const int a = e_nb < e_ex ? e_nb : e_ex, bb = e_nb < e_ex ? e_ex : e_nb;
+      const unsigned long long key = ((unsigned long long)(uint32_t)a << 32) | ((unsigned long long)(uint32_t)bb + 1ULL);
+      e_h = border_slot(f, key);
+      atomicMin(&f.bt_val[e_h], stamp_hi | (unsigned long long)(uint32_t)e_i);
+    }
+    if (threadIdx.x < 64) {
+      __threadfence();                         // the stamps are in the table before the word says so
+      if (threadIdx.x == 0) kc_publish(pub + KC_POSTED, seq, 1u);
+    }
+    KC_TRACE(3);
+    if ((int)threadIdx.x < b) (void)kc_wait(f.wg_pub + (size_t)threadIdx.x * SFFK_PUB_WORDS + KC_POSTED, seq, A.fault_pending);
+    __syncthreads();
+    KC_TRACE(5);
+    bool own = false;
+    if (is_ev) {
+      // (atomic read: the stamps were written by L2 atomics a moment ago)
+      const unsigned long long owner = __hip_atomic_load(&f.bt_val[e_h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      own = owner == (stamp_hi | (unsigned long long)(uint32_t)e_i);
+    }
+    unsigned long long wo = 0ULL;
+    if (threadIdx.x < 64) {
+      wo = __ballot(own);
+      if (threadIdx.x == 0) { s_ev_total = __popcll(wo); kc_publish(pub + KC_OWN, seq, (unsigned)__popcll(wo)); }
+    }
+    __syncthreads();
+    n_own = s_ev_total;
+    if (n_own > 0 || last) {
+      unsigned long long pe = 0;
+      if ((int)threadIdx.x < b) pe = kc_wait(f.wg_pub + (size_t)threadIdx.x * SFFK_PUB_WORDS + KC_OWN, seq, A.fault_pending);
+      ev_pref = (int)kc_block_sum(pe, &s_sum);
+    }
+    KC_TRACE(6);
+    if (own) {
+      const int at = nb0 + ev_pref + __popcll(wo & ((1ULL << threadIdx.x) - 1ULL));
+      // d = costs to the roots + the edge (:291).  A neighbour accepted in this very round is not in the store yet
+      // (k_append runs next): its tree is its parent's, its position the sample's, its cost the one k_append will write.
+      double pn[6], pe6[6], dn;
+      int ta;
+      const int raw = A.rec_nb[(size_t)e_i * A.nbcap + s_dk[threadIdx.x]];
+      if (raw >= Tb) {
+        const int j = raw - Tb;
+        for (int q = 0; q < 6; ++q) pn[q] = A.newpos[6 * (size_t)j + q];
+        dn = A.pdist[j] + f.d_root[A.parent[j]];
+        ta = A.st.tree[A.parent[j]];
+      } else {
+        for (int q = 0; q < 6; ++q) pn[q] = A.st.pos[6 * (size_t)e_nb + q];
+        dn = f.d_root[e_nb];
+        ta = A.st.tree[e_nb];
+      }
+      const int tb = A.st.tree[e_ex];
+      f.b_n1[at] = e_nb < e_ex ? e_nb : e_ex; f.b_n2[at] = e_nb < e_ex ? e_ex : e_nb;
+      f.b_ta[at] = ta < tb ? ta : tb; f.b_tb[at] = ta < tb ? tb : ta;
+      for (int q = 0; q < 6; ++q) pe6[q] = A.st.pos[6 * (size_t)e_ex + q];
+      if (A.star) {
+        // SFF*: the two costs are the ones the sample's turn finds (earlier samples of the round may have rewired either
+        // node): k_star_pass adds them to the distance
+        const int e = at - nb0;
+        A.S.ev_sample[e] = e_i; A.S.ev_nb[e] = e_nb; A.S.ev_ex[e] = e_ex; A.S.ev_dist[e] = dist6(pn, pe6);
+        f.b_dist[at] = 0.0;
+      } else
+      f.b_dist[at] = dn + f.d_root[e_ex] + dist6(pn, pe6);
+      f.pair[(size_t)ta * f.n_trees + tb] = 1;
+      f.pair[(size_t)tb * f.n_trees + ta] = 1;
+    }
+  } else if (threadIdx.x == 0) {
+    kc_publish(pub + KC_POSTED, seq, 1u);
+    kc_publish(pub + KC_OWN, seq, 0u);
+  }
+  KC_TRACE(7);
+  if (!last) return;
+  // ---- 5. the last workgroup of the round: totals, the control block (the next round's active list = the slots of this
+  // round that were not accepted, then the slots the iteration cap kept out of it: k_append writes it)
+  if (clk) tk[3] = wall_clock64();
+  unsigned long long tot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if ((int)threadIdx.x < b) {   // (every lower workgroup has published its counters long ago: one batch of loads)
+    const unsigned long long* pp = f.wg_pub + (size_t)threadIdx.x * SFFK_PUB_WORDS;
+    unsigned long long w[7];
+    for (int q = 0; q < 7; ++q) w[q] = kc_load(pp + KC_CNT + q);
+    for (int q = 0; q < 7; ++q) tot[q] = (unsigned)(w[q] >> 32) == seq ? (unsigned)w[q] : kc_wait(pp + KC_CNT + q, seq, A.fault_pending);
+  }
+  // (a fault is raised before its workgroup publishes anything: with every lower workgroup's words in, the flag is final)
+  if (threadIdx.x == 1023) s_ev_total = __hip_atomic_load(A.fault_pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  kc_block_sum8(tot, s_tot, 0);
+  for (int q = 0; q < 7; ++q) tot[q] += s_c6[q];
+  const int n_acc = acc_pref + __popcll(wa), n_ev = ev_pref + n_own, n_dep = (int)tot[6];
+  const bool faulted = s_ev_total != 0;
+  auto roll_back = [&](DevCtrl* k) {
+    // a bounded device list overflowed somewhere in this round: nothing is committed, the bookkeeping of the round's
+    // begin is rolled back and the host redoes the round on its unbounded path
+    k->fault = SFFK_FAULT_LISTS;
+    k->halt = 1;
+    k->round -= 1;
+    k->iter = k->iter0;
+    k->cursor = k->words_base;
+    k->rounds -= 1;
+    k->round_nodes -= (unsigned long long)(k->N0 + n);
+    k->round_queries -= (unsigned long long)n;
+    k->n_act = 0;
+    k->app_n = 0;
+  };
+  if (A.star && !faulted) {
+    // SFF*: the star stage may still fault after this kernel has committed the round's bookkeeping (a member edge's
+    // candidate list, the fixed point's launch budget): the control block as a rolled-back round leaves it, for k_star_apply
+    for (int w = threadIdx.x; w < (int)(sizeof(DevCtrl) / 4); w += 1024)
+      reinterpret_cast<int32_t*>(A.S.backup)[w] = reinterpret_cast<const int32_t*>(&K)[w];
+    __syncthreads();
+    if (threadIdx.x == 0) roll_back(A.S.backup);
+  }
+  if (threadIdx.x == 0) {
+    if (faulted) {
+      roll_back(&K);
+      *A.fault_pending = 0;
+      if (A.star) { A.S.hdr[0] = 0; A.S.hdr[1] = 1; A.S.hdr[2] = 0; A.S.hdr[4] = 0; }
+    } else {
+      const int fn0 = K.frontier_n, act_cnt = K.act_cnt, act_sel = K.act_sel;
+      K.collide_calls += tot[0];
+      K.path_free_calls += tot[1];
+      K.nn_queries += tot[2];
+      K.poses_executed += tot[3];
+      K.segments_executed += tot[4];
+      K.samples_executed += tot[5];
+      K.work_items += (unsigned long long)work_items;
+      if (K.q_t1 > K.q_t0) { K.q_ticks += K.q_t1 - K.q_t0; K.q_launches += 1ULL; }
+      K.app_n = n;                  // k_append applies this commit
+      K.app_N0 = N0;
+      K.app_fn0 = fn0;
+      K.app_act_sel = act_sel;
+      K.app_act_cnt = act_cnt;
+      K.iter0_app = K.iter0;
+      K.n_nodes = N0 + n_acc;
+      K.frontier_n = fn0 + n_acc;
+      K.n_borders = nb0 + n_ev;
+      K.n_unsettled += n_dep;
+      K.epoch += 1ULL;
+      if (A.star) {
+        K.nn_queries += (unsigned long long)n_acc;       // one knnSearch per accepted sample (src/forest.h:317)
+        A.S.hdr[0] = n_acc; A.S.hdr[1] = 0; A.S.hdr[2] = n_ev; A.S.hdr[3] = nb0; A.S.hdr[4] = 0;
+      }
+      K.act_sel = act_sel ^ 1;
+      K.act_cnt = (n - n_acc) + (act_cnt - n);
+      round_begin_scalars(f, &K);
+      if (clk) {
+        tk[4] = wall_clock64();
+        for (int q = 0; q < 4; ++q) K.prof[q] += tk[q + 1] - tk[q];
+      }
+      K.prof[5] += (unsigned long long)passes;
+      K.prof[6] += 1ULL;
+      if ((unsigned long long)passes > K.prof[7]) K.prof[7] = (unsigned long long)passes;
+    }
+    f.commit_seq[0] = (int32_t)seq;
+  }
+  __syncthreads();
+  for (int w = threadIdx.x; w < (int)(sizeof(DevCtrl) / 4); w += 1024)
+    reinterpret_cast<int32_t*>(c)[w] = reinterpret_cast<const int32_t*>(&K)[w];
+}
+
 // k_append (wide): the accepted samples become nodes - store columns, node records, neighbour grid, frontier
 // (src/forest.h:353-367).  Runs although the NEXT round may already be halted: this commit is final.
 __global__ __launch_bounds__(256) void k_append(ResolveArgs A) {
@@ -889,7 +1342,8 @@ __global__ __launch_bounds__(DF_THREADS) void k_wave_end(DevForestView f, const 
   const int32_t* act = act_now(f);
   int removed = 0;
   unsigned long long tw[7];
-  for (int q = 0; q < 7; ++q) tw[q] = wall_clock64();
+  const bool clk = f.profile != 0;
+  for (int q = 0; q < 7; ++q) tw[q] = clk ? wall_clock64() : 0ULL;
   // ---- exhausted slots: the node leaves the frontier for the closed list (src/forest.h:160-178); a node held by
   // several slots moves once, at its first slot.  Its position in the frontier (the pick index) is marked in rm_words.
   if (!from_closed) {
@@ -910,7 +1364,7 @@ __global__ __launch_bounds__(DF_THREADS) void k_wave_end(DevForestView f, const 
     }
     __threadfence_block();   // (one workgroup: its L1 and the barrier order everything; an agent-scope fence would write the L2 back)
     __syncthreads();
-    tw[1] = wall_clock64();
+    if (clk) tw[1] = wall_clock64();
     {   // flags: the slot that owns its node's claim (four groups of 64 per wave in flight)
       const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
       const int ngf = (n_fail + 63) >> 6;
@@ -931,7 +1385,7 @@ __global__ __launch_bounds__(DF_THREADS) void k_wave_end(DevForestView f, const 
       }
     }
     removed = wg_prefix(L, n_fail);
-    tw[2] = wall_clock64();
+    if (clk) tw[2] = wall_clock64();
     const int cn0 = c->closed_n;
     for (int e0 = 0; e0 < n_fail; e0 += 8 * DF_THREADS) {
       int nd[8], ps[8], fl[8];
@@ -954,14 +1408,14 @@ __global__ __launch_bounds__(DF_THREADS) void k_wave_end(DevForestView f, const 
       }
     }
     __syncthreads();
-    tw[3] = wall_clock64();
+    if (clk) tw[3] = wall_clock64();
     for (int e = threadIdx.x; e < n_fail; e += DF_THREADS)     // (claims cleared only now: every slot of a node saw them)
       f.claim[nodes[e]] = 0x7fffffff;
     // exclusive prefix of the removed positions per 64-entry word (k_frontier_compact shifts by it): every thread
     // sums a contiguous run of words, the runs are scanned through LDS
     __threadfence_block();
     __syncthreads();
-    tw[4] = wall_clock64();
+    if (clk) tw[4] = wall_clock64();
     if (removed > 0) {
       const int per = (nw + DF_THREADS - 1) / DF_THREADS;
       const int w0 = threadIdx.x * per;
@@ -1004,7 +1458,7 @@ __global__ __launch_bounds__(DF_THREADS) void k_wave_end(DevForestView f, const 
     __syncthreads();
   }
   // ---- termination (src/forest.h:184-201)
-  tw[5] = wall_clock64();
+  if (clk) tw[5] = wall_clock64();
   if (threadIdx.x == 0) {
     c->closed_n += removed;
     c->compact_from = removed > 0 ? fn : 0;     // k_frontier_compact: entries of the old buffer to sift
@@ -1041,8 +1495,8 @@ __global__ __launch_bounds__(DF_THREADS) void k_wave_end(DevForestView f, const 
       c->collide_calls += star_s[0]; c->path_free_calls += star_s[1];
       c->star_rounds += star_s[2]; c->star_passes += star_s[3]; c->star_members += star_s[4]; c->star_rewires += star_s[5];
     }
-    tw[6] = wall_clock64();
-    if (!from_closed) for (int q = 0; q < 6; ++q) c->wprof[q] += tw[q + 1] - tw[q];
+    if (clk) tw[6] = wall_clock64();
+    if (clk && !from_closed) for (int q = 0; q < 6; ++q) c->wprof[q] += tw[q + 1] - tw[q];
     c->wprof[7] += 1ULL;
   }
 }
@@ -1123,8 +1577,14 @@ void launch_wave_begin(hipStream_t s, const DevForestView& f) {
 }
 void launch_commit(hipStream_t s, const ResolveArgs& a, int n_bound, const StarLaunch* star) {
   if (n_bound <= 0) return;
-  hipLaunchKernelGGL(k_decide, dim3((n_bound + 63) / 64), dim3(1024), 0, s, a, n_bound);
-  hipLaunchKernelGGL(k_resolve, dim3(1), dim3(DF_THREADS), 0, s, a);
+  // (SFFGPU_OLD_COMMIT=1: the commit as k_decide + the single-workgroup k_resolve, for comparison)
+  static const bool two_kernels = getenv("SFFGPU_OLD_COMMIT") && atoi(getenv("SFFGPU_OLD_COMMIT")) != 0;
+  if (two_kernels) {
+    hipLaunchKernelGGL(k_decide, dim3((n_bound + 63) / 64), dim3(1024), 0, s, a, n_bound);
+    hipLaunchKernelGGL(k_resolve, dim3(1), dim3(DF_THREADS), 0, s, a);
+  } else {
+    hipLaunchKernelGGL(k_commit, dim3((n_bound + 63) / 64), dim3(1024), 0, s, a, n_bound);
+  }
   if (a.star && star) launch_star_stage(s, a, n_bound, *star);
   hipLaunchKernelGGL(k_append, dim3((n_bound + 255) / 256), dim3(256), 0, s, a);
 }

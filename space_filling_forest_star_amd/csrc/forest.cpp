@@ -308,7 +308,7 @@ Forest::~Forest() {
                     &dev.slot_pos, &dev.act_slot2, &dev.dk, &dev.trig, &dev.s_ktab, &dev.s_tree_cnt, &dev.s_head, &dev.s_mcnt, &dev.s_mid, &dev.s_md,
                     &dev.s_next, &dev.s_prop, &dev.s_best, &dev.s_psel, &dev.s_dcl, &dev.s_cnt, &dev.s_accs, &dev.s_hdr, &dev.s_changed,
                     &dev.s_ew, &dev.s_ida, &dev.s_idb, &dev.s_sub, &dev.s_segns, &dev.s_fh, &dev.s_sovf, &dev.s_evs, &dev.s_evn, &dev.s_eve,
-                    &dev.s_evd, &dev.s_acc, &dev.s_backup, &dev.s_items, &dev.s_dbg, &dev.s_hist, &dev.w_dep, &dev.w_acc, &dev.w_ev, &dev.acc_pref, &dev.w_cnt, &dev.dep_rec, &x_send, &x_recv};
+                    &dev.s_evd, &dev.s_acc, &dev.s_backup, &dev.s_items, &dev.s_dbg, &dev.s_hist, &dev.w_dep, &dev.w_acc, &dev.w_ev, &dev.acc_pref, &dev.w_cnt, &dev.dep_rec, &dev.ustate32, &dev.wg_pub, &dev.commit_seq, &dev.kc_trace, &x_send, &x_recv};
   if (dev.inited) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);

@@ -180,6 +180,13 @@ sffk::DevForestView Forest::dev_view() const {
   v.acc_pref = d.acc_pref.as<int32_t>();
   v.w_cnt = d.w_cnt.as<unsigned long long>();
   v.dep_rec = d.dep_rec.as<int32_t>();
+  v.ustate32 = d.ustate32.as<int32_t>();
+  v.wg_pub = d.wg_pub.as<unsigned long long>();
+  v.commit_seq = d.commit_seq.as<int32_t>();
+  static const int profile = getenv("SFFGPU_PROFILE") ? 1 : 0;
+  v.profile = profile;
+  v.kc_trace = d.kc_trace.as<unsigned long long>();
+  v.kc_trace_round = getenv("SFFGPU_KC_TRACE") ? atoi(getenv("SFFGPU_KC_TRACE")) : -1;
   v.b_n1 = d.b_n1.as<int32_t>();
   v.b_n2 = d.b_n2.as<int32_t>();
   v.b_ta = d.b_ta.as<int32_t>();
@@ -358,6 +365,17 @@ void Forest::dev_upload_state() {
     d.w_cnt.ensure(((size_t)wave / 64 + 2) * 6 * 8);
     d.dep_rec.ensure(((size_t)wave + 64) * SFFK_DEP_REC * 4);
     d.ustate.ensure((size_t)wave);
+    // k_commit's sequence-stamped words start at zero once and are never cleared again
+    d.ustate32.ensure(((size_t)wave + 64) * 4);
+    d.wg_pub.ensure(((size_t)wave / 64 + 2) * SFFK_PUB_WORDS * 8);
+    d.commit_seq.ensure(16);
+    if (getenv("SFFGPU_KC_TRACE")) {
+      d.kc_trace.ensure(((size_t)wave / 64 + 2) * 64);
+      HIPCHK(hipMemsetAsync(d.kc_trace.p, 0, ((size_t)wave / 64 + 2) * 64, c.stream));
+    }
+    HIPCHK(hipMemsetAsync(d.ustate32.p, 0, ((size_t)wave + 64) * 4, c.stream));
+    HIPCHK(hipMemsetAsync(d.wg_pub.p, 0, ((size_t)wave / 64 + 2) * SFFK_PUB_WORDS * 8, c.stream));
+    HIPCHK(hipMemsetAsync(d.commit_seq.p, 0, 16, c.stream));
     d.ulist.ensure((size_t)wave * 4);
     d.uacc.ensure((size_t)wave * 4);
     d.d_parent.ensure((size_t)wave * 4);
@@ -1215,9 +1233,28 @@ void Forest::run_device(int max_waves) {
               g[10] / w / 100.0, g[11] / w / 100.0, g[12] / w / 100.0);
     }
     const double r = (double)std::max<unsigned long long>(1ULL, k.prof[6]);
-    fprintf(stderr, "[sffgpu k_resolve us/commit] states %.1f fixed point %.1f (%.2f passes, max %llu) ranks %.1f borders %.1f "
-            "next list+counters %.1f | dependent/round %.0f\n", k.prof[0] / r / 100.0, k.prof[1] / r / 100.0, k.prof[5] / r,
-            (unsigned long long)k.prof[7], k.prof[2] / r / 100.0, k.prof[3] / r / 100.0, k.prof[4] / r / 100.0,
+    if (d.kc_trace.p) {
+      const size_t nw = (size_t)cfg.wave / 64 + 2;
+      std::vector<unsigned long long> tr(nw * 8);
+      HIPCHK(hipMemcpy(tr.data(), d.kc_trace.p, nw * 64, hipMemcpyDeviceToHost));
+      unsigned long long t0 = ~0ULL;
+      size_t used = 0;
+      for (size_t w = 0; w < nw; ++w) if (tr[8 * w]) { t0 = std::min(t0, tr[8 * w]); used = w + 1; }
+      static const char* names[8] = {"start", "walk done", "count published", "stamps posted", "lower counts in (ids)", "lower stamps in", "lower owned counts in", "end"};
+      for (int k = 0; k < 8 && used; ++k) {
+        std::vector<double> v;
+        for (size_t w = 0; w < used; ++w) if (tr[8 * w + k]) v.push_back((double)(tr[8 * w + k] - t0) / 100.0);
+        if (v.empty()) continue;
+        std::vector<double> sv = v;
+        std::sort(sv.begin(), sv.end());
+        fprintf(stderr, "[sffgpu k_commit trace, %zu workgroups] %-24s us after the first start: min %.1f median %.1f max %.1f | first wg %.1f last wg %.1f\n",
+                used, names[k], sv.front(), sv[sv.size() / 2], sv.back(), v.front(), v.back());
+      }
+    }
+    // (the LAST workgroup's clock: what the others do is over by then)
+    fprintf(stderr, "[sffgpu k_commit us/commit, last workgroup] walks + waits for earlier samples %.1f (%.2f polls, max %llu) "
+            "lower workgroups' counts %.1f borders %.1f control block %.1f | dependent/round %.0f\n", k.prof[0] / r / 100.0, k.prof[5] / r,
+            (unsigned long long)k.prof[7], k.prof[1] / r / 100.0, k.prof[2] / r / 100.0, k.prof[3] / r / 100.0,
             (double)k.n_unsettled / r);
 #ifdef SFFK_DEBUG_COUNTERS
     unsigned long long g[16];

@@ -126,8 +126,9 @@ struct DevCtrl {
   unsigned long long waves, rounds, round_nodes, round_queries;
   unsigned long long epoch;         // commit counter (border dedup stamps)
   unsigned long long work_items;    // (edge, chunk) items of all rounds
-  // k_resolve phase clocks (wall_clock64 ticks of 10 ns, thread 0): open list, fixed point, append, borders,
-  // counters + next active list; [5] = passes of the fixed point, [6] = commits, [7] = longest pass count
+  // k_commit phase clocks (wall_clock64 ticks of 10 ns, thread 0 of the round's LAST workgroup, SFFGPU_PROFILE only):
+  // walks + waits for earlier samples, lower workgroups' counts (ids), borders, totals + control block;
+  // [5] = polls of the walk phase, [6] = commits, [7] = most polls
   unsigned long long prof[8];
   // device-clock bracket of the neighbour-query kernel of the current round (first wave in .. last wave out, 100 MHz
   // wall_clock64 ticks) and its sum over all committed rounds: the duration rocprofv3 reports, without the ~3 us a
@@ -362,7 +363,16 @@ struct DevForestView {
   unsigned long long* w_dep; unsigned long long* w_acc; unsigned long long* w_ev; int32_t* acc_pref;
   int32_t* dep_rec;            // SFFK_DEP_REC ints per sample: what is left of a dependent sample's neighbour walk (k_decide -> k_resolve)
   unsigned long long* w_cnt;   // 6 counters per word (k_decide's sums over its 64 samples; k_resolve adds them up)
+  // k_commit (the wide commit kernel): what its workgroups tell each other.  Every word carries the launch's sequence
+  // number (commit_seq[0] + 1) in its upper half, so nothing is ever cleared and a stale word is never taken for news.
+  int32_t* ustate32;           // per sample: (seq << 2 | state), state 1 rejected / 2 accepted / 3 rejected + border event
+  unsigned long long* wg_pub;  // SFFK_PUB_WORDS words per workgroup of 64 samples (one 128-byte line), see k_commit
+  int32_t* commit_seq;         // [0] = launches that reached their end so far
+  unsigned long long* kc_trace; int32_t kc_trace_round;   // SFFGPU_KC_TRACE=<round>: 8 clock reads per workgroup of that round's k_commit
+  int32_t profile;             // SFFGPU_PROFILE: the single-workgroup kernels read their phase clocks (a clock read is a scalar
+                               // memory round trip: a dozen of them is microseconds)
 };
+#define SFFK_PUB_WORDS 16
 // ---- SFF* (optimize = true) on the device engine: choose-parent + rewire of src/forest.h:307-351 (devstar.hip).
 // The accept / reject logic does not depend on costs, so k_decide / k_resolve settle WHICH samples of the round become
 // nodes (and their ids) exactly as for plain SFF; then, for the accepted samples only:

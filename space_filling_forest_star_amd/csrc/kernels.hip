@@ -2466,8 +2466,9 @@ __global__ __launch_bounds__(64) void k_seq_waves(SeqArgs A) {
   // phase clocks (10 ns ticks): pick + node, sample, pose, parent edge, neighbour query, neighbour loop, append, wave end
   uint64_t pre_w[6] = {0, 0, 0, 0, 0, 0};
   unsigned long long pre_at = ~0ULL;
-  unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tq = wall_clock64();
-  auto lap = [&](int k) { const unsigned long long t = wall_clock64(); ph[k] += t - tq; tq = t; };
+  const bool clk = A.f.profile != 0;   // (a clock read is a scalar memory round trip)
+  unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tq = clk ? wall_clock64() : 0ULL;
+  auto lap = [&](int k) { if (!clk) return; const unsigned long long t = wall_clock64(); ph[k] += t - tq; tq = t; };
   for (int wv = 0; wv < A.max_waves && !terminated && !fault; ++wv) {
     // ---- what the round engine checks before a round (round_begin_scalars), and what this launch has to leave to the host
     if (n_nodes + 1 > f.node_cap - 8 || nb + TM > f.border_cap) { fault = SFFK_FAULT_CAPACITY; break; }
