@@ -1273,27 +1273,31 @@ __global__ __launch_bounds__(1024) void k_commit(ResolveArgs A, int n_bound) {
 
 // k_append (wide): the accepted samples become nodes - store columns, node records, neighbour grid, frontier
 // (src/forest.h:353-367).  Runs although the NEXT round may already be halted: this commit is final.
-__global__ __launch_bounds__(256) void k_append(ResolveArgs A) {
+// One slot's share of the append.  Returns the slot's index in the NEXT round's active list (-1: none - accepted, or
+// nothing was committed) and the slot itself.
+__device__ __forceinline__ int append_one(const ResolveArgs& A, int i, int& slot_out) {
   const DevForestView& f = A.f;
   const DevCtrl* c = f.ctrl;
   const int n = c->app_n;
-  if (n <= 0) return;
-  const int i = blockIdx.x * 256 + threadIdx.x;
+  slot_out = -1;
+  if (n <= 0) return -1;
   const int act_cnt = c->app_act_cnt;
   const int32_t* act_old = c->app_act_sel ? f.act_slot2 : f.act_slot;
   int32_t* act_new = c->app_act_sel ? f.act_slot : f.act_slot2;
   if (i >= n) {
     // the slots the iteration cap kept out of the committed round stay on the list, behind the still-failing ones
+    // (the cap has been reached: they never draw again)
     if (i < act_cnt) act_new[(c->act_cnt - (act_cnt - n)) + (i - n)] = act_old[i];
-    return;
+    return -1;
   }
   const unsigned long long w = f.w_acc[i >> 6];
   const int rank = f.acc_pref[i >> 6] + __popcll(w & ((1ULL << (i & 63)) - 1ULL));
   if (!((w >> (i & 63)) & 1ULL)) {
-    act_new[i - rank] = act_old[i];     // not accepted: the slot tries again (rank = accepted samples before it)
-    return;
+    slot_out = act_old[i];
+    act_new[i - rank] = slot_out;       // not accepted: the slot tries again (rank = accepted samples before it)
+    return i - rank;
   }
-  if (A.star) return;                   // SFF*: k_star_apply has made the accepted samples nodes
+  if (A.star) return -1;                // SFF*: k_star_apply has made the accepted samples nodes
   const int N0 = c->app_N0, fn0 = c->app_fn0;
   int32_t* const frontier = frontier_now(f);
   const int id = N0 + rank;
@@ -1317,6 +1321,23 @@ __global__ __launch_bounds__(256) void k_append(ResolveArgs A) {
   f.nflag[o] = 2;
   frontier[fn0 + rank] = id;                         // :365
   grid_put(A.g, it);                                 // flannIndex->addPoints, :367
+  return -1;
+}
+__global__ __launch_bounds__(256) void k_append(ResolveArgs A) {
+  int slot;
+  (void)append_one(A, blockIdx.x * 256 + threadIdx.x, slot);
+}
+// k_append + the NEXT round's k_sample_steer in one launch: a slot that was not accepted draws its next sample right
+// away (its place in the next round's list is its old place minus the accepted samples before it; the round's size,
+// word base and epoch are in the control block since k_commit).  The sample reads what the append of this very launch
+// writes nowhere: its centre is a node of an earlier wave, its temporaries lie behind the node arrays.  The append's
+// inputs (newpos, pdist, parent of the committed round) are the sampling's outputs: the rounds of a wave alternate
+// between two sets of these arrays (A = the committed round's, P = the next round's).
+__global__ __launch_bounds__(256) void k_append_sample(ResolveArgs A, SampleLaunch P) {
+  const int tid = blockIdx.x * 256 + threadIdx.x;
+  int slot;
+  const int next = append_one(A, tid, slot);
+  sample_steer_one(tid, next, slot, P);
 }
 
 // ------------------------------------------------------------------ wave end
@@ -1575,7 +1596,7 @@ __global__ __launch_bounds__(256) void k_border_rehash(DevForestView f, int n) {
 void launch_wave_begin(hipStream_t s, const DevForestView& f) {
   hipLaunchKernelGGL(k_wave_begin, dim3(1), dim3(DF_THREADS), 0, s, f);
 }
-void launch_commit(hipStream_t s, const ResolveArgs& a, int n_bound, const StarLaunch* star) {
+void launch_commit(hipStream_t s, const ResolveArgs& a, int n_bound, const StarLaunch* star, const SampleLaunch* next) {
   if (n_bound <= 0) return;
   // (SFFGPU_OLD_COMMIT=1: the commit as k_decide + the single-workgroup k_resolve, for comparison)
   static const bool two_kernels = getenv("SFFGPU_OLD_COMMIT") && atoi(getenv("SFFGPU_OLD_COMMIT")) != 0;
@@ -1586,7 +1607,8 @@ void launch_commit(hipStream_t s, const ResolveArgs& a, int n_bound, const StarL
     hipLaunchKernelGGL(k_commit, dim3((n_bound + 63) / 64), dim3(1024), 0, s, a, n_bound);
   }
   if (a.star && star) launch_star_stage(s, a, n_bound, *star);
-  hipLaunchKernelGGL(k_append, dim3((n_bound + 255) / 256), dim3(256), 0, s, a);
+  if (next) hipLaunchKernelGGL(k_append_sample, dim3((n_bound + 255) / 256), dim3(256), 0, s, a, *next);
+  else hipLaunchKernelGGL(k_append, dim3((n_bound + 255) / 256), dim3(256), 0, s, a);
 }
 void launch_wave_end(hipStream_t s, const DevForestView& f, const int32_t* grid_ovf, const int32_t* tgrid_ovf,
                      unsigned long long* star_acc) {

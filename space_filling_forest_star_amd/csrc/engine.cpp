@@ -228,7 +228,7 @@ Ctx::~Ctx() {
   for (auto& t : pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto e : pool) (void)hipEventDestroy(e);
   DevBuf* bufs[] = {&env_tri, &env_box, &env_plane, &rob_tri, &sx, &sy, &sz, &syaw, &spitch, &sroll, &stree, &spos,
-                    &d_a, &d_b, &d_c, &d_d, &d_e, &d_f, &d_g, &d_h, &r_in, &r_out, &r_q, &r_cnt, &r_hidx,
+                    &d_a, &d_b, &d_c, &d_d, &d_e, &d_f, &d_g, &d_h, &r_in, &r_out, &r_out2, &r_q, &r_cnt, &r_hidx,
                     &r_hdist, &r_sega, &r_segb, &r_items, &r_items2, &r_center, &env_clear, &g_cnt, &g_items, &g_ovfcnt, &g_ovf, &t_cnt, &t_items, &t_ovfcnt, &t_ovf, &t_occ, &env_tg_start, &env_tg_list, &r_sub, &env_ext};
   for (DevBuf* b : bufs) b->release();
   for (auto& b : level_box) b.release();

@@ -128,6 +128,7 @@ struct Ctx {
   PinBuf h_a, h_b, h_c, h_d, h_e, h_f, h_g, h_h;
   // round pipeline buffers of the forest engine (kept apart from the batch entry points' scratch)
   DevBuf r_in, r_out, r_q, r_cnt, r_hidx, r_hdist, r_sega, r_segb, r_items, r_items2, r_sub, r_center;
+  DevBuf r_out2;   // device engine: positions + parent distances of the odd rounds of a wave (see Forest::dev_enqueue_wave_kernels)
   PinBuf p_in, p_out;
 
   // kernel timing (HIP events on the launch stream)
@@ -244,7 +245,7 @@ struct DevEngine {
   bool table_dirty = false, ring_pending = false;
   DevBuf frontier2, rm_words, rm_pref, slot_pos, act_slot2, dk, w_dep, w_acc, w_ev, acc_pref, w_cnt, dep_rec, ustate32, wg_pub, commit_seq, kc_trace;
   DevBuf ctrl, parent, d_root, d_closest, iter, nflag, frontier, closed, claim, slot_node, slot_fail, act_slot, b_n1,
-      b_n2, b_ta, b_tb, b_dist, bt_key, bt_val, pair, ring, ustate, ulist, uacc, d_parent, d_force, fault_pending;
+      b_n2, b_ta, b_tb, b_dist, bt_key, bt_val, pair, ring, ustate, ulist, uacc, d_parent, d_parent2, d_force, fault_pending;
   // SFF* on the device (devstar.hip; StarView in kernels.h)
   DevBuf s_ktab, s_tree_cnt, s_head, s_mcnt, s_mid, s_md, s_next, s_prop, s_best, s_psel, s_dcl, s_cnt, s_accs, s_hdr, s_changed,
       s_ew, s_ida, s_idb, s_sub, s_segns, s_fh, s_sovf, s_evs, s_evn, s_eve, s_evd, s_acc, s_backup, s_items, s_dbg, s_hist;
@@ -257,6 +258,7 @@ struct DevEngine {
   hipGraphExec_t wave_graph = nullptr;
   uint64_t wave_graph_sig = 0;
   bool graph_enabled = true;
+  int round_parity = 0;              // which set of sample arrays the round being enqueued uses (fused append + sampling)
   int force_timing = -1;             // >= 0: dev_enqueue_round_eval takes this instead of the per-round stride
   bool round_timing = false;         // the timing decision of the round being enqueued (evaluation -> commit)
   uint64_t graph_calls[T_KINDS] = {0, 0, 0, 0, 0};   // timed-kernel launches one replay stands for
@@ -287,8 +289,8 @@ struct Forest {
   void dev_upload_state();
   void dev_to_host();
   void dev_enqueue_begin();
-  void dev_enqueue_round_eval(void* send_dev);
-  void dev_enqueue_round_commit(const void* recv_dev);
+  void dev_enqueue_round_eval(void* send_dev, bool sample = true);
+  void dev_enqueue_round_commit(const void* recv_dev, bool sample_next = false);
   void dev_enqueue_end(int slot = 0);
   int dev_finish_wave(double* wait_ms, int slot = 0, bool stream_idle = true);
   void dev_enqueue_wave(int slot);

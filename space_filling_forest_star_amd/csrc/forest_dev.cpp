@@ -379,6 +379,7 @@ void Forest::dev_upload_state() {
     d.ulist.ensure((size_t)wave * 4);
     d.uacc.ensure((size_t)wave * 4);
     d.d_parent.ensure((size_t)wave * 4);
+    d.d_parent2.ensure((size_t)wave * 4);
     d.d_force.ensure((size_t)wave);
     d.fault_pending.ensure(16);
     HIPCHK(hipMemsetAsync(d.fault_pending.p, 0, 16, c.stream));
@@ -661,6 +662,11 @@ static DevRoundBufs dev_round_bufs(Forest& F) {
   char* dout = c.r_out.as<char>();
   B.d_pos = reinterpret_cast<double*>(dout + o_pos);
   B.d_pd = reinterpret_cast<double*>(dout + o_pd);
+  if (F.dev.round_parity) {   // (the odd rounds of a wave: the append of round r reads what the sampling of round r + 1 writes)
+    c.r_out2.ensure((size_t)n * 56);
+    B.d_pos = c.r_out2.as<double>();
+    B.d_pd = B.d_pos + (size_t)n * 6;
+  }
   B.d_rec = reinterpret_cast<int32_t*>(dout + o_rec);
   B.d_rctrl = reinterpret_cast<int32_t*>(dout + o_ctrl);
   B.d_lim = reinterpret_cast<uint8_t*>(dout + o_lim);
@@ -694,7 +700,7 @@ static sffk::ResolveArgs dev_resolve_args(Forest& F, const DevRoundBufs& B) {
   ra.world = F.cfg.world;
   ra.newpos = B.d_pos;
   ra.pdist = B.d_pd;
-  ra.parent = d.d_parent.as<int32_t>();
+  ra.parent = (d.round_parity ? d.d_parent2 : d.d_parent).as<int32_t>();
   ra.code = B.code;
   ra.in_lim = B.d_lim;
   ra.rec_flags = B.d_rec;
@@ -729,7 +735,52 @@ void Forest::dev_enqueue_begin() {
 
 // sample -> neighbour query + classification -> collision, for the samples this rank owns; with send_dev the owned
 // samples' answer records are packed for the all-gather
-void Forest::dev_enqueue_round_eval(void* send_dev) {
+// k_sample_steer's arguments for the round whose buffers are B (DevEngine::round_parity)
+static sffk::SampleLaunch dev_sample_launch(Forest& F, const DevRoundBufs& B) {
+  Ctx& c = *F.ctx;
+  DevEngine& d = F.dev;
+  const sffk::DevForestView V = F.dev_view();
+  sffk::NodeStoreMut stm{c.sx.as<float>(), c.sy.as<float>(), c.sz.as<float>(), c.syaw.as<float>(),
+                         c.spitch.as<float>(), c.sroll.as<float>(), c.stree.as<int32_t>(), c.spos.as<double>()};
+  sffk::SampleLaunch P{};
+  memcpy(P.prm.limits, F.cfg.limits, sizeof P.prm.limits);
+  P.prm.dist_tree = F.cfg.dist_tree;
+  P.prm.sweep_abs_eps = c.sweep_eps();
+  P.prm.rank = F.cfg.rank;
+  P.prm.world = F.cfg.world;
+  P.tmp.st = stm;
+  P.tmp.cnt = c.r_cnt.as<int32_t>();
+  P.tmp.tg = c.tgridv;
+  P.tmp.ctrl = B.d_rctrl;
+  P.tmp.sub = c.r_sub.as<int32_t>();
+  P.tmp.n_perm = d.temp_base;
+  P.tmp.base = d.temp_base;
+  P.tmp.center_out = c.r_center.as<double>();
+  P.dv.ctrl = V.ctrl;
+  P.dv.act_slot = V.act_slot;
+  P.dv.act_slot2 = V.act_slot2;
+  P.dv.slot_node = V.slot_node;
+  P.dv.nflag = V.nflag;
+  P.dv.ring = V.ring;
+  P.dv.ring_mask = V.ring_mask;
+  P.dv.words_per = V.words_per;
+  P.dv.trig = F.cfg.libm_sampling ? d.trig.as<double>() : nullptr;
+  P.dv.parent_out = (d.round_parity ? d.d_parent2 : d.d_parent).as<int32_t>();
+  P.dv.force_out = d.d_force.as<uint8_t>();
+  P.dv.qclk = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(d.ctrl.p) + offsetof(sffk::DevCtrl, q_t0));
+  P.node_pos = c.spos.as<double>();
+  P.n = B.n;
+  P.dist = F.cfg.sampling_dist;
+  P.dim = F.cfg.dim;
+  P.out6 = B.d_pos;
+  P.in_lim = B.d_lim;
+  P.parent_dist = B.d_pd;
+  P.queries = c.r_q.as<sffk::SweepQuery>();
+  P.q_max_base = d.temp_base;
+  return P;
+}
+
+void Forest::dev_enqueue_round_eval(void* send_dev, bool sample) {
   Ctx& c = *ctx;
   DevEngine& d = dev;
   const sffk::DevForestView V = dev_view();
@@ -743,38 +794,14 @@ void Forest::dev_enqueue_round_eval(void* send_dev) {
   d.round_timing = c.timing_on;   // (the commit of this round is timed like its evaluation)
   c.round_scope = true;
   ++d.rounds_enqueued;
-  sffk::SampleParams prm{};
-  memcpy(prm.limits, cfg.limits, sizeof prm.limits);
-  prm.dist_tree = cfg.dist_tree;
-  prm.sweep_abs_eps = c.sweep_eps();
-  prm.rank = cfg.rank;
-  prm.world = cfg.world;
-  sffk::RoundTemps tmp{};
-  tmp.st = stm;
-  tmp.cnt = c.r_cnt.as<int32_t>();
-  tmp.tg = c.tgridv;
-  tmp.ctrl = B.d_rctrl;
-  tmp.sub = c.r_sub.as<int32_t>();
-  tmp.n_perm = d.temp_base;
-  tmp.base = d.temp_base;
-  tmp.center_out = c.r_center.as<double>();
-  sffk::DevRound dv{};
-  dv.ctrl = V.ctrl;
-  dv.act_slot = V.act_slot;
-  dv.act_slot2 = V.act_slot2;
-  dv.slot_node = V.slot_node;
-  dv.nflag = V.nflag;
-  dv.ring = V.ring;
-  dv.ring_mask = V.ring_mask;
-  dv.words_per = V.words_per;
-  dv.trig = cfg.libm_sampling ? d.trig.as<double>() : nullptr;
-  dv.parent_out = d.d_parent.as<int32_t>();
-  dv.force_out = d.d_force.as<uint8_t>();
-  dv.qclk = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(d.ctrl.p) + offsetof(sffk::DevCtrl, q_t0));
-  c.time_begin(T_SAMPLE);
-  sffk::launch_sample_steer(c.stream, nullptr, nullptr, c.spos.as<double>(), nullptr, n, cfg.sampling_dist, cfg.dim, prm,
-                            B.d_pos, B.d_lim, B.d_pd, c.r_q.as<sffk::SweepQuery>(), d.temp_base, tmp, &dv);
-  c.time_end();
+  if (sample) {
+    const sffk::SampleLaunch P = dev_sample_launch(*this, B);
+    c.time_begin(T_SAMPLE);
+    sffk::launch_sample_steer(c.stream, P);
+    c.time_end();
+  }
+  int32_t* const round_parent = (d.round_parity ? d.d_parent2 : d.d_parent).as<int32_t>();
+  unsigned long long* const qclk = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(d.ctrl.p) + offsetof(sffk::DevCtrl, q_t0));
   sffk::ClassifyArgs ca{};
   ca.n = n; ca.N0 = d.temp_base; ca.cap = B.CAP; ca.nbcap = B.NBCAP; ca.rank = cfg.rank; ca.world = cfg.world;
   ca.goal_id = -1;
@@ -782,7 +809,7 @@ void Forest::dev_enqueue_round_eval(void* send_dev) {
   ca.newpos = B.d_pos;
   ca.in_lim = B.d_lim;
   ca.pdist = B.d_pd;
-  ca.parent = d.d_parent.as<int32_t>();
+  ca.parent = round_parent;
   ca.center = c.r_center.as<double>();
   ca.force = d.d_force.as<uint8_t>();
   ca.cnt = c.r_cnt.as<int32_t>();
@@ -801,7 +828,7 @@ void Forest::dev_enqueue_round_eval(void* send_dev) {
   ca.seg_ovf = B.seg_ovf;
   ca.ctrl = B.d_rctrl;
   ca.dev_n = dev_n;
-  ca.qclk = dv.qclk;
+  ca.qclk = qclk;
   c.time_begin(T_SWEEP);
   ca.items = c.r_items.p;
   ca.items_cap = B.list_cap;
@@ -831,13 +858,20 @@ void Forest::dev_enqueue_round_eval(void* send_dev) {
 }
 
 // the in-order commit, replicated on every rank; with recv_dev the other ranks' answer records are unpacked first
-void Forest::dev_enqueue_round_commit(const void* recv_dev) {
+void Forest::dev_enqueue_round_commit(const void* recv_dev, bool sample_next) {
   Ctx& c = *ctx;
   const DevRoundBufs B = dev_round_bufs(*this);
   const sffk::ResolveArgs ra = dev_resolve_args(*this, B);
   if (recv_dev) {
     sffk::launch_unpack_records(c.stream, ra, cfg.rank, cfg.world, B.n, static_cast<const int32_t*>(recv_dev));
     if (exchange_open) { HIPCHK(hipEventRecord(c.pending[exchange_idx].b, c.stream)); exchange_open = false; }
+  }
+  // (the commit's last kernel also draws the next round's samples - into the other set of sample arrays)
+  sffk::SampleLaunch next{};
+  if (sample_next) {
+    dev.round_parity ^= 1;
+    next = dev_sample_launch(*this, dev_round_bufs(*this));
+    dev.round_parity ^= 1;
   }
   c.round_scope = true;
   c.timing_on = dev.round_timing;
@@ -854,9 +888,9 @@ void Forest::dev_enqueue_round_commit(const void* recv_dev) {
     sl.slack = 8 * c.sweep_eps();
     sl.cube_reach = 2.0 * cfg.sampling_dist;
     sl.passes = star_pass_limit;
-    sffk::launch_commit(c.stream, ra, B.n, &sl);
+    sffk::launch_commit(c.stream, ra, B.n, &sl, sample_next ? &next : nullptr);
   } else {
-    sffk::launch_commit(c.stream, ra, B.n);
+    sffk::launch_commit(c.stream, ra, B.n, nullptr, sample_next ? &next : nullptr);
   }
   c.time_end();
   c.timing_on = true;
@@ -880,10 +914,14 @@ uint64_t Forest::dev_launch_signature() {
     const unsigned char* q = static_cast<const unsigned char*>(p);
     for (size_t i = 0; i < n; ++i) { x ^= q[i]; x *= 1099511628211ULL; }
   };
-  const DevRoundBufs B = dev_round_bufs(*this);
-  const sffk::ResolveArgs ra = dev_resolve_args(*this, B);
-  mix(&B, sizeof B);
-  mix(&ra, sizeof ra);
+  for (int parity = 0; parity < 2; ++parity) {
+    dev.round_parity = parity;
+    const DevRoundBufs B = dev_round_bufs(*this);
+    const sffk::ResolveArgs ra = dev_resolve_args(*this, B);
+    mix(&B, sizeof B);
+    mix(&ra, sizeof ra);
+  }
+  dev.round_parity = 0;
   mix(&c.gridv, sizeof c.gridv);
   mix(&c.tgridv, sizeof c.tgridv);
   mix(&c.envv, sizeof c.envv);
@@ -900,11 +938,17 @@ uint64_t Forest::dev_launch_signature() {
 
 void Forest::dev_enqueue_wave_kernels(bool sharded, size_t words) {
   sffk::launch_wave_begin(ctx->stream, dev_view());
-  for (int r = 0; r < std::max(1, cfg.threshold_misses); ++r) {
-    dev_enqueue_round_eval(sharded ? x_send.p : nullptr);
+  // round r's append and round r + 1's sampling are one launch (k_append_sample): the rounds alternate between two sets
+  // of sample arrays, only the first round of the wave samples on its own
+  const int R = std::max(1, cfg.threshold_misses);
+  static const bool fuse = !(getenv("SFFGPU_NO_FUSED_SAMPLE") && atoi(getenv("SFFGPU_NO_FUSED_SAMPLE")) != 0);
+  for (int r = 0; r < R; ++r) {
+    dev.round_parity = fuse ? (r & 1) : 0;
+    dev_enqueue_round_eval(sharded ? x_send.p : nullptr, !fuse || r == 0);
     if (sharded) ctx->rccl_all_gather_i32(x_send.p, x_recv.p, words);
-    dev_enqueue_round_commit(sharded ? x_recv.p : nullptr);
+    dev_enqueue_round_commit(sharded ? x_recv.p : nullptr, fuse && r + 1 < R);
   }
+  dev.round_parity = 0;
   sffk::launch_wave_end(ctx->stream, dev_view(), ctx->gridv.ovf_cnt, ctx->tgridv.ovf_cnt,
                         cfg.optimize ? dev.s_acc.as<unsigned long long>() : nullptr);
 }

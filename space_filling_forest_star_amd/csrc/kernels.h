@@ -187,6 +187,8 @@ void launch_sample_steer(hipStream_t s, const uint64_t* words, const int32_t* pa
                          const double* center_in, int n, double dist, int dim, const SampleParams& prm, double* out6,
                          uint8_t* in_lim, double* parent_dist, SweepQuery* queries, int32_t q_max_base,
                          const RoundTemps& tmp, const DevRound* dev = nullptr);
+struct SampleLaunch;
+void launch_sample_steer(hipStream_t s, const SampleLaunch& P);
 
 // grid != nullptr: the written nodes are also inserted into the neighbour grid in the same launch
 void launch_store_write(hipStream_t s, const NodeStoreMut& st, const double* pos6, const int32_t* tree,
@@ -497,7 +499,16 @@ void launch_star_exact(hipStream_t s, const EnvView& env, const RobotView& rob, 
                        int pass);
 // the commit of one round: k_decide (wide) -> k_resolve (one workgroup) [-> the SFF* stage] -> k_append (wide);
 // n_bound = launch bound
-void launch_commit(hipStream_t s, const ResolveArgs& a, int n_bound, const StarLaunch* star = nullptr);
+// the arguments of k_sample_steer as one block: the commit's last kernel (k_append_sample) also draws the NEXT round's
+// samples - a slot that was not accepted knows its place in the next round's list the moment it writes it
+struct SampleLaunch {
+  const uint64_t* words; const int32_t* parent; const double* node_pos; const double* center_in;
+  int n; double dist; int dim; SampleParams prm;
+  double* out6; uint8_t* in_lim; double* parent_dist; SweepQuery* queries; int32_t q_max_base;
+  RoundTemps tmp; DevRound dv;
+};
+void launch_commit(hipStream_t s, const ResolveArgs& a, int n_bound, const StarLaunch* star = nullptr,
+                   const SampleLaunch* next = nullptr);
 void launch_wave_end(hipStream_t s, const DevForestView& f, const int32_t* grid_ovf, const int32_t* tgrid_ovf,
                      unsigned long long* star_acc = nullptr);
 // border table maintenance: re-insert list entries [0, n) after the host grew the table

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "kernels.h"
+#include "sff_geom.h"
 
 namespace sffk {
 
@@ -92,5 +93,127 @@ __device__ __forceinline__ double topk_worst(const TopK& t, int k, int have) {  
   return have < k ? 1.0e300 : __shfl(t.d, k - 1);
 }
 
+// ---- sample + steer of one slot (k_sample_steer; the device engine's k_append_sample runs it for the NEXT round right
+// behind the append).  tid = the thread's index in the launch (per-round housekeeping), i = the sample it draws (< 0:
+// none), slot >= 0: the sample's slot (k_append_sample knows it; otherwise it is read from the active list).
+__device__ __forceinline__ void sample_steer_one(int tid, int i, int slot, const SampleLaunch& P) {
+  using namespace sffg;
+  const uint64_t* __restrict__ words = P.words;
+  const int32_t* __restrict__ parent = P.parent;
+  const double* __restrict__ node_pos = P.node_pos;
+  const double* __restrict__ center_in = P.center_in;
+  int n = P.n;
+  const double dist = P.dist;
+  const int dim = P.dim;
+  const SampleParams& prm = P.prm;
+  double* __restrict__ out6 = P.out6;
+  uint8_t* __restrict__ in_lim = P.in_lim;
+  double* __restrict__ parent_dist = P.parent_dist;
+  SweepQuery* __restrict__ queries = P.queries;
+  const int32_t q_max_base = P.q_max_base;
+  const RoundTemps& tmp = P.tmp;
+  const DevRound& dv = P.dv;
+  if (dv.ctrl) {   // device-resident forest: the round's size lives in HBM
+    if (dv.ctrl->halt) return;
+    n = dv.ctrl->n_act;
+    if (tid == 0 && dv.qclk) { dv.qclk[0] = ~0ULL; dv.qclk[1] = 0ULL; }
+  }
+  if (tmp.cnt) {
+    // per-round housekeeping folded into this launch: hit counters, the work-list cursor, and NaN
+    // placeholders for the store entries between the permanent nodes and the 4-aligned temporaries
+    if (tid < n) tmp.cnt[tid] = 0;
+    if (tid < 32) tmp.ctrl[tid] = 0;
+    if (tmp.sub && tid < SFFK_SUBLISTS) tmp.sub[tid * SFFK_SUB_STRIDE] = 0;
+    if (tid < tmp.base - tmp.n_perm) {
+      const float nanv = __int_as_float(0x7fc00000);
+      const size_t o = (size_t)tmp.n_perm + tid;
+      tmp.st.x[o] = nanv; tmp.st.y[o] = nanv; tmp.st.z[o] = nanv;
+      tmp.st.yaw[o] = nanv; tmp.st.pitch[o] = nanv; tmp.st.roll[o] = nanv;
+    }
+  }
+  if (i < 0 || i >= n) return;
+  double c[6], o[6];
+  int par = 0;
+  if (dv.ctrl) {
+    par = dv.slot_node[slot >= 0 ? slot : (dv.ctrl->act_sel ? dv.act_slot2 : dv.act_slot)[i]];
+    dv.parent_out[i] = par;
+    dv.force_out[i] = dv.nflag[par] & 1;
+  } else if (!center_in) {
+    par = parent[i];
+  }
+  const double* src = center_in ? center_in + 6 * (size_t)i : node_pos + 6 * (size_t)par;
+  for (int k = 0; k < 6; ++k) c[k] = src[k];
+  if (tmp.center_out) for (int k = 0; k < 6; ++k) tmp.center_out[6 * (size_t)i + k] = c[k];
+  uint64_t w[6];
+  SampleTrig host_trig{};
+  if (dv.ctrl) {   // the sample's words sit in the engine-word ring, in the reference's draw order
+    const unsigned long long base = dv.ctrl->words_base + (unsigned long long)dv.words_per * (unsigned long long)i;
+    for (int k = 0; k < 6; ++k) w[k] = k < dv.words_per ? dv.ring[(base + k) & dv.ring_mask] : 0ULL;
+    if (dv.trig) {   // libm parity mode: the transcendental values of these words, evaluated by the host's C library
+      const double* t0 = dv.trig + 3 * (size_t)(base & dv.ring_mask);
+      host_trig.c_phi = t0[0]; host_trig.s_phi = t0[1];
+      if (dv.words_per == 6) {
+        const double* t1 = dv.trig + 3 * (size_t)((base + 1) & dv.ring_mask);
+        const double* t3 = dv.trig + 3 * (size_t)((base + 3) & dv.ring_mask);
+        host_trig.c_theta = t1[0]; host_trig.s_theta = t1[1];
+        host_trig.acos_u = t3[2];
+      }
+    }
+  } else {
+    for (int k = 0; k < 6; ++k) w[k] = words[6 * (size_t)i + k];
+  }
+  bool ok;
+  if (dv.ctrl && dv.trig) {
+    ok = sample_point_with(w, c, dist, dim, prm.limits, o, host_trig);
+  } else if (tmp.preset) {
+    for (int k = 0; k < 6; ++k) o[k] = tmp.preset[6 * (size_t)i + k];
+    ok = in_limits(o, prm.limits);
+  } else {
+    ok = sample_point(w, c, dist, dim, prm.limits, o);
+  }
+  for (int k = 0; k < 6; ++k) out6[6 * (size_t)i + k] = o[k];
+  in_lim[i] = ok ? 1 : 0;
+  if (tmp.cnt) {
+    // the sample becomes temporary store entry base + i (NaN floats when out of limits, so that no query
+    // can match it), with the tree of the node it was expanded from
+    const float nanv = __int_as_float(0x7fc00000);
+    const size_t t = (size_t)tmp.base + i;
+    tmp.st.x[t] = ok ? (float)o[0] : nanv;
+    tmp.st.y[t] = ok ? (float)o[1] : nanv;
+    tmp.st.z[t] = ok ? (float)o[2] : nanv;
+    tmp.st.yaw[t] = ok ? (float)o[3] : nanv;
+    tmp.st.pitch[t] = ok ? (float)o[4] : nanv;
+    tmp.st.roll[t] = ok ? (float)o[5] : nanv;
+    for (int k = 0; k < 6; ++k) tmp.st.pos[6 * t + k] = o[k];
+    const int tr = tmp.st.tree[par];
+    tmp.st.tree[t] = tr;
+    if (ok && tmp.tg.cnt) {   // and into the round's own grid, where the later samples of the round look for it
+      GridItem it;
+      for (int k = 0; k < 6; ++k) it.p[k] = o[k];
+      it.id = (int32_t)t;
+      it.tree = tr;
+      it.pad[0] = it.pad[1] = 0;
+      grid_put(tmp.tg, it);
+    }
+  }
+  if (parent_dist) {
+    double pd = dist6(c, o);  // parentDistance, src/forest.h:250
+    parent_dist[i] = pd;
+    if (queries) {
+      SweepQuery q;
+      q.x = (float)o[0]; q.y = (float)o[1]; q.z = (float)o[2];
+      q.yaw = (float)o[3]; q.pitch = (float)o[4]; q.roll = (float)o[5];
+      double r = pd > prm.dist_tree ? pd : prm.dist_tree;
+      q.r = r;
+      double ri = (r + prm.sweep_abs_eps) * (1.0 + 1e-5);
+      q.r2f = (float)(ri * ri) * 1.000001f;
+      q.tree = -1;
+      q.max_id = q_max_base + i;
+      q.active = (ok && (prm.world <= 1 || i % prm.world == prm.rank)) ? 1 : 0;
+      q.pad = 0;
+      queries[i] = q;
+    }
+  }
+}
 
 }  // namespace sffk
