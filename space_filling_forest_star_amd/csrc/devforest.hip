@@ -8,11 +8,13 @@
 //
 //   k_wave_begin  one workgroup: frontier picks of every slot (uniform_int_distribution on the engine-word ring,
 //                 exact incl. the rejection redraw: src/forest.h:136-151), then the first round's active list
-//   k_resolve     one workgroup: the in-order commit of one round.  Samples the wide k_settle could not settle are
-//                 resolved by a fixed-point iteration over their (rare) dependencies on EARLIER samples of the same
-//                 round; accepted samples get their node ids by a prefix sum in slot order and are appended to the
-//                 node store, the neighbour grid and the frontier; border events are de-duplicated "first in slot
-//                 order wins" through a stamped hash table; then the next round's active list is built
+//   k_commit      wide (64 samples per workgroup): the in-order commit of one round.  A sample whose neighbour walk
+//                 reaches an EARLIER sample of the same round polls that sample's state; accepted samples get their
+//                 node ids from the lower workgroups' published counts (slot order); border events are de-duplicated
+//                 "first in slot order wins" through a stamped hash table; the round's last workgroup writes the
+//                 control block.  Workgroups wait for lower ones only (see the kernel)
+//   k_append_sample  wide: accepted samples -> node store, neighbour grid, frontier; the slots that were not accepted
+//                 form the next round's active list AND draw that round's samples in the same launch
 //   k_wave_end    one workgroup: exhausted slots move their node to the closed list (first occurrence in slot
 //                 order) and mark their frontier position; termination tests (src/forest.h:184-201)
 //   k_frontier_compact  wide: order-preserving removal of the marked positions (the reference erases them one by
@@ -37,8 +39,6 @@ using namespace sffg;
 
 #define DF_THREADS 1024
 #define DF_WAVES (DF_THREADS / 64)
-#define DF_DEPB 32                          // x 64 dependent samples whose records k_resolve keeps in registers (two per thread)
-#define DF_EV_LDS 1024                      // border events of a round whose details stay in LDS
 #define DF_MAX_GROUPS SFFK_DEV_MAX_GROUPS   // ballot words in LDS: 64 x this many elements per list
 
 __device__ __forceinline__ int record_words_dev(int nbcap) { return 6 + 4 * nbcap; }
@@ -211,191 +211,6 @@ __global__ __launch_bounds__(DF_THREADS) void k_wave_begin(DevForestView f) {
   }
 }
 
-// ------------------------------------------------------------------ the commit of one round
-// k_decide (wide): everything about a sample that does not depend on the other samples of the round.  Walks the
-// neighbour list in the reference's order (src/forest.h:262-300) until a verdict falls or the first round-mate is
-// reached; the reference-equivalent counters of what it walked go straight into the round's bulk sums (they are
-// plain sums), so k_resolve only adds what it walks itself.
-// One sample's verdict from its answers, walking the neighbours one after the other (any list width).
-__device__ __forceinline__ void decide_serial(const ResolveArgs& A, const DevForestView& f, int i, int& code, int& dk,
-                                              unsigned long long* cnt) {
-  auto calls = [](int fh, int ns) -> unsigned long long {
-    return fh != 0x7fffffff ? (unsigned long long)fh : (unsigned long long)ns;
-  };
-  unsigned long long &cc = cnt[0], &pf = cnt[1], &nq = cnt[2], &ex_pose = cnt[3], &ex_seg = cnt[4], &ex_smp = cnt[5];
-  const size_t s0 = (size_t)i * A.stride;
-  const int nnb = A.rec_nnb[i];
-  bool ovf = A.first_hit[s0] == 0;            // 0 = the edge's triangle candidate list ran over
-  const bool mine = A.world <= 1 || i % A.world == A.rank;   // (executed work is counted by the rank that ran it)
-  if (mine) {
-    ex_pose = 1;
-    ex_seg = 1 + (unsigned long long)nnb;
-    ex_smp = (unsigned long long)A.seg_ns[s0];
-  }
-  for (int k = 0; k < nnb; ++k) {
-    ovf |= A.first_hit[s0 + 1 + k] == 0;
-    if (mine) ex_smp += (unsigned long long)A.seg_ns[s0 + 1 + k];
-  }
-  if (ovf) { atomicOr(A.fault_pending, 1); return; }
-  cc = 1;                                    // :246 env.Collide(newPoint)
-  if (A.pose_hit[i]) return;
-  pf = 1;
-  cc += calls(A.first_hit[s0], A.seg_ns[s0]);
-  if (A.first_hit[s0] != 0x7fffffff) return;
-  nq = (unsigned long long)f.n_trees;        // parent edge free: the neighbour loop decides (:262-267 one radiusSearch per tree)
-  code = SFFK_ACCEPT;
-  for (int k = 0; k < nnb; ++k) {
-    if (A.rec_nb[(size_t)i * A.nbcap + k] >= f.temp_base) { code = SFFK_DEPENDS; dk = k; break; }
-    const int fh = A.first_hit[s0 + 1 + k];
-    const bool fr = fh == 0x7fffffff;
-    pf += 1;
-    cc += calls(fh, A.seg_ns[s0 + 1 + k]);
-    if (A.rec_meta[(size_t)i * A.nbcap + k] & 1) {
-      if (fr) { code = SFFK_REJECTED; break; }                       // :276-280 overcrowded
-    } else {
-      code = fr ? SFFK_REJECT_EVENT : SFFK_REJECTED;                  // :288-299
-      dk = k;
-      break;
-    }
-  }
-}
-
-// k_decide (wide): every sample's verdict as far as it can be told without the slot order.  16 lanes per sample -
-// lane 0 holds the parent edge, lane l the l-th neighbour - so the answers of a sample arrive with ONE round of
-// loads instead of one per neighbour visited (the kernel is a chain of dependent loads, nothing else); the walk
-// over the neighbours (src/forest.h:262-300) becomes "first lane that stops it".  64 samples per workgroup = one
-// word of each of the three lists k_resolve works on.
-__global__ __launch_bounds__(1024) void k_decide(ResolveArgs A, int n_bound) {
-  __shared__ int s_verdict[64];
-  __shared__ unsigned long long s_cnt[64][6];
-  const DevForestView& f = A.f;
-  const int grp = threadIdx.x >> 4, gl = threadIdx.x & 15, lane = threadIdx.x & 63;
-  const int i = blockIdx.x * 64 + grp;
-  // every answer the verdict may need is requested before anything is looked at - control block included: after a
-  // kernel boundary each dependent step is a trip to the memory side of the chip (the L2s start cold), and the buffers
-  // hold n_bound samples whatever the round's size is
-  const bool inb = i < n_bound;
-  const bool par16 = A.stride <= 16;
-  const size_t s0 = (size_t)i * A.stride;
-  const bool inl = inb && A.in_lim[i] != 0;
-  const int flags = inb ? A.rec_flags[i] : 0;
-  const int nnb = inb ? A.rec_nnb[i] : 0;
-  const bool pose_hit = inb && A.pose_hit[i] != 0;
-  int fh = 0x7fffffff, ns = 0, nb = 0, meta = 0;
-  if (inb && par16) {
-    fh = A.first_hit[s0 + gl]; ns = A.seg_ns[s0 + gl];
-    if (gl > 0) { nb = A.rec_nb[(size_t)i * A.nbcap + gl - 1]; meta = A.rec_meta[(size_t)i * A.nbcap + gl - 1]; }
-  }
-  if (f.ctrl->halt) return;
-  const int n = f.ctrl->n_act;
-  if (blockIdx.x * 64 >= n) return;
-  unsigned long long cnt[6] = {0, 0, 0, 0, 0, 0};   // cc, pf, nq, ex_pose, ex_seg, ex_smp
-  int verdict = -1;
-  if (i < n) {
-    int code = SFFK_REJECTED, dk = 0;
-    if (!inl) code = SFFK_OUTSIDE;
-    else if (flags & 2) { if (gl == 0) atomicOr(A.fault_pending, 1); }   // hit / neighbour list overflow: host path
-    else if ((flags & 3) == 1) {
-      if (A.stride > 16) {
-        if (gl == 0) decide_serial(A, f, i, code, dk, cnt);
-        code = __shfl(code, lane & 48); dk = __shfl(dk, lane & 48);
-      } else {
-        auto calls = [](int fh, int ns) -> unsigned long long {
-          return fh != 0x7fffffff ? (unsigned long long)fh : (unsigned long long)ns;
-        };
-        const int gsh = lane & 48;                         // first lane of the group in its wavefront
-        auto gballot = [&](bool p) -> unsigned { return (unsigned)((__ballot(p) >> gsh) & 0xffffULL); };
-        auto gsum = [&](unsigned long long v) -> unsigned long long {
-          for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off);
-          return v;
-        };
-        const bool have = gl <= nnb;                       // (nnb <= nbcap <= 15)
-        if (!have) { fh = 0x7fffffff; ns = 0; nb = 0; meta = 0; }
-        const bool ovf = gballot(have && fh == 0) != 0;    // 0 = the edge's triangle candidate list ran over
-        const bool mine = A.world <= 1 || i % A.world == A.rank;   // (executed work is counted by the rank that ran it)
-        const unsigned long long smp = gsum(have ? (unsigned long long)ns : 0ULL);
-        if (mine) { cnt[3] = 1; cnt[4] = 1 + (unsigned long long)nnb; cnt[5] = smp; }
-        const bool fr = fh == 0x7fffffff;
-        const int fh0 = __shfl(fh, gsh), ns0 = __shfl(ns, gsh);
-        const bool walk = !ovf && !pose_hit && fh0 == 0x7fffffff;
-        // the neighbour walk: a lane stops it when its neighbour is a round-mate (the verdict waits), of another
-        // tree (:283-299), or of the same tree with a free edge (:276-280 overcrowded)
-        const bool is_nb = have && gl > 0;
-        const bool mate = is_nb && nb >= f.temp_base;
-        const bool same = (meta & 1) != 0;
-        const unsigned stops = gballot(is_nb && (mate || !same || fr));
-        const int ks = stops ? __ffs((int)stops) - 1 : 16;            // (group lane of the first stop)
-        const unsigned mates = gballot(mate);
-        const bool ks_mate = stops && ((mates >> ks) & 1u);
-        const bool visited = walk && is_nb && (gl < ks || (gl == ks && !ks_mate));
-        const unsigned long long v_pf = gsum(visited ? 1ULL : 0ULL), v_cc = gsum(visited ? calls(fh, ns) : 0ULL);
-        if (ovf) { if (gl == 0) atomicOr(A.fault_pending, 1); }
-        else {
-          cnt[0] = 1;                                // :246 env.Collide(newPoint)
-          if (!pose_hit) {
-            cnt[1] = 1;
-            cnt[0] += calls(fh0, ns0);
-            if (walk) {                              // parent edge free: the neighbour loop decides
-              cnt[2] = (unsigned long long)f.n_trees;   // :262-267 one radiusSearch per tree
-              cnt[1] += v_pf;
-              cnt[0] += v_cc;
-              code = SFFK_ACCEPT;
-              if (stops) {
-                const bool s_same = __shfl((int)same, gsh + ks) != 0, s_fr = __shfl((int)fr, gsh + ks) != 0;
-                if (ks_mate) {
-                  code = SFFK_DEPENDS; dk = ks - 1;
-                  // what is left of the walk, for k_resolve: the neighbours from the round-mate on, up to the first one
-                  // that ends the walk whatever the round-mates turn out to be.  The first four entries travel in the
-                  // record (id | edge free, same tree, reference-equivalent calls); longer walks are rare and re-read
-                  // the lists.
-                  const unsigned defs = gballot(is_nb && gl > ks && !mate && (!same || fr));
-                  const int last = defs ? __ffs((int)defs) - 1 : nnb;            // (group lane of the last entry)
-                  int32_t* rec = f.dep_rec + (size_t)i * SFFK_DEP_REC;
-                  if (gl == 0) { rec[0] = last - ks + 1; rec[1] = dk; }
-                  const int at = gl - ks;
-                  if (at >= 0 && at < 4 && gl <= last) {
-                    rec[2 + 2 * at] = nb;
-                    rec[3 + 2 * at] = (int)((calls(fh, ns) << 2) | (fr ? 2ULL : 0ULL) | (same ? 1ULL : 0ULL));
-                  }
-                }
-                else if (s_same) code = SFFK_REJECTED;
-                else { code = s_fr ? SFFK_REJECT_EVENT : SFFK_REJECTED; dk = ks - 1; }
-              }
-            }
-          }
-        }
-      }
-    }
-    if (gl == 0) {
-      A.code[i] = (uint8_t)code;
-      f.dk[i] = (uint8_t)dk;
-      // sample state for the commit: 0 undecided (depends on a round-mate), 1 rejected, 2 accepted, 3 rejected + border event
-      f.ustate[i] = code == SFFK_DEPENDS ? 0 : (code == SFFK_ACCEPT ? 2 : (code == SFFK_REJECT_EVENT ? 3 : 1));
-    }
-    verdict = code;
-  }
-  if (gl == 0) {
-    s_verdict[grp] = verdict;
-    for (int q = 0; q < 6; ++q) s_cnt[grp][q] = cnt[q];
-  }
-  __syncthreads();
-  if (threadIdx.x < 64) {   // one word per 64 samples for each of the three lists k_resolve works on
-    const int v = s_verdict[threadIdx.x];
-    const unsigned long long wd = __ballot(v == SFFK_DEPENDS), wa = __ballot(v == SFFK_ACCEPT), we = __ballot(v == SFFK_REJECT_EVENT);
-    unsigned long long c6[6];
-    for (int q = 0; q < 6; ++q) {
-      c6[q] = s_cnt[threadIdx.x][q];
-      for (int off = 32; off > 0; off >>= 1) c6[q] += __shfl_xor(c6[q], off);
-    }
-    if (threadIdx.x == 0) {
-      const int g = blockIdx.x;
-      f.w_dep[g] = wd; f.w_acc[g] = wa; f.w_ev[g] = we;
-      // (no atomics: a thousand of them on one cache line take longer than the rest of this kernel)
-      for (int q = 0; q < 6; ++q) f.w_cnt[6 * (size_t)g + q] = c6[q];
-    }
-  }
-}
-
 // border de-duplication: open addressing on the key (n1 << 32 | n2 + 1); the value is a stamp (epoch << 32 | sample)
 // that only ever decreases, so among the events of one round the smallest sample index owns the key and every
 // entry of an earlier round (smaller epoch) beats them all
@@ -412,415 +227,10 @@ __device__ __forceinline__ size_t border_slot(const DevForestView& f, unsigned l
   }
 }
 
-// A dependent sample's neighbour walk out of the answer lists, from the neighbour k_decide stopped at (f.dk).  Returns
-// the verdict (0 = a round-mate it meets is not decided yet, 1 rejected, 2 accepted, 3 rejected + border event at
-// neighbour ev_nb) and the reference-equivalent call counts of what it visited.
-__device__ int walk_lists(const ResolveArgs& A, const DevForestView& f, int i, int Tb, unsigned long long& c1,
-                          unsigned long long& p1, int& ev_nb, const WgLists* dep = nullptr, const uint8_t* dstate = nullptr) {
-  const size_t s0 = (size_t)i * A.stride;
-  const int nnb = A.rec_nnb[i];
-  c1 = 0; p1 = 0;
-  for (int k = f.dk[i]; k < nnb; ++k) {
-    const int id = A.rec_nb[(size_t)i * A.nbcap + k];
-    if (id >= Tb) {
-      int sj = f.ustate[id - Tb];
-      // (dep: the verdicts of this round's dependent samples are still in LDS, by position in the dependent list)
-      if (sj == 0 && dep) sj = dstate[wg_rank(*dep, id - Tb)];
-      if (sj == 0) return 0;                      // not known yet: next pass
-      if (sj != 2) continue;                      // that sample never became a node
-    }
-    const int fh = A.first_hit[s0 + 1 + k];
-    const bool fr = fh == 0x7fffffff;
-    p1 += 1;
-    c1 += fr ? (unsigned long long)A.seg_ns[s0 + 1 + k] : (unsigned long long)fh;
-    if (A.rec_meta[(size_t)i * A.nbcap + k] & 1) {
-      if (fr) return 1;                           // :276-280 overcrowded
-    } else {
-      ev_nb = k;                                  // :288-299
-      return fr ? 3 : 1;
-    }
-  }
-  return 2;
-}
-
-// k_resolve (one workgroup): what needs the slot order.  Sample states: 0 undecided, 1 rejected, 2 accepted,
-// 3 rejected with a border event (neighbour dk).
-__global__ __launch_bounds__(DF_THREADS) void k_resolve(ResolveArgs A) {
-  __shared__ WgLists L;
-  __shared__ int undecided_s;
-  __shared__ unsigned long long cnt_s[8];
-  __shared__ DevCtrl K;              // the control block, worked on in LDS and written back once
-  __shared__ int ev_nb_s[DF_EV_LDS], ev_ex_s[DF_EV_LDS];
-  __shared__ unsigned int ev_h_s[DF_EV_LDS];
-  __shared__ unsigned long long W_acc[DF_MAX_GROUPS], W_ev[DF_MAX_GROUPS];   // accepted / border-event words of the round
-  __shared__ int W_accp[DF_MAX_GROUPS];
-  __shared__ int dep_s[DF_DEPB * 64];
-  __shared__ uint8_t dstate_s[DF_DEPB * 64];
-   // verdicts of the dependent samples, by position in the dependent list
-  const DevForestView& f = A.f;
-  DevCtrl* c = f.ctrl;
-  if (threadIdx.x == 0) c->app_n = 0;
-  if (A.star && threadIdx.x == 0) { A.S.hdr[0] = 0; A.S.hdr[1] = 1; A.S.hdr[2] = 0; A.S.hdr[4] = 0; }   // (no star stage unless this round commits)
-  if (c->halt) return;
-  const int n = c->n_act;
-  if (n == 0) return;      // (a wave that is over keeps n_act = 0)
-  for (int w = threadIdx.x; w < (int)(sizeof(DevCtrl) / 4); w += DF_THREADS)
-    reinterpret_cast<int32_t*>(&K)[w] = reinterpret_cast<const int32_t*>(c)[w];
-  if (*A.fault_pending) {
-    // a bounded device list overflowed somewhere in this round: nothing is committed, the bookkeeping of the
-    // round's begin is rolled back and the host redoes the round on its unbounded path
-    if (threadIdx.x == 0) {
-      c->fault = SFFK_FAULT_LISTS;
-      c->halt = 1;
-      c->round -= 1;
-      c->iter = c->iter0;
-      c->cursor = c->words_base;
-      c->rounds -= 1;
-      c->round_nodes -= (unsigned long long)(c->N0 + n);
-      c->round_queries -= (unsigned long long)n;
-      c->n_act = 0;
-      *A.fault_pending = 0;
-    }
-    return;
-  }
-  __syncthreads();
-  if (A.star) {
-    // SFF*: the star stage may still fault after this kernel has committed the round's bookkeeping (a member edge's
-    // candidate list, the fixed point's launch budget): the control block as a rolled-back round leaves it, for k_star_apply
-    for (int w = threadIdx.x; w < (int)(sizeof(DevCtrl) / 4); w += DF_THREADS)
-      reinterpret_cast<int32_t*>(A.S.backup)[w] = reinterpret_cast<const int32_t*>(&K)[w];
-    __threadfence_block();
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      DevCtrl* b = A.S.backup;
-      b->fault = SFFK_FAULT_LISTS;
-      b->halt = 1;
-      b->round -= 1;
-      b->iter = b->iter0;
-      b->cursor = b->words_base;
-      b->rounds -= 1;
-      b->round_nodes -= (unsigned long long)(b->N0 + n);
-      b->round_queries -= (unsigned long long)n;
-      b->n_act = 0;
-      b->app_n = 0;
-    }
-  }
-  const int Tb = f.temp_base, N0 = K.N0, fn0 = K.frontier_n, nb0 = K.n_borders, act_cnt = K.act_cnt;
-  const int act_sel = K.act_sel;
-  const unsigned long long stamp_hi = (K.epoch + 1ULL) << 32;
-  const int stride = A.stride, nbcap = A.nbcap;
-  const int ng = (n + 63) >> 6;
-  if (threadIdx.x < 8) cnt_s[threadIdx.x] = 0ULL;
-  unsigned long long tk[6];
-  tk[0] = wall_clock64();
-  // k_decide's counter sums, one set per 64 samples: requested now, added up at the end
-  unsigned long long d6[6] = {0, 0, 0, 0, 0, 0};
-  for (int g = threadIdx.x; g < ng; g += DF_THREADS)
-    for (int q = 0; q < 6; ++q) d6[q] += f.w_cnt[6 * (size_t)g + q];
-  // ---- 1. k_decide's words: dependent samples (they wait for an earlier sample of the round), accepted, border events
-  for (int g = threadIdx.x; g < ng; g += DF_THREADS) { L.words[g] = f.w_dep[g]; W_acc[g] = f.w_acc[g]; W_ev[g] = f.w_ev[g]; }
-  const int n_dep = wg_prefix(L, n);
-  const bool fast = stride <= 16 && n_dep <= DF_DEPB * 64;   // (k_decide left a record per dependent sample)
-  for (int g = threadIdx.x; g < ng; g += DF_THREADS) {   // the dependent list, in slot order (set bits only)
-    unsigned long long w = L.words[g];
-    int at = L.pref[g];
-    while (w) {
-      const int i = g * 64 + __ffsll((long long)w) - 1;
-      if (fast) dep_s[at] = i;
-      f.ulist[at++] = i;
-      w &= w - 1;
-    }
-  }
-  __threadfence_block();
-  __syncthreads();
-  // ---- 2. fixed point: a dependent sample continues its neighbour walk (order of src/forest.h:262-300) at the
-  // round-mate where k_decide stopped.  A round-mate neighbour only exists if that sample was accepted.
-  unsigned long long cc = 0, pf = 0;
-  tk[1] = wall_clock64();
-  int passes = 0;
-  bool fast_done = false;
-  if (fast && n_dep > 0) {
-    // one thread per dependent sample (two if there are more than a workgroup's worth): its record is read ONCE and
-    // stays in registers, a pass only polls LDS - no global traffic, no fence.  (One workgroup = one compute unit:
-    // walking the lists out of global memory pass after pass is bound by that unit's address rate and by the
-    // write-through of every verdict.)  A record longer than four entries walks the lists, polling LDS as well.
-    int ri[2], rlen[2], rbase[2], ra[2][4], rb[2][4], vr[2], ve[2];
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      const int u = r * DF_THREADS + threadIdx.x;
-      ri[r] = u < n_dep ? dep_s[u] : -1;
-      rlen[r] = 0; rbase[r] = 0; vr[r] = 0; ve[r] = 0;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { ra[r][e] = 0; rb[r][e] = 0; }
-      if (u < n_dep) dstate_s[u] = 0;
-      if (ri[r] >= 0) {
-        const int4* rec = reinterpret_cast<const int4*>(f.dep_rec + (size_t)ri[r] * SFFK_DEP_REC);
-        const int4 q0 = rec[0], q1 = rec[1], q2 = rec[2];
-        rlen[r] = q0.x; rbase[r] = q0.y;
-        ra[r][0] = q0.z; rb[r][0] = q0.w; ra[r][1] = q1.x; rb[r][1] = q1.y;
-        ra[r][2] = q1.z; rb[r][2] = q1.w; ra[r][3] = q2.x; rb[r][3] = q2.y;
-      }
-    }
-    // round-mates k_decide has settled are folded into the entries for good (accepted: an ordinary neighbour,
-    // rejected: no neighbour at all); the others are dependent samples themselves and are polled in LDS by their
-    // position in the dependent list (L still holds the dependent words and their prefix)
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      if (ri[r] < 0) continue;
-      int sj[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) sj[e] = (e < rlen[r] && ra[r][e] >= Tb) ? (int)f.ustate[ra[r][e] - Tb] : -1;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (sj[e] < 0) continue;                                         // (an ordinary neighbour)
-        if (sj[e] == 0) ra[r][e] = -1 - wg_rank(L, ra[r][e] - Tb);
-        else if (sj[e] == 2) ra[r][e] = 0;
-        else rb[r][e] = -1;                                              // that sample never became a node
-      }
-    }
-    __syncthreads();
-    {
-      fast_done = true;
-      for (int pass = 0; pass < n + 2; ++pass) {
-        ++passes;
-        if (threadIdx.x == 0) undecided_s = 0;
-        __syncthreads();
-        int mine_undecided = 0;
-#pragma unroll
-        for (int r = 0; r < 2; ++r) {
-          if (ri[r] < 0 || vr[r] != 0) continue;
-          unsigned long long c1 = 0, p1 = 0;
-          int verdict = 2, ev_nb = 0;
-          bool walking = rlen[r] <= 4;
-          if (!walking) verdict = walk_lists(A, f, ri[r], Tb, c1, p1, ev_nb, &L, dstate_s);   // (a long walk: rare)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            if (!walking || e >= rlen[r]) continue;
-            const int id = ra[r][e], fl = rb[r][e];
-            if (fl < 0) continue;                                        // (a round-mate that never became a node)
-            if (id < 0) {
-              const int sj = dstate_s[-1 - id];
-              if (sj == 0) { verdict = 0; walking = false; continue; }   // not known yet: next pass
-              if (sj != 2) continue;                                     // that sample never became a node
-            }
-            p1 += 1;
-            c1 += (unsigned long long)(fl >> 2);
-            if (fl & 1) {
-              if (fl & 2) { verdict = 1; walking = false; }              // :276-280 overcrowded
-            } else {
-              verdict = (fl & 2) ? 3 : 1;                                // :288-299
-              ev_nb = rbase[r] + e;
-              walking = false;
-            }
-          }
-          if (verdict == 0) { mine_undecided = 1; continue; }
-          cc += c1; pf += p1;
-          vr[r] = verdict; ve[r] = ev_nb;
-          dstate_s[r * DF_THREADS + threadIdx.x] = (uint8_t)verdict;
-        }
-        if (mine_undecided) undecided_s = 1;
-        __syncthreads();
-        if (!undecided_s) break;
-        __syncthreads();
-      }
-#pragma unroll
-      for (int r = 0; r < 2; ++r) {   // the verdicts, for the steps below and for k_append
-        const int i = ri[r];
-        if (i < 0) continue;
-        if (vr[r] == 3) { f.dk[i] = (uint8_t)ve[r]; atomicOr(&W_ev[i >> 6], 1ULL << (i & 63)); }
-        if (vr[r] == 2) atomicOr(&W_acc[i >> 6], 1ULL << (i & 63));
-        f.ustate[i] = (uint8_t)vr[r];
-      }
-      __threadfence_block();
-    }
-  }
-  for (int pass = 0; pass < n + 2 && n_dep > 0 && !fast_done; ++pass) {
-    ++passes;
-    if (threadIdx.x == 0) undecided_s = 0;
-    __syncthreads();
-    int mine_undecided = 0;
-    for (int u = threadIdx.x; u < n_dep; u += DF_THREADS) {
-      const int i = f.ulist[u];
-      if (f.ustate[i] != 0) continue;
-      unsigned long long c1 = 0, p1 = 0;
-      int ev_nb = 0;
-      const int verdict = walk_lists(A, f, i, Tb, c1, p1, ev_nb);
-      if (verdict == 0) { mine_undecided = 1; continue; }
-      cc += c1; pf += p1;
-      if (verdict == 3) { f.dk[i] = (uint8_t)ev_nb; atomicOr(&W_ev[i >> 6], 1ULL << (i & 63)); }
-      if (verdict == 2) atomicOr(&W_acc[i >> 6], 1ULL << (i & 63));
-      __threadfence_block();
-      f.ustate[i] = (uint8_t)verdict;
-    }
-    if (mine_undecided) undecided_s = 1;
-    __syncthreads();
-    if (!undecided_s) break;
-    __syncthreads();
-  }
-  // ---- 3. node ids of the accepted samples: N0 + rank in slot order.  Only the words are touched here; k_append
-  // turns (word, prefix) into ids, store entries and the next round's active list.
-  tk[2] = wall_clock64();
-  __syncthreads();
-  for (int g = threadIdx.x; g < ng; g += DF_THREADS) L.words[g] = W_acc[g];
-  const int n_acc = wg_prefix(L, n);
-  for (int g = threadIdx.x; g < ng; g += DF_THREADS) { f.w_acc[g] = L.words[g]; f.acc_pref[g] = L.pref[g]; W_accp[g] = L.pref[g]; }
-  if (A.star)   // SFF*: the accepted samples as a list (rank -> sample), for the star stage
-    for (int g = threadIdx.x; g < ng; g += DF_THREADS) {
-      unsigned long long w = L.words[g];
-      int at = L.pref[g];
-      while (w) {
-        A.S.acc_sample[at++] = g * 64 + __ffsll((long long)w) - 1;
-        w &= w - 1;
-      }
-    }
-  __syncthreads();
-  auto id_of = [&](int j) {   // node id of sample j, accepted in this round
-    return N0 + W_accp[j >> 6] + __popcll(W_acc[j >> 6] & ((1ULL << (j & 63)) - 1ULL));
-  };
-  // ---- 4. border events (a free edge to a neighbour of another tree, :288-294), first in slot order wins
-  tk[3] = wall_clock64();
-  for (int g = threadIdx.x; g < ng; g += DF_THREADS) L.words[g] = W_ev[g];
-  const int n_evc = wg_prefix(L, n);
-  for (int g = threadIdx.x; g < ng; g += DF_THREADS) {
-    unsigned long long w = L.words[g];
-    int at = L.pref[g];
-    while (w) {
-      f.ulist[at++] = g * 64 + __ffsll((long long)w) - 1;          // (the dependent list is done with: reuse)
-      w &= w - 1;
-    }
-  }
-  __threadfence_block();
-  __syncthreads();
-  auto event_of = [&](int i, int& nb, int& ex, unsigned long long& key) {
-    const int raw = A.rec_nb[(size_t)i * nbcap + f.dk[i]];
-    nb = raw >= Tb ? id_of(raw - Tb) : raw;        // (a round-mate neighbour was accepted: its new id)
-    ex = A.parent[i];
-    const int a = nb < ex ? nb : ex, b = nb < ex ? ex : nb;
-    key = ((unsigned long long)(uint32_t)a << 32) | ((unsigned long long)(uint32_t)b + 1ULL);
-  };
-  // (what an event needs - neighbour id, expanded node, table slot - is kept in LDS between the three steps)
-  for (int e = threadIdx.x; e < n_evc; e += DF_THREADS) {
-    const int i = f.ulist[e];
-    int nb, ex;
-    unsigned long long key;
-    event_of(i, nb, ex, key);
-    const size_t h = border_slot(f, key);
-    if (e < DF_EV_LDS) { ev_nb_s[e] = nb; ev_ex_s[e] = ex; ev_h_s[e] = (unsigned int)h; }
-    atomicMin(&f.bt_val[h], stamp_hi | (unsigned long long)(uint32_t)i);
-  }
-  __threadfence_block();
-  __syncthreads();
-  wg_flags(L, n_evc, [&](int e) {
-    const int i = f.ulist[e];
-    size_t h;
-    if (e < DF_EV_LDS) h = ev_h_s[e];
-    else {
-      int nb, ex;
-      unsigned long long key;
-      event_of(i, nb, ex, key);
-      h = border_slot(f, key);
-    }
-    // (atomic read: the stamps were written by L2 atomics a moment ago)
-    const unsigned long long owner = __hip_atomic_load(&f.bt_val[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return owner == (stamp_hi | (unsigned long long)(uint32_t)i);
-  });
-  const int n_ev = n_evc > 0 ? wg_prefix(L, n_evc) : 0;
-  for (int e = threadIdx.x; e < n_evc; e += DF_THREADS) {
-    if (!wg_flagged(L, e)) continue;
-    const int i = f.ulist[e];
-    int nb, ex;
-    if (e < DF_EV_LDS) { nb = ev_nb_s[e]; ex = ev_ex_s[e]; }
-    else {
-      unsigned long long key;
-      event_of(i, nb, ex, key);
-    }
-    const int at = nb0 + wg_rank(L, e);
-    // d = costs to the roots + the edge (:291).  A neighbour accepted in this very round is not in the store yet
-    // (k_append runs next): its tree is its parent's, its position the sample's, its cost the one k_append will write.
-    double pn[6], pe[6], dn;
-    int ta;
-    const int raw = A.rec_nb[(size_t)i * nbcap + f.dk[i]];
-    if (raw >= Tb) {
-      const int j = raw - Tb;
-      for (int q = 0; q < 6; ++q) pn[q] = A.newpos[6 * (size_t)j + q];
-      dn = A.pdist[j] + f.d_root[A.parent[j]];
-      ta = A.st.tree[A.parent[j]];
-    } else {
-      for (int q = 0; q < 6; ++q) pn[q] = A.st.pos[6 * (size_t)nb + q];
-      dn = f.d_root[nb];
-      ta = A.st.tree[nb];
-    }
-    const int tb = A.st.tree[ex];
-    f.b_n1[at] = nb < ex ? nb : ex; f.b_n2[at] = nb < ex ? ex : nb;
-    f.b_ta[at] = ta < tb ? ta : tb; f.b_tb[at] = ta < tb ? tb : ta;
-    for (int q = 0; q < 6; ++q) pe[q] = A.st.pos[6 * (size_t)ex + q];
-    if (A.star) {
-      // SFF*: the two costs are the ones the sample's turn finds (earlier samples of the round may have rewired either
-      // node): k_star_pass adds them to the distance
-      const int e = at - nb0;
-      A.S.ev_sample[e] = i; A.S.ev_nb[e] = nb; A.S.ev_ex[e] = ex; A.S.ev_dist[e] = dist6(pn, pe);
-      f.b_dist[at] = 0.0;
-    } else
-    f.b_dist[at] = dn + f.d_root[ex] + dist6(pn, pe);
-    f.pair[(size_t)ta * f.n_trees + tb] = 1;
-    f.pair[(size_t)tb * f.n_trees + ta] = 1;
-  }
-  // ---- 5. counters, sizes (the next round's active list = the slots of this round that were not accepted, then
-  // the slots the iteration cap kept out of it: k_append writes it from the accepted words)
-  tk[4] = wall_clock64();
-  {   // + k_decide's sums, one set per 64 samples
-    cc += d6[0]; pf += d6[1];
-    for (int off = 32; off > 0; off >>= 1) {
-      cc += __shfl_xor(cc, off); pf += __shfl_xor(pf, off);
-      for (int q = 2; q < 6; ++q) d6[q] += __shfl_xor(d6[q], off);
-    }
-    if ((threadIdx.x & 63) == 0 && (cc | pf | d6[3])) {
-      atomicAdd(&cnt_s[0], cc); atomicAdd(&cnt_s[1], pf);
-      for (int q = 2; q < 6; ++q) atomicAdd(&cnt_s[q], d6[q]);
-    }
-  }
-  __threadfence_block();
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    K.collide_calls += cnt_s[0];
-    K.path_free_calls += cnt_s[1];
-    K.nn_queries += cnt_s[2];
-    K.poses_executed += cnt_s[3];
-    K.segments_executed += cnt_s[4];
-    K.samples_executed += cnt_s[5];
-    K.work_items += (unsigned long long)A.round_ctrl[2];
-    if (K.q_t1 > K.q_t0) { K.q_ticks += K.q_t1 - K.q_t0; K.q_launches += 1ULL; }
-    K.app_n = n;                  // k_append applies this commit
-    K.app_N0 = N0;
-    K.app_fn0 = fn0;
-    K.app_act_sel = act_sel;
-    K.app_act_cnt = act_cnt;
-    K.iter0_app = K.iter0;
-    K.n_nodes = N0 + n_acc;
-    K.frontier_n = fn0 + n_acc;
-    K.n_borders = nb0 + n_ev;
-    K.n_unsettled += n_dep;
-    K.epoch += 1ULL;
-    if (A.star) {
-      K.nn_queries += (unsigned long long)n_acc;       // one knnSearch per accepted sample (src/forest.h:317)
-      A.S.hdr[0] = n_acc; A.S.hdr[1] = 0; A.S.hdr[2] = n_ev; A.S.hdr[3] = nb0;
-    }
-    K.act_sel = act_sel ^ 1;
-    K.act_cnt = (n - n_acc) + (act_cnt - n);
-    round_begin_scalars(f, &K);
-    tk[5] = wall_clock64();
-    for (int q = 0; q < 5; ++q) K.prof[q] += tk[q + 1] - tk[q];
-    K.prof[5] += (unsigned long long)passes;
-    K.prof[6] += 1ULL;
-    if ((unsigned long long)passes > K.prof[7]) K.prof[7] = (unsigned long long)passes;
-  }
-  __syncthreads();
-  for (int w = threadIdx.x; w < (int)(sizeof(DevCtrl) / 4); w += DF_THREADS)
-    reinterpret_cast<int32_t*>(c)[w] = reinterpret_cast<const int32_t*>(&K)[w];
-}
 
 // ------------------------------------------------------------------ the commit of one round as ONE wide kernel
-// k_commit = k_decide + k_resolve without the single workgroup: 64 samples per workgroup, 16 lanes per sample (lane 0 the
+// k_commit = the accept / reject logic of expandNode (src/forest.h:246-300) for all samples of a round at once, with no
+// single-workgroup step (rounds 1-2 had k_decide + a one-workgroup k_resolve): 64 samples per workgroup, 16 lanes per sample (lane 0 the
 // parent edge, lane l the l-th neighbour).  Everything that needs the slot order only ever looks BACKWARDS in it:
 //   - a sample whose walk (src/forest.h:262-300) reaches a sample of the same round waits for that sample's state
 //     (ustate32, polled; the earlier sample sits in this or in a lower workgroup);
@@ -828,7 +238,7 @@ __global__ __launch_bounds__(DF_THREADS) void k_resolve(ResolveArgs A) {
 //   - a border key belongs to the first event in slot order: an event knows its fate once the lower workgroups (and its
 //     own) have posted their stamps (atomicMin on the table entry) - later stamps can only be larger.
 // So a workgroup waits for lower ones only, and workgroups start in index order: the lowest unfinished one never waits.
-// The LAST workgroup of the round adds everything up and writes the control block (what k_resolve's thread 0 did).
+// The LAST workgroup of the round adds everything up and writes the control block.
 // Published words are (launch sequence number << 32 | value): nothing is cleared between launches.
 #define KC_SPIN_LIMIT (1 << 20)   // polls before a wait gives up (then: fault, the host redoes the round) - never reached
 #define KC_ACC 0      // accepted samples of the workgroup
@@ -837,7 +247,7 @@ __global__ __launch_bounds__(DF_THREADS) void k_resolve(ResolveArgs A) {
 #define KC_WHI 3
 #define KC_POSTED 4   // its border stamps are in the table
 #define KC_OWN 5      // border events it owns
-#define KC_CNT 6      // 6 counters (k_decide's) + [12] dependent samples
+#define KC_CNT 6      // 6 counters of the walks + [12] dependent samples
 #define KC_DEP 12
 
 __device__ __forceinline__ unsigned long long kc_load(const unsigned long long* p) {
@@ -959,6 +369,12 @@ __global__ __launch_bounds__(1024) void k_commit(ResolveArgs A, int n_bound) {
   const unsigned long long my_calls = calls_of(fh, ns);
   const unsigned stops = gballot(is_nb && (mate || !same || fr));
   const unsigned mates = gballot(mate), sames = gballot(same), frees = gballot(fr);
+  // single-goal mode (src/forest.h:283-299 with hasGoal): a neighbour of another tree rejects the sample without a look at
+  // its edge - unless it is the goal: a free edge to it ends the run IN THE MIDDLE of the round, which is the host
+  // engine's business (the round is rolled back like a faulted one and replayed there)
+  const bool goal_mode = f.goal_id >= 0;
+  const unsigned goals = gballot(goal_mode && is_nb && nb == f.goal_id);
+  bool count_end = true;                            // (the neighbour that ended the walk had its edge looked at)
   if (live) {
     if (!inl) code = SFFK_OUTSIDE;
     else if (flags & 2) { if (gl == 0) atomicOr(A.fault_pending, 1); }   // hit / neighbour list overflow: host path
@@ -1011,7 +427,12 @@ __global__ __launch_bounds__(1024) void k_commit(ResolveArgs A, int n_bound) {
           const int nxt = after ? __ffs((int)after) - 1 : 16;
           if (k_mate && ms == 0) blocked = true;                       // not known yet
           else if (k_mate && ms != 2) ks = nxt;                        // that sample never became a node
-          else {
+          else if (goal_mode && !k_same) {
+            const bool is_goal = (goals >> ks) & 1u;
+            if (is_goal && k_fr && gl == 0) atomicOr(A.fault_pending, 1);   // :286-287 goal reached
+            count_end = is_goal;
+            st = 1; code = SFFK_REJECTED; end = ks; pending = false;         // :296-299
+          } else {
             if (k_mate) { m_pf += 1; m_cc += ck; }                     // (an ordinary neighbour now)
             if (k_same) {
               if (k_fr) { st = 1; code = SFFK_REJECTED; end = ks; pending = false; }   // :276-280 overcrowded
@@ -1042,7 +463,7 @@ __global__ __launch_bounds__(1024) void k_commit(ResolveArgs A, int n_bound) {
   }
   {
     const bool walked = cnt[2] != 0;
-    const bool vis = walked && is_nb && !mate && gl <= end;
+    const bool vis = walked && is_nb && !mate && (gl < end || (gl == end && count_end));
     const unsigned long long v_pf = gsum(vis ? 1ULL : 0ULL), v_cc = gsum(vis ? my_calls : 0ULL);
     if (walked) { cnt[1] += v_pf + m_pf; cnt[0] += v_cc + m_cc; }
   }
@@ -1486,7 +907,7 @@ __global__ __launch_bounds__(DF_THREADS) void k_wave_end(DevForestView f, const 
     c->frontier_n = fn - removed;
     if (removed > 0) c->front_sel ^= 1;
     c->empty_frontier = c->frontier_n == 0 ? 1 : 0;
-    if (!c->solved && c->empty_frontier) {
+    if (!c->solved && c->empty_frontier && f.goal_id < 0) {   // (with a goal only reaching it solves, :204-206)
       // maxConnected() == numRoots (:379-418): every tree reachable from tree 0 over pairs that hold a border
       const int R = f.n_trees;
       int reached = 1;
@@ -1598,14 +1019,7 @@ void launch_wave_begin(hipStream_t s, const DevForestView& f) {
 }
 void launch_commit(hipStream_t s, const ResolveArgs& a, int n_bound, const StarLaunch* star, const SampleLaunch* next) {
   if (n_bound <= 0) return;
-  // (SFFGPU_OLD_COMMIT=1: the commit as k_decide + the single-workgroup k_resolve, for comparison)
-  static const bool two_kernels = getenv("SFFGPU_OLD_COMMIT") && atoi(getenv("SFFGPU_OLD_COMMIT")) != 0;
-  if (two_kernels) {
-    hipLaunchKernelGGL(k_decide, dim3((n_bound + 63) / 64), dim3(1024), 0, s, a, n_bound);
-    hipLaunchKernelGGL(k_resolve, dim3(1), dim3(DF_THREADS), 0, s, a);
-  } else {
-    hipLaunchKernelGGL(k_commit, dim3((n_bound + 63) / 64), dim3(1024), 0, s, a, n_bound);
-  }
+  hipLaunchKernelGGL(k_commit, dim3((n_bound + 63) / 64), dim3(1024), 0, s, a, n_bound);
   if (a.star && star) launch_star_stage(s, a, n_bound, *star);
   if (next) hipLaunchKernelGGL(k_append_sample, dim3((n_bound + 255) / 256), dim3(256), 0, s, a, *next);
   else hipLaunchKernelGGL(k_append, dim3((n_bound + 255) / 256), dim3(256), 0, s, a);

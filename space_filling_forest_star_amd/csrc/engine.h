@@ -243,9 +243,9 @@ struct DevEngine {
   bool active = false;    // the authoritative state currently lives on the device
   bool host_stale = false;// ... and is ahead of the host mirror
   bool table_dirty = false, ring_pending = false;
-  DevBuf frontier2, rm_words, rm_pref, slot_pos, act_slot2, dk, w_dep, w_acc, w_ev, acc_pref, w_cnt, dep_rec, ustate32, wg_pub, commit_seq, kc_trace;
+  DevBuf frontier2, rm_words, rm_pref, slot_pos, act_slot2, w_acc, acc_pref, ustate32, wg_pub, commit_seq, kc_trace;
   DevBuf ctrl, parent, d_root, d_closest, iter, nflag, frontier, closed, claim, slot_node, slot_fail, act_slot, b_n1,
-      b_n2, b_ta, b_tb, b_dist, bt_key, bt_val, pair, ring, ustate, ulist, uacc, d_parent, d_parent2, d_force, fault_pending;
+      b_n2, b_ta, b_tb, b_dist, bt_key, bt_val, pair, ring, ulist, d_parent, d_parent2, d_force, fault_pending;
   // SFF* on the device (devstar.hip; StarView in kernels.h)
   DevBuf s_ktab, s_tree_cnt, s_head, s_mcnt, s_mid, s_md, s_next, s_prop, s_best, s_psel, s_dcl, s_cnt, s_accs, s_hdr, s_changed,
       s_ew, s_ida, s_idb, s_sub, s_segns, s_fh, s_sovf, s_evs, s_evn, s_eve, s_evd, s_acc, s_backup, s_items, s_dbg, s_hist;

@@ -37,7 +37,7 @@ static uint64_t next_pow2(uint64_t v) {
 bool Forest::device_eligible() const {
   // plain SFF and SFF* (choose-parent + rewire on the device: devstar.hip); single-goal and priority-frontier modes run
   // on the host-replay engine
-  return !cfg.has_goal && !use_priority();
+  return !use_priority();
 }
 
 sffk::StarView Forest::star_view() const {
@@ -173,16 +173,12 @@ sffk::DevForestView Forest::dev_view() const {
   v.slot_node = d.slot_node.as<int32_t>();
   v.act_slot = d.act_slot.as<int32_t>();
   v.act_slot2 = d.act_slot2.as<int32_t>();
-  v.dk = d.dk.as<uint8_t>();
-  v.w_dep = d.w_dep.as<unsigned long long>();
   v.w_acc = d.w_acc.as<unsigned long long>();
-  v.w_ev = d.w_ev.as<unsigned long long>();
   v.acc_pref = d.acc_pref.as<int32_t>();
-  v.w_cnt = d.w_cnt.as<unsigned long long>();
-  v.dep_rec = d.dep_rec.as<int32_t>();
   v.ustate32 = d.ustate32.as<int32_t>();
   v.wg_pub = d.wg_pub.as<unsigned long long>();
   v.commit_seq = d.commit_seq.as<int32_t>();
+  v.goal_id = cfg.has_goal ? goal_node : -1;
   static const int profile = getenv("SFFGPU_PROFILE") ? 1 : 0;
   v.profile = profile;
   v.kc_trace = d.kc_trace.as<unsigned long long>();
@@ -207,9 +203,7 @@ sffk::DevForestView Forest::dev_view() const {
   v.max_iterations = cfg.max_iterations;
   v.node_budget = cfg.node_budget;
   v.temp_base = d.temp_base;
-  v.ustate = d.ustate.as<uint8_t>();
   v.ulist = d.ulist.as<int32_t>();
-  v.uacc = d.uacc.as<int32_t>();
   return v;
 }
 
@@ -357,14 +351,8 @@ void Forest::dev_upload_state() {
     d.slot_pos.ensure((size_t)wave * 4);
     d.act_slot.ensure((size_t)wave * 4);
     d.act_slot2.ensure((size_t)wave * 4);
-    d.dk.ensure((size_t)wave);
-    d.w_dep.ensure(((size_t)wave / 64 + 2) * 8);
     d.w_acc.ensure(((size_t)wave / 64 + 2) * 8);
-    d.w_ev.ensure(((size_t)wave / 64 + 2) * 8);
     d.acc_pref.ensure(((size_t)wave / 64 + 2) * 4);
-    d.w_cnt.ensure(((size_t)wave / 64 + 2) * 6 * 8);
-    d.dep_rec.ensure(((size_t)wave + 64) * SFFK_DEP_REC * 4);
-    d.ustate.ensure((size_t)wave);
     // k_commit's sequence-stamped words start at zero once and are never cleared again
     d.ustate32.ensure(((size_t)wave + 64) * 4);
     d.wg_pub.ensure(((size_t)wave / 64 + 2) * SFFK_PUB_WORDS * 8);
@@ -377,7 +365,6 @@ void Forest::dev_upload_state() {
     HIPCHK(hipMemsetAsync(d.wg_pub.p, 0, ((size_t)wave / 64 + 2) * SFFK_PUB_WORDS * 8, c.stream));
     HIPCHK(hipMemsetAsync(d.commit_seq.p, 0, 16, c.stream));
     d.ulist.ensure((size_t)wave * 4);
-    d.uacc.ensure((size_t)wave * 4);
     d.d_parent.ensure((size_t)wave * 4);
     d.d_parent2.ensure((size_t)wave * 4);
     d.d_force.ensure((size_t)wave);
@@ -804,7 +791,7 @@ void Forest::dev_enqueue_round_eval(void* send_dev, bool sample) {
   unsigned long long* const qclk = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(d.ctrl.p) + offsetof(sffk::DevCtrl, q_t0));
   sffk::ClassifyArgs ca{};
   ca.n = n; ca.N0 = d.temp_base; ca.cap = B.CAP; ca.nbcap = B.NBCAP; ca.rank = cfg.rank; ca.world = cfg.world;
-  ca.goal_id = -1;
+  ca.goal_id = cfg.has_goal ? goal_node : -1;
   ca.dist_tree = cfg.dist_tree;
   ca.newpos = B.d_pos;
   ca.in_lim = B.d_lim;
@@ -1087,7 +1074,7 @@ bool Forest::dev_wave_begin() {
 
 bool Forest::seq_eligible() const {
   static const bool off = getenv("SFFGPU_NO_SEQ") != nullptr && atoi(getenv("SFFGPU_NO_SEQ")) != 0;
-  return dev.on && cfg.wave == 1 && cfg.world == 1 && !off && !seq_suspended && num_roots <= 64;
+  return dev.on && cfg.wave == 1 && cfg.world == 1 && !off && !seq_suspended && num_roots <= 64 && !cfg.has_goal;
 }
 
 // waves of ONE slot (the reference's own order): k_seq_waves runs whole outer iterations back to back inside one launch,

@@ -141,7 +141,6 @@ struct DevCtrl {
   // took, the k-nearest members they looked at, the rewires they applied (folded in from StarView::acc by k_wave_end)
   unsigned long long star_rounds, star_passes, star_members, star_rewires;
 };
-#define SFFK_DEP_REC 12   // {entries, first neighbour index, 4 x (id, calls << 2 | edge free << 1 | same tree)}, 16-byte aligned
 #define SFFK_DEV_MAX_GROUPS 1024   // single-workgroup list kernels: 64 x this many slots per wave at most
 #define SFFK_FAULT_LISTS 1        // a hit / neighbour / triangle-candidate list overflowed: redo the round on the host
 #define SFFK_FAULT_BORDER_TABLE 2 // the border hash table is full: the host grows it
@@ -357,14 +356,11 @@ struct DevForestView {
   const uint64_t* ring; uint64_t ring_mask;
   int32_t node_cap, border_cap, wave, n_trees, words_per, threshold_misses, max_iterations, node_budget;
   int32_t temp_base;           // store index of the round's temporaries
-  uint8_t* ustate; int32_t* ulist; int32_t* uacc;   // k_resolve scratch: per sample state / dependent list / accepted id
-  uint8_t* dk;                 // per sample: neighbour index where k_decide stopped (first round-mate / border event)
-  // one 64-bit word per 64 samples, written by k_decide (ballots) and finished by k_resolve: dependent / accepted /
-  // border-event flags; acc_pref = accepted samples before the word (k_append turns both into node ids and the
-  // next round's active list without k_resolve ever walking the samples)
-  unsigned long long* w_dep; unsigned long long* w_acc; unsigned long long* w_ev; int32_t* acc_pref;
-  int32_t* dep_rec;            // SFFK_DEP_REC ints per sample: what is left of a dependent sample's neighbour walk (k_decide -> k_resolve)
-  unsigned long long* w_cnt;   // 6 counters per word (k_decide's sums over its 64 samples; k_resolve adds them up)
+  int32_t goal_id;             // Problem::hasGoal: the goal's node (a one-node tree that is searched, never expanded), -1 = none
+  int32_t* ulist;              // scratch list of a wave's slots (k_wave_end)
+  // one 64-bit word per 64 samples: the accepted samples, and how many were accepted before the word (k_commit ->
+  // k_append_sample / the star stage: node ids and the next round's active list without walking the samples)
+  unsigned long long* w_acc; int32_t* acc_pref;
   // k_commit (the wide commit kernel): what its workgroups tell each other.  Every word carries the launch's sequence
   // number (commit_seq[0] + 1) in its upper half, so nothing is ever cleared and a stale word is never taken for news.
   int32_t* ustate32;           // per sample: (seq << 2 | state), state 1 rejected / 2 accepted / 3 rejected + border event
@@ -428,7 +424,7 @@ struct StarView {
   int32_t* hist; int32_t* hist_ctl; int hist_cap;
 };
 // per-sample verdicts of k_decide
-#define SFFK_DEPENDS 0     // the neighbour walk reached a sample of the same round first: k_resolve continues at dk
+#define SFFK_DEPENDS 0     // (host engine's k_settle: the neighbour walk reached a sample of the same round first)
 #define SFFK_REJECTED 1
 #define SFFK_OUTSIDE 2
 #define SFFK_ACCEPT 3

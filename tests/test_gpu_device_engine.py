@@ -45,12 +45,16 @@ class engine:
                 os.environ[k] = v
 
 
-def make(S, ctx, name, wave, iters, seed, n_roots=5, budget=0, which="device", optimize=False, **env):
+def make(S, ctx, name, wave, iters, seed, n_roots=5, budget=0, which="device", optimize=False, goal_offset=None, **env):
     sc, w = load_world(ctx, name)
     roots = sc["xml_points"][:n_roots] if sc["xml_points"] is not None else \
         common.free_roots(w.collide, sc["limits"], n_roots, seed=seed, dim=sc["dim"])
     kw = dict(dist_tree=sc["dist_tree"], sampling_dist=sc["sampling_dist"], dim=sc["dim"], max_iterations=iters,
               node_budget=budget, wave=wave, seed=seed, optimize=optimize)
+    if goal_offset is not None:
+        g = roots[0].copy()
+        g[:3] += np.array(goal_offset, dtype=np.float64)
+        kw["goal"] = g
     fo = O.Forest(w, roots, sc["limits"], **kw)
     with engine(SFFGPU_ENGINE=which, **env):
         fg = S.Forest(ctx, roots, sc["limits"], **kw)
@@ -69,6 +73,23 @@ def test_device_engine_equals_the_oracle(S, ctx, name, wave, iters):
     fg.run()
     assert fo.stats()["n_nodes"] > 40
     assert_same_forest(fo, fg)
+
+
+@pytest.mark.parametrize("name,wave,n_roots,optimize,offset", [
+    ("triang", 64, 2, False, [12, 8, 5]), ("triang", 512, 3, False, [30, 20, 10]), ("triang", 256, 1, True, [12, 8, 5]),
+    ("building", 128, 1, False, [12, 8, 5]), ("dense3d", 1024, 4, False, [30, 25, 8]),
+])
+def test_single_goal_mode_on_the_device_engine(S, ctx, name, wave, n_roots, optimize, offset):
+    """Problem::hasGoal (src/forest.h:91-109, :283-299, :369-372) on the device engine: a neighbour of another tree
+    rejects the sample without an edge check unless it is the goal; the round in which a sample reaches the goal is
+    rolled back on the device and replayed by the host engine, which stops in the middle of it like the reference."""
+    fo, fg = make(S, ctx, name, wave, 60000, seed=8, n_roots=n_roots, optimize=optimize, goal_offset=offset)
+    fo.run()
+    fg.run()
+    assert_same_forest(fo, fg)
+    st = fg.stats()
+    assert fg.device_engine() and st["solved"] == 1 and st["n_borders"] >= 1
+    assert st["waves"] > st["host_fallback_waves"] >= 1   # (only the solving wave went to the host)
 
 
 @pytest.mark.parametrize("name,wave,iters", [
