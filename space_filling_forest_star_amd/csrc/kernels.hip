@@ -954,12 +954,21 @@ __global__ __launch_bounds__(64 * POSE_WAVES) void k_collide_poses(EnvView env, 
 
 // ------------------------------------------------------------------ segment kernel
 #define SEG_WAVES 4
+// boxes of the robot triangles as loaded (no rotation): lo xyz, hi xyz per triangle, next to the triangles in LDS
+__device__ __forceinline__ void fill_robot_boxes(const double* rtri, double* rbox, int n_tri, int tid, int nthreads) {
+  for (int r = tid; r < n_tri; r += nthreads)
+    for (int ax = 0; ax < 3; ++ax) {
+      rbox[6 * r + ax] = min3(rtri[9 * r + ax], rtri[9 * r + 3 + ax], rtri[9 * r + 6 + ax]);
+      rbox[6 * r + 3 + ax] = max3(rtri[9 * r + ax], rtri[9 * r + 3 + ax], rtri[9 * r + 6 + ax]);
+    }
+}
+
 #define QUEUE_CAP 128
 
 // One wavefront per (edge, chunk of 64 consecutive samples): lane = sample.  The chunk's own swept
 // box gives a tight broad phase; the smallest colliding sample index of an edge is reduced with
 // atomicMin, so the answer does not depend on which chunk finishes first.
-__device__ void segment_chunk(const EnvView& env, const RobotView& rob, const double* rtri, int32_t* stack,
+__device__ void segment_chunk(const EnvView& env, const RobotView& rob, const double* rtri, const double* rbox, int32_t* stack,
                               int32_t* cand, int32_t* queue, double* stage, const double* a, const double* b, int seg,
                               int chunk, bool have_mask, unsigned long long mask, int32_t* __restrict__ first_hit,
                               int32_t* __restrict__ overflow_flag, int lane DBG_ARG) {
@@ -1083,10 +1092,14 @@ __device__ void segment_chunk(const EnvView& env, const RobotView& rob, const do
           const int r = r0 + lane;
           bool ok = false;
           if (r < rob.n_tri) {
-            double Q[9];
-            for (int vv = 0; vv < 3; ++vv)
-              for (int ax = 0; ax < 3; ++ax) Q[3 * vv + ax] = rtri[9 * r + 3 * vv + ax] + S[ax];
-            ok = tri_box_overlap(bx, bx + 3, Q);
+            // box of the (un-rotated) robot triangle, shifted to the sample: min / max over its vertices of fl(v + S) =
+            // fl(min / max v + S) - rounding is monotone - so this is tri_box_overlap on the shifted triangle, bit for bit
+            const double* rb = rbox + 6 * r;
+            ok = true;
+            for (int ax = 0; ax < 3; ++ax) {
+              const double qmin = rb[ax] + S[ax], qmax = rb[3 + ax] + S[ax];
+              if (bx[ax] > qmax || qmin > bx[3 + ax]) ok = false;
+            }
           }
           const unsigned long long mm = __ballot(ok);
           if (mm) {
@@ -1305,6 +1318,9 @@ __global__ __launch_bounds__(64 * SEG_WAVES) void k_collide_segments_dyn(EnvView
   int32_t* ibase = reinterpret_cast<int32_t*>(rtri + (size_t)rob.n_tri * 9 + (size_t)SEG_WAVES * STAGE_DOUBLES);
   for (int i = threadIdx.x; i < rob.n_tri * 9; i += blockDim.x) rtri[i] = rob.tri[i];
   __syncthreads();
+  double* rbox = reinterpret_cast<double*>(ibase + SEG_WAVES * (STACK_CAP + TG_HASH + CAND_CAP + QUEUE_CAP));
+  fill_robot_boxes(rtri, rbox, rob.n_tri, threadIdx.x, blockDim.x);
+  __syncthreads();
   if (env.n_tri == 0) return;
   int32_t* stack = ibase + wave * (STACK_CAP + TG_HASH);   // (+ the wave's triangle-grid hash set behind its stack)
   int32_t* cand = ibase + SEG_WAVES * (STACK_CAP + TG_HASH) + wave * CAND_CAP;
@@ -1365,7 +1381,7 @@ __global__ __launch_bounds__(64 * SEG_WAVES) void k_collide_segments_dyn(EnvView
         if (chunk > 0 && first_hit[slot] <= 64 * chunk) continue;
         double a[6], b[6];
         for (int k = 0; k < 6; ++k) { a[k] = a6[6 * (size_t)slot + k]; b[k] = b6[6 * (size_t)slot + k]; }
-        segment_chunk(env, rob, rtri, stack, cand, queue, stage, a, b, slot, chunk, true, nm, first_hit, overflow_flag, lane DBG_PASS);
+        segment_chunk(env, rob, rtri, rbox, stack, cand, queue, stage, a, b, slot, chunk, true, nm, first_hit, overflow_flag, lane DBG_PASS);
       }
       __syncthreads();
     }
@@ -1390,7 +1406,7 @@ __global__ __launch_bounds__(64 * SEG_WAVES) void k_collide_segments_dyn(EnvView
       double a[6], bb[6];
       for (int k = 0; k < 6; ++k) { a[k] = a6[6 * (size_t)(first + b) + k]; bb[k] = b6[6 * (size_t)(first + b) + k]; }
       for (int chunk = 0; chunk * 64 < nsb; ++chunk)
-        segment_chunk(env, rob, rtri, stack, cand, queue, stage, a, bb, first + b, chunk, false, 0ULL, first_hit, overflow_flag, lane DBG_PASS);
+        segment_chunk(env, rob, rtri, rbox, stack, cand, queue, stage, a, bb, first + b, chunk, false, 0ULL, first_hit, overflow_flag, lane DBG_PASS);
     }
   }
 }
@@ -1968,6 +1984,9 @@ __global__ __launch_bounds__(64 * SEG_WAVES) __attribute__((amdgpu_waves_per_eu(
   if ((M <= 0 && !ran_over) || env.n_tri == 0) return;
   for (int i = threadIdx.x; i < rob.n_tri * 9; i += blockDim.x) rtri[i] = rob.tri[i];
   __syncthreads();
+  double* rbox = reinterpret_cast<double*>(ibase + SEG_WAVES * (STACK_CAP + TG_HASH + CAND_CAP + QUEUE_CAP));
+  fill_robot_boxes(rtri, rbox, rob.n_tri, threadIdx.x, blockDim.x);
+  __syncthreads();
   int32_t* stack = ibase + wave * (STACK_CAP + TG_HASH);
   int32_t* cand = ibase + SEG_WAVES * (STACK_CAP + TG_HASH) + wave * CAND_CAP;
   int32_t* queue = ibase + SEG_WAVES * (STACK_CAP + TG_HASH + CAND_CAP) + wave * QUEUE_CAP;
@@ -2006,7 +2025,7 @@ __global__ __launch_bounds__(64 * SEG_WAVES) __attribute__((amdgpu_waves_per_eu(
     for (int k = 0; k < 6; ++k) { a[k] = a6[6 * (size_t)slot + k]; b[k] = b6[6 * (size_t)slot + k]; }
     for (int chunk = c_lo; chunk < c_hi; ++chunk) {
       if (chunk > 0 && first_hit[slot] <= 64 * chunk) break;
-      segment_chunk(env, rob, rtri, stack, cand, queue, stage, a, b, slot, chunk, !ran_over, mask, first_hit, overflow_flag, lane DBG_PASS);
+      segment_chunk(env, rob, rtri, rbox, stack, cand, queue, stage, a, b, slot, chunk, !ran_over, mask, first_hit, overflow_flag, lane DBG_PASS);
     }
   }
   DBG_FLUSH();
@@ -2040,6 +2059,9 @@ __global__ __launch_bounds__(64 * SEG_WAVES) __attribute__((amdgpu_waves_per_eu(
   if (M <= 0 || env.n_tri == 0) return;
   for (int i = threadIdx.x; i < rob.n_tri * 9; i += blockDim.x) rtri[i] = rob.tri[i];
   __syncthreads();
+  double* rbox = reinterpret_cast<double*>(ibase + SEG_WAVES * (STACK_CAP + TG_HASH + CAND_CAP + QUEUE_CAP));
+  fill_robot_boxes(rtri, rbox, rob.n_tri, threadIdx.x, blockDim.x);
+  __syncthreads();
   int32_t* stack = ibase + wave * (STACK_CAP + TG_HASH);
   int32_t* cand = ibase + SEG_WAVES * (STACK_CAP + TG_HASH) + wave * CAND_CAP;
   int32_t* queue = ibase + SEG_WAVES * (STACK_CAP + TG_HASH + CAND_CAP) + wave * QUEUE_CAP;
@@ -2055,7 +2077,7 @@ __global__ __launch_bounds__(64 * SEG_WAVES) __attribute__((amdgpu_waves_per_eu(
     const double* pa = store_pos + 6 * (size_t)ida[slot];
     const double* pb = store_pos + 6 * (size_t)idb[slot];
     for (int k = 0; k < 6; ++k) { a[k] = pa[k]; b[k] = pb[k]; }
-    segment_chunk(env, rob, rtri, stack, cand, queue, stage, a, b, slot, it.chunk, true, it.mask, first_hit, overflow_flag, lane DBG_PASS);
+    segment_chunk(env, rob, rtri, rbox, stack, cand, queue, stage, a, b, slot, it.chunk, true, it.mask, first_hit, overflow_flag, lane DBG_PASS);
   }
 }
 
@@ -2169,6 +2191,7 @@ __device__ __forceinline__ int sq_lemire(unsigned long long word, unsigned long 
 __device__ __attribute__((noinline)) bool sq_path_free(const EnvView& env, const RobotView& rob, const double* rtri, int32_t* stack, int32_t* cand, int32_t* queue,
                              double* stage, const double* a, const double* b, int32_t* fh_lds, int32_t* ovf_lds, int lane,
                              unsigned long long& calls, unsigned long long& samples, bool& fault) {
+  const double* rbox = reinterpret_cast<const double*>(queue + QUEUE_CAP);   // (k_seq_waves: one wave, the boxes lie behind its queue)
   const double parts = edge_parts(a, b);
   const int ns = edge_samples(parts);
   samples += (unsigned long long)ns;
@@ -2224,7 +2247,7 @@ __device__ __attribute__((noinline)) bool sq_path_free(const EnvView& env, const
       for (int u = 0; u < 4 && fh == 0x7fffffff; ++u) {
         const unsigned long long mask = u == 0 ? m0 : (u == 1 ? m1 : (u == 2 ? m2 : m3));
         if (mask == 0ULL) continue;
-        segment_chunk(env, rob, rtri, stack, cand, queue, stage, a, b, 0, c0 + u, true, mask, fh_lds, ovf_lds, lane DBG_PASS);
+        segment_chunk(env, rob, rtri, rbox, stack, cand, queue, stage, a, b, 0, c0 + u, true, mask, fh_lds, ovf_lds, lane DBG_PASS);
         __builtin_amdgcn_wave_barrier();
         fh = *fh_lds;
         if (*ovf_lds) {
@@ -2344,6 +2367,8 @@ __global__ __launch_bounds__(64) void k_seq_waves(SeqArgs A) {
   int32_t* cand = ibase + (STACK_CAP + TG_HASH);
   int32_t* queue = cand + CAND_CAP;
   for (int i = lane; i < A.rob.n_tri * 9; i += 64) rtri[i] = A.rob.tri[i];
+  __builtin_amdgcn_wave_barrier();
+  fill_robot_boxes(rtri, reinterpret_cast<double*>(queue + QUEUE_CAP), A.rob.n_tri, lane, 64);
   __builtin_amdgcn_wave_barrier();
   // ---- the control block, in registers (everything here is the same in every lane)
   int n_nodes = c->n_nodes, iter = c->iter, fn = c->frontier_n, cn = c->closed_n, nb = c->n_borders;
@@ -2777,7 +2802,8 @@ __global__ __launch_bounds__(256) void k_store_write(NodeStoreMut st, const doub
 // ------------------------------------------------------------------ launchers
 size_t collide_lds_bytes(int n_robot_tri, int waves) {
   return (size_t)n_robot_tri * 9 * sizeof(double) + (size_t)waves * STAGE_DOUBLES * sizeof(double) +
-         (size_t)waves * (STACK_CAP + CAND_CAP + QUEUE_CAP + TG_HASH) * sizeof(int32_t);
+         (size_t)waves * (STACK_CAP + CAND_CAP + QUEUE_CAP + TG_HASH) * sizeof(int32_t) +
+         (size_t)n_robot_tri * 6 * sizeof(double);   // + the robot triangles' boxes (edge samples carry no rotation)
 }
 
 void launch_sample_steer(hipStream_t s, const uint64_t* words, const int32_t* parent, const double* node_pos,
