@@ -1532,11 +1532,14 @@ __global__ __launch_bounds__(256) void k_classify(ClassifyArgs A) {
 // filter, exact fp64 re-test of the survivors.  The hits are compacted with __ballot into the wave's LDS slice
 // (no atomics, no hit list in HBM) and classified right away exactly like k_classify does.
 #define QC_WAVES 4
-__device__ __forceinline__ void qc_candidates(const GridView& g, int m, int cell, int lane, const SweepQuery& Q,
-                                              const double* qp, int32_t* h_id, double* h_d, int32_t* h_tree, double* h_pos,
-                                              int& nh) {
+// g + tg: the node grid's and the round's own grid's items of the same cells in ONE flattened pass (lane = candidate):
+// both cell counts arrive with the same round of loads, so do both grids' items
+__device__ __forceinline__ void qc_candidates(const GridView& g, const GridView& tg, int m, int mt, int cell, int lane,
+                                              const SweepQuery& Q, const double* qp, int32_t* h_id, double* h_d,
+                                              int32_t* h_tree, double* h_pos, int& nh) {
   // exclusive prefix of the per-lane item counts
-  int inc = m;
+  const int mm = m + mt;
+  int inc = mm;
   for (int off = 1; off < 64; off <<= 1) {
     const int o = __shfl_up(inc, off);
     if (lane >= off) inc += o;
@@ -1557,9 +1560,12 @@ __device__ __forceinline__ void qc_candidates(const GridView& g, int m, int cell
       if (__shfl(inc, mid) > jj) hi = mid; else lo = mid + 1;
     }
     const int src_cell = __shfl(cell, lo);
-    const int slot = jj - (__shfl(inc, lo) - __shfl(m, lo));
+    const int src_m = __shfl(m, lo);
+    const int slot = jj - (__shfl(inc, lo) - __shfl(mm, lo));
     if (j < total) {
-      it = g.items[(size_t)src_cell * g.bk + slot];
+      const GridItem* src = slot < src_m ? g.items + ((size_t)src_cell * g.bk + slot)
+                                         : tg.items + ((size_t)src_cell * tg.bk + (slot - src_m));
+      it = *src;
       if (it.id < Q.max_id && (Q.tree < 0 || it.tree == Q.tree)) {
         d = dist6(it.p, qp);          // the item carries the node's fp64 position: exact at once
         hit = d < Q.r;
@@ -1694,15 +1700,14 @@ __global__ __launch_bounds__(64 * QC_WAVES) __attribute__((amdgpu_waves_per_eu(Q
         }
         const int cx = lx + (c - q1 * wx), cy = ly + (q1 - q2 * wy), cz = lz + q2;
         cell = (cz * g.ny + cy) * g.nx + cx;
+        // (both counts with one round of loads: the round grid's count array is small and stays in the L2 - going
+        // through its occupancy bits first would put one more dependent load into every sample's chain)
         m = g.cnt[cell];
+        if (tg.cnt) mt = tg.cnt[cell];
         if (m > g.bk) m = g.bk;
-        if (tg.cnt) {
-          const bool maybe = tg.occ ? ((tg.occ[cell >> 5] >> (cell & 31)) & 1u) != 0 : true;
-          if (maybe) { mt = tg.cnt[cell]; if (mt > tg.bk) mt = tg.bk; }
-        }
+        if (mt > tg.bk) mt = tg.bk;
       }
-      qc_candidates(g, m, cell, lane, Q, qp, h_id, h_d, h_tree, h_pos, nh);
-      if (tg.cnt && __any(mt > 0)) qc_candidates(tg, mt, cell, lane, Q, qp, h_id, h_d, h_tree, h_pos, nh);
+      qc_candidates(g, tg, m, mt, cell, lane, Q, qp, h_id, h_d, h_tree, h_pos, nh);
     }
     if (no_g > 0) qc_overflow(g, no_g, lane, Q, qp, h_id, h_d, h_tree, h_pos, nh);
     if (no_t > 0) qc_overflow(tg, no_t, lane, Q, qp, h_id, h_d, h_tree, h_pos, nh);
