@@ -1287,6 +1287,42 @@ void Forest::run_device(int max_waves) {
             "lower workgroups' counts %.1f borders %.1f control block %.1f | dependent/round %.0f\n", k.prof[0] / r / 100.0, k.prof[5] / r,
             (unsigned long long)k.prof[7], k.prof[1] / r / 100.0, k.prof[2] / r / 100.0, k.prof[3] / r / 100.0,
             (double)k.n_unsettled / r);
+#ifdef SFFK_CI_TRACE
+    {
+      std::vector<unsigned long long> tr(4096 * 8);
+      sffk::debug_ci_trace(tr.data());
+      unsigned long long t0 = ~0ULL, tend = 0;
+      for (int w = 0; w < 4096; ++w) if (tr[8 * w]) { t0 = std::min(t0, tr[8 * w]); tend = std::max(tend, tr[8 * w + 7]); }
+      struct It { double start, broad, end; int nc, smp, items, wave; double entry, pre; };
+      std::vector<It> its;
+      int waves = 0, n_pose_items = 0;
+      double pose_us = 0, pose_max = 0;
+      for (int w = 0; w < 4096; ++w) {
+        if (!tr[8 * w]) continue;
+        ++waves;
+        { const unsigned long long pp = tr[8 * w + 6] >> 8; n_pose_items += (int)(pp & 0xff); pose_us += (double)(pp >> 8) / 100.0; if ((pp & 0xff) && (double)(pp >> 8) / 100.0 > pose_max) pose_max = (double)(pp >> 8) / 100.0; tr[8 * w + 6] &= 0xff; }
+        if (!tr[8 * w + 6]) continue;
+        its.push_back({(tr[8 * w + 1] - t0) / 100.0, tr[8 * w + 2] >= tr[8 * w + 1] ? (tr[8 * w + 2] - t0) / 100.0 : -1.0, (tr[8 * w + 3] - t0) / 100.0,
+                       (int)tr[8 * w + 4], (int)(tr[8 * w + 5] & 0xff), (int)tr[8 * w + 6], w, (tr[8 * w] - t0) / 100.0, ((tr[8 * w + 5] >> 8) - t0) / 100.0});
+      }
+      std::sort(its.begin(), its.end(), [](const It& a, const It& b) { return a.end > b.end; });
+      fprintf(stderr, "[sffgpu k_collide_items trace] %d waves, %zu with items, kernel %.1f us (first start -> last end)\n", waves, its.size(), (tend - t0) / 100.0);
+      for (size_t k = 0; k < its.size() && k < 12; ++k)
+        fprintf(stderr, "  wave %4d: entry %.1f preamble done %.1f | items %d | first item: start %.1f broad done %.1f end %.1f us | candidates %d masked samples %d\n",
+                its[k].wave, its[k].entry, its[k].pre, its[k].items, its[k].start, its[k].broad, its[k].end, its[k].nc, its[k].smp);
+      {
+        std::vector<double> e, p, st, en;
+        for (const It& i : its) { e.push_back(i.entry); p.push_back(i.pre); st.push_back(i.start); en.push_back(i.end); }
+        auto q = [](std::vector<double> v, double f) { std::sort(v.begin(), v.end()); return v.empty() ? 0.0 : v[(size_t)(f * (v.size() - 1))]; };
+        fprintf(stderr, "  entry min/med/max %.1f %.1f %.1f | preamble done %.1f %.1f %.1f | first item start %.1f %.1f %.1f | end %.1f %.1f %.1f\n",
+                q(e, 0), q(e, .5), q(e, 1), q(p, 0), q(p, .5), q(p, 1), q(st, 0), q(st, .5), q(st, 1), q(en, 0), q(en, .5), q(en, 1));
+      }
+      double sum_b = 0, sum_n = 0; int nb = 0;
+      for (const It& i : its) if (i.broad >= 0) { sum_b += i.broad - i.start; sum_n += i.end - i.broad; ++nb; }
+      if (nb) fprintf(stderr, "  first items with a broad phase: %d, avg broad %.1f us, avg after-broad %.1f us\n", nb, sum_b / nb, sum_n / nb);
+      fprintf(stderr, "  pose items: %d, avg %.1f us, longest per wave %.1f us\n", n_pose_items, n_pose_items ? pose_us / n_pose_items : 0.0, pose_max);
+    }
+#endif
 #ifdef SFFK_DEBUG_COUNTERS
     unsigned long long g[16];
     sffk::debug_counters(g);

@@ -840,6 +840,11 @@ struct DbgAcc { unsigned long long v[12]; };
 #define QDBG(i, x) do { } while (0)
 #endif
 
+#ifdef SFFK_CI_TRACE
+__device__ unsigned long long g_ci_trace[4096 * 8];   // one launch of k_collide_items: per wave {t0, item start, broad done, end, nc, samples, items, -}
+__device__ unsigned int g_ci_launch;
+__device__ unsigned long long g_ci_tmp[4096 * 2];     // per wave: broad phase done (clock), candidates of its last chunk
+#endif
 // ------------------------------------------------------------------ pose kernel
 #define POSE_WAVES 4
 #define CAND_CAP 256
@@ -1009,6 +1014,9 @@ __device__ void segment_chunk(const EnvView& env, const RobotView& rob, const do
   int nc = collect_candidates(env, qlo, qhi, lane, st, cand, CAND_CAP, &overflow);
   [[maybe_unused]] const unsigned long long t2_ = DBG_T();
   DBG_ADD(5, t2_ - t1_);
+#ifdef SFFK_CI_TRACE
+  if (lane == 0) { const int gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; if (gw < 4096) { g_ci_tmp[2 * gw] = wall_clock64(); g_ci_tmp[2 * gw + 1] = (unsigned long long)nc; } }
+#endif
   DBG_ADD(7, nc);
   if (overflow) {
     if (lane == 0) {   // host re-runs this edge through the pose kernel; first_hit 0 (no sample has index 0) also says so
@@ -1953,6 +1961,9 @@ __global__ __launch_bounds__(64 * SEG_WAVES) __attribute__((amdgpu_waves_per_eu(
                                                                   const float* __restrict__ tx, const float* __restrict__ ty,
                                                                   const float* __restrict__ tz, int n_temps,
                                                                   const int32_t* __restrict__ dev_n) {
+#ifdef SFFK_CI_TRACE
+  const unsigned long long ci_entry = wall_clock64();
+#endif
   if (dev_n) {
     if (dev_n[1]) return;
     n_pose = dev_n[0];
@@ -1997,11 +2008,31 @@ __global__ __launch_bounds__(64 * SEG_WAVES) __attribute__((amdgpu_waves_per_eu(
   int32_t* queue = ibase + SEG_WAVES * (STACK_CAP + TG_HASH + CAND_CAP) + wave * QUEUE_CAP;
   DBG_DECL
   const int W = gridDim.x * SEG_WAVES;
+#ifdef SFFK_CI_TRACE
+  const unsigned long long ci_t0 = ci_entry, ci_pre = wall_clock64();
+  // (block 0 counts the launch at its END: launches are serial, so every block of launch N reads N)
+  const unsigned int ci_seen = __hip_atomic_load(&g_ci_launch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const bool ci_on = ci_seen == SFFK_CI_TRACE;
+  int ci_items = 0;
+  unsigned long long ci_first[4] = {0, 0, 0, 0};
+#endif
   // one loop for both sources of work (the exact test is inlined once): the list's items, or - list overflow -
   // every live pose followed by every live edge with all its chunks
   const int n_slots = n_pose * stride;
   const int E = ran_over ? n_pose + n_slots : M;
-  for (int e = blockIdx.x + gridDim.x * wave; e < E; e += W) {   // (neighbouring items go to different CUs)
+  // Every wave takes one item of its own (neighbouring items go to different CUs); the items beyond one per wave are
+  // handed out as the waves come back for more - 64 groups of waves, one ticket counter each (a single counter would see
+  // every wave's last, failing draw: returning atomics on one word retire at ~90 per us).  A pose or a chunk near the
+  // obstacles takes 25 us, the median item 7: with a fixed second item the kernel's length was "a long item + another".
+  int32_t* const ticket = const_cast<int32_t*>(sub) + (size_t)((blockIdx.x + gridDim.x * wave) & (SFFK_SUBLISTS - 1)) * SFFK_SUB_STRIDE + 1;
+  auto next_item = [&](int e) -> int {
+    if (ran_over) return e + W;
+    int t = 0;
+    if (lane == 0) t = atomicAdd(ticket, 1);
+    t = __builtin_amdgcn_readfirstlane(t);
+    return W + ((blockIdx.x + gridDim.x * wave) & (SFFK_SUBLISTS - 1)) + SFFK_SUBLISTS * t;
+  };
+  for (int e = blockIdx.x + gridDim.x * wave; e < E; e = next_item(e)) {
     int slot, c_lo, c_hi;
     unsigned long long mask = 0ULL;
     if (!ran_over) {
@@ -2021,18 +2052,40 @@ __global__ __launch_bounds__(64 * SEG_WAVES) __attribute__((amdgpu_waves_per_eu(
     if (slot < 0) {
       const int pose = -1 - slot;
       double p[6], R[9], c[3];
+#ifdef SFFK_CI_TRACE
+      const unsigned long long ci_p0 = wall_clock64();
+#endif
       pose_frame(rob, pos6, pose, p, R, c);
       const bool hit = pose_exact(env, rob, rtri, stack, cand, stage, p, R, c, lane);
       if (lane == 0) pose_hit[pose] = hit ? 1 : 0;
+#ifdef SFFK_CI_TRACE
+      ci_first[3] += ((wall_clock64() - ci_p0) << 8) | 1ULL;   // (time << 8 | count)
+#endif
       continue;
     }
     double a[6], b[6];
     for (int k = 0; k < 6; ++k) { a[k] = a6[6 * (size_t)slot + k]; b[k] = b6[6 * (size_t)slot + k]; }
     for (int chunk = c_lo; chunk < c_hi; ++chunk) {
       if (chunk > 0 && first_hit[slot] <= 64 * chunk) break;
+#ifdef SFFK_CI_TRACE
+      const unsigned long long ci_a = wall_clock64();
+#endif
       segment_chunk(env, rob, rtri, rbox, stack, cand, queue, stage, a, b, slot, chunk, !ran_over, mask, first_hit, overflow_flag, lane DBG_PASS);
+#ifdef SFFK_CI_TRACE
+      if (ci_items == 0) { ci_first[0] = ci_a; ci_first[1] = wall_clock64(); ci_first[2] = (unsigned long long)__popcll(mask); }
+      ++ci_items;
+#endif
     }
   }
+#ifdef SFFK_CI_TRACE
+  if (ci_on && lane == 0) {
+    const int gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    unsigned long long* o = g_ci_trace + 8 * (size_t)gw;
+    o[0] = ci_t0; o[1] = ci_first[0]; o[2] = ci_items ? g_ci_tmp[2 * gw] : 0ULL; o[3] = ci_first[1];
+    o[4] = ci_items ? g_ci_tmp[2 * gw + 1] : 0ULL; o[5] = ci_first[2] | (ci_pre << 8); o[6] = (unsigned long long)ci_items | (ci_first[3] << 8); o[7] = wall_clock64();
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&g_ci_launch, 1u);
+#endif
   DBG_FLUSH();
 }
 
@@ -2895,6 +2948,9 @@ void launch_collide_poses(hipStream_t s, const EnvView& env, const RobotView& ro
 #ifdef SFFK_DEBUG_COUNTERS
 void debug_counters(unsigned long long* out16) { (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_dbg), sizeof(unsigned long long) * 16); }
 void debug_counters_query(unsigned long long* out8) { (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_dbg_q), sizeof(unsigned long long) * 8); }
+#endif
+#ifdef SFFK_CI_TRACE
+void debug_ci_trace(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ci_trace), sizeof(unsigned long long) * 4096 * 8); }
 #endif
 
 void launch_clear_build(hipStream_t s, const EnvView& env, double thr, uint32_t* bits, long long n_cells) {
