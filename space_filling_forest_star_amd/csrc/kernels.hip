@@ -2125,7 +2125,16 @@ __global__ __launch_bounds__(64 * SEG_WAVES) __attribute__((amdgpu_waves_per_eu(
   int32_t* queue = ibase + SEG_WAVES * (STACK_CAP + TG_HASH + CAND_CAP) + wave * QUEUE_CAP;
   DBG_DECL
   const int W = gridDim.x * SEG_WAVES;
-  for (int e = blockIdx.x + gridDim.x * wave; e < M; e += W) {
+  // (one item per wave, the rest by tickets to the waves that come back first: see k_collide_items)
+  const int grp = (blockIdx.x + gridDim.x * wave) & (SFFK_SUBLISTS - 1);
+  int32_t* const ticket = const_cast<int32_t*>(sub) + (size_t)grp * SFFK_STAR_SUB + 1;
+  auto next_item = [&]() -> int {
+    int t = 0;
+    if (lane == 0) t = atomicAdd(ticket, 1);
+    t = __builtin_amdgcn_readfirstlane(t);
+    return W + grp + SFFK_SUBLISTS * t;
+  };
+  for (int e = blockIdx.x + gridDim.x * wave; e < M; e = next_item()) {
     const int sl = __popcll(__ballot(sub_incl <= e));
     const int j = e - (__shfl(sub_incl, sl) - __shfl(sub_n, sl));
     const SurvivorItem it = list[(size_t)sl * sub_cap + j];
