@@ -139,14 +139,19 @@ __device__ void round_begin_scalars(const DevForestView& f, DevCtrl* c) {
 }
 
 // ------------------------------------------------------------------ wave begin
-__global__ __launch_bounds__(DF_THREADS) void k_wave_begin(DevForestView f) {
-  __shared__ int any_redraw;
+// Wide: one slot per thread; the workgroup that gets through last writes the control block (the picks themselves are
+// independent of each other - only the astronomically rare rejection redraw needs the words one after the other).
+#define WB_BLOCKS 64
+__global__ __launch_bounds__(256) void k_wave_begin(DevForestView f) {
+  __shared__ int s_last;
   DevCtrl* c = f.ctrl;
   const unsigned long long tb0 = f.profile ? wall_clock64() : 0ULL;
-  if (threadIdx.x == 0) { c->compact_from = 0; c->app_n = 0; }   // (no stale order for the wide follow-up kernels)
-  if (c->halt) return;
+  if (c->halt) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) { c->compact_from = 0; c->app_n = 0; }   // (no stale order for the wide follow-up kernels)
+    return;
+  }
   if (c->in_wave) {   // resuming inside a wave (after the host handled a fault): the active list is in place
-    if (threadIdx.x == 0) round_begin_scalars(f, c);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { c->compact_from = 0; c->app_n = 0; round_begin_scalars(f, c); }
     return;
   }
   // node selection of every slot, src/forest.h:136-151 (non-priority mode): a uniform pick from the frozen frontier,
@@ -158,59 +163,49 @@ __global__ __launch_bounds__(DF_THREADS) void k_wave_begin(DevForestView f) {
   const int32_t* from = use_closed ? f.closed : frontier_now(f);
   int32_t* act = act_now(f);
   const unsigned long long cur = c->cursor;
-  if (threadIdx.x == 0) any_redraw = 0;
-  __syncthreads();
-  // (eight slots per thread and step: the words, then the picked nodes, arrive as two rounds of independent loads -
-  // one slot at a time the kernel is a chain of a hundred dependent round trips)
-  for (int s0 = 0; s0 < n_slots; s0 += 8 * DF_THREADS) {
-    unsigned long long wd[8];
-    int pick[8], node[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int sl = s0 + u * DF_THREADS + threadIdx.x;
-      wd[u] = sl < n_slots ? f.ring[(cur + (unsigned long long)sl) & f.ring_mask] : 0ULL;
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int sl = s0 + u * DF_THREADS + threadIdx.x;
-      pick[u] = sl < n_slots ? lemire_pick(wd[u], (unsigned long long)pool) : -1;
-      node[u] = pick[u] >= 0 ? from[pick[u]] : 0;
-    }
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int sl = s0 + u * DF_THREADS + threadIdx.x;
-      if (sl >= n_slots) continue;
-      if (pick[u] < 0) any_redraw = 1;
-      else { f.slot_node[sl] = node[u]; f.slot_pos[sl] = pick[u]; }
-      act[sl] = sl;                 // every slot starts the wave failing
-    }
+  bool redraw = false;
+  for (int sl = blockIdx.x * 256 + threadIdx.x; sl < n_slots; sl += gridDim.x * 256) {
+    const unsigned long long wd = f.ring[(cur + (unsigned long long)sl) & f.ring_mask];
+    const int pick = lemire_pick(wd, (unsigned long long)pool);
+    if (pick < 0) redraw = true;
+    else { f.slot_node[sl] = from[pick]; f.slot_pos[sl] = pick; }
+    act[sl] = sl;                 // every slot starts the wave failing
   }
+  if (redraw) atomicOr(&f.commit_seq[2], 1);
+  __threadfence();                // (this workgroup's slots are written before it counts itself through)
   __syncthreads();
-  if (threadIdx.x == 0) {
-    unsigned long long used = (unsigned long long)n_slots;
-    if (any_redraw) {   // (probability ~ pool / 2^64 per pick) redo the picks one after another, words as they come
-      unsigned long long at = cur;
-      for (int s = 0; s < n_slots; ++s) {
-        int pick;
-        do { pick = lemire_pick(f.ring[at & f.ring_mask], (unsigned long long)pool); ++at; } while (pick < 0);
-        f.slot_node[s] = from[pick];
-        f.slot_pos[s] = pick;
-      }
-      used = at - cur;
-      c->redraws += 1;
+  if (threadIdx.x == 0) s_last = atomicAdd(&f.commit_seq[1], 1) == (int)gridDim.x - 1;
+  __syncthreads();
+  if (!s_last || threadIdx.x != 0) return;
+  unsigned long long used = (unsigned long long)n_slots;
+  if (__hip_atomic_load(&f.commit_seq[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+    // (probability ~ pool / 2^64 per pick) redo the picks one after another, words as they come
+    unsigned long long at = cur;
+    for (int s = 0; s < n_slots; ++s) {
+      int pick;
+      do { pick = lemire_pick(f.ring[at & f.ring_mask], (unsigned long long)pool); ++at; } while (pick < 0);
+      f.slot_node[s] = from[pick];
+      f.slot_pos[s] = pick;
     }
-    c->cursor = cur + used;
-    c->n_slots = n_slots;
-    c->act_cnt = n_slots;
-    c->use_closed = use_closed ? 1 : 0;
-    c->round = 0;
-    c->in_wave = 1;
-    c->waves += 1;
-    round_begin_scalars(f, c);
-    if (f.profile) c->wprof[6] += wall_clock64() - tb0;
+    used = at - cur;
+    c->redraws += 1;
   }
+  f.commit_seq[1] = 0;
+  f.commit_seq[2] = 0;
+  c->compact_from = 0;
+  c->app_n = 0;
+  c->cursor = cur + used;
+  c->n_slots = n_slots;
+  c->act_cnt = n_slots;
+  c->use_closed = use_closed ? 1 : 0;
+  c->round = 0;
+  c->in_wave = 1;
+  c->waves += 1;
+  round_begin_scalars(f, c);
+  if (f.profile) c->wprof[6] += wall_clock64() - tb0;
 }
 
+// ------------------------------------------------------------------ the commit of one round
 // border de-duplication: open addressing on the key (n1 << 32 | n2 + 1); the value is a stamp (epoch << 32 | sample)
 // that only ever decreases, so among the events of one round the smallest sample index owns the key and every
 // entry of an earlier round (smaller epoch) beats them all
@@ -705,10 +700,24 @@ __device__ __forceinline__ int append_one(const ResolveArgs& A, int i, int& slot
   const int act_cnt = c->app_act_cnt;
   const int32_t* act_old = c->app_act_sel ? f.act_slot2 : f.act_slot;
   int32_t* act_new = c->app_act_sel ? f.act_slot : f.act_slot2;
+  // the wave is over with this commit (no next round): the slots still on the list are exhausted - each claims its node
+  // (atomicMin of its place in the list: a node held by several slots moves to the closed list once, at its first slot,
+  // src/forest.h:160-178) and parks it for k_wave_end, which would otherwise spend a pass of its one workgroup on this
+  const bool wave_over = c->n_act == 0 && !c->halt && c->in_wave && !c->use_closed;
+  auto claim = [&](int e, int slot) {
+    const int nd = f.slot_node[slot];
+    atomicMin(&f.claim[nd], e);
+    f.ulist[e] = nd;
+  };
+  if (wave_over && i == 0) f.ctrl->claims_done = 1;
   if (i >= n) {
     // the slots the iteration cap kept out of the committed round stay on the list, behind the still-failing ones
     // (the cap has been reached: they never draw again)
-    if (i < act_cnt) act_new[(c->act_cnt - (act_cnt - n)) + (i - n)] = act_old[i];
+    if (i < act_cnt) {
+      const int e = (c->act_cnt - (act_cnt - n)) + (i - n), slot = act_old[i];
+      act_new[e] = slot;
+      if (wave_over) claim(e, slot);
+    }
     return -1;
   }
   const unsigned long long w = f.w_acc[i >> 6];
@@ -716,6 +725,7 @@ __device__ __forceinline__ int append_one(const ResolveArgs& A, int i, int& slot
   if (!((w >> (i & 63)) & 1ULL)) {
     slot_out = act_old[i];
     act_new[i - rank] = slot_out;       // not accepted: the slot tries again (rank = accepted samples before it)
+    if (wave_over) claim(i - rank, slot_out);
     return i - rank;
   }
   if (A.star) return -1;                // SFF*: k_star_apply has made the accepted samples nodes
@@ -792,7 +802,8 @@ __global__ __launch_bounds__(DF_THREADS) void k_wave_end(DevForestView f, const 
     // (rm_words is all zero between waves: k_frontier_compact clears the words it has consumed.  Loads in batches of
     // eight independent ones per thread; the failing slots' nodes are parked in ulist for the later passes.)
     int32_t* nodes = f.ulist;
-    for (int e0 = 0; e0 < n_fail; e0 += 8 * DF_THREADS) {
+    const bool have_claims = c->claims_done != 0;   // (posted by the wave's last append; not after a resumed or empty wave)
+    for (int e0 = 0; e0 < n_fail && !have_claims; e0 += 8 * DF_THREADS) {
       int sl[8], nd[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) { const int e = e0 + u * DF_THREADS + threadIdx.x; sl[u] = e < n_fail ? act[e] : -1; }
@@ -851,8 +862,7 @@ __global__ __launch_bounds__(DF_THREADS) void k_wave_end(DevForestView f, const 
     }
     __syncthreads();
     if (clk) tw[3] = wall_clock64();
-    for (int e = threadIdx.x; e < n_fail; e += DF_THREADS)     // (claims cleared only now: every slot of a node saw them)
-      f.claim[nodes[e]] = 0x7fffffff;
+    // (the claims are cleared by k_frontier_compact - wide - once every slot of a node has seen them)
     // exclusive prefix of the removed positions per 64-entry word (k_frontier_compact shifts by it): every thread
     // sums a contiguous run of words, the runs are scanned through LDS
     __threadfence_block();
@@ -926,6 +936,8 @@ __global__ __launch_bounds__(DF_THREADS) void k_wave_end(DevForestView f, const 
       for (int t = 0; t < R; ++t) f.claim[t] = 0x7fffffff;
       c->solved = reached == R ? 1 : 0;
     }
+    c->claims_done = 0;
+    c->clear_n = from_closed ? 0 : n_fail;
     const bool budget = f.node_budget > 0 && c->n_nodes >= f.node_budget;
     c->terminated = (c->solved || c->iter >= f.max_iterations || budget) ? 1 : 0;
     c->halt = c->terminated;
@@ -946,6 +958,8 @@ __global__ __launch_bounds__(DF_THREADS) void k_wave_end(DevForestView f, const 
 // order-preserving removal of the marked positions: old buffer -> the other one (selected by k_wave_end already)
 __global__ __launch_bounds__(256) void k_frontier_compact(DevForestView f) {
   const DevCtrl* c = f.ctrl;
+  // the exhausted slots' claims of the wave that just ended (k_wave_end has looked at them)
+  for (int e = blockIdx.x * 256 + threadIdx.x; e < c->clear_n; e += gridDim.x * 256) f.claim[f.ulist[e]] = 0x7fffffff;
   const int n = c->compact_from;
   if (n <= 0) return;                       // nothing was removed in this wave (or the kernel ran before a wave ended)
   const int32_t* src = c->front_sel ? f.frontier : f.frontier2;   // (front_sel already names the NEW buffer)
@@ -1015,7 +1029,7 @@ __global__ __launch_bounds__(256) void k_border_rehash(DevForestView f, int n) {
 }
 
 void launch_wave_begin(hipStream_t s, const DevForestView& f) {
-  hipLaunchKernelGGL(k_wave_begin, dim3(1), dim3(DF_THREADS), 0, s, f);
+  hipLaunchKernelGGL(k_wave_begin, dim3(WB_BLOCKS), dim3(256), 0, s, f);
 }
 void launch_commit(hipStream_t s, const ResolveArgs& a, int n_bound, const StarLaunch* star, const SampleLaunch* next) {
   if (n_bound <= 0) return;

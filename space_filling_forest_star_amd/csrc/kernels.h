@@ -119,6 +119,8 @@ struct DevCtrl {
   int32_t act_sel, act_cnt; // which of the two active-slot lists is current; its length (>= n_act: the still-failing slots)
   int32_t app_n, app_N0, app_fn0, app_act_sel;   // the commit k_append has to apply (app_n = 0: none)
   int32_t iter0_app, app_act_cnt;
+  int32_t claims_done;      // the wave's last k_append(_sample) has posted the exhausted slots' claims (k_wave_end skips that pass)
+  int32_t clear_n;          // claims k_frontier_compact has to clear (the failing slots' nodes are parked in ulist)
   unsigned long long cursor;        // engine words consumed so far
   unsigned long long words_base;    // cursor at which the current round's sample words start
   unsigned long long collide_calls, path_free_calls, nn_queries;          // reference-equivalent counters
@@ -365,7 +367,7 @@ struct DevForestView {
   // number (commit_seq[0] + 1) in its upper half, so nothing is ever cleared and a stale word is never taken for news.
   int32_t* ustate32;           // per sample: (seq << 2 | state), state 1 rejected / 2 accepted / 3 rejected + border event
   unsigned long long* wg_pub;  // SFFK_PUB_WORDS words per workgroup of 64 samples (one 128-byte line), see k_commit
-  int32_t* commit_seq;         // [0] = launches that reached their end so far
+  int32_t* commit_seq;         // [0] = launches that reached their end so far; [1] workgroups of k_wave_begin that are through, [2] one of them met a redraw
   unsigned long long* kc_trace; int32_t kc_trace_round;   // SFFGPU_KC_TRACE=<round>: 8 clock reads per workgroup of that round's k_commit
   int32_t profile;             // SFFGPU_PROFILE: the single-workgroup kernels read their phase clocks (a clock read is a scalar
                                // memory round trip: a dozen of them is microseconds)
