@@ -499,6 +499,11 @@ __global__ __launch_bounds__(1024) void k_commit(ResolveArgs A, int n_bound) {
   // ---- 3. node ids: N0 + accepted samples before, in slot order
   unsigned long long part = 0;
   if ((int)threadIdx.x < b) part = kc_wait(f.wg_pub + (size_t)threadIdx.x * SFFK_PUB_WORDS + KC_ACC, seq, A.fault_pending);
+  // (the last workgroup: the lower workgroups' counters were published before their counts - requested now, looked at
+  // when the control block is written)
+  unsigned long long early[7] = {0, 0, 0, 0, 0, 0, 0};
+  if (last && (int)threadIdx.x < b)
+    for (int q = 0; q < 7; ++q) early[q] = kc_load(f.wg_pub + (size_t)threadIdx.x * SFFK_PUB_WORDS + KC_CNT + q);
   const int acc_pref = (int)kc_block_sum(part, &s_sum);
   if (threadIdx.x == 0) {
     f.acc_pref[b] = acc_pref;
@@ -537,11 +542,13 @@ __global__ __launch_bounds__(1024) void k_commit(ResolveArgs A, int n_bound) {
       atomicMin(&f.bt_val[e_h], stamp_hi | (unsigned long long)(uint32_t)e_i);
     }
     if (threadIdx.x < 64) {
-      __threadfence();                         // the stamps are in the table before the word says so
+      if (we != 0ULL) __threadfence();         // the stamps are in the table before the word says so
       if (threadIdx.x == 0) kc_publish(pub + KC_POSTED, seq, 1u);
     }
     KC_TRACE(3);
-    if ((int)threadIdx.x < b) (void)kc_wait(f.wg_pub + (size_t)threadIdx.x * SFFK_PUB_WORDS + KC_POSTED, seq, A.fault_pending);
+    // (an event's fate needs every lower workgroup's stamps; the last workgroup without events of its own is only here
+    // for the totals)
+    if (we != 0ULL && (int)threadIdx.x < b) (void)kc_wait(f.wg_pub + (size_t)threadIdx.x * SFFK_PUB_WORDS + KC_POSTED, seq, A.fault_pending);
     __syncthreads();
     KC_TRACE(5);
     bool own = false;
@@ -607,9 +614,7 @@ __global__ __launch_bounds__(1024) void k_commit(ResolveArgs A, int n_bound) {
   unsigned long long tot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if ((int)threadIdx.x < b) {   // (every lower workgroup has published its counters long ago: one batch of loads)
     const unsigned long long* pp = f.wg_pub + (size_t)threadIdx.x * SFFK_PUB_WORDS;
-    unsigned long long w[7];
-    for (int q = 0; q < 7; ++q) w[q] = kc_load(pp + KC_CNT + q);
-    for (int q = 0; q < 7; ++q) tot[q] = (unsigned)(w[q] >> 32) == seq ? (unsigned)w[q] : kc_wait(pp + KC_CNT + q, seq, A.fault_pending);
+    for (int q = 0; q < 7; ++q) tot[q] = (unsigned)(early[q] >> 32) == seq ? (unsigned)early[q] : kc_wait(pp + KC_CNT + q, seq, A.fault_pending);
   }
   // (a fault is raised before its workgroup publishes anything: with every lower workgroup's words in, the flag is final)
   if (threadIdx.x == 1023) s_ev_total = __hip_atomic_load(A.fault_pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
