@@ -1618,7 +1618,10 @@ __device__ __forceinline__ void qc_overflow(const GridView& g, int no, int lane,
   }
 }
 
-#define QC_SURV 64  // survivors of a sample gathered in LDS before they are appended (one atomic)
+#define QC_SURV 64  // survivors of a sample gathered in LDS before they are appended (one atomic per kind)
+#ifndef QC_HEAVY
+#define QC_HEAVY 40 // masked samples from which a chunk counts as a heavy item of the exact kernel (poses always do)
+#endif
 #define QC_TAB 128  // (task, chunk) pairs of a sample unfolded at a time
 #ifndef QC_OCC
 #define QC_OCC 7   // wavefronts per SIMD the register allocation aims at (59 VGPRs).  Measured 5 ... 8: 42 / 40.3 / 39.3 / 40.9 us -
@@ -1813,11 +1816,28 @@ __global__ __launch_bounds__(64 * QC_WAVES) __attribute__((amdgpu_waves_per_eu(Q
     auto flush = [&]() {
       [[maybe_unused]] const unsigned long long f0 = DBG_T();
       QDBG(6, n_buf);
-      int base = 0;
-      if (lane == 0) base = atomicAdd(A.sub + sub_list * SFFK_SUB_STRIDE, n_buf);
-      base = __shfl(base, 0);
-      for (int o = lane; o < n_buf; o += 64) {
-        if (base + o < sub_cap) list[(size_t)sub_list * sub_cap + base + o] = buf[o];
+      // heavy items (poses, chunks with most of their samples masked: 10-25 us of exact tests) go to the front half of
+      // the sub-list, light ones (median 7 us) to the back half: the exact kernel starts the heavy ones first - every
+      // wave takes one item and comes back for more, so its length is then the longest item, not "a light one + a long one"
+      const bool mine = lane < n_buf;                 // (n_buf <= 64)
+      SurvivorItem it = mine ? buf[lane] : SurvivorItem{0, 0, 0ULL};
+      const bool hv = mine && (it.slot < 0 || __popcll(it.mask) >= QC_HEAVY);
+      const unsigned long long hm = __ballot(hv), lm = __ballot(mine && !hv);
+      const unsigned long long below = (1ULL << lane) - 1ULL;
+      int bh = 0, bl = 0;
+      if (lane == 0) {
+        if (hm) bh = atomicAdd(A.sub + sub_list * SFFK_SUB_STRIDE, __popcll(hm));
+        if (lm) bl = atomicAdd(A.sub + sub_list * SFFK_SUB_STRIDE + 2, __popcll(lm));
+      }
+      bh = __shfl(bh, 0); bl = __shfl(bl, 0);
+      const int half = sub_cap / 2;
+      if (hv) {
+        const int at = bh + __popcll(hm & below);
+        if (at < half) list[(size_t)sub_list * sub_cap + at] = it;
+        else A.ctrl[3] = 1;
+      } else if (mine) {
+        const int at = bl + __popcll(lm & below);
+        if (at < sub_cap - half) list[(size_t)sub_list * sub_cap + half + at] = it;
         else A.ctrl[3] = 1;
       }
       n_buf = 0;
@@ -1986,15 +2006,18 @@ __global__ __launch_bounds__(64 * SEG_WAVES) __attribute__((amdgpu_waves_per_eu(
   double* stage = rtri + (size_t)rob.n_tri * 9 + (size_t)wave * STAGE_DOUBLES;
   int32_t* ibase = reinterpret_cast<int32_t*>(rtri + (size_t)rob.n_tri * 9 + (size_t)SEG_WAVES * STAGE_DOUBLES);
   // the sub-lists' fill counts, one per lane (SFFK_SUBLISTS == 64), and their running sum
-  const int sub_cap = items_cap / SFFK_SUBLISTS;
-  int sub_n = sub[lane * SFFK_SUB_STRIDE];
-  sub_n = sub_n < sub_cap ? sub_n : sub_cap;
-  int sub_incl = sub_n;
+  const int sub_cap = items_cap / SFFK_SUBLISTS, sub_half = sub_cap / 2;
+  // (every sub-list: heavy items in its front half, light ones in its back half, one counter each)
+  int sub_n = sub[lane * SFFK_SUB_STRIDE], sub_nl = sub[lane * SFFK_SUB_STRIDE + 2];
+  sub_n = sub_n < sub_half ? sub_n : sub_half;
+  sub_nl = sub_nl < sub_cap - sub_half ? sub_nl : sub_cap - sub_half;
+  int sub_incl = sub_n, sub_incl_l = sub_nl;
   for (int off = 1; off < 64; off <<= 1) {
-    const int o = __shfl_up(sub_incl, off);
-    if (lane >= off) sub_incl += o;
+    const int o = __shfl_up(sub_incl, off), ol = __shfl_up(sub_incl_l, off);
+    if (lane >= off) { sub_incl += o; sub_incl_l += ol; }
   }
-  const int M = __shfl(sub_incl, 63);
+  const int MH = __shfl(sub_incl, 63);
+  const int M = MH + __shfl(sub_incl_l, 63);
   const bool ran_over = ctrl[3] != 0;
   if (blockIdx.x == 0 && threadIdx.x == 0) ctrl[2] = M;   // (statistics)
   if ((M <= 0 && !ran_over) || env.n_tri == 0) return;
@@ -2036,9 +2059,16 @@ __global__ __launch_bounds__(64 * SEG_WAVES) __attribute__((amdgpu_waves_per_eu(
     int slot, c_lo, c_hi;
     unsigned long long mask = 0ULL;
     if (!ran_over) {
-      const int sl = __popcll(__ballot(sub_incl <= e));   // the sub-list item e lies in
-      const int j = e - (__shfl(sub_incl, sl) - __shfl(sub_n, sl));
-      const SurvivorItem it = list[(size_t)sl * sub_cap + j];
+      size_t at;                                          // the heavy items first, then the light ones
+      if (e < MH) {
+        const int sl = __popcll(__ballot(sub_incl <= e));   // the sub-list item e lies in
+        at = (size_t)sl * sub_cap + (e - (__shfl(sub_incl, sl) - __shfl(sub_n, sl)));
+      } else {
+        const int e2 = e - MH;
+        const int sl = __popcll(__ballot(sub_incl_l <= e2));
+        at = (size_t)sl * sub_cap + sub_half + (e2 - (__shfl(sub_incl_l, sl) - __shfl(sub_nl, sl)));
+      }
+      const SurvivorItem it = list[at];
       slot = it.slot; c_lo = it.chunk; c_hi = it.chunk + 1; mask = it.mask;
     } else if (e < n_pose) {
       if ((live_flags[e] & 3) != 1) continue;

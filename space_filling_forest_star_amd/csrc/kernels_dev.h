@@ -123,7 +123,9 @@ __device__ __forceinline__ void sample_steer_one(int tid, int i, int slot, const
     // placeholders for the store entries between the permanent nodes and the 4-aligned temporaries
     if (tid < n) tmp.cnt[tid] = 0;
     if (tid < 32) tmp.ctrl[tid] = 0;
-    if (tmp.sub && tid < SFFK_SUBLISTS) { tmp.sub[tid * SFFK_SUB_STRIDE] = 0; tmp.sub[tid * SFFK_SUB_STRIDE + 1] = 0; }   // (+ the exact kernel's item tickets)
+    if (tmp.sub && tid < SFFK_SUBLISTS) {   // heavy items, the exact kernel's item tickets, light items
+      tmp.sub[tid * SFFK_SUB_STRIDE] = 0; tmp.sub[tid * SFFK_SUB_STRIDE + 1] = 0; tmp.sub[tid * SFFK_SUB_STRIDE + 2] = 0;
+    }
     if (tid < tmp.base - tmp.n_perm) {
       const float nanv = __int_as_float(0x7fc00000);
       const size_t o = (size_t)tmp.n_perm + tid;
