@@ -696,7 +696,9 @@ __global__ __launch_bounds__(1024) void k_commit(ResolveArgs A, int n_bound) {
 // (src/forest.h:353-367).  Runs although the NEXT round may already be halted: this commit is final.
 // One slot's share of the append.  Returns the slot's index in the NEXT round's active list (-1: none - accepted, or
 // nothing was committed) and the slot itself.
-__device__ __forceinline__ int append_one(const ResolveArgs& A, int i, int& slot_out) {
+// part: 0 = everything, 1 = only the accepted sample's node, 2 = only the next round's list (+ the claims of a wave that
+// is over) - k_append_sample runs the two parts in different workgroups.
+__device__ __forceinline__ int append_one(const ResolveArgs& A, int i, int& slot_out, int part = 0) {
   const DevForestView& f = A.f;
   const DevCtrl* c = f.ctrl;
   const int n = c->app_n;
@@ -714,11 +716,11 @@ __device__ __forceinline__ int append_one(const ResolveArgs& A, int i, int& slot
     atomicMin(&f.claim[nd], e);
     f.ulist[e] = nd;
   };
-  if (wave_over && i == 0) f.ctrl->claims_done = 1;
+  if (wave_over && i == 0 && part != 1) f.ctrl->claims_done = 1;
   if (i >= n) {
     // the slots the iteration cap kept out of the committed round stay on the list, behind the still-failing ones
     // (the cap has been reached: they never draw again)
-    if (i < act_cnt) {
+    if (i < act_cnt && part != 1) {
       const int e = (c->act_cnt - (act_cnt - n)) + (i - n), slot = act_old[i];
       act_new[e] = slot;
       if (wave_over) claim(e, slot);
@@ -728,12 +730,13 @@ __device__ __forceinline__ int append_one(const ResolveArgs& A, int i, int& slot
   const unsigned long long w = f.w_acc[i >> 6];
   const int rank = f.acc_pref[i >> 6] + __popcll(w & ((1ULL << (i & 63)) - 1ULL));
   if (!((w >> (i & 63)) & 1ULL)) {
+    if (part == 1) return -1;
     slot_out = act_old[i];
     act_new[i - rank] = slot_out;       // not accepted: the slot tries again (rank = accepted samples before it)
     if (wave_over) claim(i - rank, slot_out);
     return i - rank;
   }
-  if (A.star) return -1;                // SFF*: k_star_apply has made the accepted samples nodes
+  if (A.star || part == 2) return -1;   // SFF*: k_star_apply has made the accepted samples nodes
   const int N0 = c->app_N0, fn0 = c->app_fn0;
   int32_t* const frontier = frontier_now(f);
   const int id = N0 + rank;
@@ -769,10 +772,15 @@ __global__ __launch_bounds__(256) void k_append(ResolveArgs A) {
 // writes nowhere: its centre is a node of an earlier wave, its temporaries lie behind the node arrays.  The append's
 // inputs (newpos, pdist, parent of the committed round) are the sampling's outputs: the rounds of a wave alternate
 // between two sets of these arrays (A = the committed round's, P = the next round's).
+// The first half of the workgroups creates the accepted samples' nodes, the second half writes the list and samples: a
+// wavefront that had to do both would run the two chains of dependent loads one after the other.
 __global__ __launch_bounds__(256) void k_append_sample(ResolveArgs A, SampleLaunch P) {
-  const int tid = blockIdx.x * 256 + threadIdx.x;
+  const int nb = gridDim.x >> 1;
+  const bool sampler = (int)blockIdx.x >= nb;
+  const int tid = ((int)blockIdx.x - (sampler ? nb : 0)) * 256 + threadIdx.x;
   int slot;
-  const int next = append_one(A, tid, slot);
+  if (!sampler) { (void)append_one(A, tid, slot, 1); return; }
+  const int next = append_one(A, tid, slot, 2);
   sample_steer_one(tid, next, slot, P);
 }
 
@@ -1040,7 +1048,7 @@ void launch_commit(hipStream_t s, const ResolveArgs& a, int n_bound, const StarL
   if (n_bound <= 0) return;
   hipLaunchKernelGGL(k_commit, dim3((n_bound + 63) / 64), dim3(1024), 0, s, a, n_bound);
   if (a.star && star) launch_star_stage(s, a, n_bound, *star);
-  if (next) hipLaunchKernelGGL(k_append_sample, dim3((n_bound + 255) / 256), dim3(256), 0, s, a, *next);
+  if (next) hipLaunchKernelGGL(k_append_sample, dim3(2 * ((n_bound + 255) / 256)), dim3(256), 0, s, a, *next);
   else hipLaunchKernelGGL(k_append, dim3((n_bound + 255) / 256), dim3(256), 0, s, a);
 }
 void launch_wave_end(hipStream_t s, const DevForestView& f, const int32_t* grid_ovf, const int32_t* tgrid_ovf,
