@@ -148,7 +148,7 @@ typedef struct {
   uint64_t star_members;     /* ... k-nearest members (choose-parent / rewire candidates) they looked at */
   uint64_t star_rewires;     /* ... and rewires they applied (src/forest.h:336-348) */
   uint64_t host_fallback_waves; /* device engine: waves finished on the host-replay engine after a device list overflowed */
-  double commit_ms;          /* device time of the in-order commit of all rounds (k_decide, k_resolve, the SFF* stage,
+  double commit_ms;          /* device time of the in-order commit of all rounds (k_commit, the SFF* stage,
                                 k_append): the part every rank of a sharded forest repeats; HIP events on the eagerly
                                 launched waves, scaled like sweep_ms */
   double exchange_ms;        /* sharded forests: pack + all-gather + unpack of the answer records of all rounds */

@@ -6,7 +6,7 @@
 //   * looks its k nearest up among the store AND those earlier samples (:317),
 //   * reads each member's DistanceToRoot as the earlier samples' rewires left it (:322, :337),
 //   * rewires members itself (:336-348) - a later sample of the round may rewire the same node again.
-// Acceptance (who becomes a node, with which id) does not depend on any cost, so k_decide / k_resolve settle it first,
+// Acceptance (who becomes a node, with which id) does not depend on any cost, so k_commit settles it first,
 // exactly as for plain SFF.  The costs are then the unique fixed point of
 //     view(i, x)  = proposal of the latest j < i whose rewire of x is active, else cost(x)            (per-node lists)
 //     result(i)   = choose-parent / rewire of sample i evaluated on its views                          (one wavefront)
@@ -368,14 +368,14 @@ __global__ __launch_bounds__(256) void k_star_knn(ResolveArgs A, GridView g, Gri
       if (have >= k && topk_worst(t, k, have) <= covered) break;
       if (cx - rr <= 0 && cy - rr <= 0 && cz - rr <= 0 && cx + rr >= g.nx - 1 && cy + rr >= g.ny - 1 && cz + rr >= g.nz - 1) break;
     }
-    // ---- the samples accepted earlier in this round (ranks below this one's, k_resolve's list) of the same tree: not
+    // ---- the samples accepted earlier in this round (ranks below this one's, k_commit's list) of the same tree: not
     // farther than the k-th store node - or, while the store holds fewer than k nodes of the tree, all of them
     if (S.dbg) dbg_t2 = wall_clock64();
     if (r > 0) {
       const bool all = have < k;
       const double limit = all ? 1.0e300 : topk_worst(t, k, have);
       if (r <= 64 * STAR_MATE_U) {
-        // k_resolve's list of the accepted samples: every rank's sample and tree are requested up front (two trips to
+        // k_commit's list of the accepted samples: every rank's sample and tree are requested up front (two trips to
         // memory whatever the length), the few of the same tree are compacted in LDS and measured a batch at a time
         int sidv[STAR_MATE_U], trv[STAR_MATE_U];
 #pragma unroll

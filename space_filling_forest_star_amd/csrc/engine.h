@@ -63,7 +63,7 @@ struct HitRec {
   bool operator<(const HitRec& o) const { return d < o.d || (d == o.d && id < o.id); }
 };
 
-// T_COMMIT: the in-order commit of a round (k_decide / k_resolve [/ the SFF* stage] / k_append) - the part every rank
+// T_COMMIT: the in-order commit of a round (k_commit [/ the SFF* stage] / k_append_sample) - the part every rank
 // of a sharded forest repeats; T_EXCHANGE: pack + all-gather + unpack of the answer records
 enum TimerKind { T_SWEEP = 0, T_COLLIDE = 1, T_SAMPLE = 2, T_COMMIT = 3, T_EXCHANGE = 4, T_KINDS = 5 };
 

@@ -7,7 +7,7 @@
 // (Forest::nodes, frontier, borders ...) is refreshed lazily: only when a getter, the fault path or a caller of the
 // round protocol needs it.
 //
-// Faults: a round in which a bounded device list overflowed is not committed by k_resolve; the host downloads the
+// Faults: a round in which a bounded device list overflowed is not committed by k_commit; the host downloads the
 // state, finishes that wave on the host path of forest.cpp (unbounded lists) and uploads the result.  A full border
 // table or node / border arrays that need to grow only cost a reallocation on the host and a resumed wave.
 #include <algorithm>
@@ -864,7 +864,7 @@ void Forest::dev_enqueue_round_commit(const void* recv_dev, bool sample_next) {
   c.timing_on = dev.round_timing;
   c.time_begin(T_COMMIT);
   if (cfg.optimize) {
-    // SFF*: k nearest + member edges + the rewire fixed point for the accepted samples, between k_resolve and k_append
+    // SFF*: k nearest + member edges + the rewire fixed point for the accepted samples, between k_commit and k_append
     sffk::StarLaunch sl{};
     sl.g = c.gridv;
     sl.tg = c.tgridv;

@@ -102,7 +102,7 @@ struct RobotView {
 };
 
 // ---- device-resident forest (devforest.hip): the round loop of SpaceForest::Solve with the in-order commit on the
-// GPU.  DevCtrl lives in HBM, is advanced by single-workgroup kernels (k_wave_begin / k_resolve / k_wave_end) and is
+// GPU.  DevCtrl lives in HBM, is advanced by the last workgroup of k_wave_begin / k_commit and by the one-workgroup k_wave_end and is
 // copied to the host once per wave.  Every round kernel reads the number of samples from it (the host launches
 // grids sized for the wave), and returns at once when `halt` is set (solver terminated, or a fault the host has
 // to handle: a device list overflowed and the round must be redone on the host path).
@@ -374,7 +374,7 @@ struct DevForestView {
 };
 #define SFFK_PUB_WORDS 16
 // ---- SFF* (optimize = true) on the device engine: choose-parent + rewire of src/forest.h:307-351 (devstar.hip).
-// The accept / reject logic does not depend on costs, so k_decide / k_resolve settle WHICH samples of the round become
+// The accept / reject logic does not depend on costs, so k_commit settles WHICH samples of the round become
 // nodes (and their ids) exactly as for plain SFF; then, for the accepted samples only:
 //   k_star_knn    one wavefront per accepted sample: its k = floor(2e log10(#nodes at its turn)) nearest nodes of its
 //                 tree among the store AND the samples accepted earlier in the round (replaces knnSearch, :317); every
@@ -407,7 +407,7 @@ struct StarView {
   double* prop;                // per pair: proposed DistanceToRoot when the rewire is active (:336), +inf otherwise
   double* best; int32_t* psel; double* dcl;   // per sample: cost, chosen parent (node id), distance to it (:320-329)
   unsigned long long* cnt;     // per sample: {Collide calls, isPathFree calls} of its choose-parent / rewire loops
-  int32_t* acc_sample;         // rank among the accepted samples -> sample (k_resolve)
+  int32_t* acc_sample;         // rank among the accepted samples -> sample (k_commit)
   int32_t* hdr;                // {accepted samples, skip, border entries of the round, first of them, fault}
   int32_t* changed;            // SFFK_STAR_PASSES flags: pass t changed something / still waits for an edge
   // member edges, answered LAZILY: edge slot = (sample * KC + m) * 2 + dir (0: new -> member :323, 1: member -> new :336).
@@ -416,7 +416,7 @@ struct StarView {
   int32_t* ew; int32_t* ens; int32_t* first_hit; int32_t* seg_ovf; int32_t* ida; int32_t* idb;
   int32_t* sub;                // survivor sub-list counters: SFFK_STAR_PASSES x SFFK_SUBLISTS x SFFK_STAR_SUB ints
   void* items; int items_cap;  // SurvivorItem list of the pass in flight (SFFK_SUBLISTS equal sub-lists)
-  // border entries created by the round (k_resolve): the two nodes' costs are read "at the time of the sample"
+  // border entries created by the round (k_commit): the two nodes' costs are read "at the time of the sample"
   int32_t* ev_sample; int32_t* ev_nb; int32_t* ev_ex; double* ev_dist;
   unsigned long long* acc;     // 64 lines x SFFK_STAR_ACC: Collide calls, isPathFree calls, rounds, passes, members, rewires
   DevCtrl* backup;             // the control block as a rolled-back round leaves it (restored when the star stage faults)
@@ -425,7 +425,7 @@ struct StarView {
   // rewire (also those a later sample of the round overrides); hist[0] of hist_ctl = entries, [1] = ran over
   int32_t* hist; int32_t* hist_ctl; int hist_cap;
 };
-// per-sample verdicts of k_decide
+// per-sample verdicts (A.code)
 #define SFFK_DEPENDS 0     // (host engine's k_settle: the neighbour walk reached a sample of the same round first)
 #define SFFK_REJECTED 1
 #define SFFK_OUTSIDE 2
@@ -440,7 +440,7 @@ struct ResolveArgs {
   const double* newpos; const double* pdist; const int32_t* parent; uint8_t* code;
   const uint8_t* in_lim; int32_t* rec_flags; uint8_t* pose_hit;
   int32_t* rec_nnb; int32_t* rec_nb; int32_t* rec_meta; int32_t* seg_ns; int32_t* first_hit;
-  unsigned long long* bulk;    // counters of the samples k_decide decided (7 words)
+  unsigned long long* bulk;    // (host engine's k_settle: counters of the samples it settled, 7 words)
   const int32_t* round_ctrl;   // the round's scratch block ([2] = work items)
   int32_t* fault_pending;
   int star;                    // SFF*: the accepted samples are appended by the star stage (S below)
@@ -495,7 +495,7 @@ void launch_star_stage(hipStream_t s, const ResolveArgs& a, int n_bound, const S
 // exact collision test of the member-edge chunks a star pass could not answer from the clearance bits (kernels.hip)
 void launch_star_exact(hipStream_t s, const EnvView& env, const RobotView& rob, const double* store_pos, const StarView& S,
                        int pass);
-// the commit of one round: k_decide (wide) -> k_resolve (one workgroup) [-> the SFF* stage] -> k_append (wide);
+// the commit of one round: k_commit (wide) [-> the SFF* stage] -> k_append / k_append_sample (wide);
 // n_bound = launch bound
 // the arguments of k_sample_steer as one block: the commit's last kernel (k_append_sample) also draws the NEXT round's
 // samples - a slot that was not accepted knows its place in the next round's list the moment it writes it
