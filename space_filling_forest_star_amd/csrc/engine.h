@@ -144,7 +144,8 @@ struct Ctx {
   uint64_t round_calls[T_KINDS] = {0, 0, 0, 0, 0}, round_timed[T_KINDS] = {0, 0, 0, 0, 0};
   bool round_scope = false;
   bool timing_on = true, timed_now = true;
-  int timer_stride = 8;
+  int timer_stride = 32;   // (SFFGPU_TIMER_STRIDE; an eagerly launched, event-bracketed wave costs ~0.25 ms more than its graph
+                           // replay and its HIP events read ~4 us long per kernel: 8 -> 32 is + 2-3 % on the headline job)
   double kernel_ms_total(int kind) const;
 
   explicit Ctx(int dev);
