@@ -91,7 +91,8 @@ def rccl_unique_id():
 
 
 def lib_path():
-    return os.path.join(_HERE, "libsffgpu.so")
+    # SFFGPU_LIB: another build of the same library beside the shipped one (profiling builds with debug counters)
+    return os.path.join(_HERE, os.environ.get("SFFGPU_LIB", "libsffgpu.so"))
 
 
 def build_library(force=False):

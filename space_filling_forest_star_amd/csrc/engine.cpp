@@ -229,7 +229,7 @@ Ctx::~Ctx() {
   for (auto e : pool) (void)hipEventDestroy(e);
   DevBuf* bufs[] = {&env_tri, &env_box, &env_plane, &rob_tri, &sx, &sy, &sz, &syaw, &spitch, &sroll, &stree, &spos,
                     &d_a, &d_b, &d_c, &d_d, &d_e, &d_f, &d_g, &d_h, &r_in, &r_out, &r_out2, &r_q, &r_cnt, &r_hidx,
-                    &r_hdist, &r_sega, &r_segb, &r_items, &r_items2, &r_center, &env_clear, &g_cnt, &g_items, &g_ovfcnt, &g_ovf, &t_cnt, &t_items, &t_ovfcnt, &t_ovf, &t_occ, &env_tg_start, &env_tg_list, &r_sub, &env_ext};
+                    &r_hdist, &r_sega, &r_segb, &r_items, &r_items2, &r_center, &env_clear, &g_cnt, &g_items, &g_ovfcnt, &g_ovf, &t_cnt, &t_items, &t_ovfcnt, &t_ovf, &t_occ, &g_lite, &g_ovf_lite, &t_lite, &t_ovf_lite, &env_tg_start, &env_tg_list, &r_sub, &env_ext};
   for (DevBuf* b : bufs) b->release();
   for (auto& b : level_box) b.release();
   PinBuf* pins[] = {&h_a, &h_b, &h_c, &h_d, &h_e, &h_f, &h_g, &h_h, &p_in, &p_out};
@@ -640,12 +640,16 @@ void Ctx::grid_setup(const double limits[6], double cell) {
   g_items.ensure(ncells * gridv.bk * sizeof(sffk::GridItem));
   g_ovfcnt.ensure(16);
   g_ovf.ensure((size_t)gridv.ovf_cap * sizeof(sffk::GridItem));
+  g_lite.ensure(ncells * gridv.bk * sizeof(sffk::GridItem32));
+  g_ovf_lite.ensure((size_t)gridv.ovf_cap * sizeof(sffk::GridItem32));
   HIPCHK(hipMemsetAsync(g_cnt.p, 0, ncells * sizeof(int32_t), stream));
   HIPCHK(hipMemsetAsync(g_ovfcnt.p, 0, 16, stream));
   gridv.cnt = g_cnt.as<int32_t>();
   gridv.items = g_items.as<sffk::GridItem>();
   gridv.ovf_cnt = g_ovfcnt.as<int32_t>();
   gridv.ovf = g_ovf.as<sffk::GridItem>();
+  gridv.lite = g_lite.as<sffk::GridItem32>();
+  gridv.ovf_lite = g_ovf_lite.as<sffk::GridItem32>();
   // the round's own grid: same cells, its own buckets / overflow list, all counters zero between rounds
   tgridv = gridv;
   tgridv.bk = 8;
@@ -654,12 +658,16 @@ void Ctx::grid_setup(const double limits[6], double cell) {
   t_items.ensure(ncells * tgridv.bk * sizeof(sffk::GridItem));
   t_ovfcnt.ensure(16);
   t_ovf.ensure((size_t)tgridv.ovf_cap * sizeof(sffk::GridItem));
+  t_lite.ensure(ncells * tgridv.bk * sizeof(sffk::GridItem32));
+  t_ovf_lite.ensure((size_t)tgridv.ovf_cap * sizeof(sffk::GridItem32));
   HIPCHK(hipMemsetAsync(t_cnt.p, 0, ncells * sizeof(int32_t), stream));
   HIPCHK(hipMemsetAsync(t_ovfcnt.p, 0, 16, stream));
   tgridv.cnt = t_cnt.as<int32_t>();
   tgridv.items = t_items.as<sffk::GridItem>();
   tgridv.ovf_cnt = t_ovfcnt.as<int32_t>();
   tgridv.ovf = t_ovf.as<sffk::GridItem>();
+  tgridv.lite = t_lite.as<sffk::GridItem32>();
+  tgridv.ovf_lite = t_ovf_lite.as<sffk::GridItem32>();
   t_occ.ensure((ncells / 32 + 2) * 4);
   HIPCHK(hipMemsetAsync(t_occ.p, 0, (ncells / 32 + 2) * 4, stream));
   tgridv.occ = t_occ.as<uint32_t>();

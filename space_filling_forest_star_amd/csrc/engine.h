@@ -105,8 +105,8 @@ struct Ctx {
   // uniform grid over the store (forest engine only)
   bool grid_on = false;
   sffk::GridView gridv{};
-  DevBuf g_cnt, g_items, g_ovfcnt, g_ovf;
-  DevBuf t_cnt, t_items, t_ovfcnt, t_ovf, t_occ;   // the round's own grid (same cells; filled and emptied every round)
+  DevBuf g_cnt, g_items, g_ovfcnt, g_ovf, g_lite, g_ovf_lite;
+  DevBuf t_cnt, t_items, t_ovfcnt, t_ovf, t_occ, t_lite, t_ovf_lite;   // the round's own grid (same cells; filled and emptied every round)
   sffk::GridView tgridv{};
   int grid_inserted = 0;
   void grid_setup(const double limits[6], double cell);

@@ -609,7 +609,7 @@ void Forest::round_begin() {
   ca.items_cap = list_cap;
   ca.sub = c.r_sub.as<int32_t>();
   ca.pose_hit = d_pose;
-  sffk::launch_query_classify(c.stream, c.gridv, &c.tgridv, c.store_view(), c.r_q.as<sffk::SweepQuery>(), ca, &c.envv);
+  const bool paired = sffk::launch_query_classify(c.stream, c.gridv, &c.tgridv, c.store_view(), c.r_q.as<sffk::SweepQuery>(), ca, &c.envv);
   c.time_end();
   c.time_begin(T_COLLIDE);
   c.p_out.ensure(o_bytes);
@@ -625,7 +625,8 @@ void Forest::round_begin() {
   tref_keep.tg = sffk::GridView{};
   tref_keep.n = 0;
   sffk::launch_collide_items(c.stream, c.envv, c.robv, d_pos, n, ca.rec_flags, d_pose, ca.seg_a, ca.seg_b, ca.seg_ns,
-                             STRIDE, ca.ctrl, c.r_items.p, ca.items_cap, ca.sub, ca.first_hit, ca.seg_ovf, cfg.optimize ? &tref_keep : &tref);
+                             STRIDE, ca.ctrl, c.r_items.p, ca.items_cap, ca.sub, ca.first_hit, ca.seg_ovf, cfg.optimize ? &tref_keep : &tref,
+                             nullptr, paired ? &ca : nullptr);
   c.time_end();
   // samples this rank can settle alone need no replay (with a goal the replay may stop in the middle of the
   // round, so there every sample stays in it)

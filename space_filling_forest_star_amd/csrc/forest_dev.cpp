@@ -821,7 +821,7 @@ void Forest::dev_enqueue_round_eval(void* send_dev, bool sample) {
   ca.items_cap = B.list_cap;
   ca.sub = c.r_sub.as<int32_t>();
   ca.pose_hit = B.d_pose;
-  sffk::launch_query_classify(c.stream, c.gridv, &c.tgridv, c.store_view(), c.r_q.as<sffk::SweepQuery>(), ca, &c.envv);
+  const bool paired = sffk::launch_query_classify(c.stream, c.gridv, &c.tgridv, c.store_view(), c.r_q.as<sffk::SweepQuery>(), ca, &c.envv);
   c.time_end();
   c.time_begin(T_COLLIDE);
   sffk::TempGridRef tref{c.tgridv, c.sx.as<float>() + d.temp_base, c.sy.as<float>() + d.temp_base,
@@ -832,7 +832,7 @@ void Forest::dev_enqueue_round_eval(void* send_dev, bool sample) {
   tref_keep.n = 0;
   sffk::launch_collide_items(c.stream, c.envv, c.robv, B.d_pos, n, ca.rec_flags, B.d_pose, ca.seg_a, ca.seg_b, ca.seg_ns,
                              B.STRIDE, ca.ctrl, c.r_items.p, ca.items_cap, ca.sub, ca.first_hit, ca.seg_ovf,
-                             cfg.optimize ? &tref_keep : &tref, dev_n);
+                             cfg.optimize ? &tref_keep : &tref, dev_n, paired ? &ca : nullptr);
   c.time_end();
   if (send_dev) {
     c.time_begin(T_EXCHANGE);     // (closed by the commit: pack, the caller's / the library's all-gather, unpack)
@@ -1333,13 +1333,15 @@ void Forest::run_device(int max_waves) {
             (double)g[8] / (double)std::max<unsigned long long>(1ULL, g[9]) / 100.0, g[9]);
     fprintf(stderr, "[sffgpu exact kernel, chunk time histogram] <10us %llu <20 %llu <40 %llu <80 %llu >=80 %llu | candidates per chunk of "
             "the >=40us ones %.1f\n", g[10], g[11], g[12], g[13], g[14], (double)g[15] / (double)std::max<unsigned long long>(1ULL, g[13] + g[14]));
-    unsigned long long q[8];
+    unsigned long long q[16];
     sffk::debug_counters_query(q);
     const double qw = (double)std::max<unsigned long long>(1ULL, q[0]);
     fprintf(stderr, "[sffgpu query kernel, per sampled wave] us: grid scan %.2f classify %.2f cull %.2f (flushes %.2f) | live %.2f "
             "pairs/live %.1f survivors/live %.2f\n", q[1] / qw / 100.0, q[2] / qw / 100.0, q[3] / qw / 100.0, q[4] / qw / 100.0,
             q[7] / qw, (double)q[5] / (double)std::max<unsigned long long>(1ULL, q[7]),
             (double)q[6] / (double)std::max<unsigned long long>(1ULL, q[7]));
+    fprintf(stderr, "[sffgpu paired query kernel] per sampled wave: args %.2f us (its 'flushes' above) | per sampled half: candidates %.2f kept %.2f\n",
+            q[4] / qw / 100.0, q[8] / qw, q[9] / qw);
 #endif
   }
 }

@@ -42,6 +42,14 @@ struct GridItem {   // 64 bytes = one sector pair: the node's authoritative fp64
   int32_t tree;
   int32_t pad[2];
 };
+// The same item as a 32-byte fp32 filter record (the store columns' own double -> float casts): the paired query kernel
+// (k_query_pair) reads these - half the bytes per candidate - and fetches the authoritative fp64 position of the few
+// candidates that pass the superset filter from the store (one dependent gather for ~5 of ~34 candidates).
+struct GridItem32 {
+  float x, y, z, yaw, pitch, roll;
+  int32_t id;
+  int32_t tree;
+};
 struct GridView {
   float ox, oy, oz, inv_cell;
   int nx, ny, nz, bk;
@@ -50,6 +58,8 @@ struct GridView {
   int32_t* ovf_cnt;   // [0] entries in the overflow list
   GridItem* ovf;
   int ovf_cap;
+  GridItem32* lite;   // optional ncells x bk: the items as filter records (same cell / slot)
+  GridItem32* ovf_lite;
   uint32_t* occ;      // optional occupancy bits (one per cell): the round's own grid is nearly empty, its 100 KB of
                       // bits stay in L2 and spare the queries 27 scattered count loads
 };
@@ -286,15 +296,24 @@ void launch_classify(hipStream_t s, const ClassifyArgs& a);
 // neighbour query + classification in one launch (one wavefront per sample): the hits never leave the wave
 // env != nullptr: with the fused clearance cull (a.items / a.pose_hit / a.ctrl[2]); the exact work is then done by
 // launch_collide_items
-void launch_query_classify(hipStream_t s, const GridView& g, const GridView* tg, const NodeStoreView& st,
+// returns true when the paired kernel (k_query_pair) ran: it writes the end points of the edge tasks that left a survivor
+// only and does not clear unused task slots - launch_collide_items then needs `pair_src` (the same arguments)
+bool launch_query_classify(hipStream_t s, const GridView& g, const GridView* tg, const NodeStoreView& st,
                            const SweepQuery* queries, const ClassifyArgs& a, const EnvView* env = nullptr);
+bool query_pair_mode(const GridView& g, const GridView* tg, const ClassifyArgs& a, const EnvView* env);
+// where k_collide_items finds a task's end points when the survivor list ran over after k_query_pair
+struct TaskSource {
+  const int32_t* rec_nnb; const int32_t* rec_nb; const int32_t* rec_meta; const int32_t* parent;
+  const double* center; const double* pos;
+  int nbcap, goal_id, on;
+};
 // exact collision work of a round from the survivor list k_query_classify wrote (count in ctrl[2])
 struct TempGridRef;
 void launch_collide_items(hipStream_t s, const EnvView& env, const RobotView& rob, const double* pos6, int n_pose,
                           const int32_t* live_flags, uint8_t* pose_hit, const double* a6, const double* b6,
                           const int32_t* seg_ns, int stride, int32_t* ctrl, const void* items, int items_cap,
                           const int32_t* sub, int32_t* first_hit, int32_t* overflow_flag, const TempGridRef* temps,
-                          const int32_t* dev_n = nullptr);
+                          const int32_t* dev_n = nullptr, const ClassifyArgs* pair_src = nullptr);
 struct SettleArgs {
   int n, Tb, nbcap, stride, n_trees;
   const uint8_t* in_lim;
@@ -514,7 +533,7 @@ void launch_border_rehash(hipStream_t s, const DevForestView& f, int n);
 
 #ifdef SFFK_DEBUG_COUNTERS
 void debug_counters(unsigned long long* out16);   // exact-kernel phase clocks (make EXTRA=-DSFFK_DEBUG_COUNTERS)
-void debug_counters_query(unsigned long long* out8);
+void debug_counters_query(unsigned long long* out16);
 #endif
 #ifdef SFFK_CI_TRACE
 void debug_ci_trace(unsigned long long* out);     // make EXTRA=-DSFFK_CI_TRACE=<launch>: one launch of k_collide_items, per wave

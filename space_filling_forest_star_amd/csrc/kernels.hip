@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 #include "kernels.h"
 #include <algorithm>
 #include "sff_geom.h"
@@ -821,7 +822,7 @@ void launch_tgrid_build(hipStream_t s, const EnvView& env, int32_t* cnt_or_start
 
 #ifdef SFFK_DEBUG_COUNTERS
 __device__ unsigned long long g_dbg[16];
-__device__ unsigned long long g_dbg_q[8];   // k_query_classify: sampled waves | ticks: scan, classify, cull, flushes | pairs, survivors, live
+__device__ unsigned long long g_dbg_q[16];   // k_query_classify: sampled waves | ticks: scan, classify, cull, flushes | pairs, survivors, live
 #define QDBG(i, x) do { if (qdbg_on) atomicAdd(&g_dbg_q[i], (unsigned long long)(x)); } while (0)
 struct DbgAcc { unsigned long long v[12]; };
 #define DBG_DECL DbgAcc dbg_acc = {{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
@@ -1961,6 +1962,444 @@ __global__ __launch_bounds__(64 * QC_WAVES) __attribute__((amdgpu_waves_per_eu(Q
   }
 }
 
+// ------------------------------------------------------------------ paired query kernel
+// k_query_classify's work with TWO samples per wavefront (32 lanes each).  What the counters said about the one-sample
+// kernel (profiles/r3_sq_summary.json): its VALU issue slots are full (15 % of the wave cycles x 7 waves per SIMD) while
+// most of its instructions run with a third of the lanes in use (27 cells, ~34 candidates, ~5 hits, ~20 cull groups per
+// step on 64 lanes), and a round's 10 k wavefronts do not fit the 7 168 resident slots.  Here:
+//   - lane = cell (27 of 32 lanes), a lane walks its own bucket: no prefix / binary search to flatten candidates;
+//   - candidates are 32-byte fp32 filter records (GridView::lite); the fp64 position is fetched from the store only for
+//     the few that pass the superset filter (the sweep's own filter: k_sweep);
+//   - the clearance bits of the parent edge's first four chunks and of the pose are requested together with the cell counts
+//     (they depend on the sample only) and looked at after the classification;
+//   - the round's own grid is asked through its occupancy bits (96 KB, cache-resident) instead of its count array;
+//   - edge end points are written only for the tasks that leave a survivor for the exact kernel (k_collide_items derives
+//     them from the records when the survivor list ran over), unused task slots are not cleared (readers trust rec_nnb).
+// Bounded lists: 32 filter candidates per sample (A.cap hits, A.nbcap classified neighbours as before); more = flag 2,
+// the sample takes the host path like any other list overflow.  Launchers fall back to k_query_classify for deep
+// buckets (forests that pile nodes up in xyz cells).
+#define QP_WAVES 4
+#define QP_CAND 32
+#define QP_TAB 64     // (task, chunk) pairs of a sample unfolded at a time
+#define QP_SURV 32    // survivors of a sample gathered in LDS before they are appended
+#define QP_TASKS 17   // parent edge + 16 neighbour tasks
+#ifndef QP_OCC
+#define QP_OCC 5
+#endif
+__global__ __launch_bounds__(64 * QP_WAVES) __attribute__((amdgpu_waves_per_eu(QP_OCC))) void k_query_pair(
+    GridView g, GridView tg, const SweepQuery* __restrict__ queries, ClassifyArgs A, EnvView env) {
+  __shared__ SurvivorItem s_surv[QP_WAVES][2][QP_SURV];
+  __shared__ int32_t s_tab[QP_WAVES][2][QP_TAB];
+  __shared__ int32_t s_cid[QP_WAVES][2][QP_CAND];
+  __shared__ int32_t s_ctree[QP_WAVES][2][QP_CAND];
+  __shared__ float s_T[QP_WAVES][2][QP_TASKS * 8];
+  __shared__ int32_t s_NS[QP_WAVES][2][QP_TASKS];
+  __shared__ int32_t s_need[QP_WAVES][2][QP_TASKS + 3];
+  if (A.dev_n) {
+    if (A.dev_n[1]) return;
+    A.n = A.dev_n[0];
+  }
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, hl = lane & 31;
+  const int i0 = (blockIdx.x * QP_WAVES + wave) * 2;
+  if (i0 >= A.n) return;
+  const bool clocked = A.qclk && (blockIdx.x & 15) == 0 && threadIdx.x == 0;
+  if (clocked) atomicMin(A.qclk, wall_clock64());
+  [[maybe_unused]] const bool qdbg_on = (blockIdx.x & 15) == 0 && lane == 0;
+  [[maybe_unused]] const unsigned long long qt0 = DBG_T();
+  const int i = i0 + h;
+  const bool act = i < A.n;
+  const int ii = act ? i : i0;
+  const int stride = 1 + A.nbcap;
+  const uint32_t below = (1u << hl) - 1u;
+  auto hballot = [&](bool p) -> uint32_t { return (uint32_t)(__ballot(p) >> (h << 5)); };
+  int32_t* const cid = s_cid[wave][h];
+  int32_t* const ctree = s_ctree[wave][h];
+  float* const T = s_T[wave][h];
+  int32_t* const NS = s_NS[wave][h];
+  int32_t* const needf = s_need[wave][h];
+  if (hl < QP_TASKS) needf[hl] = 0;
+  // ---- the sample (every lane of the half holds it: one request per array)
+  const bool inl = act && A.in_lim[ii] != 0;
+  const bool force = A.force[ii] != 0;
+  const double pdist = A.pdist[ii];
+  const SweepQuery* qq = queries + ii;
+  const float qx = qq->x, qy = qq->y, qz = qq->z, qyaw = qq->yaw, qpitch = qq->pitch, qroll = qq->roll, r2f = qq->r2f;
+  const double qr = qq->r;
+  const int q_tree = qq->tree, max_id = qq->max_id;
+  const int ex = A.center ? 0 : A.parent[ii];
+  const int mine = A.center ? A.tree[A.N0 + ii] : A.tree[ex];
+  const double* const qsrc = A.newpos + 6 * (size_t)ii;
+  const double* const esrc = A.center ? A.center + 6 * (size_t)ii : A.pos + 6 * (size_t)ex;
+  const int no_g = g.ovf_cnt[0];
+  const int no_t = tg.cnt ? tg.ovf_cnt[0] : 0;
+  const bool mine_shard = A.world <= 1 || i % A.world == A.rank;
+  const bool evaluate = inl && mine_shard;
+  int flags = evaluate ? 1 : 0, nnb = 0;
+  // the parent edge (task 0): positions in cells of the clearance grid, fp32 (see k_query_classify)
+  double parts0;
+  int ns0;
+  float g0[3], st0[3];
+  {
+    double e3[6], q3[6];
+    for (int k = 0; k < 6; ++k) { e3[k] = esrc[k]; q3[k] = qsrc[k]; }
+    parts0 = edge_parts(e3, q3);
+    ns0 = edge_samples(parts0);
+    const float inv0 = (float)env.clear_inv * __frcp_rn((float)parts0);
+    for (int k = 0; k < 3; ++k) {
+      g0[k] = (float)((e3[k] - env.clear_org[k]) * env.clear_inv);
+      st0[k] = (float)(q3[k] - e3[k]) * inv0;
+    }
+  }
+  const bool cull_on = evaluate && env.n_tri != 0;
+  const float nxd = (float)env.clear_n[0], nyd = (float)env.clear_n[1], nzd = (float)env.clear_n[2];
+  // one group of eight consecutive edge samples -> the address of the bit that answers it (k_query_classify's scheme)
+  auto group_addr = [&](bool valid, float a0, float a1, float a2, float d0, float d1, float d2, int ns, int c, int gi,
+                        bool& need, int& left, const uint32_t*& wp, int& sh) {
+    const int first = 1 + 64 * c + 8 * gi;
+    need = valid && first <= ns;
+    left = ns - first + 1;
+    const int probe = first + 4 <= ns ? first + 4 : ns;
+    wp = nullptr;
+    sh = 0;
+    if (need && env.clear_bits) {
+      const float td = (float)probe;
+      const float fx = __builtin_fmaf(td, d0, a0), fy = __builtin_fmaf(td, d1, a1), fz = __builtin_fmaf(td, d2, a2);
+      if (fx >= 0 && fy >= 0 && fz >= 0 && fx < nxd && fy < nyd && fz < nzd) {
+        const uint32_t ci = ((uint32_t)(int)fz * (uint32_t)env.clear_n[1] + (uint32_t)(int)fy) * (uint32_t)env.clear_n[0] + (uint32_t)(int)fx;
+        wp = env.clear_bits + (ci >> 5);
+        sh = (int)(ci & 31u);
+      } else if (fx == fx && fy == fy && fz == fz) {
+        need = false;                                     // beyond the inflated box of the environment
+      }
+    }
+  };
+  // ---- requested now, looked at after the classification: the parent edge's first four chunks (lane = chunk, group)
+  // and the pose's own bit
+  const int C0 = ns0 > 0 ? (ns0 + 63) >> 6 : 0;
+  bool e_need;
+  int e_left, e_sh;
+  const uint32_t* e_wp;
+  group_addr(cull_on && (hl >> 3) < C0, g0[0], g0[1], g0[2], st0[0], st0[1], st0[2], ns0, hl >> 3, hl & 7, e_need, e_left, e_wp, e_sh);
+  const uint32_t e_word = e_wp ? *e_wp : 0u;
+  const uint32_t* wp_pose = nullptr;
+  int sh_pose = 0;
+  bool need_pose = cull_on;
+  if (cull_on && env.clear_bits) {
+    const double fx = (qsrc[0] - env.clear_org[0]) * env.clear_inv, fy = (qsrc[1] - env.clear_org[1]) * env.clear_inv,
+                 fz = (qsrc[2] - env.clear_org[2]) * env.clear_inv;
+    if (fx == fx && fy == fy && fz == fz) {
+      if (fx < 0 || fy < 0 || fz < 0 || fx >= env.clear_n[0] || fy >= env.clear_n[1] || fz >= env.clear_n[2]) {
+        need_pose = false;
+      } else {
+        const long long ci = ((long long)(int)fz * env.clear_n[1] + (int)fy) * env.clear_n[0] + (int)fx;
+        wp_pose = env.clear_bits + (ci >> 5);
+        sh_pose = (int)(ci & 31);
+      }
+    }
+  }
+  const uint32_t word_pose = wp_pose ? *wp_pose : 0u;
+
+  // ---- neighbour query: lane = cell, fp32 filter records
+  int nc = 0;                                               // filter candidates of the sample (uniform in the half)
+  auto offer = [&](bool on, const GridItem32& it) {
+    bool pass = false;
+    if (on && it.id < max_id && (q_tree < 0 || it.tree == q_tree)) {
+      const float dx = it.x - qx, dy = it.y - qy, dz = it.z - qz;
+      const float d3 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+      if (d3 <= r2f) {
+        const float da = wrapf(it.yaw - qyaw), db = wrapf(it.pitch - qpitch), dc = wrapf(it.roll - qroll);
+        pass = fmaf(dc, dc, fmaf(db, db, fmaf(da, da, d3))) <= r2f;
+      }
+    }
+    const uint32_t pm = hballot(pass);
+    if (pass) {
+      const int at = nc + __popc(pm & below);
+      if (at < QP_CAND) { cid[at] = it.id; ctree[at] = it.tree; }
+    }
+    nc += __popc(pm);
+  };
+  [[maybe_unused]] const unsigned long long qt1 = DBG_T();
+  if (__any(evaluate)) {
+    const float rf = sqrtf(r2f) * 1.000001f;
+    const int lx = grid_coord(qx - rf, g.ox, g.inv_cell, g.nx), hx = grid_coord(qx + rf, g.ox, g.inv_cell, g.nx);
+    const int ly = grid_coord(qy - rf, g.oy, g.inv_cell, g.ny), hy = grid_coord(qy + rf, g.oy, g.inv_cell, g.ny);
+    const int lz = grid_coord(qz - rf, g.oz, g.inv_cell, g.nz), hz = grid_coord(qz + rf, g.oz, g.inv_cell, g.nz);
+    const int wx = hx - lx + 1, wy = hy - ly + 1, wz = hz - lz + 1;
+    const int total = evaluate ? wx * wy * wz : 0;
+    const float rwx = __frcp_rn((float)wx), rwy = __frcp_rn((float)wy);
+    for (int c0 = 0; __any(c0 < total); c0 += 32) {
+      const int c = c0 + hl;
+      const bool on = c < total;
+      size_t cell = 0;
+      int m = 0, mt = 0;
+      uint32_t ow = 0u;
+      if (on) {
+        int q1, q2;
+        if (total <= 512) {   // (exact: see k_query_classify)
+          q1 = (int)(((float)c + 0.5f) * rwx);
+          q2 = (int)(((float)q1 + 0.5f) * rwy);
+        } else {
+          q1 = c / wx;
+          q2 = q1 / wy;
+        }
+        const int cx = lx + (c - q1 * wx), cy = ly + (q1 - q2 * wy), cz = lz + q2;
+        cell = ((size_t)cz * g.ny + cy) * g.nx + cx;
+        m = g.cnt[cell];
+        if (tg.cnt) ow = tg.occ ? tg.occ[cell >> 5] : 0xffffffffu;
+        if (m > g.bk) m = g.bk;
+      }
+      // the round's own grid: nearly empty - count and first record only where the occupancy bit is set
+      GridItem32 t0{};
+      if (on && ((ow >> (cell & 31)) & 1u)) {
+        mt = tg.cnt[cell];
+        t0 = tg.lite[cell * tg.bk];
+        if (mt > tg.bk) mt = tg.bk;
+      }
+      const GridItem32* bucket = g.lite + cell * g.bk;
+      for (int k = 0; __any(k < m); k += 2) {
+        GridItem32 a{}, b{};
+        if (k < m) a = bucket[k];
+        if (k + 1 < m) b = bucket[k + 1];
+        offer(k < m, a);
+        if (__any(k + 1 < m)) offer(k + 1 < m, b);
+      }
+      if (__any(mt > 0)) {
+        offer(mt > 0, t0);
+        for (int k = 1; __any(k < mt); ++k) {
+          GridItem32 a{};
+          if (k < mt) a = tg.lite[cell * tg.bk + k];
+          offer(k < mt, a);
+        }
+      }
+    }
+    if (no_g > 0) {
+      const int no = no_g < g.ovf_cap ? no_g : g.ovf_cap;
+      for (int j0 = 0; j0 < no; j0 += 32) {
+        GridItem32 a{};
+        const bool on = evaluate && j0 + hl < no;
+        if (on) a = g.ovf_lite[j0 + hl];
+        offer(on, a);
+      }
+    }
+    if (no_t > 0) {
+      const int no = no_t < tg.ovf_cap ? no_t : tg.ovf_cap;
+      for (int j0 = 0; j0 < no; j0 += 32) {
+        GridItem32 a{};
+        const bool on = evaluate && j0 + hl < no;
+        if (on) a = tg.ovf_lite[j0 + hl];
+        offer(on, a);
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  [[maybe_unused]] const unsigned long long qt2 = DBG_T();
+  QDBG(0, 1); QDBG(4, qt1 - qt0); QDBG(1, qt2 - qt1); QDBG(8, nc);
+  // ---- exact test of the candidates (authoritative fp64 positions from the store), classification (k_classify's logic)
+  bool keep = false, same = false;
+  int rank = 0, nb_id = 0, nb_tree = 0, ns_mine = 0;
+  double parts_mine = 0.0;
+  if (evaluate && nc > QP_CAND) flags |= 2;
+  if (__any(evaluate && nc > 0 && nc <= QP_CAND)) {
+    const bool cand = evaluate && nc <= QP_CAND && hl < nc;
+    nb_id = cand ? cid[hl] : 0x7fffffff;
+    nb_tree = cand ? ctree[hl] : 0x7fffffff;
+    double nbp[6], qp[6];
+    for (int k = 0; k < 6; ++k) qp[k] = qsrc[k];
+    double d = 0.0;
+    bool hit = false;
+    if (cand) {
+      const double* ps = A.pos + 6 * (size_t)nb_id;
+      for (int k = 0; k < 6; ++k) nbp[k] = ps[k];
+      d = dist6(nbp, qp);
+      hit = d < qr;
+    }
+    const int cnt = __popc(hballot(hit));
+    if (evaluate && cnt > A.cap) flags |= 2;
+    const int t = hit ? nb_tree : 0x7fffffff;
+    const int id = hit ? nb_id : 0x7fffffff;
+    same = t == mine;
+    bool q = false;
+    if (hit && !(flags & 2)) q = same ? (!force && d < pdist - SFFG_TOL)       // src/forest.h:276
+                                      : (d < A.dist_tree - SFFG_TOL);          // src/forest.h:283
+    uint32_t mm = hballot(q);
+    while (__any(mm != 0u)) {
+      const bool on = mm != 0u;
+      const int src = (h << 5) + (on ? __ffs((int)mm) - 1 : 0);
+      mm &= mm - 1u;
+      const int tj = __shfl(t, src), idj = __shfl(id, src);
+      const double dj = __shfl(d, src);
+      if (on && (tj < t || (tj == t && (dj < d || (dj == d && idj < id))))) ++rank;
+    }
+    int cut = (q && !same && id < A.N0) ? rank : 0x7fffffff;
+    for (int off = 16; off > 0; off >>= 1) {
+      const int o = __shfl_xor(cut, off);
+      cut = o < cut ? o : cut;
+    }
+    keep = q && rank <= cut;
+    const int nkeep = __popc(hballot(keep));
+    if (nkeep > A.nbcap) { flags |= 2; keep = false; }
+    else nnb = nkeep;
+    if (keep) {   // the kept edge's sample count and its row of the cull's table
+      double exq[6], ea[6], eb[6];
+      for (int k = 0; k < 6; ++k) exq[k] = esrc[k];
+      if (same) { for (int k = 0; k < 6; ++k) { ea[k] = nbp[k]; eb[k] = qp[k]; } }                      // isPathFree(neighbour, newPoint) :276
+      else if (nb_id == A.goal_id) { for (int k = 0; k < 6; ++k) { ea[k] = qp[k]; eb[k] = nbp[k]; } }  // isPathFree(newPoint, goal) :287
+      else { for (int k = 0; k < 6; ++k) { ea[k] = exq[k]; eb[k] = nbp[k]; } }                          // isPathFree(expanded, neighbour) :288
+      parts_mine = edge_parts(ea, eb);
+      ns_mine = edge_samples(parts_mine);
+      const float inv = (float)env.clear_inv * __frcp_rn((float)parts_mine);
+      for (int k = 0; k < 3; ++k) {
+        T[8 * (1 + rank) + k] = (float)((ea[k] - env.clear_org[k]) * env.clear_inv);
+        T[8 * (1 + rank) + 4 + k] = (float)(eb[k] - ea[k]) * inv;
+      }
+      NS[1 + rank] = ns_mine;
+    }
+  }
+  const bool live = (flags & 3) == 1 && env.n_tri != 0;
+  // ---- edge tasks: records, and the cull's per-task table (start point, step, sample count)
+  if ((flags & 3) == 1) {
+    if (keep) {
+      A.rec_nb[(size_t)i * A.nbcap + rank] = nb_id;
+      A.rec_meta[(size_t)i * A.nbcap + rank] = (nb_tree << 1) | (same ? 1 : 0);
+      const size_t slot = (size_t)i * stride + 1 + rank;
+      A.seg_ns[slot] = ns_mine;
+      A.first_hit[slot] = 0x7fffffff;
+      A.seg_ovf[slot] = 0;
+    }
+    if (hl == 0) {   // slot 0: isPathFree(expanded, newPoint)  (src/forest.h:246)
+      const size_t slot = (size_t)i * stride;
+      A.seg_ns[slot] = ns0;
+      A.first_hit[slot] = 0x7fffffff;
+      A.seg_ovf[slot] = 0;
+      for (int k = 0; k < 3; ++k) { T[k] = g0[k]; T[4 + k] = st0[k]; }
+      NS[0] = ns0;
+    }
+  }
+  if (act && hl == 0) A.pose_hit[i] = 0;
+  __builtin_amdgcn_wave_barrier();
+  [[maybe_unused]] const unsigned long long qt3 = DBG_T();
+  QDBG(2, qt3 - qt2); QDBG(9, nnb); QDBG(7, live ? 1 : 0);
+  // ---- clearance cull: survivors -> the exact kernel's list
+  if (__any(live)) {
+    SurvivorItem* list = static_cast<SurvivorItem*>(A.items);
+    SurvivorItem* buf = s_surv[wave][h];
+    int n_buf = 0;
+    const int sub_list = blockIdx.x & (SFFK_SUBLISTS - 1), sub_cap = A.items_cap / SFFK_SUBLISTS;
+    auto flush = [&](bool go) {   // (per half)
+      const bool mineb = go && hl < n_buf;
+      SurvivorItem it = mineb ? buf[hl] : SurvivorItem{0, 0, 0ULL};
+      const bool hv = mineb && (it.slot < 0 || __popcll(it.mask) >= QC_HEAVY);
+      const uint32_t hm = hballot(hv), lm = hballot(mineb && !hv);
+      int bh = 0, bl = 0;
+      if (hl == 0 && go) {
+        if (hm) bh = atomicAdd(A.sub + sub_list * SFFK_SUB_STRIDE, __popc(hm));
+        if (lm) bl = atomicAdd(A.sub + sub_list * SFFK_SUB_STRIDE + 2, __popc(lm));
+      }
+      bh = __shfl(bh, h << 5); bl = __shfl(bl, h << 5);
+      const int half = sub_cap / 2;
+      if (hv) {
+        const int at = bh + __popc(hm & below);
+        if (at < half) list[(size_t)sub_list * sub_cap + at] = it;
+        else A.ctrl[3] = 1;
+      } else if (mineb) {
+        const int at = bl + __popc(lm & below);
+        if (at < sub_cap - half) list[(size_t)sub_list * sub_cap + half + at] = it;
+        else A.ctrl[3] = 1;
+      }
+      if (go) n_buf = 0;
+    };
+    // a step's answers -> masks of the (task, chunk) pairs, survivors into the buffer
+    auto settle = [&](bool need, int left, const uint32_t* wp, int sh, uint32_t word, int t, int c) {
+      const int gi = hl & 7;
+      if (wp && ((word >> sh) & 1u)) need = false;
+      unsigned long long m = need ? (((left >= 8 ? 0xffULL : ((1ULL << left) - 1ULL))) << (8 * gi)) : 0ULL;
+      m |= __shfl_xor(m, 1);
+      m |= __shfl_xor(m, 2);
+      m |= __shfl_xor(m, 4);
+      const bool lead = gi == 0 && m != 0ULL;
+      const uint32_t lm = hballot(lead);
+      if (lead) {
+        buf[n_buf + __popc(lm & below)] = SurvivorItem{(int32_t)(i * stride + t), c, m};
+        needf[t] = 1;
+      }
+      n_buf += __popc(lm);
+      if (__any(n_buf > QP_SURV - 5)) flush(n_buf > QP_SURV - 5);
+    };
+    // the parent edge's first four chunks (requested at the top)
+    settle(live && e_need, e_left, e_wp, e_sh, e_word, 0, hl >> 3);
+    // the other pairs: parent chunks beyond four, then the kept edges' chunks (lane r = the kept edge of rank r)
+    const int C0r = live && C0 > 4 ? C0 - 4 : 0;
+    const int my_ns = live && hl < nnb ? NS[1 + hl] : 0;
+    const int my_nch = my_ns > 0 ? (my_ns + 63) >> 6 : 0;
+    int incl = my_nch;
+    for (int off = 1; off < 16; off <<= 1) {
+      const int o = __shfl_up(incl, off);
+      if (hl >= off) incl += o;
+    }
+    const int excl = incl - my_nch;
+    const int P = C0r + __shfl(incl, (h << 5) + 15);     // (nnb <= 15: lanes beyond hold the total)
+    QDBG(5, P + (C0 < 4 ? C0 : 4));
+    int32_t* tab = s_tab[wave][h];
+    const int pu = hl >> 3, gi = hl & 7;
+    for (int w0 = 0; __any(w0 < P); w0 += QP_TAB) {
+      __builtin_amdgcn_wave_barrier();
+      for (int c = hl; c < C0r; c += 32)
+        if (c >= w0 && c < w0 + QP_TAB) tab[c - w0] = 4 + c;                                   // the parent edge: task 0
+      if (hl < nnb)
+        for (int c = 0; c < my_nch; ++c) {
+          const int p = C0r + excl + c;
+          if (p >= w0 && p < w0 + QP_TAB) tab[p - w0] = ((1 + hl) << 16) | (c & 0xffff);
+        }
+      __builtin_amdgcn_wave_barrier();
+      const int wn = P - w0 < QP_TAB ? P - w0 : QP_TAB;   // (<= 0 in a half that is through)
+      for (int q0 = 0; __any(q0 < wn); q0 += 4) {
+        const bool valid = q0 + pu < wn;
+        const int ent = valid ? tab[q0 + pu] : 0;
+        const int t = ent >> 16, c = ent & 0xffff;
+        const float* tt = T + 8 * t;
+        bool need;
+        int left, sh;
+        const uint32_t* wp;
+        group_addr(valid, tt[0], tt[1], tt[2], tt[4], tt[5], tt[6], NS[t], c, gi, need, left, wp, sh);
+        const uint32_t word = wp ? *wp : 0u;
+        settle(need, left, wp, sh, word, t, c);
+      }
+    }
+    if (live && need_pose && !((word_pose >> sh_pose) & 1u)) {   // (uniform in the half)
+      if (hl == 0) buf[n_buf] = SurvivorItem{-1 - i, 0, 0ULL};
+      ++n_buf;
+    }
+    if (__any(n_buf > 0)) flush(n_buf > 0);
+    __builtin_amdgcn_wave_barrier();
+    // end points of the tasks that left a survivor (the exact kernel reads them by slot)
+    if (live) {
+      if (keep && needf[1 + rank]) {
+        double exq[6], nbp[6], qp[6];
+        const double* ps = A.pos + 6 * (size_t)nb_id;
+        for (int k = 0; k < 6; ++k) { exq[k] = esrc[k]; nbp[k] = ps[k]; qp[k] = qsrc[k]; }
+        const size_t slot = (size_t)i * stride + 1 + rank;
+        double* sa = A.seg_a + 6 * slot;
+        double* sb = A.seg_b + 6 * slot;
+        if (same) { for (int k = 0; k < 6; ++k) { sa[k] = nbp[k]; sb[k] = qp[k]; } }
+        else if (nb_id == A.goal_id) { for (int k = 0; k < 6; ++k) { sa[k] = qp[k]; sb[k] = nbp[k]; } }
+        else { for (int k = 0; k < 6; ++k) { sa[k] = exq[k]; sb[k] = nbp[k]; } }
+      }
+      if (hl == 0 && needf[0]) {
+        const size_t slot = (size_t)i * stride;
+        double* sa = A.seg_a + 6 * slot;
+        double* sb = A.seg_b + 6 * slot;
+        for (int k = 0; k < 6; ++k) { sa[k] = esrc[k]; sb[k] = qsrc[k]; }
+      }
+    }
+  }
+  if (act && hl == 0) {
+    A.rec_flags[i] = flags;
+    A.rec_nnb[i] = nnb;
+  }
+  QDBG(3, DBG_T() - qt3);
+  if (clocked) atomicMax(A.qclk + 1, wall_clock64());
+}
+
 // Exact collision work of a round straight from the survivor list: persistent wavefronts, wave w takes items
 // w, w + W, ... (about a thousand items over two thousand waves: one item per wave, no pooling needed).
 // Housekeeping first: the round's own grid has been read by the query kernel, the cells it used are emptied here.
@@ -1980,7 +2419,7 @@ __global__ __launch_bounds__(64 * SEG_WAVES) __attribute__((amdgpu_waves_per_eu(
                                                                   int32_t* __restrict__ overflow_flag, GridView tg,
                                                                   const float* __restrict__ tx, const float* __restrict__ ty,
                                                                   const float* __restrict__ tz, int n_temps,
-                                                                  const int32_t* __restrict__ dev_n) {
+                                                                  const int32_t* __restrict__ dev_n, TaskSource D) {
 #ifdef SFFK_CI_TRACE
   const unsigned long long ci_entry = wall_clock64();
 #endif
@@ -2075,6 +2514,10 @@ __global__ __launch_bounds__(64 * SEG_WAVES) __attribute__((amdgpu_waves_per_eu(
       slot = -1 - e; c_lo = c_hi = 0;
     } else {
       slot = e - n_pose;
+      if (D.on) {   // (k_query_pair does not clear the task slots a sample leaves unused)
+        const int si = slot / stride;
+        if ((live_flags[si] & 3) != 1 || slot - si * stride > D.rec_nnb[si]) continue;
+      }
       const int ns = seg_ns[slot];
       if (ns <= 0) continue;
       c_lo = 0; c_hi = (ns + 63) >> 6;
@@ -2094,7 +2537,24 @@ __global__ __launch_bounds__(64 * SEG_WAVES) __attribute__((amdgpu_waves_per_eu(
       continue;
     }
     double a[6], b[6];
-    for (int k = 0; k < 6; ++k) { a[k] = a6[6 * (size_t)slot + k]; b[k] = b6[6 * (size_t)slot + k]; }
+    if (D.on && ran_over) {
+      // k_query_pair wrote the end points of the tasks that left a survivor only: with the list run over, every task's
+      // end points come from the sample's records (the rules of src/forest.h:246,276,287,288)
+      const int si = slot / stride, t = slot - si * stride;
+      const double* pe = D.center ? D.center + 6 * (size_t)si : D.pos + 6 * (size_t)D.parent[si];
+      const double* pq = pos6 + 6 * (size_t)si;
+      if (t == 0) { for (int k = 0; k < 6; ++k) { a[k] = pe[k]; b[k] = pq[k]; } }
+      else {
+        const int id = D.rec_nb[(size_t)si * D.nbcap + t - 1];
+        const bool same = (D.rec_meta[(size_t)si * D.nbcap + t - 1] & 1) != 0;
+        const double* pn = D.pos + 6 * (size_t)id;
+        if (same) { for (int k = 0; k < 6; ++k) { a[k] = pn[k]; b[k] = pq[k]; } }
+        else if (id == D.goal_id) { for (int k = 0; k < 6; ++k) { a[k] = pq[k]; b[k] = pn[k]; } }
+        else { for (int k = 0; k < 6; ++k) { a[k] = pe[k]; b[k] = pn[k]; } }
+      }
+    } else {
+      for (int k = 0; k < 6; ++k) { a[k] = a6[6 * (size_t)slot + k]; b[k] = b6[6 * (size_t)slot + k]; }
+    }
     for (int chunk = c_lo; chunk < c_hi; ++chunk) {
       if (chunk > 0 && first_hit[slot] <= 64 * chunk) break;
 #ifdef SFFK_CI_TRACE
@@ -2986,7 +3446,7 @@ void launch_collide_poses(hipStream_t s, const EnvView& env, const RobotView& ro
 
 #ifdef SFFK_DEBUG_COUNTERS
 void debug_counters(unsigned long long* out16) { (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_dbg), sizeof(unsigned long long) * 16); }
-void debug_counters_query(unsigned long long* out8) { (void)hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_dbg_q), sizeof(unsigned long long) * 8); }
+void debug_counters_query(unsigned long long* out16) { (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_dbg_q), sizeof(unsigned long long) * 16); }
 #endif
 #ifdef SFFK_CI_TRACE
 void debug_ci_trace(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ci_trace), sizeof(unsigned long long) * 4096 * 8); }
@@ -3002,24 +3462,46 @@ void launch_settle(hipStream_t s, const SettleArgs& a) {
   hipLaunchKernelGGL(k_settle, dim3((a.n + 255) / 256), dim3(256), 0, s, a);
 }
 
-void launch_query_classify(hipStream_t s, const GridView& g, const GridView* tg, const NodeStoreView& st,
+// the paired kernel serves forests whose buckets are shallow (its lanes walk their own cell's bucket) and whose
+// samples see few neighbours (32 filter candidates); SFFGPU_QUERY=wide / pair overrides the choice
+bool query_pair_mode(const GridView& g, const GridView* tg, const ClassifyArgs& a, const EnvView* env) {
+  static const char* const knob = getenv("SFFGPU_QUERY");
+  if (!env || !g.lite || !g.ovf_lite || a.nbcap > 16) return false;
+  if (tg && tg->cnt && (!tg->lite || !tg->ovf_lite)) return false;
+  if (knob && !strcmp(knob, "wide")) return false;
+  if (knob && !strcmp(knob, "pair")) return true;
+  return g.bk <= 8;
+}
+bool launch_query_classify(hipStream_t s, const GridView& g, const GridView* tg, const NodeStoreView& st,
                            const SweepQuery* queries, const ClassifyArgs& a, const EnvView* env) {
-  if (a.n <= 0) return;
+  if (a.n <= 0) return false;
   GridView none{};
   ClassifyArgs aa = a;
   if (env) {   // tests shrink the survivor list to drive the exact kernel's table-scan path
     const int cap_override = getenv("SFFGPU_SEG_LISTCAP") ? atoi(getenv("SFFGPU_SEG_LISTCAP")) : -1;
     if (cap_override >= 0 && cap_override < aa.items_cap) aa.items_cap = cap_override;
   }
+  if (query_pair_mode(g, tg, a, env)) {
+    hipLaunchKernelGGL(k_query_pair, dim3((a.n + 2 * QP_WAVES - 1) / (2 * QP_WAVES)), dim3(64 * QP_WAVES), 0, s, g, tg ? *tg : none,
+                       queries, aa, *env);
+    return true;
+  }
   hipLaunchKernelGGL(k_query_classify, dim3((a.n + QC_WAVES - 1) / QC_WAVES), dim3(64 * QC_WAVES), 0, s, g, tg ? *tg : none, st,
                      queries, aa, env ? *env : EnvView{}, env ? 1 : 0);
+  return false;
 }
 void launch_collide_items(hipStream_t s, const EnvView& env, const RobotView& rob, const double* pos6, int n_pose,
                           const int32_t* live_flags, uint8_t* pose_hit, const double* a6, const double* b6,
                           const int32_t* seg_ns, int stride, int32_t* ctrl, const void* items, int items_cap,
                           const int32_t* sub, int32_t* first_hit, int32_t* overflow_flag, const TempGridRef* temps,
-                          const int32_t* dev_n) {
+                          const int32_t* dev_n, const ClassifyArgs* pair_src) {
   if (n_pose <= 0) return;
+  TaskSource D{};
+  if (pair_src) {
+    D.on = 1; D.rec_nnb = pair_src->rec_nnb; D.rec_nb = pair_src->rec_nb; D.rec_meta = pair_src->rec_meta;
+    D.parent = pair_src->parent; D.center = pair_src->center; D.pos = pair_src->pos; D.nbcap = pair_src->nbcap;
+    D.goal_id = pair_src->goal_id;
+  }
   {
     const int cap_override = getenv("SFFGPU_SEG_LISTCAP") ? atoi(getenv("SFFGPU_SEG_LISTCAP")) : -1;
     if (cap_override >= 0 && cap_override < items_cap) items_cap = cap_override;
@@ -3032,7 +3514,7 @@ void launch_collide_items(hipStream_t s, const EnvView& env, const RobotView& ro
                      a6, b6, seg_ns, stride, ctrl, static_cast<const SurvivorItem*>(items), items_cap, sub, first_hit,
                      overflow_flag,
                      temps ? temps->tg : GridView{}, temps ? temps->x : nullptr, temps ? temps->y : nullptr,
-                     temps ? temps->z : nullptr, temps ? temps->n : 0, dev_n);
+                     temps ? temps->z : nullptr, temps ? temps->n : 0, dev_n, D);
 }
 
 void launch_star_exact(hipStream_t s, const EnvView& env, const RobotView& rob, const double* store_pos, const StarView& S,

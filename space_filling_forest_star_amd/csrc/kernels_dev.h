@@ -22,11 +22,19 @@ __device__ __forceinline__ void grid_put(const GridView& g, const GridItem& it) 
   const size_t cell = grid_cell_of(g, (float)it.p[0], (float)it.p[1], (float)it.p[2]);
   const int slot = atomicAdd(g.cnt + cell, 1);
   if (g.occ) atomicOr(g.occ + (cell >> 5), 1u << (cell & 31));
+  GridItem32 lt;
+  lt.x = (float)it.p[0]; lt.y = (float)it.p[1]; lt.z = (float)it.p[2];
+  lt.yaw = (float)it.p[3]; lt.pitch = (float)it.p[4]; lt.roll = (float)it.p[5];
+  lt.id = it.id; lt.tree = it.tree;
   if (slot < g.bk) {
     g.items[cell * g.bk + slot] = it;
+    if (g.lite) g.lite[cell * g.bk + slot] = lt;
   } else {
     const int o = atomicAdd(g.ovf_cnt, 1);
-    if (o < g.ovf_cap) g.ovf[o] = it;   // the host checks ovf_cnt against ovf_cap
+    if (o < g.ovf_cap) {   // the host checks ovf_cnt against ovf_cap
+      g.ovf[o] = it;
+      if (g.ovf_lite) g.ovf_lite[o] = lt;
+    }
   }
 }
 
