@@ -450,6 +450,7 @@ int sffgpu_forest_dev_wave_end(sffgpu_forest* f, int32_t* fault) {
     if (*fault) {                      // (a list overflowed: the caller finishes the wave through the host protocol)
       ++f->f->st.host_fallback_waves;
       f->f->dev_to_host();
+      f->f->on_list_fault();
     }
   });
 }

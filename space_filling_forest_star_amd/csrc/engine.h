@@ -105,7 +105,9 @@ struct Ctx {
   // uniform grid over the store (forest engine only)
   bool grid_on = false;
   sffk::GridView gridv{};
-  DevBuf g_cnt, g_items, g_ovfcnt, g_ovf, g_lite, g_ovf_lite;
+  DevBuf g_cnt, g_items, g_ovfcnt, g_ovf, g_lite, g_ovf_lite, g_nl;
+  bool nlist_want = false;   // the forest's queries may use neighbourhood lists (GridView::nl) when the grid allows them
+  bool nlist_off = false;    // a list ran over: off for the rest of the context's life
   DevBuf t_cnt, t_items, t_ovfcnt, t_ovf, t_occ, t_lite, t_ovf_lite;   // the round's own grid (same cells; filled and emptied every round)
   sffk::GridView tgridv{};
   int grid_inserted = 0;
@@ -392,6 +394,12 @@ struct Forest {
   std::vector<std::vector<HitRec>> knn_out;   // scratch of the SFF* k-nearest passes
   std::vector<int32_t> edge_ia, edge_ib;      // ... and of its edge batch
   int hit_cap = 64, nb_cap = 15;  // device list capacities (env SFFGPU_TEST_HITCAP / _NBCAP shrink them in tests)
+  // which neighbour-query kernel serves the rounds: k_query_block (flat work lists of a workgroup, 24 hits per sample,
+  // neighbourhood lists) where a sample sees few neighbours - steps at least as long as the angular range, or 2-D - and
+  // k_query_classify (one wavefront per sample, 64 hits) where the forest fills the angular dimensions too; a list fault
+  // switches to the wide kernel for good
+  bool query_wide = false;
+  void on_list_fault();
   int star_pass_limit = 0;        // SFF* device stage: fixed-point launches per round (0 = SFFK_STAR_PASSES; SFFGPU_TEST_STAR_PASSES)
 
   // post-loop path extraction (src/forest.h:420-462, src/problemStruct.h:184-253)

@@ -136,6 +136,9 @@ Forest::Forest(Ctx* c, const sffgpu_forest_cfg& cf, const double* roots6, int n_
     ctx->grid_bk = 8;
     if (const char* e = getenv("SFFGPU_TEST_GRID_BK")) ctx->grid_bk = std::max(1, std::min(8, atoi(e)));   // tests: tiny buckets to start with
     ctx->grid_cell0 = cell;
+    query_wide = cfg.dim != 2 && std::min(cfg.sampling_dist, cfg.dist_tree) < 2.0 * 3.14159265358979323846;
+    if (hit_cap < 24) query_wide = true;   // (tests shrink the hit list of the wide kernel)
+    ctx->nlist_want = !query_wide && cfg.wave >= 256;
     // the overflow list is checked once per wave and re-celled at a quarter full: three quarters of it must hold
     // whatever TWO waves can add (at most `wave` nodes each; the device engine keeps one wave enqueued ahead of the
     // one whose status it reads), so that no insert is ever dropped between two checks
@@ -578,6 +581,7 @@ void Forest::round_begin() {
   sffk::ClassifyArgs ca{};
   ca.n = n; ca.N0 = Tb; ca.cap = CAP; ca.nbcap = NBCAP; ca.rank = cfg.rank; ca.world = cfg.world;
   ca.goal_id = goal_node;
+  ca.wide = query_wide ? 1 : 0;
   ca.dist_tree = cfg.dist_tree;
   ca.newpos = d_pos;
   ca.in_lim = d_lim;

@@ -792,6 +792,7 @@ void Forest::dev_enqueue_round_eval(void* send_dev, bool sample) {
   sffk::ClassifyArgs ca{};
   ca.n = n; ca.N0 = d.temp_base; ca.cap = B.CAP; ca.nbcap = B.NBCAP; ca.rank = cfg.rank; ca.world = cfg.world;
   ca.goal_id = cfg.has_goal ? goal_node : -1;
+  ca.wide = query_wide ? 1 : 0;
   ca.dist_tree = cfg.dist_tree;
   ca.newpos = B.d_pos;
   ca.in_lim = B.d_lim;
@@ -918,7 +919,7 @@ uint64_t Forest::dev_launch_signature() {
   mix(ptrs, sizeof ptrs);
   const double scal[] = {c.sweep_eps(), c.grid_cell, cfg.sampling_dist, cfg.dist_tree};
   mix(scal, sizeof scal);
-  const int ints[] = {cfg.threshold_misses, star_pass_limit, cfg.wave, c.store_cap, dev.temp_base, hit_cap, nb_cap};
+  const int ints[] = {cfg.threshold_misses, star_pass_limit, cfg.wave, c.store_cap, dev.temp_base, hit_cap, nb_cap, query_wide ? 1 : 0};
   mix(ints, sizeof ints);
   return x ? x : 1;
 }
@@ -1059,6 +1060,26 @@ int Forest::dev_finish_wave(double* wait_ms, int slot, bool stream_idle) {
   return 0;
 }
 
+// a bounded device list ran over and the wave was finished on the host path.  If it was a neighbourhood list, the lists
+// are switched off (the grid is set up again without them); otherwise the forest's queries go to the wide kernel.
+void Forest::on_list_fault() {
+  Ctx& c = *ctx;
+  if (c.gridv.nl) {
+    int32_t v = 0;
+    HIPCHK(hipMemcpyAsync(&v, c.gridv.nl_flag, 4, hipMemcpyDeviceToHost, c.stream));
+    HIPCHK(hipStreamSynchronize(c.stream));
+    if (v) {
+      c.nlist_off = true;
+      double lim[6];
+      memcpy(lim, c.grid_limits, sizeof lim);
+      c.grid_setup(lim, c.grid_cell);
+      c.grid_insert_new();
+      return;
+    }
+  }
+  query_wide = true;
+}
+
 // one wave of the device engine for a caller that owns the exchange (multi-GPU): begin -> done?
 bool Forest::dev_wave_begin() {
   if (!dev.on) throw HipError{"forest: the device engine does not drive this forest"};
@@ -1152,6 +1173,7 @@ void Forest::run_device_seq(int max_waves) {
         int32_t cnt = (int32_t)records.size();
         round_commit(records.data(), cnt, &cnt, 1);
       }
+      on_list_fault();
       dev_upload_state();
     }
   }
@@ -1240,6 +1262,7 @@ void Forest::run_device(int max_waves) {
         int32_t cnt = (int32_t)records.size();
         round_commit(records.data(), cnt, &cnt, 1);
       }
+      on_list_fault();
       dev_upload_state();
     }
   }
@@ -1340,6 +1363,10 @@ void Forest::run_device(int max_waves) {
             "pairs/live %.1f survivors/live %.2f\n", q[1] / qw / 100.0, q[2] / qw / 100.0, q[3] / qw / 100.0, q[4] / qw / 100.0,
             q[7] / qw, (double)q[5] / (double)std::max<unsigned long long>(1ULL, q[7]),
             (double)q[6] / (double)std::max<unsigned long long>(1ULL, q[7]));
+    fprintf(stderr, "[sffgpu block query kernel] us per sampled workgroup: samples %.2f | cells+lists %.2f | 2nd list %.2f | exact %.2f | classify %.2f | cull %.2f | flush %.2f\n",
+            q[1] / qw / 100.0, q[2] / qw / 100.0, q[3] / qw / 100.0, q[4] / qw / 100.0, q[5] / qw / 100.0, q[6] / qw / 100.0, q[7] / qw / 100.0);
+    fprintf(stderr, "[sffgpu block query kernel] shader clock over the sampled workgroups' lifetimes: %.0f MHz (lifetime %.2f us)\n",
+            100.0 * (double)q[10] / (double)std::max<unsigned long long>(1ULL, q[11]), q[11] / qw / 100.0);
     fprintf(stderr, "[sffgpu paired query kernel] per sampled wave: args %.2f us (its 'flushes' above) | per sampled half: candidates %.2f kept %.2f\n",
             q[4] / qw / 100.0, q[8] / qw, q[9] / qw);
 #endif

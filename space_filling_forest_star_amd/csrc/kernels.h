@@ -60,6 +60,14 @@ struct GridView {
   int ovf_cap;
   GridItem32* lite;   // optional ncells x bk: the items as filter records (same cell / slot)
   GridItem32* ovf_lite;
+  // optional neighbourhood lists: per cell the filter records of EVERY node in the 27 cells around it (each node is
+  // entered 27 times), nl_cap records of 32 bytes, record 0 = header (its id field counts the entries).  A query whose
+  // ball fits the 27 cells around its own cell reads its candidates as ONE contiguous run (~1 KB) instead of 27 counts
+  // and ~20 scattered buckets.  Costs 27 atomics + 27 record stores per accepted node and ncells x nl_cap x 32 bytes of
+  // HBM (3 GB on dense_3D).  nl_flag: a list ran over (the host then switches the lists off).
+  GridItem32* nl;
+  int nl_cap;
+  int32_t* nl_flag;
   uint32_t* occ;      // optional occupancy bits (one per cell): the round's own grid is nearly empty, its 100 KB of
                       // bits stay in L2 and spare the queries 27 scattered count loads
 };
@@ -275,6 +283,7 @@ struct ClassifyArgs {
   int32_t* first_hit;       // n x (1+nbcap): preset to INT32_MAX
   int32_t* seg_ovf;         // n x (1+nbcap)
   int32_t* ctrl;            // [1] next task slot of the persistent edge kernel
+  int wide;                 // the forest asks for k_query_classify (many neighbours per sample: see Forest::query_wide)
   const int32_t* dev_n;     // device mode: {n, halt} (n above is then the launch bound only)
   unsigned long long* qclk; // device mode: {first wave in, last wave out} clock bracket of the query kernel
   // fused clearance cull (k_query_classify): the wave that wrote a sample's edge tasks looks the clearance bits of

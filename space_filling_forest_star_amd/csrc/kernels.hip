@@ -2400,6 +2400,565 @@ __global__ __launch_bounds__(64 * QP_WAVES) __attribute__((amdgpu_waves_per_eu(Q
   if (clocked) atomicMax(A.qclk + 1, wall_clock64());
 }
 
+// ------------------------------------------------------------------ block query kernel
+// The same work as k_query_pair, organised as flat work lists of a 256-thread workgroup that serves QB_S samples.  What
+// the counters said about one-wavefront-per-sample and two-samples-per-wavefront (profiles/r3_sq_summary.json,
+// r4a_pair_sq_summary.json): the vector ALUs are the bottleneck (VALU busy 11 us per SIMD of a 25 us launch) although
+// most instructions run with a handful of useful lanes - five hits, two kept edges, seven (task, chunk) pairs per sample.
+// Here every phase runs lane = work item over ALL the workgroup's samples, with the lists in LDS:
+//   0  the samples' scalars (one thread per sample) -> LDS; cell box, parent edge in clearance-grid cells
+//   1  lane = (sample, cell): count, first filter record of the bucket, fp32 superset filter -> candidate list; the other
+//      records of deeper buckets and the cells of the round's own grid whose occupancy bit is set -> a second work list;
+//      beside it lane = one group of eight samples of the parent edges' first four chunks: clearance bit requested
+//   2  lane = entry of the second work list
+//   3  lane = candidate: authoritative fp64 position from the store, exact distance -> per-sample hit lists
+//   4  32 lanes per sample: classification (k_classify's logic), neighbour records, the kept edges' cull rows
+//   5  lane = edge task: its 64-sample chunks -> (task, chunk) pair table (block-wide prefix, windows)
+//   6  lane = one group of eight samples of a pair: clearance bit -> masks -> survivors (LDS, one pair of atomics per
+//      workgroup on the exact kernel's list)
+//   7  end points of the tasks that left a survivor, flags
+// Bounded lists: QB_HC exact hits per sample, 24 filter candidates and 48 deep-bucket records per sample on average over
+// the workgroup; a sample that loses an entry gets flag 2 (host path), like every list overflow.
+#define QB_S 8
+#define QB_HC 24
+#define QB_TASKS 17
+#ifndef QB_OCC
+#define QB_OCC 8   // 8 workgroups per CU: a round's first launches bring 2 048 workgroups, and a launch that does not fit the
+                   // chip at once takes twice a workgroup's lifetime (5 per CU = 1 280 slots for 1 275 workgroups: 27 us)
+#endif
+// the positions of `want` lanes in an LDS list (one atomic per wavefront); -1 for the others
+__device__ __forceinline__ int wave_reserve(int* counter, bool want, int lane) {
+  const unsigned long long m = __ballot(want);
+  if (!m) return -1;
+  const int leader = __ffsll((long long)m) - 1;
+  int base = 0;
+  if (lane == leader) base = atomicAdd(counter, __popcll(m));
+  base = __shfl(base, leader);
+  return want ? base + __popcll(m & ((1ULL << lane) - 1ULL)) : -1;
+}
+// n entries per lane (converged code only): first position
+__device__ __forceinline__ int wave_reserve_n(int* counter, int n, int lane) {
+  int inc = n;
+  for (int off = 1; off < 64; off <<= 1) {
+    const int o = __shfl_up(inc, off);
+    if (lane >= off) inc += o;
+  }
+  const int total = __shfl(inc, 63);
+  if (!total) return 0;
+  int base = 0;
+  if (lane == 63) base = atomicAdd(counter, total);
+  base = __shfl(base, 63);
+  return base + inc - n;
+}
+enum { QI_MAXID, QI_MINE, QI_FLAGS, QI_FORCE, QI_TOTAL, QI_LX, QI_LY, QI_LZ, QI_WX, QI_WY, QI_NS0, QI_C0, QI_EVAL, QI_QTREE, QI_NNB, QI_LIVE, QI_CELL };
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB_OCC))) void k_query_block(
+    GridView g, GridView tg, const SweepQuery* __restrict__ queries, ClassifyArgs A, EnvView env) {
+  constexpr int S = QB_S, HC = QB_HC, CANDCAP = S * 24, W2CAP = S * 40, PAIRCAP = S * 32, SURVCAP = S * 8;
+  __shared__ float s_q[S][8];            // x y z yaw pitch roll r2f
+  __shared__ int s_i[S][20];
+  __shared__ double s_pd[S], s_qr[S];
+  __shared__ double s_qp[S][6], s_ex[S][6];
+  __shared__ int s_pref[S + 1];
+  __shared__ int s_nhit[S], s_drop[S];
+  __shared__ double h_d[S][HC];
+  __shared__ int h_id[S][HC], h_tree[S][HC];
+  __shared__ int s_rankhit[S][QB_TASKS];
+  __shared__ int c_s[CANDCAP], c_id[CANDCAP], c_tree[CANDCAP];
+  __shared__ int w_s[W2CAP], w_at[W2CAP];
+  __shared__ float s_T[S][QB_TASKS][8];
+  __shared__ int s_NS[S][QB_TASKS], s_need[S][QB_TASKS];
+  __shared__ int s_tab[PAIRCAP];
+  __shared__ SurvivorItem s_surv[SURVCAP];
+  __shared__ int s_cnt[8];               // 0 candidates, 1 second work list, 2 survivors, 3 heavy base, 4 light base
+  __shared__ int s_wsum[4];
+  if (A.dev_n) {
+    if (A.dev_n[1]) return;
+    A.n = A.dev_n[0];
+  }
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int i_base = blockIdx.x * S;
+  if (i_base >= A.n) return;
+  const bool clocked = A.qclk && (blockIdx.x & 15) == 0 && tid == 0;
+  if (clocked) atomicMin(A.qclk, wall_clock64());
+  [[maybe_unused]] const bool qdbg_on = (blockIdx.x & 15) == 0 && tid == 0;
+  [[maybe_unused]] unsigned long long qtp = DBG_T();
+#ifdef SFFK_DEBUG_COUNTERS
+  const unsigned long long qb_c0 = clock64(), qb_r0 = qtp;
+#endif
+#define QB_MARK(k) do { [[maybe_unused]] const unsigned long long t_ = DBG_T(); QDBG(k, t_ - qtp); qtp = t_; } while (0)
+  QDBG(0, 1);
+  const int stride = 1 + A.nbcap;
+  const float nxd = (float)env.clear_n[0], nyd = (float)env.clear_n[1], nzd = (float)env.clear_n[2];
+  const bool have_env = env.n_tri != 0;
+  auto group_addr = [&](bool valid, const float* tt, int ns, int c, int gi, bool& need, int& left, const uint32_t*& wp, int& sh) {
+    const int first = 1 + 64 * c + 8 * gi;
+    need = valid && first <= ns;
+    left = ns - first + 1;
+    const int probe = first + 4 <= ns ? first + 4 : ns;
+    wp = nullptr;
+    sh = 0;
+    if (need && env.clear_bits) {
+      const float td = (float)probe;
+      const float fx = __builtin_fmaf(td, tt[4], tt[0]), fy = __builtin_fmaf(td, tt[5], tt[1]), fz = __builtin_fmaf(td, tt[6], tt[2]);
+      if (fx >= 0 && fy >= 0 && fz >= 0 && fx < nxd && fy < nyd && fz < nzd) {
+        const uint32_t ci = ((uint32_t)(int)fz * (uint32_t)env.clear_n[1] + (uint32_t)(int)fy) * (uint32_t)env.clear_n[0] + (uint32_t)(int)fx;
+        wp = env.clear_bits + (ci >> 5);
+        sh = (int)(ci & 31u);
+      } else if (fx == fx && fy == fy && fz == fz) {
+        need = false;                                     // beyond the inflated box of the environment
+      }
+    }
+  };
+  // ---- 0. the samples
+  if (tid < 8) s_cnt[tid] = 0;
+  for (int e = tid; e < S * QB_TASKS; e += 256) (&s_need[0][0])[e] = 0;
+  uint32_t word_pose = 0u;     // (thread s keeps its sample's pose bit to the end)
+  int sh_pose = 0;
+  bool need_pose = false;
+  if (tid < S) {
+    const int s = tid, i = i_base + s;
+    const bool act = i < A.n;
+    const int ii = act ? i : i_base;
+    const bool inl = act && A.in_lim[ii] != 0;
+    const SweepQuery* qq = queries + ii;
+    const float r2f = qq->r2f;
+    s_q[s][0] = qq->x; s_q[s][1] = qq->y; s_q[s][2] = qq->z; s_q[s][3] = qq->yaw; s_q[s][4] = qq->pitch; s_q[s][5] = qq->roll; s_q[s][6] = r2f;
+    const float qx = qq->x, qy = qq->y, qz = qq->z;
+    s_qr[s] = qq->r;
+    const double pdist = A.pdist[ii];
+    s_pd[s] = pdist;
+    const int ex = A.center ? 0 : A.parent[ii];
+    const double* qsrc = A.newpos + 6 * (size_t)ii;
+    const double* esrc = A.center ? A.center + 6 * (size_t)ii : A.pos + 6 * (size_t)ex;
+    double e3[6], q3[6];
+    for (int k = 0; k < 6; ++k) { e3[k] = esrc[k]; q3[k] = qsrc[k]; s_ex[s][k] = e3[k]; s_qp[s][k] = q3[k]; }
+    const bool evaluate = inl && (A.world <= 1 || i % A.world == A.rank);
+    s_i[s][QI_MAXID] = qq->max_id; s_i[s][QI_QTREE] = qq->tree;
+    s_i[s][QI_MINE] = A.center ? A.tree[A.N0 + ii] : A.tree[ex];
+    s_i[s][QI_FORCE] = A.force[ii] != 0;
+    s_i[s][QI_FLAGS] = evaluate ? 1 : 0;
+    s_i[s][QI_EVAL] = evaluate ? 1 : 0;
+    s_i[s][QI_NNB] = 0; s_i[s][QI_LIVE] = 0;
+    s_nhit[s] = 0; s_drop[s] = 0;
+    // the parent edge (task 0): isPathFree(expanded, newPoint), src/forest.h:246 - its length is the sample's parentDistance
+    const double parts0 = edge_parts(e3, q3);
+    const int ns0 = edge_samples(parts0);
+    s_i[s][QI_NS0] = ns0;
+    s_i[s][QI_C0] = ns0 > 0 ? (ns0 + 63) >> 6 : 0;
+    const float inv0 = (float)env.clear_inv * __frcp_rn((float)parts0);
+    for (int k = 0; k < 3; ++k) {
+      s_T[s][0][k] = (float)((e3[k] - env.clear_org[k]) * env.clear_inv);
+      s_T[s][0][4 + k] = (float)(q3[k] - e3[k]) * inv0;
+    }
+    s_NS[s][0] = ns0;
+    // the cells the query ball's box touches
+    const float rf = sqrtf(r2f) * 1.000001f;
+    const int lx = grid_coord(qx - rf, g.ox, g.inv_cell, g.nx), hx = grid_coord(qx + rf, g.ox, g.inv_cell, g.nx);
+    const int ly = grid_coord(qy - rf, g.oy, g.inv_cell, g.ny), hy = grid_coord(qy + rf, g.oy, g.inv_cell, g.ny);
+    const int lz = grid_coord(qz - rf, g.oz, g.inv_cell, g.nz), hz = grid_coord(qz + rf, g.oz, g.inv_cell, g.nz);
+    const int wx = hx - lx + 1, wy = hy - ly + 1, wz = hz - lz + 1;
+    const int total = evaluate ? wx * wy * wz : 0;
+    {   // neighbourhood lists: the sample's own cell; its ball must fit the 27 cells around it
+      const int cx = grid_coord(qx, g.ox, g.inv_cell, g.nx), cy = grid_coord(qy, g.oy, g.inv_cell, g.ny),
+                cz = grid_coord(qz, g.oz, g.inv_cell, g.nz);
+      s_i[s][QI_CELL] = (cz * g.ny + cy) * g.nx + cx;
+      if (g.nl && evaluate && (lx < cx - 1 || hx > cx + 1 || ly < cy - 1 || hy > cy + 1 || lz < cz - 1 || hz > cz + 1)) s_drop[s] = 1;
+    }
+    s_i[s][QI_TOTAL] = total; s_i[s][QI_LX] = lx; s_i[s][QI_LY] = ly; s_i[s][QI_LZ] = lz; s_i[s][QI_WX] = wx; s_i[s][QI_WY] = wy;
+    int inc = total;
+    for (int off = 1; off < S; off <<= 1) {
+      const int o = __shfl_up(inc, off);
+      if (s >= off) inc += o;
+    }
+    s_pref[s] = inc - total;
+    if (s == S - 1) s_pref[S] = inc;
+    // the pose's own clearance bit
+    need_pose = evaluate && have_env;
+    if (need_pose && env.clear_bits) {
+      const double fx = (q3[0] - env.clear_org[0]) * env.clear_inv, fy = (q3[1] - env.clear_org[1]) * env.clear_inv,
+                   fz = (q3[2] - env.clear_org[2]) * env.clear_inv;
+      if (fx == fx && fy == fy && fz == fz) {
+        if (fx < 0 || fy < 0 || fz < 0 || fx >= env.clear_n[0] || fy >= env.clear_n[1] || fz >= env.clear_n[2]) {
+          need_pose = false;
+        } else {
+          const long long ci = ((long long)(int)fz * env.clear_n[1] + (int)fy) * env.clear_n[0] + (int)fx;
+          word_pose = env.clear_bits[ci >> 5];
+          sh_pose = (int)(ci & 31);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  QB_MARK(1);
+  // ---- 1. requested now, settled in phase 6: the parent edges' first four chunks, thread = (sample, chunk, group)
+  bool e_need = false;
+  int e_left = 0, e_sh = 0;
+  const uint32_t* e_wp = nullptr;
+  const int e_s = tid >> 5, e_c = (tid >> 3) & 3;
+  if (e_s < S)
+    group_addr(s_i[e_s][QI_EVAL] && have_env && e_c < s_i[e_s][QI_C0], s_T[e_s][0], s_i[e_s][QI_NS0], e_c, tid & 7, e_need, e_left, e_wp, e_sh);
+  const uint32_t e_word = e_wp ? *e_wp : 0u;
+  // fp32 superset filter (the sweep's own: k_sweep)
+  auto passes = [&](int s, const GridItem32& it) -> bool {
+    if (!(it.id < s_i[s][QI_MAXID]) || (s_i[s][QI_QTREE] >= 0 && it.tree != s_i[s][QI_QTREE])) return false;
+    const float r2f = s_q[s][6];
+    const float dx = it.x - s_q[s][0], dy = it.y - s_q[s][1], dz = it.z - s_q[s][2];
+    const float d3 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+    if (!(d3 <= r2f)) return false;
+    const float da = wrapf(it.yaw - s_q[s][3]), db = wrapf(it.pitch - s_q[s][4]), dc = wrapf(it.roll - s_q[s][5]);
+    return fmaf(dc, dc, fmaf(db, db, fmaf(da, da, d3))) <= r2f;
+  };
+  auto add_cand = [&](bool pass, int s, const GridItem32& it) {
+    const int at = wave_reserve(&s_cnt[0], pass, lane);
+    if (pass) {
+      if (at < CANDCAP) { c_s[at] = s; c_id[at] = it.id; c_tree[at] = it.tree; }
+      else s_drop[s] = 1;
+    }
+  };
+  const bool NL = g.nl != nullptr;
+  if (NL) {   // 32 lanes per sample: the sample's neighbourhood list, one contiguous run of filter records
+    const int s = tid >> 5, hl = tid & 31;
+    const bool ev = s_i[s][QI_EVAL] != 0;
+    const GridItem32* L = g.nl + (size_t)s_i[s][QI_CELL] * (size_t)g.nl_cap;
+    GridItem32 a{};
+    if (ev) a = L[hl];
+    int cnt = __shfl(a.id, lane & 32);   // (record 0 = header)
+    if (!ev) cnt = 0;
+    if (cnt > g.nl_cap - 1) { cnt = g.nl_cap - 1; s_drop[s] = 1; }
+    GridItem32 b{}, c{}, d{};
+    if (32 + hl <= cnt) b = L[32 + hl];
+    if (64 + hl <= cnt) c = L[64 + hl];
+    if (96 + hl <= cnt) d = L[96 + hl];
+    add_cand(hl >= 1 && hl <= cnt && passes(s, a), s, a);
+    if (__any(cnt >= 32)) add_cand(32 + hl <= cnt && passes(s, b), s, b);
+    if (__any(cnt >= 64)) add_cand(64 + hl <= cnt && passes(s, c), s, c);
+    if (__any(cnt >= 96)) add_cand(96 + hl <= cnt && passes(s, d), s, d);
+  }
+  {
+    const int E = s_pref[S];
+    for (int e0 = 0; e0 < E; e0 += 256) {
+      const int e = e0 + tid;
+      const bool on = e < E;
+      int s = 0;
+      size_t cell = 0;
+      int m = 0;
+      uint32_t ow = 0u;
+      if (on) {
+        for (int step = S >> 1; step > 0; step >>= 1)
+          if (s_pref[s + step] <= e) s += step;
+        const int c = e - s_pref[s];
+        const int wx = s_i[s][QI_WX], wy = s_i[s][QI_WY];
+        int q1, q2;
+        if (s_i[s][QI_TOTAL] <= 512) {   // (exact: see k_query_classify)
+          q1 = (int)(((float)c + 0.5f) * __frcp_rn((float)wx));
+          q2 = (int)(((float)q1 + 0.5f) * __frcp_rn((float)wy));
+        } else {
+          q1 = c / wx;
+          q2 = q1 / wy;
+        }
+        const int cx = s_i[s][QI_LX] + (c - q1 * wx), cy = s_i[s][QI_LY] + (q1 - q2 * wy), cz = s_i[s][QI_LZ] + q2;
+        cell = ((size_t)cz * g.ny + cy) * g.nx + cx;
+        if (!NL) m = g.cnt[cell];
+        if (tg.cnt) ow = tg.occ ? tg.occ[cell >> 5] : 0xffffffffu;
+        if (m > g.bk) m = g.bk;
+      }
+      GridItem32 it{};
+      if (m > 0) it = g.lite[cell * g.bk];
+      const bool tg_here = on && ((ow >> (cell & 31)) & 1u);
+      // the bucket's other records and the round's own grid: second work list (>= 0: record index; < 0: -1 - cell of tg)
+      const int extra = (m > 1 ? m - 1 : 0) + (tg_here ? 1 : 0);
+      int at = wave_reserve_n(&s_cnt[1], extra, lane);
+      for (int k = 1; k < m; ++k, ++at) {
+        if (at < W2CAP) { w_s[at] = s; w_at[at] = (int)(cell * g.bk) + k; }
+        else s_drop[s] = 1;
+      }
+      if (tg_here) {
+        if (at < W2CAP) { w_s[at] = s; w_at[at] = -1 - (int)cell; }
+        else s_drop[s] = 1;
+      }
+      add_cand(m > 0 && passes(s, it), s, it);
+    }
+  }
+  __syncthreads();
+  QB_MARK(2);
+  // ---- 2. the second work list; the grids' overflow lists
+  {
+    const int n2 = s_cnt[1] < W2CAP ? s_cnt[1] : W2CAP;
+    for (int e0 = 0; e0 < n2; e0 += 256) {
+      const int e = e0 + tid;
+      const bool on = e < n2;
+      const int s = on ? w_s[e] : 0, at = on ? w_at[e] : 0;
+      GridItem32 it{};
+      int mt = 0;
+      size_t tcell = 0;
+      if (on) {
+        if (at >= 0) { it = g.lite[at]; mt = 1; }
+        else {
+          tcell = (size_t)(-1 - at);
+          mt = tg.cnt[tcell];
+          it = tg.lite[tcell * tg.bk];
+          if (mt > tg.bk) mt = tg.bk;
+        }
+      }
+      add_cand(mt > 0 && passes(s, it), s, it);
+      for (int k = 1; __any(k < mt); ++k) {   // (deeper buckets of the round's own grid: rare)
+        GridItem32 b{};
+        if (k < mt) b = tg.lite[tcell * tg.bk + k];
+        add_cand(k < mt && passes(s, b), s, b);
+      }
+    }
+    const int no_g = NL ? 0 : (g.ovf_cnt[0] < g.ovf_cap ? g.ovf_cnt[0] : g.ovf_cap);   // (the lists hold every node)
+    const int no_t = tg.cnt ? (tg.ovf_cnt[0] < tg.ovf_cap ? tg.ovf_cnt[0] : tg.ovf_cap) : 0;
+    for (int e0 = 0; e0 < S * (no_g + no_t); e0 += 256) {
+      const int e = e0 + tid;
+      const bool on = e < S * (no_g + no_t);
+      const int s = on ? e / (no_g + no_t) : 0, j = on ? e - s * (no_g + no_t) : 0;
+      GridItem32 it{};
+      const bool live_s = on && s_i[s][QI_EVAL];
+      if (live_s) it = j < no_g ? g.ovf_lite[j] : tg.ovf_lite[j - no_g];
+      add_cand(live_s && passes(s, it), s, it);
+    }
+  }
+  __syncthreads();
+  QB_MARK(3);
+  // ---- 3. exact test of the candidates on the authoritative fp64 positions
+  {
+    const int nc = s_cnt[0] < CANDCAP ? s_cnt[0] : CANDCAP;
+    for (int e = tid; e < nc; e += 256) {
+      const int s = c_s[e], id = c_id[e];
+      double nbp[6], qp[6];
+      const double* ps = A.pos + 6 * (size_t)id;
+      for (int k = 0; k < 6; ++k) { nbp[k] = ps[k]; qp[k] = s_qp[s][k]; }
+      const double d = dist6(nbp, qp);
+      if (d < s_qr[s]) {
+        const int slot = atomicAdd(&s_nhit[s], 1);
+        if (slot < HC) {
+          h_d[s][slot] = d; h_id[s][slot] = id; h_tree[s][slot] = c_tree[e];
+        }
+      }
+    }
+  }
+  __syncthreads();
+  QB_MARK(4);
+  // ---- 4. classification (k_classify's logic), 32 lanes per sample, lane = hit
+  {
+    const int s = tid >> 5, hl = tid & 31, h = (tid >> 5) & 1;
+    const int i = i_base + s;
+    auto hballot = [&](bool p) -> uint32_t { return (uint32_t)(__ballot(p) >> (h << 5)); };
+    int flags = s_i[s][QI_FLAGS];
+    const bool evaluate = s_i[s][QI_EVAL] != 0;
+    const int n = s_nhit[s];
+    if (evaluate && (s_drop[s] || n > HC || n > A.cap)) flags |= 2;
+    const bool hit = evaluate && !(flags & 2) && hl < n;
+    const int mine = s_i[s][QI_MINE];
+    const double d = hit ? h_d[s][hl] : 0.0;
+    const int t = hit ? h_tree[s][hl] : 0x7fffffff;
+    const int id = hit ? h_id[s][hl] : 0x7fffffff;
+    const bool same = t == mine;
+    const double pdist = s_pd[s];
+    bool q = false;
+    if (hit) q = same ? (!s_i[s][QI_FORCE] && d < pdist - SFFG_TOL)     // src/forest.h:276
+                      : (d < A.dist_tree - SFFG_TOL);                  // src/forest.h:283
+    int rank = 0;
+    uint32_t mm = hballot(q);
+    while (__any(mm != 0u)) {
+      const bool on = mm != 0u;
+      const int src = (lane & 32) + (on ? __ffs((int)mm) - 1 : 0);
+      mm &= mm - 1u;
+      const int tj = __shfl(t, src), idj = __shfl(id, src);
+      const double dj = __shfl(d, src);
+      if (on && (tj < t || (tj == t && (dj < d || (dj == d && idj < id))))) ++rank;
+    }
+    int cut = (q && !same && id < A.N0) ? rank : 0x7fffffff;
+    for (int off = 16; off > 0; off >>= 1) {
+      const int o = __shfl_xor(cut, off);
+      cut = o < cut ? o : cut;
+    }
+    bool keep = q && rank <= cut;
+    int nnb = __popc(hballot(keep));
+    if (nnb > A.nbcap) { flags |= 2; keep = false; nnb = 0; }
+    const bool live = (flags & 3) == 1 && have_env;
+    if (keep) {
+      A.rec_nb[(size_t)i * A.nbcap + rank] = id;
+      A.rec_meta[(size_t)i * A.nbcap + rank] = (t << 1) | (same ? 1 : 0);
+      double ea[6], eb[6], nbp[6];
+      const double* ps = A.pos + 6 * (size_t)id;   // (read a moment ago by this workgroup's exact test: cache-resident)
+      for (int k = 0; k < 6; ++k) nbp[k] = ps[k];
+      if (same) { for (int k = 0; k < 6; ++k) { ea[k] = nbp[k]; eb[k] = s_qp[s][k]; } }                   // isPathFree(neighbour, newPoint) :276
+      else if (id == A.goal_id) { for (int k = 0; k < 6; ++k) { ea[k] = s_qp[s][k]; eb[k] = nbp[k]; } }  // isPathFree(newPoint, goal) :287
+      else { for (int k = 0; k < 6; ++k) { ea[k] = s_ex[s][k]; eb[k] = nbp[k]; } }                        // isPathFree(expanded, neighbour) :288
+      const double parts = edge_parts(ea, eb);
+      const int ns = edge_samples(parts);
+      const size_t slot = (size_t)i * stride + 1 + rank;
+      A.seg_ns[slot] = ns;
+      A.first_hit[slot] = 0x7fffffff;
+      A.seg_ovf[slot] = 0;
+      const float inv = (float)env.clear_inv * __frcp_rn((float)parts);
+      for (int k = 0; k < 3; ++k) {
+        s_T[s][1 + rank][k] = (float)((ea[k] - env.clear_org[k]) * env.clear_inv);
+        s_T[s][1 + rank][4 + k] = (float)(eb[k] - ea[k]) * inv;
+      }
+      s_NS[s][1 + rank] = ns;
+      s_rankhit[s][1 + rank] = hl;
+    }
+    if (hl == 0 && i < A.n) {
+      if ((flags & 3) == 1) {   // slot 0: isPathFree(expanded, newPoint)  (src/forest.h:246)
+        const size_t slot = (size_t)i * stride;
+        A.seg_ns[slot] = s_i[s][QI_NS0];
+        A.first_hit[slot] = 0x7fffffff;
+        A.seg_ovf[slot] = 0;
+      }
+      A.pose_hit[i] = 0;
+      A.rec_flags[i] = flags;
+      A.rec_nnb[i] = nnb;
+      s_i[s][QI_NNB] = nnb;
+      s_i[s][QI_LIVE] = live ? 1 : 0;
+    }
+  }
+  __syncthreads();
+  QB_MARK(5);
+  // ---- 5 + 6. (task, chunk) pairs of the live samples -> groups of eight samples -> clearance bits -> survivors
+  auto add_surv = [&](bool lead, int slot, int c, unsigned long long m) {
+    const int at = wave_reserve(&s_cnt[2], lead, lane);
+    if (lead) {
+      const SurvivorItem it{slot, c, m};
+      if (at < SURVCAP) s_surv[at] = it;
+      else {   // (the workgroup's buffer is full: straight onto the exact kernel's list)
+        SurvivorItem* list = static_cast<SurvivorItem*>(A.items);
+        const int sub_list = blockIdx.x & (SFFK_SUBLISTS - 1), sub_cap = A.items_cap / SFFK_SUBLISTS, half = sub_cap / 2;
+        const bool hv = slot < 0 || __popcll(m) >= QC_HEAVY;
+        const int p = atomicAdd(A.sub + sub_list * SFFK_SUB_STRIDE + (hv ? 0 : 2), 1);
+        if (p < (hv ? half : sub_cap - half)) list[(size_t)sub_list * sub_cap + (hv ? 0 : half) + p] = it;
+        else A.ctrl[3] = 1;
+      }
+    }
+  };
+  auto settle = [&](bool need, int left, const uint32_t* wp, int sh, uint32_t word, int s, int t, int c) {
+    const int gi = lane & 7;
+    if (wp && ((word >> sh) & 1u)) need = false;
+    unsigned long long m = need ? (((left >= 8 ? 0xffULL : ((1ULL << left) - 1ULL))) << (8 * gi)) : 0ULL;
+    m |= __shfl_xor(m, 1);
+    m |= __shfl_xor(m, 2);
+    m |= __shfl_xor(m, 4);
+    const bool lead = gi == 0 && m != 0ULL;
+    if (lead) s_need[s][t] = 1;
+    add_surv(lead, (int32_t)((i_base + s) * stride + t), c, m);
+  };
+  // the parent edges' first four chunks (requested in phase 1)
+  settle(e_s < S && e_need && s_i[e_s < S ? e_s : 0][QI_LIVE], e_left, e_wp, e_sh, e_word, e_s < S ? e_s : 0, 0, e_c);
+  {
+    // pairs of a task: the parent edge's chunks beyond four, every chunk of a kept edge
+    const int tk_s = tid / QB_TASKS, tk_t = tid - tk_s * QB_TASKS;
+    int nch = 0;
+    if (tk_s < S && s_i[tk_s][QI_LIVE] && tk_t <= s_i[tk_s][QI_NNB]) {
+      const int ns = s_NS[tk_s][tk_t];
+      nch = ns > 0 ? (ns + 63) >> 6 : 0;
+      if (tk_t == 0) nch = nch > 4 ? nch - 4 : 0;
+    }
+    int inc = nch;
+    for (int off = 1; off < 64; off <<= 1) {
+      const int o = __shfl_up(inc, off);
+      if (lane >= off) inc += o;
+    }
+    if (lane == 63) s_wsum[wv] = inc;
+    __syncthreads();
+    int before = 0, P = 0;
+    for (int w = 0; w < 4; ++w) { if (w < wv) before += s_wsum[w]; P += s_wsum[w]; }
+    const int first = before + inc - nch;
+    for (int w0 = 0; w0 < P; w0 += PAIRCAP) {
+      if (w0) __syncthreads();
+      for (int c = 0; c < nch; ++c) {
+        const int p = first + c - w0;
+        if (p >= 0 && p < PAIRCAP) s_tab[p] = (tk_s << 24) | (tk_t << 16) | ((tk_t == 0 ? 4 : 0) + c);
+      }
+      __syncthreads();
+      const int wn = P - w0 < PAIRCAP ? P - w0 : PAIRCAP;
+      for (int e0 = 0; e0 < 8 * wn; e0 += 256) {
+        const int e = e0 + tid;
+        const bool valid = e < 8 * wn;
+        const int ent = valid ? s_tab[e >> 3] : 0;
+        const int s = ent >> 24, t = (ent >> 16) & 0xff, c = ent & 0xffff;
+        bool need;
+        int left, sh;
+        const uint32_t* wp;
+        group_addr(valid, s_T[s][t], s_NS[s][t], c, tid & 7, need, left, wp, sh);
+        const uint32_t word = wp ? *wp : 0u;
+        settle(need, left, wp, sh, word, s, t, c);
+      }
+    }
+  }
+  // the poses the bits leave open
+  if (tid < S) {
+    const bool open = s_i[tid][QI_LIVE] && need_pose && !((word_pose >> sh_pose) & 1u);
+    if (open) {
+      const int at = atomicAdd(&s_cnt[2], 1);
+      const SurvivorItem it{-1 - (i_base + tid), 0, 0ULL};
+      if (at < SURVCAP) s_surv[at] = it;
+      else {
+        SurvivorItem* list = static_cast<SurvivorItem*>(A.items);
+        const int sub_list = blockIdx.x & (SFFK_SUBLISTS - 1), sub_cap = A.items_cap / SFFK_SUBLISTS, half = sub_cap / 2;
+        const int p = atomicAdd(A.sub + sub_list * SFFK_SUB_STRIDE, 1);
+        if (p < half) list[(size_t)sub_list * sub_cap + p] = it;
+        else A.ctrl[3] = 1;
+      }
+    }
+  }
+  __syncthreads();
+  QB_MARK(6);
+  // ---- 7. the workgroup's survivors -> the exact kernel's list (heavy items in the front half of the sub-list: see
+  // k_query_classify); end points of the tasks that left a survivor
+  {
+    const int ns = s_cnt[2] < SURVCAP ? s_cnt[2] : SURVCAP;
+    if (wv == 0 && ns > 0) {
+      SurvivorItem* list = static_cast<SurvivorItem*>(A.items);
+      const int sub_list = blockIdx.x & (SFFK_SUBLISTS - 1), sub_cap = A.items_cap / SFFK_SUBLISTS, half = sub_cap / 2;
+      for (int b0 = 0; b0 < ns; b0 += 64) {
+        const bool mineb = b0 + lane < ns;
+        const SurvivorItem it = mineb ? s_surv[b0 + lane] : SurvivorItem{0, 0, 0ULL};
+        const bool hv = mineb && (it.slot < 0 || __popcll(it.mask) >= QC_HEAVY);
+        const unsigned long long hm = __ballot(hv), lm = __ballot(mineb && !hv), below = (1ULL << lane) - 1ULL;
+        int bh = 0, bl = 0;
+        if (lane == 0) {
+          if (hm) bh = atomicAdd(A.sub + sub_list * SFFK_SUB_STRIDE, __popcll(hm));
+          if (lm) bl = atomicAdd(A.sub + sub_list * SFFK_SUB_STRIDE + 2, __popcll(lm));
+        }
+        bh = __shfl(bh, 0); bl = __shfl(bl, 0);
+        if (hv) {
+          const int at = bh + __popcll(hm & below);
+          if (at < half) list[(size_t)sub_list * sub_cap + at] = it;
+          else A.ctrl[3] = 1;
+        } else if (mineb) {
+          const int at = bl + __popcll(lm & below);
+          if (at < sub_cap - half) list[(size_t)sub_list * sub_cap + half + at] = it;
+          else A.ctrl[3] = 1;
+        }
+      }
+    }
+    const int tk_s = tid / QB_TASKS, tk_t = tid - tk_s * QB_TASKS;
+    if (tk_s < S && s_need[tk_s][tk_t]) {
+      const int i = i_base + tk_s;
+      const size_t slot = (size_t)i * stride + tk_t;
+      double* sa = A.seg_a + 6 * slot;
+      double* sb = A.seg_b + 6 * slot;
+      if (tk_t == 0) { for (int k = 0; k < 6; ++k) { sa[k] = s_ex[tk_s][k]; sb[k] = s_qp[tk_s][k]; } }
+      else {
+        const int hj = s_rankhit[tk_s][tk_t];
+        const int id = h_id[tk_s][hj];
+        const bool same = h_tree[tk_s][hj] == s_i[tk_s][QI_MINE];
+        const double* nbp = A.pos + 6 * (size_t)id;
+        if (same) { for (int k = 0; k < 6; ++k) { sa[k] = nbp[k]; sb[k] = s_qp[tk_s][k]; } }
+        else if (id == A.goal_id) { for (int k = 0; k < 6; ++k) { sa[k] = s_qp[tk_s][k]; sb[k] = nbp[k]; } }
+        else { for (int k = 0; k < 6; ++k) { sa[k] = s_ex[tk_s][k]; sb[k] = nbp[k]; } }
+      }
+    }
+  }
+  QB_MARK(7);
+#ifdef SFFK_DEBUG_COUNTERS
+  QDBG(10, clock64() - qb_c0); QDBG(11, wall_clock64() - qb_r0);   // shader clock ticks over 100 MHz ticks: the clock the launch ran at
+#endif
+  if (clocked) atomicMax(A.qclk + 1, wall_clock64());
+}
+
 // Exact collision work of a round straight from the survivor list: persistent wavefronts, wave w takes items
 // w, w + W, ... (about a thousand items over two thousand waves: one item per wave, no pooling needed).
 // Housekeeping first: the round's own grid has been read by the query kernel, the cells it used are emptied here.
@@ -3467,9 +4026,10 @@ void launch_settle(hipStream_t s, const SettleArgs& a) {
 bool query_pair_mode(const GridView& g, const GridView* tg, const ClassifyArgs& a, const EnvView* env) {
   static const char* const knob = getenv("SFFGPU_QUERY");
   if (!env || !g.lite || !g.ovf_lite || a.nbcap > 16) return false;
+  if (a.wide) return false;
   if (tg && tg->cnt && (!tg->lite || !tg->ovf_lite)) return false;
   if (knob && !strcmp(knob, "wide")) return false;
-  if (knob && !strcmp(knob, "pair")) return true;
+  if (knob && (!strcmp(knob, "pair") || !strcmp(knob, "block"))) return true;
   return g.bk <= 8;
 }
 bool launch_query_classify(hipStream_t s, const GridView& g, const GridView* tg, const NodeStoreView& st,
@@ -3482,6 +4042,11 @@ bool launch_query_classify(hipStream_t s, const GridView& g, const GridView* tg,
     if (cap_override >= 0 && cap_override < aa.items_cap) aa.items_cap = cap_override;
   }
   if (query_pair_mode(g, tg, a, env)) {
+    static const char* const knob = getenv("SFFGPU_QUERY");
+    if (!(knob && !strcmp(knob, "pair"))) {
+      hipLaunchKernelGGL(k_query_block, dim3((a.n + QB_S - 1) / QB_S), dim3(256), 0, s, g, tg ? *tg : none, queries, aa, *env);
+      return true;
+    }
     hipLaunchKernelGGL(k_query_pair, dim3((a.n + 2 * QP_WAVES - 1) / (2 * QP_WAVES)), dim3(64 * QP_WAVES), 0, s, g, tg ? *tg : none,
                        queries, aa, *env);
     return true;

@@ -36,6 +36,18 @@ __device__ __forceinline__ void grid_put(const GridView& g, const GridItem& it) 
       if (g.ovf_lite) g.ovf_lite[o] = lt;
     }
   }
+  if (g.nl) {   // the neighbourhood lists of the 27 cells around the node's cell
+    const int cx = grid_coord(lt.x, g.ox, g.inv_cell, g.nx), cy = grid_coord(lt.y, g.oy, g.inv_cell, g.ny),
+              cz = grid_coord(lt.z, g.oz, g.inv_cell, g.nz);
+    for (int k = 0; k < 27; ++k) {
+      const int x = cx + k % 3 - 1, y = cy + (k / 3) % 3 - 1, z = cz + k / 9 - 1;
+      if (x < 0 || y < 0 || z < 0 || x >= g.nx || y >= g.ny || z >= g.nz) continue;
+      GridItem32* L = g.nl + (((size_t)z * g.ny + y) * g.nx + x) * (size_t)g.nl_cap;
+      const int at = atomicAdd(&L[0].id, 1);
+      if (at < g.nl_cap - 1) L[1 + at] = lt;
+      else *g.nl_flag = 1;
+    }
+  }
 }
 
 // ---- survivors of the clearance cull -> items of the exact kernel.  The lead lanes (lane % 8 == 0) of a step each hold one
