@@ -229,7 +229,7 @@ Ctx::~Ctx() {
   for (auto e : pool) (void)hipEventDestroy(e);
   DevBuf* bufs[] = {&env_tri, &env_box, &env_plane, &rob_tri, &sx, &sy, &sz, &syaw, &spitch, &sroll, &stree, &spos,
                     &d_a, &d_b, &d_c, &d_d, &d_e, &d_f, &d_g, &d_h, &r_in, &r_out, &r_out2, &r_q, &r_cnt, &r_hidx,
-                    &r_hdist, &r_sega, &r_segb, &r_items, &r_items2, &r_center, &env_clear, &g_cnt, &g_items, &g_ovfcnt, &g_ovf, &t_cnt, &t_items, &t_ovfcnt, &t_ovf, &t_occ, &g_lite, &g_ovf_lite, &t_lite, &t_ovf_lite, &g_nl, &env_tg_start, &env_tg_list, &r_sub, &env_ext};
+                    &r_hdist, &r_sega, &r_segb, &r_items, &r_items2, &r_center, &r_qrec, &env_clear, &g_cnt, &g_items, &g_ovfcnt, &g_ovf, &t_cnt, &t_items, &t_ovfcnt, &t_ovf, &t_occ, &g_lite, &g_ovf_lite, &t_lite, &t_ovf_lite, &env_tg_start, &env_tg_list, &r_sub, &env_ext};
   for (DevBuf* b : bufs) b->release();
   for (auto& b : level_box) b.release();
   PinBuf* pins[] = {&h_a, &h_b, &h_c, &h_d, &h_e, &h_f, &h_g, &h_h, &p_in, &p_out};
@@ -650,25 +650,8 @@ void Ctx::grid_setup(const double limits[6], double cell) {
   gridv.ovf = g_ovf.as<sffk::GridItem>();
   gridv.lite = g_lite.as<sffk::GridItem32>();
   gridv.ovf_lite = g_ovf_lite.as<sffk::GridItem32>();
-  // neighbourhood lists: only while the cells are as large as the forest asked for (a query ball then fits the 27 cells
-  // around its own), the buckets shallow (few nodes per cell) and the lists fit a few GB
-  {
-    static const int nl_knob = getenv("SFFGPU_NLIST") ? atoi(getenv("SFFGPU_NLIST")) : 0;
-    const int nl_cap = 128;
-    if (nlist_want && !nlist_off && nl_knob && grid_cell0 > 0 && cell >= grid_cell0 && grid_bk <= 8 &&
-        ncells * (size_t)nl_cap * sizeof(sffk::GridItem32) <= ((size_t)6 << 30)) {
-      g_nl.ensure(ncells * (size_t)nl_cap * sizeof(sffk::GridItem32) + 64);
-      // (only the headers have to be zero: one 32-byte column of a ncells-row matrix)
-      HIPCHK(hipMemset2DAsync(g_nl.p, (size_t)nl_cap * sizeof(sffk::GridItem32), 0, sizeof(sffk::GridItem32), ncells, stream));
-      HIPCHK(hipMemsetAsync(static_cast<char*>(g_nl.p) + ncells * (size_t)nl_cap * sizeof(sffk::GridItem32), 0, 64, stream));
-      gridv.nl = g_nl.as<sffk::GridItem32>();
-      gridv.nl_cap = nl_cap;
-      gridv.nl_flag = reinterpret_cast<int32_t*>(static_cast<char*>(g_nl.p) + ncells * (size_t)nl_cap * sizeof(sffk::GridItem32));
-    }
-  }
   // the round's own grid: same cells, its own buckets / overflow list, all counters zero between rounds
   tgridv = gridv;
-  tgridv.nl = nullptr; tgridv.nl_cap = 0; tgridv.nl_flag = nullptr;
   tgridv.bk = 8;
   tgridv.ovf_cap = std::max(1 << 20, tgrid_ovf_min);   // >= the samples of one round (Forest::Forest)
   t_cnt.ensure(ncells * sizeof(int32_t));

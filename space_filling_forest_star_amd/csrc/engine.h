@@ -105,9 +105,7 @@ struct Ctx {
   // uniform grid over the store (forest engine only)
   bool grid_on = false;
   sffk::GridView gridv{};
-  DevBuf g_cnt, g_items, g_ovfcnt, g_ovf, g_lite, g_ovf_lite, g_nl;
-  bool nlist_want = false;   // the forest's queries may use neighbourhood lists (GridView::nl) when the grid allows them
-  bool nlist_off = false;    // a list ran over: off for the rest of the context's life
+  DevBuf g_cnt, g_items, g_ovfcnt, g_ovf, g_lite, g_ovf_lite;
   DevBuf t_cnt, t_items, t_ovfcnt, t_ovf, t_occ, t_lite, t_ovf_lite;   // the round's own grid (same cells; filled and emptied every round)
   sffk::GridView tgridv{};
   int grid_inserted = 0;
@@ -130,6 +128,7 @@ struct Ctx {
   PinBuf h_a, h_b, h_c, h_d, h_e, h_f, h_g, h_h;
   // round pipeline buffers of the forest engine (kept apart from the batch entry points' scratch)
   DevBuf r_in, r_out, r_q, r_cnt, r_hidx, r_hdist, r_sega, r_segb, r_items, r_items2, r_sub, r_center;
+  DevBuf r_qrec;   // per sample: QRec (kernels.h), written by the sampling kernels for k_query_block
   DevBuf r_out2;   // device engine: positions + parent distances of the odd rounds of a wave (see Forest::dev_enqueue_wave_kernels)
   PinBuf p_in, p_out;
 

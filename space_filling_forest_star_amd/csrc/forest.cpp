@@ -138,7 +138,6 @@ Forest::Forest(Ctx* c, const sffgpu_forest_cfg& cf, const double* roots6, int n_
     ctx->grid_cell0 = cell;
     query_wide = cfg.dim != 2 && std::min(cfg.sampling_dist, cfg.dist_tree) < 2.0 * 3.14159265358979323846;
     if (hit_cap < 24) query_wide = true;   // (tests shrink the hit list of the wide kernel)
-    ctx->nlist_want = !query_wide && cfg.wave >= 256;
     // the overflow list is checked once per wave and re-celled at a quarter full: three quarters of it must hold
     // whatever TWO waves can add (at most `wave` nodes each; the device engine keeps one wave enqueued ahead of the
     // one whose status it reads), so that no insert is ever dropped between two checks
@@ -570,6 +569,10 @@ void Forest::round_begin() {
   tmp.n_perm = N0;
   tmp.base = Tb;
   tmp.preset = cfg.libm_sampling ? reinterpret_cast<const double*>(c.r_in.as<char>() + in_preset) : nullptr;
+  c.r_qrec.ensure((size_t)n * sizeof(sffk::QRec));
+  tmp.qrec = c.r_qrec.as<sffk::QRec>();
+  memcpy(tmp.clear_org, c.envv.clear_org, sizeof tmp.clear_org);
+  tmp.clear_inv = c.envv.clear_inv;
   c.time_begin(T_SAMPLE);
   sffk::launch_sample_steer(c.stream, d_words, d_parent, c.spos.as<double>(), nullptr, n, cfg.sampling_dist, cfg.dim,
                             prm, d_pos, d_lim, d_pd, c.r_q.as<sffk::SweepQuery>(), Tb, tmp);
@@ -582,6 +585,7 @@ void Forest::round_begin() {
   ca.n = n; ca.N0 = Tb; ca.cap = CAP; ca.nbcap = NBCAP; ca.rank = cfg.rank; ca.world = cfg.world;
   ca.goal_id = goal_node;
   ca.wide = query_wide ? 1 : 0;
+  ca.qrec = c.r_qrec.as<sffk::QRec>();
   ca.dist_tree = cfg.dist_tree;
   ca.newpos = d_pos;
   ca.in_lim = d_lim;
@@ -613,7 +617,7 @@ void Forest::round_begin() {
   ca.items_cap = list_cap;
   ca.sub = c.r_sub.as<int32_t>();
   ca.pose_hit = d_pose;
-  const bool paired = sffk::launch_query_classify(c.stream, c.gridv, &c.tgridv, c.store_view(), c.r_q.as<sffk::SweepQuery>(), ca, &c.envv);
+  const bool blocked = sffk::launch_query_classify(c.stream, c.gridv, &c.tgridv, c.store_view(), c.r_q.as<sffk::SweepQuery>(), ca, &c.envv);
   c.time_end();
   c.time_begin(T_COLLIDE);
   c.p_out.ensure(o_bytes);
@@ -630,7 +634,7 @@ void Forest::round_begin() {
   tref_keep.n = 0;
   sffk::launch_collide_items(c.stream, c.envv, c.robv, d_pos, n, ca.rec_flags, d_pose, ca.seg_a, ca.seg_b, ca.seg_ns,
                              STRIDE, ca.ctrl, c.r_items.p, ca.items_cap, ca.sub, ca.first_hit, ca.seg_ovf, cfg.optimize ? &tref_keep : &tref,
-                             nullptr, paired ? &ca : nullptr);
+                             nullptr, blocked ? &ca : nullptr);
   c.time_end();
   // samples this rank can settle alone need no replay (with a goal the replay may stop in the middle of the
   // round, so there every sample stays in it)

@@ -668,6 +668,7 @@ static DevRoundBufs dev_round_bufs(Forest& F) {
   c.r_sega.ensure((size_t)n * B.STRIDE * 48);
   c.r_segb.ensure((size_t)n * B.STRIDE * 48);
   c.r_center.ensure((size_t)n * 48);
+  c.r_qrec.ensure((size_t)n * sizeof(sffk::QRec));
   B.list_cap = 4 * n * B.STRIDE + 65536;
   c.r_items.ensure((size_t)B.list_cap * SFFK_ITEM_BYTES);
   c.r_sub.ensure((size_t)SFFK_SUBLISTS * SFFK_SUB_STRIDE * 4);
@@ -743,6 +744,9 @@ static sffk::SampleLaunch dev_sample_launch(Forest& F, const DevRoundBufs& B) {
   P.tmp.n_perm = d.temp_base;
   P.tmp.base = d.temp_base;
   P.tmp.center_out = c.r_center.as<double>();
+  P.tmp.qrec = c.r_qrec.as<sffk::QRec>();
+  memcpy(P.tmp.clear_org, c.envv.clear_org, sizeof P.tmp.clear_org);
+  P.tmp.clear_inv = c.envv.clear_inv;
   P.dv.ctrl = V.ctrl;
   P.dv.act_slot = V.act_slot;
   P.dv.act_slot2 = V.act_slot2;
@@ -793,6 +797,7 @@ void Forest::dev_enqueue_round_eval(void* send_dev, bool sample) {
   ca.n = n; ca.N0 = d.temp_base; ca.cap = B.CAP; ca.nbcap = B.NBCAP; ca.rank = cfg.rank; ca.world = cfg.world;
   ca.goal_id = cfg.has_goal ? goal_node : -1;
   ca.wide = query_wide ? 1 : 0;
+  ca.qrec = c.r_qrec.as<sffk::QRec>();
   ca.dist_tree = cfg.dist_tree;
   ca.newpos = B.d_pos;
   ca.in_lim = B.d_lim;
@@ -822,7 +827,7 @@ void Forest::dev_enqueue_round_eval(void* send_dev, bool sample) {
   ca.items_cap = B.list_cap;
   ca.sub = c.r_sub.as<int32_t>();
   ca.pose_hit = B.d_pose;
-  const bool paired = sffk::launch_query_classify(c.stream, c.gridv, &c.tgridv, c.store_view(), c.r_q.as<sffk::SweepQuery>(), ca, &c.envv);
+  const bool blocked = sffk::launch_query_classify(c.stream, c.gridv, &c.tgridv, c.store_view(), c.r_q.as<sffk::SweepQuery>(), ca, &c.envv);
   c.time_end();
   c.time_begin(T_COLLIDE);
   sffk::TempGridRef tref{c.tgridv, c.sx.as<float>() + d.temp_base, c.sy.as<float>() + d.temp_base,
@@ -833,7 +838,7 @@ void Forest::dev_enqueue_round_eval(void* send_dev, bool sample) {
   tref_keep.n = 0;
   sffk::launch_collide_items(c.stream, c.envv, c.robv, B.d_pos, n, ca.rec_flags, B.d_pose, ca.seg_a, ca.seg_b, ca.seg_ns,
                              B.STRIDE, ca.ctrl, c.r_items.p, ca.items_cap, ca.sub, ca.first_hit, ca.seg_ovf,
-                             cfg.optimize ? &tref_keep : &tref, dev_n, paired ? &ca : nullptr);
+                             cfg.optimize ? &tref_keep : &tref, dev_n, blocked ? &ca : nullptr);
   c.time_end();
   if (send_dev) {
     c.time_begin(T_EXCHANGE);     // (closed by the commit: pack, the caller's / the library's all-gather, unpack)
@@ -914,7 +919,7 @@ uint64_t Forest::dev_launch_signature() {
   mix(&c.tgridv, sizeof c.tgridv);
   mix(&c.envv, sizeof c.envv);
   mix(&c.robv, sizeof c.robv);
-  const void* ptrs[] = {c.r_q.p, c.r_cnt.p, c.r_sega.p, c.r_segb.p, c.r_items.p, c.r_sub.p, c.r_out.p, c.r_center.p, dev.d_parent.p, dev.d_force.p,
+  const void* ptrs[] = {c.r_q.p, c.r_cnt.p, c.r_sega.p, c.r_segb.p, c.r_items.p, c.r_sub.p, c.r_out.p, c.r_center.p, c.r_qrec.p, dev.d_parent.p, dev.d_force.p,
                         dev.ctrl.p, dev.ring.p, dev.trig.p, c.sx.p, c.spos.p, c.stree.p};
   mix(ptrs, sizeof ptrs);
   const double scal[] = {c.sweep_eps(), c.grid_cell, cfg.sampling_dist, cfg.dist_tree};
@@ -1060,25 +1065,9 @@ int Forest::dev_finish_wave(double* wait_ms, int slot, bool stream_idle) {
   return 0;
 }
 
-// a bounded device list ran over and the wave was finished on the host path.  If it was a neighbourhood list, the lists
-// are switched off (the grid is set up again without them); otherwise the forest's queries go to the wide kernel.
-void Forest::on_list_fault() {
-  Ctx& c = *ctx;
-  if (c.gridv.nl) {
-    int32_t v = 0;
-    HIPCHK(hipMemcpyAsync(&v, c.gridv.nl_flag, 4, hipMemcpyDeviceToHost, c.stream));
-    HIPCHK(hipStreamSynchronize(c.stream));
-    if (v) {
-      c.nlist_off = true;
-      double lim[6];
-      memcpy(lim, c.grid_limits, sizeof lim);
-      c.grid_setup(lim, c.grid_cell);
-      c.grid_insert_new();
-      return;
-    }
-  }
-  query_wide = true;
-}
+// a bounded device list ran over and the wave was finished on the host path: the forest's queries go to the wide kernel
+// from here on (64 hits per sample instead of 24)
+void Forest::on_list_fault() { query_wide = true; }
 
 // one wave of the device engine for a caller that owns the exchange (multi-GPU): begin -> done?
 bool Forest::dev_wave_begin() {
@@ -1367,8 +1356,6 @@ void Forest::run_device(int max_waves) {
             q[1] / qw / 100.0, q[2] / qw / 100.0, q[3] / qw / 100.0, q[4] / qw / 100.0, q[5] / qw / 100.0, q[6] / qw / 100.0, q[7] / qw / 100.0);
     fprintf(stderr, "[sffgpu block query kernel] shader clock over the sampled workgroups' lifetimes: %.0f MHz (lifetime %.2f us)\n",
             100.0 * (double)q[10] / (double)std::max<unsigned long long>(1ULL, q[11]), q[11] / qw / 100.0);
-    fprintf(stderr, "[sffgpu paired query kernel] per sampled wave: args %.2f us (its 'flushes' above) | per sampled half: candidates %.2f kept %.2f\n",
-            q[4] / qw / 100.0, q[8] / qw, q[9] / qw);
 #endif
   }
 }

@@ -43,7 +43,7 @@ struct GridItem {   // 64 bytes = one sector pair: the node's authoritative fp64
   int32_t pad[2];
 };
 // The same item as a 32-byte fp32 filter record (the store columns' own double -> float casts): the paired query kernel
-// (k_query_pair) reads these - half the bytes per candidate - and fetches the authoritative fp64 position of the few
+// (k_query_block) reads these - half the bytes per candidate - and fetches the authoritative fp64 position of the few
 // candidates that pass the superset filter from the store (one dependent gather for ~5 of ~34 candidates).
 struct GridItem32 {
   float x, y, z, yaw, pitch, roll;
@@ -60,18 +60,29 @@ struct GridView {
   int ovf_cap;
   GridItem32* lite;   // optional ncells x bk: the items as filter records (same cell / slot)
   GridItem32* ovf_lite;
-  // optional neighbourhood lists: per cell the filter records of EVERY node in the 27 cells around it (each node is
-  // entered 27 times), nl_cap records of 32 bytes, record 0 = header (its id field counts the entries).  A query whose
-  // ball fits the 27 cells around its own cell reads its candidates as ONE contiguous run (~1 KB) instead of 27 counts
-  // and ~20 scattered buckets.  Costs 27 atomics + 27 record stores per accepted node and ncells x nl_cap x 32 bytes of
-  // HBM (3 GB on dense_3D).  nl_flag: a list ran over (the host then switches the lists off).
-  GridItem32* nl;
-  int nl_cap;
-  int32_t* nl_flag;
   uint32_t* occ;      // optional occupancy bits (one per cell): the round's own grid is nearly empty, its 100 KB of
                       // bits stay in L2 and spare the queries 27 scattered count loads
 };
 
+// What k_query_block needs of a sample, written by the kernel that draws it (one thread per sample, lane-dense) instead
+// of being derived by a few lanes of every query workgroup: 32 words, read back with one coalesced load.
+struct QRec {
+  float q[6];        // 0-5   the sample as the fp32 filter sees it
+  float r2f;         // 6     inflated fp32 squared radius
+  int32_t max_id;    // 7     only ids below
+  int32_t mine;      // 8     tree of the expanded node
+  int32_t evaluate;  // 9     inside the limits and owned by this rank
+  int32_t q_tree;    // 10    -1 = all trees
+  int32_t total;     // 11    cells the query ball's box touches (0 when not evaluated)
+  int32_t lx, ly, lz;  // 12-14 its low corner
+  int32_t wx;        // 15    its extent in x ...
+  int32_t ns0;       // 16    samples of the parent edge (src/problemStruct.h:154-168)
+  float t0[6];       // 17-22 parent edge in cells of the clearance grid: start point, step per sample
+  int32_t wy;        // 23    ... and in y
+  double pdist;      // 24-25 parentDistance (src/forest.h:250)
+  double qr;         // 26-27 exact query radius
+  int32_t scratch[4];  // 28-31 (the query kernel's own per-sample words)
+};
 struct SampleParams {
   double limits[6];
   double dist_tree;
@@ -198,6 +209,9 @@ struct RoundTemps {
                           // then only applies the limits test and does its bookkeeping
   double* center_out;     // optional n x 6: the expanded node's position, for k_query_classify (which would otherwise
                           // wait for the sample's parent id before it can ask for that position: one dependent load less)
+  QRec* qrec;             // optional n: the sample as k_query_block wants it (cells of tg, clearance grid below)
+  double clear_org[3];
+  double clear_inv;
 };
 
 size_t collide_lds_bytes(int n_robot_tri, int waves);
@@ -283,6 +297,7 @@ struct ClassifyArgs {
   int32_t* first_hit;       // n x (1+nbcap): preset to INT32_MAX
   int32_t* seg_ovf;         // n x (1+nbcap)
   int32_t* ctrl;            // [1] next task slot of the persistent edge kernel
+  const QRec* qrec;         // n records written by the sampling kernel (RoundTemps::qrec), or null (then no k_query_block)
   int wide;                 // the forest asks for k_query_classify (many neighbours per sample: see Forest::query_wide)
   const int32_t* dev_n;     // device mode: {n, halt} (n above is then the launch bound only)
   unsigned long long* qclk; // device mode: {first wave in, last wave out} clock bracket of the query kernel
@@ -305,12 +320,12 @@ void launch_classify(hipStream_t s, const ClassifyArgs& a);
 // neighbour query + classification in one launch (one wavefront per sample): the hits never leave the wave
 // env != nullptr: with the fused clearance cull (a.items / a.pose_hit / a.ctrl[2]); the exact work is then done by
 // launch_collide_items
-// returns true when the paired kernel (k_query_pair) ran: it writes the end points of the edge tasks that left a survivor
-// only and does not clear unused task slots - launch_collide_items then needs `pair_src` (the same arguments)
+// returns true when the block kernel (k_query_block) ran: it writes the end points of the edge tasks that left a survivor
+// only and does not clear unused task slots - launch_collide_items then needs `block_src` (the same arguments)
 bool launch_query_classify(hipStream_t s, const GridView& g, const GridView* tg, const NodeStoreView& st,
                            const SweepQuery* queries, const ClassifyArgs& a, const EnvView* env = nullptr);
-bool query_pair_mode(const GridView& g, const GridView* tg, const ClassifyArgs& a, const EnvView* env);
-// where k_collide_items finds a task's end points when the survivor list ran over after k_query_pair
+bool query_block_mode(const GridView& g, const GridView* tg, const ClassifyArgs& a, const EnvView* env);
+// where k_collide_items finds a task's end points when the survivor list ran over after k_query_block
 struct TaskSource {
   const int32_t* rec_nnb; const int32_t* rec_nb; const int32_t* rec_meta; const int32_t* parent;
   const double* center; const double* pos;
@@ -322,7 +337,7 @@ void launch_collide_items(hipStream_t s, const EnvView& env, const RobotView& ro
                           const int32_t* live_flags, uint8_t* pose_hit, const double* a6, const double* b6,
                           const int32_t* seg_ns, int stride, int32_t* ctrl, const void* items, int items_cap,
                           const int32_t* sub, int32_t* first_hit, int32_t* overflow_flag, const TempGridRef* temps,
-                          const int32_t* dev_n = nullptr, const ClassifyArgs* pair_src = nullptr);
+                          const int32_t* dev_n = nullptr, const ClassifyArgs* block_src = nullptr);
 struct SettleArgs {
   int n, Tb, nbcap, stride, n_trees;
   const uint8_t* in_lim;

@@ -1962,461 +1962,36 @@ __global__ __launch_bounds__(64 * QC_WAVES) __attribute__((amdgpu_waves_per_eu(Q
   }
 }
 
-// ------------------------------------------------------------------ paired query kernel
-// k_query_classify's work with TWO samples per wavefront (32 lanes each).  What the counters said about the one-sample
-// kernel (profiles/r3_sq_summary.json): its VALU issue slots are full (15 % of the wave cycles x 7 waves per SIMD) while
-// most of its instructions run with a third of the lanes in use (27 cells, ~34 candidates, ~5 hits, ~20 cull groups per
-// step on 64 lanes), and a round's 10 k wavefronts do not fit the 7 168 resident slots.  Here:
-//   - lane = cell (27 of 32 lanes), a lane walks its own bucket: no prefix / binary search to flatten candidates;
-//   - candidates are 32-byte fp32 filter records (GridView::lite); the fp64 position is fetched from the store only for
-//     the few that pass the superset filter (the sweep's own filter: k_sweep);
-//   - the clearance bits of the parent edge's first four chunks and of the pose are requested together with the cell counts
-//     (they depend on the sample only) and looked at after the classification;
+// ------------------------------------------------------------------ block query kernel
+// k_query_classify's work (neighbour query + classification + clearance cull of a round's samples) organised as flat work
+// lists of a 256-thread workgroup that serves QB_S samples.  One wavefront per sample runs most of its instructions with a
+// handful of useful lanes - 27 cells, ~34 candidates, five hits, two kept edges, seven (task, chunk) pairs per sample - and
+// reads every candidate as a 64-byte item.  Here every phase runs lane = work item over ALL the workgroup's samples, with
+// the lists in LDS, and:
+//   - candidates are 32-byte fp32 filter records (GridView::lite); the authoritative fp64 position is fetched from the
+//     store only for the few that pass the superset filter (the sweep's own filter: k_sweep);
+//   - what depends on the sample alone (cell box, parent edge in clearance-grid cells, ...) comes as a QRec from the kernel
+//     that drew the sample; the clearance bits of the parent edge's first four chunks and of the pose are requested
+//     together with the cell counts and looked at after the classification;
 //   - the round's own grid is asked through its occupancy bits (96 KB, cache-resident) instead of its count array;
 //   - edge end points are written only for the tasks that leave a survivor for the exact kernel (k_collide_items derives
 //     them from the records when the survivor list ran over), unused task slots are not cleared (readers trust rec_nnb).
-// Bounded lists: 32 filter candidates per sample (A.cap hits, A.nbcap classified neighbours as before); more = flag 2,
-// the sample takes the host path like any other list overflow.  Launchers fall back to k_query_classify for deep
-// buckets (forests that pile nodes up in xyz cells).
-#define QP_WAVES 4
-#define QP_CAND 32
-#define QP_TAB 64     // (task, chunk) pairs of a sample unfolded at a time
-#define QP_SURV 32    // survivors of a sample gathered in LDS before they are appended
-#define QP_TASKS 17   // parent edge + 16 neighbour tasks
-#ifndef QP_OCC
-#define QP_OCC 5
-#endif
-__global__ __launch_bounds__(64 * QP_WAVES) __attribute__((amdgpu_waves_per_eu(QP_OCC))) void k_query_pair(
-    GridView g, GridView tg, const SweepQuery* __restrict__ queries, ClassifyArgs A, EnvView env) {
-  __shared__ SurvivorItem s_surv[QP_WAVES][2][QP_SURV];
-  __shared__ int32_t s_tab[QP_WAVES][2][QP_TAB];
-  __shared__ int32_t s_cid[QP_WAVES][2][QP_CAND];
-  __shared__ int32_t s_ctree[QP_WAVES][2][QP_CAND];
-  __shared__ float s_T[QP_WAVES][2][QP_TASKS * 8];
-  __shared__ int32_t s_NS[QP_WAVES][2][QP_TASKS];
-  __shared__ int32_t s_need[QP_WAVES][2][QP_TASKS + 3];
-  if (A.dev_n) {
-    if (A.dev_n[1]) return;
-    A.n = A.dev_n[0];
-  }
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, h = lane >> 5, hl = lane & 31;
-  const int i0 = (blockIdx.x * QP_WAVES + wave) * 2;
-  if (i0 >= A.n) return;
-  const bool clocked = A.qclk && (blockIdx.x & 15) == 0 && threadIdx.x == 0;
-  if (clocked) atomicMin(A.qclk, wall_clock64());
-  [[maybe_unused]] const bool qdbg_on = (blockIdx.x & 15) == 0 && lane == 0;
-  [[maybe_unused]] const unsigned long long qt0 = DBG_T();
-  const int i = i0 + h;
-  const bool act = i < A.n;
-  const int ii = act ? i : i0;
-  const int stride = 1 + A.nbcap;
-  const uint32_t below = (1u << hl) - 1u;
-  auto hballot = [&](bool p) -> uint32_t { return (uint32_t)(__ballot(p) >> (h << 5)); };
-  int32_t* const cid = s_cid[wave][h];
-  int32_t* const ctree = s_ctree[wave][h];
-  float* const T = s_T[wave][h];
-  int32_t* const NS = s_NS[wave][h];
-  int32_t* const needf = s_need[wave][h];
-  if (hl < QP_TASKS) needf[hl] = 0;
-  // ---- the sample (every lane of the half holds it: one request per array)
-  const bool inl = act && A.in_lim[ii] != 0;
-  const bool force = A.force[ii] != 0;
-  const double pdist = A.pdist[ii];
-  const SweepQuery* qq = queries + ii;
-  const float qx = qq->x, qy = qq->y, qz = qq->z, qyaw = qq->yaw, qpitch = qq->pitch, qroll = qq->roll, r2f = qq->r2f;
-  const double qr = qq->r;
-  const int q_tree = qq->tree, max_id = qq->max_id;
-  const int ex = A.center ? 0 : A.parent[ii];
-  const int mine = A.center ? A.tree[A.N0 + ii] : A.tree[ex];
-  const double* const qsrc = A.newpos + 6 * (size_t)ii;
-  const double* const esrc = A.center ? A.center + 6 * (size_t)ii : A.pos + 6 * (size_t)ex;
-  const int no_g = g.ovf_cnt[0];
-  const int no_t = tg.cnt ? tg.ovf_cnt[0] : 0;
-  const bool mine_shard = A.world <= 1 || i % A.world == A.rank;
-  const bool evaluate = inl && mine_shard;
-  int flags = evaluate ? 1 : 0, nnb = 0;
-  // the parent edge (task 0): positions in cells of the clearance grid, fp32 (see k_query_classify)
-  double parts0;
-  int ns0;
-  float g0[3], st0[3];
-  {
-    double e3[6], q3[6];
-    for (int k = 0; k < 6; ++k) { e3[k] = esrc[k]; q3[k] = qsrc[k]; }
-    parts0 = edge_parts(e3, q3);
-    ns0 = edge_samples(parts0);
-    const float inv0 = (float)env.clear_inv * __frcp_rn((float)parts0);
-    for (int k = 0; k < 3; ++k) {
-      g0[k] = (float)((e3[k] - env.clear_org[k]) * env.clear_inv);
-      st0[k] = (float)(q3[k] - e3[k]) * inv0;
-    }
-  }
-  const bool cull_on = evaluate && env.n_tri != 0;
-  const float nxd = (float)env.clear_n[0], nyd = (float)env.clear_n[1], nzd = (float)env.clear_n[2];
-  // one group of eight consecutive edge samples -> the address of the bit that answers it (k_query_classify's scheme)
-  auto group_addr = [&](bool valid, float a0, float a1, float a2, float d0, float d1, float d2, int ns, int c, int gi,
-                        bool& need, int& left, const uint32_t*& wp, int& sh) {
-    const int first = 1 + 64 * c + 8 * gi;
-    need = valid && first <= ns;
-    left = ns - first + 1;
-    const int probe = first + 4 <= ns ? first + 4 : ns;
-    wp = nullptr;
-    sh = 0;
-    if (need && env.clear_bits) {
-      const float td = (float)probe;
-      const float fx = __builtin_fmaf(td, d0, a0), fy = __builtin_fmaf(td, d1, a1), fz = __builtin_fmaf(td, d2, a2);
-      if (fx >= 0 && fy >= 0 && fz >= 0 && fx < nxd && fy < nyd && fz < nzd) {
-        const uint32_t ci = ((uint32_t)(int)fz * (uint32_t)env.clear_n[1] + (uint32_t)(int)fy) * (uint32_t)env.clear_n[0] + (uint32_t)(int)fx;
-        wp = env.clear_bits + (ci >> 5);
-        sh = (int)(ci & 31u);
-      } else if (fx == fx && fy == fy && fz == fz) {
-        need = false;                                     // beyond the inflated box of the environment
-      }
-    }
-  };
-  // ---- requested now, looked at after the classification: the parent edge's first four chunks (lane = chunk, group)
-  // and the pose's own bit
-  const int C0 = ns0 > 0 ? (ns0 + 63) >> 6 : 0;
-  bool e_need;
-  int e_left, e_sh;
-  const uint32_t* e_wp;
-  group_addr(cull_on && (hl >> 3) < C0, g0[0], g0[1], g0[2], st0[0], st0[1], st0[2], ns0, hl >> 3, hl & 7, e_need, e_left, e_wp, e_sh);
-  const uint32_t e_word = e_wp ? *e_wp : 0u;
-  const uint32_t* wp_pose = nullptr;
-  int sh_pose = 0;
-  bool need_pose = cull_on;
-  if (cull_on && env.clear_bits) {
-    const double fx = (qsrc[0] - env.clear_org[0]) * env.clear_inv, fy = (qsrc[1] - env.clear_org[1]) * env.clear_inv,
-                 fz = (qsrc[2] - env.clear_org[2]) * env.clear_inv;
-    if (fx == fx && fy == fy && fz == fz) {
-      if (fx < 0 || fy < 0 || fz < 0 || fx >= env.clear_n[0] || fy >= env.clear_n[1] || fz >= env.clear_n[2]) {
-        need_pose = false;
-      } else {
-        const long long ci = ((long long)(int)fz * env.clear_n[1] + (int)fy) * env.clear_n[0] + (int)fx;
-        wp_pose = env.clear_bits + (ci >> 5);
-        sh_pose = (int)(ci & 31);
-      }
-    }
-  }
-  const uint32_t word_pose = wp_pose ? *wp_pose : 0u;
-
-  // ---- neighbour query: lane = cell, fp32 filter records
-  int nc = 0;                                               // filter candidates of the sample (uniform in the half)
-  auto offer = [&](bool on, const GridItem32& it) {
-    bool pass = false;
-    if (on && it.id < max_id && (q_tree < 0 || it.tree == q_tree)) {
-      const float dx = it.x - qx, dy = it.y - qy, dz = it.z - qz;
-      const float d3 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
-      if (d3 <= r2f) {
-        const float da = wrapf(it.yaw - qyaw), db = wrapf(it.pitch - qpitch), dc = wrapf(it.roll - qroll);
-        pass = fmaf(dc, dc, fmaf(db, db, fmaf(da, da, d3))) <= r2f;
-      }
-    }
-    const uint32_t pm = hballot(pass);
-    if (pass) {
-      const int at = nc + __popc(pm & below);
-      if (at < QP_CAND) { cid[at] = it.id; ctree[at] = it.tree; }
-    }
-    nc += __popc(pm);
-  };
-  [[maybe_unused]] const unsigned long long qt1 = DBG_T();
-  if (__any(evaluate)) {
-    const float rf = sqrtf(r2f) * 1.000001f;
-    const int lx = grid_coord(qx - rf, g.ox, g.inv_cell, g.nx), hx = grid_coord(qx + rf, g.ox, g.inv_cell, g.nx);
-    const int ly = grid_coord(qy - rf, g.oy, g.inv_cell, g.ny), hy = grid_coord(qy + rf, g.oy, g.inv_cell, g.ny);
-    const int lz = grid_coord(qz - rf, g.oz, g.inv_cell, g.nz), hz = grid_coord(qz + rf, g.oz, g.inv_cell, g.nz);
-    const int wx = hx - lx + 1, wy = hy - ly + 1, wz = hz - lz + 1;
-    const int total = evaluate ? wx * wy * wz : 0;
-    const float rwx = __frcp_rn((float)wx), rwy = __frcp_rn((float)wy);
-    for (int c0 = 0; __any(c0 < total); c0 += 32) {
-      const int c = c0 + hl;
-      const bool on = c < total;
-      size_t cell = 0;
-      int m = 0, mt = 0;
-      uint32_t ow = 0u;
-      if (on) {
-        int q1, q2;
-        if (total <= 512) {   // (exact: see k_query_classify)
-          q1 = (int)(((float)c + 0.5f) * rwx);
-          q2 = (int)(((float)q1 + 0.5f) * rwy);
-        } else {
-          q1 = c / wx;
-          q2 = q1 / wy;
-        }
-        const int cx = lx + (c - q1 * wx), cy = ly + (q1 - q2 * wy), cz = lz + q2;
-        cell = ((size_t)cz * g.ny + cy) * g.nx + cx;
-        m = g.cnt[cell];
-        if (tg.cnt) ow = tg.occ ? tg.occ[cell >> 5] : 0xffffffffu;
-        if (m > g.bk) m = g.bk;
-      }
-      // the round's own grid: nearly empty - count and first record only where the occupancy bit is set
-      GridItem32 t0{};
-      if (on && ((ow >> (cell & 31)) & 1u)) {
-        mt = tg.cnt[cell];
-        t0 = tg.lite[cell * tg.bk];
-        if (mt > tg.bk) mt = tg.bk;
-      }
-      const GridItem32* bucket = g.lite + cell * g.bk;
-      for (int k = 0; __any(k < m); k += 2) {
-        GridItem32 a{}, b{};
-        if (k < m) a = bucket[k];
-        if (k + 1 < m) b = bucket[k + 1];
-        offer(k < m, a);
-        if (__any(k + 1 < m)) offer(k + 1 < m, b);
-      }
-      if (__any(mt > 0)) {
-        offer(mt > 0, t0);
-        for (int k = 1; __any(k < mt); ++k) {
-          GridItem32 a{};
-          if (k < mt) a = tg.lite[cell * tg.bk + k];
-          offer(k < mt, a);
-        }
-      }
-    }
-    if (no_g > 0) {
-      const int no = no_g < g.ovf_cap ? no_g : g.ovf_cap;
-      for (int j0 = 0; j0 < no; j0 += 32) {
-        GridItem32 a{};
-        const bool on = evaluate && j0 + hl < no;
-        if (on) a = g.ovf_lite[j0 + hl];
-        offer(on, a);
-      }
-    }
-    if (no_t > 0) {
-      const int no = no_t < tg.ovf_cap ? no_t : tg.ovf_cap;
-      for (int j0 = 0; j0 < no; j0 += 32) {
-        GridItem32 a{};
-        const bool on = evaluate && j0 + hl < no;
-        if (on) a = tg.ovf_lite[j0 + hl];
-        offer(on, a);
-      }
-    }
-  }
-  __builtin_amdgcn_wave_barrier();
-  [[maybe_unused]] const unsigned long long qt2 = DBG_T();
-  QDBG(0, 1); QDBG(4, qt1 - qt0); QDBG(1, qt2 - qt1); QDBG(8, nc);
-  // ---- exact test of the candidates (authoritative fp64 positions from the store), classification (k_classify's logic)
-  bool keep = false, same = false;
-  int rank = 0, nb_id = 0, nb_tree = 0, ns_mine = 0;
-  double parts_mine = 0.0;
-  if (evaluate && nc > QP_CAND) flags |= 2;
-  if (__any(evaluate && nc > 0 && nc <= QP_CAND)) {
-    const bool cand = evaluate && nc <= QP_CAND && hl < nc;
-    nb_id = cand ? cid[hl] : 0x7fffffff;
-    nb_tree = cand ? ctree[hl] : 0x7fffffff;
-    double nbp[6], qp[6];
-    for (int k = 0; k < 6; ++k) qp[k] = qsrc[k];
-    double d = 0.0;
-    bool hit = false;
-    if (cand) {
-      const double* ps = A.pos + 6 * (size_t)nb_id;
-      for (int k = 0; k < 6; ++k) nbp[k] = ps[k];
-      d = dist6(nbp, qp);
-      hit = d < qr;
-    }
-    const int cnt = __popc(hballot(hit));
-    if (evaluate && cnt > A.cap) flags |= 2;
-    const int t = hit ? nb_tree : 0x7fffffff;
-    const int id = hit ? nb_id : 0x7fffffff;
-    same = t == mine;
-    bool q = false;
-    if (hit && !(flags & 2)) q = same ? (!force && d < pdist - SFFG_TOL)       // src/forest.h:276
-                                      : (d < A.dist_tree - SFFG_TOL);          // src/forest.h:283
-    uint32_t mm = hballot(q);
-    while (__any(mm != 0u)) {
-      const bool on = mm != 0u;
-      const int src = (h << 5) + (on ? __ffs((int)mm) - 1 : 0);
-      mm &= mm - 1u;
-      const int tj = __shfl(t, src), idj = __shfl(id, src);
-      const double dj = __shfl(d, src);
-      if (on && (tj < t || (tj == t && (dj < d || (dj == d && idj < id))))) ++rank;
-    }
-    int cut = (q && !same && id < A.N0) ? rank : 0x7fffffff;
-    for (int off = 16; off > 0; off >>= 1) {
-      const int o = __shfl_xor(cut, off);
-      cut = o < cut ? o : cut;
-    }
-    keep = q && rank <= cut;
-    const int nkeep = __popc(hballot(keep));
-    if (nkeep > A.nbcap) { flags |= 2; keep = false; }
-    else nnb = nkeep;
-    if (keep) {   // the kept edge's sample count and its row of the cull's table
-      double exq[6], ea[6], eb[6];
-      for (int k = 0; k < 6; ++k) exq[k] = esrc[k];
-      if (same) { for (int k = 0; k < 6; ++k) { ea[k] = nbp[k]; eb[k] = qp[k]; } }                      // isPathFree(neighbour, newPoint) :276
-      else if (nb_id == A.goal_id) { for (int k = 0; k < 6; ++k) { ea[k] = qp[k]; eb[k] = nbp[k]; } }  // isPathFree(newPoint, goal) :287
-      else { for (int k = 0; k < 6; ++k) { ea[k] = exq[k]; eb[k] = nbp[k]; } }                          // isPathFree(expanded, neighbour) :288
-      parts_mine = edge_parts(ea, eb);
-      ns_mine = edge_samples(parts_mine);
-      const float inv = (float)env.clear_inv * __frcp_rn((float)parts_mine);
-      for (int k = 0; k < 3; ++k) {
-        T[8 * (1 + rank) + k] = (float)((ea[k] - env.clear_org[k]) * env.clear_inv);
-        T[8 * (1 + rank) + 4 + k] = (float)(eb[k] - ea[k]) * inv;
-      }
-      NS[1 + rank] = ns_mine;
-    }
-  }
-  const bool live = (flags & 3) == 1 && env.n_tri != 0;
-  // ---- edge tasks: records, and the cull's per-task table (start point, step, sample count)
-  if ((flags & 3) == 1) {
-    if (keep) {
-      A.rec_nb[(size_t)i * A.nbcap + rank] = nb_id;
-      A.rec_meta[(size_t)i * A.nbcap + rank] = (nb_tree << 1) | (same ? 1 : 0);
-      const size_t slot = (size_t)i * stride + 1 + rank;
-      A.seg_ns[slot] = ns_mine;
-      A.first_hit[slot] = 0x7fffffff;
-      A.seg_ovf[slot] = 0;
-    }
-    if (hl == 0) {   // slot 0: isPathFree(expanded, newPoint)  (src/forest.h:246)
-      const size_t slot = (size_t)i * stride;
-      A.seg_ns[slot] = ns0;
-      A.first_hit[slot] = 0x7fffffff;
-      A.seg_ovf[slot] = 0;
-      for (int k = 0; k < 3; ++k) { T[k] = g0[k]; T[4 + k] = st0[k]; }
-      NS[0] = ns0;
-    }
-  }
-  if (act && hl == 0) A.pose_hit[i] = 0;
-  __builtin_amdgcn_wave_barrier();
-  [[maybe_unused]] const unsigned long long qt3 = DBG_T();
-  QDBG(2, qt3 - qt2); QDBG(9, nnb); QDBG(7, live ? 1 : 0);
-  // ---- clearance cull: survivors -> the exact kernel's list
-  if (__any(live)) {
-    SurvivorItem* list = static_cast<SurvivorItem*>(A.items);
-    SurvivorItem* buf = s_surv[wave][h];
-    int n_buf = 0;
-    const int sub_list = blockIdx.x & (SFFK_SUBLISTS - 1), sub_cap = A.items_cap / SFFK_SUBLISTS;
-    auto flush = [&](bool go) {   // (per half)
-      const bool mineb = go && hl < n_buf;
-      SurvivorItem it = mineb ? buf[hl] : SurvivorItem{0, 0, 0ULL};
-      const bool hv = mineb && (it.slot < 0 || __popcll(it.mask) >= QC_HEAVY);
-      const uint32_t hm = hballot(hv), lm = hballot(mineb && !hv);
-      int bh = 0, bl = 0;
-      if (hl == 0 && go) {
-        if (hm) bh = atomicAdd(A.sub + sub_list * SFFK_SUB_STRIDE, __popc(hm));
-        if (lm) bl = atomicAdd(A.sub + sub_list * SFFK_SUB_STRIDE + 2, __popc(lm));
-      }
-      bh = __shfl(bh, h << 5); bl = __shfl(bl, h << 5);
-      const int half = sub_cap / 2;
-      if (hv) {
-        const int at = bh + __popc(hm & below);
-        if (at < half) list[(size_t)sub_list * sub_cap + at] = it;
-        else A.ctrl[3] = 1;
-      } else if (mineb) {
-        const int at = bl + __popc(lm & below);
-        if (at < sub_cap - half) list[(size_t)sub_list * sub_cap + half + at] = it;
-        else A.ctrl[3] = 1;
-      }
-      if (go) n_buf = 0;
-    };
-    // a step's answers -> masks of the (task, chunk) pairs, survivors into the buffer
-    auto settle = [&](bool need, int left, const uint32_t* wp, int sh, uint32_t word, int t, int c) {
-      const int gi = hl & 7;
-      if (wp && ((word >> sh) & 1u)) need = false;
-      unsigned long long m = need ? (((left >= 8 ? 0xffULL : ((1ULL << left) - 1ULL))) << (8 * gi)) : 0ULL;
-      m |= __shfl_xor(m, 1);
-      m |= __shfl_xor(m, 2);
-      m |= __shfl_xor(m, 4);
-      const bool lead = gi == 0 && m != 0ULL;
-      const uint32_t lm = hballot(lead);
-      if (lead) {
-        buf[n_buf + __popc(lm & below)] = SurvivorItem{(int32_t)(i * stride + t), c, m};
-        needf[t] = 1;
-      }
-      n_buf += __popc(lm);
-      if (__any(n_buf > QP_SURV - 5)) flush(n_buf > QP_SURV - 5);
-    };
-    // the parent edge's first four chunks (requested at the top)
-    settle(live && e_need, e_left, e_wp, e_sh, e_word, 0, hl >> 3);
-    // the other pairs: parent chunks beyond four, then the kept edges' chunks (lane r = the kept edge of rank r)
-    const int C0r = live && C0 > 4 ? C0 - 4 : 0;
-    const int my_ns = live && hl < nnb ? NS[1 + hl] : 0;
-    const int my_nch = my_ns > 0 ? (my_ns + 63) >> 6 : 0;
-    int incl = my_nch;
-    for (int off = 1; off < 16; off <<= 1) {
-      const int o = __shfl_up(incl, off);
-      if (hl >= off) incl += o;
-    }
-    const int excl = incl - my_nch;
-    const int P = C0r + __shfl(incl, (h << 5) + 15);     // (nnb <= 15: lanes beyond hold the total)
-    QDBG(5, P + (C0 < 4 ? C0 : 4));
-    int32_t* tab = s_tab[wave][h];
-    const int pu = hl >> 3, gi = hl & 7;
-    for (int w0 = 0; __any(w0 < P); w0 += QP_TAB) {
-      __builtin_amdgcn_wave_barrier();
-      for (int c = hl; c < C0r; c += 32)
-        if (c >= w0 && c < w0 + QP_TAB) tab[c - w0] = 4 + c;                                   // the parent edge: task 0
-      if (hl < nnb)
-        for (int c = 0; c < my_nch; ++c) {
-          const int p = C0r + excl + c;
-          if (p >= w0 && p < w0 + QP_TAB) tab[p - w0] = ((1 + hl) << 16) | (c & 0xffff);
-        }
-      __builtin_amdgcn_wave_barrier();
-      const int wn = P - w0 < QP_TAB ? P - w0 : QP_TAB;   // (<= 0 in a half that is through)
-      for (int q0 = 0; __any(q0 < wn); q0 += 4) {
-        const bool valid = q0 + pu < wn;
-        const int ent = valid ? tab[q0 + pu] : 0;
-        const int t = ent >> 16, c = ent & 0xffff;
-        const float* tt = T + 8 * t;
-        bool need;
-        int left, sh;
-        const uint32_t* wp;
-        group_addr(valid, tt[0], tt[1], tt[2], tt[4], tt[5], tt[6], NS[t], c, gi, need, left, wp, sh);
-        const uint32_t word = wp ? *wp : 0u;
-        settle(need, left, wp, sh, word, t, c);
-      }
-    }
-    if (live && need_pose && !((word_pose >> sh_pose) & 1u)) {   // (uniform in the half)
-      if (hl == 0) buf[n_buf] = SurvivorItem{-1 - i, 0, 0ULL};
-      ++n_buf;
-    }
-    if (__any(n_buf > 0)) flush(n_buf > 0);
-    __builtin_amdgcn_wave_barrier();
-    // end points of the tasks that left a survivor (the exact kernel reads them by slot)
-    if (live) {
-      if (keep && needf[1 + rank]) {
-        double exq[6], nbp[6], qp[6];
-        const double* ps = A.pos + 6 * (size_t)nb_id;
-        for (int k = 0; k < 6; ++k) { exq[k] = esrc[k]; nbp[k] = ps[k]; qp[k] = qsrc[k]; }
-        const size_t slot = (size_t)i * stride + 1 + rank;
-        double* sa = A.seg_a + 6 * slot;
-        double* sb = A.seg_b + 6 * slot;
-        if (same) { for (int k = 0; k < 6; ++k) { sa[k] = nbp[k]; sb[k] = qp[k]; } }
-        else if (nb_id == A.goal_id) { for (int k = 0; k < 6; ++k) { sa[k] = qp[k]; sb[k] = nbp[k]; } }
-        else { for (int k = 0; k < 6; ++k) { sa[k] = exq[k]; sb[k] = nbp[k]; } }
-      }
-      if (hl == 0 && needf[0]) {
-        const size_t slot = (size_t)i * stride;
-        double* sa = A.seg_a + 6 * slot;
-        double* sb = A.seg_b + 6 * slot;
-        for (int k = 0; k < 6; ++k) { sa[k] = esrc[k]; sb[k] = qsrc[k]; }
-      }
-    }
-  }
-  if (act && hl == 0) {
-    A.rec_flags[i] = flags;
-    A.rec_nnb[i] = nnb;
-  }
-  QDBG(3, DBG_T() - qt3);
-  if (clocked) atomicMax(A.qclk + 1, wall_clock64());
-}
-
-// ------------------------------------------------------------------ block query kernel
-// The same work as k_query_pair, organised as flat work lists of a 256-thread workgroup that serves QB_S samples.  What
-// the counters said about one-wavefront-per-sample and two-samples-per-wavefront (profiles/r3_sq_summary.json,
-// r4a_pair_sq_summary.json): the vector ALUs are the bottleneck (VALU busy 11 us per SIMD of a 25 us launch) although
-// most instructions run with a handful of useful lanes - five hits, two kept edges, seven (task, chunk) pairs per sample.
-// Here every phase runs lane = work item over ALL the workgroup's samples, with the lists in LDS:
+// Measured on the bench job: 28.0 -> 23.1 us per launch; two samples per wavefront (32 lanes each) 24.8 us.
+// Phases:
 //   0  the samples' scalars (one thread per sample) -> LDS; cell box, parent edge in clearance-grid cells
-//   1  lane = (sample, cell): count, first filter record of the bucket, fp32 superset filter -> candidate list; the other
-//      records of deeper buckets and the cells of the round's own grid whose occupancy bit is set -> a second work list;
-//      beside it lane = one group of eight samples of the parent edges' first four chunks: clearance bit requested
-//   2  lane = entry of the second work list
+//   1  lane = (sample, cell): count, up to three filter records of the bucket and the first one of the round's own grid
+//      (where its occupancy bit is set) at once, fp32 superset filter -> candidate list; deeper buckets -> a second work
+//      list; beside it lane = one group of eight samples of the parent edges' first four chunks: clearance bit requested
+//   2  lane = entry of the second work list (rare), the grids' overflow lists
 //   3  lane = candidate: authoritative fp64 position from the store, exact distance -> per-sample hit lists
-//   4  32 lanes per sample: classification (k_classify's logic), neighbour records, the kept edges' cull rows
-//   5  lane = edge task: its 64-sample chunks -> (task, chunk) pair table (block-wide prefix, windows)
+//   4  lane = (sample, hit): classification (k_classify's logic: rank by a loop over the sample's hits in LDS, the cut
+//      by an LDS atomicMin), neighbour records, the kept edges' cull rows
+//   5  lane = edge task: its 64-sample chunks -> (task, chunk) pair table
 //   6  lane = one group of eight samples of a pair: clearance bit -> masks -> survivors (LDS, one pair of atomics per
 //      workgroup on the exact kernel's list)
-//   7  end points of the tasks that left a survivor, flags
+//   7  end points of the tasks that left a survivor
+// QB_S samples per workgroup: the instruction stream of a phase is paid once per 64 work items whatever sample they
+// belong to - with 8 samples per workgroup (two per wavefront, like k_query_block) the vector ALUs were as busy as before.
 // Bounded lists: QB_HC exact hits per sample, 24 filter candidates and 48 deep-bucket records per sample on average over
 // the workgroup; a sample that loses an entry gets flag 2 (host path), like every list overflow.
 #define QB_S 8
@@ -2450,13 +2025,13 @@ __device__ __forceinline__ int wave_reserve_n(int* counter, int n, int lane) {
   base = __shfl(base, 63);
   return base + inc - n;
 }
-enum { QI_MAXID, QI_MINE, QI_FLAGS, QI_FORCE, QI_TOTAL, QI_LX, QI_LY, QI_LZ, QI_WX, QI_WY, QI_NS0, QI_C0, QI_EVAL, QI_QTREE, QI_NNB, QI_LIVE, QI_CELL };
+// words of a sample's record in LDS: QRec as the sampling kernel wrote it, the last four words are the kernel's own
+enum { QI_MAXID = 7, QI_MINE = 8, QI_EVAL = 9, QI_QTREE = 10, QI_TOTAL = 11, QI_LX = 12, QI_LY = 13, QI_LZ = 14, QI_WX = 15, QI_NS0 = 16,
+       QI_T0 = 17, QI_WY = 23, QI_PD = 24, QI_QR = 26, QI_FLAGS = 28, QI_NNB = 29, QI_FORCE = 30, QI_LIVE = 31 };
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB_OCC))) void k_query_block(
     GridView g, GridView tg, const SweepQuery* __restrict__ queries, ClassifyArgs A, EnvView env) {
   constexpr int S = QB_S, HC = QB_HC, CANDCAP = S * 24, W2CAP = S * 40, PAIRCAP = S * 32, SURVCAP = S * 8;
-  __shared__ float s_q[S][8];            // x y z yaw pitch roll r2f
-  __shared__ int s_i[S][20];
-  __shared__ double s_pd[S], s_qr[S];
+  __shared__ __attribute__((aligned(16))) int s_i[S][32];   // QRec
   __shared__ double s_qp[S][6], s_ex[S][6];
   __shared__ int s_pref[S + 1];
   __shared__ int s_nhit[S], s_drop[S];
@@ -2509,62 +2084,44 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB_OCC))) v
       }
     }
   };
-  // ---- 0. the samples
-  if (tid < 8) s_cnt[tid] = 0;
+  // ---- 0. the samples' records (written by the sampling kernel: one coalesced word per thread), their fp64 positions
+  auto RF = [&](int s, int w) -> float { return __int_as_float(s_i[s][w]); };
+  auto RD = [&](int s, int w) -> double { return *reinterpret_cast<const double*>(&s_i[s][w]); };
+  if (tid < 5) s_cnt[tid] = 0;
+  if (tid == 255) {   // the grids' overflow lists (empty unless a cell holds more nodes than its bucket)
+    s_cnt[5] = g.ovf_cnt[0] < g.ovf_cap ? g.ovf_cnt[0] : g.ovf_cap;
+    s_cnt[6] = tg.cnt ? (tg.ovf_cnt[0] < tg.ovf_cap ? tg.ovf_cnt[0] : tg.ovf_cap) : 0;
+  }
   for (int e = tid; e < S * QB_TASKS; e += 256) (&s_need[0][0])[e] = 0;
+  for (int e = tid; e < S * 32; e += 256) {
+    const int s = e >> 5, w = e & 31, i = i_base + s;
+    int v = i < A.n ? reinterpret_cast<const int32_t*>(A.qrec)[(size_t)i * 32 + w] : 0;
+    if (w == QI_FLAGS) v = (i < A.n && reinterpret_cast<const int32_t*>(A.qrec)[(size_t)i * 32 + QI_EVAL]) ? 1 : 0;
+    if (w == QI_FORCE) v = i < A.n && A.force[i] != 0;
+    if (w == QI_NNB || w == QI_LIVE) v = 0;
+    s_i[s][w] = v;
+  }
+  for (int e = tid; e < S * 12; e += 256) {
+    const int s = e / 12, k = e - s * 12, i = i_base + s;
+    double v = 0.0;
+    if (i < A.n) {
+      if (k < 6) v = A.newpos[6 * (size_t)i + k];
+      else v = A.center ? A.center[6 * (size_t)i + k - 6] : A.pos[6 * (size_t)A.parent[i] + k - 6];
+    }
+    if (k < 6) s_qp[s][k] = v; else s_ex[s][k - 6] = v;
+  }
   uint32_t word_pose = 0u;     // (thread s keeps its sample's pose bit to the end)
   int sh_pose = 0;
   bool need_pose = false;
   if (tid < S) {
     const int s = tid, i = i_base + s;
     const bool act = i < A.n;
-    const int ii = act ? i : i_base;
-    const bool inl = act && A.in_lim[ii] != 0;
-    const SweepQuery* qq = queries + ii;
-    const float r2f = qq->r2f;
-    s_q[s][0] = qq->x; s_q[s][1] = qq->y; s_q[s][2] = qq->z; s_q[s][3] = qq->yaw; s_q[s][4] = qq->pitch; s_q[s][5] = qq->roll; s_q[s][6] = r2f;
-    const float qx = qq->x, qy = qq->y, qz = qq->z;
-    s_qr[s] = qq->r;
-    const double pdist = A.pdist[ii];
-    s_pd[s] = pdist;
-    const int ex = A.center ? 0 : A.parent[ii];
-    const double* qsrc = A.newpos + 6 * (size_t)ii;
-    const double* esrc = A.center ? A.center + 6 * (size_t)ii : A.pos + 6 * (size_t)ex;
-    double e3[6], q3[6];
-    for (int k = 0; k < 6; ++k) { e3[k] = esrc[k]; q3[k] = qsrc[k]; s_ex[s][k] = e3[k]; s_qp[s][k] = q3[k]; }
-    const bool evaluate = inl && (A.world <= 1 || i % A.world == A.rank);
-    s_i[s][QI_MAXID] = qq->max_id; s_i[s][QI_QTREE] = qq->tree;
-    s_i[s][QI_MINE] = A.center ? A.tree[A.N0 + ii] : A.tree[ex];
-    s_i[s][QI_FORCE] = A.force[ii] != 0;
-    s_i[s][QI_FLAGS] = evaluate ? 1 : 0;
-    s_i[s][QI_EVAL] = evaluate ? 1 : 0;
-    s_i[s][QI_NNB] = 0; s_i[s][QI_LIVE] = 0;
+    const QRec* rec = A.qrec + (act ? i : i_base);
+    const bool evaluate = act && rec->evaluate != 0;
+    const int total = evaluate ? rec->total : 0;
     s_nhit[s] = 0; s_drop[s] = 0;
-    // the parent edge (task 0): isPathFree(expanded, newPoint), src/forest.h:246 - its length is the sample's parentDistance
-    const double parts0 = edge_parts(e3, q3);
-    const int ns0 = edge_samples(parts0);
-    s_i[s][QI_NS0] = ns0;
-    s_i[s][QI_C0] = ns0 > 0 ? (ns0 + 63) >> 6 : 0;
-    const float inv0 = (float)env.clear_inv * __frcp_rn((float)parts0);
-    for (int k = 0; k < 3; ++k) {
-      s_T[s][0][k] = (float)((e3[k] - env.clear_org[k]) * env.clear_inv);
-      s_T[s][0][4 + k] = (float)(q3[k] - e3[k]) * inv0;
-    }
-    s_NS[s][0] = ns0;
-    // the cells the query ball's box touches
-    const float rf = sqrtf(r2f) * 1.000001f;
-    const int lx = grid_coord(qx - rf, g.ox, g.inv_cell, g.nx), hx = grid_coord(qx + rf, g.ox, g.inv_cell, g.nx);
-    const int ly = grid_coord(qy - rf, g.oy, g.inv_cell, g.ny), hy = grid_coord(qy + rf, g.oy, g.inv_cell, g.ny);
-    const int lz = grid_coord(qz - rf, g.oz, g.inv_cell, g.nz), hz = grid_coord(qz + rf, g.oz, g.inv_cell, g.nz);
-    const int wx = hx - lx + 1, wy = hy - ly + 1, wz = hz - lz + 1;
-    const int total = evaluate ? wx * wy * wz : 0;
-    {   // neighbourhood lists: the sample's own cell; its ball must fit the 27 cells around it
-      const int cx = grid_coord(qx, g.ox, g.inv_cell, g.nx), cy = grid_coord(qy, g.oy, g.inv_cell, g.ny),
-                cz = grid_coord(qz, g.oz, g.inv_cell, g.nz);
-      s_i[s][QI_CELL] = (cz * g.ny + cy) * g.nx + cx;
-      if (g.nl && evaluate && (lx < cx - 1 || hx > cx + 1 || ly < cy - 1 || hy > cy + 1 || lz < cz - 1 || hz > cz + 1)) s_drop[s] = 1;
-    }
-    s_i[s][QI_TOTAL] = total; s_i[s][QI_LX] = lx; s_i[s][QI_LY] = ly; s_i[s][QI_LZ] = lz; s_i[s][QI_WX] = wx; s_i[s][QI_WY] = wy;
+    for (int k = 0; k < 3; ++k) { s_T[s][0][k] = rec->t0[k]; s_T[s][0][4 + k] = rec->t0[3 + k]; }
+    s_NS[s][0] = rec->ns0;
     int inc = total;
     for (int off = 1; off < S; off <<= 1) {
       const int o = __shfl_up(inc, off);
@@ -2575,6 +2132,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB_OCC))) v
     // the pose's own clearance bit
     need_pose = evaluate && have_env;
     if (need_pose && env.clear_bits) {
+      const double* q3 = A.newpos + 6 * (size_t)i;
       const double fx = (q3[0] - env.clear_org[0]) * env.clear_inv, fy = (q3[1] - env.clear_org[1]) * env.clear_inv,
                    fz = (q3[2] - env.clear_org[2]) * env.clear_inv;
       if (fx == fx && fy == fy && fz == fz) {
@@ -2596,16 +2154,16 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB_OCC))) v
   const uint32_t* e_wp = nullptr;
   const int e_s = tid >> 5, e_c = (tid >> 3) & 3;
   if (e_s < S)
-    group_addr(s_i[e_s][QI_EVAL] && have_env && e_c < s_i[e_s][QI_C0], s_T[e_s][0], s_i[e_s][QI_NS0], e_c, tid & 7, e_need, e_left, e_wp, e_sh);
+    group_addr(s_i[e_s][QI_EVAL] && have_env && e_c < ((s_i[e_s][QI_NS0] + 63) >> 6), s_T[e_s][0], s_i[e_s][QI_NS0], e_c, tid & 7, e_need, e_left, e_wp, e_sh);
   const uint32_t e_word = e_wp ? *e_wp : 0u;
   // fp32 superset filter (the sweep's own: k_sweep)
   auto passes = [&](int s, const GridItem32& it) -> bool {
     if (!(it.id < s_i[s][QI_MAXID]) || (s_i[s][QI_QTREE] >= 0 && it.tree != s_i[s][QI_QTREE])) return false;
-    const float r2f = s_q[s][6];
-    const float dx = it.x - s_q[s][0], dy = it.y - s_q[s][1], dz = it.z - s_q[s][2];
+    const float r2f = RF(s, 6);
+    const float dx = it.x - RF(s, 0), dy = it.y - RF(s, 1), dz = it.z - RF(s, 2);
     const float d3 = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
     if (!(d3 <= r2f)) return false;
-    const float da = wrapf(it.yaw - s_q[s][3]), db = wrapf(it.pitch - s_q[s][4]), dc = wrapf(it.roll - s_q[s][5]);
+    const float da = wrapf(it.yaw - RF(s, 3)), db = wrapf(it.pitch - RF(s, 4)), dc = wrapf(it.roll - RF(s, 5));
     return fmaf(dc, dc, fmaf(db, db, fmaf(da, da, d3))) <= r2f;
   };
   auto add_cand = [&](bool pass, int s, const GridItem32& it) {
@@ -2615,25 +2173,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB_OCC))) v
       else s_drop[s] = 1;
     }
   };
-  const bool NL = g.nl != nullptr;
-  if (NL) {   // 32 lanes per sample: the sample's neighbourhood list, one contiguous run of filter records
-    const int s = tid >> 5, hl = tid & 31;
-    const bool ev = s_i[s][QI_EVAL] != 0;
-    const GridItem32* L = g.nl + (size_t)s_i[s][QI_CELL] * (size_t)g.nl_cap;
-    GridItem32 a{};
-    if (ev) a = L[hl];
-    int cnt = __shfl(a.id, lane & 32);   // (record 0 = header)
-    if (!ev) cnt = 0;
-    if (cnt > g.nl_cap - 1) { cnt = g.nl_cap - 1; s_drop[s] = 1; }
-    GridItem32 b{}, c{}, d{};
-    if (32 + hl <= cnt) b = L[32 + hl];
-    if (64 + hl <= cnt) c = L[64 + hl];
-    if (96 + hl <= cnt) d = L[96 + hl];
-    add_cand(hl >= 1 && hl <= cnt && passes(s, a), s, a);
-    if (__any(cnt >= 32)) add_cand(32 + hl <= cnt && passes(s, b), s, b);
-    if (__any(cnt >= 64)) add_cand(64 + hl <= cnt && passes(s, c), s, c);
-    if (__any(cnt >= 96)) add_cand(96 + hl <= cnt && passes(s, d), s, d);
-  }
   {
     const int E = s_pref[S];
     for (int e0 = 0; e0 < E; e0 += 256) {
@@ -2658,25 +2197,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB_OCC))) v
         }
         const int cx = s_i[s][QI_LX] + (c - q1 * wx), cy = s_i[s][QI_LY] + (q1 - q2 * wy), cz = s_i[s][QI_LZ] + q2;
         cell = ((size_t)cz * g.ny + cy) * g.nx + cx;
-        if (!NL) m = g.cnt[cell];
+        m = g.cnt[cell];
         if (tg.cnt) ow = tg.occ ? tg.occ[cell >> 5] : 0xffffffffu;
         if (m > g.bk) m = g.bk;
       }
-      GridItem32 it{};
-      if (m > 0) it = g.lite[cell * g.bk];
-      const bool tg_here = on && ((ow >> (cell & 31)) & 1u);
-      // the bucket's other records and the round's own grid: second work list (>= 0: record index; < 0: -1 - cell of tg)
-      const int extra = (m > 1 ? m - 1 : 0) + (tg_here ? 1 : 0);
-      int at = wave_reserve_n(&s_cnt[1], extra, lane);
-      for (int k = 1; k < m; ++k, ++at) {
-        if (at < W2CAP) { w_s[at] = s; w_at[at] = (int)(cell * g.bk) + k; }
-        else s_drop[s] = 1;
+      // up to three records of the bucket and the first one of the round's own grid (where its occupancy bit is set) are
+      // requested at once; deeper buckets go through the second work list (>= 0: record of the node grid; < 0: -1 - record
+      // of the round's own grid)
+      GridItem32 i0{}, i1{}, i2{}, t0{};
+      const GridItem32* bucket = g.lite + cell * g.bk;
+      if (m > 0) i0 = bucket[0];
+      if (m > 1) i1 = bucket[1];
+      if (m > 2) i2 = bucket[2];
+      int mt = 0;
+      if (on && ((ow >> (cell & 31)) & 1u)) {
+        mt = tg.cnt[cell];
+        t0 = tg.lite[cell * tg.bk];
+        if (mt > tg.bk) mt = tg.bk;
       }
-      if (tg_here) {
-        if (at < W2CAP) { w_s[at] = s; w_at[at] = -1 - (int)cell; }
-        else s_drop[s] = 1;
+      const int extra = (m > 3 ? m - 3 : 0) + (mt > 1 ? mt - 1 : 0);
+      if (__any(extra > 0)) {
+        int at = wave_reserve_n(&s_cnt[1], extra, lane);
+        for (int k = 3; k < m; ++k, ++at) {
+          if (at < W2CAP) { w_s[at] = s; w_at[at] = (int)(cell * g.bk) + k; }
+          else s_drop[s] = 1;
+        }
+        for (int k = 1; k < mt; ++k, ++at) {
+          if (at < W2CAP) { w_s[at] = s; w_at[at] = -1 - ((int)(cell * tg.bk) + k); }
+          else s_drop[s] = 1;
+        }
       }
-      add_cand(m > 0 && passes(s, it), s, it);
+      add_cand(m > 0 && passes(s, i0), s, i0);
+      if (__any(m > 1)) add_cand(m > 1 && passes(s, i1), s, i1);
+      if (__any(m > 2)) add_cand(m > 2 && passes(s, i2), s, i2);
+      if (__any(mt > 0)) add_cand(mt > 0 && passes(s, t0), s, t0);
     }
   }
   __syncthreads();
@@ -2689,26 +2243,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB_OCC))) v
       const bool on = e < n2;
       const int s = on ? w_s[e] : 0, at = on ? w_at[e] : 0;
       GridItem32 it{};
-      int mt = 0;
-      size_t tcell = 0;
-      if (on) {
-        if (at >= 0) { it = g.lite[at]; mt = 1; }
-        else {
-          tcell = (size_t)(-1 - at);
-          mt = tg.cnt[tcell];
-          it = tg.lite[tcell * tg.bk];
-          if (mt > tg.bk) mt = tg.bk;
-        }
-      }
-      add_cand(mt > 0 && passes(s, it), s, it);
-      for (int k = 1; __any(k < mt); ++k) {   // (deeper buckets of the round's own grid: rare)
-        GridItem32 b{};
-        if (k < mt) b = tg.lite[tcell * tg.bk + k];
-        add_cand(k < mt && passes(s, b), s, b);
-      }
+      if (on) it = at >= 0 ? g.lite[at] : tg.lite[-1 - at];
+      add_cand(on && passes(s, it), s, it);
     }
-    const int no_g = NL ? 0 : (g.ovf_cnt[0] < g.ovf_cap ? g.ovf_cnt[0] : g.ovf_cap);   // (the lists hold every node)
-    const int no_t = tg.cnt ? (tg.ovf_cnt[0] < tg.ovf_cap ? tg.ovf_cnt[0] : tg.ovf_cap) : 0;
+    const int no_g = s_cnt[5], no_t = s_cnt[6];   // (requested in phase 0)
     for (int e0 = 0; e0 < S * (no_g + no_t); e0 += 256) {
       const int e = e0 + tid;
       const bool on = e < S * (no_g + no_t);
@@ -2730,7 +2268,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB_OCC))) v
       const double* ps = A.pos + 6 * (size_t)id;
       for (int k = 0; k < 6; ++k) { nbp[k] = ps[k]; qp[k] = s_qp[s][k]; }
       const double d = dist6(nbp, qp);
-      if (d < s_qr[s]) {
+      if (d < RD(s, QI_QR)) {
         const int slot = atomicAdd(&s_nhit[s], 1);
         if (slot < HC) {
           h_d[s][slot] = d; h_id[s][slot] = id; h_tree[s][slot] = c_tree[e];
@@ -2755,7 +2293,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB_OCC))) v
     const int t = hit ? h_tree[s][hl] : 0x7fffffff;
     const int id = hit ? h_id[s][hl] : 0x7fffffff;
     const bool same = t == mine;
-    const double pdist = s_pd[s];
+    const double pdist = RD(s, QI_PD);
     bool q = false;
     if (hit) q = same ? (!s_i[s][QI_FORCE] && d < pdist - SFFG_TOL)     // src/forest.h:276
                       : (d < A.dist_tree - SFFG_TOL);                  // src/forest.h:283
@@ -3073,7 +2611,7 @@ __global__ __launch_bounds__(64 * SEG_WAVES) __attribute__((amdgpu_waves_per_eu(
       slot = -1 - e; c_lo = c_hi = 0;
     } else {
       slot = e - n_pose;
-      if (D.on) {   // (k_query_pair does not clear the task slots a sample leaves unused)
+      if (D.on) {   // (k_query_block does not clear the task slots a sample leaves unused)
         const int si = slot / stride;
         if ((live_flags[si] & 3) != 1 || slot - si * stride > D.rec_nnb[si]) continue;
       }
@@ -3097,7 +2635,7 @@ __global__ __launch_bounds__(64 * SEG_WAVES) __attribute__((amdgpu_waves_per_eu(
     }
     double a[6], b[6];
     if (D.on && ran_over) {
-      // k_query_pair wrote the end points of the tasks that left a survivor only: with the list run over, every task's
+      // k_query_block wrote the end points of the tasks that left a survivor only: with the list run over, every task's
       // end points come from the sample's records (the rules of src/forest.h:246,276,287,288)
       const int si = slot / stride, t = slot - si * stride;
       const double* pe = D.center ? D.center + 6 * (size_t)si : D.pos + 6 * (size_t)D.parent[si];
@@ -4021,15 +3559,15 @@ void launch_settle(hipStream_t s, const SettleArgs& a) {
   hipLaunchKernelGGL(k_settle, dim3((a.n + 255) / 256), dim3(256), 0, s, a);
 }
 
-// the paired kernel serves forests whose buckets are shallow (its lanes walk their own cell's bucket) and whose
-// samples see few neighbours (32 filter candidates); SFFGPU_QUERY=wide / pair overrides the choice
-bool query_pair_mode(const GridView& g, const GridView* tg, const ClassifyArgs& a, const EnvView* env) {
+// k_query_block serves forests whose buckets are shallow and whose samples see few neighbours (24 exact hits per sample:
+// Forest::query_wide); SFFGPU_QUERY=wide / block overrides the choice
+bool query_block_mode(const GridView& g, const GridView* tg, const ClassifyArgs& a, const EnvView* env) {
   static const char* const knob = getenv("SFFGPU_QUERY");
-  if (!env || !g.lite || !g.ovf_lite || a.nbcap > 16) return false;
+  if (!env || !g.lite || !g.ovf_lite || !a.qrec || a.nbcap > 16) return false;
   if (a.wide) return false;
   if (tg && tg->cnt && (!tg->lite || !tg->ovf_lite)) return false;
   if (knob && !strcmp(knob, "wide")) return false;
-  if (knob && (!strcmp(knob, "pair") || !strcmp(knob, "block"))) return true;
+  if (knob && !strcmp(knob, "block")) return true;
   return g.bk <= 8;
 }
 bool launch_query_classify(hipStream_t s, const GridView& g, const GridView* tg, const NodeStoreView& st,
@@ -4041,14 +3579,8 @@ bool launch_query_classify(hipStream_t s, const GridView& g, const GridView* tg,
     const int cap_override = getenv("SFFGPU_SEG_LISTCAP") ? atoi(getenv("SFFGPU_SEG_LISTCAP")) : -1;
     if (cap_override >= 0 && cap_override < aa.items_cap) aa.items_cap = cap_override;
   }
-  if (query_pair_mode(g, tg, a, env)) {
-    static const char* const knob = getenv("SFFGPU_QUERY");
-    if (!(knob && !strcmp(knob, "pair"))) {
-      hipLaunchKernelGGL(k_query_block, dim3((a.n + QB_S - 1) / QB_S), dim3(256), 0, s, g, tg ? *tg : none, queries, aa, *env);
-      return true;
-    }
-    hipLaunchKernelGGL(k_query_pair, dim3((a.n + 2 * QP_WAVES - 1) / (2 * QP_WAVES)), dim3(64 * QP_WAVES), 0, s, g, tg ? *tg : none,
-                       queries, aa, *env);
+  if (query_block_mode(g, tg, a, env)) {
+    hipLaunchKernelGGL(k_query_block, dim3((a.n + QB_S - 1) / QB_S), dim3(256), 0, s, g, tg ? *tg : none, queries, aa, *env);
     return true;
   }
   hipLaunchKernelGGL(k_query_classify, dim3((a.n + QC_WAVES - 1) / QC_WAVES), dim3(64 * QC_WAVES), 0, s, g, tg ? *tg : none, st,
@@ -4059,13 +3591,13 @@ void launch_collide_items(hipStream_t s, const EnvView& env, const RobotView& ro
                           const int32_t* live_flags, uint8_t* pose_hit, const double* a6, const double* b6,
                           const int32_t* seg_ns, int stride, int32_t* ctrl, const void* items, int items_cap,
                           const int32_t* sub, int32_t* first_hit, int32_t* overflow_flag, const TempGridRef* temps,
-                          const int32_t* dev_n, const ClassifyArgs* pair_src) {
+                          const int32_t* dev_n, const ClassifyArgs* block_src) {
   if (n_pose <= 0) return;
   TaskSource D{};
-  if (pair_src) {
-    D.on = 1; D.rec_nnb = pair_src->rec_nnb; D.rec_nb = pair_src->rec_nb; D.rec_meta = pair_src->rec_meta;
-    D.parent = pair_src->parent; D.center = pair_src->center; D.pos = pair_src->pos; D.nbcap = pair_src->nbcap;
-    D.goal_id = pair_src->goal_id;
+  if (block_src) {
+    D.on = 1; D.rec_nnb = block_src->rec_nnb; D.rec_nb = block_src->rec_nb; D.rec_meta = block_src->rec_meta;
+    D.parent = block_src->parent; D.center = block_src->center; D.pos = block_src->pos; D.nbcap = block_src->nbcap;
+    D.goal_id = block_src->goal_id;
   }
   {
     const int cap_override = getenv("SFFGPU_SEG_LISTCAP") ? atoi(getenv("SFFGPU_SEG_LISTCAP")) : -1;

@@ -36,18 +36,6 @@ __device__ __forceinline__ void grid_put(const GridView& g, const GridItem& it) 
       if (g.ovf_lite) g.ovf_lite[o] = lt;
     }
   }
-  if (g.nl) {   // the neighbourhood lists of the 27 cells around the node's cell
-    const int cx = grid_coord(lt.x, g.ox, g.inv_cell, g.nx), cy = grid_coord(lt.y, g.oy, g.inv_cell, g.ny),
-              cz = grid_coord(lt.z, g.oz, g.inv_cell, g.nz);
-    for (int k = 0; k < 27; ++k) {
-      const int x = cx + k % 3 - 1, y = cy + (k / 3) % 3 - 1, z = cz + k / 9 - 1;
-      if (x < 0 || y < 0 || z < 0 || x >= g.nx || y >= g.ny || z >= g.nz) continue;
-      GridItem32* L = g.nl + (((size_t)z * g.ny + y) * g.nx + x) * (size_t)g.nl_cap;
-      const int at = atomicAdd(&L[0].id, 1);
-      if (at < g.nl_cap - 1) L[1 + at] = lt;
-      else *g.nl_flag = 1;
-    }
-  }
 }
 
 // ---- survivors of the clearance cull -> items of the exact kernel.  The lead lanes (lane % 8 == 0) of a step each hold one
@@ -234,6 +222,32 @@ __device__ __forceinline__ void sample_steer_one(int tid, int i, int slot, const
       q.active = (ok && (prm.world <= 1 || i % prm.world == prm.rank)) ? 1 : 0;
       q.pad = 0;
       queries[i] = q;
+      if (tmp.qrec) {
+        QRec r;
+        r.q[0] = q.x; r.q[1] = q.y; r.q[2] = q.z; r.q[3] = q.yaw; r.q[4] = q.pitch; r.q[5] = q.roll;
+        r.r2f = q.r2f; r.max_id = q.max_id; r.q_tree = q.tree;
+        r.mine = tmp.cnt ? tmp.st.tree[par] : 0;
+        r.evaluate = q.active;
+        // the cells the query ball's box touches (the round's own grid has the node grid's cells)
+        const GridView& g = tmp.tg;
+        const float rf = sqrtf(q.r2f) * 1.000001f;
+        const int lx = grid_coord(q.x - rf, g.ox, g.inv_cell, g.nx), hx = grid_coord(q.x + rf, g.ox, g.inv_cell, g.nx);
+        const int ly = grid_coord(q.y - rf, g.oy, g.inv_cell, g.ny), hy = grid_coord(q.y + rf, g.oy, g.inv_cell, g.ny);
+        const int lz = grid_coord(q.z - rf, g.oz, g.inv_cell, g.nz), hz = grid_coord(q.z + rf, g.oz, g.inv_cell, g.nz);
+        r.lx = lx; r.ly = ly; r.lz = lz; r.wx = hx - lx + 1; r.wy = hy - ly + 1;
+        r.total = q.active ? r.wx * r.wy * (hz - lz + 1) : 0;
+        // the parent edge, isPathFree(expanded, newPoint) (src/forest.h:246): its length is parentDistance
+        const double parts0 = pd / 0.1;   // = edge_parts(c, o)
+        r.ns0 = edge_samples(parts0);
+        const float inv0 = (float)tmp.clear_inv * __frcp_rn((float)parts0);
+        for (int k = 0; k < 3; ++k) {
+          r.t0[k] = (float)((c[k] - tmp.clear_org[k]) * tmp.clear_inv);
+          r.t0[3 + k] = (float)(o[k] - c[k]) * inv0;
+        }
+        r.pdist = pd; r.qr = q.r;
+        r.scratch[0] = r.scratch[1] = r.scratch[2] = r.scratch[3] = 0;
+        tmp.qrec[i] = r;
+      }
     }
   }
 }
