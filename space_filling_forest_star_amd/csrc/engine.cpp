@@ -694,9 +694,9 @@ void Ctx::grid_check(bool bulk) {
       const size_t cells_now = (size_t)gridv.nx * gridv.ny * gridv.nz;
       double cell = grid_cell;
       if (cells_now * 4 <= 16777216 && grid_cell * 0.63 >= 0.5 * grid_cell0) cell = grid_cell * 0.63;
-      else if (grid_bk < 64 && cells_now * (size_t)grid_bk * 2 * sizeof(sffk::GridItem) <= ((size_t)24 << 30)) grid_bk *= 2;
+      else if (grid_bk < grid_bk_max() && cells_now * (size_t)grid_bk * 2 * sizeof(sffk::GridItem) <= ((size_t)24 << 30)) grid_bk *= 2;
       else if (cells_now * 4 <= 16777216) cell = grid_cell * 0.63;
-      else gridv_ovf_cap_next = gridv.ovf_cap * 4;
+      else grid_grow_list();
       double lim[6];
       memcpy(lim, grid_limits, sizeof lim);
       grid_setup(lim, cell);
@@ -716,9 +716,9 @@ void Ctx::grid_check(bool bulk) {
   const size_t cells_now = (size_t)gridv.nx * gridv.ny * gridv.nz;
   double cell = grid_cell;
   if (cells_now * 4 <= 16777216 && grid_cell * 0.63 >= 0.5 * grid_cell0) cell = grid_cell * 0.63;   // ~4x the cells
-  else if (grid_bk < 64 && cells_now * (size_t)grid_bk * 2 * sizeof(sffk::GridItem) <= ((size_t)24 << 30))
+  else if (grid_bk < grid_bk_max() && cells_now * (size_t)grid_bk * 2 * sizeof(sffk::GridItem) <= ((size_t)24 << 30))
     grid_bk *= 2;                                           // cell count exhausted: deeper buckets (HBM is plentiful) ...
-  else gridv_ovf_cap_next = gridv.ovf_cap * 4;              // ... and only then a longer list
+  else grid_grow_list();                                    // ... and only then a longer list
   double lim[6];
   memcpy(lim, grid_limits, sizeof lim);
   grid_setup(lim, cell);
@@ -727,6 +727,14 @@ void Ctx::grid_check(bool bulk) {
   HIPCHK(hipMemcpyAsync(&v, g_ovfcnt.p, 4, hipMemcpyDeviceToHost, stream));
   HIPCHK(hipStreamSynchronize(stream));
   if (v > gridv.ovf_cap) throw HipError{"grid overflow list exhausted"};
+}
+
+// cells and buckets cannot grow any further: the overflow list does (x 4, at most 2^26 entries = 4 GB of items), and from
+// here on the re-cell trigger is a quarter of the list instead of 128 entries
+void Ctx::grid_grow_list() {
+  grid_exhausted = true;
+  if (gridv.ovf_cap > (1 << 24)) throw HipError{"neighbour grid: more than 2^24 nodes do not fit their cells' buckets (too many nodes per xyz cell)"};
+  gridv_ovf_cap_next = gridv.ovf_cap * 4;
 }
 
 // slack that makes the fp32 sweep filter a superset of the exact fp64 test: a few fp32 ulps of

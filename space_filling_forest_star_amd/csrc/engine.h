@@ -118,7 +118,13 @@ struct Ctx {
   int gridv_ovf_cap_next = 65536;
   int grid_bk = 8;          // items per cell bucket (doubled when the cells cannot shrink any further)
   // the shared overflow list is scanned by EVERY query: the grid is re-celled as soon as it holds a few batches' worth
-  int grid_rebuild_at() const { return std::min(gridv.ovf_cap / 4, 128); }
+  // overflow entries at which the grid re-cells itself: 128 (every query scans the list) while smaller cells or deeper
+  // buckets can still absorb them; once both are exhausted the list is all that is left to grow, and the trigger scales
+  // with it again (a fixed 128 would re-insert every node and quadruple the list after every wave)
+  bool grid_exhausted = false;
+  int grid_rebuild_at() const { return grid_exhausted ? std::max(128, gridv.ovf_cap / 4) : std::min(gridv.ovf_cap / 4, 128); }
+  void grid_grow_list();
+  static int grid_bk_max() { const char* e = getenv("SFFGPU_TEST_GRID_BKMAX"); return e ? std::max(1, std::min(64, atoi(e))) : 64; }   // (tests: shallow buckets)
   double grid_cell0 = 0;    // the cell edge the forest asked for (re-celling never goes below half of it: a query's
                             // cell count grows with the cube of the ratio)
   int tgrid_ovf_min = 0;    // lower bound of the round grid's overflow list (one wave of samples)

@@ -133,6 +133,7 @@ Forest::Forest(Ctx* c, const sffgpu_forest_cfg& cf, const double* roots6, int n_
     // cell edge >= the planner's neighbour radius max(parentDistance ~ SamplingDistance, treeDistance)
     double cell = 1.01 * std::max(cfg.sampling_dist, cfg.dist_tree) + 4 * ctx->sweep_eps();
     ctx->grid_rebuilds = 0;
+    ctx->grid_exhausted = false;
     ctx->grid_bk = 8;
     if (const char* e = getenv("SFFGPU_TEST_GRID_BK")) ctx->grid_bk = std::max(1, std::min(8, atoi(e)));   // tests: tiny buckets to start with
     ctx->grid_cell0 = cell;

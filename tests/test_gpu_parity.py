@@ -698,6 +698,28 @@ def test_grid_recells_under_overflow_pressure(S, ctx, monkeypatch):
     assert fg.stats()["grid_rebuilds"] >= 1
 
 
+def test_grid_list_growth_settles_when_cells_and_buckets_are_exhausted(S, ctx, monkeypatch):
+    """Many nodes per xyz cell (a 6-DoF forest whose step is small against the angular range, in a box of a few cells)
+    with buckets that may not deepen: cells shrink once, then only the overflow list can grow.  The re-cell trigger has
+    to scale with the list from there on (a fixed trigger re-inserted every node and quadrupled the list after every
+    wave); the neighbour sets - hence the forest - must not change."""
+    monkeypatch.setenv("SFFGPU_TEST_GRID_BK", "1")
+    monkeypatch.setenv("SFFGPU_TEST_GRID_BKMAX", "1")
+    monkeypatch.setenv("SFFGPU_TEST_GRID_OVF", "64")
+    sc, w = load_world(ctx, "triang")
+    lim = [-100, -86, -100, -86, 60, 74]
+    roots = common.free_roots(w.collide, lim, 2, seed=5)
+    kw = dict(dist_tree=sc["dist_tree"], sampling_dist=sc["sampling_dist"], dim=6, max_iterations=9000, wave=128, seed=5)
+    fo = O.Forest(w, roots, lim, **kw)
+    fo.run()
+    fg = S.Forest(ctx, roots, lim, **kw)
+    fg.run()
+    assert_same_forest(fo, fg)
+    st = fg.stats()
+    assert st["n_nodes"] > 80, st["n_nodes"]
+    assert 2 <= st["grid_rebuilds"] <= 12, st["grid_rebuilds"]   # (cells, buckets, then a few list growths - not one per wave)
+
+
 def test_forest_errors(S, ctx):
     sc, w = load_world(ctx, "dense3d")
     roots = common.free_roots(w.collide, sc["limits"], 3)
