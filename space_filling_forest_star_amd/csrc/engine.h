@@ -306,8 +306,9 @@ struct Forest {
   uint64_t dev_launch_signature();
   DevBuf x_send, x_recv;   // answer records of a round: this rank's, all ranks' (native RCCL exchange)
   bool need_host_exchange = false;   // run(): a sharded wave has to be finished through round_begin / round_commit
-  bool exchange_open = false;        // a T_EXCHANGE timer waits for its closing event (recorded behind the unpack)
-  size_t exchange_idx = 0;
+  bool exchange_open = false;        // a T_EXCHANGE timer waits for its closing event (recorded behind the unpack):
+  Ctx::Timed exchange_t{};           // its event pair is kept HERE until then (never as an index into Ctx::pending, which a
+  void exchange_timer_drop();        // sync in between clears), and returned to the pool if the commit never comes
   bool dev_wave_begin();
   size_t dev_exchange_bytes() const;
   void run_device(int max_waves);

@@ -183,7 +183,10 @@ Forest::Forest(Ctx* c, const sffgpu_forest_cfg& cf, const double* roots6, int n_
     // rocprofv3 (ROCm 7.2) crashes while tracing replays of the SFF* wave graph (~130 kernel nodes; the plain SFF graph
     // of ~35 nodes traces fine): under the profiler SFF* waves are launched kernel by kernel
     const char* pre = getenv("LD_PRELOAD");
-    if (pre && strstr(pre, "rocprofiler")) dev.graph_enabled = false;
+    if (pre && strstr(pre, "rocprofiler")) {
+      dev.graph_enabled = false;
+      fprintf(stderr, "[sffgpu] profiler library in LD_PRELOAD: SFF* waves are launched kernel by kernel (SFFGPU_NO_GRAPH=0 / 1 overrides)\n");
+    }
   }
 }
 

@@ -608,6 +608,7 @@ void Forest::sync_host() {
 // leave device mode: the host path owns the state again (its rng continues at the device's cursor)
 void Forest::dev_to_host() {
   DevEngine& d = dev;
+  exchange_timer_drop();
   if (!d.active) return;
   d.host_stale = true;
   sync_host();
@@ -843,8 +844,9 @@ void Forest::dev_enqueue_round_eval(void* send_dev, bool sample) {
   if (send_dev) {
     c.time_begin(T_EXCHANGE);     // (closed by the commit: pack, the caller's / the library's all-gather, unpack)
     sffk::launch_pack_records(c.stream, dev_resolve_args(*this, B), cfg.rank, cfg.world, n, static_cast<int32_t*>(send_dev));
+    exchange_timer_drop();
     exchange_open = c.timed_now;
-    exchange_idx = c.pending.empty() ? 0 : c.pending.size() - 1;
+    if (exchange_open) { exchange_t = c.pending.back(); c.pending.pop_back(); }
   }
   c.timing_on = true;
   c.round_scope = false;
@@ -857,7 +859,11 @@ void Forest::dev_enqueue_round_commit(const void* recv_dev, bool sample_next) {
   const sffk::ResolveArgs ra = dev_resolve_args(*this, B);
   if (recv_dev) {
     sffk::launch_unpack_records(c.stream, ra, cfg.rank, cfg.world, B.n, static_cast<const int32_t*>(recv_dev));
-    if (exchange_open) { HIPCHK(hipEventRecord(c.pending[exchange_idx].b, c.stream)); exchange_open = false; }
+    if (exchange_open) {
+      HIPCHK(hipEventRecord(exchange_t.b, c.stream));
+      c.pending.push_back(exchange_t);
+      exchange_open = false;
+    }
   }
   // (the commit's last kernel also draws the next round's samples - into the other set of sample arrays)
   sffk::SampleLaunch next{};
@@ -1065,6 +1071,13 @@ int Forest::dev_finish_wave(double* wait_ms, int slot, bool stream_idle) {
   return 0;
 }
 
+void Forest::exchange_timer_drop() {
+  if (!exchange_open) return;
+  ctx->pool.push_back(exchange_t.a);
+  ctx->pool.push_back(exchange_t.b);
+  exchange_open = false;
+}
+
 // a bounded device list ran over and the wave was finished on the host path: the forest's queries go to the wide kernel
 // from here on (64 hits per sample instead of 24)
 void Forest::on_list_fault() { query_wide = true; }
@@ -1073,6 +1086,7 @@ void Forest::on_list_fault() { query_wide = true; }
 bool Forest::dev_wave_begin() {
   if (!dev.on) throw HipError{"forest: the device engine does not drive this forest"};
   HIPCHK(hipSetDevice(ctx->device));
+  exchange_timer_drop();
   if (!dev.active) dev_upload_state();
   const sffk::DevCtrl& k = dev.last;
   if (!k.in_wave && k.terminated) return false;

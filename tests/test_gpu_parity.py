@@ -524,11 +524,13 @@ def test_sff_star_at_two_million_nodes(S, ctx):
     f.close()
 
 
-@pytest.mark.parametrize("fixture", ["c5_full_run.json", "c5_full_run_w8192.json"])
+@pytest.mark.parametrize("fixture", ["c5_full_run.json", "c5_full_run_w8192.json", "c5_full_run_w16384.json",
+                                     "c5_full_run_w32768.json"])
 def test_c5_building_sff_star_whole_job_equals_the_oracle(S, ctx, golden_dir, fixture):
     """BASELINE configs[4] run to its END (building.obj, 20 seeded roots, SFF* with rewire, 2 M-node budget): the forest
     saturates - frontier empty, every tree connected, "solved" - at about 2e5 nodes, so the WHOLE job is pinned against
-    the CPU oracle (tests/golden/make_c5_full.py; waves of 4096 and of 8192 slots): fingerprint over every node,
+    the CPU oracle (tests/golden/make_c5_full.py; waves of 4096, 8192, 16 384 and 32 768 slots - the open list never holds more
+    than 16 384 nodes, so the last two are the same job): fingerprint over every node,
     counters, checksums.  Runs on the device-resident engine (rewire fixed point on the GPU, csrc/devstar.hip)."""
     import json
     import os
