@@ -784,6 +784,48 @@ __global__ __launch_bounds__(256) void k_append_sample(ResolveArgs A, SampleLaun
   sample_steer_one(tid, next, slot, P);
 }
 
+// the control block at the end of a wave: closed list / frontier sizes, termination (src/forest.h:184-201); one thread
+__device__ void wave_end_control(const DevForestView& f, DevCtrl* c, int removed, int fn, bool from_closed, int n_fail,
+                                 const int32_t* grid_ovf, const int32_t* tgrid_ovf, const unsigned long long* star_s) {
+  c->closed_n += removed;
+  c->compact_from = removed > 0 ? fn : 0;     // k_frontier_compact: entries of the old buffer to sift
+  c->frontier_n = fn - removed;
+  if (removed > 0) c->front_sel ^= 1;
+  c->empty_frontier = c->frontier_n == 0 ? 1 : 0;
+  if (!c->solved && c->empty_frontier && f.goal_id < 0) {   // (with a goal only reaching it solves, :204-206)
+    // maxConnected() == numRoots (:379-418): every tree reachable from tree 0 over pairs that hold a border
+    const int R = f.n_trees;
+    int reached = 1;
+    // (claim[] is free again: use its first R ints as the visited marks, restored afterwards)
+    for (int t = 0; t < R; ++t) f.claim[t] = t == 0 ? 1 : 0;
+    bool grew = true;
+    while (grew) {
+      grew = false;
+      for (int a = 0; a < R; ++a) {
+        if (f.claim[a] != 1) continue;
+        f.claim[a] = 2;
+        for (int b = 0; b < R; ++b)
+          if (f.claim[b] == 0 && f.pair[(size_t)a * R + b]) { f.claim[b] = 1; ++reached; grew = true; }
+      }
+    }
+    for (int t = 0; t < R; ++t) f.claim[t] = 0x7fffffff;
+    c->solved = reached == R ? 1 : 0;
+  }
+  c->claims_done = 0;
+  c->clear_n = from_closed ? 0 : n_fail;
+  const bool budget = f.node_budget > 0 && c->n_nodes >= f.node_budget;
+  c->terminated = (c->solved || c->iter >= f.max_iterations || budget) ? 1 : 0;
+  c->halt = c->terminated;
+  c->in_wave = 0;
+  c->n_act = 0;
+  c->grid_ovf = grid_ovf[0];
+  c->tgrid_ovf = tgrid_ovf[0];
+  if (star_s) {
+    c->collide_calls += star_s[0]; c->path_free_calls += star_s[1];
+    c->star_rounds += star_s[2]; c->star_passes += star_s[3]; c->star_members += star_s[4]; c->star_rewires += star_s[5];
+  }
+}
+
 // ------------------------------------------------------------------ wave end
 __global__ __launch_bounds__(DF_THREADS) void k_wave_end(DevForestView f, const int32_t* __restrict__ grid_ovf,
                                                          const int32_t* __restrict__ tgrid_ovf, unsigned long long* star_acc) {
@@ -925,45 +967,128 @@ __global__ __launch_bounds__(DF_THREADS) void k_wave_end(DevForestView f, const 
   // ---- termination (src/forest.h:184-201)
   if (clk) tw[5] = wall_clock64();
   if (threadIdx.x == 0) {
-    c->closed_n += removed;
-    c->compact_from = removed > 0 ? fn : 0;     // k_frontier_compact: entries of the old buffer to sift
-    c->frontier_n = fn - removed;
-    if (removed > 0) c->front_sel ^= 1;
-    c->empty_frontier = c->frontier_n == 0 ? 1 : 0;
-    if (!c->solved && c->empty_frontier && f.goal_id < 0) {   // (with a goal only reaching it solves, :204-206)
-      // maxConnected() == numRoots (:379-418): every tree reachable from tree 0 over pairs that hold a border
-      const int R = f.n_trees;
-      int reached = 1;
-      // (claim[] is free again: use its first R ints as the visited marks, restored afterwards)
-      for (int t = 0; t < R; ++t) f.claim[t] = t == 0 ? 1 : 0;
-      bool grew = true;
-      while (grew) {
-        grew = false;
-        for (int a = 0; a < R; ++a) {
-          if (f.claim[a] != 1) continue;
-          f.claim[a] = 2;
-          for (int b = 0; b < R; ++b)
-            if (f.claim[b] == 0 && f.pair[(size_t)a * R + b]) { f.claim[b] = 1; ++reached; grew = true; }
-        }
-      }
-      for (int t = 0; t < R; ++t) f.claim[t] = 0x7fffffff;
-      c->solved = reached == R ? 1 : 0;
-    }
-    c->claims_done = 0;
-    c->clear_n = from_closed ? 0 : n_fail;
-    const bool budget = f.node_budget > 0 && c->n_nodes >= f.node_budget;
-    c->terminated = (c->solved || c->iter >= f.max_iterations || budget) ? 1 : 0;
-    c->halt = c->terminated;
-    c->in_wave = 0;
-    c->n_act = 0;
-    c->grid_ovf = grid_ovf[0];
-    c->tgrid_ovf = tgrid_ovf[0];
-    if (star_acc) {
-      c->collide_calls += star_s[0]; c->path_free_calls += star_s[1];
-      c->star_rounds += star_s[2]; c->star_passes += star_s[3]; c->star_members += star_s[4]; c->star_rewires += star_s[5];
-    }
+    wave_end_control(f, c, removed, fn, from_closed, n_fail, grid_ovf, tgrid_ovf, star_acc ? star_s : nullptr);
     if (clk) tw[6] = wall_clock64();
     if (clk && !from_closed) for (int q = 0; q < 6; ++q) c->wprof[q] += tw[q + 1] - tw[q];
+    c->wprof[7] += 1ULL;
+  }
+}
+
+// ------------------------------------------------------------------ wave end, wide
+// k_wave_end's work when the exhausted slots' claims are already posted (the normal case: the wave's last append did it) as
+// a launch of many workgroups - the one-workgroup kernel spent 30 of its 34 us on two passes of scattered accesses that a
+// single CU retires at about one address per cycle.  256 slots per workgroup:
+//   owner flags (the slot that holds its node's claim) -> the workgroup's count, published like k_commit's words
+//   ((sequence << 32) | count, word KW_CNT of the workgroup's line) -> closed-list positions = closed_n + the LOWER
+//   workgroups' counts + rank in the workgroup (decoupled look-back: a workgroup waits for lower ones only, and
+//   workgroups start in index order) -> closed list, node flags, removed frontier positions (atomicOr on rm_words)
+//   -> the workgroup that finishes last (a counter) adds the removal prefix per frontier word and the termination tests.
+// Returns at once (and leaves everything to k_wave_end) when the claims are not posted: after a resumed or an empty wave.
+#define KW_CNT 15          // word of the workgroup's wg_pub line (k_commit uses 0..12)
+__global__ __launch_bounds__(256) void k_wave_end_wide(DevForestView f, const int32_t* __restrict__ grid_ovf,
+                                                       const int32_t* __restrict__ tgrid_ovf, unsigned long long* star_acc) {
+  __shared__ unsigned long long s_words[4];
+  __shared__ unsigned long long s_sum;
+  __shared__ int s_last;
+  __shared__ int s_pref[256];
+  __shared__ unsigned long long star_s[SFFK_STAR_ACC];
+  DevCtrl* c = f.ctrl;
+  if (c->halt || !c->in_wave) return;
+  const bool from_closed = c->use_closed != 0;
+  if (!from_closed && !c->claims_done) return;     // (k_wave_end posts the claims itself)
+  const int n_fail = from_closed ? 0 : c->act_cnt;
+  const int nwg = n_fail > 0 ? (n_fail + 255) >> 8 : 1;
+  const int b = blockIdx.x;
+  if (b >= nwg) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const unsigned seq = (unsigned)f.commit_seq[3] + 1u;
+  const int fn = c->frontier_n, cn0 = c->closed_n;
+  const int32_t* act = act_now(f);
+  const int32_t* nodes = f.ulist;
+  unsigned long long* pub = f.wg_pub + (size_t)b * SFFK_PUB_WORDS + KW_CNT;
+  // ---- the slot that owns its node's claim; what the closed-list pass needs is requested with it
+  const int e = b * 256 + (int)threadIdx.x;
+  const bool on = e < n_fail;
+  const int nd = on ? nodes[e] : -1;
+  const int sl = on ? act[e] : 0;
+  const int own = nd >= 0 ? __hip_atomic_load(&f.claim[nd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
+  const int ps = on ? f.slot_pos[sl] : 0;
+  const int fl = nd >= 0 ? f.nflag[nd] : 0;
+  const bool mine = nd >= 0 && own == e;
+  const unsigned long long m = __ballot(mine);
+  if (lane == 0) s_words[wave] = m;
+  __syncthreads();
+  int cnt = 0, before = 0;
+  for (int w = 0; w < 4; ++w) { const int pc = __popcll(s_words[w]); cnt += pc; if (w < wave) before += pc; }
+  if (threadIdx.x == 0) kc_publish(pub, seq, (unsigned)cnt);
+  // ---- closed-list positions: the lower workgroups' counts
+  unsigned long long part = 0;
+  if ((int)threadIdx.x < b) part = kc_wait(f.wg_pub + (size_t)threadIdx.x * SFFK_PUB_WORDS + KW_CNT, seq, &c->fault_pending);
+  const int base = (int)kc_block_sum(part, &s_sum);
+  if (mine) {
+    const int rank = base + before + __popcll(m & ((1ULL << lane) - 1ULL));
+    f.closed[cn0 + rank] = nd;
+    f.nflag[nd] = (uint8_t)((fl & ~2) | 1);
+    atomicOr(&f.rm_words[ps >> 6], 1ULL << (ps & 63));
+  }
+  // ---- the workgroup that is through last: removal prefix, termination
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) s_last = atomicAdd(&f.commit_seq[4], 1) == nwg - 1;
+  __syncthreads();
+  if (!s_last) return;
+  if (star_acc) {   // SFF*: the wave's sub-counters (64 lines, k_star_apply) are folded into the control block below
+    if (threadIdx.x < SFFK_STAR_ACC) star_s[threadIdx.x] = 0ULL;
+    __syncthreads();
+    for (int q = threadIdx.x; q < 64 * SFFK_STAR_ACC; q += 256) {
+      const unsigned long long v = star_acc[q];
+      if (v) { atomicAdd(&star_s[q % SFFK_STAR_ACC], v); star_acc[q] = 0ULL; }
+    }
+    __syncthreads();
+  }
+  unsigned long long tot = 0;
+  for (int w = threadIdx.x; w < nwg && n_fail > 0; w += 256) tot += (unsigned long long)(unsigned)kc_wait(f.wg_pub + (size_t)w * SFFK_PUB_WORDS + KW_CNT, seq, &c->fault_pending);
+  const int removed = (int)kc_block_sum(tot, &s_sum);
+  const int nw = (fn + 63) >> 6;
+  if (removed > 0) {
+    // exclusive prefix of the removed positions per 64-entry word (k_frontier_compact shifts by it): every thread sums a
+    // contiguous run of words, the runs are scanned through LDS
+    const int per = (nw + 255) / 256;
+    const int w0 = threadIdx.x * per;
+    int mine_n = 0;
+    for (int k = 0; k < per; ++k) {
+      const int w = w0 + k;
+      if (w < nw) mine_n += __popcll(__hip_atomic_load(&f.rm_words[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+    s_pref[threadIdx.x] = mine_n;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+      int run = 0;
+      for (int q = 0; q < 256; q += 64) {
+        const int v = s_pref[q + lane];
+        int inc = v;
+        for (int off = 1; off < 64; off <<= 1) {
+          const int o = __shfl_up(inc, off);
+          if (lane >= off) inc += o;
+        }
+        s_pref[q + lane] = run + inc - v;
+        run += __shfl(inc, 63);
+      }
+    }
+    __syncthreads();
+    int run = s_pref[threadIdx.x];
+    for (int k = 0; k < per; ++k) {
+      const int w = w0 + k;
+      if (w >= nw) break;
+      f.rm_pref[w] = run;
+      run += __popcll(__hip_atomic_load(&f.rm_words[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    f.commit_seq[3] = (int32_t)seq;
+    f.commit_seq[4] = 0;
+    wave_end_control(f, c, removed, fn, from_closed, n_fail, grid_ovf, tgrid_ovf, star_acc ? star_s : nullptr);
     c->wprof[7] += 1ULL;
   }
 }
@@ -1053,7 +1178,9 @@ void launch_commit(hipStream_t s, const ResolveArgs& a, int n_bound, const StarL
 }
 void launch_wave_end(hipStream_t s, const DevForestView& f, const int32_t* grid_ovf, const int32_t* tgrid_ovf,
                      unsigned long long* star_acc) {
-  hipLaunchKernelGGL(k_wave_end, dim3(1), dim3(DF_THREADS), 0, s, f, grid_ovf, tgrid_ovf, star_acc);
+  static const bool wide = !(getenv("SFFGPU_NO_WIDE_WAVE_END") && atoi(getenv("SFFGPU_NO_WIDE_WAVE_END")) != 0);
+  if (wide) hipLaunchKernelGGL(k_wave_end_wide, dim3((f.wave + 255) / 256), dim3(256), 0, s, f, grid_ovf, tgrid_ovf, star_acc);
+  hipLaunchKernelGGL(k_wave_end, dim3(1), dim3(DF_THREADS), 0, s, f, grid_ovf, tgrid_ovf, star_acc);   // (returns at once when the wide kernel ended the wave)
   hipLaunchKernelGGL(k_frontier_compact, dim3(512), dim3(256), 0, s, f);
 }
 void launch_pack_records(hipStream_t s, const ResolveArgs& a, int rank, int world, int n_bound, int32_t* send) {

@@ -356,14 +356,14 @@ void Forest::dev_upload_state() {
     // k_commit's sequence-stamped words start at zero once and are never cleared again
     d.ustate32.ensure(((size_t)wave + 64) * 4);
     d.wg_pub.ensure(((size_t)wave / 64 + 2) * SFFK_PUB_WORDS * 8);
-    d.commit_seq.ensure(16);
+    d.commit_seq.ensure(64);
     if (getenv("SFFGPU_KC_TRACE")) {
       d.kc_trace.ensure(((size_t)wave / 64 + 2) * 64);
       HIPCHK(hipMemsetAsync(d.kc_trace.p, 0, ((size_t)wave / 64 + 2) * 64, c.stream));
     }
     HIPCHK(hipMemsetAsync(d.ustate32.p, 0, ((size_t)wave + 64) * 4, c.stream));
     HIPCHK(hipMemsetAsync(d.wg_pub.p, 0, ((size_t)wave / 64 + 2) * SFFK_PUB_WORDS * 8, c.stream));
-    HIPCHK(hipMemsetAsync(d.commit_seq.p, 0, 16, c.stream));
+    HIPCHK(hipMemsetAsync(d.commit_seq.p, 0, 64, c.stream));
     d.ulist.ensure((size_t)wave * 4);
     d.d_parent.ensure((size_t)wave * 4);
     d.d_parent2.ensure((size_t)wave * 4);

@@ -410,7 +410,8 @@ struct DevForestView {
   // number (commit_seq[0] + 1) in its upper half, so nothing is ever cleared and a stale word is never taken for news.
   int32_t* ustate32;           // per sample: (seq << 2 | state), state 1 rejected / 2 accepted / 3 rejected + border event
   unsigned long long* wg_pub;  // SFFK_PUB_WORDS words per workgroup of 64 samples (one 128-byte line), see k_commit
-  int32_t* commit_seq;         // [0] = launches that reached their end so far; [1] workgroups of k_wave_begin that are through, [2] one of them met a redraw
+  int32_t* commit_seq;         // [0] = launches that reached their end so far; [1] workgroups of k_wave_begin that are through, [2] one of them met a redraw;
+                               // [3] = k_wave_end_wide launches that ended a wave, [4] its workgroups that are through
   unsigned long long* kc_trace; int32_t kc_trace_round;   // SFFGPU_KC_TRACE=<round>: 8 clock reads per workgroup of that round's k_commit
   int32_t profile;             // SFFGPU_PROFILE: the single-workgroup kernels read their phase clocks (a clock read is a scalar
                                // memory round trip: a dozen of them is microseconds)
