@@ -154,6 +154,9 @@ __global__ __launch_bounds__(256) void k_wave_begin(DevForestView f) {
     if (blockIdx.x == 0 && threadIdx.x == 0) { c->compact_from = 0; c->app_n = 0; round_begin_scalars(f, c); }
     return;
   }
+  // priority-frontier mode: the slots take their nodes from the trees' heaps (k_prio_begin, launched behind this kernel)
+  // unless every heap is empty
+  if (f.prio.n_heaps && !c->empty_frontier) return;
   // node selection of every slot, src/forest.h:136-151 (non-priority mode): a uniform pick from the frozen frontier,
   // or from the closed list once the frontier has run empty
   const bool use_closed = c->closed_n > 0 && c->empty_frontier;
@@ -201,6 +204,8 @@ __global__ __launch_bounds__(256) void k_wave_begin(DevForestView f) {
   c->round = 0;
   c->in_wave = 1;
   c->waves += 1;
+  c->prio_wave = 0;
+  c->prio_n0 = c->n_nodes;
   round_begin_scalars(f, c);
   if (f.profile) c->wprof[6] += wall_clock64() - tb0;
 }
@@ -415,7 +420,10 @@ __global__ __launch_bounds__(1024) void k_commit(ResolveArgs A, int n_bound) {
       const int ms = __shfl(mate_state, gsh + kq);
       const unsigned long long ck = __shfl(my_calls, gsh + kq);
       if (pending && !blocked) {
-        if (ks >= 16) { st = 2; code = SFFK_ACCEPT; end = 16; pending = false; }
+        if (ks >= 16 && (flags & 4)) {   // the walk ran off the end of a CUT neighbour record: the host path has the whole list
+          if (gl == 0) atomicOr(A.fault_pending, 1);
+          st = 1; code = SFFK_REJECTED; end = 16; pending = false;
+        } else if (ks >= 16) { st = 2; code = SFFK_ACCEPT; end = 16; pending = false; }
         else {
           const bool k_mate = (mates >> ks) & 1u, k_same = (sames >> ks) & 1u, k_fr = (frees >> ks) & 1u;
           const unsigned after = stops & ~((2u << ks) - 1u);
@@ -666,7 +674,7 @@ __global__ __launch_bounds__(1024) void k_commit(ResolveArgs A, int n_bound) {
       K.app_act_cnt = act_cnt;
       K.iter0_app = K.iter0;
       K.n_nodes = N0 + n_acc;
-      K.frontier_n = fn0 + n_acc;
+      K.frontier_n = f.prio.n_heaps ? fn0 : fn0 + n_acc;
       K.n_borders = nb0 + n_ev;
       K.n_unsettled += n_dep;
       K.epoch += 1ULL;
@@ -757,8 +765,8 @@ __device__ __forceinline__ int append_one(const ResolveArgs& A, int i, int& slot
   f.d_closest[o] = pd;
   f.d_root[o] = pd + f.d_root[ex];
   f.iter[o] = (uint32_t)(c->iter0_app + i + 1);
-  f.nflag[o] = 2;
-  frontier[fn0 + rank] = id;                         // :365
+  f.nflag[o] = f.prio.n_heaps ? 0 : 2;
+  if (!f.prio.n_heaps) frontier[fn0 + rank] = id;    // :365 (priority mode: the tree's heaps, at the wave's end - k_prio_end)
   grid_put(A.g, it);                                 // flannIndex->addPoints, :367
   return -1;
 }
@@ -788,10 +796,15 @@ __global__ __launch_bounds__(256) void k_append_sample(ResolveArgs A, SampleLaun
 __device__ void wave_end_control(const DevForestView& f, DevCtrl* c, int removed, int fn, bool from_closed, int n_fail,
                                  const int32_t* grid_ovf, const int32_t* tgrid_ovf, const unsigned long long* star_s) {
   c->closed_n += removed;
-  c->compact_from = removed > 0 ? fn : 0;     // k_frontier_compact: entries of the old buffer to sift
-  c->frontier_n = fn - removed;
-  if (removed > 0) c->front_sel ^= 1;
-  c->empty_frontier = c->frontier_n == 0 ? 1 : 0;
+  if (f.prio.n_heaps) {                       // priority mode: no frontier list; "empty" = every heap is (k_prio_end)
+    c->compact_from = 0;
+    c->empty_frontier = c->prio_all_empty;
+  } else {
+    c->compact_from = removed > 0 ? fn : 0;   // k_frontier_compact: entries of the old buffer to sift
+    c->frontier_n = fn - removed;
+    if (removed > 0) c->front_sel ^= 1;
+    c->empty_frontier = c->frontier_n == 0 ? 1 : 0;
+  }
   if (!c->solved && c->empty_frontier && f.goal_id < 0) {   // (with a goal only reaching it solves, :204-206)
     // maxConnected() == numRoots (:379-418): every tree reachable from tree 0 over pairs that hold a border
     const int R = f.n_trees;
@@ -881,8 +894,10 @@ __global__ __launch_bounds__(DF_THREADS) void k_wave_end(DevForestView f, const 
 #pragma unroll
         for (int u = 0; u < 4; ++u) { const int e = (g0 + u * DF_WAVES) * 64 + lane; nd[u] = e < n_fail ? nodes[e] : -1; }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < 4; ++u) {
           own[u] = nd[u] >= 0 ? __hip_atomic_load(&f.claim[nd[u]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
+          if (f.prio.n_heaps && nd[u] >= 0 && (f.nflag[nd[u]] & 1)) own[u] = -1;   // (priority mode: closed once, :174-177)
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           const int g = g0 + u * DF_WAVES;
@@ -912,7 +927,7 @@ __global__ __launch_bounds__(DF_THREADS) void k_wave_end(DevForestView f, const 
         if (nd[u] < 0) continue;
         f.closed[cn0 + wg_rank(L, e)] = nd[u];
         f.nflag[nd[u]] = (uint8_t)((fl[u] & ~2) | 1);
-        atomicOr(&f.rm_words[ps[u] >> 6], 1ULL << (ps[u] & 63));
+        if (!f.prio.n_heaps) atomicOr(&f.rm_words[ps[u] >> 6], 1ULL << (ps[u] & 63));
       }
     }
     __syncthreads();
@@ -923,7 +938,7 @@ __global__ __launch_bounds__(DF_THREADS) void k_wave_end(DevForestView f, const 
     __threadfence_block();
     __syncthreads();
     if (clk) tw[4] = wall_clock64();
-    if (removed > 0) {
+    if (removed > 0 && !f.prio.n_heaps) {
       const int per = (nw + DF_THREADS - 1) / DF_THREADS;
       const int w0 = threadIdx.x * per;
       int mine = 0;
@@ -1014,7 +1029,9 @@ __global__ __launch_bounds__(256) void k_wave_end_wide(DevForestView f, const in
   const int own = nd >= 0 ? __hip_atomic_load(&f.claim[nd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
   const int ps = on ? f.slot_pos[sl] : 0;
   const int fl = nd >= 0 ? f.nflag[nd] : 0;
-  const bool mine = nd >= 0 && own == e;
+  // (priority mode: a node may be held again after it has been closed - put back by another slot - and is closed once,
+  // src/forest.h:174-177)
+  const bool mine = nd >= 0 && own == e && !(f.prio.n_heaps && (fl & 1));
   const unsigned long long m = __ballot(mine);
   if (lane == 0) s_words[wave] = m;
   __syncthreads();
@@ -1029,7 +1046,7 @@ __global__ __launch_bounds__(256) void k_wave_end_wide(DevForestView f, const in
     const int rank = base + before + __popcll(m & ((1ULL << lane) - 1ULL));
     f.closed[cn0 + rank] = nd;
     f.nflag[nd] = (uint8_t)((fl & ~2) | 1);
-    atomicOr(&f.rm_words[ps >> 6], 1ULL << (ps & 63));
+    if (!f.prio.n_heaps) atomicOr(&f.rm_words[ps >> 6], 1ULL << (ps & 63));
   }
   // ---- the workgroup that is through last: removal prefix, termination
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1050,7 +1067,7 @@ __global__ __launch_bounds__(256) void k_wave_end_wide(DevForestView f, const in
   for (int w = threadIdx.x; w < nwg && n_fail > 0; w += 256) tot += (unsigned long long)(unsigned)kc_wait(f.wg_pub + (size_t)w * SFFK_PUB_WORDS + KW_CNT, seq, &c->fault_pending);
   const int removed = (int)kc_block_sum(tot, &s_sum);
   const int nw = (fn + 63) >> 6;
-  if (removed > 0) {
+  if (removed > 0 && !f.prio.n_heaps) {
     // exclusive prefix of the removed positions per 64-entry word (k_frontier_compact shifts by it): every thread sums a
     // contiguous run of words, the runs are scanned through LDS
     const int per = (nw + 255) / 256;
@@ -1166,7 +1183,12 @@ __global__ __launch_bounds__(256) void k_border_rehash(DevForestView f, int n) {
   f.bt_val[h] = 0ULL;   // older than every future stamp
 }
 
+void launch_wave_begin_only(hipStream_t s, const DevForestView& f);
 void launch_wave_begin(hipStream_t s, const DevForestView& f) {
+  launch_wave_begin_only(s, f);
+  if (f.prio.n_heaps) launch_prio_begin(s, f);
+}
+void launch_wave_begin_only(hipStream_t s, const DevForestView& f) {
   hipLaunchKernelGGL(k_wave_begin, dim3(WB_BLOCKS), dim3(256), 0, s, f);
 }
 void launch_commit(hipStream_t s, const ResolveArgs& a, int n_bound, const StarLaunch* star, const SampleLaunch* next) {

@@ -897,8 +897,8 @@ __global__ __launch_bounds__(256) void k_star_apply(ResolveArgs A, GridView tg, 
     f.d_closest[o] = dc;
     f.d_root[o] = dr;
     f.iter[o] = (uint32_t)(c->iter0_app + i + 1);
-    f.nflag[o] = 2;
-    (c->front_sel ? f.frontier2 : f.frontier)[fn0 + r] = id;   // :365
+    f.nflag[o] = f.prio.n_heaps ? 0 : 2;
+    if (!f.prio.n_heaps) (c->front_sel ? f.frontier2 : f.frontier)[fn0 + r] = id;   // :365 (priority mode: k_prio_end)
     grid_put(A.g, it);                                          // flannIndex->addPoints, :367
     atomicAdd(S.tree_cnt + 16 * it.tree, 1);
     unsigned long long* acc = S.acc + (size_t)(blockIdx.x & 63) * SFFK_STAR_ACC;

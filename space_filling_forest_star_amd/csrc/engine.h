@@ -254,6 +254,9 @@ struct DevEngine {
   DevBuf frontier2, rm_words, rm_pref, slot_pos, act_slot2, w_acc, acc_pref, ustate32, wg_pub, commit_seq, kc_trace;
   DevBuf ctrl, parent, d_root, d_closest, iter, nflag, frontier, closed, claim, slot_node, slot_fail, act_slot, b_n1,
       b_n2, b_ta, b_tb, b_dist, bt_key, bt_val, pair, ring, ulist, d_parent, d_parent2, d_force, fault_pending;
+  // priority-frontier mode on the device (devprio.hip; PrioView in kernels.h)
+  DevBuf hp_base, hp_size, hp_v, hp_key, hp_pos, hp_ref, hp_gen, hp_cnt, slot_tree, slot_heap, slot_idx, slot_word, hp_plan;
+  int prio_heaps = 0, prio_cap = 0;
   // SFF* on the device (devstar.hip; StarView in kernels.h)
   DevBuf s_ktab, s_tree_cnt, s_head, s_mcnt, s_mid, s_md, s_next, s_prop, s_best, s_psel, s_dcl, s_cnt, s_accs, s_hdr, s_changed,
       s_ew, s_ida, s_idb, s_sub, s_segns, s_fh, s_sovf, s_evs, s_evn, s_eve, s_evd, s_acc, s_backup, s_items, s_dbg, s_hist;
@@ -343,6 +346,10 @@ struct Forest {
   std::vector<Slot> slots;
   std::vector<std::vector<PHeap>> heaps;   // Tree::frontiers (priorityBias != 0 only)
   bool use_priority() const { return cfg.priority_bias != 0; }
+  void dev_prio_upload(int gen = -2);   // host heaps -> PrioView arrays (entries per heap = the device's node capacity); gen: the wave
+                                         // whose pops the heaps have behind them (DevCtrl::prio_gen; -2 = none on the device yet)
+  void dev_prio_download();   // and back
+  void dev_prio_regrow();     // the node capacity has grown: the heaps' rows are laid out again, on the device
   bool tree_frontiers_empty(int t) const;
   bool all_frontiers_empty() const;
   int round = 0;

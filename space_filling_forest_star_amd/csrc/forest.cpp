@@ -138,7 +138,7 @@ Forest::Forest(Ctx* c, const sffgpu_forest_cfg& cf, const double* roots6, int n_
     if (const char* e = getenv("SFFGPU_TEST_GRID_BK")) ctx->grid_bk = std::max(1, std::min(8, atoi(e)));   // tests: tiny buckets to start with
     ctx->grid_cell0 = cell;
     query_wide = cfg.dim != 2 && std::min(cfg.sampling_dist, cfg.dist_tree) < 2.0 * 3.14159265358979323846;
-    if (hit_cap < 24) query_wide = true;   // (tests shrink the hit list of the wide kernel)
+    if (use_priority()) query_wide = true; // (the heaps crowd the samples around the trees' best nodes: more than 24 hits happen)
     // the overflow list is checked once per wave and re-celled at a quarter full: three quarters of it must hold
     // whatever TWO waves can add (at most `wave` nodes each; the device engine keeps one wave enqueued ahead of the
     // one whose status it reads), so that no insert is ever dropped between two checks
@@ -176,6 +176,7 @@ Forest::Forest(Ctx* c, const sffgpu_forest_cfg& cf, const double* roots6, int n_
   memset(&st, 0, sizeof st);
   knn_r = 2.5 * cfg.sampling_dist;
   if (const char* e = getenv("SFFGPU_TEST_HITCAP")) hit_cap = std::min(64, std::max(1, atoi(e)));  // one lane per hit
+  if (hit_cap < 24) query_wide = true;   // (tests shrink the hit list of the wide kernel)
   if (const char* e = getenv("SFFGPU_TEST_NBCAP")) nb_cap = std::max(1, atoi(e));
   if (const char* e = getenv("SFFGPU_TEST_STAR_PASSES")) star_pass_limit = std::max(1, atoi(e));
   if (const char* e = getenv("SFFGPU_NO_GRAPH")) dev.graph_enabled = atoi(e) == 0;
@@ -314,7 +315,8 @@ Forest::~Forest() {
                     &dev.slot_pos, &dev.act_slot2, &dev.trig, &dev.s_ktab, &dev.s_tree_cnt, &dev.s_head, &dev.s_mcnt, &dev.s_mid, &dev.s_md,
                     &dev.s_next, &dev.s_prop, &dev.s_best, &dev.s_psel, &dev.s_dcl, &dev.s_cnt, &dev.s_accs, &dev.s_hdr, &dev.s_changed,
                     &dev.s_ew, &dev.s_ida, &dev.s_idb, &dev.s_sub, &dev.s_segns, &dev.s_fh, &dev.s_sovf, &dev.s_evs, &dev.s_evn, &dev.s_eve,
-                    &dev.s_evd, &dev.s_acc, &dev.s_backup, &dev.s_items, &dev.s_dbg, &dev.s_hist, &dev.w_acc, &dev.acc_pref, &dev.ustate32, &dev.wg_pub, &dev.commit_seq, &dev.kc_trace, &x_send, &x_recv};
+                    &dev.s_evd, &dev.s_acc, &dev.s_backup, &dev.s_items, &dev.s_dbg, &dev.s_hist, &dev.w_acc, &dev.acc_pref, &dev.ustate32, &dev.wg_pub, &dev.commit_seq, &dev.kc_trace, &x_send, &x_recv,
+                    &dev.hp_base, &dev.hp_size, &dev.hp_v, &dev.hp_key, &dev.hp_pos, &dev.hp_ref, &dev.hp_gen, &dev.hp_cnt, &dev.slot_tree, &dev.slot_heap, &dev.slot_idx, &dev.slot_word, &dev.hp_plan};
   if (dev.inited) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);

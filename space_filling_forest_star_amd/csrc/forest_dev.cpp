@@ -35,9 +35,108 @@ static uint64_t next_pow2(uint64_t v) {
 }
 
 bool Forest::device_eligible() const {
-  // plain SFF and SFF* (choose-parent + rewire on the device: devstar.hip); single-goal and priority-frontier modes run
-  // on the host-replay engine
-  return !use_priority();
+  // plain SFF and SFF* (choose-parent + rewire on the device: devstar.hip), the single-goal mode, and the priority-frontier
+  // mode without a goal (heaps in HBM, one workgroup per heap: devprio.hip); priority + goal runs on the host-replay engine
+  if (!use_priority()) return true;
+  // (waves below ~2 000 slots take the very top of every heap: their samples crowd together, the bounded neighbour lists of
+  // the device run over in most waves and every overflow costs a round trip through the host engine - measured on
+  // dense_3D: 54 k nodes/s at 1 024 slots against the host engine's 98 k, 124 k at 2 048, 1.49 M at 8 192;
+  // SFFGPU_PRIO_DEVICE=1 / 0 overrides)
+  const char* const knob = getenv("SFFGPU_PRIO_DEVICE");
+  const int min_wave = knob ? (atoi(knob) ? 2 : 0x7fffffff) : 2048;
+  if (cfg.has_goal || cfg.wave < min_wave || cfg.world > 1) return false;
+  const long long heaps_n = (long long)num_roots * (num_roots - 1);
+  const long long cap = (long long)std::max(cfg.node_budget, 4096) + 2LL * cfg.wave + 128;
+  return heaps_n >= 1 && heaps_n <= SFFK_PRIO_MAX_HEAPS && heaps_n * cap * 16 <= (32LL << 30);   // (ids + keys + position map)
+}
+
+// ---- priority-frontier mode: the trees' heaps between the host mirror (PHeap) and the device arrays
+void Forest::dev_prio_upload(int gen) {
+  DevEngine& d = dev;
+  Ctx& c = *ctx;
+  int H = 0;
+  std::vector<int32_t> base(heaps.size() + 1, 0);
+  for (size_t t = 0; t < heaps.size(); ++t) { base[t] = H; H += (int)heaps[t].size(); }
+  base[heaps.size()] = H;
+  const int cap = d.node_cap;
+  d.prio_heaps = H;
+  d.prio_cap = cap;
+  d.hp_base.ensure(base.size() * 4);
+  d.hp_size.ensure((size_t)H * 4);
+  d.hp_gen.ensure((size_t)H * 4);
+  d.hp_cnt.ensure(16);
+  d.hp_ref.ensure((size_t)H * 48);
+  d.hp_v.ensure((size_t)H * cap * 4);
+  d.hp_key.ensure((size_t)H * cap * 8);
+  d.hp_pos.ensure((size_t)H * cap * 4);
+  d.slot_tree.ensure((size_t)cfg.wave * 4);
+  d.slot_heap.ensure((size_t)cfg.wave * 4);
+  d.slot_idx.ensure((size_t)cfg.wave * 4);
+  d.slot_word.ensure((size_t)cfg.wave * 8);
+  {
+    int levels = 0;
+    while ((1 << levels) < cfg.wave + 1) ++levels;
+    d.hp_plan.ensure((size_t)(levels + 2) * (4 * (size_t)cfg.wave + 16) * 4);
+  }
+  std::vector<int32_t> sizes(H);
+  std::vector<double> refs((size_t)H * 6);
+  HIPCHK(hipMemsetAsync(d.hp_pos.p, 0xFF, (size_t)H * cap * 4, c.stream));
+  HIPCHK(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d.hp_gen.p), gen, (size_t)H, c.stream));
+  HIPCHK(hipMemsetAsync(d.hp_cnt.p, 0, 16, c.stream));
+  std::vector<double> keys;
+  int h = 0;
+  for (size_t t = 0; t < heaps.size(); ++t)
+    for (PHeap& hp : heaps[t]) {
+      sizes[h] = (int32_t)hp.v.size();
+      memcpy(&refs[6 * (size_t)h], hp.ref, 48);
+      if (!hp.v.empty()) {
+        keys.resize(hp.v.size());
+        for (size_t i = 0; i < hp.v.size(); ++i) keys[i] = hp.cost((int)i);
+        HIPCHK(hipMemcpy(d.hp_v.as<int32_t>() + (size_t)h * cap, hp.v.data(), hp.v.size() * 4, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d.hp_key.as<double>() + (size_t)h * cap, keys.data(), keys.size() * 8, hipMemcpyHostToDevice));
+      }
+      ++h;
+    }
+  HIPCHK(hipMemcpy(d.hp_base.p, base.data(), base.size() * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d.hp_size.p, sizes.data(), (size_t)H * 4, hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(d.hp_ref.p, refs.data(), refs.size() * 8, hipMemcpyHostToDevice));
+  sffk::launch_prio_index(c.stream, dev_view().prio);
+  HIPCHK(hipStreamSynchronize(c.stream));
+}
+// (keys and entries stay on the device: the host mirror may not even know the newest nodes)
+void Forest::dev_prio_regrow() {
+  DevEngine& d = dev;
+  Ctx& c = *ctx;
+  const int H = d.prio_heaps, old_cap = d.prio_cap, cap = d.node_cap;
+  if (!H || cap <= old_cap) return;
+  DevBuf nv, nk;
+  nv.ensure((size_t)H * cap * 4);
+  nk.ensure((size_t)H * cap * 8);
+  HIPCHK(hipMemcpy2DAsync(nv.p, (size_t)cap * 4, d.hp_v.p, (size_t)old_cap * 4, (size_t)old_cap * 4, H, hipMemcpyDeviceToDevice, c.stream));
+  HIPCHK(hipMemcpy2DAsync(nk.p, (size_t)cap * 8, d.hp_key.p, (size_t)old_cap * 8, (size_t)old_cap * 8, H, hipMemcpyDeviceToDevice, c.stream));
+  HIPCHK(hipStreamSynchronize(c.stream));
+  d.hp_v.release(); d.hp_key.release(); d.hp_pos.release();
+  d.hp_v = nv; d.hp_key = nk;
+  nv.p = nullptr; nv.cap = 0; nk.p = nullptr; nk.cap = 0;
+  d.hp_pos.ensure((size_t)H * cap * 4);
+  d.prio_cap = cap;
+  HIPCHK(hipMemsetAsync(d.hp_pos.p, 0xFF, (size_t)H * cap * 4, c.stream));
+  sffk::launch_prio_index(c.stream, dev_view().prio);
+  HIPCHK(hipStreamSynchronize(c.stream));
+}
+void Forest::dev_prio_download() {
+  DevEngine& d = dev;
+  if (!d.prio_heaps) return;
+  const int H = d.prio_heaps, cap = d.prio_cap;
+  std::vector<int32_t> sizes(H);
+  HIPCHK(hipMemcpy(sizes.data(), d.hp_size.p, (size_t)H * 4, hipMemcpyDeviceToHost));
+  int h = 0;
+  for (size_t t = 0; t < heaps.size(); ++t)
+    for (PHeap& hp : heaps[t]) {
+      hp.v.resize((size_t)sizes[h]);
+      if (sizes[h]) HIPCHK(hipMemcpy(hp.v.data(), d.hp_v.as<int32_t>() + (size_t)h * cap, (size_t)sizes[h] * 4, hipMemcpyDeviceToHost));
+      ++h;
+    }
 }
 
 sffk::StarView Forest::star_view() const {
@@ -179,6 +278,17 @@ sffk::DevForestView Forest::dev_view() const {
   v.wg_pub = d.wg_pub.as<unsigned long long>();
   v.commit_seq = d.commit_seq.as<int32_t>();
   v.goal_id = cfg.has_goal ? goal_node : -1;
+  if (use_priority() && d.prio_heaps) {
+    v.prio.n_heaps = d.prio_heaps; v.prio.cap = d.prio_cap;
+    v.prio.base = d.hp_base.as<int32_t>(); v.prio.size = d.hp_size.as<int32_t>(); v.prio.v = d.hp_v.as<int32_t>();
+    v.prio.key = d.hp_key.as<double>(); v.prio.pos = d.hp_pos.as<int32_t>(); v.prio.ref = d.hp_ref.as<double>();
+    v.prio.slot_tree = d.slot_tree.as<int32_t>(); v.prio.slot_heap = d.slot_heap.as<int32_t>(); v.prio.slot_idx = d.slot_idx.as<int32_t>();
+    v.prio.counters = d.hp_cnt.as<int32_t>(); v.prio.gen = d.hp_gen.as<int32_t>();
+    v.prio.slot_word = d.slot_word.as<unsigned long long>();
+    static const bool seq_only = getenv("SFFGPU_PRIO_SEQ") && atoi(getenv("SFFGPU_PRIO_SEQ")) != 0;   // (tests: the sequential picks)
+    v.prio.plan = seq_only ? nullptr : d.hp_plan.as<int32_t>();
+    v.prio.bias = cfg.priority_bias;
+  }
   static const int profile = getenv("SFFGPU_PROFILE") ? 1 : 0;
   v.profile = profile;
   v.kc_trace = d.kc_trace.as<unsigned long long>();
@@ -334,7 +444,8 @@ void Forest::dev_upload_state() {
     HIPCHK(hipEventCreateWithFlags(&d.ev_ring, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&d.ev_wave, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&d.ev_wave2, hipEventDisableTiming));
-    d.max_wave_words = (uint64_t)wave * (1 + (uint64_t)std::max(1, cfg.threshold_misses) * words_per) + 64;
+    // (a slot's pick takes one word - four or so in the priority-frontier mode, whose plan also looks a few words ahead)
+    d.max_wave_words = (uint64_t)wave * ((use_priority() ? 5 : 1) + (uint64_t)std::max(1, cfg.threshold_misses) * words_per) + 64;
     // (room for four waves' worth - and for everything the host engine may have generated ahead when the state moves
     // to the device in the middle of a run)
     d.ring_words = next_pow2(std::max<uint64_t>(4 * d.max_wave_words, (uint64_t)rng_ahead.size() + 2 * d.max_wave_words + 64));
@@ -384,6 +495,7 @@ void Forest::dev_upload_state() {
     dev_size_border_arrays(first_cap);
   }
   if (cfg.optimize) dev_star_setup();
+  if (use_priority()) dev_prio_upload();
   // all nodes lie inside the limits: a bound for the fp32 filter slack that does not depend on the nodes to come
   for (int a = 0; a < 6; ++a) c.store_maxabs = std::max(c.store_maxabs, std::fabs(cfg.limits[a]));
 
@@ -468,6 +580,16 @@ void Forest::dev_upload_state() {
     k.star_members = st.star_members;
     k.star_rewires = st.star_rewires;
     k.epoch = 1;
+    k.prio_n0 = n;               // (the host engine has pushed the nodes it created itself)
+    k.prio_all_empty = (use_priority() && all_frontiers_empty()) ? 1 : 0;
+    k.prio_gen = -2;
+    if (in_wave && use_priority() && !slots.empty() && slots[0].tree >= 0) {
+      k.prio_wave = 1;
+      std::vector<int32_t> stt(slots.size()), sh(slots.size());
+      for (size_t s = 0; s < slots.size(); ++s) { stt[s] = slots[s].tree; sh[s] = slots[s].heap; }
+      HIPCHK(hipMemcpy(d.slot_tree.p, stt.data(), stt.size() * 4, hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(d.slot_heap.p, sh.data(), sh.size() * 4, hipMemcpyHostToDevice));
+    }
     if (in_wave) {
       k.n_slots = (int)slots.size();
       k.use_closed = (!slots.empty() && slots[0].from_closed) ? 1 : 0;
@@ -590,6 +712,14 @@ void Forest::sync_host() {
   st.star_passes = k.star_passes;
   st.star_members = k.star_members;
   st.star_rewires = k.star_rewires;
+  if (use_priority()) {
+    dev_prio_download();
+    // the device pushes a wave's new nodes at the wave's END (k_prio_end); a wave that stopped in the middle has not
+    // pushed them yet - the mirror does it here, in creation order, like the host engine does when it accepts them
+    if (in_wave)
+      for (int id = std::max(k.prio_n0, 0); id < n; ++id)
+        for (PHeap& hp : heaps[nodes[id].tree]) hp.push(id);
+  }
   if (in_wave) {
     std::vector<int32_t> sn(k.n_slots), act((size_t)k.act_cnt);
     std::vector<uint8_t> sf(k.n_slots, 0);
@@ -598,6 +728,12 @@ void Forest::sync_host() {
     for (int32_t s : act) sf[s] = 1;     // still failing = still on the active list
     slots.resize((size_t)k.n_slots);
     for (int s = 0; s < k.n_slots; ++s) { slots[s].node = sn[s]; slots[s].failing = sf[s] != 0; slots[s].from_closed = k.use_closed != 0; slots[s].tree = -1; slots[s].heap = -1; }
+    if (use_priority() && k.prio_wave) {   // the slots hold heap nodes: where each came from
+      std::vector<int32_t> stt(k.n_slots), sh(k.n_slots);
+      HIPCHK(hipMemcpy(stt.data(), d.slot_tree.p, (size_t)k.n_slots * 4, hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(sh.data(), d.slot_heap.p, (size_t)k.n_slots * 4, hipMemcpyDeviceToHost));
+      for (int s = 0; s < k.n_slots; ++s) { slots[s].tree = stt[s]; slots[s].heap = sh[s]; slots[s].from_closed = false; }
+    }
   }
   c.store_n = n;
   c.grid_inserted = n;
@@ -798,6 +934,7 @@ void Forest::dev_enqueue_round_eval(void* send_dev, bool sample) {
   ca.n = n; ca.N0 = d.temp_base; ca.cap = B.CAP; ca.nbcap = B.NBCAP; ca.rank = cfg.rank; ca.world = cfg.world;
   ca.goal_id = cfg.has_goal ? goal_node : -1;
   ca.wide = query_wide ? 1 : 0;
+  ca.lazy_nb = (cfg.world <= 1 && !cfg.optimize) ? 1 : 0;   // (SFF*'s choose-parent reads whole records; sharded rounds exchange them)
   ca.qrec = c.r_qrec.as<sffk::QRec>();
   ca.dist_tree = cfg.dist_tree;
   ca.newpos = B.d_pos;
@@ -899,6 +1036,7 @@ void Forest::dev_enqueue_round_commit(const void* recv_dev, bool sample_next) {
 void Forest::dev_enqueue_end(int slot) {
   Ctx& c = *ctx;
   DevEngine& d = dev;
+  if (use_priority()) sffk::launch_prio_end(c.stream, dev_view(), c.store_view());
   sffk::launch_wave_end(c.stream, dev_view(), c.gridv.ovf_cnt, c.tgridv.ovf_cnt,
                         cfg.optimize ? d.s_acc.as<unsigned long long>() : nullptr);
   HIPCHK(hipMemcpyAsync(d.h_ctrl.as<sffk::DevCtrl>() + slot, d.ctrl.p, sizeof(sffk::DevCtrl), hipMemcpyDeviceToHost, c.stream));
@@ -948,6 +1086,7 @@ void Forest::dev_enqueue_wave_kernels(bool sharded, size_t words) {
     dev_enqueue_round_commit(sharded ? x_recv.p : nullptr, fuse && r + 1 < R);
   }
   dev.round_parity = 0;
+  if (use_priority()) sffk::launch_prio_end(ctx->stream, dev_view(), ctx->store_view());
   sffk::launch_wave_end(ctx->stream, dev_view(), ctx->gridv.ovf_cnt, ctx->tgridv.ovf_cnt,
                         cfg.optimize ? dev.s_acc.as<unsigned long long>() : nullptr);
 }
@@ -1042,9 +1181,12 @@ int Forest::dev_finish_wave(double* wait_ms, int slot, bool stream_idle) {
       // (nodes and temporaries share the store: grow it, re-place the temporaries)
       c.store_reserve(std::max(c.store_cap * 2, s.n_nodes + 4 * cfg.wave + 64));
       dev_size_node_arrays();
+      if (use_priority()) dev_prio_regrow();   // (entries per heap = node capacity)
       dev_size_border_arrays(std::max(d.border_cap, 2 * (s.n_borders + cfg.wave)));
     } else if (fault == SFFK_FAULT_BORDER_TABLE) {
       dev_size_border_arrays(std::max(4 * d.border_cap, 2 * (s.n_borders + cfg.wave)));
+    } else if (fault == SFFK_FAULT_PRIO_REDRAW) {
+      throw HipError{"forest: a priority-frontier draw fell into the rejection zone of the uniform-int algorithm (probability ~ heap size / 2^64); run this forest with SFFGPU_PRIO_SEQ=1"};
     } else {
       throw HipError{"forest: unknown device fault"};
     }
@@ -1098,7 +1240,7 @@ bool Forest::dev_wave_begin() {
 
 bool Forest::seq_eligible() const {
   static const bool off = getenv("SFFGPU_NO_SEQ") != nullptr && atoi(getenv("SFFGPU_NO_SEQ")) != 0;
-  return dev.on && cfg.wave == 1 && cfg.world == 1 && !off && !seq_suspended && num_roots <= 64 && !cfg.has_goal;
+  return dev.on && cfg.wave == 1 && cfg.world == 1 && !off && !seq_suspended && num_roots <= 64 && !cfg.has_goal && !use_priority();
 }
 
 // waves of ONE slot (the reference's own order): k_seq_waves runs whole outer iterations back to back inside one launch,

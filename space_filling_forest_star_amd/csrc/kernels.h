@@ -168,6 +168,9 @@ struct DevCtrl {
   // k_wave_end phase clocks (thread 0): claims, owner flags, closed list, clear claims, removal prefix, termination;
   // [6] = k_wave_begin as a whole, [7] = waves
   unsigned long long wprof[8];
+  // priority-frontier mode: nodes when the wave began (the wave's new nodes are pushed at its end), whether the wave took
+  // its nodes from the heaps, whether every heap is empty (the mode's "frontier empty")
+  int32_t prio_n0, prio_wave, prio_all_empty, prio_gen;   // (prio_gen: the wave whose pops are due, PrioView::gen)
   // SFF* on the device (devstar.hip): rounds whose choose-parent / rewire step ran here, the fixed-point passes they
   // took, the k-nearest members they looked at, the rewires they applied (folded in from StarView::acc by k_wave_end)
   unsigned long long star_rounds, star_passes, star_members, star_rewires;
@@ -176,6 +179,7 @@ struct DevCtrl {
 #define SFFK_FAULT_LISTS 1        // a hit / neighbour / triangle-candidate list overflowed: redo the round on the host
 #define SFFK_FAULT_BORDER_TABLE 2 // the border hash table is full: the host grows it
 #define SFFK_FAULT_CAPACITY 4     // node / frontier / border arrays would overflow: the host grows them
+#define SFFK_FAULT_PRIO_REDRAW 8   // priority mode: a random-entry draw fell into Lemire's rejection zone (p ~ heap size / 2^64)
 
 // indirections of the round kernels in device mode (ctrl == nullptr: host mode, everything comes as arguments)
 struct DevRound {
@@ -298,6 +302,7 @@ struct ClassifyArgs {
   int32_t* seg_ovf;         // n x (1+nbcap)
   int32_t* ctrl;            // [1] next task slot of the persistent edge kernel
   const QRec* qrec;         // n records written by the sampling kernel (RoundTemps::qrec), or null (then no k_query_block)
+  int lazy_nb;              // device engine: more than nbcap qualifying neighbours cut the record (flag bit 2) instead of faulting
   int wide;                 // the forest asks for k_query_classify (many neighbours per sample: see Forest::query_wide)
   const int32_t* dev_n;     // device mode: {n, halt} (n above is then the launch bound only)
   unsigned long long* qclk; // device mode: {first wave in, last wave out} clock bracket of the query kernel
@@ -385,8 +390,33 @@ void launch_round_collide(hipStream_t s, const EnvView& env, const RobotView& ro
                           const int32_t* dev_n = nullptr, int stride = 0);
 
 // ---- device-resident forest: state views + the single-workgroup kernels that advance it
+// Priority-frontier mode (Problem::priorityBias != 0; src/forest.h:78-88,126-147,160-181,360-363): every tree keeps one
+// binary heap per OTHER tree (ordered by the distance to that tree's root; with a goal: one heap, ordered by the distance
+// to it), a slot takes its node from a random heap of a random tree - the minimum with probability priorityBias, a random
+// ENTRY of the heap array otherwise, so the array order of src/heap.h (BubbleUp / BubbleDown / pop-at-index) is part of
+// the result.  The heaps live in HBM as (node id, key) arrays with a position map (the reference finds a node in a heap
+// by linear search, src/forest.h:169-171); heaps are independent of each other, so their operations of a wave - pops at
+// its beginning, pushes of the accepted nodes and the exhausted slots' removals at its end, in the reference's order -
+// run one workgroup per heap (devprio.hip).
+struct PrioView {
+  int n_heaps;                 // 0 = mode off
+  int cap;                     // entries per heap (= node capacity)
+  const int32_t* base;         // per tree: its first heap; base[n_trees] = n_heaps
+  int32_t* size;               // per heap: entries
+  int32_t* v;                  // n_heaps x cap: node ids in the reference's array order
+  double* key;                 // n_heaps x cap: Distance(node, refPoint) of the entry
+  int32_t* pos;                // n_heaps x cap: where node id sits in the heap, -1 = not in it
+  const double* ref;           // n_heaps x 6: refPoint
+  int32_t* slot_tree; int32_t* slot_heap; int32_t* slot_idx;   // per slot: tree, heap within the tree, pop-at index (-1 = pop the minimum, -2 = draw it from slot_word)
+  unsigned long long* slot_word;   // per slot: the engine word of its random-entry draw (k_prio_plan)
+  int32_t* plan;               // k_prio_plan's jump tables: (log2(wave) + 2) x (4 wave + 16) ints, or null (sequential picks only)
+  int32_t* counters;           // [0] heaps through with k_prio_end, [1] non-empty ones among them
+  int32_t* gen;                // per heap: the wave (DevCtrl::prio_gen) whose pops it has done
+  double bias;
+};
 struct DevForestView {
   DevCtrl* ctrl;
+  PrioView prio;
   // node records beside the store columns (store_view / NodeStoreMut)
   int32_t* parent; double* d_root; double* d_closest; uint32_t* iter; uint8_t* nflag;
   int32_t* frontier; int32_t* frontier2;                   // two buffers: compaction sifts from one into the other
@@ -417,6 +447,7 @@ struct DevForestView {
                                // memory round trip: a dozen of them is microseconds)
 };
 #define SFFK_PUB_WORDS 16
+#define SFFK_PRIO_MAX_HEAPS 1024
 // ---- SFF* (optimize = true) on the device engine: choose-parent + rewire of src/forest.h:307-351 (devstar.hip).
 // The accept / reject logic does not depend on costs, so k_commit settles WHICH samples of the round become
 // nodes (and their ids) exactly as for plain SFF; then, for the accepted samples only:
@@ -491,6 +522,11 @@ struct ResolveArgs {
   StarView S;
 };
 void launch_wave_begin(hipStream_t s, const DevForestView& f);
+// priority-frontier mode (devprio.hip): picks + pops before the rounds, pushes + removals behind them; the position map
+// of freshly uploaded heaps
+void launch_prio_begin(hipStream_t s, const DevForestView& f);
+void launch_prio_end(hipStream_t s, const DevForestView& f, const NodeStoreView& st);
+void launch_prio_index(hipStream_t s, const PrioView& p);
 // ---- waves of ONE slot = the reference's own loop order (src/forest.h:122-202): one persistent wavefront runs whole
 // outer iterations - frontier pick, up to ThresholdMisses x (sample, pose check, parent edge, 27-cell neighbour query,
 // the neighbour edges in the order the reference reaches them, append), closed list / frontier erase, termination - for as

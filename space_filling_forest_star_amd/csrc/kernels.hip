@@ -1748,8 +1748,15 @@ __global__ __launch_bounds__(64 * QC_WAVES) __attribute__((amdgpu_waves_per_eu(Q
         const int o = __shfl_xor(cut, off);
         cut = o < cut ? o : cut;
       }
-      const bool keep = q && rank <= cut;
-      const int nkeep = __popcll(__ballot(keep));
+      bool keep = q && rank <= cut;
+      int nkeep = __popcll(__ballot(keep));
+      if (nkeep > A.nbcap && A.lazy_nb) {
+        // more neighbours qualify than the record holds: the first nbcap in the reference's order are kept and the sample
+        // is marked (bit 2) - the walk nearly always ends among them (k_commit faults only if it runs off their end)
+        flags |= 4;
+        keep = keep && rank < A.nbcap;
+        nkeep = A.nbcap;
+      }
       if (nkeep > A.nbcap) {
         flags |= 2;   // the host path redoes this sample with unbounded lists
       } else {
@@ -2314,6 +2321,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB_OCC))) v
     }
     bool keep = q && rank <= cut;
     int nnb = __popc(hballot(keep));
+    if (nnb > A.nbcap && A.lazy_nb) {   // (see k_query_classify: the first nbcap neighbours, bit 2 marks the cut)
+      flags |= 4;
+      keep = keep && rank < A.nbcap;
+      nnb = A.nbcap;
+    }
     if (nnb > A.nbcap) { flags |= 2; keep = false; nnb = 0; }
     const bool live = (flags & 3) == 1 && have_env;
     if (keep) {

@@ -282,16 +282,78 @@ def test_path_costs_and_plans_match(S, ctx, optimize):
     ("dense3d_coarse", 1, 5, False, None), ("dense3d_coarse", 64, 5, False, None), ("triang", 128, 4, True, None),
     ("triang", 1, 1, False, [12, 8, 5]), ("triang", 32, 2, False, [12, 8, 5]), ("dense2d", 16, 3, False, None),
 ])
-def test_priority_frontier_mode(S, ctx, name, wave, n_roots, optimize, goal):
+def test_priority_frontier_mode(S, ctx, name, wave, n_roots, optimize, goal, monkeypatch):
     """Problem::priorityBias = 0.95 (what the reference's example XMLs set): frontier nodes come from the
     per-tree priority heaps of src/heap.h (best node w.p. bias, random heap position otherwise)."""
+    monkeypatch.setenv("SFFGPU_PRIO_DEVICE", "1")   # (small waves default to the host engine: see Forest::device_eligible)
     fo, fg = run_pair(S, ctx, name, wave, 5000, seed=14, n_roots=n_roots, optimize=optimize, goal_idx=goal,
                       priority_bias=0.95)
     assert fo.stats()["n_nodes"] > 5
     assert_same_forest(fo, fg)
+    # the heaps live on the device (devprio.hip) unless there is a goal or the wave is the reference's one-slot loop
+    assert bool(fg.device_engine()) == (goal is None and wave >= 2), (fg.device_engine(), goal, wave)
     # and it is not the plain mode in disguise
     fp, _ = run_pair(S, ctx, name, wave, 5000, seed=14, n_roots=n_roots, optimize=optimize, goal_idx=goal)
     assert fp.fingerprint() != fo.fingerprint()
+
+
+@pytest.mark.parametrize("name,wave,n_roots,optimize,iters", [
+    ("dense3d", 1024, 10, False, 40000), ("dense3d", 4096, 10, False, 60000), ("dense3d", 512, 6, True, 20000),
+    ("triang", 2048, 5, False, 30000), ("dense3d_coarse", 256, 8, False, 30000),
+])
+def test_priority_frontier_mode_on_the_device_engine(S, ctx, name, wave, n_roots, optimize, iters, monkeypatch):
+    """The priority-frontier mode at the wave sizes it is run at: thousands of pops per wave (minimum / random heap entry,
+    src/heap.h:175-238), pushes of the accepted nodes onto every heap of their tree, exhausted nodes leaving the tree's
+    other heaps (src/forest.h:160-181), heaps running empty (dense3d_coarse saturates: closed-list waves and back).  The
+    heap ARRAY order is part of the result (random entries are taken by index): the forest must equal the oracle's."""
+    monkeypatch.setenv("SFFGPU_PRIO_DEVICE", "1")
+    fo, fg = run_pair(S, ctx, name, wave, iters, seed=21, n_roots=n_roots, optimize=optimize, priority_bias=0.95)
+    assert fg.device_engine()
+    assert fo.stats()["n_nodes"] > 500
+    assert_same_forest(fo, fg)
+    # (the heaps crowd the samples together: at these small waves a bounded device list runs over now and then and the
+    # wave is finished by the host engine - heaps, slots and the wave's pending pushes travel with it)
+
+
+def test_priority_frontier_mode_default_engine_choice(S, ctx):
+    """Without the knob: waves of 2 048 slots and more on the device engine, smaller ones on the host-replay engine."""
+    sc, w = load_world(ctx, "dense3d")
+    roots = common.free_roots(w.collide, sc["limits"], 4, seed=2)
+    kw = dict(dist_tree=sc["dist_tree"], sampling_dist=sc["sampling_dist"], dim=6, max_iterations=100, seed=2, priority_bias=0.9)
+    small = S.Forest(ctx, roots, sc["limits"], wave=512, **kw)
+    assert not small.device_engine()
+    small.close()
+    big = S.Forest(ctx, roots, sc["limits"], wave=4096, **kw)
+    assert big.device_engine()
+    big.close()
+
+
+def test_priority_frontier_mode_sequential_picks(S, ctx, monkeypatch):
+    """The picks one slot after the other (k_prio_begin: what runs when the parallel plan is not valid - a heap asked for
+    more nodes than it holds, a draw in the rejection zone) give the same forest."""
+    monkeypatch.setenv("SFFGPU_PRIO_SEQ", "1")
+    monkeypatch.setenv("SFFGPU_PRIO_DEVICE", "1")
+    fo, fg = run_pair(S, ctx, "dense3d", 512, 15000, seed=22, n_roots=6, priority_bias=0.95)
+    assert fg.device_engine()
+    assert_same_forest(fo, fg)
+
+
+def test_priority_frontier_mode_staged_runs(S, ctx, monkeypatch):
+    """run() in pieces (the mirror is read between the pieces) and a hand-over to the host engine and back: the heaps
+    travel with the state."""
+    monkeypatch.setenv("SFFGPU_PRIO_DEVICE", "1")
+    sc, w = load_world(ctx, "dense3d")
+    roots = common.free_roots(w.collide, sc["limits"], 6, seed=9)
+    kw = dict(dist_tree=sc["dist_tree"], sampling_dist=sc["sampling_dist"], dim=6, wave=512, seed=9, priority_bias=0.95)
+    fo = O.Forest(w, roots, sc["limits"], max_iterations=30000, **kw)
+    fo.run()
+    fg = S.Forest(ctx, roots, sc["limits"], max_iterations=30000, **kw)
+    assert fg.device_engine()
+    for k in range(6):
+        fg.run(3)
+        assert fg.stats()["n_nodes"] > 0      # (reads the mirror: heaps and slots come down and go up again)
+    fg.run()
+    assert_same_forest(fo, fg)
 
 
 def test_gpu_matches_committed_golden_runs(S, ctx, golden_dir):
