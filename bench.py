@@ -33,7 +33,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r3_bench_pmc_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r4_bench_pmc_summary.json")
 
 
 def parse_args():
@@ -227,7 +227,7 @@ def main():
         try:
             pm = json.load(open(PMC_SUMMARY))
             if pm.get("bench_args") == run_key:
-                k = pm.get("query_kernel", "sffk::k_query_classify")
+                k = pm.get("query_kernel", "sffk::k_query_block")
                 traffic = 1024.0 * (2.0 * pm["FETCH_SIZE"][k]["avg_KiB_per_launch"] + pm["WRITE_SIZE"][k]["avg_KiB_per_launch"])
                 traffic_source = "profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; 2 x FETCH + WRITE (gfx950 correction of MI355X_MICROARCH.md)" % os.path.basename(PMC_SUMMARY)
                 k = "sffk::k_sweep"
@@ -273,9 +273,9 @@ def main():
                 # re-test, classification of the hits: one fused kernel), timed live on the library's launch stream:
                 # device-clock bracket of every launch (and HIP events around every 8th round beside it).
                 # Algorithmic bytes = 24 B x nodes the query has to cover.
-                "bound": "hbm", "kernel": "sffk::k_query_classify (node grid + the round's own grid + hit classification; "
-                                          "since r2 the same launch also looks up the clearance bits of the sample's pose "
-                                          "and edge samples - about an eighth of its time, DESIGN.md 5)",
+                "bound": "hbm", "kernel": "sffk::k_query_block (node grid + the round's own grid + hit classification + the "
+                                          "clearance bits of the sample's pose and edge samples; flat work lists of a "
+                                          "256-thread workgroup per 8 samples, DESIGN.md 5)",
                 "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                 "traffic": traffic, "traffic_source": traffic_source,
                 "launches": int(sweeps), "avg_launch_us": 1e3 * sweep_ms / max(1, sweeps),
@@ -428,6 +428,58 @@ def main():
                 "cpu_oracle_sequential": {"iterations_per_s": sro["iterations"] / dtro,
                                           "accepted_nodes_per_s": (sro["n_nodes"] - 1) / dtro, "iterations": sro["iterations"],
                                           "seconds": dtro, "cores": 1, "collision_checks_per_s": sro["collide_calls"] / dtro}}
+            # ---- plain RRT (src/rrt.h:128-322 without the rewire) and Multi-T-RRT (5 roots, merging trees, :234-316)
+            for key, nroot, opt, iters, oiters in (("rrt", 1, False, 150000, 5000), ("multi_t_rrt", 5, False, 150000, 5000)):
+                for rep in range(2):
+                    r = S.Rrt(ctx, roots[:nroot], sc["limits"], max_iterations=iters, wave=0, dist_tree=sc["dist_tree"],
+                              sampling_dist=sc["sampling_dist"], dim=6, optimize=opt, seed=1)
+                    c0 = time.perf_counter()
+                    r.run()
+                    dtr = time.perf_counter() - c0
+                    sr = r.stats()
+                    r.close()
+                ro = O.Rrt(wr, roots[:nroot], sc["limits"], max_iterations=oiters, dist_tree=sc["dist_tree"],
+                           sampling_dist=sc["sampling_dist"], dim=6, optimize=opt, seed=1)
+                c0 = time.perf_counter()
+                ro.run()
+                dtro = time.perf_counter() - c0
+                sro = ro.stats()
+                legs[key] = {
+                    "workload": "dense_3D.obj, 6-DoF, %s from %d root(s), no goal, %d iterations, adaptive speculative waves"
+                                % ("RRT" if nroot == 1 else "Multi-T-RRT (merging trees)", nroot, iters),
+                    "iterations_per_s": sr["iterations"] / dtr, "accepted_nodes_per_s": (sr["n_nodes"] - nroot) / dtr,
+                    "collision_checks_per_s": sr["collide_calls"] / dtr, "nodes": sr["n_nodes"], "iterations": sr["iterations"],
+                    "waves": sr["waves"], "speculated": sr["speculated"], "committed": sr["committed"], "seconds": dtr,
+                    "cpu_oracle_sequential": {"iterations_per_s": sro["iterations"] / dtro, "iterations": sro["iterations"],
+                                              "accepted_nodes_per_s": (sro["n_nodes"] - nroot) / dtro, "seconds": dtro, "cores": 1}}
+            # ---- the priority-frontier mode (priorityBias = 0.95: what every XML the reference ships sets; src/forest.h:126-147,
+            # 160-181, 360-363, src/heap.h): the headline map, heaps on the device engine (devprio.hip)
+            pl = {}
+            for wv in (8192, 16384):
+                for rep in range(2):
+                    f = S.Forest(ctx, roots, sc["limits"], dist_tree=sc["dist_tree"], sampling_dist=sc["sampling_dist"], dim=6,
+                                 max_iterations=2**31 - 1, node_budget=300000, wave=wv, seed=1, priority_bias=0.95)
+                    c0 = time.perf_counter()
+                    f.run()
+                    dtp = time.perf_counter() - c0
+                    sp = f.stats()
+                    dev_on = bool(f.device_engine())
+                    f.close()
+                pl["wave_%d" % wv] = {"accepted_nodes_per_s": (sp["n_nodes"] - 10) / dtp, "nodes": sp["n_nodes"],
+                                      "iterations": sp["iterations"], "waves": sp["waves"], "seconds": dtp,
+                                      "collision_checks_per_s": sp["collide_calls"] / dtp, "device_engine": dev_on,
+                                      "host_fallback_waves": sp["host_fallback_waves"]}
+            fo = O.Forest(wr, roots, sc["limits"], dist_tree=sc["dist_tree"], sampling_dist=sc["sampling_dist"], dim=6,
+                          max_iterations=30000, wave=1, seed=1, priority_bias=0.95)
+            c0 = time.perf_counter()
+            fo.run()
+            dto = time.perf_counter() - c0
+            so = fo.stats()
+            pl["workload"] = ("dense_3D.obj, 6-DoF, 10 seeded roots, SFF with priorityBias 0.95 (90 heaps: one per ordered pair of "
+                              "trees), 300 k-node budget")
+            pl["cpu_oracle_wave_1"] = {"accepted_nodes_per_s": (so["n_nodes"] - 10) / dto, "iterations": so["iterations"],
+                                       "nodes": so["n_nodes"], "seconds": dto, "cores": 1}
+            legs["sff_priority"] = pl
             out["extra_legs"] = legs
         if args.cpu_iters > 0 and world == 1:
             import oracle_lib as O

@@ -377,14 +377,14 @@ __global__ __launch_bounds__(1024) void k_commit(ResolveArgs A, int n_bound) {
   bool count_end = true;                            // (the neighbour that ended the walk had its edge looked at)
   if (live) {
     if (!inl) code = SFFK_OUTSIDE;
-    else if (flags & 2) { if (gl == 0) atomicOr(A.fault_pending, 1); }   // hit / neighbour list overflow: host path
+    else if (flags & 2) { if (gl == 0) { atomicOr(A.fault_pending, 1); atomicAdd(A.fault_pending + 1, 1); } }   // hit / neighbour list overflow: host path
     else if ((flags & 3) == 1) {
       const bool ovf = gballot(have && fh == 0) != 0;    // 0 = the edge's triangle candidate list ran over
       const bool mine = A.world <= 1 || i % A.world == A.rank;   // (executed work is counted by the rank that ran it)
       const unsigned long long smp = gsum(have ? (unsigned long long)ns : 0ULL);
       if (mine) { cnt[3] = 1; cnt[4] = 1 + (unsigned long long)nnb; cnt[5] = smp; }
       const int fh0 = __shfl(fh, gsh), ns0 = __shfl(ns, gsh);
-      if (ovf) { if (gl == 0) atomicOr(A.fault_pending, 1); }
+      if (ovf) { if (gl == 0) { atomicOr(A.fault_pending, 1); atomicAdd(A.fault_pending + 2, 1); } }
       else {
         cnt[0] = 1;                                // :246 env.Collide(newPoint)
         if (!pose_hit) {
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(1024) void k_commit(ResolveArgs A, int n_bound) {
       const unsigned long long ck = __shfl(my_calls, gsh + kq);
       if (pending && !blocked) {
         if (ks >= 16 && (flags & 4)) {   // the walk ran off the end of a CUT neighbour record: the host path has the whole list
-          if (gl == 0) atomicOr(A.fault_pending, 1);
+          if (gl == 0) { atomicOr(A.fault_pending, 1); atomicAdd(A.fault_pending + 3, 1); }
           st = 1; code = SFFK_REJECTED; end = 16; pending = false;
         } else if (ks >= 16) { st = 2; code = SFFK_ACCEPT; end = 16; pending = false; }
         else {

@@ -1414,6 +1414,12 @@ void Forest::run_device(int max_waves) {
   st.total_ms += ms_since(t0);
   st.host_ms += ms_since(t0) - wait_ms;
   if (getenv("SFFGPU_PROFILE")) {
+    int32_t why[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpy(why, dev.fault_pending.p, 16, hipMemcpyDeviceToHost));
+    fprintf(stderr, "[sffgpu samples that sent their round to the host path] hit / neighbour list overflow %d, triangle candidate list %d, walk past a cut neighbour record %d | host fallback waves %llu\n",
+            why[1], why[2], why[3], (unsigned long long)st.host_fallback_waves);
+  }
+  if (getenv("SFFGPU_PROFILE")) {
     const sffk::DevCtrl& k = d.last;
     {
       const double w = (double)std::max<unsigned long long>(1ULL, k.wprof[7]);

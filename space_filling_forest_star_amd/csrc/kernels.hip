@@ -1541,11 +1541,44 @@ __global__ __launch_bounds__(256) void k_classify(ClassifyArgs A) {
 // filter, exact fp64 re-test of the survivors.  The hits are compacted with __ballot into the wave's LDS slice
 // (no atomics, no hit list in HBM) and classified right away exactly like k_classify does.
 #define QC_WAVES 4
+// A sample with more than 64 hits (the round's samples crowd together: priority-frontier mode, forests that fill the
+// angular dimensions) cannot rank them with one lane per hit.  Its grid scan is then run a second time with this
+// collector: only the hits that QUALIFY as neighbours (src/forest.h:276,283) matter, and of those only the first 16 in
+// the reference's (tree, distance, id) order - the neighbour record holds 15, the 16th says "there are more".  Lane j
+// holds the j-th of them (rank insertion like the k-nearest kernels' TopK).
+#define QC_TOP 16
+struct QcTop {
+  int t, id;
+  double d;
+  int have;          // (uniform)
+  int mine;          // the sample's tree, ForceChildren of the expanded node, parentDistance, treeDistance
+  bool force;
+  double pdist, dist_tree;
+};
+__device__ __forceinline__ void qc_top_offer(QcTop& T, int lane, bool hit, double d, int id, int tree) {
+  bool q = false;
+  if (hit) q = tree == T.mine ? (!T.force && d < T.pdist - SFFG_TOL) : (d < T.dist_tree - SFFG_TOL);
+  unsigned long long take = __ballot(q);
+  while (take) {
+    const int src = __ffsll((long long)take) - 1;
+    take &= take - 1;
+    const double nd = __shfl(d, src);
+    const int ni = __shfl(id, src), nt = __shfl(tree, src);
+    const bool before = lane < T.have && (T.t < nt || (T.t == nt && (T.d < nd || (T.d == nd && T.id < ni))));
+    const int rank = __popcll(__ballot(before));
+    if (rank >= QC_TOP) continue;
+    const double pd = __shfl_up(T.d, 1);
+    const int pi = __shfl_up(T.id, 1), pt = __shfl_up(T.t, 1);
+    if (lane > rank) { T.d = pd; T.id = pi; T.t = pt; }
+    else if (lane == rank) { T.d = nd; T.id = ni; T.t = nt; }
+    if (T.have < QC_TOP) T.have += 1;
+  }
+}
 // g + tg: the node grid's and the round's own grid's items of the same cells in ONE flattened pass (lane = candidate):
 // both cell counts arrive with the same round of loads, so do both grids' items
 __device__ __forceinline__ void qc_candidates(const GridView& g, const GridView& tg, int m, int mt, int cell, int lane,
                                               const SweepQuery& Q, const double* qp, int32_t* h_id, double* h_d,
-                                              int32_t* h_tree, double* h_pos, int& nh) {
+                                              int32_t* h_tree, double* h_pos, int& nh, QcTop* top = nullptr) {
   // exclusive prefix of the per-lane item counts
   const int mm = m + mt;
   int inc = mm;
@@ -1580,6 +1613,7 @@ __device__ __forceinline__ void qc_candidates(const GridView& g, const GridView&
         hit = d < Q.r;
       }
     }
+    if (top) { qc_top_offer(*top, lane, hit, d, it.id, it.tree); continue; }
     const unsigned long long hm = __ballot(hit);
     if (hit) {
       const int at = nh + __popcll(hm & ((1ULL << lane) - 1ULL));
@@ -1592,7 +1626,8 @@ __device__ __forceinline__ void qc_candidates(const GridView& g, const GridView&
   }
 }
 __device__ __forceinline__ void qc_overflow(const GridView& g, int no, int lane, const SweepQuery& Q, const double* qp,
-                                            int32_t* h_id, double* h_d, int32_t* h_tree, double* h_pos, int& nh) {
+                                            int32_t* h_id, double* h_d, int32_t* h_tree, double* h_pos, int& nh,
+                                            QcTop* top = nullptr) {
   if (no > g.ovf_cap) no = g.ovf_cap;
   for (int base = 0; base < no; base += 64) {
     const int j = base + lane;
@@ -1607,6 +1642,7 @@ __device__ __forceinline__ void qc_overflow(const GridView& g, int no, int lane,
         hit = d < Q.r;
       }
     }
+    if (top) { qc_top_offer(*top, lane, hit, d, it.id, it.tree); continue; }
     const unsigned long long hm = __ballot(hit);
     if (hit) {
       const int at = nh + __popcll(hm & ((1ULL << lane) - 1ULL));
@@ -1695,6 +1731,7 @@ __global__ __launch_bounds__(64 * QC_WAVES) __attribute__((amdgpu_waves_per_eu(Q
     const int wx = hx - lx + 1, wy = hy - ly + 1, wz = hz - lz + 1;
     const int total = wx * wy * wz;
     const float rwx = __frcp_rn((float)wx), rwy = __frcp_rn((float)wy);
+    auto scan = [&](QcTop* top) {
     for (int c0 = 0; c0 < total; c0 += 64) {
       const int c = c0 + lane;
       int cell = 0, m = 0, mt = 0;
@@ -1719,20 +1756,34 @@ __global__ __launch_bounds__(64 * QC_WAVES) __attribute__((amdgpu_waves_per_eu(Q
         if (m > g.bk) m = g.bk;
         if (mt > tg.bk) mt = tg.bk;
       }
-      qc_candidates(g, tg, m, mt, cell, lane, Q, qp, h_id, h_d, h_tree, h_pos, nh);
+      qc_candidates(g, tg, m, mt, cell, lane, Q, qp, h_id, h_d, h_tree, h_pos, nh, top);
     }
-    if (no_g > 0) qc_overflow(g, no_g, lane, Q, qp, h_id, h_d, h_tree, h_pos, nh);
-    if (no_t > 0) qc_overflow(tg, no_t, lane, Q, qp, h_id, h_d, h_tree, h_pos, nh);
+    if (no_g > 0) qc_overflow(g, no_g, lane, Q, qp, h_id, h_d, h_tree, h_pos, nh, top);
+    if (no_t > 0) qc_overflow(tg, no_t, lane, Q, qp, h_id, h_d, h_tree, h_pos, nh, top);
+    };
+    scan(nullptr);
     // ---- classification (k_classify's logic on the wave's own hit list)
     qt1 = DBG_T();
-    const int cnt = nh;
+    int cnt = nh;
+    // more hits than lanes (and no test asks for a smaller list): the scan again, keeping the first QC_TOP qualifying hits
+    QcTop top{0x7fffffff, 0x7fffffff, 0.0, 0, mine, force, pdist, A.dist_tree};
+    const bool topped = cnt > 64 && A.cap >= 64;
+    if (topped) {
+      scan(&top);
+      cnt = top.have;
+      if (lane < cnt) {   // (the kept hits' positions: from the store)
+        const double* ps = A.pos + 6 * (size_t)top.id;
+        for (int k = 0; k < 6; ++k) h_pos[6 * lane + k] = ps[k];
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
     if (cnt > A.cap) {
       flags |= 2;
     } else {
       const bool have = lane < cnt;
-      const int id = have ? h_id[lane] : 0x7fffffff;
-      const double d = have ? h_d[lane] : 0.0;
-      const int t = have ? h_tree[lane] : 0x7fffffff;
+      const int id = have ? (topped ? top.id : h_id[lane]) : 0x7fffffff;
+      const double d = have ? (topped ? top.d : h_d[lane]) : 0.0;
+      const int t = have ? (topped ? top.t : h_tree[lane]) : 0x7fffffff;
       const bool same = t == mine;
       bool q = false;
       if (have) q = same ? (!force && d < pdist - SFFG_TOL)          // src/forest.h:276
