@@ -38,12 +38,11 @@ bool Forest::device_eligible() const {
   // plain SFF and SFF* (choose-parent + rewire on the device: devstar.hip), the single-goal mode, and the priority-frontier
   // mode without a goal (heaps in HBM, one workgroup per heap: devprio.hip); priority + goal runs on the host-replay engine
   if (!use_priority()) return true;
-  // (waves below ~2 000 slots take the very top of every heap: their samples crowd together, the bounded neighbour lists of
-  // the device run over in most waves and every overflow costs a round trip through the host engine - measured on
-  // dense_3D: 54 k nodes/s at 1 024 slots against the host engine's 98 k, 124 k at 2 048, 1.49 M at 8 192;
-  // SFFGPU_PRIO_DEVICE=1 / 0 overrides)
+  // (measured on dense_3D, 100 k nodes: 73 k nodes/s at waves of 64 slots against the host engine's 29 k, 0.83 M at 1 024
+  // against 98 k, 1.6 M at 8 192; waves of one slot - the reference's own loop - stay on the host engine;
+  // SFFGPU_PRIO_DEVICE=0 keeps the whole mode there)
   const char* const knob = getenv("SFFGPU_PRIO_DEVICE");
-  const int min_wave = knob ? (atoi(knob) ? 2 : 0x7fffffff) : 2048;
+  const int min_wave = (knob && !atoi(knob)) ? 0x7fffffff : 2;
   if (cfg.has_goal || cfg.wave < min_wave || cfg.world > 1) return false;
   const long long heaps_n = (long long)num_roots * (num_roots - 1);
   const long long cap = (long long)std::max(cfg.node_budget, 4096) + 2LL * cfg.wave + 128;

@@ -1,6 +1,7 @@
 """GPU parity: every hot-path entry point of libsffgpu.so (through the C ABI) against the CPU
 oracle on the same seeded inputs.  Integer / boolean / index results must be identical and the
 fp64 values bit-equal (both sides evaluate the same IEEE expressions, -ffp-contract=off)."""
+import os
 import numpy as np
 import pytest
 
@@ -285,7 +286,6 @@ def test_path_costs_and_plans_match(S, ctx, optimize):
 def test_priority_frontier_mode(S, ctx, name, wave, n_roots, optimize, goal, monkeypatch):
     """Problem::priorityBias = 0.95 (what the reference's example XMLs set): frontier nodes come from the
     per-tree priority heaps of src/heap.h (best node w.p. bias, random heap position otherwise)."""
-    monkeypatch.setenv("SFFGPU_PRIO_DEVICE", "1")   # (small waves default to the host engine: see Forest::device_eligible)
     fo, fg = run_pair(S, ctx, name, wave, 5000, seed=14, n_roots=n_roots, optimize=optimize, goal_idx=goal,
                       priority_bias=0.95)
     assert fo.stats()["n_nodes"] > 5
@@ -316,16 +316,24 @@ def test_priority_frontier_mode_on_the_device_engine(S, ctx, name, wave, n_roots
 
 
 def test_priority_frontier_mode_default_engine_choice(S, ctx):
-    """Without the knob: waves of 2 048 slots and more on the device engine, smaller ones on the host-replay engine."""
+    """Every wave size but the reference's one-slot loop runs on the device engine; SFFGPU_PRIO_DEVICE=0 keeps the mode on
+    the host-replay engine."""
     sc, w = load_world(ctx, "dense3d")
     roots = common.free_roots(w.collide, sc["limits"], 4, seed=2)
     kw = dict(dist_tree=sc["dist_tree"], sampling_dist=sc["sampling_dist"], dim=6, max_iterations=100, seed=2, priority_bias=0.9)
-    small = S.Forest(ctx, roots, sc["limits"], wave=512, **kw)
-    assert not small.device_engine()
-    small.close()
+    one = S.Forest(ctx, roots, sc["limits"], wave=1, **kw)
+    assert not one.device_engine()
+    one.close()
     big = S.Forest(ctx, roots, sc["limits"], wave=4096, **kw)
     assert big.device_engine()
     big.close()
+    os.environ["SFFGPU_PRIO_DEVICE"] = "0"
+    try:
+        off = S.Forest(ctx, roots, sc["limits"], wave=4096, **kw)
+        assert not off.device_engine()
+        off.close()
+    finally:
+        os.environ.pop("SFFGPU_PRIO_DEVICE")
 
 
 def test_priority_frontier_mode_sequential_picks(S, ctx, monkeypatch):
