@@ -10,7 +10,7 @@ import sys
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--bench-args", default="")
-ap.add_argument("--query-kernel", default="sffk::k_query_pair")
+ap.add_argument("--query-kernel", default="sffk::k_query_block")
 ap.add_argument("files", nargs="+")
 a = ap.parse_args()
 

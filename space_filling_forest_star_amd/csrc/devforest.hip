@@ -504,6 +504,37 @@ __global__ __launch_bounds__(1024) void k_commit(ResolveArgs A, int n_bound) {
   }
   __syncthreads();
   const unsigned long long wa = s_wa, we = s_we;
+  // ---- 2b. border events (a free edge to a neighbour of another tree, :288-294) whose neighbour is a STORE node need
+  // nothing of the other workgroups: their stamps go out now, and a workgroup none of whose events waits for a
+  // round-mate's id says "posted" before it collects the lower workgroups' counts - the higher workgroups then find the
+  // word in place when they get to their own events (it used to be published behind two waits)
+  int e_nb = 0, e_ex = 0, e_i = 0;
+  size_t e_h = 0;
+  bool is_ev = false, stamped = false, posted = false;
+  if (threadIdx.x < 64) {
+    if ((we >> threadIdx.x) & 1ULL) {
+      is_ev = true;
+      e_i = b * 64 + (int)threadIdx.x;
+      const int raw = A.rec_nb[(size_t)e_i * A.nbcap + s_dk[threadIdx.x]];
+      e_ex = A.parent[e_i];
+      if (raw < Tb) {
+        e_nb = raw;
+        const int a = e_nb < e_ex ? e_nb : e_ex, bb = e_nb < e_ex ? e_ex : e_nb;
+        const unsigned long long key = ((unsigned long long)(uint32_t)a << 32) | ((unsigned long long)(uint32_t)bb + 1ULL);
+        e_h = border_slot(f, key);
+        atomicMin(&f.bt_val[e_h], stamp_hi | (unsigned long long)(uint32_t)e_i);
+        stamped = true;
+      }
+    }
+    if (__ballot(is_ev && !stamped) == 0ULL) {
+      if (we != 0ULL) __threadfence();         // the stamps are in the table before the word says so
+      if (threadIdx.x == 0) {
+        kc_publish(pub + KC_POSTED, seq, 1u);
+        if (we == 0ULL) kc_publish(pub + KC_OWN, seq, 0u);
+      }
+      posted = true;
+    }
+  }
   // ---- 3. node ids: N0 + accepted samples before, in slot order
   unsigned long long part = 0;
   if ((int)threadIdx.x < b) part = kc_wait(f.wg_pub + (size_t)threadIdx.x * SFFK_PUB_WORDS + KC_ACC, seq, A.fault_pending);
@@ -524,32 +555,24 @@ __global__ __launch_bounds__(1024) void k_commit(ResolveArgs A, int n_bound) {
   // ---- 4. border events (a free edge to a neighbour of another tree, :288-294), first in slot order wins
   int n_own = 0, ev_pref = 0;
   if (we != 0ULL || last) {
-    int e_nb = 0, e_ex = 0, e_i = 0;
-    size_t e_h = 0;
-    bool is_ev = false;
-    if (threadIdx.x < 64 && ((we >> threadIdx.x) & 1ULL)) {
-      is_ev = true;
-      e_i = b * 64 + (int)threadIdx.x;
+    if (is_ev && !stamped) {                 // (a round-mate neighbour was accepted: its new id)
       const int raw = A.rec_nb[(size_t)e_i * A.nbcap + s_dk[threadIdx.x]];
-      if (raw >= Tb) {                       // (a round-mate neighbour was accepted: its new id)
-        const int j = raw - Tb, bj = j >> 6;
-        int pj = acc_pref;
-        unsigned long long wj = wa;
-        if (bj != b) {
-          const unsigned long long* pp = f.wg_pub + (size_t)bj * SFFK_PUB_WORDS;
-          pj = (int)kc_wait(pp + KC_PREF, seq, A.fault_pending);
-          wj = (unsigned long long)kc_wait(pp + KC_WLO, seq, A.fault_pending) |
-               ((unsigned long long)kc_wait(pp + KC_WHI, seq, A.fault_pending) << 32);
-        }
-        e_nb = N0 + pj + __popcll(wj & ((1ULL << (j & 63)) - 1ULL));
-      } else e_nb = raw;
-      e_ex = A.parent[e_i];
+      const int j = raw - Tb, bj = j >> 6;
+      int pj = acc_pref;
+      unsigned long long wj = wa;
+      if (bj != b) {
+        const unsigned long long* pp = f.wg_pub + (size_t)bj * SFFK_PUB_WORDS;
+        pj = (int)kc_wait(pp + KC_PREF, seq, A.fault_pending);
+        wj = (unsigned long long)kc_wait(pp + KC_WLO, seq, A.fault_pending) |
+             ((unsigned long long)kc_wait(pp + KC_WHI, seq, A.fault_pending) << 32);
+      }
+      e_nb = N0 + pj + __popcll(wj & ((1ULL << (j & 63)) - 1ULL));
       const int a = e_nb < e_ex ? e_nb : e_ex, bb = e_nb < e_ex ? e_ex : e_nb;
       const unsigned long long key = ((unsigned long long)(uint32_t)a << 32) | ((unsigned long long)(uint32_t)bb + 1ULL);
       e_h = border_slot(f, key);
       atomicMin(&f.bt_val[e_h], stamp_hi | (unsigned long long)(uint32_t)e_i);
     }
-    if (threadIdx.x < 64) {
+    if (threadIdx.x < 64 && !posted) {
       if (we != 0ULL) __threadfence();         // the stamps are in the table before the word says so
       if (threadIdx.x == 0) kc_publish(pub + KC_POSTED, seq, 1u);
     }
@@ -610,9 +633,6 @@ __global__ __launch_bounds__(1024) void k_commit(ResolveArgs A, int n_bound) {
       f.pair[(size_t)ta * f.n_trees + tb] = 1;
       f.pair[(size_t)tb * f.n_trees + ta] = 1;
     }
-  } else if (threadIdx.x == 0) {
-    kc_publish(pub + KC_POSTED, seq, 1u);
-    kc_publish(pub + KC_OWN, seq, 0u);
   }
   KC_TRACE(7);
   if (!last) return;
