@@ -311,18 +311,20 @@ def main():
             for a in range(3):
                 pts[:, a] = rs.uniform(lim[2 * a], lim[2 * a + 1], Nn)
             pts[:, 3:] = rs.uniform(-np.pi, np.pi, (Nn, 3))
-            ctx.nodes_reset(Nn + 64)
+            cs = S.Context(local_rank)   # (a context of its own: the forests below size their arrays by their context's store)
+            cs.nodes_reset(Nn + 64)
             for a0 in range(0, Nn, 4000000):
-                ctx.nodes_append(pts[a0:a0 + 4000000], np.zeros(len(pts[a0:a0 + 4000000]), np.int32))
+                cs.nodes_append(pts[a0:a0 + 4000000], np.zeros(len(pts[a0:a0 + 4000000]), np.int32))
             vol = (lim[1] - lim[0]) * (lim[3] - lim[2]) * (lim[5] - lim[4])
             rad = (32.0 * vol / Nn / 4.19) ** (1.0 / 3.0)
             qq = pts[rs.randint(0, Nn, 1)] + rs.normal(0, 5.0, (1, 6))
-            ctx.radius(qq, rad, cap=64)
-            ms0, _ = ctx.kernel_times()
+            cs.radius(qq, rad, cap=64)
+            ms0, _ = cs.kernel_times()
             reps = 30
             for _ in range(reps):
-                ctx.radius(qq, rad, cap=64)
-            ms1, _ = ctx.kernel_times()
+                cs.radius(qq, rad, cap=64)
+            ms1, _ = cs.kernel_times()
+            cs.close()
             tt = (ms1[0] - ms0[0]) / reps * 1e-3
             out["sweep_kernel_roofline"] = {"kernel": "sffk::k_sweep", "bound": "hbm", "nodes": Nn, "queries_per_pass": 1,
                                             "us_per_pass": tt * 1e6, "achieved": 24.0 * Nn / tt / 1e9, "peak": 8000.0,

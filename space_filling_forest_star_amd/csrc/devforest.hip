@@ -15,14 +15,10 @@
 //                 control block.  Workgroups wait for lower ones only (see the kernel)
 //   k_append_sample  wide: accepted samples -> node store, neighbour grid, frontier; the slots that were not accepted
 //                 form the next round's active list AND draw that round's samples in the same launch
-//   k_wave_end    one workgroup: exhausted slots move their node to the closed list (first occurrence in slot
+//   k_wave_end_wide  256 slots per workgroup: exhausted slots move their node to the closed list (first occurrence in slot
 //                 order) and mark their frontier position; termination tests (src/forest.h:184-201)
 //   k_frontier_compact  wide: order-preserving removal of the marked positions (the reference erases them one by
 //                 one, :160-163) from one frontier buffer into the other
-//
-// Ordered compactions inside the single-workgroup kernels use 64-bit ballot words kept in LDS (one word per 64
-// elements, a prefix over the words' popcounts by one wavefront) instead of block-wide scans per 1024 elements:
-// two barriers per list, whatever its length.
 //
 // Everything here is integer / index bookkeeping plus the few fp64 expressions of expandNode, evaluated in the same
 // order as the host engine (-ffp-contract=off), so the forests are bit-identical.
@@ -37,57 +33,7 @@ namespace sffk {
 
 using namespace sffg;
 
-#define DF_THREADS 1024
-#define DF_WAVES (DF_THREADS / 64)
-#define DF_MAX_GROUPS SFFK_DEV_MAX_GROUPS   // ballot words in LDS: 64 x this many elements per list
-
 __device__ __forceinline__ int record_words_dev(int nbcap) { return 6 + 4 * nbcap; }
-
-struct WgLists {                     // LDS of the single-workgroup kernels
-  unsigned long long words[DF_MAX_GROUPS];
-  int pref[DF_MAX_GROUPS];
-  int total;
-};
-
-// flags of elements [0, n) -> ballot words (every wave takes every 16th group of 64 elements)
-template <class Pred>
-__device__ __forceinline__ void wg_flags(WgLists& L, int n, Pred pred) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int ng = (n + 63) >> 6;
-  for (int g = wave; g < ng; g += DF_WAVES) {
-    const int i = g * 64 + lane;
-    const bool fl = i < n && pred(i);
-    const unsigned long long m = __ballot(fl);
-    if (lane == 0) L.words[g] = m;
-  }
-}
-// exclusive prefix of the words' popcounts (wave 0); returns the number of flagged elements.  Barriers inside.
-__device__ __forceinline__ int wg_prefix(WgLists& L, int n) {
-  const int ng = (n + 63) >> 6;
-  __syncthreads();
-  if (threadIdx.x < 64) {
-    const int lane = threadIdx.x;
-    int run = 0;
-    for (int b = 0; b < ng; b += 64) {
-      const int g = b + lane;
-      const int c = g < ng ? __popcll(L.words[g]) : 0;
-      int inc = c;
-      for (int off = 1; off < 64; off <<= 1) {
-        const int o = __shfl_up(inc, off);
-        if (lane >= off) inc += o;
-      }
-      if (g < ng) L.pref[g] = run + inc - c;
-      run += __shfl(inc, 63);
-    }
-    if (lane == 0) L.total = run;
-  }
-  __syncthreads();
-  return L.total;
-}
-__device__ __forceinline__ bool wg_flagged(const WgLists& L, int i) { return (L.words[i >> 6] >> (i & 63)) & 1ULL; }
-__device__ __forceinline__ int wg_rank(const WgLists& L, int i) {
-  return L.pref[i >> 6] + __popcll(L.words[i >> 6] & ((1ULL << (i & 63)) - 1ULL));
-}
 
 // libstdc++ uniform_int_distribution<int>(0, range - 1) on one 64-bit engine word (Lemire's multiply-shift):
 // returns the draw, or -1 when the word falls into the rejection zone (the reference then draws again)
@@ -737,7 +683,7 @@ __device__ __forceinline__ int append_one(const ResolveArgs& A, int i, int& slot
   int32_t* act_new = c->app_act_sel ? f.act_slot : f.act_slot2;
   // the wave is over with this commit (no next round): the slots still on the list are exhausted - each claims its node
   // (atomicMin of its place in the list: a node held by several slots moves to the closed list once, at its first slot,
-  // src/forest.h:160-178) and parks it for k_wave_end, which would otherwise spend a pass of its one workgroup on this
+  // src/forest.h:160-178) and parks it for k_wave_end_wide, which would otherwise post the claims itself and meet at a counter first
   const bool wave_over = c->n_act == 0 && !c->halt && c->in_wave && !c->use_closed;
   auto claim = [&](int e, int slot) {
     const int nd = f.slot_node[slot];
@@ -859,166 +805,16 @@ __device__ void wave_end_control(const DevForestView& f, DevCtrl* c, int removed
   }
 }
 
-// ------------------------------------------------------------------ wave end
-__global__ __launch_bounds__(DF_THREADS) void k_wave_end(DevForestView f, const int32_t* __restrict__ grid_ovf,
-                                                         const int32_t* __restrict__ tgrid_ovf, unsigned long long* star_acc) {
-  __shared__ WgLists L;
-  __shared__ unsigned long long star_s[SFFK_STAR_ACC];
-  DevCtrl* c = f.ctrl;
-  if (c->halt || !c->in_wave) return;
-  if (star_acc) {   // SFF*: the wave's sub-counters (64 lines, k_star_apply) are folded into the control block below
-    if (threadIdx.x < SFFK_STAR_ACC) star_s[threadIdx.x] = 0ULL;
-    __syncthreads();
-    if (threadIdx.x < 64 * SFFK_STAR_ACC) {
-      const unsigned long long v = star_acc[threadIdx.x];
-      if (v) { atomicAdd(&star_s[threadIdx.x % SFFK_STAR_ACC], v); star_acc[threadIdx.x] = 0ULL; }
-    }
-    __syncthreads();
-  }
-  const bool from_closed = c->use_closed != 0;
-  const int fn = c->frontier_n;
-  const int nw = (fn + 63) >> 6;
-  const int n_fail = c->act_cnt;                 // the slots still failing, in slot order
-  const int32_t* act = act_now(f);
-  int removed = 0;
-  unsigned long long tw[7];
-  const bool clk = f.profile != 0;
-  for (int q = 0; q < 7; ++q) tw[q] = clk ? wall_clock64() : 0ULL;
-  // ---- exhausted slots: the node leaves the frontier for the closed list (src/forest.h:160-178); a node held by
-  // several slots moves once, at its first slot.  Its position in the frontier (the pick index) is marked in rm_words.
-  if (!from_closed) {
-    // (rm_words is all zero between waves: k_frontier_compact clears the words it has consumed.  Loads in batches of
-    // eight independent ones per thread; the failing slots' nodes are parked in ulist for the later passes.)
-    int32_t* nodes = f.ulist;
-    const bool have_claims = c->claims_done != 0;   // (posted by the wave's last append; not after a resumed or empty wave)
-    for (int e0 = 0; e0 < n_fail && !have_claims; e0 += 8 * DF_THREADS) {
-      int sl[8], nd[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) { const int e = e0 + u * DF_THREADS + threadIdx.x; sl[u] = e < n_fail ? act[e] : -1; }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) nd[u] = sl[u] >= 0 ? f.slot_node[sl[u]] : -1;
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int e = e0 + u * DF_THREADS + threadIdx.x;
-        if (nd[u] >= 0) { atomicMin(&f.claim[nd[u]], e); nodes[e] = nd[u]; }
-      }
-    }
-    __threadfence_block();   // (one workgroup: its L1 and the barrier order everything; an agent-scope fence would write the L2 back)
-    __syncthreads();
-    if (clk) tw[1] = wall_clock64();
-    {   // flags: the slot that owns its node's claim (four groups of 64 per wave in flight)
-      const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-      const int ngf = (n_fail + 63) >> 6;
-      for (int g0 = wave; g0 < ngf; g0 += 4 * DF_WAVES) {
-        int nd[4], own[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { const int e = (g0 + u * DF_WAVES) * 64 + lane; nd[u] = e < n_fail ? nodes[e] : -1; }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          own[u] = nd[u] >= 0 ? __hip_atomic_load(&f.claim[nd[u]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
-          if (f.prio.n_heaps && nd[u] >= 0 && (f.nflag[nd[u]] & 1)) own[u] = -1;   // (priority mode: closed once, :174-177)
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int g = g0 + u * DF_WAVES;
-          const int e = g * 64 + lane;
-          const unsigned long long m = __ballot(nd[u] >= 0 && own[u] == e);
-          if (lane == 0 && g < ngf) L.words[g] = m;
-        }
-      }
-    }
-    removed = wg_prefix(L, n_fail);
-    if (clk) tw[2] = wall_clock64();
-    const int cn0 = c->closed_n;
-    for (int e0 = 0; e0 < n_fail; e0 += 8 * DF_THREADS) {
-      int nd[8], ps[8], fl[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int e = e0 + u * DF_THREADS + threadIdx.x;
-        const bool on = e < n_fail && wg_flagged(L, e);
-        nd[u] = on ? nodes[e] : -1;
-        ps[u] = on ? f.slot_pos[act[e]] : 0;
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) fl[u] = nd[u] >= 0 ? f.nflag[nd[u]] : 0;
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int e = e0 + u * DF_THREADS + threadIdx.x;
-        if (nd[u] < 0) continue;
-        f.closed[cn0 + wg_rank(L, e)] = nd[u];
-        f.nflag[nd[u]] = (uint8_t)((fl[u] & ~2) | 1);
-        if (!f.prio.n_heaps) atomicOr(&f.rm_words[ps[u] >> 6], 1ULL << (ps[u] & 63));
-      }
-    }
-    __syncthreads();
-    if (clk) tw[3] = wall_clock64();
-    // (the claims are cleared by k_frontier_compact - wide - once every slot of a node has seen them)
-    // exclusive prefix of the removed positions per 64-entry word (k_frontier_compact shifts by it): every thread
-    // sums a contiguous run of words, the runs are scanned through LDS
-    __threadfence_block();
-    __syncthreads();
-    if (clk) tw[4] = wall_clock64();
-    if (removed > 0 && !f.prio.n_heaps) {
-      const int per = (nw + DF_THREADS - 1) / DF_THREADS;
-      const int w0 = threadIdx.x * per;
-      int mine = 0;
-      for (int k0 = 0; k0 < per; k0 += 8) {
-        unsigned long long wv[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int w = w0 + k0 + u;
-          wv[u] = (k0 + u < per && w < nw) ? __hip_atomic_load(&f.rm_words[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ULL;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) mine += __popcll(wv[u]);
-      }
-      L.pref[threadIdx.x] = mine;        // (DF_THREADS <= DF_MAX_GROUPS)
-      __syncthreads();
-      if (threadIdx.x < 64) {
-        const int lane = threadIdx.x;
-        int run = 0;
-        for (int b = 0; b < DF_THREADS; b += 64) {
-          const int v = L.pref[b + lane];
-          int inc = v;
-          for (int off = 1; off < 64; off <<= 1) {
-            const int o = __shfl_up(inc, off);
-            if (lane >= off) inc += o;
-          }
-          L.pref[b + lane] = run + inc - v;
-          run += __shfl(inc, 63);
-        }
-      }
-      __syncthreads();
-      int run = L.pref[threadIdx.x];
-      for (int k = 0; k < per; ++k) {
-        const int w = w0 + k;
-        if (w >= nw) break;
-        f.rm_pref[w] = run;
-        run += __popcll(__hip_atomic_load(&f.rm_words[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-      }
-    }
-    __syncthreads();
-  }
-  // ---- termination (src/forest.h:184-201)
-  if (clk) tw[5] = wall_clock64();
-  if (threadIdx.x == 0) {
-    wave_end_control(f, c, removed, fn, from_closed, n_fail, grid_ovf, tgrid_ovf, star_acc ? star_s : nullptr);
-    if (clk) tw[6] = wall_clock64();
-    if (clk && !from_closed) for (int q = 0; q < 6; ++q) c->wprof[q] += tw[q + 1] - tw[q];
-    c->wprof[7] += 1ULL;
-  }
-}
-
 // ------------------------------------------------------------------ wave end, wide
-// k_wave_end's work when the exhausted slots' claims are already posted (the normal case: the wave's last append did it) as
-// a launch of many workgroups - the one-workgroup kernel spent 30 of its 34 us on two passes of scattered accesses that a
-// single CU retires at about one address per cycle.  256 slots per workgroup:
+// The end of a wave (src/forest.h:160-201) as a launch of many workgroups - the one-workgroup kernel of rounds 2-3 spent
+// 30 of its 34 us on two passes of scattered accesses that a single CU retires at about one address per cycle.  The
+// exhausted slots' claims are normally posted by the wave's last append; after a resumed or an empty wave the launch posts
+// them itself and its workgroups meet at a counter first.  256 slots per workgroup:
 //   owner flags (the slot that holds its node's claim) -> the workgroup's count, published like k_commit's words
 //   ((sequence << 32) | count, word KW_CNT of the workgroup's line) -> closed-list positions = closed_n + the LOWER
 //   workgroups' counts + rank in the workgroup (decoupled look-back: a workgroup waits for lower ones only, and
 //   workgroups start in index order) -> closed list, node flags, removed frontier positions (atomicOr on rm_words)
 //   -> the workgroup that finishes last (a counter) adds the removal prefix per frontier word and the termination tests.
-// Returns at once (and leaves everything to k_wave_end) when the claims are not posted: after a resumed or an empty wave.
 #define KW_CNT 15          // word of the workgroup's wg_pub line (k_commit uses 0..12)
 __global__ __launch_bounds__(256) void k_wave_end_wide(DevForestView f, const int32_t* __restrict__ grid_ovf,
                                                        const int32_t* __restrict__ tgrid_ovf, unsigned long long* star_acc) {
@@ -1030,7 +826,7 @@ __global__ __launch_bounds__(256) void k_wave_end_wide(DevForestView f, const in
   DevCtrl* c = f.ctrl;
   if (c->halt || !c->in_wave) return;
   const bool from_closed = c->use_closed != 0;
-  if (!from_closed && !c->claims_done) return;     // (k_wave_end posts the claims itself)
+  const bool post_claims = !from_closed && !c->claims_done;   // (not posted by the wave's last append: a resumed or empty wave)
   const int n_fail = from_closed ? 0 : c->act_cnt;
   const int nwg = n_fail > 0 ? (n_fail + 255) >> 8 : 1;
   const int b = blockIdx.x;
@@ -1041,11 +837,26 @@ __global__ __launch_bounds__(256) void k_wave_end_wide(DevForestView f, const in
   const int32_t* act = act_now(f);
   const int32_t* nodes = f.ulist;
   unsigned long long* pub = f.wg_pub + (size_t)b * SFFK_PUB_WORDS + KW_CNT;
-  // ---- the slot that owns its node's claim; what the closed-list pass needs is requested with it
   const int e = b * 256 + (int)threadIdx.x;
   const bool on = e < n_fail;
-  const int nd = on ? nodes[e] : -1;
   const int sl = on ? act[e] : 0;
+  if (post_claims) {
+    // every exhausted slot claims its node (atomicMin of its place in the list), then all workgroups of the launch meet:
+    // at most wave / 256 of them, all resident, so a counter they spin on is a safe barrier
+    if (on) { const int nd0 = f.slot_node[sl]; atomicMin(&f.claim[nd0], e); f.ulist[e] = nd0; }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      atomicAdd(&f.commit_seq[5], 1);
+      for (int spin = 0; spin < KC_SPIN_LIMIT; ++spin) {
+        if (__hip_atomic_load(&f.commit_seq[5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= nwg) break;
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    __syncthreads();
+  }
+  // ---- the slot that owns its node's claim; what the closed-list pass needs is requested with it
+  const int nd = on ? __hip_atomic_load(&nodes[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
   const int own = nd >= 0 ? __hip_atomic_load(&f.claim[nd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : -1;
   const int ps = on ? f.slot_pos[sl] : 0;
   const int fl = nd >= 0 ? f.nflag[nd] : 0;
@@ -1125,15 +936,16 @@ __global__ __launch_bounds__(256) void k_wave_end_wide(DevForestView f, const in
   if (threadIdx.x == 0) {
     f.commit_seq[3] = (int32_t)seq;
     f.commit_seq[4] = 0;
+    f.commit_seq[5] = 0;
     wave_end_control(f, c, removed, fn, from_closed, n_fail, grid_ovf, tgrid_ovf, star_acc ? star_s : nullptr);
     c->wprof[7] += 1ULL;
   }
 }
 
-// order-preserving removal of the marked positions: old buffer -> the other one (selected by k_wave_end already)
+// order-preserving removal of the marked positions: old buffer -> the other one (selected by k_wave_end_wide already)
 __global__ __launch_bounds__(256) void k_frontier_compact(DevForestView f) {
   const DevCtrl* c = f.ctrl;
-  // the exhausted slots' claims of the wave that just ended (k_wave_end has looked at them)
+  // the exhausted slots' claims of the wave that just ended (k_wave_end_wide has looked at them)
   for (int e = blockIdx.x * 256 + threadIdx.x; e < c->clear_n; e += gridDim.x * 256) f.claim[f.ulist[e]] = 0x7fffffff;
   const int n = c->compact_from;
   if (n <= 0) return;                       // nothing was removed in this wave (or the kernel ran before a wave ended)
@@ -1220,9 +1032,7 @@ void launch_commit(hipStream_t s, const ResolveArgs& a, int n_bound, const StarL
 }
 void launch_wave_end(hipStream_t s, const DevForestView& f, const int32_t* grid_ovf, const int32_t* tgrid_ovf,
                      unsigned long long* star_acc) {
-  static const bool wide = !(getenv("SFFGPU_NO_WIDE_WAVE_END") && atoi(getenv("SFFGPU_NO_WIDE_WAVE_END")) != 0);
-  if (wide) hipLaunchKernelGGL(k_wave_end_wide, dim3((f.wave + 255) / 256), dim3(256), 0, s, f, grid_ovf, tgrid_ovf, star_acc);
-  hipLaunchKernelGGL(k_wave_end, dim3(1), dim3(DF_THREADS), 0, s, f, grid_ovf, tgrid_ovf, star_acc);   // (returns at once when the wide kernel ended the wave)
+  hipLaunchKernelGGL(k_wave_end_wide, dim3((f.wave + 255) / 256), dim3(256), 0, s, f, grid_ovf, tgrid_ovf, star_acc);
   hipLaunchKernelGGL(k_frontier_compact, dim3(512), dim3(256), 0, s, f);
 }
 void launch_pack_records(hipStream_t s, const ResolveArgs& a, int rank, int world, int n_bound, int32_t* send) {

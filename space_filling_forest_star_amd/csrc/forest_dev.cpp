@@ -57,7 +57,9 @@ void Forest::dev_prio_upload(int gen) {
   std::vector<int32_t> base(heaps.size() + 1, 0);
   for (size_t t = 0; t < heaps.size(); ++t) { base[t] = H; H += (int)heaps[t].size(); }
   base[heaps.size()] = H;
-  const int cap = d.node_cap;
+  // entries per heap (and the range of its position map): what the forest can hold - its node budget plus the wave that
+  // may run past it - not the store's capacity, which an earlier user of the context may have left very large
+  const int cap = cfg.node_budget > 0 ? std::min(d.node_cap, cfg.node_budget + 2 * cfg.wave + 256) : d.node_cap;
   d.prio_heaps = H;
   d.prio_cap = cap;
   d.hp_base.ensure(base.size() * 4);
@@ -106,7 +108,8 @@ void Forest::dev_prio_upload(int gen) {
 void Forest::dev_prio_regrow() {
   DevEngine& d = dev;
   Ctx& c = *ctx;
-  const int H = d.prio_heaps, old_cap = d.prio_cap, cap = d.node_cap;
+  const int H = d.prio_heaps, old_cap = d.prio_cap;
+  const int cap = cfg.node_budget > 0 ? std::min(d.node_cap, cfg.node_budget + 2 * cfg.wave + 256) : d.node_cap;
   if (!H || cap <= old_cap) return;
   DevBuf nv, nk;
   nv.ensure((size_t)H * cap * 4);
