@@ -74,11 +74,7 @@ void Forest::dev_prio_upload(int gen) {
   d.slot_heap.ensure((size_t)cfg.wave * 4);
   d.slot_idx.ensure((size_t)cfg.wave * 4);
   d.slot_word.ensure((size_t)cfg.wave * 8);
-  {
-    int levels = 0;
-    while ((1 << levels) < cfg.wave + 1) ++levels;
-    d.hp_plan.ensure((size_t)(levels + 2) * (4 * (size_t)cfg.wave + 16) * 4);
-  }
+  d.hp_plan.ensure(64);     // (k_prio_plan works in LDS; the pointer says "plan in parallel")
   std::vector<int32_t> sizes(H);
   std::vector<double> refs((size_t)H * 6);
   HIPCHK(hipMemsetAsync(d.hp_pos.p, 0xFF, (size_t)H * cap * 4, c.stream));
@@ -1401,14 +1397,17 @@ void Forest::run_device(int max_waves) {
       break;
     }
     if (fault == SFFK_FAULT_LISTS) {
-      // a bounded device list overflowed: finish this wave on the host path, then come back
+      // a bounded device list overflowed: the round that did is redone on the host path (unbounded lists), the rest of
+      // the wave comes back to the device - k_wave_begin resumes a wave in progress (until round 4 the host finished
+      // the whole wave: 130 ms for a wave of 16 384 slots instead of ~30)
       ++st.host_fallback_waves;
       dev_to_host();
-      while (in_wave) {
+      const bool whole_wave = getenv("SFFGPU_FALLBACK_WHOLE_WAVE") != nullptr;
+      do {
         round_begin();
         int32_t cnt = (int32_t)records.size();
         round_commit(records.data(), cnt, &cnt, 1);
-      }
+      } while (in_wave && whole_wave);
       on_list_fault();
       dev_upload_state();
     }
@@ -1418,6 +1417,14 @@ void Forest::run_device(int max_waves) {
   if (getenv("SFFGPU_PROFILE")) {
     int32_t why[4] = {0, 0, 0, 0};
     HIPCHK(hipMemcpy(why, dev.fault_pending.p, 16, hipMemcpyDeviceToHost));
+    {
+      unsigned long long pd[16];
+      sffk::debug_counters_prio(pd);
+      if (pd[0]) fprintf(stderr, "[sffgpu prio heap 0] pops %llu, us per pop %.2f (first loads %.2f), windows per pop %.2f, us per window load %.2f, walk %.2f\n",
+                         pd[0], pd[1] * 0.01 / pd[0], pd[2] * 0.01 / pd[0], (double)pd[3] / pd[0], pd[4] * 0.01 / (pd[3] ? pd[3] : 1), pd[5] * 0.01 / (pd[3] ? pd[3] : 1));
+      if (pd[0]) fprintf(stderr, "[sffgpu prio heap 0, wave ends] new nodes pushed %llu (gather %.1f ms, pushes %.1f ms) | slot operations %llu, %llu of them removals (gather %.1f ms, apply %.1f ms)\n",
+                         pd[6], pd[7] * 1e-5, pd[8] * 1e-5, pd[9], pd[12], pd[10] * 1e-5, pd[11] * 1e-5);
+    }
     fprintf(stderr, "[sffgpu samples that sent their round to the host path] hit / neighbour list overflow %d, triangle candidate list %d, walk past a cut neighbour record %d | host fallback waves %llu\n",
             why[1], why[2], why[3], (unsigned long long)st.host_fallback_waves);
   }

@@ -596,6 +596,7 @@ void launch_border_rehash(hipStream_t s, const DevForestView& f, int n);
 void debug_counters(unsigned long long* out16);   // exact-kernel phase clocks (make EXTRA=-DSFFK_DEBUG_COUNTERS)
 void debug_counters_query(unsigned long long* out16);
 #endif
+void debug_counters_prio(unsigned long long* out16);   // heap-kernel clocks (make EXTRA=-DSFFK_PRIO_DEBUG; zeros otherwise)
 #ifdef SFFK_CI_TRACE
 void debug_ci_trace(unsigned long long* out);     // make EXTRA=-DSFFK_CI_TRACE=<launch>: one launch of k_collide_items, per wave
 #endif
