@@ -1011,7 +1011,7 @@ void Ctx::knn(const double* q6, int nq, int k, const int32_t* tree, const int32_
     time_begin(T_SWEEP);
     if (by_grid)
       sffk::launch_knn_grid(stream, gridv, nullptr, store_view(), d_a.as<sffk::KnnQuery>(), nq, k, d_b.as<int32_t>(),
-                            d_c.as<double>(), d_d.as<int32_t>(), nullptr, nullptr, grid_cell, 8 * sweep_eps());
+                            d_c.as<double>(), d_d.as<int32_t>(), nullptr, nullptr, grid_cell, 8 * sweep_eps(), SFFK_KNN_MATES, store_n);
     else
       sffk::launch_knn_linear(stream, store_view(), store_n, d_a.as<sffk::KnnQuery>(), nq, k, d_b.as<int32_t>(),
                               d_c.as<double>(), d_d.as<int32_t>(), sweep_eps());

@@ -268,7 +268,7 @@ void launch_knn_linear(hipStream_t s, const NodeStoreView& st, int n_store, cons
 // (> mate_cap = overflow: the caller asks again with a larger list; SFFK_KNN_MATES is the first pass's capacity).
 void launch_knn_grid(hipStream_t s, const GridView& g, const GridView* tg, const NodeStoreView& st, const KnnQuery* q, int nq,
                      int kcap, int32_t* idx, double* dist, int32_t* cnt, int32_t* mate_idx, int32_t* mate_cnt, double cell,
-                     double slack, int mate_cap = SFFK_KNN_MATES);
+                     double slack, int mate_cap = SFFK_KNN_MATES, int n_store = 0);   // n_store > 0: far queries fall back to a sweep of the store
 
 // explicit_rt: pos6 holds n x 12 doubles (row-major rotation + translation) instead of n x 6 pose parameters
 void launch_collide_poses(hipStream_t s, const EnvView& env, const RobotView& rob, const double* pos6, int n,

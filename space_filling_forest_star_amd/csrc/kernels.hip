@@ -256,7 +256,8 @@ __global__ __launch_bounds__(256) void k_knn_linear(NodeStoreView st, int n_stor
 
 // candidates of one group of up to 64 cells (lane = cell, m = its item count), flattened over the lanes
 __device__ __forceinline__ void knn_cells(const GridView& g, int m, int cell, int lane, const KnnQuery& Q, const NodeStoreView& st,
-                                          TopK& t, int k, int& have, bool mates, double mate_limit, int32_t* mate_out, int& n_mates, int mate_cap) {
+                                          TopK& t, int k, int& have, bool mates, double mate_limit, int32_t* mate_out, int& n_mates, int mate_cap,
+                                          double bound_d = 1.0e300, int bound_id = 0x7fffffff) {
   int inc = m;
   for (int off = 1; off < 64; off <<= 1) {
     const int o = __shfl_up(inc, off);
@@ -294,7 +295,7 @@ __device__ __forceinline__ void knn_cells(const GridView& g, int m, int cell, in
       n_mates += __popcll(mm);
     } else {
       const double worst = topk_worst(t, k, have);
-      cand = cand && (have < k || key_less(d, id, worst, 0x7fffffff));
+      cand = cand && key_less(d, id, bound_d, bound_id) && (have < k || key_less(d, id, worst, 0x7fffffff));
       topk_insert(t, lane, k, have, __ballot(cand), d, id);
     }
   }
@@ -303,7 +304,8 @@ __device__ __forceinline__ void knn_cells(const GridView& g, int m, int cell, in
 __global__ __launch_bounds__(256) void k_knn_grid(GridView g, GridView tg, NodeStoreView st, const KnnQuery* __restrict__ queries,
                                                   int nq, int kcap, int32_t* __restrict__ idx, double* __restrict__ dist,
                                                   int32_t* __restrict__ cnt, int32_t* __restrict__ mate_idx,
-                                                  int32_t* __restrict__ mate_cnt, double cell_edge, double slack, int mate_cap) {
+                                                  int32_t* __restrict__ mate_cnt, double cell_edge, double slack, int mate_cap,
+                                                  int n_store) {
   const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (q >= nq) return;
@@ -335,33 +337,87 @@ __global__ __launch_bounds__(256) void k_knn_grid(GridView g, GridView tg, NodeS
     }
   }
   // shells of cells around the query's cell: shell r = the cube of half-width r minus the cube of half-width r-1.
-  // After shell r every node within r * cell_edge (minus fp32 slack) of the query has been seen.
+  // After shell r every node within r * cell_edge (minus fp32 slack) of the query has been seen.  Only the shell's own
+  // cells are enumerated (two caps of w x w cells, w - 2 rings of 8 r in between; until round 4 the loop ran over the
+  // whole cube and masked its inside: sum of (2r+1)^3 instead of (2R+1)^3 - ten times the work at 40 shells), four
+  // cells per lane and trip.  A query far from every node (RRT's random steering targets while the tree is small and
+  // its cells already fine) would still visit the whole grid: once the cells asked for outnumber the store four to
+  // one the query is answered by a sweep of the store instead (same keys, so the same k nearest).
   const int rmax = max(max(g.nx, g.ny), g.nz);
-  int r_done = -1;
+  long long scanned = 0;
+  bool sweep = false;
   for (int r = 0; r <= rmax; ++r) {
     const int w = 2 * r + 1;
-    const int total = w * w * w;
-    const int inner = r > 0 ? (w - 2) * (w - 2) * (w - 2) : 0;
-    (void)inner;
-    for (int c0 = 0; c0 < total; c0 += 64) {
-      const int c = c0 + lane;
-      int cell = 0, m = 0;
-      if (c < total) {
-        const int ox = c % w - r, oy = (c / w) % w - r, oz = c / (w * w) - r;
-        const bool shell = ox == -r || ox == r || oy == -r || oy == r || oz == -r || oz == r;
-        const int x = cx + ox, y = cy + oy, z = cz + oz;
-        if (shell && x >= 0 && x < g.nx && y >= 0 && y < g.ny && z >= 0 && z < g.nz) {
-          cell = (z * g.ny + y) * g.nx + x;
-          m = g.cnt[cell];
-          if (m > g.bk) m = g.bk;
+    const int ww = w * w, ring = 8 * r;
+    const int total = r > 0 ? 2 * ww + (w - 2) * ring : 1;
+    if (n_store > 0 && scanned + total > 4LL * n_store + 4096) { sweep = true; break; }
+    scanned += total;
+    for (int c0 = 0; c0 < total; c0 += 256) {
+      int cell[4], m[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = c0 + u * 64 + lane;
+        cell[u] = 0; m[u] = 0;
+        if (c < total) {
+          int ox, oy, oz;
+          if (c < 2 * ww) {
+            const int face = c >= ww ? 1 : 0, i = c - face * ww;
+            ox = i % w - r; oy = i / w - r; oz = face ? r : -r;
+          } else {
+            const int cc = c - 2 * ww;
+            const int layer = cc / ring, pp = cc - layer * ring;
+            const int side = pp / (2 * r), t_ = pp - side * 2 * r;
+            oz = -r + 1 + layer;
+            ox = side == 0 ? -r + t_ : side == 1 ? r : side == 2 ? r - t_ : -r;
+            oy = side == 0 ? -r : side == 1 ? -r + t_ : side == 2 ? r : r - t_;
+          }
+          const int x = cx + ox, y = cy + oy, z = cz + oz;
+          if (x >= 0 && x < g.nx && y >= 0 && y < g.ny && z >= 0 && z < g.nz) {
+            cell[u] = (z * g.ny + y) * g.nx + x;
+            m[u] = g.cnt[cell[u]];
+            if (m[u] > g.bk) m[u] = g.bk;
+          }
         }
       }
-      if (__any(m > 0)) knn_cells(g, m, cell, lane, Q, st, t, k, have, false, 0.0, nullptr, n_mates, 0);
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (__any(m[u] > 0)) knn_cells(g, m[u], cell[u], lane, Q, st, t, k, have, false, 0.0, nullptr, n_mates, 0);
     }
-    r_done = r;
     const double covered = (double)r * cell_edge - slack;   // (cells are assigned from fp32 coordinates)
     if (have >= k && topk_worst(t, k, have) <= covered) break;
     if (cx - r <= 0 && cy - r <= 0 && cz - r <= 0 && cx + r >= g.nx - 1 && cy + r >= g.ny - 1 && cz + r >= g.nz - 1) break;
+  }
+  if (sweep) {   // (k_knn_linear's loop; what the shells found is found again)
+    t = TopK{1.0e300, 0x7fffffff};
+    have = 0;
+    const float qx = (float)Q.pos[0], qy = (float)Q.pos[1], qz = (float)Q.pos[2];
+    const float qa = (float)Q.pos[3], qb = (float)Q.pos[4], qc = (float)Q.pos[5];
+    int lim = n_store < Q.max_id ? n_store : Q.max_id;
+    if (Q.mate_base < lim) lim = Q.mate_base;
+    for (int base = 0; base < lim; base += 64) {
+      const int id = base + lane;
+      const double worst = topk_worst(t, k, have);
+      bool cand = false;
+      if (id < lim) {
+        const float dx = st.x[id] - qx, dy = st.y[id] - qy, dz = st.z[id] - qz;
+        const float da = wrapf(st.yaw[id] - qa), db = wrapf(st.pitch[id] - qb), dc = wrapf(st.roll[id] - qc);
+        const float d6 = fmaf(dc, dc, fmaf(db, db, fmaf(da, da, fmaf(dz, dz, fmaf(dy, dy, dx * dx)))));
+        if (d6 == d6) {                                 // (NaN placeholders never match)
+          const double wi = (worst + slack) * (1.0 + 1e-5);
+          cand = worst >= 1.0e299 || (double)d6 <= wi * wi * 1.000001;
+          if (cand && Q.tree >= 0 && st.tree[id] != Q.tree) cand = false;
+        }
+      }
+      if (!__any(cand)) continue;
+      double d = 1.0e300;
+      if (cand) {
+        double np[6];
+        for (int c = 0; c < 6; ++c) np[c] = st.pos[6 * (size_t)id + c];
+        d = dist6(np, Q.pos);
+        cand = have < k || key_less(d, id, worst, 0x7fffffff);
+      }
+      topk_insert(t, lane, k, have, __ballot(cand), d, id);
+    }
   }
   // the round's temporaries not farther than the k-th store node - all of the tree's while the k nearest are the
   // whole tree (then they are read straight from the temporary store entries: coalesced, no cube over the grid)
@@ -421,11 +477,182 @@ __global__ __launch_bounds__(256) void k_knn_grid(GridView g, GridView tg, NodeS
       }
     }
   }
-  (void)r_done;
   if (lane == 0) { cnt[q] = have; if (mate_cnt) mate_cnt[q] = n_mates; }
   if (lane < have && lane < kcap) {
     idx[(size_t)q * kcap + lane] = t.id;
     dist[(size_t)q * kcap + lane] = t.d;
+  }
+}
+
+// The same question without a round grid (the RRT session's k-nearest queries, sffgpu_knn over an indexed store):
+// ONE WORKGROUP per query.  A launch holds a few dozen queries - a wavefront each left the chip idle and the launch as
+// slow as its slowest query (RRT*: 72 % of the GPU time).  The four wavefronts take the shell's batches of 64 cells
+// in turn, each keeps what IT found in a list of its own; after every shell the lists are merged (rank = own index +
+// entries of the other lists that sort before, by bisection in LDS), wave 0 keeps the merged k best, the others start
+// empty again and only take candidates that beat the merged k-th key.  Same keys, same order: the same k nearest.
+__global__ __launch_bounds__(256) void k_knn_grid_wg(GridView g, NodeStoreView st, const KnnQuery* __restrict__ queries, int nq, int kcap,
+                                                     int32_t* __restrict__ idx, double* __restrict__ dist, int32_t* __restrict__ cnt,
+                                                     double cell_edge, double slack, int n_store, int sweep_only) {
+  __shared__ double s_d[4][64];
+  __shared__ int s_id[4][64];
+  __shared__ int s_have[4];
+  __shared__ double m_d[64];
+  __shared__ int m_id[64];
+  const int q = blockIdx.x, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (q >= nq) return;
+  const KnnQuery Q = queries[q];
+  const int k = Q.k < 64 ? Q.k : 64;
+  TopK t{1.0e300, 0x7fffffff};
+  int have = 0, n_mates = 0;
+  double bd = 1.0e300;       // the merged k-th key (inf while fewer than k are known)
+  int bi = 0x7fffffff, G = 0;
+  auto merge = [&]() {
+    s_d[wv][lane] = lane < have ? t.d : 1.0e300;
+    s_id[wv][lane] = lane < have ? t.id : 0x7fffffff;
+    if (lane == 0) s_have[wv] = have;
+    __syncthreads();
+    int rank = lane, total = 0;
+    for (int o = 0; o < 4; ++o) {
+      const int ho = s_have[o];
+      total += ho;
+      if (o != wv && lane < have) {
+        int lo = 0, hi = ho;
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (key_less(s_d[o][mid], s_id[o][mid], t.d, t.id)) lo = mid + 1; else hi = mid;
+        }
+        rank += lo;
+      }
+    }
+    if (lane < have && rank < k) { m_d[rank] = t.d; m_id[rank] = t.id; }
+    __syncthreads();
+    G = total < k ? total : k;
+    if (wv == 0) {
+      t.d = lane < G ? m_d[lane] : 1.0e300;
+      t.id = lane < G ? m_id[lane] : 0x7fffffff;
+      have = G;
+    } else {
+      t = TopK{1.0e300, 0x7fffffff};
+      have = 0;
+    }
+    if (G >= k) { bd = m_d[k - 1]; bi = m_id[k - 1]; }
+    __syncthreads();
+  };
+  const int cx = grid_coord((float)Q.pos[0], g.ox, g.inv_cell, g.nx), cy = grid_coord((float)Q.pos[1], g.oy, g.inv_cell, g.ny),
+            cz = grid_coord((float)Q.pos[2], g.oz, g.inv_cell, g.nz);
+  if (!sweep_only) {   // shared overflow list (usually empty)
+    int no = g.ovf_cnt[0];
+    if (no > g.ovf_cap) no = g.ovf_cap;
+    for (int base = wv * 64; base < no; base += 256) {
+      const int j = base + lane;
+      bool cand = false;
+      double d = 1.0e300;
+      int id = 0x7fffffff;
+      const double worst = topk_worst(t, k, have);
+      if (j < no) {
+        const GridItem it = g.ovf[j];
+        id = it.id;
+        if (id < Q.max_id && id < Q.mate_base && (Q.tree < 0 || it.tree == Q.tree)) {
+          d = dist6(it.p, Q.pos);
+          cand = have < k || key_less(d, id, worst, 0x7fffffff);
+        }
+      }
+      topk_insert(t, lane, k, have, __ballot(cand), d, id);
+    }
+  }
+  const int rmax = sweep_only ? -1 : max(max(g.nx, g.ny), g.nz);
+  long long scanned = 0;
+  bool sweep = sweep_only != 0;
+  for (int r = 0; r <= rmax; ++r) {
+    const int w = 2 * r + 1;
+    const int ww = w * w, ring = 8 * r;
+    const int total = r > 0 ? 2 * ww + (w - 2) * ring : 1;
+    if (n_store > 0 && scanned + total > 4LL * n_store + 4096) { sweep = true; break; }
+    scanned += total;
+    for (int b0 = 0; b0 * 64 < total; b0 += 16) {
+      int cell[4], m[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = (b0 + 4 * u + wv) * 64 + lane;
+        cell[u] = 0; m[u] = 0;
+        if (c < total) {
+          int ox, oy, oz;
+          if (c < 2 * ww) {
+            const int face = c >= ww ? 1 : 0, i = c - face * ww;
+            ox = i % w - r; oy = i / w - r; oz = face ? r : -r;
+          } else {
+            const int cc = c - 2 * ww;
+            const int layer = cc / ring, pp = cc - layer * ring;
+            const int side = pp / (2 * r), t_ = pp - side * 2 * r;
+            oz = -r + 1 + layer;
+            ox = side == 0 ? -r + t_ : side == 1 ? r : side == 2 ? r - t_ : -r;
+            oy = side == 0 ? -r : side == 1 ? -r + t_ : side == 2 ? r : r - t_;
+          }
+          const int x = cx + ox, y = cy + oy, z = cz + oz;
+          if (x >= 0 && x < g.nx && y >= 0 && y < g.ny && z >= 0 && z < g.nz) {
+            cell[u] = (z * g.ny + y) * g.nx + x;
+            m[u] = g.cnt[cell[u]];
+            if (m[u] > g.bk) m[u] = g.bk;
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (__any(m[u] > 0)) knn_cells(g, m[u], cell[u], lane, Q, st, t, k, have, false, 0.0, nullptr, n_mates, 0, bd, bi);
+    }
+    merge();
+    const double covered = (double)r * cell_edge - slack;   // (cells are assigned from fp32 coordinates)
+    if (G >= k && bd <= covered) break;
+    if (cx - r <= 0 && cy - r <= 0 && cz - r <= 0 && cx + r >= g.nx - 1 && cy + r >= g.ny - 1 && cz + r >= g.nz - 1) break;
+  }
+  if (sweep) {   // (k_knn_linear's loop, 256 nodes per wavefront and trip; what the shells found is found again)
+    t = TopK{1.0e300, 0x7fffffff};
+    have = 0; G = 0; bd = 1.0e300; bi = 0x7fffffff;
+    const float qx = (float)Q.pos[0], qy = (float)Q.pos[1], qz = (float)Q.pos[2];
+    const float qa = (float)Q.pos[3], qb = (float)Q.pos[4], qc = (float)Q.pos[5];
+    int lim = n_store < Q.max_id ? n_store : Q.max_id;
+    if (Q.mate_base < lim) lim = Q.mate_base;
+    for (int base = wv * 256; base < lim; base += 1024) {
+      float d6[4];
+      bool in[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int id = base + u * 64 + lane;
+        in[u] = id < lim;
+        const int ic = in[u] ? id : lim - 1;
+        const float dx = st.x[ic] - qx, dy = st.y[ic] - qy, dz = st.z[ic] - qz;
+        const float da = wrapf(st.yaw[ic] - qa), db = wrapf(st.pitch[ic] - qb), dc = wrapf(st.roll[ic] - qc);
+        d6[u] = fmaf(dc, dc, fmaf(db, db, fmaf(da, da, fmaf(dz, dz, fmaf(dy, dy, dx * dx)))));
+        if (in[u] && Q.tree >= 0 && st.tree[ic] != Q.tree) in[u] = false;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int id = base + u * 64 + lane;
+        const double worst = topk_worst(t, k, have);
+        bool cand = false;
+        if (in[u] && d6[u] == d6[u]) {                  // (NaN placeholders never match)
+          const double wi = (worst + slack) * (1.0 + 1e-5);
+          cand = worst >= 1.0e299 || (double)d6[u] <= wi * wi * 1.000001;
+        }
+        if (!__any(cand)) continue;
+        double d = 1.0e300;
+        if (cand) {
+          double np[6];
+          for (int c = 0; c < 6; ++c) np[c] = st.pos[6 * (size_t)id + c];
+          d = dist6(np, Q.pos);
+          cand = have < k || key_less(d, id, worst, 0x7fffffff);
+        }
+        topk_insert(t, lane, k, have, __ballot(cand), d, id);
+      }
+    }
+    merge();
+  }
+  if (wv == 0) {
+    if (lane == 0) cnt[q] = G;
+    if (lane < G && lane < kcap) {
+      idx[(size_t)q * kcap + lane] = t.id;
+      dist[(size_t)q * kcap + lane] = t.d;
+    }
   }
 }
 
@@ -3580,15 +3807,24 @@ void launch_grid_query(hipStream_t s, const GridView& g, const GridView* tg, con
 void launch_knn_linear(hipStream_t s, const NodeStoreView& st, int n_store, const KnnQuery* q, int nq, int kcap,
                        int32_t* idx, double* dist, int32_t* cnt, double abs_eps) {
   if (nq <= 0) return;
+  if (nq <= 2048) {   // a few queries: a workgroup each (k_knn_grid_wg's sweep: the same keys, sixteen times the loads in flight)
+    GridView none{};
+    hipLaunchKernelGGL(k_knn_grid_wg, dim3(nq), dim3(256), 0, s, none, st, q, nq, kcap, idx, dist, cnt, 1.0, abs_eps, n_store, 1);
+    return;
+  }
   hipLaunchKernelGGL(k_knn_linear, dim3((nq + 3) / 4), dim3(256), 0, s, st, n_store, q, nq, kcap, idx, dist, cnt, abs_eps);
 }
 void launch_knn_grid(hipStream_t s, const GridView& g, const GridView* tg, const NodeStoreView& st, const KnnQuery* q, int nq,
                      int kcap, int32_t* idx, double* dist, int32_t* cnt, int32_t* mate_idx, int32_t* mate_cnt, double cell,
-                     double slack, int mate_cap) {
+                     double slack, int mate_cap, int n_store) {
   if (nq <= 0) return;
   GridView none{};
+  if (!tg && !mate_idx && !mate_cnt) {
+    hipLaunchKernelGGL(k_knn_grid_wg, dim3(nq), dim3(256), 0, s, g, st, q, nq, kcap, idx, dist, cnt, cell, slack, n_store, 0);
+    return;
+  }
   hipLaunchKernelGGL(k_knn_grid, dim3((nq + 3) / 4), dim3(256), 0, s, g, tg ? *tg : none, st, q, nq, kcap, idx, dist, cnt,
-                     mate_idx, mate_cnt, cell, slack, mate_cap);
+                     mate_idx, mate_cnt, cell, slack, mate_cap, n_store);
 }
 void launch_set_tree(hipStream_t s, int32_t* tree_col, const int32_t* ids, int n, int32_t value) {
   if (n <= 0) return;
