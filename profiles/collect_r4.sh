@@ -1,7 +1,8 @@
 #!/bin/bash
 # the round-4 profile set (run through gpurun from the repo root): bash profiles/collect_r4.sh
 # -> gpurun_out/r4_*: kernel stats + FETCH / WRITE per kernel + bench lines of the driver's command, SQ counters, memory-side
-# counters of the query kernel, configs[4] and priority-mode kernel stats, small-wave probe, per-round multi-GPU budget
+# counters of the query kernel, configs[4] and priority-mode kernel stats, small-wave probe, per-round multi-GPU budget,
+# RRT legs (kernel stats, per-call k-nearest split), the k-NN and heap micro-benchmarks
 set -u
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out
@@ -17,4 +18,9 @@ SFFGPU_PRIO_DEVICE=0 timeout 600 python3 profiles/priority_probe.py 100000 1024 
 timeout 600 python3 profiles/small_wave_probe.py > $out/r4_small_waves.txt 2>&1
 timeout 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 --force-dist --cpu-iters 0 --no-sweep-micro --no-wave-sweep --no-extra-legs 2>/dev/null | tail -1 > $out/r4_force_dist_line.json
 SFFGPU_PROFILE=1 timeout 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 --cpu-iters 0 --no-sweep-micro --no-wave-sweep --no-extra-legs 2>&1 | grep -E "k_wave_end us|k_commit us|host path" | tail -3 > $out/r4_phase_clocks.txt
+bash profiles/trace_cmd.sh r4_rrt_star profiles/rrt_probe.py 150000 star > $out/r4_rrt_star_trace_top.txt 2>&1
+for m in star rrt multi; do timeout 300 python3 profiles/rrt_probe.py 150000 $m 2>/dev/null | tail -1; done > $out/r4_rrt_probe.jsonl
+bash profiles/rrt_knn_split.sh 60000 > $out/r4_rrt_knn_split.txt 2>&1
+timeout 900 python3 profiles/knn_microbench.py 2>/dev/null | grep -E "^\{" > $out/r4_knn_microbench.jsonl
+( cd profiles/micro && [ -x ./heap_microbench ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -w -I../../space_filling_forest_star_amd/csrc -I../../include -I../../include/sff heap_microbench.hip -o heap_microbench; ./heap_microbench 90 30000 90; ./heap_microbench 90 300000 90 ) > $out/r4_heap_microbench.txt 2>&1
 echo done

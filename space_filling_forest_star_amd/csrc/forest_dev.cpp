@@ -488,7 +488,9 @@ void Forest::dev_upload_state() {
   int nb = 0;
   for (auto& kv : borders) nb += (int)kv.second.size();
   {
-    int first_cap = std::max(1 << 16, 2 * (nb + wave));
+    // (borders end up at 6-7 % of the nodes on the maps of BASELINE.json: room for a tenth of the node budget, so that a
+    // job sized by its budget does not stop in the middle to grow these arrays - 4 ms at 850 k nodes on the bench job)
+    int first_cap = std::max(std::max(1 << 16, 2 * (nb + wave)), cfg.node_budget > 0 ? cfg.node_budget / 10 + 2 * wave : 0);
     if (const char* e = getenv("SFFGPU_TEST_BORDER_CAP")) first_cap = std::max(nb + 1, atoi(e));   // tests: force growth
     dev_size_border_arrays(first_cap);
   }
@@ -1172,15 +1174,19 @@ int Forest::dev_finish_wave(double* wait_ms, int slot, bool stream_idle) {
   if (!stream_idle) return d.last.fault;
   d.host_stale = true;
   const sffk::DevCtrl& s = d.last;
+  static const bool prof = getenv("SFFGPU_PROFILE") != nullptr;
+  const auto t_ev = Clock::now();
   if (s.fault) {
     const int fault = s.fault;
     if (fault == SFFK_FAULT_LISTS) return fault;
     if (fault == SFFK_FAULT_CAPACITY) {
-      // (nodes and temporaries share the store: grow it, re-place the temporaries)
-      c.store_reserve(std::max(c.store_cap * 2, s.n_nodes + 4 * cfg.wave + 64));
-      dev_size_node_arrays();
-      if (use_priority()) dev_prio_regrow();   // (entries per heap = node capacity)
-      dev_size_border_arrays(std::max(d.border_cap, 2 * (s.n_borders + cfg.wave)));
+      // (nodes and temporaries share the store: grow it, re-place the temporaries) - only the side that is short
+      if (s.n_nodes + cfg.wave > d.node_cap - 8) {
+        c.store_reserve(std::max(c.store_cap * 2, s.n_nodes + 4 * cfg.wave + 64));
+        dev_size_node_arrays();
+        if (use_priority()) dev_prio_regrow();   // (entries per heap = node capacity)
+      }
+      if (s.n_borders + cfg.wave > d.border_cap) dev_size_border_arrays(2 * (s.n_borders + cfg.wave));
     } else if (fault == SFFK_FAULT_BORDER_TABLE) {
       dev_size_border_arrays(std::max(4 * d.border_cap, 2 * (s.n_borders + cfg.wave)));
     } else if (fault == SFFK_FAULT_PRIO_REDRAW) {
@@ -1198,6 +1204,8 @@ int Forest::dev_finish_wave(double* wait_ms, int slot, bool stream_idle) {
     HIPCHK(hipStreamSynchronize(c.stream));
     d.last.fault = 0;
     d.last.halt = 0;
+    if (prof) fprintf(stderr, "[sffgpu host event] wave %llu: growth fault %d handled in %.2f ms (%d nodes, %d borders)\n",
+                      (unsigned long long)s.waves, fault, ms_since(t_ev), s.n_nodes, s.n_borders);
     return 0;   // (in_wave is still set: the next k_wave_begin resumes the wave)
   }
   // the neighbour grid's shared overflow list (checked once per wave like the host path does)
@@ -1207,6 +1215,8 @@ int Forest::dev_finish_wave(double* wait_ms, int slot, bool stream_idle) {
     c.store_n = s.n_nodes;
     c.grid_inserted = s.n_nodes;
     c.grid_check();
+    if (prof) fprintf(stderr, "[sffgpu host event] wave %llu: node grid re-celled in %.2f ms (%d nodes, overflow list %d, cell %.3f)\n",
+                      (unsigned long long)s.waves, ms_since(t_ev), s.n_nodes, s.grid_ovf, c.grid_cell);
   }
   return 0;
 }

@@ -3819,7 +3819,7 @@ void launch_knn_grid(hipStream_t s, const GridView& g, const GridView* tg, const
                      double slack, int mate_cap, int n_store) {
   if (nq <= 0) return;
   GridView none{};
-  if (!tg && !mate_idx && !mate_cnt) {
+  if (!tg && !mate_idx && !mate_cnt && nq <= 2048) {   // (more queries than that fill the chip with a wavefront each)
     hipLaunchKernelGGL(k_knn_grid_wg, dim3(nq), dim3(256), 0, s, g, st, q, nq, kcap, idx, dist, cnt, cell, slack, n_store, 0);
     return;
   }
