@@ -625,28 +625,6 @@ __global__ __launch_bounds__(256) void k_prio_end(DevForestView f, NodeStoreView
       for (int j = 0; j < 8; ++j) node[j] = op[j] ? f.slot_node[c0 + tid * 8 + j] : 0;
       hkey_t k[8];                                           // put back: the key; remove: where the node stands (a hint)
       for (int j = 0; j < 8; ++j) k[j] = op[j] == 2 ? hk_bits(key_of(node[j])) : op[j] == 1 ? (hkey_t)(unsigned int)hr.pos[node[j]] : 0ULL;
-      // a removal touches entries all over the heap (where the node stands, its ancestors, the entries below): ask for
-      // those lines now, side by side for the whole chunk - the operations then find them in the L2 (0.65 -> 0.4 us each)
-      {
-        unsigned long long warm = 0ULL;
-        for (int j = 0; j < 8; ++j)
-          if (op[j] == 1) {
-            const int at = (int)(unsigned int)k[j];
-            if (at >= 0 && at < hr.n) {
-              const unsigned long long* kk = reinterpret_cast<const unsigned long long*>(hr.key);
-              warm += kk[at] + (unsigned long long)hr.v[at];
-              for (int a = 1; a <= 10; ++a) {
-                const int pa = (int)(((unsigned int)at + 1u) >> a) - 1;
-                if (pa >= 31) warm += kk[pa] + (unsigned long long)hr.v[pa];     // (the top five levels are hot anyway)
-              }
-              for (int cdn = 1; cdn <= 2; ++cdn) {
-                const long long c0_ = (((long long)at + 1) << cdn) - 1;
-                if (c0_ < hr.n) warm += kk[c0_] + (unsigned long long)hr.v[c0_];
-              }
-            }
-          }
-        asm volatile("" :: "v"((unsigned int)warm), "v"((unsigned int)(warm >> 32)));
-      }
       int total;
       int at = block_excl_scan_256(cnt, s_w, &total);
       for (int j = 0; j < 8; ++j)
