@@ -155,10 +155,20 @@ def test_indexed_knn_equals_the_linear_sweep(ctx):
     ctx.nodes_reset(n + 64)
     ctx.nodes_append(pts[:40000], tree[:40000])
     lin = {k: ctx.knn(q, k) for k in (1, 32, 64)}
+    big = ctx.knn(np.tile(q, (13, 1))[:2600], 32)           # (> 2048 queries: k_knn_linear itself)
+    assert np.array_equal(big[0][:len(q)], lin[32][0]) and np.array_equal(big[1][:len(q)], lin[32][1])
     ctx.nodes_index(lim, 18.2)
     for k in (1, 32, 64):
         gi, gd, gc = ctx.knn(q, k)
         assert np.array_equal(gc, lin[k][2]) and np.array_equal(gi, lin[k][0]) and np.array_equal(gd, lin[k][1])
+    # launches of more than 2048 queries take the one-wavefront-per-query kernels (k_knn_grid with the same shell
+    # enumeration and sweep fallback), smaller ones a workgroup per query (k_knn_grid_wg): the same lists
+    reps = 2600 // len(q) + 1
+    qb = np.tile(q, (reps, 1))[:2600]
+    for k in (1, 32):
+        bi, bd, bc = ctx.knn(qb, k)
+        want = [np.tile(a, (reps,) + (1,) * (a.ndim - 1))[:2600] for a in lin[k]]
+        assert np.array_equal(bc, want[2]) and np.array_equal(bi, want[0]) and np.array_equal(bd, want[1])
     ctx.nodes_append(pts[40000:], tree[40000:])             # enters the index in the same launch
     gi, gd, gc = ctx.knn(q, 32)
     L = O.lib()
