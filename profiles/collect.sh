@@ -19,7 +19,7 @@ LEAN="--cpu-iters 0 --no-sweep-micro --no-wave-sweep --no-extra-legs"
 cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_trace -o t -- python3 $BENCH $LEAN > $out/${tag}_trace.log 2>&1
 cp $out/${tag}_trace/t_kernel_stats.csv $out/${tag}_kernel_stats.csv
-tail -1 $out/${tag}_trace.log > $out/${tag}_bench_line_under_trace.json
+grep -E "^\{\"metric\"" $out/${tag}_trace.log | tail -1 > $out/${tag}_bench_line_under_trace.json
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $c --output-format csv -d $out/${tag}_pmc_$c -o p -- python3 $BENCH $LEAN > $out/${tag}_pmc_$c.log 2>&1
 done

@@ -17,7 +17,7 @@ timeout 300 python3 profiles/priority_probe.py 300000 1024 8192 16384 2>/dev/nul
 SFFGPU_PRIO_DEVICE=0 timeout 600 python3 profiles/priority_probe.py 100000 1024 8192 2>/dev/null | grep -E "^\{" > $out/r4_priority_probe_host_engine.jsonl
 timeout 600 python3 profiles/small_wave_probe.py > $out/r4_small_waves.txt 2>&1
 timeout 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 --force-dist --cpu-iters 0 --no-sweep-micro --no-wave-sweep --no-extra-legs 2>/dev/null | tail -1 > $out/r4_force_dist_line.json
-SFFGPU_PROFILE=1 timeout 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 --cpu-iters 0 --no-sweep-micro --no-wave-sweep --no-extra-legs 2>&1 | grep -E "k_wave_end us|k_commit us|host path" | tail -3 > $out/r4_phase_clocks.txt
+SFFGPU_PROFILE=1 timeout 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 --cpu-iters 0 --no-sweep-micro --no-wave-sweep --no-extra-legs 2>&1 | grep -E "^\[sffgpu" | tail -6 > $out/r4_phase_clocks.txt
 bash profiles/trace_cmd.sh r4_rrt_star profiles/rrt_probe.py 150000 star > $out/r4_rrt_star_trace_top.txt 2>&1
 for m in star rrt multi; do timeout 300 python3 profiles/rrt_probe.py 150000 $m 2>/dev/null | tail -1; done > $out/r4_rrt_probe.jsonl
 bash profiles/rrt_knn_split.sh 60000 > $out/r4_rrt_knn_split.txt 2>&1

@@ -379,7 +379,14 @@ int sffgpu_forest_get_parent_history(sffgpu_forest* f, int32_t* node, int32_t* p
     return n;
   }
   // (entries of one iteration touch distinct nodes; creation order of the entries is kept among equal keys)
-  std::stable_sort(F.hist.begin(), F.hist.end(), [](const Forest::HistRec& a, const Forest::HistRec& b) { return a.iter < b.iter; });
+  // Only what was appended since the last call is sorted, then merged in (the compat layer asks once per iter_<k> dump).
+  {
+    auto less = [](const Forest::HistRec& a, const Forest::HistRec& b) { return a.iter < b.iter; };
+    if (F.hist_sorted > F.hist.size()) F.hist_sorted = 0;
+    std::stable_sort(F.hist.begin() + F.hist_sorted, F.hist.end(), less);
+    std::inplace_merge(F.hist.begin(), F.hist.begin() + F.hist_sorted, F.hist.end(), less);   // (stable: older entries first)
+    F.hist_sorted = F.hist.size();
+  }
   const int n = (int)F.hist.size();
   for (int i = 0; i < n && i < cap; ++i) {
     if (node) node[i] = F.hist[i].node;

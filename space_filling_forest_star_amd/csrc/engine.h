@@ -326,6 +326,7 @@ struct Forest {
   // cfg.record_parents (SFF*): every node creation and applied rewire as (node, parent from then on, iteration)
   struct HistRec { int32_t node, parent; uint32_t iter; };
   std::vector<HistRec> hist;
+  size_t hist_sorted = 0;   // hist[0, hist_sorted) is in iteration order (sffgpu_forest_get_parent_history merges the tail in)
   bool hist_overflow = false;
   std::vector<FNode> nodes;
   // per node, kept apart from the 88-byte records because whole-frontier passes and the per-sample input only

@@ -967,9 +967,12 @@ void Forest::round_begin() {
         std::vector<int> big;
         for (int k = 0; k < m; ++k)
           if (kmax[k] > 0 && r_mcnt[k] > SFFK_KNN_MATES) big.push_back(k);
-        std::vector<int32_t> big_mates;
+        const int32_t* big_mates = nullptr;
+        int big_mcap = 0;                  // (the first pass reports every query's true count: the largest one is enough)
+        for (int k : big) big_mcap = std::max(big_mcap, (int)r_mcnt[k]);
+        big_mcap = std::min(big_mcap, n);
         if (!big.empty()) {
-          const int mb = (int)big.size(), mcap = n;
+          const int mb = (int)big.size(), mcap = big_mcap;
           c.h_e.ensure((size_t)mb * sizeof(sffk::KnnQuery));
           sffk::KnnQuery* bq = c.h_e.as<sffk::KnnQuery>();
           for (int j = 0; j < mb; ++j) bq[j] = hq[big[j]];
@@ -984,9 +987,11 @@ void Forest::round_begin() {
                                 reinterpret_cast<int32_t*>(db + b_idx), c.d_d.as<double>(), reinterpret_cast<int32_t*>(db + b_cnt),
                                 reinterpret_cast<int32_t*>(db + b_mate), reinterpret_cast<int32_t*>(db + b_mcnt), c.grid_cell,
                                 8 * c.sweep_eps(), mcap);
-          big_mates.resize((size_t)mb * mcap + mb);
-          HIPCHK(hipMemcpyAsync(big_mates.data(), db + b_mate, ((size_t)mb * mcap + mb) * 4, hipMemcpyDeviceToHost, c.stream));
+          HIPCHK(hipStreamSynchronize(c.stream));                 // (h_e holds the queries of the launch above)
+          c.h_e.ensure(std::max((size_t)mb * sizeof(sffk::KnnQuery), ((size_t)mb * mcap + mb) * 4));   // (pinned: no staged copy)
+          HIPCHK(hipMemcpyAsync(c.h_e.p, db + b_mate, ((size_t)mb * mcap + mb) * 4, hipMemcpyDeviceToHost, c.stream));
           timed_sync();
+          big_mates = c.h_e.as<int32_t>();
           st.mate_overflow_requeries += (uint64_t)mb;
         }
         size_t big_at = 0;
@@ -996,8 +1001,8 @@ void Forest::round_begin() {
           const int32_t* mate_list = r_mate + (size_t)k * SFFK_KNN_MATES;
           int mate_n = r_mcnt[k];
           if (mate_n > SFFK_KNN_MATES) {     // the second pass's list (same store neighbours, every mate)
-            const int mb = (int)big.size(), mcap = n;
-            mate_list = big_mates.data() + big_at * mcap;
+            const int mb = (int)big.size(), mcap = big_mcap;
+            mate_list = big_mates + big_at * mcap;
             mate_n = big_mates[(size_t)mb * mcap + big_at];
             if (mate_n != r_mcnt[k] || mate_n > mcap) throw HipError{"forest: k-nearest mate list of the second pass is inconsistent (internal error)"};
             ++big_at;
