@@ -2315,7 +2315,13 @@ enum { QI_MAXID = 7, QI_MINE = 8, QI_EVAL = 9, QI_QTREE = 10, QI_TOTAL = 11, QI_
        QI_T0 = 17, QI_WY = 23, QI_PD = 24, QI_QR = 26, QI_FLAGS = 28, QI_NNB = 29, QI_FORCE = 30, QI_LIVE = 31 };
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB_OCC))) void k_query_block(
     GridView g, GridView tg, const SweepQuery* __restrict__ queries, ClassifyArgs A, EnvView env) {
-  constexpr int S = QB_S, HC = QB_HC, CANDCAP = S * 24, W2CAP = S * 40, PAIRCAP = S * 32, SURVCAP = S * 8;
+#ifndef QB_INL
+#define QB_INL 0      // records of a bucket looked at in the cell pass itself; the rest through the second work list
+#endif
+#ifndef QB_W2
+#define QB_W2 64
+#endif
+  constexpr int S = QB_S, HC = QB_HC, CANDCAP = S * 24, W2CAP = S * QB_W2, PAIRCAP = S * 32, SURVCAP = S * 8, INL = QB_INL;
   __shared__ __attribute__((aligned(16))) int s_i[S][32];   // QRec
   __shared__ double s_qp[S][6], s_ex[S][6];
   __shared__ int s_pref[S + 1];
@@ -2491,31 +2497,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB_OCC))) v
       // of the round's own grid)
       GridItem32 i0{}, i1{}, i2{}, t0{};
       const GridItem32* bucket = g.lite + cell * g.bk;
-      if (m > 0) i0 = bucket[0];
-      if (m > 1) i1 = bucket[1];
-      if (m > 2) i2 = bucket[2];
+      if (INL > 0 && m > 0) i0 = bucket[0];
+      if (INL > 1 && m > 1) i1 = bucket[1];
+      if (INL > 2 && m > 2) i2 = bucket[2];
       int mt = 0;
+      constexpr int TINL = INL > 0 ? 1 : 0;
       if (on && ((ow >> (cell & 31)) & 1u)) {
         mt = tg.cnt[cell];
-        t0 = tg.lite[cell * tg.bk];
+        if (TINL) t0 = tg.lite[cell * tg.bk];
         if (mt > tg.bk) mt = tg.bk;
       }
-      const int extra = (m > 3 ? m - 3 : 0) + (mt > 1 ? mt - 1 : 0);
+      const int extra = (m > INL ? m - INL : 0) + (mt > TINL ? mt - TINL : 0);
       if (__any(extra > 0)) {
         int at = wave_reserve_n(&s_cnt[1], extra, lane);
-        for (int k = 3; k < m; ++k, ++at) {
+        for (int k = INL; k < m; ++k, ++at) {
           if (at < W2CAP) { w_s[at] = s; w_at[at] = (int)(cell * g.bk) + k; }
           else s_drop[s] = 1;
         }
-        for (int k = 1; k < mt; ++k, ++at) {
+        for (int k = TINL; k < mt; ++k, ++at) {
           if (at < W2CAP) { w_s[at] = s; w_at[at] = -1 - ((int)(cell * tg.bk) + k); }
           else s_drop[s] = 1;
         }
       }
-      add_cand(m > 0 && passes(s, i0), s, i0);
-      if (__any(m > 1)) add_cand(m > 1 && passes(s, i1), s, i1);
-      if (__any(m > 2)) add_cand(m > 2 && passes(s, i2), s, i2);
-      if (__any(mt > 0)) add_cand(mt > 0 && passes(s, t0), s, t0);
+      if (INL > 0) add_cand(m > 0 && passes(s, i0), s, i0);
+      if (INL > 1 && __any(m > 1)) add_cand(m > 1 && passes(s, i1), s, i1);
+      if (INL > 2 && __any(m > 2)) add_cand(m > 2 && passes(s, i2), s, i2);
+      if (TINL && __any(mt > 0)) add_cand(mt > 0 && passes(s, t0), s, t0);
     }
   }
   __syncthreads();
