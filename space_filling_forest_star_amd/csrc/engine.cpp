@@ -996,10 +996,10 @@ void Ctx::knn(const double* q6, int nq, int k, const int32_t* tree, const int32_
       hq[i].whole_tree = 0;
       hq[i].pad_ = 0;
     }
+    // one result block (distances | indices | counts), so that the answer comes back in ONE copy
+    const size_t o_dist = 0, o_idx = o_dist + (size_t)nq * k * 8, o_cnt = o_idx + (size_t)nq * k * 4, o_end = o_cnt + (size_t)nq * 4;
     d_a.ensure((size_t)nq * sizeof(sffk::KnnQuery));
-    d_b.ensure((size_t)nq * k * 4);
-    d_c.ensure((size_t)nq * k * 8);
-    d_d.ensure((size_t)nq * 4);
+    d_b.ensure(o_end);
     HIPCHK(hipMemcpyAsync(d_a.p, h_a.p, (size_t)nq * sizeof(sffk::KnnQuery), hipMemcpyHostToDevice, stream));
     // with an index over the store (sffgpu_nodes_index) and no per-tree restriction (a tree with fewer than k nodes
     // would make the shells grow over the whole grid) every query is answered from the cells around it
@@ -1008,27 +1008,30 @@ void Ctx::knn(const double* q6, int nq, int k, const int32_t* tree, const int32_
       grid_insert_new();
       grid_check(/*bulk=*/true);
     }
+    char* db = d_b.as<char>();
+    int32_t* r_idx = reinterpret_cast<int32_t*>(db + o_idx);
+    double* r_dist = reinterpret_cast<double*>(db + o_dist);
+    int32_t* r_cnt = reinterpret_cast<int32_t*>(db + o_cnt);
     time_begin(T_SWEEP);
     if (by_grid)
-      sffk::launch_knn_grid(stream, gridv, nullptr, store_view(), d_a.as<sffk::KnnQuery>(), nq, k, d_b.as<int32_t>(),
-                            d_c.as<double>(), d_d.as<int32_t>(), nullptr, nullptr, grid_cell, 8 * sweep_eps(), SFFK_KNN_MATES, store_n);
+      sffk::launch_knn_grid(stream, gridv, nullptr, store_view(), d_a.as<sffk::KnnQuery>(), nq, k, r_idx, r_dist, r_cnt, nullptr, nullptr,
+                            grid_cell, 8 * sweep_eps(), SFFK_KNN_MATES, store_n);
     else
-      sffk::launch_knn_linear(stream, store_view(), store_n, d_a.as<sffk::KnnQuery>(), nq, k, d_b.as<int32_t>(),
-                              d_c.as<double>(), d_d.as<int32_t>(), sweep_eps());
+      sffk::launch_knn_linear(stream, store_view(), store_n, d_a.as<sffk::KnnQuery>(), nq, k, r_idx, r_dist, r_cnt, sweep_eps());
     time_end();
-    h_b.ensure((size_t)nq * k * 4);
-    h_c.ensure((size_t)nq * k * 8);
-    h_d.ensure((size_t)nq * 4);
-    HIPCHK(hipMemcpyAsync(h_b.p, d_b.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost, stream));
-    HIPCHK(hipMemcpyAsync(h_c.p, d_c.p, (size_t)nq * k * 8, hipMemcpyDeviceToHost, stream));
-    HIPCHK(hipMemcpyAsync(h_d.p, d_d.p, (size_t)nq * 4, hipMemcpyDeviceToHost, stream));
+    h_b.ensure(o_end);
+    HIPCHK(hipMemcpyAsync(h_b.p, d_b.p, o_end, hipMemcpyDeviceToHost, stream));
     sync();
+    const char* hb = h_b.as<char>();
+    const int32_t* g_idx = reinterpret_cast<const int32_t*>(hb + o_idx);
+    const double* g_dist = reinterpret_cast<const double*>(hb + o_dist);
+    const int32_t* g_cnt = reinterpret_cast<const int32_t*>(hb + o_cnt);
     for (int i = 0; i < nq; ++i) {
-      const int m = h_d.as<int32_t>()[i];
+      const int m = g_cnt[i];
       cnt[i] = m;
       for (int j = 0; j < m; ++j) {
-        idx[(size_t)i * k + j] = h_b.as<int32_t>()[(size_t)i * k + j];
-        if (dist) dist[(size_t)i * k + j] = h_c.as<double>()[(size_t)i * k + j];
+        idx[(size_t)i * k + j] = g_idx[(size_t)i * k + j];
+        if (dist) dist[(size_t)i * k + j] = g_dist[(size_t)i * k + j];
       }
     }
     return;
