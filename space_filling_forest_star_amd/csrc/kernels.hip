@@ -2570,11 +2570,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB_OCC))) v
   }
   __syncthreads();
   QB_MARK(4);
-  // ---- 4. classification (k_classify's logic), 32 lanes per sample, lane = hit
-  {
-    const int s = tid >> 5, hl = tid & 31, h = (tid >> 5) & 1;
+  // ---- 4. classification (k_classify's logic), lane = hit: 16 lanes per sample when no sample of the workgroup has more
+  // than 16 hits (the usual case: ~5) - two wavefronts do the pass, the other two skip it -, else 32 lanes per sample
+  int gsh = 4;
+  for (int q = 0; q < S; ++q) if (s_nhit[q] > 16) gsh = 5;
+  if (tid < (S << gsh)) {
+    const int gw = 1 << gsh;
+    const int s = tid >> gsh, hl = tid & (gw - 1);
     const int i = i_base + s;
-    auto hballot = [&](bool p) -> uint32_t { return (uint32_t)(__ballot(p) >> (h << 5)); };
+    const int gbase = lane & ~(gw - 1);
+    const uint32_t gmask = gsh == 5 ? 0xffffffffu : 0xffffu;
+    auto hballot = [&](bool p) -> uint32_t { return (uint32_t)(__ballot(p) >> gbase) & gmask; };
     int flags = s_i[s][QI_FLAGS];
     const bool evaluate = s_i[s][QI_EVAL] != 0;
     const int n = s_nhit[s];
@@ -2593,14 +2599,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB_OCC))) v
     uint32_t mm = hballot(q);
     while (__any(mm != 0u)) {
       const bool on = mm != 0u;
-      const int src = (lane & 32) + (on ? __ffs((int)mm) - 1 : 0);
+      const int src = gbase + (on ? __ffs((int)mm) - 1 : 0);
       mm &= mm - 1u;
       const int tj = __shfl(t, src), idj = __shfl(id, src);
       const double dj = __shfl(d, src);
       if (on && (tj < t || (tj == t && (dj < d || (dj == d && idj < id))))) ++rank;
     }
     int cut = (q && !same && id < A.N0) ? rank : 0x7fffffff;
-    for (int off = 16; off > 0; off >>= 1) {
+    for (int off = gw >> 1; off > 0; off >>= 1) {
       const int o = __shfl_xor(cut, off);
       cut = o < cut ? o : cut;
     }

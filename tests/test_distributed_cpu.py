@@ -43,8 +43,13 @@ def _worker(rank, world, port, out_dir):
 
 def test_exchange_records_gloo(tmp_path):
     world = 2
-    port = _free_port()
-    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for attempt in range(3):   # (the port is free when it is picked, not necessarily when the workers bind it)
+        try:
+            mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+            break
+        except Exception as e:
+            if attempt == 2 or "EADDRINUSE" not in str(e):
+                raise
     a = np.load(tmp_path / "r0.npy")
     b = np.load(tmp_path / "r1.npy")
     assert np.array_equal(a, b) and len(a) > 0

@@ -7,6 +7,8 @@ import os
 import socket
 import subprocess
 import sys
+import tempfile
+import time
 
 import numpy as np
 import pytest
@@ -31,15 +33,32 @@ def free_port():
 @pytest.mark.parametrize("name,world,wave,iters,optimize", [("dense3d", 2, 512, 12000, 0), ("triang", 3, 256, 6000, 1),
                                                              ("dense3d", 4, 1024, 40000, 0), ("dense3d", 2, 64, 3000, 0)])
 def test_sharded_forest_across_processes_equals_the_oracle(name, world, wave, iters, optimize):
-    port = free_port()
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
-    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "mp_forest_worker.py"), str(r), str(world),
-                               str(port), name, str(wave), str(iters), "3", str(optimize)],
-                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for r in range(world)]
+    for attempt in range(3):   # (the rendezvous port is free when it is picked, not necessarily seconds later: retry on EADDRINUSE)
+        port = free_port()
+        files = [(tempfile.TemporaryFile("w+"), tempfile.TemporaryFile("w+")) for _ in range(world)]
+        procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "mp_forest_worker.py"), str(r), str(world),
+                                   str(port), name, str(wave), str(iters), "3", str(optimize)],
+                                  stdout=files[r][0], stderr=files[r][1], text=True, env=env) for r in range(world)]
+        # (a rank that dies leaves the others waiting in the rendezvous: end them with it)
+        t_end = time.time() + 600
+        while time.time() < t_end and any(p.poll() is None for p in procs) and not any(p.poll() not in (None, 0) for p in procs):
+            time.sleep(0.2)
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        res = []
+        for r, p in enumerate(procs):
+            p.wait(timeout=60)
+            files[r][0].seek(0); files[r][1].seek(0)
+            res.append((files[r][0].read(), files[r][1].read(), p.returncode))
+            files[r][0].close(); files[r][1].close()
+        if attempt < 2 and any(rc != 0 and "EADDRINUSE" in se for _, se, rc in res):
+            continue
+        break
     outs = []
-    for p in procs:
-        so, se = p.communicate(timeout=600)
-        assert p.returncode == 0, se[-2000:]
+    for so, se, rc in res:
+        assert rc == 0, se[-2000:]
         line = [ln for ln in so.splitlines() if ln.startswith("RESULT ")][-1]
         outs.append(json.loads(line[7:]))
     sc = common.scenario(name)
