@@ -313,9 +313,12 @@ struct WCand {
 };
 }  // namespace
 
+static double g_rrt_sec[8];   // SFFGPU_PROFILE: ms in the sections of run_wave
 int Rrt::run_wave(int B) {
   using namespace sffg;
   Ctx& c = *ctx;
+  auto t_sec = std::chrono::steady_clock::now();
+  auto lap = [&](int k) { const auto t = std::chrono::steady_clock::now(); g_rrt_sec[k] += std::chrono::duration<double, std::milli>(t - t_sec).count(); t_sec = t; };
   if (iter + B > cfg.max_iterations) B = cfg.max_iterations - iter;
   if (B <= 0) return 0;
   const Mt64 snapshot = rng;
@@ -328,6 +331,7 @@ int Rrt::run_wave(int B) {
     draw_target(w[j].rnd);
   }
   const uint64_t draws_end = rng.draws;
+  lap(0);
   // ---- 2. nearest node of the frozen tree (:143), steer (:148)
   {
     std::vector<double> q((size_t)B * 6);
@@ -343,6 +347,7 @@ int Rrt::run_wave(int B) {
       steer(nodes[w[j].nearest].pos, w[j].rnd, cfg.sampling_dist, w[j].np);
     }
   }
+  lap(1);
   // ---- 3. new pose + parent edge (:149-151)
   {
     std::vector<double> p((size_t)B * 6), a((size_t)B * 6);
@@ -358,6 +363,7 @@ int Rrt::run_wave(int B) {
       w[j].par_ns = ns[j];
     }
   }
+  lap(2);
   std::vector<int> alive;
   for (int j = 0; j < B; ++j)
     if (!w[j].pose_hit && w[j].par_free) alive.push_back(j);
@@ -374,6 +380,7 @@ int Rrt::run_wave(int B) {
     st.nn_queries = keep;
     for (int k = 0; k < nA; ++k) w[alive[k]].members = res[k];
   }
+  lap(3);
   // ---- 5. other trees: every node within treeDistance of the new point; per tree the nearest one (:228-231)
   if (nA > 0 && tree_frontier.size() > 1) {
     std::vector<double> q((size_t)nA * 6), rr(nA, cfg.dist_tree);
@@ -407,6 +414,7 @@ int Rrt::run_wave(int B) {
       }
     }
   }
+  lap(4);
   // ---- 6. all remaining edges in one launch: RRT* member edges in both directions (store members and the
   // earlier new points of the same tree that may enter the k-nearest set), links to other trees (store
   // nearest and earlier new points of other trees within treeDistance)
@@ -468,6 +476,7 @@ int Rrt::run_wave(int B) {
     else if (r.kind == 1) { cd.medges[r.idx].free_b = efr[e] != 0; cd.medges[r.idx].fh_b = efh[e]; cd.medges[r.idx].ns_b = ens[e]; }
     else if (r.kind == 2) { cd.conns[r.idx].free = efr[e] != 0; cd.conns[r.idx].fh = efh[e]; cd.conns[r.idx].ns = ens[e]; }
   }
+  lap(5);
   // ---- 7. replay in order; cut the wave at the first iteration the speculation does not cover
   defer_append = true;
   int done = 0;
@@ -568,6 +577,7 @@ int Rrt::run_wave(int B) {
       merged = true;                               // tree ids / frontier changed: later picks are stale
     }
   }
+  lap(6);
   // ---- 8. commit: device store, RNG position
   if (!pend_tree.empty()) {
     c.store_append(pend_pos.data(), pend_tree.data(), (int)pend_tree.size());
@@ -582,6 +592,7 @@ int Rrt::run_wave(int B) {
   } else if (rng.draws != draws_end) {
     throw HipError{"rrt: RNG bookkeeping error"};
   }
+  lap(7);
   st.waves += 1;
   st.speculated += (uint64_t)B;
   st.committed += (uint64_t)done;
@@ -613,6 +624,11 @@ void Rrt::run(int max_iters) {
     if (got == 0 && want > 0 && iter >= cfg.max_iterations) break;
   }
   st.total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  if (getenv("SFFGPU_PROFILE")) {
+    fprintf(stderr, "[sffgpu rrt run_wave ms] draws %.1f | nearest %.1f | pose + parent edge %.1f | k nearest %.1f | other trees %.1f | edge lists + edges %.1f | replay %.1f | append %.1f  (%llu waves)\n",
+            g_rrt_sec[0], g_rrt_sec[1], g_rrt_sec[2], g_rrt_sec[3], g_rrt_sec[4], g_rrt_sec[5], g_rrt_sec[6], g_rrt_sec[7], (unsigned long long)st.waves);
+    for (double& x : g_rrt_sec) x = 0;
+  }
 }
 
 // RapidExpTree::getConnectedTrees (src/rrt.h:381-393) + getPaths (:324-352)
