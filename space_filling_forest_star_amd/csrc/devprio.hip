@@ -1,14 +1,19 @@
 // devprio.hip - the priority-frontier mode of SpaceForest::Solve on the device-resident engine (PrioView, kernels.h).
 //
-//   k_prio_begin  one wavefront: the wave's picks in slot order - tree, heap, "minimum or random entry" - exactly as
-//                 src/forest.h:126-147 draws them (libstdc++ uniform_int = Lemire with rejection, uniform_real), with the
-//                 heap sizes counted down as the slots take their nodes; control block of the wave
-//   k_prio_pops   one workgroup per heap: its slots' pops in slot order (src/heap.h:175-238: pop / pop at index)
+//   k_prio_plan   one workgroup of 1024 threads, everything in LDS: the wave's picks - tree, heap, "minimum or random
+//                 entry" - exactly as src/forest.h:126-147 draws them (libstdc++ uniform_int = Lemire with rejection,
+//                 uniform_real), every slot's start in the engine-word stream found by a scan over per-block functions
+//   k_prio_begin  the same one slot after the other by one wavefront (heap sizes counted down as the slots take their
+//                 nodes): only when the plan is not valid (a draw in the rejection zone, a heap asked for more than it
+//                 holds) or SFFGPU_PRIO_SEQ is set; control block of the wave
+//   k_prio_pops   one workgroup per heap: its slots found by all 256 threads, their pops in slot order on the first
+//                 wavefront (src/heap.h:175-238: pop / pop at index)
 //   k_prio_end    one workgroup per heap, behind the wave's rounds: pushes of the wave's new nodes of the heap's tree in
 //                 creation order (src/forest.h:360-363), then per slot of the tree in slot order: an exhausted slot's node
 //                 leaves the tree's OTHER heaps (:164-173), a slot that expanded its node puts it back onto the heap it
 //                 came from (:178-180); the last heap through says whether every heap is empty (:184-191)
 // The order of operations per heap is the reference's; heaps do not see each other, so one workgroup per heap is exact.
+// A sift is ONE memory round trip (HeapWin / HeapAnc below) and its walk a ballot: see the comments there.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "kernels.h"
