@@ -90,6 +90,7 @@ __device__ void round_begin_scalars(const DevForestView& f, DevCtrl* c) {
 #define WB_BLOCKS 64
 __global__ __launch_bounds__(256) void k_wave_begin(DevForestView f) {
   __shared__ int s_last;
+  __shared__ int s_scan[4];
   DevCtrl* c = f.ctrl;
   const unsigned long long tb0 = f.profile ? wall_clock64() : 0ULL;
   if (c->halt) {
@@ -97,7 +98,8 @@ __global__ __launch_bounds__(256) void k_wave_begin(DevForestView f) {
     return;
   }
   if (c->in_wave) {   // resuming inside a wave (after the host handled a fault): the active list is in place
-    if (blockIdx.x == 0 && threadIdx.x == 0) { c->compact_from = 0; c->app_n = 0; round_begin_scalars(f, c); }
+    // (the slots' sorted positions are not: the query kernel walks the sample indices for the rest of this wave)
+    if (blockIdx.x == 0 && threadIdx.x == 0) { c->compact_from = 0; c->app_n = 0; c->ord_valid = 0; round_begin_scalars(f, c); }
     return;
   }
   // priority-frontier mode: the slots take their nodes from the trees' heaps (k_prio_begin, launched behind this kernel)
@@ -117,7 +119,18 @@ __global__ __launch_bounds__(256) void k_wave_begin(DevForestView f) {
     const unsigned long long wd = f.ring[(cur + (unsigned long long)sl) & f.ring_mask];
     const int pick = lemire_pick(wd, (unsigned long long)pool);
     if (pick < 0) redraw = true;
-    else { f.slot_node[sl] = from[pick]; f.slot_pos[sl] = pick; }
+    else {
+      const int node = from[pick];
+      f.slot_node[sl] = node; f.slot_pos[sl] = pick;
+      if (f.ord.hist) {   // the slot's bucket in the wave's spatial order: the coarse grid cell of its node (OrderView)
+        const int cx = grid_coord(f.ord.x[node], f.ord.ox, f.ord.inv_cell, f.ord.nx) >> f.ord.shift,
+                  cy = grid_coord(f.ord.y[node], f.ord.oy, f.ord.inv_cell, f.ord.ny) >> f.ord.shift,
+                  cz = grid_coord(f.ord.z[node], f.ord.oz, f.ord.inv_cell, f.ord.nz) >> f.ord.shift;
+        const int key = (cz * f.ord.cny + cy) * f.ord.cnx + cx;
+        f.ord.slot_key[sl] = key;
+        f.ord.slot_rank[sl] = atomicAdd(&f.ord.hist[key], 1);
+      }
+    }
     act[sl] = sl;                 // every slot starts the wave failing
   }
   if (redraw) atomicOr(&f.commit_seq[2], 1);
@@ -125,7 +138,39 @@ __global__ __launch_bounds__(256) void k_wave_begin(DevForestView f) {
   __syncthreads();
   if (threadIdx.x == 0) s_last = atomicAdd(&f.commit_seq[1], 1) == (int)gridDim.x - 1;
   __syncthreads();
-  if (!s_last || threadIdx.x != 0) return;
+  if (!s_last) return;
+  if (f.ord.hist) {   // bucket counts -> bucket starts (exclusive scan; the counters are zero again for the next wave)
+    // only the buckets the grid's coarse cells use (1 575 of 4 096 on the bench job); wave-level scans, one trip through LDS
+    constexpr int PERMAX = SFFK_ORD_BUCKETS / 256;
+    const int nb = f.ord.n_buckets, per = (nb + 255) >> 8, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int v[PERMAX], sum = 0;
+#pragma unroll
+    for (int k = 0; k < PERMAX; ++k) {
+      const int at = (int)threadIdx.x * per + k;
+      v[k] = (k < per && at < nb) ? __hip_atomic_load(&f.ord.hist[at], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+      sum += v[k];
+    }
+    int inc = sum;
+    for (int off = 1; off < 64; off <<= 1) {
+      const int o = __shfl_up(inc, off);
+      if (lane >= off) inc += o;
+    }
+    if (lane == 63) s_scan[wv] = inc;
+    __syncthreads();
+    int run = inc - sum;
+    for (int w = 0; w < wv; ++w) run += s_scan[w];
+#pragma unroll
+    for (int k = 0; k < PERMAX; ++k) {
+      const int at = (int)threadIdx.x * per + k;
+      if (k < per && at < nb) {
+        f.ord.start[at] = run;
+        run += v[k];
+        f.ord.hist[at] = 0;
+      }
+    }
+  }
+  if (threadIdx.x != 0) return;
+  c->ord_valid = (f.ord.hist && !__hip_atomic_load(&f.commit_seq[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ? 1 : 0;
   unsigned long long used = (unsigned long long)n_slots;
   if (__hip_atomic_load(&f.commit_seq[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
     // (probability ~ pool / 2^64 per pick) redo the picks one after another, words as they come
@@ -270,6 +315,8 @@ __global__ __launch_bounds__(1024) void k_commit(ResolveArgs A, int n_bound) {
     }
     return;
   }
+  if (b == 0 && f.ord.hist)   // the sub-range lists the append behind this commit fills start empty (OrderView)
+    for (int r = threadIdx.x; r < f.ord.n_sub; r += 1024) (c->act_sel ? f.ord.cnt[0] : f.ord.cnt[1])[r * SFFK_ORD_CNT_STRIDE] = 0;
   if (b * 64 >= n) return;
   const int nwg = (n + 63) >> 6;
   const bool last = b == nwg - 1;
@@ -672,7 +719,11 @@ __global__ __launch_bounds__(1024) void k_commit(ResolveArgs A, int n_bound) {
 // nothing was committed) and the slot itself.
 // part: 0 = everything, 1 = only the accepted sample's node, 2 = only the next round's list (+ the claims of a wave that
 // is over) - k_append_sample runs the two parts in different workgroups.
-__device__ __forceinline__ int append_one(const ResolveArgs& A, int i, int& slot_out, int part = 0) {
+__device__ __forceinline__ void append_ord_store(const ResolveArgs& A, int ord_at, int next) {
+  if (ord_at >= 0) (A.f.ctrl->app_act_sel ? A.f.ord.lst[0] : A.f.ord.lst[1])[ord_at] = next;
+}
+__device__ __forceinline__ int append_one(const ResolveArgs& A, int i, int& slot_out, int& ord_at, int part = 0) {
+  ord_at = -1;
   const DevForestView& f = A.f;
   const DevCtrl* c = f.ctrl;
   const int n = c->app_n;
@@ -685,6 +736,7 @@ __device__ __forceinline__ int append_one(const ResolveArgs& A, int i, int& slot
   // (atomicMin of its place in the list: a node held by several slots moves to the closed list once, at its first slot,
   // src/forest.h:160-178) and parks it for k_wave_end_wide, which would otherwise post the claims itself and meet at a counter first
   const bool wave_over = c->n_act == 0 && !c->halt && c->in_wave && !c->use_closed;
+  const bool ord_on = f.ord.hist && c->ord_valid;
   auto claim = [&](int e, int slot) {
     const int nd = f.slot_node[slot];
     atomicMin(&f.claim[nd], e);
@@ -707,6 +759,12 @@ __device__ __forceinline__ int append_one(const ResolveArgs& A, int i, int& slot
     if (part == 1) return -1;
     slot_out = act_old[i];
     act_new[i - rank] = slot_out;       // not accepted: the slot tries again (rank = accepted samples before it)
+    if (ord_on) {   // its sample's index in the next round joins the list of its sub-range (OrderView): the place is
+      // asked for here, the entry is written by the caller once it has nothing else to wait for (append_ord_store)
+      const int sub = f.ord.slot_pos[slot_out] >> 6;
+      const bool first = c->app_act_sel != 0;   // (the buffer that is NOT the committed round's)
+      ord_at = sub * 64 + atomicAdd(&(first ? f.ord.cnt[0] : f.ord.cnt[1])[sub * SFFK_ORD_CNT_STRIDE], 1);
+    }
     if (wave_over) claim(i - rank, slot_out);
     return i - rank;
   }
@@ -737,8 +795,9 @@ __device__ __forceinline__ int append_one(const ResolveArgs& A, int i, int& slot
   return -1;
 }
 __global__ __launch_bounds__(256) void k_append(ResolveArgs A) {
-  int slot;
-  (void)append_one(A, blockIdx.x * 256 + threadIdx.x, slot);
+  int slot, ord_at;
+  const int next = append_one(A, blockIdx.x * 256 + threadIdx.x, slot, ord_at);
+  append_ord_store(A, ord_at, next);
 }
 // k_append + the NEXT round's k_sample_steer in one launch: a slot that was not accepted draws its next sample right
 // away (its place in the next round's list is its old place minus the accepted samples before it; the round's size,
@@ -752,10 +811,11 @@ __global__ __launch_bounds__(256) void k_append_sample(ResolveArgs A, SampleLaun
   const int nb = gridDim.x >> 1;
   const bool sampler = (int)blockIdx.x >= nb;
   const int tid = ((int)blockIdx.x - (sampler ? nb : 0)) * 256 + threadIdx.x;
-  int slot;
-  if (!sampler) { (void)append_one(A, tid, slot, 1); return; }
-  const int next = append_one(A, tid, slot, 2);
-  sample_steer_one(tid, next, slot, P);
+  int slot, ord_at;
+  if (!sampler) { (void)append_one(A, tid, slot, ord_at, 1); return; }
+  const int next = append_one(A, tid, slot, ord_at, 2);
+  sample_steer_one(tid, next, slot < 0 ? -2 : slot, P);   // (-1 is k_sample_steer's "look the slot up")
+  append_ord_store(A, ord_at, next);
 }
 
 // the control block at the end of a wave: closed list / frontier sizes, termination (src/forest.h:184-201); one thread

@@ -688,12 +688,12 @@ __global__ __launch_bounds__(256) void k_star_pass(ResolveArgs A, EnvView env, N
         const int probe = first + 4 <= ns ? first + 4 : ns;
         const uint32_t* wp = nullptr;
         int sh = 0;
-        if (need && env.clear_bits) {
+        if (need && env.clear_bits_edge) {
           const float td = (float)probe;
           const float fx = __builtin_fmaf(td, ee[4], ee[0]), fy = __builtin_fmaf(td, ee[5], ee[1]), fz = __builtin_fmaf(td, ee[6], ee[2]);
           if (fx >= 0 && fy >= 0 && fz >= 0 && fx < nxd && fy < nyd && fz < nzd) {
             const uint32_t ci = ((uint32_t)(int)fz * (uint32_t)env.clear_n[1] + (uint32_t)(int)fy) * (uint32_t)env.clear_n[0] + (uint32_t)(int)fx;
-            wp = env.clear_bits + (ci >> 5);
+            wp = env.clear_bits_edge + (ci >> 5);
             sh = (int)(ci & 31u);
           } else if (fx == fx && fy == fy && fz == fz) {
             need = false;                                     // beyond the inflated box of the environment

@@ -229,7 +229,7 @@ Ctx::~Ctx() {
   for (auto e : pool) (void)hipEventDestroy(e);
   DevBuf* bufs[] = {&env_tri, &env_box, &env_plane, &rob_tri, &sx, &sy, &sz, &syaw, &spitch, &sroll, &stree, &spos,
                     &d_a, &d_b, &d_c, &d_d, &d_e, &d_f, &d_g, &d_h, &r_in, &r_out, &r_out2, &r_q, &r_cnt, &r_hidx,
-                    &r_hdist, &r_sega, &r_segb, &r_items, &r_items2, &r_center, &r_qrec, &env_clear, &g_cnt, &g_items, &g_ovfcnt, &g_ovf, &t_cnt, &t_items, &t_ovfcnt, &t_ovf, &t_occ, &g_lite, &g_ovf_lite, &t_lite, &t_ovf_lite, &env_tg_start, &env_tg_list, &r_sub, &env_ext};
+                    &r_hdist, &r_sega, &r_segb, &r_items, &r_items2, &r_center, &r_qrec, &env_clear, &env_clear_edge, &env_cand, &g_cnt, &g_items, &g_ovfcnt, &g_ovf, &t_cnt, &t_items, &t_ovfcnt, &t_ovf, &t_occ, &g_lite, &g_ovf_lite, &t_lite, &t_ovf_lite, &env_tg_start, &env_tg_list, &r_sub, &env_ext};
   for (DevBuf* b : bufs) b->release();
   for (auto& b : level_box) b.release();
   PinBuf* pins[] = {&h_a, &h_b, &h_c, &h_d, &h_e, &h_f, &h_g, &h_h, &p_in, &p_out};
@@ -426,6 +426,7 @@ void Ctx::upload_mesh(int role, const double* tri9, int n) {
 // comparison per (sample, triangle) in the exact kernel.
 void Ctx::build_robot_extents() {
   envv.tri_ext = nullptr;
+  envv.cand = nullptr;
   if (!have_env || !have_robot || envv.n_tri <= 0 || h_rob.empty() || h_plane.size() != (size_t)envv.n_tri * 5) return;
   std::vector<double> ext((size_t)envv.n_tri * 2);
   const size_t nv = h_rob.size() / 3;
@@ -443,6 +444,22 @@ void Ctx::build_robot_extents() {
   env_ext.ensure(ext.size() * sizeof(double));
   HIPCHK(hipMemcpy(env_ext.p, ext.data(), ext.size() * sizeof(double), hipMemcpyHostToDevice));
   envv.tri_ext = env_ext.as<double>();
+  // everything the exact kernels stage per candidate triangle, as one record (kernels.h, EnvView::cand)
+  std::vector<double> tb((size_t)envv.n_tri * 6), tt((size_t)envv.n_tri * 9), rec((size_t)envv.n_tri * 22);
+  HIPCHK(hipMemcpy(tb.data(), env_box.p, tb.size() * sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(tt.data(), env_tri.p, tt.size() * sizeof(double), hipMemcpyDeviceToHost));
+  for (int k = 0; k < envv.n_tri; ++k) {
+    double* r = &rec[22 * (size_t)k];
+    memcpy(r, &tb[6 * (size_t)k], 6 * sizeof(double));
+    memcpy(r + 6, &h_plane[5 * (size_t)k], 5 * sizeof(double));
+    memcpy(r + 11, &tt[9 * (size_t)k], 9 * sizeof(double));
+    r[20] = ext[2 * (size_t)k];
+    r[21] = ext[2 * (size_t)k + 1];
+  }
+  env_cand.ensure(rec.size() * sizeof(double));
+  HIPCHK(hipMemcpy(env_cand.p, rec.data(), rec.size() * sizeof(double), hipMemcpyHostToDevice));
+  envv.cand = env_cand.as<double>();
+  if (const char* e = getenv("SFFGPU_NO_CAND")) if (atoi(e)) envv.cand = nullptr;   // (A/B: the four-array gather)
 }
 
 // Clearance bits over the environment box (kernels.h, EnvView): one bit per cell, set when a robot whose
@@ -450,6 +467,7 @@ void Ctx::build_robot_extents() {
 // robot radius but the grid is capped at 2^27 cells (16 MB of bits) and by the build cost.
 void Ctx::build_clearance() {
   envv.clear_bits = nullptr;
+  envv.clear_bits_edge = nullptr;
   clear_cells = 0;
   if (!have_env || !have_robot || envv.n_tri <= 0) return;
   if (const char* e = getenv("SFFGPU_NO_CLEARANCE")) if (atoi(e)) return;
@@ -462,18 +480,23 @@ void Ctx::build_clearance() {
   double cap = 134217728.0;
   if (const char* e = getenv("SFFGPU_CLEAR_CELLS")) cap = std::max(512.0, atof(e));
   cap = std::min(cap, std::max(32768.0, 4e10 / (double)std::max(1, envv.level_count[0])));
-  double h = std::max(rr * 0.5, vol_ext * 1e-4);
+  double hdiv = 2.0;
+  if (const char* e = getenv("SFFGPU_CLEAR_HDIV")) hdiv = std::max(0.5, atof(e));
+  double h = std::max(rr / hdiv, vol_ext * 1e-4);
   int n[3];
-  double thr = 0;
+  double thr = 0, lin_slack = 0;
+  const double reach = 0.4 * (1 + 1e-6);
   for (int it = 0; it < 64; ++it) {
     const double halfdiag = 0.5 * std::sqrt(3.0) * h;
     const double m0 = rr + halfdiag;
-    thr = rr * (1 + 1e-9) + halfdiag * (1 + 1e-5) + 1e-8 * (3 * (env_maxabs + 2 * m0) + 1);
+    // additive slack of every test about a cell centre: rounding of the centre / the sample, and (below) the fp32 placement
+    lin_slack = 1e-8 * (3 * (env_maxabs + 2 * m0) + 1);
+    thr = rr * (1 + 1e-9) + halfdiag * (1 + 1e-5) + lin_slack;
     double cells = 1, nmax = 1;
     for (int pass = 0; pass < 2; ++pass) {
       cells = 1;
       for (int a = 0; a < 3; ++a) {
-        double c = std::ceil((ext[a] + 2 * thr) / h) + 1;
+        double c = std::ceil((ext[a] + 2 * (thr + reach)) / h) + 1;
         n[a] = (int)std::min(c, 1e9);
         cells *= c;
         nmax = std::max(nmax, c);
@@ -481,22 +504,51 @@ void Ctx::build_clearance() {
       // the neighbour-query kernel places edge samples in fp32 cell units (k_query_classify): three roundings of
       // at most 2^-24 * cells-per-axis each; the bits cover 1e-6 * cells-per-axis cells of misplacement
       // ... and tests ONE sample for a group of eight consecutive ones: they lie within four sample spacings
-      // (4 x 0.1 scaled units, src/problemStruct.h:121) of it, so the bits hold that reach on top
-      if (pass == 0) thr += 1e-6 * (nmax + 2) * h + 0.4 * (1 + 1e-6);
+      // (4 x 0.1 scaled units, src/problemStruct.h:121) of it, so the EDGE plane holds that reach on top
+      if (pass == 0) { const double fp32 = 1e-6 * (nmax + 2) * h; thr += fp32; lin_slack += fp32; }
     }
     if (cells <= cap) break;
     h *= std::max(1.02, std::cbrt(cells / cap));
   }
   const long long cells = (long long)n[0] * n[1] * n[2];
   if (cells <= 0 || cells > (1LL << 31)) return;
-  for (int a = 0; a < 3; ++a) { envv.clear_org[a] = env_lo[a] - thr; envv.clear_n[a] = n[a]; }
+  // (the grid spans the environment's box inflated by the larger of the two sphere radii: outside it everything is clear)
+  for (int a = 0; a < 3; ++a) { envv.clear_org[a] = env_lo[a] - (thr + reach); envv.clear_n[a] = n[a]; }
   envv.clear_inv = 1.0 / h;
+  sffk::ClearBuildArgs P{};
+  P.thr_pose = thr;
+  P.thr_edge = thr + reach;
+  const double cell_half = 0.5 * h * (1 + 1e-5) + lin_slack;
+  for (int a = 0; a < 3; ++a) {
+    // pose plane: the robot in any rotation stays inside the cube of the bounding radius about its model origin
+    P.pose_lo[a] = -(cell_half + rr * (1 + 1e-9));
+    P.pose_hi[a] = cell_half + rr * (1 + 1e-9);
+    // edge plane: the un-rotated robot's own box about the model origin, + the reach of a group of eight samples
+    P.edge_lo[a] = -(cell_half + reach) + std::min(0.0, robv.lo[a]) * (1 + 1e-9);
+    P.edge_hi[a] = cell_half + reach + std::max(0.0, robv.hi[a]) * (1 + 1e-9);
+  }
   const long long padded = (cells + 255) / 256 * 256;
   env_clear.ensure((size_t)(padded / 8));
-  sffk::launch_clear_build(stream, envv, thr, env_clear.as<uint32_t>(), cells);
+  env_clear_edge.ensure((size_t)(padded / 8));
+  const auto t_build = std::chrono::steady_clock::now();
+  sffk::launch_clear_build(stream, envv, P, env_clear.as<uint32_t>(), env_clear_edge.as<uint32_t>(), cells);
   HIPCHK(hipStreamSynchronize(stream));
+  if (getenv("SFFGPU_PROFILE"))
+    fprintf(stderr, "[sffgpu clearance bits] both planes built in %.2f ms\n",
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build).count());
   envv.clear_bits = env_clear.as<uint32_t>();
+  envv.clear_bits_edge = env_clear_edge.as<uint32_t>();
   clear_cells = cells;
+  if (getenv("SFFGPU_PROFILE")) {   // share of blocked cells per plane
+    std::vector<uint32_t> w((size_t)(padded / 32));
+    long long blocked[2] = {0, 0};
+    for (int pl = 0; pl < 2; ++pl) {
+      HIPCHK(hipMemcpy(w.data(), pl ? env_clear_edge.p : env_clear.p, w.size() * 4, hipMemcpyDeviceToHost));
+      for (long long k = 0; k < cells; ++k) blocked[pl] += !((w[(size_t)(k >> 5)] >> (k & 31)) & 1u);
+    }
+    fprintf(stderr, "[sffgpu clearance bits] %lld cells of edge %.3f (%d x %d x %d), blocked: pose plane %.2f %%, edge plane %.2f %%\n", cells, h,
+            n[0], n[1], n[2], 100.0 * (double)blocked[0] / (double)cells, 100.0 * (double)blocked[1] / (double)cells);
+  }
 }
 
 // Triangle grid over the environment's box (kernels.h, EnvView): cell edge = a third of the largest query box the

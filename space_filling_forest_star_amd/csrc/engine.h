@@ -78,7 +78,7 @@ struct Ctx {
   std::string err;
 
   // collision models
-  DevBuf env_tri, env_box, env_plane, level_box[SFFK_MAX_LEVELS], rob_tri, env_clear, env_ext;
+  DevBuf env_tri, env_box, env_plane, level_box[SFFK_MAX_LEVELS], rob_tri, env_clear, env_clear_edge, env_ext, env_cand;
   std::vector<double> h_plane, h_rob;   // host copies (robot extents along the triangle normals)
   void build_robot_extents();
   // RCCL communicator of the library's own (multi-GPU device engine; librccl is bound at run time)
@@ -252,6 +252,8 @@ struct DevEngine {
   bool host_stale = false;// ... and is ahead of the host mirror
   bool table_dirty = false, ring_pending = false;
   DevBuf frontier2, rm_words, rm_pref, slot_pos, act_slot2, w_acc, acc_pref, ustate32, wg_pub, commit_seq, kc_trace;
+  DevBuf ord_hist, ord_start, ord_key, ord_rank, ord_pos, ord_lst, ord_cnt;
+  bool ord_enabled = true;   // spatial order of a wave's slots (sffk::OrderView)
   DevBuf ctrl, parent, d_root, d_closest, iter, nflag, frontier, closed, claim, slot_node, slot_fail, act_slot, b_n1,
       b_n2, b_ta, b_tb, b_dist, bt_key, bt_val, pair, ring, ulist, d_parent, d_parent2, d_force, fault_pending;
   // priority-frontier mode on the device (devprio.hip; PrioView in kernels.h)

@@ -276,6 +276,28 @@ sffk::DevForestView Forest::dev_view() const {
   v.wg_pub = d.wg_pub.as<unsigned long long>();
   v.commit_seq = d.commit_seq.as<int32_t>();
   v.goal_id = cfg.has_goal ? goal_node : -1;
+  {
+    // spatial order of the wave's slots (sffk::OrderView): plain frontier picks only - in priority mode the slots' nodes
+    // come from k_prio_begin - and only with the node grid in place; SFFGPU_NO_ORDER=1 switches it off
+    const sffk::GridView& g = ctx->gridv;
+    if (d.ord_enabled && !use_priority() && d.ord_hist.p && g.cnt && g.nx > 0 && cfg.wave > 1) {
+      sffk::OrderView& o = v.ord;
+      o.hist = d.ord_hist.as<int32_t>(); o.start = d.ord_start.as<int32_t>();
+      o.slot_key = d.ord_key.as<int32_t>(); o.slot_rank = d.ord_rank.as<int32_t>();
+      o.slot_pos = d.ord_pos.as<int32_t>();
+      o.n_sub = (cfg.wave + 63) / 64;
+      o.lst[0] = d.ord_lst.as<int32_t>(); o.lst[1] = o.lst[0] + (size_t)o.n_sub * 64;
+      o.cnt[0] = d.ord_cnt.as<int32_t>(); o.cnt[1] = o.cnt[0] + (size_t)o.n_sub * SFFK_ORD_CNT_STRIDE;
+      o.x = ctx->sx.as<float>(); o.y = ctx->sy.as<float>(); o.z = ctx->sz.as<float>();
+      o.ox = g.ox; o.oy = g.oy; o.oz = g.oz; o.inv_cell = g.inv_cell;
+      o.nx = g.nx; o.ny = g.ny; o.nz = g.nz;
+      int sh = 0;
+      auto coarse = [&](int n) { return ((n - 1) >> sh) + 1; };
+      while ((long long)coarse(g.nx) * coarse(g.ny) * coarse(g.nz) > SFFK_ORD_BUCKETS) ++sh;
+      o.shift = sh; o.cnx = coarse(g.nx); o.cny = coarse(g.ny);
+      o.n_buckets = coarse(g.nx) * coarse(g.ny) * coarse(g.nz);
+    }
+  }
   if (use_priority() && d.prio_heaps) {
     v.prio.n_heaps = d.prio_heaps; v.prio.cap = d.prio_cap;
     v.prio.base = d.hp_base.as<int32_t>(); v.prio.size = d.hp_size.as<int32_t>(); v.prio.v = d.hp_v.as<int32_t>();
@@ -466,6 +488,18 @@ void Forest::dev_upload_state() {
     d.ustate32.ensure(((size_t)wave + 64) * 4);
     d.wg_pub.ensure(((size_t)wave / 64 + 2) * SFFK_PUB_WORDS * 8);
     d.commit_seq.ensure(64);
+    d.ord_hist.ensure((size_t)SFFK_ORD_BUCKETS * 4);
+    d.ord_start.ensure((size_t)SFFK_ORD_BUCKETS * 4);
+    d.ord_key.ensure((size_t)wave * 4);
+    d.ord_rank.ensure((size_t)wave * 4);
+    d.ord_pos.ensure((size_t)wave * 4);
+    {
+      const size_t n_sub = ((size_t)wave + 63) / 64;
+      d.ord_lst.ensure(2 * n_sub * 64 * 4);
+      d.ord_cnt.ensure(2 * n_sub * SFFK_ORD_CNT_STRIDE * 4);
+      HIPCHK(hipMemsetAsync(d.ord_cnt.p, 0, 2 * n_sub * SFFK_ORD_CNT_STRIDE * 4, c.stream));
+    }
+    HIPCHK(hipMemsetAsync(d.ord_hist.p, 0, (size_t)SFFK_ORD_BUCKETS * 4, c.stream));
     if (getenv("SFFGPU_KC_TRACE")) {
       d.kc_trace.ensure(((size_t)wave / 64 + 2) * 64);
       HIPCHK(hipMemsetAsync(d.kc_trace.p, 0, ((size_t)wave / 64 + 2) * 64, c.stream));
@@ -896,6 +930,7 @@ static sffk::SampleLaunch dev_sample_launch(Forest& F, const DevRoundBufs& B) {
   P.dv.parent_out = (d.round_parity ? d.d_parent2 : d.d_parent).as<int32_t>();
   P.dv.force_out = d.d_force.as<uint8_t>();
   P.dv.qclk = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(d.ctrl.p) + offsetof(sffk::DevCtrl, q_t0));
+  P.dv.ord = V.ord;
   P.node_pos = c.spos.as<double>();
   P.n = B.n;
   P.dist = F.cfg.sampling_dist;
@@ -960,6 +995,12 @@ void Forest::dev_enqueue_round_eval(void* send_dev, bool sample) {
   ca.ctrl = B.d_rctrl;
   ca.dev_n = dev_n;
   ca.qclk = qclk;
+  if (V.ord.hist) {
+    ca.ord_valid = reinterpret_cast<const int32_t*>(reinterpret_cast<char*>(d.ctrl.p) + offsetof(sffk::DevCtrl, ord_valid));
+    ca.ord_nslots = reinterpret_cast<const int32_t*>(reinterpret_cast<char*>(d.ctrl.p) + offsetof(sffk::DevCtrl, n_slots));
+    ca.ord_sel = reinterpret_cast<const int32_t*>(reinterpret_cast<char*>(d.ctrl.p) + offsetof(sffk::DevCtrl, act_sel));
+    for (int q = 0; q < 2; ++q) { ca.ord_lst[q] = V.ord.lst[q]; ca.ord_cnt[q] = V.ord.cnt[q]; }
+  }
   c.time_begin(T_SWEEP);
   ca.items = c.r_items.p;
   ca.items_cap = B.list_cap;
@@ -1523,8 +1564,10 @@ void Forest::run_device(int max_waves) {
             "candidates %.1f | us: setup %.2f hierarchy %.2f narrow %.2f | per wave total %.1f us over %llu waves\n",
             g[0], g[1], g[2], g[3] / items, g[7] / items, g[4] / items / 100.0, g[5] / items / 100.0, g[6] / items / 100.0,
             (double)g[8] / (double)std::max<unsigned long long>(1ULL, g[9]) / 100.0, g[9]);
-    fprintf(stderr, "[sffgpu exact kernel, chunk time histogram] <10us %llu <20 %llu <40 %llu <80 %llu >=80 %llu | candidates per chunk of "
-            "the >=40us ones %.1f\n", g[10], g[11], g[12], g[13], g[14], (double)g[15] / (double)std::max<unsigned long long>(1ULL, g[13] + g[14]));
+    fprintf(stderr, "[sffgpu exact kernel, narrow phase per chunk with candidates] us: staging %.2f culls %.2f exact steps %.2f (the rest: pair formation) | "
+            "touching (sample, candidate) pairs %.2f\n", g[10] / 100.0 / (double)std::max<unsigned long long>(1ULL, g[2]),
+            g[11] / 100.0 / (double)std::max<unsigned long long>(1ULL, g[2]), g[13] / 100.0 / (double)std::max<unsigned long long>(1ULL, g[2]),
+            (double)g[14] / (double)std::max<unsigned long long>(1ULL, g[2]));
     unsigned long long q[16];
     sffk::debug_counters_query(q);
     const double qw = (double)std::max<unsigned long long>(1ULL, q[0]);

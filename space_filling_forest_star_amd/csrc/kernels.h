@@ -97,6 +97,8 @@ struct EnvView {
   const double* tri_box;  // n_tri x 6 (lo xyz, hi xyz), exact
   const double* tri_plane; // n_tri x 5: unnormalised normal, offset n.p1, |n|
   const double* tri_ext;   // n_tri x 2 or null: extent of the un-rotated robot's vertices along that normal (min, max of n.v)
+  const double* cand;      // n_tri x 22 or null: {box 6, plane 5, vertices 9, ext 2} of a triangle in one 176-byte record - what the exact
+                           // kernels stage per candidate triangle (round 5: one coalesced pass instead of 22 gathers from four arrays)
   int n_tri;
   int n_levels;           // level 0 groups 64 triangles, level k groups 64 boxes of level k-1
   const double* level_box[SFFK_MAX_LEVELS];
@@ -105,6 +107,10 @@ struct EnvView {
   // every triangle than the radius of the sphere around the robot's model origin that holds the robot in any
   // rotation (plus slack), so a robot posed there cannot touch the environment.  The grid spans the environment box inflated by clear_thr; null = not built.
   const uint32_t* clear_bits;
+  // second plane over the same cells (round 5): the same statement for a robot that is NOT rotated - what every sample of
+  // an edge check is (src/problemStruct.h:157-165) - with the robot's own box instead of its bounding sphere, and the reach
+  // of a group of eight consecutive edge samples on top (the cull tests one sample for the group)
+  const uint32_t* clear_bits_edge;
   double clear_org[3];
   double clear_inv;       // 1 / cell edge
   int clear_n[3];
@@ -119,8 +125,17 @@ struct EnvView {
 };
 // triangle grid build: per cell the number of triangles touching it (cnt), then - after the host's prefix sum - their ids
 void launch_tgrid_build(hipStream_t s, const EnvView& env, int32_t* cnt_or_start, int32_t* list, bool fill);
-// thr = radius below which a cell centre blocks the cell (robot radius + half cell diagonal + slack)
-void launch_clear_build(hipStream_t s, const EnvView& env, double thr, uint32_t* bits, long long n_cells);
+// clearance bits, two planes (kernels.hip k_clear_scatter).  thr_* = distance from the cell centre below which a triangle can
+// block the cell (robot radius + half the cell diagonal + slack; the edge plane adds the reach of a group of eight samples);
+// *_lo / *_hi = the box around the cell centre, relative to it, that holds the robot placed anywhere in the cell (pose
+// plane: cube of the bounding radius; edge plane: the un-rotated robot's own box + the group's reach)
+struct ClearBuildArgs {
+  double thr_pose, thr_edge;
+  double pose_lo[3], pose_hi[3];
+  double edge_lo[3], edge_hi[3];
+};
+void launch_clear_build(hipStream_t s, const EnvView& env, const ClearBuildArgs& P, uint32_t* bits_pose, uint32_t* bits_edge,
+                        long long n_cells);
 
 struct RobotView {
   const double* tri;  // n_tri x 9, model frame
@@ -174,6 +189,8 @@ struct DevCtrl {
   // SFF* on the device (devstar.hip): rounds whose choose-parent / rewire step ran here, the fixed-point passes they
   // took, the k-nearest members they looked at, the rewires they applied (folded in from StarView::acc by k_wave_end)
   unsigned long long star_rounds, star_passes, star_members, star_rewires;
+  // spatial order of the wave's slots (OrderView): 1 = the wave's slots have sorted positions and ord.pos_i is maintained
+  int32_t ord_valid, ord_pad;
 };
 #define SFFK_DEV_MAX_GROUPS 1024   // single-workgroup list kernels: 64 x this many slots per wave at most
 #define SFFK_FAULT_LISTS 1        // a hit / neighbour / triangle-candidate list overflowed: redo the round on the host
@@ -181,7 +198,35 @@ struct DevCtrl {
 #define SFFK_FAULT_CAPACITY 4     // node / frontier / border arrays would overflow: the host grows them
 #define SFFK_FAULT_PRIO_REDRAW 8   // priority mode: a random-entry draw fell into Lemire's rejection zone (p ~ heap size / 2^64)
 
-// indirections of the round kernels in device mode (ctrl == nullptr: host mode, everything comes as arguments)
+// Spatial order of a wave's slots (round 5).  A slot's five samples all lie within one sampling distance of its node, and
+// the slots are frontier picks in random spatial order - the query kernel's workgroups (8 samples each) and the 8 XCDs'
+// L2s therefore shared nothing: 37 missed 128-byte lines per sample.  k_wave_begin counts the slots per COARSE grid cell
+// of their node (hist), its last workgroup turns the counts into bucket starts, the wave's first sampling launch gives
+// every slot its sorted position (slot_pos).  The positions are cut into sub-ranges of 64; per sub-range a list of the
+// sample indices of its still-failing slots in the CURRENT round (two buffers, named like the active-slot lists by
+// DevCtrl::act_sel: the wave's first sampling launch fills the first one position by position, k_append(_sample) appends a
+// slot that tries again to the other buffer's list of its sub-range - one atomic per slot, spread over hundreds of
+// counters on lines of their own; k_commit empties the buffer the append is about to fill).  The query kernel takes its
+// samples from these lists, 8 per workgroup, every XCD one contiguous run of sub-ranges; records, commit order and
+// everything else stay keyed by the sample index.  Measured on the bench job: FETCH_SIZE of the query kernel 22.3 ->
+// 11.9 MB per launch, L2 misses 384 k -> 236 k.
+#define SFFK_ORD_BUCKETS 4096
+#define SFFK_ORD_CNT_STRIDE 32    // ints between two sub-range counters (128-byte lines of their own)
+struct OrderView {
+  int32_t* hist;        // SFFK_ORD_BUCKETS counters, zero between waves; null = off
+  int32_t* start;       // SFFK_ORD_BUCKETS bucket starts of the current wave
+  int32_t* slot_key;    // per slot: bucket
+  int32_t* slot_rank;   // per slot: arrival rank within its bucket
+  int32_t* slot_pos;    // per slot: sorted position
+  int32_t* lst[2];      // per buffer: 64 entries per sub-range - sample indices of the current round (-1 = none)
+  int32_t* cnt[2];      // per buffer: entries of every sub-range's list (SFFK_ORD_CNT_STRIDE ints apart)
+  int32_t n_sub;        // sub-ranges the buffers hold (ceil(wave / 64))
+  const float* x; const float* y; const float* z;   // store columns
+  float ox, oy, oz, inv_cell;                        // the node grid's cells
+  int32_t nx, ny, nz, shift, cnx, cny;              // coarse cell = cell >> shift; cnx x cny x .. coarse cells
+  int32_t n_buckets;                                 // coarse cells = buckets in use (<= SFFK_ORD_BUCKETS)
+};
+
 struct DevRound {
   const DevCtrl* ctrl;
   const int32_t* act_slot;     // n_act slot indices (ascending): list 0 / list 1, DevCtrl::act_sel names the current one
@@ -197,6 +242,7 @@ struct DevRound {
   int32_t* parent_out;         // n: expanded node of every sample (read by k_classify)
   uint8_t* force_out;          // n: its ForceChildren flag
   unsigned long long* qclk;    // DevCtrl::q_t0 / q_t1, reset here for the query kernel that follows
+  OrderView ord;               // the wave's first sampling launch gives the slots their sorted positions (hist == null: off)
 };
 
 // forest rounds only: where k_sample_steer writes the round's temporary store entries and which per-round
@@ -313,6 +359,10 @@ struct ClassifyArgs {
   int items_cap;            // sub-list b % SFFK_SUBLISTS): one counter would see every append of the round, and
   int32_t* sub;             // returning atomics on ONE word saturate near 90 per microsecond chip-wide
   uint8_t* pose_hit;        // n: preset to 0 here, 1 written by the exact kernel
+  // device engine: k_query_block takes its samples from the sub-range lists of the wave's spatial order (OrderView) when
+  // *ord_valid; ord_nslots = the wave's slots, *ord_sel = the current buffer (DevCtrl::act_sel)
+  const int32_t* ord_valid; const int32_t* ord_nslots; const int32_t* ord_sel;
+  const int32_t* ord_lst[2]; const int32_t* ord_cnt[2];
 };
 #define SFFK_SUBLISTS 64
 #define SFFK_SUB_STRIDE 64   // ints between two sub-list counters (their own cache lines)
@@ -417,6 +467,7 @@ struct PrioView {
 struct DevForestView {
   DevCtrl* ctrl;
   PrioView prio;
+  OrderView ord;
   // node records beside the store columns (store_view / NodeStoreMut)
   int32_t* parent; double* d_root; double* d_closest; uint32_t* iter; uint8_t* nflag;
   int32_t* frontier; int32_t* frontier2;                   // two buffers: compaction sifts from one into the other

@@ -681,6 +681,18 @@ struct WaveStack {
 #define STAGE_DOUBLES (STAGE_N * STAGE_TRI)
 #define TG_HASH 512   // per-wave LDS hash set: a triangle listed by several cells of a query enters the candidates once
 __device__ __forceinline__ void stage_candidates(const EnvView& env, const int32_t* cand, int k0, int kc, int lane, double* stage) {
+  if (env.cand) {
+    // packed records: lane = one 16-byte unit of one candidate's record, consecutive lanes read consecutive units
+    const int units = kc * (STAGE_TRI / 2);
+    for (int u = lane; u < units; u += 64) {
+      const int k = u / (STAGE_TRI / 2), part = u - k * (STAGE_TRI / 2);
+      const double2 v = reinterpret_cast<const double2*>(env.cand + (size_t)STAGE_TRI * (size_t)cand[k0 + k])[part];
+      stage[k * STAGE_TRI + 2 * part] = v.x;
+      stage[k * STAGE_TRI + 2 * part + 1] = v.y;
+    }
+    __builtin_amdgcn_wave_barrier();
+    return;
+  }
   if (lane < kc) {
     const int t = cand[k0 + lane];
     double* o = stage + lane * STAGE_TRI;
@@ -970,43 +982,104 @@ __device__ __forceinline__ bool surely_clear(const EnvView& env, const double* c
   const long long idx = ((long long)(int)fz * env.clear_n[1] + (int)fy) * env.clear_n[0] + (int)fx;
   return (env.clear_bits[idx >> 5] >> (idx & 31)) & 1u;
 }
-
-__device__ __forceinline__ double box_dist2(const double* b, const double* c) {
-  double d2 = 0;
-  for (int a = 0; a < 3; ++a) {
-    double d = b[a] - c[a] > c[a] - b[3 + a] ? b[a] - c[a] : c[a] - b[3 + a];
-    d = d > 0 ? d : 0;
-    d2 += d * d;
-  }
-  return d2;
+// the same for an UN-ROTATED robot (edge samples, src/problemStruct.h:157-165): the edge plane of the bits
+__device__ __forceinline__ bool surely_clear_edge(const EnvView& env, const double* c) {
+  if (!env.clear_bits_edge) return false;
+  const double fx = (c[0] - env.clear_org[0]) * env.clear_inv, fy = (c[1] - env.clear_org[1]) * env.clear_inv,
+               fz = (c[2] - env.clear_org[2]) * env.clear_inv;
+  if (!(fx == fx && fy == fy && fz == fz)) return false;
+  if (fx < 0 || fy < 0 || fz < 0 || fx >= env.clear_n[0] || fy >= env.clear_n[1] || fz >= env.clear_n[2]) return true;
+  const long long idx = ((long long)(int)fz * env.clear_n[1] + (int)fy) * env.clear_n[0] + (int)fx;
+  return (env.clear_bits_edge[idx >> 5] >> (idx & 31)) & 1u;
 }
 
-// one thread per cell: blocked as soon as one triangle comes within thr of the cell centre (group boxes
-// first, then the triangle boxes of a near group, then the conservative sphere / triangle test)
-__global__ __launch_bounds__(256) void k_clear_build(EnvView env, double thr, uint32_t* __restrict__ bits,
-                                                     long long n_cells) {
-  const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-  const int nx = env.clear_n[0], ny = env.clear_n[1];
-  const double h = 1.0 / env.clear_inv;
-  const long long iz = idx / ((long long)nx * ny), rem = idx - iz * (long long)nx * ny;
-  const long long iy = rem / nx, ix = rem - iy * nx;
-  const double c[3] = {env.clear_org[0] + ((double)ix + 0.5) * h, env.clear_org[1] + ((double)iy + 0.5) * h,
-                       env.clear_org[2] + ((double)iz + 0.5) * h};
-  const double lim2 = thr * thr * (1.0 + 1e-9);
-  bool blocked = idx >= n_cells;
-  const int n_groups = env.level_count[0];
-  for (int g = 0; g < n_groups && !blocked; ++g) {
-    if (box_dist2(env.level_box[0] + 6 * (size_t)g, c) > lim2) continue;
-    const int t1 = g * 64 + 64 < env.n_tri ? g * 64 + 64 : env.n_tri;
-    for (int t = g * 64; t < t1 && !blocked; ++t) {
-      if (box_dist2(env.tri_box + 6 * (size_t)t, c) > lim2) continue;
-      if (!tri_far(env.tri + 9 * (size_t)t, c, thr)) blocked = true;
-    }
+// Conservative triangle / axis-aligned box test (box = centre c + [blo, bhi], blo <= 0 <= bhi per axis): false only when a
+// separating axis exists by more than the rounding noise (box axes, the triangle's normal, the nine edge x axis
+// directions); NaNs compare false, so garbage never separates.
+__device__ __forceinline__ bool tri_box_maybe(const double* T, const double* c, const double* blo, const double* bhi) {
+  double bc[3], bh[3], v[3][3];
+  for (int a = 0; a < 3; ++a) {
+    bc[a] = c[a] + 0.5 * (blo[a] + bhi[a]);
+    bh[a] = 0.5 * (bhi[a] - blo[a]);
+    bh[a] += 1e-9 * (fabs(bc[a]) + bh[a] + 1.0);
   }
-  const unsigned long long m = __ballot(!blocked);
-  if ((threadIdx.x & 63) == 0) {
-    bits[idx >> 5] = (uint32_t)m;
-    bits[(idx >> 5) + 1] = (uint32_t)(m >> 32);
+  for (int k = 0; k < 3; ++k)
+    for (int a = 0; a < 3; ++a) v[k][a] = T[3 * k + a] - bc[a];
+  for (int a = 0; a < 3; ++a) {
+    const double lo = min3(v[0][a], v[1][a], v[2][a]), hi = max3(v[0][a], v[1][a], v[2][a]);
+    if (lo > bh[a] || hi < -bh[a]) return false;
+  }
+  const double e[3][3] = {{v[1][0] - v[0][0], v[1][1] - v[0][1], v[1][2] - v[0][2]},
+                          {v[2][0] - v[1][0], v[2][1] - v[1][1], v[2][2] - v[1][2]},
+                          {v[0][0] - v[2][0], v[0][1] - v[2][1], v[0][2] - v[2][2]}};
+  double vmax[3];
+  for (int a = 0; a < 3; ++a) vmax[a] = max3(fabs(v[0][a]), fabs(v[1][a]), fabs(v[2][a]));
+  auto separated = [&](const double* ax) -> bool {
+    const double p0 = dot(ax, v[0]), p1 = dot(ax, v[1]), p2 = dot(ax, v[2]);
+    const double aa[3] = {fabs(ax[0]), fabs(ax[1]), fabs(ax[2])};
+    const double r = aa[0] * bh[0] + aa[1] * bh[1] + aa[2] * bh[2];
+    const double slack = 1e-9 * (aa[0] * (vmax[0] + bh[0]) + aa[1] * (vmax[1] + bh[1]) + aa[2] * (vmax[2] + bh[2]));
+    return min3(p0, p1, p2) > r + slack || max3(p0, p1, p2) < -(r + slack);
+  };
+  double n[3];
+  cross(e[0], e[1], n);
+  if (separated(n)) return false;
+  for (int k = 0; k < 3; ++k) {
+    const double a0[3] = {0.0, -e[k][2], e[k][1]}, a1[3] = {e[k][2], 0.0, -e[k][0]}, a2[3] = {-e[k][1], e[k][0], 0.0};
+    if (separated(a0) || separated(a1) || separated(a2)) return false;
+  }
+  return true;
+}
+
+// Clearance bits by scatter from the triangles (round 5; the gather - every cell over every triangle group - took 57 ms
+// for dense_3D's 134 M cells): one workgroup per triangle walks the cells whose centre lies within the sphere radius of the
+// triangle's box, a thread takes one 32-cell word of one row, tests its cells and clears the blocked ones with one
+// atomicAnd per plane.  TWO planes over the same cells:
+//   pose plane  a robot whose model origin lies in the cell cannot touch the triangle in ANY rotation: the triangle is
+//               farther from the cell centre than the bounding-sphere radius + half the cell diagonal (the old test), OR it
+//               misses the cube of that radius around the cell (a cell is a box, not a ball: the sphere over-covers its faces);
+//   edge plane  the same for the UN-ROTATED robot (edge samples carry no rotation, src/problemStruct.h:157-165): the
+//               triangle misses cell + [robot box], inflated by the reach of a group of eight samples.
+// A cell stays clear in a plane unless some triangle fails BOTH tests of that plane.
+__global__ __launch_bounds__(256) void k_clear_scatter(EnvView env, ClearBuildArgs P, uint32_t* __restrict__ bits_pose,
+                                                       uint32_t* __restrict__ bits_edge) {
+  const int t = blockIdx.x;
+  const double* T = env.tri + 9 * (size_t)t;
+  const double* tb = env.tri_box + 6 * (size_t)t;
+  const double h = 1.0 / env.clear_inv;
+  const double reach = P.thr_edge > P.thr_pose ? P.thr_edge : P.thr_pose;
+  int i0[3], i1[3];
+  for (int a = 0; a < 3; ++a) {
+    const double lo = (tb[a] - reach - env.clear_org[a]) * env.clear_inv - 0.5, hi = (tb[3 + a] + reach - env.clear_org[a]) * env.clear_inv - 0.5;
+    if (!(lo == lo) || !(hi == hi)) { i0[a] = 0; i1[a] = env.clear_n[a] - 1; continue; }
+    i0[a] = lo < 1.0 ? 0 : (lo >= (double)env.clear_n[a] ? env.clear_n[a] : (int)lo - 1);
+    i1[a] = hi < -1.0 ? -1 : (hi + 1.0 >= (double)env.clear_n[a] ? env.clear_n[a] - 1 : (int)hi + 1);
+    if (i1[a] < i0[a]) return;
+  }
+  const int nyr = i1[1] - i0[1] + 1;
+  const long long rows = (long long)nyr * (i1[2] - i0[2] + 1);
+  const int nwmax = ((i1[0] - i0[0]) >> 5) + 2;
+  const long long tasks = rows * nwmax;
+  for (long long task = threadIdx.x; task < tasks; task += 256) {
+    const long long row = task / nwmax;
+    const int k = (int)(task - row * nwmax);
+    const int iy = i0[1] + (int)(row % nyr), iz = i0[2] + (int)(row / nyr);
+    const long long base = ((long long)iz * env.clear_n[1] + iy) * env.clear_n[0];
+    const long long l0 = base + i0[0], l1 = base + i1[0];
+    const long long w = (l0 >> 5) + k;
+    if (w > (l1 >> 5)) continue;
+    const long long c0 = w * 32 > l0 ? w * 32 : l0, c1 = w * 32 + 31 < l1 ? w * 32 + 31 : l1;
+    uint32_t mp = 0u, me = 0u;
+    for (long long l = c0; l <= c1; ++l) {
+      const long long ix = l - base;
+      const double c[3] = {env.clear_org[0] + ((double)ix + 0.5) * h, env.clear_org[1] + ((double)iy + 0.5) * h,
+                           env.clear_org[2] + ((double)iz + 0.5) * h};
+      if (tri_far(T, c, reach)) continue;
+      if (!tri_far(T, c, P.thr_pose) && tri_box_maybe(T, c, P.pose_lo, P.pose_hi)) mp |= 1u << (int)(l & 31);
+      if (!tri_far(T, c, P.thr_edge) && tri_box_maybe(T, c, P.edge_lo, P.edge_hi)) me |= 1u << (int)(l & 31);
+    }
+    if (mp) atomicAnd(bits_pose + w, ~mp);
+    if (me) atomicAnd(bits_edge + w, ~me);
   }
 }
 
@@ -1051,13 +1124,13 @@ void launch_tgrid_build(hipStream_t s, const EnvView& env, int32_t* cnt_or_start
 __device__ unsigned long long g_dbg[16];
 __device__ unsigned long long g_dbg_q[16];   // k_query_classify: sampled waves | ticks: scan, classify, cull, flushes | pairs, survivors, live
 #define QDBG(i, x) do { if (qdbg_on) atomicAdd(&g_dbg_q[i], (unsigned long long)(x)); } while (0)
-struct DbgAcc { unsigned long long v[12]; };
-#define DBG_DECL DbgAcc dbg_acc = {{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
+struct DbgAcc { unsigned long long v[16]; };
+#define DBG_DECL DbgAcc dbg_acc = {{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}};
 #define DBG_ARG , DbgAcc& dbg_acc
 #define DBG_PASS , dbg_acc
 #define DBG_T() wall_clock64()
 #define DBG_ADD(i, x) dbg_acc.v[i] += (unsigned long long)(x)
-#define DBG_FLUSH() do { if (lane == 0) for (int q_ = 0; q_ < 12; ++q_) if (dbg_acc.v[q_]) atomicAdd(&g_dbg[q_], dbg_acc.v[q_]); } while (0)
+#define DBG_FLUSH() do { if (lane == 0) for (int q_ = 0; q_ < 16; ++q_) if (dbg_acc.v[q_]) atomicAdd(&g_dbg[q_], dbg_acc.v[q_]); } while (0)
 #else
 #define DBG_DECL
 #define DBG_ARG
@@ -1219,7 +1292,7 @@ __device__ void segment_chunk(const EnvView& env, const RobotView& rob, const do
   const double C[3] = {P[0] + rob.center[0], P[1] + rob.center[1], P[2] + rob.center[2]};
   // samples whose clearance bit is set need nothing; the others bound the chunk's broad-phase box
   // (the cull kernel already looked the bits up when it hands a mask over)
-  const bool need = have_mask ? ((mask >> lane) & 1ULL) != 0 : (live && !surely_clear(env, P));
+  const bool need = have_mask ? ((mask >> lane) & 1ULL) != 0 : (live && !surely_clear_edge(env, P));
   const unsigned long long nm = __ballot(need);
   [[maybe_unused]] const unsigned long long t1_ = DBG_T();
   DBG_ADD(4, t1_ - t0_);
@@ -1263,6 +1336,7 @@ __device__ void segment_chunk(const EnvView& env, const RobotView& rob, const do
   int minhit = 0x7fffffff;
   auto flush = [&](int count) {
     DBG_ADD(3, 1);
+    [[maybe_unused]] const unsigned long long tf_ = DBG_T();
     int v = 0x7fffffff;
     if (lane < count) {
       const int e = queue[lane];
@@ -1287,11 +1361,15 @@ __device__ void segment_chunk(const EnvView& env, const RobotView& rob, const do
     if (lane + count < qn) keep = queue[lane + count];
     if (lane + count < qn) queue[lane] = keep;
     qn -= count;
+    DBG_ADD(13, DBG_T() - tf_);
   };
   for (int k0 = 0; k0 < nc; k0 += STAGE_N) {
     const int kc = nc - k0 < STAGE_N ? nc - k0 : STAGE_N;
+    [[maybe_unused]] const unsigned long long ts_ = DBG_T();
     stage_candidates(env, cand, k0, kc, lane, stage);
+    DBG_ADD(10, DBG_T() - ts_);
     for (int k = 0; k < kc; ++k) {
+      [[maybe_unused]] const unsigned long long tc_ = DBG_T();
       const double* bx = stage + k * STAGE_TRI;
       // extent of the (un-rotated: edge samples carry no rotation) robot along the triangle's normal, over all its
       // triangle vertices: a sample whose whole robot stays on one side of the triangle's plane touches nothing of it
@@ -1318,6 +1396,8 @@ __device__ void segment_chunk(const EnvView& env, const RobotView& rob, const do
         if (touch && tri_far(bx + 11, C, rr)) touch = false;
       }
       unsigned long long todo = __ballot(touch);
+      DBG_ADD(11, DBG_T() - tc_);
+      DBG_ADD(14, __popcll(todo));
       while (todo) {
         const int sl = __ffsll((long long)todo) - 1;
         todo &= todo - 1;
@@ -1352,13 +1432,6 @@ __device__ void segment_chunk(const EnvView& env, const RobotView& rob, const do
   }
   while (qn > 0) flush(qn < 64 ? qn : 64);
   DBG_ADD(6, DBG_T() - t2_);
-#ifdef SFFK_DEBUG_COUNTERS
-  {   // histogram of the chunk's total time: < 10, < 20, < 40, < 80, >= 80 us; [15] = candidates of the >= 40 us ones
-    const unsigned long long dt = DBG_T() - t0_;
-    const int bk = dt < 1000 ? 10 : (dt < 2000 ? 11 : (dt < 4000 ? 12 : (dt < 8000 ? 13 : 14)));
-    if (lane == 0) { atomicAdd(&g_dbg[bk], 1ULL); if (dt >= 4000) atomicAdd(&g_dbg[15], (unsigned long long)nc); }
-  }
-#endif
   if (minhit != 0x7fffffff && lane == 0) atomicMin(first_hit + seg, minhit);
 }
 
@@ -1503,12 +1576,12 @@ __global__ __launch_bounds__(256) void k_cull(EnvView env, const double* __restr
       if (need[u]) {
         const double fx = (C[0] - env.clear_org[0]) * env.clear_inv, fy = (C[1] - env.clear_org[1]) * env.clear_inv,
                      fz = (C[2] - env.clear_org[2]) * env.clear_inv;
-        if (env.clear_bits && fx == fx && fy == fy && fz == fz) {
+        if (env.clear_bits_edge && fx == fx && fy == fy && fz == fz) {
           if (fx < 0 || fy < 0 || fz < 0 || fx >= env.clear_n[0] || fy >= env.clear_n[1] || fz >= env.clear_n[2]) {
             need[u] = false;                        // beyond the inflated box of the environment
           } else {                                  // (the grid has fewer than 2^31 cells)
             const uint32_t ci = ((uint32_t)(int)fz * (uint32_t)env.clear_n[1] + (uint32_t)(int)fy) * (uint32_t)env.clear_n[0] + (uint32_t)(int)fx;
-            wp[u] = env.clear_bits + (ci >> 5);
+            wp[u] = env.clear_bits_edge + (ci >> 5);
             sh[u] = (int)(ci & 31u);
           }
         }
@@ -2207,12 +2280,12 @@ __global__ __launch_bounds__(64 * QC_WAVES) __attribute__((amdgpu_waves_per_eu(Q
           const int probe = first + 4 <= ns ? first + 4 : ns;   // within four steps of every valid sample of the group
           const uint32_t* wp = nullptr;
           int sh = 0;
-          if (need && env.clear_bits) {
+          if (need && env.clear_bits_edge) {
             const float td = (float)probe;
             const float fx = __builtin_fmaf(td, d0, a0), fy = __builtin_fmaf(td, d1, a1), fz = __builtin_fmaf(td, d2, a2);
             if (fx >= 0 && fy >= 0 && fz >= 0 && fx < nxd && fy < nyd && fz < nzd) {   // (the grid has fewer than 2^31 cells)
               const uint32_t ci = ((uint32_t)(int)fz * (uint32_t)env.clear_n[1] + (uint32_t)(int)fy) * (uint32_t)env.clear_n[0] + (uint32_t)(int)fx;
-              wp = env.clear_bits + (ci >> 5);
+              wp = env.clear_bits_edge + (ci >> 5);
               sh = (int)(ci & 31u);
             } else if (fx == fx && fy == fy && fz == fz) {
               need = false;                                     // beyond the inflated box of the environment
@@ -2342,8 +2415,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB_OCC))) v
     A.n = A.dev_n[0];
   }
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int i_base = blockIdx.x * S;
-  if (i_base >= A.n) return;
+  // which samples: 8 consecutive sample indices, or - device engine, OrderView - 8 entries of one sub-range's list of the
+  // wave's spatial order, the sub-ranges dealt out so that every XCD (workgroup b runs on XCD b % 8) gets one contiguous
+  // run of them: neighbouring samples then find each other's count, bucket and clearance lines in that XCD's L2
+  __shared__ int s_map[S];
+  {
+    const bool ordered = A.ord_valid && *A.ord_valid;
+    int i = -1;
+    if (ordered) {
+      const int n_slots = *A.ord_nslots, sel = *A.ord_sel, R = (n_slots + 63) >> 6, perx = (R + 7) >> 3;
+      const int y = (int)blockIdx.x >> 3, r = ((int)blockIdx.x & 7) * perx + (y >> 3), j = y & 7;
+      if ((y >> 3) >= perx || r >= R) return;
+      // (no run-time index into the argument struct: that would move all of it to scratch memory)
+      const int32_t* const o_cnt = sel ? A.ord_cnt[1] : A.ord_cnt[0];
+      const int32_t* const o_lst = sel ? A.ord_lst[1] : A.ord_lst[0];
+      int cnt = o_cnt[r * SFFK_ORD_CNT_STRIDE];
+      int e = tid < S ? o_lst[r * 64 + 8 * j + tid] : -1;   // (requested beside the count)
+      cnt = cnt < 64 ? cnt : 64;
+      if (8 * j >= cnt) return;
+      if (tid < S && 8 * j + tid < cnt) i = e;
+      if (i >= A.n) i = -1;
+    } else {
+      if ((int)blockIdx.x * S >= A.n) return;
+      if (tid < S) { i = blockIdx.x * S + tid; if (i >= A.n) i = -1; }
+    }
+    if (tid < S) s_map[tid] = i;
+    __syncthreads();
+    bool any = false;
+    for (int q = 0; q < S; ++q) any = any || s_map[q] >= 0;
+    if (!any) return;
+  }
   const bool clocked = A.qclk && (blockIdx.x & 15) == 0 && tid == 0;
   if (clocked) atomicMin(A.qclk, wall_clock64());
   [[maybe_unused]] const bool qdbg_on = (blockIdx.x & 15) == 0 && tid == 0;
@@ -2363,12 +2464,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB_OCC))) v
     const int probe = first + 4 <= ns ? first + 4 : ns;
     wp = nullptr;
     sh = 0;
-    if (need && env.clear_bits) {
+    if (need && env.clear_bits_edge) {
       const float td = (float)probe;
       const float fx = __builtin_fmaf(td, tt[4], tt[0]), fy = __builtin_fmaf(td, tt[5], tt[1]), fz = __builtin_fmaf(td, tt[6], tt[2]);
       if (fx >= 0 && fy >= 0 && fz >= 0 && fx < nxd && fy < nyd && fz < nzd) {
         const uint32_t ci = ((uint32_t)(int)fz * (uint32_t)env.clear_n[1] + (uint32_t)(int)fy) * (uint32_t)env.clear_n[0] + (uint32_t)(int)fx;
-        wp = env.clear_bits + (ci >> 5);
+        wp = env.clear_bits_edge + (ci >> 5);
         sh = (int)(ci & 31u);
       } else if (fx == fx && fy == fy && fz == fz) {
         need = false;                                     // beyond the inflated box of the environment
@@ -2385,17 +2486,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB_OCC))) v
   }
   for (int e = tid; e < S * QB_TASKS; e += 256) (&s_need[0][0])[e] = 0;
   for (int e = tid; e < S * 32; e += 256) {
-    const int s = e >> 5, w = e & 31, i = i_base + s;
-    int v = i < A.n ? reinterpret_cast<const int32_t*>(A.qrec)[(size_t)i * 32 + w] : 0;
-    if (w == QI_FLAGS) v = (i < A.n && reinterpret_cast<const int32_t*>(A.qrec)[(size_t)i * 32 + QI_EVAL]) ? 1 : 0;
-    if (w == QI_FORCE) v = i < A.n && A.force[i] != 0;
+    const int s = e >> 5, w = e & 31, i = s_map[s];
+    int v = i >= 0 ? reinterpret_cast<const int32_t*>(A.qrec)[(size_t)i * 32 + w] : 0;
+    if (w == QI_FLAGS) v = (i >= 0 && reinterpret_cast<const int32_t*>(A.qrec)[(size_t)i * 32 + QI_EVAL]) ? 1 : 0;
+    if (w == QI_FORCE) v = i >= 0 && A.force[i] != 0;
     if (w == QI_NNB || w == QI_LIVE) v = 0;
     s_i[s][w] = v;
   }
   for (int e = tid; e < S * 12; e += 256) {
-    const int s = e / 12, k = e - s * 12, i = i_base + s;
+    const int s = e / 12, k = e - s * 12, i = s_map[s];
     double v = 0.0;
-    if (i < A.n) {
+    if (i >= 0) {
       if (k < 6) v = A.newpos[6 * (size_t)i + k];
       else v = A.center ? A.center[6 * (size_t)i + k - 6] : A.pos[6 * (size_t)A.parent[i] + k - 6];
     }
@@ -2405,9 +2506,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB_OCC))) v
   int sh_pose = 0;
   bool need_pose = false;
   if (tid < S) {
-    const int s = tid, i = i_base + s;
-    const bool act = i < A.n;
-    const QRec* rec = A.qrec + (act ? i : i_base);
+    const int s = tid, i = s_map[s];
+    const bool act = i >= 0;
+    const QRec* rec = A.qrec + (act ? i : 0);
     const bool evaluate = act && rec->evaluate != 0;
     const int total = evaluate ? rec->total : 0;
     s_nhit[s] = 0; s_drop[s] = 0;
@@ -2577,7 +2678,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB_OCC))) v
   if (tid < (S << gsh)) {
     const int gw = 1 << gsh;
     const int s = tid >> gsh, hl = tid & (gw - 1);
-    const int i = i_base + s;
+    const int i = s_map[s];
     const int gbase = lane & ~(gw - 1);
     const uint32_t gmask = gsh == 5 ? 0xffffffffu : 0xffffu;
     auto hballot = [&](bool p) -> uint32_t { return (uint32_t)(__ballot(p) >> gbase) & gmask; };
@@ -2642,7 +2743,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB_OCC))) v
       s_NS[s][1 + rank] = ns;
       s_rankhit[s][1 + rank] = hl;
     }
-    if (hl == 0 && i < A.n) {
+    if (hl == 0 && i >= 0) {
       if ((flags & 3) == 1) {   // slot 0: isPathFree(expanded, newPoint)  (src/forest.h:246)
         const size_t slot = (size_t)i * stride;
         A.seg_ns[slot] = s_i[s][QI_NS0];
@@ -2683,7 +2784,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB_OCC))) v
     m |= __shfl_xor(m, 4);
     const bool lead = gi == 0 && m != 0ULL;
     if (lead) s_need[s][t] = 1;
-    add_surv(lead, (int32_t)((i_base + s) * stride + t), c, m);
+    add_surv(lead, (int32_t)(s_map[s] * stride + t), c, m);
   };
   // the parent edges' first four chunks (requested in phase 1)
   settle(e_s < S && e_need && s_i[e_s < S ? e_s : 0][QI_LIVE], e_left, e_wp, e_sh, e_word, e_s < S ? e_s : 0, 0, e_c);
@@ -2733,7 +2834,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB_OCC))) v
     const bool open = s_i[tid][QI_LIVE] && need_pose && !((word_pose >> sh_pose) & 1u);
     if (open) {
       const int at = atomicAdd(&s_cnt[2], 1);
-      const SurvivorItem it{-1 - (i_base + tid), 0, 0ULL};
+      const SurvivorItem it{-1 - s_map[tid], 0, 0ULL};
       if (at < SURVCAP) s_surv[at] = it;
       else {
         SurvivorItem* list = static_cast<SurvivorItem*>(A.items);
@@ -2777,7 +2878,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB_OCC))) v
     }
     const int tk_s = tid / QB_TASKS, tk_t = tid - tk_s * QB_TASKS;
     if (tk_s < S && s_need[tk_s][tk_t]) {
-      const int i = i_base + tk_s;
+      const int i = s_map[tk_s];
       const size_t slot = (size_t)i * stride + tk_t;
       double* sa = A.seg_a + 6 * slot;
       double* sb = A.seg_b + 6 * slot;
@@ -2828,26 +2929,53 @@ __global__ __launch_bounds__(64 * SEG_WAVES) __attribute__((amdgpu_waves_per_eu(
     n_pose = dev_n[0];
     if (n_temps) n_temps = dev_n[0];
   }
+  extern __shared__ double lds_d[];
+  double* rtri = lds_d;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  // Every load of the preamble is issued before anything waits (round 5: the trace of a launch showed its first item
+  // starting 4.5 us in - four memory round trips one after the other: the round grid's cleanup, the sub-lists' counters,
+  // the overflow flag, the robot): the sub-lists' fill counts, one per lane (SFFK_SUBLISTS == 64) ...
+  int sub_n = sub[lane * SFFK_SUB_STRIDE], sub_nl = sub[lane * SFFK_SUB_STRIDE + 2];
+  const int ctrl3 = ctrl[3];
+  // ... the robot's triangles (up to CI_PRE doubles per thread in registers, the rest - large robots - by the loop below) ...
+  constexpr int CI_PRE = 6;
+  const int n9 = rob.n_tri * 9;
+  double rv[CI_PRE];
+#pragma unroll
+  for (int k = 0; k < CI_PRE; ++k) {
+    const int idx = (int)threadIdx.x + k * 256;
+    rv[k] = idx < n9 ? rob.tri[idx] : 0.0;
+  }
+  // ... and the first of this thread's temporaries of the round grid that has to be emptied
+  const int gt0 = blockIdx.x * blockDim.x + threadIdx.x;
+  float cx0 = __int_as_float(0x7fc00000), cy0 = 0.0f, cz0 = 0.0f;
+  if (tg.cnt && gt0 < n_temps) { cx0 = tx[gt0]; cy0 = ty[gt0]; cz0 = tz[gt0]; }
+#pragma unroll
+  for (int k = 0; k < CI_PRE; ++k) {
+    const int idx = (int)threadIdx.x + k * 256;
+    if (idx < n9) rtri[idx] = rv[k];
+  }
+  for (int i = (int)threadIdx.x + CI_PRE * 256; i < n9; i += blockDim.x) rtri[i] = rob.tri[i];
   if (tg.cnt) {
-    for (int t = blockIdx.x * blockDim.x + threadIdx.x; t < n_temps; t += gridDim.x * blockDim.x) {
+    if (cx0 == cx0) {
+      const size_t cell = grid_cell_of(tg, cx0, cy0, cz0);
+      tg.cnt[cell] = 0;
+      if (tg.occ) tg.occ[cell >> 5] = 0u;   // (every set bit of the word belongs to a sample of this round)
+    }
+    for (int t = gt0 + gridDim.x * blockDim.x; t < n_temps; t += gridDim.x * blockDim.x) {
       const float x = tx[t];
       if (x == x) {
         const size_t cell = grid_cell_of(tg, x, ty[t], tz[t]);
         tg.cnt[cell] = 0;
-        if (tg.occ) tg.occ[cell >> 5] = 0u;   // (every set bit of the word belongs to a sample of this round)
+        if (tg.occ) tg.occ[cell >> 5] = 0u;
       }
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) tg.ovf_cnt[0] = 0;
   }
-  extern __shared__ double lds_d[];
-  double* rtri = lds_d;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   double* stage = rtri + (size_t)rob.n_tri * 9 + (size_t)wave * STAGE_DOUBLES;
   int32_t* ibase = reinterpret_cast<int32_t*>(rtri + (size_t)rob.n_tri * 9 + (size_t)SEG_WAVES * STAGE_DOUBLES);
-  // the sub-lists' fill counts, one per lane (SFFK_SUBLISTS == 64), and their running sum
   const int sub_cap = items_cap / SFFK_SUBLISTS, sub_half = sub_cap / 2;
   // (every sub-list: heavy items in its front half, light ones in its back half, one counter each)
-  int sub_n = sub[lane * SFFK_SUB_STRIDE], sub_nl = sub[lane * SFFK_SUB_STRIDE + 2];
   sub_n = sub_n < sub_half ? sub_n : sub_half;
   sub_nl = sub_nl < sub_cap - sub_half ? sub_nl : sub_cap - sub_half;
   int sub_incl = sub_n, sub_incl_l = sub_nl;
@@ -2857,10 +2985,9 @@ __global__ __launch_bounds__(64 * SEG_WAVES) __attribute__((amdgpu_waves_per_eu(
   }
   const int MH = __shfl(sub_incl, 63);
   const int M = MH + __shfl(sub_incl_l, 63);
-  const bool ran_over = ctrl[3] != 0;
+  const bool ran_over = ctrl3 != 0;
   if (blockIdx.x == 0 && threadIdx.x == 0) ctrl[2] = M;   // (statistics)
-  if ((M <= 0 && !ran_over) || env.n_tri == 0) return;
-  for (int i = threadIdx.x; i < rob.n_tri * 9; i += blockDim.x) rtri[i] = rob.tri[i];
+  if ((M <= 0 && !ran_over) || env.n_tri == 0) return;   // (uniform over the launch: no barrier is left waiting)
   __syncthreads();
   double* rbox = reinterpret_cast<double*>(ibase + SEG_WAVES * (STACK_CAP + TG_HASH + CAND_CAP + QUEUE_CAP));
   fill_robot_boxes(rtri, rbox, rob.n_tri, threadIdx.x, blockDim.x);
@@ -3176,12 +3303,12 @@ __device__ __attribute__((noinline)) bool sq_path_free(const EnvView& env, const
         const int idx = 1 + 64 * (c0 + u) + lane;
         need[u] = idx <= ns;
         wp[u] = nullptr; sh[u] = 0;
-        if (need[u] && env.clear_bits) {
+        if (need[u] && env.clear_bits_edge) {
           const float td = (float)idx;
           const float fx = __builtin_fmaf(td, d0, g0), fy = __builtin_fmaf(td, d1, g1), fz = __builtin_fmaf(td, d2, g2);
           if (fx >= 0 && fy >= 0 && fz >= 0 && fx < nxd && fy < nyd && fz < nzd) {
             const uint32_t ci = ((uint32_t)(int)fz * (uint32_t)env.clear_n[1] + (uint32_t)(int)fy) * (uint32_t)env.clear_n[0] + (uint32_t)(int)fx;
-            wp[u] = env.clear_bits + (ci >> 5);
+            wp[u] = env.clear_bits_edge + (ci >> 5);
             sh[u] = (int)(ci & 31u);
           } else if (fx == fx && fy == fy && fz == fz) {
             need[u] = false;                                  // beyond the inflated box of the environment
@@ -3219,7 +3346,7 @@ __device__ __attribute__((noinline)) bool sq_path_free(const EnvView& env, const
           for (int idx = 1 + 64 * (c0 + u); idx <= last && fh == 0x7fffffff; ++idx) {
             double P[6] = {0, 0, 0, 0, 0, 0}, Rm[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, c3[3];
             edge_sample_pos(a, dir, parts, idx, P);
-            if (surely_clear(env, P)) continue;
+            if (surely_clear_edge(env, P)) continue;
             xform(Rm, P, rob.center, c3);
             if (pose_exact(env, rob, rtri, stack, cand, stage, P, Rm, c3, lane)) fh = idx;
           }
@@ -3861,9 +3988,13 @@ void debug_counters_query(unsigned long long* out16) { (void)hipMemcpyFromSymbol
 void debug_ci_trace(unsigned long long* out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_ci_trace), sizeof(unsigned long long) * 4096 * 8); }
 #endif
 
-void launch_clear_build(hipStream_t s, const EnvView& env, double thr, uint32_t* bits, long long n_cells) {
-  const long long blocks = (n_cells + 255) / 256;
-  hipLaunchKernelGGL(k_clear_build, dim3((unsigned)blocks), dim3(256), 0, s, env, thr, bits, n_cells);
+void launch_clear_build(hipStream_t s, const EnvView& env, const ClearBuildArgs& P, uint32_t* bits_pose, uint32_t* bits_edge,
+                        long long n_cells) {
+  // every cell starts clear (padding words included: no lookup reaches them); the triangles clear what they block
+  const size_t bytes = (size_t)((n_cells + 255) / 256 * 256 / 8);
+  (void)hipMemsetAsync(bits_pose, 0xff, bytes, s);
+  (void)hipMemsetAsync(bits_edge, 0xff, bytes, s);
+  if (env.n_tri > 0) hipLaunchKernelGGL(k_clear_scatter, dim3((unsigned)env.n_tri), dim3(256), 0, s, env, P, bits_pose, bits_edge);
 }
 
 void launch_settle(hipStream_t s, const SettleArgs& a) {
@@ -3892,7 +4023,10 @@ bool launch_query_classify(hipStream_t s, const GridView& g, const GridView* tg,
     if (cap_override >= 0 && cap_override < aa.items_cap) aa.items_cap = cap_override;
   }
   if (query_block_mode(g, tg, a, env)) {
-    hipLaunchKernelGGL(k_query_block, dim3((a.n + QB_S - 1) / QB_S), dim3(256), 0, s, g, tg ? *tg : none, queries, aa, *env);
+    // (the ordered walk deals 8 workgroups to each sub-range of 64 positions, a multiple of 8 sub-ranges per XCD)
+    const int by_sub = 64 * ((((a.n + 63) / 64) + 7) / 8);
+    const int by_n = (a.n + QB_S - 1) / QB_S;
+    hipLaunchKernelGGL(k_query_block, dim3(a.ord_valid && by_sub > by_n ? by_sub : by_n), dim3(256), 0, s, g, tg ? *tg : none, queries, aa, *env);
     return true;
   }
   hipLaunchKernelGGL(k_query_classify, dim3((a.n + QC_WAVES - 1) / QC_WAVES), dim3(64 * QC_WAVES), 0, s, g, tg ? *tg : none, st,

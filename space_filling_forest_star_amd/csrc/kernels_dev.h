@@ -141,6 +141,14 @@ __device__ __forceinline__ void sample_steer_one(int tid, int i, int slot, const
       tmp.st.yaw[o] = nanv; tmp.st.pitch[o] = nanv; tmp.st.roll[o] = nanv;
     }
   }
+  // the wave's first sampling launch (sample index == slot): every slot gets its position in the wave's spatial order
+  if (dv.ctrl && dv.ord.hist && slot == -1 && dv.ctrl->ord_valid && dv.ctrl->round == 1 && tid < dv.ctrl->n_slots) {
+    const int pos = dv.ord.start[dv.ord.slot_key[tid]] + dv.ord.slot_rank[tid];
+    const int sel = dv.ctrl->act_sel, n_slots = dv.ctrl->n_slots;
+    dv.ord.slot_pos[tid] = pos;
+    (sel ? dv.ord.lst[1] : dv.ord.lst[0])[pos] = tid < n ? tid : -1;      // (this round: every position holds its slot's sample)
+    if ((pos & 63) == 0) (sel ? dv.ord.cnt[1] : dv.ord.cnt[0])[(pos >> 6) * SFFK_ORD_CNT_STRIDE] = n_slots - pos < 64 ? n_slots - pos : 64;
+  }
   if (i < 0 || i >= n) return;
   double c[6], o[6];
   int par = 0;

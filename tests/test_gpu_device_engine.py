@@ -209,6 +209,25 @@ def test_device_engine_is_the_default_for_gpu_sized_waves_and_equals_the_host_en
     assert sd["host_ms"] < 0.6 * sh["host_ms"]
 
 
+def test_spatial_order_of_the_slots_changes_nothing(S, ctx):
+    """round 5: the query kernel takes a round's samples from per-sub-range lists of the wave's spatial order
+    (sffk::OrderView) instead of by sample index; SFFGPU_NO_ORDER=1 is the walk by index.  Same forest either way,
+    plain SFF and SFF*, also when a wave holds fewer slots than the launch is sized for."""
+    for name, wave, iters, optimize in (("dense3d", 2048, 90000, False), ("dense3d", 1000, 40000, True),
+                                        ("building", 4096, 60000, False)):
+        fo, fg = make(S, ctx, name, wave, iters, seed=5, optimize=optimize)
+        fo.run()
+        fg.run()
+        assert fg.device_engine()
+        assert_same_forest(fo, fg)
+        fp = fg.fingerprint()
+        fg.close()
+        _, fn = make(S, ctx, name, wave, iters, seed=5, optimize=optimize, SFFGPU_NO_ORDER=1)
+        fn.run()
+        assert fn.fingerprint() == fp
+        fn.close()
+
+
 def test_saturating_forest_terminates_solved_with_closed_list_picks(S, ctx):
     """coarse steps: the frontier runs empty, the engine keeps expanding from the closed list (src/forest.h:
     136-141) until every tree is connected -> solved"""
