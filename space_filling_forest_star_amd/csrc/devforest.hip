@@ -240,6 +240,7 @@ __device__ __forceinline__ size_t border_slot(const DevForestView& f, unsigned l
 #define KC_OWN 5      // border events it owns
 #define KC_CNT 6      // 6 counters of the walks + [12] dependent samples
 #define KC_DEP 12
+#define KC_EVN 13     // border events (before the first-in-slot-order rule)
 
 __device__ __forceinline__ unsigned long long kc_load(const unsigned long long* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -493,10 +494,17 @@ __global__ __launch_bounds__(1024) void k_commit(ResolveArgs A, int n_bound) {
       KC_TRACE(2);
       for (int q = 0; q < 6; ++q) kc_publish(pub + KC_CNT + q, seq, (unsigned)c6[q]);
       kc_publish(pub + KC_DEP, seq, (unsigned)__popcll(wd));
+      kc_publish(pub + KC_EVN, seq, (unsigned)__popcll(we));
+      f.w_ev[b] = we;                               // (k_border_finalize)
     }
   }
   __syncthreads();
   const unsigned long long wa = s_wa, we = s_we;
+  // plain SFF: which event owns its key (the first in slot order) and where the border list gets it is settled by the
+  // append launch that follows (k_border_finalize) - by then every stamp is in the table, and the two rounds of "wait
+  // for every lower workgroup" (stamps posted, owned counts) leave this kernel's critical path.  SFF* needs the entries
+  // in its passes: there they are settled here.
+  const bool defer = !A.star;
   // ---- 2b. border events (a free edge to a neighbour of another tree, :288-294) whose neighbour is a STORE node need
   // nothing of the other workgroups: their stamps go out now, and a workgroup none of whose events waits for a
   // round-mate's id says "posted" before it collects the lower workgroups' counts - the higher workgroups then find the
@@ -517,9 +525,10 @@ __global__ __launch_bounds__(1024) void k_commit(ResolveArgs A, int n_bound) {
         e_h = border_slot(f, key);
         atomicMin(&f.bt_val[e_h], stamp_hi | (unsigned long long)(uint32_t)e_i);
         stamped = true;
+        if (defer) { f.ev_h[e_i] = (unsigned long long)e_h; f.ev_nb[e_i] = e_nb; f.ev_raw[e_i] = raw; }
       }
     }
-    if (__ballot(is_ev && !stamped) == 0ULL) {
+    if (!defer && __ballot(is_ev && !stamped) == 0ULL) {
       if (we != 0ULL) __threadfence();         // the stamps are in the table before the word says so
       if (threadIdx.x == 0) {
         kc_publish(pub + KC_POSTED, seq, 1u);
@@ -533,9 +542,9 @@ __global__ __launch_bounds__(1024) void k_commit(ResolveArgs A, int n_bound) {
   if ((int)threadIdx.x < b) part = kc_wait(f.wg_pub + (size_t)threadIdx.x * SFFK_PUB_WORDS + KC_ACC, seq, A.fault_pending);
   // (the last workgroup: the lower workgroups' counters were published before their counts - requested now, looked at
   // when the control block is written)
-  unsigned long long early[7] = {0, 0, 0, 0, 0, 0, 0};
+  unsigned long long early[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (last && (int)threadIdx.x < b)
-    for (int q = 0; q < 7; ++q) early[q] = kc_load(f.wg_pub + (size_t)threadIdx.x * SFFK_PUB_WORDS + KC_CNT + q);
+    for (int q = 0; q < 8; ++q) early[q] = kc_load(f.wg_pub + (size_t)threadIdx.x * SFFK_PUB_WORDS + KC_CNT + q);
   const int acc_pref = (int)kc_block_sum(part, &s_sum);
   if (threadIdx.x == 0) {
     f.acc_pref[b] = acc_pref;
@@ -564,7 +573,10 @@ __global__ __launch_bounds__(1024) void k_commit(ResolveArgs A, int n_bound) {
       const unsigned long long key = ((unsigned long long)(uint32_t)a << 32) | ((unsigned long long)(uint32_t)bb + 1ULL);
       e_h = border_slot(f, key);
       atomicMin(&f.bt_val[e_h], stamp_hi | (unsigned long long)(uint32_t)e_i);
+      if (defer) { f.ev_h[e_i] = (unsigned long long)e_h; f.ev_nb[e_i] = e_nb; f.ev_raw[e_i] = raw; }
     }
+  }
+  if (!defer && (we != 0ULL || last)) {
     if (threadIdx.x < 64 && !posted) {
       if (we != 0ULL) __threadfence();         // the stamps are in the table before the word says so
       if (threadIdx.x == 0) kc_publish(pub + KC_POSTED, seq, 1u);
@@ -635,13 +647,15 @@ __global__ __launch_bounds__(1024) void k_commit(ResolveArgs A, int n_bound) {
   unsigned long long tot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if ((int)threadIdx.x < b) {   // (every lower workgroup has published its counters long ago: one batch of loads)
     const unsigned long long* pp = f.wg_pub + (size_t)threadIdx.x * SFFK_PUB_WORDS;
-    for (int q = 0; q < 7; ++q) tot[q] = (unsigned)(early[q] >> 32) == seq ? (unsigned)early[q] : kc_wait(pp + KC_CNT + q, seq, A.fault_pending);
+    for (int q = 0; q < 8; ++q) tot[q] = (unsigned)(early[q] >> 32) == seq ? (unsigned)early[q] : kc_wait(pp + KC_CNT + q, seq, A.fault_pending);
   }
   // (a fault is raised before its workgroup publishes anything: with every lower workgroup's words in, the flag is final)
   if (threadIdx.x == 1023) s_ev_total = __hip_atomic_load(A.fault_pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   kc_block_sum8(tot, s_tot, 0);
   for (int q = 0; q < 7; ++q) tot[q] += s_c6[q];
-  const int n_acc = acc_pref + __popcll(wa), n_ev = ev_pref + n_own, n_dep = (int)tot[6];
+  tot[7] += (unsigned long long)__popcll(we);
+  // (deferred: every event counted - an upper bound until the append launch has entered the ones that own their key)
+  const int n_acc = acc_pref + __popcll(wa), n_ev = defer ? (int)tot[7] : ev_pref + n_own, n_dep = (int)tot[6];
   const bool faulted = s_ev_total != 0;
   auto roll_back = [&](DevCtrl* k) {
     // a bounded device list overflowed somewhere in this round: nothing is committed, the bookkeeping of the round's
@@ -689,6 +703,7 @@ __global__ __launch_bounds__(1024) void k_commit(ResolveArgs A, int n_bound) {
       K.n_nodes = N0 + n_acc;
       K.frontier_n = f.prio.n_heaps ? fn0 : fn0 + n_acc;
       K.n_borders = nb0 + n_ev;
+      K.app_nb0 = nb0;
       K.n_unsettled += n_dep;
       K.epoch += 1ULL;
       if (A.star) {
@@ -794,7 +809,80 @@ __device__ __forceinline__ int append_one(const ResolveArgs& A, int i, int& slot
   grid_put(A.g, it);                                 // flannIndex->addPoints, :367
   return -1;
 }
-__global__ __launch_bounds__(256) void k_append(ResolveArgs A) {
+// Plain SFF: the committed round's border events (src/forest.h:288-294) are entered here, one workgroup per 64 samples
+// beside the append's own workgroups: an event owns its key when its stamp is the table entry's minimum (every stamp of
+// the round is in the table - k_commit has ended), its place in the list is border count before the round + the owned
+// events of the LOWER workgroups (published like k_commit's words, polled; a workgroup waits for lower ones only) + its
+// rank in the workgroup.  The round's last workgroup writes the exact border count over k_commit's upper bound.
+__device__ void border_finalize(const ResolveArgs& A, int b) {
+  __shared__ unsigned long long s_bsum;
+  __shared__ int s_bown;
+  const DevForestView& f = A.f;
+  DevCtrl* c = f.ctrl;
+  const int n = c->app_n;
+  if (n <= 0 || A.star) return;
+  const int nwg = (n + 63) >> 6;
+  if (b >= nwg) return;
+  const unsigned seq = (unsigned)f.commit_seq[0];                 // (the commit's launch number)
+  const unsigned long long stamp_hi = c->epoch << 32;             // (the commit's epoch: incremented when it committed)
+  const int Tb = f.temp_base, nb0 = c->app_nb0;
+  const unsigned long long we = f.w_ev[b];
+  unsigned long long* pub = f.wg_pub + (size_t)b * SFFK_PUB_WORDS;
+  const int tid = threadIdx.x;
+  bool own = false;
+  int e_i = 0;
+  unsigned long long wo = 0ULL;
+  if (tid < 64) {
+    if ((we >> tid) & 1ULL) {
+      e_i = b * 64 + tid;
+      // (atomic read: the stamps were written by L2 atomics)
+      const unsigned long long owner = __hip_atomic_load(&f.bt_val[f.ev_h[e_i]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      own = owner == (stamp_hi | (unsigned long long)(uint32_t)e_i);
+    }
+    wo = __ballot(own);
+    if (tid == 0) { s_bown = __popcll(wo); kc_publish(pub + KC_OWN, seq, (unsigned)__popcll(wo)); }
+  }
+  __syncthreads();
+  const int n_own = s_bown;
+  const bool last = b == nwg - 1;
+  if (n_own == 0 && !last) return;
+  unsigned long long pe = 0;
+  for (int t = tid; t < b; t += 256) pe += kc_wait(f.wg_pub + (size_t)t * SFFK_PUB_WORDS + KC_OWN, seq, A.fault_pending);
+  for (int off = 32; off > 0; off >>= 1) pe += __shfl_xor(pe, off);
+  if (tid == 0) s_bsum = 0ULL;
+  __syncthreads();
+  if ((tid & 63) == 0 && pe) atomicAdd(&s_bsum, pe);
+  __syncthreads();
+  const int ev_pref = (int)s_bsum;
+  if (own) {
+    const int at = nb0 + ev_pref + __popcll(wo & ((1ULL << tid) - 1ULL));
+    // d = costs to the roots + the edge (:291).  A neighbour accepted in this very round: its tree is its parent's, its
+    // position the sample's, its cost the one this launch's append writes (other workgroups: computed, not read).
+    double pn[6], pe6[6], dn;
+    int ta;
+    const int raw = f.ev_raw[e_i], e_nb = f.ev_nb[e_i], e_ex = A.parent[e_i];
+    if (raw >= Tb) {
+      const int j = raw - Tb;
+      for (int q = 0; q < 6; ++q) pn[q] = A.newpos[6 * (size_t)j + q];
+      dn = A.pdist[j] + f.d_root[A.parent[j]];
+      ta = A.st.tree[A.parent[j]];
+    } else {
+      for (int q = 0; q < 6; ++q) pn[q] = A.st.pos[6 * (size_t)e_nb + q];
+      dn = f.d_root[e_nb];
+      ta = A.st.tree[e_nb];
+    }
+    const int tb = A.st.tree[e_ex];
+    f.b_n1[at] = e_nb < e_ex ? e_nb : e_ex; f.b_n2[at] = e_nb < e_ex ? e_ex : e_nb;
+    f.b_ta[at] = ta < tb ? ta : tb; f.b_tb[at] = ta < tb ? tb : ta;
+    for (int q = 0; q < 6; ++q) pe6[q] = A.st.pos[6 * (size_t)e_ex + q];
+    f.b_dist[at] = dn + f.d_root[e_ex] + dist6(pn, pe6);
+    f.pair[(size_t)ta * f.n_trees + tb] = 1;
+    f.pair[(size_t)tb * f.n_trees + ta] = 1;
+  }
+  if (last && tid == 0) c->n_borders = nb0 + ev_pref + n_own;
+}
+__global__ __launch_bounds__(256) void k_append(ResolveArgs A, int append_blocks) {
+  if ((int)blockIdx.x >= append_blocks) { border_finalize(A, (int)blockIdx.x - append_blocks); return; }
   int slot, ord_at;
   const int next = append_one(A, blockIdx.x * 256 + threadIdx.x, slot, ord_at);
   append_ord_store(A, ord_at, next);
@@ -807,8 +895,9 @@ __global__ __launch_bounds__(256) void k_append(ResolveArgs A) {
 // between two sets of these arrays (A = the committed round's, P = the next round's).
 // The first half of the workgroups creates the accepted samples' nodes, the second half writes the list and samples: a
 // wavefront that had to do both would run the two chains of dependent loads one after the other.
-__global__ __launch_bounds__(256) void k_append_sample(ResolveArgs A, SampleLaunch P) {
-  const int nb = gridDim.x >> 1;
+__global__ __launch_bounds__(256) void k_append_sample(ResolveArgs A, SampleLaunch P, int append_blocks) {
+  if ((int)blockIdx.x >= 2 * append_blocks) { border_finalize(A, (int)blockIdx.x - 2 * append_blocks); return; }
+  const int nb = append_blocks;
   const bool sampler = (int)blockIdx.x >= nb;
   const int tid = ((int)blockIdx.x - (sampler ? nb : 0)) * 256 + threadIdx.x;
   int slot, ord_at;
@@ -1087,8 +1176,10 @@ void launch_commit(hipStream_t s, const ResolveArgs& a, int n_bound, const StarL
   if (n_bound <= 0) return;
   hipLaunchKernelGGL(k_commit, dim3((n_bound + 63) / 64), dim3(1024), 0, s, a, n_bound);
   if (a.star && star) launch_star_stage(s, a, n_bound, *star);
-  if (next) hipLaunchKernelGGL(k_append_sample, dim3(2 * ((n_bound + 255) / 256)), dim3(256), 0, s, a, *next);
-  else hipLaunchKernelGGL(k_append, dim3((n_bound + 255) / 256), dim3(256), 0, s, a);
+  // (plain SFF: + one workgroup per 64 samples that enters the round's border events, border_finalize)
+  const int ab = (n_bound + 255) / 256, fb = a.star ? 0 : (n_bound + 63) / 64;
+  if (next) hipLaunchKernelGGL(k_append_sample, dim3(2 * ab + fb), dim3(256), 0, s, a, *next, ab);
+  else hipLaunchKernelGGL(k_append, dim3(ab + fb), dim3(256), 0, s, a, ab);
 }
 void launch_wave_end(hipStream_t s, const DevForestView& f, const int32_t* grid_ovf, const int32_t* tgrid_ovf,
                      unsigned long long* star_acc) {

@@ -272,6 +272,10 @@ sffk::DevForestView Forest::dev_view() const {
   v.act_slot2 = d.act_slot2.as<int32_t>();
   v.w_acc = d.w_acc.as<unsigned long long>();
   v.acc_pref = d.acc_pref.as<int32_t>();
+  v.w_ev = d.w_ev.as<unsigned long long>();
+  v.ev_h = d.ev_h.as<unsigned long long>();
+  v.ev_nb = d.ev_nb.as<int32_t>();
+  v.ev_raw = d.ev_raw.as<int32_t>();
   v.ustate32 = d.ustate32.as<int32_t>();
   v.wg_pub = d.wg_pub.as<unsigned long long>();
   v.commit_seq = d.commit_seq.as<int32_t>();
@@ -484,6 +488,10 @@ void Forest::dev_upload_state() {
     d.act_slot2.ensure((size_t)wave * 4);
     d.w_acc.ensure(((size_t)wave / 64 + 2) * 8);
     d.acc_pref.ensure(((size_t)wave / 64 + 2) * 4);
+    d.w_ev.ensure(((size_t)wave / 64 + 2) * 8);
+    d.ev_h.ensure(((size_t)wave + 64) * 8);
+    d.ev_nb.ensure(((size_t)wave + 64) * 4);
+    d.ev_raw.ensure(((size_t)wave + 64) * 4);
     // k_commit's sequence-stamped words start at zero once and are never cleared again
     d.ustate32.ensure(((size_t)wave + 64) * 4);
     d.wg_pub.ensure(((size_t)wave / 64 + 2) * SFFK_PUB_WORDS * 8);

@@ -190,7 +190,10 @@ struct DevCtrl {
   // took, the k-nearest members they looked at, the rewires they applied (folded in from StarView::acc by k_wave_end)
   unsigned long long star_rounds, star_passes, star_members, star_rewires;
   // spatial order of the wave's slots (OrderView): 1 = the wave's slots have sorted positions and ord.pos_i is maintained
-  int32_t ord_valid, ord_pad;
+  int32_t ord_valid;
+  // plain SFF: the border events of the committed round are entered by the append launch (k_border_finalize): border list
+  // length before that round; n_borders holds an upper bound (every event counted) until the append has run
+  int32_t app_nb0;
 };
 #define SFFK_DEV_MAX_GROUPS 1024   // single-workgroup list kernels: 64 x this many slots per wave at most
 #define SFFK_FAULT_LISTS 1        // a hit / neighbour / triangle-candidate list overflowed: redo the round on the host
@@ -487,6 +490,9 @@ struct DevForestView {
   // one 64-bit word per 64 samples: the accepted samples, and how many were accepted before the word (k_commit ->
   // k_append_sample / the star stage: node ids and the next round's active list without walking the samples)
   unsigned long long* w_acc; int32_t* acc_pref;
+  // border events of a round (plain SFF: entered by the append launch): the samples with an event, per 64 samples; per
+  // sample the table entry its stamp went to, the neighbour's node id and the raw neighbour (store id or temporary)
+  unsigned long long* w_ev; unsigned long long* ev_h; int32_t* ev_nb; int32_t* ev_raw;
   // k_commit (the wide commit kernel): what its workgroups tell each other.  Every word carries the launch's sequence
   // number (commit_seq[0] + 1) in its upper half, so nothing is ever cleared and a stale word is never taken for news.
   int32_t* ustate32;           // per sample: (seq << 2 | state), state 1 rejected / 2 accepted / 3 rejected + border event

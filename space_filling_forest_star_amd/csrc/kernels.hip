@@ -1060,7 +1060,8 @@ __global__ __launch_bounds__(256) void k_clear_scatter(EnvView env, ClearBuildAr
   const long long rows = (long long)nyr * (i1[2] - i0[2] + 1);
   const int nwmax = ((i1[0] - i0[0]) >> 5) + 2;
   const long long tasks = rows * nwmax;
-  for (long long task = threadIdx.x; task < tasks; task += 256) {
+  // (blockIdx.y: the triangle's tasks dealt out to several workgroups - a few large triangles were the whole launch)
+  for (long long task = (long long)blockIdx.y * 256 + threadIdx.x; task < tasks; task += 256LL * gridDim.y) {
     const long long row = task / nwmax;
     const int k = (int)(task - row * nwmax);
     const int iy = i0[1] + (int)(row % nyr), iz = i0[2] + (int)(row / nyr);
@@ -3994,7 +3995,8 @@ void launch_clear_build(hipStream_t s, const EnvView& env, const ClearBuildArgs&
   const size_t bytes = (size_t)((n_cells + 255) / 256 * 256 / 8);
   (void)hipMemsetAsync(bits_pose, 0xff, bytes, s);
   (void)hipMemsetAsync(bits_edge, 0xff, bytes, s);
-  if (env.n_tri > 0) hipLaunchKernelGGL(k_clear_scatter, dim3((unsigned)env.n_tri), dim3(256), 0, s, env, P, bits_pose, bits_edge);
+  const unsigned split = env.n_tri < 4096 ? 32u : (env.n_tri < 65536 ? 4u : 1u);
+  if (env.n_tri > 0) hipLaunchKernelGGL(k_clear_scatter, dim3((unsigned)env.n_tri, split), dim3(256), 0, s, env, P, bits_pose, bits_edge);
 }
 
 void launch_settle(hipStream_t s, const SettleArgs& a) {
