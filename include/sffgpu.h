@@ -285,6 +285,15 @@ int sffgpu_ctx_set_stream(sffgpu_ctx* ctx, void* hip_stream);   /* NULL: back to
 #define SFFGPU_NEED_HOST_EXCHANGE 100
 int sffgpu_rccl_unique_id(uint8_t id128[128]);
 int sffgpu_ctx_rccl_init(sffgpu_ctx* ctx, const uint8_t id128[128], int rank, int world);
+/* The library-driven exchange over a collective of the CALLER's instead of RCCL (process groups that are not RCCL, and
+ * the way the library-driven path is tested with several ranks on one GPU): once set, sffgpu_forest_run() of a
+ * device-engine forest created with this rank / world calls fn(user, send_dev, recv_dev, words, hip_stream) wherever it
+ * would enqueue ncclAllGather - `words` int32 of this rank at send_dev, world x words at recv_dev in rank order, both in
+ * device memory.  fn either enqueues the collective on hip_stream or completes it before it returns (it may synchronise
+ * the stream); non-zero = failure (the run returns SFFGPU_ERR_HIP).  fn == NULL removes it.  Every rank must make the
+ * same sequence of calls: the library enqueues whole waves, one wave ahead, identically on every (identical) replica. */
+typedef int (*sffgpu_allgather_fn)(void* user, const void* send_dev, void* recv_dev, size_t words_i32, void* hip_stream);
+int sffgpu_ctx_set_allgather(sffgpu_ctx* ctx, sffgpu_allgather_fn fn, void* user, int rank, int world);
 int sffgpu_forest_device_engine(sffgpu_forest* f);
 long long sffgpu_forest_exchange_bytes(sffgpu_forest* f);
 int sffgpu_forest_rounds_per_wave(sffgpu_forest* f);

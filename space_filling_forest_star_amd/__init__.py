@@ -4,8 +4,8 @@ Thin ctypes binding of libsffgpu.so (C ABI in include/sffgpu.h).  There is no CP
 importing works anywhere (so the symbol table can be checked), but creating a Context
 without a gfx950 GPU raises.
 """
-from ._lib import (Rrt, RrtCfg, RrtStats, exchange_records, run_distributed, Context, Forest, ForestCfg, ForestStats, SffGpuError, lib, lib_path, build_library,
+from ._lib import (Rrt, RrtCfg, RrtStats, exchange_records, run_distributed, host_staged_allgather, Context, Forest, ForestCfg, ForestStats, SffGpuError, lib, lib_path, build_library,
                    EXPORTED_SYMBOLS)
 
-__all__ = ["Rrt", "RrtCfg", "RrtStats", "exchange_records", "run_distributed", "Context", "Forest", "ForestCfg", "ForestStats", "SffGpuError", "lib", "lib_path", "build_library",
+__all__ = ["Rrt", "RrtCfg", "RrtStats", "exchange_records", "run_distributed", "host_staged_allgather", "Context", "Forest", "ForestCfg", "ForestStats", "SffGpuError", "lib", "lib_path", "build_library",
            "EXPORTED_SYMBOLS"]

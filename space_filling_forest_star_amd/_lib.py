@@ -20,11 +20,13 @@ EXPORTED_SYMBOLS = [
     "sffgpu_rrt_create", "sffgpu_rrt_destroy", "sffgpu_rrt_run", "sffgpu_rrt_get_stats", "sffgpu_rrt_get_nodes",
     "sffgpu_rrt_get_links", "sffgpu_rrt_paths", "sffgpu_rrt_path_plan", "sffgpu_rrt_smooth_paths",
     "sffgpu_rrt_link_plan", "sffgpu_rrt_lazy_plan", "sffgpu_kernel_times", "sffgpu_forest_get_frontier",
-    "sffgpu_collide_transforms", "sffgpu_ctx_set_stream", "sffgpu_rccl_unique_id", "sffgpu_ctx_rccl_init", "sffgpu_forest_device_engine", "sffgpu_forest_exchange_bytes",
+    "sffgpu_collide_transforms", "sffgpu_ctx_set_stream", "sffgpu_rccl_unique_id", "sffgpu_ctx_rccl_init", "sffgpu_ctx_set_allgather", "sffgpu_forest_device_engine", "sffgpu_forest_exchange_bytes",
     "sffgpu_forest_rounds_per_wave", "sffgpu_forest_dev_wave_begin", "sffgpu_forest_dev_round_eval",
     "sffgpu_forest_dev_round_commit", "sffgpu_forest_dev_wave_end", "sffgpu_forest_in_wave", "sffgpu_forest_round_begin", "sffgpu_forest_round_records", "sffgpu_forest_round_commit",
 ]
 
+# sffgpu_allgather_fn: int fn(void* user, const void* send_dev, void* recv_dev, size_t words_i32, void* hip_stream)
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
 c_dp = C.POINTER(C.c_double)
 c_ip = C.POINTER(C.c_int32)
 c_u8p = C.POINTER(C.c_uint8)
@@ -156,6 +158,7 @@ def lib():
     L.sffgpu_ctx_set_stream.argtypes = [C.c_void_p, C.c_void_p]
     L.sffgpu_rccl_unique_id.argtypes = [C.c_void_p]
     L.sffgpu_ctx_rccl_init.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int]
+    L.sffgpu_ctx_set_allgather.argtypes = [C.c_void_p, ALLGATHER_FN, C.c_void_p, C.c_int, C.c_int]
     L.sffgpu_forest_device_engine.argtypes = [C.c_void_p]
     L.sffgpu_forest_exchange_bytes.argtypes = [C.c_void_p]
     L.sffgpu_forest_exchange_bytes.restype = C.c_longlong
@@ -278,6 +281,25 @@ class Context:
         buf = (C.c_uint8 * 128)(*bytes(id128))
         self._chk(self._L.sffgpu_ctx_rccl_init(self.h, buf, rank, world))
         self.rccl = (rank, world)
+
+    def set_allgather(self, fn, rank, world):
+        """the library-driven exchange over the caller's collective (sffgpu_ctx_set_allgather): fn(send_dev, recv_dev,
+        words, hip_stream) -> 0 on success, called wherever the library would enqueue ncclAllGather; None removes it"""
+        if fn is None:
+            self._chk(self._L.sffgpu_ctx_set_allgather(self.h, ALLGATHER_FN(0), None, 0, 1))
+            self._xchg_cb, self.xchg = None, None
+            return
+
+        def tramp(_user, send, recv, words, stream):
+            try:
+                return int(fn(send, recv, int(words), stream) or 0)
+            except Exception as e:   # (an exception must not unwind through the C frames)
+                print("sffgpu: the caller's all-gather raised %r" % (e,), file=sys.stderr)
+                return 1
+
+        cb = ALLGATHER_FN(tramp)
+        self._chk(self._L.sffgpu_ctx_set_allgather(self.h, cb, None, rank, world))
+        self._xchg_cb, self.xchg = cb, (rank, world)   # (the trampoline lives as long as the context uses it)
 
     def nodes_reset(self, capacity=0):
         self._chk(self._L.sffgpu_nodes_reset(self.h, capacity))
@@ -721,6 +743,31 @@ def _native_rccl(forest, group):
     return agreed(ok)
 
 
+def host_staged_allgather(group):
+    """A sffgpu_allgather_fn for process groups without device collectives (gloo): waits for the stream, stages this
+    rank's words through the host, all-gathers them over the group and copies every rank's words back to the device -
+    complete when it returns.  What the multi-process tests drive the library-driven exchange with on one GPU."""
+    import torch
+    import torch.distributed as dist
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    world = dist.get_world_size(group)
+
+    def fn(send, recv, words, stream):
+        if hip.hipStreamSynchronize(C.c_void_p(stream)) != 0:
+            return 1
+        mine = torch.empty(words, dtype=torch.int32)
+        if hip.hipMemcpy(C.c_void_p(mine.data_ptr()), C.c_void_p(send), words * 4, 2) != 0:   # hipMemcpyDeviceToHost
+            return 1
+        parts = [torch.empty(words, dtype=torch.int32) for _ in range(world)]
+        dist.all_gather(parts, mine, group=group)
+        allw = torch.cat(parts).contiguous()
+        return 0 if hip.hipMemcpy(C.c_void_p(recv), C.c_void_p(allw.data_ptr()), world * words * 4, 1) == 0 else 1   # HostToDevice
+
+    return fn
+
+
 def _run_distributed_native(forest, max_waves, group):
     w0 = forest.stats()["waves"]
     while True:
@@ -744,7 +791,10 @@ def _run_distributed_native(forest, max_waves, group):
 def run_distributed(forest, max_waves=0, group=None):
     """Drive one shared forest over all ranks of the process group; returns waves done."""
     if forest.device_engine():
-        if _native_rccl(forest, group):
+        import torch.distributed as dist
+        # the library drives the waves itself when its context has a collective of this rank / world: the caller's
+        # (Context.set_allgather) or an RCCL communicator of its own (_native_rccl)
+        if getattr(forest.ctx, "xchg", None) == (dist.get_rank(group), dist.get_world_size(group)) or _native_rccl(forest, group):
             return _run_distributed_native(forest, max_waves, group)
         return _run_distributed_device(forest, max_waves, group)
     w0 = forest.stats()["waves"]

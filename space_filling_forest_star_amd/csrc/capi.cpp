@@ -1,5 +1,6 @@
 // capi.cpp — extern "C" surface of libsffgpu.so (declared in include/sffgpu.h).
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 
@@ -163,6 +164,11 @@ int sffgpu_rccl_unique_id(uint8_t id128[128]) {
   if (!id128) return SFFGPU_ERR_ARG;
   try { Ctx::rccl_unique_id(id128); } catch (const HipError&) { return SFFGPU_ERR_HIP; }
   return SFFGPU_OK;
+}
+int sffgpu_ctx_set_allgather(sffgpu_ctx* ctx, sffgpu_allgather_fn fn, void* user, int rank, int world) {
+  if (!ctx) return SFFGPU_ERR_ARG;
+  if (fn && (world < 1 || rank < 0 || rank >= world)) return SFFGPU_ERR_ARG;
+  GUARD(ctx, { ctx->c->sync(); ctx->c->xchg_fn = fn; ctx->c->xchg_user = user; ctx->c->xchg_rank = fn ? rank : 0; ctx->c->xchg_world = fn ? world : 1; });
 }
 int sffgpu_ctx_rccl_init(sffgpu_ctx* ctx, const uint8_t id128[128], int rank, int world) {
   if (!ctx || !id128) return SFFGPU_ERR_ARG;
@@ -443,11 +449,12 @@ int sffgpu_forest_dev_wave_begin(sffgpu_forest* f, int32_t* done) {
 }
 int sffgpu_forest_dev_round_eval(sffgpu_forest* f, void* send_dev) {
   if (!f) return SFFGPU_ERR_ARG;
-  GUARD(f->owner, f->f->dev_enqueue_round_eval(f->f->cfg.world > 1 ? send_dev : nullptr));
+  // (SFFGPU_TEST_EXCHANGE_SELF: a one-rank forest packs and unpacks too - bench.py --force-dist prices the exchange with it)
+  GUARD(f->owner, f->f->dev_enqueue_round_eval((f->f->cfg.world > 1 || getenv("SFFGPU_TEST_EXCHANGE_SELF")) ? send_dev : nullptr));
 }
 int sffgpu_forest_dev_round_commit(sffgpu_forest* f, const void* recv_dev) {
   if (!f) return SFFGPU_ERR_ARG;
-  GUARD(f->owner, f->f->dev_enqueue_round_commit(f->f->cfg.world > 1 ? recv_dev : nullptr));
+  GUARD(f->owner, f->f->dev_enqueue_round_commit((f->f->cfg.world > 1 || getenv("SFFGPU_TEST_EXCHANGE_SELF")) ? recv_dev : nullptr));
 }
 int sffgpu_forest_dev_wave_end(sffgpu_forest* f, int32_t* fault) {
   if (!f || !fault) return SFFGPU_ERR_ARG;

@@ -488,13 +488,15 @@ __global__ __launch_bounds__(1024) void k_commit(ResolveArgs A, int n_bound) {
       for (int q = 0; q < 6; ++q) s_c6[q] = c6[q];
       s_c6[6] = (unsigned long long)__popcll(wd);
       f.w_acc[b] = wa;                              // (k_append, the star stage)
+      // (the counters first, the accepted count last: the words share one 128-byte line, so whoever has seen the count
+      // finds the counters in place - the round's last workgroup used to ask for them early and mostly had to ask again)
+      for (int q = 0; q < 6; ++q) kc_publish(pub + KC_CNT + q, seq, (unsigned)c6[q]);
+      kc_publish(pub + KC_DEP, seq, (unsigned)__popcll(wd));
+      kc_publish(pub + KC_EVN, seq, (unsigned)__popcll(we));
       kc_publish(pub + KC_WLO, seq, (unsigned)(wa & 0xffffffffULL));
       kc_publish(pub + KC_WHI, seq, (unsigned)(wa >> 32));
       kc_publish(pub + KC_ACC, seq, (unsigned)__popcll(wa));
       KC_TRACE(2);
-      for (int q = 0; q < 6; ++q) kc_publish(pub + KC_CNT + q, seq, (unsigned)c6[q]);
-      kc_publish(pub + KC_DEP, seq, (unsigned)__popcll(wd));
-      kc_publish(pub + KC_EVN, seq, (unsigned)__popcll(we));
       f.w_ev[b] = we;                               // (k_border_finalize)
     }
   }
@@ -543,7 +545,7 @@ __global__ __launch_bounds__(1024) void k_commit(ResolveArgs A, int n_bound) {
   // (the last workgroup: the lower workgroups' counters were published before their counts - requested now, looked at
   // when the control block is written)
   unsigned long long early[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (last && (int)threadIdx.x < b)
+  if (last && (int)threadIdx.x < b)   // (behind the count: published before it)
     for (int q = 0; q < 8; ++q) early[q] = kc_load(f.wg_pub + (size_t)threadIdx.x * SFFK_PUB_WORDS + KC_CNT + q);
   const int acc_pref = (int)kc_block_sum(part, &s_sum);
   if (threadIdx.x == 0) {

@@ -213,6 +213,10 @@ void Ctx::rccl_init(const uint8_t* id128, int rank, int world) {
   rccl_world = world;
 }
 void Ctx::rccl_all_gather_i32(const void* send, void* recv, size_t words) {
+  if (xchg_fn) {   // the caller's collective (sffgpu_ctx_set_allgather)
+    if (xchg_fn(xchg_user, send, recv, words, stream) != 0) throw HipError{"exchange: the caller's all-gather failed"};
+    return;
+  }
   rccl_check(rccl().AllGather(send, recv, words, /* ncclInt32 */ 2, rccl_comm, stream), "ncclAllGather");
 }
 

@@ -86,6 +86,13 @@ struct Ctx {
   int rccl_rank = 0, rccl_world = 1;
   void rccl_init(const uint8_t* id128, int rank, int world);
   void rccl_all_gather_i32(const void* send, void* recv, size_t words);
+  // the caller's collective instead (sffgpu_ctx_set_allgather): same call sites as the RCCL all-gather
+  int (*xchg_fn)(void* user, const void* send_dev, void* recv_dev, size_t words_i32, void* hip_stream) = nullptr;
+  void* xchg_user = nullptr;
+  int xchg_rank = 0, xchg_world = 1;
+  bool can_exchange(int rank, int world) const {
+    return (xchg_fn && xchg_world == world && xchg_rank == rank) || (rccl_comm && rccl_world == world && rccl_rank == rank);
+  }
   static void rccl_unique_id(uint8_t* id128);
   sffk::EnvView envv{};
   sffk::RobotView robv{};

@@ -1365,9 +1365,9 @@ void Forest::round_commit(const int32_t* all, int total_words, const int32_t* co
 void Forest::run(int max_waves) {
   if (cfg.world != 1) {
     // the library's own RCCL exchange (sffgpu_ctx_rccl_init) drives a sharded device-engine forest by itself
-    if (!(dev.on && ctx->rccl_comm && ctx->rccl_world == cfg.world && ctx->rccl_rank == cfg.rank))
+    if (!(dev.on && ctx->can_exchange(cfg.rank, cfg.world)))
       throw HipError{"forest: run() drives a single-GPU forest, or a device-engine forest on a context with an RCCL "
-                     "communicator of the same rank / world; otherwise use round_begin/round_commit"};
+                     "communicator (or a caller's all-gather) of the same rank / world; otherwise use round_begin/round_commit"};
   }
   if (dev.on) { run_device(max_waves); return; }
   auto t0 = Clock::now();

@@ -1150,7 +1150,7 @@ void Forest::dev_enqueue_wave(int slot) {
   }
   // (SFFGPU_TEST_EXCHANGE_SELF: a one-rank forest packs, all-gathers and unpacks too - the collective on one GPU)
   const bool self_exchange = getenv("SFFGPU_TEST_EXCHANGE_SELF") != nullptr;
-  const bool sharded = cfg.world > 1 || (self_exchange && ctx->rccl_comm != nullptr);
+  const bool sharded = cfg.world > 1 || (self_exchange && (ctx->rccl_comm != nullptr || ctx->xchg_fn != nullptr));
   size_t words = 0;
   if (sharded) {   // this rank's answer records of a round -> all ranks' (ncclAllGather between device buffers)
     words = dev_exchange_bytes() / 4;
@@ -1451,7 +1451,9 @@ void Forest::run_device(int max_waves) {
     }
     if (fault == SFFK_FAULT_LISTS && cfg.world > 1) {
       // sharded forest: the host protocol of that wave needs the caller's variable-size record exchange
+      ++st.host_fallback_waves;
       dev_to_host();
+      on_list_fault();
       need_host_exchange = true;
       break;
     }

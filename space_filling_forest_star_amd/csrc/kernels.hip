@@ -1162,9 +1162,74 @@ __device__ __forceinline__ void pose_frame(const RobotView& rob, const double* _
   xform(R, p, rob.center, c);
 }
 
+// ---- an item with many candidate triangles is shared by the wavefronts of its workgroup (round 5).  The narrow phase
+// costs ~2.5 us per CANDIDATE whatever the number of samples (a serial loop of fp64 culls on one wavefront), and on
+// building.obj a chunk near the walls has 35 and more of them: the exact kernels' launches were as long as their one or
+// two worst items (k_collide_items 93 us on average / 317 at most per round, k_star_exact up to 403 us) while most
+// wavefronts had long finished.  The owner publishes the item in LDS (ShareSlot) and the candidate list stays where its
+// broad phase left it; owner and idle siblings take blocks of SHARE_BLK candidates off one 64-bit word (sequence << 32 |
+// next candidate: a grab names the item it belongs to), run narrow_block on their own stage / queue buffers and
+// atomicMin the first hit; the owner waits until every candidate is accounted for.  A wavefront helps only once its own
+// items are done, and leaves when all wavefronts of the workgroup are (no barrier anywhere).
+#define SEG_WAVES 4
+// when an item is shared, and in blocks of how many candidates.  A chunk's narrow phase costs per (candidate, touching
+// sample): on building.obj (a robot as wide as the corridors) 8-12 candidates x 35 samples ran 80-130 us, on dense_3D
+// 6 candidates x 64 samples 15 us - shared from `SHARE_WORK` (candidates x masked samples) on; a pose from 8 candidates on
+#ifndef SHARE_WORK
+#define SHARE_WORK 192
+#endif
+#ifndef SHARE_POSE_MIN
+#define SHARE_POSE_MIN 8
+#endif
+#define SHARE_IDLE (1 << 30)
+__device__ __forceinline__ int share_block(int nc) { return nc >= 64 ? 4 : (nc >= 24 ? 2 : 1); }
+struct ShareSlot {
+  unsigned long long sk;     // (item sequence << 32) | next candidate to hand out (>= SHARE_IDLE: nothing to take)
+  int nc, done_k, minhit, seg, chunk, kind;   // kind 0: chunk of an edge (a, b = its end points, mask); 1: pose (a = pose, b = centre, R)
+  unsigned long long mask;
+  double a[6], b[6], R[9];
+};
+struct ShareArea {
+  ShareSlot slot[SEG_WAVES];
+  int done_waves;            // wavefronts whose own items are finished
+};
+__device__ __forceinline__ unsigned long long lds_load64(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ int lds_load32(const int* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ void share_init(ShareArea& sh) {   // (every thread of the workgroup, before its first barrier)
+  if (threadIdx.x < SEG_WAVES) { sh.slot[threadIdx.x].sk = (unsigned long long)SHARE_IDLE; sh.slot[threadIdx.x].nc = 0; }
+  if (threadIdx.x == 0) sh.done_waves = 0;
+}
+
+// a block of a pose item's candidate triangles (cand[k0 .. k0 + kc)) against the posed robot: lane = robot triangle
+__device__ bool pose_block(const EnvView& env, const RobotView& rob, const double* rtri, double* stage, const int32_t* cand,
+                           int k0, int kc, const double* p, const double* R, const double* c, double rr, int lane) {
+  bool hit = false;
+  stage_candidates(env, cand, k0, kc, lane, stage);
+  for (int r0 = 0; r0 < rob.n_tri && !hit; r0 += 64) {
+    const int r = r0 + lane;
+    double Q[9];
+    const bool have = r < rob.n_tri;
+    if (have)
+      for (int v = 0; v < 3; ++v) xform(R, p, rtri + 9 * r + 3 * v, Q + 3 * v);
+    bool lane_hit = false;
+    for (int k = 0; k < kc; ++k) {
+      const double* sb = stage + k * STAGE_TRI;
+      if (plane_clear(sb + 6, c, rr)) continue;  // wave-uniform
+      if (have && !lane_hit) {
+        if (tri_box_overlap(sb, sb + 3, Q)) lane_hit = sat17(sb + 11, Q);
+      }
+    }
+    hit = __any(lane_hit);
+  }
+  __builtin_amdgcn_wave_barrier();
+  return hit;
+}
+
 // exact test of one posed robot (pose p, rotation R, bounding-sphere centre c) by one wavefront
 __device__ bool pose_exact(const EnvView& env, const RobotView& rob, const double* rtri, int32_t* stack, int32_t* cand,
-                           double* stage, const double* p, const double* R, const double* c, int lane) {
+                           double* stage, const double* p, const double* R, const double* c, int lane, ShareArea* share = nullptr) {
   // conservative query box around the posed bounding sphere
   double qlo[3], qhi[3];
   double rr = rob.radius * (1 + 1e-9) + 1e-9 * (fabs(c[0]) + fabs(c[1]) + fabs(c[2]) + 1);
@@ -1192,27 +1257,52 @@ __device__ bool pose_exact(const EnvView& env, const RobotView& rob, const doubl
       hit = __any(lane_hit);
     }
   } else {
-    // candidates staged 64 at a time; every lane poses up to ceil(n_tri/64) robot triangles and walks the stage
-    for (int k0 = 0; k0 < nc && !hit; k0 += STAGE_N) {
-      const int kc = nc - k0 < STAGE_N ? nc - k0 : STAGE_N;
-      stage_candidates(env, cand, k0, kc, lane, stage);
-      for (int r0 = 0; r0 < rob.n_tri && !hit; r0 += 64) {
-        const int r = r0 + lane;
-        double Q[9];
-        const bool have = r < rob.n_tri;
-        if (have)
-          for (int v = 0; v < 3; ++v) xform(R, p, rtri + 9 * r + 3 * v, Q + 3 * v);
-        bool lane_hit = false;
-        for (int k = 0; k < kc; ++k) {
-          const double* sb = stage + k * STAGE_TRI;
-          if (plane_clear(sb + 6, c, rr)) continue;  // wave-uniform
-          if (have && !lane_hit) {
-            if (tri_box_overlap(sb, sb + 3, Q)) lane_hit = sat17(sb + 11, Q);
-          }
+    // candidates staged 64 at a time; every lane poses up to ceil(n_tri/64) robot triangles and walks the stage - or, with
+    // many candidates, blocks of them shared with the workgroup's idle wavefronts (ShareSlot, kind 1)
+    const bool shared = share && nc >= SHARE_POSE_MIN;
+    ShareSlot* const hs = shared ? &share->slot[threadIdx.x >> 6] : nullptr;
+    unsigned seq = 0;
+    if (shared && lane == 0) {
+      seq = (unsigned)(hs->sk >> 32) + 1u;
+      hs->nc = nc; hs->done_k = 0; hs->minhit = 0x7fffffff; hs->kind = 1;
+      for (int k = 0; k < 6; ++k) hs->a[k] = p[k];
+      for (int k = 0; k < 3; ++k) hs->b[k] = c[k];
+      for (int k = 0; k < 9; ++k) hs->R[k] = R[k];
+      __threadfence_block();
+      __hip_atomic_store(&hs->sk, (unsigned long long)seq << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    const int blk = shared ? share_block(nc) : STAGE_N;
+    for (int knext = 0; !hit; knext += STAGE_N) {
+      int k0 = knext;
+      if (shared) {
+        int seen = 0x7fffffff;
+        if (lane == 0) {
+          k0 = (int)(unsigned)(atomicAdd(&hs->sk, (unsigned long long)blk) & 0xffffffffULL);
+          seen = lds_load32(&hs->minhit);
         }
-        hit = __any(lane_hit);
+        k0 = __builtin_amdgcn_readfirstlane(k0);
+        seen = __builtin_amdgcn_readfirstlane(seen);
+        if (k0 >= nc) break;
+        const int kc = nc - k0 < blk ? nc - k0 : blk;
+        const bool h = seen == 0 ? true : pose_block(env, rob, rtri, stage, cand, k0, kc, p, R, c, rr, lane);
+        if (lane == 0) {
+          if (h) atomicMin(&hs->minhit, 0);
+          atomicAdd(&hs->done_k, kc);
+        }
+        continue;   // (the owner keeps taking blocks until none is left: the word says when)
       }
-      __builtin_amdgcn_wave_barrier();
+      if (k0 >= nc) break;
+      const int kc = nc - k0 < blk ? nc - k0 : blk;
+      hit = pose_block(env, rob, rtri, stage, cand, k0, kc, p, R, c, rr, lane);
+    }
+    if (shared) {
+      int out = 0;
+      if (lane == 0) {
+        while (lds_load32(&hs->done_k) < nc) __builtin_amdgcn_s_sleep(2);
+        out = lds_load32(&hs->minhit);
+        __hip_atomic_store(&hs->sk, ((unsigned long long)seq << 32) | (unsigned long long)SHARE_IDLE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+      hit = __builtin_amdgcn_readfirstlane(out) == 0;
     }
   }
   return hit;
@@ -1260,7 +1350,6 @@ __global__ __launch_bounds__(64 * POSE_WAVES) void k_collide_poses(EnvView env, 
 }
 
 // ------------------------------------------------------------------ segment kernel
-#define SEG_WAVES 4
 // boxes of the robot triangles as loaded (no rotation): lo xyz, hi xyz per triangle, next to the triangles in LDS
 __device__ __forceinline__ void fill_robot_boxes(const double* rtri, double* rbox, int n_tri, int tid, int nthreads) {
   for (int r = tid; r < n_tri; r += nthreads)
@@ -1272,69 +1361,25 @@ __device__ __forceinline__ void fill_robot_boxes(const double* rtri, double* rbo
 
 #define QUEUE_CAP 128
 
-// One wavefront per (edge, chunk of 64 consecutive samples): lane = sample.  The chunk's own swept
-// box gives a tight broad phase; the smallest colliding sample index of an edge is reduced with
-// atomicMin, so the answer does not depend on which chunk finishes first.
-__device__ void segment_chunk(const EnvView& env, const RobotView& rob, const double* rtri, const double* rbox, int32_t* stack,
-                              int32_t* cand, int32_t* queue, double* stage, const double* a, const double* b, int seg,
-                              int chunk, bool have_mask, unsigned long long mask, int32_t* __restrict__ first_hit,
-                              int32_t* __restrict__ overflow_flag, int lane DBG_ARG) {
-  [[maybe_unused]] const unsigned long long t0_ = DBG_T();
-  DBG_ADD(0, 1);
-  const double parts = edge_parts(a, b);
-  const int ns = edge_samples(parts);
-  const int s0 = 1 + 64 * chunk;
-  if (s0 > ns) return;
-  const double dir[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
-  const int idx = s0 + lane;
-  const bool live = idx <= ns;
-  double P[3] = {0, 0, 0};
-  if (live) edge_sample_pos(a, dir, parts, idx, P);
-  const double C[3] = {P[0] + rob.center[0], P[1] + rob.center[1], P[2] + rob.center[2]};
-  // samples whose clearance bit is set need nothing; the others bound the chunk's broad-phase box
-  // (the cull kernel already looked the bits up when it hands a mask over)
-  const bool need = have_mask ? ((mask >> lane) & 1ULL) != 0 : (live && !surely_clear_edge(env, P));
-  const unsigned long long nm = __ballot(need);
-  [[maybe_unused]] const unsigned long long t1_ = DBG_T();
-  DBG_ADD(4, t1_ - t0_);
-  if (!nm) return;
-  DBG_ADD(1, 1);
-  const int l0 = __ffsll((long long)nm) - 1, l1 = 63 - __clzll((long long)nm);
-  // sample positions are monotone in the index per coordinate (monotone rounding), so the first and the
-  // last sample that need a test bound all of them; + the un-rotated robot box bounds every posed vertex
-  double F[3], L[3], qlo[3], qhi[3];
-  edge_sample_pos(a, dir, parts, s0 + l0, F);
-  edge_sample_pos(a, dir, parts, s0 + l1, L);
-  for (int k = 0; k < 3; ++k) {
-    double lo = F[k] < L[k] ? F[k] : L[k], hi = F[k] > L[k] ? F[k] : L[k];
-    double slack = 1e-9 * (fabs(lo) + fabs(hi) + 1);
-    qlo[k] = lo + rob.lo[k] - slack;
-    qhi[k] = hi + rob.hi[k] + slack;
-  }
-  WaveStack st{stack, 0, stack + STACK_CAP};
-  bool overflow;
-  int nc = collect_candidates(env, qlo, qhi, lane, st, cand, CAND_CAP, &overflow);
-  [[maybe_unused]] const unsigned long long t2_ = DBG_T();
-  DBG_ADD(5, t2_ - t1_);
-#ifdef SFFK_CI_TRACE
-  if (lane == 0) { const int gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; if (gw < 4096) { g_ci_tmp[2 * gw] = wall_clock64(); g_ci_tmp[2 * gw + 1] = (unsigned long long)nc; } }
-#endif
-  DBG_ADD(7, nc);
-  if (overflow) {
-    if (lane == 0) {   // host re-runs this edge through the pose kernel; first_hit 0 (no sample has index 0) also says so
-      atomicOr(overflow_flag + seg, 1);
-      atomicMin(first_hit + seg, 0);
-    }
-    return;
-  }
-  if (nc == 0) return;
-  DBG_ADD(2, 1);
-  const double rr = rob.radius * (1 + 1e-9) + 1e-9 * (fabs(C[0]) + fabs(C[1]) + fabs(C[2]) + 1);
-  // Narrow phase with compaction: (sample, robot triangle, candidate) triples that survive the cheap box
-  // tests are queued in LDS and the expensive exact test runs on 64 queued triples at a time, so every
-  // lane of an exact-test step does useful work.  minhit = smallest colliding sample of this chunk so far.
+// One block of an item's candidate triangles (kc <= STAGE_N of them, cand[k0 .. k0 + kc)) against the chunk's samples: the
+// narrow phase of segment_chunk.  Lane = sample (SegLane); returns the smallest colliding sample index found (minhit in:
+// what is known so far - later samples are skipped).  The wave's own stage / queue buffers; the candidate list may be
+// another wavefront's of the same workgroup (share_items).
+struct SegLane {
+  double a[3], dir[3], parts;   // (uniform) the edge: start point, b - a, dist6 / 0.1
+  int s0;                       // (uniform) first sample index of the chunk
+  int idx;                      // this lane's sample
+  bool need;
+  double P[3], C[3], rr;
+};
+__device__ int narrow_block(const EnvView& env, const RobotView& rob, const double* rtri, const double* rbox, int32_t* queue,
+                            double* stage, const int32_t* cand, int k0, int kc, const SegLane& L, int minhit, int lane DBG_ARG) {
+  const double* a = L.a; const double* dir = L.dir;
+  const double parts = L.parts, rr = L.rr;
+  const int s0 = L.s0, idx = L.idx;
+  const bool need = L.need;
+  const double* P = L.P; const double* C = L.C;
   int qn = 0;
-  int minhit = 0x7fffffff;
   auto flush = [&](int count) {
     DBG_ADD(3, 1);
     [[maybe_unused]] const unsigned long long tf_ = DBG_T();
@@ -1364,8 +1409,6 @@ __device__ void segment_chunk(const EnvView& env, const RobotView& rob, const do
     qn -= count;
     DBG_ADD(13, DBG_T() - tf_);
   };
-  for (int k0 = 0; k0 < nc; k0 += STAGE_N) {
-    const int kc = nc - k0 < STAGE_N ? nc - k0 : STAGE_N;
     [[maybe_unused]] const unsigned long long ts_ = DBG_T();
     stage_candidates(env, cand, k0, kc, lane, stage);
     DBG_ADD(10, DBG_T() - ts_);
@@ -1428,10 +1471,191 @@ __device__ void segment_chunk(const EnvView& env, const RobotView& rob, const do
         }
       }
     }
-    while (qn > 0) flush(qn < 64 ? qn : 64);   // (the stage is about to be overwritten)
-    __builtin_amdgcn_wave_barrier();
+  while (qn > 0) flush(qn < 64 ? qn : 64);   // (the stage is the caller's to overwrite after this)
+  return minhit;
+}
+
+// a wavefront whose own items are done: blocks of its siblings' items until every wavefront of the workgroup is done
+__device__ void share_help(const EnvView& env, const RobotView& rob, const double* rtri, const double* rbox, int32_t* queue,
+                           double* stage, const int32_t* cand_base, ShareArea& sh, int lane DBG_ARG) {
+  const int wave = threadIdx.x >> 6;
+  if (lane == 0) atomicAdd(&sh.done_waves, 1);
+  while (true) {
+    bool worked = false;
+    for (int w2 = 0; w2 < SEG_WAVES; ++w2) {
+      if (w2 == wave) continue;
+      ShareSlot& hs = sh.slot[w2];
+      int k0 = SHARE_IDLE, nc = 0, blk = 1;
+      if (lane == 0) {
+        const unsigned long long cur = lds_load64(&hs.sk);
+        const int nc0 = lds_load32(&hs.nc);
+        if ((int)(unsigned)(cur & 0xffffffffULL) < nc0) {
+          // (the grab names its item: the parameters read behind it are that item's - the owner cannot leave the item
+          // before the block is accounted for; whoever reserves [k0, k0 + blk) works on exactly that range)
+          blk = share_block(nc0);
+          k0 = (int)(unsigned)(atomicAdd(&hs.sk, (unsigned long long)blk) & 0xffffffffULL);
+          __threadfence_block();
+          nc = lds_load32(&hs.nc);
+        }
+      }
+      __threadfence_block();
+      k0 = __builtin_amdgcn_readfirstlane(k0);
+      nc = __builtin_amdgcn_readfirstlane(nc);
+      blk = __builtin_amdgcn_readfirstlane(blk);
+      if (k0 >= nc) continue;
+      worked = true;
+      const int kc = nc - k0 < blk ? nc - k0 : blk;
+      int mh = 0;
+      if (lane == 0) mh = lds_load32(&hs.minhit);
+      mh = __builtin_amdgcn_readfirstlane(mh);
+      if (hs.kind == 1) {   // a pose: a = the pose, b = the sphere centre, R
+        if (mh != 0) {
+          double pp[6], RR[9], cc[3];
+          for (int k = 0; k < 6; ++k) pp[k] = hs.a[k];
+          for (int k = 0; k < 3; ++k) cc[k] = hs.b[k];
+          for (int k = 0; k < 9; ++k) RR[k] = hs.R[k];
+          const double rr = rob.radius * (1 + 1e-9) + 1e-9 * (fabs(cc[0]) + fabs(cc[1]) + fabs(cc[2]) + 1);
+          if (pose_block(env, rob, rtri, stage, cand_base + w2 * CAND_CAP, k0, kc, pp, RR, cc, rr, lane)) mh = 0;
+        }
+      } else {
+        double a[6], b[6];
+        for (int k = 0; k < 6; ++k) { a[k] = hs.a[k]; b[k] = hs.b[k]; }
+        const unsigned long long mask = hs.mask;
+        const int chunk = hs.chunk;
+        SegLane L;
+        L.parts = edge_parts(a, b);
+        L.s0 = 1 + 64 * chunk;
+        for (int k = 0; k < 3; ++k) { L.a[k] = a[k]; L.dir[k] = b[k] - a[k]; L.P[k] = 0.0; }
+        L.idx = L.s0 + lane;
+        L.need = ((mask >> lane) & 1ULL) != 0;
+        if (L.idx <= edge_samples(L.parts)) edge_sample_pos(L.a, L.dir, L.parts, L.idx, L.P);
+        for (int k = 0; k < 3; ++k) L.C[k] = L.P[k] + rob.center[k];
+        L.rr = rob.radius * (1 + 1e-9) + 1e-9 * (fabs(L.C[0]) + fabs(L.C[1]) + fabs(L.C[2]) + 1);
+        mh = narrow_block(env, rob, rtri, rbox, queue, stage, cand_base + w2 * CAND_CAP, k0, kc, L, mh, lane DBG_PASS);
+      }
+      __builtin_amdgcn_wave_barrier();
+      if (lane == 0) {
+        if (mh != 0x7fffffff) atomicMin(&hs.minhit, mh);
+        __threadfence_block();
+        atomicAdd(&hs.done_k, kc);
+      }
+    }
+    if (!worked) {
+      int dw = 0;
+      if (lane == 0) dw = lds_load32(&sh.done_waves);
+      if (__builtin_amdgcn_readfirstlane(dw) >= SEG_WAVES) break;
+      // (a waiting wavefront shares its SIMD with a working one of another workgroup: it looks again every ~0.5 us, not
+      // every few hundred cycles)
+      __builtin_amdgcn_s_sleep(20);
+    }
   }
-  while (qn > 0) flush(qn < 64 ? qn : 64);
+}
+
+// One wavefront per (edge, chunk of 64 consecutive samples): lane = sample.  The chunk's own swept
+// box gives a tight broad phase; the smallest colliding sample index of an edge is reduced with
+// atomicMin, so the answer does not depend on which chunk finishes first.
+__device__ void segment_chunk(const EnvView& env, const RobotView& rob, const double* rtri, const double* rbox, int32_t* stack,
+                              int32_t* cand, int32_t* queue, double* stage, const double* a, const double* b, int seg,
+                              int chunk, bool have_mask, unsigned long long mask, int32_t* __restrict__ first_hit,
+                              int32_t* __restrict__ overflow_flag, int lane DBG_ARG, ShareArea* share = nullptr) {
+  [[maybe_unused]] const unsigned long long t0_ = DBG_T();
+  DBG_ADD(0, 1);
+  const double parts = edge_parts(a, b);
+  const int ns = edge_samples(parts);
+  const int s0 = 1 + 64 * chunk;
+  if (s0 > ns) return;
+  const double dir[3] = {b[0] - a[0], b[1] - a[1], b[2] - a[2]};
+  const int idx = s0 + lane;
+  const bool live = idx <= ns;
+  double P[3] = {0, 0, 0};
+  if (live) edge_sample_pos(a, dir, parts, idx, P);
+  const double C[3] = {P[0] + rob.center[0], P[1] + rob.center[1], P[2] + rob.center[2]};
+  // samples whose clearance bit is set need nothing; the others bound the chunk's broad-phase box
+  // (the cull kernel already looked the bits up when it hands a mask over)
+  const bool need = have_mask ? ((mask >> lane) & 1ULL) != 0 : (live && !surely_clear_edge(env, P));
+  const unsigned long long nm = __ballot(need);
+  [[maybe_unused]] const unsigned long long t1_ = DBG_T();
+  DBG_ADD(4, t1_ - t0_);
+  if (!nm) return;
+  DBG_ADD(1, 1);
+  const int l0 = __ffsll((long long)nm) - 1, l1 = 63 - __clzll((long long)nm);
+  // sample positions are monotone in the index per coordinate (monotone rounding), so the first and the
+  // last sample that need a test bound all of them; + the un-rotated robot box bounds every posed vertex
+  double F[3], L[3], qlo[3], qhi[3];
+  edge_sample_pos(a, dir, parts, s0 + l0, F);
+  edge_sample_pos(a, dir, parts, s0 + l1, L);
+  for (int k = 0; k < 3; ++k) {
+    double lo = F[k] < L[k] ? F[k] : L[k], hi = F[k] > L[k] ? F[k] : L[k];
+    double slack = 1e-9 * (fabs(lo) + fabs(hi) + 1);
+    qlo[k] = lo + rob.lo[k] - slack;
+    qhi[k] = hi + rob.hi[k] + slack;
+  }
+  WaveStack st{stack, 0, stack + STACK_CAP};
+  bool overflow;
+  int nc = collect_candidates(env, qlo, qhi, lane, st, cand, CAND_CAP, &overflow);
+  [[maybe_unused]] const unsigned long long t2_ = DBG_T();
+  DBG_ADD(5, t2_ - t1_);
+#ifdef SFFK_CI_TRACE
+  if (lane == 0) { const int gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6; if (gw < 4096) { g_ci_tmp[2 * gw] = wall_clock64(); g_ci_tmp[2 * gw + 1] = (unsigned long long)nc; } }
+#endif
+  DBG_ADD(7, nc);
+  if (overflow) {
+    if (lane == 0) {   // host re-runs this edge through the pose kernel; first_hit 0 (no sample has index 0) also says so
+      atomicOr(overflow_flag + seg, 1);
+      atomicMin(first_hit + seg, 0);
+    }
+    return;
+  }
+  if (nc == 0) return;
+  DBG_ADD(2, 1);
+  SegLane SL;
+  for (int k = 0; k < 3; ++k) { SL.a[k] = a[k]; SL.dir[k] = dir[k]; SL.P[k] = P[k]; SL.C[k] = C[k]; }
+  SL.parts = parts; SL.s0 = s0; SL.idx = idx; SL.need = need;
+  SL.rr = rob.radius * (1 + 1e-9) + 1e-9 * (fabs(C[0]) + fabs(C[1]) + fabs(C[2]) + 1);
+  int minhit = 0x7fffffff;
+  // many candidates: the item is published for the workgroup's idle wavefronts (ShareSlot) and the candidates are taken in
+  // blocks of SHARE_BLK off the shared word - by this wavefront too; otherwise STAGE_N at a time, all here (one call site
+  // of narrow_block for both: the exact kernel sits at its register limit)
+  const bool shared = share && nc >= 4 && nc * __popcll(nm) >= SHARE_WORK;
+  ShareSlot* const hs = shared ? &share->slot[threadIdx.x >> 6] : nullptr;
+  unsigned seq = 0;
+  if (shared && lane == 0) {
+    seq = (unsigned)(hs->sk >> 32) + 1u;
+    hs->nc = nc; hs->done_k = 0; hs->minhit = 0x7fffffff; hs->seg = seg; hs->chunk = chunk; hs->mask = nm; hs->kind = 0;
+    for (int k = 0; k < 6; ++k) { hs->a[k] = a[k]; hs->b[k] = b[k]; }
+    __threadfence_block();
+    __hip_atomic_store(&hs->sk, (unsigned long long)seq << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+  const int blk = shared ? share_block(nc) : STAGE_N;
+  for (int knext = 0; ; knext += STAGE_N) {
+    int k0 = knext;
+    if (shared) {
+      if (lane == 0) {
+        k0 = (int)(unsigned)(atomicAdd(&hs->sk, (unsigned long long)blk) & 0xffffffffULL);
+        const int mh = lds_load32(&hs->minhit);
+        if (mh < minhit) minhit = mh;
+      }
+      k0 = __builtin_amdgcn_readfirstlane(k0);
+      minhit = __builtin_amdgcn_readfirstlane(minhit);
+    }
+    if (k0 >= nc) break;
+    const int kc = nc - k0 < blk ? nc - k0 : blk;
+    minhit = narrow_block(env, rob, rtri, rbox, queue, stage, cand, k0, kc, SL, minhit, lane DBG_PASS);
+    __builtin_amdgcn_wave_barrier();
+    if (shared && lane == 0) {
+      if (minhit != 0x7fffffff) atomicMin(&hs->minhit, minhit);
+      atomicAdd(&hs->done_k, kc);
+    }
+  }
+  if (shared) {
+    if (lane == 0) {
+      while (lds_load32(&hs->done_k) < nc) __builtin_amdgcn_s_sleep(2);   // the siblings' blocks
+      minhit = lds_load32(&hs->minhit);
+      // (idle again, same sequence: a late grab finds nothing to take)
+      __hip_atomic_store(&hs->sk, ((unsigned long long)seq << 32) | (unsigned long long)SHARE_IDLE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    minhit = __builtin_amdgcn_readfirstlane(minhit);
+  }
   DBG_ADD(6, DBG_T() - t2_);
   if (minhit != 0x7fffffff && lane == 0) atomicMin(first_hit + seg, minhit);
 }
@@ -2909,6 +3133,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB_OCC))) v
 #ifndef CI_OCC
 #define CI_OCC 2
 #endif
+// SHARE: many-candidate items are shared by the workgroup's wavefronts (share_help).  Two instantiations: the sharing code
+// costs the kernel its last free registers (256 VGPRs + spills, + 7 % on dense_3D, whose items have 2-8 candidates), so
+// small environments run the one without it (launch_collide_items).
+template <bool SHARE>
 __global__ __launch_bounds__(64 * SEG_WAVES) __attribute__((amdgpu_waves_per_eu(CI_OCC))) void k_collide_items(EnvView env, RobotView rob, const double* __restrict__ pos6,
                                                                   int n_pose, const int32_t* __restrict__ live_flags,
                                                                   uint8_t* __restrict__ pose_hit,
@@ -2989,6 +3217,8 @@ __global__ __launch_bounds__(64 * SEG_WAVES) __attribute__((amdgpu_waves_per_eu(
   const bool ran_over = ctrl3 != 0;
   if (blockIdx.x == 0 && threadIdx.x == 0) ctrl[2] = M;   // (statistics)
   if ((M <= 0 && !ran_over) || env.n_tri == 0) return;   // (uniform over the launch: no barrier is left waiting)
+  __shared__ ShareArea s_share;
+  share_init(s_share);
   __syncthreads();
   double* rbox = reinterpret_cast<double*>(ibase + SEG_WAVES * (STACK_CAP + TG_HASH + CAND_CAP + QUEUE_CAP));
   fill_robot_boxes(rtri, rbox, rob.n_tri, threadIdx.x, blockDim.x);
@@ -3057,7 +3287,7 @@ __global__ __launch_bounds__(64 * SEG_WAVES) __attribute__((amdgpu_waves_per_eu(
       const unsigned long long ci_p0 = wall_clock64();
 #endif
       pose_frame(rob, pos6, pose, p, R, c);
-      const bool hit = pose_exact(env, rob, rtri, stack, cand, stage, p, R, c, lane);
+      const bool hit = pose_exact(env, rob, rtri, stack, cand, stage, p, R, c, lane, (SHARE && !ran_over) ? &s_share : nullptr);
       if (lane == 0) pose_hit[pose] = hit ? 1 : 0;
 #ifdef SFFK_CI_TRACE
       ci_first[3] += ((wall_clock64() - ci_p0) << 8) | 1ULL;   // (time << 8 | count)
@@ -3088,13 +3318,16 @@ __global__ __launch_bounds__(64 * SEG_WAVES) __attribute__((amdgpu_waves_per_eu(
 #ifdef SFFK_CI_TRACE
       const unsigned long long ci_a = wall_clock64();
 #endif
-      segment_chunk(env, rob, rtri, rbox, stack, cand, queue, stage, a, b, slot, chunk, !ran_over, mask, first_hit, overflow_flag, lane DBG_PASS);
+      segment_chunk(env, rob, rtri, rbox, stack, cand, queue, stage, a, b, slot, chunk, !ran_over, mask, first_hit, overflow_flag, lane DBG_PASS,
+                    (SHARE && !ran_over) ? &s_share : nullptr);
 #ifdef SFFK_CI_TRACE
       if (ci_items == 0) { ci_first[0] = ci_a; ci_first[1] = wall_clock64(); ci_first[2] = (unsigned long long)__popcll(mask); }
       ++ci_items;
 #endif
     }
   }
+  // own items done: blocks of the siblings' many-candidate items (share_help), until the whole workgroup is through
+  if (SHARE) share_help(env, rob, rtri, rbox, queue, stage, ibase + SEG_WAVES * (STACK_CAP + TG_HASH), s_share, lane DBG_PASS);
 #ifdef SFFK_CI_TRACE
   if (ci_on && lane == 0) {
     const int gw = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -3133,6 +3366,8 @@ __global__ __launch_bounds__(64 * SEG_WAVES) __attribute__((amdgpu_waves_per_eu(
   }
   const int M = __shfl(sub_incl, 63);
   if (M <= 0 || env.n_tri == 0) return;
+  __shared__ ShareArea s_share;
+  share_init(s_share);
   for (int i = threadIdx.x; i < rob.n_tri * 9; i += blockDim.x) rtri[i] = rob.tri[i];
   __syncthreads();
   double* rbox = reinterpret_cast<double*>(ibase + SEG_WAVES * (STACK_CAP + TG_HASH + CAND_CAP + QUEUE_CAP));
@@ -3162,8 +3397,10 @@ __global__ __launch_bounds__(64 * SEG_WAVES) __attribute__((amdgpu_waves_per_eu(
     const double* pa = store_pos + 6 * (size_t)ida[slot];
     const double* pb = store_pos + 6 * (size_t)idb[slot];
     for (int k = 0; k < 6; ++k) { a[k] = pa[k]; b[k] = pb[k]; }
-    segment_chunk(env, rob, rtri, rbox, stack, cand, queue, stage, a, b, slot, it.chunk, true, it.mask, first_hit, overflow_flag, lane DBG_PASS);
+    segment_chunk(env, rob, rtri, rbox, stack, cand, queue, stage, a, b, slot, it.chunk, true, it.mask, first_hit, overflow_flag, lane DBG_PASS,
+                  &s_share);
   }
+  share_help(env, rob, rtri, rbox, queue, stage, ibase + SEG_WAVES * (STACK_CAP + TG_HASH), s_share, lane DBG_PASS);
 }
 
 // Samples whose fate needs no in-order replay (src/forest.h:246-299): rejected by their own pose or parent-edge
@@ -4052,10 +4289,15 @@ void launch_collide_items(hipStream_t s, const EnvView& env, const RobotView& ro
     if (cap_override >= 0 && cap_override < items_cap) items_cap = cap_override;
   }
   size_t lds = collide_lds_bytes(rob.n_tri, SEG_WAVES);
-  if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_collide_items), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  // many-candidate items shared by the workgroup's wavefronts: environments of more than 4 096 triangles (building.obj:
+  // 26 908, chunks with 35-130 candidates; dense_3D's 1 832 give 2-8 per item); SFFGPU_SHARE=0 / 1 overrides
+  const char* se = getenv("SFFGPU_SHARE");
+  const bool share = se ? atoi(se) != 0 : env.n_tri > 4096;
+  auto kern = share ? k_collide_items<true> : k_collide_items<false>;
+  if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   // 2 workgroups of 4 waves per CU = what the exact kernel's register budget keeps resident (256 CUs)
   static const int blocks = std::min(4096, std::max(1, getenv("SFFGPU_SEG_BLOCKS") ? atoi(getenv("SFFGPU_SEG_BLOCKS")) : 256 * CI_OCC));
-  hipLaunchKernelGGL(k_collide_items, dim3(blocks), dim3(64 * SEG_WAVES), lds, s, env, rob, pos6, n_pose, live_flags, pose_hit,
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(64 * SEG_WAVES), lds, s, env, rob, pos6, n_pose, live_flags, pose_hit,
                      a6, b6, seg_ns, stride, ctrl, static_cast<const SurvivorItem*>(items), items_cap, sub, first_hit,
                      overflow_flag,
                      temps ? temps->tg : GridView{}, temps ? temps->x : nullptr, temps ? temps->y : nullptr,

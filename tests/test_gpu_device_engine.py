@@ -228,6 +228,25 @@ def test_spatial_order_of_the_slots_changes_nothing(S, ctx):
         fn.close()
 
 
+def test_many_candidate_items_shared_by_the_workgroup_change_nothing(S, ctx):
+    """round 5: an exact-kernel item (edge chunk or pose) with many candidate triangles is worked off in blocks by the
+    idle wavefronts of its workgroup (share_help in csrc/kernels.hip; environments above 4 096 triangles by default).
+    SFFGPU_SHARE=0 / 1 forces the choice at every launch: same forest - and the oracle's - either way, plain SFF and SFF*."""
+    for name, wave, iters, optimize in (("building", 2048, 50000, False), ("building", 1024, 20000, True),
+                                        ("dense3d", 1024, 30000, False)):
+        fps = []
+        for share in ("0", "1"):
+            with engine(SFFGPU_SHARE=share):
+                fo, fg = make(S, ctx, name, wave, iters, seed=9, optimize=optimize)
+                fg.run()
+                if share == "0":
+                    fo.run()
+                    assert_same_forest(fo, fg)
+                fps.append((fg.fingerprint(), fg.stats()["collide_calls"], fg.stats()["path_free_calls"]))
+                fg.close()
+        assert fps[0] == fps[1]
+
+
 def test_saturating_forest_terminates_solved_with_closed_list_picks(S, ctx):
     """coarse steps: the frontier runs empty, the engine keeps expanding from the closed list (src/forest.h:
     136-141) until every tree is connected -> solved"""

@@ -30,15 +30,22 @@ def free_port():
 
 # (SFF and SFF* run on the device-resident engine at every wave size: answer records all-gathered between device
 #  buffers, commit - and for SFF* the rewire fixed point - replicated on every rank's GPU)
-@pytest.mark.parametrize("name,world,wave,iters,optimize", [("dense3d", 2, 512, 12000, 0), ("triang", 3, 256, 6000, 1),
-                                                             ("dense3d", 4, 1024, 40000, 0), ("dense3d", 2, 64, 3000, 0)])
-def test_sharded_forest_across_processes_equals_the_oracle(name, world, wave, iters, optimize):
+# driver "library": sffgpu_forest_run enqueues whole waves, one ahead, and issues the collective itself through the
+# all-gather the context was given (sffgpu_ctx_set_allgather; here staged through the host over gloo) - the call
+# sequence of bench.py --native-rccl with ncclAllGather, run with 2 and 4 ranks; fault_rank: ONE rank shrinks its hit
+# lists, the overflow flags travel in the records and every rank falls back for the same rounds
+@pytest.mark.parametrize("name,world,wave,iters,optimize,driver,fault_rank",
+                         [("dense3d", 2, 512, 12000, 0, "caller", -1), ("triang", 3, 256, 6000, 1, "caller", -1),
+                          ("dense3d", 4, 1024, 40000, 0, "caller", -1), ("dense3d", 2, 64, 3000, 0, "caller", -1),
+                          ("dense3d", 2, 512, 12000, 0, "library", -1), ("dense3d", 4, 1024, 30000, 0, "library", -1),
+                          ("dense3d_coarse", 2, 512, 12000, 0, "library", 1), ("dense3d_coarse", 2, 512, 12000, 0, "caller", 0)])
+def test_sharded_forest_across_processes_equals_the_oracle(name, world, wave, iters, optimize, driver, fault_rank):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     for attempt in range(3):   # (the rendezvous port is free when it is picked, not necessarily seconds later: retry on EADDRINUSE)
         port = free_port()
         files = [(tempfile.TemporaryFile("w+"), tempfile.TemporaryFile("w+")) for _ in range(world)]
         procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "mp_forest_worker.py"), str(r), str(world),
-                                   str(port), name, str(wave), str(iters), "3", str(optimize)],
+                                   str(port), name, str(wave), str(iters), "3", str(optimize), driver, str(fault_rank)],
                                   stdout=files[r][0], stderr=files[r][1], text=True, env=env) for r in range(world)]
         # (a rank that dies leaves the others waiting in the rendezvous: end them with it)
         t_end = time.time() + 600
@@ -78,3 +85,6 @@ def test_sharded_forest_across_processes_equals_the_oracle(name, world, wave, it
     # the candidates were sharded: no rank evaluated all poses, together they evaluated each exactly once
     ex = np.array([o["executed"] for o in outs])
     assert ex.max() < 0.75 * ex.sum() and ex.min() > 0
+    if fault_rank >= 0:   # the forced overflow really happened, and every rank handed the same waves to the host protocol
+        assert outs[0]["host_fallback_waves"] > 0
+        assert len({o["host_fallback_waves"] for o in outs}) == 1
