@@ -142,6 +142,16 @@ __global__ __launch_bounds__(256) void k_star_knn(ResolveArgs A, GridView g, Gri
   const int mine = st.tree[self];
   double qp[6];
   for (int q = 0; q < 6; ++q) qp[q] = A.newpos[6 * (size_t)i + q];
+  // (round 5) what the END of this kernel needs is asked for now, beside the cube's own loads: the earlier accepted samples
+  // of the round (rank -> sample -> tree: two dependent trips that used to follow the cube and the shells, 12.5 us per
+  // sample) and lane 0's first guess (expanded node -> its cost)
+  int sidv[STAR_MATE_U];
+  const bool mates_small = r > 0 && r <= 64 * STAR_MATE_U;
+#pragma unroll
+  for (int u = 0; u < STAR_MATE_U; ++u) { const int rq = 64 * u + lane; sidv[u] = (mates_small && rq < r) ? Tb + S.acc_sample[rq] : -1; }
+  const int ex0 = A.parent[i];
+  const double pd0 = A.pdist[i];
+  const int no_raw = g.ovf_cnt[0];
   const int tcnt = S.tree_cnt[16 * mine];
   {   // the sample's edge slots: nothing asked for yet
     const size_t s0 = ((size_t)i * SFFK_STAR_KC + lane) * 2;
@@ -155,13 +165,18 @@ __global__ __launch_bounds__(256) void k_star_knn(ResolveArgs A, GridView g, Gri
   const int k_store = k < tcnt ? k : tcnt;
   TopK t{1.0e300, 0x7fffffff};
   int have = 0;
+  int trv[STAR_MATE_U];
+#pragma unroll
+  for (int u = 0; u < STAR_MATE_U; ++u) trv[u] = -1;
+  double dr0 = 0.0;
+  if (k <= 0) dr0 = f.d_root[ex0];
   if (k > 0) {
     const int cx = grid_coord((float)qp[0], g.ox, g.inv_cell, g.nx), cy = grid_coord((float)qp[1], g.oy, g.inv_cell, g.ny),
               cz = grid_coord((float)qp[2], g.oz, g.inv_cell, g.nz);
     // ---- the cube of half-width R0 in one go: every cell's count is requested before anything is looked at (one
     // trip to memory instead of one per shell), then the cube's candidates are flattened over the lanes
     int cellv[STAR_U], mv[STAR_U];
-    const int no_raw = g.ovf_cnt[0];
+    GridItem ovf_pre[2];
     const int W5 = 2 * R0 + 1, cube = W5 * W5 * W5;
 #pragma unroll
     for (int u = 0; u < STAR_U; ++u) {
@@ -174,6 +189,17 @@ __global__ __launch_bounds__(256) void k_star_knn(ResolveArgs A, GridView g, Gri
           mv[u] = g.cnt[cellv[u]];
         }
       }
+    }
+    // (the second trips of the loads asked for at the top go out while the cube's counts are on their way; so do the first
+    // 128 entries of the node grid's shared overflow list, which every sample scans after its cube)
+#pragma unroll
+    for (int u = 0; u < STAR_MATE_U; ++u) trv[u] = sidv[u] >= 0 ? st.tree[sidv[u]] : -1;
+    dr0 = f.d_root[ex0];
+    const int no_pre = no_raw < g.ovf_cap ? no_raw : g.ovf_cap;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      ovf_pre[h].id = 0x7fffffff; ovf_pre[h].tree = -1;
+      if (64 * h + lane < no_pre) ovf_pre[h] = g.ovf[64 * h + lane];
     }
 #pragma unroll
     for (int u = 0; u < STAR_U; ++u) if (mv[u] > g.bk) mv[u] = g.bk;
@@ -237,34 +263,62 @@ __global__ __launch_bounds__(256) void k_star_knn(ResolveArgs A, GridView g, Gri
       }
       {
         if (S.dbg) dbg_c2 = wall_clock64();
+        // Selection of the k smallest keys (distance bits, then id) among the pool, round 5: the bisection runs on the HIGH
+        // 32 bits of the keys first (a 32-bit compare per batch and round instead of a 64-bit one, 31 rounds instead of 63,
+        // only the batches the cube filled); everything below the boundary value is in, the (usually single) keys that
+        // share the boundary's high word are told apart by their low words, equal distances by their ids - the same set as
+        // the 63-round bisection on the whole key picked.
+        const int nbat = (total + 63) >> 6;           // batches of the pool that hold candidates
+        unsigned hi[STAR_POOL], lo[STAR_POOL];
         int n_valid = 0;
 #pragma unroll
-        for (int b = 0; b < STAR_POOL; ++b) n_valid += __popcll(__ballot(kb[b] < STAR_INF_BITS));
-        unsigned long long V = STAR_INF_BITS;     // winners: key < V, or key == V with id <= I
+        for (int b = 0; b < STAR_POOL; ++b) {
+          hi[b] = (unsigned)(kb[b] >> 32); lo[b] = (unsigned)(kb[b] & 0xffffffffULL);
+          if (b < nbat) n_valid += __popcll(__ballot(kb[b] < STAR_INF_BITS));
+        }
+        const unsigned INF_HI = (unsigned)(STAR_INF_BITS >> 32);
+        unsigned Vh = INF_HI, Vl = 0xffffffffu;       // winners: hi < Vh, or hi == Vh with (lo < Vl, or lo == Vl with id <= I)
         int I = 0x7fffffff;
         if (n_valid > k) {
-          V = 0ULL;
-          for (int bit = 62; bit >= 0; --bit) {   // V = the k-th smallest distance: the largest x with count(key < x) < k
-            const unsigned long long trial = V | (1ULL << bit);
+          Vh = 0u;
+          for (int bit = 30; bit >= 0; --bit) {       // Vh = high word of the k-th smallest key: the largest x with count(hi < x) < k
+            const unsigned trial = Vh | (1u << bit);
             int cnt_less = 0;
 #pragma unroll
-            for (int b = 0; b < STAR_POOL; ++b) cnt_less += __popcll(__ballot(kb[b] < trial));
-            if (cnt_less < k) V = trial;
+            for (int b = 0; b < STAR_POOL; ++b) if (b < nbat) cnt_less += __popcll(__ballot(hi[b] < trial));
+            if (cnt_less < k) Vh = trial;
           }
-          int c_less = 0, ties = 0;
+          int cA = 0, tB = 0;
 #pragma unroll
-          for (int b = 0; b < STAR_POOL; ++b) { c_less += __popcll(__ballot(kb[b] < V)); ties += __popcll(__ballot(kb[b] == V)); }
-          const int need = k - c_less;
-          if (ties > need) {                      // equal distances: the smallest ids among them
-            unsigned int Iu = 0u;
-            for (int bit = 30; bit >= 0; --bit) {
-              const unsigned int trial = Iu | (1u << bit);
+          for (int b = 0; b < STAR_POOL; ++b)
+            if (b < nbat) { cA += __popcll(__ballot(hi[b] < Vh)); tB += __popcll(__ballot(hi[b] == Vh)); }
+          const int needB = k - cA;
+          if (tB > needB) {                            // several keys share the boundary's high word: their low words
+            Vl = 0u;
+            for (int bit = 31; bit >= 0; --bit) {
+              const unsigned trial = Vl | (1u << bit);
               int cl = 0;
 #pragma unroll
-              for (int b = 0; b < STAR_POOL; ++b) cl += __popcll(__ballot(kb[b] == V && (unsigned int)kid[b] < trial));
-              if (cl < need) Iu = trial;
+              for (int b = 0; b < STAR_POOL; ++b) if (b < nbat) cl += __popcll(__ballot(hi[b] == Vh && lo[b] < trial));
+              if (cl < needB) Vl = trial;
             }
-            I = (int)Iu;
+            int cB = 0, tC = 0;
+#pragma unroll
+            for (int b = 0; b < STAR_POOL; ++b)
+              if (b < nbat) { cB += __popcll(__ballot(hi[b] == Vh && lo[b] < Vl)); tC += __popcll(__ballot(hi[b] == Vh && lo[b] == Vl)); }
+            const int needC = needB - cB;
+            if (tC > needC) {                          // equal distances: the smallest ids among them
+              unsigned int Iu = 0u;
+              for (int bit = 30; bit >= 0; --bit) {
+                const unsigned int trial = Iu | (1u << bit);
+                int cl = 0;
+#pragma unroll
+                for (int b = 0; b < STAR_POOL; ++b)
+                  if (b < nbat) cl += __popcll(__ballot(hi[b] == Vh && lo[b] == Vl && (unsigned int)kid[b] < trial));
+                if (cl < needC) Iu = trial;
+              }
+              I = (int)Iu;
+            }
           }
         }
         if (S.dbg) dbg_c3 = wall_clock64();
@@ -274,7 +328,8 @@ __global__ __launch_bounds__(256) void k_star_knn(ResolveArgs A, GridView g, Gri
         int nsel = 0;
 #pragma unroll
         for (int b = 0; b < STAR_POOL; ++b) {
-          const bool win = kb[b] < V || (kb[b] == V && kb[b] < STAR_INF_BITS && kid[b] <= I);
+          const bool win = b < nbat && kb[b] < STAR_INF_BITS &&
+                           (hi[b] < Vh || (hi[b] == Vh && (lo[b] < Vl || (lo[b] == Vl && kid[b] <= I))));
           const unsigned long long m = __ballot(win);
           if (win) {
             const int at = nsel + __popcll(m & ((1ULL << lane) - 1ULL));
@@ -328,7 +383,7 @@ __global__ __launch_bounds__(256) void k_star_knn(ResolveArgs A, GridView g, Gri
         int id = 0x7fffffff;
         const double worst = topk_worst(t, k, have);
         if (j < no) {
-          const GridItem it = g.ovf[j];
+          const GridItem it = base == 0 ? ovf_pre[0] : (base == 64 ? ovf_pre[1] : g.ovf[j]);
           id = it.id;
           if (id < N0 && it.tree == mine) {
             d = dist6(it.p, qp);
@@ -346,22 +401,42 @@ __global__ __launch_bounds__(256) void k_star_knn(ResolveArgs A, GridView g, Gri
       if (have >= k_store && k_store == tcnt) break;      // the whole tree is in the list
       if (rr > R0) {
         ++dbg_shells;
+        // only the shell's own cells (two caps of w x w, w - 2 rings of 8 rr: 24 rr^2 + 2 of the cube's (2 rr + 1)^3 - the
+        // loop used to run over the whole cube and mask its inside), four cells per lane and trip so that the counts of
+        // 256 cells are on their way together (round 5, like k_knn_grid)
         const int w = 2 * rr + 1;
-        const int total = w * w * w;
-        for (int c0 = 0; c0 < total; c0 += 64) {
-          const int cc = c0 + lane;
-          int cell = 0, m = 0;
-          if (cc < total) {
-            const int ox = cc % w - rr, oy = (cc / w) % w - rr, oz = cc / (w * w) - rr;
-            const bool shell = ox == -rr || ox == rr || oy == -rr || oy == rr || oz == -rr || oz == rr;
-            const int x = cx + ox, y = cy + oy, z = cz + oz;
-            if (shell && x >= 0 && x < g.nx && y >= 0 && y < g.ny && z >= 0 && z < g.nz) {
-              cell = (z * g.ny + y) * g.nx + x;
-              m = g.cnt[cell];
-              if (m > g.bk) m = g.bk;
+        const int ww = w * w, ring = 8 * rr;
+        const int total = 2 * ww + (w - 2) * ring;
+        for (int c0 = 0; c0 < total; c0 += 256) {
+          int cellq[4], mq[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int cq = c0 + u * 64 + lane;
+            cellq[u] = 0; mq[u] = 0;
+            if (cq < total) {
+              int ox, oy, oz;
+              if (cq < 2 * ww) {
+                const int face = cq >= ww ? 1 : 0, ii = cq - face * ww;
+                ox = ii % w - rr; oy = ii / w - rr; oz = face ? rr : -rr;
+              } else {
+                const int cc = cq - 2 * ww;
+                const int layer = cc / ring, pp = cc - layer * ring;
+                const int side = pp / (2 * rr), t_ = pp - side * 2 * rr;
+                oz = -rr + 1 + layer;
+                ox = side == 0 ? -rr + t_ : side == 1 ? rr : side == 2 ? rr - t_ : -rr;
+                oy = side == 0 ? -rr : side == 1 ? -rr + t_ : side == 2 ? rr : rr - t_;
+              }
+              const int x = cx + ox, y = cy + oy, z = cz + oz;
+              if (x >= 0 && x < g.nx && y >= 0 && y < g.ny && z >= 0 && z < g.nz) {
+                cellq[u] = (z * g.ny + y) * g.nx + x;
+                mq[u] = g.cnt[cellq[u]];
+                if (mq[u] > g.bk) mq[u] = g.bk;
+              }
             }
           }
-          if (__any(m > 0)) star_cells(g, m, cell, lane, qp, mine, N0, t, k, have);
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            if (__any(mq[u] > 0)) star_cells(g, mq[u], cellq[u], lane, qp, mine, N0, t, k, have);
         }
       }
       const double covered = (double)rr * cell_edge - slack;
@@ -377,11 +452,6 @@ __global__ __launch_bounds__(256) void k_star_knn(ResolveArgs A, GridView g, Gri
       if (r <= 64 * STAR_MATE_U) {
         // k_commit's list of the accepted samples: every rank's sample and tree are requested up front (two trips to
         // memory whatever the length), the few of the same tree are compacted in LDS and measured a batch at a time
-        int sidv[STAR_MATE_U], trv[STAR_MATE_U];
-#pragma unroll
-        for (int u = 0; u < STAR_MATE_U; ++u) { const int rq = 64 * u + lane; sidv[u] = rq < r ? Tb + S.acc_sample[rq] : -1; }
-#pragma unroll
-        for (int u = 0; u < STAR_MATE_U; ++u) trv[u] = sidv[u] >= 0 ? st.tree[sidv[u]] : -1;
         int* ml = s_mate[wave];
         int nm = 0;
 #pragma unroll
@@ -489,10 +559,9 @@ __global__ __launch_bounds__(256) void k_star_knn(ResolveArgs A, GridView g, Gri
   }
   if (lane == 0) {
     S.m_cnt[i] = cnt;
-    const int ex = A.parent[i];
-    S.best[i] = A.pdist[i] + f.d_root[ex];   // (first guess: the plain SFF cost)
-    S.psel[i] = ex;
-    S.dcl[i] = A.pdist[i];
+    S.best[i] = pd0 + dr0;   // (first guess: the plain SFF cost)
+    S.psel[i] = ex0;
+    S.dcl[i] = pd0;
     S.cnt[2 * (size_t)i] = 0ULL; S.cnt[2 * (size_t)i + 1] = 0ULL;
     if (S.dbg && k > 0) {   // waves | ticks: cube, shells, mates, lists | shells walked | cube candidates | longest wave
       const unsigned long long t4 = wall_clock64();
