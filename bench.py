@@ -33,7 +33,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r4_bench_pmc_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r5_bench_pmc_summary.json")
+SWEEP_PMC_SUMMARY = os.path.join(ROOT, "profiles", "r5_sweep_pmc_summary.json")   # profiles/collect_sweep.sh
 
 
 def parse_args():
@@ -326,9 +327,20 @@ def main():
             ms1, _ = cs.kernel_times()
             cs.close()
             tt = (ms1[0] - ms0[0]) / reps * 1e-3
+            sweep_src = None
+            try:   # HBM-side bytes per pass from the rocprofv3 --pmc passes of exactly this leg (profiles/collect_sweep.sh)
+                sp = json.load(open(SWEEP_PMC_SUMMARY))
+                if sp.get("nodes") == Nn:
+                    sweep_traffic = 1024.0 * (2.0 * sp["FETCH_SIZE"]["avg_KiB_per_launch"] + sp["WRITE_SIZE"]["avg_KiB_per_launch"])
+                    sweep_src = ("profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of profiles/sweep_leg.py (this leg on its "
+                                 "own); 2 x FETCH + WRITE; kernel trace average %.1f us" % (os.path.basename(SWEEP_PMC_SUMMARY),
+                                                                                             sp.get("kernel_trace", {}).get("avg_us", float("nan"))))
+            except Exception:
+                pass
             out["sweep_kernel_roofline"] = {"kernel": "sffk::k_sweep", "bound": "hbm", "nodes": Nn, "queries_per_pass": 1,
                                             "us_per_pass": tt * 1e6, "achieved": 24.0 * Nn / tt / 1e9, "peak": 8000.0,
-                                            "unit": "GB/s", "frac": 24.0 * Nn / tt / 8e12, "traffic": sweep_traffic}
+                                            "unit": "GB/s", "frac": 24.0 * Nn / tt / 8e12, "traffic": sweep_traffic,
+                                            "traffic_source": sweep_src}
         if world == 1 and not args.no_wave_sweep:
             # the small-wave end: wave = 1 IS the reference's sequential loop (one sample per GPU round trip)
             legs = {}

@@ -123,9 +123,10 @@ __global__ __launch_bounds__(256) void k_wave_begin(DevForestView f) {
       const int node = from[pick];
       f.slot_node[sl] = node; f.slot_pos[sl] = pick;
       if (f.ord.hist) {   // the slot's bucket in the wave's spatial order: the coarse grid cell of its node (OrderView)
-        const int cx = grid_coord(f.ord.x[node], f.ord.ox, f.ord.inv_cell, f.ord.nx) >> f.ord.shift,
-                  cy = grid_coord(f.ord.y[node], f.ord.oy, f.ord.inv_cell, f.ord.ny) >> f.ord.shift,
-                  cz = grid_coord(f.ord.z[node], f.ord.oz, f.ord.inv_cell, f.ord.nz) >> f.ord.shift;
+        const double* np = f.ord.pos + 6 * (size_t)node;   // (the grid's own cell: the store columns are these casts)
+        const int cx = grid_coord((float)np[0], f.ord.ox, f.ord.inv_cell, f.ord.nx) >> f.ord.shift,
+                  cy = grid_coord((float)np[1], f.ord.oy, f.ord.inv_cell, f.ord.ny) >> f.ord.shift,
+                  cz = grid_coord((float)np[2], f.ord.oz, f.ord.inv_cell, f.ord.nz) >> f.ord.shift;
         const int key = (cz * f.ord.cny + cy) * f.ord.cnx + cx;
         f.ord.slot_key[sl] = key;
         f.ord.slot_rank[sl] = atomicAdd(&f.ord.hist[key], 1);
@@ -773,15 +774,21 @@ __device__ __forceinline__ int append_one(const ResolveArgs& A, int i, int& slot
   const unsigned long long w = f.w_acc[i >> 6];
   const int rank = f.acc_pref[i >> 6] + __popcll(w & ((1ULL << (i & 63)) - 1ULL));
   if (!((w >> (i & 63)) & 1ULL)) {
-    if (part == 1) return -1;
-    slot_out = act_old[i];
-    act_new[i - rank] = slot_out;       // not accepted: the slot tries again (rank = accepted samples before it)
-    if (ord_on) {   // its sample's index in the next round joins the list of its sub-range (OrderView): the place is
-      // asked for here, the entry is written by the caller once it has nothing else to wait for (append_ord_store)
-      const int sub = f.ord.slot_pos[slot_out] >> 6;
+    // its sample's index in the next round joins the list of its sub-range (OrderView): a returning atomic behind two
+    // dependent loads - in k_append_sample the NODE-creating half of the workgroups does it (for a sample that was not
+    // accepted it has nothing else to do), so that the sampling half's chain stays as short as it was
+    auto ord_append = [&](int slot) {
+      const int sub = f.ord.slot_pos[slot] >> 6;
       const bool first = c->app_act_sel != 0;   // (the buffer that is NOT the committed round's)
       ord_at = sub * 64 + atomicAdd(&(first ? f.ord.cnt[0] : f.ord.cnt[1])[sub * SFFK_ORD_CNT_STRIDE], 1);
+    };
+    if (part == 1) {
+      if (ord_on) { ord_append(act_old[i]); append_ord_store(A, ord_at, i - rank); }
+      return -1;
     }
+    slot_out = act_old[i];
+    act_new[i - rank] = slot_out;       // not accepted: the slot tries again (rank = accepted samples before it)
+    if (ord_on && part == 0) ord_append(slot_out);   // (k_append: everything in one thread; the caller stores the entry)
     if (wave_over) claim(i - rank, slot_out);
     return i - rank;
   }

@@ -261,6 +261,7 @@ struct DevEngine {
   DevBuf frontier2, rm_words, rm_pref, slot_pos, act_slot2, w_acc, acc_pref, ustate32, wg_pub, commit_seq, kc_trace;
   DevBuf ord_hist, ord_start, ord_key, ord_rank, ord_pos, ord_lst, ord_cnt;
   bool ord_enabled = true;
+  int ord_min_wave = 4096;   // (SFFGPU_ORDER_MIN_WAVE, read when the forest is created)
   DevBuf w_ev, ev_h, ev_nb, ev_raw;   // border events of a round, entered by the append launch (sffk::DevForestView)   // spatial order of a wave's slots (sffk::OrderView)
   DevBuf ctrl, parent, d_root, d_closest, iter, nflag, frontier, closed, claim, slot_node, slot_fail, act_slot, b_n1,
       b_n2, b_ta, b_tb, b_dist, bt_key, bt_val, pair, ring, ulist, d_parent, d_parent2, d_force, fault_pending;

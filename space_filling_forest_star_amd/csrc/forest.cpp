@@ -177,6 +177,7 @@ Forest::Forest(Ctx* c, const sffgpu_forest_cfg& cf, const double* roots6, int n_
   knn_r = 2.5 * cfg.sampling_dist;
   if (const char* e = getenv("SFFGPU_TEST_HITCAP")) hit_cap = std::min(64, std::max(1, atoi(e)));  // one lane per hit
   dev.ord_enabled = !(getenv("SFFGPU_NO_ORDER") && atoi(getenv("SFFGPU_NO_ORDER")) != 0);   // spatial order of a wave's slots (sffk::OrderView)
+  if (const char* e = getenv("SFFGPU_ORDER_MIN_WAVE")) dev.ord_min_wave = std::max(2, atoi(e));
   if (hit_cap < 24) query_wide = true;   // (tests shrink the hit list of the wide kernel)
   if (const char* e = getenv("SFFGPU_TEST_NBCAP")) nb_cap = std::max(1, atoi(e));
   if (const char* e = getenv("SFFGPU_TEST_STAR_PASSES")) star_pass_limit = std::max(1, atoi(e));

@@ -284,7 +284,8 @@ sffk::DevForestView Forest::dev_view() const {
     // spatial order of the wave's slots (sffk::OrderView): plain frontier picks only - in priority mode the slots' nodes
     // come from k_prio_begin - and only with the node grid in place; SFFGPU_NO_ORDER=1 switches it off
     const sffk::GridView& g = ctx->gridv;
-    if (d.ord_enabled && !use_priority() && d.ord_hist.p && g.cnt && g.nx > 0 && cfg.wave > 1) {
+    // (waves below 4 096 slots: a few hundred samples per round share one XCD's L2 anyway, the bookkeeping only costs)
+    if (d.ord_enabled && !use_priority() && d.ord_hist.p && g.cnt && g.nx > 0 && cfg.wave >= d.ord_min_wave) {
       sffk::OrderView& o = v.ord;
       o.hist = d.ord_hist.as<int32_t>(); o.start = d.ord_start.as<int32_t>();
       o.slot_key = d.ord_key.as<int32_t>(); o.slot_rank = d.ord_rank.as<int32_t>();
@@ -292,7 +293,7 @@ sffk::DevForestView Forest::dev_view() const {
       o.n_sub = (cfg.wave + 63) / 64;
       o.lst[0] = d.ord_lst.as<int32_t>(); o.lst[1] = o.lst[0] + (size_t)o.n_sub * 64;
       o.cnt[0] = d.ord_cnt.as<int32_t>(); o.cnt[1] = o.cnt[0] + (size_t)o.n_sub * SFFK_ORD_CNT_STRIDE;
-      o.x = ctx->sx.as<float>(); o.y = ctx->sy.as<float>(); o.z = ctx->sz.as<float>();
+      o.pos = ctx->spos.as<double>();
       o.ox = g.ox; o.oy = g.oy; o.oz = g.oz; o.inv_cell = g.inv_cell;
       o.nx = g.nx; o.ny = g.ny; o.nz = g.nz;
       int sh = 0;

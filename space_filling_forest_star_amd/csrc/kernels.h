@@ -224,7 +224,7 @@ struct OrderView {
   int32_t* lst[2];      // per buffer: 64 entries per sub-range - sample indices of the current round (-1 = none)
   int32_t* cnt[2];      // per buffer: entries of every sub-range's list (SFFK_ORD_CNT_STRIDE ints apart)
   int32_t n_sub;        // sub-ranges the buffers hold (ceil(wave / 64))
-  const float* x; const float* y; const float* z;   // store columns
+  const double* pos;    // node positions (6 doubles per node: the three coordinates of a node lie in ONE line; the float columns would be three)
   float ox, oy, oz, inv_cell;                        // the node grid's cells
   int32_t nx, ny, nz, shift, cnx, cny;              // coarse cell = cell >> shift; cnx x cny x .. coarse cells
   int32_t n_buckets;                                 // coarse cells = buckets in use (<= SFFK_ORD_BUCKETS)

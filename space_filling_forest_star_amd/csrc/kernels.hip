@@ -969,6 +969,67 @@ __device__ __forceinline__ bool tri_far(const double* T, const double* c, double
   double lim = rr * (1.0 + 1e-9) + 1e-9 * (mag + 1.0);
   return dd > lim * lim;
 }
+// squared distance of c to the closest point of triangle T and the magnitude of the operands (tri_far's own computation,
+// for callers that compare ONE distance with several radii); false: degenerate triangle or NaN - never cull
+__device__ __forceinline__ bool tri_dist2(const double* T, const double* c, double& dd_out, double& mag_out) {
+  double ab[3], ac[3], ap[3];
+  for (int i = 0; i < 3; ++i) { ab[i] = T[3 + i] - T[i]; ac[i] = T[6 + i] - T[i]; ap[i] = c[i] - T[i]; }
+  double d1 = dot(ab, ap), d2 = dot(ac, ap);
+  double q[3];
+  bool done = false;
+  if (d1 <= 0 && d2 <= 0) { for (int i = 0; i < 3; ++i) q[i] = T[i]; done = true; }
+  double bp[3], cp[3], d3 = 0, d4 = 0, d5 = 0, d6 = 0;
+  if (!done) {
+    for (int i = 0; i < 3; ++i) bp[i] = c[i] - T[3 + i];
+    d3 = dot(ab, bp); d4 = dot(ac, bp);
+    if (d3 >= 0 && d4 <= d3) { for (int i = 0; i < 3; ++i) q[i] = T[3 + i]; done = true; }
+  }
+  if (!done) {
+    double vc = d1 * d4 - d3 * d2;
+    if (vc <= 0 && d1 >= 0 && d3 <= 0) {
+      double v = d1 / (d1 - d3);
+      for (int i = 0; i < 3; ++i) q[i] = T[i] + v * ab[i];
+      done = true;
+    }
+  }
+  if (!done) {
+    for (int i = 0; i < 3; ++i) cp[i] = c[i] - T[6 + i];
+    d5 = dot(ab, cp); d6 = dot(ac, cp);
+    if (d6 >= 0 && d5 <= d6) { for (int i = 0; i < 3; ++i) q[i] = T[6 + i]; done = true; }
+  }
+  if (!done) {
+    double vb = d5 * d2 - d1 * d6;
+    if (vb <= 0 && d2 >= 0 && d6 <= 0) {
+      double w = d2 / (d2 - d6);
+      for (int i = 0; i < 3; ++i) q[i] = T[i] + w * ac[i];
+      done = true;
+    }
+  }
+  if (!done) {
+    double va = d3 * d6 - d5 * d4;
+    if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) {
+      double w = (d4 - d3) / ((d4 - d3) + (d5 - d6));
+      for (int i = 0; i < 3; ++i) q[i] = T[3 + i] + w * (T[6 + i] - T[3 + i]);
+      done = true;
+    }
+  }
+  if (!done) {
+    double vc = d1 * d4 - d3 * d2, vb = d5 * d2 - d1 * d6, va = d3 * d6 - d5 * d4;
+    double den = va + vb + vc;
+    if (!(den != 0)) return false;          // degenerate triangle
+    double v = vb / den, w = vc / den;
+    for (int i = 0; i < 3; ++i) q[i] = T[i] + ab[i] * v + ac[i] * w;
+  }
+  double dd = 0, mag = 0;
+  for (int i = 0; i < 3; ++i) { double e = c[i] - q[i]; dd += e * e; mag += fabs(c[i]) + fabs(q[i]); }
+  if (!(dd == dd)) return false;            // NaN guard
+  dd_out = dd; mag_out = mag;
+  return true;
+}
+__device__ __forceinline__ bool dist2_far(double dd, double mag, double rr) {   // tri_far's verdict from tri_dist2's outputs
+  const double lim = rr * (1.0 + 1e-9) + 1e-9 * (mag + 1.0);
+  return dd > lim * lim;
+}
 
 // Clearance bits: true when a robot whose MODEL ORIGIN is at c provably touches nothing in any rotation (the
 // exact test would find a separating axis for every pair), so the traversal and the exact tests can be skipped.
@@ -1075,9 +1136,12 @@ __global__ __launch_bounds__(256) void k_clear_scatter(EnvView env, ClearBuildAr
       const long long ix = l - base;
       const double c[3] = {env.clear_org[0] + ((double)ix + 0.5) * h, env.clear_org[1] + ((double)iy + 0.5) * h,
                            env.clear_org[2] + ((double)iz + 0.5) * h};
-      if (tri_far(T, c, reach)) continue;
-      if (!tri_far(T, c, P.thr_pose) && tri_box_maybe(T, c, P.pose_lo, P.pose_hi)) mp |= 1u << (int)(l & 31);
-      if (!tri_far(T, c, P.thr_edge) && tri_box_maybe(T, c, P.edge_lo, P.edge_hi)) me |= 1u << (int)(l & 31);
+      // (one closest-point computation, compared with both radii: tri_far's arithmetic)
+      double dd = 0.0, mag = 0.0;
+      const bool known = tri_dist2(T, c, dd, mag);
+      if (known && dist2_far(dd, mag, reach)) continue;
+      if (!(known && dist2_far(dd, mag, P.thr_pose)) && tri_box_maybe(T, c, P.pose_lo, P.pose_hi)) mp |= 1u << (int)(l & 31);
+      if (!(known && dist2_far(dd, mag, P.thr_edge)) && tri_box_maybe(T, c, P.edge_lo, P.edge_hi)) me |= 1u << (int)(l & 31);
     }
     if (mp) atomicAnd(bits_pose + w, ~mp);
     if (me) atomicAnd(bits_edge + w, ~me);
@@ -1375,10 +1439,12 @@ struct SegLane {
 __device__ int narrow_block(const EnvView& env, const RobotView& rob, const double* rtri, const double* rbox, int32_t* queue,
                             double* stage, const int32_t* cand, int k0, int kc, const SegLane& L, int minhit, int lane DBG_ARG) {
   const double* a = L.a; const double* dir = L.dir;
-  const double parts = L.parts, rr = L.rr;
-  const int s0 = L.s0, idx = L.idx;
+  const double parts = L.parts;
+  const int s0 = L.s0;
+  const int idx = L.idx;
   const bool need = L.need;
   const double* P = L.P; const double* C = L.C;
+  const double rr = L.rr;
   int qn = 0;
   auto flush = [&](int count) {
     DBG_ADD(3, 1);
@@ -2575,8 +2641,8 @@ __global__ __launch_bounds__(64 * QC_WAVES) __attribute__((amdgpu_waves_per_eu(Q
 //   7  end points of the tasks that left a survivor
 // QB_S samples per workgroup: the instruction stream of a phase is paid once per 64 work items whatever sample they
 // belong to - with 8 samples per workgroup (two per wavefront, like k_query_block) the vector ALUs were as busy as before.
-// Bounded lists: QB_HC exact hits per sample, 24 filter candidates and 48 deep-bucket records per sample on average over
-// the workgroup; a sample that loses an entry gets flag 2 (host path), like every list overflow.
+// Bounded lists: QB_HC exact hits per sample, 36 filter candidates and 128 bucket records per sample on average over
+// the workgroup (packed entries, round 5: a workgroup's samples are spatial neighbours and dense together); a sample that loses an entry gets flag 2 (host path), like every list overflow.
 #define QB_S 8
 #define QB_HC 24
 #define QB_TASKS 17
@@ -2617,9 +2683,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB_OCC))) v
 #define QB_INL 0      // records of a bucket looked at in the cell pass itself; the rest through the second work list
 #endif
 #ifndef QB_W2
-#define QB_W2 64
+#define QB_W2 128
 #endif
-  constexpr int S = QB_S, HC = QB_HC, CANDCAP = S * 24, W2CAP = S * QB_W2, PAIRCAP = S * 32, SURVCAP = S * 8, INL = QB_INL;
+  // (the work lists are POOLED over the workgroup's samples; since the samples of a workgroup are spatial neighbours - OrderView -
+  // they are dense together: entries are packed - sample in the top bits - so that the same LDS holds 36 candidates and 128
+  // bucket records per sample instead of 24 and 64)
+  constexpr int S = QB_S, HC = QB_HC, CANDCAP = S * 36, W2CAP = S * QB_W2, PAIRCAP = S * 32, SURVCAP = S * 8, INL = QB_INL;
   __shared__ __attribute__((aligned(16))) int s_i[S][32];   // QRec
   __shared__ double s_qp[S][6], s_ex[S][6];
   __shared__ int s_pref[S + 1];
@@ -2627,8 +2696,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB_OCC))) v
   __shared__ double h_d[S][HC];
   __shared__ int h_id[S][HC], h_tree[S][HC];
   __shared__ int s_rankhit[S][QB_TASKS];
-  __shared__ int c_s[CANDCAP], c_id[CANDCAP], c_tree[CANDCAP];
-  __shared__ int w_s[W2CAP], w_at[W2CAP];
+  __shared__ int c_id[CANDCAP], c_tree[CANDCAP];   // c_tree: sample << 28 | tree
+  __shared__ int w_at[W2CAP];                      // sample << 28 | round's own grid << 27 | record index (< 2^27: query_block_mode)
   __shared__ float s_T[S][QB_TASKS][8];
   __shared__ int s_NS[S][QB_TASKS], s_need[S][QB_TASKS];
   __shared__ int s_tab[PAIRCAP];
@@ -2640,7 +2709,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB_OCC))) v
     A.n = A.dev_n[0];
   }
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  // which samples: 8 consecutive sample indices, or - device engine, OrderView - 8 entries of one sub-range's list of the
+  // which samples: 8 consecutive sample indices, or - device engine, OrderView - entries of the sub-range lists of the
   // wave's spatial order, the sub-ranges dealt out so that every XCD (workgroup b runs on XCD b % 8) gets one contiguous
   // run of them: neighbouring samples then find each other's count, bucket and clearance lines in that XCD's L2
   __shared__ int s_map[S];
@@ -2648,18 +2717,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB_OCC))) v
     const bool ordered = A.ord_valid && *A.ord_valid;
     int i = -1;
     if (ordered) {
-      const int n_slots = *A.ord_nslots, sel = *A.ord_sel, R = (n_slots + 63) >> 6, perx = (R + 7) >> 3;
-      const int y = (int)blockIdx.x >> 3, r = ((int)blockIdx.x & 7) * perx + (y >> 3), j = y & 7;
-      if ((y >> 3) >= perx || r >= R) return;
+      // XCD x owns the sub-ranges [x perx, (x + 1) perx) - one contiguous piece of the wave's spatial order; a workgroup
+      // takes ONE entry (number j) from each of 8 sub-ranges spread over that piece: its samples share the XCD's L2 with
+      // their spatial neighbours, but a dense region's samples do not all land in the same workgroups (8 entries of ONE
+      // list per workgroup made the dense regions' workgroups the launch's stragglers: SFF* at 2 M nodes 603 -> 654 ms)
+      const int n_slots = *A.ord_nslots, sel = *A.ord_sel, R = (n_slots + 63) >> 6, perx = (R + 7) >> 3, nsets = (perx + 7) >> 3;
+      const int y = (int)blockIdx.x >> 3, gset = y >> 6, j = y & 63;
+      if (gset >= nsets) return;
       // (no run-time index into the argument struct: that would move all of it to scratch memory)
       const int32_t* const o_cnt = sel ? A.ord_cnt[1] : A.ord_cnt[0];
       const int32_t* const o_lst = sel ? A.ord_lst[1] : A.ord_lst[0];
-      int cnt = o_cnt[r * SFFK_ORD_CNT_STRIDE];
-      int e = tid < S ? o_lst[r * 64 + 8 * j + tid] : -1;   // (requested beside the count)
-      cnt = cnt < 64 ? cnt : 64;
-      if (8 * j >= cnt) return;
-      if (tid < S && 8 * j + tid < cnt) i = e;
-      if (i >= A.n) i = -1;
+      if (tid < S) {
+        const int off = gset + nsets * tid, r = ((int)blockIdx.x & 7) * perx + off;
+        if (off < perx && r < R) {
+          const int cnt = o_cnt[r * SFFK_ORD_CNT_STRIDE];
+          const int e = o_lst[r * 64 + j];   // (requested beside the count)
+          if (j < cnt) i = e;
+        }
+        if (i >= A.n) i = -1;
+      }
     } else {
       if ((int)blockIdx.x * S >= A.n) return;
       if (tid < S) { i = blockIdx.x * S + tid; if (i >= A.n) i = -1; }
@@ -2786,7 +2862,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB_OCC))) v
   auto add_cand = [&](bool pass, int s, const GridItem32& it) {
     const int at = wave_reserve(&s_cnt[0], pass, lane);
     if (pass) {
-      if (at < CANDCAP) { c_s[at] = s; c_id[at] = it.id; c_tree[at] = it.tree; }
+      if (at < CANDCAP) { c_id[at] = it.id; c_tree[at] = (s << 28) | (it.tree & 0x0fffffff); }
       else s_drop[s] = 1;
     }
   };
@@ -2837,11 +2913,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB_OCC))) v
       if (__any(extra > 0)) {
         int at = wave_reserve_n(&s_cnt[1], extra, lane);
         for (int k = INL; k < m; ++k, ++at) {
-          if (at < W2CAP) { w_s[at] = s; w_at[at] = (int)(cell * g.bk) + k; }
+          if (at < W2CAP) w_at[at] = (s << 28) | ((int)(cell * g.bk) + k);
           else s_drop[s] = 1;
         }
         for (int k = TINL; k < mt; ++k, ++at) {
-          if (at < W2CAP) { w_s[at] = s; w_at[at] = -1 - ((int)(cell * tg.bk) + k); }
+          if (at < W2CAP) w_at[at] = (s << 28) | (1 << 27) | ((int)(cell * tg.bk) + k);
           else s_drop[s] = 1;
         }
       }
@@ -2859,7 +2935,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB_OCC))) v
     for (int e0 = 0; e0 < n2; e0 += 256) {
       const int e = e0 + tid;
       const bool on = e < n2;
-      const int s = on ? w_s[e] : 0, at = on ? w_at[e] : 0;
+      const int ent = on ? w_at[e] : 0;
+      const int s = (ent >> 28) & 7, at = (ent & (1 << 27)) ? -1 - (ent & 0x07ffffff) : (ent & 0x07ffffff);
       GridItem32 it{};
       if (on) it = at >= 0 ? g.lite[at] : tg.lite[-1 - at];
       add_cand(on && passes(s, it), s, it);
@@ -2881,7 +2958,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB_OCC))) v
   {
     const int nc = s_cnt[0] < CANDCAP ? s_cnt[0] : CANDCAP;
     for (int e = tid; e < nc; e += 256) {
-      const int s = c_s[e], id = c_id[e];
+      const int s = (c_tree[e] >> 28) & 7, id = c_id[e];
       double nbp[6], qp[6];
       const double* ps = A.pos + 6 * (size_t)id;
       for (int k = 0; k < 6; ++k) { nbp[k] = ps[k]; qp[k] = s_qp[s][k]; }
@@ -2889,7 +2966,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB_OCC))) v
       if (d < RD(s, QI_QR)) {
         const int slot = atomicAdd(&s_nhit[s], 1);
         if (slot < HC) {
-          h_d[s][slot] = d; h_id[s][slot] = id; h_tree[s][slot] = c_tree[e];
+          h_d[s][slot] = d; h_id[s][slot] = id; h_tree[s][slot] = c_tree[e] & 0x0fffffff;
         }
       }
     }
@@ -3319,7 +3396,7 @@ __global__ __launch_bounds__(64 * SEG_WAVES) __attribute__((amdgpu_waves_per_eu(
       const unsigned long long ci_a = wall_clock64();
 #endif
       segment_chunk(env, rob, rtri, rbox, stack, cand, queue, stage, a, b, slot, chunk, !ran_over, mask, first_hit, overflow_flag, lane DBG_PASS,
-                    (SHARE && !ran_over) ? &s_share : nullptr);
+                            (SHARE && !ran_over) ? &s_share : nullptr);
 #ifdef SFFK_CI_TRACE
       if (ci_items == 0) { ci_first[0] = ci_a; ci_first[1] = wall_clock64(); ci_first[2] = (unsigned long long)__popcll(mask); }
       ++ci_items;
@@ -4249,6 +4326,9 @@ bool query_block_mode(const GridView& g, const GridView* tg, const ClassifyArgs&
   if (a.wide) return false;
   if (tg && tg->cnt && (!tg->lite || !tg->ovf_lite)) return false;
   if (knob && !strcmp(knob, "wide")) return false;
+  // (the kernel's bucket work list packs a record index into 27 bits)
+  if ((long long)g.nx * g.ny * g.nz * g.bk >= (1LL << 27)) return false;
+  if (tg && tg->cnt && (long long)tg->nx * tg->ny * tg->nz * tg->bk >= (1LL << 27)) return false;
   if (knob && !strcmp(knob, "block")) return true;
   return g.bk <= 8;
 }
@@ -4262,8 +4342,9 @@ bool launch_query_classify(hipStream_t s, const GridView& g, const GridView* tg,
     if (cap_override >= 0 && cap_override < aa.items_cap) aa.items_cap = cap_override;
   }
   if (query_block_mode(g, tg, a, env)) {
-    // (the ordered walk deals 8 workgroups to each sub-range of 64 positions, a multiple of 8 sub-ranges per XCD)
-    const int by_sub = 64 * ((((a.n + 63) / 64) + 7) / 8);
+    // (the ordered walk: per XCD ceil(perx / 8) sets of 8 sub-ranges x 64 entry numbers, perx = sub-ranges per XCD)
+    const int perx_max = (((a.n + 63) / 64) + 7) / 8;
+    const int by_sub = 8 * 64 * ((perx_max + 7) / 8);
     const int by_n = (a.n + QB_S - 1) / QB_S;
     hipLaunchKernelGGL(k_query_block, dim3(a.ord_valid && by_sub > by_n ? by_sub : by_n), dim3(256), 0, s, g, tg ? *tg : none, queries, aa, *env);
     return true;

@@ -214,8 +214,9 @@ def test_spatial_order_of_the_slots_changes_nothing(S, ctx):
     (sffk::OrderView) instead of by sample index; SFFGPU_NO_ORDER=1 is the walk by index.  Same forest either way,
     plain SFF and SFF*, also when a wave holds fewer slots than the launch is sized for."""
     for name, wave, iters, optimize in (("dense3d", 2048, 90000, False), ("dense3d", 1000, 40000, True),
-                                        ("building", 4096, 60000, False)):
-        fo, fg = make(S, ctx, name, wave, iters, seed=5, optimize=optimize)
+                                        ("building", 4096, 60000, False), ("dense3d", 8192, 200000, False)):
+        # (the order is on by default from waves of 4 096 slots; SFFGPU_ORDER_MIN_WAVE lowers that for the smaller cases)
+        fo, fg = make(S, ctx, name, wave, iters, seed=5, optimize=optimize, SFFGPU_ORDER_MIN_WAVE=2)
         fo.run()
         fg.run()
         assert fg.device_engine()
