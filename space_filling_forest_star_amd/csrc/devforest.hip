@@ -974,6 +974,21 @@ __device__ void wave_end_control(const DevForestView& f, DevCtrl* c, int removed
 //   workgroups start in index order) -> closed list, node flags, removed frontier positions (atomicOr on rm_words)
 //   -> the workgroup that finishes last (a counter) adds the removal prefix per frontier word and the termination tests.
 #define KW_CNT 15          // word of the workgroup's wg_pub line (k_commit uses 0..12)
+// The wave's status for the host: the control block as it stands, into slot (status_seq % ring) of the pinned ring (round 5:
+// a copy launch behind every wave cost ~5 us of stream time).  One wavefront (threadIdx < 64) of ONE workgroup calls it,
+// after everything this launch writes to the control block; the reads go past the vector L1 (this CU read the block
+// earlier in the launch).  The block's own status_seq names it; the counter then moves on.
+__device__ void status_publish(const DevForestView& f) {
+  if (!f.host_status || threadIdx.x >= 64) return;
+  DevCtrl* c = f.ctrl;
+  const int sq = __hip_atomic_load(&c->status_seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  int32_t* dst = reinterpret_cast<int32_t*>(f.host_status + (sq & (SFFK_STATUS_RING - 1)));
+  const int32_t* src = reinterpret_cast<const int32_t*>(c);
+  for (int w = threadIdx.x; w < (int)(sizeof(DevCtrl) / 4); w += 64)
+    dst[w] = __hip_atomic_load(src + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __builtin_amdgcn_wave_barrier();
+  if (threadIdx.x == 0) c->status_seq = sq + 1;
+}
 __global__ __launch_bounds__(256) void k_wave_end_wide(DevForestView f, const int32_t* __restrict__ grid_ovf,
                                                        const int32_t* __restrict__ tgrid_ovf, unsigned long long* star_acc) {
   __shared__ unsigned long long s_words[4];
@@ -982,7 +997,10 @@ __global__ __launch_bounds__(256) void k_wave_end_wide(DevForestView f, const in
   __shared__ int s_pref[256];
   __shared__ unsigned long long star_s[SFFK_STAR_ACC];
   DevCtrl* c = f.ctrl;
-  if (c->halt || !c->in_wave) return;
+  if (c->halt || !c->in_wave) {   // (nothing to end: the block is the wave's status as it is)
+    if (blockIdx.x == 0) status_publish(f);
+    return;
+  }
   const bool from_closed = c->use_closed != 0;
   const bool post_claims = !from_closed && !c->claims_done;   // (not posted by the wave's last append: a resumed or empty wave)
   const int n_fail = from_closed ? 0 : c->act_cnt;
@@ -1097,7 +1115,10 @@ __global__ __launch_bounds__(256) void k_wave_end_wide(DevForestView f, const in
     f.commit_seq[5] = 0;
     wave_end_control(f, c, removed, fn, from_closed, n_fail, grid_ovf, tgrid_ovf, star_acc ? star_s : nullptr);
     c->wprof[7] += 1ULL;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the control block's stores have reached the L2)
   }
+  __syncthreads();          // (... before the first wavefront reads the block back past the L1)
+  status_publish(f);
 }
 
 // order-preserving removal of the marked positions: old buffer -> the other one (selected by k_wave_end_wide already)

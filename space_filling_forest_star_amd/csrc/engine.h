@@ -294,6 +294,10 @@ struct DevEngine {
   uint64_t rounds_enqueued = 0;
   int host_nodes = 0, host_borders = 0;   // how much of the device arrays the host mirror holds
   sffk::DevCtrl last{};         // status block after the last completed wave
+  bool zc_status = true;        // the wave's last kernel writes the status block into the pinned ring itself (sffk::status_publish)
+  uint32_t status_next = 0;     // sequence number the next published block will carry
+  uint32_t status_of[2] = {0, 0};   // ... and the ones the two enqueued waves' blocks carry
+  bool status_copied[2] = {true, true};   // the slot's block came by a copy into h_ctrl[slot] (k_seq_waves, SFFGPU_NO_ZC_STATUS)
 };
 
 struct Forest {

@@ -316,6 +316,7 @@ sffk::DevForestView Forest::dev_view() const {
   }
   static const int profile = getenv("SFFGPU_PROFILE") ? 1 : 0;
   v.profile = profile;
+  v.host_status = (d.zc_status && d.h_ctrl.p) ? d.h_ctrl.as<sffk::DevCtrl>() : nullptr;   // (hipHostMalloc: one address on both sides)
   v.kc_trace = d.kc_trace.as<unsigned long long>();
   v.kc_trace_round = getenv("SFFGPU_KC_TRACE") ? atoi(getenv("SFFGPU_KC_TRACE")) : -1;
   v.b_n1 = d.b_n1.as<int32_t>();
@@ -482,7 +483,8 @@ void Forest::dev_upload_state() {
       d.h_trig.ensure((size_t)d.ring_words * 24);
     }
     d.ctrl.ensure(sizeof(sffk::DevCtrl));
-    d.h_ctrl.ensure(2 * sizeof(sffk::DevCtrl));
+    d.h_ctrl.ensure((size_t)SFFK_STATUS_RING * sizeof(sffk::DevCtrl));   // (>= 2: the copy path's two slots)
+    d.zc_status = !(getenv("SFFGPU_NO_ZC_STATUS") && atoi(getenv("SFFGPU_NO_ZC_STATUS")) != 0);
     d.slot_node.ensure((size_t)wave * 4);
     d.slot_pos.ensure((size_t)wave * 4);
     d.act_slot.ensure((size_t)wave * 4);
@@ -596,6 +598,7 @@ void Forest::dev_upload_state() {
     if (left > d.ring_words) throw HipError{"forest: look-ahead queue larger than the engine-word ring"};
     rng.draws = d.produced;
     sffk::DevCtrl k{};
+    k.status_seq = (int32_t)d.status_next;   // (the ring's numbering goes on)
     k.n_nodes = n;
     k.iter = iter;
     k.round = round;
@@ -1089,7 +1092,9 @@ void Forest::dev_enqueue_end(int slot) {
   if (use_priority()) sffk::launch_prio_end(c.stream, dev_view(), c.store_view());
   sffk::launch_wave_end(c.stream, dev_view(), c.gridv.ovf_cnt, c.tgridv.ovf_cnt,
                         cfg.optimize ? d.s_acc.as<unsigned long long>() : nullptr);
-  HIPCHK(hipMemcpyAsync(d.h_ctrl.as<sffk::DevCtrl>() + slot, d.ctrl.p, sizeof(sffk::DevCtrl), hipMemcpyDeviceToHost, c.stream));
+  d.status_copied[slot] = !d.zc_status;
+  if (d.zc_status) d.status_of[slot] = d.status_next++;   // (k_wave_end_wide published the block itself)
+  else HIPCHK(hipMemcpyAsync(d.h_ctrl.as<sffk::DevCtrl>() + slot, d.ctrl.p, sizeof(sffk::DevCtrl), hipMemcpyDeviceToHost, c.stream));
   HIPCHK(hipEventRecord(slot ? d.ev_wave2 : d.ev_wave, c.stream));
 }
 
@@ -1202,7 +1207,9 @@ void Forest::dev_enqueue_wave(int slot) {
     dev_enqueue_wave_kernels(sharded, words);
     d.force_timing = -1;
   }
-  HIPCHK(hipMemcpyAsync(d.h_ctrl.as<sffk::DevCtrl>() + slot, d.ctrl.p, sizeof(sffk::DevCtrl), hipMemcpyDeviceToHost, c.stream));
+  d.status_copied[slot] = !d.zc_status;
+  if (d.zc_status) d.status_of[slot] = d.status_next++;   // (k_wave_end_wide published the block itself)
+  else HIPCHK(hipMemcpyAsync(d.h_ctrl.as<sffk::DevCtrl>() + slot, d.ctrl.p, sizeof(sffk::DevCtrl), hipMemcpyDeviceToHost, c.stream));
   HIPCHK(hipEventRecord(slot ? d.ev_wave2 : d.ev_wave, c.stream));
   dev.host_stale = true;
 }
@@ -1220,7 +1227,14 @@ int Forest::dev_finish_wave(double* wait_ms, int slot, bool stream_idle) {
     if (stream_idle) c.sync();   // (harvests the timing events; the stream is idle)
     if (wait_ms) *wait_ms += ms_since(tw);
   }
-  d.last = d.h_ctrl.as<sffk::DevCtrl>()[slot];
+  if (!d.status_copied[slot]) {
+    d.last = d.h_ctrl.as<sffk::DevCtrl>()[d.status_of[slot] & (SFFK_STATUS_RING - 1)];
+    if ((uint32_t)d.last.status_seq != d.status_of[slot])
+      throw HipError{"device engine: the wave's status block is not the one expected (sequence " + std::to_string(d.last.status_seq) +
+                     ", expected " + std::to_string(d.status_of[slot]) + ")"};
+  } else {
+    d.last = d.h_ctrl.as<sffk::DevCtrl>()[slot];
+  }
   if (!stream_idle) return d.last.fault;
   d.host_stale = true;
   const sffk::DevCtrl& s = d.last;
@@ -1365,6 +1379,7 @@ void Forest::run_device_seq(int max_waves) {
     }
     sffk::launch_seq_waves(c.stream, a);
     HIPCHK(hipMemcpyAsync(d.h_ctrl.as<sffk::DevCtrl>(), d.ctrl.p, sizeof(sffk::DevCtrl), hipMemcpyDeviceToHost, c.stream));
+    d.status_copied[0] = true;
     HIPCHK(hipEventRecord(d.ev_wave, c.stream));
     d.host_stale = true;
     const int fault = dev_finish_wave(&wait_ms, 0, true);

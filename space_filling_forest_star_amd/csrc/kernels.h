@@ -194,7 +194,11 @@ struct DevCtrl {
   // plain SFF: the border events of the committed round are entered by the append launch (k_border_finalize): border list
   // length before that round; n_borders holds an upper bound (every event counted) until the append has run
   int32_t app_nb0;
+  // status blocks published so far (DevForestView::host_status): the wave's last kernel writes the control block straight
+  // into a ring of pinned host memory, numbered by this counter - no copy launch behind every wave
+  int32_t status_seq, status_pad;
 };
+#define SFFK_STATUS_RING 4
 #define SFFK_DEV_MAX_GROUPS 1024   // single-workgroup list kernels: 64 x this many slots per wave at most
 #define SFFK_FAULT_LISTS 1        // a hit / neighbour / triangle-candidate list overflowed: redo the round on the host
 #define SFFK_FAULT_BORDER_TABLE 2 // the border hash table is full: the host grows it
@@ -500,6 +504,7 @@ struct DevForestView {
   int32_t* commit_seq;         // [0] = launches that reached their end so far; [1] workgroups of k_wave_begin that are through, [2] one of them met a redraw;
                                // [3] = k_wave_end_wide launches that ended a wave, [4] its workgroups that are through
   unsigned long long* kc_trace; int32_t kc_trace_round;   // SFFGPU_KC_TRACE=<round>: 8 clock reads per workgroup of that round's k_commit
+  DevCtrl* host_status;        // SFFK_STATUS_RING control blocks in pinned host memory (device-visible); null = the host copies
   int32_t profile;             // SFFGPU_PROFILE: the single-workgroup kernels read their phase clocks (a clock read is a scalar
                                // memory round trip: a dozen of them is microseconds)
 };
