@@ -232,6 +232,9 @@ __device__ __forceinline__ size_t border_slot(const DevForestView& f, unsigned l
 // So a workgroup waits for lower ones only, and workgroups start in index order: the lowest unfinished one never waits.
 // The LAST workgroup of the round adds everything up and writes the control block.
 // Published words are (launch sequence number << 32 | value): nothing is cleared between launches.
+// (a fault raised in a walk has reached the L2 before its workgroup publishes a word: the round's last workgroup reads the
+// flag as soon as it has every lower workgroup's count)
+#define KC_FAULT_SETTLE() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #define KC_SPIN_LIMIT (1 << 20)   // polls before a wait gives up (then: fault, the host redoes the round) - never reached
 #define KC_ACC 0      // accepted samples of the workgroup
 #define KC_PREF 1     // accepted samples of all lower workgroups
@@ -372,14 +375,14 @@ __global__ __launch_bounds__(1024) void k_commit(ResolveArgs A, int n_bound) {
   bool count_end = true;                            // (the neighbour that ended the walk had its edge looked at)
   if (live) {
     if (!inl) code = SFFK_OUTSIDE;
-    else if (flags & 2) { if (gl == 0) { atomicOr(A.fault_pending, 1); atomicAdd(A.fault_pending + 1, 1); } }   // hit / neighbour list overflow: host path
+    else if (flags & 2) { if (gl == 0) { atomicOr(A.fault_pending, 1); atomicAdd(A.fault_pending + 1, 1); KC_FAULT_SETTLE(); } }   // hit / neighbour list overflow: host path
     else if ((flags & 3) == 1) {
       const bool ovf = gballot(have && fh == 0) != 0;    // 0 = the edge's triangle candidate list ran over
       const bool mine = A.world <= 1 || i % A.world == A.rank;   // (executed work is counted by the rank that ran it)
       const unsigned long long smp = gsum(have ? (unsigned long long)ns : 0ULL);
       if (mine) { cnt[3] = 1; cnt[4] = 1 + (unsigned long long)nnb; cnt[5] = smp; }
       const int fh0 = __shfl(fh, gsh), ns0 = __shfl(ns, gsh);
-      if (ovf) { if (gl == 0) { atomicOr(A.fault_pending, 1); atomicAdd(A.fault_pending + 2, 1); } }
+      if (ovf) { if (gl == 0) { atomicOr(A.fault_pending, 1); atomicAdd(A.fault_pending + 2, 1); KC_FAULT_SETTLE(); } }
       else {
         cnt[0] = 1;                                // :246 env.Collide(newPoint)
         if (!pose_hit) {
@@ -416,7 +419,7 @@ __global__ __launch_bounds__(1024) void k_commit(ResolveArgs A, int n_bound) {
       const unsigned long long ck = __shfl(my_calls, gsh + kq);
       if (pending && !blocked) {
         if (ks >= 16 && (flags & 4)) {   // the walk ran off the end of a CUT neighbour record: the host path has the whole list
-          if (gl == 0) { atomicOr(A.fault_pending, 1); atomicAdd(A.fault_pending + 3, 1); }
+          if (gl == 0) { atomicOr(A.fault_pending, 1); atomicAdd(A.fault_pending + 3, 1); KC_FAULT_SETTLE(); }
           st = 1; code = SFFK_REJECTED; end = 16; pending = false;
         } else if (ks >= 16) { st = 2; code = SFFK_ACCEPT; end = 16; pending = false; }
         else {
@@ -427,7 +430,7 @@ __global__ __launch_bounds__(1024) void k_commit(ResolveArgs A, int n_bound) {
           else if (k_mate && ms != 2) ks = nxt;                        // that sample never became a node
           else if (goal_mode && !k_same) {
             const bool is_goal = (goals >> ks) & 1u;
-            if (is_goal && k_fr && gl == 0) atomicOr(A.fault_pending, 1);   // :286-287 goal reached
+            if (is_goal && k_fr && gl == 0) { atomicOr(A.fault_pending, 1); KC_FAULT_SETTLE(); }   // :286-287 goal reached
             count_end = is_goal;
             st = 1; code = SFFK_REJECTED; end = ks; pending = false;         // :296-299
           } else {
@@ -451,7 +454,7 @@ __global__ __launch_bounds__(1024) void k_commit(ResolveArgs A, int n_bound) {
     if (!__any(pending)) break;
     ++passes;
     if (spin >= KC_SPIN_LIMIT) {                    // (never: the states it waits for are earlier samples')
-      if (gl == 0 && pending) atomicOr(A.fault_pending, 1);
+      if (gl == 0 && pending) { atomicOr(A.fault_pending, 1); KC_FAULT_SETTLE(); }
       pending = false; st = 1; code = SFFK_REJECTED;
       if (live && !published && gl == 0) __hip_atomic_store(&f.ustate32[i], (seq30 << 2) | 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       published = true;
@@ -542,13 +545,20 @@ __global__ __launch_bounds__(1024) void k_commit(ResolveArgs A, int n_bound) {
   }
   // ---- 3. node ids: N0 + accepted samples before, in slot order
   unsigned long long part = 0;
-  if ((int)threadIdx.x < b) part = kc_wait(f.wg_pub + (size_t)threadIdx.x * SFFK_PUB_WORDS + KC_ACC, seq, A.fault_pending);
+  if ((int)threadIdx.x < b) part = kc_wait(f.wg_pub + (size_t)threadIdx.x * SFFK_PUB_WORDS + KC_ACC, seq, f.commit_seq + 6);
   // (the last workgroup: the lower workgroups' counters were published before their counts - requested now, looked at
   // when the control block is written)
   unsigned long long early[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (last && (int)threadIdx.x < b)   // (behind the count: published before it)
     for (int q = 0; q < 8; ++q) early[q] = kc_load(f.wg_pub + (size_t)threadIdx.x * SFFK_PUB_WORDS + KC_CNT + q);
   const int acc_pref = (int)kc_block_sum(part, &s_sum);
+  // The round's fault flag (a bounded list that overflowed, the goal reached: raised in a workgroup's WALKS, before it
+  // publishes anything) is final once every lower workgroup's count is in - the block sum's barriers are behind all the
+  // waits, and behind this workgroup's own walks: asked for now, looked at when the control block is written (it used to
+  // be asked for there: a round trip on the round's critical path).  A wait that gives up (never: KC_SPIN_LIMIT) raises
+  // commit_seq[6] instead, which ends the run at the wave's end (SFFK_FAULT_INTERNAL).
+  int fault_seen = 0;
+  if (last && threadIdx.x == 1023) fault_seen = __hip_atomic_load(A.fault_pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (threadIdx.x == 0) {
     f.acc_pref[b] = acc_pref;
     kc_publish(pub + KC_PREF, seq, (unsigned)acc_pref);
@@ -567,9 +577,9 @@ __global__ __launch_bounds__(1024) void k_commit(ResolveArgs A, int n_bound) {
       unsigned long long wj = wa;
       if (bj != b) {
         const unsigned long long* pp = f.wg_pub + (size_t)bj * SFFK_PUB_WORDS;
-        pj = (int)kc_wait(pp + KC_PREF, seq, A.fault_pending);
-        wj = (unsigned long long)kc_wait(pp + KC_WLO, seq, A.fault_pending) |
-             ((unsigned long long)kc_wait(pp + KC_WHI, seq, A.fault_pending) << 32);
+        pj = (int)kc_wait(pp + KC_PREF, seq, f.commit_seq + 6);
+        wj = (unsigned long long)kc_wait(pp + KC_WLO, seq, f.commit_seq + 6) |
+             ((unsigned long long)kc_wait(pp + KC_WHI, seq, f.commit_seq + 6) << 32);
       }
       e_nb = N0 + pj + __popcll(wj & ((1ULL << (j & 63)) - 1ULL));
       const int a = e_nb < e_ex ? e_nb : e_ex, bb = e_nb < e_ex ? e_ex : e_nb;
@@ -587,7 +597,7 @@ __global__ __launch_bounds__(1024) void k_commit(ResolveArgs A, int n_bound) {
     KC_TRACE(3);
     // (an event's fate needs every lower workgroup's stamps; the last workgroup without events of its own is only here
     // for the totals)
-    if (we != 0ULL && (int)threadIdx.x < b) (void)kc_wait(f.wg_pub + (size_t)threadIdx.x * SFFK_PUB_WORDS + KC_POSTED, seq, A.fault_pending);
+    if (we != 0ULL && (int)threadIdx.x < b) (void)kc_wait(f.wg_pub + (size_t)threadIdx.x * SFFK_PUB_WORDS + KC_POSTED, seq, f.commit_seq + 6);
     __syncthreads();
     KC_TRACE(5);
     bool own = false;
@@ -605,7 +615,7 @@ __global__ __launch_bounds__(1024) void k_commit(ResolveArgs A, int n_bound) {
     n_own = s_ev_total;
     if (n_own > 0 || last) {
       unsigned long long pe = 0;
-      if ((int)threadIdx.x < b) pe = kc_wait(f.wg_pub + (size_t)threadIdx.x * SFFK_PUB_WORDS + KC_OWN, seq, A.fault_pending);
+      if ((int)threadIdx.x < b) pe = kc_wait(f.wg_pub + (size_t)threadIdx.x * SFFK_PUB_WORDS + KC_OWN, seq, f.commit_seq + 6);
       ev_pref = (int)kc_block_sum(pe, &s_sum);
     }
     KC_TRACE(6);
@@ -650,10 +660,10 @@ __global__ __launch_bounds__(1024) void k_commit(ResolveArgs A, int n_bound) {
   unsigned long long tot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if ((int)threadIdx.x < b) {   // (every lower workgroup has published its counters long ago: one batch of loads)
     const unsigned long long* pp = f.wg_pub + (size_t)threadIdx.x * SFFK_PUB_WORDS;
-    for (int q = 0; q < 8; ++q) tot[q] = (unsigned)(early[q] >> 32) == seq ? (unsigned)early[q] : kc_wait(pp + KC_CNT + q, seq, A.fault_pending);
+    for (int q = 0; q < 8; ++q) tot[q] = (unsigned)(early[q] >> 32) == seq ? (unsigned)early[q] : kc_wait(pp + KC_CNT + q, seq, f.commit_seq + 6);
   }
   // (a fault is raised before its workgroup publishes anything: with every lower workgroup's words in, the flag is final)
-  if (threadIdx.x == 1023) s_ev_total = __hip_atomic_load(A.fault_pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 1023) s_ev_total = fault_seen;
   kc_block_sum8(tot, s_tot, 0);
   for (int q = 0; q < 7; ++q) tot[q] += s_c6[q];
   tot[7] += (unsigned long long)__popcll(we);
@@ -856,7 +866,7 @@ __device__ void border_finalize(const ResolveArgs& A, int b) {
   const bool last = b == nwg - 1;
   if (n_own == 0 && !last) return;
   unsigned long long pe = 0;
-  for (int t = tid; t < b; t += 256) pe += kc_wait(f.wg_pub + (size_t)t * SFFK_PUB_WORDS + KC_OWN, seq, A.fault_pending);
+  for (int t = tid; t < b; t += 256) pe += kc_wait(f.wg_pub + (size_t)t * SFFK_PUB_WORDS + KC_OWN, seq, f.commit_seq + 6);
   for (int off = 32; off > 0; off >>= 1) pe += __shfl_xor(pe, off);
   if (tid == 0) s_bsum = 0ULL;
   __syncthreads();
@@ -953,6 +963,7 @@ __device__ void wave_end_control(const DevForestView& f, DevCtrl* c, int removed
   const bool budget = f.node_budget > 0 && c->n_nodes >= f.node_budget;
   c->terminated = (c->solved || c->iter >= f.max_iterations || budget) ? 1 : 0;
   c->halt = c->terminated;
+  if (f.commit_seq[6]) { c->fault = SFFK_FAULT_INTERNAL; c->halt = 1; }   // (a workgroup gave up waiting for a lower one: never)
   c->in_wave = 0;
   c->n_act = 0;
   c->grid_ovf = grid_ovf[0];

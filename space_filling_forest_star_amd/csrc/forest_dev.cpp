@@ -1242,6 +1242,7 @@ int Forest::dev_finish_wave(double* wait_ms, int slot, bool stream_idle) {
   const auto t_ev = Clock::now();
   if (s.fault) {
     const int fault = s.fault;
+    if (fault == SFFK_FAULT_INTERNAL) throw HipError{"device engine: a workgroup of the commit waited in vain for a lower one's word"};
     if (fault == SFFK_FAULT_LISTS) return fault;
     if (fault == SFFK_FAULT_CAPACITY) {
       // (nodes and temporaries share the store: grow it, re-place the temporaries) - only the side that is short

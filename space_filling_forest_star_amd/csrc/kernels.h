@@ -203,6 +203,7 @@ struct DevCtrl {
 #define SFFK_FAULT_LISTS 1        // a hit / neighbour / triangle-candidate list overflowed: redo the round on the host
 #define SFFK_FAULT_BORDER_TABLE 2 // the border hash table is full: the host grows it
 #define SFFK_FAULT_CAPACITY 4     // node / frontier / border arrays would overflow: the host grows them
+#define SFFK_FAULT_INTERNAL 16    // a workgroup of the commit gave up waiting for a lower one's word (never): the host ends the run
 #define SFFK_FAULT_PRIO_REDRAW 8   // priority mode: a random-entry draw fell into Lemire's rejection zone (p ~ heap size / 2^64)
 
 // Spatial order of a wave's slots (round 5).  A slot's five samples all lie within one sampling distance of its node, and

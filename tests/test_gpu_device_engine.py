@@ -213,8 +213,8 @@ def test_spatial_order_of_the_slots_changes_nothing(S, ctx):
     """round 5: the query kernel takes a round's samples from per-sub-range lists of the wave's spatial order
     (sffk::OrderView) instead of by sample index; SFFGPU_NO_ORDER=1 is the walk by index.  Same forest either way,
     plain SFF and SFF*, also when a wave holds fewer slots than the launch is sized for."""
-    for name, wave, iters, optimize in (("dense3d", 2048, 90000, False), ("dense3d", 1000, 40000, True),
-                                        ("building", 4096, 60000, False), ("dense3d", 8192, 200000, False)):
+    for name, wave, iters, optimize in (("dense3d", 2048, 30000, False), ("dense3d", 1000, 15000, True),
+                                        ("building", 4096, 24000, False), ("dense3d", 8192, 70000, False)):
         # (the order is on by default from waves of 4 096 slots; SFFGPU_ORDER_MIN_WAVE lowers that for the smaller cases)
         fo, fg = make(S, ctx, name, wave, iters, seed=5, optimize=optimize, SFFGPU_ORDER_MIN_WAVE=2)
         fo.run()
@@ -233,8 +233,8 @@ def test_many_candidate_items_shared_by_the_workgroup_change_nothing(S, ctx):
     """round 5: an exact-kernel item (edge chunk or pose) with many candidate triangles is worked off in blocks by the
     idle wavefronts of its workgroup (share_help in csrc/kernels.hip; environments above 4 096 triangles by default).
     SFFGPU_SHARE=0 / 1 forces the choice at every launch: same forest - and the oracle's - either way, plain SFF and SFF*."""
-    for name, wave, iters, optimize in (("building", 2048, 50000, False), ("building", 1024, 20000, True),
-                                        ("dense3d", 1024, 30000, False)):
+    for name, wave, iters, optimize in (("building", 2048, 30000, False), ("building", 1024, 12000, True),
+                                        ("dense3d", 1024, 15000, False)):
         fps = []
         for share in ("0", "1"):
             with engine(SFFGPU_SHARE=share):
