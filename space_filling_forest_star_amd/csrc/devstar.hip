@@ -19,6 +19,8 @@
 #include "sff_geom.h"
 #include "kernels_dev.h"
 #include <cmath>
+#include <cstring>
+#include <cstdlib>
 
 namespace sffk {
 
@@ -27,11 +29,6 @@ using namespace sffg;
 #define STAR_INF __longlong_as_double(0x7ff0000000000000LL)
 #define STAR_FAULT 4   // index in StarView::hdr
 
-__device__ __forceinline__ bool star_accepted(const DevForestView& f, int i, int& rank) {
-  const unsigned long long w = f.w_acc[i >> 6];
-  rank = f.acc_pref[i >> 6] + __popcll(w & ((1ULL << (i & 63)) - 1ULL));
-  return (w >> (i & 63)) & 1ULL;
-}
 
 // candidates of a group of up to 64 cells of the node grid (lane = cell, m = its item count), flattened over the lanes:
 // permanent nodes (id < N0) of the sample's tree
@@ -60,44 +57,6 @@ __device__ __forceinline__ void star_cells(const GridView& g, int m, int cell, i
       const GridItem it = g.items[(size_t)src_cell * g.bk + slot];
       id = it.id;
       if (it.tree == tree && id < N0) { d = dist6(it.p, qp); cand = true; }
-    }
-    const double worst = topk_worst(t, k, have);
-    cand = cand && (have < k || key_less(d, id, worst, 0x7fffffff));
-    topk_insert(t, lane, k, have, __ballot(cand), d, id);
-  }
-}
-
-// the same over cells of the round's own grid: samples accepted EARLIER in the round (temporary id in [Tb, self)) of
-// the same tree, not farther than `limit`
-__device__ __forceinline__ void star_cells_mates(const GridView& tg, int m, int cell, int lane, const double* qp, int tree, int Tb,
-                                                 int self, double limit, const DevForestView& f, TopK& t, int k, int& have) {
-  int inc = m;
-  for (int off = 1; off < 64; off <<= 1) {
-    const int o = __shfl_up(inc, off);
-    if (lane >= off) inc += o;
-  }
-  const int total = __shfl(inc, 63);
-  for (int base = 0; base < total; base += 64) {
-    const int j = base + lane;
-    const int jj = j < total ? j : total - 1;
-    int lo = 0, hi = 63;
-    while (lo < hi) {
-      const int mid = (lo + hi) >> 1;
-      if (__shfl(inc, mid) > jj) hi = mid; else lo = mid + 1;
-    }
-    const int src_cell = __shfl(cell, lo);
-    const int slot = jj - (__shfl(inc, lo) - __shfl(m, lo));
-    bool cand = false;
-    double d = 1.0e300;
-    int id = 0x7fffffff;
-    if (j < total) {
-      const GridItem it = tg.items[(size_t)src_cell * tg.bk + slot];
-      id = it.id;
-      int rk;
-      if (it.tree == tree && id >= Tb && id < self && star_accepted(f, id - Tb, rk)) {
-        d = dist6(it.p, qp);
-        cand = d <= limit;
-      }
     }
     const double worst = topk_worst(t, k, have);
     cand = cand && (have < k || key_less(d, id, worst, 0x7fffffff));
@@ -984,7 +943,9 @@ void launch_star_stage(hipStream_t s, const ResolveArgs& a, int n_bound, const S
   const int sample_blocks = (n_bound + 3) / 4;
   int R0 = (int)std::ceil(L.cube_reach / L.cell_edge);
   R0 = R0 < 2 ? 2 : (R0 > STAR_R0_MAX ? STAR_R0_MAX : R0);
-  hipLaunchKernelGGL(k_star_knn, dim3(sample_blocks), dim3(256), 0, s, a, L.g, L.tg, L.st, L.cell_edge, L.slack, R0);
+  static const bool lone = getenv("SFFGPU_STAR_KNN") && !strcmp(getenv("SFFGPU_STAR_KNN"), "lone");
+  if (lone) hipLaunchKernelGGL(k_star_knn, dim3(sample_blocks), dim3(256), 0, s, a, L.g, L.tg, L.st, L.cell_edge, L.slack, R0);
+  else launch_star_knn_wg(s, a, L.g, L.tg, L.st, L.cell_edge, L.slack, n_bound, R0);
   const int event_blocks = (n_bound + 255) / 256;
   const int passes = L.passes > 0 && L.passes < SFFK_STAR_PASSES ? L.passes : SFFK_STAR_PASSES;
   for (int pass = 0; pass < passes; ++pass) {

@@ -648,6 +648,10 @@ struct SampleLaunch {
   double* out6; uint8_t* in_lim; double* parent_dist; SweepQuery* queries; int32_t q_max_base;
   RoundTemps tmp; DevRound dv;
 };
+// SFF*: the k nearest of every accepted sample, one workgroup per sample (k_star_knn_wg in kernels.hip; devstar.hip's
+// k_star_knn - one wavefront per sample - remains behind SFFGPU_STAR_KNN=lone)
+void launch_star_knn_wg(hipStream_t s, const ResolveArgs& a, const GridView& g, const GridView& tg, const NodeStoreView& st,
+                        double cell_edge, double slack, int n_bound, int R0);
 void launch_commit(hipStream_t s, const ResolveArgs& a, int n_bound, const StarLaunch* star = nullptr,
                    const SampleLaunch* next = nullptr);
 void launch_wave_end(hipStream_t s, const DevForestView& f, const int32_t* grid_ovf, const int32_t* tgrid_ovf,

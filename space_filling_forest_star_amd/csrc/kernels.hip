@@ -490,19 +490,19 @@ __global__ __launch_bounds__(256) void k_knn_grid(GridView g, GridView tg, NodeS
 // in turn, each keeps what IT found in a list of its own; after every shell the lists are merged (rank = own index +
 // entries of the other lists that sort before, by bisection in LDS), wave 0 keeps the merged k best, the others start
 // empty again and only take candidates that beat the merged k-th key.  Same keys, same order: the same k nearest.
-__global__ __launch_bounds__(256) void k_knn_grid_wg(GridView g, NodeStoreView st, const KnnQuery* __restrict__ queries, int nq, int kcap,
-                                                     int32_t* __restrict__ idx, double* __restrict__ dist, int32_t* __restrict__ cnt,
-                                                     double cell_edge, double slack, int n_store, int sweep_only) {
+// The search of k_knn_grid_wg as a function of the whole workgroup (barriers inside; every wavefront must call it with the
+// same arguments): the k nearest of Q among the grid's nodes, merged list in wave 0's lanes (t, G entries).  tree_nodes:
+// nodes the queried tree holds (the search stops once a tree of no more than k nodes is in; INT_MAX: unknown).  Also the
+// store part of SFF*'s k-nearest sets (k_star_knn_wg).
+__device__ void knn_wg_search(const GridView& g, const NodeStoreView& st, const KnnQuery& Q, int k, double cell_edge, double slack,
+                              int n_store, int sweep_only, int tree_nodes, TopK& t, int& G_out, int r_first = 0) {
   __shared__ double s_d[4][64];
   __shared__ int s_id[4][64];
   __shared__ int s_have[4];
   __shared__ double m_d[64];
   __shared__ int m_id[64];
-  const int q = blockIdx.x, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (q >= nq) return;
-  const KnnQuery Q = queries[q];
-  const int k = Q.k < 64 ? Q.k : 64;
-  TopK t{1.0e300, 0x7fffffff};
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  t = TopK{1.0e300, 0x7fffffff};
   int have = 0, n_mates = 0;
   double bd = 1.0e300;       // the merged k-th key (inf while fewer than k are known)
   int bi = 0x7fffffff, G = 0;
@@ -563,7 +563,40 @@ __global__ __launch_bounds__(256) void k_knn_grid_wg(GridView g, NodeStoreView s
   const int rmax = sweep_only ? -1 : max(max(g.nx, g.ny), g.nz);
   long long scanned = 0;
   bool sweep = sweep_only != 0;
-  for (int r = 0; r <= rmax; ++r) {
+  int r_start = 0;
+  bool done = false;
+  if (r_first > 0 && !sweep_only) {
+    // the cube of half-width r_first in one go (SFF*'s sets lie within about two steps of the sample): every cell's count
+    // is on its way before anything is looked at, one merge instead of one per shell
+    const int w = 2 * r_first + 1, total = w * w * w;
+    scanned += total;
+    for (int b0 = 0; b0 * 64 < total; b0 += 16) {
+      int cell[4], m[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int c = (b0 + 4 * u + wv) * 64 + lane;
+        cell[u] = 0; m[u] = 0;
+        if (c < total) {
+          const int x = cx + c % w - r_first, y = cy + (c / w) % w - r_first, z = cz + c / (w * w) - r_first;
+          if (x >= 0 && x < g.nx && y >= 0 && y < g.ny && z >= 0 && z < g.nz) {
+            cell[u] = (z * g.ny + y) * g.nx + x;
+            m[u] = g.cnt[cell[u]];
+            if (m[u] > g.bk) m[u] = g.bk;
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (__any(m[u] > 0)) knn_cells(g, m[u], cell[u], lane, Q, st, t, k, have, false, 0.0, nullptr, n_mates, 0, bd, bi);
+    }
+    merge();
+    const int r = r_first;
+    const double covered = (double)r * cell_edge - slack;
+    done = (tree_nodes <= k && G >= tree_nodes) || (G >= k && bd <= covered) ||
+           (cx - r <= 0 && cy - r <= 0 && cz - r <= 0 && cx + r >= g.nx - 1 && cy + r >= g.ny - 1 && cz + r >= g.nz - 1);
+    r_start = r_first + 1;
+  }
+  for (int r = r_start; r <= rmax && !done; ++r) {
     const int w = 2 * r + 1;
     const int ww = w * w, ring = 8 * r;
     const int total = r > 0 ? 2 * ww + (w - 2) * ring : 1;
@@ -601,6 +634,7 @@ __global__ __launch_bounds__(256) void k_knn_grid_wg(GridView g, NodeStoreView s
         if (__any(m[u] > 0)) knn_cells(g, m[u], cell[u], lane, Q, st, t, k, have, false, 0.0, nullptr, n_mates, 0, bd, bi);
     }
     merge();
+    if (tree_nodes <= k && G >= tree_nodes) break;          // (a tree with no more than k nodes: all of them are in)
     const double covered = (double)r * cell_edge - slack;   // (cells are assigned from fp32 coordinates)
     if (G >= k && bd <= covered) break;
     if (cx - r <= 0 && cy - r <= 0 && cz - r <= 0 && cx + r >= g.nx - 1 && cy + r >= g.ny - 1 && cz + r >= g.nz - 1) break;
@@ -647,6 +681,19 @@ __global__ __launch_bounds__(256) void k_knn_grid_wg(GridView g, NodeStoreView s
     }
     merge();
   }
+  G_out = G;
+}
+
+__global__ __launch_bounds__(256) void k_knn_grid_wg(GridView g, NodeStoreView st, const KnnQuery* __restrict__ queries, int nq, int kcap,
+                                                     int32_t* __restrict__ idx, double* __restrict__ dist, int32_t* __restrict__ cnt,
+                                                     double cell_edge, double slack, int n_store, int sweep_only) {
+  const int q = blockIdx.x, wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (q >= nq) return;
+  const KnnQuery Q = queries[q];
+  const int k = Q.k < 64 ? Q.k : 64;
+  TopK t{1.0e300, 0x7fffffff};
+  int G = 0;
+  knn_wg_search(g, st, Q, k, cell_edge, slack, n_store, sweep_only, 0x7fffffff, t, G);
   if (wv == 0) {
     if (lane == 0) cnt[q] = G;
     if (lane < G && lane < kcap) {
@@ -654,6 +701,204 @@ __global__ __launch_bounds__(256) void k_knn_grid_wg(GridView g, NodeStoreView s
       dist[(size_t)q * kcap + lane] = t.d;
     }
   }
+}
+
+
+// ------------------------------------------------------------------ SFF*: k nearest of an accepted sample, one WORKGROUP per sample
+// k_star_knn (devstar.hip) with the store part done by the whole workgroup (round 5): the four wavefronts take a shell's
+// batches of cells in turn and merge their lists after every shell (knn_wg_search, the RRT session's k-nearest search) -
+// one lone wavefront per accepted sample was 44 us per sample on configs[4] and 80 for the tenth of them that walk shells,
+// and the launch is as long as its slowest sample.  Wave 0 then adds the round's earlier accepted samples and writes the
+// members and their toucher lists exactly as k_star_knn does.  Same keys: the same sets.
+#define SKW_MATE_U 16
+#ifndef SKW_FIRST
+#define SKW_FIRST 1
+#endif
+__global__ __launch_bounds__(256) void k_star_knn_wg(ResolveArgs A, GridView g, GridView tg, NodeStoreView st, double cell_edge,
+                                                     double slack, int R0) {
+  __shared__ int s_mate[64 * SKW_MATE_U];
+  const DevForestView& f = A.f;
+  const StarView& S = A.S;
+  const DevCtrl* c = f.ctrl;
+  const int n = c->app_n;
+  if (blockIdx.x == 0 && threadIdx.x < SFFK_STAR_PASSES) S.changed[threadIdx.x] = 0;
+  for (int t = blockIdx.x * 256 + threadIdx.x; t < SFFK_STAR_PASSES * SFFK_SUBLISTS * SFFK_STAR_SUB; t += gridDim.x * 256) S.sub[t] = 0;
+  if (n <= 0) return;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int n_acc = S.hdr[0];                      // (k_commit: the accepted samples, S.acc_sample[rank])
+  const int N0 = c->app_N0, Tb = f.temp_base;
+  const unsigned ep = (unsigned)c->epoch;
+  for (int r = blockIdx.x; r < n_acc; r += gridDim.x) {
+    const int i = S.acc_sample[r];
+    // k = (size_t)(2e log10(#nodes)) with the nodes accepted before this sample counted in (src/forest.h:309)
+    const int Nn = N0 + r;
+    const int k_ref = __popcll(__ballot(lane > 0 && lane <= SFFK_STAR_KMAX + 1 && S.ktab[lane] <= Nn));
+    const int self = Tb + i;
+    const int mine = st.tree[self];
+    double qp[6];
+    for (int q = 0; q < 6; ++q) qp[q] = A.newpos[6 * (size_t)i + q];
+    // (wave 0: what the end needs, asked for beside the search - see k_star_knn)
+    int sidv[SKW_MATE_U], trv[SKW_MATE_U];
+    const bool mates_small = wave == 0 && r > 0 && r <= 64 * SKW_MATE_U;
+#pragma unroll
+    for (int u = 0; u < SKW_MATE_U; ++u) { const int rq = 64 * u + lane; sidv[u] = (mates_small && rq < r) ? Tb + S.acc_sample[rq] : -1; }
+    const int ex0 = A.parent[i];
+    const double pd0 = A.pdist[i];
+    const int tcnt = S.tree_cnt[16 * mine];
+    if (wave == 0) {   // the sample's edge slots: nothing asked for yet
+      const size_t s0 = ((size_t)i * SFFK_STAR_KC + lane) * 2;
+      S.ew[s0] = 0; S.ew[s0 + 1] = 0;
+    }
+    if (k_ref > SFFK_STAR_KMAX) {   // (a node count beyond what the member slots are sized for: host path)
+      if (threadIdx.x == 0) atomicOr(S.hdr + 4, 1);
+      continue;
+    }
+    const int k = k_ref;
+#pragma unroll
+    for (int u = 0; u < SKW_MATE_U; ++u) trv[u] = sidv[u] >= 0 ? st.tree[sidv[u]] : -1;
+    const double dr0 = f.d_root[ex0];
+    TopK t{1.0e300, 0x7fffffff};
+    int have = 0;
+    if (k > 0) {
+      KnnQuery Q;
+      for (int q = 0; q < 6; ++q) Q.pos[q] = qp[q];
+      Q.tree = mine; Q.max_id = N0; Q.k = k; Q.mate_base = 0x7fffffff; Q.whole_tree = 0; Q.pad_ = 0;
+      // (the first shells in one go - up to SKW_FIRST: beyond that the search usually ends before the cube does - then shell by shell)
+      knn_wg_search(g, st, Q, k, cell_edge, slack, N0, 0, tcnt, t, have, R0 < SKW_FIRST ? R0 : SKW_FIRST);
+    }
+    if (wave == 0) {
+      const int cx = grid_coord((float)qp[0], g.ox, g.inv_cell, g.nx), cy = grid_coord((float)qp[1], g.oy, g.inv_cell, g.ny),
+                cz = grid_coord((float)qp[2], g.oz, g.inv_cell, g.nz);
+      const int rmax = max(max(g.nx, g.ny), g.nz);
+      if (k > 0) {
+    // ---- the samples accepted earlier in this round (ranks below this one's, k_commit's list) of the same tree: not
+    // farther than the k-th store node - or, while the store holds fewer than k nodes of the tree, all of them
+    if (r > 0) {
+      const bool all = have < k;
+      const double limit = all ? 1.0e300 : topk_worst(t, k, have);
+      if (r <= 64 * SKW_MATE_U) {
+        // k_commit's list of the accepted samples: every rank's sample and tree are requested up front (two trips to
+        // memory whatever the length), the few of the same tree are compacted in LDS and measured a batch at a time
+        int* ml = s_mate;
+        int nm = 0;
+#pragma unroll
+        for (int u = 0; u < SKW_MATE_U; ++u) {
+          if (64 * u >= r) break;
+          const bool mt = sidv[u] >= 0 && trv[u] == mine;
+          const unsigned long long mm = __ballot(mt);
+          if (mt) ml[nm + __popcll(mm & ((1ULL << lane) - 1ULL))] = sidv[u];
+          nm += __popcll(mm);
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int base = 0; base < nm; base += 64) {
+          const int j = base + lane;
+          bool cand = false;
+          double d = 1.0e300;
+          int sid = 0x7fffffff;
+          if (j < nm) {
+            sid = ml[j];
+            double mp[6];
+            for (int q = 0; q < 6; ++q) mp[q] = st.pos[6 * (size_t)sid + q];
+            d = dist6(mp, qp);
+            cand = d <= limit;
+          }
+          const double worst = topk_worst(t, k, have);
+          cand = cand && (have < k || key_less(d, sid, worst, 0x7fffffff));
+          topk_insert(t, lane, k, have, __ballot(cand), d, sid);
+        }
+      } else if (all) {
+        for (int base = 0; base < r; base += 64) {   // (a tree wanted whole in a huge round: rare)
+          const int rq = base + lane;
+          bool cand = false;
+          double d = 1.0e300;
+          int sid = 0x7fffffff;
+          if (rq < r) {
+            sid = Tb + S.acc_sample[rq];
+            if (st.tree[sid] == mine) {
+              double mp[6];
+              for (int q = 0; q < 6; ++q) mp[q] = st.pos[6 * (size_t)sid + q];
+              d = dist6(mp, qp);
+              cand = true;
+            }
+          }
+          const double worst = topk_worst(t, k, have);
+          cand = cand && (have < k || key_less(d, sid, worst, 0x7fffffff));
+          topk_insert(t, lane, k, have, __ballot(cand), d, sid);
+        }
+      } else {
+        // a large round: the round's own grid, cells of the cube around the ball of the k-th store node
+        int rr = (int)((limit + slack) / cell_edge) + 1;
+        if (rr > rmax) rr = rmax;
+        const int w = 2 * rr + 1;
+        const int total = w * w * w;
+        for (int c0 = 0; c0 < total; c0 += 64) {
+          const int cc = c0 + lane;
+          int cell = 0, m = 0;
+          if (cc < total) {
+            const int x = cx + cc % w - rr, y = cy + (cc / w) % w - rr, z = cz + cc / (w * w) - rr;
+            if (x >= 0 && x < g.nx && y >= 0 && y < g.ny && z >= 0 && z < g.nz) {
+              cell = (z * g.ny + y) * g.nx + x;
+              const bool maybe = tg.occ ? ((tg.occ[cell >> 5] >> (cell & 31)) & 1u) != 0 : true;
+              if (maybe) { m = tg.cnt[cell]; if (m > tg.bk) m = tg.bk; }
+            }
+          }
+          if (__any(m > 0)) star_cells_mates(tg, m, cell, lane, qp, mine, Tb, self, limit, f, t, k, have);
+        }
+        int no = tg.ovf_cnt[0];
+        if (no > tg.ovf_cap) no = tg.ovf_cap;
+        for (int base = 0; base < no; base += 64) {
+          const int j = base + lane;
+          bool cand = false;
+          double d = 1.0e300;
+          int id = 0x7fffffff;
+          const double worst = topk_worst(t, k, have);
+          if (j < no) {
+            const GridItem it = tg.ovf[j];
+            id = it.id;
+            int rk;
+            if (it.tree == mine && id >= Tb && id < self && star_accepted(f, id - Tb, rk)) {
+              d = dist6(it.p, qp);
+              cand = d <= limit && (have < k || key_less(d, id, worst, 0x7fffffff));
+            }
+          }
+          topk_insert(t, lane, k, have, __ballot(cand), d, id);
+        }
+      }
+    }
+  }
+  // ---- the members: ids, distances, toucher lists
+  const int cnt = have;
+  const bool mem = lane < cnt;
+  int node = -1;
+  if (mem) {
+    if (t.id < N0) node = t.id;
+    else { int rk; star_accepted(f, t.id - Tb, rk); node = N0 + rk; }
+  }
+  const size_t p = (size_t)i * SFFK_STAR_KC + lane;
+  S.prop[p] = __longlong_as_double(0x7ff0000000000000LL);
+  if (mem) {
+    S.m_id[p] = node;
+    S.m_d[p] = t.d;
+    const unsigned long long mark = ((unsigned long long)ep << 32) | (unsigned long long)(p + 1);
+    const unsigned long long old = atomicExch(&S.head[node], mark);
+    S.next[p] = (unsigned)(old >> 32) == ep ? (int)(unsigned)(old & 0xffffffffULL) : 0;
+  }
+  if (lane == 0) {
+    S.m_cnt[i] = cnt;
+    S.best[i] = pd0 + dr0;   // (first guess: the plain SFF cost)
+    S.psel[i] = ex0;
+    S.dcl[i] = pd0;
+    S.cnt[2 * (size_t)i] = 0ULL; S.cnt[2 * (size_t)i + 1] = 0ULL;
+    }
+    }
+    __syncthreads();   // (the search's LDS and s_mate are the next sample's)
+  }
+}
+void launch_star_knn_wg(hipStream_t s, const ResolveArgs& a, const GridView& g, const GridView& tg, const NodeStoreView& st,
+                        double cell_edge, double slack, int n_bound, int R0) {
+  int blocks = n_bound < 2048 ? n_bound : 2048;   // (a workgroup per accepted sample; more than 2 048 of them loop)
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(k_star_knn_wg, dim3(blocks), dim3(256), 0, s, a, g, tg, st, cell_edge, slack, R0);
 }
 
 __global__ __launch_bounds__(256) void k_set_tree(int32_t* __restrict__ tree_col, const int32_t* __restrict__ ids, int n,

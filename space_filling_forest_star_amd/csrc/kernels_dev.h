@@ -101,6 +101,52 @@ __device__ __forceinline__ double topk_worst(const TopK& t, int k, int have) {  
   return have < k ? 1.0e300 : __shfl(t.d, k - 1);
 }
 
+// ---- SFF* (devstar.hip, k_star_knn_wg in kernels.hip): is sample i of the committed round accepted, and its rank among them
+__device__ __forceinline__ bool star_accepted(const DevForestView& f, int i, int& rank) {
+  const unsigned long long w = f.w_acc[i >> 6];
+  rank = f.acc_pref[i >> 6] + __popcll(w & ((1ULL << (i & 63)) - 1ULL));
+  return (w >> (i & 63)) & 1ULL;
+}
+
+// the same over cells of the round's own grid: samples accepted EARLIER in the round (temporary id in [Tb, self)) of
+// the same tree, not farther than `limit`
+__device__ __forceinline__ void star_cells_mates(const GridView& tg, int m, int cell, int lane, const double* qp, int tree, int Tb,
+                                                 int self, double limit, const DevForestView& f, TopK& t, int k, int& have) {
+  int inc = m;
+  for (int off = 1; off < 64; off <<= 1) {
+    const int o = __shfl_up(inc, off);
+    if (lane >= off) inc += o;
+  }
+  const int total = __shfl(inc, 63);
+  for (int base = 0; base < total; base += 64) {
+    const int j = base + lane;
+    const int jj = j < total ? j : total - 1;
+    int lo = 0, hi = 63;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (__shfl(inc, mid) > jj) hi = mid; else lo = mid + 1;
+    }
+    const int src_cell = __shfl(cell, lo);
+    const int slot = jj - (__shfl(inc, lo) - __shfl(m, lo));
+    bool cand = false;
+    double d = 1.0e300;
+    int id = 0x7fffffff;
+    if (j < total) {
+      const GridItem it = tg.items[(size_t)src_cell * tg.bk + slot];
+      id = it.id;
+      int rk;
+      if (it.tree == tree && id >= Tb && id < self && star_accepted(f, id - Tb, rk)) {
+        d = sffg::dist6(it.p, qp);
+        cand = d <= limit;
+      }
+    }
+    const double worst = topk_worst(t, k, have);
+    cand = cand && (have < k || key_less(d, id, worst, 0x7fffffff));
+    topk_insert(t, lane, k, have, __ballot(cand), d, id);
+  }
+}
+
+
 // ---- sample + steer of one slot (k_sample_steer; the device engine's k_append_sample runs it for the NEXT round right
 // behind the append).  tid = the thread's index in the launch (per-round housekeeping), i = the sample it draws (< 0:
 // none), slot >= 0: the sample's slot (k_append_sample knows it; otherwise it is read from the active list).
