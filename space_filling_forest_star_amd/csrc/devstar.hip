@@ -18,6 +18,7 @@
 #include "kernels.h"
 #include "sff_geom.h"
 #include "kernels_dev.h"
+#include "star_pass_dev.h"
 #include <cmath>
 #include <cstring>
 #include <cstdlib>
@@ -26,8 +27,6 @@ namespace sffk {
 
 using namespace sffg;
 
-#define STAR_INF __longlong_as_double(0x7ff0000000000000LL)
-#define STAR_FAULT 4   // index in StarView::hdr
 
 
 // candidates of a group of up to 64 cells of the node grid (lane = cell, m = its item count), flattened over the lanes:
@@ -82,6 +81,7 @@ __global__ __launch_bounds__(256) void k_star_knn(ResolveArgs A, GridView g, Gri
   const DevCtrl* c = f.ctrl;
   const int n = c->app_n;
   if (blockIdx.x == 0 && threadIdx.x < SFFK_STAR_PASSES) S.changed[threadIdx.x] = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { S.changed[SFFK_STAR_BAR] = 0; S.hdr[STAR_PASSES_RUN] = 0; S.hdr[STAR_CONVERGED] = 0; }   // (k_star_tail)
   for (int t = blockIdx.x * 256 + threadIdx.x; t < SFFK_STAR_PASSES * SFFK_SUBLISTS * SFFK_STAR_SUB; t += gridDim.x * 256) S.sub[t] = 0;
   if (n <= 0) return;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -534,277 +534,37 @@ __global__ __launch_bounds__(256) void k_star_knn(ResolveArgs A, GridView g, Gri
   }
 }
 
-// DistanceToRoot of node x as sample `i` finds it: the proposal of the latest accepted sample before i whose rewire
-// of x is active, else the node's own cost (a node created by this round: its sample's chosen cost)
-__device__ __forceinline__ double star_view(const DevForestView& f, const StarView& S, int x, int i, int N0, unsigned ep) {
-  const unsigned long long h = S.head[x];
-  int q = (unsigned)(h >> 32) == ep ? (int)(unsigned)(h & 0xffffffffULL) : 0;
-  int bs = -1;
-  double bv = 0;
-  for (int guard = 0; q && guard < (1 << 17); ++guard) {   // (a list holds at most one pair per accepted sample)
-    const int p = q - 1;
-    const int s = p / SFFK_STAR_KC;
-    if (s < i && s > bs) {
-      const double pr = S.prop[p];
-      if (pr < STAR_INF) { bs = s; bv = pr; }
-    }
-    q = S.next[p];
-  }
-  if (bs >= 0) return bv;
-  return x < N0 ? f.d_root[x] : S.best[S.acc_sample[x - N0]];
-}
-
-// ------------------------------------------------------------------ one pass of the fixed point
-#define STAR_SURV 64   // survivors of a sample gathered in LDS before they are appended (one atomic)
-#define STAR_TAB 128   // (edge, chunk) pairs of a sample unfolded at a time
-__device__ __forceinline__ int star_pack(int calls, bool free_) { return (((calls << 1) | (free_ ? 1 : 0)) << 1) | 1; }
-
+// ------------------------------------------------------------------ one pass of the fixed point (bodies: star_pass_dev.h)
 __global__ __launch_bounds__(256) void k_star_pass(ResolveArgs A, EnvView env, NodeStoreView st, int pass, int sample_blocks) {
-  __shared__ SurvivorItem s_surv[4][STAR_SURV];
-  __shared__ int32_t s_tab[4][STAR_TAB];
-  __shared__ float s_edge[4][128][8];     // per requested edge (lane * 2 + dir): start (clearance cells), step, samples
-  __shared__ int32_t s_any[4][128];       // ... 1 = some chunk of it went to the exact kernel
+  __shared__ StarPassLds L;
   const DevForestView& f = A.f;
   const StarView& S = A.S;
   const DevCtrl* c = f.ctrl;
-  if (c->app_n <= 0 || S.hdr[1] || S.hdr[STAR_FAULT]) return;
-  if (pass > 0 && S.changed[pass - 1] == 0) return;        // the pass before wrote nothing: fixed point reached
-  const int N0 = c->app_N0, Tb = f.temp_base;
+  // (every word the early returns look at is asked for before the first of them is tested: a launch that finds nothing to
+  //  do - most of a round's 15 pass / exact launches - costs one trip to memory instead of three one after the other)
+  const int app_n = c->app_n, N0 = c->app_N0;
   const unsigned ep = (unsigned)c->epoch;
+  const int h_n = S.hdr[0], h_skip = S.hdr[1], h_fault = S.hdr[STAR_FAULT];
+  const int chg = pass > 0 ? S.changed[pass - 1] : 1;
+  // (the rank's sample with them; all but the last sample workgroup lie within the list whatever the round's count is)
+  const int i_pre = (int)blockIdx.x < sample_blocks - 1 ? S.acc_sample[blockIdx.x * 4 + (threadIdx.x >> 6)] : -1;
+  if (app_n <= 0 || h_skip || h_fault) return;
+  if (chg == 0) return;                                     // the pass before wrote nothing: fixed point reached
+  const int Tb = f.temp_base;
   if ((int)blockIdx.x >= sample_blocks) {
-    // border entries of the round (src/forest.h:288-294): d = cost(neighbour) + cost(expanded) + their distance, the
-    // costs as the rejected sample's turn finds them
     const int e = ((int)blockIdx.x - sample_blocks) * 256 + threadIdx.x;
-    if (e >= S.hdr[2]) return;
-    const int s = S.ev_sample[e];
-    const double vn = star_view(f, S, S.ev_nb[e], s, N0, ep), ve = star_view(f, S, S.ev_ex[e], s, N0, ep);
-    f.b_dist[S.hdr[3] + e] = vn + ve + S.ev_dist[e];
+    if (e < S.hdr[2]) star_pass_event<false>(f, S, e, S.hdr[3], N0, ep);
     return;
   }
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int r = blockIdx.x * 4 + wave;
-  if (r >= S.hdr[0]) return;
-  const int i = S.acc_sample[r];
-  const int cnt = S.m_cnt[i];
-  const size_t p = (size_t)i * SFFK_STAR_KC + lane;
-  const bool mem = lane < cnt;
-  const int ex = A.parent[i];
-  const int x = mem ? S.m_id[p] : (lane == cnt ? ex : -1);
-  const double d = mem ? S.m_d[p] : 0.0;
-  const size_t s0 = p * 2;
-  int ew_f = mem ? S.ew[s0] : 0, ew_b = mem ? S.ew[s0 + 1] : 0;
-  const double pd = A.pdist[i];
-  const double v = x >= 0 ? star_view(f, S, x, i, N0, ep) : 0.0;
-  // ---- edges sent to the exact kernel by the pass before: their answers are in
-  {
-    bool bad = false;
-    if (ew_f == -1) {
-      const int fh = S.first_hit[s0], ns = S.ens[s0];
-      bad |= fh == 0;                                     // 0 = the edge's triangle candidate list ran over
-      ew_f = star_pack(fh == 0x7fffffff ? ns : fh, fh == 0x7fffffff);
-      S.ew[s0] = ew_f;
-    }
-    if (ew_b == -1) {
-      const int fh = S.first_hit[s0 + 1], ns = S.ens[s0 + 1];
-      bad |= fh == 0;
-      ew_b = star_pack(fh == 0x7fffffff ? ns : fh, fh == 0x7fffffff);
-      S.ew[s0 + 1] = ew_b;
-    }
-    if (__any(bad)) {
-      if (lane == 0) atomicOr(S.hdr + STAR_FAULT, 1);
-      return;
-    }
-  }
-  // ---- which member edges can the two loops reach at all, given the views?  Choose-parent (:320-327) only looks at a
-  // member whose cost through it beats the running best, and the running best never exceeds its start value; the rewire
-  // loop (:332-350) only at a member the new node's cost - at least the smallest cost any member offers - improves.
-  const double best0 = pd + __shfl(v, cnt);           // dist(new, expanded) + expanded->DistanceToRoot (:308)
-  const double nd = d + v;
-  const bool need_f = mem && nd < best0 - SFFG_TOL;
-  double best_low = need_f ? nd : best0;
-  for (int off = 32; off > 0; off >>= 1) {
-    const double o = __shfl_xor(best_low, off);
-    best_low = o < best_low ? o : best_low;
-  }
-  const bool need_b = mem && best_low + d < v - SFFG_TOL;
-  const bool req_f = need_f && ew_f == 0, req_b = need_b && ew_b == 0;
-  if (__any(req_f || req_b)) {
-    // ---- new requests: sample counts, then the clearance cull of their samples right here (~97 % of the chunks are
-    // answered "free" by the bits); what is not goes onto the exact kernel's list and is answered before the next pass
-    const double qp[6] = {A.newpos[6 * (size_t)i], A.newpos[6 * (size_t)i + 1], A.newpos[6 * (size_t)i + 2],
-                          A.newpos[6 * (size_t)i + 3], A.newpos[6 * (size_t)i + 4], A.newpos[6 * (size_t)i + 5]};
-    int nch_f = 0, nch_b = 0, ns_f = 0, ns_b = 0;
-    const int sid = mem ? (x < N0 ? x : Tb + S.acc_sample[x - N0]) : 0;
-    if (req_f || req_b) {
-      double mp[6];
-      for (int q = 0; q < 6; ++q) mp[q] = st.pos[6 * (size_t)sid + q];
-      float* ef = s_edge[wave][2 * lane];
-      float* eb = s_edge[wave][2 * lane + 1];
-      if (req_f) {
-        const double parts = edge_parts(qp, mp);
-        ns_f = edge_samples(parts);
-        nch_f = ns_f > 0 ? (ns_f + 63) >> 6 : 0;
-        const float inv = (float)env.clear_inv * __frcp_rn((float)parts);
-        for (int q = 0; q < 3; ++q) {
-          ef[q] = (float)((qp[q] - env.clear_org[q]) * env.clear_inv);
-          ef[4 + q] = (float)(mp[q] - qp[q]) * inv;
-        }
-        ef[3] = __int_as_float(ns_f);
-        s_any[wave][2 * lane] = 0;
-      }
-      if (req_b) {
-        const double parts = edge_parts(mp, qp);
-        ns_b = edge_samples(parts);
-        nch_b = ns_b > 0 ? (ns_b + 63) >> 6 : 0;
-        const float inv = (float)env.clear_inv * __frcp_rn((float)parts);
-        for (int q = 0; q < 3; ++q) {
-          eb[q] = (float)((mp[q] - env.clear_org[q]) * env.clear_inv);
-          eb[4 + q] = (float)(qp[q] - mp[q]) * inv;
-        }
-        eb[3] = __int_as_float(ns_b);
-        s_any[wave][2 * lane + 1] = 0;
-      }
-    }
-    const int my_nch = nch_f + nch_b;
-    int incl = my_nch;
-    for (int off = 1; off < 64; off <<= 1) {
-      const int o = __shfl_up(incl, off);
-      if (lane >= off) incl += o;
-    }
-    const int excl = incl - my_nch;
-    const int P = __shfl(incl, 63);
-    SurvivorItem* list = static_cast<SurvivorItem*>(S.items);
-    SurvivorItem* buf = s_surv[wave];
-    int32_t* tab = s_tab[wave];
-    int n_buf = 0;
-    const int sub_list = blockIdx.x & (SFFK_SUBLISTS - 1), sub_cap = S.items_cap / SFFK_SUBLISTS;
-    int32_t* sub = S.sub + ((size_t)pass * SFFK_SUBLISTS + sub_list) * SFFK_STAR_SUB;
-    auto flush = [&]() {
-      int base = 0;
-      if (lane == 0) base = atomicAdd(sub, n_buf);
-      base = __shfl(base, 0);
-      for (int o = lane; o < n_buf; o += 64)
-        if (base + o < sub_cap) list[(size_t)sub_list * sub_cap + base + o] = buf[o];
-      n_buf = 0;     // (a sub-list that ran over is noticed by k_star_exact: fault)
-    };
-    const float nxd = (float)env.clear_n[0], nyd = (float)env.clear_n[1], nzd = (float)env.clear_n[2];
-    const int pu = lane >> 3, gq = lane & 7;
-    for (int w0 = 0; w0 < P; w0 += STAR_TAB) {
-      __builtin_amdgcn_wave_barrier();
-      for (int cc = 0; cc < my_nch; ++cc) {
-        const int pp = excl + cc;
-        if (pp >= w0 && pp < w0 + STAR_TAB) {
-          const int e = cc < nch_f ? 2 * lane : 2 * lane + 1;
-          const int ch = cc < nch_f ? cc : cc - nch_f;
-          tab[pp - w0] = (e << 16) | ch;
-        }
-      }
-      __builtin_amdgcn_wave_barrier();
-      const int wn = P - w0 < STAR_TAB ? P - w0 : STAR_TAB;
-      for (int q0 = 0; q0 < wn; q0 += 8) {
-        // eight consecutive samples of an edge lie within 0.4 units of the fifth one (the sample spacing never exceeds
-        // the 0.1 of src/problemStruct.h:121) and the bits are built with that reach on top (Ctx::build_clearance): one
-        // lookup answers a group of eight samples, a lane takes a group, a step of the wave eight (edge, chunk) pairs
-        const bool valid = q0 + pu < wn;
-        const int ent = valid ? tab[q0 + pu] : 0;
-        const int e = ent >> 16, ch = ent & 0xffff;
-        const float* ee = s_edge[wave][e];
-        const int ns = __float_as_int(ee[3]);
-        const int first = 1 + 64 * ch + 8 * gq;
-        bool need = valid && first <= ns;
-        const int left = ns - first + 1;
-        const int probe = first + 4 <= ns ? first + 4 : ns;
-        const uint32_t* wp = nullptr;
-        int sh = 0;
-        if (need && env.clear_bits_edge) {
-          const float td = (float)probe;
-          const float fx = __builtin_fmaf(td, ee[4], ee[0]), fy = __builtin_fmaf(td, ee[5], ee[1]), fz = __builtin_fmaf(td, ee[6], ee[2]);
-          if (fx >= 0 && fy >= 0 && fz >= 0 && fx < nxd && fy < nyd && fz < nzd) {
-            const uint32_t ci = ((uint32_t)(int)fz * (uint32_t)env.clear_n[1] + (uint32_t)(int)fy) * (uint32_t)env.clear_n[0] + (uint32_t)(int)fx;
-            wp = env.clear_bits_edge + (ci >> 5);
-            sh = (int)(ci & 31u);
-          } else if (fx == fx && fy == fy && fz == fz) {
-            need = false;                                     // beyond the inflated box of the environment
-          }
-        }
-        const uint32_t word = wp ? *wp : 0u;
-        if (wp && ((word >> sh) & 1u)) need = false;
-        unsigned long long m = need ? (((left >= 8 ? 0xffULL : ((1ULL << left) - 1ULL))) << (8 * gq)) : 0ULL;
-        m |= __shfl_xor(m, 1);
-        m |= __shfl_xor(m, 2);
-        m |= __shfl_xor(m, 4);
-        const bool lead = gq == 0 && m != 0ULL && env.n_tri != 0;
-        if (__any(lead)) {
-          if (lead) s_any[wave][e] = 1;
-          surv_emit(buf, n_buf, lead, lane, (int)(((size_t)i * SFFK_STAR_KC) * 2) + e, ch, m);
-          if (n_buf > STAR_SURV - 33) flush();
-        }
-      }
-    }
-    if (n_buf) flush();
-    __builtin_amdgcn_wave_barrier();
-    if (req_f) {
-      if (s_any[wave][2 * lane]) {
-        ew_f = -1;
-        S.first_hit[s0] = 0x7fffffff; S.seg_ovf[s0] = 0; S.ens[s0] = ns_f; S.ida[s0] = Tb + i; S.idb[s0] = sid;
-      } else ew_f = star_pack(ns_f, true);
-      S.ew[s0] = ew_f;
-    }
-    if (req_b) {
-      if (s_any[wave][2 * lane + 1]) {
-        ew_b = -1;
-        S.first_hit[s0 + 1] = 0x7fffffff; S.seg_ovf[s0 + 1] = 0; S.ens[s0 + 1] = ns_b; S.ida[s0 + 1] = sid; S.idb[s0 + 1] = Tb + i;
-      } else ew_b = star_pack(ns_b, true);
-      S.ew[s0 + 1] = ew_b;
-    }
-  }
-  const bool pending = __any((need_f && ew_f == -1) || (need_b && ew_b == -1));
-  // (an edge still with the exact kernel counts as blocked here; the pass after its answer redoes the sample)
-  const bool free_f = ew_f > 0 && ((ew_f >> 1) & 1), free_b = ew_b > 0 && ((ew_b >> 1) & 1);
-  const unsigned long long calls_f = ew_f > 0 ? (unsigned long long)(ew_f >> 2) : 0ULL;
-  const unsigned long long calls_b = ew_b > 0 ? (unsigned long long)(ew_b >> 2) : 0ULL;
-  // ---- choose parent (:320-327): the members in (distance, id) order against the running best
-  double best = best0;
-  int psel = ex;
-  double dcl = pd;
-  unsigned long long cc = 0, pf = 0;
-  int cur = 0;
-  while (true) {
-    const unsigned long long m = __ballot(mem && lane >= cur && nd < best - SFFG_TOL);
-    if (!m) break;
-    const int b = __ffsll((long long)m) - 1;
-    pf += 1;
-    cc += __shfl(calls_f, b);
-    if (__shfl((int)free_f, b)) { best = __shfl(nd, b); psel = __shfl(x, b); dcl = __shfl(d, b); }
-    cur = b + 1;
-  }
-  // ---- rewire (:332-350)
-  const double proposed = best + d;
-  const bool test = mem && proposed < v - SFFG_TOL;
-  const bool act = test && free_b;
-  pf += (unsigned long long)__popcll(__ballot(test));
-  unsigned long long cb = test ? calls_b : 0ULL;
-  for (int off = 32; off > 0; off >>= 1) cb += __shfl_xor(cb, off);
-  cc += cb;
-  const double np = act ? proposed : STAR_INF;
-  // ---- write what changed
-  bool diff = mem && __double_as_longlong(S.prop[p]) != __double_as_longlong(np);
-  if (lane == 0)
-    diff |= __double_as_longlong(S.best[i]) != __double_as_longlong(best) || S.psel[i] != psel ||
-            __double_as_longlong(S.dcl[i]) != __double_as_longlong(dcl) || S.cnt[2 * (size_t)i] != cc || S.cnt[2 * (size_t)i + 1] != pf;
-  if (diff && mem) S.prop[p] = np;
-  const bool any_diff = __any(diff);
-  if (lane == 0) {
-    if (any_diff) {
-      S.best[i] = best; S.psel[i] = psel; S.dcl[i] = dcl;
-      S.cnt[2 * (size_t)i] = cc; S.cnt[2 * (size_t)i + 1] = pf;
-    }
-    if (any_diff || pending) S.changed[pass] = 1;
-  }
+  if (r >= h_n) return;
+  const int i = i_pre >= 0 ? i_pre : S.acc_sample[r];
+  star_pass_sample<false>(A, env, st, pass, blockIdx.x & (SFFK_SUBLISTS - 1), i, N0, Tb, ep, L, wave, lane);
 }
 
 // ------------------------------------------------------------------ apply: nodes, rewires, housekeeping
-__global__ __launch_bounds__(256) void k_star_apply(ResolveArgs A, GridView tg, int n_bound, int max_passes) {
+__global__ __launch_bounds__(256) void k_star_apply(ResolveArgs A, GridView tg, int n_bound, int max_passes, int tail) {
   const DevForestView& f = A.f;
   const StarView& S = A.S;
   DevCtrl* c = f.ctrl;
@@ -822,15 +582,28 @@ __global__ __launch_bounds__(256) void k_star_apply(ResolveArgs A, GridView tg, 
     if (i == 0) tg.ovf_cnt[0] = 0;
   }
   const int n = c->app_n;
-  if (n <= 0 || S.hdr[1]) return;
+  const int h_skip = S.hdr[1], h_fault = S.hdr[STAR_FAULT];
+  int chg[SFFK_STAR_PASSES];                  // (asked for together: one trip to memory, not one per pass)
+#pragma unroll
+  for (int t = 0; t < SFFK_STAR_PASSES; ++t) chg[t] = S.changed[t];
+  const int t_passes = S.hdr[STAR_PASSES_RUN], t_conv = S.hdr[STAR_CONVERGED];
+  if (n <= 0 || h_skip) return;
   // fixed point reached?  (the first pass that wrote nothing; none = not converged within the launches of a round)
   int passes = 0;
   bool conv = false;
-  for (int t = 0; t < max_passes; ++t) {
-    ++passes;
-    if (S.changed[t] == 0) { conv = true; break; }
+  if (tail) {                                   // (the passes after the first ran in k_star_tail: its count, its verdict)
+    passes = t_passes;
+    conv = t_conv != 0;
+  } else {
+#pragma unroll
+    for (int t = 0; t < SFFK_STAR_PASSES; ++t) {
+      if (t < max_passes && !conv) {
+        ++passes;
+        if (chg[t] == 0) conv = true;
+      }
+    }
   }
-  if (!conv || S.hdr[STAR_FAULT]) {
+  if (!conv || h_fault) {
     // nothing of this round is kept: the control block goes back to where the round began and the host redoes the
     // round on its unbounded path (k_append finds app_n = 0)
     if (blockIdx.x == 0) {
@@ -947,13 +720,24 @@ void launch_star_stage(hipStream_t s, const ResolveArgs& a, int n_bound, const S
   if (lone) hipLaunchKernelGGL(k_star_knn, dim3(sample_blocks), dim3(256), 0, s, a, L.g, L.tg, L.st, L.cell_edge, L.slack, R0);
   else launch_star_knn_wg(s, a, L.g, L.tg, L.st, L.cell_edge, L.slack, n_bound, R0);
   const int event_blocks = (n_bound + 255) / 256;
+  // the passes after the first: one launch (k_star_tail, as many passes as the round needs, up to SFFK_STAR_TAIL_PASSES) or -
+  // SFFGPU_STAR_TAIL=0 - the fixed chain of up to SFFK_STAR_PASSES pass / exact launches
+  static const bool tail = !(getenv("SFFGPU_STAR_TAIL") && atoi(getenv("SFFGPU_STAR_TAIL")) == 0);
+  if (tail) {
+    const int passes = L.passes > 0 ? L.passes : SFFK_STAR_TAIL_PASSES;
+    hipLaunchKernelGGL(k_star_pass, dim3(sample_blocks + event_blocks), dim3(256), 0, s, a, L.env, L.st, 0, sample_blocks);
+    if (passes > 1) launch_star_exact(s, L.env, L.rob, L.st.pos, a.S, 0);
+    launch_star_tail(s, a, L.env, L.rob, L.st, n_bound, passes);
+    hipLaunchKernelGGL(k_star_apply, dim3(sample_blocks), dim3(256), 0, s, a, L.tg, n_bound, passes, 1);
+    return;
+  }
   const int passes = L.passes > 0 && L.passes < SFFK_STAR_PASSES ? L.passes : SFFK_STAR_PASSES;
   for (int pass = 0; pass < passes; ++pass) {
     hipLaunchKernelGGL(k_star_pass, dim3(sample_blocks + event_blocks), dim3(256), 0, s, a, L.env, L.st, pass, sample_blocks);
     // (what the pass could not answer from the clearance bits; nothing to do = the launch returns at once)
     if (pass + 1 < passes) launch_star_exact(s, L.env, L.rob, L.st.pos, a.S, pass);
   }
-  hipLaunchKernelGGL(k_star_apply, dim3(sample_blocks), dim3(256), 0, s, a, L.tg, n_bound, passes);
+  hipLaunchKernelGGL(k_star_apply, dim3(sample_blocks), dim3(256), 0, s, a, L.tg, n_bound, passes, 0);
 }
 
 }  // namespace sffk

@@ -211,7 +211,7 @@ void Forest::dev_star_setup() {
     d.s_cnt.ensure(W * 16);
     d.s_accs.ensure(W * 4);
     d.s_hdr.ensure(64);
-    d.s_changed.ensure(64);
+    d.s_changed.ensure(256);
     d.s_ew.ensure(W * KC * 2 * 4);
     d.s_ida.ensure(W * KC * 2 * 4);
     d.s_idb.ensure(W * KC * 2 * 4);
@@ -235,7 +235,7 @@ void Forest::dev_star_setup() {
       HIPCHK(hipMemset(d.s_dbg.p, 0, 32 * 8));
     }
     HIPCHK(hipMemset(d.s_hdr.p, 0, 64));
-    HIPCHK(hipMemset(d.s_changed.p, 0, 64));
+    HIPCHK(hipMemset(d.s_changed.p, 0, 256));
     HIPCHK(hipMemset(d.s_acc.p, 0, 64 * SFFK_STAR_ACC * 8));
     d.star_inited = true;
   }
@@ -1522,6 +1522,14 @@ void Forest::run_device(int max_waves) {
               g[4] / w / 100.0, g[7] / 100.0, g[5] / w, g[8] / w, g[6] / w, g[0]);
       fprintf(stderr, "[sffgpu k_star_knn cube phase] us: counts %.1f items+distances %.1f bisection %.1f sort+rest %.1f\n", g[9] / w / 100.0,
               g[10] / w / 100.0, g[11] / w / 100.0, g[12] / w / 100.0);
+      if (g[16]) {
+        const double n = (double)g[16], ps = (double)std::max<unsigned long long>(1ULL, g[17]);
+        fprintf(stderr, "[sffgpu k_star_tail, workgroup 0] launches that ran passes %llu, passes each %.2f | us per pass: pass phase %.1f exact phase %.1f "
+                "barriers (two): release %.1f wait %.1f acquire %.1f\n", g[16], g[17] / n, g[18] / ps / 100.0, g[19] / ps / 100.0, g[20] / ps / 100.0,
+                g[21] / ps / 100.0, g[22] / ps / 100.0);
+        if (g[24]) fprintf(stderr, "[sffgpu k_star_tail, sections of a sample's pass (STAR_PASS_TRACE build)] us: first loads %.1f views %.1f evaluate %.1f (of it requests %.1f) "
+                           "loops %.1f writes %.1f\n", g[24] / ps / 100.0, g[25] / ps / 100.0, (g[26] + g[27]) / ps / 100.0, g[27] / ps / 100.0, g[28] / ps / 100.0, g[29] / ps / 100.0);
+      }
     }
     const double r = (double)std::max<unsigned long long>(1ULL, k.prof[6]);
     if (d.kc_trace.p) {

@@ -531,7 +531,9 @@ struct DevForestView {
 //                 order is written (descendants' costs are NOT propagated, as in the reference, :344-348)
 #define SFFK_STAR_KC 64        // member slots per sample (k <= 50 for any int32 node count; lane k holds the expanded node)
 #define SFFK_STAR_KMAX 56
-#define SFFK_STAR_PASSES 8     // most launches per round; not converged by then = fault (the round is redone on the host)
+#define SFFK_STAR_PASSES 8     // counter sets / changed flags (pass p uses set p mod 8); the fixed chain's most passes per round
+#define SFFK_STAR_TAIL_PASSES 48  // k_star_tail: most passes per round; not converged by then = fault (the round is redone on the host)
+#define SFFK_STAR_BAR 32       // index in StarView::changed of k_star_tail's barrier counter (its own cache line)
 #define SFFK_STAR_ACC 8        // sub-counter words per line of StarView::acc
 #define SFFK_STAR_SUB 16       // ints between two survivor sub-list counters (their own cache lines)
 struct StarView {
@@ -546,8 +548,8 @@ struct StarView {
   double* best; int32_t* psel; double* dcl;   // per sample: cost, chosen parent (node id), distance to it (:320-329)
   unsigned long long* cnt;     // per sample: {Collide calls, isPathFree calls} of its choose-parent / rewire loops
   int32_t* acc_sample;         // rank among the accepted samples -> sample (k_commit)
-  int32_t* hdr;                // {accepted samples, skip, border entries of the round, first of them, fault}
-  int32_t* changed;            // SFFK_STAR_PASSES flags: pass t changed something / still waits for an edge
+  int32_t* hdr;                // {accepted samples, skip, border entries of the round, first of them, fault, passes run, converged}
+  int32_t* changed;            // SFFK_STAR_PASSES flags: pass t changed something / still waits for an edge; [SFFK_STAR_BAR]: k_star_tail's barrier
   // member edges, answered LAZILY: edge slot = (sample * KC + m) * 2 + dir (0: new -> member :323, 1: member -> new :336).
   // ew: 0 = never asked for; -1 = on the exact kernel's list (answer in first_hit after the launch that follows the pass);
   // else ((Collide calls << 1 | free) << 1) | 1.  Only the edges the loops can reach at all are ever looked at.
@@ -636,6 +638,8 @@ struct StarLaunch {            // what the host adds for the SFF* stage of a com
 };
 void launch_star_stage(hipStream_t s, const ResolveArgs& a, int n_bound, const StarLaunch& L);   // devstar.hip
 // exact collision test of the member-edge chunks a star pass could not answer from the clearance bits (kernels.hip)
+void launch_star_tail(hipStream_t s, const ResolveArgs& a, const EnvView& env, const RobotView& rob, const NodeStoreView& st,
+                      int n_bound, int max_passes);
 void launch_star_exact(hipStream_t s, const EnvView& env, const RobotView& rob, const double* store_pos, const StarView& S,
                        int pass);
 // the commit of one round: k_commit (wide) [-> the SFF* stage] -> k_append / k_append_sample (wide);

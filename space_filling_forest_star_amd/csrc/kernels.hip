@@ -24,6 +24,7 @@
 #include <algorithm>
 #include "sff_geom.h"
 #include "kernels_dev.h"
+#include "star_pass_dev.h"
 
 namespace sffk {
 
@@ -721,15 +722,17 @@ __global__ __launch_bounds__(256) void k_star_knn_wg(ResolveArgs A, GridView g, 
   const StarView& S = A.S;
   const DevCtrl* c = f.ctrl;
   const int n = c->app_n;
-  if (blockIdx.x == 0 && threadIdx.x < SFFK_STAR_PASSES) S.changed[threadIdx.x] = 0;
-  for (int t = blockIdx.x * 256 + threadIdx.x; t < SFFK_STAR_PASSES * SFFK_SUBLISTS * SFFK_STAR_SUB; t += gridDim.x * 256) S.sub[t] = 0;
-  if (n <= 0) return;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int n_acc = S.hdr[0];                      // (k_commit: the accepted samples, S.acc_sample[rank])
   const int N0 = c->app_N0, Tb = f.temp_base;
   const unsigned ep = (unsigned)c->epoch;
+  const int i_first = S.acc_sample[blockIdx.x];    // (asked for with the header words; the grid never exceeds the list's size)
+  if (blockIdx.x == 0 && threadIdx.x < SFFK_STAR_PASSES) S.changed[threadIdx.x] = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { S.changed[SFFK_STAR_BAR] = 0; S.hdr[STAR_PASSES_RUN] = 0; S.hdr[STAR_CONVERGED] = 0; }   // (k_star_tail)
+  for (int t = blockIdx.x * 256 + threadIdx.x; t < SFFK_STAR_PASSES * SFFK_SUBLISTS * SFFK_STAR_SUB; t += gridDim.x * 256) S.sub[t] = 0;
+  if (n <= 0) return;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int r = blockIdx.x; r < n_acc; r += gridDim.x) {
-    const int i = S.acc_sample[r];
+    const int i = r == (int)blockIdx.x ? i_first : S.acc_sample[r];
     // k = (size_t)(2e log10(#nodes)) with the nodes accepted before this sample counted in (src/forest.h:309)
     const int Nn = N0 + r;
     const int k_ref = __popcll(__ballot(lane > 0 && lane <= SFFK_STAR_KMAX + 1 && S.ktab[lane] <= Nn));
@@ -3665,18 +3668,69 @@ __global__ __launch_bounds__(64 * SEG_WAVES) __attribute__((amdgpu_waves_per_eu(
 // SFF* on the device (devstar.hip): the member-edge chunks a star pass could not answer from the clearance bits.  Same
 // persistent scheme as k_collide_items; an edge's end points are store entries (the new sample's temporary entry and
 // the member), named per edge slot by ida / idb.
+// star_exact_items: the item loop, by workgroup `wg` of `nwg` (k_star_exact: the grid; k_star_tail: its active workgroups).
+// sub = the pass's SFFK_SUBLISTS counters + tickets; sub_n / sub_incl = lane's sub-list length and their running sum.
+struct ExactLds {
+  double* rtri; double* rbox; double* stage; int32_t* stack; int32_t* cand; int32_t* queue; int32_t* cand_base;
+};
+__device__ __forceinline__ ExactLds exact_lds(double* lds_d, int n_rob_tri, int wave) {
+  ExactLds E;
+  E.rtri = lds_d;
+  E.stage = E.rtri + (size_t)n_rob_tri * 9 + (size_t)wave * STAGE_DOUBLES;
+  int32_t* ibase = reinterpret_cast<int32_t*>(E.rtri + (size_t)n_rob_tri * 9 + (size_t)SEG_WAVES * STAGE_DOUBLES);
+  E.rbox = reinterpret_cast<double*>(ibase + SEG_WAVES * (STACK_CAP + TG_HASH + CAND_CAP + QUEUE_CAP));
+  E.stack = ibase + wave * (STACK_CAP + TG_HASH);
+  E.cand_base = ibase + SEG_WAVES * (STACK_CAP + TG_HASH);
+  E.cand = E.cand_base + wave * CAND_CAP;
+  E.queue = ibase + SEG_WAVES * (STACK_CAP + TG_HASH + CAND_CAP) + wave * QUEUE_CAP;
+  return E;
+}
+template <bool COH>
+__device__ __forceinline__ void star_exact_items(const EnvView& env, const RobotView& rob, const ExactLds& E,
+                                                 const double* __restrict__ store_pos, const int32_t* ida,
+                                                 const int32_t* idb, const SurvivorItem* list,
+                                                 int sub_cap, int32_t* sub, int sub_n, int sub_incl, int M,
+                                                 int32_t* first_hit, int32_t* overflow_flag,
+                                                 ShareArea& s_share, int wg, int nwg, int wave, int lane) {
+  DBG_DECL
+  const int W = nwg * SEG_WAVES;
+  // (one item per wave, the rest by tickets to the waves that come back first: see k_collide_items)
+  const int grp = (wg + nwg * wave) & (SFFK_SUBLISTS - 1);
+  int32_t* const ticket = sub + (size_t)grp * SFFK_STAR_SUB + 1;
+  auto next_item = [&]() -> int {
+    int t = 0;
+    if (lane == 0) t = atomicAdd(ticket, 1);
+    t = __builtin_amdgcn_readfirstlane(t);
+    return W + grp + SFFK_SUBLISTS * t;
+  };
+  for (int e = wg + nwg * wave; e < M; e = next_item()) {
+    const int sl = __popcll(__ballot(sub_incl <= e));
+    const int j = e - (__shfl(sub_incl, sl) - __shfl(sub_n, sl));
+    const SurvivorItem it = sld<COH>(list + (size_t)sl * sub_cap + j);
+    const int slot = it.slot;
+    if (it.chunk > 0 && sld<COH>(first_hit + slot) <= 64 * it.chunk) continue;
+    double a[6], b[6];
+    const double* pa = store_pos + 6 * (size_t)sld<COH>(ida + slot);
+    const double* pb = store_pos + 6 * (size_t)sld<COH>(idb + slot);
+    for (int k = 0; k < 6; ++k) { a[k] = pa[k]; b[k] = pb[k]; }
+    segment_chunk(env, rob, E.rtri, E.rbox, E.stack, E.cand, E.queue, E.stage, a, b, slot, it.chunk, true, it.mask, first_hit,
+                  overflow_flag, lane DBG_PASS, &s_share);
+  }
+  share_help(env, rob, E.rtri, E.rbox, E.queue, E.stage, E.cand_base, s_share, lane DBG_PASS);
+}
+
 __global__ __launch_bounds__(64 * SEG_WAVES) __attribute__((amdgpu_waves_per_eu(CI_OCC))) void k_star_exact(
     EnvView env, RobotView rob, const double* __restrict__ store_pos, const int32_t* __restrict__ ida,
-    const int32_t* __restrict__ idb, const SurvivorItem* __restrict__ list, int items_cap, const int32_t* __restrict__ sub,
+    const int32_t* __restrict__ idb, const SurvivorItem* __restrict__ list, int items_cap, int32_t* __restrict__ sub,
     int32_t* __restrict__ first_hit, int32_t* __restrict__ overflow_flag, int32_t* __restrict__ hdr) {
-  if (hdr[1] || hdr[4]) return;
-  extern __shared__ double lds_d[];
-  double* rtri = lds_d;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  double* stage = rtri + (size_t)rob.n_tri * 9 + (size_t)wave * STAGE_DOUBLES;
-  int32_t* ibase = reinterpret_cast<int32_t*>(rtri + (size_t)rob.n_tri * 9 + (size_t)SEG_WAVES * STAGE_DOUBLES);
-  const int sub_cap = items_cap / SFFK_SUBLISTS;
+  // (the sub-list counts are asked for before the header words are tested: an idle launch is one trip to memory)
   int sub_n = sub[lane * SFFK_STAR_SUB];
+  const int h_skip = hdr[1], h_fault = hdr[4];
+  if (h_skip || h_fault) return;
+  extern __shared__ double lds_d[];
+  const ExactLds E = exact_lds(lds_d, rob.n_tri, wave);
+  const int sub_cap = items_cap / SFFK_SUBLISTS;
   if (sub_n > sub_cap) {   // a sub-list ran over: items were dropped - the round is redone on the host path
     if (blockIdx.x == 0 && wave == 0) atomicOr(hdr + 4, 1);
     sub_n = sub_cap;
@@ -3690,39 +3744,133 @@ __global__ __launch_bounds__(64 * SEG_WAVES) __attribute__((amdgpu_waves_per_eu(
   if (M <= 0 || env.n_tri == 0) return;
   __shared__ ShareArea s_share;
   share_init(s_share);
-  for (int i = threadIdx.x; i < rob.n_tri * 9; i += blockDim.x) rtri[i] = rob.tri[i];
+  for (int i = threadIdx.x; i < rob.n_tri * 9; i += blockDim.x) E.rtri[i] = rob.tri[i];
   __syncthreads();
-  double* rbox = reinterpret_cast<double*>(ibase + SEG_WAVES * (STACK_CAP + TG_HASH + CAND_CAP + QUEUE_CAP));
-  fill_robot_boxes(rtri, rbox, rob.n_tri, threadIdx.x, blockDim.x);
+  fill_robot_boxes(E.rtri, E.rbox, rob.n_tri, threadIdx.x, blockDim.x);
   __syncthreads();
-  int32_t* stack = ibase + wave * (STACK_CAP + TG_HASH);
-  int32_t* cand = ibase + SEG_WAVES * (STACK_CAP + TG_HASH) + wave * CAND_CAP;
-  int32_t* queue = ibase + SEG_WAVES * (STACK_CAP + TG_HASH + CAND_CAP) + wave * QUEUE_CAP;
-  DBG_DECL
-  const int W = gridDim.x * SEG_WAVES;
-  // (one item per wave, the rest by tickets to the waves that come back first: see k_collide_items)
-  const int grp = (blockIdx.x + gridDim.x * wave) & (SFFK_SUBLISTS - 1);
-  int32_t* const ticket = const_cast<int32_t*>(sub) + (size_t)grp * SFFK_STAR_SUB + 1;
-  auto next_item = [&]() -> int {
-    int t = 0;
-    if (lane == 0) t = atomicAdd(ticket, 1);
-    t = __builtin_amdgcn_readfirstlane(t);
-    return W + grp + SFFK_SUBLISTS * t;
-  };
-  for (int e = blockIdx.x + gridDim.x * wave; e < M; e = next_item()) {
-    const int sl = __popcll(__ballot(sub_incl <= e));
-    const int j = e - (__shfl(sub_incl, sl) - __shfl(sub_n, sl));
-    const SurvivorItem it = list[(size_t)sl * sub_cap + j];
-    const int slot = it.slot;
-    if (it.chunk > 0 && first_hit[slot] <= 64 * it.chunk) continue;
-    double a[6], b[6];
-    const double* pa = store_pos + 6 * (size_t)ida[slot];
-    const double* pb = store_pos + 6 * (size_t)idb[slot];
-    for (int k = 0; k < 6; ++k) { a[k] = pa[k]; b[k] = pb[k]; }
-    segment_chunk(env, rob, rtri, rbox, stack, cand, queue, stage, a, b, slot, it.chunk, true, it.mask, first_hit, overflow_flag, lane DBG_PASS,
-                  &s_share);
+  star_exact_items<false>(env, rob, E, store_pos, ida, idb, list, sub_cap, sub, sub_n, sub_incl, M, first_hit, overflow_flag, s_share,
+                          blockIdx.x, gridDim.x, wave, lane);
+}
+
+// ------------------------------------------------------------------ SFF*: the passes after the first as ONE launch
+// A round's fixed point takes 3.2 passes on average (configs[4]) and up to 6; as launches - 8 passes + 7 exact kernels per
+// round, sized for the worst round - the ones with nothing to do cost ~3 us each and every working one a launch boundary:
+// 65 of a round's 280 us.  k_star_tail runs "pass p, the exact items it left, pass p + 1, ..." until a pass changes nothing,
+// in the first `g_act` workgroups of its grid (one per four accepted samples; the others return at once) with a barrier
+// over them between the phases: an agent-scope release / acquire pair around one counter (what a kernel boundary does to
+// the caches, without the boundary).  The grid is small enough to be resident at once (<= one workgroup per CU, <= 64 when
+// several processes may share the GPU - the launcher's choice); a barrier that is not complete within STAR_BAR_TICKS
+// raises the stage's fault flag instead of waiting for ever (the round is then redone on the host path like any fault).
+// Pass p uses the counter set / changed flag p mod SFFK_STAR_PASSES; workgroup 0 clears the set of pass p + 1 during pass p.
+#define STAR_BAR_TICKS 4000000ULL      // 40 ms of the 100 MHz wall clock
+__device__ __forceinline__ void star_grid_barrier(int32_t* bar, int target, int32_t* fault, unsigned long long* dbg) {
+  // (what the workgroup hands over it wrote through - sst<true> - and every such store has been acknowledged before the
+  //  workgroup counts itself in; what it takes over behind the barrier it reads from memory - sld<true>: no cache-wide
+  //  write-back / invalidate, the fixed data of the round stays in the L2 from pass to pass)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_waitcnt(0);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long ta = wall_clock64();
+    __hip_atomic_fetch_add(bar, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(2);
+      if (wall_clock64() - t0 > STAR_BAR_TICKS) { atomicOr(fault, 1); break; }
+    }
+    const unsigned long long t1 = wall_clock64();
+    if (dbg) { const unsigned long long t2 = wall_clock64(); dbg[0] += t0 - ta; dbg[1] += t1 - t0; dbg[2] += t2 - t1; }
   }
-  share_help(env, rob, rtri, rbox, queue, stage, ibase + SEG_WAVES * (STACK_CAP + TG_HASH), s_share, lane DBG_PASS);
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(64 * SEG_WAVES) __attribute__((amdgpu_waves_per_eu(CI_OCC))) void k_star_tail(
+    ResolveArgs A, EnvView env, RobotView rob, NodeStoreView st, int max_passes) {
+  __shared__ StarPassLds L;
+  __shared__ ShareArea s_share;
+  extern __shared__ double lds_d[];
+  const DevForestView& f = A.f;
+  const StarView& S = A.S;
+  const DevCtrl* c = f.ctrl;
+  const int app_n = c->app_n, N0 = c->app_N0;
+  const unsigned ep = (unsigned)c->epoch;
+  const int h_n = S.hdr[0], h_skip = S.hdr[1], n_ev = S.hdr[2], ev_first = S.hdr[3], h_fault = S.hdr[STAR_FAULT];
+  const int chg0 = S.changed[0];
+  if (app_n <= 0 || h_skip || h_fault) return;
+  const int wg = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (chg0 == 0 || max_passes <= 1) {            // the first pass wrote nothing (or is all the caller allows)
+    if (wg == 0 && threadIdx.x == 0) { S.hdr[STAR_PASSES_RUN] = 1; S.hdr[STAR_CONVERGED] = chg0 == 0; }
+    return;
+  }
+  int g_act = (h_n + 3) >> 2;
+  g_act = g_act < 16 ? 16 : g_act;
+  g_act = g_act > (int)gridDim.x ? (int)gridDim.x : g_act;
+  if (wg >= g_act) return;
+  const int Tb = f.temp_base;
+  const ExactLds E = exact_lds(lds_d, rob.n_tri, wave);
+  const int sub_cap = S.items_cap / SFFK_SUBLISTS;
+  int32_t* const bar = S.changed + SFFK_STAR_BAR;
+  int32_t* const fault = S.hdr + STAR_FAULT;
+  bool robot_ready = false, conv = false;
+  int n_bar = 0, pass = 1;
+  // SFFGPU_PROFILE, workgroup 0: [16] launches that ran passes, [17] passes, ticks of [18] pass phases, [19] exact phases,
+  // [20..22] barriers: release, wait, acquire
+  unsigned long long* const dbg = (S.dbg && wg == 0) ? S.dbg + 16 : nullptr;
+  unsigned long long tp = dbg ? wall_clock64() : 0ULL;
+  if (dbg && threadIdx.x == 0) dbg[0] += 1;
+  while (true) {
+    const int slot = pass & (SFFK_STAR_PASSES - 1);
+    // ---- pass `pass`
+    if (wg == 0) {
+      const int nx = (pass + 1) & (SFFK_STAR_PASSES - 1);
+      for (int t = threadIdx.x; t < SFFK_SUBLISTS * SFFK_STAR_SUB; t += blockDim.x) sst<true>(S.sub + (size_t)nx * SFFK_SUBLISTS * SFFK_STAR_SUB + t, 0);
+      if (threadIdx.x == 0) sst<true>(S.changed + nx, 0);
+    }
+    for (int r = wg * 4 + wave; r < h_n; r += g_act * 4)
+      star_pass_sample<true>(A, env, st, slot, (r >> 2) & (SFFK_SUBLISTS - 1), S.acc_sample[r], N0, Tb, ep, L, wave, lane);
+    if (dbg && threadIdx.x == 0) { const unsigned long long t = wall_clock64(); dbg[1] += 1; dbg[2] += t - tp; }
+    star_grid_barrier(bar, ++n_bar * g_act, fault, dbg ? dbg + 4 : nullptr);
+    if (dbg) tp = wall_clock64();
+    const int flt = __hip_atomic_load(fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int chg = __hip_atomic_load(S.changed + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (flt) break;
+    if (chg == 0) { conv = true; break; }
+    if (pass + 1 >= max_passes) break;
+    // ---- the edges it sent to the exact test
+    int32_t* sub = S.sub + (size_t)slot * SFFK_SUBLISTS * SFFK_STAR_SUB;
+    int sub_n = __hip_atomic_load(sub + lane * SFFK_STAR_SUB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (sub_n > sub_cap) {   // a sub-list ran over: items were dropped - the round is redone on the host path
+      if (wg == 0 && wave == 0) atomicOr(fault, 1);
+      sub_n = sub_cap;
+    }
+    int sub_incl = sub_n;
+    for (int off = 1; off < 64; off <<= 1) {
+      const int o = __shfl_up(sub_incl, off);
+      if (lane >= off) sub_incl += o;
+    }
+    const int M = __shfl(sub_incl, 63);
+    if (M > 0 && env.n_tri != 0) {
+      if (!robot_ready) {
+        for (int i = threadIdx.x; i < rob.n_tri * 9; i += blockDim.x) E.rtri[i] = rob.tri[i];
+        __syncthreads();
+        fill_robot_boxes(E.rtri, E.rbox, rob.n_tri, threadIdx.x, blockDim.x);
+        robot_ready = true;
+      }
+      share_init(s_share);
+      __syncthreads();
+      star_exact_items<true>(env, rob, E, st.pos, S.ida, S.idb, static_cast<const SurvivorItem*>(S.items), sub_cap, sub, sub_n, sub_incl,
+                       M, S.first_hit, S.seg_ovf, s_share, wg, g_act, wave, lane);
+    }
+    if (dbg && threadIdx.x == 0) dbg[3] += wall_clock64() - tp;
+    star_grid_barrier(bar, ++n_bar * g_act, fault, dbg ? dbg + 4 : nullptr);
+    if (dbg) tp = wall_clock64();
+    if (__hip_atomic_load(fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+    ++pass;
+  }
+  // the border entries' costs, once, on the costs the fixed point ended with (all written before the last barrier)
+  if (conv)
+    for (int e = wg * 256 + (int)threadIdx.x; e < n_ev; e += g_act * 256) star_pass_event<true>(f, S, e, ev_first, N0, ep);
+  if (wg == 0 && threadIdx.x == 0) { S.hdr[STAR_PASSES_RUN] = pass + 1; S.hdr[STAR_CONVERGED] = conv ? 1 : 0; }
 }
 
 // Samples whose fate needs no in-order replay (src/forest.h:246-299): rejected by their own pose or parent-edge
@@ -4638,6 +4786,28 @@ void launch_star_exact(hipStream_t s, const EnvView& env, const RobotView& rob, 
   hipLaunchKernelGGL(k_star_exact, dim3(blocks), dim3(64 * SEG_WAVES), lds, s, env, rob, store_pos, S.ida, S.idb,
                      static_cast<const SurvivorItem*>(S.items), S.items_cap, S.sub + (size_t)pass * SFFK_SUBLISTS * SFFK_STAR_SUB,
                      S.first_hit, S.seg_ovf, S.hdr);
+}
+
+void launch_star_tail(hipStream_t s, const ResolveArgs& a, const EnvView& env, const RobotView& rob, const NodeStoreView& st,
+                      int n_bound, int max_passes) {
+  static size_t lds_set = 0;
+  const size_t lds = collide_lds_bytes(rob.n_tri, SEG_WAVES);
+  if (lds > lds_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_star_tail), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    lds_set = lds;
+  }
+  // resident at once: at most one workgroup per CU of an otherwise idle GPU; SFFGPU_STAR_TAIL_WGS bounds it further (processes
+  // sharing one GPU: the sum of their grids must fit, or their barriers wait for each other until the time-out faults)
+  static const int cap = [] {
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const char* e = getenv("SFFGPU_STAR_TAIL_WGS");
+    const int want = e ? atoi(e) : cus;
+    return std::max(1, std::min(want, cus));
+  }();
+  const int blocks = std::max(1, std::min(cap, std::max(16, (n_bound + 3) / 4)));
+  hipLaunchKernelGGL(k_star_tail, dim3(blocks), dim3(64 * SEG_WAVES), lds, s, a, env, rob, st, max_passes);
 }
 
 void launch_classify(hipStream_t s, const ClassifyArgs& a) {
