@@ -721,13 +721,12 @@ void launch_star_stage(hipStream_t s, const ResolveArgs& a, int n_bound, const S
   else launch_star_knn_wg(s, a, L.g, L.tg, L.st, L.cell_edge, L.slack, n_bound, R0);
   const int event_blocks = (n_bound + 255) / 256;
   // the passes after the first: one launch (k_star_tail, as many passes as the round needs, up to SFFK_STAR_TAIL_PASSES) or -
-  // SFFGPU_STAR_TAIL=0 - the fixed chain of up to SFFK_STAR_PASSES pass / exact launches
-  static const bool tail = !(getenv("SFFGPU_STAR_TAIL") && atoi(getenv("SFFGPU_STAR_TAIL")) == 0);
-  if (tail) {
+  // SFFGPU_STAR_TAIL=0 when the forest was created - the fixed chain of up to SFFK_STAR_PASSES pass / exact launches
+  if (L.tail) {
     const int passes = L.passes > 0 ? L.passes : SFFK_STAR_TAIL_PASSES;
     hipLaunchKernelGGL(k_star_pass, dim3(sample_blocks + event_blocks), dim3(256), 0, s, a, L.env, L.st, 0, sample_blocks);
     if (passes > 1) launch_star_exact(s, L.env, L.rob, L.st.pos, a.S, 0);
-    launch_star_tail(s, a, L.env, L.rob, L.st, n_bound, passes);
+    launch_star_tail(s, a, L.env, L.rob, L.st, n_bound, passes, L.tail_wgs);
     hipLaunchKernelGGL(k_star_apply, dim3(sample_blocks), dim3(256), 0, s, a, L.tg, n_bound, passes, 1);
     return;
   }

@@ -429,7 +429,9 @@ struct Forest {
   // switches to the wide kernel for good
   bool query_wide = false;
   void on_list_fault();
-  int star_pass_limit = 0;        // SFF* device stage: fixed-point launches per round (0 = SFFK_STAR_PASSES; SFFGPU_TEST_STAR_PASSES)
+  int star_pass_limit = 0;        // SFF* device stage: most passes of a round's fixed point (0 = the kernels' own limit; SFFGPU_TEST_STAR_PASSES)
+  bool star_tail = true;          // ... the passes after the first as one launch (k_star_tail); SFFGPU_STAR_TAIL=0: one launch per pass
+  int star_tail_wgs = 0;          // ... its grid's upper bound (0 = one workgroup per CU; SFFGPU_STAR_TAIL_WGS)
 
   // post-loop path extraction (src/forest.h:420-462, src/problemStruct.h:184-253)
   struct Holder {            // DistanceHolder (src/primitives.h:598-655)

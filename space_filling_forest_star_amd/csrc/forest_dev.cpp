@@ -1077,6 +1077,8 @@ void Forest::dev_enqueue_round_commit(const void* recv_dev, bool sample_next) {
     sl.slack = 8 * c.sweep_eps();
     sl.cube_reach = 2.0 * cfg.sampling_dist;
     sl.passes = star_pass_limit;
+    sl.tail = star_tail ? 1 : 0;
+    sl.tail_wgs = star_tail_wgs;
     sffk::launch_commit(c.stream, ra, B.n, &sl, sample_next ? &next : nullptr);
   } else {
     sffk::launch_commit(c.stream, ra, B.n, nullptr, sample_next ? &next : nullptr);

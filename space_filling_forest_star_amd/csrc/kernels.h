@@ -634,12 +634,14 @@ struct StarLaunch {            // what the host adds for the SFF* stage of a com
   RobotView rob;
   double cell_edge, slack;
   double cube_reach;         // k_star_knn gathers the cube of cells that covers this radius in one go (~ 2 sampling distances)
-  int passes;                // fixed-point launches per round (<= SFFK_STAR_PASSES; tests shrink it to drive the fault path)
+  int passes;                // most passes of the fixed point per round (0 = the kernels' limit; tests shrink it to drive the fault path)
+  int tail;                  // the passes after the first as one launch (k_star_tail) instead of one launch per pass
+  int tail_wgs;              // ... bound of its grid (0 = one workgroup per CU)
 };
 void launch_star_stage(hipStream_t s, const ResolveArgs& a, int n_bound, const StarLaunch& L);   // devstar.hip
 // exact collision test of the member-edge chunks a star pass could not answer from the clearance bits (kernels.hip)
 void launch_star_tail(hipStream_t s, const ResolveArgs& a, const EnvView& env, const RobotView& rob, const NodeStoreView& st,
-                      int n_bound, int max_passes);
+                      int n_bound, int max_passes, int wgs_bound);
 void launch_star_exact(hipStream_t s, const EnvView& env, const RobotView& rob, const double* store_pos, const StarView& S,
                        int pass);
 // the commit of one round: k_commit (wide) [-> the SFF* stage] -> k_append / k_append_sample (wide);

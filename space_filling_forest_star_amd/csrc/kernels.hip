@@ -4789,23 +4789,22 @@ void launch_star_exact(hipStream_t s, const EnvView& env, const RobotView& rob, 
 }
 
 void launch_star_tail(hipStream_t s, const ResolveArgs& a, const EnvView& env, const RobotView& rob, const NodeStoreView& st,
-                      int n_bound, int max_passes) {
+                      int n_bound, int max_passes, int wgs_bound) {
   static size_t lds_set = 0;
   const size_t lds = collide_lds_bytes(rob.n_tri, SEG_WAVES);
   if (lds > lds_set) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_star_tail), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     lds_set = lds;
   }
-  // resident at once: at most one workgroup per CU of an otherwise idle GPU; SFFGPU_STAR_TAIL_WGS bounds it further (processes
-  // sharing one GPU: the sum of their grids must fit, or their barriers wait for each other until the time-out faults)
-  static const int cap = [] {
-    int dev = 0, cus = 256;
+  // resident at once: at most one workgroup per CU of an otherwise idle GPU; wgs_bound (SFFGPU_STAR_TAIL_WGS) bounds it further
+  // (processes sharing one GPU: the sum of their grids must fit, or their barriers wait for each other until the time-out faults)
+  static const int cus = [] {
+    int dev = 0, n = 256;
     (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const char* e = getenv("SFFGPU_STAR_TAIL_WGS");
-    const int want = e ? atoi(e) : cus;
-    return std::max(1, std::min(want, cus));
+    (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return std::max(1, n);
   }();
+  const int cap = wgs_bound > 0 ? std::min(wgs_bound, cus) : cus;
   const int blocks = std::max(1, std::min(cap, std::max(16, (n_bound + 3) / 4)));
   hipLaunchKernelGGL(k_star_tail, dim3(blocks), dim3(64 * SEG_WAVES), lds, s, a, env, rob, st, max_passes);
 }

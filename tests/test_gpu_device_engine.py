@@ -158,6 +158,27 @@ def test_sff_star_device_faults_finish_the_wave_on_the_host_path(S, ctx, env):
     assert_same_forest(fo, fg)
 
 
+@pytest.mark.parametrize("name,wave,iters,env,faults", [
+    ("dense3d", 2048, 80000, dict(SFFGPU_STAR_TAIL=0), False),          # one launch per pass (the fixed chain)
+    ("dense3d", 2048, 80000, dict(SFFGPU_STAR_TAIL_WGS=3), False),      # three workgroups loop over all accepted samples / items
+    ("building", 1024, 40000, dict(SFFGPU_STAR_TAIL_WGS=16), False),
+    ("building", 1024, 40000, dict(SFFGPU_TEST_STAR_PASSES=3), True),   # the tail gives up after its second pass: host path
+])
+def test_sff_star_passes_as_one_launch_and_as_a_chain_build_the_same_forest(S, ctx, name, wave, iters, env, faults):
+    """the rewire fixed point's passes after the first run as ONE launch (k_star_tail: the first workgroups alternate pass
+    and exact phases with a barrier between them, the words they exchange written through / read from memory) - the
+    forest must be the oracle's whatever the number of workgroups, equal to what one launch per pass builds, and a round
+    that does not settle within the allowed passes must go to the host path"""
+    fo, fg = make(S, ctx, name, wave, iters, seed=6, optimize=True, **env)
+    fo.run()
+    fg.run()
+    assert fo.stats()["n_nodes"] > 1000
+    assert_same_forest(fo, fg)
+    sg = fg.stats()
+    assert sg["star_rounds"] > 0 and sg["star_passes"] > sg["star_rounds"]      # some round needed more than its first pass
+    assert (sg["host_fallback_waves"] > 0) == faults
+
+
 @pytest.mark.parametrize("which", ["device", "host"])
 def test_sff_star_parent_history_gives_the_forest_after_any_iteration(S, ctx, which):
     """record_parents: the (node, parent, iteration) history of node creations and applied rewires - what an exact
