@@ -3861,10 +3861,13 @@ __global__ __launch_bounds__(64 * SEG_WAVES) __attribute__((amdgpu_waves_per_eu(
       star_exact_items<true>(env, rob, E, st.pos, S.ida, S.idb, static_cast<const SurvivorItem*>(S.items), sub_cap, sub, sub_n, sub_incl,
                        M, S.first_hit, S.seg_ovf, s_share, wg, g_act, wave, lane);
     }
-    if (dbg && threadIdx.x == 0) dbg[3] += wall_clock64() - tp;
-    star_grid_barrier(bar, ++n_bar * g_act, fault, dbg ? dbg + 4 : nullptr);
-    if (dbg) tp = wall_clock64();
-    if (__hip_atomic_load(fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+    // (no items: every workgroup read the same counts - nothing to wait for before the next pass)
+    if (M > 0) {
+      if (dbg && threadIdx.x == 0) dbg[3] += wall_clock64() - tp;
+      star_grid_barrier(bar, ++n_bar * g_act, fault, dbg ? dbg + 4 : nullptr);
+      if (dbg) tp = wall_clock64();
+      if (__hip_atomic_load(fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+    }
     ++pass;
   }
   // the border entries' costs, once, on the costs the fixed point ended with (all written before the last barrier)
