@@ -16,6 +16,9 @@ cpn r5_sweep_pmc_summary.json r5_sweep_pmc_summary.json
 cpn r5_sweep_line.json r5_sweep_line.json
 cpn r5_c5_kernel_stats.csv r5_c5_kernel_stats.csv
 cpn r5_c5_probe.json r5_c5_probe.json
+cpn r5_tail_ab.txt r5_tail_ab.txt
+cpn r5_c5_star_clocks.txt r5_c5_star_clocks.txt
+cpn r5_star_chain.txt r5_star_chain.txt
 cpn r5_force_dist_line.json r5_force_dist_line.json
 cpn r5_phase_clocks.txt r5_phase_clocks.txt
 cpn r5_small_waves.txt r5_small_waves.txt

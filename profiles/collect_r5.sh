@@ -14,6 +14,9 @@ SFFGPU_NO_ORDER=1 bash profiles/collect_counters.sh r5_query_no_order "TCC_REQ_s
 bash profiles/collect_sweep.sh r5 > /dev/null 2>&1
 bash profiles/r5_c5_trace.sh r5_c5 > $out/r5_c5_trace_top.txt 2>&1
 timeout 300 python3 profiles/c5_probe.py 2>/dev/null | tail -1 > $out/r5_c5_probe.json
+bash profiles/r5_tail_ab.sh > $out/r5_tail_ab.txt 2>&1
+SFFGPU_PROFILE=1 timeout 300 python3 profiles/c5_probe.py 2>&1 | grep -E "k_star_tail|k_star_knn" > $out/r5_c5_star_clocks.txt
+bash profiles/r5_star_chain.sh > /dev/null 2>&1
 timeout 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 --force-dist --cpu-iters 0 --no-sweep-micro --no-wave-sweep --no-extra-legs 2>/dev/null | tail -1 > $out/r5_force_dist_line.json
 SFFGPU_PROFILE=1 timeout 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 --cpu-iters 0 --no-sweep-micro --no-wave-sweep --no-extra-legs 2>&1 | grep -E "^\[sffgpu" | tail -8 > $out/r5_phase_clocks.txt
 timeout 600 python3 profiles/small_wave_probe.py > $out/r5_small_waves.txt 2>&1

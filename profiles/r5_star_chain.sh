@@ -1,8 +1,9 @@
 #!/bin/bash
-# SFF* chain of configs[4] launch by launch (eager): duration of k_star_pass / k_star_exact by their position in the round
+# SFF* as one launch per pass (SFFGPU_STAR_TAIL=0), configs[4], launch by launch (eager): duration of k_star_pass / k_star_exact by
+# their position in the round (the grid of an idle launch is as large as a working one's: ~4.4 us under the profiler)
 root=${GRAFT_REPO_ROOT:-$(pwd)}; out=$root/gpurun_out; mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
-SFFGPU_NO_GRAPH=1 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $out/star_chain -o t -- python3 $root/profiles/c5_probe.py 2000000 8192 > $out/star_chain.log 2>&1
+SFFGPU_STAR_TAIL=0 SFFGPU_NO_GRAPH=1 timeout 300 rocprofv3 --kernel-trace --output-format csv -d $out/star_chain -o t -- python3 $root/profiles/c5_probe.py 2000000 8192 > $out/star_chain.log 2>&1
 python3 - $out/star_chain/t_kernel_trace.csv > $out/r5_star_chain.txt <<'PY'
 import csv,sys,collections
 rows=list(csv.DictReader(open(sys.argv[1])))

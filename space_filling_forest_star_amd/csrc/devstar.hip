@@ -12,7 +12,9 @@
 //     result(i)   = choose-parent / rewire of sample i evaluated on its views                          (one wavefront)
 // and because j < i always, iterating "every sample recomputes" reaches it in (longest dependency chain + 1) passes
 // whatever the order inside a pass; a pass that writes nothing proves it (kernel boundaries make a pass's writes visible
-// to the next).  Everything is evaluated in the host engine's expression order (-ffp-contract=off): bit-identical.
+// to the next; inside k_star_tail - kernels.hip, all passes after the first in one launch - the exchanged words are written
+// through and read from memory, star_pass_dev.h).  Everything is evaluated in the host engine's expression order
+// (-ffp-contract=off): bit-identical.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "kernels.h"

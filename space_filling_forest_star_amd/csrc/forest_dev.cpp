@@ -1519,16 +1519,18 @@ void Forest::run_device(int max_waves) {
       unsigned long long g[32];
       HIPCHK(hipMemcpy(g, d.s_dbg.p, sizeof g, hipMemcpyDeviceToHost));
       const double w = (double)std::max<unsigned long long>(1ULL, g[0]);
+      if (g[0])   // (the one-wavefront kernel, SFFGPU_STAR_KNN=lone; k_star_knn_wg carries no clocks)
       fprintf(stderr, "[sffgpu k_star_knn per accepted sample] us: cube %.1f shells %.1f mates %.1f lists %.1f | longest %.1f | shells walked %.2f "
               "(samples beyond the cube %.3f) cube candidates %.0f | samples %llu\n", g[1] / w / 100.0, g[2] / w / 100.0, g[3] / w / 100.0,
               g[4] / w / 100.0, g[7] / 100.0, g[5] / w, g[8] / w, g[6] / w, g[0]);
+      if (g[0])
       fprintf(stderr, "[sffgpu k_star_knn cube phase] us: counts %.1f items+distances %.1f bisection %.1f sort+rest %.1f\n", g[9] / w / 100.0,
               g[10] / w / 100.0, g[11] / w / 100.0, g[12] / w / 100.0);
       if (g[16]) {
         const double n = (double)g[16], ps = (double)std::max<unsigned long long>(1ULL, g[17]);
         fprintf(stderr, "[sffgpu k_star_tail, workgroup 0] launches that ran passes %llu, passes each %.2f | us per pass: pass phase %.1f exact phase %.1f "
-                "barriers (two): release %.1f wait %.1f acquire %.1f\n", g[16], g[17] / n, g[18] / ps / 100.0, g[19] / ps / 100.0, g[20] / ps / 100.0,
-                g[21] / ps / 100.0, g[22] / ps / 100.0);
+                "barriers: counting in %.1f waiting for the others %.1f\n", g[16], g[17] / n, g[18] / ps / 100.0, g[19] / ps / 100.0, g[20] / ps / 100.0,
+                g[21] / ps / 100.0);
         if (g[24]) fprintf(stderr, "[sffgpu k_star_tail, sections of a sample's pass (STAR_PASS_TRACE build)] us: first loads %.1f views %.1f evaluate %.1f (of it requests %.1f) "
                            "loops %.1f writes %.1f\n", g[24] / ps / 100.0, g[25] / ps / 100.0, (g[26] + g[27]) / ps / 100.0, g[27] / ps / 100.0, g[28] / ps / 100.0, g[29] / ps / 100.0);
       }

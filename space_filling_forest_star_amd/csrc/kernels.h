@@ -514,7 +514,7 @@ struct DevForestView {
 // ---- SFF* (optimize = true) on the device engine: choose-parent + rewire of src/forest.h:307-351 (devstar.hip).
 // The accept / reject logic does not depend on costs, so k_commit settles WHICH samples of the round become
 // nodes (and their ids) exactly as for plain SFF; then, for the accepted samples only:
-//   k_star_knn    one wavefront per accepted sample: its k = floor(2e log10(#nodes at its turn)) nearest nodes of its
+//   k_star_knn(_wg) one wavefront (_wg: one workgroup, kernels.hip) per accepted sample: its k = floor(2e log10(#nodes at its turn)) nearest nodes of its
 //                 tree among the store AND the samples accepted earlier in the round (replaces knnSearch, :317); every
 //                 member joins the toucher list of its node (per-node linked lists, heads stamped with the round's
 //                 epoch: no clearing)
@@ -523,7 +523,10 @@ struct DevForestView {
 //                 rewires that node (walk of the node's toucher list), else the node's stored cost; from its views it
 //                 recomputes its parent / cost / rewire proposals.  Dependencies only point backwards in slot order, so
 //                 the iteration reaches the unique fixed point in (longest chain + 1) passes; a pass that changes
-//                 nothing proves it.  One launch per pass, later launches return at once.
+//                 nothing proves it.  The first pass is a launch of its own; the later ones run inside ONE launch,
+//                 k_star_tail (kernels.hip: pass / exact phases of the first workgroups of a resident grid, a barrier
+//                 over them in between, the exchanged words written through / read from memory) - or, without it, as a
+//                 chain of one launch per pass whose later launches return at once.
 //                 Member edges (new -> member :323, member -> new :336) are answered lazily: only the edges the two loops
 //                 can reach given the views are looked at - the pass culls their samples against the clearance bits
 //                 itself (most edges are answered right there), the rest goes to k_star_exact between two passes.
