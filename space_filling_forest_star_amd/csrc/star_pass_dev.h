@@ -335,18 +335,21 @@ template <bool COH> __device__ __forceinline__ void star_pass_sample(const Resol
   const double np = act ? proposed : STAR_INF;
   STAR_T(4);
   // ---- write what changed
-  bool diff = mem && __double_as_longlong(o_prop) != __double_as_longlong(np);
-  if (lane == 0)
-    diff |= __double_as_longlong(o_best) != __double_as_longlong(best) || o_psel != psel ||
-            __double_as_longlong(o_dcl) != __double_as_longlong(dcl) || o_cc != cc || o_pf != pf;
-  if (diff && mem) sst<COH>(S.prop + p, np);
-  const bool any_diff = __any(diff);
+  // what OTHER samples read of this one is its proposals and its cost (star_view); parent choice, distance and the call counters
+  // are outputs only: a pass in which no proposal and no cost changed and no sample waits for an edge has reached the fixed
+  // point, whatever else it wrote
+  const bool diff_view = (mem && __double_as_longlong(o_prop) != __double_as_longlong(np)) ||
+                         (lane == 0 && __double_as_longlong(o_best) != __double_as_longlong(best));
+  const bool diff_out = lane == 0 && (o_psel != psel || __double_as_longlong(o_dcl) != __double_as_longlong(dcl) || o_cc != cc || o_pf != pf);
+  if (mem && __double_as_longlong(o_prop) != __double_as_longlong(np)) sst<COH>(S.prop + p, np);
+  const bool any_view = __any(diff_view);
+  const bool any_diff = any_view || __any(diff_out);
   if (lane == 0) {
     if (any_diff) {
       sst<COH>(S.best + i, best); S.psel[i] = psel; S.dcl[i] = dcl;
       S.cnt[2 * (size_t)i] = cc; S.cnt[2 * (size_t)i + 1] = pf;
     }
-    if (any_diff || pending) sst<COH>(S.changed + slot, 1);
+    if (any_view || pending) sst<COH>(S.changed + slot, 1);
   }
   STAR_T(5);
 }
