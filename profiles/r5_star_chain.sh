@@ -25,8 +25,7 @@ for k in ("pass","exact"):
     for p in range(8):
         v=acc.get((k,p))
         if not v: continue
-        real=[x for x in v if x>2.0]
-        print("%-5s %d: n %4d avg %7.2f us  max %7.2f | doing work (>2 us): %4d avg %7.2f | idle avg %5.2f" % (k,p,len(v),sum(v)/len(v),max(v),len(real),sum(real)/max(1,len(real)),(sum(v)-sum(real))/max(1,len(v)-len(real))))
+        print("%-5s %d: n %4d avg %7.2f us  max %7.2f  (longer than 6 us: %4d)" % (k,p,len(v),sum(v)/len(v),max(v),sum(1 for x in v if x>6.0)))
 gaps.sort()
 print("gap before a chain launch (eager): median %.2f us, mean %.2f" % (gaps[len(gaps)//2], sum(gaps)/len(gaps)))
 PY
