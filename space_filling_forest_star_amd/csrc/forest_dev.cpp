@@ -1519,7 +1519,7 @@ void Forest::run_device(int max_waves) {
       unsigned long long g[32];
       HIPCHK(hipMemcpy(g, d.s_dbg.p, sizeof g, hipMemcpyDeviceToHost));
       const double w = (double)std::max<unsigned long long>(1ULL, g[0]);
-      if (g[0])   // (the one-wavefront kernel, SFFGPU_STAR_KNN=lone; k_star_knn_wg carries no clocks)
+      if (g[0])   // (k_star_knn_wg: "cube" = the whole store search by its four wavefronts, no shell / cube-phase split)
       fprintf(stderr, "[sffgpu k_star_knn per accepted sample] us: cube %.1f shells %.1f mates %.1f lists %.1f | longest %.1f | shells walked %.2f "
               "(samples beyond the cube %.3f) cube candidates %.0f | samples %llu\n", g[1] / w / 100.0, g[2] / w / 100.0, g[3] / w / 100.0,
               g[4] / w / 100.0, g[7] / 100.0, g[5] / w, g[8] / w, g[6] / w, g[0]);

@@ -733,6 +733,7 @@ __global__ __launch_bounds__(256) void k_star_knn_wg(ResolveArgs A, GridView g, 
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int r = blockIdx.x; r < n_acc; r += gridDim.x) {
     const int i = r == (int)blockIdx.x ? i_first : S.acc_sample[r];
+    const unsigned long long dbg_t0 = S.dbg ? wall_clock64() : 0ULL;
     // k = (size_t)(2e log10(#nodes)) with the nodes accepted before this sample counted in (src/forest.h:309)
     const int Nn = N0 + r;
     const int k_ref = __popcll(__ballot(lane > 0 && lane <= SFFK_STAR_KMAX + 1 && S.ktab[lane] <= Nn));
@@ -769,6 +770,8 @@ __global__ __launch_bounds__(256) void k_star_knn_wg(ResolveArgs A, GridView g, 
       // (the first shells in one go - up to SKW_FIRST: beyond that the search usually ends before the cube does - then shell by shell)
       knn_wg_search(g, st, Q, k, cell_edge, slack, N0, 0, tcnt, t, have, R0 < SKW_FIRST ? R0 : SKW_FIRST);
     }
+    const unsigned long long dbg_t1 = S.dbg ? wall_clock64() : 0ULL;
+    unsigned long long dbg_t2 = 0ULL;
     if (wave == 0) {
       const int cx = grid_coord((float)qp[0], g.ox, g.inv_cell, g.nx), cy = grid_coord((float)qp[1], g.oy, g.inv_cell, g.ny),
                 cz = grid_coord((float)qp[2], g.oz, g.inv_cell, g.nz);
@@ -869,6 +872,7 @@ __global__ __launch_bounds__(256) void k_star_knn_wg(ResolveArgs A, GridView g, 
       }
     }
   }
+  if (S.dbg) dbg_t2 = wall_clock64();
   // ---- the members: ids, distances, toucher lists
   const int cnt = have;
   const bool mem = lane < cnt;
@@ -892,6 +896,11 @@ __global__ __launch_bounds__(256) void k_star_knn_wg(ResolveArgs A, GridView g, 
     S.psel[i] = ex0;
     S.dcl[i] = pd0;
     S.cnt[2 * (size_t)i] = 0ULL; S.cnt[2 * (size_t)i + 1] = 0ULL;
+    if (S.dbg && k > 0) {   // SFFGPU_PROFILE: samples | ticks: search (four wavefronts), earlier samples, lists | longest sample
+      const unsigned long long t3 = wall_clock64();
+      atomicAdd(S.dbg + 0, 1ULL); atomicAdd(S.dbg + 1, dbg_t1 - dbg_t0); atomicAdd(S.dbg + 3, dbg_t2 - dbg_t1); atomicAdd(S.dbg + 4, t3 - dbg_t2);
+      atomicMax(S.dbg + 7, t3 - dbg_t0);
+    }
     }
     }
     __syncthreads();   // (the search's LDS and s_mate are the next sample's)
