@@ -728,7 +728,7 @@ void launch_star_stage(hipStream_t s, const ResolveArgs& a, int n_bound, const S
     const int passes = L.passes > 0 ? L.passes : SFFK_STAR_TAIL_PASSES;
     hipLaunchKernelGGL(k_star_pass, dim3(sample_blocks + event_blocks), dim3(256), 0, s, a, L.env, L.st, 0, sample_blocks);
     if (passes > 1) launch_star_exact(s, L.env, L.rob, L.st.pos, a.S, 0);
-    launch_star_tail(s, a, L.env, L.rob, L.st, n_bound, passes, L.tail_wgs);
+    launch_star_tail(s, a, L.env, L.rob, L.st, n_bound, passes, L.tail_wgs, L.tail_stall);
     hipLaunchKernelGGL(k_star_apply, dim3(sample_blocks), dim3(256), 0, s, a, L.tg, n_bound, passes, 1);
     return;
   }

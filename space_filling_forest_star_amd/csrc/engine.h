@@ -432,6 +432,7 @@ struct Forest {
   int star_pass_limit = 0;        // SFF* device stage: most passes of a round's fixed point (0 = the kernels' own limit; SFFGPU_TEST_STAR_PASSES)
   bool star_tail = true;          // ... the passes after the first as one launch (k_star_tail); SFFGPU_STAR_TAIL=0: one launch per pass
   int star_tail_wgs = 0;          // ... its grid's upper bound (0 = one workgroup per CU; SFFGPU_STAR_TAIL_WGS)
+  int star_tail_stall = 0;        // ... tests: in every n-th round one workgroup never arrives at the first barrier (SFFGPU_TEST_STAR_STALL=n)
 
   // post-loop path extraction (src/forest.h:420-462, src/problemStruct.h:184-253)
   struct Holder {            // DistanceHolder (src/primitives.h:598-655)

@@ -183,6 +183,7 @@ Forest::Forest(Ctx* c, const sffgpu_forest_cfg& cf, const double* roots6, int n_
   if (const char* e = getenv("SFFGPU_TEST_STAR_PASSES")) star_pass_limit = std::max(1, atoi(e));
   if (const char* e = getenv("SFFGPU_STAR_TAIL")) star_tail = atoi(e) != 0;
   if (const char* e = getenv("SFFGPU_STAR_TAIL_WGS")) star_tail_wgs = std::max(1, atoi(e));
+  if (const char* e = getenv("SFFGPU_TEST_STAR_STALL")) star_tail_stall = std::max(0, atoi(e));
   if (const char* e = getenv("SFFGPU_NO_GRAPH")) dev.graph_enabled = atoi(e) == 0;
   else if (cfg.optimize) {
     // rocprofv3 (ROCm 7.2) crashes while tracing replays of the SFF* wave graph (~130 kernel nodes; the plain SFF graph

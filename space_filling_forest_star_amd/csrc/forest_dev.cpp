@@ -1079,6 +1079,7 @@ void Forest::dev_enqueue_round_commit(const void* recv_dev, bool sample_next) {
     sl.passes = star_pass_limit;
     sl.tail = star_tail ? 1 : 0;
     sl.tail_wgs = star_tail_wgs;
+    sl.tail_stall = star_tail_stall;
     sffk::launch_commit(c.stream, ra, B.n, &sl, sample_next ? &next : nullptr);
   } else {
     sffk::launch_commit(c.stream, ra, B.n, nullptr, sample_next ? &next : nullptr);

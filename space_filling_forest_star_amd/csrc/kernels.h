@@ -640,11 +640,12 @@ struct StarLaunch {            // what the host adds for the SFF* stage of a com
   int passes;                // most passes of the fixed point per round (0 = the kernels' limit; tests shrink it to drive the fault path)
   int tail;                  // the passes after the first as one launch (k_star_tail) instead of one launch per pass
   int tail_wgs;              // ... bound of its grid (0 = one workgroup per CU)
+  int tail_stall;            // ... tests: every n-th round one workgroup stays away from the first barrier (the time-out's fault path)
 };
 void launch_star_stage(hipStream_t s, const ResolveArgs& a, int n_bound, const StarLaunch& L);   // devstar.hip
 // exact collision test of the member-edge chunks a star pass could not answer from the clearance bits (kernels.hip)
 void launch_star_tail(hipStream_t s, const ResolveArgs& a, const EnvView& env, const RobotView& rob, const NodeStoreView& st,
-                      int n_bound, int max_passes, int wgs_bound);
+                      int n_bound, int max_passes, int wgs_bound, int test_stall);
 void launch_star_exact(hipStream_t s, const EnvView& env, const RobotView& rob, const double* store_pos, const StarView& S,
                        int pass);
 // the commit of one round: k_commit (wide) [-> the SFF* stage] -> k_append / k_append_sample (wide);

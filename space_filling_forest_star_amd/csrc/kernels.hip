@@ -3794,7 +3794,7 @@ __device__ __forceinline__ void star_grid_barrier(int32_t* bar, int target, int3
 }
 
 __global__ __launch_bounds__(64 * SEG_WAVES) __attribute__((amdgpu_waves_per_eu(CI_OCC))) void k_star_tail(
-    ResolveArgs A, EnvView env, RobotView rob, NodeStoreView st, int max_passes) {
+    ResolveArgs A, EnvView env, RobotView rob, NodeStoreView st, int max_passes, int test_stall) {
   __shared__ StarPassLds L;
   __shared__ ShareArea s_share;
   extern __shared__ double lds_d[];
@@ -3815,6 +3815,8 @@ __global__ __launch_bounds__(64 * SEG_WAVES) __attribute__((amdgpu_waves_per_eu(
   g_act = g_act < 16 ? 16 : g_act;
   g_act = g_act > (int)gridDim.x ? (int)gridDim.x : g_act;
   if (wg >= g_act) return;
+  // (tests: a workgroup that never arrives - the others' barrier must time out into the stage's fault flag, the round go to the host)
+  if (test_stall > 0 && g_act > 1 && wg == g_act - 1 && ep % (unsigned)test_stall == 0u) return;
   const int Tb = f.temp_base;
   const ExactLds E = exact_lds(lds_d, rob.n_tri, wave);
   const int sub_cap = S.items_cap / SFFK_SUBLISTS;
@@ -4801,7 +4803,7 @@ void launch_star_exact(hipStream_t s, const EnvView& env, const RobotView& rob, 
 }
 
 void launch_star_tail(hipStream_t s, const ResolveArgs& a, const EnvView& env, const RobotView& rob, const NodeStoreView& st,
-                      int n_bound, int max_passes, int wgs_bound) {
+                      int n_bound, int max_passes, int wgs_bound, int test_stall) {
   static size_t lds_set = 0;
   const size_t lds = collide_lds_bytes(rob.n_tri, SEG_WAVES);
   if (lds > lds_set) {
@@ -4818,7 +4820,7 @@ void launch_star_tail(hipStream_t s, const ResolveArgs& a, const EnvView& env, c
   }();
   const int cap = wgs_bound > 0 ? std::min(wgs_bound, cus) : cus;
   const int blocks = std::max(1, std::min(cap, std::max(16, (n_bound + 3) / 4)));
-  hipLaunchKernelGGL(k_star_tail, dim3(blocks), dim3(64 * SEG_WAVES), lds, s, a, env, rob, st, max_passes);
+  hipLaunchKernelGGL(k_star_tail, dim3(blocks), dim3(64 * SEG_WAVES), lds, s, a, env, rob, st, max_passes, test_stall);
 }
 
 void launch_classify(hipStream_t s, const ClassifyArgs& a) {

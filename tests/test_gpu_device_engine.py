@@ -163,6 +163,7 @@ def test_sff_star_device_faults_finish_the_wave_on_the_host_path(S, ctx, env):
     ("dense3d", 2048, 80000, dict(SFFGPU_STAR_TAIL_WGS=3), False),      # three workgroups loop over all accepted samples / items
     ("building", 1024, 40000, dict(SFFGPU_STAR_TAIL_WGS=16), False),
     ("building", 1024, 40000, dict(SFFGPU_TEST_STAR_PASSES=3), True),   # the tail gives up after its second pass: host path
+    ("building", 1024, 40000, dict(SFFGPU_TEST_STAR_STALL=7), True),    # every 7th round a workgroup stays away: the barrier times out
 ])
 def test_sff_star_passes_as_one_launch_and_as_a_chain_build_the_same_forest(S, ctx, name, wave, iters, env, faults):
     """the rewire fixed point's passes after the first run as ONE launch (k_star_tail: the first workgroups alternate pass
