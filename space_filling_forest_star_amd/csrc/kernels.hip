@@ -1492,7 +1492,9 @@ __device__ __forceinline__ void pose_frame(const RobotView& rob, const double* _
 // next candidate: a grab names the item it belongs to), run narrow_block on their own stage / queue buffers and
 // atomicMin the first hit; the owner waits until every candidate is accounted for.  A wavefront helps only once its own
 // items are done, and leaves when all wavefronts of the workgroup are (no barrier anywhere).
+#ifndef SEG_WAVES
 #define SEG_WAVES 4
+#endif
 // when an item is shared, and in blocks of how many candidates.  A chunk's narrow phase costs per (candidate, touching
 // sample): on building.obj (a robot as wide as the corridors) 8-12 candidates x 35 samples ran 80-130 us, on dense_3D
 // 6 candidates x 64 samples 15 us - shared from `SHARE_WORK` (candidates x masked samples) on; a pose from 8 candidates on
