@@ -1520,13 +1520,16 @@ void Forest::run_device(int max_waves) {
       unsigned long long g[32];
       HIPCHK(hipMemcpy(g, d.s_dbg.p, sizeof g, hipMemcpyDeviceToHost));
       const double w = (double)std::max<unsigned long long>(1ULL, g[0]);
-      if (g[0])   // (k_star_knn_wg: "cube" = the whole store search by its four wavefronts, no shell / cube-phase split)
-      fprintf(stderr, "[sffgpu k_star_knn per accepted sample] us: cube %.1f shells %.1f mates %.1f lists %.1f | longest %.1f | shells walked %.2f "
-              "(samples beyond the cube %.3f) cube candidates %.0f | samples %llu\n", g[1] / w / 100.0, g[2] / w / 100.0, g[3] / w / 100.0,
-              g[4] / w / 100.0, g[7] / 100.0, g[5] / w, g[8] / w, g[6] / w, g[0]);
-      if (g[0])
-      fprintf(stderr, "[sffgpu k_star_knn cube phase] us: counts %.1f items+distances %.1f bisection %.1f sort+rest %.1f\n", g[9] / w / 100.0,
-              g[10] / w / 100.0, g[11] / w / 100.0, g[12] / w / 100.0);
+      if (g[0] && !g[9])   // (k_star_knn_wg: the store search by its four wavefronts as one section)
+        fprintf(stderr, "[sffgpu k_star_knn_wg per accepted sample] us: store search %.1f earlier samples of the round %.1f lists %.1f | longest sample %.1f | samples %llu\n",
+                g[1] / w / 100.0, g[3] / w / 100.0, g[4] / w / 100.0, g[7] / 100.0, g[0]);
+      if (g[0] && g[9]) {   // (the one-wavefront kernel, SFFGPU_STAR_KNN=lone)
+        fprintf(stderr, "[sffgpu k_star_knn per accepted sample] us: cube %.1f shells %.1f mates %.1f lists %.1f | longest %.1f | shells walked %.2f "
+                "(samples beyond the cube %.3f) cube candidates %.0f | samples %llu\n", g[1] / w / 100.0, g[2] / w / 100.0, g[3] / w / 100.0,
+                g[4] / w / 100.0, g[7] / 100.0, g[5] / w, g[8] / w, g[6] / w, g[0]);
+        fprintf(stderr, "[sffgpu k_star_knn cube phase] us: counts %.1f items+distances %.1f bisection %.1f sort+rest %.1f\n", g[9] / w / 100.0,
+                g[10] / w / 100.0, g[11] / w / 100.0, g[12] / w / 100.0);
+      }
       if (g[16]) {
         const double n = (double)g[16], ps = (double)std::max<unsigned long long>(1ULL, g[17]);
         fprintf(stderr, "[sffgpu k_star_tail, workgroup 0] launches that ran passes %llu, passes each %.2f | us per pass: pass phase %.1f exact phase %.1f "
