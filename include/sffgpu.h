@@ -153,6 +153,9 @@ typedef struct {
                                 launched waves, scaled like sweep_ms */
   double exchange_ms;        /* sharded forests: pack + all-gather + unpack of the answer records of all rounds */
   uint64_t graph_launches;   /* device engine: waves launched as one hipGraph replay */
+  uint64_t spec_steps;       /* waves of one slot, speculated (k_spec_waves): publish -> evaluate -> commit steps ... */
+  uint64_t spec_evaluated;   /* ... attempts its workers evaluated (speculation included) ... */
+  uint64_t spec_committed;   /* ... and attempts that were committed (= iterations run by that kernel) */
 } sffgpu_forest_stats;
 
 int sffgpu_forest_create(sffgpu_ctx* ctx, const sffgpu_forest_cfg* cfg, const double* roots6, int n_roots,

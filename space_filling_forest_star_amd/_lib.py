@@ -57,7 +57,8 @@ class ForestStats(C.Structure):
                 ("total_ms", C.c_double), ("query_clock_ms", C.c_double), ("query_clock_launches", C.c_uint64),
                 ("mate_overflow_requeries", C.c_uint64), ("star_rounds", C.c_uint64), ("star_passes", C.c_uint64),
                 ("star_members", C.c_uint64), ("star_rewires", C.c_uint64), ("host_fallback_waves", C.c_uint64),
-                ("commit_ms", C.c_double), ("exchange_ms", C.c_double), ("graph_launches", C.c_uint64)]
+                ("commit_ms", C.c_double), ("exchange_ms", C.c_double), ("graph_launches", C.c_uint64),
+                ("spec_steps", C.c_uint64), ("spec_evaluated", C.c_uint64), ("spec_committed", C.c_uint64)]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -298,6 +298,10 @@ struct DevEngine {
   uint32_t status_next = 0;     // sequence number the next published block will carry
   uint32_t status_of[2] = {0, 0};   // ... and the ones the two enqueued waves' blocks carry
   bool status_copied[2] = {true, true};   // the slot's block came by a copy into h_ctrl[slot] (k_seq_waves, SFFGPU_NO_ZC_STATUS)
+  // waves of one slot, speculated (k_spec_waves): scenario tree, control blocks, records (sffk::SpecArgs)
+  DevBuf spec_tab, spec_area;
+  int spec_n_sc = 0, spec_sets = 0, spec_tm = 0;
+  bool spec_off = false;        // SFFGPU_SPEC=0, or a launch stalled (its workgroups were not resident together)
 };
 
 struct Forest {
@@ -332,6 +336,7 @@ struct Forest {
   void run_device(int max_waves);
   bool seq_eligible() const;        // waves of one slot, plain SFF: the persistent single-wavefront loop (k_seq_waves)
   void run_device_seq(int max_waves);
+  bool spec_setup();                // the speculative kernel's scenario tree and buffers; false = k_seq_waves runs the loop
   bool seq_suspended = false;
   void sync_host();             // refresh the host mirror (nodes, frontier, borders, counters) from the device
   void fill_stats(sffgpu_forest_stats* out);

@@ -284,6 +284,9 @@ void Forest::fill_stats(sffgpu_forest_stats* out) {
     s.star_passes = k.star_passes;
     s.star_members = k.star_members;
     s.star_rewires = k.star_rewires;
+    s.spec_steps = k.spec_steps;
+    s.spec_evaluated = k.spec_evaluated;
+    s.spec_committed = k.spec_committed;
   } else {
     s.iterations = iter;
     bool sv = solved;

@@ -625,6 +625,9 @@ void Forest::dev_upload_state() {
     k.star_passes = st.star_passes;
     k.star_members = st.star_members;
     k.star_rewires = st.star_rewires;
+    k.spec_steps = st.spec_steps;
+    k.spec_evaluated = st.spec_evaluated;
+    k.spec_committed = st.spec_committed;
     k.epoch = 1;
     k.prio_n0 = n;               // (the host engine has pushed the nodes it created itself)
     k.prio_all_empty = (use_priority() && all_frontiers_empty()) ? 1 : 0;
@@ -758,6 +761,9 @@ void Forest::sync_host() {
   st.star_passes = k.star_passes;
   st.star_members = k.star_members;
   st.star_rewires = k.star_rewires;
+  st.spec_steps = k.spec_steps;
+  st.spec_evaluated = k.spec_evaluated;
+  st.spec_committed = k.spec_committed;
   if (use_priority()) {
     dev_prio_download();
     // the device pushes a wave's new nodes at the wave's END (k_prio_end); a wave that stopped in the middle has not
@@ -1319,6 +1325,57 @@ bool Forest::seq_eligible() const {
   return dev.on && cfg.wave == 1 && cfg.world == 1 && !off && !seq_suspended && num_roots <= 64 && !cfg.has_goal && !use_priority();
 }
 
+// The scenario tree of k_spec_waves (kernels.h: SpecArgs).  Plain SFF: the full tree of outcomes (accept at attempt
+// 0 .. TM-1 | all fail) to SFFGPU_SPEC_DEPTH waves (default 2: 1 + (TM + 1) scenarios, TM workers each); SFF*: the
+// chain of all-fail scenarios (default 3 waves).  SFFGPU_SPEC=0 keeps the single wavefront (k_seq_waves).
+bool Forest::spec_setup() {
+  DevEngine& d = dev;
+  if (d.spec_off) return false;
+  const int TM = std::max(1, cfg.threshold_misses);
+  if (d.spec_n_sc > 0 && d.spec_tm == TM) return true;
+  if (getenv("SFFGPU_SPEC") && atoi(getenv("SFFGPU_SPEC")) == 0) { d.spec_off = true; return false; }
+  if (TM > 8) { d.spec_off = true; return false; }
+  int depth = cfg.optimize ? 3 : 2;
+  if (getenv("SFFGPU_SPEC_DEPTH")) depth = atoi(getenv("SFFGPU_SPEC_DEPTH"));
+  depth = std::max(1, std::min(depth, SFFK_SPEC_DEPTH));
+  int sets = 2;
+  if (getenv("SFFGPU_SPEC_SETS")) sets = atoi(getenv("SFFGPU_SPEC_SETS"));
+  sets = std::max(1, std::min(sets, 4));
+  struct Sc { int level; int out[SFFK_SPEC_DEPTH]; int anc[SFFK_SPEC_DEPTH]; int child[9]; };
+  std::vector<Sc> tab;
+  Sc root{};
+  for (int& v : root.child) v = -1;
+  tab.push_back(root);
+  for (size_t i = 0; i < tab.size(); ++i) {
+    if (tab[i].level + 1 >= depth) continue;
+    for (int o = cfg.optimize ? TM : 0; o <= TM; ++o) {
+      if ((tab.size() + 1) * (size_t)TM * (size_t)sets > 900) break;   // (every workgroup has to be resident)
+      Sc ch = tab[i];
+      ch.level = tab[i].level + 1;
+      ch.out[tab[i].level] = o;
+      ch.anc[tab[i].level] = (int)i;
+      for (int& v : ch.child) v = -1;
+      tab[i].child[o] = (int)tab.size();
+      tab.push_back(ch);
+    }
+  }
+  std::vector<int32_t> flat(tab.size() * SFFK_SPEC_TAB, 0);
+  for (size_t i = 0; i < tab.size(); ++i) {
+    int32_t* t = flat.data() + i * SFFK_SPEC_TAB;
+    t[0] = tab[i].level;
+    for (int l = 0; l < SFFK_SPEC_DEPTH; ++l) { t[1 + l] = tab[i].out[l]; t[1 + SFFK_SPEC_DEPTH + l] = tab[i].anc[l]; }
+    for (int o = 0; o < 9; ++o) t[1 + 2 * SFFK_SPEC_DEPTH + o] = tab[i].child[o];
+  }
+  d.spec_tab.ensure(flat.size() * 4);
+  HIPCHK(hipMemcpy(d.spec_tab.p, flat.data(), flat.size() * 4, hipMemcpyHostToDevice));
+  d.spec_n_sc = (int)tab.size();
+  d.spec_sets = sets;
+  d.spec_tm = TM;
+  // control blocks (16 granules per set, 4 sets at most) | cur_step (a line of its own) | records
+  d.spec_area.ensure(1024 + (size_t)sets * d.spec_n_sc * TM * (SFFK_SPEC_REC * 8 + 8) + 1024);   // (+ the debugging words, SpecArgs::hb)
+  return true;
+}
+
 // waves of ONE slot (the reference's own order): k_seq_waves runs whole outer iterations back to back inside one launch,
 // thousands of waves per launch; the host tops the engine-word ring up between launches and handles what the round engine's
 // host side handles (growth, re-celling, a list overflow -> that wave is finished on the host-replay engine)
@@ -1381,12 +1438,61 @@ void Forest::run_device_seq(int max_waves) {
       a.cell_edge = c.grid_cell;
       a.knn_slack = 8 * c.sweep_eps();
     }
-    sffk::launch_seq_waves(c.stream, a);
+    const char* trace_path = getenv("SFFGPU_SEQ_TRACE");
+    DevBuf trace_buf;
+    if (trace_path) {
+      trace_buf.ensure((size_t)batch * 32);
+      HIPCHK(hipMemsetAsync(trace_buf.p, 0xff, (size_t)batch * 32, c.stream));
+      a.trace = trace_buf.as<int32_t>();
+      a.trace_cap = batch;
+    }
+    const uint64_t waves_before = k.waves;
+    const bool spec = spec_setup();
+    if (spec) {
+      sffk::SpecArgs sa{};
+      sa.q = a;
+      sa.sc_tab = d.spec_tab.as<int32_t>();
+      sa.n_sc = d.spec_n_sc;
+      sa.tm = d.spec_tm;
+      sa.n_slots = d.spec_n_sc * d.spec_tm;
+      sa.n_sets = d.spec_sets;
+      sa.base = d.spec_area.as<unsigned long long>();
+      sa.cur_step = reinterpret_cast<int32_t*>(d.spec_area.as<uint8_t>() + 768);
+      sa.rec = d.spec_area.as<unsigned long long>() + 128;
+      sa.timeout_ticks = 20000000ULL;   // 200 ms
+      const size_t rec_bytes = (size_t)sa.n_sets * sa.n_slots * SFFK_SPEC_REC * 8;
+      if (getenv("SFFGPU_PROFILE")) sa.hb = reinterpret_cast<unsigned long long*>(d.spec_area.as<uint8_t>() + 1024 + rec_bytes);
+      HIPCHK(hipMemsetAsync(d.spec_area.p, 0, d.spec_area.cap, c.stream));
+      sffk::launch_spec_waves(c.stream, sa);
+    } else {
+      sffk::launch_seq_waves(c.stream, a);
+    }
     HIPCHK(hipMemcpyAsync(d.h_ctrl.as<sffk::DevCtrl>(), d.ctrl.p, sizeof(sffk::DevCtrl), hipMemcpyDeviceToHost, c.stream));
     d.status_copied[0] = true;
     HIPCHK(hipEventRecord(d.ev_wave, c.stream));
     d.host_stale = true;
     const int fault = dev_finish_wave(&wait_ms, 0, true);
+    if (trace_path) {
+      const size_t nw = (size_t)(d.last.waves - waves_before);
+      std::vector<int32_t> tr(nw * 8);
+      if (nw) HIPCHK(hipMemcpy(tr.data(), trace_buf.p, nw * 32, hipMemcpyDeviceToHost));
+      if (FILE* fp = fopen(trace_path, "ab")) { fwrite(tr.data(), 4, tr.size(), fp); fclose(fp); }
+      trace_buf.release();
+    }
+    if (spec && d.last.spec_stalled) {   // (its workgroups were not resident together: the single wavefront from here on)
+      d.spec_off = true;
+      if (getenv("SFFGPU_PROFILE")) {
+        fprintf(stderr, "[sffgpu k_spec_waves] a record did not arrive: back to k_seq_waves\n");
+        const int nw = d.spec_sets * d.spec_n_sc * d.spec_tm;
+        std::vector<unsigned long long> hb((size_t)nw + 8 + 34);
+        HIPCHK(hipMemcpy(hb.data(), d.spec_area.as<uint8_t>() + 1024 + (size_t)nw * SFFK_SPEC_REC * 8, hb.size() * 8, hipMemcpyDeviceToHost));
+        fprintf(stderr, "  leader waited at step %llu scenario %llu attempt %llu set %llu; granules seen:", hb[nw], hb[nw + 1], hb[nw + 2], hb[nw + 3]);
+        for (int q = 0; q < 34; ++q) fprintf(stderr, " %llx", hb[nw + 8 + q]);
+        fprintf(stderr, "\n  workers (step:phase):");
+        for (int w = 0; w < nw; ++w) fprintf(stderr, " %llu:%llu", hb[w] >> 8, hb[w] & 255);
+        fprintf(stderr, "\n");
+      }
+    }
     if (fault == SFFK_FAULT_LISTS) {
       ++st.host_fallback_waves;
       dev_to_host();

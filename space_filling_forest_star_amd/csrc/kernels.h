@@ -197,6 +197,10 @@ struct DevCtrl {
   // status blocks published so far (DevForestView::host_status): the wave's last kernel writes the control block straight
   // into a ring of pinned host memory, numbered by this counter - no copy launch behind every wave
   int32_t status_seq, status_pad;
+  // waves of one slot, speculated (k_spec_waves): steps (publish -> evaluate -> commit), attempts the workers evaluated,
+  // attempts that were committed; stalled = a worker's record did not arrive in time (the host goes back to k_seq_waves)
+  unsigned long long spec_steps, spec_evaluated, spec_committed;
+  int32_t spec_stalled, spec_pad;
 };
 #define SFFK_STATUS_RING 4
 #define SFFK_DEV_MAX_GROUPS 1024   // single-workgroup list kernels: 64 x this many slots per wave at most
@@ -620,8 +624,42 @@ struct SeqArgs {
   int32_t* tree_cnt;                  // StarView::tree_cnt
   int32_t* hist; int32_t* hist_ctl; int hist_cap;   // StarView's parent history (record_parents) or null
   double cell_edge, knn_slack;
+  // SFFGPU_SEQ_TRACE=<file>: per wave {node, pick, iteration at its start, cursor at its start, outcome (attempt that was
+  // accepted, ThresholdMisses = none), nodes} - 8 ints, indexed by the launch's wave number; null = off
+  int32_t* trace; int trace_cap;
 };
 void launch_seq_waves(hipStream_t s, const SeqArgs& a);
+// ---- the same loop, SPECULATED over many wavefronts (round 6, k_spec_waves).  One wavefront computes an attempt in
+// ~10-15 us however idle the other 1 023 SIMDs are; but what an attempt of the NEXT waves will be is known in advance
+// up to one small unknown per wave - which of its ThresholdMisses attempts, if any, is accepted (src/forest.h:138-178: the
+// frontier pick is a Lemire draw from the pool, a wave that fails erases its node order-preservingly, a wave that accepts
+// at attempt r has consumed 1 + 6 (r + 1) engine words and appended one node).  So a STEP evaluates a small tree of
+// scenarios side by side, one workgroup of one wavefront per (scenario, attempt): scenario = the outcomes (accept at
+// attempt r | all fail) assumed for the waves before it.  Every worker derives its scenario's frontier pick and word
+// position from the published control block alone (scalar arithmetic on ring words), evaluates its attempt against the
+// frozen store plus the samples its scenario assumes accepted (read from their workers' records), and writes a record;
+// nothing else.  The LEADER (workgroup 0) owns the forest: it walks the records in the reference's order - it recomputes
+// every pick itself and only takes a scenario's records when node, word position, iteration and node count agree with its
+// own state - applies counters, border events, the accepted node, the closed list / frontier erase and the termination
+// tests exactly like k_seq_waves, follows the tree by the outcome that really happened, and publishes the next step.
+// Everything a worker reads of what the leader wrote in the same launch is stored write-through (`sc1`) and loaded `sc1`;
+// control block and records travel as 8-byte {value, step} granules, so no fence and no flag is needed.
+// SFF*: a chain of all-fail scenarios only (an accepted node's rewires change costs the later attempts would read).
+#define SFFK_SPEC_DEPTH 4          // most waves of one step
+#define SFFK_SPEC_TAB 20           // ints per scenario: level | out[DEPTH] | anc[DEPTH] | child[9] | pad
+#define SFFK_SPEC_REC 400          // granules per record: row 0 (64) | SFF* rewires (64 x 5) | early row (16)
+#define SFFK_SPEC_EARLY 384
+struct SpecArgs {
+  SeqArgs q;
+  const int32_t* sc_tab;              // the scenario tree (host-built): SFFK_SPEC_TAB ints per scenario
+  int n_sc, n_slots, n_sets, tm;      // scenarios; workers per set = n_sc x ThresholdMisses; sets take the steps in turn
+  unsigned long long* base;           // per set: 16 granules = the control block of its current step
+  unsigned long long* rec;            // n_sets x n_slots records of SFFK_SPEC_REC granules
+  int32_t* cur_step;                  // the step the leader is at (workers of older steps give up), -1 = the launch is over
+  unsigned long long timeout_ticks;   // a record that is not there after this many 10 ns ticks = stalled
+  unsigned long long* hb;             // debugging (SFFGPU_PROFILE): per worker (step << 8 | phase), [n_sets x n_slots ..]: the leader's last wait; null = off
+};
+void launch_spec_waves(hipStream_t s, const SpecArgs& a);
 // multi-GPU: the answer record of one sample as it travels in the all-gather of a round:
 // flags, nnb, pose_hit, 0 | nb[nbcap] | meta[nbcap] | seg_ns[1 + nbcap] | first_hit[1 + nbcap]
 inline int record_words(int nbcap) { return 6 + 4 * nbcap; }

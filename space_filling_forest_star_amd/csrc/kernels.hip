@@ -4538,6 +4538,10 @@ __global__ __launch_bounds__(64) void k_seq_waves(SeqArgs A) {
     }
     const bool budget = f.node_budget > 0 && n_nodes >= f.node_budget;
     terminated = (solved || iter >= f.max_iterations || budget) ? 1 : 0;
+    if (A.trace && wv < A.trace_cap && lane == 0) {
+      int32_t* t = A.trace + 8 * (size_t)wv;
+      t[0] = node; t[1] = pick; t[2] = iter; t[3] = (int32_t)(cursor & 0x7fffffffULL); t[4] = failing ? TM : 0; t[5] = n_nodes; t[6] = fn; t[7] = cn;
+    }
     lap(7);
   }
   if (lane == 0) {
@@ -4570,6 +4574,803 @@ void launch_seq_waves(hipStream_t s, const SeqArgs& a) {
   } else {
     if (lds > 48 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_seq_waves<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(k_seq_waves<false>, dim3(1), dim3(64), lds, s, a);
+  }
+}
+
+// ------------------------------------------------------------------ waves of one slot, SPECULATED (kernels.h: SpecArgs)
+// write-through stores: what the leader writes and a worker on another XCD reads in the same launch
+__device__ __forceinline__ void wt_i32(int32_t* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void wt_u64(unsigned long long* p, unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void wt_f64(double* p, double v) {
+  wt_u64(reinterpret_cast<unsigned long long*>(p), (unsigned long long)__double_as_longlong(v));
+}
+__device__ __forceinline__ void wt_u8(uint8_t* p, uint8_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned long long sp_gran(uint32_t tag, uint32_t v) { return ((unsigned long long)tag << 32) | (unsigned long long)v; }
+__device__ __forceinline__ uint32_t sp_lo(double v) { return (uint32_t)((unsigned long long)__double_as_longlong(v) & 0xffffffffULL); }
+__device__ __forceinline__ uint32_t sp_hi(double v) { return (uint32_t)((unsigned long long)__double_as_longlong(v) >> 32); }
+__device__ __forceinline__ double sp_f64(uint32_t lo, uint32_t hi) {
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | (unsigned long long)lo));
+}
+// grid_put (kernels_dev.h) by the launch's only writer, with write-through stores of what the workers read
+__device__ __forceinline__ void grid_put_wt(const GridView& g, const GridItem& it) {
+  const size_t cell = grid_cell_of(g, (float)it.p[0], (float)it.p[1], (float)it.p[2]);
+  const int slot = sq_i32(g.cnt + cell);
+  if (g.occ) atomicOr(g.occ + (cell >> 5), 1u << (cell & 31));
+  GridItem32 lt;
+  lt.x = (float)it.p[0]; lt.y = (float)it.p[1]; lt.z = (float)it.p[2];
+  lt.yaw = (float)it.p[3]; lt.pitch = (float)it.p[4]; lt.roll = (float)it.p[5];
+  lt.id = it.id; lt.tree = it.tree;
+  const unsigned long long tail = ((unsigned long long)(uint32_t)it.tree << 32) | (unsigned long long)(uint32_t)it.id;
+  if (slot < g.bk) {
+    unsigned long long* q8 = reinterpret_cast<unsigned long long*>(g.items + cell * g.bk + slot);
+    for (int k = 0; k < 6; ++k) wt_u64(q8 + k, (unsigned long long)__double_as_longlong(it.p[k]));
+    wt_u64(q8 + 6, tail); wt_u64(q8 + 7, 0ULL);
+    if (g.lite) g.lite[cell * g.bk + slot] = lt;
+  } else {
+    const int o = sq_i32(g.ovf_cnt);
+    if (o < g.ovf_cap) {   // the host checks ovf_cnt against ovf_cap
+      unsigned long long* q8 = reinterpret_cast<unsigned long long*>(g.ovf + o);
+      for (int k = 0; k < 6; ++k) wt_u64(q8 + k, (unsigned long long)__double_as_longlong(it.p[k]));
+      wt_u64(q8 + 6, tail); wt_u64(q8 + 7, 0ULL);
+      if (g.ovf_lite) g.ovf_lite[o] = lt;
+    }
+    sq_drain();
+    wt_i32(g.ovf_cnt, o + 1);
+  }
+  sq_drain();
+  wt_i32(g.cnt + cell, slot + 1);
+}
+
+// record row 0 (granule = {value, step}); doubles as two granules (lo, hi)
+#define SPG_STATUS 0
+#define SPG_NODE 1
+#define SPG_ITER 2
+#define SPG_CUR 3      // + 4
+#define SPG_NN 5
+#define SPG_CC 6
+#define SPG_PF 7
+#define SPG_NQ 8
+#define SPG_EVENT 9
+#define SPG_EV_ID 10
+#define SPG_EV_TREE 11
+#define SPG_EV_DIST 12 // + 13
+#define SPG_MINE 14
+#define SPG_QP 15      // .. 26
+#define SPG_BEST 27    // + 28
+#define SPG_PAR 29
+#define SPG_DCL 30     // + 31
+#define SPG_NRW 32
+#define SPG_NMEM 33
+#define SPG_USED 34
+#define SPS_REJECT 1
+#define SPS_ACCEPT 2
+#define SPS_FAULT 3
+#define SPS_INVALID 4
+#define SPS_SKIPPED 5
+// the published control block of a step
+#define SPB_CUR 0      // + 1
+#define SPB_FN 2
+#define SPB_CN 3
+#define SPB_NN 4
+#define SPB_ITER 5
+#define SPB_EF 6
+#define SPB_USED 7
+#define SP_QUIT 0xffffffffu
+
+template <bool OPT>
+__global__ __launch_bounds__(64) void k_spec_waves(SpecArgs S) {
+  extern __shared__ double lds_d[];
+  __shared__ int32_t s_fh, s_ovf;
+  __shared__ int32_t h_id[64], h_tree[64];
+  __shared__ double h_d[64], h_pos[64 * 6];
+  __shared__ uint32_t s_row[64];
+  __shared__ double p_pos[SFFK_SPEC_DEPTH * 6], p_best[SFFK_SPEC_DEPTH];
+  __shared__ int32_t p_tree[SFFK_SPEC_DEPTH];
+  __shared__ uint32_t s_rw[OPT ? SFFK_STAR_KC * 5 : 1];
+  const SeqArgs& A = S.q;
+  const DevForestView& f = A.f;
+  DevCtrl* c = f.ctrl;
+  const int lane = threadIdx.x;
+  if (c->halt || c->in_wave) return;            // (a wave the host left half done goes through the round engine)
+  const int TM = f.threshold_misses, WP = f.words_per, R = f.n_trees;
+  const int front_sel = c->front_sel;
+  int32_t* frontier = front_sel ? f.frontier2 : f.frontier;
+
+  if (blockIdx.x == 0) {
+    // =================================================================== the leader: owns the forest, commits in order
+    int n_nodes = c->n_nodes, iter = c->iter, fn = c->frontier_n, cn = c->closed_n, nb = c->n_borders;
+    int solved = c->solved, empty_frontier = c->empty_frontier, terminated = c->terminated;
+    unsigned long long cursor = c->cursor, cc = c->collide_calls, pf = c->path_free_calls, nq = c->nn_queries;
+    unsigned long long waves = c->waves, rounds = c->rounds, rnodes = c->round_nodes, rqueries = c->round_queries, redraws = 0;
+    int fault = 0, w_round = 0, w_node = 0, w_pos = 0, w_closed = 0, in_wave = 0, stalled = 0;
+    unsigned long long st_rounds = 0, st_members = 0, st_rewires = 0, n_steps = 0, n_commit = 0;
+    uint32_t step = 0;
+    int waves_done = 0;
+    bool stop = false;
+    const unsigned long long epoch = c->epoch;
+    // The frontier array does not change while a step runs (its workers read it whenever they get to it): the erases of
+    // the step's failed waves are kept as a sorted list of positions (the workers model them the same way) and applied
+    // when the step is over; accepted nodes go behind the step's first fn entries.
+    int fn_base = fn, nn_base = n_nodes, ner = 0, na_l = 0, erl[SFFK_SPEC_DEPTH];
+    for (int e = 0; e < SFFK_SPEC_DEPTH; ++e) erl[e] = 0x7fffffff;
+    auto flush_erases = [&]() {
+      int pfn = fn_base + na_l;
+      for (int e = SFFK_SPEC_DEPTH - 1; e >= 0; --e) {
+        if (e >= ner) continue;
+        int at = 0x7fffffff;
+        for (int q = 0; q < SFFK_SPEC_DEPTH; ++q) if (q == e) at = erl[q];
+        for (int j0 = at; j0 < pfn - 1; j0 += 256) {
+          int v[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { const int j = j0 + 64 * u + lane; v[u] = j < pfn - 1 ? sq_i32(frontier + j + 1) : 0; }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { const int j = j0 + 64 * u + lane; if (j < pfn - 1) wt_i32(frontier + j, v[u]); }
+          sq_drain();
+        }
+        --pfn;
+      }
+      for (int e = 0; e < SFFK_SPEC_DEPTH; ++e) erl[e] = 0x7fffffff;
+      ner = 0; na_l = 0; fn_base = fn; nn_base = n_nodes;
+    };
+    while (!terminated && !fault && !stop && waves_done < A.max_waves) {
+      ++step; ++n_steps;
+      const int set = (int)(step % (uint32_t)S.n_sets);
+      {   // ---- publish the control block of this step
+        uint32_t v = 0;
+        v = lane == SPB_CUR ? (uint32_t)(cursor & 0xffffffffULL) : v;
+        v = lane == SPB_CUR + 1 ? (uint32_t)(cursor >> 32) : v;
+        v = lane == SPB_FN ? (uint32_t)fn : v;
+        v = lane == SPB_CN ? (uint32_t)cn : v;
+        v = lane == SPB_NN ? (uint32_t)n_nodes : v;
+        v = lane == SPB_ITER ? (uint32_t)iter : v;
+        v = lane == SPB_EF ? (uint32_t)empty_frontier : v;
+        if (lane < 16) wt_u64(S.base + 16 * set + lane, sp_gran(step, v));
+        if (lane == 0) wt_i32(S.cur_step, (int)step);
+      }
+      int sc = 0;
+      for (;;) {   // ---- the waves of this step, in the reference's order
+        // what the round engine checks before a round (round_begin_scalars), and what this launch has to leave to the host
+        if (n_nodes + 1 > f.node_cap - 8 || nb + TM > f.border_cap) { fault = SFFK_FAULT_CAPACITY; break; }
+        if ((unsigned long long)(nb + TM) * 2ULL > f.bt_mask + 1ULL) { fault = SFFK_FAULT_BORDER_TABLE; break; }
+        if (cursor + 8ULL + (unsigned long long)(TM * WP) > A.words_end) { stop = true; break; }
+        if (sq_i32(A.grid_ovf_src) > A.grid_ovf_limit) { stop = true; break; }
+        // node selection (src/forest.h:136-151) - tentative until the scenario's records are known to be about this wave
+        const int use_closed = cn > 0 && empty_frontier;
+        const int pool = use_closed ? cn : fn;
+        if (pool < 1) { terminated = 1; break; }
+        unsigned long long cur2 = cursor, rdw = 0;
+        int pick;
+        do { pick = sq_lemire(f.ring[cur2 & f.ring_mask], (unsigned long long)pool); ++cur2; if (pick < 0) ++rdw; } while (pick < 0);
+        int node;
+        if (use_closed) node = sq_i32(f.closed + pick);
+        else if (pick >= fn_base - ner) node = nn_base + (pick - (fn_base - ner));   // (a node of this step)
+        else {
+          int idx = pick;
+          for (int e = 0; e < SFFK_SPEC_DEPTH; ++e) if (e < ner && erl[e] <= idx) ++idx;
+          node = sq_i32(frontier + idx);
+        }
+        const unsigned long long* rec0 = S.rec + ((size_t)set * S.n_slots + (size_t)sc * TM) * SFFK_SPEC_REC;
+        auto fetch = [&](int rd) -> bool {       // row 0 of attempt rd's record -> s_row
+          const unsigned long long* rp = rec0 + (size_t)rd * SFFK_SPEC_REC;
+          const unsigned long long t0 = wall_clock64();
+          __syncthreads();
+          for (int spin = 0;; ++spin) {
+            const unsigned long long g = sq_u64(rp + lane);
+            if (__all(lane >= SPG_USED || (uint32_t)(g >> 32) == step)) { s_row[lane] = (uint32_t)g; break; }
+            if ((spin & 63) == 63 && wall_clock64() - t0 > S.timeout_ticks) {
+              if (S.hb) {
+                unsigned long long* o = S.hb + (size_t)S.n_sets * S.n_slots;
+                if (lane == 0) { o[0] = step; o[1] = (unsigned long long)sc; o[2] = (unsigned long long)rd; o[3] = (unsigned long long)set; }
+                if (lane < SPG_USED) o[8 + lane] = g;
+              }
+              return false;
+            }
+            __builtin_amdgcn_s_sleep(1);
+          }
+          __syncthreads();
+          return true;
+        };
+        bool have0 = false;
+        if (iter < f.max_iterations) {
+          if (!fetch(0)) { stalled = 1; stop = true; break; }
+          have0 = true;
+          const unsigned long long rc = ((unsigned long long)s_row[SPG_CUR + 1] << 32) | (unsigned long long)s_row[SPG_CUR];
+          const bool same = s_row[SPG_STATUS] != SPS_INVALID && (int)s_row[SPG_NODE] == node && (int)s_row[SPG_ITER] == iter &&
+                            rc == cur2 && (int)s_row[SPG_NN] == n_nodes;
+          if (!same) {                           // the scenario is not what happened: the step ends in front of this wave
+            if (sc == 0) fault = SFFK_FAULT_INTERNAL;
+            break;
+          }
+        }
+        cursor = cur2; redraws += rdw; ++waves;
+        w_node = node; w_pos = pick; w_closed = use_closed;
+        bool failing = true;
+        int outcome = TM;
+        for (int rd = 0; rd < TM && failing && iter < f.max_iterations; ++rd) {
+          if (!(rd == 0 && have0) && !fetch(rd)) {
+            stalled = 1; fault = SFFK_FAULT_LISTS; w_round = rd; in_wave = 1;   // (the host finishes the wave)
+            break;
+          }
+          const int status = (int)s_row[SPG_STATUS];
+          if ((int)s_row[SPG_NODE] != node || (int)s_row[SPG_ITER] != iter || (int)s_row[SPG_NN] != n_nodes ||
+              (((unsigned long long)s_row[SPG_CUR + 1] << 32) | (unsigned long long)s_row[SPG_CUR]) != cursor) { fault = SFFK_FAULT_INTERNAL; break; }
+          if (status == SPS_FAULT) { fault = SFFK_FAULT_LISTS; w_round = rd; in_wave = 1; break; }
+          if (status != SPS_REJECT && status != SPS_ACCEPT) { fault = SFFK_FAULT_INTERNAL; break; }
+          cursor += (unsigned long long)WP;
+          ++iter;
+          ++rounds; rnodes += (unsigned long long)(n_nodes + 1); ++rqueries; ++n_commit;
+          cc += (unsigned long long)s_row[SPG_CC]; pf += (unsigned long long)s_row[SPG_PF]; nq += (unsigned long long)s_row[SPG_NQ];
+          const int mine = (int)s_row[SPG_MINE];
+          if (s_row[SPG_EVENT]) {                // :288-294 border entry unless the pair has one
+            const int s_id = (int)s_row[SPG_EV_ID], s_tree = (int)s_row[SPG_EV_TREE];
+            const int a = s_id < node ? s_id : node, b = s_id < node ? node : s_id;
+            const unsigned long long key = ((unsigned long long)(uint32_t)a << 32) | ((unsigned long long)(uint32_t)b + 1ULL);
+            size_t h = (size_t)((key * 0x9E3779B97F4A7C15ULL) >> 17) & (size_t)f.bt_mask;
+            bool fresh = false;
+            for (int guard = 0; guard < (1 << 24); ++guard) {
+              const unsigned long long cur = sq_u64(f.bt_key + h);
+              if (cur == key) { fresh = sq_u64(f.bt_val + h) == ~0ULL; break; }
+              if (cur == 0ULL) { fresh = true; break; }
+              h = (h + 1) & (size_t)f.bt_mask;
+            }
+            if (fresh) {
+              if (lane == 0) {
+                f.bt_key[h] = key;
+                f.bt_val[h] = epoch << 32;
+                f.b_n1[nb] = a; f.b_n2[nb] = b;
+                f.b_ta[nb] = s_tree < mine ? s_tree : mine; f.b_tb[nb] = s_tree < mine ? mine : s_tree;
+                f.b_dist[nb] = sp_f64(s_row[SPG_EV_DIST], s_row[SPG_EV_DIST + 1]);
+                f.pair[(size_t)s_tree * R + mine] = 1;
+                f.pair[(size_t)mine * R + s_tree] = 1;
+              }
+              sq_drain();
+              ++nb;
+            }
+          }
+          if (status != SPS_ACCEPT) continue;
+          // ---- the new node (:329, :353-367)
+          const int idn = n_nodes;
+          double qp[6];
+          for (int k = 0; k < 6; ++k) qp[k] = sp_f64(s_row[SPG_QP + 2 * k], s_row[SPG_QP + 2 * k + 1]);
+          const int par_new = (int)s_row[SPG_PAR];
+          const double dcl_new = sp_f64(s_row[SPG_DCL], s_row[SPG_DCL + 1]), best = sp_f64(s_row[SPG_BEST], s_row[SPG_BEST + 1]);
+          const int n_rw = OPT ? (int)s_row[SPG_NRW] : 0;
+          if (OPT) { ++st_rounds; st_members += (unsigned long long)s_row[SPG_NMEM]; }
+          if (OPT && n_rw > 0) {                 // the rewires behind row 0 (written and drained before it)
+            const unsigned long long* rp = rec0 + (size_t)rd * SFFK_SPEC_REC + 64;
+            for (int q = lane; q < 5 * n_rw; q += 64) s_rw[q] = (uint32_t)sq_u64(rp + q);
+          }
+          __syncthreads();
+          if (lane == 0) {
+            const size_t o = (size_t)idn;
+            A.st.x[o] = (float)qp[0]; A.st.y[o] = (float)qp[1]; A.st.z[o] = (float)qp[2];
+            A.st.yaw[o] = (float)qp[3]; A.st.pitch[o] = (float)qp[4]; A.st.roll[o] = (float)qp[5];
+            for (int k = 0; k < 6; ++k) wt_f64(A.st.pos + 6 * o + k, qp[k]);
+            wt_i32(A.st.tree + o, mine);
+            wt_i32(f.parent + o, par_new);
+            wt_f64(f.d_closest + o, dcl_new);
+            wt_f64(f.d_root + o, best);
+            f.iter[o] = (uint32_t)iter;
+            wt_u8(f.nflag + o, 2);
+            wt_i32(frontier + fn_base + na_l, idn);
+            if (OPT) {
+              atomicAdd(A.tree_cnt + 16 * mine, 1);
+              if (A.hist) {
+                const int at = atomicAdd(A.hist_ctl, 1);
+                if (at < A.hist_cap) { A.hist[3 * (size_t)at] = idn; A.hist[3 * (size_t)at + 1] = par_new; A.hist[3 * (size_t)at + 2] = iter; }
+                else A.hist_ctl[1] = 1;
+              }
+            }
+            GridItem it;
+            for (int k = 0; k < 6; ++k) it.p[k] = qp[k];
+            it.id = idn; it.tree = mine; it.pad[0] = it.pad[1] = 0;
+            grid_put_wt(A.g, it);
+            if (OPT) {
+              // rewire (:332-350), as the worker found them in the reference's order
+              for (int j = 0; j < n_rw; ++j) {
+                const int idm = (int)s_rw[5 * j];
+                wt_i32(f.parent + idm, idn);
+                wt_f64(f.d_closest + idm, sp_f64(s_rw[5 * j + 1], s_rw[5 * j + 2]));
+                wt_f64(f.d_root + idm, sp_f64(s_rw[5 * j + 3], s_rw[5 * j + 4]));
+                if (A.hist) {
+                  const int at = atomicAdd(A.hist_ctl, 1);
+                  if (at < A.hist_cap) { A.hist[3 * (size_t)at] = idm; A.hist[3 * (size_t)at + 1] = idn; A.hist[3 * (size_t)at + 2] = iter; }
+                  else A.hist_ctl[1] = 1;
+                }
+              }
+            }
+          }
+          sq_drain();
+          st_rewires += (unsigned long long)n_rw;
+          ++n_nodes; ++fn; ++na_l;
+          failing = false;
+          outcome = rd;
+        }
+        if (fault) break;
+        // ---- the slot is exhausted: its node leaves the frontier for the closed list (:160-178; the erase keeps the order)
+        bool desync = false;
+        if (failing && !use_closed) {
+          const int fl = sq_u8(f.nflag + node);
+          if (fl & 2) {
+            if (lane == 0) { wt_u8(f.nflag + node, (uint8_t)((fl & ~2) | 1)); wt_i32(f.closed + cn, node); }
+            ++cn;
+            int idx = pick;
+            if (pick >= fn_base - ner) { flush_erases(); desync = true; }   // (a node of this step: the array first becomes what the list says)
+            else for (int e = 0; e < SFFK_SPEC_DEPTH; ++e) if (e < ner && erl[e] <= idx) ++idx;
+            for (int e = SFFK_SPEC_DEPTH - 1; e > 0; --e) if (erl[e - 1] > idx) erl[e] = erl[e - 1];
+            int at = 0;
+            for (int e = 0; e < SFFK_SPEC_DEPTH; ++e) if (e < ner && erl[e] < idx) at = e + 1;
+            for (int e = 0; e < SFFK_SPEC_DEPTH; ++e) if (e == at) erl[e] = idx;
+            ++ner;
+            --fn;
+          } else desync = true;                  // (the scenarios below assumed the erase)
+        }
+        sq_drain();
+        // ---- termination (:184-201)
+        empty_frontier = fn == 0 ? 1 : 0;
+        if (!solved && empty_frontier) {
+          unsigned long long reach = 1ULL, frontier_set = 1ULL;
+          if (R <= 64) {
+            unsigned long long row = 0ULL;   // lane a: bit b = pair (a, b) has a border
+            if (lane < R) for (int b2 = 0; b2 < R; ++b2) if (sq_u8(f.pair + (size_t)lane * R + b2)) row |= 1ULL << b2;
+            while (frontier_set) {
+              const int a = __ffsll((long long)frontier_set) - 1;
+              frontier_set &= frontier_set - 1;
+              const unsigned long long ra = __shfl(row, a) & ~reach;
+              reach |= ra; frontier_set |= ra;
+            }
+            solved = __popcll(reach) == R ? 1 : 0;
+          } else fault = SFFK_FAULT_LISTS;
+        }
+        const bool budget = f.node_budget > 0 && n_nodes >= f.node_budget;
+        terminated = (solved || iter >= f.max_iterations || budget) ? 1 : 0;
+        if (A.trace && waves_done < A.trace_cap && lane == 0) {
+          int32_t* t = A.trace + 8 * (size_t)waves_done;
+          t[0] = node; t[1] = pick; t[2] = iter; t[3] = (int32_t)(cursor & 0x7fffffffULL); t[4] = failing ? TM : 0; t[5] = n_nodes; t[6] = fn; t[7] = cn;
+        }
+        ++waves_done;
+        if (terminated || fault || desync || waves_done >= A.max_waves) break;
+        sc = S.sc_tab[sc * SFFK_SPEC_TAB + 1 + 2 * SFFK_SPEC_DEPTH + outcome];
+        if (sc < 0) break;
+      }
+      flush_erases();                            // (before anybody is told about the next step)
+    }
+    // ---- the launch is over: every set's next control block says so
+    for (int s2 = 0; s2 < S.n_sets; ++s2)
+      if (lane < 16) wt_u64(S.base + 16 * s2 + lane, sp_gran(SP_QUIT, 0u));
+    if (lane == 0) wt_i32(S.cur_step, -1);
+    if (lane == 0) {
+      c->n_nodes = n_nodes; c->iter = iter; c->frontier_n = fn; c->closed_n = cn; c->n_borders = nb;
+      c->solved = solved; c->empty_frontier = empty_frontier; c->terminated = terminated;
+      c->cursor = cursor; c->collide_calls = cc; c->path_free_calls = pf; c->nn_queries = nq;
+      c->waves = waves; c->rounds = rounds; c->round_nodes = rnodes; c->round_queries = rqueries;
+      c->redraws += (int)redraws;
+      c->star_rounds += st_rounds; c->star_passes += st_rounds; c->star_members += st_members; c->star_rewires += st_rewires;
+      c->spec_steps += n_steps; c->spec_committed += n_commit; c->spec_stalled = stalled;
+      c->n_act = 0; c->app_n = 0; c->compact_from = 0;
+      c->grid_ovf = sq_i32(A.grid_ovf_src); c->tgrid_ovf = 0;
+      c->fault = fault;
+      c->halt = (terminated || fault) ? 1 : 0;
+      c->in_wave = in_wave;
+      if (in_wave) {   // the state the host engine resumes the wave from: its one slot, still failing, w_round rounds done
+        c->round = w_round; c->n_slots = 1; c->use_closed = w_closed; c->act_sel = 0; c->act_cnt = 1;
+        f.slot_node[0] = w_node; f.slot_pos[0] = w_pos; f.act_slot[0] = 0;
+      } else c->round = 0;
+    }
+    return;
+  }
+
+  // ===================================================================== a worker: one (scenario, attempt) of every step of its set
+  const int wid = (int)blockIdx.x - 1;
+  const int set = wid / S.n_slots, slot = wid - set * S.n_slots;
+  const int sc = slot / TM, att = slot - sc * TM;
+  const int32_t* T = S.sc_tab + sc * SFFK_SPEC_TAB;
+  const int level = T[0];
+  int out_[SFFK_SPEC_DEPTH], anc_[SFFK_SPEC_DEPTH];
+  for (int l = 0; l < SFFK_SPEC_DEPTH; ++l) { out_[l] = T[1 + l]; anc_[l] = T[1 + SFFK_SPEC_DEPTH + l]; }
+  unsigned long long* my_rec = S.rec + ((size_t)set * S.n_slots + slot) * SFFK_SPEC_REC;
+  double* rtri = lds_d;
+  double* stage = rtri + (size_t)A.rob.n_tri * 9;
+  int32_t* ibase = reinterpret_cast<int32_t*>(stage + STAGE_DOUBLES);
+  int32_t* stack = ibase;                        // (+ the triangle-grid hash set behind it)
+  int32_t* cand = ibase + (STACK_CAP + TG_HASH);
+  int32_t* queue = cand + CAND_CAP;
+  for (int i = lane; i < A.rob.n_tri * 9; i += 64) rtri[i] = A.rob.tri[i];
+  __builtin_amdgcn_wave_barrier();
+  fill_robot_boxes(rtri, reinterpret_cast<double*>(queue + QUEUE_CAP), A.rob.n_tri, lane, 64);
+  __builtin_amdgcn_wave_barrier();
+  uint32_t last = 0;
+  unsigned long long ex_pose = 0, ex_seg = 0, ex_smp = 0, evals = 0;
+  for (;;) {
+    // ---- the next step of my set
+    uint32_t step = 0;
+    bool quit = false;
+    __syncthreads();
+    for (;;) {
+      const unsigned long long g = sq_u64(S.base + 16 * set + (lane & 15));
+      const uint32_t tg = (uint32_t)(g >> 32);
+      const uint32_t t0 = (uint32_t)__shfl((int)tg, 0);
+      const bool whole = __all(tg == t0);
+      if (whole && t0 == SP_QUIT) { quit = true; break; }
+      if (whole && t0 > last) { step = t0; s_row[lane] = (uint32_t)g; break; }
+      __builtin_amdgcn_s_sleep(2);
+    }
+    if (quit) break;
+    __syncthreads();
+    last = step;
+    const unsigned long long cur0 = ((unsigned long long)s_row[SPB_CUR + 1] << 32) | (unsigned long long)s_row[SPB_CUR];
+    const int fn0 = (int)s_row[SPB_FN], cn0 = (int)s_row[SPB_CN], nn0 = (int)s_row[SPB_NN], it0 = (int)s_row[SPB_ITER];
+    const int ef0 = (int)s_row[SPB_EF];
+    __syncthreads();
+    // (the leader is past my step; its store of cur_step may become visible after the control block's: never "!=")
+    auto stale = [&]() -> bool { return (uint32_t)__builtin_amdgcn_readfirstlane(sq_i32(S.cur_step)) > step; };
+    auto beat = [&](int phase) { if (S.hb && lane == 0) wt_u64(S.hb + wid, ((unsigned long long)step << 8) | (unsigned long long)phase); };
+    beat(1);
+    // ---- my scenario: the waves before mine, with the outcomes it assumes
+    unsigned long long cur = cur0;
+    int sfn = fn0, scn = cn0, snn = nn0, sit = it0;
+    int ne = 0, na = 0, er[SFFK_SPEC_DEPTH], pslot[SFFK_SPEC_DEPTH];
+    for (int l = 0; l < SFFK_SPEC_DEPTH; ++l) { er[l] = 0x7fffffff; pslot[l] = 0; }
+    bool valid = true;
+    for (int l = 0; l < level && valid; ++l) {
+      const int ucl = scn > 0 && ef0;
+      const int pool = ucl ? scn : sfn;
+      if (pool < 1) { valid = false; break; }
+      int pk;
+      do { pk = sq_lemire(f.ring[cur & f.ring_mask], (unsigned long long)pool); ++cur; } while (pk < 0);
+      const int o = out_[l];
+      if (o < TM) {                              // accepted at attempt o: one more node, at the frontier's end
+        if (sit + o + 1 > f.max_iterations) { valid = false; break; }
+        cur += (unsigned long long)((o + 1) * WP); sit += o + 1;
+        pslot[na++] = anc_[l] * TM + o;
+        ++sfn; ++snn;
+        if (f.node_budget > 0 && snn >= f.node_budget) valid = false;
+      } else {                                   // all attempts failed: the node leaves the frontier (order kept)
+        if (sit + TM > f.max_iterations) { valid = false; break; }
+        cur += (unsigned long long)(TM * WP); sit += TM;
+        if (!ucl) {
+          if (pk >= fn0 - ne) { valid = false; break; }   // (a node of this step: not modelled)
+          int idx = pk;
+          for (int e = 0; e < SFFK_SPEC_DEPTH; ++e) if (e < ne && er[e] <= idx) ++idx;
+          // keep er sorted
+          for (int e = SFFK_SPEC_DEPTH - 1; e > 0; --e) if (er[e - 1] > idx) er[e] = er[e - 1];
+          int at = 0;
+          for (int e = 0; e < SFFK_SPEC_DEPTH; ++e) if (e < ne && er[e] < idx) at = e + 1;
+          er[at] = idx;
+          ++ne; --sfn; ++scn;
+        }
+      }
+      if (sit >= f.max_iterations) valid = false;
+      if ((sfn == 0) != (ef0 != 0)) valid = false;   // frontier <-> closed-list mode switches end the step
+    }
+    int node = -1;
+    if (valid) {
+      const int ucl = scn > 0 && ef0;
+      const int pool = ucl ? scn : sfn;
+      if (pool < 1) valid = false;
+      else {
+        int pk;
+        do { pk = sq_lemire(f.ring[cur & f.ring_mask], (unsigned long long)pool); ++cur; } while (pk < 0);
+        if (ucl) { if (pk >= cn0) valid = false; else node = sq_i32(f.closed + pk); }
+        else if (pk >= fn0 - ne) valid = false;
+        else {
+          int idx = pk;
+          for (int e = 0; e < SFFK_SPEC_DEPTH; ++e) if (e < ne && er[e] <= idx) ++idx;
+          node = sq_i32(frontier + idx);
+        }
+      }
+    }
+    if (OPT && na > 0) valid = false;            // (SFF*: an accepted node's rewires change what a later attempt reads)
+    const unsigned long long cursor_a = cur + (unsigned long long)(att * WP);
+    const int iter_a = sit + att;
+    int status = SPS_REJECT;
+    if (!valid) status = SPS_INVALID;
+    else if (iter_a >= f.max_iterations) status = SPS_SKIPPED;
+    // ---- the attempt (k_seq_waves's, without its writes)
+    unsigned long long cc_l = 0;
+    int pf_l = 0, nq_l = 0, event = 0, ev_id = 0, ev_tree = 0, mine = 0, par_new = node, n_rw = 0, n_mem = 0;
+    double ev_dist = 0, pdist = 0, best = 0, dcl_new = 0, qp[6] = {0, 0, 0, 0, 0, 0};
+    bool aborted = false;
+    if (status == SPS_REJECT) {
+      double cpos[6];
+      for (int k = 0; k < 6; ++k) cpos[k] = sq_f64(A.st.pos + 6 * (size_t)node + k);
+      mine = sq_i32(A.st.tree + node);
+      const double droot_ex = sq_f64(f.d_root + node);
+      const bool force = (sq_u8(f.nflag + node) & 1) != 0;
+      uint64_t w[6];
+      for (int k = 0; k < 6; ++k) w[k] = k < WP ? f.ring[(cursor_a + k) & f.ring_mask] : 0ULL;
+      SampleTrig ht{};
+      if (A.trig) {
+        const double* t0 = A.trig + 3 * (size_t)(cursor_a & f.ring_mask);
+        ht.c_phi = t0[0]; ht.s_phi = t0[1];
+        if (WP == 6) {
+          const double* t1 = A.trig + 3 * (size_t)((cursor_a + 1) & f.ring_mask);
+          const double* t3 = A.trig + 3 * (size_t)((cursor_a + 3) & f.ring_mask);
+          ht.c_theta = t1[0]; ht.s_theta = t1[1]; ht.acos_u = t3[2];
+        }
+      } else {
+        const double ang = sample_angle(lane == 1 ? w[1] : w[0]);
+        const double sv = sffp::psin(ang), cv = sffp::pcos(ang);
+        ht.s_phi = __shfl(sv, 0); ht.c_phi = __shfl(cv, 0);
+        ht.s_theta = __shfl(sv, 1); ht.c_theta = __shfl(cv, 1);
+        ht.acos_u = WP == 6 ? sffp::pacos(sample_acos_arg(w[3])) : 0.0;
+      }
+      const bool ok = sample_point_with(w, cpos, A.sampling_dist, A.dim, A.limits, qp, ht);
+      pdist = dist6(cpos, qp);                                     // parentDistance, :250
+      best = pdist + droot_ex; dcl_new = pdist;
+      ++evals;
+      {   // the early row: what the scenarios that assume this sample accepted need of it
+        uint32_t v = 0;
+        for (int k = 0; k < 6; ++k) { v = lane == 2 * k ? sp_lo(qp[k]) : v; v = lane == 2 * k + 1 ? sp_hi(qp[k]) : v; }
+        v = lane == 12 ? (uint32_t)mine : v;
+        v = lane == 13 ? sp_lo(best) : v; v = lane == 14 ? sp_hi(best) : v;
+        v = lane == 15 ? (ok ? 1u : 0u) : v;
+        if (lane < 16) wt_u64(my_rec + SFFK_SPEC_EARLY + lane, sp_gran(step, v));
+      }
+      bool flt = false, reject = true;
+      if (ok) {
+        // ---- Environment::Collide(newPoint)
+        cc_l += 1; ex_pose += 1;
+        bool hit = false;
+        if (A.env.n_tri != 0 && !surely_clear(A.env, qp)) {
+          double Rm[9], c3[3];
+          if (qp[3] == 0 && qp[4] == 0 && qp[5] == 0) { Rm[0] = Rm[4] = Rm[8] = 1; Rm[1] = Rm[2] = Rm[3] = Rm[5] = Rm[6] = Rm[7] = 0; }
+          else rotation(qp, Rm);
+          xform(Rm, qp, A.rob.center, c3);
+          hit = pose_exact(A.env, A.rob, rtri, stack, cand, stage, qp, Rm, c3, lane);
+        }
+        beat(2);
+        if (!hit && stale()) aborted = true;
+        if (!hit && !aborted) {
+          // ---- isPathFree(expanded, newPoint)
+          pf_l += 1; ex_seg += 1;
+          const bool free0 = sq_path_free(A.env, A.rob, rtri, stack, cand, queue, stage, cpos, qp, &s_fh, &s_ovf, lane, cc_l, ex_smp, flt);
+          reject = !free0;
+          beat(3);
+          if (!reject && stale()) aborted = true;
+          int n_hit = 0;
+          if (!flt && !reject && !aborted) {
+            nq_l += R;                                               // :262-267 one radiusSearch per tree
+            const double r = pdist > A.dist_tree ? pdist : A.dist_tree;
+            const double ri = (r + A.sweep_abs_eps) * (1.0 + 1e-5);
+            const float rf = sqrtf((float)(ri * ri) * 1.000001f) * 1.000001f;
+            const GridView& g = A.g;
+            const float qx = (float)qp[0], qy = (float)qp[1], qz = (float)qp[2];
+            const int lx = grid_coord(qx - rf, g.ox, g.inv_cell, g.nx), hx = grid_coord(qx + rf, g.ox, g.inv_cell, g.nx);
+            const int ly = grid_coord(qy - rf, g.oy, g.inv_cell, g.ny), hy = grid_coord(qy + rf, g.oy, g.inv_cell, g.ny);
+            const int lz = grid_coord(qz - rf, g.oz, g.inv_cell, g.nz), hz = grid_coord(qz + rf, g.oz, g.inv_cell, g.nz);
+            const int wx = hx - lx + 1, wy = hy - ly + 1, wz = hz - lz + 1;
+            const int total = wx * wy * wz;
+            auto take = [&](bool vld, const GridItem* src) {        // one candidate per lane -> the hit list in LDS
+              bool h = false;
+              double d = 0, p6[6];
+              int id = 0, tr = 0;
+              if (vld) {
+                const unsigned long long* q8 = reinterpret_cast<const unsigned long long*>(src);
+                for (int k = 0; k < 6; ++k) p6[k] = __longlong_as_double((long long)sq_u64(q8 + k));
+                const unsigned long long it = sq_u64(q8 + 6);
+                id = (int)(unsigned)(it & 0xffffffffULL); tr = (int)(unsigned)(it >> 32);
+                d = dist6(p6, qp);
+                h = d < r && id < nn0;                               // (a node the leader commits while this step runs reaches me through my scenario, below)
+              }
+              const unsigned long long hm = __ballot(h);
+              if (h) {
+                const int at = n_hit + __popcll(hm & ((1ULL << lane) - 1ULL));
+                if (at < 64) { h_id[at] = id; h_tree[at] = tr; h_d[at] = d; for (int k = 0; k < 6; ++k) h_pos[6 * at + k] = p6[k]; }
+              }
+              n_hit += __popcll(hm);
+            };
+            for (int c0 = 0; c0 < total; c0 += 64) {
+              const int ci = c0 + lane;
+              int cell = 0, m = 0;
+              if (ci < total) {
+                const int q1 = ci / wx, q2 = q1 / wy;
+                cell = ((lz + q2) * g.ny + (ly + q1 - q2 * wy)) * g.nx + (lx + ci - q1 * wx);
+                m = sq_i32(g.cnt + cell);
+                if (m > g.bk) m = g.bk;
+              }
+              int inc = m;
+              for (int off = 1; off < 64; off <<= 1) {
+                const int o = __shfl_up(inc, off);
+                if (lane >= off) inc += o;
+              }
+              const int tot = __shfl(inc, 63);
+              for (int base = 0; base < tot; base += 64) {
+                const int j = base + lane;
+                const int jj = j < tot ? j : tot - 1;
+                int lo = 0, hi = 63;
+                while (lo < hi) {
+                  const int mid = (lo + hi) >> 1;
+                  if (__shfl(inc, mid) > jj) hi = mid; else lo = mid + 1;
+                }
+                const int src_cell = __shfl(cell, lo);
+                const int slot2 = jj - (__shfl(inc, lo) - __shfl(m, lo));
+                take(j < tot, g.items + (size_t)src_cell * g.bk + slot2);
+              }
+            }
+            int no = sq_i32(g.ovf_cnt);
+            if (no > g.ovf_cap) no = g.ovf_cap;
+            for (int base = 0; base < no; base += 64) take(base + lane < no, g.ovf + base + lane);
+            // ---- the samples my scenario assumes accepted before me: nodes nn0 .. nn0 + na - 1
+            for (int p = 0; p < na && !aborted; ++p) {
+              const unsigned long long* ep = S.rec + ((size_t)set * S.n_slots + pslot[p]) * SFFK_SPEC_REC + SFFK_SPEC_EARLY;
+              __syncthreads();
+              for (int spin = 0;; ++spin) {   // (its worker publishes it as long as the step is the current one)
+                const unsigned long long g2 = sq_u64(ep + (lane & 15));
+                if (__all((uint32_t)(g2 >> 32) == step)) { s_row[lane] = (uint32_t)g2; break; }
+                if ((spin & 15) == 15 && stale()) { aborted = true; break; }
+                __builtin_amdgcn_s_sleep(1);
+              }
+              __syncthreads();
+              if (aborted) break;
+              if (s_row[15] == 0u) { status = SPS_INVALID; break; }      // (that sample left the limits: my scenario cannot happen)
+              double pp[6];
+              for (int k = 0; k < 6; ++k) pp[k] = sp_f64(s_row[2 * k], s_row[2 * k + 1]);
+              const double pb = sp_f64(s_row[13], s_row[14]);
+              const int ptree = (int)s_row[12];
+              __syncthreads();
+              if (lane == 0) { for (int k = 0; k < 6; ++k) p_pos[6 * p + k] = pp[k]; p_best[p] = pb; p_tree[p] = ptree; }
+              const double d = dist6(pp, qp);
+              if (d < r) {
+                if (lane == 0 && n_hit < 64) {
+                  h_id[n_hit] = nn0 + p; h_tree[n_hit] = ptree; h_d[n_hit] = d;
+                  for (int k = 0; k < 6; ++k) h_pos[6 * n_hit + k] = pp[k];
+                }
+                ++n_hit;
+              }
+            }
+            if (n_hit > A.hit_cap || n_hit > 64) flt = true;
+          }
+          beat(4);
+          if (!flt && !reject && !aborted && status == SPS_REJECT) {
+            // ---- the neighbour loop (:270-300) in the reference's order: tree id, then distance, then id
+            __syncthreads();
+            const bool have = lane < n_hit;
+            const int id = have ? h_id[lane] : 0x7fffffff;
+            const int t = have ? h_tree[lane] : 0x7fffffff;
+            const double d = have ? h_d[lane] : 0.0;
+            const bool same = t == mine;
+            const bool qk = have && (same ? (!force && d < pdist - SFFG_TOL) : (d < A.dist_tree - SFFG_TOL));   // :276 / :283
+            int rank = 0;
+            for (int j = 0; j < n_hit; ++j) {
+              const int tj = __shfl(t, j), idj = __shfl(id, j), qj = __shfl((int)qk, j);
+              const double dj = __shfl(d, j);
+              if (qj && (tj < t || (tj == t && (dj < d || (dj == d && idj < id))))) ++rank;
+            }
+            const int n_q = __popcll(__ballot(qk));
+            for (int rk = 0; rk < n_q && !reject && !flt && !aborted; ++rk) {
+              const unsigned long long sel = __ballot(qk && rank == rk);
+              const int src = __ffsll((long long)sel) - 1;
+              const int s_same = __shfl((int)same, src), s_id = __shfl(id, src), s_tree = __shfl(t, src);
+              double np6[6];
+              for (int k = 0; k < 6; ++k) np6[k] = h_pos[6 * src + k];
+              pf_l += 1; ex_seg += 1;
+              if (s_same) {
+                const bool fr = sq_path_free(A.env, A.rob, rtri, stack, cand, queue, stage, np6, qp, &s_fh, &s_ovf, lane, cc_l, ex_smp, flt);
+                if (fr) reject = true;                                 // :276-280 overcrowded
+              } else {
+                const bool fr = sq_path_free(A.env, A.rob, rtri, stack, cand, queue, stage, cpos, np6, &s_fh, &s_ovf, lane, cc_l, ex_smp, flt);
+                if (fr && !flt) {                                      // :288-294 border entry (the leader knows whether the pair has one)
+                  event = 1; ev_id = s_id; ev_tree = s_tree;
+                  const double dr = s_id >= nn0 ? p_best[s_id - nn0] : sq_f64(f.d_root + s_id);
+                  ev_dist = dr + droot_ex + dist6(np6, cpos);
+                }
+                reject = true;                                         // :296-299
+              }
+              if (!reject && stale()) aborted = true;
+            }
+          }
+          beat(5);
+          if (status == SPS_REJECT && !aborted) {
+            if (flt) status = SPS_FAULT;
+            else if (!reject) {
+              status = SPS_ACCEPT;
+              if (OPT) {
+                // ---- SFF* (:307-351): the k nearest of the tree, choose parent, rewire - each edge checked when its turn comes
+                const int k = __popcll(__ballot(lane > 0 && lane <= SFFK_STAR_KMAX + 1 && A.ktab[lane] <= snn));   // (size_t)(2e log10 N), :309
+                if (k > SFFK_STAR_KMAX) flt = true;
+                else {
+                  TopK mt{1.0e300, 0x7fffffff};
+                  double m_droot = 0;
+                  nq_l += 1;                                                                        // :317 knnSearch
+                  sq_knn(A.g, qp, mine, k, sq_i32(A.tree_cnt + 16 * mine), A.cell_edge, A.knn_slack, lane, mt, n_mem);
+                  if (lane < n_mem) m_droot = sq_f64(f.d_root + mt.id);
+                  for (int m = 0; m < n_mem && !flt; ++m) {                                         // :320-327
+                    const double nd = __shfl(mt.d, m) + __shfl(m_droot, m);
+                    if (nd < best - SFFG_TOL) {
+                      const int idm = __shfl(mt.id, m);
+                      double mp[6];
+                      for (int q = 0; q < 6; ++q) mp[q] = sq_f64(A.st.pos + 6 * (size_t)idm + q);
+                      pf_l += 1; ex_seg += 1;
+                      if (sq_path_free(A.env, A.rob, rtri, stack, cand, queue, stage, qp, mp, &s_fh, &s_ovf, lane, cc_l, ex_smp, flt) && !flt) {
+                        best = nd; par_new = idm; dcl_new = __shfl(mt.d, m);
+                      }
+                    }
+                  }
+                  // rewire (:332-350): a member the new node's cost improves, if the edge member -> new is free
+                  __syncthreads();
+                  for (int m = 0; m < n_mem && !flt; ++m) {
+                    const double dm = __shfl(mt.d, m), drm = __shfl(m_droot, m);
+                    const double proposed = best + dm;
+                    if (proposed < drm - SFFG_TOL) {
+                      const int idm = __shfl(mt.id, m);
+                      double mp[6];
+                      for (int q = 0; q < 6; ++q) mp[q] = sq_f64(A.st.pos + 6 * (size_t)idm + q);
+                      pf_l += 1; ex_seg += 1;
+                      bool f2 = false;
+                      if (sq_path_free(A.env, A.rob, rtri, stack, cand, queue, stage, mp, qp, &s_fh, &s_ovf, lane, cc_l, ex_smp, f2)) {
+                        if (lane == 0) {
+                          s_rw[5 * n_rw] = (uint32_t)idm;
+                          s_rw[5 * n_rw + 1] = sp_lo(dm); s_rw[5 * n_rw + 2] = sp_hi(dm);
+                          s_rw[5 * n_rw + 3] = sp_lo(proposed); s_rw[5 * n_rw + 4] = sp_hi(proposed);
+                        }
+                        ++n_rw;
+                      }
+                    }
+                  }
+                }
+                if (flt) status = SPS_FAULT;
+              }
+            }
+          }
+        }
+      }
+    }
+    if (aborted) { beat(9); continue; }          // (the leader has moved on: nobody reads this record)
+    beat(status == SPS_INVALID ? 7 : 8);
+    // ---- the record: SFF*'s rewires first, drained, then row 0
+    if (OPT && status == SPS_ACCEPT && n_rw > 0) {
+      __syncthreads();
+      for (int q = lane; q < 5 * n_rw; q += 64) wt_u64(my_rec + 64 + q, sp_gran(step, s_rw[q]));
+      sq_drain();
+    }
+    {
+      uint32_t v = 0;
+      v = lane == SPG_STATUS ? (uint32_t)status : v;
+      v = lane == SPG_NODE ? (uint32_t)node : v;
+      v = lane == SPG_ITER ? (uint32_t)iter_a : v;
+      v = lane == SPG_CUR ? (uint32_t)(cursor_a & 0xffffffffULL) : v;
+      v = lane == SPG_CUR + 1 ? (uint32_t)(cursor_a >> 32) : v;
+      v = lane == SPG_NN ? (uint32_t)snn : v;
+      v = lane == SPG_CC ? (uint32_t)cc_l : v;
+      v = lane == SPG_PF ? (uint32_t)pf_l : v;
+      v = lane == SPG_NQ ? (uint32_t)nq_l : v;
+      v = lane == SPG_EVENT ? (uint32_t)event : v;
+      v = lane == SPG_EV_ID ? (uint32_t)ev_id : v;
+      v = lane == SPG_EV_TREE ? (uint32_t)ev_tree : v;
+      v = lane == SPG_EV_DIST ? sp_lo(ev_dist) : v;
+      v = lane == SPG_EV_DIST + 1 ? sp_hi(ev_dist) : v;
+      v = lane == SPG_MINE ? (uint32_t)mine : v;
+      for (int k = 0; k < 6; ++k) { v = lane == SPG_QP + 2 * k ? sp_lo(qp[k]) : v; v = lane == SPG_QP + 2 * k + 1 ? sp_hi(qp[k]) : v; }
+      v = lane == SPG_BEST ? sp_lo(best) : v;
+      v = lane == SPG_BEST + 1 ? sp_hi(best) : v;
+      v = lane == SPG_PAR ? (uint32_t)par_new : v;
+      v = lane == SPG_DCL ? sp_lo(dcl_new) : v;
+      v = lane == SPG_DCL + 1 ? sp_hi(dcl_new) : v;
+      v = lane == SPG_NRW ? (uint32_t)n_rw : v;
+      v = lane == SPG_NMEM ? (uint32_t)n_mem : v;
+      wt_u64(my_rec + lane, sp_gran(step, v));
+    }
+  }
+  if (lane == 0) {
+    if (ex_pose) atomicAdd(&c->poses_executed, ex_pose);
+    if (ex_seg) atomicAdd(&c->segments_executed, ex_seg);
+    if (ex_smp) atomicAdd(&c->samples_executed, ex_smp);
+    if (evals) atomicAdd(&c->spec_evaluated, evals);
+  }
+}
+
+void launch_spec_waves(hipStream_t s, const SpecArgs& a) {
+  const size_t lds = collide_lds_bytes(a.q.rob.n_tri, 1);
+  const unsigned grid = 1u + (unsigned)(a.n_sets * a.n_slots);
+  if (a.q.optimize) {
+    if (lds > 32 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_spec_waves<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_spec_waves<true>, dim3(grid), dim3(64), lds, s, a);
+  } else {
+    if (lds > 32 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_spec_waves<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(k_spec_waves<false>, dim3(grid), dim3(64), lds, s, a);
   }
 }
 
