@@ -287,6 +287,7 @@ struct DevEngine {
   uint64_t waves_enqueued = 0, graph_launches = 0, graph_captures = 0;
   PinBuf h_ctrl, h_ring, h_trig;
   DevBuf trig;   // libm parity mode: the C library's cos / sin / acos of every ring word (3 doubles per word)
+  bool dev_trig = false;   // waves of one slot without the parity mode: the same table, filled on the device (k_ring_trig)
   hipEvent_t ev_ring = nullptr, ev_wave = nullptr, ev_wave2 = nullptr;   // (two status slots: one wave may be enqueued ahead)
   int node_cap = 0, border_cap = 0, temp_base = 0;
   uint64_t bt_size = 0, ring_words = 0, max_wave_words = 0;

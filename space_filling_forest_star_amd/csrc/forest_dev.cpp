@@ -443,6 +443,8 @@ void Forest::dev_ring_append(const uint64_t* words, size_t n) {   // words for a
         for (auto& x : th) x.join();
       }
       HIPCHK(hipMemcpyAsync(d.trig.as<double>() + 3 * at, ht, run * 24, hipMemcpyHostToDevice, c.copy_stream));
+    } else if (d.dev_trig) {
+      sffk::launch_ring_trig(c.copy_stream, d.ring.as<uint64_t>() + at, d.trig.as<double>() + 3 * at, (int)run);
     }
     done += run;
   }
@@ -481,6 +483,10 @@ void Forest::dev_upload_state() {
     if (cfg.libm_sampling) {
       d.trig.ensure((size_t)d.ring_words * 24);
       d.h_trig.ensure((size_t)d.ring_words * 24);
+    } else if (cfg.wave == 1 && !(getenv("SFFGPU_NO_DEV_TRIG") && atoi(getenv("SFFGPU_NO_DEV_TRIG")) != 0)) {
+      // waves of one slot: the one wavefront that is waited for looks its sample's cos / sin / acos up (k_ring_trig fills the table)
+      d.trig.ensure((size_t)d.ring_words * 24);
+      d.dev_trig = true;
     }
     d.ctrl.ensure(sizeof(sffk::DevCtrl));
     d.h_ctrl.ensure((size_t)SFFK_STATUS_RING * sizeof(sffk::DevCtrl));   // (>= 2: the copy path's two slots)
@@ -1335,10 +1341,10 @@ bool Forest::spec_setup() {
   if (d.spec_n_sc > 0 && d.spec_tm == TM) return true;
   if (getenv("SFFGPU_SPEC") && atoi(getenv("SFFGPU_SPEC")) == 0) { d.spec_off = true; return false; }
   if (TM > 8) { d.spec_off = true; return false; }
-  int depth = cfg.optimize ? 3 : 2;
+  int depth = 3;
   if (getenv("SFFGPU_SPEC_DEPTH")) depth = atoi(getenv("SFFGPU_SPEC_DEPTH"));
   depth = std::max(1, std::min(depth, SFFK_SPEC_DEPTH));
-  int sets = 2;
+  int sets = 1;
   if (getenv("SFFGPU_SPEC_SETS")) sets = atoi(getenv("SFFGPU_SPEC_SETS"));
   sets = std::max(1, std::min(sets, 4));
   struct Sc { int level; int out[SFFK_SPEC_DEPTH]; int anc[SFFK_SPEC_DEPTH]; int child[9]; };
@@ -1372,7 +1378,7 @@ bool Forest::spec_setup() {
   d.spec_sets = sets;
   d.spec_tm = TM;
   // control blocks (16 granules per set, 4 sets at most) | cur_step (a line of its own) | records
-  d.spec_area.ensure(1024 + (size_t)sets * d.spec_n_sc * TM * (SFFK_SPEC_REC * 8 + 8) + 1024);   // (+ the debugging words, SpecArgs::hb)
+  d.spec_area.ensure(1024 + (size_t)sets * d.spec_n_sc * TM * (SFFK_SPEC_REC * 8 + 8) + 2048);   // (+ the debugging words, SpecArgs::hb)
   return true;
 }
 
@@ -1420,7 +1426,7 @@ void Forest::run_device_seq(int max_waves) {
     a.dist_tree = cfg.dist_tree;
     a.sampling_dist = cfg.sampling_dist;
     a.sweep_abs_eps = c.sweep_eps();
-    a.trig = cfg.libm_sampling ? d.trig.as<double>() : nullptr;
+    a.trig = (cfg.libm_sampling || d.dev_trig) ? d.trig.as<double>() : nullptr;
     a.words_end = d.produced;
     a.grid_ovf_src = c.gridv.ovf_cnt;
     a.dim = cfg.dim;
@@ -1479,6 +1485,15 @@ void Forest::run_device_seq(int max_waves) {
       if (FILE* fp = fopen(trace_path, "ab")) { fwrite(tr.data(), 4, tr.size(), fp); fclose(fp); }
       trace_buf.release();
     }
+    if (spec && getenv("SFFGPU_PROFILE")) {
+      const int nw = d.spec_sets * d.spec_n_sc * d.spec_tm;
+      unsigned long long wp[9];
+      HIPCHK(hipMemcpy(wp, d.spec_area.as<uint8_t>() + 1024 + (size_t)nw * SFFK_SPEC_REC * 8 + ((size_t)nw + 64) * 8, sizeof wp, hipMemcpyDeviceToHost));
+      const double n = (double)std::max<unsigned long long>(1, wp[8]) * 100.0;
+      fprintf(stderr, "[sffgpu k_spec_waves worker us per ACCEPTED attempt, this launch] control block -> scenario + node %.2f | pose %.2f parent edge %.2f "
+              "neighbour query %.2f neighbour loop + SFF* %.2f | node data + words %.2f sample %.2f | record %.2f (%llu attempts)\n",
+              wp[0] / n, wp[1] / n, wp[2] / n, wp[3] / n, wp[4] / n, wp[5] / n, wp[6] / n, wp[7] / n, wp[8]);
+    }
     if (spec && d.last.spec_stalled) {   // (its workgroups were not resident together: the single wavefront from here on)
       d.spec_off = true;
       if (getenv("SFFGPU_PROFILE")) {
@@ -1507,7 +1522,15 @@ void Forest::run_device_seq(int max_waves) {
   }
   st.total_ms += ms_since(t0);
   st.host_ms += ms_since(t0) - wait_ms;
-  if (getenv("SFFGPU_PROFILE")) {
+  if (getenv("SFFGPU_PROFILE") && d.last.spec_steps > 0) {
+    const sffk::DevCtrl& k = d.last;
+    const double sp = (double)k.spec_steps;
+    fprintf(stderr, "[sffgpu k_spec_waves leader us/step] publish %.2f first record of the first wave %.2f of the later waves %.2f other records %.2f accepted node %.2f "
+            "closed list + termination %.2f erases %.2f other %.2f | %llu steps, %.2f iterations/step, %.2f evaluated/committed\n",
+            k.wprof[0] / sp / 100.0, k.wprof[1] / sp / 100.0, k.wprof[7] / sp / 100.0, k.wprof[2] / sp / 100.0, k.wprof[3] / sp / 100.0, k.wprof[4] / sp / 100.0,
+            k.wprof[5] / sp / 100.0, k.wprof[6] / sp / 100.0, (unsigned long long)k.spec_steps, (double)k.spec_committed / sp,
+            (double)k.spec_evaluated / (double)std::max<uint64_t>(1, k.spec_committed));
+  } else if (getenv("SFFGPU_PROFILE")) {
     const sffk::DevCtrl& k = d.last;
     const double it = (double)std::max(1, k.iter);
     fprintf(stderr, "[sffgpu k_seq_waves us/iteration] pick + node %.2f sample %.2f pose %.2f parent edge %.2f neighbour query %.2f "

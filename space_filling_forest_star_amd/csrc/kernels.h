@@ -660,6 +660,8 @@ struct SpecArgs {
   unsigned long long* hb;             // debugging (SFFGPU_PROFILE): per worker (step << 8 | phase), [n_sets x n_slots ..]: the leader's last wait; null = off
 };
 void launch_spec_waves(hipStream_t s, const SpecArgs& a);
+// the transcendental values of n engine words (3 doubles per word: cos, sin of the word as an angle, acos of it as the pitch draw)
+void launch_ring_trig(hipStream_t s, const uint64_t* words, double* trig, int n);
 // multi-GPU: the answer record of one sample as it travels in the all-gather of a round:
 // flags, nnb, pose_hit, 0 | nb[nbcap] | meta[nbcap] | seg_ns[1 + nbcap] | first_hit[1 + nbcap]
 inline int record_words(int nbcap) { return 6 + 4 * nbcap; }

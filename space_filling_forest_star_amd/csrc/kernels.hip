@@ -4084,8 +4084,10 @@ __device__ __attribute__((noinline)) bool sq_path_free(const EnvView& env, const
 
 // the k nearest nodes of one tree around qp, by the wavefront (lane j = j-th nearest, (distance, id) order): shells of grid
 // cells until the k-th distance lies inside the covered ball; a tree with fewer than k nodes is complete once all are in
+// max_id: only nodes with smaller ids (k_spec_waves: a node the leader commits while the step runs is not the worker's
+// business); give_up / step: the search ends when that word is beyond step (the leader has moved on: nobody reads the result)
 __device__ __attribute__((noinline)) void sq_knn(const GridView& g, const double* qp, int tree, int k, int tcnt, double cell_edge, double slack, int lane,
-                       TopK& t, int& have) {
+                       TopK& t, int& have, int max_id = 0x7fffffff, const int32_t* give_up = nullptr, uint32_t step = 0) {
   t.d = 1.0e300; t.id = 0x7fffffff;
   have = 0;
   if (k <= 0) return;
@@ -4098,7 +4100,7 @@ __device__ __attribute__((noinline)) void sq_knn(const GridView& g, const double
       const unsigned long long* q8 = reinterpret_cast<const unsigned long long*>(src);
       const unsigned long long it = sq_u64(q8 + 6);
       id = (int)(unsigned)(it & 0xffffffffULL);
-      if ((int)(unsigned)(it >> 32) == tree) {
+      if ((int)(unsigned)(it >> 32) == tree && id < max_id) {
         double p6[6];
         for (int q = 0; q < 6; ++q) p6[q] = __longlong_as_double((long long)sq_u64(q8 + q));
         d = dist6(p6, qp);
@@ -4117,6 +4119,7 @@ __device__ __attribute__((noinline)) void sq_knn(const GridView& g, const double
   const int rmax = max(max(g.nx, g.ny), g.nz);
   for (int rr = 0; rr <= rmax; ++rr) {
     if (have >= k_store && k_store == tcnt) break;
+    if (give_up && rr >= 4 && (uint32_t)__builtin_amdgcn_readfirstlane(sq_i32(give_up)) > step) break;
     const int w = 2 * rr + 1;
     const int total = w * w * w;
     for (int c0 = 0; c0 < total; c0 += 64) {
@@ -4593,36 +4596,6 @@ __device__ __forceinline__ uint32_t sp_hi(double v) { return (uint32_t)((unsigne
 __device__ __forceinline__ double sp_f64(uint32_t lo, uint32_t hi) {
   return __longlong_as_double((long long)(((unsigned long long)hi << 32) | (unsigned long long)lo));
 }
-// grid_put (kernels_dev.h) by the launch's only writer, with write-through stores of what the workers read
-__device__ __forceinline__ void grid_put_wt(const GridView& g, const GridItem& it) {
-  const size_t cell = grid_cell_of(g, (float)it.p[0], (float)it.p[1], (float)it.p[2]);
-  const int slot = sq_i32(g.cnt + cell);
-  if (g.occ) atomicOr(g.occ + (cell >> 5), 1u << (cell & 31));
-  GridItem32 lt;
-  lt.x = (float)it.p[0]; lt.y = (float)it.p[1]; lt.z = (float)it.p[2];
-  lt.yaw = (float)it.p[3]; lt.pitch = (float)it.p[4]; lt.roll = (float)it.p[5];
-  lt.id = it.id; lt.tree = it.tree;
-  const unsigned long long tail = ((unsigned long long)(uint32_t)it.tree << 32) | (unsigned long long)(uint32_t)it.id;
-  if (slot < g.bk) {
-    unsigned long long* q8 = reinterpret_cast<unsigned long long*>(g.items + cell * g.bk + slot);
-    for (int k = 0; k < 6; ++k) wt_u64(q8 + k, (unsigned long long)__double_as_longlong(it.p[k]));
-    wt_u64(q8 + 6, tail); wt_u64(q8 + 7, 0ULL);
-    if (g.lite) g.lite[cell * g.bk + slot] = lt;
-  } else {
-    const int o = sq_i32(g.ovf_cnt);
-    if (o < g.ovf_cap) {   // the host checks ovf_cnt against ovf_cap
-      unsigned long long* q8 = reinterpret_cast<unsigned long long*>(g.ovf + o);
-      for (int k = 0; k < 6; ++k) wt_u64(q8 + k, (unsigned long long)__double_as_longlong(it.p[k]));
-      wt_u64(q8 + 6, tail); wt_u64(q8 + 7, 0ULL);
-      if (g.ovf_lite) g.ovf_lite[o] = lt;
-    }
-    sq_drain();
-    wt_i32(g.ovf_cnt, o + 1);
-  }
-  sq_drain();
-  wt_i32(g.cnt + cell, slot + 1);
-}
-
 // record row 0 (granule = {value, step}); doubles as two granules (lo, hi)
 #define SPG_STATUS 0
 #define SPG_NODE 1
@@ -4643,7 +4616,10 @@ __device__ __forceinline__ void grid_put_wt(const GridView& g, const GridItem& i
 #define SPG_DCL 30     // + 31
 #define SPG_NRW 32
 #define SPG_NMEM 33
-#define SPG_USED 34
+#define SPG_PICK 34     // position of the node in the frontier array (or the closed list)
+#define SPG_UCL 35      // ... which of the two
+#define SPG_FL 36       // the node's flags (bit 1: in the frontier)
+#define SPG_USED 37
 #define SPS_REJECT 1
 #define SPS_ACCEPT 2
 #define SPS_FAULT 3
@@ -4701,19 +4677,27 @@ __global__ __launch_bounds__(64) void k_spec_waves(SpecArgs S) {
         if (e >= ner) continue;
         int at = 0x7fffffff;
         for (int q = 0; q < SFFK_SPEC_DEPTH; ++q) if (q == e) at = erl[q];
-        for (int j0 = at; j0 < pfn - 1; j0 += 256) {
-          int v[4];
+        // (no wait between the blocks: a block's stores go below everything a later block loads, and the loads of an
+        // earlier block have returned - loads return in order - before a later block's stores can be issued)
+        for (int j0 = at; j0 < pfn - 1; j0 += 1024) {
+          int v[16];
 #pragma unroll
-          for (int u = 0; u < 4; ++u) { const int j = j0 + 64 * u + lane; v[u] = j < pfn - 1 ? sq_i32(frontier + j + 1) : 0; }
+          for (int u = 0; u < 16; ++u) { const int j = j0 + 64 * u + lane; v[u] = sq_i32(frontier + (j < pfn - 1 ? j : pfn - 2) + 1); }
 #pragma unroll
-          for (int u = 0; u < 4; ++u) { const int j = j0 + 64 * u + lane; if (j < pfn - 1) wt_i32(frontier + j, v[u]); }
-          sq_drain();
+          for (int u = 0; u < 16; ++u) { const int j = j0 + 64 * u + lane; if (j < pfn - 1) wt_i32(frontier + j, v[u]); }
         }
+        sq_drain();
         --pfn;
       }
       for (int e = 0; e < SFFK_SPEC_DEPTH; ++e) erl[e] = 0x7fffffff;
       ner = 0; na_l = 0; fn_base = fn; nn_base = n_nodes;
+      sq_drain();
     };
+    // phase clocks (10 ns ticks, SFFGPU_PROFILE): publish, wait for a wave's first record, its other records, the accepted
+    // node, closed list + termination, the erases
+    const bool clk = f.profile != 0;
+    unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tq = clk ? wall_clock64() : 0ULL;
+    auto lap = [&](int k) { if (!clk) return; const unsigned long long t = wall_clock64(); ph[k] += t - tq; tq = t; };
     while (!terminated && !fault && !stop && waves_done < A.max_waves) {
       ++step; ++n_steps;
       const int set = (int)(step % (uint32_t)S.n_sets);
@@ -4729,60 +4713,80 @@ __global__ __launch_bounds__(64) void k_spec_waves(SpecArgs S) {
         if (lane < 16) wt_u64(S.base + 16 * set + lane, sp_gran(step, v));
         if (lane == 0) wt_i32(S.cur_step, (int)step);
       }
+      lap(0);
+      if (sq_i32(A.grid_ovf_src) > A.grid_ovf_limit) { stop = true; }   // (once per step: the list has room for a step's nodes)
       int sc = 0;
-      for (;;) {   // ---- the waves of this step, in the reference's order
+      for (; !stop;) {   // ---- the waves of this step, in the reference's order
         // what the round engine checks before a round (round_begin_scalars), and what this launch has to leave to the host
         if (n_nodes + 1 > f.node_cap - 8 || nb + TM > f.border_cap) { fault = SFFK_FAULT_CAPACITY; break; }
         if ((unsigned long long)(nb + TM) * 2ULL > f.bt_mask + 1ULL) { fault = SFFK_FAULT_BORDER_TABLE; break; }
         if (cursor + 8ULL + (unsigned long long)(TM * WP) > A.words_end) { stop = true; break; }
-        if (sq_i32(A.grid_ovf_src) > A.grid_ovf_limit) { stop = true; break; }
-        // node selection (src/forest.h:136-151) - tentative until the scenario's records are known to be about this wave
+        // node selection (src/forest.h:136-151) - tentative until the scenario's records are known to be about this wave.
+        // The leader computes the POSITION; the node behind it (and its flags) come with the records, whose worker read
+        // the frontier while it could not change.
         const int use_closed = cn > 0 && empty_frontier;
         const int pool = use_closed ? cn : fn;
         if (pool < 1) { terminated = 1; break; }
         unsigned long long cur2 = cursor, rdw = 0;
         int pick;
         do { pick = sq_lemire(f.ring[cur2 & f.ring_mask], (unsigned long long)pool); ++cur2; if (pick < 0) ++rdw; } while (pick < 0);
-        int node;
-        if (use_closed) node = sq_i32(f.closed + pick);
-        else if (pick >= fn_base - ner) node = nn_base + (pick - (fn_base - ner));   // (a node of this step)
-        else {
-          int idx = pick;
-          for (int e = 0; e < SFFK_SPEC_DEPTH; ++e) if (e < ner && erl[e] <= idx) ++idx;
-          node = sq_i32(frontier + idx);
-        }
+        const bool own = !use_closed && pick >= fn_base - ner;          // (a node of this step: no scenario models that)
+        int idx = pick;
+        if (!use_closed && !own) for (int e = 0; e < SFFK_SPEC_DEPTH; ++e) if (e < ner && erl[e] <= idx) ++idx;
         const unsigned long long* rec0 = S.rec + ((size_t)set * S.n_slots + (size_t)sc * TM) * SFFK_SPEC_REC;
-        auto fetch = [&](int rd) -> bool {       // row 0 of attempt rd's record -> s_row
-          const unsigned long long* rp = rec0 + (size_t)rd * SFFK_SPEC_REC;
-          const unsigned long long t0 = wall_clock64();
-          __syncthreads();
-          for (int spin = 0;; ++spin) {
-            const unsigned long long g = sq_u64(rp + lane);
-            if (__all(lane >= SPG_USED || (uint32_t)(g >> 32) == step)) { s_row[lane] = (uint32_t)g; break; }
-            if ((spin & 63) == 63 && wall_clock64() - t0 > S.timeout_ticks) {
-              if (S.hb) {
-                unsigned long long* o = S.hb + (size_t)S.n_sets * S.n_slots;
-                if (lane == 0) { o[0] = step; o[1] = (unsigned long long)sc; o[2] = (unsigned long long)rd; o[3] = (unsigned long long)set; }
-                if (lane < SPG_USED) o[8 + lane] = g;
+        // row 0 of the scenario's records, one granule per lane and attempt; all asked for together
+        unsigned long long gr[8];
+        auto ready = [&](unsigned long long g) -> bool { return __all(lane >= SPG_USED || (uint32_t)(g >> 32) == step); };
+        auto ask_all = [&](int from) {
+#pragma unroll
+          for (int q = 0; q < 8; ++q) if (q >= from && q < TM) gr[q] = sq_u64(rec0 + (size_t)q * SFFK_SPEC_REC + lane);
+        };
+        auto fetch = [&](int rd) -> bool {       // attempt rd's row 0 -> s_row (waits for it)
+          unsigned long long g = 0;
+#pragma unroll
+          for (int q = 0; q < 8; ++q) if (q == rd) g = gr[q];
+          if (!ready(g)) {
+            const unsigned long long* rp = rec0 + (size_t)rd * SFFK_SPEC_REC;
+            const unsigned long long t0 = wall_clock64();
+            for (int spin = 0;; ++spin) {
+              g = sq_u64(rp + lane);
+              if (ready(g)) break;
+              if ((spin & 63) == 63 && wall_clock64() - t0 > S.timeout_ticks) {
+                if (S.hb) {
+                  unsigned long long* o = S.hb + (size_t)S.n_sets * S.n_slots;
+                  if (lane == 0) { o[0] = step; o[1] = (unsigned long long)sc; o[2] = (unsigned long long)rd; o[3] = (unsigned long long)set; }
+                  if (lane < SPG_USED) o[8 + lane] = g;
+                }
+                return false;
               }
-              return false;
+              __builtin_amdgcn_s_sleep(1);
             }
-            __builtin_amdgcn_s_sleep(1);
+            ask_all(rd + 1);                     // (the others of the wave were written about when this one was)
           }
+          __syncthreads();
+          s_row[lane] = (uint32_t)g;
           __syncthreads();
           return true;
         };
         bool have0 = false;
+        int node = -1, fl_node = 2;
+        lap(6);
         if (iter < f.max_iterations) {
+          ask_all(0);
           if (!fetch(0)) { stalled = 1; stop = true; break; }
+          lap(sc == 0 ? 1 : 7);
           have0 = true;
           const unsigned long long rc = ((unsigned long long)s_row[SPG_CUR + 1] << 32) | (unsigned long long)s_row[SPG_CUR];
-          const bool same = s_row[SPG_STATUS] != SPS_INVALID && (int)s_row[SPG_NODE] == node && (int)s_row[SPG_ITER] == iter &&
-                            rc == cur2 && (int)s_row[SPG_NN] == n_nodes;
+          const bool same = !own && s_row[SPG_STATUS] != SPS_INVALID && (int)s_row[SPG_PICK] == idx && (int)s_row[SPG_UCL] == use_closed &&
+                            (int)s_row[SPG_ITER] == iter && rc == cur2 && (int)s_row[SPG_NN] == n_nodes;
           if (!same) {                           // the scenario is not what happened: the step ends in front of this wave
             if (sc == 0) fault = SFFK_FAULT_INTERNAL;
             break;
           }
+          node = (int)s_row[SPG_NODE]; fl_node = (int)s_row[SPG_FL];
+        } else {                                 // (no attempt left: the wave only closes its node)
+          node = use_closed ? sq_i32(f.closed + pick) : (own ? nn_base + (pick - (fn_base - ner)) : sq_i32(frontier + idx));
+          fl_node = sq_u8(f.nflag + node);
         }
         cursor = cur2; redraws += rdw; ++waves;
         w_node = node; w_pos = pick; w_closed = use_closed;
@@ -4793,6 +4797,7 @@ __global__ __launch_bounds__(64) void k_spec_waves(SpecArgs S) {
             stalled = 1; fault = SFFK_FAULT_LISTS; w_round = rd; in_wave = 1;   // (the host finishes the wave)
             break;
           }
+          lap(2);
           const int status = (int)s_row[SPG_STATUS];
           if ((int)s_row[SPG_NODE] != node || (int)s_row[SPG_ITER] != iter || (int)s_row[SPG_NN] != n_nodes ||
               (((unsigned long long)s_row[SPG_CUR + 1] << 32) | (unsigned long long)s_row[SPG_CUR]) != cursor) { fault = SFFK_FAULT_INTERNAL; break; }
@@ -4829,45 +4834,66 @@ __global__ __launch_bounds__(64) void k_spec_waves(SpecArgs S) {
               ++nb;
             }
           }
-          if (status != SPS_ACCEPT) continue;
-          // ---- the new node (:329, :353-367)
+          if (status != SPS_ACCEPT) { lap(6); continue; }
+          // ---- the new node (:329, :353-367): a lane per word (one store instruction per width instead of thirty stores of lane 0)
           const int idn = n_nodes;
-          double qp[6];
-          for (int k = 0; k < 6; ++k) qp[k] = sp_f64(s_row[SPG_QP + 2 * k], s_row[SPG_QP + 2 * k + 1]);
           const int par_new = (int)s_row[SPG_PAR];
-          const double dcl_new = sp_f64(s_row[SPG_DCL], s_row[SPG_DCL + 1]), best = sp_f64(s_row[SPG_BEST], s_row[SPG_BEST + 1]);
           const int n_rw = OPT ? (int)s_row[SPG_NRW] : 0;
           if (OPT) { ++st_rounds; st_members += (unsigned long long)s_row[SPG_NMEM]; }
           if (OPT && n_rw > 0) {                 // the rewires behind row 0 (written and drained before it)
             const unsigned long long* rp = rec0 + (size_t)rd * SFFK_SPEC_REC + 64;
             for (int q = lane; q < 5 * n_rw; q += 64) s_rw[q] = (uint32_t)sq_u64(rp + q);
           }
-          __syncthreads();
-          if (lane == 0) {
-            const size_t o = (size_t)idn;
-            A.st.x[o] = (float)qp[0]; A.st.y[o] = (float)qp[1]; A.st.z[o] = (float)qp[2];
-            A.st.yaw[o] = (float)qp[3]; A.st.pitch[o] = (float)qp[4]; A.st.roll[o] = (float)qp[5];
-            for (int k = 0; k < 6; ++k) wt_f64(A.st.pos + 6 * o + k, qp[k]);
-            wt_i32(A.st.tree + o, mine);
-            wt_i32(f.parent + o, par_new);
-            wt_f64(f.d_closest + o, dcl_new);
-            wt_f64(f.d_root + o, best);
-            f.iter[o] = (uint32_t)iter;
-            wt_u8(f.nflag + o, 2);
-            wt_i32(frontier + fn_base + na_l, idn);
-            if (OPT) {
-              atomicAdd(A.tree_cnt + 16 * mine, 1);
+          sq_drain();                            // (an earlier node of the step may have written the cell's count)
+          const GridView& g = A.g;
+          const float q0 = (float)sp_f64(s_row[SPG_QP], s_row[SPG_QP + 1]), q1 = (float)sp_f64(s_row[SPG_QP + 2], s_row[SPG_QP + 3]),
+                      q2 = (float)sp_f64(s_row[SPG_QP + 4], s_row[SPG_QP + 5]);
+          const size_t cell = grid_cell_of(g, q0, q1, q2);
+          const int gslot = sq_i32(g.cnt + cell);
+          int govf = -1;
+          if (gslot >= g.bk) govf = sq_i32(g.ovf_cnt);
+          if (g.occ && lane == 0) atomicOr(g.occ + (cell >> 5), 1u << (cell & 31));
+          const bool put = gslot < g.bk || govf < g.ovf_cap;          // (the host checks ovf_cnt against ovf_cap)
+          GridItem* gi = gslot < g.bk ? g.items + cell * g.bk + gslot : g.ovf + (govf < 0 ? 0 : govf);
+          GridItem32* gl = gslot < g.bk ? (g.lite ? g.lite + cell * g.bk + gslot : nullptr) : (g.ovf_lite ? g.ovf_lite + (govf < 0 ? 0 : govf) : nullptr);
+          const size_t o = (size_t)idn;
+          {   // 64-bit words: position (6), distance to the parent, cost, the grid item (8)
+            unsigned long long* p64 = nullptr;
+            unsigned long long v64 = 0;
+            const int qk = lane < 6 ? lane : (lane >= 8 && lane < 14 ? lane - 8 : 0);
+            const unsigned long long qbits = ((unsigned long long)s_row[SPG_QP + 2 * qk + 1] << 32) | (unsigned long long)s_row[SPG_QP + 2 * qk];
+            if (lane < 6) { p64 = reinterpret_cast<unsigned long long*>(A.st.pos + 6 * o + lane); v64 = qbits; }
+            else if (lane == 6) { p64 = reinterpret_cast<unsigned long long*>(f.d_closest + o); v64 = ((unsigned long long)s_row[SPG_DCL + 1] << 32) | s_row[SPG_DCL]; }
+            else if (lane == 7) { p64 = reinterpret_cast<unsigned long long*>(f.d_root + o); v64 = ((unsigned long long)s_row[SPG_BEST + 1] << 32) | s_row[SPG_BEST]; }
+            else if (lane < 16 && put) {
+              p64 = reinterpret_cast<unsigned long long*>(gi) + (lane - 8);
+              v64 = lane < 14 ? qbits : (lane == 14 ? (((unsigned long long)(uint32_t)mine << 32) | (unsigned long long)(uint32_t)idn) : 0ULL);
+            }
+            if (p64) wt_u64(p64, v64);
+          }
+          {   // 32-bit words: tree, parent, frontier entry (write-through); the fp32 columns, the filter record, the iteration (plain)
+            const int fk = lane >= 19 && lane < 25 ? lane - 19 : (lane >= 25 && lane < 31 ? lane - 25 : 0);
+            const float qf = (float)sp_f64(s_row[SPG_QP + 2 * fk], s_row[SPG_QP + 2 * fk + 1]);
+            if (lane == 16) wt_i32(A.st.tree + o, mine);
+            else if (lane == 17) wt_i32(f.parent + o, par_new);
+            else if (lane == 18) wt_i32(frontier + fn_base + na_l, idn);
+            else if (lane >= 19 && lane < 25) {
+              float* col = fk == 0 ? A.st.x : (fk == 1 ? A.st.y : (fk == 2 ? A.st.z : (fk == 3 ? A.st.yaw : (fk == 4 ? A.st.pitch : A.st.roll))));
+              col[o] = qf;
+            } else if (lane >= 25 && lane < 31) { if (gl && put) reinterpret_cast<float*>(gl)[fk] = qf; }
+            else if (lane == 31) { if (gl && put) gl->id = idn; }
+            else if (lane == 32) { if (gl && put) gl->tree = mine; }
+            else if (lane == 33) f.iter[o] = (uint32_t)iter;
+            else if (lane == 34) wt_u8(f.nflag + o, 2);
+          }
+          if (OPT) {
+            __syncthreads();
+            if (lane == 0) {
               if (A.hist) {
                 const int at = atomicAdd(A.hist_ctl, 1);
                 if (at < A.hist_cap) { A.hist[3 * (size_t)at] = idn; A.hist[3 * (size_t)at + 1] = par_new; A.hist[3 * (size_t)at + 2] = iter; }
                 else A.hist_ctl[1] = 1;
               }
-            }
-            GridItem it;
-            for (int k = 0; k < 6; ++k) it.p[k] = qp[k];
-            it.id = idn; it.tree = mine; it.pad[0] = it.pad[1] = 0;
-            grid_put_wt(A.g, it);
-            if (OPT) {
               // rewire (:332-350), as the worker found them in the reference's order
               for (int j = 0; j < n_rw; ++j) {
                 const int idm = (int)s_rw[5 * j];
@@ -4882,32 +4908,36 @@ __global__ __launch_bounds__(64) void k_spec_waves(SpecArgs S) {
               }
             }
           }
-          sq_drain();
+          sq_drain();                            // (the item is written: now the counts that make it visible)
+          if (lane == 0) {
+            if (govf >= 0) wt_i32(g.ovf_cnt, govf + 1);
+            wt_i32(g.cnt + cell, gslot + 1);
+            if (OPT) atomicAdd(A.tree_cnt + 16 * mine, 1);
+          }
           st_rewires += (unsigned long long)n_rw;
           ++n_nodes; ++fn; ++na_l;
           failing = false;
           outcome = rd;
+          lap(3);
         }
         if (fault) break;
         // ---- the slot is exhausted: its node leaves the frontier for the closed list (:160-178; the erase keeps the order)
         bool desync = false;
         if (failing && !use_closed) {
-          const int fl = sq_u8(f.nflag + node);
+          const int fl = fl_node;
           if (fl & 2) {
             if (lane == 0) { wt_u8(f.nflag + node, (uint8_t)((fl & ~2) | 1)); wt_i32(f.closed + cn, node); }
             ++cn;
-            int idx = pick;
-            if (pick >= fn_base - ner) { flush_erases(); desync = true; }   // (a node of this step: the array first becomes what the list says)
-            else for (int e = 0; e < SFFK_SPEC_DEPTH; ++e) if (e < ner && erl[e] <= idx) ++idx;
-            for (int e = SFFK_SPEC_DEPTH - 1; e > 0; --e) if (erl[e - 1] > idx) erl[e] = erl[e - 1];
+            int at_idx = idx;
+            if (own) { flush_erases(); desync = true; at_idx = pick; }   // (a node of this step: the array first becomes what the list says)
+            for (int e = SFFK_SPEC_DEPTH - 1; e > 0; --e) if (erl[e - 1] > at_idx) erl[e] = erl[e - 1];
             int at = 0;
-            for (int e = 0; e < SFFK_SPEC_DEPTH; ++e) if (e < ner && erl[e] < idx) at = e + 1;
-            for (int e = 0; e < SFFK_SPEC_DEPTH; ++e) if (e == at) erl[e] = idx;
+            for (int e = 0; e < SFFK_SPEC_DEPTH; ++e) if (e < ner && erl[e] < at_idx) at = e + 1;
+            for (int e = 0; e < SFFK_SPEC_DEPTH; ++e) if (e == at) erl[e] = at_idx;
             ++ner;
             --fn;
           } else desync = true;                  // (the scenarios below assumed the erase)
         }
-        sq_drain();
         // ---- termination (:184-201)
         empty_frontier = fn == 0 ? 1 : 0;
         if (!solved && empty_frontier) {
@@ -4931,11 +4961,13 @@ __global__ __launch_bounds__(64) void k_spec_waves(SpecArgs S) {
           t[0] = node; t[1] = pick; t[2] = iter; t[3] = (int32_t)(cursor & 0x7fffffffULL); t[4] = failing ? TM : 0; t[5] = n_nodes; t[6] = fn; t[7] = cn;
         }
         ++waves_done;
+        lap(4);
         if (terminated || fault || desync || waves_done >= A.max_waves) break;
         sc = S.sc_tab[sc * SFFK_SPEC_TAB + 1 + 2 * SFFK_SPEC_DEPTH + outcome];
         if (sc < 0) break;
       }
       flush_erases();                            // (before anybody is told about the next step)
+      lap(5);
     }
     // ---- the launch is over: every set's next control block says so
     for (int s2 = 0; s2 < S.n_sets; ++s2)
@@ -4949,6 +4981,7 @@ __global__ __launch_bounds__(64) void k_spec_waves(SpecArgs S) {
       c->redraws += (int)redraws;
       c->star_rounds += st_rounds; c->star_passes += st_rounds; c->star_members += st_members; c->star_rewires += st_rewires;
       c->spec_steps += n_steps; c->spec_committed += n_commit; c->spec_stalled = stalled;
+      for (int k = 0; k < 8; ++k) c->wprof[k] += ph[k];
       c->n_act = 0; c->app_n = 0; c->compact_from = 0;
       c->grid_ovf = sq_i32(A.grid_ovf_src); c->tgrid_ovf = 0;
       c->fault = fault;
@@ -5006,8 +5039,13 @@ __global__ __launch_bounds__(64) void k_spec_waves(SpecArgs S) {
     __syncthreads();
     // (the leader is past my step; its store of cur_step may become visible after the control block's: never "!=")
     auto stale = [&]() -> bool { return (uint32_t)__builtin_amdgcn_readfirstlane(sq_i32(S.cur_step)) > step; };
-    auto beat = [&](int phase) { if (S.hb && lane == 0) wt_u64(S.hb + wid, ((unsigned long long)step << 8) | (unsigned long long)phase); };
-    beat(1);
+    unsigned long long wt0 = S.hb ? wall_clock64() : 0ULL, wlast = wt0, wph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    auto beat = [&](int phase) {
+      if (!S.hb) return;
+      const unsigned long long t = wall_clock64();
+      if (phase >= 1 && phase <= 8) wph[phase - 1] = t - wlast;
+      wlast = t;
+    };
     // ---- my scenario: the waves before mine, with the outcomes it assumes
     unsigned long long cur = cur0;
     int sfn = fn0, scn = cn0, snn = nn0, sit = it0;
@@ -5045,24 +5083,27 @@ __global__ __launch_bounds__(64) void k_spec_waves(SpecArgs S) {
       if (sit >= f.max_iterations) valid = false;
       if ((sfn == 0) != (ef0 != 0)) valid = false;   // frontier <-> closed-list mode switches end the step
     }
-    int node = -1;
+    int node = -1, pick_idx = -1, my_ucl = 0, fl_node = 0;
     if (valid) {
       const int ucl = scn > 0 && ef0;
       const int pool = ucl ? scn : sfn;
+      my_ucl = ucl;
       if (pool < 1) valid = false;
       else {
         int pk;
         do { pk = sq_lemire(f.ring[cur & f.ring_mask], (unsigned long long)pool); ++cur; } while (pk < 0);
-        if (ucl) { if (pk >= cn0) valid = false; else node = sq_i32(f.closed + pk); }
+        if (ucl) { if (pk >= cn0) valid = false; else { pick_idx = pk; node = sq_i32(f.closed + pk); } }
         else if (pk >= fn0 - ne) valid = false;
         else {
           int idx = pk;
           for (int e = 0; e < SFFK_SPEC_DEPTH; ++e) if (e < ne && er[e] <= idx) ++idx;
+          pick_idx = idx;
           node = sq_i32(frontier + idx);
         }
       }
     }
     if (OPT && na > 0) valid = false;            // (SFF*: an accepted node's rewires change what a later attempt reads)
+    beat(1);
     const unsigned long long cursor_a = cur + (unsigned long long)(att * WP);
     const int iter_a = sit + att;
     int status = SPS_REJECT;
@@ -5078,7 +5119,8 @@ __global__ __launch_bounds__(64) void k_spec_waves(SpecArgs S) {
       for (int k = 0; k < 6; ++k) cpos[k] = sq_f64(A.st.pos + 6 * (size_t)node + k);
       mine = sq_i32(A.st.tree + node);
       const double droot_ex = sq_f64(f.d_root + node);
-      const bool force = (sq_u8(f.nflag + node) & 1) != 0;
+      fl_node = sq_u8(f.nflag + node);
+      const bool force = (fl_node & 1) != 0;
       uint64_t w[6];
       for (int k = 0; k < 6; ++k) w[k] = k < WP ? f.ring[(cursor_a + k) & f.ring_mask] : 0ULL;
       SampleTrig ht{};
@@ -5097,10 +5139,12 @@ __global__ __launch_bounds__(64) void k_spec_waves(SpecArgs S) {
         ht.s_theta = __shfl(sv, 1); ht.c_theta = __shfl(cv, 1);
         ht.acos_u = WP == 6 ? sffp::pacos(sample_acos_arg(w[3])) : 0.0;
       }
+      beat(6);
       const bool ok = sample_point_with(w, cpos, A.sampling_dist, A.dim, A.limits, qp, ht);
       pdist = dist6(cpos, qp);                                     // parentDistance, :250
       best = pdist + droot_ex; dcl_new = pdist;
       ++evals;
+      beat(7);
       {   // the early row: what the scenarios that assume this sample accepted need of it
         uint32_t v = 0;
         for (int k = 0; k < 6; ++k) { v = lane == 2 * k ? sp_lo(qp[k]) : v; v = lane == 2 * k + 1 ? sp_hi(qp[k]) : v; }
@@ -5275,9 +5319,10 @@ __global__ __launch_bounds__(64) void k_spec_waves(SpecArgs S) {
                   TopK mt{1.0e300, 0x7fffffff};
                   double m_droot = 0;
                   nq_l += 1;                                                                        // :317 knnSearch
-                  sq_knn(A.g, qp, mine, k, sq_i32(A.tree_cnt + 16 * mine), A.cell_edge, A.knn_slack, lane, mt, n_mem);
+                  sq_knn(A.g, qp, mine, k, sq_i32(A.tree_cnt + 16 * mine), A.cell_edge, A.knn_slack, lane, mt, n_mem, snn, S.cur_step, step);
+                  if (stale()) aborted = true;
                   if (lane < n_mem) m_droot = sq_f64(f.d_root + mt.id);
-                  for (int m = 0; m < n_mem && !flt; ++m) {                                         // :320-327
+                  for (int m = 0; m < n_mem && !flt && !aborted; ++m) {                             // :320-327
                     const double nd = __shfl(mt.d, m) + __shfl(m_droot, m);
                     if (nd < best - SFFG_TOL) {
                       const int idm = __shfl(mt.id, m);
@@ -5291,7 +5336,8 @@ __global__ __launch_bounds__(64) void k_spec_waves(SpecArgs S) {
                   }
                   // rewire (:332-350): a member the new node's cost improves, if the edge member -> new is free
                   __syncthreads();
-                  for (int m = 0; m < n_mem && !flt; ++m) {
+                  if (stale()) aborted = true;
+                  for (int m = 0; m < n_mem && !flt && !aborted; ++m) {
                     const double dm = __shfl(mt.d, m), drm = __shfl(m_droot, m);
                     const double proposed = best + dm;
                     if (proposed < drm - SFFG_TOL) {
@@ -5318,8 +5364,13 @@ __global__ __launch_bounds__(64) void k_spec_waves(SpecArgs S) {
         }
       }
     }
-    if (aborted) { beat(9); continue; }          // (the leader has moved on: nobody reads this record)
-    beat(status == SPS_INVALID ? 7 : 8);
+    if (aborted) continue;                       // (the leader has moved on: nobody reads this record)
+    beat(8);
+    if (S.hb && status == SPS_ACCEPT && lane == 0) {   // where an ACCEPTED attempt's time went (debugging)
+      unsigned long long* o = S.hb + (size_t)S.n_sets * S.n_slots + 64;
+      for (int k = 0; k < 8; ++k) atomicAdd(o + k, wph[k]);
+      atomicAdd(o + 8, 1ULL);
+    }
     // ---- the record: SFF*'s rewires first, drained, then row 0
     if (OPT && status == SPS_ACCEPT && n_rw > 0) {
       __syncthreads();
@@ -5351,6 +5402,9 @@ __global__ __launch_bounds__(64) void k_spec_waves(SpecArgs S) {
       v = lane == SPG_DCL + 1 ? sp_hi(dcl_new) : v;
       v = lane == SPG_NRW ? (uint32_t)n_rw : v;
       v = lane == SPG_NMEM ? (uint32_t)n_mem : v;
+      v = lane == SPG_PICK ? (uint32_t)pick_idx : v;
+      v = lane == SPG_UCL ? (uint32_t)my_ucl : v;
+      v = lane == SPG_FL ? (uint32_t)fl_node : v;
       wt_u64(my_rec + lane, sp_gran(step, v));
     }
   }
@@ -5360,6 +5414,22 @@ __global__ __launch_bounds__(64) void k_spec_waves(SpecArgs S) {
     if (ex_smp) atomicAdd(&c->samples_executed, ex_smp);
     if (evals) atomicAdd(&c->spec_evaluated, evals);
   }
+}
+
+// cos / sin of every engine word as an angle, acos of it as the pitch draw (src/randGen.h:78-100) with the portable routines the
+// sampling code itself calls - the same bits - computed once per word by the whole chip instead of by the one wavefront
+// that is waited for (the table the libm parity mode fills on the host, DevRound::trig)
+__global__ __launch_bounds__(256) void k_ring_trig(const uint64_t* __restrict__ words, double* __restrict__ trig, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t w = words[i];
+  const double ang = sample_angle(w);
+  trig[3 * (size_t)i] = sffp::pcos(ang);
+  trig[3 * (size_t)i + 1] = sffp::psin(ang);
+  trig[3 * (size_t)i + 2] = sffp::pacos(sample_acos_arg(w));
+}
+void launch_ring_trig(hipStream_t s, const uint64_t* words, double* trig, int n) {
+  if (n > 0) hipLaunchKernelGGL(k_ring_trig, dim3((n + 255) / 256), dim3(256), 0, s, words, trig, n);
 }
 
 void launch_spec_waves(hipStream_t s, const SpecArgs& a) {
