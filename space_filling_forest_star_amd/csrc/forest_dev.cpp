@@ -1487,12 +1487,15 @@ void Forest::run_device_seq(int max_waves) {
     }
     if (spec && getenv("SFFGPU_PROFILE")) {
       const int nw = d.spec_sets * d.spec_n_sc * d.spec_tm;
-      unsigned long long wp[9];
-      HIPCHK(hipMemcpy(wp, d.spec_area.as<uint8_t>() + 1024 + (size_t)nw * SFFK_SPEC_REC * 8 + ((size_t)nw + 64) * 8, sizeof wp, hipMemcpyDeviceToHost));
-      const double n = (double)std::max<unsigned long long>(1, wp[8]) * 100.0;
-      fprintf(stderr, "[sffgpu k_spec_waves worker us per ACCEPTED attempt, this launch] control block -> scenario + node %.2f | pose %.2f parent edge %.2f "
-              "neighbour query %.2f neighbour loop + SFF* %.2f | node data + words %.2f sample %.2f | record %.2f (%llu attempts)\n",
-              wp[0] / n, wp[1] / n, wp[2] / n, wp[3] / n, wp[4] / n, wp[5] / n, wp[6] / n, wp[7] / n, wp[8]);
+      unsigned long long wq[22];
+      HIPCHK(hipMemcpy(wq, d.spec_area.as<uint8_t>() + 1024 + (size_t)nw * SFFK_SPEC_REC * 8 + ((size_t)nw + 64) * 8, sizeof wq, hipMemcpyDeviceToHost));
+      const unsigned long long* wp = wq + 1;
+      const double n = (double)std::max<unsigned long long>(1, wq[0]) * 100.0;
+      fprintf(stderr, "[sffgpu k_spec_waves worker us per ACCEPTED attempt, this launch] control block -> scenario + node %.2f | node data + words %.2f sample %.2f "
+              "pose %.2f parent edge %.2f neighbour query %.2f neighbour loop %.2f | SFF*: k %.2f k nearest %.2f choose parent %.2f rewire + record %.2f (%llu attempts)\n",
+              wp[0] / n, wp[5] / n, wp[6] / n, wp[1] / n, wp[2] / n, wp[3] / n, wp[4] / n, wp[8] / n, wp[9] / n, wp[10] / n, wp[7] / n, wq[0]);
+      if (wq[20]) fprintf(stderr, "   k nearest searches: %llu, per search: shells %.2f count groups %.2f item batches %.2f insertions %.2f overflow-list entries %.1f\n", wq[20],
+                          (double)wq[16] / wq[20], (double)wq[17] / wq[20], (double)wq[18] / wq[20], (double)wq[19] / wq[20], (double)wq[21] / wq[20]);
     }
     if (spec && d.last.spec_stalled) {   // (its workgroups were not resident together: the single wavefront from here on)
       d.spec_off = true;

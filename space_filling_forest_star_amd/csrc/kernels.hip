@@ -4087,78 +4087,197 @@ __device__ __attribute__((noinline)) bool sq_path_free(const EnvView& env, const
 // max_id: only nodes with smaller ids (k_spec_waves: a node the leader commits while the step runs is not the worker's
 // business); give_up / step: the search ends when that word is beyond step (the leader has moved on: nobody reads the result)
 __device__ __attribute__((noinline)) void sq_knn(const GridView& g, const double* qp, int tree, int k, int tcnt, double cell_edge, double slack, int lane,
-                       TopK& t, int& have, int max_id = 0x7fffffff, const int32_t* give_up = nullptr, uint32_t step = 0) {
+                       TopK& t, int& have, int max_id = 0x7fffffff, const int32_t* give_up = nullptr, uint32_t step = 0,
+                       unsigned long long* dbg = nullptr) {
   t.d = 1.0e300; t.id = 0x7fffffff;
   have = 0;
+  unsigned long long d_sh = 0, d_ob = 0, d_cg = 0, d_in = 0;
   if (k <= 0) return;
   const int k_store = k < tcnt ? k : tcnt;
   auto offer = [&](bool valid, const GridItem* src) {
     bool cand = false;
     double d = 1.0e300;
     int id = 0x7fffffff;
-    if (valid) {
+    if (valid) {   // (all seven words asked for together: one round trip per batch, whatever the tree)
       const unsigned long long* q8 = reinterpret_cast<const unsigned long long*>(src);
+      unsigned long long pw[6];
+      for (int q = 0; q < 6; ++q) pw[q] = sq_u64(q8 + q);
       const unsigned long long it = sq_u64(q8 + 6);
       id = (int)(unsigned)(it & 0xffffffffULL);
       if ((int)(unsigned)(it >> 32) == tree && id < max_id) {
         double p6[6];
-        for (int q = 0; q < 6; ++q) p6[q] = __longlong_as_double((long long)sq_u64(q8 + q));
+        for (int q = 0; q < 6; ++q) p6[q] = __longlong_as_double((long long)pw[q]);
         d = dist6(p6, qp);
         cand = true;
       }
     }
     const double worst = topk_worst(t, k, have);
     cand = cand && (have < k || key_less(d, id, worst, 0x7fffffff));
-    topk_insert(t, lane, k, have, __ballot(cand), d, id);
+    ++d_ob; d_in += (unsigned long long)__popcll(__ballot(cand));
+    topk_merge(t, lane, k, have, cand, d, id);
   };
   int no = sq_i32(g.ovf_cnt);
   if (no > g.ovf_cap) no = g.ovf_cap;
-  for (int base = 0; base < no; base += 64) offer(base + lane < no, g.ovf + base + lane);
   const int cx = grid_coord((float)qp[0], g.ox, g.inv_cell, g.nx), cy = grid_coord((float)qp[1], g.oy, g.inv_cell, g.ny),
             cz = grid_coord((float)qp[2], g.oz, g.inv_cell, g.nz);
   const int rmax = max(max(g.nx, g.ny), g.nz);
-  for (int rr = 0; rr <= rmax; ++rr) {
-    if (have >= k_store && k_store == tcnt) break;
-    if (give_up && rr >= 4 && (uint32_t)__builtin_amdgcn_readfirstlane(sq_i32(give_up)) > step) break;
-    const int w = 2 * rr + 1;
-    const int total = w * w * w;
-    for (int c0 = 0; c0 < total; c0 += 64) {
-      const int cc = c0 + lane;
-      int cell = 0, m = 0;
-      if (cc < total) {
-        const int ox = cc % w - rr, oy = (cc / w) % w - rr, oz = cc / (w * w) - rr;
-        const bool shell = ox == -rr || ox == rr || oy == -rr || oy == rr || oz == -rr || oz == rr;
-        const int x = cx + ox, y = cy + oy, z = cz + oz;
-        if (shell && x >= 0 && x < g.nx && y >= 0 && y < g.ny && z >= 0 && z < g.nz) {
-          cell = (z * g.ny + y) * g.nx + x;
-          m = sq_i32(g.cnt + cell);
-          if (m > g.bk) m = g.bk;
-        }
+  // Shells 0-2 in one go (the 125 cells of the cube: two counts per lane asked for together, their candidates flattened over
+  // the lanes, two batches of items in flight).  A search that a single shell would have ended loses nothing but the surplus
+  // candidates: what lies outside shell r is farther than the k-th distance that ended the search there.
+  int rr0 = 0;
+  {
+    int cl[2], mm[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int j = 64 * u + lane;
+      cl[u] = 0; mm[u] = 0;
+      if (j < 125) {
+        const int x = cx + j % 5 - 2, y = cy + (j / 5) % 5 - 2, z = cz + j / 25 - 2;
+        if (x >= 0 && x < g.nx && y >= 0 && y < g.ny && z >= 0 && z < g.nz) { cl[u] = (z * g.ny + y) * g.nx + x; mm[u] = sq_i32(g.cnt + cl[u]); }
       }
-      if (!__any(m > 0)) continue;
-      int inc = m;
+    }
+    ++d_sh; ++d_cg;
+    int inc[2], tot[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      if (mm[u] > g.bk) mm[u] = g.bk;
+      inc[u] = mm[u];
       for (int off = 1; off < 64; off <<= 1) {
-        const int o = __shfl_up(inc, off);
-        if (lane >= off) inc += o;
+        const int o = __shfl_up(inc[u], off);
+        if (lane >= off) inc[u] += o;
       }
-      const int tot = __shfl(inc, 63);
-      for (int base = 0; base < tot; base += 64) {
-        const int j = base + lane;
-        const int jj = j < tot ? j : tot - 1;
+      tot[u] = __shfl(inc[u], 63);
+    }
+    const int total = tot[0] + tot[1];
+    for (int base = 0; base < total; base += 128) {
+      const GridItem* src[2];
+      bool vld[2];
+#pragma unroll
+      for (int v = 0; v < 2; ++v) {
+        const int j = base + 64 * v + lane;
+        vld[v] = j < total;
+        const int jc = vld[v] ? j : total - 1;
+        const bool second = jc >= tot[0];
+        const int jj = second ? jc - tot[0] : jc;
         int lo = 0, hi = 63;
         while (lo < hi) {
           const int mid = (lo + hi) >> 1;
-          if (__shfl(inc, mid) > jj) hi = mid; else lo = mid + 1;
+          const int im0 = __shfl(inc[0], mid), im1 = __shfl(inc[1], mid);   // (both by every lane: a shuffle under a divergent branch reads nothing from the lanes outside it)
+          if ((second ? im1 : im0) > jj) hi = mid; else lo = mid + 1;
         }
-        const int src_cell = __shfl(cell, lo);
-        const int slot = jj - (__shfl(inc, lo) - __shfl(m, lo));
-        offer(j < tot, g.items + (size_t)src_cell * g.bk + slot);
+        const int c_a = __shfl(cl[0], lo), c_b = __shfl(cl[1], lo);
+        const int i_a = __shfl(inc[0], lo), i_b = __shfl(inc[1], lo), m_a = __shfl(mm[0], lo), m_b = __shfl(mm[1], lo);
+        const int src_cell = second ? c_b : c_a;
+        const int slot = jj - ((second ? i_b : i_a) - (second ? m_b : m_a));
+        src[v] = g.items + (size_t)src_cell * g.bk + slot;
+      }
+      // (the binary search's shuffles need every lane: the loads are issued for both batches before the first is offered)
+      unsigned long long pw[2][7];
+#pragma unroll
+      for (int v = 0; v < 2; ++v)
+        if (vld[v]) {
+          const unsigned long long* q8 = reinterpret_cast<const unsigned long long*>(src[v]);
+          for (int q = 0; q < 7; ++q) pw[v][q] = sq_u64(q8 + q);
+        }
+      // the candidates of my tree: (distance, id) keys, two per lane
+      double cd[2];
+      int cid[2];
+      bool cv[2];
+#pragma unroll
+      for (int v = 0; v < 2; ++v) {
+        cd[v] = 1.0e300; cid[v] = 0x7fffffff; cv[v] = false;
+        if (vld[v]) {
+          const int id = (int)(unsigned)(pw[v][6] & 0xffffffffULL);
+          if ((int)(unsigned)(pw[v][6] >> 32) == tree && id < max_id) {
+            double p6[6];
+            for (int q = 0; q < 6; ++q) p6[q] = __longlong_as_double((long long)pw[v][q]);
+            cd[v] = dist6(p6, qp);
+            cid[v] = id;
+            cv[v] = true;
+          }
+        }
+      }
+      ++d_ob;
+#pragma unroll
+      for (int v = 0; v < 2; ++v) {
+        if (base + 64 * v >= total) continue;
+        const double worst = topk_worst(t, k, have);
+        const bool cand = cv[v] && (have < k || key_less(cd[v], cid[v], worst, 0x7fffffff));
+        d_in += (unsigned long long)__popcll(__ballot(cand));
+        topk_merge(t, lane, k, have, cand, cd[v], cid[v]);
+      }
+    }
+    for (int base = 0; base < no; base += 64) offer(base + lane < no, g.ovf + base + lane);
+    const double covered = 2.0 * cell_edge - slack;
+    const bool done = (have >= k_store && k_store == tcnt) || (have >= k && topk_worst(t, k, have) <= covered) ||
+                      (cx - 2 <= 0 && cy - 2 <= 0 && cz - 2 <= 0 && cx + 2 >= g.nx - 1 && cy + 2 >= g.ny - 1 && cz + 2 >= g.nz - 1);
+    rr0 = done ? rmax + 1 : 3;
+  }
+  for (int rr = rr0; rr <= rmax; ++rr) {
+    if (have >= k_store && k_store == tcnt) break;
+    if (give_up && rr >= 4 && (uint32_t)__builtin_amdgcn_readfirstlane(sq_i32(give_up)) > step) break;
+    // the cells of shell rr only (two full slices + the rings of the slices between them: 6 w^2 - 12 w + 8 of the cube's w^3),
+    // the counts of eight batches of 64 cells asked for together
+    const int w = 2 * rr + 1, w2 = w * w, per = 4 * w - 4;
+    const int S = rr == 0 ? 1 : 6 * w2 - 12 * w + 8;
+    ++d_sh;
+    for (int b0 = 0; b0 < S; b0 += 512) {
+      ++d_cg;
+      int mm[8], cl[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int j = b0 + 64 * u + lane;
+        mm[u] = 0; cl[u] = 0;
+        if (j < S) {
+          int ox, oy, oz;
+          if (j < w2) { oz = -rr; ox = j % w - rr; oy = j / w - rr; }
+          else if (j < 2 * w2) { const int j2 = j - w2; oz = rr; ox = j2 % w - rr; oy = j2 / w - rr; }
+          else {
+            const int r = j - 2 * w2, sl = r / per, t2 = r - sl * per;
+            oz = -rr + 1 + sl;
+            if (t2 < w) { ox = t2 - rr; oy = -rr; }
+            else if (t2 < 2 * w) { ox = t2 - w - rr; oy = rr; }
+            else if (t2 < 3 * w - 2) { ox = -rr; oy = -rr + 1 + (t2 - 2 * w); }
+            else { ox = rr; oy = -rr + 1 + (t2 - (3 * w - 2)); }
+          }
+          const int x = cx + ox, y = cy + oy, z = cz + oz;
+          if (x >= 0 && x < g.nx && y >= 0 && y < g.ny && z >= 0 && z < g.nz) {
+            cl[u] = (z * g.ny + y) * g.nx + x;
+            mm[u] = sq_i32(g.cnt + cl[u]);
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (b0 + 64 * u >= S) continue;
+        const int cell = cl[u];
+        const int m = mm[u] > g.bk ? g.bk : mm[u];
+        if (!__any(m > 0)) continue;
+        int inc = m;
+        for (int off = 1; off < 64; off <<= 1) {
+          const int o = __shfl_up(inc, off);
+          if (lane >= off) inc += o;
+        }
+        const int tot = __shfl(inc, 63);
+        for (int base = 0; base < tot; base += 64) {
+          const int j = base + lane;
+          const int jj = j < tot ? j : tot - 1;
+          int lo = 0, hi = 63;
+          while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (__shfl(inc, mid) > jj) hi = mid; else lo = mid + 1;
+          }
+          const int src_cell = __shfl(cell, lo);
+          const int slot = jj - (__shfl(inc, lo) - __shfl(m, lo));
+          offer(j < tot, g.items + (size_t)src_cell * g.bk + slot);
+        }
       }
     }
     const double covered = (double)rr * cell_edge - slack;
     if (have >= k && topk_worst(t, k, have) <= covered) break;
     if (cx - rr <= 0 && cy - rr <= 0 && cz - rr <= 0 && cx + rr >= g.nx - 1 && cy + rr >= g.ny - 1 && cz + rr >= g.nz - 1) break;
   }
+  if (dbg && lane == 0) { atomicAdd(dbg, d_sh); atomicAdd(dbg + 1, d_cg); atomicAdd(dbg + 2, d_ob); atomicAdd(dbg + 3, d_in); atomicAdd(dbg + 4, 1ULL); atomicAdd(dbg + 5, (unsigned long long)no); }
 }
 
 template <bool OPT>
@@ -5039,11 +5158,11 @@ __global__ __launch_bounds__(64) void k_spec_waves(SpecArgs S) {
     __syncthreads();
     // (the leader is past my step; its store of cur_step may become visible after the control block's: never "!=")
     auto stale = [&]() -> bool { return (uint32_t)__builtin_amdgcn_readfirstlane(sq_i32(S.cur_step)) > step; };
-    unsigned long long wt0 = S.hb ? wall_clock64() : 0ULL, wlast = wt0, wph[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long wt0 = S.hb ? wall_clock64() : 0ULL, wlast = wt0, wph[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     auto beat = [&](int phase) {
       if (!S.hb) return;
       const unsigned long long t = wall_clock64();
-      if (phase >= 1 && phase <= 8) wph[phase - 1] = t - wlast;
+      if (phase >= 1 && phase <= 11) wph[phase - 1] = t - wlast;
       wlast = t;
     };
     // ---- my scenario: the waves before mine, with the outcomes it assumes
@@ -5319,7 +5438,10 @@ __global__ __launch_bounds__(64) void k_spec_waves(SpecArgs S) {
                   TopK mt{1.0e300, 0x7fffffff};
                   double m_droot = 0;
                   nq_l += 1;                                                                        // :317 knnSearch
-                  sq_knn(A.g, qp, mine, k, sq_i32(A.tree_cnt + 16 * mine), A.cell_edge, A.knn_slack, lane, mt, n_mem, snn, S.cur_step, step);
+                  beat(9);
+                  sq_knn(A.g, qp, mine, k, sq_i32(A.tree_cnt + 16 * mine), A.cell_edge, A.knn_slack, lane, mt, n_mem, snn, S.cur_step, step,
+                         S.hb ? S.hb + (size_t)S.n_sets * S.n_slots + 80 : nullptr);
+                  beat(10);
                   if (stale()) aborted = true;
                   if (lane < n_mem) m_droot = sq_f64(f.d_root + mt.id);
                   for (int m = 0; m < n_mem && !flt && !aborted; ++m) {                             // :320-327
@@ -5336,6 +5458,7 @@ __global__ __launch_bounds__(64) void k_spec_waves(SpecArgs S) {
                   }
                   // rewire (:332-350): a member the new node's cost improves, if the edge member -> new is free
                   __syncthreads();
+                  beat(11);
                   if (stale()) aborted = true;
                   for (int m = 0; m < n_mem && !flt && !aborted; ++m) {
                     const double dm = __shfl(mt.d, m), drm = __shfl(m_droot, m);
@@ -5368,8 +5491,8 @@ __global__ __launch_bounds__(64) void k_spec_waves(SpecArgs S) {
     beat(8);
     if (S.hb && status == SPS_ACCEPT && lane == 0) {   // where an ACCEPTED attempt's time went (debugging)
       unsigned long long* o = S.hb + (size_t)S.n_sets * S.n_slots + 64;
-      for (int k = 0; k < 8; ++k) atomicAdd(o + k, wph[k]);
-      atomicAdd(o + 8, 1ULL);
+      for (int k = 0; k < 11; ++k) atomicAdd(o + k + 1, wph[k]);
+      atomicAdd(o, 1ULL);
     }
     // ---- the record: SFF*'s rewires first, drained, then row 0
     if (OPT && status == SPS_ACCEPT && n_rw > 0) {

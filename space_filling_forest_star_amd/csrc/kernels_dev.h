@@ -97,6 +97,48 @@ __device__ __forceinline__ void topk_insert(TopK& t, int lane, int k, int& have,
     if (have < k) ++have;
   }
 }
+// merges one candidate per lane (cv: valid, key (cd, cid)) into the list by RANKING instead of inserting one by one: every
+// candidate and every list entry is broadcast once (scalar reads of its lane), every lane counts the keys below its own
+// entry and below its own candidate, and each survivor is pushed to the lane of its rank (ds_permute; lane 63 takes what
+// falls out - k <= 56).  One insertion is a dozen DEPENDENT cross-lane operations, ~0.6 us on a wavefront that is alone on
+// its SIMD; a merge of five candidates into seventeen entries costs about what two insertions cost.  Same list as
+// topk_insert leaves (keys are unique: ids are).
+__device__ __forceinline__ void topk_merge(TopK& t, int lane, int k, int& have, bool cv, double cd, int cid) {
+  unsigned long long mb = __ballot(cv);
+  if (!mb) return;
+  const int nb = __popcll(mb);
+  const unsigned long long tb = (unsigned long long)__double_as_longlong(t.d), cb = (unsigned long long)__double_as_longlong(cd);
+  const int tlo = (int)(unsigned)(tb & 0xffffffffULL), thi = (int)(unsigned)(tb >> 32);
+  const int clo = (int)(unsigned)(cb & 0xffffffffULL), chi = (int)(unsigned)(cb >> 32);
+  int ra = lane, rb = 0;       // my list entry's / my candidate's rank in the union (the list is sorted: lane entries of it are below mine)
+  while (mb) {
+    const int j = __ffsll((long long)mb) - 1;
+    mb &= mb - 1;
+    const double sd = __longlong_as_double((long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane(chi, j) << 32) |
+                                                       (unsigned long long)(unsigned)__builtin_amdgcn_readlane(clo, j)));
+    const int si = __builtin_amdgcn_readlane(cid, j);
+    ra += key_less(sd, si, t.d, t.id) ? 1 : 0;
+    rb += key_less(sd, si, cd, cid) ? 1 : 0;
+  }
+  for (int j = 0; j < have; ++j) {
+    const double sd = __longlong_as_double((long long)(((unsigned long long)(unsigned)__builtin_amdgcn_readlane(thi, j) << 32) |
+                                                       (unsigned long long)(unsigned)__builtin_amdgcn_readlane(tlo, j)));
+    const int si = __builtin_amdgcn_readlane(t.id, j);
+    rb += key_less(sd, si, cd, cid) ? 1 : 0;
+  }
+  const int da = (lane < have && ra < k) ? ra : 63, db = (cv && rb < k) ? rb : 63;
+  const int a_lo = __builtin_amdgcn_ds_permute(da << 2, tlo), a_hi = __builtin_amdgcn_ds_permute(da << 2, thi);
+  const int a_id = __builtin_amdgcn_ds_permute(da << 2, t.id), a_on = __builtin_amdgcn_ds_permute(da << 2, 1);
+  const int b_lo = __builtin_amdgcn_ds_permute(db << 2, clo), b_hi = __builtin_amdgcn_ds_permute(db << 2, chi);
+  const int b_id = __builtin_amdgcn_ds_permute(db << 2, cid);
+  const int total = have + nb;
+  have = total < k ? total : k;
+  if (lane < have) {
+    const unsigned long long bits = a_on ? (((unsigned long long)(unsigned)a_hi << 32) | (unsigned)a_lo) : (((unsigned long long)(unsigned)b_hi << 32) | (unsigned)b_lo);
+    t.d = __longlong_as_double((long long)bits);
+    t.id = a_on ? a_id : b_id;
+  } else { t.d = 1.0e300; t.id = 0x7fffffff; }
+}
 __device__ __forceinline__ double topk_worst(const TopK& t, int k, int have) {   // current k-th distance (inf while not full)
   return have < k ? 1.0e300 : __shfl(t.d, k - 1);
 }
