@@ -182,6 +182,12 @@ Forest::Forest(Ctx* c, const sffgpu_forest_cfg& cf, const double* roots6, int n_
   if (const char* e = getenv("SFFGPU_TEST_NBCAP")) nb_cap = std::max(1, atoi(e));
   if (const char* e = getenv("SFFGPU_TEST_STAR_PASSES")) star_pass_limit = std::max(1, atoi(e));
   if (const char* e = getenv("SFFGPU_STAR_TAIL")) star_tail = atoi(e) != 0;
+  // waves of one slot: the speculative kernel's shape (k_spec_waves; forest_dev.cpp: spec_setup)
+  if (const char* e = getenv("SFFGPU_SPEC")) dev.spec_off = atoi(e) == 0;
+  if (const char* e = getenv("SFFGPU_SPEC_DEPTH")) dev.spec_depth = atoi(e);
+  if (const char* e = getenv("SFFGPU_SPEC_SETS")) dev.spec_sets_want = atoi(e);
+  if (const char* e = getenv("SFFGPU_TEST_SPEC_STALL")) dev.spec_test_stall = atoi(e);
+  if (const char* e = getenv("SFFGPU_NO_DEV_TRIG")) dev.dev_trig_off = atoi(e) != 0;
   if (const char* e = getenv("SFFGPU_STAR_TAIL_WGS")) star_tail_wgs = std::max(1, atoi(e));
   if (const char* e = getenv("SFFGPU_TEST_STAR_STALL")) star_tail_stall = std::max(0, atoi(e));
   if (const char* e = getenv("SFFGPU_NO_GRAPH")) dev.graph_enabled = atoi(e) == 0;

@@ -483,7 +483,7 @@ void Forest::dev_upload_state() {
     if (cfg.libm_sampling) {
       d.trig.ensure((size_t)d.ring_words * 24);
       d.h_trig.ensure((size_t)d.ring_words * 24);
-    } else if (cfg.wave == 1 && !(getenv("SFFGPU_NO_DEV_TRIG") && atoi(getenv("SFFGPU_NO_DEV_TRIG")) != 0)) {
+    } else if (cfg.wave == 1 && !d.dev_trig_off) {
       // waves of one slot: the one wavefront that is waited for looks its sample's cos / sin / acos up (k_ring_trig fills the table)
       d.trig.ensure((size_t)d.ring_words * 24);
       d.dev_trig = true;
@@ -1332,21 +1332,18 @@ bool Forest::seq_eligible() const {
 }
 
 // The scenario tree of k_spec_waves (kernels.h: SpecArgs).  Plain SFF: the full tree of outcomes (accept at attempt
-// 0 .. TM-1 | all fail) to SFFGPU_SPEC_DEPTH waves (default 2: 1 + (TM + 1) scenarios, TM workers each); SFF*: the
-// chain of all-fail scenarios (default 3 waves).  SFFGPU_SPEC=0 keeps the single wavefront (k_seq_waves).
+// 0 .. TM-1 | all fail) to SFFGPU_SPEC_DEPTH waves (default 3: 1 + 6 + 36 scenarios at ThresholdMisses = 5, one workgroup
+// per scenario and attempt), cut where the grid would no longer be resident at once; SFF*: the chain of all-fail
+// scenarios.  SFFGPU_SPEC_SETS sets of workers take the steps in turn (default 1).  SFFGPU_SPEC=0 keeps the single
+// wavefront (k_seq_waves).  All read when the forest is created (forest.cpp).
 bool Forest::spec_setup() {
   DevEngine& d = dev;
   if (d.spec_off) return false;
   const int TM = std::max(1, cfg.threshold_misses);
   if (d.spec_n_sc > 0 && d.spec_tm == TM) return true;
-  if (getenv("SFFGPU_SPEC") && atoi(getenv("SFFGPU_SPEC")) == 0) { d.spec_off = true; return false; }
   if (TM > 8) { d.spec_off = true; return false; }
-  int depth = 3;
-  if (getenv("SFFGPU_SPEC_DEPTH")) depth = atoi(getenv("SFFGPU_SPEC_DEPTH"));
-  depth = std::max(1, std::min(depth, SFFK_SPEC_DEPTH));
-  int sets = 1;
-  if (getenv("SFFGPU_SPEC_SETS")) sets = atoi(getenv("SFFGPU_SPEC_SETS"));
-  sets = std::max(1, std::min(sets, 4));
+  const int depth = std::max(1, std::min(d.spec_depth, SFFK_SPEC_DEPTH));
+  const int sets = std::max(1, std::min(d.spec_sets_want, 4));
   struct Sc { int level; int out[SFFK_SPEC_DEPTH]; int anc[SFFK_SPEC_DEPTH]; int child[9]; };
   std::vector<Sc> tab;
   Sc root{};
@@ -1355,7 +1352,8 @@ bool Forest::spec_setup() {
   for (size_t i = 0; i < tab.size(); ++i) {
     if (tab[i].level + 1 >= depth) continue;
     for (int o = cfg.optimize ? TM : 0; o <= TM; ++o) {
-      if ((tab.size() + 1) * (size_t)TM * (size_t)sets > 900) break;   // (every workgroup has to be resident)
+      // (every workgroup has to be resident: one wavefront per SIMD at this kernel's register count, two - SFF*: three - per workgroup)
+      if ((tab.size() + 1) * (size_t)TM * (size_t)sets * (cfg.optimize ? 3 : 2) + 3 > 960) break;
       Sc ch = tab[i];
       ch.level = tab[i].level + 1;
       ch.out[tab[i].level] = o;
@@ -1466,6 +1464,7 @@ void Forest::run_device_seq(int max_waves) {
       sa.cur_step = reinterpret_cast<int32_t*>(d.spec_area.as<uint8_t>() + 768);
       sa.rec = d.spec_area.as<unsigned long long>() + 128;
       sa.timeout_ticks = 20000000ULL;   // 200 ms
+      if (d.spec_test_stall && st.spec_steps == 0 && d.last.spec_steps == 0) sa.test_stall = d.spec_test_stall;
       const size_t rec_bytes = (size_t)sa.n_sets * sa.n_slots * SFFK_SPEC_REC * 8;
       if (getenv("SFFGPU_PROFILE")) sa.hb = reinterpret_cast<unsigned long long*>(d.spec_area.as<uint8_t>() + 1024 + rec_bytes);
       HIPCHK(hipMemsetAsync(d.spec_area.p, 0, d.spec_area.cap, c.stream));

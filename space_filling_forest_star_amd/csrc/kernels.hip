@@ -4088,7 +4088,7 @@ __device__ __attribute__((noinline)) bool sq_path_free(const EnvView& env, const
 // business); give_up / step: the search ends when that word is beyond step (the leader has moved on: nobody reads the result)
 __device__ __attribute__((noinline)) void sq_knn(const GridView& g, const double* qp, int tree, int k, int tcnt, double cell_edge, double slack, int lane,
                        TopK& t, int& have, int max_id = 0x7fffffff, const int32_t* give_up = nullptr, uint32_t step = 0,
-                       unsigned long long* dbg = nullptr) {
+                       unsigned long long* dbg = nullptr, const int32_t* lds_cancel = nullptr, int job = 0) {
   t.d = 1.0e300; t.id = 0x7fffffff;
   have = 0;
   unsigned long long d_sh = 0, d_ob = 0, d_cg = 0, d_in = 0;
@@ -4216,6 +4216,7 @@ __device__ __attribute__((noinline)) void sq_knn(const GridView& g, const double
   for (int rr = rr0; rr <= rmax; ++rr) {
     if (have >= k_store && k_store == tcnt) break;
     if (give_up && rr >= 4 && (uint32_t)__builtin_amdgcn_readfirstlane(sq_i32(give_up)) > step) break;
+    if (lds_cancel && __hip_atomic_load(lds_cancel, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) >= job) break;   // (the attempt was rejected meanwhile)
     // the cells of shell rr only (two full slices + the rings of the slices between them: 6 w^2 - 12 w + 8 of the cube's w^3),
     // the counts of eight batches of 64 cells asked for together
     const int w = 2 * rr + 1, w2 = w * w, per = 4 * w - 4;
@@ -4754,8 +4755,15 @@ __device__ __forceinline__ double sp_f64(uint32_t lo, uint32_t hi) {
 #define SPB_USED 7
 #define SP_QUIT 0xffffffffu
 
+// LDS words two wavefronts of a workgroup hand to each other (in-order LDS operations of a wavefront; the words themselves
+// through workgroup-scope atomics so that the compiler keeps every access)
+__device__ __forceinline__ int lds_ld(const int32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void lds_st(int32_t* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+// one wavefront's own LDS traffic: what a lane wrote, the other lanes read behind this
+#define SP_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+
 template <bool OPT>
-__global__ __launch_bounds__(64) void k_spec_waves(SpecArgs S) {
+__global__ __launch_bounds__(OPT ? 192 : 128) void k_spec_waves(SpecArgs S) {
   extern __shared__ double lds_d[];
   __shared__ int32_t s_fh, s_ovf;
   __shared__ int32_t h_id[64], h_tree[64];
@@ -4764,17 +4772,27 @@ __global__ __launch_bounds__(64) void k_spec_waves(SpecArgs S) {
   __shared__ double p_pos[SFFK_SPEC_DEPTH * 6], p_best[SFFK_SPEC_DEPTH];
   __shared__ int32_t p_tree[SFFK_SPEC_DEPTH];
   __shared__ uint32_t s_rw[OPT ? SFFK_STAR_KC * 5 : 1];
+  // the job the worker's first wavefront hands to its second one right after the sample is drawn: the neighbour query
+  // (and, SFF*, the k nearest of the sample's tree) run BESIDE the pose check and the parent edge
+  __shared__ int32_t j_seq, j_cancel, j_done, j_done_k, j_nhit, j_mine, j_k, j_tcnt, j_nmem, j_nn0, j_snn, j_step;
+  __shared__ double j_qp[6], j_pdist;
+  __shared__ double k_d[64];
+  __shared__ int32_t k_id[64];
   const SeqArgs& A = S.q;
   const DevForestView& f = A.f;
   DevCtrl* c = f.ctrl;
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int wv = threadIdx.x >> 6;
   if (c->halt || c->in_wave) return;            // (a wave the host left half done goes through the round engine)
+  if (threadIdx.x == 0) { j_seq = 0; j_cancel = 0; j_done = 0; j_done_k = 0; }
+  __syncthreads();
   const int TM = f.threshold_misses, WP = f.words_per, R = f.n_trees;
   const int front_sel = c->front_sel;
   int32_t* frontier = front_sel ? f.frontier2 : f.frontier;
 
   if (blockIdx.x == 0) {
     // =================================================================== the leader: owns the forest, commits in order
+    if (wv) return;
     int n_nodes = c->n_nodes, iter = c->iter, fn = c->frontier_n, cn = c->closed_n, nb = c->n_borders;
     int solved = c->solved, empty_frontier = c->empty_frontier, terminated = c->terminated;
     unsigned long long cursor = c->cursor, cc = c->collide_calls, pf = c->path_free_calls, nq = c->nn_queries;
@@ -4882,9 +4900,9 @@ __global__ __launch_bounds__(64) void k_spec_waves(SpecArgs S) {
             }
             ask_all(rd + 1);                     // (the others of the wave were written about when this one was)
           }
-          __syncthreads();
+          SP_WAVE_SYNC();
           s_row[lane] = (uint32_t)g;
-          __syncthreads();
+          SP_WAVE_SYNC();
           return true;
         };
         bool have0 = false;
@@ -5006,7 +5024,7 @@ __global__ __launch_bounds__(64) void k_spec_waves(SpecArgs S) {
             else if (lane == 34) wt_u8(f.nflag + o, 2);
           }
           if (OPT) {
-            __syncthreads();
+            SP_WAVE_SYNC();
             if (lane == 0) {
               if (A.hist) {
                 const int at = atomicAdd(A.hist_ctl, 1);
@@ -5115,6 +5133,106 @@ __global__ __launch_bounds__(64) void k_spec_waves(SpecArgs S) {
   }
 
   // ===================================================================== a worker: one (scenario, attempt) of every step of its set
+  if (wv >= 1) {
+    // ---- its second wavefront: the neighbour query of the sample the first one has just drawn; SFF*: a third one for the
+    // k nearest of the sample's tree
+    int seen = 0;
+    for (;;) {
+      const int sq = lds_ld(&j_seq);
+      if (sq < 0) break;
+      if (sq == seen) { __builtin_amdgcn_s_sleep(1); continue; }
+      double qp[6];
+      for (int k = 0; k < 6; ++k) qp[k] = j_qp[k];
+      const double pdist = j_pdist;
+      const int mine = lds_ld(&j_mine), kk = lds_ld(&j_k), nn0 = lds_ld(&j_nn0), snn = lds_ld(&j_snn);
+      const uint32_t step = (uint32_t)lds_ld(&j_step);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      if (lds_ld(&j_seq) != sq) continue;        // (overwritten while it was read: that job is nobody's business any more)
+      seen = sq;
+      int n_hit = 0;
+      if (wv == 1) {
+        // the neighbours: exact 6-D ball of radius max(parentDistance, treeDistance) from the cells its box touches (:262-267)
+        const double r = pdist > A.dist_tree ? pdist : A.dist_tree;
+        const double ri = (r + A.sweep_abs_eps) * (1.0 + 1e-5);
+        const float rf = sqrtf((float)(ri * ri) * 1.000001f) * 1.000001f;
+        const GridView& g = A.g;
+        const float qx = (float)qp[0], qy = (float)qp[1], qz = (float)qp[2];
+        const int lx = grid_coord(qx - rf, g.ox, g.inv_cell, g.nx), hx = grid_coord(qx + rf, g.ox, g.inv_cell, g.nx);
+        const int ly = grid_coord(qy - rf, g.oy, g.inv_cell, g.ny), hy = grid_coord(qy + rf, g.oy, g.inv_cell, g.ny);
+        const int lz = grid_coord(qz - rf, g.oz, g.inv_cell, g.nz), hz = grid_coord(qz + rf, g.oz, g.inv_cell, g.nz);
+        const int wx = hx - lx + 1, wy = hy - ly + 1, wz = hz - lz + 1;
+        const int total = wx * wy * wz;
+        auto take = [&](bool vld, const GridItem* src) {        // one candidate per lane -> the hit list in LDS
+          bool h = false;
+          double d = 0, p6[6];
+          int id = 0, tr = 0;
+          if (vld) {
+            const unsigned long long* q8 = reinterpret_cast<const unsigned long long*>(src);
+            for (int k = 0; k < 6; ++k) p6[k] = __longlong_as_double((long long)sq_u64(q8 + k));
+            const unsigned long long it = sq_u64(q8 + 6);
+            id = (int)(unsigned)(it & 0xffffffffULL); tr = (int)(unsigned)(it >> 32);
+            d = dist6(p6, qp);
+            h = d < r && id < nn0;                               // (a node the leader commits while this step runs reaches the attempt through its scenario)
+          }
+          const unsigned long long hm = __ballot(h);
+          if (h) {
+            const int at = n_hit + __popcll(hm & ((1ULL << lane) - 1ULL));
+            if (at < 64) { h_id[at] = id; h_tree[at] = tr; h_d[at] = d; for (int k = 0; k < 6; ++k) h_pos[6 * at + k] = p6[k]; }
+          }
+          n_hit += __popcll(hm);
+        };
+        for (int c0 = 0; c0 < total; c0 += 64) {
+          const int ci = c0 + lane;
+          int cell = 0, m = 0;
+          if (ci < total) {
+            const int q1 = ci / wx, q2 = q1 / wy;
+            cell = ((lz + q2) * g.ny + (ly + q1 - q2 * wy)) * g.nx + (lx + ci - q1 * wx);
+            m = sq_i32(g.cnt + cell);
+            if (m > g.bk) m = g.bk;
+          }
+          int inc = m;
+          for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(inc, off);
+            if (lane >= off) inc += o;
+          }
+          const int tot = __shfl(inc, 63);
+          for (int base = 0; base < tot; base += 64) {
+            const int j = base + lane;
+            const int jj = j < tot ? j : tot - 1;
+            int lo = 0, hi = 63;
+            while (lo < hi) {
+              const int mid = (lo + hi) >> 1;
+              if (__shfl(inc, mid) > jj) hi = mid; else lo = mid + 1;
+            }
+            const int src_cell = __shfl(cell, lo);
+            const int slot2 = jj - (__shfl(inc, lo) - __shfl(m, lo));
+            take(j < tot, g.items + (size_t)src_cell * g.bk + slot2);
+          }
+        }
+        int no = sq_i32(g.ovf_cnt);
+        if (no > g.ovf_cap) no = g.ovf_cap;
+        for (int base = 0; base < no; base += 64) take(base + lane < no, g.ovf + base + lane);
+      }
+      if (wv == 1) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) { lds_st(&j_nhit, n_hit); }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) lds_st(&j_done, seen);
+      }
+      if (OPT && wv == 2) {
+        TopK mt{1.0e300, 0x7fffffff};
+        int n_mem = 0;
+        if (kk <= SFFK_STAR_KMAX && lds_ld(&j_cancel) < seen)
+          sq_knn(A.g, qp, mine, kk, sq_i32(A.tree_cnt + 16 * mine), A.cell_edge, A.knn_slack, lane, mt, n_mem, snn, S.cur_step, step,
+                 S.hb ? S.hb + (size_t)S.n_sets * S.n_slots + 80 : nullptr, &j_cancel, seen);
+        k_d[lane] = mt.d; k_id[lane] = mt.id;
+        if (lane == 0) lds_st(&j_nmem, n_mem);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) lds_st(&j_done_k, seen);
+      }
+    }
+    return;
+  }
   const int wid = (int)blockIdx.x - 1;
   const int set = wid / S.n_slots, slot = wid - set * S.n_slots;
   const int sc = slot / TM, att = slot - sc * TM;
@@ -5135,11 +5253,12 @@ __global__ __launch_bounds__(64) void k_spec_waves(SpecArgs S) {
   __builtin_amdgcn_wave_barrier();
   uint32_t last = 0;
   unsigned long long ex_pose = 0, ex_seg = 0, ex_smp = 0, evals = 0;
+  int myseq = 0;                                 // jobs handed to the second wavefront so far
   for (;;) {
     // ---- the next step of my set
     uint32_t step = 0;
     bool quit = false;
-    __syncthreads();
+    SP_WAVE_SYNC();
     for (;;) {
       const unsigned long long g = sq_u64(S.base + 16 * set + (lane & 15));
       const uint32_t tg = (uint32_t)(g >> 32);
@@ -5149,13 +5268,13 @@ __global__ __launch_bounds__(64) void k_spec_waves(SpecArgs S) {
       if (whole && t0 > last) { step = t0; s_row[lane] = (uint32_t)g; break; }
       __builtin_amdgcn_s_sleep(2);
     }
-    if (quit) break;
-    __syncthreads();
+    if (quit) { if (lane == 0) lds_st(&j_seq, -1); break; }
+    SP_WAVE_SYNC();
     last = step;
     const unsigned long long cur0 = ((unsigned long long)s_row[SPB_CUR + 1] << 32) | (unsigned long long)s_row[SPB_CUR];
     const int fn0 = (int)s_row[SPB_FN], cn0 = (int)s_row[SPB_CN], nn0 = (int)s_row[SPB_NN], it0 = (int)s_row[SPB_ITER];
     const int ef0 = (int)s_row[SPB_EF];
-    __syncthreads();
+    SP_WAVE_SYNC();
     // (the leader is past my step; its store of cur_step may become visible after the control block's: never "!=")
     auto stale = [&]() -> bool { return (uint32_t)__builtin_amdgcn_readfirstlane(sq_i32(S.cur_step)) > step; };
     unsigned long long wt0 = S.hb ? wall_clock64() : 0ULL, wlast = wt0, wph[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -5273,6 +5392,22 @@ __global__ __launch_bounds__(64) void k_spec_waves(SpecArgs S) {
         if (lane < 16) wt_u64(my_rec + SFFK_SPEC_EARLY + lane, sp_gran(step, v));
       }
       bool flt = false, reject = true;
+      int kstar = 0;
+      if (OPT) kstar = __popcll(__ballot(lane > 0 && lane <= SFFK_STAR_KMAX + 1 && A.ktab[lane] <= snn));   // (size_t)(2e log10 N), :309
+      if (ok) {   // the second wavefront starts on the neighbours now
+        if (lane == 0) {
+          for (int k = 0; k < 6; ++k) j_qp[k] = qp[k];
+          j_pdist = pdist;
+          lds_st(&j_mine, mine); lds_st(&j_k, kstar); lds_st(&j_nn0, nn0); lds_st(&j_snn, snn); lds_st(&j_step, (int)step);
+        }
+        ++myseq;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) lds_st(&j_seq, myseq);
+      }
+      auto helper_wait = [&](const int32_t* word, int want) {   // the other wavefront's answer (every lane reads the word: uniform)
+        while (lds_ld(word) < want) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      };
       if (ok) {
         // ---- Environment::Collide(newPoint)
         cc_l += 1; ex_pose += 1;
@@ -5297,83 +5432,26 @@ __global__ __launch_bounds__(64) void k_spec_waves(SpecArgs S) {
           if (!flt && !reject && !aborted) {
             nq_l += R;                                               // :262-267 one radiusSearch per tree
             const double r = pdist > A.dist_tree ? pdist : A.dist_tree;
-            const double ri = (r + A.sweep_abs_eps) * (1.0 + 1e-5);
-            const float rf = sqrtf((float)(ri * ri) * 1.000001f) * 1.000001f;
-            const GridView& g = A.g;
-            const float qx = (float)qp[0], qy = (float)qp[1], qz = (float)qp[2];
-            const int lx = grid_coord(qx - rf, g.ox, g.inv_cell, g.nx), hx = grid_coord(qx + rf, g.ox, g.inv_cell, g.nx);
-            const int ly = grid_coord(qy - rf, g.oy, g.inv_cell, g.ny), hy = grid_coord(qy + rf, g.oy, g.inv_cell, g.ny);
-            const int lz = grid_coord(qz - rf, g.oz, g.inv_cell, g.nz), hz = grid_coord(qz + rf, g.oz, g.inv_cell, g.nz);
-            const int wx = hx - lx + 1, wy = hy - ly + 1, wz = hz - lz + 1;
-            const int total = wx * wy * wz;
-            auto take = [&](bool vld, const GridItem* src) {        // one candidate per lane -> the hit list in LDS
-              bool h = false;
-              double d = 0, p6[6];
-              int id = 0, tr = 0;
-              if (vld) {
-                const unsigned long long* q8 = reinterpret_cast<const unsigned long long*>(src);
-                for (int k = 0; k < 6; ++k) p6[k] = __longlong_as_double((long long)sq_u64(q8 + k));
-                const unsigned long long it = sq_u64(q8 + 6);
-                id = (int)(unsigned)(it & 0xffffffffULL); tr = (int)(unsigned)(it >> 32);
-                d = dist6(p6, qp);
-                h = d < r && id < nn0;                               // (a node the leader commits while this step runs reaches me through my scenario, below)
-              }
-              const unsigned long long hm = __ballot(h);
-              if (h) {
-                const int at = n_hit + __popcll(hm & ((1ULL << lane) - 1ULL));
-                if (at < 64) { h_id[at] = id; h_tree[at] = tr; h_d[at] = d; for (int k = 0; k < 6; ++k) h_pos[6 * at + k] = p6[k]; }
-              }
-              n_hit += __popcll(hm);
-            };
-            for (int c0 = 0; c0 < total; c0 += 64) {
-              const int ci = c0 + lane;
-              int cell = 0, m = 0;
-              if (ci < total) {
-                const int q1 = ci / wx, q2 = q1 / wy;
-                cell = ((lz + q2) * g.ny + (ly + q1 - q2 * wy)) * g.nx + (lx + ci - q1 * wx);
-                m = sq_i32(g.cnt + cell);
-                if (m > g.bk) m = g.bk;
-              }
-              int inc = m;
-              for (int off = 1; off < 64; off <<= 1) {
-                const int o = __shfl_up(inc, off);
-                if (lane >= off) inc += o;
-              }
-              const int tot = __shfl(inc, 63);
-              for (int base = 0; base < tot; base += 64) {
-                const int j = base + lane;
-                const int jj = j < tot ? j : tot - 1;
-                int lo = 0, hi = 63;
-                while (lo < hi) {
-                  const int mid = (lo + hi) >> 1;
-                  if (__shfl(inc, mid) > jj) hi = mid; else lo = mid + 1;
-                }
-                const int src_cell = __shfl(cell, lo);
-                const int slot2 = jj - (__shfl(inc, lo) - __shfl(m, lo));
-                take(j < tot, g.items + (size_t)src_cell * g.bk + slot2);
-              }
-            }
-            int no = sq_i32(g.ovf_cnt);
-            if (no > g.ovf_cap) no = g.ovf_cap;
-            for (int base = 0; base < no; base += 64) take(base + lane < no, g.ovf + base + lane);
+            helper_wait(&j_done, myseq);                             // (asked for when the sample was drawn)
+            n_hit = lds_ld(&j_nhit);
             // ---- the samples my scenario assumes accepted before me: nodes nn0 .. nn0 + na - 1
             for (int p = 0; p < na && !aborted; ++p) {
               const unsigned long long* ep = S.rec + ((size_t)set * S.n_slots + pslot[p]) * SFFK_SPEC_REC + SFFK_SPEC_EARLY;
-              __syncthreads();
+              SP_WAVE_SYNC();
               for (int spin = 0;; ++spin) {   // (its worker publishes it as long as the step is the current one)
                 const unsigned long long g2 = sq_u64(ep + (lane & 15));
                 if (__all((uint32_t)(g2 >> 32) == step)) { s_row[lane] = (uint32_t)g2; break; }
                 if ((spin & 15) == 15 && stale()) { aborted = true; break; }
                 __builtin_amdgcn_s_sleep(1);
               }
-              __syncthreads();
+              SP_WAVE_SYNC();
               if (aborted) break;
               if (s_row[15] == 0u) { status = SPS_INVALID; break; }      // (that sample left the limits: my scenario cannot happen)
               double pp[6];
               for (int k = 0; k < 6; ++k) pp[k] = sp_f64(s_row[2 * k], s_row[2 * k + 1]);
               const double pb = sp_f64(s_row[13], s_row[14]);
               const int ptree = (int)s_row[12];
-              __syncthreads();
+              SP_WAVE_SYNC();
               if (lane == 0) { for (int k = 0; k < 6; ++k) p_pos[6 * p + k] = pp[k]; p_best[p] = pb; p_tree[p] = ptree; }
               const double d = dist6(pp, qp);
               if (d < r) {
@@ -5389,7 +5467,7 @@ __global__ __launch_bounds__(64) void k_spec_waves(SpecArgs S) {
           beat(4);
           if (!flt && !reject && !aborted && status == SPS_REJECT) {
             // ---- the neighbour loop (:270-300) in the reference's order: tree id, then distance, then id
-            __syncthreads();
+            SP_WAVE_SYNC();
             const bool have = lane < n_hit;
             const int id = have ? h_id[lane] : 0x7fffffff;
             const int t = have ? h_tree[lane] : 0x7fffffff;
@@ -5426,21 +5504,22 @@ __global__ __launch_bounds__(64) void k_spec_waves(SpecArgs S) {
             }
           }
           beat(5);
+          if (OPT && (reject || flt || aborted || status != SPS_REJECT) && lane == 0) lds_st(&j_cancel, myseq);   // (no k nearest needed)
           if (status == SPS_REJECT && !aborted) {
             if (flt) status = SPS_FAULT;
             else if (!reject) {
               status = SPS_ACCEPT;
               if (OPT) {
                 // ---- SFF* (:307-351): the k nearest of the tree, choose parent, rewire - each edge checked when its turn comes
-                const int k = __popcll(__ballot(lane > 0 && lane <= SFFK_STAR_KMAX + 1 && A.ktab[lane] <= snn));   // (size_t)(2e log10 N), :309
-                if (k > SFFK_STAR_KMAX) flt = true;
+                if (kstar > SFFK_STAR_KMAX) flt = true;
                 else {
                   TopK mt{1.0e300, 0x7fffffff};
                   double m_droot = 0;
                   nq_l += 1;                                                                        // :317 knnSearch
                   beat(9);
-                  sq_knn(A.g, qp, mine, k, sq_i32(A.tree_cnt + 16 * mine), A.cell_edge, A.knn_slack, lane, mt, n_mem, snn, S.cur_step, step,
-                         S.hb ? S.hb + (size_t)S.n_sets * S.n_slots + 80 : nullptr);
+                  helper_wait(&j_done_k, myseq);                                                     // (the third wavefront's, beside everything above)
+                  mt.d = k_d[lane]; mt.id = k_id[lane];
+                  n_mem = lds_ld(&j_nmem);
                   beat(10);
                   if (stale()) aborted = true;
                   if (lane < n_mem) m_droot = sq_f64(f.d_root + mt.id);
@@ -5457,7 +5536,7 @@ __global__ __launch_bounds__(64) void k_spec_waves(SpecArgs S) {
                     }
                   }
                   // rewire (:332-350): a member the new node's cost improves, if the edge member -> new is free
-                  __syncthreads();
+                  SP_WAVE_SYNC();
                   beat(11);
                   if (stale()) aborted = true;
                   for (int m = 0; m < n_mem && !flt && !aborted; ++m) {
@@ -5487,7 +5566,9 @@ __global__ __launch_bounds__(64) void k_spec_waves(SpecArgs S) {
         }
       }
     }
+    if (OPT && (status != SPS_ACCEPT || aborted) && lane == 0) lds_st(&j_cancel, myseq);   // (the second wavefront need not finish the k nearest)
     if (aborted) continue;                       // (the leader has moved on: nobody reads this record)
+    if (S.test_stall && (int)step == (S.test_stall >> 3) && slot == (S.test_stall & 7)) continue;   // (tests: the leader's time-out path)
     beat(8);
     if (S.hb && status == SPS_ACCEPT && lane == 0) {   // where an ACCEPTED attempt's time went (debugging)
       unsigned long long* o = S.hb + (size_t)S.n_sets * S.n_slots + 64;
@@ -5496,7 +5577,7 @@ __global__ __launch_bounds__(64) void k_spec_waves(SpecArgs S) {
     }
     // ---- the record: SFF*'s rewires first, drained, then row 0
     if (OPT && status == SPS_ACCEPT && n_rw > 0) {
-      __syncthreads();
+      SP_WAVE_SYNC();
       for (int q = lane; q < 5 * n_rw; q += 64) wt_u64(my_rec + 64 + q, sp_gran(step, s_rw[q]));
       sq_drain();
     }
@@ -5560,10 +5641,10 @@ void launch_spec_waves(hipStream_t s, const SpecArgs& a) {
   const unsigned grid = 1u + (unsigned)(a.n_sets * a.n_slots);
   if (a.q.optimize) {
     if (lds > 32 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_spec_waves<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_spec_waves<true>, dim3(grid), dim3(64), lds, s, a);
+    hipLaunchKernelGGL(k_spec_waves<true>, dim3(grid), dim3(192), lds, s, a);
   } else {
     if (lds > 32 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_spec_waves<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(k_spec_waves<false>, dim3(grid), dim3(64), lds, s, a);
+    hipLaunchKernelGGL(k_spec_waves<false>, dim3(grid), dim3(128), lds, s, a);
   }
 }
 

@@ -321,6 +321,97 @@ def test_waves_of_one_slot_run_as_one_persistent_wavefront(S, ctx):
     fg.close()
 
 
+@pytest.mark.parametrize("name,iters,seed,optimize,env", [
+    ("dense3d", 6000, 2, False, dict()),                                   # the default tree: 3 waves deep, one set of workers
+    ("dense3d", 6000, 2, True, dict()),                                    # SFF*: the chain of all-fail scenarios
+    ("dense3d", 3000, 7, False, dict(SFFGPU_SPEC_DEPTH=1)),
+    ("dense3d", 3000, 7, False, dict(SFFGPU_SPEC_DEPTH=2, SFFGPU_SPEC_SETS=2)),
+    ("dense3d", 3000, 7, False, dict(SFFGPU_SPEC_DEPTH=4, SFFGPU_SPEC_SETS=1)),
+    ("dense3d", 3000, 7, True, dict(SFFGPU_SPEC_DEPTH=4, SFFGPU_SPEC_SETS=3)),
+    ("triang", 4000, 5, False, dict()),
+    ("triang", 4000, 5, True, dict()),
+    ("dense2d", 3000, 4, False, dict()),                                   # one engine word per attempt
+    ("dense3d_coarse", 10 ** 7, 2, False, dict()),                         # runs into saturation: closed-list picks, maxConnected
+    ("dense3d_coarse", 10 ** 7, 2, True, dict()),                          # (seed 2 saturates after 36 705 iterations)
+])
+def test_waves_of_one_slot_speculated_over_many_wavefronts(S, ctx, name, iters, seed, optimize, env):
+    """wave = 1 through k_spec_waves (round 6): a step evaluates the tree of scenarios (which attempt of each of the next
+    waves is accepted, if any) side by side, one workgroup per (scenario, attempt); the leader commits the path that really
+    happened in the reference's order.  The forest, the reference-equivalent counters and the border list equal the oracle's
+    sequential loop (src/forest.h:122-202) and the single-wavefront kernel's; every iteration went through the kernel."""
+    fo, fg = make(S, ctx, name, 1, iters, seed=seed, optimize=optimize, **env)
+    fo.run()
+    fg.run()
+    so, sg = fo.stats(), fg.stats()
+    assert so["n_nodes"] > 60
+    assert_same_forest(fo, fg)
+    assert sg["spec_committed"] == so["iterations"] and sg["host_fallback_waves"] == 0
+    assert sg["spec_evaluated"] >= sg["spec_committed"] and sg["spec_steps"] > 0
+    print("\n[k_spec_waves %s%s %s] %d iterations in %d steps (%.2f per step), %d attempts evaluated: speculation ratio %.2f"
+          % (name, " SFF*" if optimize else "", env, so["iterations"], sg["spec_steps"], so["iterations"] / sg["spec_steps"],
+             sg["spec_evaluated"], sg["spec_evaluated"] / sg["spec_committed"]))
+    fp = fg.fingerprint()
+    fg.close()
+    _, f1 = make(S, ctx, name, 1, iters, seed=seed, optimize=optimize, SFFGPU_SPEC=0)     # one wavefront (k_seq_waves)
+    f1.run()
+    assert f1.fingerprint() == fp and f1.stats()["spec_steps"] == 0
+    f1.close()
+
+
+def test_speculated_waves_staged_budget_faults_and_parity_mode(S, ctx):
+    """k_spec_waves where the launch has to stop in the middle of a step: staged runs (run(n) ends after exactly n waves), the
+    node budget, a hit list of three entries (the attempt that overflows is rolled back and its wave finished on the host
+    engine), arrays that grow, the libm parity mode (the host's trig table), and a worker that never answers (tests only: the
+    leader times out, the wave is finished on the host path and the single-wavefront kernel takes over)."""
+    fo, fg = make(S, ctx, "triang", 1, 10 ** 7, seed=5, budget=3000)
+    fo.run()
+    while True:
+        w0 = fg.stats()["waves"]
+        fg.run(333)
+        w1 = fg.stats()["waves"]
+        if w1 == w0:
+            break
+        assert w1 - w0 == 333 or fg.stats()["n_nodes"] >= 3000
+        assert len(fg.nodes()["parent"]) == fg.stats()["n_nodes"] and len(fg.frontier()) == fg.stats()["frontier_size"]
+    assert_same_forest(fo, fg)
+    assert fg.stats()["spec_steps"] > 0
+    fg.close()
+    fo, fg = make(S, ctx, "dense3d_coarse", 1, 6000, seed=4, SFFGPU_TEST_HITCAP=3)
+    fo.run()
+    fg.run()
+    assert fg.stats()["host_fallback_waves"] > 0 and fg.stats()["spec_steps"] > 0
+    assert_same_forest(fo, fg)
+    fg.close()
+    for opt in (False, True):
+        sc, w = load_world(ctx, "dense3d")
+        roots = common.free_roots(w.collide, sc["limits"], 5, seed=9, dim=6)
+        kw = dict(dist_tree=sc["dist_tree"], sampling_dist=sc["sampling_dist"], dim=6, max_iterations=2500, wave=1, seed=9, optimize=opt)
+        wl = O.World(sc["env"], sc["robot"], O.TRIG_LIBM)
+        fo = O.Forest(wl, roots, sc["limits"], **kw)
+        fg = S.Forest(ctx, roots, sc["limits"], libm_sampling=True, **kw)
+        fo.run()
+        fg.run()
+        assert_same_forest(fo, fg)
+        assert fg.stats()["spec_committed"] == fo.stats()["iterations"]
+        fg.close()
+    mid_wave = 0
+    for knob in (8 * 40 + 0, 8 * 40 + 1, 8 * 41 + 1, 8 * 42 + 1, 8 * 43 + 2, 8 * 44 + 1):
+        # slot 0 = the step's first attempt (always waited for: the launch ends in front of the wave); the others are only
+        # waited for when the attempts before them were rejected (then the wave is finished on the host engine)
+        fo, fg = make(S, ctx, "dense3d", 1, 3000, seed=6, SFFGPU_TEST_SPEC_STALL=knob)
+        fo.run()
+        fg.run()
+        sg = fg.stats()
+        assert_same_forest(fo, fg)
+        if knob & 7 == 0:
+            assert 0 < sg["spec_steps"] <= 41 and sg["spec_committed"] < fo.stats()["iterations"]      # the rest: k_seq_waves
+        elif sg["spec_committed"] < fo.stats()["iterations"]:
+            mid_wave += 1
+            assert sg["host_fallback_waves"] == 1
+        fg.close()
+    assert mid_wave > 0
+
+
 def test_staged_runs_with_getters_in_between(S, ctx):
     fo, fg = make(S, ctx, "dense3d", 512, 10 ** 7, seed=5, budget=20000)
     fo.run()
