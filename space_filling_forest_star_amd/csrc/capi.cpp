@@ -450,11 +450,11 @@ int sffgpu_forest_dev_wave_begin(sffgpu_forest* f, int32_t* done) {
 int sffgpu_forest_dev_round_eval(sffgpu_forest* f, void* send_dev) {
   if (!f) return SFFGPU_ERR_ARG;
   // (SFFGPU_TEST_EXCHANGE_SELF: a one-rank forest packs and unpacks too - bench.py --force-dist prices the exchange with it)
-  GUARD(f->owner, f->f->dev_enqueue_round_eval((f->f->cfg.world > 1 || getenv("SFFGPU_TEST_EXCHANGE_SELF")) ? send_dev : nullptr));
+  GUARD(f->owner, f->f->dev_enqueue_round_eval((f->f->cfg.world > 1 || f->f->test_exchange_self) ? send_dev : nullptr));
 }
 int sffgpu_forest_dev_round_commit(sffgpu_forest* f, const void* recv_dev) {
   if (!f) return SFFGPU_ERR_ARG;
-  GUARD(f->owner, f->f->dev_enqueue_round_commit((f->f->cfg.world > 1 || getenv("SFFGPU_TEST_EXCHANGE_SELF")) ? recv_dev : nullptr));
+  GUARD(f->owner, f->f->dev_enqueue_round_commit((f->f->cfg.world > 1 || f->f->test_exchange_self) ? recv_dev : nullptr));
 }
 int sffgpu_forest_dev_wave_end(sffgpu_forest* f, int32_t* fault) {
   if (!f || !fault) return SFFGPU_ERR_ARG;

@@ -341,6 +341,7 @@ struct Forest {
   void run_device_seq(int max_waves);
   bool spec_setup();                // the speculative kernel's scenario tree and buffers; false = k_seq_waves runs the loop
   bool seq_suspended = false;
+  bool test_exchange_self = false;  // SFFGPU_TEST_EXCHANGE_SELF (read when the forest is created): a one-rank forest packs / unpacks its records too
   void sync_host();             // refresh the host mirror (nodes, frontier, borders, counters) from the device
   void fill_stats(sffgpu_forest_stats* out);
   ~Forest();

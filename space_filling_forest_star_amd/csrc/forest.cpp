@@ -181,6 +181,7 @@ Forest::Forest(Ctx* c, const sffgpu_forest_cfg& cf, const double* roots6, int n_
   if (hit_cap < 24) query_wide = true;   // (tests shrink the hit list of the wide kernel)
   if (const char* e = getenv("SFFGPU_TEST_NBCAP")) nb_cap = std::max(1, atoi(e));
   if (const char* e = getenv("SFFGPU_TEST_STAR_PASSES")) star_pass_limit = std::max(1, atoi(e));
+  if (getenv("SFFGPU_TEST_EXCHANGE_SELF")) test_exchange_self = true;
   if (const char* e = getenv("SFFGPU_STAR_TAIL")) star_tail = atoi(e) != 0;
   // waves of one slot: the speculative kernel's shape (k_spec_waves; forest_dev.cpp: spec_setup)
   if (const char* e = getenv("SFFGPU_SPEC")) dev.spec_off = atoi(e) == 0;

@@ -1170,7 +1170,7 @@ void Forest::dev_enqueue_wave(int slot) {
     d.ring_pending = false;
   }
   // (SFFGPU_TEST_EXCHANGE_SELF: a one-rank forest packs, all-gathers and unpacks too - the collective on one GPU)
-  const bool self_exchange = getenv("SFFGPU_TEST_EXCHANGE_SELF") != nullptr;
+  const bool self_exchange = test_exchange_self;
   const bool sharded = cfg.world > 1 || (self_exchange && (ctx->rccl_comm != nullptr || ctx->xchg_fn != nullptr));
   size_t words = 0;
   if (sharded) {   // this rank's answer records of a round -> all ranks' (ncclAllGather between device buffers)

@@ -3705,14 +3705,19 @@ __device__ __forceinline__ void star_exact_items(const EnvView& env, const Robot
                                                  ShareArea& s_share, int wg, int nwg, int wave, int lane) {
   DBG_DECL
   const int W = nwg * SEG_WAVES;
-  // (one item per wave, the rest by tickets to the waves that come back first: see k_collide_items)
-  const int grp = (wg + nwg * wave) & (SFFK_SUBLISTS - 1);
+  // (one item per wave, the rest by tickets to the waves that come back first: see k_collide_items).  The items behind the
+  // first W are dealt over SFFK_SUBLISTS ticket groups, a wave draws from the group of its first item - which only reaches
+  // every group when there are at least that many waves: a smaller launch (k_star_tail bounded to a few workgroups, a
+  // device with few CUs) draws all of them from ONE ticket word instead (round 5 left the items of the groups without a
+  // wave untested: their first_hit stayed "free").
+  const bool few = W < SFFK_SUBLISTS;
+  const int grp = few ? 0 : ((wg + nwg * wave) & (SFFK_SUBLISTS - 1));
   int32_t* const ticket = sub + (size_t)grp * SFFK_STAR_SUB + 1;
   auto next_item = [&]() -> int {
     int t = 0;
     if (lane == 0) t = atomicAdd(ticket, 1);
     t = __builtin_amdgcn_readfirstlane(t);
-    return W + grp + SFFK_SUBLISTS * t;
+    return few ? W + t : W + grp + SFFK_SUBLISTS * t;
   };
   for (int e = wg + nwg * wave; e < M; e = next_item()) {
     const int sl = __popcll(__ballot(sub_incl <= e));
@@ -3774,6 +3779,16 @@ __global__ __launch_bounds__(64 * SEG_WAVES) __attribute__((amdgpu_waves_per_eu(
 // raises the stage's fault flag instead of waiting for ever (the round is then redone on the host path like any fault).
 // Pass p uses the counter set / changed flag p mod SFFK_STAR_PASSES; workgroup 0 clears the set of pass p + 1 during pass p.
 #define STAR_BAR_TICKS 4000000ULL      // 40 ms of the 100 MHz wall clock
+// what the workgroup decides behind a barrier (fault raised? pass changed something?) is read ONCE, by thread 0: a flag another
+// workgroup raises just then must not send some of its wavefronts out of the kernel and others into a phase that waits for them
+__device__ __forceinline__ void star_decide(int32_t* s_dec, const int32_t* fault, const int32_t* chg) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    s_dec[0] = __hip_atomic_load(fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_dec[1] = chg ? __hip_atomic_load(chg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+  }
+  __syncthreads();
+}
 __device__ __forceinline__ void star_grid_barrier(int32_t* bar, int target, int32_t* fault, unsigned long long* dbg) {
   // (what the workgroup hands over it wrote through - sst<true> - and every such store has been acknowledged before the
   //  workgroup counts itself in; what it takes over behind the barrier it reads from memory - sld<true>: no cache-wide
@@ -3799,6 +3814,7 @@ __global__ __launch_bounds__(64 * SEG_WAVES) __attribute__((amdgpu_waves_per_eu(
     ResolveArgs A, EnvView env, RobotView rob, NodeStoreView st, int max_passes, int test_stall) {
   __shared__ StarPassLds L;
   __shared__ ShareArea s_share;
+  __shared__ int32_t s_dec[2];
   extern __shared__ double lds_d[];
   const DevForestView& f = A.f;
   const StarView& S = A.S;
@@ -3844,17 +3860,18 @@ __global__ __launch_bounds__(64 * SEG_WAVES) __attribute__((amdgpu_waves_per_eu(
     if (dbg && threadIdx.x == 0) { const unsigned long long t = wall_clock64(); dbg[1] += 1; dbg[2] += t - tp; }
     star_grid_barrier(bar, ++n_bar * g_act, fault, dbg ? dbg + 4 : nullptr);
     if (dbg) tp = wall_clock64();
-    const int flt = __hip_atomic_load(fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int chg = __hip_atomic_load(S.changed + slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    star_decide(s_dec, fault, S.changed + slot);
+    const int flt = s_dec[0], chg = s_dec[1];
     if (flt) break;
     if (chg == 0) { conv = true; break; }
     if (pass + 1 >= max_passes) break;
     // ---- the edges it sent to the exact test
     int32_t* sub = S.sub + (size_t)slot * SFFK_SUBLISTS * SFFK_STAR_SUB;
     int sub_n = __hip_atomic_load(sub + lane * SFFK_STAR_SUB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (sub_n > sub_cap) {   // a sub-list ran over: items were dropped - the round is redone on the host path
-      if (wg == 0 && wave == 0) atomicOr(fault, 1);
-      sub_n = sub_cap;
+    const bool ran_over = __any(sub_n > sub_cap);   // a sub-list ran over: items were dropped - the round is redone on the host path
+    if (ran_over) {                                  // (every workgroup reads the same counts: they all leave here)
+      if (wg == 0 && threadIdx.x == 0) atomicOr(fault, 1);
+      break;
     }
     int sub_incl = sub_n;
     for (int off = 1; off < 64; off <<= 1) {
@@ -3879,7 +3896,8 @@ __global__ __launch_bounds__(64 * SEG_WAVES) __attribute__((amdgpu_waves_per_eu(
       if (dbg && threadIdx.x == 0) dbg[3] += wall_clock64() - tp;
       star_grid_barrier(bar, ++n_bar * g_act, fault, dbg ? dbg + 4 : nullptr);
       if (dbg) tp = wall_clock64();
-      if (__hip_atomic_load(fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+      star_decide(s_dec, fault, nullptr);
+      if (s_dec[0]) break;
     }
     ++pass;
   }
@@ -5881,20 +5899,20 @@ void launch_star_exact(hipStream_t s, const EnvView& env, const RobotView& rob, 
 
 void launch_star_tail(hipStream_t s, const ResolveArgs& a, const EnvView& env, const RobotView& rob, const NodeStoreView& st,
                       int n_bound, int max_passes, int wgs_bound, int test_stall) {
-  static size_t lds_set = 0;
+  // (per call, for the CURRENT device: a process may hold contexts on several)
   const size_t lds = collide_lds_bytes(rob.n_tri, SEG_WAVES);
-  if (lds > lds_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_star_tail), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    lds_set = lds;
-  }
+  if (lds > 32 * 1024) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_star_tail), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   // resident at once: at most one workgroup per CU of an otherwise idle GPU; wgs_bound (SFFGPU_STAR_TAIL_WGS) bounds it further
   // (processes sharing one GPU: the sum of their grids must fit, or their barriers wait for each other until the time-out faults)
-  static const int cus = [] {
-    int dev = 0, n = 256;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
-    return std::max(1, n);
-  }();
+  int dev = 0, cus = 256;
+  (void)hipGetDevice(&dev);
+  static int cu_of[64] = {0};
+  if (dev >= 0 && dev < 64 && cu_of[dev] > 0) cus = cu_of[dev];
+  else {
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    cus = std::max(1, cus);
+    if (dev >= 0 && dev < 64) cu_of[dev] = cus;
+  }
   const int cap = wgs_bound > 0 ? std::min(wgs_bound, cus) : cus;
   const int blocks = std::max(1, std::min(cap, std::max(16, (n_bound + 3) / 4)));
   hipLaunchKernelGGL(k_star_tail, dim3(blocks), dim3(64 * SEG_WAVES), lds, s, a, env, rob, st, max_passes, test_stall);

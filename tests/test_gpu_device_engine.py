@@ -162,6 +162,7 @@ def test_sff_star_device_faults_finish_the_wave_on_the_host_path(S, ctx, env):
     ("dense3d", 2048, 80000, dict(SFFGPU_STAR_TAIL=0), False),          # one launch per pass (the fixed chain)
     ("dense3d", 2048, 80000, dict(SFFGPU_STAR_TAIL_WGS=3), False),      # three workgroups loop over all accepted samples / items
     ("building", 1024, 40000, dict(SFFGPU_STAR_TAIL_WGS=16), False),
+    ("building", 4096, 120000, dict(SFFGPU_STAR_TAIL_WGS=2), False),    # 8 wavefronts < the 64 ticket groups of the exact items: one ticket word
     ("building", 1024, 40000, dict(SFFGPU_TEST_STAR_PASSES=3), True),   # the tail gives up after its second pass: host path
     ("building", 1024, 40000, dict(SFFGPU_TEST_STAR_STALL=7), True),    # every 7th round a workgroup stays away: the barrier times out
 ])
