@@ -344,16 +344,49 @@ def main():
         if world == 1 and not args.no_wave_sweep:
             # the small-wave end: wave = 1 IS the reference's sequential loop (one sample per GPU round trip)
             legs = {}
-            for wv, iters in ((1, 8000), (64, 150000), (512, 1000000)):
-                f = make_forest(wave=wv, budget=0, max_iterations=iters, rk=0, wd=1)
+
+            def small_wave_leg(wv, iters, optimize=False, spec=None):
+                # (the knob is read when the forest is created; SFFGPU_SPEC=0 = the single wavefront of round 5, k_seq_waves)
+                old = os.environ.get("SFFGPU_SPEC")
+                if spec is not None:
+                    os.environ["SFFGPU_SPEC"] = spec
+                try:
+                    f = S.Forest(ctx, roots, sc["limits"], dist_tree=sc["dist_tree"], sampling_dist=sc["sampling_dist"], dim=6,
+                                 max_iterations=iters, node_budget=0, wave=wv, seed=args.seed, optimize=optimize)
+                finally:
+                    if spec is not None:
+                        if old is None:
+                            os.environ.pop("SFFGPU_SPEC", None)
+                        else:
+                            os.environ["SFFGPU_SPEC"] = old
                 c0 = time.perf_counter()
                 f.run()
                 dt = time.perf_counter() - c0
                 st = f.stats()
-                legs["wave_%d" % wv] = {"accepted_nodes_per_s": (st["n_nodes"] - len(roots)) / dt,
-                                        "iterations_per_s": st["iterations"] / dt, "iterations": st["iterations"],
-                                        "nodes": st["n_nodes"], "seconds": dt}
+                leg = {"accepted_nodes_per_s": (st["n_nodes"] - len(roots)) / dt, "iterations_per_s": st["iterations"] / dt,
+                       "iterations": st["iterations"], "nodes": st["n_nodes"], "seconds": dt}
+                if wv == 1:
+                    # wave = 1 is the reference's own order of operations (src/forest.h:122-202).  k_spec_waves evaluates the
+                    # next waves' attempts side by side on many wavefronts and commits the path that really happened
+                    leg["kernel"] = "k_spec_waves" if st["spec_steps"] else "k_seq_waves (one wavefront)"
+                    if st["spec_steps"]:
+                        leg["speculation"] = {"steps": st["spec_steps"], "attempts_evaluated": st["spec_evaluated"],
+                                              "attempts_committed": st["spec_committed"],
+                                              "evaluated_per_committed": st["spec_evaluated"] / max(1, st["spec_committed"]),
+                                              "iterations_per_step": st["spec_committed"] / max(1, st["spec_steps"]),
+                                              "host_fallback_waves": st["host_fallback_waves"]}
                 f.close()
+                return leg
+
+            small_wave_leg(1, 2000)                      # (first launch of the kernel: code object load, LDS attribute)
+            legs["wave_1"] = small_wave_leg(1, 8000)
+            legs["wave_1_one_wavefront"] = small_wave_leg(1, 8000, spec="0")
+            legs["wave_1_100k_iterations"] = small_wave_leg(1, 100000)
+            small_wave_leg(1, 2000, optimize=True)
+            legs["wave_1_sff_star"] = small_wave_leg(1, 8000, optimize=True)
+            legs["wave_1_sff_star_one_wavefront"] = small_wave_leg(1, 8000, optimize=True, spec="0")
+            for wv, iters in ((64, 150000), (512, 1000000)):
+                legs["wave_%d" % wv] = small_wave_leg(wv, iters)
             out["wave_sweep"] = legs
             # does a large wave degrade the planner?  The same 30 k-node budget at wave 64 (close to the sequential
             # loop: the frontier holds thousands of nodes) and at the bench's wave

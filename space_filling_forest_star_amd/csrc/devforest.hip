@@ -657,6 +657,15 @@ __global__ __launch_bounds__(1024) void k_commit(ResolveArgs A, int n_bound) {
   // ---- 5. the last workgroup of the round: totals, the control block (the next round's active list = the slots of this
   // round that were not accepted, then the slots the iteration cap kept out of it: k_append writes it)
   if (clk) tk[3] = wall_clock64();
+  // the query kernel's clock bracket: every workgroup of it reported into one of 64 shards (DevForestView::qclk_sh)
+  unsigned long long q_end = 0ULL, q_beg = ~0ULL;
+  if (f.qclk_sh && threadIdx.x < 64) {
+    q_end = f.qclk_sh[threadIdx.x * 16]; q_beg = f.qclk_sh[threadIdx.x * 16 + 1];
+    for (int off = 32; off > 0; off >>= 1) {
+      const unsigned long long e2 = __shfl_xor(q_end, off), b2 = __shfl_xor(q_beg, off);
+      q_end = e2 > q_end ? e2 : q_end; q_beg = b2 < q_beg ? b2 : q_beg;
+    }
+  }
   unsigned long long tot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if ((int)threadIdx.x < b) {   // (every lower workgroup has published its counters long ago: one batch of loads)
     const unsigned long long* pp = f.wg_pub + (size_t)threadIdx.x * SFFK_PUB_WORDS;
@@ -706,6 +715,7 @@ __global__ __launch_bounds__(1024) void k_commit(ResolveArgs A, int n_bound) {
       K.segments_executed += tot[4];
       K.samples_executed += tot[5];
       K.work_items += (unsigned long long)work_items;
+      if (f.qclk_sh) { K.q_t0 = q_beg; K.q_t1 = q_end; }
       if (K.q_t1 > K.q_t0) { K.q_ticks += K.q_t1 - K.q_t0; K.q_launches += 1ULL; }
       K.app_n = n;                  // k_append applies this commit
       K.app_N0 = N0;

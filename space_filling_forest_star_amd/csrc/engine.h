@@ -301,6 +301,7 @@ struct DevEngine {
   bool status_copied[2] = {true, true};   // the slot's block came by a copy into h_ctrl[slot] (k_seq_waves, SFFGPU_NO_ZC_STATUS)
   // waves of one slot, speculated (k_spec_waves): scenario tree, control blocks, records (sffk::SpecArgs)
   DevBuf spec_tab, spec_area;
+  DevBuf qclk_sh;               // the query kernel's clock bracket, 64 shards (sffk::DevForestView::qclk_sh)
   int spec_n_sc = 0, spec_sets = 0, spec_tm = 0;
   bool spec_off = false;        // SFFGPU_SPEC=0, or a launch stalled (its workgroups were not resident together)
   int spec_depth = 3, spec_sets_want = 1, spec_test_stall = 0;   // (SFFGPU_SPEC_DEPTH / _SETS / SFFGPU_TEST_SPEC_STALL, read when the forest is created)

@@ -316,6 +316,7 @@ sffk::DevForestView Forest::dev_view() const {
   }
   static const int profile = getenv("SFFGPU_PROFILE") ? 1 : 0;
   v.profile = profile;
+  v.qclk_sh = d.qclk_sh.as<unsigned long long>();
   v.host_status = (d.zc_status && d.h_ctrl.p) ? d.h_ctrl.as<sffk::DevCtrl>() : nullptr;   // (hipHostMalloc: one address on both sides)
   v.kc_trace = d.kc_trace.as<unsigned long long>();
   v.kc_trace_round = getenv("SFFGPU_KC_TRACE") ? atoi(getenv("SFFGPU_KC_TRACE")) : -1;
@@ -505,6 +506,8 @@ void Forest::dev_upload_state() {
     d.ustate32.ensure(((size_t)wave + 64) * 4);
     d.wg_pub.ensure(((size_t)wave / 64 + 2) * SFFK_PUB_WORDS * 8);
     d.commit_seq.ensure(64);
+    d.qclk_sh.ensure(64 * 16 * 8);
+    HIPCHK(hipMemsetAsync(d.qclk_sh.p, 0, 64 * 16 * 8, c.stream));
     d.ord_hist.ensure((size_t)SFFK_ORD_BUCKETS * 4);
     d.ord_start.ensure((size_t)SFFK_ORD_BUCKETS * 4);
     d.ord_key.ensure((size_t)wave * 4);
@@ -954,6 +957,7 @@ static sffk::SampleLaunch dev_sample_launch(Forest& F, const DevRoundBufs& B) {
   P.dv.parent_out = (d.round_parity ? d.d_parent2 : d.d_parent).as<int32_t>();
   P.dv.force_out = d.d_force.as<uint8_t>();
   P.dv.qclk = reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(d.ctrl.p) + offsetof(sffk::DevCtrl, q_t0));
+  P.dv.qclk_sh = d.qclk_sh.as<unsigned long long>();
   P.dv.ord = V.ord;
   P.node_pos = c.spos.as<double>();
   P.n = B.n;
@@ -1019,6 +1023,7 @@ void Forest::dev_enqueue_round_eval(void* send_dev, bool sample) {
   ca.ctrl = B.d_rctrl;
   ca.dev_n = dev_n;
   ca.qclk = qclk;
+  ca.qclk_sh = d.qclk_sh.as<unsigned long long>();
   if (V.ord.hist) {
     ca.ord_valid = reinterpret_cast<const int32_t*>(reinterpret_cast<char*>(d.ctrl.p) + offsetof(sffk::DevCtrl, ord_valid));
     ca.ord_nslots = reinterpret_cast<const int32_t*>(reinterpret_cast<char*>(d.ctrl.p) + offsetof(sffk::DevCtrl, n_slots));

@@ -254,6 +254,7 @@ struct DevRound {
   int32_t* parent_out;         // n: expanded node of every sample (read by k_classify)
   uint8_t* force_out;          // n: its ForceChildren flag
   unsigned long long* qclk;    // DevCtrl::q_t0 / q_t1, reset here for the query kernel that follows
+  unsigned long long* qclk_sh; // ... and the 64 shards EVERY workgroup of that kernel reports into (DevForestView::qclk_sh)
   OrderView ord;               // the wave's first sampling launch gives the slots their sorted positions (hist == null: off)
 };
 
@@ -364,6 +365,7 @@ struct ClassifyArgs {
   int wide;                 // the forest asks for k_query_classify (many neighbours per sample: see Forest::query_wide)
   const int32_t* dev_n;     // device mode: {n, halt} (n above is then the launch bound only)
   unsigned long long* qclk; // device mode: {first wave in, last wave out} clock bracket of the query kernel
+  unsigned long long* qclk_sh;   // ... its 64 shards (DevForestView::qclk_sh)
   // fused clearance cull (k_query_classify): the wave that wrote a sample's edge tasks looks the clearance bits of
   // their samples (and of the sample's own pose) up right away and appends only the (edge, 64-sample chunk, mask) /
   // pose items that need the exact test to `items` (ctrl[2] = count) - no work-list compaction, no cull kernel
@@ -510,6 +512,11 @@ struct DevForestView {
                                // [3] = k_wave_end_wide launches that ended a wave, [4] its workgroups that are through
   unsigned long long* kc_trace; int32_t kc_trace_round;   // SFFGPU_KC_TRACE=<round>: 8 clock reads per workgroup of that round's k_commit
   DevCtrl* host_status;        // SFFK_STATUS_RING control blocks in pinned host memory (device-visible); null = the host copies
+  // Device-clock bracket of the neighbour-query kernel, by EVERY workgroup (round 6; round 5 sampled every 16th one and so
+  // could miss the last workgroup out): 64 shards of {latest end, earliest start} on lines of their own (16 words apart) -
+  // thread 0 of workgroup b adds its two clock reads to shard b % 64 with atomics that return nothing; the sampling launch
+  // in front resets them, k_commit's last workgroup folds them into DevCtrl::q_t0 / q_t1
+  unsigned long long* qclk_sh;
   int32_t profile;             // SFFGPU_PROFILE: the single-workgroup kernels read their phase clocks (a clock read is a scalar
                                // memory round trip: a dozen of them is microseconds)
 };

@@ -2532,8 +2532,8 @@ __global__ __launch_bounds__(64 * QC_WAVES) __attribute__((amdgpu_waves_per_eu(Q
   const int i = blockIdx.x * QC_WAVES + wave;
   if (i >= A.n) return;
   // (every 16th workgroup reports: ten thousand atomics on one word would cost more than the kernel itself)
-  const bool clocked = A.qclk && (blockIdx.x & 15) == 0 && threadIdx.x == 0;
-  if (clocked) atomicMin(A.qclk, wall_clock64());
+  const bool clocked = A.qclk_sh && threadIdx.x == 0;
+  if (clocked) atomicMin(A.qclk_sh + (blockIdx.x & 63) * 16 + 1, wall_clock64());
   [[maybe_unused]] const bool qdbg_on = (blockIdx.x & 15) == 0 && lane == 0;
   [[maybe_unused]] const unsigned long long qt0 = DBG_T();
   [[maybe_unused]] unsigned long long qt1 = qt0, qt_fl = 0;
@@ -2866,8 +2866,9 @@ __global__ __launch_bounds__(64 * QC_WAVES) __attribute__((amdgpu_waves_per_eu(Q
   if (lane == 0) {
     A.rec_flags[i] = flags;
     A.rec_nnb[i] = nnb;
-    if (clocked) atomicMax(A.qclk + 1, wall_clock64());
   }
+  // (every workgroup: its last wavefront out is not known, so every wavefront's lane 0 reports)
+  if (lane == 0 && A.qclk_sh) atomicMax(A.qclk_sh + (blockIdx.x & 63) * 16, wall_clock64());
 }
 
 // ------------------------------------------------------------------ block query kernel
@@ -3005,8 +3006,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB_OCC))) v
     for (int q = 0; q < S; ++q) any = any || s_map[q] >= 0;
     if (!any) return;
   }
-  const bool clocked = A.qclk && (blockIdx.x & 15) == 0 && tid == 0;
-  if (clocked) atomicMin(A.qclk, wall_clock64());
+  const bool clocked = A.qclk_sh && tid == 0;   // (every workgroup, into its shard: see DevForestView::qclk_sh)
+  if (clocked) atomicMin(A.qclk_sh + (blockIdx.x & 63) * 16 + 1, wall_clock64());
   [[maybe_unused]] const bool qdbg_on = (blockIdx.x & 15) == 0 && tid == 0;
   [[maybe_unused]] unsigned long long qtp = DBG_T();
 #ifdef SFFK_DEBUG_COUNTERS
@@ -3459,7 +3460,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(QB_OCC))) v
 #ifdef SFFK_DEBUG_COUNTERS
   QDBG(10, clock64() - qb_c0); QDBG(11, wall_clock64() - qb_r0);   // shader clock ticks over 100 MHz ticks: the clock the launch ran at
 #endif
-  if (clocked) atomicMax(A.qclk + 1, wall_clock64());
+  if (clocked) {   // (thread 0 is through its workgroup's last phase: the others are at most a wavefront's tail behind)
+    atomicMax(A.qclk_sh + (blockIdx.x & 63) * 16, wall_clock64());
+  }
 }
 
 // Exact collision work of a round straight from the survivor list: persistent wavefronts, wave w takes items

@@ -213,6 +213,7 @@ __device__ __forceinline__ void sample_steer_one(int tid, int i, int slot, const
     if (dv.ctrl->halt) return;
     n = dv.ctrl->n_act;
     if (tid == 0 && dv.qclk) { dv.qclk[0] = ~0ULL; dv.qclk[1] = 0ULL; }
+    if (dv.qclk_sh && tid < 128) dv.qclk_sh[(tid >> 1) * 16 + (tid & 1)] = (tid & 1) ? ~0ULL : 0ULL;
   }
   if (tmp.cnt) {
     // per-round housekeeping folded into this launch: hit counters, the work-list cursor, and NaN
