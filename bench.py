@@ -33,7 +33,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-PMC_SUMMARY = os.path.join(ROOT, "profiles", "r5_bench_pmc_summary.json")
+PMC_SUMMARY = os.path.join(ROOT, "profiles", "r6_bench_pmc_summary.json")
 SWEEP_PMC_SUMMARY = os.path.join(ROOT, "profiles", "r5_sweep_pmc_summary.json")   # profiles/collect_sweep.sh
 
 
@@ -48,6 +48,12 @@ def parse_args():
     ap.add_argument("--budget", type=int, default=1000000)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--force-dist", action="store_true", help="run the RCCL record exchange even with one rank")
+    ap.add_argument("--torch-exchange", action="store_true",
+                    help="--force-dist with one rank: the caller (Python, torch.distributed) issues the collective of every round "
+                         "instead of the library's own RCCL communicator - a host-paced figure, kept for comparison")
+    ap.add_argument("--scaled-wave", type=int, default=0,
+                    help="--force-dist with one rank: also run the job at this wave size (the wave that grows with the rank count: "
+                         "8 ranks x 8192 slots = 65536) and print what ONE OF 8 RANKS would spend per round - measured one-GPU terms")
     ap.add_argument("--native-rccl", action="store_true",
                     help="sharded runs: the library drives the exchange itself (ncclAllGather on its own communicator, "
                          "whole waves enqueued ahead) instead of torch.distributed per round; opt-in until validated on "
@@ -129,7 +135,9 @@ def main():
     if world != args.gpus:
         sys.exit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with --nproc-per-node %d)" % (args.gpus, world, args.gpus))
     distributed = world > 1 or args.force_dist
-    if args.native_rccl:
+    if args.native_rccl or (args.force_dist and world == 1 and not args.torch_exchange):
+        # (one rank: the library's own communicator - whole waves enqueued by the library, no Python between the rounds; with
+        # more ranks it is opt-in: ncclAllGather on a communicator of the library's own has never run with more than one rank)
         os.environ["SFFGPU_NATIVE_RCCL"] = "1"
     if args.force_dist and world == 1:
         os.environ["SFFGPU_TEST_EXCHANGE_SELF"] = "1"   # pack -> ncclAllGather (one rank) -> unpack in every round
@@ -214,15 +222,18 @@ def main():
         sweeps = s1["sweeps"] - s0["sweeps"]
         sweep_nodes = s1["sweep_nodes"] - s0["sweep_nodes"]
         event_ms = sweep_ms
-        # the device engine brackets the query kernel of EVERY round on the device clock (first wavefront in .. last
-        # wavefront out): that is the duration rocprofv3 reports; a HIP event pair adds ~3 us around a ~20 us kernel
+        # `frac` is priced with the HIP events the contract names (on the library's launch stream, every 32nd wave launched
+        # kernel by kernel; ~1.5 us ABOVE the rocprofv3 kernel duration of the same command, profiles/r6_bench_kernel_stats.csv).
+        # Beside it: the device-clock bracket of EVERY launch - since round 6 every workgroup reports its first / last clock
+        # read into one of 64 shards (round 5 sampled every 16th workgroup and so could miss the last one out) - which is
+        # first instruction in .. last instruction out, ~2 us BELOW rocprofv3's dispatch begin .. end.  The rocprofv3 average
+        # itself is printed when the committed summary was collected with exactly this run's arguments.
         clock_launches = s1["query_clock_launches"] - s0["query_clock_launches"]
-        if clock_launches > 0 and clock_launches == sweeps:
-            sweep_ms = s1["query_clock_ms"] - s0["query_clock_ms"]
+        clock_ms = (s1["query_clock_ms"] - s0["query_clock_ms"]) if (clock_launches > 0 and clock_launches == sweeps) else None
         achieved = (24.0 * sweep_nodes / (sweep_ms * 1e-3)) / 1e9 if sweep_ms > 0 else 0.0
         # HBM-side bytes per launch of the neighbour-query kernel: only from a PMC summary that was collected
         # (separate rocprofv3 --pmc passes, profiles/collect.sh) with exactly the arguments of this run
-        traffic, traffic_source, sweep_traffic = None, None, None
+        traffic, traffic_source, sweep_traffic, rocprof_us = None, None, None, None
         run_key = {"steps": args.steps, "warmup": args.warmup, "wave": args.wave, "waves_per_step": B,
                    "budget": args.budget, "seed": args.seed, "gpus": world}
         try:
@@ -231,6 +242,7 @@ def main():
                 k = pm.get("query_kernel", "sffk::k_query_block")
                 traffic = 1024.0 * (2.0 * pm["FETCH_SIZE"][k]["avg_KiB_per_launch"] + pm["WRITE_SIZE"][k]["avg_KiB_per_launch"])
                 traffic_source = "profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command; 2 x FETCH + WRITE (gfx950 correction of MI355X_MICROARCH.md)" % os.path.basename(PMC_SUMMARY)
+                rocprof_us = pm.get("kernel_trace_avg_us", {}).get(pm.get("query_kernel", "sffk::k_query_block"))
                 k = "sffk::k_sweep"
                 if k in pm["FETCH_SIZE"]:
                     sweep_traffic = 1024.0 * (2.0 * pm["FETCH_SIZE"][k]["avg_KiB_per_launch"] + pm["WRITE_SIZE"][k]["avg_KiB_per_launch"])
@@ -280,8 +292,10 @@ def main():
                 "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                 "traffic": traffic, "traffic_source": traffic_source,
                 "launches": int(sweeps), "avg_launch_us": 1e3 * sweep_ms / max(1, sweeps),
-                "timing": "device clock around every launch" if sweep_ms is not event_ms else "HIP events, every 8th round",
-                "avg_launch_us_by_hip_events": 1e3 * event_ms / max(1, sweeps),
+                "timing": "HIP events on the launch stream (every 32nd wave is launched kernel by kernel), scaled to all launches",
+                "avg_launch_us_by_device_clock_every_workgroup": (1e3 * clock_ms / max(1, sweeps)) if clock_ms is not None else None,
+                "avg_launch_us_by_rocprofv3": rocprof_us,
+                "own_bytes_GBps": (traffic / (1e-3 * sweep_ms / max(1, sweeps)) / 1e9) if (traffic and sweep_ms > 0) else None,
                 "avg_nodes_per_launch": sweep_nodes / max(1, sweeps),
                 "avg_queries_per_launch": (s1["sweep_queries"] - s0["sweep_queries"]) / max(1, sweeps),
             },
@@ -301,7 +315,43 @@ def main():
             out["dist_budget_us_per_round"] = {
                 "replicated": rep, "sharded_over_ranks": shd, "pack_gather_unpack": exc, "ranks": world,
                 "amdahl_speedup_bound_at_8_ranks": (rep + shd) / (rep + shd / 8.0 + exc) if rep + shd > 0 else None,
+                "exchange_driver": "the library's own RCCL communicator (whole waves enqueued by the library)" if getattr(ctx, "rccl", None)
+                else "torch.distributed from Python between the library's round calls (host-paced: the figure includes the host's gaps)",
                 "note": "measured with %d rank(s); the all-gather of 8 ranks moves 8 x the bytes over xGMI" % world}
+            if world == 1 and args.scaled_wave > 0:
+                # The wave that grows with the rank count: strong scaling at a fixed wave is bounded by the part
+                # every rank repeats; with wave = ranks x a fixed share the sharded kernels of a rank stay the size they are
+                # on one GPU at that share while the job needs fewer rounds.  ONE GPU runs the whole job at the scaled wave
+                # here (all of the sharded work itself): rounds, replicated time, sharded time and exchange per round are
+                # measured, the time of one of R ranks is composed from them - an Amdahl composition of one-GPU terms,
+                # not a multi-GPU measurement.  The forest is the oracle's at that wave
+                # (tests/golden/full_size_run_w65536.json).
+                R = 8
+                fs = make_forest(wave=args.scaled_wave)
+                q0 = fs.stats()
+                c0 = time.perf_counter()
+                run_waves(fs, 0)
+                torch.cuda.synchronize()
+                dts = time.perf_counter() - c0
+                q1 = fs.stats()
+                fs.close()
+                rs = max(1, q1["sweeps"] - q0["sweeps"])
+                rep_s = 1e3 * ((q1["sample_ms"] - q0["sample_ms"]) + (q1["commit_ms"] - q0["commit_ms"])) / rs
+                shd_s = 1e3 * ((q1["sweep_ms"] - q0["sweep_ms"]) + (q1["collide_ms"] - q0["collide_ms"])) / rs
+                exc_s = 1e3 * (q1["exchange_ms"] - q0["exchange_ms"]) / rs
+                timed = rep_s + shd_s + exc_s                       # (the per-round kernels; the per-wave ones are in `other`)
+                other = 1e3 * dts / rs * 1e3 - timed if dts > 0 else 0.0
+                per_rank = rep_s + shd_s / R + exc_s + max(0.0, other)
+                out["wave_scaled_budget"] = {
+                    "wave": args.scaled_wave, "ranks_modelled": R, "slots_per_rank": args.scaled_wave // R,
+                    "nodes": q1["n_nodes"], "waves": int(q1["waves"] - q0["waves"]), "rounds": int(rs),
+                    "one_gpu_seconds_at_this_wave": dts, "one_gpu_nodes_per_s_at_this_wave": (q1["n_nodes"] - q0["n_nodes"]) / dts,
+                    "us_per_round": {"replicated": rep_s, "sharded_over_ranks": shd_s, "pack_gather_unpack": exc_s,
+                                     "per_wave_kernels_and_gaps": max(0.0, other)},
+                    "modelled_seconds_of_one_of_%d_ranks" % R: per_rank * rs * 1e-6,
+                    "modelled_speedup_over_the_one_gpu_job_at_wave_%d" % args.wave: elapsed / (per_rank * rs * 1e-6),
+                    "kind": "Amdahl composition of measured ONE-GPU terms (no multi-GPU hardware here); the exchange is the "
+                            "one-rank figure - 8 ranks move 8 x the bytes"}
         if world == 1 and not args.no_sweep_micro:
             # the linear k-NN sweep on its own (SURVEY.md 8(d) micro-benchmark, see profiles/sweep_microbench.py): N
             # uniform nodes, ONE query per pass, radius for ~32 neighbours; kernel time from the library's HIP events

@@ -23,7 +23,7 @@ grep -E "^\{\"metric\"" $out/${tag}_trace.log | tail -1 > $out/${tag}_bench_line
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --pmc $c --output-format csv -d $out/${tag}_pmc_$c -o p -- python3 $BENCH $LEAN > $out/${tag}_pmc_$c.log 2>&1
 done
-python3 $root/profiles/summarize_pmc.py --bench-args "--steps 20 --warmup 5 $extra" \
+python3 $root/profiles/summarize_pmc.py --kernel-stats $out/${tag}_kernel_stats.csv --bench-args "--steps 20 --warmup 5 $extra" \
   $out/${tag}_pmc_FETCH_SIZE/p_counter_collection.csv $out/${tag}_pmc_WRITE_SIZE/p_counter_collection.csv > $out/${tag}_pmc_summary.json
 cd $root && timeout 600 python3 $BENCH > $out/${tag}_bench_full.log 2>&1
 tail -1 $out/${tag}_bench_full.log > $out/${tag}_bench_line.json

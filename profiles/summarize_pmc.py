@@ -11,6 +11,7 @@ import sys
 ap = argparse.ArgumentParser()
 ap.add_argument("--bench-args", default="")
 ap.add_argument("--query-kernel", default="sffk::k_query_block")
+ap.add_argument("--kernel-stats", default="", help="rocprofv3 --kernel-trace --stats summary (t_kernel_stats.csv) of the same command: per-kernel average durations")
 ap.add_argument("files", nargs="+")
 a = ap.parse_args()
 
@@ -35,4 +36,6 @@ for path in a.files:
         acc[k][0] += 1
         acc[k][1] += float(r["Counter_Value"])
     out[name] = {k: {"launches": v[0], "sum_KiB": v[1], "avg_KiB_per_launch": v[1] / max(1, v[0])} for k, v in acc.items()}
+if a.kernel_stats:
+    out["kernel_trace_avg_us"] = {r["Name"].split("(")[0].replace("void ", ""): float(r["AverageNs"]) / 1e3 for r in csv.DictReader(open(a.kernel_stats))}
 json.dump(out, sys.stdout, indent=1)

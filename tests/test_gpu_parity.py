@@ -400,15 +400,18 @@ def test_gpu_matches_committed_golden_runs(S, ctx, golden_dir):
         r.close()
 
 
-def test_full_size_run_at_the_bench_wave_equals_the_oracle(S, ctx, golden_dir):
+@pytest.mark.parametrize("fixture", ["full_size_run_w16384.json", "full_size_run_w65536.json"])
+def test_full_size_run_at_the_bench_wave_equals_the_oracle(S, ctx, golden_dir, fixture):
     """The headline job exactly as bench.py runs it (waves of 16 384 slots, to the 1 M-node budget) against the CPU
     oracle's run of the same configuration (tests/golden/full_size_run_w16384.json, FULL_SIZE_WAVE=16384
-    FULL_SIZE_WAVES=0 tests/golden/make_full_size.py): fingerprint over every node, counters, checksums."""
+    FULL_SIZE_WAVES=0 tests/golden/make_full_size.py): fingerprint over every node, counters, checksums.  The same at
+    waves of 65 536 slots - the wave that grows with the rank count (8 ranks x 8 192 slots; bench.py --force-dist
+    --scaled-wave 65536), the largest the device engine takes."""
     import json
     import os
-    path = os.path.join(golden_dir, "full_size_run_w16384.json")
+    path = os.path.join(golden_dir, fixture)
     if not os.path.exists(path):
-        pytest.skip("tests/golden/full_size_run_w16384.json not generated")
+        pytest.skip("tests/golden/%s not generated" % fixture)
     g = json.load(open(path))
     sc, w = load_world(ctx, "dense3d")
     roots = common.free_roots(lambda p: int(ctx.collide_poses(p[None, :])[0]), sc["limits"], 10, seed=1)
