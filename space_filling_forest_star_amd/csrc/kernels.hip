@@ -1393,6 +1393,9 @@ __global__ __launch_bounds__(256) void k_clear_scatter(EnvView env, ClearBuildAr
       const long long ix = l - base;
       const double c[3] = {env.clear_org[0] + ((double)ix + 0.5) * h, env.clear_org[1] + ((double)iy + 0.5) * h,
                            env.clear_org[2] + ((double)iz + 0.5) * h};
+      // (a cell farther from the triangle's PLANE than the reach is farther from the triangle: six flops instead of the
+      // closest-point computation for most cells of a slanted triangle's box - the launch was as long as those boxes)
+      if (env.tri_plane && plane_clear(env.tri_plane + 5 * (size_t)t, c, reach)) continue;
       // (one closest-point computation, compared with both radii: tri_far's arithmetic)
       double dd = 0.0, mag = 0.0;
       const bool known = tri_dist2(T, c, dd, mag);
