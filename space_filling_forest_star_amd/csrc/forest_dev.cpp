@@ -1341,6 +1341,7 @@ bool Forest::seq_eligible() const {
 // per scenario and attempt), cut where the grid would no longer be resident at once; SFF*: the chain of all-fail
 // scenarios.  SFFGPU_SPEC_SETS sets of workers take the steps in turn (default 1).  SFFGPU_SPEC=0 keeps the single
 // wavefront (k_seq_waves).  All read when the forest is created (forest.cpp).
+static const size_t SPEC_HEAD = 4096;   // bytes in front of the records: 4 x 64 control-block granules, the step word
 bool Forest::spec_setup() {
   DevEngine& d = dev;
   if (d.spec_off) return false;
@@ -1380,8 +1381,8 @@ bool Forest::spec_setup() {
   d.spec_n_sc = (int)tab.size();
   d.spec_sets = sets;
   d.spec_tm = TM;
-  // control blocks (16 granules per set, 4 sets at most) | cur_step (a line of its own) | records
-  d.spec_area.ensure(1024 + (size_t)sets * d.spec_n_sc * TM * (SFFK_SPEC_REC * 8 + 8) + 2048);   // (+ the debugging words, SpecArgs::hb)
+  // control blocks (64 granules per set, 4 sets at most) | cur_step (a line of its own) | records
+  d.spec_area.ensure(SPEC_HEAD + (size_t)sets * d.spec_n_sc * TM * (SFFK_SPEC_REC * 8 + 8) + 2048);   // (+ the debugging words, SpecArgs::hb)
   return true;
 }
 
@@ -1466,12 +1467,12 @@ void Forest::run_device_seq(int max_waves) {
       sa.n_slots = d.spec_n_sc * d.spec_tm;
       sa.n_sets = d.spec_sets;
       sa.base = d.spec_area.as<unsigned long long>();
-      sa.cur_step = reinterpret_cast<int32_t*>(d.spec_area.as<uint8_t>() + 768);
-      sa.rec = d.spec_area.as<unsigned long long>() + 128;
+      sa.cur_step = reinterpret_cast<int32_t*>(d.spec_area.as<uint8_t>() + SPEC_HEAD - 256);
+      sa.rec = reinterpret_cast<unsigned long long*>(d.spec_area.as<uint8_t>() + SPEC_HEAD);
       sa.timeout_ticks = 20000000ULL;   // 200 ms
       if (d.spec_test_stall && st.spec_steps == 0 && d.last.spec_steps == 0) sa.test_stall = d.spec_test_stall;
       const size_t rec_bytes = (size_t)sa.n_sets * sa.n_slots * SFFK_SPEC_REC * 8;
-      if (getenv("SFFGPU_PROFILE")) sa.hb = reinterpret_cast<unsigned long long*>(d.spec_area.as<uint8_t>() + 1024 + rec_bytes);
+      if (getenv("SFFGPU_PROFILE")) sa.hb = reinterpret_cast<unsigned long long*>(d.spec_area.as<uint8_t>() + SPEC_HEAD + rec_bytes);
       HIPCHK(hipMemsetAsync(d.spec_area.p, 0, d.spec_area.cap, c.stream));
       sffk::launch_spec_waves(c.stream, sa);
     } else {
@@ -1492,7 +1493,7 @@ void Forest::run_device_seq(int max_waves) {
     if (spec && getenv("SFFGPU_PROFILE")) {
       const int nw = d.spec_sets * d.spec_n_sc * d.spec_tm;
       unsigned long long wq[22];
-      HIPCHK(hipMemcpy(wq, d.spec_area.as<uint8_t>() + 1024 + (size_t)nw * SFFK_SPEC_REC * 8 + ((size_t)nw + 64) * 8, sizeof wq, hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(wq, d.spec_area.as<uint8_t>() + SPEC_HEAD + (size_t)nw * SFFK_SPEC_REC * 8 + ((size_t)nw + 64) * 8, sizeof wq, hipMemcpyDeviceToHost));
       const unsigned long long* wp = wq + 1;
       const double n = (double)std::max<unsigned long long>(1, wq[0]) * 100.0;
       fprintf(stderr, "[sffgpu k_spec_waves worker us per ACCEPTED attempt, this launch] control block -> scenario + node %.2f | node data + words %.2f sample %.2f "
@@ -1507,7 +1508,7 @@ void Forest::run_device_seq(int max_waves) {
         fprintf(stderr, "[sffgpu k_spec_waves] a record did not arrive: back to k_seq_waves\n");
         const int nw = d.spec_sets * d.spec_n_sc * d.spec_tm;
         std::vector<unsigned long long> hb((size_t)nw + 8 + 34);
-        HIPCHK(hipMemcpy(hb.data(), d.spec_area.as<uint8_t>() + 1024 + (size_t)nw * SFFK_SPEC_REC * 8, hb.size() * 8, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(hb.data(), d.spec_area.as<uint8_t>() + SPEC_HEAD + (size_t)nw * SFFK_SPEC_REC * 8, hb.size() * 8, hipMemcpyDeviceToHost));
         fprintf(stderr, "  leader waited at step %llu scenario %llu attempt %llu set %llu; granules seen:", hb[nw], hb[nw + 1], hb[nw + 2], hb[nw + 3]);
         for (int q = 0; q < 34; ++q) fprintf(stderr, " %llx", hb[nw + 8 + q]);
         fprintf(stderr, "\n  workers (step:phase):");

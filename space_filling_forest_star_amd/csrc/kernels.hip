@@ -4776,7 +4776,13 @@ __device__ __forceinline__ double sp_f64(uint32_t lo, uint32_t hi) {
 #define SPB_NN 4
 #define SPB_ITER 5
 #define SPB_EF 6
-#define SPB_USED 7
+#define SPB_NE 7       // frontier positions erased since the array was last compacted (SPB_ER + ...)
+#define SPB_FNPC 8     // entries of the array when it was last compacted
+#define SPB_NNC 9      // nodes then: the array's entry FNPC + i is node NNC + i
+#define SPB_ER 16      // the erased positions, ascending (SP_ER_MAX)
+#define SPB_USED 32
+#define SP_ER_MAX 16
+#define SP_BASE 64     // granules per control block
 #define SP_QUIT 0xffffffffu
 
 // LDS words two wavefronts of a workgroup hand to each other (in-order LDS operations of a wavefront; the words themselves
@@ -4796,6 +4802,7 @@ __global__ __launch_bounds__(OPT ? 192 : 128) void k_spec_waves(SpecArgs S) {
   __shared__ double p_pos[SFFK_SPEC_DEPTH * 6], p_best[SFFK_SPEC_DEPTH];
   __shared__ int32_t p_tree[SFFK_SPEC_DEPTH];
   __shared__ uint32_t s_rw[OPT ? SFFK_STAR_KC * 5 : 1];
+  __shared__ int32_t s_er[SP_ER_MAX + SFFK_SPEC_DEPTH + 1];   // erased frontier positions, ascending (leader: since the last compaction; worker: + its scenario's)
   // the job the worker's first wavefront hands to its second one right after the sample is drawn: the neighbour query
   // (and, SFF*, the k nearest of the sample's tree) run BESIDE the pose check and the parent edge
   __shared__ int32_t j_seq, j_cancel, j_done, j_done_k, j_nhit, j_mine, j_k, j_tcnt, j_nmem, j_nn0, j_snn, j_step;
@@ -4827,32 +4834,51 @@ __global__ __launch_bounds__(OPT ? 192 : 128) void k_spec_waves(SpecArgs S) {
     int waves_done = 0;
     bool stop = false;
     const unsigned long long epoch = c->epoch;
-    // The frontier array does not change while a step runs (its workers read it whenever they get to it): the erases of
-    // the step's failed waves are kept as a sorted list of positions (the workers model them the same way) and applied
-    // when the step is over; accepted nodes go behind the step's first fn entries.
-    int fn_base = fn, nn_base = n_nodes, ner = 0, na_l = 0, erl[SFFK_SPEC_DEPTH];
-    for (int e = 0; e < SFFK_SPEC_DEPTH; ++e) erl[e] = 0x7fffffff;
-    auto flush_erases = [&]() {
-      int pfn = fn_base + na_l;
-      for (int e = SFFK_SPEC_DEPTH - 1; e >= 0; --e) {
-        if (e >= ner) continue;
-        int at = 0x7fffffff;
-        for (int q = 0; q < SFFK_SPEC_DEPTH; ++q) if (q == e) at = erl[q];
-        // (no wait between the blocks: a block's stores go below everything a later block loads, and the loads of an
-        // earlier block have returned - loads return in order - before a later block's stores can be issued)
-        for (int j0 = at; j0 < pfn - 1; j0 += 1024) {
+    // The frontier ARRAY only ever grows while the launch runs (its workers read it whenever they get to it): new nodes go
+    // behind its last entry, and the positions of the nodes that left it are kept as a sorted list (the workers get the list
+    // with the control block and map their picks through it, adding the erases their scenario assumes).  When the list is
+    // nearly full - and when the launch ends - the array is compacted in one pass.  Since the last compaction: fn_pc entries
+    // then, nn_c nodes then (entry fn_pc + i holds node nn_c + i), ner erased positions in s_er.
+    int fn_pc = fn, nn_c = n_nodes, ner = 0, nn_base = n_nodes;
+    auto er_map = [&](int logical) -> int {      // position in the array of the logical-th entry that is still there
+      int idx = logical;
+      for (int e = 0; e < ner; ++e) if (s_er[e] <= idx) ++idx;
+      return idx;
+    };
+    auto er_insert = [&](int idx) {
+      SP_WAVE_SYNC();
+      if (lane == 0) {
+        int at = ner;
+        while (at > 0 && s_er[at - 1] > idx) { s_er[at] = s_er[at - 1]; --at; }
+        s_er[at] = idx;
+      }
+      ++ner;
+      SP_WAVE_SYNC();
+    };
+    auto compact = [&]() {
+      if (ner > 0) {
+        const int pfn = fn_pc + (n_nodes - nn_c);
+        // (one pass from the first erased position: an entry moves down by the number of erased positions below it; a block's
+        // stores go below everything a later block loads, and loads return in order: no wait between the blocks)
+        const int first = s_er[0];
+        for (int j0 = first; j0 < pfn; j0 += 1024) {
           int v[16];
 #pragma unroll
-          for (int u = 0; u < 16; ++u) { const int j = j0 + 64 * u + lane; v[u] = sq_i32(frontier + (j < pfn - 1 ? j : pfn - 2) + 1); }
+          for (int u = 0; u < 16; ++u) { const int j = j0 + 64 * u + lane; v[u] = sq_i32(frontier + (j < pfn ? j : pfn - 1)); }
 #pragma unroll
-          for (int u = 0; u < 16; ++u) { const int j = j0 + 64 * u + lane; if (j < pfn - 1) wt_i32(frontier + j, v[u]); }
+          for (int u = 0; u < 16; ++u) {
+            const int j = j0 + 64 * u + lane;
+            if (j >= pfn) continue;
+            int below = 0;
+            bool gone = false;
+            for (int e = 0; e < ner; ++e) { const int x = s_er[e]; below += x < j ? 1 : 0; gone = gone || x == j; }
+            if (!gone) wt_i32(frontier + j - below, v[u]);
+          }
         }
-        sq_drain();
-        --pfn;
       }
-      for (int e = 0; e < SFFK_SPEC_DEPTH; ++e) erl[e] = 0x7fffffff;
-      ner = 0; na_l = 0; fn_base = fn; nn_base = n_nodes;
+      ner = 0; fn_pc = fn; nn_c = n_nodes;
       sq_drain();
+      SP_WAVE_SYNC();
     };
     // phase clocks (10 ns ticks, SFFGPU_PROFILE): publish, wait for a wave's first record, its other records, the accepted
     // node, closed list + termination, the erases
@@ -4871,8 +4897,13 @@ __global__ __launch_bounds__(OPT ? 192 : 128) void k_spec_waves(SpecArgs S) {
         v = lane == SPB_NN ? (uint32_t)n_nodes : v;
         v = lane == SPB_ITER ? (uint32_t)iter : v;
         v = lane == SPB_EF ? (uint32_t)empty_frontier : v;
-        if (lane < 16) wt_u64(S.base + 16 * set + lane, sp_gran(step, v));
+        v = lane == SPB_NE ? (uint32_t)ner : v;
+        v = lane == SPB_FNPC ? (uint32_t)fn_pc : v;
+        v = lane == SPB_NNC ? (uint32_t)nn_c : v;
+        if (lane >= SPB_ER && lane < SPB_ER + SP_ER_MAX) v = lane - SPB_ER < ner ? (uint32_t)s_er[lane - SPB_ER] : 0u;
+        wt_u64(S.base + SP_BASE * set + lane, sp_gran(step, v));
         if (lane == 0) wt_i32(S.cur_step, (int)step);
+        nn_base = n_nodes;
       }
       lap(0);
       if (sq_i32(A.grid_ovf_src) > A.grid_ovf_limit) { stop = true; }   // (once per step: the list has room for a step's nodes)
@@ -4891,9 +4922,8 @@ __global__ __launch_bounds__(OPT ? 192 : 128) void k_spec_waves(SpecArgs S) {
         unsigned long long cur2 = cursor, rdw = 0;
         int pick;
         do { pick = sq_lemire(f.ring[cur2 & f.ring_mask], (unsigned long long)pool); ++cur2; if (pick < 0) ++rdw; } while (pick < 0);
-        const bool own = !use_closed && pick >= fn_base - ner;          // (a node of this step: no scenario models that)
-        int idx = pick;
-        if (!use_closed && !own) for (int e = 0; e < SFFK_SPEC_DEPTH; ++e) if (e < ner && erl[e] <= idx) ++idx;
+        const int idx = use_closed ? pick : er_map(pick);
+        const bool own = !use_closed && idx >= fn_pc + (nn_base - nn_c);   // (a node of this step: no scenario models that)
         const unsigned long long* rec0 = S.rec + ((size_t)set * S.n_slots + (size_t)sc * TM) * SFFK_SPEC_REC;
         // row 0 of the scenario's records, one granule per lane and attempt; all asked for together
         unsigned long long gr[8];
@@ -4946,7 +4976,7 @@ __global__ __launch_bounds__(OPT ? 192 : 128) void k_spec_waves(SpecArgs S) {
           }
           node = (int)s_row[SPG_NODE]; fl_node = (int)s_row[SPG_FL];
         } else {                                 // (no attempt left: the wave only closes its node)
-          node = use_closed ? sq_i32(f.closed + pick) : (own ? nn_base + (pick - (fn_base - ner)) : sq_i32(frontier + idx));
+          node = use_closed ? sq_i32(f.closed + pick) : (idx >= fn_pc ? nn_c + (idx - fn_pc) : sq_i32(frontier + idx));
           fl_node = sq_u8(f.nflag + node);
         }
         cursor = cur2; redraws += rdw; ++waves;
@@ -5037,7 +5067,7 @@ __global__ __launch_bounds__(OPT ? 192 : 128) void k_spec_waves(SpecArgs S) {
             const float qf = (float)sp_f64(s_row[SPG_QP + 2 * fk], s_row[SPG_QP + 2 * fk + 1]);
             if (lane == 16) wt_i32(A.st.tree + o, mine);
             else if (lane == 17) wt_i32(f.parent + o, par_new);
-            else if (lane == 18) wt_i32(frontier + fn_base + na_l, idn);
+            else if (lane == 18) wt_i32(frontier + fn_pc + (idn - nn_c), idn);
             else if (lane >= 19 && lane < 25) {
               float* col = fk == 0 ? A.st.x : (fk == 1 ? A.st.y : (fk == 2 ? A.st.z : (fk == 3 ? A.st.yaw : (fk == 4 ? A.st.pitch : A.st.roll))));
               col[o] = qf;
@@ -5076,7 +5106,7 @@ __global__ __launch_bounds__(OPT ? 192 : 128) void k_spec_waves(SpecArgs S) {
             if (OPT) atomicAdd(A.tree_cnt + 16 * mine, 1);
           }
           st_rewires += (unsigned long long)n_rw;
-          ++n_nodes; ++fn; ++na_l;
+          ++n_nodes; ++fn;
           failing = false;
           outcome = rd;
           lap(3);
@@ -5089,13 +5119,7 @@ __global__ __launch_bounds__(OPT ? 192 : 128) void k_spec_waves(SpecArgs S) {
           if (fl & 2) {
             if (lane == 0) { wt_u8(f.nflag + node, (uint8_t)((fl & ~2) | 1)); wt_i32(f.closed + cn, node); }
             ++cn;
-            int at_idx = idx;
-            if (own) { flush_erases(); desync = true; at_idx = pick; }   // (a node of this step: the array first becomes what the list says)
-            for (int e = SFFK_SPEC_DEPTH - 1; e > 0; --e) if (erl[e - 1] > at_idx) erl[e] = erl[e - 1];
-            int at = 0;
-            for (int e = 0; e < SFFK_SPEC_DEPTH; ++e) if (e < ner && erl[e] < at_idx) at = e + 1;
-            for (int e = 0; e < SFFK_SPEC_DEPTH; ++e) if (e == at) erl[e] = at_idx;
-            ++ner;
+            er_insert(idx);
             --fn;
           } else desync = true;                  // (the scenarios below assumed the erase)
         }
@@ -5127,12 +5151,13 @@ __global__ __launch_bounds__(OPT ? 192 : 128) void k_spec_waves(SpecArgs S) {
         sc = S.sc_tab[sc * SFFK_SPEC_TAB + 1 + 2 * SFFK_SPEC_DEPTH + outcome];
         if (sc < 0) break;
       }
-      flush_erases();                            // (before anybody is told about the next step)
+      if (ner + SFFK_SPEC_DEPTH > SP_ER_MAX) compact();   // (room for a step's erases)
+      sq_drain();                                // (everything written, before anybody is told about the next step)
       lap(5);
     }
-    // ---- the launch is over: every set's next control block says so
-    for (int s2 = 0; s2 < S.n_sets; ++s2)
-      if (lane < 16) wt_u64(S.base + 16 * s2 + lane, sp_gran(SP_QUIT, 0u));
+    // ---- the launch is over: every set's next control block says so; the frontier array as everybody else expects it
+    for (int s2 = 0; s2 < S.n_sets; ++s2) wt_u64(S.base + SP_BASE * s2 + lane, sp_gran(SP_QUIT, 0u));
+    compact();
     if (lane == 0) wt_i32(S.cur_step, -1);
     if (lane == 0) {
       c->n_nodes = n_nodes; c->iter = iter; c->frontier_n = fn; c->closed_n = cn; c->n_borders = nb;
@@ -5284,10 +5309,10 @@ __global__ __launch_bounds__(OPT ? 192 : 128) void k_spec_waves(SpecArgs S) {
     bool quit = false;
     SP_WAVE_SYNC();
     for (;;) {
-      const unsigned long long g = sq_u64(S.base + 16 * set + (lane & 15));
+      const unsigned long long g = sq_u64(S.base + SP_BASE * set + lane);
       const uint32_t tg = (uint32_t)(g >> 32);
       const uint32_t t0 = (uint32_t)__shfl((int)tg, 0);
-      const bool whole = __all(tg == t0);
+      const bool whole = __all(lane >= SPB_USED || tg == t0);
       if (whole && t0 == SP_QUIT) { quit = true; break; }
       if (whole && t0 > last) { step = t0; s_row[lane] = (uint32_t)g; break; }
       __builtin_amdgcn_s_sleep(2);
@@ -5298,6 +5323,8 @@ __global__ __launch_bounds__(OPT ? 192 : 128) void k_spec_waves(SpecArgs S) {
     const unsigned long long cur0 = ((unsigned long long)s_row[SPB_CUR + 1] << 32) | (unsigned long long)s_row[SPB_CUR];
     const int fn0 = (int)s_row[SPB_FN], cn0 = (int)s_row[SPB_CN], nn0 = (int)s_row[SPB_NN], it0 = (int)s_row[SPB_ITER];
     const int ef0 = (int)s_row[SPB_EF];
+    const int ne0 = (int)s_row[SPB_NE], fnpc = (int)s_row[SPB_FNPC], nnc = (int)s_row[SPB_NNC];
+    if (lane < SP_ER_MAX) s_er[lane] = (int)s_row[SPB_ER + lane];
     SP_WAVE_SYNC();
     // (the leader is past my step; its store of cur_step may become visible after the control block's: never "!=")
     auto stale = [&]() -> bool { return (uint32_t)__builtin_amdgcn_readfirstlane(sq_i32(S.cur_step)) > step; };
@@ -5311,9 +5338,16 @@ __global__ __launch_bounds__(OPT ? 192 : 128) void k_spec_waves(SpecArgs S) {
     // ---- my scenario: the waves before mine, with the outcomes it assumes
     unsigned long long cur = cur0;
     int sfn = fn0, scn = cn0, snn = nn0, sit = it0;
-    int ne = 0, na = 0, er[SFFK_SPEC_DEPTH], pslot[SFFK_SPEC_DEPTH];
-    for (int l = 0; l < SFFK_SPEC_DEPTH; ++l) { er[l] = 0x7fffffff; pslot[l] = 0; }
-    bool valid = true;
+    // (s_er: the positions erased since the array was last compacted - from the control block - and, behind them in the same
+    // sorted list, the ones my scenario's failed waves erase; ne = mine among them)
+    int ne = 0, na = 0, nel = ne0, pslot[SFFK_SPEC_DEPTH];
+    for (int l = 0; l < SFFK_SPEC_DEPTH; ++l) pslot[l] = 0;
+    auto er_map = [&](int logical) -> int {
+      int idx = logical;
+      for (int e = 0; e < nel; ++e) if (s_er[e] <= idx) ++idx;
+      return idx;
+    };
+    bool valid = ne0 >= 0 && ne0 <= SP_ER_MAX;
     for (int l = 0; l < level && valid; ++l) {
       const int ucl = scn > 0 && ef0;
       const int pool = ucl ? scn : sfn;
@@ -5332,13 +5366,15 @@ __global__ __launch_bounds__(OPT ? 192 : 128) void k_spec_waves(SpecArgs S) {
         cur += (unsigned long long)(TM * WP); sit += TM;
         if (!ucl) {
           if (pk >= fn0 - ne) { valid = false; break; }   // (a node of this step: not modelled)
-          int idx = pk;
-          for (int e = 0; e < SFFK_SPEC_DEPTH; ++e) if (e < ne && er[e] <= idx) ++idx;
-          // keep er sorted
-          for (int e = SFFK_SPEC_DEPTH - 1; e > 0; --e) if (er[e - 1] > idx) er[e] = er[e - 1];
-          int at = 0;
-          for (int e = 0; e < SFFK_SPEC_DEPTH; ++e) if (e < ne && er[e] < idx) at = e + 1;
-          er[at] = idx;
+          const int idx = er_map(pk);
+          SP_WAVE_SYNC();
+          if (lane == 0) {                       // keep the list sorted
+            int at = nel;
+            while (at > 0 && s_er[at - 1] > idx) { s_er[at] = s_er[at - 1]; --at; }
+            s_er[at] = idx;
+          }
+          ++nel;
+          SP_WAVE_SYNC();
           ++ne; --sfn; ++scn;
         }
       }
@@ -5357,10 +5393,10 @@ __global__ __launch_bounds__(OPT ? 192 : 128) void k_spec_waves(SpecArgs S) {
         if (ucl) { if (pk >= cn0) valid = false; else { pick_idx = pk; node = sq_i32(f.closed + pk); } }
         else if (pk >= fn0 - ne) valid = false;
         else {
-          int idx = pk;
-          for (int e = 0; e < SFFK_SPEC_DEPTH; ++e) if (e < ne && er[e] <= idx) ++idx;
+          const int idx = er_map(pk);
           pick_idx = idx;
-          node = sq_i32(frontier + idx);
+          // (behind the entries the array had when it was last compacted: the nodes created since, in order)
+          node = idx >= fnpc ? nnc + (idx - fnpc) : sq_i32(frontier + idx);
         }
       }
     }

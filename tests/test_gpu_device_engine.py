@@ -472,7 +472,7 @@ def test_library_driven_rccl_exchange_on_one_rank(S):
 def test_arrays_and_border_table_grow_on_demand(S, ctx):
     """no node budget: the store starts at 4096 nodes and has to grow; many borders: the border list and its hash
     table start small (test knob) and have to grow too"""
-    fo, fg = make(S, ctx, "dense3d_coarse", 256, 45000, seed=6, SFFGPU_TEST_BORDER_CAP=64)
+    fo, fg = make(S, ctx, "dense3d_coarse", 256, 32000, seed=6, SFFGPU_TEST_BORDER_CAP=64)
     fo.run()
     fg.run()
     assert fo.stats()["n_nodes"] > 3000 and fo.stats()["n_borders"] > 300

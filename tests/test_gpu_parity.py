@@ -309,7 +309,7 @@ def test_priority_frontier_mode(S, ctx, name, wave, n_roots, optimize, goal, mon
 
 @pytest.mark.parametrize("name,wave,n_roots,optimize,iters", [
     ("dense3d", 1024, 10, False, 40000), ("dense3d", 4096, 10, False, 60000), ("dense3d", 512, 6, True, 20000),
-    ("triang", 2048, 5, False, 30000), ("dense3d_coarse", 256, 8, False, 30000),
+    ("triang", 2048, 5, False, 30000), ("dense3d_coarse", 256, 8, False, 20000),
 ])
 def test_priority_frontier_mode_on_the_device_engine(S, ctx, name, wave, n_roots, optimize, iters, monkeypatch):
     """The priority-frontier mode at the wave sizes it is run at: thousands of pops per wave (minimum / random heap entry,
@@ -564,16 +564,16 @@ def test_sff_star_at_two_million_nodes(S, ctx):
     """The regime BASELINE configs[4] names but its own map never reaches (building.obj saturates at 2e5 nodes): SFF* with
     a 2 M-node store and k = floor(2e log10 N) = 34 neighbours per accepted sample.  dense_3D with a step of 11 (dtree 14)
     has the room: 10 roots, waves of 16 384 slots, optimize = true, 2 M-node budget on the device engine.  The start of the job is pinned bit for bit
-    against the oracle (60 k-node budget, same waves); the whole 2 M-node forest is checked through the size-independent
+    against the oracle (35 k-node budget, same waves); the whole 2 M-node forest is checked through the size-independent
     properties (limits, trees, edge lengths = stored parent distances bit for bit, costs never below parent cost + edge,
     equal where nothing above was rewired, oracle-checked poses and edges on a sample)."""
     sc, w = load_world(ctx, "dense3d")
     roots = common.free_roots(w.collide, sc["limits"], 10, seed=1)
     # (with the bench's step - circum 14 / dtree 18 - dense_3D saturates at 1.05 M nodes: a step of 11 / 14 has room for 2 M)
     kw = dict(dist_tree=14.0, sampling_dist=11.0, dim=6, optimize=True, max_iterations=2**31 - 1, wave=16384, seed=1)
-    fo = O.Forest(w, roots, sc["limits"], node_budget=60000, **kw)
+    fo = O.Forest(w, roots, sc["limits"], node_budget=35000, **kw)
     fo.run()
-    fg = S.Forest(ctx, roots, sc["limits"], node_budget=60000, **kw)
+    fg = S.Forest(ctx, roots, sc["limits"], node_budget=35000, **kw)
     assert fg.device_engine()
     fg.run()
     assert_same_forest(fo, fg)
