@@ -306,6 +306,7 @@ struct DevEngine {
   bool spec_off = false;        // SFFGPU_SPEC=0, or a launch stalled (its workgroups were not resident together)
   int spec_depth = 3, spec_sets_want = 1, spec_test_stall = 0;   // (SFFGPU_SPEC_DEPTH / _SETS / SFFGPU_TEST_SPEC_STALL, read when the forest is created)
   bool dev_trig_off = false;
+  bool spec_pipe = true;        // SFFGPU_SPEC_PIPE
 };
 
 struct Forest {

@@ -188,6 +188,7 @@ Forest::Forest(Ctx* c, const sffgpu_forest_cfg& cf, const double* roots6, int n_
   if (const char* e = getenv("SFFGPU_SPEC_DEPTH")) dev.spec_depth = atoi(e);
   if (const char* e = getenv("SFFGPU_SPEC_SETS")) dev.spec_sets_want = atoi(e);
   if (const char* e = getenv("SFFGPU_TEST_SPEC_STALL")) dev.spec_test_stall = atoi(e);
+  if (const char* e = getenv("SFFGPU_SPEC_PIPE")) dev.spec_pipe = atoi(e) != 0;
   if (const char* e = getenv("SFFGPU_NO_DEV_TRIG")) dev.dev_trig_off = atoi(e) != 0;
   if (const char* e = getenv("SFFGPU_STAR_TAIL_WGS")) star_tail_wgs = std::max(1, atoi(e));
   if (const char* e = getenv("SFFGPU_TEST_STAR_STALL")) star_tail_stall = std::max(0, atoi(e));

@@ -1470,6 +1470,7 @@ void Forest::run_device_seq(int max_waves) {
       sa.cur_step = reinterpret_cast<int32_t*>(d.spec_area.as<uint8_t>() + SPEC_HEAD - 256);
       sa.rec = reinterpret_cast<unsigned long long*>(d.spec_area.as<uint8_t>() + SPEC_HEAD);
       sa.timeout_ticks = 20000000ULL;   // 200 ms
+      sa.pipeline = d.spec_pipe ? 1 : 0;
       if (d.spec_test_stall && st.spec_steps == 0 && d.last.spec_steps == 0) sa.test_stall = d.spec_test_stall;
       const size_t rec_bytes = (size_t)sa.n_sets * sa.n_slots * SFFK_SPEC_REC * 8;
       if (getenv("SFFGPU_PROFILE")) sa.hb = reinterpret_cast<unsigned long long*>(d.spec_area.as<uint8_t>() + SPEC_HEAD + rec_bytes);

@@ -664,6 +664,7 @@ struct SpecArgs {
   unsigned long long* rec;            // n_sets x n_slots records of SFFK_SPEC_REC granules
   int32_t* cur_step;                  // the step the leader is at (workers of older steps give up), -1 = the launch is over
   unsigned long long timeout_ticks;   // a record that is not there after this many 10 ns ticks = stalled
+  int pipeline;                       // plain SFF: a step is published before the accepted nodes of the one before are written (SFFGPU_SPEC_PIPE=0: after)
   int test_stall;                     // tests (SFFGPU_TEST_SPEC_STALL = 8 x step + slot): that worker never writes that step's record
   unsigned long long* hb;             // debugging (SFFGPU_PROFILE): per worker (step << 8 | phase), [n_sets x n_slots ..]: the leader's last wait; null = off
 };

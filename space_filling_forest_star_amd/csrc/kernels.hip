@@ -4779,10 +4779,13 @@ __device__ __forceinline__ double sp_f64(uint32_t lo, uint32_t hi) {
 #define SPB_NE 7       // frontier positions erased since the array was last compacted (SPB_ER + ...)
 #define SPB_FNPC 8     // entries of the array when it was last compacted
 #define SPB_NNC 9      // nodes then: the array's entry FNPC + i is node NNC + i
+#define SPB_NNS 10     // nodes whose store entries are complete; the NN - NNS behind them are PENDING: accepted in the step before, written
+                       // by the leader while this step is evaluated - their early rows travel in the block (SPB_PEND)
 #define SPB_ER 16      // the erased positions, ascending (SP_ER_MAX)
-#define SPB_USED 32
+#define SPB_PEND 32    // pending nodes: 16 granules each (the early row's layout), SFFK_SPEC_DEPTH of them at most
+#define SPB_USED (SPB_PEND + 16 * SFFK_SPEC_DEPTH)
 #define SP_ER_MAX 16
-#define SP_BASE 64     // granules per control block
+#define SP_BASE 128    // granules per control block
 #define SP_QUIT 0xffffffffu
 
 // LDS words two wavefronts of a workgroup hand to each other (in-order LDS operations of a wavefront; the words themselves
@@ -4799,9 +4802,11 @@ __global__ __launch_bounds__(OPT ? 192 : 128) void k_spec_waves(SpecArgs S) {
   __shared__ int32_t h_id[64], h_tree[64];
   __shared__ double h_d[64], h_pos[64 * 6];
   __shared__ uint32_t s_row[64];
-  __shared__ double p_pos[SFFK_SPEC_DEPTH * 6], p_best[SFFK_SPEC_DEPTH];
-  __shared__ int32_t p_tree[SFFK_SPEC_DEPTH];
+  __shared__ double p_pos[2 * SFFK_SPEC_DEPTH * 6], p_best[2 * SFFK_SPEC_DEPTH];
+  __shared__ int32_t p_tree[2 * SFFK_SPEC_DEPTH];
   __shared__ uint32_t s_rw[OPT ? SFFK_STAR_KC * 5 : 1];
+  __shared__ uint32_t s_acc[SFFK_SPEC_DEPTH][64];           // leader: row 0 of the step's accepted attempts (applied behind the next step's publication); worker: the pending rows
+  __shared__ int32_t s_acc_id[SFFK_SPEC_DEPTH], s_acc_iter[SFFK_SPEC_DEPTH];
   __shared__ int32_t s_er[SP_ER_MAX + SFFK_SPEC_DEPTH + 1];   // erased frontier positions, ascending (leader: since the last compaction; worker: + its scenario's)
   // the job the worker's first wavefront hands to its second one right after the sample is drawn: the neighbour query
   // (and, SFF*, the k nearest of the sample's tree) run BESIDE the pose check and the parent edge
@@ -4885,26 +4890,115 @@ __global__ __launch_bounds__(OPT ? 192 : 128) void k_spec_waves(SpecArgs S) {
     const bool clk = f.profile != 0;
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tq = clk ? wall_clock64() : 0ULL;
     auto lap = [&](int k) { if (!clk) return; const unsigned long long t = wall_clock64(); ph[k] += t - tq; tq = t; };
-    while (!terminated && !fault && !stop && waves_done < A.max_waves) {
-      ++step; ++n_steps;
-      const int set = (int)(step % (uint32_t)S.n_sets);
-      {   // ---- publish the control block of this step
-        uint32_t v = 0;
-        v = lane == SPB_CUR ? (uint32_t)(cursor & 0xffffffffULL) : v;
-        v = lane == SPB_CUR + 1 ? (uint32_t)(cursor >> 32) : v;
-        v = lane == SPB_FN ? (uint32_t)fn : v;
-        v = lane == SPB_CN ? (uint32_t)cn : v;
-        v = lane == SPB_NN ? (uint32_t)n_nodes : v;
-        v = lane == SPB_ITER ? (uint32_t)iter : v;
-        v = lane == SPB_EF ? (uint32_t)empty_frontier : v;
-        v = lane == SPB_NE ? (uint32_t)ner : v;
-        v = lane == SPB_FNPC ? (uint32_t)fn_pc : v;
-        v = lane == SPB_NNC ? (uint32_t)nn_c : v;
-        if (lane >= SPB_ER && lane < SPB_ER + SP_ER_MAX) v = lane - SPB_ER < ner ? (uint32_t)s_er[lane - SPB_ER] : 0u;
-        wt_u64(S.base + SP_BASE * set + lane, sp_gran(step, v));
-        if (lane == 0) wt_i32(S.cur_step, (int)step);
-        nn_base = n_nodes;
+    // the node of an accepted attempt (row 0 of its record): a lane per word - one store instruction per width instead of
+    // thirty stores of lane 0
+    auto apply_accept = [&](const uint32_t* row, int idn, int iter_v, int n_rw) {
+      const int par_new = (int)row[SPG_PAR], mine = (int)row[SPG_MINE];
+      sq_drain();                            // (an earlier node of the step may have written the cell's count)
+      const GridView& g = A.g;
+      const float q0 = (float)sp_f64(row[SPG_QP], row[SPG_QP + 1]), q1 = (float)sp_f64(row[SPG_QP + 2], row[SPG_QP + 3]),
+                  q2 = (float)sp_f64(row[SPG_QP + 4], row[SPG_QP + 5]);
+      const size_t cell = grid_cell_of(g, q0, q1, q2);
+      const int gslot = sq_i32(g.cnt + cell);
+      int govf = -1;
+      if (gslot >= g.bk) govf = sq_i32(g.ovf_cnt);
+      if (g.occ && lane == 0) atomicOr(g.occ + (cell >> 5), 1u << (cell & 31));
+      const bool put = gslot < g.bk || govf < g.ovf_cap;          // (the host checks ovf_cnt against ovf_cap)
+      GridItem* gi = gslot < g.bk ? g.items + cell * g.bk + gslot : g.ovf + (govf < 0 ? 0 : govf);
+      GridItem32* gl = gslot < g.bk ? (g.lite ? g.lite + cell * g.bk + gslot : nullptr) : (g.ovf_lite ? g.ovf_lite + (govf < 0 ? 0 : govf) : nullptr);
+      const size_t o = (size_t)idn;
+      {   // 64-bit words: position (6), distance to the parent, cost, the grid item (8)
+        unsigned long long* p64 = nullptr;
+        unsigned long long v64 = 0;
+        const int qk = lane < 6 ? lane : (lane >= 8 && lane < 14 ? lane - 8 : 0);
+        const unsigned long long qbits = ((unsigned long long)row[SPG_QP + 2 * qk + 1] << 32) | (unsigned long long)row[SPG_QP + 2 * qk];
+        if (lane < 6) { p64 = reinterpret_cast<unsigned long long*>(A.st.pos + 6 * o + lane); v64 = qbits; }
+        else if (lane == 6) { p64 = reinterpret_cast<unsigned long long*>(f.d_closest + o); v64 = ((unsigned long long)row[SPG_DCL + 1] << 32) | row[SPG_DCL]; }
+        else if (lane == 7) { p64 = reinterpret_cast<unsigned long long*>(f.d_root + o); v64 = ((unsigned long long)row[SPG_BEST + 1] << 32) | row[SPG_BEST]; }
+        else if (lane < 16 && put) {
+          p64 = reinterpret_cast<unsigned long long*>(gi) + (lane - 8);
+          v64 = lane < 14 ? qbits : (lane == 14 ? (((unsigned long long)(uint32_t)mine << 32) | (unsigned long long)(uint32_t)idn) : 0ULL);
+        }
+        if (p64) wt_u64(p64, v64);
       }
+      {   // 32-bit words: tree, parent, frontier entry (write-through); the fp32 columns, the filter record, the iteration (plain)
+        const int fk = lane >= 19 && lane < 25 ? lane - 19 : (lane >= 25 && lane < 31 ? lane - 25 : 0);
+        const float qf = (float)sp_f64(row[SPG_QP + 2 * fk], row[SPG_QP + 2 * fk + 1]);
+        if (lane == 16) wt_i32(A.st.tree + o, mine);
+        else if (lane == 17) wt_i32(f.parent + o, par_new);
+        else if (lane == 18) wt_i32(frontier + fn_pc + (idn - nn_c), idn);
+        else if (lane >= 19 && lane < 25) {
+          float* col = fk == 0 ? A.st.x : (fk == 1 ? A.st.y : (fk == 2 ? A.st.z : (fk == 3 ? A.st.yaw : (fk == 4 ? A.st.pitch : A.st.roll))));
+          col[o] = qf;
+        } else if (lane >= 25 && lane < 31) { if (gl && put) reinterpret_cast<float*>(gl)[fk] = qf; }
+        else if (lane == 31) { if (gl && put) gl->id = idn; }
+        else if (lane == 32) { if (gl && put) gl->tree = mine; }
+        else if (lane == 33) f.iter[o] = (uint32_t)iter_v;
+        else if (lane == 34) wt_u8(f.nflag + o, 2);
+      }
+      if (OPT) {
+        SP_WAVE_SYNC();
+        if (lane == 0) {
+          if (A.hist) {
+            const int at = atomicAdd(A.hist_ctl, 1);
+            if (at < A.hist_cap) { A.hist[3 * (size_t)at] = idn; A.hist[3 * (size_t)at + 1] = par_new; A.hist[3 * (size_t)at + 2] = iter_v; }
+            else A.hist_ctl[1] = 1;
+          }
+          // rewire (:332-350), as the worker found them in the reference's order
+          for (int j = 0; j < n_rw; ++j) {
+            const int idm = (int)s_rw[5 * j];
+            wt_i32(f.parent + idm, idn);
+            wt_f64(f.d_closest + idm, sp_f64(s_rw[5 * j + 1], s_rw[5 * j + 2]));
+            wt_f64(f.d_root + idm, sp_f64(s_rw[5 * j + 3], s_rw[5 * j + 4]));
+            if (A.hist) {
+              const int at = atomicAdd(A.hist_ctl, 1);
+              if (at < A.hist_cap) { A.hist[3 * (size_t)at] = idm; A.hist[3 * (size_t)at + 1] = idn; A.hist[3 * (size_t)at + 2] = iter_v; }
+              else A.hist_ctl[1] = 1;
+            }
+          }
+        }
+      }
+      sq_drain();                            // (the item is written: now the counts that make it visible)
+      if (lane == 0) {
+        if (govf >= 0) wt_i32(g.ovf_cnt, govf + 1);
+        wt_i32(g.cnt + cell, gslot + 1);
+        if (OPT) atomicAdd(A.tree_cnt + 16 * mine, 1);
+      }
+    };
+    int n_acc = 0;                               // accepted attempts of the step whose rows wait in s_acc
+    // ---- publish the control block of the next step; n_pend of its nodes are still to be written (their rows in s_acc)
+    auto publish = [&](int n_pend) {
+      ++step; ++n_steps;
+      const int set_p = (int)(step % (uint32_t)S.n_sets);
+      for (int half = 0; half < 2; ++half) {
+        const int gidx = 64 * half + lane;
+        uint32_t v = 0;
+        v = gidx == SPB_CUR ? (uint32_t)(cursor & 0xffffffffULL) : v;
+        v = gidx == SPB_CUR + 1 ? (uint32_t)(cursor >> 32) : v;
+        v = gidx == SPB_FN ? (uint32_t)fn : v;
+        v = gidx == SPB_CN ? (uint32_t)cn : v;
+        v = gidx == SPB_NN ? (uint32_t)n_nodes : v;
+        v = gidx == SPB_ITER ? (uint32_t)iter : v;
+        v = gidx == SPB_EF ? (uint32_t)empty_frontier : v;
+        v = gidx == SPB_NE ? (uint32_t)ner : v;
+        v = gidx == SPB_FNPC ? (uint32_t)fn_pc : v;
+        v = gidx == SPB_NNC ? (uint32_t)nn_c : v;
+        v = gidx == SPB_NNS ? (uint32_t)(n_nodes - n_pend) : v;
+        if (gidx >= SPB_ER && gidx < SPB_ER + SP_ER_MAX) v = gidx - SPB_ER < ner ? (uint32_t)s_er[gidx - SPB_ER] : 0u;
+        if (gidx >= SPB_PEND && gidx < SPB_PEND + 16 * SFFK_SPEC_DEPTH) {
+          const int k = (gidx - SPB_PEND) >> 4, j = (gidx - SPB_PEND) & 15;
+          if (k < n_pend) v = j < 12 ? s_acc[k][SPG_QP + j] : (j == 12 ? s_acc[k][SPG_MINE] : (j == 13 ? s_acc[k][SPG_BEST] : (j == 14 ? s_acc[k][SPG_BEST + 1] : 1u)));
+        }
+        wt_u64(S.base + SP_BASE * set_p + gidx, sp_gran(step, v));
+      }
+      if (lane == 0) wt_i32(S.cur_step, (int)step);
+      nn_base = n_nodes;
+    };
+    bool published = false, step_desync = false;
+    while (!terminated && !fault && !stop && waves_done < A.max_waves) {
+      if (!published) { publish(0); lap(0); }
+      published = false;
+      const int set = (int)(step % (uint32_t)S.n_sets);
       lap(0);
       if (sq_i32(A.grid_ovf_src) > A.grid_ovf_limit) { stop = true; }   // (once per step: the list has room for a step's nodes)
       int sc = 0;
@@ -5026,84 +5120,22 @@ __global__ __launch_bounds__(OPT ? 192 : 128) void k_spec_waves(SpecArgs S) {
             }
           }
           if (status != SPS_ACCEPT) { lap(6); continue; }
-          // ---- the new node (:329, :353-367): a lane per word (one store instruction per width instead of thirty stores of lane 0)
+          // ---- the new node (:329, :353-367).  SFF*: written now (the step ends with it); plain SFF: its row is kept and written
+          // behind the publication of the next step, whose workers get the node from the control block meanwhile
           const int idn = n_nodes;
-          const int par_new = (int)s_row[SPG_PAR];
           const int n_rw = OPT ? (int)s_row[SPG_NRW] : 0;
-          if (OPT) { ++st_rounds; st_members += (unsigned long long)s_row[SPG_NMEM]; }
-          if (OPT && n_rw > 0) {                 // the rewires behind row 0 (written and drained before it)
-            const unsigned long long* rp = rec0 + (size_t)rd * SFFK_SPEC_REC + 64;
-            for (int q = lane; q < 5 * n_rw; q += 64) s_rw[q] = (uint32_t)sq_u64(rp + q);
-          }
-          sq_drain();                            // (an earlier node of the step may have written the cell's count)
-          const GridView& g = A.g;
-          const float q0 = (float)sp_f64(s_row[SPG_QP], s_row[SPG_QP + 1]), q1 = (float)sp_f64(s_row[SPG_QP + 2], s_row[SPG_QP + 3]),
-                      q2 = (float)sp_f64(s_row[SPG_QP + 4], s_row[SPG_QP + 5]);
-          const size_t cell = grid_cell_of(g, q0, q1, q2);
-          const int gslot = sq_i32(g.cnt + cell);
-          int govf = -1;
-          if (gslot >= g.bk) govf = sq_i32(g.ovf_cnt);
-          if (g.occ && lane == 0) atomicOr(g.occ + (cell >> 5), 1u << (cell & 31));
-          const bool put = gslot < g.bk || govf < g.ovf_cap;          // (the host checks ovf_cnt against ovf_cap)
-          GridItem* gi = gslot < g.bk ? g.items + cell * g.bk + gslot : g.ovf + (govf < 0 ? 0 : govf);
-          GridItem32* gl = gslot < g.bk ? (g.lite ? g.lite + cell * g.bk + gslot : nullptr) : (g.ovf_lite ? g.ovf_lite + (govf < 0 ? 0 : govf) : nullptr);
-          const size_t o = (size_t)idn;
-          {   // 64-bit words: position (6), distance to the parent, cost, the grid item (8)
-            unsigned long long* p64 = nullptr;
-            unsigned long long v64 = 0;
-            const int qk = lane < 6 ? lane : (lane >= 8 && lane < 14 ? lane - 8 : 0);
-            const unsigned long long qbits = ((unsigned long long)s_row[SPG_QP + 2 * qk + 1] << 32) | (unsigned long long)s_row[SPG_QP + 2 * qk];
-            if (lane < 6) { p64 = reinterpret_cast<unsigned long long*>(A.st.pos + 6 * o + lane); v64 = qbits; }
-            else if (lane == 6) { p64 = reinterpret_cast<unsigned long long*>(f.d_closest + o); v64 = ((unsigned long long)s_row[SPG_DCL + 1] << 32) | s_row[SPG_DCL]; }
-            else if (lane == 7) { p64 = reinterpret_cast<unsigned long long*>(f.d_root + o); v64 = ((unsigned long long)s_row[SPG_BEST + 1] << 32) | s_row[SPG_BEST]; }
-            else if (lane < 16 && put) {
-              p64 = reinterpret_cast<unsigned long long*>(gi) + (lane - 8);
-              v64 = lane < 14 ? qbits : (lane == 14 ? (((unsigned long long)(uint32_t)mine << 32) | (unsigned long long)(uint32_t)idn) : 0ULL);
-            }
-            if (p64) wt_u64(p64, v64);
-          }
-          {   // 32-bit words: tree, parent, frontier entry (write-through); the fp32 columns, the filter record, the iteration (plain)
-            const int fk = lane >= 19 && lane < 25 ? lane - 19 : (lane >= 25 && lane < 31 ? lane - 25 : 0);
-            const float qf = (float)sp_f64(s_row[SPG_QP + 2 * fk], s_row[SPG_QP + 2 * fk + 1]);
-            if (lane == 16) wt_i32(A.st.tree + o, mine);
-            else if (lane == 17) wt_i32(f.parent + o, par_new);
-            else if (lane == 18) wt_i32(frontier + fn_pc + (idn - nn_c), idn);
-            else if (lane >= 19 && lane < 25) {
-              float* col = fk == 0 ? A.st.x : (fk == 1 ? A.st.y : (fk == 2 ? A.st.z : (fk == 3 ? A.st.yaw : (fk == 4 ? A.st.pitch : A.st.roll))));
-              col[o] = qf;
-            } else if (lane >= 25 && lane < 31) { if (gl && put) reinterpret_cast<float*>(gl)[fk] = qf; }
-            else if (lane == 31) { if (gl && put) gl->id = idn; }
-            else if (lane == 32) { if (gl && put) gl->tree = mine; }
-            else if (lane == 33) f.iter[o] = (uint32_t)iter;
-            else if (lane == 34) wt_u8(f.nflag + o, 2);
-          }
           if (OPT) {
-            SP_WAVE_SYNC();
-            if (lane == 0) {
-              if (A.hist) {
-                const int at = atomicAdd(A.hist_ctl, 1);
-                if (at < A.hist_cap) { A.hist[3 * (size_t)at] = idn; A.hist[3 * (size_t)at + 1] = par_new; A.hist[3 * (size_t)at + 2] = iter; }
-                else A.hist_ctl[1] = 1;
-              }
-              // rewire (:332-350), as the worker found them in the reference's order
-              for (int j = 0; j < n_rw; ++j) {
-                const int idm = (int)s_rw[5 * j];
-                wt_i32(f.parent + idm, idn);
-                wt_f64(f.d_closest + idm, sp_f64(s_rw[5 * j + 1], s_rw[5 * j + 2]));
-                wt_f64(f.d_root + idm, sp_f64(s_rw[5 * j + 3], s_rw[5 * j + 4]));
-                if (A.hist) {
-                  const int at = atomicAdd(A.hist_ctl, 1);
-                  if (at < A.hist_cap) { A.hist[3 * (size_t)at] = idm; A.hist[3 * (size_t)at + 1] = idn; A.hist[3 * (size_t)at + 2] = iter; }
-                  else A.hist_ctl[1] = 1;
-                }
-              }
+            ++st_rounds; st_members += (unsigned long long)s_row[SPG_NMEM];
+            if (n_rw > 0) {                      // the rewires behind row 0 (written and drained before it)
+              const unsigned long long* rp = rec0 + (size_t)rd * SFFK_SPEC_REC + 64;
+              for (int q = lane; q < 5 * n_rw; q += 64) s_rw[q] = (uint32_t)sq_u64(rp + q);
             }
-          }
-          sq_drain();                            // (the item is written: now the counts that make it visible)
-          if (lane == 0) {
-            if (govf >= 0) wt_i32(g.ovf_cnt, govf + 1);
-            wt_i32(g.cnt + cell, gslot + 1);
-            if (OPT) atomicAdd(A.tree_cnt + 16 * mine, 1);
+            apply_accept(s_row, idn, iter, n_rw);
+          } else {
+            s_acc[n_acc][lane] = s_row[lane];
+            if (lane == 0) { s_acc_id[n_acc] = idn; s_acc_iter[n_acc] = iter; }
+            ++n_acc;
+            SP_WAVE_SYNC();
           }
           st_rewires += (unsigned long long)n_rw;
           ++n_nodes; ++fn;
@@ -5123,6 +5155,7 @@ __global__ __launch_bounds__(OPT ? 192 : 128) void k_spec_waves(SpecArgs S) {
             --fn;
           } else desync = true;                  // (the scenarios below assumed the erase)
         }
+        step_desync = step_desync || desync;
         // ---- termination (:184-201)
         empty_frontier = fn == 0 ? 1 : 0;
         if (!solved && empty_frontier) {
@@ -5151,12 +5184,21 @@ __global__ __launch_bounds__(OPT ? 192 : 128) void k_spec_waves(SpecArgs S) {
         sc = S.sc_tab[sc * SFFK_SPEC_TAB + 1 + 2 * SFFK_SPEC_DEPTH + outcome];
         if (sc < 0) break;
       }
+      // ---- the step is decided.  Plain SFF: the next step is published NOW - its workers evaluate while the accepted nodes
+      // of this one are written (they get those nodes from the control block and skip their grid items) - unless something
+      // the workers could trip over is due: the array's compaction, the closed-list mode, the launch's end
+      const bool more = !terminated && !fault && !stop && waves_done < A.max_waves;
+      const bool pipe = !OPT && S.pipeline && more && !step_desync && !empty_frontier && n_acc > 0 && ner + SFFK_SPEC_DEPTH <= SP_ER_MAX;
+      if (pipe) { publish(n_acc); published = true; lap(0); }
+      for (int k = 0; k < n_acc; ++k) apply_accept(s_acc[k], s_acc_id[k], s_acc_iter[k], 0);
+      n_acc = 0;
       if (ner + SFFK_SPEC_DEPTH > SP_ER_MAX) compact();   // (room for a step's erases)
-      sq_drain();                                // (everything written, before anybody is told about the next step)
+      sq_drain();                                // (everything written, before anybody is told about the step after)
+      step_desync = false;
       lap(5);
     }
     // ---- the launch is over: every set's next control block says so; the frontier array as everybody else expects it
-    for (int s2 = 0; s2 < S.n_sets; ++s2) wt_u64(S.base + SP_BASE * s2 + lane, sp_gran(SP_QUIT, 0u));
+    for (int s2 = 0; s2 < S.n_sets; ++s2) { wt_u64(S.base + SP_BASE * s2 + lane, sp_gran(SP_QUIT, 0u)); wt_u64(S.base + SP_BASE * s2 + 64 + lane, sp_gran(SP_QUIT, 0u)); }
     compact();
     if (lane == 0) wt_i32(S.cur_step, -1);
     if (lane == 0) {
@@ -5309,12 +5351,18 @@ __global__ __launch_bounds__(OPT ? 192 : 128) void k_spec_waves(SpecArgs S) {
     bool quit = false;
     SP_WAVE_SYNC();
     for (;;) {
-      const unsigned long long g = sq_u64(S.base + SP_BASE * set + lane);
-      const uint32_t tg = (uint32_t)(g >> 32);
+      const unsigned long long g = sq_u64(S.base + SP_BASE * set + lane), g2 = sq_u64(S.base + SP_BASE * set + 64 + lane);
+      const uint32_t tg = (uint32_t)(g >> 32), tg2 = (uint32_t)(g2 >> 32);
       const uint32_t t0 = (uint32_t)__shfl((int)tg, 0);
-      const bool whole = __all(lane >= SPB_USED || tg == t0);
+      const bool whole = __all(tg == t0 && (64 + lane >= SPB_USED || tg2 == t0));
       if (whole && t0 == SP_QUIT) { quit = true; break; }
-      if (whole && t0 > last) { step = t0; s_row[lane] = (uint32_t)g; break; }
+      if (whole && t0 > last) {
+        step = t0; s_row[lane] = (uint32_t)g;
+        // (the pending rows: granules SPB_PEND .. SPB_USED - 1 of the block, 16 per node)
+        if (lane >= SPB_PEND) s_acc[(lane - SPB_PEND) >> 4][(lane - SPB_PEND) & 15] = (uint32_t)g;
+        if (64 + lane < SPB_USED) s_acc[(64 + lane - SPB_PEND) >> 4][(64 + lane - SPB_PEND) & 15] = (uint32_t)g2;
+        break;
+      }
       __builtin_amdgcn_s_sleep(2);
     }
     if (quit) { if (lane == 0) lds_st(&j_seq, -1); break; }
@@ -5323,8 +5371,11 @@ __global__ __launch_bounds__(OPT ? 192 : 128) void k_spec_waves(SpecArgs S) {
     const unsigned long long cur0 = ((unsigned long long)s_row[SPB_CUR + 1] << 32) | (unsigned long long)s_row[SPB_CUR];
     const int fn0 = (int)s_row[SPB_FN], cn0 = (int)s_row[SPB_CN], nn0 = (int)s_row[SPB_NN], it0 = (int)s_row[SPB_ITER];
     const int ef0 = (int)s_row[SPB_EF];
-    const int ne0 = (int)s_row[SPB_NE], fnpc = (int)s_row[SPB_FNPC], nnc = (int)s_row[SPB_NNC];
+    const int ne0 = (int)s_row[SPB_NE], fnpc = (int)s_row[SPB_FNPC], nnc = (int)s_row[SPB_NNC], nns = (int)s_row[SPB_NNS];
+    const int n_pend = nn0 - nns;                // nodes the leader is still writing: from the block, never from the store
     if (lane < SP_ER_MAX) s_er[lane] = (int)s_row[SPB_ER + lane];
+    if (lane < 6 * SFFK_SPEC_DEPTH) { const int k = lane / 6, q = lane - 6 * k; p_pos[6 * k + q] = sp_f64(s_acc[k][2 * q], s_acc[k][2 * q + 1]); }
+    if (lane < SFFK_SPEC_DEPTH) { p_tree[lane] = (int)s_acc[lane][12]; p_best[lane] = sp_f64(s_acc[lane][13], s_acc[lane][14]); }
     SP_WAVE_SYNC();
     // (the leader is past my step; its store of cur_step may become visible after the control block's: never "!=")
     auto stale = [&]() -> bool { return (uint32_t)__builtin_amdgcn_readfirstlane(sq_i32(S.cur_step)) > step; };
@@ -5347,7 +5398,7 @@ __global__ __launch_bounds__(OPT ? 192 : 128) void k_spec_waves(SpecArgs S) {
       for (int e = 0; e < nel; ++e) if (s_er[e] <= idx) ++idx;
       return idx;
     };
-    bool valid = ne0 >= 0 && ne0 <= SP_ER_MAX;
+    bool valid = ne0 >= 0 && ne0 <= SP_ER_MAX && n_pend >= 0 && n_pend <= SFFK_SPEC_DEPTH;
     for (int l = 0; l < level && valid; ++l) {
       const int ucl = scn > 0 && ef0;
       const int pool = ucl ? scn : sfn;
@@ -5413,11 +5464,16 @@ __global__ __launch_bounds__(OPT ? 192 : 128) void k_spec_waves(SpecArgs S) {
     double ev_dist = 0, pdist = 0, best = 0, dcl_new = 0, qp[6] = {0, 0, 0, 0, 0, 0};
     bool aborted = false;
     if (status == SPS_REJECT) {
-      double cpos[6];
-      for (int k = 0; k < 6; ++k) cpos[k] = sq_f64(A.st.pos + 6 * (size_t)node + k);
-      mine = sq_i32(A.st.tree + node);
-      const double droot_ex = sq_f64(f.d_root + node);
-      fl_node = sq_u8(f.nflag + node);
+      double cpos[6], droot_ex;
+      if (node >= nns) {                         // (a node of the step before: the leader is just writing it - its row came with the block)
+        for (int k = 0; k < 6; ++k) cpos[k] = p_pos[6 * (node - nns) + k];
+        mine = p_tree[node - nns]; droot_ex = p_best[node - nns]; fl_node = 2;
+      } else {
+        for (int k = 0; k < 6; ++k) cpos[k] = sq_f64(A.st.pos + 6 * (size_t)node + k);
+        mine = sq_i32(A.st.tree + node);
+        droot_ex = sq_f64(f.d_root + node);
+        fl_node = sq_u8(f.nflag + node);
+      }
       const bool force = (fl_node & 1) != 0;
       uint64_t w[6];
       for (int k = 0; k < 6; ++k) w[k] = k < WP ? f.ring[(cursor_a + k) & f.ring_mask] : 0ULL;
@@ -5458,7 +5514,7 @@ __global__ __launch_bounds__(OPT ? 192 : 128) void k_spec_waves(SpecArgs S) {
         if (lane == 0) {
           for (int k = 0; k < 6; ++k) j_qp[k] = qp[k];
           j_pdist = pdist;
-          lds_st(&j_mine, mine); lds_st(&j_k, kstar); lds_st(&j_nn0, nn0); lds_st(&j_snn, snn); lds_st(&j_step, (int)step);
+          lds_st(&j_mine, mine); lds_st(&j_k, kstar); lds_st(&j_nn0, nns); lds_st(&j_snn, snn); lds_st(&j_step, (int)step);
         }
         ++myseq;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -5480,8 +5536,7 @@ __global__ __launch_bounds__(OPT ? 192 : 128) void k_spec_waves(SpecArgs S) {
           hit = pose_exact(A.env, A.rob, rtri, stack, cand, stage, qp, Rm, c3, lane);
         }
         beat(2);
-        if (!hit && stale()) aborted = true;
-        if (!hit && !aborted) {
+        if (!hit) {
           // ---- isPathFree(expanded, newPoint)
           pf_l += 1; ex_seg += 1;
           const bool free0 = sq_path_free(A.env, A.rob, rtri, stack, cand, queue, stage, cpos, qp, &s_fh, &s_ovf, lane, cc_l, ex_smp, flt);
@@ -5494,6 +5549,19 @@ __global__ __launch_bounds__(OPT ? 192 : 128) void k_spec_waves(SpecArgs S) {
             const double r = pdist > A.dist_tree ? pdist : A.dist_tree;
             helper_wait(&j_done, myseq);                             // (asked for when the sample was drawn)
             n_hit = lds_ld(&j_nhit);
+            // ---- the nodes of the step before that the leader is still writing: nodes nns .. nn0 - 1, from the control block
+            for (int p = 0; p < n_pend; ++p) {
+              double pp[6];
+              for (int k = 0; k < 6; ++k) pp[k] = p_pos[6 * p + k];
+              const double d = dist6(pp, qp);
+              if (d < r) {
+                if (lane == 0 && n_hit < 64) {
+                  h_id[n_hit] = nns + p; h_tree[n_hit] = p_tree[p]; h_d[n_hit] = d;
+                  for (int k = 0; k < 6; ++k) h_pos[6 * n_hit + k] = pp[k];
+                }
+                ++n_hit;
+              }
+            }
             // ---- the samples my scenario assumes accepted before me: nodes nn0 .. nn0 + na - 1
             for (int p = 0; p < na && !aborted; ++p) {
               const unsigned long long* ep = S.rec + ((size_t)set * S.n_slots + pslot[p]) * SFFK_SPEC_REC + SFFK_SPEC_EARLY;
@@ -5512,7 +5580,7 @@ __global__ __launch_bounds__(OPT ? 192 : 128) void k_spec_waves(SpecArgs S) {
               const double pb = sp_f64(s_row[13], s_row[14]);
               const int ptree = (int)s_row[12];
               SP_WAVE_SYNC();
-              if (lane == 0) { for (int k = 0; k < 6; ++k) p_pos[6 * p + k] = pp[k]; p_best[p] = pb; p_tree[p] = ptree; }
+              if (lane == 0) { for (int k = 0; k < 6; ++k) p_pos[6 * (n_pend + p) + k] = pp[k]; p_best[n_pend + p] = pb; p_tree[n_pend + p] = ptree; }
               const double d = dist6(pp, qp);
               if (d < r) {
                 if (lane == 0 && n_hit < 64) {
@@ -5555,7 +5623,7 @@ __global__ __launch_bounds__(OPT ? 192 : 128) void k_spec_waves(SpecArgs S) {
                 const bool fr = sq_path_free(A.env, A.rob, rtri, stack, cand, queue, stage, cpos, np6, &s_fh, &s_ovf, lane, cc_l, ex_smp, flt);
                 if (fr && !flt) {                                      // :288-294 border entry (the leader knows whether the pair has one)
                   event = 1; ev_id = s_id; ev_tree = s_tree;
-                  const double dr = s_id >= nn0 ? p_best[s_id - nn0] : sq_f64(f.d_root + s_id);
+                  const double dr = s_id >= nns ? p_best[s_id - nns] : sq_f64(f.d_root + s_id);
                   ev_dist = dr + droot_ex + dist6(np6, cpos);
                 }
                 reject = true;                                         // :296-299
