@@ -304,7 +304,7 @@ struct DevEngine {
   DevBuf qclk_sh;               // the query kernel's clock bracket, 64 shards (sffk::DevForestView::qclk_sh)
   int spec_n_sc = 0, spec_sets = 0, spec_tm = 0;
   bool spec_off = false;        // SFFGPU_SPEC=0, or a launch stalled (its workgroups were not resident together)
-  int spec_depth = 3, spec_sets_want = 1, spec_test_stall = 0;   // (SFFGPU_SPEC_DEPTH / _SETS / SFFGPU_TEST_SPEC_STALL, read when the forest is created)
+  int spec_depth = 0 /* 0 = 3 (the tree), SFF*: 4 (the chain) */, spec_sets_want = 1, spec_test_stall = 0;   // (SFFGPU_SPEC_DEPTH / _SETS / SFFGPU_TEST_SPEC_STALL, read when the forest is created)
   bool dev_trig_off = false;
   bool spec_pipe = true;        // SFFGPU_SPEC_PIPE
 };

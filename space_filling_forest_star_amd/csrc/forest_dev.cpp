@@ -1348,7 +1348,7 @@ bool Forest::spec_setup() {
   const int TM = std::max(1, cfg.threshold_misses);
   if (d.spec_n_sc > 0 && d.spec_tm == TM) return true;
   if (TM > 8) { d.spec_off = true; return false; }
-  const int depth = std::max(1, std::min(d.spec_depth, SFFK_SPEC_DEPTH));
+  const int depth = std::max(1, std::min(d.spec_depth > 0 ? d.spec_depth : (cfg.optimize ? 4 : 3), SFFK_SPEC_DEPTH));
   const int sets = std::max(1, std::min(d.spec_sets_want, 4));
   struct Sc { int level; int out[SFFK_SPEC_DEPTH]; int anc[SFFK_SPEC_DEPTH]; int child[9]; };
   std::vector<Sc> tab;

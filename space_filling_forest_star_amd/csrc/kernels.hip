@@ -4018,6 +4018,53 @@ __device__ __forceinline__ int sq_lemire(unsigned long long word, unsigned long 
   return (int)hi;
 }
 
+// isPathFree's common case INLINE: every sample of the edge lies in a cell the clearance bits (edge plane) call clear - the
+// same placement arithmetic as sq_path_free's first phase, so the same bits are asked; edges of up to 512 samples.  True =
+// free, the reference's counters advanced; false = undecided, nothing touched: the caller runs sq_path_free (out of line:
+// its call saves and restores a good part of a wavefront's registers - 1.5-2 us on the wavefront everybody waits for).
+__device__ __forceinline__ bool sq_edge_clear_fast(const EnvView& env, const double* a, const double* b, int lane,
+                                                   unsigned long long& calls, unsigned long long& samples) {
+  if (env.n_tri == 0 || !env.clear_bits_edge) return false;
+  const double parts = edge_parts(a, b);
+  const int ns = edge_samples(parts);
+  if (ns > 512) return false;
+  const float inv = (float)env.clear_inv * __frcp_rn((float)parts);
+  const float g0 = (float)((a[0] - env.clear_org[0]) * env.clear_inv), g1 = (float)((a[1] - env.clear_org[1]) * env.clear_inv),
+              g2 = (float)((a[2] - env.clear_org[2]) * env.clear_inv);
+  const float d0 = (float)(b[0] - a[0]) * inv, d1 = (float)(b[1] - a[1]) * inv, d2 = (float)(b[2] - a[2]) * inv;
+  const float nxd = (float)env.clear_n[0], nyd = (float)env.clear_n[1], nzd = (float)env.clear_n[2];
+  const uint32_t* wp[8];
+  int sh[8];
+  bool need[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    const int idx = 1 + 64 * u + lane;
+    need[u] = idx <= ns;
+    wp[u] = nullptr; sh[u] = 0;
+    if (need[u]) {
+      const float td = (float)idx;
+      const float fx = __builtin_fmaf(td, d0, g0), fy = __builtin_fmaf(td, d1, g1), fz = __builtin_fmaf(td, d2, g2);
+      if (fx >= 0 && fy >= 0 && fz >= 0 && fx < nxd && fy < nyd && fz < nzd) {
+        const uint32_t ci = ((uint32_t)(int)fz * (uint32_t)env.clear_n[1] + (uint32_t)(int)fy) * (uint32_t)env.clear_n[0] + (uint32_t)(int)fx;
+        wp[u] = env.clear_bits_edge + (ci >> 5);
+        sh[u] = (int)(ci & 31u);
+      } else if (fx == fx && fy == fy && fz == fz) {
+        need[u] = false;                                  // beyond the inflated box of the environment
+      }
+    }
+  }
+  uint32_t word[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) word[u] = wp[u] ? *wp[u] : 0u;
+  bool open = false;
+#pragma unroll
+  for (int u = 0; u < 8; ++u) open = open || (need[u] && !(wp[u] && ((word[u] >> sh[u]) & 1u)));
+  if (__any(open)) return false;
+  calls += (unsigned long long)ns;
+  samples += (unsigned long long)ns;
+  return true;
+}
+
 // Solver::isPathFree(a, b) by the wavefront: chunk after chunk until the first hit (the chunks come in sample order, so
 // the first chunk with a hit holds the edge's first hit).  Returns free; calls = Collide calls the reference makes.
 __device__ __attribute__((noinline)) bool sq_path_free(const EnvView& env, const RobotView& rob, const double* rtri, int32_t* stack, int32_t* cand, int32_t* queue,
@@ -4416,7 +4463,7 @@ __global__ __launch_bounds__(64) void k_seq_waves(SeqArgs A) {
       if (hit) continue;
       // ---- isPathFree(expanded, newPoint)
       pf += 1; ex_seg += 1;
-      const bool free0 = sq_path_free(A.env, A.rob, rtri, stack, cand, queue, stage, cpos, qp, &s_fh, &s_ovf, lane, cc, ex_smp, flt);
+      const bool free0 = (sq_edge_clear_fast(A.env, cpos, qp, lane, cc, ex_smp) || sq_path_free(A.env, A.rob, rtri, stack, cand, queue, stage, cpos, qp, &s_fh, &s_ovf, lane, cc, ex_smp, flt));
       bool reject = !free0;
       lap(3);
       const double pdist = dist6(cpos, qp);                        // parentDistance, :250
@@ -4512,10 +4559,10 @@ __global__ __launch_bounds__(64) void k_seq_waves(SeqArgs A) {
           for (int k = 0; k < 6; ++k) np6[k] = h_pos[6 * src + k];
           pf += 1; ex_seg += 1;
           if (s_same) {
-            const bool fr = sq_path_free(A.env, A.rob, rtri, stack, cand, queue, stage, np6, qp, &s_fh, &s_ovf, lane, cc, ex_smp, flt);
+            const bool fr = (sq_edge_clear_fast(A.env, np6, qp, lane, cc, ex_smp) || sq_path_free(A.env, A.rob, rtri, stack, cand, queue, stage, np6, qp, &s_fh, &s_ovf, lane, cc, ex_smp, flt));
             if (fr) reject = true;                                 // :276-280 overcrowded
           } else {
-            const bool fr = sq_path_free(A.env, A.rob, rtri, stack, cand, queue, stage, cpos, np6, &s_fh, &s_ovf, lane, cc, ex_smp, flt);
+            const bool fr = (sq_edge_clear_fast(A.env, cpos, np6, lane, cc, ex_smp) || sq_path_free(A.env, A.rob, rtri, stack, cand, queue, stage, cpos, np6, &s_fh, &s_ovf, lane, cc, ex_smp, flt));
             if (fr && !flt) {                                      // :288-294 border entry unless the pair has one
               const int a = s_id < node ? s_id : node, b = s_id < node ? node : s_id;
               const unsigned long long key = ((unsigned long long)(uint32_t)a << 32) | ((unsigned long long)(uint32_t)b + 1ULL);
@@ -4574,7 +4621,7 @@ __global__ __launch_bounds__(64) void k_seq_waves(SeqArgs A) {
               double mp[6];
               for (int q = 0; q < 6; ++q) mp[q] = sq_f64(A.st.pos + 6 * (size_t)idm + q);
               pf += 1; ex_seg += 1;
-              if (sq_path_free(A.env, A.rob, rtri, stack, cand, queue, stage, qp, mp, &s_fh, &s_ovf, lane, cc, ex_smp, flt) && !flt) {
+              if ((sq_edge_clear_fast(A.env, qp, mp, lane, cc, ex_smp) || sq_path_free(A.env, A.rob, rtri, stack, cand, queue, stage, qp, mp, &s_fh, &s_ovf, lane, cc, ex_smp, flt)) && !flt) {
                 best = nd; par_new = idm; dcl_new = __shfl(mt.d, m);
               }
             }
@@ -4629,7 +4676,7 @@ __global__ __launch_bounds__(64) void k_seq_waves(SeqArgs A) {
             for (int q = 0; q < 6; ++q) mp[q] = sq_f64(A.st.pos + 6 * (size_t)idm + q);
             pf += 1; ex_seg += 1;
             bool f2 = false;
-            const bool fr = sq_path_free(A.env, A.rob, rtri, stack, cand, queue, stage, mp, qp, &s_fh, &s_ovf, lane, cc, ex_smp, f2);
+            const bool fr = (sq_edge_clear_fast(A.env, mp, qp, lane, cc, ex_smp) || sq_path_free(A.env, A.rob, rtri, stack, cand, queue, stage, mp, qp, &s_fh, &s_ovf, lane, cc, ex_smp, f2));
             if (fr) {
               if (lane == 0) {
                 f.parent[idm] = idn; f.d_closest[idm] = dm; f.d_root[idm] = proposed;
@@ -5539,7 +5586,7 @@ __global__ __launch_bounds__(OPT ? 192 : 128) void k_spec_waves(SpecArgs S) {
         if (!hit) {
           // ---- isPathFree(expanded, newPoint)
           pf_l += 1; ex_seg += 1;
-          const bool free0 = sq_path_free(A.env, A.rob, rtri, stack, cand, queue, stage, cpos, qp, &s_fh, &s_ovf, lane, cc_l, ex_smp, flt);
+          const bool free0 = (sq_edge_clear_fast(A.env, cpos, qp, lane, cc_l, ex_smp) || sq_path_free(A.env, A.rob, rtri, stack, cand, queue, stage, cpos, qp, &s_fh, &s_ovf, lane, cc_l, ex_smp, flt));
           reject = !free0;
           beat(3);
           if (!reject && stale()) aborted = true;
@@ -5617,10 +5664,10 @@ __global__ __launch_bounds__(OPT ? 192 : 128) void k_spec_waves(SpecArgs S) {
               for (int k = 0; k < 6; ++k) np6[k] = h_pos[6 * src + k];
               pf_l += 1; ex_seg += 1;
               if (s_same) {
-                const bool fr = sq_path_free(A.env, A.rob, rtri, stack, cand, queue, stage, np6, qp, &s_fh, &s_ovf, lane, cc_l, ex_smp, flt);
+                const bool fr = (sq_edge_clear_fast(A.env, np6, qp, lane, cc_l, ex_smp) || sq_path_free(A.env, A.rob, rtri, stack, cand, queue, stage, np6, qp, &s_fh, &s_ovf, lane, cc_l, ex_smp, flt));
                 if (fr) reject = true;                                 // :276-280 overcrowded
               } else {
-                const bool fr = sq_path_free(A.env, A.rob, rtri, stack, cand, queue, stage, cpos, np6, &s_fh, &s_ovf, lane, cc_l, ex_smp, flt);
+                const bool fr = (sq_edge_clear_fast(A.env, cpos, np6, lane, cc_l, ex_smp) || sq_path_free(A.env, A.rob, rtri, stack, cand, queue, stage, cpos, np6, &s_fh, &s_ovf, lane, cc_l, ex_smp, flt));
                 if (fr && !flt) {                                      // :288-294 border entry (the leader knows whether the pair has one)
                   event = 1; ev_id = s_id; ev_tree = s_tree;
                   const double dr = s_id >= nns ? p_best[s_id - nns] : sq_f64(f.d_root + s_id);
@@ -5658,7 +5705,7 @@ __global__ __launch_bounds__(OPT ? 192 : 128) void k_spec_waves(SpecArgs S) {
                       double mp[6];
                       for (int q = 0; q < 6; ++q) mp[q] = sq_f64(A.st.pos + 6 * (size_t)idm + q);
                       pf_l += 1; ex_seg += 1;
-                      if (sq_path_free(A.env, A.rob, rtri, stack, cand, queue, stage, qp, mp, &s_fh, &s_ovf, lane, cc_l, ex_smp, flt) && !flt) {
+                      if ((sq_edge_clear_fast(A.env, qp, mp, lane, cc_l, ex_smp) || sq_path_free(A.env, A.rob, rtri, stack, cand, queue, stage, qp, mp, &s_fh, &s_ovf, lane, cc_l, ex_smp, flt)) && !flt) {
                         best = nd; par_new = idm; dcl_new = __shfl(mt.d, m);
                       }
                     }
@@ -5676,7 +5723,7 @@ __global__ __launch_bounds__(OPT ? 192 : 128) void k_spec_waves(SpecArgs S) {
                       for (int q = 0; q < 6; ++q) mp[q] = sq_f64(A.st.pos + 6 * (size_t)idm + q);
                       pf_l += 1; ex_seg += 1;
                       bool f2 = false;
-                      if (sq_path_free(A.env, A.rob, rtri, stack, cand, queue, stage, mp, qp, &s_fh, &s_ovf, lane, cc_l, ex_smp, f2)) {
+                      if ((sq_edge_clear_fast(A.env, mp, qp, lane, cc_l, ex_smp) || sq_path_free(A.env, A.rob, rtri, stack, cand, queue, stage, mp, qp, &s_fh, &s_ovf, lane, cc_l, ex_smp, f2))) {
                         if (lane == 0) {
                           s_rw[5 * n_rw] = (uint32_t)idm;
                           s_rw[5 * n_rw + 1] = sp_lo(dm); s_rw[5 * n_rw + 2] = sp_hi(dm);
