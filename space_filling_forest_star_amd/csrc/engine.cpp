@@ -825,8 +825,12 @@ void Ctx::collide_segments_ids(const int32_t* ida, const int32_t* idb, int n, ui
                                int32_t* n_samples) {
   collide_segments_core(nullptr, nullptr, ida, idb, n, is_free, first_hit, n_samples);
 }
+void Ctx::collide_segments_refs(const int32_t* ida, const int32_t* idb, int n, uint8_t* is_free, int32_t* first_hit, int32_t* n_samples) {
+  if (!rr_np_dev) throw HipError{"collide_segments_refs: no rrt_chain has run"};
+  collide_segments_core(nullptr, nullptr, ida, idb, n, is_free, first_hit, n_samples, rr_np_dev);
+}
 void Ctx::collide_segments_core(const double* a6, const double* b6, const int32_t* ida, const int32_t* idb, int n,
-                                uint8_t* is_free, int32_t* first_hit, int32_t* n_samples) {
+                                uint8_t* is_free, int32_t* first_hit, int32_t* n_samples, const double* extra_dev) {
   if (n <= 0) return;
   if (!have_env || !have_robot) throw HipError{"collide_segments: upload ENV and ROBOT meshes first"};
   HIPCHK(hipSetDevice(device));
@@ -856,7 +860,7 @@ void Ctx::collide_segments_core(const double* a6, const double* b6, const int32_
     HIPCHK(hipMemcpyAsync(d_d.p, h_a.p, (size_t)n * 4, hipMemcpyHostToDevice, stream));
     HIPCHK(hipMemcpyAsync(d_d.as<int32_t>() + n, h_b.p, (size_t)n * 4, hipMemcpyHostToDevice, stream));
     sffk::launch_seg_gather(stream, spos.as<double>(), d_d.as<int32_t>(), d_d.as<int32_t>() + n, n, d_a.as<double>(),
-                            d_b.as<double>());
+                            d_b.as<double>(), extra_dev);
   }
   HIPCHK(hipMemsetAsync(d_ctrl, 0, 64, stream));
   const int list_cap = 8 * n + 65536;
@@ -909,6 +913,103 @@ void Ctx::collide_segments_core(const double* a6, const double* b6, const int32_
     is_free[i] = fh[i] < 0 ? 1 : 0;
     if (first_hit) first_hit[i] = fh[i];
     if (n_samples) n_samples[i] = ns[i];
+  }
+}
+
+void Ctx::rrt_chain(const double* rnd6, const int32_t* tree, int n, double dist, bool by_grid1, int kmax, bool by_gridk,
+                    int32_t* near_idx, double* near_d, int32_t* near_cnt, double* np6, uint8_t* hit, int32_t* seg,
+                    int32_t* mem_idx, double* mem_d, int32_t* mem_cnt) {
+  if (n <= 0) return;
+  if (!have_env || !have_robot) throw HipError{"rrt_chain: upload ENV and ROBOT meshes first"};
+  HIPCHK(hipSetDevice(device));
+  const int K1 = 2;
+  rr_hq.ensure((size_t)n * sizeof(sffk::KnnQuery));
+  sffk::KnnQuery* hq = rr_hq.as<sffk::KnnQuery>();
+  for (int i = 0; i < n; ++i) {
+    memcpy(hq[i].pos, rnd6 + 6 * (size_t)i, sizeof hq[i].pos);
+    hq[i].tree = tree ? tree[i] : -1;
+    hq[i].max_id = std::numeric_limits<int32_t>::max();
+    hq[i].k = K1;
+    hq[i].mate_base = std::numeric_limits<int32_t>::max();
+    hq[i].whole_tree = 0;
+    hq[i].pad_ = 0;
+  }
+  // one result block, 8-byte parts first: near_d | np6 | mem_d | near_idx | near_cnt | seg (3 n + 16 control words) | mem_idx | mem_cnt | hit
+  const size_t km = (size_t)std::max(kmax, 0);
+  size_t o = 0;
+  const size_t o_nd = o; o += (size_t)n * K1 * 8;
+  const size_t o_np = o; o += (size_t)n * 48;
+  const size_t o_md = o; o += (size_t)n * km * 8;
+  const size_t o_ni = o; o += (size_t)n * K1 * 4;
+  const size_t o_nc = o; o += (size_t)n * 4;
+  const size_t o_sg = o; o += ((size_t)n * 3 + 16) * 4;
+  const size_t o_mi = o; o += (size_t)n * km * 4;
+  const size_t o_mc = o; o += (size_t)n * 4;
+  const size_t o_ht = o; o += ((size_t)n + 7) / 8 * 8;
+  const size_t o_end = o;
+  rr_q1.ensure((size_t)n * sizeof(sffk::KnnQuery));
+  rr_q2.ensure((size_t)n * sizeof(sffk::KnnQuery));
+  rr_a.ensure((size_t)n * 48);
+  rr_out.ensure(o_end);
+  rr_hout.ensure(o_end);
+  char* db = rr_out.as<char>();
+  HIPCHK(hipMemcpyAsync(rr_q1.p, rr_hq.p, (size_t)n * sizeof(sffk::KnnQuery), hipMemcpyHostToDevice, stream));
+  if ((by_grid1 || (kmax > 0 && by_gridk)) && grid_on) {
+    grid_insert_new();
+    grid_check(/*bulk=*/true);
+  }
+  int32_t* r_ni = reinterpret_cast<int32_t*>(db + o_ni);
+  double* r_nd = reinterpret_cast<double*>(db + o_nd);
+  int32_t* r_nc = reinterpret_cast<int32_t*>(db + o_nc);
+  double* r_np = reinterpret_cast<double*>(db + o_np);
+  int32_t* d_ns = reinterpret_cast<int32_t*>(db + o_sg);
+  int32_t* d_fh = d_ns + n;
+  int32_t* d_ov = d_fh + n;
+  int32_t* d_ctrl = d_ov + n;
+  time_begin(T_SWEEP);
+  if (by_grid1 && grid_on && store_n >= K1)
+    sffk::launch_knn_grid(stream, gridv, nullptr, store_view(), rr_q1.as<sffk::KnnQuery>(), n, K1, r_ni, r_nd, r_nc, nullptr, nullptr,
+                          grid_cell, 8 * sweep_eps(), SFFK_KNN_MATES, store_n);
+  else
+    sffk::launch_knn_linear(stream, store_view(), store_n, rr_q1.as<sffk::KnnQuery>(), n, K1, r_ni, r_nd, r_nc, sweep_eps());
+  time_end();
+  sffk::launch_rrt_steer(stream, rr_q1.as<sffk::KnnQuery>(), r_ni, K1, spos.as<double>(), dist, rr_a.as<double>(), r_np,
+                         kmax > 0 ? rr_q2.as<sffk::KnnQuery>() : nullptr, kmax, n);
+  HIPCHK(hipMemsetAsync(d_ctrl, 0, 64, stream));
+  const int list_cap = 8 * n + 65536;
+  r_items.ensure((size_t)list_cap * SFFK_ITEM_BYTES);
+  r_items2.ensure(((size_t)list_cap + (1u << 20)) * 8);
+  time_begin(T_COLLIDE);
+  sffk::launch_collide_poses(stream, envv, robv, r_np, n, nullptr, reinterpret_cast<uint8_t*>(db + o_ht), false);
+  sffk::launch_seg_prepare(stream, rr_a.as<double>(), r_np, n, d_ns, d_fh, d_ov);
+  sffk::launch_collide_segments_dyn(stream, envv, robv, rr_a.as<double>(), r_np, d_ns, n, d_ctrl, r_items.p, list_cap, r_items2.p,
+                                    d_fh, d_ov);
+  time_end();
+  if (kmax > 0) {
+    time_begin(T_SWEEP);
+    if (by_gridk && grid_on && store_n >= kmax)
+      sffk::launch_knn_grid(stream, gridv, nullptr, store_view(), rr_q2.as<sffk::KnnQuery>(), n, kmax, reinterpret_cast<int32_t*>(db + o_mi),
+                            reinterpret_cast<double*>(db + o_md), reinterpret_cast<int32_t*>(db + o_mc), nullptr, nullptr, grid_cell,
+                            8 * sweep_eps(), SFFK_KNN_MATES, store_n);
+    else
+      sffk::launch_knn_linear(stream, store_view(), store_n, rr_q2.as<sffk::KnnQuery>(), n, kmax, reinterpret_cast<int32_t*>(db + o_mi),
+                              reinterpret_cast<double*>(db + o_md), reinterpret_cast<int32_t*>(db + o_mc), sweep_eps());
+    time_end();
+  }
+  HIPCHK(hipMemcpyAsync(rr_hout.p, rr_out.p, o_end, hipMemcpyDeviceToHost, stream));
+  sync();
+  rr_np_dev = r_np;   // (stays on the device until the next chain: the wave's member edges name its rows, collide_segments_refs)
+  const char* hb = rr_hout.as<char>();
+  memcpy(near_idx, hb + o_ni, (size_t)n * K1 * 4);
+  memcpy(near_d, hb + o_nd, (size_t)n * K1 * 8);
+  memcpy(near_cnt, hb + o_nc, (size_t)n * 4);
+  memcpy(np6, hb + o_np, (size_t)n * 48);
+  memcpy(hit, hb + o_ht, (size_t)n);
+  memcpy(seg, hb + o_sg, (size_t)n * 12);
+  if (kmax > 0) {
+    memcpy(mem_idx, hb + o_mi, (size_t)n * km * 4);
+    memcpy(mem_d, hb + o_md, (size_t)n * km * 8);
+    memcpy(mem_cnt, hb + o_mc, (size_t)n * 4);
   }
 }
 

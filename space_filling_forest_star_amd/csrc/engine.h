@@ -183,8 +183,11 @@ struct Ctx {
   // round's temporary entries): 8 bytes per edge over PCIe instead of 96
   void collide_segments_ids(const int32_t* ida, const int32_t* idb, int n, uint8_t* is_free, int32_t* first_hit,
                             int32_t* n_samples);
+  // ids < 0 name row -1 - id of the new points the last rrt_chain left on the device (edges of an RRT wave: 8 bytes per edge up)
+  void collide_segments_refs(const int32_t* ida, const int32_t* idb, int n, uint8_t* is_free, int32_t* first_hit, int32_t* n_samples);
+  const double* rr_np_dev = nullptr;   // the new points of the last rrt_chain (inside rr_out)
   void collide_segments_core(const double* a6, const double* b6, const int32_t* ida, const int32_t* idb, int n,
-                             uint8_t* is_free, int32_t* first_hit, int32_t* n_samples);
+                             uint8_t* is_free, int32_t* first_hit, int32_t* n_samples, const double* extra_dev = nullptr);
   void sample_steer(const uint64_t* words, const double* center6, int n, double dist, int dim, const double* limits,
                     double* out6, uint8_t* in_limits);
   // exact radius query; results sorted by (dist, id).  Returns per-query totals in cnt.
@@ -194,6 +197,16 @@ struct Ctx {
   // index too (sffgpu_nodes_index / the RRT session's grid)
   void knn(const double* q6, int nq, int k, const int32_t* tree, const int32_t* max_id, int32_t* idx, double* dist,
            int32_t* cnt, bool tree_by_grid = false);
+  // RRT session, the first half of a speculative wave as ONE enqueued chain and one wait (was: three calls, three waits):
+  // the two nearest nodes of every steering target in its tree (near_* n x 2; the first is the nearest - two, so that the
+  // caller sees a tie) -> the steered new point (np6) -> its pose check (hit) -> the edge nearest -> new point (seg: n_samples |
+  // first_hit or INT_MAX | candidate list overflowed, n each) -> kmax > 0: the kmax nearest nodes of the new point in the tree
+  // (mem_* n x kmax).  Replaces src/rrt.h:143-151,166.
+  void rrt_chain(const double* rnd6, const int32_t* tree, int n, double dist, bool by_grid1, int kmax, bool by_gridk,
+                 int32_t* near_idx, double* near_d, int32_t* near_cnt, double* np6, uint8_t* hit, int32_t* seg,
+                 int32_t* mem_idx, double* mem_d, int32_t* mem_cnt);
+  DevBuf rr_q1, rr_q2, rr_a, rr_out;
+  PinBuf rr_hq, rr_hout;
   double sweep_eps() const;
   // one sweep launch over the first n_store entries; per-query hit lists sorted by (dist, id)
   void sweep_lists(const double* q6, int nq, const std::vector<double>& r, const int32_t* tree, const int32_t* max_id,
@@ -507,6 +520,8 @@ struct Rrt {
   int add_node(const double* pos, int root_tree, int tree, int parent, double dc, double dr, unsigned it);
   RLink make_link(int a, int b);
   void knn(const double* q, int nq, const int32_t* tree, int k, std::vector<std::vector<int>>& out);
+  bool knn_by_grid(const int32_t* tree, int nq, int k) const;
+  bool chain_on = true;   // SFFGPU_RRT_CHAIN (read when the session is created): nearest -> steer -> pose -> parent edge -> k nearest as one chain
   void expand(int tree_to_expand, unsigned iteration);
   void draw_target(double rnd[6]);
   int merge_or_link(int tree_to_expand, int new_id, int nb, bool edge_free, int fh, int ns, int& i);

@@ -325,6 +325,9 @@ void launch_knn_linear(hipStream_t s, const NodeStoreView& st, int n_store, cons
 // inside the covered ball.  Besides the k nearest STORE nodes it reports the round's temporaries (ids in
 // [mate_base, max_id)) that are not farther than the k-th store node: mate_idx nq x mate_cap, mate_cnt nq
 // (> mate_cap = overflow: the caller asks again with a larger list; SFFK_KNN_MATES is the first pass's capacity).
+// RRT session: nearest node -> steered point on the device (k_rrt_steer), see Ctx::rrt_chain
+void launch_rrt_steer(hipStream_t s, const KnnQuery* q1, const int32_t* idx1, int k1, const double* store_pos, double dist,
+                      double* a6, double* np6, KnnQuery* q2, int kmax, int n);
 void launch_knn_grid(hipStream_t s, const GridView& g, const GridView* tg, const NodeStoreView& st, const KnnQuery* q, int nq,
                      int kcap, int32_t* idx, double* dist, int32_t* cnt, int32_t* mate_idx, int32_t* mate_cnt, double cell,
                      double slack, int mate_cap = SFFK_KNN_MATES, int n_store = 0);   // n_store > 0: far queries fall back to a sweep of the store
@@ -427,8 +430,9 @@ struct SettleArgs {
 };
 void launch_settle(hipStream_t s, const SettleArgs& a);
 // end points of edges given as store ids -> a6 / b6
+// (ids < 0: row -1 - id of `extra`, device points that are not in the store)
 void launch_seg_gather(hipStream_t s, const double* store_pos, const int32_t* ida, const int32_t* idb, int n, double* a6,
-                       double* b6);
+                       double* b6, const double* extra = nullptr);
 void launch_seg_prepare(hipStream_t s, const double* a6, const double* b6, int n, int32_t* seg_ns, int32_t* first_hit,
                         int32_t* ovf);
 // ctrl = 16 zeroed ints: [1] scan cursor, [2] work items, [3] list overflow, [4..11] settle counters.

@@ -2273,14 +2273,16 @@ __global__ __launch_bounds__(64 * SEG_WAVES) void k_collide_segments_dyn(EnvView
   }
 }
 
+// (an id < 0 names row -1 - id of `extra`: points that are not in the store - the RRT session's new points of the wave)
 __global__ __launch_bounds__(256) void k_seg_gather(const double* __restrict__ store_pos, const int32_t* __restrict__ ida,
                                                     const int32_t* __restrict__ idb, int n, double* __restrict__ a6,
-                                                    double* __restrict__ b6) {
+                                                    double* __restrict__ b6, const double* __restrict__ extra) {
   const int t = blockIdx.x * 256 + threadIdx.x;   // 6 threads per edge end: one double each
   const int e = t / 12, k = t % 12;
   if (e >= n) return;
-  if (k < 6) a6[6 * (size_t)e + k] = store_pos[6 * (size_t)ida[e] + k];
-  else b6[6 * (size_t)e + (k - 6)] = store_pos[6 * (size_t)idb[e] + (k - 6)];
+  const int id = k < 6 ? ida[e] : idb[e], q = k < 6 ? k : k - 6;
+  const double v = id >= 0 ? store_pos[6 * (size_t)id + q] : extra[6 * (size_t)(-1 - id) + q];
+  if (k < 6) a6[6 * (size_t)e + q] = v; else b6[6 * (size_t)e + q] = v;
 }
 
 // sample counts + result presets for a host-supplied batch of edges (C-ABI sffgpu_collide_segments)
@@ -5811,6 +5813,32 @@ void launch_ring_trig(hipStream_t s, const uint64_t* words, double* trig, int n)
   if (n > 0) hipLaunchKernelGGL(k_ring_trig, dim3((n + 255) / 256), dim3(256), 0, s, words, trig, n);
 }
 
+// RRT session (csrc/rrt.cpp): nearest node -> steered point, on the device, so that the pose check, the parent edge and the
+// k nearest of the new point follow in the same enqueued chain (src/rrt.h:143-166).  q1: the steering targets, idx1 their
+// nearest nodes (k1 per query, the first one is used); writes the nearest node's position (a6), the new point (np6) and,
+// q2 != null, the k-nearest query of the new point.
+__global__ __launch_bounds__(256) void k_rrt_steer(const KnnQuery* __restrict__ q1, const int32_t* __restrict__ idx1, int k1,
+                                                   const double* __restrict__ store_pos, double dist, double* __restrict__ a6,
+                                                   double* __restrict__ np6, KnnQuery* __restrict__ q2, int kmax, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int near = idx1[(size_t)i * k1];
+  double a[6], t[6], o[6];
+  for (int k = 0; k < 6; ++k) { a[k] = store_pos[6 * (size_t)near + k]; t[k] = q1[i].pos[k]; }
+  steer(a, t, dist, o);
+  for (int k = 0; k < 6; ++k) { a6[6 * (size_t)i + k] = a[k]; np6[6 * (size_t)i + k] = o[k]; }
+  if (q2) {
+    KnnQuery q;
+    for (int k = 0; k < 6; ++k) q.pos[k] = o[k];
+    q.tree = q1[i].tree; q.max_id = 0x7fffffff; q.k = kmax; q.mate_base = 0x7fffffff; q.whole_tree = 0; q.pad_ = 0;
+    q2[i] = q;
+  }
+}
+void launch_rrt_steer(hipStream_t s, const KnnQuery* q1, const int32_t* idx1, int k1, const double* store_pos, double dist,
+                      double* a6, double* np6, KnnQuery* q2, int kmax, int n) {
+  if (n > 0) hipLaunchKernelGGL(k_rrt_steer, dim3((n + 255) / 256), dim3(256), 0, s, q1, idx1, k1, store_pos, dist, a6, np6, q2, kmax, n);
+}
+
 void launch_spec_waves(hipStream_t s, const SpecArgs& a) {
   const size_t lds = collide_lds_bytes(a.q.rob.n_tri, 1);
   const unsigned grid = 1u + (unsigned)(a.n_sets * a.n_slots);
@@ -6081,10 +6109,10 @@ void launch_classify(hipStream_t s, const ClassifyArgs& a) {
 }
 
 void launch_seg_gather(hipStream_t s, const double* store_pos, const int32_t* ida, const int32_t* idb, int n, double* a6,
-                       double* b6) {
+                       double* b6, const double* extra) {
   if (n <= 0) return;
   const long long threads = (long long)n * 12;
-  hipLaunchKernelGGL(k_seg_gather, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, store_pos, ida, idb, n, a6, b6);
+  hipLaunchKernelGGL(k_seg_gather, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, store_pos, ida, idb, n, a6, b6, extra);
 }
 
 void launch_seg_prepare(hipStream_t s, const double* a6, const double* b6, int n, int32_t* seg_ns, int32_t* first_hit,

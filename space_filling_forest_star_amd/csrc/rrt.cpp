@@ -21,6 +21,7 @@ namespace sff {
 #define HIPCHK(x) hip_check((x), #x)
 
 Rrt::Rrt(Ctx* c, const sffgpu_rrt_cfg& cf, const double* roots6, int n_roots) : ctx(c), cfg(cf) {
+  if (const char* e = getenv("SFFGPU_RRT_CHAIN")) chain_on = atoi(e) != 0;
   if (cfg.dim != 2 && cfg.dim != 6) throw HipError{"rrt: dim must be 2 or 6"};
   if (n_roots < 1) throw HipError{"rrt: at least one root"};
   if (cfg.priority_bias != 0 && !cfg.has_goal) throw HipError{"rrt: goal bias needs a goal (src/main.cpp:330-331)"};
@@ -95,18 +96,23 @@ RLink Rrt::make_link(int a, int b) {            // DistanceHolder(first, second)
 }
 
 // k nearest of one tree in the reference's order (distance, index in the tree's list)
-void Rrt::knn(const double* q, int nq, const int32_t* tree, int k, std::vector<std::vector<int>>& out) {
-  std::vector<int32_t> idx((size_t)nq * k), cnt(nq);
-  std::vector<double> dist((size_t)nq * k);
-  // One tree that holds (nearly) every node - single-root RRT / RRT*, lazy edges, a forest after its merges: the
-  // queries are answered from the grid cells around them (k_knn_grid) instead of one sweep of the store per query.
-  // (Several live trees: a query for a small tree far away would grow its shells over the whole grid - linear sweep.)
+// One tree that holds (nearly) every node - single-root RRT / RRT*, lazy edges, a forest after its merges: the
+// queries are answered from the grid cells around them (k_knn_grid) instead of one sweep of the store per query.
+// (Several live trees: a query for a small tree far away would grow its shells over the whole grid - linear sweep.)
+bool Rrt::knn_by_grid(const int32_t* tree, int nq, int k) const {
   bool by_grid = ctx->grid_on && nq > 0 && (int)nodes.size() >= 2048;
   for (int i = 0; i < nq && by_grid; ++i) {
     const int t = tree ? tree[i] : -1;
     if (t >= 0 && (int)trees[t].size() * 10 < (int)nodes.size() * 9) by_grid = false;
     if (t >= 0 && (int)trees[t].size() < std::max(k, 1024)) by_grid = false;
   }
+  return by_grid;
+}
+
+void Rrt::knn(const double* q, int nq, const int32_t* tree, int k, std::vector<std::vector<int>>& out) {
+  std::vector<int32_t> idx((size_t)nq * k), cnt(nq);
+  std::vector<double> dist((size_t)nq * k);
+  const bool by_grid = knn_by_grid(tree, nq, k);
   ctx->knn(q, nq, k, tree, nullptr, idx.data(), dist.data(), cnt.data(), by_grid);
   out.assign(nq, {});
   for (int i = 0; i < nq; ++i) {
@@ -332,55 +338,108 @@ int Rrt::run_wave(int B) {
   }
   const uint64_t draws_end = rng.draws;
   lap(0);
-  // ---- 2. nearest node of the frozen tree (:143), steer (:148)
-  {
-    std::vector<double> q((size_t)B * 6);
-    std::vector<int32_t> tq(B);
-    for (int j = 0; j < B; ++j) { memcpy(&q[6 * (size_t)j], w[j].rnd, 48); tq[j] = w[j].tree; }
-    std::vector<std::vector<int>> res;
-    const uint64_t keep = st.nn_queries;
-    knn(q.data(), B, tq.data(), 1, res);
-    st.nn_queries = keep;   // accounted per committed iteration below
-    for (int j = 0; j < B; ++j) {
-      w[j].nearest = res[j][0];
-      w[j].d_near = dist6(w[j].rnd, nodes[w[j].nearest].pos);
-      steer(nodes[w[j].nearest].pos, w[j].rnd, cfg.sampling_dist, w[j].np);
-    }
-  }
-  lap(1);
-  // ---- 3. new pose + parent edge (:149-151)
-  {
-    std::vector<double> p((size_t)B * 6), a((size_t)B * 6);
-    for (int j = 0; j < B; ++j) { memcpy(&p[6 * (size_t)j], w[j].np, 48); memcpy(&a[6 * (size_t)j], nodes[w[j].nearest].pos, 48); }
-    std::vector<uint8_t> hit(B), fr(B);
-    std::vector<int32_t> fh(B), ns(B);
-    c.collide_poses(p.data(), B, hit.data());
-    c.collide_segments(a.data(), p.data(), B, fr.data(), fh.data(), ns.data());
-    for (int j = 0; j < B; ++j) {
-      w[j].pose_hit = hit[j] != 0;
-      w[j].par_free = fr[j] != 0;
-      w[j].par_fh = fh[j];
-      w[j].par_ns = ns[j];
-    }
-  }
-  lap(2);
-  std::vector<int> alive;
-  for (int j = 0; j < B; ++j)
-    if (!w[j].pose_hit && w[j].par_free) alive.push_back(j);
-  const int nA = (int)alive.size();
-  // ---- 4. RRT*: k_max nearest store nodes around every surviving new point (:166)
   const int kmax = cfg.optimize ? (int)(size_t)(2 * M_E * std::log10((double)(N0 + B) + (cfg.lazy_edge ? 1.0 : 0.0))) : 0;
-  if (kmax > 0 && nA > 0) {
-    std::vector<double> q((size_t)nA * 6);
-    std::vector<int32_t> tq(nA);
-    for (int k = 0; k < nA; ++k) { memcpy(&q[6 * (size_t)k], w[alive[k]].np, 48); tq[k] = w[alive[k]].tree; }
-    std::vector<std::vector<int>> res;
-    const uint64_t keep = st.nn_queries;
-    knn(q.data(), nA, tq.data(), kmax, res);
-    st.nn_queries = keep;
-    for (int k = 0; k < nA; ++k) w[alive[k]].members = res[k];
+  std::vector<int> alive;
+  int nA = 0;
+  bool chained = false;
+  if (chain_on && kmax <= 64) {
+    // ---- 2-4 as ONE enqueued chain and one wait (Ctx::rrt_chain): the nearest node of the frozen tree (:143), the steered
+    // point (:148), its pose and parent edge (:149-151) and - RRT* - the k_max nearest store nodes of EVERY new point (:166;
+    // those of the points that die in between are thrown away)
+    std::vector<double> q((size_t)B * 6), np((size_t)B * 6), nd((size_t)B * 2), md((size_t)B * std::max(kmax, 1));
+    std::vector<int32_t> tq(B), ni((size_t)B * 2), nc(B), seg((size_t)B * 3), mi((size_t)B * std::max(kmax, 1)), mc(B);
+    std::vector<uint8_t> hit(B);
+    for (int j = 0; j < B; ++j) { memcpy(&q[6 * (size_t)j], w[j].rnd, 48); tq[j] = w[j].tree; }
+    c.rrt_chain(q.data(), tq.data(), B, cfg.sampling_dist, knn_by_grid(tq.data(), B, 1), kmax, kmax > 0 && knn_by_grid(tq.data(), B, kmax),
+                ni.data(), nd.data(), nc.data(), np.data(), hit.data(), seg.data(), mi.data(), md.data(), mc.data());
+    // (the nearest node is the first by (distance, position in its tree); the device orders by (distance, id): two nodes at
+    // exactly the same distance - or a query nobody answered - send the wave through the separate calls below)
+    chained = true;
+    for (int j = 0; j < B && chained; ++j)
+      if (nc[j] < 1 || (nc[j] >= 2 && nd[2 * (size_t)j] == nd[2 * (size_t)j + 1])) chained = false;
+    if (chained) {
+      lap(1);
+      for (int j = 0; j < B; ++j) {
+        WCand& cd = w[j];
+        cd.nearest = ni[2 * (size_t)j];
+        cd.d_near = dist6(cd.rnd, nodes[cd.nearest].pos);
+        memcpy(cd.np, &np[6 * (size_t)j], 48);
+        cd.pose_hit = hit[j] != 0;
+        int ns_j = seg[j], fh_j = seg[(size_t)B + j] == 0x7fffffff ? -1 : seg[(size_t)B + j];
+        if (seg[2 * (size_t)B + j]) {   // (the edge's triangle candidate list ran over: by itself through the batch call, which handles that)
+          uint8_t fr1 = 0; int32_t fh1 = -1, ns1 = 0;
+          c.collide_segments(nodes[cd.nearest].pos, cd.np, 1, &fr1, &fh1, &ns1);
+          fh_j = fh1; ns_j = ns1;
+        }
+        cd.par_free = fh_j < 0;
+        cd.par_fh = fh_j;
+        cd.par_ns = ns_j;
+      }
+      lap(2);
+      for (int j = 0; j < B; ++j)
+        if (!w[j].pose_hit && w[j].par_free) alive.push_back(j);
+      nA = (int)alive.size();
+      if (kmax > 0)
+        for (int j : alive) {
+          struct E { double d; int order; int id; };
+          std::vector<E> e;
+          for (int m = 0; m < mc[j]; ++m) { const int id = mi[(size_t)j * kmax + m]; e.push_back({md[(size_t)j * kmax + m], nodes[id].idx_in_tree, id}); }
+          std::sort(e.begin(), e.end(), [](const E& a, const E& b) { return a.d < b.d || (a.d == b.d && a.order < b.order); });
+          w[j].members.clear();
+          for (const E& x : e) w[j].members.push_back(x.id);
+        }
+      lap(3);
+    }
   }
-  lap(3);
+  if (!chained) {
+    // ---- 2. nearest node of the frozen tree (:143), steer (:148)
+    {
+      std::vector<double> q((size_t)B * 6);
+      std::vector<int32_t> tq(B);
+      for (int j = 0; j < B; ++j) { memcpy(&q[6 * (size_t)j], w[j].rnd, 48); tq[j] = w[j].tree; }
+      std::vector<std::vector<int>> res;
+      const uint64_t keep = st.nn_queries;
+      knn(q.data(), B, tq.data(), 1, res);
+      st.nn_queries = keep;   // accounted per committed iteration below
+      for (int j = 0; j < B; ++j) {
+        w[j].nearest = res[j][0];
+        w[j].d_near = dist6(w[j].rnd, nodes[w[j].nearest].pos);
+        steer(nodes[w[j].nearest].pos, w[j].rnd, cfg.sampling_dist, w[j].np);
+      }
+    }
+    lap(1);
+    // ---- 3. new pose + parent edge (:149-151)
+    {
+      std::vector<double> p((size_t)B * 6), a((size_t)B * 6);
+      for (int j = 0; j < B; ++j) { memcpy(&p[6 * (size_t)j], w[j].np, 48); memcpy(&a[6 * (size_t)j], nodes[w[j].nearest].pos, 48); }
+      std::vector<uint8_t> hit(B), fr(B);
+      std::vector<int32_t> fh(B), ns(B);
+      c.collide_poses(p.data(), B, hit.data());
+      c.collide_segments(a.data(), p.data(), B, fr.data(), fh.data(), ns.data());
+      for (int j = 0; j < B; ++j) {
+        w[j].pose_hit = hit[j] != 0;
+        w[j].par_free = fr[j] != 0;
+        w[j].par_fh = fh[j];
+        w[j].par_ns = ns[j];
+      }
+    }
+    lap(2);
+    for (int j = 0; j < B; ++j)
+      if (!w[j].pose_hit && w[j].par_free) alive.push_back(j);
+    nA = (int)alive.size();
+    // ---- 4. RRT*: k_max nearest store nodes around every surviving new point (:166)
+    if (kmax > 0 && nA > 0) {
+      std::vector<double> q((size_t)nA * 6);
+      std::vector<int32_t> tq(nA);
+      for (int k = 0; k < nA; ++k) { memcpy(&q[6 * (size_t)k], w[alive[k]].np, 48); tq[k] = w[alive[k]].tree; }
+      std::vector<std::vector<int>> res;
+      const uint64_t keep = st.nn_queries;
+      knn(q.data(), nA, tq.data(), kmax, res);
+      st.nn_queries = keep;
+      for (int k = 0; k < nA; ++k) w[alive[k]].members = res[k];
+    }
+    lap(3);
+  }
   // ---- 5. other trees: every node within treeDistance of the new point; per tree the nearest one (:228-231)
   if (nA > 0 && tree_frontier.size() > 1) {
     std::vector<double> q((size_t)nA * 6), rr(nA, cfg.dist_tree);
@@ -418,8 +477,12 @@ int Rrt::run_wave(int B) {
   // ---- 6. all remaining edges in one launch: RRT* member edges in both directions (store members and the
   // earlier new points of the same tree that may enter the k-nearest set), links to other trees (store
   // nearest and earlier new points of other trees within treeDistance)
+  // (a chained wave: the new points are still on the device - an edge travels as two references, a store node's id or
+  // -1 - j for the wave's j-th new point, 8 bytes instead of 96)
   std::vector<double> ea, eb;
-  auto add_edge = [&](const double* a, const double* b) {
+  std::vector<int32_t> ra, rb;
+  auto add_edge = [&](const double* a, const double* b, int ref_a, int ref_b) {
+    if (chained) { ra.push_back(ref_a); rb.push_back(ref_b); return (int)ra.size() - 1; }
     int id = (int)(ea.size() / 6);
     ea.insert(ea.end(), a, a + 6);
     eb.insert(eb.end(), b, b + 6);
@@ -445,30 +508,32 @@ int Rrt::run_wave(int B) {
       }
       for (size_t e = 0; e < cd.medges.size(); ++e) {
         const double* op = cd.medges[e].other >= 0 ? nodes[cd.medges[e].other].pos : w[-1 - cd.medges[e].other].np;
+        const int oref = cd.medges[e].other;   // (a store node's id, or -1 - i: the same encoding)
         refs.push_back({j, 0, (int)e});
-        add_edge(cd.np, op);          // isPathFree(newPoint, neighbor)  :172
+        add_edge(cd.np, op, -1 - j, oref);          // isPathFree(newPoint, neighbor)  :172
         refs.push_back({j, 1, (int)e});
-        add_edge(op, cd.np);          // isPathFree(neighbor, newPoint)  :184
+        add_edge(op, cd.np, oref, -1 - j);          // isPathFree(neighbor, newPoint)  :184
       }
     }
     for (size_t e = 0; e < cd.conns.size(); ++e) {
       refs.push_back({j, 2, (int)e});
-      add_edge(cd.np, nodes[cd.conns[e].node].pos);   // isPathFree(newPoint, neighbor)  :231
+      add_edge(cd.np, nodes[cd.conns[e].node].pos, -1 - j, cd.conns[e].node);   // isPathFree(newPoint, neighbor)  :231
     }
     for (int kk = 0; kk < k; ++kk) {
       const int i = alive[kk];
       if (w[i].tree == cd.tree) continue;
       if (std::fabs(w[i].np[0] - cd.np[0]) >= cfg.dist_tree) continue;
       if (dist6(w[i].np, cd.np) < cfg.dist_tree) {
-        mate_conns.push_back({j, i, add_edge(cd.np, w[i].np)});
+        mate_conns.push_back({j, i, add_edge(cd.np, w[i].np, -1 - j, -1 - i)});
         refs.push_back({j, 3, (int)mate_conns.size() - 1});
       }
     }
   }
-  const int nE = (int)(ea.size() / 6);
+  const int nE = chained ? (int)ra.size() : (int)(ea.size() / 6);
   std::vector<uint8_t> efr(nE);
   std::vector<int32_t> efh(nE), ens(nE);
-  if (nE) c.collide_segments(ea.data(), eb.data(), nE, efr.data(), efh.data(), ens.data());
+  if (nE && chained) c.collide_segments_refs(ra.data(), rb.data(), nE, efr.data(), efh.data(), ens.data());
+  else if (nE) c.collide_segments(ea.data(), eb.data(), nE, efr.data(), efh.data(), ens.data());
   for (int e = 0; e < nE; ++e) {
     const Ref& r = refs[e];
     WCand& cd = w[r.cand];
@@ -580,7 +645,8 @@ int Rrt::run_wave(int B) {
   lap(6);
   // ---- 8. commit: device store, RNG position
   if (!pend_tree.empty()) {
-    c.store_append(pend_pos.data(), pend_tree.data(), (int)pend_tree.size());
+    // (after a chained wave nothing touches the staging buffer before the next wave's chain has waited for the stream)
+    c.store_append(pend_pos.data(), pend_tree.data(), (int)pend_tree.size(), /*wait=*/!chained);
     pend_pos.clear();
     pend_tree.clear();
   }
@@ -623,6 +689,7 @@ void Rrt::run(int max_iters) {
     }
     if (got == 0 && want > 0 && iter >= cfg.max_iterations) break;
   }
+  if (chain_on) ctx->sync();   // (the last wave's append)
   st.total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   if (getenv("SFFGPU_PROFILE")) {
     fprintf(stderr, "[sffgpu rrt run_wave ms] draws %.1f | nearest %.1f | pose + parent edge %.1f | k nearest %.1f | other trees %.1f | edge lists + edges %.1f | replay %.1f | append %.1f  (%llu waves)\n",
