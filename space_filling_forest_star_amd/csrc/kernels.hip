@@ -1378,31 +1378,76 @@ __global__ __launch_bounds__(256) void k_clear_scatter(EnvView env, ClearBuildAr
   const long long rows = (long long)nyr * (i1[2] - i0[2] + 1);
   const int nwmax = ((i1[0] - i0[0]) >> 5) + 2;
   const long long tasks = rows * nwmax;
-  // (blockIdx.y: the triangle's tasks dealt out to several workgroups - a few large triangles were the whole launch)
-  for (long long task = (long long)blockIdx.y * 256 + threadIdx.x; task < tasks; task += 256LL * gridDim.y) {
-    const long long row = task / nwmax;
-    const int k = (int)(task - row * nwmax);
-    const int iy = i0[1] + (int)(row % nyr), iz = i0[2] + (int)(row / nyr);
-    const long long base = ((long long)iz * env.clear_n[1] + iy) * env.clear_n[0];
-    const long long l0 = base + i0[0], l1 = base + i1[0];
-    const long long w = (l0 >> 5) + k;
-    if (w > (l1 >> 5)) continue;
-    const long long c0 = w * 32 > l0 ? w * 32 : l0, c1 = w * 32 + 31 < l1 ? w * 32 + 31 : l1;
-    uint32_t mp = 0u, me = 0u;
-    for (long long l = c0; l <= c1; ++l) {
-      const long long ix = l - base;
-      const double c[3] = {env.clear_org[0] + ((double)ix + 0.5) * h, env.clear_org[1] + ((double)iy + 0.5) * h,
-                           env.clear_org[2] + ((double)iz + 0.5) * h};
-      // (a cell farther from the triangle's PLANE than the reach is farther from the triangle: six flops instead of the
-      // closest-point computation for most cells of a slanted triangle's box - the launch was as long as those boxes)
-      if (env.tri_plane && plane_clear(env.tri_plane + 5 * (size_t)t, c, reach)) continue;
-      // (one closest-point computation, compared with both radii: tri_far's arithmetic)
-      double dd = 0.0, mag = 0.0;
-      const bool known = tri_dist2(T, c, dd, mag);
-      if (known && dist2_far(dd, mag, reach)) continue;
-      if (!(known && dist2_far(dd, mag, P.thr_pose)) && tri_box_maybe(T, c, P.pose_lo, P.pose_hi)) mp |= 1u << (int)(l & 31);
-      if (!(known && dist2_far(dd, mag, P.thr_edge)) && tri_box_maybe(T, c, P.edge_lo, P.edge_hi)) me |= 1u << (int)(l & 31);
+  // (blockIdx.y: the triangle's tasks dealt out to several workgroups - a few large triangles were the whole launch).
+  // Round 6: a thread still owns one 32-cell word of a row, but it only FILTERS its cells (six flops each: farther from the
+  // triangle's plane than the reach = untouched); the cells that pass are then dealt out over the wavefront's lanes, 64 at a
+  // time, for the closest-point computation and the two box tests (hundreds of fp64 operations), and their verdicts come
+  // back to the word's owner through LDS.  Before, every thread walked its 32 cells one after the other and a wavefront was
+  // as slow as its busiest lane.
+  __shared__ uint32_t s_mp[256], s_me[256];
+  const int lane = threadIdx.x & 63, wbase = threadIdx.x & ~63;
+  const double* pl = env.tri_plane ? env.tri_plane + 5 * (size_t)t : nullptr;
+  const long long stride = 256LL * gridDim.y;
+  for (long long task0 = (long long)blockIdx.y * 256; task0 < tasks; task0 += stride) {
+    const long long task = task0 + threadIdx.x;
+    long long w = 0, base = 0, c0 = 0, c1 = -1;
+    int iy = 0, iz = 0;
+    uint32_t cand = 0u;
+    if (task < tasks) {
+      const long long row = task / nwmax;
+      const int k = (int)(task - row * nwmax);
+      iy = i0[1] + (int)(row % nyr); iz = i0[2] + (int)(row / nyr);
+      base = ((long long)iz * env.clear_n[1] + iy) * env.clear_n[0];
+      const long long l0 = base + i0[0], l1 = base + i1[0];
+      w = (l0 >> 5) + k;
+      if (w <= (l1 >> 5)) {
+        c0 = w * 32 > l0 ? w * 32 : l0; c1 = w * 32 + 31 < l1 ? w * 32 + 31 : l1;
+        const double cy = env.clear_org[1] + ((double)iy + 0.5) * h, cz = env.clear_org[2] + ((double)iz + 0.5) * h;
+        for (long long l = c0; l <= c1; ++l) {
+          const double c[3] = {env.clear_org[0] + ((double)(l - base) + 0.5) * h, cy, cz};
+          if (!(pl && plane_clear(pl, c, reach))) cand |= 1u << (int)(l & 31);
+        }
+      }
     }
+    s_mp[threadIdx.x] = 0u; s_me[threadIdx.x] = 0u;
+    // the wavefront's candidates, 64 at a time (wavefront-local: no barrier - the LDS words are this wavefront's own)
+    int cnt = __popc(cand), inc = cnt;
+    for (int off = 1; off < 64; off <<= 1) {
+      const int o = __shfl_up(inc, off);
+      if (lane >= off) inc += o;
+    }
+    const int total = __shfl(inc, 63);
+    __builtin_amdgcn_wave_barrier();
+    for (int b0 = 0; b0 < total; b0 += 64) {
+      const int j = b0 + lane;
+      const int jj = j < total ? j : total - 1;
+      int lo = 0, hi = 63;
+      while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (__shfl(inc, mid) > jj) hi = mid; else lo = mid + 1;
+      }
+      const int nth = jj - (__shfl(inc, lo) - __shfl(cnt, lo));   // which of the owner's candidates
+      uint32_t m = (uint32_t)__shfl((int)cand, lo);
+      for (int q = 0; q < nth; ++q) m &= m - 1u;
+      const int bit = __ffs((int)m) - 1;
+      const long long ow = __shfl((long long)w, lo), ob = __shfl((long long)base, lo);
+      const int oy = __shfl(iy, lo), oz = __shfl(iz, lo);
+      if (j < total) {
+        const long long ix = ow * 32 + bit - ob;
+        const double c[3] = {env.clear_org[0] + ((double)ix + 0.5) * h, env.clear_org[1] + ((double)oy + 0.5) * h,
+                             env.clear_org[2] + ((double)oz + 0.5) * h};
+        // (one closest-point computation, compared with both radii: tri_far's arithmetic)
+        double dd = 0.0, mag = 0.0;
+        const bool known = tri_dist2(T, c, dd, mag);
+        if (!(known && dist2_far(dd, mag, reach))) {
+          if (!(known && dist2_far(dd, mag, P.thr_pose)) && tri_box_maybe(T, c, P.pose_lo, P.pose_hi)) atomicOr(&s_mp[wbase + lo], 1u << bit);
+          if (!(known && dist2_far(dd, mag, P.thr_edge)) && tri_box_maybe(T, c, P.edge_lo, P.edge_hi)) atomicOr(&s_me[wbase + lo], 1u << bit);
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t mp = __hip_atomic_load(&s_mp[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    const uint32_t me = __hip_atomic_load(&s_me[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (mp) atomicAnd(bits_pose + w, ~mp);
     if (me) atomicAnd(bits_edge + w, ~me);
   }

@@ -62,7 +62,7 @@ def make(S, ctx, name, wave, iters, seed, n_roots=5, budget=0, which="device", o
 
 
 @pytest.mark.parametrize("name,wave,iters", [
-    ("dense3d", 1, 600), ("dense3d", 7, 2500), ("dense3d", 64, 8000), ("dense3d", 512, 40000), ("dense3d", 4096, 100000),
+    ("dense3d", 1, 600), ("dense3d", 7, 2500), ("dense3d", 64, 8000), ("dense3d", 512, 40000), ("dense3d", 4096, 75000),
     ("dense3d_coarse", 1, 800), ("dense3d_coarse", 64, 8000), ("dense3d_coarse", 1024, 20000),
     ("triang", 1, 600), ("triang", 128, 10000), ("triang", 2048, 60000),
     ("dense2d", 3, 1500), ("dense2d", 256, 8000), ("building", 256, 8000),
@@ -93,7 +93,7 @@ def test_single_goal_mode_on_the_device_engine(S, ctx, name, wave, n_roots, opti
 
 
 @pytest.mark.parametrize("name,wave,iters", [
-    ("dense3d", 1, 500), ("dense3d", 7, 2500), ("dense3d", 64, 8000), ("dense3d", 512, 40000), ("dense3d", 4096, 100000),
+    ("dense3d", 1, 500), ("dense3d", 7, 2500), ("dense3d", 64, 8000), ("dense3d", 512, 40000), ("dense3d", 4096, 75000),
     ("dense3d_coarse", 64, 8000), ("dense3d_coarse", 1024, 20000),
     ("triang", 1, 600), ("triang", 128, 10000), ("triang", 2048, 60000),
     ("dense2d", 3, 1500), ("dense2d", 256, 8000), ("building", 256, 8000), ("building", 2048, 80000),
@@ -472,7 +472,7 @@ def test_library_driven_rccl_exchange_on_one_rank(S):
 def test_arrays_and_border_table_grow_on_demand(S, ctx):
     """no node budget: the store starts at 4096 nodes and has to grow; many borders: the border list and its hash
     table start small (test knob) and have to grow too"""
-    fo, fg = make(S, ctx, "dense3d_coarse", 256, 32000, seed=6, SFFGPU_TEST_BORDER_CAP=64)
+    fo, fg = make(S, ctx, "dense3d_coarse", 256, 26000, seed=6, SFFGPU_TEST_BORDER_CAP=64)
     fo.run()
     fg.run()
     assert fo.stats()["n_nodes"] > 3000 and fo.stats()["n_borders"] > 300
