@@ -411,6 +411,45 @@ def test_speculated_waves_staged_budget_faults_and_parity_mode(S, ctx):
     assert mid_wave > 0
 
 
+def test_speculated_waves_other_attempt_counts_iteration_caps_and_the_parent_history(S, ctx):
+    """k_spec_waves off the beaten path: ThresholdMisses other than 5 (the tree has ThresholdMisses + 1 outcomes per wave), an
+    iteration cap that ends the run in the middle of a wave (the attempts beyond it are never evaluated: src/forest.h:155-159),
+    and SFF*'s parent history (record_parents: creations and rewires in the reference's order, written by the leader)."""
+    sc, w = load_world(ctx, "dense3d")
+    roots = common.free_roots(w.collide, sc["limits"], 6, seed=11, dim=6)
+    base = dict(dist_tree=sc["dist_tree"], sampling_dist=sc["sampling_dist"], dim=6, wave=1, seed=11)
+    for tm, optimize in ((1, False), (2, True), (3, False), (8, False), (7, True)):
+        kw = dict(base, threshold_misses=tm, max_iterations=2200, optimize=optimize)
+        fo = O.Forest(w, roots, sc["limits"], **kw)
+        fg = S.Forest(ctx, roots, sc["limits"], **kw)
+        fo.run()
+        fg.run()
+        assert_same_forest(fo, fg)
+        assert fg.stats()["spec_committed"] == fo.stats()["iterations"], tm
+        fg.close()
+    for iters in (1501, 1502, 1503, 1504, 1505, 1506):
+        for optimize in (False, True):
+            kw = dict(base, max_iterations=iters, optimize=optimize)
+            fo = O.Forest(w, roots, sc["limits"], **kw)
+            fg = S.Forest(ctx, roots, sc["limits"], **kw)
+            fo.run()
+            fg.run()
+            assert fo.stats()["iterations"] == iters
+            assert_same_forest(fo, fg)
+            fg.close()
+    hist = {}
+    for spec in ("1", "0"):
+        with engine(SFFGPU_SPEC=spec):
+            fg = S.Forest(ctx, roots, sc["limits"], max_iterations=5000, optimize=True, record_parents=True, **base)
+        fg.run()
+        assert (fg.stats()["spec_steps"] > 0) == (spec == "1")
+        hist[spec] = fg.parent_history()
+        fg.close()
+    for k in ("node", "parent", "iter"):
+        assert np.array_equal(hist["1"][k], hist["0"][k]), k
+    assert len(hist["1"]["node"]) > 1000
+
+
 def test_staged_runs_with_getters_in_between(S, ctx):
     fo, fg = make(S, ctx, "dense3d", 512, 10 ** 7, seed=5, budget=20000)
     fo.run()
