@@ -4875,10 +4875,10 @@ __device__ __forceinline__ double sp_f64(uint32_t lo, uint32_t hi) {
 #define SPB_NNC 9      // nodes then: the array's entry FNPC + i is node NNC + i
 #define SPB_NNS 10     // nodes whose store entries are complete; the NN - NNS behind them are PENDING: accepted in the step before, written
                        // by the leader while this step is evaluated - their early rows travel in the block (SPB_PEND)
-#define SPB_ER 16      // the erased positions, ascending (SP_ER_MAX)
-#define SPB_PEND 32    // pending nodes: 16 granules each (the early row's layout), SFFK_SPEC_DEPTH of them at most
-#define SPB_USED (SPB_PEND + 16 * SFFK_SPEC_DEPTH)
-#define SP_ER_MAX 16
+#define SPB_PEND 16    // pending nodes: 16 granules each (the early row's layout), SFFK_SPEC_DEPTH of them at most
+#define SPB_ER (SPB_PEND + 16 * SFFK_SPEC_DEPTH)   // the erased positions, ascending (SP_ER_MAX)
+#define SP_ER_MAX 48
+#define SPB_USED (SPB_ER + SP_ER_MAX)
 #define SP_BASE 128    // granules per control block
 #define SP_QUIT 0xffffffffu
 
@@ -4888,6 +4888,27 @@ __device__ __forceinline__ int lds_ld(const int32_t* p) { return __hip_atomic_lo
 __device__ __forceinline__ void lds_st(int32_t* p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 // one wavefront's own LDS traffic: what a lane wrote, the other lanes read behind this
 #define SP_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+
+// The sorted list of erased frontier positions (LDS, n <= 64 entries), by one wavefront.
+// Position in the array of the logical-th entry that is still there.  The sequential rule - walk the list in ascending order,
+// every erased position at or below the running index pushes it up by one - hits a PREFIX of the list (once an entry lies
+// above the index all later ones do), and entry e is in that prefix iff er[e] - e <= logical (er[e] - e never decreases): one
+// LDS read per lane and a ballot instead of a loop over the list.
+__device__ __forceinline__ int sp_er_map(const int32_t* er, int n, int logical, int lane) {
+  const bool hit = lane < n && er[lane] - lane <= logical;
+  return logical + __popcll(__ballot(hit));
+}
+// inserts idx (not in the list), keeping it sorted: every lane moves its entry up by one if it lies above idx
+__device__ __forceinline__ void sp_er_insert(int32_t* er, int& n, int idx, int lane) {
+  SP_WAVE_SYNC();
+  const int mine = lane < n ? er[lane] : 0x7fffffff;
+  const int at = __popcll(__ballot(lane < n && mine < idx));
+  SP_WAVE_SYNC();
+  if (lane < n && mine > idx) er[lane + 1] = mine;
+  if (lane == 0) er[at] = idx;
+  ++n;
+  SP_WAVE_SYNC();
+}
 
 template <bool OPT>
 __global__ __launch_bounds__(OPT ? 192 : 128) void k_spec_waves(SpecArgs S) {
@@ -4939,21 +4960,8 @@ __global__ __launch_bounds__(OPT ? 192 : 128) void k_spec_waves(SpecArgs S) {
     // nearly full - and when the launch ends - the array is compacted in one pass.  Since the last compaction: fn_pc entries
     // then, nn_c nodes then (entry fn_pc + i holds node nn_c + i), ner erased positions in s_er.
     int fn_pc = fn, nn_c = n_nodes, ner = 0, nn_base = n_nodes;
-    auto er_map = [&](int logical) -> int {      // position in the array of the logical-th entry that is still there
-      int idx = logical;
-      for (int e = 0; e < ner; ++e) if (s_er[e] <= idx) ++idx;
-      return idx;
-    };
-    auto er_insert = [&](int idx) {
-      SP_WAVE_SYNC();
-      if (lane == 0) {
-        int at = ner;
-        while (at > 0 && s_er[at - 1] > idx) { s_er[at] = s_er[at - 1]; --at; }
-        s_er[at] = idx;
-      }
-      ++ner;
-      SP_WAVE_SYNC();
-    };
+    auto er_map = [&](int logical) -> int { return sp_er_map(s_er, ner, logical, lane); };
+    auto er_insert = [&](int idx) { sp_er_insert(s_er, ner, idx, lane); };
     auto compact = [&]() {
       if (ner > 0) {
         const int pfn = fn_pc + (n_nodes - nn_c);
@@ -4968,10 +4976,11 @@ __global__ __launch_bounds__(OPT ? 192 : 128) void k_spec_waves(SpecArgs S) {
           for (int u = 0; u < 16; ++u) {
             const int j = j0 + 64 * u + lane;
             if (j >= pfn) continue;
-            int below = 0;
-            bool gone = false;
-            for (int e = 0; e < ner; ++e) { const int x = s_er[e]; below += x < j ? 1 : 0; gone = gone || x == j; }
-            if (!gone) wt_i32(frontier + j - below, v[u]);
+            // (erased positions below j, by bisection of the sorted list)
+            int lo = 0, hi = ner;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (s_er[mid] < j) lo = mid + 1; else hi = mid; }
+            const bool gone = lo < ner && s_er[lo] == j;
+            if (!gone) wt_i32(frontier + j - lo, v[u]);
           }
         }
       }
@@ -5453,8 +5462,13 @@ __global__ __launch_bounds__(OPT ? 192 : 128) void k_spec_waves(SpecArgs S) {
       if (whole && t0 > last) {
         step = t0; s_row[lane] = (uint32_t)g;
         // (the pending rows: granules SPB_PEND .. SPB_USED - 1 of the block, 16 per node)
-        if (lane >= SPB_PEND) s_acc[(lane - SPB_PEND) >> 4][(lane - SPB_PEND) & 15] = (uint32_t)g;
-        if (64 + lane < SPB_USED) s_acc[(64 + lane - SPB_PEND) >> 4][(64 + lane - SPB_PEND) & 15] = (uint32_t)g2;
+        {   // granule gi of the block -> the pending rows / the erase list
+          const int gi0 = lane, gi1 = 64 + lane;
+          if (gi0 >= SPB_PEND && gi0 < SPB_ER) s_acc[(gi0 - SPB_PEND) >> 4][(gi0 - SPB_PEND) & 15] = (uint32_t)g;
+          if (gi1 >= SPB_PEND && gi1 < SPB_ER) s_acc[(gi1 - SPB_PEND) >> 4][(gi1 - SPB_PEND) & 15] = (uint32_t)g2;
+          if (gi0 >= SPB_ER && gi0 < SPB_USED) s_er[gi0 - SPB_ER] = (int)(uint32_t)g;
+          if (gi1 >= SPB_ER && gi1 < SPB_USED) s_er[gi1 - SPB_ER] = (int)(uint32_t)g2;
+        }
         break;
       }
       __builtin_amdgcn_s_sleep(2);
@@ -5467,7 +5481,6 @@ __global__ __launch_bounds__(OPT ? 192 : 128) void k_spec_waves(SpecArgs S) {
     const int ef0 = (int)s_row[SPB_EF];
     const int ne0 = (int)s_row[SPB_NE], fnpc = (int)s_row[SPB_FNPC], nnc = (int)s_row[SPB_NNC], nns = (int)s_row[SPB_NNS];
     const int n_pend = nn0 - nns;                // nodes the leader is still writing: from the block, never from the store
-    if (lane < SP_ER_MAX) s_er[lane] = (int)s_row[SPB_ER + lane];
     if (lane < 6 * SFFK_SPEC_DEPTH) { const int k = lane / 6, q = lane - 6 * k; p_pos[6 * k + q] = sp_f64(s_acc[k][2 * q], s_acc[k][2 * q + 1]); }
     if (lane < SFFK_SPEC_DEPTH) { p_tree[lane] = (int)s_acc[lane][12]; p_best[lane] = sp_f64(s_acc[lane][13], s_acc[lane][14]); }
     SP_WAVE_SYNC();
@@ -5487,11 +5500,7 @@ __global__ __launch_bounds__(OPT ? 192 : 128) void k_spec_waves(SpecArgs S) {
     // sorted list, the ones my scenario's failed waves erase; ne = mine among them)
     int ne = 0, na = 0, nel = ne0, pslot[SFFK_SPEC_DEPTH];
     for (int l = 0; l < SFFK_SPEC_DEPTH; ++l) pslot[l] = 0;
-    auto er_map = [&](int logical) -> int {
-      int idx = logical;
-      for (int e = 0; e < nel; ++e) if (s_er[e] <= idx) ++idx;
-      return idx;
-    };
+    auto er_map = [&](int logical) -> int { return sp_er_map(s_er, nel, logical, lane); };
     bool valid = ne0 >= 0 && ne0 <= SP_ER_MAX && n_pend >= 0 && n_pend <= SFFK_SPEC_DEPTH;
     for (int l = 0; l < level && valid; ++l) {
       const int ucl = scn > 0 && ef0;
@@ -5512,14 +5521,7 @@ __global__ __launch_bounds__(OPT ? 192 : 128) void k_spec_waves(SpecArgs S) {
         if (!ucl) {
           if (pk >= fn0 - ne) { valid = false; break; }   // (a node of this step: not modelled)
           const int idx = er_map(pk);
-          SP_WAVE_SYNC();
-          if (lane == 0) {                       // keep the list sorted
-            int at = nel;
-            while (at > 0 && s_er[at - 1] > idx) { s_er[at] = s_er[at - 1]; --at; }
-            s_er[at] = idx;
-          }
-          ++nel;
-          SP_WAVE_SYNC();
+          sp_er_insert(s_er, nel, idx, lane);   // (keeps the list sorted)
           ++ne; --sfn; ++scn;
         }
       }
