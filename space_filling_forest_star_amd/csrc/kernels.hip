@@ -4993,6 +4993,7 @@ __global__ __launch_bounds__(OPT ? 192 : 128) void k_spec_waves(SpecArgs S) {
     const bool clk = f.profile != 0;
     unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tq = clk ? wall_clock64() : 0ULL;
     auto lap = [&](int k) { if (!clk) return; const unsigned long long t = wall_clock64(); ph[k] += t - tq; tq = t; };
+    int grid_ovf_now = sq_i32(A.grid_ovf_src);   // (read once: only apply_accept below adds to the overflow list while the launch runs)
     // the node of an accepted attempt (row 0 of its record): a lane per word - one store instruction per width instead of
     // thirty stores of lane 0
     auto apply_accept = [&](const uint32_t* row, int idn, int iter_v, int n_rw) {
@@ -5067,6 +5068,7 @@ __global__ __launch_bounds__(OPT ? 192 : 128) void k_spec_waves(SpecArgs S) {
         wt_i32(g.cnt + cell, gslot + 1);
         if (OPT) atomicAdd(A.tree_cnt + 16 * mine, 1);
       }
+      if (govf >= 0 && g.ovf_cnt == A.grid_ovf_src) grid_ovf_now = govf + 1;
     };
     int n_acc = 0;                               // accepted attempts of the step whose rows wait in s_acc
     // ---- publish the control block of the next step; n_pend of its nodes are still to be written (their rows in s_acc)
@@ -5103,7 +5105,7 @@ __global__ __launch_bounds__(OPT ? 192 : 128) void k_spec_waves(SpecArgs S) {
       published = false;
       const int set = (int)(step % (uint32_t)S.n_sets);
       lap(0);
-      if (sq_i32(A.grid_ovf_src) > A.grid_ovf_limit) { stop = true; }   // (once per step: the list has room for a step's nodes)
+      if (grid_ovf_now > A.grid_ovf_limit) { stop = true; }   // (once per step: the list has room for a step's nodes; the leader is the count's only writer)
       int sc = 0;
       for (; !stop;) {   // ---- the waves of this step, in the reference's order
         // what the round engine checks before a round (round_begin_scalars), and what this launch has to leave to the host
@@ -5202,9 +5204,11 @@ __global__ __launch_bounds__(OPT ? 192 : 128) void k_spec_waves(SpecArgs S) {
             const unsigned long long key = ((unsigned long long)(uint32_t)a << 32) | ((unsigned long long)(uint32_t)b + 1ULL);
             size_t h = (size_t)((key * 0x9E3779B97F4A7C15ULL) >> 17) & (size_t)f.bt_mask;
             bool fresh = false;
+            // (the table is the leader's alone while the launch runs - written by this wavefront, read through its own CU's
+            // caches: plain loads, no round trip to memory per probe)
             for (int guard = 0; guard < (1 << 24); ++guard) {
-              const unsigned long long cur = sq_u64(f.bt_key + h);
-              if (cur == key) { fresh = sq_u64(f.bt_val + h) == ~0ULL; break; }
+              const unsigned long long cur = f.bt_key[h];
+              if (cur == key) { fresh = f.bt_val[h] == ~0ULL; break; }
               if (cur == 0ULL) { fresh = true; break; }
               h = (h + 1) & (size_t)f.bt_mask;
             }
