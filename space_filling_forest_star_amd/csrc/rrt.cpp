@@ -319,7 +319,7 @@ struct WCand {
 };
 }  // namespace
 
-static double g_rrt_sec[8];   // SFFGPU_PROFILE: ms in the sections of run_wave
+static double g_rrt_sec[10];   // SFFGPU_PROFILE: ms in the sections of run_wave
 int Rrt::run_wave(int B) {
   using namespace sffg;
   Ctx& c = *ctx;
@@ -492,6 +492,15 @@ int Rrt::run_wave(int B) {
   std::vector<Ref> refs;
   struct MateConn { int cand, mate; int edge; };
   std::vector<MateConn> mate_conns;
+  {   // (room for everything up front; the surviving points' x and tree side by side for the two mate scans)
+    const size_t guess = (size_t)nA * (size_t)(2 * std::max(kmax, 0) + 4) + 16;
+    refs.reserve(guess);
+    if (chained) { ra.reserve(guess); rb.reserve(guess); } else { ea.reserve(6 * guess); eb.reserve(6 * guess); }
+  }
+  std::vector<double> ax(nA);
+  std::vector<int> at(nA);
+  for (int k = 0; k < nA; ++k) { ax[k] = w[alive[k]].np[0]; at[k] = w[alive[k]].tree; }
+  const bool several_trees = tree_frontier.size() > 1;
   for (int k = 0; k < nA; ++k) {
     const int j = alive[k];
     WCand& cd = w[j];
@@ -499,11 +508,12 @@ int Rrt::run_wave(int B) {
       // distance of the k_max-th store member bounds which mates can enter the set
       double dk = std::numeric_limits<double>::infinity();
       if ((int)cd.members.size() >= kmax) dk = dist6(cd.np, nodes[cd.members[kmax - 1]].pos);
+      cd.medges.reserve(cd.members.size() + 8);
       for (int id : cd.members) cd.medges.push_back({id, false, false, -1, 0, -1, 0});
+      const double x0 = cd.np[0];
       for (int kk = 0; kk < k; ++kk) {
+        if (at[kk] != cd.tree || std::fabs(ax[kk] - x0) > dk) continue;
         const int i = alive[kk];
-        if (w[i].tree != cd.tree) continue;
-        if (std::fabs(w[i].np[0] - cd.np[0]) > dk) continue;
         if (dist6(cd.np, w[i].np) <= dk) cd.medges.push_back({-1 - i, false, false, -1, 0, -1, 0});
       }
       for (size_t e = 0; e < cd.medges.size(); ++e) {
@@ -519,21 +529,22 @@ int Rrt::run_wave(int B) {
       refs.push_back({j, 2, (int)e});
       add_edge(cd.np, nodes[cd.conns[e].node].pos, -1 - j, cd.conns[e].node);   // isPathFree(newPoint, neighbor)  :231
     }
-    for (int kk = 0; kk < k; ++kk) {
+    for (int kk = 0; several_trees && kk < k; ++kk) {
+      if (at[kk] == cd.tree || std::fabs(ax[kk] - cd.np[0]) >= cfg.dist_tree) continue;
       const int i = alive[kk];
-      if (w[i].tree == cd.tree) continue;
-      if (std::fabs(w[i].np[0] - cd.np[0]) >= cfg.dist_tree) continue;
       if (dist6(w[i].np, cd.np) < cfg.dist_tree) {
         mate_conns.push_back({j, i, add_edge(cd.np, w[i].np, -1 - j, -1 - i)});
         refs.push_back({j, 3, (int)mate_conns.size() - 1});
       }
     }
   }
+  lap(8);
   const int nE = chained ? (int)ra.size() : (int)(ea.size() / 6);
   std::vector<uint8_t> efr(nE);
   std::vector<int32_t> efh(nE), ens(nE);
   if (nE && chained) c.collide_segments_refs(ra.data(), rb.data(), nE, efr.data(), efh.data(), ens.data());
   else if (nE) c.collide_segments(ea.data(), eb.data(), nE, efr.data(), efh.data(), ens.data());
+  lap(9);
   for (int e = 0; e < nE; ++e) {
     const Ref& r = refs[e];
     WCand& cd = w[r.cand];
@@ -692,8 +703,8 @@ void Rrt::run(int max_iters) {
   if (chain_on) ctx->sync();   // (the last wave's append)
   st.total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   if (getenv("SFFGPU_PROFILE")) {
-    fprintf(stderr, "[sffgpu rrt run_wave ms] draws %.1f | nearest %.1f | pose + parent edge %.1f | k nearest %.1f | other trees %.1f | edge lists + edges %.1f | replay %.1f | append %.1f  (%llu waves)\n",
-            g_rrt_sec[0], g_rrt_sec[1], g_rrt_sec[2], g_rrt_sec[3], g_rrt_sec[4], g_rrt_sec[5], g_rrt_sec[6], g_rrt_sec[7], (unsigned long long)st.waves);
+    fprintf(stderr, "[sffgpu rrt run_wave ms] draws %.1f | nearest %.1f | pose + parent edge %.1f | k nearest %.1f | other trees %.1f | edge lists %.1f + edges on the GPU %.1f + results %.1f | replay %.1f | append %.1f  (%llu waves)\n",
+            g_rrt_sec[0], g_rrt_sec[1], g_rrt_sec[2], g_rrt_sec[3], g_rrt_sec[4], g_rrt_sec[8], g_rrt_sec[9], g_rrt_sec[5], g_rrt_sec[6], g_rrt_sec[7], (unsigned long long)st.waves);
     for (double& x : g_rrt_sec) x = 0;
   }
 }
