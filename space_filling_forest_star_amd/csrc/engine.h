@@ -185,7 +185,7 @@ struct Ctx {
                             int32_t* n_samples);
   // ids < 0 name row -1 - id of the new points the last rrt_chain left on the device (edges of an RRT wave: 8 bytes per edge up)
   void collide_segments_refs(const int32_t* ida, const int32_t* idb, int n, uint8_t* is_free, int32_t* first_hit, int32_t* n_samples);
-  const double* rr_np_dev = nullptr;   // the new points of the last rrt_chain (inside rr_out)
+  const double* rr_np_dev = nullptr;   // the new points of the last rrt_chain (+ rrt_chain_alt): rr_np
   void collide_segments_core(const double* a6, const double* b6, const int32_t* ida, const int32_t* idb, int n,
                              uint8_t* is_free, int32_t* first_hit, int32_t* n_samples, const double* extra_dev = nullptr);
   void sample_steer(const uint64_t* words, const double* center6, int n, double dist, int dim, const double* limits,
@@ -197,15 +197,29 @@ struct Ctx {
   // index too (sffgpu_nodes_index / the RRT session's grid)
   void knn(const double* q6, int nq, int k, const int32_t* tree, const int32_t* max_id, int32_t* idx, double* dist,
            int32_t* cnt, bool tree_by_grid = false);
-  // RRT session, the first half of a speculative wave as ONE enqueued chain and one wait (was: three calls, three waits):
-  // the two nearest nodes of every steering target in its tree (near_* n x 2; the first is the nearest - two, so that the
-  // caller sees a tie) -> the steered new point (np6) -> its pose check (hit) -> the edge nearest -> new point (seg: n_samples |
-  // first_hit or INT_MAX | candidate list overflowed, n each) -> kmax > 0: the kmax nearest nodes of the new point in the tree
-  // (mem_* n x kmax).  Replaces src/rrt.h:143-151,166.
+  // RRT session, the GPU half of a speculative wave as enqueued chains with one wait each (was: three calls, three waits).
+  // rrt_chain: the two nearest nodes of every steering target in its tree (near_* n x 2; the first is the nearest - two, so that
+  // the caller sees a tie) -> the steered new point -> per row (RrtRows): its pose check (hit), the edge nearest -> new point
+  // (seg: n_samples | first_hit or INT_MAX | candidate list overflowed, n each), kmax > 0: the kmax nearest nodes of the new
+  // point in the tree (mem_* n x kmax), conn_r > 0 (several live trees): every node of the OTHER trees within conn_r of the
+  // new point (:228-231; conn_cnt n - > conn_cap: the list ran over, ask Ctx::radius -, conn_idx / conn_d n x conn_cap in no
+  // order) -> mate != null: per slot the earlier new point of the wave that would be its nearest node (-1: none).
+  // rrt_chain_alt: the same rows for the slots repaired by hand of that answer - slot[i] steered from new point mate[i] (a row
+  // of the last rrt_chain) -; their new points become rows n.. of the table collide_segments_refs reads.
+  // Replaces src/rrt.h:143-151,166,228-231.
+  struct RrtRows {
+    double* np6; uint8_t* hit; int32_t* seg; int32_t* mem_idx; double* mem_d; int32_t* mem_cnt;   // host, caller-owned
+    int32_t* conn_idx; double* conn_d; int32_t* conn_cnt;
+    int phase = 0; double* np_copy = nullptr; int32_t* near_idx = nullptr; double* near_d = nullptr; int32_t* near_cnt = nullptr;   // (device, internal)
+  };
   void rrt_chain(const double* rnd6, const int32_t* tree, int n, double dist, bool by_grid1, int kmax, bool by_gridk,
-                 int32_t* near_idx, double* near_d, int32_t* near_cnt, double* np6, uint8_t* hit, int32_t* seg,
-                 int32_t* mem_idx, double* mem_d, int32_t* mem_cnt);
-  DevBuf rr_q1, rr_q2, rr_a, rr_out;
+                 int32_t* near_idx, double* near_d, int32_t* near_cnt, int32_t* mate, RrtRows& R, double conn_r = 0, int conn_cap = 0);
+  void rrt_chain_alt(const int32_t* slot, const int32_t* mate, int n_alt, double dist, int kmax, bool by_gridk, RrtRows& R,
+                     double conn_r = 0, int conn_cap = 0);
+  void rrt_rows(RrtRows& R, int row0, int n, int kmax, bool by_gridk, double conn_r, int conn_cap, int n_near, int32_t* near_idx,
+                double* near_d, int32_t* near_cnt, int32_t* mate);
+  int rr_rows0 = 0;   // slots of the last rrt_chain
+  DevBuf rr_q1, rr_q2, rr_a, rr_out, rr_sq, rr_np, rr_alt;
   PinBuf rr_hq, rr_hout;
   double sweep_eps() const;
   // one sweep launch over the first n_store entries; per-query hit lists sorted by (dist, id)
@@ -522,6 +536,9 @@ struct Rrt {
   void knn(const double* q, int nq, const int32_t* tree, int k, std::vector<std::vector<int>>& out);
   bool knn_by_grid(const int32_t* tree, int nq, int k) const;
   bool chain_on = true;   // SFFGPU_RRT_CHAIN (read when the session is created): nearest -> steer -> pose -> parent edge -> k nearest as one chain
+  bool repair_on = true;  // SFFGPU_RRT_REPAIR: slots whose nearest node would be an earlier new point of the wave are evaluated from it too
+  int small_mul = 4, small_cap = 48;   // SFFGPU_RRT_SMALL (cap): ... or small_mul x that, up to small_cap slots
+  int grow_pct = 150;     // SFFGPU_RRT_GROW: after a cut wave the next one speculates grow_pct % of what survived (+ 1)
   void expand(int tree_to_expand, unsigned iteration);
   void draw_target(double rnd[6]);
   int merge_or_link(int tree_to_expand, int new_id, int nb, bool edge_free, int fh, int ns, int& i);

@@ -332,7 +332,9 @@ Forest::~Forest() {
                     &dev.s_next, &dev.s_prop, &dev.s_best, &dev.s_psel, &dev.s_dcl, &dev.s_cnt, &dev.s_accs, &dev.s_hdr, &dev.s_changed,
                     &dev.s_ew, &dev.s_ida, &dev.s_idb, &dev.s_sub, &dev.s_segns, &dev.s_fh, &dev.s_sovf, &dev.s_evs, &dev.s_evn, &dev.s_eve,
                     &dev.s_evd, &dev.s_acc, &dev.s_backup, &dev.s_items, &dev.s_dbg, &dev.s_hist, &dev.w_acc, &dev.acc_pref, &dev.ustate32, &dev.wg_pub, &dev.commit_seq, &dev.kc_trace, &x_send, &x_recv,
-                    &dev.hp_base, &dev.hp_size, &dev.hp_v, &dev.hp_key, &dev.hp_pos, &dev.hp_ref, &dev.hp_gen, &dev.hp_cnt, &dev.slot_tree, &dev.slot_heap, &dev.slot_idx, &dev.slot_word, &dev.hp_plan};
+                    &dev.hp_base, &dev.hp_size, &dev.hp_v, &dev.hp_key, &dev.hp_pos, &dev.hp_ref, &dev.hp_gen, &dev.hp_cnt, &dev.slot_tree, &dev.slot_heap, &dev.slot_idx, &dev.slot_word, &dev.hp_plan,
+                    &dev.ord_hist, &dev.ord_start, &dev.ord_key, &dev.ord_rank, &dev.ord_pos, &dev.ord_lst, &dev.ord_cnt,
+                    &dev.w_ev, &dev.ev_h, &dev.ev_nb, &dev.ev_raw, &dev.spec_tab, &dev.spec_area, &dev.qclk_sh};
   if (dev.inited) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);

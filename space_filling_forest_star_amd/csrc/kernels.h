@@ -27,7 +27,7 @@ struct NodeStoreMut {
 struct SweepQuery {   // 56 bytes, read through the scalar cache
   float x, y, z, yaw, pitch, roll;
   float r2f;          // inflated fp32 squared radius (superset filter)
-  int32_t tree;       // -1 = all trees
+  int32_t tree;       // -1 = all trees, -2 - t = every tree but t
   double r;           // exact radius (strict <)
   int32_t max_id;     // only node ids < max_id
   int32_t active;
@@ -327,7 +327,11 @@ void launch_knn_linear(hipStream_t s, const NodeStoreView& st, int n_store, cons
 // (> mate_cap = overflow: the caller asks again with a larger list; SFFK_KNN_MATES is the first pass's capacity).
 // RRT session: nearest node -> steered point on the device (k_rrt_steer), see Ctx::rrt_chain
 void launch_rrt_steer(hipStream_t s, const KnnQuery* q1, const int32_t* idx1, int k1, const double* store_pos, double dist,
-                      double* a6, double* np6, KnnQuery* q2, int kmax, int n);
+                      double* a6, double* np6, KnnQuery* q2, int kmax, int n, SweepQuery* sq, double sq_r, float sq_r2f,
+                      double* np_copy, const int32_t* alt_slot = nullptr, const int32_t* alt_mate = nullptr, int row0 = 0);
+// (sq: the other-trees radius query of every new point; alt_slot / alt_mate: the rows are repaired slots, written from row0 on)
+void launch_rrt_mates(hipStream_t s, const KnnQuery* q1, const double* near_d, int k1, const double* np6, const uint8_t* hit,
+                      const int32_t* fh, const int32_t* ov, int n, int32_t* mate);
 void launch_knn_grid(hipStream_t s, const GridView& g, const GridView* tg, const NodeStoreView& st, const KnnQuery* q, int nq,
                      int kcap, int32_t* idx, double* dist, int32_t* cnt, int32_t* mate_idx, int32_t* mate_cnt, double cell,
                      double slack, int mate_cap = SFFK_KNN_MATES, int n_store = 0);   // n_store > 0: far queries fall back to a sweep of the store

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void k_sweep(NodeStoreView st, int first, int 
         float da = wrapf(as[j] - Q.yaw), db = wrapf(bs[j] - Q.pitch), dc = wrapf(cs[j] - Q.roll);
         float d6 = fmaf(dc, dc, fmaf(db, db, fmaf(da, da, d3[j])));
         if (!(d6 <= Q.r2f)) continue;
-        if (Q.tree >= 0 && st.tree[id] != Q.tree) continue;
+        if (Q.tree >= 0 ? st.tree[id] != Q.tree : (Q.tree < -1 && st.tree[id] == -2 - Q.tree)) continue;   // (-2 - t: every tree but t)
         // exact re-test in fp64 on the authoritative positions (reference: realDist, src/forest.h:274)
         double np[6], qp[6];
         for (int k = 0; k < 6; ++k) { np[k] = st.pos[6 * (size_t)id + k]; qp[k] = qpos[6 * (size_t)q + k]; }
@@ -121,7 +121,7 @@ __device__ __forceinline__ void grid_test(const GridItem& it, const SweepQuery& 
                                           const double* __restrict__ qpos, int32_t* __restrict__ cnt,
                                           int32_t* __restrict__ hit_idx, double* __restrict__ hit_dist, int cap) {
   if (it.id >= Q.max_id) return;
-  if (Q.tree >= 0 && it.tree != Q.tree) return;
+  if (Q.tree >= 0 ? it.tree != Q.tree : (Q.tree < -1 && it.tree == -2 - Q.tree)) return;
   double qp[6];
   for (int k = 0; k < 6; ++k) qp[k] = qpos[6 * (size_t)q + k];
   const double d = dist6(it.p, qp);
@@ -5870,24 +5870,83 @@ void launch_ring_trig(hipStream_t s, const uint64_t* words, double* trig, int n)
 // q2 != null, the k-nearest query of the new point.
 __global__ __launch_bounds__(256) void k_rrt_steer(const KnnQuery* __restrict__ q1, const int32_t* __restrict__ idx1, int k1,
                                                    const double* __restrict__ store_pos, double dist, double* __restrict__ a6,
-                                                   double* __restrict__ np6, KnnQuery* __restrict__ q2, int kmax, int n) {
+                                                   double* __restrict__ np6, KnnQuery* __restrict__ q2, int kmax, int n,
+                                                   SweepQuery* __restrict__ sq, double sq_r, float sq_r2f,
+                                                   double* __restrict__ np_copy, const int32_t* __restrict__ alt_slot,
+                                                   const int32_t* __restrict__ alt_mate, int row0) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  const int near = idx1[(size_t)i * k1];
+  // alt_slot != null: row i is the REPAIRED version of slot alt_slot[i] - the wave's new point alt_mate[i] (a row of np6)
+  // would be its nearest node if it becomes a node - and is written as row row0 + i of np6
+  const int slot = alt_slot ? alt_slot[i] : i;
   double a[6], t[6], o[6];
-  for (int k = 0; k < 6; ++k) { a[k] = store_pos[6 * (size_t)near + k]; t[k] = q1[i].pos[k]; }
+  if (alt_slot) {
+    const int m = alt_mate[i];
+    for (int k = 0; k < 6; ++k) a[k] = np6[6 * (size_t)m + k];
+  } else {
+    const int near = idx1[(size_t)i * k1];
+    for (int k = 0; k < 6; ++k) a[k] = store_pos[6 * (size_t)near + k];
+  }
+  for (int k = 0; k < 6; ++k) t[k] = q1[slot].pos[k];
   steer(a, t, dist, o);
-  for (int k = 0; k < 6; ++k) { a6[6 * (size_t)i + k] = a[k]; np6[6 * (size_t)i + k] = o[k]; }
+  for (int k = 0; k < 6; ++k) { a6[6 * (size_t)i + k] = a[k]; np6[6 * (size_t)(row0 + i) + k] = o[k]; np_copy[6 * (size_t)i + k] = o[k]; }
   if (q2) {
     KnnQuery q;
     for (int k = 0; k < 6; ++k) q.pos[k] = o[k];
-    q.tree = q1[i].tree; q.max_id = 0x7fffffff; q.k = kmax; q.mate_base = 0x7fffffff; q.whole_tree = 0; q.pad_ = 0;
+    q.tree = q1[slot].tree; q.max_id = 0x7fffffff; q.k = kmax; q.mate_base = 0x7fffffff; q.whole_tree = 0; q.pad_ = 0;
     q2[i] = q;
+  }
+  if (sq) {   // the nodes of the OTHER trees within sq_r of the new point (src/rrt.h:228-231), same fields as Ctx::sweep_lists writes
+    SweepQuery Q;
+    Q.x = (float)o[0]; Q.y = (float)o[1]; Q.z = (float)o[2]; Q.yaw = (float)o[3]; Q.pitch = (float)o[4]; Q.roll = (float)o[5];
+    Q.r2f = sq_r2f; Q.tree = -2 - q1[slot].tree; Q.r = sq_r; Q.max_id = 0x7fffffff; Q.active = 1; Q.pad = Q.pad2 = 0;
+    sq[i] = Q;
   }
 }
 void launch_rrt_steer(hipStream_t s, const KnnQuery* q1, const int32_t* idx1, int k1, const double* store_pos, double dist,
-                      double* a6, double* np6, KnnQuery* q2, int kmax, int n) {
-  if (n > 0) hipLaunchKernelGGL(k_rrt_steer, dim3((n + 255) / 256), dim3(256), 0, s, q1, idx1, k1, store_pos, dist, a6, np6, q2, kmax, n);
+                      double* a6, double* np6, KnnQuery* q2, int kmax, int n, SweepQuery* sq, double sq_r, float sq_r2f,
+                      double* np_copy, const int32_t* alt_slot, const int32_t* alt_mate, int row0) {
+  if (n > 0) hipLaunchKernelGGL(k_rrt_steer, dim3((n + 255) / 256), dim3(256), 0, s, q1, idx1, k1, store_pos, dist, a6, np6, q2, kmax, n,
+                                sq, sq_r, sq_r2f, np_copy, alt_slot, alt_mate, row0);
+}
+
+// RRT session: which EARLIER new point of the wave would be slot j's nearest node?  (The replay of Rrt::run_wave cuts the
+// wave at the first such slot unless the repaired version of the slot was evaluated too, k_rrt_steer's alt rows.)
+// One wavefront per slot: the nearest - ties: the oldest - of the earlier new points of the same tree whose pose is free and
+// whose parent edge is free (or not known yet: the candidate list ran over) and that are strictly nearer to the steering target
+// than the nearest node of the frozen tree (near_d, k1 per slot).  mate[j] = that slot or -1.
+__global__ __launch_bounds__(256) void k_rrt_mates(const KnnQuery* __restrict__ q1, const double* __restrict__ near_d, int k1,
+                                                   const double* __restrict__ np6, const uint8_t* __restrict__ hit,
+                                                   const int32_t* __restrict__ fh, const int32_t* __restrict__ ov, int n,
+                                                   int32_t* __restrict__ mate) {
+  const int j = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (j >= n) return;
+  double t[6];
+  for (int k = 0; k < 6; ++k) t[k] = q1[j].pos[k];
+  const int tree = q1[j].tree;
+  const double dn = near_d[(size_t)j * k1];
+  double best = dn;
+  int bi = 0x7fffffff;
+  for (int i = lane; i < j; i += 64) {
+    if (hit[i] || (fh[i] != 0x7fffffff && !ov[i]) || q1[i].tree != tree) continue;
+    const double x = np6[6 * (size_t)i];
+    if (!(fabs(x - t[0]) < dn)) continue;
+    double p[6];
+    for (int k = 0; k < 6; ++k) p[k] = np6[6 * (size_t)i + k];
+    const double d = dist6(t, p);
+    if (d < best) { best = d; bi = i; }   // (ascending i per lane: the oldest of equal distances stays)
+  }
+  for (int off = 32; off; off >>= 1) {
+    const double ob = __shfl_xor(best, off);
+    const int oi = __shfl_xor(bi, off);
+    if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+  }
+  if (lane == 0) mate[j] = bi == 0x7fffffff ? -1 : bi;
+}
+void launch_rrt_mates(hipStream_t s, const KnnQuery* q1, const double* near_d, int k1, const double* np6, const uint8_t* hit,
+                      const int32_t* fh, const int32_t* ov, int n, int32_t* mate) {
+  if (n > 0) hipLaunchKernelGGL(k_rrt_mates, dim3((n + 3) / 4), dim3(256), 0, s, q1, near_d, k1, np6, hit, fh, ov, n, mate);
 }
 
 void launch_spec_waves(hipStream_t s, const SpecArgs& a) {

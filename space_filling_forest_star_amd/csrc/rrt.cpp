@@ -22,6 +22,9 @@ namespace sff {
 
 Rrt::Rrt(Ctx* c, const sffgpu_rrt_cfg& cf, const double* roots6, int n_roots) : ctx(c), cfg(cf) {
   if (const char* e = getenv("SFFGPU_RRT_CHAIN")) chain_on = atoi(e) != 0;
+  if (const char* e = getenv("SFFGPU_RRT_REPAIR")) repair_on = atoi(e) != 0;
+  if (const char* e = getenv("SFFGPU_RRT_SMALL")) { small_cap = std::max(1, atoi(e)); }
+  if (const char* e = getenv("SFFGPU_RRT_GROW")) grow_pct = std::max(100, atoi(e));
   if (cfg.dim != 2 && cfg.dim != 6) throw HipError{"rrt: dim must be 2 or 6"};
   if (n_roots < 1) throw HipError{"rrt: at least one root"};
   if (cfg.priority_bias != 0 && !cfg.has_goal) throw HipError{"rrt: goal bias needs a goal (src/main.cpp:330-331)"};
@@ -316,9 +319,14 @@ struct WCand {
   struct Conn { int tree; int node; double d; int order; bool free; int fh, ns; };
   std::vector<Conn> conns;                        // nearest node of each OTHER tree within treeDistance
   int accepted = -1;
+  // rows past the wave's slots are REPAIRED slots: evaluated as if the new point of row near_row (an earlier slot) were a node
+  // and the slot's nearest one (that is what it is if that slot is accepted as speculated)
+  int slot = -1, near_row = -1, alt_row = -1;
+  bool cut_here = false;                          // nothing evaluated covers this slot if it is reached
 };
 }  // namespace
 
+static unsigned long long g_rrt_alt[3];   // SFFGPU_PROFILE: repaired rows evaluated, taken by the replay, waves cut for lack of one
 static double g_rrt_sec[10];   // SFFGPU_PROFILE: ms in the sections of run_wave
 int Rrt::run_wave(int B) {
   using namespace sffg;
@@ -333,6 +341,7 @@ int Rrt::run_wave(int B) {
   // ---- 1. per iteration: tree pick (:95) and steering target (:130-134), in the reference's draw order
   for (int j = 0; j < B; ++j) {
     w[j].draws_before = rng.draws;
+    w[j].slot = j;
     w[j].tree = cfg.lazy_edge ? 0 : tree_frontier[rng.uniform_int(0, num_trees)];   // (src/lazy.h:181 draws no tree)
     draw_target(w[j].rnd);
   }
@@ -342,16 +351,32 @@ int Rrt::run_wave(int B) {
   std::vector<int> alive;
   int nA = 0;
   bool chained = false;
+  // (several live trees: the other trees' nodes around every new point ride the same chain, src/rrt.h:228-231)
+  const int conn_cap = 32;
+  bool conn_have = false;
+  std::vector<int32_t> conn_i, conn_c;
+  std::vector<double> conn_dd;
+  bool have_mates = false;
+  std::vector<int32_t> mate;
   if (chain_on && kmax <= 64) {
     // ---- 2-4 as ONE enqueued chain and one wait (Ctx::rrt_chain): the nearest node of the frozen tree (:143), the steered
-    // point (:148), its pose and parent edge (:149-151) and - RRT* - the k_max nearest store nodes of EVERY new point (:166;
-    // those of the points that die in between are thrown away)
-    std::vector<double> q((size_t)B * 6), np((size_t)B * 6), nd((size_t)B * 2), md((size_t)B * std::max(kmax, 1));
-    std::vector<int32_t> tq(B), ni((size_t)B * 2), nc(B), seg((size_t)B * 3), mi((size_t)B * std::max(kmax, 1)), mc(B);
+    // point (:148), its pose and parent edge (:149-151), - RRT* - the k_max nearest store nodes of EVERY new point (:166;
+    // those of the points that die in between are thrown away), - several trees - the other trees' nodes around it, and per slot
+    // the earlier new point of the wave that would be its nearest node if it becomes one
+    const int km = std::max(kmax, 1);
+    std::vector<double> q((size_t)B * 6), np((size_t)B * 6), nd((size_t)B * 2), md((size_t)B * km);
+    std::vector<int32_t> tq(B), ni((size_t)B * 2), nc(B), seg((size_t)B * 3), mi((size_t)B * km), mc(B);
     std::vector<uint8_t> hit(B);
     for (int j = 0; j < B; ++j) { memcpy(&q[6 * (size_t)j], w[j].rnd, 48); tq[j] = w[j].tree; }
-    c.rrt_chain(q.data(), tq.data(), B, cfg.sampling_dist, knn_by_grid(tq.data(), B, 1), kmax, kmax > 0 && knn_by_grid(tq.data(), B, kmax),
-                ni.data(), nd.data(), nc.data(), np.data(), hit.data(), seg.data(), mi.data(), md.data(), mc.data());
+    const bool conn_q = tree_frontier.size() > 1 && !getenv("SFFGPU_RRT_NO_CHAIN_CONN");
+    if (conn_q) { conn_i.resize((size_t)B * conn_cap); conn_dd.resize((size_t)B * conn_cap); conn_c.resize(B); }
+    mate.assign(B, -1);
+    const bool by_gridk = kmax > 0 && knn_by_grid(tq.data(), B, kmax);
+    const double conn_r = conn_q ? cfg.dist_tree : 0.0;
+    Ctx::RrtRows R1{np.data(), hit.data(), seg.data(), mi.data(), md.data(), mc.data(), conn_i.data(), conn_dd.data(), conn_c.data()};
+    c.rrt_chain(q.data(), tq.data(), B, cfg.sampling_dist, knn_by_grid(tq.data(), B, 1), kmax, by_gridk, ni.data(), nd.data(), nc.data(),
+                mate.data(), R1, conn_r, conn_cap);
+    conn_have = conn_q;
     // (the nearest node is the first by (distance, position in its tree); the device orders by (distance, id): two nodes at
     // exactly the same distance - or a query nobody answered - send the wave through the separate calls below)
     chained = true;
@@ -359,35 +384,87 @@ int Rrt::run_wave(int B) {
       if (nc[j] < 1 || (nc[j] >= 2 && nd[2 * (size_t)j] == nd[2 * (size_t)j + 1])) chained = false;
     if (chained) {
       lap(1);
-      for (int j = 0; j < B; ++j) {
-        WCand& cd = w[j];
-        cd.nearest = ni[2 * (size_t)j];
-        cd.d_near = dist6(cd.rnd, nodes[cd.nearest].pos);
-        memcpy(cd.np, &np[6 * (size_t)j], 48);
-        cd.pose_hit = hit[j] != 0;
-        int ns_j = seg[j], fh_j = seg[(size_t)B + j] == 0x7fffffff ? -1 : seg[(size_t)B + j];
-        if (seg[2 * (size_t)B + j]) {   // (the edge's triangle candidate list ran over: by itself through the batch call, which handles that)
+      // one row of results -> its candidate (an edge whose triangle candidate list ran over: by itself through the batch call)
+      auto fill_row = [&](WCand& cd, const double* a_pos, const double* np_r, uint8_t hit_r, const int32_t* seg_r, int n_r, int r) {
+        memcpy(cd.np, np_r + 6 * (size_t)r, 48);
+        cd.pose_hit = hit_r != 0;
+        int ns_j = seg_r[r], fh_j = seg_r[(size_t)n_r + r] == 0x7fffffff ? -1 : seg_r[(size_t)n_r + r];
+        if (seg_r[2 * (size_t)n_r + r]) {
           uint8_t fr1 = 0; int32_t fh1 = -1, ns1 = 0;
-          c.collide_segments(nodes[cd.nearest].pos, cd.np, 1, &fr1, &fh1, &ns1);
+          c.collide_segments(a_pos, cd.np, 1, &fr1, &fh1, &ns1);
           fh_j = fh1; ns_j = ns1;
         }
         cd.par_free = fh_j < 0;
         cd.par_fh = fh_j;
         cd.par_ns = ns_j;
+      };
+      auto fill_members = [&](WCand& cd, const int32_t* mi_r, const double* md_r, const int32_t* mc_r, int r) {
+        struct E { double d; int order; int id; };
+        std::vector<E> e;
+        for (int m = 0; m < mc_r[r]; ++m) { const int id = mi_r[(size_t)r * kmax + m]; e.push_back({md_r[(size_t)r * kmax + m], nodes[id].idx_in_tree, id}); }
+        std::sort(e.begin(), e.end(), [](const E& a, const E& b) { return a.d < b.d || (a.d == b.d && a.order < b.order); });
+        cd.members.clear();
+        for (const E& x : e) cd.members.push_back(x.id);
+      };
+      for (int j = 0; j < B; ++j) {
+        WCand& cd = w[j];
+        cd.slot = j;
+        cd.nearest = ni[2 * (size_t)j];
+        cd.d_near = dist6(cd.rnd, nodes[cd.nearest].pos);
+        fill_row(cd, nodes[cd.nearest].pos, np.data(), hit[j], seg.data(), B, j);
+      }
+      // ---- the repaired slots: a slot whose nearest node would be an earlier new point of the wave is evaluated a second
+      // time from that point (Ctx::rrt_chain_alt) - the replay takes that row when the earlier slot is accepted as speculated
+      have_mates = true;
+      std::vector<int32_t> a_slot, a_mate;
+      for (int j = 0; j < B; ++j) {
+        const int i = mate[j];
+        if (i < 0) continue;
+        if (!repair_on || w[i].pose_hit || !w[i].par_free) { w[j].cut_here = true; continue; }   // (what the device took for alive is not)
+        a_slot.push_back(j);
+        a_mate.push_back(i);
+      }
+      const int nalt = (int)a_slot.size();
+      g_rrt_alt[0] += (unsigned long long)nalt;
+      if (nalt > 0) {
+        std::vector<double> np2((size_t)nalt * 6), md2((size_t)nalt * km), cd2;
+        std::vector<int32_t> seg2((size_t)nalt * 3), mi2((size_t)nalt * km), mc2(nalt), ci2, cc2;
+        std::vector<uint8_t> hit2(nalt);
+        if (conn_q) { ci2.resize((size_t)nalt * conn_cap); cd2.resize((size_t)nalt * conn_cap); cc2.resize(nalt); }
+        Ctx::RrtRows R2{np2.data(), hit2.data(), seg2.data(), mi2.data(), md2.data(), mc2.data(), ci2.data(), cd2.data(), cc2.data()};
+        c.rrt_chain_alt(a_slot.data(), a_mate.data(), nalt, cfg.sampling_dist, kmax, by_gridk, R2, conn_r, conn_cap);
+        w.resize((size_t)B + nalt);
+        for (int r = 0; r < nalt; ++r) {
+          WCand& cd = w[(size_t)B + r];
+          const WCand& sl = w[a_slot[r]];
+          cd.tree = sl.tree;
+          cd.draws_before = sl.draws_before;
+          memcpy(cd.rnd, sl.rnd, 48);
+          cd.slot = a_slot[r];
+          cd.near_row = a_mate[r];
+          cd.nearest = -1;                                   // (the node row near_row becomes: known in the replay)
+          cd.d_near = dist6(cd.rnd, w[a_mate[r]].np);
+          fill_row(cd, w[a_mate[r]].np, np2.data(), hit2[r], seg2.data(), nalt, r);
+          w[a_slot[r]].alt_row = B + r;
+          if (kmax > 0 && !cd.pose_hit && cd.par_free) fill_members(cd, mi2.data(), md2.data(), mc2.data(), r);
+        }
+        if (conn_q) {   // (one list for all rows)
+          conn_i.insert(conn_i.end(), ci2.begin(), ci2.end());
+          conn_dd.insert(conn_dd.end(), cd2.begin(), cd2.end());
+          conn_c.insert(conn_c.end(), cc2.begin(), cc2.end());
+        }
       }
       lap(2);
-      for (int j = 0; j < B; ++j)
+      // (rows in the order of their slots, a slot's repaired row after its speculated one)
+      for (int j = 0; j < B; ++j) {
         if (!w[j].pose_hit && w[j].par_free) alive.push_back(j);
+        const int a = w[j].alt_row;
+        if (a >= 0 && !w[a].pose_hit && w[a].par_free) alive.push_back(a);
+      }
       nA = (int)alive.size();
       if (kmax > 0)
-        for (int j : alive) {
-          struct E { double d; int order; int id; };
-          std::vector<E> e;
-          for (int m = 0; m < mc[j]; ++m) { const int id = mi[(size_t)j * kmax + m]; e.push_back({md[(size_t)j * kmax + m], nodes[id].idx_in_tree, id}); }
-          std::sort(e.begin(), e.end(), [](const E& a, const E& b) { return a.d < b.d || (a.d == b.d && a.order < b.order); });
-          w[j].members.clear();
-          for (const E& x : e) w[j].members.push_back(x.id);
-        }
+        for (int j : alive)
+          if (j < B) fill_members(w[j], mi.data(), md.data(), mc.data(), j);
       lap(3);
     }
   }
@@ -441,7 +518,25 @@ int Rrt::run_wave(int B) {
     lap(3);
   }
   // ---- 5. other trees: every node within treeDistance of the new point; per tree the nearest one (:228-231)
-  if (nA > 0 && tree_frontier.size() > 1) {
+  auto note_conn = [&](WCand& cd, int id, double d) {
+    const int t = nodes[id].tree;
+    if (t == cd.tree) return;
+    for (auto& cn : cd.conns)
+      if (cn.tree == t) {
+        if (d < cn.d || (d == cn.d && nodes[id].idx_in_tree < cn.order)) { cn.node = id; cn.d = d; cn.order = nodes[id].idx_in_tree; }
+        return;
+      }
+    cd.conns.push_back({t, id, d, nodes[id].idx_in_tree, false, -1, 0});
+  };
+  if (chained && conn_have)
+    for (int k = 0; k < nA && conn_have; ++k)
+      if (conn_c[alive[k]] > conn_cap) conn_have = false;   // (a list ran over: the separate query below, with its growing lists)
+  if (nA > 0 && tree_frontier.size() > 1 && chained && conn_have) {
+    for (int k = 0; k < nA; ++k) {
+      const int j = alive[k];
+      for (int h = 0; h < conn_c[j]; ++h) note_conn(w[j], conn_i[(size_t)j * conn_cap + h], conn_dd[(size_t)j * conn_cap + h]);
+    }
+  } else if (nA > 0 && tree_frontier.size() > 1) {
     std::vector<double> q((size_t)nA * 6), rr(nA, cfg.dist_tree);
     for (int k = 0; k < nA; ++k) memcpy(&q[6 * (size_t)k], w[alive[k]].np, 48);
     int cap = 256;
@@ -458,19 +553,7 @@ int Rrt::run_wave(int B) {
     }
     for (int k = 0; k < nA; ++k) {
       WCand& cd = w[alive[k]];
-      for (int h = 0; h < cnt[k]; ++h) {
-        const int id = idx[(size_t)k * cap + h];
-        const int t = nodes[id].tree;
-        if (t == cd.tree) continue;
-        const double d = dd[(size_t)k * cap + h];
-        bool found = false;
-        for (auto& cn : cd.conns)
-          if (cn.tree == t) {
-            found = true;
-            if (d < cn.d || (d == cn.d && nodes[id].idx_in_tree < cn.order)) { cn.node = id; cn.d = d; cn.order = nodes[id].idx_in_tree; }
-          }
-        if (!found) cd.conns.push_back({t, id, d, nodes[id].idx_in_tree, false, -1, 0});
-      }
+      for (int h = 0; h < cnt[k]; ++h) note_conn(cd, idx[(size_t)k * cap + h], dd[(size_t)k * cap + h]);
     }
   }
   lap(4);
@@ -498,9 +581,21 @@ int Rrt::run_wave(int B) {
     if (chained) { ra.reserve(guess); rb.reserve(guess); } else { ea.reserve(6 * guess); eb.reserve(6 * guess); }
   }
   std::vector<double> ax(nA);
-  std::vector<int> at(nA);
-  for (int k = 0; k < nA; ++k) { ax[k] = w[alive[k]].np[0]; at[k] = w[alive[k]].tree; }
+  std::vector<int> at(nA), as(nA);
+  for (int k = 0; k < nA; ++k) { ax[k] = w[alive[k]].np[0]; at[k] = w[alive[k]].tree; as[k] = w[alive[k]].slot; }
   const bool several_trees = tree_frontier.size() > 1;
+  // RRT*: the earlier new points that may enter a point's k-nearest set are looked up in a coarse xyz grid that fills as the
+  // rows are walked (a wave of hundreds of rows: every earlier row against every later one was most of this section)
+  const int G = 16;
+  double g_lo[3], g_inv[3];
+  for (int a = 0; a < 3; ++a) {
+    g_lo[a] = cfg.limits[2 * a];
+    const double ext = cfg.limits[2 * a + 1] - cfg.limits[2 * a];
+    g_inv[a] = ext > 0 ? G / ext : 0.0;
+  }
+  auto g_cell = [&](double v, int a) { const int cidx = (int)std::floor((v - g_lo[a]) * g_inv[a]); return cidx < 0 ? 0 : cidx >= G ? G - 1 : cidx; };
+  std::vector<int> g_head, g_next, g_found;
+  if (kmax > 0) { g_head.assign((size_t)G * G * G, -1); g_next.assign(nA, -1); }
   for (int k = 0; k < nA; ++k) {
     const int j = alive[k];
     WCand& cd = w[j];
@@ -510,11 +605,25 @@ int Rrt::run_wave(int B) {
       if ((int)cd.members.size() >= kmax) dk = dist6(cd.np, nodes[cd.members[kmax - 1]].pos);
       cd.medges.reserve(cd.members.size() + 8);
       for (int id : cd.members) cd.medges.push_back({id, false, false, -1, 0, -1, 0});
-      const double x0 = cd.np[0];
-      for (int kk = 0; kk < k; ++kk) {
-        if (at[kk] != cd.tree || std::fabs(ax[kk] - x0) > dk) continue;
-        const int i = alive[kk];
-        if (dist6(cd.np, w[i].np) <= dk) cd.medges.push_back({-1 - i, false, false, -1, 0, -1, 0});
+      int c0[3], c1[3];
+      for (int a = 0; a < 3; ++a) {
+        c0[a] = std::isfinite(dk) ? g_cell(cd.np[a] - dk, a) : 0;
+        c1[a] = std::isfinite(dk) ? g_cell(cd.np[a] + dk, a) : G - 1;
+      }
+      g_found.clear();
+      for (int cx = c0[0]; cx <= c1[0]; ++cx)
+        for (int cy = c0[1]; cy <= c1[1]; ++cy)
+          for (int cz = c0[2]; cz <= c1[2]; ++cz)
+            for (int kk = g_head[((size_t)cx * G + cy) * G + cz]; kk >= 0; kk = g_next[kk]) {
+              if (at[kk] != cd.tree || as[kk] == cd.slot) continue;   // (not the slot's own other row)
+              if (dist6(cd.np, w[alive[kk]].np) <= dk) g_found.push_back(kk);
+            }
+      std::sort(g_found.begin(), g_found.end());
+      for (int kk : g_found) cd.medges.push_back({-1 - alive[kk], false, false, -1, 0, -1, 0});
+      {
+        const size_t cell = ((size_t)g_cell(cd.np[0], 0) * G + g_cell(cd.np[1], 1)) * G + g_cell(cd.np[2], 2);
+        g_next[k] = g_head[cell];
+        g_head[cell] = k;
       }
       for (size_t e = 0; e < cd.medges.size(); ++e) {
         const double* op = cd.medges[e].other >= 0 ? nodes[cd.medges[e].other].pos : w[-1 - cd.medges[e].other].np;
@@ -530,7 +639,7 @@ int Rrt::run_wave(int B) {
       add_edge(cd.np, nodes[cd.conns[e].node].pos, -1 - j, cd.conns[e].node);   // isPathFree(newPoint, neighbor)  :231
     }
     for (int kk = 0; several_trees && kk < k; ++kk) {
-      if (at[kk] == cd.tree || std::fabs(ax[kk] - cd.np[0]) >= cfg.dist_tree) continue;
+      if (at[kk] == cd.tree || std::fabs(ax[kk] - cd.np[0]) >= cfg.dist_tree || as[kk] == cd.slot) continue;
       const int i = alive[kk];
       if (dist6(w[i].np, cd.np) < cfg.dist_tree) {
         mate_conns.push_back({j, i, add_edge(cd.np, w[i].np, -1 - j, -1 - i)});
@@ -558,16 +667,37 @@ int Rrt::run_wave(int B) {
   int done = 0;
   bool merged = false;
   std::vector<int> acc;   // wave indices of the iterations that became nodes
+  std::vector<int> acc_alt;   // the repaired rows among them (their points are not what k_rrt_mates saw)
   for (int j = 0; j < B && !merged && !solved; ++j) {
-    WCand& cd = w[j];
     // would a node added earlier in this wave have been the nearest neighbour? (ties go to the older node)
+    int row = j;
     bool conflict = false;
-    for (int i : acc) {
-      if (w[i].tree != cd.tree) continue;
-      if (std::fabs(w[i].np[0] - cd.rnd[0]) >= cd.d_near) continue;
-      if (dist6(cd.rnd, w[i].np) < cd.d_near) { conflict = true; break; }
+    if (have_mates) {
+      // the device named the nearest earlier new point that looked alive (mate): the slot's repaired row stands if that point
+      // became a node as speculated; no repaired node of the wave may be as near as the row's nearest node
+      if (w[j].cut_here) { ++g_rrt_alt[2]; break; }
+      const int cand = mate[j];
+      if (cand >= 0) {
+        if (w[cand].accepted < 0 || w[j].alt_row < 0) { ++g_rrt_alt[2]; break; }
+        row = w[j].alt_row;
+        ++g_rrt_alt[0 + 1];
+      }
+      const WCand& cr = w[row];
+      for (int i : acc_alt) {
+        if (w[i].tree != cr.tree) continue;
+        if (std::fabs(w[i].np[0] - cr.rnd[0]) > cr.d_near) continue;
+        if (dist6(cr.rnd, w[i].np) <= cr.d_near) { conflict = true; break; }
+      }
+    } else {
+      const WCand& cr = w[j];
+      for (int i : acc) {
+        if (w[i].tree != cr.tree) continue;
+        if (std::fabs(w[i].np[0] - cr.rnd[0]) >= cr.d_near) continue;
+        if (dist6(cr.rnd, w[i].np) < cr.d_near) { conflict = true; break; }
+      }
     }
     if (conflict) break;
+    WCand& cd = w[row];
     ++done;
     ++iter;
     const unsigned iteration = (unsigned)iter;
@@ -578,7 +708,7 @@ int Rrt::run_wave(int B) {
     st.collide_calls += seg_calls(cd.par_fh, cd.par_ns);
     if (!cd.par_free) continue;
     int tree_to_expand = cd.tree;
-    int nearest = cd.nearest;
+    int nearest = cd.near_row >= 0 ? w[cd.near_row].accepted : cd.nearest;
     int new_id;
     if (cfg.optimize) {                                                          // :156-201
       double best = dist6(cd.np, nodes[nearest].pos) + nodes[nearest].d_root;
@@ -623,7 +753,8 @@ int Rrt::run_wave(int B) {
                         nodes[nearest].d_root + cfg.sampling_dist, iteration);
     }
     cd.accepted = new_id;
-    acc.push_back(j);
+    acc.push_back(row);
+    if (row != j) acc_alt.push_back(row);
     if (cfg.lazy_edge) { lazy_goal_check(new_id); continue; }   // (solved ends the replay loop)
     // :219-319 links to the other live trees, in frontier order
     for (int i = 0; i < (int)tree_frontier.size(); ++i) {
@@ -637,7 +768,7 @@ int Rrt::run_wave(int B) {
       for (const WCand::Conn& cn : cd.conns)
         if (cn.tree == tree) { nb = cn.node; nbd = cn.d; nb_order = cn.order; nb_free = cn.free; fh = cn.fh; ns = cn.ns; }
       for (const MateConn& mc : mate_conns) {
-        if (mc.cand != j || w[mc.mate].tree != tree || w[mc.mate].accepted < 0) continue;
+        if (mc.cand != row || w[mc.mate].tree != tree || w[mc.mate].accepted < 0) continue;
         const int id = w[mc.mate].accepted;
         const double d = dist6(nodes[id].pos, cd.np);
         if (nb < 0 || d < nbd || (d == nbd && nodes[id].idx_in_tree < nb_order)) {
@@ -696,16 +827,23 @@ void Rrt::run(int max_iters) {
     done += got;
     if (cfg.wave <= 0) {
       if (got >= want) B = std::min(4096, B * 2);
-      else B = std::max(1, std::min(4096, (3 * got) / 2 + 1));
+      else {
+        // (a cut wave: the next one speculates grow_pct % of what survived; a SMALL wave costs the chain's latency whatever
+        // its size, so it may as well carry a few times that)
+        const int by_rule = (int)((long long)got * grow_pct / 100) + 1;
+        B = std::max(1, std::min(4096, std::max(by_rule, std::min(small_mul * got + 1, small_cap))));
+      }
     }
     if (got == 0 && want > 0 && iter >= cfg.max_iterations) break;
   }
   if (chain_on) ctx->sync();   // (the last wave's append)
   st.total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
   if (getenv("SFFGPU_PROFILE")) {
-    fprintf(stderr, "[sffgpu rrt run_wave ms] draws %.1f | nearest %.1f | pose + parent edge %.1f | k nearest %.1f | other trees %.1f | edge lists %.1f + edges on the GPU %.1f + results %.1f | replay %.1f | append %.1f  (%llu waves)\n",
+    fprintf(stderr, "[sffgpu rrt run_wave ms] draws %.1f | chain %.1f | repaired slots %.1f | k nearest %.1f | other trees %.1f | edge lists %.1f + edges on the GPU %.1f + results %.1f | replay %.1f | append %.1f  (%llu waves)\n",
             g_rrt_sec[0], g_rrt_sec[1], g_rrt_sec[2], g_rrt_sec[3], g_rrt_sec[4], g_rrt_sec[8], g_rrt_sec[9], g_rrt_sec[5], g_rrt_sec[6], g_rrt_sec[7], (unsigned long long)st.waves);
+    fprintf(stderr, "[sffgpu rrt repaired slots] %llu evaluated, %llu taken, %llu waves cut at a slot without one\n", g_rrt_alt[0], g_rrt_alt[1], g_rrt_alt[2]);
     for (double& x : g_rrt_sec) x = 0;
+    for (auto& x : g_rrt_alt) x = 0;
   }
 }
 
