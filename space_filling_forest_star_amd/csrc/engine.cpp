@@ -943,11 +943,15 @@ void Ctx::rrt_rows(RrtRows& R, int row0, int n, int kmax, bool by_gridk, double 
   if (R.phase == 0) {   // layout only: the caller's kernels write into the block before the rows' own
     rr_out.ensure(o_end);
     rr_hout.ensure(o_end);
+    r_items.ensure((size_t)(8 * n + 65536) * SFFK_ITEM_BYTES);
+    r_items2.ensure(((size_t)(8 * n + 65536) + (1u << 20)) * 8);
     char* db = rr_out.as<char>();
     R.np_copy = reinterpret_cast<double*>(db + o_np);
     R.near_idx = reinterpret_cast<int32_t*>(db + o_ni);
     R.near_d = reinterpret_cast<double*>(db + o_nd);
     R.near_cnt = reinterpret_cast<int32_t*>(db + o_nc);
+    R.seg_dev = reinterpret_cast<int32_t*>(db + o_sg);
+    R.conn_cnt_dev = kc ? reinterpret_cast<int32_t*>(db + o_cc) : nullptr;
     return;
   }
   char* db = rr_out.as<char>();
@@ -957,13 +961,10 @@ void Ctx::rrt_rows(RrtRows& R, int row0, int n, int kmax, bool by_gridk, double 
   int32_t* d_ov = d_fh + n;
   int32_t* d_ctrl = d_ov + n;
   uint8_t* d_hit = reinterpret_cast<uint8_t*>(db + o_ht);
-  HIPCHK(hipMemsetAsync(d_ctrl, 0, 64, stream));
+  // (sample counts, result presets and the zeroed control words: written by k_rrt_steer)
   const int list_cap = 8 * n + 65536;
-  r_items.ensure((size_t)list_cap * SFFK_ITEM_BYTES);
-  r_items2.ensure(((size_t)list_cap + (1u << 20)) * 8);
   time_begin(T_COLLIDE);
   sffk::launch_collide_poses(stream, envv, robv, r_np, n, nullptr, d_hit, false);
-  sffk::launch_seg_prepare(stream, rr_a.as<double>(), r_np, n, d_ns, d_fh, d_ov);
   sffk::launch_collide_segments_dyn(stream, envv, robv, rr_a.as<double>(), r_np, d_ns, n, d_ctrl, r_items.p, list_cap, r_items2.p,
                                     d_fh, d_ov);
   time_end();
@@ -981,7 +982,6 @@ void Ctx::rrt_rows(RrtRows& R, int row0, int n, int kmax, bool by_gridk, double 
     time_end();
   }
   if (kc) {
-    HIPCHK(hipMemsetAsync(db + o_cc, 0, (size_t)n * 4, stream));
     time_begin(T_SWEEP);
     sffk::launch_sweep(stream, store_view(), 0, store_n, rr_sq.as<sffk::SweepQuery>(), r_np, n, reinterpret_cast<int32_t*>(db + o_cc),
                        reinterpret_cast<int32_t*>(db + o_ci), reinterpret_cast<double*>(db + o_cd), conn_cap);
@@ -1056,7 +1056,7 @@ void Ctx::rrt_chain(const double* rnd6, const int32_t* tree, int n, double dist,
   time_end();
   sffk::launch_rrt_steer(stream, rr_q1.as<sffk::KnnQuery>(), R.near_idx, K1, spos.as<double>(), dist, rr_a.as<double>(), rr_np.as<double>(),
                          kmax > 0 ? rr_q2.as<sffk::KnnQuery>() : nullptr, kmax, n, kc ? rr_sq.as<sffk::SweepQuery>() : nullptr, conn_r,
-                         kc ? rrt_conn_r2f(conn_r, sweep_eps()) : 0.f, R.np_copy);
+                         kc ? rrt_conn_r2f(conn_r, sweep_eps()) : 0.f, R.np_copy, R.seg_dev, R.conn_cnt_dev);
   R.phase = 1;
   rrt_rows(R, 0, n, kmax, by_gridk, conn_r, conn_cap, n, near_idx, near_d, near_cnt, mate);
   rr_rows0 = n;
@@ -1077,8 +1077,8 @@ void Ctx::rrt_chain_alt(const int32_t* slot, const int32_t* mate, int n_alt, dou
   rrt_rows(R, rr_rows0, n_alt, kmax, by_gridk, conn_r, conn_cap, 0, nullptr, nullptr, nullptr, nullptr);
   sffk::launch_rrt_steer(stream, rr_q1.as<sffk::KnnQuery>(), nullptr, 0, spos.as<double>(), dist, rr_a.as<double>(), rr_np.as<double>(),
                          kmax > 0 ? rr_q2.as<sffk::KnnQuery>() : nullptr, kmax, n_alt, kc ? rr_sq.as<sffk::SweepQuery>() : nullptr, conn_r,
-                         kc ? rrt_conn_r2f(conn_r, sweep_eps()) : 0.f, R.np_copy, rr_alt.as<int32_t>(), rr_alt.as<int32_t>() + n_alt,
-                         rr_rows0);
+                         kc ? rrt_conn_r2f(conn_r, sweep_eps()) : 0.f, R.np_copy, R.seg_dev, R.conn_cnt_dev, rr_alt.as<int32_t>(),
+                         rr_alt.as<int32_t>() + n_alt, rr_rows0);
   R.phase = 1;
   rrt_rows(R, rr_rows0, n_alt, kmax, by_gridk, conn_r, conn_cap, 0, nullptr, nullptr, nullptr, nullptr);
 }

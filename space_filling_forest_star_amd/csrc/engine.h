@@ -210,6 +210,7 @@ struct Ctx {
   struct RrtRows {
     double* np6; uint8_t* hit; int32_t* seg; int32_t* mem_idx; double* mem_d; int32_t* mem_cnt;   // host, caller-owned
     int32_t* conn_idx; double* conn_d; int32_t* conn_cnt;
+    int32_t* seg_dev = nullptr; int32_t* conn_cnt_dev = nullptr;
     int phase = 0; double* np_copy = nullptr; int32_t* near_idx = nullptr; double* near_d = nullptr; int32_t* near_cnt = nullptr;   // (device, internal)
   };
   void rrt_chain(const double* rnd6, const int32_t* tree, int n, double dist, bool by_grid1, int kmax, bool by_gridk,

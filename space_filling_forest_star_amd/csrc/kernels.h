@@ -328,7 +328,10 @@ void launch_knn_linear(hipStream_t s, const NodeStoreView& st, int n_store, cons
 // RRT session: nearest node -> steered point on the device (k_rrt_steer), see Ctx::rrt_chain
 void launch_rrt_steer(hipStream_t s, const KnnQuery* q1, const int32_t* idx1, int k1, const double* store_pos, double dist,
                       double* a6, double* np6, KnnQuery* q2, int kmax, int n, SweepQuery* sq, double sq_r, float sq_r2f,
-                      double* np_copy, const int32_t* alt_slot = nullptr, const int32_t* alt_mate = nullptr, int row0 = 0);
+                      double* np_copy, int32_t* seg_ns, int32_t* conn_cnt, const int32_t* alt_slot = nullptr,
+                      const int32_t* alt_mate = nullptr, int row0 = 0);
+// (seg_ns: 3 n + 16 words - the parent edges' sample counts, result presets and the edge kernels' control words, zeroed here;
+// conn_cnt: n hit counters of the other-trees query, zeroed here)
 // (sq: the other-trees radius query of every new point; alt_slot / alt_mate: the rows are repaired slots, written from row0 on)
 void launch_rrt_mates(hipStream_t s, const KnnQuery* q1, const double* near_d, int k1, const double* np6, const uint8_t* hit,
                       const int32_t* fh, const int32_t* ov, int n, int32_t* mate);

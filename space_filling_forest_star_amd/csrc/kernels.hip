@@ -5873,7 +5873,8 @@ __global__ __launch_bounds__(256) void k_rrt_steer(const KnnQuery* __restrict__ 
                                                    double* __restrict__ np6, KnnQuery* __restrict__ q2, int kmax, int n,
                                                    SweepQuery* __restrict__ sq, double sq_r, float sq_r2f,
                                                    double* __restrict__ np_copy, const int32_t* __restrict__ alt_slot,
-                                                   const int32_t* __restrict__ alt_mate, int row0) {
+                                                   const int32_t* __restrict__ alt_mate, int row0, int32_t* __restrict__ seg_ns,
+                                                   int32_t* __restrict__ conn_cnt) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   // alt_slot != null: row i is the REPAIRED version of slot alt_slot[i] - the wave's new point alt_mate[i] (a row of np6)
@@ -5890,6 +5891,15 @@ __global__ __launch_bounds__(256) void k_rrt_steer(const KnnQuery* __restrict__ 
   for (int k = 0; k < 6; ++k) t[k] = q1[slot].pos[k];
   steer(a, t, dist, o);
   for (int k = 0; k < 6; ++k) { a6[6 * (size_t)i + k] = a[k]; np6[6 * (size_t)(row0 + i) + k] = o[k]; np_copy[6 * (size_t)i + k] = o[k]; }
+  // the parent edge's sample count and result presets (k_seg_prepare) and the edge kernels' control words (seg_ns: n sample
+  // counts | n first hits | n overflow marks | 16 control words), so that the chain needs no launch of its own for them
+  seg_ns[i] = edge_samples(edge_parts(a, o));
+  seg_ns[(size_t)n + i] = 0x7fffffff;
+  seg_ns[2 * (size_t)n + i] = 0;
+  if (i < 16) seg_ns[3 * (size_t)n + i] = 0;
+  if (n < 16 && i == 0)
+    for (int k = n; k < 16; ++k) seg_ns[3 * (size_t)n + k] = 0;
+  if (conn_cnt) conn_cnt[i] = 0;
   if (q2) {
     KnnQuery q;
     for (int k = 0; k < 6; ++k) q.pos[k] = o[k];
@@ -5905,9 +5915,9 @@ __global__ __launch_bounds__(256) void k_rrt_steer(const KnnQuery* __restrict__ 
 }
 void launch_rrt_steer(hipStream_t s, const KnnQuery* q1, const int32_t* idx1, int k1, const double* store_pos, double dist,
                       double* a6, double* np6, KnnQuery* q2, int kmax, int n, SweepQuery* sq, double sq_r, float sq_r2f,
-                      double* np_copy, const int32_t* alt_slot, const int32_t* alt_mate, int row0) {
+                      double* np_copy, int32_t* seg_ns, int32_t* conn_cnt, const int32_t* alt_slot, const int32_t* alt_mate, int row0) {
   if (n > 0) hipLaunchKernelGGL(k_rrt_steer, dim3((n + 255) / 256), dim3(256), 0, s, q1, idx1, k1, store_pos, dist, a6, np6, q2, kmax, n,
-                                sq, sq_r, sq_r2f, np_copy, alt_slot, alt_mate, row0);
+                                sq, sq_r, sq_r2f, np_copy, alt_slot, alt_mate, row0, seg_ns, conn_cnt);
 }
 
 // RRT session: which EARLIER new point of the wave would be slot j's nearest node?  (The replay of Rrt::run_wave cuts the

@@ -399,9 +399,19 @@ int Rrt::run_wave(int B) {
         cd.par_ns = ns_j;
       };
       auto fill_members = [&](WCand& cd, const int32_t* mi_r, const double* md_r, const int32_t* mc_r, int r) {
+        // (the device's order is (distance, id): already the reference's (distance, position in the tree) unless two nodes
+        // are at one distance and the tree's list is not in id order - after a merge)
+        const int n_m = mc_r[r];
+        const int32_t* ids = mi_r + (size_t)r * kmax;
+        const double* ds = md_r + (size_t)r * kmax;
+        bool in_order = true;
+        for (int m = 1; m < n_m && in_order; ++m)
+          in_order = ds[m - 1] < ds[m] || (ds[m - 1] == ds[m] && nodes[ids[m - 1]].idx_in_tree < nodes[ids[m]].idx_in_tree);
+        cd.members.assign(ids, ids + n_m);
+        if (in_order) return;
         struct E { double d; int order; int id; };
         std::vector<E> e;
-        for (int m = 0; m < mc_r[r]; ++m) { const int id = mi_r[(size_t)r * kmax + m]; e.push_back({md_r[(size_t)r * kmax + m], nodes[id].idx_in_tree, id}); }
+        for (int m = 0; m < n_m; ++m) e.push_back({ds[m], nodes[ids[m]].idx_in_tree, ids[m]});
         std::sort(e.begin(), e.end(), [](const E& a, const E& b) { return a.d < b.d || (a.d == b.d && a.order < b.order); });
         cd.members.clear();
         for (const E& x : e) cd.members.push_back(x.id);
@@ -667,6 +677,9 @@ int Rrt::run_wave(int B) {
   int done = 0;
   bool merged = false;
   std::vector<int> acc;   // wave indices of the iterations that became nodes
+  struct KN { double d; int order; int node; const WCand::Edge* e; };
+  std::vector<KN> kn;
+  kn.reserve(128);
   std::vector<int> acc_alt;   // the repaired rows among them (their points are not what k_rrt_mates saw)
   for (int j = 0; j < B && !merged && !solved; ++j) {
     // would a node added earlier in this wave have been the nearest neighbour? (ties go to the older node)
@@ -714,8 +727,7 @@ int Rrt::run_wave(int B) {
       double best = dist6(cd.np, nodes[nearest].pos) + nodes[nearest].d_root;
       const size_t krrt = (size_t)(2 * M_E * std::log10((double)nodes.size() + (cfg.lazy_edge ? 1.0 : 0.0)));
       st.nn_queries += 1;
-      struct KN { double d; int order; int node; const WCand::Edge* e; };
-      std::vector<KN> kn;
+      kn.clear();
       for (const WCand::Edge& e : cd.medges) {
         int nd = e.other >= 0 ? e.other : w[-1 - e.other].accepted;
         if (nd < 0) continue;
@@ -726,7 +738,7 @@ int Rrt::run_wave(int B) {
       if (kn.size() < std::min(krrt, trees[tree_to_expand].size()))
         throw HipError{"rrt: k-nearest candidate set incomplete (internal error)"};
       for (const KN& x : kn) {                                                   // :168-175
-        double nd = dist6(cd.np, nodes[x.node].pos) + nodes[x.node].d_root;
+        double nd = x.d + nodes[x.node].d_root;   // (x.d = dist6(cd.np, the node))
         if (nd < best - SFFG_TOL) {
           st.path_free_calls += 1;
           st.collide_calls += seg_calls(x.e->fh_f, x.e->ns_f);

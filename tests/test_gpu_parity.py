@@ -374,6 +374,46 @@ def test_priority_frontier_mode_staged_runs(S, ctx, monkeypatch):
     assert_same_forest(fo, fg)
 
 
+@pytest.mark.parametrize("name,optimize,n_roots,iters", [
+    ("dense3d", False, 1, 6000), ("dense3d", True, 1, 4000), ("dense3d", False, 10, 6000), ("dense2d", True, 1, 2500),
+])
+def test_rrt_waves_with_repaired_slots_identical(S, ctx, monkeypatch, name, optimize, n_roots, iters):
+    """A speculative RRT wave (csrc/rrt.cpp run_wave) used to end at the first slot whose nearest node would be a new point
+    of the same wave.  Such a slot is now evaluated a second time FROM that point (k_rrt_mates names it, Ctx::rrt_chain_alt
+    evaluates the repaired row) and the replay takes that row when the earlier slot became a node as speculated: the
+    committed sequence stays the reference's (src/rrt.h:128-322) - nodes, parents, costs, links, counters, stream position
+    equal the oracle's at every wave size - and the job takes fewer waves than with the repair switched off."""
+    sc, w = load_world(ctx, name)
+    pts = sc["xml_points"] if sc["xml_points"] is not None else common.free_roots(w.collide, sc["limits"], 10, seed=5,
+                                                                                 dim=sc["dim"])
+    roots = pts[:n_roots]
+    kw = dict(dist_tree=sc["dist_tree"], sampling_dist=sc["sampling_dist"], dim=sc["dim"], optimize=optimize,
+              max_iterations=iters, seed=7)
+    ro = O.Rrt(w, roots, sc["limits"], **kw)
+    ro.run()
+    so, no, lo = ro.stats(), ro.nodes(), ro.links()
+    assert so["n_nodes"] > 500
+    waves = {}
+    for repair in ("1", "0"):
+        monkeypatch.setenv("SFFGPU_RRT_REPAIR", repair)
+        for wave in (0, 256, 4096):
+            rg = S.Rrt(ctx, roots, sc["limits"], wave=wave, **kw)
+            rg.run()
+            sg = rg.stats()
+            for k in so:
+                assert so[k] == sg[k], (repair, wave, k, so[k], sg[k])
+            ng, lg = rg.nodes(), rg.links()
+            for k in no:
+                assert np.array_equal(no[k], ng[k]), (repair, wave, k)
+            for k in lo:
+                assert np.array_equal(lo[k], lg[k]), (repair, wave, k)
+            waves[(repair, wave)] = sg["waves"]
+            rg.close()
+    for wave in (0, 256, 4096):
+        assert waves[("1", wave)] < waves[("0", wave)], waves
+    assert 2 * waves[("1", 0)] < waves[("0", 0)] or n_roots > 1, waves
+
+
 def test_gpu_matches_committed_golden_runs(S, ctx, golden_dir):
     """The GPU path against the COMMITTED fixture tests/golden/oracle_runs.json (not only against the oracle
     built on this box): node counts, reference-equivalent collision calls, parent and cost checksums."""
