@@ -845,8 +845,6 @@ void Ctx::collide_segments_core(const double* a6, const double* b6, const int32_
     memcpy(h_a.p, ida, (size_t)n * 4);
     memcpy(h_b.p, idb, (size_t)n * 4);
   }
-  std::vector<int32_t> ns(n, 0), fh(n, -1);
-  std::vector<uint8_t> ovf(n, 0);
   d_a.ensure(pb); d_b.ensure(pb); d_c.ensure((size_t)n * 12 + 64);
   int32_t* d_ns = d_c.as<int32_t>();
   int32_t* d_fh = d_ns + n;
@@ -873,18 +871,33 @@ void Ctx::collide_segments_core(const double* a6, const double* b6, const int32_
   time_end();
   HIPCHK(hipMemcpyAsync(h_c.p, d_c.p, (size_t)n * 12, hipMemcpyDeviceToHost, stream));
   sync();
+  // (one pass over the answer: a wave of the RRT* session brings tens of thousands of edges per call)
+  bool any_ovf = false;
   {
     const int32_t* hn = h_c.as<int32_t>();
+    const int32_t* hf = hn + n;
+    const int32_t* ho = hn + 2 * (size_t)n;
+    for (int i = 0; i < n; ++i) {
+      const int32_t v = hf[i] == 0x7fffffff ? -1 : hf[i];
+      is_free[i] = v < 0 ? 1 : 0;
+      if (first_hit) first_hit[i] = v;
+      if (n_samples) n_samples[i] = hn[i];
+      any_ovf |= ho[i] != 0;
+    }
+  }
+  if (!any_ovf) return;
+  // edges whose candidate list overflowed are re-run sample by sample through the pose kernel
+  std::vector<int32_t> ns(n), fh(n);
+  std::vector<uint8_t> ovf(n);
+  {
+    const int32_t* hn = h_c.as<int32_t>();   // (still the answer: nothing has been enqueued since)
     for (int i = 0; i < n; ++i) {
       ns[i] = hn[i];
-      int32_t v = hn[n + i];
+      const int32_t v = hn[(size_t)n + i];
       fh[i] = v == 0x7fffffff ? -1 : v;
       ovf[i] = hn[2 * (size_t)n + i] != 0;
     }
   }
-  // edges whose candidate list overflowed are re-run sample by sample through the pose kernel
-  bool any_ovf = false;
-  for (int i = 0; i < n; ++i) any_ovf |= ovf[i] != 0;
   std::vector<double> ga, gb;
   if (any_ovf && !a6) {   // (their end points only exist on the device: fetch the gathered arrays)
     ga.resize((size_t)n * 6);
