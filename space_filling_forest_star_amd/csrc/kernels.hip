@@ -4112,6 +4112,65 @@ __device__ __forceinline__ bool sq_edge_clear_fast(const EnvView& env, const dou
   return true;
 }
 
+// sq_edge_clear_fast's question for up to three edges at once, the clearance words of all of them in flight together (SFF*'s
+// choose-parent / rewire candidates in k_spec_waves: a wavefront alone on its SIMD pays a full memory round trip per edge
+// otherwise).  clear[e]: the bits alone say "free" (an edge of more than 256 samples answers false: the caller asks
+// sq_edge_clear_fast / sq_path_free); ns[e]: its sample count = the Collide calls the reference makes on a free edge.
+// Counts nothing: the caller does, for the edges whose turn really comes.
+__device__ __forceinline__ void sq_edges_clear_probe(const EnvView& env, const double (*a)[6], const double (*b)[6], int n, int lane,
+                                                     bool* clear, int* ns_out) {
+  const uint32_t* wp[3][4];
+  int sh[3][4];
+  bool need[3][4];
+  bool can[3];
+#pragma unroll
+  for (int e = 0; e < 3; ++e) {
+    can[e] = false;
+    ns_out[e] = 0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { wp[e][u] = nullptr; sh[e][u] = 0; need[e][u] = false; }
+    if (e >= n || env.n_tri == 0 || !env.clear_bits_edge) continue;
+    const double parts = edge_parts(a[e], b[e]);
+    const int ns = edge_samples(parts);
+    ns_out[e] = ns;
+    if (ns > 256) continue;
+    can[e] = true;
+    const float inv = (float)env.clear_inv * __frcp_rn((float)parts);
+    const float g0 = (float)((a[e][0] - env.clear_org[0]) * env.clear_inv), g1 = (float)((a[e][1] - env.clear_org[1]) * env.clear_inv),
+                g2 = (float)((a[e][2] - env.clear_org[2]) * env.clear_inv);
+    const float d0 = (float)(b[e][0] - a[e][0]) * inv, d1 = (float)(b[e][1] - a[e][1]) * inv, d2 = (float)(b[e][2] - a[e][2]) * inv;
+    const float nxd = (float)env.clear_n[0], nyd = (float)env.clear_n[1], nzd = (float)env.clear_n[2];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = 1 + 64 * u + lane;
+      need[e][u] = idx <= ns;
+      if (need[e][u]) {
+        const float td = (float)idx;
+        const float fx = __builtin_fmaf(td, d0, g0), fy = __builtin_fmaf(td, d1, g1), fz = __builtin_fmaf(td, d2, g2);
+        if (fx >= 0 && fy >= 0 && fz >= 0 && fx < nxd && fy < nyd && fz < nzd) {
+          const uint32_t ci = ((uint32_t)(int)fz * (uint32_t)env.clear_n[1] + (uint32_t)(int)fy) * (uint32_t)env.clear_n[0] + (uint32_t)(int)fx;
+          wp[e][u] = env.clear_bits_edge + (ci >> 5);
+          sh[e][u] = (int)(ci & 31u);
+        } else if (fx == fx && fy == fy && fz == fz) {
+          need[e][u] = false;                               // beyond the inflated box of the environment
+        }
+      }
+    }
+  }
+  uint32_t word[3][4];
+#pragma unroll
+  for (int e = 0; e < 3; ++e)
+#pragma unroll
+    for (int u = 0; u < 4; ++u) word[e][u] = wp[e][u] ? *wp[e][u] : 0u;
+#pragma unroll
+  for (int e = 0; e < 3; ++e) {
+    bool open = false;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) open = open || (need[e][u] && !(wp[e][u] && ((word[e][u] >> sh[e][u]) & 1u)));
+    clear[e] = can[e] && !__any(open);
+  }
+}
+
 // Solver::isPathFree(a, b) by the wavefront: chunk after chunk until the first hit (the chunks come in sample order, so
 // the first chunk with a hit holds the edge's first hit).  Returns free; calls = Collide calls the reference makes.
 __device__ __attribute__((noinline)) bool sq_path_free(const EnvView& env, const RobotView& rob, const double* rtri, int32_t* stack, int32_t* cand, int32_t* queue,
@@ -5750,39 +5809,90 @@ __global__ __launch_bounds__(OPT ? 192 : 128) void k_spec_waves(SpecArgs S) {
                   n_mem = lds_ld(&j_nmem);
                   beat(10);
                   if (stale()) aborted = true;
-                  if (lane < n_mem) m_droot = sq_f64(f.d_root + mt.id);
-                  for (int m = 0; m < n_mem && !flt && !aborted; ++m) {                             // :320-327
-                    const double nd = __shfl(mt.d, m) + __shfl(m_droot, m);
-                    if (nd < best - SFFG_TOL) {
-                      const int idm = __shfl(mt.id, m);
-                      double mp[6];
-                      for (int q = 0; q < 6; ++q) mp[q] = sq_f64(A.st.pos + 6 * (size_t)idm + q);
-                      pf_l += 1; ex_seg += 1;
-                      if ((sq_edge_clear_fast(A.env, qp, mp, lane, cc_l, ex_smp) || sq_path_free(A.env, A.rob, rtri, stack, cand, queue, stage, qp, mp, &s_fh, &s_ovf, lane, cc_l, ex_smp, flt)) && !flt) {
-                        best = nd; par_new = idm; dcl_new = __shfl(mt.d, m);
+                  // (every member's cost and position in one round trip, lane = member: a candidate's position is a shuffle away)
+                  double m_pos[6] = {0, 0, 0, 0, 0, 0};
+                  if (lane < n_mem) {
+                    m_droot = sq_f64(f.d_root + mt.id);
+                    for (int q = 0; q < 6; ++q) m_pos[q] = sq_f64(A.st.pos + 6 * (size_t)mt.id + q);
+                  }
+                  // (:320-327 walks the members in order and checks an edge when its cost beats the best so far.  Only members
+                  // that beat the cost through the expansion's parent can ever be checked: their positions and clearance words
+                  // are fetched three edges at a time, the walk itself stays the reference's)
+                  {
+                    const double nd_l = mt.d + m_droot;
+                    unsigned long long cm = __ballot(lane < n_mem && nd_l < best - SFFG_TOL);
+                    while (cm && !flt && !aborted) {
+                      int ix[3] = {0, 0, 0};
+                      int nb = 0;
+                      unsigned long long t = cm;
+#pragma unroll
+                      for (int e = 0; e < 3; ++e)
+                        if (t) { ix[e] = __ffsll((long long)t) - 1; t &= t - 1; nb = e + 1; }
+                      double mp3[3][6], qp3[3][6];
+                      int id3[3];
+#pragma unroll
+                      for (int e = 0; e < 3; ++e) {
+                        id3[e] = __shfl(mt.id, ix[e]);
+                        for (int q = 0; q < 6; ++q) { mp3[e][q] = __shfl(m_pos[q], ix[e]); qp3[e][q] = qp[q]; }
                       }
+                      bool clr[3];
+                      int ns3[3];
+                      sq_edges_clear_probe(A.env, qp3, mp3, nb, lane, clr, ns3);
+#pragma unroll
+                      for (int e = 0; e < 3; ++e) {
+                        if (e >= nb || flt || aborted) continue;
+                        const double nd = __shfl(nd_l, ix[e]);
+                        if (!(nd < best - SFFG_TOL)) continue;
+                        pf_l += 1; ex_seg += 1;
+                        bool fr;
+                        if (clr[e]) { cc_l += (unsigned long long)ns3[e]; ex_smp += (unsigned long long)ns3[e]; fr = true; }
+                        else fr = sq_edge_clear_fast(A.env, qp, mp3[e], lane, cc_l, ex_smp) || sq_path_free(A.env, A.rob, rtri, stack, cand, queue, stage, qp, mp3[e], &s_fh, &s_ovf, lane, cc_l, ex_smp, flt);
+                        if (fr && !flt) { best = nd; par_new = id3[e]; dcl_new = __shfl(mt.d, ix[e]); }
+                      }
+                      cm = t & __ballot(lane < n_mem && nd_l < best - SFFG_TOL);
                     }
                   }
                   // rewire (:332-350): a member the new node's cost improves, if the edge member -> new is free
                   SP_WAVE_SYNC();
                   beat(11);
                   if (stale()) aborted = true;
-                  for (int m = 0; m < n_mem && !flt && !aborted; ++m) {
-                    const double dm = __shfl(mt.d, m), drm = __shfl(m_droot, m);
-                    const double proposed = best + dm;
-                    if (proposed < drm - SFFG_TOL) {
-                      const int idm = __shfl(mt.id, m);
-                      double mp[6];
-                      for (int q = 0; q < 6; ++q) mp[q] = sq_f64(A.st.pos + 6 * (size_t)idm + q);
-                      pf_l += 1; ex_seg += 1;
-                      bool f2 = false;
-                      if ((sq_edge_clear_fast(A.env, mp, qp, lane, cc_l, ex_smp) || sq_path_free(A.env, A.rob, rtri, stack, cand, queue, stage, mp, qp, &s_fh, &s_ovf, lane, cc_l, ex_smp, f2))) {
-                        if (lane == 0) {
-                          s_rw[5 * n_rw] = (uint32_t)idm;
-                          s_rw[5 * n_rw + 1] = sp_lo(dm); s_rw[5 * n_rw + 2] = sp_hi(dm);
-                          s_rw[5 * n_rw + 3] = sp_lo(proposed); s_rw[5 * n_rw + 4] = sp_hi(proposed);
+                  // (every member the new node's cost improves is checked, whatever the others answer: three edges at a time)
+                  if (!flt && !aborted) {
+                    unsigned long long cm = __ballot(lane < n_mem && best + mt.d < m_droot - SFFG_TOL);
+                    while (cm) {
+                      int ix[3] = {0, 0, 0};
+                      int nb = 0;
+#pragma unroll
+                      for (int e = 0; e < 3; ++e)
+                        if (cm) { ix[e] = __ffsll((long long)cm) - 1; cm &= cm - 1; nb = e + 1; }
+                      double mp3[3][6], qp3[3][6];
+                      int id3[3];
+#pragma unroll
+                      for (int e = 0; e < 3; ++e) {
+                        id3[e] = __shfl(mt.id, ix[e]);
+                        for (int q = 0; q < 6; ++q) { mp3[e][q] = __shfl(m_pos[q], ix[e]); qp3[e][q] = qp[q]; }
+                      }
+                      bool clr[3];
+                      int ns3[3];
+                      sq_edges_clear_probe(A.env, mp3, qp3, nb, lane, clr, ns3);
+#pragma unroll
+                      for (int e = 0; e < 3; ++e) {
+                        if (e >= nb) continue;
+                        const double dm = __shfl(mt.d, ix[e]);
+                        const double proposed = best + dm;
+                        pf_l += 1; ex_seg += 1;
+                        bool f2 = false;
+                        bool fr;
+                        if (clr[e]) { cc_l += (unsigned long long)ns3[e]; ex_smp += (unsigned long long)ns3[e]; fr = true; }
+                        else fr = sq_edge_clear_fast(A.env, mp3[e], qp, lane, cc_l, ex_smp) || sq_path_free(A.env, A.rob, rtri, stack, cand, queue, stage, mp3[e], qp, &s_fh, &s_ovf, lane, cc_l, ex_smp, f2);
+                        if (fr) {
+                          if (lane == 0) {
+                            s_rw[5 * n_rw] = (uint32_t)id3[e];
+                            s_rw[5 * n_rw + 1] = sp_lo(dm); s_rw[5 * n_rw + 2] = sp_hi(dm);
+                            s_rw[5 * n_rw + 3] = sp_lo(proposed); s_rw[5 * n_rw + 4] = sp_hi(proposed);
+                          }
+                          ++n_rw;
                         }
-                        ++n_rw;
                       }
                     }
                   }
