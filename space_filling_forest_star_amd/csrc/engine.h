@@ -537,6 +537,7 @@ struct Rrt {
   void knn(const double* q, int nq, const int32_t* tree, int k, std::vector<std::vector<int>>& out);
   bool knn_by_grid(const int32_t* tree, int nq, int k) const;
   bool chain_on = true;   // SFFGPU_RRT_CHAIN (read when the session is created): nearest -> steer -> pose -> parent edge -> k nearest as one chain
+  bool dry_on = true;     // SFFGPU_RRT_DRY: the replay's nearest-node walk done once ahead, so that only the rows it takes get edges
   bool repair_on = true;  // SFFGPU_RRT_REPAIR: slots whose nearest node would be an earlier new point of the wave are evaluated from it too
   int small_mul = 4, small_cap = 48;   // SFFGPU_RRT_SMALL (cap): ... or small_mul x that, up to small_cap slots
   int grow_pct = 150;     // SFFGPU_RRT_GROW: after a cut wave the next one speculates grow_pct % of what survived (+ 1)

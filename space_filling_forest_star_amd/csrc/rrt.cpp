@@ -23,6 +23,7 @@ namespace sff {
 Rrt::Rrt(Ctx* c, const sffgpu_rrt_cfg& cf, const double* roots6, int n_roots) : ctx(c), cfg(cf) {
   if (const char* e = getenv("SFFGPU_RRT_CHAIN")) chain_on = atoi(e) != 0;
   if (const char* e = getenv("SFFGPU_RRT_REPAIR")) repair_on = atoi(e) != 0;
+  if (const char* e = getenv("SFFGPU_RRT_DRY")) dry_on = atoi(e) != 0;
   if (const char* e = getenv("SFFGPU_RRT_SMALL")) { small_cap = std::max(1, atoi(e)); }
   if (const char* e = getenv("SFFGPU_RRT_GROW")) grow_pct = std::max(100, atoi(e));
   if (cfg.dim != 2 && cfg.dim != 6) throw HipError{"rrt: dim must be 2 or 6"};
@@ -323,6 +324,7 @@ struct WCand {
   // and the slot's nearest one (that is what it is if that slot is accepted as speculated)
   int slot = -1, near_row = -1, alt_row = -1;
   bool cut_here = false;                          // nothing evaluated covers this slot if it is reached
+  bool prepared = false;                          // its member lists / link candidates / edges are in the wave's batches
 };
 }  // namespace
 
@@ -465,11 +467,42 @@ int Rrt::run_wave(int B) {
         }
       }
       lap(2);
-      // (rows in the order of their slots, a slot's repaired row after its speculated one)
-      for (int j = 0; j < B; ++j) {
-        if (!w[j].pose_hit && w[j].par_free) alive.push_back(j);
-        const int a = w[j].alt_row;
-        if (a >= 0 && !w[a].pose_hit && w[a].par_free) alive.push_back(a);
+      // ---- which row of which slot will the replay take, and where will it stop?  That depends on the nearest-node logic
+      // alone (a row that is alive becomes a node whatever its other edges say): the replay's walk is done once ahead, dry, and
+      // only the rows it takes get member lists, link candidates and edges - nothing past the cut, not both rows of a slot.
+      // (Tree merges end the real replay earlier; a row the replay reaches unprepared ends the wave there.)
+      if (dry_on) {
+        std::vector<int> alt_acc;
+        std::vector<char> took(w.size(), 0);
+        for (int j = 0; j < B; ++j) {
+          if (w[j].cut_here) break;
+          int row = j;
+          const int cand = mate[j];
+          if (cand >= 0) {
+            if (!took[cand] || w[j].alt_row < 0) break;
+            row = w[j].alt_row;
+          }
+          const WCand& cr = w[row];
+          bool conflict = false;
+          for (int i : alt_acc) {
+            if (w[i].tree != cr.tree) continue;
+            if (std::fabs(w[i].np[0] - cr.rnd[0]) > cr.d_near) continue;
+            if (dist6(cr.rnd, w[i].np) <= cr.d_near) { conflict = true; break; }
+          }
+          if (conflict) break;
+          if (cr.pose_hit || !cr.par_free) continue;
+          took[row] = 1;
+          w[row].prepared = true;
+          alive.push_back(row);
+          if (row != j) alt_acc.push_back(row);
+        }
+      } else {
+        // (rows in the order of their slots, a slot's repaired row after its speculated one)
+        for (int j = 0; j < B; ++j) {
+          if (!w[j].pose_hit && w[j].par_free) { alive.push_back(j); w[j].prepared = true; }
+          const int a = w[j].alt_row;
+          if (a >= 0 && !w[a].pose_hit && w[a].par_free) { alive.push_back(a); w[a].prepared = true; }
+        }
       }
       nA = (int)alive.size();
       if (kmax > 0)
@@ -711,6 +744,7 @@ int Rrt::run_wave(int B) {
     }
     if (conflict) break;
     WCand& cd = w[row];
+    if (have_mates && !cd.prepared && !cd.pose_hit && cd.par_free) { ++g_rrt_alt[2]; break; }   // (the dry walk stopped before it)
     ++done;
     ++iter;
     const unsigned iteration = (unsigned)iter;
