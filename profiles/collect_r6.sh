@@ -14,6 +14,7 @@ SFFGPU_SPEC_PIPE=0 PROBE_ITERS=8000,100000 timeout 300 python3 profiles/spec_pro
 bash profiles/r6_force_dist.sh > /dev/null 2>&1
 timeout 400 python3 bench.py --gpus 1 --steps 20 --warmup 5 --force-dist --scaled-wave 65536 --cpu-iters 0 --no-sweep-micro --no-wave-sweep --no-extra-legs 2>/dev/null | tail -1 > $out/r6_wave_scaled_line.json
 for m in star rrt multi; do SFFGPU_PROFILE=1 timeout 300 python3 profiles/rrt_probe.py 150000 $m 2>&1 | grep -E "run_wave|iterations_per_s" | tail -2; done > $out/r6_rrt_probe.txt
+bash profiles/r6_rrt_repair.sh; bash profiles/r6_rrt_dry.sh
 for m in star rrt multi; do SFFGPU_RRT_CHAIN=0 timeout 300 python3 profiles/rrt_probe.py 150000 $m 2>/dev/null | tail -1; done > $out/r6_rrt_probe_no_chain.jsonl
 timeout 300 python3 profiles/c5_probe.py 2>/dev/null | tail -1 > $out/r6_c5_probe.json
 cd /tmp && export TMPDIR=/tmp
