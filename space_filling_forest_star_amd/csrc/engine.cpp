@@ -233,10 +233,10 @@ Ctx::~Ctx() {
   for (auto e : pool) (void)hipEventDestroy(e);
   DevBuf* bufs[] = {&env_tri, &env_box, &env_plane, &rob_tri, &sx, &sy, &sz, &syaw, &spitch, &sroll, &stree, &spos,
                     &d_a, &d_b, &d_c, &d_d, &d_e, &d_f, &d_g, &d_h, &r_in, &r_out, &r_out2, &r_q, &r_cnt, &r_hidx,
-                    &r_hdist, &r_sega, &r_segb, &r_items, &r_items2, &r_center, &r_qrec, &env_clear, &env_clear_edge, &env_cand, &g_cnt, &g_items, &g_ovfcnt, &g_ovf, &t_cnt, &t_items, &t_ovfcnt, &t_ovf, &t_occ, &g_lite, &g_ovf_lite, &t_lite, &t_ovf_lite, &env_tg_start, &env_tg_list, &r_sub, &env_ext, &rr_q1, &rr_q2, &rr_a, &rr_out, &rr_sq, &rr_np, &rr_alt};
+                    &r_hdist, &r_sega, &r_segb, &r_items, &r_items2, &r_center, &r_qrec, &env_clear, &env_clear_edge, &env_cand, &g_cnt, &g_items, &g_ovfcnt, &g_ovf, &t_cnt, &t_items, &t_ovfcnt, &t_ovf, &t_occ, &g_lite, &g_ovf_lite, &t_lite, &t_ovf_lite, &env_tg_start, &env_tg_list, &r_sub, &env_ext, &rr_q1, &rr_q2, &rr_a, &rr_out, &rr_out2, &rr_sq, &rr_np, &rr_alt};
   for (DevBuf* b : bufs) b->release();
   for (auto& b : level_box) b.release();
-  PinBuf* pins[] = {&h_a, &h_b, &h_c, &h_d, &h_e, &h_f, &h_g, &h_h, &p_in, &p_out, &rr_hq, &rr_hout};
+  PinBuf* pins[] = {&h_a, &h_b, &h_c, &h_d, &h_e, &h_f, &h_g, &h_h, &p_in, &p_out, &rr_hq, &rr_hout, &rr_hout2};
   for (PinBuf* b : pins) b->release();
   if (copy_stream) (void)hipStreamDestroy(copy_stream);
   if (own_stream) (void)hipStreamDestroy(own_stream);
@@ -929,113 +929,107 @@ void Ctx::collide_segments_core(const double* a6, const double* b6, const int32_
   }
 }
 
-// RRT session (csrc/rrt.cpp): the GPU half of one speculative wave as enqueued chains with ONE wait each.
-// rrt_chain: the two nearest nodes of every steering target -> the steered new point -> (rrt_rows) its pose, its parent edge,
-// its k nearest nodes, the other trees' nodes around it -> which earlier new point of the wave would be nearer than the nearest
-// node (k_rrt_mates).  rrt_chain_alt: the same rows for the REPAIRED slots - steered from that earlier new point instead.
+// RRT session (csrc/rrt.cpp): the GPU half of one speculative wave as ONE enqueued chain and one wait.
+// rrt_chain: the two nearest nodes of every steering target -> the steered new point -> per row (rr_enqueue) its pose, its
+// parent edge, its k nearest nodes, the other trees' nodes around it -> which earlier new point of the wave would be nearer
+// than the nearest node (k_rrt_mates) -> the slots that have one, in slot order (k_rrt_alt_list) -> the same rows for those
+// REPAIRED slots, steered from that earlier new point instead (alt_cap rows; the unused ones are degenerate copies of row 0).
+// rrt_chain_alt: the repaired rows as a second chain from a host-built list (SFFGPU_RRT_ONE_CHAIN=0).
 // The new points of both stay in rr_np (rows 0..n-1, then the repaired ones): the wave's later edges name them by row.
-void Ctx::rrt_rows(RrtRows& R, int row0, int n, int kmax, bool by_gridk, double conn_r, int conn_cap, int n_near, int32_t* near_idx,
-                   double* near_d, int32_t* near_cnt, int32_t* mate) {
-  // one result block, 8-byte parts first
-  const size_t km = (size_t)std::max(kmax, 0), kc = conn_r > 0 ? (size_t)conn_cap : 0, K1 = 2;
+namespace {
+struct RrLayout {   // one result block, 8-byte parts first
+  size_t o_np, o_md, o_cd, o_nd, o_sg, o_mi, o_mc, o_ci, o_cc, o_ni, o_nc, o_mt, o_al, o_ht, o_end, km, kc;
+};
+RrLayout rr_layout(int n, int kmax, bool conn, int conn_cap, int n_near, int n_alt_list) {
+  RrLayout L{};
+  const size_t K1 = 2;
+  L.km = (size_t)std::max(kmax, 0);
+  L.kc = conn ? (size_t)conn_cap : 0;
   size_t o = 0;
-  const size_t o_np = o; o += (size_t)n * 48;
-  const size_t o_md = o; o += (size_t)n * km * 8;
-  const size_t o_cd = o; o += (size_t)n * kc * 8;
-  const size_t o_nd = o; o += (size_t)n_near * K1 * 8;
-  const size_t o_sg = o; o += ((size_t)n * 3 + 16) * 4;
-  const size_t o_mi = o; o += (size_t)n * km * 4;
-  const size_t o_mc = o; o += (size_t)n * 4;
-  const size_t o_ci = o; o += (size_t)n * kc * 4;
-  const size_t o_cc = o; o += (kc ? (size_t)n : 0) * 4;
-  const size_t o_ni = o; o += (size_t)n_near * K1 * 4;
-  const size_t o_nc = o; o += (size_t)n_near * 4;
-  const size_t o_mt = o; o += (size_t)n_near * 4;
-  const size_t o_ht = o; o += ((size_t)n + 7) / 8 * 8;
-  const size_t o_end = o;
-  if (R.phase == 0) {   // layout only: the caller's kernels write into the block before the rows' own
-    rr_out.ensure(o_end);
-    rr_hout.ensure(o_end);
-    r_items.ensure((size_t)(8 * n + 65536) * SFFK_ITEM_BYTES);
-    r_items2.ensure(((size_t)(8 * n + 65536) + (1u << 20)) * 8);
-    char* db = rr_out.as<char>();
-    R.np_copy = reinterpret_cast<double*>(db + o_np);
-    R.near_idx = reinterpret_cast<int32_t*>(db + o_ni);
-    R.near_d = reinterpret_cast<double*>(db + o_nd);
-    R.near_cnt = reinterpret_cast<int32_t*>(db + o_nc);
-    R.seg_dev = reinterpret_cast<int32_t*>(db + o_sg);
-    R.conn_cnt_dev = kc ? reinterpret_cast<int32_t*>(db + o_cc) : nullptr;
-    return;
-  }
-  char* db = rr_out.as<char>();
-  double* r_np = rr_np.as<double>() + 6 * (size_t)row0;
-  int32_t* d_ns = reinterpret_cast<int32_t*>(db + o_sg);
-  int32_t* d_fh = d_ns + n;
-  int32_t* d_ov = d_fh + n;
-  int32_t* d_ctrl = d_ov + n;
-  uint8_t* d_hit = reinterpret_cast<uint8_t*>(db + o_ht);
-  // (sample counts, result presets and the zeroed control words: written by k_rrt_steer)
-  const int list_cap = 8 * n + 65536;
-  time_begin(T_COLLIDE);
-  sffk::launch_collide_poses(stream, envv, robv, r_np, n, nullptr, d_hit, false);
-  sffk::launch_collide_segments_dyn(stream, envv, robv, rr_a.as<double>(), r_np, d_ns, n, d_ctrl, r_items.p, list_cap, r_items2.p,
-                                    d_fh, d_ov);
-  time_end();
-  if (mate) sffk::launch_rrt_mates(stream, rr_q1.as<sffk::KnnQuery>(), R.near_d, (int)K1, r_np, d_hit, d_fh, d_ov, n,
-                                   reinterpret_cast<int32_t*>(db + o_mt));
-  if (kmax > 0) {
-    time_begin(T_SWEEP);
-    if (by_gridk && grid_on && store_n >= kmax)
-      sffk::launch_knn_grid(stream, gridv, nullptr, store_view(), rr_q2.as<sffk::KnnQuery>(), n, kmax, reinterpret_cast<int32_t*>(db + o_mi),
-                            reinterpret_cast<double*>(db + o_md), reinterpret_cast<int32_t*>(db + o_mc), nullptr, nullptr, grid_cell,
-                            8 * sweep_eps(), SFFK_KNN_MATES, store_n);
-    else
-      sffk::launch_knn_linear(stream, store_view(), store_n, rr_q2.as<sffk::KnnQuery>(), n, kmax, reinterpret_cast<int32_t*>(db + o_mi),
-                              reinterpret_cast<double*>(db + o_md), reinterpret_cast<int32_t*>(db + o_mc), sweep_eps());
-    time_end();
-  }
-  if (kc) {
-    time_begin(T_SWEEP);
-    sffk::launch_sweep(stream, store_view(), 0, store_n, rr_sq.as<sffk::SweepQuery>(), r_np, n, reinterpret_cast<int32_t*>(db + o_cc),
-                       reinterpret_cast<int32_t*>(db + o_ci), reinterpret_cast<double*>(db + o_cd), conn_cap);
-    time_end();
-  }
-  HIPCHK(hipMemcpyAsync(rr_hout.p, rr_out.p, o_end, hipMemcpyDeviceToHost, stream));
-  sync();
-  rr_np_dev = rr_np.as<double>();
-  const char* hb = rr_hout.as<char>();
-  if (n_near) {
-    memcpy(near_idx, hb + o_ni, (size_t)n_near * K1 * 4);
-    memcpy(near_d, hb + o_nd, (size_t)n_near * K1 * 8);
-    memcpy(near_cnt, hb + o_nc, (size_t)n_near * 4);
-    if (mate) memcpy(mate, hb + o_mt, (size_t)n_near * 4);
-  }
-  memcpy(R.np6, hb + o_np, (size_t)n * 48);
-  memcpy(R.hit, hb + o_ht, (size_t)n);
-  memcpy(R.seg, hb + o_sg, (size_t)n * 12);
-  if (kmax > 0) {
-    memcpy(R.mem_idx, hb + o_mi, (size_t)n * km * 4);
-    memcpy(R.mem_d, hb + o_md, (size_t)n * km * 8);
-    memcpy(R.mem_cnt, hb + o_mc, (size_t)n * 4);
-  }
-  if (kc) {
-    memcpy(R.conn_idx, hb + o_ci, (size_t)n * kc * 4);
-    memcpy(R.conn_d, hb + o_cd, (size_t)n * kc * 8);
-    memcpy(R.conn_cnt, hb + o_cc, (size_t)n * 4);
-  }
+  L.o_np = o; o += (size_t)n * 48;
+  L.o_md = o; o += (size_t)n * L.km * 8;
+  L.o_cd = o; o += (size_t)n * L.kc * 8;
+  L.o_nd = o; o += (size_t)n_near * K1 * 8;
+  L.o_sg = o; o += ((size_t)n * 3 + 16) * 4;
+  L.o_mi = o; o += (size_t)n * L.km * 4;
+  L.o_mc = o; o += (size_t)n * 4;
+  L.o_ci = o; o += (size_t)n * L.kc * 4;
+  L.o_cc = o; o += (L.kc ? (size_t)n : 0) * 4;
+  L.o_ni = o; o += (size_t)n_near * K1 * 4;
+  L.o_nc = o; o += (size_t)n_near * 4;
+  L.o_mt = o; o += (size_t)n_near * 4;
+  L.o_al = o; o += (n_alt_list ? 2 * (size_t)n_alt_list + 2 : 0) * 4;   // slot[cap] | mate[cap] | listed, found
+  L.o_ht = o; o += ((size_t)n + 7) / 8 * 8;
+  L.o_end = o;
+  return L;
 }
-
-static float rrt_conn_r2f(double conn_r, double eps) {   // (the superset radius of Ctx::sweep_lists)
+float rrt_conn_r2f(double conn_r, double eps) {   // (the superset radius of Ctx::sweep_lists)
   const double ri = (conn_r + eps) * (1.0 + 1e-5);
   return (float)(ri * ri) * 1.000001f;
 }
+}  // namespace
+
+// pose, parent edge, k nearest, other trees, (mates) of rows row0 .. row0 + n - 1 of rr_np into the block `db`; k_rrt_steer has
+// written the rows' new points, nearest positions (rr_a), queries (rr_q2 / rr_sq) and the edge presets before
+static void rr_enqueue(Ctx& c, char* db, const RrLayout& L, int row0, int n, int kmax, bool by_gridk, int conn_cap, bool mates) {
+  double* r_np = c.rr_np.as<double>() + 6 * (size_t)row0;
+  int32_t* d_ns = reinterpret_cast<int32_t*>(db + L.o_sg);
+  int32_t* d_fh = d_ns + n;
+  int32_t* d_ov = d_fh + n;
+  int32_t* d_ctrl = d_ov + n;
+  uint8_t* d_hit = reinterpret_cast<uint8_t*>(db + L.o_ht);
+  const int list_cap = 8 * n + 65536;
+  c.time_begin(T_COLLIDE);
+  sffk::launch_collide_poses(c.stream, c.envv, c.robv, r_np, n, nullptr, d_hit, false);
+  sffk::launch_collide_segments_dyn(c.stream, c.envv, c.robv, c.rr_a.as<double>(), r_np, d_ns, n, d_ctrl, c.r_items.p, list_cap, c.r_items2.p,
+                                    d_fh, d_ov);
+  c.time_end();
+  if (mates) sffk::launch_rrt_mates(c.stream, c.rr_q1.as<sffk::KnnQuery>(), reinterpret_cast<double*>(db + L.o_nd), 2, r_np, d_hit, d_fh, d_ov, n,
+                                    reinterpret_cast<int32_t*>(db + L.o_mt));
+  if (kmax > 0) {
+    c.time_begin(T_SWEEP);
+    if (by_gridk && c.grid_on && c.store_n >= kmax)
+      sffk::launch_knn_grid(c.stream, c.gridv, nullptr, c.store_view(), c.rr_q2.as<sffk::KnnQuery>(), n, kmax, reinterpret_cast<int32_t*>(db + L.o_mi),
+                            reinterpret_cast<double*>(db + L.o_md), reinterpret_cast<int32_t*>(db + L.o_mc), nullptr, nullptr, c.grid_cell,
+                            8 * c.sweep_eps(), SFFK_KNN_MATES, c.store_n);
+    else
+      sffk::launch_knn_linear(c.stream, c.store_view(), c.store_n, c.rr_q2.as<sffk::KnnQuery>(), n, kmax, reinterpret_cast<int32_t*>(db + L.o_mi),
+                              reinterpret_cast<double*>(db + L.o_md), reinterpret_cast<int32_t*>(db + L.o_mc), c.sweep_eps());
+    c.time_end();
+  }
+  if (L.kc) {
+    c.time_begin(T_SWEEP);
+    sffk::launch_sweep(c.stream, c.store_view(), 0, c.store_n, c.rr_sq.as<sffk::SweepQuery>(), r_np, n, reinterpret_cast<int32_t*>(db + L.o_cc),
+                       reinterpret_cast<int32_t*>(db + L.o_ci), reinterpret_cast<double*>(db + L.o_cd), conn_cap);
+    c.time_end();
+  }
+}
+
+static void rr_unpack(const char* hb, const RrLayout& L, Ctx::RrtRows& R, int n, int kmax) {
+  memcpy(R.np6, hb + L.o_np, (size_t)n * 48);
+  memcpy(R.hit, hb + L.o_ht, (size_t)n);
+  memcpy(R.seg, hb + L.o_sg, (size_t)n * 12);
+  if (kmax > 0) {
+    memcpy(R.mem_idx, hb + L.o_mi, (size_t)n * L.km * 4);
+    memcpy(R.mem_d, hb + L.o_md, (size_t)n * L.km * 8);
+    memcpy(R.mem_cnt, hb + L.o_mc, (size_t)n * 4);
+  }
+  if (L.kc) {
+    memcpy(R.conn_idx, hb + L.o_ci, (size_t)n * L.kc * 4);
+    memcpy(R.conn_d, hb + L.o_cd, (size_t)n * L.kc * 8);
+    memcpy(R.conn_cnt, hb + L.o_cc, (size_t)n * 4);
+  }
+}
 
 void Ctx::rrt_chain(const double* rnd6, const int32_t* tree, int n, double dist, bool by_grid1, int kmax, bool by_gridk,
-                    int32_t* near_idx, double* near_d, int32_t* near_cnt, int32_t* mate, RrtRows& R, double conn_r, int conn_cap) {
+                    int32_t* near_idx, double* near_d, int32_t* near_cnt, int32_t* mate, RrtRows& R, double conn_r, int conn_cap,
+                    int alt_cap, int32_t* alt_slot, int32_t* alt_mate, int32_t* n_alt, RrtRows* R2) {
   if (n <= 0) return;
   if (!have_env || !have_robot) throw HipError{"rrt_chain: upload ENV and ROBOT meshes first"};
   HIPCHK(hipSetDevice(device));
   const int K1 = 2;
+  if (alt_cap > n) alt_cap = n;
+  if (!mate || !R2) alt_cap = 0;
   rr_hq.ensure((size_t)n * sizeof(sffk::KnnQuery));
   sffk::KnnQuery* hq = rr_hq.as<sffk::KnnQuery>();
   for (int i = 0; i < n; ++i) {
@@ -1048,13 +1042,21 @@ void Ctx::rrt_chain(const double* rnd6, const int32_t* tree, int n, double dist,
     hq[i].pad_ = 0;
   }
   const bool kc = conn_r > 0;
+  const RrLayout L1 = rr_layout(n, kmax, kc, conn_cap, n, alt_cap), L2 = rr_layout(alt_cap, kmax, kc, conn_cap, 0, 0);
   rr_q1.ensure((size_t)n * sizeof(sffk::KnnQuery));
   rr_q2.ensure((size_t)n * sizeof(sffk::KnnQuery));
   rr_a.ensure((size_t)n * 48);
-  rr_np.ensure((size_t)n * 2 * 48);   // (+ the repaired rows of rrt_chain_alt)
+  rr_np.ensure((size_t)n * 2 * 48);   // (+ the repaired rows)
   if (kc) rr_sq.ensure((size_t)n * sizeof(sffk::SweepQuery));
-  R.phase = 0;
-  rrt_rows(R, 0, n, kmax, by_gridk, conn_r, conn_cap, n, nullptr, nullptr, nullptr, nullptr);
+  rr_out.ensure(L1.o_end);
+  rr_hout.ensure(L1.o_end);
+  if (alt_cap) { rr_out2.ensure(L2.o_end); rr_hout2.ensure(L2.o_end); }
+  r_items.ensure((size_t)(8 * n + 65536) * SFFK_ITEM_BYTES);
+  r_items2.ensure(((size_t)(8 * n + 65536) + (1u << 20)) * 8);
+  char* db = rr_out.as<char>();
+  int32_t* r_ni = reinterpret_cast<int32_t*>(db + L1.o_ni);
+  double* r_nd = reinterpret_cast<double*>(db + L1.o_nd);
+  int32_t* r_nc = reinterpret_cast<int32_t*>(db + L1.o_nc);
   HIPCHK(hipMemcpyAsync(rr_q1.p, rr_hq.p, (size_t)n * sizeof(sffk::KnnQuery), hipMemcpyHostToDevice, stream));
   if ((by_grid1 || (kmax > 0 && by_gridk)) && grid_on) {
     grid_insert_new();
@@ -1062,17 +1064,49 @@ void Ctx::rrt_chain(const double* rnd6, const int32_t* tree, int n, double dist,
   }
   time_begin(T_SWEEP);
   if (by_grid1 && grid_on && store_n >= K1)
-    sffk::launch_knn_grid(stream, gridv, nullptr, store_view(), rr_q1.as<sffk::KnnQuery>(), n, K1, R.near_idx, R.near_d, R.near_cnt, nullptr,
-                          nullptr, grid_cell, 8 * sweep_eps(), SFFK_KNN_MATES, store_n);
+    sffk::launch_knn_grid(stream, gridv, nullptr, store_view(), rr_q1.as<sffk::KnnQuery>(), n, K1, r_ni, r_nd, r_nc, nullptr, nullptr, grid_cell,
+                          8 * sweep_eps(), SFFK_KNN_MATES, store_n);
   else
-    sffk::launch_knn_linear(stream, store_view(), store_n, rr_q1.as<sffk::KnnQuery>(), n, K1, R.near_idx, R.near_d, R.near_cnt, sweep_eps());
+    sffk::launch_knn_linear(stream, store_view(), store_n, rr_q1.as<sffk::KnnQuery>(), n, K1, r_ni, r_nd, r_nc, sweep_eps());
   time_end();
-  sffk::launch_rrt_steer(stream, rr_q1.as<sffk::KnnQuery>(), R.near_idx, K1, spos.as<double>(), dist, rr_a.as<double>(), rr_np.as<double>(),
-                         kmax > 0 ? rr_q2.as<sffk::KnnQuery>() : nullptr, kmax, n, kc ? rr_sq.as<sffk::SweepQuery>() : nullptr, conn_r,
-                         kc ? rrt_conn_r2f(conn_r, sweep_eps()) : 0.f, R.np_copy, R.seg_dev, R.conn_cnt_dev);
-  R.phase = 1;
-  rrt_rows(R, 0, n, kmax, by_gridk, conn_r, conn_cap, n, near_idx, near_d, near_cnt, mate);
+  const float r2f = kc ? rrt_conn_r2f(conn_r, sweep_eps()) : 0.f;
+  sffk::launch_rrt_steer(stream, rr_q1.as<sffk::KnnQuery>(), r_ni, K1, spos.as<double>(), dist, rr_a.as<double>(), rr_np.as<double>(),
+                         kmax > 0 ? rr_q2.as<sffk::KnnQuery>() : nullptr, kmax, n, kc ? rr_sq.as<sffk::SweepQuery>() : nullptr, conn_r, r2f,
+                         reinterpret_cast<double*>(db + L1.o_np), reinterpret_cast<int32_t*>(db + L1.o_sg),
+                         kc ? reinterpret_cast<int32_t*>(db + L1.o_cc) : nullptr);
+  rr_enqueue(*this, db, L1, 0, n, kmax, by_gridk, conn_cap, mate != nullptr);
+  if (alt_cap) {
+    // the repaired rows behind them, without a word from the host: the list of the slots that have a mate, the rows steered
+    // from it (rr_a, rr_q2, rr_sq are free again: the stream keeps the order)
+    char* db2 = rr_out2.as<char>();
+    int32_t* d_al = reinterpret_cast<int32_t*>(db + L1.o_al);
+    sffk::launch_rrt_alt_list(stream, reinterpret_cast<int32_t*>(db + L1.o_mt), n, alt_cap, d_al, d_al + alt_cap, d_al + 2 * alt_cap);
+    sffk::launch_rrt_steer(stream, rr_q1.as<sffk::KnnQuery>(), nullptr, 0, spos.as<double>(), dist, rr_a.as<double>(), rr_np.as<double>(),
+                           kmax > 0 ? rr_q2.as<sffk::KnnQuery>() : nullptr, kmax, alt_cap, kc ? rr_sq.as<sffk::SweepQuery>() : nullptr, conn_r, r2f,
+                           reinterpret_cast<double*>(db2 + L2.o_np), reinterpret_cast<int32_t*>(db2 + L2.o_sg),
+                           kc ? reinterpret_cast<int32_t*>(db2 + L2.o_cc) : nullptr, d_al, d_al + alt_cap, n);
+    rr_enqueue(*this, db2, L2, n, alt_cap, kmax, by_gridk, conn_cap, false);
+    HIPCHK(hipMemcpyAsync(rr_hout2.p, rr_out2.p, L2.o_end, hipMemcpyDeviceToHost, stream));
+  }
+  HIPCHK(hipMemcpyAsync(rr_hout.p, rr_out.p, L1.o_end, hipMemcpyDeviceToHost, stream));
+  sync();
+  rr_np_dev = rr_np.as<double>();
   rr_rows0 = n;
+  const char* hb = rr_hout.as<char>();
+  memcpy(near_idx, hb + L1.o_ni, (size_t)n * K1 * 4);
+  memcpy(near_d, hb + L1.o_nd, (size_t)n * K1 * 8);
+  memcpy(near_cnt, hb + L1.o_nc, (size_t)n * 4);
+  if (mate) memcpy(mate, hb + L1.o_mt, (size_t)n * 4);
+  rr_unpack(hb, L1, R, n, kmax);
+  if (n_alt) *n_alt = 0;
+  if (alt_cap) {
+    const int32_t* al = reinterpret_cast<const int32_t*>(hb + L1.o_al);
+    const int listed = al[2 * (size_t)alt_cap];
+    memcpy(alt_slot, al, (size_t)listed * 4);
+    memcpy(alt_mate, al + alt_cap, (size_t)listed * 4);
+    *n_alt = listed;
+    rr_unpack(rr_hout2.as<char>(), L2, *R2, alt_cap, kmax);   // (all alt_cap rows: the caller's arrays have that many, seg's three columns that stride)
+  }
 }
 
 void Ctx::rrt_chain_alt(const int32_t* slot, const int32_t* mate, int n_alt, double dist, int kmax, bool by_gridk, RrtRows& R,
@@ -1081,19 +1115,26 @@ void Ctx::rrt_chain_alt(const int32_t* slot, const int32_t* mate, int n_alt, dou
   if (!rr_np_dev || n_alt > rr_rows0) throw HipError{"rrt_chain_alt: no rrt_chain has run (or more repaired slots than slots)"};
   HIPCHK(hipSetDevice(device));
   const bool kc = conn_r > 0;
+  const RrLayout L = rr_layout(n_alt, kmax, kc, conn_cap, 0, 0);
   rr_hq.ensure((size_t)n_alt * 8);
   memcpy(rr_hq.as<int32_t>(), slot, (size_t)n_alt * 4);
   memcpy(rr_hq.as<int32_t>() + n_alt, mate, (size_t)n_alt * 4);
   rr_alt.ensure((size_t)n_alt * 8);
+  rr_out.ensure(L.o_end);
+  rr_hout.ensure(L.o_end);
+  r_items.ensure((size_t)(8 * n_alt + 65536) * SFFK_ITEM_BYTES);
+  r_items2.ensure(((size_t)(8 * n_alt + 65536) + (1u << 20)) * 8);
+  char* db = rr_out.as<char>();
   HIPCHK(hipMemcpyAsync(rr_alt.p, rr_hq.p, (size_t)n_alt * 8, hipMemcpyHostToDevice, stream));
-  R.phase = 0;
-  rrt_rows(R, rr_rows0, n_alt, kmax, by_gridk, conn_r, conn_cap, 0, nullptr, nullptr, nullptr, nullptr);
   sffk::launch_rrt_steer(stream, rr_q1.as<sffk::KnnQuery>(), nullptr, 0, spos.as<double>(), dist, rr_a.as<double>(), rr_np.as<double>(),
                          kmax > 0 ? rr_q2.as<sffk::KnnQuery>() : nullptr, kmax, n_alt, kc ? rr_sq.as<sffk::SweepQuery>() : nullptr, conn_r,
-                         kc ? rrt_conn_r2f(conn_r, sweep_eps()) : 0.f, R.np_copy, R.seg_dev, R.conn_cnt_dev, rr_alt.as<int32_t>(),
+                         kc ? rrt_conn_r2f(conn_r, sweep_eps()) : 0.f, reinterpret_cast<double*>(db + L.o_np),
+                         reinterpret_cast<int32_t*>(db + L.o_sg), kc ? reinterpret_cast<int32_t*>(db + L.o_cc) : nullptr, rr_alt.as<int32_t>(),
                          rr_alt.as<int32_t>() + n_alt, rr_rows0);
-  R.phase = 1;
-  rrt_rows(R, rr_rows0, n_alt, kmax, by_gridk, conn_r, conn_cap, 0, nullptr, nullptr, nullptr, nullptr);
+  rr_enqueue(*this, db, L, rr_rows0, n_alt, kmax, by_gridk, conn_cap, false);
+  HIPCHK(hipMemcpyAsync(rr_hout.p, rr_out.p, L.o_end, hipMemcpyDeviceToHost, stream));
+  sync();
+  rr_unpack(rr_hout.as<char>(), L, R, n_alt, kmax);
 }
 
 void Ctx::sample_steer(const uint64_t* words, const double* center6, int n, double dist, int dim, const double* limits,

@@ -210,18 +210,17 @@ struct Ctx {
   struct RrtRows {
     double* np6; uint8_t* hit; int32_t* seg; int32_t* mem_idx; double* mem_d; int32_t* mem_cnt;   // host, caller-owned
     int32_t* conn_idx; double* conn_d; int32_t* conn_cnt;
-    int32_t* seg_dev = nullptr; int32_t* conn_cnt_dev = nullptr;
-    int phase = 0; double* np_copy = nullptr; int32_t* near_idx = nullptr; double* near_d = nullptr; int32_t* near_cnt = nullptr;   // (device, internal)
   };
+  // alt_cap > 0 (with mate and R2): the repaired rows ride the same chain - alt_slot / alt_mate / n_alt: the slots that have a mate,
+  // in slot order, at most alt_cap of them (the others are the caller's to cut at); R2: their rows (arrays of alt_cap rows)
   void rrt_chain(const double* rnd6, const int32_t* tree, int n, double dist, bool by_grid1, int kmax, bool by_gridk,
-                 int32_t* near_idx, double* near_d, int32_t* near_cnt, int32_t* mate, RrtRows& R, double conn_r = 0, int conn_cap = 0);
+                 int32_t* near_idx, double* near_d, int32_t* near_cnt, int32_t* mate, RrtRows& R, double conn_r = 0, int conn_cap = 0,
+                 int alt_cap = 0, int32_t* alt_slot = nullptr, int32_t* alt_mate = nullptr, int32_t* n_alt = nullptr, RrtRows* R2 = nullptr);
   void rrt_chain_alt(const int32_t* slot, const int32_t* mate, int n_alt, double dist, int kmax, bool by_gridk, RrtRows& R,
                      double conn_r = 0, int conn_cap = 0);
-  void rrt_rows(RrtRows& R, int row0, int n, int kmax, bool by_gridk, double conn_r, int conn_cap, int n_near, int32_t* near_idx,
-                double* near_d, int32_t* near_cnt, int32_t* mate);
   int rr_rows0 = 0;   // slots of the last rrt_chain
-  DevBuf rr_q1, rr_q2, rr_a, rr_out, rr_sq, rr_np, rr_alt;
-  PinBuf rr_hq, rr_hout;
+  DevBuf rr_q1, rr_q2, rr_a, rr_out, rr_out2, rr_sq, rr_np, rr_alt;
+  PinBuf rr_hq, rr_hout, rr_hout2;
   double sweep_eps() const;
   // one sweep launch over the first n_store entries; per-query hit lists sorted by (dist, id)
   void sweep_lists(const double* q6, int nq, const std::vector<double>& r, const int32_t* tree, const int32_t* max_id,
@@ -537,6 +536,7 @@ struct Rrt {
   void knn(const double* q, int nq, const int32_t* tree, int k, std::vector<std::vector<int>>& out);
   bool knn_by_grid(const int32_t* tree, int nq, int k) const;
   bool chain_on = true;   // SFFGPU_RRT_CHAIN (read when the session is created): nearest -> steer -> pose -> parent edge -> k nearest as one chain
+  bool one_chain = true;  // SFFGPU_RRT_ONE_CHAIN: the repaired rows inside the wave's one chain (the device lists them) instead of a second chain
   bool dry_on = true;     // SFFGPU_RRT_DRY: the replay's nearest-node walk done once ahead, so that only the rows it takes get edges
   bool repair_on = true;  // SFFGPU_RRT_REPAIR: slots whose nearest node would be an earlier new point of the wave are evaluated from it too
   int small_mul = 4, small_cap = 48;   // SFFGPU_RRT_SMALL (cap): ... or small_mul x that, up to small_cap slots

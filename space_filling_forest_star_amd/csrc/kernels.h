@@ -333,6 +333,7 @@ void launch_rrt_steer(hipStream_t s, const KnnQuery* q1, const int32_t* idx1, in
 // (seg_ns: 3 n + 16 words - the parent edges' sample counts, result presets and the edge kernels' control words, zeroed here;
 // conn_cnt: n hit counters of the other-trees query, zeroed here)
 // (sq: the other-trees radius query of every new point; alt_slot / alt_mate: the rows are repaired slots, written from row0 on)
+void launch_rrt_alt_list(hipStream_t s, const int32_t* mate, int n, int cap, int32_t* alt_slot, int32_t* alt_mate, int32_t* cnt);
 void launch_rrt_mates(hipStream_t s, const KnnQuery* q1, const double* near_d, int k1, const double* np6, const uint8_t* hit,
                       const int32_t* fh, const int32_t* ov, int n, int32_t* mate);
 void launch_knn_grid(hipStream_t s, const GridView& g, const GridView* tg, const NodeStoreView& st, const KnnQuery* q, int nq,

@@ -5989,17 +5989,20 @@ __global__ __launch_bounds__(256) void k_rrt_steer(const KnnQuery* __restrict__ 
   if (i >= n) return;
   // alt_slot != null: row i is the REPAIRED version of slot alt_slot[i] - the wave's new point alt_mate[i] (a row of np6)
   // would be its nearest node if it becomes a node - and is written as row row0 + i of np6
-  const int slot = alt_slot ? alt_slot[i] : i;
+  // (alt_slot[i] < 0: an unused row of a list built on the device - a degenerate copy of row 0, nothing to check)
+  const bool dummy = alt_slot && alt_slot[i] < 0;
+  const int slot = alt_slot && !dummy ? alt_slot[i] : (dummy ? 0 : i);
   double a[6], t[6], o[6];
   if (alt_slot) {
-    const int m = alt_mate[i];
+    const int m = dummy ? 0 : alt_mate[i];
     for (int k = 0; k < 6; ++k) a[k] = np6[6 * (size_t)m + k];
   } else {
     const int near = idx1[(size_t)i * k1];
     for (int k = 0; k < 6; ++k) a[k] = store_pos[6 * (size_t)near + k];
   }
   for (int k = 0; k < 6; ++k) t[k] = q1[slot].pos[k];
-  steer(a, t, dist, o);
+  if (dummy) { for (int k = 0; k < 6; ++k) o[k] = a[k]; }
+  else steer(a, t, dist, o);
   for (int k = 0; k < 6; ++k) { a6[6 * (size_t)i + k] = a[k]; np6[6 * (size_t)(row0 + i) + k] = o[k]; np_copy[6 * (size_t)i + k] = o[k]; }
   // the parent edge's sample count and result presets (k_seg_prepare) and the edge kernels' control words (seg_ns: n sample
   // counts | n first hits | n overflow marks | 16 control words), so that the chain needs no launch of its own for them
@@ -6063,6 +6066,37 @@ __global__ __launch_bounds__(256) void k_rrt_mates(const KnnQuery* __restrict__ 
     if (ob < best || (ob == best && oi < bi)) { best = ob; bi = oi; }
   }
   if (lane == 0) mate[j] = bi == 0x7fffffff ? -1 : bi;
+}
+// the slots that have a mate, in slot order: alt_slot / alt_mate (cap entries, the unused ones -1 / 0), cnt[0] = listed (<= cap),
+// cnt[1] = found.  One workgroup (a wave holds at most 4 096 slots): per-thread counts, block prefix sum.
+__global__ __launch_bounds__(1024) void k_rrt_alt_list(const int32_t* __restrict__ mate, int n, int cap, int32_t* __restrict__ alt_slot,
+                                                       int32_t* __restrict__ alt_mate, int32_t* __restrict__ cnt) {
+  __shared__ int s_sum[1024];
+  const int t = threadIdx.x;
+  const int per = (n + 1023) / 1024;
+  const int j0 = t * per, j1 = j0 + per < n ? j0 + per : n;
+  int own = 0;
+  for (int j = j0; j < j1; ++j) own += mate[j] >= 0 ? 1 : 0;
+  s_sum[t] = own;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    const int v = t >= off ? s_sum[t - off] : 0;
+    __syncthreads();
+    s_sum[t] += v;
+    __syncthreads();
+  }
+  const int total = s_sum[1023];
+  int at = s_sum[t] - own;
+  for (int j = j0; j < j1; ++j)
+    if (mate[j] >= 0) {
+      if (at < cap) { alt_slot[at] = j; alt_mate[at] = mate[j]; }
+      ++at;
+    }
+  for (int r = total + t; r < cap; r += 1024) { alt_slot[r] = -1; alt_mate[r] = 0; }
+  if (t == 0) { cnt[0] = total < cap ? total : cap; cnt[1] = total; }
+}
+void launch_rrt_alt_list(hipStream_t s, const int32_t* mate, int n, int cap, int32_t* alt_slot, int32_t* alt_mate, int32_t* cnt) {
+  hipLaunchKernelGGL(k_rrt_alt_list, dim3(1), dim3(1024), 0, s, mate, n, cap, alt_slot, alt_mate, cnt);
 }
 void launch_rrt_mates(hipStream_t s, const KnnQuery* q1, const double* near_d, int k1, const double* np6, const uint8_t* hit,
                       const int32_t* fh, const int32_t* ov, int n, int32_t* mate) {

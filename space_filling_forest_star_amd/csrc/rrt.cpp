@@ -24,6 +24,7 @@ Rrt::Rrt(Ctx* c, const sffgpu_rrt_cfg& cf, const double* roots6, int n_roots) : 
   if (const char* e = getenv("SFFGPU_RRT_CHAIN")) chain_on = atoi(e) != 0;
   if (const char* e = getenv("SFFGPU_RRT_REPAIR")) repair_on = atoi(e) != 0;
   if (const char* e = getenv("SFFGPU_RRT_DRY")) dry_on = atoi(e) != 0;
+  if (const char* e = getenv("SFFGPU_RRT_ONE_CHAIN")) one_chain = atoi(e) != 0;
   if (const char* e = getenv("SFFGPU_RRT_SMALL")) { small_cap = std::max(1, atoi(e)); }
   if (const char* e = getenv("SFFGPU_RRT_GROW")) grow_pct = std::max(100, atoi(e));
   if (cfg.dim != 2 && cfg.dim != 6) throw HipError{"rrt: dim must be 2 or 6"};
@@ -376,8 +377,18 @@ int Rrt::run_wave(int B) {
     const bool by_gridk = kmax > 0 && knn_by_grid(tq.data(), B, kmax);
     const double conn_r = conn_q ? cfg.dist_tree : 0.0;
     Ctx::RrtRows R1{np.data(), hit.data(), seg.data(), mi.data(), md.data(), mc.data(), conn_i.data(), conn_dd.data(), conn_c.data()};
+    // (the repaired rows ride the same chain: the device lists the slots that have a mate - at most alt_cap of them, a slot
+    // beyond that ends the wave if it is reached - and evaluates them behind the others)
+    const int alt_cap = one_chain && repair_on ? std::min(B, B / 4 + 32) : 0;
+    const int acap = std::max(alt_cap, 1);
+    std::vector<double> np2((size_t)acap * 6), md2((size_t)acap * km), cd2;
+    std::vector<int32_t> seg2((size_t)acap * 3), mi2((size_t)acap * km), mc2(acap), ci2, cc2, d_slot(acap), d_mate(acap);
+    std::vector<uint8_t> hit2(acap);
+    if (conn_q) { ci2.resize((size_t)acap * conn_cap); cd2.resize((size_t)acap * conn_cap); cc2.resize(acap); }
+    Ctx::RrtRows R2{np2.data(), hit2.data(), seg2.data(), mi2.data(), md2.data(), mc2.data(), ci2.data(), cd2.data(), cc2.data()};
+    int32_t n_listed = 0;
     c.rrt_chain(q.data(), tq.data(), B, cfg.sampling_dist, knn_by_grid(tq.data(), B, 1), kmax, by_gridk, ni.data(), nd.data(), nc.data(),
-                mate.data(), R1, conn_r, conn_cap);
+                mate.data(), R1, conn_r, conn_cap, alt_cap, d_slot.data(), d_mate.data(), &n_listed, &R2);
     conn_have = conn_q;
     // (the nearest node is the first by (distance, position in its tree); the device orders by (distance, id): two nodes at
     // exactly the same distance - or a query nobody answered - send the wave through the separate calls below)
@@ -428,23 +439,43 @@ int Rrt::run_wave(int B) {
       // ---- the repaired slots: a slot whose nearest node would be an earlier new point of the wave is evaluated a second
       // time from that point (Ctx::rrt_chain_alt) - the replay takes that row when the earlier slot is accepted as speculated
       have_mates = true;
+      // rows behind the wave's slots, one per listed (slot, mate); a mate the device took for alive and that is not (its
+      // edge's candidate list had run over) leaves its row unused and the slot uncovered
       std::vector<int32_t> a_slot, a_mate;
-      for (int j = 0; j < B; ++j) {
-        const int i = mate[j];
-        if (i < 0) continue;
-        if (!repair_on || w[i].pose_hit || !w[i].par_free) { w[j].cut_here = true; continue; }   // (what the device took for alive is not)
-        a_slot.push_back(j);
-        a_mate.push_back(i);
+      std::vector<uint8_t> a_use;
+      int seg_rows = 0;
+      if (alt_cap > 0) {
+        std::vector<uint8_t> listed(B, 0);
+        for (int r = 0; r < n_listed; ++r) {
+          const int js = d_slot[r], i = d_mate[r];
+          if (js < 0 || js >= B || i != mate[js]) throw HipError{"rrt: repaired-slot list out of step (internal error)"};
+          listed[js] = 1;
+          const bool use = !w[i].pose_hit && w[i].par_free;
+          if (!use) w[js].cut_here = true;
+          a_slot.push_back(js); a_mate.push_back(i); a_use.push_back(use ? 1 : 0);
+        }
+        for (int js = 0; js < B; ++js)
+          if (mate[js] >= 0 && !listed[js]) w[js].cut_here = true;      // (more slots with a mate than rows)
+        seg_rows = alt_cap;
+      } else {
+        for (int js = 0; js < B; ++js) {
+          const int i = mate[js];
+          if (i < 0) continue;
+          if (!repair_on || w[i].pose_hit || !w[i].par_free) { w[js].cut_here = true; continue; }   // (what the device took for alive is not)
+          a_slot.push_back(js); a_mate.push_back(i); a_use.push_back(1);
+        }
+        seg_rows = (int)a_slot.size();
       }
       const int nalt = (int)a_slot.size();
       g_rrt_alt[0] += (unsigned long long)nalt;
       if (nalt > 0) {
-        std::vector<double> np2((size_t)nalt * 6), md2((size_t)nalt * km), cd2;
-        std::vector<int32_t> seg2((size_t)nalt * 3), mi2((size_t)nalt * km), mc2(nalt), ci2, cc2;
-        std::vector<uint8_t> hit2(nalt);
-        if (conn_q) { ci2.resize((size_t)nalt * conn_cap); cd2.resize((size_t)nalt * conn_cap); cc2.resize(nalt); }
-        Ctx::RrtRows R2{np2.data(), hit2.data(), seg2.data(), mi2.data(), md2.data(), mc2.data(), ci2.data(), cd2.data(), cc2.data()};
-        c.rrt_chain_alt(a_slot.data(), a_mate.data(), nalt, cfg.sampling_dist, kmax, by_gridk, R2, conn_r, conn_cap);
+        if (alt_cap == 0) {   // (the second chain, from the host's list)
+          np2.resize((size_t)nalt * 6); md2.resize((size_t)nalt * km); seg2.resize((size_t)nalt * 3); mi2.resize((size_t)nalt * km); mc2.resize(nalt);
+          hit2.resize(nalt);
+          if (conn_q) { ci2.resize((size_t)nalt * conn_cap); cd2.resize((size_t)nalt * conn_cap); cc2.resize(nalt); }
+          Ctx::RrtRows R3{np2.data(), hit2.data(), seg2.data(), mi2.data(), md2.data(), mc2.data(), ci2.data(), cd2.data(), cc2.data()};
+          c.rrt_chain_alt(a_slot.data(), a_mate.data(), nalt, cfg.sampling_dist, kmax, by_gridk, R3, conn_r, conn_cap);
+        }
         w.resize((size_t)B + nalt);
         for (int r = 0; r < nalt; ++r) {
           WCand& cd = w[(size_t)B + r];
@@ -455,8 +486,9 @@ int Rrt::run_wave(int B) {
           cd.slot = a_slot[r];
           cd.near_row = a_mate[r];
           cd.nearest = -1;                                   // (the node row near_row becomes: known in the replay)
+          if (!a_use[r]) { cd.pose_hit = true; cd.d_near = 0; memcpy(cd.np, sl.np, 48); continue; }   // (nobody takes this row)
           cd.d_near = dist6(cd.rnd, w[a_mate[r]].np);
-          fill_row(cd, w[a_mate[r]].np, np2.data(), hit2[r], seg2.data(), nalt, r);
+          fill_row(cd, w[a_mate[r]].np, np2.data(), hit2[r], seg2.data(), seg_rows, r);
           w[a_slot[r]].alt_row = B + r;
           if (kmax > 0 && !cd.pose_hit && cd.par_free) fill_members(cd, mi2.data(), md2.data(), mc2.data(), r);
         }
