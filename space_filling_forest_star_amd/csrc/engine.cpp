@@ -233,10 +233,10 @@ Ctx::~Ctx() {
   for (auto e : pool) (void)hipEventDestroy(e);
   DevBuf* bufs[] = {&env_tri, &env_box, &env_plane, &rob_tri, &sx, &sy, &sz, &syaw, &spitch, &sroll, &stree, &spos,
                     &d_a, &d_b, &d_c, &d_d, &d_e, &d_f, &d_g, &d_h, &r_in, &r_out, &r_out2, &r_q, &r_cnt, &r_hidx,
-                    &r_hdist, &r_sega, &r_segb, &r_items, &r_items2, &r_center, &r_qrec, &env_clear, &env_clear_edge, &env_cand, &g_cnt, &g_items, &g_ovfcnt, &g_ovf, &t_cnt, &t_items, &t_ovfcnt, &t_ovf, &t_occ, &g_lite, &g_ovf_lite, &t_lite, &t_ovf_lite, &env_tg_start, &env_tg_list, &r_sub, &env_ext, &rr_q1, &rr_q2, &rr_a, &rr_out, &rr_out2, &rr_sq, &rr_np, &rr_alt};
+                    &r_hdist, &r_sega, &r_segb, &r_items, &r_items2, &r_center, &r_qrec, &env_clear, &env_clear_edge, &env_cand, &g_cnt, &g_items, &g_ovfcnt, &g_ovf, &t_cnt, &t_items, &t_ovfcnt, &t_ovf, &t_occ, &g_lite, &g_ovf_lite, &t_lite, &t_ovf_lite, &env_tg_start, &env_tg_list, &r_sub, &env_ext, &rr_q1, &rr_q2, &rr_a, &rr_out, &rr_sq, &rr_np, &rr_alt};
   for (DevBuf* b : bufs) b->release();
   for (auto& b : level_box) b.release();
-  PinBuf* pins[] = {&h_a, &h_b, &h_c, &h_d, &h_e, &h_f, &h_g, &h_h, &p_in, &p_out, &rr_hq, &rr_hout, &rr_hout2};
+  PinBuf* pins[] = {&h_a, &h_b, &h_c, &h_d, &h_e, &h_f, &h_g, &h_h, &p_in, &p_out, &rr_hq, &rr_hout};
   for (PinBuf* b : pins) b->release();
   if (copy_stream) (void)hipStreamDestroy(copy_stream);
   if (own_stream) (void)hipStreamDestroy(own_stream);
@@ -980,9 +980,9 @@ static void rr_enqueue(Ctx& c, char* db, const RrLayout& L, int row0, int n, int
   uint8_t* d_hit = reinterpret_cast<uint8_t*>(db + L.o_ht);
   const int list_cap = 8 * n + 65536;
   c.time_begin(T_COLLIDE);
-  sffk::launch_collide_poses(c.stream, c.envv, c.robv, r_np, n, nullptr, d_hit, false);
-  sffk::launch_collide_segments_dyn(c.stream, c.envv, c.robv, c.rr_a.as<double>(), r_np, d_ns, n, d_ctrl, c.r_items.p, list_cap, c.r_items2.p,
-                                    d_fh, d_ov);
+  // (the poses ride the edge kernels: the cull pass marks the ones that need the exact test, the exact kernel takes them first)
+  sffk::launch_round_collide(c.stream, c.envv, c.robv, r_np, n, nullptr, d_hit, c.rr_a.as<double>(), r_np, d_ns, n, d_ctrl, c.r_items.p, list_cap,
+                             c.r_items2.p, d_fh, d_ov, nullptr);
   c.time_end();
   if (mates) sffk::launch_rrt_mates(c.stream, c.rr_q1.as<sffk::KnnQuery>(), reinterpret_cast<double*>(db + L.o_nd), 2, r_np, d_hit, d_fh, d_ov, n,
                                     reinterpret_cast<int32_t*>(db + L.o_mt));
@@ -1048,9 +1048,9 @@ void Ctx::rrt_chain(const double* rnd6, const int32_t* tree, int n, double dist,
   rr_a.ensure((size_t)n * 48);
   rr_np.ensure((size_t)n * 2 * 48);   // (+ the repaired rows)
   if (kc) rr_sq.ensure((size_t)n * sizeof(sffk::SweepQuery));
-  rr_out.ensure(L1.o_end);
-  rr_hout.ensure(L1.o_end);
-  if (alt_cap) { rr_out2.ensure(L2.o_end); rr_hout2.ensure(L2.o_end); }
+  const size_t o_b2 = (L1.o_end + 63) / 64 * 64;   // (the repaired rows' block behind the slots': one copy back)
+  rr_out.ensure(o_b2 + (alt_cap ? L2.o_end : 0));
+  rr_hout.ensure(o_b2 + (alt_cap ? L2.o_end : 0));
   r_items.ensure((size_t)(8 * n + 65536) * SFFK_ITEM_BYTES);
   r_items2.ensure(((size_t)(8 * n + 65536) + (1u << 20)) * 8);
   char* db = rr_out.as<char>();
@@ -1078,7 +1078,7 @@ void Ctx::rrt_chain(const double* rnd6, const int32_t* tree, int n, double dist,
   if (alt_cap) {
     // the repaired rows behind them, without a word from the host: the list of the slots that have a mate, the rows steered
     // from it (rr_a, rr_q2, rr_sq are free again: the stream keeps the order)
-    char* db2 = rr_out2.as<char>();
+    char* db2 = db + o_b2;
     int32_t* d_al = reinterpret_cast<int32_t*>(db + L1.o_al);
     sffk::launch_rrt_alt_list(stream, reinterpret_cast<int32_t*>(db + L1.o_mt), n, alt_cap, d_al, d_al + alt_cap, d_al + 2 * alt_cap);
     sffk::launch_rrt_steer(stream, rr_q1.as<sffk::KnnQuery>(), nullptr, 0, spos.as<double>(), dist, rr_a.as<double>(), rr_np.as<double>(),
@@ -1086,9 +1086,8 @@ void Ctx::rrt_chain(const double* rnd6, const int32_t* tree, int n, double dist,
                            reinterpret_cast<double*>(db2 + L2.o_np), reinterpret_cast<int32_t*>(db2 + L2.o_sg),
                            kc ? reinterpret_cast<int32_t*>(db2 + L2.o_cc) : nullptr, d_al, d_al + alt_cap, n);
     rr_enqueue(*this, db2, L2, n, alt_cap, kmax, by_gridk, conn_cap, false);
-    HIPCHK(hipMemcpyAsync(rr_hout2.p, rr_out2.p, L2.o_end, hipMemcpyDeviceToHost, stream));
   }
-  HIPCHK(hipMemcpyAsync(rr_hout.p, rr_out.p, L1.o_end, hipMemcpyDeviceToHost, stream));
+  HIPCHK(hipMemcpyAsync(rr_hout.p, rr_out.p, o_b2 + (alt_cap ? L2.o_end : 0), hipMemcpyDeviceToHost, stream));
   sync();
   rr_np_dev = rr_np.as<double>();
   rr_rows0 = n;
@@ -1105,7 +1104,7 @@ void Ctx::rrt_chain(const double* rnd6, const int32_t* tree, int n, double dist,
     memcpy(alt_slot, al, (size_t)listed * 4);
     memcpy(alt_mate, al + alt_cap, (size_t)listed * 4);
     *n_alt = listed;
-    rr_unpack(rr_hout2.as<char>(), L2, *R2, alt_cap, kmax);   // (all alt_cap rows: the caller's arrays have that many, seg's three columns that stride)
+    rr_unpack(hb + o_b2, L2, *R2, alt_cap, kmax);   // (all alt_cap rows: the caller's arrays have that many, seg's three columns that stride)
   }
 }
 

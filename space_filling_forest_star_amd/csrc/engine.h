@@ -219,8 +219,8 @@ struct Ctx {
   void rrt_chain_alt(const int32_t* slot, const int32_t* mate, int n_alt, double dist, int kmax, bool by_gridk, RrtRows& R,
                      double conn_r = 0, int conn_cap = 0);
   int rr_rows0 = 0;   // slots of the last rrt_chain
-  DevBuf rr_q1, rr_q2, rr_a, rr_out, rr_out2, rr_sq, rr_np, rr_alt;
-  PinBuf rr_hq, rr_hout, rr_hout2;
+  DevBuf rr_q1, rr_q2, rr_a, rr_out, rr_sq, rr_np, rr_alt;
+  PinBuf rr_hq, rr_hout;
   double sweep_eps() const;
   // one sweep launch over the first n_store entries; per-query hit lists sorted by (dist, id)
   void sweep_lists(const double* q6, int nq, const std::vector<double>& r, const int32_t* tree, const int32_t* max_id,
