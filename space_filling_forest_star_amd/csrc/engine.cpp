@@ -227,13 +227,14 @@ Ctx::~Ctx() {
   if (own_stream && own_stream != stream) (void)hipStreamSynchronize(own_stream);
   if (copy_stream) (void)hipStreamSynchronize(copy_stream);
   if (rccl_comm && rccl().CommDestroy) { (void)rccl().CommDestroy(rccl_comm); rccl_comm = nullptr; }
+  for (hipEvent_t e : rr_ev) if (e) (void)hipEventDestroy(e);
   if (ev_mid) (void)hipEventDestroy(ev_mid);
   if (ev_early) (void)hipEventDestroy(ev_early);
   for (auto& t : pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto e : pool) (void)hipEventDestroy(e);
   DevBuf* bufs[] = {&env_tri, &env_box, &env_plane, &rob_tri, &sx, &sy, &sz, &syaw, &spitch, &sroll, &stree, &spos,
                     &d_a, &d_b, &d_c, &d_d, &d_e, &d_f, &d_g, &d_h, &r_in, &r_out, &r_out2, &r_q, &r_cnt, &r_hidx,
-                    &r_hdist, &r_sega, &r_segb, &r_items, &r_items2, &r_center, &r_qrec, &env_clear, &env_clear_edge, &env_cand, &g_cnt, &g_items, &g_ovfcnt, &g_ovf, &t_cnt, &t_items, &t_ovfcnt, &t_ovf, &t_occ, &g_lite, &g_ovf_lite, &t_lite, &t_ovf_lite, &env_tg_start, &env_tg_list, &r_sub, &env_ext, &rr_q1, &rr_q2, &rr_a, &rr_out, &rr_sq, &rr_np, &rr_alt};
+                    &r_hdist, &r_sega, &r_segb, &r_items, &r_items2, &r_center, &r_qrec, &env_clear, &env_clear_edge, &env_cand, &g_cnt, &g_items, &g_ovfcnt, &g_ovf, &t_cnt, &t_items, &t_ovfcnt, &t_ovf, &t_occ, &g_lite, &g_ovf_lite, &t_lite, &t_ovf_lite, &env_tg_start, &env_tg_list, &r_sub, &env_ext, &rr_q1, &rr_q2, &rr_a, &rr_out, &rr_sq, &rr_np, &rr_alt, &rr_q2b, &rr_sqb};
   for (DevBuf* b : bufs) b->release();
   for (auto& b : level_box) b.release();
   PinBuf* pins[] = {&h_a, &h_b, &h_c, &h_d, &h_e, &h_f, &h_g, &h_h, &p_in, &p_out, &rr_hq, &rr_hout};
@@ -971,7 +972,14 @@ float rrt_conn_r2f(double conn_r, double eps) {   // (the superset radius of Ctx
 
 // pose, parent edge, k nearest, other trees, (mates) of rows row0 .. row0 + n - 1 of rr_np into the block `db`; k_rrt_steer has
 // written the rows' new points, nearest positions (rr_a), queries (rr_q2 / rr_sq) and the edge presets before
-static void rr_enqueue(Ctx& c, char* db, const RrLayout& L, int row0, int n, int kmax, bool by_gridk, int conn_cap, bool mates) {
+// (parts: 1 = pose + parent edge (+ mates) on the context's stream, 2 = the two queries - they only need the new points - on
+// stream `qs` from the query records q2 / sq; 3 = both)
+static void rr_enqueue(Ctx& c, char* db, const RrLayout& L, int row0, int n, int kmax, bool by_gridk, int conn_cap, bool mates, int parts = 3,
+                       hipStream_t qs = nullptr, const sffk::KnnQuery* q2 = nullptr, const sffk::SweepQuery* sq = nullptr) {
+  if (!qs) qs = c.stream;
+  if (!q2) q2 = c.rr_q2.as<sffk::KnnQuery>();
+  if (!sq) sq = c.rr_sq.as<sffk::SweepQuery>();
+  const bool timed = qs == c.stream;
   double* r_np = c.rr_np.as<double>() + 6 * (size_t)row0;
   int32_t* d_ns = reinterpret_cast<int32_t*>(db + L.o_sg);
   int32_t* d_fh = d_ns + n;
@@ -979,6 +987,7 @@ static void rr_enqueue(Ctx& c, char* db, const RrLayout& L, int row0, int n, int
   int32_t* d_ctrl = d_ov + n;
   uint8_t* d_hit = reinterpret_cast<uint8_t*>(db + L.o_ht);
   const int list_cap = 8 * n + 65536;
+  if (parts & 1) {
   c.time_begin(T_COLLIDE);
   // (the poses ride the edge kernels: the cull pass marks the ones that need the exact test, the exact kernel takes them first)
   sffk::launch_round_collide(c.stream, c.envv, c.robv, r_np, n, nullptr, d_hit, c.rr_a.as<double>(), r_np, d_ns, n, d_ctrl, c.r_items.p, list_cap,
@@ -986,22 +995,24 @@ static void rr_enqueue(Ctx& c, char* db, const RrLayout& L, int row0, int n, int
   c.time_end();
   if (mates) sffk::launch_rrt_mates(c.stream, c.rr_q1.as<sffk::KnnQuery>(), reinterpret_cast<double*>(db + L.o_nd), 2, r_np, d_hit, d_fh, d_ov, n,
                                     reinterpret_cast<int32_t*>(db + L.o_mt));
+  }
+  if (!(parts & 2)) return;
   if (kmax > 0) {
-    c.time_begin(T_SWEEP);
+    if (timed) c.time_begin(T_SWEEP);
     if (by_gridk && c.grid_on && c.store_n >= kmax)
-      sffk::launch_knn_grid(c.stream, c.gridv, nullptr, c.store_view(), c.rr_q2.as<sffk::KnnQuery>(), n, kmax, reinterpret_cast<int32_t*>(db + L.o_mi),
+      sffk::launch_knn_grid(qs, c.gridv, nullptr, c.store_view(), q2, n, kmax, reinterpret_cast<int32_t*>(db + L.o_mi),
                             reinterpret_cast<double*>(db + L.o_md), reinterpret_cast<int32_t*>(db + L.o_mc), nullptr, nullptr, c.grid_cell,
                             8 * c.sweep_eps(), SFFK_KNN_MATES, c.store_n);
     else
-      sffk::launch_knn_linear(c.stream, c.store_view(), c.store_n, c.rr_q2.as<sffk::KnnQuery>(), n, kmax, reinterpret_cast<int32_t*>(db + L.o_mi),
+      sffk::launch_knn_linear(qs, c.store_view(), c.store_n, q2, n, kmax, reinterpret_cast<int32_t*>(db + L.o_mi),
                               reinterpret_cast<double*>(db + L.o_md), reinterpret_cast<int32_t*>(db + L.o_mc), c.sweep_eps());
-    c.time_end();
+    if (timed) c.time_end();
   }
   if (L.kc) {
-    c.time_begin(T_SWEEP);
-    sffk::launch_sweep(c.stream, c.store_view(), 0, c.store_n, c.rr_sq.as<sffk::SweepQuery>(), r_np, n, reinterpret_cast<int32_t*>(db + L.o_cc),
+    if (timed) c.time_begin(T_SWEEP);
+    sffk::launch_sweep(qs, c.store_view(), 0, c.store_n, sq, r_np, n, reinterpret_cast<int32_t*>(db + L.o_cc),
                        reinterpret_cast<int32_t*>(db + L.o_ci), reinterpret_cast<double*>(db + L.o_cd), conn_cap);
-    c.time_end();
+    if (timed) c.time_end();
   }
 }
 
@@ -1074,18 +1085,39 @@ void Ctx::rrt_chain(const double* rnd6, const int32_t* tree, int n, double dist,
                          kmax > 0 ? rr_q2.as<sffk::KnnQuery>() : nullptr, kmax, n, kc ? rr_sq.as<sffk::SweepQuery>() : nullptr, conn_r, r2f,
                          reinterpret_cast<double*>(db + L1.o_np), reinterpret_cast<int32_t*>(db + L1.o_sg),
                          kc ? reinterpret_cast<int32_t*>(db + L1.o_cc) : nullptr);
-  rr_enqueue(*this, db, L1, 0, n, kmax, by_gridk, conn_cap, mate != nullptr);
+  // the k nearest and the other trees' nodes of the new points need nothing of the pose / edge answers: they run on a second
+  // stream beside them (RRT*: the k-nearest kernel is the longest of the chain)
+  const bool fork = rr_fork && (kmax > 0 || kc) && copy_stream;
+  if (fork) {
+    if (!rr_ev[0]) for (hipEvent_t& e : rr_ev) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(rr_ev[0], stream));
+    HIPCHK(hipStreamWaitEvent(copy_stream, rr_ev[0], 0));
+    rr_enqueue(*this, db, L1, 0, n, kmax, by_gridk, conn_cap, false, 2, copy_stream);
+  }
+  rr_enqueue(*this, db, L1, 0, n, kmax, by_gridk, conn_cap, mate != nullptr, fork ? 1 : 3);
   if (alt_cap) {
     // the repaired rows behind them, without a word from the host: the list of the slots that have a mate, the rows steered
     // from it (rr_a, rr_q2, rr_sq are free again: the stream keeps the order)
     char* db2 = db + o_b2;
     int32_t* d_al = reinterpret_cast<int32_t*>(db + L1.o_al);
     sffk::launch_rrt_alt_list(stream, reinterpret_cast<int32_t*>(db + L1.o_mt), n, alt_cap, d_al, d_al + alt_cap, d_al + 2 * alt_cap);
+    // (their query records: arrays of their own - the slots' may still be read on the second stream)
+    if (kmax > 0) rr_q2b.ensure((size_t)alt_cap * sizeof(sffk::KnnQuery));
+    if (kc) rr_sqb.ensure((size_t)alt_cap * sizeof(sffk::SweepQuery));
     sffk::launch_rrt_steer(stream, rr_q1.as<sffk::KnnQuery>(), nullptr, 0, spos.as<double>(), dist, rr_a.as<double>(), rr_np.as<double>(),
-                           kmax > 0 ? rr_q2.as<sffk::KnnQuery>() : nullptr, kmax, alt_cap, kc ? rr_sq.as<sffk::SweepQuery>() : nullptr, conn_r, r2f,
+                           kmax > 0 ? rr_q2b.as<sffk::KnnQuery>() : nullptr, kmax, alt_cap, kc ? rr_sqb.as<sffk::SweepQuery>() : nullptr, conn_r, r2f,
                            reinterpret_cast<double*>(db2 + L2.o_np), reinterpret_cast<int32_t*>(db2 + L2.o_sg),
                            kc ? reinterpret_cast<int32_t*>(db2 + L2.o_cc) : nullptr, d_al, d_al + alt_cap, n);
-    rr_enqueue(*this, db2, L2, n, alt_cap, kmax, by_gridk, conn_cap, false);
+    if (fork) {
+      HIPCHK(hipEventRecord(rr_ev[1], stream));
+      HIPCHK(hipStreamWaitEvent(copy_stream, rr_ev[1], 0));
+      rr_enqueue(*this, db2, L2, n, alt_cap, kmax, by_gridk, conn_cap, false, 2, copy_stream, rr_q2b.as<sffk::KnnQuery>(), rr_sqb.as<sffk::SweepQuery>());
+    }
+    rr_enqueue(*this, db2, L2, n, alt_cap, kmax, by_gridk, conn_cap, false, fork ? 1 : 3, nullptr, rr_q2b.as<sffk::KnnQuery>(), rr_sqb.as<sffk::SweepQuery>());
+  }
+  if (fork) {
+    HIPCHK(hipEventRecord(rr_ev[2], copy_stream));
+    HIPCHK(hipStreamWaitEvent(stream, rr_ev[2], 0));
   }
   HIPCHK(hipMemcpyAsync(rr_hout.p, rr_out.p, o_b2 + (alt_cap ? L2.o_end : 0), hipMemcpyDeviceToHost, stream));
   sync();

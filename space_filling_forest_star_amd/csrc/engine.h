@@ -219,7 +219,9 @@ struct Ctx {
   void rrt_chain_alt(const int32_t* slot, const int32_t* mate, int n_alt, double dist, int kmax, bool by_gridk, RrtRows& R,
                      double conn_r = 0, int conn_cap = 0);
   int rr_rows0 = 0;   // slots of the last rrt_chain
-  DevBuf rr_q1, rr_q2, rr_a, rr_out, rr_sq, rr_np, rr_alt;
+  DevBuf rr_q1, rr_q2, rr_a, rr_out, rr_sq, rr_np, rr_alt, rr_q2b, rr_sqb;
+  hipEvent_t rr_ev[3] = {nullptr, nullptr, nullptr};   // rrt_chain: fork after each steer, join before the copy back
+  bool rr_fork = true;                                  // SFFGPU_RRT_FORK=0: the chain's queries on the one stream
   PinBuf rr_hq, rr_hout;
   double sweep_eps() const;
   // one sweep launch over the first n_store entries; per-query hit lists sorted by (dist, id)

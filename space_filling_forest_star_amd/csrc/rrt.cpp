@@ -22,6 +22,7 @@ namespace sff {
 
 Rrt::Rrt(Ctx* c, const sffgpu_rrt_cfg& cf, const double* roots6, int n_roots) : ctx(c), cfg(cf) {
   if (const char* e = getenv("SFFGPU_RRT_CHAIN")) chain_on = atoi(e) != 0;
+  if (const char* e = getenv("SFFGPU_RRT_FORK")) c->rr_fork = atoi(e) != 0;
   if (const char* e = getenv("SFFGPU_RRT_REPAIR")) repair_on = atoi(e) != 0;
   if (const char* e = getenv("SFFGPU_RRT_DRY")) dry_on = atoi(e) != 0;
   if (const char* e = getenv("SFFGPU_RRT_ONE_CHAIN")) one_chain = atoi(e) != 0;
