@@ -228,16 +228,20 @@ Ctx::~Ctx() {
   if (copy_stream) (void)hipStreamSynchronize(copy_stream);
   if (rccl_comm && rccl().CommDestroy) { (void)rccl().CommDestroy(rccl_comm); rccl_comm = nullptr; }
   for (hipEvent_t e : rr_ev) if (e) (void)hipEventDestroy(e);
+  for (SegJob& J : seg_job) if (J.ev) (void)hipEventDestroy(J.ev);
   if (ev_mid) (void)hipEventDestroy(ev_mid);
   if (ev_early) (void)hipEventDestroy(ev_early);
   for (auto& t : pending) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
   for (auto e : pool) (void)hipEventDestroy(e);
   DevBuf* bufs[] = {&env_tri, &env_box, &env_plane, &rob_tri, &sx, &sy, &sz, &syaw, &spitch, &sroll, &stree, &spos,
                     &d_a, &d_b, &d_c, &d_d, &d_e, &d_f, &d_g, &d_h, &r_in, &r_out, &r_out2, &r_q, &r_cnt, &r_hidx,
-                    &r_hdist, &r_sega, &r_segb, &r_items, &r_items2, &r_center, &r_qrec, &env_clear, &env_clear_edge, &env_cand, &g_cnt, &g_items, &g_ovfcnt, &g_ovf, &t_cnt, &t_items, &t_ovfcnt, &t_ovf, &t_occ, &g_lite, &g_ovf_lite, &t_lite, &t_ovf_lite, &env_tg_start, &env_tg_list, &r_sub, &env_ext, &rr_q1, &rr_q2, &rr_a, &rr_out, &rr_sq, &rr_np, &rr_alt, &rr_q2b, &rr_sqb};
+                    &r_hdist, &r_sega, &r_segb, &r_items, &r_items2, &r_center, &r_qrec, &env_clear, &env_clear_edge, &env_cand, &g_cnt, &g_items, &g_ovfcnt, &g_ovf, &t_cnt, &t_items, &t_ovfcnt, &t_ovf, &t_occ, &g_lite, &g_ovf_lite, &t_lite, &t_ovf_lite, &env_tg_start, &env_tg_list, &r_sub, &env_ext, &rr_q1, &rr_q2, &rr_a, &rr_out, &rr_sq, &rr_np, &rr_alt, &rr_q2b, &rr_sqb, &seg_job[0].ids, &seg_job[0].a, &seg_job[0].b, &seg_job[0].c, &seg_job[1].ids, &seg_job[1].a,
+                    &seg_job[1].b, &seg_job[1].c, &seg_job[2].ids, &seg_job[2].a, &seg_job[2].b, &seg_job[2].c, &seg_job[3].ids, &seg_job[3].a,
+                    &seg_job[3].b, &seg_job[3].c};
   for (DevBuf* b : bufs) b->release();
   for (auto& b : level_box) b.release();
-  PinBuf* pins[] = {&h_a, &h_b, &h_c, &h_d, &h_e, &h_f, &h_g, &h_h, &p_in, &p_out, &rr_hq, &rr_hout};
+  PinBuf* pins[] = {&h_a, &h_b, &h_c, &h_d, &h_e, &h_f, &h_g, &h_h, &p_in, &p_out, &rr_hq, &rr_hout, &seg_job[0].hids, &seg_job[0].hc, &seg_job[1].hids, &seg_job[1].hc, &seg_job[2].hids, &seg_job[2].hc,
+                    &seg_job[3].hids, &seg_job[3].hc};
   for (PinBuf* b : pins) b->release();
   if (copy_stream) (void)hipStreamDestroy(copy_stream);
   if (own_stream) (void)hipStreamDestroy(own_stream);
@@ -872,10 +876,19 @@ void Ctx::collide_segments_core(const double* a6, const double* b6, const int32_
   time_end();
   HIPCHK(hipMemcpyAsync(h_c.p, d_c.p, (size_t)n * 12, hipMemcpyDeviceToHost, stream));
   sync();
+  seg_finish(h_c.as<int32_t>(), n, a6, b6, d_a.p, d_b.p, is_free, first_hit, n_samples);
+}
+
+// the answer of an edge batch (n sample counts | n first hits or INT_MAX | n overflow marks) -> the caller's arrays; edges whose
+// triangle candidate list ran over are re-run sample by sample through the pose kernel (dev_a / dev_b: the batch's end points on
+// the device, fetched when the caller has none)
+void Ctx::seg_finish(const int32_t* hn_in, int n, const double* a6, const double* b6, const void* dev_a, const void* dev_b, uint8_t* is_free,
+                     int32_t* first_hit, int32_t* n_samples) {
+  const size_t pb = (size_t)n * 6 * sizeof(double);
   // (one pass over the answer: a wave of the RRT* session brings tens of thousands of edges per call)
   bool any_ovf = false;
   {
-    const int32_t* hn = h_c.as<int32_t>();
+    const int32_t* hn = hn_in;
     const int32_t* hf = hn + n;
     const int32_t* ho = hn + 2 * (size_t)n;
     for (int i = 0; i < n; ++i) {
@@ -891,7 +904,7 @@ void Ctx::collide_segments_core(const double* a6, const double* b6, const int32_
   std::vector<int32_t> ns(n), fh(n);
   std::vector<uint8_t> ovf(n);
   {
-    const int32_t* hn = h_c.as<int32_t>();   // (still the answer: nothing has been enqueued since)
+    const int32_t* hn = hn_in;   // (still the answer: nothing has been enqueued on its buffer since)
     for (int i = 0; i < n; ++i) {
       ns[i] = hn[i];
       const int32_t v = hn[(size_t)n + i];
@@ -903,8 +916,8 @@ void Ctx::collide_segments_core(const double* a6, const double* b6, const int32_
   if (any_ovf && !a6) {   // (their end points only exist on the device: fetch the gathered arrays)
     ga.resize((size_t)n * 6);
     gb.resize((size_t)n * 6);
-    HIPCHK(hipMemcpy(ga.data(), d_a.p, pb, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(gb.data(), d_b.p, pb, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(ga.data(), dev_a, pb, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(gb.data(), dev_b, pb, hipMemcpyDeviceToHost));
     a6 = ga.data();
     b6 = gb.data();
   }
@@ -928,6 +941,47 @@ void Ctx::collide_segments_core(const double* a6, const double* b6, const int32_
     if (first_hit) first_hit[i] = fh[i];
     if (n_samples) n_samples[i] = ns[i];
   }
+}
+
+// Several edge batches in flight (the RRT* wave's member edges in parts: the host builds the later parts' lists and replays the
+// earlier parts' rows while the GPU checks the others).  seg_refs_begin enqueues and returns; seg_refs_end waits for that batch.
+void Ctx::seg_refs_begin(int which, const int32_t* ida, const int32_t* idb, int n, int n_hint) {
+  SegJob& J = seg_job[which];
+  J.n = n;
+  if (n <= 0) return;
+  if (!rr_np_dev) throw HipError{"seg_refs_begin: no rrt_chain has run"};
+  if (!have_env || !have_robot) throw HipError{"collide_segments: upload ENV and ROBOT meshes first"};
+  HIPCHK(hipSetDevice(device));
+  if (!J.ev) HIPCHK(hipEventCreateWithFlags(&J.ev, hipEventDisableTiming));
+  const size_t pb = (size_t)n * 6 * sizeof(double);
+  J.hids.ensure((size_t)n * 8);
+  memcpy(J.hids.p, ida, (size_t)n * 4);
+  memcpy(J.hids.as<int32_t>() + n, idb, (size_t)n * 4);
+  J.ids.ensure((size_t)n * 8); J.a.ensure(pb); J.b.ensure(pb); J.c.ensure((size_t)n * 12 + 64); J.hc.ensure((size_t)n * 12);
+  int32_t* d_ns = J.c.as<int32_t>();
+  int32_t* d_fh = d_ns + n;
+  int32_t* d_ov = d_fh + n;
+  int32_t* d_ctrl = d_ov + n;
+  HIPCHK(hipMemcpyAsync(J.ids.p, J.hids.p, (size_t)n * 8, hipMemcpyHostToDevice, stream));
+  sffk::launch_seg_gather(stream, spos.as<double>(), J.ids.as<int32_t>(), J.ids.as<int32_t>() + n, n, J.a.as<double>(), J.b.as<double>(), rr_np_dev);
+  HIPCHK(hipMemsetAsync(d_ctrl, 0, 64, stream));
+  const int big = std::max(n, n_hint);   // (the work lists are shared: sized once for the larger batch, nothing is reallocated under a batch in flight)
+  r_items.ensure((size_t)(8 * big + 65536) * SFFK_ITEM_BYTES);
+  r_items2.ensure(((size_t)(8 * big + 65536) + (1u << 20)) * 8);
+  const int list_cap = 8 * n + 65536;
+  time_begin(T_COLLIDE);
+  sffk::launch_seg_prepare(stream, J.a.as<double>(), J.b.as<double>(), n, d_ns, d_fh, d_ov);
+  sffk::launch_collide_segments_dyn(stream, envv, robv, J.a.as<double>(), J.b.as<double>(), d_ns, n, d_ctrl, r_items.p, list_cap, r_items2.p, d_fh, d_ov);
+  time_end();
+  HIPCHK(hipMemcpyAsync(J.hc.p, J.c.p, (size_t)n * 12, hipMemcpyDeviceToHost, stream));
+  HIPCHK(hipEventRecord(J.ev, stream));
+}
+void Ctx::seg_refs_end(int which, uint8_t* is_free, int32_t* first_hit, int32_t* n_samples) {
+  SegJob& J = seg_job[which];
+  if (J.n <= 0) return;
+  HIPCHK(hipEventSynchronize(J.ev));
+  seg_finish(J.hc.as<int32_t>(), J.n, nullptr, nullptr, J.a.p, J.b.p, is_free, first_hit, n_samples);
+  J.n = 0;
 }
 
 // RRT session (csrc/rrt.cpp): the GPU half of one speculative wave as ONE enqueued chain and one wait.

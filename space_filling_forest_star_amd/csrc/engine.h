@@ -220,6 +220,13 @@ struct Ctx {
                      double conn_r = 0, int conn_cap = 0);
   int rr_rows0 = 0;   // slots of the last rrt_chain
   DevBuf rr_q1, rr_q2, rr_a, rr_out, rr_sq, rr_np, rr_alt, rr_q2b, rr_sqb;
+  // up to four edge batches of references in flight (Rrt::run_wave: the member edges of an RRT* wave in parts)
+  struct SegJob { DevBuf ids, a, b, c; PinBuf hids, hc; hipEvent_t ev = nullptr; int n = 0; };
+  SegJob seg_job[4];
+  void seg_refs_begin(int which, const int32_t* ida, const int32_t* idb, int n, int n_hint);
+  void seg_refs_end(int which, uint8_t* is_free, int32_t* first_hit, int32_t* n_samples);
+  void seg_finish(const int32_t* hn_in, int n, const double* a6, const double* b6, const void* dev_a, const void* dev_b, uint8_t* is_free,
+                  int32_t* first_hit, int32_t* n_samples);
   hipEvent_t rr_ev[3] = {nullptr, nullptr, nullptr};   // rrt_chain: fork after each steer, join before the copy back
   bool rr_fork = true;                                  // SFFGPU_RRT_FORK=0: the chain's queries on the one stream
   PinBuf rr_hq, rr_hout;
@@ -538,6 +545,7 @@ struct Rrt {
   void knn(const double* q, int nq, const int32_t* tree, int k, std::vector<std::vector<int>>& out);
   bool knn_by_grid(const int32_t* tree, int nq, int k) const;
   bool chain_on = true;   // SFFGPU_RRT_CHAIN (read when the session is created): nearest -> steer -> pose -> parent edge -> k nearest as one chain
+  int split_parts = 2;    // SFFGPU_RRT_SPLIT (1..4): an RRT* wave's member edges in that many batches, the later ones checked while the earlier ones' rows are replayed
   bool one_chain = true;  // SFFGPU_RRT_ONE_CHAIN: the repaired rows inside the wave's one chain (the device lists them) instead of a second chain
   bool dry_on = true;     // SFFGPU_RRT_DRY: the replay's nearest-node walk done once ahead, so that only the rows it takes get edges
   bool repair_on = true;  // SFFGPU_RRT_REPAIR: slots whose nearest node would be an earlier new point of the wave are evaluated from it too

@@ -26,6 +26,7 @@ Rrt::Rrt(Ctx* c, const sffgpu_rrt_cfg& cf, const double* roots6, int n_roots) : 
   if (const char* e = getenv("SFFGPU_RRT_REPAIR")) repair_on = atoi(e) != 0;
   if (const char* e = getenv("SFFGPU_RRT_DRY")) dry_on = atoi(e) != 0;
   if (const char* e = getenv("SFFGPU_RRT_ONE_CHAIN")) one_chain = atoi(e) != 0;
+  if (const char* e = getenv("SFFGPU_RRT_SPLIT")) split_parts = std::max(1, atoi(e));
   if (const char* e = getenv("SFFGPU_RRT_SMALL")) { small_cap = std::max(1, atoi(e)); }
   if (const char* e = getenv("SFFGPU_RRT_GROW")) grow_pct = std::max(100, atoi(e));
   if (cfg.dim != 2 && cfg.dim != 6) throw HipError{"rrt: dim must be 2 or 6"};
@@ -327,6 +328,7 @@ struct WCand {
   int slot = -1, near_row = -1, alt_row = -1;
   bool cut_here = false;                          // nothing evaluated covers this slot if it is reached
   bool prepared = false;                          // its member lists / link candidates / edges are in the wave's batches
+  int apos = -1;                                  // its place among the rows that got them
 };
 }  // namespace
 
@@ -672,9 +674,11 @@ int Rrt::run_wave(int B) {
   auto g_cell = [&](double v, int a) { const int cidx = (int)std::floor((v - g_lo[a]) * g_inv[a]); return cidx < 0 ? 0 : cidx >= G ? G - 1 : cidx; };
   std::vector<int> g_head, g_next, g_found;
   if (kmax > 0) { g_head.assign((size_t)G * G * G, -1); g_next.assign(nA, -1); }
-  for (int k = 0; k < nA; ++k) {
+  auto build_rows = [&](int k_first, int k_end) {
+  for (int k = k_first; k < k_end; ++k) {
     const int j = alive[k];
     WCand& cd = w[j];
+    cd.apos = k;
     if (kmax > 0) {
       // distance of the k_max-th store member bounds which mates can enter the set
       double dk = std::numeric_limits<double>::infinity();
@@ -723,19 +727,49 @@ int Rrt::run_wave(int B) {
       }
     }
   }
+  };
+  // RRT* waves of some size: the edges go to the GPU in batches - the later batches' lists are built and the earlier
+  // batches' rows replayed while the GPU checks the others (Ctx::seg_refs_begin / _end)
+  // (two: a batch is a chain of eight launches and copies, ~80 us whatever its size - four batches measured no better)
+  const int n_parts = chained && split_parts > 1 && kmax > 0 && nA >= 64 ? std::min(split_parts, 4) : 1;
+  int part_k[5], part_e[5];          // rows / edges where the batches start
+  for (int q = 0; q <= n_parts; ++q) part_k[q] = (int)((long long)nA * q / n_parts);
+  part_e[0] = 0;
+  for (int q = 0; q < n_parts; ++q) {
+    build_rows(part_k[q], part_k[q + 1]);
+    part_e[q + 1] = chained ? (int)ra.size() : (int)(ea.size() / 6);
+    if (n_parts > 1) c.seg_refs_begin(q, ra.data() + part_e[q], rb.data() + part_e[q], part_e[q + 1] - part_e[q], (n_parts + 1) * (part_e[1] + 1024));
+  }
   lap(8);
-  const int nE = chained ? (int)ra.size() : (int)(ea.size() / 6);
+  const int nE = part_e[n_parts];
   std::vector<uint8_t> efr(nE);
   std::vector<int32_t> efh(nE), ens(nE);
-  if (nE && chained) c.collide_segments_refs(ra.data(), rb.data(), nE, efr.data(), efh.data(), ens.data());
-  else if (nE) c.collide_segments(ea.data(), eb.data(), nE, efr.data(), efh.data(), ens.data());
-  lap(9);
-  for (int e = 0; e < nE; ++e) {
-    const Ref& r = refs[e];
-    WCand& cd = w[r.cand];
-    if (r.kind == 0) { cd.medges[r.idx].free_f = efr[e] != 0; cd.medges[r.idx].fh_f = efh[e]; cd.medges[r.idx].ns_f = ens[e]; }
-    else if (r.kind == 1) { cd.medges[r.idx].free_b = efr[e] != 0; cd.medges[r.idx].fh_b = efh[e]; cd.medges[r.idx].ns_b = ens[e]; }
-    else if (r.kind == 2) { cd.conns[r.idx].free = efr[e] != 0; cd.conns[r.idx].fh = efh[e]; cd.conns[r.idx].ns = ens[e]; }
+  auto deal = [&](int e0, int e1) {   // the edges' answers -> the rows' lists
+    for (int e = e0; e < e1; ++e) {
+      const Ref& r = refs[e];
+      WCand& cd = w[r.cand];
+      if (r.kind == 0) { cd.medges[r.idx].free_f = efr[e] != 0; cd.medges[r.idx].fh_f = efh[e]; cd.medges[r.idx].ns_f = ens[e]; }
+      else if (r.kind == 1) { cd.medges[r.idx].free_b = efr[e] != 0; cd.medges[r.idx].fh_b = efh[e]; cd.medges[r.idx].ns_b = ens[e]; }
+      else if (r.kind == 2) { cd.conns[r.idx].free = efr[e] != 0; cd.conns[r.idx].fh = efh[e]; cd.conns[r.idx].ns = ens[e]; }
+    }
+  };
+  int parts_home = 0;                // batches whose answers have been dealt out
+  auto take_parts = [&](int upto) {  // ... up to and including batch `upto`
+    for (; parts_home <= upto && parts_home < n_parts; ++parts_home) {
+      const int e0 = part_e[parts_home], e1 = part_e[parts_home + 1];
+      c.seg_refs_end(parts_home, efr.data() + e0, efh.data() + e0, ens.data() + e0);
+      deal(e0, e1);
+    }
+  };
+  if (n_parts > 1) {
+    take_parts(0);
+    lap(9);
+  } else {
+    if (nE && chained) c.collide_segments_refs(ra.data(), rb.data(), nE, efr.data(), efh.data(), ens.data());
+    else if (nE) c.collide_segments(ea.data(), eb.data(), nE, efr.data(), efh.data(), ens.data());
+    lap(9);
+    deal(0, nE);
+    parts_home = 1;
   }
   lap(5);
   // ---- 7. replay in order; cut the wave at the first iteration the speculation does not cover
@@ -778,6 +812,7 @@ int Rrt::run_wave(int B) {
     if (conflict) break;
     WCand& cd = w[row];
     if (have_mates && !cd.prepared && !cd.pose_hit && cd.par_free) { ++g_rrt_alt[2]; break; }   // (the dry walk stopped before it)
+    while (parts_home < n_parts && cd.apos >= part_k[parts_home]) take_parts(parts_home);
     ++done;
     ++iter;
     const unsigned iteration = (unsigned)iter;
@@ -863,6 +898,7 @@ int Rrt::run_wave(int B) {
       merged = true;                               // tree ids / frontier changed: later picks are stale
     }
   }
+  take_parts(n_parts - 1);   // (a replay that ended early: the batches still have to come home before their buffers are used again)
   lap(6);
   // ---- 8. commit: device store, RNG position
   if (!pend_tree.empty()) {
