@@ -157,7 +157,7 @@ __device__ void up_finish(HeapRef& h, int index, int node, hkey_t k, HeapAnc a) 
   heap_put1(h, (int)(i1 >> up) - 1, node, k);
 }
 __device__ int heap_pop(HeapRef& h) {                       // Heap::pop()
-  const long long t_a = PCLK();
+  [[maybe_unused]] const long long t_a = PCLK();
   const int size = uni_i32(h.n);
   const int last_v = hl_i32(h.v + size - 1);
   const hkey_t last_k = hl_key(h.key + size - 1);
@@ -581,7 +581,7 @@ __global__ __launch_bounds__(256) void k_prio_end(DevForestView f, NodeStoreView
   const int n0 = c->prio_n0, n1 = c->n_nodes;
 #define h hr
   for (int c0 = n0; c0 < n1; c0 += PG_CHUNK) {
-    const long long t_g = PCLK();
+    [[maybe_unused]] const long long t_g = PCLK();
     bool mine[8];
     int cnt = 0;
     for (int j = 0; j < 8; ++j) {
@@ -596,7 +596,7 @@ __global__ __launch_bounds__(256) void k_prio_end(DevForestView f, NodeStoreView
     for (int j = 0; j < 8; ++j)
       if (mine[j]) { s_op[at] = c0 + tid * 8 + j; s_key[at] = hk_bits(k[j]); ++at; }
     __syncthreads();
-    const long long t_p = PCLK();
+    [[maybe_unused]] const long long t_p = PCLK();
     PDBG(6, total); PDBG(7, t_p - t_g);
     if (tid < 64)
       for (int e = 0; e < total; ++e) heap_push(hr, s_op[e], s_key[e]);
@@ -612,7 +612,7 @@ __global__ __launch_bounds__(256) void k_prio_end(DevForestView f, NodeStoreView
     for (int e = tid; e < n_fail; e += 256) { const int s = act[e]; atomicOr(&s_fail[s >> 5], 1u << (s & 31)); }
     __syncthreads();
     for (int c0 = 0; c0 < n_slots; c0 += PG_CHUNK) {
-      const long long t_g = PCLK();
+      [[maybe_unused]] const long long t_g = PCLK();
       int op[8];                                             // 1 = remove the node, 2 = put it back
       int cnt = 0;
       for (int j = 0; j < 8; ++j) {
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(256) void k_prio_end(DevForestView f, NodeStoreView
       for (int j = 0; j < 8; ++j)
         if (op[j]) { s_op[at] = op[j] == 1 ? ~node[j] : node[j]; s_key[at] = k[j]; ++at; }
       __syncthreads();
-      const long long t_p = PCLK();
+      [[maybe_unused]] const long long t_p = PCLK();
       PDBG(9, total); PDBG(10, t_p - t_g);
       if (tid < 64) {
         for (int e = 0; e < total; ++e) {

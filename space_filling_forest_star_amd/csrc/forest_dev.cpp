@@ -978,8 +978,6 @@ void Forest::dev_enqueue_round_eval(void* send_dev, bool sample) {
   const DevRoundBufs B = dev_round_bufs(*this);
   const int n = B.n;
   const int32_t* dev_n = reinterpret_cast<const int32_t*>(d.ctrl.p);   // {n_act, halt}
-  sffk::NodeStoreMut stm{c.sx.as<float>(), c.sy.as<float>(), c.sz.as<float>(), c.syaw.as<float>(),
-                         c.spitch.as<float>(), c.sroll.as<float>(), c.stree.as<int32_t>(), c.spos.as<double>()};
   c.timing_on = d.force_timing >= 0 ? d.force_timing != 0
                                    : (c.timer_stride <= 1 || d.rounds_enqueued % (uint64_t)c.timer_stride == 0);
   d.round_timing = c.timing_on;   // (the commit of this round is timed like its evaluation)

@@ -4984,7 +4984,7 @@ __global__ __launch_bounds__(OPT ? 192 : 128) void k_spec_waves(SpecArgs S) {
   __shared__ int32_t s_er[SP_ER_MAX + SFFK_SPEC_DEPTH + 1];   // erased frontier positions, ascending (leader: since the last compaction; worker: + its scenario's)
   // the job the worker's first wavefront hands to its second one right after the sample is drawn: the neighbour query
   // (and, SFF*, the k nearest of the sample's tree) run BESIDE the pose check and the parent edge
-  __shared__ int32_t j_seq, j_cancel, j_done, j_done_k, j_nhit, j_mine, j_k, j_tcnt, j_nmem, j_nn0, j_snn, j_step;
+  __shared__ int32_t j_seq, j_cancel, j_done, j_done_k, j_nhit, j_mine, j_k, j_nmem, j_nn0, j_snn, j_step;
   __shared__ double j_qp[6], j_pdist;
   __shared__ double k_d[64];
   __shared__ int32_t k_id[64];
