@@ -413,6 +413,22 @@ def test_rrt_waves_with_repaired_slots_identical(S, ctx, monkeypatch, name, opti
     assert 2 * waves[("1", 0)] < waves[("0", 0)] or n_roots > 1 or iters < 2000, waves
 
 
+def test_rrt_wave_engine_variants_agree_on_random_configurations():
+    """profiles/rrt_stress.py, one configuration per map: the RRT session with its default wave engine (one chain, repaired slots, the
+    replay's walk done ahead, edges in two batches), without the repair, without the dry walk, without the chain and - small
+    budgets - one iteration per round trip must commit the same nodes, parents, costs, links, counters and stream position
+    on random maps / root counts / goal biases / wave sizes (no oracle in the loop: the oracle pins the engines elsewhere)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, STRESS_SEEDS="2")
+    out = subprocess.run([sys.executable, os.path.join(root, "profiles", "rrt_stress.py")], env=env, capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    last = [ln for ln in out.stdout.splitlines() if ln.startswith("cases ")]
+    assert last and "mismatches 0," in last[-1] and not last[-1].startswith("cases 0,"), out.stdout[-2000:]
+
+
 def test_gpu_matches_committed_golden_runs(S, ctx, golden_dir):
     """The GPU path against the COMMITTED fixture tests/golden/oracle_runs.json (not only against the oracle
     built on this box): node counts, reference-equivalent collision calls, parent and cost checksums."""
