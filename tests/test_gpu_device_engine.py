@@ -62,7 +62,7 @@ def make(S, ctx, name, wave, iters, seed, n_roots=5, budget=0, which="device", o
 
 
 @pytest.mark.parametrize("name,wave,iters", [
-    ("dense3d", 1, 600), ("dense3d", 7, 2500), ("dense3d", 64, 8000), ("dense3d", 512, 40000), ("dense3d", 4096, 75000),
+    ("dense3d", 1, 600), ("dense3d", 7, 2500), ("dense3d", 64, 8000), ("dense3d", 512, 40000), ("dense3d", 4096, 60000),
     ("dense3d_coarse", 1, 800), ("dense3d_coarse", 64, 8000), ("dense3d_coarse", 1024, 20000),
     ("triang", 1, 600), ("triang", 128, 10000), ("triang", 2048, 60000),
     ("dense2d", 3, 1500), ("dense2d", 256, 8000), ("building", 256, 8000),
@@ -93,7 +93,7 @@ def test_single_goal_mode_on_the_device_engine(S, ctx, name, wave, n_roots, opti
 
 
 @pytest.mark.parametrize("name,wave,iters", [
-    ("dense3d", 1, 500), ("dense3d", 7, 2500), ("dense3d", 64, 8000), ("dense3d", 512, 40000), ("dense3d", 4096, 75000),
+    ("dense3d", 1, 500), ("dense3d", 7, 2500), ("dense3d", 64, 8000), ("dense3d", 512, 40000), ("dense3d", 4096, 60000),
     ("dense3d_coarse", 64, 8000), ("dense3d_coarse", 1024, 20000),
     ("triang", 1, 600), ("triang", 128, 10000), ("triang", 2048, 60000),
     ("dense2d", 3, 1500), ("dense2d", 256, 8000), ("building", 256, 8000), ("building", 2048, 80000),

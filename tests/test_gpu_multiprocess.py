@@ -41,7 +41,7 @@ def free_port():
                           ("dense3d_coarse", 2, 512, 12000, 0, "library", 1), ("dense3d_coarse", 2, 512, 12000, 0, "caller", 0),
                           # the wave that grows with the rank count (4 ranks x 16 384 slots: the largest wave the device
                           # engine takes), library-driven
-                          ("dense3d", 4, 65536, 50000, 0, "library", -1)])
+                          ("dense3d", 4, 65536, 35000, 0, "library", -1)])
 def test_sharded_forest_across_processes_equals_the_oracle(name, world, wave, iters, optimize, driver, fault_rank):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1")
     for attempt in range(3):   # (the rendezvous port is free when it is picked, not necessarily seconds later: retry on EADDRINUSE)

@@ -308,7 +308,7 @@ def test_priority_frontier_mode(S, ctx, name, wave, n_roots, optimize, goal, mon
 
 
 @pytest.mark.parametrize("name,wave,n_roots,optimize,iters", [
-    ("dense3d", 1024, 10, False, 40000), ("dense3d", 4096, 10, False, 60000), ("dense3d", 512, 6, True, 20000),
+    ("dense3d", 1024, 10, False, 40000), ("dense3d", 4096, 10, False, 45000), ("dense3d", 512, 6, True, 20000),
     ("triang", 2048, 5, False, 30000), ("dense3d_coarse", 256, 8, False, 20000),
 ])
 def test_priority_frontier_mode_on_the_device_engine(S, ctx, name, wave, n_roots, optimize, iters, monkeypatch):
