@@ -197,15 +197,17 @@ struct Ctx {
   // index too (sffgpu_nodes_index / the RRT session's grid)
   void knn(const double* q6, int nq, int k, const int32_t* tree, const int32_t* max_id, int32_t* idx, double* dist,
            int32_t* cnt, bool tree_by_grid = false);
-  // RRT session, the GPU half of a speculative wave as enqueued chains with one wait each (was: three calls, three waits).
+  // RRT session, the GPU half of a speculative wave as ONE enqueued chain with one wait (was: three calls, three waits; DESIGN.md
+  // 3, "The RRT session's wave").
   // rrt_chain: the two nearest nodes of every steering target in its tree (near_* n x 2; the first is the nearest - two, so that
   // the caller sees a tie) -> the steered new point -> per row (RrtRows): its pose check (hit), the edge nearest -> new point
   // (seg: n_samples | first_hit or INT_MAX | candidate list overflowed, n each), kmax > 0: the kmax nearest nodes of the new
   // point in the tree (mem_* n x kmax), conn_r > 0 (several live trees): every node of the OTHER trees within conn_r of the
   // new point (:228-231; conn_cnt n - > conn_cap: the list ran over, ask Ctx::radius -, conn_idx / conn_d n x conn_cap in no
   // order) -> mate != null: per slot the earlier new point of the wave that would be its nearest node (-1: none).
-  // rrt_chain_alt: the same rows for the slots repaired by hand of that answer - slot[i] steered from new point mate[i] (a row
-  // of the last rrt_chain) -; their new points become rows n.. of the table collide_segments_refs reads.
+  // rrt_chain_alt (SFFGPU_RRT_ONE_CHAIN=0; by default the repaired rows ride rrt_chain itself, below): the same rows for the slots
+  // repaired by hand of that answer - slot[i] steered from new point mate[i] (a row of the last rrt_chain) -; their new points become
+  // rows n.. of the table collide_segments_refs / seg_refs_begin read.
   // Replaces src/rrt.h:143-151,166,228-231.
   struct RrtRows {
     double* np6; uint8_t* hit; int32_t* seg; int32_t* mem_idx; double* mem_d; int32_t* mem_cnt;   // host, caller-owned

@@ -793,7 +793,7 @@ int Rrt::run_wave(int B) {
       if (cand >= 0) {
         if (w[cand].accepted < 0 || w[j].alt_row < 0) { ++g_rrt_alt[2]; break; }
         row = w[j].alt_row;
-        ++g_rrt_alt[0 + 1];
+        ++g_rrt_alt[1];
       }
       const WCand& cr = w[row];
       for (int i : acc_alt) {
